@@ -1,0 +1,152 @@
+"""ctypes binding of the C ABI in include/gnss_sdr_hip.h.
+
+The shared library is built in-tree by ``__graft_entry__.build()`` (hipcc, gfx950).  There is no
+fallback of any kind: if the library is missing or a call fails, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgnss_sdr_hip.so")
+
+GSH_MAX_TAPS = 8
+GSH_OK = 0
+ERR_NAMES = {1: "GSH_ERR_INVALID", 2: "GSH_ERR_NO_DEVICE", 3: "GSH_ERR_HIP", 4: "GSH_ERR_STATE", 5: "GSH_ERR_UNSUPPORTED"}
+
+
+class GshError(RuntimeError):
+    def __init__(self, code: int, text: str):
+        super().__init__(f"{ERR_NAMES.get(code, code)}: {text}")
+        self.code = code
+
+
+class CorrJob(C.Structure):
+    """gsh_corr_job (80 bytes)."""
+    _fields_ = [
+        ("sample_offset", C.c_uint64),
+        ("n_samples", C.c_int32),
+        ("code_slot", C.c_int32),
+        ("rem_carr_phase_rad", C.c_float),
+        ("phase_step_rad", C.c_float),
+        ("phase_rate_step_rad", C.c_float),
+        ("rem_code_phase_chips", C.c_float),
+        ("code_phase_step_chips", C.c_float),
+        ("code_phase_rate_step_chips", C.c_float),
+        ("n_taps", C.c_int32),
+        ("high_dyn", C.c_int32),
+        ("shifts_chips", C.c_float * GSH_MAX_TAPS),
+    ]
+
+
+class AcqConf(C.Structure):
+    """gsh_acq_conf."""
+    _fields_ = [
+        ("fs_in", C.c_int64),
+        ("fft_size", C.c_uint32),
+        ("effective_fft_size", C.c_uint32),
+        ("consumed_samples", C.c_uint32),
+        ("num_doppler_bins", C.c_uint32),
+        ("doppler_max", C.c_int32),
+        ("doppler_step", C.c_int32),
+        ("doppler_center", C.c_int32),
+        ("doppler_bias", C.c_int32),
+        ("samples_per_chip", C.c_uint32),
+        ("samples_per_code", C.c_float),
+        ("bit_transition_flag", C.c_int32),
+        ("use_cfar", C.c_int32),
+        ("max_prn", C.c_uint32),
+    ]
+
+
+class AcqResult(C.Structure):
+    """gsh_acq_result."""
+    _fields_ = [
+        ("index_time", C.c_uint32),
+        ("index_doppler", C.c_uint32),
+        ("doppler_hz", C.c_int32),
+        ("acq_delay_samples", C.c_float),
+        ("peak", C.c_float),
+        ("input_power", C.c_float),
+        ("second_peak", C.c_float),
+        ("test_statistics", C.c_float),
+    ]
+
+
+# every symbol include/gnss_sdr_hip.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+_F = C.POINTER(C.c_float)
+SYMBOLS = {
+    "gsh_abi_version": (C.c_int, []),
+    "gsh_device_count": (C.c_int, []),
+    "gsh_last_error": (C.c_char_p, []),
+    "gsh_device_name": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
+    "gsh_mcorr_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
+    "gsh_mcorr_destroy": (None, [_P]),
+    "gsh_mcorr_init": (C.c_int, [_P, C.c_int, C.c_int]),
+    "gsh_mcorr_set_local_code_and_taps": (C.c_int, [_P, C.c_int, _F, _F]),
+    "gsh_mcorr_set_input_output_vectors": (C.c_int, [_P, _F, _F]),
+    "gsh_mcorr_set_high_dynamics_resampler": (C.c_int, [_P, C.c_int]),
+    "gsh_mcorr_carrier_wipeoff_multicorrelator_resampler": (C.c_int, [_P] + [C.c_float] * 6 + [C.c_int]),
+    "gsh_mcorr_carrier_wipeoff_multicorrelator_resampler6": (C.c_int, [_P] + [C.c_float] * 5 + [C.c_int]),
+    "gsh_mcorr_free": (C.c_int, [_P]),
+    "gsh_bank_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    "gsh_bank_destroy": (None, [_P]),
+    "gsh_bank_set_code": (C.c_int, [_P, C.c_int, _F, C.c_int]),
+    "gsh_bank_set_stream_host": (C.c_int, [_P, _F, C.c_uint64]),
+    "gsh_bank_set_stream_device": (C.c_int, [_P, _P, C.c_uint64]),
+    "gsh_bank_correlate": (C.c_int, [_P, C.POINTER(CorrJob), C.c_int, _F]),
+    "gsh_bank_upload_jobs": (C.c_int, [_P, C.POINTER(CorrJob), C.c_int]),
+    "gsh_bank_launch": (C.c_int, [_P, _P]),
+    "gsh_bank_synchronize": (C.c_int, [_P]),
+    "gsh_bank_read_outputs": (C.c_int, [_P, _F, C.c_int]),
+    "gsh_bank_time_launches": (C.c_int, [_P, C.c_int, _F]),
+    "gsh_bank_set_splits": (C.c_int, [_P, C.c_int]),
+    "gsh_acq_create": (C.c_int, [C.c_int, C.POINTER(AcqConf), C.POINTER(_P)]),
+    "gsh_acq_destroy": (None, [_P]),
+    "gsh_acq_set_local_code": (C.c_int, [_P, C.c_uint32, _F]),
+    "gsh_acq_set_doppler_center": (C.c_int, [_P, C.c_int32]),
+    "gsh_acq_dwell": (C.c_int, [_P, _F, C.c_uint32, C.c_int, C.c_uint32, C.POINTER(AcqResult)]),
+    "gsh_acq_dwell_device": (C.c_int, [_P, _P, C.c_uint32, C.c_int, C.c_uint32, C.POINTER(AcqResult)]),
+    "gsh_acq_read_grid": (C.c_int, [_P, C.c_uint32, _F]),
+    "gsh_acq_time_dwells": (C.c_int, [_P, C.c_uint32, C.c_int, _F]),
+    "gsh_acq_compute_threshold": (C.c_float, [C.c_float, C.c_uint32, C.c_uint32, C.c_uint32]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libgnss_sdr_hip.so; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(
+                f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(the HIP engine has no CPU fallback)")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name, None)
+            if fn is None:
+                continue  # reported by missing_symbols(); calling it later raises AttributeError
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def missing_symbols() -> list:
+    """Names declared in include/gnss_sdr_hip.h (SYMBOLS) that the built library does not export."""
+    lib = load()
+    return [name for name in SYMBOLS if getattr(lib, name, None) is None]
+
+
+def check(rc: int) -> None:
+    if rc != GSH_OK:
+        raise GshError(rc, load().gsh_last_error().decode("utf-8", "replace"))
+
+
+def fptr(arr):
+    """float32/complex64 numpy array -> float*."""
+    return arr.ctypes.data_as(_F)

@@ -1,0 +1,32 @@
+// Internal C++ interface between the C-ABI layer (gsh_api.hip) and the correlator kernels
+// (multicorrelator.hip).  Not part of the ABI.
+#ifndef GSH_MULTICORRELATOR_H
+#define GSH_MULTICORRELATOR_H
+
+#include "gsh_internal.h"
+
+namespace gsh
+{
+struct McorrArgs
+{
+    const float2* stream;            // device, complex64 IF samples
+    unsigned long long stream_len;   // samples
+    const gsh_corr_job* jobs;        // device, n_jobs entries
+    const float* codes;              // device, n_slots * code_stride floats
+    const int* code_lens;            // device, n_slots
+    int code_stride;
+    float2* out;                     // device, n_jobs * GSH_MAX_TAPS
+    float2* partials;                // device, n_jobs * splits * GSH_MAX_TAPS (splits > 1 only)
+    int n_jobs;
+    int splits;
+};
+
+// Largest n_taps over the jobs and which mode combinations occur decide the template
+// instance; all jobs of one launch must share `mode` (gsh_corr_job::high_dyn).
+int mcorr_launch(const McorrArgs& args, int max_taps, int mode, int max_code_len, hipStream_t stream);
+
+// dynamic LDS bytes the kernel needs for a code of max_code_len samples
+size_t mcorr_lds_bytes(int max_code_len);
+}  // namespace gsh
+
+#endif

@@ -1,0 +1,483 @@
+// C-ABI tracking entry points (include/gnss_sdr_hip.h): the batched correlator bank
+// (gsh_bank_*) and the one-to-one Cpu_Multicorrelator_Real_Codes replacement (gsh_mcorr_*)
+// built on top of it.  Host-side bookkeeping only; the arithmetic is in multicorrelator.hip.
+#include "multicorrelator.h"
+#include <algorithm>
+#include <cmath>
+#include <new>
+#include <vector>
+
+struct gsh_bank
+{
+    int device{0};
+    hipStream_t stream{nullptr};
+    int n_slots{0};
+    int max_code_len{0};
+    float* d_codes{nullptr};
+    int* d_code_lens{nullptr};
+    std::vector<int> h_code_lens;
+    float2* d_stream_owned{nullptr};
+    size_t stream_owned_cap{0};
+    const float2* d_stream{nullptr};
+    unsigned long long stream_len{0};
+    gsh_corr_job* d_jobs{nullptr};
+    float2* d_out{nullptr};
+    float2* d_partials{nullptr};
+    size_t partials_cap{0};
+    int jobs_cap{0};
+    int n_jobs{0};
+    int max_taps{0};
+    int mode{0};
+    int min_samples{0};
+    unsigned long long max_end{0};
+    int splits_user{0};
+    hipEvent_t ev0{nullptr}, ev1{nullptr};
+};
+
+namespace
+{
+using gsh::set_error;
+
+int bank_reserve_jobs(gsh_bank* b, int n)
+{
+    if (n <= b->jobs_cap) return GSH_OK;
+    if (b->d_jobs) GSH_HIP(hipFree(b->d_jobs));
+    if (b->d_out) GSH_HIP(hipFree(b->d_out));
+    b->d_jobs = nullptr;
+    b->d_out = nullptr;
+    b->jobs_cap = 0;
+    GSH_HIP(hipMalloc(&b->d_jobs, sizeof(gsh_corr_job) * static_cast<size_t>(n)));
+    GSH_HIP(hipMalloc(&b->d_out, sizeof(float2) * GSH_MAX_TAPS * static_cast<size_t>(n)));
+    b->jobs_cap = n;
+    return GSH_OK;
+}
+
+int bank_splits(const gsh_bank* b)
+{
+    int s = b->splits_user;
+    if (s <= 0)
+        {
+            // throughput mode once there are a few work-groups per CU; otherwise spread each
+            // epoch over several CUs (latency mode for closed-loop tracking)
+            s = (b->n_jobs >= 1024) ? 1 : (2048 + b->n_jobs - 1) / std::max(b->n_jobs, 1);
+        }
+    const int by_len = std::max(1, b->min_samples / 2048);  // keep >= 2048 samples per work-group
+    s = std::min(s, by_len);
+    s = std::min(s, 64);
+    return std::max(s, 1);
+}
+
+int validate_job(const gsh_bank* b, const gsh_corr_job& j, int idx)
+{
+    if (j.n_taps < 1 || j.n_taps > GSH_MAX_TAPS) return set_error(GSH_ERR_INVALID, "job %d: n_taps %d outside 1..%d", idx, j.n_taps, GSH_MAX_TAPS);
+    if (j.n_samples < 1 || j.n_samples > (1 << 30)) return set_error(GSH_ERR_INVALID, "job %d: n_samples %d", idx, j.n_samples);
+    if (j.code_slot < 0 || j.code_slot >= b->n_slots || b->h_code_lens[j.code_slot] <= 0)
+        return set_error(GSH_ERR_STATE, "job %d: code slot %d has no local code", idx, j.code_slot);
+    if (j.high_dyn < 0 || j.high_dyn > 2) return set_error(GSH_ERR_INVALID, "job %d: high_dyn %d", idx, j.high_dyn);
+    if (j.high_dyn != 0)
+        {
+            // the reference derives taps 1..T-1 by rotating tap 0 by round(dshift/step) samples
+            // (K/..high_dynamics_resampler..:82-90); a rotation outside [0, n] is undefined there.
+            unsigned acc = 0;
+            for (int t = 1; t < j.n_taps; t++)
+                {
+                    const float q = (j.shifts_chips[t] - j.shifts_chips[t - 1]) / j.code_phase_step_chips;
+                    if (!std::isfinite(q)) return set_error(GSH_ERR_INVALID, "job %d: high-dynamics tap spacing / code step is not finite", idx);
+                    acc += static_cast<unsigned>(static_cast<int>(std::round(q)));
+                    if (acc > static_cast<unsigned>(j.n_samples))
+                        return set_error(GSH_ERR_INVALID, "job %d: high-dynamics tap rotation %u outside [0, %d] (taps must ascend)", idx, acc, j.n_samples);
+                }
+        }
+    return GSH_OK;
+}
+}  // namespace
+
+extern "C"
+{
+    int gsh_bank_create(int device, int n_code_slots, int max_code_length, gsh_bank_t** out)
+    {
+        GSH_REQUIRE(out != nullptr, "null out pointer");
+        *out = nullptr;
+        GSH_REQUIRE(n_code_slots >= 1 && n_code_slots <= 65536, "n_code_slots %d", n_code_slots);
+        GSH_REQUIRE(max_code_length >= 1, "max_code_length %d", max_code_length);
+        GSH_REQUIRE(gsh::mcorr_lds_bytes(max_code_length) <= 64 * 1024, "max_code_length %d does not fit the LDS code table (limit %d samples)", max_code_length, 64 * 1024 / 4 - 128);
+        int rc = gsh::use_device(device);
+        if (rc != GSH_OK) return rc;
+        gsh_bank* b = new (std::nothrow) gsh_bank();
+        GSH_REQUIRE(b != nullptr, "out of host memory");
+        b->device = device;
+        b->n_slots = n_code_slots;
+        b->max_code_len = max_code_length;
+        b->h_code_lens.assign(n_code_slots, 0);
+        auto fail = [&](hipError_t e, const char* what) {
+            gsh::hip_fail(e, what, __FILE__, __LINE__);
+            gsh_bank_destroy(b);
+            return GSH_ERR_HIP;
+        };
+        hipError_t e;
+        if ((e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
+        if ((e = hipMalloc(&b->d_codes, sizeof(float) * static_cast<size_t>(n_code_slots) * max_code_length)) != hipSuccess) return fail(e, "hipMalloc(codes)");
+        if ((e = hipMalloc(&b->d_code_lens, sizeof(int) * n_code_slots)) != hipSuccess) return fail(e, "hipMalloc(code_lens)");
+        if ((e = hipMemset(b->d_code_lens, 0, sizeof(int) * n_code_slots)) != hipSuccess) return fail(e, "hipMemset");
+        if ((e = hipEventCreate(&b->ev0)) != hipSuccess) return fail(e, "hipEventCreate");
+        if ((e = hipEventCreate(&b->ev1)) != hipSuccess) return fail(e, "hipEventCreate");
+        *out = b;
+        return GSH_OK;
+    }
+
+    void gsh_bank_destroy(gsh_bank_t* b)
+    {
+        if (!b) return;
+        (void)hipSetDevice(b->device);
+        if (b->stream) (void)hipStreamSynchronize(b->stream);
+        if (b->d_codes) (void)hipFree(b->d_codes);
+        if (b->d_code_lens) (void)hipFree(b->d_code_lens);
+        if (b->d_stream_owned) (void)hipFree(b->d_stream_owned);
+        if (b->d_jobs) (void)hipFree(b->d_jobs);
+        if (b->d_out) (void)hipFree(b->d_out);
+        if (b->d_partials) (void)hipFree(b->d_partials);
+        if (b->ev0) (void)hipEventDestroy(b->ev0);
+        if (b->ev1) (void)hipEventDestroy(b->ev1);
+        if (b->stream) (void)hipStreamDestroy(b->stream);
+        delete b;
+    }
+
+    int gsh_bank_set_code(gsh_bank_t* b, int slot, const float* code, int code_length)
+    {
+        GSH_REQUIRE(b && code, "null argument");
+        GSH_REQUIRE(slot >= 0 && slot < b->n_slots, "slot %d outside 0..%d", slot, b->n_slots - 1);
+        GSH_REQUIRE(code_length >= 1 && code_length <= b->max_code_len, "code_length %d outside 1..%d", code_length, b->max_code_len);
+        GSH_HIP(hipSetDevice(b->device));
+        GSH_HIP(hipStreamSynchronize(b->stream));
+        GSH_HIP(hipMemcpy(b->d_codes + static_cast<size_t>(slot) * b->max_code_len, code, sizeof(float) * code_length, hipMemcpyHostToDevice));
+        GSH_HIP(hipMemcpy(b->d_code_lens + slot, &code_length, sizeof(int), hipMemcpyHostToDevice));
+        b->h_code_lens[slot] = code_length;
+        return GSH_OK;
+    }
+
+    int gsh_bank_set_stream_host(gsh_bank_t* b, const float* iq, uint64_t n_samples)
+    {
+        GSH_REQUIRE(b && iq, "null argument");
+        GSH_REQUIRE(n_samples >= 1, "empty stream");
+        GSH_HIP(hipSetDevice(b->device));
+        GSH_HIP(hipStreamSynchronize(b->stream));
+        const size_t need = static_cast<size_t>(n_samples) + 2;  // one spare pair: 16-byte loads may touch sample n
+        if (need > b->stream_owned_cap)
+            {
+                if (b->d_stream_owned) GSH_HIP(hipFree(b->d_stream_owned));
+                b->d_stream_owned = nullptr;
+                b->stream_owned_cap = 0;
+                GSH_HIP(hipMalloc(&b->d_stream_owned, sizeof(float2) * need));
+                b->stream_owned_cap = need;
+            }
+        GSH_HIP(hipMemcpy(b->d_stream_owned, iq, sizeof(float2) * n_samples, hipMemcpyHostToDevice));
+        GSH_HIP(hipMemset(b->d_stream_owned + n_samples, 0, sizeof(float2) * 2));
+        b->d_stream = b->d_stream_owned;
+        b->stream_len = n_samples;
+        return GSH_OK;
+    }
+
+    int gsh_bank_set_stream_device(gsh_bank_t* b, const void* device_iq, uint64_t n_samples)
+    {
+        GSH_REQUIRE(b && device_iq, "null argument");
+        GSH_REQUIRE(n_samples >= 1, "empty stream");
+        GSH_REQUIRE((reinterpret_cast<uintptr_t>(device_iq) & 15u) == 0, "device stream must be 16-byte aligned");
+        b->d_stream = static_cast<const float2*>(device_iq);
+        b->stream_len = n_samples;
+        return GSH_OK;
+    }
+
+    int gsh_bank_set_splits(gsh_bank_t* b, int splits)
+    {
+        GSH_REQUIRE(b != nullptr, "null bank");
+        GSH_REQUIRE(splits >= 0 && splits <= 64, "splits %d outside 0..64", splits);
+        b->splits_user = splits;
+        return GSH_OK;
+    }
+
+    int gsh_bank_upload_jobs(gsh_bank_t* b, const gsh_corr_job* jobs, int n_jobs)
+    {
+        GSH_REQUIRE(b != nullptr, "null bank");
+        GSH_REQUIRE(n_jobs >= 0, "n_jobs %d", n_jobs);
+        GSH_REQUIRE(n_jobs == 0 || jobs != nullptr, "null jobs");
+        b->n_jobs = 0;
+        if (n_jobs == 0) return GSH_OK;
+        int max_taps = 0, mode = jobs[0].high_dyn, min_samples = jobs[0].n_samples;
+        unsigned long long max_end = 0;
+        for (int i = 0; i < n_jobs; i++)
+            {
+                int rc = validate_job(b, jobs[i], i);
+                if (rc != GSH_OK) return rc;
+                if (jobs[i].high_dyn != mode)
+                    return set_error(GSH_ERR_UNSUPPORTED, "job %d: all jobs of one batch must share high_dyn (%d vs %d); split the batch", i, jobs[i].high_dyn, mode);
+                max_taps = std::max(max_taps, jobs[i].n_taps);
+                min_samples = std::min(min_samples, jobs[i].n_samples);
+                max_end = std::max(max_end, static_cast<unsigned long long>(jobs[i].sample_offset) + static_cast<unsigned long long>(jobs[i].n_samples));
+            }
+        GSH_HIP(hipSetDevice(b->device));
+        int rc = bank_reserve_jobs(b, n_jobs);
+        if (rc != GSH_OK) return rc;
+        GSH_HIP(hipMemcpyAsync(b->d_jobs, jobs, sizeof(gsh_corr_job) * static_cast<size_t>(n_jobs), hipMemcpyHostToDevice, b->stream));
+        GSH_HIP(hipStreamSynchronize(b->stream));
+        b->n_jobs = n_jobs;
+        b->max_taps = max_taps;
+        b->mode = mode;
+        b->min_samples = min_samples;
+        b->max_end = max_end;
+        return GSH_OK;
+    }
+
+    int gsh_bank_launch(gsh_bank_t* b, void* hip_stream)
+    {
+        GSH_REQUIRE(b != nullptr, "null bank");
+        if (b->n_jobs == 0) return GSH_OK;
+        if (b->d_stream == nullptr) return set_error(GSH_ERR_STATE, "no sample stream attached (gsh_bank_set_stream_*)");
+        if (b->max_end > b->stream_len)
+            return set_error(GSH_ERR_INVALID, "a job window ends at sample %llu, past the %llu-sample stream", b->max_end, b->stream_len);
+        GSH_HIP(hipSetDevice(b->device));
+        const int splits = bank_splits(b);
+        if (splits > 1)
+            {
+                const size_t need = static_cast<size_t>(b->n_jobs) * splits * GSH_MAX_TAPS;
+                if (need > b->partials_cap)
+                    {
+                        if (b->d_partials) GSH_HIP(hipFree(b->d_partials));
+                        b->d_partials = nullptr;
+                        b->partials_cap = 0;
+                        GSH_HIP(hipMalloc(&b->d_partials, sizeof(float2) * need));
+                        b->partials_cap = need;
+                    }
+            }
+        gsh::McorrArgs a;
+        a.stream = b->d_stream;
+        a.stream_len = b->stream_len;
+        a.jobs = b->d_jobs;
+        a.codes = b->d_codes;
+        a.code_lens = b->d_code_lens;
+        a.code_stride = b->max_code_len;
+        a.out = b->d_out;
+        a.partials = b->d_partials;
+        a.n_jobs = b->n_jobs;
+        a.splits = splits;
+        hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : b->stream;
+        return gsh::mcorr_launch(a, b->max_taps, b->mode, b->max_code_len, s);
+    }
+
+    int gsh_bank_synchronize(gsh_bank_t* b)
+    {
+        GSH_REQUIRE(b != nullptr, "null bank");
+        GSH_HIP(hipSetDevice(b->device));
+        GSH_HIP(hipStreamSynchronize(b->stream));
+        return GSH_OK;
+    }
+
+    int gsh_bank_read_outputs(gsh_bank_t* b, float* out_iq, int n_jobs)
+    {
+        GSH_REQUIRE(b && out_iq, "null argument");
+        GSH_REQUIRE(n_jobs >= 0 && n_jobs <= b->n_jobs, "n_jobs %d outside 0..%d", n_jobs, b->n_jobs);
+        if (n_jobs == 0) return GSH_OK;
+        GSH_HIP(hipSetDevice(b->device));
+        GSH_HIP(hipMemcpyAsync(out_iq, b->d_out, sizeof(float2) * GSH_MAX_TAPS * static_cast<size_t>(n_jobs), hipMemcpyDeviceToHost, b->stream));
+        GSH_HIP(hipStreamSynchronize(b->stream));
+        return GSH_OK;
+    }
+
+    int gsh_bank_correlate(gsh_bank_t* b, const gsh_corr_job* jobs, int n_jobs, float* out_iq)
+    {
+        int rc = gsh_bank_upload_jobs(b, jobs, n_jobs);
+        if (rc != GSH_OK) return rc;
+        rc = gsh_bank_launch(b, nullptr);
+        if (rc != GSH_OK) return rc;
+        return gsh_bank_read_outputs(b, out_iq, n_jobs);
+    }
+
+    int gsh_bank_time_launches(gsh_bank_t* b, int reps, float* avg_ms)
+    {
+        GSH_REQUIRE(b && avg_ms, "null argument");
+        GSH_REQUIRE(reps >= 1, "reps %d", reps);
+        GSH_HIP(hipSetDevice(b->device));
+        int rc = gsh_bank_launch(b, nullptr);  // warm-up, also validates state
+        if (rc != GSH_OK) return rc;
+        GSH_HIP(hipEventRecord(b->ev0, b->stream));
+        for (int i = 0; i < reps; i++)
+            {
+                rc = gsh_bank_launch(b, nullptr);
+                if (rc != GSH_OK) return rc;
+            }
+        GSH_HIP(hipEventRecord(b->ev1, b->stream));
+        GSH_HIP(hipEventSynchronize(b->ev1));
+        float ms = 0.0f;
+        GSH_HIP(hipEventElapsedTime(&ms, b->ev0, b->ev1));
+        *avg_ms = ms / static_cast<float>(reps);
+        return GSH_OK;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// gsh_mcorr_*: Cpu_Multicorrelator_Real_Codes replacement (mcorr.h:37-61)
+// ------------------------------------------------------------------------------------------
+struct gsh_mcorr
+{
+    int device{0};
+    gsh_bank* bank{nullptr};
+    int max_len{0};
+    int n_correlators{0};
+    int code_len{0};
+    float* shifts{nullptr};       // borrowed, re-read every call (mcorr.cc:58)
+    const float* sig_in{nullptr}; // borrowed (mcorr.cc:69)
+    float* corr_out{nullptr};     // borrowed (mcorr.cc:70)
+    bool high_dyn{true};          // mcorr.h:60 default
+    float2* h_pinned_in{nullptr};
+    float2* h_pinned_out{nullptr};
+    float2* d_in{nullptr};
+};
+
+namespace
+{
+int mcorr_run(gsh_mcorr* h, int mode, float rem_carr, float phase_step, float phase_rate, float rem_code, float code_step, float code_rate, int n)
+{
+    GSH_REQUIRE(h != nullptr, "null handle");
+    if (h->bank == nullptr || h->d_in == nullptr) return set_error(GSH_ERR_STATE, "init() has not been called");
+    if (h->code_len <= 0 || h->shifts == nullptr) return set_error(GSH_ERR_STATE, "set_local_code_and_taps() has not been called");
+    if (h->sig_in == nullptr || h->corr_out == nullptr) return set_error(GSH_ERR_STATE, "set_input_output_vectors() has not been called");
+    GSH_REQUIRE(n >= 1 && n <= h->max_len, "signal_length_samples %d outside 1..%d (init size)", n, h->max_len);
+    gsh_bank* b = h->bank;
+    GSH_HIP(hipSetDevice(h->device));
+
+    gsh_corr_job j;
+    std::memset(&j, 0, sizeof(j));
+    j.sample_offset = 0;
+    j.n_samples = n;
+    j.code_slot = 0;
+    j.rem_carr_phase_rad = rem_carr;
+    j.phase_step_rad = phase_step;
+    j.phase_rate_step_rad = phase_rate;
+    j.rem_code_phase_chips = rem_code;
+    j.code_phase_step_chips = code_step;
+    j.code_phase_rate_step_chips = code_rate;
+    j.n_taps = h->n_correlators;
+    j.high_dyn = mode;
+    for (int t = 0; t < h->n_correlators; t++) j.shifts_chips[t] = h->shifts[t];
+
+    // H2D of the epoch through pinned staging, one launch, D2H of T complex values
+    std::memcpy(h->h_pinned_in, h->sig_in, sizeof(float2) * static_cast<size_t>(n));
+    GSH_HIP(hipMemcpyAsync(h->d_in, h->h_pinned_in, sizeof(float2) * static_cast<size_t>(n), hipMemcpyHostToDevice, b->stream));
+    b->d_stream = h->d_in;
+    b->stream_len = static_cast<unsigned long long>(n);
+    int rc = gsh_bank_upload_jobs(b, &j, 1);
+    if (rc != GSH_OK) return rc;
+    rc = gsh_bank_launch(b, nullptr);
+    if (rc != GSH_OK) return rc;
+    GSH_HIP(hipMemcpyAsync(h->h_pinned_out, b->d_out, sizeof(float2) * GSH_MAX_TAPS, hipMemcpyDeviceToHost, b->stream));
+    GSH_HIP(hipStreamSynchronize(b->stream));
+    std::memcpy(h->corr_out, h->h_pinned_out, sizeof(float2) * static_cast<size_t>(h->n_correlators));
+    return GSH_OK;
+}
+}  // namespace
+
+extern "C"
+{
+    int gsh_mcorr_create(int device, gsh_mcorr_t** out)
+    {
+        GSH_REQUIRE(out != nullptr, "null out pointer");
+        *out = nullptr;
+        int rc = gsh::use_device(device);
+        if (rc != GSH_OK) return rc;
+        gsh_mcorr* h = new (std::nothrow) gsh_mcorr();
+        GSH_REQUIRE(h != nullptr, "out of host memory");
+        h->device = device;
+        *out = h;
+        return GSH_OK;
+    }
+
+    int gsh_mcorr_free(gsh_mcorr_t* h)
+    {
+        GSH_REQUIRE(h != nullptr, "null handle");
+        (void)hipSetDevice(h->device);
+        if (h->bank) gsh_bank_destroy(h->bank);
+        h->bank = nullptr;
+        if (h->h_pinned_in) (void)hipHostFree(h->h_pinned_in);
+        if (h->h_pinned_out) (void)hipHostFree(h->h_pinned_out);
+        if (h->d_in) (void)hipFree(h->d_in);
+        h->h_pinned_in = nullptr;
+        h->h_pinned_out = nullptr;
+        h->d_in = nullptr;
+        h->max_len = 0;
+        h->code_len = 0;
+        return GSH_OK;
+    }
+
+    void gsh_mcorr_destroy(gsh_mcorr_t* h)
+    {
+        if (!h) return;
+        gsh_mcorr_free(h);
+        delete h;
+    }
+
+    int gsh_mcorr_init(gsh_mcorr_t* h, int max_signal_length_samples, int n_correlators)
+    {
+        GSH_REQUIRE(h != nullptr, "null handle");
+        GSH_REQUIRE(max_signal_length_samples >= 1, "max_signal_length_samples %d", max_signal_length_samples);
+        GSH_REQUIRE(n_correlators >= 1 && n_correlators <= GSH_MAX_TAPS, "n_correlators %d outside 1..%d", n_correlators, GSH_MAX_TAPS);
+        gsh_mcorr_free(h);
+        GSH_HIP(hipSetDevice(h->device));
+        h->max_len = max_signal_length_samples;
+        h->n_correlators = n_correlators;
+        GSH_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->h_pinned_in), sizeof(float2) * static_cast<size_t>(max_signal_length_samples), hipHostMallocDefault));
+        GSH_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->h_pinned_out), sizeof(float2) * GSH_MAX_TAPS, hipHostMallocDefault));
+        GSH_HIP(hipMalloc(&h->d_in, sizeof(float2) * (static_cast<size_t>(max_signal_length_samples) + 2)));
+        GSH_HIP(hipMemset(h->d_in, 0, sizeof(float2) * (static_cast<size_t>(max_signal_length_samples) + 2)));
+        return GSH_OK;
+    }
+
+    int gsh_mcorr_set_local_code_and_taps(gsh_mcorr_t* h, int code_length_chips, const float* local_code_in, float* shifts_chips)
+    {
+        GSH_REQUIRE(h && local_code_in && shifts_chips, "null argument");
+        GSH_REQUIRE(code_length_chips >= 1, "code_length_chips %d", code_length_chips);
+        if (h->d_in == nullptr) return set_error(GSH_ERR_STATE, "init() has not been called");
+        if (h->bank == nullptr || h->bank->max_code_len < code_length_chips)
+            {
+                if (h->bank) gsh_bank_destroy(h->bank);
+                h->bank = nullptr;
+                int rc = gsh_bank_create(h->device, 1, code_length_chips, &h->bank);
+                if (rc != GSH_OK) return rc;
+            }
+        int rc = gsh_bank_set_code(h->bank, 0, local_code_in, code_length_chips);
+        if (rc != GSH_OK) return rc;
+        h->code_len = code_length_chips;
+        h->shifts = shifts_chips;
+        return GSH_OK;
+    }
+
+    int gsh_mcorr_set_input_output_vectors(gsh_mcorr_t* h, float* corr_out_iq, const float* sig_in_iq)
+    {
+        GSH_REQUIRE(h && corr_out_iq && sig_in_iq, "null argument");
+        h->corr_out = corr_out_iq;
+        h->sig_in = sig_in_iq;
+        return GSH_OK;
+    }
+
+    int gsh_mcorr_set_high_dynamics_resampler(gsh_mcorr_t* h, int use_high_dynamics_resampler)
+    {
+        GSH_REQUIRE(h != nullptr, "null handle");
+        h->high_dyn = use_high_dynamics_resampler != 0;
+        return GSH_OK;
+    }
+
+    int gsh_mcorr_carrier_wipeoff_multicorrelator_resampler(gsh_mcorr_t* h, float rem_carrier_phase_in_rad, float phase_step_rad,
+        float phase_rate_step_rad, float rem_code_phase_chips, float code_phase_step_chips, float code_phase_rate_step_chips,
+        int signal_length_samples)
+    {
+        GSH_REQUIRE(h != nullptr, "null handle");
+        return mcorr_run(h, h->high_dyn ? 1 : 0, rem_carrier_phase_in_rad, phase_step_rad, phase_rate_step_rad, rem_code_phase_chips,
+            code_phase_step_chips, code_phase_rate_step_chips, signal_length_samples);
+    }
+
+    int gsh_mcorr_carrier_wipeoff_multicorrelator_resampler6(gsh_mcorr_t* h, float rem_carrier_phase_in_rad, float phase_step_rad,
+        float rem_code_phase_chips, float code_phase_step_chips, float code_phase_rate_step_chips, int signal_length_samples)
+    {
+        GSH_REQUIRE(h != nullptr, "null handle");
+        return mcorr_run(h, h->high_dyn ? 2 : 0, rem_carrier_phase_in_rad, phase_step_rad, 0.0f, rem_code_phase_chips,
+            code_phase_step_chips, code_phase_rate_step_chips, signal_length_samples);
+    }
+}

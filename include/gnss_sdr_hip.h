@@ -1,0 +1,203 @@
+/*
+ * gnss_sdr_hip.h -- C ABI of the MI355X (gfx950) acquisition + tracking correlator engine.
+ *
+ * This is the drop-in boundary for gnss-sdr's one data-parallel hot path.  Plain C,
+ * plain pointers and sizes, opaque handles, int status returns (0 = GSH_OK); no HIP,
+ * torch or C++ types cross it and no exception ever does.  The shared library that
+ * implements it is gnss-sdr_amd/libgnss_sdr_hip.so (hand-written HIP, built by
+ * __graft_entry__.build()).  There is NO CPU fallback: every entry point that needs the
+ * GPU returns GSH_ERR_NO_DEVICE / GSH_ERR_HIP when it cannot run there.
+ *
+ * Each group of entry points names the reference interface it replaces; paths are
+ * relative to the gnss-sdr tree (/root/reference):
+ *   mcorr.h  = src/algorithms/tracking/libs/cpu_multicorrelator_real_codes.h
+ *   mcorr.cc = src/algorithms/tracking/libs/cpu_multicorrelator_real_codes.cc
+ *   acq.cc   = src/algorithms/acquisition/gnuradio_blocks/pcps_acquisition.cc
+ *   acq.h    = src/algorithms/acquisition/gnuradio_blocks/pcps_acquisition.h
+ *   trk.cc   = src/algorithms/tracking/gnuradio_blocks/dll_pll_veml_tracking.cc
+ *
+ * Complex samples are interleaved little-endian float32 I,Q everywhere ("iq" pointers
+ * address 2*n floats), i.e. gr_complex / std::complex<float> / lv_32fc_t memory.
+ */
+#ifndef GNSS_SDR_HIP_H
+#define GNSS_SDR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C"
+{
+#endif
+
+#define GSH_ABI_VERSION 1
+#define GSH_MAX_TAPS 8 /* VE/E/P/L/VL needs 5 (trk.cc:609-650); 8 leaves room for multi-tap dumps */
+
+    enum
+    {
+        GSH_OK = 0,
+        GSH_ERR_INVALID = 1,   /* bad argument (null pointer, size out of range, taps > GSH_MAX_TAPS ...) */
+        GSH_ERR_NO_DEVICE = 2, /* no HIP device / device index out of range */
+        GSH_ERR_HIP = 3,       /* a HIP runtime call failed; gsh_last_error() has the text */
+        GSH_ERR_STATE = 4,     /* call order violated (e.g. correlate before set_local_code) */
+        GSH_ERR_UNSUPPORTED = 5
+    };
+
+    /* ------------------------------------------------------------------ library */
+    int gsh_abi_version(void);
+    int gsh_device_count(void);               /* 0 when no GPU is visible */
+    const char* gsh_last_error(void);         /* thread-local, never NULL */
+    int gsh_device_name(int device, char* buf, size_t buflen);
+
+    /* ================================================================== TRACKING
+     * (1) gsh_mcorr_*: one-to-one replacement of class Cpu_Multicorrelator_Real_Codes
+     *     (mcorr.h:37-61).  Same call order, same argument meaning, same borrowed-pointer
+     *     rules as the reference: `shifts_chips`, `corr_out` and `sig_in` are BORROWED
+     *     (read / written at every correlate call, mcorr.cc:53-72); the local code is
+     *     copied to the device once per set_local_code_and_taps (the reference keeps a
+     *     pointer, trk.cc:1030 sets it once per start_tracking).
+     *     The reference's bool returns (always true, never checked: mcorr.cc:49,62,71,125)
+     *     become int status codes.
+     */
+    typedef struct gsh_mcorr gsh_mcorr_t;
+
+    int gsh_mcorr_create(int device, gsh_mcorr_t** out);
+    void gsh_mcorr_destroy(gsh_mcorr_t* h);
+
+    /* mcorr.cc:36-50  bool init(int max_signal_length_samples, int n_correlators) */
+    int gsh_mcorr_init(gsh_mcorr_t* h, int max_signal_length_samples, int n_correlators);
+    /* mcorr.cc:53-63  bool set_local_code_and_taps(int, const float*, float*) */
+    int gsh_mcorr_set_local_code_and_taps(gsh_mcorr_t* h, int code_length_chips, const float* local_code_in, float* shifts_chips);
+    /* mcorr.cc:66-72  bool set_input_output_vectors(std::complex<float>*, const std::complex<float>*) */
+    int gsh_mcorr_set_input_output_vectors(gsh_mcorr_t* h, float* corr_out_iq, const float* sig_in_iq);
+    /* mcorr.cc:163-167 void set_high_dynamics_resampler(bool)   (object default: true, mcorr.h:60) */
+    int gsh_mcorr_set_high_dynamics_resampler(gsh_mcorr_t* h, int use_high_dynamics_resampler);
+    /* mcorr.cc:103-126 bool Carrier_wipeoff_multicorrelator_resampler(7 args): synchronous,
+     * corr_out[0..n_correlators) is valid on return. */
+    int gsh_mcorr_carrier_wipeoff_multicorrelator_resampler(gsh_mcorr_t* h, float rem_carrier_phase_in_rad,
+        float phase_step_rad, float phase_rate_step_rad, float rem_code_phase_chips, float code_phase_step_chips,
+        float code_phase_rate_step_chips, int signal_length_samples);
+    /* mcorr.cc:129-144 6-argument overload: always the standard rotator, but the code
+     * resampler still follows the high-dynamics flag (mcorr.cc:137 calls update_local_code). */
+    int gsh_mcorr_carrier_wipeoff_multicorrelator_resampler6(gsh_mcorr_t* h, float rem_carrier_phase_in_rad,
+        float phase_step_rad, float rem_code_phase_chips, float code_phase_step_chips,
+        float code_phase_rate_step_chips, int signal_length_samples);
+    /* mcorr.cc:147-160 bool free() */
+    int gsh_mcorr_free(gsh_mcorr_t* h);
+
+    /*
+     * (2) gsh_bank_*: the batched form the GPU wants -- one launch serves every
+     *     (channel, epoch) "job" that is ready.  A job is exactly one reference
+     *     Carrier_wipeoff_multicorrelator_resampler call (mcorr.cc:103-126) whose input
+     *     window is addressed by sample index inside a device-resident IF stream instead
+     *     of a host pointer, so each sample crosses PCIe / xGMI once, not once per channel.
+     */
+    typedef struct gsh_bank gsh_bank_t;
+
+    typedef struct gsh_corr_job
+    {
+        uint64_t sample_offset;      /* first sample of the window inside the attached stream */
+        int32_t n_samples;           /* signal_length_samples, trk.cc:1243 passes vector_length */
+        int32_t code_slot;           /* which uploaded local code (one per channel / PRN) */
+        float rem_carr_phase_rad;    /* mcorr.cc:104 */
+        float phase_step_rad;        /* mcorr.cc:105 */
+        float phase_rate_step_rad;   /* mcorr.cc:106 (used only when high_dyn) */
+        float rem_code_phase_chips;  /* mcorr.cc:107, already multiplied by samples-per-chip (trk.cc:1240) */
+        float code_phase_step_chips; /* mcorr.cc:108 */
+        float code_phase_rate_step_chips; /* mcorr.cc:109 (used only when high_dyn) */
+        int32_t n_taps;              /* 1..GSH_MAX_TAPS */
+        int32_t high_dyn;            /* 0: resampler_32f_xn + rotator_dot_prod; 1: the high-dynamics pair */
+        float shifts_chips[GSH_MAX_TAPS]; /* tap offsets in code samples, ascending (trk.cc:632-648) */
+    } gsh_corr_job;                  /* 80 bytes, POD */
+
+    int gsh_bank_create(int device, int n_code_slots, int max_code_length, gsh_bank_t** out);
+    void gsh_bank_destroy(gsh_bank_t* b);
+    /* copy one real-valued local code (trk.cc:810-1028 generate it) into slot `slot` */
+    int gsh_bank_set_code(gsh_bank_t* b, int slot, const float* code, int code_length);
+    /* IF sample stream.  _host copies n samples to the device (H2D);
+     * _device borrows device memory the caller keeps alive (16-byte aligned). */
+    int gsh_bank_set_stream_host(gsh_bank_t* b, const float* iq, uint64_t n_samples);
+    int gsh_bank_set_stream_device(gsh_bank_t* b, const void* device_iq, uint64_t n_samples);
+    /* one synchronous batch: upload jobs, launch, download.  out_iq: n_jobs*GSH_MAX_TAPS complex64
+     * (job-major, tap-minor; taps >= n_taps are zero). */
+    int gsh_bank_correlate(gsh_bank_t* b, const gsh_corr_job* jobs, int n_jobs, float* out_iq);
+    /* the same, split so that a caller can keep the job table and results on the device and
+     * time launches alone: upload once, launch many, read once.  hip_stream: a hipStream_t cast to
+     * void* (NULL = the bank's own stream).  gsh_bank_launch is asynchronous. */
+    int gsh_bank_upload_jobs(gsh_bank_t* b, const gsh_corr_job* jobs, int n_jobs);
+    int gsh_bank_launch(gsh_bank_t* b, void* hip_stream);
+    int gsh_bank_synchronize(gsh_bank_t* b);
+    int gsh_bank_read_outputs(gsh_bank_t* b, float* out_iq, int n_jobs);
+    /* HIP-event timing of `reps` back-to-back launches of the uploaded job table on the bank's
+     * stream: average milliseconds per launch of the correlator kernel. */
+    int gsh_bank_time_launches(gsh_bank_t* b, int reps, float* avg_ms);
+    /* work-groups per job used by the next launches (1 = throughput mode; >1 spreads one epoch
+     * over more CUs for latency-bound closed-loop use).  0 = choose automatically. */
+    int gsh_bank_set_splits(gsh_bank_t* b, int splits);
+
+    /* ================================================================ ACQUISITION
+     * gsh_acq_*: the arithmetic of class pcps_acquisition (acq.h:93-251) without its
+     * GNU Radio shell: set_local_code (acq.cc:218-251), update_grid_doppler_wipeoffs
+     * (acq.cc:284-291), doppler_grid (acq.cc:522-560), both statistics (acq.cc:409-519).
+     * One handle searches n_prn local codes against the same input block in one go
+     * (the reference runs one block per channel, each recomputing the D forward FFTs).
+     */
+    typedef struct gsh_acq gsh_acq_t;
+
+    typedef struct gsh_acq_conf
+    {
+        int64_t fs_in;              /* Acq_Conf::fs_in (resampled_fs when the resampler is on), acq.cc:277 */
+        uint32_t fft_size;          /* d_fft_size, acq.cc:111 */
+        uint32_t effective_fft_size; /* d_effective_fft_size, acq.cc:112 */
+        uint32_t consumed_samples;  /* d_consumed_samples, acq.cc:110 */
+        uint32_t num_doppler_bins;  /* d_num_doppler_bins, acq.cc:113; 0 = ceil(2*doppler_max/doppler_step) */
+        int32_t doppler_max;        /* Acq_Conf::doppler_max */
+        int32_t doppler_step;       /* Acq_Conf::doppler_step */
+        int32_t doppler_center;     /* set_doppler_center, acq.cc:737-746 */
+        int32_t doppler_bias;       /* GLONASS FDMA offset, acq.cc:254-272; 0 otherwise */
+        uint32_t samples_per_chip;  /* Acq_Conf::samples_per_chip, acq_conf.cc:122 */
+        float samples_per_code;     /* Acq_Conf::samples_per_code, acq_conf.cc:123 */
+        int32_t bit_transition_flag; /* acq.cc:230-235,544 */
+        int32_t use_cfar;           /* d_use_CFAR_algorithm_flag: 1 = max_to_input_power, 0 = first_vs_second_peak */
+        uint32_t max_prn;           /* how many local codes this handle can hold */
+    } gsh_acq_conf;
+
+    typedef struct gsh_acq_result
+    {
+        uint32_t index_time;        /* AcquisitionResult::index_time  (lowest index on ties) */
+        uint32_t index_doppler;     /* winning Doppler bin (first bin on ties, acq.cc:420) */
+        int32_t doppler_hz;         /* AcquisitionResult::doppler, acq.cc:431 */
+        float acq_delay_samples;    /* fmod((float)index_time, samples_per_code), acq.cc:582 */
+        float peak;                 /* grid maximum */
+        float input_power;          /* d_input_power (CFAR only), acq.cc:430 */
+        float second_peak;          /* peak-ratio statistic only, acq.cc:511-513 */
+        float test_statistics;      /* acq.cc:439-445 or :516 */
+    } gsh_acq_result;
+
+    int gsh_acq_create(int device, const gsh_acq_conf* conf, gsh_acq_t** out);
+    void gsh_acq_destroy(gsh_acq_t* a);
+    /* acq.cc:218-251: place the time-domain replica per the padding rules, FFT, conjugate.
+     * `code_iq` holds consumed_samples complex samples (fft_size/2 when bit_transition_flag). */
+    int gsh_acq_set_local_code(gsh_acq_t* a, uint32_t prn_slot, const float* code_iq);
+    /* acq.cc:737-746 */
+    int gsh_acq_set_doppler_center(gsh_acq_t* a, int32_t doppler_center);
+    /* one acquisition_core pass (acq.cc:648-684) for prn_slot 0..n_prn-1 over the same
+     * consumed_samples input block.  `accumulate` != 0 adds to the stored grids
+     * (non-coherent dwell number > 1, acq.cc:549-553); `dwell_count` is
+     * d_num_noncoherent_integrations_counter after the increment (acq.cc:668), used by the
+     * CFAR power normalisation (acq.cc:430). */
+    int gsh_acq_dwell(gsh_acq_t* a, const float* in_iq, uint32_t n_prn, int accumulate, uint32_t dwell_count, gsh_acq_result* results);
+    /* same with the input block already in device memory (16-byte aligned) */
+    int gsh_acq_dwell_device(gsh_acq_t* a, const void* device_in_iq, uint32_t n_prn, int accumulate, uint32_t dwell_count, gsh_acq_result* results);
+    /* dump support (acq.cc:555-558): copy |.|^2 grid of one PRN, D rows of effective_fft_size floats */
+    int gsh_acq_read_grid(gsh_acq_t* a, uint32_t prn_slot, float* grid);
+    /* HIP-event average milliseconds per full dwell batch (n_prn codes), inputs resident */
+    int gsh_acq_time_dwells(gsh_acq_t* a, uint32_t n_prn, int reps, float* avg_ms);
+
+    /* compute_threshold, acq.cc:52-56: 2*gamma_p_inv(2*max_dwells, (1-pfa)^(1/(effective*bins))) */
+    float gsh_acq_compute_threshold(float pfa, uint32_t effective_fft_size, uint32_t num_doppler_bins, uint32_t max_dwells);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GNSS_SDR_HIP_H */

@@ -1,0 +1,226 @@
+/*
+ * TEST INFRASTRUCTURE ONLY (oracle/_ref build) -- never linked into the product.
+ *
+ * C entry points over the *reference's own* objects, compiled from
+ * /root/reference by oracle/Makefile:
+ *   - Cpu_Multicorrelator_Real_Codes  (src/algorithms/tracking/libs/cpu_multicorrelator_real_codes.cc)
+ *   - gps_l1_ca_code_gen_*            (src/algorithms/libs/gps_sdr_signal_replica.cc)
+ *   - galileo_e1_code_gen_*           (src/algorithms/libs/galileo_e1_signal_replica.cc)
+ *   - gps_l5{i,q}_code_gen_*          (src/algorithms/libs/gps_l5_signal_replica.cc)
+ *   - volk_gnsssdr protokernels       (through oracle/ref_kernels.c)
+ *
+ * Used to (1) pin oracle/gnss_oracle.c against the reference, (2) mint the
+ * golden fixtures under tests/golden/, (3) time the reference CPU path
+ * (bench.py cpu_baseline, kind "reference").
+ */
+#include "cpu_multicorrelator_real_codes.h"
+#include "galileo_e1_signal_replica.h"
+#include "gps_l5_signal_replica.h"
+#include "gps_sdr_signal_replica.h"
+#include <volk_gnsssdr/volk_gnsssdr.h>
+#include <array>
+#include <atomic>
+#include <chrono>
+#include <complex>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+extern "C"
+{
+    /* protokernels with external linkage, oracle/ref_kernels.c */
+    void ref_generic_resampler(float**, const float*, float, float, float*, unsigned int, int, unsigned int);
+    void ref_generic_hd_resampler(float**, const float*, float, float, float, float*, unsigned int, int, unsigned int);
+    void ref_generic_rotator_dot_prod(lv_32fc_t*, const lv_32fc_t*, const lv_32fc_t, lv_32fc_t*, const float**, int, unsigned int);
+    void ref_generic_hd_rotator_dot_prod(lv_32fc_t*, const lv_32fc_t*, const lv_32fc_t, const lv_32fc_t, lv_32fc_t*, const float**, int, unsigned int);
+    void ref_simd_resampler(float**, const float*, float, float, float*, unsigned int, int, unsigned int);
+    void ref_simd_hd_resampler(float**, const float*, float, float, float, float*, unsigned int, int, unsigned int);
+    void ref_simd_rotator_dot_prod(lv_32fc_t*, const lv_32fc_t*, const lv_32fc_t, lv_32fc_t*, const float**, int, unsigned int);
+    void ref_simd_hd_rotator_dot_prod(lv_32fc_t*, const lv_32fc_t*, const lv_32fc_t, const lv_32fc_t, lv_32fc_t*, const float**, int, unsigned int);
+    void ref_generic_sincos(lv_32fc_t*, float, float*, unsigned int);
+    void ref_generic_index_max(uint32_t*, const float*, uint32_t);
+}
+
+namespace
+{
+/* 0 = _generic protokernels (parity oracle); 1 = x86 SIMD protokernels (timing baseline). */
+std::atomic<int> g_flavour{0};
+}  // namespace
+
+extern "C"
+{
+    /* ---- what the generated volk_gnsssdr library would provide ---------------- */
+    size_t volk_gnsssdr_get_alignment(void) { return 32; }
+
+    void* volk_gnsssdr_malloc(size_t size, size_t alignment)
+    {
+        void* p = nullptr;
+        if (alignment < sizeof(void*)) alignment = sizeof(void*);
+        if (posix_memalign(&p, alignment, size ? size : alignment) != 0) return nullptr;
+        return p;
+    }
+
+    void volk_gnsssdr_free(void* p) { std::free(p); }
+
+    void volk_gnsssdr_32f_xn_resampler_32f_xn(float** r, const float* c, float rem, float step, float* sh, unsigned int L, int nv, unsigned int n)
+    {
+        (g_flavour.load() ? ref_simd_resampler : ref_generic_resampler)(r, c, rem, step, sh, L, nv, n);
+    }
+
+    void volk_gnsssdr_32f_xn_high_dynamics_resampler_32f_xn(float** r, const float* c, float rem, float step, float rate, float* sh, unsigned int L, int nv, unsigned int n)
+    {
+        (g_flavour.load() ? ref_simd_hd_resampler : ref_generic_hd_resampler)(r, c, rem, step, rate, sh, L, nv, n);
+    }
+
+    void volk_gnsssdr_32fc_32f_rotator_dot_prod_32fc_xn(lv_32fc_t* res, const lv_32fc_t* in, const lv_32fc_t inc, lv_32fc_t* ph, const float** a, int nv, unsigned int n)
+    {
+        (g_flavour.load() ? ref_simd_rotator_dot_prod : ref_generic_rotator_dot_prod)(res, in, inc, ph, a, nv, n);
+    }
+
+    void volk_gnsssdr_32fc_32f_high_dynamic_rotator_dot_prod_32fc_xn(lv_32fc_t* res, const lv_32fc_t* in, const lv_32fc_t inc, const lv_32fc_t inc_rate, lv_32fc_t* ph, const float** a, int nv, unsigned int n)
+    {
+        (g_flavour.load() ? ref_simd_hd_rotator_dot_prod : ref_generic_hd_rotator_dot_prod)(res, in, inc, inc_rate, ph, a, nv, n);
+    }
+
+    /* ---- test-facing API --------------------------------------------------------- */
+
+    /* returns 1 if the SIMD flavour can run on this CPU */
+    int ref_simd_supported(void)
+    {
+        __builtin_cpu_init();
+        return (__builtin_cpu_supports("avx") && __builtin_cpu_supports("sse4.1")) ? 1 : 0;
+    }
+
+    void ref_set_flavour(int simd) { g_flavour.store((simd && ref_simd_supported()) ? 1 : 0); }
+
+    /*
+     * One call of the reference correlator object, exactly as
+     * dll_pll_veml_tracking::do_correlation_step drives it (trk.cc:1232-1243):
+     * init(2*n) -> set_high_dynamics_resampler -> set_local_code_and_taps ->
+     * set_input_output_vectors -> Carrier_wipeoff_multicorrelator_resampler.
+     * in/out are interleaved complex64.
+     */
+    int ref_mcorr_run(const float* code, int code_len, const float* shifts, int n_taps,
+        const float* in_iq, int n, float rem_carr, float phase_step, float phase_rate_step,
+        float rem_code, float code_step, float code_rate_step, int high_dyn, float* out_iq)
+    {
+        Cpu_Multicorrelator_Real_Codes mc;
+        std::vector<float> taps(shifts, shifts + n_taps);
+        std::vector<std::complex<float>> out(n_taps);
+        mc.init(2 * n, n_taps);
+        mc.set_high_dynamics_resampler(high_dyn != 0);
+        mc.set_local_code_and_taps(code_len, code, taps.data());
+        mc.set_input_output_vectors(out.data(), reinterpret_cast<const std::complex<float>*>(in_iq));
+        if (high_dyn == 2)
+            {
+                /* the 6-argument overload (cpu_multicorrelator_real_codes.cc:129-144) */
+                mc.Carrier_wipeoff_multicorrelator_resampler(rem_carr, phase_step, rem_code, code_step, code_rate_step, n);
+            }
+        else
+            {
+                mc.Carrier_wipeoff_multicorrelator_resampler(rem_carr, phase_step, phase_rate_step, rem_code, code_step, code_rate_step, n);
+            }
+        std::memcpy(out_iq, out.data(), sizeof(float) * 2 * n_taps);
+        mc.free();
+        return 0;
+    }
+
+    /*
+     * Timing harness in the style of cpu_multicorrelator_real_codes_test.cc:137-158:
+     * one std::thread per channel, each running `epochs` correlations of n samples
+     * over its own window of a shared stream.  Returns elapsed seconds.
+     * params: per channel 6 floats {rem_carr, phase_step, rem_code, code_step, start_offset, unused}.
+     */
+    double ref_mcorr_time(const float* codes, int code_len, const float* shifts, int n_taps,
+        const float* stream_iq, long stream_len, int n, int n_channels, int epochs, int n_threads,
+        const float* params, float* out_iq)
+    {
+        std::vector<std::thread> pool;
+        const auto t0 = std::chrono::steady_clock::now();
+        std::atomic<int> next{0};
+        auto worker = [&]() {
+            for (;;)
+                {
+                    const int ch = next.fetch_add(1);
+                    if (ch >= n_channels) break;
+                    Cpu_Multicorrelator_Real_Codes mc;
+                    std::vector<float> taps(shifts, shifts + n_taps);
+                    std::vector<std::complex<float>> out(n_taps);
+                    mc.init(2 * n, n_taps);
+                    mc.set_high_dynamics_resampler(false);
+                    mc.set_local_code_and_taps(code_len, codes + static_cast<size_t>(ch) * code_len, taps.data());
+                    const float* p = params + 6 * ch;
+                    long pos = static_cast<long>(p[4]);
+                    for (int e = 0; e < epochs; e++)
+                        {
+                            if (pos + n > stream_len) pos = static_cast<long>(p[4]);
+                            mc.set_input_output_vectors(out.data(), reinterpret_cast<const std::complex<float>*>(stream_iq) + pos);
+                            mc.Carrier_wipeoff_multicorrelator_resampler(p[0], p[1], 0.0F, p[2], p[3], 0.0F, n);
+                            pos += n;
+                        }
+                    std::memcpy(out_iq + static_cast<size_t>(ch) * 2 * n_taps, out.data(), sizeof(float) * 2 * n_taps);
+                    mc.free();
+                }
+        };
+        for (int t = 0; t < n_threads; t++) pool.emplace_back(worker);
+        for (auto& th : pool) th.join();
+        return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+
+    /* single protokernels, generic flavour */
+    void ref_resampler_generic(float** r, const float* c, float rem, float step, float* sh, unsigned int L, int nv, unsigned int n)
+    {
+        ref_generic_resampler(r, c, rem, step, sh, L, nv, n);
+    }
+
+    void ref_hd_resampler_generic(float** r, const float* c, float rem, float step, float rate, float* sh, unsigned int L, int nv, unsigned int n)
+    {
+        ref_generic_hd_resampler(r, c, rem, step, rate, sh, L, nv, n);
+    }
+
+    void ref_sincos_generic(float* out_iq, float phase_inc, float* phase, unsigned int n)
+    {
+        ref_generic_sincos(reinterpret_cast<lv_32fc_t*>(out_iq), phase_inc, phase, n);
+    }
+
+    void ref_index_max_generic(uint32_t* target, const float* src, uint32_t n)
+    {
+        ref_generic_index_max(target, src, n);
+    }
+
+    /* PRN generators */
+    void ref_gps_l1_ca_code_gen_float(float* dest, int prn, unsigned int chip_shift)
+    {
+        gps_l1_ca_code_gen_float(own::span<float>(dest, 1023), prn, chip_shift);
+    }
+
+    void ref_gps_l1_ca_code_gen_complex_sampled(float* dest_iq, int n, unsigned int prn, int fs, unsigned int chip_shift)
+    {
+        gps_l1_ca_code_gen_complex_sampled(own::span<std::complex<float>>(reinterpret_cast<std::complex<float>*>(dest_iq), n), prn, fs, chip_shift);
+    }
+
+    /* signal: "1B" or "1C"; dest holds 2*4092 floats */
+    void ref_galileo_e1_code_gen_sinboc11_float(float* dest, const char* signal, unsigned int prn)
+    {
+        std::array<char, 3> sig{{signal[0], signal[1], '\0'}};
+        galileo_e1_code_gen_sinboc11_float(own::span<float>(dest, 2 * 4092), sig, prn);
+    }
+
+    void ref_galileo_e1_code_gen_complex_sampled(float* dest_iq, int n, const char* signal, int cboc, unsigned int prn, int fs, unsigned int chip_shift)
+    {
+        std::array<char, 3> sig{{signal[0], signal[1], '\0'}};
+        galileo_e1_code_gen_complex_sampled(own::span<std::complex<float>>(reinterpret_cast<std::complex<float>*>(dest_iq), n), sig, cboc != 0, prn, fs, chip_shift);
+    }
+
+    void ref_gps_l5i_code_gen_float(float* dest, unsigned int prn)
+    {
+        gps_l5i_code_gen_float(own::span<float>(dest, 10230), prn);
+    }
+
+    void ref_gps_l5q_code_gen_float(float* dest, unsigned int prn)
+    {
+        gps_l5q_code_gen_float(own::span<float>(dest, 10230), prn);
+    }
+}
