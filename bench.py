@@ -1,0 +1,313 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's headline metric on MI355X: tracking correlators/s.
+
+Workload (config.workload): BASELINE config 2 -- GPS L1 C/A, 32 channels (PRN 1..32), fs = 25 Msps,
+N = 25 000 samples per 1 ms epoch, 3-tap E/P/L -- open-loop (pre-computed NCO parameter table), every channel
+reading its own window sequence of ONE shared complex64 IF stream (noise + 8 embedded signals at 45 dB-Hz).
+A "step" is one pass of the hot path over one batch: channels x epochs jobs in one launch, inputs (stream, codes,
+job table) already resident in HBM.  value = channels*taps*epochs / time, whole job.
+
+  python bench.py --gpus N --steps K --warmup W
+  N > 1: launched by torch.distributed.run, one rank per GPU; every rank tracks its own 32 channels of the same
+  stream (weak scaling); the stream block is re-broadcast from rank 0 over RCCL every step (double-buffered on
+  the communicator's stream, overlapped with the previous block's correlation) and that time IS inside the
+  timed region.
+
+One JSON line on stdout (rank 0).  Besides the contract keys it carries
+  roofline      -- dominant kernel (mcorr_kernel<3,0>) vs the HBM roofline, algorithmic bytes 8N+8T per job,
+                   duration from HIP events on the launch stream
+  cpu_baseline  -- the reference's own Cpu_Multicorrelator_Real_Codes (oracle/_ref, x86 SIMD protokernels) timed on
+                   this box's host cores over a bounded sample (falls back to the C port when _ref is absent)
+  acquisition   -- secondary metric: PCPS dwells/s for BASELINE config 3 (32 PRN x 41 bins x 25 000)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md (6.3 TB/s measured achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--channels", type=int, default=32)
+    ap.add_argument("--epochs", type=int, default=400, help="1 ms epochs per channel per step")
+    ap.add_argument("--fs", type=float, default=25e6)
+    ap.add_argument("--taps", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-acq", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline leg")
+    return ap.parse_args()
+
+
+def make_stream_torch(torch, dev, n_samples, fs, n_sig=8, cn0=45.0):
+    """Synthetic IF stream on the device: N(0,1)+jN(0,1) + n_sig GPS C/A signals at cn0 dB-Hz."""
+    import oracle
+    g = torch.Generator(device=dev)
+    g.manual_seed(0x5EED0002)
+    x = torch.randn(n_samples, 2, generator=g, device=dev, dtype=torch.float32)
+    x = torch.view_as_complex(x).contiguous()
+    rng = np.random.default_rng(0x5EED0003)
+    dop = rng.uniform(-5000, 5000, n_sig)
+    cph = rng.uniform(0, 1023, n_sig)
+    amp = float(np.sqrt(10.0 ** (cn0 / 10.0) * 2.0 / fs))
+    t = torch.arange(n_samples, device=dev, dtype=torch.float64)
+    for i in range(n_sig):
+        code = torch.from_numpy(oracle.ca_code(i + 1)).to(dev)
+        f_code = 1.023e6 * (1.0 + dop[i] / 1575.42e6)
+        chip = torch.floor(t * (f_code / fs) + cph[i]).to(torch.int64) % 1023
+        ph = (2.0 * np.pi * dop[i] / fs) * t
+        ph = ph - 2.0 * np.pi * torch.floor(ph / (2.0 * np.pi))
+        x += (amp * code[chip]).to(torch.complex64) * torch.polar(torch.ones_like(ph, dtype=torch.float32), ph.to(torch.float32))
+        del chip, ph
+    return x, dop, cph
+
+
+def build_jobs(channels, epochs, n, fs, taps, dop, cph, rank):
+    """Epoch-major, channel-minor job table (jobs that read the same samples are adjacent: they share an XCD L2)."""
+    from gnss_sdr_amd.tracking import make_jobs
+    from helpers import tracking_params_for
+    rng = np.random.default_rng(0x5EED0004 + rank)
+    per_ch = []
+    for c in range(channels):
+        if c < len(dop) and rank == 0:
+            fd = float(dop[c])
+            f_code = 1.023e6 * (1 + fd / 1575.42e6)
+            start = (1023.0 - cph[c]) / f_code * fs
+            off = int(np.ceil(start))
+            p = tracking_params_for(fs, fd, rng)
+            p["rem_code_phase_chips"] = float(np.float32(-(off - start) * f_code / fs))
+        else:
+            off = int(rng.integers(0, n))
+            p = tracking_params_for(fs, rng.uniform(-5000, 5000), rng)
+        per_ch.append((off, p))
+    if taps == 3:
+        shifts = [-0.5, 0.0, 0.5]
+    elif taps == 5:
+        shifts = [-0.5, -0.15, 0.0, 0.15, 0.5]
+    else:
+        shifts = list(np.linspace(-0.5, 0.5, taps))
+    rows = []
+    for e in range(epochs):
+        for c in range(channels):
+            off, p = per_ch[c]
+            rows.append(dict(sample_offset=off + e * n, n_samples=n, code_slot=c, shifts_chips=shifts, **p))
+    return make_jobs(rows), rows
+
+
+def cpu_baseline(channels, n, fs, taps, target_s):
+    """The reference CPU path on this box's host cores over a bounded sample of the same workload."""
+    import oracle
+    from helpers import synth_gps_l1_stream, tracking_params_for
+    cores = os.cpu_count() or 1
+    R = oracle.ref()
+    kind = "reference" if R is not None else "port"
+    epochs_stream = 8
+    x = synth_gps_l1_stream((epochs_stream + 2) * n, fs, [1, 2], [1000.0, -2500.0], [10.0, 500.0], seed_noise=3)
+    xi = np.ascontiguousarray(x).view(np.float32)
+    codes = np.concatenate([oracle.ca_code(c % 32 + 1) for c in range(channels)]).astype(np.float32)
+    shifts = np.array([-0.5, 0.0, 0.5] if taps == 3 else np.linspace(-0.5, 0.5, taps), np.float32)
+    rng = np.random.default_rng(9)
+    params = np.zeros((channels, 6), np.float32)
+    for c in range(channels):
+        p = tracking_params_for(fs, rng.uniform(-5000, 5000), rng)
+        params[c] = [p["rem_carr_phase_rad"], p["phase_step_rad"], p["rem_code_phase_chips"], p["code_phase_step_chips"], rng.integers(0, n), 0]
+    out = np.zeros(channels * 2 * taps, np.float32)
+
+    def run(epochs):
+        if R is not None:
+            R.ref_set_flavour(1)  # x86 SIMD protokernels = what volk_gnsssdr dispatches to on this host
+            try:
+                return R.ref_mcorr_time(codes, 1023, shifts, taps, xi, len(x), n, channels, epochs, cores, params, out)
+            finally:
+                R.ref_set_flavour(0)
+        return oracle.lib().oracle_mcorr_time(codes, 1023, shifts, taps, xi, len(x), n, channels, epochs, cores, params, out)
+
+    epochs = 16
+    t = run(epochs)  # calibration, then grow the sample until it fills about target_s of wall time
+    while t < target_s / 3.0 and epochs < 200000:
+        epochs = int(min(200000, max(epochs * 2, epochs * 0.9 * target_s / max(t, 1e-6))))
+        t = run(epochs)
+    simd = bool(R is not None and R.ref_simd_supported())
+    return {
+        "value": channels * taps * epochs / t,
+        "unit": "correlators/s",
+        "cores": cores,
+        "kind": kind,
+        "sample": f"{channels} channels x {epochs} epochs of {n} samples, {taps} taps, {cores} threads, "
+                  + ("Cpu_Multicorrelator_Real_Codes over volk_gnsssdr " + ("u_avx" if simd else "generic") + " protokernels (oracle/_ref)"
+                     if kind == "reference" else "oracle/gnss_oracle.c scalar port"),
+        "seconds": t,
+    }
+
+
+def acquisition_metric(torch, dev_index, x_block, fs):
+    """Secondary metric: PCPS dwells/s, BASELINE config 3 (32 PRN x 41 Doppler bins x 25 000 samples)."""
+    try:
+        from gnss_sdr_amd.acquisition import PcpsAcquisitionBank
+    except Exception as e:  # acquisition not built yet
+        return {"error": f"acquisition unavailable: {e}"}
+    import oracle
+    n = int(fs * 1e-3)
+    acq = PcpsAcquisitionBank(fs_in=int(fs), fft_size=n, doppler_max=5000, doppler_step=250, num_doppler_bins=41,
+                              samples_per_chip=int(np.ceil(fs / 1.023e6)), samples_per_code=float(n), max_prn=32, device=dev_index)
+    for p in range(32):
+        acq.set_local_code(p, oracle.ca_code_complex_sampled(p + 1, int(fs)))
+    ms = acq.time_dwells(x_block, 32, reps=10)
+    nbytes = 16.0 * n * 41 * (32 + 1)
+    res = {"metric": "acquisition dwells/s", "value": 32.0 / (ms * 1e-3), "unit": "dwells/s", "ms_per_batch": ms,
+           "config": {"workload": "GPS L1 C/A PCPS, 32 PRN x 41 Doppler bins, N=25000, 1 dwell"},
+           "roofline": {"bound": "hbm", "achieved": nbytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None}}
+    acq.close()
+    return res
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import gnss_sdr_amd
+    from gnss_sdr_amd.tracking import CorrelatorBank
+    import oracle
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP engine has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    fs, n, C, E, T = a.fs, int(round(a.fs * 1e-3)), a.channels, a.epochs, a.taps
+    n_samples = (E + 2) * n
+    n_samples += (-n_samples) % 2
+
+    # ---- inputs, resident in HBM before the timed region
+    if rank == 0:
+        x, dop, cph = make_stream_torch(torch, dev, n_samples, fs)
+    else:
+        x = torch.zeros(n_samples, dtype=torch.complex64, device=dev)
+        dop, cph = np.zeros(0), np.zeros(0)
+    bufs = [x]
+    if world > 1:
+        dist.broadcast(torch.view_as_real(x), src=0)
+        bufs.append(x.clone())
+    bank = CorrelatorBank(C, 1023, device=local)
+    for c in range(C):
+        bank.set_code(c, oracle.ca_code((rank * C + c) % 32 + 1))
+    jobs, rows = build_jobs(C, E, n, fs, T, dop, cph, rank)
+    bank.upload_jobs(jobs)
+    bank.set_splits(1)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(k):
+        cur = bufs[k % len(bufs)]
+        pending = None
+        if world > 1:
+            # re-broadcast the NEXT block on the communicator's stream while this block is correlated
+            pending = dist.broadcast(torch.view_as_real(bufs[(k + 1) % 2]), src=0, async_op=True)
+        bank.set_stream_device(cur.data_ptr(), n_samples, keepalive=cur)
+        bank.launch(stream)
+        if pending is not None:
+            pending.wait()
+
+    for k in range(a.warmup):
+        step(k)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        step(a.warmup + k)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # ---- spot-check against the oracle (not timed): a few jobs of the last launch
+    out = bank.read_outputs()
+    if rank == 0:
+        from helpers import oracle_job, scale_err
+        xh = bufs[(a.warmup + a.steps - 1) % len(bufs)].cpu().numpy()
+        for j in (0, 1, C + 3, len(rows) - 1):
+            o32, t64, sabs = oracle_job(oracle.ca_code(rows[j]["code_slot"] % 32 + 1), xh, rows[j])
+            err = scale_err(out[j, :T], t64, sabs)
+            if not np.all(err <= 1e-6):
+                raise SystemExit(f"bench: GPU result of job {j} disagrees with the oracle: {out[j, :T]} vs {t64}")
+
+    # ---- roofline of the dominant kernel: HIP events on the launch stream, inputs resident
+    bank.set_stream_device(bufs[0].data_ptr(), n_samples, keepalive=bufs[0])
+    k_ms = bank.time_launches(20)
+    n_jobs = C * E
+    alg_bytes = n_jobs * (8.0 * n + 8.0 * T)
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("jobs") == n_jobs and tj.get("n") == n:
+                traffic = tj.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    if rank == 0:
+        total_corr = float(C) * T * E * a.steps * world
+        res = {
+            "metric": "correlators/s",
+            "value": total_corr / dt,
+            "unit": "correlators/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"GPS L1 C/A tracking, {C} channels/GPU x {E} epochs/step, fs={fs / 1e6:g} Msps, N={n}, {T}-tap E/P/L, open-loop",
+                       "channels_per_gpu": C, "epochs_per_step": E, "samples_per_epoch": n, "taps": T,
+                       "parallelism": f"channels sharded over {world} GPU(s)" + (", stream block broadcast over RCCL each step (overlapped)" if world > 1 else "")},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "kernel": f"mcorr_kernel<{3 if T <= 3 else (5 if T <= 5 else 8)},0>",
+                         "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes},
+            "kernel_only_value": float(C) * T * E / (k_ms * 1e-3),
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(C, n, fs, T, a.cpu_seconds)
+        if world == 1 and not a.no_acq:
+            try:
+                res["acquisition"] = acquisition_metric(torch, local, bufs[0][:n].contiguous(), fs)
+            except Exception as e:
+                res["acquisition"] = {"error": str(e)}
+        print(json.dumps(res))
+    bank.close()
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -358,26 +358,33 @@ typedef struct
     pthread_mutex_t mu;
 } time_job;
 
+#define TIME_BLOCK 16
+
+/* work items are (channel, block of TIME_BLOCK epochs) so that every host core has work */
 static void* time_worker(void* arg)
 {
     time_job* j = (time_job*)arg;
+    const int blocks = (j->epochs + TIME_BLOCK - 1) / TIME_BLOCK;
+    const int n_items = j->n_channels * blocks;
+    const long span = j->stream_len - j->n;
     for (;;)
         {
             pthread_mutex_lock(&j->mu);
-            const int ch = j->next++;
+            const int item = j->next++;
             pthread_mutex_unlock(&j->mu);
-            if (ch >= j->n_channels) break;
+            if (item >= n_items) break;
+            const int ch = item / blocks;
+            const int e0 = (item % blocks) * TIME_BLOCK;
+            const int e1 = e0 + TIME_BLOCK < j->epochs ? e0 + TIME_BLOCK : j->epochs;
             const float* p = j->params + 6 * ch;
-            long pos = (long)p[4];
             float out[128];
-            for (int e = 0; e < j->epochs; e++)
+            for (int e = e0; e < e1; e++)
                 {
-                    if (pos + j->n > j->stream_len) pos = (long)p[4];
+                    const long pos = ((long)p[4] + (long)e * j->n) % (span > 0 ? span : 1);
                     oracle_mcorr(j->codes + (size_t)ch * j->code_len, j->code_len, j->shifts, j->n_taps,
                         j->stream + 2 * pos, j->n, p[0], p[1], 0.0F, p[2], p[3], 0.0F, 0, out);
-                    pos += j->n;
                 }
-            memcpy(j->out + (size_t)ch * 2 * j->n_taps, out, sizeof(float) * 2 * j->n_taps);
+            if (e1 == j->epochs) memcpy(j->out + (size_t)ch * 2 * j->n_taps, out, sizeof(float) * 2 * j->n_taps);
         }
     return NULL;
 }

@@ -128,41 +128,47 @@ extern "C"
     }
 
     /*
-     * Timing harness in the style of cpu_multicorrelator_real_codes_test.cc:137-158:
-     * one std::thread per channel, each running `epochs` correlations of n samples
-     * over its own window of a shared stream.  Returns elapsed seconds.
+     * Timing harness in the style of cpu_multicorrelator_real_codes_test.cc:137-158 (one
+     * Cpu_Multicorrelator_Real_Codes object per worker thread, all reading one shared stream), extended so
+     * that every host core has work: the (channel, block of 16 epochs) items are pulled from a queue by
+     * n_threads std::threads.  Returns elapsed seconds.
      * params: per channel 6 floats {rem_carr, phase_step, rem_code, code_step, start_offset, unused}.
      */
     double ref_mcorr_time(const float* codes, int code_len, const float* shifts, int n_taps,
         const float* stream_iq, long stream_len, int n, int n_channels, int epochs, int n_threads,
         const float* params, float* out_iq)
     {
+        constexpr int kBlock = 16;
+        const int blocks = (epochs + kBlock - 1) / kBlock;
+        const int n_items = n_channels * blocks;
         std::vector<std::thread> pool;
         const auto t0 = std::chrono::steady_clock::now();
         std::atomic<int> next{0};
         auto worker = [&]() {
+            Cpu_Multicorrelator_Real_Codes mc;
+            std::vector<float> taps(shifts, shifts + n_taps);
+            std::vector<std::complex<float>> out(n_taps);
+            mc.init(2 * n, n_taps);
+            mc.set_high_dynamics_resampler(false);
             for (;;)
                 {
-                    const int ch = next.fetch_add(1);
-                    if (ch >= n_channels) break;
-                    Cpu_Multicorrelator_Real_Codes mc;
-                    std::vector<float> taps(shifts, shifts + n_taps);
-                    std::vector<std::complex<float>> out(n_taps);
-                    mc.init(2 * n, n_taps);
-                    mc.set_high_dynamics_resampler(false);
+                    const int item = next.fetch_add(1);
+                    if (item >= n_items) break;
+                    const int ch = item / blocks;
+                    const int e0 = (item % blocks) * kBlock;
+                    const int e1 = e0 + kBlock < epochs ? e0 + kBlock : epochs;
                     mc.set_local_code_and_taps(code_len, codes + static_cast<size_t>(ch) * code_len, taps.data());
                     const float* p = params + 6 * ch;
-                    long pos = static_cast<long>(p[4]);
-                    for (int e = 0; e < epochs; e++)
+                    const long span = stream_len - n;
+                    for (int e = e0; e < e1; e++)
                         {
-                            if (pos + n > stream_len) pos = static_cast<long>(p[4]);
+                            const long pos = (static_cast<long>(p[4]) + static_cast<long>(e) * n) % (span > 0 ? span : 1);
                             mc.set_input_output_vectors(out.data(), reinterpret_cast<const std::complex<float>*>(stream_iq) + pos);
                             mc.Carrier_wipeoff_multicorrelator_resampler(p[0], p[1], 0.0F, p[2], p[3], 0.0F, n);
-                            pos += n;
                         }
-                    std::memcpy(out_iq + static_cast<size_t>(ch) * 2 * n_taps, out.data(), sizeof(float) * 2 * n_taps);
-                    mc.free();
+                    if (e1 == epochs) std::memcpy(out_iq + static_cast<size_t>(ch) * 2 * n_taps, out.data(), sizeof(float) * 2 * n_taps);
                 }
+            mc.free();
         };
         for (int t = 0; t < n_threads; t++) pool.emplace_back(worker);
         for (auto& th : pool) th.join();
