@@ -1,0 +1,118 @@
+"""Python face of the acquisition half of the C ABI (gsh_acq_*), for tests and bench.
+
+``PcpsAcquisitionBank`` wraps one handle: the arithmetic core of the reference's ``pcps_acquisition`` block
+(src/algorithms/acquisition/gnuradio_blocks/pcps_acquisition.cc) for up to ``max_prn`` local codes at once.
+Method names follow the reference block: set_local_code (:218), set_doppler_center (:737), and ``dwell`` = one
+acquisition_core pass (:648) returning what max_to_input_power_statistic / first_vs_second_peak_statistic and
+update_synchro produce.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib
+from ._lib import AcqConf, AcqResult, check, fptr
+
+
+def acq_sizes(fs_in: int, sampled_ms: int = 1, ms_per_code: int = 1, bit_transition_flag: bool = False, chips_per_second: float = 1.023e6):
+    """Derived sizes exactly as the reference computes them (acq_conf.cc:119-124, pcps_acquisition.cc:110-112)."""
+    samples_per_ms = np.float32(fs_in) * np.float32(0.001)
+    consumed = int(np.float64(sampled_ms) * np.float64(samples_per_ms) * (2.0 if bit_transition_flag else 1.0))
+    fft_size = consumed if sampled_ms == ms_per_code else 2 * consumed
+    effective = fft_size // 2 if bit_transition_flag else fft_size
+    samples_per_chip = int(math.ceil(float(np.float32(fs_in) / np.float32(chips_per_second))))
+    samples_per_code = float(samples_per_ms * np.float32(ms_per_code))
+    return dict(consumed_samples=consumed, fft_size=fft_size, effective_fft_size=effective,
+                samples_per_chip=samples_per_chip, samples_per_code=samples_per_code)
+
+
+class PcpsAcquisitionBank:
+    def __init__(self, fs_in: int, fft_size: int, doppler_max: int, doppler_step: int, samples_per_chip: int,
+                 samples_per_code: float, max_prn: int = 1, num_doppler_bins: int = 0, consumed_samples: int | None = None,
+                 effective_fft_size: int | None = None, doppler_center: int = 0, doppler_bias: int = 0,
+                 bit_transition_flag: bool = False, use_cfar: bool = True, device: int = 0):
+        self._lib = _lib.load()
+        c = AcqConf()
+        c.fs_in = int(fs_in)
+        c.fft_size = int(fft_size)
+        c.consumed_samples = int(fft_size if consumed_samples is None else consumed_samples)
+        c.effective_fft_size = int((fft_size // 2 if bit_transition_flag else fft_size) if effective_fft_size is None else effective_fft_size)
+        c.num_doppler_bins = int(num_doppler_bins)
+        c.doppler_max = int(doppler_max)
+        c.doppler_step = int(doppler_step)
+        c.doppler_center = int(doppler_center)
+        c.doppler_bias = int(doppler_bias)
+        c.samples_per_chip = int(samples_per_chip)
+        c.samples_per_code = float(samples_per_code)
+        c.bit_transition_flag = int(bool(bit_transition_flag))
+        c.use_cfar = int(bool(use_cfar))
+        c.max_prn = int(max_prn)
+        self.conf = c
+        self.num_doppler_bins = int(num_doppler_bins) if num_doppler_bins else int(math.ceil(2.0 * doppler_max / doppler_step))
+        self._h = C.c_void_p()
+        check(self._lib.gsh_acq_create(device, C.byref(c), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            self._lib.gsh_acq_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_local_code(self, prn_slot: int, code: np.ndarray) -> None:
+        """code: the time-domain complex replica the adapter generates (e.g. gps_l1_ca_code_gen_complex_sampled),
+        consumed_samples long (fft_size/2 with bit_transition_flag)."""
+        code = np.ascontiguousarray(code, np.complex64)
+        need = self.conf.fft_size // 2 if self.conf.bit_transition_flag else self.conf.consumed_samples
+        if len(code) < need:
+            raise ValueError(f"code has {len(code)} samples, {need} needed")
+        check(self._lib.gsh_acq_set_local_code(self._h, prn_slot, fptr(code)))
+
+    def set_doppler_center(self, doppler_center: int) -> None:
+        check(self._lib.gsh_acq_set_doppler_center(self._h, int(doppler_center)))
+
+    def dwell(self, x: np.ndarray, n_prn: int, accumulate: bool = False, dwell_count: int = 1):
+        """One acquisition_core pass over x[:consumed_samples] for prn slots 0..n_prn-1.  Returns a list of dicts."""
+        x = np.ascontiguousarray(x, np.complex64)
+        if len(x) < self.conf.consumed_samples:
+            raise ValueError("input shorter than consumed_samples")
+        res = (AcqResult * n_prn)()
+        check(self._lib.gsh_acq_dwell(self._h, fptr(x), n_prn, int(accumulate), dwell_count, res))
+        return [self._to_dict(r) for r in res]
+
+    def dwell_device(self, device_ptr: int, n_prn: int, accumulate: bool = False, dwell_count: int = 1):
+        res = (AcqResult * n_prn)()
+        check(self._lib.gsh_acq_dwell_device(self._h, C.c_void_p(device_ptr), n_prn, int(accumulate), dwell_count, res))
+        return [self._to_dict(r) for r in res]
+
+    def read_grid(self, prn_slot: int) -> np.ndarray:
+        g = np.empty((self.num_doppler_bins, self.conf.effective_fft_size), np.float32)
+        check(self._lib.gsh_acq_read_grid(self._h, prn_slot, fptr(g)))
+        return g
+
+    def time_dwells(self, x, n_prn: int, reps: int = 10) -> float:
+        """Average milliseconds per full dwell batch, input resident (x: numpy array or torch cuda tensor)."""
+        if hasattr(x, "data_ptr"):
+            self.dwell_device(x.data_ptr(), n_prn)
+        else:
+            self.dwell(x, n_prn)
+        ms = C.c_float(0.0)
+        check(self._lib.gsh_acq_time_dwells(self._h, n_prn, reps, C.byref(ms)))
+        return ms.value
+
+    @staticmethod
+    def _to_dict(r: AcqResult) -> dict:
+        return dict(index_time=int(r.index_time), index_doppler=int(r.index_doppler), doppler_hz=int(r.doppler_hz),
+                    acq_delay_samples=float(r.acq_delay_samples), peak=float(r.peak), input_power=float(r.input_power),
+                    second_peak=float(r.second_peak), test_statistics=float(r.test_statistics))
+
+
+def compute_threshold(pfa: float, effective_fft_size: int, num_doppler_bins: int, max_dwells: int) -> float:
+    return float(_lib.load().gsh_acq_compute_threshold(pfa, effective_fft_size, num_doppler_bins, max_dwells))

@@ -1,0 +1,390 @@
+// C-ABI acquisition entry points (include/gnss_sdr_hip.h, gsh_acq_*): host bookkeeping around the
+// kernels of pcps_fft.hip.  Mirrors the data flow of pcps_acquisition::acquisition_core
+// (gnss-sdr, src/algorithms/acquisition/gnuradio_blocks/pcps_acquisition.cc:648-684) for a whole batch of
+// local codes: the D wiped-off forward FFTs are computed ONCE and shared by every PRN (the reference recomputes
+// them in every channel's block).
+#include "pcps_fft.h"
+#include <algorithm>
+#include <cmath>
+#include <new>
+#include <vector>
+
+struct gsh_acq
+{
+    int device{0};
+    gsh_acq_conf conf{};
+    hipStream_t stream{nullptr};
+    gsh::FftPlan plan;
+    int n_bins{0};
+    std::vector<int> h_bins_hz;
+    int* d_bins_hz{nullptr};
+    float2* d_in{nullptr};        // consumed_samples
+    float2* d_spectra{nullptr};   // n_bins * n
+    float2* d_codes{nullptr};     // max_prn * n   (forward FFT of the placed code, permuted layout, unconjugated)
+    float2* d_tmp{nullptr};       // chunk_prn * n_bins * n
+    float* d_grid{nullptr};       // max_prn * n_bins * effective
+    gsh::RowStat* d_rows{nullptr};
+    gsh::DevAcqResult* d_results{nullptr};
+    gsh::DevAcqResult* h_results{nullptr};  // pinned
+    float2* h_stage{nullptr};               // pinned, max(consumed, code length)
+    std::vector<char> code_set;
+    int chunk_prn{1};
+    bool have_input{false};
+    hipEvent_t ev0{nullptr}, ev1{nullptr};
+};
+
+namespace
+{
+using gsh::set_error;
+
+void fill_bins(gsh_acq* a)
+{
+    // acq.cc:284-291: doppler = -doppler_max + doppler_center + doppler_step * index (+ FDMA bias, :289)
+    for (int d = 0; d < a->n_bins; d++)
+        a->h_bins_hz[d] = a->conf.doppler_bias + (-a->conf.doppler_max + a->conf.doppler_center + a->conf.doppler_step * d);
+}
+
+int upload_bins(gsh_acq* a)
+{
+    GSH_HIP(hipMemcpyAsync(a->d_bins_hz, a->h_bins_hz.data(), sizeof(int) * a->n_bins, hipMemcpyHostToDevice, a->stream));
+    GSH_HIP(hipStreamSynchronize(a->stream));
+    return GSH_OK;
+}
+
+// queue one full dwell batch on the handle's stream (input already in d_in)
+int enqueue_dwell(gsh_acq* a, uint32_t n_prn, int accumulate, uint32_t dwell_count)
+{
+    const gsh_acq_conf& c = a->conf;
+    const int n = static_cast<int>(c.fft_size);
+    const int eff = static_cast<int>(c.effective_fft_size);
+    // acq.cc:657-664 (zero padding) + :531-535 (wipe-off, forward FFT) for every bin
+    int rc = gsh::fft_forward(a->plan, a->d_in, 0, static_cast<int>(c.consumed_samples), 0, a->d_bins_hz, static_cast<double>(c.fs_in),
+        a->d_tmp, a->d_spectra, a->n_bins, a->stream);
+    if (rc != GSH_OK) return rc;
+    const int grid_off = c.bit_transition_flag ? eff : 0;  // acq.cc:544
+    for (uint32_t p0 = 0; p0 < n_prn; p0 += static_cast<uint32_t>(a->chunk_prn))
+        {
+            const int np = static_cast<int>(std::min<uint32_t>(a->chunk_prn, n_prn - p0));
+            rc = gsh::correlate_grid(a->plan, a->d_spectra, a->d_codes + static_cast<size_t>(p0) * n, a->d_tmp,
+                a->d_grid + static_cast<size_t>(p0) * a->n_bins * eff, np, a->n_bins, grid_off, eff, accumulate, a->stream);
+            if (rc != GSH_OK) return rc;
+        }
+    return gsh::grid_statistics(a->d_grid, a->d_rows, a->d_results, static_cast<int>(n_prn), a->n_bins, eff,
+        static_cast<int>(c.samples_per_chip), c.use_cfar, dwell_count ? dwell_count : 1u, a->stream);
+}
+
+int check_dwell_args(gsh_acq* a, uint32_t n_prn, const void* results)
+{
+    GSH_REQUIRE(a != nullptr && results != nullptr, "null argument");
+    GSH_REQUIRE(n_prn >= 1 && n_prn <= a->conf.max_prn, "n_prn %u outside 1..%u", n_prn, a->conf.max_prn);
+    for (uint32_t p = 0; p < n_prn; p++)
+        if (!a->code_set[p]) return set_error(GSH_ERR_STATE, "local code of prn slot %u has not been set (set_local_code)", p);
+    return GSH_OK;
+}
+
+int finish_results(gsh_acq* a, uint32_t n_prn, gsh_acq_result* results)
+{
+    GSH_HIP(hipMemcpyAsync(a->h_results, a->d_results, sizeof(gsh::DevAcqResult) * n_prn, hipMemcpyDeviceToHost, a->stream));
+    GSH_HIP(hipStreamSynchronize(a->stream));
+    for (uint32_t p = 0; p < n_prn; p++)
+        {
+            const gsh::DevAcqResult& r = a->h_results[p];
+            gsh_acq_result& o = results[p];
+            o.index_time = r.index_time;
+            o.index_doppler = r.index_doppler;
+            o.doppler_hz = -a->conf.doppler_max + a->conf.doppler_center + a->conf.doppler_step * static_cast<int32_t>(r.index_doppler);  // acq.cc:431/:478
+            o.acq_delay_samples = std::fmod(static_cast<float>(r.index_time), a->conf.samples_per_code);                                    // acq.cc:582
+            o.peak = r.peak;
+            o.input_power = r.input_power;
+            o.second_peak = r.second_peak;
+            o.test_statistics = r.test_statistics;
+        }
+    return GSH_OK;
+}
+
+// ---- regularized lower incomplete gamma P(a, x) and its inverse (for compute_threshold) -------------------
+double gamma_p(double a, double x)
+{
+    if (x <= 0.0) return 0.0;
+    const double lg = std::lgamma(a);
+    if (x < a + 1.0)
+        {
+            // series: P = e^{-x} x^a / Gamma(a) * sum_{k>=0} x^k / (a (a+1) ... (a+k))
+            double term = 1.0 / a, sum = term;
+            for (int k = 1; k < 10000; k++)
+                {
+                    term *= x / (a + k);
+                    sum += term;
+                    if (std::fabs(term) < std::fabs(sum) * 1e-17) break;
+                }
+            return sum * std::exp(-x + a * std::log(x) - lg);
+        }
+    // continued fraction for Q = 1 - P (modified Lentz)
+    const double tiny = 1e-300;
+    double b = x + 1.0 - a;
+    double cc = 1.0 / tiny;
+    double d = 1.0 / b;
+    double h = d;
+    for (int i = 1; i < 10000; i++)
+        {
+            const double an = -static_cast<double>(i) * (static_cast<double>(i) - a);
+            b += 2.0;
+            d = an * d + b;
+            if (std::fabs(d) < tiny) d = tiny;
+            cc = b + an / cc;
+            if (std::fabs(cc) < tiny) cc = tiny;
+            d = 1.0 / d;
+            const double del = d * cc;
+            h *= del;
+            if (std::fabs(del - 1.0) < 1e-16) break;
+        }
+    return 1.0 - std::exp(-x + a * std::log(x) - lg) * h;
+}
+
+double gamma_p_inv(double a, double p)
+{
+    if (p <= 0.0) return 0.0;
+    if (p >= 1.0) return INFINITY;
+    // bracket, then bisection refined by Newton steps (dP/dx = x^{a-1} e^{-x} / Gamma(a))
+    double lo = 0.0, hi = std::max(1.0, a);
+    while (gamma_p(a, hi) < p) hi *= 2.0;
+    double x = 0.5 * (lo + hi);
+    const double lg = std::lgamma(a);
+    for (int it = 0; it < 200; it++)
+        {
+            const double f = gamma_p(a, x) - p;
+            if (f > 0.0)
+                hi = x;
+            else
+                lo = x;
+            const double dfdx = std::exp((a - 1.0) * std::log(x) - x - lg);
+            double xn = (dfdx > 0.0) ? x - f / dfdx : 0.5 * (lo + hi);
+            if (!(xn > lo && xn < hi)) xn = 0.5 * (lo + hi);
+            if (std::fabs(xn - x) <= 1e-15 * std::fabs(x)) return xn;
+            x = xn;
+        }
+    return x;
+}
+}  // namespace
+
+extern "C"
+{
+    int gsh_acq_create(int device, const gsh_acq_conf* conf, gsh_acq_t** out)
+    {
+        GSH_REQUIRE(out != nullptr && conf != nullptr, "null argument");
+        *out = nullptr;
+        gsh_acq_conf c = *conf;
+        GSH_REQUIRE(c.fs_in > 0, "fs_in must be positive");
+        GSH_REQUIRE(c.fft_size >= 4 && c.fft_size <= (1u << 24), "fft_size %u outside 4..2^24", c.fft_size);
+        GSH_REQUIRE(c.consumed_samples >= 1 && c.consumed_samples <= c.fft_size, "consumed_samples %u outside 1..fft_size", c.consumed_samples);
+        GSH_REQUIRE(c.consumed_samples == c.fft_size || 2 * c.consumed_samples == c.fft_size,
+            "fft_size must be consumed_samples or twice it (acq.cc:111)");
+        if (c.bit_transition_flag)
+            GSH_REQUIRE(c.effective_fft_size * 2 == c.fft_size, "bit_transition_flag needs effective_fft_size = fft_size/2 (acq.cc:112)");
+        else
+            GSH_REQUIRE(c.effective_fft_size == c.fft_size, "effective_fft_size must equal fft_size without bit_transition_flag (acq.cc:112)");
+        GSH_REQUIRE(c.doppler_step > 0, "doppler_step must be positive");
+        if (c.num_doppler_bins == 0)
+            c.num_doppler_bins = static_cast<uint32_t>(std::ceil(static_cast<double>(2 * c.doppler_max) / static_cast<double>(c.doppler_step)));  // acq.cc:113
+        GSH_REQUIRE(c.num_doppler_bins >= 1 && c.num_doppler_bins <= 4096, "num_doppler_bins %u outside 1..4096", c.num_doppler_bins);
+        GSH_REQUIRE(c.max_prn >= 1 && c.max_prn <= 4096, "max_prn %u outside 1..4096", c.max_prn);
+        GSH_REQUIRE(2 * c.samples_per_chip < c.effective_fft_size, "samples_per_chip %u too large for %u cells (acq.cc:485-509 would not terminate)", c.samples_per_chip, c.effective_fft_size);
+        int rc = gsh::use_device(device);
+        if (rc != GSH_OK) return rc;
+        gsh_acq* a = new (std::nothrow) gsh_acq();
+        GSH_REQUIRE(a != nullptr, "out of host memory");
+        a->device = device;
+        a->conf = c;
+        a->n_bins = static_cast<int>(c.num_doppler_bins);
+        a->h_bins_hz.assign(a->n_bins, 0);
+        a->code_set.assign(c.max_prn, 0);
+        rc = gsh::plan_create(static_cast<int>(c.fft_size), &a->plan);
+        if (rc != GSH_OK)
+            {
+                delete a;
+                return rc;
+            }
+        const size_t n = c.fft_size, eff = c.effective_fft_size, D = a->n_bins, P = c.max_prn;
+        // scratch for the inverse's intermediate: bound it to 2 GiB and to the 65535-cell launch limit
+        const size_t per_prn = D * n * sizeof(float2);
+        size_t chunk = std::max<size_t>(1, (size_t(2) << 30) / per_prn);
+        chunk = std::min(chunk, P);
+        chunk = std::min<size_t>(chunk, std::max<size_t>(1, 65535 / D));
+        a->chunk_prn = static_cast<int>(chunk);
+        auto fail = [&](hipError_t e, const char* what) {
+            gsh::hip_fail(e, what, __FILE__, __LINE__);
+            gsh_acq_destroy(a);
+            return GSH_ERR_HIP;
+        };
+        hipError_t e;
+        if ((e = hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
+        if ((e = hipMalloc(&a->d_bins_hz, sizeof(int) * D)) != hipSuccess) return fail(e, "hipMalloc(bins)");
+        if ((e = hipMalloc(&a->d_in, sizeof(float2) * n)) != hipSuccess) return fail(e, "hipMalloc(in)");
+        if ((e = hipMalloc(&a->d_spectra, sizeof(float2) * D * n)) != hipSuccess) return fail(e, "hipMalloc(spectra)");
+        if ((e = hipMalloc(&a->d_codes, sizeof(float2) * P * n)) != hipSuccess) return fail(e, "hipMalloc(codes)");
+        if ((e = hipMalloc(&a->d_tmp, sizeof(float2) * std::max(chunk * D, size_t(1)) * n)) != hipSuccess) return fail(e, "hipMalloc(tmp)");
+        if ((e = hipMalloc(&a->d_grid, sizeof(float) * P * D * eff)) != hipSuccess) return fail(e, "hipMalloc(grid)");
+        if ((e = hipMemset(a->d_grid, 0, sizeof(float) * P * D * eff)) != hipSuccess) return fail(e, "hipMemset(grid)");
+        if ((e = hipMalloc(&a->d_rows, sizeof(gsh::RowStat) * P * D)) != hipSuccess) return fail(e, "hipMalloc(rows)");
+        if ((e = hipMalloc(&a->d_results, sizeof(gsh::DevAcqResult) * P)) != hipSuccess) return fail(e, "hipMalloc(results)");
+        if ((e = hipHostMalloc(reinterpret_cast<void**>(&a->h_results), sizeof(gsh::DevAcqResult) * P, hipHostMallocDefault)) != hipSuccess) return fail(e, "hipHostMalloc");
+        if ((e = hipHostMalloc(reinterpret_cast<void**>(&a->h_stage), sizeof(float2) * n, hipHostMallocDefault)) != hipSuccess) return fail(e, "hipHostMalloc");
+        if ((e = hipEventCreate(&a->ev0)) != hipSuccess) return fail(e, "hipEventCreate");
+        if ((e = hipEventCreate(&a->ev1)) != hipSuccess) return fail(e, "hipEventCreate");
+        fill_bins(a);
+        rc = upload_bins(a);
+        if (rc != GSH_OK)
+            {
+                gsh_acq_destroy(a);
+                return rc;
+            }
+        *out = a;
+        return GSH_OK;
+    }
+
+    void gsh_acq_destroy(gsh_acq_t* a)
+    {
+        if (!a) return;
+        (void)hipSetDevice(a->device);
+        if (a->stream) (void)hipStreamSynchronize(a->stream);
+        gsh::plan_destroy(&a->plan);
+        if (a->d_bins_hz) (void)hipFree(a->d_bins_hz);
+        if (a->d_in) (void)hipFree(a->d_in);
+        if (a->d_spectra) (void)hipFree(a->d_spectra);
+        if (a->d_codes) (void)hipFree(a->d_codes);
+        if (a->d_tmp) (void)hipFree(a->d_tmp);
+        if (a->d_grid) (void)hipFree(a->d_grid);
+        if (a->d_rows) (void)hipFree(a->d_rows);
+        if (a->d_results) (void)hipFree(a->d_results);
+        if (a->h_results) (void)hipHostFree(a->h_results);
+        if (a->h_stage) (void)hipHostFree(a->h_stage);
+        if (a->ev0) (void)hipEventDestroy(a->ev0);
+        if (a->ev1) (void)hipEventDestroy(a->ev1);
+        if (a->stream) (void)hipStreamDestroy(a->stream);
+        delete a;
+    }
+
+    int gsh_acq_set_local_code(gsh_acq_t* a, uint32_t prn_slot, const float* code_iq)
+    {
+        GSH_REQUIRE(a != nullptr && code_iq != nullptr, "null argument");
+        GSH_REQUIRE(prn_slot < a->conf.max_prn, "prn_slot %u outside 0..%u", prn_slot, a->conf.max_prn - 1);
+        GSH_HIP(hipSetDevice(a->device));
+        const gsh_acq_conf& c = a->conf;
+        // placement rules of acq.cc:230-247
+        int n_in, place_off;
+        if (c.bit_transition_flag)
+            {
+                n_in = static_cast<int>(c.fft_size / 2);
+                place_off = static_cast<int>(c.fft_size / 2);
+            }
+        else if (c.consumed_samples == c.fft_size)
+            {
+                n_in = static_cast<int>(c.consumed_samples);
+                place_off = 0;
+            }
+        else
+            {
+                n_in = static_cast<int>(c.consumed_samples);
+                place_off = static_cast<int>(c.fft_size - c.consumed_samples);
+            }
+        std::memcpy(a->h_stage, code_iq, sizeof(float2) * static_cast<size_t>(n_in));
+        // stage the time-domain replica in d_tmp's tail-free area: d_in is reserved for the signal, so use d_spectra[0] row
+        // as scratch input is unsafe while a dwell is queued; everything here is on one stream, so order is preserved.
+        float2* d_code_time = a->d_tmp + static_cast<size_t>(c.fft_size);  // second row of tmp (tmp holds >= n_bins rows)
+        float2* d_scratch = a->d_tmp;                                      // first row: column-pass output
+        if (a->n_bins < 2)
+            {
+                // tmp has a single row: borrow the grid-independent spectra buffer instead
+                d_code_time = a->d_spectra;
+            }
+        GSH_HIP(hipMemcpyAsync(d_code_time, a->h_stage, sizeof(float2) * static_cast<size_t>(n_in), hipMemcpyHostToDevice, a->stream));
+        int rc = gsh::fft_forward(a->plan, d_code_time, 0, n_in, place_off, nullptr, 1.0, d_scratch,
+            a->d_codes + static_cast<size_t>(prn_slot) * c.fft_size, 1, a->stream);
+        if (rc != GSH_OK) return rc;
+        GSH_HIP(hipStreamSynchronize(a->stream));
+        a->code_set[prn_slot] = 1;
+        return GSH_OK;
+    }
+
+    int gsh_acq_set_doppler_center(gsh_acq_t* a, int32_t doppler_center)
+    {
+        GSH_REQUIRE(a != nullptr, "null handle");
+        GSH_HIP(hipSetDevice(a->device));
+        if (doppler_center != a->conf.doppler_center)  // acq.cc:741-745
+            {
+                a->conf.doppler_center = doppler_center;
+                fill_bins(a);
+                return upload_bins(a);
+            }
+        return GSH_OK;
+    }
+
+    int gsh_acq_dwell_device(gsh_acq_t* a, const void* device_in_iq, uint32_t n_prn, int accumulate, uint32_t dwell_count, gsh_acq_result* results)
+    {
+        int rc = check_dwell_args(a, n_prn, results);
+        if (rc != GSH_OK) return rc;
+        GSH_REQUIRE(device_in_iq != nullptr, "null input");
+        GSH_HIP(hipSetDevice(a->device));
+        GSH_HIP(hipMemcpyAsync(a->d_in, device_in_iq, sizeof(float2) * a->conf.consumed_samples, hipMemcpyDeviceToDevice, a->stream));
+        a->have_input = true;
+        rc = enqueue_dwell(a, n_prn, accumulate, dwell_count);
+        if (rc != GSH_OK) return rc;
+        return finish_results(a, n_prn, results);
+    }
+
+    int gsh_acq_dwell(gsh_acq_t* a, const float* in_iq, uint32_t n_prn, int accumulate, uint32_t dwell_count, gsh_acq_result* results)
+    {
+        int rc = check_dwell_args(a, n_prn, results);
+        if (rc != GSH_OK) return rc;
+        GSH_REQUIRE(in_iq != nullptr, "null input");
+        GSH_HIP(hipSetDevice(a->device));
+        std::memcpy(a->h_stage, in_iq, sizeof(float2) * a->conf.consumed_samples);
+        GSH_HIP(hipMemcpyAsync(a->d_in, a->h_stage, sizeof(float2) * a->conf.consumed_samples, hipMemcpyHostToDevice, a->stream));
+        a->have_input = true;
+        rc = enqueue_dwell(a, n_prn, accumulate, dwell_count);
+        if (rc != GSH_OK) return rc;
+        return finish_results(a, n_prn, results);
+    }
+
+    int gsh_acq_read_grid(gsh_acq_t* a, uint32_t prn_slot, float* grid)
+    {
+        GSH_REQUIRE(a != nullptr && grid != nullptr, "null argument");
+        GSH_REQUIRE(prn_slot < a->conf.max_prn, "prn_slot %u outside 0..%u", prn_slot, a->conf.max_prn - 1);
+        GSH_HIP(hipSetDevice(a->device));
+        const size_t row = static_cast<size_t>(a->n_bins) * a->conf.effective_fft_size;
+        GSH_HIP(hipMemcpyAsync(grid, a->d_grid + prn_slot * row, sizeof(float) * row, hipMemcpyDeviceToHost, a->stream));
+        GSH_HIP(hipStreamSynchronize(a->stream));
+        return GSH_OK;
+    }
+
+    int gsh_acq_time_dwells(gsh_acq_t* a, uint32_t n_prn, int reps, float* avg_ms)
+    {
+        GSH_REQUIRE(a != nullptr && avg_ms != nullptr, "null argument");
+        GSH_REQUIRE(reps >= 1, "reps %d", reps);
+        GSH_REQUIRE(n_prn >= 1 && n_prn <= a->conf.max_prn, "n_prn %u outside 1..%u", n_prn, a->conf.max_prn);
+        if (!a->have_input) return set_error(GSH_ERR_STATE, "no input block resident: call gsh_acq_dwell[_device] once first");
+        GSH_HIP(hipSetDevice(a->device));
+        int rc = enqueue_dwell(a, n_prn, 0, 1);  // warm-up
+        if (rc != GSH_OK) return rc;
+        GSH_HIP(hipEventRecord(a->ev0, a->stream));
+        for (int i = 0; i < reps; i++)
+            {
+                rc = enqueue_dwell(a, n_prn, 0, 1);
+                if (rc != GSH_OK) return rc;
+            }
+        GSH_HIP(hipEventRecord(a->ev1, a->stream));
+        GSH_HIP(hipEventSynchronize(a->ev1));
+        float ms = 0.0f;
+        GSH_HIP(hipEventElapsedTime(&ms, a->ev0, a->ev1));
+        *avg_ms = ms / static_cast<float>(reps);
+        return GSH_OK;
+    }
+
+    float gsh_acq_compute_threshold(float pfa, uint32_t effective_fft_size, uint32_t num_doppler_bins, uint32_t max_dwells)
+    {
+        // acq.cc:52-56
+        const int num_bins = static_cast<int>(effective_fft_size * num_doppler_bins);
+        const double prob = std::pow(1.0 - static_cast<double>(pfa), 1.0 / static_cast<double>(static_cast<float>(num_bins)));
+        return static_cast<float>(2.0 * gamma_p_inv(2.0 * static_cast<double>(max_dwells), prob));
+    }
+}

@@ -1,0 +1,168 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU restatement of the PCPS acquisition arithmetic.
+
+Follows pcps_acquisition (src/algorithms/acquisition/gnuradio_blocks/pcps_acquisition.cc, cited per function as
+acq.cc:line) in float32 / complex64, in the reference's order of operations.
+
+Parity status: the in-tree pieces are PINNED -- the Doppler wipe-off table goes through oracle_sincos
+(== volk_gnsssdr_s32f_sincos_32fc_generic, bit-exact, tests/test_oracle_vs_ref.py), arg-max through
+oracle_index_max (== volk_gnsssdr_32f_index_max_32u_generic), code replicas through the pinned generators.
+The FFT itself is UNPINNED: the reference calls gr::fft::fft_complex_fwd/rev (GNU Radio gr-fft over FFTW3f,
+gnss_sdr_fft.h:26-61) and upstream VOLK for the element-wise products (acq.cc:250,531,538,547-552); neither
+library is vendored in /root/reference nor installed here, and no test of the reference pins their numerics.
+This file uses scipy's pocketfft in single precision in their place (same mathematical definition: forward
+e^{-j}, unnormalised inverse = N * ifft).  Peak INDICES are what north_star requires bit-exact; they are robust
+to FFT rounding wherever a signal is present and are additionally checked against a float64 evaluation.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+import scipy.fft
+
+from . import lib
+
+TWO_PI = np.float32(6.283185307179586)
+
+
+class PcpsOracle:
+    def __init__(self, fs_in: int, fft_size: int, doppler_max: int, doppler_step: int, samples_per_chip: int,
+                 samples_per_code: float, num_doppler_bins: int = 0, consumed_samples: int | None = None,
+                 doppler_center: int = 0, doppler_bias: int = 0, bit_transition_flag: bool = False, use_cfar: bool = True,
+                 precise: bool = False):
+        self.fs_in = fs_in
+        self.fft_size = fft_size
+        self.consumed = fft_size if consumed_samples is None else consumed_samples
+        self.effective = fft_size // 2 if bit_transition_flag else fft_size                      # acq.cc:112
+        self.doppler_max, self.doppler_step = doppler_max, doppler_step
+        self.doppler_center, self.doppler_bias = doppler_center, doppler_bias
+        self.n_bins = num_doppler_bins or int(math.ceil(2.0 * doppler_max / doppler_step))        # acq.cc:113
+        self.spc = samples_per_chip
+        self.samples_per_code = np.float32(samples_per_code)
+        self.bit_transition = bit_transition_flag
+        self.use_cfar = use_cfar
+        self.precise = precise  # float64 evaluation (arbiter for near-ties), not the reference's arithmetic
+        self.grid = None
+        self.fft_codes = None
+        self._wipeoffs()
+
+    # acq.cc:275-291: D tables exp(-j 2 pi f n / fs), phase accumulated in float32 by the volk kernel
+    def _wipeoffs(self):
+        self.wipe = np.empty((self.n_bins, self.fft_size), np.complex128 if self.precise else np.complex64)
+        self.freqs = []
+        for d in range(self.n_bins):
+            doppler = -int(self.doppler_max) + self.doppler_center + self.doppler_step * d       # acq.cc:288
+            self.freqs.append(doppler)
+            freq = np.float32(self.doppler_bias + doppler)                                        # acq.cc:289 cast
+            if self.precise:
+                n = np.arange(self.fft_size, dtype=np.float64)
+                self.wipe[d] = np.exp(-2j * np.pi * float(self.doppler_bias + doppler) * n / self.fs_in)
+                continue
+            phase_step = TWO_PI * freq / np.float32(self.fs_in)                                   # acq.cc:278
+            out = np.empty(2 * self.fft_size, np.float32)
+            ph = C.c_float(0.0)
+            lib().oracle_sincos(out, float(-phase_step), C.byref(ph), self.fft_size)              # acq.cc:280
+            self.wipe[d] = out.view(np.complex64)
+
+    def set_doppler_center(self, center: int):                                                    # acq.cc:737-746
+        if center != self.doppler_center:
+            self.doppler_center = center
+            self._wipeoffs()
+
+    # acq.cc:218-251
+    def set_local_code(self, code: np.ndarray):
+        dt = np.complex128 if self.precise else np.complex64
+        buf = np.zeros(self.fft_size, dt)
+        if self.bit_transition:
+            off = self.fft_size // 2
+            buf[off:] = code[:off]
+        elif self.consumed == self.fft_size:
+            buf[:] = code[:self.consumed]
+        else:
+            buf[self.consumed:] = code[:self.consumed]                                            # acq.cc:245-246
+        self.fft_codes = np.conj(scipy.fft.fft(buf)).astype(dt)                                   # acq.cc:249-250
+
+    # acq.cc:522-560 with the zero padding of :657-664
+    def doppler_grid(self, x: np.ndarray, dwell_count: int = 1):
+        dt = np.complex128 if self.precise else np.complex64
+        sig = np.zeros(self.fft_size, dt)
+        sig[:self.consumed] = x[:self.consumed]
+        if self.grid is None or dwell_count == 1:
+            self.grid = np.zeros((self.n_bins, self.effective), np.float64 if self.precise else np.float32)
+        off = self.effective if self.bit_transition else 0
+        for d in range(self.n_bins):
+            a = (sig * self.wipe[d]).astype(dt)                                                   # :531
+            A = scipy.fft.fft(a)                                                                  # :535
+            B = (A * self.fft_codes).astype(dt)                                                   # :538
+            y = scipy.fft.ifft(B) * dt(self.fft_size)                                             # :541 unnormalised
+            y = y.astype(dt)[off:off + self.effective]
+            mag = (y.real * y.real + y.imag * y.imag)                                             # :547
+            if dwell_count == 1:
+                self.grid[d] = mag
+            else:
+                self.grid[d] = self.grid[d] + mag                                                 # :551-552
+        return self.grid
+
+    def _argmax(self, row: np.ndarray) -> int:
+        if self.precise:
+            return int(np.argmax(row))  # numpy returns the first maximum too
+        t = np.zeros(1, np.uint32)
+        lib().oracle_index_max(t, np.ascontiguousarray(row, np.float32), len(row))
+        return int(t[0])
+
+    # acq.cc:409-449 and :452-519
+    def statistics(self, dwell_count: int = 1) -> dict:
+        g = self.grid
+        gmax, idx_d, idx_t = 0.0, 0, 0
+        for d in range(self.n_bins):
+            t = self._argmax(g[d])
+            if g[d][t] > gmax:                                                                   # :420 strict
+                gmax, idx_d, idx_t = g[d][t], d, t
+        res = dict(index_time=idx_t, index_doppler=idx_d, peak=float(gmax),
+                   doppler_hz=-int(self.doppler_max) + self.doppler_center + self.doppler_step * idx_d,
+                   acq_delay_samples=float(np.fmod(np.float32(idx_t), self.samples_per_code)))   # :582
+        if self.use_cfar:
+            opp = (idx_d + self.n_bins // 2) % self.n_bins                                        # :429
+            if self.precise:
+                power = float(np.sum(g[opp]) / self.effective / 2.0 / dwell_count)
+            else:
+                s = np.float32(0.0)
+                # std::accumulate in float32, sequential (:430)
+                s = np.cumsum(g[opp].astype(np.float32), dtype=np.float32)[-1]
+                power = float(np.float32(np.float64(s / np.float32(self.effective)) / 2.0 / dwell_count))
+            res["input_power"] = power
+            res["test_statistics"] = 0.0 if power < np.finfo(np.float32).eps else float(gmax) / power  # :438-445
+            res["second_peak"] = 0.0
+        else:
+            e1, e2 = idx_t - self.spc, idx_t + self.spc                                          # :485-486
+            if e1 < 0:
+                e1 += self.effective
+            elif e2 >= self.effective:
+                e2 -= self.effective
+            tmp = g[idx_d].copy()
+            i = e1
+            while True:                                                                           # :498-509 do-while
+                tmp[i] = 0.0
+                i += 1
+                if i == self.effective:
+                    i = 0
+                if i == e2:
+                    break
+            second = tmp[self._argmax(tmp)]
+            res["second_peak"] = float(second)
+            res["input_power"] = 0.0
+            res["test_statistics"] = float(np.float32(gmax) / np.float32(second)) if not self.precise else float(gmax / second)
+        return res
+
+    def dwell(self, x: np.ndarray, dwell_count: int = 1) -> dict:
+        self.doppler_grid(x, dwell_count)
+        return self.statistics(dwell_count)
+
+
+def compute_threshold(pfa: float, effective_fft_size: int, num_doppler_bins: int, max_dwells: int) -> float:
+    """acq.cc:52-56 with scipy.special.gammaincinv == boost::math::gamma_p_inv."""
+    from scipy.special import gammaincinv
+    num_bins = effective_fft_size * num_doppler_bins
+    prob = (1.0 - float(np.float32(pfa))) ** (1.0 / float(np.float32(num_bins)))
+    return float(np.float32(2.0 * gammaincinv(2.0 * max_dwells, prob)))

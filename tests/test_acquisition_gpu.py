@@ -1,0 +1,177 @@
+"""GPU parity tests of the PCPS acquisition engine (through the C ABI) against oracle/pcps_oracle.py.
+
+Bars: peak indices (index_time, index_doppler) bit-exact with the oracle -- unless the float64 evaluation shows the
+two candidates tie within float32 FFT rounding (possible only on signal-free grids); grid values, peaks, input power
+and test statistics within RTOL (float32 FFTs of different factorisation + the reference's float32-accumulated
+wipe-off phase vs our exact one).
+
+Known-answer case mirrors the reference's synthetic acquisition test
+(tests/unit-tests/signal-processing-blocks/acquisition/gps_l1_ca_pcps_acquisition_gsoc2013_test.cc:197-264,384-401):
+PRN 10, Doppler 750 Hz, delay 600 chips, fs 4 Msps, doppler_max 10000, step 250; pass when the delay error is
+below 0.5 chip and the Doppler error below 2/(3*T_int).
+"""
+import numpy as np
+import pytest
+
+import oracle
+from oracle.pcps_oracle import PcpsOracle, compute_threshold as oracle_threshold
+from helpers import synth_gps_l1_stream
+
+pytestmark = pytest.mark.gpu
+
+RTOL_GRID = 2e-3
+
+
+def _bank(gpu, **kw):
+    from gnss_sdr_amd.acquisition import PcpsAcquisitionBank
+    return PcpsAcquisitionBank(device=gpu, **kw)
+
+
+def _same_peak(res, ora, prec, tag):
+    """indices equal, or a documented float64 near-tie between the two candidates"""
+    if res["index_time"] == ora["index_time"] and res["index_doppler"] == ora["index_doppler"]:
+        return
+    g = prec.grid
+    a = g[res["index_doppler"], res["index_time"]]
+    b = g[ora["index_doppler"], ora["index_time"]]
+    assert abs(a - b) <= 2e-5 * max(a, b), f"{tag}: peak index mismatch gpu={res} oracle={ora} (float64 values {a} vs {b})"
+
+
+@pytest.mark.parametrize("n,consumed,fs,bt", [(4000, 4000, 4000000, False), (2048, 2048, 2048000, False),
+                                              (2046, 2046, 2046000, False), (5000, 5000, 5000000, False),
+                                              (16368, 16368, 16368000, False), (8000, 8000, 4000000, True),
+                                              (8000, 4000, 4000000, False), (25000, 25000, 25000000, False)])
+def test_grid_matches_oracle(gpu, n, consumed, fs, bt):
+    """FFT sizes with radix-2/3/4/5/8 and generic (11, 31) passes; bit_transition_flag (acq.cc:230-235) and
+    fft_size = 2*consumed (sampled_ms != ms_per_code, acq.cc:111,243-247) paddings."""
+    rng = np.random.default_rng(n)
+    spms = fs // 1000
+    prn = 7
+    x = synth_gps_l1_stream(consumed, fs, [prn], [1250.0], [333.3], cn0_dbhz=50.0, seed_noise=n)
+    code1 = oracle.ca_code_complex_sampled(prn, fs)
+    code = np.tile(code1, (consumed + len(code1) - 1) // len(code1))[:consumed] if not bt else code1
+    spc = int(np.ceil(fs / 1.023e6))
+    kw = dict(fs_in=fs, fft_size=n, doppler_max=5000, doppler_step=500, samples_per_chip=spc, samples_per_code=float(spms),
+              bit_transition_flag=bt, consumed_samples=consumed)
+    for use_cfar in (True, False):
+        acq = _bank(gpu, max_prn=1, use_cfar=use_cfar, **kw)
+        ora = PcpsOracle(use_cfar=use_cfar, **kw)
+        prec = PcpsOracle(use_cfar=use_cfar, precise=True, **kw)
+        acq.set_local_code(0, code)
+        ora.set_local_code(code)
+        prec.set_local_code(code)
+        res = acq.dwell(x, 1)[0]
+        exp = ora.dwell(x)
+        prec.dwell(x)
+        _same_peak(res, exp, prec, f"n={n}")
+        g = acq.read_grid(0)
+        scale = float(exp["peak"])
+        assert np.max(np.abs(g - ora.grid)) <= RTOL_GRID * scale, (n, np.max(np.abs(g - ora.grid)) / scale)
+        # tighter against the float64 evaluation: our wipe-off phase is exact, the reference's drifts
+        assert np.max(np.abs(g - prec.grid)) <= 2e-4 * scale, (n, np.max(np.abs(g - prec.grid)) / scale)
+        assert res["doppler_hz"] == exp["doppler_hz"]
+        assert res["acq_delay_samples"] == pytest.approx(exp["acq_delay_samples"], abs=0)
+        assert res["peak"] == pytest.approx(exp["peak"], rel=RTOL_GRID)
+        assert res["test_statistics"] == pytest.approx(exp["test_statistics"], rel=5e-3)
+        if use_cfar:
+            assert res["input_power"] == pytest.approx(exp["input_power"], rel=RTOL_GRID)
+        else:
+            assert res["second_peak"] == pytest.approx(exp["second_peak"], rel=RTOL_GRID)
+        acq.close()
+
+
+def test_gsoc2013_known_answer(gpu):
+    fs = 4000000
+    n = 4000
+    prn, doppler, delay_chips = 10, 750.0, 600.0
+    # code phase such that the code START is delayed by 600 chips inside the block
+    x = synth_gps_l1_stream(n, fs, [prn], [doppler], [1023.0 - delay_chips], cn0_dbhz=44.0, seed_noise=2013)
+    kw = dict(fs_in=fs, fft_size=n, doppler_max=10000, doppler_step=250, samples_per_chip=4, samples_per_code=4000.0)
+    acq = _bank(gpu, max_prn=1, use_cfar=True, **kw)
+    acq.set_local_code(0, oracle.ca_code_complex_sampled(prn, fs))
+    res = acq.dwell(x, 1)[0]
+    thr = oracle_threshold(0.001, n, acq.num_doppler_bins, 1)
+    assert res["test_statistics"] > thr, (res, thr)
+    delay_error_chips = abs(delay_chips - res["acq_delay_samples"] * 1023.0 / 4000.0)
+    assert delay_error_chips < 0.5, res
+    assert abs(res["doppler_hz"] - doppler) < 2.0 / (3.0 * 1e-3), res
+    from gnss_sdr_amd.acquisition import compute_threshold
+    assert compute_threshold(0.001, n, acq.num_doppler_bins, 1) == pytest.approx(thr, rel=1e-6)
+    acq.close()
+
+
+def test_config3_32prn_41bins(gpu):
+    """BASELINE config 3: 32 PRN x 41 Doppler bins (-5000..+5000 step 250, explicit count), fs 25 Msps, N 25 000,
+    1 ms of the config-2 stream: 8 embedded PRNs must be detected with bit-exact indices, the other 24 rejected."""
+    fs = 25000000
+    n = 25000
+    rng = np.random.default_rng(0x5EED0003)
+    dop = rng.uniform(-5000, 5000, 8)
+    cph = rng.uniform(0, 1023, 8)
+    x = synth_gps_l1_stream(n, fs, list(range(1, 9)), dop, cph)
+    kw = dict(fs_in=fs, fft_size=n, doppler_max=5000, doppler_step=250, num_doppler_bins=41, samples_per_chip=25, samples_per_code=25000.0)
+    thr = oracle_threshold(0.001, n, 41, 1)
+    for use_cfar in (True, False):
+        acq = _bank(gpu, max_prn=32, use_cfar=use_cfar, **kw)
+        for p in range(32):
+            acq.set_local_code(p, oracle.ca_code_complex_sampled(p + 1, fs))
+        results = acq.dwell(x, 32)
+        for p in range(32):
+            code = oracle.ca_code_complex_sampled(p + 1, fs)
+            ora = PcpsOracle(use_cfar=use_cfar, **kw)
+            ora.set_local_code(code)
+            exp = ora.dwell(x)
+            prec = PcpsOracle(use_cfar=use_cfar, precise=True, **kw)
+            prec.set_local_code(code)
+            prec.dwell(x)
+            res = results[p]
+            _same_peak(res, exp, prec, f"prn {p + 1}")
+            assert res["test_statistics"] == pytest.approx(exp["test_statistics"], rel=5e-3), (p, res, exp)
+            if p < 8:
+                assert (res["index_time"], res["index_doppler"]) == (exp["index_time"], exp["index_doppler"]), (p, res, exp)
+                # the acquired delay/doppler are the embedded ones
+                f_d = dop[p]
+                assert abs(res["doppler_hz"] - f_d) <= 125 + 1, (p, res, f_d)
+                true_delay = ((1023.0 - cph[p]) % 1023.0) * fs / 1.023e6
+                err = abs(res["acq_delay_samples"] - true_delay)
+                assert min(err, n - err) < 0.5 * 25, (p, res, true_delay)
+                if use_cfar:
+                    assert res["test_statistics"] > thr, (p, res, thr)
+            elif use_cfar:
+                assert res["test_statistics"] < thr, (p, res, thr)
+        acq.close()
+
+
+def test_noncoherent_dwells_center_and_errors(gpu):
+    from gnss_sdr_amd import GshError
+    fs = 4000000
+    n = 4000
+    x = synth_gps_l1_stream(2 * n, fs, [3], [-2100.0], [77.7], cn0_dbhz=41.0, seed_noise=5)
+    kw = dict(fs_in=fs, fft_size=n, doppler_max=5000, doppler_step=500, samples_per_chip=4, samples_per_code=4000.0)
+    acq = _bank(gpu, max_prn=2, use_cfar=True, **kw)
+    ora = PcpsOracle(use_cfar=True, **kw)
+    code = oracle.ca_code_complex_sampled(3, fs)
+    with pytest.raises(GshError):
+        acq.dwell(x, 1)  # no local code yet
+    acq.set_local_code(0, code)
+    ora.set_local_code(code)
+    # two non-coherent dwells (acq.cc:545-553): grid accumulates, power is normalised by the dwell count
+    r1 = acq.dwell(x[:n], 1, accumulate=False, dwell_count=1)[0]
+    e1 = ora.dwell(x[:n], 1)
+    r2 = acq.dwell(x[n:], 1, accumulate=True, dwell_count=2)[0]
+    e2 = ora.dwell(x[n:], 2)
+    for r, e in ((r1, e1), (r2, e2)):
+        assert (r["index_time"], r["index_doppler"]) == (e["index_time"], e["index_doppler"])
+        assert r["test_statistics"] == pytest.approx(e["test_statistics"], rel=5e-3)
+    assert np.max(np.abs(acq.read_grid(0) - ora.grid)) <= RTOL_GRID * e2["peak"]
+    # set_doppler_center moves the grid (acq.cc:737-746)
+    acq.set_doppler_center(-2000)
+    ora.set_doppler_center(-2000)
+    r3 = acq.dwell(x[:n], 1)[0]
+    e3 = ora.dwell(x[:n], 1)
+    assert (r3["index_time"], r3["index_doppler"], r3["doppler_hz"]) == (e3["index_time"], e3["index_doppler"], e3["doppler_hz"])
+    with pytest.raises(GshError):
+        acq.dwell(x, 2)  # slot 1 has no code
+    acq.close()
+    with pytest.raises(GshError):
+        _bank(gpu, max_prn=1, fs_in=fs, fft_size=4007 * 2, doppler_max=5000, doppler_step=500, samples_per_chip=4, samples_per_code=4000.0)  # prime factor 4007
