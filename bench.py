@@ -124,16 +124,29 @@ def cpu_baseline(channels, n, fs, taps, target_s):
         params[c] = [p["rem_carr_phase_rad"], p["phase_step_rad"], p["rem_code_phase_chips"], p["code_phase_step_chips"], rng.integers(0, n), 0]
     out = np.zeros(channels * 2 * taps, np.float32)
 
+    threads = cores
+
     def run(epochs):
         if R is not None:
             R.ref_set_flavour(1)  # x86 SIMD protokernels = what volk_gnsssdr dispatches to on this host
             try:
-                return R.ref_mcorr_time(codes, 1023, shifts, taps, xi, len(x), n, channels, epochs, cores, params, out)
+                return R.ref_mcorr_time(codes, 1023, shifts, taps, xi, len(x), n, channels, epochs, threads, params, out)
             finally:
                 R.ref_set_flavour(0)
-        return oracle.lib().oracle_mcorr_time(codes, 1023, shifts, taps, xi, len(x), n, channels, epochs, cores, params, out)
+        return oracle.lib().oracle_mcorr_time(codes, 1023, shifts, taps, xi, len(x), n, channels, epochs, threads, params, out)
 
-    epochs = 16
+    # pick the thread count that serves the CPU best (more threads than memory channels can hurt this streaming kernel)
+    best = (0.0, cores)
+    for cand in sorted({min(cores, c) for c in (8, 16, 32, 64, 128, 256, cores)}):
+        threads = cand
+        e = max(16, 2 * cand * 16 // channels)
+        run(e)
+        rate = channels * e / max(run(e), 1e-9)
+        if rate > best[0]:
+            best = (rate, cand)
+    threads = best[1]
+    cores = threads
+    epochs = 64
     t = run(epochs)  # calibration, then grow the sample until it fills about target_s of wall time
     while t < target_s / 3.0 and epochs < 200000:
         epochs = int(min(200000, max(epochs * 2, epochs * 0.9 * target_s / max(t, 1e-6))))

@@ -102,30 +102,40 @@ int finish_results(gsh_acq* a, uint32_t n_prn, gsh_acq_result* results)
     return GSH_OK;
 }
 
-// ---- regularized lower incomplete gamma P(a, x) and its inverse (for compute_threshold) -------------------
-double gamma_p(double a, double x)
+// ---- regularized incomplete gamma P(a, x), Q(a, x) = 1 - P and the inverse of P (for compute_threshold) ----
+// Both tails are produced without cancellation: the series gives P (used where P is not close to 1), the
+// continued fraction gives Q directly (the thresholds of interest sit at Q ~ 1e-9 ... 1e-13).
+void gamma_pq(double a, double x, double* p_out, double* q_out)
 {
-    if (x <= 0.0) return 0.0;
+    if (x <= 0.0)
+        {
+            *p_out = 0.0;
+            *q_out = 1.0;
+            return;
+        }
     const double lg = std::lgamma(a);
+    const double front = std::exp(-x + a * std::log(x) - lg);
     if (x < a + 1.0)
         {
-            // series: P = e^{-x} x^a / Gamma(a) * sum_{k>=0} x^k / (a (a+1) ... (a+k))
+            // P = e^{-x} x^a / Gamma(a) * sum_{k>=0} x^k / (a (a+1) ... (a+k))
             double term = 1.0 / a, sum = term;
-            for (int k = 1; k < 10000; k++)
+            for (int k = 1; k < 100000; k++)
                 {
                     term *= x / (a + k);
                     sum += term;
                     if (std::fabs(term) < std::fabs(sum) * 1e-17) break;
                 }
-            return sum * std::exp(-x + a * std::log(x) - lg);
+            *p_out = sum * front;
+            *q_out = 1.0 - *p_out;
+            return;
         }
-    // continued fraction for Q = 1 - P (modified Lentz)
+    // Q by the continued fraction (modified Lentz)
     const double tiny = 1e-300;
     double b = x + 1.0 - a;
     double cc = 1.0 / tiny;
     double d = 1.0 / b;
     double h = d;
-    for (int i = 1; i < 10000; i++)
+    for (int i = 1; i < 100000; i++)
         {
             const double an = -static_cast<double>(i) * (static_cast<double>(i) - a);
             b += 2.0;
@@ -138,29 +148,36 @@ double gamma_p(double a, double x)
             h *= del;
             if (std::fabs(del - 1.0) < 1e-16) break;
         }
-    return 1.0 - std::exp(-x + a * std::log(x) - lg) * h;
+    *q_out = front * h;
+    *p_out = 1.0 - *q_out;
 }
 
 double gamma_p_inv(double a, double p)
 {
     if (p <= 0.0) return 0.0;
     if (p >= 1.0) return INFINITY;
-    // bracket, then bisection refined by Newton steps (dP/dx = x^{a-1} e^{-x} / Gamma(a))
-    double lo = 0.0, hi = std::max(1.0, a);
-    while (gamma_p(a, hi) < p) hi *= 2.0;
-    double x = 0.5 * (lo + hi);
+    const double q = 1.0 - p;          // exact for p in [0.5, 1)
+    const bool upper = p > 0.5;        // solve on the tail that is not close to 1
     const double lg = std::lgamma(a);
-    for (int it = 0; it < 200; it++)
+    auto resid = [&](double x) {
+        double pp, qq;
+        gamma_pq(a, x, &pp, &qq);
+        return upper ? (q - qq) : (pp - p);  // increasing in x either way
+    };
+    double lo = 0.0, hi = std::max(1.0, a);
+    while (resid(hi) < 0.0) hi *= 2.0;
+    double x = 0.5 * (lo + hi);
+    for (int it = 0; it < 300; it++)
         {
-            const double f = gamma_p(a, x) - p;
+            const double f = resid(x);
             if (f > 0.0)
                 hi = x;
             else
                 lo = x;
-            const double dfdx = std::exp((a - 1.0) * std::log(x) - x - lg);
+            const double dfdx = std::exp((a - 1.0) * std::log(x) - x - lg);  // dP/dx = -dQ/dx
             double xn = (dfdx > 0.0) ? x - f / dfdx : 0.5 * (lo + hi);
             if (!(xn > lo && xn < hi)) xn = 0.5 * (lo + hi);
-            if (std::fabs(xn - x) <= 1e-15 * std::fabs(x)) return xn;
+            if (std::fabs(xn - x) <= 4e-16 * std::fabs(x)) return xn;
             x = xn;
         }
     return x;

@@ -1,0 +1,47 @@
+"""CPU tests of the acquisition oracle (oracle/pcps_oracle.py): the reference's synthetic known-answer case and the
+agreement of its float32 path with the float64 arbiter.  (The GPU engine is compared with this oracle in
+tests/test_acquisition_gpu.py.)"""
+import numpy as np
+
+import oracle
+from oracle.pcps_oracle import PcpsOracle, compute_threshold
+from helpers import synth_gps_l1_stream
+
+
+def test_gsoc2013_known_answer_on_the_oracle():
+    """gps_l1_ca_pcps_acquisition_gsoc2013_test.cc:197-264,384-401: PRN 10, 750 Hz, 600 chips, 4 Msps,
+    doppler_max 10000, step 250, pfa 1e-3: delay error < 0.5 chip, Doppler error < 2/(3 T)."""
+    fs, n = 4000000, 4000
+    x = synth_gps_l1_stream(n, fs, [10], [750.0], [1023.0 - 600.0], cn0_dbhz=47.0, seed_noise=2013)
+    kw = dict(fs_in=fs, fft_size=n, doppler_max=10000, doppler_step=250, samples_per_chip=4, samples_per_code=4000.0)
+    for use_cfar in (True, False):
+        o = PcpsOracle(use_cfar=use_cfar, **kw)
+        assert o.n_bins == 80
+        o.set_local_code(oracle.ca_code_complex_sampled(10, fs))
+        r = o.dwell(x)
+        assert abs(600.0 - r["acq_delay_samples"] * 1023.0 / 4000.0) < 0.5
+        assert abs(r["doppler_hz"] - 750.0) < 2.0 / 3e-3
+        if use_cfar:
+            assert r["test_statistics"] > compute_threshold(0.001, n, 80, 1)
+        else:
+            assert r["test_statistics"] > 2.0
+        p = PcpsOracle(use_cfar=use_cfar, precise=True, **kw)
+        p.set_local_code(oracle.ca_code_complex_sampled(10, fs))
+        rp = p.dwell(x)
+        assert (r["index_time"], r["index_doppler"]) == (rp["index_time"], rp["index_doppler"])
+        assert abs(r["test_statistics"] - rp["test_statistics"]) <= 2e-3 * rp["test_statistics"]
+
+
+def test_exclusion_window_wraps_like_the_reference():
+    """first_vs_second_peak_statistic blanks [tau-spc, tau+spc) cyclically (acq.cc:485-509), including across the ends."""
+    kw = dict(fs_in=4000000, fft_size=4000, doppler_max=1000, doppler_step=500, samples_per_chip=4, samples_per_code=4000.0, use_cfar=False)
+    o = PcpsOracle(**kw)
+    g = np.ones((o.n_bins, 4000), np.float32)
+    g[1, 2] = 50.0      # peak near the start: window wraps to the end of the row
+    g[1, 3998] = 40.0   # inside the wrapped window -> must be blanked
+    g[1, 5] = 30.0      # inside the window (idx 2-4 .. 2+4 exclusive)
+    g[1, 6] = 20.0      # first cell after the window -> the second peak
+    o.grid = g
+    r = o.statistics()
+    assert (r["index_time"], r["index_doppler"]) == (2, 1)
+    assert r["second_peak"] == 20.0 and r["test_statistics"] == 2.5
