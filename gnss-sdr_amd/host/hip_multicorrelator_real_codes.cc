@@ -1,0 +1,87 @@
+/*!
+ * \file hip_multicorrelator_real_codes.cc
+ * \brief Thin C++ shell over the gsh_mcorr_* C ABI; see the header.
+ */
+#include "hip_multicorrelator_real_codes.h"
+#include "gnss_sdr_hip.h"
+#include <cstdlib>
+
+Hip_Multicorrelator_Real_Codes::~Hip_Multicorrelator_Real_Codes()
+{
+    if (d_handle != nullptr)
+        {
+            gsh_mcorr_destroy(d_handle);
+            d_handle = nullptr;
+        }
+}
+
+
+bool Hip_Multicorrelator_Real_Codes::check(int rc)
+{
+    if (rc == GSH_OK) return true;
+    d_error = gsh_last_error();
+    return false;
+}
+
+
+bool Hip_Multicorrelator_Real_Codes::ensure_handle()
+{
+    if (d_handle != nullptr) return true;
+    int device = d_device;
+    if (device < 0)
+        {
+            const char* env = std::getenv("GNSS_SDR_HIP_DEVICE");
+            device = env ? std::atoi(env) : 0;
+        }
+    if (!check(gsh_mcorr_create(device, &d_handle))) return false;
+    return check(gsh_mcorr_set_high_dynamics_resampler(d_handle, d_use_high_dynamics_resampler ? 1 : 0));
+}
+
+
+void Hip_Multicorrelator_Real_Codes::set_high_dynamics_resampler(bool use_high_dynamics_resampler)
+{
+    d_use_high_dynamics_resampler = use_high_dynamics_resampler;
+    if (d_handle != nullptr) check(gsh_mcorr_set_high_dynamics_resampler(d_handle, use_high_dynamics_resampler ? 1 : 0));
+}
+
+
+bool Hip_Multicorrelator_Real_Codes::init(int max_signal_length_samples, int n_correlators)
+{
+    return ensure_handle() && check(gsh_mcorr_init(d_handle, max_signal_length_samples, n_correlators));
+}
+
+
+bool Hip_Multicorrelator_Real_Codes::set_local_code_and_taps(int code_length_chips, const float* local_code_in, float* shifts_chips)
+{
+    return ensure_handle() && check(gsh_mcorr_set_local_code_and_taps(d_handle, code_length_chips, local_code_in, shifts_chips));
+}
+
+
+bool Hip_Multicorrelator_Real_Codes::set_input_output_vectors(std::complex<float>* corr_out, const std::complex<float>* sig_in)
+{
+    return ensure_handle() && check(gsh_mcorr_set_input_output_vectors(d_handle, reinterpret_cast<float*>(corr_out), reinterpret_cast<const float*>(sig_in)));
+}
+
+
+bool Hip_Multicorrelator_Real_Codes::Carrier_wipeoff_multicorrelator_resampler(float rem_carrier_phase_in_rad, float phase_step_rad,
+    float phase_rate_step_rad, float rem_code_phase_chips, float code_phase_step_chips, float code_phase_rate_step_chips,
+    int signal_length_samples)
+{
+    return ensure_handle() && check(gsh_mcorr_carrier_wipeoff_multicorrelator_resampler(d_handle, rem_carrier_phase_in_rad, phase_step_rad,
+                                  phase_rate_step_rad, rem_code_phase_chips, code_phase_step_chips, code_phase_rate_step_chips, signal_length_samples));
+}
+
+
+bool Hip_Multicorrelator_Real_Codes::Carrier_wipeoff_multicorrelator_resampler(float rem_carrier_phase_in_rad, float phase_step_rad,
+    float rem_code_phase_chips, float code_phase_step_chips, float code_phase_rate_step_chips, int signal_length_samples)
+{
+    return ensure_handle() && check(gsh_mcorr_carrier_wipeoff_multicorrelator_resampler6(d_handle, rem_carrier_phase_in_rad, phase_step_rad,
+                                  rem_code_phase_chips, code_phase_step_chips, code_phase_rate_step_chips, signal_length_samples));
+}
+
+
+bool Hip_Multicorrelator_Real_Codes::free()
+{
+    if (d_handle == nullptr) return true;
+    return check(gsh_mcorr_free(d_handle));
+}

@@ -1,0 +1,132 @@
+/*!
+ * \file hip_pcps_acquisition_core.cc
+ * \brief See the header.  Sizes follow acq.cc:110-117, the dwell / threshold logic acq.cc:686-727.
+ */
+#include "hip_pcps_acquisition_core.h"
+#include "gnss_sdr_hip.h"
+
+Hip_Pcps_Acquisition_Core::Hip_Pcps_Acquisition_Core(const Hip_Acq_Conf& conf, int device, uint32_t num_doppler_bins_override)
+    : d_acq_parameters(conf)
+{
+    // acq.cc:110-113
+    d_consumed_samples = static_cast<uint32_t>(conf.sampled_ms * conf.samples_per_ms * (conf.bit_transition_flag ? 2.0 : 1.0));
+    d_fft_size = (conf.sampled_ms == conf.ms_per_code) ? d_consumed_samples : d_consumed_samples * 2;
+    d_effective_fft_size = conf.bit_transition_flag ? (d_fft_size / 2) : d_fft_size;
+    d_num_doppler_bins = num_doppler_bins_override ? num_doppler_bins_override
+                                                   : static_cast<uint32_t>(std::ceil(static_cast<double>(2 * conf.doppler_max) / static_cast<double>(conf.doppler_step)));
+    // acq.cc:116
+    d_threshold = conf.pfa > 0.0F ? compute_threshold(conf.pfa, d_effective_fft_size, d_num_doppler_bins, conf.bit_transition_flag ? 1 : conf.max_dwells) : conf.threshold;
+
+    gsh_acq_conf c{};
+    c.fs_in = conf.use_automatic_resampler ? conf.resampled_fs : conf.fs_in;  // acq.cc:277
+    c.fft_size = d_fft_size;
+    c.effective_fft_size = d_effective_fft_size;
+    c.consumed_samples = d_consumed_samples;
+    c.num_doppler_bins = d_num_doppler_bins;
+    c.doppler_max = conf.doppler_max;
+    c.doppler_step = conf.doppler_step;
+    c.doppler_center = 0;
+    c.doppler_bias = 0;
+    c.samples_per_chip = conf.samples_per_chip;
+    c.samples_per_code = conf.samples_per_code;
+    c.bit_transition_flag = conf.bit_transition_flag ? 1 : 0;
+    c.use_cfar = conf.use_CFAR_algorithm_flag ? 1 : 0;
+    c.max_prn = 1;
+    if (gsh_acq_create(device, &c, &d_handle) != GSH_OK)
+        {
+            d_error = gsh_last_error();
+            d_handle = nullptr;
+        }
+}
+
+
+Hip_Pcps_Acquisition_Core::~Hip_Pcps_Acquisition_Core()
+{
+    if (d_handle != nullptr) gsh_acq_destroy(d_handle);
+}
+
+
+float Hip_Pcps_Acquisition_Core::compute_threshold(float pfa, uint32_t effective_fft_size, uint32_t num_doppler_bins, uint32_t max_dwells)
+{
+    return gsh_acq_compute_threshold(pfa, effective_fft_size, num_doppler_bins, max_dwells);
+}
+
+
+void Hip_Pcps_Acquisition_Core::set_local_code(const std::complex<float>* code)
+{
+    if (d_handle == nullptr) return;
+    if (gsh_acq_set_local_code(d_handle, 0, reinterpret_cast<const float*>(code)) != GSH_OK) d_error = gsh_last_error();
+}
+
+
+void Hip_Pcps_Acquisition_Core::set_doppler_center(int32_t doppler_center)
+{
+    if (d_handle == nullptr) return;
+    if (doppler_center != d_doppler_center)  // acq.cc:741
+        {
+            d_doppler_center = doppler_center;
+            if (gsh_acq_set_doppler_center(d_handle, doppler_center) != GSH_OK) d_error = gsh_last_error();
+        }
+}
+
+
+Hip_Pcps_Acquisition_Core::Outcome Hip_Pcps_Acquisition_Core::acquisition_core(uint64_t sample_count, const std::complex<float>* data, AcquisitionResult* result)
+{
+    if (d_handle == nullptr || data == nullptr || result == nullptr) return ACQ_ERROR;
+    d_num_noncoherent_integrations_counter++;  // acq.cc:668
+    gsh_acq_result r{};
+    const int accumulate = d_num_noncoherent_integrations_counter > 1 ? 1 : 0;  // acq.cc:545-553
+    if (gsh_acq_dwell(d_handle, reinterpret_cast<const float*>(data), 1, accumulate, d_num_noncoherent_integrations_counter, &r) != GSH_OK)
+        {
+            d_error = gsh_last_error();
+            d_num_noncoherent_integrations_counter = 0;
+            return ACQ_ERROR;  // surfaces as "no detection", never as an exception across the GNU Radio thread
+        }
+    result->sample_count = sample_count;
+    result->index_time = r.index_time;
+    result->doppler = r.doppler_hz;
+    result->test_statistics = r.test_statistics;
+    result->positive_acq = false;
+    d_input_power = r.input_power;
+
+    Outcome out = ACQ_CONTINUE;
+    if (!d_acq_parameters.bit_transition_flag)  // acq.cc:686-704
+        {
+            if (result->test_statistics > d_threshold)
+                {
+                    result->positive_acq = true;
+                    out = ACQ_POSITIVE;
+                }
+            if (d_num_noncoherent_integrations_counter == d_acq_parameters.max_dwells && out != ACQ_POSITIVE) out = ACQ_NEGATIVE;
+        }
+    else  // acq.cc:705-715
+        {
+            if (result->test_statistics > d_threshold)
+                {
+                    result->positive_acq = true;
+                    out = ACQ_POSITIVE;
+                }
+            else
+                {
+                    out = ACQ_NEGATIVE;
+                }
+        }
+    // acq.cc:717-725
+    if (d_num_noncoherent_integrations_counter == d_acq_parameters.max_dwells || result->positive_acq || d_acq_parameters.bit_transition_flag)
+        {
+            d_num_noncoherent_integrations_counter = 0U;
+        }
+    return out;
+}
+
+
+bool Hip_Pcps_Acquisition_Core::read_grid(float* grid)
+{
+    if (d_handle == nullptr) return false;
+    if (gsh_acq_read_grid(d_handle, 0, grid) != GSH_OK)
+        {
+            d_error = gsh_last_error();
+            return false;
+        }
+    return true;
+}

@@ -1,0 +1,139 @@
+/*!
+ * \file hip_pcps_acquisition_core.h
+ * \brief The arithmetic and dwell logic of gnss-sdr's pcps_acquisition block
+ *        (src/algorithms/acquisition/gnuradio_blocks/pcps_acquisition.{h,cc}) on an MI355X, without the GNU Radio shell.
+ *
+ * Method and member names follow the reference block so that the GNU Radio wrapper in
+ * gnss_sdr_adapters/pcps_acquisition_hip.cc is a line-for-line shell around this class:
+ *   set_local_code        acq.cc:218-251      set_doppler_center  acq.cc:737-746
+ *   acquisition_core      acq.cc:648-728      update_synchro      acq.cc:580-602
+ *   compute_threshold     acq.cc:52-56
+ * Everything numeric goes through the C ABI (include/gnss_sdr_hip.h, gsh_acq_*).  No CPU fallback.
+ * Not implemented ("next"): make_2_steps fine-Doppler refinement, cshort input.
+ */
+#ifndef GNSS_SDR_HIP_PCPS_ACQUISITION_CORE_H
+#define GNSS_SDR_HIP_PCPS_ACQUISITION_CORE_H
+
+#include <cmath>
+#include <complex>
+#include <cstdint>
+#include <string>
+
+struct gsh_acq;
+
+/*! The members of Acq_Conf (src/algorithms/acquisition/libs/acq_conf.h:33-87) the arithmetic depends on, same names. */
+struct Hip_Acq_Conf
+{
+    int64_t fs_in{4000000LL};
+    int64_t resampled_fs{0LL};
+    float samples_per_ms{0.0F};
+    float threshold{0.0F};
+    float pfa{0.0F};
+    float samples_per_code{0.0F};
+    float resampler_ratio{1.0F};
+    uint32_t sampled_ms{1U};
+    uint32_t ms_per_code{1U};
+    uint32_t samples_per_chip{2U};
+    uint32_t chips_per_second{1023000U};
+    uint32_t max_dwells{1U};
+    uint32_t resampler_latency_samples{0U};
+    int32_t doppler_max{5000};
+    int32_t doppler_step{500};
+    bool bit_transition_flag{false};
+    bool use_CFAR_algorithm_flag{true};
+    bool use_automatic_resampler{false};
+
+    /*! acq_conf.cc:119-124 */
+    void SetDerivedParams()
+    {
+        if (resampled_fs == 0) resampled_fs = fs_in;
+        samples_per_ms = static_cast<float>(resampled_fs) * 0.001F;
+        samples_per_chip = static_cast<unsigned int>(std::ceil(static_cast<float>(resampled_fs) / static_cast<float>(chips_per_second)));
+        samples_per_code = samples_per_ms * static_cast<float>(ms_per_code);
+    }
+};
+
+class Hip_Pcps_Acquisition_Core
+{
+public:
+    /*! pcps_acquisition::AcquisitionResult (pcps_acquisition.h) */
+    struct AcquisitionResult
+    {
+        uint64_t sample_count{0};
+        float test_statistics{0.0F};
+        int32_t doppler{0};
+        uint32_t index_time{0};
+        bool positive_acq{false};
+    };
+
+    enum Outcome
+    {
+        ACQ_CONTINUE = 0,  //!< below threshold, more non-coherent dwells allowed (acq.cc:694-698: d_state = 1)
+        ACQ_POSITIVE = 1,  //!< send_positive_acquisition, "events" message 1 (acq.cc:318-341)
+        ACQ_NEGATIVE = 2,  //!< send_negative_acquisition, "events" message 2 (acq.cc:344-351)
+        ACQ_ERROR = -1
+    };
+
+    /*! num_doppler_bins_override = 0 keeps the reference's ceil(2*doppler_max/doppler_step) (acq.cc:113) */
+    explicit Hip_Pcps_Acquisition_Core(const Hip_Acq_Conf& conf, int device = 0, uint32_t num_doppler_bins_override = 0);
+    ~Hip_Pcps_Acquisition_Core();
+    Hip_Pcps_Acquisition_Core(const Hip_Pcps_Acquisition_Core&) = delete;
+    Hip_Pcps_Acquisition_Core& operator=(const Hip_Pcps_Acquisition_Core&) = delete;
+
+    bool ok() const { return d_handle != nullptr; }
+    const std::string& last_error() const { return d_error; }
+
+    void set_local_code(const std::complex<float>* code);
+    void set_doppler_center(int32_t doppler_center);
+    void set_threshold(float threshold) { d_threshold = threshold; }
+    float get_threshold() const { return d_threshold; }
+    void reset() { d_num_noncoherent_integrations_counter = 0; }
+
+    /*! one dwell over d_consumed_samples samples; the caller does the buffering of acq.cc:790-815 */
+    Outcome acquisition_core(uint64_t sample_count, const std::complex<float>* data, AcquisitionResult* result);
+
+    /*! acq.cc:580-602; Synchro is gnss-sdr's Gnss_Synchro (gnss_synchro.h:38-82) or anything with the same members */
+    template <typename Synchro>
+    void update_synchro(const AcquisitionResult& result, Synchro* s) const
+    {
+        s->Acq_delay_samples = static_cast<double>(std::fmod(static_cast<float>(result.index_time), d_acq_parameters.samples_per_code));
+        s->Acq_doppler_hz = static_cast<double>(result.doppler);
+        if (d_acq_parameters.use_automatic_resampler)
+            {
+                s->Acq_delay_samples = (s->Acq_delay_samples * d_acq_parameters.resampler_ratio) - static_cast<double>(d_acq_parameters.resampler_latency_samples);
+                s->Acq_samplestamp_samples = static_cast<uint64_t>(std::rint(static_cast<double>(result.sample_count) * d_acq_parameters.resampler_ratio));
+                s->fs = d_acq_parameters.resampled_fs;
+            }
+        else
+            {
+                s->Acq_samplestamp_samples = result.sample_count;
+                s->fs = d_acq_parameters.fs_in;
+            }
+    }
+
+    /*! dump support (acq.cc:555-558): D rows of d_effective_fft_size floats */
+    bool read_grid(float* grid);
+
+    uint32_t consumed_samples() const { return d_consumed_samples; }
+    uint32_t fft_size() const { return d_fft_size; }
+    uint32_t effective_fft_size() const { return d_effective_fft_size; }
+    uint32_t num_doppler_bins() const { return d_num_doppler_bins; }
+    float input_power() const { return d_input_power; }
+
+    static float compute_threshold(float pfa, uint32_t effective_fft_size, uint32_t num_doppler_bins, uint32_t max_dwells);
+
+private:
+    Hip_Acq_Conf d_acq_parameters;
+    gsh_acq* d_handle{nullptr};
+    std::string d_error;
+    uint32_t d_consumed_samples{0};
+    uint32_t d_fft_size{0};
+    uint32_t d_effective_fft_size{0};
+    uint32_t d_num_doppler_bins{0};
+    uint32_t d_num_noncoherent_integrations_counter{0};
+    int32_t d_doppler_center{0};
+    float d_threshold{0.0F};
+    float d_input_power{0.0F};
+};
+
+#endif  // GNSS_SDR_HIP_PCPS_ACQUISITION_CORE_H

@@ -118,6 +118,7 @@ def test_config3_32prn_41bins(gpu):
         for p in range(32):
             acq.set_local_code(p, oracle.ca_code_complex_sampled(p + 1, fs))
         results = acq.dwell(x, 32)
+        detected = 0
         for p in range(32):
             code = oracle.ca_code_complex_sampled(p + 1, fs)
             ora = PcpsOracle(use_cfar=use_cfar, **kw)
@@ -137,10 +138,16 @@ def test_config3_32prn_41bins(gpu):
                 true_delay = ((1023.0 - cph[p]) % 1023.0) * fs / 1.023e6
                 err = abs(res["acq_delay_samples"] - true_delay)
                 assert min(err, n - err) < 0.5 * 25, (p, res, true_delay)
-                if use_cfar:
-                    assert res["test_statistics"] > thr, (p, res, thr)
-            elif use_cfar:
-                assert res["test_statistics"] < thr, (p, res, thr)
+            if use_cfar:
+                # same decision as the oracle (unless the statistic sits within FFT rounding of the threshold);
+                # at 45 dB-Hz / 1 ms the expected statistic 2*C/N0*T = 63 minus scalloping losses is close to the
+                # pfa = 1e-3 threshold over 10^6 cells (47.9), so a weak PRN may legitimately stay below it
+                if abs(exp["test_statistics"] - thr) > 5e-3 * thr:
+                    assert (res["test_statistics"] > thr) == (exp["test_statistics"] > thr), (p, res, exp, thr)
+                detected += int(res["test_statistics"] > thr and p < 8)
+                assert p < 8 or res["test_statistics"] < thr, (p, res, thr)
+        if use_cfar:
+            assert detected >= 6, detected
         acq.close()
 
 
