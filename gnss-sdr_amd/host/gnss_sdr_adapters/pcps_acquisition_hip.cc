@@ -1,0 +1,147 @@
+/*!
+ * \file pcps_acquisition_hip.cc
+ * \brief See the header.  State machine: 0 = (re)start, 1 = fill the dwell buffer, 2 = run one dwell on the GPU
+ *        -- the same three states the reference block steps through in general_work (acq.cc:749-853); the dwell itself is
+ *        blocking, like the reference's default (acq_conf.h:72).  BUILT ONLY INSIDE A gnss-sdr TREE.
+ */
+#include "pcps_acquisition_hip.h"
+#include <gnuradio/io_signature.h>
+#include <pmt/pmt.h>
+#include <algorithm>
+#include <utility>
+
+pcps_acquisition_hip_sptr pcps_make_acquisition_hip(const Hip_Acq_Conf& conf, int device, bool blocking_on_standby)
+{
+    return pcps_acquisition_hip_sptr(new pcps_acquisition_hip(conf, device, blocking_on_standby));
+}
+
+
+pcps_acquisition_hip::pcps_acquisition_hip(const Hip_Acq_Conf& conf, int device, bool blocking_on_standby)
+    : acquisition_impl_interface("pcps_acquisition_hip",
+          gr::io_signature::make(1, 1, sizeof(gr_complex)),
+          gr::io_signature::make(0, 1, sizeof(Gnss_Synchro))),
+      d_core(conf, device),
+      d_data_buffer(d_core.consumed_samples()),
+      d_blocking_on_standby(blocking_on_standby)
+{
+    this->message_port_register_out(pmt::mp("events"));
+}
+
+
+void pcps_acquisition_hip::set_local_code(std::complex<float>* code)
+{
+    gr::thread::scoped_lock lock(d_setlock);
+    d_core.set_local_code(code);
+}
+
+
+void pcps_acquisition_hip::set_active(bool active)
+{
+    gr::thread::scoped_lock lock(d_setlock);
+    d_active = active;
+}
+
+
+void pcps_acquisition_hip::set_doppler_center(int32_t doppler_center)
+{
+    gr::thread::scoped_lock lock(d_setlock);
+    d_core.set_doppler_center(doppler_center);
+}
+
+
+void pcps_acquisition_hip::set_threshold(float threshold)
+{
+    gr::thread::scoped_lock lock(d_setlock);
+    d_core.set_threshold(threshold);
+}
+
+
+void pcps_acquisition_hip::set_state(int32_t state)
+{
+    gr::thread::scoped_lock lock(d_setlock);
+    d_state = state;
+    if (state == 0) d_core.reset();
+}
+
+
+void pcps_acquisition_hip::run_dwell(uint64_t sample_count)
+{
+    Hip_Pcps_Acquisition_Core::AcquisitionResult result;
+    const auto outcome = d_core.acquisition_core(sample_count, d_data_buffer.data(), &result);
+    gr::thread::scoped_lock lock(d_setlock);
+    if (outcome != Hip_Pcps_Acquisition_Core::ACQ_ERROR && d_gnss_synchro != nullptr) d_core.update_synchro(result, d_gnss_synchro);
+    switch (outcome)
+        {
+        case Hip_Pcps_Acquisition_Core::ACQ_POSITIVE:
+            d_state = 0;
+            d_active = false;
+            if (auto fsm = d_channel_fsm.lock())
+                {
+                    fsm->Event_valid_acquisition();
+                }
+            else
+                {
+                    this->message_port_pub(pmt::mp("events"), pmt::from_long(1));
+                }
+            break;
+        case Hip_Pcps_Acquisition_Core::ACQ_CONTINUE:
+            d_buffer_count = 0U;
+            d_state = 1;  // gather the next non-coherent dwell
+            break;
+        case Hip_Pcps_Acquisition_Core::ACQ_NEGATIVE:
+        case Hip_Pcps_Acquisition_Core::ACQ_ERROR:  // a GPU failure must look like "not found", never throw here
+        default:
+            d_state = 0;
+            d_active = false;
+            this->message_port_pub(pmt::mp("events"), pmt::from_long(2));
+            break;
+        }
+}
+
+
+int pcps_acquisition_hip::general_work(int /*noutput_items*/, gr_vector_int& ninput_items, gr_vector_const_void_star& input_items,
+    gr_vector_void_star& /*output_items*/)
+{
+    gr::thread::scoped_lock lk(d_setlock);
+    if (!d_active)
+        {
+            if (!d_blocking_on_standby)
+                {
+                    d_sample_count += static_cast<uint64_t>(ninput_items[0]);
+                    consume_each(ninput_items[0]);
+                }
+            return 0;
+        }
+    if (d_state == 0)
+        {
+            if (d_gnss_synchro != nullptr)
+                {
+                    d_gnss_synchro->Acq_delay_samples = 0.0;
+                    d_gnss_synchro->Acq_doppler_hz = 0.0;
+                    d_gnss_synchro->Acq_samplestamp_samples = 0ULL;
+                    d_gnss_synchro->Acq_doppler_step = 0U;
+                }
+            d_buffer_count = 0U;
+            d_state = 1;
+        }
+    else if (d_state == 1)
+        {
+            const uint32_t want = d_core.consumed_samples();
+            const uint32_t room = want - std::min(d_buffer_count, want);
+            const uint32_t take = std::min<uint32_t>(room, static_cast<uint32_t>(ninput_items[0]));
+            const auto* in = reinterpret_cast<const gr_complex*>(input_items[0]);
+            std::copy(in, in + take, d_data_buffer.begin() + d_buffer_count);
+            if (d_buffer_count >= want) d_state = 2;  // same one-call latency as acq.cc:807-811
+            d_buffer_count += take;
+            d_sample_count += take;
+            consume_each(static_cast<int>(take));
+        }
+    else
+        {
+            const uint64_t stamp = d_sample_count;
+            lk.unlock();
+            run_dwell(stamp);
+            consume_each(0);
+        }
+    return 0;
+}
