@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgnss_sdr_hip.so")
+LIB_PATH = os.environ.get("GSH_LIB_PATH") or os.path.join(_HERE, "libgnss_sdr_hip.so")  # override: kernel-tuning experiments only
 
 GSH_MAX_TAPS = 8
 GSH_OK = 0

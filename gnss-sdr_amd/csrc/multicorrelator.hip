@@ -17,7 +17,7 @@
 //     -ffp-contract=off), so chip selection is BIT-EXACT with the _generic protokernel;
 //   * the carrier NCO is evaluated, not recurred from n=0: every thread seeds
 //     exp(-j(rem + n*step)) exactly (double-precision phase, reduced mod 2pi) and steps it
-//     by exp(-j*512*step) for at most MC_RESEED strides before re-seeding, which keeps the
+//     by exp(-j*512*step) for at most MC_RESEED (32) strides before re-seeding, which keeps the
 //     rotator within ~1e-6 of the exact value instead of the reference's O(1e-5) drift;
 //   * each work-group (256 threads = 4 waves) streams its window with 16-byte loads
 //     (two complex64 per lane, 1 KiB per wave-instruction), accumulates T complex sums per
@@ -35,7 +35,13 @@ namespace
 constexpr int MC_THREADS = 256;
 constexpr int MC_WAVES = MC_THREADS / 64;
 constexpr int MC_MARGIN = 32;  // guard entries on each side of the LDS code table
-constexpr int MC_RESEED = 16;  // strides of 512 samples between exact NCO re-seeds
+#ifndef GSH_MC_RESEED
+#define GSH_MC_RESEED 32
+#endif
+#ifndef GSH_MC_CVT_FLR
+#define GSH_MC_CVT_FLR 1
+#endif
+constexpr int MC_RESEED = GSH_MC_RESEED;  // strides of 512 samples between exact NCO re-seeds
 constexpr int MC_PAIRS_PER_CHUNK = MC_THREADS;  // one float4 (2 samples) per thread per chunk
 constexpr double INV_TWO_PI = 0.15915494309189533576888376337251436;
 constexpr double TWO_PI_D = 6.283185307179586476925286766559;
@@ -91,10 +97,22 @@ __device__ __forceinline__ int wrap_chip(int k, int len)
     return k;
 }
 
+// (int)floor(x) in one VALU instruction (v_cvt_flr_i32_f32: round toward -inf, then convert)
+__device__ __forceinline__ int floor_to_int(float x)
+{
+#if GSH_MC_CVT_FLR
+    int k;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(k) : "v"(x));
+    return k;
+#else
+    return static_cast<int>(floorf(x));
+#endif
+}
+
 // raw (unwrapped) chip index, standard resampler: floor((step*(float)n + shift) - rem)
 __device__ __forceinline__ int raw_chip_std(float step_x_n, float shift, float rem)
 {
-    return static_cast<int>(floorf(__fsub_rn(__fadd_rn(step_x_n, shift), rem)));
+    return floor_to_int(__fsub_rn(__fadd_rn(step_x_n, shift), rem));
 }
 
 // raw chip index, high-dynamics resampler tap 0 expression evaluated at sample m:
@@ -103,7 +121,7 @@ __device__ __forceinline__ int raw_chip_hd(float step, float rate, unsigned m, f
 {
     const float a = __fmul_rn(step, static_cast<float>(m));
     const float q = __fmul_rn(rate, static_cast<float>(m * m));
-    return static_cast<int>(floorf(__fsub_rn(__fadd_rn(__fadd_rn(a, q), shift0), rem)));
+    return floor_to_int(__fsub_rn(__fadd_rn(__fadd_rn(a, q), shift0), rem));
 }
 
 struct JobCtx
@@ -239,21 +257,23 @@ __device__ __forceinline__ void run_segment(const JobCtx& c, const float2* __res
                 }
             else
                 {
-                    // stride rotator exp(-j * 512 * step), exact
+                    // stride rotator exp(-j * 512 * step) and sample rotator exp(-j * step), both seeded exactly
                     const float2 w = expmj(static_cast<double>(2 * MC_PAIRS_PER_CHUNK) * static_cast<double>(c.phase_step));
-                    int k = k_full_begin;
-                    while (k < k_full_end)
+                    const float2 inc = expmj(static_cast<double>(c.phase_step));
+                    for (int kb = k_full_begin; kb < k_full_end; kb += MC_RESEED)
                         {
-                            const int n0 = c.n_first + 2 * (tid + k * MC_PAIRS_PER_CHUNK);
-                            float2 pa = expmj(carrier_phase<false>(c.rem_carr, c.phase_step, 0.0f, n0));
-                            float2 pb = expmj(carrier_phase<false>(c.rem_carr, c.phase_step, 0.0f, n0 + 1));
-                            const int k_stop = min(k + MC_RESEED, k_full_end);
-#pragma unroll 4
-                            for (; k < k_stop; k++)
+                            const int cnt = min(MC_RESEED, k_full_end - kb);
+                            int pair = tid + kb * MC_PAIRS_PER_CHUNK;
+                            // exact re-seed of this lane's phasor; the second sample of the pair is one step further
+                            float2 pa = expmj(carrier_phase<false>(c.rem_carr, c.phase_step, 0.0f, c.n_first + 2 * pair));
+                            float2 pb = cmul(pa, inc);
+#pragma unroll 2
+                            for (int i = 0; i < cnt; i++)
                                 {
-                                    process_pair<NT, MODE, WRAP, false>(c, base, tab, sh, rot, tid + k * MC_PAIRS_PER_CHUNK, pa, pb, acc);
+                                    process_pair<NT, MODE, WRAP, false>(c, base, tab, sh, rot, pair, pa, pb, acc);
                                     pa = cmul(pa, w);
                                     pb = cmul(pb, w);
+                                    pair += MC_PAIRS_PER_CHUNK;
                                 }
                         }
                 }
