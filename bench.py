@@ -173,12 +173,15 @@ def acquisition_metric(torch, dev_index, x_block, fs):
     import oracle
     n = int(fs * 1e-3)
     acq = PcpsAcquisitionBank(fs_in=int(fs), fft_size=n, doppler_max=5000, doppler_step=250, num_doppler_bins=41,
-                              samples_per_chip=int(np.ceil(fs / 1.023e6)), samples_per_code=float(n), max_prn=32, device=dev_index)
+                              samples_per_chip=int(np.ceil(fs / 1.023e6)), samples_per_code=float(n), max_prn=32, device=dev_index,
+                              keep_grid=False)  # max_dwells = 1, dump = false: the statistics are formed on chip
     for p in range(32):
         acq.set_local_code(p, oracle.ca_code_complex_sampled(p + 1, int(fs)))
-    ms = acq.time_dwells(x_block, 32, reps=10)
+    ms_serial = acq.time_dwells(x_block, 32, reps=10)             # one batch after the other on one stream: latency
+    ms = acq.time_dwells(x_block, 32, reps=20, pipelined=True)    # batches alternating on two streams: throughput
     nbytes = 16.0 * n * 41 * (32 + 1)
     res = {"metric": "acquisition dwells/s", "value": 32.0 / (ms * 1e-3), "unit": "dwells/s", "ms_per_batch": ms,
+           "ms_per_batch_single_stream": ms_serial,
            "config": {"workload": "GPS L1 C/A PCPS, 32 PRN x 41 Doppler bins, N=25000, 1 dwell"},
            "roofline": {"bound": "hbm", "achieved": nbytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None}}

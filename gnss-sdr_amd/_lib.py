@@ -57,6 +57,8 @@ class AcqConf(C.Structure):
         ("bit_transition_flag", C.c_int32),
         ("use_cfar", C.c_int32),
         ("max_prn", C.c_uint32),
+        ("no_grid", C.c_int32),
+        ("transform_path", C.c_int32),
     ]
 
 
@@ -111,6 +113,7 @@ SYMBOLS = {
     "gsh_acq_dwell_device": (C.c_int, [_P, _P, C.c_uint32, C.c_int, C.c_uint32, C.POINTER(AcqResult)]),
     "gsh_acq_read_grid": (C.c_int, [_P, C.c_uint32, _F]),
     "gsh_acq_time_dwells": (C.c_int, [_P, C.c_uint32, C.c_int, _F]),
+    "gsh_acq_time_dwells_pipelined": (C.c_int, [_P, C.c_uint32, C.c_int, _F]),
     "gsh_acq_compute_threshold": (C.c_float, [C.c_float, C.c_uint32, C.c_uint32, C.c_uint32]),
 }
 

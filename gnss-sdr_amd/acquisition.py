@@ -33,7 +33,8 @@ class PcpsAcquisitionBank:
     def __init__(self, fs_in: int, fft_size: int, doppler_max: int, doppler_step: int, samples_per_chip: int,
                  samples_per_code: float, max_prn: int = 1, num_doppler_bins: int = 0, consumed_samples: int | None = None,
                  effective_fft_size: int | None = None, doppler_center: int = 0, doppler_bias: int = 0,
-                 bit_transition_flag: bool = False, use_cfar: bool = True, device: int = 0):
+                 bit_transition_flag: bool = False, use_cfar: bool = True, device: int = 0, keep_grid: bool = True,
+                 transform_path: int = 0):
         self._lib = _lib.load()
         c = AcqConf()
         c.fs_in = int(fs_in)
@@ -50,6 +51,8 @@ class PcpsAcquisitionBank:
         c.bit_transition_flag = int(bool(bit_transition_flag))
         c.use_cfar = int(bool(use_cfar))
         c.max_prn = int(max_prn)
+        c.no_grid = 0 if keep_grid else 1  # keep_grid=False: max_dwells == 1 and no dump (no accumulate, no read_grid)
+        c.transform_path = int(transform_path)
         self.conf = c
         self.num_doppler_bins = int(num_doppler_bins) if num_doppler_bins else int(math.ceil(2.0 * doppler_max / doppler_step))
         self._h = C.c_void_p()
@@ -97,14 +100,16 @@ class PcpsAcquisitionBank:
         check(self._lib.gsh_acq_read_grid(self._h, prn_slot, fptr(g)))
         return g
 
-    def time_dwells(self, x, n_prn: int, reps: int = 10) -> float:
-        """Average milliseconds per full dwell batch, input resident (x: numpy array or torch cuda tensor)."""
+    def time_dwells(self, x, n_prn: int, reps: int = 10, pipelined: bool = False) -> float:
+        """Average milliseconds per full dwell batch, input resident (x: numpy array or torch cuda tensor).
+        pipelined=True: the batches are issued on two HIP streams (steady-state throughput, not latency)."""
         if hasattr(x, "data_ptr"):
             self.dwell_device(x.data_ptr(), n_prn)
         else:
             self.dwell(x, n_prn)
         ms = C.c_float(0.0)
-        check(self._lib.gsh_acq_time_dwells(self._h, n_prn, reps, C.byref(ms)))
+        fn = self._lib.gsh_acq_time_dwells_pipelined if pipelined else self._lib.gsh_acq_time_dwells
+        check(fn(self._h, n_prn, reps, C.byref(ms)))
         return ms.value
 
     @staticmethod

@@ -25,12 +25,22 @@ struct gsh_acq
     float* d_grid{nullptr};       // max_prn * n_bins * effective
     gsh::RowStat* d_rows{nullptr};
     gsh::DevAcqResult* d_results{nullptr};
+    unsigned* d_arrivals{nullptr};          // on-chip path: per-PRN arrival counters, zero between launches
     gsh::DevAcqResult* h_results{nullptr};  // pinned
     float2* h_stage{nullptr};               // pinned, max(consumed, code length)
     std::vector<char> code_set;
     int chunk_prn{1};
+    bool onchip{false};  // whole-transform-on-chip path (pcps_onchip.hip); spectra then sit in natural order
     bool have_input{false};
     hipEvent_t ev0{nullptr}, ev1{nullptr};
+    // second issue lane for gsh_acq_time_dwells_pipelined (on-chip path): its own stream and per-batch buffers, so that
+    // batch k+1's forward transforms fill the compute units batch k's last cells leave idle
+    hipStream_t stream2{nullptr};
+    float2* d_spectra2{nullptr};
+    gsh::RowStat* d_rows2{nullptr};
+    gsh::DevAcqResult* d_results2{nullptr};
+    unsigned* d_arrivals2{nullptr};
+    hipEvent_t ev2{nullptr};
 };
 
 namespace
@@ -57,6 +67,17 @@ int enqueue_dwell(gsh_acq* a, uint32_t n_prn, int accumulate, uint32_t dwell_cou
     const gsh_acq_conf& c = a->conf;
     const int n = static_cast<int>(c.fft_size);
     const int eff = static_cast<int>(c.effective_fft_size);
+    if (a->onchip)
+        {
+            // acq.cc:657-664 (zero padding) + :531-535 (wipe-off, forward FFT): one work-group per bin
+            int rc = gsh::onchip_forward(n, a->d_in, 0, static_cast<int>(c.consumed_samples), 0, a->d_bins_hz, static_cast<double>(c.fs_in),
+                a->d_spectra, a->n_bins, a->stream);
+            if (rc != GSH_OK) return rc;
+            // acq.cc:538-553 + the per-row part of :409-519: one work-group per (PRN, bin) cell, nothing leaves the CU
+            return gsh::onchip_correlate(n, a->d_spectra, a->d_codes, a->d_grid, a->d_rows, a->d_results, a->d_arrivals, static_cast<int>(n_prn),
+                a->n_bins, eff, accumulate, c.no_grid ? 0 : 1, static_cast<int>(c.samples_per_chip), c.use_cfar, dwell_count ? dwell_count : 1u,
+                a->stream);
+        }
     // acq.cc:657-664 (zero padding) + :531-535 (wipe-off, forward FFT) for every bin
     int rc = gsh::fft_forward(a->plan, a->d_in, 0, static_cast<int>(c.consumed_samples), 0, a->d_bins_hz, static_cast<double>(c.fs_in),
         a->d_tmp, a->d_spectra, a->n_bins, a->stream);
@@ -79,6 +100,13 @@ int check_dwell_args(gsh_acq* a, uint32_t n_prn, const void* results)
     GSH_REQUIRE(n_prn >= 1 && n_prn <= a->conf.max_prn, "n_prn %u outside 1..%u", n_prn, a->conf.max_prn);
     for (uint32_t p = 0; p < n_prn; p++)
         if (!a->code_set[p]) return set_error(GSH_ERR_STATE, "local code of prn slot %u has not been set (set_local_code)", p);
+    return GSH_OK;
+}
+
+int check_accumulate(gsh_acq* a, int accumulate)
+{
+    if (accumulate && a->conf.no_grid)
+        return set_error(GSH_ERR_STATE, "accumulate != 0 needs the stored grid, but the handle was created with no_grid = 1");
     return GSH_OK;
 }
 
@@ -206,6 +234,7 @@ extern "C"
         GSH_REQUIRE(c.num_doppler_bins >= 1 && c.num_doppler_bins <= 4096, "num_doppler_bins %u outside 1..4096", c.num_doppler_bins);
         GSH_REQUIRE(c.max_prn >= 1 && c.max_prn <= 4096, "max_prn %u outside 1..4096", c.max_prn);
         GSH_REQUIRE(2 * c.samples_per_chip < c.effective_fft_size, "samples_per_chip %u too large for %u cells (acq.cc:485-509 would not terminate)", c.samples_per_chip, c.effective_fft_size);
+        GSH_REQUIRE(c.transform_path == 0 || c.transform_path == 1, "transform_path %d outside 0..1", c.transform_path);
         int rc = gsh::use_device(device);
         if (rc != GSH_OK) return rc;
         gsh_acq* a = new (std::nothrow) gsh_acq();
@@ -215,11 +244,16 @@ extern "C"
         a->n_bins = static_cast<int>(c.num_doppler_bins);
         a->h_bins_hz.assign(a->n_bins, 0);
         a->code_set.assign(c.max_prn, 0);
-        rc = gsh::plan_create(static_cast<int>(c.fft_size), &a->plan);
-        if (rc != GSH_OK)
+        // the on-chip kernels assume effective_fft_size == fft_size: bit_transition_flag searches go through the four-step path
+        a->onchip = (c.transform_path == 0) && !c.bit_transition_flag && gsh::onchip_supported(static_cast<int>(c.fft_size));
+        if (!a->onchip)
             {
-                delete a;
-                return rc;
+                rc = gsh::plan_create(static_cast<int>(c.fft_size), &a->plan);
+                if (rc != GSH_OK)
+                    {
+                        delete a;
+                        return rc;
+                    }
             }
         const size_t n = c.fft_size, eff = c.effective_fft_size, D = a->n_bins, P = c.max_prn;
         // scratch for the inverse's intermediate: bound it to 2 GiB and to the 65535-cell launch limit
@@ -239,11 +273,19 @@ extern "C"
         if ((e = hipMalloc(&a->d_in, sizeof(float2) * n)) != hipSuccess) return fail(e, "hipMalloc(in)");
         if ((e = hipMalloc(&a->d_spectra, sizeof(float2) * D * n)) != hipSuccess) return fail(e, "hipMalloc(spectra)");
         if ((e = hipMalloc(&a->d_codes, sizeof(float2) * P * n)) != hipSuccess) return fail(e, "hipMalloc(codes)");
-        if ((e = hipMalloc(&a->d_tmp, sizeof(float2) * std::max(chunk * D, size_t(1)) * n)) != hipSuccess) return fail(e, "hipMalloc(tmp)");
-        if ((e = hipMalloc(&a->d_grid, sizeof(float) * P * D * eff)) != hipSuccess) return fail(e, "hipMalloc(grid)");
-        if ((e = hipMemset(a->d_grid, 0, sizeof(float) * P * D * eff)) != hipSuccess) return fail(e, "hipMemset(grid)");
+        // the four-step path keeps its inter-pass intermediate in HBM; the on-chip path only needs one row to stage a code
+        const size_t tmp_rows = a->onchip ? size_t(1) : std::max(chunk * D, size_t(2));
+        if ((e = hipMalloc(&a->d_tmp, sizeof(float2) * tmp_rows * n)) != hipSuccess) return fail(e, "hipMalloc(tmp)");
+        const bool need_grid = !(a->onchip && c.no_grid);
+        if (need_grid)
+            {
+                if ((e = hipMalloc(&a->d_grid, sizeof(float) * P * D * eff)) != hipSuccess) return fail(e, "hipMalloc(grid)");
+                if ((e = hipMemset(a->d_grid, 0, sizeof(float) * P * D * eff)) != hipSuccess) return fail(e, "hipMemset(grid)");
+            }
         if ((e = hipMalloc(&a->d_rows, sizeof(gsh::RowStat) * P * D)) != hipSuccess) return fail(e, "hipMalloc(rows)");
         if ((e = hipMalloc(&a->d_results, sizeof(gsh::DevAcqResult) * P)) != hipSuccess) return fail(e, "hipMalloc(results)");
+        if ((e = hipMalloc(&a->d_arrivals, sizeof(unsigned) * P)) != hipSuccess) return fail(e, "hipMalloc(arrivals)");
+        if ((e = hipMemset(a->d_arrivals, 0, sizeof(unsigned) * P)) != hipSuccess) return fail(e, "hipMemset(arrivals)");
         if ((e = hipHostMalloc(reinterpret_cast<void**>(&a->h_results), sizeof(gsh::DevAcqResult) * P, hipHostMallocDefault)) != hipSuccess) return fail(e, "hipHostMalloc");
         if ((e = hipHostMalloc(reinterpret_cast<void**>(&a->h_stage), sizeof(float2) * n, hipHostMallocDefault)) != hipSuccess) return fail(e, "hipHostMalloc");
         if ((e = hipEventCreate(&a->ev0)) != hipSuccess) return fail(e, "hipEventCreate");
@@ -273,10 +315,18 @@ extern "C"
         if (a->d_grid) (void)hipFree(a->d_grid);
         if (a->d_rows) (void)hipFree(a->d_rows);
         if (a->d_results) (void)hipFree(a->d_results);
+        if (a->d_arrivals) (void)hipFree(a->d_arrivals);
         if (a->h_results) (void)hipHostFree(a->h_results);
         if (a->h_stage) (void)hipHostFree(a->h_stage);
         if (a->ev0) (void)hipEventDestroy(a->ev0);
         if (a->ev1) (void)hipEventDestroy(a->ev1);
+        if (a->stream2) (void)hipStreamSynchronize(a->stream2);
+        if (a->d_spectra2) (void)hipFree(a->d_spectra2);
+        if (a->d_rows2) (void)hipFree(a->d_rows2);
+        if (a->d_results2) (void)hipFree(a->d_results2);
+        if (a->d_arrivals2) (void)hipFree(a->d_arrivals2);
+        if (a->ev2) (void)hipEventDestroy(a->ev2);
+        if (a->stream2) (void)hipStreamDestroy(a->stream2);
         if (a->stream) (void)hipStreamDestroy(a->stream);
         delete a;
     }
@@ -305,6 +355,16 @@ extern "C"
                 place_off = static_cast<int>(c.fft_size - c.consumed_samples);
             }
         std::memcpy(a->h_stage, code_iq, sizeof(float2) * static_cast<size_t>(n_in));
+        if (a->onchip)
+            {
+                GSH_HIP(hipMemcpyAsync(a->d_tmp, a->h_stage, sizeof(float2) * static_cast<size_t>(n_in), hipMemcpyHostToDevice, a->stream));
+                int rc1 = gsh::onchip_forward(static_cast<int>(c.fft_size), a->d_tmp, 0, n_in, place_off, nullptr, 1.0,
+                    a->d_codes + static_cast<size_t>(prn_slot) * c.fft_size, 1, a->stream);
+                if (rc1 != GSH_OK) return rc1;
+                GSH_HIP(hipStreamSynchronize(a->stream));
+                a->code_set[prn_slot] = 1;
+                return GSH_OK;
+            }
         // stage the time-domain replica in d_tmp's tail-free area: d_in is reserved for the signal, so use d_spectra[0] row
         // as scratch input is unsafe while a dwell is queued; everything here is on one stream, so order is preserved.
         float2* d_code_time = a->d_tmp + static_cast<size_t>(c.fft_size);  // second row of tmp (tmp holds >= n_bins rows)
@@ -339,6 +399,7 @@ extern "C"
     int gsh_acq_dwell_device(gsh_acq_t* a, const void* device_in_iq, uint32_t n_prn, int accumulate, uint32_t dwell_count, gsh_acq_result* results)
     {
         int rc = check_dwell_args(a, n_prn, results);
+        if (rc == GSH_OK) rc = check_accumulate(a, accumulate);
         if (rc != GSH_OK) return rc;
         GSH_REQUIRE(device_in_iq != nullptr, "null input");
         GSH_HIP(hipSetDevice(a->device));
@@ -352,6 +413,7 @@ extern "C"
     int gsh_acq_dwell(gsh_acq_t* a, const float* in_iq, uint32_t n_prn, int accumulate, uint32_t dwell_count, gsh_acq_result* results)
     {
         int rc = check_dwell_args(a, n_prn, results);
+        if (rc == GSH_OK) rc = check_accumulate(a, accumulate);
         if (rc != GSH_OK) return rc;
         GSH_REQUIRE(in_iq != nullptr, "null input");
         GSH_HIP(hipSetDevice(a->device));
@@ -367,6 +429,7 @@ extern "C"
     {
         GSH_REQUIRE(a != nullptr && grid != nullptr, "null argument");
         GSH_REQUIRE(prn_slot < a->conf.max_prn, "prn_slot %u outside 0..%u", prn_slot, a->conf.max_prn - 1);
+        if (a->d_grid == nullptr) return set_error(GSH_ERR_STATE, "the handle was created with no_grid = 1: no grid is stored");
         GSH_HIP(hipSetDevice(a->device));
         const size_t row = static_cast<size_t>(a->n_bins) * a->conf.effective_fft_size;
         GSH_HIP(hipMemcpyAsync(grid, a->d_grid + prn_slot * row, sizeof(float) * row, hipMemcpyDeviceToHost, a->stream));
@@ -389,6 +452,59 @@ extern "C"
                 rc = enqueue_dwell(a, n_prn, 0, 1);
                 if (rc != GSH_OK) return rc;
             }
+        GSH_HIP(hipEventRecord(a->ev1, a->stream));
+        GSH_HIP(hipEventSynchronize(a->ev1));
+        float ms = 0.0f;
+        GSH_HIP(hipEventElapsedTime(&ms, a->ev0, a->ev1));
+        *avg_ms = ms / static_cast<float>(reps);
+        return GSH_OK;
+    }
+
+    int gsh_acq_time_dwells_pipelined(gsh_acq_t* a, uint32_t n_prn, int reps, float* avg_ms)
+    {
+        GSH_REQUIRE(a != nullptr && avg_ms != nullptr, "null argument");
+        GSH_REQUIRE(reps >= 2, "reps %d (need >= 2)", reps);
+        GSH_REQUIRE(n_prn >= 1 && n_prn <= a->conf.max_prn, "n_prn %u outside 1..%u", n_prn, a->conf.max_prn);
+        if (!a->have_input) return set_error(GSH_ERR_STATE, "no input block resident: call gsh_acq_dwell[_device] once first");
+        if (!a->onchip) return gsh_acq_time_dwells(a, n_prn, reps, avg_ms);  // the four-step path shares one scratch buffer
+        GSH_HIP(hipSetDevice(a->device));
+        const gsh_acq_conf& c = a->conf;
+        const size_t n = c.fft_size, D = static_cast<size_t>(a->n_bins), P = c.max_prn;
+        if (a->stream2 == nullptr)
+            {
+                GSH_HIP(hipStreamCreateWithFlags(&a->stream2, hipStreamNonBlocking));
+                GSH_HIP(hipMalloc(&a->d_spectra2, sizeof(float2) * D * n));
+                GSH_HIP(hipMalloc(&a->d_rows2, sizeof(gsh::RowStat) * P * D));
+                GSH_HIP(hipMalloc(&a->d_results2, sizeof(gsh::DevAcqResult) * P));
+                GSH_HIP(hipMalloc(&a->d_arrivals2, sizeof(unsigned) * P));
+                GSH_HIP(hipMemset(a->d_arrivals2, 0, sizeof(unsigned) * P));
+                GSH_HIP(hipEventCreate(&a->ev2));
+            }
+        auto enqueue = [&](int lane) -> int {
+            hipStream_t st = lane ? a->stream2 : a->stream;
+            float2* spectra = lane ? a->d_spectra2 : a->d_spectra;
+            int rc = gsh::onchip_forward(static_cast<int>(n), a->d_in, 0, static_cast<int>(c.consumed_samples), 0, a->d_bins_hz,
+                static_cast<double>(c.fs_in), spectra, a->n_bins, st);
+            if (rc != GSH_OK) return rc;
+            // no_grid handles only: two batches in flight must not share the magnitude grid
+            return gsh::onchip_correlate(static_cast<int>(n), spectra, a->d_codes, a->d_grid, lane ? a->d_rows2 : a->d_rows,
+                lane ? a->d_results2 : a->d_results, lane ? a->d_arrivals2 : a->d_arrivals, static_cast<int>(n_prn), a->n_bins,
+                static_cast<int>(c.effective_fft_size), 0, 0, static_cast<int>(c.samples_per_chip), c.use_cfar, 1u, st);
+        };
+        int rc = enqueue(0);  // warm-up on both lanes
+        if (rc == GSH_OK) rc = enqueue(1);
+        if (rc != GSH_OK) return rc;
+        GSH_HIP(hipStreamSynchronize(a->stream));
+        GSH_HIP(hipStreamSynchronize(a->stream2));
+        GSH_HIP(hipEventRecord(a->ev0, a->stream));
+        GSH_HIP(hipStreamWaitEvent(a->stream2, a->ev0, 0));
+        for (int i = 0; i < reps; i++)
+            {
+                rc = enqueue(i & 1);
+                if (rc != GSH_OK) return rc;
+            }
+        GSH_HIP(hipEventRecord(a->ev2, a->stream2));
+        GSH_HIP(hipStreamWaitEvent(a->stream, a->ev2, 0));
         GSH_HIP(hipEventRecord(a->ev1, a->stream));
         GSH_HIP(hipEventSynchronize(a->ev1));
         float ms = 0.0f;

@@ -1,0 +1,397 @@
+// Whole-transform-on-one-CU FFT building blocks for MI355X (gfx950): the length-N transform of one acquisition
+// cell (pcps_acquisition.cc:538-541, the IFFT of X_bin * conj(FFT(code))) never leaves the compute unit.
+//
+//   N = R1 * R2 * R3 (25 000 = 25 * 25 * 40).  Every thread keeps R elements of the current stage in REGISTERS,
+//   runs one radix-R DFT on them (composite radices built at compile time from radix 2/3/4/5/8 butterflies with
+//   literal twiddles), multiplies by the inter-stage twiddles (one sincospi seed + a power tree per thread),
+//   and the two re-distributions between the three stages go through LDS one float component at a time
+//   (N * 4 bytes <= 160 KiB although N * 8 is not).  Complex values are clang ext-vectors so the arithmetic maps
+//   to gfx950's packed FP32 instructions (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32).
+//
+// Index maps (decimation in frequency, natural order in AND out):
+//   n = n1*(R2*R3) + n2*R3 + n3          k = k1 + R1*k2 + R1*R2*k3
+//   stage 1: thread t1 = n2*R3 + n3  holds n1 = 0..R1-1 -> DFT_R1 -> * W_N^{k1*t1}
+//   stage 2: thread t2 = k1*R3 + n3  holds n2 = 0..R2-1 -> DFT_R2 -> * W_{R2*R3}^{k2*n3}
+//   stage 3: thread t3 = k1 + R1*k2  holds n3 = 0..R3-1 -> DFT_R3 -> X[t3 + R1*R2*k3]
+// so both the first load and the last store are unit-stride across lanes.
+//
+// The per-thread phase functions are __host__ __device__: tests/host/fft_onchip_host.cc runs the very same code
+// thread by thread on the CPU (no GPU needed) against numpy.fft.  Nothing here derives from FFTW, GNU Radio or
+// VOLK (the libraries behind the reference's transform).
+#ifndef GSH_FFT_ONCHIP_H
+#define GSH_FFT_ONCHIP_H
+
+#include <type_traits>
+#include <utility>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define GSH_HD __host__ __device__ __forceinline__
+#else
+#define GSH_HD inline __attribute__((always_inline))
+#endif
+#define GSH_AI __attribute__((always_inline))
+
+#pragma clang fp contract(fast)
+
+namespace gsh
+{
+namespace oc
+{
+typedef float cf __attribute__((ext_vector_type(2)));  // complex: .x = re, .y = im
+
+// ------------------------------------------------------------------------------------------ compile-time loops
+template <int... Is, class F>
+GSH_HD void static_for_impl(std::integer_sequence<int, Is...>, F&& f)
+{
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+GSH_HD void static_for(F&& f)
+{
+    static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
+
+// ------------------------------------------------------------------------------------------ compile-time trig
+constexpr double PI_D = 3.141592653589793238462643383279502884;
+
+constexpr double cx_sin_small(double x)  // |x| <= pi/4
+{
+    const double x2 = x * x;
+    double term = x, sum = x;
+    for (int i = 1; i < 14; i++)
+        {
+            term *= -x2 / static_cast<double>((2 * i) * (2 * i + 1));
+            sum += term;
+        }
+    return sum;
+}
+constexpr double cx_cos_small(double x)  // |x| <= pi/4
+{
+    const double x2 = x * x;
+    double term = 1.0, sum = 1.0;
+    for (int i = 1; i < 14; i++)
+        {
+            term *= -x2 / static_cast<double>((2 * i - 1) * (2 * i));
+            sum += term;
+        }
+    return sum;
+}
+// cos / sin of 2*pi*m/r with the octant picked in integer arithmetic (exact 0, +-1 and equal +-sqrt(1/2) pairs)
+constexpr double cx_trig_turn(int m, int r, bool want_sin)
+{
+    m %= r;
+    if (m < 0) m += r;
+    const long long num = 8LL * m;
+    const int oct = static_cast<int>(num / r);
+    const long long rem = num - static_cast<long long>(oct) * r;
+    const double th = (PI_D / 4.0) * static_cast<double>(rem) / static_cast<double>(r);          // [0, pi/4)
+    const double tc = (PI_D / 4.0) * static_cast<double>(r - rem) / static_cast<double>(r);      // pi/4 - th
+    double c = 0.0, s = 0.0;
+    switch (oct)
+        {
+        case 0: c = cx_cos_small(th); s = cx_sin_small(th); break;
+        case 1: c = cx_sin_small(tc); s = cx_cos_small(tc); break;
+        case 2: c = -cx_sin_small(th); s = cx_cos_small(th); break;
+        case 3: c = -cx_cos_small(tc); s = cx_sin_small(tc); break;
+        case 4: c = -cx_cos_small(th); s = -cx_sin_small(th); break;
+        case 5: c = -cx_sin_small(tc); s = -cx_cos_small(tc); break;
+        case 6: c = cx_sin_small(th); s = -cx_cos_small(th); break;
+        default: c = cx_cos_small(tc); s = -cx_sin_small(tc); break;
+        }
+    return want_sin ? s : c;
+}
+
+// ------------------------------------------------------------------------------------------ complex helpers
+GSH_HD cf cmul(cf a, cf b) { return a.xx * b + a.yy * cf{-b.y, b.x}; }
+GSH_HD cf csqr(cf a) { return cf{a.x * a.x - a.y * a.y, 2.0f * a.x * a.y}; }
+GSH_HD cf mulmj(cf a) { return cf{a.y, -a.x}; }  // * (-j)
+GSH_HD cf mulpj(cf a) { return cf{-a.y, a.x}; }  // * (+j)
+// conj(a) * b
+GSH_HD cf cmul_conj(cf a, cf b) { return a.xx * b + a.yy * cf{b.y, -b.x}; }
+
+// v * W_R^M, W_R = exp(-2 pi i / R), with the trivial rotations specialised
+template <int M, int R>
+GSH_HD cf mul_w(cf v)
+{
+    constexpr int m = ((M % R) + R) % R;
+    constexpr float H = 0.70710678118654752440f;
+    if constexpr (m == 0)
+        return v;
+    else if constexpr (4 * m == R)
+        return mulmj(v);
+    else if constexpr (2 * m == R)
+        return -v;
+    else if constexpr (4 * m == 3 * R)
+        return mulpj(v);
+    else if constexpr (8 * m == R)
+        return cf{v.x + v.y, v.y - v.x} * H;
+    else if constexpr (8 * m == 3 * R)
+        return cf{v.y - v.x, -(v.x + v.y)} * H;
+    else if constexpr (8 * m == 5 * R)
+        return cf{-(v.x + v.y), v.x - v.y} * H;
+    else if constexpr (8 * m == 7 * R)
+        return cf{v.x - v.y, v.x + v.y} * H;
+    else
+        {
+            constexpr float c = static_cast<float>(cx_trig_turn(m, R, false));
+            constexpr float s = static_cast<float>(cx_trig_turn(m, R, true));
+            // (x + jy)(c - js) = (xc + ys) + j(yc - xs)
+            return v * c + cf{v.y, -v.x} * s;
+        }
+}
+
+// ------------------------------------------------------------------------------------------ register DFTs
+// Dft<R>::run(a): a[k] <- sum_j a[j] exp(-2 pi i j k / R), natural order in and out, everything in registers.
+template <int R>
+struct Dft;
+
+template <>
+struct Dft<1>
+{
+    static GSH_HD void run(cf (&)[1]) {}
+};
+
+template <>
+struct Dft<2>
+{
+    static GSH_HD void run(cf (&a)[2])
+    {
+        const cf t = a[0];
+        a[0] = t + a[1];
+        a[1] = t - a[1];
+    }
+};
+
+template <>
+struct Dft<3>
+{
+    static GSH_HD void run(cf (&a)[3])
+    {
+        constexpr float S = 0.86602540378443864676f;  // sin(2 pi / 3)
+        const cf t = a[1] + a[2];
+        const cf d = (a[1] - a[2]) * S;
+        const cf u = a[0] - t * 0.5f;
+        const cf v = mulmj(d);
+        a[0] = a[0] + t;
+        a[1] = u + v;
+        a[2] = u - v;
+    }
+};
+
+template <>
+struct Dft<4>
+{
+    static GSH_HD void run(cf (&a)[4])
+    {
+        const cf s02 = a[0] + a[2], d02 = a[0] - a[2];
+        const cf s13 = a[1] + a[3], d13 = mulmj(a[1] - a[3]);
+        a[0] = s02 + s13;
+        a[2] = s02 - s13;
+        a[1] = d02 + d13;
+        a[3] = d02 - d13;
+    }
+};
+
+template <>
+struct Dft<5>
+{
+    static GSH_HD void run(cf (&a)[5])
+    {
+        constexpr float C1 = 0.30901699437494742410f;   // cos(2 pi / 5)
+        constexpr float C2 = -0.80901699437494742410f;  // cos(4 pi / 5)
+        constexpr float S1 = 0.95105651629515357212f;   // sin(2 pi / 5)
+        constexpr float S2 = 0.58778525229247312917f;   // sin(4 pi / 5)
+        const cf t1 = a[1] + a[4], t2 = a[2] + a[3];
+        const cf t3 = a[1] - a[4], t4 = a[2] - a[3];
+        const cf m1 = a[0] + t1 * C1 + t2 * C2;
+        const cf m2 = a[0] + t1 * C2 + t2 * C1;
+        const cf n1 = mulmj(t3 * S1 + t4 * S2);
+        const cf n2 = mulmj(t3 * S2 - t4 * S1);
+        a[0] = a[0] + t1 + t2;
+        a[1] = m1 + n1;
+        a[4] = m1 - n1;
+        a[2] = m2 + n2;
+        a[3] = m2 - n2;
+    }
+};
+
+template <>
+struct Dft<8>
+{
+    static GSH_HD void run(cf (&a)[8])
+    {
+        cf e[4] = {a[0], a[2], a[4], a[6]};
+        cf o[4] = {a[1], a[3], a[5], a[7]};
+        Dft<4>::run(e);
+        Dft<4>::run(o);
+        const cf o1 = mul_w<1, 8>(o[1]);
+        const cf o2 = mulmj(o[2]);
+        const cf o3 = mul_w<3, 8>(o[3]);
+        a[0] = e[0] + o[0];
+        a[4] = e[0] - o[0];
+        a[1] = e[1] + o1;
+        a[5] = e[1] - o1;
+        a[2] = e[2] + o2;
+        a[6] = e[2] - o2;
+        a[3] = e[3] + o3;
+        a[7] = e[3] - o3;
+    }
+};
+
+// first factor of a composite radix: the largest hand-written butterfly that divides it
+constexpr int first_factor(int r)
+{
+    for (int f : {8, 5, 4, 3, 2})
+        if (r % f == 0 && r / f >= 1) return f;
+    return r;
+}
+
+// R = Ra * Rb:  j = j1*Rb + j2,  k = k1 + Ra*k2,  W_R^{jk} = W_Ra^{j1 k1} * W_R^{j2 k1} * W_Rb^{j2 k2}
+template <int Ra, int Rb>
+struct DftComposite
+{
+    static constexpr int R = Ra * Rb;
+    static GSH_HD void run(cf (&a)[R])
+    {
+        cf t[R];
+        static_for<Rb>([&](auto J2) GSH_AI {
+            constexpr int j2 = decltype(J2)::value;
+            cf v[Ra];
+            static_for<Ra>([&](auto J1) GSH_AI { v[decltype(J1)::value] = a[decltype(J1)::value * Rb + j2]; });
+            Dft<Ra>::run(v);
+            static_for<Ra>([&](auto K1) GSH_AI {
+                constexpr int k1 = decltype(K1)::value;
+                t[k1 * Rb + j2] = mul_w<j2 * k1, R>(v[k1]);
+            });
+        });
+        static_for<Ra>([&](auto K1) GSH_AI {
+            constexpr int k1 = decltype(K1)::value;
+            cf v[Rb];
+            static_for<Rb>([&](auto J2) GSH_AI { v[decltype(J2)::value] = t[k1 * Rb + decltype(J2)::value]; });
+            Dft<Rb>::run(v);
+            static_for<Rb>([&](auto K2) GSH_AI { a[k1 + Ra * decltype(K2)::value] = v[decltype(K2)::value]; });
+        });
+    }
+};
+
+template <int R>
+struct Dft : DftComposite<first_factor(R), R / first_factor(R)>
+{
+    static_assert(first_factor(R) != R || R == 1, "radix has a prime factor without a butterfly");
+};
+
+// a[k] *= w^k, powers by a squaring tree (rounding-error depth log2 R, not R)
+template <int R>
+GSH_HD void mul_powers(cf (&a)[R], cf w)
+{
+    cf p[R];
+    static_for<R>([&](auto K) GSH_AI {
+        constexpr int k = decltype(K)::value;
+        if constexpr (k == 1) p[1] = w;
+        if constexpr (k >= 2)
+            {
+                if constexpr (k % 2 == 0)
+                    p[k] = csqr(p[k / 2]);
+                else
+                    p[k] = cmul(p[k - 1], w);
+            }
+        if constexpr (k >= 1) a[k] = cmul(a[k], p[k]);
+    });
+}
+
+// exp(-2 pi i * num / den), 0 <= num < den, den < 2^23
+GSH_HD cf unit_root(int num, int den)
+{
+    const float x = 2.0f * static_cast<float>(num) / static_cast<float>(den);
+    float s, c;
+#if defined(__HIP_DEVICE_COMPILE__)
+    sincospif(x, &s, &c);
+#else
+    s = static_cast<float>(__builtin_sin(PI_D * static_cast<double>(x)));
+    c = static_cast<float>(__builtin_cos(PI_D * static_cast<double>(x)));
+#endif
+    return cf{c, -s};
+}
+
+// ------------------------------------------------------------------------------------------ the three-stage plan
+constexpr int round_up_congruent(int at_least, int minus, int mod)
+{
+    // smallest s >= at_least with (s - minus) % mod == 0
+    int s = at_least;
+    while (((s - minus) % mod + mod) % mod != 0) s++;
+    return s;
+}
+
+template <int R1_, int R2_, int R3_>
+struct Plan
+{
+    static constexpr int R1 = R1_, R2 = R2_, R3 = R3_;
+    static constexpr int N = R1 * R2 * R3;
+    static constexpr int T1 = R2 * R3;  // threads that own a stage-1 butterfly
+    static constexpr int T2 = R1 * R3;
+    static constexpr int T3 = R1 * R2;
+    static constexpr int TMAX = T1 > T2 ? (T1 > T3 ? T1 : T3) : (T2 > T3 ? T2 : T3);
+    static constexpr int THREADS = (TMAX + 63) / 64 * 64;
+    // exchange 1 (stage 1 -> 2): float address k1*S1 + n2*R3 + n3.
+    //   writer lanes t1 -> consecutive addresses; reader lanes t2 = k1*R3 + n3 -> t2 + k1*(S1 - R3) + const:
+    //   conflict-free for ds_read_b32 (32 banks) when S1 - R3 is a multiple of 32.
+    static constexpr int S1 = round_up_congruent(T1, R3, 32);
+    // exchange 2 (stage 2 -> 3): float address k2*S2 + n3*P2 + k1, P2 odd so that the writer lanes (n3 fastest)
+    //   spread over the banks; reader lanes t3 = k1 + R1*k2 -> t3 + k2*(S2 - R1) + const: conflict-free when
+    //   S2 - R1 is a multiple of 32.
+    static constexpr int P2 = R1 | 1;
+    static constexpr int S2 = round_up_congruent(R3 * P2, R1, 32);
+    static constexpr int LDS_FLOATS = (R1 * S1 > R2 * S2) ? R1 * S1 : R2 * S2;
+
+    // ---- stage 1: a[n1] = x[n1*T1 + t1]
+    static GSH_HD void stage1(cf (&a)[R1], int t1)
+    {
+        Dft<R1>::run(a);
+        mul_powers<R1>(a, unit_root(t1, N));
+    }
+    template <int COMP>
+    static GSH_HD void ex1_write(const cf (&a)[R1], int t1, float* lds)
+    {
+        static_for<R1>([&](auto K1) GSH_AI { lds[decltype(K1)::value * S1 + t1] = a[decltype(K1)::value][COMP]; });
+    }
+    template <int COMP>
+    static GSH_HD void ex1_read(cf (&b)[R2], int t2, const float* lds)
+    {
+        const int k1 = t2 / R3, n3 = t2 - k1 * R3;
+        const float* p = lds + k1 * S1 + n3;
+        static_for<R2>([&](auto N2) GSH_AI { b[decltype(N2)::value][COMP] = p[decltype(N2)::value * R3]; });
+    }
+    // ---- stage 2
+    static GSH_HD void stage2(cf (&b)[R2], int t2)
+    {
+        const int n3 = t2 % R3;
+        Dft<R2>::run(b);
+        mul_powers<R2>(b, unit_root(n3, R2 * R3));
+    }
+    template <int COMP>
+    static GSH_HD void ex2_write(const cf (&b)[R2], int t2, float* lds)
+    {
+        const int k1 = t2 / R3, n3 = t2 - k1 * R3;
+        float* p = lds + n3 * P2 + k1;
+        static_for<R2>([&](auto K2) GSH_AI { p[decltype(K2)::value * S2] = b[decltype(K2)::value][COMP]; });
+    }
+    template <int COMP>
+    static GSH_HD void ex2_read(cf (&c)[R3], int t3, const float* lds)
+    {
+        const int k2 = t3 / R1, k1 = t3 - k2 * R1;
+        const float* p = lds + k2 * S2 + k1;
+        static_for<R3>([&](auto N3) GSH_AI { c[decltype(N3)::value][COMP] = p[decltype(N3)::value * P2]; });
+    }
+    // ---- stage 3: c[k3] -> X[t3 + T3*k3]
+    static GSH_HD void stage3(cf (&c)[R3]) { Dft<R3>::run(c); }
+};
+}  // namespace oc
+}  // namespace gsh
+
+// transform lengths with an on-chip plan: X(R1, R2, R3), N = R1*R2*R3 (N*4 bytes of LDS, <= 1024 threads)
+#define GSH_OC_PLANS(X) \
+    X(25, 25, 40) /* 25 000: 25 Msps x 1 ms */ \
+    X(10, 20, 20) /*  4 000:  4 Msps x 1 ms */
+
+#endif

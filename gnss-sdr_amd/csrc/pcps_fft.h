@@ -42,7 +42,7 @@ struct RowStat
     float maxv;
     unsigned idx;
     float sum;
-    float pad;
+    float second;  // on-chip path: second peak of the row with +-samples_per_chip around its peak blanked
 };
 
 struct DevAcqResult
@@ -74,5 +74,17 @@ int correlate_grid(const FftPlan& p, const float2* spectra, const float2* codes,
 // per-row (max, lowest arg-max, sum) then the two statistics of acq.cc:409-519 per PRN
 int grid_statistics(const float* grid, RowStat* rows, DevAcqResult* results, int n_prn, int n_bins, int effective,
     int samples_per_chip, int use_cfar, unsigned dwell_count, hipStream_t s);
+
+// ---- whole-transform-on-chip path (pcps_onchip.hip): lengths with a plan in fft_onchip.h -------------------
+// Spectra are in NATURAL order here (the four-step path above uses its permuted [k1][k2] layout).
+bool onchip_supported(int n);
+int onchip_forward(int n, const float2* src, size_t src_stride, int n_in, int place_off, const int* wipe_hz, double fs, float2* dst,
+    int batch, hipStream_t s);
+// one work-group per (PRN, bin) cell: spectrum product, inverse transform, |.|^2, row statistics, and (by the last cell
+// of each PRN, counted in `arrivals`, n_prn zero-initialised counters) the PRN's statistic into `results`; the grid is
+// read only when `accumulate` and written only when `store_grid`
+int onchip_correlate(int n, const float2* spectra, const float2* codes, float* grid, RowStat* rows, DevAcqResult* results,
+    unsigned* arrivals, int n_prn, int n_bins, int effective, int accumulate, int store_grid, int samples_per_chip, int use_cfar,
+    unsigned dwell_count, hipStream_t s);
 }  // namespace gsh
 #endif

@@ -475,7 +475,7 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict_
             r.maxv = best;
             r.idx = at;
             r.sum = sum;
-            r.pad = 0.0f;
+            r.second = 0.0f;
             rows[blockIdx.x] = r;
         }
 }

@@ -1,0 +1,441 @@
+// PCPS acquisition, whole-transform-on-chip path (MI355X / gfx950).
+//
+// For transform lengths that have a plan in fft_onchip.h (N * 4 bytes of LDS, three register-resident stages) one
+// work-group per compute unit carries out a complete length-N transform without touching HBM in between:
+//
+//   oc_forward_kernel   x (zero padded, acq.cc:230-247 / :657-664) * Doppler wipe-off (acq.cc:275-281, :531)
+//                       -> FFT -> spectrum in NATURAL order               one work-group per Doppler bin (or code)
+//   oc_cell_kernel      conj(X_bin[k]) * FFT(code_prn)[k] on load (acq.cc:538) -> FFT (= the reference's IFFT up to a
+//                       conjugation that |.|^2 does not see, :541) -> |.|^2 (+ non-coherent accumulation, :545-553)
+//                       -> per-row maximum, lowest arg-max, sum and second peak, all on chip (acq.cc:417-431, :485-513)
+//                       one work-group per (PRN, bin) cell; the magnitude grid is written only when asked for
+//                       the last cell of a PRN to finish also runs the bin scan + statistic of acq.cc:409-519 (agent-scope
+//                       release / acquire hand-off through an arrival counter), so a dwell batch is two launches
+//
+// HBM traffic per cell is two N*8-byte reads that hit L2 / Infinity Cache (a bin's spectrum is shared by every PRN,
+// a code spectrum by every bin; the cell -> XCD mapping keeps both inside one XCD's L2) and one 16-byte record.
+#include "pcps_fft.h"
+#include "fft_onchip.h"
+#include <cmath>
+
+namespace gsh
+{
+namespace
+{
+using oc::cf;
+
+constexpr int OC_MAX_WAVES = 16;
+
+struct OcFwdArgs
+{
+    const cf* src;
+    size_t src_stride;
+    int n_in;
+    int place_off;
+    const int* wipe_hz;
+    double inv_fs;
+    cf* dst;
+};
+
+struct OcCellArgs
+{
+    const cf* spectra;  // n_bins * N, natural order
+    const cf* codes;    // n_prn * N, natural order, UNconjugated forward FFT of the placed code
+    float* grid;        // n_prn * n_bins * effective (touched only when store_grid / accumulate)
+    RowStat* rows;      // n_prn * n_bins
+    DevAcqResult* results;   // n_prn
+    unsigned* arrivals;      // n_prn arrival counters (zero between launches): the last cell of a PRN forms its statistic
+    int n_prn, n_bins;
+    int xp, prn_per, bin_per;  // XCD tiling: xp * (8 / xp) XCDs, each owns prn_per PRNs x bin_per bins
+    int effective, accumulate, store_grid;  // effective == N on this path
+    int samples_per_chip, want_second;
+    int use_cfar;
+    unsigned dwell_count;
+};
+
+// exp(-j 2 pi f n / fs) with the product reduced in double before the float sincos
+__device__ __forceinline__ cf wipe_phasor(int f_hz, int n, double inv_fs)
+{
+    double rev = static_cast<double>(f_hz) * static_cast<double>(n) * inv_fs;
+    rev -= rint(rev);
+    float s, c;
+    sincospif(static_cast<float>(2.0 * rev), &s, &c);
+    return cf{c, -s};
+}
+
+// ---- the two LDS re-distributions, one float component at a time (N * 8 bytes do not fit, N * 4 do)
+template <class P>
+__device__ __forceinline__ void exchange1(const cf (&ra)[P::R1], cf (&rb)[P::R2], int t, float* lds)
+{
+    if (t < P::T1) P::template ex1_write<0>(ra, t, lds);
+    __syncthreads();
+    if (t < P::T2) P::template ex1_read<0>(rb, t, lds);
+    __syncthreads();
+    if (t < P::T1) P::template ex1_write<1>(ra, t, lds);
+    __syncthreads();
+    if (t < P::T2) P::template ex1_read<1>(rb, t, lds);
+}
+
+template <class P>
+__device__ __forceinline__ void exchange2(const cf (&rb)[P::R2], cf (&rc)[P::R3], int t, float* lds)
+{
+    __syncthreads();  // every exchange-1 read has been issued and consumed
+    if (t < P::T2) P::template ex2_write<0>(rb, t, lds);
+    __syncthreads();
+    if (t < P::T3) P::template ex2_read<0>(rc, t, lds);
+    __syncthreads();
+    if (t < P::T2) P::template ex2_write<1>(rb, t, lds);
+    __syncthreads();
+    if (t < P::T3) P::template ex2_read<1>(rc, t, lds);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+template <class P>
+__global__ __launch_bounds__(P::THREADS) void oc_forward_kernel(OcFwdArgs a)
+{
+    __shared__ __align__(16) float lds[P::LDS_FLOATS];
+    const int t = threadIdx.x;
+    const int b = blockIdx.x;
+    cf ra[P::R1], rb[P::R2], rc[P::R3];
+    if (t < P::T1)
+        {
+            const cf* __restrict__ src = a.src + static_cast<size_t>(b) * a.src_stride;
+            oc::static_for<P::R1>([&](auto N1) GSH_AI {
+                constexpr int n1 = decltype(N1)::value;
+                const int k = n1 * P::T1 + t - a.place_off;
+                ra[n1] = (k >= 0 && k < a.n_in) ? src[k] : cf{0.0f, 0.0f};
+            });
+            if (a.wipe_hz != nullptr)
+                {
+                    // w[n] = w[t] * (w[T1])^n1, both seeds exact, powers by the squaring tree
+                    const int f = a.wipe_hz[b];
+                    const cf w0 = wipe_phasor(f, t, a.inv_fs);
+                    oc::mul_powers<P::R1>(ra, wipe_phasor(f, P::T1, a.inv_fs));
+                    oc::static_for<P::R1>([&](auto N1) GSH_AI { ra[decltype(N1)::value] = oc::cmul(ra[decltype(N1)::value], w0); });
+                }
+            P::stage1(ra, t);
+        }
+    exchange1<P>(ra, rb, t, lds);
+    if (t < P::T2) P::stage2(rb, t);
+    exchange2<P>(rb, rc, t, lds);
+    if (t < P::T3)
+        {
+            P::stage3(rc);
+            cf* __restrict__ dst = a.dst + static_cast<size_t>(b) * P::N + t;
+            oc::static_for<P::R3>([&](auto K3) GSH_AI { dst[decltype(K3)::value * P::T3] = rc[decltype(K3)::value]; });
+        }
+}
+
+// lowest index wins ties (K/volk_gnsssdr_32f_index_max_32u.h:457: strict '>' scanning upwards)
+__device__ __forceinline__ void argmax_merge(float& v, unsigned& i, float ov, unsigned oi)
+{
+    if (ov > v || (ov == v && oi < i))
+        {
+            v = ov;
+            i = oi;
+        }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// GRID: the magnitude grid is read (accumulate) and / or written (store_grid); SECOND: the peak-ratio statistic's
+// second peak is wanted.  Both are compile-time so that the headline configuration (CFAR statistic, single dwell,
+// no dump) carries neither the grid addressing nor the second scan in its register budget.
+template <class P, bool GRID, bool SECOND>
+__global__ __launch_bounds__(P::THREADS) void oc_cell_kernel(OcCellArgs a)
+{
+    __shared__ __align__(16) float lds[P::LDS_FLOATS];
+    __shared__ float s_v[OC_MAX_WAVES];
+    __shared__ unsigned s_i[OC_MAX_WAVES];
+    __shared__ float s_s[OC_MAX_WAVES];
+    __shared__ float s_peak;
+    __shared__ unsigned s_tau;
+
+    // ---- which cell: block b runs on XCD b % 8; each XCD owns a (PRN range) x (bin range) tile and walks it
+    // PRN-fastest, so the cells in flight on one XCD share a few code spectra and a few bin spectra in its L2
+    const int xcd = static_cast<int>(blockIdx.x & 7u), slot = static_cast<int>(blockIdx.x >> 3);
+    const int xp_i = xcd % a.xp, xb_i = xcd / a.xp;
+    const int bl = slot / a.prn_per, pl = slot - bl * a.prn_per;
+    const int prn = xp_i * a.prn_per + pl, bin = xb_i * a.bin_per + bl;
+    if (prn >= a.n_prn || bin >= a.n_bins) return;  // uniform over the work-group
+    const int cell = prn * a.n_bins + bin;
+    const int t = threadIdx.x;
+
+    cf ra[P::R1], rb[P::R2], rc[P::R3];
+    if (t < P::T1)
+        {
+            const cf* __restrict__ X = a.spectra + static_cast<size_t>(bin) * P::N + t;
+            const cf* __restrict__ C = a.codes + static_cast<size_t>(prn) * P::N + t;
+            oc::static_for<P::R1>([&](auto N1) GSH_AI {
+                constexpr int n1 = decltype(N1)::value;
+                ra[n1] = oc::cmul_conj(X[n1 * P::T1], C[n1 * P::T1]);
+            });
+            P::stage1(ra, t);
+        }
+    exchange1<P>(ra, rb, t, lds);
+    if (t < P::T2) P::stage2(rb, t);
+    exchange2<P>(rb, rc, t, lds);
+
+    // ---- |.|^2, optional accumulation / grid store, per-thread (max, lowest arg-max, sum)
+    float best = -1.0f, sum = 0.0f;
+    unsigned at = 0xFFFFFFFFu;
+    if (t < P::T3)
+        {
+            P::stage3(rc);
+            float* __restrict__ g = a.grid + static_cast<size_t>(cell) * a.effective;
+            // effective == N and no offset on this path (bit_transition_flag goes through the four-step kernels)
+            if (GRID)
+                {
+                    oc::static_for<P::R3>([&](auto K3) GSH_AI {
+                        constexpr int k3 = decltype(K3)::value;
+                        rc[k3].x = rc[k3].x * rc[k3].x + rc[k3].y * rc[k3].y;
+                    });
+                    if (a.accumulate)  // acq.cc:549-553
+                        oc::static_for<P::R3>([&](auto K3) GSH_AI { rc[decltype(K3)::value].x += g[t + P::T3 * decltype(K3)::value]; });
+                    if (a.store_grid)
+                        oc::static_for<P::R3>([&](auto K3) GSH_AI { g[t + P::T3 * decltype(K3)::value] = rc[decltype(K3)::value].x; });
+                }
+            oc::static_for<P::R3>([&](auto K3) GSH_AI {
+                constexpr int k3 = decltype(K3)::value;
+                const float m = GRID ? rc[k3].x : rc[k3].x * rc[k3].x + rc[k3].y * rc[k3].y;
+                // branch-free bookkeeping (selects): k3 ascending = tau ascending, so '>' keeps the lowest index
+                sum += m;
+                const bool better = m > best;
+                best = better ? m : best;
+                at = better ? static_cast<unsigned>(t + P::T3 * k3) : at;
+                if (SECOND && !GRID) rc[k3].x = m;  // kept (in place) for the second scan
+            });
+        }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        {
+            const float ov = __shfl_down(best, off, 64);
+            const unsigned oi = __shfl_down(at, off, 64);
+            sum += __shfl_down(sum, off, 64);
+            argmax_merge(best, at, ov, oi);
+        }
+    const int wave = t >> 6;
+    constexpr int n_waves = P::THREADS / 64;
+    static_assert(n_waves <= OC_MAX_WAVES, "work-group too large for the reduction scratch");
+    if ((t & 63) == 0)
+        {
+            s_v[wave] = best;
+            s_i[wave] = at;
+            s_s[wave] = sum;
+        }
+    __syncthreads();
+    if (t == 0)
+        {
+            for (int w = 1; w < n_waves; w++)
+                {
+                    argmax_merge(best, at, s_v[w], s_i[w]);
+                    sum += s_s[w];
+                }
+            s_peak = best;
+            s_tau = at;
+        }
+    float second = 0.0f;  // blanked cells hold 0.0
+    if (SECOND)
+        {
+
+    // ---- second peak of THIS row with +-samples_per_chip around its own peak blanked (acq.cc:485-513); the final
+    // scan uses the record of the winning row, whose peak is the global one
+            __syncthreads();
+            const int tau_pk = static_cast<int>(s_tau);
+            int e1 = tau_pk - a.samples_per_chip;
+            int e2 = tau_pk + a.samples_per_chip;
+            if (e1 < 0)
+                e1 += a.effective;
+            else if (e2 >= a.effective)
+                e2 -= a.effective;
+            const bool wraps = e1 > e2, blank_all = e1 == e2;  // the do-while of acq.cc:498-509 blanks everything when e1 == e2
+            if (t < P::T3)
+                {
+                    oc::static_for<P::R3>([&](auto K3) GSH_AI {
+                        constexpr int k3 = decltype(K3)::value;
+                        const int tau = t + P::T3 * k3;
+                        const bool ge1 = tau >= e1, lt2 = tau < e2;
+                        const bool blank = blank_all | (wraps ? (ge1 | lt2) : (ge1 & lt2));
+                        second = blank ? second : fmaxf(second, rc[k3].x);
+                    });
+                }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) second = fmaxf(second, __shfl_down(second, off, 64));
+            __syncthreads();  // s_v is reused
+            if ((t & 63) == 0) s_v[wave] = second;
+            __syncthreads();
+            if (t == 0)
+                for (int w = 1; w < n_waves; w++) second = fmaxf(second, s_v[w]);
+        }
+
+    // ---- publish the row record; the LAST cell of this PRN to arrive forms the PRN's statistic (acq.cc:409-519).
+    // Placement-independent hand-off: plain store -> agent-scope release -> relaxed ticket; the last arriver acquires.
+    if (t == 0)
+        {
+            RowStat r;
+            r.maxv = s_peak;
+            r.idx = s_tau;
+            r.sum = sum;
+            r.second = second;
+            a.rows[cell] = r;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned ticket = __hip_atomic_fetch_add(&a.arrivals[prn], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_i[0] = (ticket == static_cast<unsigned>(a.n_bins) - 1u) ? 1u : 0u;
+        }
+    __syncthreads();
+    if (s_i[0] == 0u || t >= 64) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    {
+        // bin scan of acq.cc:417-426 / :463-474 over one wave: gmax starts at 0 and only a strictly larger row
+        // maximum replaces it, so ties keep the lowest bin
+        const RowStat* __restrict__ rs = a.rows + static_cast<size_t>(prn) * a.n_bins;
+        float gmax = 0.0f;
+        unsigned gbin = 0xFFFFFFFFu, gtau = 0u;
+        for (int d = t; d < a.n_bins; d += 64)
+            {
+                const RowStat r = rs[d];
+                if (r.maxv > gmax)
+                    {
+                        gmax = r.maxv;
+                        gbin = static_cast<unsigned>(d);
+                        gtau = r.idx;
+                    }
+            }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+            {
+                const float ov = __shfl_down(gmax, off, 64);
+                const unsigned ob = __shfl_down(gbin, off, 64);
+                const unsigned ot = __shfl_down(gtau, off, 64);
+                if (ov > gmax || (ov == gmax && ob < gbin))
+                    {
+                        gmax = ov;
+                        gbin = ob;
+                        gtau = ot;
+                    }
+            }
+        if (t == 0)
+            {
+                if (gbin == 0xFFFFFFFFu)  // every row maximum was 0: the reference leaves bin 0 / index 0
+                    {
+                        gbin = 0u;
+                        gtau = 0u;
+                    }
+                DevAcqResult out;
+                out.index_time = gtau;
+                out.index_doppler = gbin;
+                out.peak = gmax;
+                out.input_power = 0.0f;
+                out.second_peak = 0.0f;
+                out.test_statistics = 0.0f;
+                if (a.use_cfar)
+                    {
+                        // acq.cc:429-431: power of the bin half a grid away, / effective / 2 / dwells
+                        const unsigned opp = (gbin + static_cast<unsigned>(a.n_bins) / 2u) % static_cast<unsigned>(a.n_bins);
+                        const float per_sample = rs[opp].sum / static_cast<float>(static_cast<unsigned>(a.effective));
+                        const float power = static_cast<float>(static_cast<double>(per_sample) / 2.0 / static_cast<double>(a.dwell_count));
+                        out.input_power = power;
+                        out.test_statistics = (power < 1.1920928955078125e-07f) ? 0.0f : gmax / power;  // acq.cc:438-445
+                    }
+                else
+                    {
+                        out.second_peak = rs[gbin].second;
+                        out.test_statistics = gmax / rs[gbin].second;  // acq.cc:516
+                    }
+                a.results[prn] = out;
+                __hip_atomic_store(&a.arrivals[prn], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+            }
+    }
+}
+
+template <class P>
+int launch_forward(const OcFwdArgs& a, int batch, hipStream_t s)
+{
+    hipLaunchKernelGGL((oc_forward_kernel<P>), dim3(batch), dim3(P::THREADS), 0, s, a);
+    GSH_HIP(hipGetLastError());
+    return GSH_OK;
+}
+
+template <class P>
+int launch_cells(const OcCellArgs& a, int n_blocks, hipStream_t s)
+{
+    const bool grid = a.accumulate || a.store_grid;
+    if (grid && a.want_second)
+        hipLaunchKernelGGL((oc_cell_kernel<P, true, true>), dim3(n_blocks), dim3(P::THREADS), 0, s, a);
+    else if (grid)
+        hipLaunchKernelGGL((oc_cell_kernel<P, true, false>), dim3(n_blocks), dim3(P::THREADS), 0, s, a);
+    else if (a.want_second)
+        hipLaunchKernelGGL((oc_cell_kernel<P, false, true>), dim3(n_blocks), dim3(P::THREADS), 0, s, a);
+    else
+        hipLaunchKernelGGL((oc_cell_kernel<P, false, false>), dim3(n_blocks), dim3(P::THREADS), 0, s, a);
+    GSH_HIP(hipGetLastError());
+    return GSH_OK;
+}
+}  // namespace
+
+bool onchip_supported(int n)
+{
+#define GSH_OC_CASE(r1, r2, r3) \
+    if (n == (r1) * (r2) * (r3)) return true;
+    GSH_OC_PLANS(GSH_OC_CASE)
+#undef GSH_OC_CASE
+    return false;
+}
+
+int onchip_forward(int n, const float2* src, size_t src_stride, int n_in, int place_off, const int* wipe_hz, double fs, float2* dst,
+    int batch, hipStream_t s)
+{
+    if (batch <= 0) return GSH_OK;
+    OcFwdArgs a;
+    a.src = reinterpret_cast<const cf*>(src);
+    a.src_stride = src_stride;
+    a.n_in = n_in;
+    a.place_off = place_off;
+    a.wipe_hz = wipe_hz;
+    a.inv_fs = 1.0 / fs;
+    a.dst = reinterpret_cast<cf*>(dst);
+#define GSH_OC_CASE(r1, r2, r3) \
+    if (n == (r1) * (r2) * (r3)) return launch_forward<oc::Plan<r1, r2, r3>>(a, batch, s);
+    GSH_OC_PLANS(GSH_OC_CASE)
+#undef GSH_OC_CASE
+    return set_error(GSH_ERR_UNSUPPORTED, "no on-chip plan for fft_size %d", n);
+}
+
+int onchip_correlate(int n, const float2* spectra, const float2* codes, float* grid, RowStat* rows, DevAcqResult* results,
+    unsigned* arrivals, int n_prn, int n_bins, int effective, int accumulate, int store_grid, int samples_per_chip, int use_cfar,
+    unsigned dwell_count, hipStream_t s)
+{
+    if (n_prn <= 0 || n_bins <= 0) return GSH_OK;
+    GSH_REQUIRE(effective == n, "the on-chip path needs effective_fft_size == fft_size");
+    OcCellArgs a;
+    a.spectra = reinterpret_cast<const cf*>(spectra);
+    a.codes = reinterpret_cast<const cf*>(codes);
+    a.grid = grid;
+    a.rows = rows;
+    a.results = results;
+    a.arrivals = arrivals;
+    a.n_prn = n_prn;
+    a.n_bins = n_bins;
+    int xp = 1;
+    while (xp < 8 && 2 * xp <= n_prn) xp *= 2;
+    const int xb = 8 / xp;
+    a.xp = xp;
+    a.prn_per = (n_prn + xp - 1) / xp;
+    a.bin_per = (n_bins + xb - 1) / xb;
+    a.effective = effective;
+    a.accumulate = accumulate;
+    a.store_grid = store_grid;
+    a.samples_per_chip = samples_per_chip;
+    a.want_second = use_cfar ? 0 : 1;
+    a.use_cfar = use_cfar;
+    a.dwell_count = dwell_count ? dwell_count : 1u;
+    const int n_blocks = 8 * a.prn_per * a.bin_per;
+#define GSH_OC_CASE(r1, r2, r3) \
+    if (n == (r1) * (r2) * (r3)) return launch_cells<oc::Plan<r1, r2, r3>>(a, n_blocks, s);
+    GSH_OC_PLANS(GSH_OC_CASE)
+#undef GSH_OC_CASE
+    return set_error(GSH_ERR_UNSUPPORTED, "no on-chip plan for fft_size %d", n);
+}
+
+}  // namespace gsh

@@ -32,6 +32,9 @@ Hip_Pcps_Acquisition_Core::Hip_Pcps_Acquisition_Core(const Hip_Acq_Conf& conf, i
     c.bit_transition_flag = conf.bit_transition_flag ? 1 : 0;
     c.use_cfar = conf.use_CFAR_algorithm_flag ? 1 : 0;
     c.max_prn = 1;
+    // the |.|^2 grid is only consumed by later non-coherent dwells (acq.cc:549-553) and by dump (acq.cc:555-558)
+    c.no_grid = (conf.max_dwells <= 1U && !conf.dump) ? 1 : 0;
+    c.transform_path = 0;
     if (gsh_acq_create(device, &c, &d_handle) != GSH_OK)
         {
             d_error = gsh_last_error();

@@ -42,6 +42,7 @@ struct Hip_Acq_Conf
     bool bit_transition_flag{false};
     bool use_CFAR_algorithm_flag{true};
     bool use_automatic_resampler{false};
+    bool dump{false};  //!< Acq_Conf::dump: the grid must stay readable (read_grid)
 
     /*! acq_conf.cc:119-124 */
     void SetDerivedParams()

@@ -30,7 +30,7 @@ extern "C"
 {
 #endif
 
-#define GSH_ABI_VERSION 1
+#define GSH_ABI_VERSION 2
 #define GSH_MAX_TAPS 8 /* VE/E/P/L/VL needs 5 (trk.cc:609-650); 8 leaves room for multi-tap dumps */
 
     enum
@@ -160,6 +160,12 @@ extern "C"
         int32_t bit_transition_flag; /* acq.cc:230-235,544 */
         int32_t use_cfar;           /* d_use_CFAR_algorithm_flag: 1 = max_to_input_power, 0 = first_vs_second_peak */
         uint32_t max_prn;           /* how many local codes this handle can hold */
+        int32_t no_grid;            /* 0: the |.|^2 grid d_magnitude_grid (acq.cc:137) is kept in device memory, as the
+                                       reference keeps it (needed by accumulate != 0, i.e. max_dwells > 1, and by
+                                       gsh_acq_read_grid, i.e. dump).  1: the caller promises neither; lengths with an
+                                       on-chip plan then never write the grid (statistics are formed on chip) */
+        int32_t transform_path;     /* 0: automatic (whole transform on one CU when the length has a plan, else the
+                                       four-step path through HBM); 1: force the four-step path (A/B testing) */
     } gsh_acq_conf;
 
     typedef struct gsh_acq_result
@@ -193,6 +199,12 @@ extern "C"
     int gsh_acq_read_grid(gsh_acq_t* a, uint32_t prn_slot, float* grid);
     /* HIP-event average milliseconds per full dwell batch (n_prn codes), inputs resident */
     int gsh_acq_time_dwells(gsh_acq_t* a, uint32_t n_prn, int reps, float* avg_ms);
+    /* the same stream of `reps` dwell batches issued alternately on two HIP streams with per-batch spectra / row /
+     * result buffers, so batch k+1's forward transforms and first cells run on the compute units batch k's tail
+     * leaves idle: average milliseconds per batch in steady state (throughput; the single-batch latency is what
+     * gsh_acq_time_dwells reports).  Statistics only (as no_grid = 1); lengths without an on-chip plan fall back to
+     * gsh_acq_time_dwells. */
+    int gsh_acq_time_dwells_pipelined(gsh_acq_t* a, uint32_t n_prn, int reps, float* avg_ms);
 
     /* compute_threshold, acq.cc:52-56: 2*gamma_p_inv(2*max_dwells, (1-pfa)^(1/(effective*bins))) */
     float gsh_acq_compute_threshold(float pfa, uint32_t effective_fft_size, uint32_t num_doppler_bins, uint32_t max_dwells);

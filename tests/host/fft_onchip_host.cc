@@ -1,0 +1,87 @@
+// CPU emulation of the on-chip FFT (gnss-sdr_amd/csrc/fft_onchip.h): the SAME per-thread phase functions the
+// HIP kernels call, executed thread by thread with a plain array standing in for LDS.  Test infrastructure:
+// lets `pytest -m "not gpu"` check the index maps, the register DFTs, the twiddles and the LDS layouts against
+// numpy.fft without a GPU.  Built by __graft_entry__.build() with the host side of clang (ext-vector types).
+#include "fft_onchip.h"
+#include <vector>
+
+namespace
+{
+using gsh::oc::cf;
+
+template <class P>
+void run_plan(const float* in_iq, float* out_iq)
+{
+    struct A { cf v[P::R1]; };
+    struct B { cf v[P::R2]; };
+    struct C { cf v[P::R3]; };
+    std::vector<A> a(P::T1);
+    std::vector<B> b(P::T2);
+    std::vector<C> c(P::T3);
+    std::vector<float> lds(P::LDS_FLOATS, 0.0f);
+    for (int t = 0; t < P::T1; t++)
+        {
+            for (int n1 = 0; n1 < P::R1; n1++)
+                {
+                    const int n = n1 * P::T1 + t;
+                    a[t].v[n1] = cf{in_iq[2 * n], in_iq[2 * n + 1]};
+                }
+            P::stage1(a[t].v, t);
+        }
+    for (int t = 0; t < P::T1; t++) P::template ex1_write<0>(a[t].v, t, lds.data());
+    for (int t = 0; t < P::T2; t++) P::template ex1_read<0>(b[t].v, t, lds.data());
+    for (int t = 0; t < P::T1; t++) P::template ex1_write<1>(a[t].v, t, lds.data());
+    for (int t = 0; t < P::T2; t++) P::template ex1_read<1>(b[t].v, t, lds.data());
+    for (int t = 0; t < P::T2; t++) P::stage2(b[t].v, t);
+    for (int t = 0; t < P::T2; t++) P::template ex2_write<0>(b[t].v, t, lds.data());
+    for (int t = 0; t < P::T3; t++) P::template ex2_read<0>(c[t].v, t, lds.data());
+    for (int t = 0; t < P::T2; t++) P::template ex2_write<1>(b[t].v, t, lds.data());
+    for (int t = 0; t < P::T3; t++) P::template ex2_read<1>(c[t].v, t, lds.data());
+    for (int t = 0; t < P::T3; t++)
+        {
+            P::stage3(c[t].v);
+            for (int k3 = 0; k3 < P::R3; k3++)
+                {
+                    const int k = t + P::T3 * k3;
+                    out_iq[2 * k] = c[t].v[k3].x;
+                    out_iq[2 * k + 1] = c[t].v[k3].y;
+                }
+        }
+}
+}  // namespace
+
+extern "C"
+{
+    // forward DFT of n complex64 values with the on-chip plan for n; returns 0, or -1 when n has no plan
+    int oc_host_fft(int n, const float* in_iq, float* out_iq)
+    {
+#define GSH_OC_CASE(r1, r2, r3)                                  \
+    if (n == (r1) * (r2) * (r3))                                 \
+        {                                                        \
+            run_plan<gsh::oc::Plan<r1, r2, r3>>(in_iq, out_iq);  \
+            return 0;                                            \
+        }
+        GSH_OC_PLANS(GSH_OC_CASE)
+#undef GSH_OC_CASE
+        return -1;
+    }
+
+    // plan geometry for the tests: {threads, lds_floats, S1, S2, P2}
+    int oc_host_plan_info(int n, int* info)
+    {
+#define GSH_OC_CASE(r1, r2, r3)                                  \
+    if (n == (r1) * (r2) * (r3))                                 \
+        {                                                        \
+            using P = gsh::oc::Plan<r1, r2, r3>;                 \
+            info[0] = P::THREADS;                                \
+            info[1] = P::LDS_FLOATS;                             \
+            info[2] = P::S1;                                     \
+            info[3] = P::S2;                                     \
+            info[4] = P::P2;                                     \
+            return 0;                                            \
+        }
+        GSH_OC_PLANS(GSH_OC_CASE)
+#undef GSH_OC_CASE
+        return -1;
+    }
+}

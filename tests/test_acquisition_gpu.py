@@ -102,9 +102,31 @@ def test_gsoc2013_known_answer(gpu):
     acq.close()
 
 
-def test_config3_32prn_41bins(gpu):
+_CFG3_ORACLE = {}
+
+
+def _cfg3_oracle(p, use_cfar, kw, x, fs):
+    """oracle + float64 evaluation of one PRN of config 3, computed once and shared by the path variants"""
+    key = (p, use_cfar)
+    if key not in _CFG3_ORACLE:
+        code = oracle.ca_code_complex_sampled(p + 1, fs)
+        ora = PcpsOracle(use_cfar=use_cfar, **kw)
+        ora.set_local_code(code)
+        exp = ora.dwell(x)
+        prec = PcpsOracle(use_cfar=use_cfar, precise=True, **kw)
+        prec.set_local_code(code)
+        prec.dwell(x)
+        ora.grid = None
+        _CFG3_ORACLE[key] = (exp, prec)
+    return _CFG3_ORACLE[key]
+
+
+@pytest.mark.parametrize("path", ["onchip_nogrid", "onchip_grid", "fourstep"])
+def test_config3_32prn_41bins(gpu, path):
     """BASELINE config 3: 32 PRN x 41 Doppler bins (-5000..+5000 step 250, explicit count), fs 25 Msps, N 25 000,
-    1 ms of the config-2 stream: 8 embedded PRNs must be detected with bit-exact indices, the other 24 rejected."""
+    1 ms of the config-2 stream: 8 embedded PRNs must be detected with bit-exact indices, the other 24 rejected.
+    Run through the whole-transform-on-chip kernels (with and without the stored grid) and the four-step kernels."""
+    bank_kw = dict(keep_grid=(path != "onchip_nogrid"), transform_path=(1 if path == "fourstep" else 0))
     fs = 25000000
     n = 25000
     rng = np.random.default_rng(0x5EED0003)
@@ -114,19 +136,13 @@ def test_config3_32prn_41bins(gpu):
     kw = dict(fs_in=fs, fft_size=n, doppler_max=5000, doppler_step=250, num_doppler_bins=41, samples_per_chip=25, samples_per_code=25000.0)
     thr = oracle_threshold(0.001, n, 41, 1)
     for use_cfar in (True, False):
-        acq = _bank(gpu, max_prn=32, use_cfar=use_cfar, **kw)
+        acq = _bank(gpu, max_prn=32, use_cfar=use_cfar, **kw, **bank_kw)
         for p in range(32):
             acq.set_local_code(p, oracle.ca_code_complex_sampled(p + 1, fs))
         results = acq.dwell(x, 32)
         detected = 0
         for p in range(32):
-            code = oracle.ca_code_complex_sampled(p + 1, fs)
-            ora = PcpsOracle(use_cfar=use_cfar, **kw)
-            ora.set_local_code(code)
-            exp = ora.dwell(x)
-            prec = PcpsOracle(use_cfar=use_cfar, precise=True, **kw)
-            prec.set_local_code(code)
-            prec.dwell(x)
+            exp, prec = _cfg3_oracle(p, use_cfar, kw, x, fs)
             res = results[p]
             _same_peak(res, exp, prec, f"prn {p + 1}")
             assert res["test_statistics"] == pytest.approx(exp["test_statistics"], rel=5e-3), (p, res, exp)
@@ -184,3 +200,48 @@ def test_noncoherent_dwells_center_and_errors(gpu):
     acq.close()
     with pytest.raises(GshError):
         _bank(gpu, max_prn=1, fs_in=fs, fft_size=4007 * 2, doppler_max=5000, doppler_step=500, samples_per_chip=4, samples_per_code=4000.0)  # prime factor 4007
+
+
+@pytest.mark.parametrize("n,fs", [(4000, 4000000), (25000, 25000000)])
+def test_onchip_agrees_with_fourstep_and_nogrid_rules(gpu, n, fs):
+    """Lengths with an on-chip plan: the whole-transform-on-chip kernels and the four-step kernels are two independent
+    FFT factorisations of the same dwell -- identical peak indices, values within float32 FFT rounding; with
+    keep_grid=False nothing but the statistics is produced, and the calls that need the grid fail loudly."""
+    from gnss_sdr_amd import GshError
+    spc = int(np.ceil(fs / 1.023e6))
+    x = synth_gps_l1_stream(2 * n, fs, [5, 9], [-3300.0, 1875.0], [100.25, 871.5], cn0_dbhz=48.0, seed_noise=n + 1)
+    kw = dict(fs_in=fs, fft_size=n, doppler_max=5000, doppler_step=250, samples_per_chip=spc, samples_per_code=float(n), max_prn=3)
+    codes = [oracle.ca_code_complex_sampled(p, fs) for p in (5, 9, 20)]
+    for use_cfar in (True, False):
+        banks = {name: _bank(gpu, use_cfar=use_cfar, **kw, **bk) for name, bk in
+                 (("onchip", dict()), ("nogrid", dict(keep_grid=False)), ("fourstep", dict(transform_path=1)))}
+        out = {}
+        for name, acq in banks.items():
+            for i, c in enumerate(codes):
+                acq.set_local_code(i, c)
+            out[name] = acq.dwell(x[:n], 3)
+        for i in range(3):
+            a, b, c = out["onchip"][i], out["fourstep"][i], out["nogrid"][i]
+            if i < 2:  # a signal is present: indices are robust to rounding
+                assert (a["index_time"], a["index_doppler"]) == (b["index_time"], b["index_doppler"]), (i, a, b)
+            assert (a["index_time"], a["index_doppler"]) == (c["index_time"], c["index_doppler"]), (i, a, c)
+            for k in ("peak", "test_statistics", "input_power", "second_peak"):
+                if i < 2:
+                    assert a[k] == pytest.approx(b[k], rel=2e-4), (i, k, a, b)
+                assert a[k] == pytest.approx(c[k], rel=1e-5), (i, k, a, c)
+        g_on = banks["onchip"].read_grid(1)
+        g_fs = banks["fourstep"].read_grid(1)
+        assert np.max(np.abs(g_on - g_fs)) <= 1e-4 * out["onchip"][1]["peak"]
+        # second non-coherent dwell on both grid-keeping paths (acq.cc:545-553)
+        r_on = banks["onchip"].dwell(x[n:], 3, accumulate=True, dwell_count=2)
+        r_fs = banks["fourstep"].dwell(x[n:], 3, accumulate=True, dwell_count=2)
+        for i in range(2):
+            assert (r_on[i]["index_time"], r_on[i]["index_doppler"]) == (r_fs[i]["index_time"], r_fs[i]["index_doppler"])
+            assert r_on[i]["test_statistics"] == pytest.approx(r_fs[i]["test_statistics"], rel=2e-4)
+        assert np.max(np.abs(banks["onchip"].read_grid(0) - banks["fourstep"].read_grid(0))) <= 1e-4 * r_on[0]["peak"]
+        with pytest.raises(GshError):
+            banks["nogrid"].dwell(x[n:], 3, accumulate=True, dwell_count=2)
+        with pytest.raises(GshError):
+            banks["nogrid"].read_grid(0)
+        for acq in banks.values():
+            acq.close()
