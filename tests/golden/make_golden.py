@@ -54,6 +54,33 @@ def main():
         l5[f"l5q_{prn}"] = b.astype(np.int8)
     np.savez_compressed(os.path.join(HERE, "codes.npz"), **ca, **e1, **l5)
 
+    # ---- full tracking-replica sets for BASELINE configs 4 and 5 (Galileo E1 B/C sinBOC(1,1) at 2 samples per chip,
+    # trk.cc:289,837-844; GPS L5 I/Q, trk.cc:903-915), bit-packed: bit = 1 where the reference's float chip is +1
+    full = {}
+    e1b = np.empty((50, 8184), np.int8)
+    e1c = np.empty((50, 8184), np.int8)
+    b = np.empty(8184, np.float32)
+    for prn in range(1, 51):
+        R.ref_galileo_e1_code_gen_sinboc11_float(b, b"1B", prn)
+        assert np.all(np.abs(b) == 1.0)
+        e1b[prn - 1] = b
+        R.ref_galileo_e1_code_gen_sinboc11_float(b, b"1C", prn)
+        e1c[prn - 1] = b
+    full["e1b_sinboc11"] = np.packbits(e1b > 0, axis=1)
+    full["e1c_sinboc11"] = np.packbits(e1c > 0, axis=1)
+    l5i = np.empty((32, 10230), np.int8)
+    l5q = np.empty((32, 10230), np.int8)
+    b = np.empty(10230, np.float32)
+    for prn in range(1, 33):
+        R.ref_gps_l5i_code_gen_float(b, prn)
+        assert np.all(np.abs(b) == 1.0)
+        l5i[prn - 1] = b
+        R.ref_gps_l5q_code_gen_float(b, prn)
+        l5q[prn - 1] = b
+    full["l5i"] = np.packbits(l5i > 0, axis=1)
+    full["l5q"] = np.packbits(l5q > 0, axis=1)
+    np.savez_compressed(os.path.join(HERE, "codes_e1_l5.npz"), **full)
+
     # ---- multicorrelator known answers ----------------------------------------------------------------
     rng = np.random.default_rng(20260922)
     cases = {}

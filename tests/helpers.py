@@ -83,3 +83,24 @@ TOL_REF = 5e-5
 
 def scale_err(gpu, truth, sabs):
     return np.abs(np.asarray(gpu, np.complex128) - truth) / sabs
+
+
+def golden_e1_l5_codes():
+    """Tracking replicas minted from the reference build (tests/golden/make_golden.py): dict of float32 arrays
+    e1b / e1c [50, 8184] (Galileo E1 B/C, sinBOC(1,1), 2 samples per chip) and l5i / l5q [32, 10230]."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "codes_e1_l5.npz"))
+    out = {}
+    for key, name, length in (("e1b_sinboc11", "e1b", 8184), ("e1c_sinboc11", "e1c", 8184), ("l5i", "l5i", 10230), ("l5q", "l5q", 10230)):
+        bits = np.unpackbits(z[key], axis=1)[:, :length]
+        out[name] = (2.0 * bits.astype(np.float32) - 1.0)
+    return out
+
+
+def add_code_signal(x: np.ndarray, code: np.ndarray, fs: float, code_rate_samples: float, code_phase_samples: float,
+                    doppler_hz: float, amp: float, carrier_phase: float = 0.0) -> None:
+    """x += amp * code[floor(n * code_rate_samples + code_phase_samples) mod len] * exp(j(2 pi fd n / fs + phase)), in place.
+    code_rate_samples: code samples (chips x samples-per-chip) advanced per input sample."""
+    n = np.arange(len(x), dtype=np.float64)
+    idx = np.floor(n * code_rate_samples + code_phase_samples).astype(np.int64) % len(code)
+    x += (amp * code[idx].astype(np.float64) * np.exp(1j * (TWO_PI * doppler_hz / fs * n + carrier_phase))).astype(np.complex64)

@@ -105,3 +105,46 @@ def test_oracle_equals_live_reference():
     gen = oracle.ref_mcorr(code, [-0.5, 0, 0.5], x, **kw)
     simd = oracle.ref_mcorr(code, [-0.5, 0, 0.5], x, simd=True, **kw)
     assert np.all(np.abs(gen - simd) / np.abs(gen) < 1e-3)  # the reference's QA bound, kernel_tests.h:41,88-89
+
+
+def test_e1_l5_fixture_properties():
+    """tests/golden/codes_e1_l5.npz: shapes, +-1 values, sinBOC(1,1) structure (each E1 chip is the pair {+c, -c},
+    galileo_e1_signal_replica.cc:98-108) and the small per-PRN samples stored in codes.npz by the same script."""
+    from helpers import golden_e1_l5_codes
+    import os
+    g = golden_e1_l5_codes()
+    assert g["e1b"].shape == (50, 8184) and g["e1c"].shape == (50, 8184)
+    assert g["l5i"].shape == (32, 10230) and g["l5q"].shape == (32, 10230)
+    for k, v in g.items():
+        assert np.all(np.abs(v) == 1.0), k
+    for k in ("e1b", "e1c"):
+        assert np.array_equal(g[k][:, 0::2], -g[k][:, 1::2]), k
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "codes.npz"))
+    for prn in (1, 11, 50):
+        assert np.array_equal(z[f"e1_1B_{prn}"].astype(np.float32), g["e1b"][prn - 1])
+        assert np.array_equal(z[f"e1_1C_{prn}"].astype(np.float32), g["e1c"][prn - 1])
+    for prn in (1, 32):
+        assert np.array_equal(z[f"l5i_{prn}"].astype(np.float32), g["l5i"][prn - 1])
+        assert np.array_equal(z[f"l5q_{prn}"].astype(np.float32), g["l5q"][prn - 1])
+    # distinct PRNs are nearly orthogonal over a period
+    c = g["l5i"] @ g["l5i"].T / 10230.0
+    assert np.all(np.abs(c - np.eye(32)) < 0.05)
+
+
+@pytest.mark.skipif(oracle.ref() is None, reason="oracle/_ref not built (needs /root/reference)")
+def test_e1_l5_fixture_equals_live_reference():
+    from helpers import golden_e1_l5_codes
+    g = golden_e1_l5_codes()
+    R = oracle.ref()
+    b = np.empty(8184, np.float32)
+    for prn in (2, 25, 49):
+        R.ref_galileo_e1_code_gen_sinboc11_float(b, b"1B", prn)
+        assert np.array_equal(b, g["e1b"][prn - 1])
+        R.ref_galileo_e1_code_gen_sinboc11_float(b, b"1C", prn)
+        assert np.array_equal(b, g["e1c"][prn - 1])
+    b = np.empty(10230, np.float32)
+    for prn in (3, 17, 31):
+        R.ref_gps_l5i_code_gen_float(b, prn)
+        assert np.array_equal(b, g["l5i"][prn - 1])
+        R.ref_gps_l5q_code_gen_float(b, prn)
+        assert np.array_equal(b, g["l5q"][prn - 1])
