@@ -21,6 +21,40 @@ _f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
 _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 _u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
 
+
+
+class LoopFilter(C.Structure):
+    """oracle_loop_filter"""
+    _fields_ = [("in_c", C.c_float * 4), ("out_c", C.c_float * 4), ("in_h", C.c_float * 4), ("out_h", C.c_float * 4),
+                ("n_in", C.c_int), ("n_out", C.c_int), ("idx", C.c_int), ("order", C.c_int), ("last_integrator", C.c_int)]
+
+
+class FllPllFilter(C.Structure):
+    """oracle_fll_pll_filter"""
+    _fields_ = [(k, C.c_float) for k in ("w", "x", "w0p", "w0p2", "w0p3", "w0f", "w0f2", "a2", "a3", "b3")] + [("order", C.c_int)]
+
+
+class TrkConf(C.Structure):
+    """oracle_trk_conf (same layout as gsh_trk_conf)"""
+    _fields_ = [("fs_in", C.c_double), ("code_chip_rate", C.c_double), ("signal_carrier_freq", C.c_double), ("cfo_frequency_hz", C.c_double),
+                ("code_length_chips", C.c_uint32), ("code_samples_per_chip", C.c_uint32), ("vector_length", C.c_uint32),
+                ("veml", C.c_int32), ("track_pilot", C.c_int32),
+                ("early_late_space_chips", C.c_float), ("very_early_late_space_chips", C.c_float),
+                ("pll_bw_hz", C.c_float), ("dll_bw_hz", C.c_float), ("fll_bw_hz", C.c_float),
+                ("pll_filter_order", C.c_int32), ("dll_filter_order", C.c_int32),
+                ("enable_fll_pull_in", C.c_int32), ("enable_fll_steady_state", C.c_int32), ("carrier_aiding", C.c_int32), ("cloop", C.c_int32),
+                ("pull_in_time_s", C.c_uint32), ("spc", C.c_float), ("slope", C.c_float), ("y_intercept", C.c_float)]
+
+
+class TrkEpoch(C.Structure):
+    """oracle_trk_epoch (same layout as gsh_trk_epoch)"""
+    _fields_ = [("sample_counter", C.c_uint64), ("prn_length_samples", C.c_int32), ("flags", C.c_int32),
+                ("corr", C.c_float * 10), ("prompt_data", C.c_float * 2), ("rem_carr_phase_rad", C.c_float), ("pad_", C.c_float),
+                ("carrier_doppler_hz", C.c_double), ("code_freq_chips", C.c_double), ("carr_phase_error_hz", C.c_double),
+                ("carr_freq_error_hz", C.c_double), ("carr_error_filt_hz", C.c_double), ("code_error_chips", C.c_double),
+                ("code_error_filt_chips", C.c_double), ("rem_code_phase_samples", C.c_double), ("acc_carrier_phase_rad", C.c_double)]
+
+
 _lib = None
 _ref = None
 _ref_tried = False
@@ -55,6 +89,24 @@ def lib():
         L.oracle_index_max.restype = None
         L.oracle_mcorr_time.argtypes = [_f32p, C.c_int, _f32p, C.c_int, _f32p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, _f32p, _f32p]
         L.oracle_mcorr_time.restype = C.c_double
+        # ---- loop closure (gnss_oracle_loop.c)
+        L.oracle_fll_diff_atan.argtypes = [C.c_float] * 4 + [C.c_double] * 2
+        L.oracle_fll_diff_atan.restype = C.c_double
+        for name, n in (("oracle_pll_four_quadrant_atan", 2), ("oracle_pll_cloop_two_quadrant_atan", 2),
+                        ("oracle_dll_nc_e_minus_l_normalized", 7), ("oracle_dll_nc_vemlp_normalized", 8)):
+            getattr(L, name).argtypes = [C.c_float] * n
+            getattr(L, name).restype = C.c_double
+        L.oracle_loop_filter_design.argtypes = [C.POINTER(LoopFilter), C.c_float, C.c_float, C.c_int, C.c_int]
+        L.oracle_loop_filter_initialize.argtypes = [C.POINTER(LoopFilter), C.c_float]
+        L.oracle_loop_filter_apply.argtypes = [C.POINTER(LoopFilter), C.c_float]
+        L.oracle_loop_filter_apply.restype = C.c_float
+        L.oracle_fll_pll_design.argtypes = [C.POINTER(FllPllFilter), C.c_float, C.c_float, C.c_int]
+        L.oracle_fll_pll_initialize.argtypes = [C.POINTER(FllPllFilter), C.c_float]
+        L.oracle_fll_pll_carrier_error.argtypes = [C.POINTER(FllPllFilter), C.c_float, C.c_float, C.c_float]
+        L.oracle_fll_pll_carrier_error.restype = C.c_float
+        L.oracle_trk_run.argtypes = [C.POINTER(TrkConf), _f32p, C.c_void_p, C.c_int, _f32p, C.c_uint64, C.c_uint64, C.c_uint64,
+                                     C.c_double, C.c_int, C.POINTER(TrkEpoch)]
+        L.oracle_trk_run.restype = C.c_int
         _lib = L
     return _lib
 
@@ -88,6 +140,15 @@ def ref():
             R.ref_gps_l5q_code_gen_float.argtypes = [_f32p, C.c_uint]
             R.ref_resampler_generic.argtypes = [C.POINTER(C.POINTER(C.c_float)), _f32p, C.c_float, C.c_float, _f32p, C.c_uint, C.c_int, C.c_uint]
             R.ref_hd_resampler_generic.argtypes = [C.POINTER(C.POINTER(C.c_float)), _f32p, C.c_float, C.c_float, C.c_float, _f32p, C.c_uint, C.c_int, C.c_uint]
+            if hasattr(R, "ref_fll_diff_atan"):  # loop-closure objects (added with SURVEY 8f-1)
+                R.ref_fll_diff_atan.argtypes = [C.c_float] * 4 + [C.c_double] * 2
+                R.ref_fll_diff_atan.restype = C.c_double
+                for name, n in (("ref_pll_four_quadrant_atan", 2), ("ref_pll_cloop_two_quadrant_atan", 2),
+                                ("ref_dll_nc_e_minus_l_normalized", 7), ("ref_dll_nc_vemlp_normalized", 8)):
+                    getattr(R, name).argtypes = [C.c_float] * n
+                    getattr(R, name).restype = C.c_double
+                R.ref_loop_filter_run.argtypes = [C.c_float, C.c_float, C.c_int, C.c_int, C.c_float, _f32p, _f32p, C.c_int]
+                R.ref_fll_pll_filter_run.argtypes = [C.c_float, C.c_float, C.c_int, C.c_float, _f32p, _f32p, C.c_float, _f32p, C.c_int]
             _ref = R
     return _ref
 
@@ -169,3 +230,50 @@ def ref_mcorr(code, shifts, x, rem_carr, phase_step, rem_code, code_step, phase_
     finally:
         R.ref_set_flavour(0)
     return out.view(np.complex64)
+
+
+# --------------------------------------------------------------------------- loop closure helpers
+
+def loop_filter_run(update_interval, noise_bandwidth, order, include_last_integrator, initial_output, x):
+    """Tracking_loop_filter: design, initialize(initial_output), apply every element of x"""
+    f = LoopFilter()
+    L = lib()
+    L.oracle_loop_filter_design(C.byref(f), update_interval, noise_bandwidth, order, int(include_last_integrator))
+    L.oracle_loop_filter_initialize(C.byref(f), initial_output)
+    return np.array([L.oracle_loop_filter_apply(C.byref(f), float(v)) for v in np.asarray(x, np.float32)], np.float32)
+
+
+def fll_pll_filter_run(fll_bw_hz, pll_bw_hz, order, acq_doppler_hz, fll_disc, pll_disc, correlation_time_s):
+    f = FllPllFilter()
+    L = lib()
+    L.oracle_fll_pll_design(C.byref(f), fll_bw_hz, pll_bw_hz, order)
+    L.oracle_fll_pll_initialize(C.byref(f), acq_doppler_hz)
+    return np.array([L.oracle_fll_pll_carrier_error(C.byref(f), float(a), float(b), correlation_time_s)
+                     for a, b in zip(np.asarray(fll_disc, np.float32), np.asarray(pll_disc, np.float32))], np.float32)
+
+
+def trk_conf(**kw) -> TrkConf:
+    """oracle_trk_conf with Dll_Pll_Conf's defaults (dll_pll_conf.h:33-90) for the fields that have one"""
+    c = TrkConf()
+    d = dict(fs_in=4e6, code_chip_rate=1.023e6, signal_carrier_freq=1575.42e6, cfo_frequency_hz=0.0, code_length_chips=1023,
+             code_samples_per_chip=1, vector_length=4000, veml=0, track_pilot=0, early_late_space_chips=0.5,
+             very_early_late_space_chips=0.6, pll_bw_hz=35.0, dll_bw_hz=2.0, fll_bw_hz=35.0, pll_filter_order=3, dll_filter_order=2,
+             enable_fll_pull_in=0, enable_fll_steady_state=0, carrier_aiding=1, cloop=1, pull_in_time_s=5, spc=0.5, slope=1.0,
+             y_intercept=1.0)
+    d.update(kw)
+    for k, v in d.items():
+        setattr(c, k, v)
+    return c
+
+
+def trk_run(conf: TrkConf, code, x, start_sample, acq_sample_stamp, acq_doppler_hz, n_epochs, data_code=None):
+    """closed DLL/PLL loop of one channel on the CPU; returns the list of completed TrkEpoch records"""
+    code = np.ascontiguousarray(code, np.float32)
+    rec = (TrkEpoch * n_epochs)()
+    dc = None
+    if data_code is not None:
+        data_code = np.ascontiguousarray(data_code, np.float32)
+        dc = data_code.ctypes.data_as(C.c_void_p)
+    n = lib().oracle_trk_run(C.byref(conf), code, dc, len(code), _iq(x), len(x), int(start_sample), int(acq_sample_stamp),
+                             float(acq_doppler_hz), n_epochs, rec)
+    return list(rec)[:n]

@@ -75,6 +75,65 @@ extern "C"
         const float* stream_iq, long stream_len, int n, int n_channels, int epochs, int n_threads,
         const float* params, float* out_iq);
 
+    /* ================= loop closure (gnss_oracle_loop.c) ================= */
+    /* T/ = src/algorithms/tracking/libs/ ; trk.cc = src/algorithms/tracking/gnuradio_blocks/dll_pll_veml_tracking.cc */
+    double oracle_fll_diff_atan(float p1re, float p1im, float p2re, float p2im, double t1, double t2);        /* T/tracking_discriminators.cc:68-76 */
+    double oracle_pll_four_quadrant_atan(float re, float im);                                                 /* :86-89 (atan2f for gr::fast_atan2f) */
+    double oracle_pll_cloop_two_quadrant_atan(float re, float im);                                            /* :99-106 */
+    double oracle_dll_nc_e_minus_l_normalized(float ere, float eim, float lre, float lim, float spc, float slope, float y_intercept); /* :117-127 */
+    double oracle_dll_nc_vemlp_normalized(float vere, float veim, float ere, float eim, float lre, float lim, float vlre, float vlim); /* :139-149 */
+
+    typedef struct oracle_loop_filter  /* Tracking_loop_filter, T/tracking_loop_filter.h */
+    {
+        float in_c[4], out_c[4];
+        float in_h[4], out_h[4];
+        int n_in, n_out, idx, order, last_integrator;
+    } oracle_loop_filter;
+    void oracle_loop_filter_design(oracle_loop_filter* f, float update_interval, float noise_bandwidth, int order, int include_last_integrator);
+    void oracle_loop_filter_initialize(oracle_loop_filter* f, float initial_output);
+    float oracle_loop_filter_apply(oracle_loop_filter* f, float x);
+
+    typedef struct oracle_fll_pll_filter  /* Tracking_FLL_PLL_filter, T/tracking_FLL_PLL_filter.h */
+    {
+        float w, x, w0p, w0p2, w0p3, w0f, w0f2, a2, a3, b3;
+        int order;
+    } oracle_fll_pll_filter;
+    void oracle_fll_pll_design(oracle_fll_pll_filter* f, float fll_bw_hz, float pll_bw_hz, int order);
+    void oracle_fll_pll_initialize(oracle_fll_pll_filter* f, float acq_carrier_doppler_hz);
+    float oracle_fll_pll_carrier_error(oracle_fll_pll_filter* f, float fll_disc, float pll_disc, float correlation_time_s);
+
+    /* same field order as gsh_trk_conf / gsh_trk_epoch (include/gnss_sdr_hip.h) so that one ctypes layout serves both */
+    typedef struct oracle_trk_conf
+    {
+        double fs_in, code_chip_rate, signal_carrier_freq, cfo_frequency_hz;
+        uint32_t code_length_chips, code_samples_per_chip, vector_length;
+        int32_t veml, track_pilot;
+        float early_late_space_chips, very_early_late_space_chips;
+        float pll_bw_hz, dll_bw_hz, fll_bw_hz;
+        int32_t pll_filter_order, dll_filter_order;
+        int32_t enable_fll_pull_in, enable_fll_steady_state, carrier_aiding, cloop;
+        uint32_t pull_in_time_s;
+        float spc, slope, y_intercept;
+    } oracle_trk_conf;
+
+    typedef struct oracle_trk_epoch
+    {
+        uint64_t sample_counter;
+        int32_t prn_length_samples;
+        int32_t flags;
+        float corr[10];
+        float prompt_data[2];
+        float rem_carr_phase_rad;
+        float pad_;
+        double carrier_doppler_hz, code_freq_chips, carr_phase_error_hz, carr_freq_error_hz, carr_error_filt_hz;
+        double code_error_chips, code_error_filt_chips, rem_code_phase_samples, acc_carrier_phase_rad;
+    } oracle_trk_epoch;
+
+    /* closed loop of ONE channel over a resident stream; returns the number of epochs completed */
+    int oracle_trk_run(const oracle_trk_conf* c, const float* code, const float* data_code, int code_len, const float* stream_iq,
+        uint64_t n_stream, uint64_t start_sample, uint64_t acq_sample_stamp, double acq_carrier_doppler_hz, int n_epochs,
+        oracle_trk_epoch* rec);
+
 #ifdef __cplusplus
 }
 #endif

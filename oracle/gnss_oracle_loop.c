@@ -1,0 +1,384 @@
+/*
+ * TEST INFRASTRUCTURE ONLY -- CPU restatement ("oracle") of the DLL/PLL loop closure of gnss-sdr's
+ * dll_pll_veml_tracking, the checker of gnss-sdr_amd/csrc/tracking_loop.hip.
+ *
+ * Parity status: PINNED for the discriminators that use libm (fll_diff_atan, pll_cloop_two_quadrant_atan,
+ * dll_nc_e_minus_l_normalized, dll_nc_vemlp_normalized) and for both loop filters -- exact equality with the
+ * reference's own objects compiled into oracle/_ref (tests/test_oracle_loop.py) and with the known answers of the
+ * reference's unit tests (tracking_loop_filter_test.cc:22-206, discriminator_test.cc:35-174).
+ * UNPINNED for pll_four_quadrant_atan: the reference calls gr::fast_atan2f (GNU Radio, un-vendored, version unpinned,
+ * a 255-entry table approximation); atan2f is used here and in the oracle/_ref shim.
+ *
+ * Citations are relative to /root/reference/:  trk.cc = src/algorithms/tracking/gnuradio_blocks/dll_pll_veml_tracking.cc,
+ * T/ = src/algorithms/tracking/libs/.
+ */
+#include "gnss_oracle.h"
+#include <math.h>
+#include <string.h>
+
+/* the reference's pi is the GNSS ICD value, MATH_CONSTANTS.h:47-49 */
+#define ORA_PI 3.1415926535898
+#define ORA_HALF_PI (ORA_PI / 2.0)
+#define ORA_TWO_PI (2.0 * ORA_PI)
+
+/* T/tracking_discriminators.cc:27-41 */
+static double phase_unwrap(double phase_rad)
+{
+    if (phase_rad >= ORA_HALF_PI) return phase_rad - ORA_PI;
+    if (phase_rad <= -ORA_HALF_PI) return phase_rad + ORA_PI;
+    return phase_rad;
+}
+
+/* T/tracking_discriminators.cc:68-76: atan(Q2/I2) - atan(Q1/I1); std::atan of a float IS the float overload, so the
+ * two arctangents and their difference are float32, only then widened; NaN (0/0) -> 0 */
+double oracle_fll_diff_atan(float p1re, float p1im, float p2re, float p2im, double t1, double t2)
+{
+    double d = atanf(p2im / p2re) - atanf(p1im / p1re);
+    if (isnan(d)) d = 0.0;
+    return phase_unwrap(d) / (t2 - t1);
+}
+
+/* T/tracking_discriminators.cc:86-89 (gr::fast_atan2f -> atan2f, see the header of this file) */
+double oracle_pll_four_quadrant_atan(float re, float im) { return (double)atan2f(im, re); }
+
+/* T/tracking_discriminators.cc:99-106 */
+double oracle_pll_cloop_two_quadrant_atan(float re, float im)
+{
+    if (re != 0.0) return (double)atanf(im / re);  /* std::atan(float): the float overload */
+    return 0.0;
+}
+
+static double cabs_f(float re, float im) { return (double)hypotf(re, im); }
+
+/* T/tracking_discriminators.cc:117-127: std::abs(gr_complex) is a float hypot, widened to double */
+double oracle_dll_nc_e_minus_l_normalized(float ere, float eim, float lre, float lim, float spc, float slope, float y_intercept)
+{
+    const double pe = cabs_f(ere, eim);
+    const double pl = cabs_f(lre, lim);
+    const double s = pe + pl;
+    if (s == 0.0) return 0.0;
+    return ((y_intercept - slope * spc) / slope) * (pe - pl) / s;
+}
+
+/* T/tracking_discriminators.cc:139-149: float sums of squares, float sqrt, widened to double */
+double oracle_dll_nc_vemlp_normalized(float vere, float veim, float ere, float eim, float lre, float lim, float vlre, float vlim)
+{
+    const double early = sqrtf(vere * vere + veim * veim + ere * ere + eim * eim);
+    const double late = sqrtf(lre * lre + lim * lim + vlre * vlre + vlim * vlim);
+    const double s = early + late;
+    if (s == 0.0) return 0.0;
+    return (early - late) / s;
+}
+
+/* ---- Tracking_loop_filter (T/tracking_loop_filter.cc): bilinear-transform loop of order 1..3 ---------------- */
+#define HIST 4 /* MAX_LOOP_HISTORY_LENGTH, :31 */
+
+/* update_coefficients, T/tracking_loop_filter.cc:101-196 (Kaplan & Hegarty table 5.6).  The float / double mix of
+ * every expression is the reference's: products of float gains stay float, divisions by the literal 2.0 widen. */
+void oracle_loop_filter_design(oracle_loop_filter* f, float update_interval, float noise_bandwidth, int order, int include_last_integrator)
+{
+    memset(f, 0, sizeof(*f));
+    f->order = order;
+    f->last_integrator = include_last_integrator;
+    const float T = update_interval;
+    const float zeta = 1.0F / sqrtf(2.0F);
+    float g1, g2, g3, wn;
+    switch (order)
+        {
+        case 1:
+            wn = noise_bandwidth * 4.0F;
+            g1 = wn;
+            if (include_last_integrator)
+                {
+                    f->n_in = 2;
+                    f->in_c[0] = (float)(g1 * T / 2.0);
+                    f->in_c[1] = (float)(g1 * T / 2.0);
+                    f->n_out = 1;
+                    f->out_c[0] = 1.0F;
+                }
+            else
+                {
+                    f->n_in = 1;
+                    f->in_c[0] = g1;
+                    f->n_out = 0;
+                }
+            break;
+        case 2:
+            wn = noise_bandwidth * (8.0F * zeta) / (4.0F * zeta * zeta + 1.0F);
+            g1 = wn * wn;
+            g2 = wn * 2.0F * zeta;
+            if (include_last_integrator)
+                {
+                    f->n_in = 3;
+                    f->in_c[0] = (float)(T / 2.0 * (g1 * T / 2.0 + g2));
+                    f->in_c[1] = (float)(T * T / 2.0 * g1);
+                    f->in_c[2] = (float)(T / 2.0 * (g1 * T / 2.0 - g2));
+                    f->n_out = 2;
+                    f->out_c[0] = 2.0F;
+                    f->out_c[1] = -1.0F;
+                }
+            else
+                {
+                    f->n_in = 2;
+                    f->in_c[0] = (float)(g1 * T / 2.0 + g2);
+                    f->in_c[1] = (float)(g1 * T / 2.0 - g2);
+                    f->n_out = 1;
+                    f->out_c[0] = 1.0F;
+                }
+            break;
+        default:
+            {
+                wn = noise_bandwidth / 0.7845F;
+                const float a3 = 1.1;
+                const float b3 = 2.4;
+                g1 = wn * wn * wn;
+                g2 = a3 * wn * wn;
+                g3 = b3 * wn;
+                if (include_last_integrator)
+                    {
+                        f->n_in = 4;
+                        f->in_c[0] = (float)(T / 2.0 * (g3 + T / 2.0 * (g2 + T / 2.0 * g1)));
+                        f->in_c[1] = (float)(T / 2.0 * (-g3 + T / 2.0 * (g2 + 3.0 * T / 2.0 * g1)));
+                        f->in_c[2] = (float)(T / 2.0 * (-g3 - T / 2.0 * (g2 - 3.0 * T / 2.0 * g1)));
+                        f->in_c[3] = (float)(T / 2.0 * (g3 - T / 2.0 * (g2 - T / 2.0 * g1)));
+                        f->n_out = 3;
+                        f->out_c[0] = 3.0F;
+                        f->out_c[1] = -3.0F;
+                        f->out_c[2] = 1.0F;
+                    }
+                else
+                    {
+                        f->n_in = 3;
+                        f->in_c[0] = (float)(g3 + T / 2.0 * (g2 + T / 2.0 * g1));
+                        f->in_c[1] = (float)(g1 * T * T / 2.0 - 2.0 * g3);
+                        f->in_c[2] = (float)(g3 + T / 2.0 * (-g2 + T / 2.0 * g1));
+                        f->n_out = 2;
+                        f->out_c[0] = 2.0F;
+                        f->out_c[1] = -1.0F;
+                    }
+            }
+            break;
+        }
+    oracle_loop_filter_initialize(f, 0.0F);
+}
+
+/* initialize, T/tracking_loop_filter.cc:266-271 */
+void oracle_loop_filter_initialize(oracle_loop_filter* f, float initial_output)
+{
+    for (int i = 0; i < HIST; i++)
+        {
+            f->in_h[i] = 0.0F;
+            f->out_h[i] = initial_output;
+        }
+    f->idx = HIST - 1;
+}
+
+/* apply, T/tracking_loop_filter.cc:63-98: old outputs first, then move the ring index, then the inputs */
+float oracle_loop_filter_apply(oracle_loop_filter* f, float x)
+{
+    float r = 0.0F;
+    for (int i = 0; i < f->n_out; i++) r += f->out_c[i] * f->out_h[(f->idx + i) % HIST];
+    f->idx--;
+    if (f->idx < 0) f->idx += HIST;
+    f->in_h[f->idx] = x;
+    for (int i = 0; i < f->n_in; i++) r += f->in_c[i] * f->in_h[(f->idx + i) % HIST];
+    f->out_h[f->idx] = r;
+    return r;
+}
+
+/* ---- Tracking_FLL_PLL_filter (T/tracking_FLL_PLL_filter.cc): Kaplan 2nd ed. FLL-assisted PLL ------------------ */
+/* set_params :23-54 */
+void oracle_fll_pll_design(oracle_fll_pll_filter* f, float fll_bw_hz, float pll_bw_hz, int order)
+{
+    memset(f, 0, sizeof(*f));
+    f->order = order;
+    if (order == 3)
+        {
+            f->b3 = 2.400;
+            f->a3 = 1.100;
+            f->a2 = 1.414;
+            f->w0p = pll_bw_hz / 0.7845F;
+            f->w0p2 = f->w0p * f->w0p;
+            f->w0p3 = f->w0p2 * f->w0p;
+            f->w0f = fll_bw_hz / 0.53F;
+            f->w0f2 = f->w0f * f->w0f;
+        }
+    else
+        {
+            f->a2 = 1.414;
+            f->w0p = pll_bw_hz / 0.53F;
+            f->w0p2 = f->w0p * f->w0p;
+            f->w0f = fll_bw_hz / 0.25F;
+        }
+}
+
+/* initialize :57-69 */
+void oracle_fll_pll_initialize(oracle_fll_pll_filter* f, float acq_carrier_doppler_hz)
+{
+    if (f->order == 3)
+        {
+            f->x = 2.0F * acq_carrier_doppler_hz;
+            f->w = 0;
+        }
+    else
+        {
+            f->w = acq_carrier_doppler_hz;
+            f->x = 0;
+        }
+}
+
+/* get_carrier_error :72-99 */
+float oracle_fll_pll_carrier_error(oracle_fll_pll_filter* f, float fll_disc, float pll_disc, float t)
+{
+    float out;
+    if (f->order == 3)
+        {
+            f->w = f->w + t * (f->w0p3 * pll_disc + f->w0f2 * fll_disc);
+            f->x = f->x + t * (0.5F * f->w + f->a2 * f->w0f * fll_disc + f->a3 * f->w0p2 * pll_disc);
+            out = 0.5F * f->x + f->b3 * f->w0p * pll_disc;
+        }
+    else
+        {
+            const float w_new = f->w + pll_disc * f->w0p2 * t + fll_disc * f->w0f * t;
+            out = 0.5F * (w_new + f->w) + f->a2 * f->w0p * pll_disc;
+            f->w = w_new;
+        }
+    return out;
+}
+
+/* ---- the closed loop of one channel -------------------------------------------------------------------------
+ * trk.cc state 2 (:1975-2001) per code period: do_correlation_step (:1232-1257) -> accumulators (:1978-1985)
+ * -> run_dll_pll (:1260-1347) -> update_tracking_vars (:1409-1483) -> consume d_current_prn_length_samples (:2287),
+ * initial conditions of start_tracking (:796-866) and of the pull-in state (:1949-1964).
+ * Not modelled (out of this row): bit / secondary-code synchronisation, extended integration, lock detectors,
+ * the experimental Doppler correction (:1326-1346), high_dyn smoothing (:1425-1443).
+ */
+int oracle_trk_run(const oracle_trk_conf* c, const float* code, const float* data_code, int code_len, const float* stream_iq,
+    uint64_t n_stream, uint64_t start_sample, uint64_t acq_sample_stamp, double acq_carrier_doppler_hz, int n_epochs,
+    oracle_trk_epoch* rec)
+{
+    const int n_taps = c->veml ? 5 : 3;
+    const int prompt = c->veml ? 2 : 1;
+    float shifts[5] = {0, 0, 0, 0, 0};
+    const float spcf = (float)c->code_samples_per_chip;
+    if (c->veml)  /* trk.cc:829-835 */
+        {
+            shifts[0] = -c->very_early_late_space_chips * spcf;
+            shifts[1] = -c->early_late_space_chips * spcf;
+            shifts[3] = c->early_late_space_chips * spcf;
+            shifts[4] = c->very_early_late_space_chips * spcf;
+        }
+    else
+        {
+            shifts[0] = -c->early_late_space_chips * spcf;
+            shifts[2] = c->early_late_space_chips * spcf;
+        }
+    const float zero_shift[1] = {0.0F};
+    const double code_period = (double)c->code_length_chips / c->code_chip_rate;  /* d_code_period */
+    oracle_loop_filter dll;
+    oracle_fll_pll_filter pll;
+    oracle_loop_filter_design(&dll, (float)code_period, c->dll_bw_hz, c->dll_filter_order, 0);  /* trk.cc:604, 845-846 */
+    oracle_fll_pll_design(&pll, c->fll_bw_hz, c->pll_bw_hz, c->pll_filter_order);                 /* trk.cc:605, 844 */
+    oracle_fll_pll_initialize(&pll, (float)acq_carrier_doppler_hz);                               /* trk.cc:848 */
+    oracle_loop_filter_initialize(&dll, 0.0F);                                                    /* trk.cc:849 */
+
+    /* start_tracking :803-826 + pull-in :1956-1958 */
+    double carrier_doppler_hz = acq_carrier_doppler_hz;
+    double carrier_phase_step_rad = ORA_TWO_PI * carrier_doppler_hz / c->fs_in;
+    double code_freq_chips = c->code_chip_rate;
+    double code_phase_step_chips = code_freq_chips / c->fs_in;
+    double rem_code_phase_samples = 0.0, rem_code_phase_chips = 0.0, acc_carrier_phase_rad = 0.0;
+    float rem_carr_phase_rad = 0.0F;
+    float p_old_re = 0.0F, p_old_im = 0.0F;  /* d_P_accu_old */
+    const double corr_time = code_period;    /* d_current_correlation_time_s, trk.cc:841 */
+    uint64_t pos = start_sample;
+
+    for (int e = 0; e < n_epochs; e++)
+        {
+            if (pos + c->vector_length > n_stream) return e;
+            oracle_trk_epoch* r = &rec[e];
+            memset(r, 0, sizeof(*r));
+            /* trk.cc:1912-1915: pull-in ends once more than pull_in_time_s whole seconds have passed since acquisition */
+            const int pull_in = !((uint64_t)c->pull_in_time_s < (pos - acq_sample_stamp) / (uint64_t)((int)c->fs_in));
+            float out[16];
+            /* do_correlation_step, trk.cc:1232-1257 (rate terms are 0 outside high_dyn) */
+            const float rem_code = (float)rem_code_phase_chips * spcf;
+            const float code_step = (float)code_phase_step_chips * spcf;
+            oracle_mcorr(code, code_len, shifts, n_taps, stream_iq + 2 * pos, (int)c->vector_length, rem_carr_phase_rad,
+                (float)carrier_phase_step_rad, 0.0F, rem_code, code_step, 0.0F * spcf, 0, out);
+            memcpy(r->corr, out, sizeof(float) * 2 * n_taps);
+            if (c->track_pilot && data_code)
+                {
+                    float pd[2];
+                    oracle_mcorr(data_code, code_len, zero_shift, 1, stream_iq + 2 * pos, (int)c->vector_length, rem_carr_phase_rad,
+                        (float)carrier_phase_step_rad, 0.0F, rem_code, code_step, 0.0F * spcf, 0, pd);
+                    r->prompt_data[0] = pd[0];
+                    r->prompt_data[1] = pd[1];
+                }
+            const float* P = out + 2 * prompt;
+            const float* E = out + 2 * (prompt - 1);
+            const float* L = out + 2 * (prompt + 1);
+
+            /* run_dll_pll, trk.cc:1260-1324 */
+            double carr_phase_error_hz, carr_freq_error_hz = 0.0;
+            float carr_error_filt;
+            if (c->cloop)
+                carr_phase_error_hz = oracle_pll_cloop_two_quadrant_atan(P[0], P[1]) / ORA_TWO_PI;
+            else
+                carr_phase_error_hz = oracle_pll_four_quadrant_atan(P[0], P[1]) / ORA_TWO_PI;
+            if ((pull_in && c->enable_fll_pull_in) || c->enable_fll_steady_state)
+                {
+                    carr_freq_error_hz = oracle_fll_diff_atan(p_old_re, p_old_im, P[0], P[1], 0, corr_time) / ORA_TWO_PI;
+                    p_old_re = P[0];
+                    p_old_im = P[1];
+                    if (pull_in && c->enable_fll_pull_in)
+                        carr_error_filt = oracle_fll_pll_carrier_error(&pll, (float)carr_freq_error_hz, 0.0F, (float)corr_time);
+                    else
+                        carr_error_filt = oracle_fll_pll_carrier_error(&pll, (float)carr_freq_error_hz, (float)carr_phase_error_hz, (float)corr_time);
+                }
+            else
+                {
+                    carr_error_filt = oracle_fll_pll_carrier_error(&pll, 0, (float)carr_phase_error_hz, (float)corr_time);
+                }
+            const double carr_error_filt_hz = carr_error_filt;
+            carrier_doppler_hz = carr_error_filt_hz;
+            double code_error_chips;
+            if (c->veml)
+                code_error_chips = oracle_dll_nc_vemlp_normalized(out[0], out[1], out[2], out[3], out[6], out[7], out[8], out[9]);
+            else
+                code_error_chips = oracle_dll_nc_e_minus_l_normalized(E[0], E[1], L[0], L[1], c->spc, c->slope, c->y_intercept);
+            const double code_error_filt_chips = oracle_loop_filter_apply(&dll, (float)code_error_chips);
+            code_freq_chips = c->code_chip_rate - code_error_filt_chips;
+            if (c->carrier_aiding) code_freq_chips += carrier_doppler_hz * c->code_chip_rate / c->signal_carrier_freq;
+
+            /* update_tracking_vars, trk.cc:1409-1483 */
+            const double t_chip = 1.0 / code_freq_chips;
+            const double t_prn = t_chip * (double)c->code_length_chips;
+            const double t_prn_samples = t_prn * c->fs_in;
+            const double k_blk = t_prn_samples + rem_code_phase_samples;
+            const int32_t prn_len = (int32_t)floor(k_blk);
+            carrier_phase_step_rad = ORA_TWO_PI * (carrier_doppler_hz + c->cfo_frequency_hz) / c->fs_in;
+            rem_carr_phase_rad += (float)(carrier_phase_step_rad * (double)prn_len + 0.5 * 0.0 * (double)prn_len * (double)prn_len);
+            rem_carr_phase_rad = (float)fmod(rem_carr_phase_rad, ORA_TWO_PI);
+            acc_carrier_phase_rad -= (carrier_phase_step_rad * (double)prn_len + 0.5 * 0.0 * (double)prn_len * (double)prn_len);
+            code_phase_step_chips = code_freq_chips / c->fs_in;
+            rem_code_phase_samples = k_blk - (double)prn_len;
+            rem_code_phase_chips = code_freq_chips * rem_code_phase_samples / c->fs_in;
+
+            r->sample_counter = pos;
+            r->prn_length_samples = prn_len;
+            r->flags = pull_in ? 1 : 0;
+            r->carrier_doppler_hz = carrier_doppler_hz;
+            r->code_freq_chips = code_freq_chips;
+            r->carr_phase_error_hz = carr_phase_error_hz;
+            r->carr_freq_error_hz = carr_freq_error_hz;
+            r->carr_error_filt_hz = carr_error_filt_hz;
+            r->code_error_chips = code_error_chips;
+            r->code_error_filt_chips = code_error_filt_chips;
+            r->rem_code_phase_samples = rem_code_phase_samples;
+            r->acc_carrier_phase_rad = acc_carrier_phase_rad;
+            r->rem_carr_phase_rad = rem_carr_phase_rad;
+            pos += (uint64_t)prn_len;
+        }
+    return n_epochs;
+}

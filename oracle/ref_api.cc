@@ -14,6 +14,9 @@
  * (bench.py cpu_baseline, kind "reference").
  */
 #include "cpu_multicorrelator_real_codes.h"
+#include "tracking_FLL_PLL_filter.h"
+#include "tracking_discriminators.h"
+#include "tracking_loop_filter.h"
 #include "galileo_e1_signal_replica.h"
 #include "gps_l5_signal_replica.h"
 #include "gps_sdr_signal_replica.h"
@@ -228,5 +231,38 @@ extern "C"
     void ref_gps_l5q_code_gen_float(float* dest, unsigned int prn)
     {
         gps_l5q_code_gen_float(own::span<float>(dest, 10230), prn);
+    }
+
+    /* ---- loop closure: discriminators (tracking_discriminators.cc) and loop filters, the reference's own objects ---- */
+    double ref_fll_diff_atan(float p1re, float p1im, float p2re, float p2im, double t1, double t2)
+    {
+        return fll_diff_atan(gr_complex(p1re, p1im), gr_complex(p2re, p2im), t1, t2);
+    }
+    double ref_pll_four_quadrant_atan(float re, float im) { return pll_four_quadrant_atan(gr_complex(re, im)); }
+    double ref_pll_cloop_two_quadrant_atan(float re, float im) { return pll_cloop_two_quadrant_atan(gr_complex(re, im)); }
+    double ref_dll_nc_e_minus_l_normalized(float ere, float eim, float lre, float lim, float spc, float slope, float y_intercept)
+    {
+        return dll_nc_e_minus_l_normalized(gr_complex(ere, eim), gr_complex(lre, lim), spc, slope, y_intercept);
+    }
+    double ref_dll_nc_vemlp_normalized(float vere, float veim, float ere, float eim, float lre, float lim, float vlre, float vlim)
+    {
+        return dll_nc_vemlp_normalized(gr_complex(vere, veim), gr_complex(ere, eim), gr_complex(lre, lim), gr_complex(vlre, vlim));
+    }
+    /* Tracking_loop_filter: construct, initialize(initial_output), apply n inputs */
+    void ref_loop_filter_run(float update_interval, float noise_bandwidth, int order, int include_last_integrator, float initial_output,
+        const float* in, float* out, int n)
+    {
+        Tracking_loop_filter f(update_interval, noise_bandwidth, order, include_last_integrator != 0);
+        f.initialize(initial_output);
+        for (int i = 0; i < n; i++) out[i] = f.apply(in[i]);
+    }
+    /* Tracking_FLL_PLL_filter: set_params, initialize(doppler), n get_carrier_error calls */
+    void ref_fll_pll_filter_run(float fll_bw_hz, float pll_bw_hz, int order, float acq_doppler_hz, const float* fll_disc,
+        const float* pll_disc, float correlation_time_s, float* out, int n)
+    {
+        Tracking_FLL_PLL_filter f;
+        f.set_params(fll_bw_hz, pll_bw_hz, order);
+        f.initialize(acq_doppler_hz);
+        for (int i = 0; i < n; i++) out[i] = f.get_carrier_error(fll_disc[i], pll_disc[i], correlation_time_s);
     }
 }

@@ -81,6 +81,32 @@ def main():
     full["l5q"] = np.packbits(l5q > 0, axis=1)
     np.savez_compressed(os.path.join(HERE, "codes_e1_l5.npz"), **full)
 
+    # ---- loop closure: discriminators, loop filters (the reference's own objects) ----------------------------
+    if hasattr(R, "ref_fll_diff_atan"):
+        rl = np.random.default_rng(20260923)
+        v = (rl.standard_normal((64, 8)) * 1000.0).astype(np.float32)
+        v[0] = 0.0
+        v[1, 0] = 0.0
+        outs = np.array([[R.ref_pll_cloop_two_quadrant_atan(*map(float, r[:2])), R.ref_fll_diff_atan(*map(float, r[:4]), 0.0, 0.001),
+                          R.ref_dll_nc_e_minus_l_normalized(*map(float, r[:4]), 0.5, 1.0, 1.0), R.ref_dll_nc_vemlp_normalized(*map(float, r))]
+                         for r in v])
+        loop = {"disc_inputs": v, "disc_outputs": outs}
+        lf_in = rl.standard_normal(100).astype(np.float32)
+        loop["lf_in"] = lf_in
+        for order in (1, 2, 3):
+            for last in (0, 1):
+                o = np.zeros(len(lf_in), np.float32)
+                R.ref_loop_filter_run(0.001, 2.0, order, last, 0.0, lf_in, o, len(lf_in))
+                loop[f"lf_out_{order}_{last}"] = o
+        fp_fll = (rl.standard_normal(100) * 3).astype(np.float32)
+        fp_pll = (rl.standard_normal(100) * 0.05).astype(np.float32)
+        loop["fp_fll"], loop["fp_pll"] = fp_fll, fp_pll
+        for order in (2, 3):
+            o = np.zeros(100, np.float32)
+            R.ref_fll_pll_filter_run(35.0, 35.0, order, 1500.0, fp_fll, fp_pll, 0.001, o, 100)
+            loop[f"fp_out_{order}"] = o
+        np.savez_compressed(os.path.join(HERE, "loop.npz"), **loop)
+
     # ---- multicorrelator known answers ----------------------------------------------------------------
     rng = np.random.default_rng(20260922)
     cases = {}

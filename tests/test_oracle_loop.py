@@ -1,0 +1,122 @@
+"""CPU tests of the loop-closure oracle (oracle/gnss_oracle_loop.c) -- discriminators, Tracking_loop_filter,
+Tracking_FLL_PLL_filter and the closed DLL/PLL loop -- against
+  * the known answers of the reference's own unit tests
+    (tests/unit-tests/signal-processing-blocks/tracking/tracking_loop_filter_test.cc:22-206, discriminator_test.cc:35-85),
+  * the reference's own objects compiled into oracle/_ref (exact equality; skipped where _ref is absent),
+  * golden vectors minted from those objects (tests/golden/loop.npz, tests/golden/make_golden.py).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from helpers import synth_gps_l1_stream
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+# ---- tracking_loop_filter_test.cc: impulse responses, bandwidth 5 Hz, T = 1 ms ----------------------------------
+@pytest.mark.parametrize("order,last,expected,tol", [
+    (1, False, [0.0, 0.0, 20.0, 0.0, 0.0, 0.0], 1e-5),                                # :44-52 (result == input * g1)
+    (1, True, [0.0, 0.0, 0.01, 0.02, 0.02, 0.02], 1e-4),                              # :72-82
+    (2, False, [0.0, 0.0, 13.37778, 0.0889, 0.0889, 0.0889], 1e-4),                   # :102-112
+    (2, True, [0.0, 0.0, 0.006689, 0.013422, 0.013511, 0.013600], 1e-4),              # :132-142
+    (3, False, [0.0, 0.0, 15.31877, 0.04494, 0.04520, 0.04546], 1e-4),                # :162-172
+    (3, True, [0.0, 0.0, 0.007659, 0.015341, 0.015386, 0.015432], 1e-4),              # :192-202
+])
+def test_loop_filter_reference_known_answers(order, last, expected, tol):
+    out = oracle.loop_filter_run(0.001, 5.0, order, last, 0.0, [0.0, 0.0, 1.0, 0.0, 0.0, 0.0])
+    assert np.allclose(out, expected, atol=tol), (order, last, out)
+
+
+def _bpsk_corr(tau):  # discriminator_test.cc:23-32
+    return max(0.0, 1.0 - abs(tau))
+
+
+def test_dll_discriminator_reference_known_answers():
+    """DllNcEMinusLNormalizedTest.Bpsk (discriminator_test.cc:35-69): the discriminator returns the code error"""
+    L = oracle.lib()
+    for a in (1 + 0j, -1 + 0j, 1j, 1 + 1j):
+        for spacing in (0.5, 0.25, 0.1, 0.01):
+            for err in (0.0, 0.01, 0.1, 0.25, -0.25, -0.1, -0.01):
+                e = np.complex64(a * np.float32(_bpsk_corr(err - spacing)))
+                l = np.complex64(a * np.float32(_bpsk_corr(err + spacing)))
+                d = L.oracle_dll_nc_e_minus_l_normalized(e.real, e.imag, l.real, l.imag, spacing, 1.0, 1.0)
+                if abs(err) < 2.0 * spacing:
+                    assert abs(d - err) < 1e-4, (a, spacing, err, d)
+                else:
+                    assert err * d >= 0.0
+
+
+@pytest.mark.skipif(oracle.ref() is None or not hasattr(oracle.ref(), "ref_fll_diff_atan"), reason="oracle/_ref without loop objects")
+def test_loop_oracle_equals_live_reference():
+    L, R = oracle.lib(), oracle.ref()
+    rng = np.random.default_rng(11)
+    v = rng.standard_normal((200, 8)).astype(np.float32) * np.float32(1000.0)
+    v[0, :] = 0.0          # zero prompt / zero early+late
+    v[1, 0] = 0.0          # I = 0: Costas discriminator returns 0, FLL sees a NaN
+    for row in v:
+        a = [float(t) for t in row]
+        assert L.oracle_pll_cloop_two_quadrant_atan(a[0], a[1]) == R.ref_pll_cloop_two_quadrant_atan(a[0], a[1])
+        assert L.oracle_pll_four_quadrant_atan(a[0], a[1]) == R.ref_pll_four_quadrant_atan(a[0], a[1])
+        assert L.oracle_fll_diff_atan(a[0], a[1], a[2], a[3], 0.0, 0.001) == R.ref_fll_diff_atan(a[0], a[1], a[2], a[3], 0.0, 0.001)
+        assert L.oracle_dll_nc_e_minus_l_normalized(a[0], a[1], a[2], a[3], 0.5, 1.0, 1.0) == R.ref_dll_nc_e_minus_l_normalized(a[0], a[1], a[2], a[3], 0.5, 1.0, 1.0)
+        assert L.oracle_dll_nc_e_minus_l_normalized(a[0], a[1], a[2], a[3], 0.15, -2.9, 1.2) == R.ref_dll_nc_e_minus_l_normalized(a[0], a[1], a[2], a[3], 0.15, -2.9, 1.2)
+        assert L.oracle_dll_nc_vemlp_normalized(*a) == R.ref_dll_nc_vemlp_normalized(*a)
+    x = rng.standard_normal(300).astype(np.float32)
+    for order in (1, 2, 3):
+        for last in (0, 1):
+            for bw, T, init in ((2.0, 0.001, 0.0), (5.0, 0.004, 0.3), (0.75, 0.02, -1.5)):
+                out = np.zeros(len(x), np.float32)
+                R.ref_loop_filter_run(T, bw, order, last, init, x, out, len(x))
+                assert np.array_equal(out, oracle.loop_filter_run(T, bw, order, last, init, x)), (order, last, bw)
+    fd = (rng.standard_normal(300) * 3).astype(np.float32)
+    pd = (rng.standard_normal(300) * 0.05).astype(np.float32)
+    for order in (2, 3):
+        for fll, pll, dop, T in ((35.0, 35.0, 1234.5, 0.001), (10.0, 5.0, -3000.0, 0.004), (0.0, 15.0, 0.0, 0.02)):
+            out = np.zeros(len(fd), np.float32)
+            R.ref_fll_pll_filter_run(fll, pll, order, dop, fd, pd, T, out, len(fd))
+            assert np.array_equal(out, oracle.fll_pll_filter_run(fll, pll, order, dop, fd, pd, T)), (order, fll, pll)
+
+
+def test_loop_oracle_matches_golden():
+    z = np.load(os.path.join(HERE, "golden", "loop.npz"))
+    L = oracle.lib()
+    v = z["disc_inputs"]
+    got = np.array([[L.oracle_pll_cloop_two_quadrant_atan(*map(float, r[:2])), L.oracle_fll_diff_atan(*map(float, r[:4]), 0.0, 0.001),
+                     L.oracle_dll_nc_e_minus_l_normalized(*map(float, r[:4]), 0.5, 1.0, 1.0), L.oracle_dll_nc_vemlp_normalized(*map(float, r))]
+                    for r in v])
+    assert np.array_equal(got, z["disc_outputs"])
+    for key in [k for k in z.files if k.startswith("lf_out_")]:
+        _, _, order, last = key.split("_")
+        assert np.array_equal(oracle.loop_filter_run(0.001, 2.0, int(order), int(last), 0.0, z["lf_in"]), z[key]), key
+    for key in [k for k in z.files if k.startswith("fp_out_")]:
+        order = int(key.split("_")[2])
+        assert np.array_equal(oracle.fll_pll_filter_run(35.0, 35.0, order, 1500.0, z["fp_fll"], z["fp_pll"], 0.001), z[key]), key
+
+
+def test_closed_loop_locks_onto_a_synthetic_signal():
+    """A GPS L1 C/A signal at 47 dB-Hz, 1.2 kHz Doppler, handed over with acquisition errors of 20 Hz and 0.2 chip: the
+    loop must pull in (mean Doppler within 1 Hz, prompt energy near A*N, mean code error below 0.06 chip) and stay
+    there, for the 3rd- and 2nd-order carrier filters and with the FLL pull-in."""
+    fs, n, epochs = 4e6, 4000, 500
+    fd, cph = 1200.0, 417.3
+    x = synth_gps_l1_stream(epochs * n + 2 * n, fs, [9], [fd], [cph], cn0_dbhz=47.0, seed_noise=21)
+    f_code = 1.023e6 * (1 + fd / 1575.42e6)
+    start_exact = (1023.0 - cph) / f_code * fs
+    start = int(round(start_exact + 0.2 * fs / 1.023e6))  # 0.2 chip late
+    amp = np.sqrt(10 ** 4.7 * 2.0 / fs) * n
+    for kw in (dict(), dict(pll_filter_order=2), dict(enable_fll_pull_in=1, pull_in_time_s=0)):
+        conf = oracle.trk_conf(fs_in=fs, vector_length=n, pll_bw_hz=35.0, dll_bw_hz=4.0, **kw)
+        rec = oracle.trk_run(conf, oracle.ca_code(9), x, start, 0, fd - 20.0, epochs)
+        assert len(rec) == epochs
+        tail = rec[-100:]
+        assert abs(np.mean([r.carrier_doppler_hz for r in tail]) - fd) < 1.0, kw
+        p = np.array([complex(r.corr[2], r.corr[3]) for r in tail])
+        assert np.mean(np.abs(p)) > 0.9 * amp, kw
+        assert abs(np.mean([r.code_error_chips for r in tail])) < 0.06, kw
+        # window positions advance by one code period (+-1 sample) and follow the code Doppler
+        steps = np.diff([r.sample_counter for r in rec])
+        assert set(np.unique(steps)) <= {3999, 4000, 4001}
+        assert rec[0].flags == 1  # pull-in transitory: less than pull_in_time_s whole seconds since acquisition
