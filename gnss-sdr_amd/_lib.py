@@ -62,6 +62,31 @@ class AcqConf(C.Structure):
     ]
 
 
+class TrkConf(C.Structure):
+    """gsh_trk_conf."""
+    _fields_ = [
+        ("fs_in", C.c_double), ("code_chip_rate", C.c_double), ("signal_carrier_freq", C.c_double), ("cfo_frequency_hz", C.c_double),
+        ("code_length_chips", C.c_uint32), ("code_samples_per_chip", C.c_uint32), ("vector_length", C.c_uint32),
+        ("veml", C.c_int32), ("track_pilot", C.c_int32),
+        ("early_late_space_chips", C.c_float), ("very_early_late_space_chips", C.c_float),
+        ("pll_bw_hz", C.c_float), ("dll_bw_hz", C.c_float), ("fll_bw_hz", C.c_float),
+        ("pll_filter_order", C.c_int32), ("dll_filter_order", C.c_int32),
+        ("enable_fll_pull_in", C.c_int32), ("enable_fll_steady_state", C.c_int32), ("carrier_aiding", C.c_int32), ("cloop", C.c_int32),
+        ("pull_in_time_s", C.c_uint32), ("spc", C.c_float), ("slope", C.c_float), ("y_intercept", C.c_float),
+    ]
+
+
+class TrkEpoch(C.Structure):
+    """gsh_trk_epoch."""
+    _fields_ = [
+        ("sample_counter", C.c_uint64), ("prn_length_samples", C.c_int32), ("flags", C.c_int32),
+        ("corr", C.c_float * 10), ("prompt_data", C.c_float * 2), ("rem_carr_phase_rad", C.c_float), ("pad_", C.c_float),
+        ("carrier_doppler_hz", C.c_double), ("code_freq_chips", C.c_double), ("carr_phase_error_hz", C.c_double),
+        ("carr_freq_error_hz", C.c_double), ("carr_error_filt_hz", C.c_double), ("code_error_chips", C.c_double),
+        ("code_error_filt_chips", C.c_double), ("rem_code_phase_samples", C.c_double), ("acc_carrier_phase_rad", C.c_double),
+    ]
+
+
 class AcqResult(C.Structure):
     """gsh_acq_result."""
     _fields_ = [
@@ -105,6 +130,13 @@ SYMBOLS = {
     "gsh_bank_read_outputs": (C.c_int, [_P, _F, C.c_int]),
     "gsh_bank_time_launches": (C.c_int, [_P, C.c_int, _F]),
     "gsh_bank_set_splits": (C.c_int, [_P, C.c_int]),
+    "gsh_trk_create": (C.c_int, [C.c_int, C.POINTER(TrkConf), C.c_int, C.c_int, C.POINTER(_P)]),
+    "gsh_trk_destroy": (None, [_P]),
+    "gsh_trk_set_stream_host": (C.c_int, [_P, _F, C.c_uint64]),
+    "gsh_trk_set_stream_device": (C.c_int, [_P, _P, C.c_uint64]),
+    "gsh_trk_start": (C.c_int, [_P, C.c_int, _F, _F, C.c_int, C.c_uint64, C.c_uint64, C.c_double]),
+    "gsh_trk_run": (C.c_int, [_P, C.c_int, C.POINTER(TrkEpoch), C.POINTER(C.c_int32)]),
+    "gsh_trk_time_run": (C.c_int, [_P, C.c_int, C.c_int, _F]),
     "gsh_acq_create": (C.c_int, [C.c_int, C.POINTER(AcqConf), C.POINTER(_P)]),
     "gsh_acq_destroy": (None, [_P]),
     "gsh_acq_set_local_code": (C.c_int, [_P, C.c_uint32, _F]),

@@ -26,272 +26,14 @@
 //   * blockIdx is remapped so that consecutive jobs (host order: epoch-major, channel-minor,
 //     i.e. jobs that read the same samples) run on the same XCD and share its L2.
 #include "multicorrelator.h"
+#include "mcorr_device.h"
 #include <cmath>
 
 namespace gsh
 {
 namespace
 {
-constexpr int MC_THREADS = 256;
-constexpr int MC_WAVES = MC_THREADS / 64;
-constexpr int MC_MARGIN = 32;  // guard entries on each side of the LDS code table
-#ifndef GSH_MC_RESEED
-#define GSH_MC_RESEED 32
-#endif
-#ifndef GSH_MC_CVT_FLR
-#define GSH_MC_CVT_FLR 1
-#endif
-constexpr int MC_RESEED = GSH_MC_RESEED;  // strides of 512 samples between exact NCO re-seeds
-constexpr int MC_PAIRS_PER_CHUNK = MC_THREADS;  // one float4 (2 samples) per thread per chunk
-constexpr double INV_TWO_PI = 0.15915494309189533576888376337251436;
-constexpr double TWO_PI_D = 6.283185307179586476925286766559;
-
-// job mode bits (gsh_corr_job::high_dyn): 0 std/std, 1 hd resampler + hd rotator,
-// 2 hd resampler + std rotator (the 6-argument overload, mcorr.cc:129-144, with the flag set)
-__host__ __device__ constexpr bool mode_hd_code(int mode) { return mode != 0; }
-__host__ __device__ constexpr bool mode_hd_phase(int mode) { return mode == 1; }
-
-__device__ __forceinline__ float2 cmul(float2 a, float2 b)
-{
-    return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x));
-}
-
-// exp(-j*phase), phase given in double radians
-__device__ __forceinline__ float2 expmj(double phase)
-{
-    double rev = phase * INV_TWO_PI;
-    rev -= rint(rev);  // [-0.5, 0.5]
-    const float r = static_cast<float>(rev * TWO_PI_D);
-    float s, c;
-    sincosf(r, &s, &c);
-    return make_float2(c, -s);
-}
-
-// carrier phase (radians, double) of sample n.
-// standard: rem + n*step (mcorr.cc:115,123: phase0 = exp(-j rem), inc = exp(-j step)).
-// high dynamics: + rate*(float)((n-1)^2) for n >= 1: the rate factor computed in iteration
-// n-1 from (unsigned)(n-1)*(n-1) is the one applied to sample n (K/..high_dynamic_rotator..:94-103).
-template <bool HDP>
-__device__ __forceinline__ double carrier_phase(float rem, float step, float rate, int n)
-{
-    double ph = static_cast<double>(rem) + static_cast<double>(n) * static_cast<double>(step);
-    if (HDP)
-        {
-            if (n > 0)
-                {
-                    const unsigned m = static_cast<unsigned>(n - 1);
-                    ph += static_cast<double>(rate) * static_cast<double>(static_cast<float>(m * m));
-                }
-        }
-    return ph;
-}
-
-// mathematical modulo, same result as K/..resampler_32f_xn.h:75-76
-__device__ __forceinline__ int wrap_chip(int k, int len)
-{
-    if (static_cast<unsigned>(k) >= static_cast<unsigned>(len))
-        {
-            k %= len;
-            if (k < 0) k += len;
-        }
-    return k;
-}
-
-// (int)floor(x) in one VALU instruction (v_cvt_flr_i32_f32: round toward -inf, then convert)
-__device__ __forceinline__ int floor_to_int(float x)
-{
-#if GSH_MC_CVT_FLR
-    int k;
-    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(k) : "v"(x));
-    return k;
-#else
-    return static_cast<int>(floorf(x));
-#endif
-}
-
-// raw (unwrapped) chip index, standard resampler: floor((step*(float)n + shift) - rem)
-__device__ __forceinline__ int raw_chip_std(float step_x_n, float shift, float rem)
-{
-    return floor_to_int(__fsub_rn(__fadd_rn(step_x_n, shift), rem));
-}
-
-// raw chip index, high-dynamics resampler tap 0 expression evaluated at sample m:
-// floor(((step*(float)m + rate*(float)(m*m)) + shift0) - rem), m*m in unsigned
-__device__ __forceinline__ int raw_chip_hd(float step, float rate, unsigned m, float shift0, float rem)
-{
-    const float a = __fmul_rn(step, static_cast<float>(m));
-    const float q = __fmul_rn(rate, static_cast<float>(m * m));
-    return floor_to_int(__fsub_rn(__fadd_rn(__fadd_rn(a, q), shift0), rem));
-}
-
-struct JobCtx
-{
-    int n_total;     // job n_samples
-    int n_begin;     // this work-group's segment [n_begin, n_end)
-    int n_end;
-    int n_first;     // sample index of pair 0's first element (n_begin or n_begin-1)
-    int code_len;
-    float rem_carr, phase_step, phase_rate;
-    float rem_code, code_step, code_rate;
-};
-
-// One chunk = 256 pairs = 512 consecutive samples; thread `tid` owns samples n0, n0+1.
-template <int NT, int MODE, bool WRAP, bool MASKED>
-__device__ __forceinline__ void process_pair(const JobCtx& c, const float2* __restrict__ base, const float* __restrict__ tab,
-    const float (&sh)[NT], const int (&rot)[NT], int pair, float2 pa, float2 pb, float2 (&acc)[NT])
-{
-    const int n0 = c.n_first + 2 * pair;
-    float2 x0, x1;
-    if (MASKED)
-        {
-            const bool v0 = (n0 >= c.n_begin) && (n0 < c.n_end);
-            const bool v1 = (n0 + 1 >= c.n_begin) && (n0 + 1 < c.n_end);
-            x0 = v0 ? base[2 * pair] : make_float2(0.0f, 0.0f);
-            x1 = v1 ? base[2 * pair + 1] : make_float2(0.0f, 0.0f);
-        }
-    else
-        {
-            const float4 v = *reinterpret_cast<const float4*>(base + 2 * pair);
-            x0 = make_float2(v.x, v.y);
-            x1 = make_float2(v.z, v.w);
-        }
-    const float2 y0 = cmul(x0, pa);
-    const float2 y1 = cmul(x1, pb);
-
-    if (!mode_hd_code(MODE))
-        {
-            const float a0 = __fmul_rn(c.code_step, static_cast<float>(n0));
-            const float a1 = __fmul_rn(c.code_step, static_cast<float>(n0 + 1));
-#pragma unroll
-            for (int t = 0; t < NT; t++)
-                {
-                    int k0 = raw_chip_std(a0, sh[t], c.rem_code);
-                    int k1 = raw_chip_std(a1, sh[t], c.rem_code);
-                    if (WRAP)
-                        {
-                            k0 = wrap_chip(k0, c.code_len);
-                            k1 = wrap_chip(k1, c.code_len);
-                        }
-                    if (MASKED)
-                        {
-                            // masked lanes may sit at n = -1 / n = n_end with any index: keep the lookup in range
-                            k0 = wrap_chip(k0, c.code_len);
-                            k1 = wrap_chip(k1, c.code_len);
-                        }
-                    const float c0 = tab[k0 + MC_MARGIN];
-                    const float c1 = tab[k1 + MC_MARGIN];
-                    acc[t].x = fmaf(y0.x, c0, acc[t].x);
-                    acc[t].y = fmaf(y0.y, c0, acc[t].y);
-                    acc[t].x = fmaf(y1.x, c1, acc[t].x);
-                    acc[t].y = fmaf(y1.y, c1, acc[t].y);
-                }
-        }
-    else
-        {
-#pragma unroll
-            for (int t = 0; t < NT; t++)
-                {
-                    // tap t is tap 0 advanced circularly by rot[t] samples (K/..high_dynamics_resampler..:84-90)
-                    int m0 = n0 + rot[t];
-                    int m1 = n0 + 1 + rot[t];
-                    if (m0 >= c.n_total) m0 -= c.n_total;
-                    if (m1 >= c.n_total) m1 -= c.n_total;
-                    if (MASKED)
-                        {
-                            if (m0 < 0) m0 = 0;
-                            if (m1 >= c.n_total) m1 = 0;
-                        }
-                    const int k0 = wrap_chip(raw_chip_hd(c.code_step, c.code_rate, static_cast<unsigned>(m0), sh[0], c.rem_code), c.code_len);
-                    const int k1 = wrap_chip(raw_chip_hd(c.code_step, c.code_rate, static_cast<unsigned>(m1), sh[0], c.rem_code), c.code_len);
-                    const float c0 = tab[k0 + MC_MARGIN];
-                    const float c1 = tab[k1 + MC_MARGIN];
-                    acc[t].x = fmaf(y0.x, c0, acc[t].x);
-                    acc[t].y = fmaf(y0.y, c0, acc[t].y);
-                    acc[t].x = fmaf(y1.x, c1, acc[t].x);
-                    acc[t].y = fmaf(y1.y, c1, acc[t].y);
-                }
-        }
-}
-
-template <int NT, int MODE, bool WRAP>
-__device__ __forceinline__ void run_segment(const JobCtx& c, const float2* __restrict__ base, const float* __restrict__ tab,
-    const float (&sh)[NT], const int (&rot)[NT], float2 (&acc)[NT])
-{
-    const int tid = threadIdx.x;
-    const int span = c.n_end - c.n_first;          // samples covered from pair 0's first element
-    const int n_pairs = (span + 1) >> 1;           // pairs touching the segment
-    const int n_full = span >> 1;                  // leading pairs whose second sample is in range
-    const int odd = c.n_begin - c.n_first;         // 1 when pair 0's first sample is outside
-    const int n_chunks = (n_pairs + MC_PAIRS_PER_CHUNK - 1) / MC_PAIRS_PER_CHUNK;
-    const int k_full_begin = odd ? 1 : 0;
-    const int k_full_end = n_full / MC_PAIRS_PER_CHUNK;  // chunks [k_full_begin, k_full_end) need no masking
-    constexpr bool HDP = mode_hd_phase(MODE);
-
-    // masked head chunk (only when the window starts on an odd absolute sample)
-    if (odd && n_chunks > 0)
-        {
-            const int pair = tid;
-            if (pair < n_pairs)
-                {
-                    const int n0 = c.n_first + 2 * pair;
-                    const float2 pa = expmj(carrier_phase<HDP>(c.rem_carr, c.phase_step, c.phase_rate, n0));
-                    const float2 pb = expmj(carrier_phase<HDP>(c.rem_carr, c.phase_step, c.phase_rate, n0 + 1));
-                    process_pair<NT, MODE, WRAP, true>(c, base, tab, sh, rot, pair, pa, pb, acc);
-                }
-        }
-
-    // unmasked body
-    if (k_full_end > k_full_begin)
-        {
-            if (HDP)
-                {
-                    // chirped carrier: no constant-stride recurrence exists, evaluate per sample
-                    for (int k = k_full_begin; k < k_full_end; k++)
-                        {
-                            const int pair = tid + k * MC_PAIRS_PER_CHUNK;
-                            const int n0 = c.n_first + 2 * pair;
-                            const float2 pa = expmj(carrier_phase<true>(c.rem_carr, c.phase_step, c.phase_rate, n0));
-                            const float2 pb = expmj(carrier_phase<true>(c.rem_carr, c.phase_step, c.phase_rate, n0 + 1));
-                            process_pair<NT, MODE, WRAP, false>(c, base, tab, sh, rot, pair, pa, pb, acc);
-                        }
-                }
-            else
-                {
-                    // stride rotator exp(-j * 512 * step) and sample rotator exp(-j * step), both seeded exactly
-                    const float2 w = expmj(static_cast<double>(2 * MC_PAIRS_PER_CHUNK) * static_cast<double>(c.phase_step));
-                    const float2 inc = expmj(static_cast<double>(c.phase_step));
-                    for (int kb = k_full_begin; kb < k_full_end; kb += MC_RESEED)
-                        {
-                            const int cnt = min(MC_RESEED, k_full_end - kb);
-                            int pair = tid + kb * MC_PAIRS_PER_CHUNK;
-                            // exact re-seed of this lane's phasor; the second sample of the pair is one step further
-                            float2 pa = expmj(carrier_phase<false>(c.rem_carr, c.phase_step, 0.0f, c.n_first + 2 * pair));
-                            float2 pb = cmul(pa, inc);
-#pragma unroll 2
-                            for (int i = 0; i < cnt; i++)
-                                {
-                                    process_pair<NT, MODE, WRAP, false>(c, base, tab, sh, rot, pair, pa, pb, acc);
-                                    pa = cmul(pa, w);
-                                    pb = cmul(pb, w);
-                                    pair += MC_PAIRS_PER_CHUNK;
-                                }
-                        }
-                }
-        }
-
-    // masked tail chunks (at most two: a partially filled chunk and, when the body was empty, chunk 0)
-    for (int k = max(k_full_end, k_full_begin); k < n_chunks; k++)
-        {
-            const int pair = tid + k * MC_PAIRS_PER_CHUNK;
-            if (pair < n_pairs)
-                {
-                    const int n0 = c.n_first + 2 * pair;
-                    const float2 pa = expmj(carrier_phase<HDP>(c.rem_carr, c.phase_step, c.phase_rate, n0));
-                    const float2 pb = expmj(carrier_phase<HDP>(c.rem_carr, c.phase_step, c.phase_rate, n0 + 1));
-                    process_pair<NT, MODE, WRAP, true>(c, base, tab, sh, rot, pair, pa, pb, acc);
-                }
-        }
-}
+using namespace mcdev;
 
 template <int NT, int MODE>
 __global__ __launch_bounds__(MC_THREADS) void mcorr_kernel(McorrArgs a)

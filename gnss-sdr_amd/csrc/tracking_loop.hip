@@ -1,0 +1,655 @@
+// DLL/PLL tracking loop closed on the device (MI355X / gfx950): gsh_trk_* of include/gnss_sdr_hip.h.
+//
+// What it replaces, per code period, in gnss-sdr's dll_pll_veml_tracking (trk.cc =
+// src/algorithms/tracking/gnuradio_blocks/dll_pll_veml_tracking.cc, T/ = src/algorithms/tracking/libs/):
+//   do_correlation_step      trk.cc:1232-1257   -> mcdev::correlate_window_std (csrc/mcorr_device.h)
+//   run_dll_pll              trk.cc:1260-1324   -> discriminators of T/tracking_discriminators.cc:27-149,
+//                                                  Tracking_FLL_PLL_filter::get_carrier_error (T/tracking_FLL_PLL_filter.cc:72-99),
+//                                                  Tracking_loop_filter::apply (T/tracking_loop_filter.cc:63-98)
+//   update_tracking_vars     trk.cc:1409-1483
+//   consume_each(d_current_prn_length_samples)  trk.cc:2287
+// The host block calls the correlator once per channel per period and runs ~100 lines of scalar loop arithmetic in
+// between; on a GPU that is one launch + one synchronisation per period.  Here ONE work-group per channel walks
+// through all the periods of a device-resident stream: 256 threads correlate the window, thread 0 then runs the loop
+// arithmetic in the reference's own float / double mix, publishes the next NCO settings through LDS, and the next
+// window starts -- no host involvement until the requested number of periods is done.  The two local replicas
+// (pilot + data for track_pilot signals) stay in LDS for the whole launch.
+#include "mcorr_device.h"
+#include <cmath>
+#include <new>
+#include <vector>
+
+namespace gsh
+{
+namespace
+{
+using namespace mcdev;
+
+// the reference's pi (GNSS ICD value, src/core/system_parameters/MATH_CONSTANTS.h:47-49)
+constexpr double GNSS_PI_D = 3.1415926535898;
+constexpr double GNSS_HALF_PI_D = GNSS_PI_D / 2.0;
+constexpr double GNSS_TWO_PI_D = 2.0 * GNSS_PI_D;
+
+struct LoopFilterState  // Tracking_loop_filter (T/tracking_loop_filter.h): coefficients + the two 4-deep rings
+{
+    float in_c[4], out_c[4];
+    float in_h[4], out_h[4];
+    int n_in, n_out, idx;
+};
+
+struct FllPllState  // Tracking_FLL_PLL_filter (T/tracking_FLL_PLL_filter.h)
+{
+    float w, x, w0p, w0p2, w0p3, w0f, w0f2, a2, a3, b3;
+    int order;
+};
+
+struct TrkChannel  // loop state of one channel, resident in device memory between launches
+{
+    double carrier_doppler_hz, carrier_phase_step_rad, code_freq_chips, code_phase_step_chips;
+    double rem_code_phase_samples, rem_code_phase_chips, acc_carrier_phase_rad;
+    unsigned long long pos, acq_stamp;
+    float rem_carr_phase_rad, p_old_re, p_old_im;
+    int active, code_len;
+    LoopFilterState dll;
+    FllPllState pll;
+};
+
+struct TrkArgs
+{
+    gsh_trk_conf conf;
+    const float2* stream;
+    unsigned long long n_stream;
+    const float* codes;       // n_channels * 2 * code_stride (pilot/primary code, then data code)
+    int code_stride;
+    TrkChannel* chan;
+    gsh_trk_epoch* records;   // n_channels * n_epochs or nullptr
+    int* epochs_done;         // n_channels
+    int n_epochs;
+};
+
+// ---- discriminators, T/tracking_discriminators.cc (float / double mix as written there) ---------------------
+__device__ __forceinline__ double phase_unwrap_d(double p)  // :27-41
+{
+    if (p >= GNSS_HALF_PI_D) return p - GNSS_PI_D;
+    if (p <= -GNSS_HALF_PI_D) return p + GNSS_PI_D;
+    return p;
+}
+__device__ __forceinline__ double fll_diff_atan_d(float2 p1, float2 p2, double t1, double t2)  // :68-76, float arctangents
+{
+    double d = atanf(p2.y / p2.x) - atanf(p1.y / p1.x);
+    if (isnan(d)) d = 0.0;
+    return phase_unwrap_d(d) / (t2 - t1);
+}
+__device__ __forceinline__ double pll_cloop_two_quadrant_atan_d(float2 p)  // :99-106
+{
+    if (p.x != 0.0f) return static_cast<double>(atanf(p.y / p.x));
+    return 0.0;
+}
+// :86-89; the reference calls gr::fast_atan2f (GNU Radio's table approximation, not vendored): exact atan2f here
+__device__ __forceinline__ double pll_four_quadrant_atan_d(float2 p) { return static_cast<double>(atan2f(p.y, p.x)); }
+__device__ __forceinline__ double dll_nc_e_minus_l_normalized_d(float2 e, float2 l, float spc, float slope, float y_intercept)  // :117-127
+{
+    const double pe = static_cast<double>(hypotf(e.x, e.y));
+    const double pl = static_cast<double>(hypotf(l.x, l.y));
+    const double s = pe + pl;
+    if (s == 0.0) return 0.0;
+    return ((y_intercept - slope * spc) / slope) * (pe - pl) / s;
+}
+__device__ __forceinline__ double dll_nc_vemlp_normalized_d(float2 ve, float2 e, float2 l, float2 vl)  // :139-149
+{
+    const double early = static_cast<double>(sqrtf(ve.x * ve.x + ve.y * ve.y + e.x * e.x + e.y * e.y));
+    const double late = static_cast<double>(sqrtf(l.x * l.x + l.y * l.y + vl.x * vl.x + vl.y * vl.y));
+    const double s = early + late;
+    if (s == 0.0) return 0.0;
+    return (early - late) / s;
+}
+
+// ---- loop filters ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float loop_filter_apply(LoopFilterState& f, float x)  // T/tracking_loop_filter.cc:63-98
+{
+    float r = 0.0f;
+    for (int i = 0; i < f.n_out; i++) r += f.out_c[i] * f.out_h[(f.idx + i) & 3];
+    f.idx = (f.idx + 3) & 3;  // d_current_index-- with wrap over MAX_LOOP_HISTORY_LENGTH = 4
+    f.in_h[f.idx] = x;
+    for (int i = 0; i < f.n_in; i++) r += f.in_c[i] * f.in_h[(f.idx + i) & 3];
+    f.out_h[f.idx] = r;
+    return r;
+}
+__device__ __forceinline__ float fll_pll_carrier_error(FllPllState& f, float fll_disc, float pll_disc, float t)  // T/tracking_FLL_PLL_filter.cc:72-99
+{
+    float out;
+    if (f.order == 3)
+        {
+            f.w = f.w + t * (f.w0p3 * pll_disc + f.w0f2 * fll_disc);
+            f.x = f.x + t * (0.5f * f.w + f.a2 * f.w0f * fll_disc + f.a3 * f.w0p2 * pll_disc);
+            out = 0.5f * f.x + f.b3 * f.w0p * pll_disc;
+        }
+    else
+        {
+            const float w_new = f.w + pll_disc * f.w0p2 * t + fll_disc * f.w0f * t;
+            out = 0.5f * (w_new + f.w) + f.a2 * f.w0p * pll_disc;
+            f.w = w_new;
+        }
+    return out;
+}
+
+struct NextWindow  // what thread 0 publishes for the next correlation (do_correlation_step's casts, trk.cc:1237-1243)
+{
+    unsigned long long pos;
+    float rem_carr, phase_step, rem_code, code_step;
+    int go;
+};
+
+__device__ __forceinline__ void publish(NextWindow& w, const TrkChannel& s, const gsh_trk_conf& c, unsigned long long n_stream, int more)
+{
+    const float spcf = static_cast<float>(c.code_samples_per_chip);
+    w.pos = s.pos;
+    w.rem_carr = s.rem_carr_phase_rad;
+    w.phase_step = static_cast<float>(s.carrier_phase_step_rad);
+    w.rem_code = __fmul_rn(static_cast<float>(s.rem_code_phase_chips), spcf);
+    w.code_step = __fmul_rn(static_cast<float>(s.code_phase_step_chips), spcf);
+    w.go = (more && s.active && s.pos + c.vector_length <= n_stream) ? 1 : 0;
+}
+
+template <int NT>
+__global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
+{
+    extern __shared__ __align__(16) float lds[];
+    __shared__ NextWindow win;
+    const int ch = blockIdx.x;
+    const int tid = threadIdx.x;
+    const gsh_trk_conf& c = a.conf;
+    TrkChannel s = a.chan[ch];  // every thread reads it; only thread 0 advances and stores it
+    const int code_len = s.code_len;
+
+    // ---- local replicas stay in LDS for the whole launch
+    float* tab = lds;
+    float* tab_data = lds + code_table_floats(code_len);
+    float2* red = reinterpret_cast<float2*>(tab_data + (c.track_pilot ? code_table_floats(code_len) : 0));
+    if (s.active)
+        {
+            stage_code_table(tab, a.codes + static_cast<size_t>(ch) * 2 * a.code_stride, code_len);
+            if (c.track_pilot) stage_code_table(tab_data, a.codes + (static_cast<size_t>(ch) * 2 + 1) * a.code_stride, code_len);
+        }
+
+    // ---- tap offsets in code samples, trk.cc:632-648 / :829-840
+    float sh[NT];
+    const float spcf = static_cast<float>(c.code_samples_per_chip);
+    if (NT == 5)
+        {
+            sh[0] = -c.very_early_late_space_chips * spcf;
+            sh[1] = -c.early_late_space_chips * spcf;
+            sh[2] = 0.0f;
+            sh[NT - 2] = c.early_late_space_chips * spcf;
+            sh[NT - 1] = c.very_early_late_space_chips * spcf;
+        }
+    else
+        {
+            sh[0] = -c.early_late_space_chips * spcf;
+            sh[1] = 0.0f;
+            sh[NT - 1] = c.early_late_space_chips * spcf;
+        }
+    const float sh_data[1] = {0.0f};
+    constexpr int PROMPT = NT / 2;
+    const double corr_time = static_cast<double>(c.code_length_chips) / c.code_chip_rate;  // d_current_correlation_time_s = d_code_period, trk.cc:841
+
+    if (tid == 0) publish(win, s, c, a.n_stream, a.n_epochs > 0);
+    __syncthreads();
+
+    int done = 0;
+    for (int e = 0; e < a.n_epochs; e++)
+        {
+            if (!win.go) break;  // uniform: win is only rewritten between the barriers below
+            const unsigned long long pos = win.pos;
+            const float rem_carr = win.rem_carr, phase_step = win.phase_step, rem_code = win.rem_code, code_step = win.code_step;
+            correlate_window_std<NT>(a.stream, pos, static_cast<int>(c.vector_length), tab, code_len, sh, rem_carr, phase_step, rem_code, code_step, red);
+            float2 out[NT];
+#pragma unroll
+            for (int t = 0; t < NT; t++) out[t] = red[t];
+            float2 pdata = make_float2(0.0f, 0.0f);
+            if (c.track_pilot)
+                {
+                    __syncthreads();  // everyone has read red[0..NT) before it is reused
+                    correlate_window_std<1>(a.stream, pos, static_cast<int>(c.vector_length), tab_data, code_len, sh_data, rem_carr, phase_step, rem_code, code_step, red);
+                    pdata = red[0];
+                }
+            __syncthreads();  // win and red have been read by everyone
+            if (tid == 0)
+                {
+                    // trk.cc:1912-1915: pull-in ends once more than pull_in_time_s whole seconds have passed since acquisition
+                    const bool pull_in = !(static_cast<unsigned long long>(c.pull_in_time_s) < (pos - s.acq_stamp) / static_cast<unsigned long long>(static_cast<int>(c.fs_in)));
+                    const float2 P = out[PROMPT], E = out[PROMPT - 1], L = out[PROMPT + 1];
+                    // ---- run_dll_pll, trk.cc:1260-1324
+                    const double carr_phase_error_hz = (c.cloop ? pll_cloop_two_quadrant_atan_d(P) : pll_four_quadrant_atan_d(P)) / GNSS_TWO_PI_D;
+                    double carr_freq_error_hz = 0.0;
+                    float carr_error_filt;
+                    if ((pull_in && c.enable_fll_pull_in) || c.enable_fll_steady_state)
+                        {
+                            carr_freq_error_hz = fll_diff_atan_d(make_float2(s.p_old_re, s.p_old_im), P, 0.0, corr_time) / GNSS_TWO_PI_D;
+                            s.p_old_re = P.x;
+                            s.p_old_im = P.y;
+                            if (pull_in && c.enable_fll_pull_in)
+                                carr_error_filt = fll_pll_carrier_error(s.pll, static_cast<float>(carr_freq_error_hz), 0.0f, static_cast<float>(corr_time));
+                            else
+                                carr_error_filt = fll_pll_carrier_error(s.pll, static_cast<float>(carr_freq_error_hz), static_cast<float>(carr_phase_error_hz), static_cast<float>(corr_time));
+                        }
+                    else
+                        {
+                            carr_error_filt = fll_pll_carrier_error(s.pll, 0.0f, static_cast<float>(carr_phase_error_hz), static_cast<float>(corr_time));
+                        }
+                    const double carr_error_filt_hz = carr_error_filt;
+                    s.carrier_doppler_hz = carr_error_filt_hz;
+                    double code_error_chips;
+                    if (NT == 5)
+                        code_error_chips = dll_nc_vemlp_normalized_d(out[0], out[1], out[NT - 2], out[NT - 1]);
+                    else
+                        code_error_chips = dll_nc_e_minus_l_normalized_d(E, L, c.spc, c.slope, c.y_intercept);
+                    const double code_error_filt_chips = loop_filter_apply(s.dll, static_cast<float>(code_error_chips));
+                    s.code_freq_chips = c.code_chip_rate - code_error_filt_chips;
+                    if (c.carrier_aiding) s.code_freq_chips += s.carrier_doppler_hz * c.code_chip_rate / c.signal_carrier_freq;
+
+                    // ---- update_tracking_vars, trk.cc:1409-1483 (rate terms are zero outside high_dyn)
+                    const double t_chip = 1.0 / s.code_freq_chips;
+                    const double t_prn = t_chip * static_cast<double>(c.code_length_chips);
+                    const double t_prn_samples = t_prn * c.fs_in;
+                    const double k_blk = t_prn_samples + s.rem_code_phase_samples;
+                    const int prn_len = static_cast<int>(floor(k_blk));
+                    s.carrier_phase_step_rad = GNSS_TWO_PI_D * (s.carrier_doppler_hz + c.cfo_frequency_hz) / c.fs_in;
+                    const double dphi = s.carrier_phase_step_rad * static_cast<double>(prn_len);
+                    s.rem_carr_phase_rad += static_cast<float>(dphi);
+                    s.rem_carr_phase_rad = static_cast<float>(fmod(static_cast<double>(s.rem_carr_phase_rad), GNSS_TWO_PI_D));
+                    s.acc_carrier_phase_rad -= dphi;
+                    s.code_phase_step_chips = s.code_freq_chips / c.fs_in;
+                    s.rem_code_phase_samples = k_blk - static_cast<double>(prn_len);
+                    s.rem_code_phase_chips = s.code_freq_chips * s.rem_code_phase_samples / c.fs_in;
+
+                    if (a.records != nullptr)
+                        {
+                            gsh_trk_epoch r;
+                            r.sample_counter = pos;
+                            r.prn_length_samples = prn_len;
+                            r.flags = pull_in ? 1 : 0;
+#pragma unroll
+                            for (int t = 0; t < 5; t++)
+                                {
+                                    r.corr[2 * t] = (t < NT) ? out[t < NT ? t : 0].x : 0.0f;
+                                    r.corr[2 * t + 1] = (t < NT) ? out[t < NT ? t : 0].y : 0.0f;
+                                }
+                            r.prompt_data[0] = pdata.x;
+                            r.prompt_data[1] = pdata.y;
+                            r.rem_carr_phase_rad = s.rem_carr_phase_rad;
+                            r.pad_ = 0.0f;
+                            r.carrier_doppler_hz = s.carrier_doppler_hz;
+                            r.code_freq_chips = s.code_freq_chips;
+                            r.carr_phase_error_hz = carr_phase_error_hz;
+                            r.carr_freq_error_hz = carr_freq_error_hz;
+                            r.carr_error_filt_hz = carr_error_filt_hz;
+                            r.code_error_chips = code_error_chips;
+                            r.code_error_filt_chips = code_error_filt_chips;
+                            r.rem_code_phase_samples = s.rem_code_phase_samples;
+                            r.acc_carrier_phase_rad = s.acc_carrier_phase_rad;
+                            a.records[static_cast<size_t>(ch) * a.n_epochs + e] = r;
+                        }
+                    s.pos = pos + static_cast<unsigned long long>(prn_len);  // consume_each, trk.cc:2287
+                    publish(win, s, c, a.n_stream, e + 1 < a.n_epochs);
+                }
+            done = e + 1;
+            __syncthreads();
+        }
+    if (tid == 0)
+        {
+            a.chan[ch] = s;
+            a.epochs_done[ch] = done;
+        }
+}
+
+// ---- host: filter design in the reference's float / double mix ---------------------------------------------------
+// Tracking_loop_filter::update_coefficients, T/tracking_loop_filter.cc:101-196 (Kaplan & Hegarty table 5.6, bilinear
+// transform of the integrator cascade); include_last_integrator is false for the code loop (trk.cc:604)
+void design_loop_filter(LoopFilterState& f, float T, float bw, int order, bool last_integrator)
+{
+    f = LoopFilterState{};
+    const float zeta = 1.0F / std::sqrt(2.0F);
+    float g1, g2, g3, wn;
+    auto set_in = [&](std::initializer_list<double> v) {
+        f.n_in = 0;
+        for (double d : v) f.in_c[f.n_in++] = static_cast<float>(d);
+    };
+    auto set_out = [&](std::initializer_list<float> v) {
+        f.n_out = 0;
+        for (float d : v) f.out_c[f.n_out++] = d;
+    };
+    switch (order)
+        {
+        case 1:
+            wn = bw * 4.0F;
+            g1 = wn;
+            if (last_integrator)
+                {
+                    set_in({g1 * T / 2.0, g1 * T / 2.0});
+                    set_out({1.0F});
+                }
+            else
+                {
+                    set_in({static_cast<double>(g1)});
+                    set_out({});
+                }
+            break;
+        case 2:
+            wn = bw * (8.0F * zeta) / (4.0F * zeta * zeta + 1.0F);
+            g1 = wn * wn;
+            g2 = wn * 2.0F * zeta;
+            if (last_integrator)
+                {
+                    set_in({T / 2.0 * (g1 * T / 2.0 + g2), T * T / 2.0 * g1, T / 2.0 * (g1 * T / 2.0 - g2)});
+                    set_out({2.0F, -1.0F});
+                }
+            else
+                {
+                    set_in({g1 * T / 2.0 + g2, g1 * T / 2.0 - g2});
+                    set_out({1.0F});
+                }
+            break;
+        default:
+            {
+                wn = bw / 0.7845F;
+                const float a3 = 1.1;
+                const float b3 = 2.4;
+                g1 = wn * wn * wn;
+                g2 = a3 * wn * wn;
+                g3 = b3 * wn;
+                if (last_integrator)
+                    {
+                        set_in({T / 2.0 * (g3 + T / 2.0 * (g2 + T / 2.0 * g1)), T / 2.0 * (-g3 + T / 2.0 * (g2 + 3.0 * T / 2.0 * g1)),
+                            T / 2.0 * (-g3 - T / 2.0 * (g2 - 3.0 * T / 2.0 * g1)), T / 2.0 * (g3 - T / 2.0 * (g2 - T / 2.0 * g1))});
+                        set_out({3.0F, -3.0F, 1.0F});
+                    }
+                else
+                    {
+                        set_in({g3 + T / 2.0 * (g2 + T / 2.0 * g1), g1 * T * T / 2.0 - 2.0 * g3, g3 + T / 2.0 * (-g2 + T / 2.0 * g1)});
+                        set_out({2.0F, -1.0F});
+                    }
+            }
+            break;
+        }
+    // initialize(0), T/tracking_loop_filter.cc:266-271
+    for (int i = 0; i < 4; i++)
+        {
+            f.in_h[i] = 0.0F;
+            f.out_h[i] = 0.0F;
+        }
+    f.idx = 3;
+}
+
+// Tracking_FLL_PLL_filter::set_params + initialize, T/tracking_FLL_PLL_filter.cc:23-69
+void design_fll_pll(FllPllState& f, float fll_bw_hz, float pll_bw_hz, int order, float acq_doppler_hz)
+{
+    f = FllPllState{};
+    f.order = order;
+    if (order == 3)
+        {
+            f.b3 = 2.400;
+            f.a3 = 1.100;
+            f.a2 = 1.414;
+            f.w0p = pll_bw_hz / 0.7845F;
+            f.w0p2 = f.w0p * f.w0p;
+            f.w0p3 = f.w0p2 * f.w0p;
+            f.w0f = fll_bw_hz / 0.53F;
+            f.w0f2 = f.w0f * f.w0f;
+            f.x = 2.0F * acq_doppler_hz;
+            f.w = 0;
+        }
+    else
+        {
+            f.a2 = 1.414;
+            f.w0p = pll_bw_hz / 0.53F;
+            f.w0p2 = f.w0p * f.w0p;
+            f.w0f = fll_bw_hz / 0.25F;
+            f.w = acq_doppler_hz;
+            f.x = 0;
+        }
+}
+}  // namespace
+}  // namespace gsh
+
+struct gsh_trk
+{
+    int device{0};
+    gsh_trk_conf conf{};
+    int n_channels{0};
+    int max_code_len{0};
+    hipStream_t stream{nullptr};
+    float* d_codes{nullptr};
+    gsh::TrkChannel* d_chan{nullptr};
+    gsh::TrkChannel* d_chan_backup{nullptr};
+    std::vector<gsh::TrkChannel> h_chan;
+    float2* d_stream_owned{nullptr};
+    size_t stream_owned_cap{0};
+    const float2* d_stream{nullptr};
+    unsigned long long n_stream{0};
+    gsh_trk_epoch* d_records{nullptr};
+    size_t records_cap{0};
+    int* d_done{nullptr};
+    hipEvent_t ev0{nullptr}, ev1{nullptr};
+};
+
+namespace
+{
+using gsh::set_error;
+
+size_t trk_lds_bytes(const gsh_trk* t)
+{
+    const size_t tabs = static_cast<size_t>(gsh::mcdev::code_table_floats(t->max_code_len)) * (t->conf.track_pilot ? 2 : 1);
+    return tabs * sizeof(float) + gsh::mcdev::MC_WAVES * GSH_MAX_TAPS * sizeof(float2);
+}
+
+int trk_launch(gsh_trk* t, int n_epochs, gsh_trk_epoch* d_records)
+{
+    gsh::TrkArgs a;
+    a.conf = t->conf;
+    a.stream = t->d_stream;
+    a.n_stream = t->n_stream;
+    a.codes = t->d_codes;
+    a.code_stride = t->max_code_len;
+    a.chan = t->d_chan;
+    a.records = d_records;
+    a.epochs_done = t->d_done;
+    a.n_epochs = n_epochs;
+    const size_t lds = trk_lds_bytes(t);
+    if (t->conf.veml)
+        hipLaunchKernelGGL((gsh::trk_loop_kernel<5>), dim3(t->n_channels), dim3(gsh::mcdev::MC_THREADS), lds, t->stream, a);
+    else
+        hipLaunchKernelGGL((gsh::trk_loop_kernel<3>), dim3(t->n_channels), dim3(gsh::mcdev::MC_THREADS), lds, t->stream, a);
+    GSH_HIP(hipGetLastError());
+    return GSH_OK;
+}
+}  // namespace
+
+extern "C"
+{
+    int gsh_trk_create(int device, const gsh_trk_conf* conf, int n_channels, int max_code_length, gsh_trk_t** out)
+    {
+        GSH_REQUIRE(out != nullptr && conf != nullptr, "null argument");
+        *out = nullptr;
+        const gsh_trk_conf& c = *conf;
+        GSH_REQUIRE(n_channels >= 1 && n_channels <= 65535, "n_channels %d outside 1..65535", n_channels);
+        GSH_REQUIRE(max_code_length >= 1, "max_code_length %d", max_code_length);
+        GSH_REQUIRE(c.fs_in >= 1.0 && c.code_chip_rate > 0.0 && c.signal_carrier_freq > 0.0, "fs_in, code_chip_rate and signal_carrier_freq must be positive");
+        GSH_REQUIRE(c.code_length_chips >= 1 && c.code_samples_per_chip >= 1 && c.vector_length >= 1, "code_length_chips, code_samples_per_chip, vector_length must be >= 1");
+        GSH_REQUIRE(c.pll_filter_order == 2 || c.pll_filter_order == 3, "pll_filter_order %d (2 or 3: T/tracking_FLL_PLL_filter.cc:23-54)", c.pll_filter_order);
+        GSH_REQUIRE(c.dll_filter_order >= 1 && c.dll_filter_order <= 3, "dll_filter_order %d outside 1..3", c.dll_filter_order);
+        GSH_REQUIRE(static_cast<uint64_t>(c.code_length_chips) * c.code_samples_per_chip <= static_cast<uint64_t>(max_code_length), "max_code_length %d smaller than code_length_chips * code_samples_per_chip", max_code_length);
+        gsh_trk probe;
+        probe.conf = c;
+        probe.max_code_len = max_code_length;
+        GSH_REQUIRE(trk_lds_bytes(&probe) <= 160 * 1024, "local replica(s) of %d samples do not fit the 160 KiB LDS", max_code_length);
+        int rc = gsh::use_device(device);
+        if (rc != GSH_OK) return rc;
+        gsh_trk* t = new (std::nothrow) gsh_trk();
+        GSH_REQUIRE(t != nullptr, "out of host memory");
+        t->device = device;
+        t->conf = c;
+        t->n_channels = n_channels;
+        t->max_code_len = max_code_length;
+        t->h_chan.assign(static_cast<size_t>(n_channels), gsh::TrkChannel{});
+        auto fail = [&](hipError_t e, const char* what) {
+            gsh::hip_fail(e, what, __FILE__, __LINE__);
+            gsh_trk_destroy(t);
+            return GSH_ERR_HIP;
+        };
+        hipError_t e;
+        if ((e = hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
+        if ((e = hipMalloc(&t->d_codes, sizeof(float) * 2 * static_cast<size_t>(n_channels) * max_code_length)) != hipSuccess) return fail(e, "hipMalloc(codes)");
+        if ((e = hipMalloc(&t->d_chan, sizeof(gsh::TrkChannel) * n_channels)) != hipSuccess) return fail(e, "hipMalloc(state)");
+        if ((e = hipMalloc(&t->d_chan_backup, sizeof(gsh::TrkChannel) * n_channels)) != hipSuccess) return fail(e, "hipMalloc(state)");
+        if ((e = hipMemset(t->d_chan, 0, sizeof(gsh::TrkChannel) * n_channels)) != hipSuccess) return fail(e, "hipMemset(state)");
+        if ((e = hipMalloc(&t->d_done, sizeof(int) * n_channels)) != hipSuccess) return fail(e, "hipMalloc(done)");
+        if ((e = hipEventCreate(&t->ev0)) != hipSuccess) return fail(e, "hipEventCreate");
+        if ((e = hipEventCreate(&t->ev1)) != hipSuccess) return fail(e, "hipEventCreate");
+        if (trk_lds_bytes(t) > 64 * 1024)
+            {
+                const int bytes = static_cast<int>(trk_lds_bytes(t));
+                if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(gsh::trk_loop_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes)) != hipSuccess) return fail(e, "hipFuncSetAttribute");
+                if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(gsh::trk_loop_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes)) != hipSuccess) return fail(e, "hipFuncSetAttribute");
+            }
+        *out = t;
+        return GSH_OK;
+    }
+
+    void gsh_trk_destroy(gsh_trk_t* t)
+    {
+        if (!t) return;
+        (void)hipSetDevice(t->device);
+        if (t->stream) (void)hipStreamSynchronize(t->stream);
+        if (t->d_codes) (void)hipFree(t->d_codes);
+        if (t->d_chan) (void)hipFree(t->d_chan);
+        if (t->d_chan_backup) (void)hipFree(t->d_chan_backup);
+        if (t->d_stream_owned) (void)hipFree(t->d_stream_owned);
+        if (t->d_records) (void)hipFree(t->d_records);
+        if (t->d_done) (void)hipFree(t->d_done);
+        if (t->ev0) (void)hipEventDestroy(t->ev0);
+        if (t->ev1) (void)hipEventDestroy(t->ev1);
+        if (t->stream) (void)hipStreamDestroy(t->stream);
+        delete t;
+    }
+
+    int gsh_trk_set_stream_host(gsh_trk_t* t, const float* iq, uint64_t n_samples)
+    {
+        GSH_REQUIRE(t != nullptr && iq != nullptr && n_samples >= 1, "null / empty stream");
+        GSH_HIP(hipSetDevice(t->device));
+        if (n_samples + 2 > t->stream_owned_cap)
+            {
+                if (t->d_stream_owned) GSH_HIP(hipFree(t->d_stream_owned));
+                t->d_stream_owned = nullptr;
+                t->stream_owned_cap = 0;
+                GSH_HIP(hipMalloc(&t->d_stream_owned, sizeof(float2) * (n_samples + 2)));  // +2: the last 16-byte load of an odd window
+                t->stream_owned_cap = n_samples + 2;
+            }
+        GSH_HIP(hipMemsetAsync(t->d_stream_owned + n_samples, 0, sizeof(float2) * 2, t->stream));
+        GSH_HIP(hipMemcpyAsync(t->d_stream_owned, iq, sizeof(float2) * n_samples, hipMemcpyHostToDevice, t->stream));
+        GSH_HIP(hipStreamSynchronize(t->stream));
+        t->d_stream = t->d_stream_owned;
+        t->n_stream = n_samples;
+        return GSH_OK;
+    }
+
+    int gsh_trk_set_stream_device(gsh_trk_t* t, const void* device_iq, uint64_t n_samples)
+    {
+        GSH_REQUIRE(t != nullptr && device_iq != nullptr && n_samples >= 1, "null / empty stream");
+        GSH_REQUIRE((reinterpret_cast<uintptr_t>(device_iq) & 15u) == 0, "device stream must be 16-byte aligned");
+        t->d_stream = static_cast<const float2*>(device_iq);
+        t->n_stream = n_samples;
+        return GSH_OK;
+    }
+
+    int gsh_trk_start(gsh_trk_t* t, int channel, const float* code, const float* data_code, int code_length, uint64_t start_sample,
+        uint64_t acq_sample_stamp, double acq_carrier_doppler_hz)
+    {
+        GSH_REQUIRE(t != nullptr && code != nullptr, "null argument");
+        GSH_REQUIRE(channel >= 0 && channel < t->n_channels, "channel %d outside 0..%d", channel, t->n_channels - 1);
+        GSH_REQUIRE(code_length >= gsh::mcdev::MC_MARGIN && code_length <= t->max_code_len, "code_length %d outside %d..%d", code_length, gsh::mcdev::MC_MARGIN, t->max_code_len);
+        GSH_REQUIRE(!t->conf.track_pilot || data_code != nullptr, "track_pilot needs the data-component code");
+        GSH_REQUIRE(acq_sample_stamp <= start_sample, "acq_sample_stamp must not be later than start_sample");
+        GSH_HIP(hipSetDevice(t->device));
+        const gsh_trk_conf& c = t->conf;
+        gsh::TrkChannel s{};
+        // start_tracking, trk.cc:803-826, and the pull-in state, :1956-1958
+        s.carrier_doppler_hz = acq_carrier_doppler_hz;
+        s.carrier_phase_step_rad = gsh::GNSS_TWO_PI_D * s.carrier_doppler_hz / c.fs_in;
+        s.code_freq_chips = c.code_chip_rate;
+        s.code_phase_step_chips = s.code_freq_chips / c.fs_in;
+        s.rem_code_phase_samples = 0.0;
+        s.rem_code_phase_chips = 0.0;
+        s.acc_carrier_phase_rad = 0.0;
+        s.rem_carr_phase_rad = 0.0F;
+        s.p_old_re = 0.0F;
+        s.p_old_im = 0.0F;
+        s.pos = start_sample;
+        s.acq_stamp = acq_sample_stamp;
+        s.active = 1;
+        s.code_len = code_length;
+        const double code_period = static_cast<double>(c.code_length_chips) / c.code_chip_rate;
+        gsh::design_loop_filter(s.dll, static_cast<float>(code_period), c.dll_bw_hz, c.dll_filter_order, false);     // trk.cc:604, 845-849
+        gsh::design_fll_pll(s.pll, c.fll_bw_hz, c.pll_bw_hz, c.pll_filter_order, static_cast<float>(acq_carrier_doppler_hz));  // trk.cc:605, 844, 848
+        t->h_chan[channel] = s;
+        float* dst = t->d_codes + static_cast<size_t>(channel) * 2 * t->max_code_len;
+        GSH_HIP(hipMemcpyAsync(dst, code, sizeof(float) * code_length, hipMemcpyHostToDevice, t->stream));
+        if (data_code) GSH_HIP(hipMemcpyAsync(dst + t->max_code_len, data_code, sizeof(float) * code_length, hipMemcpyHostToDevice, t->stream));
+        GSH_HIP(hipMemcpyAsync(t->d_chan + channel, &t->h_chan[channel], sizeof(gsh::TrkChannel), hipMemcpyHostToDevice, t->stream));
+        GSH_HIP(hipStreamSynchronize(t->stream));
+        return GSH_OK;
+    }
+
+    int gsh_trk_run(gsh_trk_t* t, int n_epochs, gsh_trk_epoch* records, int32_t* epochs_done)
+    {
+        GSH_REQUIRE(t != nullptr, "null handle");
+        GSH_REQUIRE(n_epochs >= 0, "n_epochs %d", n_epochs);
+        if (t->d_stream == nullptr) return set_error(GSH_ERR_STATE, "no IF stream attached (gsh_trk_set_stream_*)");
+        GSH_HIP(hipSetDevice(t->device));
+        const size_t n_rec = static_cast<size_t>(t->n_channels) * static_cast<size_t>(n_epochs);
+        if (records != nullptr && n_rec > t->records_cap)
+            {
+                if (t->d_records) GSH_HIP(hipFree(t->d_records));
+                t->d_records = nullptr;
+                t->records_cap = 0;
+                GSH_HIP(hipMalloc(&t->d_records, sizeof(gsh_trk_epoch) * n_rec));
+                t->records_cap = n_rec;
+            }
+        if (records != nullptr && n_rec > 0) GSH_HIP(hipMemsetAsync(t->d_records, 0, sizeof(gsh_trk_epoch) * n_rec, t->stream));
+        int rc = trk_launch(t, n_epochs, records != nullptr ? t->d_records : nullptr);
+        if (rc != GSH_OK) return rc;
+        if (records != nullptr && n_rec > 0) GSH_HIP(hipMemcpyAsync(records, t->d_records, sizeof(gsh_trk_epoch) * n_rec, hipMemcpyDeviceToHost, t->stream));
+        if (epochs_done != nullptr) GSH_HIP(hipMemcpyAsync(epochs_done, t->d_done, sizeof(int) * t->n_channels, hipMemcpyDeviceToHost, t->stream));
+        GSH_HIP(hipStreamSynchronize(t->stream));
+        return GSH_OK;
+    }
+
+    int gsh_trk_time_run(gsh_trk_t* t, int n_epochs, int reps, float* avg_ms)
+    {
+        GSH_REQUIRE(t != nullptr && avg_ms != nullptr, "null argument");
+        GSH_REQUIRE(n_epochs >= 1 && reps >= 1, "n_epochs %d reps %d", n_epochs, reps);
+        if (t->d_stream == nullptr) return set_error(GSH_ERR_STATE, "no IF stream attached (gsh_trk_set_stream_*)");
+        GSH_HIP(hipSetDevice(t->device));
+        const size_t bytes = sizeof(gsh::TrkChannel) * t->n_channels;
+        GSH_HIP(hipMemcpyAsync(t->d_chan_backup, t->d_chan, bytes, hipMemcpyDeviceToDevice, t->stream));
+        int rc = trk_launch(t, n_epochs, nullptr);  // warm-up
+        if (rc != GSH_OK) return rc;
+        float total = 0.0f;
+        for (int i = 0; i < reps; i++)
+            {
+                GSH_HIP(hipMemcpyAsync(t->d_chan, t->d_chan_backup, bytes, hipMemcpyDeviceToDevice, t->stream));
+                GSH_HIP(hipEventRecord(t->ev0, t->stream));
+                rc = trk_launch(t, n_epochs, nullptr);
+                if (rc != GSH_OK) return rc;
+                GSH_HIP(hipEventRecord(t->ev1, t->stream));
+                GSH_HIP(hipEventSynchronize(t->ev1));
+                float ms = 0.0f;
+                GSH_HIP(hipEventElapsedTime(&ms, t->ev0, t->ev1));
+                total += ms;
+            }
+        GSH_HIP(hipMemcpyAsync(t->d_chan, t->d_chan_backup, bytes, hipMemcpyDeviceToDevice, t->stream));
+        GSH_HIP(hipStreamSynchronize(t->stream));
+        *avg_ms = total / static_cast<float>(reps);
+        return GSH_OK;
+    }
+}

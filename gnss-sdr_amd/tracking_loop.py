@@ -1,0 +1,84 @@
+"""Python face of the device-resident DLL/PLL loop (gsh_trk_*), for tests and bench.
+
+``TrackingLoop`` owns one handle: n_channels channels of one signal type sharing an IF stream.  ``start`` is the
+reference's ``start_tracking`` + pull-in hand-over (dll_pll_veml_tracking.cc:796-866, 1949-1973), ``run`` executes
+n code periods of every started channel in one launch and returns the per-period records (what ``log_data`` dumps).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import TrkConf, TrkEpoch, check, fptr
+
+
+def trk_conf(**kw) -> TrkConf:
+    """gsh_trk_conf with Dll_Pll_Conf's defaults (src/algorithms/tracking/libs/dll_pll_conf.h:33-90)."""
+    c = TrkConf()
+    d = dict(fs_in=4e6, code_chip_rate=1.023e6, signal_carrier_freq=1575.42e6, cfo_frequency_hz=0.0, code_length_chips=1023,
+             code_samples_per_chip=1, vector_length=4000, veml=0, track_pilot=0, early_late_space_chips=0.5,
+             very_early_late_space_chips=0.6, pll_bw_hz=35.0, dll_bw_hz=2.0, fll_bw_hz=35.0, pll_filter_order=3, dll_filter_order=2,
+             enable_fll_pull_in=0, enable_fll_steady_state=0, carrier_aiding=1, cloop=1, pull_in_time_s=5, spc=0.5, slope=1.0,
+             y_intercept=1.0)
+    d.update(kw)
+    for k, v in d.items():
+        setattr(c, k, v)
+    return c
+
+
+class TrackingLoop:
+    def __init__(self, conf: TrkConf, n_channels: int, max_code_length: int, device: int = 0):
+        self._lib = _lib.load()
+        self.conf = conf
+        self.n_channels = n_channels
+        self._h = C.c_void_p()
+        self._keep = {}
+        check(self._lib.gsh_trk_create(device, C.byref(conf), n_channels, max_code_length, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            self._lib.gsh_trk_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream_host(self, x: np.ndarray) -> None:
+        x = np.ascontiguousarray(x, np.complex64)
+        check(self._lib.gsh_trk_set_stream_host(self._h, fptr(x), len(x)))
+
+    def set_stream_device(self, device_ptr: int, n_samples: int, keepalive=None) -> None:
+        self._keep["stream"] = keepalive
+        check(self._lib.gsh_trk_set_stream_device(self._h, C.c_void_p(device_ptr), n_samples))
+
+    def start(self, channel: int, code: np.ndarray, start_sample: int, acq_sample_stamp: int, acq_carrier_doppler_hz: float,
+              data_code: np.ndarray | None = None) -> None:
+        code = np.ascontiguousarray(code, np.float32)
+        dc = None
+        if data_code is not None:
+            data_code = np.ascontiguousarray(data_code, np.float32)
+            dc = fptr(data_code)
+        check(self._lib.gsh_trk_start(self._h, channel, fptr(code), dc, len(code), int(start_sample), int(acq_sample_stamp),
+                                      float(acq_carrier_doppler_hz)))
+
+    def run(self, n_epochs: int, want_records: bool = True):
+        """-> (records[channel][epoch] as lists of TrkEpoch, epochs_done per channel)"""
+        done = (C.c_int32 * self.n_channels)()
+        if want_records:
+            rec = (TrkEpoch * (self.n_channels * n_epochs))()
+            check(self._lib.gsh_trk_run(self._h, n_epochs, rec, done))
+            out = [[rec[ch * n_epochs + e] for e in range(done[ch])] for ch in range(self.n_channels)]
+        else:
+            check(self._lib.gsh_trk_run(self._h, n_epochs, None, done))
+            out = None
+        return out, list(done)
+
+    def time_run(self, n_epochs: int, reps: int = 5) -> float:
+        ms = C.c_float(0.0)
+        check(self._lib.gsh_trk_time_run(self._h, n_epochs, reps, C.byref(ms)))
+        return ms.value

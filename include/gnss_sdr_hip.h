@@ -30,7 +30,7 @@ extern "C"
 {
 #endif
 
-#define GSH_ABI_VERSION 2
+#define GSH_ABI_VERSION 3
 #define GSH_MAX_TAPS 8 /* VE/E/P/L/VL needs 5 (trk.cc:609-650); 8 leaves room for multi-tap dumps */
 
     enum
@@ -134,6 +134,73 @@ extern "C"
     /* work-groups per job used by the next launches (1 = throughput mode; >1 spreads one epoch
      * over more CUs for latency-bound closed-loop use).  0 = choose automatically. */
     int gsh_bank_set_splits(gsh_bank_t* b, int splits);
+
+    /* ================================================================ TRACKING LOOP (closed on the device)
+     * gsh_trk_*: the steady-state loop of dll_pll_veml_tracking (trk.cc state 2, :1975-2001), one code period per
+     * iteration:  do_correlation_step (trk.cc:1232-1257) -> run_dll_pll (:1260-1324: Costas / four-quadrant PLL
+     * discriminator, fll_diff_atan, Tracking_FLL_PLL_filter, E-L or VEMLP DLL discriminator, Tracking_loop_filter,
+     * carrier aiding) -> update_tracking_vars (:1409-1483) -> consume d_current_prn_length_samples (:2287),
+     * with the initial conditions of start_tracking (:796-866) and the pull-in state (:1949-1973).
+     * All of it runs on the GPU: one work-group per channel iterates over the code periods of a device-resident IF
+     * stream and leaves one record per period, so n_epochs periods cost one launch instead of n_epochs host round
+     * trips.  Not modelled here (the host block keeps them): bit / secondary-code synchronisation, extended
+     * integration, lock detectors and CN0, high_dyn smoothing, the experimental Doppler correction (:1326-1346).
+     * T/ = src/algorithms/tracking/libs/.
+     */
+    typedef struct gsh_trk gsh_trk_t;
+
+    typedef struct gsh_trk_conf
+    {
+        double fs_in;                    /* Dll_Pll_Conf::fs_in */
+        double code_chip_rate;           /* d_code_chip_rate [chips/s] */
+        double signal_carrier_freq;      /* d_signal_carrier_freq [Hz] (carrier aiding, trk.cc:1320-1323) */
+        double cfo_frequency_hz;         /* d_cfo_frequency_hz, trk.cc:1423 */
+        uint32_t code_length_chips;      /* d_code_length_chips */
+        uint32_t code_samples_per_chip;  /* d_code_samples_per_chip: 1, or 2 for the E1 sinBOC replica (trk.cc:289) */
+        uint32_t vector_length;          /* samples per correlation, trk.cc:1243 */
+        int32_t veml;                    /* 0: E/P/L, 1: VE/E/P/L/VL (trk.cc:609-650) */
+        int32_t track_pilot;             /* also correlate the data-component code, 1 tap (trk.cc:1246-1256) */
+        float early_late_space_chips;
+        float very_early_late_space_chips;
+        float pll_bw_hz, dll_bw_hz, fll_bw_hz;
+        int32_t pll_filter_order;        /* 2 or 3 (T/tracking_FLL_PLL_filter.cc:23-54) */
+        int32_t dll_filter_order;        /* 1..3 (T/tracking_loop_filter.cc:101-196) */
+        int32_t enable_fll_pull_in, enable_fll_steady_state, carrier_aiding;
+        int32_t cloop;                   /* d_cloop: 1 = Costas two-quadrant arctangent, 0 = four-quadrant */
+        uint32_t pull_in_time_s;         /* Dll_Pll_Conf::pull_in_time_s, trk.cc:1912-1915 */
+        float spc, slope, y_intercept;   /* dll_nc_e_minus_l_normalized parameters (trk.cc:1986, dll_pll_conf.h:55-57) */
+    } gsh_trk_conf;
+
+    typedef struct gsh_trk_epoch         /* what log_data dumps per period (trk.cc:1599-1702), POD */
+    {
+        uint64_t sample_counter;         /* first sample of the correlated window */
+        int32_t prn_length_samples;      /* d_current_prn_length_samples: samples consumed after this period */
+        int32_t flags;                   /* bit 0: d_pull_in_transitory was set */
+        float corr[10];                  /* E,P,L or VE,E,P,L,VL as interleaved complex64 */
+        float prompt_data[2];            /* d_Prompt_Data (track_pilot) */
+        float rem_carr_phase_rad;
+        float pad_;
+        double carrier_doppler_hz, code_freq_chips, carr_phase_error_hz, carr_freq_error_hz, carr_error_filt_hz;
+        double code_error_chips, code_error_filt_chips, rem_code_phase_samples, acc_carrier_phase_rad;
+    } gsh_trk_epoch;
+
+    int gsh_trk_create(int device, const gsh_trk_conf* conf, int n_channels, int max_code_length, gsh_trk_t** out);
+    void gsh_trk_destroy(gsh_trk_t* t);
+    /* IF sample stream shared by every channel: _host copies, _device borrows 16-byte aligned device memory */
+    int gsh_trk_set_stream_host(gsh_trk_t* t, const float* iq, uint64_t n_samples);
+    int gsh_trk_set_stream_device(gsh_trk_t* t, const void* device_iq, uint64_t n_samples);
+    /* start_tracking (trk.cc:796-866) for one channel: local replica(s) (code_length floats = chips x samples per
+     * chip; data_code NULL unless track_pilot), Acq_doppler_hz, Acq_samplestamp_samples, and the first sample of the
+     * first code period, i.e. the stream position after the pull-in alignment of trk.cc:1949-1973 */
+    int gsh_trk_start(gsh_trk_t* t, int channel, const float* code, const float* data_code, int code_length, uint64_t start_sample,
+        uint64_t acq_sample_stamp, double acq_carrier_doppler_hz);
+    /* n_epochs code periods of every started channel in ONE launch; the loop state stays on the device, so a later
+     * call continues where this one stopped.  records: n_channels * n_epochs (channel-major) or NULL;
+     * epochs_done[n_channels]: periods completed (a channel stops when its window would leave the stream). */
+    int gsh_trk_run(gsh_trk_t* t, int n_epochs, gsh_trk_epoch* records, int32_t* epochs_done);
+    /* HIP-event milliseconds of one gsh_trk_run-sized launch, averaged over reps (each rep restarts from the state at
+     * entry; the state is restored afterwards) */
+    int gsh_trk_time_run(gsh_trk_t* t, int n_epochs, int reps, float* avg_ms);
 
     /* ================================================================ ACQUISITION
      * gsh_acq_*: the arithmetic of class pcps_acquisition (acq.h:93-251) without its

@@ -1,0 +1,146 @@
+"""GPU tests of the device-resident DLL/PLL loop (gsh_trk_*) against the CPU oracle loop (oracle.trk_run).
+
+The loop has feedback, so the comparison is a trajectory comparison: correlator outputs differ from the float32 oracle at
+the 1e-7..1e-5 level (tests/test_tracking_gpu.py), libm differs from the device math library in the last ulp, and both
+are fed back through the loop filters.  Because the fed-back float32 code phase can differ in its last bit, a sample that
+sits exactly on a chip edge may pick the neighbouring chip on one side (the accumulator then moves by 2|x[n]|): at most
+2 % of the periods may show such a flip, bounded by two samples' worth.  Bars: every period's window position identical (a +-1-sample difference may only
+appear where the float64 block length sits within 1e-6 of an integer -- asserted), Doppler within 0.05 Hz, code
+frequency within 2e-3 chip/s, correlator outputs within 2e-4 of the prompt magnitude, discriminator outputs within 1e-4.
+"""
+import numpy as np
+import pytest
+
+import oracle
+from helpers import add_code_signal, cn0_to_amplitude, golden_e1_l5_codes, synth_gps_l1_stream
+
+pytestmark = pytest.mark.gpu
+
+
+def _loop(gpu, conf_kw, n_channels, max_len):
+    from gnss_sdr_amd.tracking_loop import TrackingLoop, trk_conf
+    return TrackingLoop(trk_conf(**conf_kw), n_channels, max_len, device=gpu)
+
+
+def _compare(rec_gpu, rec_ora, n_taps, tag, xmax=6.0):
+    assert len(rec_gpu) == len(rec_ora), (tag, len(rec_gpu), len(rec_ora))
+    flips = 0
+    for e, (g, o) in enumerate(zip(rec_gpu, rec_ora)):
+        if g.sample_counter != o.sample_counter:
+            # only legitimate when an earlier block length sat on an integer boundary
+            prev = rec_ora[e - 1]
+            k_blk = prev.prn_length_samples + prev.rem_code_phase_samples
+            assert min(prev.rem_code_phase_samples, 1.0 - prev.rem_code_phase_samples) < 1e-6, (tag, e, g.sample_counter, o.sample_counter, k_blk)
+            return  # trajectories are offset by one sample from here on: nothing further to compare sample-exactly
+        assert g.prn_length_samples == o.prn_length_samples or min(o.rem_code_phase_samples, 1 - o.rem_code_phase_samples) < 1e-6, (tag, e)
+        assert g.flags == o.flags, (tag, e)
+        pg = np.array(g.corr[:2 * n_taps]).view(np.float64) if False else np.array(list(g.corr)[:2 * n_taps])
+        po = np.array(list(o.corr)[:2 * n_taps])
+        scale = max(np.hypot(po[n_taps - 1 if n_taps == 3 else 4], po[n_taps if n_taps == 3 else 5]), 50.0)
+        if np.max(np.abs(pg - po)) > 2e-4 * scale:
+            flips += 1  # a chip-edge sample went the other way in one tap (see the module docstring)
+            assert np.max(np.abs(pg - po)) <= 4.0 * xmax, (tag, e, pg, po)
+            assert flips <= max(2, len(rec_ora) // 50), (tag, e, flips)
+        assert abs(g.carrier_doppler_hz - o.carrier_doppler_hz) <= 0.05, (tag, e, g.carrier_doppler_hz, o.carrier_doppler_hz)
+        assert abs(g.code_freq_chips - o.code_freq_chips) <= 2e-3, (tag, e, g.code_freq_chips, o.code_freq_chips)
+        assert abs(g.code_error_chips - o.code_error_chips) <= 1e-4 + 8.0 * xmax / scale * (np.max(np.abs(pg - po)) > 2e-4 * scale), (tag, e)
+        assert abs(g.carr_phase_error_hz - o.carr_phase_error_hz) <= 1e-4 + 8.0 * xmax / scale * (np.max(np.abs(pg - po)) > 2e-4 * scale), (tag, e)
+        assert abs(g.rem_code_phase_samples - o.rem_code_phase_samples) <= 1e-4 or min(o.rem_code_phase_samples, 1 - o.rem_code_phase_samples) < 1e-4, (tag, e)
+        assert abs(g.acc_carrier_phase_rad - o.acc_carrier_phase_rad) <= 1e-3 * max(1.0, abs(o.acc_carrier_phase_rad)), (tag, e)
+
+
+@pytest.mark.parametrize("variant", ["pll3", "pll2_fll", "no_aiding_dll1"])
+def test_gps_l1_closed_loop_matches_oracle_and_locks(gpu, variant):
+    fs, n, epochs = 4e6, 4000, 300
+    kw = dict(fs_in=fs, vector_length=n, pll_bw_hz=35.0, dll_bw_hz=4.0)
+    if variant == "pll2_fll":
+        kw.update(pll_filter_order=2, enable_fll_pull_in=1, enable_fll_steady_state=1, fll_bw_hz=10.0, pull_in_time_s=0)
+    if variant == "no_aiding_dll1":
+        kw.update(carrier_aiding=0, dll_filter_order=1, dll_bw_hz=1.0, cloop=0)
+    prns = [3, 9, 17, 22]
+    dops = [1200.0, -2750.0, 4100.0, 35.0]
+    cphs = [417.3, 12.9, 800.4, 333.3]
+    x = synth_gps_l1_stream(epochs * n + 3 * n, fs, prns, dops, cphs, cn0_dbhz=47.0, seed_noise=31)
+    loop = _loop(gpu, kw, n_channels=5, max_len=1023)   # channel 4 is never started
+    loop.set_stream_host(x)
+    conf_o = oracle.trk_conf(**kw)
+    starts = []
+    for ch, (prn, fd, cph) in enumerate(zip(prns, dops, cphs)):
+        f_code = 1.023e6 * (1 + fd / 1575.42e6)
+        start = int(round((1023.0 - cph) / f_code * fs + 0.15 * fs / 1.023e6))  # 0.15 chip late
+        starts.append(start)
+        loop.start(ch, oracle.ca_code(prn), start, 0, fd - 12.0)
+    rec, done = loop.run(epochs)
+    assert done[4] == 0 and len(rec[4]) == 0
+    amp = cn0_to_amplitude(47.0, fs) * n
+    for ch, (prn, fd) in enumerate(zip(prns, dops)):
+        ora = oracle.trk_run(conf_o, oracle.ca_code(prn), x, starts[ch], 0, fd - 12.0, epochs)
+        assert done[ch] == epochs == len(ora)
+        _compare(rec[ch], ora, 3, f"{variant} ch{ch}")
+        tail = rec[ch][-80:]
+        assert abs(np.mean([r.carrier_doppler_hz for r in tail]) - fd) < 1.5, (variant, ch)
+        if variant != "no_aiding_dll1":
+            # (a first-order 1 Hz code loop without carrier aiding keeps a steady-state error of code-Doppler / 4 chips:
+            #  up to 0.67 chip at 4.1 kHz -- agreement with the oracle is the only claim for that variant)
+            assert np.mean([np.hypot(r.corr[2], r.corr[3]) for r in tail]) > 0.9 * amp, (variant, ch)
+    # a second call continues from the device-resident state: identical to one long run
+    rec2, done2 = loop.run(50)
+    ora_long = oracle.trk_run(conf_o, oracle.ca_code(prns[0]), x, starts[0], 0, dops[0] - 12.0, epochs + 50)
+    n_more = len(ora_long) - epochs
+    assert done2[0] == n_more
+    _compare(rec2[0], ora_long[epochs:], 3, f"{variant} continuation")
+    loop.close()
+
+
+def test_galileo_e1_veml_pilot_and_data(gpu):
+    """E1: 4 ms code period, 32 Msps -> N = 128 000, VE/E/P/L/VL on E1C + data prompt on E1B, sinBOC replica at 2 samples
+    per chip, VEMLP discriminator, four-quadrant PLL discriminator (pilot)."""
+    fs, n, epochs = 32e6, 128000, 40
+    g = golden_e1_l5_codes()
+    rng = np.random.default_rng(41)
+    n_stream = (epochs + 2) * n
+    x = (rng.standard_normal(n_stream) + 1j * rng.standard_normal(n_stream)).astype(np.complex64)
+    amp = cn0_to_amplitude(45.0, fs)
+    fd, ph = -1830.0, 3000.0
+    rate = 1.023e6 * (1 + fd / 1575.42e6) / fs * 2.0
+    add_code_signal(x, (g["e1b"][7] - g["e1c"][7]) / np.sqrt(2.0), fs, rate, ph, fd, amp)
+    kw = dict(fs_in=fs, vector_length=n, code_length_chips=4092, code_samples_per_chip=2, veml=1, track_pilot=1, cloop=0,
+              early_late_space_chips=0.15, very_early_late_space_chips=0.5, pll_bw_hz=15.0, dll_bw_hz=0.75, pll_filter_order=3, dll_filter_order=2)
+    loop = _loop(gpu, kw, n_channels=2, max_len=8184)
+    loop.set_stream_host(x)
+    start = int(round((8184.0 - ph) / rate))
+    loop.start(0, g["e1c"][7], start, 0, fd - 5.0, data_code=g["e1b"][7])
+    loop.start(1, g["e1c"][20], start + 777, 0, 950.0, data_code=g["e1b"][20])  # no such signal: noise-driven loop
+    rec, done = loop.run(epochs)
+    conf_o = oracle.trk_conf(**kw)
+    for ch, (prn_i, st, dop) in enumerate(((7, start, fd - 5.0), (20, start + 777, 950.0))):
+        ora = oracle.trk_run(conf_o, g["e1c"][prn_i], x, st, 0, dop, epochs, data_code=g["e1b"][prn_i])
+        assert done[ch] == len(ora)
+        _compare(rec[ch], ora, 5, f"e1 ch{ch}")
+        for rg, ro in zip(rec[ch], ora):
+            assert abs(rg.prompt_data[0] - ro.prompt_data[0]) <= 2e-4 * max(50.0, abs(complex(*ro.prompt_data)))
+    # the tracked channel holds the signal: pilot and data prompts both carry A*N/sqrt(2)
+    tail = rec[0][-10:]
+    expect = amp * n / np.sqrt(2.0)
+    assert np.mean([np.hypot(r.corr[4], r.corr[5]) for r in tail]) > 0.85 * expect
+    assert np.mean([np.hypot(*r.prompt_data) for r in tail]) > 0.85 * expect
+    loop.close()
+
+
+def test_loop_errors_and_stream_end(gpu):
+    from gnss_sdr_amd import GshError
+    from gnss_sdr_amd.tracking_loop import TrackingLoop, trk_conf
+    with pytest.raises(GshError):
+        TrackingLoop(trk_conf(pll_filter_order=4), 1, 1023, device=gpu)
+    loop = TrackingLoop(trk_conf(), 1, 1023, device=gpu)
+    with pytest.raises(GshError):
+        loop.run(1)  # no stream
+    x = synth_gps_l1_stream(10 * 4000 + 100, 4e6, [1], [500.0], [0.0], cn0_dbhz=50.0, seed_noise=3)
+    loop.set_stream_host(x)
+    rec, done = loop.run(5)
+    assert done == [0]  # nothing started
+    loop.start(0, oracle.ca_code(1), 10, 0, 500.0)
+    rec, done = loop.run(100)  # only 10 windows fit
+    assert 9 <= done[0] <= 10 and len(rec[0]) == done[0]
+    assert rec[0][-1].sample_counter + 4000 <= len(x)
+    loop.close()
