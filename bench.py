@@ -189,6 +189,39 @@ def acquisition_metric(torch, dev_index, x_block, fs):
     return res
 
 
+def closed_loop_metric(dev_index, x_dev, n_samples, fs, n, dop, cph, channels=32, epochs=200):
+    """Secondary metric: the DLL/PLL loop closed on the device (gsh_trk_*), BASELINE config 2 shape -- every channel runs
+    `epochs` consecutive code periods with its own discriminators / loop filters / NCO update between them, one launch."""
+    try:
+        from gnss_sdr_amd.tracking_loop import TrackingLoop, trk_conf
+    except Exception as e:
+        return {"error": f"tracking loop unavailable: {e}"}
+    import oracle
+    conf = trk_conf(fs_in=fs, vector_length=n, pll_bw_hz=35.0, dll_bw_hz=2.0)
+    loop = TrackingLoop(conf, channels, 1023, device=dev_index)
+    loop.set_stream_device(x_dev.data_ptr(), n_samples, keepalive=x_dev)
+    rng = np.random.default_rng(0x5EED0006)
+    for c in range(channels):
+        if c < len(dop):  # hand-over from a (simulated) acquisition: code start of the embedded signal, Doppler off by <= 20 Hz
+            f_code = 1.023e6 * (1 + dop[c] / 1575.42e6)
+            start = int(round((1023.0 - cph[c]) / f_code * fs))
+            loop.start(c, oracle.ca_code(c + 1), start, 0, float(dop[c]) + rng.uniform(-20, 20))
+        else:
+            loop.start(c, oracle.ca_code(c % 32 + 1), int(rng.integers(0, n)), 0, float(rng.uniform(-5000, 5000)))
+    ms = loop.time_run(epochs, reps=3)
+    rec, done = loop.run(epochs)
+    locked = 0
+    for c in range(min(channels, len(dop))):
+        tail = rec[c][-20:]
+        if abs(np.mean([r.carrier_doppler_hz for r in tail]) - dop[c]) < 5.0:
+            locked += 1
+    loop.close()
+    return {"metric": "correlators/s, loop closed on device", "value": channels * 3 * epochs / (ms * 1e-3), "unit": "correlators/s",
+            "ms_per_launch": ms, "us_per_epoch": ms * 1e3 / epochs, "channels": channels, "epochs_per_launch": epochs,
+            "channels_with_signal_locked": f"{locked}/{min(channels, len(dop))}",
+            "real_time_factor": epochs * 1e-3 / (ms * 1e-3)}
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -318,6 +351,10 @@ def main():
                 res["acquisition"] = acquisition_metric(torch, local, bufs[0][:n].contiguous(), fs)
             except Exception as e:
                 res["acquisition"] = {"error": str(e)}
+            try:
+                res["closed_loop"] = closed_loop_metric(local, bufs[0], n_samples, fs, n, dop, cph, channels=C, epochs=min(E - 2, 200))
+            except Exception as e:
+                res["closed_loop"] = {"error": str(e)}
         print(json.dumps(res))
     bank.close()
     if dist:

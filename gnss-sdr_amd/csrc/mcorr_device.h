@@ -7,11 +7,21 @@
 #include "gsh_internal.h"
 #include <cmath>
 
+// Work-group size of the correlator code below.  A translation unit may define GSH_MC_THREADS (a multiple of 64, <= 1024)
+// before including this header; the code then lives in its own namespace (mcdev_<threads>) so that two translation
+// units with different sizes never define the same entity differently.
+#ifndef GSH_MC_THREADS
+#define GSH_MC_THREADS 256
+#endif
+#define GSH_MC_NS_CAT2(a, b) a##b
+#define GSH_MC_NS_CAT(a, b) GSH_MC_NS_CAT2(a, b)
+#define GSH_MC_NS GSH_MC_NS_CAT(mcdev_, GSH_MC_THREADS)
+
 namespace gsh
 {
-namespace mcdev
+namespace GSH_MC_NS
 {
-constexpr int MC_THREADS = 256;
+constexpr int MC_THREADS = GSH_MC_THREADS;
 constexpr int MC_WAVES = MC_THREADS / 64;
 constexpr int MC_MARGIN = 32;  // guard entries on each side of the LDS code table
 #ifndef GSH_MC_RESEED
@@ -361,6 +371,7 @@ __device__ __forceinline__ void correlate_window_std(const float2* __restrict__ 
     if (tid < NT) red[tid] = s;
     __syncthreads();
 }
-}  // namespace mcdev
+}  // namespace GSH_MC_NS
+namespace mcdev = GSH_MC_NS;
 }  // namespace gsh
 #endif

@@ -14,6 +14,10 @@
 // arithmetic in the reference's own float / double mix, publishes the next NCO settings through LDS, and the next
 // window starts -- no host involvement until the requested number of periods is done.  The two local replicas
 // (pilot + data for track_pilot signals) stay in LDS for the whole launch.
+// 1024 threads per channel: a channel owns at most one compute unit and every period is a dependent step, so the
+// only way to hide the window's load latency is more waves on that unit (measured: 16.6 us per 25 000-sample period
+// with 256 threads)
+#define GSH_MC_THREADS 1024
 #include "mcorr_device.h"
 #include <cmath>
 #include <new>
