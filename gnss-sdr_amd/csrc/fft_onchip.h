@@ -389,9 +389,21 @@ struct Plan
 }  // namespace oc
 }  // namespace gsh
 
-// transform lengths with an on-chip plan: X(R1, R2, R3), N = R1*R2*R3 (N*4 bytes of LDS, <= 1024 threads)
+// transform lengths with an on-chip plan: X(R1, R2, R3), N = R1*R2*R3 (N*4 bytes of LDS, <= 1024 threads, <= 40
+// elements per thread).  1 ms (GPS L1 / L5) and 4 ms (Galileo E1) code periods at the usual front-end rates.
 #define GSH_OC_PLANS(X) \
-    X(25, 25, 40) /* 25 000: 25 Msps x 1 ms */ \
-    X(10, 20, 20) /*  4 000:  4 Msps x 1 ms */
+    X(25, 25, 40) /* 25 000: 25 Msps x 1 ms, 6.25 Msps x 4 ms */ \
+    X(10, 20, 20) /*  4 000:  4 Msps x 1 ms */ \
+    X(8, 16, 16)  /*  2 048:  2.048 Msps x 1 ms */ \
+    X(16, 16, 16) /*  4 096 */ \
+    X(10, 20, 25) /*  5 000:  5 Msps x 1 ms */ \
+    X(20, 20, 20) /*  8 000:  8 Msps x 1 ms, 2 Msps x 4 ms */ \
+    X(16, 16, 32) /*  8 192 */ \
+    X(20, 20, 25) /* 10 000: 10 Msps x 1 ms, 2.5 Msps x 4 ms */ \
+    X(20, 25, 25) /* 12 500: 12.5 Msps x 1 ms */ \
+    X(20, 20, 40) /* 16 000: 16 Msps x 1 ms, 4 Msps x 4 ms */ \
+    X(16, 32, 32) /* 16 384 */ \
+    X(25, 25, 32) /* 20 000: 20 Msps x 1 ms, 5 Msps x 4 ms */ \
+    X(32, 32, 32) /* 32 768 */
 
 #endif

@@ -40,10 +40,16 @@ def _same_peak(res, ora, prec, tag):
 @pytest.mark.parametrize("n,consumed,fs,bt", [(4000, 4000, 4000000, False), (2048, 2048, 2048000, False),
                                               (2046, 2046, 2046000, False), (5000, 5000, 5000000, False),
                                               (16368, 16368, 16368000, False), (8000, 8000, 4000000, True),
-                                              (8000, 4000, 4000000, False), (25000, 25000, 25000000, False)])
+                                              (8000, 4000, 4000000, False), (25000, 25000, 25000000, False),
+                                              (4096, 4096, 4096000, False), (8192, 8192, 8192000, False),
+                                              (10000, 10000, 10000000, False), (12500, 12500, 12500000, False),
+                                              (16000, 16000, 16000000, False), (16384, 16384, 16384000, False),
+                                              (20000, 20000, 20000000, False), (32768, 32768, 32768000, False)])
 def test_grid_matches_oracle(gpu, n, consumed, fs, bt):
     """FFT sizes with radix-2/3/4/5/8 and generic (11, 31) passes; bit_transition_flag (acq.cc:230-235) and
-    fft_size = 2*consumed (sampled_ms != ms_per_code, acq.cc:111,243-247) paddings."""
+    fft_size = 2*consumed (sampled_ms != ms_per_code, acq.cc:111,243-247) paddings.  Every length with an on-chip plan
+    (GSH_OC_PLANS in csrc/fft_onchip.h) goes through the whole-transform-on-chip kernels, the others (2046, 16368, the
+    bit-transition case) through the four-step kernels."""
     rng = np.random.default_rng(n)
     spms = fs // 1000
     prn = 7
@@ -202,7 +208,7 @@ def test_noncoherent_dwells_center_and_errors(gpu):
         _bank(gpu, max_prn=1, fs_in=fs, fft_size=4007 * 2, doppler_max=5000, doppler_step=500, samples_per_chip=4, samples_per_code=4000.0)  # prime factor 4007
 
 
-@pytest.mark.parametrize("n,fs", [(4000, 4000000), (25000, 25000000)])
+@pytest.mark.parametrize("n,fs", [(4000, 4000000), (25000, 25000000), (16384, 16384000), (20000, 20000000)])
 def test_onchip_agrees_with_fourstep_and_nogrid_rules(gpu, n, fs):
     """Lengths with an on-chip plan: the whole-transform-on-chip kernels and the four-step kernels are two independent
     FFT factorisations of the same dwell -- identical peak indices, values within float32 FFT rounding; with
