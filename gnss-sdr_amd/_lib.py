@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("GSH_LIB_PATH") or os.path.join(_HERE, "libgnss_sdr_hi
 
 GSH_MAX_TAPS = 8
 GSH_OK = 0
+GSH_ITEM_GR_COMPLEX, GSH_ITEM_SHORT, GSH_ITEM_BYTE = 0, 1, 2
 ERR_NAMES = {1: "GSH_ERR_INVALID", 2: "GSH_ERR_NO_DEVICE", 3: "GSH_ERR_HIP", 4: "GSH_ERR_STATE", 5: "GSH_ERR_UNSUPPORTED"}
 
 
@@ -59,6 +60,8 @@ class AcqConf(C.Structure):
         ("max_prn", C.c_uint32),
         ("no_grid", C.c_int32),
         ("transform_path", C.c_int32),
+        ("num_doppler_bins_step2", C.c_uint32),
+        ("doppler_step2", C.c_float),
     ]
 
 
@@ -130,6 +133,14 @@ SYMBOLS = {
     "gsh_bank_read_outputs": (C.c_int, [_P, _F, C.c_int]),
     "gsh_bank_time_launches": (C.c_int, [_P, C.c_int, _F]),
     "gsh_bank_set_splits": (C.c_int, [_P, C.c_int]),
+    "gsh_bank_set_stream_ring": (C.c_int, [_P, _P]),
+    "gsh_stream_create": (C.c_int, [C.c_int, C.c_uint64, C.c_uint32, C.POINTER(_P)]),
+    "gsh_stream_destroy": (None, [_P]),
+    "gsh_stream_push": (C.c_int, [_P, _P, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64)]),
+    "gsh_stream_push_device": (C.c_int, [_P, _P, C.c_uint64, C.c_int, C.c_int, _P, C.POINTER(C.c_uint64)]),
+    "gsh_stream_range": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "gsh_stream_read": (C.c_int, [_P, C.c_uint64, C.c_uint64, _F]),
+    "gsh_convert_samples_device": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, _P, C.c_uint64, _P]),
     "gsh_trk_create": (C.c_int, [C.c_int, C.POINTER(TrkConf), C.c_int, C.c_int, C.POINTER(_P)]),
     "gsh_trk_destroy": (None, [_P]),
     "gsh_trk_set_stream_host": (C.c_int, [_P, _F, C.c_uint64]),
@@ -143,6 +154,9 @@ SYMBOLS = {
     "gsh_acq_set_doppler_center": (C.c_int, [_P, C.c_int32]),
     "gsh_acq_dwell": (C.c_int, [_P, _F, C.c_uint32, C.c_int, C.c_uint32, C.POINTER(AcqResult)]),
     "gsh_acq_dwell_device": (C.c_int, [_P, _P, C.c_uint32, C.c_int, C.c_uint32, C.POINTER(AcqResult)]),
+    "gsh_acq_dwell_step2": (C.c_int, [_P, _F, C.c_uint32, C.POINTER(C.c_uint32), _F, _F, C.c_int, C.c_uint32, C.POINTER(AcqResult)]),
+    "gsh_acq_dwell_step2_device": (C.c_int, [_P, _P, C.c_uint32, C.POINTER(C.c_uint32), _F, _F, C.c_int, C.c_uint32, C.POINTER(AcqResult)]),
+    "gsh_acq_dwell_cshort": (C.c_int, [_P, C.POINTER(C.c_int16), C.c_uint32, C.c_int, C.c_uint32, C.POINTER(AcqResult)]),
     "gsh_acq_read_grid": (C.c_int, [_P, C.c_uint32, _F]),
     "gsh_acq_time_dwells": (C.c_int, [_P, C.c_uint32, C.c_int, _F]),
     "gsh_acq_time_dwells_pipelined": (C.c_int, [_P, C.c_uint32, C.c_int, _F]),

@@ -34,7 +34,7 @@ class PcpsAcquisitionBank:
                  samples_per_code: float, max_prn: int = 1, num_doppler_bins: int = 0, consumed_samples: int | None = None,
                  effective_fft_size: int | None = None, doppler_center: int = 0, doppler_bias: int = 0,
                  bit_transition_flag: bool = False, use_cfar: bool = True, device: int = 0, keep_grid: bool = True,
-                 transform_path: int = 0):
+                 transform_path: int = 0, num_doppler_bins_step2: int = 0, doppler_step2: float = 125.0):
         self._lib = _lib.load()
         c = AcqConf()
         c.fs_in = int(fs_in)
@@ -53,6 +53,8 @@ class PcpsAcquisitionBank:
         c.max_prn = int(max_prn)
         c.no_grid = 0 if keep_grid else 1  # keep_grid=False: max_dwells == 1 and no dump (no accumulate, no read_grid)
         c.transform_path = int(transform_path)
+        c.num_doppler_bins_step2 = int(num_doppler_bins_step2)  # 0: make_two_steps off
+        c.doppler_step2 = float(doppler_step2)
         self.conf = c
         self.num_doppler_bins = int(num_doppler_bins) if num_doppler_bins else int(math.ceil(2.0 * doppler_max / doppler_step))
         self._h = C.c_void_p()
@@ -93,6 +95,27 @@ class PcpsAcquisitionBank:
     def dwell_device(self, device_ptr: int, n_prn: int, accumulate: bool = False, dwell_count: int = 1):
         res = (AcqResult * n_prn)()
         check(self._lib.gsh_acq_dwell_device(self._h, C.c_void_p(device_ptr), n_prn, int(accumulate), dwell_count, res))
+        return [self._to_dict(r) for r in res]
+
+    def dwell_cshort(self, x16: np.ndarray, n_prn: int, accumulate: bool = False, dwell_count: int = 1):
+        """item_type = cshort (acq.cc:653-656): x16 is int16 [consumed_samples, 2] (I, Q), converted on the device."""
+        x16 = np.ascontiguousarray(x16, np.int16).reshape(-1)
+        if len(x16) < 2 * self.conf.consumed_samples:
+            raise ValueError("input shorter than consumed_samples")
+        res = (AcqResult * n_prn)()
+        check(self._lib.gsh_acq_dwell_cshort(self._h, x16.ctypes.data_as(C.POINTER(C.c_int16)), n_prn, int(accumulate), dwell_count, res))
+        return [self._to_dict(r) for r in res]
+
+    def dwell_step2(self, x: np.ndarray, prn_slots, doppler_centers, input_powers=None, accumulate: bool = False, dwell_count: int = 1):
+        """Step two of make_two_steps (acq.cc:294-301, 428-437, 605-624): a narrow grid around each slot's step-one Doppler."""
+        x = np.ascontiguousarray(x, np.complex64)
+        n = len(prn_slots)
+        slots = np.ascontiguousarray(prn_slots, np.uint32)
+        cen = np.ascontiguousarray(doppler_centers, np.float32)
+        pw = np.ascontiguousarray(input_powers if input_powers is not None else np.zeros(n), np.float32)
+        res = (AcqResult * n)()
+        check(self._lib.gsh_acq_dwell_step2(self._h, fptr(x), n, slots.ctypes.data_as(C.POINTER(C.c_uint32)), fptr(cen),
+                                            fptr(pw) if (input_powers is not None or self.conf.use_cfar) else None, int(accumulate), dwell_count, res))
         return [self._to_dict(r) for r in res]
 
     def read_grid(self, prn_slot: int) -> np.ndarray:

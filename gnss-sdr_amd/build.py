@@ -20,16 +20,20 @@ def sources() -> list[str]:
     return sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")))
 
 
+def _headers() -> list[str]:
+    return glob.glob(os.path.join(_HERE, "csrc", "*.h")) + glob.glob(os.path.join(_ROOT, "include", "*.h"))
+
+
 def _stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = sources() + glob.glob(os.path.join(_HERE, "csrc", "*.h")) + glob.glob(os.path.join(_ROOT, "include", "*.h"))
-    return any(os.path.getmtime(p) > t for p in deps)
+    return any(os.path.getmtime(p) > t for p in sources() + _headers())
 
 
 def build_library(force: bool = False, verbose: bool = False) -> str:
-    """Compile every HIP translation unit for gfx950 into one shared library.  Returns its path."""
+    """Compile every HIP translation unit for gfx950 (one object per file, stale ones only, in parallel) and link them
+    into one shared library.  Returns its path."""
     if not force and not _stale():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
@@ -37,10 +41,26 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         if os.path.exists(LIB):
             return LIB  # GPU box without a compiler: use the prebuilt library that travelled with the tree
         raise RuntimeError("hipcc not found and no prebuilt libgnss_sdr_hip.so present")
-    cmd = [hipcc] + HIPCC_FLAGS + ["-I" + os.path.join(_ROOT, "include"), "-I" + os.path.join(_HERE, "csrc"),
-                                   "-o", LIB + ".tmp"] + sources()
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+    from concurrent.futures import ThreadPoolExecutor
+    objdir = os.path.join(_HERE, "_build")
+    os.makedirs(objdir, exist_ok=True)
+    hdr_t = max(os.path.getmtime(h) for h in _headers())
+    flags = [f for f in HIPCC_FLAGS if f != "-shared"]
+    inc = ["-I" + os.path.join(_ROOT, "include"), "-I" + os.path.join(_HERE, "csrc")]
+    objs, jobs = [], []
+    for src in sources():
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
+            jobs.append([hipcc] + flags + inc + ["-c", src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+
+    with ThreadPoolExecutor(max(1, min(len(jobs), os.cpu_count() or 1))) as ex:
+        list(ex.map(run, jobs))
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB + ".tmp"] + objs)
     os.replace(LIB + ".tmp", LIB)
     return LIB

@@ -4,8 +4,10 @@
 // local codes: the D wiped-off forward FFTs are computed ONCE and shared by every PRN (the reference recomputes
 // them in every channel's block).
 #include "pcps_fft.h"
+#include "sample_convert.h"
 #include <algorithm>
 #include <cmath>
+#include <limits>
 #include <new>
 #include <vector>
 
@@ -16,8 +18,12 @@ struct gsh_acq
     hipStream_t stream{nullptr};
     gsh::FftPlan plan;
     int n_bins{0};
-    std::vector<int> h_bins_hz;
-    int* d_bins_hz{nullptr};
+    std::vector<float> h_bins_hz;   // the float the reference hands to update_local_carrier (acq.cc:289, :299)
+    float* d_bins_hz{nullptr};
+    int n_bins2{0};                 // num_doppler_bins_step2 (0: no fine-Doppler step)
+    std::vector<float> h_bins2_hz;  // max_prn * n_bins2, rebuilt by every gsh_acq_dwell_step2 call
+    float* d_bins2_hz{nullptr};
+    int16_t* d_in16{nullptr};       // cshort input staging (gsh_acq_dwell_cshort), allocated on first use
     float2* d_in{nullptr};        // consumed_samples
     float2* d_spectra{nullptr};   // n_bins * n
     float2* d_codes{nullptr};     // max_prn * n   (forward FFT of the placed code, permuted layout, unconjugated)
@@ -51,12 +57,12 @@ void fill_bins(gsh_acq* a)
 {
     // acq.cc:284-291: doppler = -doppler_max + doppler_center + doppler_step * index (+ FDMA bias, :289)
     for (int d = 0; d < a->n_bins; d++)
-        a->h_bins_hz[d] = a->conf.doppler_bias + (-a->conf.doppler_max + a->conf.doppler_center + a->conf.doppler_step * d);
+        a->h_bins_hz[d] = static_cast<float>(a->conf.doppler_bias + (-a->conf.doppler_max + a->conf.doppler_center + a->conf.doppler_step * d));
 }
 
 int upload_bins(gsh_acq* a)
 {
-    GSH_HIP(hipMemcpyAsync(a->d_bins_hz, a->h_bins_hz.data(), sizeof(int) * a->n_bins, hipMemcpyHostToDevice, a->stream));
+    GSH_HIP(hipMemcpyAsync(a->d_bins_hz, a->h_bins_hz.data(), sizeof(float) * a->n_bins, hipMemcpyHostToDevice, a->stream));
     GSH_HIP(hipStreamSynchronize(a->stream));
     return GSH_OK;
 }
@@ -235,6 +241,9 @@ extern "C"
         GSH_REQUIRE(c.max_prn >= 1 && c.max_prn <= 4096, "max_prn %u outside 1..4096", c.max_prn);
         GSH_REQUIRE(2 * c.samples_per_chip < c.effective_fft_size, "samples_per_chip %u too large for %u cells (acq.cc:485-509 would not terminate)", c.samples_per_chip, c.effective_fft_size);
         GSH_REQUIRE(c.transform_path == 0 || c.transform_path == 1, "transform_path %d outside 0..1", c.transform_path);
+        GSH_REQUIRE(c.num_doppler_bins_step2 <= c.num_doppler_bins, "num_doppler_bins_step2 %u exceeds num_doppler_bins %u (the narrow grid reuses the wide grid's buffers, as d_magnitude_grid does, acq.cc:137)",
+            c.num_doppler_bins_step2, c.num_doppler_bins);
+        GSH_REQUIRE(c.num_doppler_bins_step2 == 0 || (std::isfinite(c.doppler_step2) && c.doppler_step2 > 0.0f), "doppler_step2 must be positive");
         int rc = gsh::use_device(device);
         if (rc != GSH_OK) return rc;
         gsh_acq* a = new (std::nothrow) gsh_acq();
@@ -242,7 +251,9 @@ extern "C"
         a->device = device;
         a->conf = c;
         a->n_bins = static_cast<int>(c.num_doppler_bins);
-        a->h_bins_hz.assign(a->n_bins, 0);
+        a->h_bins_hz.assign(a->n_bins, 0.0f);
+        a->n_bins2 = static_cast<int>(c.num_doppler_bins_step2);
+        a->h_bins2_hz.assign(static_cast<size_t>(a->n_bins2) * c.max_prn, 0.0f);
         a->code_set.assign(c.max_prn, 0);
         // the on-chip kernels assume effective_fft_size == fft_size: bit_transition_flag searches go through the four-step path
         a->onchip = (c.transform_path == 0) && !c.bit_transition_flag && gsh::onchip_supported(static_cast<int>(c.fft_size));
@@ -269,7 +280,8 @@ extern "C"
         };
         hipError_t e;
         if ((e = hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
-        if ((e = hipMalloc(&a->d_bins_hz, sizeof(int) * D)) != hipSuccess) return fail(e, "hipMalloc(bins)");
+        if ((e = hipMalloc(&a->d_bins_hz, sizeof(float) * D)) != hipSuccess) return fail(e, "hipMalloc(bins)");
+        if (a->n_bins2 > 0 && (e = hipMalloc(&a->d_bins2_hz, sizeof(float) * a->n_bins2 * P)) != hipSuccess) return fail(e, "hipMalloc(bins2)");
         if ((e = hipMalloc(&a->d_in, sizeof(float2) * n)) != hipSuccess) return fail(e, "hipMalloc(in)");
         if ((e = hipMalloc(&a->d_spectra, sizeof(float2) * D * n)) != hipSuccess) return fail(e, "hipMalloc(spectra)");
         if ((e = hipMalloc(&a->d_codes, sizeof(float2) * P * n)) != hipSuccess) return fail(e, "hipMalloc(codes)");
@@ -308,6 +320,8 @@ extern "C"
         if (a->stream) (void)hipStreamSynchronize(a->stream);
         gsh::plan_destroy(&a->plan);
         if (a->d_bins_hz) (void)hipFree(a->d_bins_hz);
+        if (a->d_bins2_hz) (void)hipFree(a->d_bins2_hz);
+        if (a->d_in16) (void)hipFree(a->d_in16);
         if (a->d_in) (void)hipFree(a->d_in);
         if (a->d_spectra) (void)hipFree(a->d_spectra);
         if (a->d_codes) (void)hipFree(a->d_codes);
@@ -423,6 +437,137 @@ extern "C"
         rc = enqueue_dwell(a, n_prn, accumulate, dwell_count);
         if (rc != GSH_OK) return rc;
         return finish_results(a, n_prn, results);
+    }
+
+    int gsh_acq_dwell_cshort(gsh_acq_t* a, const int16_t* in_iq16, uint32_t n_prn, int accumulate, uint32_t dwell_count, gsh_acq_result* results)
+    {
+        int rc = check_dwell_args(a, n_prn, results);
+        if (rc == GSH_OK) rc = check_accumulate(a, accumulate);
+        if (rc != GSH_OK) return rc;
+        GSH_REQUIRE(in_iq16 != nullptr, "null input");
+        GSH_HIP(hipSetDevice(a->device));
+        const size_t n = a->conf.consumed_samples;
+        if (a->d_in16 == nullptr) GSH_HIP(hipMalloc(&a->d_in16, sizeof(int16_t) * 2 * n));
+        // h_stage holds fft_size complex64 = room for 4 * fft_size int16
+        std::memcpy(a->h_stage, in_iq16, sizeof(int16_t) * 2 * n);
+        GSH_HIP(hipMemcpyAsync(a->d_in16, a->h_stage, sizeof(int16_t) * 2 * n, hipMemcpyHostToDevice, a->stream));
+        rc = gsh::convert_to_complex(a->d_in16, GSH_ITEM_SHORT, 0, a->d_in, n, a->stream);  // acq.cc:653-656
+        if (rc != GSH_OK) return rc;
+        a->have_input = true;
+        rc = enqueue_dwell(a, n_prn, accumulate, dwell_count);
+        if (rc != GSH_OK) return rc;
+        return finish_results(a, n_prn, results);
+    }
+
+    static int dwell_step2_common(gsh_acq_t* a, uint32_t n, const uint32_t* prn_slots, const float* centers, const float* powers, int accumulate,
+        uint32_t dwell_count, gsh_acq_result* results)
+    {
+        const gsh_acq_conf& c = a->conf;
+        const int nfft = static_cast<int>(c.fft_size);
+        const int eff = static_cast<int>(c.effective_fft_size);
+        const int D2 = a->n_bins2;
+        const float half = static_cast<float>(std::floor(static_cast<double>(D2) / 2.0));  // acq.cc:298
+        for (uint32_t i = 0; i < n; i++)
+            for (int d = 0; d < D2; d++)
+                {
+                    const float doppler = (static_cast<float>(d) - half) * c.doppler_step2;    // acq.cc:298
+                    a->h_bins2_hz[static_cast<size_t>(i) * D2 + d] = centers[i] + doppler;     // acq.cc:299
+                }
+        GSH_HIP(hipMemcpyAsync(a->d_bins2_hz, a->h_bins2_hz.data(), sizeof(float) * D2 * n, hipMemcpyHostToDevice, a->stream));
+        const size_t grid_per_prn = static_cast<size_t>(a->n_bins) * eff;
+        for (uint32_t i = 0; i < n; i++)
+            {
+                const uint32_t slot = prn_slots[i];
+                const float* bins = a->d_bins2_hz + static_cast<size_t>(i) * D2;
+                float* grid = a->d_grid ? a->d_grid + slot * grid_per_prn : nullptr;  // rows 0..D2-1 of the PRN's grid (acq.cc:526 reuses d_magnitude_grid)
+                int rc;
+                if (a->onchip)
+                    {
+                        rc = gsh::onchip_forward(nfft, a->d_in, 0, static_cast<int>(c.consumed_samples), 0, bins, static_cast<double>(c.fs_in), a->d_spectra, D2,
+                            a->stream);
+                        if (rc != GSH_OK) return rc;
+                        rc = gsh::onchip_correlate(nfft, a->d_spectra, a->d_codes + static_cast<size_t>(slot) * nfft, grid, a->d_rows + static_cast<size_t>(i) * D2,
+                            a->d_results + i, a->d_arrivals + i, 1, D2, eff, accumulate, c.no_grid ? 0 : 1, static_cast<int>(c.samples_per_chip), c.use_cfar,
+                            dwell_count ? dwell_count : 1u, a->stream);
+                    }
+                else
+                    {
+                        rc = gsh::fft_forward(a->plan, a->d_in, 0, static_cast<int>(c.consumed_samples), 0, bins, static_cast<double>(c.fs_in), a->d_tmp,
+                            a->d_spectra, D2, a->stream);
+                        if (rc != GSH_OK) return rc;
+                        rc = gsh::correlate_grid(a->plan, a->d_spectra, a->d_codes + static_cast<size_t>(slot) * nfft, a->d_tmp, grid, 1, D2,
+                            c.bit_transition_flag ? eff : 0, eff, accumulate, a->stream);
+                        if (rc != GSH_OK) return rc;
+                        rc = gsh::grid_statistics(grid, a->d_rows + static_cast<size_t>(i) * D2, a->d_results + i, 1, D2, eff, static_cast<int>(c.samples_per_chip),
+                            c.use_cfar, dwell_count ? dwell_count : 1u, a->stream);
+                    }
+                if (rc != GSH_OK) return rc;
+            }
+        GSH_HIP(hipMemcpyAsync(a->h_results, a->d_results, sizeof(gsh::DevAcqResult) * n, hipMemcpyDeviceToHost, a->stream));
+        GSH_HIP(hipStreamSynchronize(a->stream));
+        for (uint32_t i = 0; i < n; i++)
+            {
+                const gsh::DevAcqResult& r = a->h_results[i];
+                gsh_acq_result& o = results[i];
+                o.index_time = r.index_time;
+                o.index_doppler = r.index_doppler;
+                o.doppler_hz = static_cast<int32_t>(centers[i] + (static_cast<float>(r.index_doppler) - half) * c.doppler_step2);  // acq.cc:436 / :481
+                o.acq_delay_samples = std::fmod(static_cast<float>(r.index_time), c.samples_per_code);
+                o.peak = r.peak;
+                o.second_peak = r.second_peak;
+                if (c.use_cfar)
+                    {
+                        // acq.cc:428-445: d_input_power is NOT recomputed in step two; the statistic divides by step one's value
+                        o.input_power = powers[i];
+                        o.test_statistics = (powers[i] < std::numeric_limits<float>::epsilon()) ? 0.0f : r.peak / powers[i];
+                    }
+                else
+                    {
+                        o.input_power = r.input_power;
+                        o.test_statistics = r.test_statistics;
+                    }
+            }
+        return GSH_OK;
+    }
+
+    static int check_step2_args(gsh_acq_t* a, const void* in, uint32_t n, const uint32_t* prn_slots, const float* centers, const float* powers, int accumulate,
+        gsh_acq_result* results)
+    {
+        GSH_REQUIRE(a != nullptr && in != nullptr && prn_slots != nullptr && centers != nullptr && results != nullptr, "null argument");
+        if (a->n_bins2 <= 0) return set_error(GSH_ERR_STATE, "the handle was created with num_doppler_bins_step2 = 0 (make_two_steps off)");
+        GSH_REQUIRE(n >= 1 && n <= a->conf.max_prn, "n %u outside 1..%u", n, a->conf.max_prn);
+        GSH_REQUIRE(!a->conf.use_cfar || powers != nullptr, "the CFAR statistic of step two needs step one's input power (acq.cc:428-445)");
+        for (uint32_t i = 0; i < n; i++)
+            {
+                GSH_REQUIRE(prn_slots[i] < a->conf.max_prn, "prn slot %u outside 0..%u", prn_slots[i], a->conf.max_prn - 1);
+                if (!a->code_set[prn_slots[i]]) return set_error(GSH_ERR_STATE, "local code of prn slot %u has not been set (set_local_code)", prn_slots[i]);
+                GSH_REQUIRE(std::isfinite(centers[i]), "doppler_center_step_two[%u] is not finite", i);
+                for (uint32_t k = 0; k < i; k++) GSH_REQUIRE(prn_slots[k] != prn_slots[i], "prn slot %u listed twice", prn_slots[i]);
+            }
+        return check_accumulate(a, accumulate);
+    }
+
+    int gsh_acq_dwell_step2_device(gsh_acq_t* a, const void* device_in_iq, uint32_t n, const uint32_t* prn_slots, const float* doppler_center_step_two,
+        const float* input_power_step_one, int accumulate, uint32_t dwell_count, gsh_acq_result* results)
+    {
+        int rc = check_step2_args(a, device_in_iq, n, prn_slots, doppler_center_step_two, input_power_step_one, accumulate, results);
+        if (rc != GSH_OK) return rc;
+        GSH_HIP(hipSetDevice(a->device));
+        GSH_HIP(hipMemcpyAsync(a->d_in, device_in_iq, sizeof(float2) * a->conf.consumed_samples, hipMemcpyDeviceToDevice, a->stream));
+        a->have_input = true;
+        return dwell_step2_common(a, n, prn_slots, doppler_center_step_two, input_power_step_one, accumulate, dwell_count, results);
+    }
+
+    int gsh_acq_dwell_step2(gsh_acq_t* a, const float* in_iq, uint32_t n, const uint32_t* prn_slots, const float* doppler_center_step_two,
+        const float* input_power_step_one, int accumulate, uint32_t dwell_count, gsh_acq_result* results)
+    {
+        int rc = check_step2_args(a, in_iq, n, prn_slots, doppler_center_step_two, input_power_step_one, accumulate, results);
+        if (rc != GSH_OK) return rc;
+        GSH_HIP(hipSetDevice(a->device));
+        std::memcpy(a->h_stage, in_iq, sizeof(float2) * a->conf.consumed_samples);
+        GSH_HIP(hipMemcpyAsync(a->d_in, a->h_stage, sizeof(float2) * a->conf.consumed_samples, hipMemcpyHostToDevice, a->stream));
+        a->have_input = true;
+        return dwell_step2_common(a, n, prn_slots, doppler_center_step_two, input_power_step_one, accumulate, dwell_count, results);
     }
 
     int gsh_acq_read_grid(gsh_acq_t* a, uint32_t prn_slot, float* grid)

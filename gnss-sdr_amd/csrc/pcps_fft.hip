@@ -236,7 +236,7 @@ __device__ __forceinline__ float2* lds_fft(float2* x, float2* y, const float2* t
 
 // exp(-j 2 pi f n / fs), exact phase: the product f*n is exact in double, the fraction is reduced before the
 // float sincos (the reference accumulates the phase in float32, K/volk_gnsssdr_s32f_sincos_32fc.h:390-400)
-__device__ __forceinline__ float2 wipeoff(int f_hz, int n, double inv_fs)
+__device__ __forceinline__ float2 wipeoff(float f_hz, int n, double inv_fs)
 {
     double rev = static_cast<double>(f_hz) * static_cast<double>(n) * inv_fs;
     rev -= rint(rev);
@@ -254,7 +254,7 @@ struct FwdColsArgs
     size_t src_stride;
     int n_in;
     int place_off;
-    const int* wipe_hz;
+    const float* wipe_hz;
     double inv_fs;
     float2* dst;
     const float2* tw_n;
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(FFT_THREADS) void fwd_cols_kernel(FwdColsArgs a)
     const int c0 = blockIdx.x * tile;
     const float2* __restrict__ src = a.src + static_cast<size_t>(b) * a.src_stride;
     const bool wipe = a.wipe_hz != nullptr;
-    const int f_hz = wipe ? a.wipe_hz[b] : 0;
+    const float f_hz = wipe ? a.wipe_hz[b] : 0.0f;
     for (int i = threadIdx.x; i < a.n1; i += FFT_THREADS) tw[i] = a.tw_1[i];
     const int elems = a.n1 * tile;
     for (int i = threadIdx.x; i < elems; i += FFT_THREADS)
@@ -697,7 +697,7 @@ void plan_destroy(FftPlan* plan)
 // ---------------------------------------------------------------------------------------------------------
 // host side: launches
 // ---------------------------------------------------------------------------------------------------------
-int fft_forward(const FftPlan& p, const float2* src, size_t src_stride, int n_in, int place_off, const int* wipe_hz, double fs,
+int fft_forward(const FftPlan& p, const float2* src, size_t src_stride, int n_in, int place_off, const float* wipe_hz, double fs,
     float2* tmp, float2* dst, int batch, hipStream_t s)
 {
     if (batch <= 0) return GSH_OK;

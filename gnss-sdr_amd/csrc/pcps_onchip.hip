@@ -32,7 +32,7 @@ struct OcFwdArgs
     size_t src_stride;
     int n_in;
     int place_off;
-    const int* wipe_hz;
+    const float* wipe_hz;
     double inv_fs;
     cf* dst;
 };
@@ -54,7 +54,7 @@ struct OcCellArgs
 };
 
 // exp(-j 2 pi f n / fs) with the product reduced in double before the float sincos
-__device__ __forceinline__ cf wipe_phasor(int f_hz, int n, double inv_fs)
+__device__ __forceinline__ cf wipe_phasor(float f_hz, int n, double inv_fs)
 {
     double rev = static_cast<double>(f_hz) * static_cast<double>(n) * inv_fs;
     rev -= rint(rev);
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(P::THREADS) void oc_forward_kernel(OcFwdArgs a)
             if (a.wipe_hz != nullptr)
                 {
                     // w[n] = w[t] * (w[T1])^n1, both seeds exact, powers by the squaring tree
-                    const int f = a.wipe_hz[b];
+                    const float f = a.wipe_hz[b];
                     const cf w0 = wipe_phasor(f, t, a.inv_fs);
                     oc::mul_powers<P::R1>(ra, wipe_phasor(f, P::T1, a.inv_fs));
                     oc::static_for<P::R1>([&](auto N1) GSH_AI { ra[decltype(N1)::value] = oc::cmul(ra[decltype(N1)::value], w0); });
@@ -383,7 +383,7 @@ bool onchip_supported(int n)
     return false;
 }
 
-int onchip_forward(int n, const float2* src, size_t src_stride, int n_in, int place_off, const int* wipe_hz, double fs, float2* dst,
+int onchip_forward(int n, const float2* src, size_t src_stride, int n_in, int place_off, const float* wipe_hz, double fs, float2* dst,
     int batch, hipStream_t s)
 {
     if (batch <= 0) return GSH_OK;

@@ -1,0 +1,26 @@
+// Device-resident IF sample ring (C ABI gsh_stream_*, include/gnss_sdr_hip.h).  Internal view for the other
+// translation units of the library.
+#ifndef GSH_SAMPLE_STREAM_H
+#define GSH_SAMPLE_STREAM_H
+#include "gsh_internal.h"
+
+struct gsh_stream
+{
+    int device{0};
+    hipStream_t stream{nullptr};
+    unsigned long long capacity{0};    // C: samples kept
+    unsigned long long max_window{0};  // M: mirror length; any window <= M is contiguous
+    float2* d_ring{nullptr};           // C + M + 2 samples; absolute index i lives at i % C (and at C + i % C when i % C < M)
+    void* d_raw{nullptr};              // staging for raw host items before conversion
+    size_t raw_cap{0};                 // bytes
+    unsigned long long next{0};        // absolute index of the next sample to be pushed
+    hipEvent_t pushed{nullptr};        // recorded after the last push's device work
+};
+
+namespace gsh
+{
+// device address of absolute sample `index`, contiguous for n samples; GSH_ERR_INVALID when [index, index+n) is not resident
+int stream_window(const gsh_stream* s, unsigned long long index, unsigned long long n, const float2** ptr);
+inline unsigned long long stream_oldest(const gsh_stream* s) { return s->next > s->capacity ? s->next - s->capacity : 0ull; }
+}  // namespace gsh
+#endif

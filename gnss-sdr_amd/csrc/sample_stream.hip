@@ -1,0 +1,176 @@
+// gsh_stream_*: the IF sample stream of one front-end as a ring in device memory, addressed by absolute sample index.
+// See include/gnss_sdr_hip.h for the contract and the reference pieces it stands in for.
+#include "sample_stream.h"
+#include "sample_convert.h"
+#include <algorithm>
+#include <new>
+
+namespace gsh
+{
+int stream_window(const gsh_stream* s, unsigned long long index, unsigned long long n, const float2** ptr)
+{
+    if (n > s->max_window) return set_error(GSH_ERR_INVALID, "window of %llu samples exceeds the ring's max_window_samples %llu", n, s->max_window);
+    if (index < stream_oldest(s) || index + n > s->next)
+        return set_error(GSH_ERR_INVALID, "samples [%llu, %llu) are not resident (ring holds [%llu, %llu))", index, index + n, stream_oldest(s), s->next);
+    *ptr = s->d_ring + (index % s->capacity);
+    return GSH_OK;
+}
+}  // namespace gsh
+
+namespace
+{
+using gsh::set_error;
+
+// queue the conversion of n items at d_src into ring positions of absolute indices [first, first + n) on `st`
+int write_items(gsh_stream* s, const void* d_src, unsigned long long n, int item_type, int conj, hipStream_t st)
+{
+    const size_t isz = gsh::item_bytes(item_type);
+    const unsigned long long C = s->capacity, M = s->max_window;
+    unsigned long long done = 0;
+    while (done < n)
+        {
+            const unsigned long long p = (s->next + done) % C;
+            const unsigned long long len = std::min(n - done, C - p);
+            const char* src = static_cast<const char*>(d_src) + done * isz;
+            int rc = gsh::convert_to_complex(src, item_type, conj, s->d_ring + p, len, st);
+            if (rc != GSH_OK) return rc;
+            if (p < M)  // keep the mirror behind the end in step
+                {
+                    const unsigned long long ml = std::min(len, M - p);
+                    GSH_HIP(hipMemcpyAsync(s->d_ring + C + p, s->d_ring + p, sizeof(float2) * ml, hipMemcpyDeviceToDevice, st));
+                }
+            done += len;
+        }
+    return GSH_OK;
+}
+}  // namespace
+
+extern "C"
+{
+    int gsh_stream_create(int device, uint64_t capacity_samples, uint32_t max_window_samples, gsh_stream_t** out)
+    {
+        GSH_REQUIRE(out != nullptr, "null out pointer");
+        *out = nullptr;
+        GSH_REQUIRE(max_window_samples >= 1, "max_window_samples must be positive");
+        GSH_REQUIRE(capacity_samples >= 2ull * max_window_samples, "capacity_samples %llu must be at least twice max_window_samples %u",
+            static_cast<unsigned long long>(capacity_samples), max_window_samples);
+        GSH_REQUIRE(capacity_samples <= (1ull << 34), "capacity_samples %llu too large", static_cast<unsigned long long>(capacity_samples));
+        int rc = gsh::use_device(device);
+        if (rc != GSH_OK) return rc;
+        gsh_stream* s = new (std::nothrow) gsh_stream();
+        GSH_REQUIRE(s != nullptr, "out of host memory");
+        s->device = device;
+        s->capacity = capacity_samples + (capacity_samples & 1ull);  // even: windows keep their 16-byte phase across the wrap
+        s->max_window = max_window_samples;
+        auto fail = [&](hipError_t e, const char* what) {
+            gsh::hip_fail(e, what, __FILE__, __LINE__);
+            gsh_stream_destroy(s);
+            return GSH_ERR_HIP;
+        };
+        hipError_t e;
+        if ((e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
+        const size_t total = static_cast<size_t>(s->capacity + s->max_window + 2);
+        if ((e = hipMalloc(&s->d_ring, sizeof(float2) * total)) != hipSuccess) return fail(e, "hipMalloc(ring)");
+        if ((e = hipMemset(s->d_ring, 0, sizeof(float2) * total)) != hipSuccess) return fail(e, "hipMemset(ring)");
+        if ((e = hipEventCreateWithFlags(&s->pushed, hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
+        *out = s;
+        return GSH_OK;
+    }
+
+    void gsh_stream_destroy(gsh_stream_t* s)
+    {
+        if (!s) return;
+        (void)hipSetDevice(s->device);
+        if (s->stream) (void)hipStreamSynchronize(s->stream);
+        if (s->d_ring) (void)hipFree(s->d_ring);
+        if (s->d_raw) (void)hipFree(s->d_raw);
+        if (s->pushed) (void)hipEventDestroy(s->pushed);
+        if (s->stream) (void)hipStreamDestroy(s->stream);
+        delete s;
+    }
+
+    int gsh_stream_push_device(gsh_stream_t* s, const void* device_items, uint64_t n, int item_type, int inverted_spectrum, void* hip_stream,
+        uint64_t* first_index)
+    {
+        GSH_REQUIRE(s != nullptr, "null stream");
+        GSH_REQUIRE(n == 0 || device_items != nullptr, "null items");
+        GSH_REQUIRE(gsh::item_bytes(item_type) != 0, "unknown item type %d", item_type);
+        GSH_REQUIRE(n <= s->capacity, "a push of %llu samples exceeds the ring capacity %llu", static_cast<unsigned long long>(n), s->capacity);
+        if (first_index) *first_index = s->next;
+        if (n == 0) return GSH_OK;
+        GSH_HIP(hipSetDevice(s->device));
+        hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : s->stream;
+        int rc = write_items(s, device_items, n, item_type, inverted_spectrum ? 1 : 0, st);
+        if (rc != GSH_OK) return rc;
+        GSH_HIP(hipEventRecord(s->pushed, st));
+        s->next += n;
+        if (!hip_stream) GSH_HIP(hipStreamSynchronize(st));
+        return GSH_OK;
+    }
+
+    int gsh_stream_push(gsh_stream_t* s, const void* items, uint64_t n, int item_type, int inverted_spectrum, uint64_t* first_index)
+    {
+        GSH_REQUIRE(s != nullptr, "null stream");
+        GSH_REQUIRE(n == 0 || items != nullptr, "null items");
+        const size_t isz = gsh::item_bytes(item_type);
+        GSH_REQUIRE(isz != 0, "unknown item type %d", item_type);
+        GSH_REQUIRE(n <= s->capacity, "a push of %llu samples exceeds the ring capacity %llu", static_cast<unsigned long long>(n), s->capacity);
+        if (first_index) *first_index = s->next;
+        if (n == 0) return GSH_OK;
+        GSH_HIP(hipSetDevice(s->device));
+        const size_t bytes = static_cast<size_t>(n) * isz;
+        if (bytes > s->raw_cap)
+            {
+                if (s->d_raw) GSH_HIP(hipFree(s->d_raw));
+                s->d_raw = nullptr;
+                s->raw_cap = 0;
+                GSH_HIP(hipMalloc(&s->d_raw, bytes));
+                s->raw_cap = bytes;
+            }
+        GSH_HIP(hipMemcpyAsync(s->d_raw, items, bytes, hipMemcpyHostToDevice, s->stream));
+        int rc = write_items(s, s->d_raw, n, item_type, inverted_spectrum ? 1 : 0, s->stream);
+        if (rc != GSH_OK) return rc;
+        GSH_HIP(hipEventRecord(s->pushed, s->stream));
+        GSH_HIP(hipStreamSynchronize(s->stream));
+        s->next += n;
+        return GSH_OK;
+    }
+
+    int gsh_stream_range(gsh_stream_t* s, uint64_t* oldest, uint64_t* next)
+    {
+        GSH_REQUIRE(s != nullptr, "null stream");
+        if (oldest) *oldest = gsh::stream_oldest(s);
+        if (next) *next = s->next;
+        return GSH_OK;
+    }
+
+    int gsh_stream_read(gsh_stream_t* s, uint64_t index, uint64_t n, float* out_iq)
+    {
+        GSH_REQUIRE(s != nullptr && (n == 0 || out_iq != nullptr), "null argument");
+        GSH_REQUIRE(index >= gsh::stream_oldest(s) && index + n <= s->next, "samples [%llu, %llu) are not resident (ring holds [%llu, %llu))",
+            static_cast<unsigned long long>(index), static_cast<unsigned long long>(index + n), gsh::stream_oldest(s), s->next);
+        GSH_HIP(hipSetDevice(s->device));
+        GSH_HIP(hipStreamSynchronize(s->stream));
+        unsigned long long done = 0;
+        while (done < n)
+            {
+                const unsigned long long p = (index + done) % s->capacity;
+                const unsigned long long len = std::min<unsigned long long>(n - done, s->capacity - p);
+                GSH_HIP(hipMemcpy(out_iq + 2 * done, s->d_ring + p, sizeof(float2) * len, hipMemcpyDeviceToHost));
+                done += len;
+            }
+        return GSH_OK;
+    }
+
+    int gsh_convert_samples_device(int device, const void* device_items, int item_type, int inverted_spectrum, void* device_dst, uint64_t n,
+        void* hip_stream)
+    {
+        GSH_REQUIRE(n == 0 || (device_items != nullptr && device_dst != nullptr), "null argument");
+        GSH_REQUIRE(gsh::item_bytes(item_type) != 0, "unknown item type %d", item_type);
+        GSH_REQUIRE((reinterpret_cast<uintptr_t>(device_dst) & 7u) == 0, "destination must be 8-byte aligned");
+        int rc = gsh::use_device(device);
+        if (rc != GSH_OK) return rc;
+        return gsh::convert_to_complex(device_items, item_type, inverted_spectrum ? 1 : 0, static_cast<float2*>(device_dst), n,
+            static_cast<hipStream_t>(hip_stream));
+    }
+}

@@ -2,6 +2,7 @@
 // (gsh_bank_*) and the one-to-one Cpu_Multicorrelator_Real_Codes replacement (gsh_mcorr_*)
 // built on top of it.  Host-side bookkeeping only; the arithmetic is in multicorrelator.hip.
 #include "multicorrelator.h"
+#include "sample_stream.h"
 #include <algorithm>
 #include <cmath>
 #include <new>
@@ -32,6 +33,10 @@ struct gsh_bank
     unsigned long long max_end{0};
     int splits_user{0};
     hipEvent_t ev0{nullptr}, ev1{nullptr};
+    gsh_stream* ring{nullptr};          // when set, job windows are absolute sample indices inside this ring
+    gsh_corr_job* h_jobs{nullptr};      // pinned staging (ring translation; one-synchronisation gsh_bank_correlate)
+    float2* h_out{nullptr};             // pinned
+    int h_cap{0};
 };
 
 namespace
@@ -49,6 +54,66 @@ int bank_reserve_jobs(gsh_bank* b, int n)
     GSH_HIP(hipMalloc(&b->d_jobs, sizeof(gsh_corr_job) * static_cast<size_t>(n)));
     GSH_HIP(hipMalloc(&b->d_out, sizeof(float2) * GSH_MAX_TAPS * static_cast<size_t>(n)));
     b->jobs_cap = n;
+    return GSH_OK;
+}
+
+int validate_job(const gsh_bank* b, const gsh_corr_job& j, int idx);
+
+int bank_reserve_staging(gsh_bank* b, int n)
+{
+    if (n <= b->h_cap) return GSH_OK;
+    if (b->h_jobs) GSH_HIP(hipHostFree(b->h_jobs));
+    if (b->h_out) GSH_HIP(hipHostFree(b->h_out));
+    b->h_jobs = nullptr;
+    b->h_out = nullptr;
+    b->h_cap = 0;
+    const int cap = std::max(n, 64);
+    GSH_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->h_jobs), sizeof(gsh_corr_job) * static_cast<size_t>(cap), hipHostMallocDefault));
+    GSH_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->h_out), sizeof(float2) * GSH_MAX_TAPS * static_cast<size_t>(cap), hipHostMallocDefault));
+    b->h_cap = cap;
+    return GSH_OK;
+}
+
+// validate the batch, stage it in pinned memory (ring mode: absolute sample indices -> ring positions) and queue the
+// host-to-device copy on the bank's stream.  No synchronisation.
+int bank_stage_jobs(gsh_bank* b, const gsh_corr_job* jobs, int n_jobs)
+{
+    int max_taps = 0, mode = jobs[0].high_dyn, min_samples = jobs[0].n_samples;
+    unsigned long long max_end = 0;
+    for (int i = 0; i < n_jobs; i++)
+        {
+            int rc = validate_job(b, jobs[i], i);
+            if (rc != GSH_OK) return rc;
+            if (jobs[i].high_dyn != mode)
+                return set_error(GSH_ERR_UNSUPPORTED, "job %d: all jobs of one batch must share high_dyn (%d vs %d); split the batch", i, jobs[i].high_dyn, mode);
+            max_taps = std::max(max_taps, jobs[i].n_taps);
+            min_samples = std::min(min_samples, jobs[i].n_samples);
+            max_end = std::max(max_end, static_cast<unsigned long long>(jobs[i].sample_offset) + static_cast<unsigned long long>(jobs[i].n_samples));
+        }
+    GSH_HIP(hipSetDevice(b->device));
+    int rc = bank_reserve_jobs(b, n_jobs);
+    if (rc == GSH_OK) rc = bank_reserve_staging(b, n_jobs);
+    if (rc != GSH_OK) return rc;
+    std::memcpy(b->h_jobs, jobs, sizeof(gsh_corr_job) * static_cast<size_t>(n_jobs));
+    if (b->ring != nullptr)
+        {
+            for (int i = 0; i < n_jobs; i++)
+                {
+                    const float2* w = nullptr;
+                    rc = gsh::stream_window(b->ring, jobs[i].sample_offset, static_cast<unsigned long long>(jobs[i].n_samples), &w);
+                    if (rc != GSH_OK) return rc;
+                    b->h_jobs[i].sample_offset = static_cast<uint64_t>(w - b->ring->d_ring);
+                }
+            b->d_stream = b->ring->d_ring;
+            b->stream_len = b->ring->capacity + b->ring->max_window;
+            max_end = 0;  // residency was checked per job
+        }
+    GSH_HIP(hipMemcpyAsync(b->d_jobs, b->h_jobs, sizeof(gsh_corr_job) * static_cast<size_t>(n_jobs), hipMemcpyHostToDevice, b->stream));
+    b->n_jobs = n_jobs;
+    b->max_taps = max_taps;
+    b->mode = mode;
+    b->min_samples = min_samples;
+    b->max_end = max_end;
     return GSH_OK;
 }
 
@@ -138,6 +203,8 @@ extern "C"
         if (b->d_partials) (void)hipFree(b->d_partials);
         if (b->ev0) (void)hipEventDestroy(b->ev0);
         if (b->ev1) (void)hipEventDestroy(b->ev1);
+        if (b->h_jobs) (void)hipHostFree(b->h_jobs);
+        if (b->h_out) (void)hipHostFree(b->h_out);
         if (b->stream) (void)hipStreamDestroy(b->stream);
         delete b;
     }
@@ -174,6 +241,7 @@ extern "C"
         GSH_HIP(hipMemset(b->d_stream_owned + n_samples, 0, sizeof(float2) * 2));
         b->d_stream = b->d_stream_owned;
         b->stream_len = n_samples;
+        b->ring = nullptr;
         return GSH_OK;
     }
 
@@ -184,6 +252,7 @@ extern "C"
         GSH_REQUIRE((reinterpret_cast<uintptr_t>(device_iq) & 15u) == 0, "device stream must be 16-byte aligned");
         b->d_stream = static_cast<const float2*>(device_iq);
         b->stream_len = n_samples;
+        b->ring = nullptr;
         return GSH_OK;
     }
 
@@ -202,28 +271,32 @@ extern "C"
         GSH_REQUIRE(n_jobs == 0 || jobs != nullptr, "null jobs");
         b->n_jobs = 0;
         if (n_jobs == 0) return GSH_OK;
-        int max_taps = 0, mode = jobs[0].high_dyn, min_samples = jobs[0].n_samples;
-        unsigned long long max_end = 0;
-        for (int i = 0; i < n_jobs; i++)
+        int rc = bank_stage_jobs(b, jobs, n_jobs);
+        if (rc != GSH_OK)
             {
-                int rc = validate_job(b, jobs[i], i);
-                if (rc != GSH_OK) return rc;
-                if (jobs[i].high_dyn != mode)
-                    return set_error(GSH_ERR_UNSUPPORTED, "job %d: all jobs of one batch must share high_dyn (%d vs %d); split the batch", i, jobs[i].high_dyn, mode);
-                max_taps = std::max(max_taps, jobs[i].n_taps);
-                min_samples = std::min(min_samples, jobs[i].n_samples);
-                max_end = std::max(max_end, static_cast<unsigned long long>(jobs[i].sample_offset) + static_cast<unsigned long long>(jobs[i].n_samples));
+                b->n_jobs = 0;
+                return rc;
             }
-        GSH_HIP(hipSetDevice(b->device));
-        int rc = bank_reserve_jobs(b, n_jobs);
-        if (rc != GSH_OK) return rc;
-        GSH_HIP(hipMemcpyAsync(b->d_jobs, jobs, sizeof(gsh_corr_job) * static_cast<size_t>(n_jobs), hipMemcpyHostToDevice, b->stream));
         GSH_HIP(hipStreamSynchronize(b->stream));
-        b->n_jobs = n_jobs;
-        b->max_taps = max_taps;
-        b->mode = mode;
-        b->min_samples = min_samples;
-        b->max_end = max_end;
+        return GSH_OK;
+    }
+
+    int gsh_bank_set_stream_ring(gsh_bank_t* b, gsh_stream_t* s)
+    {
+        GSH_REQUIRE(b != nullptr, "null bank");
+        GSH_REQUIRE(s == nullptr || s->device == b->device, "the ring lives on device %d, the bank on device %d", s ? s->device : -1, b->device);
+        b->ring = s;
+        b->n_jobs = 0;  // an uploaded job table was translated against the previous attachment
+        if (s != nullptr)
+            {
+                b->d_stream = s->d_ring;
+                b->stream_len = s->capacity + s->max_window;
+            }
+        else
+            {
+                b->d_stream = nullptr;
+                b->stream_len = 0;
+            }
         return GSH_OK;
     }
 
@@ -260,6 +333,7 @@ extern "C"
         a.n_jobs = b->n_jobs;
         a.splits = splits;
         hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : b->stream;
+        if (b->ring != nullptr) GSH_HIP(hipStreamWaitEvent(s, b->ring->pushed, 0));  // conversions queued by gsh_stream_push_device
         return gsh::mcorr_launch(a, b->max_taps, b->mode, b->max_code_len, s);
     }
 
@@ -284,11 +358,25 @@ extern "C"
 
     int gsh_bank_correlate(gsh_bank_t* b, const gsh_corr_job* jobs, int n_jobs, float* out_iq)
     {
-        int rc = gsh_bank_upload_jobs(b, jobs, n_jobs);
-        if (rc != GSH_OK) return rc;
-        rc = gsh_bank_launch(b, nullptr);
-        if (rc != GSH_OK) return rc;
-        return gsh_bank_read_outputs(b, out_iq, n_jobs);
+        // one synchronisation per batch: pinned job table -> H2D -> kernel -> D2H into pinned memory, all queued on the bank's stream
+        GSH_REQUIRE(b != nullptr, "null bank");
+        GSH_REQUIRE(n_jobs >= 0, "n_jobs %d", n_jobs);
+        GSH_REQUIRE(n_jobs == 0 || (jobs != nullptr && out_iq != nullptr), "null argument");
+        b->n_jobs = 0;
+        if (n_jobs == 0) return GSH_OK;
+        int rc = bank_stage_jobs(b, jobs, n_jobs);
+        if (rc == GSH_OK) rc = gsh_bank_launch(b, nullptr);
+        if (rc != GSH_OK)
+            {
+                (void)hipStreamSynchronize(b->stream);
+                b->n_jobs = 0;
+                return rc;
+            }
+        const size_t bytes = sizeof(float2) * GSH_MAX_TAPS * static_cast<size_t>(n_jobs);
+        GSH_HIP(hipMemcpyAsync(b->h_out, b->d_out, bytes, hipMemcpyDeviceToHost, b->stream));
+        GSH_HIP(hipStreamSynchronize(b->stream));
+        std::memcpy(out_iq, b->h_out, bytes);
+        return GSH_OK;
     }
 
     int gsh_bank_time_launches(gsh_bank_t* b, int reps, float* avg_ms)

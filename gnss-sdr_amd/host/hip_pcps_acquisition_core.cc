@@ -14,8 +14,9 @@ Hip_Pcps_Acquisition_Core::Hip_Pcps_Acquisition_Core(const Hip_Acq_Conf& conf, i
     d_effective_fft_size = conf.bit_transition_flag ? (d_fft_size / 2) : d_fft_size;
     d_num_doppler_bins = num_doppler_bins_override ? num_doppler_bins_override
                                                    : static_cast<uint32_t>(std::ceil(static_cast<double>(2 * conf.doppler_max) / static_cast<double>(conf.doppler_step)));
-    // acq.cc:116
+    // acq.cc:116-117
     d_threshold = conf.pfa > 0.0F ? compute_threshold(conf.pfa, d_effective_fft_size, d_num_doppler_bins, conf.bit_transition_flag ? 1 : conf.max_dwells) : conf.threshold;
+    d_threshold_step_two = conf.pfa2 > 0.0F ? compute_threshold(conf.pfa2, d_effective_fft_size, conf.num_doppler_bins_step2, conf.bit_transition_flag ? 1 : conf.max_dwells) : conf.threshold;
 
     gsh_acq_conf c{};
     c.fs_in = conf.use_automatic_resampler ? conf.resampled_fs : conf.fs_in;  // acq.cc:277
@@ -35,6 +36,8 @@ Hip_Pcps_Acquisition_Core::Hip_Pcps_Acquisition_Core(const Hip_Acq_Conf& conf, i
     // the |.|^2 grid is only consumed by later non-coherent dwells (acq.cc:549-553) and by dump (acq.cc:555-558)
     c.no_grid = (conf.max_dwells <= 1U && !conf.dump) ? 1 : 0;
     c.transform_path = 0;
+    c.num_doppler_bins_step2 = conf.make_2_steps ? conf.num_doppler_bins_step2 : 0U;  // acq.cc:171-175
+    c.doppler_step2 = conf.doppler_step2;
     if (gsh_acq_create(device, &c, &d_handle) != GSH_OK)
         {
             d_error = gsh_last_error();
@@ -73,46 +76,87 @@ void Hip_Pcps_Acquisition_Core::set_doppler_center(int32_t doppler_center)
 }
 
 
-Hip_Pcps_Acquisition_Core::Outcome Hip_Pcps_Acquisition_Core::acquisition_core(uint64_t sample_count, const std::complex<float>* data, AcquisitionResult* result)
+// one gsh_acq_* dwell in the current step; `in` is complex<float> or complex<int16_t> data
+template <typename In>
+static int run_dwell(gsh_acq* h, const In* data, bool cshort, bool step_two, float center_step_two, float input_power, int accumulate, uint32_t count,
+    gsh_acq_result* r)
 {
-    if (d_handle == nullptr || data == nullptr || result == nullptr) return ACQ_ERROR;
-    d_num_noncoherent_integrations_counter++;  // acq.cc:668
-    gsh_acq_result r{};
-    const int accumulate = d_num_noncoherent_integrations_counter > 1 ? 1 : 0;  // acq.cc:545-553
-    if (gsh_acq_dwell(d_handle, reinterpret_cast<const float*>(data), 1, accumulate, d_num_noncoherent_integrations_counter, &r) != GSH_OK)
+    if (step_two)
+        {
+            const uint32_t slot = 0;
+            if (cshort) return GSH_ERR_UNSUPPORTED;  // handled by the caller (converted on the host side of the ABI is not offered)
+            return gsh_acq_dwell_step2(h, reinterpret_cast<const float*>(data), 1, &slot, &center_step_two, &input_power, accumulate, count, r);
+        }
+    if (cshort) return gsh_acq_dwell_cshort(h, reinterpret_cast<const int16_t*>(data), 1, accumulate, count, r);
+    return gsh_acq_dwell(h, reinterpret_cast<const float*>(data), 1, accumulate, count, r);
+}
+
+
+Hip_Pcps_Acquisition_Core::Outcome Hip_Pcps_Acquisition_Core::core_after_dwell(uint64_t sample_count, bool dwell_ok, const void* gsh_result, AcquisitionResult* result)
+{
+    if (!dwell_ok)
         {
             d_error = gsh_last_error();
             d_num_noncoherent_integrations_counter = 0;
+            d_step_two = false;
             return ACQ_ERROR;  // surfaces as "no detection", never as an exception across the GNU Radio thread
         }
+    const gsh_acq_result& r = *static_cast<const gsh_acq_result*>(gsh_result);
     result->sample_count = sample_count;
     result->index_time = r.index_time;
     result->doppler = r.doppler_hz;
     result->test_statistics = r.test_statistics;
     result->positive_acq = false;
-    d_input_power = r.input_power;
+    result->step_two = d_step_two;
+    if (!d_step_two) d_input_power = r.input_power;  // acq.cc:428-431: only step one refreshes d_input_power
 
     Outcome out = ACQ_CONTINUE;
+    bool integration_done = false;
+    // acq.cc:605-632 handle_threshold_reached
+    auto threshold_reached = [&]() {
+        if (d_acq_parameters.make_2_steps)
+            {
+                if (d_step_two)
+                    {
+                        result->positive_acq = true;
+                        out = ACQ_POSITIVE;
+                    }
+                else
+                    {
+                        d_doppler_center_step_two = static_cast<float>(result->doppler);  // acq.cc:619
+                        d_num_noncoherent_integrations_counter = 0;                       // acq.cc:621
+                    }
+                d_step_two = !d_step_two;  // acq.cc:624
+            }
+        else
+            {
+                result->positive_acq = true;
+                out = ACQ_POSITIVE;
+            }
+    };
     if (!d_acq_parameters.bit_transition_flag)  // acq.cc:686-704
         {
-            if (result->test_statistics > d_threshold)
+            if (result->test_statistics > get_threshold())
                 {
-                    result->positive_acq = true;
-                    out = ACQ_POSITIVE;
+                    threshold_reached();
                 }
-            if (d_num_noncoherent_integrations_counter == d_acq_parameters.max_dwells && out != ACQ_POSITIVE) out = ACQ_NEGATIVE;
+            if (d_num_noncoherent_integrations_counter == d_acq_parameters.max_dwells) integration_done = true;
         }
     else  // acq.cc:705-715
         {
             if (result->test_statistics > d_threshold)
                 {
-                    result->positive_acq = true;
-                    out = ACQ_POSITIVE;
+                    threshold_reached();
                 }
             else
                 {
-                    out = ACQ_NEGATIVE;
+                    integration_done = true;
                 }
+        }
+    if (integration_done)  // acq.cc:635-645 handle_integration_done: negative unless this very dwell was the positive one
+        {
+            if (out != ACQ_POSITIVE) out = ACQ_NEGATIVE;
+            d_step_two = false;
         }
     // acq.cc:717-725
     if (d_num_noncoherent_integrations_counter == d_acq_parameters.max_dwells || result->positive_acq || d_acq_parameters.bit_transition_flag)
@@ -120,6 +164,41 @@ Hip_Pcps_Acquisition_Core::Outcome Hip_Pcps_Acquisition_Core::acquisition_core(u
             d_num_noncoherent_integrations_counter = 0U;
         }
     return out;
+}
+
+
+Hip_Pcps_Acquisition_Core::Outcome Hip_Pcps_Acquisition_Core::acquisition_core(uint64_t sample_count, const std::complex<float>* data, AcquisitionResult* result)
+{
+    if (d_handle == nullptr || data == nullptr || result == nullptr) return ACQ_ERROR;
+    d_num_noncoherent_integrations_counter++;  // acq.cc:668
+    gsh_acq_result r{};
+    const int accumulate = d_num_noncoherent_integrations_counter > 1 ? 1 : 0;  // acq.cc:545-553
+    const int rc = run_dwell(d_handle, data, false, d_step_two, d_doppler_center_step_two, d_input_power, accumulate, d_num_noncoherent_integrations_counter, &r);
+    return core_after_dwell(sample_count, rc == GSH_OK, &r, result);
+}
+
+
+Hip_Pcps_Acquisition_Core::Outcome Hip_Pcps_Acquisition_Core::acquisition_core(uint64_t sample_count, const std::complex<int16_t>* data, AcquisitionResult* result)
+{
+    if (d_handle == nullptr || data == nullptr || result == nullptr) return ACQ_ERROR;
+    d_num_noncoherent_integrations_counter++;  // acq.cc:668
+    gsh_acq_result r{};
+    const int accumulate = d_num_noncoherent_integrations_counter > 1 ? 1 : 0;
+    int rc;
+    if (d_step_two)
+        {
+            // acq.cc:653-656 converts before either step; the narrow-grid entry point takes complex64
+            d_cshort_scratch.resize(d_consumed_samples);
+            for (uint32_t i = 0; i < d_consumed_samples; i++)
+                d_cshort_scratch[i] = std::complex<float>(static_cast<float>(data[i].real()), static_cast<float>(data[i].imag()));
+            rc = run_dwell(d_handle, d_cshort_scratch.data(), false, true, d_doppler_center_step_two, d_input_power, accumulate,
+                d_num_noncoherent_integrations_counter, &r);
+        }
+    else
+        {
+            rc = run_dwell(d_handle, data, true, false, 0.0F, 0.0F, accumulate, d_num_noncoherent_integrations_counter, &r);
+        }
+    return core_after_dwell(sample_count, rc == GSH_OK, &r, result);
 }
 
 

@@ -9,7 +9,7 @@
  *   acquisition_core      acq.cc:648-728      update_synchro      acq.cc:580-602
  *   compute_threshold     acq.cc:52-56
  * Everything numeric goes through the C ABI (include/gnss_sdr_hip.h, gsh_acq_*).  No CPU fallback.
- * Not implemented ("next"): make_2_steps fine-Doppler refinement, cshort input.
+ * make_2_steps (acq.cc:294-301, 605-632) and item_type = cshort (acq.cc:653-656) are handled like the reference does.
  */
 #ifndef GNSS_SDR_HIP_PCPS_ACQUISITION_CORE_H
 #define GNSS_SDR_HIP_PCPS_ACQUISITION_CORE_H
@@ -18,6 +18,7 @@
 #include <complex>
 #include <cstdint>
 #include <string>
+#include <vector>
 
 struct gsh_acq;
 
@@ -39,6 +40,11 @@ struct Hip_Acq_Conf
     uint32_t resampler_latency_samples{0U};
     int32_t doppler_max{5000};
     int32_t doppler_step{500};
+    float doppler_step2{125.0F};          //!< acq_conf.h:50, key second_doppler_step
+    float pfa2{0.0F};                     //!< acq_conf.h:45, key pfa_second_step
+    uint32_t num_doppler_bins_step2{4U};  //!< acq_conf.h:62, key second_nbins
+    bool make_2_steps{false};             //!< acq_conf.h:74, key make_two_steps
+    bool cshort{false};                   //!< item_type == "cshort" (acq_conf.cc:33-36): acquisition_core takes lv_16sc_t samples
     bool bit_transition_flag{false};
     bool use_CFAR_algorithm_flag{true};
     bool use_automatic_resampler{false};
@@ -65,6 +71,7 @@ public:
         int32_t doppler{0};
         uint32_t index_time{0};
         bool positive_acq{false};
+        bool step_two{false};  //!< the dwell that produced this result ran the narrow grid (d_step_two at acq.cc:598)
     };
 
     enum Outcome
@@ -87,11 +94,19 @@ public:
     void set_local_code(const std::complex<float>* code);
     void set_doppler_center(int32_t doppler_center);
     void set_threshold(float threshold) { d_threshold = threshold; }
-    float get_threshold() const { return d_threshold; }
-    void reset() { d_num_noncoherent_integrations_counter = 0; }
+    float get_threshold() const { return d_step_two ? d_threshold_step_two : d_threshold; }  //!< acq.cc:731-734
+    void reset()
+    {
+        d_num_noncoherent_integrations_counter = 0;
+        d_step_two = false;
+    }
+    bool step_two() const { return d_step_two; }
 
-    /*! one dwell over d_consumed_samples samples; the caller does the buffering of acq.cc:790-815 */
+    /*! one dwell over d_consumed_samples samples; the caller does the buffering of acq.cc:790-815.  With make_2_steps a
+        threshold crossing in step one returns ACQ_CONTINUE and arms step two for the next block (acq.cc:609-624). */
     Outcome acquisition_core(uint64_t sample_count, const std::complex<float>* data, AcquisitionResult* result);
+    /*! the same for item_type = cshort: `data` holds d_consumed_samples interleaved int16 I,Q pairs (acq.cc:653-656) */
+    Outcome acquisition_core(uint64_t sample_count, const std::complex<int16_t>* data, AcquisitionResult* result);
 
     /*! acq.cc:580-602; Synchro is gnss-sdr's Gnss_Synchro (gnss_synchro.h:38-82) or anything with the same members */
     template <typename Synchro>
@@ -110,6 +125,7 @@ public:
                 s->Acq_samplestamp_samples = result.sample_count;
                 s->fs = d_acq_parameters.fs_in;
             }
+        if (result.step_two) s->Acq_doppler_step = d_acq_parameters.doppler_step2;  // acq.cc:598-601
     }
 
     /*! dump support (acq.cc:555-558): D rows of d_effective_fft_size floats */
@@ -134,7 +150,13 @@ private:
     uint32_t d_num_noncoherent_integrations_counter{0};
     int32_t d_doppler_center{0};
     float d_threshold{0.0F};
+    float d_threshold_step_two{0.0F};
     float d_input_power{0.0F};
+    float d_doppler_center_step_two{0.0F};
+    bool d_step_two{false};
+    std::vector<std::complex<float>> d_cshort_scratch;
+
+    Outcome core_after_dwell(uint64_t sample_count, bool dwell_ok, const void* gsh_result, AcquisitionResult* result);
 };
 
 #endif  // GNSS_SDR_HIP_PCPS_ACQUISITION_CORE_H

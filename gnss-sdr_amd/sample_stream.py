@@ -1,0 +1,62 @@
+"""Python face of gsh_stream_* (include/gnss_sdr_hip.h): the device-resident IF sample ring, for tests and bench."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import GSH_ITEM_BYTE, GSH_ITEM_GR_COMPLEX, GSH_ITEM_SHORT, check, fptr
+
+ITEM_TYPES = {"gr_complex": GSH_ITEM_GR_COMPLEX, "ishort": GSH_ITEM_SHORT, "cshort": GSH_ITEM_SHORT, "ibyte": GSH_ITEM_BYTE, "cbyte": GSH_ITEM_BYTE}
+_NP = {GSH_ITEM_GR_COMPLEX: np.complex64, GSH_ITEM_SHORT: np.int16, GSH_ITEM_BYTE: np.int8}
+
+
+class SampleStream:
+    def __init__(self, capacity_samples: int, max_window_samples: int, device: int = 0):
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        self.device = device
+        check(self._lib.gsh_stream_create(device, capacity_samples, max_window_samples, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            self._lib.gsh_stream_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def push(self, items: np.ndarray, item_type: str = "gr_complex", inverted_spectrum: bool = False) -> int:
+        """Append samples held in host memory (complex64 [n], or int16 / int8 [n, 2] interleaved I,Q).  Returns the absolute
+        index of the first one."""
+        t = ITEM_TYPES[item_type]
+        a = np.ascontiguousarray(items, _NP[t])
+        n = a.size if t == GSH_ITEM_GR_COMPLEX else a.size // 2
+        first = C.c_uint64(0)
+        check(self._lib.gsh_stream_push(self._h, C.c_void_p(a.ctypes.data), n, t, int(inverted_spectrum), C.byref(first)))
+        return int(first.value)
+
+    def push_device(self, device_ptr: int, n: int, item_type: str = "gr_complex", inverted_spectrum: bool = False, hip_stream: int = 0) -> int:
+        first = C.c_uint64(0)
+        check(self._lib.gsh_stream_push_device(self._h, C.c_void_p(device_ptr), n, ITEM_TYPES[item_type], int(inverted_spectrum),
+                                               C.c_void_p(hip_stream) if hip_stream else None, C.byref(first)))
+        return int(first.value)
+
+    def range(self):
+        lo, hi = C.c_uint64(0), C.c_uint64(0)
+        check(self._lib.gsh_stream_range(self._h, C.byref(lo), C.byref(hi)))
+        return int(lo.value), int(hi.value)
+
+    def read(self, index: int, n: int) -> np.ndarray:
+        out = np.empty(n, np.complex64)
+        check(self._lib.gsh_stream_read(self._h, index, n, fptr(out)))
+        return out
+
+
+def convert_samples_device(device: int, src_ptr: int, item_type: str, dst_ptr: int, n: int, inverted_spectrum: bool = False, hip_stream: int = 0) -> None:
+    check(_lib.load().gsh_convert_samples_device(device, C.c_void_p(src_ptr), ITEM_TYPES[item_type], int(inverted_spectrum), C.c_void_p(dst_ptr), n,
+                                                 C.c_void_p(hip_stream) if hip_stream else None))

@@ -138,6 +138,11 @@ class CorrelatorBank:
         self._keep["stream"] = keepalive
         check(self._lib.gsh_bank_set_stream_device(self._h, C.c_void_p(device_ptr), n_samples))
 
+    def set_stream_ring(self, ring) -> None:
+        """Bind to a SampleStream: job sample_offset becomes an absolute sample index (None detaches)."""
+        self._keep["stream"] = ring
+        check(self._lib.gsh_bank_set_stream_ring(self._h, ring._h if ring is not None else None))
+
     def set_splits(self, splits: int) -> None:
         check(self._lib.gsh_bank_set_splits(self._h, splits))
 

@@ -30,7 +30,7 @@ extern "C"
 {
 #endif
 
-#define GSH_ABI_VERSION 3
+#define GSH_ABI_VERSION 4
 #define GSH_MAX_TAPS 8 /* VE/E/P/L/VL needs 5 (trk.cc:609-650); 8 leaves room for multi-tap dumps */
 
     enum
@@ -135,6 +135,42 @@ extern "C"
      * over more CUs for latency-bound closed-loop use).  0 = choose automatically. */
     int gsh_bank_set_splits(gsh_bank_t* b, int splits);
 
+    /* ================================================================ SAMPLE STREAM (device-resident ring)
+     * gsh_stream_*: the IF sample stream of one RF front-end kept in device memory, addressed by ABSOLUTE sample index
+     * (sample 0 = the first sample ever pushed), so that every channel's correlation window refers to bytes that crossed
+     * PCIe / xGMI once.  In the reference every tracking / acquisition block reads the same GNU Radio buffer
+     * (gnss_flowgraph.cc:1227-1231); this is that buffer's device-side twin.  Raw front-end formats are converted on the
+     * device with the arithmetic of the reference's data_type_adapter blocks (ibyte_to_complex.cc:45-51,
+     * ishort_to_complex.cc:45-51: integer -> float cast, no scaling; inverted_spectrum -> conjugate).
+     * The ring keeps the last `capacity_samples`; any window of up to `max_window_samples` is contiguous in device
+     * memory (the first max_window samples are mirrored behind the end), so the correlator kernels never wrap. */
+    typedef struct gsh_stream gsh_stream_t;
+    enum gsh_item_type
+    {
+        GSH_ITEM_GR_COMPLEX = 0, /* interleaved float32 I,Q (gr_complex), 8 bytes per sample */
+        GSH_ITEM_SHORT = 1,      /* interleaved int16 I,Q (item_type ishort / cshort), 4 bytes per sample */
+        GSH_ITEM_BYTE = 2        /* interleaved int8 I,Q (item_type ibyte / cbyte), 2 bytes per sample */
+    };
+    int gsh_stream_create(int device, uint64_t capacity_samples, uint32_t max_window_samples, gsh_stream_t** out);
+    void gsh_stream_destroy(gsh_stream_t* s);
+    /* append n samples held in host memory; *first_index (may be NULL) receives the absolute index of items[0].
+     * Synchronous: the samples are resident (and any older ones they displace are gone) on return. */
+    int gsh_stream_push(gsh_stream_t* s, const void* items, uint64_t n, int item_type, int inverted_spectrum, uint64_t* first_index);
+    /* the same with the items already in device memory (e.g. a block received over RCCL); the conversion is queued on
+     * `hip_stream` (a hipStream_t cast to void*, NULL = the ring's own stream and synchronous) */
+    int gsh_stream_push_device(gsh_stream_t* s, const void* device_items, uint64_t n, int item_type, int inverted_spectrum, void* hip_stream,
+        uint64_t* first_index);
+    /* [*oldest, *next): the absolute sample indices currently resident */
+    int gsh_stream_range(gsh_stream_t* s, uint64_t* oldest, uint64_t* next);
+    /* copy resident samples [index, index + n) back to the host as complex64 (tests, dumps) */
+    int gsh_stream_read(gsh_stream_t* s, uint64_t index, uint64_t n, float* out_iq);
+    /* stand-alone conversion of n device-resident items to complex64 (device_dst 8-byte aligned), asynchronous on hip_stream */
+    int gsh_convert_samples_device(int device, const void* device_items, int item_type, int inverted_spectrum, void* device_dst, uint64_t n,
+        void* hip_stream);
+    /* bind a bank to a ring: from now on gsh_corr_job.sample_offset is an ABSOLUTE sample index; a job whose window is not
+     * fully resident (or longer than max_window_samples) fails with GSH_ERR_INVALID.  NULL detaches. */
+    int gsh_bank_set_stream_ring(gsh_bank_t* b, gsh_stream_t* s);
+
     /* ================================================================ TRACKING LOOP (closed on the device)
      * gsh_trk_*: the steady-state loop of dll_pll_veml_tracking (trk.cc state 2, :1975-2001), one code period per
      * iteration:  do_correlation_step (trk.cc:1232-1257) -> run_dll_pll (:1260-1324: Costas / four-quadrant PLL
@@ -233,6 +269,9 @@ extern "C"
                                        on-chip plan then never write the grid (statistics are formed on chip) */
         int32_t transform_path;     /* 0: automatic (whole transform on one CU when the length has a plan, else the
                                        four-step path through HBM); 1: force the four-step path (A/B testing) */
+        uint32_t num_doppler_bins_step2; /* Acq_Conf::num_doppler_bins_step2 (acq_conf.h:62, key second_nbins); 0 = the handle
+                                       never runs the fine-Doppler step (make_two_steps = false); must be <= num_doppler_bins */
+        float doppler_step2;        /* Acq_Conf::doppler_step2 (acq_conf.h:50, key second_doppler_step) */
     } gsh_acq_conf;
 
     typedef struct gsh_acq_result
@@ -262,6 +301,20 @@ extern "C"
     int gsh_acq_dwell(gsh_acq_t* a, const float* in_iq, uint32_t n_prn, int accumulate, uint32_t dwell_count, gsh_acq_result* results);
     /* same with the input block already in device memory (16-byte aligned) */
     int gsh_acq_dwell_device(gsh_acq_t* a, const void* device_in_iq, uint32_t n_prn, int accumulate, uint32_t dwell_count, gsh_acq_result* results);
+    /* Step two of make_two_steps (acq.cc:294-301, 522-560 with d_step_two, 428-437 / 475-482): for each i < n a narrow
+     * grid of num_doppler_bins_step2 bins at  center[i] + ((float)d - floor(nbins2/2)) * doppler_step2  (float arithmetic,
+     * acq.cc:298-299) for local code prn_slots[i] over one consumed_samples block.  `doppler_center_step_two[i]` is the
+     * step-one result's Doppler (acq.cc:619); `input_power_step_one[i]` is d_input_power left by step one -- the CFAR
+     * statistic of step two divides by it without recomputing it (acq.cc:428-445); ignored for the peak-ratio statistic.
+     * results[i].doppler_hz = (int32_t)(center + ((float)index_doppler - floor(nbins2/2)) * doppler_step2) (acq.cc:436).
+     * `accumulate`/`dwell_count` as in gsh_acq_dwell (non-coherent dwells inside step two, acq.cc:545-553). */
+    int gsh_acq_dwell_step2(gsh_acq_t* a, const float* in_iq, uint32_t n, const uint32_t* prn_slots, const float* doppler_center_step_two,
+        const float* input_power_step_one, int accumulate, uint32_t dwell_count, gsh_acq_result* results);
+    int gsh_acq_dwell_step2_device(gsh_acq_t* a, const void* device_in_iq, uint32_t n, const uint32_t* prn_slots,
+        const float* doppler_center_step_two, const float* input_power_step_one, int accumulate, uint32_t dwell_count, gsh_acq_result* results);
+    /* item_type = cshort (acq.cc:653-656): `in_iq16` holds consumed_samples interleaved int16 I,Q pairs, converted to
+     * complex64 on the device (volk_gnsssdr_16ic_convert_32fc: exact int -> float), then as gsh_acq_dwell */
+    int gsh_acq_dwell_cshort(gsh_acq_t* a, const int16_t* in_iq16, uint32_t n_prn, int accumulate, uint32_t dwell_count, gsh_acq_result* results);
     /* dump support (acq.cc:555-558): copy |.|^2 grid of one PRN, D rows of effective_fft_size floats */
     int gsh_acq_read_grid(gsh_acq_t* a, uint32_t prn_slot, float* grid);
     /* HIP-event average milliseconds per full dwell batch (n_prn codes), inputs resident */

@@ -155,6 +155,60 @@ class PcpsOracle:
             res["test_statistics"] = float(np.float32(gmax) / np.float32(second)) if not self.precise else float(gmax / second)
         return res
 
+    # ---- step two of make_two_steps -------------------------------------------------------------------------
+    # acq.cc:294-301 (update_grid_doppler_wipeoffs_step2), :522-560 with d_step_two (same loop over the narrow tables,
+    # rows 0..nbins2-1 of d_magnitude_grid), :428-437 / :475-482 (result.doppler, d_input_power NOT recomputed)
+    def dwell_step2(self, x: np.ndarray, doppler_center_step_two: float, num_doppler_bins_step2: int, doppler_step2: float,
+                    input_power_step_one: float = 0.0, dwell_count: int = 1) -> dict:
+        nb2 = int(num_doppler_bins_step2)
+        center = np.float32(doppler_center_step_two)
+        half = np.float32(math.floor(nb2 / 2.0))
+        step2 = np.float32(doppler_step2)
+        saved = (self.wipe, self.n_bins, self.grid)
+        wipe = np.empty((nb2, self.fft_size), np.complex128 if self.precise else np.complex64)
+        freqs = []
+        for d in range(nb2):
+            doppler = (np.float32(d) - half) * step2                                              # acq.cc:298
+            freq = np.float32(center + doppler)                                                   # acq.cc:299
+            freqs.append(float(freq))
+            if self.precise:
+                n = np.arange(self.fft_size, dtype=np.float64)
+                wipe[d] = np.exp(-2j * np.pi * float(freq) * n / self.fs_in)
+                continue
+            phase_step = TWO_PI * freq / np.float32(self.fs_in)                                   # acq.cc:278
+            out = np.empty(2 * self.fft_size, np.float32)
+            ph = C.c_float(0.0)
+            lib().oracle_sincos(out, float(-phase_step), C.byref(ph), self.fft_size)              # acq.cc:280
+            wipe[d] = out.view(np.complex64)
+        try:
+            self.wipe, self.n_bins = wipe, nb2
+            if dwell_count == 1:
+                self.grid = None
+            elif self.grid is not None:
+                self.grid = self.grid[:nb2]
+            g = self.doppler_grid(x, dwell_count)
+            gmax, idx_d, idx_t = 0.0, 0, 0
+            for d in range(nb2):
+                t = self._argmax(g[d])
+                if g[d][t] > gmax:                                                               # :420 strict
+                    gmax, idx_d, idx_t = g[d][t], d, t
+            res = dict(index_time=idx_t, index_doppler=idx_d, peak=float(gmax),
+                       doppler_hz=int(np.float32(center + (np.float32(idx_d) - half) * step2)),  # :436 static_cast<int32_t>
+                       acq_delay_samples=float(np.fmod(np.float32(idx_t), self.samples_per_code)), freqs=freqs)
+            if self.use_cfar:
+                p = np.float32(input_power_step_one)
+                res["input_power"] = float(p)
+                res["test_statistics"] = 0.0 if p < np.finfo(np.float32).eps else float(np.float32(gmax) / p)   # :438-445
+                res["second_peak"] = 0.0
+            else:
+                self.n_bins = nb2
+                st = self.statistics(dwell_count)                                                 # same blanking / second scan
+                res["second_peak"], res["test_statistics"], res["input_power"] = st["second_peak"], st["test_statistics"], 0.0
+            res["grid"] = g
+            return res
+        finally:
+            self.wipe, self.n_bins, self.grid = saved
+
     def dwell(self, x: np.ndarray, dwell_count: int = 1) -> dict:
         self.doppler_grid(x, dwell_count)
         return self.statistics(dwell_count)

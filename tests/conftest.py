@@ -15,6 +15,12 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def gsh():
     """The built C-ABI library (fails loudly when it has not been built)."""
+    try:
+        # tests that also use torch for device memory: torch must bring in ITS HIP runtime before libgnss_sdr_hip.so pulls in
+        # /opt/rocm's (two runtimes in one process: the second one to initialise sees no GPU).  bench.py has the same order.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     import gnss_sdr_amd
     return gnss_sdr_amd.load()
 

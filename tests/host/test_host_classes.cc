@@ -34,6 +34,7 @@ struct Synchro  // the members of Gnss_Synchro (gnss_synchro.h:46-82) that updat
     double Acq_doppler_hz{0.0};
     uint64_t Acq_samplestamp_samples{0};
     int64_t fs{0};
+    uint32_t Acq_doppler_step{0};
 };
 
 std::vector<std::complex<float>> make_signal(int n, double fs, int prn, double doppler, double code_phase_chips, double amp, unsigned seed)
@@ -127,6 +128,62 @@ int main()
         oracle_gps_l1_ca_code_gen_complex_sampled(code_iq.data(), 11, 4000000, 0);
         acq.set_local_code(reinterpret_cast<const std::complex<float>*>(code_iq.data()));
         EXPECT(acq.acquisition_core(0, x.data(), &res) == Hip_Pcps_Acquisition_Core::ACQ_NEGATIVE, "absent PRN must be rejected (stat %f)", res.test_statistics);
+    }
+    // ---------------------------------------------------------------- make_two_steps (acq.cc:605-632) and cshort input (acq.cc:653-656)
+    {
+        Hip_Acq_Conf conf;
+        conf.fs_in = 4000000;
+        conf.doppler_max = 5000;
+        conf.doppler_step = 500;
+        conf.pfa = 0.001F;
+        conf.pfa2 = 0.001F;
+        conf.max_dwells = 2;
+        conf.make_2_steps = true;
+        conf.num_doppler_bins_step2 = 4;
+        conf.doppler_step2 = 125.0F;
+        conf.SetDerivedParams();
+        Hip_Pcps_Acquisition_Core acq(conf, 0);
+        EXPECT(acq.ok(), "two-step acq create: %s", acq.last_error().c_str());
+        std::vector<float> code_iq(2 * 4000);
+        oracle_gps_l1_ca_code_gen_complex_sampled(code_iq.data(), 17, 4000000, 0);
+        acq.set_local_code(reinterpret_cast<const std::complex<float>*>(code_iq.data()));
+        const double amp = std::sqrt(std::pow(10.0, 4.8) * 2.0 / 4e6);
+        auto x = make_signal(8000, 4e6, 17, 1310.0, 200.0, amp, 99);
+        Hip_Pcps_Acquisition_Core::AcquisitionResult res;
+        // step one crosses the threshold: no message yet, step two armed (acq.cc:617-624)
+        auto out = acq.acquisition_core(4000, x.data(), &res);
+        EXPECT(out == Hip_Pcps_Acquisition_Core::ACQ_CONTINUE && acq.step_two() && !res.positive_acq, "step one outcome %d step_two %d", out, acq.step_two());
+        EXPECT(res.doppler == 1500 || res.doppler == 1000, "coarse doppler %d", res.doppler);
+        const float thr1 = Hip_Pcps_Acquisition_Core::compute_threshold(0.001F, 4000, 20, 2);
+        const float thr2 = Hip_Pcps_Acquisition_Core::compute_threshold(0.001F, 4000, 4, 2);
+        EXPECT(acq.get_threshold() == thr2 && thr2 < thr1, "step-two threshold %f (step one %f)", acq.get_threshold(), thr1);
+        // step two on the next block: positive, Doppler within one fine bin, Acq_doppler_step reported (acq.cc:598-601)
+        out = acq.acquisition_core(8000, x.data() + 4000, &res);
+        EXPECT(out == Hip_Pcps_Acquisition_Core::ACQ_POSITIVE && res.positive_acq && res.step_two && !acq.step_two(), "step two outcome %d", out);
+        EXPECT(std::abs(res.doppler - 1310) <= 125, "fine doppler %d", res.doppler);
+        Synchro syn;
+        acq.update_synchro(res, &syn);
+        EXPECT(syn.Acq_doppler_step == 125 && syn.Acq_samplestamp_samples == 8000, "synchro after step two: step %u stamp %llu", syn.Acq_doppler_step, (unsigned long long)syn.Acq_samplestamp_samples);
+        // cshort input gives the same decision as the float path over the converted samples
+        Hip_Acq_Conf c16 = conf;
+        c16.make_2_steps = false;
+        c16.max_dwells = 1;
+        c16.cshort = true;
+        Hip_Pcps_Acquisition_Core acq16(c16, 0), acqf(c16, 0);
+        acq16.set_local_code(reinterpret_cast<const std::complex<float>*>(code_iq.data()));
+        acqf.set_local_code(reinterpret_cast<const std::complex<float>*>(code_iq.data()));
+        std::vector<std::complex<int16_t>> x16(4000);
+        std::vector<std::complex<float>> xf(4000);
+        for (int i = 0; i < 4000; i++)
+            {
+                x16[i] = std::complex<int16_t>(static_cast<int16_t>(std::lrint(x[i].real() * 300.0F)), static_cast<int16_t>(std::lrint(x[i].imag() * 300.0F)));
+                xf[i] = std::complex<float>(x16[i].real(), x16[i].imag());
+            }
+        Hip_Pcps_Acquisition_Core::AcquisitionResult r16, rf;
+        const auto o16 = acq16.acquisition_core(1, x16.data(), &r16);
+        const auto of = acqf.acquisition_core(1, xf.data(), &rf);
+        EXPECT(o16 == of && o16 == Hip_Pcps_Acquisition_Core::ACQ_POSITIVE, "cshort outcome %d vs %d", o16, of);
+        EXPECT(r16.index_time == rf.index_time && r16.doppler == rf.doppler && r16.test_statistics == rf.test_statistics, "cshort result differs from the float path");
     }
     if (fails == 0) std::printf("HOST CLASSES OK\n");
     return fails == 0 ? 0 : 1;

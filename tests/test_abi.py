@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol(gsh):
     declared = _header_functions()
     assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
     assert _lib.missing_symbols() == []
-    assert gsh.gsh_abi_version() == 3
+    assert gsh.gsh_abi_version() == 4
 
 
 def test_struct_layouts_match_header():
@@ -29,7 +29,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(CorrJob) == 80
     assert CorrJob.shifts_chips.offset == 48
     assert C.sizeof(AcqResult) == 32
-    assert C.sizeof(AcqConf) == 72
+    assert C.sizeof(AcqConf) == 80
 
 
 def test_no_gpu_means_loud_failure(gsh):

@@ -2,6 +2,7 @@
 agreement of its float32 path with the float64 arbiter.  (The GPU engine is compared with this oracle in
 tests/test_acquisition_gpu.py.)"""
 import numpy as np
+import pytest
 
 import oracle
 from oracle.pcps_oracle import PcpsOracle, compute_threshold
@@ -45,3 +46,24 @@ def test_exclusion_window_wraps_like_the_reference():
     r = o.statistics()
     assert (r["index_time"], r["index_doppler"]) == (2, 1)
     assert r["second_peak"] == 20.0 and r["test_statistics"] == 2.5
+
+
+def test_oracle_step_two_refines_doppler():
+    """make_two_steps (acq.cc:294-301, 428-437, 609-624): the narrow grid sits at center + (d - floor(nb2/2)) * step2 in float32,
+    the reported Doppler is the truncated float, and the CFAR statistic divides by step one's input power."""
+    from helpers import synth_gps_l1_stream
+    import oracle
+    from oracle.pcps_oracle import PcpsOracle
+    fs, n = 4000000, 4000
+    x = synth_gps_l1_stream(2 * n, fs, [6], [1437.0], [321.4], cn0_dbhz=50.0, seed_noise=1)
+    o = PcpsOracle(fs, n, 5000, 250, 4, float(n))
+    o.set_local_code(oracle.ca_code_complex_sampled(6, fs))
+    r1 = o.dwell(x[:n])
+    assert r1["doppler_hz"] in (1250, 1500)
+    r2 = o.dwell_step2(x[n:], float(r1["doppler_hz"]), 4, 125.0, input_power_step_one=r1["input_power"])
+    assert r2["freqs"] == [r1["doppler_hz"] + k * 125.0 for k in (-2, -1, 0, 1)]
+    assert abs(r2["doppler_hz"] - 1437.0) <= 125.0
+    assert r2["test_statistics"] == pytest.approx(r2["peak"] / r1["input_power"], rel=1e-6)
+    assert o.n_bins == 40 and o.grid.shape == (40, n)      # the wide-grid state is untouched
+    r3 = o.dwell_step2(x[n:], 1437.4, 5, 62.5)
+    assert r3["freqs"][2] == float(np.float32(1437.4)) and r3["doppler_hz"] == int(np.float32(np.float32(1437.4) + (np.float32(r3["index_doppler"]) - np.float32(2)) * np.float32(62.5)))
