@@ -1,0 +1,351 @@
+/*!
+ * \file hip_correlator_runtime.cc
+ * \brief See the header.
+ */
+#include "hip_correlator_runtime.h"
+#include <algorithm>
+#include <cstring>
+
+// ------------------------------------------------------------------------------------------------ Hip_Sample_Ring
+Hip_Sample_Ring::Hip_Sample_Ring(int device, uint64_t capacity_samples, uint32_t max_window_samples) : d_device(device)
+{
+    if (gsh_stream_create(device, capacity_samples, max_window_samples, &d_handle) != GSH_OK)
+        {
+            d_error = gsh_last_error();
+            d_handle = nullptr;
+        }
+}
+
+
+Hip_Sample_Ring::~Hip_Sample_Ring()
+{
+    if (d_handle != nullptr) gsh_stream_destroy(d_handle);
+}
+
+
+uint64_t Hip_Sample_Ring::push_items(const void* items, uint64_t n, int item_type, bool inverted_spectrum)
+{
+    if (d_handle == nullptr) return UINT64_MAX;
+    uint64_t first = 0;
+    {
+        std::lock_guard<std::mutex> lk(d_mutex);
+        if (gsh_stream_push(d_handle, items, n, item_type, inverted_spectrum ? 1 : 0, &first) != GSH_OK)
+            {
+                d_error = gsh_last_error();
+                return UINT64_MAX;
+            }
+        d_next = first + n;
+    }
+    d_pushed.notify_all();
+    return first;
+}
+
+
+uint64_t Hip_Sample_Ring::push(const std::complex<float>* samples, uint64_t n, bool inverted_spectrum)
+{
+    return push_items(samples, n, GSH_ITEM_GR_COMPLEX, inverted_spectrum);
+}
+
+
+uint64_t Hip_Sample_Ring::push_ishort(const int16_t* iq, uint64_t n, bool inverted_spectrum)
+{
+    return push_items(iq, n, GSH_ITEM_SHORT, inverted_spectrum);
+}
+
+
+uint64_t Hip_Sample_Ring::push_ibyte(const int8_t* iq, uint64_t n, bool inverted_spectrum)
+{
+    return push_items(iq, n, GSH_ITEM_BYTE, inverted_spectrum);
+}
+
+
+void Hip_Sample_Ring::range(uint64_t* oldest, uint64_t* next) const
+{
+    std::lock_guard<std::mutex> lk(d_mutex);
+    uint64_t lo = 0, hi = 0;
+    if (d_handle != nullptr) (void)gsh_stream_range(d_handle, &lo, &hi);
+    if (oldest) *oldest = lo;
+    if (next) *next = hi;
+}
+
+
+bool Hip_Sample_Ring::wait_for(uint64_t end, std::chrono::milliseconds timeout) const
+{
+    std::unique_lock<std::mutex> lk(d_mutex);
+    return d_pushed.wait_for(lk, timeout, [&] { return d_next >= end; });
+}
+
+
+// ------------------------------------------------------------------------------------------------ Hip_Correlator_Runtime
+Hip_Correlator_Runtime::Hip_Correlator_Runtime(Hip_Sample_Ring* ring, int max_channels, int max_code_length, std::chrono::microseconds max_wait)
+    : d_ring(ring), d_max_wait(max_wait), d_current(std::make_shared<Batch>())
+{
+    if (ring == nullptr || !ring->ok())
+        {
+            d_error = "no sample ring";
+            return;
+        }
+    if (gsh_bank_create(ring->device(), max_channels, max_code_length, &d_bank) != GSH_OK || gsh_bank_set_stream_ring(d_bank, ring->handle()) != GSH_OK)
+        {
+            d_error = gsh_last_error();
+            if (d_bank != nullptr) gsh_bank_destroy(d_bank);
+            d_bank = nullptr;
+            return;
+        }
+    d_slot_used.assign(static_cast<size_t>(max_channels), 0);
+}
+
+
+Hip_Correlator_Runtime::~Hip_Correlator_Runtime()
+{
+    if (d_bank != nullptr) gsh_bank_destroy(d_bank);
+}
+
+
+int Hip_Correlator_Runtime::register_channel()
+{
+    std::lock_guard<std::mutex> lk(d_mutex);
+    for (size_t i = 0; i < d_slot_used.size(); i++)
+        if (!d_slot_used[i])
+            {
+                d_slot_used[i] = 1;
+                d_active++;
+                return static_cast<int>(i);
+            }
+    return -1;
+}
+
+
+void Hip_Correlator_Runtime::unregister_channel(int channel)
+{
+    {
+        std::lock_guard<std::mutex> lk(d_mutex);
+        if (channel < 0 || channel >= static_cast<int>(d_slot_used.size()) || !d_slot_used[channel]) return;
+        d_slot_used[channel] = 0;
+        d_active--;
+    }
+    d_arrived.notify_all();  // a leader waiting for this channel must re-evaluate
+}
+
+
+bool Hip_Correlator_Runtime::set_code(int channel, const float* code, int code_length)
+{
+    if (d_bank == nullptr) return false;
+    std::lock_guard<std::mutex> bl(d_bank_mutex);
+    if (gsh_bank_set_code(d_bank, channel, code, code_length) != GSH_OK)
+        {
+            std::lock_guard<std::mutex> lk(d_mutex);
+            d_error = gsh_last_error();
+            return false;
+        }
+    return true;
+}
+
+
+bool Hip_Correlator_Runtime::correlate(int channel, const gsh_corr_job& job_in, std::complex<float>* out)
+{
+    if (d_bank == nullptr || out == nullptr) return false;
+    std::unique_lock<std::mutex> lk(d_mutex);
+    std::shared_ptr<Batch> b = d_current;
+    const size_t idx = b->jobs.size();
+    b->jobs.push_back(job_in);
+    b->jobs.back().code_slot = channel;
+    if (idx == 0)
+        {
+            // batch leader: wait for the other channels that are tracking right now, bounded by max_wait
+            const auto deadline = std::chrono::steady_clock::now() + d_max_wait;
+            bool timed_out = false;
+            while (static_cast<int>(b->jobs.size()) < d_active)
+                {
+                    if (d_arrived.wait_until(lk, deadline) == std::cv_status::timeout)
+                        {
+                            timed_out = static_cast<int>(b->jobs.size()) < d_active;
+                            break;
+                        }
+                }
+            d_current = std::make_shared<Batch>();  // later arrivals start the next batch (with their own leader)
+            const int n = static_cast<int>(b->jobs.size());
+            d_stats.batches++;
+            d_stats.jobs += static_cast<uint64_t>(n);
+            d_stats.timeouts += timed_out ? 1u : 0u;
+            d_stats.largest_batch = std::max<uint32_t>(d_stats.largest_batch, static_cast<uint32_t>(n));
+            lk.unlock();
+            b->out.assign(static_cast<size_t>(n) * GSH_MAX_TAPS * 2, 0.0F);
+            int rc;
+            std::string err;
+            {
+                std::lock_guard<std::mutex> bl(d_bank_mutex);
+                // pushes must not move the ring's residency window between the job translation and the launch
+                std::lock_guard<std::mutex> rl(d_ring->d_mutex);
+                // one launch per correlator flavour present in the batch (a launch shares one kernel specialisation; channels in
+                // high-dynamics mode, trk.cc:675, are batched separately from the standard ones)
+                rc = GSH_OK;
+                bool uniform = true;
+                for (int i = 1; i < n; i++) uniform = uniform && (b->jobs[i].high_dyn == b->jobs[0].high_dyn);
+                if (uniform)
+                    {
+                        rc = gsh_bank_correlate(d_bank, b->jobs.data(), n, b->out.data());
+                    }
+                else
+                    {
+                        std::vector<gsh_corr_job> part;
+                        std::vector<int> where;
+                        std::vector<float> part_out;
+                        for (int mode = 0; mode <= 2 && rc == GSH_OK; mode++)
+                            {
+                                part.clear();
+                                where.clear();
+                                for (int i = 0; i < n; i++)
+                                    if (b->jobs[i].high_dyn == mode)
+                                        {
+                                            part.push_back(b->jobs[i]);
+                                            where.push_back(i);
+                                        }
+                                if (part.empty()) continue;
+                                part_out.assign(part.size() * GSH_MAX_TAPS * 2, 0.0F);
+                                rc = gsh_bank_correlate(d_bank, part.data(), static_cast<int>(part.size()), part_out.data());
+                                for (size_t k = 0; k < where.size() && rc == GSH_OK; k++)
+                                    std::memcpy(&b->out[static_cast<size_t>(where[k]) * GSH_MAX_TAPS * 2], &part_out[k * GSH_MAX_TAPS * 2], sizeof(float) * GSH_MAX_TAPS * 2);
+                            }
+                    }
+                if (rc != GSH_OK) err = gsh_last_error();
+            }
+            lk.lock();
+            b->status = rc;
+            b->error = err;
+            b->done = true;
+            b->done_cv.notify_all();
+        }
+    else
+        {
+            d_arrived.notify_all();
+            b->done_cv.wait(lk, [&] { return b->done; });
+        }
+    if (b->status != GSH_OK)
+        {
+            d_error = b->error;
+            return false;
+        }
+    const int taps = std::min(std::max(job_in.n_taps, 0), GSH_MAX_TAPS);
+    for (int t = 0; t < taps; t++)
+        out[t] = std::complex<float>(b->out[(idx * GSH_MAX_TAPS + t) * 2], b->out[(idx * GSH_MAX_TAPS + t) * 2 + 1]);
+    return true;
+}
+
+
+Hip_Correlator_Runtime::Stats Hip_Correlator_Runtime::stats() const
+{
+    std::lock_guard<std::mutex> lk(d_mutex);
+    return d_stats;
+}
+
+
+// ------------------------------------------------------------------------------------------------ Hip_Multicorrelator_Batched
+bool Hip_Multicorrelator_Batched::init(int max_signal_length_samples, int n_correlators)
+{
+    if (d_runtime == nullptr || !d_runtime->ok())
+        {
+            d_error = d_runtime ? d_runtime->last_error() : "no runtime";
+            return false;
+        }
+    if (n_correlators < 1 || n_correlators > GSH_MAX_TAPS || max_signal_length_samples < 1)
+        {
+            d_error = "init: n_correlators outside 1..GSH_MAX_TAPS or empty signal length";
+            return false;
+        }
+    if (d_channel < 0) d_channel = d_runtime->register_channel();
+    if (d_channel < 0)
+        {
+            d_error = "init: the runtime has no free channel slot";
+            return false;
+        }
+    d_max_len = max_signal_length_samples;
+    d_n_correlators = n_correlators;
+    return true;
+}
+
+
+bool Hip_Multicorrelator_Batched::set_local_code_and_taps(int code_length_chips, const float* local_code_in, float* shifts_chips)
+{
+    if (d_channel < 0 || local_code_in == nullptr || shifts_chips == nullptr)
+        {
+            d_error = "set_local_code_and_taps before init, or null argument";
+            return false;
+        }
+    d_shifts = shifts_chips;
+    if (!d_runtime->set_code(d_channel, local_code_in, code_length_chips))
+        {
+            d_error = d_runtime->last_error();
+            return false;
+        }
+    return true;
+}
+
+
+bool Hip_Multicorrelator_Batched::set_input_output_vectors(std::complex<float>* corr_out, const std::complex<float>* /*sig_in*/)
+{
+    d_corr_out = corr_out;
+    return corr_out != nullptr;
+}
+
+
+bool Hip_Multicorrelator_Batched::run(int mode, float rem_carr, float phase_step, float phase_rate, float rem_code, float code_step, float code_rate, int n)
+{
+    if (d_channel < 0 || d_shifts == nullptr || d_corr_out == nullptr)
+        {
+            d_error = "correlate before init / set_local_code_and_taps / set_input_output_vectors";
+            return false;
+        }
+    if (n < 1 || n > d_max_len)
+        {
+            d_error = "signal_length_samples outside 1..init size";
+            return false;
+        }
+    gsh_corr_job j;
+    std::memset(&j, 0, sizeof(j));
+    j.sample_offset = d_sample_index;
+    j.n_samples = n;
+    j.rem_carr_phase_rad = rem_carr;
+    j.phase_step_rad = phase_step;
+    j.phase_rate_step_rad = phase_rate;
+    j.rem_code_phase_chips = rem_code;
+    j.code_phase_step_chips = code_step;
+    j.code_phase_rate_step_chips = code_rate;
+    j.n_taps = d_n_correlators;
+    j.high_dyn = mode;
+    for (int t = 0; t < d_n_correlators; t++) j.shifts_chips[t] = d_shifts[t];  // re-read every call: the caller mutates them in place (trk.cc:2132-2146)
+    if (!d_runtime->correlate(d_channel, j, d_corr_out))
+        {
+            d_error = d_runtime->last_error();
+            return false;
+        }
+    return true;
+}
+
+
+bool Hip_Multicorrelator_Batched::Carrier_wipeoff_multicorrelator_resampler(float rem_carrier_phase_in_rad, float phase_step_rad, float phase_rate_step_rad,
+    float rem_code_phase_chips, float code_phase_step_chips, float code_phase_rate_step_chips, int signal_length_samples)
+{
+    // mcorr.cc:103-126: the flag picks the high-dynamics resampler + rotator pair
+    return run(d_use_high_dynamics_resampler ? 1 : 0, rem_carrier_phase_in_rad, phase_step_rad, phase_rate_step_rad, rem_code_phase_chips, code_phase_step_chips,
+        code_phase_rate_step_chips, signal_length_samples);
+}
+
+
+bool Hip_Multicorrelator_Batched::Carrier_wipeoff_multicorrelator_resampler(float rem_carrier_phase_in_rad, float phase_step_rad, float rem_code_phase_chips,
+    float code_phase_step_chips, float code_phase_rate_step_chips, int signal_length_samples)
+{
+    // mcorr.cc:129-144: the six-argument overload keeps the standard rotator whatever the flag says
+    return run(d_use_high_dynamics_resampler ? 2 : 0, rem_carrier_phase_in_rad, phase_step_rad, 0.0F, rem_code_phase_chips, code_phase_step_chips,
+        code_phase_rate_step_chips, signal_length_samples);
+}
+
+
+bool Hip_Multicorrelator_Batched::free()
+{
+    if (d_channel >= 0 && d_runtime != nullptr) d_runtime->unregister_channel(d_channel);
+    d_channel = -1;
+    d_shifts = nullptr;
+    d_corr_out = nullptr;
+    return true;
+}

@@ -1,0 +1,160 @@
+/*!
+ * \file hip_correlator_runtime.h
+ * \brief Receiver-side batching runtime for the MI355X correlator engine.
+ *
+ * In gnss-sdr every channel's tracking block runs on its own GNU Radio thread and calls its own correlator object once per
+ * code period (dll_pll_veml_tracking.cc:1232-1257 from general_work, :1975-2001); all of them read the same input buffer
+ * (gnss_flowgraph.cc:1227-1231).  One GPU launch per call is latency-bound (launch + synchronisation ~ tens of microseconds
+ * for ~1 microsecond of work).  This runtime keeps that threading model and removes the per-call cost:
+ *
+ *  - Hip_Sample_Ring: the IF stream of one RF front-end, pushed to the device ONCE by whoever owns the input (a sink block
+ *    next to the signal conditioner), converted there from the front-end's item type (data_type_adapter arithmetic), and
+ *    addressed by absolute sample index -- the same counter the tracking block already keeps (d_sample_counter,
+ *    dll_pll_veml_tracking.cc:1963-1978, 2287).
+ *  - Hip_Correlator_Runtime: the channel threads rendezvous; the first to arrive becomes the batch leader, waits until the
+ *    channels that are currently tracking have all arrived (or a bounded time), and issues ONE gsh_bank_correlate for the
+ *    whole batch; every caller returns with its own taps.  Callers block exactly as they do inside the reference's
+ *    synchronous correlator call.
+ *  - Hip_Multicorrelator_Batched: the eight methods of Cpu_Multicorrelator_Real_Codes (cpu_multicorrelator_real_codes.h:40-49)
+ *    on top of the runtime, plus set_input_sample_index(): the window is named by its absolute index instead of a host pointer.
+ *
+ * Plain C++17 over the C ABI (include/gnss_sdr_hip.h); no HIP headers, no GNU Radio.
+ */
+#ifndef GNSS_SDR_HIP_CORRELATOR_RUNTIME_H
+#define GNSS_SDR_HIP_CORRELATOR_RUNTIME_H
+
+#include "gnss_sdr_hip.h"
+#include <chrono>
+#include <complex>
+#include <condition_variable>
+#include <cstdint>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+class Hip_Sample_Ring
+{
+public:
+    /*! capacity_samples: how much of the stream stays resident; max_window_samples: longest correlation window (2 * vector_length
+        covers dll_pll_veml_tracking's forecast, trk.cc:747-754) */
+    Hip_Sample_Ring(int device, uint64_t capacity_samples, uint32_t max_window_samples);
+    ~Hip_Sample_Ring();
+    Hip_Sample_Ring(const Hip_Sample_Ring&) = delete;
+    Hip_Sample_Ring& operator=(const Hip_Sample_Ring&) = delete;
+
+    bool ok() const { return d_handle != nullptr; }
+    const std::string& last_error() const { return d_error; }
+    /*! append samples; returns the absolute index of the first one (UINT64_MAX on failure).  One producer thread. */
+    uint64_t push(const std::complex<float>* samples, uint64_t n, bool inverted_spectrum = false);
+    uint64_t push_ishort(const int16_t* iq, uint64_t n, bool inverted_spectrum = false);  //!< item_type ishort / cshort
+    uint64_t push_ibyte(const int8_t* iq, uint64_t n, bool inverted_spectrum = false);    //!< item_type ibyte / cbyte
+    /*! [oldest, next) resident */
+    void range(uint64_t* oldest, uint64_t* next) const;
+    /*! blocks until sample index `end` has been pushed (next >= end) or the timeout expires */
+    bool wait_for(uint64_t end, std::chrono::milliseconds timeout) const;
+    gsh_stream_t* handle() const { return d_handle; }
+    int device() const { return d_device; }
+
+private:
+    uint64_t push_items(const void* items, uint64_t n, int item_type, bool inverted_spectrum);
+    gsh_stream_t* d_handle{nullptr};
+    int d_device{0};
+    std::string d_error;
+    mutable std::mutex d_mutex;  // serialises pushes against job translation (the C handle is not thread-safe)
+    mutable std::condition_variable d_pushed;
+    uint64_t d_next{0};
+    friend class Hip_Correlator_Runtime;
+};
+
+class Hip_Correlator_Runtime
+{
+public:
+    struct Stats
+    {
+        uint64_t batches{0};
+        uint64_t jobs{0};
+        uint64_t timeouts{0};  //!< batches launched because max_wait expired before every active channel arrived
+        uint32_t largest_batch{0};
+    };
+
+    /*! max_wait: how long a batch leader waits for the other active channels before launching with what it has */
+    Hip_Correlator_Runtime(Hip_Sample_Ring* ring, int max_channels, int max_code_length,
+        std::chrono::microseconds max_wait = std::chrono::microseconds(200));
+    ~Hip_Correlator_Runtime();
+    Hip_Correlator_Runtime(const Hip_Correlator_Runtime&) = delete;
+    Hip_Correlator_Runtime& operator=(const Hip_Correlator_Runtime&) = delete;
+
+    bool ok() const { return d_bank != nullptr; }
+    const std::string& last_error() const { return d_error; }
+
+    /*! a tracking block entering / leaving state "tracking" (start_tracking / loss of lock): returns the code slot, -1 when full */
+    int register_channel();
+    void unregister_channel(int channel);
+    bool set_code(int channel, const float* code, int code_length);
+    /*! one Carrier_wipeoff_multicorrelator_resampler call (mcorr.cc:103-144) of channel `channel`: job.sample_offset is an absolute
+        sample index, job.code_slot is overwritten with the channel's slot.  Blocks until the batch it joined has run; out receives
+        job.n_taps complex values.  Thread-safe; at most one call in flight per channel. */
+    bool correlate(int channel, const gsh_corr_job& job, std::complex<float>* out);
+    Stats stats() const;
+
+private:
+    struct Batch
+    {
+        std::vector<gsh_corr_job> jobs;
+        std::vector<float> out;  // n_jobs * GSH_MAX_TAPS * 2
+        std::condition_variable done_cv;
+        bool done{false};
+        int status{0};
+        std::string error;
+    };
+    Hip_Sample_Ring* d_ring;
+    gsh_bank_t* d_bank{nullptr};
+    std::string d_error;
+    std::chrono::microseconds d_max_wait;
+    mutable std::mutex d_mutex;
+    std::condition_variable d_arrived;
+    std::shared_ptr<Batch> d_current;
+    std::vector<char> d_slot_used;
+    int d_active{0};
+    std::mutex d_bank_mutex;  // one batch on the bank at a time
+    Stats d_stats;
+};
+
+class Hip_Multicorrelator_Batched
+{
+public:
+    explicit Hip_Multicorrelator_Batched(Hip_Correlator_Runtime* runtime) : d_runtime(runtime) {}
+    ~Hip_Multicorrelator_Batched() { free(); }
+    Hip_Multicorrelator_Batched(const Hip_Multicorrelator_Batched&) = delete;
+    Hip_Multicorrelator_Batched& operator=(const Hip_Multicorrelator_Batched&) = delete;
+
+    // ---- the reference's eight methods (cpu_multicorrelator_real_codes.h:40-49), same argument order and meaning
+    void set_high_dynamics_resampler(bool use_high_dynamics_resampler) { d_use_high_dynamics_resampler = use_high_dynamics_resampler; }
+    bool init(int max_signal_length_samples, int n_correlators);
+    bool set_local_code_and_taps(int code_length_chips, const float* local_code_in, float* shifts_chips);
+    /*! sig_in is accepted for signature compatibility and ignored: the window is named by set_input_sample_index() */
+    bool set_input_output_vectors(std::complex<float>* corr_out, const std::complex<float>* sig_in);
+    bool Carrier_wipeoff_multicorrelator_resampler(float rem_carrier_phase_in_rad, float phase_step_rad, float phase_rate_step_rad,
+        float rem_code_phase_chips, float code_phase_step_chips, float code_phase_rate_step_chips, int signal_length_samples);
+    bool Carrier_wipeoff_multicorrelator_resampler(float rem_carrier_phase_in_rad, float phase_step_rad, float rem_code_phase_chips,
+        float code_phase_step_chips, float code_phase_rate_step_chips, int signal_length_samples);
+    bool free();
+    // ---- the one addition: absolute index (in the ring) of the first sample of the window the next call correlates
+    void set_input_sample_index(uint64_t index) { d_sample_index = index; }
+    const std::string& last_error() const { return d_error; }
+
+private:
+    bool run(int mode, float rem_carr, float phase_step, float phase_rate, float rem_code, float code_step, float code_rate, int n);
+    Hip_Correlator_Runtime* d_runtime;
+    int d_channel{-1};
+    int d_max_len{0};
+    int d_n_correlators{0};
+    float* d_shifts{nullptr};               // borrowed, re-read every call (mcorr.cc:58)
+    std::complex<float>* d_corr_out{nullptr};  // borrowed (mcorr.cc:70)
+    uint64_t d_sample_index{0};
+    bool d_use_high_dynamics_resampler{true};  // same default as the reference (mcorr.h:60)
+    std::string d_error;
+};
+
+#endif  // GNSS_SDR_HIP_CORRELATOR_RUNTIME_H
