@@ -9,9 +9,10 @@ job table) already resident in HBM.  value = channels*taps*epochs / time, whole 
 
   python bench.py --gpus N --steps K --warmup W
   N > 1: launched by torch.distributed.run, one rank per GPU; every rank tracks its own 32 channels of the same
-  stream (weak scaling); the stream block is re-broadcast from rank 0 over RCCL every step (double-buffered on
-  the communicator's stream, overlapped with the previous block's correlation) and that time IS inside the
-  timed region.
+  stream (weak scaling).  Every step the ingest rank re-distributes the stream block over RCCL in the front-end's
+  8-bit format (scatter + all-gather across all xGMI links, double-buffered on the communicator's stream and
+  overlapped with the previous block's correlation), every rank converts it to complex64 on its GPU and
+  correlates; all of that IS inside the timed region.
 
 One JSON line on stdout (rank 0).  Besides the contract keys it carries
   roofline      -- dominant kernel (mcorr_kernel<3,0>) vs the HBM roofline, algorithmic bytes 8N+8T per job,
@@ -290,43 +291,67 @@ def main():
     else:
         x = torch.zeros(n_samples, dtype=torch.complex64, device=dev)
         dop, cph = np.zeros(0), np.zeros(0)
-    bufs = [x]
-    if world > 1:
-        dist.broadcast(torch.view_as_real(x), src=0)
-        bufs.append(x.clone())
+    cs = torch.cuda.Stream(device=dev)      # a real (non-null) stream: the engine's launches and RCCL's waits are ordered on it
+    stream = cs.cuda_stream
+    D = None
+    # GSH_BENCH_FORCE_DIST=1 runs the N > 1 step structure (raw block -> convert -> correlate) on one GPU: a self-test of that path
+    if world > 1 or os.environ.get("GSH_BENCH_FORCE_DIST") == "1":
+        # N > 1: the shared IF stream reaches the other GPUs the way a front-end delivers it -- 8-bit I/Q (item_type ibyte,
+        # 2 bytes per sample) -- and every rank converts it to complex64 on its own GPU (data_type_adapter arithmetic,
+        # gsh_convert_samples_device) before correlating.  Distribution: scatter + all-gather over all xGMI links
+        # (gnss_sdr_amd.sharding.BlockDistributor), double-buffered: block k+1 travels while block k is correlated.
+        from gnss_sdr_amd.sharding import BlockDistributor
+        from gnss_sdr_amd.sample_stream import convert_samples_device
+        D = BlockDistributor(2 * n_samples, world, rank, 0, os.environ.get("GSH_BENCH_DIST", "scatter_allgather"))
+        raw = [torch.zeros(D.padded, dtype=torch.int8, device=dev) for _ in range(2)]
+        piece = [torch.zeros(D.chunk, dtype=torch.int8, device=dev) for _ in range(2)]
+        raw_src = None
+        if rank == 0:
+            raw_src = torch.zeros(D.padded, dtype=torch.int8, device=dev)
+            raw_src[:2 * n_samples] = torch.view_as_real(x).mul(30.0).round_().clamp_(-127, 127).to(torch.int8).reshape(-1)
+        torch.cuda.synchronize()
+        try:
+            D.finish(D.start(raw[0], raw_src, piece[0]))
+            torch.cuda.synchronize()
+        except Exception as e:  # keep the run alive on a communicator that refuses scatter / all_gather_into_tensor
+            if rank == 0:
+                print(f"bench: scatter+all_gather distribution failed ({e}); falling back to broadcast", file=sys.stderr)
+            D = BlockDistributor(2 * n_samples, world, rank, 0, "broadcast")
+            D.finish(D.start(raw[0], raw_src, piece[0]))
+            torch.cuda.synchronize()
     bank = CorrelatorBank(C, 1023, device=local)
     for c in range(C):
         bank.set_code(c, oracle.ca_code((rank * C + c) % 32 + 1))
     jobs, rows = build_jobs(C, E, n, fs, T, dop, cph, rank)
     bank.upload_jobs(jobs)
     bank.set_splits(1)
-    stream = torch.cuda.current_stream().cuda_stream
+    bank.set_stream_device(x.data_ptr(), n_samples, keepalive=x)
 
     def step(k):
-        cur = bufs[k % len(bufs)]
-        pending = None
-        if world > 1:
-            # re-broadcast the NEXT block on the communicator's stream while this block is correlated
-            pending = dist.broadcast(torch.view_as_real(bufs[(k + 1) % 2]), src=0, async_op=True)
-        bank.set_stream_device(cur.data_ptr(), n_samples, keepalive=cur)
-        bank.launch(stream)
-        if pending is not None:
-            pending.wait()
+        if D is None:
+            bank.launch(stream)
+            return
+        cur, nxt = k % 2, (k + 1) % 2
+        works = D.start(raw[nxt], raw_src, piece[nxt])      # block k+1 on the communicator's stream
+        convert_samples_device(local, raw[cur].data_ptr(), "ibyte", x.data_ptr(), n_samples, hip_stream=stream)
+        bank.launch(stream)                                  # block k: convert, then correlate, on the compute stream
+        D.finish(works)                                      # the compute stream waits for block k+1 before the next step reads it
 
-    for k in range(a.warmup):
-        step(k)
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(a.steps):
-        step(a.warmup + k)
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    with torch.cuda.stream(cs):
+        for k in range(a.warmup):
+            step(k)
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(a.steps):
+            step(a.warmup + k)
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
     if dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -336,7 +361,7 @@ def main():
     out = bank.read_outputs()
     if rank == 0:
         from helpers import oracle_job, scale_err
-        xh = bufs[(a.warmup + a.steps - 1) % len(bufs)].cpu().numpy()
+        xh = x.cpu().numpy()
         for j in (0, 1, C + 3, len(rows) - 1):
             o32, t64, sabs = oracle_job(oracle.ca_code(rows[j]["code_slot"] % 32 + 1), xh, rows[j])
             err = scale_err(out[j, :T], t64, sabs)
@@ -344,7 +369,6 @@ def main():
                 raise SystemExit(f"bench: GPU result of job {j} disagrees with the oracle: {out[j, :T]} vs {t64}")
 
     # ---- roofline of the dominant kernel: HIP events on the launch stream, inputs resident
-    bank.set_stream_device(bufs[0].data_ptr(), n_samples, keepalive=bufs[0])
     k_ms = bank.time_launches(20)
     n_jobs = C * E
     alg_bytes = n_jobs * (8.0 * n + 8.0 * T)
@@ -376,7 +400,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"GPS L1 C/A tracking, {C} channels/GPU x {E} epochs/step, fs={fs / 1e6:g} Msps, N={n}, {T}-tap E/P/L, open-loop",
                        "channels_per_gpu": C, "epochs_per_step": E, "samples_per_epoch": n, "taps": T,
-                       "parallelism": f"channels sharded over {world} GPU(s)" + (", stream block broadcast over RCCL each step (overlapped)" if world > 1 else "")},
+                       "parallelism": f"channels sharded over {world} GPU(s)" + (f", 8-bit stream block re-distributed over RCCL each step ({D.mode}, overlapped) and converted on every GPU" if D is not None else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": f"mcorr_kernel<{3 if T <= 3 else (5 if T <= 5 else 8)},0>",
                          "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes},
@@ -386,11 +410,11 @@ def main():
             res["cpu_baseline"] = cpu_baseline(C, n, fs, T, a.cpu_seconds)
         if world == 1 and not a.no_acq:
             try:
-                res["acquisition"] = acquisition_metric(torch, local, bufs[0][:n].contiguous(), fs)
+                res["acquisition"] = acquisition_metric(torch, local, x[:n].contiguous(), fs)
             except Exception as e:
                 res["acquisition"] = {"error": str(e)}
             try:
-                res["closed_loop"] = closed_loop_metric(local, bufs[0], n_samples, fs, n, dop, cph, channels=C, epochs=min(E - 2, 200))
+                res["closed_loop"] = closed_loop_metric(local, x, n_samples, fs, n, dop, cph, channels=C, epochs=min(E - 2, 200))
             except Exception as e:
                 res["closed_loop"] = {"error": str(e)}
         print(json.dumps(res))

@@ -103,3 +103,55 @@ def test_two_rank_broadcast_and_channel_shards():
         o32, _, _ = oracle_job(oracle.ca_code(r["code_slot"] % 32 + 1), x, r)
         got = merged[(r["code_slot"], r["sample_offset"])]
         assert np.array_equal(got.view(np.float32), o32.view(np.float32))
+
+
+def _dist_worker(rank, world, port, nbytes, mode, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    from gnss_sdr_amd.sharding import BlockDistributor
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    d = BlockDistributor(nbytes, world, rank, src=0, mode=mode)
+    g = torch.Generator().manual_seed(5)
+    ok = True
+    for blk in range(3):  # double-buffered like bench.py: block k+1 travels while block k is in use
+        src = None
+        if rank == 0:
+            src = torch.randint(-128, 128, (d.padded,), dtype=torch.int8, generator=g)
+        dst = torch.zeros(d.padded, dtype=torch.int8)
+        piece = torch.zeros(d.chunk, dtype=torch.int8)
+        works = d.start(dst, src, piece)
+        d.finish(works)
+        ref = torch.randint(-128, 128, (d.padded,), dtype=torch.int8, generator=torch.Generator().manual_seed(5)) if blk == 0 else None
+        if blk == 0:
+            ok = ok and bool(torch.equal(dst, ref))
+        chk = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(chk, dst.to(torch.int64).sum().reshape(1))
+        ok = ok and all(int(c) == int(chk[0]) for c in chk)
+    if rank == 0:
+        q.put(ok)
+    flags = [None] * world
+    dist.all_gather_object(flags, ok)
+    dist.barrier()
+    dist.destroy_process_group()
+    assert all(flags)
+
+
+@pytest.mark.parametrize("mode", ["scatter_allgather", "broadcast"])
+def test_block_distributor_two_ranks(mode):
+    """The raw-sample block reaches every rank intact through scatter + all-gather (and through the plain broadcast fallback);
+    nbytes deliberately not a multiple of the world size."""
+    import torch.multiprocessing as mp
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dist_worker, args=(r, world, port, 100001, mode, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    assert q.get(timeout=180) is True
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
