@@ -18,10 +18,12 @@ pcps_acquisition_hip_sptr pcps_make_acquisition_hip(const Hip_Acq_Conf& conf, in
 
 pcps_acquisition_hip::pcps_acquisition_hip(const Hip_Acq_Conf& conf, int device, bool blocking_on_standby)
     : acquisition_impl_interface("pcps_acquisition_hip",
-          gr::io_signature::make(1, 1, sizeof(gr_complex)),
+          gr::io_signature::make(1, 1, conf.cshort ? sizeof(std::complex<int16_t>) : sizeof(gr_complex)),  // acq.cc:102-103 (it_size)
           gr::io_signature::make(0, 1, sizeof(Gnss_Synchro))),
       d_core(conf, device),
-      d_data_buffer(d_core.consumed_samples()),
+      d_data_buffer(conf.cshort ? 0U : d_core.consumed_samples()),
+      d_data_buffer_sc(conf.cshort ? d_core.consumed_samples() : 0U),
+      d_cshort(conf.cshort),
       d_blocking_on_standby(blocking_on_standby)
 {
     this->message_port_register_out(pmt::mp("events"));
@@ -67,7 +69,9 @@ void pcps_acquisition_hip::set_state(int32_t state)
 void pcps_acquisition_hip::run_dwell(uint64_t sample_count)
 {
     Hip_Pcps_Acquisition_Core::AcquisitionResult result;
-    const auto outcome = d_core.acquisition_core(sample_count, d_data_buffer.data(), &result);
+    const bool was_step_two = d_core.step_two();
+    const auto outcome = d_cshort ? d_core.acquisition_core(sample_count, d_data_buffer_sc.data(), &result)
+                                  : d_core.acquisition_core(sample_count, d_data_buffer.data(), &result);
     gr::thread::scoped_lock lock(d_setlock);
     if (outcome != Hip_Pcps_Acquisition_Core::ACQ_ERROR && d_gnss_synchro != nullptr) d_core.update_synchro(result, d_gnss_synchro);
     switch (outcome)
@@ -86,7 +90,9 @@ void pcps_acquisition_hip::run_dwell(uint64_t sample_count)
             break;
         case Hip_Pcps_Acquisition_Core::ACQ_CONTINUE:
             d_buffer_count = 0U;
-            d_state = 1;  // gather the next non-coherent dwell
+            // step one crossed its threshold and armed the fine-Doppler step: the reference restarts from state 0 (acq.cc:607, 617-624);
+            // otherwise gather the next non-coherent dwell (acq.cc:694-698)
+            d_state = (!was_step_two && d_core.step_two()) ? 0 : 1;
             break;
         case Hip_Pcps_Acquisition_Core::ACQ_NEGATIVE:
         case Hip_Pcps_Acquisition_Core::ACQ_ERROR:  // a GPU failure must look like "not found", never throw here
@@ -129,8 +135,16 @@ int pcps_acquisition_hip::general_work(int /*noutput_items*/, gr_vector_int& nin
             const uint32_t want = d_core.consumed_samples();
             const uint32_t room = want - std::min(d_buffer_count, want);
             const uint32_t take = std::min<uint32_t>(room, static_cast<uint32_t>(ninput_items[0]));
-            const auto* in = reinterpret_cast<const gr_complex*>(input_items[0]);
-            std::copy(in, in + take, d_data_buffer.begin() + d_buffer_count);
+            if (d_cshort)  // acq.cc:789-798
+                {
+                    const auto* in = reinterpret_cast<const std::complex<int16_t>*>(input_items[0]);
+                    std::copy(in, in + take, d_data_buffer_sc.begin() + d_buffer_count);
+                }
+            else
+                {
+                    const auto* in = reinterpret_cast<const gr_complex*>(input_items[0]);
+                    std::copy(in, in + take, d_data_buffer.begin() + d_buffer_count);
+                }
             if (d_buffer_count >= want) d_state = 2;  // same one-call latency as acq.cc:807-811
             d_buffer_count += take;
             d_sample_count += take;

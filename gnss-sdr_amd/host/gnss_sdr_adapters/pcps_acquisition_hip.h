@@ -7,7 +7,7 @@
  * image).  See INTEGRATION.md for the CMake lines.  It derives from the reference's own abstract block
  * acquisition_impl_interface (acquisition_impl_interface.h:50-64), so the existing adapters' plumbing
  * (BasePcpsAcquisition-style connect/disconnect, Channel, ChannelFsm) works with it unchanged.
- * Same stream contract as the reference block: 1 input of gr_complex, 0..1 output of Gnss_Synchro, message port
+ * Same stream contract as the reference block: 1 input of gr_complex (lv_16sc_t for item_type = cshort), 0..1 output of Gnss_Synchro, message port
  * "events" carrying 1 (positive) / 2 (negative) unless a ChannelFsm is set (acq.cc:102-104,146,318-351).
  */
 #ifndef GNSS_SDR_PCPS_ACQUISITION_HIP_H
@@ -53,6 +53,13 @@ public:
     void set_doppler_center(int32_t doppler_center);
     void set_threshold(float threshold);
     void set_state(int32_t state);
+    void set_resampler_latency(uint32_t latency_samples)
+    {
+        gr::thread::scoped_lock lock(d_setlock);
+        d_core.set_resampler_latency(latency_samples);
+    }
+    /*! false when the engine could not be created (no GPU, unsupported transform length): the adapter then reports item_size() == 0 */
+    bool ok() const { return d_core.ok(); }
 
     int general_work(int noutput_items, gr_vector_int& ninput_items, gr_vector_const_void_star& input_items,
         gr_vector_void_star& output_items) override;
@@ -64,6 +71,8 @@ private:
 
     Hip_Pcps_Acquisition_Core d_core;
     std::vector<std::complex<float>> d_data_buffer;
+    std::vector<std::complex<int16_t>> d_data_buffer_sc;  // item_type = cshort (acq.cc:161-164)
+    bool d_cshort{false};
     std::weak_ptr<ChannelFsm> d_channel_fsm;
     Gnss_Synchro* d_gnss_synchro{nullptr};
     uint64_t d_sample_count{0};

@@ -94,6 +94,7 @@ public:
     void set_local_code(const std::complex<float>* code);
     void set_doppler_center(int32_t doppler_center);
     void set_threshold(float threshold) { d_threshold = threshold; }
+    void set_resampler_latency(uint32_t latency_samples) { d_acq_parameters.resampler_latency_samples = latency_samples; }  //!< acq.h:168-172
     float get_threshold() const { return d_step_two ? d_threshold_step_two : d_threshold; }  //!< acq.cc:731-734
     void reset()
     {

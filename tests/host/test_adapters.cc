@@ -1,0 +1,246 @@
+// End-to-end test of the gnss-sdr adapters (gnss-sdr_amd/host/gnss_sdr_adapters/) on the GPU box, compiled against the
+// reference's OWN interface headers (acquisition_interface.h, acquisition_impl_interface.h, gnss_synchro.h, acq_conf.{h,cc},
+// in_memory_configuration.{h,cc}, the signal replica generators -- taken from /root/reference at build time) and against
+// tests/host/mock_gnuradio/ for the GNU Radio runtime.  Each case builds the adapter exactly as GNSSBlockFactory::GetAcqBlock does
+// (gnss_block_factory.cc:449-580: constructor(configuration, role, in_streams, out_streams)), wires it the way Channel does
+// (channel.cc:53-61: set_channel, set_gnss_synchro; :192-208 set_local_code + reset), then plays the role of the GNU Radio
+// scheduler: general_work() is called with chunks of a synthetic IF stream until the block publishes its "events" message
+// (acq.cc:146, 318-351: 1 = positive, 2 = negative).  The stream is generated with the reference's own replica generators.
+// Prints "ADAPTERS OK".  Built by __graft_entry__.build() when /root/reference is present; run by tests/test_adapters_gpu.py.
+#include "galileo_e1_pcps_ambiguous_acquisition_hip.h"
+#include "galileo_e1_signal_replica.h"
+#include "gnss_synchro.h"
+#include "gps_l1_ca_pcps_acquisition_hip.h"
+#include "gps_l5_signal_replica.h"
+#include "gps_l5i_pcps_acquisition_hip.h"
+#include "gps_sdr_signal_replica.h"
+#include "in_memory_configuration.h"
+#include "item_type_helpers.h"
+#include <array>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <random>
+#include <string>
+#include <vector>
+
+// ---- the two item_type helpers acq_conf.cc needs (item_type_helpers.h:43,48); the reference's .cc also pulls in VOLK converters
+bool item_type_valid(const std::string& t)
+{
+    for (const char* k : {"byte", "cbyte", "ibyte", "short", "cshort", "ishort", "float", "gr_complex"})
+        if (t == k) return true;
+    return false;
+}
+size_t item_type_size(const std::string& t)
+{
+    if (t == "byte" || t == "ibyte") return 1;
+    if (t == "cbyte" || t == "short" || t == "ishort") return 2;
+    if (t == "cshort" || t == "float") return 4;
+    if (t == "gr_complex") return 8;
+    return 0;
+}
+
+namespace
+{
+int fails = 0;
+#define EXPECT(cond, ...)                                        \
+    do                                                           \
+        {                                                        \
+            if (!(cond))                                         \
+                {                                                \
+                    std::printf("FAIL %s:%d: ", __FILE__, __LINE__); \
+                    std::printf(__VA_ARGS__);                    \
+                    std::printf("\n");                           \
+                    fails++;                                     \
+                }                                                \
+        }                                                        \
+    while (0)
+
+// noise + one signal: replica (one code period sampled at fs, from the reference generator) delayed by `delay` samples, Doppler `fd`
+std::vector<std::complex<float>> make_stream(const std::vector<std::complex<float>>& replica, size_t n, double fs, size_t delay, double fd, float amp, unsigned seed)
+{
+    std::mt19937 gen(seed);
+    std::normal_distribution<float> g(0.0F, 1.0F);
+    std::vector<std::complex<float>> x(n);
+    const size_t L = replica.size();
+    for (size_t i = 0; i < n; i++)
+        {
+            const std::complex<float> c = replica[(i + L - (delay % L)) % L];
+            const double ph = std::fmod(2.0 * M_PI * fd / fs * static_cast<double>(i), 2.0 * M_PI);
+            x[i] = std::complex<float>(g(gen), g(gen)) + amp * c * std::complex<float>(static_cast<float>(std::cos(ph)), static_cast<float>(std::sin(ph)));
+        }
+    return x;
+}
+
+struct RunResult
+{
+    long event{0};
+    long long calls{0};
+    long long consumed{0};
+};
+
+// the scheduler's part: feed the block until it reports
+template <typename Item>
+RunResult run_block(AcquisitionInterface& acq, const std::vector<Item>& stream, size_t chunk)
+{
+    auto blk = std::dynamic_pointer_cast<gr::block>(acq.get_left_block());
+    RunResult r;
+    if (!blk) return r;
+    blk->published.clear();
+    size_t pos = 0;
+    gr_vector_void_star outs;
+    while (blk->published.empty() && r.calls < 100000)
+        {
+            const size_t avail = std::min(chunk, stream.size() - pos);
+            gr_vector_int nin{static_cast<int>(avail)};
+            gr_vector_const_void_star ins{static_cast<const void*>(stream.data() + pos)};
+            blk->consumed_last = 0;
+            blk->general_work(0, nin, ins, outs);
+            pos += static_cast<size_t>(blk->consumed_last);
+            r.calls++;
+            if (avail == 0 && blk->consumed_last == 0 && blk->published.empty() && pos >= stream.size()) break;
+        }
+    r.consumed = static_cast<long long>(pos);
+    if (!blk->published.empty())
+        {
+            EXPECT(blk->published[0].first == "events", "message on port %s", blk->published[0].first.c_str());
+            r.event = pmt::to_long(blk->published[0].second);
+        }
+    return r;
+}
+
+std::shared_ptr<InMemoryConfiguration> base_config(const std::string& role, long fs)
+{
+    auto c = std::make_shared<InMemoryConfiguration>();
+    c->set_property("GNSS-SDR.internal_fs_sps", std::to_string(fs));
+    c->set_property(role + ".doppler_max", "5000");
+    c->set_property(role + ".doppler_step", "250");
+    c->set_property(role + ".pfa", "0.001");
+    c->set_property(role + ".blocking", "true");
+    c->set_property(role + ".hip_device", "0");
+    return c;
+}
+}  // namespace
+
+int main()
+{
+    // ------------------------------------------------------------------ GPS L1 C/A, gr_complex, CFAR threshold from pfa
+    {
+        const long fs = 4000000;
+        auto conf = base_config("Acquisition_1C", fs);
+        GpsL1CaPcpsAcquisitionHip acq(conf.get(), "Acquisition_1C", 1, 0);
+        EXPECT(acq.implementation() == "GPS_L1_CA_PCPS_Acquisition_HIP" && acq.role() == "Acquisition_1C", "names");
+        EXPECT(acq.item_size() == sizeof(gr_complex), "item_size %zu", acq.item_size());
+        Gnss_Synchro syn{};
+        syn.System = 'G';
+        std::memcpy(syn.Signal, "1C", 3);
+        syn.PRN = 14;
+        acq.set_channel(3);
+        acq.set_gnss_synchro(&syn);
+        acq.set_local_code();
+        std::vector<std::complex<float>> rep(4000);
+        gps_l1_ca_code_gen_complex_sampled(rep, 14, static_cast<int32_t>(fs), 0);
+        auto x = make_stream(rep, 40000, fs, 1234, 1760.0, 0.12F, 1);
+        acq.reset();
+        auto r = run_block(acq, x, 1000);
+        EXPECT(r.event == 1, "GPS L1: event %ld after %lld calls", r.event, r.calls);
+        EXPECT(std::fabs(syn.Acq_delay_samples - 1234.0) <= 1.0, "GPS L1 delay %f", syn.Acq_delay_samples);
+        EXPECT(std::fabs(syn.Acq_doppler_hz - 1760.0) <= 500.0, "GPS L1 doppler %f", syn.Acq_doppler_hz);
+        EXPECT(syn.Acq_samplestamp_samples > 0 && syn.fs == fs, "GPS L1 stamp %llu fs %lld", (unsigned long long)syn.Acq_samplestamp_samples, (long long)syn.fs);
+        // a satellite that is not there: event 2 after max_dwells, block goes inactive (acq.cc:344-351, 635-645)
+        syn.PRN = 15;
+        acq.set_local_code();
+        acq.reset();
+        r = run_block(acq, x, 1000);
+        EXPECT(r.event == 2, "GPS L1 absent PRN: event %ld", r.event);
+        // stop_acquisition: samples are consumed, nothing is reported (acq.cc:768-779)
+        acq.stop_acquisition();
+        r = run_block(acq, x, 1000);
+        EXPECT(r.event == 0 && r.consumed == static_cast<long long>(x.size()), "inactive block must only consume (event %ld consumed %lld)", r.event, r.consumed);
+    }
+    // ------------------------------------------------------------------ GPS L1 C/A, make_two_steps + cshort items
+    {
+        const long fs = 4000000;
+        auto conf = base_config("Acquisition_1C", fs);
+        conf->set_property("Acquisition_1C.item_type", "cshort");
+        conf->set_property("Acquisition_1C.make_two_steps", "true");
+        conf->set_property("Acquisition_1C.second_nbins", "8");
+        conf->set_property("Acquisition_1C.second_doppler_step", "62.5");   // 8 bins x 62.5 Hz = the +-250 Hz a coarse bin can be off
+        conf->set_property("Acquisition_1C.max_dwells", "2");
+        GpsL1CaPcpsAcquisitionHip acq(conf.get(), "Acquisition_1C", 1, 0);
+        EXPECT(acq.item_size() == 4, "cshort item_size %zu", acq.item_size());
+        Gnss_Synchro syn{};
+        syn.System = 'G';
+        std::memcpy(syn.Signal, "1C", 3);
+        syn.PRN = 21;
+        acq.set_gnss_synchro(&syn);
+        acq.set_local_code();
+        std::vector<std::complex<float>> rep(4000);
+        gps_l1_ca_code_gen_complex_sampled(rep, 21, static_cast<int32_t>(fs), 0);
+        auto x = make_stream(rep, 60000, fs, 777, -2290.0, 0.15F, 2);
+        std::vector<std::complex<int16_t>> x16(x.size());
+        for (size_t i = 0; i < x.size(); i++)
+            x16[i] = std::complex<int16_t>(static_cast<int16_t>(std::lrint(x[i].real() * 200.0F)), static_cast<int16_t>(std::lrint(x[i].imag() * 200.0F)));
+        acq.reset();
+        auto r = run_block(acq, x16, 1300);
+        EXPECT(r.event == 1, "two-step cshort: event %ld", r.event);
+        EXPECT(std::fabs(syn.Acq_delay_samples - 777.0) <= 1.0, "two-step delay %f", syn.Acq_delay_samples);
+        EXPECT(std::fabs(syn.Acq_doppler_hz + 2290.0) <= 62.5, "two-step doppler %f (fine bins of 62.5 Hz)", syn.Acq_doppler_hz);
+        EXPECT(syn.Acq_doppler_step == 62U, "Acq_doppler_step %u (acq.cc:598-601 stores the float step in a uint32)", syn.Acq_doppler_step);
+        EXPECT(r.consumed >= 2 * 4000, "two steps must have consumed two blocks (%lld)", r.consumed);
+    }
+    // ------------------------------------------------------------------ Galileo E1B, 4 ms code (fft 16000), CBOC replica
+    {
+        const long fs = 4000000;
+        auto conf = base_config("Acquisition_1B", fs);
+        conf->set_property("Acquisition_1B.cboc", "false");
+        GalileoE1PcpsAmbiguousAcquisitionHip acq(conf.get(), "Acquisition_1B", 1, 0);
+        EXPECT(acq.implementation() == "Galileo_E1_PCPS_Ambiguous_Acquisition_HIP", "E1 name");
+        Gnss_Synchro syn{};
+        syn.System = 'E';
+        std::memcpy(syn.Signal, "1B", 3);
+        syn.PRN = 11;
+        acq.set_gnss_synchro(&syn);
+        acq.set_local_code();
+        std::vector<std::complex<float>> rep(16000);
+        const std::array<char, 3> sig = {{'1', 'B', '\0'}};
+        galileo_e1_code_gen_complex_sampled(rep, sig, false, 11, static_cast<int32_t>(fs), 0, false);
+        auto x = make_stream(rep, 100000, fs, 9001, 640.0, 0.08F, 3);
+        acq.reset();
+        auto r = run_block(acq, x, 4096);
+        EXPECT(r.event == 1, "Galileo E1: event %ld", r.event);
+        EXPECT(std::fabs(syn.Acq_delay_samples - 9001.0) <= 1.0, "Galileo E1 delay %f", syn.Acq_delay_samples);
+        EXPECT(std::fabs(syn.Acq_doppler_hz - 640.0) <= 250.0, "Galileo E1 doppler %f", syn.Acq_doppler_hz);  // 4 ms: 2/(3 T) = 167 Hz + half a bin
+    }
+    // ------------------------------------------------------------------ GPS L5I at 12.5 Msps (fft 12500)
+    {
+        const long fs = 12500000;
+        auto conf = base_config("Acquisition_L5", fs);
+        GpsL5iPcpsAcquisitionHip acq(conf.get(), "Acquisition_L5", 1, 0);
+        Gnss_Synchro syn{};
+        syn.System = 'G';
+        std::memcpy(syn.Signal, "L5", 3);
+        syn.PRN = 6;
+        acq.set_gnss_synchro(&syn);
+        acq.set_local_code();
+        std::vector<std::complex<float>> rep(12500);
+        gps_l5i_code_gen_complex_sampled(rep, 6, static_cast<int32_t>(fs));
+        auto x = make_stream(rep, 100000, fs, 4321, -3010.0, 0.07F, 4);
+        acq.reset();
+        auto r = run_block(acq, x, 8192);
+        EXPECT(r.event == 1, "GPS L5: event %ld", r.event);
+        EXPECT(std::fabs(syn.Acq_delay_samples - 4321.0) <= 1.0, "GPS L5 delay %f", syn.Acq_delay_samples);
+        // the reference's own acquisition tests accept 2/(3 T_int) = 666 Hz at 1 ms (gps_l1_ca_pcps_acquisition_gsoc2013_test.cc:384-401)
+        EXPECT(std::fabs(syn.Acq_doppler_hz + 3010.0) <= 500.0, "GPS L5 doppler %f", syn.Acq_doppler_hz);
+    }
+    // ------------------------------------------------------------------ an item type the engine does not ingest: unusable block, not a crash
+    {
+        auto conf = base_config("Acquisition_1C", 4000000);
+        conf->set_property("Acquisition_1C.item_type", "cbyte");
+        GpsL1CaPcpsAcquisitionHip acq(conf.get(), "Acquisition_1C", 1, 0);
+        EXPECT(acq.item_size() == 0, "cbyte must yield item_size 0 (gnss_block_factory.cc:1048-1052 rejects it), got %zu", acq.item_size());
+    }
+    if (fails == 0) std::printf("ADAPTERS OK\n");
+    return fails == 0 ? 0 : 1;
+}
