@@ -76,6 +76,9 @@ class TrkConf(C.Structure):
         ("pll_filter_order", C.c_int32), ("dll_filter_order", C.c_int32),
         ("enable_fll_pull_in", C.c_int32), ("enable_fll_steady_state", C.c_int32), ("carrier_aiding", C.c_int32), ("cloop", C.c_int32),
         ("pull_in_time_s", C.c_uint32), ("spc", C.c_float), ("slope", C.c_float), ("y_intercept", C.c_float),
+        ("enable_lock_detectors", C.c_int32), ("cn0_samples", C.c_int32), ("cn0_min", C.c_int32), ("max_code_lock_fail", C.c_int32),
+        ("max_carrier_lock_fail", C.c_int32), ("cn0_smoother_samples", C.c_int32), ("carrier_lock_test_smoother_samples", C.c_int32),
+        ("cn0_smoother_alpha", C.c_float), ("carrier_lock_test_smoother_alpha", C.c_float), ("carrier_lock_th", C.c_double),
     ]
 
 
@@ -83,10 +86,10 @@ class TrkEpoch(C.Structure):
     """gsh_trk_epoch."""
     _fields_ = [
         ("sample_counter", C.c_uint64), ("prn_length_samples", C.c_int32), ("flags", C.c_int32),
-        ("corr", C.c_float * 10), ("prompt_data", C.c_float * 2), ("rem_carr_phase_rad", C.c_float), ("pad_", C.c_float),
+        ("corr", C.c_float * 10), ("prompt_data", C.c_float * 2), ("rem_carr_phase_rad", C.c_float), ("cn0_db_hz", C.c_float),
         ("carrier_doppler_hz", C.c_double), ("code_freq_chips", C.c_double), ("carr_phase_error_hz", C.c_double),
         ("carr_freq_error_hz", C.c_double), ("carr_error_filt_hz", C.c_double), ("code_error_chips", C.c_double),
-        ("code_error_filt_chips", C.c_double), ("rem_code_phase_samples", C.c_double), ("acc_carrier_phase_rad", C.c_double),
+        ("code_error_filt_chips", C.c_double), ("rem_code_phase_samples", C.c_double), ("acc_carrier_phase_rad", C.c_double), ("carrier_lock_test", C.c_double),
     ]
 
 

@@ -47,6 +47,21 @@ struct FllPllState  // Tracking_FLL_PLL_filter (T/tracking_FLL_PLL_filter.h)
     int order;
 };
 
+struct SmootherState  // Exponential_Smoother (T/exponential_smoother.h:40-69); the init buffer is only ever summed front to back
+{
+    float alpha, one_minus_alpha, old_value, min_value, offset, init_sum;
+    int samples_for_initialization, init_counter, initializing;
+};
+
+struct LockState  // what cn0_and_tracking_lock_status keeps between periods (trk.cc:1167-1224)
+{
+    float prompt_buffer[2 * GSH_MAX_CN0_SAMPLES];
+    SmootherState cn0_smoother, carrier_lock_test_smoother;
+    int cn0_estimation_counter, carrier_lock_fail_counter, code_lock_fail_counter, pull_in_latched;
+    float cn0_db_hz;
+    double carrier_lock_test;
+};
+
 struct TrkChannel  // loop state of one channel, resident in device memory between launches
 {
     double carrier_doppler_hz, carrier_phase_step_rad, code_freq_chips, code_phase_step_chips;
@@ -66,6 +81,7 @@ struct TrkArgs
     const float* codes;       // n_channels * 2 * code_stride (pilot/primary code, then data code)
     int code_stride;
     TrkChannel* chan;
+    LockState* lock;          // n_channels (used with conf.enable_lock_detectors)
     gsh_trk_epoch* records;   // n_channels * n_epochs or nullptr
     int* epochs_done;         // n_channels
     int n_epochs;
@@ -135,6 +151,125 @@ __device__ __forceinline__ float fll_pll_carrier_error(FllPllState& f, float fll
             f.w = w_new;
         }
     return out;
+}
+
+// ---- lock detectors and C/N0 (T/lock_detectors.cc, T/exponential_smoother.cc), float32 and sequential as written there ----
+__device__ float cn0_m2m4_estimator_d(const float* prompt_iq, int length, float coh_integration_time_s)  // T/lock_detectors.cc:61-110
+{
+    float SNR_aux = 0.0f, Psig = 0.0f, m_2 = 0.0f, m_4 = 0.0f, aux;
+    const float n = static_cast<float>(length);
+    if (length == 0 || coh_integration_time_s == 0.0f) return -100.0f;
+    for (int i = 0; i < length; i++)
+        {
+            const float re = prompt_iq[2 * i], im = prompt_iq[2 * i + 1];
+            Psig = __fadd_rn(Psig, fabsf(re));
+            aux = __fadd_rn(__fmul_rn(im, im), __fmul_rn(re, re));
+            m_2 = __fadd_rn(m_2, aux);
+            m_4 = __fadd_rn(m_4, __fmul_rn(aux, aux));
+        }
+    Psig = __fdiv_rn(Psig, n);
+    Psig = __fmul_rn(Psig, Psig);
+    m_2 = __fdiv_rn(m_2, n);
+    m_4 = __fdiv_rn(m_4, n);
+    aux = __fsqrt_rn(__fsub_rn(__fmul_rn(__fmul_rn(2.0f, m_2), m_2), m_4));
+    float denominator;
+    if (isnan(aux))
+        {
+            denominator = __fsub_rn(m_2, Psig);
+            if (denominator == 0.0f) return -100.0f;
+            SNR_aux = __fdiv_rn(Psig, denominator);
+        }
+    else
+        {
+            denominator = __fsub_rn(m_2, aux);
+            if (denominator == 0.0f) return -100.0f;
+            SNR_aux = __fdiv_rn(aux, denominator);
+        }
+    if (SNR_aux == 0.0f) return -100.0f;
+    return __fsub_rn(__fmul_rn(10.0f, log10f(SNR_aux)), __fmul_rn(10.0f, log10f(coh_integration_time_s)));
+}
+
+__device__ float carrier_lock_detector_d(const float* prompt_iq, int length)  // T/lock_detectors.cc:113-133
+{
+    float si = 0.0f, sq = 0.0f;
+    for (int i = 0; i < length; i++)
+        {
+            si = __fadd_rn(si, prompt_iq[2 * i]);
+            sq = __fadd_rn(sq, prompt_iq[2 * i + 1]);
+        }
+    const float nbp = __fadd_rn(__fmul_rn(si, si), __fmul_rn(sq, sq));
+    const float nbd = __fsub_rn(__fmul_rn(si, si), __fmul_rn(sq, sq));
+    if (nbp == 0.0f) return 0.0f;
+    return __fdiv_rn(nbd, nbp);
+}
+
+__device__ float smoother_smooth_d(SmootherState& s, float raw)  // T/exponential_smoother.cc:83-112
+{
+    float smoothed;
+    if (s.initializing)
+        {
+            s.init_counter++;
+            smoothed = raw;
+            s.init_sum = __fadd_rn(s.init_sum, smoothed);
+            if (s.init_counter == s.samples_for_initialization)
+                {
+                    s.old_value = __fdiv_rn(s.init_sum, static_cast<float>(s.init_counter));
+                    if (s.old_value < __fadd_rn(s.min_value, s.offset))
+                        {
+                            s.init_counter = 0;  // flush buffer and start again
+                            s.init_sum = 0.0f;
+                        }
+                    else
+                        {
+                            s.initializing = 0;
+                        }
+                }
+        }
+    else
+        {
+            smoothed = __fadd_rn(__fmul_rn(s.alpha, raw), __fmul_rn(s.one_minus_alpha, s.old_value));
+            s.old_value = smoothed;
+        }
+    return smoothed;
+}
+
+// cn0_and_tracking_lock_status, trk.cc:1167-1224: true while locked
+__device__ bool lock_status_d(LockState& st, const gsh_trk_conf& c, float2 P, double coh_integration_time_s, bool pull_in_transitory)
+{
+    const int ns = c.cn0_samples;
+    if (st.cn0_estimation_counter < ns)
+        {
+            st.prompt_buffer[2 * st.cn0_estimation_counter] = P.x;
+            st.prompt_buffer[2 * st.cn0_estimation_counter + 1] = P.y;
+            st.cn0_estimation_counter++;
+            return true;
+        }
+    const int slot = st.cn0_estimation_counter % ns;
+    st.prompt_buffer[2 * slot] = P.x;
+    st.prompt_buffer[2 * slot + 1] = P.y;
+    st.cn0_estimation_counter++;
+    const float cn0_raw = cn0_m2m4_estimator_d(st.prompt_buffer, ns, static_cast<float>(coh_integration_time_s));
+    st.cn0_db_hz = smoother_smooth_d(st.cn0_smoother, cn0_raw);
+    // carrier_lock_detector(d_Prompt_buffer.data(), 1): length ONE, as the reference calls it (trk.cc:1184)
+    st.carrier_lock_test = static_cast<double>(smoother_smooth_d(st.carrier_lock_test_smoother, carrier_lock_detector_d(st.prompt_buffer, 1)));
+    if (!pull_in_transitory)
+        {
+            if (st.carrier_lock_test < c.carrier_lock_th)
+                st.carrier_lock_fail_counter++;
+            else if (st.carrier_lock_fail_counter > 0)
+                st.carrier_lock_fail_counter--;
+            if (st.cn0_db_hz < static_cast<float>(c.cn0_min))
+                st.code_lock_fail_counter++;
+            else if (st.code_lock_fail_counter > 0)
+                st.code_lock_fail_counter--;
+        }
+    if (st.carrier_lock_fail_counter > c.max_carrier_lock_fail || st.code_lock_fail_counter > c.max_code_lock_fail)
+        {
+            st.carrier_lock_fail_counter = 0;
+            st.code_lock_fail_counter = 0;
+            return false;
+        }
+    return true;
 }
 
 struct NextWindow  // what thread 0 publishes for the next correlation (do_correlation_step's casts, trk.cc:1237-1243)
@@ -223,6 +358,47 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
                     // trk.cc:1912-1915: pull-in ends once more than pull_in_time_s whole seconds have passed since acquisition
                     const bool pull_in = !(static_cast<unsigned long long>(c.pull_in_time_s) < (pos - s.acq_stamp) / static_cast<unsigned long long>(static_cast<int>(c.fs_in)));
                     const float2 P = out[PROMPT], E = out[PROMPT - 1], L = out[PROMPT + 1];
+                    float rec_cn0 = 0.0f;
+                    double rec_lock_test = 0.0;
+                    bool lost = false;
+                    if (c.enable_lock_detectors)
+                        {
+                            LockState& lk = a.lock[ch];  // touched by this thread only; lives in device memory between launches
+                            if (lk.pull_in_latched && !pull_in)  // trk.cc:1912-1916
+                                {
+                                    lk.pull_in_latched = 0;
+                                    lk.carrier_lock_fail_counter = 0;
+                                    lk.code_lock_fail_counter = 0;
+                                }
+                            lost = !lock_status_d(lk, c, P, corr_time, pull_in);  // trk.cc:2008
+                            rec_cn0 = lk.cn0_db_hz;
+                            rec_lock_test = lk.carrier_lock_test;
+                        }
+                    if (lost)  // trk.cc:2009-2014: clear_tracking_vars, d_state = 0 -- the channel stops here
+                        {
+                            if (a.records != nullptr)
+                                {
+                                    gsh_trk_epoch r;
+                                    memset(&r, 0, sizeof(r));
+                                    r.sample_counter = pos;
+                                    r.flags = (pull_in ? 1 : 0) | 2;
+#pragma unroll
+                                    for (int t = 0; t < 5; t++)
+                                        {
+                                            r.corr[2 * t] = (t < NT) ? out[t < NT ? t : 0].x : 0.0f;
+                                            r.corr[2 * t + 1] = (t < NT) ? out[t < NT ? t : 0].y : 0.0f;
+                                        }
+                                    r.prompt_data[0] = pdata.x;
+                                    r.prompt_data[1] = pdata.y;
+                                    r.cn0_db_hz = rec_cn0;
+                                    r.carrier_lock_test = rec_lock_test;
+                                    a.records[static_cast<size_t>(ch) * a.n_epochs + e] = r;
+                                }
+                            s.active = 0;
+                            publish(win, s, c, a.n_stream, 0);
+                        }
+                    else
+                        {
                     // ---- run_dll_pll, trk.cc:1260-1324
                     const double carr_phase_error_hz = (c.cloop ? pll_cloop_two_quadrant_atan_d(P) : pll_four_quadrant_atan_d(P)) / GNSS_TWO_PI_D;
                     double carr_freq_error_hz = 0.0;
@@ -282,7 +458,8 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
                             r.prompt_data[0] = pdata.x;
                             r.prompt_data[1] = pdata.y;
                             r.rem_carr_phase_rad = s.rem_carr_phase_rad;
-                            r.pad_ = 0.0f;
+                            r.cn0_db_hz = rec_cn0;
+                            r.carrier_lock_test = rec_lock_test;
                             r.carrier_doppler_hz = s.carrier_doppler_hz;
                             r.code_freq_chips = s.code_freq_chips;
                             r.carr_phase_error_hz = carr_phase_error_hz;
@@ -296,6 +473,7 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
                         }
                     s.pos = pos + static_cast<unsigned long long>(prn_len);  // consume_each, trk.cc:2287
                     publish(win, s, c, a.n_stream, e + 1 < a.n_epochs);
+                        }
                 }
             done = e + 1;
             __syncthreads();
@@ -426,6 +604,8 @@ struct gsh_trk
     float* d_codes{nullptr};
     gsh::TrkChannel* d_chan{nullptr};
     gsh::TrkChannel* d_chan_backup{nullptr};
+    gsh::LockState* d_lock{nullptr};         // lock-detector state per channel (enable_lock_detectors)
+    gsh::LockState* d_lock_backup{nullptr};
     std::vector<gsh::TrkChannel> h_chan;
     float2* d_stream_owned{nullptr};
     size_t stream_owned_cap{0};
@@ -456,6 +636,7 @@ int trk_launch(gsh_trk* t, int n_epochs, gsh_trk_epoch* d_records)
     a.codes = t->d_codes;
     a.code_stride = t->max_code_len;
     a.chan = t->d_chan;
+    a.lock = t->d_lock;
     a.records = d_records;
     a.epochs_done = t->d_done;
     a.n_epochs = n_epochs;
@@ -482,6 +663,11 @@ extern "C"
         GSH_REQUIRE(c.code_length_chips >= 1 && c.code_samples_per_chip >= 1 && c.vector_length >= 1, "code_length_chips, code_samples_per_chip, vector_length must be >= 1");
         GSH_REQUIRE(c.pll_filter_order == 2 || c.pll_filter_order == 3, "pll_filter_order %d (2 or 3: T/tracking_FLL_PLL_filter.cc:23-54)", c.pll_filter_order);
         GSH_REQUIRE(c.dll_filter_order >= 1 && c.dll_filter_order <= 3, "dll_filter_order %d outside 1..3", c.dll_filter_order);
+        if (c.enable_lock_detectors)
+            {
+                GSH_REQUIRE(c.cn0_samples >= 1 && c.cn0_samples <= GSH_MAX_CN0_SAMPLES, "cn0_samples %d outside 1..%d", c.cn0_samples, GSH_MAX_CN0_SAMPLES);
+                GSH_REQUIRE(c.max_code_lock_fail >= 0 && c.max_carrier_lock_fail >= 0, "lock fail limits must not be negative");
+            }
         GSH_REQUIRE(static_cast<uint64_t>(c.code_length_chips) * c.code_samples_per_chip <= static_cast<uint64_t>(max_code_length), "max_code_length %d smaller than code_length_chips * code_samples_per_chip", max_code_length);
         gsh_trk probe;
         probe.conf = c;
@@ -507,6 +693,9 @@ extern "C"
         if ((e = hipMalloc(&t->d_chan, sizeof(gsh::TrkChannel) * n_channels)) != hipSuccess) return fail(e, "hipMalloc(state)");
         if ((e = hipMalloc(&t->d_chan_backup, sizeof(gsh::TrkChannel) * n_channels)) != hipSuccess) return fail(e, "hipMalloc(state)");
         if ((e = hipMemset(t->d_chan, 0, sizeof(gsh::TrkChannel) * n_channels)) != hipSuccess) return fail(e, "hipMemset(state)");
+        if ((e = hipMalloc(&t->d_lock, sizeof(gsh::LockState) * n_channels)) != hipSuccess) return fail(e, "hipMalloc(lock)");
+        if ((e = hipMalloc(&t->d_lock_backup, sizeof(gsh::LockState) * n_channels)) != hipSuccess) return fail(e, "hipMalloc(lock)");
+        if ((e = hipMemset(t->d_lock, 0, sizeof(gsh::LockState) * n_channels)) != hipSuccess) return fail(e, "hipMemset(lock)");
         if ((e = hipMalloc(&t->d_done, sizeof(int) * n_channels)) != hipSuccess) return fail(e, "hipMalloc(done)");
         if ((e = hipEventCreate(&t->ev0)) != hipSuccess) return fail(e, "hipEventCreate");
         if ((e = hipEventCreate(&t->ev1)) != hipSuccess) return fail(e, "hipEventCreate");
@@ -528,6 +717,8 @@ extern "C"
         if (t->d_codes) (void)hipFree(t->d_codes);
         if (t->d_chan) (void)hipFree(t->d_chan);
         if (t->d_chan_backup) (void)hipFree(t->d_chan_backup);
+        if (t->d_lock) (void)hipFree(t->d_lock);
+        if (t->d_lock_backup) (void)hipFree(t->d_lock_backup);
         if (t->d_stream_owned) (void)hipFree(t->d_stream_owned);
         if (t->d_records) (void)hipFree(t->d_records);
         if (t->d_done) (void)hipFree(t->d_done);
@@ -600,6 +791,23 @@ extern "C"
         GSH_HIP(hipMemcpyAsync(dst, code, sizeof(float) * code_length, hipMemcpyHostToDevice, t->stream));
         if (data_code) GSH_HIP(hipMemcpyAsync(dst + t->max_code_len, data_code, sizeof(float) * code_length, hipMemcpyHostToDevice, t->stream));
         GSH_HIP(hipMemcpyAsync(t->d_chan + channel, &t->h_chan[channel], sizeof(gsh::TrkChannel), hipMemcpyHostToDevice, t->stream));
+        // lock detectors as the constructor / start_tracking leave them (trk.cc:676-692, 1039, 1073, 1970-1971)
+        gsh::LockState lk{};
+        auto init_smoother = [](gsh::SmootherState& sm, float alpha, int samples, float min_value, float offset) {
+            sm = gsh::SmootherState{};
+            sm.alpha = alpha < 0.0F ? 0.0F : (alpha > 1.0F ? 1.0F : alpha);  // set_alpha, T/exponential_smoother.cc:28-40
+            sm.one_minus_alpha = 1.0F - sm.alpha;
+            sm.samples_for_initialization = samples <= 0 ? 1 : samples;     // :49-58
+            sm.min_value = min_value;
+            sm.offset = offset;
+            sm.initializing = 1;
+        };
+        int cn0_init = 200;  // T/exponential_smoother.h:66
+        if (code_period > 0.0) cn0_init = c.cn0_smoother_samples / static_cast<int>(code_period * 1000.0);  // trk.cc:683-686
+        init_smoother(lk.cn0_smoother, c.cn0_smoother_alpha, cn0_init, 25.0F, 12.0F);                        // class defaults, T/exponential_smoother.h:64-65
+        init_smoother(lk.carrier_lock_test_smoother, c.carrier_lock_test_smoother_alpha, c.carrier_lock_test_smoother_samples, -1.0F, 0.0F);  // trk.cc:688-692
+        lk.pull_in_latched = 1;
+        GSH_HIP(hipMemcpyAsync(t->d_lock + channel, &lk, sizeof(lk), hipMemcpyHostToDevice, t->stream));
         GSH_HIP(hipStreamSynchronize(t->stream));
         return GSH_OK;
     }
@@ -635,13 +843,16 @@ extern "C"
         if (t->d_stream == nullptr) return set_error(GSH_ERR_STATE, "no IF stream attached (gsh_trk_set_stream_*)");
         GSH_HIP(hipSetDevice(t->device));
         const size_t bytes = sizeof(gsh::TrkChannel) * t->n_channels;
+        const size_t lbytes = sizeof(gsh::LockState) * t->n_channels;
         GSH_HIP(hipMemcpyAsync(t->d_chan_backup, t->d_chan, bytes, hipMemcpyDeviceToDevice, t->stream));
+        GSH_HIP(hipMemcpyAsync(t->d_lock_backup, t->d_lock, lbytes, hipMemcpyDeviceToDevice, t->stream));
         int rc = trk_launch(t, n_epochs, nullptr);  // warm-up
         if (rc != GSH_OK) return rc;
         float total = 0.0f;
         for (int i = 0; i < reps; i++)
             {
                 GSH_HIP(hipMemcpyAsync(t->d_chan, t->d_chan_backup, bytes, hipMemcpyDeviceToDevice, t->stream));
+                GSH_HIP(hipMemcpyAsync(t->d_lock, t->d_lock_backup, lbytes, hipMemcpyDeviceToDevice, t->stream));
                 GSH_HIP(hipEventRecord(t->ev0, t->stream));
                 rc = trk_launch(t, n_epochs, nullptr);
                 if (rc != GSH_OK) return rc;
@@ -652,6 +863,7 @@ extern "C"
                 total += ms;
             }
         GSH_HIP(hipMemcpyAsync(t->d_chan, t->d_chan_backup, bytes, hipMemcpyDeviceToDevice, t->stream));
+        GSH_HIP(hipMemcpyAsync(t->d_lock, t->d_lock_backup, lbytes, hipMemcpyDeviceToDevice, t->stream));
         GSH_HIP(hipStreamSynchronize(t->stream));
         *avg_ms = total / static_cast<float>(reps);
         return GSH_OK;

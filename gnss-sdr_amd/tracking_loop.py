@@ -21,7 +21,11 @@ def trk_conf(**kw) -> TrkConf:
              code_samples_per_chip=1, vector_length=4000, veml=0, track_pilot=0, early_late_space_chips=0.5,
              very_early_late_space_chips=0.6, pll_bw_hz=35.0, dll_bw_hz=2.0, fll_bw_hz=35.0, pll_filter_order=3, dll_filter_order=2,
              enable_fll_pull_in=0, enable_fll_steady_state=0, carrier_aiding=1, cloop=1, pull_in_time_s=5, spc=0.5, slope=1.0,
-             y_intercept=1.0)
+             y_intercept=1.0,
+             # lock detectors / C/N0: Dll_Pll_Conf defaults (gnss_sdr_flags.cc:44-53, dll_pll_conf.h:58-59,70-71); off unless asked for
+             enable_lock_detectors=0, cn0_samples=20, cn0_min=25, max_code_lock_fail=50, max_carrier_lock_fail=5000,
+             cn0_smoother_samples=200, carrier_lock_test_smoother_samples=25, cn0_smoother_alpha=0.002,
+             carrier_lock_test_smoother_alpha=0.002, carrier_lock_th=0.7)
     d.update(kw)
     for k, v in d.items():
         setattr(c, k, v)

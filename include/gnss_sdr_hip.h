@@ -30,7 +30,7 @@ extern "C"
 {
 #endif
 
-#define GSH_ABI_VERSION 4
+#define GSH_ABI_VERSION 5
 #define GSH_MAX_TAPS 8 /* VE/E/P/L/VL needs 5 (trk.cc:609-650); 8 leaves room for multi-tap dumps */
 
     enum
@@ -179,8 +179,11 @@ extern "C"
      * with the initial conditions of start_tracking (:796-866) and the pull-in state (:1949-1973).
      * All of it runs on the GPU: one work-group per channel iterates over the code periods of a device-resident IF
      * stream and leaves one record per period, so n_epochs periods cost one launch instead of n_epochs host round
-     * trips.  Not modelled here (the host block keeps them): bit / secondary-code synchronisation, extended
-     * integration, lock detectors and CN0, high_dyn smoothing, the experimental Doppler correction (:1326-1346).
+     * trips.  With enable_lock_detectors the C/N0 estimator, the carrier lock detector, their smoothers and the loss-of-lock
+     * counters (cn0_and_tracking_lock_status, trk.cc:1167-1224; T/lock_detectors.cc, T/exponential_smoother.cc) run on the device
+     * too, between the correlation and run_dll_pll as state 2 orders them (:2008-2018).  Not modelled here (the host block
+     * keeps them): bit / secondary-code synchronisation, extended integration, high_dyn smoothing, the experimental Doppler
+     * correction (:1326-1346).
      * T/ = src/algorithms/tracking/libs/.
      */
     typedef struct gsh_trk gsh_trk_t;
@@ -205,19 +208,33 @@ extern "C"
         int32_t cloop;                   /* d_cloop: 1 = Costas two-quadrant arctangent, 0 = four-quadrant */
         uint32_t pull_in_time_s;         /* Dll_Pll_Conf::pull_in_time_s, trk.cc:1912-1915 */
         float spc, slope, y_intercept;   /* dll_nc_e_minus_l_normalized parameters (trk.cc:1986, dll_pll_conf.h:55-57) */
+        int32_t enable_lock_detectors;   /* 0: the loop never declares loss of lock (the host block runs the detectors) */
+        int32_t cn0_samples;             /* Dll_Pll_Conf::cn0_samples, 1..GSH_MAX_CN0_SAMPLES (flag default 20) */
+        int32_t cn0_min;                 /* [dB-Hz] (25) */
+        int32_t max_code_lock_fail;      /* (50) */
+        int32_t max_carrier_lock_fail;   /* (5000) */
+        int32_t cn0_smoother_samples;    /* (200) divided by the code period in ms, trk.cc:683-686 */
+        int32_t carrier_lock_test_smoother_samples; /* (25) */
+        float cn0_smoother_alpha;        /* (0.002) */
+        float carrier_lock_test_smoother_alpha;     /* (0.002) */
+        double carrier_lock_th;          /* (0.7) */
     } gsh_trk_conf;
+#define GSH_MAX_CN0_SAMPLES 64
 
     typedef struct gsh_trk_epoch         /* what log_data dumps per period (trk.cc:1599-1702), POD */
     {
         uint64_t sample_counter;         /* first sample of the correlated window */
         int32_t prn_length_samples;      /* d_current_prn_length_samples: samples consumed after this period */
-        int32_t flags;                   /* bit 0: d_pull_in_transitory was set */
+        int32_t flags;                   /* bit 0: d_pull_in_transitory was set; bit 1: loss of lock declared in this period
+                                            (trk.cc:1208-1221, "events" message 3): the channel stops, the record carries the
+                                            correlator outputs and the detector values only, prn_length_samples = 0 */
         float corr[10];                  /* E,P,L or VE,E,P,L,VL as interleaved complex64 */
         float prompt_data[2];            /* d_Prompt_Data (track_pilot) */
         float rem_carr_phase_rad;
-        float pad_;
+        float cn0_db_hz;                 /* d_CN0_SNV_dB_Hz (0 until cn0_samples periods have passed, or with the detectors off) */
         double carrier_doppler_hz, code_freq_chips, carr_phase_error_hz, carr_freq_error_hz, carr_error_filt_hz;
         double code_error_chips, code_error_filt_chips, rem_code_phase_samples, acc_carrier_phase_rad;
+        double carrier_lock_test;        /* d_carrier_lock_test */
     } gsh_trk_epoch;
 
     int gsh_trk_create(int device, const gsh_trk_conf* conf, int n_channels, int max_code_length, gsh_trk_t** out);

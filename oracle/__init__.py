@@ -43,16 +43,19 @@ class TrkConf(C.Structure):
                 ("pll_bw_hz", C.c_float), ("dll_bw_hz", C.c_float), ("fll_bw_hz", C.c_float),
                 ("pll_filter_order", C.c_int32), ("dll_filter_order", C.c_int32),
                 ("enable_fll_pull_in", C.c_int32), ("enable_fll_steady_state", C.c_int32), ("carrier_aiding", C.c_int32), ("cloop", C.c_int32),
-                ("pull_in_time_s", C.c_uint32), ("spc", C.c_float), ("slope", C.c_float), ("y_intercept", C.c_float)]
+                ("pull_in_time_s", C.c_uint32), ("spc", C.c_float), ("slope", C.c_float), ("y_intercept", C.c_float),
+                ("enable_lock_detectors", C.c_int32), ("cn0_samples", C.c_int32), ("cn0_min", C.c_int32), ("max_code_lock_fail", C.c_int32),
+                ("max_carrier_lock_fail", C.c_int32), ("cn0_smoother_samples", C.c_int32), ("carrier_lock_test_smoother_samples", C.c_int32),
+                ("cn0_smoother_alpha", C.c_float), ("carrier_lock_test_smoother_alpha", C.c_float), ("carrier_lock_th", C.c_double)]
 
 
 class TrkEpoch(C.Structure):
     """oracle_trk_epoch (same layout as gsh_trk_epoch)"""
     _fields_ = [("sample_counter", C.c_uint64), ("prn_length_samples", C.c_int32), ("flags", C.c_int32),
-                ("corr", C.c_float * 10), ("prompt_data", C.c_float * 2), ("rem_carr_phase_rad", C.c_float), ("pad_", C.c_float),
+                ("corr", C.c_float * 10), ("prompt_data", C.c_float * 2), ("rem_carr_phase_rad", C.c_float), ("cn0_db_hz", C.c_float),
                 ("carrier_doppler_hz", C.c_double), ("code_freq_chips", C.c_double), ("carr_phase_error_hz", C.c_double),
                 ("carr_freq_error_hz", C.c_double), ("carr_error_filt_hz", C.c_double), ("code_error_chips", C.c_double),
-                ("code_error_filt_chips", C.c_double), ("rem_code_phase_samples", C.c_double), ("acc_carrier_phase_rad", C.c_double)]
+                ("code_error_filt_chips", C.c_double), ("rem_code_phase_samples", C.c_double), ("acc_carrier_phase_rad", C.c_double), ("carrier_lock_test", C.c_double)]
 
 
 _lib = None
@@ -107,6 +110,14 @@ def lib():
         L.oracle_trk_run.argtypes = [C.POINTER(TrkConf), _f32p, C.c_void_p, C.c_int, _f32p, C.c_uint64, C.c_uint64, C.c_uint64,
                                      C.c_double, C.c_int, C.POINTER(TrkEpoch)]
         L.oracle_trk_run.restype = C.c_int
+        L.oracle_cn0_m2m4_estimator.argtypes = [_f32p, C.c_int, C.c_float]
+        L.oracle_cn0_m2m4_estimator.restype = C.c_float
+        L.oracle_carrier_lock_detector.argtypes = [_f32p, C.c_int]
+        L.oracle_carrier_lock_detector.restype = C.c_float
+        L.oracle_smoother_init.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_float, C.c_float]
+        L.oracle_smoother_init.restype = None
+        L.oracle_smoother_smooth.argtypes = [C.c_void_p, C.c_float]
+        L.oracle_smoother_smooth.restype = C.c_float
         _lib = L
     return _lib
 
@@ -149,6 +160,12 @@ def ref():
                     getattr(R, name).restype = C.c_double
                 R.ref_loop_filter_run.argtypes = [C.c_float, C.c_float, C.c_int, C.c_int, C.c_float, _f32p, _f32p, C.c_int]
                 R.ref_fll_pll_filter_run.argtypes = [C.c_float, C.c_float, C.c_int, C.c_float, _f32p, _f32p, C.c_float, _f32p, C.c_int]
+            if hasattr(R, "ref_smoother_run"):  # lock detectors + smoother (added with SURVEY 8f-2)
+                R.ref_cn0_m2m4_estimator.argtypes = [_f32p, C.c_int, C.c_float]
+                R.ref_cn0_m2m4_estimator.restype = C.c_float
+                R.ref_carrier_lock_detector.argtypes = [_f32p, C.c_int]
+                R.ref_carrier_lock_detector.restype = C.c_float
+                R.ref_smoother_run.argtypes = [C.c_float, C.c_int, C.c_float, C.c_float, _f32p, C.c_int, _f32p]
             _ref = R
     return _ref
 
@@ -252,6 +269,30 @@ def fll_pll_filter_run(fll_bw_hz, pll_bw_hz, order, acq_doppler_hz, fll_disc, pl
                      for a, b in zip(np.asarray(fll_disc, np.float32), np.asarray(pll_disc, np.float32))], np.float32)
 
 
+class Smoother(C.Structure):
+    """oracle_smoother"""
+    _fields_ = [(k, C.c_float) for k in ("alpha", "one_minus_alpha", "old_value", "min_value", "offset", "init_sum")] + [
+        (k, C.c_int) for k in ("samples_for_initialization", "init_counter", "initializing")]
+
+
+def cn0_m2m4_estimator(prompt: np.ndarray, coh_integration_time_s: float) -> float:
+    p = _iq(prompt)
+    return float(lib().oracle_cn0_m2m4_estimator(p.reshape(-1), len(prompt), coh_integration_time_s))
+
+
+def carrier_lock_detector(prompt: np.ndarray, length: int | None = None) -> float:
+    p = _iq(prompt)
+    return float(lib().oracle_carrier_lock_detector(p.reshape(-1), len(prompt) if length is None else length))
+
+
+def smoother_run(alpha: float, samples_for_initialization: int, raw, min_value: float = 25.0, offset: float = 12.0) -> np.ndarray:
+    """Exponential_Smoother configured as trk.cc:680-692 does, fed with `raw`"""
+    L = lib()
+    s = Smoother()
+    L.oracle_smoother_init(C.byref(s), alpha, samples_for_initialization, min_value, offset)
+    return np.array([L.oracle_smoother_smooth(C.byref(s), float(v)) for v in np.asarray(raw, np.float32)], np.float32)
+
+
 def trk_conf(**kw) -> TrkConf:
     """oracle_trk_conf with Dll_Pll_Conf's defaults (dll_pll_conf.h:33-90) for the fields that have one"""
     c = TrkConf()
@@ -259,7 +300,11 @@ def trk_conf(**kw) -> TrkConf:
              code_samples_per_chip=1, vector_length=4000, veml=0, track_pilot=0, early_late_space_chips=0.5,
              very_early_late_space_chips=0.6, pll_bw_hz=35.0, dll_bw_hz=2.0, fll_bw_hz=35.0, pll_filter_order=3, dll_filter_order=2,
              enable_fll_pull_in=0, enable_fll_steady_state=0, carrier_aiding=1, cloop=1, pull_in_time_s=5, spc=0.5, slope=1.0,
-             y_intercept=1.0)
+             y_intercept=1.0,
+             # lock detectors / C/N0: Dll_Pll_Conf defaults (gnss_sdr_flags.cc:44-53, dll_pll_conf.h:58-59,70-71); off unless asked for
+             enable_lock_detectors=0, cn0_samples=20, cn0_min=25, max_code_lock_fail=50, max_carrier_lock_fail=5000,
+             cn0_smoother_samples=200, carrier_lock_test_smoother_samples=25, cn0_smoother_alpha=0.002,
+             carrier_lock_test_smoother_alpha=0.002, carrier_lock_th=0.7)
     d.update(kw)
     for k, v in d.items():
         setattr(c, k, v)

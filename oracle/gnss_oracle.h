@@ -102,6 +102,27 @@ extern "C"
     void oracle_fll_pll_initialize(oracle_fll_pll_filter* f, float acq_carrier_doppler_hz);
     float oracle_fll_pll_carrier_error(oracle_fll_pll_filter* f, float fll_disc, float pll_disc, float correlation_time_s);
 
+    /* ---- lock detectors and C/N0: T/lock_detectors.cc, T/exponential_smoother.cc, trk.cc:1167-1224 ---- */
+    float oracle_cn0_m2m4_estimator(const float* prompt_iq, int length, float coh_integration_time_s); /* T/lock_detectors.cc:61-110 */
+    float oracle_carrier_lock_detector(const float* prompt_iq, int length);                             /* T/lock_detectors.cc:113-133 */
+    typedef struct oracle_smoother  /* Exponential_Smoother, T/exponential_smoother.h:40-69 */
+    {
+        float alpha, one_minus_alpha, old_value, min_value, offset, init_sum;
+        int samples_for_initialization, init_counter, initializing;
+    } oracle_smoother;
+    void oracle_smoother_init(oracle_smoother* s, float alpha, int samples_for_initialization, float min_value, float offset);
+    void oracle_smoother_reset(oracle_smoother* s);
+    float oracle_smoother_smooth(oracle_smoother* s, float raw);
+#define ORACLE_MAX_CN0_SAMPLES 64
+    typedef struct oracle_lock_state  /* the members cn0_and_tracking_lock_status touches (trk.cc:1167-1224) */
+    {
+        float prompt_buffer[2 * ORACLE_MAX_CN0_SAMPLES];
+        oracle_smoother cn0_smoother, carrier_lock_test_smoother;
+        int cn0_estimation_counter, carrier_lock_fail_counter, code_lock_fail_counter;
+        float cn0_db_hz;
+        double carrier_lock_test;
+    } oracle_lock_state;
+
     /* same field order as gsh_trk_conf / gsh_trk_epoch (include/gnss_sdr_hip.h) so that one ctypes layout serves both */
     typedef struct oracle_trk_conf
     {
@@ -114,7 +135,16 @@ extern "C"
         int32_t enable_fll_pull_in, enable_fll_steady_state, carrier_aiding, cloop;
         uint32_t pull_in_time_s;
         float spc, slope, y_intercept;
+        /* lock detectors and C/N0 (0 = off: the loop never declares loss of lock) */
+        int32_t enable_lock_detectors;
+        int32_t cn0_samples, cn0_min, max_code_lock_fail, max_carrier_lock_fail;
+        int32_t cn0_smoother_samples, carrier_lock_test_smoother_samples;
+        float cn0_smoother_alpha, carrier_lock_test_smoother_alpha;
+        double carrier_lock_th;
     } oracle_trk_conf;
+    void oracle_lock_init(oracle_lock_state* st, const oracle_trk_conf* c);
+    /* cn0_and_tracking_lock_status, trk.cc:1167-1224: returns 1 while locked, 0 when loss of lock is declared */
+    int oracle_lock_status(oracle_lock_state* st, const oracle_trk_conf* c, float p_re, float p_im, double coh_integration_time_s, int pull_in_transitory);
 
     typedef struct oracle_trk_epoch
     {
@@ -124,9 +154,10 @@ extern "C"
         float corr[10];
         float prompt_data[2];
         float rem_carr_phase_rad;
-        float pad_;
+        float cn0_db_hz;
         double carrier_doppler_hz, code_freq_chips, carr_phase_error_hz, carr_freq_error_hz, carr_error_filt_hz;
         double code_error_chips, code_error_filt_chips, rem_code_phase_samples, acc_carrier_phase_rad;
+        double carrier_lock_test;
     } oracle_trk_epoch;
 
     /* closed loop of ONE channel over a resident stream; returns the number of epochs completed */

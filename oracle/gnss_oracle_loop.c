@@ -246,11 +246,165 @@ float oracle_fll_pll_carrier_error(oracle_fll_pll_filter* f, float fll_disc, flo
     return out;
 }
 
+/* ---- lock detectors and C/N0 ---------------------------------------------------------------------------------
+ * T/lock_detectors.cc:61-110: second / fourth moment estimator, everything float32, sequential sums */
+float oracle_cn0_m2m4_estimator(const float* prompt_iq, int length, float coh_integration_time_s)
+{
+    float SNR_aux = 0.0F, Psig = 0.0F, m_2 = 0.0F, m_4 = 0.0F, aux;
+    const float n = (float)length;
+    if (length == 0 || coh_integration_time_s == 0.0) return -100.0F;
+    for (int i = 0; i < length; i++)
+        {
+            const float re = prompt_iq[2 * i], im = prompt_iq[2 * i + 1];
+            Psig += fabsf(re);
+            aux = im * im + re * re;
+            m_2 += aux;
+            m_4 += (aux * aux);
+        }
+    Psig /= n;
+    Psig = Psig * Psig;
+    m_2 /= n;
+    m_4 /= n;
+    aux = sqrtf(2.0F * m_2 * m_2 - m_4);
+    float denominator;
+    if (isnan(aux))
+        {
+            denominator = m_2 - Psig;
+            if (denominator == 0) return -100.0F;
+            SNR_aux = Psig / denominator;
+        }
+    else
+        {
+            denominator = m_2 - aux;
+            if (denominator == 0) return -100.0F;
+            SNR_aux = aux / denominator;
+        }
+    if (SNR_aux == 0) return -100.0F;
+    return 10.0F * log10f(SNR_aux) - 10.0F * log10f(coh_integration_time_s);
+}
+
+/* T/lock_detectors.cc:113-133 */
+float oracle_carrier_lock_detector(const float* prompt_iq, int length)
+{
+    float tmp_sum_I = 0.0F, tmp_sum_Q = 0.0F;
+    for (int i = 0; i < length; i++)
+        {
+            tmp_sum_I += prompt_iq[2 * i];
+            tmp_sum_Q += prompt_iq[2 * i + 1];
+        }
+    const float NBP = tmp_sum_I * tmp_sum_I + tmp_sum_Q * tmp_sum_Q;
+    const float NBD = tmp_sum_I * tmp_sum_I - tmp_sum_Q * tmp_sum_Q;
+    if (NBP == 0) return 0.0F;
+    return NBD / NBP;
+}
+
+/* Exponential_Smoother, T/exponential_smoother.cc:28-112.  The initialisation buffer is only ever summed front to back in
+ * float (std::accumulate with a 0.0F seed, :93), which a running float sum reproduces exactly. */
+void oracle_smoother_init(oracle_smoother* s, float alpha, int samples_for_initialization, float min_value, float offset)
+{
+    memset(s, 0, sizeof(*s));
+    s->alpha = alpha < 0 ? 0 : (alpha > 1 ? 1 : alpha);  /* set_alpha :28-40 */
+    s->one_minus_alpha = 1.0F - s->alpha;
+    s->samples_for_initialization = samples_for_initialization <= 0 ? 1 : samples_for_initialization;  /* :49-58 */
+    s->min_value = min_value;
+    s->offset = offset;
+    s->initializing = 1;
+}
+
+void oracle_smoother_reset(oracle_smoother* s)  /* :61-66 */
+{
+    s->initializing = 1;
+    s->init_counter = 0;
+    s->init_sum = 0.0F;
+}
+
+float oracle_smoother_smooth(oracle_smoother* s, float raw)  /* :83-112 */
+{
+    float smoothed;
+    if (s->initializing)
+        {
+            s->init_counter++;
+            smoothed = raw;
+            s->init_sum += smoothed;
+            if (s->init_counter == s->samples_for_initialization)
+                {
+                    s->old_value = s->init_sum / (float)s->init_counter;
+                    if (s->old_value < (s->min_value + s->offset))
+                        {
+                            s->init_counter = 0; /* flush buffer and start again */
+                            s->init_sum = 0.0F;
+                        }
+                    else
+                        {
+                            s->initializing = 0;
+                        }
+                }
+        }
+    else
+        {
+            smoothed = s->alpha * raw + s->one_minus_alpha * s->old_value;
+            s->old_value = smoothed;
+        }
+    return smoothed;
+}
+
+/* trk.cc:676-692 (buffers and smoothers as the constructor sets them) */
+void oracle_lock_init(oracle_lock_state* st, const oracle_trk_conf* c)
+{
+    memset(st, 0, sizeof(*st));
+    const double code_period = (double)c->code_length_chips / c->code_chip_rate;
+    int cn0_init = 200;  /* Exponential_Smoother default, T/exponential_smoother.h:66 */
+    if (code_period > 0.0) cn0_init = c->cn0_smoother_samples / (int)(code_period * 1000.0);  /* trk.cc:683-686 */
+    oracle_smoother_init(&st->cn0_smoother, c->cn0_smoother_alpha, cn0_init, 25.0F, 12.0F);  /* defaults of T/exponential_smoother.h:64-65 */
+    oracle_smoother_init(&st->carrier_lock_test_smoother, c->carrier_lock_test_smoother_alpha, c->carrier_lock_test_smoother_samples, -1.0F, 0.0F);  /* :688-692 */
+}
+
+/* cn0_and_tracking_lock_status, trk.cc:1167-1224 */
+int oracle_lock_status(oracle_lock_state* st, const oracle_trk_conf* c, float p_re, float p_im, double coh_integration_time_s, int pull_in_transitory)
+{
+    const int ns = c->cn0_samples;
+    if (st->cn0_estimation_counter < ns)
+        {
+            st->prompt_buffer[2 * st->cn0_estimation_counter] = p_re;  /* fill buffer with prompt correlator output values */
+            st->prompt_buffer[2 * st->cn0_estimation_counter + 1] = p_im;
+            st->cn0_estimation_counter++;
+            return 1;
+        }
+    st->prompt_buffer[2 * (st->cn0_estimation_counter % ns)] = p_re;
+    st->prompt_buffer[2 * (st->cn0_estimation_counter % ns) + 1] = p_im;
+    st->cn0_estimation_counter++;
+    const float cn0_raw = oracle_cn0_m2m4_estimator(st->prompt_buffer, ns, (float)coh_integration_time_s);
+    st->cn0_db_hz = oracle_smoother_smooth(&st->cn0_smoother, cn0_raw);
+    /* carrier_lock_detector(d_Prompt_buffer.data(), 1): length ONE -- only the buffer's first entry is looked at (trk.cc:1184).
+     * d_carrier_lock_test is a double: the double overload of smooth() narrows, smooths in float, widens (T/exponential_smoother.cc:75-80) */
+    st->carrier_lock_test = (double)oracle_smoother_smooth(&st->carrier_lock_test_smoother, (float)(double)oracle_carrier_lock_detector(st->prompt_buffer, 1));
+    if (!pull_in_transitory)
+        {
+            if (st->carrier_lock_test < c->carrier_lock_th)
+                st->carrier_lock_fail_counter++;
+            else if (st->carrier_lock_fail_counter > 0)
+                st->carrier_lock_fail_counter--;
+            if (st->cn0_db_hz < (float)c->cn0_min)
+                st->code_lock_fail_counter++;
+            else if (st->code_lock_fail_counter > 0)
+                st->code_lock_fail_counter--;
+        }
+    if (st->carrier_lock_fail_counter > c->max_carrier_lock_fail || st->code_lock_fail_counter > c->max_code_lock_fail)
+        {
+            st->carrier_lock_fail_counter = 0;
+            st->code_lock_fail_counter = 0;
+            return 0;
+        }
+    return 1;
+}
+
 /* ---- the closed loop of one channel -------------------------------------------------------------------------
  * trk.cc state 2 (:1975-2001) per code period: do_correlation_step (:1232-1257) -> accumulators (:1978-1985)
  * -> run_dll_pll (:1260-1347) -> update_tracking_vars (:1409-1483) -> consume d_current_prn_length_samples (:2287),
  * initial conditions of start_tracking (:796-866) and of the pull-in state (:1949-1964).
- * Not modelled (out of this row): bit / secondary-code synchronisation, extended integration, lock detectors,
+ * With enable_lock_detectors: cn0_and_tracking_lock_status (:1167-1224) between the correlation and run_dll_pll, as state 2
+ * orders them (:2008-2018); a loss of lock ends the channel (flags bit 1), the period's record carries the correlators only.
+ * Not modelled (out of this row): bit / secondary-code synchronisation, extended integration,
  * the experimental Doppler correction (:1326-1346), high_dyn smoothing (:1425-1443).
  */
 int oracle_trk_run(const oracle_trk_conf* c, const float* code, const float* data_code, int code_len, const float* stream_iq,
@@ -292,6 +446,13 @@ int oracle_trk_run(const oracle_trk_conf* c, const float* code, const float* dat
     float p_old_re = 0.0F, p_old_im = 0.0F;  /* d_P_accu_old */
     const double corr_time = code_period;    /* d_current_correlation_time_s, trk.cc:841 */
     uint64_t pos = start_sample;
+    oracle_lock_state lock;
+    int pull_in_latched = 1;  /* d_pull_in_transitory, cleared once (trk.cc:1910-1917) */
+    if (c->enable_lock_detectors)
+        {
+            if (c->cn0_samples < 1 || c->cn0_samples > ORACLE_MAX_CN0_SAMPLES) return -1;
+            oracle_lock_init(&lock, c);
+        }
 
     for (int e = 0; e < n_epochs; e++)
         {
@@ -318,6 +479,25 @@ int oracle_trk_run(const oracle_trk_conf* c, const float* code, const float* dat
             const float* P = out + 2 * prompt;
             const float* E = out + 2 * (prompt - 1);
             const float* L = out + 2 * (prompt + 1);
+            if (c->enable_lock_detectors)
+                {
+                    if (pull_in_latched && !pull_in)  /* trk.cc:1912-1916: leaving the pull-in transitory clears both fail counters */
+                        {
+                            pull_in_latched = 0;
+                            lock.carrier_lock_fail_counter = 0;
+                            lock.code_lock_fail_counter = 0;
+                        }
+                    const int locked = oracle_lock_status(&lock, c, P[0], P[1], code_period, pull_in);  /* trk.cc:2008 */
+                    r->cn0_db_hz = lock.cn0_db_hz;
+                    r->carrier_lock_test = lock.carrier_lock_test;
+                    if (!locked)  /* trk.cc:2009-2014: clear_tracking_vars, d_state = 0 */
+                        {
+                            r->sample_counter = pos;
+                            r->prn_length_samples = 0;
+                            r->flags = (pull_in ? 1 : 0) | 2;
+                            return e + 1;
+                        }
+                }
 
             /* run_dll_pll, trk.cc:1260-1324 */
             double carr_phase_error_hz, carr_freq_error_hz = 0.0;

@@ -17,6 +17,8 @@
 #include "tracking_FLL_PLL_filter.h"
 #include "tracking_discriminators.h"
 #include "tracking_loop_filter.h"
+#include "exponential_smoother.h"
+#include "lock_detectors.h"
 #include "galileo_e1_signal_replica.h"
 #include "gps_l5_signal_replica.h"
 #include "gps_sdr_signal_replica.h"
@@ -264,5 +266,25 @@ extern "C"
         f.set_params(fll_bw_hz, pll_bw_hz, order);
         f.initialize(acq_doppler_hz);
         for (int i = 0; i < n; i++) out[i] = f.get_carrier_error(fll_disc[i], pll_disc[i], correlation_time_s);
+    }
+
+    /* ---- lock detectors and smoother: the reference's own objects (T/lock_detectors.cc, T/exponential_smoother.cc) ---- */
+    float ref_cn0_m2m4_estimator(const float* prompt_iq, int length, float coh_integration_time_s)
+    {
+        return cn0_m2m4_estimator(reinterpret_cast<const gr_complex*>(prompt_iq), length, coh_integration_time_s);
+    }
+    float ref_carrier_lock_detector(const float* prompt_iq, int length)
+    {
+        return carrier_lock_detector(reinterpret_cast<const gr_complex*>(prompt_iq), length);
+    }
+    /* configure like trk.cc:680-692 (min_value / offset < -1e30 keep the class defaults), then smooth n values */
+    void ref_smoother_run(float alpha, int samples_for_initialization, float min_value, float offset, const float* raw, int n, float* out)
+    {
+        Exponential_Smoother s;
+        s.set_alpha(alpha);
+        if (min_value > -1e30F) s.set_min_value(min_value);
+        if (offset > -1e30F) s.set_offset(offset);
+        s.set_samples_for_initialization(samples_for_initialization);
+        for (int i = 0; i < n; i++) out[i] = s.smooth(raw[i]);
     }
 }

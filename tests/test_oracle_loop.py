@@ -120,3 +120,86 @@ def test_closed_loop_locks_onto_a_synthetic_signal():
         steps = np.diff([r.sample_counter for r in rec])
         assert set(np.unique(steps)) <= {3999, 4000, 4001}
         assert rec[0].flags == 1  # pull-in transitory: less than pull_in_time_s whole seconds since acquisition
+
+
+# ---- lock detectors and C/N0: the C restatement against the reference's own objects (oracle/_ref) ---------
+def _ref_or_skip():
+    R = oracle.ref()
+    if R is None or not hasattr(R, "ref_smoother_run"):
+        pytest.skip("oracle/_ref (reference build) not present")
+    return R
+
+
+def test_lock_detectors_equal_reference_objects():
+    """cn0_m2m4_estimator and carrier_lock_detector (T/lock_detectors.cc:61-133): bit equality with the reference's functions on
+    noisy prompts of several C/N0, on noise alone (the NaN branch of :92-100), on zeros, and for the length-1 call of trk.cc:1184."""
+    R = _ref_or_skip()
+    rng = np.random.default_rng(41)
+    for amp in (0.0, 0.3, 1.0, 5.0, 40.0, 1000.0):
+        for n in (1, 2, 20, 64):
+            p = (amp * rng.choice([-1.0, 1.0], n) + rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+            pf = np.ascontiguousarray(p).view(np.float32)
+            for t in (0.001, 0.004, 0.02):
+                a = oracle.cn0_m2m4_estimator(p, t)
+                b = float(R.ref_cn0_m2m4_estimator(pf, n, t))
+                assert (np.isnan(a) and np.isnan(b)) or a == b, (amp, n, t, a, b)
+            assert oracle.carrier_lock_detector(p) == float(R.ref_carrier_lock_detector(pf, n))
+            assert oracle.carrier_lock_detector(p, 1) == float(R.ref_carrier_lock_detector(pf, 1))
+    z = np.zeros(20, np.complex64)
+    assert oracle.cn0_m2m4_estimator(z, 0.001) == float(R.ref_cn0_m2m4_estimator(z.view(np.float32), 20, 0.001)) == -100.0
+    assert oracle.carrier_lock_detector(z) == 0.0
+    # a sanity anchor in physical units: 45 dB-Hz over 1 ms -> SNR per sample 10^(4.5) * 1e-3 = 31.6
+    amp = np.sqrt(10 ** 4.5 * 1e-3 * 2.0)
+    est = [oracle.cn0_m2m4_estimator((amp * rng.choice([-1.0, 1.0], 20) + rng.standard_normal(20) + 1j * rng.standard_normal(20)).astype(np.complex64), 0.001)
+           for _ in range(200)]
+    assert abs(np.mean(est) - 45.0) < 1.0
+
+
+def test_exponential_smoother_equals_reference_object():
+    """Exponential_Smoother (T/exponential_smoother.cc) as trk.cc:680-692 configures its two instances: initialisation by averaging,
+    the flush-and-restart when the average is below min_value + offset (:95-100), then the recursion -- bit equality."""
+    R = _ref_or_skip()
+    rng = np.random.default_rng(43)
+    for alpha, n_init, mn, off in ((0.002, 200, 25.0, 12.0), (0.002, 50, 25.0, 12.0), (0.002, 25, -1.0, 0.0), (0.5, 1, -1.0, 0.0), (1.5, 0, 25.0, 12.0)):
+        for base in (10.0, 36.9, 37.1, 45.0, 0.9):
+            raw = (base + rng.standard_normal(700)).astype(np.float32)
+            raw[300:340] -= 30.0  # a fade
+            exp = np.zeros_like(raw)
+            R.ref_smoother_run(alpha, n_init, mn, off, raw, len(raw), exp)
+            got = oracle.smoother_run(alpha, n_init, raw, mn, off)
+            assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), (alpha, n_init, mn, off, base)
+
+
+def test_oracle_loop_lock_detectors_declare_loss_on_noise_only():
+    """cn0_and_tracking_lock_status in the loop (trk.cc:1167-1224, 2008-2014): a channel with a signal reports its C/N0 and stays
+    locked; a channel correlating noise runs its code-lock fail counter past max_code_lock_fail once the pull-in transitory is
+    over and stops with flags bit 1 -- at the period the counter arithmetic predicts."""
+    fs, n = 2.046e6, 2046
+    epochs = 1200
+    x = synth_gps_l1_stream((epochs + 3) * n, fs, [4], [1500.0], [0.0], cn0_dbhz=47.0, seed_noise=5)
+    conf = oracle.trk_conf(fs_in=fs, vector_length=n, pll_bw_hz=25.0, dll_bw_hz=2.0, pull_in_time_s=0, enable_lock_detectors=1, max_code_lock_fail=50)
+    rec = oracle.trk_run(conf, oracle.ca_code(4), x, 0, 0, 1490.0, epochs)
+    assert len(rec) == epochs and not any(r.flags & 2 for r in rec)
+    tail = [r.cn0_db_hz for r in rec[-200:]]
+    assert abs(np.mean(tail) - 47.0) < 2.0, np.mean(tail)
+    lt = [r.carrier_lock_test for r in rec[-200:]]       # alpha = 0.002: still converging towards 1 after 1.2 s
+    assert np.mean(lt) > conf.carrier_lock_th and lt[-1] > lt[0]
+    assert all(r.cn0_db_hz == 0.0 for r in rec[:20]) and rec[20].cn0_db_hz != 0.0   # the first cn0_samples periods only fill the buffer
+    # noise only (PRN 9 is not in the stream).  The M2M4 estimate of pure noise hovers around 25-27 dB-Hz (its NaN branch,
+    # T/lock_detectors.cc:92-100, gives (E|I|)^2 / (m2 - (E|I|)^2) ~ 0.47 -> 26.7 dB-Hz at 1 ms), so the flag default cn0_min = 25 does
+    # not separate it; 32 dB-Hz does
+    conf.cn0_min = 32
+    rec = oracle.trk_run(conf, oracle.ca_code(9), x, 0, 0, -800.0, epochs)
+    assert rec[-1].flags & 2 and len(rec) < epochs
+    # pull-in ends at the first period whose start is at least (pull_in_time_s + 1) whole seconds after the acquisition stamp
+    first_free = next(i for i, r in enumerate(rec) if not (r.flags & 1))
+    assert rec[first_free].sample_counter >= int(fs) > rec[first_free - 1].sample_counter
+    # replay of the code-lock counter (trk.cc:1199-1209) from the recorded C/N0 values: up below cn0_min, down (not below 0) otherwise
+    cnt, lost_at = 0, None
+    for i in range(first_free, len(rec)):
+        cnt = cnt + 1 if rec[i].cn0_db_hz < conf.cn0_min else max(cnt - 1, 0)
+        if cnt > conf.max_code_lock_fail:
+            lost_at = i
+            break
+    assert lost_at == len(rec) - 1
+    assert rec[-1].prn_length_samples == 0

@@ -152,3 +152,56 @@ def test_loop_errors_and_stream_end(gpu):
     assert 9 <= done[0] <= 10 and len(rec[0]) == done[0]
     assert rec[0][-1].sample_counter + 4000 <= len(x)
     loop.close()
+
+
+def test_lock_detectors_and_cn0_on_device(gpu):
+    """cn0_and_tracking_lock_status (trk.cc:1167-1224) inside the device loop.  Channels with a signal report the
+    oracle loop's C/N0 and carrier-lock values and stay locked; a channel correlating noise is dropped (flags bit 1, channel
+    inactive afterwards) at the same period as in the oracle loop, give or take the periods where its noisy C/N0 estimate sits
+    within float rounding of cn0_min."""
+    fs, n, epochs = 2.046e6, 2046, 1150
+    kw = dict(fs_in=fs, vector_length=n, pll_bw_hz=25.0, dll_bw_hz=2.0, pull_in_time_s=0, enable_lock_detectors=1, cn0_min=32,
+              max_code_lock_fail=50)
+    prns, dops, cphs = [4, 12], [1500.0, -2200.0], [0.0, 511.5]
+    x = synth_gps_l1_stream((epochs + 3) * n, fs, prns, dops, cphs, cn0_dbhz=47.0, seed_noise=5)
+    loop = _loop(gpu, kw, n_channels=3, max_len=1023)
+    loop.set_stream_host(x)
+    conf_o = oracle.trk_conf(**kw)
+    starts = []
+    for ch, (prn, fd, cph) in enumerate(zip(prns, dops, cphs)):
+        f_code = 1.023e6 * (1 + fd / 1575.42e6)
+        start = int(round(((1023.0 - cph) % 1023.0) / f_code * fs))
+        starts.append(start)
+        loop.start(ch, oracle.ca_code(prn), start, 0, fd - 8.0)
+    loop.start(2, oracle.ca_code(9), 0, 0, -800.0)          # PRN 9 is not in the stream
+    rec, done = loop.run(epochs)
+    for ch, (prn, fd) in enumerate(zip(prns, dops)):
+        ora = oracle.trk_run(conf_o, oracle.ca_code(prn), x, starts[ch], 0, fd - 8.0, epochs)
+        assert done[ch] == len(ora) == epochs and not any(r.flags & 2 for r in rec[ch])
+        g_cn0 = np.array([r.cn0_db_hz for r in rec[ch]])
+        o_cn0 = np.array([r.cn0_db_hz for r in ora])
+        assert np.all(g_cn0[:20] == 0.0) and g_cn0[20] != 0.0
+        # the estimator sees the prompts of both loops, which agree to ~1e-4 of their magnitude: C/N0 within a few hundredths of a dB
+        assert np.max(np.abs(g_cn0 - o_cn0)) < 0.25, (ch, np.max(np.abs(g_cn0 - o_cn0)))
+        assert abs(np.mean(g_cn0[-200:]) - 47.0) < 2.0
+        g_lt = np.array([r.carrier_lock_test for r in rec[ch]])
+        o_lt = np.array([r.carrier_lock_test for r in ora])
+        assert np.max(np.abs(g_lt - o_lt)) < 2e-2
+        assert np.mean(g_lt[-200:]) > 0.7
+    ora = oracle.trk_run(conf_o, oracle.ca_code(9), x, 0, 0, -800.0, epochs)
+    assert ora[-1].flags & 2 and len(ora) < epochs
+    assert done[2] < epochs and rec[2][-1].flags & 2 and rec[2][-1].prn_length_samples == 0
+    assert abs(done[2] - len(ora)) <= 12, (done[2], len(ora))
+    # the counter arithmetic, replayed from the device's own C/N0 record, predicts the device's own loss period exactly
+    first_free = next(i for i, r in enumerate(rec[2]) if not (r.flags & 1))
+    cnt, lost_at = 0, None
+    for i in range(first_free, len(rec[2])):
+        cnt = cnt + 1 if rec[2][i].cn0_db_hz < kw["cn0_min"] else max(cnt - 1, 0)
+        if cnt > kw["max_code_lock_fail"]:
+            lost_at = i
+            break
+    assert lost_at == len(rec[2]) - 1
+    # a dropped channel stays dropped; the others continue
+    rec2, done2 = loop.run(2)
+    assert done2[2] == 0 and done2[0] == 2 and done2[1] == 2
+    loop.close()
