@@ -273,13 +273,19 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP engine has no CPU fallback)")
+    if os.environ.get("GSH_BENCH_SHARE_GPU") == "1":
+        local = 0  # self-test of the N > 1 code path on a one-GPU box (with GSH_BENCH_BACKEND=gloo): every rank uses GPU 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("GSH_BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm; gloo only for the one-GPU self-test
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     fs, n, C, E, T = a.fs, int(round(a.fs * 1e-3)), a.channels, a.epochs, a.taps
     n_samples = (E + 2) * n
