@@ -34,6 +34,9 @@ class SampleStream:
         """Append samples held in host memory (complex64 [n], or int16 / int8 [n, 2] interleaved I,Q).  Returns the absolute
         index of the first one."""
         t = ITEM_TYPES[item_type]
+        items = np.asarray(items)
+        if t == GSH_ITEM_GR_COMPLEX and not np.iscomplexobj(items):
+            items = np.ascontiguousarray(items, np.float32).reshape(-1).view(np.complex64)   # interleaved float32 I,Q as read from a file
         a = np.ascontiguousarray(items, _NP[t])
         n = a.size if t == GSH_ITEM_GR_COMPLEX else a.size // 2
         first = C.c_uint64(0)
