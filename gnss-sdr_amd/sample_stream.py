@@ -63,3 +63,12 @@ class SampleStream:
 def convert_samples_device(device: int, src_ptr: int, item_type: str, dst_ptr: int, n: int, inverted_spectrum: bool = False, hip_stream: int = 0) -> None:
     check(_lib.load().gsh_convert_samples_device(device, C.c_void_p(src_ptr), ITEM_TYPES[item_type], int(inverted_spectrum), C.c_void_p(dst_ptr), n,
                                                  C.c_void_p(hip_stream) if hip_stream else None))
+
+
+def direct_resample_device(device: int, src_ptr: int, in0: int, n_in: int, fs_in: float, fs_out: float, out0: int, dst_ptr: int, max_out: int,
+                           hip_stream: int = 0):
+    """direct_resampler_conditioner_cc on the device (gsh_direct_resample_device).  -> (n_out, n_in_consumed)"""
+    n_out, n_cons = C.c_uint64(0), C.c_uint64(0)
+    check(_lib.load().gsh_direct_resample_device(device, C.c_void_p(src_ptr), in0, n_in, fs_in, fs_out, out0, C.c_void_p(dst_ptr), max_out,
+                                                 C.byref(n_out), C.byref(n_cons), C.c_void_p(hip_stream) if hip_stream else None))
+    return int(n_out.value), int(n_cons.value)

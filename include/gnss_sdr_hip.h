@@ -167,6 +167,15 @@ extern "C"
     /* stand-alone conversion of n device-resident items to complex64 (device_dst 8-byte aligned), asynchronous on hip_stream */
     int gsh_convert_samples_device(int device, const void* device_items, int item_type, int inverted_spectrum, void* device_dst, uint64_t n,
         void* hip_stream);
+    /* Direct (nearest-neighbour) resampler, the arithmetic of direct_resampler_conditioner_cc (src/algorithms/resampler/gnuradio_blocks/
+     * direct_resampler_conditioner_cc.cc:39-129; used by the signal conditioner and the acquisition decimator, gnss_flowgraph.cc:1165-1209):
+     * 32-bit phase accumulator, a sample is copied on every wrap.  Stateless form: outputs are numbered from the start of the stream,
+     * output j reads input ceil(j 2^32 / phase_step) (decimation) or floor((j + 1) phase_step / 2^32) (interpolation) -- what the reference's
+     * loop produces, however the stream is cut into blocks.  device_src[0] is absolute input sample in0 (n_in samples, complex64), device_dst[0]
+     * receives absolute output out0; *n_out = how many outputs this block feeds (<= max_out), *n_in_consumed (may be NULL) = input samples the
+     * reference block would have consumed by then.  Asynchronous on hip_stream. */
+    int gsh_direct_resample_device(int device, const void* device_src, uint64_t in0, uint64_t n_in, double fs_in, double fs_out, uint64_t out0,
+        void* device_dst, uint64_t max_out, uint64_t* n_out, uint64_t* n_in_consumed, void* hip_stream);
     /* bind a bank to a ring: from now on gsh_corr_job.sample_offset is an ABSOLUTE sample index; a job whose window is not
      * fully resident (or longer than max_window_samples) fails with GSH_ERR_INVALID.  NULL detaches. */
     int gsh_bank_set_stream_ring(gsh_bank_t* b, gsh_stream_t* s);

@@ -269,6 +269,42 @@ def fll_pll_filter_run(fll_bw_hz, pll_bw_hz, order, acq_doppler_hz, fll_disc, pl
                      for a, b in zip(np.asarray(fll_disc, np.float32), np.asarray(pll_disc, np.float32))], np.float32)
 
 
+class Resampler(C.Structure):
+    """oracle_resampler"""
+    _fields_ = [("fs_in", C.c_double), ("fs_out", C.c_double), ("phase", C.c_uint32), ("lphase", C.c_uint32), ("phase_step", C.c_uint32)]
+
+
+def direct_resampler(x: np.ndarray, fs_in: float, fs_out: float, call_sizes=None) -> np.ndarray:
+    """direct_resampler_conditioner_cc run over the whole of x as a sequence of general_work calls asking for call_sizes outputs each
+    (default: one call).  Returns the concatenated output."""
+    L = lib()
+    L.oracle_direct_resampler_init.argtypes = [C.c_void_p, C.c_double, C.c_double]
+    L.oracle_direct_resampler_init.restype = None
+    L.oracle_direct_resampler_work.argtypes = [C.c_void_p, _f32p, C.c_int, _f32p, C.c_int, C.POINTER(C.c_int)]
+    L.oracle_direct_resampler_work.restype = C.c_int
+    r = Resampler()
+    L.oracle_direct_resampler_init(C.byref(r), fs_in, fs_out)
+    xi = _iq(x).reshape(-1)
+    cap = int(len(x) * max(1.0, fs_out / fs_in)) + 8
+    sizes = list(call_sizes) if call_sizes is not None else [cap]
+    outs, pos, k = [], 0, 0
+    while pos < len(x):
+        want = sizes[k % len(sizes)]
+        k += 1
+        buf = np.zeros(2 * want, np.float32)
+        cons = C.c_int(0)
+        rest = np.ascontiguousarray(xi[2 * pos:])
+        n = L.oracle_direct_resampler_work(C.byref(r), rest, len(x) - pos, buf, want, C.byref(cons))
+        outs.append(buf[:2 * n].copy())
+        if n == 0 and cons.value == 0:
+            break
+        pos += cons.value
+        if fs_in < fs_out and n < want:
+            break
+    out = np.concatenate(outs) if outs else np.zeros(0, np.float32)
+    return out.view(np.complex64)
+
+
 class Smoother(C.Structure):
     """oracle_smoother"""
     _fields_ = [(k, C.c_float) for k in ("alpha", "one_minus_alpha", "old_value", "min_value", "offset", "init_sum")] + [

@@ -102,6 +102,18 @@ extern "C"
     void oracle_fll_pll_initialize(oracle_fll_pll_filter* f, float acq_carrier_doppler_hz);
     float oracle_fll_pll_carrier_error(oracle_fll_pll_filter* f, float fll_disc, float pll_disc, float correlation_time_s);
 
+    /* ---- direct resampler: direct_resampler_conditioner_cc.cc:39-129, the block's own stateful loop ---- */
+    typedef struct oracle_direct_resampler_s
+    {
+        double fs_in, fs_out;
+        uint32_t phase, lphase, phase_step;
+    } oracle_direct_resampler_t;
+    void oracle_direct_resampler_init(oracle_direct_resampler_t* r, double fs_in, double fs_out);
+    /* one general_work call: produce up to noutput_items from `in` (n_in complex samples available); returns the number produced, *consumed
+     * = min(count, n_in) as the block's consume_each (:127).  Like the block, it reads in[] as far as it needs to: the caller sizes n_in by
+     * forecast (:64-69). */
+    int oracle_direct_resampler_work(oracle_direct_resampler_t* r, const float* in_iq, int n_in, float* out_iq, int noutput_items, int* consumed);
+
     /* ---- lock detectors and C/N0: T/lock_detectors.cc, T/exponential_smoother.cc, trk.cc:1167-1224 ---- */
     float oracle_cn0_m2m4_estimator(const float* prompt_iq, int length, float coh_integration_time_s); /* T/lock_detectors.cc:61-110 */
     float oracle_carrier_lock_detector(const float* prompt_iq, int length);                             /* T/lock_detectors.cc:113-133 */

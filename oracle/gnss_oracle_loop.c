@@ -246,6 +246,65 @@ float oracle_fll_pll_carrier_error(oracle_fll_pll_filter* f, float fll_disc, flo
     return out;
 }
 
+/* ---- direct resampler: direct_resampler_conditioner_cc.cc, statement by statement ---------------------------- */
+void oracle_direct_resampler_init(oracle_direct_resampler_t* r, double fs_in, double fs_out)  /* :39-61 */
+{
+    const double two_32 = 4294967296.0;
+    r->fs_in = fs_in;
+    r->fs_out = fs_out;
+    r->phase = 0;
+    r->lphase = 0;
+    double v;
+    if (fs_in >= fs_out)
+        v = floor(two_32 * fs_out / fs_in);
+    else
+        v = floor(two_32 * fs_in / fs_out);
+    r->phase_step = v >= two_32 ? 0u : (uint32_t)v; /* a ratio of one does not fit the uint32 cast: 0 = every sample passes */
+}
+
+int oracle_direct_resampler_work(oracle_direct_resampler_t* r, const float* in_iq, int n_in, float* out_iq, int noutput_items, int* consumed)  /* :72-129 */
+{
+    int lcv = 0, count = 0;
+    const float* in = in_iq;
+    if (r->fs_in >= r->fs_out)
+        {
+            while (lcv < noutput_items && count < n_in)   /* (the block trusts forecast; the bound keeps the checker inside its buffer) */
+                {
+                    if (r->phase <= r->lphase)
+                        {
+                            out_iq[2 * lcv] = in[0];
+                            out_iq[2 * lcv + 1] = in[1];
+                            lcv++;
+                        }
+                    r->lphase = r->phase;
+                    r->phase += r->phase_step;
+                    in += 2;
+                    count++;
+                }
+        }
+    else
+        {
+            while (lcv < noutput_items)
+                {
+                    const uint32_t lph = r->phase;
+                    const uint32_t ph = r->phase + r->phase_step;
+                    if (ph <= lph && count + 1 >= n_in) break; /* the next sample is not in this buffer yet */
+                    r->lphase = lph;
+                    r->phase = ph;
+                    if (r->phase <= r->lphase)
+                        {
+                            in += 2;
+                            count++;
+                        }
+                    out_iq[2 * lcv] = in[0];
+                    out_iq[2 * lcv + 1] = in[1];
+                    lcv++;
+                }
+        }
+    *consumed = count < n_in ? count : n_in;
+    return lcv;
+}
+
 /* ---- lock detectors and C/N0 ---------------------------------------------------------------------------------
  * T/lock_detectors.cc:61-110: second / fourth moment estimator, everything float32, sequential sums */
 float oracle_cn0_m2m4_estimator(const float* prompt_iq, int length, float coh_integration_time_s)
