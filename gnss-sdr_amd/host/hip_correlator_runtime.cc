@@ -5,6 +5,7 @@
 #include "hip_correlator_runtime.h"
 #include <algorithm>
 #include <cstring>
+#include <thread>
 
 // ------------------------------------------------------------------------------------------------ Hip_Sample_Ring
 Hip_Sample_Ring::Hip_Sample_Ring(int device, uint64_t capacity_samples, uint32_t max_window_samples) : d_device(device)
@@ -77,9 +78,10 @@ bool Hip_Sample_Ring::wait_for(uint64_t end, std::chrono::milliseconds timeout) 
 
 
 // ------------------------------------------------------------------------------------------------ Hip_Correlator_Runtime
-Hip_Correlator_Runtime::Hip_Correlator_Runtime(Hip_Sample_Ring* ring, int max_channels, int max_code_length, std::chrono::microseconds max_wait)
+Hip_Correlator_Runtime::Hip_Correlator_Runtime(Hip_Sample_Ring* ring, int max_channels, int max_code_length, std::chrono::microseconds max_wait, int spin_us)
     : d_ring(ring), d_max_wait(max_wait), d_current(std::make_shared<Batch>())
 {
+    d_spin_us = spin_us >= 0 ? spin_us : (static_cast<int>(std::thread::hardware_concurrency()) >= 2 * max_channels ? 150 : 0);
     if (ring == nullptr || !ring->ok())
         {
             d_error = "no sample ring";
@@ -142,87 +144,132 @@ bool Hip_Correlator_Runtime::set_code(int channel, const float* code, int code_l
 }
 
 
+// launch one closed batch and publish its results (called by exactly one thread per batch, without d_mutex)
+void Hip_Correlator_Runtime::run_batch(const std::shared_ptr<Batch>& b, bool timed_out)
+{
+    const int n = static_cast<int>(b->jobs.size());
+    b->out.assign(static_cast<size_t>(n) * GSH_MAX_TAPS * 2, 0.0F);
+    int rc = GSH_OK;
+    std::string err;
+    {
+        std::lock_guard<std::mutex> bl(d_bank_mutex);
+        // pushes must not move the ring's residency window between the job translation and the launch
+        std::lock_guard<std::mutex> rl(d_ring->d_mutex);
+        // one launch per correlator flavour present in the batch (a launch shares one kernel specialisation; channels in
+        // high-dynamics mode, trk.cc:675, are batched separately from the standard ones)
+        bool uniform = true;
+        for (int i = 1; i < n; i++) uniform = uniform && (b->jobs[i].high_dyn == b->jobs[0].high_dyn);
+        if (uniform)
+            {
+                rc = gsh_bank_correlate(d_bank, b->jobs.data(), n, b->out.data());
+            }
+        else
+            {
+                std::vector<gsh_corr_job> part;
+                std::vector<int> where;
+                std::vector<float> part_out;
+                for (int mode = 0; mode <= 2 && rc == GSH_OK; mode++)
+                    {
+                        part.clear();
+                        where.clear();
+                        for (int i = 0; i < n; i++)
+                            if (b->jobs[i].high_dyn == mode)
+                                {
+                                    part.push_back(b->jobs[i]);
+                                    where.push_back(i);
+                                }
+                        if (part.empty()) continue;
+                        part_out.assign(part.size() * GSH_MAX_TAPS * 2, 0.0F);
+                        rc = gsh_bank_correlate(d_bank, part.data(), static_cast<int>(part.size()), part_out.data());
+                        for (size_t k = 0; k < where.size() && rc == GSH_OK; k++)
+                            std::memcpy(&b->out[static_cast<size_t>(where[k]) * GSH_MAX_TAPS * 2], &part_out[k * GSH_MAX_TAPS * 2], sizeof(float) * GSH_MAX_TAPS * 2);
+                    }
+            }
+        if (rc != GSH_OK) err = gsh_last_error();
+    }
+    {
+        std::lock_guard<std::mutex> lk(d_mutex);
+        d_stats.batches++;
+        d_stats.jobs += static_cast<uint64_t>(n);
+        d_stats.timeouts += timed_out ? 1u : 0u;
+        d_stats.largest_batch = std::max<uint32_t>(d_stats.largest_batch, static_cast<uint32_t>(n));
+    }
+    b->status = rc;
+    b->error = err;
+    {
+        std::lock_guard<std::mutex> bl(b->m);
+        b->done.store(1, std::memory_order_release);
+    }
+    b->done_cv.notify_all();
+}
+
+
 bool Hip_Correlator_Runtime::correlate(int channel, const gsh_corr_job& job_in, std::complex<float>* out)
 {
     if (d_bank == nullptr || out == nullptr) return false;
-    std::unique_lock<std::mutex> lk(d_mutex);
-    std::shared_ptr<Batch> b = d_current;
-    const size_t idx = b->jobs.size();
-    b->jobs.push_back(job_in);
-    b->jobs.back().code_slot = channel;
-    if (idx == 0)
-        {
-            // batch leader: wait for the other channels that are tracking right now, bounded by max_wait
-            const auto deadline = std::chrono::steady_clock::now() + d_max_wait;
-            bool timed_out = false;
-            while (static_cast<int>(b->jobs.size()) < d_active)
-                {
-                    if (d_arrived.wait_until(lk, deadline) == std::cv_status::timeout)
-                        {
-                            timed_out = static_cast<int>(b->jobs.size()) < d_active;
-                            break;
-                        }
-                }
-            d_current = std::make_shared<Batch>();  // later arrivals start the next batch (with their own leader)
-            const int n = static_cast<int>(b->jobs.size());
-            d_stats.batches++;
-            d_stats.jobs += static_cast<uint64_t>(n);
-            d_stats.timeouts += timed_out ? 1u : 0u;
-            d_stats.largest_batch = std::max<uint32_t>(d_stats.largest_batch, static_cast<uint32_t>(n));
-            lk.unlock();
-            b->out.assign(static_cast<size_t>(n) * GSH_MAX_TAPS * 2, 0.0F);
-            int rc;
-            std::string err;
+    std::shared_ptr<Batch> b;
+    size_t idx;
+    bool close_now = false, first = false;
+    {
+        std::unique_lock<std::mutex> lk(d_mutex);
+        b = d_current;
+        idx = b->jobs.size();
+        b->jobs.push_back(job_in);
+        b->jobs.back().code_slot = channel;
+        first = (idx == 0);
+        if (static_cast<int>(b->jobs.size()) >= d_active)
             {
-                std::lock_guard<std::mutex> bl(d_bank_mutex);
-                // pushes must not move the ring's residency window between the job translation and the launch
-                std::lock_guard<std::mutex> rl(d_ring->d_mutex);
-                // one launch per correlator flavour present in the batch (a launch shares one kernel specialisation; channels in
-                // high-dynamics mode, trk.cc:675, are batched separately from the standard ones)
-                rc = GSH_OK;
-                bool uniform = true;
-                for (int i = 1; i < n; i++) uniform = uniform && (b->jobs[i].high_dyn == b->jobs[0].high_dyn);
-                if (uniform)
-                    {
-                        rc = gsh_bank_correlate(d_bank, b->jobs.data(), n, b->out.data());
-                    }
-                else
-                    {
-                        std::vector<gsh_corr_job> part;
-                        std::vector<int> where;
-                        std::vector<float> part_out;
-                        for (int mode = 0; mode <= 2 && rc == GSH_OK; mode++)
-                            {
-                                part.clear();
-                                where.clear();
-                                for (int i = 0; i < n; i++)
-                                    if (b->jobs[i].high_dyn == mode)
-                                        {
-                                            part.push_back(b->jobs[i]);
-                                            where.push_back(i);
-                                        }
-                                if (part.empty()) continue;
-                                part_out.assign(part.size() * GSH_MAX_TAPS * 2, 0.0F);
-                                rc = gsh_bank_correlate(d_bank, part.data(), static_cast<int>(part.size()), part_out.data());
-                                for (size_t k = 0; k < where.size() && rc == GSH_OK; k++)
-                                    std::memcpy(&b->out[static_cast<size_t>(where[k]) * GSH_MAX_TAPS * 2], &part_out[k * GSH_MAX_TAPS * 2], sizeof(float) * GSH_MAX_TAPS * 2);
-                            }
-                    }
-                if (rc != GSH_OK) err = gsh_last_error();
+                // this arrival completes the batch: close it and launch from this very thread
+                b->taken = true;
+                d_current = std::make_shared<Batch>();  // later arrivals start the next batch
+                close_now = true;
             }
-            lk.lock();
-            b->status = rc;
-            b->error = err;
-            b->done = true;
-            b->done_cv.notify_all();
-        }
-    else
+        else if (first)
+            {
+                // first arriver: bounded wait for the channels that are tracking right now; whoever completes the batch takes it,
+                // otherwise this thread closes it with what has arrived
+                const auto deadline = std::chrono::steady_clock::now() + d_max_wait;
+                while (!b->taken && static_cast<int>(b->jobs.size()) < d_active)
+                    {
+                        if (d_arrived.wait_until(lk, deadline) == std::cv_status::timeout) break;
+                    }
+                if (!b->taken)
+                    {
+                        b->taken = true;
+                        if (d_current == b) d_current = std::make_shared<Batch>();
+                        close_now = true;
+                        lk.unlock();
+                        run_batch(b, static_cast<int>(b->jobs.size()) < d_active);
+                        close_now = false;  // already run
+                    }
+            }
+    }
+    if (close_now)
         {
-            d_arrived.notify_all();
-            b->done_cv.wait(lk, [&] { return b->done; });
+            d_arrived.notify_all();  // the first arriver (if it is not this thread) stops its timed wait
+            run_batch(b, false);
+        }
+    // wait for the batch's results: poll the flag for a short while (the launch is tens of microseconds), then block
+    if (b->done.load(std::memory_order_acquire) == 0 && d_spin_us > 0)
+        {
+            const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(d_spin_us);
+            while (b->done.load(std::memory_order_acquire) == 0 && std::chrono::steady_clock::now() < until)
+                {
+#if defined(__x86_64__) || defined(__i386__)
+                    __builtin_ia32_pause();
+#else
+                    std::this_thread::yield();
+#endif
+                }
+        }
+    if (b->done.load(std::memory_order_acquire) == 0)
+        {
+            std::unique_lock<std::mutex> bl(b->m);
+            b->done_cv.wait(bl, [&] { return b->done.load(std::memory_order_acquire) != 0; });
         }
     if (b->status != GSH_OK)
         {
+            std::lock_guard<std::mutex> lk(d_mutex);
             d_error = b->error;
             return false;
         }

@@ -11,10 +11,11 @@
  *    next to the signal conditioner), converted there from the front-end's item type (data_type_adapter arithmetic), and
  *    addressed by absolute sample index -- the same counter the tracking block already keeps (d_sample_counter,
  *    dll_pll_veml_tracking.cc:1963-1978, 2287).
- *  - Hip_Correlator_Runtime: the channel threads rendezvous; the first to arrive becomes the batch leader, waits until the
- *    channels that are currently tracking have all arrived (or a bounded time), and issues ONE gsh_bank_correlate for the
- *    whole batch; every caller returns with its own taps.  Callers block exactly as they do inside the reference's
- *    synchronous correlator call.
+ *  - Hip_Correlator_Runtime: the channel threads rendezvous; the thread whose arrival completes the batch (every channel that is
+ *    currently tracking has a job in it) issues ONE gsh_bank_correlate for the whole batch on the spot -- no wake-up sits on the
+ *    critical path -- and the first arriver closes it after a bounded wait if a channel is late; every caller returns with its
+ *    own taps.  Waiters spin briefly on the batch's completion flag before they block (the launch takes tens of microseconds, a
+ *    futex sleep + wake costs as much).  Callers block exactly as they do inside the reference's synchronous correlator call.
  *  - Hip_Multicorrelator_Batched: the eight methods of Cpu_Multicorrelator_Real_Codes (cpu_multicorrelator_real_codes.h:40-49)
  *    on top of the runtime, plus set_input_sample_index(): the window is named by its absolute index instead of a host pointer.
  *
@@ -24,6 +25,7 @@
 #define GNSS_SDR_HIP_CORRELATOR_RUNTIME_H
 
 #include "gnss_sdr_hip.h"
+#include <atomic>
 #include <chrono>
 #include <complex>
 #include <condition_variable>
@@ -78,9 +80,11 @@ public:
         uint32_t largest_batch{0};
     };
 
-    /*! max_wait: how long a batch leader waits for the other active channels before launching with what it has */
+    /*! max_wait: how long the first arriver of a batch waits for the other active channels before launching with what it has.
+        spin_us: how long a waiter polls the completion flag before blocking; -1 = automatic (150 us when the host has at least
+        twice as many hardware threads as max_channels, else 0: spinning on an oversubscribed host only steals the launcher's core) */
     Hip_Correlator_Runtime(Hip_Sample_Ring* ring, int max_channels, int max_code_length,
-        std::chrono::microseconds max_wait = std::chrono::microseconds(200));
+        std::chrono::microseconds max_wait = std::chrono::microseconds(200), int spin_us = -1);
     ~Hip_Correlator_Runtime();
     Hip_Correlator_Runtime(const Hip_Correlator_Runtime&) = delete;
     Hip_Correlator_Runtime& operator=(const Hip_Correlator_Runtime&) = delete;
@@ -103,15 +107,19 @@ private:
     {
         std::vector<gsh_corr_job> jobs;
         std::vector<float> out;  // n_jobs * GSH_MAX_TAPS * 2
+        std::mutex m;            // guards done_cv only: the next batch's arrivals never contend with this batch's wake-ups
         std::condition_variable done_cv;
-        bool done{false};
+        std::atomic<int> done{0};
+        bool taken{false};       // a closer has claimed it (under d_mutex)
         int status{0};
         std::string error;
     };
+    void run_batch(const std::shared_ptr<Batch>& b, bool timed_out);
     Hip_Sample_Ring* d_ring;
     gsh_bank_t* d_bank{nullptr};
     std::string d_error;
     std::chrono::microseconds d_max_wait;
+    int d_spin_us{0};
     mutable std::mutex d_mutex;
     std::condition_variable d_arrived;
     std::shared_ptr<Batch> d_current;
