@@ -430,6 +430,8 @@ def main():
                 res["acquisition"] = {"error": str(e)}
             try:
                 res["closed_loop"] = closed_loop_metric(local, x, n_samples, fs, n, dop, cph, channels=C, epochs=min(E - 2, 200))
+                # one compute unit per channel: 32 channels use an eighth of the chip, 256 (BASELINE config 5's channel count) fill it
+                res["closed_loop_256ch"] = closed_loop_metric(local, x, n_samples, fs, n, dop, cph, channels=256, epochs=min(E - 2, 200))
             except Exception as e:
                 res["closed_loop"] = {"error": str(e)}
         print(json.dumps(res))
