@@ -150,6 +150,7 @@ SYMBOLS = {
     "gsh_trk_destroy": (None, [_P]),
     "gsh_trk_set_stream_host": (C.c_int, [_P, _F, C.c_uint64]),
     "gsh_trk_set_stream_device": (C.c_int, [_P, _P, C.c_uint64]),
+    "gsh_trk_set_stream_ring": (C.c_int, [_P, _P]),
     "gsh_trk_start": (C.c_int, [_P, C.c_int, _F, _F, C.c_int, C.c_uint64, C.c_uint64, C.c_double]),
     "gsh_trk_run": (C.c_int, [_P, C.c_int, C.POINTER(TrkEpoch), C.POINTER(C.c_int32)]),
     "gsh_trk_time_run": (C.c_int, [_P, C.c_int, C.c_int, _F]),

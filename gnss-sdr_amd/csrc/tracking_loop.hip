@@ -19,6 +19,7 @@
 // with 256 threads)
 #define GSH_MC_THREADS 1024
 #include "mcorr_device.h"
+#include "sample_stream.h"
 #include <cmath>
 #include <new>
 #include <vector>
@@ -77,7 +78,9 @@ struct TrkArgs
 {
     gsh_trk_conf conf;
     const float2* stream;
-    unsigned long long n_stream;
+    unsigned long long n_stream;       // flat buffer: its length; ring: absolute index one past the newest resident sample
+    unsigned long long ring_capacity;  // 0: flat buffer; else absolute sample i lives at stream[i % ring_capacity] (windows are contiguous: mirror)
+    unsigned long long ring_oldest;    // ring: absolute index of the oldest resident sample
     const float* codes;       // n_channels * 2 * code_stride (pilot/primary code, then data code)
     int code_stride;
     TrkChannel* chan;
@@ -279,7 +282,8 @@ struct NextWindow  // what thread 0 publishes for the next correlation (do_corre
     int go;
 };
 
-__device__ __forceinline__ void publish(NextWindow& w, const TrkChannel& s, const gsh_trk_conf& c, unsigned long long n_stream, int more)
+__device__ __forceinline__ void publish(NextWindow& w, const TrkChannel& s, const gsh_trk_conf& c, unsigned long long n_stream, int more,
+    unsigned long long ring_oldest = 0ull)
 {
     const float spcf = static_cast<float>(c.code_samples_per_chip);
     w.pos = s.pos;
@@ -287,7 +291,7 @@ __device__ __forceinline__ void publish(NextWindow& w, const TrkChannel& s, cons
     w.phase_step = static_cast<float>(s.carrier_phase_step_rad);
     w.rem_code = __fmul_rn(static_cast<float>(s.rem_code_phase_chips), spcf);
     w.code_step = __fmul_rn(static_cast<float>(s.code_phase_step_chips), spcf);
-    w.go = (more && s.active && s.pos + c.vector_length <= n_stream) ? 1 : 0;
+    w.go = (more && s.active && s.pos + c.vector_length <= n_stream && s.pos >= ring_oldest) ? 1 : 0;
 }
 
 template <int NT>
@@ -332,7 +336,7 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
     constexpr int PROMPT = NT / 2;
     const double corr_time = static_cast<double>(c.code_length_chips) / c.code_chip_rate;  // d_current_correlation_time_s = d_code_period, trk.cc:841
 
-    if (tid == 0) publish(win, s, c, a.n_stream, a.n_epochs > 0);
+    if (tid == 0) publish(win, s, c, a.n_stream, a.n_epochs > 0, a.ring_oldest);
     __syncthreads();
 
     int done = 0;
@@ -340,8 +344,9 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
         {
             if (!win.go) break;  // uniform: win is only rewritten between the barriers below
             const unsigned long long pos = win.pos;
+            const unsigned long long wpos = a.ring_capacity ? pos % a.ring_capacity : pos;  // where the window sits in memory
             const float rem_carr = win.rem_carr, phase_step = win.phase_step, rem_code = win.rem_code, code_step = win.code_step;
-            correlate_window_std<NT>(a.stream, pos, static_cast<int>(c.vector_length), tab, code_len, sh, rem_carr, phase_step, rem_code, code_step, red);
+            correlate_window_std<NT>(a.stream, wpos, static_cast<int>(c.vector_length), tab, code_len, sh, rem_carr, phase_step, rem_code, code_step, red);
             float2 out[NT];
 #pragma unroll
             for (int t = 0; t < NT; t++) out[t] = red[t];
@@ -349,7 +354,7 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
             if (c.track_pilot)
                 {
                     __syncthreads();  // everyone has read red[0..NT) before it is reused
-                    correlate_window_std<1>(a.stream, pos, static_cast<int>(c.vector_length), tab_data, code_len, sh_data, rem_carr, phase_step, rem_code, code_step, red);
+                    correlate_window_std<1>(a.stream, wpos, static_cast<int>(c.vector_length), tab_data, code_len, sh_data, rem_carr, phase_step, rem_code, code_step, red);
                     pdata = red[0];
                 }
             __syncthreads();  // win and red have been read by everyone
@@ -472,7 +477,7 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
                             a.records[static_cast<size_t>(ch) * a.n_epochs + e] = r;
                         }
                     s.pos = pos + static_cast<unsigned long long>(prn_len);  // consume_each, trk.cc:2287
-                    publish(win, s, c, a.n_stream, e + 1 < a.n_epochs);
+                    publish(win, s, c, a.n_stream, e + 1 < a.n_epochs, a.ring_oldest);
                         }
                 }
             done = e + 1;
@@ -611,6 +616,7 @@ struct gsh_trk
     size_t stream_owned_cap{0};
     const float2* d_stream{nullptr};
     unsigned long long n_stream{0};
+    gsh_stream* ring{nullptr};  // when set, the loop follows the live ring: positions are absolute sample indices
     gsh_trk_epoch* d_records{nullptr};
     size_t records_cap{0};
     int* d_done{nullptr};
@@ -633,6 +639,16 @@ int trk_launch(gsh_trk* t, int n_epochs, gsh_trk_epoch* d_records)
     a.conf = t->conf;
     a.stream = t->d_stream;
     a.n_stream = t->n_stream;
+    a.ring_capacity = 0;
+    a.ring_oldest = 0;
+    if (t->ring != nullptr)
+        {
+            a.stream = t->ring->d_ring;
+            a.n_stream = t->ring->next;
+            a.ring_capacity = t->ring->capacity;
+            a.ring_oldest = gsh::stream_oldest(t->ring);
+            GSH_HIP(hipStreamWaitEvent(t->stream, t->ring->pushed, 0));  // conversions queued by gsh_stream_push_device
+        }
     a.codes = t->d_codes;
     a.code_stride = t->max_code_len;
     a.chan = t->d_chan;
@@ -745,6 +761,7 @@ extern "C"
         GSH_HIP(hipStreamSynchronize(t->stream));
         t->d_stream = t->d_stream_owned;
         t->n_stream = n_samples;
+        t->ring = nullptr;
         return GSH_OK;
     }
 
@@ -754,6 +771,27 @@ extern "C"
         GSH_REQUIRE((reinterpret_cast<uintptr_t>(device_iq) & 15u) == 0, "device stream must be 16-byte aligned");
         t->d_stream = static_cast<const float2*>(device_iq);
         t->n_stream = n_samples;
+        t->ring = nullptr;
+        return GSH_OK;
+    }
+
+    int gsh_trk_set_stream_ring(gsh_trk_t* t, gsh_stream_t* s)
+    {
+        GSH_REQUIRE(t != nullptr, "null handle");
+        GSH_REQUIRE(s == nullptr || s->device == t->device, "the ring lives on device %d, the loop on device %d", s ? s->device : -1, t->device);
+        GSH_REQUIRE(s == nullptr || s->max_window >= t->conf.vector_length, "the ring's max_window_samples %llu is shorter than vector_length %u",
+            s ? s->max_window : 0ull, t->conf.vector_length);
+        t->ring = s;
+        if (s != nullptr)
+            {
+                t->d_stream = s->d_ring;
+                t->n_stream = s->next;
+            }
+        else
+            {
+                t->d_stream = nullptr;
+                t->n_stream = 0;
+            }
         return GSH_OK;
     }
 

@@ -60,6 +60,11 @@ class TrackingLoop:
         self._keep["stream"] = keepalive
         check(self._lib.gsh_trk_set_stream_device(self._h, C.c_void_p(device_ptr), n_samples))
 
+    def set_stream_ring(self, ring) -> None:
+        """Follow a live SampleStream ring: positions become absolute sample indices; run() processes what is resident."""
+        self._keep["stream"] = ring
+        check(self._lib.gsh_trk_set_stream_ring(self._h, ring._h if ring is not None else None))
+
     def start(self, channel: int, code: np.ndarray, start_sample: int, acq_sample_stamp: int, acq_carrier_doppler_hz: float,
               data_code: np.ndarray | None = None) -> None:
         code = np.ascontiguousarray(code, np.float32)

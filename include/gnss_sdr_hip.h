@@ -251,6 +251,10 @@ extern "C"
     /* IF sample stream shared by every channel: _host copies, _device borrows 16-byte aligned device memory */
     int gsh_trk_set_stream_host(gsh_trk_t* t, const float* iq, uint64_t n_samples);
     int gsh_trk_set_stream_device(gsh_trk_t* t, const void* device_iq, uint64_t n_samples);
+    /* follow a live sample ring: start_sample / sample_counter are absolute sample indices; every gsh_trk_run works through the
+     * periods whose windows are resident at the time of the call and stops at the newest sample, the next call (after more pushes)
+     * continues.  A channel whose next window has already been overwritten (it fell more than the ring's capacity behind) stops. */
+    int gsh_trk_set_stream_ring(gsh_trk_t* t, gsh_stream_t* s);
     /* start_tracking (trk.cc:796-866) for one channel: local replica(s) (code_length floats = chips x samples per
      * chip; data_code NULL unless track_pilot), Acq_doppler_hz, Acq_samplestamp_samples, and the first sample of the
      * first code period, i.e. the stream position after the pull-in alignment of trk.cc:1949-1973 */

@@ -205,3 +205,64 @@ def test_lock_detectors_and_cn0_on_device(gpu):
     rec2, done2 = loop.run(2)
     assert done2[2] == 0 and done2[0] == 2 and done2[1] == 2
     loop.close()
+
+
+def test_loop_follows_a_live_ring(gpu):
+    """gsh_trk_set_stream_ring: the loop works through whatever the ring holds at each gsh_trk_run call and continues after the next
+    push; the ring is much shorter than the stream (it wraps many times) and is fed with 8-bit items.  Same kernel, same arithmetic,
+    only the window addresses differ: the records must equal those of one run over the flat converted stream BIT FOR BIT."""
+    import ctypes as C
+    from gnss_sdr_amd.sample_stream import SampleStream
+    from gnss_sdr_amd._lib import TrkEpoch
+    fs, n, epochs = 4e6, 4000, 260
+    prns, dops, cphs = [5, 18], [-1900.0, 3300.0], [100.0, 900.5]
+    total = (epochs + 3) * n
+    x = synth_gps_l1_stream(total, fs, prns, dops, cphs, cn0_dbhz=47.0, seed_noise=77)
+    x8 = np.clip(np.round(np.stack([x.real, x.imag], axis=1) * 25.0), -127, 127).astype(np.int8)
+    xf = (x8[:, 0].astype(np.float32) + 1j * x8[:, 1].astype(np.float32)).astype(np.complex64)
+    kw = dict(fs_in=fs, vector_length=n, pll_bw_hz=35.0, dll_bw_hz=3.0, enable_lock_detectors=1)
+    starts = []
+    for fd, cph in zip(dops, cphs):
+        f_code = 1.023e6 * (1 + fd / 1575.42e6)
+        starts.append(int(round((1023.0 - cph) / f_code * fs)))
+    # reference run: flat buffer
+    flat = _loop(gpu, kw, n_channels=2, max_len=1023)
+    flat.set_stream_host(xf)
+    for ch in range(2):
+        flat.start(ch, oracle.ca_code(prns[ch]), starts[ch], 0, dops[ch] + 6.0)
+    rec_flat, done_flat = flat.run(epochs + 10)   # to the end of the stream
+    flat.close()
+    # live run: ring of 23 periods + 7 samples, blocks of 9.5 periods
+    ring = SampleStream(23 * n + 7, 2 * n, device=gpu)
+    live = _loop(gpu, kw, n_channels=2, max_len=1023)
+    live.set_stream_ring(ring)
+    for ch in range(2):
+        live.start(ch, oracle.ca_code(prns[ch]), starts[ch], 0, dops[ch] + 6.0)
+    rec_live = [[], []]
+    pushed, blk = 0, 9 * n + n // 2
+    n_calls = 0
+    while pushed < total:
+        m = min(blk, total - pushed)
+        ring.push(x8[pushed:pushed + m], "ibyte")
+        pushed += m
+        rec, done = live.run(12)            # more than a block holds: the loop must stop at the newest sample by itself
+        n_calls += 1
+        for ch in range(2):
+            assert done[ch] <= 10
+            rec_live[ch] += rec[ch]
+    assert n_calls > 25
+    for ch in range(2):
+        assert len(rec_live[ch]) == done_flat[ch] == len(rec_flat[ch])
+        a = b"".join(bytes(memoryview(r)) for r in rec_live[ch])
+        b = b"".join(bytes(memoryview(r)) for r in rec_flat[ch])
+        assert a == b, f"channel {ch}: live-ring records differ from the flat-buffer run"
+        assert abs(np.mean([r.carrier_doppler_hz for r in rec_live[ch][-60:]]) - dops[ch]) < 2.0
+    # a channel that falls further behind than the ring holds stops instead of reading overwritten samples
+    late = _loop(gpu, kw, n_channels=1, max_len=1023)
+    late.set_stream_ring(ring)
+    late.start(0, oracle.ca_code(prns[0]), starts[0], 0, dops[0])
+    rec, done = late.run(5)
+    assert done[0] == 0
+    late.close()
+    live.close()
+    ring.close()
