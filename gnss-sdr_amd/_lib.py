@@ -154,6 +154,7 @@ SYMBOLS = {
     "gsh_trk_start": (C.c_int, [_P, C.c_int, _F, _F, C.c_int, C.c_uint64, C.c_uint64, C.c_double]),
     "gsh_trk_run": (C.c_int, [_P, C.c_int, C.POINTER(TrkEpoch), C.POINTER(C.c_int32)]),
     "gsh_trk_time_run": (C.c_int, [_P, C.c_int, C.c_int, _F]),
+    "gsh_trk_write_dump": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(TrkConf), C.c_uint32, C.POINTER(TrkEpoch), C.c_int]),
     "gsh_acq_create": (C.c_int, [C.c_int, C.POINTER(AcqConf), C.POINTER(_P)]),
     "gsh_acq_destroy": (None, [_P]),
     "gsh_acq_set_local_code": (C.c_int, [_P, C.c_uint32, _F]),

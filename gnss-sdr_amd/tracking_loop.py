@@ -91,3 +91,9 @@ class TrackingLoop:
         ms = C.c_float(0.0)
         check(self._lib.gsh_trk_time_run(self._h, n_epochs, reps, C.byref(ms)))
         return ms.value
+
+
+def write_dump(path: str, conf: TrkConf, prn: int, records, append: bool = False) -> None:
+    """Tracking dump file in the reference's binary layout (log_data, trk.cc:1599-1702) from a list of TrkEpoch records."""
+    arr = (TrkEpoch * len(records))(*records)
+    check(_lib.load().gsh_trk_write_dump(str(path).encode(), int(append), C.byref(conf), prn, arr, len(records)))

@@ -267,6 +267,11 @@ extern "C"
     /* HIP-event milliseconds of one gsh_trk_run-sized launch, averaged over reps (each rep restarts from the state at
      * entry; the state is restored afterwards) */
     int gsh_trk_time_run(gsh_trk_t* t, int n_epochs, int reps, float* avg_ms);
+    /* write (append != 0: append) the records of one channel as a tracking dump file in the reference's own binary layout
+     * (log_data, trk.cc:1599-1702: 96 bytes per period), readable by utils/python/lib/dll_pll_veml_read_tracking_dump.py and
+     * utils/matlab/libs/dll_pll_veml_read_tracking_dump.m.  Host-only; periods flagged as loss of lock are skipped, as the
+     * reference skips log_data there. */
+    int gsh_trk_write_dump(const char* path, int append, const gsh_trk_conf* conf, uint32_t prn, const gsh_trk_epoch* records, int n_records);
 
     /* ================================================================ ACQUISITION
      * gsh_acq_*: the arithmetic of class pcps_acquisition (acq.h:93-251) without its
