@@ -79,6 +79,8 @@ class TrkConf(C.Structure):
         ("enable_lock_detectors", C.c_int32), ("cn0_samples", C.c_int32), ("cn0_min", C.c_int32), ("max_code_lock_fail", C.c_int32),
         ("max_carrier_lock_fail", C.c_int32), ("cn0_smoother_samples", C.c_int32), ("carrier_lock_test_smoother_samples", C.c_int32),
         ("cn0_smoother_alpha", C.c_float), ("carrier_lock_test_smoother_alpha", C.c_float), ("carrier_lock_th", C.c_double),
+                ("enable_symbol_sync", C.c_int32), ("symbols_per_bit", C.c_int32), ("has_secondary", C.c_int32), ("secondary_code_length", C.c_int32),
+                ("data_secondary_code_length", C.c_int32), ("pad_sync_", C.c_int32), ("secondary_code", C.c_uint8 * 200), ("data_secondary_code", C.c_uint8 * 200),
     ]
 
 
@@ -90,6 +92,7 @@ class TrkEpoch(C.Structure):
         ("carrier_doppler_hz", C.c_double), ("code_freq_chips", C.c_double), ("carr_phase_error_hz", C.c_double),
         ("carr_freq_error_hz", C.c_double), ("carr_error_filt_hz", C.c_double), ("code_error_chips", C.c_double),
         ("code_error_filt_chips", C.c_double), ("rem_code_phase_samples", C.c_double), ("acc_carrier_phase_rad", C.c_double), ("carrier_lock_test", C.c_double),
+                ("state", C.c_int32), ("symbol_flags", C.c_int32), ("p_data_accu", C.c_float * 2),
     ]
 
 

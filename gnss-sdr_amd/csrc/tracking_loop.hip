@@ -61,6 +61,13 @@ struct LockState  // what cn0_and_tracking_lock_status keeps between periods (tr
     int cn0_estimation_counter, carrier_lock_fail_counter, code_lock_fail_counter, pull_in_latched;
     float cn0_db_hz;
     double carrier_lock_test;
+    // symbol synchronisation / narrow tracking (trk.cc:2026-2104, state 4 :2197-2252, save_correlation_results :1486-1596)
+    int state;                 // d_state: 2 or 4
+    int cloop;                 // d_cloop
+    int ring_count, ring_head; // d_Prompt_circular_buffer (capacity d_secondary_code_length)
+    int current_symbol, current_data_symbol, flag_pll_180, acc_phase_initialized;
+    float p_data_accu[2];
+    float ring[2 * GSH_MAX_SECONDARY];
 };
 
 struct TrkChannel  // loop state of one channel, resident in device memory between launches
@@ -362,13 +369,57 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
                 {
                     // trk.cc:1912-1915: pull-in ends once more than pull_in_time_s whole seconds have passed since acquisition
                     const bool pull_in = !(static_cast<unsigned long long>(c.pull_in_time_s) < (pos - s.acq_stamp) / static_cast<unsigned long long>(static_cast<int>(c.fs_in)));
-                    const float2 P = out[PROMPT], E = out[PROMPT - 1], L = out[PROMPT + 1];
+                    LockState& lk = a.lock[ch];  // touched by this thread only; lives in device memory between launches
+                    // the accumulators the loop works on (d_VE_accu .. d_VL_accu): the period's outputs in state 2 (trk.cc:1984-1991); in state 4
+                    // save_correlation_results adds them, times the secondary code chip, to accumulators zeroed at the end of the previous period
+                    float2 acc[NT];
+#pragma unroll
+                    for (int t = 0; t < NT; t++) acc[t] = out[t];
+                    const int run_state = c.enable_symbol_sync ? lk.state : 0;
+                    if (run_state == 4)
+                        {
+                            float sgn = 1.0f;
+                            if (c.has_secondary)
+                                {
+                                    sgn = c.secondary_code[lk.current_symbol] == '0' ? 1.0f : -1.0f;
+                                    lk.current_symbol = (lk.current_symbol + 1) % c.secondary_code_length;
+                                }
+#pragma unroll
+                            for (int t = 0; t < NT; t++)
+                                {
+                                    acc[t].x = __fadd_rn(0.0f, __fmul_rn(sgn, out[t].x));
+                                    acc[t].y = __fadd_rn(0.0f, __fmul_rn(sgn, out[t].y));
+                                }
+                            const float2 pd = c.track_pilot ? pdata : out[PROMPT];
+                            if (c.symbols_per_bit > 1)
+                                {
+                                    float ds = 1.0f;
+                                    if (c.data_secondary_code_length > 0)
+                                        {
+                                            ds = c.data_secondary_code[lk.current_data_symbol] == '0' ? 1.0f : -1.0f;
+                                            lk.current_data_symbol = (lk.current_data_symbol + 1) % c.data_secondary_code_length;
+                                        }
+                                    else
+                                        {
+                                            lk.current_data_symbol = (lk.current_data_symbol + 1) % c.symbols_per_bit;
+                                        }
+                                    lk.p_data_accu[0] = __fadd_rn(lk.p_data_accu[0], __fmul_rn(ds, pd.x));
+                                    lk.p_data_accu[1] = __fadd_rn(lk.p_data_accu[1], __fmul_rn(ds, pd.y));
+                                }
+                            else
+                                {
+                                    lk.p_data_accu[0] = pd.x;
+                                    lk.p_data_accu[1] = pd.y;
+                                }
+                            lk.cloop = c.track_pilot ? 0 : 1;  // trk.cc:1587-1595
+                        }
+                    const bool cloop_now = c.enable_symbol_sync ? (lk.cloop != 0) : (c.cloop != 0);
+                    const float2 P = acc[PROMPT], E = acc[PROMPT - 1], L = acc[PROMPT + 1];
                     float rec_cn0 = 0.0f;
                     double rec_lock_test = 0.0;
                     bool lost = false;
                     if (c.enable_lock_detectors)
                         {
-                            LockState& lk = a.lock[ch];  // touched by this thread only; lives in device memory between launches
                             if (lk.pull_in_latched && !pull_in)  // trk.cc:1912-1916
                                 {
                                     lk.pull_in_latched = 0;
@@ -397,6 +448,7 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
                                     r.prompt_data[1] = pdata.y;
                                     r.cn0_db_hz = rec_cn0;
                                     r.carrier_lock_test = rec_lock_test;
+                                    r.state = run_state;
                                     a.records[static_cast<size_t>(ch) * a.n_epochs + e] = r;
                                 }
                             s.active = 0;
@@ -405,7 +457,7 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
                     else
                         {
                     // ---- run_dll_pll, trk.cc:1260-1324
-                    const double carr_phase_error_hz = (c.cloop ? pll_cloop_two_quadrant_atan_d(P) : pll_four_quadrant_atan_d(P)) / GNSS_TWO_PI_D;
+                    const double carr_phase_error_hz = (cloop_now ? pll_cloop_two_quadrant_atan_d(P) : pll_four_quadrant_atan_d(P)) / GNSS_TWO_PI_D;
                     double carr_freq_error_hz = 0.0;
                     float carr_error_filt;
                     if ((pull_in && c.enable_fll_pull_in) || c.enable_fll_steady_state)
@@ -426,7 +478,7 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
                     s.carrier_doppler_hz = carr_error_filt_hz;
                     double code_error_chips;
                     if (NT == 5)
-                        code_error_chips = dll_nc_vemlp_normalized_d(out[0], out[1], out[NT - 2], out[NT - 1]);
+                        code_error_chips = dll_nc_vemlp_normalized_d(acc[0], acc[1], acc[NT - 2], acc[NT - 1]);
                     else
                         code_error_chips = dll_nc_e_minus_l_normalized_d(E, L, c.spc, c.slope, c.y_intercept);
                     const double code_error_filt_chips = loop_filter_apply(s.dll, static_cast<float>(code_error_chips));
@@ -448,9 +500,90 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
                     s.rem_code_phase_samples = k_blk - static_cast<double>(prn_len);
                     s.rem_code_phase_chips = s.code_freq_chips * s.rem_code_phase_samples / c.fs_in;
 
+                    // ---- symbol synchronisation (state 2, trk.cc:2026-2112) / symbol output (state 4, :2205-2246)
+                    int rec_symbol_flags = 0;
+                    float rec_pdata[2] = {0.0f, 0.0f};
+                    if (c.enable_symbol_sync)
+                        {
+                            if (run_state == 2)
+                                {
+                                    bool next_state = false;
+                                    if (!pull_in)
+                                        {
+                                            if (c.has_secondary || c.symbols_per_bit > 1)
+                                                {
+                                                    const int len = c.secondary_code_length;
+                                                    if (lk.ring_count < len)  // d_Prompt_circular_buffer.push_back(*d_Prompt)
+                                                        {
+                                                            lk.ring[2 * lk.ring_count] = out[PROMPT].x;
+                                                            lk.ring[2 * lk.ring_count + 1] = out[PROMPT].y;
+                                                            lk.ring_count++;
+                                                        }
+                                                    else if (len > 0)
+                                                        {
+                                                            lk.ring[2 * lk.ring_head] = out[PROMPT].x;
+                                                            lk.ring[2 * lk.ring_head + 1] = out[PROMPT].y;
+                                                            lk.ring_head = (lk.ring_head + 1) % len;
+                                                        }
+                                                    if (len > 0 && lk.ring_count == len)
+                                                        {
+                                                            int corr_value = 0;  // acquire_secondary, trk.cc:1118-1160
+                                                            int idx = lk.ring_head;
+                                                            for (int i = 0; i < len; i++)
+                                                                {
+                                                                    const bool zero = c.secondary_code[i] == '0';
+                                                                    if (lk.ring[2 * idx] < 0.0f)
+                                                                        corr_value += zero ? 1 : -1;
+                                                                    else
+                                                                        corr_value += zero ? -1 : 1;
+                                                                    idx = (idx + 1 == len) ? 0 : idx + 1;
+                                                                }
+                                                            if (abs(corr_value) == len)
+                                                                {
+                                                                    lk.flag_pll_180 = corr_value < 0 ? 1 : 0;
+                                                                    next_state = true;
+                                                                }
+                                                        }
+                                                }
+                                            else
+                                                {
+                                                    next_state = true;
+                                                }
+                                        }
+                                    if (next_state)  // trk.cc:2101-2112, 2151-2154 (no extended integration)
+                                        {
+                                            lk.p_data_accu[0] = lk.p_data_accu[1] = 0.0f;
+                                            lk.ring_count = lk.ring_head = 0;
+                                            lk.current_symbol = 0;
+                                            lk.current_data_symbol = 0;
+                                            lk.state = 4;
+                                        }
+                                }
+                            else
+                                {
+                                    if (!lk.acc_phase_initialized)  // check_carrier_phase_coherent_initialization, trk.cc:1350-1357
+                                        {
+                                            s.acc_carrier_phase_rad = -static_cast<double>(s.rem_carr_phase_rad);
+                                            lk.acc_phase_initialized = 1;
+                                        }
+                                    rec_pdata[0] = lk.p_data_accu[0];
+                                    rec_pdata[1] = lk.p_data_accu[1];
+                                    if (lk.current_data_symbol == 0)
+                                        {
+                                            rec_symbol_flags |= 1;
+                                            lk.p_data_accu[0] = lk.p_data_accu[1] = 0.0f;
+                                        }
+                                }
+                            if (lk.flag_pll_180) rec_symbol_flags |= 2;
+                        }
+
                     if (a.records != nullptr)
                         {
                             gsh_trk_epoch r;
+                            r.state = run_state;
+                            r.symbol_flags = rec_symbol_flags;
+                            r.p_data_accu[0] = rec_pdata[0];
+                            r.p_data_accu[1] = rec_pdata[1];
                             r.sample_counter = pos;
                             r.prn_length_samples = prn_len;
                             r.flags = pull_in ? 1 : 0;
@@ -679,6 +812,13 @@ extern "C"
         GSH_REQUIRE(c.code_length_chips >= 1 && c.code_samples_per_chip >= 1 && c.vector_length >= 1, "code_length_chips, code_samples_per_chip, vector_length must be >= 1");
         GSH_REQUIRE(c.pll_filter_order == 2 || c.pll_filter_order == 3, "pll_filter_order %d (2 or 3: T/tracking_FLL_PLL_filter.cc:23-54)", c.pll_filter_order);
         GSH_REQUIRE(c.dll_filter_order >= 1 && c.dll_filter_order <= 3, "dll_filter_order %d outside 1..3", c.dll_filter_order);
+        if (c.enable_symbol_sync)
+            {
+                GSH_REQUIRE(c.secondary_code_length >= 0 && c.secondary_code_length <= GSH_MAX_SECONDARY, "secondary_code_length %d outside 0..%d", c.secondary_code_length, GSH_MAX_SECONDARY);
+                GSH_REQUIRE(c.data_secondary_code_length >= 0 && c.data_secondary_code_length <= GSH_MAX_SECONDARY, "data_secondary_code_length %d outside 0..%d", c.data_secondary_code_length, GSH_MAX_SECONDARY);
+                GSH_REQUIRE(!c.has_secondary || c.secondary_code_length >= 1, "has_secondary needs a secondary code");
+                GSH_REQUIRE(c.symbols_per_bit >= 0, "symbols_per_bit %d", c.symbols_per_bit);
+            }
         if (c.enable_lock_detectors)
             {
                 GSH_REQUIRE(c.cn0_samples >= 1 && c.cn0_samples <= GSH_MAX_CN0_SAMPLES, "cn0_samples %d outside 1..%d", c.cn0_samples, GSH_MAX_CN0_SAMPLES);
@@ -845,6 +985,8 @@ extern "C"
         init_smoother(lk.cn0_smoother, c.cn0_smoother_alpha, cn0_init, 25.0F, 12.0F);                        // class defaults, T/exponential_smoother.h:64-65
         init_smoother(lk.carrier_lock_test_smoother, c.carrier_lock_test_smoother_alpha, c.carrier_lock_test_smoother_samples, -1.0F, 0.0F);  // trk.cc:688-692
         lk.pull_in_latched = 1;
+        lk.state = 2;            // pull-in hands over to state 2 (trk.cc:1963)
+        lk.cloop = c.cloop;      // d_cloop = true at start_tracking (trk.cc:1072); conf.cloop lets a caller start four-quadrant
         GSH_HIP(hipMemcpyAsync(t->d_lock + channel, &lk, sizeof(lk), hipMemcpyHostToDevice, t->stream));
         GSH_HIP(hipStreamSynchronize(t->stream));
         return GSH_OK;

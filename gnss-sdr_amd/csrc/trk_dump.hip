@@ -21,6 +21,7 @@ extern "C"
             {
                 const gsh_trk_epoch& r = records[i];
                 if (r.flags & 2) continue;  // loss of lock: the reference does not call log_data in that period (trk.cc:2009-2014)
+                if (r.state == 4 && !(r.symbol_flags & 1)) continue;  // narrow tracking logs once per telemetry symbol (trk.cc:2212-2215)
                 struct __attribute__((packed)) Rec
                 {
                     float ve, e, pr, l, vl, prompt_i, prompt_q;

@@ -25,7 +25,8 @@ def trk_conf(**kw) -> TrkConf:
              # lock detectors / C/N0: Dll_Pll_Conf defaults (gnss_sdr_flags.cc:44-53, dll_pll_conf.h:58-59,70-71); off unless asked for
              enable_lock_detectors=0, cn0_samples=20, cn0_min=25, max_code_lock_fail=50, max_carrier_lock_fail=5000,
              cn0_smoother_samples=200, carrier_lock_test_smoother_samples=25, cn0_smoother_alpha=0.002,
-             carrier_lock_test_smoother_alpha=0.002, carrier_lock_th=0.7)
+             carrier_lock_test_smoother_alpha=0.002, carrier_lock_th=0.7,
+             enable_symbol_sync=0, symbols_per_bit=0, has_secondary=0, secondary_code_length=0, data_secondary_code_length=0)
     d.update(kw)
     for k, v in d.items():
         setattr(c, k, v)
@@ -97,3 +98,18 @@ def write_dump(path: str, conf: TrkConf, prn: int, records, append: bool = False
     """Tracking dump file in the reference's binary layout (log_data, trk.cc:1599-1702) from a list of TrkEpoch records."""
     arr = (TrkEpoch * len(records))(*records)
     check(_lib.load().gsh_trk_write_dump(str(path).encode(), int(append), C.byref(conf), prn, arr, len(records)))
+
+
+def set_symbol_sync(conf, symbols_per_bit: int, secondary_code: str = "", has_secondary: bool = False, data_secondary_code: str = "") -> None:
+    """Fill the symbol-synchronisation fields as the tracking block's constructor does per signal (trk.cc:196-300): e.g. GPS L1 C/A:
+    symbols_per_bit = 20, secondary_code = the 160-symbol telemetry preamble, has_secondary = False; Galileo E1 pilot: symbols_per_bit = 1,
+    secondary_code = the 25-chip E1C code, has_secondary = True."""
+    conf.enable_symbol_sync = 1
+    conf.symbols_per_bit = symbols_per_bit
+    conf.has_secondary = int(has_secondary)
+    conf.secondary_code_length = len(secondary_code)
+    conf.data_secondary_code_length = len(data_secondary_code)
+    for i, ch in enumerate(secondary_code.encode()):
+        conf.secondary_code[i] = ch
+    for i, ch in enumerate(data_secondary_code.encode()):
+        conf.data_secondary_code[i] = ch

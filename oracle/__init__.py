@@ -46,7 +46,9 @@ class TrkConf(C.Structure):
                 ("pull_in_time_s", C.c_uint32), ("spc", C.c_float), ("slope", C.c_float), ("y_intercept", C.c_float),
                 ("enable_lock_detectors", C.c_int32), ("cn0_samples", C.c_int32), ("cn0_min", C.c_int32), ("max_code_lock_fail", C.c_int32),
                 ("max_carrier_lock_fail", C.c_int32), ("cn0_smoother_samples", C.c_int32), ("carrier_lock_test_smoother_samples", C.c_int32),
-                ("cn0_smoother_alpha", C.c_float), ("carrier_lock_test_smoother_alpha", C.c_float), ("carrier_lock_th", C.c_double)]
+                ("cn0_smoother_alpha", C.c_float), ("carrier_lock_test_smoother_alpha", C.c_float), ("carrier_lock_th", C.c_double),
+                ("enable_symbol_sync", C.c_int32), ("symbols_per_bit", C.c_int32), ("has_secondary", C.c_int32), ("secondary_code_length", C.c_int32),
+                ("data_secondary_code_length", C.c_int32), ("pad_sync_", C.c_int32), ("secondary_code", C.c_uint8 * 200), ("data_secondary_code", C.c_uint8 * 200)]
 
 
 class TrkEpoch(C.Structure):
@@ -55,7 +57,8 @@ class TrkEpoch(C.Structure):
                 ("corr", C.c_float * 10), ("prompt_data", C.c_float * 2), ("rem_carr_phase_rad", C.c_float), ("cn0_db_hz", C.c_float),
                 ("carrier_doppler_hz", C.c_double), ("code_freq_chips", C.c_double), ("carr_phase_error_hz", C.c_double),
                 ("carr_freq_error_hz", C.c_double), ("carr_error_filt_hz", C.c_double), ("code_error_chips", C.c_double),
-                ("code_error_filt_chips", C.c_double), ("rem_code_phase_samples", C.c_double), ("acc_carrier_phase_rad", C.c_double), ("carrier_lock_test", C.c_double)]
+                ("code_error_filt_chips", C.c_double), ("rem_code_phase_samples", C.c_double), ("acc_carrier_phase_rad", C.c_double), ("carrier_lock_test", C.c_double),
+                ("state", C.c_int32), ("symbol_flags", C.c_int32), ("p_data_accu", C.c_float * 2)]
 
 
 _lib = None
@@ -340,7 +343,8 @@ def trk_conf(**kw) -> TrkConf:
              # lock detectors / C/N0: Dll_Pll_Conf defaults (gnss_sdr_flags.cc:44-53, dll_pll_conf.h:58-59,70-71); off unless asked for
              enable_lock_detectors=0, cn0_samples=20, cn0_min=25, max_code_lock_fail=50, max_carrier_lock_fail=5000,
              cn0_smoother_samples=200, carrier_lock_test_smoother_samples=25, cn0_smoother_alpha=0.002,
-             carrier_lock_test_smoother_alpha=0.002, carrier_lock_th=0.7)
+             carrier_lock_test_smoother_alpha=0.002, carrier_lock_th=0.7,
+             enable_symbol_sync=0, symbols_per_bit=0, has_secondary=0, secondary_code_length=0, data_secondary_code_length=0)
     d.update(kw)
     for k, v in d.items():
         setattr(c, k, v)
@@ -358,3 +362,18 @@ def trk_run(conf: TrkConf, code, x, start_sample, acq_sample_stamp, acq_doppler_
     n = lib().oracle_trk_run(C.byref(conf), code, dc, len(code), _iq(x), len(x), int(start_sample), int(acq_sample_stamp),
                              float(acq_doppler_hz), n_epochs, rec)
     return list(rec)[:n]
+
+
+def set_symbol_sync(conf, symbols_per_bit: int, secondary_code: str = "", has_secondary: bool = False, data_secondary_code: str = "") -> None:
+    """Fill the symbol-synchronisation fields as the tracking block's constructor does per signal (trk.cc:196-300): e.g. GPS L1 C/A:
+    symbols_per_bit = 20, secondary_code = the 160-symbol telemetry preamble, has_secondary = False; Galileo E1 pilot: symbols_per_bit = 1,
+    secondary_code = the 25-chip E1C code, has_secondary = True."""
+    conf.enable_symbol_sync = 1
+    conf.symbols_per_bit = symbols_per_bit
+    conf.has_secondary = int(has_secondary)
+    conf.secondary_code_length = len(secondary_code)
+    conf.data_secondary_code_length = len(data_secondary_code)
+    for i, ch in enumerate(secondary_code.encode()):
+        conf.secondary_code[i] = ch
+    for i, ch in enumerate(data_secondary_code.encode()):
+        conf.data_secondary_code[i] = ch

@@ -126,6 +126,7 @@ extern "C"
     void oracle_smoother_reset(oracle_smoother* s);
     float oracle_smoother_smooth(oracle_smoother* s, float raw);
 #define ORACLE_MAX_CN0_SAMPLES 64
+#define ORACLE_MAX_SECONDARY 200
     typedef struct oracle_lock_state  /* the members cn0_and_tracking_lock_status touches (trk.cc:1167-1224) */
     {
         float prompt_buffer[2 * ORACLE_MAX_CN0_SAMPLES];
@@ -153,6 +154,15 @@ extern "C"
         int32_t cn0_smoother_samples, carrier_lock_test_smoother_samples;
         float cn0_smoother_alpha, carrier_lock_test_smoother_alpha;
         double carrier_lock_th;
+        /* symbol synchronisation and the narrow-tracking state (0 = off: the loop stays in state 2) */
+        int32_t enable_symbol_sync;
+        int32_t symbols_per_bit;             /* d_symbols_per_bit */
+        int32_t has_secondary;               /* d_secondary */
+        int32_t secondary_code_length;       /* d_secondary_code_length (the telemetry preamble for signals without a secondary code) */
+        int32_t data_secondary_code_length;  /* d_data_secondary_code_length */
+        int32_t pad_sync_;
+        uint8_t secondary_code[ORACLE_MAX_SECONDARY];       /* characters '0' / '1' */
+        uint8_t data_secondary_code[ORACLE_MAX_SECONDARY];
     } oracle_trk_conf;
     void oracle_lock_init(oracle_lock_state* st, const oracle_trk_conf* c);
     /* cn0_and_tracking_lock_status, trk.cc:1167-1224: returns 1 while locked, 0 when loss of lock is declared */
@@ -170,6 +180,9 @@ extern "C"
         double carrier_doppler_hz, code_freq_chips, carr_phase_error_hz, carr_freq_error_hz, carr_error_filt_hz;
         double code_error_chips, code_error_filt_chips, rem_code_phase_samples, acc_carrier_phase_rad;
         double carrier_lock_test;
+        int32_t state;          /* d_state in which the period ran: 2 (wide tracking, symbol search) or 4 (narrow tracking) */
+        int32_t symbol_flags;   /* bit 0: Flag_valid_symbol_output; bit 1: Flag_PLL_180_deg_phase_locked */
+        float p_data_accu[2];   /* d_P_data_accu when a symbol is output (Prompt_I / Prompt_Q of the Gnss_Synchro), else the running sum */
     } oracle_trk_epoch;
 
     /* closed loop of ONE channel over a resident stream; returns the number of epochs completed */

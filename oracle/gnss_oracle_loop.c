@@ -14,6 +14,7 @@
  */
 #include "gnss_oracle.h"
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 /* the reference's pi is the GNSS ICD value, MATH_CONSTANTS.h:47-49 */
@@ -507,6 +508,15 @@ int oracle_trk_run(const oracle_trk_conf* c, const float* code, const float* dat
     uint64_t pos = start_sample;
     oracle_lock_state lock;
     int pull_in_latched = 1;  /* d_pull_in_transitory, cleared once (trk.cc:1910-1917) */
+    /* symbol synchronisation (trk.cc:2026-2104) and narrow tracking (state 4, :2197-2252) */
+    int state = 2, cloop = c->cloop;
+    float ring[2 * ORACLE_MAX_SECONDARY];  /* d_Prompt_circular_buffer: boost::circular_buffer of capacity d_secondary_code_length */
+    int ring_count = 0, ring_head = 0;     /* ring_head: index of the oldest element once the buffer is full */
+    int current_symbol = 0, current_data_symbol = 0, flag_pll_180 = 0, acc_phase_initialized = 0;
+    float p_data_accu[2] = {0.0F, 0.0F};
+    if (c->enable_symbol_sync && (c->secondary_code_length < 0 || c->secondary_code_length > ORACLE_MAX_SECONDARY ||
+                                     c->data_secondary_code_length < 0 || c->data_secondary_code_length > ORACLE_MAX_SECONDARY))
+        return -1;
     if (c->enable_lock_detectors)
         {
             if (c->cn0_samples < 1 || c->cn0_samples > ORACLE_MAX_CN0_SAMPLES) return -1;
@@ -535,6 +545,42 @@ int oracle_trk_run(const oracle_trk_conf* c, const float* code, const float* dat
                     r->prompt_data[0] = pd[0];
                     r->prompt_data[1] = pd[1];
                 }
+            r->state = state;
+            if (state == 4)
+                {
+                    /* save_correlation_results, trk.cc:1486-1596, into accumulators that were zeroed at the end of the previous period
+                     * (:2241-2246): the correlators enter the loop multiplied by the secondary code chip */
+                    float sgn = 1.0F;
+                    if (c->has_secondary)
+                        {
+                            sgn = c->secondary_code[current_symbol] == '0' ? 1.0F : -1.0F;
+                            current_symbol = (current_symbol + 1) % c->secondary_code_length;
+                        }
+                    for (int t = 0; t < 2 * n_taps; t++) out[t] = 0.0F + sgn * out[t];  /* 0 + x or 0 - x: the float += / -= of :1493-1512 */
+                    const float* pd = (c->track_pilot && data_code) ? r->prompt_data : (const float*)(r->corr + 2 * prompt);
+                    if (c->symbols_per_bit > 1)
+                        {
+                            if (c->data_secondary_code_length > 0)
+                                {
+                                    const float ds = c->data_secondary_code[current_data_symbol] == '0' ? 1.0F : -1.0F;
+                                    p_data_accu[0] += ds * pd[0];
+                                    p_data_accu[1] += ds * pd[1];
+                                    current_data_symbol = (current_data_symbol + 1) % c->data_secondary_code_length;
+                                }
+                            else
+                                {
+                                    p_data_accu[0] += pd[0];
+                                    p_data_accu[1] += pd[1];
+                                    current_data_symbol = (current_data_symbol + 1) % c->symbols_per_bit;
+                                }
+                        }
+                    else
+                        {
+                            p_data_accu[0] = pd[0];
+                            p_data_accu[1] = pd[1];
+                        }
+                    cloop = c->track_pilot ? 0 : 1;  /* :1587-1595: pilot tracking disables the Costas loop */
+                }
             const float* P = out + 2 * prompt;
             const float* E = out + 2 * (prompt - 1);
             const float* L = out + 2 * (prompt + 1);
@@ -561,7 +607,7 @@ int oracle_trk_run(const oracle_trk_conf* c, const float* code, const float* dat
             /* run_dll_pll, trk.cc:1260-1324 */
             double carr_phase_error_hz, carr_freq_error_hz = 0.0;
             float carr_error_filt;
-            if (c->cloop)
+            if (cloop)
                 carr_phase_error_hz = oracle_pll_cloop_two_quadrant_atan(P[0], P[1]) / ORA_TWO_PI;
             else
                 carr_phase_error_hz = oracle_pll_four_quadrant_atan(P[0], P[1]) / ORA_TWO_PI;
@@ -617,6 +663,82 @@ int oracle_trk_run(const oracle_trk_conf* c, const float* code, const float* dat
             r->rem_code_phase_samples = rem_code_phase_samples;
             r->acc_carrier_phase_rad = acc_carrier_phase_rad;
             r->rem_carr_phase_rad = rem_carr_phase_rad;
+            if (c->enable_symbol_sync)
+                {
+                    if (state == 2)
+                        {
+                            int next_state = 0;
+                            if (!pull_in)  /* trk.cc:2026 */
+                                {
+                                    if (c->has_secondary || c->symbols_per_bit > 1)  /* :2028-2089 (the histogram bit synchroniser is not modelled) */
+                                        {
+                                            /* d_Prompt_circular_buffer.push_back(*d_Prompt) */
+                                            const float* pr = r->corr + 2 * prompt;
+                                            const int len = c->secondary_code_length;
+                                            if (ring_count < len)
+                                                {
+                                                    ring[2 * ring_count] = pr[0];
+                                                    ring[2 * ring_count + 1] = pr[1];
+                                                    ring_count++;
+                                                }
+                                            else if (len > 0)
+                                                {
+                                                    ring[2 * ring_head] = pr[0];
+                                                    ring[2 * ring_head + 1] = pr[1];
+                                                    ring_head = (ring_head + 1) % len;
+                                                }
+                                            if (len > 0 && ring_count == len)
+                                                {
+                                                    /* acquire_secondary, trk.cc:1118-1160: sign pattern of the buffered prompts against the code */
+                                                    int corr_value = 0;
+                                                    for (int i = 0; i < len; i++)
+                                                        {
+                                                            const float re = ring[2 * ((ring_head + i) % len)];
+                                                            if (re < 0.0)
+                                                                corr_value += c->secondary_code[i] == '0' ? 1 : -1;
+                                                            else
+                                                                corr_value += c->secondary_code[i] == '0' ? -1 : 1;
+                                                        }
+                                                    if (abs(corr_value) == len)
+                                                        {
+                                                            flag_pll_180 = corr_value < 0 ? 1 : 0;
+                                                            next_state = 1;
+                                                        }
+                                                }
+                                        }
+                                    else
+                                        {
+                                            next_state = 1;  /* :2091-2094 */
+                                        }
+                                }
+                            if (next_state)  /* :2101-2112 + :2151-2154 (no extended integration) */
+                                {
+                                    p_data_accu[0] = p_data_accu[1] = 0.0F;
+                                    ring_count = ring_head = 0;
+                                    current_symbol = 0;
+                                    current_data_symbol = 0;
+                                    state = 4;
+                                }
+                        }
+                    else
+                        {
+                            /* state 4 after run_dll_pll / update_tracking_vars: check_carrier_phase_coherent_initialization (:1350-1357) */
+                            if (!acc_phase_initialized)
+                                {
+                                    acc_carrier_phase_rad = -(double)rem_carr_phase_rad;
+                                    acc_phase_initialized = 1;
+                                    r->acc_carrier_phase_rad = acc_carrier_phase_rad;
+                                }
+                            r->p_data_accu[0] = p_data_accu[0];
+                            r->p_data_accu[1] = p_data_accu[1];
+                            if (current_data_symbol == 0)  /* :2212-2236: one telemetry symbol leaves the block */
+                                {
+                                    r->symbol_flags |= 1;
+                                    p_data_accu[0] = p_data_accu[1] = 0.0F;
+                                }
+                        }
+                    if (flag_pll_180) r->symbol_flags |= 2;
+                }
             pos += (uint64_t)prn_len;
         }
     return n_epochs;

@@ -1,0 +1,137 @@
+"""Symbol synchronisation and the narrow-tracking state of the loop (trk.cc:1118-1160 acquire_secondary, :1486-1596
+save_correlation_results, :2026-2112 the search in state 2, :2197-2252 state 4) -- the CPU oracle loop against the truth built into the
+synthetic signal, then the device loop against the oracle loop."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from helpers import golden_e1_l5_codes
+from symbol_sync_cases import GALILEO_E1_C_SECONDARY_CODE, GPS_CA_PREAMBLE_SYMBOLS, galileo_e1_with_secondary, gps_l1_with_nav_bits
+
+FS_L1 = 2.046e6
+
+
+def _gps_case():
+    # 1 s of pull-in (pull_in_time_s = 0 -> the transitory ends once a whole second has passed), then alternating bits, the preamble, more bits
+    bits = "01" * 27 + "10001011" + "0110100111000101"
+    x, n = gps_l1_with_nav_bits(1600, FS_L1, 7, -1750.0, bits, first_bit_period=0)
+    kw = dict(fs_in=FS_L1, vector_length=n, pll_bw_hz=25.0, dll_bw_hz=2.0, pull_in_time_s=0, enable_lock_detectors=1)
+    return x, n, bits, kw
+
+
+def test_constants_match_the_reference_headers():
+    h = "/root/reference/src/core/system_parameters/GPS_L1_CA.h"
+    if not os.path.exists(h):
+        pytest.skip("reference tree not present")
+    assert f'GPS_CA_PREAMBLE_SYMBOLS_STR[161] = "{GPS_CA_PREAMBLE_SYMBOLS}"' in open(h).read()
+    assert f'GALILEO_E1_C_SECONDARY_CODE[26] = "{GALILEO_E1_C_SECONDARY_CODE}"' in open("/root/reference/src/core/system_parameters/Galileo_E1.h").read()
+
+
+def test_oracle_gps_l1_bit_synchronisation_and_symbols():
+    x, n, bits, kw = _gps_case()
+    conf = oracle.trk_conf(**kw)
+    oracle.set_symbol_sync(conf, 20, GPS_CA_PREAMBLE_SYMBOLS, has_secondary=False)
+    rec = oracle.trk_run(conf, oracle.ca_code(7), x, 0, 0, -1742.0, 1600)
+    assert len(rec) == 1600
+    states = np.array([r.state for r in rec])
+    first4 = int(np.argmax(states == 4))
+    # the preamble's 160 symbols end with bit 61 (54 alternating bits + 8): the search succeeds in the period that completes it
+    assert states[first4 - 1] == 2 and np.all(states[first4:] == 4)
+    assert first4 == (54 + 8) * 20, first4
+    # from then on one telemetry symbol (= one bit: the sum of 20 prompts) leaves every 20 periods, aligned to the bit edges
+    out = [(i, r) for i, r in enumerate(rec[first4:], start=first4) if r.symbol_flags & 1]
+    assert [i for i, _ in out][:3] == [first4 + 19, first4 + 39, first4 + 59]
+    flip = -1.0 if (rec[-1].symbol_flags & 2) else 1.0            # Flag_PLL_180_deg_phase_locked tells the decoder to invert
+    got = "".join("1" if flip * r.p_data_accu[0] > 0 else "0" for _, r in out)
+    m = len(bits) - 62                                            # past the defined bits the signal carries +1
+    assert got[:m] == bits[62:] and m >= 15 and set(got[m:]) <= {"1"}
+    assert all(abs(r.p_data_accu[0]) > 10 * abs(r.p_data_accu[1]) for _, r in out[2:])      # a bit is 20 coherent prompts: it sits on I
+
+
+def test_oracle_galileo_e1_secondary_code_lock():
+    g = golden_e1_l5_codes()
+    fs = 8.184e6
+    rng = np.random.default_rng(3)
+    data = "".join(rng.choice(["0", "1"], 400))
+    x, n = galileo_e1_with_secondary(330, fs, g["e1b"][3], g["e1c"][3], 940.0, data)
+    kw = dict(fs_in=fs, vector_length=n, code_length_chips=4092, code_samples_per_chip=2, veml=1, track_pilot=1, early_late_space_chips=0.15,
+              very_early_late_space_chips=0.5, pll_bw_hz=15.0, dll_bw_hz=0.75, pull_in_time_s=0, enable_lock_detectors=1)
+    conf = oracle.trk_conf(**kw)
+    oracle.set_symbol_sync(conf, 1, GALILEO_E1_C_SECONDARY_CODE, has_secondary=True)
+    rec = oracle.trk_run(conf, g["e1c"][3], x, 0, 0, 935.0, 330, data_code=g["e1b"][3])
+    states = np.array([r.state for r in rec])
+    first4 = int(np.argmax(states == 4))
+    # pull-in ends at the first period that starts a whole second after the hand-over (period 250 or 251: the periods are a little
+    # shorter than 4 ms at +940 Hz), then the 25-symbol window has to line up with CS25: at most two code-lengths later
+    assert 250 <= first4 <= 250 + 51 and np.all(states[first4:] == 4)
+    assert (first4 % 25) == 0                                                   # the buffer matched when it held CS25 from its first chip
+    # in state 4 every period outputs one E1B symbol; four-quadrant PLL on the sign-stripped pilot keeps the data on I
+    tail = rec[first4:]
+    assert all(r.symbol_flags & 1 for r in tail)
+    # Entering state 4 switches the PLL from the Costas to the four-quadrant discriminator on the sign-stripped pilot (trk.cc:1587-1595):
+    # if the Costas loop sat half a cycle away from "stripped pilot on +I" the loop now turns by 180 degrees, and the data polarity with
+    # it (the telemetry decoder resolves polarity from its own preamble).  After that transient the symbols are the data, all with one sign.
+    got = np.array([1 if r.p_data_accu[0] > 0 else -1 for r in tail[12:]])
+    exp = np.array([1 if b == "1" else -1 for b in data[first4 + 12:first4 + 12 + len(got)]])
+    assert abs(int(np.sum(got * exp))) == len(got) and len(got) >= 15
+    assert np.mean([abs(r.carr_phase_error_hz) for r in tail[12:]]) < 0.06      # cycles: thermal noise at 47 dB-Hz over 4 ms, no half-cycle slips
+
+
+@pytest.mark.gpu
+def test_device_gps_l1_bit_synchronisation_matches_oracle(gpu):
+    from gnss_sdr_amd.tracking_loop import TrackingLoop, set_symbol_sync, trk_conf
+    x, n, bits, kw = _gps_case()
+    conf_o = oracle.trk_conf(**kw)
+    oracle.set_symbol_sync(conf_o, 20, GPS_CA_PREAMBLE_SYMBOLS, has_secondary=False)
+    ora = oracle.trk_run(conf_o, oracle.ca_code(7), x, 0, 0, -1742.0, 1600)
+    conf = trk_conf(**kw)
+    set_symbol_sync(conf, 20, GPS_CA_PREAMBLE_SYMBOLS, has_secondary=False)
+    loop = TrackingLoop(conf, 1, 1023, device=gpu)
+    loop.set_stream_host(x)
+    loop.start(0, oracle.ca_code(7), 0, 0, -1742.0)
+    rec, done = loop.run(1000)
+    rec2, done2 = loop.run(600)                      # the state machine survives the launch boundary
+    rec = rec[0] + rec2[0]
+    assert len(rec) == len(ora) == 1600
+    assert [r.state for r in rec] == [r.state for r in ora]
+    assert [r.symbol_flags for r in rec] == [r.symbol_flags for r in ora]
+    g = np.array([r.p_data_accu[0] for r in rec if r.symbol_flags & 1])
+    o = np.array([r.p_data_accu[0] for r in ora if r.symbol_flags & 1])
+    assert np.array_equal(np.sign(g), np.sign(o)) and np.max(np.abs(g - o)) < 2e-2 * np.mean(np.abs(o))
+    assert abs(rec[-1].acc_carrier_phase_rad - ora[-1].acc_carrier_phase_rad) < 0.05 * abs(ora[-1].acc_carrier_phase_rad)
+    loop.close()
+
+
+@pytest.mark.gpu
+def test_device_galileo_e1_secondary_lock_matches_oracle(gpu):
+    from gnss_sdr_amd.tracking_loop import TrackingLoop, set_symbol_sync, trk_conf
+    g = golden_e1_l5_codes()
+    fs = 8.184e6
+    rng = np.random.default_rng(3)
+    data = "".join(rng.choice(["0", "1"], 400))
+    x, n = galileo_e1_with_secondary(330, fs, g["e1b"][3], g["e1c"][3], 940.0, data)
+    kw = dict(fs_in=fs, vector_length=n, code_length_chips=4092, code_samples_per_chip=2, veml=1, track_pilot=1, early_late_space_chips=0.15,
+              very_early_late_space_chips=0.5, pll_bw_hz=15.0, dll_bw_hz=0.75, pull_in_time_s=0, enable_lock_detectors=1)
+    conf_o = oracle.trk_conf(**kw)
+    oracle.set_symbol_sync(conf_o, 1, GALILEO_E1_C_SECONDARY_CODE, has_secondary=True)
+    ora = oracle.trk_run(conf_o, g["e1c"][3], x, 0, 0, 935.0, 330, data_code=g["e1b"][3])
+    conf = trk_conf(**kw)
+    set_symbol_sync(conf, 1, GALILEO_E1_C_SECONDARY_CODE, has_secondary=True)
+    loop = TrackingLoop(conf, 1, 8184, device=gpu)
+    loop.set_stream_host(x)
+    loop.start(0, g["e1c"][3], 0, 0, 935.0, data_code=g["e1b"][3])
+    rec, done = loop.run(330)
+    rec = rec[0]
+    assert len(rec) == len(ora)
+    assert [r.state for r in rec] == [r.state for r in ora]
+    assert [r.symbol_flags for r in rec] == [r.symbol_flags for r in ora]
+    first4 = [r.state for r in rec].index(4)
+    got = "".join("1" if r.p_data_accu[0] > 0 else "0" for r in rec[first4:])
+    exp = "".join("1" if r.p_data_accu[0] > 0 else "0" for r in ora[first4:])
+    assert got == exp
+    # (the last periods include the half-cycle turn after the switch to the four-quadrant discriminator: compare with the oracle loop)
+    assert abs(np.mean([r.carrier_doppler_hz for r in rec[-40:]]) - np.mean([r.carrier_doppler_hz for r in ora[-40:]])) < 0.5
+    assert abs(np.mean([r.carrier_doppler_hz for r in rec[200:250]]) - 940.0) < 1.5
+    loop.close()
