@@ -68,6 +68,15 @@ struct LockState  // what cn0_and_tracking_lock_status keeps between periods (tr
     int current_symbol, current_data_symbol, flag_pll_180, acc_phase_initialized;
     float p_data_accu[2];
     float ring[2 * GSH_MAX_SECONDARY];
+    // extended integration (states 3 / 4, trk.cc:2114-2149, 2156-2195, 2241-2251)
+    float2 accv[5];            // d_VE_accu .. d_VL_accu across the coherent integration
+    int ext_count;             // d_extend_correlation_symbols_count
+    int narrow;                // narrow loop filters / correlator spacing are in force
+    float spc_now;             // d_trk_parameters.spc
+    double corr_time;          // d_current_correlation_time_s
+    float dll_narrow_in_c[4], dll_narrow_out_c[4];  // Tracking_loop_filter coefficients for (extend * period, dll_bw_narrow_hz), designed at start
+    int dll_narrow_n_in, dll_narrow_n_out;
+    FllPllState pll_narrow;    // Tracking_FLL_PLL_filter::set_params(fll_bw_hz, pll_bw_narrow_hz, order): coefficients only
 };
 
 struct TrkChannel  // loop state of one channel, resident in device memory between launches
@@ -287,6 +296,7 @@ struct NextWindow  // what thread 0 publishes for the next correlation (do_corre
     unsigned long long pos;
     float rem_carr, phase_step, rem_code, code_step;
     int go;
+    int narrow;  // correlate with the narrow tap spacing (after extended integration has started)
 };
 
 __device__ __forceinline__ void publish(NextWindow& w, const TrkChannel& s, const gsh_trk_conf& c, unsigned long long n_stream, int more,
@@ -299,6 +309,7 @@ __device__ __forceinline__ void publish(NextWindow& w, const TrkChannel& s, cons
     w.rem_code = __fmul_rn(static_cast<float>(s.rem_code_phase_chips), spcf);
     w.code_step = __fmul_rn(static_cast<float>(s.code_phase_step_chips), spcf);
     w.go = (more && s.active && s.pos + c.vector_length <= n_stream && s.pos >= ring_oldest) ? 1 : 0;
+    w.narrow = 0;  // the caller overrides it from the channel's LockState
 }
 
 template <int NT>
@@ -322,28 +333,41 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
             if (c.track_pilot) stage_code_table(tab_data, a.codes + (static_cast<size_t>(ch) * 2 + 1) * a.code_stride, code_len);
         }
 
-    // ---- tap offsets in code samples, trk.cc:632-648 / :829-840
-    float sh[NT];
+    // ---- tap offsets in code samples, trk.cc:632-648 / :829-840 (wide) and :2130-2148 (narrow)
+    float sh_w[NT], sh_n[NT];
     const float spcf = static_cast<float>(c.code_samples_per_chip);
     if (NT == 5)
         {
-            sh[0] = -c.very_early_late_space_chips * spcf;
-            sh[1] = -c.early_late_space_chips * spcf;
-            sh[2] = 0.0f;
-            sh[NT - 2] = c.early_late_space_chips * spcf;
-            sh[NT - 1] = c.very_early_late_space_chips * spcf;
+            sh_w[0] = -c.very_early_late_space_chips * spcf;
+            sh_w[1] = -c.early_late_space_chips * spcf;
+            sh_w[2] = 0.0f;
+            sh_w[NT - 2] = c.early_late_space_chips * spcf;
+            sh_w[NT - 1] = c.very_early_late_space_chips * spcf;
+            sh_n[0] = -c.very_early_late_space_narrow_chips * spcf;
+            sh_n[1] = -c.early_late_space_narrow_chips * spcf;
+            sh_n[2] = 0.0f;
+            sh_n[NT - 2] = c.early_late_space_narrow_chips * spcf;
+            sh_n[NT - 1] = c.very_early_late_space_narrow_chips * spcf;
         }
     else
         {
-            sh[0] = -c.early_late_space_chips * spcf;
-            sh[1] = 0.0f;
-            sh[NT - 1] = c.early_late_space_chips * spcf;
+            sh_w[0] = -c.early_late_space_chips * spcf;
+            sh_w[1] = 0.0f;
+            sh_w[NT - 1] = c.early_late_space_chips * spcf;
+            sh_n[0] = -c.early_late_space_narrow_chips * spcf;
+            sh_n[1] = 0.0f;
+            sh_n[NT - 1] = c.early_late_space_narrow_chips * spcf;
         }
     const float sh_data[1] = {0.0f};
     constexpr int PROMPT = NT / 2;
-    const double corr_time = static_cast<double>(c.code_length_chips) / c.code_chip_rate;  // d_current_correlation_time_s = d_code_period, trk.cc:841
+    const double code_period = static_cast<double>(c.code_length_chips) / c.code_chip_rate;  // d_code_period
+    const int extend = (c.enable_symbol_sync && c.extend_correlation_symbols > 1) ? c.extend_correlation_symbols : 1;
 
-    if (tid == 0) publish(win, s, c, a.n_stream, a.n_epochs > 0, a.ring_oldest);
+    if (tid == 0)
+        {
+            publish(win, s, c, a.n_stream, a.n_epochs > 0, a.ring_oldest);
+            win.narrow = a.lock[ch].narrow;
+        }
     __syncthreads();
 
     int done = 0;
@@ -353,6 +377,9 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
             const unsigned long long pos = win.pos;
             const unsigned long long wpos = a.ring_capacity ? pos % a.ring_capacity : pos;  // where the window sits in memory
             const float rem_carr = win.rem_carr, phase_step = win.phase_step, rem_code = win.rem_code, code_step = win.code_step;
+            float sh[NT];
+#pragma unroll
+            for (int t = 0; t < NT; t++) sh[t] = win.narrow ? sh_n[t] : sh_w[t];
             correlate_window_std<NT>(a.stream, wpos, static_cast<int>(c.vector_length), tab, code_len, sh, rem_carr, phase_step, rem_code, code_step, red);
             float2 out[NT];
 #pragma unroll
@@ -376,7 +403,7 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
 #pragma unroll
                     for (int t = 0; t < NT; t++) acc[t] = out[t];
                     const int run_state = c.enable_symbol_sync ? lk.state : 0;
-                    if (run_state == 4)
+                    if (run_state == 3 || run_state == 4)
                         {
                             float sgn = 1.0f;
                             if (c.has_secondary)
@@ -387,8 +414,9 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
 #pragma unroll
                             for (int t = 0; t < NT; t++)
                                 {
-                                    acc[t].x = __fadd_rn(0.0f, __fmul_rn(sgn, out[t].x));
-                                    acc[t].y = __fadd_rn(0.0f, __fmul_rn(sgn, out[t].y));
+                                    lk.accv[t].x = __fadd_rn(lk.accv[t].x, __fmul_rn(sgn, out[t].x));  // the float += / -= of trk.cc:1493-1512
+                                    lk.accv[t].y = __fadd_rn(lk.accv[t].y, __fmul_rn(sgn, out[t].y));
+                                    acc[t] = lk.accv[t];
                                 }
                             const float2 pd = c.track_pilot ? pdata : out[PROMPT];
                             if (c.symbols_per_bit > 1)
@@ -414,6 +442,8 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
                             lk.cloop = c.track_pilot ? 0 : 1;  // trk.cc:1587-1595
                         }
                     const bool cloop_now = c.enable_symbol_sync ? (lk.cloop != 0) : (c.cloop != 0);
+                    const double corr_time = (c.enable_symbol_sync && lk.corr_time > 0.0) ? lk.corr_time : code_period;  // d_current_correlation_time_s
+                    const float spc_now = (c.enable_symbol_sync && lk.narrow) ? lk.spc_now : c.spc;
                     const float2 P = acc[PROMPT], E = acc[PROMPT - 1], L = acc[PROMPT + 1];
                     float rec_cn0 = 0.0f;
                     double rec_lock_test = 0.0;
@@ -426,7 +456,8 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
                                     lk.carrier_lock_fail_counter = 0;
                                     lk.code_lock_fail_counter = 0;
                                 }
-                            lost = !lock_status_d(lk, c, P, corr_time, pull_in);  // trk.cc:2008
+                            if (run_state != 3)  // coherent integration runs no lock test (trk.cc:2156-2161)
+                                lost = !lock_status_d(lk, c, P, run_state == 4 ? code_period * static_cast<double>(extend) : code_period, pull_in);  // trk.cc:2008, :2203
                             rec_cn0 = lk.cn0_db_hz;
                             rec_lock_test = lk.carrier_lock_test;
                         }
@@ -456,9 +487,11 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
                         }
                     else
                         {
-                    // ---- run_dll_pll, trk.cc:1260-1324
-                    const double carr_phase_error_hz = (cloop_now ? pll_cloop_two_quadrant_atan_d(P) : pll_four_quadrant_atan_d(P)) / GNSS_TWO_PI_D;
-                    double carr_freq_error_hz = 0.0;
+                    // ---- run_dll_pll, trk.cc:1260-1324 (skipped during coherent integration, state 3: trk.cc:2156-2161)
+                    double carr_phase_error_hz = 0.0, carr_freq_error_hz = 0.0, carr_error_filt_hz = 0.0, code_error_chips = 0.0, code_error_filt_chips = 0.0;
+                    if (run_state != 3)
+                        {
+                    carr_phase_error_hz = (cloop_now ? pll_cloop_two_quadrant_atan_d(P) : pll_four_quadrant_atan_d(P)) / GNSS_TWO_PI_D;
                     float carr_error_filt;
                     if ((pull_in && c.enable_fll_pull_in) || c.enable_fll_steady_state)
                         {
@@ -474,16 +507,16 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
                         {
                             carr_error_filt = fll_pll_carrier_error(s.pll, 0.0f, static_cast<float>(carr_phase_error_hz), static_cast<float>(corr_time));
                         }
-                    const double carr_error_filt_hz = carr_error_filt;
+                    carr_error_filt_hz = carr_error_filt;
                     s.carrier_doppler_hz = carr_error_filt_hz;
-                    double code_error_chips;
                     if (NT == 5)
                         code_error_chips = dll_nc_vemlp_normalized_d(acc[0], acc[1], acc[NT - 2], acc[NT - 1]);
                     else
-                        code_error_chips = dll_nc_e_minus_l_normalized_d(E, L, c.spc, c.slope, c.y_intercept);
-                    const double code_error_filt_chips = loop_filter_apply(s.dll, static_cast<float>(code_error_chips));
+                        code_error_chips = dll_nc_e_minus_l_normalized_d(E, L, spc_now, c.slope, c.y_intercept);
+                    code_error_filt_chips = loop_filter_apply(s.dll, static_cast<float>(code_error_chips));
                     s.code_freq_chips = c.code_chip_rate - code_error_filt_chips;
                     if (c.carrier_aiding) s.code_freq_chips += s.carrier_doppler_hz * c.code_chip_rate / c.signal_carrier_freq;
+                        }
 
                     // ---- update_tracking_vars, trk.cc:1409-1483 (rate terms are zero outside high_dyn)
                     const double t_chip = 1.0 / s.code_freq_chips;
@@ -503,7 +536,25 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
                     // ---- symbol synchronisation (state 2, trk.cc:2026-2112) / symbol output (state 4, :2205-2246)
                     int rec_symbol_flags = 0;
                     float rec_pdata[2] = {0.0f, 0.0f};
-                    if (c.enable_symbol_sync)
+                    if (c.enable_symbol_sync && run_state == 3)
+                        {
+                            // trk.cc:2162-2194: a telemetry symbol may complete inside the coherent integration; then count the period
+                            rec_pdata[0] = lk.p_data_accu[0];
+                            rec_pdata[1] = lk.p_data_accu[1];
+                            if (lk.current_data_symbol == 0)
+                                {
+                                    rec_symbol_flags |= 1;
+                                    lk.p_data_accu[0] = lk.p_data_accu[1] = 0.0f;
+                                }
+                            if (lk.flag_pll_180) rec_symbol_flags |= 2;
+                            lk.ext_count++;
+                            if (lk.ext_count == extend - 1)
+                                {
+                                    lk.ext_count = 0;
+                                    lk.state = 4;
+                                }
+                        }
+                    else if (c.enable_symbol_sync)
                         {
                             if (run_state == 2)
                                 {
@@ -556,7 +607,32 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
                                             lk.ring_count = lk.ring_head = 0;
                                             lk.current_symbol = 0;
                                             lk.current_data_symbol = 0;
-                                            lk.state = 4;
+#pragma unroll
+                                            for (int t = 0; t < 5; t++) lk.accv[t] = make_float2(0.0f, 0.0f);
+                                            if (extend > 1)  // trk.cc:2114-2149: stretch the integration, narrow the loops and the correlator spacing
+                                                {
+                                                    lk.ext_count = 0;
+                                                    lk.corr_time = static_cast<double>(__fmul_rn(static_cast<float>(extend), static_cast<float>(code_period)));
+                                                    lk.state = 3;
+#pragma unroll
+                                                    for (int k = 0; k < 4; k++)  // update_coefficients keeps the filter memories
+                                                        {
+                                                            s.dll.in_c[k] = lk.dll_narrow_in_c[k];
+                                                            s.dll.out_c[k] = lk.dll_narrow_out_c[k];
+                                                        }
+                                                    s.dll.n_in = lk.dll_narrow_n_in;
+                                                    s.dll.n_out = lk.dll_narrow_n_out;
+                                                    const float keep_w = s.pll.w, keep_x = s.pll.x;  // set_params keeps d_pll_w / d_pll_x
+                                                    s.pll = lk.pll_narrow;
+                                                    s.pll.w = keep_w;
+                                                    s.pll.x = keep_x;
+                                                    lk.narrow = 1;
+                                                    lk.spc_now = c.early_late_space_narrow_chips;
+                                                }
+                                            else
+                                                {
+                                                    lk.state = 4;
+                                                }
                                         }
                                 }
                             else
@@ -573,6 +649,9 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
                                             rec_symbol_flags |= 1;
                                             lk.p_data_accu[0] = lk.p_data_accu[1] = 0.0f;
                                         }
+#pragma unroll
+                                    for (int t = 0; t < 5; t++) lk.accv[t] = make_float2(0.0f, 0.0f);  // trk.cc:2241-2246
+                                    if (extend > 1) lk.state = 3;                                     // trk.cc:2247-2250
                                 }
                             if (lk.flag_pll_180) rec_symbol_flags |= 2;
                         }
@@ -611,6 +690,7 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
                         }
                     s.pos = pos + static_cast<unsigned long long>(prn_len);  // consume_each, trk.cc:2287
                     publish(win, s, c, a.n_stream, e + 1 < a.n_epochs, a.ring_oldest);
+                    win.narrow = lk.narrow;
                         }
                 }
             done = e + 1;
@@ -818,6 +898,7 @@ extern "C"
                 GSH_REQUIRE(c.data_secondary_code_length >= 0 && c.data_secondary_code_length <= GSH_MAX_SECONDARY, "data_secondary_code_length %d outside 0..%d", c.data_secondary_code_length, GSH_MAX_SECONDARY);
                 GSH_REQUIRE(!c.has_secondary || c.secondary_code_length >= 1, "has_secondary needs a secondary code");
                 GSH_REQUIRE(c.symbols_per_bit >= 0, "symbols_per_bit %d", c.symbols_per_bit);
+                GSH_REQUIRE(c.extend_correlation_symbols >= 0 && c.extend_correlation_symbols <= 1000, "extend_correlation_symbols %d", c.extend_correlation_symbols);
             }
         if (c.enable_lock_detectors)
             {
@@ -985,6 +1066,21 @@ extern "C"
         init_smoother(lk.cn0_smoother, c.cn0_smoother_alpha, cn0_init, 25.0F, 12.0F);                        // class defaults, T/exponential_smoother.h:64-65
         init_smoother(lk.carrier_lock_test_smoother, c.carrier_lock_test_smoother_alpha, c.carrier_lock_test_smoother_samples, -1.0F, 0.0F);  // trk.cc:688-692
         lk.pull_in_latched = 1;
+        if (c.enable_symbol_sync && c.extend_correlation_symbols > 1)
+            {
+                // what set_update_interval / set_noise_bandwidth / set_params will install when extended integration starts (trk.cc:2126-2129)
+                const float t_ext = static_cast<float>(c.extend_correlation_symbols) * static_cast<float>(code_period);
+                gsh::LoopFilterState nd;
+                gsh::design_loop_filter(nd, t_ext, c.dll_bw_narrow_hz, c.dll_filter_order, false);
+                for (int k = 0; k < 4; k++)
+                    {
+                        lk.dll_narrow_in_c[k] = nd.in_c[k];
+                        lk.dll_narrow_out_c[k] = nd.out_c[k];
+                    }
+                lk.dll_narrow_n_in = nd.n_in;
+                lk.dll_narrow_n_out = nd.n_out;
+                gsh::design_fll_pll(lk.pll_narrow, c.fll_bw_hz, c.pll_bw_narrow_hz, c.pll_filter_order, 0.0F);
+            }
         lk.state = 2;            // pull-in hands over to state 2 (trk.cc:1963)
         lk.cloop = c.cloop;      // d_cloop = true at start_tracking (trk.cc:1072); conf.cloop lets a caller start four-quadrant
         GSH_HIP(hipMemcpyAsync(t->d_lock + channel, &lk, sizeof(lk), hipMemcpyHostToDevice, t->stream));

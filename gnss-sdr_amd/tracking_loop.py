@@ -26,7 +26,10 @@ def trk_conf(**kw) -> TrkConf:
              enable_lock_detectors=0, cn0_samples=20, cn0_min=25, max_code_lock_fail=50, max_carrier_lock_fail=5000,
              cn0_smoother_samples=200, carrier_lock_test_smoother_samples=25, cn0_smoother_alpha=0.002,
              carrier_lock_test_smoother_alpha=0.002, carrier_lock_th=0.7,
-             enable_symbol_sync=0, symbols_per_bit=0, has_secondary=0, secondary_code_length=0, data_secondary_code_length=0)
+             enable_symbol_sync=0, symbols_per_bit=0, has_secondary=0, secondary_code_length=0, data_secondary_code_length=0,
+             # extended integration: Dll_Pll_Conf defaults (dll_pll_conf.h:49-54, 68)
+             extend_correlation_symbols=1, pll_bw_narrow_hz=5.0, dll_bw_narrow_hz=0.75, early_late_space_narrow_chips=0.15,
+             very_early_late_space_narrow_chips=0.5)
     d.update(kw)
     for k, v in d.items():
         setattr(c, k, v)

@@ -30,7 +30,7 @@ extern "C"
 {
 #endif
 
-#define GSH_ABI_VERSION 6
+#define GSH_ABI_VERSION 7
 #define GSH_MAX_TAPS 8 /* VE/E/P/L/VL needs 5 (trk.cc:609-650); 8 leaves room for multi-tap dumps */
 
     enum
@@ -230,16 +230,22 @@ extern "C"
         /* symbol synchronisation and the narrow-tracking state (trk.cc:2026-2104 and state 4, :2197-2252); 0 = the loop stays in state 2.
          * Per-signal values as the block's constructor sets them (trk.cc:196-300): GPS L1 C/A symbols_per_bit 20, secondary_code = the
          * 160-symbol telemetry preamble (GPS_CA_PREAMBLE_SYMBOLS_STR), has_secondary 0; Galileo E1 pilot symbols_per_bit 1,
-         * secondary_code = the 25-chip E1C code, has_secondary 1; GPS L5 the NH codes.  The histogram bit synchroniser and extended
-         * integration (state 3) are not modelled. */
+         * secondary_code = the 25-chip E1C code, has_secondary 1; GPS L5 the NH codes.  extend_correlation_symbols > 1 adds the coherent
+         * integration of trk.cc:2114-2149, 2156-2195: after synchronisation the loop filters are re-parameterised (dll_bw_narrow_hz and
+         * pll_bw_narrow_hz over the stretched update interval, filter memories kept), the correlator spacing narrows, and the loop closes
+         * once every extend_correlation_symbols periods on the accumulated correlators.  The histogram bit synchroniser is not modelled. */
         int32_t enable_symbol_sync;
         int32_t symbols_per_bit;         /* d_symbols_per_bit */
         int32_t has_secondary;           /* d_secondary: in state 4 the correlators are multiplied by the secondary code chip */
         int32_t secondary_code_length;   /* d_secondary_code_length, <= GSH_MAX_SECONDARY */
         int32_t data_secondary_code_length; /* d_data_secondary_code_length */
-        int32_t pad_sync_;
+        int32_t extend_correlation_symbols; /* Dll_Pll_Conf::extend_correlation_symbols (1) */
         uint8_t secondary_code[200];     /* characters '0' / '1' (d_secondary_code_string) */
         uint8_t data_secondary_code[200];
+        float pll_bw_narrow_hz;          /* (5.0)  dll_pll_conf.h:49 */
+        float dll_bw_narrow_hz;          /* (0.75) */
+        float early_late_space_narrow_chips;      /* (0.15) */
+        float very_early_late_space_narrow_chips; /* (0.5) */
     } gsh_trk_conf;
 #define GSH_MAX_CN0_SAMPLES 64
 #define GSH_MAX_SECONDARY 200
@@ -258,7 +264,8 @@ extern "C"
         double carrier_doppler_hz, code_freq_chips, carr_phase_error_hz, carr_freq_error_hz, carr_error_filt_hz;
         double code_error_chips, code_error_filt_chips, rem_code_phase_samples, acc_carrier_phase_rad;
         double carrier_lock_test;        /* d_carrier_lock_test */
-        int32_t state;                   /* d_state the period ran in: 2 wide tracking / symbol search, 4 narrow tracking (0 with symbol sync off) */
+        int32_t state;                   /* d_state the period ran in: 2 wide tracking / symbol search, 3 coherent integration (no loop update:
+                                            the loop fields of the record are 0), 4 narrow tracking (0 with symbol sync off) */
         int32_t symbol_flags;            /* bit 0: Flag_valid_symbol_output (a telemetry symbol leaves the block, trk.cc:2212-2236);
                                             bit 1: Flag_PLL_180_deg_phase_locked (trk.cc:1148-1156) */
         float p_data_accu[2];            /* d_P_data_accu: Prompt_I / Prompt_Q of the symbol when bit 0 is set, else the running sum */

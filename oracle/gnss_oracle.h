@@ -160,9 +160,11 @@ extern "C"
         int32_t has_secondary;               /* d_secondary */
         int32_t secondary_code_length;       /* d_secondary_code_length (the telemetry preamble for signals without a secondary code) */
         int32_t data_secondary_code_length;  /* d_data_secondary_code_length */
-        int32_t pad_sync_;
+        int32_t extend_correlation_symbols;  /* Dll_Pll_Conf::extend_correlation_symbols; > 1 enables extended integration (states 3/4) */
         uint8_t secondary_code[ORACLE_MAX_SECONDARY];       /* characters '0' / '1' */
         uint8_t data_secondary_code[ORACLE_MAX_SECONDARY];
+        /* narrow-tracking parameters applied when extended integration starts (trk.cc:2126-2149; dll_pll_conf.h:49-54) */
+        float pll_bw_narrow_hz, dll_bw_narrow_hz, early_late_space_narrow_chips, very_early_late_space_narrow_chips;
     } oracle_trk_conf;
     void oracle_lock_init(oracle_lock_state* st, const oracle_trk_conf* c);
     /* cn0_and_tracking_lock_status, trk.cc:1167-1224: returns 1 while locked, 0 when loss of lock is declared */

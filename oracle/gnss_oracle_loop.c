@@ -504,7 +504,7 @@ int oracle_trk_run(const oracle_trk_conf* c, const float* code, const float* dat
     double rem_code_phase_samples = 0.0, rem_code_phase_chips = 0.0, acc_carrier_phase_rad = 0.0;
     float rem_carr_phase_rad = 0.0F;
     float p_old_re = 0.0F, p_old_im = 0.0F;  /* d_P_accu_old */
-    const double corr_time = code_period;    /* d_current_correlation_time_s, trk.cc:841 */
+    double corr_time = code_period;          /* d_current_correlation_time_s, trk.cc:841; extended integration stretches it (:2118) */
     uint64_t pos = start_sample;
     oracle_lock_state lock;
     int pull_in_latched = 1;  /* d_pull_in_transitory, cleared once (trk.cc:1910-1917) */
@@ -514,6 +514,11 @@ int oracle_trk_run(const oracle_trk_conf* c, const float* code, const float* dat
     int ring_count = 0, ring_head = 0;     /* ring_head: index of the oldest element once the buffer is full */
     int current_symbol = 0, current_data_symbol = 0, flag_pll_180 = 0, acc_phase_initialized = 0;
     float p_data_accu[2] = {0.0F, 0.0F};
+    /* extended integration (states 3 / 4, trk.cc:2114-2149, 2156-2195, 2241-2251) */
+    const int extend = (c->enable_symbol_sync && c->extend_correlation_symbols > 1) ? c->extend_correlation_symbols : 1;
+    float accv[10] = {0};  /* d_VE_accu .. d_VL_accu */
+    int ext_count = 0;     /* d_extend_correlation_symbols_count */
+    float spc_now = c->spc;
     if (c->enable_symbol_sync && (c->secondary_code_length < 0 || c->secondary_code_length > ORACLE_MAX_SECONDARY ||
                                      c->data_secondary_code_length < 0 || c->data_secondary_code_length > ORACLE_MAX_SECONDARY))
         return -1;
@@ -546,7 +551,7 @@ int oracle_trk_run(const oracle_trk_conf* c, const float* code, const float* dat
                     r->prompt_data[1] = pd[1];
                 }
             r->state = state;
-            if (state == 4)
+            if (state == 3 || state == 4)
                 {
                     /* save_correlation_results, trk.cc:1486-1596, into accumulators that were zeroed at the end of the previous period
                      * (:2241-2246): the correlators enter the loop multiplied by the secondary code chip */
@@ -556,7 +561,11 @@ int oracle_trk_run(const oracle_trk_conf* c, const float* code, const float* dat
                             sgn = c->secondary_code[current_symbol] == '0' ? 1.0F : -1.0F;
                             current_symbol = (current_symbol + 1) % c->secondary_code_length;
                         }
-                    for (int t = 0; t < 2 * n_taps; t++) out[t] = 0.0F + sgn * out[t];  /* 0 + x or 0 - x: the float += / -= of :1493-1512 */
+                    for (int t = 0; t < 2 * n_taps; t++)
+                        {
+                            accv[t] = accv[t] + sgn * out[t];  /* the float += / -= of :1493-1512 */
+                            out[t] = accv[t];                  /* the loop works on the accumulators from here on */
+                        }
                     const float* pd = (c->track_pilot && data_code) ? r->prompt_data : (const float*)(r->corr + 2 * prompt);
                     if (c->symbols_per_bit > 1)
                         {
@@ -584,6 +593,8 @@ int oracle_trk_run(const oracle_trk_conf* c, const float* code, const float* dat
             const float* P = out + 2 * prompt;
             const float* E = out + 2 * (prompt - 1);
             const float* L = out + 2 * (prompt + 1);
+            double carr_phase_error_hz = 0.0, carr_freq_error_hz = 0.0, carr_error_filt_hz = 0.0, code_error_chips = 0.0, code_error_filt_chips = 0.0;
+            if (state == 3) goto update_vars;  /* coherent integration: no lock test, no loop update (trk.cc:2156-2161) */
             if (c->enable_lock_detectors)
                 {
                     if (pull_in_latched && !pull_in)  /* trk.cc:1912-1916: leaving the pull-in transitory clears both fail counters */
@@ -592,7 +603,7 @@ int oracle_trk_run(const oracle_trk_conf* c, const float* code, const float* dat
                             lock.carrier_lock_fail_counter = 0;
                             lock.code_lock_fail_counter = 0;
                         }
-                    const int locked = oracle_lock_status(&lock, c, P[0], P[1], code_period, pull_in);  /* trk.cc:2008 */
+                    const int locked = oracle_lock_status(&lock, c, P[0], P[1], state == 4 ? code_period * (double)extend : code_period, pull_in);  /* trk.cc:2008, :2203 */
                     r->cn0_db_hz = lock.cn0_db_hz;
                     r->carrier_lock_test = lock.carrier_lock_test;
                     if (!locked)  /* trk.cc:2009-2014: clear_tracking_vars, d_state = 0 */
@@ -605,7 +616,7 @@ int oracle_trk_run(const oracle_trk_conf* c, const float* code, const float* dat
                 }
 
             /* run_dll_pll, trk.cc:1260-1324 */
-            double carr_phase_error_hz, carr_freq_error_hz = 0.0;
+            {
             float carr_error_filt;
             if (cloop)
                 carr_phase_error_hz = oracle_pll_cloop_two_quadrant_atan(P[0], P[1]) / ORA_TWO_PI;
@@ -625,17 +636,18 @@ int oracle_trk_run(const oracle_trk_conf* c, const float* code, const float* dat
                 {
                     carr_error_filt = oracle_fll_pll_carrier_error(&pll, 0, (float)carr_phase_error_hz, (float)corr_time);
                 }
-            const double carr_error_filt_hz = carr_error_filt;
+            carr_error_filt_hz = carr_error_filt;
             carrier_doppler_hz = carr_error_filt_hz;
-            double code_error_chips;
             if (c->veml)
                 code_error_chips = oracle_dll_nc_vemlp_normalized(out[0], out[1], out[2], out[3], out[6], out[7], out[8], out[9]);
             else
-                code_error_chips = oracle_dll_nc_e_minus_l_normalized(E[0], E[1], L[0], L[1], c->spc, c->slope, c->y_intercept);
-            const double code_error_filt_chips = oracle_loop_filter_apply(&dll, (float)code_error_chips);
+                code_error_chips = oracle_dll_nc_e_minus_l_normalized(E[0], E[1], L[0], L[1], spc_now, c->slope, c->y_intercept);
+            code_error_filt_chips = oracle_loop_filter_apply(&dll, (float)code_error_chips);
             code_freq_chips = c->code_chip_rate - code_error_filt_chips;
             if (c->carrier_aiding) code_freq_chips += carrier_doppler_hz * c->code_chip_rate / c->signal_carrier_freq;
+            }
 
+        update_vars:;
             /* update_tracking_vars, trk.cc:1409-1483 */
             const double t_chip = 1.0 / code_freq_chips;
             const double t_prn = t_chip * (double)c->code_length_chips;
@@ -663,7 +675,25 @@ int oracle_trk_run(const oracle_trk_conf* c, const float* code, const float* dat
             r->rem_code_phase_samples = rem_code_phase_samples;
             r->acc_carrier_phase_rad = acc_carrier_phase_rad;
             r->rem_carr_phase_rad = rem_carr_phase_rad;
-            if (c->enable_symbol_sync)
+            if (c->enable_symbol_sync && state == 3)
+                {
+                    /* trk.cc:2162-2194: a telemetry symbol may complete inside the coherent integration; then count the period */
+                    r->p_data_accu[0] = p_data_accu[0];
+                    r->p_data_accu[1] = p_data_accu[1];
+                    if (current_data_symbol == 0)
+                        {
+                            r->symbol_flags |= 1;
+                            p_data_accu[0] = p_data_accu[1] = 0.0F;
+                        }
+                    if (flag_pll_180) r->symbol_flags |= 2;
+                    ext_count++;
+                    if (ext_count == extend - 1)
+                        {
+                            ext_count = 0;
+                            state = 4;
+                        }
+                }
+            else if (c->enable_symbol_sync)
                 {
                     if (state == 2)
                         {
@@ -717,7 +747,41 @@ int oracle_trk_run(const oracle_trk_conf* c, const float* code, const float* dat
                                     ring_count = ring_head = 0;
                                     current_symbol = 0;
                                     current_data_symbol = 0;
-                                    state = 4;
+                                    for (int t = 0; t < 10; t++) accv[t] = 0.0F;
+                                    if (extend > 1)  /* trk.cc:2114-2149: stretch the integration time, narrow the loops and the correlator spacing */
+                                        {
+                                            ext_count = 0;
+                                            corr_time = (double)((float)extend * (float)code_period);
+                                            state = 3;
+                                            oracle_loop_filter narrow_dll;
+                                            oracle_loop_filter_design(&narrow_dll, (float)corr_time, c->dll_bw_narrow_hz, c->dll_filter_order, 0);
+                                            memcpy(dll.in_c, narrow_dll.in_c, sizeof(dll.in_c));   /* update_coefficients keeps the histories (T/tracking_loop_filter.cc:101-196) */
+                                            memcpy(dll.out_c, narrow_dll.out_c, sizeof(dll.out_c));
+                                            dll.n_in = narrow_dll.n_in;
+                                            dll.n_out = narrow_dll.n_out;
+                                            oracle_fll_pll_filter narrow_pll;
+                                            oracle_fll_pll_design(&narrow_pll, c->fll_bw_hz, c->pll_bw_narrow_hz, c->pll_filter_order);  /* set_params keeps d_pll_w / d_pll_x */
+                                            narrow_pll.w = pll.w;
+                                            narrow_pll.x = pll.x;
+                                            pll = narrow_pll;
+                                            if (c->veml)
+                                                {
+                                                    shifts[0] = -c->very_early_late_space_narrow_chips * spcf;
+                                                    shifts[1] = -c->early_late_space_narrow_chips * spcf;
+                                                    shifts[3] = c->early_late_space_narrow_chips * spcf;
+                                                    shifts[4] = c->very_early_late_space_narrow_chips * spcf;
+                                                }
+                                            else
+                                                {
+                                                    shifts[0] = -c->early_late_space_narrow_chips * spcf;
+                                                    shifts[2] = c->early_late_space_narrow_chips * spcf;
+                                                }
+                                            spc_now = c->early_late_space_narrow_chips;
+                                        }
+                                    else
+                                        {
+                                            state = 4;
+                                        }
                                 }
                         }
                     else
@@ -736,6 +800,8 @@ int oracle_trk_run(const oracle_trk_conf* c, const float* code, const float* dat
                                     r->symbol_flags |= 1;
                                     p_data_accu[0] = p_data_accu[1] = 0.0F;
                                 }
+                            for (int t = 0; t < 10; t++) accv[t] = 0.0F;  /* :2241-2246 reset extended correlator */
+                            if (extend > 1) state = 3;                  /* :2247-2250 */
                         }
                     if (flag_pll_180) r->symbol_flags |= 2;
                 }

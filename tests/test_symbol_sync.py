@@ -135,3 +135,71 @@ def test_device_galileo_e1_secondary_lock_matches_oracle(gpu):
     assert abs(np.mean([r.carrier_doppler_hz for r in rec[-40:]]) - np.mean([r.carrier_doppler_hz for r in ora[-40:]])) < 0.5
     assert abs(np.mean([r.carrier_doppler_hz for r in rec[200:250]]) - 940.0) < 1.5
     loop.close()
+
+
+def _gps_extended_kw():
+    x, n, bits, kw = _gps_case()
+    kw = dict(kw, pll_bw_narrow_hz=10.0, dll_bw_narrow_hz=1.0, early_late_space_narrow_chips=0.2)
+    return x, n, bits, kw
+
+
+def test_oracle_gps_l1_extended_integration():
+    """extend_correlation_symbols = 20 (one navigation bit): after bit synchronisation the loop alternates 19 periods of coherent integration
+    (state 3, no loop update) and one period that closes the loop on the 20 ms accumulators (state 4), trk.cc:2114-2195, 2241-2251."""
+    x, n, bits, kw = _gps_extended_kw()
+    conf = oracle.trk_conf(**kw)
+    oracle.set_symbol_sync(conf, 20, GPS_CA_PREAMBLE_SYMBOLS, has_secondary=False)
+    conf.extend_correlation_symbols = 20
+    rec = oracle.trk_run(conf, oracle.ca_code(7), x, 0, 0, -1742.0, 1600)
+    states = [r.state for r in rec]
+    first3 = states.index(3)
+    assert first3 == (54 + 8) * 20 and set(states[:first3]) == {2}
+    assert states[first3:first3 + 40] == ([3] * 19 + [4]) * 2
+    closes = [i for i in range(first3, len(rec)) if states[i] == 4]
+    # the loop closes once per bit, on accumulators 20 times the single-period prompt; the bit leaves in the same period
+    for i in closes[1:8]:
+        p20 = abs(rec[i].p_data_accu[0])
+        p1 = np.mean([np.hypot(r.corr[2], r.corr[3]) for r in rec[i - 19:i + 1]])
+        assert rec[i].symbol_flags & 1 and 0.9 * 20 * p1 < p20 < 1.1 * 20 * p1
+        assert all(not (rec[k].symbol_flags & 1) for k in range(i - 19, i))
+        assert all(rec[k].carr_error_filt_hz == 0.0 and rec[k].prn_length_samples > 0 for k in range(i - 19, i))   # state 3: NCOs frozen, windows advance
+    flip = -1.0 if (rec[-1].symbol_flags & 2) else 1.0
+    got = "".join("1" if flip * rec[i].p_data_accu[0] > 0 else "0" for i in closes)
+    m = len(bits) - 62
+    assert got[:m] == bits[62:] and m >= 15
+    # narrow correlator spacing took effect: early and late sit closer to the prompt (0.2 chip -> ~0.8 of the peak instead of 0.5)
+    i = closes[5]
+    assert np.hypot(rec[i].corr[0], rec[i].corr[1]) > 0.7 * np.hypot(rec[i].corr[2], rec[i].corr[3])
+    assert abs(np.mean([rec[i].carrier_doppler_hz for i in closes[3:]]) + 1750.0) < 1.0
+
+
+@pytest.mark.gpu
+def test_device_gps_l1_extended_integration_matches_oracle(gpu):
+    from gnss_sdr_amd.tracking_loop import TrackingLoop, set_symbol_sync, trk_conf
+    x, n, bits, kw = _gps_extended_kw()
+    conf_o = oracle.trk_conf(**kw)
+    oracle.set_symbol_sync(conf_o, 20, GPS_CA_PREAMBLE_SYMBOLS, has_secondary=False)
+    conf_o.extend_correlation_symbols = 20
+    ora = oracle.trk_run(conf_o, oracle.ca_code(7), x, 0, 0, -1742.0, 1600)
+    conf = trk_conf(**kw)
+    set_symbol_sync(conf, 20, GPS_CA_PREAMBLE_SYMBOLS, has_secondary=False)
+    conf.extend_correlation_symbols = 20
+    loop = TrackingLoop(conf, 1, 1023, device=gpu)
+    loop.set_stream_host(x)
+    loop.start(0, oracle.ca_code(7), 0, 0, -1742.0)
+    rec, _ = loop.run(1250)
+    rec2, _ = loop.run(350)                          # the second launch starts in the middle of a coherent integration
+    rec = rec[0] + rec2[0]
+    assert len(rec) == len(ora)
+    assert [r.state for r in rec] == [r.state for r in ora]
+    assert [r.symbol_flags for r in rec] == [r.symbol_flags for r in ora]
+    closes = [i for i, r in enumerate(ora) if r.state == 4]
+    g = np.array([rec[i].p_data_accu[0] for i in closes])
+    o = np.array([ora[i].p_data_accu[0] for i in closes])
+    assert np.array_equal(np.sign(g), np.sign(o)) and np.max(np.abs(g - o)) < 2e-2 * np.mean(np.abs(o))
+    gd = np.array([rec[i].carrier_doppler_hz for i in closes])
+    od = np.array([ora[i].carrier_doppler_hz for i in closes])
+    assert np.max(np.abs(gd - od)) < 0.5
+    same = sum(1 for a, b in zip(rec, ora) if a.sample_counter == b.sample_counter)
+    assert same >= 0.95 * len(ora)
+    loop.close()
