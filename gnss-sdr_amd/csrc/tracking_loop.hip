@@ -77,6 +77,12 @@ struct LockState  // what cn0_and_tracking_lock_status keeps between periods (tr
     float dll_narrow_in_c[4], dll_narrow_out_c[4];  // Tracking_loop_filter coefficients for (extend * period, dll_bw_narrow_hz), designed at start
     int dll_narrow_n_in, dll_narrow_n_out;
     FllPllState pll_narrow;    // Tracking_FLL_PLL_filter::set_params(fll_bw_hz, pll_bw_narrow_hz, order): coefficients only
+    // HistogramBitSynchronizer (T/bit_synchronizer.{h,cc}) + the block's use of it (trk.cc:2046-2072)
+    int bs_hist[GSH_MAX_BITSYNC_BINS];
+    int bs_total_events, bs_locked, bs_edge_phase, bs_has_last_prompt, bs_has_last_sign, bs_last_sign, bs_has_last_best_bin, bs_last_best_bin, bs_stable_best_count;
+    long long bs_epoch_count, bs_target_epoch;
+    float bs_last_prompt[2];
+    int use_hist, wait_for_bit_edge;
 };
 
 struct TrkChannel  // loop state of one channel, resident in device memory between launches
@@ -289,6 +295,73 @@ __device__ bool lock_status_d(LockState& st, const gsh_trk_conf& c, float2 P, do
             return false;
         }
     return true;
+}
+
+// HistogramBitSynchronizer::update, T/bit_synchronizer.cc:41-124: true on the lock event
+__device__ bool bit_sync_update_d(LockState& b, const gsh_trk_conf& c, float2 p, bool tracking_quality_ok)
+{
+    const int N = c.symbols_per_bit;  // bins() = bit_period_ms / epoch_ms (trk.cc:1397-1398)
+    const int phase = (N > 0) ? static_cast<int>(b.bs_epoch_count % N) : 0;
+    ++b.bs_epoch_count;
+    if (!tracking_quality_ok || (hypotf(p.x, p.y) < c.bs_min_prompt_mag))
+        {
+            b.bs_last_prompt[0] = p.x;
+            b.bs_last_prompt[1] = p.y;
+            b.bs_has_last_prompt = 1;
+            return false;
+        }
+    bool edge_event = false;
+    if (c.bs_use_phase_dot_detector)
+        {
+            if (b.bs_has_last_prompt)
+                {
+                    const float dot = __fadd_rn(__fmul_rn(p.x, b.bs_last_prompt[0]), __fmul_rn(p.y, b.bs_last_prompt[1]));  // Re(Pk conj(Pk-1))
+                    edge_event = static_cast<double>(dot) < 0.0;
+                }
+            b.bs_last_prompt[0] = p.x;
+            b.bs_last_prompt[1] = p.y;
+            b.bs_has_last_prompt = 1;
+        }
+    else
+        {
+            const int sgn = (p.x >= 0.0f) ? +1 : -1;
+            if (b.bs_has_last_sign) edge_event = (sgn != b.bs_last_sign);
+            b.bs_last_sign = sgn;
+            b.bs_has_last_sign = 1;
+        }
+    if (edge_event && N > 0)
+        {
+            ++b.bs_hist[phase];
+            ++b.bs_total_events;
+        }
+    if (!b.bs_locked && (b.bs_total_events >= c.bs_min_events_for_lock))
+        {
+            int best_bin = 0, best_count = N > 0 ? b.bs_hist[0] : 0;
+            for (int i = 1; i < N; i++)
+                if (b.bs_hist[i] > best_count)
+                    {
+                        best_count = b.bs_hist[i];
+                        best_bin = i;
+                    }
+            const double ratio = (b.bs_total_events > 0) ? (static_cast<double>(best_count) / static_cast<double>(b.bs_total_events)) : 0.0;
+            if (!b.bs_has_last_best_bin || (best_bin != b.bs_last_best_bin))
+                {
+                    b.bs_last_best_bin = best_bin;
+                    b.bs_has_last_best_bin = 1;
+                    b.bs_stable_best_count = 1;
+                }
+            else
+                {
+                    ++b.bs_stable_best_count;
+                }
+            if ((ratio >= c.bs_dominance_ratio) && (b.bs_stable_best_count >= c.bs_stable_best_required))
+                {
+                    b.bs_locked = 1;
+                    b.bs_edge_phase = best_bin;
+                    return true;
+                }
+        }
+    return false;
 }
 
 struct NextWindow  // what thread 0 publishes for the next correlation (do_correlation_step's casts, trk.cc:1237-1243)
@@ -561,7 +634,31 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
                                     bool next_state = false;
                                     if (!pull_in)
                                         {
-                                            if (c.has_secondary || c.symbols_per_bit > 1)
+                                            if (!c.has_secondary && c.symbols_per_bit > 1 && lk.use_hist)  // trk.cc:2046-2072
+                                                {
+                                                    const bool lock_event = bit_sync_update_d(lk, c, out[PROMPT], true);
+                                                    if (lock_event)
+                                                        {
+                                                            lk.wait_for_bit_edge = 1;
+                                                            const long long k_now = lk.bs_epoch_count - 1;
+                                                            const int B = c.symbols_per_bit;
+                                                            // epochs_until_next_edge() - 1 (T/bit_synchronizer.cc:164-182)
+                                                            int wait = ((lk.bs_edge_phase - static_cast<int>(k_now % B) + B) % B) - 1;
+                                                            if (wait < 0) wait = wait + B;
+                                                            lk.bs_target_epoch = k_now + wait;
+                                                        }
+                                                    if (lk.wait_for_bit_edge)
+                                                        {
+                                                            const long long k_now = lk.bs_epoch_count - 1;
+                                                            if (k_now == lk.bs_target_epoch)
+                                                                {
+                                                                    next_state = true;
+                                                                    lk.wait_for_bit_edge = 0;
+                                                                    lk.use_hist = 0;  // disabled after its first lock (trk.cc:2067)
+                                                                }
+                                                        }
+                                                }
+                                            if (!next_state && (c.has_secondary || c.symbols_per_bit > 1))
                                                 {
                                                     const int len = c.secondary_code_length;
                                                     if (lk.ring_count < len)  // d_Prompt_circular_buffer.push_back(*d_Prompt)
@@ -596,10 +693,7 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
                                                                 }
                                                         }
                                                 }
-                                            else
-                                                {
-                                                    next_state = true;
-                                                }
+                                            if (!c.has_secondary && c.symbols_per_bit <= 1) next_state = true;  // trk.cc:2091-2094
                                         }
                                     if (next_state)  // trk.cc:2101-2112, 2151-2154 (no extended integration)
                                         {
@@ -898,6 +992,7 @@ extern "C"
                 GSH_REQUIRE(c.data_secondary_code_length >= 0 && c.data_secondary_code_length <= GSH_MAX_SECONDARY, "data_secondary_code_length %d outside 0..%d", c.data_secondary_code_length, GSH_MAX_SECONDARY);
                 GSH_REQUIRE(!c.has_secondary || c.secondary_code_length >= 1, "has_secondary needs a secondary code");
                 GSH_REQUIRE(c.symbols_per_bit >= 0, "symbols_per_bit %d", c.symbols_per_bit);
+                GSH_REQUIRE(!c.use_histogram_bit_sync || c.symbols_per_bit <= GSH_MAX_BITSYNC_BINS, "symbols_per_bit %d exceeds the %d histogram bins", c.symbols_per_bit, GSH_MAX_BITSYNC_BINS);
                 GSH_REQUIRE(c.extend_correlation_symbols >= 0 && c.extend_correlation_symbols <= 1000, "extend_correlation_symbols %d", c.extend_correlation_symbols);
             }
         if (c.enable_lock_detectors)
@@ -1081,6 +1176,9 @@ extern "C"
                 lk.dll_narrow_n_out = nd.n_out;
                 gsh::design_fll_pll(lk.pll_narrow, c.fll_bw_hz, c.pll_bw_narrow_hz, c.pll_filter_order, 0.0F);
             }
+        lk.bs_edge_phase = -1;   // HistogramBitSynchronizer::reset (T/bit_synchronizer.cc:20-38)
+        lk.bs_last_sign = +1;
+        lk.use_hist = (c.enable_symbol_sync && c.use_histogram_bit_sync && !c.has_secondary && c.symbols_per_bit > 1) ? 1 : 0;  // trk.cc:1389
         lk.state = 2;            // pull-in hands over to state 2 (trk.cc:1963)
         lk.cloop = c.cloop;      // d_cloop = true at start_tracking (trk.cc:1072); conf.cloop lets a caller start four-quadrant
         GSH_HIP(hipMemcpyAsync(t->d_lock + channel, &lk, sizeof(lk), hipMemcpyHostToDevice, t->stream));

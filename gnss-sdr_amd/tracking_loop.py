@@ -29,7 +29,11 @@ def trk_conf(**kw) -> TrkConf:
              enable_symbol_sync=0, symbols_per_bit=0, has_secondary=0, secondary_code_length=0, data_secondary_code_length=0,
              # extended integration: Dll_Pll_Conf defaults (dll_pll_conf.h:49-54, 68)
              extend_correlation_symbols=1, pll_bw_narrow_hz=5.0, dll_bw_narrow_hz=0.75, early_late_space_narrow_chips=0.15,
-             very_early_late_space_narrow_chips=0.5)
+             very_early_late_space_narrow_chips=0.5,
+             # histogram bit synchroniser: Dll_Pll_Conf defaults (dll_pll_conf.h:43,60,75-76,88); the block switches it on for signals
+             # without a secondary code and more than one symbol per bit (trk.cc:1389) -- here the caller does
+             use_histogram_bit_sync=0, bs_min_events_for_lock=10, bs_stable_best_required=3, bs_use_phase_dot_detector=1,
+             bs_min_prompt_mag=0.0, bs_dominance_ratio=0.6)
     d.update(kw)
     for k, v in d.items():
         setattr(c, k, v)

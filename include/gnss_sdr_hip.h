@@ -30,7 +30,7 @@ extern "C"
 {
 #endif
 
-#define GSH_ABI_VERSION 7
+#define GSH_ABI_VERSION 8
 #define GSH_MAX_TAPS 8 /* VE/E/P/L/VL needs 5 (trk.cc:609-650); 8 leaves room for multi-tap dumps */
 
     enum
@@ -233,7 +233,9 @@ extern "C"
          * secondary_code = the 25-chip E1C code, has_secondary 1; GPS L5 the NH codes.  extend_correlation_symbols > 1 adds the coherent
          * integration of trk.cc:2114-2149, 2156-2195: after synchronisation the loop filters are re-parameterised (dll_bw_narrow_hz and
          * pll_bw_narrow_hz over the stretched update interval, filter memories kept), the correlator spacing narrows, and the loop closes
-         * once every extend_correlation_symbols periods on the accumulated correlators.  The histogram bit synchroniser is not modelled. */
+         * once every extend_correlation_symbols periods on the accumulated correlators.  use_histogram_bit_sync adds the
+         * HistogramBitSynchronizer of T/bit_synchronizer.cc in front of the preamble search, as the block configures it for signals
+         * without a secondary code and more than one symbol per bit (trk.cc:1387-1406, 2046-2072). */
         int32_t enable_symbol_sync;
         int32_t symbols_per_bit;         /* d_symbols_per_bit */
         int32_t has_secondary;           /* d_secondary: in state 4 the correlators are multiplied by the secondary code chip */
@@ -246,7 +248,15 @@ extern "C"
         float dll_bw_narrow_hz;          /* (0.75) */
         float early_late_space_narrow_chips;      /* (0.15) */
         float very_early_late_space_narrow_chips; /* (0.5) */
+        int32_t use_histogram_bit_sync;  /* d_use_histogram_bit_sync */
+        int32_t bs_min_events_for_lock;  /* (10) dll_pll_conf.h:76 */
+        int32_t bs_stable_best_required; /* (3) */
+        int32_t bs_use_phase_dot_detector; /* (1) */
+        float bs_min_prompt_mag;         /* (0.0) */
+        int32_t pad_bs_;
+        double bs_dominance_ratio;       /* (0.6) */
     } gsh_trk_conf;
+#define GSH_MAX_BITSYNC_BINS 64
 #define GSH_MAX_CN0_SAMPLES 64
 #define GSH_MAX_SECONDARY 200
 

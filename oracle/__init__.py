@@ -49,7 +49,9 @@ class TrkConf(C.Structure):
                 ("cn0_smoother_alpha", C.c_float), ("carrier_lock_test_smoother_alpha", C.c_float), ("carrier_lock_th", C.c_double),
                 ("enable_symbol_sync", C.c_int32), ("symbols_per_bit", C.c_int32), ("has_secondary", C.c_int32), ("secondary_code_length", C.c_int32),
                 ("data_secondary_code_length", C.c_int32), ("extend_correlation_symbols", C.c_int32), ("secondary_code", C.c_uint8 * 200), ("data_secondary_code", C.c_uint8 * 200),
-                ("pll_bw_narrow_hz", C.c_float), ("dll_bw_narrow_hz", C.c_float), ("early_late_space_narrow_chips", C.c_float), ("very_early_late_space_narrow_chips", C.c_float)]
+                ("pll_bw_narrow_hz", C.c_float), ("dll_bw_narrow_hz", C.c_float), ("early_late_space_narrow_chips", C.c_float), ("very_early_late_space_narrow_chips", C.c_float),
+                ("use_histogram_bit_sync", C.c_int32), ("bs_min_events_for_lock", C.c_int32), ("bs_stable_best_required", C.c_int32),
+                ("bs_use_phase_dot_detector", C.c_int32), ("bs_min_prompt_mag", C.c_float), ("pad_bs_", C.c_int32), ("bs_dominance_ratio", C.c_double)]
 
 
 class TrkEpoch(C.Structure):
@@ -164,6 +166,9 @@ def ref():
                     getattr(R, name).restype = C.c_double
                 R.ref_loop_filter_run.argtypes = [C.c_float, C.c_float, C.c_int, C.c_int, C.c_float, _f32p, _f32p, C.c_int]
                 R.ref_fll_pll_filter_run.argtypes = [C.c_float, C.c_float, C.c_int, C.c_float, _f32p, _f32p, C.c_float, _f32p, C.c_int]
+            if hasattr(R, "ref_bit_sync_run"):
+                _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+                R.ref_bit_sync_run.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_float, C.c_int, _f32p, _i32p, C.c_int, _i32p, _i32p, _i32p]
             if hasattr(R, "ref_smoother_run"):  # lock detectors + smoother (added with SURVEY 8f-2)
                 R.ref_cn0_m2m4_estimator.argtypes = [_f32p, C.c_int, C.c_float]
                 R.ref_cn0_m2m4_estimator.restype = C.c_float
@@ -309,6 +314,25 @@ def direct_resampler(x: np.ndarray, fs_in: float, fs_out: float, call_sizes=None
     return out.view(np.complex64)
 
 
+def bit_sync_run(prompts: np.ndarray, bins: int, min_events_for_lock=10, stable_best_required=3, dominance_ratio=0.6, min_prompt_mag=0.0,
+                 use_phase_dot_detector=True, quality_ok=None):
+    """HistogramBitSynchronizer (T/bit_synchronizer.cc) restated in C: -> (lock_event[n], edge_phase[n], epochs_until_next_edge[n])"""
+    L = lib()
+    L.oracle_bit_sync_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_float, C.c_int]
+    L.oracle_bit_sync_init.restype = None
+    L.oracle_bit_sync_update.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_int]
+    L.oracle_bit_sync_epochs_until_next_edge.argtypes = [C.c_void_p]
+    buf = C.create_string_buffer(1024)
+    L.oracle_bit_sync_init(buf, bins, min_events_for_lock, stable_best_required, dominance_ratio, min_prompt_mag, int(use_phase_dot_detector))
+    p = np.ascontiguousarray(prompts, np.complex64)
+    q = np.ones(len(p), np.int32) if quality_ok is None else np.asarray(quality_ok, np.int32)
+    ev, un = np.zeros(len(p), np.int32), np.zeros(len(p), np.int32)
+    for i, v in enumerate(p):
+        ev[i] = L.oracle_bit_sync_update(buf, float(v.real), float(v.imag), int(q[i]))
+        un[i] = L.oracle_bit_sync_epochs_until_next_edge(buf)
+    return ev, un
+
+
 class Smoother(C.Structure):
     """oracle_smoother"""
     _fields_ = [(k, C.c_float) for k in ("alpha", "one_minus_alpha", "old_value", "min_value", "offset", "init_sum")] + [
@@ -348,7 +372,11 @@ def trk_conf(**kw) -> TrkConf:
              enable_symbol_sync=0, symbols_per_bit=0, has_secondary=0, secondary_code_length=0, data_secondary_code_length=0,
              # extended integration: Dll_Pll_Conf defaults (dll_pll_conf.h:49-54, 68)
              extend_correlation_symbols=1, pll_bw_narrow_hz=5.0, dll_bw_narrow_hz=0.75, early_late_space_narrow_chips=0.15,
-             very_early_late_space_narrow_chips=0.5)
+             very_early_late_space_narrow_chips=0.5,
+             # histogram bit synchroniser: Dll_Pll_Conf defaults (dll_pll_conf.h:43,60,75-76,88); the block switches it on for signals
+             # without a secondary code and more than one symbol per bit (trk.cc:1389) -- here the caller does
+             use_histogram_bit_sync=0, bs_min_events_for_lock=10, bs_stable_best_required=3, bs_use_phase_dot_detector=1,
+             bs_min_prompt_mag=0.0, bs_dominance_ratio=0.6)
     d.update(kw)
     for k, v in d.items():
         setattr(c, k, v)

@@ -136,6 +136,25 @@ extern "C"
         double carrier_lock_test;
     } oracle_lock_state;
 
+    /* ---- histogram bit synchroniser (T/bit_synchronizer.{h,cc}) ---------------------------------------------------------- */
+#define ORACLE_MAX_BITSYNC_BINS 64
+    typedef struct oracle_bit_sync
+    {
+        /* Config (T/bit_synchronizer.h:104-137) */
+        int32_t bins, min_events_for_lock, stable_best_required, use_phase_dot_detector;
+        double dominance_ratio;
+        float min_prompt_mag;
+        /* state */
+        int32_t hist[ORACLE_MAX_BITSYNC_BINS];
+        int32_t total_events, locked, edge_phase, has_last_prompt, has_last_sign, last_sign, has_last_best_bin, last_best_bin, stable_best_count;
+        int64_t epoch_count;
+        float last_prompt[2];
+    } oracle_bit_sync;
+    void oracle_bit_sync_init(oracle_bit_sync* b, int bins, int min_events_for_lock, int stable_best_required, double dominance_ratio,
+        float min_prompt_mag, int use_phase_dot_detector);
+    int oracle_bit_sync_update(oracle_bit_sync* b, float p_re, float p_im, int tracking_quality_ok); /* 1 on the lock event */
+    int oracle_bit_sync_epochs_until_next_edge(const oracle_bit_sync* b);
+
     /* same field order as gsh_trk_conf / gsh_trk_epoch (include/gnss_sdr_hip.h) so that one ctypes layout serves both */
     typedef struct oracle_trk_conf
     {
@@ -165,6 +184,11 @@ extern "C"
         uint8_t data_secondary_code[ORACLE_MAX_SECONDARY];
         /* narrow-tracking parameters applied when extended integration starts (trk.cc:2126-2149; dll_pll_conf.h:49-54) */
         float pll_bw_narrow_hz, dll_bw_narrow_hz, early_late_space_narrow_chips, very_early_late_space_narrow_chips;
+        /* histogram bit synchroniser (configure_bit_synchronizer, trk.cc:1387-1406; defaults dll_pll_conf.h:43,60,75-76,88) */
+        int32_t use_histogram_bit_sync, bs_min_events_for_lock, bs_stable_best_required, bs_use_phase_dot_detector;
+        float bs_min_prompt_mag;
+        int32_t pad_bs_;
+        double bs_dominance_ratio;
     } oracle_trk_conf;
     void oracle_lock_init(oracle_lock_state* st, const oracle_trk_conf* c);
     /* cn0_and_tracking_lock_status, trk.cc:1167-1224: returns 1 while locked, 0 when loss of lock is declared */

@@ -306,6 +306,98 @@ int oracle_direct_resampler_work(oracle_direct_resampler_t* r, const float* in_i
     return lcv;
 }
 
+/* ---- histogram bit synchroniser, T/bit_synchronizer.cc ---------------------------------------------------------- */
+void oracle_bit_sync_init(oracle_bit_sync* b, int bins, int min_events_for_lock, int stable_best_required, double dominance_ratio,
+    float min_prompt_mag, int use_phase_dot_detector)
+{
+    memset(b, 0, sizeof(*b));  /* reset(), :20-38 */
+    b->bins = bins > 0 ? bins : 0;
+    b->min_events_for_lock = min_events_for_lock;
+    b->stable_best_required = stable_best_required;
+    b->dominance_ratio = dominance_ratio;
+    b->min_prompt_mag = min_prompt_mag;
+    b->use_phase_dot_detector = use_phase_dot_detector;
+    b->edge_phase = -1;
+    b->last_sign = +1;
+}
+
+int oracle_bit_sync_update(oracle_bit_sync* b, float p_re, float p_im, int tracking_quality_ok)  /* :41-124 */
+{
+    const int N = b->bins;
+    const int phase = (N > 0) ? (int)(b->epoch_count % N) : 0;
+    ++b->epoch_count;  /* always advance: even if gated out the phase stays consistent */
+    if (!tracking_quality_ok || (hypotf(p_re, p_im) < b->min_prompt_mag))
+        {
+            b->last_prompt[0] = p_re;
+            b->last_prompt[1] = p_im;
+            b->has_last_prompt = 1;
+            return 0;
+        }
+    int edge_event = 0;
+    if (b->use_phase_dot_detector)
+        {
+            if (b->has_last_prompt)
+                {
+                    /* dot = Re(Pk * conj(Pk-1)) in complex<float> arithmetic, widened afterwards */
+                    const float dot_f = p_re * b->last_prompt[0] + p_im * b->last_prompt[1];
+                    edge_event = ((double)dot_f < 0.0);
+                }
+            b->last_prompt[0] = p_re;
+            b->last_prompt[1] = p_im;
+            b->has_last_prompt = 1;
+        }
+    else
+        {
+            const int s = (p_re >= 0.0F) ? +1 : -1;
+            if (b->has_last_sign) edge_event = (s != b->last_sign);
+            b->last_sign = s;
+            b->has_last_sign = 1;
+        }
+    if (edge_event && N > 0)
+        {
+            ++b->hist[phase];
+            ++b->total_events;
+        }
+    if (!b->locked && (b->total_events >= b->min_events_for_lock))
+        {
+            int best_bin = 0, best_count = N > 0 ? b->hist[0] : 0;  /* best_bin_and_count, :149-161: first maximum */
+            for (int i = 1; i < N; i++)
+                if (b->hist[i] > best_count)
+                    {
+                        best_count = b->hist[i];
+                        best_bin = i;
+                    }
+            const double ratio = (b->total_events > 0) ? ((double)best_count / (double)b->total_events) : 0.0;
+            if (!b->has_last_best_bin || (best_bin != b->last_best_bin))
+                {
+                    b->last_best_bin = best_bin;
+                    b->has_last_best_bin = 1;
+                    b->stable_best_count = 1;
+                }
+            else
+                {
+                    ++b->stable_best_count;
+                }
+            if ((ratio >= b->dominance_ratio) && (b->stable_best_count >= b->stable_best_required))
+                {
+                    b->locked = 1;
+                    b->edge_phase = best_bin;
+                    return 1;
+                }
+        }
+    return 0;
+}
+
+int oracle_bit_sync_epochs_until_next_edge(const oracle_bit_sync* b)  /* :164-182 */
+{
+    if (!b->locked || b->edge_phase < 0) return -1;
+    const int B = b->bins;
+    if (B <= 0) return -1;
+    const int64_t k_now = b->epoch_count - 1;
+    const int cur_phase = (int)(k_now % B);
+    return (b->edge_phase - cur_phase + B) % B;
+}
+
 /* ---- lock detectors and C/N0 ---------------------------------------------------------------------------------
  * T/lock_detectors.cc:61-110: second / fourth moment estimator, everything float32, sequential sums */
 float oracle_cn0_m2m4_estimator(const float* prompt_iq, int length, float coh_integration_time_s)
@@ -519,6 +611,17 @@ int oracle_trk_run(const oracle_trk_conf* c, const float* code, const float* dat
     float accv[10] = {0};  /* d_VE_accu .. d_VL_accu */
     int ext_count = 0;     /* d_extend_correlation_symbols_count */
     float spc_now = c->spc;
+    /* histogram bit synchroniser (trk.cc:2046-2072); switched off after its first lock */
+    oracle_bit_sync bs;
+    int use_hist = c->enable_symbol_sync && c->use_histogram_bit_sync && !c->has_secondary && c->symbols_per_bit > 1;
+    int wait_for_bit_edge = 0;
+    int64_t bit_sync_target_epoch = 0;
+    if (use_hist)
+        {
+            if (c->symbols_per_bit > ORACLE_MAX_BITSYNC_BINS) return -1;
+            oracle_bit_sync_init(&bs, c->symbols_per_bit, c->bs_min_events_for_lock, c->bs_stable_best_required, c->bs_dominance_ratio, c->bs_min_prompt_mag,
+                c->bs_use_phase_dot_detector);
+        }
     if (c->enable_symbol_sync && (c->secondary_code_length < 0 || c->secondary_code_length > ORACLE_MAX_SECONDARY ||
                                      c->data_secondary_code_length < 0 || c->data_secondary_code_length > ORACLE_MAX_SECONDARY))
         return -1;
@@ -700,7 +803,29 @@ int oracle_trk_run(const oracle_trk_conf* c, const float* code, const float* dat
                             int next_state = 0;
                             if (!pull_in)  /* trk.cc:2026 */
                                 {
-                                    if (c->has_secondary || c->symbols_per_bit > 1)  /* :2028-2089 (the histogram bit synchroniser is not modelled) */
+                                    if (!c->has_secondary && c->symbols_per_bit > 1 && use_hist)  /* :2046-2072 */
+                                        {
+                                            const int lock_event = oracle_bit_sync_update(&bs, r->corr[2 * prompt], r->corr[2 * prompt + 1], 1);
+                                            if (lock_event)
+                                                {
+                                                    wait_for_bit_edge = 1;
+                                                    const int64_t k_now = bs.epoch_count - 1;
+                                                    int wait = oracle_bit_sync_epochs_until_next_edge(&bs) - 1;
+                                                    if (wait < 0) wait = wait + bs.bins;
+                                                    bit_sync_target_epoch = k_now + wait;
+                                                }
+                                            if (wait_for_bit_edge)
+                                                {
+                                                    const int64_t k_now = bs.epoch_count - 1;
+                                                    if (k_now == bit_sync_target_epoch)
+                                                        {
+                                                            next_state = 1;
+                                                            wait_for_bit_edge = 0;
+                                                            use_hist = 0;
+                                                        }
+                                                }
+                                        }
+                                    if (!next_state && (c->has_secondary || c->symbols_per_bit > 1))  /* :2028-2045, :2074-2089 */
                                         {
                                             /* d_Prompt_circular_buffer.push_back(*d_Prompt) */
                                             const float* pr = r->corr + 2 * prompt;
@@ -736,7 +861,7 @@ int oracle_trk_run(const oracle_trk_conf* c, const float* code, const float* dat
                                                         }
                                                 }
                                         }
-                                    else
+                                    if (!c->has_secondary && c->symbols_per_bit <= 1)
                                         {
                                             next_state = 1;  /* :2091-2094 */
                                         }

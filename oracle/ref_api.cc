@@ -17,6 +17,7 @@
 #include "tracking_FLL_PLL_filter.h"
 #include "tracking_discriminators.h"
 #include "tracking_loop_filter.h"
+#include "bit_synchronizer.h"
 #include "exponential_smoother.h"
 #include "lock_detectors.h"
 #include "galileo_e1_signal_replica.h"
@@ -286,5 +287,29 @@ extern "C"
         if (offset > -1e30F) s.set_offset(offset);
         s.set_samples_for_initialization(samples_for_initialization);
         for (int i = 0; i < n; i++) out[i] = s.smooth(raw[i]);
+    }
+
+    /* HistogramBitSynchronizer (T/bit_synchronizer.cc): feed n prompts, record the lock event, locked flag, edge phase and
+     * epochs_until_next_edge after every update */
+    void ref_bit_sync_run(int bit_period_ms, int epoch_ms, int min_events_for_lock, int stable_best_required, double dominance_ratio,
+        float min_prompt_mag, int use_phase_dot_detector, const float* prompts_iq, const int* quality_ok, int n, int* lock_event, int* edge_phase,
+        int* until_next_edge)
+    {
+        HistogramBitSynchronizer::Config cfg;
+        cfg.bit_period_ms = bit_period_ms;
+        cfg.epoch_ms = epoch_ms;
+        cfg.min_events_for_lock = min_events_for_lock;
+        cfg.stable_best_required = stable_best_required;
+        cfg.dominance_ratio = dominance_ratio;
+        cfg.min_prompt_mag = min_prompt_mag;
+        cfg.use_phase_dot_detector = use_phase_dot_detector != 0;
+        HistogramBitSynchronizer b(cfg);
+        b.reset();
+        for (int i = 0; i < n; i++)
+            {
+                lock_event[i] = b.update(std::complex<float>(prompts_iq[2 * i], prompts_iq[2 * i + 1]), quality_ok[i] != 0) ? 1 : 0;
+                edge_phase[i] = b.edge_phase();
+                until_next_edge[i] = b.epochs_until_next_edge();
+            }
     }
 }

