@@ -150,6 +150,9 @@ SYMBOLS = {
     "gsh_stream_range": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "gsh_stream_read": (C.c_int, [_P, C.c_uint64, C.c_uint64, _F]),
     "gsh_convert_samples_device": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, _P, C.c_uint64, _P]),
+    "gsh_fir_create": (C.c_int, [C.c_int, _F, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.POINTER(_P)]),
+    "gsh_fir_destroy": (None, [_P]),
+    "gsh_fir_process_device": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint64, C.POINTER(C.c_uint64), _P]),
     "gsh_direct_resample_device": (C.c_int, [C.c_int, _P, C.c_uint64, C.c_uint64, C.c_double, C.c_double, C.c_uint64, _P, C.c_uint64,
                                              C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _P]),
     "gsh_trk_create": (C.c_int, [C.c_int, C.POINTER(TrkConf), C.c_int, C.c_int, C.POINTER(_P)]),

@@ -72,3 +72,32 @@ def direct_resample_device(device: int, src_ptr: int, in0: int, n_in: int, fs_in
     check(_lib.load().gsh_direct_resample_device(device, C.c_void_p(src_ptr), in0, n_in, fs_in, fs_out, out0, C.c_void_p(dst_ptr), max_out,
                                                  C.byref(n_out), C.byref(n_cons), C.c_void_p(hip_stream) if hip_stream else None))
     return int(n_out.value), int(n_cons.value)
+
+
+class FirFilter:
+    """gsh_fir_*: frequency-translating decimating FIR filter with stream history (freq_xlating_fir_filter_ccf / fir_filter_ccf on the device)."""
+    KINDS = {"gr_complex": 0, "float": 1, "short": 2, "byte": 3}
+
+    def __init__(self, taps, decimation: int = 1, center_freq_hz: float = 0.0, sampling_freq_hz: float = 1.0, input_kind: str = "gr_complex", device: int = 0):
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        t = np.ascontiguousarray(taps, np.float32)
+        self.decimation = decimation
+        check(self._lib.gsh_fir_create(device, fptr(t), len(t), decimation, center_freq_hz, sampling_freq_hz, self.KINDS[input_kind], C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            self._lib.gsh_fir_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def process_device(self, in_ptr: int, n_in: int, out_ptr: int, max_out: int, hip_stream: int = 0) -> int:
+        n_out = C.c_uint64(0)
+        check(self._lib.gsh_fir_process_device(self._h, C.c_void_p(in_ptr), n_in, C.c_void_p(out_ptr), max_out, C.byref(n_out),
+                                               C.c_void_p(hip_stream) if hip_stream else None))
+        return int(n_out.value)

@@ -176,6 +176,17 @@ extern "C"
      * reference block would have consumed by then.  Asynchronous on hip_stream. */
     int gsh_direct_resample_device(int device, const void* device_src, uint64_t in0, uint64_t n_in, double fs_in, double fs_out, uint64_t out0,
         void* device_dst, uint64_t max_out, uint64_t* n_out, uint64_t* n_in_consumed, void* hip_stream);
+    /* Frequency-translating decimating FIR filter: what the input-filter adapters instantiate (src/algorithms/input_filter/adapters/
+     * freq_xlating_fir_filter.cc:115-161: gr::filter::freq_xlating_fir_filter_{ccf,fcf,scf}::make(decimation, taps, IF, sampling_frequency);
+     * fir_filter.cc: fir_filter_ccf = the same with IF 0, decimation 1).  y[m] = sum_k taps[k] x[mD - k] exp(-j 2 pi IF (mD - k) / fs), zero
+     * history before the stream starts.  The taps are the adapter's (pm_remez / firdes, computed once on the host).  input_kind: 0 complex64
+     * (ccf), 1 real float32 (fcf), 2 real int16, 3 real int8 (scf after byte_to_short).  The handle carries the filter history, so a stream may
+     * be fed in blocks of any size: *n_out outputs are written per call (every output whose newest input has arrived). */
+    typedef struct gsh_fir gsh_fir_t;
+    int gsh_fir_create(int device, const float* taps, int n_taps, int decimation, double center_freq_hz, double sampling_freq_hz, int input_kind,
+        gsh_fir_t** out);
+    void gsh_fir_destroy(gsh_fir_t* f);
+    int gsh_fir_process_device(gsh_fir_t* f, const void* device_in, uint64_t n_in, void* device_out, uint64_t max_out, uint64_t* n_out, void* hip_stream);
     /* bind a bank to a ring: from now on gsh_corr_job.sample_offset is an ABSOLUTE sample index; a job whose window is not
      * fully resident (or longer than max_window_samples) fails with GSH_ERR_INVALID.  NULL detaches. */
     int gsh_bank_set_stream_ring(gsh_bank_t* b, gsh_stream_t* s);
