@@ -452,10 +452,15 @@ int mcorr_run(gsh_mcorr* h, int mode, float rem_carr, float phase_step, float ph
     GSH_HIP(hipMemcpyAsync(h->d_in, h->h_pinned_in, sizeof(float2) * static_cast<size_t>(n), hipMemcpyHostToDevice, b->stream));
     b->d_stream = h->d_in;
     b->stream_len = static_cast<unsigned long long>(n);
-    int rc = gsh_bank_upload_jobs(b, &j, 1);
-    if (rc != GSH_OK) return rc;
-    rc = gsh_bank_launch(b, nullptr);
-    if (rc != GSH_OK) return rc;
+    // one synchronisation per call: pinned job record -> H2D, kernel and D2H are all queued on the bank's stream
+    int rc = bank_stage_jobs(b, &j, 1);
+    if (rc == GSH_OK) rc = gsh_bank_launch(b, nullptr);
+    if (rc != GSH_OK)
+        {
+            (void)hipStreamSynchronize(b->stream);
+            b->n_jobs = 0;
+            return rc;
+        }
     GSH_HIP(hipMemcpyAsync(h->h_pinned_out, b->d_out, sizeof(float2) * GSH_MAX_TAPS, hipMemcpyDeviceToHost, b->stream));
     GSH_HIP(hipStreamSynchronize(b->stream));
     std::memcpy(h->corr_out, h->h_pinned_out, sizeof(float2) * static_cast<size_t>(h->n_correlators));
