@@ -84,6 +84,7 @@ class TrkConf(C.Structure):
                 ("pll_bw_narrow_hz", C.c_float), ("dll_bw_narrow_hz", C.c_float), ("early_late_space_narrow_chips", C.c_float), ("very_early_late_space_narrow_chips", C.c_float),
                 ("use_histogram_bit_sync", C.c_int32), ("bs_min_events_for_lock", C.c_int32), ("bs_stable_best_required", C.c_int32),
                 ("bs_use_phase_dot_detector", C.c_int32), ("bs_min_prompt_mag", C.c_float), ("pad_bs_", C.c_int32), ("bs_dominance_ratio", C.c_double),
+                ("high_dyn", C.c_int32), ("smoother_length", C.c_uint32),
     ]
 
 
@@ -96,6 +97,7 @@ class TrkEpoch(C.Structure):
         ("carr_freq_error_hz", C.c_double), ("carr_error_filt_hz", C.c_double), ("code_error_chips", C.c_double),
         ("code_error_filt_chips", C.c_double), ("rem_code_phase_samples", C.c_double), ("acc_carrier_phase_rad", C.c_double), ("carrier_lock_test", C.c_double),
                 ("state", C.c_int32), ("symbol_flags", C.c_int32), ("p_data_accu", C.c_float * 2),
+                ("carrier_phase_rate_step_rad", C.c_double), ("code_phase_rate_step_chips", C.c_double),
     ]
 
 

@@ -293,14 +293,14 @@ __device__ __forceinline__ void stage_code_table(float* tab, const float* __rest
 // floats of LDS one staged code occupies (rounded to 16 bytes)
 __host__ __device__ constexpr int code_table_floats(int code_len) { return (code_len + 2 * MC_MARGIN + 3) & ~3; }
 
-// One standard-mode (high_dyn = 0) correlation of the window [sample_offset, sample_offset + n) of `stream` by a whole
-// 256-thread work-group: the body of mcorr_kernel for splits == 1.  `tab` is a staged code table, `red` MC_WAVES *
+// One correlation of the window [sample_offset, sample_offset + n) of `stream` by a whole work-group: the body of mcorr_kernel for
+// splits == 1.  MODE as gsh_corr_job::high_dyn: 0 standard resampler + rotator, 1 the high-dynamics pair (phase_rate / code_rate used).  `tab` is a staged code table, `red` MC_WAVES *
 // GSH_MAX_TAPS float2 of LDS scratch.  On return red[0..NT) holds the tap sums and every thread may read them
 // (a __syncthreads() has been executed); the caller must __syncthreads() again before `red` is reused.
-template <int NT>
-__device__ __forceinline__ void correlate_window_std(const float2* __restrict__ stream, unsigned long long sample_offset, int n_samples,
-    const float* __restrict__ tab, int code_len, const float (&sh)[NT], float rem_carr, float phase_step, float rem_code, float code_step,
-    float2* __restrict__ red)
+template <int NT, int MODE>
+__device__ __forceinline__ void correlate_window(const float2* __restrict__ stream, unsigned long long sample_offset, int n_samples,
+    const float* __restrict__ tab, int code_len, const float (&sh)[NT], float rem_carr, float phase_step, float phase_rate, float rem_code,
+    float code_step, float code_rate, float2* __restrict__ red)
 {
     const int tid = threadIdx.x;
     JobCtx c;
@@ -308,18 +308,33 @@ __device__ __forceinline__ void correlate_window_std(const float2* __restrict__ 
     c.code_len = code_len;
     c.rem_carr = rem_carr;
     c.phase_step = phase_step;
-    c.phase_rate = 0.0f;
+    c.phase_rate = phase_rate;
     c.rem_code = rem_code;
     c.code_step = code_step;
-    c.code_rate = 0.0f;
+    c.code_rate = code_rate;
     c.n_begin = 0;
     c.n_end = n_samples;
     const int odd = static_cast<int>(sample_offset & 1ULL);
     c.n_first = -odd;
     const float2* __restrict__ base = stream + (sample_offset - static_cast<unsigned long long>(odd));
     int rot[NT];
+    rot[0] = 0;
+    if (mode_hd_code(MODE))
+        {
+            // K/..high_dynamics_resampler..:82-85: shift_samples += (int)round((shift[t]-shift[t-1])/step)
+            unsigned accum = 0;
 #pragma unroll
-    for (int t = 0; t < NT; t++) rot[t] = 0;
+            for (int t = 1; t < NT; t++)
+                {
+                    accum += static_cast<unsigned>(static_cast<int>(roundf(__fdiv_rn(__fsub_rn(sh[t], sh[t - 1]), code_step))));
+                    rot[t] = static_cast<int>(accum);
+                }
+        }
+    else
+        {
+#pragma unroll
+            for (int t = 1; t < NT; t++) rot[t] = 0;
+        }
     float2 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; t++) acc[t] = make_float2(0.0f, 0.0f);
@@ -334,11 +349,11 @@ __device__ __forceinline__ void correlate_window_std(const float2* __restrict__ 
                 }
             const int lo = raw_chip_std(__fmul_rn(code_step, 0.0f), smin, rem_code);
             const int hi = raw_chip_std(__fmul_rn(code_step, static_cast<float>(n_samples - 1)), smax, rem_code);
-            const bool fast = (code_step >= 0.0f) && (lo >= -MC_MARGIN) && (hi < code_len + MC_MARGIN) && (code_len >= MC_MARGIN);
+            const bool fast = !mode_hd_code(MODE) && (code_step >= 0.0f) && (lo >= -MC_MARGIN) && (hi < code_len + MC_MARGIN) && (code_len >= MC_MARGIN);
             if (fast)
-                run_segment<NT, 0, false>(c, base, tab, sh, rot, acc);
+                run_segment<NT, MODE, false>(c, base, tab, sh, rot, acc);
             else
-                run_segment<NT, 0, true>(c, base, tab, sh, rot, acc);
+                run_segment<NT, MODE, true>(c, base, tab, sh, rot, acc);
         }
 #pragma unroll
     for (int t = 0; t < NT; t++)
@@ -370,6 +385,15 @@ __device__ __forceinline__ void correlate_window_std(const float2* __restrict__ 
     __syncthreads();
     if (tid < NT) red[tid] = s;
     __syncthreads();
+}
+
+// the standard-mode form the batched callers use
+template <int NT>
+__device__ __forceinline__ void correlate_window_std(const float2* __restrict__ stream, unsigned long long sample_offset, int n_samples,
+    const float* __restrict__ tab, int code_len, const float (&sh)[NT], float rem_carr, float phase_step, float rem_code, float code_step,
+    float2* __restrict__ red)
+{
+    correlate_window<NT, 0>(stream, sample_offset, n_samples, tab, code_len, sh, rem_carr, phase_step, 0.0f, rem_code, code_step, 0.0f, red);
 }
 }  // namespace GSH_MC_NS
 namespace mcdev = GSH_MC_NS;

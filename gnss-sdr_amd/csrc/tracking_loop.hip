@@ -83,12 +83,17 @@ struct LockState  // what cn0_and_tracking_lock_status keeps between periods (tr
     long long bs_epoch_count, bs_target_epoch;
     float bs_last_prompt[2];
     int use_hist, wait_for_bit_edge;
+    // high dynamics: boost::circular_buffer<pair<step, samples>>(2 * smoother_length) for the carrier and the code NCO (trk.cc:698-699)
+    double carr_hist[2 * GSH_MAX_SMOOTHER][2], code_hist[2 * GSH_MAX_SMOOTHER][2];
+    int carr_hist_n, code_hist_n;
+    long long carr_pushes, code_pushes;
 };
 
 struct TrkChannel  // loop state of one channel, resident in device memory between launches
 {
     double carrier_doppler_hz, carrier_phase_step_rad, code_freq_chips, code_phase_step_chips;
     double rem_code_phase_samples, rem_code_phase_chips, acc_carrier_phase_rad;
+    double carrier_phase_rate_step_rad, code_phase_rate_step_chips;  // high_dyn (trk.cc:1425-1443, 1458-1480); 0 otherwise
     unsigned long long pos, acq_stamp;
     float rem_carr_phase_rad, p_old_re, p_old_im;
     int active, code_len;
@@ -368,6 +373,7 @@ struct NextWindow  // what thread 0 publishes for the next correlation (do_corre
 {
     unsigned long long pos;
     float rem_carr, phase_step, rem_code, code_step;
+    float phase_rate, code_rate;  // high_dyn only
     int go;
     int narrow;  // correlate with the narrow tap spacing (after extended integration has started)
 };
@@ -381,6 +387,8 @@ __device__ __forceinline__ void publish(NextWindow& w, const TrkChannel& s, cons
     w.phase_step = static_cast<float>(s.carrier_phase_step_rad);
     w.rem_code = __fmul_rn(static_cast<float>(s.rem_code_phase_chips), spcf);
     w.code_step = __fmul_rn(static_cast<float>(s.code_phase_step_chips), spcf);
+    w.phase_rate = static_cast<float>(s.carrier_phase_rate_step_rad);
+    w.code_rate = __fmul_rn(static_cast<float>(s.code_phase_rate_step_chips), spcf);
     w.go = (more && s.active && s.pos + c.vector_length <= n_stream && s.pos >= ring_oldest) ? 1 : 0;
     w.narrow = 0;  // the caller overrides it from the channel's LockState
 }
@@ -453,7 +461,11 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
             float sh[NT];
 #pragma unroll
             for (int t = 0; t < NT; t++) sh[t] = win.narrow ? sh_n[t] : sh_w[t];
-            correlate_window_std<NT>(a.stream, wpos, static_cast<int>(c.vector_length), tab, code_len, sh, rem_carr, phase_step, rem_code, code_step, red);
+            const float phase_rate = win.phase_rate, code_rate = win.code_rate;
+            if (c.high_dyn)  // set_high_dynamics_resampler(high_dyn), trk.cc:669-675: the high-dynamics resampler + rotator pair
+                correlate_window<NT, 1>(a.stream, wpos, static_cast<int>(c.vector_length), tab, code_len, sh, rem_carr, phase_step, phase_rate, rem_code, code_step, code_rate, red);
+            else
+                correlate_window_std<NT>(a.stream, wpos, static_cast<int>(c.vector_length), tab, code_len, sh, rem_carr, phase_step, rem_code, code_step, red);
             float2 out[NT];
 #pragma unroll
             for (int t = 0; t < NT; t++) out[t] = red[t];
@@ -461,7 +473,10 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
             if (c.track_pilot)
                 {
                     __syncthreads();  // everyone has read red[0..NT) before it is reused
-                    correlate_window_std<1>(a.stream, wpos, static_cast<int>(c.vector_length), tab_data, code_len, sh_data, rem_carr, phase_step, rem_code, code_step, red);
+                    if (c.high_dyn)
+                        correlate_window<1, 1>(a.stream, wpos, static_cast<int>(c.vector_length), tab_data, code_len, sh_data, rem_carr, phase_step, phase_rate, rem_code, code_step, code_rate, red);
+                    else
+                        correlate_window_std<1>(a.stream, wpos, static_cast<int>(c.vector_length), tab_data, code_len, sh_data, rem_carr, phase_step, rem_code, code_step, red);
                     pdata = red[0];
                 }
             __syncthreads();  // win and red have been read by everyone
@@ -598,11 +613,56 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
                     const double k_blk = t_prn_samples + s.rem_code_phase_samples;
                     const int prn_len = static_cast<int>(floor(k_blk));
                     s.carrier_phase_step_rad = GNSS_TWO_PI_D * (s.carrier_doppler_hz + c.cfo_frequency_hz) / c.fs_in;
-                    const double dphi = s.carrier_phase_step_rad * static_cast<double>(prn_len);
+                    if (c.high_dyn)  // trk.cc:1425-1443
+                        {
+                            const int SL = static_cast<int>(c.smoother_length), cap = 2 * SL;
+                            lk.carr_hist[lk.carr_pushes % cap][0] = s.carrier_phase_step_rad;
+                            lk.carr_hist[lk.carr_pushes % cap][1] = static_cast<double>(prn_len);
+                            lk.carr_pushes++;
+                            if (lk.carr_hist_n < cap) lk.carr_hist_n++;
+                            if (lk.carr_hist_n == cap)
+                                {
+                                    const long long oldest = lk.carr_pushes % cap;
+                                    double cp1 = 0.0, cp2 = 0.0, smp = 0.0;
+                                    for (int k = 0; k < SL; k++)
+                                        {
+                                            cp1 += lk.carr_hist[(oldest + k) % cap][0];
+                                            cp2 += lk.carr_hist[(oldest + cap - k - 1) % cap][0];
+                                            smp += lk.carr_hist[(oldest + cap - k - 1) % cap][1];
+                                        }
+                                    cp1 /= static_cast<double>(SL);
+                                    cp2 /= static_cast<double>(SL);
+                                    s.carrier_phase_rate_step_rad = (smp != 0.0) ? (cp2 - cp1) / smp : 0.0;
+                                }
+                        }
+                    const double dphi = s.carrier_phase_step_rad * static_cast<double>(prn_len) +
+                                        0.5 * s.carrier_phase_rate_step_rad * static_cast<double>(prn_len) * static_cast<double>(prn_len);
                     s.rem_carr_phase_rad += static_cast<float>(dphi);
                     s.rem_carr_phase_rad = static_cast<float>(fmod(static_cast<double>(s.rem_carr_phase_rad), GNSS_TWO_PI_D));
                     s.acc_carrier_phase_rad -= dphi;
                     s.code_phase_step_chips = s.code_freq_chips / c.fs_in;
+                    if (c.high_dyn)  // trk.cc:1458-1480
+                        {
+                            const int SL = static_cast<int>(c.smoother_length), cap = 2 * SL;
+                            lk.code_hist[lk.code_pushes % cap][0] = s.code_phase_step_chips;
+                            lk.code_hist[lk.code_pushes % cap][1] = static_cast<double>(prn_len);
+                            lk.code_pushes++;
+                            if (lk.code_hist_n < cap) lk.code_hist_n++;
+                            if (lk.code_hist_n == cap)
+                                {
+                                    const long long oldest = lk.code_pushes % cap;
+                                    double cp1 = 0.0, cp2 = 0.0, smp = 0.0;
+                                    for (int k = 0; k < SL; k++)
+                                        {
+                                            cp1 += lk.code_hist[(oldest + k) % cap][0];
+                                            cp2 += lk.code_hist[(oldest + cap - k - 1) % cap][0];
+                                            smp += lk.code_hist[(oldest + cap - k - 1) % cap][1];
+                                        }
+                                    cp1 /= static_cast<double>(SL);
+                                    cp2 /= static_cast<double>(SL);
+                                    if (smp >= 1.0) s.code_phase_rate_step_chips = (cp2 - cp1) / smp;
+                                }
+                        }
                     s.rem_code_phase_samples = k_blk - static_cast<double>(prn_len);
                     s.rem_code_phase_chips = s.code_freq_chips * s.rem_code_phase_samples / c.fs_in;
 
@@ -754,6 +814,8 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
                         {
                             gsh_trk_epoch r;
                             r.state = run_state;
+                            r.carrier_phase_rate_step_rad = s.carrier_phase_rate_step_rad;
+                            r.code_phase_rate_step_chips = s.code_phase_rate_step_chips;
                             r.symbol_flags = rec_symbol_flags;
                             r.p_data_accu[0] = rec_pdata[0];
                             r.p_data_accu[1] = rec_pdata[1];
@@ -986,6 +1048,7 @@ extern "C"
         GSH_REQUIRE(c.code_length_chips >= 1 && c.code_samples_per_chip >= 1 && c.vector_length >= 1, "code_length_chips, code_samples_per_chip, vector_length must be >= 1");
         GSH_REQUIRE(c.pll_filter_order == 2 || c.pll_filter_order == 3, "pll_filter_order %d (2 or 3: T/tracking_FLL_PLL_filter.cc:23-54)", c.pll_filter_order);
         GSH_REQUIRE(c.dll_filter_order >= 1 && c.dll_filter_order <= 3, "dll_filter_order %d outside 1..3", c.dll_filter_order);
+        GSH_REQUIRE(!c.high_dyn || (c.smoother_length >= 1 && c.smoother_length <= GSH_MAX_SMOOTHER), "smoother_length %u outside 1..%d", c.smoother_length, GSH_MAX_SMOOTHER);
         if (c.enable_symbol_sync)
             {
                 GSH_REQUIRE(c.secondary_code_length >= 0 && c.secondary_code_length <= GSH_MAX_SECONDARY, "secondary_code_length %d outside 0..%d", c.secondary_code_length, GSH_MAX_SECONDARY);

@@ -42,9 +42,9 @@ extern "C"
                 o.prn_start_sample = r.sample_counter + static_cast<uint64_t>(r.prn_length_samples);  // nitems_read + d_current_prn_length_samples, :1650
                 o.acc_carrier_phase_rad = static_cast<float>(r.acc_carrier_phase_rad);
                 o.carrier_doppler_hz = static_cast<float>(r.carrier_doppler_hz);
-                o.carrier_doppler_rate_hz_s = 0.0f;  // d_carrier_phase_rate_step_rad is 0 outside high_dyn (:1659)
+                o.carrier_doppler_rate_hz_s = static_cast<float>(r.carrier_phase_rate_step_rad * conf->fs_in * conf->fs_in / 6.283185307179586);  // :1659 (TWO_PI of MATH_CONSTANTS.h differs in the 13th digit: below float precision)
                 o.code_freq_chips = static_cast<float>(r.code_freq_chips);
-                o.code_freq_rate = 0.0f;             // d_code_phase_rate_step_chips is 0 outside high_dyn (:1664)
+                o.code_freq_rate = static_cast<float>(r.code_phase_rate_step_chips * conf->fs_in * conf->fs_in);  // :1664
                 o.carr_error_hz = static_cast<float>(r.carr_phase_error_hz);
                 o.carr_error_filt_hz = static_cast<float>(r.carr_error_filt_hz);
                 o.code_error_chips = static_cast<float>(r.code_error_chips);

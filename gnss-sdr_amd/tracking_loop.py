@@ -33,7 +33,8 @@ def trk_conf(**kw) -> TrkConf:
              # histogram bit synchroniser: Dll_Pll_Conf defaults (dll_pll_conf.h:43,60,75-76,88); the block switches it on for signals
              # without a secondary code and more than one symbol per bit (trk.cc:1389) -- here the caller does
              use_histogram_bit_sync=0, bs_min_events_for_lock=10, bs_stable_best_required=3, bs_use_phase_dot_detector=1,
-             bs_min_prompt_mag=0.0, bs_dominance_ratio=0.6)
+             bs_min_prompt_mag=0.0, bs_dominance_ratio=0.6,
+             high_dyn=0, smoother_length=10)
     d.update(kw)
     for k, v in d.items():
         setattr(c, k, v)

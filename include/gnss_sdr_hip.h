@@ -30,7 +30,7 @@ extern "C"
 {
 #endif
 
-#define GSH_ABI_VERSION 8
+#define GSH_ABI_VERSION 9
 #define GSH_MAX_TAPS 8 /* VE/E/P/L/VL needs 5 (trk.cc:609-650); 8 leaves room for multi-tap dumps */
 
     enum
@@ -202,8 +202,8 @@ extern "C"
      * trips.  With enable_lock_detectors the C/N0 estimator, the carrier lock detector, their smoothers and the loss-of-lock
      * counters (cn0_and_tracking_lock_status, trk.cc:1167-1224; T/lock_detectors.cc, T/exponential_smoother.cc) run on the device
      * too, between the correlation and run_dll_pll as state 2 orders them (:2008-2018).  Not modelled here (the host block
-     * keeps them): bit / secondary-code synchronisation, extended integration, high_dyn smoothing, the experimental Doppler
-     * correction (:1326-1346).
+     * keeps them): the experimental Doppler correction (:1326-1346).  Symbol synchronisation, narrow tracking, extended integration,
+     * the histogram bit synchroniser and high dynamics are switched on by the corresponding gsh_trk_conf fields.
      * T/ = src/algorithms/tracking/libs/.
      */
     typedef struct gsh_trk gsh_trk_t;
@@ -266,8 +266,12 @@ extern "C"
         float bs_min_prompt_mag;         /* (0.0) */
         int32_t pad_bs_;
         double bs_dominance_ratio;       /* (0.6) */
+        int32_t high_dyn;                /* Dll_Pll_Conf::high_dyn: the high-dynamics resampler + rotator (trk.cc:669-675) fed with the rate-of-change
+                                            estimates of both NCO steps (trk.cc:1425-1443, 1458-1480) */
+        uint32_t smoother_length;        /* (10) periods per average, <= GSH_MAX_SMOOTHER */
     } gsh_trk_conf;
 #define GSH_MAX_BITSYNC_BINS 64
+#define GSH_MAX_SMOOTHER 32
 #define GSH_MAX_CN0_SAMPLES 64
 #define GSH_MAX_SECONDARY 200
 
@@ -290,6 +294,8 @@ extern "C"
         int32_t symbol_flags;            /* bit 0: Flag_valid_symbol_output (a telemetry symbol leaves the block, trk.cc:2212-2236);
                                             bit 1: Flag_PLL_180_deg_phase_locked (trk.cc:1148-1156) */
         float p_data_accu[2];            /* d_P_data_accu: Prompt_I / Prompt_Q of the symbol when bit 0 is set, else the running sum */
+        double carrier_phase_rate_step_rad; /* d_carrier_phase_rate_step_rad [rad/sample^2] after this period (0 outside high_dyn) */
+        double code_phase_rate_step_chips;  /* d_code_phase_rate_step_chips [chips/sample^2] */
     } gsh_trk_epoch;
 
     int gsh_trk_create(int device, const gsh_trk_conf* conf, int n_channels, int max_code_length, gsh_trk_t** out);

@@ -51,7 +51,8 @@ class TrkConf(C.Structure):
                 ("data_secondary_code_length", C.c_int32), ("extend_correlation_symbols", C.c_int32), ("secondary_code", C.c_uint8 * 200), ("data_secondary_code", C.c_uint8 * 200),
                 ("pll_bw_narrow_hz", C.c_float), ("dll_bw_narrow_hz", C.c_float), ("early_late_space_narrow_chips", C.c_float), ("very_early_late_space_narrow_chips", C.c_float),
                 ("use_histogram_bit_sync", C.c_int32), ("bs_min_events_for_lock", C.c_int32), ("bs_stable_best_required", C.c_int32),
-                ("bs_use_phase_dot_detector", C.c_int32), ("bs_min_prompt_mag", C.c_float), ("pad_bs_", C.c_int32), ("bs_dominance_ratio", C.c_double)]
+                ("bs_use_phase_dot_detector", C.c_int32), ("bs_min_prompt_mag", C.c_float), ("pad_bs_", C.c_int32), ("bs_dominance_ratio", C.c_double),
+                ("high_dyn", C.c_int32), ("smoother_length", C.c_uint32)]
 
 
 class TrkEpoch(C.Structure):
@@ -61,7 +62,8 @@ class TrkEpoch(C.Structure):
                 ("carrier_doppler_hz", C.c_double), ("code_freq_chips", C.c_double), ("carr_phase_error_hz", C.c_double),
                 ("carr_freq_error_hz", C.c_double), ("carr_error_filt_hz", C.c_double), ("code_error_chips", C.c_double),
                 ("code_error_filt_chips", C.c_double), ("rem_code_phase_samples", C.c_double), ("acc_carrier_phase_rad", C.c_double), ("carrier_lock_test", C.c_double),
-                ("state", C.c_int32), ("symbol_flags", C.c_int32), ("p_data_accu", C.c_float * 2)]
+                ("state", C.c_int32), ("symbol_flags", C.c_int32), ("p_data_accu", C.c_float * 2),
+                ("carrier_phase_rate_step_rad", C.c_double), ("code_phase_rate_step_chips", C.c_double)]
 
 
 _lib = None
@@ -376,7 +378,8 @@ def trk_conf(**kw) -> TrkConf:
              # histogram bit synchroniser: Dll_Pll_Conf defaults (dll_pll_conf.h:43,60,75-76,88); the block switches it on for signals
              # without a secondary code and more than one symbol per bit (trk.cc:1389) -- here the caller does
              use_histogram_bit_sync=0, bs_min_events_for_lock=10, bs_stable_best_required=3, bs_use_phase_dot_detector=1,
-             bs_min_prompt_mag=0.0, bs_dominance_ratio=0.6)
+             bs_min_prompt_mag=0.0, bs_dominance_ratio=0.6,
+             high_dyn=0, smoother_length=10)
     d.update(kw)
     for k, v in d.items():
         setattr(c, k, v)

@@ -189,6 +189,9 @@ extern "C"
         float bs_min_prompt_mag;
         int32_t pad_bs_;
         double bs_dominance_ratio;
+        /* high dynamics (Dll_Pll_Conf::high_dyn, smoother_length; trk.cc:669-675, 1425-1443, 1458-1480) */
+        int32_t high_dyn;
+        uint32_t smoother_length;
     } oracle_trk_conf;
     void oracle_lock_init(oracle_lock_state* st, const oracle_trk_conf* c);
     /* cn0_and_tracking_lock_status, trk.cc:1167-1224: returns 1 while locked, 0 when loss of lock is declared */
@@ -209,7 +212,9 @@ extern "C"
         int32_t state;          /* d_state in which the period ran: 2 (wide tracking, symbol search) or 4 (narrow tracking) */
         int32_t symbol_flags;   /* bit 0: Flag_valid_symbol_output; bit 1: Flag_PLL_180_deg_phase_locked */
         float p_data_accu[2];   /* d_P_data_accu when a symbol is output (Prompt_I / Prompt_Q of the Gnss_Synchro), else the running sum */
+        double carrier_phase_rate_step_rad, code_phase_rate_step_chips;  /* after update_tracking_vars (0 outside high_dyn) */
     } oracle_trk_epoch;
+#define ORACLE_MAX_SMOOTHER 32
 
     /* closed loop of ONE channel over a resident stream; returns the number of epochs completed */
     int oracle_trk_run(const oracle_trk_conf* c, const float* code, const float* data_code, int code_len, const float* stream_iq,

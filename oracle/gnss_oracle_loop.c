@@ -611,6 +611,14 @@ int oracle_trk_run(const oracle_trk_conf* c, const float* code, const float* dat
     float accv[10] = {0};  /* d_VE_accu .. d_VL_accu */
     int ext_count = 0;     /* d_extend_correlation_symbols_count */
     float spc_now = c->spc;
+    /* high dynamics: rate-of-change estimates of both NCO steps from two adjacent averages over smoother_length periods (trk.cc:1425-1443, 1458-1480) */
+    const int hd = c->high_dyn ? 1 : 0;
+    const int SL = (int)c->smoother_length;
+    double carr_hist[2 * ORACLE_MAX_SMOOTHER][2], code_hist[2 * ORACLE_MAX_SMOOTHER][2];  /* boost::circular_buffer<pair<double,double>>(2 * smoother_length) */
+    int carr_hist_n = 0, code_hist_n = 0;   /* size; once full the oldest sits at index (pushes % capacity) */
+    long carr_pushes = 0, code_pushes = 0;
+    double carrier_phase_rate_step_rad = 0.0, code_phase_rate_step_chips = 0.0;
+    if (hd && (SL < 1 || SL > ORACLE_MAX_SMOOTHER)) return -1;
     /* histogram bit synchroniser (trk.cc:2046-2072); switched off after its first lock */
     oracle_bit_sync bs;
     int use_hist = c->enable_symbol_sync && c->use_histogram_bit_sync && !c->has_secondary && c->symbols_per_bit > 1;
@@ -642,14 +650,15 @@ int oracle_trk_run(const oracle_trk_conf* c, const float* code, const float* dat
             /* do_correlation_step, trk.cc:1232-1257 (rate terms are 0 outside high_dyn) */
             const float rem_code = (float)rem_code_phase_chips * spcf;
             const float code_step = (float)code_phase_step_chips * spcf;
+            const float code_rate = (float)code_phase_rate_step_chips * spcf;
             oracle_mcorr(code, code_len, shifts, n_taps, stream_iq + 2 * pos, (int)c->vector_length, rem_carr_phase_rad,
-                (float)carrier_phase_step_rad, 0.0F, rem_code, code_step, 0.0F * spcf, 0, out);
+                (float)carrier_phase_step_rad, (float)carrier_phase_rate_step_rad, rem_code, code_step, code_rate, hd, out);
             memcpy(r->corr, out, sizeof(float) * 2 * n_taps);
             if (c->track_pilot && data_code)
                 {
                     float pd[2];
                     oracle_mcorr(data_code, code_len, zero_shift, 1, stream_iq + 2 * pos, (int)c->vector_length, rem_carr_phase_rad,
-                        (float)carrier_phase_step_rad, 0.0F, rem_code, code_step, 0.0F * spcf, 0, pd);
+                        (float)carrier_phase_step_rad, (float)carrier_phase_rate_step_rad, rem_code, code_step, code_rate, hd, pd);
                     r->prompt_data[0] = pd[0];
                     r->prompt_data[1] = pd[1];
                 }
@@ -758,10 +767,54 @@ int oracle_trk_run(const oracle_trk_conf* c, const float* code, const float* dat
             const double k_blk = t_prn_samples + rem_code_phase_samples;
             const int32_t prn_len = (int32_t)floor(k_blk);
             carrier_phase_step_rad = ORA_TWO_PI * (carrier_doppler_hz + c->cfo_frequency_hz) / c->fs_in;
-            rem_carr_phase_rad += (float)(carrier_phase_step_rad * (double)prn_len + 0.5 * 0.0 * (double)prn_len * (double)prn_len);
+            if (hd)  /* :1425-1443 */
+                {
+                    const int cap = 2 * SL;
+                    carr_hist[carr_pushes % cap][0] = carrier_phase_step_rad;
+                    carr_hist[carr_pushes % cap][1] = (double)prn_len;
+                    carr_pushes++;
+                    if (carr_hist_n < cap) carr_hist_n++;
+                    if (carr_hist_n == cap)
+                        {
+                            const long oldest = carr_pushes % cap;  /* index 0 of the circular buffer */
+                            double tmp_cp1 = 0.0, tmp_cp2 = 0.0, tmp_samples = 0.0;
+                            for (int k = 0; k < SL; k++)
+                                {
+                                    tmp_cp1 += carr_hist[(oldest + k) % cap][0];
+                                    tmp_cp2 += carr_hist[(oldest + cap - k - 1) % cap][0];
+                                    tmp_samples += carr_hist[(oldest + cap - k - 1) % cap][1];
+                                }
+                            tmp_cp1 /= (double)SL;
+                            tmp_cp2 /= (double)SL;
+                            carrier_phase_rate_step_rad = (tmp_samples != 0) ? (tmp_cp2 - tmp_cp1) / tmp_samples : 0.0;
+                        }
+                }
+            rem_carr_phase_rad += (float)(carrier_phase_step_rad * (double)prn_len + 0.5 * carrier_phase_rate_step_rad * (double)prn_len * (double)prn_len);
             rem_carr_phase_rad = (float)fmod(rem_carr_phase_rad, ORA_TWO_PI);
-            acc_carrier_phase_rad -= (carrier_phase_step_rad * (double)prn_len + 0.5 * 0.0 * (double)prn_len * (double)prn_len);
+            acc_carrier_phase_rad -= (carrier_phase_step_rad * (double)prn_len + 0.5 * carrier_phase_rate_step_rad * (double)prn_len * (double)prn_len);
             code_phase_step_chips = code_freq_chips / c->fs_in;
+            if (hd)  /* :1458-1480 */
+                {
+                    const int cap = 2 * SL;
+                    code_hist[code_pushes % cap][0] = code_phase_step_chips;
+                    code_hist[code_pushes % cap][1] = (double)prn_len;
+                    code_pushes++;
+                    if (code_hist_n < cap) code_hist_n++;
+                    if (code_hist_n == cap)
+                        {
+                            const long oldest = code_pushes % cap;
+                            double tmp_cp1 = 0.0, tmp_cp2 = 0.0, tmp_samples = 0.0;
+                            for (int k = 0; k < SL; k++)
+                                {
+                                    tmp_cp1 += code_hist[(oldest + k) % cap][0];
+                                    tmp_cp2 += code_hist[(oldest + cap - k - 1) % cap][0];
+                                    tmp_samples += code_hist[(oldest + cap - k - 1) % cap][1];
+                                }
+                            tmp_cp1 /= (double)SL;
+                            tmp_cp2 /= (double)SL;
+                            if (tmp_samples >= 1.0) code_phase_rate_step_chips = (tmp_cp2 - tmp_cp1) / tmp_samples;
+                        }
+                }
             rem_code_phase_samples = k_blk - (double)prn_len;
             rem_code_phase_chips = code_freq_chips * rem_code_phase_samples / c->fs_in;
 
@@ -778,6 +831,8 @@ int oracle_trk_run(const oracle_trk_conf* c, const float* code, const float* dat
             r->rem_code_phase_samples = rem_code_phase_samples;
             r->acc_carrier_phase_rad = acc_carrier_phase_rad;
             r->rem_carr_phase_rad = rem_carr_phase_rad;
+            r->carrier_phase_rate_step_rad = carrier_phase_rate_step_rad;
+            r->code_phase_rate_step_chips = code_phase_rate_step_chips;
             if (c->enable_symbol_sync && state == 3)
                 {
                     /* trk.cc:2162-2194: a telemetry symbol may complete inside the coherent integration; then count the period */

@@ -285,3 +285,64 @@ def test_device_gps_l1_histogram_bit_sync_matches_oracle(gpu):
     o = np.array([r.p_data_accu[0] for r in ora if r.symbol_flags & 1])
     assert np.array_equal(np.sign(g), np.sign(o))
     loop.close()
+
+
+# ---- high dynamics inside the loop (Dll_Pll_Conf::high_dyn; trk.cc:669-675, 1425-1443, 1458-1480) -------------------------------------
+def _chirp_case():
+    fs, n, epochs = 4e6, 4000, 700
+    rate_hz_s = 400.0                                   # Doppler rate
+    f0 = 1500.0
+    total = (epochs + 3) * n
+    rng = np.random.default_rng(21)
+    x = rng.standard_normal(total) + 1j * rng.standard_normal(total)
+    t = np.arange(total, dtype=np.float64) / fs
+    code = oracle.ca_code(12).astype(np.float64)
+    # code Doppler follows the carrier: chips(t) = integral of 1.023e6 (1 + f(t)/1575.42e6)
+    chips = 1.023e6 * (t + (f0 * t + 0.5 * rate_hz_s * t * t) / 1575.42e6)
+    from helpers import cn0_to_amplitude
+    x += cn0_to_amplitude(48.0, fs) * code[np.floor(chips).astype(np.int64) % 1023] * np.exp(2j * np.pi * (f0 * t + 0.5 * rate_hz_s * t * t))
+    kw = dict(fs_in=fs, vector_length=n, pll_bw_hz=30.0, dll_bw_hz=2.0, high_dyn=1, smoother_length=10)
+    return x.astype(np.complex64), n, epochs, f0, rate_hz_s, kw
+
+
+def test_oracle_high_dyn_estimates_the_doppler_rate():
+    x, n, epochs, f0, rate, kw = _chirp_case()
+    rec = oracle.trk_run(oracle.trk_conf(**kw), oracle.ca_code(12), x, 0, 0, f0 - 5.0, epochs)
+    assert len(rec) == epochs
+    assert all(r.carrier_phase_rate_step_rad == 0.0 for r in rec[:19]) and rec[19].carrier_phase_rate_step_rad != 0.0   # 2 x smoother_length periods fill the history
+    est = np.array([r.carrier_phase_rate_step_rad for r in rec[200:]]) * kw["fs_in"] ** 2 / (2 * np.pi)
+    assert abs(np.mean(est) - rate) < 0.1 * rate, np.mean(est)
+    t_end = rec[-1].sample_counter / kw["fs_in"]
+    # the loop follows the ramp (its frequency output trails the true Doppler by some tens of milliseconds of ramp: the filter memory)
+    assert 0.0 <= (f0 + rate * t_end) - rec[-1].carrier_doppler_hz < 0.1 * rate
+    code_rate = np.mean([r.code_phase_rate_step_chips for r in rec[200:]]) * kw["fs_in"] ** 2          # chips / s^2
+    assert abs(code_rate - rate * 1.023e6 / 1575.42e6) < 0.5 * rate * 1.023e6 / 1575.42e6
+
+
+@pytest.mark.gpu
+def test_device_high_dyn_loop_matches_oracle(gpu):
+    """The device loop in high-dynamics mode (high-dynamics resampler + rotator fed with the smoothed rate estimates) against the oracle loop.
+    The reference's high-dynamics rotator never renormalises its phasor (K/..high_dynamic_rotator..:73,97) and drifts by up to 4e-4 per period,
+    the device evaluates the chirped phase exactly -- so the two loops agree as two loops tracking the same signal, not sample for sample."""
+    from gnss_sdr_amd.tracking_loop import TrackingLoop, trk_conf
+    x, n, epochs, f0, rate, kw = _chirp_case()
+    ora = oracle.trk_run(oracle.trk_conf(**kw), oracle.ca_code(12), x, 0, 0, f0 - 5.0, epochs)
+    loop = TrackingLoop(trk_conf(**kw), 1, 1023, device=gpu)
+    loop.set_stream_host(x)
+    loop.start(0, oracle.ca_code(12), 0, 0, f0 - 5.0)
+    rec, done = loop.run(epochs)
+    rec = rec[0]
+    assert len(rec) == len(ora) == epochs
+    assert all(r.carrier_phase_rate_step_rad == 0.0 for r in rec[:19]) and rec[19].carrier_phase_rate_step_rad != 0.0
+    gd = np.array([r.carrier_doppler_hz for r in rec])
+    od = np.array([r.carrier_doppler_hz for r in ora])
+    assert np.max(np.abs(gd[50:] - od[50:])) < 1.5
+    ge = np.mean([r.carrier_phase_rate_step_rad for r in rec[200:]]) * kw["fs_in"] ** 2 / (2 * np.pi)
+    oe = np.mean([r.carrier_phase_rate_step_rad for r in ora[200:]]) * kw["fs_in"] ** 2 / (2 * np.pi)
+    assert abs(ge - rate) < 0.1 * rate and abs(ge - oe) < 0.05 * rate
+    same = sum(1 for a, b in zip(rec, ora) if a.sample_counter == b.sample_counter)
+    assert same >= 0.9 * epochs
+    gp = np.mean([np.hypot(r.corr[2], r.corr[3]) for r in rec[300:]])
+    op = np.mean([np.hypot(r.corr[2], r.corr[3]) for r in ora[300:]])
+    assert abs(gp - op) < 0.01 * op
+    loop.close()
