@@ -393,7 +393,8 @@ __device__ __forceinline__ void publish(NextWindow& w, const TrkChannel& s, cons
     w.narrow = 0;  // the caller overrides it from the channel's LockState
 }
 
-template <int NT>
+// HD: Dll_Pll_Conf::high_dyn -- a compile-time switch so that the standard path does not carry the high-dynamics correlator's registers
+template <int NT, bool HD>
 __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
 {
     extern __shared__ __align__(16) float lds[];
@@ -462,7 +463,7 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
 #pragma unroll
             for (int t = 0; t < NT; t++) sh[t] = win.narrow ? sh_n[t] : sh_w[t];
             const float phase_rate = win.phase_rate, code_rate = win.code_rate;
-            if (c.high_dyn)  // set_high_dynamics_resampler(high_dyn), trk.cc:669-675: the high-dynamics resampler + rotator pair
+            if (HD)  // set_high_dynamics_resampler(high_dyn), trk.cc:669-675: the high-dynamics resampler + rotator pair
                 correlate_window<NT, 1>(a.stream, wpos, static_cast<int>(c.vector_length), tab, code_len, sh, rem_carr, phase_step, phase_rate, rem_code, code_step, code_rate, red);
             else
                 correlate_window_std<NT>(a.stream, wpos, static_cast<int>(c.vector_length), tab, code_len, sh, rem_carr, phase_step, rem_code, code_step, red);
@@ -473,7 +474,7 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
             if (c.track_pilot)
                 {
                     __syncthreads();  // everyone has read red[0..NT) before it is reused
-                    if (c.high_dyn)
+                    if (HD)
                         correlate_window<1, 1>(a.stream, wpos, static_cast<int>(c.vector_length), tab_data, code_len, sh_data, rem_carr, phase_step, phase_rate, rem_code, code_step, code_rate, red);
                     else
                         correlate_window_std<1>(a.stream, wpos, static_cast<int>(c.vector_length), tab_data, code_len, sh_data, rem_carr, phase_step, rem_code, code_step, red);
@@ -613,7 +614,7 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
                     const double k_blk = t_prn_samples + s.rem_code_phase_samples;
                     const int prn_len = static_cast<int>(floor(k_blk));
                     s.carrier_phase_step_rad = GNSS_TWO_PI_D * (s.carrier_doppler_hz + c.cfo_frequency_hz) / c.fs_in;
-                    if (c.high_dyn)  // trk.cc:1425-1443
+                    if (HD)  // trk.cc:1425-1443
                         {
                             const int SL = static_cast<int>(c.smoother_length), cap = 2 * SL;
                             lk.carr_hist[lk.carr_pushes % cap][0] = s.carrier_phase_step_rad;
@@ -641,7 +642,7 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
                     s.rem_carr_phase_rad = static_cast<float>(fmod(static_cast<double>(s.rem_carr_phase_rad), GNSS_TWO_PI_D));
                     s.acc_carrier_phase_rad -= dphi;
                     s.code_phase_step_chips = s.code_freq_chips / c.fs_in;
-                    if (c.high_dyn)  // trk.cc:1458-1480
+                    if (HD)  // trk.cc:1458-1480
                         {
                             const int SL = static_cast<int>(c.smoother_length), cap = 2 * SL;
                             lk.code_hist[lk.code_pushes % cap][0] = s.code_phase_step_chips;
@@ -1026,10 +1027,21 @@ int trk_launch(gsh_trk* t, int n_epochs, gsh_trk_epoch* d_records)
     a.epochs_done = t->d_done;
     a.n_epochs = n_epochs;
     const size_t lds = trk_lds_bytes(t);
+    const dim3 grid(t->n_channels), block(gsh::mcdev::MC_THREADS);
     if (t->conf.veml)
-        hipLaunchKernelGGL((gsh::trk_loop_kernel<5>), dim3(t->n_channels), dim3(gsh::mcdev::MC_THREADS), lds, t->stream, a);
+        {
+            if (t->conf.high_dyn)
+                hipLaunchKernelGGL((gsh::trk_loop_kernel<5, true>), grid, block, lds, t->stream, a);
+            else
+                hipLaunchKernelGGL((gsh::trk_loop_kernel<5, false>), grid, block, lds, t->stream, a);
+        }
     else
-        hipLaunchKernelGGL((gsh::trk_loop_kernel<3>), dim3(t->n_channels), dim3(gsh::mcdev::MC_THREADS), lds, t->stream, a);
+        {
+            if (t->conf.high_dyn)
+                hipLaunchKernelGGL((gsh::trk_loop_kernel<3, true>), grid, block, lds, t->stream, a);
+            else
+                hipLaunchKernelGGL((gsh::trk_loop_kernel<3, false>), grid, block, lds, t->stream, a);
+        }
     GSH_HIP(hipGetLastError());
     return GSH_OK;
 }
@@ -1097,8 +1109,10 @@ extern "C"
         if (trk_lds_bytes(t) > 64 * 1024)
             {
                 const int bytes = static_cast<int>(trk_lds_bytes(t));
-                if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(gsh::trk_loop_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes)) != hipSuccess) return fail(e, "hipFuncSetAttribute");
-                if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(gsh::trk_loop_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes)) != hipSuccess) return fail(e, "hipFuncSetAttribute");
+                if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(gsh::trk_loop_kernel<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes)) != hipSuccess) return fail(e, "hipFuncSetAttribute");
+                if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(gsh::trk_loop_kernel<5, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes)) != hipSuccess) return fail(e, "hipFuncSetAttribute");
+                if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(gsh::trk_loop_kernel<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes)) != hipSuccess) return fail(e, "hipFuncSetAttribute");
+                if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(gsh::trk_loop_kernel<5, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes)) != hipSuccess) return fail(e, "hipFuncSetAttribute");
             }
         *out = t;
         return GSH_OK;

@@ -1,0 +1,19 @@
+"""A/B timing of the closed-loop kernel between two builds of the library on the same box (GSH_LIB_PATH selects the build)."""
+import os, sys
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import numpy as np, torch
+import gnss_sdr_amd, oracle
+from gnss_sdr_amd.tracking_loop import TrackingLoop, trk_conf
+fs, n, E = 25e6, 25000, 200
+dev = torch.device("cuda", 0)
+x = torch.randn((E + 3) * n, 2, device=dev)
+x = torch.view_as_complex(x).contiguous()
+for ch in (32, 256):
+    loop = TrackingLoop(trk_conf(fs_in=fs, vector_length=n, pll_bw_hz=35.0, dll_bw_hz=2.0), ch, 1023, device=0)
+    loop.set_stream_device(x.data_ptr(), x.numel(), keepalive=x)
+    rng = np.random.default_rng(1)
+    for c in range(ch):
+        loop.start(c, oracle.ca_code(c % 32 + 1), int(rng.integers(0, n)), 0, float(rng.uniform(-5000, 5000)))
+    ms = min(loop.time_run(E, reps=5) for _ in range(3))
+    print(os.environ.get("GSH_LIB_PATH", "current"), "channels", ch, "us/epoch %.3f" % (ms * 1e3 / E))
+    loop.close()
