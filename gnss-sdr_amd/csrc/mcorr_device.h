@@ -125,9 +125,11 @@ struct JobCtx
 };
 
 // One chunk = 256 pairs = 512 consecutive samples; thread `tid` owns samples n0, n0+1.
-template <int NT, int MODE, bool WRAP, bool MASKED>
+// ZP: the centre tap's shift is exactly 0.0f (the prompt of an E/P/L or VE/E/P/L/VL set): (a + 0.0f) == a, so its add is skipped.
+// nf0 = (float)n0, maintained by the caller (exact: sample indices stay below 2^24).
+template <int NT, int MODE, bool WRAP, bool MASKED, bool ZP = false>
 __device__ __forceinline__ void process_pair(const JobCtx& c, const float2* __restrict__ base, const float* __restrict__ tab,
-    const float (&sh)[NT], const int (&rot)[NT], int pair, float2 pa, float2 pb, float2 (&acc)[NT])
+    const float (&sh)[NT], const int (&rot)[NT], int pair, float2 pa, float2 pb, float2 (&acc)[NT], float nf0)
 {
     const int n0 = c.n_first + 2 * pair;
     float2 x0, x1;
@@ -149,13 +151,22 @@ __device__ __forceinline__ void process_pair(const JobCtx& c, const float2* __re
 
     if (!mode_hd_code(MODE))
         {
-            const float a0 = __fmul_rn(c.code_step, static_cast<float>(n0));
-            const float a1 = __fmul_rn(c.code_step, static_cast<float>(n0 + 1));
+            const float a0 = __fmul_rn(c.code_step, nf0);
+            const float a1 = __fmul_rn(c.code_step, __fadd_rn(nf0, 1.0f));
 #pragma unroll
             for (int t = 0; t < NT; t++)
                 {
-                    int k0 = raw_chip_std(a0, sh[t], c.rem_code);
-                    int k1 = raw_chip_std(a1, sh[t], c.rem_code);
+                    int k0, k1;
+                    if (ZP && t == NT / 2)
+                        {
+                            k0 = floor_to_int(__fsub_rn(a0, c.rem_code));
+                            k1 = floor_to_int(__fsub_rn(a1, c.rem_code));
+                        }
+                    else
+                        {
+                            k0 = raw_chip_std(a0, sh[t], c.rem_code);
+                            k1 = raw_chip_std(a1, sh[t], c.rem_code);
+                        }
                     if (WRAP)
                         {
                             k0 = wrap_chip(k0, c.code_len);
@@ -202,7 +213,7 @@ __device__ __forceinline__ void process_pair(const JobCtx& c, const float2* __re
         }
 }
 
-template <int NT, int MODE, bool WRAP>
+template <int NT, int MODE, bool WRAP, bool ZP = false>
 __device__ __forceinline__ void run_segment(const JobCtx& c, const float2* __restrict__ base, const float* __restrict__ tab,
     const float (&sh)[NT], const int (&rot)[NT], float2 (&acc)[NT])
 {
@@ -225,7 +236,7 @@ __device__ __forceinline__ void run_segment(const JobCtx& c, const float2* __res
                     const int n0 = c.n_first + 2 * pair;
                     const float2 pa = expmj(carrier_phase<HDP>(c.rem_carr, c.phase_step, c.phase_rate, n0));
                     const float2 pb = expmj(carrier_phase<HDP>(c.rem_carr, c.phase_step, c.phase_rate, n0 + 1));
-                    process_pair<NT, MODE, WRAP, true>(c, base, tab, sh, rot, pair, pa, pb, acc);
+                    process_pair<NT, MODE, WRAP, true>(c, base, tab, sh, rot, pair, pa, pb, acc, static_cast<float>(n0));
                 }
         }
 
@@ -241,7 +252,7 @@ __device__ __forceinline__ void run_segment(const JobCtx& c, const float2* __res
                             const int n0 = c.n_first + 2 * pair;
                             const float2 pa = expmj(carrier_phase<true>(c.rem_carr, c.phase_step, c.phase_rate, n0));
                             const float2 pb = expmj(carrier_phase<true>(c.rem_carr, c.phase_step, c.phase_rate, n0 + 1));
-                            process_pair<NT, MODE, WRAP, false>(c, base, tab, sh, rot, pair, pa, pb, acc);
+                            process_pair<NT, MODE, WRAP, false>(c, base, tab, sh, rot, pair, pa, pb, acc, static_cast<float>(n0));
                         }
                 }
             else
@@ -256,13 +267,15 @@ __device__ __forceinline__ void run_segment(const JobCtx& c, const float2* __res
                             // exact re-seed of this lane's phasor; the second sample of the pair is one step further
                             float2 pa = expmj(carrier_phase<false>(c.rem_carr, c.phase_step, 0.0f, c.n_first + 2 * pair));
                             float2 pb = cmul(pa, inc);
+                            float nf0 = static_cast<float>(c.n_first + 2 * pair);  // exact; advanced by 2 * 256 per chunk (exact below 2^24)
 #pragma unroll 2
                             for (int i = 0; i < cnt; i++)
                                 {
-                                    process_pair<NT, MODE, WRAP, false>(c, base, tab, sh, rot, pair, pa, pb, acc);
+                                    process_pair<NT, MODE, WRAP, false, ZP>(c, base, tab, sh, rot, pair, pa, pb, acc, nf0);
                                     pa = cmul(pa, w);
                                     pb = cmul(pb, w);
                                     pair += MC_PAIRS_PER_CHUNK;
+                                    nf0 = __fadd_rn(nf0, static_cast<float>(2 * MC_PAIRS_PER_CHUNK));
                                 }
                         }
                 }
@@ -277,7 +290,7 @@ __device__ __forceinline__ void run_segment(const JobCtx& c, const float2* __res
                     const int n0 = c.n_first + 2 * pair;
                     const float2 pa = expmj(carrier_phase<HDP>(c.rem_carr, c.phase_step, c.phase_rate, n0));
                     const float2 pb = expmj(carrier_phase<HDP>(c.rem_carr, c.phase_step, c.phase_rate, n0 + 1));
-                    process_pair<NT, MODE, WRAP, true>(c, base, tab, sh, rot, pair, pa, pb, acc);
+                    process_pair<NT, MODE, WRAP, true>(c, base, tab, sh, rot, pair, pa, pb, acc, static_cast<float>(n0));
                 }
         }
 }
@@ -350,7 +363,10 @@ __device__ __forceinline__ void correlate_window(const float2* __restrict__ stre
             const int lo = raw_chip_std(__fmul_rn(code_step, 0.0f), smin, rem_code);
             const int hi = raw_chip_std(__fmul_rn(code_step, static_cast<float>(n_samples - 1)), smax, rem_code);
             const bool fast = !mode_hd_code(MODE) && (code_step >= 0.0f) && (lo >= -MC_MARGIN) && (hi < code_len + MC_MARGIN) && (code_len >= MC_MARGIN);
-            if (fast)
+            const bool zp = (NT & 1) && (sh[NT / 2] == 0.0f) && !mode_hd_code(MODE) && (n_samples < (1 << 24));
+            if (fast && zp)
+                run_segment<NT, MODE, false, true>(c, base, tab, sh, rot, acc);
+            else if (fast)
                 run_segment<NT, MODE, false>(c, base, tab, sh, rot, acc);
             else
                 run_segment<NT, MODE, true>(c, base, tab, sh, rot, acc);

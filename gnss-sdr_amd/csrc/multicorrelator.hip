@@ -120,7 +120,11 @@ __global__ __launch_bounds__(MC_THREADS) void mcorr_kernel(McorrArgs a)
                     const int hi = raw_chip_std(__fmul_rn(c.code_step, static_cast<float>(c.n_end - 1)), smax, c.rem_code);
                     fast = (c.code_step >= 0.0f) && (lo >= -MC_MARGIN) && (hi < c.code_len + MC_MARGIN) && (c.code_len >= MC_MARGIN);
                 }
-            if (fast)
+            // centre tap at exactly 0 (E/P/L, VE/E/P/L/VL): its (a + 0.0f) is skipped; needs sample indices exact in float
+            const bool zp = (NT & 1) && (NT == J.n_taps) && (sh[NT / 2] == 0.0f) && !mode_hd_code(MODE) && (c.n_total < (1 << 24));
+            if (fast && zp)
+                run_segment<NT, MODE, false, true>(c, base, tab, sh, rot, acc);
+            else if (fast)
                 run_segment<NT, MODE, false>(c, base, tab, sh, rot, acc);
             else
                 run_segment<NT, MODE, true>(c, base, tab, sh, rot, acc);
