@@ -175,6 +175,7 @@ SYMBOLS = {
     "gsh_acq_dwell_step2": (C.c_int, [_P, _F, C.c_uint32, C.POINTER(C.c_uint32), _F, _F, C.c_int, C.c_uint32, C.POINTER(AcqResult)]),
     "gsh_acq_dwell_step2_device": (C.c_int, [_P, _P, C.c_uint32, C.POINTER(C.c_uint32), _F, _F, C.c_int, C.c_uint32, C.POINTER(AcqResult)]),
     "gsh_acq_dwell_cshort": (C.c_int, [_P, C.POINTER(C.c_int16), C.c_uint32, C.c_int, C.c_uint32, C.POINTER(AcqResult)]),
+    "gsh_acq_dwell_ring": (C.c_int, [_P, _P, C.c_uint64, C.c_uint32, C.c_int, C.c_uint32, C.POINTER(AcqResult)]),
     "gsh_acq_read_grid": (C.c_int, [_P, C.c_uint32, _F]),
     "gsh_acq_time_dwells": (C.c_int, [_P, C.c_uint32, C.c_int, _F]),
     "gsh_acq_time_dwells_pipelined": (C.c_int, [_P, C.c_uint32, C.c_int, _F]),

@@ -118,6 +118,12 @@ class PcpsAcquisitionBank:
                                             fptr(pw) if (input_powers is not None or self.conf.use_cfar) else None, int(accumulate), dwell_count, res))
         return [self._to_dict(r) for r in res]
 
+    def dwell_ring(self, ring, first_sample: int, n_prn: int, accumulate: bool = False, dwell_count: int = 1):
+        """One dwell over consumed_samples resident samples of a SampleStream ring starting at absolute index first_sample."""
+        res = (AcqResult * n_prn)()
+        check(self._lib.gsh_acq_dwell_ring(self._h, ring._h, int(first_sample), n_prn, int(accumulate), dwell_count, res))
+        return [self._to_dict(r) for r in res]
+
     def read_grid(self, prn_slot: int) -> np.ndarray:
         g = np.empty((self.num_doppler_bins, self.conf.effective_fft_size), np.float32)
         check(self._lib.gsh_acq_read_grid(self._h, prn_slot, fptr(g)))

@@ -5,6 +5,7 @@
 // them in every channel's block).
 #include "pcps_fft.h"
 #include "sample_convert.h"
+#include "sample_stream.h"
 #include <algorithm>
 #include <cmath>
 #include <limits>
@@ -422,6 +423,19 @@ extern "C"
         rc = enqueue_dwell(a, n_prn, accumulate, dwell_count);
         if (rc != GSH_OK) return rc;
         return finish_results(a, n_prn, results);
+    }
+
+    int gsh_acq_dwell_ring(gsh_acq_t* a, gsh_stream_t* ring, uint64_t first_sample, uint32_t n_prn, int accumulate, uint32_t dwell_count,
+        gsh_acq_result* results)
+    {
+        GSH_REQUIRE(a != nullptr && ring != nullptr, "null argument");
+        GSH_REQUIRE(ring->device == a->device, "the ring lives on device %d, the acquisition on device %d", ring->device, a->device);
+        const float2* w = nullptr;
+        int rc = gsh::stream_window(ring, first_sample, a->conf.consumed_samples, &w);
+        if (rc != GSH_OK) return rc;
+        GSH_HIP(hipSetDevice(a->device));
+        GSH_HIP(hipStreamWaitEvent(a->stream, ring->pushed, 0));  // conversions queued by gsh_stream_push_device
+        return gsh_acq_dwell_device(a, w, n_prn, accumulate, dwell_count, results);
     }
 
     int gsh_acq_dwell(gsh_acq_t* a, const float* in_iq, uint32_t n_prn, int accumulate, uint32_t dwell_count, gsh_acq_result* results)

@@ -402,6 +402,10 @@ extern "C"
     /* item_type = cshort (acq.cc:653-656): `in_iq16` holds consumed_samples interleaved int16 I,Q pairs, converted to
      * complex64 on the device (volk_gnsssdr_16ic_convert_32fc: exact int -> float), then as gsh_acq_dwell */
     int gsh_acq_dwell_cshort(gsh_acq_t* a, const int16_t* in_iq16, uint32_t n_prn, int accumulate, uint32_t dwell_count, gsh_acq_result* results);
+    /* the input block is consumed_samples resident samples of a device ring starting at absolute index first_sample (the ring's
+     * max_window_samples must cover consumed_samples): what the acquisition block copies out of its input buffer (acq.cc:790-815) */
+    int gsh_acq_dwell_ring(gsh_acq_t* a, gsh_stream_t* ring, uint64_t first_sample, uint32_t n_prn, int accumulate, uint32_t dwell_count,
+        gsh_acq_result* results);
     /* dump support (acq.cc:555-558): copy |.|^2 grid of one PRN, D rows of effective_fft_size floats */
     int gsh_acq_read_grid(gsh_acq_t* a, uint32_t prn_slot, float* grid);
     /* HIP-event average milliseconds per full dwell batch (n_prn codes), inputs resident */

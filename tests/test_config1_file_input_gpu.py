@@ -61,7 +61,8 @@ def test_file_input_acquisition_to_tracking(gpu, tmp_path, item_type):
     acq = PcpsAcquisitionBank(device=gpu, max_prn=1, **kw)
     code = oracle.ca_code_complex_sampled(1, FS)
     acq.set_local_code(0, code)
-    res = acq.dwell(ring.read(0, N), 1)[0]
+    res = acq.dwell_ring(ring, 0, 1)[0]                # straight from the device ring: the samples crossed PCIe once
+    assert res == acq.dwell(ring.read(0, N), 1)[0]     # ... and equal the dwell over the same samples handed over from the host
     ora = PcpsOracle(**kw)
     ora.set_local_code(code)
     exp = ora.dwell(xf[:N])
@@ -79,7 +80,7 @@ def test_file_input_acquisition_to_tracking(gpu, tmp_path, item_type):
     start = acq_stamp + int(round(delay))             # code start inside the NEXT period
     conf_kw = dict(fs_in=float(FS), vector_length=N, pll_bw_hz=40.0, dll_bw_hz=4.0, early_late_space_chips=0.5)
     loop = TrackingLoop(trk_conf(**conf_kw), 1, 1023, device=gpu)
-    loop.set_stream_host(xf)                          # the loop reads the same resident samples
+    loop.set_stream_ring(ring)                        # the loop reads the same resident samples (absolute sample indices)
     loop.start(0, oracle.ca_code(1), start, acq_stamp, float(res["doppler_hz"]))
     rec, done = loop.run(EPOCHS)
     ora_rec = oracle.trk_run(oracle.trk_conf(**conf_kw), oracle.ca_code(1), xf, start, acq_stamp, float(res["doppler_hz"]), EPOCHS)
