@@ -203,3 +203,26 @@ def test_oracle_loop_lock_detectors_declare_loss_on_noise_only():
             break
     assert lost_at == len(rec) - 1
     assert rec[-1].prn_length_samples == 0
+
+
+def test_trackstate_restatements_equal_the_golden_vectors():
+    """tests/golden/trackstate.npz holds outputs of the reference's own lock_detectors.cc / exponential_smoother.cc / bit_synchronizer.cc
+    (minted by tests/golden/make_golden_trackstate.py from oracle/_ref); the C restatements must reproduce them bit for bit -- this pin
+    does not need the reference tree at test time."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "trackstate.npz"))
+    for i, p in enumerate(g["lock_prompts"]):
+        for j, t in enumerate((0.001, 0.004, 0.02)):
+            a, b = np.float32(oracle.cn0_m2m4_estimator(p, t)), g["lock_cn0_out"][i, j]
+            assert (np.isnan(a) and np.isnan(b)) or a == b
+        assert np.float32(oracle.carrier_lock_detector(p)) == g["lock_detector_out"][i, 0]
+        assert np.float32(oracle.carrier_lock_detector(p, 1)) == g["lock_detector_out"][i, 1]
+    k = 0
+    for (alpha, n_init, mn, off) in g["smoother_cfg"]:
+        for _ in range(5):
+            got = oracle.smoother_run(float(alpha), int(n_init), g["smoother_raw"][k], float(mn), float(off))
+            assert np.array_equal(got.view(np.uint32), g["smoother_out"][k].view(np.uint32)), k
+            k += 1
+    for cfg, p, ok, ev, un in zip(g["bitsync_cfg"], g["bitsync_prompts"], g["bitsync_ok"], g["bitsync_event_out"], g["bitsync_until_edge_out"]):
+        e2, u2 = oracle.bit_sync_run(p, int(cfg[0]), int(cfg[1]), int(cfg[2]), float(cfg[3]), float(cfg[4]), bool(cfg[5]), quality_ok=ok)
+        assert np.array_equal(e2, ev) and np.array_equal(u2, un)
