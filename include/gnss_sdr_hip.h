@@ -188,7 +188,11 @@ extern "C"
     void gsh_fir_destroy(gsh_fir_t* f);
     int gsh_fir_process_device(gsh_fir_t* f, const void* device_in, uint64_t n_in, void* device_out, uint64_t max_out, uint64_t* n_out, void* hip_stream);
     /* bind a bank to a ring: from now on gsh_corr_job.sample_offset is an ABSOLUTE sample index; a job whose window is not
-     * fully resident (or longer than max_window_samples) fails with GSH_ERR_INVALID.  NULL detaches. */
+     * fully resident (or longer than max_window_samples) fails with GSH_ERR_INVALID.  NULL detaches.
+     * Residency is checked when the job table is staged (gsh_bank_correlate / gsh_bank_upload_jobs): a table uploaded once and
+     * launched repeatedly (gsh_bank_launch) keeps pointing at the ring positions it was translated to, so the caller must not push
+     * past those windows in between.  The handles are not internally synchronised: one thread at a time per handle, and pushes
+     * into a ring are serialised against the calls that read it (Hip_Correlator_Runtime does both for a receiver). */
     int gsh_bank_set_stream_ring(gsh_bank_t* b, gsh_stream_t* s);
 
     /* ================================================================ TRACKING LOOP (closed on the device)
