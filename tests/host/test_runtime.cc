@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <random>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -51,6 +52,9 @@ int main(int argc, char** argv)
 {
     const int C = argc > 1 ? std::atoi(argv[1]) : 32;
     const int E = argc > 2 ? std::atoi(argv[2]) : 200;
+    // "mixed": odd channels run the high-dynamics resampler + rotator (trk.cc:675), so every batch holds two correlator flavours and the
+    // runtime has to split it into one launch per flavour
+    const bool mixed = argc > 3 && std::string(argv[3]) == "mixed";
     const int N = 25000, T = 3;
     const double fs = 25e6;
     const uint64_t total = static_cast<uint64_t>(E + 2) * N;
@@ -119,7 +123,7 @@ int main(int argc, char** argv)
             {
                 mc[c] = std::make_unique<Hip_Multicorrelator_Batched>(&rt);
                 EXPECT(mc[c]->init(2 * N, T), "init: %s", mc[c]->last_error().c_str());
-                mc[c]->set_high_dynamics_resampler(false);
+                mc[c]->set_high_dynamics_resampler(mixed && (c & 1));
                 EXPECT(mc[c]->set_local_code_and_taps(1023, ch[c].code.data(), shifts[c].data()), "set_local_code_and_taps: %s", mc[c]->last_error().c_str());
             }
         const auto t0 = std::chrono::steady_clock::now();
@@ -156,7 +160,9 @@ int main(int argc, char** argv)
                                 break;
                             }
                         mc[c]->set_input_sample_index(w0);
-                        const bool ok = mc[c]->Carrier_wipeoff_multicorrelator_resampler(ch[c].rem_carr, ch[c].phase_step, 0.0F, ch[c].rem_code, ch[c].code_step, 0.0F, N);
+                        const bool hd = mixed && (c & 1);
+                        const bool ok = mc[c]->Carrier_wipeoff_multicorrelator_resampler(ch[c].rem_carr, ch[c].phase_step, hd ? 2.0e-9F : 0.0F, ch[c].rem_code, ch[c].code_step,
+                            hd ? 1.0e-9F : 0.0F, N);
                         EXPECT(ok, "channel %d epoch %d: %s", c, e, mc[c]->last_error().c_str());
                         if (!ok) break;
                         for (int t = 0; t < T; t++) ch[c].results[static_cast<size_t>(e) * T + t] = outs[t];
@@ -177,8 +183,9 @@ int main(int argc, char** argv)
             {
                 const uint64_t w0 = ch[c].offset + static_cast<uint64_t>(e) * N;
                 double truth[2 * T], sabs = 0.0;
-                oracle_mcorr_f64(ch[c].code.data(), 1023, shifts_init, T, reinterpret_cast<const float*>(xf.data() + w0), N, ch[c].rem_carr, ch[c].phase_step, 0.0F,
-                    ch[c].rem_code, ch[c].code_step, 0.0F, 0, truth, &sabs);
+                const bool hd = mixed && (c & 1);
+                oracle_mcorr_f64(ch[c].code.data(), 1023, shifts_init, T, reinterpret_cast<const float*>(xf.data() + w0), N, ch[c].rem_carr, ch[c].phase_step, hd ? 2.0e-9F : 0.0F,
+                    ch[c].rem_code, ch[c].code_step, hd ? 1.0e-9F : 0.0F, hd ? 1 : 0, truth, &sabs);
                 for (int t = 0; t < T; t++)
                     {
                         const auto& r = ch[c].results[static_cast<size_t>(e) * T + t];
@@ -191,6 +198,7 @@ int main(int argc, char** argv)
 
     // ---------------------------------------------------------------- the synchronous drop-in class, same work, same threads
     double dropin_s = 0.0;
+    if (!mixed)
     {
         const int E2 = std::min(E, 50);
         std::vector<std::unique_ptr<Hip_Multicorrelator_Real_Codes>> mc(C);

@@ -23,3 +23,14 @@ def test_batching_runtime_threads(gpu):
     print(line)
     assert st["avg_batch"] > 4.0          # the rendezvous really batches channels together
     assert st["worst_scale_error"] < 1e-6
+
+
+@pytest.mark.gpu
+def test_batching_runtime_mixed_correlator_flavours(gpu):
+    """Odd channels in high-dynamics mode: every rendezvous holds two kernel flavours and is split into one launch per flavour;
+    all results (both flavours) are checked against the float64 oracle inside the program."""
+    if not os.path.exists(BIN):
+        import __graft_entry__ as g
+        g.build_host_test()
+    r = subprocess.run([BIN, "16", "40", "mixed"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RUNTIME OK" in r.stdout, r.stdout[-4000:] + r.stderr[-2000:]
