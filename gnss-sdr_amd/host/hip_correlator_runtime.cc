@@ -35,7 +35,7 @@ uint64_t Hip_Sample_Ring::push_items(const void* items, uint64_t n, int item_typ
                 d_error = gsh_last_error();
                 return UINT64_MAX;
             }
-        d_next = first + n;
+        d_next.store(first + n, std::memory_order_release);
     }
     d_pushed.notify_all();
     return first;
@@ -72,8 +72,9 @@ void Hip_Sample_Ring::range(uint64_t* oldest, uint64_t* next) const
 
 bool Hip_Sample_Ring::wait_for(uint64_t end, std::chrono::milliseconds timeout) const
 {
+    if (d_next.load(std::memory_order_acquire) >= end) return true;  // the usual case: no lock, no convoy behind a running launch
     std::unique_lock<std::mutex> lk(d_mutex);
-    return d_pushed.wait_for(lk, timeout, [&] { return d_next >= end; });
+    return d_pushed.wait_for(lk, timeout, [&] { return d_next.load(std::memory_order_acquire) >= end; });
 }
 
 
@@ -81,6 +82,7 @@ bool Hip_Sample_Ring::wait_for(uint64_t end, std::chrono::milliseconds timeout) 
 Hip_Correlator_Runtime::Hip_Correlator_Runtime(Hip_Sample_Ring* ring, int max_channels, int max_code_length, std::chrono::microseconds max_wait, int spin_us)
     : d_ring(ring), d_max_wait(max_wait), d_current(std::make_shared<Batch>())
 {
+    d_current->jobs.reserve(static_cast<size_t>(std::max(max_channels, 1)));
     d_spin_us = spin_us >= 0 ? spin_us : (static_cast<int>(std::thread::hardware_concurrency()) >= 2 * max_channels ? 150 : 0);
     if (ring == nullptr || !ring->ok())
         {
@@ -141,6 +143,14 @@ bool Hip_Correlator_Runtime::set_code(int channel, const float* code, int code_l
             return false;
         }
     return true;
+}
+
+
+std::shared_ptr<Hip_Correlator_Runtime::Batch> Hip_Correlator_Runtime::new_batch() const
+{
+    auto b = std::make_shared<Batch>();
+    b->jobs.reserve(d_slot_used.size());  // arrivals never reallocate while they hold d_mutex
+    return b;
 }
 
 
@@ -221,7 +231,7 @@ bool Hip_Correlator_Runtime::correlate(int channel, const gsh_corr_job& job_in, 
             {
                 // this arrival completes the batch: close it and launch from this very thread
                 b->taken = true;
-                d_current = std::make_shared<Batch>();  // later arrivals start the next batch
+                d_current = new_batch();  // later arrivals start the next batch
                 close_now = true;
             }
         else if (first)
@@ -236,7 +246,7 @@ bool Hip_Correlator_Runtime::correlate(int channel, const gsh_corr_job& job_in, 
                 if (!b->taken)
                     {
                         b->taken = true;
-                        if (d_current == b) d_current = std::make_shared<Batch>();
+                        if (d_current == b) d_current = new_batch();
                         close_now = true;
                         lk.unlock();
                         run_batch(b, static_cast<int>(b->jobs.size()) < d_active);

@@ -65,7 +65,7 @@ private:
     std::string d_error;
     mutable std::mutex d_mutex;  // serialises pushes against job translation (the C handle is not thread-safe)
     mutable std::condition_variable d_pushed;
-    uint64_t d_next{0};
+    std::atomic<uint64_t> d_next{0};  // read without the lock on the fast path of wait_for (32 channel threads ask at the same instant)
     friend class Hip_Correlator_Runtime;
 };
 
@@ -115,6 +115,7 @@ private:
         std::string error;
     };
     void run_batch(const std::shared_ptr<Batch>& b, bool timed_out);
+    std::shared_ptr<Batch> new_batch() const;
     Hip_Sample_Ring* d_ring;
     gsh_bank_t* d_bank{nullptr};
     std::string d_error;
