@@ -9,8 +9,12 @@
 // Prints "ADAPTERS OK".  Built by __graft_entry__.build() when /root/reference is present; run by tests/test_adapters_gpu.py.
 #include "galileo_e1_pcps_ambiguous_acquisition_hip.h"
 #include "galileo_e1_signal_replica.h"
+#include "galileo_e5_signal_replica.h"
+#include "galileo_e5a_pcps_acquisition_hip.h"
 #include "gnss_synchro.h"
 #include "gps_l1_ca_pcps_acquisition_hip.h"
+#include "gps_l2_m_pcps_acquisition_hip.h"
+#include "gps_l2c_signal_replica.h"
 #include "gps_l5_signal_replica.h"
 #include "gps_l5i_pcps_acquisition_hip.h"
 #include "gps_sdr_signal_replica.h"
@@ -233,6 +237,50 @@ int main()
         EXPECT(std::fabs(syn.Acq_delay_samples - 4321.0) <= 1.0, "GPS L5 delay %f", syn.Acq_delay_samples);
         // the reference's own acquisition tests accept 2/(3 T_int) = 666 Hz at 1 ms (gps_l1_ca_pcps_acquisition_gsoc2013_test.cc:384-401)
         EXPECT(std::fabs(syn.Acq_doppler_hz + 3010.0) <= 500.0, "GPS L5 doppler %f", syn.Acq_doppler_hz);
+    }
+    // ------------------------------------------------------------------ GPS L2C (M): 20 ms code at 4 Msps -> an 80 000-point transform (four-step path)
+    {
+        const long fs = 4000000;
+        auto conf = base_config("Acquisition_2S", fs);
+        GpsL2MPcpsAcquisitionHip acq(conf.get(), "Acquisition_2S", 1, 0);
+        EXPECT(acq.implementation() == "GPS_L2_M_PCPS_Acquisition_HIP" && acq.item_size() == sizeof(gr_complex), "L2C adapter: item_size %zu", acq.item_size());
+        Gnss_Synchro syn{};
+        syn.System = 'G';
+        std::memcpy(syn.Signal, "2S", 3);
+        syn.PRN = 9;
+        acq.set_gnss_synchro(&syn);
+        acq.set_local_code();
+        std::vector<std::complex<float>> rep(80000);
+        gps_l2c_m_code_gen_complex_sampled(rep, 9, static_cast<int32_t>(fs));
+        // 20 ms of coherent integration: the Doppler response is 50 Hz wide, so the signal sits on a grid point of the 250 Hz search
+        auto x = make_stream(rep, 400000, fs, 31007, 1250.0, 0.03F, 5);
+        acq.reset();
+        auto r = run_block(acq, x, 8192);
+        EXPECT(r.event == 1, "GPS L2C: event %ld", r.event);
+        EXPECT(std::fabs(syn.Acq_delay_samples - 31007.0) <= 2.0, "GPS L2C delay %f", syn.Acq_delay_samples);
+        EXPECT(syn.Acq_doppler_hz == 1250.0, "GPS L2C doppler %f", syn.Acq_doppler_hz);
+    }
+    // ------------------------------------------------------------------ Galileo E5a (data component) at 12.5 Msps (12 500-point transform)
+    {
+        const long fs = 12500000;
+        auto conf = base_config("Acquisition_5X", fs);
+        GalileoE5aPcpsAcquisitionHip acq(conf.get(), "Acquisition_5X", 1, 0);
+        EXPECT(acq.implementation() == "Galileo_E5a_Pcps_Acquisition_HIP", "E5a name");
+        Gnss_Synchro syn{};
+        syn.System = 'E';
+        std::memcpy(syn.Signal, "5X", 3);
+        syn.PRN = 19;
+        acq.set_gnss_synchro(&syn);
+        acq.set_local_code();
+        std::vector<std::complex<float>> rep(12500);
+        const std::array<char, 3> sig = {{'5', 'I', '\0'}};
+        galileo_e5_a_code_gen_complex_sampled(rep, 19, sig, static_cast<int32_t>(fs), 0);
+        auto x = make_stream(rep, 100000, fs, 7777, 2480.0, 0.07F, 6);
+        acq.reset();
+        auto r = run_block(acq, x, 8192);
+        EXPECT(r.event == 1, "Galileo E5a: event %ld", r.event);
+        EXPECT(std::fabs(syn.Acq_delay_samples - 7777.0) <= 1.0, "Galileo E5a delay %f", syn.Acq_delay_samples);
+        EXPECT(std::fabs(syn.Acq_doppler_hz - 2480.0) <= 500.0, "Galileo E5a doppler %f", syn.Acq_doppler_hz);
     }
     // ------------------------------------------------------------------ an item type the engine does not ingest: unusable block, not a crash
     {
