@@ -165,10 +165,20 @@ __global__ __launch_bounds__(P::THREADS) void oc_cell_kernel(OcCellArgs a)
         {
             const cf* __restrict__ X = a.spectra + static_cast<size_t>(bin) * P::N + t;
             const cf* __restrict__ C = a.codes + static_cast<size_t>(prn) * P::N + t;
+            // all 2 * R1 operand loads are issued before the first product: the cell's registers are still free here, and one round of
+            // L2 / Infinity-Cache latency is cheaper than the two the scheduler otherwise settles for (12 loads, wait, 38 loads)
+            cf xv[P::R1], cv[P::R1];
             oc::static_for<P::R1>([&](auto N1) GSH_AI {
                 constexpr int n1 = decltype(N1)::value;
-                ra[n1] = oc::cmul_conj(X[n1 * P::T1], C[n1 * P::T1]);
+                xv[n1] = X[n1 * P::T1];
+                cv[n1] = C[n1 * P::T1];
             });
+            __builtin_amdgcn_sched_group_barrier(0x20, 2 * P::R1, 0);  // VMEM reads first ...
+            oc::static_for<P::R1>([&](auto N1) GSH_AI {
+                constexpr int n1 = decltype(N1)::value;
+                ra[n1] = oc::cmul_conj(xv[n1], cv[n1]);
+            });
+            __builtin_amdgcn_sched_group_barrier(0x2, 8 * P::R1, 0);   // ... then the products
             P::stage1(ra, t);
         }
     exchange1<P>(ra, rb, t, lds);
