@@ -152,7 +152,9 @@ __device__ __forceinline__ void process_pair(const JobCtx& c, const float2* __re
     if (!mode_hd_code(MODE))
         {
             const float a0 = __fmul_rn(c.code_step, nf0);
-            const float a1 = __fmul_rn(c.code_step, __fadd_rn(nf0, 1.0f));
+            // (float)(n0 + 1): on the ZP path (selected only for windows shorter than 2^24 samples) nf0 + 1.0f is exactly that value
+            const float nf1 = ZP ? __fadd_rn(nf0, 1.0f) : static_cast<float>(n0 + 1);
+            const float a1 = __fmul_rn(c.code_step, nf1);
 #pragma unroll
             for (int t = 0; t < NT; t++)
                 {
@@ -267,7 +269,9 @@ __device__ __forceinline__ void run_segment(const JobCtx& c, const float2* __res
                             // exact re-seed of this lane's phasor; the second sample of the pair is one step further
                             float2 pa = expmj(carrier_phase<false>(c.rem_carr, c.phase_step, 0.0f, c.n_first + 2 * pair));
                             float2 pb = cmul(pa, inc);
-                            float nf0 = static_cast<float>(c.n_first + 2 * pair);  // exact; advanced by 2 * 256 per chunk (exact below 2^24)
+                            // on the ZP path (windows shorter than 2^24 samples) (float)n is carried along and advanced by 2 * 256 per chunk,
+                            // which is exact there; the general path converts every time, as the reference's (float)n does
+                            float nf0 = static_cast<float>(c.n_first + 2 * pair);
 #pragma unroll 2
                             for (int i = 0; i < cnt; i++)
                                 {
@@ -275,7 +279,7 @@ __device__ __forceinline__ void run_segment(const JobCtx& c, const float2* __res
                                     pa = cmul(pa, w);
                                     pb = cmul(pb, w);
                                     pair += MC_PAIRS_PER_CHUNK;
-                                    nf0 = __fadd_rn(nf0, static_cast<float>(2 * MC_PAIRS_PER_CHUNK));
+                                    nf0 = ZP ? __fadd_rn(nf0, static_cast<float>(2 * MC_PAIRS_PER_CHUNK)) : static_cast<float>(c.n_first + 2 * pair);
                                 }
                         }
                 }
