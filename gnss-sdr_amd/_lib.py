@@ -170,6 +170,12 @@ SYMBOLS = {
     "gsh_acq_destroy": (None, [_P]),
     "gsh_acq_set_local_code": (C.c_int, [_P, C.c_uint32, _F]),
     "gsh_acq_set_doppler_center": (C.c_int, [_P, C.c_int32]),
+    "gsh_acq_set_grid_weight": (C.c_int, [_P, C.c_float]),
+    "gsh_acq_input_power": (C.c_int, [_P, C.POINTER(C.c_float)]),
+    "gsh_acq_stage_input": (C.c_int, [_P, C.POINTER(C.c_float)]),
+    "gsh_acq_stage_input_device": (C.c_int, [_P, C.c_void_p]),
+    "gsh_acq_dwell_resident": (C.c_int, [_P, C.c_uint32, C.c_int, C.c_uint32, C.POINTER(AcqResult)]),
+    "gsh_acq_read_row_peaks": (C.c_int, [_P, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]),
     "gsh_acq_dwell": (C.c_int, [_P, _F, C.c_uint32, C.c_int, C.c_uint32, C.POINTER(AcqResult)]),
     "gsh_acq_dwell_device": (C.c_int, [_P, _P, C.c_uint32, C.c_int, C.c_uint32, C.POINTER(AcqResult)]),
     "gsh_acq_dwell_step2": (C.c_int, [_P, _F, C.c_uint32, C.POINTER(C.c_uint32), _F, _F, C.c_int, C.c_uint32, C.POINTER(AcqResult)]),

@@ -83,6 +83,42 @@ class PcpsAcquisitionBank:
     def set_doppler_center(self, doppler_center: int) -> None:
         check(self._lib.gsh_acq_set_doppler_center(self._h, int(doppler_center)))
 
+    def set_grid_weight(self, weight: float) -> None:
+        """Factor applied to every |y|^2 before it reaches the grid (pcps_tong_acquisition_cc.cc:243-249)."""
+        check(self._lib.gsh_acq_set_grid_weight(self._h, float(weight)))
+
+    def input_power(self) -> float:
+        """mean |x|^2 of the block most recently handed to a dwell (pcps_tong_acquisition_cc.cc:208-210)."""
+        p = C.c_float(0.0)
+        check(self._lib.gsh_acq_input_power(self._h, C.byref(p)))
+        return float(p.value)
+
+    def stage_input(self, x) -> None:
+        """Make x[:consumed_samples] (numpy array or torch cuda tensor) the handle's resident block without running a dwell."""
+        if hasattr(x, "data_ptr"):
+            check(self._lib.gsh_acq_stage_input_device(self._h, C.c_void_p(x.data_ptr())))
+            return
+        x = np.ascontiguousarray(x, np.complex64)
+        if len(x) < self.conf.consumed_samples:
+            raise ValueError("input shorter than consumed_samples")
+        check(self._lib.gsh_acq_stage_input(self._h, fptr(x)))
+
+    def stage_and_input_power(self, x) -> float:
+        self.stage_input(x)
+        return self.input_power()
+
+    def dwell_resident(self, n_prn: int, accumulate: bool = False, dwell_count: int = 1):
+        res = (AcqResult * n_prn)()
+        check(self._lib.gsh_acq_dwell_resident(self._h, n_prn, int(accumulate), dwell_count, res))
+        return [self._to_dict(r) for r in res]
+
+    def read_row_peaks(self, prn_slot: int):
+        """(per-bin maximum, per-bin lowest arg-max) of prn_slot's grid after the last dwell."""
+        pk = np.empty(self.num_doppler_bins, np.float32)
+        ix = np.empty(self.num_doppler_bins, np.uint32)
+        check(self._lib.gsh_acq_read_row_peaks(self._h, prn_slot, fptr(pk), ix.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return pk, ix
+
     def dwell(self, x: np.ndarray, n_prn: int, accumulate: bool = False, dwell_count: int = 1):
         """One acquisition_core pass over x[:consumed_samples] for prn slots 0..n_prn-1.  Returns a list of dicts."""
         x = np.ascontiguousarray(x, np.complex64)

@@ -39,6 +39,8 @@ struct gsh_acq
     int chunk_prn{1};
     bool onchip{false};  // whole-transform-on-chip path (pcps_onchip.hip); spectra then sit in natural order
     bool have_input{false};
+    float grid_weight{1.0f};  // gsh_acq_set_grid_weight
+    double* d_power{nullptr};  // gsh_acq_input_power scratch
     hipEvent_t ev0{nullptr}, ev1{nullptr};
     // second issue lane for gsh_acq_time_dwells_pipelined (on-chip path): its own stream and per-batch buffers, so that
     // batch k+1's forward transforms fill the compute units batch k's last cells leave idle
@@ -53,6 +55,30 @@ struct gsh_acq
 namespace
 {
 using gsh::set_error;
+
+// sum of |x|^2 over one input block (pcps_tong_acquisition_cc.cc:208-209, galileo_pcps_8ms_acquisition_cc.cc:190-191).
+// Each term is the float the reference's volk_32fc_magnitude_squared_32f forms; the terms are added in double (the
+// reference's volk_32f_accumulator_s32f adds them in float in an ISA-dependent lane order, so its last bits are not defined).
+__global__ __launch_bounds__(1024) void input_power_kernel(const float2* __restrict__ x, int n, double* __restrict__ out)
+{
+    __shared__ double part[16];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 1024)
+        {
+            const float2 v = x[i];
+            s += static_cast<double>(__fadd_rn(__fmul_rn(v.x, v.x), __fmul_rn(v.y, v.y)));
+        }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        {
+            double t = 0.0;
+            for (int w = 0; w < 16; w++) t += part[w];
+            *out = t;
+        }
+}
 
 void fill_bins(gsh_acq* a)
 {
@@ -83,7 +109,7 @@ int enqueue_dwell(gsh_acq* a, uint32_t n_prn, int accumulate, uint32_t dwell_cou
             // acq.cc:538-553 + the per-row part of :409-519: one work-group per (PRN, bin) cell, nothing leaves the CU
             return gsh::onchip_correlate(n, a->d_spectra, a->d_codes, a->d_grid, a->d_rows, a->d_results, a->d_arrivals, static_cast<int>(n_prn),
                 a->n_bins, eff, accumulate, c.no_grid ? 0 : 1, static_cast<int>(c.samples_per_chip), c.use_cfar, dwell_count ? dwell_count : 1u,
-                a->stream);
+                a->grid_weight, a->stream);
         }
     // acq.cc:657-664 (zero padding) + :531-535 (wipe-off, forward FFT) for every bin
     int rc = gsh::fft_forward(a->plan, a->d_in, 0, static_cast<int>(c.consumed_samples), 0, a->d_bins_hz, static_cast<double>(c.fs_in),
@@ -94,7 +120,7 @@ int enqueue_dwell(gsh_acq* a, uint32_t n_prn, int accumulate, uint32_t dwell_cou
         {
             const int np = static_cast<int>(std::min<uint32_t>(a->chunk_prn, n_prn - p0));
             rc = gsh::correlate_grid(a->plan, a->d_spectra, a->d_codes + static_cast<size_t>(p0) * n, a->d_tmp,
-                a->d_grid + static_cast<size_t>(p0) * a->n_bins * eff, np, a->n_bins, grid_off, eff, accumulate, a->stream);
+                a->d_grid + static_cast<size_t>(p0) * a->n_bins * eff, np, a->n_bins, grid_off, eff, accumulate, a->grid_weight, a->stream);
             if (rc != GSH_OK) return rc;
         }
     return gsh::grid_statistics(a->d_grid, a->d_rows, a->d_results, static_cast<int>(n_prn), a->n_bins, eff,
@@ -323,6 +349,7 @@ extern "C"
         if (a->d_bins_hz) (void)hipFree(a->d_bins_hz);
         if (a->d_bins2_hz) (void)hipFree(a->d_bins2_hz);
         if (a->d_in16) (void)hipFree(a->d_in16);
+        if (a->d_power) (void)hipFree(a->d_power);
         if (a->d_in) (void)hipFree(a->d_in);
         if (a->d_spectra) (void)hipFree(a->d_spectra);
         if (a->d_codes) (void)hipFree(a->d_codes);
@@ -411,6 +438,32 @@ extern "C"
         return GSH_OK;
     }
 
+    int gsh_acq_set_grid_weight(gsh_acq_t* a, float weight)
+    {
+        GSH_REQUIRE(a != nullptr, "null handle");
+        GSH_REQUIRE(std::isfinite(weight), "weight must be finite");
+        if (weight != 1.0f && a->conf.no_grid)
+            return set_error(GSH_ERR_STATE, "a grid weight applies to the stored grid, but the handle was created with no_grid = 1");
+        a->grid_weight = weight;
+        return GSH_OK;
+    }
+
+    int gsh_acq_input_power(gsh_acq_t* a, float* mean_power)
+    {
+        GSH_REQUIRE(a != nullptr && mean_power != nullptr, "null argument");
+        if (!a->have_input) return set_error(GSH_ERR_STATE, "no input block has been handed to this handle yet");
+        GSH_HIP(hipSetDevice(a->device));
+        if (a->d_power == nullptr) GSH_HIP(hipMalloc(&a->d_power, sizeof(double)));
+        hipLaunchKernelGGL(input_power_kernel, dim3(1), dim3(1024), 0, a->stream, a->d_in, static_cast<int>(a->conf.consumed_samples), a->d_power);
+        GSH_HIP(hipGetLastError());
+        double sum = 0.0;
+        GSH_HIP(hipMemcpyAsync(&sum, a->d_power, sizeof(double), hipMemcpyDeviceToHost, a->stream));
+        GSH_HIP(hipStreamSynchronize(a->stream));
+        // pcps_tong_acquisition_cc.cc:208-210: float sum of float |x|^2, then / (float) fft_size
+        *mean_power = static_cast<float>(sum) / static_cast<float>(a->conf.consumed_samples);
+        return GSH_OK;
+    }
+
     int gsh_acq_dwell_device(gsh_acq_t* a, const void* device_in_iq, uint32_t n_prn, int accumulate, uint32_t dwell_count, gsh_acq_result* results)
     {
         int rc = check_dwell_args(a, n_prn, results);
@@ -420,6 +473,38 @@ extern "C"
         GSH_HIP(hipSetDevice(a->device));
         GSH_HIP(hipMemcpyAsync(a->d_in, device_in_iq, sizeof(float2) * a->conf.consumed_samples, hipMemcpyDeviceToDevice, a->stream));
         a->have_input = true;
+        rc = enqueue_dwell(a, n_prn, accumulate, dwell_count);
+        if (rc != GSH_OK) return rc;
+        return finish_results(a, n_prn, results);
+    }
+
+    int gsh_acq_stage_input(gsh_acq_t* a, const float* in_iq)
+    {
+        GSH_REQUIRE(a != nullptr && in_iq != nullptr, "null argument");
+        GSH_HIP(hipSetDevice(a->device));
+        std::memcpy(a->h_stage, in_iq, sizeof(float2) * a->conf.consumed_samples);
+        GSH_HIP(hipMemcpyAsync(a->d_in, a->h_stage, sizeof(float2) * a->conf.consumed_samples, hipMemcpyHostToDevice, a->stream));
+        GSH_HIP(hipStreamSynchronize(a->stream));  // h_stage may be rewritten by the next call
+        a->have_input = true;
+        return GSH_OK;
+    }
+
+    int gsh_acq_stage_input_device(gsh_acq_t* a, const void* device_in_iq)
+    {
+        GSH_REQUIRE(a != nullptr && device_in_iq != nullptr, "null argument");
+        GSH_HIP(hipSetDevice(a->device));
+        GSH_HIP(hipMemcpyAsync(a->d_in, device_in_iq, sizeof(float2) * a->conf.consumed_samples, hipMemcpyDeviceToDevice, a->stream));
+        a->have_input = true;
+        return GSH_OK;
+    }
+
+    int gsh_acq_dwell_resident(gsh_acq_t* a, uint32_t n_prn, int accumulate, uint32_t dwell_count, gsh_acq_result* results)
+    {
+        int rc = check_dwell_args(a, n_prn, results);
+        if (rc == GSH_OK) rc = check_accumulate(a, accumulate);
+        if (rc != GSH_OK) return rc;
+        if (!a->have_input) return set_error(GSH_ERR_STATE, "no input block resident: call gsh_acq_stage_input[_device] first");
+        GSH_HIP(hipSetDevice(a->device));
         rc = enqueue_dwell(a, n_prn, accumulate, dwell_count);
         if (rc != GSH_OK) return rc;
         return finish_results(a, n_prn, results);
@@ -502,7 +587,7 @@ extern "C"
                         if (rc != GSH_OK) return rc;
                         rc = gsh::onchip_correlate(nfft, a->d_spectra, a->d_codes + static_cast<size_t>(slot) * nfft, grid, a->d_rows + static_cast<size_t>(i) * D2,
                             a->d_results + i, a->d_arrivals + i, 1, D2, eff, accumulate, c.no_grid ? 0 : 1, static_cast<int>(c.samples_per_chip), c.use_cfar,
-                            dwell_count ? dwell_count : 1u, a->stream);
+                            dwell_count ? dwell_count : 1u, a->grid_weight, a->stream);
                     }
                 else
                     {
@@ -510,7 +595,7 @@ extern "C"
                             a->d_spectra, D2, a->stream);
                         if (rc != GSH_OK) return rc;
                         rc = gsh::correlate_grid(a->plan, a->d_spectra, a->d_codes + static_cast<size_t>(slot) * nfft, a->d_tmp, grid, 1, D2,
-                            c.bit_transition_flag ? eff : 0, eff, accumulate, a->stream);
+                            c.bit_transition_flag ? eff : 0, eff, accumulate, a->grid_weight, a->stream);
                         if (rc != GSH_OK) return rc;
                         rc = gsh::grid_statistics(grid, a->d_rows + static_cast<size_t>(i) * D2, a->d_results + i, 1, D2, eff, static_cast<int>(c.samples_per_chip),
                             c.use_cfar, dwell_count ? dwell_count : 1u, a->stream);
@@ -596,6 +681,24 @@ extern "C"
         return GSH_OK;
     }
 
+    int gsh_acq_read_row_peaks(gsh_acq_t* a, uint32_t prn_slot, float* row_peak, uint32_t* row_index_time)
+    {
+        GSH_REQUIRE(a != nullptr && row_peak != nullptr && row_index_time != nullptr, "null argument");
+        GSH_REQUIRE(prn_slot < a->conf.max_prn, "prn_slot %u outside 0..%u", prn_slot, a->conf.max_prn - 1);
+        if (!a->have_input) return set_error(GSH_ERR_STATE, "no dwell has run on this handle yet");
+        GSH_HIP(hipSetDevice(a->device));
+        std::vector<gsh::RowStat> rows(static_cast<size_t>(a->n_bins));
+        GSH_HIP(hipMemcpyAsync(rows.data(), a->d_rows + static_cast<size_t>(prn_slot) * a->n_bins, sizeof(gsh::RowStat) * a->n_bins, hipMemcpyDeviceToHost,
+            a->stream));
+        GSH_HIP(hipStreamSynchronize(a->stream));
+        for (int d = 0; d < a->n_bins; d++)
+            {
+                row_peak[d] = rows[static_cast<size_t>(d)].maxv;
+                row_index_time[d] = rows[static_cast<size_t>(d)].idx;
+            }
+        return GSH_OK;
+    }
+
     int gsh_acq_time_dwells(gsh_acq_t* a, uint32_t n_prn, int reps, float* avg_ms)
     {
         GSH_REQUIRE(a != nullptr && avg_ms != nullptr, "null argument");
@@ -648,7 +751,7 @@ extern "C"
             // no_grid handles only: two batches in flight must not share the magnitude grid
             return gsh::onchip_correlate(static_cast<int>(n), spectra, a->d_codes, a->d_grid, lane ? a->d_rows2 : a->d_rows,
                 lane ? a->d_results2 : a->d_results, lane ? a->d_arrivals2 : a->d_arrivals, static_cast<int>(n_prn), a->n_bins,
-                static_cast<int>(c.effective_fft_size), 0, 0, static_cast<int>(c.samples_per_chip), c.use_cfar, 1u, st);
+                static_cast<int>(c.effective_fft_size), 0, 0, static_cast<int>(c.samples_per_chip), c.use_cfar, 1u, 1.0f, st);
         };
         int rc = enqueue(0);  // warm-up on both lanes
         if (rc == GSH_OK) rc = enqueue(1);

@@ -69,7 +69,7 @@ int fft_forward(const FftPlan& p, const float2* src, size_t src_stride, int n_in
 //   spectra: n_bins * n; codes: n_prn * n (UNconjugated forward FFT of the placed code);
 //   tmp: n_prn * n_bins * n complex scratch; grid rows are `effective` floats, taken from y[grid_off .. grid_off+effective).
 int correlate_grid(const FftPlan& p, const float2* spectra, const float2* codes, float2* tmp, float* grid, int n_prn, int n_bins,
-    int grid_off, int effective, int accumulate, hipStream_t s);
+    int grid_off, int effective, int accumulate, float weight, hipStream_t s);
 
 // per-row (max, lowest arg-max, sum) then the two statistics of acq.cc:409-519 per PRN
 int grid_statistics(const float* grid, RowStat* rows, DevAcqResult* results, int n_prn, int n_bins, int effective,
@@ -85,6 +85,6 @@ int onchip_forward(int n, const float2* src, size_t src_stride, int n_in, int pl
 // read only when `accumulate` and written only when `store_grid`
 int onchip_correlate(int n, const float2* spectra, const float2* codes, float* grid, RowStat* rows, DevAcqResult* results,
     unsigned* arrivals, int n_prn, int n_bins, int effective, int accumulate, int store_grid, int samples_per_chip, int use_cfar,
-    unsigned dwell_count, hipStream_t s);
+    unsigned dwell_count, float weight, hipStream_t s);
 }  // namespace gsh
 #endif

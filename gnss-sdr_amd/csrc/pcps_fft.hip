@@ -380,6 +380,7 @@ struct InvColsArgs
     const float2* tw_1;
     int n1, n2, tile;
     int grid_off, effective, accumulate;
+    float weight;  // every |.|^2 is scaled before it reaches the grid (pcps_tong_acquisition_cc.cc:243-249); 1 otherwise
     SubPlan sp;
 };
 
@@ -412,7 +413,7 @@ __global__ __launch_bounds__(FFT_THREADS) void inv_cols_kernel(InvColsArgs a)
             const int tau = r * a.n2 + col - a.grid_off;
             if (tau < 0 || tau >= a.effective) continue;
             const float2 v = res[i];
-            const float mag = fmaf(v.x, v.x, v.y * v.y);
+            const float mag = fmaf(v.x, v.x, v.y * v.y) * a.weight;
             grid[tau] = a.accumulate ? grid[tau] + mag : mag;
         }
 }
@@ -736,7 +737,7 @@ int fft_forward(const FftPlan& p, const float2* src, size_t src_stride, int n_in
 }
 
 int correlate_grid(const FftPlan& p, const float2* spectra, const float2* codes, float2* tmp, float* grid, int n_prn, int n_bins,
-    int grid_off, int effective, int accumulate, hipStream_t s)
+    int grid_off, int effective, int accumulate, float weight, hipStream_t s)
 {
     const int cells = n_prn * n_bins;
     if (cells <= 0) return GSH_OK;
@@ -765,6 +766,7 @@ int correlate_grid(const FftPlan& p, const float2* spectra, const float2* codes,
     c.grid_off = grid_off;
     c.effective = effective;
     c.accumulate = accumulate;
+    c.weight = weight;
     c.sp = p.p1;
     const size_t lds_c = (2 * static_cast<size_t>(p.n1) * p.tile_cols + p.n1) * sizeof(float2);
     hipLaunchKernelGGL(inv_cols_kernel, dim3((p.n2 + p.tile_cols - 1) / p.tile_cols, cells), dim3(FFT_THREADS), lds_c, s, c);

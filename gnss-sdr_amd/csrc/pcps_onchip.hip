@@ -51,6 +51,7 @@ struct OcCellArgs
     int samples_per_chip, want_second;
     int use_cfar;
     unsigned dwell_count;
+    float weight;  // GRID path: every |.|^2 is scaled before it is added / stored (pcps_tong_acquisition_cc.cc:243-249); 1 otherwise
 };
 
 // exp(-j 2 pi f n / fs) with the product reduced in double before the float sincos
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(P::THREADS) void oc_cell_kernel(OcCellArgs a)
                 {
                     oc::static_for<P::R3>([&](auto K3) GSH_AI {
                         constexpr int k3 = decltype(K3)::value;
-                        rc[k3].x = rc[k3].x * rc[k3].x + rc[k3].y * rc[k3].y;
+                        rc[k3].x = (rc[k3].x * rc[k3].x + rc[k3].y * rc[k3].y) * a.weight;
                     });
                     if (a.accumulate)  // acq.cc:549-553
                         oc::static_for<P::R3>([&](auto K3) GSH_AI { rc[decltype(K3)::value].x += g[t + P::T3 * decltype(K3)::value]; });
@@ -414,7 +415,7 @@ int onchip_forward(int n, const float2* src, size_t src_stride, int n_in, int pl
 
 int onchip_correlate(int n, const float2* spectra, const float2* codes, float* grid, RowStat* rows, DevAcqResult* results,
     unsigned* arrivals, int n_prn, int n_bins, int effective, int accumulate, int store_grid, int samples_per_chip, int use_cfar,
-    unsigned dwell_count, hipStream_t s)
+    unsigned dwell_count, float weight, hipStream_t s)
 {
     if (n_prn <= 0 || n_bins <= 0) return GSH_OK;
     GSH_REQUIRE(effective == n, "the on-chip path needs effective_fft_size == fft_size");
@@ -440,6 +441,7 @@ int onchip_correlate(int n, const float2* spectra, const float2* codes, float* g
     a.want_second = use_cfar ? 0 : 1;
     a.use_cfar = use_cfar;
     a.dwell_count = dwell_count ? dwell_count : 1u;
+    a.weight = weight;
     const int n_blocks = 8 * a.prn_per * a.bin_per;
 #define GSH_OC_CASE(r1, r2, r3) \
     if (n == (r1) * (r2) * (r3)) return launch_cells<oc::Plan<r1, r2, r3>>(a, n_blocks, s);

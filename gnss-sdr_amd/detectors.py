@@ -1,0 +1,151 @@
+"""The other PCPS detectors of the reference on the same device engine, for tests: host-side mirrors of
+
+  pcps_tong_acquisition_cc          src/algorithms/acquisition/gnuradio_blocks/pcps_tong_acquisition_cc.cc  (tong.cc)
+  galileo_pcps_8ms_acquisition_cc   src/algorithms/acquisition/gnuradio_blocks/galileo_pcps_8ms_acquisition_cc.cc  (8ms.cc)
+
+Only the per-block state machine lives here (counters, thresholds); every sample-rate operation -- wipe-off, transforms,
+|.|^2, weighting, grid accumulation, arg-max, input power -- runs on the GPU through the C ABI (gsh_acq_*).  The C++ product
+classes with the same logic are host/hip_pcps_detectors.{h,cc}.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from .acquisition import PcpsAcquisitionBank
+
+
+def count_doppler_bins(doppler_max: int, doppler_step: int) -> int:
+    """tong.cc:97-100, 8ms.cc:65-68: -doppler_max ... +doppler_max inclusive."""
+    return 2 * doppler_max // doppler_step + 1 if doppler_max >= 0 else 0
+
+
+def threshold_compute_doppler(pfa: float, vector_length: int, doppler_max: int, doppler_step: int) -> float:
+    """ThresholdComputeDoppler::calculate_threshold (base_pcps_acquisition_custom.cc:89-112): quantile of an exponential
+    distribution with lambda = vector_length at (1 - pfa)^(1 / ncells)."""
+    bins = count_doppler_bins(doppler_max, doppler_step)
+    ncells = vector_length * bins
+    val = math.pow(1.0 - pfa, 1.0 / float(ncells))
+    return float(np.float32(-math.log1p(-val) / float(vector_length)))
+
+
+class PcpsTongAcquisition:
+    """general_work of pcps_tong_acquisition_cc for one channel (tong.cc:147-400)."""
+
+    def __init__(self, fs_in: int, fft_size: int, doppler_max: int, doppler_step: int, samples_per_code: float, threshold: float,
+                 tong_init_val: int, tong_max_val: int, tong_max_dwells: int, device: int = 0, transform_path: int = 0):
+        self.n_bins = count_doppler_bins(doppler_max, doppler_step)
+        self.bank = PcpsAcquisitionBank(fs_in, fft_size, doppler_max, doppler_step, 1, samples_per_code, max_prn=1,
+                                        num_doppler_bins=self.n_bins, device=device, transform_path=transform_path)
+        self.fft_size = fft_size
+        self.doppler_max, self.doppler_step = doppler_max, doppler_step
+        self.samples_per_code = int(samples_per_code)
+        self.threshold = np.float32(threshold)
+        self.tong_init_val, self.tong_max_val, self.tong_max_dwells = tong_init_val, tong_max_val, tong_max_dwells
+        self.init()
+
+    def close(self):
+        self.bank.close()
+
+    def set_local_code(self, code: np.ndarray) -> None:                                          # tong.cc:136-144
+        self.bank.set_local_code(0, code)
+
+    def init(self) -> None:                                                                      # tong.cc:162-184 (state 0)
+        self.dwell_count = 0
+        self.tong_count = self.tong_init_val
+        self.mag = np.float32(0.0)
+        self.input_power = np.float32(0.0)
+        self.test_statistics = np.float32(0.0)
+        self.state = 1
+        self.result = dict(acq_delay_samples=0.0, doppler_hz=0.0, doppler_step=0)
+
+    def work(self, x: np.ndarray) -> int:                                                        # tong.cc:187-301 (state 1)
+        x = np.ascontiguousarray(x[:self.fft_size], np.complex64)
+        self.dwell_count += 1
+        # this dwell's weight needs this block's power before its magnitudes reach the grid: stage, reduce, then dwell
+        self.input_power = np.float32(self.bank.stage_and_input_power(x))                         # :208-210
+        fnf = np.float32(self.fft_size) * np.float32(self.fft_size)                               # :195
+        self.weight = np.float32(1.0) / (fnf * fnf * self.input_power)                            # :245
+        self.bank.set_grid_weight(float(self.weight))
+        r = self.bank.dwell_resident(1, accumulate=self.dwell_count > 1, dwell_count=self.dwell_count)[0]
+        self.mag = np.float32(r["peak"])                                                          # :252-259 (d_mag starts at 0)
+        if self.mag > 0.0:
+            self.result = dict(acq_delay_samples=float(r["index_time"] % self.samples_per_code),
+                               doppler_hz=float(-self.doppler_max + self.doppler_step * r["index_doppler"]),
+                               doppler_step=self.doppler_step, index_time=r["index_time"], index_doppler=r["index_doppler"])
+        self.test_statistics = self.mag                                                           # :277
+        if self.test_statistics > self.threshold * np.float32(self.dwell_count):                  # :279-294
+            self.tong_count += 1
+            if self.tong_count == self.tong_max_val:
+                self.state = 2
+        else:
+            self.tong_count -= 1
+            if self.tong_count == 0:
+                self.state = 3
+        if self.dwell_count >= self.tong_max_dwells:                                              # :296-299
+            self.state = 3
+        return self.state
+
+
+class GalileoPcps8msAcquisition:
+    """general_work of galileo_pcps_8ms_acquisition_cc for one channel (8ms.cc:134-300): local code A in slot 0, B in slot 1,
+    both searched by ONE dwell over shared forward transforms."""
+
+    def __init__(self, fs_in: int, fft_size: int, doppler_max: int, doppler_step: int, samples_per_code: float, threshold: float,
+                 max_dwells: int, device: int = 0, transform_path: int = 0):
+        self.n_bins = count_doppler_bins(doppler_max, doppler_step)
+        self.bank = PcpsAcquisitionBank(fs_in, fft_size, doppler_max, doppler_step, 1, samples_per_code, max_prn=2,
+                                        num_doppler_bins=self.n_bins, device=device, transform_path=transform_path)
+        self.fft_size = fft_size
+        self.doppler_max, self.doppler_step = doppler_max, doppler_step
+        self.samples_per_code = int(samples_per_code)
+        self.threshold = np.float32(threshold)
+        self.max_dwells = max_dwells
+        self.init()
+
+    def close(self):
+        self.bank.close()
+
+    def set_local_code(self, code: np.ndarray) -> None:                                          # 8ms.cc:103-131
+        code = np.ascontiguousarray(code[:self.fft_size], np.complex64)
+        self.bank.set_local_code(0, code)
+        b = code.copy()
+        spc = self.samples_per_code
+        b[spc:2 * spc] *= np.complex64(-1.0)
+        self.bank.set_local_code(1, b)
+
+    def init(self) -> None:                                                                      # 8ms.cc:147-160
+        self.well_count = 0
+        self.mag = np.float32(0.0)
+        self.input_power = np.float32(0.0)
+        self.test_statistics = np.float32(0.0)
+        self.state = 1
+        self.result = dict(acq_delay_samples=0.0, doppler_hz=0.0, doppler_step=0)
+
+    def work(self, x: np.ndarray) -> int:                                                        # 8ms.cc:163-287
+        x = np.ascontiguousarray(x[:self.fft_size], np.complex64)
+        fnf = np.float32(self.fft_size) * np.float32(self.fft_size)
+        self.mag = np.float32(0.0)
+        self.well_count += 1
+        self.bank.dwell(x, 2)
+        self.input_power = np.float32(self.bank.input_power())                                    # :190-192
+        pa, ta = self.bank.read_row_peaks(0)
+        pb, tb = self.bank.read_row_peaks(1)
+        self.rows = []
+        for d in range(self.n_bins):
+            ma = np.float32(pa[d] / (fnf * fnf))                                                  # :222
+            mb = np.float32(pb[d] / (fnf * fnf))                                                  # :237
+            magt, t, which = (ma, int(ta[d]), 0) if ma >= mb else (mb, int(tb[d]), 1)             # :240-249
+            self.rows.append((float(ma), int(ta[d]), float(mb), int(tb[d])))
+            if self.mag < magt:                                                                   # :252
+                self.mag = magt
+                self.result = dict(acq_delay_samples=float(t % self.samples_per_code),
+                                   doppler_hz=float(-self.doppler_max + self.doppler_step * d), doppler_step=self.doppler_step,
+                                   index_time=t, index_doppler=d, code=which)
+        self.test_statistics = np.float32(self.mag / self.input_power)                            # :278
+        if self.test_statistics > self.threshold:
+            self.state = 2
+        elif self.well_count == self.max_dwells:
+            self.state = 3
+        return self.state

@@ -1,0 +1,247 @@
+/*!
+ * \file hip_pcps_detectors.cc
+ * \brief See the header.
+ */
+#include "hip_pcps_detectors.h"
+#include "gnss_sdr_hip.h"
+#include <cmath>
+
+namespace
+{
+uint32_t count_bins(int32_t doppler_max, int32_t doppler_step)
+{
+    uint32_t n = 0;  // tong.cc:97-100, 8ms.cc:65-68: inclusive of +doppler_max
+    for (int32_t doppler = -doppler_max; doppler <= doppler_max; doppler += doppler_step) n++;
+    return n;
+}
+
+gsh_acq* make_handle(const Hip_Acq_Conf& conf, uint32_t fft_size, uint32_t bins, uint32_t max_prn, int device, std::string* err)
+{
+    gsh_acq_conf c{};
+    c.fs_in = conf.fs_in;
+    c.fft_size = fft_size;
+    c.effective_fft_size = fft_size;
+    c.consumed_samples = fft_size;
+    c.num_doppler_bins = bins;
+    c.doppler_max = conf.doppler_max;
+    c.doppler_step = conf.doppler_step;
+    c.samples_per_chip = conf.samples_per_chip;
+    c.samples_per_code = conf.samples_per_code;
+    c.use_cfar = 1;
+    c.max_prn = max_prn;
+    c.no_grid = 0;
+    gsh_acq* h = nullptr;
+    if (gsh_acq_create(device, &c, &h) != GSH_OK)
+        {
+            *err = gsh_last_error();
+            return nullptr;
+        }
+    return h;
+}
+}  // namespace
+
+
+float hip_threshold_compute_doppler(float pfa, uint32_t vector_length, int32_t doppler_max, int32_t doppler_step)
+{
+    const uint32_t frequency_bins = count_bins(doppler_max, doppler_step);
+    const auto ncells = vector_length * frequency_bins;
+    const auto exponent = 1 / static_cast<double>(ncells);
+    const auto val = std::pow(1.0 - pfa, exponent);
+    const auto lambda = static_cast<double>(vector_length);
+    return static_cast<float>(-std::log1p(-val) / lambda);  // quantile of the exponential distribution
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------- Tong
+Hip_Pcps_Tong_Core::Hip_Pcps_Tong_Core(const Hip_Acq_Conf& conf, uint32_t tong_init_val, uint32_t tong_max_val, uint32_t tong_max_dwells, int device)
+    : d_acq_params(conf), d_tong_init_val(tong_init_val), d_tong_max_val(tong_max_val), d_tong_max_dwells(tong_max_dwells), d_tong_count(tong_init_val)
+{
+    d_fft_size = static_cast<uint32_t>(conf.sampled_ms * conf.samples_per_ms);  // tong.cc:85
+    d_num_doppler_bins = count_bins(conf.doppler_max, conf.doppler_step);
+    d_handle = make_handle(conf, d_fft_size, d_num_doppler_bins, 1, device, &d_error);
+}
+
+
+Hip_Pcps_Tong_Core::~Hip_Pcps_Tong_Core()
+{
+    if (d_handle != nullptr) gsh_acq_destroy(d_handle);
+}
+
+
+void Hip_Pcps_Tong_Core::set_local_code(const std::complex<float>* code)
+{
+    if (d_handle == nullptr) return;
+    if (gsh_acq_set_local_code(d_handle, 0, reinterpret_cast<const float*>(code)) != GSH_OK) d_error = gsh_last_error();
+}
+
+
+void Hip_Pcps_Tong_Core::init()
+{
+    d_result = Hip_Detector_Result();
+    d_dwell_count = 0;
+    d_tong_count = d_tong_init_val;
+    d_mag = 0.0;
+    d_input_power = 0.0;
+    d_test_statistics = 0.0;
+    // d_grid_data is cleared by the first dwell overwriting it (accumulate = 0)
+    d_state = 1;
+}
+
+
+int Hip_Pcps_Tong_Core::work(uint64_t sample_counter, const std::complex<float>* in)
+{
+    if (d_handle == nullptr) return -1;
+    const float fft_normalization_factor = static_cast<float>(d_fft_size) * static_cast<float>(d_fft_size);
+    d_input_power = 0.0;
+    d_mag = 0.0;
+    d_dwell_count++;
+
+    // 1- input signal power estimation of THIS block (tong.cc:208-210): it scales this block's magnitudes
+    if (gsh_acq_stage_input(d_handle, reinterpret_cast<const float*>(in)) != GSH_OK || gsh_acq_input_power(d_handle, &d_input_power) != GSH_OK)
+        {
+            d_error = gsh_last_error();
+            return -1;
+        }
+    // 2..4- Doppler loop: |y|^2 / (norm^2 P) added to d_grid_data, per-bin maxima, first strictly greater bin wins (tong.cc:213-264)
+    const float weight = 1 / (fft_normalization_factor * fft_normalization_factor * d_input_power);
+    gsh_acq_result r{};
+    if (gsh_acq_set_grid_weight(d_handle, weight) != GSH_OK || gsh_acq_dwell_resident(d_handle, 1, d_dwell_count > 1 ? 1 : 0, d_dwell_count, &r) != GSH_OK)
+        {
+            d_error = gsh_last_error();
+            return -1;
+        }
+    if (d_mag < r.peak)
+        {
+            d_mag = r.peak;
+            d_result.index_time = r.index_time;
+            d_result.index_doppler = r.index_doppler;
+            d_result.Acq_delay_samples = static_cast<double>(r.index_time % static_cast<int32_t>(d_acq_params.samples_per_code));
+            d_result.Acq_doppler_hz = static_cast<double>(-d_acq_params.doppler_max + d_acq_params.doppler_step * static_cast<int32_t>(r.index_doppler));
+            d_result.Acq_samplestamp_samples = sample_counter;
+            d_result.Acq_doppler_step = static_cast<uint32_t>(d_acq_params.doppler_step);
+        }
+
+    // 5- test statistics against the threshold (tong.cc:277-299)
+    d_test_statistics = d_mag;
+    if (d_test_statistics > d_acq_params.threshold * d_dwell_count)
+        {
+            d_tong_count++;
+            if (d_tong_count == d_tong_max_val) d_state = 2;  // Positive acquisition
+        }
+    else
+        {
+            d_tong_count--;
+            if (d_tong_count == 0) d_state = 3;  // Negative acquisition
+        }
+    if (d_dwell_count >= d_tong_max_dwells) d_state = 3;  // Negative acquisition
+    return d_state;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------- 8 ms
+Hip_Galileo_Pcps_8ms_Core::Hip_Galileo_Pcps_8ms_Core(const Hip_Acq_Conf& conf, int device) : d_acq_params(conf)
+{
+    d_fft_size = static_cast<uint32_t>(conf.sampled_ms * conf.samples_per_ms);  // 8ms.cc:53
+    d_num_doppler_bins = count_bins(conf.doppler_max, conf.doppler_step);
+    d_handle = make_handle(conf, d_fft_size, d_num_doppler_bins, 2, device, &d_error);  // slot 0: code A, slot 1: code B
+    d_peak_a.resize(d_num_doppler_bins);
+    d_peak_b.resize(d_num_doppler_bins);
+    d_index_a.resize(d_num_doppler_bins);
+    d_index_b.resize(d_num_doppler_bins);
+    d_code_b.resize(d_fft_size);
+}
+
+
+Hip_Galileo_Pcps_8ms_Core::~Hip_Galileo_Pcps_8ms_Core()
+{
+    if (d_handle != nullptr) gsh_acq_destroy(d_handle);
+}
+
+
+void Hip_Galileo_Pcps_8ms_Core::set_local_code(const std::complex<float>* code)
+{
+    if (d_handle == nullptr) return;
+    // code A: two replicas of a primary code
+    if (gsh_acq_set_local_code(d_handle, 0, reinterpret_cast<const float*>(code)) != GSH_OK) d_error = gsh_last_error();
+    // code B: two replicas of a primary code; the second replica is inverted
+    const auto samples_per_code = static_cast<uint32_t>(d_acq_params.samples_per_code);
+    for (uint32_t i = 0; i < d_fft_size; i++) d_code_b[i] = code[i];
+    for (uint32_t i = samples_per_code; i < 2 * samples_per_code && i < d_fft_size; i++) d_code_b[i] = code[i] * std::complex<float>(-1, 0);
+    if (gsh_acq_set_local_code(d_handle, 1, reinterpret_cast<const float*>(d_code_b.data())) != GSH_OK) d_error = gsh_last_error();
+}
+
+
+void Hip_Galileo_Pcps_8ms_Core::init()
+{
+    d_result = Hip_Detector_Result();
+    d_well_count = 0;
+    d_mag = 0.0;
+    d_input_power = 0.0;
+    d_test_statistics = 0.0;
+    d_state = 1;
+}
+
+
+int Hip_Galileo_Pcps_8ms_Core::work(uint64_t sample_counter, const std::complex<float>* in)
+{
+    if (d_handle == nullptr) return -1;
+    const float fft_normalization_factor = static_cast<float>(d_fft_size) * static_cast<float>(d_fft_size);
+    d_input_power = 0.0;
+    d_mag = 0.0;
+    d_well_count++;
+
+    // one dwell searches both local codes over shared forward transforms (8ms.cc:195-237 does two inverse FFTs per bin)
+    gsh_acq_result r[2]{};
+    if (gsh_acq_dwell(d_handle, reinterpret_cast<const float*>(in), 2, 0, 1, r) != GSH_OK || gsh_acq_input_power(d_handle, &d_input_power) != GSH_OK ||
+        gsh_acq_read_row_peaks(d_handle, 0, d_peak_a.data(), d_index_a.data()) != GSH_OK ||
+        gsh_acq_read_row_peaks(d_handle, 1, d_peak_b.data(), d_index_b.data()) != GSH_OK)
+        {
+            d_error = gsh_last_error();
+            return -1;
+        }
+    for (uint32_t doppler_index = 0; doppler_index < d_num_doppler_bins; doppler_index++)
+        {
+            const int32_t doppler = -d_acq_params.doppler_max + d_acq_params.doppler_step * static_cast<int32_t>(doppler_index);
+            // normalise the maxima (8ms.cc:222, :237), take the greater (:240-249), first strictly greater bin wins (:252)
+            const float magt_A = d_peak_a[doppler_index] / (fft_normalization_factor * fft_normalization_factor);
+            const float magt_B = d_peak_b[doppler_index] / (fft_normalization_factor * fft_normalization_factor);
+            float magt;
+            uint32_t indext;
+            int which;
+            if (magt_A >= magt_B)
+                {
+                    magt = magt_A;
+                    indext = d_index_a[doppler_index];
+                    which = 0;
+                }
+            else
+                {
+                    magt = magt_B;
+                    indext = d_index_b[doppler_index];
+                    which = 1;
+                }
+            if (d_mag < magt)
+                {
+                    d_mag = magt;
+                    d_winning_code = which;
+                    d_result.index_time = indext;
+                    d_result.index_doppler = doppler_index;
+                    d_result.Acq_delay_samples = static_cast<double>(indext % static_cast<int32_t>(d_acq_params.samples_per_code));
+                    d_result.Acq_doppler_hz = static_cast<double>(doppler);
+                    d_result.Acq_samplestamp_samples = sample_counter;
+                    d_result.Acq_doppler_step = static_cast<uint32_t>(d_acq_params.doppler_step);
+                }
+        }
+
+    // 5- test statistics against the threshold (8ms.cc:278-287)
+    d_test_statistics = d_mag / d_input_power;
+    if (d_test_statistics > d_acq_params.threshold)
+        {
+            d_state = 2;  // Positive acquisition
+        }
+    else if (d_well_count == d_acq_params.max_dwells)
+        {
+            d_state = 3;  // Negative acquisition
+        }
+    return d_state;
+}

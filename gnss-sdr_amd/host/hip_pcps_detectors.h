@@ -1,0 +1,111 @@
+/*!
+ * \file hip_pcps_detectors.h
+ * \brief The dwell logic of the reference's other PCPS detector blocks on the MI355X engine, without the GNU Radio shell:
+ *
+ *   Hip_Pcps_Tong_Core         pcps_tong_acquisition_cc          (gnuradio_blocks/pcps_tong_acquisition_cc.cc, "tong.cc")
+ *   Hip_Galileo_Pcps_8ms_Core  galileo_pcps_8ms_acquisition_cc   (gnuradio_blocks/galileo_pcps_8ms_acquisition_cc.cc, "8ms.cc")
+ *
+ * Each class keeps the reference block's member names and its general_work state numbering: init() is state 0, work() is
+ * one pass of state 1 over one input vector and returns the next state (1 = keep going, 2 = positive, 3 = negative).
+ * Only the counters live on the host; wipe-off, transforms, |.|^2, power normalisation, grid accumulation, arg-max and the
+ * input-power estimate run on the GPU through the C ABI (gsh_acq_*).  No CPU fallback.
+ */
+#ifndef GNSS_SDR_HIP_PCPS_DETECTORS_H
+#define GNSS_SDR_HIP_PCPS_DETECTORS_H
+
+#include "hip_pcps_acquisition_core.h"
+#include <complex>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+/*! ThresholdComputeDoppler::calculate_threshold (adapters/base_pcps_acquisition_custom.cc:89-112) */
+float hip_threshold_compute_doppler(float pfa, uint32_t vector_length, int32_t doppler_max, int32_t doppler_step);
+
+/*! what both blocks write into their Gnss_Synchro (tong.cc:259-264, 8ms.cc:254-259) */
+struct Hip_Detector_Result
+{
+    double Acq_delay_samples{0.0};
+    double Acq_doppler_hz{0.0};
+    uint64_t Acq_samplestamp_samples{0ULL};
+    uint32_t Acq_doppler_step{0U};
+    uint32_t index_time{0U};
+    uint32_t index_doppler{0U};
+};
+
+class Hip_Pcps_Tong_Core
+{
+public:
+    Hip_Pcps_Tong_Core(const Hip_Acq_Conf& conf, uint32_t tong_init_val, uint32_t tong_max_val, uint32_t tong_max_dwells, int device = 0);
+    ~Hip_Pcps_Tong_Core();
+    Hip_Pcps_Tong_Core(const Hip_Pcps_Tong_Core&) = delete;
+    Hip_Pcps_Tong_Core& operator=(const Hip_Pcps_Tong_Core&) = delete;
+
+    bool ok() const { return d_handle != nullptr; }
+    const std::string& last_error() const { return d_error; }
+
+    void set_local_code(const std::complex<float>* code);  //!< tong.cc:136-144
+    void init();                                           //!< state 0, tong.cc:162-184
+    /*! state 1, tong.cc:187-301; sample_counter is d_sample_counter after the block's increment (:200).  Returns d_state, -1 on error */
+    int work(uint64_t sample_counter, const std::complex<float>* in);
+
+    const Hip_Detector_Result& result() const { return d_result; }
+    uint32_t num_doppler_bins() const { return d_num_doppler_bins; }
+    uint32_t fft_size() const { return d_fft_size; }
+    uint32_t dwell_count() const { return d_dwell_count; }
+    uint32_t tong_count() const { return d_tong_count; }
+    float mag() const { return d_mag; }
+    float input_power() const { return d_input_power; }
+    float test_statistics() const { return d_test_statistics; }
+    int state() const { return d_state; }
+
+private:
+    Hip_Acq_Conf d_acq_params;
+    gsh_acq* d_handle{nullptr};
+    std::string d_error;
+    Hip_Detector_Result d_result;
+    float d_mag{0.0F}, d_input_power{0.0F}, d_test_statistics{0.0F};
+    int d_state{0};
+    uint32_t d_dwell_count{0}, d_tong_init_val, d_tong_max_val, d_tong_max_dwells, d_tong_count;
+    uint32_t d_fft_size{0}, d_num_doppler_bins{0};
+};
+
+class Hip_Galileo_Pcps_8ms_Core
+{
+public:
+    explicit Hip_Galileo_Pcps_8ms_Core(const Hip_Acq_Conf& conf, int device = 0);
+    ~Hip_Galileo_Pcps_8ms_Core();
+    Hip_Galileo_Pcps_8ms_Core(const Hip_Galileo_Pcps_8ms_Core&) = delete;
+    Hip_Galileo_Pcps_8ms_Core& operator=(const Hip_Galileo_Pcps_8ms_Core&) = delete;
+
+    bool ok() const { return d_handle != nullptr; }
+    const std::string& last_error() const { return d_error; }
+
+    void set_local_code(const std::complex<float>* code);  //!< 8ms.cc:103-131: code A as given, code B with the second period inverted
+    void init();                                           //!< state 0, 8ms.cc:147-160
+    int work(uint64_t sample_counter, const std::complex<float>* in);  //!< state 1, 8ms.cc:163-287
+
+    const Hip_Detector_Result& result() const { return d_result; }
+    uint32_t num_doppler_bins() const { return d_num_doppler_bins; }
+    uint32_t fft_size() const { return d_fft_size; }
+    int winning_code() const { return d_winning_code; }  //!< 0 = A, 1 = B (not exposed by the reference; for tests)
+    float mag() const { return d_mag; }
+    float input_power() const { return d_input_power; }
+    float test_statistics() const { return d_test_statistics; }
+    int state() const { return d_state; }
+
+private:
+    Hip_Acq_Conf d_acq_params;
+    gsh_acq* d_handle{nullptr};
+    std::string d_error;
+    Hip_Detector_Result d_result;
+    std::vector<float> d_peak_a, d_peak_b;
+    std::vector<uint32_t> d_index_a, d_index_b;
+    std::vector<std::complex<float>> d_code_b;
+    float d_mag{0.0F}, d_input_power{0.0F}, d_test_statistics{0.0F};
+    int d_state{0}, d_winning_code{0};
+    uint32_t d_well_count{0};
+    uint32_t d_fft_size{0}, d_num_doppler_bins{0};
+};
+
+#endif

@@ -30,7 +30,7 @@ extern "C"
 {
 #endif
 
-#define GSH_ABI_VERSION 9
+#define GSH_ABI_VERSION 10
 #define GSH_MAX_TAPS 8 /* VE/E/P/L/VL needs 5 (trk.cc:609-650); 8 leaves room for multi-tap dumps */
 
     enum
@@ -384,6 +384,26 @@ extern "C"
     int gsh_acq_set_local_code(gsh_acq_t* a, uint32_t prn_slot, const float* code_iq);
     /* acq.cc:737-746 */
     int gsh_acq_set_doppler_center(gsh_acq_t* a, int32_t doppler_center);
+    /* The other PCPS detectors on the same engine:
+     * pcps_tong_acquisition_cc.cc:243-249 scales every |y|^2 by 1 / (fft_norm^2 * input_power) BEFORE adding it to its
+     * d_grid_data; `weight` is that factor, applied (one float multiply per cell) to every magnitude that is added to or
+     * stored in the grid by the dwells that follow.  Default 1 (the multiply is then exact).  Needs no_grid == 0 when != 1. */
+    int gsh_acq_set_grid_weight(gsh_acq_t* a, float weight);
+    /* mean |x|^2 of the consumed_samples block most recently handed to the handle -- d_input_power of
+     * pcps_tong_acquisition_cc.cc:208-210 and galileo_pcps_8ms_acquisition_cc.cc:190-192.  Per-sample terms are the
+     * reference's float values; they are summed in double (the reference's float VOLK accumulator has no defined lane
+     * order), so the value agrees with the reference to float rounding of the sum (~1e-7 relative), not bit for bit. */
+    int gsh_acq_input_power(gsh_acq_t* a, float* mean_power);
+    /* The Tong weight of a block depends on that block's own power, so the block must be resident before its dwell is
+     * queued: stage_input[_device] copies consumed_samples complex64 samples into the handle (what gsh_acq_dwell[_device]
+     * do first), dwell_resident then runs the dwell of gsh_acq_dwell over the resident block. */
+    int gsh_acq_stage_input(gsh_acq_t* a, const float* in_iq);
+    int gsh_acq_stage_input_device(gsh_acq_t* a, const void* device_in_iq);
+    int gsh_acq_dwell_resident(gsh_acq_t* a, uint32_t n_prn, int accumulate, uint32_t dwell_count, gsh_acq_result* results);
+    /* per-Doppler-bin maximum and its (lowest) time index of prn_slot's grid after the last full dwell -- magt / indext of
+     * the per-bin loops of galileo_pcps_8ms_acquisition_cc.cc:226-262, which compares two local codes bin by bin.
+     * num_doppler_bins entries each. */
+    int gsh_acq_read_row_peaks(gsh_acq_t* a, uint32_t prn_slot, float* row_peak, uint32_t* row_index_time);
     /* one acquisition_core pass (acq.cc:648-684) for prn_slot 0..n_prn-1 over the same
      * consumed_samples input block.  `accumulate` != 0 adds to the stored grids
      * (non-coherent dwell number > 1, acq.cc:549-553); `dwell_count` is

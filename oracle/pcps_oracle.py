@@ -220,3 +220,160 @@ def compute_threshold(pfa: float, effective_fft_size: int, num_doppler_bins: int
     num_bins = effective_fft_size * num_doppler_bins
     prob = (1.0 - float(np.float32(pfa))) ** (1.0 / float(np.float32(num_bins)))
     return float(np.float32(2.0 * gammaincinv(2.0 * max_dwells, prob)))
+
+
+# =====================================================================================================================
+# The other PCPS detectors.  Both reuse PcpsOracle's pinned pieces (wipe-off tables through oracle_sincos,
+# arg-max through oracle_index_max); the FFT stays the unpinned scipy one, as above.
+# =====================================================================================================================
+def count_doppler_bins(doppler_max: int, doppler_step: int) -> int:
+    """pcps_tong_acquisition_cc.cc:97-100 / galileo_pcps_8ms_acquisition_cc.cc:65-68: bins counted INCLUSIVE of +doppler_max
+    (the main PCPS block uses ceil(2*max/step), acq.cc:113)."""
+    n, d = 0, -doppler_max
+    while d <= doppler_max:
+        n += 1
+        d += doppler_step
+    return n
+
+
+def mean_input_power(x: np.ndarray) -> np.float32:
+    """tong.cc:208-210 / 8ms.cc:190-192: float |x|^2 per sample (volk_32fc_magnitude_squared_32f), summed, / (float) N.
+    The reference sums in float32 in the lane order of whichever volk_32f_accumulator_s32f kernel its machine dispatches
+    (unpinned); here the float terms are summed in float64 and rounded once."""
+    x = np.asarray(x, np.complex64)
+    terms = (x.real * x.real + x.imag * x.imag).astype(np.float32)
+    return np.float32(np.float32(np.sum(terms, dtype=np.float64)) / np.float32(len(x)))
+
+
+class TongOracle:
+    """pcps_tong_acquisition_cc::general_work (pcps_tong_acquisition_cc.cc:147-400) for one channel: every dwell adds the
+    power-normalised |y|^2 of the new block to d_grid_data; the grid maximum is compared with threshold * dwell_count and
+    moves the Tong counter up or down."""
+
+    def __init__(self, fs_in: int, fft_size: int, doppler_max: int, doppler_step: int, samples_per_code: float, threshold: float,
+                 tong_init_val: int, tong_max_val: int, tong_max_dwells: int):
+        self.n_bins = count_doppler_bins(doppler_max, doppler_step)
+        self.p = PcpsOracle(fs_in, fft_size, doppler_max, doppler_step, 1, samples_per_code, num_doppler_bins=self.n_bins)
+        self.fft_size = fft_size
+        self.samples_per_code = int(samples_per_code)
+        self.threshold = np.float32(threshold)
+        self.tong_init_val, self.tong_max_val, self.tong_max_dwells = tong_init_val, tong_max_val, tong_max_dwells
+        self.state = 0
+        self.init()
+
+    def set_local_code(self, code: np.ndarray):                                                  # tong.cc:136-144
+        self.p.set_local_code(code)
+
+    def init(self):                                                                              # tong.cc:162-184 (state 0)
+        self.dwell_count = 0
+        self.tong_count = self.tong_init_val
+        self.mag = np.float32(0.0)
+        self.input_power = np.float32(0.0)
+        self.test_statistics = np.float32(0.0)
+        self.grid = np.zeros((self.n_bins, self.fft_size), np.float32)
+        self.state = 1
+        self.result = dict(acq_delay_samples=0.0, doppler_hz=0.0, doppler_step=0)
+
+    def work(self, x: np.ndarray) -> int:                                                        # tong.cc:187-301 (state 1)
+        p = self.p
+        x = np.asarray(x[:self.fft_size], np.complex64)
+        fnf = np.float32(self.fft_size) * np.float32(self.fft_size)                               # :195
+        self.mag = np.float32(0.0)
+        self.dwell_count += 1
+        self.input_power = mean_input_power(x)                                                    # :208-210
+        weight = np.float32(1.0) / (fnf * fnf * self.input_power)                                 # :245: N^4 P, the statistic is the captured fraction of the block's power
+        self.weight = weight
+        for d in range(self.n_bins):
+            doppler = -int(p.doppler_max) + p.doppler_step * d                                    # :216
+            a = (x * p.wipe[d]).astype(np.complex64)                                              # :218
+            A = scipy.fft.fft(a)
+            B = (A * p.fft_codes).astype(np.complex64)                                            # :227
+            y = (scipy.fft.ifft(B) * np.complex64(self.fft_size)).astype(np.complex64)            # :231 unnormalised
+            mag = (y.real * y.real + y.imag * y.imag).astype(np.float32)                          # :234
+            mag = (mag * weight).astype(np.float32)                                               # :244-246
+            self.grid[d] = self.grid[d] + mag                                                     # :249
+            t = p._argmax(self.grid[d])                                                           # :252
+            magt = self.grid[d][t]
+            if self.mag < magt:                                                                   # :257 strict
+                self.mag = magt
+                self.result = dict(acq_delay_samples=float(t % self.samples_per_code), doppler_hz=float(doppler),
+                                   doppler_step=p.doppler_step, index_time=t, index_doppler=d)
+        self.test_statistics = self.mag                                                           # :277
+        if self.test_statistics > self.threshold * np.float32(self.dwell_count):                  # :279
+            self.tong_count += 1
+            if self.tong_count == self.tong_max_val:
+                self.state = 2
+        else:
+            self.tong_count -= 1
+            if self.tong_count == 0:
+                self.state = 3
+        if self.dwell_count >= self.tong_max_dwells:                                              # :296
+            self.state = 3
+        return self.state
+
+
+class Galileo8msOracle:
+    """galileo_pcps_8ms_acquisition_cc::general_work (galileo_pcps_8ms_acquisition_cc.cc:134-300): the 8 ms block is
+    correlated with two local codes -- A = the two 4 ms primary-code periods as generated, B = the second period
+    sign-inverted (a secondary-code / data transition in the middle) -- and the larger per-bin maximum is kept."""
+
+    def __init__(self, fs_in: int, fft_size: int, doppler_max: int, doppler_step: int, samples_per_code: float, threshold: float,
+                 max_dwells: int):
+        self.n_bins = count_doppler_bins(doppler_max, doppler_step)
+        self.pa = PcpsOracle(fs_in, fft_size, doppler_max, doppler_step, 1, samples_per_code, num_doppler_bins=self.n_bins)
+        self.fft_size = fft_size
+        self.samples_per_code = int(samples_per_code)
+        self.threshold = np.float32(threshold)
+        self.max_dwells = max_dwells
+        self.init()
+
+    def set_local_code(self, code: np.ndarray):                                                  # 8ms.cc:103-131
+        code = np.asarray(code[:self.fft_size], np.complex64)
+        self.pa.set_local_code(code)
+        self.fft_code_a = self.pa.fft_codes
+        b = code.copy()
+        spc = self.samples_per_code
+        b[spc:2 * spc] = b[spc:2 * spc] * np.complex64(-1.0)                                      # :114-123
+        self.pa.set_local_code(b)
+        self.fft_code_b = self.pa.fft_codes
+
+    def init(self):                                                                              # 8ms.cc:147-160 (state 0)
+        self.well_count = 0
+        self.mag = np.float32(0.0)
+        self.input_power = np.float32(0.0)
+        self.test_statistics = np.float32(0.0)
+        self.state = 1
+        self.result = dict(acq_delay_samples=0.0, doppler_hz=0.0, doppler_step=0)
+
+    def work(self, x: np.ndarray) -> int:                                                        # 8ms.cc:163-287 (state 1)
+        p = self.pa
+        x = np.asarray(x[:self.fft_size], np.complex64)
+        fnf = np.float32(self.fft_size) * np.float32(self.fft_size)
+        self.mag = np.float32(0.0)
+        self.well_count += 1
+        self.input_power = mean_input_power(x)                                                    # :190-192
+        self.rows = []
+        for d in range(self.n_bins):
+            doppler = -int(p.doppler_max) + p.doppler_step * d
+            a = (x * p.wipe[d]).astype(np.complex64)
+            A = scipy.fft.fft(a)
+            best = []
+            for codes in (self.fft_code_a, self.fft_code_b):
+                B = (A * codes).astype(np.complex64)
+                y = (scipy.fft.ifft(B) * np.complex64(self.fft_size)).astype(np.complex64)
+                mag = (y.real * y.real + y.imag * y.imag).astype(np.float32)
+                t = p._argmax(mag)
+                best.append((np.float32(mag[t] / (fnf * fnf)), t))                                # :222, :237
+            (ma, ta), (mb, tb) = best
+            magt, t, which = (ma, ta, 0) if ma >= mb else (mb, tb, 1)                             # :240-249
+            self.rows.append((float(ma), ta, float(mb), tb))
+            if self.mag < magt:                                                                   # :252 strict
+                self.mag = magt
+                self.result = dict(acq_delay_samples=float(t % self.samples_per_code), doppler_hz=float(doppler),
+                                   doppler_step=p.doppler_step, index_time=t, index_doppler=d, code=which)
+        self.test_statistics = np.float32(self.mag / self.input_power)                            # :278
+        if self.test_statistics > self.threshold:
+            self.state = 2
+        elif self.well_count == self.max_dwells:
+            self.state = 3
+        return self.state

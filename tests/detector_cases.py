@@ -1,0 +1,49 @@
+"""Shared signal builders for the Tong / Galileo 8 ms detector tests (CPU oracle tests and GPU parity tests)."""
+import numpy as np
+
+import oracle
+from helpers import add_code_signal, cn0_to_amplitude, golden_e1_l5_codes, synth_gps_l1_stream
+
+FS = 4000000
+
+
+def tong_case(n_blocks: int = 12, signal: bool = True, seed: int = 2013):
+    """gps_l1_ca_pcps_tong_acquisition_gsoc2013_test.cc:199-258: PRN 10, 750 Hz, 600 chips, 44 dB-Hz, 4 Msps, 1 ms blocks,
+    doppler_max 10000, step 250, threshold 0.00108, tong_init_val 1, tong_max_val 8 (tong_max_dwells defaults to max_val + 1)."""
+    n = 4000
+    x = synth_gps_l1_stream(n_blocks * n, FS, [10] if signal else [], [750.0] if signal else [], [1023.0 - 600.0] if signal else [],
+                            cn0_dbhz=44.0, seed_noise=seed)
+    kw = dict(fs_in=FS, fft_size=n, doppler_max=10000, doppler_step=250, samples_per_code=4000.0, threshold=0.00108,
+              tong_init_val=1, tong_max_val=8, tong_max_dwells=9)
+    return x, kw, oracle.ca_code_complex_sampled(10, FS)
+
+
+def e1b_local_code_8ms(prn: int) -> np.ndarray:
+    """two 4 ms periods of the E1B sinBOC(1,1) replica at 4 Msps (what the adapter hands to set_local_code with
+    coherent_integration_time_ms = 8: base_pcps_acquisition_custom.cc:79-81 num_codes = 2)."""
+    e1b = golden_e1_l5_codes()["e1b"][prn - 1]
+    idx = np.floor(np.arange(16000) * (8184.0 / 16000.0)).astype(np.int64)
+    one = e1b[idx].astype(np.complex64)
+    return np.concatenate([one, one])
+
+
+def e1_8ms_case(flip: bool, prn: int = 11, cn0: float = 44.0, seed: int = 8, signal: bool = True):
+    """galileo_e1_pcps_8ms_ambiguous_acquisition_gsoc2013_test.cc:203-259: 8 ms at 4 Msps, 750 Hz, delay 600 chips,
+    doppler_max 10000, step 250, max_dwells 1; threshold from pfa = 0.1 as in the test's second configuration (:341) through
+    ThresholdComputeDoppler (base_pcps_acquisition_custom.cc:89-112).  `flip`: the data symbol changes sign between the two periods."""
+    n = 32000
+    rng = np.random.default_rng(seed)
+    x = (rng.standard_normal(2 * n) + 1j * rng.standard_normal(2 * n)).astype(np.complex64)
+    if signal:
+        e1b = golden_e1_l5_codes()["e1b"][prn - 1]
+        delay_samples = 600.0 * (4000000.0 / 1.023e6)  # the block starts `delay` into the code
+        amp = cn0_to_amplitude(cn0, FS)
+        nn = np.arange(2 * n, dtype=np.float64)
+        idx = np.floor((nn - delay_samples) * (8184.0 / 16000.0)).astype(np.int64) % 8184
+        period = np.floor((nn - delay_samples) / 16000.0).astype(np.int64)
+        sym = np.where((period % 2 == 1) & flip, -1.0, 1.0)
+        x += (amp * sym * e1b[idx] * np.exp(2j * np.pi * 750.0 / FS * nn)).astype(np.complex64)
+    val = (1.0 - 0.1) ** (1.0 / (n * 81))
+    threshold = float(np.float32(-np.log1p(-val) / n))
+    kw = dict(fs_in=FS, fft_size=n, doppler_max=10000, doppler_step=250, samples_per_code=16000.0, threshold=threshold, max_dwells=1)
+    return x, kw, e1b_local_code_8ms(prn), delay_samples if signal else 0.0

@@ -5,6 +5,7 @@
 #include "gnss_oracle.h"
 #include "hip_multicorrelator_real_codes.h"
 #include "hip_pcps_acquisition_core.h"
+#include "hip_pcps_detectors.h"
 #include <cmath>
 #include <complex>
 #include <cstdio>
@@ -184,6 +185,100 @@ int main()
         const auto of = acqf.acquisition_core(1, xf.data(), &rf);
         EXPECT(o16 == of && o16 == Hip_Pcps_Acquisition_Core::ACQ_POSITIVE, "cshort outcome %d vs %d", o16, of);
         EXPECT(r16.index_time == rf.index_time && r16.doppler == rf.doppler && r16.test_statistics == rf.test_statistics, "cshort result differs from the float path");
+    }
+    // ---------------------------------------------------------------- Tong detector, pcps_tong_acquisition_cc call pattern
+    {
+        // gps_l1_ca_pcps_tong_acquisition_gsoc2013_test.cc:199-258: PRN 10, 750 Hz, 600 chips, 44 dB-Hz, threshold 0.00108, init 1, max 8
+        const double amp = std::sqrt(std::pow(10.0, 4.4) * 2.0 / 4e6);
+        auto x = make_signal(12 * 4000, 4e6, 10, 750.0, 1023.0 - 600.0, amp, 2013);
+        Hip_Acq_Conf conf;
+        conf.fs_in = 4000000;
+        conf.doppler_max = 10000;
+        conf.doppler_step = 250;
+        conf.threshold = 0.00108F;
+        conf.SetDerivedParams();
+        Hip_Pcps_Tong_Core tong(conf, 1, 8, 9, 0);
+        EXPECT(tong.ok(), "tong create: %s", tong.last_error().c_str());
+        EXPECT(tong.num_doppler_bins() == 81 && tong.fft_size() == 4000, "tong sizes %u %u", tong.num_doppler_bins(), tong.fft_size());
+        std::vector<float> code_iq(2 * 4000);
+        oracle_gps_l1_ca_code_gen_complex_sampled(code_iq.data(), 10, 4000000, 0);
+        tong.set_local_code(reinterpret_cast<const std::complex<float>*>(code_iq.data()));
+        tong.init();
+        int st = 1, k = 0;
+        float last = 0.0F;
+        while (st == 1 && k < 12)
+            {
+                st = tong.work(4000ULL * (k + 1), x.data() + 4000 * k);
+                EXPECT(st >= 1, "tong work: %s", tong.last_error().c_str());
+                EXPECT(tong.tong_count() == static_cast<uint32_t>(k + 2), "tong counter %u after dwell %d", tong.tong_count(), k + 1);
+                EXPECT(tong.mag() > last && tong.mag() > 0.00108F * (k + 1), "accumulated statistic %g after dwell %d", tong.mag(), k + 1);
+                last = tong.mag();
+                k++;
+            }
+        EXPECT(st == 2 && k == 7, "tong ends in state %d after %d dwells", st, k);
+        EXPECT(std::abs(600.0 - tong.result().Acq_delay_samples * 1023.0 / 4000.0) < 0.5, "tong delay %f", tong.result().Acq_delay_samples);
+        EXPECT(std::abs(tong.result().Acq_doppler_hz - 750.0) < 2.0 / 3e-3, "tong doppler %f", tong.result().Acq_doppler_hz);
+        EXPECT(tong.result().Acq_samplestamp_samples == 28000ULL && tong.result().Acq_doppler_step == 250U, "tong synchro fields");
+        // noise only: the first miss takes the counter 1 -> 0 (tong.cc:288-294)
+        auto noise = make_signal(4000, 4e6, 10, 0.0, 0.0, 0.0, 5);
+        Hip_Acq_Conf cn = conf;
+        cn.threshold = 0.004F;
+        Hip_Pcps_Tong_Core tn(cn, 1, 8, 9, 0);
+        tn.set_local_code(reinterpret_cast<const std::complex<float>*>(code_iq.data()));
+        tn.init();
+        EXPECT(tn.work(4000, noise.data()) == 3 && tn.tong_count() == 0, "tong noise-only: state %d count %u", tn.state(), tn.tong_count());
+        EXPECT(std::abs(hip_threshold_compute_doppler(0.1F, 4000, 10000, 250) - 0.0037F) < 2e-4F, "ThresholdComputeDoppler %g", hip_threshold_compute_doppler(0.1F, 4000, 10000, 250));
+    }
+    // ---------------------------------------------------------------- 8 ms detector logic, galileo_pcps_8ms_acquisition_cc call pattern
+    {
+        // the class is code-agnostic; two C/A periods stand in for the two E1 primary-code periods (the E1 case runs in
+        // tests/test_pcps_detectors_gpu.py): a sign flip between the periods must select code B, none code A
+        const double amp = std::sqrt(std::pow(10.0, 4.4) * 2.0 / 4e6);
+        Hip_Acq_Conf conf;
+        conf.fs_in = 4000000;
+        conf.sampled_ms = 2;
+        conf.ms_per_code = 1;
+        conf.doppler_max = 5000;
+        conf.doppler_step = 250;
+        conf.max_dwells = 1;
+        conf.SetDerivedParams();
+        conf.threshold = hip_threshold_compute_doppler(0.01F, 8000, 5000, 250);
+        std::vector<float> one(2 * 4000), code_iq(2 * 8000);
+        oracle_gps_l1_ca_code_gen_complex_sampled(one.data(), 7, 4000000, 0);
+        for (int i = 0; i < 8000; i++) code_iq[i] = one[i], code_iq[8000 + i] = one[i];
+        for (int flip = 0; flip < 2; flip++)
+            {
+                // the block starts exactly on a code period (delay 0) so that the symbol boundary sits mid-block
+                auto x = make_signal(8000, 4e6, 7, -1250.0, 0.0, amp, 31 + flip);
+                if (flip)
+                    {
+                        // subtract twice the signal part of the second period: x = noise + s  ->  noise - s
+                        std::vector<float> ca(1023);
+                        oracle_gps_l1_ca_code_gen_float(ca.data(), 7, 0);
+                        const double f_code = 1.023e6 * (1.0 - 1250.0 / 1575.42e6);
+                        for (int i = 4000; i < 8000; i++)
+                            {
+                                const long chip = static_cast<long>(std::floor(i * f_code / 4e6)) % 1023;
+                                const double ph = 2.0 * M_PI * -1250.0 / 4e6 * i;
+                                x[i] -= 2.0F * std::complex<float>(static_cast<float>(amp * ca[chip] * std::cos(ph)), static_cast<float>(amp * ca[chip] * std::sin(ph)));
+                            }
+                    }
+                Hip_Galileo_Pcps_8ms_Core e8(conf, 0);
+                EXPECT(e8.ok() && e8.num_doppler_bins() == 41 && e8.fft_size() == 8000, "8ms create: %s", e8.last_error().c_str());
+                e8.set_local_code(reinterpret_cast<const std::complex<float>*>(code_iq.data()));
+                e8.init();
+                const int st = e8.work(8000, x.data());
+                EXPECT(st == 2, "8ms state %d (%s), statistic %g threshold %g", st, e8.last_error().c_str(), e8.test_statistics(), conf.threshold);
+                EXPECT(e8.winning_code() == flip, "8ms picked code %d with flip %d", e8.winning_code(), flip);
+                EXPECT(e8.result().Acq_delay_samples < 2.0 || e8.result().Acq_delay_samples > 3998.0, "8ms delay %f", e8.result().Acq_delay_samples);
+                EXPECT(std::abs(e8.result().Acq_doppler_hz + 1250.0) <= 250.0, "8ms doppler %f", e8.result().Acq_doppler_hz);
+                EXPECT(e8.input_power() > 1.9F && e8.input_power() < 2.2F, "8ms input power %g", e8.input_power());
+            }
+        auto noise = make_signal(8000, 4e6, 7, 0.0, 0.0, 0.0, 77);
+        Hip_Galileo_Pcps_8ms_Core e8(conf, 0);
+        e8.set_local_code(reinterpret_cast<const std::complex<float>*>(code_iq.data()));
+        e8.init();
+        EXPECT(e8.work(8000, noise.data()) == 3, "8ms noise-only state %d statistic %g", e8.state(), e8.test_statistics());
     }
     if (fails == 0) std::printf("HOST CLASSES OK\n");
     return fails == 0 ? 0 : 1;
