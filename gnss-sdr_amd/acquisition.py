@@ -34,7 +34,7 @@ class PcpsAcquisitionBank:
                  samples_per_code: float, max_prn: int = 1, num_doppler_bins: int = 0, consumed_samples: int | None = None,
                  effective_fft_size: int | None = None, doppler_center: int = 0, doppler_bias: int = 0,
                  bit_transition_flag: bool = False, use_cfar: bool = True, device: int = 0, keep_grid: bool = True,
-                 transform_path: int = 0, num_doppler_bins_step2: int = 0, doppler_step2: float = 125.0):
+                 transform_path: int = 0, num_doppler_bins_step2: int = 0, doppler_step2: float = 125.0, fold: int = 0):
         self._lib = _lib.load()
         c = AcqConf()
         c.fs_in = int(fs_in)
@@ -55,6 +55,7 @@ class PcpsAcquisitionBank:
         c.transform_path = int(transform_path)
         c.num_doppler_bins_step2 = int(num_doppler_bins_step2)  # 0: make_two_steps off
         c.doppler_step2 = float(doppler_step2)
+        c.fold = int(fold)  # > 1: QuickSync folding, consumed_samples = fold * fft_size
         self.conf = c
         self.num_doppler_bins = int(num_doppler_bins) if num_doppler_bins else int(math.ceil(2.0 * doppler_max / doppler_step))
         self._h = C.c_void_p()
@@ -75,7 +76,7 @@ class PcpsAcquisitionBank:
         """code: the time-domain complex replica the adapter generates (e.g. gps_l1_ca_code_gen_complex_sampled),
         consumed_samples long (fft_size/2 with bit_transition_flag)."""
         code = np.ascontiguousarray(code, np.complex64)
-        need = self.conf.fft_size // 2 if self.conf.bit_transition_flag else self.conf.consumed_samples
+        need = self.conf.fft_size // 2 if self.conf.bit_transition_flag else (self.conf.fft_size if self.conf.fold > 1 else self.conf.consumed_samples)
         if len(code) < need:
             raise ValueError(f"code has {len(code)} samples, {need} needed")
         check(self._lib.gsh_acq_set_local_code(self._h, prn_slot, fptr(code)))
@@ -111,6 +112,14 @@ class PcpsAcquisitionBank:
         res = (AcqResult * n_prn)()
         check(self._lib.gsh_acq_dwell_resident(self._h, n_prn, int(accumulate), dwell_count, res))
         return [self._to_dict(r) for r in res]
+
+    def time_correlate(self, code: np.ndarray, doppler_index: int, delays) -> np.ndarray:
+        """sum_j x[delay + j] w_bin[delay + j] code[j] over the resident block for each candidate delay (quicksync.cc:295-323)."""
+        code = np.ascontiguousarray(code, np.complex64)
+        d = np.ascontiguousarray(delays, np.uint32)
+        out = np.empty(len(d), np.complex64)
+        check(self._lib.gsh_acq_time_correlate(self._h, fptr(code), len(code), int(doppler_index), d.ctypes.data_as(C.POINTER(C.c_uint32)), len(d), fptr(out)))
+        return out
 
     def read_row_peaks(self, prn_slot: int):
         """(per-bin maximum, per-bin lowest arg-max) of prn_slot's grid after the last dwell."""

@@ -41,6 +41,10 @@ struct gsh_acq
     bool have_input{false};
     float grid_weight{1.0f};  // gsh_acq_set_grid_weight
     double* d_power{nullptr};  // gsh_acq_input_power scratch
+    float2* d_tc_code{nullptr};  // gsh_acq_time_correlate: code, delays and results
+    size_t tc_code_len{0};
+    uint32_t* d_tc_delays{nullptr};
+    float2* d_tc_out{nullptr};
     hipEvent_t ev0{nullptr}, ev1{nullptr};
     // second issue lane for gsh_acq_time_dwells_pipelined (on-chip path): its own stream and per-batch buffers, so that
     // batch k+1's forward transforms fill the compute units batch k's last cells leave idle
@@ -104,7 +108,7 @@ int enqueue_dwell(gsh_acq* a, uint32_t n_prn, int accumulate, uint32_t dwell_cou
         {
             // acq.cc:657-664 (zero padding) + :531-535 (wipe-off, forward FFT): one work-group per bin
             int rc = gsh::onchip_forward(n, a->d_in, 0, static_cast<int>(c.consumed_samples), 0, a->d_bins_hz, static_cast<double>(c.fs_in),
-                a->d_spectra, a->n_bins, a->stream);
+                a->d_spectra, a->n_bins, a->stream, static_cast<int>(std::max(1u, c.fold)));
             if (rc != GSH_OK) return rc;
             // acq.cc:538-553 + the per-row part of :409-519: one work-group per (PRN, bin) cell, nothing leaves the CU
             return gsh::onchip_correlate(n, a->d_spectra, a->d_codes, a->d_grid, a->d_rows, a->d_results, a->d_arrivals, static_cast<int>(n_prn),
@@ -113,7 +117,7 @@ int enqueue_dwell(gsh_acq* a, uint32_t n_prn, int accumulate, uint32_t dwell_cou
         }
     // acq.cc:657-664 (zero padding) + :531-535 (wipe-off, forward FFT) for every bin
     int rc = gsh::fft_forward(a->plan, a->d_in, 0, static_cast<int>(c.consumed_samples), 0, a->d_bins_hz, static_cast<double>(c.fs_in),
-        a->d_tmp, a->d_spectra, a->n_bins, a->stream);
+        a->d_tmp, a->d_spectra, a->n_bins, a->stream, static_cast<int>(std::max(1u, c.fold)));
     if (rc != GSH_OK) return rc;
     const int grid_off = c.bit_transition_flag ? eff : 0;  // acq.cc:544
     for (uint32_t p0 = 0; p0 < n_prn; p0 += static_cast<uint32_t>(a->chunk_prn))
@@ -125,6 +129,54 @@ int enqueue_dwell(gsh_acq* a, uint32_t n_prn, int accumulate, uint32_t dwell_cou
         }
     return gsh::grid_statistics(a->d_grid, a->d_rows, a->d_results, static_cast<int>(n_prn), a->n_bins, eff,
         static_cast<int>(c.samples_per_chip), c.use_cfar, dwell_count ? dwell_count : 1u, a->stream);
+}
+
+// time-domain correlation of the resident block with an unfolded code at a few candidate delays, at one Doppler bin
+// (pcps_quicksync_acquisition_cc.cc:300-323): out[c] = sum_j x[delay_c + j] w[delay_c + j] code[j].  One work-group per candidate;
+// products in float as the reference forms them, the sum in double (the reference adds sequentially in float).
+constexpr int TC_MAX_DELAYS = 100;  // complex_acumulator is std::array<gr_complex, 100> (quicksync.cc:295)
+__global__ __launch_bounds__(1024) void time_correlate_kernel(const float2* __restrict__ x, const float2* __restrict__ code, int code_len,
+    const uint32_t* __restrict__ delays, float f_hz, double inv_fs, float2* __restrict__ out)
+{
+    __shared__ double pr[16], pi[16];
+    const int delay = static_cast<int>(delays[blockIdx.x]);
+    double sr = 0.0, si = 0.0;
+    for (int j = threadIdx.x; j < code_len; j += 1024)
+        {
+            const int n = delay + j;
+            double rev = static_cast<double>(f_hz) * static_cast<double>(n) * inv_fs;
+            rev -= rint(rev);
+            float sn, cs;
+            sincospif(static_cast<float>(2.0 * rev), &sn, &cs);
+            const float2 v = x[n], c = code[j];
+            // in_temp = in * wipe-off (quicksync.cc:251), then * code (:311): two float complex products
+            const float wr = __fsub_rn(__fmul_rn(v.x, cs), __fmul_rn(v.y, -sn));
+            const float wi = __fadd_rn(__fmul_rn(v.x, -sn), __fmul_rn(v.y, cs));
+            sr += static_cast<double>(__fsub_rn(__fmul_rn(wr, c.x), __fmul_rn(wi, c.y)));
+            si += static_cast<double>(__fadd_rn(__fmul_rn(wr, c.y), __fmul_rn(wi, c.x)));
+        }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        {
+            sr += __shfl_down(sr, off, 64);
+            si += __shfl_down(si, off, 64);
+        }
+    if ((threadIdx.x & 63) == 0)
+        {
+            pr[threadIdx.x >> 6] = sr;
+            pi[threadIdx.x >> 6] = si;
+        }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        {
+            double tr = 0.0, ti = 0.0;
+            for (int w = 0; w < 16; w++)
+                {
+                    tr += pr[w];
+                    ti += pi[w];
+                }
+            out[blockIdx.x] = make_float2(static_cast<float>(tr), static_cast<float>(ti));
+        }
 }
 
 int check_dwell_args(gsh_acq* a, uint32_t n_prn, const void* results)
@@ -254,9 +306,19 @@ extern "C"
         gsh_acq_conf c = *conf;
         GSH_REQUIRE(c.fs_in > 0, "fs_in must be positive");
         GSH_REQUIRE(c.fft_size >= 4 && c.fft_size <= (1u << 24), "fft_size %u outside 4..2^24", c.fft_size);
-        GSH_REQUIRE(c.consumed_samples >= 1 && c.consumed_samples <= c.fft_size, "consumed_samples %u outside 1..fft_size", c.consumed_samples);
-        GSH_REQUIRE(c.consumed_samples == c.fft_size || 2 * c.consumed_samples == c.fft_size,
-            "fft_size must be consumed_samples or twice it (acq.cc:111)");
+        if (c.fold > 1)
+            {
+                // pcps_quicksync_acquisition_cc.cc:243-263: the block is `fold` transform lengths long and is folded after the wipe-off
+                GSH_REQUIRE(c.fold <= 10000, "fold %u outside 1..10000", c.fold);
+                GSH_REQUIRE(static_cast<uint64_t>(c.fold) * c.fft_size == c.consumed_samples, "with fold = %u, consumed_samples must be fold * fft_size", c.fold);
+                GSH_REQUIRE(!c.bit_transition_flag && c.num_doppler_bins_step2 == 0, "fold > 1 excludes bit_transition_flag and the two-step search");
+            }
+        else
+            {
+                GSH_REQUIRE(c.consumed_samples >= 1 && c.consumed_samples <= c.fft_size, "consumed_samples %u outside 1..fft_size", c.consumed_samples);
+                GSH_REQUIRE(c.consumed_samples == c.fft_size || 2 * c.consumed_samples == c.fft_size,
+                    "fft_size must be consumed_samples or twice it (acq.cc:111)");
+            }
         if (c.bit_transition_flag)
             GSH_REQUIRE(c.effective_fft_size * 2 == c.fft_size, "bit_transition_flag needs effective_fft_size = fft_size/2 (acq.cc:112)");
         else
@@ -309,7 +371,8 @@ extern "C"
         if ((e = hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
         if ((e = hipMalloc(&a->d_bins_hz, sizeof(float) * D)) != hipSuccess) return fail(e, "hipMalloc(bins)");
         if (a->n_bins2 > 0 && (e = hipMalloc(&a->d_bins2_hz, sizeof(float) * a->n_bins2 * P)) != hipSuccess) return fail(e, "hipMalloc(bins2)");
-        if ((e = hipMalloc(&a->d_in, sizeof(float2) * n)) != hipSuccess) return fail(e, "hipMalloc(in)");
+        const size_t in_len = std::max<size_t>(n, c.consumed_samples);  // fold > 1: the block is longer than the transform
+        if ((e = hipMalloc(&a->d_in, sizeof(float2) * in_len)) != hipSuccess) return fail(e, "hipMalloc(in)");
         if ((e = hipMalloc(&a->d_spectra, sizeof(float2) * D * n)) != hipSuccess) return fail(e, "hipMalloc(spectra)");
         if ((e = hipMalloc(&a->d_codes, sizeof(float2) * P * n)) != hipSuccess) return fail(e, "hipMalloc(codes)");
         // the four-step path keeps its inter-pass intermediate in HBM; the on-chip path only needs one row to stage a code
@@ -326,7 +389,7 @@ extern "C"
         if ((e = hipMalloc(&a->d_arrivals, sizeof(unsigned) * P)) != hipSuccess) return fail(e, "hipMalloc(arrivals)");
         if ((e = hipMemset(a->d_arrivals, 0, sizeof(unsigned) * P)) != hipSuccess) return fail(e, "hipMemset(arrivals)");
         if ((e = hipHostMalloc(reinterpret_cast<void**>(&a->h_results), sizeof(gsh::DevAcqResult) * P, hipHostMallocDefault)) != hipSuccess) return fail(e, "hipHostMalloc");
-        if ((e = hipHostMalloc(reinterpret_cast<void**>(&a->h_stage), sizeof(float2) * n, hipHostMallocDefault)) != hipSuccess) return fail(e, "hipHostMalloc");
+        if ((e = hipHostMalloc(reinterpret_cast<void**>(&a->h_stage), sizeof(float2) * in_len, hipHostMallocDefault)) != hipSuccess) return fail(e, "hipHostMalloc");
         if ((e = hipEventCreate(&a->ev0)) != hipSuccess) return fail(e, "hipEventCreate");
         if ((e = hipEventCreate(&a->ev1)) != hipSuccess) return fail(e, "hipEventCreate");
         fill_bins(a);
@@ -350,6 +413,9 @@ extern "C"
         if (a->d_bins2_hz) (void)hipFree(a->d_bins2_hz);
         if (a->d_in16) (void)hipFree(a->d_in16);
         if (a->d_power) (void)hipFree(a->d_power);
+        if (a->d_tc_code) (void)hipFree(a->d_tc_code);
+        if (a->d_tc_delays) (void)hipFree(a->d_tc_delays);
+        if (a->d_tc_out) (void)hipFree(a->d_tc_out);
         if (a->d_in) (void)hipFree(a->d_in);
         if (a->d_spectra) (void)hipFree(a->d_spectra);
         if (a->d_codes) (void)hipFree(a->d_codes);
@@ -386,9 +452,9 @@ extern "C"
                 n_in = static_cast<int>(c.fft_size / 2);
                 place_off = static_cast<int>(c.fft_size / 2);
             }
-        else if (c.consumed_samples == c.fft_size)
+        else if (c.consumed_samples == c.fft_size || c.fold > 1)
             {
-                n_in = static_cast<int>(c.consumed_samples);
+                n_in = static_cast<int>(c.fft_size);  // fold > 1: the caller hands over the code already folded to fft_size (quicksync.cc:137-152)
                 place_off = 0;
             }
         else
@@ -699,6 +765,38 @@ extern "C"
         return GSH_OK;
     }
 
+    int gsh_acq_time_correlate(gsh_acq_t* a, const float* code_iq, uint32_t code_len, uint32_t doppler_index, const uint32_t* delays, uint32_t n_delays,
+        float* out_iq)
+    {
+        GSH_REQUIRE(a != nullptr && code_iq != nullptr && delays != nullptr && out_iq != nullptr, "null argument");
+        if (!a->have_input) return set_error(GSH_ERR_STATE, "no input block resident");
+        GSH_REQUIRE(code_len >= 1 && code_len <= a->conf.consumed_samples, "code_len %u outside 1..consumed_samples", code_len);
+        GSH_REQUIRE(n_delays >= 1 && n_delays <= static_cast<uint32_t>(TC_MAX_DELAYS), "n_delays %u outside 1..%d", n_delays, TC_MAX_DELAYS);
+        GSH_REQUIRE(doppler_index < static_cast<uint32_t>(a->n_bins), "doppler_index %u outside 0..%d", doppler_index, a->n_bins - 1);
+        for (uint32_t i = 0; i < n_delays; i++)
+            GSH_REQUIRE(static_cast<uint64_t>(delays[i]) + code_len <= a->conf.consumed_samples, "delay %u + code_len %u runs past the %u resident samples", delays[i],
+                code_len, a->conf.consumed_samples);
+        GSH_HIP(hipSetDevice(a->device));
+        if (a->tc_code_len < code_len)
+            {
+                if (a->d_tc_code) (void)hipFree(a->d_tc_code);
+                a->d_tc_code = nullptr;
+                a->tc_code_len = 0;
+                GSH_HIP(hipMalloc(&a->d_tc_code, sizeof(float2) * code_len));
+                a->tc_code_len = code_len;
+            }
+        if (a->d_tc_delays == nullptr) GSH_HIP(hipMalloc(&a->d_tc_delays, sizeof(uint32_t) * TC_MAX_DELAYS));
+        if (a->d_tc_out == nullptr) GSH_HIP(hipMalloc(&a->d_tc_out, sizeof(float2) * TC_MAX_DELAYS));
+        GSH_HIP(hipMemcpyAsync(a->d_tc_code, code_iq, sizeof(float2) * code_len, hipMemcpyHostToDevice, a->stream));
+        GSH_HIP(hipMemcpyAsync(a->d_tc_delays, delays, sizeof(uint32_t) * n_delays, hipMemcpyHostToDevice, a->stream));
+        hipLaunchKernelGGL(time_correlate_kernel, dim3(n_delays), dim3(1024), 0, a->stream, a->d_in, a->d_tc_code, static_cast<int>(code_len), a->d_tc_delays,
+            a->h_bins_hz[doppler_index], 1.0 / static_cast<double>(a->conf.fs_in), a->d_tc_out);
+        GSH_HIP(hipGetLastError());
+        GSH_HIP(hipMemcpyAsync(out_iq, a->d_tc_out, sizeof(float2) * n_delays, hipMemcpyDeviceToHost, a->stream));
+        GSH_HIP(hipStreamSynchronize(a->stream));
+        return GSH_OK;
+    }
+
     int gsh_acq_time_dwells(gsh_acq_t* a, uint32_t n_prn, int reps, float* avg_ms)
     {
         GSH_REQUIRE(a != nullptr && avg_ms != nullptr, "null argument");
@@ -745,6 +843,7 @@ extern "C"
         auto enqueue = [&](int lane) -> int {
             hipStream_t st = lane ? a->stream2 : a->stream;
             float2* spectra = lane ? a->d_spectra2 : a->d_spectra;
+            GSH_REQUIRE(c.fold <= 1, "the pipelined timing loop does not fold");
             int rc = gsh::onchip_forward(static_cast<int>(n), a->d_in, 0, static_cast<int>(c.consumed_samples), 0, a->d_bins_hz,
                 static_cast<double>(c.fs_in), spectra, a->n_bins, st);
             if (rc != GSH_OK) return rc;

@@ -62,7 +62,7 @@ struct DevAcqResult
 //   wipe_hz != nullptr: sequence b is multiplied by exp(-j 2 pi wipe_hz[b] n / fs) on load (acq.cc:275-281,531).
 //   tmp: batch * n complex scratch; dst: batch * n complex.
 int fft_forward(const FftPlan& p, const float2* src, size_t src_stride, int n_in, int place_off, const float* wipe_hz, double fs,
-    float2* tmp, float2* dst, int batch, hipStream_t s);
+    float2* tmp, float2* dst, int batch, hipStream_t s, int fold = 1);
 
 // Circular correlation of n_prn code spectra with n_bins signal spectra (both in permuted layout) and
 // |.|^2 into grid[prn][bin][effective]: y = IFFT(X_bin * conj(FFT(code_prn))), unnormalised (acq.cc:538-553).
@@ -79,7 +79,7 @@ int grid_statistics(const float* grid, RowStat* rows, DevAcqResult* results, int
 // Spectra are in NATURAL order here (the four-step path above uses its permuted [k1][k2] layout).
 bool onchip_supported(int n);
 int onchip_forward(int n, const float2* src, size_t src_stride, int n_in, int place_off, const float* wipe_hz, double fs, float2* dst,
-    int batch, hipStream_t s);
+    int batch, hipStream_t s, int fold = 1);
 // one work-group per (PRN, bin) cell: spectrum product, inverse transform, |.|^2, row statistics, and (by the last cell
 // of each PRN, counted in `arrivals`, n_prn zero-initialised counters) the PRN's statistic into `results`; the grid is
 // read only when `accumulate` and written only when `store_grid`

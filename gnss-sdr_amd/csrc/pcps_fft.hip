@@ -260,6 +260,7 @@ struct FwdColsArgs
     const float2* tw_n;
     const float2* tw_1;
     int n1, n2, tile;
+    int fold;  // > 1: the wiped-off input is summed over `fold` segments of n1*n2 samples (pcps_quicksync_acquisition_cc.cc:243-263)
     SubPlan sp;
 };
 
@@ -286,7 +287,21 @@ __global__ __launch_bounds__(FFT_THREADS) void fwd_cols_kernel(FwdColsArgs a)
                 {
                     const int n = r * a.n2 + col;
                     const int k = n - a.place_off;
-                    if (k >= 0 && k < a.n_in)
+                    if (a.fold > 1)
+                        {
+                            // quicksync.cc:251-263: product with the wipe-off first, then the segments are added in order
+                            const int len = a.n1 * a.n2;
+                            for (int seg = 0; seg < a.fold; seg++)
+                                {
+                                    const int ks = k + seg * len;
+                                    if (ks < 0 || ks >= a.n_in) continue;
+                                    float2 u = src[ks];
+                                    if (wipe) u = cmul(u, wipeoff(f_hz, n + seg * len, a.inv_fs));
+                                    v.x += u.x;
+                                    v.y += u.y;
+                                }
+                        }
+                    else if (k >= 0 && k < a.n_in)
                         {
                             v = src[k];
                             if (wipe) v = cmul(v, wipeoff(f_hz, n, a.inv_fs));
@@ -699,10 +714,11 @@ void plan_destroy(FftPlan* plan)
 // host side: launches
 // ---------------------------------------------------------------------------------------------------------
 int fft_forward(const FftPlan& p, const float2* src, size_t src_stride, int n_in, int place_off, const float* wipe_hz, double fs,
-    float2* tmp, float2* dst, int batch, hipStream_t s)
+    float2* tmp, float2* dst, int batch, hipStream_t s, int fold)
 {
     if (batch <= 0) return GSH_OK;
     FwdColsArgs c;
+    c.fold = fold;
     c.src = src;
     c.src_stride = src_stride;
     c.n_in = n_in;

@@ -35,6 +35,7 @@ struct OcFwdArgs
     const float* wipe_hz;
     double inv_fs;
     cf* dst;
+    int fold;  // > 1: the wiped-off input is summed over `fold` segments of N samples (pcps_quicksync_acquisition_cc.cc:243-263)
 };
 
 struct OcCellArgs
@@ -101,11 +102,33 @@ __global__ __launch_bounds__(P::THREADS) void oc_forward_kernel(OcFwdArgs a)
     if (t < P::T1)
         {
             const cf* __restrict__ src = a.src + static_cast<size_t>(b) * a.src_stride;
-            oc::static_for<P::R1>([&](auto N1) GSH_AI {
-                constexpr int n1 = decltype(N1)::value;
-                const int k = n1 * P::T1 + t - a.place_off;
-                ra[n1] = (k >= 0 && k < a.n_in) ? src[k] : cf{0.0f, 0.0f};
-            });
+            if (a.fold > 1)
+                {
+                    // sum_seg x[n + seg N] w[n + seg N] = w[n] * sum_seg x[n + seg N] W_seg with W_seg = w[seg N], uniform over the
+                    // work-group: the segments are folded with their scalar phasor here, the per-sample wipe-off follows below
+                    oc::static_for<P::R1>([&](auto N1) GSH_AI { ra[decltype(N1)::value] = cf{0.0f, 0.0f}; });
+                    const float f = a.wipe_hz != nullptr ? a.wipe_hz[b] : 0.0f;
+                    for (int seg = 0; seg < a.fold; seg++)
+                        {
+                            const cf ws = a.wipe_hz != nullptr ? wipe_phasor(f, seg * P::N, a.inv_fs) : cf{1.0f, 0.0f};
+                            oc::static_for<P::R1>([&](auto N1) GSH_AI {
+                                constexpr int n1 = decltype(N1)::value;
+                                const int k = n1 * P::T1 + t + seg * P::N;
+                                if (k < a.n_in)
+                                    {
+                                        const cf u = oc::cmul(src[k], ws);
+                                        ra[n1].x += u.x;
+                                        ra[n1].y += u.y;
+                                    }
+                            });
+                        }
+                }
+            else
+                oc::static_for<P::R1>([&](auto N1) GSH_AI {
+                    constexpr int n1 = decltype(N1)::value;
+                    const int k = n1 * P::T1 + t - a.place_off;
+                    ra[n1] = (k >= 0 && k < a.n_in) ? src[k] : cf{0.0f, 0.0f};
+                });
             if (a.wipe_hz != nullptr)
                 {
                     // w[n] = w[t] * (w[T1])^n1, both seeds exact, powers by the squaring tree
@@ -395,7 +418,7 @@ bool onchip_supported(int n)
 }
 
 int onchip_forward(int n, const float2* src, size_t src_stride, int n_in, int place_off, const float* wipe_hz, double fs, float2* dst,
-    int batch, hipStream_t s)
+    int batch, hipStream_t s, int fold)
 {
     if (batch <= 0) return GSH_OK;
     OcFwdArgs a;
@@ -406,6 +429,7 @@ int onchip_forward(int n, const float2* src, size_t src_stride, int n_in, int pl
     a.wipe_hz = wipe_hz;
     a.inv_fs = 1.0 / fs;
     a.dst = reinterpret_cast<cf*>(dst);
+    a.fold = fold;
 #define GSH_OC_CASE(r1, r2, r3) \
     if (n == (r1) * (r2) * (r3)) return launch_forward<oc::Plan<r1, r2, r3>>(a, batch, s);
     GSH_OC_PLANS(GSH_OC_CASE)

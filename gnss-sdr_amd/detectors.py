@@ -149,3 +149,80 @@ class GalileoPcps8msAcquisition:
         elif self.well_count == self.max_dwells:
             self.state = 3
         return self.state
+
+
+class PcpsQuickSyncAcquisition:
+    """general_work of pcps_quicksync_acquisition_cc for one channel (pcps_quicksync_acquisition_cc.cc:155-400, "qs.cc").
+    The handle is created with fold = folding_factor^2: wipe-off, folding, both transforms, |.|^2 and the per-bin maxima run in
+    one dwell; the alias of the winning folded delay is resolved by gsh_acq_time_correlate on the resident block."""
+
+    def __init__(self, fs_in: int, samples_per_code: int, folding_factor: int, doppler_max: int, doppler_step: int, threshold: float,
+                 max_dwells: int = 1, bit_transition_flag: bool = False, device: int = 0, transform_path: int = 0):
+        self.p = int(folding_factor)
+        self.spc = int(samples_per_code)
+        self.fft_size = self.spc // self.p                                                        # qs.cc:58
+        self.n_in = self.spc * self.p
+        self.n_bins = count_doppler_bins(doppler_max, doppler_step)
+        self.bank = PcpsAcquisitionBank(fs_in, self.fft_size, doppler_max, doppler_step, 1, float(self.spc), max_prn=1,
+                                        num_doppler_bins=self.n_bins, consumed_samples=self.n_in, fold=self.p * self.p, device=device,
+                                        transform_path=transform_path)
+        self.doppler_max, self.doppler_step = doppler_max, doppler_step
+        self.threshold = np.float32(threshold)
+        self.bit_transition_flag = bool(bit_transition_flag)
+        self.max_dwells = 2 if self.bit_transition_flag else max_dwells                            # adapter, gps_l1_ca_pcps_quicksync_acquisition.cc:74
+        self.init()
+
+    def close(self):
+        self.bank.close()
+
+    def set_local_code(self, code: np.ndarray) -> None:                                          # qs.cc:133-156
+        self.code = np.ascontiguousarray(code[:self.spc], np.complex64).copy()
+        folded = np.zeros(self.fft_size, np.complex64)
+        for i in range(self.p):
+            folded = (folded + self.code[i * self.fft_size:(i + 1) * self.fft_size]).astype(np.complex64)
+        self.bank.set_local_code(0, folded)
+
+    def init(self) -> None:                                                                      # qs.cc:180-192
+        self.well_count = 0
+        self.mag = np.float32(0.0)
+        self.input_power = np.float32(0.0)
+        self.test_statistics = np.float32(0.0)
+        self.state = 1
+        self.result = dict(acq_delay_samples=0.0, doppler_hz=0.0, doppler_step=0)
+
+    def work(self, x: np.ndarray) -> int:                                                        # qs.cc:195-395
+        x = np.ascontiguousarray(x[:self.n_in], np.complex64)
+        fnf = np.float32(self.fft_size) * np.float32(self.fft_size)
+        self.mag = np.float32(0.0)
+        self.test_statistics = np.float32(0.0)
+        self.well_count += 1
+        self.bank.dwell(x, 1)
+        self.input_power = np.float32(self.bank.input_power())                                    # :227-230
+        pk, ix = self.bank.read_row_peaks(0)
+        self.rows = []
+        best = None
+        for d in range(self.n_bins):
+            magt = np.float32(pk[d] / (fnf * fnf))                                                # :289
+            self.rows.append((float(magt), int(ix[d])))
+            if self.mag < magt:                                                                   # :292
+                self.mag = magt
+                best = (d, int(ix[d]))
+        if best is not None:
+            # :306-343 runs at every update of d_mag; only the last one (the winning bin) survives, so it is done once
+            d, t = best
+            possible = [t % self.spc + i * self.fft_size for i in range(self.p)]
+            acc = self.bank.time_correlate(self.code, d, possible)
+            corr = (acc.real * acc.real + acc.imag * acc.imag).astype(np.float32)
+            k = int(np.argmax(corr))
+            self.candidates = acc
+            self.result = dict(acq_delay_samples=float(possible[k]), doppler_hz=float(-self.doppler_max + self.doppler_step * d),
+                               doppler_step=self.doppler_step, index_time=t, index_doppler=d, alias=k)
+            self.test_statistics = np.float32(self.mag / self.input_power)                        # :342
+        if not self.bit_transition_flag:                                                          # :366-375
+            if self.test_statistics > self.threshold:
+                self.state = 2
+            elif self.well_count == self.max_dwells:
+                self.state = 3
+        elif self.well_count == self.max_dwells:                                                  # :377-390
+            self.state = 2 if self.test_statistics > self.threshold else 3
+        return self.state

@@ -15,13 +15,14 @@ uint32_t count_bins(int32_t doppler_max, int32_t doppler_step)
     return n;
 }
 
-gsh_acq* make_handle(const Hip_Acq_Conf& conf, uint32_t fft_size, uint32_t bins, uint32_t max_prn, int device, std::string* err)
+gsh_acq* make_handle(const Hip_Acq_Conf& conf, uint32_t fft_size, uint32_t bins, uint32_t max_prn, int device, std::string* err, uint32_t fold = 0)
 {
     gsh_acq_conf c{};
     c.fs_in = conf.fs_in;
     c.fft_size = fft_size;
     c.effective_fft_size = fft_size;
-    c.consumed_samples = fft_size;
+    c.consumed_samples = fold > 1 ? fold * fft_size : fft_size;
+    c.fold = fold;
     c.num_doppler_bins = bins;
     c.doppler_max = conf.doppler_max;
     c.doppler_step = conf.doppler_step;
@@ -49,6 +50,17 @@ float hip_threshold_compute_doppler(float pfa, uint32_t vector_length, int32_t d
     const auto val = std::pow(1.0 - pfa, exponent);
     const auto lambda = static_cast<double>(vector_length);
     return static_cast<float>(-std::log1p(-val) / lambda);  // quantile of the exponential distribution
+}
+
+
+float hip_threshold_compute_quicksync(float pfa, uint32_t code_length, uint32_t folding_factor, int32_t doppler_max, int32_t doppler_step)
+{
+    const uint32_t frequency_bins = count_bins(doppler_max, doppler_step);
+    const auto ncells = (code_length / folding_factor) * frequency_bins;
+    const auto exponent = 1.0 / static_cast<double>(ncells);
+    const auto val = std::pow(1.0 - pfa, exponent);
+    const auto lambda = static_cast<double>(code_length) / static_cast<double>(folding_factor);
+    return static_cast<float>(-std::log1p(-val) / lambda);
 }
 
 
@@ -242,6 +254,136 @@ int Hip_Galileo_Pcps_8ms_Core::work(uint64_t sample_counter, const std::complex<
     else if (d_well_count == d_acq_params.max_dwells)
         {
             d_state = 3;  // Negative acquisition
+        }
+    return d_state;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------- QuickSync
+Hip_Pcps_Quicksync_Core::Hip_Pcps_Quicksync_Core(const Hip_Acq_Conf& conf, uint32_t code_length, uint32_t folding_factor, uint32_t max_dwells, int device)
+    : d_acq_params(conf), d_samples_per_code(code_length), d_folding_factor(folding_factor), d_max_dwells(max_dwells)
+{
+    if (folding_factor < 1 || folding_factor > 100 || code_length < folding_factor)  // complex_acumulator is std::array<gr_complex, 100> (qs.cc:295)
+        {
+            d_error = "folding_factor outside 1..100";
+            return;
+        }
+    d_fft_size = d_samples_per_code / d_folding_factor;  // qs.cc:58
+    d_num_doppler_bins = count_bins(conf.doppler_max, conf.doppler_step);
+    d_handle = make_handle(conf, d_fft_size, d_num_doppler_bins, 1, device, &d_error, d_folding_factor * d_folding_factor);
+    d_code.assign(d_samples_per_code, std::complex<float>(0.0F, 0.0F));
+    d_code_folded.assign(d_fft_size, std::complex<float>(0.0F, 0.0F));
+    d_accumulator.resize(d_folding_factor);
+    d_corr_output_f.resize(d_folding_factor);
+    d_possible_delay.resize(d_folding_factor);
+    d_peak.resize(d_num_doppler_bins);
+    d_index.resize(d_num_doppler_bins);
+}
+
+
+Hip_Pcps_Quicksync_Core::~Hip_Pcps_Quicksync_Core()
+{
+    if (d_handle != nullptr) gsh_acq_destroy(d_handle);
+}
+
+
+void Hip_Pcps_Quicksync_Core::set_local_code(const std::complex<float>* code)
+{
+    if (d_handle == nullptr) return;
+    // a local copy of the code without the folding, for the correlation in time of the final step
+    for (uint32_t i = 0; i < d_samples_per_code; i++) d_code[i] = code[i];
+    // folding of the code by the folding factor (qs.cc:142-150)
+    for (uint32_t k = 0; k < d_fft_size; k++) d_code_folded[k] = std::complex<float>(0.0F, 0.0F);
+    for (uint32_t i = 0; i < d_folding_factor; i++)
+        for (uint32_t k = 0; k < d_fft_size; k++) d_code_folded[k] += code[i * d_fft_size + k];
+    if (gsh_acq_set_local_code(d_handle, 0, reinterpret_cast<const float*>(d_code_folded.data())) != GSH_OK) d_error = gsh_last_error();
+}
+
+
+void Hip_Pcps_Quicksync_Core::init()
+{
+    d_result = Hip_Detector_Result();
+    d_well_count = 0;
+    d_mag = 0.0;
+    d_input_power = 0.0;
+    d_test_statistics = 0.0;
+    d_state = 1;
+}
+
+
+int Hip_Pcps_Quicksync_Core::work(uint64_t sample_counter, const std::complex<float>* in)
+{
+    if (d_handle == nullptr) return -1;
+    const float fft_normalization_factor = static_cast<float>(d_fft_size) * static_cast<float>(d_fft_size);
+    d_input_power = 0.0;
+    d_mag = 0.0;
+    d_test_statistics = 0.0;
+    d_well_count++;
+
+    // wipe-off, folding, transforms, |.|^2 and per-bin maxima for every Doppler bin (qs.cc:232-289): one dwell
+    gsh_acq_result r{};
+    if (gsh_acq_dwell(d_handle, reinterpret_cast<const float*>(in), 1, 0, 1, &r) != GSH_OK || gsh_acq_input_power(d_handle, &d_input_power) != GSH_OK ||
+        gsh_acq_read_row_peaks(d_handle, 0, d_peak.data(), d_index.data()) != GSH_OK)
+        {
+            d_error = gsh_last_error();
+            return -1;
+        }
+    bool found = false;
+    uint32_t best_bin = 0, best_index = 0;
+    for (uint32_t doppler_index = 0; doppler_index < d_num_doppler_bins; doppler_index++)
+        {
+            const float magt = d_peak[doppler_index] / (fft_normalization_factor * fft_normalization_factor);  // qs.cc:289
+            if (d_mag < magt)  // qs.cc:292
+                {
+                    d_mag = magt;
+                    best_bin = doppler_index;
+                    best_index = d_index[doppler_index];
+                    found = true;
+                }
+        }
+    if (found)
+        {
+            // qs.cc:306-343 runs at every update of d_mag and each run overwrites the previous one: only the winning bin's survives
+            const uint32_t detected_delay_samples_folded = best_index % d_samples_per_code;
+            for (uint32_t i = 0; i < d_folding_factor; i++) d_possible_delay[i] = detected_delay_samples_folded + i * d_fft_size;
+            if (gsh_acq_time_correlate(d_handle, reinterpret_cast<const float*>(d_code.data()), d_samples_per_code, best_bin, d_possible_delay.data(), d_folding_factor,
+                    reinterpret_cast<float*>(d_accumulator.data())) != GSH_OK)
+                {
+                    d_error = gsh_last_error();
+                    return -1;
+                }
+            uint32_t indext = 0;
+            for (uint32_t i = 0; i < d_folding_factor; i++)
+                {
+                    d_corr_output_f[i] = d_accumulator[i].real() * d_accumulator[i].real() + d_accumulator[i].imag() * d_accumulator[i].imag();
+                    if (d_corr_output_f[i] > d_corr_output_f[indext]) indext = i;  // volk_gnsssdr_32f_index_max_32u: first maximum
+                }
+            d_result.index_time = best_index;
+            d_result.index_doppler = best_bin;
+            d_result.Acq_delay_samples = static_cast<double>(d_possible_delay[indext]);
+            d_result.Acq_doppler_hz = static_cast<double>(-d_acq_params.doppler_max + d_acq_params.doppler_step * static_cast<int32_t>(best_bin));
+            d_result.Acq_samplestamp_samples = sample_counter;
+            d_result.Acq_doppler_step = static_cast<uint32_t>(d_acq_params.doppler_step);
+            d_test_statistics = d_mag / d_input_power;  // qs.cc:342
+        }
+
+    if (!d_acq_params.bit_transition_flag)  // qs.cc:366-390
+        {
+            if (d_test_statistics > d_acq_params.threshold)
+                {
+                    d_state = 2;  // Positive acquisition
+                }
+            else if (d_well_count == d_max_dwells)
+                {
+                    d_state = 3;  // Negative acquisition
+                }
+        }
+    else
+        {
+            if (d_well_count == d_max_dwells)  // d_max_dwells = 2
+                {
+                    d_state = (d_test_statistics > d_acq_params.threshold) ? 2 : 3;
+                }
         }
     return d_state;
 }

@@ -4,6 +4,7 @@
  *
  *   Hip_Pcps_Tong_Core         pcps_tong_acquisition_cc          (gnuradio_blocks/pcps_tong_acquisition_cc.cc, "tong.cc")
  *   Hip_Galileo_Pcps_8ms_Core  galileo_pcps_8ms_acquisition_cc   (gnuradio_blocks/galileo_pcps_8ms_acquisition_cc.cc, "8ms.cc")
+ *   Hip_Pcps_Quicksync_Core    pcps_quicksync_acquisition_cc     (gnuradio_blocks/pcps_quicksync_acquisition_cc.cc, "qs.cc")
  *
  * Each class keeps the reference block's member names and its general_work state numbering: init() is state 0, work() is
  * one pass of state 1 over one input vector and returns the next state (1 = keep going, 2 = positive, 3 = negative).
@@ -18,6 +19,9 @@
 #include <cstdint>
 #include <string>
 #include <vector>
+
+/*! ThresholdComputeQuickSync::calculate_threshold (adapters/base_pcps_acquisition_custom.cc:118-140) */
+float hip_threshold_compute_quicksync(float pfa, uint32_t code_length, uint32_t folding_factor, int32_t doppler_max, int32_t doppler_step);
 
 /*! ThresholdComputeDoppler::calculate_threshold (adapters/base_pcps_acquisition_custom.cc:89-112) */
 float hip_threshold_compute_doppler(float pfa, uint32_t vector_length, int32_t doppler_max, int32_t doppler_step);
@@ -105,6 +109,47 @@ private:
     float d_mag{0.0F}, d_input_power{0.0F}, d_test_statistics{0.0F};
     int d_state{0}, d_winning_code{0};
     uint32_t d_well_count{0};
+    uint32_t d_fft_size{0}, d_num_doppler_bins{0};
+};
+
+class Hip_Pcps_Quicksync_Core
+{
+public:
+    /*! code_length = Acq_Conf::code_length (samples per code period), as pcps_quicksync_make_acquisition_cc reads it (qs.cc:52) */
+    Hip_Pcps_Quicksync_Core(const Hip_Acq_Conf& conf, uint32_t code_length, uint32_t folding_factor, uint32_t max_dwells, int device = 0);
+    ~Hip_Pcps_Quicksync_Core();
+    Hip_Pcps_Quicksync_Core(const Hip_Pcps_Quicksync_Core&) = delete;
+    Hip_Pcps_Quicksync_Core& operator=(const Hip_Pcps_Quicksync_Core&) = delete;
+
+    bool ok() const { return d_handle != nullptr; }
+    const std::string& last_error() const { return d_error; }
+
+    void set_local_code(const std::complex<float>* code);  //!< qs.cc:133-156: keeps the unfolded code, hands the folded one to the engine
+    void init();                                           //!< state 0, qs.cc:180-192
+    /*! state 1, qs.cc:195-395 over folding_factor * code_length samples */
+    int work(uint64_t sample_counter, const std::complex<float>* in);
+
+    const Hip_Detector_Result& result() const { return d_result; }
+    uint32_t num_doppler_bins() const { return d_num_doppler_bins; }
+    uint32_t fft_size() const { return d_fft_size; }
+    uint32_t input_length() const { return d_samples_per_code * d_folding_factor; }
+    const std::vector<float>& corr_output_f() const { return d_corr_output_f; }  //!< |.|^2 of the alias correlations (qs.cc:332)
+    float mag() const { return d_mag; }
+    float input_power() const { return d_input_power; }
+    float test_statistics() const { return d_test_statistics; }
+    int state() const { return d_state; }
+
+private:
+    Hip_Acq_Conf d_acq_params;
+    gsh_acq* d_handle{nullptr};
+    std::string d_error;
+    Hip_Detector_Result d_result;
+    std::vector<std::complex<float>> d_code, d_code_folded, d_accumulator;
+    std::vector<float> d_peak, d_corr_output_f;
+    std::vector<uint32_t> d_index, d_possible_delay;
+    float d_mag{0.0F}, d_input_power{0.0F}, d_test_statistics{0.0F};
+    int d_state{0};
+    uint32_t d_samples_per_code, d_folding_factor, d_max_dwells, d_well_count{0};
     uint32_t d_fft_size{0}, d_num_doppler_bins{0};
 };
 

@@ -30,7 +30,7 @@ extern "C"
 {
 #endif
 
-#define GSH_ABI_VERSION 10
+#define GSH_ABI_VERSION 11
 #define GSH_MAX_TAPS 8 /* VE/E/P/L/VL needs 5 (trk.cc:609-650); 8 leaves room for multi-tap dumps */
 
     enum
@@ -363,6 +363,10 @@ extern "C"
         uint32_t num_doppler_bins_step2; /* Acq_Conf::num_doppler_bins_step2 (acq_conf.h:62, key second_nbins); 0 = the handle
                                        never runs the fine-Doppler step (make_two_steps = false); must be <= num_doppler_bins */
         float doppler_step2;        /* Acq_Conf::doppler_step2 (acq_conf.h:50, key second_doppler_step) */
+        uint32_t fold;              /* 0 or 1: off.  > 1 (QuickSync, pcps_quicksync_acquisition_cc.cc:243-263): the input block is
+                                       fold * fft_size samples (= consumed_samples); after the Doppler wipe-off its `fold` segments
+                                       are added into one fft_size-long block before the forward transform.  The block passes
+                                       folding_factor^2; set_local_code takes the code already folded to fft_size (:137-152) */
     } gsh_acq_conf;
 
     typedef struct gsh_acq_result
@@ -404,6 +408,12 @@ extern "C"
      * the per-bin loops of galileo_pcps_8ms_acquisition_cc.cc:226-262, which compares two local codes bin by bin.
      * num_doppler_bins entries each. */
     int gsh_acq_read_row_peaks(gsh_acq_t* a, uint32_t prn_slot, float* row_peak, uint32_t* row_index_time);
+    /* QuickSync's de-ambiguation (pcps_quicksync_acquisition_cc.cc:295-323): time-domain correlation of the resident block,
+     * wiped off at Doppler bin `doppler_index`, with the UNfolded code (code_len complex64 samples, host memory) at n_delays
+     * (<= 100) candidate delays: out[c] = sum_j x[delays[c] + j] w[delays[c] + j] code[j].  Float products as the reference forms
+     * them, summed in double (the reference adds sequentially in float: agreement ~1e-6 relative, not bit for bit). */
+    int gsh_acq_time_correlate(gsh_acq_t* a, const float* code_iq, uint32_t code_len, uint32_t doppler_index, const uint32_t* delays,
+        uint32_t n_delays, float* out_iq);
     /* one acquisition_core pass (acq.cc:648-684) for prn_slot 0..n_prn-1 over the same
      * consumed_samples input block.  `accumulate` != 0 adds to the stored grids
      * (non-coherent dwell number > 1, acq.cc:549-553); `dwell_count` is

@@ -377,3 +377,96 @@ class Galileo8msOracle:
         elif self.well_count == self.max_dwells:
             self.state = 3
         return self.state
+
+
+class QuickSyncOracle:
+    """pcps_quicksync_acquisition_cc::general_work (pcps_quicksync_acquisition_cc.cc:155-360), bit_transition_flag = false:
+    the block of folding_factor code periods is wiped off, folded (its folding_factor^2 segments of fft_size =
+    samples_per_code / folding_factor samples are added), circularly correlated with the equally folded code, and the winning
+    folded delay is resolved among its folding_factor aliases by a direct correlation with the unfolded code."""
+
+    def __init__(self, fs_in: int, samples_per_code: int, folding_factor: int, doppler_max: int, doppler_step: int, threshold: float,
+                 max_dwells: int = 1):
+        self.p = folding_factor
+        self.spc = samples_per_code
+        self.fft_size = samples_per_code // folding_factor                                        # quicksync.cc:58
+        self.n_in = samples_per_code * folding_factor
+        self.n_bins = count_doppler_bins(doppler_max, doppler_step)
+        self.doppler_max, self.doppler_step = doppler_max, doppler_step
+        self.threshold = np.float32(threshold)
+        self.max_dwells = max_dwells
+        # wipe-off tables are n_in long, phase accumulated in float32 by the volk kernel (:84-91)
+        self.wipe = np.empty((self.n_bins, self.n_in), np.complex64)
+        for d in range(self.n_bins):
+            doppler = -doppler_max + doppler_step * d
+            phase_step = TWO_PI * np.float32(doppler) / np.float32(fs_in)
+            out = np.empty(2 * self.n_in, np.float32)
+            ph = C.c_float(0.0)
+            lib().oracle_sincos(out, float(-phase_step), C.byref(ph), self.n_in)
+            self.wipe[d] = out.view(np.complex64)
+        self.init()
+
+    def set_local_code(self, code: np.ndarray):                                                  # quicksync.cc:133-156
+        self.code = np.asarray(code[:self.spc], np.complex64).copy()
+        folded = np.zeros(self.fft_size, np.complex64)
+        for i in range(self.p):
+            folded = (folded + self.code[i * self.fft_size:(i + 1) * self.fft_size]).astype(np.complex64)
+        self.code_folded = folded
+        self.fft_codes = np.conj(scipy.fft.fft(folded)).astype(np.complex64)
+
+    def init(self):                                                                              # :180-192 (state 0)
+        self.well_count = 0
+        self.mag = np.float32(0.0)
+        self.input_power = np.float32(0.0)
+        self.test_statistics = np.float32(0.0)
+        self.state = 1
+        self.result = dict(acq_delay_samples=0.0, doppler_hz=0.0, doppler_step=0)
+
+    def _argmax(self, row):
+        t = np.zeros(1, np.uint32)
+        lib().oracle_index_max(t, np.ascontiguousarray(row, np.float32), len(row))
+        return int(t[0])
+
+    def work(self, x: np.ndarray) -> int:                                                        # :195-360 (state 1)
+        x = np.asarray(x[:self.n_in], np.complex64)
+        N = self.fft_size
+        fnf = np.float32(N) * np.float32(N)
+        self.mag = np.float32(0.0)
+        self.test_statistics = np.float32(0.0)
+        self.well_count += 1
+        self.input_power = mean_input_power(x)                                                    # :227-230
+        self.rows = []
+        for d in range(self.n_bins):
+            doppler = -self.doppler_max + self.doppler_step * d
+            in_temp = (x * self.wipe[d]).astype(np.complex64)                                     # :251-253
+            folded = np.zeros(N, np.complex64)
+            for i in range(self.p * self.p):                                                      # :258-265
+                folded = (folded + in_temp[i * N:(i + 1) * N]).astype(np.complex64)
+            A = scipy.fft.fft(folded)
+            B = (A * self.fft_codes).astype(np.complex64)                                         # :274-275
+            y = (scipy.fft.ifft(B) * np.complex64(N)).astype(np.complex64)
+            mag = (y.real * y.real + y.imag * y.imag).astype(np.float32)                          # :282-283
+            t = self._argmax(mag)
+            magt = np.float32(mag[t] / (fnf * fnf))                                               # :289
+            self.rows.append((float(magt), t))
+            if self.mag < magt:                                                                   # :292
+                self.mag = magt
+                folded_delay = t % self.spc                                                       # :306
+                possible = [folded_delay + i * N for i in range(self.p)]                          # :309-312
+                acc = np.zeros(self.p, np.complex64)
+                for i in range(self.p):                                                           # :314-330: sequential float sums
+                    seg = (in_temp[possible[i]:possible[i] + self.spc] * self.code).astype(np.complex64)
+                    re = np.cumsum(seg.real, dtype=np.float32)[-1]
+                    im = np.cumsum(seg.imag, dtype=np.float32)[-1]
+                    acc[i] = np.complex64(complex(re, im))
+                corr = (acc.real * acc.real + acc.imag * acc.imag).astype(np.float32)             # :332
+                k = self._argmax(corr)
+                self.candidates = acc
+                self.result = dict(acq_delay_samples=float(possible[k]), doppler_hz=float(doppler), doppler_step=self.doppler_step,
+                                   index_time=t, index_doppler=d, alias=k)
+                self.test_statistics = np.float32(self.mag / self.input_power)                    # :342
+        if self.test_statistics > self.threshold:                                                 # :366-375
+            self.state = 2
+        elif self.well_count == self.max_dwells:
+            self.state = 3
+        return self.state

@@ -47,3 +47,17 @@ def e1_8ms_case(flip: bool, prn: int = 11, cn0: float = 44.0, seed: int = 8, sig
     threshold = float(np.float32(-np.log1p(-val) / n))
     kw = dict(fs_in=FS, fft_size=n, doppler_max=10000, doppler_step=250, samples_per_code=16000.0, threshold=threshold, max_dwells=1)
     return x, kw, e1b_local_code_8ms(prn), delay_samples if signal else 0.0
+
+
+def quicksync_case(fs: int = 8000000, folding_factor: int = 4, signal: bool = True, seed: int = 2014):
+    """gps_l1_ca_pcps_quicksync_acquisition_gsoc2014_test.cc:222-279: PRN 10, 750 Hz, 600 chips, 44 dB-Hz, fs 8 Msps, 4 ms, the
+    adapter's default folding factor ceil(sqrt(log2(8000))) = 4 (gps_l1_ca_pcps_quicksync_acquisition.cc:39), doppler_max 10000,
+    step 250."""
+    spc = fs // 1000
+    n = spc * folding_factor
+    x = synth_gps_l1_stream(n, fs, [10] if signal else [], [750.0] if signal else [], [1023.0 - 600.0] if signal else [], cn0_dbhz=44.0,
+                            seed_noise=seed)
+    # the block's statistic is not normalised for the folding (noise floor ~ p^3 / fft_size), so the threshold is per configuration
+    threshold = {(8000000, 4): 0.7, (4000000, 4): 1.0, (8000000, 2): 0.033}[(fs, folding_factor)]
+    kw = dict(fs_in=fs, samples_per_code=spc, folding_factor=folding_factor, doppler_max=10000, doppler_step=250, threshold=threshold, max_dwells=1)
+    return x, kw, oracle.ca_code_complex_sampled(10, fs)

@@ -280,6 +280,43 @@ int main()
         e8.init();
         EXPECT(e8.work(8000, noise.data()) == 3, "8ms noise-only state %d statistic %g", e8.state(), e8.test_statistics());
     }
+    // ---------------------------------------------------------------- QuickSync detector, pcps_quicksync_acquisition_cc call pattern
+    {
+        // gps_l1_ca_pcps_quicksync_acquisition_gsoc2014_test.cc:222-279: fs 8 Msps, 4 ms, PRN 10, 750 Hz, 600 chips, folding factor 4
+        const double amp = std::sqrt(std::pow(10.0, 4.4) * 2.0 / 8e6);
+        auto x = make_signal(32000, 8e6, 10, 750.0, 1023.0 - 600.0, amp, 2014);
+        Hip_Acq_Conf conf;
+        conf.fs_in = 8000000;
+        conf.doppler_max = 10000;
+        conf.doppler_step = 250;
+        conf.threshold = 0.7F;
+        conf.SetDerivedParams();
+        Hip_Pcps_Quicksync_Core qs(conf, 8000, 4, 1, 0);
+        EXPECT(qs.ok() && qs.fft_size() == 2000 && qs.num_doppler_bins() == 81 && qs.input_length() == 32000, "quicksync create: %s", qs.last_error().c_str());
+        std::vector<float> code_iq(2 * 8000);
+        oracle_gps_l1_ca_code_gen_complex_sampled(code_iq.data(), 10, 8000000, 0);
+        qs.set_local_code(reinterpret_cast<const std::complex<float>*>(code_iq.data()));
+        qs.init();
+        const int st = qs.work(32000, x.data());
+        EXPECT(st == 2, "quicksync state %d (%s) statistic %g", st, qs.last_error().c_str(), qs.test_statistics());
+        EXPECT(std::abs(600.0 - qs.result().Acq_delay_samples * 1023.0 / 8000.0) < 0.5, "quicksync delay %f", qs.result().Acq_delay_samples);
+        EXPECT(std::abs(qs.result().Acq_doppler_hz - 750.0) < 2.0 / (3 * 4e-3), "quicksync doppler %f", qs.result().Acq_doppler_hz);
+        EXPECT(qs.result().Acq_delay_samples == qs.result().index_time + 2.0 * 2000, "alias: delay %f folded %u", qs.result().Acq_delay_samples, qs.result().index_time);
+        float top = 0.0F, second = 0.0F;
+        for (float v : qs.corr_output_f())
+            {
+                if (v > top)
+                    {
+                        second = top;
+                        top = v;
+                    }
+                else if (v > second) second = v;
+            }
+        EXPECT(top > 4.0F * second, "alias correlations not separated: %g vs %g", top, second);
+        EXPECT(std::abs(hip_threshold_compute_quicksync(0.1F, 8000, 4, 10000, 250) - 0.0071F) < 3e-4F, "ThresholdComputeQuickSync %g", hip_threshold_compute_quicksync(0.1F, 8000, 4, 10000, 250));
+        Hip_Pcps_Quicksync_Core bad(conf, 8000, 101, 1, 0);
+        EXPECT(!bad.ok(), "folding factor 101 must be refused");
+    }
     if (fails == 0) std::printf("HOST CLASSES OK\n");
     return fails == 0 ? 0 : 1;
 }

@@ -3,8 +3,8 @@ reference's own synthetic test cases (gps_l1_ca_pcps_tong_acquisition_gsoc2013_t
 galileo_e1_pcps_8ms_ambiguous_acquisition_gsoc2013_test.cc): delay error < 0.5 chip, Doppler error < 2 / (3 T)."""
 import numpy as np
 
-from oracle.pcps_oracle import Galileo8msOracle, TongOracle, count_doppler_bins, mean_input_power
-from detector_cases import e1_8ms_case, tong_case
+from oracle.pcps_oracle import Galileo8msOracle, QuickSyncOracle, TongOracle, count_doppler_bins, mean_input_power
+from detector_cases import e1_8ms_case, quicksync_case, tong_case
 
 
 def test_bin_count_is_inclusive():
@@ -72,3 +72,24 @@ def test_8ms_picks_the_code_that_matches_the_symbol_transition():
     o = Galileo8msOracle(**kw)
     o.set_local_code(code)
     assert o.work(x[:32000]) == 3
+
+
+def test_quicksync_known_answer_and_alias_resolution():
+    """delay error < 0.5 chip, Doppler error < 2 / (3 * 4 ms) (gps_l1_ca_pcps_quicksync_acquisition_gsoc2014_test.cc:225-228), and the
+    direct correlation picks the right one of the folding_factor aliases of the folded delay."""
+    for fs, p in ((8000000, 4), (4000000, 4), (8000000, 2)):
+        x, kw, code = quicksync_case(fs, p)
+        o = QuickSyncOracle(**kw)
+        assert o.fft_size == fs // 1000 // p and o.n_bins == 81 and o.n_in == p * fs // 1000
+        o.set_local_code(code)
+        assert o.work(x) == 2
+        spc = fs // 1000
+        assert abs(600.0 - o.result["acq_delay_samples"] * 1023.0 / spc) < 0.5
+        assert abs(o.result["doppler_hz"] - 750.0) < 2.0 / (3 * 4e-3)
+        assert o.result["acq_delay_samples"] == o.result["index_time"] + o.result["alias"] * o.fft_size
+        c = np.abs(o.candidates)
+        assert c[o.result["alias"]] > 1.5 * np.max(np.delete(c, o.result["alias"]))
+    x, kw, code = quicksync_case(signal=False, seed=3)
+    o = QuickSyncOracle(**kw)
+    o.set_local_code(code)
+    assert o.work(x) == 3

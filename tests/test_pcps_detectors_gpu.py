@@ -6,12 +6,18 @@ RTOL (float32 transforms of different factorisation)."""
 import numpy as np
 import pytest
 
-from oracle.pcps_oracle import Galileo8msOracle, TongOracle
-from detector_cases import e1_8ms_case, tong_case
+from oracle.pcps_oracle import Galileo8msOracle, QuickSyncOracle, TongOracle
+from detector_cases import e1_8ms_case, quicksync_case, tong_case
 
 pytestmark = pytest.mark.gpu
 
 RTOL = 2e-3
+# QuickSync wipes off blocks of up to 32 000 samples with the reference's table kernel (volk_gnsssdr_s32f_sincos_32fc, pinned bit-exact
+# in the oracle), whose fixed-point phase drifts up to 0.043 rad from exp(-j 2 pi f n / fs) by the end of such a block (0.005 rad at
+# 750 Hz).  The engine's phasor is exact, so values agree to the reference's own table error, not to float rounding: a signal peak moves
+# by ~1e-3, the maximum of a noise-only grid by up to ~1e-2.  Indices, aliases, states are compared exactly.
+RTOL_QS = 5e-3
+RTOL_QS_NOISE = 2e-2
 
 
 @pytest.mark.parametrize("path", [0, 1])
@@ -112,3 +118,69 @@ def test_8ms_noise_only_negative(gpu):
     assert g.work(x[:32000]) == o.work(x[:32000]) == 3
     assert abs(float(g.test_statistics) - float(o.test_statistics)) <= RTOL * float(o.test_statistics)
     g.close()
+
+
+@pytest.mark.parametrize("fs,p,path", [(8000000, 4, 0), (4000000, 4, 0), (8000000, 2, 0), (8000000, 2, 1)])
+def test_quicksync_matches_oracle(gpu, fs, p, path):
+    """Folded search + alias resolution.  (8 Msps, p = 2) folds into the 4000-point on-chip plan (path 0) and is repeated through
+    the four-step kernels (path 1); the other lengths (2000, 1000) have no plan and take the four-step path either way."""
+    from gnss_sdr_amd.detectors import PcpsQuickSyncAcquisition
+    x, kw, code = quicksync_case(fs, p)
+    o = QuickSyncOracle(**kw)
+    g = PcpsQuickSyncAcquisition(device=gpu, transform_path=path, **kw)
+    assert (g.fft_size, g.n_in, g.n_bins) == (o.fft_size, o.n_in, o.n_bins)
+    o.set_local_code(code)
+    g.set_local_code(code)
+    assert g.work(x) == o.work(x) == 2
+    assert g.result == o.result
+    assert abs(float(g.input_power) - float(o.input_power)) <= 1e-6 * float(o.input_power)
+    assert abs(float(g.test_statistics) - float(o.test_statistics)) <= RTOL_QS * float(o.test_statistics)
+    # the alias correlations themselves (sequential float sums in the reference, double sums here)
+    assert np.max(np.abs(g.candidates - o.candidates)) <= RTOL_QS * np.max(np.abs(o.candidates))
+    # per-bin maxima of the folded grid around the winner
+    d = o.result["index_doppler"]
+    for dd in (d - 1, d, d + 1):
+        assert abs(g.rows[dd][0] - o.rows[dd][0]) <= RTOL_QS * o.rows[d][0]
+    assert g.rows[d][1] == o.rows[d][1]
+    g.close()
+
+
+def test_quicksync_noise_only_and_bit_transition_rule(gpu):
+    from gnss_sdr_amd.detectors import PcpsQuickSyncAcquisition
+    x, kw, code = quicksync_case(signal=False, seed=3)
+    o = QuickSyncOracle(**kw)
+    g = PcpsQuickSyncAcquisition(device=gpu, **kw)
+    o.set_local_code(code)
+    g.set_local_code(code)
+    assert g.work(x) == o.work(x) == 3
+    assert abs(float(g.test_statistics) - float(o.test_statistics)) <= RTOL_QS_NOISE * float(o.test_statistics)
+    g.close()
+    # bit_transition_flag: two dwells, decided only after the second one (qs.cc:377-390)
+    xs, kw, code = quicksync_case()
+    g = PcpsQuickSyncAcquisition(device=gpu, bit_transition_flag=True, **kw)
+    g.set_local_code(code)
+    assert g.max_dwells == 2 and g.work(xs) == 1 and g.work(xs) == 2
+    g.close()
+
+
+def test_fold_conf_rules(gpu):
+    from gnss_sdr_amd._lib import GshError
+    from gnss_sdr_amd.acquisition import PcpsAcquisitionBank
+    with pytest.raises(GshError):   # consumed_samples must be fold * fft_size
+        PcpsAcquisitionBank(4000000, 1000, 5000, 500, 1, 4000.0, consumed_samples=4000, fold=16, device=gpu)
+    with pytest.raises(GshError):   # no bit-transition placement with folding
+        PcpsAcquisitionBank(4000000, 1000, 5000, 500, 1, 4000.0, consumed_samples=16000, effective_fft_size=500, fold=16, bit_transition_flag=True, device=gpu)
+    b = PcpsAcquisitionBank(4000000, 1000, 5000, 500, 1, 4000.0, consumed_samples=16000, fold=16, device=gpu)
+    rng = np.random.default_rng(1)
+    x = (rng.standard_normal(16000) + 1j * rng.standard_normal(16000)).astype(np.complex64)
+    b.set_local_code(0, np.sign(rng.standard_normal(1000)).astype(np.complex64))
+    b.dwell(x, 1)
+    with pytest.raises(GshError):   # a candidate window must stay inside the resident block
+        b.time_correlate(np.ones(4000, np.complex64), 0, [12001])
+    with pytest.raises(GshError):
+        b.time_correlate(np.ones(4000, np.complex64), 99, [0])
+    # bin 10 is 0 Hz here (-5000 + 10 * 500): the correlation is a plain dot product
+    got = b.time_correlate(np.ones(4000, np.complex64), 10, [0, 12000])
+    ref = np.array([x[:4000].astype(np.complex128).sum(), x[12000:].astype(np.complex128).sum()])
+    assert np.max(np.abs(got - ref)) <= 1e-5 * np.max(np.abs(ref)) + 1e-4
+    b.close()
