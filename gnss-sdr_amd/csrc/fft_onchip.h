@@ -31,6 +31,16 @@
 #define GSH_HD inline __attribute__((always_inline))
 #endif
 #define GSH_AI __attribute__((always_inline))
+// The exchange reads fill ONE component of R complex registers.  Left alone, the compiler pairs neighbouring reads into
+// ds_read2_b32, whose two results land in a register pair = the same component of two different elements, and then spends
+// a v_mov per value to take the pair apart again.  Volatile keeps them single ds_read_b32 straight into place.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GSH_OC_NO_PK_ASM)
+typedef const volatile __attribute__((address_space(3))) float* gsh_lds_rd_ptr;
+#define GSH_LDS_RD_PTR(p) ((gsh_lds_rd_ptr)(p))
+#else
+typedef const float* gsh_lds_rd_ptr;
+#define GSH_LDS_RD_PTR(p) (p)
+#endif
 
 #pragma clang fp contract(fast)
 
@@ -103,12 +113,68 @@ constexpr double cx_trig_turn(int m, int r, bool want_sin)
 }
 
 // ------------------------------------------------------------------------------------------ complex helpers
-GSH_HD cf cmul(cf a, cf b) { return a.xx * b + a.yy * cf{-b.y, b.x}; }
-GSH_HD cf csqr(cf a) { return cf{a.x * a.x - a.y * a.y, 2.0f * a.x * a.y}; }
 GSH_HD cf mulmj(cf a) { return cf{a.y, -a.x}; }  // * (-j)
 GSH_HD cf mulpj(cf a) { return cf{-a.y, a.x}; }  // * (+j)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GSH_OC_NO_PK_ASM)
+// gfx950's packed-FP32 instructions pick each source half (op_sel / op_sel_hi) and negate it (neg_lo / neg_hi) for free, so
+// a complex product is two instructions and "+- j * d" folds into the add.  The compiler only finds the broadcast forms on its
+// own (every swap costs it a v_mov + v_xor), hence the instruction selection is spelled out here.
+//   lo result: src halves op_sel[i];  hi result: src halves op_sel_hi[i];  0 = .x, 1 = .y
+GSH_HD cf cmul(cf a, cf b)
+{
+    cf t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));  // (ax bx, ax by)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));  // (-ay by, ay bx) + t
+    return r;
+}
+GSH_HD cf csqr(cf a) { return cmul(a, a); }
+// conj(a) * b
+GSH_HD cf cmul_conj(cf a, cf b)
+{
+    cf t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));  // (ax bx, ax by)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));  // (ay by, -ay bx) + t
+    return r;
+}
+// u + (-j) d  and  u - (-j) d
+GSH_HD cf add_mj(cf u, cf d)
+{
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(u), "v"(d));  // (ux + dy, uy - dx)
+    return r;
+}
+GSH_HD cf sub_mj(cf u, cf d)
+{
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(u), "v"(d));  // (ux - dy, uy + dx)
+    return r;
+}
+// v * (c - j s), cs = (c, s) a uniform constant
+GSH_HD cf mul_cs(cf v, cf cs)
+{
+    cf t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(t) : "v"(v), "s"(cs));  // (x c, y c)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(v), "s"(cs), "v"(t));  // (y s, -x s) + t
+    return r;
+}
+// |v|^2 as two scalar instructions (left to itself the vectoriser pairs two elements' sums and shuffles registers to do so)
+GSH_HD float norm2(cf v)
+{
+    float t, m;
+    asm("v_mul_f32 %0, %1, %1" : "=v"(t) : "v"(v.y));
+    asm("v_fma_f32 %0, %1, %1, %2" : "=v"(m) : "v"(v.x), "v"(t));
+    return m;
+}
+#else
+GSH_HD float norm2(cf v) { return v.x * v.x + v.y * v.y; }
+GSH_HD cf cmul(cf a, cf b) { return a.xx * b + a.yy * cf{-b.y, b.x}; }
+GSH_HD cf csqr(cf a) { return cf{a.x * a.x - a.y * a.y, 2.0f * a.x * a.y}; }
 // conj(a) * b
 GSH_HD cf cmul_conj(cf a, cf b) { return a.xx * b + a.yy * cf{b.y, -b.x}; }
+GSH_HD cf add_mj(cf u, cf d) { return u + mulmj(d); }
+GSH_HD cf sub_mj(cf u, cf d) { return u - mulmj(d); }
+GSH_HD cf mul_cs(cf v, cf cs) { return v * cs.x + cf{v.y, -v.x} * cs.y; }
+#endif
 
 // v * W_R^M, W_R = exp(-2 pi i / R), with the trivial rotations specialised
 template <int M, int R>
@@ -125,19 +191,19 @@ GSH_HD cf mul_w(cf v)
     else if constexpr (4 * m == 3 * R)
         return mulpj(v);
     else if constexpr (8 * m == R)
-        return cf{v.x + v.y, v.y - v.x} * H;
+        return add_mj(v, v) * H;  // (x + y, y - x) / sqrt 2
     else if constexpr (8 * m == 3 * R)
-        return cf{v.y - v.x, -(v.x + v.y)} * H;
+        return mulmj(add_mj(v, v)) * H;
     else if constexpr (8 * m == 5 * R)
-        return cf{-(v.x + v.y), v.x - v.y} * H;
+        return add_mj(v, v) * -H;
     else if constexpr (8 * m == 7 * R)
-        return cf{v.x - v.y, v.x + v.y} * H;
+        return sub_mj(v, v) * H;  // (x - y, y + x) / sqrt 2
     else
         {
             constexpr float c = static_cast<float>(cx_trig_turn(m, R, false));
             constexpr float s = static_cast<float>(cx_trig_turn(m, R, true));
             // (x + jy)(c - js) = (xc + ys) + j(yc - xs)
-            return v * c + cf{v.y, -v.x} * s;
+            return mul_cs(v, cf{c, s});
         }
 }
 
@@ -172,10 +238,9 @@ struct Dft<3>
         const cf t = a[1] + a[2];
         const cf d = (a[1] - a[2]) * S;
         const cf u = a[0] - t * 0.5f;
-        const cf v = mulmj(d);
         a[0] = a[0] + t;
-        a[1] = u + v;
-        a[2] = u - v;
+        a[1] = add_mj(u, d);
+        a[2] = sub_mj(u, d);
     }
 };
 
@@ -185,11 +250,11 @@ struct Dft<4>
     static GSH_HD void run(cf (&a)[4])
     {
         const cf s02 = a[0] + a[2], d02 = a[0] - a[2];
-        const cf s13 = a[1] + a[3], d13 = mulmj(a[1] - a[3]);
+        const cf s13 = a[1] + a[3], d13 = a[1] - a[3];
         a[0] = s02 + s13;
         a[2] = s02 - s13;
-        a[1] = d02 + d13;
-        a[3] = d02 - d13;
+        a[1] = add_mj(d02, d13);
+        a[3] = sub_mj(d02, d13);
     }
 };
 
@@ -206,13 +271,13 @@ struct Dft<5>
         const cf t3 = a[1] - a[4], t4 = a[2] - a[3];
         const cf m1 = a[0] + t1 * C1 + t2 * C2;
         const cf m2 = a[0] + t1 * C2 + t2 * C1;
-        const cf n1 = mulmj(t3 * S1 + t4 * S2);
-        const cf n2 = mulmj(t3 * S2 - t4 * S1);
+        const cf n1 = t3 * S1 + t4 * S2;  // times -j below
+        const cf n2 = t3 * S2 - t4 * S1;
         a[0] = a[0] + t1 + t2;
-        a[1] = m1 + n1;
-        a[4] = m1 - n1;
-        a[2] = m2 + n2;
-        a[3] = m2 - n2;
+        a[1] = add_mj(m1, n1);
+        a[4] = sub_mj(m1, n1);
+        a[2] = add_mj(m2, n2);
+        a[3] = sub_mj(m2, n2);
     }
 };
 
@@ -226,16 +291,15 @@ struct Dft<8>
         Dft<4>::run(e);
         Dft<4>::run(o);
         const cf o1 = mul_w<1, 8>(o[1]);
-        const cf o2 = mulmj(o[2]);
-        const cf o3 = mul_w<3, 8>(o[3]);
+        const cf q3 = mul_w<1, 8>(o[3]);  // o[3] W_8^3 = -j q3, folded into the adds below
         a[0] = e[0] + o[0];
         a[4] = e[0] - o[0];
         a[1] = e[1] + o1;
         a[5] = e[1] - o1;
-        a[2] = e[2] + o2;
-        a[6] = e[2] - o2;
-        a[3] = e[3] + o3;
-        a[7] = e[3] - o3;
+        a[2] = add_mj(e[2], o[2]);
+        a[6] = sub_mj(e[2], o[2]);
+        a[3] = add_mj(e[3], q3);
+        a[7] = sub_mj(e[3], q3);
     }
 };
 
@@ -359,7 +423,7 @@ struct Plan
     static GSH_HD void ex1_read(cf (&b)[R2], int t2, const float* lds)
     {
         const int k1 = t2 / R3, n3 = t2 - k1 * R3;
-        const float* p = lds + k1 * S1 + n3;
+        gsh_lds_rd_ptr p = GSH_LDS_RD_PTR(lds + k1 * S1 + n3);
         static_for<R2>([&](auto N2) GSH_AI { b[decltype(N2)::value][COMP] = p[decltype(N2)::value * R3]; });
     }
     // ---- stage 2
@@ -380,7 +444,7 @@ struct Plan
     static GSH_HD void ex2_read(cf (&c)[R3], int t3, const float* lds)
     {
         const int k2 = t3 / R1, k1 = t3 - k2 * R1;
-        const float* p = lds + k2 * S2 + k1;
+        gsh_lds_rd_ptr p = GSH_LDS_RD_PTR(lds + k2 * S2 + k1);
         static_for<R3>([&](auto N3) GSH_AI { c[decltype(N3)::value][COMP] = p[decltype(N3)::value * P2]; });
     }
     // ---- stage 3: c[k3] -> X[t3 + T3*k3]

@@ -221,7 +221,7 @@ __global__ __launch_bounds__(P::THREADS) void oc_cell_kernel(OcCellArgs a)
                 {
                     oc::static_for<P::R3>([&](auto K3) GSH_AI {
                         constexpr int k3 = decltype(K3)::value;
-                        rc[k3].x = (rc[k3].x * rc[k3].x + rc[k3].y * rc[k3].y) * a.weight;
+                        rc[k3].x = oc::norm2(rc[k3]) * a.weight;
                     });
                     if (a.accumulate)  // acq.cc:549-553
                         oc::static_for<P::R3>([&](auto K3) GSH_AI { rc[decltype(K3)::value].x += g[t + P::T3 * decltype(K3)::value]; });
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(P::THREADS) void oc_cell_kernel(OcCellArgs a)
                 }
             oc::static_for<P::R3>([&](auto K3) GSH_AI {
                 constexpr int k3 = decltype(K3)::value;
-                const float m = GRID ? rc[k3].x : rc[k3].x * rc[k3].x + rc[k3].y * rc[k3].y;
+                const float m = GRID ? rc[k3].x : oc::norm2(rc[k3]);
                 // branch-free bookkeeping (selects): k3 ascending = tau ascending, so '>' keeps the lowest index
                 sum += m;
                 const bool better = m > best;
