@@ -101,3 +101,35 @@ class FirFilter:
         check(self._lib.gsh_fir_process_device(self._h, C.c_void_p(in_ptr), n_in, C.c_void_p(out_ptr), max_out, C.byref(n_out),
                                                C.c_void_p(hip_stream) if hip_stream else None))
         return int(n_out.value)
+
+
+def firdes_low_pass(gain: float, sampling_freq: float, cutoff_freq: float, transition_width: float) -> np.ndarray:
+    """gr::filter::firdes::low_pass with the default Hamming window, as restated in host/hip_acq_resampler.h (GNU Radio is not
+    vendored: published algorithm, parity unpinned)."""
+    ntaps = int(53.0 * sampling_freq / (22.0 * transition_width))
+    if ntaps % 2 == 0:
+        ntaps += 1
+    n = np.arange(ntaps)
+    w = (0.54 - 0.46 * np.cos(2.0 * np.pi * n / (ntaps - 1))).astype(np.float32)
+    m = (ntaps - 1) // 2
+    k = n - m
+    fw = 2.0 * np.pi * cutoff_freq / sampling_freq
+    with np.errstate(invalid="ignore", divide="ignore"):
+        taps = np.where(k == 0, fw / np.pi, np.sin(k * fw) / (k * np.pi)) * w
+    taps = taps.astype(np.float32)
+    fmax = float(taps[m]) + 2.0 * float(np.sum(taps[m + 1:].astype(np.float64)))
+    return (taps.astype(np.float64) * (gain / fmax)).astype(np.float32)
+
+
+def acquisition_resampler_design(fs: int, acq_fs: float):
+    """(decimation, decimated rate, taps, latency) as GNSSFlowgraph sets the acquisition resampler up (gnss_flowgraph.cc:1165-1211)."""
+    if not acq_fs < fs:
+        return 1, float(fs), np.zeros(0, np.float32), 0
+    decimation = int(np.floor(fs / acq_fs))
+    while fs % decimation > 0:
+        decimation -= 1
+    if decimation <= 1:
+        return 1, float(fs), np.zeros(0, np.float32), 0
+    dec_fs = fs / decimation
+    taps = firdes_low_pass(1.0, fs, dec_fs / 2.1, dec_fs / 2)
+    return decimation, dec_fs, taps, (len(taps) - 1) // 2

@@ -6,6 +6,7 @@
 #include "hip_multicorrelator_real_codes.h"
 #include "hip_pcps_acquisition_core.h"
 #include "hip_pcps_detectors.h"
+#include "hip_acq_resampler.h"
 #include <cmath>
 #include <complex>
 #include <cstdio>
@@ -316,6 +317,21 @@ int main()
         EXPECT(std::abs(hip_threshold_compute_quicksync(0.1F, 8000, 4, 10000, 250) - 0.0071F) < 3e-4F, "ThresholdComputeQuickSync %g", hip_threshold_compute_quicksync(0.1F, 8000, 4, 10000, 250));
         Hip_Pcps_Quicksync_Core bad(conf, 8000, 101, 1, 0);
         EXPECT(!bad.ok(), "folding factor 101 must be refused");
+    }
+    // ---------------------------------------------------------------- acquisition resampler design, gnss_flowgraph.cc:1165-1211
+    {
+        const auto d = hip_design_acq_resampler(16000000U, 2e6);
+        EXPECT(d.decimation == 8 && d.acq_fs_decimated == 2e6 && d.taps.size() == 39 && d.resampler_latency == 19, "design: D %d fs %g taps %zu latency %u",
+            d.decimation, d.acq_fs_decimated, d.taps.size(), d.resampler_latency);
+        double sum = 0.0;
+        for (float t : d.taps) sum += t;
+        EXPECT(std::abs(sum - 1.0) < 1e-6 && d.taps[19] > d.taps[18] && d.taps[0] == d.taps[38], "low-pass taps: sum %g", sum);
+        // centre tap of a Hamming-windowed sinc with cutoff fs_dec / 2.1 at fs = 16 Msps (scipy.signal.firwin(39, 2e6/2.1, fs=16e6)[19])
+        EXPECT(std::abs(d.taps[19] - 0.118619F) < 1e-5F, "centre tap %g", d.taps[19]);
+        const auto d2 = hip_design_acq_resampler(25000000U, 2e6);
+        EXPECT(d2.decimation == 10 && d2.acq_fs_decimated == 2.5e6, "25 Msps: D %d", d2.decimation);
+        const auto d3 = hip_design_acq_resampler(3000000U, 2e6);
+        EXPECT(d3.decimation == 1 && d3.taps.empty() && d3.resampler_latency == 0, "3 Msps: resampler disabled");
     }
     if (fails == 0) std::printf("HOST CLASSES OK\n");
     return fails == 0 ? 0 : 1;

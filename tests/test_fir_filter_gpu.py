@@ -69,3 +69,39 @@ def test_real_input_kinds(gpu, kind, dtype):
     # the tone came down to +150 kHz: phase advances by 2 pi 150e3 D / fs per output
     ph = np.angle(got[200:] * np.conj(got[199:-1]))
     assert abs(np.median(ph) - 2 * np.pi * 150e3 * D / fs) < 0.02
+
+
+def test_acquisition_through_the_flowgraph_decimator(gpu):
+    """GNSS-SDR.use_acquisition_resampler (gnss_flowgraph.cc:1116-1211): 16 Msps stream -> low-pass + decimate by 8 on the GPU ->
+    PCPS acquisition at 2 Msps; the code start maps back to the input rate as update_synchro does with the resampler fields
+    (acq.cc:584-589): delay * resampler_ratio - resampler_latency_samples."""
+    import torch
+    import oracle
+    from helpers import synth_gps_l1_stream
+    from gnss_sdr_amd.acquisition import PcpsAcquisitionBank
+    from gnss_sdr_amd.sample_stream import FirFilter, acquisition_resampler_design
+    fs, prn, fd, code_phase = 16000000, 7, 1250.0, 311.25
+    dec, dec_fs, taps, latency = acquisition_resampler_design(fs, 2e6)
+    assert (dec, dec_fs, len(taps), latency) == (8, 2e6, 39, 19)
+    n_in = 3 * 16000
+    x = synth_gps_l1_stream(n_in, fs, [prn], [fd], [code_phase], cn0_dbhz=50.0, seed_noise=4)
+    dev = torch.device("cuda", gpu)
+    d_x = torch.from_numpy(x).to(dev)
+    d_y = torch.zeros(n_in // dec + 2, dtype=torch.complex64, device=dev)
+    f = FirFilter(taps, dec, 0.0, float(fs), "gr_complex", device=gpu)
+    n_out = f.process_device(d_x.data_ptr(), n_in, d_y.data_ptr(), d_y.numel())
+    assert n_out == n_in // dec
+    f.close()
+    n = 2000
+    acq = PcpsAcquisitionBank(int(dec_fs), n, 5000, 250, 2, float(n), device=gpu)
+    acq.set_local_code(0, oracle.ca_code_complex_sampled(prn, int(dec_fs)))
+    first = 1000                                      # any block start: the search is circular in the code period
+    r = acq.dwell_device(d_y.data_ptr() + 8 * first, 1)[0]
+    acq.close()
+    assert abs(r["doppler_hz"] - fd) <= 250 and r["test_statistics"] > 10.0
+    # code start in input samples: block start + (delay at the decimated rate) * ratio - filter latency  (acq.cc:584-589)
+    start_in = first * dec + r["acq_delay_samples"] * dec - latency
+    samples_per_chip = fs / 1.023e6
+    true_start = ((1023.0 - code_phase) * samples_per_chip) % 16000.0
+    err = (start_in - true_start + 8000.0) % 16000.0 - 8000.0
+    assert abs(err) <= dec                            # one decimated sample

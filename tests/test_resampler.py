@@ -75,3 +75,25 @@ def test_device_resampler_equals_reference_loop(gpu, fs_in, fs_out):
     m = min(len(got), len(exp))
     assert m >= len(exp) - 1 and m > 0.9 * n * min(1.0, fs_out / fs_in)
     assert np.array_equal(got[:m].view(np.uint32), exp[:m].view(np.uint32))
+
+
+def test_acquisition_resampler_design_matches_windowed_sinc():
+    """gnss_flowgraph.cc:1165-1211: decimation = the largest divisor of fs not above fs / acq_fs; taps = firdes::low_pass(1, fs,
+    fs_dec / 2.1, fs_dec / 2) = Hamming-windowed sinc with unit DC gain (compared with scipy.signal.firwin, the same definition);
+    latency = (ntaps - 1) / 2."""
+    from scipy.signal import firwin
+    from gnss_sdr_amd.sample_stream import acquisition_resampler_design, firdes_low_pass
+    for fs, acq_fs, want_dec in ((16000000, 2e6, 8), (25000000, 2e6, 10), (4000000, 2e6, 2), (50000000, 10e6, 5), (2000000, 2e6, 1),
+                                 (3000000, 2e6, 1), (12500000, 2e6, 5)):
+        dec, dec_fs, taps, latency = acquisition_resampler_design(fs, acq_fs)
+        assert dec == want_dec and fs % dec == 0 and dec_fs == fs / dec
+        if dec == 1:
+            assert len(taps) == 0 and latency == 0
+            continue
+        ntaps = int(53.0 * fs / (22.0 * dec_fs / 2))
+        ntaps += 1 - ntaps % 2
+        assert len(taps) == ntaps and latency == (ntaps - 1) // 2
+        ref = firwin(ntaps, dec_fs / 2.1, window="hamming", fs=fs)
+        assert np.max(np.abs(taps - ref)) < 2e-7 and abs(float(np.sum(taps.astype(np.float64))) - 1.0) < 1e-6
+        assert np.array_equal(taps, taps[::-1])        # linear phase: the group delay is exactly `latency` input samples
+    assert abs(float(np.sum(firdes_low_pass(2.5, 1e6, 1e5, 5e4).astype(np.float64))) - 2.5) < 1e-5
