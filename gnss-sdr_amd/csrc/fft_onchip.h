@@ -468,6 +468,10 @@ struct Plan
     X(20, 20, 40) /* 16 000: 16 Msps x 1 ms, 4 Msps x 4 ms */ \
     X(16, 32, 32) /* 16 384 */ \
     X(25, 25, 32) /* 20 000: 20 Msps x 1 ms, 5 Msps x 4 ms */ \
-    X(32, 32, 32) /* 32 768 */
+    X(32, 32, 32) /* 32 768 */ \
+    X(10, 10, 10) /*  1 000: QuickSync folds of 4 000 (p = 4), 1 Msps x 1 ms */ \
+    X(10, 10, 20) /*  2 000: 2 Msps x 1 ms (the flowgraph's acquisition resampler for L1 / E1), QuickSync folds of 8 000 */ \
+    X(10, 10, 25) /*  2 500: 2.5 Msps x 1 ms (25 Msps decimated by 10) */ \
+    X(10, 25, 25) /*  6 250: 6.25 Msps x 1 ms */
 
 #endif
