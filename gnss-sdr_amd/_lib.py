@@ -171,6 +171,7 @@ SYMBOLS = {
     "gsh_acq_destroy": (None, [_P]),
     "gsh_acq_set_local_code": (C.c_int, [_P, C.c_uint32, _F]),
     "gsh_acq_set_doppler_center": (C.c_int, [_P, C.c_int32]),
+    "gsh_acq_set_doppler_bias": (C.c_int, [_P, C.c_int32]),
     "gsh_acq_set_grid_weight": (C.c_int, [_P, C.c_float]),
     "gsh_acq_input_power": (C.c_int, [_P, C.POINTER(C.c_float)]),
     "gsh_acq_stage_input": (C.c_int, [_P, C.POINTER(C.c_float)]),

@@ -84,6 +84,10 @@ class PcpsAcquisitionBank:
     def set_doppler_center(self, doppler_center: int) -> None:
         check(self._lib.gsh_acq_set_doppler_center(self._h, int(doppler_center)))
 
+    def set_doppler_bias(self, doppler_bias: int) -> None:
+        """GLONASS FDMA carrier offset of the satellite being searched (acq.cc:252-272, 289)."""
+        check(self._lib.gsh_acq_set_doppler_bias(self._h, int(doppler_bias)))
+
     def set_grid_weight(self, weight: float) -> None:
         """Factor applied to every |y|^2 before it reaches the grid (pcps_tong_acquisition_cc.cc:243-249)."""
         check(self._lib.gsh_acq_set_grid_weight(self._h, float(weight)))

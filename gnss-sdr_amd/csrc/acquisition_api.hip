@@ -504,6 +504,19 @@ extern "C"
         return GSH_OK;
     }
 
+    int gsh_acq_set_doppler_bias(gsh_acq_t* a, int32_t doppler_bias)
+    {
+        GSH_REQUIRE(a != nullptr, "null handle");
+        GSH_HIP(hipSetDevice(a->device));
+        if (doppler_bias != a->conf.doppler_bias)  // acq.cc:252-272: is_fdma() re-derives d_doppler_bias for the PRN at hand
+            {
+                a->conf.doppler_bias = doppler_bias;
+                fill_bins(a);
+                return upload_bins(a);
+            }
+        return GSH_OK;
+    }
+
     int gsh_acq_set_grid_weight(gsh_acq_t* a, float weight)
     {
         GSH_REQUIRE(a != nullptr, "null handle");

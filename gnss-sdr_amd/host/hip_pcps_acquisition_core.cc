@@ -76,6 +76,13 @@ void Hip_Pcps_Acquisition_Core::set_doppler_center(int32_t doppler_center)
 }
 
 
+void Hip_Pcps_Acquisition_Core::set_doppler_bias(int32_t doppler_bias)
+{
+    if (d_handle == nullptr) return;
+    if (gsh_acq_set_doppler_bias(d_handle, doppler_bias) != GSH_OK) d_error = gsh_last_error();
+}
+
+
 // one gsh_acq_* dwell in the current step; `in` is complex<float> or complex<int16_t> data
 template <typename In>
 static int run_dwell(gsh_acq* h, const In* data, bool cshort, bool step_two, float center_step_two, float input_power, int accumulate, uint32_t count,

@@ -93,6 +93,8 @@ public:
 
     void set_local_code(const std::complex<float>* code);
     void set_doppler_center(int32_t doppler_center);
+    /*! d_doppler_bias of is_fdma() (acq.cc:252-272): the adapter passes DFRQ1_GLO (or DFRQ2_GLO) * GLONASS_PRN.at(prn), 0 for CDMA signals */
+    void set_doppler_bias(int32_t doppler_bias);
     void set_threshold(float threshold) { d_threshold = threshold; }
     void set_resampler_latency(uint32_t latency_samples) { d_acq_parameters.resampler_latency_samples = latency_samples; }  //!< acq.h:168-172
     float get_threshold() const { return d_step_two ? d_threshold_step_two : d_threshold; }  //!< acq.cc:731-734

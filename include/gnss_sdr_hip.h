@@ -388,6 +388,10 @@ extern "C"
     int gsh_acq_set_local_code(gsh_acq_t* a, uint32_t prn_slot, const float* code_iq);
     /* acq.cc:737-746 */
     int gsh_acq_set_doppler_center(gsh_acq_t* a, int32_t doppler_center);
+    /* acq.cc:252-272 (is_fdma): GLONASS L1 / L2 satellites sit on their own FDMA carrier, DFRQ{1,2}_GLO * channel number away from
+     * the band centre; the offset is re-derived whenever the PRN changes and enters only the wipe-off frequency (acq.cc:289), never
+     * the reported Doppler.  Applies to every prn slot of the handle: search GLONASS satellites one frequency channel per handle. */
+    int gsh_acq_set_doppler_bias(gsh_acq_t* a, int32_t doppler_bias);
     /* The other PCPS detectors on the same engine:
      * pcps_tong_acquisition_cc.cc:243-249 scales every |y|^2 by 1 / (fft_norm^2 * input_power) BEFORE adding it to its
      * d_grid_data; `weight` is that factor, applied (one float multiply per cell) to every magnitude that is added to or

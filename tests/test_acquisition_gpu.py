@@ -253,3 +253,45 @@ def test_onchip_agrees_with_fourstep_and_nogrid_rules(gpu, n, fs):
             banks["nogrid"].read_grid(0)
         for acq in banks.values():
             acq.close()
+
+
+@pytest.mark.parametrize("path", [0, 1])
+def test_glonass_fdma_doppler_bias(gpu, path):
+    """is_fdma (acq.cc:252-272): the satellite's FDMA carrier offset (DFRQ1_GLO = 562 500 Hz per channel number) is added to the
+    wipe-off frequency only (acq.cc:289); the reported Doppler stays relative to that carrier.  A code on a carrier at
+    bias + 1 300 Hz is found at ~1 300 Hz when the bias is set, and not at all without it."""
+    from helpers import add_code_signal, cn0_to_amplitude
+    fs, n = 8000000, 8000
+    bias = int(562500.0 * -3)  # GLONASS L1 frequency channel -3
+    rng = np.random.default_rng(12)
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    code511 = np.sign(np.random.default_rng(3).standard_normal(511)).astype(np.float32)  # any 511-chip +-1 code stands in for the GLONASS C/A code
+    spc = fs / 0.511e6
+    add_code_signal(x, code511, fs, 1.0 / spc, 123.4, bias + 1300.0, cn0_to_amplitude(50.0, fs))
+    local = code511[(np.floor(np.arange(n) / spc).astype(np.int64)) % 511].astype(np.complex64)
+    kw = dict(fs_in=fs, fft_size=n, doppler_max=5000, doppler_step=250, samples_per_chip=16, samples_per_code=float(n))
+    acq = _bank(gpu, max_prn=1, transform_path=path, **kw)
+    acq.set_local_code(0, local)
+    r0 = acq.dwell(x, 1)[0]
+    acq.set_doppler_bias(bias)
+    r1 = acq.dwell(x, 1)[0]
+    ora = PcpsOracle(doppler_bias=bias, **kw)
+    ora.set_local_code(local)
+    e1 = ora.dwell(x)
+    assert (r1["index_time"], r1["index_doppler"], r1["doppler_hz"]) == (e1["index_time"], e1["index_doppler"], e1["doppler_hz"])
+    assert abs(r1["doppler_hz"] - 1300) <= 250 and r1["test_statistics"] > 5 * r0["test_statistics"]
+    # at |f| ~ 1.7 MHz the reference's wipe-off table (float32 phase accumulation in volk_gnsssdr_s32f_sincos_32fc, reproduced by the
+    # oracle) has drifted enough by the end of the block to cost 2-3 % of the peak; the engine's phasor is exact, so its VALUE is held
+    # against the float64 evaluation and only the indices against the float32 oracle
+    assert r1["test_statistics"] == pytest.approx(e1["test_statistics"], rel=5e-2)
+    prec = PcpsOracle(doppler_bias=bias, precise=True, **kw)
+    prec.set_local_code(local)
+    p1 = prec.dwell(x)
+    assert (r1["index_time"], r1["index_doppler"]) == (p1["index_time"], p1["index_doppler"])
+    assert r1["test_statistics"] == pytest.approx(p1["test_statistics"], rel=2e-3)
+    # the code starts (511 - 123.4) chips into the block
+    assert abs(r1["acq_delay_samples"] - (511 - 123.4) * spc) < 0.5 * spc
+    acq.set_doppler_bias(0)
+    r2 = acq.dwell(x, 1)[0]
+    assert r2["test_statistics"] == pytest.approx(r0["test_statistics"], rel=1e-6)
+    acq.close()
