@@ -1,0 +1,18 @@
+/*!
+ * \file glonass_l1_ca_pcps_acquisition_hip.cc
+ * \brief See the header.  BUILT ONLY INSIDE A gnss-sdr TREE.
+ */
+#include "glonass_l1_ca_pcps_acquisition_hip.h"
+#include "GLONASS_L1_L2_CA.h"
+#include "glonass_l1_signal_replica.h"
+
+GlonassL1CaPcpsAcquisitionHip::GlonassL1CaPcpsAcquisitionHip(const ConfigurationInterface* configuration, const std::string& role, unsigned int in_streams, unsigned int out_streams)
+    : BasePcpsAcquisitionHip(configuration, role, in_streams, out_streams, GLONASS_L1_CA_CODE_RATE_CPS, 100e6, GLONASS_L1_CA_CODE_LENGTH_CHIPS, GLONASS_L1_CA_CODE_PERIOD_MS)
+{
+}
+
+
+void GlonassL1CaPcpsAcquisitionHip::code_gen_complex_sampled(own::span<std::complex<float>> dest, uint32_t /*prn*/, int32_t sampling_freq)
+{
+    glonass_l1_ca_code_gen_complex_sampled(dest, sampling_freq, 0);
+}

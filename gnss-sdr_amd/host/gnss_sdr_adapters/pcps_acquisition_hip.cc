@@ -5,6 +5,8 @@
  *        blocking, like the reference's default (acq_conf.h:72).  BUILT ONLY INSIDE A gnss-sdr TREE.
  */
 #include "pcps_acquisition_hip.h"
+#include "GLONASS_L1_L2_CA.h"
+#include <cstring>
 #include <gnuradio/io_signature.h>
 #include <pmt/pmt.h>
 #include <algorithm>
@@ -32,7 +34,20 @@ pcps_acquisition_hip::pcps_acquisition_hip(const Hip_Acq_Conf& conf, int device,
 
 void pcps_acquisition_hip::set_local_code(std::complex<float>* code)
 {
+    // acq.cc:220-223 + is_fdma (:252-272): a GLONASS satellite sits on its own FDMA carrier; the offset enters the wipe-off only
+    int32_t doppler_bias = 0;
+    if (d_gnss_synchro != nullptr)
+        {
+            const auto is_1G = strcmp(d_gnss_synchro->Signal, "1G") == 0;
+            const auto is_2G = strcmp(d_gnss_synchro->Signal, "2G") == 0;
+            if (is_1G || is_2G)
+                {
+                    const auto freq = is_1G ? DFRQ1_GLO : DFRQ2_GLO;
+                    doppler_bias = static_cast<int32_t>(freq * GLONASS_PRN.at(d_gnss_synchro->PRN));
+                }
+        }
     gr::thread::scoped_lock lock(d_setlock);
+    d_core.set_doppler_bias(doppler_bias);
     d_core.set_local_code(code);
 }
 

@@ -7,7 +7,22 @@
 // scheduler: general_work() is called with chunks of a synthetic IF stream until the block publishes its "events" message
 // (acq.cc:146, 318-351: 1 = positive, 2 = negative).  The stream is generated with the reference's own replica generators.
 // Prints "ADAPTERS OK".  Built by __graft_entry__.build() when /root/reference is present; run by tests/test_adapters_gpu.py.
+#include "GLONASS_L1_L2_CA.h"
+#include "beidou_b1i_pcps_acquisition_hip.h"
+#include "beidou_b1i_signal_replica.h"
+#include "beidou_b3i_pcps_acquisition_hip.h"
+#include "beidou_b3i_signal_replica.h"
 #include "galileo_e1_pcps_ambiguous_acquisition_hip.h"
+#include "galileo_e5b_pcps_acquisition_hip.h"
+#include "galileo_e6_pcps_acquisition_hip.h"
+#include "galileo_e6_signal_replica.h"
+#include "glonass_l1_ca_pcps_acquisition_hip.h"
+#include "glonass_l1_signal_replica.h"
+#include "glonass_l2_ca_pcps_acquisition_hip.h"
+#include "glonass_l2_signal_replica.h"
+#include "qzss_l1_pcps_acquisition_hip.h"
+#include "qzss_l5i_pcps_acquisition_hip.h"
+#include "qzss_signal_replica.h"
 #include "galileo_e1_signal_replica.h"
 #include "galileo_e5_signal_replica.h"
 #include "galileo_e5a_pcps_acquisition_hip.h"
@@ -124,6 +139,33 @@ std::shared_ptr<InMemoryConfiguration> base_config(const std::string& role, long
     c->set_property(role + ".blocking", "true");
     c->set_property(role + ".hip_device", "0");
     return c;
+}
+
+// one 1 ms-code adapter driven like the cases above: the replica comes from the reference's own generator, the stream carries it
+// at `carrier_hz` (= Doppler, plus the FDMA offset for GLONASS), the block must report the delay and the Doppler
+template <class Adapter, class Gen>
+void run_simple_case(const char* name, const char* role, long fs, char system, const char* signal, uint32_t prn, const char* impl, Gen gen, size_t delay, double fd,
+    double fdma_offset_hz, unsigned seed)
+{
+    auto conf = base_config(role, fs);
+    Adapter acq(conf.get(), role, 1, 0);
+    EXPECT(acq.implementation() == impl && acq.item_size() == sizeof(gr_complex), "%s adapter: implementation %s item_size %zu", name, acq.implementation().c_str(),
+        acq.item_size());
+    Gnss_Synchro syn{};
+    syn.System = system;
+    std::memcpy(syn.Signal, signal, 3);
+    syn.PRN = prn;
+    acq.set_gnss_synchro(&syn);
+    acq.set_local_code();
+    const size_t n = static_cast<size_t>(fs / 1000);
+    std::vector<std::complex<float>> rep(n);
+    gen(rep);
+    auto x = make_stream(rep, 8 * n, static_cast<double>(fs), delay, fd + fdma_offset_hz, 0.09F, seed);
+    acq.reset();
+    auto r = run_block(acq, x, 4096);
+    EXPECT(r.event == 1, "%s: event %ld", name, r.event);
+    EXPECT(std::fabs(syn.Acq_delay_samples - static_cast<double>(delay)) <= 1.0, "%s delay %f (expected %zu)", name, syn.Acq_delay_samples, delay);
+    EXPECT(std::fabs(syn.Acq_doppler_hz - fd) <= 500.0, "%s doppler %f (expected %f)", name, syn.Acq_doppler_hz, fd);
 }
 }  // namespace
 
@@ -289,6 +331,29 @@ int main()
         GpsL1CaPcpsAcquisitionHip acq(conf.get(), "Acquisition_1C", 1, 0);
         EXPECT(acq.item_size() == 0, "cbyte must yield item_size 0 (gnss_block_factory.cc:1048-1052 rejects it), got %zu", acq.item_size());
     }
+    // ------------------------------------------------------------------ the other BasePcpsAcquisition signals (1 ms codes)
+    run_simple_case<BeidouB1iPcpsAcquisitionHip>("BeiDou B1I", "Acquisition_B1", 8000000, 'C', "B1", 8, "BEIDOU_B1I_PCPS_Acquisition_HIP",
+        [](std::vector<std::complex<float>>& rep) { beidou_b1i_code_gen_complex_sampled(rep, 8, 8000000, 0); }, 1234, 1800.0, 0.0, 21);
+    run_simple_case<BeidouB3iPcpsAcquisitionHip>("BeiDou B3I", "Acquisition_B3", 25000000, 'C', "B3", 20, "BEIDOU_B3I_PCPS_Acquisition_HIP",
+        [](std::vector<std::complex<float>>& rep) { beidou_b3i_code_gen_complex_sampled(rep, 20, 25000000, 0); }, 17001, -2600.0, 0.0, 22);
+    run_simple_case<GalileoE5bPcpsAcquisitionHip>("Galileo E5b", "Acquisition_7X", 25000000, 'E', "7X", 14, "Galileo_E5b_Pcps_Acquisition_HIP",
+        [](std::vector<std::complex<float>>& rep) {
+            const std::array<char, 3> sig = {{'7', 'I', '\0'}};
+            galileo_e5_b_code_gen_complex_sampled(rep, 14, sig, 25000000, 0);
+        },
+        7777, 900.0, 0.0, 23);
+    run_simple_case<GalileoE6PcpsAcquisitionHip>("Galileo E6", "Acquisition_E6", 12500000, 'E', "E6", 3, "Galileo_E6_PCPS_Acquisition_HIP",
+        [](std::vector<std::complex<float>>& rep) { galileo_e6_b_code_gen_complex_sampled(rep, 3, 12500000, 0); }, 555, -4100.0, 0.0, 24);
+    // GLONASS: PRN 1 sits on frequency channel GLONASS_PRN.at(1); the stream carries the code on that FDMA carrier and the block must
+    // search around it (is_fdma, acq.cc:252-272) and report the Doppler relative to it
+    run_simple_case<GlonassL1CaPcpsAcquisitionHip>("GLONASS L1", "Acquisition_1G", 8000000, 'R', "1G", 1, "GLONASS_L1_CA_PCPS_Acquisition_HIP",
+        [](std::vector<std::complex<float>>& rep) { glonass_l1_ca_code_gen_complex_sampled(rep, 8000000, 0); }, 2500, 1300.0, DFRQ1_GLO * GLONASS_PRN.at(1), 25);
+    run_simple_case<GlonassL2CaPcpsAcquisitionHip>("GLONASS L2", "Acquisition_2G", 8000000, 'R', "2G", 2, "GLONASS_L2_CA_PCPS_Acquisition_HIP",
+        [](std::vector<std::complex<float>>& rep) { glonass_l2_ca_code_gen_complex_sampled(rep, 8000000, 0); }, 6001, -700.0, DFRQ2_GLO * GLONASS_PRN.at(2), 26);
+    run_simple_case<QzssL1PcpsAcquisitionHip>("QZSS L1", "Acquisition_J1", 8000000, 'J', "J1", 193, "QZSS_L1_PCPS_Acquisition_HIP",
+        [](std::vector<std::complex<float>>& rep) { qzss_l1_code_gen_complex_sampled(rep, 193, 8000000); }, 3210, 2200.0, 0.0, 27);
+    run_simple_case<QzssL5iPcpsAcquisitionHip>("QZSS L5I", "Acquisition_J5", 25000000, 'J', "J5", 194, "QZSS_L5i_PCPS_Acquisition_HIP",
+        [](std::vector<std::complex<float>>& rep) { qzss_l5i_code_gen_complex_sampled(rep, 194, 25000000); }, 12321, -1500.0, 0.0, 28);
     if (fails == 0) std::printf("ADAPTERS OK\n");
     return fails == 0 ? 0 : 1;
 }
