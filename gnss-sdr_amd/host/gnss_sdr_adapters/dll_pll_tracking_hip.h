@@ -1,9 +1,9 @@
 /*!
  * \file dll_pll_tracking_hip.h
- * \brief TrackingInterface adapters "GPS_L1_CA_DLL_PLL_Tracking_HIP", "Galileo_E1_DLL_PLL_VEML_Tracking_HIP",
- *        "GPS_L5_DLL_PLL_Tracking_HIP": the reference's own DLL/PLL adapters
- *        (src/algorithms/tracking/adapters/gps_l1_ca_dll_pll_tracking.h:37-58, galileo_e1_dll_pll_veml_tracking.h,
- *        gps_l5_dll_pll_tracking.h over base_dll_pll_tracking.h:39-121) with the MI355X multicorrelator inside.
+ * \brief TrackingInterface adapters "<reference name>_HIP" for every signal the reference tracks with dll_pll_veml_tracking
+ *        (GPS L1 / L2C / L5, Galileo E1 / E5a / E5b / E6, GLONASS L1 / L2, BeiDou B1I / B3I, QZSS L1 / L5): the reference's own DLL/PLL
+ *        adapters (src/algorithms/tracking/adapters/gps_l1_ca_dll_pll_tracking.h:37-58 and its twelve siblings over
+ *        base_dll_pll_tracking.h:39-121) with the MI355X multicorrelator inside.
  *
  * BUILT ONLY INSIDE A gnss-sdr TREE, with -DENABLE_HIP_MI355X=1, i.e. with dll_pll_veml_tracking's two correlator members
  * (dll_pll_veml_tracking.h:94-95) declared as Hip_Multicorrelator_Real_Codes.  The 2 300 lines of
@@ -21,10 +21,20 @@
 #error "dll_pll_tracking_hip.h needs -DENABLE_HIP_MI355X=1 (the tracking block must be compiled with the HIP correlator members)"
 #endif
 
+#include "beidou_b1i_dll_pll_tracking.h"
+#include "beidou_b3i_dll_pll_tracking.h"
 #include "configuration_interface.h"
 #include "galileo_e1_dll_pll_veml_tracking.h"
+#include "galileo_e5a_dll_pll_tracking.h"
+#include "galileo_e5b_dll_pll_tracking.h"
+#include "galileo_e6_dll_pll_tracking.h"
+#include "glonass_l1_ca_dll_pll_tracking.h"
+#include "glonass_l2_ca_dll_pll_tracking.h"
 #include "gps_l1_ca_dll_pll_tracking.h"
+#include "gps_l2_m_dll_pll_tracking.h"
 #include "gps_l5_dll_pll_tracking.h"
+#include "qzss_l1_dll_pll_tracking.h"
+#include "qzss_l5_dll_pll_tracking.h"
 #include <cstdlib>
 #include <string>
 
@@ -55,5 +65,15 @@ struct DeviceSelector
 GSH_DECLARE_TRACKING_HIP_ADAPTER(GpsL1CaDllPllTrackingHip, GpsL1CaDllPllTracking, "GPS_L1_CA_DLL_PLL_Tracking_HIP");
 GSH_DECLARE_TRACKING_HIP_ADAPTER(GalileoE1DllPllVemlTrackingHip, GalileoE1DllPllVemlTracking, "Galileo_E1_DLL_PLL_VEML_Tracking_HIP");
 GSH_DECLARE_TRACKING_HIP_ADAPTER(GpsL5DllPllTrackingHip, GpsL5DllPllTracking, "GPS_L5_DLL_PLL_Tracking_HIP");
+GSH_DECLARE_TRACKING_HIP_ADAPTER(GpsL2MDllPllTrackingHip, GpsL2MDllPllTracking, "GPS_L2_M_DLL_PLL_Tracking_HIP");
+GSH_DECLARE_TRACKING_HIP_ADAPTER(GalileoE5aDllPllTrackingHip, GalileoE5aDllPllTracking, "Galileo_E5a_DLL_PLL_Tracking_HIP");
+GSH_DECLARE_TRACKING_HIP_ADAPTER(GalileoE5bDllPllTrackingHip, GalileoE5bDllPllTracking, "Galileo_E5b_DLL_PLL_Tracking_HIP");
+GSH_DECLARE_TRACKING_HIP_ADAPTER(GalileoE6DllPllTrackingHip, GalileoE6DllPllTracking, "Galileo_E6_DLL_PLL_Tracking_HIP");
+GSH_DECLARE_TRACKING_HIP_ADAPTER(GlonassL1CaDllPllTrackingHip, GlonassL1CaDllPllTracking, "GLONASS_L1_CA_DLL_PLL_Tracking_HIP");
+GSH_DECLARE_TRACKING_HIP_ADAPTER(GlonassL2CaDllPllTrackingHip, GlonassL2CaDllPllTracking, "GLONASS_L2_CA_DLL_PLL_Tracking_HIP");
+GSH_DECLARE_TRACKING_HIP_ADAPTER(BeidouB1iDllPllTrackingHip, BeidouB1iDllPllTracking, "BEIDOU_B1I_DLL_PLL_Tracking_HIP");
+GSH_DECLARE_TRACKING_HIP_ADAPTER(BeidouB3iDllPllTrackingHip, BeidouB3iDllPllTracking, "BEIDOU_B3I_DLL_PLL_Tracking_HIP");
+GSH_DECLARE_TRACKING_HIP_ADAPTER(QzssL1DllPllTrackingHip, QzssL1DllPllTracking, "QZSS_L1_CA_DLL_PLL_Tracking_HIP");
+GSH_DECLARE_TRACKING_HIP_ADAPTER(QzssL5DllPllTrackingHip, QzssL5DllPllTracking, "QZSS_L5_DLL_PLL_Tracking_HIP");
 
 #endif  // GNSS_SDR_DLL_PLL_TRACKING_HIP_H
