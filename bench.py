@@ -56,7 +56,7 @@ def parse():
 
 def make_stream_torch(torch, dev, n_samples, fs, n_sig=8, cn0=45.0):
     """Synthetic IF stream on the device: N(0,1)+jN(0,1) + n_sig GPS C/A signals at cn0 dB-Hz."""
-    import oracle
+    from gnss_sdr_amd.codes import gps_l1_ca_code
     g = torch.Generator(device=dev)
     g.manual_seed(0x5EED0002)
     x = torch.randn(n_samples, 2, generator=g, device=dev, dtype=torch.float32)
@@ -67,7 +67,7 @@ def make_stream_torch(torch, dev, n_samples, fs, n_sig=8, cn0=45.0):
     amp = float(np.sqrt(10.0 ** (cn0 / 10.0) * 2.0 / fs))
     t = torch.arange(n_samples, device=dev, dtype=torch.float64)
     for i in range(n_sig):
-        code = torch.from_numpy(oracle.ca_code(i + 1)).to(dev)
+        code = torch.from_numpy(gps_l1_ca_code(i + 1)).to(dev)
         f_code = 1.023e6 * (1.0 + dop[i] / 1575.42e6)
         chip = torch.floor(t * (f_code / fs) + cph[i]).to(torch.int64) % 1023
         ph = (2.0 * np.pi * dop[i] / fs) * t
@@ -80,7 +80,14 @@ def make_stream_torch(torch, dev, n_samples, fs, n_sig=8, cn0=45.0):
 def build_jobs(channels, epochs, n, fs, taps, dop, cph, rank):
     """Epoch-major, channel-minor job table (jobs that read the same samples are adjacent: they share an XCD L2)."""
     from gnss_sdr_amd.tracking import make_jobs
-    from helpers import tracking_params_for
+
+    def tracking_params_for(fs, doppler_hz, rng):
+        """Per-channel NCO parameters as the tracking block would pass them (trk.cc:1237-1243)."""
+        two_pi = 6.283185307179586
+        return dict(rem_carr_phase_rad=float(np.float32(rng.uniform(0.0, two_pi))),
+                    phase_step_rad=float(np.float32(two_pi * doppler_hz / fs)),
+                    rem_code_phase_chips=float(np.float32(rng.uniform(0.0, 1.0))),
+                    code_phase_step_chips=float(np.float32(1.023e6 * (1.0 + doppler_hz / 1575.42e6) / fs)))
     rng = np.random.default_rng(0x5EED0004 + rank)
     per_ch = []
     for c in range(channels):
@@ -174,13 +181,13 @@ def acquisition_metric(torch, dev_index, x_block, fs):
         from gnss_sdr_amd.acquisition import PcpsAcquisitionBank
     except Exception as e:  # acquisition not built yet
         return {"error": f"acquisition unavailable: {e}"}
-    import oracle
+    from gnss_sdr_amd.codes import gps_l1_ca_code_sampled
     n = int(fs * 1e-3)
     acq = PcpsAcquisitionBank(fs_in=int(fs), fft_size=n, doppler_max=5000, doppler_step=250, num_doppler_bins=41,
                               samples_per_chip=int(np.ceil(fs / 1.023e6)), samples_per_code=float(n), max_prn=32, device=dev_index,
                               keep_grid=False)  # max_dwells = 1, dump = false: the statistics are formed on chip
     for p in range(32):
-        acq.set_local_code(p, oracle.ca_code_complex_sampled(p + 1, int(fs)))
+        acq.set_local_code(p, gps_l1_ca_code_sampled(p + 1, int(fs)))
     acq.time_dwells(x_block, 32, reps=400, pipelined=True)        # ~60 ms untimed: the clocks settle (profiles/ab/clock_ramp.py)
     ms_serial = acq.time_dwells(x_block, 32, reps=20)             # one batch after the other on one stream: latency
     ms = acq.time_dwells(x_block, 32, reps=200, pipelined=True)   # batches alternating on two streams: throughput
@@ -245,14 +252,14 @@ def pcie_inclusive_metric(torch, dev_index, x_dev, jobs, C, E, T, n_samples, rep
     buffer -> gsh_stream_push (H2D + cast on the device) -> one launch over all channels / epochs, nothing overlapped."""
     from gnss_sdr_amd.sample_stream import SampleStream
     from gnss_sdr_amd.tracking import CorrelatorBank
-    import oracle
+    from gnss_sdr_amd.codes import gps_l1_ca_code
     q = torch.view_as_real(x_dev).mul(30.0).round_().clamp_(-127, 127).to(torch.int8).cpu()
     host = torch.empty_like(q).pin_memory()
     host.copy_(q)
     ring = SampleStream(n_samples + 2, n_samples // 2, device=dev_index)
     bank = CorrelatorBank(C, 1023, device=dev_index)
     for c in range(C):
-        bank.set_code(c, oracle.ca_code(c % 32 + 1))
+        bank.set_code(c, gps_l1_ca_code(c % 32 + 1))
     bank.set_stream_ring(ring)
     bank.set_splits(1)
     h = host.numpy()
@@ -286,7 +293,7 @@ def closed_loop_metric(dev_index, x_dev, n_samples, fs, n, dop, cph, channels=32
         from gnss_sdr_amd.tracking_loop import TrackingLoop, trk_conf
     except Exception as e:
         return {"error": f"tracking loop unavailable: {e}"}
-    import oracle
+    from gnss_sdr_amd.codes import gps_l1_ca_code
     conf = trk_conf(fs_in=fs, vector_length=n, pll_bw_hz=35.0, dll_bw_hz=2.0)
     loop = TrackingLoop(conf, channels, 1023, device=dev_index)
     loop.set_stream_device(x_dev.data_ptr(), n_samples, keepalive=x_dev)
@@ -295,9 +302,9 @@ def closed_loop_metric(dev_index, x_dev, n_samples, fs, n, dop, cph, channels=32
         if c < len(dop):  # hand-over from a (simulated) acquisition: code start of the embedded signal, Doppler off by <= 20 Hz
             f_code = 1.023e6 * (1 + dop[c] / 1575.42e6)
             start = int(round((1023.0 - cph[c]) / f_code * fs))
-            loop.start(c, oracle.ca_code(c + 1), start, 0, float(dop[c]) + rng.uniform(-20, 20))
+            loop.start(c, gps_l1_ca_code(c + 1), start, 0, float(dop[c]) + rng.uniform(-20, 20))
         else:
-            loop.start(c, oracle.ca_code(c % 32 + 1), int(rng.integers(0, n)), 0, float(rng.uniform(-5000, 5000)))
+            loop.start(c, gps_l1_ca_code(c % 32 + 1), int(rng.integers(0, n)), 0, float(rng.uniform(-5000, 5000)))
     loop.time_run(epochs, reps=20)   # ~45 ms untimed: the clocks settle (profiles/ab/clock_ramp.py)
     ms = loop.time_run(epochs, reps=5)
     rec, done = loop.run(epochs)
@@ -321,7 +328,8 @@ def main():
     import torch
     import gnss_sdr_amd
     from gnss_sdr_amd.tracking import CorrelatorBank
-    import oracle
+    from gnss_sdr_amd.codes import gps_l1_ca_code
+    import oracle  # the checker (spot check below) and the CPU baseline only; nothing the GPU legs consume comes from it
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP engine has no CPU fallback)")
@@ -379,7 +387,7 @@ def main():
             torch.cuda.synchronize()
     bank = CorrelatorBank(C, 1023, device=local)
     for c in range(C):
-        bank.set_code(c, oracle.ca_code((rank * C + c) % 32 + 1))
+        bank.set_code(c, gps_l1_ca_code((rank * C + c) % 32 + 1))
     jobs, rows = build_jobs(C, E, n, fs, T, dop, cph, rank)
     bank.upload_jobs(jobs)
     bank.set_splits(1)
