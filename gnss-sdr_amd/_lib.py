@@ -170,6 +170,11 @@ SYMBOLS = {
     "gsh_acq_create": (C.c_int, [C.c_int, C.POINTER(AcqConf), C.POINTER(_P)]),
     "gsh_acq_destroy": (None, [_P]),
     "gsh_acq_set_local_code": (C.c_int, [_P, C.c_uint32, _F]),
+    "gsh_pb_create": (C.c_int, [C.c_int, C.c_float, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_P)]),
+    "gsh_pb_destroy": (None, [_P]),
+    "gsh_pb_threshold": (C.c_float, [_P]),
+    "gsh_pb_process_device": (C.c_int, [_P, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64)]),
+    "gsh_pb_get_state": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "gsh_acq_set_doppler_center": (C.c_int, [_P, C.c_int32]),
     "gsh_acq_set_doppler_bias": (C.c_int, [_P, C.c_int32]),
     "gsh_acq_set_grid_weight": (C.c_int, [_P, C.c_float]),

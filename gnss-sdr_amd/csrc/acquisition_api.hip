@@ -265,7 +265,7 @@ void gamma_pq(double a, double x, double* p_out, double* q_out)
     *p_out = 1.0 - *q_out;
 }
 
-double gamma_p_inv(double a, double p)
+double gamma_p_inv_impl(double a, double p)
 {
     if (p <= 0.0) return 0.0;
     if (p >= 1.0) return INFINITY;
@@ -296,6 +296,11 @@ double gamma_p_inv(double a, double p)
     return x;
 }
 }  // namespace
+
+namespace gsh
+{
+double gamma_p_inv(double a, double p) { return gamma_p_inv_impl(a, p); }
+}  // namespace gsh
 
 extern "C"
 {
@@ -892,6 +897,6 @@ extern "C"
         // acq.cc:52-56
         const int num_bins = static_cast<int>(effective_fft_size * num_doppler_bins);
         const double prob = std::pow(1.0 - static_cast<double>(pfa), 1.0 / static_cast<double>(static_cast<float>(num_bins)));
-        return static_cast<float>(2.0 * gamma_p_inv(2.0 * static_cast<double>(max_dwells), prob));
+        return static_cast<float>(2.0 * gamma_p_inv_impl(2.0 * static_cast<double>(max_dwells), prob));
     }
 }

@@ -23,6 +23,9 @@ inline int hip_fail(hipError_t e, const char* what, const char* file, int line)
 // select `device` for the calling thread; GSH_ERR_NO_DEVICE if it does not exist
 int use_device(int device);
 
+// inverse of the regularized lower incomplete gamma function P(a, x) in x (boost::math::gamma_p_inv); acquisition_api.hip
+double gamma_p_inv(double a, double p);
+
 // XCD-aware remap of a linear work-group id (MI355X: block b runs on XCD b % 8, each XCD has
 // its own 4 MiB L2).  Consecutive *logical* ids land on the same XCD so that jobs which share
 // input (same epoch, neighbouring channels) share an L2.  Bijective for any grid size.

@@ -133,3 +133,39 @@ def acquisition_resampler_design(fs: int, acq_fs: float):
     dec_fs = fs / decimation
     taps = firdes_low_pass(1.0, fs, dec_fs / 2.1, dec_fs / 2)
     return decimation, dec_fs, taps, (len(taps) - 1) // 2
+
+
+class PulseBlanking:
+    """gsh_pb_*: pulse_blanking_cc on the device (pulse_blanking_cc.cc:33-106)."""
+
+    def __init__(self, pfa: float = 0.04, length: int = 32, n_segments_est: int = 12500, n_segments_reset: int = 5000000, device: int = 0):
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        check(self._lib.gsh_pb_create(device, pfa, length, n_segments_est, n_segments_reset, C.byref(self._h)))
+        self.length = length
+
+    def close(self):
+        if self._h:
+            self._lib.gsh_pb_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def threshold(self) -> float:
+        return float(self._lib.gsh_pb_threshold(self._h))
+
+    def process_device(self, d_in: int, n_items: int, d_out: int) -> int:
+        """One general_work call over n_items resident samples; returns how many were consumed (= produced)."""
+        done = C.c_uint64(0)
+        check(self._lib.gsh_pb_process_device(self._h, C.c_void_p(d_in), n_items, C.c_void_p(d_out), C.byref(done)))
+        return int(done.value)
+
+    def state(self):
+        noise, n, last = C.c_float(0.0), C.c_int32(0), C.c_int32(0)
+        check(self._lib.gsh_pb_get_state(self._h, C.byref(noise), C.byref(n), C.byref(last)))
+        return float(noise.value), int(n.value), bool(last.value)

@@ -30,7 +30,7 @@ extern "C"
 {
 #endif
 
-#define GSH_ABI_VERSION 11
+#define GSH_ABI_VERSION 12
 #define GSH_MAX_TAPS 8 /* VE/E/P/L/VL needs 5 (trk.cc:609-650); 8 leaves room for multi-tap dumps */
 
     enum
@@ -454,6 +454,22 @@ extern "C"
      * gsh_acq_time_dwells reports).  Statistics only (as no_grid = 1); lengths without an on-chip plan fall back to
      * gsh_acq_time_dwells. */
     int gsh_acq_time_dwells_pipelined(gsh_acq_t* a, uint32_t n_prn, int reps, float* avg_ms);
+
+    /* ---- pulse blanking (input filter in front of the channels) ---------------------------------------------------------------
+     * pulse_blanking_cc (src/algorithms/input_filter/gnuradio_blocks/pulse_blanking_cc.cc:33-106; adapter key
+     * InputFilter.implementation=Pulse_Blanking_Filter, pulse_blanking_filter.cc: pfa, length, segments_est, segments_reset): the
+     * stream is tiled into `length`-sample segments; a segment whose energy over the estimated noise power exceeds the chi-squared
+     * (2 * length degrees of freedom) threshold for `pfa` is zeroed.  State (noise estimate, segment counter, last_filtered) lives on
+     * the device and carries over between calls. */
+    typedef struct gsh_pulse_blanking gsh_pb_t;
+    int gsh_pb_create(int device, float pfa, int32_t length, int32_t n_segments_est, int32_t n_segments_reset, gsh_pb_t** out);
+    void gsh_pb_destroy(gsh_pb_t* p);
+    float gsh_pb_threshold(const gsh_pb_t* p); /* thres_, pulse_blanking_cc.cc:48-49 */
+    /* one general_work call (:57-106) over n_items resident complex64 samples: whole segments are filtered while
+     * (index + length) < n_items, exactly as the block consumes them; *n_done = samples consumed = samples produced (the caller
+     * presents the remainder again, followed by new samples, like the GNU Radio scheduler does).  In-place (out == in) is allowed. */
+    int gsh_pb_process_device(gsh_pb_t* p, const void* device_in_iq, uint64_t n_items, void* device_out_iq, uint64_t* n_done);
+    int gsh_pb_get_state(gsh_pb_t* p, float* noise_power_estimation, int32_t* n_segments, int32_t* last_filtered);
 
     /* compute_threshold, acq.cc:52-56: 2*gamma_p_inv(2*max_dwells, (1-pfa)^(1/(effective*bins))) */
     float gsh_acq_compute_threshold(float pfa, uint32_t effective_fft_size, uint32_t num_doppler_bins, uint32_t max_dwells);
