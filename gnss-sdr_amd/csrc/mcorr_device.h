@@ -122,6 +122,10 @@ struct JobCtx
     int code_len;
     float rem_carr, phase_step, phase_rate;
     float rem_code, code_step, code_rate;
+    // windowed code table (multicorrelator.hip): only the code samples k_lo..k_hi this segment can touch are staged, and `tab` is
+    // indexed through k_off.  k_hi < k_lo: the whole code is staged (no window).
+    int k_lo{0}, k_hi{-1};
+    int k_off{MC_MARGIN};  // tab[k + k_off] is code sample k (window: -k_lo)
 };
 
 // One chunk = 256 pairs = 512 consecutive samples; thread `tid` owns samples n0, n0+1.
@@ -176,12 +180,21 @@ __device__ __forceinline__ void process_pair(const JobCtx& c, const float2* __re
                         }
                     if (MASKED)
                         {
-                            // masked lanes may sit at n = -1 / n = n_end with any index: keep the lookup in range
-                            k0 = wrap_chip(k0, c.code_len);
-                            k1 = wrap_chip(k1, c.code_len);
+                            // masked lanes may sit at n = -1 / n = n_end with any index: keep the lookup in range (their sample is 0, the
+                            // value read only has to be finite).  In-range lanes are untouched by either form.
+                            if (c.k_hi >= c.k_lo)
+                                {
+                                    k0 = min(max(k0, c.k_lo), c.k_hi);
+                                    k1 = min(max(k1, c.k_lo), c.k_hi);
+                                }
+                            else
+                                {
+                                    k0 = wrap_chip(k0, c.code_len);
+                                    k1 = wrap_chip(k1, c.code_len);
+                                }
                         }
-                    const float c0 = tab[k0 + MC_MARGIN];
-                    const float c1 = tab[k1 + MC_MARGIN];
+                    const float c0 = tab[k0 + c.k_off];
+                    const float c1 = tab[k1 + c.k_off];
                     acc[t].x = fmaf(y0.x, c0, acc[t].x);
                     acc[t].y = fmaf(y0.y, c0, acc[t].y);
                     acc[t].x = fmaf(y1.x, c1, acc[t].x);
@@ -205,8 +218,8 @@ __device__ __forceinline__ void process_pair(const JobCtx& c, const float2* __re
                         }
                     const int k0 = wrap_chip(raw_chip_hd(c.code_step, c.code_rate, static_cast<unsigned>(m0), sh[0], c.rem_code), c.code_len);
                     const int k1 = wrap_chip(raw_chip_hd(c.code_step, c.code_rate, static_cast<unsigned>(m1), sh[0], c.rem_code), c.code_len);
-                    const float c0 = tab[k0 + MC_MARGIN];
-                    const float c1 = tab[k1 + MC_MARGIN];
+                    const float c0 = tab[k0 + c.k_off];
+                    const float c1 = tab[k1 + c.k_off];
                     acc[t].x = fmaf(y0.x, c0, acc[t].x);
                     acc[t].y = fmaf(y0.y, c0, acc[t].y);
                     acc[t].x = fmaf(y1.x, c1, acc[t].x);

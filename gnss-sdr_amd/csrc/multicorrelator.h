@@ -19,6 +19,7 @@ struct McorrArgs
     float2* partials;                // device, n_jobs * splits * GSH_MAX_TAPS (splits > 1 only)
     int n_jobs;
     int splits;
+    int window_floats;               // > 0: LDS holds only a window of the code per work-group (all jobs: mode 0, code_step >= 0); 0: the whole code
 };
 
 // Largest n_taps over the jobs and which mode combinations occur decide the template
@@ -27,6 +28,8 @@ int mcorr_launch(const McorrArgs& args, int max_taps, int mode, int max_code_len
 
 // dynamic LDS bytes the kernel needs for a code of max_code_len samples
 size_t mcorr_lds_bytes(int max_code_len);
+// the same when only `window_floats` code samples are staged per work-group
+size_t mcorr_lds_bytes_window(int window_floats);
 }  // namespace gsh
 
 #endif

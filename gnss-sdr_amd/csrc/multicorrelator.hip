@@ -36,7 +36,7 @@ namespace
 using namespace mcdev;
 
 template <int NT, int MODE>
-__global__ __launch_bounds__(MC_THREADS) void mcorr_kernel(McorrArgs a)
+__global__ __launch_bounds__(MC_THREADS, (NT <= 3 ? 8 : 1)) void mcorr_kernel(McorrArgs a)  // E/P/L: 8 waves per SIMD (<= 64 VGPRs)
 {
     extern __shared__ __align__(16) float lds[];
     const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
@@ -54,15 +54,6 @@ __global__ __launch_bounds__(MC_THREADS) void mcorr_kernel(McorrArgs a)
     c.rem_code = J.rem_code_phase_chips;
     c.code_step = J.code_phase_step_chips;
     c.code_rate = J.code_phase_rate_step_chips;
-
-    // ---- stage the local code (+ guard bands holding the wrapped neighbours) in LDS
-    float* tab = lds;
-    const int tab_len = c.code_len + 2 * MC_MARGIN;
-    {
-        const float* __restrict__ gcode = a.codes + static_cast<size_t>(J.code_slot) * a.code_stride;
-        for (int i = tid; i < tab_len; i += MC_THREADS) tab[i] = gcode[wrap_chip(i - MC_MARGIN, c.code_len)];
-    }
-    float2* red = reinterpret_cast<float2*>(lds + ((tab_len + 3) & ~3));
 
     // ---- this work-group's slice of the window
     int seg = (c.n_total + a.splits - 1) / a.splits;
@@ -96,30 +87,67 @@ __global__ __launch_bounds__(MC_THREADS) void mcorr_kernel(McorrArgs a)
             for (int t = 1; t < NT; t++) rot[t] = 0;
         }
 
+    // the raw chip index is monotone in n and in the shift (every rounding is monotone) when step >= 0: its range over this
+    // segment is [lo, hi], evaluated with the very expressions the samples use
+    int lo = 0, hi = -1;
+    if (!mode_hd_code(MODE) && c.n_end > c.n_begin)
+        {
+            float smin = sh[0], smax = sh[0];
+#pragma unroll
+            for (int t = 1; t < NT; t++)
+                {
+                    smin = fminf(smin, sh[t]);
+                    smax = fmaxf(smax, sh[t]);
+                }
+            lo = raw_chip_std(__fmul_rn(c.code_step, static_cast<float>(c.n_begin)), smin, c.rem_code);
+            hi = raw_chip_std(__fmul_rn(c.code_step, static_cast<float>(c.n_end - 1)), smax, c.rem_code);
+        }
+
+    // ---- stage the local code in LDS: the whole code (+ guard bands holding the wrapped neighbours), or -- when the host found that
+    // every segment of this launch touches only a short run of it (long codes, split windows) -- just the samples lo..hi, so that a
+    // 10 230-chip code does not cost 41 KB of LDS per work-group and with it most of the compute unit's occupancy
+    float* tab = lds;
+    const float* __restrict__ gcode = a.codes + static_cast<size_t>(J.code_slot) * a.code_stride;
+    bool windowed = false, misfit = false;
+    int lds_floats;
+    if (a.window_floats > 0)
+        {
+            const long long span = static_cast<long long>(hi) - lo + 1;
+            if (!mode_hd_code(MODE) && c.code_step >= 0.0f && span >= 1 && span <= a.window_floats)
+                {
+                    windowed = true;
+                    for (int i = tid; i < static_cast<int>(span); i += MC_THREADS) tab[i] = gcode[wrap_chip(lo + i, c.code_len)];
+                    c.k_lo = lo;
+                    c.k_hi = hi;
+                    c.k_off = -lo;
+                }
+            else
+                misfit = (c.n_end > c.n_begin);  // cannot happen for a batch the host admitted (bank_window_floats); reported as NaN if it does
+            lds_floats = a.window_floats;
+        }
+    else
+        {
+            const int tab_len = c.code_len + 2 * MC_MARGIN;
+            for (int i = tid; i < tab_len; i += MC_THREADS) tab[i] = gcode[wrap_chip(i - MC_MARGIN, c.code_len)];
+            lds_floats = tab_len;
+        }
+    float2* red = reinterpret_cast<float2*>(lds + ((lds_floats + 3) & ~3));
+
     float2 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; t++) acc[t] = make_float2(0.0f, 0.0f);
 
     __syncthreads();  // code table visible
 
-    if (c.n_end > c.n_begin)
+    if (misfit)
         {
-            bool fast = false;
-            if (!mode_hd_code(MODE))
-                {
-                    // the raw index is monotone in n and in the shift (rounding is monotone) when step >= 0:
-                    // bound it over the segment and skip the per-sample wrap when it stays inside the guard bands
-                    float smin = sh[0], smax = sh[0];
 #pragma unroll
-                    for (int t = 1; t < NT; t++)
-                        {
-                            smin = fminf(smin, sh[t]);
-                            smax = fmaxf(smax, sh[t]);
-                        }
-                    const int lo = raw_chip_std(__fmul_rn(c.code_step, static_cast<float>(c.n_begin)), smin, c.rem_code);
-                    const int hi = raw_chip_std(__fmul_rn(c.code_step, static_cast<float>(c.n_end - 1)), smax, c.rem_code);
-                    fast = (c.code_step >= 0.0f) && (lo >= -MC_MARGIN) && (hi < c.code_len + MC_MARGIN) && (c.code_len >= MC_MARGIN);
-                }
+            for (int t = 0; t < NT; t++) acc[t] = make_float2(__builtin_nanf(""), __builtin_nanf(""));
+        }
+    else if (c.n_end > c.n_begin)
+        {
+            // skip the per-sample wrap when the indices stay inside what is staged
+            const bool fast = windowed || (!mode_hd_code(MODE) && (c.code_step >= 0.0f) && (lo >= -MC_MARGIN) && (hi < c.code_len + MC_MARGIN) && (c.code_len >= MC_MARGIN));
             // centre tap at exactly 0 (E/P/L, VE/E/P/L/VL): its (a + 0.0f) is skipped; needs sample indices exact in float
             const bool zp = (NT & 1) && (NT == J.n_taps) && (sh[NT / 2] == 0.0f) && !mode_hd_code(MODE) && (c.n_total < (1 << 24));
             if (fast && zp)
@@ -207,6 +235,12 @@ int launch_nt(const McorrArgs& a, int mode, size_t lds, hipStream_t stream)
 }
 }  // namespace
 
+size_t mcorr_lds_bytes_window(int window_floats)
+{
+    const size_t tab = (static_cast<size_t>(window_floats) + 3) & ~static_cast<size_t>(3);
+    return tab * sizeof(float) + MC_WAVES * GSH_MAX_TAPS * sizeof(float2);
+}
+
 size_t mcorr_lds_bytes(int max_code_len)
 {
     const size_t tab = (static_cast<size_t>(max_code_len) + 2 * MC_MARGIN + 3) & ~static_cast<size_t>(3);
@@ -218,7 +252,7 @@ int mcorr_launch(const McorrArgs& a, int max_taps, int mode, int max_code_len, h
     if (a.n_jobs <= 0) return GSH_OK;
     GSH_REQUIRE(max_taps >= 1 && max_taps <= GSH_MAX_TAPS, "n_taps %d outside 1..%d", max_taps, GSH_MAX_TAPS);
     GSH_REQUIRE(a.splits >= 1, "splits must be >= 1");
-    const size_t lds = mcorr_lds_bytes(max_code_len);
+    const size_t lds = a.window_floats > 0 ? mcorr_lds_bytes_window(a.window_floats) : mcorr_lds_bytes(max_code_len);
     GSH_REQUIRE(lds <= 160 * 1024, "local code of %d samples does not fit the 160 KiB LDS", max_code_len);
     int rc;
     if (max_taps == 1)

@@ -32,6 +32,12 @@ struct gsh_bank
     int min_samples{0};
     unsigned long long max_end{0};
     int splits_user{0};
+    // windowed code staging (multicorrelator.hip): possible when every job of the batch is mode 0 with code_step >= 0
+    bool window_eligible{false};
+    double win_step_max{0.0};   // largest code_phase_step_chips of the batch (code samples per input sample)
+    double win_code_span_max{0.0};  // largest code_phase_step_chips * n_samples of the batch: code samples one window walks
+    double win_shift_span{0.0}; // largest (max shift - min shift) of the batch
+    int max_samples{0};
     hipEvent_t ev0{nullptr}, ev1{nullptr};
     gsh_stream* ring{nullptr};          // when set, job windows are absolute sample indices inside this ring
     gsh_corr_job* h_jobs{nullptr};      // pinned staging (ring translation; one-synchronisation gsh_bank_correlate)
@@ -78,12 +84,25 @@ int bank_reserve_staging(gsh_bank* b, int n)
 // host-to-device copy on the bank's stream.  No synchronisation.
 int bank_stage_jobs(gsh_bank* b, const gsh_corr_job* jobs, int n_jobs)
 {
-    int max_taps = 0, mode = jobs[0].high_dyn, min_samples = jobs[0].n_samples;
+    int max_taps = 0, mode = jobs[0].high_dyn, min_samples = jobs[0].n_samples, max_samples = 0;
     unsigned long long max_end = 0;
+    bool window_eligible = (mode == 0);
+    double step_max = 0.0, shift_span = 0.0, code_span = 0.0;
     for (int i = 0; i < n_jobs; i++)
         {
             int rc = validate_job(b, jobs[i], i);
             if (rc != GSH_OK) return rc;
+            max_samples = std::max(max_samples, jobs[i].n_samples);
+            if (!(jobs[i].code_phase_step_chips >= 0.0f)) window_eligible = false;
+            step_max = std::max(step_max, static_cast<double>(jobs[i].code_phase_step_chips));
+            code_span = std::max(code_span, static_cast<double>(jobs[i].code_phase_step_chips) * static_cast<double>(jobs[i].n_samples));
+            float smin = jobs[i].shifts_chips[0], smax = jobs[i].shifts_chips[0];
+            for (int t = 1; t < jobs[i].n_taps; t++)
+                {
+                    smin = std::min(smin, jobs[i].shifts_chips[t]);
+                    smax = std::max(smax, jobs[i].shifts_chips[t]);
+                }
+            shift_span = std::max(shift_span, static_cast<double>(smax) - static_cast<double>(smin));
             if (jobs[i].high_dyn != mode)
                 return set_error(GSH_ERR_UNSUPPORTED, "job %d: all jobs of one batch must share high_dyn (%d vs %d); split the batch", i, jobs[i].high_dyn, mode);
             max_taps = std::max(max_taps, jobs[i].n_taps);
@@ -114,6 +133,11 @@ int bank_stage_jobs(gsh_bank* b, const gsh_corr_job* jobs, int n_jobs)
     b->mode = mode;
     b->min_samples = min_samples;
     b->max_end = max_end;
+    b->max_samples = max_samples;
+    b->window_eligible = window_eligible;
+    b->win_step_max = step_max;
+    b->win_code_span_max = code_span;
+    b->win_shift_span = shift_span;
     return GSH_OK;
 }
 
@@ -127,9 +151,38 @@ int bank_splits(const gsh_bank* b)
             s = (b->n_jobs >= 1024) ? 1 : (2048 + b->n_jobs - 1) / std::max(b->n_jobs, 1);
         }
     const int by_len = std::max(1, b->min_samples / 2048);  // keep >= 2048 samples per work-group
+    if (b->splits_user <= 0 && b->window_eligible && static_cast<size_t>(b->max_code_len) * sizeof(float) > 20 * 1024)
+        {
+            // long codes (Galileo E1 / E5, GPS L5 / L2C): the whole code in LDS leaves room for 3-4 work-groups per compute unit.  Cut the
+            // windows so that a work-group only walks ~2000 code samples and stages just those (bank_window_floats).
+            const int want = static_cast<int>(std::ceil(b->win_code_span_max / 2000.0));
+            s = std::max(s, std::min(want, 16));
+        }
     s = std::min(s, by_len);
     s = std::min(s, 64);
     return std::max(s, 1);
+}
+
+// LDS floats per work-group when only the code samples a segment can touch are staged; 0 when the whole code is staged instead
+// (batch not eligible, or the window would not be clearly smaller than the code)
+int bank_window_floats(const gsh_bank* b, int splits)
+{
+    if (!b->window_eligible) return 0;
+    // hi - lo + 1 <= step * (seg - 1) + (smax - smin) + 2 in exact arithmetic, seg the job's own segment length; the float evaluation on
+    // the device moves either end by a few ulps of values below 2^24, far less than the slack added here (the kernel re-checks and
+    // reports NaN if this were ever short)
+    double walk = 0.0;
+    for (int i = 0; i < b->n_jobs; i++)
+        {
+            int seg = (b->h_jobs[i].n_samples + splits - 1) / splits;
+            seg = (seg + 1) & ~1;
+            walk = std::max(walk, static_cast<double>(b->h_jobs[i].code_phase_step_chips) * static_cast<double>(seg));
+        }
+    const double need = walk + b->win_shift_span + 16.0;
+    if (!(need < 1.0e6)) return 0;
+    const int w = (static_cast<int>(std::ceil(need)) + 3) & ~3;
+    const int full = b->max_code_len + 2 * 32;
+    return (2 * w <= full) ? w : 0;
 }
 
 int validate_job(const gsh_bank* b, const gsh_corr_job& j, int idx)
@@ -332,6 +385,7 @@ extern "C"
         a.partials = b->d_partials;
         a.n_jobs = b->n_jobs;
         a.splits = splits;
+        a.window_floats = bank_window_floats(b, splits);
         hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : b->stream;
         if (b->ring != nullptr) GSH_HIP(hipStreamWaitEvent(s, b->ring->pushed, 0));  // conversions queued by gsh_stream_push_device
         return gsh::mcorr_launch(a, b->max_taps, b->mode, b->max_code_len, s);

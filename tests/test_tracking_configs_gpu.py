@@ -151,3 +151,44 @@ def test_config5_multi_constellation_256_channels(gpu):
     out_r = b.correlate(jobs[::-1])
     assert np.array_equal(out_r[::-1].view(np.float32), out.view(np.float32))
     b.close()
+
+
+@pytest.mark.parametrize("splits", [0, 1, 3, 4, 8, 16])
+def test_windowed_code_table_chip_selection_exact(gpu, splits):
+    """Long codes with split windows stage only the code samples a segment can touch (multicorrelator.hip, bank_window_floats).
+    With x[n] = 1, zero carrier and integer-valued sums every float32 addition is exact, so the result equals sum_n code[k_t[n]]
+    exactly iff every chip index -- including the ones at segment edges, in the masked head / tail chunks and across the code wrap --
+    matches the oracle's, whatever the split (splits = 1 keeps the whole code in LDS: the two stagings must agree)."""
+    g = golden_e1_l5_codes()
+    codes = [g["e1c"][3], g["l5q"][7], g["e1b"][9]]
+    n_stream = 260000
+    x = np.ones(n_stream, np.complex64)
+    b = _bank(gpu, codes)
+    b.set_stream_host(x)
+    b.set_splits(splits)
+    rng = np.random.default_rng(40 + splits)
+    jobs = []
+    for i in range(24):
+        slot = i % 3
+        L = len(codes[slot])
+        n = int(rng.choice([50000, 128000, 200000, 31337]))
+        step = np.float32((L / n) * rng.uniform(0.98, 1.02))          # about one code period per window
+        rem = np.float32(rng.uniform(0.0, 2.0))
+        shifts = [-1.0, -0.3, 0.0, 0.3, 1.0] if slot == 0 else ([0.0] if slot == 2 else [-0.5, 0.0, 0.5])
+        jobs.append(dict(sample_offset=int(rng.integers(0, n_stream - n)), n_samples=n, code_slot=slot, shifts_chips=shifts, rem_carr_phase_rad=0.0,
+                         phase_step_rad=0.0, rem_code_phase_chips=float(rem), code_phase_step_chips=float(step)))
+    # a window that runs over more than one code period (wraps inside a segment) and one with a large negative starting index
+    jobs.append(dict(sample_offset=11, n_samples=100000, code_slot=1, shifts_chips=[-0.5, 0.0, 0.5], rem_carr_phase_rad=0.0, phase_step_rad=0.0,
+                     rem_code_phase_chips=0.25, code_phase_step_chips=0.25))
+    jobs.append(dict(sample_offset=7, n_samples=60000, code_slot=0, shifts_chips=[-1.0, -0.3, 0.0, 0.3, 1.0], rem_carr_phase_rad=0.0, phase_step_rad=0.0,
+                     rem_code_phase_chips=5000.5, code_phase_step_chips=0.064))
+    out = b.correlate(jobs)
+    for j, job in enumerate(jobs):
+        sh = np.asarray(job["shifts_chips"], np.float32)
+        L = len(codes[job["code_slot"]])
+        idx = oracle.code_indices(job["n_samples"], sh, job["rem_code_phase_chips"], job["code_phase_step_chips"], 0.0, L, False)
+        expect = np.array([codes[job["code_slot"]][idx[t]].astype(np.float64).sum() for t in range(len(sh))])
+        got = out[j, :len(sh)]
+        assert np.array_equal(got.real.astype(np.float64), expect), (splits, j, job, got, expect)
+        assert np.all(got.imag == 0)
+    b.close()
