@@ -170,6 +170,7 @@ SYMBOLS = {
     "gsh_acq_create": (C.c_int, [C.c_int, C.POINTER(AcqConf), C.POINTER(_P)]),
     "gsh_acq_destroy": (None, [_P]),
     "gsh_acq_set_local_code": (C.c_int, [_P, C.c_uint32, _F]),
+    "gsh_spectrum_peak": (C.c_int, [C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_float)]),
     "gsh_pb_create": (C.c_int, [C.c_int, C.c_float, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_P)]),
     "gsh_pb_destroy": (None, [_P]),
     "gsh_pb_threshold": (C.c_float, [_P]),

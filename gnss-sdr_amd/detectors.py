@@ -226,3 +226,82 @@ class PcpsQuickSyncAcquisition:
         elif self.well_count == self.max_dwells:                                                  # :377-390
             self.state = 2 if self.test_statistics > self.threshold else 3
         return self.state
+
+
+class PcpsAcquisitionFineDoppler:
+    """pcps_acquisition_fine_doppler_cc for one channel (gnuradio_blocks/pcps_acquisition_fine_doppler_cc.cc, "fd.cc"): non-coherent
+    accumulation of max_dwells 1 ms grids and the peak-ratio statistic are the engine's accumulate path (gsh_acq_dwell with use_cfar = 0);
+    the fine-Doppler step is gsh_spectrum_peak.  consistent_grid: see FineDopplerOracle / host/hip_pcps_detectors.h."""
+
+    def __init__(self, fs_in: int, samples_per_ms: float, doppler_max: int, doppler_step: int, threshold: float, max_dwells: int,
+                 consistent_grid: bool = False, device: int = 0, transform_path: int = 0):
+        self.fs_in = fs_in
+        self.fft_size = int(samples_per_ms)
+        self.doppler_max, self.doppler_step = doppler_max, doppler_step
+        self.n_points = int(math.floor(abs(2 * doppler_max) / doppler_step))
+        self.threshold = np.float32(threshold)
+        self.max_dwells = max_dwells
+        self.device = device
+        spc = int(math.ceil((1.0 / 1.023e6) * float(np.float32(fs_in))))
+        self.bank = PcpsAcquisitionBank(fs_in, self.fft_size, doppler_max if consistent_grid else doppler_step, doppler_step, spc, float(self.fft_size),
+                                        max_prn=1, num_doppler_bins=self.n_points, use_cfar=False, device=device, transform_path=transform_path)
+        self.init()
+
+    def close(self):
+        self.bank.close()
+
+    def set_local_code(self, code: np.ndarray) -> None:                                          # fd.cc:130-136
+        self.code = np.ascontiguousarray(code[:self.fft_size], np.complex64).copy()
+        self.bank.set_local_code(0, self.code)
+
+    def init(self) -> None:                                                                      # state 0
+        self.well_count = 0
+        self.test_statistics = np.float32(0.0)
+        self.buffer = []
+        self.result = dict(acq_delay_samples=0.0, doppler_hz=0.0, doppler_step=0)
+        self.state = 1
+
+    def dwell(self, x: np.ndarray) -> int:                                                       # state 1
+        x = np.ascontiguousarray(x[:self.fft_size], np.complex64)
+        self.well_count += 1
+        self._last = self.bank.dwell(x, 1, accumulate=self.well_count > 1, dwell_count=self.well_count)[0]
+        self.buffer.append(x.copy())
+        if self.well_count >= self.max_dwells:
+            self.state = 2
+        return self.state
+
+    def decide(self) -> int:                                                                     # state 2 + compute_CAF
+        r = self._last
+        self.test_statistics = np.float32(r["test_statistics"])
+        self.result = dict(acq_delay_samples=float(r["index_time"]), doppler_hz=float(r["index_doppler"] * self.doppler_step - self.doppler_max),
+                           doppler_step=self.doppler_step, index_time=r["index_time"], index_doppler=r["index_doppler"])
+        self.state = 3 if self.test_statistics > self.threshold else 5
+        return self.state
+
+    def estimate_doppler(self, more: np.ndarray) -> int:                                         # state 3 + estimate_Doppler
+        import ctypes as C
+        from . import _lib
+        from ._lib import check, fptr
+        buf = np.ascontiguousarray(np.concatenate(self.buffer + [np.asarray(more, np.complex64)])[:10 * self.fft_size])
+        n, N = 10 * self.fft_size, self.fft_size
+        M = n * 8
+        rep = self.code.copy()
+        shift = int(self.result["acq_delay_samples"])
+        if shift != 0:
+            rep[:N - 1] = np.roll(rep[:N - 1], -((N - shift) % (N - 1)))                          # std::rotate over [0, N - 1), fd.cc:337-340
+        rep = np.ascontiguousarray(np.tile(rep, 10))
+        k = C.c_uint32(0)
+        pk = C.c_float(0.0)
+        check(_lib.load().gsh_spectrum_peak(self.device, fptr(buf), fptr(rep), n, M, C.byref(k), C.byref(pk)))
+        k = int(k.value)
+        self.fine_index = k
+        half = np.float32(M) / np.float32(2.0)
+        if k < M // 2:
+            f = (np.float32(self.fs_in) / np.float32(2.0)) * np.float32(k) / half
+        else:
+            f = (-np.float32(self.fs_in) / np.float32(2.0)) * np.float32(M // 2 - (k - M // 2)) / half
+        self.fine_doppler = float(np.float32(f))
+        if abs(np.float32(f) - np.float32(self.result["doppler_hz"])) < 1000:
+            self.result["doppler_hz"] = float(np.float32(f))
+        self.state = 4
+        return self.state

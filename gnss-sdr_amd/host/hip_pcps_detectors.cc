@@ -387,3 +387,144 @@ int Hip_Pcps_Quicksync_Core::work(uint64_t sample_counter, const std::complex<fl
         }
     return d_state;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------- fine Doppler
+Hip_Pcps_Fine_Doppler_Core::Hip_Pcps_Fine_Doppler_Core(const Hip_Acq_Conf& conf, bool consistent_grid, int device) : d_acq_params(conf), d_device(device)
+{
+    d_fft_size = static_cast<uint32_t>(conf.samples_per_ms);  // fd.cc:61
+    d_num_doppler_points = static_cast<int>(std::floor(std::abs(2 * conf.doppler_max) / conf.doppler_step));  // :58 (integer division, as there)
+    if (d_num_doppler_points < 1) return;
+    gsh_acq_conf c{};
+    c.fs_in = conf.fs_in;
+    c.fft_size = d_fft_size;
+    c.effective_fft_size = d_fft_size;
+    c.consumed_samples = d_fft_size;
+    c.num_doppler_bins = static_cast<uint32_t>(d_num_doppler_points);
+    // bin i is wiped off at -doppler_max' + doppler_step * i: doppler_max' = doppler_step gives fd.cc:170 to the letter
+    c.doppler_max = consistent_grid ? conf.doppler_max : conf.doppler_step;
+    c.doppler_step = conf.doppler_step;
+    c.samples_per_chip = static_cast<uint32_t>(std::ceil((1.0 / 1.023e6) * static_cast<float>(conf.fs_in)));  // :214
+    c.samples_per_code = static_cast<float>(d_fft_size);
+    c.use_cfar = 0;  // first to second peak, compute_CAF :182-236
+    c.max_prn = 1;
+    c.no_grid = 0;   // the grid accumulates over the dwells (:296)
+    if (gsh_acq_create(device, &c, &d_handle) != GSH_OK)
+        {
+            d_error = gsh_last_error();
+            d_handle = nullptr;
+        }
+    d_code.assign(d_fft_size, std::complex<float>(0.0F, 0.0F));
+    d_10_ms_buffer.reserve(10U * d_fft_size);
+}
+
+
+Hip_Pcps_Fine_Doppler_Core::~Hip_Pcps_Fine_Doppler_Core()
+{
+    if (d_handle != nullptr) gsh_acq_destroy(d_handle);
+}
+
+
+void Hip_Pcps_Fine_Doppler_Core::set_local_code(const std::complex<float>* code)
+{
+    if (d_handle == nullptr) return;
+    for (uint32_t i = 0; i < d_fft_size; i++) d_code[i] = code[i];
+    if (gsh_acq_set_local_code(d_handle, 0, reinterpret_cast<const float*>(code)) != GSH_OK) d_error = gsh_last_error();
+}
+
+
+void Hip_Pcps_Fine_Doppler_Core::reset_grid()
+{
+    d_result = Hip_Detector_Result();
+    d_well_count = 0;  // the first dwell overwrites the grid (accumulate = 0)
+    d_test_statistics = 0.0;
+    d_10_ms_buffer.clear();
+}
+
+
+int Hip_Pcps_Fine_Doppler_Core::compute_and_accumulate_grid(const std::complex<float>* in)
+{
+    if (d_handle == nullptr) return -1;
+    gsh_acq_result r{};
+    d_well_count++;
+    if (gsh_acq_dwell(d_handle, reinterpret_cast<const float*>(in), 1, d_well_count > 1 ? 1 : 0, static_cast<uint32_t>(d_well_count), &r) != GSH_OK)
+        {
+            d_error = gsh_last_error();
+            return -1;
+        }
+    d_last_statistic = r.test_statistics;
+    d_last_index_time = r.index_time;
+    d_last_index_doppler = r.index_doppler;
+    d_10_ms_buffer.insert(d_10_ms_buffer.end(), in, in + d_fft_size);  // fd.cc:451-452
+    return (d_well_count >= static_cast<int>(d_acq_params.max_dwells)) ? 2 : 1;
+}
+
+
+int Hip_Pcps_Fine_Doppler_Core::compute_CAF(uint64_t sample_counter)
+{
+    // the statistic of the accumulated grid was formed on the device by the last dwell (first peak, +-1 chip blanked, second peak)
+    d_test_statistics = d_last_statistic;
+    d_result.index_time = d_last_index_time;
+    d_result.index_doppler = d_last_index_doppler;
+    d_result.Acq_delay_samples = static_cast<double>(d_last_index_time);
+    d_result.Acq_doppler_hz = static_cast<double>(static_cast<int32_t>(d_last_index_doppler) * d_acq_params.doppler_step - d_acq_params.doppler_max);  // :243
+    d_result.Acq_samplestamp_samples = sample_counter;
+    d_result.Acq_doppler_step = static_cast<uint32_t>(d_acq_params.doppler_step);
+    return (d_test_statistics > d_acq_params.threshold) ? 3 : 5;
+}
+
+
+uint32_t Hip_Pcps_Fine_Doppler_Core::buffer_more(const std::complex<float>* in, uint32_t n_items)
+{
+    const size_t want = 10U * static_cast<size_t>(d_fft_size);
+    const size_t room = d_10_ms_buffer.size() < want ? want - d_10_ms_buffer.size() : 0;
+    const uint32_t take = static_cast<uint32_t>(std::min<size_t>(room, n_items));
+    d_10_ms_buffer.insert(d_10_ms_buffer.end(), in, in + take);
+    return take;
+}
+
+
+bool Hip_Pcps_Fine_Doppler_Core::estimate_Doppler()
+{
+    // Direct FFT
+    const int zero_padding_factor = 8;
+    const int prn_replicas = 10;
+    const int signal_samples = prn_replicas * static_cast<int>(d_fft_size);
+    const int fft_size_extended = signal_samples * zero_padding_factor;
+    if (d_10_ms_buffer.size() < static_cast<size_t>(signal_samples)) return false;
+
+    // 1. local code aligned with the acquisition code phase estimation: the replica handed to set_local_code is the one :333 generates
+    std::vector<std::complex<float>> code_replica(static_cast<size_t>(signal_samples));
+    for (uint32_t i = 0; i < d_fft_size; i++) code_replica[i] = d_code[i];
+    const int shift_index = static_cast<int>(d_result.Acq_delay_samples);
+    if (shift_index != 0)
+        {
+            // std::rotate(first, first + (d_fft_size - shift_index), first + d_fft_size - 1), :339 -- the last sample stays where it is
+            const int len = static_cast<int>(d_fft_size) - 1;
+            const int mid = static_cast<int>(d_fft_size) - shift_index;
+            std::vector<std::complex<float>> head(code_replica.begin(), code_replica.begin() + len);
+            for (int i = 0; i < len; i++) code_replica[i] = head[(i + mid) % len];
+        }
+    for (int n = 0; n < prn_replicas - 1; n++)
+        for (uint32_t i = 0; i < d_fft_size; i++) code_replica[(n + 1) * d_fft_size + i] = code_replica[i];
+
+    // 2.-4. code wipe-off, zero-padded FFT, |.|^2, arg-max: on the GPU
+    uint32_t tmp_index_freq = 0;
+    if (gsh_spectrum_peak(d_device, reinterpret_cast<const float*>(d_10_ms_buffer.data()), reinterpret_cast<const float*>(code_replica.data()),
+            static_cast<uint32_t>(signal_samples), static_cast<uint32_t>(fft_size_extended), &tmp_index_freq, nullptr) != GSH_OK)
+        {
+            d_error = gsh_last_error();
+            return false;
+        }
+    // fftFreqBins[tmp_index_freq], :361-373
+    float f;
+    const int half = fft_size_extended / 2;
+    if (static_cast<int>(tmp_index_freq) < half)
+        f = ((static_cast<float>(d_acq_params.fs_in) / 2.0F) * static_cast<float>(tmp_index_freq)) / (static_cast<float>(fft_size_extended) / 2.0F);
+    else
+        f = ((-static_cast<float>(d_acq_params.fs_in) / 2.0F) * static_cast<float>(half - (static_cast<int>(tmp_index_freq) - half))) / (static_cast<float>(fft_size_extended) / 2.0F);
+    d_fine_doppler_hz = f;
+    // 5. update the Doppler estimation in Hz
+    if (std::abs(f - d_result.Acq_doppler_hz) < 1000) d_result.Acq_doppler_hz = static_cast<double>(f);
+    return true;
+}

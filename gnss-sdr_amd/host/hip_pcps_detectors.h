@@ -5,6 +5,7 @@
  *   Hip_Pcps_Tong_Core         pcps_tong_acquisition_cc          (gnuradio_blocks/pcps_tong_acquisition_cc.cc, "tong.cc")
  *   Hip_Galileo_Pcps_8ms_Core  galileo_pcps_8ms_acquisition_cc   (gnuradio_blocks/galileo_pcps_8ms_acquisition_cc.cc, "8ms.cc")
  *   Hip_Pcps_Quicksync_Core    pcps_quicksync_acquisition_cc     (gnuradio_blocks/pcps_quicksync_acquisition_cc.cc, "qs.cc")
+ *   Hip_Pcps_Fine_Doppler_Core pcps_acquisition_fine_doppler_cc  (gnuradio_blocks/pcps_acquisition_fine_doppler_cc.cc, "fd.cc")
  *
  * Each class keeps the reference block's member names and its general_work state numbering: init() is state 0, work() is
  * one pass of state 1 over one input vector and returns the next state (1 = keep going, 2 = positive, 3 = negative).
@@ -151,6 +152,57 @@ private:
     int d_state{0};
     uint32_t d_samples_per_code, d_folding_factor, d_max_dwells, d_well_count{0};
     uint32_t d_fft_size{0}, d_num_doppler_bins{0};
+};
+
+/*!
+ * GPS_L1_CA_PCPS_Acquisition_Fine_Doppler.  Members follow the block: compute_and_accumulate_grid (state 1, fd.cc:266-305),
+ * compute_CAF (state 2, :182-251), estimate_Doppler (state 3, :316-389).
+ *
+ * consistent_grid: the block as written wipes bin i off at doppler_step * i - doppler_step (:170) but reports i * doppler_step -
+ * doppler_max (:243), so with doppler_max != doppler_step the reported grid Doppler is not the one that was searched and the fine
+ * estimate fails its 1 kHz plausibility check (:376).  false (default) reproduces the file to the letter; true searches the grid
+ * that :243 reports.
+ */
+class Hip_Pcps_Fine_Doppler_Core
+{
+public:
+    explicit Hip_Pcps_Fine_Doppler_Core(const Hip_Acq_Conf& conf, bool consistent_grid = false, int device = 0);
+    ~Hip_Pcps_Fine_Doppler_Core();
+    Hip_Pcps_Fine_Doppler_Core(const Hip_Pcps_Fine_Doppler_Core&) = delete;
+    Hip_Pcps_Fine_Doppler_Core& operator=(const Hip_Pcps_Fine_Doppler_Core&) = delete;
+
+    bool ok() const { return d_handle != nullptr; }
+    const std::string& last_error() const { return d_error; }
+
+    void set_local_code(const std::complex<float>* code);  //!< fd.cc:130-136; the replica is also kept for estimate_Doppler (:330-345)
+    void reset_grid();                                     //!< state 0, fd.cc:149-160, 438-448
+    /*! state 1: one block of d_fft_size samples into the grid and into the 10 ms buffer; returns the next state (1 or 2) */
+    int compute_and_accumulate_grid(const std::complex<float>* in);
+    /*! state 2: d_test_statistics and the Gnss_Synchro fields (:238-249); returns 3 (above threshold) or 5 */
+    int compute_CAF(uint64_t sample_counter);
+    /*! state 3: append up to 10 ms of further samples (:473-483); returns how many were taken */
+    uint32_t buffer_more(const std::complex<float>* in, uint32_t n_items);
+    bool buffer_full() const { return d_10_ms_buffer.size() >= 10U * d_fft_size; }
+    /*! state 3 -> 4: the zero-padded fine transform; false when it could not run (the grid Doppler then stands) */
+    bool estimate_Doppler();
+
+    const Hip_Detector_Result& result() const { return d_result; }
+    int num_doppler_points() const { return d_num_doppler_points; }
+    uint32_t fft_size() const { return d_fft_size; }
+    float test_statistics() const { return d_test_statistics; }
+    float fine_doppler_hz() const { return d_fine_doppler_hz; }
+    int well_count() const { return d_well_count; }
+
+private:
+    Hip_Acq_Conf d_acq_params;
+    gsh_acq* d_handle{nullptr};
+    std::string d_error;
+    Hip_Detector_Result d_result;
+    std::vector<std::complex<float>> d_code, d_10_ms_buffer;
+    float d_test_statistics{0.0F}, d_fine_doppler_hz{0.0F}, d_last_statistic{0.0F};
+    uint32_t d_last_index_time{0}, d_last_index_doppler{0};
+    int d_device{0}, d_num_doppler_points{0}, d_well_count{0};
+    uint32_t d_fft_size{0};
 };
 
 #endif

@@ -30,7 +30,7 @@ extern "C"
 {
 #endif
 
-#define GSH_ABI_VERSION 12
+#define GSH_ABI_VERSION 13
 #define GSH_MAX_TAPS 8 /* VE/E/P/L/VL needs 5 (trk.cc:609-650); 8 leaves room for multi-tap dumps */
 
     enum
@@ -470,6 +470,13 @@ extern "C"
      * presents the remainder again, followed by new samples, like the GNU Radio scheduler does).  In-place (out == in) is allowed. */
     int gsh_pb_process_device(gsh_pb_t* p, const void* device_in_iq, uint64_t n_items, void* device_out_iq, uint64_t* n_done);
     int gsh_pb_get_state(gsh_pb_t* p, float* noise_power_estimation, int32_t* n_segments, int32_t* last_filtered);
+
+    /* Fine-Doppler step of pcps_acquisition_fine_doppler_cc (gnuradio_blocks/pcps_acquisition_fine_doppler_cc.cc:316-389): the
+     * n complex64 samples x (host), multiplied element-wise by w when w != NULL (the aligned code replica: code wipe-off, :348), are
+     * zero-padded to fft_size, transformed, and the index of the largest |X[k]|^2 (lowest k among equal maxima, :354-358) is returned;
+     * `peak` (nullable) receives that |X|^2.  fft_size needs a four-step split (n1 <= 1024, n2 <= 2048, prime factors <= 31):
+     * up to ~2 M points, i.e. the block's 80 x samples_per_ms up to 25 Msps. */
+    int gsh_spectrum_peak(int device, const float* x_iq, const float* w_iq, uint32_t n, uint32_t fft_size, uint32_t* index, float* peak);
 
     /* compute_threshold, acq.cc:52-56: 2*gamma_p_inv(2*max_dwells, (1-pfa)^(1/(effective*bins))) */
     float gsh_acq_compute_threshold(float pfa, uint32_t effective_fft_size, uint32_t num_doppler_bins, uint32_t max_dwells);

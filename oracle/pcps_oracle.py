@@ -470,3 +470,87 @@ class QuickSyncOracle:
         elif self.well_count == self.max_dwells:
             self.state = 3
         return self.state
+
+
+class FineDopplerOracle:
+    """pcps_acquisition_fine_doppler_cc (gnuradio_blocks/pcps_acquisition_fine_doppler_cc.cc, "fd.cc"): max_dwells 1 ms blocks are
+    accumulated non-coherently into a Doppler x delay grid (:266-305), the first-to-second-peak ratio decides (:182-251), and on success
+    ten code periods of signal are code-wiped and transformed with eightfold zero padding to refine the Doppler (:316-389).
+
+    Two things are reproduced as the file has them: the wipe-off frequency of bin i is doppler_step * i - doppler_step (:170) although
+    the reported Doppler is i * doppler_step - doppler_max (:243), and the replica alignment rotates only the first fft_size - 1
+    samples (:339, the `- 1` in the last iterator)."""
+
+    def __init__(self, fs_in: int, samples_per_ms: float, doppler_max: int, doppler_step: int, threshold: float, max_dwells: int,
+                 consistent_grid: bool = False):
+        """consistent_grid=True wipes bin i off at i * doppler_step - doppler_max, the Doppler :243 reports for it (what :170 evidently
+        means); False follows :170 to the letter."""
+        self.fs_in = fs_in
+        self.fft_size = int(samples_per_ms)                                                      # fd.cc:61
+        self.doppler_max, self.doppler_step = doppler_max, doppler_step
+        self.n_points = int(math.floor(abs(2 * doppler_max) / doppler_step))                      # :58
+        self.threshold = np.float32(threshold)
+        self.max_dwells = max_dwells
+        spc = int(math.ceil((1.0 / 1.023e6) * float(np.float32(fs_in))))                          # :214
+        # the grid the block actually searches: bin i at doppler_step * i - doppler_step (:170)
+        self.p = PcpsOracle(fs_in, self.fft_size, doppler_max if consistent_grid else doppler_step, doppler_step, spc, float(self.fft_size),
+                            num_doppler_bins=self.n_points, use_cfar=False)
+        self.init()
+
+    def set_local_code(self, code: np.ndarray):                                                  # :130-136
+        self.code = np.asarray(code[:self.fft_size], np.complex64).copy()
+        self.p.set_local_code(self.code)
+
+    def init(self):                                                                              # state 0, :438-448
+        self.well_count = 0
+        self.test_statistics = np.float32(0.0)
+        self.buffer = []
+        self.result = dict(acq_delay_samples=0.0, doppler_hz=0.0, doppler_step=0)
+        self.state = 1
+
+    def dwell(self, x: np.ndarray) -> int:                                                       # state 1, :449-459
+        x = np.asarray(x[:self.fft_size], np.complex64)
+        self.well_count += 1
+        self.p.doppler_grid(x, self.well_count)                                                   # :266-305 (accumulates)
+        self.buffer.append(x.copy())
+        if self.well_count >= self.max_dwells:
+            self.state = 2
+        return self.state
+
+    def decide(self) -> int:                                                                     # state 2, :460-472 + compute_CAF :182-251
+        st = self.p.statistics(self.well_count)
+        self.test_statistics = np.float32(st["test_statistics"])
+        self.result = dict(acq_delay_samples=float(st["index_time"]), doppler_hz=float(st["index_doppler"] * self.doppler_step - self.doppler_max),
+                           doppler_step=self.doppler_step, index_time=st["index_time"], index_doppler=st["index_doppler"])
+        self.state = 3 if self.test_statistics > self.threshold else 5
+        return self.state
+
+    def estimate_doppler(self, more: np.ndarray) -> int:                                         # state 3, :473-489 + :316-389
+        """`more`: the samples that follow the dwell blocks (the block keeps copying input until it holds 10 ms)."""
+        buf = np.concatenate(self.buffer + [np.asarray(more, np.complex64)])[:10 * self.fft_size]
+        n, N = 10 * self.fft_size, self.fft_size
+        M = n * 8                                                                                # :319-323
+        rep = self.code.copy()
+        shift = int(self.result["acq_delay_samples"])
+        if shift != 0:                                                                           # :337-340: std::rotate over [0, N - 1)
+            head = rep[:N - 1]
+            rep[:N - 1] = np.roll(head, -((N - shift) % (N - 1)))
+        rep = np.tile(rep, 10)
+        z = np.zeros(M, np.complex64)
+        z[:n] = (buf * rep).astype(np.complex64)                                                 # :348
+        Z = scipy.fft.fft(z)
+        mag = (Z.real * Z.real + Z.imag * Z.imag).astype(np.float32)
+        t = np.zeros(1, np.uint32)
+        lib().oracle_index_max(t, np.ascontiguousarray(mag), M)
+        k = int(t[0])
+        self.fine_index = k
+        half = np.float32(M) / np.float32(2.0)
+        if k < M // 2:                                                                           # :363-373
+            f = (np.float32(self.fs_in) / np.float32(2.0)) * np.float32(k) / half
+        else:
+            f = (-np.float32(self.fs_in) / np.float32(2.0)) * np.float32(M // 2 - (k - M // 2)) / half
+        self.fine_doppler = float(np.float32(f))
+        if abs(np.float32(f) - np.float32(self.result["doppler_hz"])) < 1000:                     # :376-384
+            self.result["doppler_hz"] = float(np.float32(f))
+        self.state = 4
+        return self.state

@@ -61,3 +61,12 @@ def quicksync_case(fs: int = 8000000, folding_factor: int = 4, signal: bool = Tr
     threshold = {(8000000, 4): 0.7, (4000000, 4): 1.0, (8000000, 2): 0.033}[(fs, folding_factor)]
     kw = dict(fs_in=fs, samples_per_code=spc, folding_factor=folding_factor, doppler_max=10000, doppler_step=250, threshold=threshold, max_dwells=1)
     return x, kw, oracle.ca_code_complex_sampled(10, fs)
+
+
+def fine_doppler_case(doppler_hz: float = 1730.0, fs: int = 4000000, seed: int = 77, signal: bool = True):
+    """GPS L1 C/A, PRN 10, 600 chips, 47 dB-Hz, 12 ms of signal at 4 Msps; doppler_max 5000, step 500, 2 dwells, peak-ratio threshold 2.5."""
+    n = fs // 1000
+    x = synth_gps_l1_stream(12 * n, fs, [10] if signal else [], [doppler_hz] if signal else [], [1023.0 - 600.0] if signal else [], cn0_dbhz=47.0,
+                            seed_noise=seed)
+    kw = dict(fs_in=fs, samples_per_ms=float(n), doppler_max=5000, doppler_step=500, threshold=2.5, max_dwells=2)
+    return x, kw, oracle.ca_code_complex_sampled(10, fs)

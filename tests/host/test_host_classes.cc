@@ -333,6 +333,37 @@ int main()
         const auto d3 = hip_design_acq_resampler(3000000U, 2e6);
         EXPECT(d3.decimation == 1 && d3.taps.empty() && d3.resampler_latency == 0, "3 Msps: resampler disabled");
     }
+    // ---------------------------------------------------------------- fine-Doppler acquisition, pcps_acquisition_fine_doppler_cc call pattern
+    {
+        const double amp = std::sqrt(std::pow(10.0, 4.7) * 2.0 / 4e6);
+        auto x = make_signal(12 * 4000, 4e6, 10, 1580.0, 1023.0 - 600.0, amp, 77);
+        Hip_Acq_Conf conf;
+        conf.fs_in = 4000000;
+        conf.doppler_max = 5000;
+        conf.doppler_step = 500;
+        conf.max_dwells = 2;
+        conf.threshold = 2.5F;
+        conf.SetDerivedParams();
+        std::vector<float> code_iq(2 * 4000);
+        oracle_gps_l1_ca_code_gen_complex_sampled(code_iq.data(), 10, 4000000, 0);
+        for (int consistent = 0; consistent < 2; consistent++)
+            {
+                Hip_Pcps_Fine_Doppler_Core fd(conf, consistent != 0, 0);
+                EXPECT(fd.ok() && fd.num_doppler_points() == 20 && fd.fft_size() == 4000, "fine doppler create: %s", fd.last_error().c_str());
+                fd.set_local_code(reinterpret_cast<const std::complex<float>*>(code_iq.data()));
+                fd.reset_grid();
+                EXPECT(fd.compute_and_accumulate_grid(x.data()) == 1, "first dwell");
+                EXPECT(fd.compute_and_accumulate_grid(x.data() + 4000) == 2, "second dwell");
+                EXPECT(fd.compute_CAF(8000) == 3 && fd.test_statistics() > 5.0F, "CAF: statistic %g", fd.test_statistics());
+                EXPECT(std::abs(600.0 - fd.result().Acq_delay_samples * 1023.0 / 4000.0) < 0.5, "fine doppler delay %f", fd.result().Acq_delay_samples);
+                EXPECT(fd.result().Acq_doppler_hz == (consistent ? 1500.0 : -3000.0), "grid doppler %f (consistent %d)", fd.result().Acq_doppler_hz, consistent);
+                EXPECT(fd.buffer_more(x.data() + 8000, 40000) == 32000 && fd.buffer_full(), "10 ms buffer");
+                EXPECT(fd.estimate_Doppler(), "estimate_Doppler: %s", fd.last_error().c_str());
+                EXPECT(std::abs(fd.fine_doppler_hz() - 1580.0F) <= 12.5F, "fine doppler %f", fd.fine_doppler_hz());
+                EXPECT(fd.result().Acq_doppler_hz == (consistent ? static_cast<double>(fd.fine_doppler_hz()) : -3000.0), "reported doppler %f (consistent %d)",
+                    fd.result().Acq_doppler_hz, consistent);
+            }
+    }
     if (fails == 0) std::printf("HOST CLASSES OK\n");
     return fails == 0 ? 0 : 1;
 }

@@ -3,8 +3,8 @@ reference's own synthetic test cases (gps_l1_ca_pcps_tong_acquisition_gsoc2013_t
 galileo_e1_pcps_8ms_ambiguous_acquisition_gsoc2013_test.cc): delay error < 0.5 chip, Doppler error < 2 / (3 T)."""
 import numpy as np
 
-from oracle.pcps_oracle import Galileo8msOracle, QuickSyncOracle, TongOracle, count_doppler_bins, mean_input_power
-from detector_cases import e1_8ms_case, quicksync_case, tong_case
+from oracle.pcps_oracle import FineDopplerOracle, Galileo8msOracle, QuickSyncOracle, TongOracle, count_doppler_bins, mean_input_power
+from detector_cases import e1_8ms_case, fine_doppler_case, quicksync_case, tong_case
 
 
 def test_bin_count_is_inclusive():
@@ -93,3 +93,28 @@ def test_quicksync_known_answer_and_alias_resolution():
     o = QuickSyncOracle(**kw)
     o.set_local_code(code)
     assert o.work(x) == 3
+
+
+def test_fine_doppler_block_as_written_and_with_the_consistent_grid():
+    """The block's grid bin i is wiped off at doppler_step * i - doppler_step (fd.cc:170) but reported as i * doppler_step - doppler_max
+    (:243).  As written: a 1730 Hz signal is found in bin 4 (1500 Hz), reported as -3000 Hz, and the fine estimate (1737.5 Hz, 12.5 Hz
+    resolution) is rejected by the 1 kHz plausibility check (:376).  With the consistent grid the same signal is reported at 1500 Hz and
+    refined to 1737.5 Hz."""
+    x, kw, code = fine_doppler_case()
+    n = 4000
+    for consistent in (False, True):
+        o = FineDopplerOracle(consistent_grid=consistent, **kw)
+        assert o.n_points == 20 and o.fft_size == n
+        o.set_local_code(code)
+        assert o.dwell(x[:n]) == 1 and o.dwell(x[n:2 * n]) == 2
+        assert o.decide() == 3 and float(o.test_statistics) > 5.0
+        assert abs(600.0 - o.result["acq_delay_samples"] * 1023.0 / n) < 0.5
+        assert o.result["doppler_hz"] == (1500.0 if consistent else -3000.0)
+        assert o.estimate_doppler(x[2 * n:]) == 4
+        assert abs(o.fine_doppler - 1730.0) <= 12.5
+        assert o.result["doppler_hz"] == (o.fine_doppler if consistent else -3000.0)
+    x, kw, code = fine_doppler_case(signal=False, seed=5)
+    o = FineDopplerOracle(**kw)
+    o.set_local_code(code)
+    o.dwell(x[:n]); o.dwell(x[n:2 * n])
+    assert o.decide() == 5

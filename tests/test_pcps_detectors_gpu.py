@@ -6,8 +6,8 @@ RTOL (float32 transforms of different factorisation)."""
 import numpy as np
 import pytest
 
-from oracle.pcps_oracle import Galileo8msOracle, QuickSyncOracle, TongOracle
-from detector_cases import e1_8ms_case, quicksync_case, tong_case
+from oracle.pcps_oracle import FineDopplerOracle, Galileo8msOracle, QuickSyncOracle, TongOracle
+from detector_cases import e1_8ms_case, fine_doppler_case, quicksync_case, tong_case
 
 pytestmark = pytest.mark.gpu
 
@@ -184,3 +184,48 @@ def test_fold_conf_rules(gpu):
     ref = np.array([x[:4000].astype(np.complex128).sum(), x[12000:].astype(np.complex128).sum()])
     assert np.max(np.abs(got - ref)) <= 1e-5 * np.max(np.abs(ref)) + 1e-4
     b.close()
+
+
+@pytest.mark.parametrize("consistent", [False, True])
+@pytest.mark.parametrize("fs", [4000000, 25000000])
+def test_fine_doppler_matches_oracle(gpu, consistent, fs):
+    """Accumulated grid + peak-ratio decision + zero-padded fine-Doppler transform (320 000 points at 4 Msps, 2 000 000 at 25 Msps):
+    states, delay, grid Doppler and the fine transform's arg-max equal the oracle's."""
+    from gnss_sdr_amd.detectors import PcpsAcquisitionFineDoppler
+    x, kw, code = fine_doppler_case(fs=fs)
+    n = fs // 1000
+    o = FineDopplerOracle(consistent_grid=consistent, **kw)
+    g = PcpsAcquisitionFineDoppler(consistent_grid=consistent, device=gpu, **kw)
+    o.set_local_code(code)
+    g.set_local_code(code)
+    for k in range(2):
+        assert g.dwell(x[k * n:(k + 1) * n]) == o.dwell(x[k * n:(k + 1) * n])
+    assert g.decide() == o.decide() == 3
+    assert g.result == o.result
+    assert abs(float(g.test_statistics) - float(o.test_statistics)) <= RTOL * float(o.test_statistics)
+    assert g.estimate_doppler(x[2 * n:]) == o.estimate_doppler(x[2 * n:]) == 4
+    assert g.fine_index == o.fine_index and g.fine_doppler == o.fine_doppler and g.result == o.result
+    assert abs(g.fine_doppler - 1730.0) <= fs / (80.0 * n) + 1e-6
+    g.close()
+
+
+def test_spectrum_peak_primitive(gpu):
+    import ctypes as C
+    from gnss_sdr_amd import _lib
+    from gnss_sdr_amd._lib import GshError, check, fptr
+    lib = _lib.load()
+    rng = np.random.default_rng(9)
+    n, M = 3000, 24000
+    x = (0.1 * (rng.standard_normal(n) + 1j * rng.standard_normal(n)) + np.exp(2j * np.pi * (-5000.5 / M) * np.arange(n))).astype(np.complex64)
+    k, pk = C.c_uint32(0), C.c_float(0.0)
+    check(lib.gsh_spectrum_peak(gpu, fptr(x), None, n, M, C.byref(k), C.byref(pk)))
+    z = np.zeros(M, np.complex128)
+    z[:n] = x
+    Z = np.abs(np.fft.fft(z)) ** 2
+    assert int(k.value) == int(np.argmax(Z)) and abs(pk.value - Z.max()) <= 1e-4 * Z.max()
+    # equal maxima: a real-valued input has |X[k]| = |X[M - k]|; the lower index wins (volk_gnsssdr_32f_index_max_32u)
+    xr = np.cos(2 * np.pi * 100.0 / 1000 * np.arange(1000)).astype(np.complex64)
+    check(lib.gsh_spectrum_peak(gpu, fptr(xr), None, 1000, 1000, C.byref(k), C.byref(pk)))
+    assert int(k.value) == 100
+    with pytest.raises(GshError):
+        check(lib.gsh_spectrum_peak(gpu, fptr(x), None, n, 2 * 1009 * 1013, C.byref(k), C.byref(pk)))   # no four-step split
