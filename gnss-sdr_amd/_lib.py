@@ -144,6 +144,7 @@ SYMBOLS = {
     "gsh_bank_synchronize": (C.c_int, [_P]),
     "gsh_bank_read_outputs": (C.c_int, [_P, _F, C.c_int]),
     "gsh_bank_time_launches": (C.c_int, [_P, C.c_int, _F]),
+    "gsh_bank_set_pair_fusion": (C.c_int, [_P, C.c_int]),
     "gsh_bank_set_splits": (C.c_int, [_P, C.c_int]),
     "gsh_bank_set_stream_ring": (C.c_int, [_P, _P]),
     "gsh_stream_create": (C.c_int, [C.c_int, C.c_uint64, C.c_uint32, C.POINTER(_P)]),

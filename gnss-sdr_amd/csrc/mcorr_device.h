@@ -126,14 +126,22 @@ struct JobCtx
     // indexed through k_off.  k_hi < k_lo: the whole code is staged (no window).
     int k_lo{0}, k_hi{-1};
     int k_off{MC_MARGIN};  // tab[k + k_off] is code sample k (window: -k_lo)
+    // fused second correlator (AUX kernels): one more tap over the same rotated samples with ANOTHER code -- the data-component prompt that
+    // track_pilot adds to a pilot channel (trk.cc:1246-1256), which the reference runs as a second pass over the window
+    bool aux_on{false};
+    bool aux_zero{false};   // its shift is exactly 0.0f: on the ZP path it shares the prompt tap's chip index
+    float aux_shift{0.0f};
+    int aux_code_len{1};
+    int aux_k_off{MC_MARGIN};
+    int aux_k_lo{0}, aux_k_hi{-1};
 };
 
 // One chunk = 256 pairs = 512 consecutive samples; thread `tid` owns samples n0, n0+1.
 // ZP: the centre tap's shift is exactly 0.0f (the prompt of an E/P/L or VE/E/P/L/VL set): (a + 0.0f) == a, so its add is skipped.
 // nf0 = (float)n0, maintained by the caller (exact: sample indices stay below 2^24).
-template <int NT, int MODE, bool WRAP, bool MASKED, bool ZP = false>
+template <int NT, int MODE, bool WRAP, bool MASKED, bool ZP = false, bool AUX = false>
 __device__ __forceinline__ void process_pair(const JobCtx& c, const float2* __restrict__ base, const float* __restrict__ tab,
-    const float (&sh)[NT], const int (&rot)[NT], int pair, float2 pa, float2 pb, float2 (&acc)[NT], float nf0)
+    const float (&sh)[NT], const int (&rot)[NT], int pair, float2 pa, float2 pb, float2 (&acc)[NT], float nf0, float2* acc_aux = nullptr)
 {
     const int n0 = c.n_first + 2 * pair;
     float2 x0, x1;
@@ -159,6 +167,7 @@ __device__ __forceinline__ void process_pair(const JobCtx& c, const float2* __re
             // (float)(n0 + 1): on the ZP path (selected only for windows shorter than 2^24 samples) nf0 + 1.0f is exactly that value
             const float nf1 = ZP ? __fadd_rn(nf0, 1.0f) : static_cast<float>(n0 + 1);
             const float a1 = __fmul_rn(c.code_step, nf1);
+            int kz0 = 0, kz1 = 0;  // the zero-shift prompt's raw indices (ZP), shared with a zero-shift fused tap
 #pragma unroll
             for (int t = 0; t < NT; t++)
                 {
@@ -167,6 +176,8 @@ __device__ __forceinline__ void process_pair(const JobCtx& c, const float2* __re
                         {
                             k0 = floor_to_int(__fsub_rn(a0, c.rem_code));
                             k1 = floor_to_int(__fsub_rn(a1, c.rem_code));
+                            kz0 = k0;
+                            kz1 = k1;
                         }
                     else
                         {
@@ -200,6 +211,45 @@ __device__ __forceinline__ void process_pair(const JobCtx& c, const float2* __re
                     acc[t].x = fmaf(y1.x, c1, acc[t].x);
                     acc[t].y = fmaf(y1.y, c1, acc[t].y);
                 }
+            if (AUX && c.aux_on)
+                {
+                    // the fused correlator: same samples, same rotation, its own code table (and window) behind the first one in LDS
+                    int k0, k1;
+                    if (ZP && c.aux_zero)
+                        {
+                            k0 = kz0;
+                            k1 = kz1;
+                        }
+                    else
+                        {
+                            k0 = raw_chip_std(a0, c.aux_shift, c.rem_code);
+                            k1 = raw_chip_std(a1, c.aux_shift, c.rem_code);
+                        }
+                    if (WRAP)
+                        {
+                            k0 = wrap_chip(k0, c.aux_code_len);
+                            k1 = wrap_chip(k1, c.aux_code_len);
+                        }
+                    if (MASKED)
+                        {
+                            if (c.aux_k_hi >= c.aux_k_lo)
+                                {
+                                    k0 = min(max(k0, c.aux_k_lo), c.aux_k_hi);
+                                    k1 = min(max(k1, c.aux_k_lo), c.aux_k_hi);
+                                }
+                            else
+                                {
+                                    k0 = wrap_chip(k0, c.aux_code_len);
+                                    k1 = wrap_chip(k1, c.aux_code_len);
+                                }
+                        }
+                    const float c0 = tab[k0 + c.aux_k_off];
+                    const float c1 = tab[k1 + c.aux_k_off];
+                    acc_aux->x = fmaf(y0.x, c0, acc_aux->x);
+                    acc_aux->y = fmaf(y0.y, c0, acc_aux->y);
+                    acc_aux->x = fmaf(y1.x, c1, acc_aux->x);
+                    acc_aux->y = fmaf(y1.y, c1, acc_aux->y);
+                }
         }
     else
         {
@@ -228,9 +278,9 @@ __device__ __forceinline__ void process_pair(const JobCtx& c, const float2* __re
         }
 }
 
-template <int NT, int MODE, bool WRAP, bool ZP = false>
+template <int NT, int MODE, bool WRAP, bool ZP = false, bool AUX = false>
 __device__ __forceinline__ void run_segment(const JobCtx& c, const float2* __restrict__ base, const float* __restrict__ tab,
-    const float (&sh)[NT], const int (&rot)[NT], float2 (&acc)[NT])
+    const float (&sh)[NT], const int (&rot)[NT], float2 (&acc)[NT], float2* acc_aux = nullptr)
 {
     const int tid = threadIdx.x;
     const int span = c.n_end - c.n_first;          // samples covered from pair 0's first element
@@ -251,7 +301,7 @@ __device__ __forceinline__ void run_segment(const JobCtx& c, const float2* __res
                     const int n0 = c.n_first + 2 * pair;
                     const float2 pa = expmj(carrier_phase<HDP>(c.rem_carr, c.phase_step, c.phase_rate, n0));
                     const float2 pb = expmj(carrier_phase<HDP>(c.rem_carr, c.phase_step, c.phase_rate, n0 + 1));
-                    process_pair<NT, MODE, WRAP, true>(c, base, tab, sh, rot, pair, pa, pb, acc, static_cast<float>(n0));
+                    process_pair<NT, MODE, WRAP, true, false, AUX>(c, base, tab, sh, rot, pair, pa, pb, acc, static_cast<float>(n0), acc_aux);
                 }
         }
 
@@ -267,7 +317,7 @@ __device__ __forceinline__ void run_segment(const JobCtx& c, const float2* __res
                             const int n0 = c.n_first + 2 * pair;
                             const float2 pa = expmj(carrier_phase<true>(c.rem_carr, c.phase_step, c.phase_rate, n0));
                             const float2 pb = expmj(carrier_phase<true>(c.rem_carr, c.phase_step, c.phase_rate, n0 + 1));
-                            process_pair<NT, MODE, WRAP, false>(c, base, tab, sh, rot, pair, pa, pb, acc, static_cast<float>(n0));
+                            process_pair<NT, MODE, WRAP, false, false, AUX>(c, base, tab, sh, rot, pair, pa, pb, acc, static_cast<float>(n0), acc_aux);
                         }
                 }
             else
@@ -288,7 +338,7 @@ __device__ __forceinline__ void run_segment(const JobCtx& c, const float2* __res
 #pragma unroll 2
                             for (int i = 0; i < cnt; i++)
                                 {
-                                    process_pair<NT, MODE, WRAP, false, ZP>(c, base, tab, sh, rot, pair, pa, pb, acc, nf0);
+                                    process_pair<NT, MODE, WRAP, false, ZP, AUX>(c, base, tab, sh, rot, pair, pa, pb, acc, nf0, acc_aux);
                                     pa = cmul(pa, w);
                                     pb = cmul(pb, w);
                                     pair += MC_PAIRS_PER_CHUNK;
@@ -307,7 +357,7 @@ __device__ __forceinline__ void run_segment(const JobCtx& c, const float2* __res
                     const int n0 = c.n_first + 2 * pair;
                     const float2 pa = expmj(carrier_phase<HDP>(c.rem_carr, c.phase_step, c.phase_rate, n0));
                     const float2 pb = expmj(carrier_phase<HDP>(c.rem_carr, c.phase_step, c.phase_rate, n0 + 1));
-                    process_pair<NT, MODE, WRAP, true>(c, base, tab, sh, rot, pair, pa, pb, acc, static_cast<float>(n0));
+                    process_pair<NT, MODE, WRAP, true, false, AUX>(c, base, tab, sh, rot, pair, pa, pb, acc, static_cast<float>(n0), acc_aux);
                 }
         }
 }

@@ -20,6 +20,8 @@ struct McorrArgs
     int n_jobs;
     int splits;
     int window_floats;               // > 0: LDS holds only a window of the code per work-group (all jobs: mode 0, code_step >= 0); 0: the whole code
+    const int* aux;                  // device, n_jobs, or nullptr.  aux[j] >= 0: job j also computes the single tap of job aux[j] (same window and
+                                     // NCO, another code) and writes its output row; -2: job j is computed by its leader; -1: plain job
 };
 
 // Largest n_taps over the jobs and which mode combinations occur decide the template
@@ -30,6 +32,8 @@ int mcorr_launch(const McorrArgs& args, int max_taps, int mode, int max_code_len
 size_t mcorr_lds_bytes(int max_code_len);
 // the same when only `window_floats` code samples are staged per work-group
 size_t mcorr_lds_bytes_window(int window_floats);
+// LDS bytes with room for the fused correlator's second code table (aux != nullptr)
+size_t mcorr_lds_bytes_fused(int max_code_len, int window_floats);
 }  // namespace gsh
 
 #endif

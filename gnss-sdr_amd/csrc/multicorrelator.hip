@@ -35,8 +35,8 @@ namespace
 {
 using namespace mcdev;
 
-template <int NT, int MODE>
-__global__ __launch_bounds__(MC_THREADS, (NT <= 3 ? 8 : 1)) void mcorr_kernel(McorrArgs a)  // E/P/L: 8 waves per SIMD (<= 64 VGPRs)
+template <int NT, int MODE, bool AUX>
+__global__ __launch_bounds__(MC_THREADS, ((NT <= 3 && !AUX) ? 8 : 1)) void mcorr_kernel(McorrArgs a)  // E/P/L: 8 waves per SIMD (<= 64 VGPRs)
 {
     extern __shared__ __align__(16) float lds[];
     const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
@@ -44,6 +44,8 @@ __global__ __launch_bounds__(MC_THREADS, (NT <= 3 ? 8 : 1)) void mcorr_kernel(Mc
     const int split = static_cast<int>(lb) - job * a.splits;
     const gsh_corr_job& J = a.jobs[job];
     const int tid = threadIdx.x;
+    const int aux_job = AUX ? a.aux[job] : -1;
+    if (AUX && aux_job == -2) return;  // computed (and its output row written) by the job in front of it
 
     JobCtx c;
     c.n_total = J.n_samples;
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(MC_THREADS, (NT <= 3 ? 8 : 1)) void mcorr_kernel(Mc
     // 10 230-chip code does not cost 41 KB of LDS per work-group and with it most of the compute unit's occupancy
     float* tab = lds;
     const float* __restrict__ gcode = a.codes + static_cast<size_t>(J.code_slot) * a.code_stride;
-    bool windowed = false, misfit = false;
+    bool windowed = false, misfit = false, aux_fast = true;
     int lds_floats;
     if (a.window_floats > 0)
         {
@@ -129,33 +131,75 @@ __global__ __launch_bounds__(MC_THREADS, (NT <= 3 ? 8 : 1)) void mcorr_kernel(Mc
         {
             const int tab_len = c.code_len + 2 * MC_MARGIN;
             for (int i = tid; i < tab_len; i += MC_THREADS) tab[i] = gcode[wrap_chip(i - MC_MARGIN, c.code_len)];
-            lds_floats = tab_len;
+            lds_floats = AUX ? a.code_stride + 2 * MC_MARGIN : tab_len;
         }
+    // ---- the fused correlator's code (AUX): a second table behind the first
+    if (AUX && aux_job >= 0 && !misfit)
+        {
+            const gsh_corr_job& J2 = a.jobs[aux_job];
+            const float* __restrict__ gcode2 = a.codes + static_cast<size_t>(J2.code_slot) * a.code_stride;
+            c.aux_on = true;
+            c.aux_shift = J2.shifts_chips[0];
+            c.aux_zero = (c.aux_shift == 0.0f);
+            c.aux_code_len = a.code_lens[J2.code_slot];
+            const int aux_base = (lds_floats + 3) & ~3;
+            int lo2 = 0, hi2 = -1;
+            if (c.n_end > c.n_begin)
+                {
+                    lo2 = raw_chip_std(__fmul_rn(c.code_step, static_cast<float>(c.n_begin)), c.aux_shift, c.rem_code);
+                    hi2 = raw_chip_std(__fmul_rn(c.code_step, static_cast<float>(c.n_end - 1)), c.aux_shift, c.rem_code);
+                }
+            if (a.window_floats > 0)
+                {
+                    const long long span2 = static_cast<long long>(hi2) - lo2 + 1;
+                    if (windowed && span2 >= 1 && span2 <= a.window_floats)
+                        {
+                            for (int i = tid; i < static_cast<int>(span2); i += MC_THREADS) tab[aux_base + i] = gcode2[wrap_chip(lo2 + i, c.aux_code_len)];
+                            c.aux_k_lo = lo2;
+                            c.aux_k_hi = hi2;
+                            c.aux_k_off = aux_base - lo2;
+                        }
+                    else
+                        misfit = (c.n_end > c.n_begin);
+                }
+            else
+                {
+                    const int tab_len2 = c.aux_code_len + 2 * MC_MARGIN;
+                    for (int i = tid; i < tab_len2; i += MC_THREADS) tab[aux_base + i] = gcode2[wrap_chip(i - MC_MARGIN, c.aux_code_len)];
+                    c.aux_k_off = aux_base + MC_MARGIN;
+                    aux_fast = (lo2 >= -MC_MARGIN) && (hi2 < c.aux_code_len + MC_MARGIN) && (c.aux_code_len >= MC_MARGIN);
+                }
+            lds_floats = aux_base + (a.window_floats > 0 ? a.window_floats : a.code_stride + 2 * MC_MARGIN);
+        }
+    else if (AUX)
+        lds_floats = ((lds_floats + 3) & ~3) + (a.window_floats > 0 ? a.window_floats : a.code_stride + 2 * MC_MARGIN);  // same `red` place for every work-group
     float2* red = reinterpret_cast<float2*>(lds + ((lds_floats + 3) & ~3));
 
     float2 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; t++) acc[t] = make_float2(0.0f, 0.0f);
+    float2 acc_aux = make_float2(0.0f, 0.0f);
 
-    __syncthreads();  // code table visible
+    __syncthreads();  // code table(s) visible
 
     if (misfit)
         {
 #pragma unroll
             for (int t = 0; t < NT; t++) acc[t] = make_float2(__builtin_nanf(""), __builtin_nanf(""));
+            acc_aux = make_float2(__builtin_nanf(""), __builtin_nanf(""));
         }
     else if (c.n_end > c.n_begin)
         {
             // skip the per-sample wrap when the indices stay inside what is staged
-            const bool fast = windowed || (!mode_hd_code(MODE) && (c.code_step >= 0.0f) && (lo >= -MC_MARGIN) && (hi < c.code_len + MC_MARGIN) && (c.code_len >= MC_MARGIN));
+            const bool fast = windowed || (!mode_hd_code(MODE) && (c.code_step >= 0.0f) && (lo >= -MC_MARGIN) && (hi < c.code_len + MC_MARGIN) && (c.code_len >= MC_MARGIN) && aux_fast);
             // centre tap at exactly 0 (E/P/L, VE/E/P/L/VL): its (a + 0.0f) is skipped; needs sample indices exact in float
             const bool zp = (NT & 1) && (NT == J.n_taps) && (sh[NT / 2] == 0.0f) && !mode_hd_code(MODE) && (c.n_total < (1 << 24));
             if (fast && zp)
-                run_segment<NT, MODE, false, true>(c, base, tab, sh, rot, acc);
+                run_segment<NT, MODE, false, true, AUX>(c, base, tab, sh, rot, acc, &acc_aux);
             else if (fast)
-                run_segment<NT, MODE, false>(c, base, tab, sh, rot, acc);
+                run_segment<NT, MODE, false, false, AUX>(c, base, tab, sh, rot, acc, &acc_aux);
             else
-                run_segment<NT, MODE, true>(c, base, tab, sh, rot, acc);
+                run_segment<NT, MODE, true, false, AUX>(c, base, tab, sh, rot, acc, &acc_aux);
         }
 
     // ---- integrate-and-dump: wave64 shuffle tree, then one LDS step over the 4 waves
@@ -169,13 +213,42 @@ __global__ __launch_bounds__(MC_THREADS, (NT <= 3 ? 8 : 1)) void mcorr_kernel(Mc
                     acc[t].y += __shfl_down(acc[t].y, off, 64);
                 }
         }
+    if (AUX)
+        {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1)
+                {
+                    acc_aux.x += __shfl_down(acc_aux.x, off, 64);
+                    acc_aux.y += __shfl_down(acc_aux.y, off, 64);
+                }
+        }
     const int wave = tid >> 6;
     if ((tid & 63) == 0)
         {
 #pragma unroll
             for (int t = 0; t < NT; t++) red[wave * GSH_MAX_TAPS + t] = acc[t];
+            if (AUX) red[wave * GSH_MAX_TAPS + NT] = acc_aux;  // NT < GSH_MAX_TAPS in the AUX kernels
         }
     __syncthreads();
+    if (AUX && aux_job >= 0 && tid >= GSH_MAX_TAPS && tid < 2 * GSH_MAX_TAPS)
+        {
+            // the fused job's whole output row: its one tap, zeros behind it
+            const int tap = tid - GSH_MAX_TAPS;
+            float2 s = make_float2(0.0f, 0.0f);
+            if (tap == 0)
+                {
+#pragma unroll
+                    for (int w = 0; w < MC_WAVES; w++)
+                        {
+                            s.x += red[w * GSH_MAX_TAPS + NT].x;
+                            s.y += red[w * GSH_MAX_TAPS + NT].y;
+                        }
+                }
+            if (a.splits == 1)
+                a.out[static_cast<size_t>(aux_job) * GSH_MAX_TAPS + tap] = s;
+            else
+                a.partials[(static_cast<size_t>(aux_job) * a.splits + split) * GSH_MAX_TAPS + tap] = s;
+        }
     if (tid < GSH_MAX_TAPS)
         {
             float2 s = make_float2(0.0f, 0.0f);
@@ -216,16 +289,28 @@ int launch_nt(const McorrArgs& a, int mode, size_t lds, hipStream_t stream)
 {
     const dim3 grid(static_cast<unsigned>(a.n_jobs) * static_cast<unsigned>(a.splits));
     const dim3 block(MC_THREADS);
+    if (a.aux != nullptr)
+        {
+            if constexpr (NT == 3 || NT == 5)
+                {
+                    GSH_REQUIRE(mode == 0, "fused jobs need the standard mode");
+                    hipLaunchKernelGGL((mcorr_kernel<NT, 0, true>), grid, block, lds, stream, a);
+                    GSH_HIP(hipGetLastError());
+                    return GSH_OK;
+                }
+            else
+                return set_error(GSH_ERR_INVALID, "fused jobs exist only for the 3- and 5-tap kernels");
+        }
     switch (mode)
         {
         case 0:
-            hipLaunchKernelGGL((mcorr_kernel<NT, 0>), grid, block, lds, stream, a);
+            hipLaunchKernelGGL((mcorr_kernel<NT, 0, false>), grid, block, lds, stream, a);
             break;
         case 1:
-            hipLaunchKernelGGL((mcorr_kernel<NT, 1>), grid, block, lds, stream, a);
+            hipLaunchKernelGGL((mcorr_kernel<NT, 1, false>), grid, block, lds, stream, a);
             break;
         case 2:
-            hipLaunchKernelGGL((mcorr_kernel<NT, 2>), grid, block, lds, stream, a);
+            hipLaunchKernelGGL((mcorr_kernel<NT, 2, false>), grid, block, lds, stream, a);
             break;
         default:
             return set_error(GSH_ERR_INVALID, "unknown correlator mode %d", mode);
@@ -241,6 +326,13 @@ size_t mcorr_lds_bytes_window(int window_floats)
     return tab * sizeof(float) + MC_WAVES * GSH_MAX_TAPS * sizeof(float2);
 }
 
+size_t mcorr_lds_bytes_fused(int max_code_len, int window_floats)
+{
+    const size_t one = window_floats > 0 ? static_cast<size_t>(window_floats) : static_cast<size_t>(max_code_len) + 2 * MC_MARGIN;
+    const size_t tab = ((one + 3) & ~static_cast<size_t>(3)) + ((one + 3) & ~static_cast<size_t>(3));
+    return tab * sizeof(float) + MC_WAVES * GSH_MAX_TAPS * sizeof(float2);
+}
+
 size_t mcorr_lds_bytes(int max_code_len)
 {
     const size_t tab = (static_cast<size_t>(max_code_len) + 2 * MC_MARGIN + 3) & ~static_cast<size_t>(3);
@@ -252,7 +344,8 @@ int mcorr_launch(const McorrArgs& a, int max_taps, int mode, int max_code_len, h
     if (a.n_jobs <= 0) return GSH_OK;
     GSH_REQUIRE(max_taps >= 1 && max_taps <= GSH_MAX_TAPS, "n_taps %d outside 1..%d", max_taps, GSH_MAX_TAPS);
     GSH_REQUIRE(a.splits >= 1, "splits must be >= 1");
-    const size_t lds = a.window_floats > 0 ? mcorr_lds_bytes_window(a.window_floats) : mcorr_lds_bytes(max_code_len);
+    const size_t lds = a.aux != nullptr ? mcorr_lds_bytes_fused(max_code_len, a.window_floats)
+                                        : (a.window_floats > 0 ? mcorr_lds_bytes_window(a.window_floats) : mcorr_lds_bytes(max_code_len));
     GSH_REQUIRE(lds <= 160 * 1024, "local code of %d samples does not fit the 160 KiB LDS", max_code_len);
     int rc;
     if (max_taps == 1)

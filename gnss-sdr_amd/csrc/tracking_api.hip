@@ -38,6 +38,13 @@ struct gsh_bank
     double win_code_span_max{0.0};  // largest code_phase_step_chips * n_samples of the batch: code samples one window walks
     double win_shift_span{0.0}; // largest (max shift - min shift) of the batch
     int max_samples{0};
+    // pair fusion (multicorrelator.hip, AUX kernels): a single-tap job that follows a job with the same window and NCO parameters (the data
+    // prompt track_pilot adds to a pilot channel, trk.cc:1246-1256) is computed by that job's work-groups instead of a second pass
+    int fusion_user{1};
+    int n_fused{0};
+    int* d_aux{nullptr};
+    int aux_cap{0};
+    std::vector<int> h_aux;
     hipEvent_t ev0{nullptr}, ev1{nullptr};
     gsh_stream* ring{nullptr};          // when set, job windows are absolute sample indices inside this ring
     gsh_corr_job* h_jobs{nullptr};      // pinned staging (ring translation; one-synchronisation gsh_bank_correlate)
@@ -128,6 +135,38 @@ int bank_stage_jobs(gsh_bank* b, const gsh_corr_job* jobs, int n_jobs)
             max_end = 0;  // residency was checked per job
         }
     GSH_HIP(hipMemcpyAsync(b->d_jobs, b->h_jobs, sizeof(gsh_corr_job) * static_cast<size_t>(n_jobs), hipMemcpyHostToDevice, b->stream));
+    // ---- pair fusion: job i + 1 rides on job i when it is a single tap over exactly the same samples with exactly the same NCO parameters
+    b->n_fused = 0;
+    if (b->fusion_user && mode == 0 && max_taps >= 2 && max_taps <= 5)
+        {
+            b->h_aux.assign(static_cast<size_t>(n_jobs), -1);
+            for (int i = 0; i + 1 < n_jobs; i++)
+                {
+                    const gsh_corr_job &p = jobs[i], &q = jobs[i + 1];
+                    if (p.n_taps < 2 || q.n_taps != 1 || b->h_aux[i] == -2) continue;
+                    if (p.sample_offset != q.sample_offset || p.n_samples != q.n_samples) continue;
+                    if (std::memcmp(&p.rem_carr_phase_rad, &q.rem_carr_phase_rad, sizeof(float)) != 0 || std::memcmp(&p.phase_step_rad, &q.phase_step_rad, sizeof(float)) != 0 ||
+                        std::memcmp(&p.rem_code_phase_chips, &q.rem_code_phase_chips, sizeof(float)) != 0 ||
+                        std::memcmp(&p.code_phase_step_chips, &q.code_phase_step_chips, sizeof(float)) != 0)
+                        continue;
+                    b->h_aux[i] = i + 1;
+                    b->h_aux[i + 1] = -2;
+                    b->n_fused++;
+                    i++;
+                }
+            if (b->n_fused > 0)
+                {
+                    if (b->aux_cap < n_jobs)
+                        {
+                            if (b->d_aux) GSH_HIP(hipFree(b->d_aux));
+                            b->d_aux = nullptr;
+                            b->aux_cap = 0;
+                            GSH_HIP(hipMalloc(&b->d_aux, sizeof(int) * static_cast<size_t>(n_jobs)));
+                            b->aux_cap = n_jobs;
+                        }
+                    GSH_HIP(hipMemcpyAsync(b->d_aux, b->h_aux.data(), sizeof(int) * static_cast<size_t>(n_jobs), hipMemcpyHostToDevice, b->stream));
+                }
+        }
     b->n_jobs = n_jobs;
     b->max_taps = max_taps;
     b->mode = mode;
@@ -254,6 +293,7 @@ extern "C"
         if (b->d_jobs) (void)hipFree(b->d_jobs);
         if (b->d_out) (void)hipFree(b->d_out);
         if (b->d_partials) (void)hipFree(b->d_partials);
+        if (b->d_aux) (void)hipFree(b->d_aux);
         if (b->ev0) (void)hipEventDestroy(b->ev0);
         if (b->ev1) (void)hipEventDestroy(b->ev1);
         if (b->h_jobs) (void)hipHostFree(b->h_jobs);
@@ -314,6 +354,14 @@ extern "C"
         GSH_REQUIRE(b != nullptr, "null bank");
         GSH_REQUIRE(splits >= 0 && splits <= 64, "splits %d outside 0..64", splits);
         b->splits_user = splits;
+        return GSH_OK;
+    }
+
+    int gsh_bank_set_pair_fusion(gsh_bank_t* b, int enable)
+    {
+        GSH_REQUIRE(b != nullptr, "null bank");
+        b->fusion_user = enable ? 1 : 0;
+        b->n_jobs = 0;  // the staged batch was analysed under the previous setting
         return GSH_OK;
     }
 
@@ -386,6 +434,9 @@ extern "C"
         a.n_jobs = b->n_jobs;
         a.splits = splits;
         a.window_floats = bank_window_floats(b, splits);
+        // the second code table must not cost the occupancy the fusion is meant to win: only with windowed tables or short codes
+        const bool fuse = b->n_fused > 0 && (a.window_floats > 0 || static_cast<size_t>(b->max_code_len) * sizeof(float) <= 10 * 1024);
+        a.aux = fuse ? b->d_aux : nullptr;
         hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : b->stream;
         if (b->ring != nullptr) GSH_HIP(hipStreamWaitEvent(s, b->ring->pushed, 0));  // conversions queued by gsh_stream_push_device
         return gsh::mcorr_launch(a, b->max_taps, b->mode, b->max_code_len, s);

@@ -143,6 +143,10 @@ class CorrelatorBank:
         self._keep["stream"] = ring
         check(self._lib.gsh_bank_set_stream_ring(self._h, ring._h if ring is not None else None))
 
+    def set_pair_fusion(self, enable: bool) -> None:
+        """Fuse a single-tap job into the job in front of it when both read the same window with the same NCO (default on)."""
+        check(self._lib.gsh_bank_set_pair_fusion(self._h, int(bool(enable))))
+
     def set_splits(self, splits: int) -> None:
         check(self._lib.gsh_bank_set_splits(self._h, splits))
 

@@ -30,7 +30,7 @@ extern "C"
 {
 #endif
 
-#define GSH_ABI_VERSION 13
+#define GSH_ABI_VERSION 14
 #define GSH_MAX_TAPS 8 /* VE/E/P/L/VL needs 5 (trk.cc:609-650); 8 leaves room for multi-tap dumps */
 
     enum
@@ -124,6 +124,11 @@ extern "C"
     /* the same, split so that a caller can keep the job table and results on the device and
      * time launches alone: upload once, launch many, read once.  hip_stream: a hipStream_t cast to
      * void* (NULL = the bank's own stream).  gsh_bank_launch is asynchronous. */
+    /* Pair fusion (default on): a single-tap job placed directly after a job with the same window and the same NCO parameters -- the
+     * data-component prompt that track_pilot adds to a pilot channel (trk.cc:1246-1256: a second correlator object over the same
+     * samples) -- is computed by that job's work-groups while they hold the rotated samples, instead of a second pass over the window.
+     * Results are unchanged (each tap is the same sum over the same products in the same order); 0 disables it for A/B runs. */
+    int gsh_bank_set_pair_fusion(gsh_bank_t* b, int enable);
     int gsh_bank_upload_jobs(gsh_bank_t* b, const gsh_corr_job* jobs, int n_jobs);
     int gsh_bank_launch(gsh_bank_t* b, void* hip_stream);
     int gsh_bank_synchronize(gsh_bank_t* b);

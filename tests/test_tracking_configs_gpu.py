@@ -192,3 +192,43 @@ def test_windowed_code_table_chip_selection_exact(gpu, splits):
         assert np.array_equal(got.real.astype(np.float64), expect), (splits, j, job, got, expect)
         assert np.all(got.imag == 0)
     b.close()
+
+
+@pytest.mark.parametrize("splits", [0, 1, 4])
+def test_pair_fusion_is_bit_identical(gpu, splits):
+    """track_pilot runs a second, single-tap correlator with the data code over the window the pilot's VE/E/P/L/VL just used
+    (trk.cc:1246-1256).  The bank computes such a job inside the job in front of it (gsh_bank_set_pair_fusion); every tap remains the
+    same sum of the same products in the same order, so the outputs with and without fusion are equal to the bit -- Galileo E1
+    (5 + 1 taps, windowed long code), GPS L5 (3 + 1), C/A-length codes (whole tables, two of them in LDS), odd offsets, short windows,
+    and a lone single-tap job that has nothing to ride on."""
+    g = golden_e1_l5_codes()
+    rng = np.random.default_rng(300 + splits)
+    codes = [g["e1c"][1], g["e1b"][1], g["l5q"][2], g["l5i"][2], oracle.ca_code(4), oracle.ca_code(9)]
+    n_stream = 420000
+    x = (rng.standard_normal(n_stream) + 1j * rng.standard_normal(n_stream)).astype(np.complex64)
+    jobs = []
+
+    def pair(n, pilot, data, shifts, chip_rate, spc, fs, data_shift=0.0):
+        off = int(rng.integers(0, n_stream - n))
+        p = _nco(fs, rng.uniform(-4000, 4000), F_L1, chip_rate, spc, rng)
+        jobs.append(dict(sample_offset=off, n_samples=n, code_slot=pilot, shifts_chips=shifts, **p))
+        jobs.append(dict(sample_offset=off, n_samples=n, code_slot=data, shifts_chips=[data_shift], **p))
+
+    for _ in range(3):
+        pair(128000, 0, 1, VEML_SHIFTS, E1_CHIP_RATE, 2, 32e6)
+        pair(50000, 2, 3, [-0.5, 0.0, 0.5], L5_CHIP_RATE, 1, 50e6)
+        pair(25000, 4, 5, [-0.5, 0.0, 0.5], 1.023e6, 1, 25e6)
+    pair(30001, 0, 1, VEML_SHIFTS, E1_CHIP_RATE, 2, 32e6, data_shift=0.3)   # a fused tap away from the prompt
+    pair(777, 4, 5, [-0.5, 0.0, 0.5], 1.023e6, 1, 25e6)                       # shorter than one chunk: masked paths only
+    jobs.append(dict(sample_offset=5, n_samples=40000, code_slot=3, shifts_chips=[0.0], **_nco(50e6, 100.0, F_L5, L5_CHIP_RATE, 1, rng)))  # no leader
+    b = _bank(gpu, codes)
+    b.set_stream_host(x)
+    b.set_splits(splits)
+    b.set_pair_fusion(False)
+    plain = b.correlate(jobs).copy()
+    b.set_pair_fusion(True)
+    fused = b.correlate(jobs)
+    assert np.array_equal(plain.view(np.uint32), fused.view(np.uint32))
+    worst = _check(fused, jobs, codes, x, tol_ref=TOL_REF)
+    assert worst < 1e-6
+    b.close()
