@@ -377,11 +377,14 @@ __host__ __device__ constexpr int code_table_floats(int code_len) { return (code
 // splits == 1.  MODE as gsh_corr_job::high_dyn: 0 standard resampler + rotator, 1 the high-dynamics pair (phase_rate / code_rate used).  `tab` is a staged code table, `red` MC_WAVES *
 // GSH_MAX_TAPS float2 of LDS scratch.  On return red[0..NT) holds the tap sums and every thread may read them
 // (a __syncthreads() has been executed); the caller must __syncthreads() again before `red` is reused.
-template <int NT, int MODE>
+// AUX: one more tap with the code staged at `tab_aux` (same LDS allocation as `tab`, same length) and shift `aux_shift` is computed in the same
+// pass -- the data-component prompt of track_pilot (trk.cc:1246-1256); its sum is returned in red[NT].  Standard mode only.
+template <int NT, int MODE, bool AUX = false>
 __device__ __forceinline__ void correlate_window(const float2* __restrict__ stream, unsigned long long sample_offset, int n_samples,
     const float* __restrict__ tab, int code_len, const float (&sh)[NT], float rem_carr, float phase_step, float phase_rate, float rem_code,
-    float code_step, float code_rate, float2* __restrict__ red)
+    float code_step, float code_rate, float2* __restrict__ red, const float* tab_aux = nullptr, float aux_shift = 0.0f)
 {
+    static_assert(!AUX || (MODE == 0 && NT < GSH_MAX_TAPS), "the fused tap exists for the standard mode and needs a free slot in `red`");
     const int tid = threadIdx.x;
     JobCtx c;
     c.n_total = n_samples;
@@ -418,6 +421,15 @@ __device__ __forceinline__ void correlate_window(const float2* __restrict__ stre
     float2 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; t++) acc[t] = make_float2(0.0f, 0.0f);
+    float2 acc_aux = make_float2(0.0f, 0.0f);
+    if (AUX)
+        {
+            c.aux_on = true;
+            c.aux_shift = aux_shift;
+            c.aux_zero = (aux_shift == 0.0f);
+            c.aux_code_len = code_len;
+            c.aux_k_off = static_cast<int>(tab_aux - tab) + MC_MARGIN;
+        }
     if (n_samples > 0)
         {
             float smin = sh[0], smax = sh[0];
@@ -427,16 +439,21 @@ __device__ __forceinline__ void correlate_window(const float2* __restrict__ stre
                     smin = fminf(smin, sh[t]);
                     smax = fmaxf(smax, sh[t]);
                 }
+            if (AUX)
+                {
+                    smin = fminf(smin, aux_shift);
+                    smax = fmaxf(smax, aux_shift);
+                }
             const int lo = raw_chip_std(__fmul_rn(code_step, 0.0f), smin, rem_code);
             const int hi = raw_chip_std(__fmul_rn(code_step, static_cast<float>(n_samples - 1)), smax, rem_code);
             const bool fast = !mode_hd_code(MODE) && (code_step >= 0.0f) && (lo >= -MC_MARGIN) && (hi < code_len + MC_MARGIN) && (code_len >= MC_MARGIN);
             const bool zp = (NT & 1) && (sh[NT / 2] == 0.0f) && !mode_hd_code(MODE) && (n_samples < (1 << 24));
             if (fast && zp)
-                run_segment<NT, MODE, false, true>(c, base, tab, sh, rot, acc);
+                run_segment<NT, MODE, false, true, AUX>(c, base, tab, sh, rot, acc, &acc_aux);
             else if (fast)
-                run_segment<NT, MODE, false>(c, base, tab, sh, rot, acc);
+                run_segment<NT, MODE, false, false, AUX>(c, base, tab, sh, rot, acc, &acc_aux);
             else
-                run_segment<NT, MODE, true>(c, base, tab, sh, rot, acc);
+                run_segment<NT, MODE, true, false, AUX>(c, base, tab, sh, rot, acc, &acc_aux);
         }
 #pragma unroll
     for (int t = 0; t < NT; t++)
@@ -448,15 +465,26 @@ __device__ __forceinline__ void correlate_window(const float2* __restrict__ stre
                     acc[t].y += __shfl_down(acc[t].y, off, 64);
                 }
         }
+    if (AUX)
+        {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1)
+                {
+                    acc_aux.x += __shfl_down(acc_aux.x, off, 64);
+                    acc_aux.y += __shfl_down(acc_aux.y, off, 64);
+                }
+        }
     const int wave = tid >> 6;
     if ((tid & 63) == 0)
         {
 #pragma unroll
             for (int t = 0; t < NT; t++) red[wave * GSH_MAX_TAPS + t] = acc[t];
+            if (AUX) red[wave * GSH_MAX_TAPS + NT] = acc_aux;
         }
     __syncthreads();
+    constexpr int NOUT = AUX ? NT + 1 : NT;
     float2 s = make_float2(0.0f, 0.0f);
-    if (tid < NT)
+    if (tid < NOUT)
         {
 #pragma unroll
             for (int w = 0; w < MC_WAVES; w++)
@@ -466,7 +494,7 @@ __device__ __forceinline__ void correlate_window(const float2* __restrict__ stre
                 }
         }
     __syncthreads();
-    if (tid < NT) red[tid] = s;
+    if (tid < NOUT) red[tid] = s;
     __syncthreads();
 }
 
@@ -477,6 +505,15 @@ __device__ __forceinline__ void correlate_window_std(const float2* __restrict__ 
     float2* __restrict__ red)
 {
     correlate_window<NT, 0>(stream, sample_offset, n_samples, tab, code_len, sh, rem_carr, phase_step, 0.0f, rem_code, code_step, 0.0f, red);
+}
+
+// standard mode with the fused data-component tap: red[0..NT) the taps, red[NT] the fused one
+template <int NT>
+__device__ __forceinline__ void correlate_window_std_aux(const float2* __restrict__ stream, unsigned long long sample_offset, int n_samples,
+    const float* __restrict__ tab, const float* tab_aux, float aux_shift, int code_len, const float (&sh)[NT], float rem_carr, float phase_step,
+    float rem_code, float code_step, float2* __restrict__ red)
+{
+    correlate_window<NT, 0, true>(stream, sample_offset, n_samples, tab, code_len, sh, rem_carr, phase_step, 0.0f, rem_code, code_step, 0.0f, red, tab_aux, aux_shift);
 }
 }  // namespace GSH_MC_NS
 namespace mcdev = GSH_MC_NS;

@@ -463,15 +463,21 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
 #pragma unroll
             for (int t = 0; t < NT; t++) sh[t] = win.narrow ? sh_n[t] : sh_w[t];
             const float phase_rate = win.phase_rate, code_rate = win.code_rate;
+            // track_pilot in the standard mode: the data-component prompt (trk.cc:1246-1256) rides on the pilot's pass over the window
+            const bool fused_data = !HD && c.track_pilot;
             if (HD)  // set_high_dynamics_resampler(high_dyn), trk.cc:669-675: the high-dynamics resampler + rotator pair
                 correlate_window<NT, 1>(a.stream, wpos, static_cast<int>(c.vector_length), tab, code_len, sh, rem_carr, phase_step, phase_rate, rem_code, code_step, code_rate, red);
+            else if (fused_data)
+                correlate_window_std_aux<NT>(a.stream, wpos, static_cast<int>(c.vector_length), tab, tab_data, sh_data[0], code_len, sh, rem_carr, phase_step, rem_code, code_step, red);
             else
                 correlate_window_std<NT>(a.stream, wpos, static_cast<int>(c.vector_length), tab, code_len, sh, rem_carr, phase_step, rem_code, code_step, red);
             float2 out[NT];
 #pragma unroll
             for (int t = 0; t < NT; t++) out[t] = red[t];
             float2 pdata = make_float2(0.0f, 0.0f);
-            if (c.track_pilot)
+            if (fused_data)
+                pdata = red[NT];
+            else if (c.track_pilot)
                 {
                     __syncthreads();  // everyone has read red[0..NT) before it is reused
                     if (HD)
