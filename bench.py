@@ -320,6 +320,22 @@ def closed_loop_metric(dev_index, x_dev, n_samples, fs, n, dop, cph, channels=32
             "real_time_factor": epochs * 1e-3 / (ms * 1e-3)}
 
 
+def other_configs_metric(dev_index):
+    """Secondary figures: the correlator bank at the shapes of BASELINE configs 4 and 5 (one GPU's 32 of the 256 channels), job tables
+    from profiles/config_rates.py (random +-1 codes of the right lengths: the kernel's cost does not depend on the code values)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("config_rates", os.path.join(ROOT, "profiles", "config_rates.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    out = {}
+    for key, build in (("config4_galileo_e1_50ch_32Msps", m.config4), ("config5_share_32_of_256ch_50Msps", m.config5_share)):
+        name, codes, rows, n_stream, correlators, samples = build()
+        ms = m.measure(codes, rows, n_stream, splits=0, device=dev_index)
+        out[key] = {"workload": name, "ms_per_launch": ms, "correlators_per_s": correlators / (ms * 1e-3),
+                    "channel_samples_per_s": samples / (ms * 1e-3)}
+    return out
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -495,6 +511,10 @@ def main():
                 res["closed_loop_256ch"] = closed_loop_metric(local, x, n_samples, fs, n, dop, cph, channels=256, epochs=min(E - 2, 200))
             except Exception as e:
                 res["closed_loop"] = {"error": str(e)}
+            try:
+                res["other_configs"] = other_configs_metric(local)
+            except Exception as e:
+                res["other_configs"] = {"error": str(e)}
         print(json.dumps(res))
     bank.close()
     if dist:
