@@ -20,6 +20,8 @@ struct McorrArgs
     int n_jobs;
     int splits;
     int window_floats;               // > 0: LDS holds only a window of the code per work-group (all jobs: mode 0, code_step >= 0); 0: the whole code
+    const int* job_list;             // device, n_launch job indices this launch works on (order kept), or nullptr: jobs 0..n_launch-1
+    int n_launch;                    // jobs in this launch (n_jobs stays the size of the whole table: outputs / partials are indexed by job)
     const int* aux;                  // device, n_jobs, or nullptr.  aux[j] >= 0: job j also computes the single tap of job aux[j] (same window and
                                      // NCO, another code) and writes its output row; -2: job j is computed by its leader; -1: plain job
 };
@@ -27,6 +29,17 @@ struct McorrArgs
 // Largest n_taps over the jobs and which mode combinations occur decide the template
 // instance; all jobs of one launch must share `mode` (gsh_corr_job::high_dyn).
 int mcorr_launch(const McorrArgs& args, int max_taps, int mode, int max_code_len, hipStream_t stream);
+
+// A batch whose jobs differ in tap count is launched per kernel flavour (1, <= 3, <= 5, <= 8 taps) so that a 3-tap job does not pay for
+// five: `list` holds the job indices grouped by class (device), offset / count per class, aux[c] whether class c contains fused leaders.
+struct McorrClassPlan
+{
+    const int* list;
+    int offset[4];
+    int count[4];
+    bool aux[4];
+};
+int mcorr_launch_classes(const McorrArgs& args, const McorrClassPlan& plan, int mode, int max_code_len, hipStream_t stream);
 
 // dynamic LDS bytes the kernel needs for a code of max_code_len samples
 size_t mcorr_lds_bytes(int max_code_len);

@@ -40,8 +40,9 @@ __global__ __launch_bounds__(MC_THREADS, ((NT <= 3 && !AUX) ? 8 : 1)) void mcorr
 {
     extern __shared__ __align__(16) float lds[];
     const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
-    const int job = static_cast<int>(lb) / a.splits;
-    const int split = static_cast<int>(lb) - job * a.splits;
+    const int slot = static_cast<int>(lb) / a.splits;
+    const int split = static_cast<int>(lb) - slot * a.splits;
+    const int job = a.job_list ? a.job_list[slot] : slot;
     const gsh_corr_job& J = a.jobs[job];
     const int tid = threadIdx.x;
     const int aux_job = AUX ? a.aux[job] : -1;
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(256) void mcorr_reduce_partials(const float2* __res
 template <int NT>
 int launch_nt(const McorrArgs& a, int mode, size_t lds, hipStream_t stream)
 {
-    const dim3 grid(static_cast<unsigned>(a.n_jobs) * static_cast<unsigned>(a.splits));
+    const dim3 grid(static_cast<unsigned>(a.n_launch) * static_cast<unsigned>(a.splits));
     const dim3 block(MC_THREADS);
     if (a.aux != nullptr)
         {
@@ -361,6 +362,48 @@ int mcorr_launch(const McorrArgs& a, int max_taps, int mode, int max_code_len, h
         {
             const int total = a.n_jobs * GSH_MAX_TAPS;
             hipLaunchKernelGGL(mcorr_reduce_partials, dim3((total + 255) / 256), dim3(256), 0, stream, a.partials, a.out, a.n_jobs, a.splits);
+            GSH_HIP(hipGetLastError());
+        }
+    return GSH_OK;
+}
+
+int mcorr_launch_classes(const McorrArgs& args, const McorrClassPlan& plan, int mode, int max_code_len, hipStream_t stream)
+{
+    if (args.n_jobs <= 0) return GSH_OK;
+    GSH_REQUIRE(args.splits >= 1, "splits must be >= 1");
+    static const int class_taps[4] = {1, 3, 5, GSH_MAX_TAPS};
+    for (int c = 0; c < 4; c++)
+        {
+            if (plan.count[c] <= 0) continue;
+            McorrArgs a = args;
+            a.job_list = plan.list + plan.offset[c];
+            a.n_launch = plan.count[c];
+            if (!plan.aux[c]) a.aux = nullptr;
+            const size_t lds = a.aux != nullptr ? mcorr_lds_bytes_fused(max_code_len, a.window_floats)
+                                                : (a.window_floats > 0 ? mcorr_lds_bytes_window(a.window_floats) : mcorr_lds_bytes(max_code_len));
+            GSH_REQUIRE(lds <= 160 * 1024, "local code of %d samples does not fit the 160 KiB LDS", max_code_len);
+            int rc;
+            switch (class_taps[c])
+                {
+                case 1:
+                    rc = launch_nt<1>(a, mode, lds, stream);
+                    break;
+                case 3:
+                    rc = launch_nt<3>(a, mode, lds, stream);
+                    break;
+                case 5:
+                    rc = launch_nt<5>(a, mode, lds, stream);
+                    break;
+                default:
+                    rc = launch_nt<GSH_MAX_TAPS>(a, mode, lds, stream);
+                    break;
+                }
+            if (rc != GSH_OK) return rc;
+        }
+    if (args.splits > 1)
+        {
+            const int total = args.n_jobs * GSH_MAX_TAPS;
+            hipLaunchKernelGGL(mcorr_reduce_partials, dim3((total + 255) / 256), dim3(256), 0, stream, args.partials, args.out, args.n_jobs, args.splits);
             GSH_HIP(hipGetLastError());
         }
     return GSH_OK;

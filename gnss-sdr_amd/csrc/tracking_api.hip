@@ -45,6 +45,13 @@ struct gsh_bank
     int* d_aux{nullptr};
     int aux_cap{0};
     std::vector<int> h_aux;
+    // per-flavour launch lists (jobs grouped by tap-count class, fused partners left out); used when a batch mixes classes or has fused jobs
+    bool use_classes{false};
+    bool lists_fused{false};
+    gsh::McorrClassPlan class_plan{};
+    int* d_list{nullptr};
+    int list_cap{0};
+    std::vector<int> h_list;
     hipEvent_t ev0{nullptr}, ev1{nullptr};
     gsh_stream* ring{nullptr};          // when set, job windows are absolute sample indices inside this ring
     gsh_corr_job* h_jobs{nullptr};      // pinned staging (ring translation; one-synchronisation gsh_bank_correlate)
@@ -84,6 +91,55 @@ int bank_reserve_staging(gsh_bank* b, int n)
     GSH_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->h_jobs), sizeof(gsh_corr_job) * static_cast<size_t>(cap), hipHostMallocDefault));
     GSH_HIP(hipHostMalloc(reinterpret_cast<void**>(&b->h_out), sizeof(float2) * GSH_MAX_TAPS * static_cast<size_t>(cap), hipHostMallocDefault));
     b->h_cap = cap;
+    return GSH_OK;
+}
+
+// launch classes: a 3-tap job inside a 5-tap launch would pay for five taps, so a batch that mixes tap counts is launched per kernel flavour;
+// with_fusion leaves the fused partners out (their leaders write their rows).  Reads the staged copy of the batch (h_jobs, h_aux).
+int bank_build_lists(gsh_bank* b, bool with_fusion)
+{
+    const int n_jobs = b->n_jobs;
+    const gsh_corr_job* jobs = b->h_jobs;
+    int count[4] = {0, 0, 0, 0};
+    bool has_aux[4] = {false, false, false, false};
+    auto cls_of = [](int taps) { return taps <= 1 ? 0 : (taps <= 3 ? 1 : (taps <= 5 ? 2 : 3)); };
+    for (int i = 0; i < n_jobs; i++)
+        {
+            if (with_fusion && b->h_aux[i] == -2) continue;
+            const int c = cls_of(jobs[i].n_taps);
+            count[c]++;
+            if (with_fusion && b->h_aux[i] >= 0) has_aux[c] = true;
+        }
+    const int classes = (count[0] > 0) + (count[1] > 0) + (count[2] > 0) + (count[3] > 0);
+    b->use_classes = (classes > 1) || with_fusion;
+    b->lists_fused = with_fusion;
+    if (!b->use_classes) return GSH_OK;
+    int off[4];
+    off[0] = 0;
+    for (int c = 1; c < 4; c++) off[c] = off[c - 1] + count[c - 1];
+    b->h_list.assign(static_cast<size_t>(n_jobs), 0);
+    int fill[4] = {off[0], off[1], off[2], off[3]};
+    for (int i = 0; i < n_jobs; i++)
+        {
+            if (with_fusion && b->h_aux[i] == -2) continue;
+            b->h_list[static_cast<size_t>(fill[cls_of(jobs[i].n_taps)]++)] = i;
+        }
+    if (b->list_cap < n_jobs)
+        {
+            if (b->d_list) GSH_HIP(hipFree(b->d_list));
+            b->d_list = nullptr;
+            b->list_cap = 0;
+            GSH_HIP(hipMalloc(&b->d_list, sizeof(int) * static_cast<size_t>(n_jobs)));
+            b->list_cap = n_jobs;
+        }
+    GSH_HIP(hipMemcpyAsync(b->d_list, b->h_list.data(), sizeof(int) * static_cast<size_t>(n_jobs), hipMemcpyHostToDevice, b->stream));
+    b->class_plan.list = b->d_list;
+    for (int c = 0; c < 4; c++)
+        {
+            b->class_plan.offset[c] = off[c];
+            b->class_plan.count[c] = count[c];
+            b->class_plan.aux[c] = has_aux[c];
+        }
     return GSH_OK;
 }
 
@@ -167,6 +223,15 @@ int bank_stage_jobs(gsh_bank* b, const gsh_corr_job* jobs, int n_jobs)
                     GSH_HIP(hipMemcpyAsync(b->d_aux, b->h_aux.data(), sizeof(int) * static_cast<size_t>(n_jobs), hipMemcpyHostToDevice, b->stream));
                 }
         }
+    b->n_jobs = n_jobs;
+    {
+        int rc2 = bank_build_lists(b, b->n_fused > 0);
+        if (rc2 != GSH_OK)
+            {
+                b->n_jobs = 0;
+                return rc2;
+            }
+    }
     b->n_jobs = n_jobs;
     b->max_taps = max_taps;
     b->mode = mode;
@@ -294,6 +359,7 @@ extern "C"
         if (b->d_out) (void)hipFree(b->d_out);
         if (b->d_partials) (void)hipFree(b->d_partials);
         if (b->d_aux) (void)hipFree(b->d_aux);
+        if (b->d_list) (void)hipFree(b->d_list);
         if (b->ev0) (void)hipEventDestroy(b->ev0);
         if (b->ev1) (void)hipEventDestroy(b->ev1);
         if (b->h_jobs) (void)hipHostFree(b->h_jobs);
@@ -439,6 +505,16 @@ extern "C"
         a.aux = fuse ? b->d_aux : nullptr;
         hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : b->stream;
         if (b->ring != nullptr) GSH_HIP(hipStreamWaitEvent(s, b->ring->pushed, 0));  // conversions queued by gsh_stream_push_device
+        a.job_list = nullptr;
+        a.n_launch = b->n_jobs;
+        if (b->lists_fused != fuse)
+            {
+                // the LDS rule above changed its verdict since the batch was staged (set_splits in between): regroup
+                int rc2 = bank_build_lists(b, fuse);
+                if (rc2 != GSH_OK) return rc2;
+                GSH_HIP(hipStreamSynchronize(b->stream));  // the list upload was queued on the bank's stream
+            }
+        if (b->use_classes) return gsh::mcorr_launch_classes(a, b->class_plan, b->mode, b->max_code_len, s);
         return gsh::mcorr_launch(a, b->max_taps, b->mode, b->max_code_len, s);
     }
 
