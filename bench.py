@@ -15,7 +15,7 @@ job table) already resident in HBM.  value = channels*taps*epochs / time, whole 
   correlates; all of that IS inside the timed region.
 
 One JSON line on stdout (rank 0).  Besides the contract keys it carries
-  roofline      -- dominant kernel (mcorr_kernel<3,0>) vs the HBM roofline, algorithmic bytes 8N+8T per job,
+  roofline      -- dominant kernel (mcorr_kernel<3,0,false>) vs the HBM roofline, algorithmic bytes 8N+8T per job,
                    duration from HIP events on the launch stream
   cpu_baseline  -- the reference's own Cpu_Multicorrelator_Real_Codes (oracle/_ref, x86 SIMD protokernels) timed on
                    this box's host cores over a bounded sample (falls back to the C port when _ref is absent)
@@ -50,6 +50,8 @@ def parse():
                          "period the first ~40 ms of work run up to 25 %% slower (profiles/ab/clock_ramp.py); 0 disables")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-acq", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the config 4 / config 5 figures (profiles/run_profiles.sh: keeps the "
+                    "per-kernel averages of the trace about the headline workload only)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline leg")
     return ap.parse_args()
 
@@ -490,7 +492,7 @@ def main():
                        "channels_per_gpu": C, "epochs_per_step": E, "samples_per_epoch": n, "taps": T,
                        "parallelism": f"channels sharded over {world} GPU(s)" + (f", 8-bit stream block re-distributed over RCCL each step ({D.mode}, overlapped) and converted on every GPU" if D is not None else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": f"mcorr_kernel<{3 if T <= 3 else (5 if T <= 5 else 8)},0>",
+                         "traffic": traffic, "kernel": f"mcorr_kernel<{3 if T <= 3 else (5 if T <= 5 else 8)},0,false>",
                          "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes},
             "kernel_only_value": float(C) * T * E / (k_ms * 1e-3),
         }
@@ -511,10 +513,11 @@ def main():
                 res["closed_loop_256ch"] = closed_loop_metric(local, x, n_samples, fs, n, dop, cph, channels=256, epochs=min(E - 2, 200))
             except Exception as e:
                 res["closed_loop"] = {"error": str(e)}
-            try:
-                res["other_configs"] = other_configs_metric(local)
-            except Exception as e:
-                res["other_configs"] = {"error": str(e)}
+            if not a.no_other_configs:
+                try:
+                    res["other_configs"] = other_configs_metric(local)
+                except Exception as e:
+                    res["other_configs"] = {"error": str(e)}
         print(json.dumps(res))
     bank.close()
     if dist:
