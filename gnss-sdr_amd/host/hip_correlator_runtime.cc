@@ -216,7 +216,27 @@ void Hip_Correlator_Runtime::run_batch(const std::shared_ptr<Batch>& b, bool tim
 
 bool Hip_Correlator_Runtime::correlate(int channel, const gsh_corr_job& job_in, std::complex<float>* out)
 {
-    if (d_bank == nullptr || out == nullptr) return false;
+    const gsh_corr_job* jobs[1] = {&job_in};
+    std::complex<float>* outs[1] = {out};
+    return correlate_n(1, &channel, jobs, outs);
+}
+
+
+bool Hip_Correlator_Runtime::correlate_pair(int channel, const gsh_corr_job& job, std::complex<float>* out, int channel2, const gsh_corr_job& job2, std::complex<float>* out2)
+{
+    const int channels[2] = {channel, channel2};
+    const gsh_corr_job* jobs[2] = {&job, &job2};
+    std::complex<float>* outs[2] = {out, out2};
+    return correlate_n(2, channels, jobs, outs);
+}
+
+
+// the jobs of ONE caller join the current batch side by side; a caller that brings two counts as two arrivals
+bool Hip_Correlator_Runtime::correlate_n(int n_in, const int* channels, const gsh_corr_job* const* jobs_in, std::complex<float>* const* outs)
+{
+    if (d_bank == nullptr) return false;
+    for (int k = 0; k < n_in; k++)
+        if (outs[k] == nullptr) return false;
     std::shared_ptr<Batch> b;
     size_t idx;
     bool close_now = false, first = false;
@@ -224,8 +244,11 @@ bool Hip_Correlator_Runtime::correlate(int channel, const gsh_corr_job& job_in, 
         std::unique_lock<std::mutex> lk(d_mutex);
         b = d_current;
         idx = b->jobs.size();
-        b->jobs.push_back(job_in);
-        b->jobs.back().code_slot = channel;
+        for (int k = 0; k < n_in; k++)
+            {
+                b->jobs.push_back(*jobs_in[k]);
+                b->jobs.back().code_slot = channels[k];
+            }
         first = (idx == 0);
         if (static_cast<int>(b->jobs.size()) >= d_active)
             {
@@ -283,9 +306,12 @@ bool Hip_Correlator_Runtime::correlate(int channel, const gsh_corr_job& job_in, 
             d_error = b->error;
             return false;
         }
-    const int taps = std::min(std::max(job_in.n_taps, 0), GSH_MAX_TAPS);
-    for (int t = 0; t < taps; t++)
-        out[t] = std::complex<float>(b->out[(idx * GSH_MAX_TAPS + t) * 2], b->out[(idx * GSH_MAX_TAPS + t) * 2 + 1]);
+    for (int k = 0; k < n_in; k++)
+        {
+            const int taps = std::min(std::max(jobs_in[k]->n_taps, 0), GSH_MAX_TAPS);
+            for (int t = 0; t < taps; t++)
+                outs[k][t] = std::complex<float>(b->out[((idx + k) * GSH_MAX_TAPS + t) * 2], b->out[((idx + k) * GSH_MAX_TAPS + t) * 2 + 1]);
+        }
     return true;
 }
 
@@ -359,24 +385,52 @@ bool Hip_Multicorrelator_Batched::run(int mode, float rem_carr, float phase_step
             return false;
         }
     gsh_corr_job j;
-    std::memset(&j, 0, sizeof(j));
-    j.sample_offset = d_sample_index;
-    j.n_samples = n;
-    j.rem_carr_phase_rad = rem_carr;
-    j.phase_step_rad = phase_step;
-    j.phase_rate_step_rad = phase_rate;
-    j.rem_code_phase_chips = rem_code;
-    j.code_phase_step_chips = code_step;
-    j.code_phase_rate_step_chips = code_rate;
-    j.n_taps = d_n_correlators;
-    j.high_dyn = mode;
-    for (int t = 0; t < d_n_correlators; t++) j.shifts_chips[t] = d_shifts[t];  // re-read every call: the caller mutates them in place (trk.cc:2132-2146)
+    fill_job(&j, mode, rem_carr, phase_step, phase_rate, rem_code, code_step, code_rate, n);
+    if (d_served)
+        {
+            // a leader (set_companion) computed this very call while it held the window: same window, parameters and taps -> done
+            d_served = false;
+            if (std::memcmp(&j, &d_served_job, sizeof(j)) == 0) return true;
+        }
+    Hip_Multicorrelator_Batched* cmp = d_companion;
+    if (cmp != nullptr && cmp->ready() && cmp->d_runtime == d_runtime && mode == 0 && n <= cmp->d_max_len)
+        {
+            gsh_corr_job j2;
+            cmp->fill_job(&j2, mode, rem_carr, phase_step, phase_rate, rem_code, code_step, code_rate, n);
+            j2.sample_offset = d_sample_index;  // the companion reads the window this call reads (trk.cc:1246-1256 passes the same pointer)
+            if (!d_runtime->correlate_pair(d_channel, j, d_corr_out, cmp->d_channel, j2, cmp->d_corr_out))
+                {
+                    d_error = d_runtime->last_error();
+                    return false;
+                }
+            cmp->d_served = true;
+            cmp->d_served_job = j2;
+            return true;
+        }
     if (!d_runtime->correlate(d_channel, j, d_corr_out))
         {
             d_error = d_runtime->last_error();
             return false;
         }
     return true;
+}
+
+
+void Hip_Multicorrelator_Batched::fill_job(gsh_corr_job* j, int mode, float rem_carr, float phase_step, float phase_rate, float rem_code, float code_step, float code_rate,
+    int n) const
+{
+    std::memset(j, 0, sizeof(*j));
+    j->sample_offset = d_sample_index;
+    j->n_samples = n;
+    j->rem_carr_phase_rad = rem_carr;
+    j->phase_step_rad = phase_step;
+    j->phase_rate_step_rad = phase_rate;
+    j->rem_code_phase_chips = rem_code;
+    j->code_phase_step_chips = code_step;
+    j->code_phase_rate_step_chips = code_rate;
+    j->n_taps = d_n_correlators;
+    j->high_dyn = mode;
+    for (int t = 0; t < d_n_correlators; t++) j->shifts_chips[t] = d_shifts[t];  // re-read every call: the caller mutates them in place (trk.cc:2132-2146)
 }
 
 

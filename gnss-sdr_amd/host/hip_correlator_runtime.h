@@ -100,6 +100,10 @@ public:
         sample index, job.code_slot is overwritten with the channel's slot.  Blocks until the batch it joined has run; out receives
         job.n_taps complex values.  Thread-safe; at most one call in flight per channel. */
     bool correlate(int channel, const gsh_corr_job& job, std::complex<float>* out);
+    /*! the same for TWO correlators of one tracking block that run over the same window with the same NCO parameters -- the pilot's
+        VE/E/P/L/VL and the single-tap data prompt of track_pilot (trk.cc:1236-1256): both jobs join the batch side by side (the bank
+        computes the second inside the first, gsh_bank_set_pair_fusion) and the block spends one rendezvous per epoch instead of two. */
+    bool correlate_pair(int channel, const gsh_corr_job& job, std::complex<float>* out, int channel2, const gsh_corr_job& job2, std::complex<float>* out2);
     Stats stats() const;
 
 private:
@@ -114,6 +118,7 @@ private:
         int status{0};
         std::string error;
     };
+    bool correlate_n(int n_jobs, const int* channels, const gsh_corr_job* const* jobs, std::complex<float>* const* outs);
     void run_batch(const std::shared_ptr<Batch>& b, bool timed_out);
     std::shared_ptr<Batch> new_batch() const;
     Hip_Sample_Ring* d_ring;
@@ -151,6 +156,11 @@ public:
     bool free();
     // ---- the one addition: absolute index (in the ring) of the first sample of the window the next call correlates
     void set_input_sample_index(uint64_t index) { d_sample_index = index; }
+    /*! track_pilot (trk.cc:1246-1256): `data` is the block's second correlator (d_correlator_data_cpu), called right after this one with
+        the same parameters.  Once set, this correlator's call computes both (Hip_Correlator_Runtime::correlate_pair) and leaves the
+        companion's result in the companion's output vector; the companion's own call then finds its parameters already served and
+        returns at once.  Any call the companion receives with other parameters runs normally.  nullptr detaches. */
+    void set_companion(Hip_Multicorrelator_Batched* data) { d_companion = data; }
     const std::string& last_error() const { return d_error; }
 
 private:
@@ -164,6 +174,12 @@ private:
     uint64_t d_sample_index{0};
     bool d_use_high_dynamics_resampler{true};  // same default as the reference (mcorr.h:60)
     std::string d_error;
+    Hip_Multicorrelator_Batched* d_companion{nullptr};
+    // what the companion mechanism has already computed for THIS correlator (set by the leader, consumed by the next run())
+    bool d_served{false};
+    gsh_corr_job d_served_job{};
+    bool ready() const { return d_channel >= 0 && d_shifts != nullptr && d_corr_out != nullptr; }
+    void fill_job(gsh_corr_job* j, int mode, float rem_carr, float phase_step, float phase_rate, float rem_code, float code_step, float code_rate, int n) const;
 };
 
 #endif  // GNSS_SDR_HIP_CORRELATOR_RUNTIME_H

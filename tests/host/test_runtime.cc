@@ -45,6 +45,7 @@ struct Chan
     float rem_carr, phase_step, rem_code, code_step;
     std::vector<float> code;
     std::vector<std::complex<float>> results;  // epochs * 3
+    std::vector<std::complex<float>> data_results;  // epochs (pilot mode)
 };
 }  // namespace
 
@@ -55,6 +56,11 @@ int main(int argc, char** argv)
     // "mixed": odd channels run the high-dynamics resampler + rotator (trk.cc:675), so every batch holds two correlator flavours and the
     // runtime has to split it into one launch per flavour
     const bool mixed = argc > 3 && std::string(argv[3]) == "mixed";
+    // "pilot": every channel thread drives TWO correlators per epoch like a track_pilot block (trk.cc:1236-1256): the VE/E/P/L/VL-style one and,
+    // right after it with the same parameters, a single-tap one with another code; the first has the second as its companion
+    // (Hip_Multicorrelator_Batched::set_companion).  "pilot_nocompanion": the same without the companion link, for comparison.
+    const bool pilot_plain = argc > 3 && std::string(argv[3]) == "pilot_nocompanion";
+    const bool pilot = pilot_plain || (argc > 3 && std::string(argv[3]) == "pilot");
     const int N = 25000, T = 3;
     const double fs = 25e6;
     const uint64_t total = static_cast<uint64_t>(E + 2) * N;
@@ -101,6 +107,7 @@ int main(int argc, char** argv)
                 ch[c].code.resize(1023);
                 oracle_gps_l1_ca_code_gen_float(ch[c].code.data(), ch[c].prn, 0);
                 ch[c].results.assign(static_cast<size_t>(E) * T, {0.0F, 0.0F});
+                ch[c].data_results.assign(static_cast<size_t>(E), {0.0F, 0.0F});
             }
     }
     const float shifts_init[3] = {-0.5F, 0.0F, 0.5F};
@@ -112,7 +119,7 @@ int main(int argc, char** argv)
         const uint64_t block = 5 * N;  // 5 ms per push
         Hip_Sample_Ring ring(0, 40ull * N, 2 * N);
         EXPECT(ring.ok(), "ring: %s", ring.last_error().c_str());
-        Hip_Correlator_Runtime rt(&ring, C, 1023, std::chrono::microseconds(300));
+        Hip_Correlator_Runtime rt(&ring, pilot ? 2 * C : C, 1023, std::chrono::microseconds(300));
         EXPECT(rt.ok(), "runtime: %s", rt.last_error().c_str());
         if (fails.load()) return 1;
         std::vector<std::atomic<uint64_t>> consumed(C);
@@ -125,6 +132,19 @@ int main(int argc, char** argv)
                 EXPECT(mc[c]->init(2 * N, T), "init: %s", mc[c]->last_error().c_str());
                 mc[c]->set_high_dynamics_resampler(mixed && (c & 1));
                 EXPECT(mc[c]->set_local_code_and_taps(1023, ch[c].code.data(), shifts[c].data()), "set_local_code_and_taps: %s", mc[c]->last_error().c_str());
+            }
+        std::vector<std::unique_ptr<Hip_Multicorrelator_Batched>> md(pilot ? C : 0);
+        std::vector<std::vector<float>> data_code(pilot ? C : 0, std::vector<float>(1023));
+        std::vector<std::vector<float>> data_shift(pilot ? C : 0, std::vector<float>(1, 0.0F));
+        for (int c = 0; pilot && c < C; c++)
+            {
+                oracle_gps_l1_ca_code_gen_float(data_code[c].data(), (c + 7) % 32 + 1, 0);
+                md[c] = std::make_unique<Hip_Multicorrelator_Batched>(&rt);
+                EXPECT(md[c]->init(2 * N, 1), "data init: %s", md[c]->last_error().c_str());
+                md[c]->set_high_dynamics_resampler(false);
+                EXPECT(md[c]->set_local_code_and_taps(1023, data_code[c].data(), data_shift[c].data()), "data code: %s", md[c]->last_error().c_str());
+                mc[c]->set_high_dynamics_resampler(false);
+                if (!pilot_plain) mc[c]->set_companion(md[c].get());
             }
         const auto t0 = std::chrono::steady_clock::now();
         std::thread producer([&] {
@@ -150,7 +170,9 @@ int main(int argc, char** argv)
         for (int c = 0; c < C; c++)
             workers.emplace_back([&, c] {
                 std::complex<float> outs[T];
+                std::complex<float> dout[1] = {{0.0F, 0.0F}};
                 mc[c]->set_input_output_vectors(outs, nullptr);
+                if (pilot) md[c]->set_input_output_vectors(dout, nullptr);  // once, as start_tracking does (trk.cc:668-669)
                 for (int e = 0; e < E; e++)
                     {
                         const uint64_t w0 = ch[c].offset + static_cast<uint64_t>(e) * N;
@@ -160,15 +182,28 @@ int main(int argc, char** argv)
                                 break;
                             }
                         mc[c]->set_input_sample_index(w0);
+                        if (pilot)
+                            {
+                                md[c]->set_input_sample_index(w0);
+                                dout[0] = {-1.0F, -1.0F};
+                            }
                         const bool hd = mixed && (c & 1);
                         const bool ok = mc[c]->Carrier_wipeoff_multicorrelator_resampler(ch[c].rem_carr, ch[c].phase_step, hd ? 2.0e-9F : 0.0F, ch[c].rem_code, ch[c].code_step,
                             hd ? 1.0e-9F : 0.0F, N);
                         EXPECT(ok, "channel %d epoch %d: %s", c, e, mc[c]->last_error().c_str());
                         if (!ok) break;
                         for (int t = 0; t < T; t++) ch[c].results[static_cast<size_t>(e) * T + t] = outs[t];
+                        if (pilot)
+                            {
+                                // trk.cc:1246-1256: the data correlator, same window, same parameters, right after the pilot's
+                                const bool okd = md[c]->Carrier_wipeoff_multicorrelator_resampler(ch[c].rem_carr, ch[c].phase_step, 0.0F, ch[c].rem_code, ch[c].code_step, 0.0F, N);
+                                EXPECT(okd, "data correlator channel %d epoch %d: %s", c, e, md[c]->last_error().c_str());
+                                ch[c].data_results[static_cast<size_t>(e)] = dout[0];
+                            }
                         consumed[c].store(w0 + N, std::memory_order_release);
                     }
                 consumed[c].store(UINT64_MAX, std::memory_order_release);
+                if (pilot) md[c]->free();
                 mc[c]->free();  // leaves the rendezvous: the remaining channels stop waiting for this one
             });
         for (auto& w : workers) w.join();
@@ -194,11 +229,32 @@ int main(int argc, char** argv)
                         EXPECT(err < 1e-6, "channel %d epoch %d tap %d: scale error %.3e", c, e, t, err);
                     }
             }
-    EXPECT(st.jobs == static_cast<uint64_t>(C) * E, "runtime served %llu jobs, expected %d", (unsigned long long)st.jobs, C * E);
+    if (pilot)
+        {
+            const float zero_shift[1] = {0.0F};
+            for (int c = 0; c < C; c++)
+                for (int e = 0; e < E; e += (e < 4 ? 1 : 7))
+                    {
+                        const uint64_t w0 = ch[c].offset + static_cast<uint64_t>(e) * N;
+                        std::vector<float> dc(1023);
+                        oracle_gps_l1_ca_code_gen_float(dc.data(), (c + 7) % 32 + 1, 0);
+                        double truth[2], sabs = 0.0;
+                        oracle_mcorr_f64(dc.data(), 1023, zero_shift, 1, reinterpret_cast<const float*>(xf.data() + w0), N, ch[c].rem_carr, ch[c].phase_step, 0.0F, ch[c].rem_code,
+                            ch[c].code_step, 0.0F, 0, truth, &sabs);
+                        const auto& r = ch[c].data_results[static_cast<size_t>(e)];
+                        const double err = std::hypot(r.real() - truth[0], r.imag() - truth[1]) / sabs;
+                        worst = std::max(worst, err);
+                        EXPECT(err < 1e-6, "data correlator channel %d epoch %d: scale error %.3e (got %g %g)", c, e, err, r.real(), r.imag());
+                    }
+            EXPECT(st.jobs == 2ull * C * E, "runtime served %llu jobs, expected %d", (unsigned long long)st.jobs, 2 * C * E);
+            if (!pilot_plain) EXPECT(st.batches <= static_cast<uint64_t>(E) * 3 / 2 + 8, "companion mode: %llu rendezvous for %d epochs", (unsigned long long)st.batches, E);
+        }
+    else
+        EXPECT(st.jobs == static_cast<uint64_t>(C) * E, "runtime served %llu jobs, expected %d", (unsigned long long)st.jobs, C * E);
 
     // ---------------------------------------------------------------- the synchronous drop-in class, same work, same threads
     double dropin_s = 0.0;
-    if (!mixed)
+    if (!mixed && !pilot)
     {
         const int E2 = std::min(E, 50);
         std::vector<std::unique_ptr<Hip_Multicorrelator_Real_Codes>> mc(C);
@@ -237,7 +293,7 @@ int main(int argc, char** argv)
     std::printf("RUNTIME_STATS {\"channels\": %d, \"epochs\": %d, \"samples_per_epoch\": %d, \"batched_channel_epochs_per_s\": %.1f, "
                 "\"dropin_channel_epochs_per_s\": %.1f, \"batches\": %llu, \"avg_batch\": %.2f, \"largest_batch\": %u, \"timeouts\": %llu, "
                 "\"real_time_factor_batched\": %.2f, \"worst_scale_error\": %.3e}\n",
-        C, E, N, C * static_cast<double>(E) / batched_s, C * static_cast<double>(E) / dropin_s, (unsigned long long)st.batches,
+        C, E, N, C * static_cast<double>(E) / batched_s, dropin_s > 0.0 ? C * static_cast<double>(E) / dropin_s : 0.0, (unsigned long long)st.batches,
         st.batches ? static_cast<double>(st.jobs) / st.batches : 0.0, st.largest_batch, (unsigned long long)st.timeouts, E * 1e-3 / batched_s, worst);
     if (fails.load() == 0) std::printf("RUNTIME OK\n");
     return fails.load() == 0 ? 0 : 1;
