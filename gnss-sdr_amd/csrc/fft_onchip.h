@@ -303,6 +303,58 @@ struct Dft<8>
     }
 };
 
+// Odd prime radix R (7, 11, 13, 31: the 2.046 Msps family is 2 * 3 * 11 * 31).  With s_j = a_j + a_{R-j}, d_j = a_j - a_{R-j}:
+//   X[k], X[R-k] = (a_0 + sum_j s_j cos(2 pi j k / R))  -+  i (sum_j d_j sin(2 pi j k / R)),   j, k = 1 .. (R-1)/2
+// i.e. (R-1)^2 / 2 real-coefficient multiply-adds on complex values instead of (R-1)^2 complex products.
+template <int R>
+struct DftOddPrime
+{
+    static constexpr int H = (R - 1) / 2;
+    static GSH_HD void run(cf (&a)[R])
+    {
+        cf s[H], d[H];
+        static_for<H>([&](auto J) GSH_AI {
+            constexpr int j = decltype(J)::value + 1;
+            s[j - 1] = a[j] + a[R - j];
+            d[j - 1] = a[j] - a[R - j];
+        });
+        const cf a0 = a[0];
+        cf sum = a0;
+        static_for<H>([&](auto J) GSH_AI { sum = sum + s[decltype(J)::value]; });
+        a[0] = sum;
+        static_for<H>([&](auto K) GSH_AI {
+            constexpr int k = decltype(K)::value + 1;
+            cf p = a0, q = cf{0.0f, 0.0f};
+            static_for<H>([&](auto J) GSH_AI {
+                constexpr int j = decltype(J)::value + 1;
+                constexpr float c = static_cast<float>(cx_trig_turn(j * k, R, false));
+                constexpr float sn = static_cast<float>(cx_trig_turn(j * k, R, true));
+                p = p + s[j - 1] * c;
+                q = q + d[j - 1] * sn;
+            });
+            a[k] = add_mj(p, q);      // p - i q
+            a[R - k] = sub_mj(p, q);  // p + i q
+        });
+    }
+};
+
+template <>
+struct Dft<7> : DftOddPrime<7>
+{
+};
+template <>
+struct Dft<11> : DftOddPrime<11>
+{
+};
+template <>
+struct Dft<13> : DftOddPrime<13>
+{
+};
+template <>
+struct Dft<31> : DftOddPrime<31>
+{
+};
+
 // first factor of a composite radix: the largest hand-written butterfly that divides it
 constexpr int first_factor(int r)
 {
@@ -472,6 +524,10 @@ struct Plan
     X(10, 10, 10) /*  1 000: QuickSync folds of 4 000 (p = 4), 1 Msps x 1 ms */ \
     X(10, 10, 20) /*  2 000: 2 Msps x 1 ms (the flowgraph's acquisition resampler for L1 / E1), QuickSync folds of 8 000 */ \
     X(10, 10, 25) /*  2 500: 2.5 Msps x 1 ms (25 Msps decimated by 10) */ \
-    X(10, 25, 25) /*  6 250: 6.25 Msps x 1 ms */
+    X(10, 25, 25) /*  6 250: 6.25 Msps x 1 ms */ \
+    X(6, 11, 31)  /*  2 046: 2.046 Msps x 1 ms */ \
+    X(12, 11, 31) /*  4 092: 4.092 Msps x 1 ms */ \
+    X(24, 11, 31) /*  8 184: 8.184 Msps x 1 ms (GN3S-class front ends), 2.046 Msps x 4 ms (Galileo E1) */ \
+    X(22, 24, 31) /* 16 368: 16.368 Msps x 1 ms, 4.092 Msps x 4 ms */
 
 #endif

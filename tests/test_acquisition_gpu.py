@@ -46,7 +46,7 @@ def _same_peak(res, ora, prec, tag):
                                               (16000, 16000, 16000000, False), (16384, 16384, 16384000, False),
                                               (20000, 20000, 20000000, False), (32768, 32768, 32768000, False),
                                               (1000, 1000, 1000000, False), (2000, 2000, 2000000, False), (2500, 2500, 2500000, False),
-                                              (6250, 6250, 6250000, False)])
+                                              (6250, 6250, 6250000, False), (4092, 4092, 4092000, False), (8184, 8184, 8184000, False)])
 def test_grid_matches_oracle(gpu, n, consumed, fs, bt):
     """FFT sizes with radix-2/3/4/5/8 and generic (11, 31) passes; bit_transition_flag (acq.cc:230-235) and
     fft_size = 2*consumed (sampled_ms != ms_per_code, acq.cc:111,243-247) paddings.  Every length with an on-chip plan
@@ -210,7 +210,7 @@ def test_noncoherent_dwells_center_and_errors(gpu):
         _bank(gpu, max_prn=1, fs_in=fs, fft_size=4007 * 2, doppler_max=5000, doppler_step=500, samples_per_chip=4, samples_per_code=4000.0)  # prime factor 4007
 
 
-@pytest.mark.parametrize("n,fs", [(4000, 4000000), (25000, 25000000), (16384, 16384000), (20000, 20000000), (2000, 2000000), (6250, 6250000)])
+@pytest.mark.parametrize("n,fs", [(4000, 4000000), (25000, 25000000), (16384, 16384000), (20000, 20000000), (2000, 2000000), (6250, 6250000), (2046, 2046000), (8184, 8184000)])
 def test_onchip_agrees_with_fourstep_and_nogrid_rules(gpu, n, fs):
     """Lengths with an on-chip plan: the whole-transform-on-chip kernels and the four-step kernels are two independent
     FFT factorisations of the same dwell -- identical peak indices, values within float32 FFT rounding; with
