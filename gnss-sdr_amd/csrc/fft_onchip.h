@@ -528,6 +528,9 @@ struct Plan
     X(6, 11, 31)  /*  2 046: 2.046 Msps x 1 ms */ \
     X(12, 11, 31) /*  4 092: 4.092 Msps x 1 ms */ \
     X(24, 11, 31) /*  8 184: 8.184 Msps x 1 ms (GN3S-class front ends), 2.046 Msps x 4 ms (Galileo E1) */ \
-    X(22, 24, 31) /* 16 368: 16.368 Msps x 1 ms, 4.092 Msps x 4 ms */
+    X(22, 24, 31) /* 16 368: 16.368 Msps x 1 ms, 4.092 Msps x 4 ms */ \
+    X(16, 11, 31) /*  5 456: 5.456 Msps x 1 ms */ \
+    X(10, 16, 16) /*  2 560: 2.56 Msps x 1 ms */ \
+    X(16, 16, 40) /* 10 240: 2.56 Msps x 4 ms */
 
 #endif

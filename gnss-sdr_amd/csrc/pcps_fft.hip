@@ -24,7 +24,7 @@ namespace gsh
 namespace
 {
 constexpr int FFT_THREADS = 256;
-constexpr int MAX_GENERIC_RADIX = 31;
+constexpr int MAX_GENERIC_RADIX = 61;  // 6.625 Msps (ten of the reference's example configurations) is 6625 = 5^3 * 53 samples per ms
 constexpr int MAX_SUB_LEN_COLS = 1024;  // column-pass sub-transform (x tile_cols x 16 B of LDS)
 constexpr int MAX_SUB_LEN_ROWS = 2048;  // row-pass sub-transform
 constexpr int LDS_BUDGET = 64 * 1024;
@@ -160,7 +160,7 @@ __device__ __forceinline__ void stockham_pass(const float2* __restrict__ x, floa
         }
 }
 
-// generic prime radix (7, 11, 13, ... 31): O(r^2) butterfly, root powers from the twiddle table
+// generic prime radix (7, 11, 13, ... 61): O(r^2) butterfly, root powers from the twiddle table
 __device__ __forceinline__ void stockham_pass_generic(int r, const float2* __restrict__ x, float2* __restrict__ y,
     const float2* __restrict__ tw, int len, int len_s0, int n_inst, int m, int s, int tw_stride)
 {

@@ -479,7 +479,7 @@ extern "C"
     /* Fine-Doppler step of pcps_acquisition_fine_doppler_cc (gnuradio_blocks/pcps_acquisition_fine_doppler_cc.cc:316-389): the
      * n complex64 samples x (host), multiplied element-wise by w when w != NULL (the aligned code replica: code wipe-off, :348), are
      * zero-padded to fft_size, transformed, and the index of the largest |X[k]|^2 (lowest k among equal maxima, :354-358) is returned;
-     * `peak` (nullable) receives that |X|^2.  fft_size needs a four-step split (n1 <= 1024, n2 <= 2048, prime factors <= 31):
+     * `peak` (nullable) receives that |X|^2.  fft_size needs a four-step split (n1 <= 1024, n2 <= 2048, prime factors <= 61):
      * up to ~2 M points, i.e. the block's 80 x samples_per_ms up to 25 Msps. */
     int gsh_spectrum_peak(int device, const float* x_iq, const float* w_iq, uint32_t n, uint32_t fft_size, uint32_t* index, float* peak);
 

@@ -46,7 +46,9 @@ def _same_peak(res, ora, prec, tag):
                                               (16000, 16000, 16000000, False), (16384, 16384, 16384000, False),
                                               (20000, 20000, 20000000, False), (32768, 32768, 32768000, False),
                                               (1000, 1000, 1000000, False), (2000, 2000, 2000000, False), (2500, 2500, 2500000, False),
-                                              (6250, 6250, 6250000, False), (4092, 4092, 4092000, False), (8184, 8184, 8184000, False)])
+                                              (6250, 6250, 6250000, False), (4092, 4092, 4092000, False), (8184, 8184, 8184000, False),
+                                              (5456, 5456, 5456000, False), (2560, 2560, 2560000, False), (10240, 10240, 10240000, False),
+                                              (6625, 6625, 6625000, False), (26500, 26500, 26500000, False)])
 def test_grid_matches_oracle(gpu, n, consumed, fs, bt):
     """FFT sizes with radix-2/3/4/5/8 and generic (11, 31) passes; bit_transition_flag (acq.cc:230-235) and
     fft_size = 2*consumed (sampled_ms != ms_per_code, acq.cc:111,243-247) paddings.  Every length with an on-chip plan
