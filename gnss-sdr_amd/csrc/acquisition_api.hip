@@ -40,6 +40,12 @@ struct gsh_acq
     bool onchip{false};  // whole-transform-on-chip path (pcps_onchip.hip); spectra then sit in natural order
     bool have_input{false};
     float grid_weight{1.0f};  // gsh_acq_set_grid_weight
+    // lengths without any plan (a prime factor above 61 ...): the circular correlation of length N is computed as a linear one inside a
+    // power-of-two transform of M >= 3 N points (signal at [0, N), the code twice at [0, 2 N), lags read from [M - N, M)); conf.fft_size is then M,
+    // conf.effective_fft_size stays N and every magnitude is scaled by (N / M)^2 so that values match an N-point unnormalised inverse
+    bool padded{false};
+    uint32_t logical_n{0};
+    float pad_scale{1.0f};
     double* d_power{nullptr};  // gsh_acq_input_power scratch
     float2* d_tc_code{nullptr};  // gsh_acq_time_correlate: code, delays and results
     size_t tc_code_len{0};
@@ -119,12 +125,12 @@ int enqueue_dwell(gsh_acq* a, uint32_t n_prn, int accumulate, uint32_t dwell_cou
     int rc = gsh::fft_forward(a->plan, a->d_in, 0, static_cast<int>(c.consumed_samples), 0, a->d_bins_hz, static_cast<double>(c.fs_in),
         a->d_tmp, a->d_spectra, a->n_bins, a->stream, static_cast<int>(std::max(1u, c.fold)));
     if (rc != GSH_OK) return rc;
-    const int grid_off = c.bit_transition_flag ? eff : 0;  // acq.cc:544
+    const int grid_off = a->padded ? n - eff : (c.bit_transition_flag ? eff : 0);  // acq.cc:544; padded: the lags sit in the last N outputs
     for (uint32_t p0 = 0; p0 < n_prn; p0 += static_cast<uint32_t>(a->chunk_prn))
         {
             const int np = static_cast<int>(std::min<uint32_t>(a->chunk_prn, n_prn - p0));
             rc = gsh::correlate_grid(a->plan, a->d_spectra, a->d_codes + static_cast<size_t>(p0) * n, a->d_tmp,
-                a->d_grid + static_cast<size_t>(p0) * a->n_bins * eff, np, a->n_bins, grid_off, eff, accumulate, a->grid_weight, a->stream);
+                a->d_grid + static_cast<size_t>(p0) * a->n_bins * eff, np, a->n_bins, grid_off, eff, accumulate, a->grid_weight * a->pad_scale, a->stream);
             if (rc != GSH_OK) return rc;
         }
     return gsh::grid_statistics(a->d_grid, a->d_rows, a->d_results, static_cast<int>(n_prn), a->n_bins, eff,
@@ -356,8 +362,23 @@ extern "C"
                 rc = gsh::plan_create(static_cast<int>(c.fft_size), &a->plan);
                 if (rc != GSH_OK)
                     {
-                        delete a;
-                        return rc;
+                        // no radix schedule for this length: fall back to the zero-padded power-of-two form (plain searches only)
+                        const bool plain = !c.bit_transition_flag && c.consumed_samples == c.fft_size && c.fold <= 1 && c.num_doppler_bins_step2 == 0;
+                        uint64_t m = 4;
+                        while (m < 3ull * c.fft_size) m <<= 1;
+                        if (!plain || m > (1ull << 21) || gsh::plan_create(static_cast<int>(m), &a->plan) != GSH_OK)
+                            {
+                                delete a;
+                                return set_error(GSH_ERR_UNSUPPORTED,
+                                    "fft_size %u has no radix schedule (prime factor above 61) and the zero-padded fallback covers plain searches up to 699050 points only",
+                                    c.fft_size);
+                            }
+                        a->padded = true;
+                        a->logical_n = c.fft_size;
+                        const double ratio = static_cast<double>(c.fft_size) / static_cast<double>(m);
+                        a->pad_scale = static_cast<float>(ratio * ratio);
+                        c.fft_size = static_cast<uint32_t>(m);  // effective_fft_size and consumed_samples stay N
+                        a->conf = c;
                     }
             }
         const size_t n = c.fft_size, eff = c.effective_fft_size, D = a->n_bins, P = c.max_prn;
@@ -452,6 +473,22 @@ extern "C"
         const gsh_acq_conf& c = a->conf;
         // placement rules of acq.cc:230-247
         int n_in, place_off;
+        if (a->padded)
+            {
+                // the code twice, back to back: lag -tau of the linear correlation with [c c] is lag tau of the circular one with c
+                const size_t N = a->logical_n;
+                std::memcpy(a->h_stage, code_iq, sizeof(float2) * N);
+                std::memcpy(a->h_stage + N, code_iq, sizeof(float2) * N);
+                float2* d_code_time = a->d_tmp + static_cast<size_t>(c.fft_size);
+                if (a->n_bins < 2) d_code_time = a->d_spectra;
+                GSH_HIP(hipMemcpyAsync(d_code_time, a->h_stage, sizeof(float2) * 2 * N, hipMemcpyHostToDevice, a->stream));
+                int rcp = gsh::fft_forward(a->plan, d_code_time, 0, static_cast<int>(2 * N), 0, nullptr, 1.0, a->d_tmp, a->d_codes + static_cast<size_t>(prn_slot) * c.fft_size, 1,
+                    a->stream);
+                if (rcp != GSH_OK) return rcp;
+                GSH_HIP(hipStreamSynchronize(a->stream));
+                a->code_set[prn_slot] = 1;
+                return GSH_OK;
+            }
         if (c.bit_transition_flag)
             {
                 n_in = static_cast<int>(c.fft_size / 2);

@@ -346,7 +346,8 @@ extern "C"
     typedef struct gsh_acq_conf
     {
         int64_t fs_in;              /* Acq_Conf::fs_in (resampled_fs when the resampler is on), acq.cc:277 */
-        uint32_t fft_size;          /* d_fft_size, acq.cc:111 */
+        uint32_t fft_size;          /* d_fft_size, acq.cc:111.  Any length: on-chip plans for the common ones, a four-step split for prime factors
+                                       <= 61, and for the rest (plain searches) a zero-padded power-of-two form of the same circular correlation */
         uint32_t effective_fft_size; /* d_effective_fft_size, acq.cc:112 */
         uint32_t consumed_samples;  /* d_consumed_samples, acq.cc:110 */
         uint32_t num_doppler_bins;  /* d_num_doppler_bins, acq.cc:113; 0 = ceil(2*doppler_max/doppler_step) */

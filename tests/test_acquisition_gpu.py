@@ -48,7 +48,8 @@ def _same_peak(res, ora, prec, tag):
                                               (1000, 1000, 1000000, False), (2000, 2000, 2000000, False), (2500, 2500, 2500000, False),
                                               (6250, 6250, 6250000, False), (4092, 4092, 4092000, False), (8184, 8184, 8184000, False),
                                               (5456, 5456, 5456000, False), (2560, 2560, 2560000, False), (10240, 10240, 10240000, False),
-                                              (6625, 6625, 6625000, False), (26500, 26500, 26500000, False)])
+                                              (6625, 6625, 6625000, False), (26500, 26500, 26500000, False),
+                                              (9937, 9937, 9937000, False), (4007, 4007, 4007000, False)])   # 19 * 523 and a prime: zero-padded fallback
 def test_grid_matches_oracle(gpu, n, consumed, fs, bt):
     """FFT sizes with radix-2/3/4/5/8 and generic (11, 31) passes; bit_transition_flag (acq.cc:230-235) and
     fft_size = 2*consumed (sampled_ms != ms_per_code, acq.cc:111,243-247) paddings.  Every length with an on-chip plan
@@ -208,8 +209,9 @@ def test_noncoherent_dwells_center_and_errors(gpu):
     with pytest.raises(GshError):
         acq.dwell(x, 2)  # slot 1 has no code
     acq.close()
-    with pytest.raises(GshError):
-        _bank(gpu, max_prn=1, fs_in=fs, fft_size=4007 * 2, doppler_max=5000, doppler_step=500, samples_per_chip=4, samples_per_code=4000.0)  # prime factor 4007
+    with pytest.raises(GshError):  # prime factor 4007: no radix schedule, and the zero-padded fallback only covers plain searches
+        _bank(gpu, max_prn=1, fs_in=fs, fft_size=4007 * 2, consumed_samples=4007 * 2, bit_transition_flag=True, doppler_max=5000, doppler_step=500, samples_per_chip=4,
+              samples_per_code=4000.0)
 
 
 @pytest.mark.parametrize("n,fs", [(4000, 4000000), (25000, 25000000), (16384, 16384000), (20000, 20000000), (2000, 2000000), (6250, 6250000), (2046, 2046000), (8184, 8184000)])
