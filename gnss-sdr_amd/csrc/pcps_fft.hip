@@ -175,19 +175,40 @@ __device__ __forceinline__ void stockham_pass_generic(int r, const float2* __res
             const int q = rem - p * s;
             const float2* xi = x + inst * len_s0 + q + s * p;
             float2* yo = y + inst * len_s0 + q + s * r * p;
-            float2 a[MAX_GENERIC_RADIX];
-            for (int j = 0; j < r; j++) a[j] = xi[s * m * j];
-            for (int k = 0; k < r; k++)
+            // odd prime r: with s_j = a_j + a_{r-j}, d_j = a_j - a_{r-j} (j = 1 .. h = (r-1)/2)
+            //   X[k], X[r-k] = (a_0 + sum_j s_j cos(2 pi j k / r))  -+  i (sum_j d_j sin(2 pi j k / r))
+            // -- real coefficients times complex values: half the multiplies and half the table reads of r^2 complex products
+            float2 sd[MAX_GENERIC_RADIX];  // s_1..s_h, then d_1..d_h
+            const int h = (r - 1) >> 1;
+            const float2 a0 = xi[0];
+            float2 sum = a0;
+            for (int j = 1; j <= h; j++)
                 {
-                    float2 acc = a[0];
+                    const float2 u = xi[s * m * j], v = xi[s * m * (r - j)];
+                    sd[j - 1] = cadd(u, v);
+                    sd[h + j - 1] = make_float2(u.x - v.x, u.y - v.y);
+                    sum = cadd(sum, sd[j - 1]);
+                }
+            yo[0] = sum;
+            for (int k = 1; k <= h; k++)
+                {
+                    float2 pp = a0, qq = make_float2(0.0f, 0.0f);
                     int e = 0;
-                    for (int j = 1; j < r; j++)
+                    for (int j = 1; j <= h; j++)
                         {
                             e += k;
                             if (e >= r) e -= r;
-                            acc = cadd(acc, cmul(a[j], tw[e * root_stride]));
+                            const float2 w = tw[e * root_stride];  // (cos, -sin) of 2 pi e / r
+                            pp.x = fmaf(sd[j - 1].x, w.x, pp.x);
+                            pp.y = fmaf(sd[j - 1].y, w.x, pp.y);
+                            qq.x = fmaf(sd[h + j - 1].x, w.y, qq.x);  // w.y = -sin: qq = -sum d sin
+                            qq.y = fmaf(sd[h + j - 1].y, w.y, qq.y);
                         }
-                    yo[s * k] = (k == 0) ? acc : cmul(acc, tw[p * k * tw_stride]);
+                    // X[k] = P - i Q with Q = sum d sin = -qq  ->  P + i qq = (P.x - qq.y, P.y + qq.x);  X[r-k] = P - i qq
+                    const float2 xk = make_float2(pp.x - qq.y, pp.y + qq.x);
+                    const float2 xrk = make_float2(pp.x + qq.y, pp.y - qq.x);
+                    yo[s * k] = cmul(xk, tw[p * k * tw_stride]);
+                    yo[s * (r - k)] = cmul(xrk, tw[p * (r - k) * tw_stride]);
                 }
         }
 }
