@@ -151,6 +151,70 @@ class GalileoPcps8msAcquisition:
         return self.state
 
 
+class PcpsCccwsrAcquisition:
+    """general_work of pcps_cccwsr_acquisition_cc for one channel (pcps_cccwsr_acquisition_cc.cc:137-373, cited as cccwsr.cc):
+    coherent channel combining with sign recovery.  The block combines the data and pilot correlations as data + j*pilot and
+    data - j*pilot (cccwsr.cc:235-244).  The correlation is linear in the local code, so those two are the correlations with the
+    local codes (data - j*pilot) and (data + j*pilot): slot 0 and slot 1 of ONE dwell over shared forward transforms, half the
+    inverse transforms of the block as written and no element-wise combination pass."""
+
+    def __init__(self, fs_in: int, fft_size: int, doppler_max: int, doppler_step: int, samples_per_code: float, threshold: float,
+                 max_dwells: int, device: int = 0, transform_path: int = 0):
+        self.n_bins = count_doppler_bins(doppler_max, doppler_step)                               # cccwsr.cc:79-82
+        self.bank = PcpsAcquisitionBank(fs_in, fft_size, doppler_max, doppler_step, 1, samples_per_code, max_prn=2,
+                                        num_doppler_bins=self.n_bins, device=device, transform_path=transform_path)
+        self.fft_size = fft_size
+        self.doppler_max, self.doppler_step = doppler_max, doppler_step
+        self.samples_per_code = int(samples_per_code)
+        self.threshold = np.float32(threshold)
+        self.max_dwells = max_dwells
+        self.init()
+
+    def close(self):
+        self.bank.close()
+
+    def set_local_code(self, code_data: np.ndarray, code_pilot: np.ndarray) -> None:             # cccwsr.cc:116-134
+        d = np.ascontiguousarray(code_data[:self.fft_size], np.complex64)
+        q = np.ascontiguousarray(code_pilot[:self.fft_size], np.complex64)
+        jq = (np.complex64(1j) * q).astype(np.complex64)
+        self.bank.set_local_code(0, (d - jq).astype(np.complex64))                                # -> data + j*pilot correlation
+        self.bank.set_local_code(1, (d + jq).astype(np.complex64))                                # -> data - j*pilot correlation
+
+    def init(self) -> None:                                                                      # cccwsr.cc:152-164 (state 0)
+        self.well_count = 0
+        self.mag = np.float32(0.0)
+        self.input_power = np.float32(0.0)
+        self.test_statistics = np.float32(0.0)
+        self.state = 1
+        self.result = dict(acq_delay_samples=0.0, doppler_hz=0.0, doppler_step=0)
+
+    def work(self, x: np.ndarray) -> int:                                                        # cccwsr.cc:166-306 (state 1)
+        x = np.ascontiguousarray(x[:self.fft_size], np.complex64)
+        fnf = np.float32(self.fft_size) * np.float32(self.fft_size)                               # :178
+        self.well_count += 1                                                                      # :182; d_mag is NOT cleared here
+        self.bank.dwell(x, 2)
+        self.input_power = np.float32(self.bank.input_power())                                    # :192-194
+        pp, tp = self.bank.read_row_peaks(0)
+        pm, tm = self.bank.read_row_peaks(1)
+        self.rows = []
+        for d in range(self.n_bins):
+            mp_ = np.float32(pp[d] / (fnf * fnf))                                                 # :248
+            mm = np.float32(pm[d] / (fnf * fnf))                                                  # :252
+            magt, t, which = (mp_, int(tp[d]), 0) if mp_ >= mm else (mm, int(tm[d]), 1)           # :254-263
+            self.rows.append((float(mp_), int(tp[d]), float(mm), int(tm[d])))
+            if self.mag < magt:                                                                   # :266
+                self.mag = magt
+                self.result = dict(acq_delay_samples=float(t % self.samples_per_code),
+                                   doppler_hz=float(-self.doppler_max + self.doppler_step * d), doppler_step=self.doppler_step,
+                                   index_time=t, index_doppler=d, branch=which)
+        self.test_statistics = np.float32(self.mag / self.input_power)                            # :292
+        if self.test_statistics > self.threshold:                                                 # :295
+            self.state = 2
+        elif self.well_count == self.max_dwells:                                                  # :299
+            self.state = 3
+        return self.state
+
+
 class PcpsQuickSyncAcquisition:
     """general_work of pcps_quicksync_acquisition_cc for one channel (pcps_quicksync_acquisition_cc.cc:155-400, "qs.cc").
     The handle is created with fold = folding_factor^2: wipe-off, folding, both transforms, |.|^2 and the per-bin maxima run in

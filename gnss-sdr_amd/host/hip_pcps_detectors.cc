@@ -259,6 +259,104 @@ int Hip_Galileo_Pcps_8ms_Core::work(uint64_t sample_counter, const std::complex<
 }
 
 
+// ---------------------------------------------------------------------------------------------------------------- CCCWSR
+Hip_Pcps_Cccwsr_Core::Hip_Pcps_Cccwsr_Core(const Hip_Acq_Conf& conf, int device) : d_acq_params(conf)
+{
+    d_fft_size = static_cast<uint32_t>(conf.sampled_ms * conf.samples_per_ms);  // cccwsr.cc:61
+    d_num_doppler_bins = count_bins(conf.doppler_max, conf.doppler_step);       // cccwsr.cc:79-82
+    d_handle = make_handle(conf, d_fft_size, d_num_doppler_bins, 2, device, &d_error);  // slot 0: data - j pilot, slot 1: data + j pilot
+    d_peak_plus.resize(d_num_doppler_bins);
+    d_peak_minus.resize(d_num_doppler_bins);
+    d_index_plus.resize(d_num_doppler_bins);
+    d_index_minus.resize(d_num_doppler_bins);
+    d_code_combined.resize(d_fft_size);
+}
+
+
+Hip_Pcps_Cccwsr_Core::~Hip_Pcps_Cccwsr_Core()
+{
+    if (d_handle != nullptr) gsh_acq_destroy(d_handle);
+}
+
+
+void Hip_Pcps_Cccwsr_Core::set_local_code(const std::complex<float>* code_data, const std::complex<float>* code_pilot)
+{
+    if (d_handle == nullptr) return;
+    // correlating with (data - j pilot) yields data_corr + j pilot_corr, the block's d_correlation_plus (cccwsr.cc:237-239)
+    for (uint32_t i = 0; i < d_fft_size; i++)
+        {
+            d_code_combined[i] = std::complex<float>(code_data[i].real() + code_pilot[i].imag(), code_data[i].imag() - code_pilot[i].real());
+        }
+    if (gsh_acq_set_local_code(d_handle, 0, reinterpret_cast<const float*>(d_code_combined.data())) != GSH_OK) d_error = gsh_last_error();
+    // correlating with (data + j pilot) yields data_corr - j pilot_corr, d_correlation_minus (cccwsr.cc:241-243)
+    for (uint32_t i = 0; i < d_fft_size; i++)
+        {
+            d_code_combined[i] = std::complex<float>(code_data[i].real() - code_pilot[i].imag(), code_data[i].imag() + code_pilot[i].real());
+        }
+    if (gsh_acq_set_local_code(d_handle, 1, reinterpret_cast<const float*>(d_code_combined.data())) != GSH_OK) d_error = gsh_last_error();
+}
+
+
+void Hip_Pcps_Cccwsr_Core::init()
+{
+    d_result = Hip_Detector_Result();
+    d_well_count = 0;
+    d_mag = 0.0;  // cleared here only (cccwsr.cc:160): a running maximum over the dwells of one acquisition
+    d_input_power = 0.0;
+    d_test_statistics = 0.0;
+    d_state = 1;
+}
+
+
+int Hip_Pcps_Cccwsr_Core::work(uint64_t sample_counter, const std::complex<float>* in)
+{
+    if (d_handle == nullptr) return -1;
+    const float fft_normalization_factor = static_cast<float>(d_fft_size) * static_cast<float>(d_fft_size);  // cccwsr.cc:178
+    d_well_count++;
+
+    // one dwell, two code slots, shared forward transforms; the input power is overwritten by every dwell (cccwsr.cc:192-194)
+    gsh_acq_result r[2]{};
+    if (gsh_acq_dwell(d_handle, reinterpret_cast<const float*>(in), 2, 0, 1, r) != GSH_OK || gsh_acq_input_power(d_handle, &d_input_power) != GSH_OK ||
+        gsh_acq_read_row_peaks(d_handle, 0, d_peak_plus.data(), d_index_plus.data()) != GSH_OK ||
+        gsh_acq_read_row_peaks(d_handle, 1, d_peak_minus.data(), d_index_minus.data()) != GSH_OK)
+        {
+            d_error = gsh_last_error();
+            return -1;
+        }
+    for (uint32_t doppler_index = 0; doppler_index < d_num_doppler_bins; doppler_index++)
+        {
+            const int32_t doppler = -d_acq_params.doppler_max + d_acq_params.doppler_step * static_cast<int32_t>(doppler_index);  // cccwsr.cc:200
+            const float magt_plus = d_peak_plus[doppler_index] / (fft_normalization_factor * fft_normalization_factor);    // :248
+            const float magt_minus = d_peak_minus[doppler_index] / (fft_normalization_factor * fft_normalization_factor);  // :252
+            const bool plus = magt_plus >= magt_minus;                                                                      // :254
+            const float magt = plus ? magt_plus : magt_minus;
+            const uint32_t indext = plus ? d_index_plus[doppler_index] : d_index_minus[doppler_index];
+            if (d_mag < magt)  // :266, strictly greater
+                {
+                    d_mag = magt;
+                    d_winning_branch = plus ? 0 : 1;
+                    d_result.index_time = indext;
+                    d_result.index_doppler = doppler_index;
+                    d_result.Acq_delay_samples = static_cast<double>(indext % static_cast<int32_t>(d_acq_params.samples_per_code));
+                    d_result.Acq_doppler_hz = static_cast<double>(doppler);
+                    d_result.Acq_samplestamp_samples = sample_counter;
+                    d_result.Acq_doppler_step = static_cast<uint32_t>(d_acq_params.doppler_step);
+                }
+        }
+
+    d_test_statistics = d_mag / d_input_power;  // cccwsr.cc:292
+    if (d_test_statistics > d_acq_params.threshold)
+        {
+            d_state = 2;  // Positive acquisition
+        }
+    else if (d_well_count == d_acq_params.max_dwells)
+        {
+            d_state = 3;  // Negative acquisition
+        }
+    return d_state;
+}
+
+
 // ---------------------------------------------------------------------------------------------------------------- QuickSync
 Hip_Pcps_Quicksync_Core::Hip_Pcps_Quicksync_Core(const Hip_Acq_Conf& conf, uint32_t code_length, uint32_t folding_factor, uint32_t max_dwells, int device)
     : d_acq_params(conf), d_samples_per_code(code_length), d_folding_factor(folding_factor), d_max_dwells(max_dwells)

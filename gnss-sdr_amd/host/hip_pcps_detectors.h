@@ -113,6 +113,50 @@ private:
     uint32_t d_fft_size{0}, d_num_doppler_bins{0};
 };
 
+/*!
+ * \brief The search of pcps_cccwsr_acquisition_cc (coherent channel combining with sign recovery,
+ * pcps_cccwsr_acquisition_cc.cc:137-373, cited as cccwsr.cc) on the HIP engine.
+ * The block forms data_corr + j pilot_corr and data_corr - j pilot_corr per cell (cccwsr.cc:235-244); the correlation is linear
+ * in the local code, so these are the correlations with (data - j pilot) and (data + j pilot): slot 0 and slot 1 of one dwell.
+ */
+class Hip_Pcps_Cccwsr_Core
+{
+public:
+    explicit Hip_Pcps_Cccwsr_Core(const Hip_Acq_Conf& conf, int device = 0);
+    ~Hip_Pcps_Cccwsr_Core();
+    Hip_Pcps_Cccwsr_Core(const Hip_Pcps_Cccwsr_Core&) = delete;
+    Hip_Pcps_Cccwsr_Core& operator=(const Hip_Pcps_Cccwsr_Core&) = delete;
+
+    bool ok() const { return d_handle != nullptr; }
+    const std::string& last_error() const { return d_error; }
+
+    void set_local_code(const std::complex<float>* code_data, const std::complex<float>* code_pilot);  //!< cccwsr.cc:116-134
+    void init();                                                                                       //!< state 0, cccwsr.cc:152-164
+    int work(uint64_t sample_counter, const std::complex<float>* in);                                  //!< state 1, cccwsr.cc:166-306
+
+    const Hip_Detector_Result& result() const { return d_result; }
+    uint32_t num_doppler_bins() const { return d_num_doppler_bins; }
+    uint32_t fft_size() const { return d_fft_size; }
+    int winning_branch() const { return d_winning_branch; }  //!< 0 = data + j pilot, 1 = data - j pilot (not exposed by the reference; for tests)
+    float mag() const { return d_mag; }
+    float input_power() const { return d_input_power; }
+    float test_statistics() const { return d_test_statistics; }
+    int state() const { return d_state; }
+
+private:
+    Hip_Acq_Conf d_acq_params;
+    gsh_acq* d_handle{nullptr};
+    std::string d_error;
+    Hip_Detector_Result d_result;
+    std::vector<float> d_peak_plus, d_peak_minus;
+    std::vector<uint32_t> d_index_plus, d_index_minus;
+    std::vector<std::complex<float>> d_code_combined;
+    float d_mag{0.0F}, d_input_power{0.0F}, d_test_statistics{0.0F};
+    int d_state{0}, d_winning_branch{0};
+    uint32_t d_well_count{0};
+    uint32_t d_fft_size{0}, d_num_doppler_bins{0};
+};
+
 class Hip_Pcps_Quicksync_Core
 {
 public:

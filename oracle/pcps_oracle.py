@@ -379,6 +379,77 @@ class Galileo8msOracle:
         return self.state
 
 
+class CccwsrOracle:
+    """pcps_cccwsr_acquisition_cc::general_work (pcps_cccwsr_acquisition_cc.cc:137-373, cited as cccwsr.cc:line): coherent
+    channel combining with sign recovery.  Per Doppler bin the wiped-off block is correlated with the data code and with
+    the pilot code SEPARATELY (two inverse transforms), the two complex correlations are combined as data + j*pilot and
+    data - j*pilot, and the larger of the two maxima is kept.  Restated literally -- the product uses one transform per
+    branch with pre-combined local codes, so parity against this class also checks that identity.
+    Reference behaviour kept as is: d_mag is cleared in state 0 only (cccwsr.cc:160), so it is a running maximum over the
+    dwells of one acquisition, while d_input_power is overwritten by every dwell (cccwsr.cc:192-194).
+    Note for tests: when data and pilot components share one carrier phase the two branches have EQUAL expected peaks
+    (|b + j s|^2 == |b - j s|^2), so which branch wins is decided by rounding; compare what the block publishes (delay,
+    Doppler, statistic, state), not the branch."""
+
+    def __init__(self, fs_in: int, fft_size: int, doppler_max: int, doppler_step: int, samples_per_code: float, threshold: float,
+                 max_dwells: int):
+        self.n_bins = count_doppler_bins(doppler_max, doppler_step)                               # cccwsr.cc:79-82
+        self.pa = PcpsOracle(fs_in, fft_size, doppler_max, doppler_step, 1, samples_per_code, num_doppler_bins=self.n_bins)
+        self.fft_size = fft_size
+        self.samples_per_code = int(samples_per_code)
+        self.threshold = np.float32(threshold)
+        self.max_dwells = max_dwells
+        self.init()
+
+    def set_local_code(self, code_data: np.ndarray, code_pilot: np.ndarray):                      # cccwsr.cc:116-134
+        self.pa.set_local_code(np.asarray(code_data[:self.fft_size], np.complex64))
+        self.fft_code_data = self.pa.fft_codes
+        self.pa.set_local_code(np.asarray(code_pilot[:self.fft_size], np.complex64))
+        self.fft_code_pilot = self.pa.fft_codes
+
+    def init(self):                                                                              # cccwsr.cc:152-164 (state 0)
+        self.well_count = 0
+        self.mag = np.float32(0.0)
+        self.input_power = np.float32(0.0)
+        self.test_statistics = np.float32(0.0)
+        self.state = 1
+        self.result = dict(acq_delay_samples=0.0, doppler_hz=0.0, doppler_step=0)
+
+    def work(self, x: np.ndarray) -> int:                                                        # cccwsr.cc:166-306 (state 1)
+        p = self.pa
+        n = self.fft_size
+        x = np.asarray(x[:n], np.complex64)
+        fnf = np.float32(n) * np.float32(n)                                                       # :178
+        self.well_count += 1                                                                      # :182
+        self.input_power = mean_input_power(x)                                                    # :192-194
+        self.rows = []
+        for d in range(self.n_bins):
+            doppler = -int(p.doppler_max) + p.doppler_step * d                                    # :200
+            A = scipy.fft.fft((x * p.wipe[d]).astype(np.complex64))                               # :202-207
+            cd = (scipy.fft.ifft((A * self.fft_code_data).astype(np.complex64)) * np.complex64(n)).astype(np.complex64)    # :212-220
+            cp = (scipy.fft.ifft((A * self.fft_code_pilot).astype(np.complex64)) * np.complex64(n)).astype(np.complex64)   # :225-233
+            best = []
+            for sgn in (np.float32(1.0), np.float32(-1.0)):                                       # :235-244
+                re = (cd.real - sgn * cp.imag).astype(np.float32)
+                im = (cd.imag + sgn * cp.real).astype(np.float32)
+                mag = (re * re + im * im).astype(np.float32)                                      # :246, :250
+                t = p._argmax(mag)                                                                # :247, :251
+                best.append((np.float32(mag[t] / (fnf * fnf)), t))                                # :248, :252
+            (mp_, tp), (mm, tm) = best
+            magt, t, which = (mp_, tp, 0) if mp_ >= mm else (mm, tm, 1)                           # :254-263
+            self.rows.append((float(mp_), tp, float(mm), tm))
+            if self.mag < magt:                                                                   # :266 strict
+                self.mag = magt
+                self.result = dict(acq_delay_samples=float(t % self.samples_per_code), doppler_hz=float(doppler),
+                                   doppler_step=p.doppler_step, index_time=t, index_doppler=d, branch=which)
+        self.test_statistics = np.float32(self.mag / self.input_power)                            # :292
+        if self.test_statistics > self.threshold:                                                 # :295
+            self.state = 2
+        elif self.well_count == self.max_dwells:                                                  # :299
+            self.state = 3
+        return self.state
+
+
 class QuickSyncOracle:
     """pcps_quicksync_acquisition_cc::general_work (pcps_quicksync_acquisition_cc.cc:155-360), bit_transition_flag = false:
     the block of folding_factor code periods is wiped off, folded (its folding_factor^2 segments of fft_size =

@@ -49,6 +49,37 @@ def e1_8ms_case(flip: bool, prn: int = 11, cn0: float = 44.0, seed: int = 8, sig
     return x, kw, e1b_local_code_8ms(prn), delay_samples if signal else 0.0
 
 
+def e1_local_code_4ms(prn: int, component: str) -> np.ndarray:
+    """one 4 ms period of the E1B ("e1b") or E1C ("e1c") sinBOC(1,1) replica at 4 Msps (what
+    galileo_e1_pcps_cccwsr_ambiguous_acquisition.cc:57-69 hands to set_local_code: data = 1B, pilot = 1C)."""
+    c = golden_e1_l5_codes()[component][prn - 1]
+    idx = np.floor(np.arange(16000) * (8184.0 / 16000.0)).astype(np.int64)
+    return c[idx].astype(np.complex64)
+
+
+def cccwsr_case(mode: str = "inphase", data_sign: float = 1.0, pilot_sign: float = -1.0, prn: int = 10, cn0: float = 44.0,
+                seed: int = 13, signal: bool = True, n_blocks: int = 2):
+    """galileo_e1_pcps_cccwsr_ambiguous_acquisition_gsoc2013_test.cc:265-350 (config_2): Galileo PRN 10, 4 ms at 4 Msps, 750 Hz, delay 600 chips,
+    44 dB-Hz, doppler_max 10000, step 250, max_dwells 1, threshold 0.00215.
+    mode "inphase": data_sign*E1B + pilot_sign*E1C on one carrier phase (the E1 composite is E1B - E1C) -- both combining branches
+    then have equal expected peaks.  mode "quadrature": the pilot is rotated by +90 degrees, so exactly one branch combines coherently
+    (data + j*pilot sees data_sign - pilot_sign, data - j*pilot sees data_sign + pilot_sign)."""
+    n = 16000
+    rng = np.random.default_rng(seed)
+    x = (rng.standard_normal(n_blocks * n) + 1j * rng.standard_normal(n_blocks * n)).astype(np.complex64)
+    delay_samples = 600.0 * (4000000.0 / 1.023e6)
+    if signal:
+        g = golden_e1_l5_codes()
+        amp = cn0_to_amplitude(cn0, FS)
+        nn = np.arange(n_blocks * n, dtype=np.float64)
+        idx = np.floor((nn - delay_samples) * (8184.0 / 16000.0)).astype(np.int64) % 8184
+        rot = 1.0 if mode == "inphase" else 1j
+        comp = data_sign * g["e1b"][prn - 1][idx] + rot * pilot_sign * g["e1c"][prn - 1][idx]
+        x += (amp * comp * np.exp(2j * np.pi * 750.0 / FS * nn)).astype(np.complex64)
+    kw = dict(fs_in=FS, fft_size=n, doppler_max=10000, doppler_step=250, samples_per_code=16000.0, threshold=0.00215, max_dwells=1)
+    return x, kw, e1_local_code_4ms(prn, "e1b"), e1_local_code_4ms(prn, "e1c"), delay_samples if signal else 0.0
+
+
 def quicksync_case(fs: int = 8000000, folding_factor: int = 4, signal: bool = True, seed: int = 2014):
     """gps_l1_ca_pcps_quicksync_acquisition_gsoc2014_test.cc:222-279: PRN 10, 750 Hz, 600 chips, 44 dB-Hz, fs 8 Msps, 4 ms, the
     adapter's default folding factor ceil(sqrt(log2(8000))) = 4 (gps_l1_ca_pcps_quicksync_acquisition.cc:39), doppler_max 10000,

@@ -281,6 +281,81 @@ int main()
         e8.init();
         EXPECT(e8.work(8000, noise.data()) == 3, "8ms noise-only state %d statistic %g", e8.state(), e8.test_statistics());
     }
+    // ---------------------------------------------------------------- CCCWSR detector, pcps_cccwsr_acquisition_cc call pattern
+    {
+        // the class is code-agnostic: C/A PRN 7 stands in for the data code and PRN 9 for the pilot code (the E1B / E1C case of
+        // galileo_e1_pcps_cccwsr_ambiguous_acquisition_gsoc2013_test.cc runs in tests/test_pcps_detectors_gpu.py)
+        const double amp = std::sqrt(std::pow(10.0, 4.4) * 2.0 / 4e6);
+        Hip_Acq_Conf conf;
+        conf.fs_in = 4000000;
+        conf.sampled_ms = 2;
+        conf.ms_per_code = 1;
+        conf.doppler_max = 5000;
+        conf.doppler_step = 250;
+        conf.max_dwells = 1;
+        conf.SetDerivedParams();
+        // the threshold is configuration-given for this block: its adapter passes ThresholdComputeBasic
+        // (galileo_e1_pcps_cccwsr_ambiguous_acquisition.cc:45), pfa is not used.  The single-code Pfa formula would be wrong here anyway:
+        // the combined local codes (data -+ j pilot) carry twice the energy of one code and there are two branches, so the maximum of a
+        // noise-only grid sits near 2 ln(2 * 8000 * 41) / 8000 = 0.0034 (0.00323 measured for seed 77), twice the single-code value.
+        // The coherent branch of the 44 dB-Hz signal gives about 4 A^2 / 2 = 0.025.
+        conf.threshold = 0.008F;
+        std::vector<float> one(2 * 4000), data_iq(2 * 8000), pilot_iq(2 * 8000);
+        oracle_gps_l1_ca_code_gen_complex_sampled(one.data(), 7, 4000000, 0);
+        for (int i = 0; i < 8000; i++) data_iq[i] = one[i], data_iq[8000 + i] = one[i];
+        oracle_gps_l1_ca_code_gen_complex_sampled(one.data(), 9, 4000000, 0);
+        for (int i = 0; i < 8000; i++) pilot_iq[i] = one[i], pilot_iq[8000 + i] = one[i];
+        const auto* cd = reinterpret_cast<const std::complex<float>*>(data_iq.data());
+        const auto* cp = reinterpret_cast<const std::complex<float>*>(pilot_iq.data());
+        // same seed, amplitude 0: the same noise draws (make_signal draws per sample whatever amp is) -> the bare pilot component
+        auto pilot_part = make_signal(8000, 4e6, 9, -1250.0, 0.0, amp, 41);
+        const auto pilot_noise = make_signal(8000, 4e6, 9, -1250.0, 0.0, 0.0, 41);
+        for (int i = 0; i < 8000; i++) pilot_part[i] -= pilot_noise[i];
+        // mode 0/1: pilot in quadrature (+90 deg) with sign +1 / -1: data + j pilot sees (1 - s), data - j pilot sees (1 + s) -> branch 1 / 0
+        // mode 2: pilot in phase, sign -1 (the E1 composite): equal expected peaks in both branches, only the published values are checked
+        for (int mode = 0; mode < 3; mode++)
+            {
+                auto x = make_signal(8000, 4e6, 7, -1250.0, 0.0, amp, 51 + mode);
+                const std::complex<float> w = mode == 0 ? std::complex<float>(0, 1) : (mode == 1 ? std::complex<float>(0, -1) : std::complex<float>(-1, 0));
+                for (int i = 0; i < 8000; i++) x[i] += w * pilot_part[i];
+                Hip_Pcps_Cccwsr_Core cw(conf, 0);
+                EXPECT(cw.ok() && cw.num_doppler_bins() == 41 && cw.fft_size() == 8000, "cccwsr create: %s", cw.last_error().c_str());
+                cw.set_local_code(cd, cp);
+                cw.init();
+                const int st = cw.work(8000, x.data());
+                EXPECT(st == 2, "cccwsr mode %d state %d (%s), statistic %g threshold %g", mode, st, cw.last_error().c_str(), cw.test_statistics(), conf.threshold);
+                if (mode < 2) EXPECT(cw.winning_branch() == (mode == 0 ? 1 : 0), "cccwsr mode %d picked branch %d", mode, cw.winning_branch());
+                EXPECT(cw.result().Acq_delay_samples < 2.0 || cw.result().Acq_delay_samples > 3998.0, "cccwsr mode %d delay %f", mode, cw.result().Acq_delay_samples);
+                EXPECT(std::abs(cw.result().Acq_doppler_hz + 1250.0) <= 250.0, "cccwsr mode %d doppler %f", mode, cw.result().Acq_doppler_hz);
+                EXPECT(cw.result().Acq_samplestamp_samples == 8000, "cccwsr sample stamp");
+                EXPECT(cw.input_power() > 1.9F && cw.input_power() < 2.3F, "cccwsr input power %g", cw.input_power());
+            }
+        // noise only: negative after max_dwells; then the running maximum (cccwsr.cc:160: d_mag is cleared in state 0 only) over two dwells
+        auto noise = make_signal(8000, 4e6, 7, 0.0, 0.0, 0.0, 77);
+        {
+            Hip_Pcps_Cccwsr_Core cw(conf, 0);
+            cw.set_local_code(cd, cp);
+            cw.init();
+            EXPECT(cw.work(8000, noise.data()) == 3, "cccwsr noise-only state %d statistic %g", cw.state(), cw.test_statistics());
+        }
+        {
+            Hip_Acq_Conf conf2 = conf;
+            conf2.max_dwells = 2;
+            conf2.threshold = 1e9F;
+            auto x = make_signal(8000, 4e6, 7, -1250.0, 0.0, amp, 53);
+            for (int i = 0; i < 8000; i++) x[i] -= pilot_part[i];
+            Hip_Pcps_Cccwsr_Core cw(conf2, 0);
+            cw.set_local_code(cd, cp);
+            cw.init();
+            EXPECT(cw.work(8000, x.data()) == 1, "cccwsr dwell 1 of 2 state %d", cw.state());
+            const float mag1 = cw.mag();
+            const double delay1 = cw.result().Acq_delay_samples;
+            EXPECT(cw.work(16000, noise.data()) == 3, "cccwsr dwell 2 of 2 state %d", cw.state());
+            EXPECT(cw.mag() == mag1 && cw.result().Acq_delay_samples == delay1 && cw.result().Acq_samplestamp_samples == 8000,
+                "cccwsr running maximum: mag %g -> %g, stamp %llu", mag1, cw.mag(), static_cast<unsigned long long>(cw.result().Acq_samplestamp_samples));
+            EXPECT(cw.test_statistics() == mag1 / cw.input_power(), "cccwsr statistic uses the last dwell's power");
+        }
+    }
     // ---------------------------------------------------------------- QuickSync detector, pcps_quicksync_acquisition_cc call pattern
     {
         // gps_l1_ca_pcps_quicksync_acquisition_gsoc2014_test.cc:222-279: fs 8 Msps, 4 ms, PRN 10, 750 Hz, 600 chips, folding factor 4

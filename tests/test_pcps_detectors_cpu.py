@@ -3,8 +3,8 @@ reference's own synthetic test cases (gps_l1_ca_pcps_tong_acquisition_gsoc2013_t
 galileo_e1_pcps_8ms_ambiguous_acquisition_gsoc2013_test.cc): delay error < 0.5 chip, Doppler error < 2 / (3 T)."""
 import numpy as np
 
-from oracle.pcps_oracle import FineDopplerOracle, Galileo8msOracle, QuickSyncOracle, TongOracle, count_doppler_bins, mean_input_power
-from detector_cases import e1_8ms_case, fine_doppler_case, quicksync_case, tong_case
+from oracle.pcps_oracle import CccwsrOracle, FineDopplerOracle, Galileo8msOracle, QuickSyncOracle, TongOracle, count_doppler_bins, mean_input_power
+from detector_cases import cccwsr_case, e1_8ms_case, fine_doppler_case, quicksync_case, tong_case
 
 
 def test_bin_count_is_inclusive():
@@ -118,3 +118,72 @@ def test_fine_doppler_block_as_written_and_with_the_consistent_grid():
     o.set_local_code(code)
     o.dwell(x[:n]); o.dwell(x[n:2 * n])
     assert o.decide() == 5
+
+
+def test_cccwsr_known_answer_of_the_reference_test():
+    """galileo_e1_pcps_cccwsr_ambiguous_acquisition_gsoc2013_test.cc:265-350 + its checks: positive, delay error < 0.5 chip,
+    Doppler error < 2 / (3 * 4 ms)."""
+    x, kw, cd, cp, delay = cccwsr_case("inphase")
+    o = CccwsrOracle(**kw)
+    o.set_local_code(cd, cp)
+    assert o.work(x[:16000]) == 2
+    expected = delay % 16000.0
+    err = abs(o.result["acq_delay_samples"] - expected)
+    err = min(err, 16000.0 - err)
+    assert err < 0.5 * 4000000.0 / 1.023e6
+    assert abs(o.result["doppler_hz"] - 750.0) < 2.0 / (3.0 * 4e-3)
+    # in-phase components: both branches peak at the same place with nearly equal values (see the oracle's note)
+    d = o.result["index_doppler"]
+    assert o.rows[d][1] == o.rows[d][3]
+    assert abs(o.rows[d][0] - o.rows[d][2]) < 0.2 * o.rows[d][0]
+
+
+def test_cccwsr_sign_recovery_picks_the_coherent_branch():
+    for ds, ps, branch in ((1.0, -1.0, 0), (1.0, 1.0, 1), (-1.0, 1.0, 0), (-1.0, -1.0, 1)):
+        x, kw, cd, cp, _ = cccwsr_case("quadrature", data_sign=ds, pilot_sign=ps)
+        o = CccwsrOracle(**kw)
+        o.set_local_code(cd, cp)
+        assert o.work(x[:16000]) == 2
+        assert o.result["branch"] == branch, (ds, ps)
+        d = o.result["index_doppler"]
+        win, lose = (o.rows[d][0], o.rows[d][2]) if branch == 0 else (o.rows[d][2], o.rows[d][0])
+        assert win > 8.0 * lose   # the other branch sees data and pilot cancel: only noise is left there
+
+
+def test_cccwsr_noise_only_negative_and_running_maximum_over_dwells():
+    x, kw, cd, cp, _ = cccwsr_case(signal=False)
+    o = CccwsrOracle(**kw)
+    o.set_local_code(cd, cp)
+    assert o.work(x[:16000]) == 3
+    # d_mag is cleared in state 0 only (cccwsr.cc:160): dwell 2 on a weaker block keeps dwell 1's peak and its parameters,
+    # while the input power is the second block's (cccwsr.cc:192-194)
+    xs, kw, cd, cp, _ = cccwsr_case("inphase", n_blocks=1)
+    kw2 = dict(kw, max_dwells=2, threshold=1e9)
+    o = CccwsrOracle(**kw2)
+    o.set_local_code(cd, cp)
+    assert o.work(xs[:16000]) == 1
+    mag1, res1 = o.mag, dict(o.result)
+    assert o.work(x[:16000]) == 3
+    assert o.mag == mag1 and o.result == res1
+    assert o.input_power == mean_input_power(x[:16000])
+    assert o.test_statistics == np.float32(mag1 / mean_input_power(x[:16000]))
+
+
+def test_cccwsr_branches_are_correlations_with_combined_codes():
+    """the identity the product core rests on: data_corr + j pilot_corr == correlation with (data - j pilot), and the
+    minus branch with (data + j pilot) -- checked in float64, independently of the oracle and of the GPU path."""
+    x, kw, cd, cp, _ = cccwsr_case("quadrature", data_sign=1.0, pilot_sign=1.0)
+    o = CccwsrOracle(**kw)
+    o.set_local_code(cd, cp)
+    o.work(x[:16000])
+    d = o.result["index_doppler"]
+    n = 16000
+    xw = x[:n].astype(np.complex128) * np.exp(-2j * np.pi * (-10000 + 250 * d) / 4000000.0 * np.arange(n))
+    X = np.fft.fft(xw)
+    for k, code in ((0, cd.astype(np.complex128) - 1j * cp.astype(np.complex128)), (2, cd.astype(np.complex128) + 1j * cp.astype(np.complex128))):
+        y = np.fft.ifft(X * np.conj(np.fft.fft(code))) * n
+        mag = np.abs(y) ** 2 / float(n) ** 4                       # unnormalised inverse, / fft_size^4 (cccwsr.cc:178, :248)
+        t = int(np.argmax(mag))
+        if o.rows[d][k] > 8.0 * min(o.rows[d][0], o.rows[d][2]):   # the coherent branch: a defined peak
+            assert t == o.rows[d][k + 1]
+        assert abs(mag[o.rows[d][k + 1]] - o.rows[d][k]) <= 2e-4 * max(o.rows[d][0], o.rows[d][2])

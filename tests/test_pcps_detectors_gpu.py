@@ -1,13 +1,14 @@
-"""GPU parity tests of the Tong and Galileo 8 ms detectors (gnss_sdr_amd/detectors.py over the C ABI: weighted grid
-accumulation, input power, per-bin peaks) against oracle/pcps_oracle.py (TongOracle, Galileo8msOracle) on the reference's own
+"""GPU parity tests of the Tong, Galileo 8 ms, CCCWSR, QuickSync and fine-Doppler detectors (gnss_sdr_amd/detectors.py over the C ABI:
+weighted grid accumulation, input power, per-bin peaks) against oracle/pcps_oracle.py (TongOracle, Galileo8msOracle, CccwsrOracle,
+QuickSyncOracle, FineDopplerOracle) on the reference's own
 synthetic cases.  Bars: the state / counter trajectory, peak time index and Doppler bin of every dwell equal the oracle's
 (integer work: bit-exact); input power within 1e-6 relative (float sum order, see gsh_acq_input_power); statistics within
 RTOL (float32 transforms of different factorisation)."""
 import numpy as np
 import pytest
 
-from oracle.pcps_oracle import FineDopplerOracle, Galileo8msOracle, QuickSyncOracle, TongOracle
-from detector_cases import e1_8ms_case, fine_doppler_case, quicksync_case, tong_case
+from oracle.pcps_oracle import CccwsrOracle, FineDopplerOracle, Galileo8msOracle, QuickSyncOracle, TongOracle
+from detector_cases import cccwsr_case, e1_8ms_case, fine_doppler_case, quicksync_case, tong_case
 
 pytestmark = pytest.mark.gpu
 
@@ -229,3 +230,73 @@ def test_spectrum_peak_primitive(gpu):
     assert int(k.value) == 100
     with pytest.raises(GshError):
         check(lib.gsh_spectrum_peak(gpu, fptr(x), None, n, 2 * 1009 * 1013, C.byref(k), C.byref(pk)))   # no four-step split
+
+
+def _cccwsr_pair(gpu, kw, cd, cp, path=0):
+    from gnss_sdr_amd.detectors import PcpsCccwsrAcquisition
+    o = CccwsrOracle(**kw)
+    g = PcpsCccwsrAcquisition(device=gpu, transform_path=path, **kw)
+    o.set_local_code(cd, cp)
+    g.set_local_code(cd, cp)
+    return o, g
+
+
+def _cccwsr_compare_published(o, g):
+    """what the block publishes: state, delay, Doppler, statistic (+ the input power behind it)"""
+    assert g.state == o.state
+    for k in ("acq_delay_samples", "doppler_hz", "doppler_step", "index_time", "index_doppler"):
+        assert g.result[k] == o.result[k], k
+    assert abs(float(g.input_power) - float(o.input_power)) <= 1e-6 * float(o.input_power)
+    assert abs(float(g.test_statistics) - float(o.test_statistics)) <= RTOL * float(o.test_statistics)
+
+
+@pytest.mark.parametrize("path", [0, 1])
+@pytest.mark.parametrize("ds,ps", [(1.0, -1.0), (1.0, 1.0), (-1.0, 1.0), (-1.0, -1.0)])
+def test_cccwsr_quadrature_matches_oracle(gpu, ds, ps, path):
+    """pilot in quadrature: one branch combines coherently, the other cancels -- the branch is defined and must equal the oracle's,
+    which forms the two branches the block's way (two inverse transforms + element-wise +-j combination, cccwsr.cc:212-252)
+    while the engine correlates once per branch with the combined local codes."""
+    x, kw, cd, cp, _ = cccwsr_case("quadrature", data_sign=ds, pilot_sign=ps)
+    o, g = _cccwsr_pair(gpu, kw, cd, cp, path)
+    assert o.work(x[:16000]) == g.work(x[:16000]) == 2
+    _cccwsr_compare_published(o, g)
+    assert g.result["branch"] == o.result["branch"]
+    d = o.result["index_doppler"]
+    big = max(o.rows[d][0], o.rows[d][2])
+    for k in (0, 2):   # both branch maxima at the winning bin; the cancelled branch is noise-level, so scale by the winner
+        assert abs(g.rows[d][k] - o.rows[d][k]) <= RTOL * big
+    w = 1 + 2 * o.result["branch"]
+    assert g.rows[d][w] == o.rows[d][w]
+    g.close()
+
+
+def test_cccwsr_reference_case_inphase(gpu):
+    """galileo_e1_pcps_cccwsr_ambiguous_acquisition_gsoc2013_test.cc config_2: E1B - E1C on one carrier phase.  Both branches then
+    peak at the same cell with nearly equal values, and which one the reference itself picks is decided by float rounding
+    (oracle/pcps_oracle.py CccwsrOracle note): the published values are compared, the branch is not."""
+    x, kw, cd, cp, delay = cccwsr_case("inphase")
+    o, g = _cccwsr_pair(gpu, kw, cd, cp)
+    assert o.work(x[:16000]) == g.work(x[:16000]) == 2
+    _cccwsr_compare_published(o, g)
+    d = o.result["index_doppler"]
+    assert g.rows[d][1] == g.rows[d][3] == o.rows[d][1] == o.rows[d][3]
+    for k in (0, 2):
+        assert abs(g.rows[d][k] - o.rows[d][k]) <= RTOL * o.rows[d][k]
+    g.close()
+
+
+def test_cccwsr_noise_only_and_running_maximum(gpu):
+    x, kw, cd, cp, _ = cccwsr_case(signal=False)
+    o, g = _cccwsr_pair(gpu, kw, cd, cp)
+    assert o.work(x[:16000]) == g.work(x[:16000]) == 3
+    assert abs(float(g.test_statistics) - float(o.test_statistics)) <= RTOL * float(o.test_statistics)
+    g.close()
+    # two dwells of one acquisition: the peak of dwell 1 survives dwell 2 (cccwsr.cc:160), the power is dwell 2's (cccwsr.cc:192-194)
+    xs, kw, cd, cp, _ = cccwsr_case("quadrature", n_blocks=1)
+    o, g = _cccwsr_pair(gpu, dict(kw, max_dwells=2, threshold=1e9), cd, cp)
+    assert o.work(xs[:16000]) == g.work(xs[:16000]) == 1
+    mag1 = g.mag
+    assert o.work(x[:16000]) == g.work(x[:16000]) == 3
+    assert g.mag == mag1
+    _cccwsr_compare_published(o, g)
+    g.close()
