@@ -155,8 +155,9 @@ class PcpsCccwsrAcquisition:
     """general_work of pcps_cccwsr_acquisition_cc for one channel (pcps_cccwsr_acquisition_cc.cc:137-373, cited as cccwsr.cc):
     coherent channel combining with sign recovery.  The block combines the data and pilot correlations as data + j*pilot and
     data - j*pilot (cccwsr.cc:235-244).  The correlation is linear in the local code, so those two are the correlations with the
-    local codes (data - j*pilot) and (data + j*pilot): slot 0 and slot 1 of ONE dwell over shared forward transforms, half the
-    inverse transforms of the block as written and no element-wise combination pass."""
+    local codes (data - j*pilot) and (data + j*pilot): slot 0 and slot 1 of ONE dwell over shared forward transforms -- the same
+    one forward + two inverse transforms per bin as the block, without its two complex correlation vectors and the element-wise
+    combination pass over them (|.|^2 and arg-max of each branch are fused into the cell kernel)."""
 
     def __init__(self, fs_in: int, fft_size: int, doppler_max: int, doppler_step: int, samples_per_code: float, threshold: float,
                  max_dwells: int, device: int = 0, transform_path: int = 0):
