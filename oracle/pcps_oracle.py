@@ -3,15 +3,18 @@
 Follows pcps_acquisition (src/algorithms/acquisition/gnuradio_blocks/pcps_acquisition.cc, cited per function as
 acq.cc:line) in float32 / complex64, in the reference's order of operations.
 
-Parity status: the in-tree pieces are PINNED -- the Doppler wipe-off table goes through oracle_sincos
-(== volk_gnsssdr_s32f_sincos_32fc_generic, bit-exact, tests/test_oracle_vs_ref.py), arg-max through
-oracle_index_max (== volk_gnsssdr_32f_index_max_32u_generic), code replicas through the pinned generators.
-The FFT itself is UNPINNED: the reference calls gr::fft::fft_complex_fwd/rev (GNU Radio gr-fft over FFTW3f,
-gnss_sdr_fft.h:26-61) and upstream VOLK for the element-wise products (acq.cc:250,531,538,547-552); neither
-library is vendored in /root/reference nor installed here, and no test of the reference pins their numerics.
-This file uses scipy's pocketfft in single precision in their place (same mathematical definition: forward
-e^{-j}, unnormalised inverse = N * ifft).  Peak INDICES are what north_star requires bit-exact; they are robust
-to FFT rounding wherever a signal is present and are additionally checked against a float64 evaluation.
+Parity status: PINNED (round 2).  The reference's own pcps_acquisition.cc -- and pcps_tong_acquisition_cc.cc,
+galileo_pcps_8ms_acquisition_cc.cc, pcps_cccwsr_acquisition_cc.cc, pcps_quicksync_acquisition_cc.cc, pcps_acquisition_fine_doppler_cc.cc --
+are compiled from /root/reference into oracle/_ref/libgnsssdr_ref_acq.so (oracle/Makefile, oracle/ref_acq_api.cc) against stand-ins
+for GNU Radio / VOLK / FFTW and driven through general_work; tests/test_pcps_oracle_pinned.py requires this restatement to equal
+those blocks VALUE FOR VALUE (wipe-off tables, code spectra, every grid cell, indices, power, statistic, threshold, Gnss_Synchro,
+state, messages) when both use the same transform (scipy's single-precision pocketfft plugged into the blocks' gr::fft objects),
+and index for index when the blocks run on an exact-definition float64 DFT instead.
+What stays outside the reference tree is the transform itself: gr::fft::fft_complex_fwd/rev is FFTW3f (gnss_sdr_fft.h:26-61), not
+vendored, not installed; FFTW's float32 rounding is not reproduced by anybody here.  Peak INDICES -- what north_star requires
+bit-exact -- do not depend on it (asserted with two different transforms).  The in-tree kernels go through oracle_sincos /
+oracle_index_max (== the volk_gnsssdr `_generic` protokernels, bit-exact, tests/test_oracle_vs_ref.py); VOLK's element-wise kernels
+are restated as their `_generic` definitions (cmul below).
 """
 from __future__ import annotations
 
@@ -24,6 +27,31 @@ import scipy.fft
 from . import lib
 
 TWO_PI = np.float32(6.283185307179586)
+
+
+def cmul(a: np.ndarray, b) -> np.ndarray:
+    """Element-wise complex product as VOLK's generic kernels form it (volk_32fc_x2_multiply_32fc, acq.cc:531,538): four float32
+    products, one subtraction, one addition, each rounded once.  (numpy's own complex64 multiply may contract to FMA.)  complex128
+    operands (the `precise` arbiter) go through numpy's product."""
+    a = np.asarray(a)
+    if a.dtype != np.complex64:
+        return a * b
+    b = np.asarray(b, np.complex64)
+    ar, ai, br, bi = a.real, a.imag, b.real, b.imag
+    out = np.empty(np.broadcast(a, b).shape, np.complex64)
+    out.real = ar * br - ai * bi
+    out.imag = ar * bi + ai * br
+    return out
+
+
+def fft_fwd(a: np.ndarray) -> np.ndarray:
+    """gr::fft::fft_complex_fwd::execute (FFTW forward c2c, e^{-j}, unnormalised)."""
+    return scipy.fft.fft(a)
+
+
+def fft_rev(a: np.ndarray) -> np.ndarray:
+    """gr::fft::fft_complex_rev::execute (FFTW backward c2c, e^{+j}, UNNORMALISED: N times the inverse DFT)."""
+    return scipy.fft.ifft(a, norm="forward")
 
 
 class PcpsOracle:
@@ -81,7 +109,7 @@ class PcpsOracle:
             buf[:] = code[:self.consumed]
         else:
             buf[self.consumed:] = code[:self.consumed]                                            # acq.cc:245-246
-        self.fft_codes = np.conj(scipy.fft.fft(buf)).astype(dt)                                   # acq.cc:249-250
+        self.fft_codes = np.conj(fft_fwd(buf)).astype(dt)                                   # acq.cc:249-250
 
     # acq.cc:522-560 with the zero padding of :657-664
     def doppler_grid(self, x: np.ndarray, dwell_count: int = 1):
@@ -92,10 +120,10 @@ class PcpsOracle:
             self.grid = np.zeros((self.n_bins, self.effective), np.float64 if self.precise else np.float32)
         off = self.effective if self.bit_transition else 0
         for d in range(self.n_bins):
-            a = (sig * self.wipe[d]).astype(dt)                                                   # :531
-            A = scipy.fft.fft(a)                                                                  # :535
-            B = (A * self.fft_codes).astype(dt)                                                   # :538
-            y = scipy.fft.ifft(B) * dt(self.fft_size)                                             # :541 unnormalised
+            a = cmul(sig, self.wipe[d])                                                           # :531
+            A = fft_fwd(a)                                                                        # :535
+            B = cmul(A, self.fft_codes)                                                           # :538
+            y = fft_rev(B)                                                                        # :541 unnormalised
             y = y.astype(dt)[off:off + self.effective]
             mag = (y.real * y.real + y.imag * y.imag)                                             # :547
             if dwell_count == 1:
@@ -285,10 +313,10 @@ class TongOracle:
         self.weight = weight
         for d in range(self.n_bins):
             doppler = -int(p.doppler_max) + p.doppler_step * d                                    # :216
-            a = (x * p.wipe[d]).astype(np.complex64)                                              # :218
-            A = scipy.fft.fft(a)
-            B = (A * p.fft_codes).astype(np.complex64)                                            # :227
-            y = (scipy.fft.ifft(B) * np.complex64(self.fft_size)).astype(np.complex64)            # :231 unnormalised
+            a = cmul(x, p.wipe[d])                                                                # :218
+            A = fft_fwd(a)
+            B = cmul(A, p.fft_codes)                                                              # :227
+            y = fft_rev(B)                                                                        # :231 unnormalised
             mag = (y.real * y.real + y.imag * y.imag).astype(np.float32)                          # :234
             mag = (mag * weight).astype(np.float32)                                               # :244-246
             self.grid[d] = self.grid[d] + mag                                                     # :249
@@ -355,12 +383,12 @@ class Galileo8msOracle:
         self.rows = []
         for d in range(self.n_bins):
             doppler = -int(p.doppler_max) + p.doppler_step * d
-            a = (x * p.wipe[d]).astype(np.complex64)
-            A = scipy.fft.fft(a)
+            a = cmul(x, p.wipe[d])
+            A = fft_fwd(a)
             best = []
             for codes in (self.fft_code_a, self.fft_code_b):
-                B = (A * codes).astype(np.complex64)
-                y = (scipy.fft.ifft(B) * np.complex64(self.fft_size)).astype(np.complex64)
+                B = cmul(A, codes)
+                y = fft_rev(B)
                 mag = (y.real * y.real + y.imag * y.imag).astype(np.float32)
                 t = p._argmax(mag)
                 best.append((np.float32(mag[t] / (fnf * fnf)), t))                                # :222, :237
@@ -425,9 +453,9 @@ class CccwsrOracle:
         self.rows = []
         for d in range(self.n_bins):
             doppler = -int(p.doppler_max) + p.doppler_step * d                                    # :200
-            A = scipy.fft.fft((x * p.wipe[d]).astype(np.complex64))                               # :202-207
-            cd = (scipy.fft.ifft((A * self.fft_code_data).astype(np.complex64)) * np.complex64(n)).astype(np.complex64)    # :212-220
-            cp = (scipy.fft.ifft((A * self.fft_code_pilot).astype(np.complex64)) * np.complex64(n)).astype(np.complex64)   # :225-233
+            A = fft_fwd(cmul(x, p.wipe[d]))                                                       # :202-207
+            cd = fft_rev(cmul(A, self.fft_code_data))                                             # :212-220
+            cp = fft_rev(cmul(A, self.fft_code_pilot))                                            # :225-233
             best = []
             for sgn in (np.float32(1.0), np.float32(-1.0)):                                       # :235-244
                 re = (cd.real - sgn * cp.imag).astype(np.float32)
@@ -483,7 +511,7 @@ class QuickSyncOracle:
         for i in range(self.p):
             folded = (folded + self.code[i * self.fft_size:(i + 1) * self.fft_size]).astype(np.complex64)
         self.code_folded = folded
-        self.fft_codes = np.conj(scipy.fft.fft(folded)).astype(np.complex64)
+        self.fft_codes = np.conj(fft_fwd(folded)).astype(np.complex64)
 
     def init(self):                                                                              # :180-192 (state 0)
         self.well_count = 0
@@ -509,13 +537,13 @@ class QuickSyncOracle:
         self.rows = []
         for d in range(self.n_bins):
             doppler = -self.doppler_max + self.doppler_step * d
-            in_temp = (x * self.wipe[d]).astype(np.complex64)                                     # :251-253
+            in_temp = cmul(x, self.wipe[d])                                                         # :251-253
             folded = np.zeros(N, np.complex64)
             for i in range(self.p * self.p):                                                      # :258-265
                 folded = (folded + in_temp[i * N:(i + 1) * N]).astype(np.complex64)
-            A = scipy.fft.fft(folded)
-            B = (A * self.fft_codes).astype(np.complex64)                                         # :274-275
-            y = (scipy.fft.ifft(B) * np.complex64(N)).astype(np.complex64)
+            A = fft_fwd(folded)
+            B = cmul(A, self.fft_codes)                                                           # :274-275
+            y = fft_rev(B)
             mag = (y.real * y.real + y.imag * y.imag).astype(np.float32)                          # :282-283
             t = self._argmax(mag)
             magt = np.float32(mag[t] / (fnf * fnf))                                               # :289
@@ -526,7 +554,7 @@ class QuickSyncOracle:
                 possible = [folded_delay + i * N for i in range(self.p)]                          # :309-312
                 acc = np.zeros(self.p, np.complex64)
                 for i in range(self.p):                                                           # :314-330: sequential float sums
-                    seg = (in_temp[possible[i]:possible[i] + self.spc] * self.code).astype(np.complex64)
+                    seg = cmul(in_temp[possible[i]:possible[i] + self.spc], self.code)
                     re = np.cumsum(seg.real, dtype=np.float32)[-1]
                     im = np.cumsum(seg.imag, dtype=np.float32)[-1]
                     acc[i] = np.complex64(complex(re, im))
@@ -608,8 +636,8 @@ class FineDopplerOracle:
             rep[:N - 1] = np.roll(head, -((N - shift) % (N - 1)))
         rep = np.tile(rep, 10)
         z = np.zeros(M, np.complex64)
-        z[:n] = (buf * rep).astype(np.complex64)                                                 # :348
-        Z = scipy.fft.fft(z)
+        z[:n] = cmul(buf, rep)                                                                   # :348
+        Z = fft_fwd(z)
         mag = (Z.real * Z.real + Z.imag * Z.imag).astype(np.float32)
         t = np.zeros(1, np.uint32)
         lib().oracle_index_max(t, np.ascontiguousarray(mag), M)

@@ -46,6 +46,7 @@
 #include "volk_gnsssdr_32fc_32f_high_dynamic_rotator_dot_prod_32fc_xn.h"
 #include "volk_gnsssdr_s32f_sincos_32fc.h"
 #include "volk_gnsssdr_32f_index_max_32u.h"
+#include "volk_gnsssdr_16ic_convert_32fc.h"
 
 void FLV(resampler)(float** result, const float* local_code, float rem, float step,
     float* shifts, unsigned int code_len, int n_vec, unsigned int n)
@@ -93,5 +94,21 @@ void ref_generic_sincos(lv_32fc_t* out, float phase_inc, float* phase, unsigned 
 void ref_generic_index_max(uint32_t* target, const float* src, uint32_t n)
 {
     volk_gnsssdr_32f_index_max_32u_generic(target, src, n);
+}
+
+/* dispatcher names of the kernels the acquisition blocks call, bound to the `_generic` protokernels */
+void volk_gnsssdr_s32f_sincos_32fc(lv_32fc_t* out, const float phase_inc, float* phase, unsigned int n)
+{
+    volk_gnsssdr_s32f_sincos_32fc_generic(out, phase_inc, phase, n);
+}
+
+void volk_gnsssdr_32f_index_max_32u(uint32_t* target, const float* src, uint32_t n)
+{
+    volk_gnsssdr_32f_index_max_32u_generic(target, src, n);
+}
+
+void volk_gnsssdr_16ic_convert_32fc(lv_32fc_t* out, const lv_16sc_t* in, unsigned int n)
+{
+    volk_gnsssdr_16ic_convert_32fc_generic(out, in, n);
 }
 #endif

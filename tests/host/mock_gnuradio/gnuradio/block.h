@@ -3,6 +3,8 @@
 // names and signatures of gr::basic_block / gr::block that gnss-sdr's acquisition blocks use; no scheduler behind them
 #include "gnuradio/gr_complex.h"
 #include "gnuradio/io_signature.h"
+#include "gnuradio/thread/thread.h"
+#include "gnuradio/types.h"
 #include "pmt/pmt.h"
 #include <memory>
 #include <mutex>
@@ -10,27 +12,8 @@
 #include <utility>
 #include <vector>
 
-typedef std::vector<int> gr_vector_int;
-typedef std::vector<const void*> gr_vector_const_void_star;
-typedef std::vector<void*> gr_vector_void_star;
-
 namespace gr
 {
-namespace thread
-{
-typedef std::recursive_mutex mutex;
-class scoped_lock
-{
-public:
-    explicit scoped_lock(mutex& m) : d_lock(m) {}
-    void lock() { d_lock.lock(); }
-    void unlock() { d_lock.unlock(); }
-
-private:
-    std::unique_lock<mutex> d_lock;
-};
-}  // namespace thread
-
 class basic_block : public std::enable_shared_from_this<basic_block>
 {
 public:
@@ -62,6 +45,8 @@ class block : public basic_block
 public:
     virtual int general_work(int noutput_items, gr_vector_int& ninput_items, gr_vector_const_void_star& input_items, gr_vector_void_star& output_items) = 0;
     virtual void forecast(int, gr_vector_int&) {}
+    virtual bool start() { return true; }
+    virtual bool stop() { return true; }
     void consume_each(int how_many_items) { consumed_last = how_many_items; consumed_total += how_many_items; }
     void set_relative_rate(double) {}
     void set_max_noutput_items(int) {}
