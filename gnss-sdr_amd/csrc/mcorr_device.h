@@ -27,6 +27,9 @@ constexpr int MC_MARGIN = 32;  // guard entries on each side of the LDS code tab
 #ifndef GSH_MC_RESEED
 #define GSH_MC_RESEED 32
 #endif
+#ifndef GSH_MC_PACKED
+#define GSH_MC_PACKED 1
+#endif
 #ifndef GSH_MC_CVT_FLR
 #define GSH_MC_CVT_FLR 1
 #endif
@@ -128,6 +131,7 @@ struct JobCtx
     int k_off{MC_MARGIN};  // tab[k + k_off] is code sample k (window: -k_lo)
     // fused second correlator (AUX kernels): one more tap over the same rotated samples with ANOTHER code -- the data-component prompt that
     // track_pilot adds to a pilot channel (trk.cc:1246-1256), which the reference runs as a second pass over the window
+    bool packed{true};      // run_body_packed allowed (host switch gsh_bank_set_packed_body / GSH_MC_PACKED_BODY=0 for A/B runs)
     bool aux_on{false};
     bool aux_zero{false};   // its shift is exactly 0.0f: on the ZP path it shares the prompt tap's chip index
     float aux_shift{0.0f};
@@ -278,10 +282,284 @@ __device__ __forceinline__ void process_pair(const JobCtx& c, const float2* __re
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Packed-FP32 body (round 2).  PMC of the round-1 kernel showed the SIMDs issuing VALU instructions for the whole launch
+// (SQ_ACTIVE_INST_VALU ~ kernel time): what bounds the correlator is the NUMBER of VALU instructions per sample, 48 per pair of
+// samples with three taps.  This body does the same arithmetic on FOUR samples per lane and trip -- the pair (n0, n0 + 1) of chunk A
+// and the pair 2 * MC_PAIRS_PER_CHUNK samples further (chunk B), both 16-byte loads fully coalesced as before -- and spells every step
+// that exists twice as one packed instruction (v_pk_mul/add/fma_f32, gfx950):
+//   * chip-index chains: (step * (float)n + shift) - rem for the two samples of a pair in one v_pk_mul + two v_pk_add.  The packed
+//     forms round each lane once, IEEE round-to-nearest, exactly like their scalar forms, and t + (-rem) IS t - rem; chip selection stays
+//     bit-exact (tests/test_tracking_gpu.py::test_chip_selection_bit_exact);
+//   * ONE carrier phasor per lane and trip instead of two: all four samples are rotated by the phasor of sample n0 (two packed
+//     instructions per sample) and accumulated into four accumulator sets; the missing constant rotations -- exp(-j step) for the second
+//     sample of a pair, exp(-j 2 PPC step) for chunk B -- are applied ONCE to the finished sums (the sum is linear):
+//         acc = A0 + inc * A1 + w * (B0 + inc * B1);
+//   * multiply-accumulate: one v_pk_fma per (sample, tap), the code value broadcast by op_sel from the pair the two look-ups fill.
+// Per pair of samples and three taps: 30 VALU instructions (18 packed, 6 v_cvt_flr, 6 address) instead of 48.
+// Used for the standard mode when the indices need no per-sample wrap and (float)n is exact (windows < 2^24 samples).
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ v2f pk_cmul(v2f x, v2f p)  // complex x * p
+{
+    v2f t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(x), "v"(p));                                          // (xr pr, xr pi)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(x), "v"(p), "v"(t));          // (-xi pi, xi pr) + t
+    return r;
+}
+// acc += y * c.lo / c.hi (the real code value broadcast to both components)
+__device__ __forceinline__ void pk_fma_lo(v2f& acc, v2f y, v2f c)
+{
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(y), "v"(c));
+}
+__device__ __forceinline__ void pk_fma_hi(v2f& acc, v2f y, v2f c)
+{
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(y), "v"(c));
+}
+// (v.lo * k.lo, v.hi * k.lo): k is wave-uniform (an SGPR pair)
+__device__ __forceinline__ v2f pk_mul_slo(v2f v, v2f k)
+{
+    v2f r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(r) : "v"(v), "s"(k));
+    return r;
+}
+__device__ __forceinline__ v2f pk_add_slo(v2f v, v2f k)
+{
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(r) : "v"(v), "s"(k));
+    return r;
+}
+__device__ __forceinline__ v2f pk_add_shi(v2f v, v2f k)
+{
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(v), "s"(k));
+    return r;
+}
+
+// One trip of the packed path: NCH chunks of MC_PAIRS_PER_CHUNK pairs; lane `tid` owns the pair tid of each chunk.  The caller hands over
+// the four samples (already zero where they lie outside the segment) and the sample indices the chip look-ups use (nfA / nfB: (float)n of
+// the pair; for a sample outside the segment the caller passes the nearest index INSIDE it, so that its look-up stays within what is
+// staged -- the chip index is monotone in n -- and no clamp is needed here: masked trips run the very same instructions).
+template <int NT, bool ZP, bool AUX, int NCH>
+__device__ __forceinline__ void packed_trip(const JobCtx& c, const float* __restrict__ tab, const v2f (&shp)[NT],
+    v2f k_step_nrem, v2f aux_shp, bool aux_on, v2f pa, v2f nfA, v2f nfB, float4 vA, float4 vB, v2f (&A0)[NT], v2f (&A1)[NT], v2f (&B0)[NT],
+    v2f (&B1)[NT], v2f& XA0, v2f& XA1, v2f& XB0, v2f& XB1)
+{
+    const v2f zero = {0.0f, 0.0f};
+    const v2f yA0 = pk_cmul((v2f){vA.x, vA.y}, pa);
+    const v2f yA1 = pk_cmul((v2f){vA.z, vA.w}, pa);
+    v2f yB0 = zero, yB1 = zero, aB = zero;
+    if (NCH == 2)
+        {
+            yB0 = pk_cmul((v2f){vB.x, vB.y}, pa);
+            yB1 = pk_cmul((v2f){vB.z, vB.w}, pa);
+            aB = pk_mul_slo(nfB, k_step_nrem);
+        }
+    const v2f aA = pk_mul_slo(nfA, k_step_nrem);
+    auto lookup = [&](v2f a, v2f sp, bool zero_shift, int k_off) -> v2f {
+        v2f u;
+        if (zero_shift)
+            u = pk_add_shi(a, k_step_nrem);                   // a - rem
+        else
+            u = pk_add_shi(pk_add_slo(a, sp), k_step_nrem);   // (a + shift) - rem
+        const int k0 = floor_to_int(u.x);
+        const int k1 = floor_to_int(u.y);
+        v2f cv;
+        cv.x = tab[k0 + k_off];
+        cv.y = tab[k1 + k_off];
+        return cv;
+    };
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+        {
+            const bool zs = ZP && t == NT / 2;
+            const v2f cA = lookup(aA, shp[t], zs, c.k_off);
+            pk_fma_lo(A0[t], yA0, cA);
+            pk_fma_hi(A1[t], yA1, cA);
+            if (NCH == 2)
+                {
+                    const v2f cB = lookup(aB, shp[t], zs, c.k_off);
+                    pk_fma_lo(B0[t], yB0, cB);
+                    pk_fma_hi(B1[t], yB1, cB);
+                }
+        }
+    if (AUX && aux_on)
+        {
+            const bool zs = ZP && c.aux_zero;
+            const v2f cA = lookup(aA, aux_shp, zs, c.aux_k_off);
+            pk_fma_lo(XA0, yA0, cA);
+            pk_fma_hi(XA1, yA1, cA);
+            if (NCH == 2)
+                {
+                    const v2f cB = lookup(aB, aux_shp, zs, c.aux_k_off);
+                    pk_fma_lo(XB0, yB0, cB);
+                    pk_fma_hi(XB1, yB1, cB);
+                }
+        }
+}
+
+// The whole segment on the packed path -- head, body and tail are trips of ONE loop.
+// Carrier phasors: a lane needs exp(-j (rem + n step)) for its own samples at every exact re-seed.  Evaluating that per lane (a double-
+// precision range reduction + sincosf, ~70 VALU instructions) a dozen times per window cost as much as a third of the hot loop (PMC, round 2:
+// 1 068 of the 2 556 VALU instructions of a wave were outside the loop).  Here a wave evaluates TWO transcendental phasors per lane and window:
+//   L    = exp(-j 2 tid step)                      -- the lane's offset inside a chunk, constant for the whole window;
+//   T[l] = one table entry per LANE: lane 0..2 the constant rotations inc = exp(-j step), w = exp(-j 2 PPC step), w2 = exp(-j 2 NCH PPC step),
+//          lane 4 + r the exact phasor of re-seed r at the chunk's first sample, exp(-j (rem + step (n_first + 2 PPC NCH RESEED r)));
+// a lane's seed is T[4 + r] * L (one complex product), read from the table with v_readlane.  More than 60 re-seeds: the table is refilled.
+// NCH = 2 chunks per trip (four samples per lane) for the 256-thread batched kernel; NCH = 1 for the 1024-thread closed-loop kernel
+// (128 VGPRs per lane).  One summation order for every tap count, so fused and unfused jobs stay bit-identical.
+template <int NT, bool ZP, bool AUX, int NCH>
+__device__ __forceinline__ void run_segment_packed(const JobCtx& c, const float2* __restrict__ base, const float* __restrict__ tab,
+    const float (&sh)[NT], float2 (&acc)[NT], float2* acc_aux)
+{
+    static_assert(NCH == 1 || NCH == 2, "one or two chunks per trip");
+    constexpr int PPC = MC_PAIRS_PER_CHUNK;
+    constexpr int RESEED = (MC_RESEED + NCH - 1) / NCH;  // trips between exact re-seeds
+    constexpr int TBL = 60;                               // re-seed entries per table fill
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const v2f zero = {0.0f, 0.0f};
+    const int span = c.n_end - c.n_first;
+    const int n_pairs = (span + 1) >> 1;
+    const int n_full = span >> 1;                       // leading pairs whose second sample is in range
+    const int odd = c.n_begin - c.n_first;              // 1: pair 0's first sample is outside the segment
+    const int n_trips = (n_pairs + NCH * PPC - 1) / (NCH * PPC);
+    const int first_plain = odd ? 1 : 0;                // trips [first_plain, last_plain) need no masking
+    const int last_plain = n_full / (NCH * PPC);
+    v2f A0[NT], A1[NT], B0[NT], B1[NT];
+    v2f XA0 = zero, XA1 = zero, XB0 = zero, XB1 = zero;  // the fused tap (AUX)
+#pragma unroll
+    for (int t = 0; t < NT; t++) A0[t] = A1[t] = B0[t] = B1[t] = zero;
+    const v2f k_step_nrem = {c.code_step, -c.rem_code};
+    v2f shp[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) shp[t] = (v2f){sh[t], sh[t]};
+    const v2f aux_shp = {c.aux_shift, c.aux_shift};
+    const v2f stride = {static_cast<float>(2 * NCH * PPC), static_cast<float>(2 * NCH * PPC)};
+    const bool aux_on = AUX && c.aux_on;
+    const double sd = static_cast<double>(c.phase_step);
+
+    const float2 Lf = expmj(static_cast<double>(2 * tid) * sd);
+    const v2f L = {Lf.x, Lf.y};
+    auto fill_table = [&](int r0) -> float2 {  // entry of this lane for the re-seeds r0 .. r0 + TBL - 1
+        double ph;
+        if (lane == 0)
+            ph = sd;
+        else if (lane == 1)
+            ph = static_cast<double>(2 * PPC) * sd;
+        else if (lane == 2)
+            ph = static_cast<double>(2 * NCH * PPC) * sd;
+        else
+            {
+                const int r = r0 + max(lane - 4, 0);
+                const long long nb = static_cast<long long>(c.n_first) + static_cast<long long>(2 * PPC * NCH * RESEED) * r;
+                ph = static_cast<double>(c.rem_carr) + static_cast<double>(nb) * sd;
+            }
+        return expmj(ph);
+    };
+    float2 T = fill_table(0);
+    auto table = [&](int l) -> v2f {
+        v2f r;
+        r.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, T.x), l));
+        r.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, T.y), l));
+        return r;
+    };
+    const v2f w2 = table(2);
+
+    const float2* q = base + 2 * tid;  // the lane's pair of chunk 0; advanced by one trip per iteration
+    float4 nA = make_float4(0.0f, 0.0f, 0.0f, 0.0f), nB = nA;
+    if (first_plain == 0 && last_plain > 0)
+        {
+            nA = *reinterpret_cast<const float4*>(q);
+            if (NCH == 2) nB = *reinterpret_cast<const float4*>(q + 2 * PPC);
+        }
+    v2f pa = zero, nfA = zero, nfB = zero;
+    int until_reseed = 0, r_idx = 0, tbl0 = 0;
+    for (int i = 0; i < n_trips; i++)
+        {
+            const int n0 = c.n_first + 2 * tid + i * (2 * NCH * PPC);
+            if (until_reseed == 0)  // uniform: exact re-seed of the lane's phasor and of (float)n
+                {
+                    if (r_idx - tbl0 >= TBL)
+                        {
+                            tbl0 = r_idx;
+                            T = fill_table(tbl0);
+                        }
+                    pa = pk_cmul(table(4 + r_idx - tbl0), L);
+                    nfA = (v2f){static_cast<float>(n0), static_cast<float>(n0 + 1)};
+                    nfB = (v2f){static_cast<float>(n0 + 2 * PPC), static_cast<float>(n0 + 2 * PPC + 1)};
+                    until_reseed = RESEED;
+                    r_idx++;
+                }
+            until_reseed--;
+            const bool plain = (i >= first_plain) && (i < last_plain);  // uniform
+            float4 vA = nA, vB = nB;
+            v2f ia = nfA, ib = nfB;
+            if (!plain)
+                {
+                    // edge trip (odd head, partial tail): samples outside [n_begin, n_end) are read as zero -- never loaded -- and looked up
+                    // at the nearest sample inside the segment
+                    const int lo = c.n_begin, hi = c.n_end - 1;
+                    const bool a0 = (n0 >= lo) && (n0 <= hi), a1 = (n0 + 1 >= lo) && (n0 + 1 <= hi);
+                    const float2 x0 = a0 ? q[0] : make_float2(0.0f, 0.0f);
+                    const float2 x1 = a1 ? q[1] : make_float2(0.0f, 0.0f);
+                    vA = make_float4(x0.x, x0.y, x1.x, x1.y);
+                    ia = (v2f){static_cast<float>(min(max(n0, lo), hi)), static_cast<float>(min(max(n0 + 1, lo), hi))};
+                    if (NCH == 2)
+                        {
+                            const int m0 = n0 + 2 * PPC;
+                            const bool b0 = (m0 >= lo) && (m0 <= hi), b1 = (m0 + 1 >= lo) && (m0 + 1 <= hi);
+                            const float2 z0 = b0 ? q[2 * PPC] : make_float2(0.0f, 0.0f);
+                            const float2 z1 = b1 ? q[2 * PPC + 1] : make_float2(0.0f, 0.0f);
+                            vB = make_float4(z0.x, z0.y, z1.x, z1.y);
+                            ib = (v2f){static_cast<float>(min(max(m0, lo), hi)), static_cast<float>(min(max(m0 + 1, lo), hi))};
+                        }
+                }
+            q += 2 * NCH * PPC;
+            if ((i + 1 >= first_plain) && (i + 1 < last_plain))  // uniform: the next trip's loads are issued before this trip is computed
+                {
+                    nA = *reinterpret_cast<const float4*>(q);
+                    if (NCH == 2) nB = *reinterpret_cast<const float4*>(q + 2 * PPC);
+                }
+            packed_trip<NT, ZP, AUX, NCH>(c, tab, shp, k_step_nrem, aux_shp, aux_on, pa, ia, ib, vA, vB, A0, A1, B0, B1, XA0, XA1, XB0, XB1);
+            pa = pk_cmul(pa, w2);
+            asm("v_pk_add_f32 %0, %0, %1" : "+v"(nfA) : "v"(stride));
+            if (NCH == 2) asm("v_pk_add_f32 %0, %0, %1" : "+v"(nfB) : "v"(stride));
+        }
+    // fold: acc += A0 + inc * A1 + w * (B0 + inc * B1)
+    const v2f incv = table(0), wv = table(1);
+    const float2 inc = make_float2(incv.x, incv.y), w = make_float2(wv.x, wv.y);
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+        {
+            const float2 a1 = cmul(make_float2(A1[t].x, A1[t].y), inc);
+            const float2 b1 = cmul(make_float2(B1[t].x, B1[t].y), inc);
+            const float2 b = cmul(make_float2(B0[t].x + b1.x, B0[t].y + b1.y), w);
+            acc[t].x += (A0[t].x + a1.x) + b.x;
+            acc[t].y += (A0[t].y + a1.y) + b.y;
+        }
+    if (aux_on)
+        {
+            const float2 a1 = cmul(make_float2(XA1.x, XA1.y), inc);
+            const float2 b1 = cmul(make_float2(XB1.x, XB1.y), inc);
+            const float2 b = cmul(make_float2(XB0.x + b1.x, XB0.y + b1.y), w);
+            acc_aux->x += (XA0.x + a1.x) + b.x;
+            acc_aux->y += (XA0.y + a1.y) + b.y;
+        }
+}
+
 template <int NT, int MODE, bool WRAP, bool ZP = false, bool AUX = false>
 __device__ __forceinline__ void run_segment(const JobCtx& c, const float2* __restrict__ base, const float* __restrict__ tab,
     const float (&sh)[NT], const int (&rot)[NT], float2 (&acc)[NT], float2* acc_aux = nullptr)
 {
+#if GSH_MC_PACKED
+    if (!WRAP && MODE == 0 && c.packed && c.n_total < (1 << 24))
+        {
+            constexpr int NCH = (MC_THREADS <= 256) ? 2 : 1;
+            run_segment_packed<NT, ZP, AUX, NCH>(c, base, tab, sh, acc, acc_aux);
+            return;
+        }
+#endif
     const int tid = threadIdx.x;
     const int span = c.n_end - c.n_first;          // samples covered from pair 0's first element
     const int n_pairs = (span + 1) >> 1;           // pairs touching the segment
@@ -322,10 +600,11 @@ __device__ __forceinline__ void run_segment(const JobCtx& c, const float2* __res
                 }
             else
                 {
+                    const int k_body = k_full_begin;
                     // stride rotator exp(-j * 512 * step) and sample rotator exp(-j * step), both seeded exactly
                     const float2 w = expmj(static_cast<double>(2 * MC_PAIRS_PER_CHUNK) * static_cast<double>(c.phase_step));
                     const float2 inc = expmj(static_cast<double>(c.phase_step));
-                    for (int kb = k_full_begin; kb < k_full_end; kb += MC_RESEED)
+                    for (int kb = k_body; kb < k_full_end; kb += MC_RESEED)
                         {
                             const int cnt = min(MC_RESEED, k_full_end - kb);
                             int pair = tid + kb * MC_PAIRS_PER_CHUNK;

@@ -22,12 +22,16 @@ struct McorrArgs
     int window_floats;               // > 0: LDS holds only a window of the code per work-group (all jobs: mode 0, code_step >= 0); 0: the whole code
     const int* job_list;             // device, n_launch job indices this launch works on (order kept), or nullptr: jobs 0..n_launch-1
     int n_launch;                    // jobs in this launch (n_jobs stays the size of the whole table: outputs / partials are indexed by job)
+    int packed;                      // 1: the packed four-samples-per-lane body may be used (default); 0: the round-1 body (A/B runs)
     const int* aux;                  // device, n_jobs, or nullptr.  aux[j] >= 0: job j also computes the single tap of job aux[j] (same window and
                                      // NCO, another code) and writes its output row; -2: job j is computed by its leader; -1: plain job
 };
 
 // Largest n_taps over the jobs and which mode combinations occur decide the template
 // instance; all jobs of one launch must share `mode` (gsh_corr_job::high_dyn).
+// 1 unless the environment says GSH_MC_PACKED_BODY=0 (read once; A/B switch for profiles/ab/mcorr_ab.py)
+int mcorr_packed_default();
+
 int mcorr_launch(const McorrArgs& args, int max_taps, int mode, int max_code_len, hipStream_t stream);
 
 // A batch whose jobs differ in tap count is launched per kernel flavour (1, <= 3, <= 5, <= 8 taps) so that a 3-tap job does not pay for

@@ -28,15 +28,19 @@
 #include "multicorrelator.h"
 #include "mcorr_device.h"
 #include <cmath>
+#include <cstdlib>
 
 namespace gsh
 {
 namespace
 {
 using namespace mcdev;
+#ifndef GSH_MC_MIN_WAVES
+#define GSH_MC_MIN_WAVES 5  // E/P/L: the packed body holds four accumulator sets; <= 96 VGPRs (5 waves per SIMD), the kernel is VALU-issue bound
+#endif
 
 template <int NT, int MODE, bool AUX>
-__global__ __launch_bounds__(MC_THREADS, ((NT <= 3 && !AUX) ? 8 : 1)) void mcorr_kernel(McorrArgs a)  // E/P/L: 8 waves per SIMD (<= 64 VGPRs)
+__global__ __launch_bounds__(MC_THREADS, ((NT <= 3 && !AUX) ? GSH_MC_MIN_WAVES : 1)) void mcorr_kernel(McorrArgs a)
 {
     extern __shared__ __align__(16) float lds[];
     const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
@@ -57,6 +61,7 @@ __global__ __launch_bounds__(MC_THREADS, ((NT <= 3 && !AUX) ? 8 : 1)) void mcorr
     c.rem_code = J.rem_code_phase_chips;
     c.code_step = J.code_phase_step_chips;
     c.code_rate = J.code_phase_rate_step_chips;
+    c.packed = a.packed != 0;
 
     // ---- this work-group's slice of the window
     int seg = (c.n_total + a.splits - 1) / a.splits;
@@ -71,7 +76,9 @@ __global__ __launch_bounds__(MC_THREADS, ((NT <= 3 && !AUX) ? 8 : 1)) void mcorr
     float sh[NT];
     int rot[NT];
 #pragma unroll
-    for (int t = 0; t < NT; t++) sh[t] = (t < J.n_taps) ? J.shifts_chips[t] : 0.0f;
+    // unused slots (jobs with fewer taps than the kernel flavour) repeat the last real shift: the index range [lo, hi] below then equals the
+    // one the host sized the code window for (bank_window_floats spans the real taps only); their sums are never stored
+    for (int t = 0; t < NT; t++) sh[t] = J.shifts_chips[min(t, max(J.n_taps, 1) - 1)];
     rot[0] = 0;
     if (mode_hd_code(MODE))
         {
@@ -320,6 +327,15 @@ int launch_nt(const McorrArgs& a, int mode, size_t lds, hipStream_t stream)
     return GSH_OK;
 }
 }  // namespace
+
+int mcorr_packed_default()
+{
+    static const int v = [] {
+        const char* e = std::getenv("GSH_MC_PACKED_BODY");
+        return (e != nullptr && e[0] == '0') ? 0 : 1;
+    }();
+    return v;
+}
 
 size_t mcorr_lds_bytes_window(int window_floats)
 {

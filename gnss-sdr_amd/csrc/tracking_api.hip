@@ -500,6 +500,7 @@ extern "C"
         a.n_jobs = b->n_jobs;
         a.splits = splits;
         a.window_floats = bank_window_floats(b, splits);
+        a.packed = gsh::mcorr_packed_default();
         // the second code table must not cost the occupancy the fusion is meant to win: only with windowed tables or short codes
         const bool fuse = b->n_fused > 0 && (a.window_floats > 0 || static_cast<size_t>(b->max_code_len) * sizeof(float) <= 10 * 1024);
         a.aux = fuse ? b->d_aux : nullptr;

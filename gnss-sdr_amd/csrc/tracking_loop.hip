@@ -103,7 +103,7 @@ struct TrkChannel  // loop state of one channel, resident in device memory betwe
 
 struct TrkArgs
 {
-    gsh_trk_conf conf;
+    const gsh_trk_conf* conf;  // device copy (a by-value struct with dynamically indexed arrays would be materialised in scratch by every thread)
     const float2* stream;
     unsigned long long n_stream;       // flat buffer: its length; ring: absolute index one past the newest resident sample
     unsigned long long ring_capacity;  // 0: flat buffer; else absolute sample i lives at stream[i % ring_capacity] (windows are contiguous: mirror)
@@ -399,11 +399,26 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
 {
     extern __shared__ __align__(16) float lds[];
     __shared__ NextWindow win;
+    // The channel's loop state and lock-detector / symbol-sync state live in LDS for the duration of the launch: thread 0 is the only one
+    // that works on them, and its section between two barriers is a chain of dependent accesses -- LDS latency instead of device-memory
+    // latency, and no thread holds a private copy (round 1: ~1 KB of scratch per thread, 1024 threads per channel).
+    __shared__ __align__(16) TrkChannel s;
+    __shared__ __align__(16) LockState lk;
+    static_assert(sizeof(TrkChannel) % 4 == 0 && sizeof(LockState) % 4 == 0, "state is copied as 32-bit words");
     const int ch = blockIdx.x;
     const int tid = threadIdx.x;
-    const gsh_trk_conf& c = a.conf;
-    TrkChannel s = a.chan[ch];  // every thread reads it; only thread 0 advances and stores it
+    const gsh_trk_conf& c = *a.conf;
+    {
+        const unsigned* gs = reinterpret_cast<const unsigned*>(a.chan + ch);
+        const unsigned* gl = reinterpret_cast<const unsigned*>(a.lock + ch);
+        unsigned* ls = reinterpret_cast<unsigned*>(&s);
+        unsigned* ll = reinterpret_cast<unsigned*>(&lk);
+        for (int i = tid; i < static_cast<int>(sizeof(TrkChannel) / 4); i += MC_THREADS) ls[i] = gs[i];
+        for (int i = tid; i < static_cast<int>(sizeof(LockState) / 4); i += MC_THREADS) ll[i] = gl[i];
+    }
+    __syncthreads();
     const int code_len = s.code_len;
+    const unsigned long long acq_stamp = s.acq_stamp;
 
     // ---- local replicas stay in LDS for the whole launch
     float* tab = lds;
@@ -415,40 +430,15 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
             if (c.track_pilot) stage_code_table(tab_data, a.codes + (static_cast<size_t>(ch) * 2 + 1) * a.code_stride, code_len);
         }
 
-    // ---- tap offsets in code samples, trk.cc:632-648 / :829-840 (wide) and :2130-2148 (narrow)
-    float sh_w[NT], sh_n[NT];
-    const float spcf = static_cast<float>(c.code_samples_per_chip);
-    if (NT == 5)
-        {
-            sh_w[0] = -c.very_early_late_space_chips * spcf;
-            sh_w[1] = -c.early_late_space_chips * spcf;
-            sh_w[2] = 0.0f;
-            sh_w[NT - 2] = c.early_late_space_chips * spcf;
-            sh_w[NT - 1] = c.very_early_late_space_chips * spcf;
-            sh_n[0] = -c.very_early_late_space_narrow_chips * spcf;
-            sh_n[1] = -c.early_late_space_narrow_chips * spcf;
-            sh_n[2] = 0.0f;
-            sh_n[NT - 2] = c.early_late_space_narrow_chips * spcf;
-            sh_n[NT - 1] = c.very_early_late_space_narrow_chips * spcf;
-        }
-    else
-        {
-            sh_w[0] = -c.early_late_space_chips * spcf;
-            sh_w[1] = 0.0f;
-            sh_w[NT - 1] = c.early_late_space_chips * spcf;
-            sh_n[0] = -c.early_late_space_narrow_chips * spcf;
-            sh_n[1] = 0.0f;
-            sh_n[NT - 1] = c.early_late_space_narrow_chips * spcf;
-        }
+    // ---- tap offsets in code samples, trk.cc:632-648 / :829-840 (wide) and :2130-2148 (narrow): formed from the configuration at the top of
+    // every period (a handful of scalar operations) rather than kept in registers across the whole launch
     const float sh_data[1] = {0.0f};
     constexpr int PROMPT = NT / 2;
-    const double code_period = static_cast<double>(c.code_length_chips) / c.code_chip_rate;  // d_code_period
-    const int extend = (c.enable_symbol_sync && c.extend_correlation_symbols > 1) ? c.extend_correlation_symbols : 1;
 
     if (tid == 0)
         {
             publish(win, s, c, a.n_stream, a.n_epochs > 0, a.ring_oldest);
-            win.narrow = a.lock[ch].narrow;
+            win.narrow = lk.narrow;
         }
     __syncthreads();
 
@@ -460,8 +450,25 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
             const unsigned long long wpos = a.ring_capacity ? pos % a.ring_capacity : pos;  // where the window sits in memory
             const float rem_carr = win.rem_carr, phase_step = win.phase_step, rem_code = win.rem_code, code_step = win.code_step;
             float sh[NT];
-#pragma unroll
-            for (int t = 0; t < NT; t++) sh[t] = win.narrow ? sh_n[t] : sh_w[t];
+            {
+                const float spcf = static_cast<float>(c.code_samples_per_chip);
+                const float el = (win.narrow ? c.early_late_space_narrow_chips : c.early_late_space_chips) * spcf;
+                const float vel = (win.narrow ? c.very_early_late_space_narrow_chips : c.very_early_late_space_chips) * spcf;
+                if (NT == 5)
+                    {
+                        sh[0] = -vel;
+                        sh[1] = -el;
+                        sh[2] = 0.0f;
+                        sh[NT - 2] = el;
+                        sh[NT - 1] = vel;
+                    }
+                else
+                    {
+                        sh[0] = -el;
+                        sh[1] = 0.0f;
+                        sh[NT - 1] = el;
+                    }
+            }
             const float phase_rate = win.phase_rate, code_rate = win.code_rate;
             // track_pilot in the standard mode: the data-component prompt (trk.cc:1246-1256) rides on the pilot's pass over the window
             const bool fused_data = !HD && c.track_pilot;
@@ -489,9 +496,10 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
             __syncthreads();  // win and red have been read by everyone
             if (tid == 0)
                 {
+                    const double code_period = static_cast<double>(c.code_length_chips) / c.code_chip_rate;  // d_code_period
+                    const int extend = (c.enable_symbol_sync && c.extend_correlation_symbols > 1) ? c.extend_correlation_symbols : 1;
                     // trk.cc:1912-1915: pull-in ends once more than pull_in_time_s whole seconds have passed since acquisition
-                    const bool pull_in = !(static_cast<unsigned long long>(c.pull_in_time_s) < (pos - s.acq_stamp) / static_cast<unsigned long long>(static_cast<int>(c.fs_in)));
-                    LockState& lk = a.lock[ch];  // touched by this thread only; lives in device memory between launches
+                    const bool pull_in = !(static_cast<unsigned long long>(c.pull_in_time_s) < (pos - acq_stamp) / static_cast<unsigned long long>(static_cast<int>(c.fs_in)));
                     // the accumulators the loop works on (d_VE_accu .. d_VL_accu): the period's outputs in state 2 (trk.cc:1984-1991); in state 4
                     // save_correlation_results adds them, times the secondary code chip, to accumulators zeroed at the end of the previous period
                     float2 acc[NT];
@@ -560,8 +568,11 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
                         {
                             if (a.records != nullptr)
                                 {
-                                    gsh_trk_epoch r;
-                                    memset(&r, 0, sizeof(r));
+                                    gsh_trk_epoch& r = a.records[static_cast<size_t>(ch) * a.n_epochs + e];  // written in place, field by field
+                                    {
+                                        unsigned* rw = reinterpret_cast<unsigned*>(&r);
+                                        for (int i = 0; i < static_cast<int>(sizeof(gsh_trk_epoch) / 4); i++) rw[i] = 0u;
+                                    }
                                     r.sample_counter = pos;
                                     r.flags = (pull_in ? 1 : 0) | 2;
 #pragma unroll
@@ -575,7 +586,6 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
                                     r.cn0_db_hz = rec_cn0;
                                     r.carrier_lock_test = rec_lock_test;
                                     r.state = run_state;
-                                    a.records[static_cast<size_t>(ch) * a.n_epochs + e] = r;
                                 }
                             s.active = 0;
                             publish(win, s, c, a.n_stream, 0);
@@ -819,7 +829,7 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
 
                     if (a.records != nullptr)
                         {
-                            gsh_trk_epoch r;
+                            gsh_trk_epoch& r = a.records[static_cast<size_t>(ch) * a.n_epochs + e];  // written in place (every field is assigned)
                             r.state = run_state;
                             r.carrier_phase_rate_step_rad = s.carrier_phase_rate_step_rad;
                             r.code_phase_rate_step_chips = s.code_phase_rate_step_chips;
@@ -849,7 +859,6 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
                             r.code_error_filt_chips = code_error_filt_chips;
                             r.rem_code_phase_samples = s.rem_code_phase_samples;
                             r.acc_carrier_phase_rad = s.acc_carrier_phase_rad;
-                            a.records[static_cast<size_t>(ch) * a.n_epochs + e] = r;
                         }
                     s.pos = pos + static_cast<unsigned long long>(prn_len);  // consume_each, trk.cc:2287
                     publish(win, s, c, a.n_stream, e + 1 < a.n_epochs, a.ring_oldest);
@@ -859,11 +868,21 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
             done = e + 1;
             __syncthreads();
         }
-    if (tid == 0)
-        {
-            a.chan[ch] = s;
-            a.epochs_done[ch] = done;
-        }
+    // the loop's last period ended with a barrier: state back to device memory for the next launch
+    {
+        // (the addresses are formed afresh -- laundered through an empty asm -- so that the ones of the prologue do not stay live, in
+        // registers the correlator needs, across the whole launch)
+        TrkChannel* chan_out = a.chan;
+        LockState* lock_out = a.lock;
+        asm volatile("" : "+s"(chan_out), "+s"(lock_out));
+        unsigned* gs = reinterpret_cast<unsigned*>(chan_out + ch);
+        unsigned* gl = reinterpret_cast<unsigned*>(lock_out + ch);
+        const unsigned* ls = reinterpret_cast<const unsigned*>(&s);
+        const unsigned* ll = reinterpret_cast<const unsigned*>(&lk);
+        for (int i = tid; i < static_cast<int>(sizeof(TrkChannel) / 4); i += MC_THREADS) gs[i] = ls[i];
+        for (int i = tid; i < static_cast<int>(sizeof(LockState) / 4); i += MC_THREADS) gl[i] = ll[i];
+    }
+    if (tid == 0) a.epochs_done[ch] = done;
 }
 
 // ---- host: filter design in the reference's float / double mix ---------------------------------------------------
@@ -985,6 +1004,7 @@ struct gsh_trk
     float* d_codes{nullptr};
     gsh::TrkChannel* d_chan{nullptr};
     gsh::TrkChannel* d_chan_backup{nullptr};
+    gsh_trk_conf* d_conf{nullptr};           // device copy of conf (kernel argument by pointer)
     gsh::LockState* d_lock{nullptr};         // lock-detector state per channel (enable_lock_detectors)
     gsh::LockState* d_lock_backup{nullptr};
     std::vector<gsh::TrkChannel> h_chan;
@@ -1012,7 +1032,7 @@ size_t trk_lds_bytes(const gsh_trk* t)
 int trk_launch(gsh_trk* t, int n_epochs, gsh_trk_epoch* d_records)
 {
     gsh::TrkArgs a;
-    a.conf = t->conf;
+    a.conf = t->d_conf;
     a.stream = t->d_stream;
     a.n_stream = t->n_stream;
     a.ring_capacity = 0;
@@ -1064,6 +1084,8 @@ extern "C"
         GSH_REQUIRE(max_code_length >= 1, "max_code_length %d", max_code_length);
         GSH_REQUIRE(c.fs_in >= 1.0 && c.code_chip_rate > 0.0 && c.signal_carrier_freq > 0.0, "fs_in, code_chip_rate and signal_carrier_freq must be positive");
         GSH_REQUIRE(c.code_length_chips >= 1 && c.code_samples_per_chip >= 1 && c.vector_length >= 1, "code_length_chips, code_samples_per_chip, vector_length must be >= 1");
+        GSH_REQUIRE(static_cast<int>(static_cast<double>(c.code_length_chips) / c.code_chip_rate * 1000.0) >= 1,
+            "code period %g s is shorter than 1 ms (cn0 smoother set-up divides by its whole milliseconds, trk.cc:620-627)", static_cast<double>(c.code_length_chips) / c.code_chip_rate);
         GSH_REQUIRE(c.pll_filter_order == 2 || c.pll_filter_order == 3, "pll_filter_order %d (2 or 3: T/tracking_FLL_PLL_filter.cc:23-54)", c.pll_filter_order);
         GSH_REQUIRE(c.dll_filter_order >= 1 && c.dll_filter_order <= 3, "dll_filter_order %d outside 1..3", c.dll_filter_order);
         GSH_REQUIRE(!c.high_dyn || (c.smoother_length >= 1 && c.smoother_length <= GSH_MAX_SMOOTHER), "smoother_length %u outside 1..%d", c.smoother_length, GSH_MAX_SMOOTHER);
@@ -1110,6 +1132,8 @@ extern "C"
         if ((e = hipMalloc(&t->d_lock_backup, sizeof(gsh::LockState) * n_channels)) != hipSuccess) return fail(e, "hipMalloc(lock)");
         if ((e = hipMemset(t->d_lock, 0, sizeof(gsh::LockState) * n_channels)) != hipSuccess) return fail(e, "hipMemset(lock)");
         if ((e = hipMalloc(&t->d_done, sizeof(int) * n_channels)) != hipSuccess) return fail(e, "hipMalloc(done)");
+        if ((e = hipMalloc(&t->d_conf, sizeof(gsh_trk_conf))) != hipSuccess) return fail(e, "hipMalloc(conf)");
+        if ((e = hipMemcpy(t->d_conf, &t->conf, sizeof(gsh_trk_conf), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy(conf)");
         if ((e = hipEventCreate(&t->ev0)) != hipSuccess) return fail(e, "hipEventCreate");
         if ((e = hipEventCreate(&t->ev1)) != hipSuccess) return fail(e, "hipEventCreate");
         if (trk_lds_bytes(t) > 64 * 1024)
@@ -1137,6 +1161,7 @@ extern "C"
         if (t->d_stream_owned) (void)hipFree(t->d_stream_owned);
         if (t->d_records) (void)hipFree(t->d_records);
         if (t->d_done) (void)hipFree(t->d_done);
+        if (t->d_conf) (void)hipFree(t->d_conf);
         if (t->ev0) (void)hipEventDestroy(t->ev0);
         if (t->ev1) (void)hipEventDestroy(t->ev1);
         if (t->stream) (void)hipStreamDestroy(t->stream);

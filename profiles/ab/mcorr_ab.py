@@ -1,6 +1,7 @@
 """A/B timing of the open-loop correlator bank (BASELINE config 2) between two builds (GSH_LIB_PATH selects the build)."""
 import os, sys
-sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import gnss_sdr_amd, oracle
 from gnss_sdr_amd.tracking import CorrelatorBank
