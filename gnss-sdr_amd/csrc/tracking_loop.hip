@@ -1269,6 +1269,7 @@ extern "C"
         init_smoother(lk.cn0_smoother, c.cn0_smoother_alpha, cn0_init, 25.0F, 12.0F);                        // class defaults, T/exponential_smoother.h:64-65
         init_smoother(lk.carrier_lock_test_smoother, c.carrier_lock_test_smoother_alpha, c.carrier_lock_test_smoother_samples, -1.0F, 0.0F);  // trk.cc:688-692
         lk.pull_in_latched = 1;
+        lk.carrier_lock_test = 1.0;  // d_carrier_lock_test(1.0): constructor and clear_tracking_vars (trk.cc:112, 1040)
         if (c.enable_symbol_sync && c.extend_correlation_symbols > 1)
             {
                 // what set_update_interval / set_noise_bandwidth / set_params will install when extended integration starts (trk.cc:2126-2129)

@@ -509,6 +509,7 @@ void oracle_lock_init(oracle_lock_state* st, const oracle_trk_conf* c)
     if (code_period > 0.0) cn0_init = c->cn0_smoother_samples / (int)(code_period * 1000.0);  /* trk.cc:683-686 */
     oracle_smoother_init(&st->cn0_smoother, c->cn0_smoother_alpha, cn0_init, 25.0F, 12.0F);  /* defaults of T/exponential_smoother.h:64-65 */
     oracle_smoother_init(&st->carrier_lock_test_smoother, c->carrier_lock_test_smoother_alpha, c->carrier_lock_test_smoother_samples, -1.0F, 0.0F);  /* :688-692 */
+    st->carrier_lock_test = 1.0;  /* d_carrier_lock_test(1.0) in the constructor and in clear_tracking_vars (trk.cc:112, 1040) */
 }
 
 /* cn0_and_tracking_lock_status, trk.cc:1167-1224 */
@@ -706,7 +707,15 @@ int oracle_trk_run(const oracle_trk_conf* c, const float* code, const float* dat
             const float* E = out + 2 * (prompt - 1);
             const float* L = out + 2 * (prompt + 1);
             double carr_phase_error_hz = 0.0, carr_freq_error_hz = 0.0, carr_error_filt_hz = 0.0, code_error_chips = 0.0, code_error_filt_chips = 0.0;
-            if (state == 3) goto update_vars;  /* coherent integration: no lock test, no loop update (trk.cc:2156-2161) */
+            if (state == 3)  /* coherent integration: no lock test, no loop update (trk.cc:2156-2161); the detector values stand */
+                {
+                    if (c->enable_lock_detectors)
+                        {
+                            r->cn0_db_hz = lock.cn0_db_hz;
+                            r->carrier_lock_test = lock.carrier_lock_test;
+                        }
+                    goto update_vars;
+                }
             if (c->enable_lock_detectors)
                 {
                     if (pull_in_latched && !pull_in)  /* trk.cc:1912-1916: leaving the pull-in transitory clears both fail counters */

@@ -6,6 +6,9 @@
 #include "gnuradio/thread/thread.h"
 #include "gnuradio/types.h"
 #include "pmt/pmt.h"
+#include <cstdint>
+#include <functional>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -14,6 +17,14 @@
 
 namespace gr
 {
+struct tag_t
+{
+    uint64_t offset{0};
+    pmt::pmt_t key;
+    pmt::pmt_t value;
+    pmt::pmt_t srcid;
+};
+
 class basic_block : public std::enable_shared_from_this<basic_block>
 {
 public:
@@ -24,6 +35,17 @@ public:
     io_signature::sptr output_signature() const { return d_out; }
     void message_port_register_out(pmt::pmt_t port) { d_out_ports.push_back(pmt::symbol_to_string(port)); }
     void message_port_pub(pmt::pmt_t port, pmt::pmt_t msg) { published.emplace_back(pmt::symbol_to_string(port), std::move(msg)); }
+    void message_port_register_in(pmt::pmt_t port) { d_in_ports.push_back(pmt::symbol_to_string(port)); }
+    template <typename F>
+    void set_msg_handler(pmt::pmt_t port, F handler) { d_handlers[pmt::symbol_to_string(port)] = handler; }
+    // test harness: deliver a message to an input port as the scheduler would
+    void deliver(const std::string& port, pmt::pmt_t msg)
+    {
+        auto it = d_handlers.find(port);
+        if (it != d_handlers.end()) it->second(msg);
+    }
+    std::vector<std::string> d_in_ports;
+    std::map<std::string, std::function<void(pmt::pmt_t)>> d_handlers;
     // test harness view of what the block sent
     std::vector<std::pair<std::string, pmt::pmt_t>> published;
     std::vector<std::string> d_out_ports;
@@ -47,8 +69,45 @@ public:
     virtual void forecast(int, gr_vector_int&) {}
     virtual bool start() { return true; }
     virtual bool stop() { return true; }
+    enum tag_propagation_policy_t { TPP_DONT = 0, TPP_ALL_TO_ALL = 1, TPP_ONE_TO_ONE = 2, TPP_CUSTOM = 3 };
     void consume_each(int how_many_items) { consumed_last = how_many_items; consumed_total += how_many_items; }
     void set_relative_rate(double) {}
+    void set_relative_rate(uint64_t, uint64_t) {}
+    void set_tag_propagation_policy(tag_propagation_policy_t) {}
+    // stream position as the scheduler keeps it: the harness advances nitems_read by what the block consumed and nitems_written by what
+    // general_work returned (mock_advance(), called by the harness after every general_work)
+    uint64_t nitems_read(unsigned) const { return d_nitems_read; }
+    uint64_t nitems_written(unsigned) const { return d_nitems_written; }
+    void mock_advance(int produced)
+    {
+        d_nitems_read += static_cast<uint64_t>(consumed_last);
+        if (produced > 0) d_nitems_written += static_cast<uint64_t>(produced);
+    }
+    void get_tags_in_range(std::vector<tag_t>& v, unsigned, uint64_t start, uint64_t end)
+    {
+        v.clear();
+        for (const auto& t : input_tags)
+            if (t.offset >= start && t.offset < end) v.push_back(t);
+    }
+    void get_tags_in_range(std::vector<tag_t>& v, unsigned which, uint64_t start, uint64_t end, const pmt::pmt_t& key)
+    {
+        get_tags_in_range(v, which, start, end);
+        std::vector<tag_t> k;
+        for (const auto& t : v)
+            if (pmt::eqv(t.key, key)) k.push_back(t);
+        v.swap(k);
+    }
+    void add_item_tag(unsigned, uint64_t offset, const pmt::pmt_t& key, const pmt::pmt_t& value, const pmt::pmt_t& srcid = pmt::pmt_t())
+    {
+        tag_t t;
+        t.offset = offset;
+        t.key = key;
+        t.value = value;
+        t.srcid = srcid;
+        output_tags.push_back(t);
+    }
+    std::vector<tag_t> input_tags, output_tags;  // test harness view
+    uint64_t d_nitems_read{0}, d_nitems_written{0};
     void set_max_noutput_items(int) {}
     // test harness view
     int consumed_last{0};
