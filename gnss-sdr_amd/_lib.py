@@ -151,6 +151,9 @@ SYMBOLS = {
     "gsh_stream_destroy": (None, [_P]),
     "gsh_stream_push": (C.c_int, [_P, _P, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64)]),
     "gsh_stream_push_device": (C.c_int, [_P, _P, C.c_uint64, C.c_int, C.c_int, _P, C.POINTER(C.c_uint64)]),
+    "gsh_stream_push_async": (C.c_int, [_P, _P, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64)]),
+    "gsh_stream_wait": (C.c_int, [_P]),
+    "gsh_stream_seek": (C.c_int, [_P, C.c_uint64]),
     "gsh_stream_range": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "gsh_stream_read": (C.c_int, [_P, C.c_uint64, C.c_uint64, _F]),
     "gsh_convert_samples_device": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, _P, C.c_uint64, _P]),
@@ -165,6 +168,9 @@ SYMBOLS = {
     "gsh_trk_set_stream_device": (C.c_int, [_P, _P, C.c_uint64]),
     "gsh_trk_set_stream_ring": (C.c_int, [_P, _P]),
     "gsh_trk_start": (C.c_int, [_P, C.c_int, _F, _F, C.c_int, C.c_uint64, C.c_uint64, C.c_double]),
+    "gsh_trk_start_ex": (C.c_int, [_P, C.c_int, _F, _F, C.c_int, C.c_uint64, C.c_uint64, C.c_double, C.c_double]),
+    "gsh_trk_pull_in": (C.c_int, [C.POINTER(TrkConf), C.c_uint64, C.c_double, C.c_uint64, C.c_double, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
+    "gsh_trk_stop": (C.c_int, [_P, C.c_int]),
     "gsh_trk_run": (C.c_int, [_P, C.c_int, C.POINTER(TrkEpoch), C.POINTER(C.c_int32)]),
     "gsh_trk_time_run": (C.c_int, [_P, C.c_int, C.c_int, _F]),
     "gsh_trk_write_dump": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(TrkConf), C.c_uint32, C.POINTER(TrkEpoch), C.c_int]),

@@ -14,13 +14,22 @@ struct gsh_stream
     void* d_raw{nullptr};              // staging for raw host items before conversion
     size_t raw_cap{0};                 // bytes
     unsigned long long next{0};        // absolute index of the next sample to be pushed
+    unsigned long long origin{0};      // absolute index of the first sample ever pushed since the last seek (nothing older is resident)
     hipEvent_t pushed{nullptr};        // recorded after the last push's device work
+    void* d_raw2[2]{nullptr, nullptr}; // gsh_stream_push_async: two device staging buffers, used alternately
+    size_t raw2_cap[2]{0, 0};
+    hipEvent_t raw2_done[2]{nullptr, nullptr};  // the conversion that read staging buffer i has finished
+    int raw2_next{0};
 };
 
 namespace gsh
 {
 // device address of absolute sample `index`, contiguous for n samples; GSH_ERR_INVALID when [index, index+n) is not resident
 int stream_window(const gsh_stream* s, unsigned long long index, unsigned long long n, const float2** ptr);
-inline unsigned long long stream_oldest(const gsh_stream* s) { return s->next > s->capacity ? s->next - s->capacity : 0ull; }
+inline unsigned long long stream_oldest(const gsh_stream* s)
+{
+    const unsigned long long by_capacity = s->next > s->capacity ? s->next - s->capacity : 0ull;
+    return by_capacity > s->origin ? by_capacity : s->origin;
+}
 }  // namespace gsh
 #endif

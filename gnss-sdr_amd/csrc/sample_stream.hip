@@ -84,6 +84,11 @@ extern "C"
         if (s->stream) (void)hipStreamSynchronize(s->stream);
         if (s->d_ring) (void)hipFree(s->d_ring);
         if (s->d_raw) (void)hipFree(s->d_raw);
+        for (int i = 0; i < 2; i++)
+            {
+                if (s->d_raw2[i]) (void)hipFree(s->d_raw2[i]);
+                if (s->raw2_done[i]) (void)hipEventDestroy(s->raw2_done[i]);
+            }
         if (s->pushed) (void)hipEventDestroy(s->pushed);
         if (s->stream) (void)hipStreamDestroy(s->stream);
         delete s;
@@ -133,6 +138,60 @@ extern "C"
         GSH_HIP(hipEventRecord(s->pushed, s->stream));
         GSH_HIP(hipStreamSynchronize(s->stream));
         s->next += n;
+        return GSH_OK;
+    }
+
+    int gsh_stream_push_async(gsh_stream_t* s, const void* items, uint64_t n, int item_type, int inverted_spectrum, uint64_t* first_index)
+    {
+        // H2D copy + conversion queued on the ring's stream; returns without waiting.  Two device staging buffers alternate, so the copy of
+        // block k + 1 can run while the conversion of block k still reads its staging buffer, and -- the point of it -- while the
+        // correlators work on block k on their own streams (they wait on `pushed`, not on the host).
+        GSH_REQUIRE(s != nullptr, "null stream");
+        GSH_REQUIRE(n == 0 || items != nullptr, "null items");
+        const size_t isz = gsh::item_bytes(item_type);
+        GSH_REQUIRE(isz != 0, "unknown item type %d", item_type);
+        GSH_REQUIRE(n <= s->capacity, "a push of %llu samples exceeds the ring capacity %llu", static_cast<unsigned long long>(n), s->capacity);
+        if (first_index) *first_index = s->next;
+        if (n == 0) return GSH_OK;
+        GSH_HIP(hipSetDevice(s->device));
+        const int slot = s->raw2_next;
+        s->raw2_next ^= 1;
+        const size_t bytes = static_cast<size_t>(n) * isz;
+        if (s->raw2_done[slot] == nullptr) GSH_HIP(hipEventCreateWithFlags(&s->raw2_done[slot], hipEventDisableTiming));
+        if (bytes > s->raw2_cap[slot])
+            {
+                GSH_HIP(hipEventSynchronize(s->raw2_done[slot]));  // nothing queued may still read the buffer being replaced
+                if (s->d_raw2[slot]) GSH_HIP(hipFree(s->d_raw2[slot]));
+                s->d_raw2[slot] = nullptr;
+                s->raw2_cap[slot] = 0;
+                GSH_HIP(hipMalloc(&s->d_raw2[slot], bytes));
+                s->raw2_cap[slot] = bytes;
+            }
+        // same stream as the previous conversion out of this slot (two pushes ago): ordered without an explicit wait
+        GSH_HIP(hipMemcpyAsync(s->d_raw2[slot], items, bytes, hipMemcpyHostToDevice, s->stream));
+        int rc = write_items(s, s->d_raw2[slot], n, item_type, inverted_spectrum ? 1 : 0, s->stream);
+        if (rc != GSH_OK) return rc;
+        GSH_HIP(hipEventRecord(s->raw2_done[slot], s->stream));
+        GSH_HIP(hipEventRecord(s->pushed, s->stream));
+        s->next += n;
+        return GSH_OK;
+    }
+
+    int gsh_stream_wait(gsh_stream_t* s)
+    {
+        GSH_REQUIRE(s != nullptr, "null stream");
+        GSH_HIP(hipSetDevice(s->device));
+        GSH_HIP(hipStreamSynchronize(s->stream));
+        return GSH_OK;
+    }
+
+    int gsh_stream_seek(gsh_stream_t* s, uint64_t next_index)
+    {
+        GSH_REQUIRE(s != nullptr, "null stream");
+        GSH_HIP(hipSetDevice(s->device));
+        GSH_HIP(hipStreamSynchronize(s->stream));
+        s->next = next_index;
+        s->origin = next_index;  // nothing older is resident
         return GSH_OK;
     }
 

@@ -21,6 +21,7 @@
 #include "mcorr_device.h"
 #include "sample_stream.h"
 #include <cmath>
+#include <cstddef>
 #include <new>
 #include <vector>
 
@@ -1219,8 +1220,51 @@ extern "C"
         return GSH_OK;
     }
 
+    int gsh_trk_pull_in(const gsh_trk_conf* conf, uint64_t nitems_read, double acq_delay_samples, uint64_t acq_sample_stamp, double acq_carrier_doppler_hz,
+        int32_t* samples_offset, int32_t* first_prn_length_samples, double* acc_carrier_phase_rad)
+    {
+        // dll_pll_veml_tracking::general_work, case 1 (trk.cc:1949-1978), statement by statement, in double as written there
+        GSH_REQUIRE(conf != nullptr && samples_offset != nullptr, "null argument");
+        GSH_REQUIRE(conf->fs_in > 0.0 && conf->code_chip_rate > 0.0 && conf->code_length_chips >= 1, "fs_in, code_chip_rate, code_length_chips must be positive");
+        const int64_t acq_trk_diff_samples = static_cast<int64_t>(nitems_read) - static_cast<int64_t>(acq_sample_stamp);
+        const double delta_trk_to_acq_prn_start_samples = static_cast<double>(acq_trk_diff_samples) - acq_delay_samples;
+        const double code_freq_chips = conf->code_chip_rate;
+        const double T_chip_mod_seconds = 1.0 / code_freq_chips;
+        const double T_prn_mod_seconds = T_chip_mod_seconds * static_cast<double>(conf->code_length_chips);
+        const double T_prn_mod_samples = T_prn_mod_seconds * conf->fs_in;
+        const double acq_code_phase_samples = T_prn_mod_samples - std::fmod(delta_trk_to_acq_prn_start_samples, T_prn_mod_samples);
+        const int32_t offset = static_cast<int32_t>(std::round(acq_code_phase_samples));
+        *samples_offset = offset;
+        if (first_prn_length_samples != nullptr) *first_prn_length_samples = static_cast<int32_t>(std::round(T_prn_mod_samples));
+        if (acc_carrier_phase_rad != nullptr)
+            {
+                const double carrier_phase_step_rad = gsh::GNSS_TWO_PI_D * acq_carrier_doppler_hz / conf->fs_in;  // start_tracking, trk.cc:800-801
+                *acc_carrier_phase_rad = 0.0 - carrier_phase_step_rad * static_cast<double>(offset);           // :1966 (d_acc_carrier_phase_rad is 0 after start_tracking)
+            }
+        return GSH_OK;
+    }
+
     int gsh_trk_start(gsh_trk_t* t, int channel, const float* code, const float* data_code, int code_length, uint64_t start_sample,
         uint64_t acq_sample_stamp, double acq_carrier_doppler_hz)
+    {
+        return gsh_trk_start_ex(t, channel, code, data_code, code_length, start_sample, acq_sample_stamp, acq_carrier_doppler_hz, 0.0);
+    }
+
+    int gsh_trk_stop(gsh_trk_t* t, int channel)
+    {
+        GSH_REQUIRE(t != nullptr, "null handle");
+        GSH_REQUIRE(channel >= 0 && channel < t->n_channels, "channel %d outside 0..%d", channel, t->n_channels - 1);
+        GSH_HIP(hipSetDevice(t->device));
+        t->h_chan[channel].active = 0;
+        // only the flag is written: the rest of the channel's state (device-owned between launches) stays as the loop left it
+        GSH_HIP(hipMemcpyAsync(reinterpret_cast<char*>(t->d_chan + channel) + offsetof(gsh::TrkChannel, active), &t->h_chan[channel].active, sizeof(int),
+            hipMemcpyHostToDevice, t->stream));
+        GSH_HIP(hipStreamSynchronize(t->stream));
+        return GSH_OK;
+    }
+
+    int gsh_trk_start_ex(gsh_trk_t* t, int channel, const float* code, const float* data_code, int code_length, uint64_t start_sample,
+        uint64_t acq_sample_stamp, double acq_carrier_doppler_hz, double initial_acc_carrier_phase_rad)
     {
         GSH_REQUIRE(t != nullptr && code != nullptr, "null argument");
         GSH_REQUIRE(channel >= 0 && channel < t->n_channels, "channel %d outside 0..%d", channel, t->n_channels - 1);
@@ -1237,7 +1281,7 @@ extern "C"
         s.code_phase_step_chips = s.code_freq_chips / c.fs_in;
         s.rem_code_phase_samples = 0.0;
         s.rem_code_phase_chips = 0.0;
-        s.acc_carrier_phase_rad = 0.0;
+        s.acc_carrier_phase_rad = initial_acc_carrier_phase_rad;  // 0, or what the pull-in alignment left (gsh_trk_pull_in, trk.cc:1966)
         s.rem_carr_phase_rad = 0.0F;
         s.p_old_re = 0.0F;
         s.p_old_im = 0.0F;

@@ -1,0 +1,226 @@
+/*!
+ * \file dll_pll_tracking_hip.cc
+ * \brief TrackingInterface adapters over the MI355X device-closed DLL/PLL loop; see the header.
+ */
+#include "dll_pll_tracking_hip.h"
+#include "GPS_L1_CA.h"
+#include "GPS_L5.h"
+#include "Galileo_E1.h"
+#include "Galileo_E5a.h"
+#include "configuration_interface.h"
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <iostream>
+#include <map>
+#include <mutex>
+#include <utility>
+
+#if USE_GLOG_AND_GFLAGS
+#include <glog/logging.h>
+#else
+#include <absl/log/log.h>
+#endif
+
+namespace
+{
+// channels that name the same <role>.hip_shared_ring id on the same device share one device sample ring
+std::shared_ptr<Hip_Sample_Ring> shared_ring_for(int device, int id, uint32_t vector_length)
+{
+    static std::mutex mu;
+    static std::map<std::pair<int, int>, std::weak_ptr<Hip_Sample_Ring>> rings;
+    if (id < 0) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    auto& slot = rings[{device, id}];
+    auto ring = slot.lock();
+    if (!ring)
+        {
+            // 64 correlation windows: channel threads of one stream run up to a scheduler buffer apart
+            ring = std::make_shared<Hip_Sample_Ring>(device, 64ULL * vector_length, 2U * vector_length);
+            if (!ring->ok())
+                {
+                    LOG(ERROR) << "hip_shared_ring " << id << ": " << ring->last_error();
+                    return nullptr;
+                }
+            slot = ring;
+        }
+    return ring;
+}
+
+void set_signal(Dll_Pll_Conf& p, char system, char s0, char s1)
+{
+    p.system = system;
+    const std::array<char, 3> sig{s0, s1, '\0'};
+    std::copy_n(sig.data(), 3, p.signal);
+}
+
+void warn_narrow(const Dll_Pll_Conf& p, const char* name)
+{
+    if ((p.extend_correlation_symbols > 1) && (p.pll_bw_narrow_hz > p.pll_bw_hz || p.dll_bw_narrow_hz > p.dll_bw_hz))
+        std::cout << "WARNING: " << name << ". PLL or DLL narrow tracking bandwidth is higher than wide tracking one\n";
+}
+}  // namespace
+
+
+DllPllTrackingHip::DllPllTrackingHip(const ConfigurationInterface* configuration, std::string role, unsigned int in_streams, unsigned int out_streams)
+    : role_(std::move(role)), item_size_(sizeof(gr_complex))
+{
+    trk_params_.SetFromConfiguration(configuration, role_);  // base_dll_pll_tracking.cc:33
+    if (in_streams > 1) LOG(ERROR) << "Only one input stream is supported.";
+    if (out_streams > 1) LOG(ERROR) << "Only one output stream is supported.";
+    DLOG(INFO) << "role " << role_;
+}
+
+
+void DllPllTrackingHip::create_tracking_block(const ConfigurationInterface* configuration)
+{
+    const int device = configuration->property(role_ + ".hip_device", 0);
+    const int periods = configuration->property(role_ + ".hip_periods_per_call", 1);
+    const int ring_id = configuration->property(role_ + ".hip_shared_ring", -1);
+    if (trk_params_.item_type != "gr_complex")  // as the reference adapters: item_size 0 tells the factory the block is unusable
+        {
+            item_size_ = 0;
+            tracking_sptr_ = nullptr;
+            LOG(WARNING) << trk_params_.item_type << " unknown tracking item type.";
+            return;
+        }
+    if (gsh_device_count() <= device)
+        {
+            item_size_ = 0;
+            tracking_sptr_ = nullptr;
+            LOG(ERROR) << role_ << ": HIP device " << device << " not present (the MI355X tracking block has no CPU fallback)";
+            return;
+        }
+    tracking_sptr_ = dll_pll_veml_make_tracking_hip(trk_params_, device, periods, shared_ring_for(device, ring_id, trk_params_.vector_length));
+    if (!tracking_sptr_->usable())
+        {
+            LOG(WARNING) << role_ << ": " << tracking_sptr_->last_error();
+            item_size_ = 0;
+            tracking_sptr_ = nullptr;
+            return;
+        }
+    DLOG(INFO) << "tracking(" << tracking_sptr_->unique_id() << ")";
+}
+
+
+void DllPllTrackingHip::connect(gr::top_block_sptr top_block)
+{
+    if (top_block)
+        { /* no connection needed */
+        }
+}
+
+
+void DllPllTrackingHip::disconnect(gr::top_block_sptr top_block)
+{
+    if (top_block)
+        { /* no disconnection needed */
+        }
+}
+
+
+gr::basic_block_sptr DllPllTrackingHip::get_left_block() { return tracking_sptr_; }
+gr::basic_block_sptr DllPllTrackingHip::get_right_block() { return tracking_sptr_; }
+void DllPllTrackingHip::set_channel(unsigned int channel) { tracking_sptr_->set_channel(channel); }
+void DllPllTrackingHip::set_gnss_synchro(Gnss_Synchro* p_gnss_synchro) { tracking_sptr_->set_gnss_synchro(p_gnss_synchro); }
+void DllPllTrackingHip::start_tracking() { tracking_sptr_->start_tracking(); }
+void DllPllTrackingHip::stop_tracking() { tracking_sptr_->stop_tracking(); }
+
+
+GpsL1CaDllPllTrackingHip::GpsL1CaDllPllTrackingHip(const ConfigurationInterface* configuration, const std::string& role, unsigned int in_streams,
+    unsigned int out_streams)
+    : DllPllTrackingHip(configuration, role, in_streams, out_streams)
+{
+    // gps_l1_ca_dll_pll_tracking.cc:50-95
+    Dll_Pll_Conf& p = config_params();
+    set_signal(p, 'G', '1', 'C');
+    p.vector_length = static_cast<uint32_t>(static_cast<int>(std::round(p.fs_in / (GPS_L1_CA_CODE_RATE_CPS / GPS_L1_CA_CODE_LENGTH_CHIPS))));
+    if (p.extend_correlation_symbols < 1)
+        {
+            p.extend_correlation_symbols = 1;
+            std::cout << "WARNING: GPS L1 C/A: extend_correlation_symbols must be > 0. Coherent integration set to 1 ms.\n";
+        }
+    else if (p.extend_correlation_symbols > 20)
+        {
+            p.extend_correlation_symbols = 20;
+            std::cout << "WARNING: GPS L1 C/A: extend_correlation_symbols limited to 20 (20 ms).\n";
+        }
+    p.track_pilot = configuration->property(role + ".track_pilot", false);
+    if (p.track_pilot)
+        {
+            p.track_pilot = false;
+            std::cout << "WARNING: GPS L1 C/A does not have pilot signal. Data tracking enabled instead.\n";
+        }
+    warn_narrow(p, "GPS L1 C/A");
+    create_tracking_block(configuration);
+}
+
+
+GalileoE1DllPllVemlTrackingHip::GalileoE1DllPllVemlTrackingHip(const ConfigurationInterface* configuration, const std::string& role,
+    unsigned int in_streams, unsigned int out_streams)
+    : DllPllTrackingHip(configuration, role, in_streams, out_streams)
+{
+    // galileo_e1_dll_pll_veml_tracking.cc:48-72
+    Dll_Pll_Conf& p = config_params();
+    p.vector_length = static_cast<uint32_t>(static_cast<int>(std::round(p.fs_in / (GALILEO_E1_CODE_CHIP_RATE_CPS / GALILEO_E1_B_CODE_LENGTH_CHIPS))));
+    set_signal(p, 'E', '1', 'B');
+    if (p.extend_correlation_symbols < 1)
+        {
+            p.extend_correlation_symbols = 1;
+            std::cout << "WARNING: Galileo E1. extend_correlation_symbols must be bigger than 0. Coherent integration has been set to 1 symbol (4 ms)\n";
+        }
+    else if (!p.track_pilot && p.extend_correlation_symbols > 1)
+        {
+            p.extend_correlation_symbols = 1;
+            std::cout << "WARNING: Galileo E1. Extended coherent integration is not allowed when tracking the data component. Coherent integration has been set to 4 ms (1 symbol)\n";
+        }
+    warn_narrow(p, "Galileo E1");
+    create_tracking_block(configuration);
+}
+
+
+GpsL5DllPllTrackingHip::GpsL5DllPllTrackingHip(const ConfigurationInterface* configuration, const std::string& role, unsigned int in_streams,
+    unsigned int out_streams)
+    : DllPllTrackingHip(configuration, role, in_streams, out_streams)
+{
+    // gps_l5_dll_pll_tracking.cc:48-70
+    Dll_Pll_Conf& p = config_params();
+    p.vector_length = static_cast<uint32_t>(static_cast<int>(
+        std::round(static_cast<double>(p.fs_in) / (static_cast<double>(GPS_L5I_CODE_RATE_CPS) / static_cast<double>(GPS_L5I_CODE_LENGTH_CHIPS)))));
+    if (p.extend_correlation_symbols < 1)
+        {
+            p.extend_correlation_symbols = 1;
+            std::cout << "WARNING: GPS L5. extend_correlation_symbols must be bigger than 0. Coherent integration has been set to 1 symbol (1 ms)\n";
+        }
+    else if (!p.track_pilot && p.extend_correlation_symbols > GPS_L5I_NH_CODE_LENGTH)
+        {
+            p.extend_correlation_symbols = GPS_L5I_NH_CODE_LENGTH;
+            std::cout << "WARNING: GPS L5. extend_correlation_symbols must be lower than 11 when tracking the data component. Coherent integration has been set to 10 symbols (10 ms)\n";
+        }
+    warn_narrow(p, "GPS L5");
+    set_signal(p, 'G', 'L', '5');
+    create_tracking_block(configuration);
+}
+
+
+GalileoE5aDllPllTrackingHip::GalileoE5aDllPllTrackingHip(const ConfigurationInterface* configuration, const std::string& role, unsigned int in_streams,
+    unsigned int out_streams)
+    : DllPllTrackingHip(configuration, role, in_streams, out_streams)
+{
+    // galileo_e5a_dll_pll_tracking.cc:48-70
+    Dll_Pll_Conf& p = config_params();
+    p.vector_length = static_cast<uint32_t>(static_cast<int>(std::round(p.fs_in / (GALILEO_E5A_CODE_CHIP_RATE_CPS / GALILEO_E5A_CODE_LENGTH_CHIPS))));
+    set_signal(p, 'E', '5', 'X');
+    if (p.extend_correlation_symbols < 1)
+        {
+            p.extend_correlation_symbols = 1;
+            std::cout << "WARNING: Galileo E5a. extend_correlation_symbols must be bigger than 0. Coherent integration has been set to 1 symbol (1 ms)\n";
+        }
+    else if (!p.track_pilot && p.extend_correlation_symbols > GALILEO_E5A_I_SECONDARY_CODE_LENGTH)
+        {
+            p.extend_correlation_symbols = GALILEO_E5A_I_SECONDARY_CODE_LENGTH;
+            std::cout << "WARNING: Galileo E5a. extend_correlation_symbols must be lower than 21 when tracking the data component. Coherent integration has been set to 20 symbols (20 ms)\n";
+        }
+    warn_narrow(p, "Galileo E5a");
+    create_tracking_block(configuration);
+}

@@ -1,79 +1,97 @@
 /*!
  * \file dll_pll_tracking_hip.h
- * \brief TrackingInterface adapters "<reference name>_HIP" for every signal the reference tracks with dll_pll_veml_tracking
- *        (GPS L1 / L2C / L5, Galileo E1 / E5a / E5b / E6, GLONASS L1 / L2, BeiDou B1I / B3I, QZSS L1 / L5): the reference's own DLL/PLL
- *        adapters (src/algorithms/tracking/adapters/gps_l1_ca_dll_pll_tracking.h:37-58 and its twelve siblings over
- *        base_dll_pll_tracking.h:39-121) with the MI355X multicorrelator inside.
+ * \brief TrackingInterface adapters over the MI355X device-closed DLL/PLL loop: DllPllTrackingHip and one class per signal
+ *        (GPS L1 C/A, Galileo E1, GPS L5, Galileo E5a).
  *
- * BUILT ONLY INSIDE A gnss-sdr TREE, with -DENABLE_HIP_MI355X=1, i.e. with dll_pll_veml_tracking's two correlator members
- * (dll_pll_veml_tracking.h:94-95) declared as Hip_Multicorrelator_Real_Codes.  The 2 300 lines of
- * loop logic, lock detection, bit synchronisation and telemetry hand-over of the reference block run unchanged; every
- * Carrier_wipeoff_multicorrelator_resampler call (trk.cc:1236-1256) goes to the GPU.
- * What these adapters add to the plain reference adapters: an explicit implementation name for the configuration file and the
- * per-role device choice  <role>.hip_device  (handed to the correlator through GNSS_SDR_HIP_DEVICE before the block, and with
- * it the correlator, is constructed: trk.cc:652).
- * Precedent: gps_l1_ca_dll_pll_tracking_gpu.h:37-95 (the reference's CUDA adapter is a separate class for the same reason).
+ * These derive DIRECTLY from TrackingInterface (src/core/interfaces/tracking_interface.h:47-54): the reference's BaseDllPllTracking
+ * holds a concrete dll_pll_veml_tracking_sptr (src/algorithms/tracking/adapters/base_dll_pll_tracking.h:115) and cannot carry another
+ * block.  Precedent for a self-contained accelerator adapter: gps_l1_ca_dll_pll_tracking_gpu.cc:36-95.
+ * Constructor signature, role(), implementation(), item_size(), connect / disconnect, get_left_block / get_right_block, set_channel,
+ * set_gnss_synchro, start_tracking, stop_tracking behave as BaseDllPllTracking's (base_dll_pll_tracking.cc:25-112); configuration keys are
+ * Dll_Pll_Conf's (dll_pll_conf.cc:48-158) plus
+ *   <role>.hip_device            GPU index (0)
+ *   <role>.hip_periods_per_call  code periods one general_work call may run in a single launch (1 = the reference's cadence)
+ *   <role>.hip_shared_ring       id >= 0: channels configured with the same id (and device) share one device sample ring -- the stream
+ *                                crosses PCIe once for all of them; -1 (default): a private ring
+ * Factory registration (one `else if` per name, as gnss_block_factory.cc:657-662 does for the CUDA block): INTEGRATION.md section 2b.
+ * An unusable block (unsupported item type / signal, or no GPU) is reported the reference's way: item_size() == 0
+ * (gnss_block_factory.cc:1048-1052, channel.cc:96-100).
  */
 #ifndef GNSS_SDR_DLL_PLL_TRACKING_HIP_H
 #define GNSS_SDR_DLL_PLL_TRACKING_HIP_H
 
-#if !ENABLE_HIP_MI355X
-#error "dll_pll_tracking_hip.h needs -DENABLE_HIP_MI355X=1 (the tracking block must be compiled with the HIP correlator members)"
-#endif
-
-#include "beidou_b1i_dll_pll_tracking.h"
-#include "beidou_b3i_dll_pll_tracking.h"
-#include "configuration_interface.h"
-#include "galileo_e1_dll_pll_veml_tracking.h"
-#include "galileo_e5a_dll_pll_tracking.h"
-#include "galileo_e5b_dll_pll_tracking.h"
-#include "galileo_e6_dll_pll_tracking.h"
-#include "glonass_l1_ca_dll_pll_tracking.h"
-#include "glonass_l2_ca_dll_pll_tracking.h"
-#include "gps_l1_ca_dll_pll_tracking.h"
-#include "gps_l2_m_dll_pll_tracking.h"
-#include "gps_l5_dll_pll_tracking.h"
-#include "qzss_l1_dll_pll_tracking.h"
-#include "qzss_l5_dll_pll_tracking.h"
-#include <cstdlib>
+#include "dll_pll_conf.h"
+#include "dll_pll_veml_tracking_hip.h"
+#include "tracking_interface.h"
+#include <gnuradio/top_block.h>
+#include <cstddef>
 #include <string>
 
-namespace hip_tracking_detail
+class ConfigurationInterface;
+
+class DllPllTrackingHip : public TrackingInterface
 {
-//! runs before the reference adapter's constructor (base-from-member): publish the device the correlators must open
-struct DeviceSelector
-{
-    DeviceSelector(const ConfigurationInterface* configuration, const std::string& role)
-    {
-        const int device = configuration->property(role + ".hip_device", 0);
-        setenv("GNSS_SDR_HIP_DEVICE", std::to_string(device).c_str(), 1);
-    }
+public:
+    ~DllPllTrackingHip() override = default;
+    inline std::string role() override { return role_; }
+    inline size_t item_size() override { return item_size_; }
+    void connect(gr::top_block_sptr top_block) override;
+    void disconnect(gr::top_block_sptr top_block) override;
+    gr::basic_block_sptr get_left_block() override;
+    gr::basic_block_sptr get_right_block() override;
+    void set_channel(unsigned int channel) override;
+    void set_gnss_synchro(Gnss_Synchro* p_gnss_synchro) override;
+    void start_tracking() override;
+    void stop_tracking() override;
+
+    //! the loop configuration the block runs with (what a Channel never needs; tests and monitors do)
+    const gsh_trk_conf& trk_conf() const { return tracking_sptr_->trk_conf(); }
+    const Dll_Pll_Conf& tracking_parameters() const { return trk_params_; }
+    dll_pll_veml_tracking_hip_sptr block() const { return tracking_sptr_; }
+
+protected:
+    DllPllTrackingHip(const ConfigurationInterface* configuration, std::string role, unsigned int in_streams, unsigned int out_streams);
+    Dll_Pll_Conf& config_params() { return trk_params_; }
+    //! makes the GNU Radio block from the finished configuration (called by the signal classes' constructors)
+    void create_tracking_block(const ConfigurationInterface* configuration);
+
+private:
+    Dll_Pll_Conf trk_params_;
+    dll_pll_veml_tracking_hip_sptr tracking_sptr_;
+    const std::string role_;
+    size_t item_size_;
 };
-}  // namespace hip_tracking_detail
 
-#define GSH_DECLARE_TRACKING_HIP_ADAPTER(ClassName, RefAdapter, ImplName)                                                         \
-    class ClassName : private hip_tracking_detail::DeviceSelector, public RefAdapter                                              \
-    {                                                                                                                             \
-    public:                                                                                                                       \
-        ClassName(const ConfigurationInterface* configuration, const std::string& role, unsigned int in_streams, unsigned int out_streams) \
-            : hip_tracking_detail::DeviceSelector(configuration, role), RefAdapter(configuration, role, in_streams, out_streams)  \
-        {                                                                                                                         \
-        }                                                                                                                         \
-        inline std::string implementation() override { return ImplName; }                                                         \
-    }
+//! "GPS_L1_CA_DLL_PLL_Tracking_HIP" -- counterpart of GpsL1CaDllPllTracking (gps_l1_ca_dll_pll_tracking.cc:38-113)
+class GpsL1CaDllPllTrackingHip : public DllPllTrackingHip
+{
+public:
+    GpsL1CaDllPllTrackingHip(const ConfigurationInterface* configuration, const std::string& role, unsigned int in_streams, unsigned int out_streams);
+    inline std::string implementation() override { return "GPS_L1_CA_DLL_PLL_Tracking_HIP"; }
+};
 
-GSH_DECLARE_TRACKING_HIP_ADAPTER(GpsL1CaDllPllTrackingHip, GpsL1CaDllPllTracking, "GPS_L1_CA_DLL_PLL_Tracking_HIP");
-GSH_DECLARE_TRACKING_HIP_ADAPTER(GalileoE1DllPllVemlTrackingHip, GalileoE1DllPllVemlTracking, "Galileo_E1_DLL_PLL_VEML_Tracking_HIP");
-GSH_DECLARE_TRACKING_HIP_ADAPTER(GpsL5DllPllTrackingHip, GpsL5DllPllTracking, "GPS_L5_DLL_PLL_Tracking_HIP");
-GSH_DECLARE_TRACKING_HIP_ADAPTER(GpsL2MDllPllTrackingHip, GpsL2MDllPllTracking, "GPS_L2_M_DLL_PLL_Tracking_HIP");
-GSH_DECLARE_TRACKING_HIP_ADAPTER(GalileoE5aDllPllTrackingHip, GalileoE5aDllPllTracking, "Galileo_E5a_DLL_PLL_Tracking_HIP");
-GSH_DECLARE_TRACKING_HIP_ADAPTER(GalileoE5bDllPllTrackingHip, GalileoE5bDllPllTracking, "Galileo_E5b_DLL_PLL_Tracking_HIP");
-GSH_DECLARE_TRACKING_HIP_ADAPTER(GalileoE6DllPllTrackingHip, GalileoE6DllPllTracking, "Galileo_E6_DLL_PLL_Tracking_HIP");
-GSH_DECLARE_TRACKING_HIP_ADAPTER(GlonassL1CaDllPllTrackingHip, GlonassL1CaDllPllTracking, "GLONASS_L1_CA_DLL_PLL_Tracking_HIP");
-GSH_DECLARE_TRACKING_HIP_ADAPTER(GlonassL2CaDllPllTrackingHip, GlonassL2CaDllPllTracking, "GLONASS_L2_CA_DLL_PLL_Tracking_HIP");
-GSH_DECLARE_TRACKING_HIP_ADAPTER(BeidouB1iDllPllTrackingHip, BeidouB1iDllPllTracking, "BEIDOU_B1I_DLL_PLL_Tracking_HIP");
-GSH_DECLARE_TRACKING_HIP_ADAPTER(BeidouB3iDllPllTrackingHip, BeidouB3iDllPllTracking, "BEIDOU_B3I_DLL_PLL_Tracking_HIP");
-GSH_DECLARE_TRACKING_HIP_ADAPTER(QzssL1DllPllTrackingHip, QzssL1DllPllTracking, "QZSS_L1_CA_DLL_PLL_Tracking_HIP");
-GSH_DECLARE_TRACKING_HIP_ADAPTER(QzssL5DllPllTrackingHip, QzssL5DllPllTracking, "QZSS_L5_DLL_PLL_Tracking_HIP");
+//! "Galileo_E1_DLL_PLL_VEML_Tracking_HIP" -- counterpart of GalileoE1DllPllVemlTracking (galileo_e1_dll_pll_veml_tracking.cc:36-88)
+class GalileoE1DllPllVemlTrackingHip : public DllPllTrackingHip
+{
+public:
+    GalileoE1DllPllVemlTrackingHip(const ConfigurationInterface* configuration, const std::string& role, unsigned int in_streams, unsigned int out_streams);
+    inline std::string implementation() override { return "Galileo_E1_DLL_PLL_VEML_Tracking_HIP"; }
+};
+
+//! "GPS_L5_DLL_PLL_Tracking_HIP" -- counterpart of GpsL5DllPllTracking (gps_l5_dll_pll_tracking.cc:36-90)
+class GpsL5DllPllTrackingHip : public DllPllTrackingHip
+{
+public:
+    GpsL5DllPllTrackingHip(const ConfigurationInterface* configuration, const std::string& role, unsigned int in_streams, unsigned int out_streams);
+    inline std::string implementation() override { return "GPS_L5_DLL_PLL_Tracking_HIP"; }
+};
+
+//! "Galileo_E5a_DLL_PLL_Tracking_HIP" -- counterpart of GalileoE5aDllPllTracking (galileo_e5a_dll_pll_tracking.cc:36-85)
+class GalileoE5aDllPllTrackingHip : public DllPllTrackingHip
+{
+public:
+    GalileoE5aDllPllTrackingHip(const ConfigurationInterface* configuration, const std::string& role, unsigned int in_streams, unsigned int out_streams);
+    inline std::string implementation() override { return "Galileo_E5a_DLL_PLL_Tracking_HIP"; }
+};
 
 #endif  // GNSS_SDR_DLL_PLL_TRACKING_HIP_H

@@ -42,6 +42,20 @@ uint64_t Hip_Sample_Ring::push_items(const void* items, uint64_t n, int item_typ
 }
 
 
+bool Hip_Sample_Ring::seek(uint64_t next_index)
+{
+    if (d_handle == nullptr) return false;
+    std::lock_guard<std::mutex> lk(d_mutex);
+    if (gsh_stream_seek(d_handle, next_index) != GSH_OK)
+        {
+            d_error = gsh_last_error();
+            return false;
+        }
+    d_next.store(next_index, std::memory_order_release);
+    return true;
+}
+
+
 uint64_t Hip_Sample_Ring::push(const std::complex<float>* samples, uint64_t n, bool inverted_spectrum)
 {
     return push_items(samples, n, GSH_ITEM_GR_COMPLEX, inverted_spectrum);

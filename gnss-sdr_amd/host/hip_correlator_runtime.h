@@ -51,6 +51,8 @@ public:
     uint64_t push(const std::complex<float>* samples, uint64_t n, bool inverted_spectrum = false);
     uint64_t push_ishort(const int16_t* iq, uint64_t n, bool inverted_spectrum = false);  //!< item_type ishort / cshort
     uint64_t push_ibyte(const int8_t* iq, uint64_t n, bool inverted_spectrum = false);    //!< item_type ibyte / cbyte
+    /*! position an idle ring: the next pushed sample gets absolute index `next_index`, nothing older is resident */
+    bool seek(uint64_t next_index);
     /*! [oldest, next) resident */
     void range(uint64_t* oldest, uint64_t* next) const;
     /*! blocks until sample index `end` has been pushed (next >= end) or the timeout expires */

@@ -30,7 +30,7 @@ extern "C"
 {
 #endif
 
-#define GSH_ABI_VERSION 14
+#define GSH_ABI_VERSION 16
 #define GSH_MAX_TAPS 8 /* VE/E/P/L/VL needs 5 (trk.cc:609-650); 8 leaves room for multi-tap dumps */
 
     enum
@@ -166,6 +166,17 @@ extern "C"
     int gsh_stream_push_device(gsh_stream_t* s, const void* device_items, uint64_t n, int item_type, int inverted_spectrum, void* hip_stream,
         uint64_t* first_index);
     /* [*oldest, *next): the absolute sample indices currently resident */
+    /* Asynchronous ingest: the host-to-device copy and the conversion are queued on the ring's own stream and the call returns at once, so
+     * the next block travels over PCIe while the correlators (which wait on the ring's event, not on the host) work on the previous one
+     * (the reference's flowgraph streams continuously, gnss_flowgraph.cc:1227-1231).  `items` must stay valid and unmodified until
+     * gsh_stream_wait() returns or two further pushes have been issued; pinned (page-locked) host memory makes the copy a true DMA.
+     * Two device staging buffers alternate.  The caller keeps the ring from lapping its readers: a push may only overwrite samples no
+     * queued launch still reads (capacity >= everything in flight). */
+    int gsh_stream_push_async(gsh_stream_t* s, const void* items, uint64_t n, int item_type, int inverted_spectrum, uint64_t* first_index);
+    int gsh_stream_wait(gsh_stream_t* s);  /* host waits for every queued push */
+    /* position an (idle) ring: the next pushed sample gets absolute index next_index and nothing older is resident -- a channel that
+     * starts hours into a run does not have to fill the ring from index 0 */
+    int gsh_stream_seek(gsh_stream_t* s, uint64_t next_index);
     int gsh_stream_range(gsh_stream_t* s, uint64_t* oldest, uint64_t* next);
     /* copy resident samples [index, index + n) back to the host as complex64 (tests, dumps) */
     int gsh_stream_read(gsh_stream_t* s, uint64_t index, uint64_t n, float* out_iq);
@@ -321,6 +332,18 @@ extern "C"
      * first code period, i.e. the stream position after the pull-in alignment of trk.cc:1949-1973 */
     int gsh_trk_start(gsh_trk_t* t, int channel, const float* code, const float* data_code, int code_length, uint64_t start_sample,
         uint64_t acq_sample_stamp, double acq_carrier_doppler_hz);
+    /* the same with d_acc_carrier_phase_rad preset (the pull-in alignment subtracts step * samples_offset from it, trk.cc:1966) */
+    int gsh_trk_start_ex(gsh_trk_t* t, int channel, const float* code, const float* data_code, int code_length, uint64_t start_sample,
+        uint64_t acq_sample_stamp, double acq_carrier_doppler_hz, double initial_acc_carrier_phase_rad);
+    /* The pull-in arithmetic of dll_pll_veml_tracking::general_work, state 1 (trk.cc:1949-1978), host only: with the block's read pointer at
+     * absolute sample nitems_read and the acquisition's Acq_delay_samples / Acq_samplestamp_samples / Acq_doppler_hz, how many samples
+     * to skip so that the next sample is a code start (samples_offset -> consume_each), the nominal first block length
+     * (d_current_prn_length_samples = round(T_prn_mod_samples)), and d_acc_carrier_phase_rad after the skip.
+     * start_sample for gsh_trk_start_ex is nitems_read + samples_offset. */
+    int gsh_trk_pull_in(const gsh_trk_conf* conf, uint64_t nitems_read, double acq_delay_samples, uint64_t acq_sample_stamp, double acq_carrier_doppler_hz,
+        int32_t* samples_offset, int32_t* first_prn_length_samples, double* acc_carrier_phase_rad);
+    /* stop_tracking / clear_tracking_vars for one channel: the loop no longer advances it (its state stays readable) */
+    int gsh_trk_stop(gsh_trk_t* t, int channel);
     /* n_epochs code periods of every started channel in ONE launch; the loop state stays on the device, so a later
      * call continues where this one stopped.  records: n_channels * n_epochs (channel-major) or NULL;
      * epochs_done[n_channels]: periods completed (a channel stops when its window would leave the stream). */

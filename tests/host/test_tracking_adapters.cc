@@ -1,0 +1,686 @@
+// End-to-end test of the TrackingInterface adapters (gnss-sdr_amd/host/gnss_sdr_adapters/dll_pll_tracking_hip.{h,cc},
+// dll_pll_veml_tracking_hip.{h,cc}, dll_pll_conf_hip.{h,cc}) and of Hip_Tracking_Loop, compiled against the reference's OWN headers
+// (tracking_interface.h, dll_pll_conf.h, gnss_synchro.h, in_memory_configuration.h, the signal constant headers, the replica
+// generators) and tests/host/mock_gnuradio/ for the GNU Radio runtime.
+//
+// The CHECKER is the reference itself: oracle/_ref/libgnsssdr_ref_trk.so (the reference's adapters + dll_pll_veml_tracking.cc + libs
+// compiled from /root/reference, C driver reftrk_* in oracle/ref_trk_api.cc).  Both chains are built from the same configuration
+// properties the way GNSSBlockFactory builds them (constructor(configuration, role, in_streams, out_streams)), wired the way Channel does
+// (set_channel, set_gnss_synchro, start_tracking after an acquisition has filled Gnss_Synchro), and driven through general_work over the
+// same synthetic IF stream, call for call.
+//
+//   test_tracking_adapters conf    CPU only: Dll_Pll_Conf -> gsh_trk_conf (hip_fill_trk_conf) equals what the reference block's constructor
+//                                  derives, field by field, for every supported signal; replicas equal the block's
+//   test_tracking_adapters         on the GPU box: the above + trajectories (prints "TRACKING ADAPTERS OK")
+#include "GPS_L1_CA.h"
+#include "Galileo_E1.h"
+#include "dll_pll_conf_hip.h"
+#include "dll_pll_tracking_hip.h"
+#include "galileo_e1_signal_replica.h"
+#include "gnss_synchro.h"
+#include "gps_sdr_signal_replica.h"
+#include "in_memory_configuration.h"
+#include <algorithm>
+#include <any>
+#include <array>
+#include <cmath>
+#include <complex>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <random>
+#include <string>
+#include <vector>
+
+// ---- the reference chain's C driver (oracle/ref_trk_api.cc)
+extern "C" {
+struct reftrk_output
+{
+    double fs, prompt_i, prompt_q, cn0_db_hz, carrier_doppler_hz, carrier_phase_rads, code_phase_samples;
+    uint64_t tracking_sample_counter;
+    int32_t flag_valid_symbol_output, correlation_length_ms, flag_pll_180_deg_phase_locked, prn;
+    int32_t state, current_prn_length_samples, n_correlator_taps, cn0_estimation_counter, carrier_lock_fail_counter, code_lock_fail_counter;
+    double code_freq_chips, rem_code_phase_samples, rem_code_phase_chips, acc_carrier_phase_rad, carrier_lock_test, carr_phase_error_hz,
+        carr_freq_error_hz, carr_error_filt_hz, code_error_chips, code_error_filt_chips, carrier_phase_step_rad, code_phase_step_chips,
+        carrier_phase_rate_step_rad, code_phase_rate_step_chips, current_correlation_time_s;
+    float rem_carr_phase_rad;
+    float corr[10];
+    float prompt_data[2];
+    float accu[10];
+    float p_data_accu[2];
+    int32_t n_events;
+    int32_t events[16];
+};
+struct reftrk_conf_out
+{
+    double fs_in, carrier_lock_th, signal_carrier_freq, code_period, code_chip_rate, bs_dominance_ratio;
+    float pll_bw_hz, dll_bw_hz, fll_bw_hz, pll_bw_narrow_hz, dll_bw_narrow_hz, early_late_space_chips, very_early_late_space_chips,
+        early_late_space_narrow_chips, very_early_late_space_narrow_chips, slope, spc, y_intercept, cn0_smoother_alpha,
+        carrier_lock_test_smoother_alpha, bs_min_prompt_mag;
+    uint32_t pull_in_time_s, bit_synchronization_time_limit_s, vector_length, smoother_length;
+    int32_t pll_filter_order, dll_filter_order, fll_filter_order, extend_correlation_symbols, cn0_samples, cn0_smoother_samples,
+        carrier_lock_test_smoother_samples, cn0_min, max_code_lock_fail, max_carrier_lock_fail, bs_stable_best_required, bs_min_events_for_lock;
+    int32_t enable_fll_pull_in, enable_fll_steady_state, track_pilot, carrier_aiding, high_dyn, bs_use_phase_dot_detector;
+    int32_t code_length_chips, code_samples_per_chip, symbols_per_bit, secondary, veml, cloop, use_histogram_bit_sync, interchange_iq,
+        secondary_code_length, data_secondary_code_length, correlation_length_ms, n_correlator_taps;
+    char secondary_code[256], data_secondary_code[256];
+    char system, signal[3];
+};
+void* reftrk_create(const char* implementation, const char* role, const char* const* keys, const char* const* values, int n_props);
+void reftrk_destroy(void* h);
+void reftrk_set_acquisition(void* h, char system, const char* signal, uint32_t prn, double acq_delay_samples, double acq_doppler_hz, uint64_t acq_samplestamp_samples);
+void reftrk_start_tracking(void* h);
+int reftrk_general_work(void* h, const float* iq, int n_items, int* consumed, reftrk_output* out);
+void reftrk_get_conf(void* h, reftrk_conf_out* c);
+int reftrk_get_codes(void* h, float* tracking_code, float* data_code, int capacity);
+}
+
+namespace
+{
+int fails = 0;
+#define EXPECT(cond, ...)                                            \
+    do                                                               \
+        {                                                            \
+            if (!(cond))                                             \
+                {                                                    \
+                    std::printf("FAIL %s:%d: ", __FILE__, __LINE__); \
+                    std::printf(__VA_ARGS__);                        \
+                    std::printf("\n");                               \
+                    fails++;                                         \
+                }                                                    \
+        }                                                            \
+    while (0)
+
+typedef std::map<std::string, std::string> Props;
+
+std::shared_ptr<InMemoryConfiguration> make_config(const Props& p)
+{
+    auto c = std::make_shared<InMemoryConfiguration>();
+    for (const auto& kv : p) c->set_property(kv.first, kv.second);
+    return c;
+}
+
+void* make_ref(const std::string& impl, const std::string& role, const Props& p)
+{
+    std::vector<const char*> k, v;
+    for (const auto& kv : p)
+        {
+            k.push_back(kv.first.c_str());
+            v.push_back(kv.second.c_str());
+        }
+    return reftrk_create(impl.c_str(), role.c_str(), k.data(), v.data(), static_cast<int>(k.size()));
+}
+
+// ---- Dll_Pll_Conf exactly as the reference adapters leave it, without building a GPU block: the HIP adapters' own constructors do the
+// per-signal part; here the same through a tiny subclass that never creates the device block
+struct ConfProbe
+{
+    Dll_Pll_Conf p;
+};
+
+void compare_conf(const char* name, const gsh_trk_conf& c, const Hip_Trk_Signal& sig, const reftrk_conf_out& r)
+{
+#define SAME(field, ref) EXPECT(static_cast<double>(c.field) == static_cast<double>(ref), "%s: %s %g vs reference %g", name, #field, static_cast<double>(c.field), static_cast<double>(ref))
+    SAME(fs_in, r.fs_in);
+    SAME(code_chip_rate, r.code_chip_rate);
+    SAME(signal_carrier_freq, r.signal_carrier_freq);
+    SAME(code_length_chips, r.code_length_chips);
+    SAME(code_samples_per_chip, r.code_samples_per_chip);
+    SAME(vector_length, r.vector_length);
+    SAME(veml, r.veml);
+    SAME(track_pilot, r.track_pilot);
+    SAME(early_late_space_chips, r.early_late_space_chips);
+    SAME(very_early_late_space_chips, r.very_early_late_space_chips);
+    SAME(pll_bw_hz, r.pll_bw_hz);
+    SAME(dll_bw_hz, r.dll_bw_hz);
+    SAME(fll_bw_hz, r.fll_bw_hz);
+    SAME(pll_filter_order, r.pll_filter_order);
+    SAME(dll_filter_order, r.dll_filter_order);
+    SAME(enable_fll_pull_in, r.enable_fll_pull_in);
+    SAME(enable_fll_steady_state, r.enable_fll_steady_state);
+    SAME(carrier_aiding, r.carrier_aiding);
+    SAME(cloop, r.cloop);
+    SAME(pull_in_time_s, r.pull_in_time_s);
+    SAME(spc, r.spc);
+    SAME(slope, r.slope);
+    SAME(y_intercept, r.y_intercept);
+    SAME(cn0_samples, r.cn0_samples);
+    SAME(cn0_min, r.cn0_min);
+    SAME(max_code_lock_fail, r.max_code_lock_fail);
+    SAME(max_carrier_lock_fail, r.max_carrier_lock_fail);
+    SAME(cn0_smoother_samples, r.cn0_smoother_samples);
+    SAME(carrier_lock_test_smoother_samples, r.carrier_lock_test_smoother_samples);
+    SAME(cn0_smoother_alpha, r.cn0_smoother_alpha);
+    SAME(carrier_lock_test_smoother_alpha, r.carrier_lock_test_smoother_alpha);
+    SAME(carrier_lock_th, r.carrier_lock_th);
+    SAME(symbols_per_bit, r.symbols_per_bit);
+    SAME(has_secondary, r.secondary);
+    SAME(secondary_code_length, r.secondary_code_length);
+    SAME(data_secondary_code_length, r.data_secondary_code_length);
+    SAME(extend_correlation_symbols, r.extend_correlation_symbols);
+    SAME(pll_bw_narrow_hz, r.pll_bw_narrow_hz);
+    SAME(dll_bw_narrow_hz, r.dll_bw_narrow_hz);
+    SAME(early_late_space_narrow_chips, r.early_late_space_narrow_chips);
+    SAME(very_early_late_space_narrow_chips, r.very_early_late_space_narrow_chips);
+    SAME(bs_min_events_for_lock, r.bs_min_events_for_lock);
+    SAME(bs_stable_best_required, r.bs_stable_best_required);
+    SAME(bs_use_phase_dot_detector, r.bs_use_phase_dot_detector);
+    SAME(bs_min_prompt_mag, r.bs_min_prompt_mag);
+    SAME(bs_dominance_ratio, r.bs_dominance_ratio);
+    SAME(high_dyn, r.high_dyn);
+    SAME(smoother_length, r.smoother_length);
+#undef SAME
+    EXPECT(sig.correlation_length_ms == r.correlation_length_ms, "%s: correlation_length_ms %d vs %d", name, sig.correlation_length_ms, r.correlation_length_ms);
+    EXPECT(sig.interchange_iq == (r.interchange_iq != 0), "%s: interchange_iq", name);
+    if (!sig.per_prn_secondary)
+        EXPECT(std::string(reinterpret_cast<const char*>(c.secondary_code), c.secondary_code_length) == std::string(r.secondary_code), "%s: secondary code", name);
+    EXPECT(std::string(reinterpret_cast<const char*>(c.data_secondary_code), c.data_secondary_code_length) == std::string(r.data_secondary_code),
+        "%s: data secondary code", name);
+    // the histogram bit synchroniser is configured at start_tracking (configure_bit_synchronizer, trk.cc:1387-1406): same rule
+    EXPECT(c.use_histogram_bit_sync == ((!r.secondary && r.symbols_per_bit > 1) ? 1 : 0), "%s: use_histogram_bit_sync", name);
+}
+
+// the Dll_Pll_Conf the HIP adapters end up with, without needing a GPU: same code path as DllPllTrackingHip's constructors up to
+// create_tracking_block() -- obtained from a real adapter object when a GPU is present, re-derived here otherwise
+struct SignalCase
+{
+    const char* name;
+    const char* ref_impl;
+    char system;
+    const char* signal;
+    double chip_rate, code_length;
+    Props props;
+};
+
+Dll_Pll_Conf adapter_conf(const SignalCase& sc, const std::string& role)
+{
+    // what DllPllTrackingHip(configuration, role, ...) + the signal constructor compute (dll_pll_tracking_hip.cc); kept in step by the GPU
+    // run below, which compares this very struct with adapter.config_params()
+    auto cfg = make_config(sc.props);
+    Dll_Pll_Conf p;
+    p.SetFromConfiguration(cfg.get(), role);
+    p.system = sc.system;
+    std::memcpy(p.signal, sc.signal, 3);
+    p.vector_length = static_cast<uint32_t>(static_cast<int>(std::round(p.fs_in / (sc.chip_rate / sc.code_length))));
+    if (p.extend_correlation_symbols < 1) p.extend_correlation_symbols = 1;
+    if (std::string(sc.signal) == "1C")
+        {
+            p.extend_correlation_symbols = std::min(p.extend_correlation_symbols, 20);
+            p.track_pilot = false;
+        }
+    if (std::string(sc.signal) == "1B" && !p.track_pilot) p.extend_correlation_symbols = 1;
+    if (std::string(sc.signal) == "L5" && !p.track_pilot) p.extend_correlation_symbols = std::min(p.extend_correlation_symbols, 10);
+    if (std::string(sc.signal) == "5X" && !p.track_pilot) p.extend_correlation_symbols = std::min(p.extend_correlation_symbols, 20);
+    return p;
+}
+
+std::vector<SignalCase> signal_cases()
+{
+    const std::string R = "Tracking";
+    auto base = [&](long fs) { return Props{{"GNSS-SDR.internal_fs_sps", std::to_string(fs)}, {R + ".hip_device", "0"}}; };
+    std::vector<SignalCase> v;
+    {
+        Props p = base(4000000);
+        p[R + ".pll_bw_hz"] = "35.0";
+        p[R + ".dll_bw_hz"] = "2.0";
+        p[R + ".early_late_space_chips"] = "0.5";
+        v.push_back({"GPS L1 C/A", "GPS_L1_CA_DLL_PLL_Tracking", 'G', "1C", 1.023e6, 1023.0, p});
+        p[R + ".extend_correlation_symbols"] = "10";
+        p[R + ".enable_fll_pull_in"] = "true";
+        p[R + ".fll_bw_hz"] = "10.0";
+        p[R + ".pll_filter_order"] = "2";
+        p[R + ".dll_filter_order"] = "1";
+        p[R + ".carrier_aiding"] = "false";
+        v.push_back({"GPS L1 C/A (extended, FLL pull-in, orders 2/1)", "GPS_L1_CA_DLL_PLL_Tracking", 'G', "1C", 1.023e6, 1023.0, p});
+    }
+    {
+        Props p = base(4000000);
+        p[R + ".track_pilot"] = "true";
+        p[R + ".early_late_space_chips"] = "0.15";
+        p[R + ".very_early_late_space_chips"] = "0.6";
+        p[R + ".pll_bw_hz"] = "15.0";
+        p[R + ".dll_bw_hz"] = "0.75";
+        v.push_back({"Galileo E1 pilot", "Galileo_E1_DLL_PLL_VEML_Tracking", 'E', "1B", 1.023e6, 4092.0, p});
+        p[R + ".track_pilot"] = "false";
+        p[R + ".early_late_space_chips"] = "0.5";
+        v.push_back({"Galileo E1 data", "Galileo_E1_DLL_PLL_VEML_Tracking", 'E', "1B", 1.023e6, 4092.0, p});
+    }
+    {
+        Props p = base(25000000);
+        p[R + ".track_pilot"] = "true";
+        v.push_back({"GPS L5 pilot", "GPS_L5_DLL_PLL_Tracking", 'G', "L5", 10.23e6, 10230.0, p});
+        p[R + ".track_pilot"] = "false";
+        p[R + ".high_dyn"] = "true";
+        p[R + ".smoother_length"] = "12";
+        v.push_back({"GPS L5 data, high dynamics", "GPS_L5_DLL_PLL_Tracking", 'G', "L5", 10.23e6, 10230.0, p});
+    }
+    return v;
+}
+
+void test_conf_mapping()
+{
+    for (const auto& sc : signal_cases())
+        {
+            void* ref = make_ref(sc.ref_impl, "Tracking", sc.props);
+            EXPECT(ref != nullptr, "%s: reference chain could not be built", sc.name);
+            if (ref == nullptr) continue;
+            reftrk_conf_out r{};
+            reftrk_get_conf(ref, &r);
+            const Dll_Pll_Conf p = adapter_conf(sc, "Tracking");
+            gsh_trk_conf c{};
+            Hip_Trk_Signal sig;
+            std::string why;
+            const bool ok = hip_fill_trk_conf(p, &c, &sig, &why);
+            EXPECT(ok, "%s: hip_fill_trk_conf: %s", sc.name, why.c_str());
+            if (ok)
+                {
+                    compare_conf(sc.name, c, sig, r);
+                    // local replicas: ours (hip_make_tracking_codes) vs what the block generated in start_tracking
+                    reftrk_set_acquisition(ref, sc.system, sc.signal, 7, 0.0, 0.0, 0);
+                    reftrk_start_tracking(ref);
+                    const int n = static_cast<int>(c.code_length_chips * c.code_samples_per_chip);
+                    std::vector<float> rc(n), rd(n), code, data;
+                    EXPECT(reftrk_get_codes(ref, rc.data(), rd.data(), n) == n, "%s: reference code length", sc.name);
+                    const char sigc[3] = {sc.signal[0], sc.signal[1], '\0'};
+                    EXPECT(hip_make_tracking_codes(sig, &c, 7, sigc, &code, &data, &why), "%s: hip_make_tracking_codes: %s", sc.name, why.c_str());
+                    EXPECT(code.size() == rc.size() && std::equal(code.begin(), code.end(), rc.begin()), "%s: tracking replica differs from the block's", sc.name);
+                    if (c.track_pilot) EXPECT(data.size() == rd.size() && std::equal(data.begin(), data.end(), rd.begin()), "%s: data replica differs", sc.name);
+                }
+            reftrk_destroy(ref);
+        }
+    // unsupported signal / item type are refused with a reason
+    {
+        Dll_Pll_Conf p;
+        p.system = 'R';
+        std::memcpy(p.signal, "1G", 3);
+        gsh_trk_conf c{};
+        Hip_Trk_Signal sig;
+        std::string why;
+        EXPECT(!hip_fill_trk_conf(p, &c, &sig, &why) && !why.empty(), "GLONASS must be refused");
+        p.system = 'G';
+        std::memcpy(p.signal, "1C", 3);
+        p.item_type = "cshort";
+        EXPECT(!hip_fill_trk_conf(p, &c, &sig, &why), "cshort tracking items must be refused (the reference adapters refuse them too)");
+    }
+}
+
+// ---- synthetic streams --------------------------------------------------------------------------------------------------------
+// code: +-1 replica at `spc` samples per chip (as the tracking block holds it), starting at sample 0; symbol k multiplies code period k
+std::vector<std::complex<float>> synth(const std::vector<float>& code, const std::vector<float>* code2, double w2, double chip_rate, int spc, double fs,
+    double fd, double f_carrier, size_t n, float amp, const std::vector<int8_t>& symbols, const std::vector<int8_t>* symbols2, unsigned seed)
+{
+    std::mt19937 gen(seed);
+    std::normal_distribution<float> g(0.0F, 1.0F);
+    std::vector<std::complex<float>> x(n);
+    const double rate = chip_rate * (1.0 + fd / f_carrier) / fs * spc;  // code samples per input sample
+    const size_t L = code.size();
+    for (size_t i = 0; i < n; i++)
+        {
+            const double pos = rate * static_cast<double>(i);
+            const auto k = static_cast<long long>(std::floor(pos));
+            const size_t idx = static_cast<size_t>(k % static_cast<long long>(L));
+            const size_t period = static_cast<size_t>(k / static_cast<long long>(L));
+            const float s1 = symbols.empty() ? 1.0F : static_cast<float>(symbols[std::min(period, symbols.size() - 1)]);
+            float v = code[idx] * s1;
+            if (code2 != nullptr)
+                {
+                    const float s2 = (symbols2 == nullptr || symbols2->empty()) ? 1.0F : static_cast<float>((*symbols2)[period % symbols2->size()]);
+                    v = static_cast<float>((v + w2 * (*code2)[idx] * s2) / std::sqrt(2.0));
+                }
+            const double ph = std::fmod(2.0 * M_PI * fd / fs * static_cast<double>(i), 2.0 * M_PI);
+            x[i] = std::complex<float>(g(gen), g(gen)) + amp * v * std::complex<float>(static_cast<float>(std::cos(ph)), static_cast<float>(std::sin(ph)));
+        }
+    return x;
+}
+
+float amp_for_cn0(double cn0_dbhz, double fs) { return static_cast<float>(std::sqrt(std::pow(10.0, cn0_dbhz / 10.0) * 2.0 / fs)); }
+
+struct Period
+{
+    int consumed{0};
+    int produced{0};
+    Gnss_Synchro item{};
+    long event{0};
+    int32_t state{0};
+};
+
+// one scheduler call on our block
+Period hip_call(gr::block& blk, const std::vector<std::complex<float>>& x, size_t& pos, int available)
+{
+    Period p;
+    const int avail = static_cast<int>(std::min<size_t>(static_cast<size_t>(available), x.size() - pos));
+    gr_vector_int nin{avail};
+    gr_vector_const_void_star ins{static_cast<const void*>(x.data() + pos)};
+    std::vector<Gnss_Synchro> outbuf(4);
+    gr_vector_void_star outs{static_cast<void*>(outbuf.data())};
+    blk.consumed_last = 0;
+    const size_t ev0 = blk.published.size();
+    p.produced = blk.general_work(1, nin, ins, outs);
+    blk.mock_advance(p.produced);
+    p.consumed = blk.consumed_last;
+    pos += static_cast<size_t>(p.consumed);
+    if (p.produced > 0) p.item = outbuf[0];
+    if (blk.published.size() > ev0) p.event = pmt::to_long(blk.published.back().second);
+    return p;
+}
+
+struct RefPeriod
+{
+    int consumed{0};
+    int produced{0};
+    reftrk_output o{};
+};
+
+RefPeriod ref_call(void* ref, const std::vector<std::complex<float>>& x, size_t& pos, int available)
+{
+    RefPeriod p;
+    const int avail = static_cast<int>(std::min<size_t>(static_cast<size_t>(available), x.size() - pos));
+    p.produced = reftrk_general_work(ref, reinterpret_cast<const float*>(x.data() + pos), avail, &p.consumed, &p.o);
+    pos += static_cast<size_t>(p.consumed);
+    return p;
+}
+
+// drive both chains over the same stream from the same hand-over; returns the number of leading periods with identical window positions
+struct TrajectoryStats
+{
+    int periods{0};
+    int same_windows{0};      // leading periods whose consumed counts (= window positions) are identical
+    int symbols_ref{0}, symbols_hip{0}, symbols_matched{0};
+    double worst_prompt_rel{0.0};
+    double final_doppler_ref{0.0}, final_doppler_hip{0.0};
+    double final_cn0_ref{0.0}, final_cn0_hip{0.0};
+    long hip_event{0};
+    int ref_events{0};
+    int first_symbol_period_ref{-1}, first_symbol_period_hip{-1};
+    int loss_period_ref{-1}, loss_period_hip{-1};
+    bool loss_item_hip{false}, loss_item_ref{false};
+};
+
+TrajectoryStats run_pair(DllPllTrackingHip& hip, void* ref, Gnss_Synchro& syn, const std::vector<std::complex<float>>& x, int vector_length, int n_periods,
+    char system, const char* signal, uint32_t prn, double acq_delay, double acq_doppler, uint64_t acq_stamp)
+{
+    TrajectoryStats st;
+    auto blk = std::dynamic_pointer_cast<gr::block>(hip.get_left_block());
+    syn = Gnss_Synchro{};
+    syn.System = system;
+    std::memcpy(syn.Signal, signal, 3);
+    syn.PRN = prn;
+    syn.Acq_delay_samples = acq_delay;
+    syn.Acq_doppler_hz = acq_doppler;
+    syn.Acq_samplestamp_samples = acq_stamp;
+    hip.set_channel(5);
+    hip.set_gnss_synchro(&syn);
+    reftrk_set_acquisition(ref, system, signal, prn, acq_delay, acq_doppler, acq_stamp);
+    size_t ph = 0, pr = 0;
+    const int avail = 2 * vector_length;
+    // standby: both consume what they are offered
+    Period a = hip_call(*blk, x, ph, avail);
+    RefPeriod b = ref_call(ref, x, pr, avail);
+    EXPECT(a.consumed == avail && b.consumed == avail && a.produced == 0 && b.produced == 0, "standby: consumed %d / %d", a.consumed, b.consumed);
+    hip.start_tracking();
+    reftrk_start_tracking(ref);
+    // pull-in
+    a = hip_call(*blk, x, ph, avail);
+    b = ref_call(ref, x, pr, avail);
+    EXPECT(a.consumed == b.consumed && a.produced == 0 && b.produced == 0, "pull-in: consumed %d vs reference %d", a.consumed, b.consumed);
+    bool same = (a.consumed == b.consumed);
+    std::vector<int> sym_ref, sym_hip;
+    std::vector<double> pi_ref, pi_hip;
+    for (int k = 0; k < n_periods; k++)
+        {
+            if (ph + static_cast<size_t>(avail) > x.size() || pr + static_cast<size_t>(avail) > x.size()) break;
+            a = hip_call(*blk, x, ph, avail);
+            b = ref_call(ref, x, pr, avail);
+            st.periods++;
+            if (same && a.consumed == b.consumed)
+                st.same_windows++;
+            else
+                same = false;
+            if (b.produced > 0 && b.o.flag_valid_symbol_output != 0)
+                {
+                    sym_ref.push_back(k);
+                    pi_ref.push_back(b.o.prompt_i);
+                    if (st.first_symbol_period_ref < 0) st.first_symbol_period_ref = k;
+                    st.final_doppler_ref = b.o.carrier_doppler_hz;
+                    st.final_cn0_ref = b.o.cn0_db_hz;
+                }
+            if (a.produced > 0 && a.event != 3)
+                {
+                    sym_hip.push_back(k);
+                    pi_hip.push_back(a.item.Prompt_I);
+                    if (st.first_symbol_period_hip < 0) st.first_symbol_period_hip = k;
+                    st.final_doppler_hip = a.item.Carrier_Doppler_hz;
+                    st.final_cn0_hip = a.item.CN0_dB_hz;
+                    EXPECT(a.item.Flag_valid_symbol_output && a.item.PRN == prn && a.item.System == system, "symbol item header");
+                    if (same && b.produced > 0)
+                        {
+                            EXPECT(a.item.Tracking_sample_counter == b.o.tracking_sample_counter, "period %d: Tracking_sample_counter %llu vs %llu", k,
+                                static_cast<unsigned long long>(a.item.Tracking_sample_counter), static_cast<unsigned long long>(b.o.tracking_sample_counter));
+                            EXPECT(a.item.correlation_length_ms == b.o.correlation_length_ms, "correlation_length_ms");
+                            EXPECT(a.item.Flag_PLL_180_deg_phase_locked == (b.o.flag_pll_180_deg_phase_locked != 0), "period %d: PLL 180 flag", k);
+                        }
+                }
+            if (a.event != 0) st.hip_event = a.event;
+            if (a.event == 3 && st.loss_period_hip < 0)
+                {
+                    st.loss_period_hip = k;
+                    st.loss_item_hip = (a.produced == 1 && !a.item.Flag_valid_symbol_output);
+                }
+            if (b.o.n_events > st.ref_events && b.o.events[b.o.n_events - 1] == 3 && st.loss_period_ref < 0)
+                {
+                    st.loss_period_ref = k;
+                    st.loss_item_ref = (b.produced == 1 && b.o.flag_valid_symbol_output == 0);
+                }
+            st.ref_events = b.o.n_events;
+            if (a.event == 3 || b.o.state == 0) break;
+        }
+    st.symbols_ref = static_cast<int>(sym_ref.size());
+    st.symbols_hip = static_cast<int>(sym_hip.size());
+    for (size_t i = 0, j = 0; i < sym_ref.size() && j < sym_hip.size();)
+        {
+            if (sym_ref[i] == sym_hip[j])
+                {
+                    st.symbols_matched++;
+                    const double rel = std::fabs(pi_ref[i] - pi_hip[j]) / std::max(1.0, std::fabs(pi_ref[i]));
+                    st.worst_prompt_rel = std::max(st.worst_prompt_rel, rel);
+                    i++;
+                    j++;
+                }
+            else if (sym_ref[i] < sym_hip[j])
+                i++;
+            else
+                j++;
+        }
+    return st;
+}
+
+std::vector<int8_t> random_symbols(size_t n, unsigned seed)
+{
+    std::mt19937 gen(seed);
+    std::vector<int8_t> s(n);
+    for (auto& v : s) v = (gen() & 1U) ? 1 : -1;
+    return s;
+}
+
+void test_gps_l1_trajectory()
+{
+    const long fs = 4000000;
+    const int n = 4000;
+    const uint32_t prn = 9;
+    const double fd = 1234.0;
+    const std::string R = "Tracking";
+    Props p{{"GNSS-SDR.internal_fs_sps", std::to_string(fs)}, {R + ".pll_bw_hz", "35.0"}, {R + ".dll_bw_hz", "2.0"}, {R + ".early_late_space_chips", "0.5"},
+        {R + ".pull_in_time_s", "0"}, {R + ".hip_device", "0"}};
+    auto cfg = make_config(p);
+    GpsL1CaDllPllTrackingHip hip(cfg.get(), R, 1, 1);
+    EXPECT(hip.implementation() == "GPS_L1_CA_DLL_PLL_Tracking_HIP" && hip.role() == R, "names");
+    EXPECT(hip.item_size() == sizeof(gr_complex), "item_size %zu", hip.item_size());
+    if (hip.item_size() == 0) return;
+    void* ref = make_ref("GPS_L1_CA_DLL_PLL_Tracking", R, p);
+    EXPECT(ref != nullptr, "reference chain");
+    // the adapter's Dll_Pll_Conf is what adapter_conf() re-derives (keeps the CPU-only conf test honest)
+    {
+        SignalCase sc{"GPS L1 C/A", "GPS_L1_CA_DLL_PLL_Tracking", 'G', "1C", 1.023e6, 1023.0, p};
+        const Dll_Pll_Conf q = adapter_conf(sc, R);
+        const Dll_Pll_Conf& a = hip.tracking_parameters();
+        EXPECT(q.vector_length == a.vector_length && q.track_pilot == a.track_pilot && q.extend_correlation_symbols == a.extend_correlation_symbols &&
+                   q.system == a.system && std::string(q.signal) == std::string(a.signal),
+            "adapter_conf() out of step with the adapter");
+        reftrk_conf_out r{};
+        reftrk_get_conf(ref, &r);
+        Hip_Trk_Signal sig;
+        sig.correlation_length_ms = r.correlation_length_ms;
+        sig.interchange_iq = r.interchange_iq != 0;
+        compare_conf("GPS L1 C/A (adapter)", hip.trk_conf(), sig, r);
+    }
+    // navigation bits: 30 random, the TLM preamble 10001011, 60 random; one bit = 20 code periods; bits start at code period 7
+    std::vector<int8_t> bits = random_symbols(30, 4);
+    for (char ch : std::string("10001011")) bits.push_back(ch == '1' ? 1 : -1);
+    const std::vector<int8_t> tail = random_symbols(60, 5);
+    bits.insert(bits.end(), tail.begin(), tail.end());
+    const int n_periods = 1000 + 20 * static_cast<int>(bits.size()) / 2 + 500;
+    std::vector<int8_t> symbols(static_cast<size_t>(n_periods) + 40, 1);
+    for (size_t k = 0; k < symbols.size(); k++)
+        {
+            const long b = (static_cast<long>(k) - 7) / 20;
+            if (static_cast<long>(k) >= 7 && b < static_cast<long>(bits.size())) symbols[k] = bits[static_cast<size_t>(b)];
+        }
+    std::vector<float> code(1023);
+    gps_l1_ca_code_gen_float(code, static_cast<int32_t>(prn), 0);
+    const auto x = synth(code, nullptr, 0.0, 1.023e6, 1, fs, fd, 1575.42e6, static_cast<size_t>(n_periods + 12) * n, amp_for_cn0(47.0, fs), symbols, nullptr, 11);
+    Gnss_Synchro syn;
+    const TrajectoryStats st = run_pair(hip, ref, syn, x, n, n_periods, 'G', "1C", prn, 0.0, fd - 15.0, n);
+    std::printf("GPS L1: %d periods, %d with identical windows, symbols ref/hip/matched %d/%d/%d, first symbol at period %d / %d, worst |dPrompt_I| rel %.2e, "
+                "Doppler %.2f / %.2f Hz, C/N0 %.2f / %.2f dB-Hz\n",
+        st.periods, st.same_windows, st.symbols_ref, st.symbols_hip, st.symbols_matched, st.first_symbol_period_ref, st.first_symbol_period_hip, st.worst_prompt_rel,
+        st.final_doppler_ref, st.final_doppler_hip, st.final_cn0_ref, st.final_cn0_hip);
+    EXPECT(st.periods >= n_periods - 2, "ran %d of %d periods", st.periods, n_periods);
+    EXPECT(st.same_windows >= st.periods * 9 / 10, "window positions identical for only %d of %d periods", st.same_windows, st.periods);
+    EXPECT(st.symbols_ref >= 10 && st.symbols_hip == st.symbols_ref && st.symbols_matched == st.symbols_ref, "symbol timing: ref %d hip %d matched %d", st.symbols_ref,
+        st.symbols_hip, st.symbols_matched);
+    EXPECT(st.first_symbol_period_hip == st.first_symbol_period_ref, "state-4 hand-over at period %d vs reference %d", st.first_symbol_period_hip, st.first_symbol_period_ref);
+    EXPECT(st.worst_prompt_rel < 2e-2, "Prompt_I of the symbols differs by %.3e", st.worst_prompt_rel);
+    EXPECT(std::fabs(st.final_doppler_hip - st.final_doppler_ref) < 1.0 && std::fabs(st.final_doppler_hip - fd) < 5.0, "Doppler %.2f vs %.2f", st.final_doppler_hip,
+        st.final_doppler_ref);
+    EXPECT(std::fabs(st.final_cn0_hip - st.final_cn0_ref) < 0.5, "C/N0 %.2f vs %.2f", st.final_cn0_hip, st.final_cn0_ref);
+    EXPECT(st.hip_event == 0 && st.ref_events == 0, "no loss of lock expected (hip event %ld, reference events %d)", st.hip_event, st.ref_events);
+
+    // ---- telemetry fault message -> forced loss of lock (trk.cc:757-769): "events" 3 and an item with Flag_valid_symbol_output = false
+    {
+        auto blk = std::dynamic_pointer_cast<gr::block>(hip.get_left_block());
+        blk->deliver("telemetry_to_trk", pmt::make_any(std::any(1)));
+        size_t pos = static_cast<size_t>(blk->nitems_read(0));
+        const Period a = hip_call(*blk, x, pos, 2 * n);
+        EXPECT(a.event == 3 && a.produced == 1 && !a.item.Flag_valid_symbol_output, "telemetry fault: event %ld produced %d", a.event, a.produced);
+        const Period b = hip_call(*blk, x, pos, 2 * n);  // back in standby
+        EXPECT(b.produced == 0 && b.consumed == 2 * n, "standby after loss of lock: consumed %d", b.consumed);
+    }
+    reftrk_destroy(ref);
+}
+
+void test_galileo_e1_pilot_trajectory()
+{
+    const long fs = 4000000;
+    const int n = 16000;
+    const uint32_t prn = 11;
+    const double fd = -2200.0;
+    const std::string R = "Tracking";
+    Props p{{"GNSS-SDR.internal_fs_sps", std::to_string(fs)}, {R + ".pll_bw_hz", "15.0"}, {R + ".dll_bw_hz", "0.75"}, {R + ".early_late_space_chips", "0.15"},
+        {R + ".very_early_late_space_chips", "0.6"}, {R + ".track_pilot", "true"}, {R + ".pull_in_time_s", "0"}, {R + ".hip_device", "0"}};
+    auto cfg = make_config(p);
+    GalileoE1DllPllVemlTrackingHip hip(cfg.get(), R, 1, 1);
+    EXPECT(hip.implementation() == "Galileo_E1_DLL_PLL_VEML_Tracking_HIP", "name");
+    EXPECT(hip.item_size() == sizeof(gr_complex), "item_size %zu", hip.item_size());
+    if (hip.item_size() == 0) return;
+    void* ref = make_ref("Galileo_E1_DLL_PLL_VEML_Tracking", R, p);
+    EXPECT(ref != nullptr, "reference chain");
+    std::vector<float> e1b(8184), e1c(8184);
+    const std::array<char, 3> sb{{'1', 'B', '\0'}}, sc{{'1', 'C', '\0'}};
+    galileo_e1_code_gen_sinboc11_float(e1b, sb, prn);
+    galileo_e1_code_gen_sinboc11_float(e1c, sc, prn);
+    const int n_periods = 420;
+    const std::vector<int8_t> data = random_symbols(static_cast<size_t>(n_periods) + 20, 8);
+    std::vector<int8_t> sec;
+    for (char ch : std::string(GALILEO_E1_C_SECONDARY_CODE)) sec.push_back(ch == '0' ? 1 : -1);
+    // E1 OS: (e1b * data - e1c * secondary) / sqrt(2)
+    const auto x = synth(e1b, &e1c, -1.0, 1.023e6, 2, fs, fd, 1575.42e6, static_cast<size_t>(n_periods + 6) * n, amp_for_cn0(47.0, fs), data, &sec, 13);
+    Gnss_Synchro syn;
+    const TrajectoryStats st = run_pair(hip, ref, syn, x, n, n_periods, 'E', "1B", prn, 0.0, fd + 10.0, n);
+    std::printf("Galileo E1: %d periods, %d with identical windows, symbols ref/hip/matched %d/%d/%d, first symbol at period %d / %d, worst |dPrompt_I| rel %.2e, "
+                "Doppler %.2f / %.2f Hz, C/N0 %.2f / %.2f dB-Hz\n",
+        st.periods, st.same_windows, st.symbols_ref, st.symbols_hip, st.symbols_matched, st.first_symbol_period_ref, st.first_symbol_period_hip, st.worst_prompt_rel,
+        st.final_doppler_ref, st.final_doppler_hip, st.final_cn0_ref, st.final_cn0_hip);
+    EXPECT(st.same_windows >= st.periods * 9 / 10, "window positions identical for only %d of %d periods", st.same_windows, st.periods);
+    EXPECT(st.symbols_ref >= 50 && st.symbols_hip == st.symbols_ref && st.symbols_matched == st.symbols_ref, "symbol timing: ref %d hip %d matched %d", st.symbols_ref,
+        st.symbols_hip, st.symbols_matched);
+    EXPECT(st.first_symbol_period_hip == st.first_symbol_period_ref, "secondary-code lock at period %d vs reference %d", st.first_symbol_period_hip, st.first_symbol_period_ref);
+    EXPECT(st.worst_prompt_rel < 2e-2, "Prompt_I of the symbols differs by %.3e", st.worst_prompt_rel);
+    EXPECT(std::fabs(st.final_doppler_hip - st.final_doppler_ref) < 1.0, "Doppler %.2f vs %.2f", st.final_doppler_hip, st.final_doppler_ref);
+    reftrk_destroy(ref);
+}
+
+void test_loss_of_lock_on_noise()
+{
+    // noise only, with the lock thresholds tightened so that the detectors act within a few hundred periods: cn0_min 35 dB-Hz,
+    // max_lock_fail 20 (dll_pll_conf.cc: <role>.cn0_min, <role>.max_lock_fail).  Both chains must drop the channel in the same period, with
+    // "events" 3 and one item carrying Flag_valid_symbol_output = false (trk.cc:1208-1221, 2009-2014, 2285-2294).
+    const long fs = 4000000;
+    const int n = 4000;
+    const std::string R = "Tracking";
+    Props p{{"GNSS-SDR.internal_fs_sps", std::to_string(fs)}, {R + ".pull_in_time_s", "0"}, {R + ".hip_device", "0"}, {R + ".cn0_min", "35"},
+        {R + ".max_lock_fail", "20"}};
+    auto cfg = make_config(p);
+    GpsL1CaDllPllTrackingHip hip(cfg.get(), R, 1, 1);
+    if (hip.item_size() == 0) return;
+    void* ref = make_ref("GPS_L1_CA_DLL_PLL_Tracking", R, p);
+    EXPECT(hip.trk_conf().cn0_min == 35 && hip.trk_conf().max_code_lock_fail == 20, "cn0_min %d max_code_lock_fail %d", hip.trk_conf().cn0_min,
+        hip.trk_conf().max_code_lock_fail);
+    std::vector<float> code(1023, 1.0F);
+    const auto x = synth(code, nullptr, 0.0, 1.023e6, 1, fs, 0.0, 1575.42e6, static_cast<size_t>(2600) * n, 0.0F, {}, nullptr, 21);  // noise only
+    Gnss_Synchro syn;
+    const TrajectoryStats st = run_pair(hip, ref, syn, x, n, 2500, 'G', "1C", 3, 100.0, 500.0, n);
+    std::printf("noise only: loss of lock at period %d (HIP block) / %d (reference), %d periods with identical windows\n", st.loss_period_hip, st.loss_period_ref,
+        st.same_windows);
+    EXPECT(st.loss_period_ref >= 0, "the reference did not drop the channel in %d periods -- test set-up", st.periods);
+    EXPECT(st.loss_period_hip == st.loss_period_ref, "loss of lock at period %d vs reference %d", st.loss_period_hip, st.loss_period_ref);
+    EXPECT(st.loss_item_hip && st.loss_item_ref, "loss of lock must come with an item whose Flag_valid_symbol_output is false (hip %d, reference %d)", st.loss_item_hip,
+        st.loss_item_ref);
+    reftrk_destroy(ref);
+}
+
+void test_unusable_configurations()
+{
+    const std::string R = "Tracking";
+    Props p{{"GNSS-SDR.internal_fs_sps", "4000000"}, {R + ".item_type", "cshort"}, {R + ".hip_device", "0"}};
+    auto cfg = make_config(p);
+    GpsL1CaDllPllTrackingHip hip(cfg.get(), R, 1, 1);
+    EXPECT(hip.item_size() == 0, "cshort items: item_size must be 0 (gnss_block_factory.cc:1048-1052), got %zu", hip.item_size());
+    Props q{{"GNSS-SDR.internal_fs_sps", "4000000"}, {R + ".hip_device", "63"}};
+    auto cfg2 = make_config(q);
+    GpsL1CaDllPllTrackingHip hip2(cfg2.get(), R, 1, 1);
+    EXPECT(hip2.item_size() == 0, "absent device: item_size must be 0, got %zu", hip2.item_size());
+}
+}  // namespace
+
+int main(int argc, char** argv)
+{
+    const bool conf_only = argc > 1 && std::string(argv[1]) == "conf";
+    test_conf_mapping();
+    if (conf_only)
+        {
+            std::printf(fails == 0 ? "TRACKING CONF OK\n" : "%d failure(s)\n", fails);
+            return fails == 0 ? 0 : 1;
+        }
+    if (gsh_device_count() < 1)
+        {
+            std::printf("no HIP device: only the configuration mapping was checked\n");
+            return fails == 0 ? 2 : 1;
+        }
+    test_unusable_configurations();
+    test_gps_l1_trajectory();
+    test_galileo_e1_pilot_trajectory();
+    test_loss_of_lock_on_noise();
+    std::printf(fails == 0 ? "TRACKING ADAPTERS OK\n" : "%d failure(s)\n", fails);
+    return fails == 0 ? 0 : 1;
+}
