@@ -4,15 +4,19 @@
 Workload (config.workload): BASELINE config 2 -- GPS L1 C/A, 32 channels (PRN 1..32), fs = 25 Msps,
 N = 25 000 samples per 1 ms epoch, 3-tap E/P/L -- open-loop (pre-computed NCO parameter table), every channel
 reading its own window sequence of ONE shared complex64 IF stream (noise + 8 embedded signals at 45 dB-Hz).
-A "step" is one pass of the hot path over one batch: channels x epochs jobs in one launch, inputs (stream, codes,
-job table) already resident in HBM.  value = channels*taps*epochs / time, whole job.
+A "step" is one pass of the hot path over one batch of synthetic input: `--blocks-per-step` (256) consecutive blocks of the IF stream, each
+block = channels x epochs jobs in one launch (the resident job table is re-used block after block through gsh_bank_set_sample_base).
+Inputs (stream, codes, job table) are resident in HBM before the timed region; the stream cycles through a buffer of `--ring-blocks`
+(8) blocks = 643 MB, larger than the 256 MiB Infinity Cache, so what the kernel does not find in L2 really comes from HBM.
+value = channels*taps*epochs*blocks / time, whole job.  Default K = 20 steps = 1.1 s of GPU time (long enough for the driver's SMI samples).
 
   python bench.py --gpus N --steps K --warmup W
   N > 1: launched by torch.distributed.run, one rank per GPU; every rank tracks its own 32 channels of the same
-  stream (weak scaling).  Every step the ingest rank re-distributes the stream block over RCCL in the front-end's
-  8-bit format (scatter + all-gather across all xGMI links, double-buffered on the communicator's stream and
-  overlapped with the previous block's correlation), every rank converts it to complex64 on its GPU and
-  correlates; all of that IS inside the timed region.
+  stream (weak scaling).  Every block is replicated from the ingest GPU (rank 0) to the others in the front-end's 8-bit format by the
+  engine itself -- gsh_stream_group_* (csrc/stream_group.hip: RCCL broadcast, or scatter + all-gather across all xGMI links with
+  GSH_BENCH_DIST=scatter_allgather), converted to complex64 into every GPU's sample ring and correlated there; copies and kernels are
+  ordered by events per sample range, so block k + 1 travels while block k is correlated.  All of that IS inside the timed region.
+  torch.distributed only hands the 128-byte communicator id round and provides the barrier / MAX-reduce of the contract -- no data.
 
 One JSON line on stdout (rank 0).  Besides the contract keys it carries
   roofline      -- dominant kernel (mcorr_kernel<3,0,false>) vs the HBM roofline, algorithmic bytes 8N+8T per job,
@@ -34,6 +38,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md (6.3 TB/s measured achievable)
+FP32_PEAK_TFLOPS = 157.3  # dense packed-FP32 vector peak (256 CUs x 2.4 GHz x 256 flop/clk/CU), same guide
 
 
 def parse():
@@ -45,7 +50,9 @@ def parse():
     ap.add_argument("--epochs", type=int, default=400, help="1 ms epochs per channel per step")
     ap.add_argument("--fs", type=float, default=25e6)
     ap.add_argument("--taps", type=int, default=3)
-    ap.add_argument("--settle-steps", type=int, default=800,
+    ap.add_argument("--blocks-per-step", type=int, default=256, help="stream blocks (launches) one step works through")
+    ap.add_argument("--ring-blocks", type=int, default=8, help="blocks of stream resident in HBM that the steps cycle through (8 = 643 MB > Infinity Cache)")
+    ap.add_argument("--settle-steps", type=int, default=3,
                     help="untimed steps run during set-up, before the W warm-up steps, so that the GPU clocks have settled: after an idle "
                          "period the first ~40 ms of work run up to 25 %% slower (profiles/ab/clock_ramp.py); 0 disables")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -148,6 +155,11 @@ def cpu_baseline(channels, n, fs, taps, target_s):
                 R.ref_set_flavour(0)
         return oracle.lib().oracle_mcorr_time(codes, 1023, shifts, taps, xi, len(x), n, channels, epochs, threads, params, out)
 
+    # one thread first: the yardstick for how much parallelism the box actually delivers (cgroup quotas, SMT siblings and memory channels
+    # make that much less than os.cpu_count() suggests)
+    threads = 1
+    run(16)
+    rate_1 = channels * 64 / max(run(64), 1e-9) if channels >= 1 else 0.0
     # pick the thread count that serves the CPU best (more threads than memory channels can hurt this streaming kernel)
     best = (0.0, cores)
     for cand in sorted({min(cores, c) for c in (8, 16, 32, 64, 128, 256, cores)}):
@@ -165,10 +177,14 @@ def cpu_baseline(channels, n, fs, taps, target_s):
         epochs = int(min(200000, max(epochs * 2, epochs * 0.9 * target_s / max(t, 1e-6))))
         t = run(epochs)
     simd = bool(R is not None and R.ref_simd_supported())
+    rate_best = channels * epochs / t
     return {
         "value": channels * taps * epochs / t,
         "unit": "correlators/s",
-        "cores": cores,
+        "cores": cores,                       # threads used
+        "host_logical_cpus": os.cpu_count(),
+        "single_thread_value": rate_1 * taps,
+        "effective_parallelism": (rate_best / rate_1) if rate_1 > 0 else None,   # what the threads delivered, in single-thread units
         "kind": kind,
         "sample": f"{channels} channels x {epochs} epochs of {n} samples, {taps} taps, {cores} threads, "
                   + ("Cpu_Multicorrelator_Real_Codes over volk_gnsssdr " + ("u_avx" if simd else "generic") + " protokernels (oracle/_ref)"
@@ -177,7 +193,7 @@ def cpu_baseline(channels, n, fs, taps, target_s):
     }
 
 
-def acquisition_metric(torch, dev_index, x_block, fs):
+def acquisition_metric(torch, dev_index, x_block, fs, pmc=None):
     """Secondary metric: PCPS dwells/s, BASELINE config 3 (32 PRN x 41 Doppler bins x 25 000 samples)."""
     try:
         from gnss_sdr_amd.acquisition import PcpsAcquisitionBank
@@ -194,19 +210,24 @@ def acquisition_metric(torch, dev_index, x_block, fs):
     ms_serial = acq.time_dwells(x_block, 32, reps=20)             # one batch after the other on one stream: latency
     ms = acq.time_dwells(x_block, 32, reps=200, pipelined=True)   # batches alternating on two streams: throughput
     nbytes = 16.0 * n * 41 * (32 + 1)
-    traffic = None
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("acquisition", {})
-        if tj.get("n") == n and tj.get("n_prn") == 32 and tj.get("n_bins") == 41:
-            traffic = tj.get("hbm_bytes_per_batch")
-    except Exception:
-        traffic = None
+    t = ms * 1e-3
+    # (D + P D) (5 N log2 N + 6 N) flops per batch
+    flops = (41 + 32 * 41) * (5.0 * n * np.log2(n) + 6.0 * n)
+    unique = 8.0 * n + 8.0 * n * 32 + 16.0 * 32      # the input block, the 32 code spectra, the result records: what must come from HBM once
+    roof = {"bound": "hbm", "achieved": nbytes / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / t / 1e9 / HBM_PEAK_GBS, "traffic": None,
+            "algorithmic_bytes_per_batch": nbytes, "kernels": "oc_forward_kernel + oc_cell_kernel<Plan<25,25,40>,false,false>",
+            "binding": "valu+lds (one transform per compute unit: register butterflies, LDS exchanges between barriers)",
+            "valu": {"algorithmic_flops_per_batch": flops, "achieved_tflops": flops / t / 1e12, "peak_tflops": FP32_PEAK_TFLOPS,
+                     "frac": flops / t / 1e12 / FP32_PEAK_TFLOPS},
+            "hbm_unique": {"bytes_per_batch": unique, "achieved_GBs": unique / t / 1e9, "frac": unique / t / 1e9 / HBM_PEAK_GBS}}
+    m = (pmc or {}).get("acquisition")
+    if m and m.get("n") == n and m.get("n_prn") == 32 and m.get("n_bins") == 41:
+        roof["traffic"] = m.get("hbm_bytes_per_batch")
+        roof["pmc"] = {k: v for k, v in m.items() if k not in ("n", "n_prn", "n_bins")}
     res = {"metric": "acquisition dwells/s", "value": 32.0 / (ms * 1e-3), "unit": "dwells/s", "ms_per_batch": ms,
            "ms_per_batch_single_stream": ms_serial,
            "config": {"workload": "GPS L1 C/A PCPS, 32 PRN x 41 Doppler bins, N=25000, 1 dwell"},
-           "roofline": {"bound": "hbm", "achieved": nbytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_batch": nbytes,
-                        "kernels": "oc_forward_kernel + oc_cell_kernel<Plan<25,25,40>,false,false>"}}
+           "roofline": roof}
     acq.close()
     try:
         res["cpu_baseline"] = acquisition_cpu_baseline(x_block.cpu().numpy(), fs, n)
@@ -249,43 +270,54 @@ def acquisition_cpu_baseline(x, fs, n, target_s=6.0):
             "single_process_dwells_per_s": 1.0 / t1, "seconds": dt}
 
 
-def pcie_inclusive_metric(torch, dev_index, x_dev, jobs, C, E, T, n_samples, reps=5):
-    """Not `value`: the same step when the stream block arrives from HOST memory -- 8-bit items (what a front-end delivers) in a pinned
-    buffer -> gsh_stream_push (H2D + cast on the device) -> one launch over all channels / epochs, nothing overlapped."""
+def pcie_inclusive_metric(torch, dev_index, x_dev, jobs, C, E, T, n_samples, reps=24):
+    """Not `value`: the same block when the stream arrives from HOST memory -- 8-bit items (what a front-end delivers) in a pinned buffer.
+    sequential: gsh_stream_push (H2D + cast, host waits) -> launch -> wait, block after block (round 1's figure);
+    overlapped: gsh_stream_push_async keeps block k + 1 on the PCIe bus while block k is correlated (events per sample range order the
+                ring's writer and the correlator; the host only waits at the very end)."""
     from gnss_sdr_amd.sample_stream import SampleStream
     from gnss_sdr_amd.tracking import CorrelatorBank
     from gnss_sdr_amd.codes import gps_l1_ca_code
-    q = torch.view_as_real(x_dev).mul(30.0).round_().clamp_(-127, 127).to(torch.int8).cpu()
+    q = torch.view_as_real(x_dev[:n_samples]).mul(30.0).round_().clamp_(-127, 127).to(torch.int8).cpu()
     host = torch.empty_like(q).pin_memory()
     host.copy_(q)
-    ring = SampleStream(n_samples + 2, n_samples // 2, device=dev_index)
-    bank = CorrelatorBank(C, 1023, device=dev_index)
-    for c in range(C):
-        bank.set_code(c, gps_l1_ca_code(c % 32 + 1))
-    bank.set_stream_ring(ring)
-    bank.set_splits(1)
     h = host.numpy()
-    from gnss_sdr_amd._lib import CorrJob
-    base = np.frombuffer(jobs, dtype=np.dtype(CorrJob)).copy()
-    tables = []
-    for r in range(reps + 1):  # absolute sample indices: block r starts at r * n_samples (built outside the timed region, like the bench's table)
-        t = base.copy()
-        t["sample_offset"] += np.uint64(r * n_samples)
-        tables.append((t, (CorrJob * len(t)).from_buffer(t)))
-    ts = []
-    for r in range(reps + 1):
-        t0 = time.perf_counter()
-        first = ring.push(h, "ibyte")
-        assert first == r * n_samples
-        bank.upload_jobs(tables[r][1])
+    out = {}
+    for mode in ("sequential", "overlapped"):
+        ring = SampleStream(3 * n_samples + 2, n_samples // 2, device=dev_index)
+        bank = CorrelatorBank(C, 1023, device=dev_index)
+        for c in range(C):
+            bank.set_code(c, gps_l1_ca_code(c % 32 + 1))
+        bank.set_stream_ring(ring)
+        bank.set_splits(1)
+        assert ring.push(h, "ibyte") == 0       # block 0 resident: the job table (window positions relative to a block start) is staged once
+        bank.upload_jobs(jobs)
         bank.launch()
         bank.synchronize()
-        ts.append(time.perf_counter() - t0)
-    bank.close()
-    ring.close()
-    dt = float(np.median(ts[1:]))
-    return {"value": C * T * E / dt, "unit": "correlators/s", "ms_per_step": dt * 1e3, "host_bytes_per_step": int(h.nbytes),
-            "note": "8-bit stream block from pinned host memory -> device ring (H2D + cast) -> job table upload -> launch; sequential, nothing overlapped"}
+        t0 = time.perf_counter()
+        if mode == "sequential":
+            for r in range(1, reps + 1):
+                first = ring.push(h, "ibyte")
+                bank.set_sample_base(first)
+                bank.launch()
+                bank.synchronize()
+        else:
+            first = ring.push_async(h, "ibyte")
+            for r in range(1, reps + 1):
+                nxt = ring.push_async(h, "ibyte") if r < reps else None   # block r + 1 on its way ...
+                bank.set_sample_base(first)
+                bank.launch()                                               # ... while block r is correlated
+                first = nxt
+            bank.synchronize()
+            ring.wait()
+        dt = (time.perf_counter() - t0) / reps
+        out[mode] = {"value": C * T * E / dt, "ms_per_block": dt * 1e3}
+        bank.close()
+        ring.close()
+    return {"value": out["overlapped"]["value"], "unit": "correlators/s", "ms_per_step": out["overlapped"]["ms_per_block"],
+            "sequential": out["sequential"], "host_bytes_per_block": int(h.nbytes),
+            "note": "8-bit stream block from pinned host memory -> device ring (H2D + cast) -> launch over the resident job table; `value`: "
+                    "gsh_stream_push_async, next block's copy overlapped with this block's correlation; `sequential`: nothing overlapped"}
 
 
 def closed_loop_metric(dev_index, x_dev, n_samples, fs, n, dop, cph, channels=32, epochs=200):
@@ -338,6 +370,44 @@ def other_configs_metric(dev_index):
     return out
 
 
+def load_pmc():
+    """profiles/pmc_r02.json: per-launch counter averages of the dominant kernels under this very command (profiles/run_profiles_r02.sh +
+    profiles/summarize_r02.py; rocprofv3 --pmc passes, kernel-trace only).  None when absent."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "pmc_r02.json")))
+    except Exception:
+        return None
+
+
+def tracking_roofline(C, E, T, n, k_ms, pmc):
+    """The contract's roofline object for mcorr_kernel, plus what actually binds it (DESIGN.md section 7 has the formulas).
+    bound / achieved / peak / frac / traffic: SURVEY 8(d)'s ALGORITHMIC bytes (8N + 8T per channel-epoch: every channel charged a private read
+      of its window) over the HBM peak.  32 channels share one stream, so this "fraction" exceeds 1 -- it is a rate, not a utilisation.
+    binding "valu": the kernel is bound by vector-ALU issue (the float32 chip-index arithmetic of the taps), measured against
+      SURVEY 8(d)'s algorithmic flops (6 + 4T per channel-sample) over the dense FP32 peak, with the issue counters next to it.
+    hbm_unique: the bytes that must leave HBM once per launch (the stream block, the codes, the results) over the HBM peak -- the honest HBM figure."""
+    n_jobs = C * E
+    alg_bytes = n_jobs * (8.0 * n + 8.0 * T)
+    t = k_ms * 1e-3
+    achieved = alg_bytes / t / 1e9
+    flops = float(C) * E * n * (6.0 + 4.0 * T)
+    unique = 8.0 * (E + 1) * n + 4.0 * 1023 * C + 64.0 * n_jobs
+    r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+         "kernel": f"mcorr_kernel<{3 if T <= 3 else (5 if T <= 5 else 8)},0,false>", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
+         "binding": "valu",
+         "valu": {"algorithmic_flops_per_launch": flops, "achieved_tflops": flops / t / 1e12, "peak_tflops": FP32_PEAK_TFLOPS,
+                  "frac": flops / t / 1e12 / FP32_PEAK_TFLOPS},
+         "hbm_unique": {"bytes_per_launch": unique, "achieved_GBs": unique / t / 1e9, "frac": unique / t / 1e9 / HBM_PEAK_GBS},
+         "channel_samples_per_s": float(C) * E * n / t}
+    m = (pmc or {}).get("mcorr")
+    if m and m.get("jobs") == n_jobs and m.get("n") == n:
+        r["traffic"] = m.get("hbm_bytes_per_launch")
+        r["pmc"] = {k: m[k] for k in ("source", "kernel_avg_us", "SQ_INSTS_VALU", "SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY",
+                                      "valu_insts_per_channel_sample", "valu_cycles_per_inst_per_simd", "l2_read_bytes_per_launch", "l2_GBs",
+                                      "hbm_bytes_per_launch", "hbm_GBs") if k in m}
+    return r
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -359,83 +429,91 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("GSH_BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm; gloo only for the one-GPU self-test
+        backend = os.environ.get("GSH_BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm; only the barrier / MAX-reduce / id hand-over use it
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     fs, n, C, E, T = a.fs, int(round(a.fs * 1e-3)), a.channels, a.epochs, a.taps
-    n_samples = (E + 2) * n
-    n_samples += (-n_samples) % 2
+    block = (E + 2) * n                    # one stream block: E epochs + the run-in the per-channel window offsets need
+    block += (-block) % 2
+    NB, BPS = max(a.ring_blocks, 1), max(a.blocks_per_step, 1)
+    grouped = world > 1 or os.environ.get("GSH_BENCH_FORCE_DIST") == "1"
 
     # ---- inputs, resident in HBM before the timed region
     if rank == 0:
-        x, dop, cph = make_stream_torch(torch, dev, n_samples, fs)
+        x0, dop, cph = make_stream_torch(torch, dev, block, fs)
     else:
-        x = torch.zeros(n_samples, dtype=torch.complex64, device=dev)
+        x0 = torch.zeros(block, dtype=torch.complex64, device=dev)
         dop, cph = np.zeros(0), np.zeros(0)
-    cs = torch.cuda.Stream(device=dev)      # a real (non-null) stream: the engine's launches and RCCL's waits are ordered on it
+    cs = torch.cuda.Stream(device=dev)      # a real (non-null) stream for the engine's launches
     stream = cs.cuda_stream
-    D = None
-    # GSH_BENCH_FORCE_DIST=1 runs the N > 1 step structure (raw block -> convert -> correlate) on one GPU: a self-test of that path
-    if world > 1 or os.environ.get("GSH_BENCH_FORCE_DIST") == "1":
-        # N > 1: the shared IF stream reaches the other GPUs the way a front-end delivers it -- 8-bit I/Q (item_type ibyte,
-        # 2 bytes per sample) -- and every rank converts it to complex64 on its own GPU (data_type_adapter arithmetic,
-        # gsh_convert_samples_device) before correlating.  Distribution: scatter + all-gather over all xGMI links
-        # (gnss_sdr_amd.sharding.BlockDistributor), double-buffered: block k+1 travels while block k is correlated.
-        from gnss_sdr_amd.sharding import BlockDistributor
-        from gnss_sdr_amd.sample_stream import convert_samples_device
-        D = BlockDistributor(2 * n_samples, world, rank, 0, os.environ.get("GSH_BENCH_DIST", "scatter_allgather"))
-        raw = [torch.zeros(D.padded, dtype=torch.int8, device=dev) for _ in range(2)]
-        piece = [torch.zeros(D.chunk, dtype=torch.int8, device=dev) for _ in range(2)]
-        raw_src = None
-        if rank == 0:
-            raw_src = torch.zeros(D.padded, dtype=torch.int8, device=dev)
-            raw_src[:2 * n_samples] = torch.view_as_real(x).mul(30.0).round_().clamp_(-127, 127).to(torch.int8).reshape(-1)
-        torch.cuda.synchronize()
-        try:
-            D.finish(D.start(raw[0], raw_src, piece[0]))
-            torch.cuda.synchronize()
-        except Exception as e:  # keep the run alive on a communicator that refuses scatter / all_gather_into_tensor
-            if rank == 0:
-                print(f"bench: scatter+all_gather distribution failed ({e}); falling back to broadcast", file=sys.stderr)
-            D = BlockDistributor(2 * n_samples, world, rank, 0, "broadcast")
-            D.finish(D.start(raw[0], raw_src, piece[0]))
-            torch.cuda.synchronize()
     bank = CorrelatorBank(C, 1023, device=local)
     for c in range(C):
         bank.set_code(c, gps_l1_ca_code((rank * C + c) % 32 + 1))
     jobs, rows = build_jobs(C, E, n, fs, T, dop, cph, rank)
-    bank.upload_jobs(jobs)
     bank.set_splits(1)
-    bank.set_stream_device(x.data_ptr(), n_samples, keepalive=x)
+    G = ring = raw_src = None
+    if not grouped:
+        # N = 1: NB copies of the block back to back; the steps cycle through them (643 MB: what misses L2 comes from HBM, not from the
+        # 256 MiB Infinity Cache)
+        x = torch.empty(NB * block, dtype=torch.complex64, device=dev)
+        for k in range(NB):
+            x[k * block:(k + 1) * block] = x0
+        bank.set_stream_device(x.data_ptr(), NB * block, keepalive=x)
+        bank.upload_jobs(jobs)
+    else:
+        # N > 1 (or the self-test of that path): every block reaches the GPUs through the engine's stream group -- 8-bit items in, complex64
+        # in every GPU's ring -- and the correlator bank reads the ring
+        from gnss_sdr_amd.sample_stream import StreamGroup
+        uid = [StreamGroup.unique_id() if (rank == 0 and world > 1) else None]
+        if dist and world > 1:
+            dist.broadcast_object_list(uid, src=0)     # 128 bytes of control plane
+        G = StreamGroup.from_rank(local, rank, world, uid[0], 3 * block + 2, block // 2, os.environ.get("GSH_BENCH_DIST", "broadcast"))
+        ring = G.ring(0)
+        if rank == 0:
+            raw_src = torch.view_as_real(x0).mul(30.0).round_().clamp_(-127, 127).to(torch.int8).reshape(-1).contiguous()
+        torch.cuda.synchronize()
+        first = G.push_device(raw_src.data_ptr() if raw_src is not None else None, block, "ibyte")
+        G.wait()
+        bank.set_stream_ring(ring)
+        bank.upload_jobs(jobs)                          # window positions relative to the start of a block, staged once
+        x = None
+
+    state = {"blk": 0, "next_first": None}
 
     def step(k):
-        if D is None:
-            bank.launch(stream)
+        if not grouped:
+            for j in range(BPS):
+                bank.set_sample_base(((k * BPS + j) % NB) * block)
+                bank.launch(stream)
             return
-        cur, nxt = k % 2, (k + 1) % 2
-        works = D.start(raw[nxt], raw_src, piece[nxt])      # block k+1 on the communicator's stream
-        convert_samples_device(local, raw[cur].data_ptr(), "ibyte", x.data_ptr(), n_samples, hip_stream=stream)
-        bank.launch(stream)                                  # block k: convert, then correlate, on the compute stream
-        D.finish(works)                                      # the compute stream waits for block k+1 before the next step reads it
+        for j in range(BPS):
+            # block b + 1 is queued for replication, then block b is correlated: the bank waits for the push that covers ITS windows only,
+            # and the push waits only for launches that still read what it overwrites (ring of three blocks)
+            if state["next_first"] is None:
+                state["next_first"] = G.push_device(raw_src.data_ptr() if raw_src is not None else None, block, "ibyte")
+            cur = state["next_first"]
+            state["next_first"] = G.push_device(raw_src.data_ptr() if raw_src is not None else None, block, "ibyte")
+            bank.set_sample_base(cur)
+            bank.launch(stream)
 
     with torch.cuda.stream(cs):
-        # set-up, not warm-up: bring the clocks out of their idle state with the same launches (a fixed count, identical on every rank,
-        # and even, so that the double-buffer parity of step() is preserved)
-        for k in range(2 * (max(a.settle_steps, 0) // 2)):
+        for k in range(max(a.settle_steps, 0)):   # set-up, not warm-up: bring the clocks out of their idle state with the same launches
             step(k)
         for k in range(a.warmup):
-            step(k)
+            step(a.settle_steps + k)
         torch.cuda.synchronize()
         if dist:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for k in range(a.steps):
-            step(a.warmup + k)
+            step(a.settle_steps + a.warmup + k)
         torch.cuda.synchronize()
+        if G is not None:
+            G.wait()
         if dist:
             dist.barrier()
         torch.cuda.synchronize()
@@ -447,34 +525,30 @@ def main():
 
     # ---- roofline of the dominant kernel: HIP events on the launch stream, inputs resident; taken straight after the timed region,
     # before the host-side spot check lets the GPU fall idle again
+    bank.synchronize()
     k_ms = bank.time_launches(100)
 
     # ---- spot-check against the oracle (not timed): a few jobs of the last launch
     out = bank.read_outputs()
     if rank == 0:
         from helpers import oracle_job, scale_err
-        xh = x.cpu().numpy()
+        if not grouped:
+            # time_launches() re-ran the last launch: the block the final step ended on
+            base_last = ((max(a.settle_steps, 0) + a.warmup + a.steps) * BPS - 1) % NB * block
+            xh = x[base_last:base_last + block].cpu().numpy()
+        else:
+            # the ring holds the 8-bit block converted back to float: that is what the kernel correlated
+            xh = (raw_src.to(torch.float32).reshape(-1, 2)).cpu().numpy()
+            xh = (xh[:, 0] + 1j * xh[:, 1]).astype(np.complex64)
         for j in (0, 1, C + 3, len(rows) - 1):
             o32, t64, sabs = oracle_job(oracle.ca_code(rows[j]["code_slot"] % 32 + 1), xh, rows[j])
             err = scale_err(out[j, :T], t64, sabs)
             if not np.all(err <= 1e-6):
                 raise SystemExit(f"bench: GPU result of job {j} disagrees with the oracle: {out[j, :T]} vs {t64}")
 
-    n_jobs = C * E
-    alg_bytes = n_jobs * (8.0 * n + 8.0 * T)
-    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        try:
-            tj = json.load(open(tpath))
-            if tj.get("jobs") == n_jobs and tj.get("n") == n:
-                traffic = tj.get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
-
     if rank == 0:
-        total_corr = float(C) * T * E * a.steps * world
+        pmc = load_pmc()
+        total_corr = float(C) * T * E * BPS * a.steps * world
         res = {
             "metric": "correlators/s",
             "value": total_corr / dt,
@@ -488,29 +562,30 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"GPS L1 C/A tracking, {C} channels/GPU x {E} epochs/step, fs={fs / 1e6:g} Msps, N={n}, {T}-tap E/P/L, open-loop",
-                       "channels_per_gpu": C, "epochs_per_step": E, "samples_per_epoch": n, "taps": T,
-                       "parallelism": f"channels sharded over {world} GPU(s)" + (f", 8-bit stream block re-distributed over RCCL each step ({D.mode}, overlapped) and converted on every GPU" if D is not None else "")},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": f"mcorr_kernel<{3 if T <= 3 else (5 if T <= 5 else 8)},0,false>",
-                         "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes},
+            "config": {"workload": f"GPS L1 C/A tracking, {C} channels/GPU x {E} epochs/block x {BPS} blocks/step, fs={fs / 1e6:g} Msps, N={n}, {T}-tap E/P/L, open-loop",
+                       "channels_per_gpu": C, "epochs_per_block": E, "blocks_per_step": BPS, "samples_per_epoch": n, "taps": T,
+                       "stream_resident_bytes": int(8 * NB * block) if not grouped else int(8 * (3 * block + 2)),
+                       "timed_region_s": dt,
+                       "parallelism": f"channels sharded over {world} GPU(s)" + (f", every 8-bit stream block replicated by the engine's RCCL stream group "
+                                      f"({os.environ.get('GSH_BENCH_DIST', 'broadcast')}), converted into every GPU's ring, overlapped with the correlation" if grouped else "")},
+            "roofline": tracking_roofline(C, E, T, n, k_ms, pmc),
             "kernel_only_value": float(C) * T * E / (k_ms * 1e-3),
         }
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(C, n, fs, T, a.cpu_seconds)
-        if world == 1 and not a.no_acq:
+        if world == 1 and not a.no_acq and not grouped:
             try:
-                res["pcie_inclusive"] = pcie_inclusive_metric(torch, local, x, jobs, C, E, T, n_samples)
+                res["pcie_inclusive"] = pcie_inclusive_metric(torch, local, x0, jobs, C, E, T, block)
             except Exception as e:
                 res["pcie_inclusive"] = {"error": str(e)}
             try:
-                res["acquisition"] = acquisition_metric(torch, local, x[:n].contiguous(), fs)
+                res["acquisition"] = acquisition_metric(torch, local, x0[:n].contiguous(), fs, pmc)
             except Exception as e:
                 res["acquisition"] = {"error": str(e)}
             try:
-                res["closed_loop"] = closed_loop_metric(local, x, n_samples, fs, n, dop, cph, channels=C, epochs=min(E - 2, 200))
+                res["closed_loop"] = closed_loop_metric(local, x0, block, fs, n, dop, cph, channels=C, epochs=min(E - 2, 200))
                 # one compute unit per channel: 32 channels use an eighth of the chip, 256 (BASELINE config 5's channel count) fill it
-                res["closed_loop_256ch"] = closed_loop_metric(local, x, n_samples, fs, n, dop, cph, channels=256, epochs=min(E - 2, 200))
+                res["closed_loop_256ch"] = closed_loop_metric(local, x0, block, fs, n, dop, cph, channels=256, epochs=min(E - 2, 200))
             except Exception as e:
                 res["closed_loop"] = {"error": str(e)}
             if not a.no_other_configs:
@@ -520,6 +595,8 @@ def main():
                     res["other_configs"] = {"error": str(e)}
         print(json.dumps(res))
     bank.close()
+    if G is not None:
+        G.close()
     if dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -146,6 +146,7 @@ SYMBOLS = {
     "gsh_bank_time_launches": (C.c_int, [_P, C.c_int, _F]),
     "gsh_bank_set_pair_fusion": (C.c_int, [_P, C.c_int]),
     "gsh_bank_set_splits": (C.c_int, [_P, C.c_int]),
+    "gsh_bank_set_sample_base": (C.c_int, [_P, C.c_uint64]),
     "gsh_bank_set_stream_ring": (C.c_int, [_P, _P]),
     "gsh_stream_create": (C.c_int, [C.c_int, C.c_uint64, C.c_uint32, C.POINTER(_P)]),
     "gsh_stream_destroy": (None, [_P]),
@@ -154,6 +155,15 @@ SYMBOLS = {
     "gsh_stream_push_async": (C.c_int, [_P, _P, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64)]),
     "gsh_stream_wait": (C.c_int, [_P]),
     "gsh_stream_seek": (C.c_int, [_P, C.c_uint64]),
+    "gsh_comm_unique_id": (C.c_int, [_P]),
+    "gsh_stream_group_create": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.c_uint64, C.c_uint32, C.c_int, C.POINTER(_P)]),
+    "gsh_stream_group_create_rank": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, C.c_uint64, C.c_uint32, C.c_int, C.POINTER(_P)]),
+    "gsh_stream_group_destroy": (None, [_P]),
+    "gsh_stream_group_size": (C.c_int, [_P]),
+    "gsh_stream_group_ring": (_P, [_P, C.c_int]),
+    "gsh_stream_group_push": (C.c_int, [_P, _P, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64)]),
+    "gsh_stream_group_push_device": (C.c_int, [_P, _P, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64)]),
+    "gsh_stream_group_wait": (C.c_int, [_P]),
     "gsh_stream_range": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "gsh_stream_read": (C.c_int, [_P, C.c_uint64, C.c_uint64, _F]),
     "gsh_convert_samples_device": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, _P, C.c_uint64, _P]),

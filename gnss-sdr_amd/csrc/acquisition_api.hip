@@ -641,7 +641,9 @@ extern "C"
         if (rc != GSH_OK) return rc;
         GSH_HIP(hipSetDevice(a->device));
         GSH_HIP(hipStreamWaitEvent(a->stream, ring->pushed, 0));  // conversions queued by gsh_stream_push_device
-        return gsh_acq_dwell_device(a, w, n_prn, accumulate, dwell_count, results);
+        rc = gsh_acq_dwell_device(a, w, n_prn, accumulate, dwell_count, results);
+        if (rc != GSH_OK) return rc;
+        return gsh::stream_mark_read(ring, first_sample, a->stream);  // (the dwell has already been waited for when results were asked for; harmless otherwise)
     }
 
     int gsh_acq_dwell(gsh_acq_t* a, const float* in_iq, uint32_t n_prn, int accumulate, uint32_t dwell_count, gsh_acq_result* results)

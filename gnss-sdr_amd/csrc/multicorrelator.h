@@ -22,6 +22,8 @@ struct McorrArgs
     int window_floats;               // > 0: LDS holds only a window of the code per work-group (all jobs: mode 0, code_step >= 0); 0: the whole code
     const int* job_list;             // device, n_launch job indices this launch works on (order kept), or nullptr: jobs 0..n_launch-1
     int n_launch;                    // jobs in this launch (n_jobs stays the size of the whole table: outputs / partials are indexed by job)
+    unsigned long long sample_base;  // added to every job's sample_offset at launch (gsh_bank_set_sample_base): the same resident job table serves block after block
+    unsigned long long ring_capacity;// > 0: the stream is a gsh_stream ring, positions are taken modulo its capacity (windows stay contiguous: mirror)
     int packed;                      // 1: the packed four-samples-per-lane body may be used (default); 0: the round-1 body (A/B runs)
     const int* aux;                  // device, n_jobs, or nullptr.  aux[j] >= 0: job j also computes the single tap of job aux[j] (same window and
                                      // NCO, another code) and writes its output row; -2: job j is computed by its leader; -1: plain job

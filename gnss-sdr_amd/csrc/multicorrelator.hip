@@ -68,7 +68,9 @@ __global__ __launch_bounds__(MC_THREADS, ((NT <= 3 && !AUX) ? GSH_MC_MIN_WAVES :
     seg = (seg + 1) & ~1;
     c.n_begin = min(split * seg, c.n_total);
     c.n_end = min(c.n_total, c.n_begin + seg);
-    const unsigned long long abs0 = J.sample_offset + static_cast<unsigned long long>(c.n_begin);
+    unsigned long long win0 = J.sample_offset + a.sample_base;
+    if (a.ring_capacity) win0 %= a.ring_capacity;
+    const unsigned long long abs0 = win0 + static_cast<unsigned long long>(c.n_begin);
     const int odd = static_cast<int>(abs0 & 1ULL);
     c.n_first = c.n_begin - odd;
     const float2* __restrict__ base = a.stream + (abs0 - static_cast<unsigned long long>(odd));  // 16-byte aligned

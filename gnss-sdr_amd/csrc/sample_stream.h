@@ -20,6 +20,19 @@ struct gsh_stream
     size_t raw2_cap[2]{0, 0};
     hipEvent_t raw2_done[2]{nullptr, nullptr};  // the conversion that read staging buffer i has finished
     int raw2_next{0};
+    // Ordering between the ring's writer (pushes, on the ring's stream) and its readers (banks, loops, acquisition handles, on theirs) is kept
+    // by events, never by the host, and by SAMPLE RANGE so that copies and kernels really overlap:
+    //   push history    every push records (end index, event); a reader that needs samples up to `need_end` waits for the OLDEST push that
+    //                   covers it -- not for whatever was queued last;
+    //   reader history  every launch that reads the ring records (lowest index it reads, event); a push that overwrites everything below
+    //                   `next + n - capacity` waits only for the readers that still reach below that bound.
+    static constexpr int HIST = 16;
+    unsigned long long push_end[HIST]{};
+    hipEvent_t push_ev[HIST]{};
+    int push_count{0};                 // pushes recorded so far (slot = count % HIST)
+    unsigned long long read_min[HIST]{};
+    hipEvent_t read_ev[HIST]{};
+    int read_count{0};
 };
 
 namespace gsh
@@ -31,5 +44,12 @@ inline unsigned long long stream_oldest(const gsh_stream* s)
     const unsigned long long by_capacity = s->next > s->capacity ? s->next - s->capacity : 0ull;
     return by_capacity > s->origin ? by_capacity : s->origin;
 }
+// a reader has queued work on `st` that reads ring samples at or above min_index (0: anything): pushes that overwrite below min_index + ... wait for it
+int stream_mark_read(gsh_stream* s, unsigned long long min_index, hipStream_t st);
+// make `st` wait until samples below `need_end` are in the ring (need_end = ~0ull: everything pushed so far)
+int stream_wait_pushed(gsh_stream* s, unsigned long long need_end, hipStream_t st);
+// queue the conversion of n raw items at d_src (device memory) into ring positions [next, next + n) on the ring's own stream, after the readers'
+// fences; records `pushed` and advances `next`
+int stream_write_device_items(gsh_stream* s, const void* d_src, unsigned long long n, int item_type, int conj, hipStream_t st);
 }  // namespace gsh
 #endif

@@ -15,6 +15,32 @@ int stream_window(const gsh_stream* s, unsigned long long index, unsigned long l
     *ptr = s->d_ring + (index % s->capacity);
     return GSH_OK;
 }
+int stream_mark_read(gsh_stream* s, unsigned long long min_index, hipStream_t st)
+{
+    const int slot = s->read_count % gsh_stream::HIST;
+    if (s->read_ev[slot] == nullptr) GSH_HIP(hipEventCreateWithFlags(&s->read_ev[slot], hipEventDisableTiming));
+    GSH_HIP(hipEventRecord(s->read_ev[slot], st));
+    s->read_min[slot] = min_index;
+    s->read_count++;
+    return GSH_OK;
+}
+
+int stream_wait_pushed(gsh_stream* s, unsigned long long need_end, hipStream_t st)
+{
+    const int n = s->push_count < gsh_stream::HIST ? s->push_count : gsh_stream::HIST;
+    // oldest recorded push whose end covers need_end (ends grow with the push count)
+    for (int k = n; k >= 1; k--)
+        {
+            const int slot = (s->push_count - k) % gsh_stream::HIST;
+            if (s->push_end[slot] >= need_end)
+                {
+                    GSH_HIP(hipStreamWaitEvent(st, s->push_ev[slot], 0));
+                    return GSH_OK;
+                }
+        }
+    GSH_HIP(hipStreamWaitEvent(st, s->pushed, 0));  // not in the history (or "everything"): the latest push
+    return GSH_OK;
+}
 }  // namespace gsh
 
 namespace
@@ -25,6 +51,17 @@ using gsh::set_error;
 int write_items(gsh_stream* s, const void* d_src, unsigned long long n, int item_type, int conj, hipStream_t st)
 {
     const size_t isz = gsh::item_bytes(item_type);
+    {
+        // everything below `bound` is overwritten by this push: wait for the launches that still read below it
+        const unsigned long long end = s->next + n;
+        const unsigned long long bound = end > s->capacity ? end - s->capacity : 0ull;
+        const int m = s->read_count < gsh_stream::HIST ? s->read_count : gsh_stream::HIST;
+        for (int k = 1; k <= m; k++)
+            {
+                const int slot = (s->read_count - k) % gsh_stream::HIST;
+                if (s->read_min[slot] < bound) GSH_HIP(hipStreamWaitEvent(st, s->read_ev[slot], 0));
+            }
+    }
     const unsigned long long C = s->capacity, M = s->max_window;
     unsigned long long done = 0;
     while (done < n)
@@ -44,6 +81,34 @@ int write_items(gsh_stream* s, const void* d_src, unsigned long long n, int item
     return GSH_OK;
 }
 }  // namespace
+
+namespace
+{
+// after a push's device work has been queued on `st`: the "latest" event and the (end index, event) history entry
+int record_push(gsh_stream* s, unsigned long long end_index, hipStream_t st)
+{
+    GSH_HIP(hipEventRecord(s->pushed, st));
+    const int slot = s->push_count % gsh_stream::HIST;
+    if (s->push_ev[slot] == nullptr) GSH_HIP(hipEventCreateWithFlags(&s->push_ev[slot], hipEventDisableTiming));
+    GSH_HIP(hipEventRecord(s->push_ev[slot], st));
+    s->push_end[slot] = end_index;
+    s->push_count++;
+    return GSH_OK;
+}
+}  // namespace
+
+namespace gsh
+{
+int stream_write_device_items(gsh_stream* s, const void* d_src, unsigned long long n, int item_type, int conj, hipStream_t st)
+{
+    int rc = write_items(s, d_src, n, item_type, conj, st);
+    if (rc != GSH_OK) return rc;
+    rc = record_push(s, s->next + n, st);
+    if (rc != GSH_OK) return rc;
+    s->next += n;
+    return GSH_OK;
+}
+}  // namespace gsh
 
 extern "C"
 {
@@ -90,6 +155,11 @@ extern "C"
                 if (s->raw2_done[i]) (void)hipEventDestroy(s->raw2_done[i]);
             }
         if (s->pushed) (void)hipEventDestroy(s->pushed);
+        for (int i = 0; i < gsh_stream::HIST; i++)
+            {
+                if (s->push_ev[i]) (void)hipEventDestroy(s->push_ev[i]);
+                if (s->read_ev[i]) (void)hipEventDestroy(s->read_ev[i]);
+            }
         if (s->stream) (void)hipStreamDestroy(s->stream);
         delete s;
     }
@@ -107,7 +177,8 @@ extern "C"
         hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : s->stream;
         int rc = write_items(s, device_items, n, item_type, inverted_spectrum ? 1 : 0, st);
         if (rc != GSH_OK) return rc;
-        GSH_HIP(hipEventRecord(s->pushed, st));
+        rc = record_push(s, s->next + n, st);
+        if (rc != GSH_OK) return rc;
         s->next += n;
         if (!hip_stream) GSH_HIP(hipStreamSynchronize(st));
         return GSH_OK;
@@ -135,7 +206,8 @@ extern "C"
         GSH_HIP(hipMemcpyAsync(s->d_raw, items, bytes, hipMemcpyHostToDevice, s->stream));
         int rc = write_items(s, s->d_raw, n, item_type, inverted_spectrum ? 1 : 0, s->stream);
         if (rc != GSH_OK) return rc;
-        GSH_HIP(hipEventRecord(s->pushed, s->stream));
+        rc = record_push(s, s->next + n, s->stream);
+        if (rc != GSH_OK) return rc;
         GSH_HIP(hipStreamSynchronize(s->stream));
         s->next += n;
         return GSH_OK;
@@ -172,7 +244,8 @@ extern "C"
         int rc = write_items(s, s->d_raw2[slot], n, item_type, inverted_spectrum ? 1 : 0, s->stream);
         if (rc != GSH_OK) return rc;
         GSH_HIP(hipEventRecord(s->raw2_done[slot], s->stream));
-        GSH_HIP(hipEventRecord(s->pushed, s->stream));
+        rc = record_push(s, s->next + n, s->stream);
+        if (rc != GSH_OK) return rc;
         s->next += n;
         return GSH_OK;
     }
@@ -192,6 +265,8 @@ extern "C"
         GSH_HIP(hipStreamSynchronize(s->stream));
         s->next = next_index;
         s->origin = next_index;  // nothing older is resident
+        s->push_count = 0;
+        s->read_count = 0;
         return GSH_OK;
     }
 

@@ -32,6 +32,8 @@ struct gsh_bank
     int min_samples{0};
     unsigned long long max_end{0};
     int splits_user{0};
+    unsigned long long sample_base{0};  // gsh_bank_set_sample_base
+    unsigned long long ring_min_start{0}, ring_max_end{0};  // absolute sample range of the staged batch (ring-bound banks)
     // windowed code staging (multicorrelator.hip): possible when every job of the batch is mode 0 with code_step >= 0
     bool window_eligible{false};
     double win_step_max{0.0};   // largest code_phase_step_chips of the batch (code samples per input sample)
@@ -179,6 +181,10 @@ int bank_stage_jobs(gsh_bank* b, const gsh_corr_job* jobs, int n_jobs)
     std::memcpy(b->h_jobs, jobs, sizeof(gsh_corr_job) * static_cast<size_t>(n_jobs));
     if (b->ring != nullptr)
         {
+            unsigned long long lo = ~0ull;
+            for (int i = 0; i < n_jobs; i++) lo = std::min<unsigned long long>(lo, jobs[i].sample_offset);
+            b->ring_min_start = n_jobs > 0 ? lo : 0ull;
+            b->ring_max_end = max_end;
             for (int i = 0; i < n_jobs; i++)
                 {
                     const float2* w = nullptr;
@@ -423,6 +429,13 @@ extern "C"
         return GSH_OK;
     }
 
+    int gsh_bank_set_sample_base(gsh_bank_t* b, uint64_t sample_base)
+    {
+        GSH_REQUIRE(b != nullptr, "null bank");
+        b->sample_base = sample_base;
+        return GSH_OK;
+    }
+
     int gsh_bank_set_pair_fusion(gsh_bank_t* b, int enable)
     {
         GSH_REQUIRE(b != nullptr, "null bank");
@@ -501,11 +514,18 @@ extern "C"
         a.splits = splits;
         a.window_floats = bank_window_floats(b, splits);
         a.packed = gsh::mcorr_packed_default();
+        a.sample_base = b->sample_base;
+        a.ring_capacity = b->ring != nullptr ? b->ring->capacity : 0ull;
         // the second code table must not cost the occupancy the fusion is meant to win: only with windowed tables or short codes
         const bool fuse = b->n_fused > 0 && (a.window_floats > 0 || static_cast<size_t>(b->max_code_len) * sizeof(float) <= 10 * 1024);
         a.aux = fuse ? b->d_aux : nullptr;
         hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : b->stream;
-        if (b->ring != nullptr) GSH_HIP(hipStreamWaitEvent(s, b->ring->pushed, 0));  // conversions queued by gsh_stream_push_device
+        if (b->ring != nullptr)
+            {
+                // wait for the push that completed this batch's newest window -- not for a later block that may already be on its way
+                int rcw = gsh::stream_wait_pushed(b->ring, b->ring_max_end ? b->ring_max_end + b->sample_base : ~0ull, s);
+                if (rcw != GSH_OK) return rcw;
+            }
         a.job_list = nullptr;
         a.n_launch = b->n_jobs;
         if (b->lists_fused != fuse)
@@ -515,8 +535,11 @@ extern "C"
                 if (rc2 != GSH_OK) return rc2;
                 GSH_HIP(hipStreamSynchronize(b->stream));  // the list upload was queued on the bank's stream
             }
-        if (b->use_classes) return gsh::mcorr_launch_classes(a, b->class_plan, b->mode, b->max_code_len, s);
-        return gsh::mcorr_launch(a, b->max_taps, b->mode, b->max_code_len, s);
+        const int rc_launch = b->use_classes ? gsh::mcorr_launch_classes(a, b->class_plan, b->mode, b->max_code_len, s)
+                                             : gsh::mcorr_launch(a, b->max_taps, b->mode, b->max_code_len, s);
+        if (rc_launch != GSH_OK) return rc_launch;
+        if (b->ring != nullptr) return gsh::stream_mark_read(b->ring, b->ring_min_start + b->sample_base, s);  // pushes that would overwrite these windows wait
+        return GSH_OK;
     }
 
     int gsh_bank_synchronize(gsh_bank_t* b)

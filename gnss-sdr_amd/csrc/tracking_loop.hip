@@ -1070,6 +1070,7 @@ int trk_launch(gsh_trk* t, int n_epochs, gsh_trk_epoch* d_records)
                 hipLaunchKernelGGL((gsh::trk_loop_kernel<3, false>), grid, block, lds, t->stream, a);
         }
     GSH_HIP(hipGetLastError());
+    if (t->ring != nullptr) return gsh::stream_mark_read(t->ring, 0ull, t->stream);  // any later push into the ring waits for this launch
     return GSH_OK;
 }
 }  // namespace

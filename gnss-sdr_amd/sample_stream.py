@@ -20,9 +20,9 @@ class SampleStream:
         check(self._lib.gsh_stream_create(device, capacity_samples, max_window_samples, C.byref(self._h)))
 
     def close(self):
-        if self._h:
+        if self._h and getattr(self, "_owned", True):
             self._lib.gsh_stream_destroy(self._h)
-            self._h = C.c_void_p()
+        self._h = C.c_void_p()
 
     def __del__(self):
         try:
@@ -48,6 +48,24 @@ class SampleStream:
         check(self._lib.gsh_stream_push_device(self._h, C.c_void_p(device_ptr), n, ITEM_TYPES[item_type], int(inverted_spectrum),
                                                C.c_void_p(hip_stream) if hip_stream else None, C.byref(first)))
         return int(first.value)
+
+    def push_async(self, items: np.ndarray, item_type: str = "gr_complex", inverted_spectrum: bool = False) -> int:
+        """gsh_stream_push_async: copy + conversion queued on the ring's stream, returns at once.  `items` (numpy array, or a host pointer
+        given as (ptr, n)) must stay untouched until wait() or two further pushes."""
+        first = C.c_uint64(0)
+        if isinstance(items, tuple):
+            ptr, n = items
+        else:
+            ptr, n = items.ctypes.data, (items.size // 2 if item_type != "gr_complex" or items.dtype != np.complex64 else items.size)
+            self._keep_async = getattr(self, "_keep_async", [])[-2:] + [items]
+        check(self._lib.gsh_stream_push_async(self._h, C.c_void_p(ptr), n, ITEM_TYPES[item_type], int(inverted_spectrum), C.byref(first)))
+        return int(first.value)
+
+    def wait(self) -> None:
+        check(self._lib.gsh_stream_wait(self._h))
+
+    def seek(self, next_index: int) -> None:
+        check(self._lib.gsh_stream_seek(self._h, int(next_index)))
 
     def range(self):
         lo, hi = C.c_uint64(0), C.c_uint64(0)
@@ -169,3 +187,72 @@ class PulseBlanking:
         noise, n, last = C.c_float(0.0), C.c_int32(0), C.c_int32(0)
         check(self._lib.gsh_pb_get_state(self._h, C.byref(noise), C.byref(n), C.byref(last)))
         return float(noise.value), int(n.value), bool(last.value)
+
+
+class StreamGroup:
+    """gsh_stream_group_*: one block replicated into the sample rings of several GPUs over RCCL (one process per GPU: from_rank; one process
+    driving several GPUs: local)."""
+    MODES = {"broadcast": 0, "scatter_allgather": 1}
+
+    def __init__(self, handle, lib):
+        self._h, self._lib = handle, lib
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        check(_lib.load().gsh_comm_unique_id(buf))
+        return buf.raw
+
+    @classmethod
+    def from_rank(cls, device: int, rank: int, world: int, unique_id: bytes | None, capacity_samples: int, max_window_samples: int, mode: str = "broadcast"):
+        L = _lib.load()
+        h = C.c_void_p()
+        idb = C.create_string_buffer(unique_id, 128) if unique_id is not None else None
+        check(L.gsh_stream_group_create_rank(device, rank, world, idb, capacity_samples, max_window_samples, cls.MODES[mode], C.byref(h)))
+        return cls(h, L)
+
+    @classmethod
+    def local(cls, devices, capacity_samples: int, max_window_samples: int, mode: str = "broadcast"):
+        L = _lib.load()
+        h = C.c_void_p()
+        arr = (C.c_int * len(devices))(*devices)
+        check(L.gsh_stream_group_create(arr, len(devices), capacity_samples, max_window_samples, cls.MODES[mode], C.byref(h)))
+        return cls(h, L)
+
+    def close(self):
+        if self._h:
+            self._lib.gsh_stream_group_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def size(self) -> int:
+        return self._lib.gsh_stream_group_size(self._h)
+
+    def ring(self, local_index: int = 0) -> "SampleStream":
+        """The group's ring as a SampleStream view (owned by the group: closing the view does nothing)."""
+        s = SampleStream.__new__(SampleStream)
+        s._lib = self._lib
+        s._h = C.c_void_p(self._lib.gsh_stream_group_ring(self._h, local_index))
+        s._owned = False
+        s._group = self
+        return s
+
+    def push_device(self, device_ptr: int | None, n: int, item_type: str = "ibyte", inverted_spectrum: bool = False) -> int:
+        first = C.c_uint64(0)
+        check(self._lib.gsh_stream_group_push_device(self._h, C.c_void_p(device_ptr) if device_ptr else None, n, ITEM_TYPES[item_type],
+                                                     int(inverted_spectrum), C.byref(first)))
+        return int(first.value)
+
+    def push(self, items: np.ndarray | None, n: int, item_type: str = "ibyte", inverted_spectrum: bool = False) -> int:
+        first = C.c_uint64(0)
+        ptr = C.c_void_p(items.ctypes.data) if items is not None else None
+        check(self._lib.gsh_stream_group_push(self._h, ptr, n, ITEM_TYPES[item_type], int(inverted_spectrum), C.byref(first)))
+        return int(first.value)
+
+    def wait(self) -> None:
+        check(self._lib.gsh_stream_group_wait(self._h))

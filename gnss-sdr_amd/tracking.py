@@ -147,6 +147,10 @@ class CorrelatorBank:
         """Fuse a single-tap job into the job in front of it when both read the same window with the same NCO (default on)."""
         check(self._lib.gsh_bank_set_pair_fusion(self._h, int(bool(enable))))
 
+    def set_sample_base(self, sample_base: int) -> None:
+        """Offset added to every job's sample_offset at launch: one resident job table serves block after block."""
+        check(self._lib.gsh_bank_set_sample_base(self._h, int(sample_base)))
+
     def set_splits(self, splits: int) -> None:
         check(self._lib.gsh_bank_set_splits(self._h, splits))
 

@@ -30,7 +30,7 @@ extern "C"
 {
 #endif
 
-#define GSH_ABI_VERSION 16
+#define GSH_ABI_VERSION 17
 #define GSH_MAX_TAPS 8 /* VE/E/P/L/VL needs 5 (trk.cc:609-650); 8 leaves room for multi-tap dumps */
 
     enum
@@ -139,6 +139,10 @@ extern "C"
     /* work-groups per job used by the next launches (1 = throughput mode; >1 spreads one epoch
      * over more CUs for latency-bound closed-loop use).  0 = choose automatically. */
     int gsh_bank_set_splits(gsh_bank_t* b, int splits);
+    /* an offset (in samples) added to every job's sample_offset at launch time: a job table uploaded once -- window positions relative to
+     * the start of a block -- serves block after block of a long stream or of a ring (positions are taken modulo the ring's capacity)
+     * without being re-staged and re-uploaded every time.  The caller keeps the shifted windows inside the stream / resident in the ring. */
+    int gsh_bank_set_sample_base(gsh_bank_t* b, uint64_t sample_base);
 
     /* ================================================================ SAMPLE STREAM (device-resident ring)
      * gsh_stream_*: the IF sample stream of one RF front-end kept in device memory, addressed by ABSOLUTE sample index
@@ -177,6 +181,32 @@ extern "C"
     /* position an (idle) ring: the next pushed sample gets absolute index next_index and nothing older is resident -- a channel that
      * starts hours into a run does not have to fill the ring from index 0 */
     int gsh_stream_seek(gsh_stream_t* s, uint64_t next_index);
+    /* ---- one block, N GPUs: replication of the IF sample block into N device rings over RCCL / xGMI.
+     * Channels / PRNs shard over the GPUs of a node; they all read the same stream (gnss_flowgraph.cc:1227-1231), so every block enters ONE
+     * GPU -- rank 0, the ingest GPU -- in the front-end's raw item format and is replicated to the others, each converting it to complex64
+     * into its own ring.  GSH_GROUP_BROADCAST: ncclBroadcast.  GSH_GROUP_SCATTER_ALLGATHER: rank 0 sends a different 1/N to every peer over
+     * all its xGMI links at once, then an all-gather completes the block (xGMI is point to point: every link carries block/N twice instead
+     * of one link carrying the whole block per hop).  The rings are ordinary gsh_stream_t: banks, loops and acquisition handles bind to
+     * them as usual and wait on their events; nothing here synchronises the host.  A push is queued on the rings' own streams; consecutive
+     * pushes alternate between two staging buffers.  Ring capacity must cover what is in flight (see gsh_stream_push_async). */
+    typedef struct gsh_stream_group gsh_stream_group_t;
+#define GSH_GROUP_BROADCAST 0
+#define GSH_GROUP_SCATTER_ALLGATHER 1
+    /* one process drives all n_devices GPUs (ncclCommInitAll); local ring i belongs to devices[i], rank i */
+    int gsh_stream_group_create(const int* devices, int n_devices, uint64_t capacity_samples, uint32_t max_window_samples, int mode, gsh_stream_group_t** out);
+    /* one process per GPU: id128 = 128 bytes from gsh_comm_unique_id() on one rank, handed to every rank by whoever launched them
+     * (environment, file, MPI, torch.distributed's store ... -- control plane only) */
+    int gsh_comm_unique_id(void* id128);
+    int gsh_stream_group_create_rank(int device, int rank, int world, const void* id128, uint64_t capacity_samples, uint32_t max_window_samples, int mode,
+        gsh_stream_group_t** out);
+    void gsh_stream_group_destroy(gsh_stream_group_t* g);
+    int gsh_stream_group_size(const gsh_stream_group_t* g);                       /* local rings */
+    gsh_stream_t* gsh_stream_group_ring(gsh_stream_group_t* g, int local_index);  /* owned by the group */
+    /* every rank calls it for every block (a collective); the process that owns rank 0 supplies the block (host memory, or -- _device --
+     * memory on rank 0's GPU), the others pass NULL */
+    int gsh_stream_group_push(gsh_stream_group_t* g, const void* host_items, uint64_t n, int item_type, int inverted_spectrum, uint64_t* first_index);
+    int gsh_stream_group_push_device(gsh_stream_group_t* g, const void* device_items, uint64_t n, int item_type, int inverted_spectrum, uint64_t* first_index);
+    int gsh_stream_group_wait(gsh_stream_group_t* g);
     int gsh_stream_range(gsh_stream_t* s, uint64_t* oldest, uint64_t* next);
     /* copy resident samples [index, index + n) back to the host as complex64 (tests, dumps) */
     int gsh_stream_read(gsh_stream_t* s, uint64_t index, uint64_t n, float* out_iq);

@@ -8,6 +8,7 @@
 // (acq.cc:146, 318-351: 1 = positive, 2 = negative).  The stream is generated with the reference's own replica generators.
 // Prints "ADAPTERS OK".  Built by __graft_entry__.build() when /root/reference is present; run by tests/test_adapters_gpu.py.
 #include "GLONASS_L1_L2_CA.h"
+#include "GPS_L1_CA.h"
 #include "beidou_b1i_pcps_acquisition_hip.h"
 #include "beidou_b1i_signal_replica.h"
 #include "beidou_b3i_pcps_acquisition_hip.h"
@@ -39,6 +40,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <random>
 #include <string>
@@ -166,6 +168,174 @@ void run_simple_case(const char* name, const char* role, long fs, char system, c
     EXPECT(r.event == 1, "%s: event %ld", name, r.event);
     EXPECT(std::fabs(syn.Acq_delay_samples - static_cast<double>(delay)) <= 1.0, "%s delay %f (expected %zu)", name, syn.Acq_delay_samples, delay);
     EXPECT(std::fabs(syn.Acq_doppler_hz - fd) <= 500.0, "%s doppler %f (expected %f)", name, syn.Acq_doppler_hz, fd);
+}
+}  // namespace
+
+
+// ---- the reference's own pcps_acquisition block, compiled from /root/reference (oracle/_ref/libgnsssdr_ref_acq.so, C driver in
+// oracle/ref_acq_api.cc): the CHECKER the HIP block is run next to, general_work call for general_work call
+extern "C" {
+struct refacq_status
+{
+    int32_t state, active, step_two, positive_acq;
+    uint32_t dwell_count, tong_count, num_doppler_bins, fft_size, effective_fft_size, consumed_samples, code_phase, doppler_bins_step2;
+    uint64_t sample_counter;
+    float mag, input_power, test_statistics, threshold, threshold_step_two, doppler_center_step_two;
+    double acq_delay_samples, acq_doppler_hz;
+    uint64_t acq_samplestamp_samples;
+    uint32_t acq_doppler_step;
+    int64_t fs;
+    int64_t conf_fs_in, conf_resampled_fs;
+    float conf_samples_per_ms, conf_samples_per_code, conf_resampler_ratio, conf_threshold, conf_pfa, conf_pfa2, conf_doppler_step2;
+    uint32_t conf_samples_per_chip, conf_doppler_max, conf_doppler_step, conf_sampled_ms, conf_ms_per_code, conf_max_dwells, conf_num_doppler_bins_step2;
+    int32_t conf_it_size, conf_use_cfar, conf_bit_transition_flag, conf_make_2_steps, conf_blocking, conf_use_automatic_resampler;
+    int32_t consumed_last;
+    int64_t consumed_total;
+    int32_t n_events;
+    int32_t events[32];
+};
+void* refacq_create(int kind, const char* role, const char* const* keys, const char* const* values, int n_props, double chip_rate, double opt_freq,
+    uint32_t ms_per_code, const int32_t* extra);
+void refacq_destroy(void* h);
+void refacq_set_satellite(void* h, char system, const char* signal, uint32_t prn);
+void refacq_set_local_code(void* h, const float* code, const float* code2);
+void refacq_set_active(void* h, int active);
+int refacq_general_work(void* h, const void* items, int n_items, int noutput_items, int* consumed);
+void refacq_get_status(void* h, refacq_status* st);
+}
+
+namespace
+{
+// GPS L1 C/A: the HIP adapter and the reference block built from the same properties, fed the same chunks; after EVERY scheduler call
+// the two must have consumed the same number of items, and whenever either reports, both report the same event with the same
+// Acq_delay_samples / Acq_doppler_hz / Acq_samplestamp_samples / Acq_doppler_step (acq.cc:580-602) -- exactly (peak indices are what
+// north_star requires bit-exact; the reference block runs on the float64 DFT stand-in for FFTW).
+template <typename Item>
+void side_by_side(const char* name, const std::map<std::string, std::string>& props, const std::vector<Item>& stream, size_t chunk, uint32_t prn, long fs,
+    int expect_event)
+{
+    const std::string role = "Acquisition_1C";
+    auto conf = std::make_shared<InMemoryConfiguration>();
+    std::vector<const char*> k, v;
+    for (const auto& kv : props)
+        {
+            conf->set_property(kv.first, kv.second);
+            k.push_back(kv.first.c_str());
+            v.push_back(kv.second.c_str());
+        }
+    conf->set_property(role + ".hip_device", "0");
+    GpsL1CaPcpsAcquisitionHip acq(conf.get(), role, 1, 0);
+    const int32_t extra[3] = {0, 0, 0};
+    void* ref = refacq_create(0, role.c_str(), k.data(), v.data(), static_cast<int>(k.size()), GPS_L1_CA_CODE_RATE_CPS, GPS_L1_CA_OPT_ACQ_FS_SPS, 1, extra);
+    EXPECT(ref != nullptr, "%s: reference block", name);
+    if (ref == nullptr) return;
+    Gnss_Synchro syn{};
+    syn.System = 'G';
+    std::memcpy(syn.Signal, "1C", 3);
+    syn.PRN = prn;
+    acq.set_channel(0);
+    acq.set_gnss_synchro(&syn);
+    acq.set_local_code();
+    refacq_status st{};
+    refacq_get_status(ref, &st);
+    std::vector<std::complex<float>> code(st.consumed_samples);
+    {
+        const size_t spms = static_cast<size_t>(fs / 1000);
+        std::vector<std::complex<float>> one(spms);
+        gps_l1_ca_code_gen_complex_sampled(one, prn, static_cast<int32_t>(fs), 0);
+        for (size_t i = 0; i < code.size(); i++) code[i] = one[i % spms];
+    }
+    refacq_set_satellite(ref, 'G', "1C", prn);
+    refacq_set_local_code(ref, reinterpret_cast<const float*>(code.data()), nullptr);
+    acq.reset();
+    refacq_set_active(ref, 1);
+    auto blk = std::dynamic_pointer_cast<gr::block>(acq.get_left_block());
+    blk->published.clear();
+    size_t pa = 0, pr = 0;
+    gr_vector_void_star outs;
+    long ev_hip = 0;
+    int calls = 0, mismatched_calls = 0;
+    for (; calls < 20000; calls++)
+        {
+            const size_t avail = std::min(chunk, stream.size() - std::max(pa, pr));
+            if (avail == 0) break;
+            gr_vector_int nin{static_cast<int>(avail)};
+            gr_vector_const_void_star ins{static_cast<const void*>(stream.data() + pa)};
+            blk->consumed_last = 0;
+            blk->general_work(0, nin, ins, outs);
+            int rc = 0;
+            refacq_general_work(ref, stream.data() + pr, static_cast<int>(avail), 1, &rc);
+            if (blk->consumed_last != rc) mismatched_calls++;
+            pa += static_cast<size_t>(blk->consumed_last);
+            pr += static_cast<size_t>(rc);
+            refacq_get_status(ref, &st);
+            if (!blk->published.empty()) ev_hip = pmt::to_long(blk->published.back().second);
+            if (ev_hip != 0 || st.n_events > 0) break;
+        }
+    refacq_get_status(ref, &st);
+    const int ev_ref = st.n_events > 0 ? st.events[st.n_events - 1] : 0;
+    EXPECT(mismatched_calls == 0, "%s: %d scheduler calls consumed differently from the reference block", name, mismatched_calls);
+    EXPECT(ev_hip == ev_ref && ev_ref == expect_event, "%s: event %ld vs reference %d (expected %d) after %d calls", name, ev_hip, ev_ref, expect_event, calls);
+    EXPECT(syn.Acq_delay_samples == st.acq_delay_samples, "%s: Acq_delay_samples %.6f vs reference %.6f", name, syn.Acq_delay_samples, st.acq_delay_samples);
+    EXPECT(syn.Acq_doppler_hz == st.acq_doppler_hz, "%s: Acq_doppler_hz %.3f vs reference %.3f", name, syn.Acq_doppler_hz, st.acq_doppler_hz);
+    EXPECT(syn.Acq_samplestamp_samples == st.acq_samplestamp_samples, "%s: Acq_samplestamp_samples %llu vs reference %llu", name,
+        static_cast<unsigned long long>(syn.Acq_samplestamp_samples), static_cast<unsigned long long>(st.acq_samplestamp_samples));
+    EXPECT(syn.Acq_doppler_step == st.acq_doppler_step && syn.fs == st.fs, "%s: Acq_doppler_step %u / %u, fs %lld / %lld", name, syn.Acq_doppler_step, st.acq_doppler_step,
+        static_cast<long long>(syn.fs), static_cast<long long>(st.fs));
+    std::printf("%s: event %ld, delay %.1f, Doppler %.1f Hz, stamp %llu -- identical to the reference block over %d calls\n", name, ev_hip, syn.Acq_delay_samples,
+        syn.Acq_doppler_hz, static_cast<unsigned long long>(syn.Acq_samplestamp_samples), calls + 1);
+    refacq_destroy(ref);
+}
+
+void reference_block_side_by_side()
+{
+    const long fs = 4000000;
+    std::vector<std::complex<float>> rep(4000);
+    gps_l1_ca_code_gen_complex_sampled(rep, 17, static_cast<int32_t>(fs), 0);
+    const auto x = make_stream(rep, 80000, fs, 2345, -1810.0, 0.12F, 31);
+    typedef std::map<std::string, std::string> P;
+    const std::string R = "Acquisition_1C";
+    const P base{{"GNSS-SDR.internal_fs_sps", std::to_string(fs)}, {R + ".doppler_max", "5000"}, {R + ".doppler_step", "250"}, {R + ".blocking", "true"}};
+    {
+        P p = base;
+        p[R + ".pfa"] = "0.001";
+        side_by_side("side by side, CFAR", p, x, 1000, 17, fs, 1);
+        side_by_side("side by side, CFAR, absent PRN", p, x, 1700, 18, fs, 2);
+    }
+    {
+        P p = base;
+        p[R + ".threshold"] = "2.2";  // pfa 0 -> first-vs-second-peak statistic (acq_conf.cc:83-87)
+        side_by_side("side by side, peak ratio", p, x, 900, 17, fs, 1);
+    }
+    {
+        P p = base;
+        p[R + ".pfa"] = "0.001";
+        p[R + ".max_dwells"] = "3";
+        side_by_side("side by side, 3 non-coherent dwells, absent PRN", p, x, 1300, 20, fs, 2);
+    }
+    {
+        P p = base;
+        p[R + ".pfa"] = "0.001";
+        p[R + ".make_two_steps"] = "true";
+        p[R + ".second_nbins"] = "8";
+        p[R + ".second_doppler_step"] = "62.5";
+        side_by_side("side by side, two steps", p, x, 1100, 17, fs, 1);
+    }
+    {
+        P p = base;
+        p[R + ".pfa"] = "0.001";
+        p[R + ".bit_transition_flag"] = "true";
+        side_by_side("side by side, bit_transition_flag", p, x, 1500, 17, fs, 1);
+    }
+    {
+        P p = base;
+        p[R + ".pfa"] = "0.001";
+        p[R + ".item_type"] = "cshort";
+        std::vector<std::complex<int16_t>> x16(x.size());
+        for (size_t i = 0; i < x.size(); i++)
+            x16[i] = std::complex<int16_t>(static_cast<int16_t>(std::lrint(x[i].real() * 200.0F)), static_cast<int16_t>(std::lrint(x[i].imag() * 200.0F)));
+        side_by_side("side by side, cshort", p, x16, 1000, 17, fs, 1);
+    }
 }
 }  // namespace
 
@@ -354,6 +524,7 @@ int main()
         [](std::vector<std::complex<float>>& rep) { qzss_l1_code_gen_complex_sampled(rep, 193, 8000000); }, 3210, 2200.0, 0.0, 27);
     run_simple_case<QzssL5iPcpsAcquisitionHip>("QZSS L5I", "Acquisition_J5", 25000000, 'J', "J5", 194, "QZSS_L5i_PCPS_Acquisition_HIP",
         [](std::vector<std::complex<float>>& rep) { qzss_l5i_code_gen_complex_sampled(rep, 194, 25000000); }, 12321, -1500.0, 0.0, 28);
+    reference_block_side_by_side();
     if (fails == 0) std::printf("ADAPTERS OK\n");
     return fails == 0 ? 0 : 1;
 }
