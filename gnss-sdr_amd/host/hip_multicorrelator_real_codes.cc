@@ -47,6 +47,7 @@ void Hip_Multicorrelator_Real_Codes::set_high_dynamics_resampler(bool use_high_d
 
 bool Hip_Multicorrelator_Real_Codes::init(int max_signal_length_samples, int n_correlators)
 {
+    d_n_correlators = n_correlators;
     return ensure_handle() && check(gsh_mcorr_init(d_handle, max_signal_length_samples, n_correlators));
 }
 
@@ -59,6 +60,7 @@ bool Hip_Multicorrelator_Real_Codes::set_local_code_and_taps(int code_length_chi
 
 bool Hip_Multicorrelator_Real_Codes::set_input_output_vectors(std::complex<float>* corr_out, const std::complex<float>* sig_in)
 {
+    d_corr_out = corr_out;
     return ensure_handle() && check(gsh_mcorr_set_input_output_vectors(d_handle, reinterpret_cast<float*>(corr_out), reinterpret_cast<const float*>(sig_in)));
 }
 
@@ -67,16 +69,30 @@ bool Hip_Multicorrelator_Real_Codes::Carrier_wipeoff_multicorrelator_resampler(f
     float phase_rate_step_rad, float rem_code_phase_chips, float code_phase_step_chips, float code_phase_rate_step_chips,
     int signal_length_samples)
 {
-    return ensure_handle() && check(gsh_mcorr_carrier_wipeoff_multicorrelator_resampler(d_handle, rem_carrier_phase_in_rad, phase_step_rad,
-                                  phase_rate_step_rad, rem_code_phase_chips, code_phase_step_chips, code_phase_rate_step_chips, signal_length_samples));
+    const bool ok = ensure_handle() && check(gsh_mcorr_carrier_wipeoff_multicorrelator_resampler(d_handle, rem_carrier_phase_in_rad, phase_step_rad,
+                                           phase_rate_step_rad, rem_code_phase_chips, code_phase_step_chips, code_phase_rate_step_chips, signal_length_samples));
+    if (!ok) invalidate_outputs();
+    return ok;
 }
 
 
 bool Hip_Multicorrelator_Real_Codes::Carrier_wipeoff_multicorrelator_resampler(float rem_carrier_phase_in_rad, float phase_step_rad,
     float rem_code_phase_chips, float code_phase_step_chips, float code_phase_rate_step_chips, int signal_length_samples)
 {
-    return ensure_handle() && check(gsh_mcorr_carrier_wipeoff_multicorrelator_resampler6(d_handle, rem_carrier_phase_in_rad, phase_step_rad,
-                                  rem_code_phase_chips, code_phase_step_chips, code_phase_rate_step_chips, signal_length_samples));
+    const bool ok = ensure_handle() && check(gsh_mcorr_carrier_wipeoff_multicorrelator_resampler6(d_handle, rem_carrier_phase_in_rad, phase_step_rad,
+                                           rem_code_phase_chips, code_phase_step_chips, code_phase_rate_step_chips, signal_length_samples));
+    if (!ok) invalidate_outputs();
+    return ok;
+}
+
+
+void Hip_Multicorrelator_Real_Codes::invalidate_outputs()
+{
+    // The tracking block never looks at the return value (trk.cc:1236-1256), so a failed call must not leave the previous period's
+    // correlator outputs in place: zeros make the C/N0 estimate collapse and the lock detectors drop the channel within their fail counts,
+    // instead of the loop "tracking" stale data for ever.  The error text stays in last_error().
+    if (d_corr_out != nullptr)
+        for (int i = 0; i < d_n_correlators; i++) d_corr_out[i] = std::complex<float>(0.0F, 0.0F);
 }
 
 

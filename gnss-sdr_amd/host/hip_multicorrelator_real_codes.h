@@ -44,7 +44,10 @@ public:
 private:
     bool ensure_handle();
     bool check(int rc);
+    void invalidate_outputs();  //!< a failed correlation zeroes the borrowed output vector (the caller ignores the return value, trk.cc:1236-1256)
     gsh_mcorr* d_handle{nullptr};
+    std::complex<float>* d_corr_out{nullptr};  // borrowed (mcorr.cc:70)
+    int d_n_correlators{0};
     int d_device{-1};
     bool d_use_high_dynamics_resampler{true};  // same default as the reference (mcorr.h:60)
     std::string d_error;
