@@ -30,6 +30,12 @@ constexpr int MC_MARGIN = 32;  // guard entries on each side of the LDS code tab
 #ifndef GSH_MC_PACKED
 #define GSH_MC_PACKED 1
 #endif
+#ifndef GSH_MC_PREFETCH_BANK
+#define GSH_MC_PREFETCH_BANK 1  // trips of loads in flight per lane, batched kernel
+#endif
+#ifndef GSH_MC_PREFETCH_LOOP
+#define GSH_MC_PREFETCH_LOOP 4  // the same for the 1024-thread closed-loop kernel
+#endif
 #ifndef GSH_MC_CVT_FLR
 #define GSH_MC_CVT_FLR 1
 #endif
@@ -408,7 +414,7 @@ __device__ __forceinline__ void packed_trip(const JobCtx& c, const float* __rest
 // a lane's seed is T[4 + r] * L (one complex product), read from the table with v_readlane.  More than 60 re-seeds: the table is refilled.
 // NCH = 2 chunks per trip (four samples per lane) for the 256-thread batched kernel; NCH = 1 for the 1024-thread closed-loop kernel
 // (128 VGPRs per lane).  One summation order for every tap count, so fused and unfused jobs stay bit-identical.
-template <int NT, bool ZP, bool AUX, int NCH>
+template <int NT, bool ZP, bool AUX, int NCH, int PF>
 __device__ __forceinline__ void run_segment_packed(const JobCtx& c, const float2* __restrict__ base, const float* __restrict__ tab,
     const float (&sh)[NT], float2 (&acc)[NT], float2* acc_aux)
 {
@@ -466,65 +472,89 @@ __device__ __forceinline__ void run_segment_packed(const JobCtx& c, const float2
     };
     const v2f w2 = table(2);
 
-    const float2* q = base + 2 * tid;  // the lane's pair of chunk 0; advanced by one trip per iteration
-    float4 nA = make_float4(0.0f, 0.0f, 0.0f, 0.0f), nB = nA;
-    if (first_plain == 0 && last_plain > 0)
+    // Loads run PF trips ahead of the arithmetic (a register queue, the trip loop unrolled by PF).  The batched kernel (many work-groups per
+    // compute unit) gets by with PF = 1; the closed-loop kernel has ONE work-group per channel, so it keeps PF = 4 loads in flight per lane.
+    // (Measured, round 2, profiles/r02/closed_loop_phases.txt: the depth hardly matters -- of the 11 us of a closed-loop period 2.4 us are thread
+    // 0's loop arithmetic, 2.6 us fixed cost of the correlation phase (barriers, reductions) and 6 us the 13 trips of each wave.)
+    const float2* const q0 = base + 2 * tid;  // the lane's pair of chunk 0
+    constexpr int TRIP = 2 * NCH * PPC;        // samples (float2) a trip advances by
+    // the four samples of trip i for this lane: 16-byte loads in the body; at the segment's edges (odd head, partial tail) the samples outside
+    // [n_begin, n_end) are read as zero -- never loaded.  Edge trips go through the same queue, so their latency is hidden like the others'.
+    auto load_trip = [&](int i, float4& va, float4& vb) {
+        const float2* q = q0 + static_cast<long long>(i) * TRIP;
+        if ((i >= first_plain) && (i < last_plain))  // uniform
+            {
+                va = *reinterpret_cast<const float4*>(q);
+                if (NCH == 2) vb = *reinterpret_cast<const float4*>(q + 2 * PPC);
+            }
+        else
+            {
+                const int n0 = c.n_first + 2 * tid + i * TRIP;
+                const int lo = c.n_begin, hi = c.n_end - 1;
+                const bool a0 = (n0 >= lo) && (n0 <= hi), a1 = (n0 + 1 >= lo) && (n0 + 1 <= hi);
+                const float2 x0 = a0 ? q[0] : make_float2(0.0f, 0.0f);
+                const float2 x1 = a1 ? q[1] : make_float2(0.0f, 0.0f);
+                va = make_float4(x0.x, x0.y, x1.x, x1.y);
+                if (NCH == 2)
+                    {
+                        const int m0 = n0 + 2 * PPC;
+                        const bool b0 = (m0 >= lo) && (m0 <= hi), b1 = (m0 + 1 >= lo) && (m0 + 1 <= hi);
+                        const float2 z0 = b0 ? q[2 * PPC] : make_float2(0.0f, 0.0f);
+                        const float2 z1 = b1 ? q[2 * PPC + 1] : make_float2(0.0f, 0.0f);
+                        vb = make_float4(z0.x, z0.y, z1.x, z1.y);
+                    }
+            }
+    };
+    float4 qa[PF], qb[PF];
+#pragma unroll
+    for (int j = 0; j < PF; j++)
         {
-            nA = *reinterpret_cast<const float4*>(q);
-            if (NCH == 2) nB = *reinterpret_cast<const float4*>(q + 2 * PPC);
+            qa[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            qb[j] = qa[j];
+            if (j < n_trips) load_trip(j, qa[j], qb[j]);  // uniform
         }
     v2f pa = zero, nfA = zero, nfB = zero;
     int until_reseed = 0, r_idx = 0, tbl0 = 0;
-    for (int i = 0; i < n_trips; i++)
+    for (int i0 = 0; i0 < n_trips; i0 += PF)
         {
-            const int n0 = c.n_first + 2 * tid + i * (2 * NCH * PPC);
-            if (until_reseed == 0)  // uniform: exact re-seed of the lane's phasor and of (float)n
+#pragma unroll
+            for (int j = 0; j < PF; j++)
                 {
-                    if (r_idx - tbl0 >= TBL)
+                    const int i = i0 + j;
+                    if (i >= n_trips) break;  // uniform
+                    const int n0 = c.n_first + 2 * tid + i * TRIP;
+                    if (until_reseed == 0)  // uniform: exact re-seed of the lane's phasor and of (float)n
                         {
-                            tbl0 = r_idx;
-                            T = fill_table(tbl0);
+                            if (r_idx - tbl0 >= TBL)
+                                {
+                                    tbl0 = r_idx;
+                                    T = fill_table(tbl0);
+                                }
+                            pa = pk_cmul(table(4 + r_idx - tbl0), L);
+                            nfA = (v2f){static_cast<float>(n0), static_cast<float>(n0 + 1)};
+                            nfB = (v2f){static_cast<float>(n0 + 2 * PPC), static_cast<float>(n0 + 2 * PPC + 1)};
+                            until_reseed = RESEED;
+                            r_idx++;
                         }
-                    pa = pk_cmul(table(4 + r_idx - tbl0), L);
-                    nfA = (v2f){static_cast<float>(n0), static_cast<float>(n0 + 1)};
-                    nfB = (v2f){static_cast<float>(n0 + 2 * PPC), static_cast<float>(n0 + 2 * PPC + 1)};
-                    until_reseed = RESEED;
-                    r_idx++;
-                }
-            until_reseed--;
-            const bool plain = (i >= first_plain) && (i < last_plain);  // uniform
-            float4 vA = nA, vB = nB;
-            v2f ia = nfA, ib = nfB;
-            if (!plain)
-                {
-                    // edge trip (odd head, partial tail): samples outside [n_begin, n_end) are read as zero -- never loaded -- and looked up
-                    // at the nearest sample inside the segment
-                    const int lo = c.n_begin, hi = c.n_end - 1;
-                    const bool a0 = (n0 >= lo) && (n0 <= hi), a1 = (n0 + 1 >= lo) && (n0 + 1 <= hi);
-                    const float2 x0 = a0 ? q[0] : make_float2(0.0f, 0.0f);
-                    const float2 x1 = a1 ? q[1] : make_float2(0.0f, 0.0f);
-                    vA = make_float4(x0.x, x0.y, x1.x, x1.y);
-                    ia = (v2f){static_cast<float>(min(max(n0, lo), hi)), static_cast<float>(min(max(n0 + 1, lo), hi))};
-                    if (NCH == 2)
+                    until_reseed--;
+                    const bool plain = (i >= first_plain) && (i < last_plain);  // uniform
+                    const float4 vA = qa[j], vB = qb[j];
+                    v2f ia = nfA, ib = nfB;
+                    if (!plain)
                         {
+                            // edge trip: a sample outside the segment (already zero) is looked up at the nearest sample inside it, so that its
+                            // chip index stays within what is staged
+                            const int lo = c.n_begin, hi = c.n_end - 1;
+                            ia = (v2f){static_cast<float>(min(max(n0, lo), hi)), static_cast<float>(min(max(n0 + 1, lo), hi))};
                             const int m0 = n0 + 2 * PPC;
-                            const bool b0 = (m0 >= lo) && (m0 <= hi), b1 = (m0 + 1 >= lo) && (m0 + 1 <= hi);
-                            const float2 z0 = b0 ? q[2 * PPC] : make_float2(0.0f, 0.0f);
-                            const float2 z1 = b1 ? q[2 * PPC + 1] : make_float2(0.0f, 0.0f);
-                            vB = make_float4(z0.x, z0.y, z1.x, z1.y);
-                            ib = (v2f){static_cast<float>(min(max(m0, lo), hi)), static_cast<float>(min(max(m0 + 1, lo), hi))};
+                            if (NCH == 2) ib = (v2f){static_cast<float>(min(max(m0, lo), hi)), static_cast<float>(min(max(m0 + 1, lo), hi))};
                         }
+                    if (i + PF < n_trips) load_trip(i + PF, qa[j], qb[j]);  // uniform: the loads of trip i + PF take this trip's place in the queue
+                    packed_trip<NT, ZP, AUX, NCH>(c, tab, shp, k_step_nrem, aux_shp, aux_on, pa, ia, ib, vA, vB, A0, A1, B0, B1, XA0, XA1, XB0, XB1);
+                    pa = pk_cmul(pa, w2);
+                    asm("v_pk_add_f32 %0, %0, %1" : "+v"(nfA) : "v"(stride));
+                    if (NCH == 2) asm("v_pk_add_f32 %0, %0, %1" : "+v"(nfB) : "v"(stride));
                 }
-            q += 2 * NCH * PPC;
-            if ((i + 1 >= first_plain) && (i + 1 < last_plain))  // uniform: the next trip's loads are issued before this trip is computed
-                {
-                    nA = *reinterpret_cast<const float4*>(q);
-                    if (NCH == 2) nB = *reinterpret_cast<const float4*>(q + 2 * PPC);
-                }
-            packed_trip<NT, ZP, AUX, NCH>(c, tab, shp, k_step_nrem, aux_shp, aux_on, pa, ia, ib, vA, vB, A0, A1, B0, B1, XA0, XA1, XB0, XB1);
-            pa = pk_cmul(pa, w2);
-            asm("v_pk_add_f32 %0, %0, %1" : "+v"(nfA) : "v"(stride));
-            if (NCH == 2) asm("v_pk_add_f32 %0, %0, %1" : "+v"(nfB) : "v"(stride));
         }
     // fold: acc += A0 + inc * A1 + w * (B0 + inc * B1)
     const v2f incv = table(0), wv = table(1);
@@ -555,8 +585,17 @@ __device__ __forceinline__ void run_segment(const JobCtx& c, const float2* __res
 #if GSH_MC_PACKED
     if (!WRAP && MODE == 0 && c.packed && c.n_total < (1 << 24))
         {
+#ifdef GSH_MC_NCH
+            constexpr int NCH = (NT <= 3 && !AUX) ? GSH_MC_NCH : 1;
+#else
             constexpr int NCH = (MC_THREADS <= 256) ? 2 : 1;
-            run_segment_packed<NT, ZP, AUX, NCH>(c, base, tab, sh, acc, acc_aux);
+#endif
+#ifdef GSH_MC_PREFETCH
+            constexpr int PF = GSH_MC_PREFETCH;
+#else
+            constexpr int PF = (MC_THREADS <= 256) ? GSH_MC_PREFETCH_BANK : GSH_MC_PREFETCH_LOOP;
+#endif
+            run_segment_packed<NT, ZP, AUX, NCH, PF>(c, base, tab, sh, acc, acc_aux);
             return;
         }
 #endif

@@ -17,7 +17,10 @@
 // 1024 threads per channel: a channel owns at most one compute unit and every period is a dependent step, so the
 // only way to hide the window's load latency is more waves on that unit (measured: 16.6 us per 25 000-sample period
 // with 256 threads)
-#define GSH_MC_THREADS 1024
+#ifndef GSH_TRK_THREADS
+#define GSH_TRK_THREADS 1024
+#endif
+#define GSH_MC_THREADS GSH_TRK_THREADS
 #include "mcorr_device.h"
 #include "sample_stream.h"
 #include <cmath>
@@ -447,6 +450,9 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
     for (int e = 0; e < a.n_epochs; e++)
         {
             if (!win.go) break;  // uniform: win is only rewritten between the barriers below
+#ifdef GSH_TRK_PROFILE
+            const long long t_begin = clock64();
+#endif
             const unsigned long long pos = win.pos;
             const unsigned long long wpos = a.ring_capacity ? pos % a.ring_capacity : pos;  // where the window sits in memory
             const float rem_carr = win.rem_carr, phase_step = win.phase_step, rem_code = win.rem_code, code_step = win.code_step;
@@ -495,6 +501,9 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
                     pdata = red[0];
                 }
             __syncthreads();  // win and red have been read by everyone
+#ifdef GSH_TRK_PROFILE
+            const long long t_corr_done = clock64();
+#endif
             if (tid == 0)
                 {
                     const double code_period = static_cast<double>(c.code_length_chips) / c.code_chip_rate;  // d_code_period
@@ -860,6 +869,13 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
                             r.code_error_filt_chips = code_error_filt_chips;
                             r.rem_code_phase_samples = s.rem_code_phase_samples;
                             r.acc_carrier_phase_rad = s.acc_carrier_phase_rad;
+#ifdef GSH_TRK_PROFILE
+                            if (NT == 3)  // phase durations in shader clocks, in the unused VE / VL slots
+                                {
+                                    r.corr[6] = static_cast<float>(t_corr_done - t_begin);
+                                    r.corr[7] = static_cast<float>(clock64() - t_corr_done);
+                                }
+#endif
                         }
                     s.pos = pos + static_cast<unsigned long long>(prn_len);  // consume_each, trk.cc:2287
                     publish(win, s, c, a.n_stream, e + 1 < a.n_epochs, a.ring_oldest);

@@ -1,0 +1,21 @@
+"""Phase timing of the closed-loop kernel (library built with -DGSH_TRK_PROFILE: GSH_LIB_PATH): shader clocks spent per period in the correlation
+(window load .. barrier) and in thread 0's loop arithmetic, from the records."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+import gnss_sdr_amd, oracle
+from gnss_sdr_amd.tracking_loop import TrackingLoop, trk_conf
+fs, n, E = 25e6, 25000, 200
+x = torch.view_as_complex(torch.randn((E + 3) * n, 2, device="cuda")).contiguous()
+for ch in (32,):
+    loop = TrackingLoop(trk_conf(fs_in=fs, vector_length=n, pll_bw_hz=35.0, dll_bw_hz=2.0), ch, 1023, device=0)
+    loop.set_stream_device(x.data_ptr(), x.numel(), keepalive=x)
+    rng = np.random.default_rng(1)
+    for c in range(ch):
+        loop.start(c, oracle.ca_code(c % 32 + 1), int(rng.integers(0, n)), 0, float(rng.uniform(-5000, 5000)))
+    ms = loop.time_run(E, reps=3)
+    rec, done = loop.run(E)
+    tc = np.array([[r.corr[6] for r in rr] for rr in rec]); ts = np.array([[r.corr[7] for r in rr] for rr in rec])
+    print("channels", ch, "us/epoch %.3f" % (ms * 1e3 / E), "correlation clocks avg %.0f  serial clocks avg %.0f  (clock64 units)" % (tc[:, 5:].mean(), ts[:, 5:].mean()))
+    loop.close()
