@@ -125,6 +125,37 @@ def test_chip_selection_bit_exact(gpu):
     b.close()
 
 
+def test_even_tap_counts_and_one_sided_shifts_on_a_windowed_code(gpu):
+    """Long codes (GPS L5: 10 230 chips) are staged as a per-segment window of the code whose length the host derives from the jobs'
+    REAL taps; jobs whose tap count is not 1 / 3 / 5 run in the next wider kernel with padded tap slots.  Tap sets sitting far to one side
+    of zero ({20, 21}, {-40 .. -38.5}, a lone tap at +30 in a batch of E/P/L jobs) must select exactly the oracle's chips -- a padded
+    slot at shift 0 would widen the device's window beyond what the host sized and turn a valid job into NaN."""
+    fs, n = 25e6, 25000
+    rng = np.random.default_rng(77)
+    codes = [(2 * rng.integers(0, 2, 10230) - 1).astype(np.int32) for _ in range(2)]
+    x = np.ones(2 * n + 7, np.complex64)
+    b = _bank(gpu, codes)
+    b.set_stream_host(x)
+    step = float(np.float32(10.23e6 / fs))
+    tapsets = [[20.0, 21.0], [-40.0, -39.5, -39.0, -38.5], [16.5, 17.0, 17.5, 18.0, 18.5, 19.0], [-30.0, -29.0, -28.0, -27.0, -26.0, -25.0, -24.0], [30.0], [-0.5, 0.0, 0.5]]
+    groups = [[ts] * 8 for ts in tapsets[:4]]                 # uniform batches: 2, 4, 6, 7 taps
+    groups.append([tapsets[4], tapsets[5]] * 6)               # a lone far tap among E/P/L jobs
+    groups.append([tapsets[0], tapsets[5], tapsets[1]] * 4)   # mixed
+    for group in groups:
+        jobs = [dict(sample_offset=int(rng.integers(0, n)), n_samples=n, code_slot=i % 2, shifts_chips=ts, rem_carr_phase_rad=0.0, phase_step_rad=0.0,
+                     rem_code_phase_chips=float(np.float32(rng.uniform(0, 1))), code_phase_step_chips=step) for i, ts in enumerate(group)]
+        out = b.correlate(jobs)
+        for j, job in enumerate(jobs):
+            sh = np.asarray(job["shifts_chips"], np.float32)
+            idx = oracle.code_indices(n, sh, job["rem_code_phase_chips"], step, 0.0, 10230, False)
+            expect = np.array([codes[job["code_slot"]][idx[t]].astype(np.float64).sum() for t in range(len(sh))])
+            got = out[j, :len(sh)]
+            assert np.all(np.isfinite(got.real)), (job, got)
+            assert np.array_equal(got.real.astype(np.float64), expect), (job, got, expect)
+            assert np.all(got.imag == 0)
+    b.close()
+
+
 def test_config2_tracking_parity(gpu):
     """BASELINE config 2 shape: GPS L1 C/A, fs = 25 Msps, N = 25 000, 3-tap E/P/L, 32 channels (PRN 1..32) reading
     windows of one shared stream with 8 embedded signals at 45 dB-Hz, a few epochs each."""
