@@ -31,6 +31,8 @@ struct gsh_acq
     float2* d_tmp{nullptr};       // chunk_prn * n_bins * n
     float* d_grid{nullptr};       // max_prn * n_bins * effective
     gsh::RowStat* d_rows{nullptr};
+    gsh::RowStat* d_subrows{nullptr};  // split plans (N = S * M): the sub-cells' records, S per (PRN, bin)
+    int split{0};
     gsh::DevAcqResult* d_results{nullptr};
     unsigned* d_arrivals{nullptr};          // on-chip path: per-PRN arrival counters, zero between launches
     gsh::DevAcqResult* h_results{nullptr};  // pinned
@@ -57,6 +59,7 @@ struct gsh_acq
     hipStream_t stream2{nullptr};
     float2* d_spectra2{nullptr};
     gsh::RowStat* d_rows2{nullptr};
+    gsh::RowStat* d_subrows2{nullptr};
     gsh::DevAcqResult* d_results2{nullptr};
     unsigned* d_arrivals2{nullptr};
     hipEvent_t ev2{nullptr};
@@ -117,8 +120,8 @@ int enqueue_dwell(gsh_acq* a, uint32_t n_prn, int accumulate, uint32_t dwell_cou
                 a->d_spectra, a->n_bins, a->stream, static_cast<int>(std::max(1u, c.fold)));
             if (rc != GSH_OK) return rc;
             // acq.cc:538-553 + the per-row part of :409-519: one work-group per (PRN, bin) cell, nothing leaves the CU
-            return gsh::onchip_correlate(n, a->d_spectra, a->d_codes, a->d_grid, a->d_rows, a->d_results, a->d_arrivals, static_cast<int>(n_prn),
-                a->n_bins, eff, accumulate, c.no_grid ? 0 : 1, static_cast<int>(c.samples_per_chip), c.use_cfar, dwell_count ? dwell_count : 1u,
+            return gsh::onchip_correlate(n, a->d_spectra, a->d_codes, a->d_grid, a->d_rows, a->d_subrows, a->d_results, a->d_arrivals, static_cast<int>(n_prn),
+                a->n_bins, c.bit_transition_flag ? eff : 0, eff, accumulate, c.no_grid ? 0 : 1, static_cast<int>(c.samples_per_chip), c.use_cfar, dwell_count ? dwell_count : 1u,
                 a->grid_weight, a->stream);
         }
     // acq.cc:657-664 (zero padding) + :531-535 (wipe-off, forward FFT) for every bin
@@ -355,8 +358,14 @@ extern "C"
         a->n_bins2 = static_cast<int>(c.num_doppler_bins_step2);
         a->h_bins2_hz.assign(static_cast<size_t>(a->n_bins2) * c.max_prn, 0.0f);
         a->code_set.assign(c.max_prn, 0);
-        // the on-chip kernels assume effective_fft_size == fft_size: bit_transition_flag searches go through the four-step path
-        a->onchip = (c.transform_path == 0) && !c.bit_transition_flag && gsh::onchip_supported(static_cast<int>(c.fft_size));
+        // one compute unit per transform when the length has a plan; S work-groups per transform for N = S * M (no peak-ratio statistic, no
+        // folding there); bit_transition_flag is an epilogue predicate of the same kernels
+        a->onchip = (c.transform_path == 0) && gsh::onchip_supported(static_cast<int>(c.fft_size));
+        if (!a->onchip && c.transform_path == 0 && c.use_cfar && c.fold <= 1 && gsh::onchip_split(static_cast<int>(c.fft_size)) > 0)
+            {
+                a->onchip = true;
+                a->split = gsh::onchip_split(static_cast<int>(c.fft_size));
+            }
         if (!a->onchip)
             {
                 rc = gsh::plan_create(static_cast<int>(c.fft_size), &a->plan);
@@ -411,6 +420,8 @@ extern "C"
                 if ((e = hipMemset(a->d_grid, 0, sizeof(float) * P * D * eff)) != hipSuccess) return fail(e, "hipMemset(grid)");
             }
         if ((e = hipMalloc(&a->d_rows, sizeof(gsh::RowStat) * P * D)) != hipSuccess) return fail(e, "hipMalloc(rows)");
+        if (a->split > 0 && (e = hipMalloc(&a->d_subrows, sizeof(gsh::RowStat) * P * std::max<size_t>(D, a->n_bins2) * a->split)) != hipSuccess)
+            return fail(e, "hipMalloc(subrows)");
         if ((e = hipMalloc(&a->d_results, sizeof(gsh::DevAcqResult) * P)) != hipSuccess) return fail(e, "hipMalloc(results)");
         if ((e = hipMalloc(&a->d_arrivals, sizeof(unsigned) * P)) != hipSuccess) return fail(e, "hipMalloc(arrivals)");
         if ((e = hipMemset(a->d_arrivals, 0, sizeof(unsigned) * P)) != hipSuccess) return fail(e, "hipMemset(arrivals)");
@@ -448,6 +459,8 @@ extern "C"
         if (a->d_tmp) (void)hipFree(a->d_tmp);
         if (a->d_grid) (void)hipFree(a->d_grid);
         if (a->d_rows) (void)hipFree(a->d_rows);
+        if (a->d_subrows) (void)hipFree(a->d_subrows);
+        if (a->d_subrows2) (void)hipFree(a->d_subrows2);
         if (a->d_results) (void)hipFree(a->d_results);
         if (a->d_arrivals) (void)hipFree(a->d_arrivals);
         if (a->h_results) (void)hipHostFree(a->h_results);
@@ -709,7 +722,8 @@ extern "C"
                             a->stream);
                         if (rc != GSH_OK) return rc;
                         rc = gsh::onchip_correlate(nfft, a->d_spectra, a->d_codes + static_cast<size_t>(slot) * nfft, grid, a->d_rows + static_cast<size_t>(i) * D2,
-                            a->d_results + i, a->d_arrivals + i, 1, D2, eff, accumulate, c.no_grid ? 0 : 1, static_cast<int>(c.samples_per_chip), c.use_cfar,
+                            a->d_subrows ? a->d_subrows + static_cast<size_t>(i) * D2 * a->split : nullptr,
+                            a->d_results + i, a->d_arrivals + i, 1, D2, c.bit_transition_flag ? eff : 0, eff, accumulate, c.no_grid ? 0 : 1, static_cast<int>(c.samples_per_chip), c.use_cfar,
                             dwell_count ? dwell_count : 1u, a->grid_weight, a->stream);
                     }
                 else
@@ -892,6 +906,7 @@ extern "C"
                 GSH_HIP(hipStreamCreateWithFlags(&a->stream2, hipStreamNonBlocking));
                 GSH_HIP(hipMalloc(&a->d_spectra2, sizeof(float2) * D * n));
                 GSH_HIP(hipMalloc(&a->d_rows2, sizeof(gsh::RowStat) * P * D));
+                if (a->split > 0) GSH_HIP(hipMalloc(&a->d_subrows2, sizeof(gsh::RowStat) * P * D * a->split));
                 GSH_HIP(hipMalloc(&a->d_results2, sizeof(gsh::DevAcqResult) * P));
                 GSH_HIP(hipMalloc(&a->d_arrivals2, sizeof(unsigned) * P));
                 GSH_HIP(hipMemset(a->d_arrivals2, 0, sizeof(unsigned) * P));
@@ -905,9 +920,9 @@ extern "C"
                 static_cast<double>(c.fs_in), spectra, a->n_bins, st);
             if (rc != GSH_OK) return rc;
             // no_grid handles only: two batches in flight must not share the magnitude grid
-            return gsh::onchip_correlate(static_cast<int>(n), spectra, a->d_codes, a->d_grid, lane ? a->d_rows2 : a->d_rows,
+            return gsh::onchip_correlate(static_cast<int>(n), spectra, a->d_codes, a->d_grid, lane ? a->d_rows2 : a->d_rows, lane ? a->d_subrows2 : a->d_subrows,
                 lane ? a->d_results2 : a->d_results, lane ? a->d_arrivals2 : a->d_arrivals, static_cast<int>(n_prn), a->n_bins,
-                static_cast<int>(c.effective_fft_size), 0, 0, static_cast<int>(c.samples_per_chip), c.use_cfar, 1u, 1.0f, st);
+                c.bit_transition_flag ? static_cast<int>(c.effective_fft_size) : 0, static_cast<int>(c.effective_fft_size), 0, 0, static_cast<int>(c.samples_per_chip), c.use_cfar, 1u, 1.0f, st);
         };
         int rc = enqueue(0);  // warm-up on both lanes
         if (rc == GSH_OK) rc = enqueue(1);

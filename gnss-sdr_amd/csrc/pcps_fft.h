@@ -78,13 +78,17 @@ int grid_statistics(const float* grid, RowStat* rows, DevAcqResult* results, int
 // ---- whole-transform-on-chip path (pcps_onchip.hip): lengths with a plan in fft_onchip.h -------------------
 // Spectra are in NATURAL order here (the four-step path above uses its permuted [k1][k2] layout).
 bool onchip_supported(int n);
+// N = S * M with M planned (GSH_OC_SPLIT_PLANS): S, or 0.  A cell is then S independent work-groups; no second-peak statistic, no folding.
+int onchip_split(int n);
 int onchip_forward(int n, const float2* src, size_t src_stride, int n_in, int place_off, const float* wipe_hz, double fs, float2* dst,
     int batch, hipStream_t s, int fold = 1);
 // one work-group per (PRN, bin) cell: spectrum product, inverse transform, |.|^2, row statistics, and (by the last cell
 // of each PRN, counted in `arrivals`, n_prn zero-initialised counters) the PRN's statistic into `results`; the grid is
 // read only when `accumulate` and written only when `store_grid`
-int onchip_correlate(int n, const float2* spectra, const float2* codes, float* grid, RowStat* rows, DevAcqResult* results,
-    unsigned* arrivals, int n_prn, int n_bins, int effective, int accumulate, int store_grid, int samples_per_chip, int use_cfar,
+// lags [offset, offset + effective) of the transform enter the search (offset + effective == n; offset != 0: bit_transition_flag);
+// subrows: n_prn * n_bins * onchip_split(n) records (split plans only, else nullptr)
+int onchip_correlate(int n, const float2* spectra, const float2* codes, float* grid, RowStat* rows, RowStat* subrows, DevAcqResult* results,
+    unsigned* arrivals, int n_prn, int n_bins, int offset, int effective, int accumulate, int store_grid, int samples_per_chip, int use_cfar,
     unsigned dwell_count, float weight, hipStream_t s);
 }  // namespace gsh
 #endif

@@ -14,6 +14,15 @@
 //
 // HBM traffic per cell is two N*8-byte reads that hit L2 / Infinity Cache (a bin's spectrum is shared by every PRN,
 // a code spectrum by every bin; the cell -> XCD mapping keeps both inside one XCD's L2) and one 16-byte record.
+//
+// Lengths beyond what one compute unit holds (N * 4 bytes of LDS, 1024 threads): N = S * M with M a planned length and S = 2, 4 or 8.
+// One decimation-in-frequency step of radix S in front of the planned transform makes the S output residues INDEPENDENT length-M
+// transforms:   y[S m + r] = FFT_M( a_r )[m],   a_r[n] = ( sum_q Y[n + q M] W_S^{q r} ) W_N^{n r},   0 <= n < M,
+// so a cell is S work-groups that never talk to each other (`sub-cells`: each reads the whole product spectrum, forms its own a_r in
+// registers and owns the lags tau = S m + r); their row records are merged by the PRN's last arriver.  50 000 = 2 x 25 000 (50 Msps x 1 ms,
+// and the bit-transition search at 25 Msps), 100 000 = 4 x 25 000, 128 000 = 8 x 16 000, 32 000 = 2 x 16 000 ...
+// bit_transition_flag (acq.cc:110-112, :544): only the lags [offset, offset + effective) of the transform enter the search, as index
+// tau - offset -- an epilogue predicate.
 #include "pcps_fft.h"
 #include "fft_onchip.h"
 #include <cmath>
@@ -36,6 +45,7 @@ struct OcFwdArgs
     double inv_fs;
     cf* dst;
     int fold;  // > 1: the wiped-off input is summed over `fold` segments of N samples (pcps_quicksync_acquisition_cc.cc:243-263)
+               // (S == 1 only)
 };
 
 struct OcCellArgs
@@ -44,11 +54,13 @@ struct OcCellArgs
     const cf* codes;    // n_prn * N, natural order, UNconjugated forward FFT of the placed code
     float* grid;        // n_prn * n_bins * effective (touched only when store_grid / accumulate)
     RowStat* rows;      // n_prn * n_bins
+    RowStat* subrows;   // S > 1: n_prn * n_bins * S records of the sub-cells, merged into `rows` by the PRN's last arriver
+    int offset;         // first lag of the transform that enters the search (bit_transition_flag: effective; else 0)
     DevAcqResult* results;   // n_prn
     unsigned* arrivals;      // n_prn arrival counters (zero between launches): the last cell of a PRN forms its statistic
     int n_prn, n_bins;
     int xp, prn_per, bin_per;  // XCD tiling: xp * (8 / xp) XCDs, each owns prn_per PRNs x bin_per bins
-    int effective, accumulate, store_grid;  // effective == N on this path
+    int effective, accumulate, store_grid;  // offset + effective <= N
     int samples_per_chip, want_second;
     int use_cfar;
     unsigned dwell_count;
@@ -150,6 +162,72 @@ __global__ __launch_bounds__(P::THREADS) void oc_forward_kernel(OcFwdArgs a)
         }
 }
 
+// ---- N = S * M: work-group (item, r) forms a_r on load and transforms it; X[S m + r] = FFT_M(a_r)[m]
+// exp(-2 pi i q r / S): exact for the quarter turns, correctly rounded for the eighths
+__device__ __forceinline__ cf radix_root(int qr, int s)
+{
+    return oc::unit_root(qr % s, s);
+}
+
+template <class P, int S>
+__global__ __launch_bounds__(P::THREADS) void oc_forward_split_kernel(OcFwdArgs a)
+{
+    __shared__ __align__(16) float lds[P::LDS_FLOATS];
+    constexpr int M = P::N, N = S * P::N;
+    const int t = threadIdx.x;
+    const int b = static_cast<int>(blockIdx.x) / S, r = static_cast<int>(blockIdx.x) - b * S;
+    cf ra[P::R1], rb[P::R2], rc[P::R3];
+    if (t < P::T1)
+        {
+            const cf* __restrict__ src = a.src + static_cast<size_t>(b) * a.src_stride;
+            const bool wipe = a.wipe_hz != nullptr;
+            const float f = wipe ? a.wipe_hz[b] : 0.0f;
+            // sum_q x[n + q M] w[n + q M] W_S^{q r}: the wipe-off of sample n + q M is w[n] * w[q M], the second factor uniform over the work-group
+            // (a rolled loop over q: unrolled, the scheduler hoists all S * R1 loads and spills)
+            oc::static_for<P::R1>([&](auto N1) GSH_AI {
+                constexpr int n1 = decltype(N1)::value;
+                const int k = n1 * P::T1 + t - a.place_off;
+                ra[n1] = (k >= 0 && k < a.n_in) ? src[k] : cf{0.0f, 0.0f};
+            });
+#pragma clang loop unroll(disable)
+            for (int q = 1; q < S; q++)
+                {
+                    cf cq = radix_root(q * r, S);
+                    if (wipe) cq = oc::cmul(cq, wipe_phasor(f, q * M, a.inv_fs));
+                    oc::static_for<P::R1>([&](auto N1) GSH_AI {
+                        constexpr int n1 = decltype(N1)::value;
+                        const int k = n1 * P::T1 + t + q * M - a.place_off;
+                        const cf v = (k >= 0 && k < a.n_in) ? src[k] : cf{0.0f, 0.0f};
+                        const cf u = oc::cmul(v, cq);
+                        ra[n1].x += u.x;
+                        ra[n1].y += u.y;
+                    });
+                }
+            // per-sample factor w[n] W_N^{n r}, n = n1 T1 + t: seed (t) and step (T1) of both combined before the power tree
+            cf seed = oc::unit_root((t * r) % N, N), step = oc::unit_root((P::T1 * r) % N, N);
+            if (wipe)
+                {
+                    seed = oc::cmul(seed, wipe_phasor(f, t, a.inv_fs));
+                    step = oc::cmul(step, wipe_phasor(f, P::T1, a.inv_fs));
+                }
+            if (wipe || r != 0)
+                {
+                    oc::mul_powers<P::R1>(ra, step);
+                    oc::static_for<P::R1>([&](auto N1) GSH_AI { ra[decltype(N1)::value] = oc::cmul(ra[decltype(N1)::value], seed); });
+                }
+            P::stage1(ra, t);
+        }
+    exchange1<P>(ra, rb, t, lds);
+    if (t < P::T2) P::stage2(rb, t);
+    exchange2<P>(rb, rc, t, lds);
+    if (t < P::T3)
+        {
+            P::stage3(rc);
+            cf* __restrict__ dst = a.dst + static_cast<size_t>(b) * N + static_cast<size_t>(t) * S + r;
+            oc::static_for<P::R3>([&](auto K3) GSH_AI { dst[static_cast<size_t>(decltype(K3)::value) * P::T3 * S] = rc[decltype(K3)::value]; });
+        }
+}
+
 // lowest index wins ties (K/volk_gnsssdr_32f_index_max_32u.h:457: strict '>' scanning upwards)
 __device__ __forceinline__ void argmax_merge(float& v, unsigned& i, float ov, unsigned oi)
 {
@@ -164,9 +242,12 @@ __device__ __forceinline__ void argmax_merge(float& v, unsigned& i, float ov, un
 // GRID: the magnitude grid is read (accumulate) and / or written (store_grid); SECOND: the peak-ratio statistic's
 // second peak is wanted.  Both are compile-time so that the headline configuration (CFAR statistic, single dwell,
 // no dump) carries neither the grid addressing nor the second scan in its register budget.
-template <class P, bool GRID, bool SECOND>
+template <class P, int S, bool GRID, bool SECOND, bool OFF>
 __global__ __launch_bounds__(P::THREADS) void oc_cell_kernel(OcCellArgs a)
 {
+    static_assert(S == 1 || !SECOND, "the second peak of a row needs the whole row in one work-group");
+    static_assert(GRID || !OFF, "the upper-half searches are instantiated on the GRID flavour only");
+    constexpr int M = P::N, N = S * P::N;
     __shared__ __align__(16) float lds[P::LDS_FLOATS];
     __shared__ float s_v[OC_MAX_WAVES];
     __shared__ unsigned s_i[OC_MAX_WAVES];
@@ -176,7 +257,9 @@ __global__ __launch_bounds__(P::THREADS) void oc_cell_kernel(OcCellArgs a)
 
     // ---- which cell: block b runs on XCD b % 8; each XCD owns a (PRN range) x (bin range) tile and walks it
     // PRN-fastest, so the cells in flight on one XCD share a few code spectra and a few bin spectra in its L2
-    const int xcd = static_cast<int>(blockIdx.x & 7u), slot = static_cast<int>(blockIdx.x >> 3);
+    // (S > 1: the S sub-cells of a cell follow each other on the same XCD -- they read the same two spectra)
+    const int xcd = static_cast<int>(blockIdx.x & 7u), slot_r = static_cast<int>(blockIdx.x >> 3);
+    const int slot = slot_r / S, r = slot_r - slot * S;
     const int xp_i = xcd % a.xp, xb_i = xcd / a.xp;
     const int bl = slot / a.prn_per, pl = slot - bl * a.prn_per;
     const int prn = xp_i * a.prn_per + pl, bin = xb_i * a.bin_per + bl;
@@ -187,22 +270,53 @@ __global__ __launch_bounds__(P::THREADS) void oc_cell_kernel(OcCellArgs a)
     cf ra[P::R1], rb[P::R2], rc[P::R3];
     if (t < P::T1)
         {
-            const cf* __restrict__ X = a.spectra + static_cast<size_t>(bin) * P::N + t;
-            const cf* __restrict__ C = a.codes + static_cast<size_t>(prn) * P::N + t;
-            // all 2 * R1 operand loads are issued before the first product: the cell's registers are still free here, and one round of
-            // L2 / Infinity-Cache latency is cheaper than the two the scheduler otherwise settles for (12 loads, wait, 38 loads)
-            cf xv[P::R1], cv[P::R1];
-            oc::static_for<P::R1>([&](auto N1) GSH_AI {
-                constexpr int n1 = decltype(N1)::value;
-                xv[n1] = X[n1 * P::T1];
-                cv[n1] = C[n1 * P::T1];
-            });
-            __builtin_amdgcn_sched_group_barrier(0x20, 2 * P::R1, 0);  // VMEM reads first ...
-            oc::static_for<P::R1>([&](auto N1) GSH_AI {
-                constexpr int n1 = decltype(N1)::value;
-                ra[n1] = oc::cmul_conj(xv[n1], cv[n1]);
-            });
-            __builtin_amdgcn_sched_group_barrier(0x2, 8 * P::R1, 0);   // ... then the products
+            const cf* __restrict__ X = a.spectra + static_cast<size_t>(bin) * N + t;
+            const cf* __restrict__ C = a.codes + static_cast<size_t>(prn) * N + t;
+            if constexpr (S == 1)
+                {
+                    // all 2 * R1 operand loads are issued before the first product: the cell's registers are still free here, and one round of
+                    // L2 / Infinity-Cache latency is cheaper than the two the scheduler otherwise settles for (12 loads, wait, 38 loads)
+                    cf xv[P::R1], cv[P::R1];
+                    oc::static_for<P::R1>([&](auto N1) GSH_AI {
+                        constexpr int n1 = decltype(N1)::value;
+                        xv[n1] = X[n1 * P::T1];
+                        cv[n1] = C[n1 * P::T1];
+                    });
+                    __builtin_amdgcn_sched_group_barrier(0x20, 2 * P::R1, 0);  // VMEM reads first ...
+                    oc::static_for<P::R1>([&](auto N1) GSH_AI {
+                        constexpr int n1 = decltype(N1)::value;
+                        ra[n1] = oc::cmul_conj(xv[n1], cv[n1]);
+                    });
+                    __builtin_amdgcn_sched_group_barrier(0x2, 8 * P::R1, 0);   // ... then the products
+                }
+            else
+                {
+                    // a_r[n] = ( sum_q Y[n + q M] W_S^{q r} ) W_N^{n r},  Y = conj(X) C
+                    // (q = 1 .. S-1 as a rolled loop: unrolled, the scheduler hoists all 2 S R1 loads and spills)
+                    oc::static_for<P::R1>([&](auto N1) GSH_AI {
+                        constexpr int n1 = decltype(N1)::value;
+                        ra[n1] = oc::cmul_conj(X[n1 * P::T1], C[n1 * P::T1]);
+                    });
+#pragma clang loop unroll(disable)
+                    for (int q = 1; q < S; q++)
+                        {
+                            const cf cq = radix_root(q * r, S);
+                            const cf* __restrict__ Xq = X + static_cast<size_t>(q) * M;
+                            const cf* __restrict__ Cq = C + static_cast<size_t>(q) * M;
+                            oc::static_for<P::R1>([&](auto N1) GSH_AI {
+                                constexpr int n1 = decltype(N1)::value;
+                                const cf u = oc::cmul(oc::cmul_conj(Xq[n1 * P::T1], Cq[n1 * P::T1]), cq);
+                                ra[n1].x += u.x;
+                                ra[n1].y += u.y;
+                            });
+                        }
+                    if (r != 0)  // uniform over the work-group
+                        {
+                            oc::mul_powers<P::R1>(ra, oc::unit_root((P::T1 * r) % N, N));
+                            const cf seed = oc::unit_root((t * r) % N, N);
+                            oc::static_for<P::R1>([&](auto N1) GSH_AI { ra[decltype(N1)::value] = oc::cmul(ra[decltype(N1)::value], seed); });
+                        }
+                }
             P::stage1(ra, t);
         }
     exchange1<P>(ra, rb, t, lds);
@@ -210,34 +324,62 @@ __global__ __launch_bounds__(P::THREADS) void oc_cell_kernel(OcCellArgs a)
     exchange2<P>(rb, rc, t, lds);
 
     // ---- |.|^2, optional accumulation / grid store, per-thread (max, lowest arg-max, sum)
+    // element k3 of thread t is lag tau = S (t + T3 k3) + r of the length-N correlation; it enters the search as index tau - offset when
+    // tau >= offset (offset + effective == N; offset != 0 only for bit_transition_flag, acq.cc:544)
     float best = -1.0f, sum = 0.0f;
     unsigned at = 0xFFFFFFFFu;
     if (t < P::T3)
         {
             P::stage3(rc);
             float* __restrict__ g = a.grid + static_cast<size_t>(cell) * a.effective;
-            // effective == N and no offset on this path (bit_transition_flag goes through the four-step kernels)
-            if (GRID)
-                {
-                    oc::static_for<P::R3>([&](auto K3) GSH_AI {
-                        constexpr int k3 = decltype(K3)::value;
-                        rc[k3].x = oc::norm2(rc[k3]) * a.weight;
-                    });
-                    if (a.accumulate)  // acq.cc:549-553
-                        oc::static_for<P::R3>([&](auto K3) GSH_AI { rc[decltype(K3)::value].x += g[t + P::T3 * decltype(K3)::value]; });
-                    if (a.store_grid)
-                        oc::static_for<P::R3>([&](auto K3) GSH_AI { g[t + P::T3 * decltype(K3)::value] = rc[decltype(K3)::value].x; });
-                }
-            oc::static_for<P::R3>([&](auto K3) GSH_AI {
-                constexpr int k3 = decltype(K3)::value;
-                const float m = GRID ? rc[k3].x : oc::norm2(rc[k3]);
-                // branch-free bookkeeping (selects): k3 ascending = tau ascending, so '>' keeps the lowest index
-                sum += m;
-                const bool better = m > best;
-                best = better ? m : best;
-                at = better ? static_cast<unsigned>(t + P::T3 * k3) : at;
-                if (SECOND && !GRID) rc[k3].x = m;  // kept (in place) for the second scan
-            });
+            {
+                // OFF: offset == N / 2 == S T3 R3 / 2.  Element k3 is valid for k3 > K0, invalid for k3 < K0, and element K0 is valid for every
+                // thread when R3 is even (K0 = R3 / 2) or for the threads with 2 (S t + r) >= S T3 when R3 is odd (K0 = (R3 - 1) / 2)
+                constexpr int K0 = OFF ? P::R3 / 2 : 0;
+                constexpr bool MIXED = OFF && (P::R3 % 2 == 1);
+                const bool edge_ok = !MIXED || (2 * (S * t + r) >= S * P::T3);
+                const int base = S * t + r - (OFF ? a.offset : 0);  // index of element k3 = base + S T3 k3
+                if (GRID)
+                    {
+                        oc::static_for<P::R3>([&](auto K3) GSH_AI {
+                            constexpr int k3 = decltype(K3)::value;
+                            if constexpr (k3 >= K0) rc[k3].x = oc::norm2(rc[k3]) * a.weight;
+                        });
+                        if (a.accumulate)  // acq.cc:549-553
+                            oc::static_for<P::R3>([&](auto K3) GSH_AI {
+                                constexpr int k3 = decltype(K3)::value;
+                                if constexpr (k3 > K0 || (k3 == K0 && !MIXED)) rc[k3].x += g[base + S * P::T3 * k3];
+                                if constexpr (k3 == K0 && MIXED)
+                                    if (edge_ok) rc[k3].x += g[base + S * P::T3 * k3];
+                            });
+                        if (a.store_grid)
+                            oc::static_for<P::R3>([&](auto K3) GSH_AI {
+                                constexpr int k3 = decltype(K3)::value;
+                                if constexpr (k3 > K0 || (k3 == K0 && !MIXED)) g[base + S * P::T3 * k3] = rc[k3].x;
+                                if constexpr (k3 == K0 && MIXED)
+                                    if (edge_ok) g[base + S * P::T3 * k3] = rc[k3].x;
+                            });
+                    }
+                oc::static_for<P::R3>([&](auto K3) GSH_AI {
+                    constexpr int k3 = decltype(K3)::value;
+                    if constexpr (k3 >= K0)
+                        {
+                            float m = GRID ? rc[k3].x : oc::norm2(rc[k3]);
+                            if constexpr (k3 == K0 && MIXED) m = edge_ok ? m : -1.0f;  // never better than `best`
+                            // branch-free bookkeeping (selects): k3 ascending = index ascending, so '>' keeps the lowest index
+                            if constexpr (k3 == K0 && MIXED)
+                                sum += edge_ok ? m : 0.0f;
+                            else
+                                sum += m;
+                            const bool better = m > best;
+                            best = better ? m : best;
+                            at = better ? static_cast<unsigned>(base + S * P::T3 * k3) : at;
+                            if (SECOND) rc[k3].x = m;  // kept (in place) for the second scan
+                        }
+                    else if (SECOND)
+                        rc[k3].x = -1.0f;  // lags below the offset: never the second peak either
+                });
+            }
         }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1)
@@ -286,7 +428,7 @@ __global__ __launch_bounds__(P::THREADS) void oc_cell_kernel(OcCellArgs a)
                 {
                     oc::static_for<P::R3>([&](auto K3) GSH_AI {
                         constexpr int k3 = decltype(K3)::value;
-                        const int tau = t + P::T3 * k3;
+                        const int tau = t + P::T3 * k3 - a.offset;   // S == 1 here; lags below the offset hold -1 and never win against 0.0
                         const bool ge1 = tau >= e1, lt2 = tau < e2;
                         const bool blank = blank_all | (wraps ? (ge1 | lt2) : (ge1 & lt2));
                         second = blank ? second : fmaxf(second, rc[k3].x);
@@ -305,17 +447,20 @@ __global__ __launch_bounds__(P::THREADS) void oc_cell_kernel(OcCellArgs a)
     // Placement-independent hand-off: plain store -> agent-scope release -> relaxed ticket; the last arriver acquires.
     if (t == 0)
         {
-            RowStat r;
-            r.maxv = s_peak;
-            r.idx = s_tau;
-            r.sum = sum;
-            r.second = second;
-            a.rows[cell] = r;
+            RowStat rec;
+            rec.maxv = s_peak;
+            rec.idx = s_tau;
+            rec.sum = sum;
+            rec.second = second;
+            if constexpr (S == 1)
+                a.rows[cell] = rec;
+            else
+                a.subrows[static_cast<size_t>(cell) * S + r] = rec;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const unsigned ticket = __hip_atomic_fetch_add(&a.arrivals[prn], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_i[0] = (ticket == static_cast<unsigned>(a.n_bins) - 1u) ? 1u : 0u;
+            s_i[0] = (ticket == static_cast<unsigned>(a.n_bins * S) - 1u) ? 1u : 0u;
         }
     __syncthreads();
     if (s_i[0] == 0u || t >= 64) return;
@@ -323,17 +468,36 @@ __global__ __launch_bounds__(P::THREADS) void oc_cell_kernel(OcCellArgs a)
     {
         // bin scan of acq.cc:417-426 / :463-474 over one wave: gmax starts at 0 and only a strictly larger row
         // maximum replaces it, so ties keep the lowest bin
-        const RowStat* __restrict__ rs = a.rows + static_cast<size_t>(prn) * a.n_bins;
+        RowStat* rs = a.rows + static_cast<size_t>(prn) * a.n_bins;
+        // S > 1: a row is the union of its S sub-cells' lags -- maximum with the lowest index among equals, sums added; the merged record is
+        // also what gsh_acq_read_row_peaks hands out
+        auto row_of = [&](int d) GSH_AI -> RowStat {
+            if constexpr (S == 1)
+                return rs[d];
+            else
+                {
+                    const RowStat* __restrict__ sub = a.subrows + (static_cast<size_t>(prn) * a.n_bins + d) * S;
+                    RowStat m = sub[0];
+                    for (int q = 1; q < S; q++)
+                        {
+                            const RowStat o = sub[q];
+                            argmax_merge(m.maxv, m.idx, o.maxv, o.idx);
+                            m.sum += o.sum;
+                        }
+                    return m;
+                }
+        };
         float gmax = 0.0f;
         unsigned gbin = 0xFFFFFFFFu, gtau = 0u;
         for (int d = t; d < a.n_bins; d += 64)
             {
-                const RowStat r = rs[d];
-                if (r.maxv > gmax)
+                const RowStat rw = row_of(d);
+                if constexpr (S > 1) rs[d] = rw;
+                if (rw.maxv > gmax)
                     {
-                        gmax = r.maxv;
+                        gmax = rw.maxv;
                         gbin = static_cast<unsigned>(d);
-                        gtau = r.idx;
+                        gtau = rw.idx;
                     }
             }
 #pragma unroll
@@ -367,15 +531,16 @@ __global__ __launch_bounds__(P::THREADS) void oc_cell_kernel(OcCellArgs a)
                     {
                         // acq.cc:429-431: power of the bin half a grid away, / effective / 2 / dwells
                         const unsigned opp = (gbin + static_cast<unsigned>(a.n_bins) / 2u) % static_cast<unsigned>(a.n_bins);
-                        const float per_sample = rs[opp].sum / static_cast<float>(static_cast<unsigned>(a.effective));
+                        const float per_sample = row_of(static_cast<int>(opp)).sum / static_cast<float>(static_cast<unsigned>(a.effective));
                         const float power = static_cast<float>(static_cast<double>(per_sample) / 2.0 / static_cast<double>(a.dwell_count));
                         out.input_power = power;
                         out.test_statistics = (power < 1.1920928955078125e-07f) ? 0.0f : gmax / power;  // acq.cc:438-445
                     }
                 else
                     {
-                        out.second_peak = rs[gbin].second;
-                        out.test_statistics = gmax / rs[gbin].second;  // acq.cc:516
+                        const float second_pk = row_of(static_cast<int>(gbin)).second;
+                        out.second_peak = second_pk;
+                        out.test_statistics = gmax / second_pk;  // acq.cc:516
                     }
                 a.results[prn] = out;
                 __hip_atomic_store(&a.arrivals[prn], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
@@ -391,18 +556,46 @@ int launch_forward(const OcFwdArgs& a, int batch, hipStream_t s)
     return GSH_OK;
 }
 
-template <class P>
+template <class P, int S>
+int launch_forward_split(const OcFwdArgs& a, int batch, hipStream_t s)
+{
+    GSH_REQUIRE(a.fold <= 1, "folded searches have no split plan");
+    hipLaunchKernelGGL((oc_forward_split_kernel<P, S>), dim3(batch * S), dim3(P::THREADS), 0, s, a);
+    GSH_HIP(hipGetLastError());
+    return GSH_OK;
+}
+
+template <class P, int S>
 int launch_cells(const OcCellArgs& a, int n_blocks, hipStream_t s)
 {
     const bool grid = a.accumulate || a.store_grid;
-    if (grid && a.want_second)
-        hipLaunchKernelGGL((oc_cell_kernel<P, true, true>), dim3(n_blocks), dim3(P::THREADS), 0, s, a);
-    else if (grid)
-        hipLaunchKernelGGL((oc_cell_kernel<P, true, false>), dim3(n_blocks), dim3(P::THREADS), 0, s, a);
-    else if (a.want_second)
-        hipLaunchKernelGGL((oc_cell_kernel<P, false, true>), dim3(n_blocks), dim3(P::THREADS), 0, s, a);
+    const bool off = a.offset != 0;  // the upper-half (bit_transition_flag) searches run the GRID flavour whether or not a grid is kept
+    if constexpr (S == 1)
+        {
+            if (off && a.want_second)
+                hipLaunchKernelGGL((oc_cell_kernel<P, 1, true, true, true>), dim3(n_blocks), dim3(P::THREADS), 0, s, a);
+            else if (off)
+                hipLaunchKernelGGL((oc_cell_kernel<P, 1, true, false, true>), dim3(n_blocks), dim3(P::THREADS), 0, s, a);
+            else if (grid && a.want_second)
+                hipLaunchKernelGGL((oc_cell_kernel<P, 1, true, true, false>), dim3(n_blocks), dim3(P::THREADS), 0, s, a);
+            else if (grid)
+                hipLaunchKernelGGL((oc_cell_kernel<P, 1, true, false, false>), dim3(n_blocks), dim3(P::THREADS), 0, s, a);
+            else if (a.want_second)
+                hipLaunchKernelGGL((oc_cell_kernel<P, 1, false, true, false>), dim3(n_blocks), dim3(P::THREADS), 0, s, a);
+            else
+                hipLaunchKernelGGL((oc_cell_kernel<P, 1, false, false, false>), dim3(n_blocks), dim3(P::THREADS), 0, s, a);
+        }
     else
-        hipLaunchKernelGGL((oc_cell_kernel<P, false, false>), dim3(n_blocks), dim3(P::THREADS), 0, s, a);
+        {
+            GSH_REQUIRE(!a.want_second, "the peak-ratio statistic has no split plan");
+            GSH_REQUIRE(a.subrows != nullptr, "split plan without sub-cell records");
+            if (off)
+                hipLaunchKernelGGL((oc_cell_kernel<P, S, true, false, true>), dim3(n_blocks), dim3(P::THREADS), 0, s, a);
+            else if (grid)
+                hipLaunchKernelGGL((oc_cell_kernel<P, S, true, false, false>), dim3(n_blocks), dim3(P::THREADS), 0, s, a);
+            else
+                hipLaunchKernelGGL((oc_cell_kernel<P, S, false, false, false>), dim3(n_blocks), dim3(P::THREADS), 0, s, a);
+        }
     GSH_HIP(hipGetLastError());
     return GSH_OK;
 }
@@ -415,6 +608,15 @@ bool onchip_supported(int n)
     GSH_OC_PLANS(GSH_OC_CASE)
 #undef GSH_OC_CASE
     return false;
+}
+
+int onchip_split(int n)
+{
+#define GSH_OC_CASE(sp, r1, r2, r3) \
+    if (n == (sp) * (r1) * (r2) * (r3)) return sp;
+    GSH_OC_SPLIT_PLANS(GSH_OC_CASE)
+#undef GSH_OC_CASE
+    return 0;
 }
 
 int onchip_forward(int n, const float2* src, size_t src_stride, int n_in, int place_off, const float* wipe_hz, double fs, float2* dst,
@@ -434,20 +636,26 @@ int onchip_forward(int n, const float2* src, size_t src_stride, int n_in, int pl
     if (n == (r1) * (r2) * (r3)) return launch_forward<oc::Plan<r1, r2, r3>>(a, batch, s);
     GSH_OC_PLANS(GSH_OC_CASE)
 #undef GSH_OC_CASE
+#define GSH_OC_CASE(sp, r1, r2, r3) \
+    if (n == (sp) * (r1) * (r2) * (r3)) return launch_forward_split<oc::Plan<r1, r2, r3>, sp>(a, batch, s);
+    GSH_OC_SPLIT_PLANS(GSH_OC_CASE)
+#undef GSH_OC_CASE
     return set_error(GSH_ERR_UNSUPPORTED, "no on-chip plan for fft_size %d", n);
 }
 
-int onchip_correlate(int n, const float2* spectra, const float2* codes, float* grid, RowStat* rows, DevAcqResult* results,
-    unsigned* arrivals, int n_prn, int n_bins, int effective, int accumulate, int store_grid, int samples_per_chip, int use_cfar,
+int onchip_correlate(int n, const float2* spectra, const float2* codes, float* grid, RowStat* rows, RowStat* subrows, DevAcqResult* results,
+    unsigned* arrivals, int n_prn, int n_bins, int offset, int effective, int accumulate, int store_grid, int samples_per_chip, int use_cfar,
     unsigned dwell_count, float weight, hipStream_t s)
 {
     if (n_prn <= 0 || n_bins <= 0) return GSH_OK;
-    GSH_REQUIRE(effective == n, "the on-chip path needs effective_fft_size == fft_size");
+    GSH_REQUIRE((offset == 0 && effective == n) || (2 * offset == n && effective == offset), "lags [%d, %d + %d) of a %d-point transform: neither all of it nor its upper half", offset, offset, effective, n);
     OcCellArgs a;
     a.spectra = reinterpret_cast<const cf*>(spectra);
     a.codes = reinterpret_cast<const cf*>(codes);
     a.grid = grid;
     a.rows = rows;
+    a.subrows = subrows;
+    a.offset = offset;
     a.results = results;
     a.arrivals = arrivals;
     a.n_prn = n_prn;
@@ -468,8 +676,12 @@ int onchip_correlate(int n, const float2* spectra, const float2* codes, float* g
     a.weight = weight;
     const int n_blocks = 8 * a.prn_per * a.bin_per;
 #define GSH_OC_CASE(r1, r2, r3) \
-    if (n == (r1) * (r2) * (r3)) return launch_cells<oc::Plan<r1, r2, r3>>(a, n_blocks, s);
+    if (n == (r1) * (r2) * (r3)) return launch_cells<oc::Plan<r1, r2, r3>, 1>(a, n_blocks, s);
     GSH_OC_PLANS(GSH_OC_CASE)
+#undef GSH_OC_CASE
+#define GSH_OC_CASE(sp, r1, r2, r3) \
+    if (n == (sp) * (r1) * (r2) * (r3)) return launch_cells<oc::Plan<r1, r2, r3>, sp>(a, n_blocks * (sp), s);
+    GSH_OC_SPLIT_PLANS(GSH_OC_CASE)
 #undef GSH_OC_CASE
     return set_error(GSH_ERR_UNSUPPORTED, "no on-chip plan for fft_size %d", n);
 }

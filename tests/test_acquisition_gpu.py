@@ -49,12 +49,18 @@ def _same_peak(res, ora, prec, tag):
                                               (6250, 6250, 6250000, False), (4092, 4092, 4092000, False), (8184, 8184, 8184000, False),
                                               (5456, 5456, 5456000, False), (2560, 2560, 2560000, False), (10240, 10240, 10240000, False),
                                               (6625, 6625, 6625000, False), (26500, 26500, 26500000, False),
-                                              (9937, 9937, 9937000, False), (4007, 4007, 4007000, False)])   # 19 * 523 and a prime: zero-padded fallback
+                                              (9937, 9937, 9937000, False), (4007, 4007, 4007000, False),   # 19 * 523 and a prime: zero-padded fallback
+                                              # bit_transition_flag on the on-chip kernels: R3 even (20,20,20), R3 odd (20,20,25), (22,24,31), split S = 2
+                                              (10000, 10000, 5000000, True), (16368, 16368, 8184000, True), (50000, 50000, 25000000, True),
+                                              # split plans N = S * M (GSH_OC_SPLIT_PLANS): S = 2, 4, 8
+                                              (50000, 50000, 50000000, False), (32000, 32000, 32000000, False), (32736, 32736, 32736000, False),
+                                              (100000, 50000, 50000000, False), (128000, 128000, 32000000, False)])
 def test_grid_matches_oracle(gpu, n, consumed, fs, bt):
     """FFT sizes with radix-2/3/4/5/8 and generic (11, 31) passes; bit_transition_flag (acq.cc:230-235) and
     fft_size = 2*consumed (sampled_ms != ms_per_code, acq.cc:111,243-247) paddings.  Every length with an on-chip plan
-    (GSH_OC_PLANS in csrc/fft_onchip.h) goes through the whole-transform-on-chip kernels, the others (2046, 16368, the
-    bit-transition case) through the four-step kernels."""
+    (GSH_OC_PLANS / GSH_OC_SPLIT_PLANS in csrc/fft_onchip.h) goes through the whole-transform-on-chip kernels -- bit_transition_flag
+    included (upper half of the lags, acq.cc:544) --, the others (6625, 26500, the zero-padded ones, and the peak-ratio statistic at
+    split lengths) through the four-step kernels."""
     rng = np.random.default_rng(n)
     spms = fs // 1000
     prn = 7
@@ -73,11 +79,18 @@ def test_grid_matches_oracle(gpu, n, consumed, fs, bt):
         prec.set_local_code(code)
         res = acq.dwell(x, 1)[0]
         exp = ora.dwell(x)
-        prec.dwell(x)
+        exp64 = prec.dwell(x)
+        long_block = consumed > 100000
+        if long_block:
+            # the reference's wipe-off table accumulates its phase in float32 (volk_gnsssdr_s32f_sincos_32fc, bit-exact in the oracle): over 128 000
+            # samples it has drifted far enough from the true phase to cost the float32 oracle 3 % of its peak (measured), the engine's phasor is
+            # exact -- so beyond 100 000 samples the values are held to the float64 evaluation only
+            exp = exp64
         _same_peak(res, exp, prec, f"n={n}")
         g = acq.read_grid(0)
         scale = float(exp["peak"])
-        assert np.max(np.abs(g - ora.grid)) <= RTOL_GRID * scale, (n, np.max(np.abs(g - ora.grid)) / scale)
+        if not long_block:
+            assert np.max(np.abs(g - ora.grid)) <= RTOL_GRID * scale, (n, np.max(np.abs(g - ora.grid)) / scale)
         # tighter against the float64 evaluation: our wipe-off phase is exact, the reference's drifts
         assert np.max(np.abs(g - prec.grid)) <= 2e-4 * scale, (n, np.max(np.abs(g - prec.grid)) / scale)
         assert res["doppler_hz"] == exp["doppler_hz"]
@@ -257,6 +270,58 @@ def test_onchip_agrees_with_fourstep_and_nogrid_rules(gpu, n, fs):
             banks["nogrid"].read_grid(0)
         for acq in banks.values():
             acq.close()
+
+
+@pytest.mark.parametrize("n,fs,bt", [(50000, 50000000, False), (50000, 25000000, True), (32000, 32000000, False), (65536, 65536000, False),
+                                     (100000, 50000000, False), (80000, 40000000, False), (128000, 64000000, False), (200000, 50000000, False)])
+def test_split_plans_agree_with_fourstep(gpu, n, fs, bt):
+    """N = S * M: a cell is S independent work-groups (one radix-S decimation-in-frequency step in front of the plan of M, csrc/pcps_onchip.hip).
+    Against the four-step kernels -- an independent factorisation of the same dwell: identical decisions and indices for 3 PRNs x 21 bins (two
+    with a signal, one without), values within float32 FFT rounding, two non-coherent dwells on the stored grid, and the no-grid flavour equal to the
+    grid-keeping one."""
+    spc = int(np.ceil(fs / 1.023e6))
+    consumed = n
+    x = synth_gps_l1_stream(2 * consumed, fs, [5, 9], [-3300.0, 1875.0], [100.25, 871.5], cn0_dbhz=46.0, seed_noise=n + 3)
+    kw = dict(fs_in=fs, fft_size=n, consumed_samples=consumed, doppler_max=2500, doppler_step=250, samples_per_chip=spc, samples_per_code=float(fs // 1000),
+              max_prn=3, use_cfar=True, bit_transition_flag=bt)
+    codes = []
+    for p in (5, 9, 20):
+        c1 = oracle.ca_code_complex_sampled(p, fs)
+        codes.append(c1 if bt else np.tile(c1, (consumed + len(c1) - 1) // len(c1))[:consumed])
+    banks = {name: _bank(gpu, **kw, **bk) for name, bk in (("onchip", dict()), ("nogrid", dict(keep_grid=False)), ("fourstep", dict(transform_path=1)))}
+    out = {}
+    for name, acq in banks.items():
+        for i, c in enumerate(codes):
+            acq.set_local_code(i, c)
+        out[name] = acq.dwell(x[:consumed], 3)
+    eff = n // 2 if bt else n
+    per = fs // 1000   # blocks of several code periods have that many equal peaks, one period apart: which one ranks first is rounding noise
+    key = lambda r: (r["index_time"] % per, r["index_doppler"])
+    for i in range(3):
+        a, b, c = out["onchip"][i], out["fourstep"][i], out["nogrid"][i]
+        assert a["index_time"] < eff
+        if i < 2:
+            assert key(a) == key(b), (i, a, b)
+        assert (a["index_time"], a["index_doppler"]) == (c["index_time"], c["index_doppler"]), (i, a, c)
+        for k in ("peak", "test_statistics", "input_power"):
+            if i < 2:
+                assert a[k] == pytest.approx(b[k], rel=3e-4), (i, k, a, b)
+            assert a[k] == pytest.approx(c[k], rel=1e-5), (i, k, a, c)
+    g_on, g_fs = banks["onchip"].read_grid(1), banks["fourstep"].read_grid(1)
+    assert g_on.shape == g_fs.shape and g_on.shape[-1] == eff
+    assert np.max(np.abs(g_on - g_fs)) <= 2e-4 * out["onchip"][1]["peak"]
+    # the row records the detector cores read (gsh_acq_read_row_peaks) are the merged ones
+    pk, ix = banks["onchip"].read_row_peaks(0)
+    g0 = banks["onchip"].read_grid(0)
+    assert np.array_equal(pk, g0.max(axis=-1)) and np.array_equal(ix, np.argmax(g0, axis=-1))   # np.argmax: lowest index among equals, as the reference
+    r_on = banks["onchip"].dwell(x[consumed:], 3, accumulate=True, dwell_count=2)
+    r_fs = banks["fourstep"].dwell(x[consumed:], 3, accumulate=True, dwell_count=2)
+    for i in range(2):
+        assert key(r_on[i]) == key(r_fs[i])
+        assert r_on[i]["test_statistics"] == pytest.approx(r_fs[i]["test_statistics"], rel=3e-4)
+    assert np.max(np.abs(banks["onchip"].read_grid(0) - banks["fourstep"].read_grid(0))) <= 2e-4 * r_on[0]["peak"]
+    for acq in banks.values():
+        acq.close()
 
 
 @pytest.mark.parametrize("path", [0, 1])
