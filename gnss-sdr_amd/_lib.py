@@ -202,6 +202,7 @@ SYMBOLS = {
     "gsh_acq_dwell_resident": (C.c_int, [_P, C.c_uint32, C.c_int, C.c_uint32, C.POINTER(AcqResult)]),
     "gsh_acq_time_correlate": (C.c_int, [_P, C.POINTER(C.c_float), C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_float)]),
     "gsh_acq_read_row_peaks": (C.c_int, [_P, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]),
+    "gsh_acq_noncoherent_pair_peaks": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "gsh_acq_dwell": (C.c_int, [_P, _F, C.c_uint32, C.c_int, C.c_uint32, C.POINTER(AcqResult)]),
     "gsh_acq_dwell_device": (C.c_int, [_P, _P, C.c_uint32, C.c_int, C.c_uint32, C.POINTER(AcqResult)]),
     "gsh_acq_dwell_step2": (C.c_int, [_P, _F, C.c_uint32, C.POINTER(C.c_uint32), _F, _F, C.c_int, C.c_uint32, C.POINTER(AcqResult)]),

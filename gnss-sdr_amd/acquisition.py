@@ -132,6 +132,15 @@ class PcpsAcquisitionBank:
         check(self._lib.gsh_acq_read_row_peaks(self._h, prn_slot, fptr(pk), ix.ctypes.data_as(C.POINTER(C.c_uint32))))
         return pk, ix
 
+    PAIR_PEAK = np.dtype([("peak", np.float32), ("index_time", np.uint32), ("caf_i", np.float32), ("caf_q", np.float32), ("i_slot", np.uint32), ("q_slot", np.uint32)])
+
+    def noncoherent_pair_peaks(self, slot_ia: int, slot_qa: int = -1, slot_ib: int = -1, slot_qb: int = -1) -> np.ndarray:
+        """gsh_acq_noncoherent_pair_peaks after a dwell: per Doppler bin the maximum of the SUM of the kept data and pilot magnitude rows
+        (galileo_e5a_noncoherent_iq_acquisition_caf_cc.cc:357-492), added on the device.  Structured array, one record per bin."""
+        out = np.zeros(self.num_doppler_bins, self.PAIR_PEAK)
+        check(self._lib.gsh_acq_noncoherent_pair_peaks(self._h, slot_ia, slot_qa, slot_ib, slot_qb, out.ctypes.data))
+        return out
+
     def dwell(self, x: np.ndarray, n_prn: int, accumulate: bool = False, dwell_count: int = 1):
         """One acquisition_core pass over x[:consumed_samples] for prn slots 0..n_prn-1.  Returns a list of dicts."""
         x = np.ascontiguousarray(x, np.complex64)

@@ -31,6 +31,7 @@ struct gsh_acq
     float2* d_tmp{nullptr};       // chunk_prn * n_bins * n
     float* d_grid{nullptr};       // max_prn * n_bins * effective
     gsh::RowStat* d_rows{nullptr};
+    gsh_acq_pair_peak* d_pair{nullptr};  // gsh_acq_noncoherent_pair_peaks: one record per bin
     gsh::RowStat* d_subrows{nullptr};  // split plans (N = S * M): the sub-cells' records, S per (PRN, bin)
     int split{0};
     gsh::DevAcqResult* d_results{nullptr};
@@ -185,6 +186,114 @@ __global__ __launch_bounds__(1024) void time_correlate_kernel(const float2* __re
                     ti += pi[w];
                 }
             out[blockIdx.x] = make_float2(static_cast<float>(tr), static_cast<float>(ti));
+        }
+}
+
+// Non-coherent combination of the magnitude rows of two code slots before the arg-max, per Doppler bin
+// (galileo_e5a_noncoherent_iq_acquisition_caf_cc.cc:357-492).  The block correlates up to four local codes per bin -- data (I) and pilot (Q)
+// component, each as (1,1,1) "A" and with the first code period inverted "B" --, keeps for each component the combination whose row maximum
+// is larger (:403, :410, magt = max / N^4 compared with >=), ADDS the two kept magnitude rows cell by cell (:419-431) and takes the
+// arg-max of the sum (:487-492).  One work-group per bin: thread 0 repeats the block's choice from the row records of the dwell that just
+// ran, all threads add and scan the two rows.  As written in the reference, the Q-B candidate is ranked by the I-B row read at Q-B's
+// arg-max (:393 `magt_QB = d_magnitudeIB[indext_QB] / ...`); that is reproduced.
+struct PairPeakArgs
+{
+    const float* grid;           // [slot][bin][n]
+    const gsh::RowStat* rows;    // [slot][bin]
+    int n, n_bins;
+    int ia, qa, ib, qb;          // slots; qa / ib / qb may be -1
+    float divisor;               // (N^2)^2 as the block forms it in float (:327, :369)
+    gsh_acq_pair_peak* out;      // [bin]
+};
+
+__global__ __launch_bounds__(1024) void pair_peaks_kernel(PairPeakArgs a)
+{
+    __shared__ int s_sel[2];
+    __shared__ float s_v[16];
+    __shared__ unsigned s_i[16];
+    const int d = blockIdx.x, t = threadIdx.x;
+    const size_t row = static_cast<size_t>(a.n);
+    auto rec = [&](int slot) -> gsh::RowStat { return a.rows[static_cast<size_t>(slot) * a.n_bins + d]; };
+    auto grow = [&](int slot) -> const float* { return a.grid + (static_cast<size_t>(slot) * a.n_bins + d) * row; };
+    if (t == 0)
+        {
+            int sel_i = a.ia, sel_q = a.qa;
+            const float m_ia = __fdiv_rn(rec(a.ia).maxv, a.divisor);
+            if (a.ib >= 0)
+                {
+                    const float m_ib = __fdiv_rn(rec(a.ib).maxv, a.divisor);
+                    if (!(m_ia >= m_ib)) sel_i = a.ib;
+                    if (a.qa >= 0 && a.qb >= 0)
+                        {
+                            const float m_qa = __fdiv_rn(rec(a.qa).maxv, a.divisor);
+                            const float m_qb = __fdiv_rn(grow(a.ib)[rec(a.qb).idx], a.divisor);  // :393, as written
+                            if (!(m_qa >= m_qb)) sel_q = a.qb;
+                        }
+                }
+            s_sel[0] = sel_i;
+            s_sel[1] = sel_q;
+        }
+    __syncthreads();
+    const int sel_i = s_sel[0], sel_q = s_sel[1];
+    float best = -1.0f;
+    unsigned at = 0xFFFFFFFFu;
+    if (sel_q >= 0)
+        {
+            const float* __restrict__ gi = grow(sel_i);
+            const float* __restrict__ gq = grow(sel_q);
+            for (int i = t; i < a.n; i += 1024)
+                {
+                    const float m = __fadd_rn(gi[i], gq[i]);   // d_magnitudeI[i] += d_magnitudeQ[i]
+                    if (m > best)                              // i ascending per thread: the lowest index among equals stays
+                        {
+                            best = m;
+                            at = static_cast<unsigned>(i);
+                        }
+                }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1)
+                {
+                    const float ov = __shfl_down(best, off, 64);
+                    const unsigned oi = __shfl_down(at, off, 64);
+                    if (ov > best || (ov == best && oi < at))
+                        {
+                            best = ov;
+                            at = oi;
+                        }
+                }
+            if ((t & 63) == 0)
+                {
+                    s_v[t >> 6] = best;
+                    s_i[t >> 6] = at;
+                }
+            __syncthreads();
+        }
+    if (t == 0)
+        {
+            gsh_acq_pair_peak o;
+            if (sel_q >= 0)
+                {
+                    for (int w = 1; w < 16; w++)
+                        if (s_v[w] > best || (s_v[w] == best && s_i[w] < at))
+                            {
+                                best = s_v[w];
+                                at = s_i[w];
+                            }
+                    o.peak = best;
+                    o.index_time = at;
+                    o.caf_q = rec(sel_q).maxv;   // d_magnitudeQ[A|B][indext_Q[A|B]] (:416, :427)
+                }
+            else
+                {
+                    const gsh::RowStat r = rec(sel_i);
+                    o.peak = r.maxv;
+                    o.index_time = r.idx;
+                    o.caf_q = 0.0f;
+                }
+            o.caf_i = rec(sel_i).maxv;           // :407, :441
+            o.i_slot = static_cast<uint32_t>(sel_i);
+            o.q_slot = sel_q >= 0 ? static_cast<uint32_t>(sel_q) : 0xFFFFFFFFu;
+            a.out[d] = o;
         }
 }
 
@@ -460,6 +569,7 @@ extern "C"
         if (a->d_grid) (void)hipFree(a->d_grid);
         if (a->d_rows) (void)hipFree(a->d_rows);
         if (a->d_subrows) (void)hipFree(a->d_subrows);
+        if (a->d_pair) (void)hipFree(a->d_pair);
         if (a->d_subrows2) (void)hipFree(a->d_subrows2);
         if (a->d_results) (void)hipFree(a->d_results);
         if (a->d_arrivals) (void)hipFree(a->d_arrivals);
@@ -833,6 +943,37 @@ extern "C"
                 row_peak[d] = rows[static_cast<size_t>(d)].maxv;
                 row_index_time[d] = rows[static_cast<size_t>(d)].idx;
             }
+        return GSH_OK;
+    }
+
+    int gsh_acq_noncoherent_pair_peaks(gsh_acq_t* a, int32_t slot_ia, int32_t slot_qa, int32_t slot_ib, int32_t slot_qb, gsh_acq_pair_peak* out)
+    {
+        GSH_REQUIRE(a != nullptr && out != nullptr, "null argument");
+        const int32_t P = static_cast<int32_t>(a->conf.max_prn);
+        GSH_REQUIRE(slot_ia >= 0 && slot_ia < P, "slot_ia %d outside 0..%d", slot_ia, P - 1);
+        GSH_REQUIRE(slot_qa >= -1 && slot_qa < P && slot_ib >= -1 && slot_ib < P && slot_qb >= -1 && slot_qb < P, "slot outside -1..%d", P - 1);
+        GSH_REQUIRE(slot_qb < 0 || (slot_qa >= 0 && slot_ib >= 0), "a Q-B slot needs the Q-A and I-B slots");
+        if (!a->have_input) return set_error(GSH_ERR_STATE, "no dwell has run on this handle yet");
+        if (a->d_grid == nullptr) return set_error(GSH_ERR_STATE, "the handle was created with no_grid = 1: the rows to be added are not stored");
+        GSH_REQUIRE(!a->conf.bit_transition_flag, "the E5a block has no bit-transition search");
+        GSH_HIP(hipSetDevice(a->device));
+        if (a->d_pair == nullptr) GSH_HIP(hipMalloc(&a->d_pair, sizeof(gsh_acq_pair_peak) * a->n_bins));
+        PairPeakArgs k;
+        k.grid = a->d_grid;
+        k.rows = a->d_rows;
+        k.n = static_cast<int>(a->conf.effective_fft_size);
+        k.n_bins = a->n_bins;
+        k.ia = slot_ia;
+        k.qa = slot_qa;
+        k.ib = slot_ib;
+        k.qb = slot_qb;
+        const float fnf = static_cast<float>(a->padded ? a->logical_n : a->conf.fft_size) * static_cast<float>(a->padded ? a->logical_n : a->conf.fft_size);
+        k.divisor = fnf * fnf;
+        k.out = a->d_pair;
+        hipLaunchKernelGGL(pair_peaks_kernel, dim3(a->n_bins), dim3(1024), 0, a->stream, k);
+        GSH_HIP(hipGetLastError());
+        GSH_HIP(hipMemcpyAsync(out, a->d_pair, sizeof(gsh_acq_pair_peak) * a->n_bins, hipMemcpyDeviceToHost, a->stream));
+        GSH_HIP(hipStreamSynchronize(a->stream));
         return GSH_OK;
     }
 

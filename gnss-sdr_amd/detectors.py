@@ -370,3 +370,133 @@ class PcpsAcquisitionFineDoppler:
             self.result["doppler_hz"] = float(np.float32(f))
         self.state = 4
         return self.state
+
+
+class GalileoE5aNoncoherentIQAcquisitionCaf:
+    """The search of galileo_e5a_noncoherentIQ_acquisition_caf_cc (galileo_e5a_noncoherent_iq_acquisition_caf_cc.cc: set_local_code :162-222, state 2
+    :300-665) for one channel: the block's local codes I-A, Q-A, I-B, Q-B in up to four slots of ONE dwell over shared forward transforms, the
+    per-bin A / B choice, the I + Q addition of the kept magnitude rows and the arg-max of the sum on the device
+    (gsh_acq_noncoherent_pair_peaks), the bin loop, the statistic and the CAF filter here.  The C++ product class is
+    Hip_Galileo_E5a_Noncoherent_Iq_Core (host/hip_pcps_detectors.{h,cc})."""
+
+    def __init__(self, fs_in: int, fft_size: int, doppler_max: int, doppler_step: int, samples_per_code: int, threshold: float, max_dwells: int,
+                 sampled_ms: int, both_signal_components: bool, caf_window_hz: int = 0, zero_padding: int = 0, bit_transition_flag: bool = False,
+                 device: int = 0, transform_path: int = 0):
+        self.n_bins = count_doppler_bins(doppler_max, doppler_step)                               # :113-116
+        self.sampled_ms = 1 if zero_padding > 0 else sampled_ms                                   # :85-92
+        self.both = bool(both_signal_components)
+        self.slots = {"IA": 0}
+        if self.both:
+            self.slots["QA"] = len(self.slots)
+        if self.sampled_ms > 1:
+            self.slots["IB"] = len(self.slots)
+            if self.both:
+                self.slots["QB"] = len(self.slots)
+        self.bank = PcpsAcquisitionBank(fs_in, fft_size, doppler_max, doppler_step, 1, float(samples_per_code), max_prn=len(self.slots),
+                                        num_doppler_bins=self.n_bins, device=device, transform_path=transform_path)
+        self.fft_size = fft_size
+        self.doppler_max, self.doppler_step = doppler_max, doppler_step
+        self.samples_per_code = int(samples_per_code)
+        self.threshold = np.float32(threshold)
+        self.max_dwells = max_dwells
+        self.caf_window_hz = caf_window_hz
+        self.bit_transition = bit_transition_flag
+        self.inbuf = np.zeros(fft_size, np.complex64)   # the block's FFT input buffer: the B codes overwrite its first code period only (:187-222)
+        self.test_statistics = np.float32(0.0)
+        self.init()
+
+    def close(self):
+        self.bank.close()
+
+    def set_local_code(self, code_i: np.ndarray, code_q: np.ndarray | None = None) -> None:      # :162-222
+        n, spc = self.fft_size, self.samples_per_code
+        self.inbuf[:] = np.asarray(code_i[:n], np.complex64)
+        self.bank.set_local_code(self.slots["IA"], self.inbuf)
+        if self.both:
+            self.inbuf[:] = np.asarray(code_q[:n], np.complex64)
+            self.bank.set_local_code(self.slots["QA"], self.inbuf)
+        if self.sampled_ms > 1:
+            self.inbuf[:spc] = np.asarray(code_i[:spc], np.complex64) * np.complex64(-1.0)
+            self.bank.set_local_code(self.slots["IB"], self.inbuf)
+            if self.both:
+                self.inbuf[:spc] = np.asarray(code_q[:spc], np.complex64) * np.complex64(-1.0)
+                self.bank.set_local_code(self.slots["QB"], self.inbuf)
+
+    def init(self) -> None:                                                                      # state 0, :262-274
+        self.well_count = 0
+        self.mag = np.float32(0.0)
+        self.input_power = np.float32(0.0)
+        self.test_statistics = np.float32(0.0)
+        self.state = 1
+        self.result = dict(acq_delay_samples=0.0, doppler_hz=0.0, doppler_step=0)
+
+    def _caf(self, caf_i, caf_q):
+        """:546-631, in the block's own float / double mix (see oracle.pcps_oracle.E5aNoncoherentIqOracle for the statement-by-statement notes)."""
+        f32 = np.float32
+        nb = self.n_bins
+        half = self.caf_window_hz // (2 * self.doppler_step)
+        wf = f32(0.5) / f32(half)
+        h = f32(half)
+        out = np.zeros(nb, np.float32)
+
+        def tri(vec, lo, hi, di, use_abs):
+            acc = f32(0.0)
+            for i in range(lo, hi):
+                k = abs(di - i) if use_abs else di - i
+                acc = f32(acc + f32(vec[i] * f32(f32(1.0) - f32(wf * f32(k)))))
+            return acc
+
+        for di in range(0, half):
+            den = f32(f32(f32(f32(1.0) + f32(half + di)) - f32(f32(wf * h) * f32(f32(h + f32(1.0)) / f32(2.0)))) - f32(f32(f32(wf * f32(di)) * f32(f32(di) + f32(1.0))) / f32(2.0)))
+            out[di] = f32(tri(caf_i, 0, half + di + 1, di, False) / den)
+            if self.both:
+                den = f32(f32(f32(f32(1.0) + f32(half + di)) - f32(f32(f32(wf * h) * f32(half + 1)) / f32(2.0))) - f32(f32(f32(wf * f32(di)) * f32(di + 1)) / f32(2.0)))
+                out[di] = f32(out[di] + f32(tri(caf_q, 0, half + di + 1, di, True) / den))
+        for di in range(half, nb - half):
+            den = f32(f32(f32(1.0) + f32(f32(2.0) * h)) - f32(f32(f32(f32(f32(2.0) * wf) * h) * f32(half + 1)) / f32(2.0)))
+            out[di] = f32(tri(caf_i, di - half, di + half + 1, di, False) / den)
+            if self.both:
+                out[di] = f32(out[di] + f32(tri(caf_q, di - half, di + half + 1, di, False) / den))
+        for di in range(max(nb - half, 0), nb):
+            rest = f32(nb - di - 1)
+            den = f32(f32(f32(f32(f32(1.0) + h) + rest) - f32(f32(wf * h) * f32(f32(h + f32(1.0)) / f32(2.0)))) - f32(f32(f32(wf * rest) * f32(nb - di)) / f32(2.0)))
+            out[di] = f32(tri(caf_i, di - half, nb, di, True) / den)
+            if self.both:
+                a = f32(f32(f32(1.0) + h) + rest)
+                t1 = float(f32(f32(wf * h) * f32(half + 1.0))) / 2.0
+                t2 = float(f32(f32(wf * rest) * f32(nb - di))) / 2.0
+                out[di] = f32(out[di] + f32(tri(caf_q, di - half, nb, di, True) / f32((float(a) - t1) - t2)))
+        return out
+
+    def work(self, x: np.ndarray) -> int:                                                        # state 2, :300-665
+        x = np.ascontiguousarray(x[:self.fft_size], np.complex64)
+        f32 = np.float32
+        fnf = f32(self.fft_size) * f32(self.fft_size)
+        div = f32(fnf * fnf)
+        self.mag = f32(0.0)
+        self.well_count += 1
+        self.bank.dwell(x, len(self.slots))
+        self.input_power = f32(self.bank.input_power())                                           # :333-335
+        s = self.slots
+        pk = self.bank.noncoherent_pair_peaks(s["IA"], s.get("QA", -1), s.get("IB", -1), s.get("QB", -1))
+        self.rows = pk
+        for d in range(self.n_bins):
+            magt = f32(pk["peak"][d] / div)                                                       # :436 / :466 / :491
+            t = int(pk["index_time"][d])
+            if self.mag < magt:                                                                   # :496 strict
+                self.mag = magt
+                if self.test_statistics < f32(self.mag / self.input_power) or not self.bit_transition:    # :506
+                    self.result = dict(acq_delay_samples=float(t % self.samples_per_code), doppler_hz=float(-self.doppler_max + self.doppler_step * d),
+                                       doppler_step=self.doppler_step, index_time=t, index_doppler=d)
+                    self.test_statistics = f32(self.mag / self.input_power)                       # :513
+        if self.caf_window_hz > 0:
+            self.caf = self._caf(pk["caf_i"], pk["caf_q"])
+            best = self.caf.max()
+            di = int(np.nonzero(self.caf == best)[0][0])                                          # lowest index among equals (volk_gnsssdr_32f_index_max_32u)
+            self.result["doppler_hz"] = float(-self.doppler_max + self.doppler_step * di)         # :634-636
+            self.result["caf_index_doppler"] = di
+        if self.well_count == self.max_dwells:                                                    # :651-665
+            self.state = 3 if self.test_statistics > self.threshold else 4
+        else:
+            self.state = 1
+        return self.state

@@ -30,7 +30,7 @@ extern "C"
 {
 #endif
 
-#define GSH_ABI_VERSION 17
+#define GSH_ABI_VERSION 18
 #define GSH_MAX_TAPS 8 /* VE/E/P/L/VL needs 5 (trk.cc:609-650); 8 leaves room for multi-tap dumps */
 
     enum
@@ -471,6 +471,24 @@ extern "C"
      * the per-bin loops of galileo_pcps_8ms_acquisition_cc.cc:226-262, which compares two local codes bin by bin.
      * num_doppler_bins entries each. */
     int gsh_acq_read_row_peaks(gsh_acq_t* a, uint32_t prn_slot, float* row_peak, uint32_t* row_index_time);
+    /* Non-coherent I + Q combination of galileo_e5a_noncoherent_iq_acquisition_caf_cc.cc:357-492 after a dwell over the block's local
+     * codes held in four slots of this handle: data component "A" (1,1,1) in slot_ia, pilot "A" in slot_qa (-1: data only,
+     * d_both_signal_components false), and for coherent times above one code period the "B" combinations with the first period
+     * inverted in slot_ib / slot_qb (-1: d_sampled_ms == 1).  Per Doppler bin the component's A or B row is kept as the block keeps it
+     * (row maxima / N^4 compared with >=, :403, :410 -- the Q-B candidate ranked by the I-B row at Q-B's arg-max, as :393 is written),
+     * the two kept magnitude rows are ADDED cell by cell on the device (:419-431) and the maximum of the sum with its lowest index is
+     * returned (:487-492), together with the two row maxima the CAF filter works on (:405-427).  num_doppler_bins records.
+     * Needs the stored grid (no_grid = 0). */
+    typedef struct gsh_acq_pair_peak
+    {
+        float peak;           /* d_magnitudeI[indext] after the addition, unnormalised */
+        uint32_t index_time;  /* indext */
+        float caf_i;          /* d_CAF_vector_I[doppler_index] */
+        float caf_q;          /* d_CAF_vector_Q[doppler_index] (0 without a pilot slot) */
+        uint32_t i_slot;      /* the slots whose rows were added */
+        uint32_t q_slot;      /* 0xFFFFFFFF: none */
+    } gsh_acq_pair_peak;
+    int gsh_acq_noncoherent_pair_peaks(gsh_acq_t* a, int32_t slot_ia, int32_t slot_qa, int32_t slot_ib, int32_t slot_qb, gsh_acq_pair_peak* out);
     /* QuickSync's de-ambiguation (pcps_quicksync_acquisition_cc.cc:295-323): time-domain correlation of the resident block,
      * wiped off at Doppler bin `doppler_index`, with the UNfolded code (code_len complex64 samples, host memory) at n_delays
      * (<= 100) candidate delays: out[c] = sum_j x[delays[c] + j] w[delays[c] + j] code[j].  Float products as the reference forms

@@ -653,3 +653,166 @@ class FineDopplerOracle:
             self.result["doppler_hz"] = float(np.float32(f))
         self.state = 4
         return self.state
+
+
+class E5aNoncoherentIqOracle:
+    """galileo_e5a_noncoherentIQ_acquisition_caf_cc (galileo_e5a_noncoherent_iq_acquisition_caf_cc.cc): set_local_code :162-222 and the
+    search of state 2 :300-650, statement by statement in float32.  Per Doppler bin up to four local codes are correlated -- data (I) and
+    pilot (Q) component, each as generated ("A") and with the first code period inverted ("B", coherent times above one code period) --, for
+    each component the combination with the larger row maximum is kept, the two kept |.|^2 rows are added (non-coherent I + Q) and the arg-max
+    of the sum is the bin's candidate; an optional triangular filter across the Doppler bins (CAF) re-decides the Doppler.
+
+    Quirks of the block that are reproduced because they decide what it outputs:
+      * :393  `magt_QB = d_magnitudeIB[indext_QB] / ...` -- the Q-B candidate is ranked by the I-B row;
+      * :187-222 the B codes are written over the first `samples_per_code` samples of the FFT input buffer only; the rest of the buffer is
+        whatever the previous transform left there: with both components code I-B is [-I, Q, Q] (the pilot replica was the last thing
+        copied in) and Q-B is [-Q, Q, Q]; with one component I-B is [-I, I, I];
+      * the CAF weights (:556-620): no abs() in the data component's first and body loops, abs() in its last loop and in the pilot's first
+        and last loops; the pilot's last-loop normalisation is evaluated in double (literal 2.0), all others in float.
+    Test infrastructure (pinned to the reference block itself by tests/test_pcps_oracle_pinned.py)."""
+
+    def __init__(self, fs_in: int, fft_size: int, doppler_max: int, doppler_step: int, samples_per_code: int, threshold: float, max_dwells: int,
+                 sampled_ms: int, both_signal_components: bool, caf_window_hz: int = 0, zero_padding: int = 0, bit_transition_flag: bool = False):
+        self.n_bins = count_doppler_bins(doppler_max, doppler_step)                               # :113-116
+        self.pa = PcpsOracle(fs_in, fft_size, doppler_max, doppler_step, 1, float(samples_per_code), num_doppler_bins=self.n_bins)
+        self.fft_size = fft_size
+        self.samples_per_code = int(samples_per_code)
+        self.threshold = np.float32(threshold)
+        self.max_dwells = max_dwells
+        self.sampled_ms = 1 if zero_padding > 0 else sampled_ms                                   # :85-92
+        self.both = bool(both_signal_components)
+        self.caf_window_hz = caf_window_hz
+        self.bit_transition = bit_transition_flag
+        self.inbuf = np.zeros(fft_size, np.complex64)                                             # d_fft_if's input buffer (persistent)
+        self.codes = {}
+        self.test_statistics = np.float32(0.0)
+        self.init()
+
+    def _code_fft(self):
+        return np.conj(fft_fwd(self.inbuf)).astype(np.complex64)
+
+    def set_local_code(self, code_i: np.ndarray, code_q: np.ndarray | None = None):              # :162-222
+        n, spc = self.fft_size, self.samples_per_code
+        self.inbuf[:] = np.asarray(code_i[:n], np.complex64)
+        self.codes = {"IA": self._code_fft()}
+        if self.both:
+            self.inbuf[:] = np.asarray(code_q[:n], np.complex64)
+            self.codes["QA"] = self._code_fft()
+        if self.sampled_ms > 1:
+            self.inbuf[:spc] = np.asarray(code_i[:spc], np.complex64) * np.complex64(-1.0)         # :191-199: the first period only
+            self.codes["IB"] = self._code_fft()
+            if self.both:
+                self.inbuf[:spc] = np.asarray(code_q[:spc], np.complex64) * np.complex64(-1.0)
+                self.codes["QB"] = self._code_fft()
+        self.time_codes = None
+
+    def init(self):                                                                              # state 0, :262-274
+        self.well_count = 0
+        self.mag = np.float32(0.0)
+        self.input_power = np.float32(0.0)
+        self.test_statistics = np.float32(0.0)
+        self.state = 1
+        self.result = dict(acq_delay_samples=0.0, doppler_hz=0.0, doppler_step=0)
+
+    def _caf(self, caf_i, caf_q):                                                                # :546-631
+        f32 = np.float32
+        nb = self.n_bins
+        half = self.caf_window_hz // (2 * self.pa.doppler_step)
+        wf = f32(0.5) / f32(half)
+        h = f32(half)
+        out = np.zeros(nb, np.float32)
+        for di in range(0, half):                                                                 # first iterations
+            acc = f32(0.0)
+            for i in range(0, half + di + 1):
+                acc = f32(acc + f32(caf_i[i] * f32(f32(1.0) - f32(wf * f32(di - i)))))
+            den = f32(f32(f32(f32(1.0) + f32(half + di)) - f32(f32(wf * h) * f32(f32(h + f32(1.0)) / f32(2.0)))) - f32(f32(f32(wf * f32(di)) * f32(f32(di) + f32(1.0))) / f32(2.0)))
+            out[di] = f32(acc / den)
+            if self.both:
+                acc = f32(0.0)
+                for i in range(0, half + di + 1):
+                    acc = f32(acc + f32(caf_q[i] * f32(f32(1.0) - f32(wf * f32(abs(di - i))))))
+                den = f32(f32(f32(f32(1.0) + f32(half + di)) - f32(f32(f32(wf * h) * f32(half + 1)) / f32(2.0))) - f32(f32(f32(wf * f32(di)) * f32(di + 1)) / f32(2.0)))
+                out[di] = f32(out[di] + f32(acc / den))
+        for di in range(half, nb - half):                                                         # body
+            acc = f32(0.0)
+            for i in range(di - half, di + half + 1):
+                acc = f32(acc + f32(caf_i[i] * f32(f32(1.0) - f32(wf * f32(di - i)))))
+            den = f32(f32(f32(1.0) + f32(f32(2.0) * h)) - f32(f32(f32(f32(f32(2.0) * wf) * h) * f32(half + 1)) / f32(2.0)))
+            out[di] = f32(acc / den)
+            if self.both:
+                acc = f32(0.0)
+                for i in range(di - half, di + half + 1):
+                    acc = f32(acc + f32(caf_q[i] * f32(f32(1.0) - f32(wf * f32(di - i)))))
+                out[di] = f32(out[di] + f32(acc / den))
+        for di in range(max(nb - half, 0), nb):                                                   # final iterations
+            acc = f32(0.0)
+            for i in range(di - half, nb):
+                acc = f32(acc + f32(caf_i[i] * f32(f32(1.0) - f32(wf * f32(abs(di - i))))))
+            rest = f32(nb - di - 1)
+            den = f32(f32(f32(f32(f32(1.0) + h) + rest) - f32(f32(wf * h) * f32(f32(h + f32(1.0)) / f32(2.0)))) - f32(f32(f32(wf * rest) * f32(nb - di)) / f32(2.0)))
+            out[di] = f32(acc / den)
+            if self.both:
+                acc = f32(0.0)
+                for i in range(di - half, nb):
+                    acc = f32(acc + f32(caf_q[i] * f32(f32(1.0) - f32(wf * f32(abs(di - i))))))
+                a = f32(f32(f32(1.0) + h) + rest)                                                 # float, then the double literals take over (:617)
+                t1 = float(f32(f32(wf * h) * f32(half + 1.0))) / 2.0
+                t2 = float(f32(f32(wf * rest) * f32(nb - di))) / 2.0
+                den_q = f32((float(a) - t1) - t2)
+                out[di] = f32(out[di] + f32(acc / den_q))
+        return out
+
+    def work(self, x: np.ndarray) -> int:                                                        # state 2, :300-650
+        p = self.pa
+        x = np.asarray(x[:self.fft_size], np.complex64)
+        f32 = np.float32
+        fnf = f32(self.fft_size) * f32(self.fft_size)
+        div = f32(fnf * fnf)
+        self.input_power = np.float32(0.0)
+        self.mag = f32(0.0)
+        self.well_count += 1
+        self.input_power = mean_input_power(x)                                                    # :333-335
+        caf_i = np.zeros(self.n_bins, np.float32)
+        caf_q = np.zeros(self.n_bins, np.float32)
+        self.rows = []
+        for d in range(self.n_bins):
+            doppler = -int(p.doppler_max) + p.doppler_step * d
+            A = fft_fwd(cmul(x, p.wipe[d]))                                                       # :343-348
+            mags, idx = {}, {}
+            for k, codes in self.codes.items():
+                y = fft_rev(cmul(A, codes))
+                mags[k] = (y.real * y.real + y.imag * y.imag).astype(np.float32)
+                idx[k] = p._argmax(mags[k])
+            m = {k: f32(mags[k][idx[k]] / div) for k in mags}
+            if "QB" in m:
+                m["QB"] = f32(mags["IB"][idx["QB"]] / div)                                        # :393 as written
+            if self.sampled_ms > 1:
+                sel_i = "IA" if m["IA"] >= m["IB"] else "IB"                                      # :403
+                sel_q = ("QA" if m["QA"] >= m["QB"] else "QB") if self.both else None              # :410 / :446
+            else:
+                sel_i, sel_q = "IA", ("QA" if self.both else None)
+            caf_i[d] = mags[sel_i][idx[sel_i]]
+            row = mags[sel_i]
+            if sel_q is not None:
+                caf_q[d] = mags[sel_q][idx[sel_q]]
+                row = (mags[sel_i] + mags[sel_q]).astype(np.float32)                              # :419-431
+            t = p._argmax(row)
+            magt = f32(row[t] / div)                                                              # :436 / :466 / :491
+            self.rows.append((sel_i, sel_q, float(row[t]), t))
+            if self.mag < magt:                                                                   # :496 strict
+                self.mag = magt
+                if self.test_statistics < f32(self.mag / self.input_power) or not self.bit_transition:    # :506
+                    self.result = dict(acq_delay_samples=float(t % self.samples_per_code), doppler_hz=float(doppler),
+                                       doppler_step=p.doppler_step, index_time=t, index_doppler=d)
+                    self.test_statistics = f32(self.mag / self.input_power)                       # :513
+        if self.caf_window_hz > 0:
+            self.caf = self._caf(caf_i, caf_q)
+            di = p._argmax(self.caf)                                                              # :634
+            self.result["doppler_hz"] = float(-int(p.doppler_max) + p.doppler_step * di)
+            self.result["caf_index_doppler"] = di
+        self.caf_i, self.caf_q = caf_i, caf_q
+        if self.well_count == self.max_dwells:                                                    # :651-665
+            self.state = 3 if self.test_statistics > self.threshold else 4
+        else:
+            self.state = 1
+        return self.state

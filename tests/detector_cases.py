@@ -101,3 +101,58 @@ def fine_doppler_case(doppler_hz: float = 1730.0, fs: int = 4000000, seed: int =
                             seed_noise=seed)
     kw = dict(fs_in=fs, samples_per_ms=float(n), doppler_max=5000, doppler_step=500, threshold=2.5, max_dwells=2)
     return x, kw, oracle.ca_code_complex_sampled(10, fs)
+
+
+def e5a_local_codes(fs: int, prn: int, sampled_ms: int, zero_padding: int = 0):
+    """What galileo_e5a_noncoherent_iq_acquisition_caf.cc:94-141 hands to the block: the data (5I) and pilot (5Q) primary codes sampled at fs
+    (galileo_e5_a_code_gen_complex_sampled), one code period per millisecond, `sampled_ms` periods (or one period + zeros with Zero_padding).
+    The 10 230-chip L5 I / Q golden codes stand in for the E5a-I / E5a-Q primary codes (same length and chip rate; the block never looks at the
+    chips, and the adapter test generates the real ones with the reference's generator)."""
+    g = golden_e1_l5_codes()
+    spc = fs // 1000
+    idx = np.floor(np.arange(spc) * (10230000.0 / fs)).astype(np.int64) % 10230
+    one_i, one_q = g["l5i"][prn - 1][idx].astype(np.complex64), g["l5q"][prn - 1][idx].astype(np.complex64)
+    n = spc * sampled_ms
+    ci, cq = np.zeros(n, np.complex64), np.zeros(n, np.complex64)
+    reps = 1 if zero_padding > 0 else sampled_ms
+    for k in range(reps):
+        ci[k * spc:(k + 1) * spc] = one_i
+        cq[k * spc:(k + 1) * spc] = one_q
+    return ci, cq
+
+
+def e5a_case(fs: int = 12000000, sampled_ms: int = 3, both: bool = True, data_signs=(1, 1, 1, 1, 1, 1), pilot_signs=(1, 1, 1, 1, 1, 1), doppler: float = 250.0,
+             delay_chips: float = 1000.0, cn0: float = 46.0, prn: int = 11, seed: int = 5, signal: bool = True, doppler_max: int = 5000,
+             doppler_step: int = 250, caf_window_hz: int = 0, zero_padding: int = 0, max_dwells: int = 1, n_blocks: int = 2):
+    """galileo_e5a_pcps_acquisition_gsoc2014_gensource_test.cc config_1 (:205-282: 32 Msps, 1 ms, 2800 Hz) and config_2 / config_3 (:284-430: 12 Msps,
+    3 ms, delay 1000 chips, 250 Hz, doppler_max 5000 / step 250 -- 10 000 / 250 in config_1): data on I, pilot on Q (E5a = data + j pilot), each with its
+    own secondary-code / symbol sign per millisecond (`data_signs`, `pilot_signs`), in unit-variance complex noise."""
+    spc = fs // 1000
+    n = spc * sampled_ms
+    rng = np.random.default_rng(seed)
+    total = n_blocks * n
+    x = (rng.standard_normal(total) + 1j * rng.standard_normal(total)).astype(np.complex64)
+    g = golden_e1_l5_codes()
+    if signal:
+        amp = cn0_to_amplitude(cn0, fs) / np.sqrt(2.0 if both else 1.0)
+        nn = np.arange(total, dtype=np.float64)
+        delay_samples = delay_chips * fs / 10230000.0
+        chip = np.floor((nn - delay_samples) * (10230000.0 / fs)).astype(np.int64) % 10230
+        ms = np.floor((nn - delay_samples) / spc).astype(np.int64)
+        ds = np.asarray(data_signs, np.float64)[ms % len(data_signs)]
+        ps = np.asarray(pilot_signs, np.float64)[ms % len(pilot_signs)]
+        s = ds * g["l5i"][prn - 1][chip]
+        if both:
+            s = s + 1j * ps * g["l5q"][prn - 1][chip]
+        x += (amp * s * np.exp(2j * np.pi * doppler / fs * nn)).astype(np.complex64)
+    nb = 0
+    d = -doppler_max
+    while d <= doppler_max:
+        nb += 1
+        d += doppler_step
+    val = (1.0 - 0.01) ** (1.0 / (n * nb))                                 # ThresholdComputeDoppler, pfa 0.01 (base_pcps_acquisition_custom.cc:89-112)
+    threshold = float(np.float32(-np.log1p(-val) / n))
+    kw = dict(fs_in=fs, fft_size=n, doppler_max=doppler_max, doppler_step=doppler_step, samples_per_code=spc, threshold=threshold, max_dwells=max_dwells,
+              sampled_ms=sampled_ms, both_signal_components=both, caf_window_hz=caf_window_hz, zero_padding=zero_padding)
+    ci, cq = e5a_local_codes(fs, prn, sampled_ms, zero_padding)
+    return x, kw, ci, cq
