@@ -4,7 +4,9 @@
  */
 #include "hip_pcps_detectors.h"
 #include "gnss_sdr_hip.h"
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 namespace
 {
@@ -625,4 +627,215 @@ bool Hip_Pcps_Fine_Doppler_Core::estimate_Doppler()
     // 5. update the Doppler estimation in Hz
     if (std::abs(f - d_result.Acq_doppler_hz) < 1000) d_result.Acq_doppler_hz = static_cast<double>(f);
     return true;
+}
+
+// ------------------------------------------------------------------------------------------------ Galileo E5a non-coherent I + Q
+Hip_Galileo_E5a_Noncoherent_Iq_Core::Hip_Galileo_E5a_Noncoherent_Iq_Core(const Hip_Acq_Conf& conf, bool both_signal_components, int CAF_window_hz,
+    int Zero_padding, int device)
+    : d_acq_params(conf), d_CAF_window_hz(CAF_window_hz), d_both_signal_components(both_signal_components)
+{
+    d_fft_size = static_cast<uint32_t>(static_cast<int>(conf.sampled_ms) * static_cast<int>(conf.samples_per_ms));  // e5a.cc:70
+    d_sampled_ms = Zero_padding > 0 ? 1U : conf.sampled_ms;                                                        // e5a.cc:85-92
+    d_num_doppler_bins = count_bins(conf.doppler_max, conf.doppler_step);                                           // e5a.cc:113-116
+    int32_t n_slots = 1;
+    if (d_both_signal_components) d_slot_QA = n_slots++;
+    if (d_sampled_ms > 1)
+        {
+            d_slot_IB = n_slots++;
+            if (d_both_signal_components) d_slot_QB = n_slots++;
+        }
+    d_handle = make_handle(conf, d_fft_size, d_num_doppler_bins, static_cast<uint32_t>(n_slots), device, &d_error);
+    d_pair.resize(d_num_doppler_bins);
+    d_inbuf.assign(d_fft_size, std::complex<float>(0.0F, 0.0F));
+    if (d_CAF_window_hz > 0)
+        {
+            d_CAF_vector.assign(d_num_doppler_bins, 0.0F);
+            d_CAF_vector_I.assign(d_num_doppler_bins, 0.0F);
+            if (d_both_signal_components) d_CAF_vector_Q.assign(d_num_doppler_bins, 0.0F);
+        }
+}
+
+
+Hip_Galileo_E5a_Noncoherent_Iq_Core::~Hip_Galileo_E5a_Noncoherent_Iq_Core()
+{
+    if (d_handle != nullptr) gsh_acq_destroy(d_handle);
+}
+
+
+void Hip_Galileo_E5a_Noncoherent_Iq_Core::set_local_code(const std::complex<float>* codeI, const std::complex<float>* codeQ)
+{
+    if (d_handle == nullptr) return;
+    auto load = [&](int32_t slot) {
+        if (gsh_acq_set_local_code(d_handle, static_cast<uint32_t>(slot), reinterpret_cast<const float*>(d_inbuf.data())) != GSH_OK) d_error = gsh_last_error();
+    };
+    const auto samples_per_code = std::min(static_cast<uint32_t>(d_acq_params.samples_per_code), d_fft_size);
+    // DATA SIGNAL, CODE A: (1,1,1)
+    std::copy(codeI, codeI + d_fft_size, d_inbuf.begin());
+    load(d_slot_IA);
+    // SAME FOR PILOT SIGNAL
+    if (d_both_signal_components)
+        {
+            std::copy(codeQ, codeQ + d_fft_size, d_inbuf.begin());
+            load(d_slot_QA);
+        }
+    // integration time above one code: the other possible combination.  Only the first replica is rewritten (e5a.cc:191-199); the rest of the
+    // buffer keeps what the previous transform's input was
+    if (d_sampled_ms > 1)
+        {
+            for (uint32_t i = 0; i < samples_per_code; i++) d_inbuf[i] = codeI[i] * std::complex<float>(-1, 0);
+            load(d_slot_IB);
+            if (d_both_signal_components)
+                {
+                    for (uint32_t i = 0; i < samples_per_code; i++) d_inbuf[i] = codeQ[i] * std::complex<float>(-1, 0);
+                    load(d_slot_QB);
+                }
+        }
+}
+
+
+void Hip_Galileo_E5a_Noncoherent_Iq_Core::init()
+{
+    d_result = Hip_Detector_Result();
+    d_well_count = 0;
+    d_mag = 0.0;
+    d_input_power = 0.0;
+    d_test_statistics = 0.0;
+    d_state = 1;
+}
+
+
+// e5a.cc:546-631, expression for expression (the float / double mix decides the last bits of the normalisations)
+void Hip_Galileo_E5a_Noncoherent_Iq_Core::caf_filter()
+{
+    const int num_bins = static_cast<int>(d_num_doppler_bins);
+    const int CAF_bins_half = d_CAF_window_hz / (2 * d_acq_params.doppler_step);
+    const float weighting_factor = 0.5F / static_cast<float>(CAF_bins_half);
+    float accum;
+    // Initialize first iterations
+    for (int doppler_index = 0; doppler_index < CAF_bins_half; doppler_index++)
+        {
+            d_CAF_vector[doppler_index] = 0;
+            for (int i = 0; i < CAF_bins_half + doppler_index + 1; i++)
+                {
+                    d_CAF_vector[doppler_index] += d_CAF_vector_I[i] * (1.0F - weighting_factor * static_cast<float>((doppler_index - i)));
+                }
+            d_CAF_vector[doppler_index] /= 1.0F + static_cast<float>(CAF_bins_half + doppler_index) - weighting_factor * static_cast<float>(CAF_bins_half) * ((static_cast<float>(CAF_bins_half) + 1.0F) / 2.0F) - weighting_factor * static_cast<float>(doppler_index) * (static_cast<float>(doppler_index) + 1.0F) / 2.0F;
+            if (d_both_signal_components)
+                {
+                    accum = 0;
+                    for (int i = 0; i < CAF_bins_half + doppler_index + 1; i++)
+                        {
+                            accum += d_CAF_vector_Q[i] * (1.0F - weighting_factor * static_cast<float>(std::abs(doppler_index - i)));
+                        }
+                    accum /= 1.0F + static_cast<float>(CAF_bins_half + doppler_index) - weighting_factor * static_cast<float>(CAF_bins_half) * static_cast<float>(CAF_bins_half + 1) / 2.0F - weighting_factor * static_cast<float>(doppler_index) * static_cast<float>(doppler_index + 1) / 2.0F;
+                    d_CAF_vector[doppler_index] += accum;
+                }
+        }
+    // Body loop
+    for (int doppler_index = CAF_bins_half; doppler_index < num_bins - CAF_bins_half; doppler_index++)
+        {
+            d_CAF_vector[doppler_index] = 0;
+            for (int i = doppler_index - CAF_bins_half; i < doppler_index + CAF_bins_half + 1; i++)
+                {
+                    d_CAF_vector[doppler_index] += d_CAF_vector_I[i] * (1.0F - weighting_factor * static_cast<float>((doppler_index - i)));
+                }
+            d_CAF_vector[doppler_index] /= 1.0F + 2.0F * static_cast<float>(CAF_bins_half) - 2.0F * weighting_factor * static_cast<float>(CAF_bins_half) * static_cast<float>(CAF_bins_half + 1) / 2.0F;
+            if (d_both_signal_components)
+                {
+                    accum = 0;
+                    for (int i = doppler_index - CAF_bins_half; i < doppler_index + CAF_bins_half + 1; i++)
+                        {
+                            accum += d_CAF_vector_Q[i] * (1 - weighting_factor * static_cast<float>((doppler_index - i)));
+                        }
+                    accum /= 1.0F + 2.0F * static_cast<float>(CAF_bins_half) - 2.0F * weighting_factor * static_cast<float>(CAF_bins_half) * static_cast<float>(CAF_bins_half + 1) / 2.0F;
+                    d_CAF_vector[doppler_index] += accum;
+                }
+        }
+    // Final iterations
+    for (int doppler_index = num_bins - CAF_bins_half; doppler_index < num_bins; doppler_index++)
+        {
+            if (doppler_index < 0) continue;  // (a window wider than the grid: the reference indexes out of bounds here)
+            d_CAF_vector[doppler_index] = 0;
+            for (int i = doppler_index - CAF_bins_half; i < num_bins; i++)
+                {
+                    d_CAF_vector[doppler_index] += d_CAF_vector_I[i] * (1.0F - weighting_factor * static_cast<float>(std::abs(doppler_index - i)));
+                }
+            d_CAF_vector[doppler_index] /= 1.0F + static_cast<float>(CAF_bins_half) + static_cast<float>(num_bins - doppler_index - 1) - weighting_factor * static_cast<float>(CAF_bins_half) * (static_cast<float>(CAF_bins_half) + 1.0F) / 2.0F - weighting_factor * (num_bins - doppler_index - 1) * static_cast<float>(num_bins - doppler_index) / 2.0F;
+            if (d_both_signal_components)
+                {
+                    accum = 0;
+                    for (int i = doppler_index - CAF_bins_half; i < num_bins; i++)
+                        {
+                            accum += d_CAF_vector_Q[i] * (1.0F - weighting_factor * static_cast<float>(std::abs(doppler_index - i)));
+                        }
+                    accum /= static_cast<float>(1.0F + static_cast<float>(CAF_bins_half) + static_cast<float>(num_bins - doppler_index - 1) - weighting_factor * static_cast<float>(CAF_bins_half) * static_cast<float>(CAF_bins_half + 1.0) / 2.0 - weighting_factor * static_cast<float>(num_bins - doppler_index - 1) * static_cast<float>(num_bins - doppler_index) / 2.0);
+                    d_CAF_vector[doppler_index] += accum;
+                }
+        }
+}
+
+
+int Hip_Galileo_E5a_Noncoherent_Iq_Core::work(uint64_t sample_counter, const std::complex<float>* in)
+{
+    if (d_handle == nullptr) return -1;
+    const float fft_normalization_factor = static_cast<float>(d_fft_size) * static_cast<float>(d_fft_size);
+    d_input_power = 0.0;
+    d_mag = 0.0;
+    d_well_count++;
+
+    // one dwell over the block's two to four local codes (the block: one forward and up to four inverse transforms per bin, e5a.cc:340-395), then
+    // the per-bin choice, the I + Q addition and the arg-max of the sum on the device (:399-492)
+    std::vector<gsh_acq_result> r(4);
+    const uint32_t n_slots = 1U + (d_slot_QA >= 0 ? 1U : 0U) + (d_slot_IB >= 0 ? 1U : 0U) + (d_slot_QB >= 0 ? 1U : 0U);
+    if (gsh_acq_dwell(d_handle, reinterpret_cast<const float*>(in), n_slots, 0, 1, r.data()) != GSH_OK || gsh_acq_input_power(d_handle, &d_input_power) != GSH_OK ||
+        gsh_acq_noncoherent_pair_peaks(d_handle, d_slot_IA, d_slot_QA, d_slot_IB, d_slot_QB, d_pair.data()) != GSH_OK)
+        {
+            d_error = gsh_last_error();
+            return -1;
+        }
+    for (uint32_t doppler_index = 0; doppler_index < d_num_doppler_bins; doppler_index++)
+        {
+            const int32_t doppler = -d_acq_params.doppler_max + d_acq_params.doppler_step * static_cast<int32_t>(doppler_index);
+            const gsh_acq_pair_peak& p = d_pair[doppler_index];
+            if (d_CAF_window_hz > 0)
+                {
+                    d_CAF_vector_I[doppler_index] = p.caf_i;
+                    if (d_both_signal_components) d_CAF_vector_Q[doppler_index] = p.caf_q;
+                }
+            const uint32_t indext = p.index_time;
+            const float magt = p.peak / (fft_normalization_factor * fft_normalization_factor);
+            // 4- record the maximum peak and the associated synchronization parameters (e5a.cc:496-515)
+            if (d_mag < magt)
+                {
+                    d_mag = magt;
+                    if (d_test_statistics < (d_mag / d_input_power) || !d_acq_params.bit_transition_flag)
+                        {
+                            d_result.index_time = indext;
+                            d_result.index_doppler = doppler_index;
+                            d_result.Acq_delay_samples = static_cast<double>(indext % static_cast<int32_t>(d_acq_params.samples_per_code));
+                            d_result.Acq_doppler_hz = static_cast<double>(doppler);
+                            d_result.Acq_samplestamp_samples = sample_counter;
+                            d_result.Acq_doppler_step = static_cast<uint32_t>(d_acq_params.doppler_step);
+                            d_test_statistics = d_mag / d_input_power;
+                        }
+                }
+        }
+    // 6 OPTIONAL: CAF filter to avoid Doppler ambiguity in bit transition (e5a.cc:546-650)
+    if (d_CAF_window_hz > 0)
+        {
+            caf_filter();
+            uint32_t indext = 0;
+            for (uint32_t i = 1; i < d_num_doppler_bins; i++)
+                if (d_CAF_vector[i] > d_CAF_vector[indext]) indext = i;  // volk_gnsssdr_32f_index_max_32u: the lowest index among equals
+            d_result.Acq_doppler_hz = static_cast<double>(-d_acq_params.doppler_max + d_acq_params.doppler_step * static_cast<int32_t>(indext));
+        }
+    if (d_well_count == d_acq_params.max_dwells)
+        {
+            d_state = d_test_statistics > d_acq_params.threshold ? 3 : 4;  // positive : negative acquisition (e5a.cc:651-661)
+        }
+    else
+        {
+            d_state = 1;
+        }
+    return d_state;
 }

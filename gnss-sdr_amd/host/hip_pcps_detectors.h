@@ -6,6 +6,7 @@
  *   Hip_Galileo_Pcps_8ms_Core  galileo_pcps_8ms_acquisition_cc   (gnuradio_blocks/galileo_pcps_8ms_acquisition_cc.cc, "8ms.cc")
  *   Hip_Pcps_Quicksync_Core    pcps_quicksync_acquisition_cc     (gnuradio_blocks/pcps_quicksync_acquisition_cc.cc, "qs.cc")
  *   Hip_Pcps_Fine_Doppler_Core pcps_acquisition_fine_doppler_cc  (gnuradio_blocks/pcps_acquisition_fine_doppler_cc.cc, "fd.cc")
+ *   Hip_Galileo_E5a_Noncoherent_Iq_Core  galileo_e5a_noncoherentIQ_acquisition_caf_cc  (gnuradio_blocks/galileo_e5a_noncoherent_iq_acquisition_caf_cc.cc, "e5a.cc")
  *
  * Each class keeps the reference block's member names and its general_work state numbering: init() is state 0, work() is
  * one pass of state 1 over one input vector and returns the next state (1 = keep going, 2 = positive, 3 = negative).
@@ -15,6 +16,7 @@
 #ifndef GNSS_SDR_HIP_PCPS_DETECTORS_H
 #define GNSS_SDR_HIP_PCPS_DETECTORS_H
 
+#include "gnss_sdr_hip.h"
 #include "hip_pcps_acquisition_core.h"
 #include <complex>
 #include <cstdint>
@@ -247,6 +249,59 @@ private:
     uint32_t d_last_index_time{0}, d_last_index_doppler{0};
     int d_device{0}, d_num_doppler_points{0}, d_well_count{0};
     uint32_t d_fft_size{0};
+};
+
+/*!
+ * \brief The search of galileo_e5a_noncoherentIQ_acquisition_caf_cc (e5a.cc: set_local_code :162-222, state 2 :300-665) on the HIP engine.
+ * The block's local codes -- data "A" (1,1,1), pilot "A", and for coherent times above one code period the "B" combinations with the
+ * first period inverted -- sit in up to four slots of ONE dwell over shared forward transforms; per Doppler bin the A / B choice of
+ * each component, the addition of the two kept magnitude rows and the arg-max of the sum run on the device
+ * (gsh_acq_noncoherent_pair_peaks); the bin loop, the statistic, the CAF filter across bins (:546-631) and the dwell counting are here,
+ * in the block's own float / double mix.  Reference behaviour kept as written: the B codes overwrite only the first code period of the
+ * FFT input buffer (with both components code I-B is therefore [-I, Q, Q]), and Q-B is ranked by the I-B row (:393).
+ * States as in the block: init() = state 0, work() = one pass of state 2 over a full block; returns 1 (another dwell), 3 (positive), 4 (negative).
+ */
+class Hip_Galileo_E5a_Noncoherent_Iq_Core
+{
+public:
+    Hip_Galileo_E5a_Noncoherent_Iq_Core(const Hip_Acq_Conf& conf, bool both_signal_components, int CAF_window_hz, int Zero_padding, int device = 0);
+    ~Hip_Galileo_E5a_Noncoherent_Iq_Core();
+    Hip_Galileo_E5a_Noncoherent_Iq_Core(const Hip_Galileo_E5a_Noncoherent_Iq_Core&) = delete;
+    Hip_Galileo_E5a_Noncoherent_Iq_Core& operator=(const Hip_Galileo_E5a_Noncoherent_Iq_Core&) = delete;
+
+    bool ok() const { return d_handle != nullptr; }
+    const std::string& last_error() const { return d_error; }
+
+    void set_local_code(const std::complex<float>* codeI, const std::complex<float>* codeQ);  //!< e5a.cc:162-222
+    void init();                                                                               //!< state 0, e5a.cc:262-274
+    int work(uint64_t sample_counter, const std::complex<float>* in);                          //!< state 2, e5a.cc:300-665
+
+    const Hip_Detector_Result& result() const { return d_result; }
+    uint32_t num_doppler_bins() const { return d_num_doppler_bins; }
+    uint32_t fft_size() const { return d_fft_size; }
+    uint32_t well_count() const { return d_well_count; }
+    float mag() const { return d_mag; }
+    float input_power() const { return d_input_power; }
+    float test_statistics() const { return d_test_statistics; }
+    int state() const { return d_state; }
+    const std::vector<float>& CAF_vector() const { return d_CAF_vector; }
+
+private:
+    void caf_filter();
+    Hip_Acq_Conf d_acq_params;
+    gsh_acq* d_handle{nullptr};
+    std::string d_error;
+    Hip_Detector_Result d_result;
+    std::vector<gsh_acq_pair_peak> d_pair;
+    std::vector<std::complex<float>> d_inbuf;  //!< d_fft_if's input buffer: what the previous code left there stays (e5a.cc:187-222)
+    std::vector<float> d_CAF_vector, d_CAF_vector_I, d_CAF_vector_Q;
+    float d_mag{0.0F}, d_input_power{0.0F}, d_test_statistics{0.0F};
+    int d_state{0};
+    int d_CAF_window_hz{0};
+    int32_t d_slot_IA{0}, d_slot_QA{-1}, d_slot_IB{-1}, d_slot_QB{-1};
+    uint32_t d_well_count{0}, d_sampled_ms{1};
+    uint32_t d_fft_size{0}, d_num_doppler_bins{0};
+    bool d_both_signal_components{false};
 };
 
 #endif
