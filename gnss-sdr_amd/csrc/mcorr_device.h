@@ -138,6 +138,7 @@ struct JobCtx
     // fused second correlator (AUX kernels): one more tap over the same rotated samples with ANOTHER code -- the data-component prompt that
     // track_pilot adds to a pilot channel (trk.cc:1246-1256), which the reference runs as a second pass over the window
     bool packed{true};      // run_body_packed allowed (host switch gsh_bank_set_packed_body / GSH_MC_PACKED_BODY=0 for A/B runs)
+    bool runs{false};       // the run-based path may be used (RUNS kernels)
     bool aux_on{false};
     bool aux_zero{false};   // its shift is exactly 0.0f: on the ZP path it shares the prompt tap's chip index
     float aux_shift{0.0f};
@@ -575,6 +576,227 @@ __device__ __forceinline__ void run_segment_packed(const JobCtx& c, const float2
             const float2 b = cmul(make_float2(XB0.x + b1.x, XB0.y + b1.y), w);
             acc_aux->x += (XA0.x + a1.x) + b.x;
             acc_aux->y += (XA0.y + a1.y) + b.y;
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Run-based path (round 2, experiment -> see DESIGN section 3).  The packed trips above spend two thirds of their VALU issue on evaluating
+// the float32 chip-index chain once per tap and SAMPLE, although at 25 Msps the chip index of a tap changes only every 24th sample.  Here the
+// chain is evaluated only where it changes:
+//   * a wave takes a "super-trip" of S = 64 R consecutive samples (R = 8: 512); coalesced 16-byte loads put them into the wave's LDS buffer
+//     in natural order (phase 1); each lane then owns the RUN of R consecutive samples i R .. i R + R - 1, forms the prefix sums
+//     q_p = sum_{p' <= p} x_p' w^p' of its run (w^p = exp(-j p step), wave-uniform) and writes them back in place; the run totals, rotated
+//     by the lane's phasor ph_i, are prefix-scanned across the wave (DPP) -> E_i, total T (phase 2).  P[n] = E_i + ph_i q_{p-1} is then the
+//     carrier-wiped prefix sum of the super-trip up to (not including) sample n = a + i R + p;
+//   * the sum a tap wants, sum_n code[idx_t(n)] y[n], over the super-trip is  code[k_first] T + sum_k (code[k] - code[k-1]) (T - P[n*_k])
+//     over the chip boundaries n*_k = min{n : idx_t(n) >= k} inside it.  A boundary is found EXACTLY: an estimate from the real-valued
+//     formula, then the reference's own float32 chain floor((step (float)n + shift) - rem) evaluated at n* - 1 and n* until
+//     idx(n* - 1) < k <= idx(n*) holds (the chain is monotone in n: every rounding is).  One lane per (tap, boundary): 64 / NT lanes per tap,
+//     more boundaries than that are taken in further passes (phase 3).
+// The chip selection is therefore the reference's, sample for sample; the accumulators differ from the per-sample order of summation only
+// by float rounding of the prefix differences (~ ulp of the sum over 512 samples per boundary).
+// Needs: standard mode, no per-sample wrap (indices inside what is staged), code_step > 0, windows below 2^24 samples; per wave
+// RUNS_LDS_FLOATS floats of LDS scratch.
+template <int R>
+struct RunsLayout
+{
+    static constexpr int S = 64 * R;          // samples per super-trip
+    static constexpr int STRIDE = R + 2;      // float2 per run in LDS: 16-byte aligned rows, conflict-free ds_read_b128 across 8 lanes (R = 8: 20 words)
+    static constexpr int Y_F2 = 64 * STRIDE;  // float2
+    static constexpr int FLOATS = 2 * (Y_F2 + 64 + 64);  // y / q buffer, (E_i, ph_i) per run
+};
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_read0(float v)
+{
+    // lanes whose source is outside the row / whose row is masked off read 0.0f
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true));
+}
+
+// inclusive prefix sum over the 64 lanes of a wave
+__device__ __forceinline__ float wave_scan_incl(float v)
+{
+    v += dpp_read0<0x111, 0xf>(v);  // row_shr:1
+    v += dpp_read0<0x112, 0xf>(v);  // row_shr:2
+    v += dpp_read0<0x114, 0xf>(v);  // row_shr:4
+    v += dpp_read0<0x118, 0xf>(v);  // row_shr:8
+    v += dpp_read0<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+    v += dpp_read0<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+__device__ __forceinline__ float readlane_f(float v, int l)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+
+template <int NT, int R>
+__device__ __forceinline__ void run_segment_runs(const JobCtx& c, const float2* __restrict__ base, const float* __restrict__ tab, const float (&sh)[NT],
+    float2 (&acc)[NT], float* __restrict__ wave_lds)
+{
+    using LY = RunsLayout<R>;
+    constexpr int S = LY::S, STRIDE = LY::STRIDE;
+    constexpr int LT = 64 / NT;  // lanes per tap in the boundary phase
+    static_assert(R >= 4 && R <= 16 && (R & (R - 1)) == 0, "run length: 4, 8 or 16");
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    float2* const ybuf = reinterpret_cast<float2*>(wave_lds);
+    float4* const epbuf = reinterpret_cast<float4*>(ybuf + LY::Y_F2);  // per run: (E_i, ph_i)
+    const int a0 = c.n_first;
+    const int n_st = (c.n_end - a0 + S - 1) / S;  // super-trips of the segment
+    const double sd = static_cast<double>(c.phase_step);
+
+    // ---- per-window constants of this lane: two transcendental phasors per lane and window
+    const float2 Lf = expmj(static_cast<double>(R * lane) * sd);  // the lane's run offset inside a super-trip
+    const v2f Li = {Lf.x, Lf.y};
+    // table T: lanes 0..47 hold the exact phasor of the first sample of one of this wave's next 48 super-trips, lane 48 + p holds w^p = exp(-j p step)
+    constexpr int SEEDS = 48;
+    auto fill_table = [&](int it0) -> float2 {
+        double phs;
+        if (lane >= SEEDS)
+            phs = static_cast<double>(min(lane - SEEDS, R - 1)) * sd;
+        else
+            {
+                const long long nb = static_cast<long long>(a0) + static_cast<long long>(S) * (static_cast<long long>(wave) + static_cast<long long>(MC_WAVES) * (it0 + lane));
+                phs = static_cast<double>(c.rem_carr) + static_cast<double>(nb) * sd;
+            }
+        return expmj(phs);
+    };
+    float2 Tb = fill_table(0);
+    v2f wp[R];
+#pragma unroll
+    for (int p = 0; p < R; p++) wp[p] = (v2f){readlane_f(Tb.x, SEEDS + p), readlane_f(Tb.y, SEEDS + p)};
+    const int my_t = lane / LT;           // >= NT: idle in the boundary phase
+    const int my_j = lane - my_t * LT;
+    float my_sh = sh[0];
+#pragma unroll
+    for (int t = 1; t < NT; t++) my_sh = (my_t == t) ? sh[t] : my_sh;
+    const float inv_step = __fdiv_rn(1.0f, c.code_step);
+    const float est_off = __fsub_rn(c.rem_code, my_sh);  // n ~ (k + rem - shift) / step
+    auto chip_of = [&](int n) -> int { return raw_chip_std(__fmul_rn(c.code_step, static_cast<float>(n)), my_sh, c.rem_code); };
+    float2 bacc = make_float2(0.0f, 0.0f);
+
+    // the super-trip's samples for this lane: R / 2 coalesced 16-byte loads (samples outside the segment are zero); issued one super-trip ahead
+    auto load_st = [&](int m, float4 (&v)[R / 2]) {
+        const int a = a0 + m * S;
+        const float2* __restrict__ src = base + static_cast<long long>(m) * S;
+        const bool plain = (a >= c.n_begin) && (a + S <= c.n_end);  // uniform
+#pragma unroll
+        for (int q = 0; q < R / 2; q++)
+            {
+                const int s0 = 128 * q + 2 * lane;
+                if (plain)
+                    v[q] = *reinterpret_cast<const float4*>(src + s0);
+                else
+                    {
+                        const int n0 = a + s0;
+                        const bool v0 = (n0 >= c.n_begin) && (n0 < c.n_end), v1 = (n0 + 1 >= c.n_begin) && (n0 + 1 < c.n_end);
+                        const float2 x0 = v0 ? src[s0] : make_float2(0.0f, 0.0f);
+                        const float2 x1 = v1 ? src[s0 + 1] : make_float2(0.0f, 0.0f);
+                        v[q] = make_float4(x0.x, x0.y, x1.x, x1.y);
+                    }
+            }
+    };
+    float4 nxt[R / 2];
+#pragma unroll
+    for (int q = 0; q < R / 2; q++) nxt[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (wave < n_st) load_st(wave, nxt);  // uniform
+
+    int it = 0, it0 = 0;
+    for (int m = wave; m < n_st; m += MC_WAVES, it++)
+        {
+            if (it - it0 >= SEEDS)  // uniform: long windows refill the table
+                {
+                    it0 = it;
+                    Tb = fill_table(it0);
+                }
+            const v2f U = {readlane_f(Tb.x, it - it0), readlane_f(Tb.y, it - it0)};
+            const int a = a0 + m * S;
+            const int b = min(a + S, c.n_end);       // samples [n_lo, b) of this super-trip are inside the segment
+            const int n_lo = max(a, c.n_begin);
+
+            // ---- phase 1: natural order in LDS; then the next super-trip's loads go out and fly during phases 2 and 3
+#pragma unroll
+            for (int q = 0; q < R / 2; q++)
+                {
+                    const int s0 = 128 * q + 2 * lane;
+                    *reinterpret_cast<float4*>(ybuf + (s0 / R) * STRIDE + (s0 % R)) = nxt[q];
+                }
+            asm volatile("" ::: "memory");  // LDS operations of one wave execute in order; keep the compiler from moving the reads up
+            if (m + MC_WAVES < n_st) load_st(m + MC_WAVES, nxt);  // uniform
+
+            // ---- phase 2: run prefixes in place, run totals scanned across the wave
+            float2 T = make_float2(0.0f, 0.0f);
+#ifndef GSH_RUNS_SKIP2
+            {
+                v2f x[R];
+#pragma unroll
+                for (int u = 0; u < R / 2; u++)
+                    {
+                        const float4 v = *reinterpret_cast<const float4*>(ybuf + lane * STRIDE + 2 * u);
+                        x[2 * u] = (v2f){v.x, v.y};
+                        x[2 * u + 1] = (v2f){v.z, v.w};
+                    }
+#pragma unroll
+                for (int p = 1; p < R; p++) x[p] = x[p - 1] + pk_cmul(x[p], wp[p]);
+#pragma unroll
+                for (int u = 0; u < R / 2; u++)
+                    *reinterpret_cast<float4*>(ybuf + lane * STRIDE + 2 * u) = make_float4(x[2 * u].x, x[2 * u].y, x[2 * u + 1].x, x[2 * u + 1].y);
+                const v2f ph = pk_cmul(U, Li);
+                const v2f tot = pk_cmul(x[R - 1], ph);
+                const float2 incl = make_float2(wave_scan_incl(tot.x), wave_scan_incl(tot.y));
+                epbuf[lane] = make_float4(incl.x - tot.x, incl.y - tot.y, ph.x, ph.y);
+                T = make_float2(readlane_f(incl.x, 63), readlane_f(incl.y, 63));
+            }
+#endif
+            asm volatile("" ::: "memory");
+
+            // ---- phase 3: the chip boundaries of this lane's tap inside (n_lo, b)
+#ifdef GSH_RUNS_SKIP3
+            if (false)
+#else
+            if (my_t < NT)
+#endif
+                {
+                    const int k_first = chip_of(n_lo);
+                    const int count = chip_of(b - 1) - k_first;
+                    if (my_j == 0)
+                        {
+                            const float c0 = tab[k_first + c.k_off];
+                            bacc.x = fmaf(c0, T.x, bacc.x);
+                            bacc.y = fmaf(c0, T.y, bacc.y);
+                        }
+                    for (int j = my_j; j < count; j += LT)
+                        {
+                            const int k = k_first + 1 + j;
+                            // estimate, then the exact chain: idx(n - 1) < k <= idx(n), n in (n_lo, b - 1]
+                            int n = static_cast<int>(ceilf(__fmul_rn(__fadd_rn(static_cast<float>(k), est_off), inv_step)));
+                            n = min(max(n, n_lo + 1), b - 1);
+                            while (n > n_lo + 1 && chip_of(n - 1) >= k) n--;
+                            while (n < b - 1 && chip_of(n) < k) n++;
+                            const int rel = n - a;
+                            const int run = rel / R, pos = rel % R;
+                            const float4 ep = epbuf[run];
+                            const float2 qv = ybuf[run * STRIDE + max(pos - 1, 0)];
+                            float2 P = make_float2(ep.x, ep.y);
+                            if (pos > 0)
+                                {
+                                    const float2 r = cmul(qv, make_float2(ep.z, ep.w));
+                                    P.x += r.x;
+                                    P.y += r.y;
+                                }
+                            const float d = tab[k + c.k_off] - tab[k - 1 + c.k_off];
+                            bacc.x = fmaf(d, T.x - P.x, bacc.x);
+                            bacc.y = fmaf(d, T.y - P.y, bacc.y);
+                        }
+                }
+            asm volatile("" ::: "memory");  // the next super-trip overwrites the buffers
+        }
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+        {
+            acc[t].x += (my_t == t) ? bacc.x : 0.0f;
+            acc[t].y += (my_t == t) ? bacc.y : 0.0f;
         }
 }
 

@@ -39,9 +39,15 @@ using namespace mcdev;
 #define GSH_MC_MIN_WAVES 5  // E/P/L: the packed body holds four accumulator sets; <= 96 VGPRs (5 waves per SIMD), the kernel is VALU-issue bound
 #endif
 
-template <int NT, int MODE, bool AUX>
+#ifndef GSH_MC_RUN_LEN
+#define GSH_MC_RUN_LEN 8
+#endif
+constexpr int MC_RUN_LEN = GSH_MC_RUN_LEN;  // samples per lane run of the run-based path (mcorr_device.h)
+
+template <int NT, int MODE, bool AUX, bool RUNS = false>
 __global__ __launch_bounds__(MC_THREADS, ((NT <= 3 && !AUX) ? GSH_MC_MIN_WAVES : 1)) void mcorr_kernel(McorrArgs a)
 {
+    static_assert(!RUNS || (MODE == 0 && !AUX), "the run-based path exists for the standard mode without a fused tap");
     extern __shared__ __align__(16) float lds[];
     const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
     const int slot = static_cast<int>(lb) / a.splits;
@@ -62,6 +68,7 @@ __global__ __launch_bounds__(MC_THREADS, ((NT <= 3 && !AUX) ? GSH_MC_MIN_WAVES :
     c.code_step = J.code_phase_step_chips;
     c.code_rate = J.code_phase_rate_step_chips;
     c.packed = a.packed != 0;
+    c.runs = RUNS && a.packed == 2;
 
     // ---- this work-group's slice of the window
     int seg = (c.n_total + a.splits - 1) / a.splits;
@@ -204,7 +211,15 @@ __global__ __launch_bounds__(MC_THREADS, ((NT <= 3 && !AUX) ? GSH_MC_MIN_WAVES :
             const bool fast = windowed || (!mode_hd_code(MODE) && (c.code_step >= 0.0f) && (lo >= -MC_MARGIN) && (hi < c.code_len + MC_MARGIN) && (c.code_len >= MC_MARGIN) && aux_fast);
             // centre tap at exactly 0 (E/P/L, VE/E/P/L/VL): its (a + 0.0f) is skipped; needs sample indices exact in float
             const bool zp = (NT & 1) && (NT == J.n_taps) && (sh[NT / 2] == 0.0f) && !mode_hd_code(MODE) && (c.n_total < (1 << 24));
-            if (fast && zp)
+            if (RUNS && fast && c.runs && c.code_step > 1.0e-6f && c.n_total < (1 << 24))
+                {
+                    if constexpr (RUNS)
+                        {
+                            float* const runs_lds = reinterpret_cast<float*>(red + MC_WAVES * GSH_MAX_TAPS) + (tid >> 6) * RunsLayout<MC_RUN_LEN>::FLOATS;
+                            run_segment_runs<NT, MC_RUN_LEN>(c, base, tab, sh, acc, runs_lds);
+                        }
+                }
+            else if (fast && zp)
                 run_segment<NT, MODE, false, true, AUX>(c, base, tab, sh, rot, acc, &acc_aux);
             else if (fast)
                 run_segment<NT, MODE, false, false, AUX>(c, base, tab, sh, rot, acc, &acc_aux);
@@ -314,6 +329,18 @@ int launch_nt(const McorrArgs& a, int mode, size_t lds, hipStream_t stream)
     switch (mode)
         {
         case 0:
+            if constexpr (NT <= 5)
+                {
+                    if (a.packed == 2)
+                        {
+                            const size_t lds_runs = lds + static_cast<size_t>(MC_WAVES) * RunsLayout<MC_RUN_LEN>::FLOATS * sizeof(float);
+                            if (lds_runs <= 64 * 1024)  // beyond that the scratch costs more occupancy than the path gains
+                                {
+                                    hipLaunchKernelGGL((mcorr_kernel<NT, 0, false, true>), grid, block, lds_runs, stream, a);
+                                    break;
+                                }
+                        }
+                }
             hipLaunchKernelGGL((mcorr_kernel<NT, 0, false>), grid, block, lds, stream, a);
             break;
         case 1:
@@ -332,9 +359,12 @@ int launch_nt(const McorrArgs& a, int mode, size_t lds, hipStream_t stream)
 
 int mcorr_packed_default()
 {
+    // GSH_MC_PACKED_BODY: 0 the round-1 body, 1 the packed trips, 2 the run-based path where a job qualifies (A/B switch, read once)
     static const int v = [] {
         const char* e = std::getenv("GSH_MC_PACKED_BODY");
-        return (e != nullptr && e[0] == '0') ? 0 : 1;
+        if (e != nullptr && e[0] == '0') return 0;
+        if (e != nullptr && e[0] == '2') return 2;
+        return 1;
     }();
     return v;
 }
