@@ -3,6 +3,7 @@
  * \brief Thin C++ shell over the gsh_mcorr_* C ABI; see the header.
  */
 #include "hip_multicorrelator_real_codes.h"
+#include <string>
 #include "gnss_sdr_hip.h"
 #include <cstdlib>
 
@@ -48,6 +49,7 @@ void Hip_Multicorrelator_Real_Codes::set_high_dynamics_resampler(bool use_high_d
 bool Hip_Multicorrelator_Real_Codes::init(int max_signal_length_samples, int n_correlators)
 {
     d_n_correlators = n_correlators;
+    d_max_signal_length_samples = max_signal_length_samples;
     return ensure_handle() && check(gsh_mcorr_init(d_handle, max_signal_length_samples, n_correlators));
 }
 
@@ -62,6 +64,19 @@ bool Hip_Multicorrelator_Real_Codes::set_input_output_vectors(std::complex<float
 {
     d_corr_out = corr_out;
     return ensure_handle() && check(gsh_mcorr_set_input_output_vectors(d_handle, reinterpret_cast<float*>(corr_out), reinterpret_cast<const float*>(sig_in)));
+}
+
+
+void Hip_Multicorrelator_Real_Codes::update_local_code(int correlator_length_samples, float rem_code_phase_chips, float code_phase_step_chips,
+    float code_phase_rate_step_chips)
+{
+    // nothing to resample ahead of time (see the header); a call that the reference would turn into an out-of-bounds write is reported instead
+    (void)rem_code_phase_chips;
+    (void)code_phase_step_chips;
+    (void)code_phase_rate_step_chips;
+    if (correlator_length_samples < 0 || correlator_length_samples > d_max_signal_length_samples)
+        d_error = "update_local_code: correlator_length_samples " + std::to_string(correlator_length_samples) + " outside what init() sized (" +
+                  std::to_string(d_max_signal_length_samples) + ")";
 }
 
 

@@ -31,6 +31,11 @@ public:
     bool init(int max_signal_length_samples, int n_correlators);
     bool set_local_code_and_taps(int code_length_chips, const float* local_code_in, float* shifts_chips);
     bool set_input_output_vectors(std::complex<float>* corr_out, const std::complex<float>* sig_in);
+    /*! mcorr.h:46 / mcorr.cc:75-101.  In the reference this writes the n_correlators resampled replicas that the following dot products read; both
+     * Carrier_wipeoff overloads call it first (mcorr.cc:112, :137) and nothing else in the reference does.  On this engine the replicas never exist:
+     * the chip of every (tap, sample) is selected inside the correlation kernel by the same float32 expression.  The method is kept so that code
+     * written against the reference class compiles; it checks its arguments against what init() sized and otherwise does nothing. */
+    void update_local_code(int correlator_length_samples, float rem_code_phase_chips, float code_phase_step_chips, float code_phase_rate_step_chips = 0.0);
     bool Carrier_wipeoff_multicorrelator_resampler(float rem_carrier_phase_in_rad, float phase_step_rad, float phase_rate_step_rad,
         float rem_code_phase_chips, float code_phase_step_chips, float code_phase_rate_step_chips, int signal_length_samples);
     bool Carrier_wipeoff_multicorrelator_resampler(float rem_carrier_phase_in_rad, float phase_step_rad, float rem_code_phase_chips,
@@ -48,6 +53,7 @@ private:
     gsh_mcorr* d_handle{nullptr};
     std::complex<float>* d_corr_out{nullptr};  // borrowed (mcorr.cc:70)
     int d_n_correlators{0};
+    int d_max_signal_length_samples{0};
     int d_device{-1};
     bool d_use_high_dynamics_resampler{true};  // same default as the reference (mcorr.h:60)
     std::string d_error;

@@ -1,10 +1,11 @@
 """TEST INFRASTRUCTURE ONLY -- CPU restatement of gnss-sdr's pulse blanking input filter
 (src/algorithms/input_filter/gnuradio_blocks/pulse_blanking_cc.cc:33-106), statement by statement.
 
-Parity status: the block is a gr::block and its two VOLK calls (volk_32fc_magnitude_squared_32f, volk_32f_accumulator_s32f) are
-upstream VOLK, not vendored and not installed here, so it cannot be compiled: restated, NOT pinned.  The per-sample |x|^2 is the float
-expression VOLK's generic kernel forms; the segment sum is taken in float64 and rounded once (the reference's accumulator adds in
-float32 in an ISA-dependent lane order).  thres_ uses scipy's chi-squared survival inverse in place of boost::math::quantile(complement).
+Parity status: PINNED since round 2 -- the block itself (compiled in place into oracle/_ref/libgnsssdr_ref_filt.so against the GNU Radio mock, its two
+VOLK calls as their generic loops) gives the same outputs, bit for bit, the same consumed counts for every partition of the stream into scheduler calls and the
+same noise estimate to float round-off (tests/test_notch_oracle_pinned.py::test_pulse_blanking_block).  The per-sample |x|^2 is the float expression VOLK's
+generic kernel forms; the segment sum is taken in float64 and rounded once (the reference's accumulator adds in float32 in an ISA-dependent lane order).
+thres_ uses scipy's chi-squared survival inverse in place of boost::math::quantile(complement).
 """
 from __future__ import annotations
 

@@ -72,6 +72,10 @@ public:
     enum tag_propagation_policy_t { TPP_DONT = 0, TPP_ALL_TO_ALL = 1, TPP_ONE_TO_ONE = 2, TPP_CUSTOM = 3 };
     void consume_each(int how_many_items) { consumed_last = how_many_items; consumed_total += how_many_items; }
     void set_relative_rate(double) {}
+    void set_alignment(int) {}
+    void set_history(unsigned h) { d_history = h; }
+    unsigned history() const { return d_history; }
+    unsigned d_history{1};
     void set_relative_rate(uint64_t, uint64_t) {}
     void set_tag_propagation_policy(tag_propagation_policy_t) {}
     // stream position as the scheduler keeps it: the harness advances nitems_read by what the block consumed and nitems_written by what

@@ -96,6 +96,8 @@ int main()
                     }
                 rem_carr = std::fmod(rem_carr + phase_step * 7, 2.0 * M_PI);
             }
+        mc.update_local_code(vector_length, 0.25F, code_step);  // mcorr.h:46: compiles and is harmless (the replicas are never materialised)
+        EXPECT(mc.last_error().empty(), "update_local_code: %s", mc.last_error().c_str());
         EXPECT(mc.free(), "free");
         // use before init must fail loudly, not compute garbage
         Hip_Multicorrelator_Real_Codes cold;
