@@ -193,6 +193,11 @@ SYMBOLS = {
     "gsh_pb_threshold": (C.c_float, [_P]),
     "gsh_pb_process_device": (C.c_int, [_P, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64)]),
     "gsh_pb_get_state": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "gsh_notch_create": (C.c_int, [C.c_int, C.c_float, C.c_float, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "gsh_notch_destroy": (None, [_P]),
+    "gsh_notch_threshold": (C.c_float, [_P]),
+    "gsh_notch_process_device": (C.c_int, [_P, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64)]),
+    "gsh_notch_get_state": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
     "gsh_acq_set_doppler_center": (C.c_int, [_P, C.c_int32]),
     "gsh_acq_set_doppler_bias": (C.c_int, [_P, C.c_int32]),
     "gsh_acq_set_grid_weight": (C.c_int, [_P, C.c_float]),

@@ -189,6 +189,46 @@ class PulseBlanking:
         return float(noise.value), int(n.value), bool(last.value)
 
 
+class NotchFilter:
+    """gsh_notch_*: Notch (notch_cc.cc:33-140; n_segments_coeff = 0) or NotchLite (notch_lite_cc.cc:30-150; n_segments_coeff >= 1) on the device."""
+
+    def __init__(self, pfa: float = 0.001, p_c_factor: float = 0.9, length: int = 32, n_segments_est: int = 12500, n_segments_reset: int = 5000000,
+                 n_segments_coeff: int = 0, device: int = 0):
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        check(self._lib.gsh_notch_create(device, pfa, p_c_factor, length, n_segments_est, n_segments_reset, n_segments_coeff, C.byref(self._h)))
+        self.length = length
+
+    def close(self):
+        if self._h:
+            self._lib.gsh_notch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def threshold(self) -> float:
+        return float(self._lib.gsh_notch_threshold(self._h))
+
+    def process_device(self, d_in: int, n_items: int, d_out: int) -> int:
+        """One general_work call over n_items resident items (item 0: the sample in front of the first one processed); returns how many were
+        consumed (= produced; out[k] is the filtered in[k + 1])."""
+        done = C.c_uint64(0)
+        check(self._lib.gsh_notch_process_device(self._h, C.c_void_p(d_in), n_items, C.c_void_p(d_out), C.byref(done)))
+        return int(done.value)
+
+    def state(self) -> dict:
+        noise, n, fs, nc = C.c_float(0.0), C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        lo, z0 = (C.c_float * 2)(), (C.c_float * 2)()
+        check(self._lib.gsh_notch_get_state(self._h, C.byref(noise), C.byref(n), C.byref(fs), lo, C.byref(nc), z0))
+        return dict(noise_pow_est=float(noise.value), n_segments=int(n.value), filter_state=bool(fs.value), last_out=complex(lo[0], lo[1]),
+                    n_segments_coeff=int(nc.value), z0=complex(z0[0], z0[1]))
+
+
 class StreamGroup:
     """gsh_stream_group_*: one block replicated into the sample rings of several GPUs over RCCL (one process per GPU: from_rank; one process
     driving several GPUs: local)."""

@@ -30,7 +30,7 @@ extern "C"
 {
 #endif
 
-#define GSH_ABI_VERSION 18
+#define GSH_ABI_VERSION 19
 #define GSH_MAX_TAPS 8 /* VE/E/P/L/VL needs 5 (trk.cc:609-650); 8 leaves room for multi-tap dumps */
 
     enum
@@ -547,6 +547,25 @@ extern "C"
      * presents the remainder again, followed by new samples, like the GNU Radio scheduler does).  In-place (out == in) is allowed. */
     int gsh_pb_process_device(gsh_pb_t* p, const void* device_in_iq, uint64_t n_items, void* device_out_iq, uint64_t* n_done);
     int gsh_pb_get_state(gsh_pb_t* p, float* noise_power_estimation, int32_t* n_segments, int32_t* last_filtered);
+
+    /* Notch (src/algorithms/input_filter/gnuradio_blocks/notch_cc.cc:33-140; adapter Notch_Filter: pfa, p_c_factor, length, segments_est,
+     * segments_reset) and NotchLite (.../notch_lite_cc.cc:30-150; adapter Notch_Filter_Lite, n_segments_coeff = coeff_rate-derived) -- continuous-wave
+     * interference excision: segments of `length` samples whose energy over the estimated noise floor exceeds the chi-squared threshold for `pfa`
+     * go through  out[n] = in[n] - z0 in[n-1] + p_c_factor z0 out[n-1];  the others pass unchanged.  n_segments_coeff = 0: Notch (z0 per sample
+     * from the phase of in[n] conj(in[n-1])); >= 1: NotchLite (one z0 per that many filtered segments).  The floor estimate (FFT-based spectral
+     * noise floor of the first n_segments_est segments after each reset), the segment counter, the filter state and the last output live on the
+     * device and carry over between calls. */
+    typedef struct gsh_notch gsh_notch_t;
+    int gsh_notch_create(int device, float pfa, float p_c_factor, int32_t length, int32_t n_segments_est, int32_t n_segments_reset, int32_t n_segments_coeff,
+        gsh_notch_t** out);
+    void gsh_notch_destroy(gsh_notch_t* p);
+    float gsh_notch_threshold(const gsh_notch_t* p); /* thres_, notch_cc.cc:54-55 */
+    /* one general_work call over n_items resident complex64 items, of which item 0 is the sample IN FRONT of the first one processed (notch_cc.cc:71
+     * `in++`; NotchLite's set_history(2) item): whole segments are taken while (index + length) < n_items; *n_done = items consumed = samples produced
+     * (out[k] is the filtered in[k + 1]); the caller presents the rest again like the GNU Radio scheduler does.  Not in place. */
+    int gsh_notch_process_device(gsh_notch_t* p, const void* device_in_iq, uint64_t n_items, void* device_out_iq, uint64_t* n_done);
+    int gsh_notch_get_state(gsh_notch_t* p, float* noise_pow_est, int32_t* n_segments, int32_t* filter_state, float* last_out_iq, int32_t* n_segments_coeff,
+        float* z0_iq);
 
     /* Fine-Doppler step of pcps_acquisition_fine_doppler_cc (gnuradio_blocks/pcps_acquisition_fine_doppler_cc.cc:316-389): the
      * n complex64 samples x (host), multiplied element-wise by w when w != NULL (the aligned code replica: code wipe-off, :348), are
