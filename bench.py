@@ -230,6 +230,23 @@ def acquisition_metric(torch, dev_index, x_block, fs, pmc=None):
            "roofline": roof}
     acq.close()
     try:
+        # beyond one compute unit's plan: the 50 000-point batch of BASELINE config 5's rate (50 Msps x 1 ms) on the split plan 2 x (25, 25, 40)
+        n2 = 2 * n
+        x2 = torch.view_as_complex(torch.randn(n2, 2, device=x_block.device).contiguous())
+        acq2 = PcpsAcquisitionBank(fs_in=int(2 * fs), fft_size=n2, doppler_max=5000, doppler_step=250, num_doppler_bins=41, samples_per_chip=int(np.ceil(2 * fs / 1.023e6)),
+                                   samples_per_code=float(n2), max_prn=32, device=dev_index, keep_grid=False)
+        for p in range(32):
+            acq2.set_local_code(p, gps_l1_ca_code_sampled(p + 1, int(2 * fs)))
+        acq2.time_dwells(x2, 32, reps=100, pipelined=True)
+        ms2_serial = acq2.time_dwells(x2, 32, reps=20)
+        ms2 = acq2.time_dwells(x2, 32, reps=100, pipelined=True)
+        res["split_plan_50000"] = {"workload": "32 PRN x 41 Doppler bins, N=50000 (50 Msps x 1 ms), 1 dwell, plan 2 x (25,25,40)", "ms_per_batch": ms2,
+                                   "ms_per_batch_single_stream": ms2_serial, "value": 32.0 / (ms2 * 1e-3), "unit": "dwells/s",
+                                   "algorithmic_GBs": 16.0 * n2 * 41 * 33 / (ms2 * 1e-3) / 1e9}
+        acq2.close()
+    except Exception as e:
+        res["split_plan_50000"] = {"error": str(e)}
+    try:
         res["cpu_baseline"] = acquisition_cpu_baseline(x_block.cpu().numpy(), fs, n)
     except Exception as e:
         res["cpu_baseline"] = {"error": str(e)}
@@ -393,7 +410,7 @@ def tracking_roofline(C, E, T, n, k_ms, pmc):
     flops = float(C) * E * n * (6.0 + 4.0 * T)
     unique = 8.0 * (E + 1) * n + 4.0 * 1023 * C + 64.0 * n_jobs
     r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-         "kernel": f"mcorr_kernel<{3 if T <= 3 else (5 if T <= 5 else 8)},0,false>", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
+         "kernel": f"mcorr_kernel<{3 if T <= 3 else (5 if T <= 5 else 8)},0,false,false>", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
          "binding": "valu",
          "valu": {"algorithmic_flops_per_launch": flops, "achieved_tflops": flops / t / 1e12, "peak_tflops": FP32_PEAK_TFLOPS,
                   "frac": flops / t / 1e12 / FP32_PEAK_TFLOPS},

@@ -95,6 +95,38 @@ __device__ __forceinline__ int wrap_chip(int k, int len)
     return k;
 }
 
+// index i - MARGIN of the guard-banded table, i in [0, len + 2 MARGIN): one conditional add / subtract when the code is at least a margin long
+// (the general modulo costs ~30 instructions and ran for the whole wave in the first and last staging iteration)
+__device__ __forceinline__ int wrap_margin(int k, int len)
+{
+    if (len >= MC_MARGIN) return k < 0 ? k + len : (k >= len ? k - len : k);
+    return wrap_chip(k, len);
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_read0(float v)
+{
+    // lanes whose source is outside the row / whose row is masked off read 0.0f
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true));
+}
+
+// inclusive prefix sum over the 64 lanes of a wave
+__device__ __forceinline__ float wave_scan_incl(float v)
+{
+    v += dpp_read0<0x111, 0xf>(v);  // row_shr:1
+    v += dpp_read0<0x112, 0xf>(v);  // row_shr:2
+    v += dpp_read0<0x114, 0xf>(v);  // row_shr:4
+    v += dpp_read0<0x118, 0xf>(v);  // row_shr:8
+    v += dpp_read0<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+    v += dpp_read0<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+__device__ __forceinline__ float readlane_f(float v, int l)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+
 // (int)floor(x) in one VALU instruction (v_cvt_flr_i32_f32: round toward -inf, then convert)
 __device__ __forceinline__ int floor_to_int(float x)
 {
@@ -347,21 +379,16 @@ __device__ __forceinline__ v2f pk_add_shi(v2f v, v2f k)
 // the four samples (already zero where they lie outside the segment) and the sample indices the chip look-ups use (nfA / nfB: (float)n of
 // the pair; for a sample outside the segment the caller passes the nearest index INSIDE it, so that its look-up stays within what is
 // staged -- the chip index is monotone in n -- and no clamp is needed here: masked trips run the very same instructions).
+// (the four samples arrive already rotated by the trip's phasor: the caller rotates them first and then re-uses their registers for the loads of
+//  the trip PF ahead, so the prefetch queue needs no register copies)
 template <int NT, bool ZP, bool AUX, int NCH>
 __device__ __forceinline__ void packed_trip(const JobCtx& c, const float* __restrict__ tab, const v2f (&shp)[NT],
-    v2f k_step_nrem, v2f aux_shp, bool aux_on, v2f pa, v2f nfA, v2f nfB, float4 vA, float4 vB, v2f (&A0)[NT], v2f (&A1)[NT], v2f (&B0)[NT],
+    v2f k_step_nrem, v2f aux_shp, bool aux_on, v2f nfA, v2f nfB, v2f yA0, v2f yA1, v2f yB0, v2f yB1, v2f (&A0)[NT], v2f (&A1)[NT], v2f (&B0)[NT],
     v2f (&B1)[NT], v2f& XA0, v2f& XA1, v2f& XB0, v2f& XB1)
 {
     const v2f zero = {0.0f, 0.0f};
-    const v2f yA0 = pk_cmul((v2f){vA.x, vA.y}, pa);
-    const v2f yA1 = pk_cmul((v2f){vA.z, vA.w}, pa);
-    v2f yB0 = zero, yB1 = zero, aB = zero;
-    if (NCH == 2)
-        {
-            yB0 = pk_cmul((v2f){vB.x, vB.y}, pa);
-            yB1 = pk_cmul((v2f){vB.z, vB.w}, pa);
-            aB = pk_mul_slo(nfB, k_step_nrem);
-        }
+    v2f aB = zero;
+    if (NCH == 2) aB = pk_mul_slo(nfB, k_step_nrem);
     const v2f aA = pk_mul_slo(nfA, k_step_nrem);
     auto lookup = [&](v2f a, v2f sp, bool zero_shift, int k_off) -> v2f {
         v2f u;
@@ -539,19 +566,29 @@ __device__ __forceinline__ void run_segment_packed(const JobCtx& c, const float2
                         }
                     until_reseed--;
                     const bool plain = (i >= first_plain) && (i < last_plain);  // uniform
-                    const float4 vA = qa[j], vB = qb[j];
                     v2f ia = nfA, ib = nfB;
                     if (!plain)
                         {
                             // edge trip: a sample outside the segment (already zero) is looked up at the nearest sample inside it, so that its
-                            // chip index stays within what is staged
+                            // chip index stays within what is staged.  (The empty volatile asm keeps this a BRANCH: if-converted, its 16 clamp /
+                            // convert / select instructions ran in every trip -- a fifth of the loop's VALU work, ISA of round 2.)
+                            asm volatile("" ::: "memory");
                             const int lo = c.n_begin, hi = c.n_end - 1;
                             ia = (v2f){static_cast<float>(min(max(n0, lo), hi)), static_cast<float>(min(max(n0 + 1, lo), hi))};
                             const int m0 = n0 + 2 * PPC;
                             if (NCH == 2) ib = (v2f){static_cast<float>(min(max(m0, lo), hi)), static_cast<float>(min(max(m0 + 1, lo), hi))};
                         }
-                    if (i + PF < n_trips) load_trip(i + PF, qa[j], qb[j]);  // uniform: the loads of trip i + PF take this trip's place in the queue
-                    packed_trip<NT, ZP, AUX, NCH>(c, tab, shp, k_step_nrem, aux_shp, aux_on, pa, ia, ib, vA, vB, A0, A1, B0, B1, XA0, XA1, XB0, XB1);
+                    // rotate first: the samples' registers are then free for the loads of trip i + PF, which take this trip's place in the queue
+                    const v2f yA0 = pk_cmul((v2f){qa[j].x, qa[j].y}, pa);
+                    const v2f yA1 = pk_cmul((v2f){qa[j].z, qa[j].w}, pa);
+                    v2f yB0 = zero, yB1 = zero;
+                    if (NCH == 2)
+                        {
+                            yB0 = pk_cmul((v2f){qb[j].x, qb[j].y}, pa);
+                            yB1 = pk_cmul((v2f){qb[j].z, qb[j].w}, pa);
+                        }
+                    if (i + PF < n_trips) load_trip(i + PF, qa[j], qb[j]);  // uniform
+                    packed_trip<NT, ZP, AUX, NCH>(c, tab, shp, k_step_nrem, aux_shp, aux_on, ia, ib, yA0, yA1, yB0, yB1, A0, A1, B0, B1, XA0, XA1, XB0, XB1);
                     pa = pk_cmul(pa, w2);
                     asm("v_pk_add_f32 %0, %0, %1" : "+v"(nfA) : "v"(stride));
                     if (NCH == 2) asm("v_pk_add_f32 %0, %0, %1" : "+v"(nfB) : "v"(stride));
@@ -605,30 +642,6 @@ struct RunsLayout
     static constexpr int Y_F2 = 64 * STRIDE;  // float2
     static constexpr int FLOATS = 2 * (Y_F2 + 64 + 64);  // y / q buffer, (E_i, ph_i) per run
 };
-
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_read0(float v)
-{
-    // lanes whose source is outside the row / whose row is masked off read 0.0f
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true));
-}
-
-// inclusive prefix sum over the 64 lanes of a wave
-__device__ __forceinline__ float wave_scan_incl(float v)
-{
-    v += dpp_read0<0x111, 0xf>(v);  // row_shr:1
-    v += dpp_read0<0x112, 0xf>(v);  // row_shr:2
-    v += dpp_read0<0x114, 0xf>(v);  // row_shr:4
-    v += dpp_read0<0x118, 0xf>(v);  // row_shr:8
-    v += dpp_read0<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
-    v += dpp_read0<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
-    return v;
-}
-
-__device__ __forceinline__ float readlane_f(float v, int l)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
-}
 
 template <int NT, int R>
 __device__ __forceinline__ void run_segment_runs(const JobCtx& c, const float2* __restrict__ base, const float* __restrict__ tab, const float (&sh)[NT],
@@ -995,46 +1008,41 @@ __device__ __forceinline__ void correlate_window(const float2* __restrict__ stre
             else
                 run_segment<NT, MODE, true, false, AUX>(c, base, tab, sh, rot, acc, &acc_aux);
         }
+    // wave sums in DPP steps (the last lane holds them), one row of partials per wave behind the output row, one LDS step over the waves.
+    // Outputs (red[0..NOUT)) and partials (red[GSH_MAX_TAPS ..)) do not overlap, so a call needs two barriers, not three: the caller reads the
+    // outputs and passes a barrier of its own before the next call writes them again.
 #pragma unroll
     for (int t = 0; t < NT; t++)
         {
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1)
-                {
-                    acc[t].x += __shfl_down(acc[t].x, off, 64);
-                    acc[t].y += __shfl_down(acc[t].y, off, 64);
-                }
+            acc[t].x = wave_scan_incl(acc[t].x);
+            acc[t].y = wave_scan_incl(acc[t].y);
         }
     if (AUX)
         {
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1)
-                {
-                    acc_aux.x += __shfl_down(acc_aux.x, off, 64);
-                    acc_aux.y += __shfl_down(acc_aux.y, off, 64);
-                }
+            acc_aux.x = wave_scan_incl(acc_aux.x);
+            acc_aux.y = wave_scan_incl(acc_aux.y);
         }
     const int wave = tid >> 6;
-    if ((tid & 63) == 0)
+    float2* const part = red + GSH_MAX_TAPS;
+    if ((tid & 63) == 63)
         {
 #pragma unroll
-            for (int t = 0; t < NT; t++) red[wave * GSH_MAX_TAPS + t] = acc[t];
-            if (AUX) red[wave * GSH_MAX_TAPS + NT] = acc_aux;
+            for (int t = 0; t < NT; t++) part[wave * GSH_MAX_TAPS + t] = acc[t];
+            if (AUX) part[wave * GSH_MAX_TAPS + NT] = acc_aux;
         }
     __syncthreads();
     constexpr int NOUT = AUX ? NT + 1 : NT;
-    float2 s = make_float2(0.0f, 0.0f);
     if (tid < NOUT)
         {
+            float2 s = make_float2(0.0f, 0.0f);
 #pragma unroll
             for (int w = 0; w < MC_WAVES; w++)
                 {
-                    s.x += red[w * GSH_MAX_TAPS + tid].x;
-                    s.y += red[w * GSH_MAX_TAPS + tid].y;
+                    s.x += part[w * GSH_MAX_TAPS + tid].x;
+                    s.y += part[w * GSH_MAX_TAPS + tid].y;
                 }
+            red[tid] = s;
         }
-    __syncthreads();
-    if (tid < NOUT) red[tid] = s;
     __syncthreads();
 }
 

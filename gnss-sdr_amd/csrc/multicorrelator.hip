@@ -147,7 +147,7 @@ __global__ __launch_bounds__(MC_THREADS, ((NT <= 3 && !AUX) ? GSH_MC_MIN_WAVES :
     else
         {
             const int tab_len = c.code_len + 2 * MC_MARGIN;
-            for (int i = tid; i < tab_len; i += MC_THREADS) tab[i] = gcode[wrap_chip(i - MC_MARGIN, c.code_len)];
+            for (int i = tid; i < tab_len; i += MC_THREADS) tab[i] = gcode[wrap_margin(i - MC_MARGIN, c.code_len)];
             lds_floats = AUX ? a.code_stride + 2 * MC_MARGIN : tab_len;
         }
     // ---- the fused correlator's code (AUX): a second table behind the first
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(MC_THREADS, ((NT <= 3 && !AUX) ? GSH_MC_MIN_WAVES :
             else
                 {
                     const int tab_len2 = c.aux_code_len + 2 * MC_MARGIN;
-                    for (int i = tid; i < tab_len2; i += MC_THREADS) tab[aux_base + i] = gcode2[wrap_chip(i - MC_MARGIN, c.aux_code_len)];
+                    for (int i = tid; i < tab_len2; i += MC_THREADS) tab[aux_base + i] = gcode2[wrap_margin(i - MC_MARGIN, c.aux_code_len)];
                     c.aux_k_off = aux_base + MC_MARGIN;
                     aux_fast = (lo2 >= -MC_MARGIN) && (hi2 < c.aux_code_len + MC_MARGIN) && (c.aux_code_len >= MC_MARGIN);
                 }
@@ -227,28 +227,21 @@ __global__ __launch_bounds__(MC_THREADS, ((NT <= 3 && !AUX) ? GSH_MC_MIN_WAVES :
                 run_segment<NT, MODE, true, false, AUX>(c, base, tab, sh, rot, acc, &acc_aux);
         }
 
-    // ---- integrate-and-dump: wave64 shuffle tree, then one LDS step over the 4 waves
+    // ---- integrate-and-dump: wave64 prefix sum in DPP steps (the last lane holds the wave's sum; six v_add_f32_dpp per value instead of the
+    // ds_bpermute + address + add of a shuffle tree), then one LDS step over the 4 waves
 #pragma unroll
     for (int t = 0; t < NT; t++)
         {
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1)
-                {
-                    acc[t].x += __shfl_down(acc[t].x, off, 64);
-                    acc[t].y += __shfl_down(acc[t].y, off, 64);
-                }
+            acc[t].x = wave_scan_incl(acc[t].x);
+            acc[t].y = wave_scan_incl(acc[t].y);
         }
     if (AUX)
         {
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1)
-                {
-                    acc_aux.x += __shfl_down(acc_aux.x, off, 64);
-                    acc_aux.y += __shfl_down(acc_aux.y, off, 64);
-                }
+            acc_aux.x = wave_scan_incl(acc_aux.x);
+            acc_aux.y = wave_scan_incl(acc_aux.y);
         }
     const int wave = tid >> 6;
-    if ((tid & 63) == 0)
+    if ((tid & 63) == 63)
         {
 #pragma unroll
             for (int t = 0; t < NT; t++) red[wave * GSH_MAX_TAPS + t] = acc[t];

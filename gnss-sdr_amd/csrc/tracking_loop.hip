@@ -1043,7 +1043,7 @@ using gsh::set_error;
 size_t trk_lds_bytes(const gsh_trk* t)
 {
     const size_t tabs = static_cast<size_t>(gsh::mcdev::code_table_floats(t->max_code_len)) * (t->conf.track_pilot ? 2 : 1);
-    return tabs * sizeof(float) + gsh::mcdev::MC_WAVES * GSH_MAX_TAPS * sizeof(float2);
+    return tabs * sizeof(float) + (gsh::mcdev::MC_WAVES + 1) * GSH_MAX_TAPS * sizeof(float2);  // outputs + one row of partial sums per wave (correlate_window)
 }
 
 int trk_launch(gsh_trk* t, int n_epochs, gsh_trk_epoch* d_records)

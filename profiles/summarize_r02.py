@@ -77,7 +77,7 @@ def main():
         lines.append(f"\ncalibration: torch sum over 1 GiB -> FETCH_SIZE {cal[k]['FETCH_SIZE']:.0f} KiB per launch -> read_factor = {rf:.3f}")
     legs = {name: read_counters(os.path.join(d, name)) for name in ("fetch", "write", "sq1", "sq2", "tcc")}
     out = {}
-    for label, sub, extra in (("mcorr", "mcorr_kernel<3, 0, false>", {}), ("oc_cell", "oc_cell_kernel", {}), ("oc_forward", "oc_forward_kernel", {}),
+    for label, sub, extra in (("mcorr", "mcorr_kernel<3, 0, false", {}), ("oc_cell", "oc_cell_kernel", {}), ("oc_forward", "oc_forward_kernel", {}),
                               ("trk_loop", "trk_loop_kernel<3, false>", {})):
         rec = {}
         for leg in legs.values():
