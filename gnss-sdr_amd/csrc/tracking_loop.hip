@@ -1255,7 +1255,7 @@ extern "C"
         if (first_prn_length_samples != nullptr) *first_prn_length_samples = static_cast<int32_t>(std::round(T_prn_mod_samples));
         if (acc_carrier_phase_rad != nullptr)
             {
-                const double carrier_phase_step_rad = gsh::GNSS_TWO_PI_D * acq_carrier_doppler_hz / conf->fs_in;  // start_tracking, trk.cc:800-801
+                const double carrier_phase_step_rad = gsh::GNSS_TWO_PI_D * (acq_carrier_doppler_hz + conf->cfo_frequency_hz) / conf->fs_in;  // start_tracking, trk.cc:800-801; Glonass: + the FDMA channel offset, :1003
                 *acc_carrier_phase_rad = 0.0 - carrier_phase_step_rad * static_cast<double>(offset);           // :1966 (d_acc_carrier_phase_rad is 0 after start_tracking)
             }
         return GSH_OK;
@@ -1293,7 +1293,7 @@ extern "C"
         gsh::TrkChannel s{};
         // start_tracking, trk.cc:803-826, and the pull-in state, :1956-1958
         s.carrier_doppler_hz = acq_carrier_doppler_hz;
-        s.carrier_phase_step_rad = gsh::GNSS_TWO_PI_D * s.carrier_doppler_hz / c.fs_in;
+        s.carrier_phase_step_rad = gsh::GNSS_TWO_PI_D * (s.carrier_doppler_hz + c.cfo_frequency_hz) / c.fs_in;  // trk.cc:801, :1003
         s.code_freq_chips = c.code_chip_rate;
         s.code_phase_step_chips = s.code_freq_chips / c.fs_in;
         s.rem_code_phase_samples = 0.0;

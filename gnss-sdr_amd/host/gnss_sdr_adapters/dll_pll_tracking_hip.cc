@@ -3,10 +3,17 @@
  * \brief TrackingInterface adapters over the MI355X device-closed DLL/PLL loop; see the header.
  */
 #include "dll_pll_tracking_hip.h"
+#include "Beidou_B1I.h"
+#include "Beidou_B3I.h"
+#include "GLONASS_L1_L2_CA.h"
 #include "GPS_L1_CA.h"
+#include "GPS_L2C.h"
 #include "GPS_L5.h"
 #include "Galileo_E1.h"
 #include "Galileo_E5a.h"
+#include "Galileo_E5b.h"
+#include "Galileo_E6.h"
+#include "qzss.h"
 #include "configuration_interface.h"
 #include <algorithm>
 #include <array>
@@ -222,5 +229,186 @@ GalileoE5aDllPllTrackingHip::GalileoE5aDllPllTrackingHip(const ConfigurationInte
             std::cout << "WARNING: Galileo E5a. extend_correlation_symbols must be lower than 21 when tracking the data component. Coherent integration has been set to 20 symbols (20 ms)\n";
         }
     warn_narrow(p, "Galileo E5a");
+    create_tracking_block(configuration);
+}
+
+
+namespace
+{
+// the checks most adapters share: extend_correlation_symbols in [1, limit], no pilot component
+void clamp_extend(Dll_Pll_Conf& p, int limit, const char* name, const char* unit)
+{
+    if (p.extend_correlation_symbols < 1)
+        {
+            p.extend_correlation_symbols = 1;
+            std::cout << "WARNING: " << name << ": extend_correlation_symbols must be > 0. Coherent integration set to 1 " << unit << ".\n";
+        }
+    else if (p.extend_correlation_symbols > limit)
+        {
+            p.extend_correlation_symbols = limit;
+            std::cout << "WARNING: " << name << ": extend_correlation_symbols limited to " << limit << ".\n";
+        }
+}
+
+void no_pilot(Dll_Pll_Conf& p, const ConfigurationInterface* configuration, const std::string& role, const char* name)
+{
+    p.track_pilot = configuration->property(role + ".track_pilot", false);
+    if (p.track_pilot)
+        {
+            p.track_pilot = false;
+            std::cout << "WARNING: " << name << " does not have pilot signal. Data tracking enabled instead.\n";
+        }
+}
+
+uint32_t period_samples(double fs_in, double chip_rate, double code_length_chips) { return static_cast<uint32_t>(static_cast<int>(std::round(fs_in / (chip_rate / code_length_chips)))); }
+}  // namespace
+
+
+GpsL2MDllPllTrackingHip::GpsL2MDllPllTrackingHip(const ConfigurationInterface* configuration, const std::string& role, unsigned int in_streams, unsigned int out_streams)
+    : DllPllTrackingHip(configuration, role, in_streams, out_streams)
+{
+    // gps_l2_m_dll_pll_tracking.cc: one 20 ms code period per symbol, no extended integration, no pilot
+    Dll_Pll_Conf& p = config_params();
+    p.vector_length = period_samples(static_cast<double>(p.fs_in), GPS_L2_M_CODE_RATE_CPS, GPS_L2_M_CODE_LENGTH_CHIPS);
+    if (p.extend_correlation_symbols != 1)
+        {
+            p.extend_correlation_symbols = 1;
+            std::cout << "WARNING: Extended coherent integration is not allowed in GPS L2. Coherent integration has been set to 20 ms (1 symbol)\n";
+        }
+    no_pilot(p, configuration, role, "GPS L2");
+    set_signal(p, 'G', '2', 'S');
+    create_tracking_block(configuration);
+}
+
+
+GalileoE5bDllPllTrackingHip::GalileoE5bDllPllTrackingHip(const ConfigurationInterface* configuration, const std::string& role, unsigned int in_streams, unsigned int out_streams)
+    : DllPllTrackingHip(configuration, role, in_streams, out_streams)
+{
+    Dll_Pll_Conf& p = config_params();
+    p.vector_length = period_samples(static_cast<double>(p.fs_in), GALILEO_E5B_CODE_CHIP_RATE_CPS, GALILEO_E5B_CODE_LENGTH_CHIPS);
+    if (p.extend_correlation_symbols < 1)
+        {
+            p.extend_correlation_symbols = 1;
+            std::cout << "WARNING: Galileo E5b. extend_correlation_symbols must be bigger than 0. Coherent integration has been set to 1 symbol (1 ms)\n";
+        }
+    else if (!p.track_pilot && p.extend_correlation_symbols > GALILEO_E5B_I_SECONDARY_CODE_LENGTH)
+        {
+            p.extend_correlation_symbols = GALILEO_E5B_I_SECONDARY_CODE_LENGTH;
+            std::cout << "WARNING: Galileo E5b. extend_correlation_symbols must be lower than 5 when tracking the data component. Coherent integration has been set to 4 symbols (4 ms)\n";
+        }
+    warn_narrow(p, "Galileo E5b");
+    set_signal(p, 'E', '7', 'X');
+    create_tracking_block(configuration);
+}
+
+
+GalileoE6DllPllTrackingHip::GalileoE6DllPllTrackingHip(const ConfigurationInterface* configuration, const std::string& role, unsigned int in_streams, unsigned int out_streams)
+    : DllPllTrackingHip(configuration, role, in_streams, out_streams)
+{
+    // galileo_e6_dll_pll_tracking.cc.  NOTE: the reference adapter of the version at hand writes the signal tag {'5', 'X'} (its :62-64), so the block it
+    // creates takes the E5a branch of its constructor with E6's window length.  <role>.hip_signal_e6 = true (default) hands the block "E6" -- the
+    // branch the reference block itself has for this signal (trk.cc:349-372, :904-921); false reproduces the adapter as written.
+    Dll_Pll_Conf& p = config_params();
+    p.vector_length = period_samples(static_cast<double>(p.fs_in), GALILEO_E6_B_CODE_CHIP_RATE_CPS, GALILEO_E6_B_CODE_LENGTH_CHIPS);
+    if (configuration->property(role + ".hip_signal_e6", true))
+        set_signal(p, 'E', 'E', '6');
+    else
+        set_signal(p, 'E', '5', 'X');
+    if (p.extend_correlation_symbols < 1)
+        {
+            p.extend_correlation_symbols = 1;
+            std::cout << "WARNING: Galileo E6. extend_correlation_symbols must be bigger than 0. Coherent integration has been set to 1 symbol (1 ms)\n";
+        }
+    else if (!p.track_pilot && p.extend_correlation_symbols > 1)
+        {
+            p.extend_correlation_symbols = 1;
+            std::cout << "WARNING: Galileo E6. Extended coherent integration is not allowed when tracking the data component. Coherent integration has been set to 1 ms (1 symbol)\n";
+        }
+    warn_narrow(p, "Galileo E6");
+    create_tracking_block(configuration);
+}
+
+
+BeidouB1iDllPllTrackingHip::BeidouB1iDllPllTrackingHip(const ConfigurationInterface* configuration, const std::string& role, unsigned int in_streams, unsigned int out_streams)
+    : DllPllTrackingHip(configuration, role, in_streams, out_streams)
+{
+    Dll_Pll_Conf& p = config_params();
+    p.vector_length = period_samples(static_cast<double>(p.fs_in), BEIDOU_B1I_CODE_RATE_CPS, BEIDOU_B1I_CODE_LENGTH_CHIPS);
+    set_signal(p, 'C', 'B', '1');
+    clamp_extend(p, 20, "BEIDOU B1I", "symbol (1 ms)");
+    no_pilot(p, configuration, role, "BEIDOU B1I");
+    warn_narrow(p, "BEIDOU B1I");
+    create_tracking_block(configuration);
+}
+
+
+BeidouB3iDllPllTrackingHip::BeidouB3iDllPllTrackingHip(const ConfigurationInterface* configuration, const std::string& role, unsigned int in_streams, unsigned int out_streams)
+    : DllPllTrackingHip(configuration, role, in_streams, out_streams)
+{
+    Dll_Pll_Conf& p = config_params();
+    p.vector_length = period_samples(static_cast<double>(p.fs_in), BEIDOU_B3I_CODE_RATE_CPS, BEIDOU_B3I_CODE_LENGTH_CHIPS);
+    set_signal(p, 'C', 'B', '3');
+    p.track_pilot = configuration->property(role + ".track_pilot", false);  // beidou_b3i_dll_pll_tracking.cc reads the key; the block ignores it (trk.cc:442)
+    clamp_extend(p, 20, "BEIDOU B3I", "symbol (1 ms)");
+    create_tracking_block(configuration);
+}
+
+
+GlonassL1CaDllPllTrackingHip::GlonassL1CaDllPllTrackingHip(const ConfigurationInterface* configuration, const std::string& role, unsigned int in_streams, unsigned int out_streams)
+    : DllPllTrackingHip(configuration, role, in_streams, out_streams)
+{
+    Dll_Pll_Conf& p = config_params();
+    set_signal(p, 'R', '1', 'G');
+    p.vector_length = period_samples(static_cast<double>(p.fs_in), GLONASS_L1_CA_CODE_RATE_CPS, GLONASS_L1_CA_CODE_LENGTH_CHIPS);
+    clamp_extend(p, 10, "Glonass L1", "ms");
+    no_pilot(p, configuration, role, "Glonass L1");
+    warn_narrow(p, "Glonass L1");
+    create_tracking_block(configuration);
+}
+
+
+GlonassL2CaDllPllTrackingHip::GlonassL2CaDllPllTrackingHip(const ConfigurationInterface* configuration, const std::string& role, unsigned int in_streams, unsigned int out_streams)
+    : DllPllTrackingHip(configuration, role, in_streams, out_streams)
+{
+    Dll_Pll_Conf& p = config_params();
+    set_signal(p, 'R', '2', 'G');
+    p.vector_length = period_samples(static_cast<double>(p.fs_in), GLONASS_L2_CA_CODE_RATE_CPS, GLONASS_L2_CA_CODE_LENGTH_CHIPS);
+    clamp_extend(p, 10, "Glonass L2", "ms");
+    no_pilot(p, configuration, role, "Glonass L2");
+    warn_narrow(p, "Glonass L2");
+    create_tracking_block(configuration);
+}
+
+
+QzssL1DllPllTrackingHip::QzssL1DllPllTrackingHip(const ConfigurationInterface* configuration, const std::string& role, unsigned int in_streams, unsigned int out_streams)
+    : DllPllTrackingHip(configuration, role, in_streams, out_streams)
+{
+    Dll_Pll_Conf& p = config_params();
+    set_signal(p, 'J', 'J', '1');
+    p.vector_length = period_samples(static_cast<double>(p.fs_in), QZSS_L1_CHIP_RATE, QZSS_L1_CODE_LENGTH);
+    clamp_extend(p, 20, "QZSS L1 C/A", "ms");
+    no_pilot(p, configuration, role, "QZSS L1 C/A");
+    warn_narrow(p, "QZSS L1 C/A");
+    create_tracking_block(configuration);
+}
+
+
+QzssL5DllPllTrackingHip::QzssL5DllPllTrackingHip(const ConfigurationInterface* configuration, const std::string& role, unsigned int in_streams, unsigned int out_streams)
+    : DllPllTrackingHip(configuration, role, in_streams, out_streams)
+{
+    Dll_Pll_Conf& p = config_params();
+    p.vector_length = period_samples(static_cast<double>(p.fs_in), static_cast<double>(QZSS_L5_CHIP_RATE), static_cast<double>(QZSS_L5_CODE_LENGTH));
+    if (p.extend_correlation_symbols < 1)
+        {
+            p.extend_correlation_symbols = 1;
+            std::cout << "WARNING: QZSS L5. extend_correlation_symbols must be bigger than 0. Coherent integration has been set to 1 symbol (1 ms)\n";
+        }
+    else if (!p.track_pilot && p.extend_correlation_symbols > QZSS_L5I_NH_CODE_LENGTH)
+        {
+            p.extend_correlation_symbols = QZSS_L5I_NH_CODE_LENGTH;
+            std::cout << "WARNING: QZSS L5. extend_correlation_symbols must be lower than 11 when tracking the data component. Coherent integration has been set to 10 symbols (10 ms)\n";
+        }
+    warn_narrow(p, "QZSS L5");
+    set_signal(p, 'J', 'J', '5');
     create_tracking_block(configuration);
 }

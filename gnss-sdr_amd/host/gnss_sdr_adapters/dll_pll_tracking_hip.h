@@ -1,7 +1,7 @@
 /*!
  * \file dll_pll_tracking_hip.h
  * \brief TrackingInterface adapters over the MI355X device-closed DLL/PLL loop: DllPllTrackingHip and one class per signal
- *        (GPS L1 C/A, Galileo E1, GPS L5, Galileo E5a).
+ *        of the reference's dll_pll_veml_tracking family (GPS L1 C/A, L2C, L5; Galileo E1, E5a, E5b, E6; BeiDou B1I, B3I; GLONASS L1, L2; QZSS L1, L5).
  *
  * These derive DIRECTLY from TrackingInterface (src/core/interfaces/tracking_interface.h:47-54): the reference's BaseDllPllTracking
  * holds a concrete dll_pll_veml_tracking_sptr (src/algorithms/tracking/adapters/base_dll_pll_tracking.h:115) and cannot carry another
@@ -93,5 +93,24 @@ public:
     GalileoE5aDllPllTrackingHip(const ConfigurationInterface* configuration, const std::string& role, unsigned int in_streams, unsigned int out_streams);
     inline std::string implementation() override { return "Galileo_E5a_DLL_PLL_Tracking_HIP"; }
 };
+
+// The remaining signals of the family: the same block, other constants (trk.cc:196-596) and replica generators (:812-1030).
+#define GSH_DECLARE_TRACKING_ADAPTER(CLASS, NAME)                                                                                             \
+    class CLASS : public DllPllTrackingHip                                                                                                   \
+    {                                                                                                                                        \
+    public:                                                                                                                                  \
+        CLASS(const ConfigurationInterface* configuration, const std::string& role, unsigned int in_streams, unsigned int out_streams);     \
+        inline std::string implementation() override { return NAME; }                                                                       \
+    };
+GSH_DECLARE_TRACKING_ADAPTER(GpsL2MDllPllTrackingHip, "GPS_L2_M_DLL_PLL_Tracking_HIP")            //!< gps_l2_m_dll_pll_tracking.cc
+GSH_DECLARE_TRACKING_ADAPTER(GalileoE5bDllPllTrackingHip, "Galileo_E5b_DLL_PLL_Tracking_HIP")    //!< galileo_e5b_dll_pll_tracking.cc
+GSH_DECLARE_TRACKING_ADAPTER(GalileoE6DllPllTrackingHip, "Galileo_E6_DLL_PLL_Tracking_HIP")      //!< galileo_e6_dll_pll_tracking.cc
+GSH_DECLARE_TRACKING_ADAPTER(BeidouB1iDllPllTrackingHip, "BEIDOU_B1I_DLL_PLL_Tracking_HIP")      //!< beidou_b1i_dll_pll_tracking.cc
+GSH_DECLARE_TRACKING_ADAPTER(BeidouB3iDllPllTrackingHip, "BEIDOU_B3I_DLL_PLL_Tracking_HIP")      //!< beidou_b3i_dll_pll_tracking.cc
+GSH_DECLARE_TRACKING_ADAPTER(GlonassL1CaDllPllTrackingHip, "GLONASS_L1_CA_DLL_PLL_Tracking_HIP") //!< glonass_l1_ca_dll_pll_tracking.cc
+GSH_DECLARE_TRACKING_ADAPTER(GlonassL2CaDllPllTrackingHip, "GLONASS_L2_CA_DLL_PLL_Tracking_HIP") //!< glonass_l2_ca_dll_pll_tracking.cc
+GSH_DECLARE_TRACKING_ADAPTER(QzssL1DllPllTrackingHip, "QZSS_L1_CA_DLL_PLL_Tracking_HIP")         //!< qzss_l1_dll_pll_tracking.cc
+GSH_DECLARE_TRACKING_ADAPTER(QzssL5DllPllTrackingHip, "QZSS_L5_DLL_PLL_Tracking_HIP")            //!< qzss_l5_dll_pll_tracking.cc
+#undef GSH_DECLARE_TRACKING_ADAPTER
 
 #endif  // GNSS_SDR_DLL_PLL_TRACKING_HIP_H

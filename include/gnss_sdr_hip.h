@@ -30,7 +30,7 @@ extern "C"
 {
 #endif
 
-#define GSH_ABI_VERSION 19
+#define GSH_ABI_VERSION 20
 #define GSH_MAX_TAPS 8 /* VE/E/P/L/VL needs 5 (trk.cc:609-650); 8 leaves room for multi-tap dumps */
 
     enum
@@ -303,8 +303,8 @@ extern "C"
         int32_t secondary_code_length;   /* d_secondary_code_length, <= GSH_MAX_SECONDARY */
         int32_t data_secondary_code_length; /* d_data_secondary_code_length */
         int32_t extend_correlation_symbols; /* Dll_Pll_Conf::extend_correlation_symbols (1) */
-        uint8_t secondary_code[200];     /* characters '0' / '1' (d_secondary_code_string) */
-        uint8_t data_secondary_code[200];
+        uint8_t secondary_code[320];     /* characters '0' / '1' (d_secondary_code_string) */
+        uint8_t data_secondary_code[320];
         float pll_bw_narrow_hz;          /* (5.0)  dll_pll_conf.h:49 */
         float dll_bw_narrow_hz;          /* (0.75) */
         float early_late_space_narrow_chips;      /* (0.15) */
@@ -323,7 +323,7 @@ extern "C"
 #define GSH_MAX_BITSYNC_BINS 64
 #define GSH_MAX_SMOOTHER 32
 #define GSH_MAX_CN0_SAMPLES 64
-#define GSH_MAX_SECONDARY 200
+#define GSH_MAX_SECONDARY 320  /* the longest pattern the reference correlates: the 300-symbol GLONASS GNAV preamble */
 
     typedef struct gsh_trk_epoch         /* what log_data dumps per period (trk.cc:1599-1702), POD */
     {

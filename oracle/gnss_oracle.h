@@ -126,7 +126,7 @@ extern "C"
     void oracle_smoother_reset(oracle_smoother* s);
     float oracle_smoother_smooth(oracle_smoother* s, float raw);
 #define ORACLE_MAX_CN0_SAMPLES 64
-#define ORACLE_MAX_SECONDARY 200
+#define ORACLE_MAX_SECONDARY 320
     typedef struct oracle_lock_state  /* the members cn0_and_tracking_lock_status touches (trk.cc:1167-1224) */
     {
         float prompt_buffer[2 * ORACLE_MAX_CN0_SAMPLES];

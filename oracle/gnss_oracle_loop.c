@@ -591,7 +591,7 @@ int oracle_trk_run(const oracle_trk_conf* c, const float* code, const float* dat
 
     /* start_tracking :803-826 + pull-in :1956-1958 */
     double carrier_doppler_hz = acq_carrier_doppler_hz;
-    double carrier_phase_step_rad = ORA_TWO_PI * carrier_doppler_hz / c->fs_in;
+    double carrier_phase_step_rad = ORA_TWO_PI * (carrier_doppler_hz + c->cfo_frequency_hz) / c->fs_in;  /* trk.cc:801; Glonass :1003 */
     double code_freq_chips = c->code_chip_rate;
     double code_phase_step_chips = code_freq_chips / c->fs_in;
     double rem_code_phase_samples = 0.0, rem_code_phase_chips = 0.0, acc_carrier_phase_rad = 0.0;

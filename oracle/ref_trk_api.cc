@@ -44,9 +44,19 @@
 #include "base_dll_pll_tracking.h"
 #undef protected
 #undef private
+#include "beidou_b1i_dll_pll_tracking.h"
+#include "beidou_b3i_dll_pll_tracking.h"
 #include "galileo_e1_dll_pll_veml_tracking.h"
+#include "galileo_e5a_dll_pll_tracking.h"
+#include "galileo_e5b_dll_pll_tracking.h"
+#include "galileo_e6_dll_pll_tracking.h"
+#include "glonass_l1_ca_dll_pll_tracking.h"
+#include "glonass_l2_ca_dll_pll_tracking.h"
 #include "gps_l1_ca_dll_pll_tracking.h"
+#include "gps_l2_m_dll_pll_tracking.h"
 #include "gps_l5_dll_pll_tracking.h"
+#include "qzss_l1_dll_pll_tracking.h"
+#include "qzss_l5_dll_pll_tracking.h"
 
 namespace
 {
@@ -54,6 +64,7 @@ struct Handle
 {
     InMemoryConfiguration cfg;
     std::shared_ptr<TrackingInterface> adapter;
+    dll_pll_veml_tracking_sptr own_block;  // reftrk_create_block: the block without an adapter around it
     dll_pll_veml_tracking* block{nullptr};
     Gnss_Synchro synchro{};
     std::vector<Gnss_Synchro> out_items;
@@ -110,6 +121,26 @@ void* reftrk_create(const char* implementation, const char* role, const char* co
                 h->adapter = std::make_shared<GalileoE1DllPllVemlTracking>(&h->cfg, role, 1, 1);
             else if (impl == "GPS_L5_DLL_PLL_Tracking")
                 h->adapter = std::make_shared<GpsL5DllPllTracking>(&h->cfg, role, 1, 1);
+            else if (impl == "GPS_L2_M_DLL_PLL_Tracking")
+                h->adapter = std::make_shared<GpsL2MDllPllTracking>(&h->cfg, role, 1, 1);
+            else if (impl == "Galileo_E5a_DLL_PLL_Tracking")
+                h->adapter = std::make_shared<GalileoE5aDllPllTracking>(&h->cfg, role, 1, 1);
+            else if (impl == "Galileo_E5b_DLL_PLL_Tracking")
+                h->adapter = std::make_shared<GalileoE5bDllPllTracking>(&h->cfg, role, 1, 1);
+            else if (impl == "Galileo_E6_DLL_PLL_Tracking")
+                h->adapter = std::make_shared<GalileoE6DllPllTracking>(&h->cfg, role, 1, 1);
+            else if (impl == "BEIDOU_B1I_DLL_PLL_Tracking")
+                h->adapter = std::make_shared<BeidouB1iDllPllTracking>(&h->cfg, role, 1, 1);
+            else if (impl == "BEIDOU_B3I_DLL_PLL_Tracking")
+                h->adapter = std::make_shared<BeidouB3iDllPllTracking>(&h->cfg, role, 1, 1);
+            else if (impl == "GLONASS_L1_CA_DLL_PLL_Tracking")
+                h->adapter = std::make_shared<GlonassL1CaDllPllTracking>(&h->cfg, role, 1, 1);
+            else if (impl == "GLONASS_L2_CA_DLL_PLL_Tracking")
+                h->adapter = std::make_shared<GlonassL2CaDllPllTracking>(&h->cfg, role, 1, 1);
+            else if (impl == "QZSS_L1_CA_DLL_PLL_Tracking")
+                h->adapter = std::make_shared<QzssL1DllPllTracking>(&h->cfg, role, 1, 1);
+            else if (impl == "QZSS_L5_DLL_PLL_Tracking")
+                h->adapter = std::make_shared<QzssL5DllPllTracking>(&h->cfg, role, 1, 1);
             else
                 return nullptr;
             if (h->adapter->item_size() == 0) return nullptr;  // gnss_block_factory.cc:1048-1052
@@ -122,6 +153,34 @@ void* reftrk_create(const char* implementation, const char* role, const char* co
     catch (const std::exception& e)
         {
             std::cerr << "reftrk_create: " << e.what() << '\n';
+            return nullptr;
+        }
+}
+
+/* the block on its own, configured like an adapter would but with ANY (system, signal) tag -- reaches the constructor branches no adapter of this
+ * reference version selects (Galileo "E6": its adapter writes the tag "5X", galileo_e6_dll_pll_tracking.cc:62-64) */
+void* reftrk_create_block(char system, const char* signal, uint32_t vector_length, const char* role, const char* const* keys, const char* const* values, int n_props)
+{
+    try
+        {
+            auto h = std::make_unique<Handle>();
+            for (int i = 0; i < n_props; i++) h->cfg.set_property(keys[i], values[i]);
+            Dll_Pll_Conf p;
+            p.SetFromConfiguration(&h->cfg, role);
+            p.system = system;
+            std::memset(p.signal, 0, sizeof(p.signal));
+            std::strncpy(p.signal, signal, 2);
+            p.vector_length = vector_length;
+            if (p.extend_correlation_symbols < 1) p.extend_correlation_symbols = 1;
+            h->own_block = dll_pll_veml_make_tracking(p);
+            h->block = h->own_block.get();
+            h->block->set_channel(0);
+            h->block->set_gnss_synchro(&h->synchro);
+            return h.release();
+        }
+    catch (const std::exception& e)
+        {
+            std::cerr << "reftrk_create_block: " << e.what() << '\n';
             return nullptr;
         }
 }
@@ -142,8 +201,22 @@ void reftrk_set_acquisition(void* hv, char system, const char* signal, uint32_t 
     h->synchro.Acq_samplestamp_samples = acq_samplestamp_samples;
 }
 
-void reftrk_start_tracking(void* hv) { static_cast<Handle*>(hv)->adapter->start_tracking(); }
-void reftrk_stop_tracking(void* hv) { static_cast<Handle*>(hv)->adapter->stop_tracking(); }
+void reftrk_start_tracking(void* hv)
+{
+    auto* h = static_cast<Handle*>(hv);
+    if (h->adapter)
+        h->adapter->start_tracking();
+    else
+        h->block->start_tracking();
+}
+void reftrk_stop_tracking(void* hv)
+{
+    auto* h = static_cast<Handle*>(hv);
+    if (h->adapter)
+        h->adapter->stop_tracking();
+    else
+        h->block->stop_tracking();
+}
 
 int reftrk_forecast(void* hv, int noutput)
 {
@@ -302,6 +375,14 @@ void reftrk_get_conf(void* hv, reftrk_conf_out* c)
     c->n_correlator_taps = b->d_n_correlator_taps;
     std::strncpy(c->secondary_code, b->d_secondary_code_string.c_str(), 255);
     std::strncpy(c->data_secondary_code, b->d_data_secondary_code_string.c_str(), 255);
+}
+
+/* what start_tracking changes per satellite besides the members reftrk_get_conf reads (trk.cc:930-1013) */
+void reftrk_get_live(void* hv, int32_t* extend_correlation_symbols, double* cfo_frequency_hz)
+{
+    const auto* b = static_cast<Handle*>(hv)->block;
+    *extend_correlation_symbols = b->d_extend_correlation_symbols;
+    *cfo_frequency_hz = b->d_cfo_frequency_hz;
 }
 
 /* the local replica(s) the block generated in start_tracking (trk.cc:796-866): code_len floats each; data may be NULL */

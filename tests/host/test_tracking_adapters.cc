@@ -12,8 +12,13 @@
 //   test_tracking_adapters conf    CPU only: Dll_Pll_Conf -> gsh_trk_conf (hip_fill_trk_conf) equals what the reference block's constructor
 //                                  derives, field by field, for every supported signal; replicas equal the block's
 //   test_tracking_adapters         on the GPU box: the above + trajectories (prints "TRACKING ADAPTERS OK")
+#include "Beidou_B1I.h"
+#include "GLONASS_L1_L2_CA.h"
 #include "GPS_L1_CA.h"
+#include "GPS_L2C.h"
 #include "Galileo_E1.h"
+#include "Galileo_E5b.h"
+#include "qzss.h"
 #include "dll_pll_conf_hip.h"
 #include "dll_pll_tracking_hip.h"
 #include "galileo_e1_signal_replica.h"
@@ -26,6 +31,7 @@
 #include <cmath>
 #include <complex>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -68,6 +74,8 @@ struct reftrk_conf_out
     char system, signal[3];
 };
 void* reftrk_create(const char* implementation, const char* role, const char* const* keys, const char* const* values, int n_props);
+void* reftrk_create_block(char system, const char* signal, uint32_t vector_length, const char* role, const char* const* keys, const char* const* values, int n_props);
+void reftrk_get_live(void* h, int32_t* extend_correlation_symbols, double* cfo_frequency_hz);
 void reftrk_destroy(void* h);
 void reftrk_set_acquisition(void* h, char system, const char* signal, uint32_t prn, double acq_delay_samples, double acq_doppler_hz, uint64_t acq_samplestamp_samples);
 void reftrk_start_tracking(void* h);
@@ -177,8 +185,7 @@ void compare_conf(const char* name, const gsh_trk_conf& c, const Hip_Trk_Signal&
         EXPECT(std::string(reinterpret_cast<const char*>(c.secondary_code), c.secondary_code_length) == std::string(r.secondary_code), "%s: secondary code", name);
     EXPECT(std::string(reinterpret_cast<const char*>(c.data_secondary_code), c.data_secondary_code_length) == std::string(r.data_secondary_code),
         "%s: data secondary code", name);
-    // the histogram bit synchroniser is configured at start_tracking (configure_bit_synchronizer, trk.cc:1387-1406): same rule
-    EXPECT(c.use_histogram_bit_sync == ((!r.secondary && r.symbols_per_bit > 1) ? 1 : 0), "%s: use_histogram_bit_sync", name);
+    // (the histogram bit synchroniser is configured at the end of start_tracking, trk.cc:1077: compared there)
 }
 
 // the Dll_Pll_Conf the HIP adapters end up with, without needing a GPU: same code path as DllPllTrackingHip's constructors up to
@@ -191,6 +198,9 @@ struct SignalCase
     const char* signal;
     double chip_rate, code_length;
     Props props;
+    uint32_t prn{7};
+    bool e6_adapter{false};  // the reference's Galileo E6 adapter as written: signal tag "5X" (galileo_e6_dll_pll_tracking.cc:62-64)
+    bool block_only{false};  // no reference adapter selects this branch of the block: the block is built directly (reftrk_create_block)
 };
 
 Dll_Pll_Conf adapter_conf(const SignalCase& sc, const std::string& role)
@@ -211,7 +221,28 @@ Dll_Pll_Conf adapter_conf(const SignalCase& sc, const std::string& role)
         }
     if (std::string(sc.signal) == "1B" && !p.track_pilot) p.extend_correlation_symbols = 1;
     if (std::string(sc.signal) == "L5" && !p.track_pilot) p.extend_correlation_symbols = std::min(p.extend_correlation_symbols, 10);
-    if (std::string(sc.signal) == "5X" && !p.track_pilot) p.extend_correlation_symbols = std::min(p.extend_correlation_symbols, 20);
+    if (std::string(sc.signal) == "5X" && !p.track_pilot) p.extend_correlation_symbols = std::min(p.extend_correlation_symbols, sc.e6_adapter ? 1 : 20);
+    const std::string sg(sc.signal);
+    if (sg == "2S")
+        {
+            p.extend_correlation_symbols = 1;
+            p.track_pilot = false;
+        }
+    if (sg == "7X" && !p.track_pilot) p.extend_correlation_symbols = std::min(p.extend_correlation_symbols, 4);
+    if (sg == "E6" && !p.track_pilot) p.extend_correlation_symbols = 1;
+    if (sg == "B1" || sg == "B3") p.extend_correlation_symbols = std::min(p.extend_correlation_symbols, 20);
+    if (sg == "B1") p.track_pilot = false;
+    if (sg == "1G" || sg == "2G")
+        {
+            p.extend_correlation_symbols = std::min(p.extend_correlation_symbols, 10);
+            p.track_pilot = false;
+        }
+    if (sg == "J1")
+        {
+            p.extend_correlation_symbols = std::min(p.extend_correlation_symbols, 20);
+            p.track_pilot = false;
+        }
+    if (sg == "J5" && !p.track_pilot) p.extend_correlation_symbols = std::min(p.extend_correlation_symbols, 10);
     return p;
 }
 
@@ -255,6 +286,72 @@ std::vector<SignalCase> signal_cases()
         p[R + ".smoother_length"] = "12";
         v.push_back({"GPS L5 data, high dynamics", "GPS_L5_DLL_PLL_Tracking", 'G', "L5", 10.23e6, 10230.0, p});
     }
+    // ---- the rest of the dll_pll_veml_tracking family (round 2)
+    {
+        Props p = base(4000000);
+        p[R + ".extend_correlation_symbols"] = "3";  // not allowed on L2C: the adapter sets it back to 1
+        v.push_back({"GPS L2C(M)", "GPS_L2_M_DLL_PLL_Tracking", 'G', "2S", 511.5e3, 10230.0, p});
+    }
+    {
+        Props p = base(25000000);
+        p[R + ".track_pilot"] = "true";
+        p[R + ".extend_correlation_symbols"] = "4";
+        v.push_back({"Galileo E5a pilot", "Galileo_E5a_DLL_PLL_Tracking", 'E', "5X", 10.23e6, 10230.0, p});
+        v.push_back({"Galileo E5b pilot", "Galileo_E5b_DLL_PLL_Tracking", 'E', "7X", 10.23e6, 10230.0, p});
+        p[R + ".track_pilot"] = "false";
+        p[R + ".extend_correlation_symbols"] = "8";
+        v.push_back({"Galileo E5b data", "Galileo_E5b_DLL_PLL_Tracking", 'E', "7X", 10.23e6, 10230.0, p});
+        SignalCase e6{"Galileo E6 adapter as the reference has it (tag 5X)", "Galileo_E6_DLL_PLL_Tracking", 'E', "5X", 5.115e6, 5115.0, p};
+        e6.e6_adapter = true;
+        v.push_back(e6);
+        SignalCase e6b{"Galileo E6 data, the block's own E6 branch", "", 'E', "E6", 5.115e6, 5115.0, p};
+        e6b.block_only = true;
+        v.push_back(e6b);
+        p[R + ".track_pilot"] = "true";
+        SignalCase e6c{"Galileo E6 pilot, the block's own E6 branch", "", 'E', "E6", 5.115e6, 5115.0, p};
+        e6c.block_only = true;
+        v.push_back(e6c);
+    }
+    {
+        Props p = base(8000000);
+        p[R + ".extend_correlation_symbols"] = "5";
+        v.push_back({"BeiDou B1I MEO", "BEIDOU_B1I_DLL_PLL_Tracking", 'C', "B1", 2.046e6, 2046.0, p});
+        SignalCase geo{"BeiDou B1I GEO (PRN 3)", "BEIDOU_B1I_DLL_PLL_Tracking", 'C', "B1", 2.046e6, 2046.0, p};
+        geo.prn = 3;
+        v.push_back(geo);
+    }
+    {
+        Props p = base(25000000);
+        v.push_back({"BeiDou B3I MEO", "BEIDOU_B3I_DLL_PLL_Tracking", 'C', "B3", 10.23e6, 10230.0, p});
+        SignalCase geo{"BeiDou B3I GEO (PRN 59)", "BEIDOU_B3I_DLL_PLL_Tracking", 'C', "B3", 10.23e6, 10230.0, p};
+        geo.prn = 59;
+        v.push_back(geo);
+    }
+    {
+        Props p = base(6625000);
+        p[R + ".extend_correlation_symbols"] = "20";  // limited to 10
+        v.push_back({"GLONASS L1 C/A (slot 7)", "GLONASS_L1_CA_DLL_PLL_Tracking", 'R', "1G", 511e3, 511.0, p});
+        SignalCase l2{"GLONASS L2 C/A (slot 2)", "GLONASS_L2_CA_DLL_PLL_Tracking", 'R', "2G", 511e3, 511.0, p};
+        l2.prn = 2;
+        v.push_back(l2);
+    }
+    {
+        Props p = base(4000000);
+        SignalCase j1{"QZSS L1 C/A", "QZSS_L1_CA_DLL_PLL_Tracking", 'J', "J1", 1.023e6, 1023.0, p};
+        j1.prn = 193;
+        v.push_back(j1);
+    }
+    {
+        Props p = base(25000000);
+        p[R + ".track_pilot"] = "true";
+        SignalCase j5{"QZSS L5 pilot", "QZSS_L5_DLL_PLL_Tracking", 'J', "J5", 10.23e6, 10230.0, p};
+        j5.prn = 194;
+        v.push_back(j5);
+        p[R + ".track_pilot"] = "false";
+        SignalCase j5d{"QZSS L5 data", "QZSS_L5_DLL_PLL_Tracking", 'J', "J5", 10.23e6, 10230.0, p};
+        j5d.prn = 194;
+        v.push_back(j5d);
+    }
     return v;
 }
 
@@ -262,12 +359,34 @@ void test_conf_mapping()
 {
     for (const auto& sc : signal_cases())
         {
-            void* ref = make_ref(sc.ref_impl, "Tracking", sc.props);
+            const Dll_Pll_Conf p = adapter_conf(sc, "Tracking");
+            void* ref = nullptr;
+            if (sc.block_only)
+                {
+                    std::vector<const char*> k, v;
+                    for (const auto& kv : sc.props)
+                        {
+                            k.push_back(kv.first.c_str());
+                            v.push_back(kv.second.c_str());
+                        }
+                    // the adapter-level clamps of adapter_conf() are applied by handing the block the finished extend_correlation_symbols
+                    Props pp = sc.props;
+                    pp["Tracking.extend_correlation_symbols"] = std::to_string(p.extend_correlation_symbols);
+                    k.clear();
+                    v.clear();
+                    for (const auto& kv : pp)
+                        {
+                            k.push_back(kv.first.c_str());
+                            v.push_back(kv.second.c_str());
+                        }
+                    ref = reftrk_create_block(sc.system, sc.signal, p.vector_length, "Tracking", k.data(), v.data(), static_cast<int>(k.size()));
+                }
+            else
+                ref = make_ref(sc.ref_impl, "Tracking", sc.props);
             EXPECT(ref != nullptr, "%s: reference chain could not be built", sc.name);
             if (ref == nullptr) continue;
             reftrk_conf_out r{};
             reftrk_get_conf(ref, &r);
-            const Dll_Pll_Conf p = adapter_conf(sc, "Tracking");
             gsh_trk_conf c{};
             Hip_Trk_Signal sig;
             std::string why;
@@ -277,27 +396,43 @@ void test_conf_mapping()
                 {
                     compare_conf(sc.name, c, sig, r);
                     // local replicas: ours (hip_make_tracking_codes) vs what the block generated in start_tracking
-                    reftrk_set_acquisition(ref, sc.system, sc.signal, 7, 0.0, 0.0, 0);
+                    reftrk_set_acquisition(ref, sc.system, sc.signal, sc.prn, 0.0, 0.0, 0);
                     reftrk_start_tracking(ref);
                     const int n = static_cast<int>(c.code_length_chips * c.code_samples_per_chip);
                     std::vector<float> rc(n), rd(n), code, data;
                     EXPECT(reftrk_get_codes(ref, rc.data(), rd.data(), n) == n, "%s: reference code length", sc.name);
                     const char sigc[3] = {sc.signal[0], sc.signal[1], '\0'};
-                    EXPECT(hip_make_tracking_codes(sig, &c, 7, sigc, &code, &data, &why), "%s: hip_make_tracking_codes: %s", sc.name, why.c_str());
+                    EXPECT(hip_make_tracking_codes(sig, &c, sc.prn, sigc, &code, &data, &why), "%s: hip_make_tracking_codes: %s", sc.name, why.c_str());
                     EXPECT(code.size() == rc.size() && std::equal(code.begin(), code.end(), rc.begin()), "%s: tracking replica differs from the block's", sc.name);
                     if (c.track_pilot) EXPECT(data.size() == rd.size() && std::equal(data.begin(), data.end(), rd.begin()), "%s: data replica differs", sc.name);
+                    // what start_tracking changes per satellite (BeiDou GEO, Glonass FDMA channel, per-PRN secondary codes): the block's members now
+                    reftrk_get_conf(ref, &r);
+                    int32_t ext_live = 0;
+                    double cfo = 0.0;
+                    reftrk_get_live(ref, &ext_live, &cfo);
+                    EXPECT(c.symbols_per_bit == r.symbols_per_bit && c.has_secondary == r.secondary, "%s: after start_tracking symbols_per_bit %d / %d, secondary %d / %d", sc.name,
+                        c.symbols_per_bit, r.symbols_per_bit, c.has_secondary, r.secondary);
+                    // (the driver's record carries the first 255 characters of the string; the Glonass preamble pattern has 300)
+                    EXPECT(std::string(reinterpret_cast<const char*>(c.secondary_code), std::min(c.secondary_code_length, 255)) == std::string(r.secondary_code) &&
+                               c.secondary_code_length == r.secondary_code_length,
+                        "%s: secondary code after start_tracking", sc.name);
+                    EXPECT(c.data_secondary_code_length == r.data_secondary_code_length, "%s: data secondary code length after start_tracking %d / %d", sc.name,
+                        c.data_secondary_code_length, r.data_secondary_code_length);
+                    EXPECT(c.extend_correlation_symbols == ext_live, "%s: extend_correlation_symbols after start_tracking %d vs the block's %d", sc.name, c.extend_correlation_symbols, ext_live);
+                    EXPECT(c.cfo_frequency_hz == cfo, "%s: cfo_frequency_hz %g vs the block's %g", sc.name, c.cfo_frequency_hz, cfo);
+                    EXPECT(c.use_histogram_bit_sync == r.use_histogram_bit_sync, "%s: use_histogram_bit_sync %d vs the block's %d", sc.name, c.use_histogram_bit_sync, r.use_histogram_bit_sync);
                 }
             reftrk_destroy(ref);
         }
     // unsupported signal / item type are refused with a reason
     {
         Dll_Pll_Conf p;
-        p.system = 'R';
-        std::memcpy(p.signal, "1G", 3);
+        p.system = 'G';
+        std::memcpy(p.signal, "9Z", 3);
         gsh_trk_conf c{};
         Hip_Trk_Signal sig;
         std::string why;
-        EXPECT(!hip_fill_trk_conf(p, &c, &sig, &why) && !why.empty(), "GLONASS must be refused");
+        EXPECT(!hip_fill_trk_conf(p, &c, &sig, &why) && !why.empty(), "an unknown signal tag must be refused");
         p.system = 'G';
         std::memcpy(p.signal, "1C", 3);
         p.item_type = "cshort";
@@ -433,6 +568,9 @@ TrajectoryStats run_pair(DllPllTrackingHip& hip, void* ref, Gnss_Synchro& syn, c
             a = hip_call(*blk, x, ph, avail);
             b = ref_call(ref, x, pr, avail);
             st.periods++;
+            if (std::getenv("TRK_DEBUG") != nullptr && k < 120)
+                std::printf("  k %d ref state %d P %.0f %.0f consumed %d | hip state %d consumed %d produced %d/%d\n", k, b.o.state, b.o.corr[2], b.o.corr[3], b.consumed, a.state,
+                    a.consumed, b.produced, a.produced);
             if (same && a.consumed == b.consumed)
                 st.same_windows++;
             else
@@ -620,6 +758,111 @@ void test_galileo_e1_pilot_trajectory()
     reftrk_destroy(ref);
 }
 
+// ---- the other signals of the family: adapter + block + device loop against the reference chain on one synthetic satellite each.  The stream carries the
+// signal's secondary code (where it has one) times random telemetry symbols, so that both chains go through their synchronisation state and publish symbols.
+template <typename Adapter>
+void signal_trajectory(const char* name, const char* ref_impl, const char* hip_impl, char system, const char* signal, uint32_t prn, long fs, double chip_rate,
+    double f_carrier, Props extra, int n_periods, const std::string& secondary, int symbols_per_bit, double cfo_hz, bool expect_symbols, unsigned seed,
+    const std::string& preamble_bits = std::string(), double doppler_tol_hz = 5.0, int preamble_symbols_at = -1)
+{
+    const std::string R = "Tracking";
+    Props p{{"GNSS-SDR.internal_fs_sps", std::to_string(fs)}, {R + ".pll_bw_hz", "35.0"}, {R + ".dll_bw_hz", "2.0"}, {R + ".early_late_space_chips", "0.5"},
+        {R + ".pull_in_time_s", "0"}, {R + ".hip_device", "0"}};
+    for (const auto& kv : extra) p[kv.first] = kv.second;
+    auto cfg = make_config(p);
+    Adapter hip(cfg.get(), R, 1, 1);
+    EXPECT(hip.implementation() == hip_impl, "%s: implementation name %s", name, hip.implementation().c_str());
+    EXPECT(hip.item_size() == sizeof(gr_complex), "%s: unusable adapter", name);
+    if (hip.item_size() == 0) return;
+    void* ref = make_ref(ref_impl, R, p);
+    EXPECT(ref != nullptr, "%s: reference chain", name);
+    if (ref == nullptr) return;
+    const gsh_trk_conf& c0 = hip.trk_conf();
+    const int n = static_cast<int>(c0.vector_length);
+    // the replica as the block generates it
+    gsh_trk_conf c = c0;
+    Hip_Trk_Signal sig;
+    std::string why;
+    {
+        gsh_trk_conf tmp{};
+        EXPECT(hip_fill_trk_conf(hip.tracking_parameters(), &tmp, &sig, &why), "%s: %s", name, why.c_str());
+    }
+    std::vector<float> code, data;
+    const char sigc[3] = {signal[0], signal[1], '\0'};
+    EXPECT(hip_make_tracking_codes(sig, &c, prn, sigc, &code, &data, &why), "%s: %s", name, why.c_str());
+    // symbols: secondary code chip x telemetry bit
+    std::vector<int8_t> bits = random_symbols(static_cast<size_t>(n_periods / std::max(1, symbols_per_bit) + 4), seed);
+    if (!preamble_bits.empty() && bits.size() > 12 + preamble_bits.size())  // a telemetry preamble for the chains that synchronise on it
+        for (size_t i = 0; i < preamble_bits.size(); i++) bits[12 + i] = preamble_bits[i] == '1' ? 1 : -1;
+    std::vector<int8_t> symbols(static_cast<size_t>(n_periods) + 40, 1);
+    for (size_t k = 0; k < symbols.size(); k++)
+        {
+            int8_t v = bits[std::min(bits.size() - 1, k / static_cast<size_t>(std::max(1, symbols_per_bit)))];
+            if (!secondary.empty()) v = static_cast<int8_t>(v * (secondary[k % secondary.size()] == '0' ? 1 : -1));
+            symbols[k] = v;
+        }
+    if (preamble_symbols_at >= 0)  // the chain's own preamble, symbol by symbol (GLONASS: 30 time-mark bits of 10 symbols), twice
+        for (int rep = 0; rep < 2; rep++)
+            for (int i = 0; i < c.secondary_code_length; i++)
+                {
+                    const size_t k = static_cast<size_t>(preamble_symbols_at + rep * (c.secondary_code_length + 170) + i);
+                    if (k < symbols.size()) symbols[k] = c.secondary_code[i] == '1' ? 1 : -1;
+                }
+    const double fd = 777.0;
+    // (the FDMA channel offset is part of the received carrier; code Doppler follows the satellite's Doppler only)
+    auto x = synth(code, nullptr, 0.0, chip_rate, static_cast<int>(c.code_samples_per_chip), static_cast<double>(fs), fd, f_carrier, static_cast<size_t>(n_periods + 12) * n,
+        amp_for_cn0(48.0, static_cast<double>(fs)), symbols, nullptr, seed + 1);
+    if (cfo_hz != 0.0)
+        for (size_t i = 0; i < x.size(); i++)
+            {
+                const double ph = std::fmod(2.0 * M_PI * cfo_hz / static_cast<double>(fs) * static_cast<double>(i), 2.0 * M_PI);
+                x[i] *= std::complex<float>(static_cast<float>(std::cos(ph)), static_cast<float>(std::sin(ph)));
+            }
+    Gnss_Synchro syn;
+    const TrajectoryStats st = run_pair(hip, ref, syn, x, n, n_periods, system, signal, prn, 0.0, fd - 12.0, static_cast<uint64_t>(n));
+    std::printf("%s: %d periods, %d with identical windows, symbols ref/hip/matched %d/%d/%d, first symbol at period %d / %d, worst |dPrompt_I| rel %.2e, Doppler %.2f / %.2f Hz, "
+                "C/N0 %.2f / %.2f dB-Hz\n",
+        name, st.periods, st.same_windows, st.symbols_ref, st.symbols_hip, st.symbols_matched, st.first_symbol_period_ref, st.first_symbol_period_hip, st.worst_prompt_rel,
+        st.final_doppler_ref, st.final_doppler_hip, st.final_cn0_ref, st.final_cn0_hip);
+    EXPECT(st.periods >= n_periods - 2, "%s: ran %d of %d periods", name, st.periods, n_periods);
+    EXPECT(st.same_windows >= st.periods * 9 / 10, "%s: window positions identical for only %d of %d periods", name, st.same_windows, st.periods);
+    EXPECT(st.symbols_hip == st.symbols_ref && st.symbols_matched == st.symbols_ref, "%s: symbol timing: ref %d hip %d matched %d", name, st.symbols_ref, st.symbols_hip, st.symbols_matched);
+    EXPECT(st.first_symbol_period_hip == st.first_symbol_period_ref, "%s: first symbol at period %d vs reference %d", name, st.first_symbol_period_hip, st.first_symbol_period_ref);
+    if (expect_symbols)
+        {
+            EXPECT(st.symbols_ref >= 10, "%s: the reference chain published only %d symbols", name, st.symbols_ref);
+            EXPECT(st.worst_prompt_rel < 2e-2, "%s: Prompt_I of the symbols differs by %.3e", name, st.worst_prompt_rel);
+            EXPECT(std::fabs(st.final_doppler_hip - st.final_doppler_ref) < 1.0 && std::fabs(st.final_doppler_hip - fd) < doppler_tol_hz, "%s: Doppler %.2f vs %.2f", name, st.final_doppler_hip,
+                st.final_doppler_ref);
+            EXPECT(std::fabs(st.final_cn0_hip - st.final_cn0_ref) < 0.5, "%s: C/N0 %.2f vs %.2f", name, st.final_cn0_hip, st.final_cn0_ref);
+        }
+    EXPECT(st.hip_event == 0 && st.ref_events == 0, "%s: no loss of lock expected (hip event %ld, reference events %d)", name, st.hip_event, st.ref_events);
+    reftrk_destroy(ref);
+}
+
+void test_other_signal_trajectories()
+{
+    // The block stays in its pull-in state until one whole second of samples has passed, whatever pull_in_time_s says: the elapsed time is an integer
+    // division by fs_in (trk.cc:1912), so the 1 ms signals need more than 1000 periods before the secondary code / bit search starts.
+    // BeiDou B1I, MEO satellite: 20-chip NH code on every bit (trk.cc:412-430, 958-971)
+    signal_trajectory<BeidouB1iDllPllTrackingHip>("BeiDou B1I", "BEIDOU_B1I_DLL_PLL_Tracking", "BEIDOU_B1I_DLL_PLL_Tracking_HIP", 'C', "B1", 8, 8000000, BEIDOU_B1I_CODE_RATE_CPS,
+        BEIDOU_B1I_FREQ_HZ, {}, 1400, BEIDOU_B1I_SECONDARY_CODE_STR, 20, 0.0, true, 21);
+    // QZSS L1 C/A: GPS-like, histogram bit synchronisation then the preamble
+    signal_trajectory<QzssL1DllPllTrackingHip>("QZSS L1 C/A", "QZSS_L1_CA_DLL_PLL_Tracking", "QZSS_L1_CA_DLL_PLL_Tracking_HIP", 'J', "J1", 193, 4000000, QZSS_L1_CHIP_RATE, QZSS_L1_FREQ_HZ, {},
+        2500, "", 20, 0.0, true, 22, "10001011");
+    // GLONASS L1 C/A, slot 7 (frequency channel +5: 2.8125 MHz above the band centre, in a 6.625 Msps stream): the loop carries the channel offset in its NCO
+    // (trk.cc:996-1003); bit synchronisation is the correlation with the 300-symbol GNAV time mark (no histogram for GLONASS), put into the stream
+    // after the one-second pull-in
+    signal_trajectory<GlonassL1CaDllPllTrackingHip>("GLONASS L1 C/A", "GLONASS_L1_CA_DLL_PLL_Tracking", "GLONASS_L1_CA_DLL_PLL_Tracking_HIP", 'R', "1G", 7, 6625000, GLONASS_L1_CA_CODE_RATE_CPS,
+        GLONASS_L1_CA_FREQ_HZ, {}, 1900, "", 10, DFRQ1_GLO * GLONASS_PRN.at(7), true, 23, "", 5.0, 1100);
+    // Galileo E5b data component: 4-chip secondary code
+    signal_trajectory<GalileoE5bDllPllTrackingHip>("Galileo E5b-I", "Galileo_E5b_DLL_PLL_Tracking", "Galileo_E5b_DLL_PLL_Tracking_HIP", 'E', "7X", 11, 12500000, GALILEO_E5B_CODE_CHIP_RATE_CPS,
+        GALILEO_E5B_FREQ_HZ, {{"Tracking.track_pilot", "false"}}, 1300, GALILEO_E5B_I_SECONDARY_CODE, 4, 0.0, true, 24);
+    // GPS L2C(M): 20 ms code periods, one per symbol
+    signal_trajectory<GpsL2MDllPllTrackingHip>("GPS L2C(M)", "GPS_L2_M_DLL_PLL_Tracking", "GPS_L2_M_DLL_PLL_Tracking_HIP", 'G', "2S", 5, 2000000, GPS_L2_M_CODE_RATE_CPS, GPS_L2_FREQ_HZ,
+        {{"Tracking.pll_bw_hz", "5.0"}, {"Tracking.dll_bw_hz", "0.5"}}, 120, "", 1, 0.0, true, 25, "", 30.0);
+}
+
 void test_loss_of_lock_on_noise()
 {
     // noise only, with the lock thresholds tightened so that the detectors act within a few hundred periods: cn0_min 35 dB-Hz,
@@ -680,6 +923,7 @@ int main(int argc, char** argv)
     test_unusable_configurations();
     test_gps_l1_trajectory();
     test_galileo_e1_pilot_trajectory();
+    test_other_signal_trajectories();
     test_loss_of_lock_on_noise();
     std::printf(fails == 0 ? "TRACKING ADAPTERS OK\n" : "%d failure(s)\n", fails);
     return fails == 0 ? 0 : 1;
