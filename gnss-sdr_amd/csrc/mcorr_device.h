@@ -6,6 +6,7 @@
 
 #include "gsh_internal.h"
 #include <cmath>
+#include <type_traits>
 
 // Work-group size of the correlator code below.  A translation unit may define GSH_MC_THREADS (a multiple of 64, <= 1024)
 // before including this header; the code then lives in its own namespace (mcdev_<threads>) so that two translation
@@ -38,6 +39,10 @@ constexpr int MC_MARGIN = 32;  // guard entries on each side of the LDS code tab
 #endif
 #ifndef GSH_MC_CVT_FLR
 #define GSH_MC_CVT_FLR 1
+#endif
+#ifndef GSH_MC_DER_MIXED
+#define GSH_MC_DER_MIXED 0  // 1: in a trip with one unsafe chunk the other chunk still pairs its taps (two more loop bodies: measured, the register
+                            // allocator then spills and the launch is 45 % slower -- profiles/r02/paired_taps.txt)
 #endif
 constexpr int MC_RESEED = GSH_MC_RESEED;  // strides of 512 samples between exact NCO re-seeds
 constexpr int MC_PAIRS_PER_CHUNK = MC_THREADS;  // one float4 (2 samples) per thread per chunk
@@ -121,6 +126,27 @@ __device__ __forceinline__ float wave_scan_incl(float v)
     v += dpp_read0<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
     v += dpp_read0<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
     return v;
+}
+
+// the same over N values at once, one v_add_f32_dpp per value and step (the compiler's rendering of the function above is v_mov_b32_dpp + add: half as many
+// again).  The values take turns, so a value's next step is N instructions behind its last -- for N < 3 a wait state is inserted by hand (a DPP read of a
+// VGPR needs two wait states after the VALU write; the assembler does not add them inside inline asm).
+template <int N>
+__device__ __forceinline__ void wave_scan_incl_n(float (&v)[N])
+{
+#define GSH_DPP_STEP(CTRL)                                                                                            \
+    _Pragma("unroll") for (int i = 0; i < N; i++)                                                                       \
+    {                                                                                                                   \
+        if (N < 3) asm volatile("s_nop 1");                                                                             \
+        asm volatile("v_add_f32_dpp %0, %0, %0 " CTRL " bound_ctrl:1" : "+v"(v[i]));                                     \
+    }
+    GSH_DPP_STEP("row_shr:1 row_mask:0xf bank_mask:0xf")
+    GSH_DPP_STEP("row_shr:2 row_mask:0xf bank_mask:0xf")
+    GSH_DPP_STEP("row_shr:4 row_mask:0xf bank_mask:0xf")
+    GSH_DPP_STEP("row_shr:8 row_mask:0xf bank_mask:0xf")
+    GSH_DPP_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
+    GSH_DPP_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+#undef GSH_DPP_STEP
 }
 
 __device__ __forceinline__ float readlane_f(float v, int l)
@@ -382,51 +408,110 @@ __device__ __forceinline__ v2f pk_add_shi(v2f v, v2f k)
 // staged -- the chip index is monotone in n -- and no clamp is needed here: masked trips run the very same instructions).
 // (the four samples arrive already rotated by the trip's phasor: the caller rotates them first and then re-uses their registers for the loads of
 //  the trip PF ahead, so the prefetch queue needs no register copies)
-template <int NT, bool ZP, bool AUX, int NCH>
+// Paired taps (round 2).  What the instructions of a trip cost on gfx950 (profiles/ubench/valu_rate.hip, profiles/r02/valu_rate_gfx950.txt): v_fma / v_add / v_mul
+// / v_and / v_add_u32 issue at full rate, every packed FP32 instruction, v_cvt_flr_i32_f32, v_fract_f32, v_cmp + v_cndmask and the three-operand
+// v_lshl_add_u32 at HALF rate.  Of a trip's 120 half-cycles 68 were chip-index work: per tap and sample two adds, one convert, one address.  Two
+// things cut that:
+//   * constant table offset (KC): when the whole code is staged, tab[k + MARGIN] is v_lshlrev_b32 + an immediate offset of the ds_read, not v_lshl_add_u32;
+//   * early from late (PA / PB): if shift_L - shift_E is exactly 1, then wherever no rounding step of the two chains changes its binade
+//       fl(a + shift_E) = fl(a + shift_L) - 1  and  fl(fl(a + shift_E) - rem) = fl(fl(a + shift_L) - rem) - 1
+//     hold exactly (x and x - 1 are rounded to the same quantum, and 1 is an even multiple of it: round-to-nearest-even commutes with the shift), so
+//     k_E = k_L - 1: the early code value is read next to the late one and its chain -- two adds, a convert, an address per sample -- is not evaluated.
+//     Whether a 2 PPC-sample chunk satisfies the binade conditions is a property of its range of chip indices: the caller evaluates it once per chunk
+//     (one lane per chunk, a ballot) with margins, and chunks that straddle a power of two -- or reach below 1 -- take the per-tap chains as before.
+// The products and their order of summation are the same either way: the outputs are bit-identical with the switch off
+// (tests/test_tracking_gpu.py::test_paired_taps_are_bit_identical).
+template <int NT, bool ZP, bool AUX, int NCH, bool PA = false, bool PB = false, bool KC = false>
 __device__ __forceinline__ void packed_trip(const JobCtx& c, const float* __restrict__ tab, const v2f (&shp)[NT],
     v2f k_step_nrem, v2f aux_shp, bool aux_on, v2f nfA, v2f nfB, v2f yA0, v2f yA1, v2f yB0, v2f yB1, v2f (&A0)[NT], v2f (&A1)[NT], v2f (&B0)[NT],
     v2f (&B1)[NT], v2f& XA0, v2f& XA1, v2f& XB0, v2f& XB1)
 {
+    static_assert(!(PA || PB) || NT == 3, "paired taps: early / prompt / late");
     const v2f zero = {0.0f, 0.0f};
     v2f aB = zero;
     if (NCH == 2) aB = pk_mul_slo(nfB, k_step_nrem);
     const v2f aA = pk_mul_slo(nfA, k_step_nrem);
-    auto lookup = [&](v2f a, v2f sp, bool zero_shift, int k_off) -> v2f {
+    const int koff = KC ? MC_MARGIN : c.k_off;
+    const int aux_koff = c.aux_k_off;
+    typedef const __attribute__((address_space(3))) float* lds_float_ptr;
+    // tab[k + off + D]: with KC the offset is a constant and the address one full-rate v_lshlrev_b32 (the compiler's own choice for k * 4 + constant is
+    // v_lshl_add_u32 with a zero addend -- half rate, see above); the constant rides in the ds_read's immediate offset
+    auto code_at = [&](int k, int off, auto dc, auto main_table) -> float {
+        constexpr int D = decltype(dc)::value;
+#ifdef GSH_EXP_NOLDS  // timing experiment only: the code value without the LDS look-up
+        return __builtin_bit_cast(float, 0x3f800000 | ((k + D) << 31));
+#endif
+        if constexpr (KC && decltype(main_table)::value)
+            {
+                unsigned byte_addr;
+                asm("v_lshlrev_b32 %0, 2, %1" : "=v"(byte_addr) : "v"(k));
+                return reinterpret_cast<lds_float_ptr>(byte_addr)[MC_MARGIN + D];  // KC: `tab` IS LDS address 0 (the caller checks)
+            }
+        else
+            return tab[k + off + D];
+    };
+    using d0 = std::integral_constant<int, 0>;
+    using dm1 = std::integral_constant<int, -1>;
+    auto chain = [&](v2f a, v2f sp, bool zero_shift, int& k0, int& k1) {
         v2f u;
         if (zero_shift)
             u = pk_add_shi(a, k_step_nrem);                   // a - rem
         else
             u = pk_add_shi(pk_add_slo(a, sp), k_step_nrem);   // (a + shift) - rem
-        const int k0 = floor_to_int(u.x);
-        const int k1 = floor_to_int(u.y);
+        k0 = floor_to_int(u.x);
+        k1 = floor_to_int(u.y);
+    };
+    // code values of one tap for the two samples of a pair
+    auto lookup = [&](v2f a, v2f sp, bool zero_shift, int k_off, auto main_table) -> v2f {
+        int k0, k1;
+        chain(a, sp, zero_shift, k0, k1);
         v2f cv;
-        cv.x = tab[k0 + k_off];
-        cv.y = tab[k1 + k_off];
+        cv.x = code_at(k0, k_off, d0{}, main_table);
+        cv.y = code_at(k1, k_off, d0{}, main_table);
         return cv;
     };
+    // one chunk: S0 / S1 the accumulator sets of the pair's first / second sample
+    auto chunk = [&](v2f a, v2f y0, v2f y1, v2f (&S0)[NT], v2f (&S1)[NT], auto paired) {
+        if constexpr (decltype(paired)::value && NT == 3)
+            {
+                // prompt as ever; late through its chain, early read next to it: (code[k_L - 1], code[k_L]) per sample, picked by op_sel
+                const v2f cP = lookup(a, shp[1], ZP, koff, std::true_type{});
+                int k0, k1;
+                chain(a, shp[2], false, k0, k1);
+                v2f el0, el1;
+                el0.x = code_at(k0, koff, dm1{}, std::true_type{});
+                el0.y = code_at(k0, koff, d0{}, std::true_type{});
+                el1.x = code_at(k1, koff, dm1{}, std::true_type{});
+                el1.y = code_at(k1, koff, d0{}, std::true_type{});
+                pk_fma_lo(S0[0], y0, el0);
+                pk_fma_lo(S1[0], y1, el1);
+                pk_fma_lo(S0[1], y0, cP);
+                pk_fma_hi(S1[1], y1, cP);
+                pk_fma_hi(S0[2], y0, el0);
+                pk_fma_hi(S1[2], y1, el1);
+            }
+        else
+            {
 #pragma unroll
-    for (int t = 0; t < NT; t++)
-        {
-            const bool zs = ZP && t == NT / 2;
-            const v2f cA = lookup(aA, shp[t], zs, c.k_off);
-            pk_fma_lo(A0[t], yA0, cA);
-            pk_fma_hi(A1[t], yA1, cA);
-            if (NCH == 2)
-                {
-                    const v2f cB = lookup(aB, shp[t], zs, c.k_off);
-                    pk_fma_lo(B0[t], yB0, cB);
-                    pk_fma_hi(B1[t], yB1, cB);
-                }
-        }
+                for (int t = 0; t < NT; t++)
+                    {
+                        const v2f cv = lookup(a, shp[t], ZP && t == NT / 2, koff, std::true_type{});
+                        pk_fma_lo(S0[t], y0, cv);
+                        pk_fma_hi(S1[t], y1, cv);
+                    }
+            }
+    };
+    chunk(aA, yA0, yA1, A0, A1, std::integral_constant<bool, PA>{});
+    if (NCH == 2) chunk(aB, yB0, yB1, B0, B1, std::integral_constant<bool, PB>{});
     if (AUX && aux_on)
         {
             const bool zs = ZP && c.aux_zero;
-            const v2f cA = lookup(aA, aux_shp, zs, c.aux_k_off);
+            const v2f cA = lookup(aA, aux_shp, zs, aux_koff, std::false_type{});
             pk_fma_lo(XA0, yA0, cA);
             pk_fma_hi(XA1, yA1, cA);
             if (NCH == 2)
                 {
-                    const v2f cB = lookup(aB, aux_shp, zs, c.aux_k_off);
+                    const v2f cB = lookup(aB, aux_shp, zs, aux_koff, std::false_type{});
                     pk_fma_lo(XB0, yB0, cB);
                     pk_fma_hi(XB1, yB1, cB);
                 }
@@ -443,7 +528,7 @@ __device__ __forceinline__ void packed_trip(const JobCtx& c, const float* __rest
 // a lane's seed is T[4 + r] * L (one complex product), read from the table with v_readlane.  More than 60 re-seeds: the table is refilled.
 // NCH = 2 chunks per trip (four samples per lane) for the 256-thread batched kernel; NCH = 1 for the 1024-thread closed-loop kernel
 // (128 VGPRs per lane).  One summation order for every tap count, so fused and unfused jobs stay bit-identical.
-template <int NT, bool ZP, bool AUX, int NCH, int PF>
+template <int NT, bool ZP, bool AUX, int NCH, int PF, bool DER = false, bool KC = false>
 __device__ __forceinline__ void run_segment_packed(const JobCtx& c, const float2* __restrict__ base, const float* __restrict__ tab,
     const float (&sh)[NT], float2 (&acc)[NT], float2* acc_aux)
 {
@@ -509,12 +594,23 @@ __device__ __forceinline__ void run_segment_packed(const JobCtx& c, const float2
     constexpr int TRIP = 2 * NCH * PPC;        // samples (float2) a trip advances by
     // the four samples of trip i for this lane: 16-byte loads in the body; at the segment's edges (odd head, partial tail) the samples outside
     // [n_begin, n_end) are read as zero -- never loaded.  Edge trips go through the same queue, so their latency is hidden like the others'.
+    const unsigned lane_bytes = 16u * static_cast<unsigned>(tid);  // the lane's 16 bytes inside a chunk
     auto load_trip = [&](int i, float4& va, float4& vb) {
         const float2* q = q0 + static_cast<long long>(i) * TRIP;
         if ((i >= first_plain) && (i < last_plain))  // uniform
             {
-                va = *reinterpret_cast<const float4*>(q);
-                if (NCH == 2) vb = *reinterpret_cast<const float4*>(q + 2 * PPC);
+                // a wave-uniform 64-bit base plus a 32-bit lane offset: the loads take their base from SGPRs, and no per-lane pointer is carried (and advanced) in VGPRs
+                const char* const ua = reinterpret_cast<const char*>(base + static_cast<long long>(i) * TRIP);
+                const char* const ub = ua + 16 * PPC;
+#ifdef GSH_EXP_NOLOAD  // timing experiment only (profiles/r02/mcorr_bound_experiments.txt): no sample traffic
+                va = make_float4(1.0f, static_cast<float>(i), 0.5f, 0.25f);
+                if (NCH == 2) vb = make_float4(0.5f, static_cast<float>(i), 1.0f, 0.25f);
+                asm volatile("" : "+v"(va.x), "+v"(va.y), "+v"(va.z), "+v"(va.w));
+                if (NCH == 2) asm volatile("" : "+v"(vb.x), "+v"(vb.y), "+v"(vb.z), "+v"(vb.w));
+#else
+                va = *reinterpret_cast<const float4*>(ua + lane_bytes);
+                if (NCH == 2) vb = *reinterpret_cast<const float4*>(ub + lane_bytes);
+#endif
             }
         else
             {
@@ -534,6 +630,26 @@ __device__ __forceinline__ void run_segment_packed(const JobCtx& c, const float2
                     }
             }
     };
+    // paired taps (DER): one bit per chunk of 2 PPC samples, set where every value of the early and the late index chain stays inside one binade
+    // (margins of 1/8 chip; see packed_trip).  Lane l judges chunk 64 m + l.  All of it happens HERE, before the accumulators exist: evaluated inside the
+    // trip loop its temporaries cost the loop a dozen VGPRs and with them one wave per SIMD.  Two masks = 128 chunks; what lies
+    // beyond (windows longer than 2^16 samples at 256 threads) runs the per-tap chains.
+    unsigned long long der_mask0 = 0ULL, der_mask1 = 0ULL;  // chunks 0..63, 64..127
+    if constexpr (DER)
+        {
+            // float arithmetic is enough: the margins (1/8 chip) exceed its error (< 2^-7 below the 2^16 bound) by far, and a chunk judged unsafe only loses speed
+            auto judge = [&](int first_chunk) -> unsigned long long {
+                const float n_lo = static_cast<float>(c.n_first + 2 * PPC * (first_chunk + lane));
+                const float lo1 = c.code_step * n_lo + (sh[0] - 0.125f);
+                const float hi1 = c.code_step * (n_lo + static_cast<float>(2 * PPC - 1)) + (sh[NT - 1] + 0.125f);
+                const float lo2 = lo1 - c.rem_code, hi2 = hi1 - c.rem_code;
+                const bool one_binade_a = (lo1 >= 1.0f) && (hi1 < 65536.0f) && ((__float_as_uint(lo1) >> 23) == (__float_as_uint(hi1) >> 23));
+                const bool one_binade_u = (lo2 >= 1.0f) && (hi2 < 65536.0f) && ((__float_as_uint(lo2) >> 23) == (__float_as_uint(hi2) >> 23));
+                return __ballot(one_binade_a && one_binade_u);
+            };
+            der_mask0 = judge(0);
+            if (NCH * n_trips > 64) der_mask1 = judge(64);  // uniform
+        }
     float4 qa[PF], qb[PF];
 #pragma unroll
     for (int j = 0; j < PF; j++)
@@ -544,55 +660,112 @@ __device__ __forceinline__ void run_segment_packed(const JobCtx& c, const float2
         }
     v2f pa = zero, nfA = zero, nfB = zero;
     int until_reseed = 0, r_idx = 0, tbl0 = 0;
-    for (int i0 = 0; i0 < n_trips; i0 += PF)
+    // one trip; j: its slot in the load queue; FA / FB (compile time): chunk A / B reads its early tap next to the late one
+    auto trip = [&](int i, auto jc, auto fa, auto fb) {
+        constexpr int j = decltype(jc)::value;
+        constexpr bool FA = decltype(fa)::value, FB = decltype(fb)::value;
+        const int n0 = (c.n_first + i * TRIP) + 2 * tid;  // (uniform part first: used at re-seeds and edges only)
+        if (until_reseed == 0)  // uniform: exact re-seed of the lane's phasor and of (float)n
+            {
+                if (r_idx - tbl0 >= TBL)
+                    {
+                        tbl0 = r_idx;
+                        T = fill_table(tbl0);
+                    }
+                pa = pk_cmul(table(4 + r_idx - tbl0), L);
+                nfA = (v2f){static_cast<float>(n0), static_cast<float>(n0 + 1)};
+                nfB = (v2f){static_cast<float>(n0 + 2 * PPC), static_cast<float>(n0 + 2 * PPC + 1)};
+                until_reseed = RESEED;
+                r_idx++;
+            }
+        until_reseed--;
+        const bool plain = (i >= first_plain) && (i < last_plain);  // uniform
+        v2f ia = nfA, ib = nfB;
+        if (!(FA || FB) && !plain)  // (derived trips are plain ones)
+            {
+                // edge trip: a sample outside the segment (already zero) is looked up at the nearest sample inside it, so that its
+                // chip index stays within what is staged.  (The empty volatile asm keeps this a BRANCH: if-converted, its 16 clamp /
+                // convert / select instructions ran in every trip -- a fifth of the loop's VALU work, ISA of round 2.)
+                asm volatile("" ::: "memory");
+                const int lo = c.n_begin, hi = c.n_end - 1;
+                ia = (v2f){static_cast<float>(min(max(n0, lo), hi)), static_cast<float>(min(max(n0 + 1, lo), hi))};
+                const int m0 = n0 + 2 * PPC;
+                if (NCH == 2) ib = (v2f){static_cast<float>(min(max(m0, lo), hi)), static_cast<float>(min(max(m0 + 1, lo), hi))};
+            }
+        // rotate first: the samples' registers are then free for the loads of trip i + PF, which take this trip's place in the queue
+        const v2f yA0 = pk_cmul((v2f){qa[j].x, qa[j].y}, pa);
+        const v2f yA1 = pk_cmul((v2f){qa[j].z, qa[j].w}, pa);
+        v2f yB0 = zero, yB1 = zero;
+        if (NCH == 2)
+            {
+                yB0 = pk_cmul((v2f){qb[j].x, qb[j].y}, pa);
+                yB1 = pk_cmul((v2f){qb[j].z, qb[j].w}, pa);
+            }
+        if (i + PF < n_trips) load_trip(i + PF, qa[j], qb[j]);  // uniform
+        packed_trip<NT, ZP, AUX, NCH, FA, FB, KC>(c, tab, shp, k_step_nrem, aux_shp, aux_on, ia, ib, yA0, yA1, yB0, yB1, A0, A1, B0, B1, XA0, XA1, XB0, XB1);
+        pa = pk_cmul(pa, w2);
+        asm("v_pk_add_f32 %0, %0, %1" : "+v"(nfA) : "v"(stride));
+        if (NCH == 2) asm("v_pk_add_f32 %0, %0, %1" : "+v"(nfB) : "v"(stride));
+    };
+    using std::integral_constant;
+    using no = integral_constant<bool, false>;
+    using yes = integral_constant<bool, true>;
+    if constexpr (DER)
         {
-#pragma unroll
-            for (int j = 0; j < PF; j++)
+            // Runs of trips of one kind, each kind its own loop over straight-line code.  (A branch per trip between the two forms made the
+            // register allocator merge the twelve accumulator pairs with 23 copies at every join -- ISA, round 2.)
+            static_assert(PF == 1, "the paired-tap trips run with a one-deep load queue");
+            using j0 = integral_constant<int, 0>;
+            auto flags = [&](int i) -> unsigned {  // bit 0 / 1: chunk A / B of trip i may pair its taps
+#ifdef GSH_EXP_ALLSAFE  // timing experiment only: every plain trip pairs its taps (wrong chips near powers of two)
+                return ((i >= first_plain) && (i < last_plain)) ? (NCH == 2 ? 3U : 1U) : 0U;
+#endif
+                const int ch = NCH * i;
+                const unsigned long long mask = (ch < 64) ? der_mask0 : der_mask1;  // uniform select
+                const bool plain = (i >= first_plain) && (i < last_plain) && (ch < 128);
+                const unsigned bits = static_cast<unsigned>(mask >> (ch & 63)) & (NCH == 2 ? 3U : 1U);
+                return plain ? bits : 0U;
+            };
+            constexpr unsigned ALL = (NCH == 2) ? 3U : 1U;
+            int i = 0;
+            while (i < n_trips)
                 {
-                    const int i = i0 + j;
-                    if (i >= n_trips) break;  // uniform
-                    const int n0 = c.n_first + 2 * tid + i * TRIP;
-                    if (until_reseed == 0)  // uniform: exact re-seed of the lane's phasor and of (float)n
+                    unsigned f = flags(i);
+                    while (f == ALL)
                         {
-                            if (r_idx - tbl0 >= TBL)
-                                {
-                                    tbl0 = r_idx;
-                                    T = fill_table(tbl0);
-                                }
-                            pa = pk_cmul(table(4 + r_idx - tbl0), L);
-                            nfA = (v2f){static_cast<float>(n0), static_cast<float>(n0 + 1)};
-                            nfB = (v2f){static_cast<float>(n0 + 2 * PPC), static_cast<float>(n0 + 2 * PPC + 1)};
-                            until_reseed = RESEED;
-                            r_idx++;
+                            trip(i, j0{}, yes{}, integral_constant<bool, NCH == 2>{});
+                            i++;
+                            if (i >= n_trips) break;
+                            f = flags(i);
                         }
-                    until_reseed--;
-                    const bool plain = (i >= first_plain) && (i < last_plain);  // uniform
-                    v2f ia = nfA, ib = nfB;
-                    if (!plain)
-                        {
-                            // edge trip: a sample outside the segment (already zero) is looked up at the nearest sample inside it, so that its
-                            // chip index stays within what is staged.  (The empty volatile asm keeps this a BRANCH: if-converted, its 16 clamp /
-                            // convert / select instructions ran in every trip -- a fifth of the loop's VALU work, ISA of round 2.)
-                            asm volatile("" ::: "memory");
-                            const int lo = c.n_begin, hi = c.n_end - 1;
-                            ia = (v2f){static_cast<float>(min(max(n0, lo), hi)), static_cast<float>(min(max(n0 + 1, lo), hi))};
-                            const int m0 = n0 + 2 * PPC;
-                            if (NCH == 2) ib = (v2f){static_cast<float>(min(max(m0, lo), hi)), static_cast<float>(min(max(m0 + 1, lo), hi))};
-                        }
-                    // rotate first: the samples' registers are then free for the loads of trip i + PF, which take this trip's place in the queue
-                    const v2f yA0 = pk_cmul((v2f){qa[j].x, qa[j].y}, pa);
-                    const v2f yA1 = pk_cmul((v2f){qa[j].z, qa[j].w}, pa);
-                    v2f yB0 = zero, yB1 = zero;
-                    if (NCH == 2)
-                        {
-                            yB0 = pk_cmul((v2f){qb[j].x, qb[j].y}, pa);
-                            yB1 = pk_cmul((v2f){qb[j].z, qb[j].w}, pa);
-                        }
-                    if (i + PF < n_trips) load_trip(i + PF, qa[j], qb[j]);  // uniform
-                    packed_trip<NT, ZP, AUX, NCH>(c, tab, shp, k_step_nrem, aux_shp, aux_on, ia, ib, yA0, yA1, yB0, yB1, A0, A1, B0, B1, XA0, XA1, XB0, XB1);
-                    pa = pk_cmul(pa, w2);
-                    asm("v_pk_add_f32 %0, %0, %1" : "+v"(nfA) : "v"(stride));
-                    if (NCH == 2) asm("v_pk_add_f32 %0, %0, %1" : "+v"(nfB) : "v"(stride));
+                    if (i >= n_trips) break;
+#if GSH_MC_DER_MIXED
+                    if (NCH == 2 && f == 1U)
+                        trip(i, j0{}, yes{}, no{});
+                    else if (NCH == 2 && f == 2U)
+                        trip(i, j0{}, no{}, yes{});
+                    else
+#endif
+                        trip(i, j0{}, no{}, no{});
+                    i++;
+                }
+        }
+    else
+        {
+            for (int i0 = 0; i0 < n_trips; i0 += PF)
+                {
+                    auto slot = [&](auto jc) -> bool {
+                        const int i = i0 + decltype(jc)::value;
+                        if (i >= n_trips) return false;  // uniform
+                        trip(i, jc, no{}, no{});
+                        return true;
+                    };
+                    bool go = slot(integral_constant<int, 0>{});
+                    if constexpr (PF > 1) go = go && slot(integral_constant<int, 1>{});
+                    if constexpr (PF > 2) go = go && slot(integral_constant<int, 2>{});
+                    if constexpr (PF > 3) go = go && slot(integral_constant<int, 3>{});
+                    static_assert(PF <= 4, "load queue: at most four trips");
+                    (void)go;
                 }
         }
     // fold: acc += A0 + inc * A1 + w * (B0 + inc * B1)
@@ -814,7 +987,9 @@ __device__ __forceinline__ void run_segment_runs(const JobCtx& c, const float2* 
         }
 }
 
-template <int NT, int MODE, bool WRAP, bool ZP = false, bool AUX = false>
+// KC: the whole code is staged behind a MARGIN-entry guard band (c.k_off == MC_MARGIN) at LDS address 0: look-ups use a constant offset
+// PAIRK: zero-shift-prompt E/P/L jobs read their early tap next to the late one (the caller checked the job: mcorr_pair_eligible, multicorrelator.h)
+template <int NT, int MODE, bool WRAP, bool ZP = false, bool AUX = false, bool KC = false, bool PAIRK = false>
 __device__ __forceinline__ void run_segment(const JobCtx& c, const float2* __restrict__ base, const float* __restrict__ tab,
     const float (&sh)[NT], const int (&rot)[NT], float2 (&acc)[NT], float2* acc_aux = nullptr)
 {
@@ -831,7 +1006,13 @@ __device__ __forceinline__ void run_segment(const JobCtx& c, const float2* __res
 #else
             constexpr int PF = (MC_THREADS <= 256) ? GSH_MC_PREFETCH_BANK : GSH_MC_PREFETCH_LOOP;
 #endif
-            run_segment_packed<NT, ZP, AUX, NCH, PF>(c, base, tab, sh, acc, acc_aux);
+            if constexpr (PAIRK && NT == 3 && ZP && !AUX && PF == 1)
+                {
+                    // early read next to late (packed_trip); the caller vouches for the job: shifts exactly one chip apart, code running forward
+                    run_segment_packed<NT, ZP, AUX, NCH, PF, true, KC>(c, base, tab, sh, acc, acc_aux);
+                    return;
+                }
+            run_segment_packed<NT, ZP, AUX, NCH, PF, false, KC>(c, base, tab, sh, acc, acc_aux);
             return;
         }
 #endif
@@ -1012,17 +1193,24 @@ __device__ __forceinline__ void correlate_window(const float2* __restrict__ stre
     // wave sums in DPP steps (the last lane holds them), one row of partials per wave behind the output row, one LDS step over the waves.
     // Outputs (red[0..NOUT)) and partials (red[GSH_MAX_TAPS ..)) do not overlap, so a call needs two barriers, not three: the caller reads the
     // outputs and passes a barrier of its own before the next call writes them again.
+    {
+        float sums[2 * NT + (AUX ? 2 : 0)];
 #pragma unroll
-    for (int t = 0; t < NT; t++)
-        {
-            acc[t].x = wave_scan_incl(acc[t].x);
-            acc[t].y = wave_scan_incl(acc[t].y);
-        }
-    if (AUX)
-        {
-            acc_aux.x = wave_scan_incl(acc_aux.x);
-            acc_aux.y = wave_scan_incl(acc_aux.y);
-        }
+        for (int t = 0; t < NT; t++)
+            {
+                sums[2 * t] = acc[t].x;
+                sums[2 * t + 1] = acc[t].y;
+            }
+        if (AUX)
+            {
+                sums[2 * NT] = acc_aux.x;
+                sums[2 * NT + 1] = acc_aux.y;
+            }
+        wave_scan_incl_n(sums);
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] = make_float2(sums[2 * t], sums[2 * t + 1]);
+        if (AUX) acc_aux = make_float2(sums[2 * NT], sums[2 * NT + 1]);
+    }
     const int wave = tid >> 6;
     float2* const part = red + GSH_MAX_TAPS;
     if ((tid & 63) == 63)

@@ -7,6 +7,13 @@
 
 namespace gsh
 {
+// a job whose early tap may be read next to its late tap (mcorr_device.h packed_trip): E/P/L, prompt at exactly 0, late - early exactly 1 chip,
+// standard mode, the code running forward
+__host__ __device__ inline bool mcorr_pair_eligible(int n_taps, const float* shifts, float code_step, int mode)
+{
+    return n_taps == 3 && mode == 0 && shifts[1] == 0.0f && (static_cast<double>(shifts[2]) - static_cast<double>(shifts[0]) == 1.0) && code_step > 0.0f;
+}
+
 struct McorrArgs
 {
     const float2* stream;            // device, complex64 IF samples
@@ -25,6 +32,8 @@ struct McorrArgs
     unsigned long long sample_base;  // added to every job's sample_offset at launch (gsh_bank_set_sample_base): the same resident job table serves block after block
     unsigned long long ring_capacity;// > 0: the stream is a gsh_stream ring, positions are taken modulo its capacity (windows stay contiguous: mirror)
     int packed;                      // 1: the packed four-samples-per-lane body may be used (default); 0: the round-1 body (A/B runs)
+    int pair;                        // 1: every job with two or three taps in this batch is an E/P/L set with a zero-shift prompt, early and late exactly one chip
+                                     // apart and the code running forward (the host checked): the 3-tap launch reads early next to late (mcorr_device.h)
     const int* aux;                  // device, n_jobs, or nullptr.  aux[j] >= 0: job j also computes the single tap of job aux[j] (same window and
                                      // NCO, another code) and writes its output row; -2: job j is computed by its leader; -1: plain job
 };

@@ -44,9 +44,13 @@ using namespace mcdev;
 #endif
 constexpr int MC_RUN_LEN = GSH_MC_RUN_LEN;  // samples per lane run of the run-based path (mcorr_device.h)
 
-template <int NT, int MODE, bool AUX, bool RUNS = false>
+// WIN: the launch stages per-segment windows of the codes (a.window_floats > 0); otherwise every work-group stages its whole code at the start of the
+// LDS and the look-ups use a constant offset
+// PAIR: every job of the launch is pair_eligible (the host checked, a.pair): the early tap is read next to the late one
+template <int NT, int MODE, bool AUX, bool RUNS = false, bool WIN = false, bool PAIR = false>
 __global__ __launch_bounds__(MC_THREADS, ((NT <= 3 && !AUX) ? GSH_MC_MIN_WAVES : 1)) void mcorr_kernel(McorrArgs a)
 {
+    static_assert(!PAIR || (NT == 3 && MODE == 0 && !AUX && !RUNS), "paired taps: the plain E/P/L launch");
     static_assert(!RUNS || (MODE == 0 && !AUX), "the run-based path exists for the standard mode without a fused tap");
     extern __shared__ __align__(16) float lds[];
     const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
@@ -129,7 +133,14 @@ __global__ __launch_bounds__(MC_THREADS, ((NT <= 3 && !AUX) ? GSH_MC_MIN_WAVES :
     const float* __restrict__ gcode = a.codes + static_cast<size_t>(J.code_slot) * a.code_stride;
     bool windowed = false, misfit = false, aux_fast = true;
     int lds_floats;
-    if (a.window_floats > 0)
+    typedef const __attribute__((address_space(3))) float* lds_float_ptr;
+    const bool pair_ok = !PAIR || gsh::mcorr_pair_eligible(J.n_taps, J.shifts_chips, J.code_phase_step_chips, J.high_dyn);
+    if (WIN != (a.window_floats > 0) || !pair_ok || (!WIN && reinterpret_cast<size_t>((lds_float_ptr)lds) != 0))  // (this kernel has no static LDS: the dynamic array starts at 0)
+        {
+            misfit = (c.n_end > c.n_begin);  // cannot happen: the launcher picks the flavour from the same field; reported as NaN if it does
+            lds_floats = a.window_floats > 0 ? a.window_floats : c.code_len + 2 * MC_MARGIN;
+        }
+    else if (a.window_floats > 0)
         {
             const long long span = static_cast<long long>(hi) - lo + 1;
             if (!mode_hd_code(MODE) && c.code_step >= 0.0f && span >= 1 && span <= a.window_floats)
@@ -146,8 +157,15 @@ __global__ __launch_bounds__(MC_THREADS, ((NT <= 3 && !AUX) ? GSH_MC_MIN_WAVES :
         }
     else
         {
+            // the code itself: straight copies (no wrap arithmetic); then the two guard bands, one element per thread of the first wave
+            // (the single loop with a wrap per element cost ~150 VALU instructions per wave -- 7 % of everything a wave executes for a 25 000-sample window)
             const int tab_len = c.code_len + 2 * MC_MARGIN;
-            for (int i = tid; i < tab_len; i += MC_THREADS) tab[i] = gcode[wrap_margin(i - MC_MARGIN, c.code_len)];
+            for (int j = tid; j < c.code_len; j += MC_THREADS) tab[MC_MARGIN + j] = gcode[j];
+            if (tid < 2 * MC_MARGIN)
+                {
+                    const int k = tid < MC_MARGIN ? tid - MC_MARGIN : c.code_len + (tid - MC_MARGIN);  // -MARGIN .. -1, len .. len + MARGIN - 1
+                    tab[MC_MARGIN + k] = gcode[wrap_margin(k, c.code_len)];
+                }
             lds_floats = AUX ? a.code_stride + 2 * MC_MARGIN : tab_len;
         }
     // ---- the fused correlator's code (AUX): a second table behind the first
@@ -220,26 +238,33 @@ __global__ __launch_bounds__(MC_THREADS, ((NT <= 3 && !AUX) ? GSH_MC_MIN_WAVES :
                         }
                 }
             else if (fast && zp)
-                run_segment<NT, MODE, false, true, AUX>(c, base, tab, sh, rot, acc, &acc_aux);
+                run_segment<NT, MODE, false, true, AUX, !WIN, PAIR>(c, base, tab, sh, rot, acc, &acc_aux);
             else if (fast)
-                run_segment<NT, MODE, false, false, AUX>(c, base, tab, sh, rot, acc, &acc_aux);
+                run_segment<NT, MODE, false, false, AUX, !WIN>(c, base, tab, sh, rot, acc, &acc_aux);
             else
                 run_segment<NT, MODE, true, false, AUX>(c, base, tab, sh, rot, acc, &acc_aux);
         }
 
     // ---- integrate-and-dump: wave64 prefix sum in DPP steps (the last lane holds the wave's sum; six v_add_f32_dpp per value instead of the
     // ds_bpermute + address + add of a shuffle tree), then one LDS step over the 4 waves
+    {
+        float sums[2 * NT + (AUX ? 2 : 0)];
 #pragma unroll
-    for (int t = 0; t < NT; t++)
-        {
-            acc[t].x = wave_scan_incl(acc[t].x);
-            acc[t].y = wave_scan_incl(acc[t].y);
-        }
-    if (AUX)
-        {
-            acc_aux.x = wave_scan_incl(acc_aux.x);
-            acc_aux.y = wave_scan_incl(acc_aux.y);
-        }
+        for (int t = 0; t < NT; t++)
+            {
+                sums[2 * t] = acc[t].x;
+                sums[2 * t + 1] = acc[t].y;
+            }
+        if (AUX)
+            {
+                sums[2 * NT] = acc_aux.x;
+                sums[2 * NT + 1] = acc_aux.y;
+            }
+        wave_scan_incl_n(sums);
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] = make_float2(sums[2 * t], sums[2 * t + 1]);
+        if (AUX) acc_aux = make_float2(sums[2 * NT], sums[2 * NT + 1]);
+    }
     const int wave = tid >> 6;
     if ((tid & 63) == 63)
         {
@@ -312,7 +337,10 @@ int launch_nt(const McorrArgs& a, int mode, size_t lds, hipStream_t stream)
             if constexpr (NT == 3 || NT == 5)
                 {
                     GSH_REQUIRE(mode == 0, "fused jobs need the standard mode");
-                    hipLaunchKernelGGL((mcorr_kernel<NT, 0, true>), grid, block, lds, stream, a);
+                    if (a.window_floats > 0)
+                        hipLaunchKernelGGL((mcorr_kernel<NT, 0, true, false, true>), grid, block, lds, stream, a);
+                    else
+                        hipLaunchKernelGGL((mcorr_kernel<NT, 0, true>), grid, block, lds, stream, a);
                     GSH_HIP(hipGetLastError());
                     return GSH_OK;
                 }
@@ -324,7 +352,7 @@ int launch_nt(const McorrArgs& a, int mode, size_t lds, hipStream_t stream)
         case 0:
             if constexpr (NT <= 5)
                 {
-                    if (a.packed == 2)
+                    if (a.packed == 2 && a.window_floats == 0)
                         {
                             const size_t lds_runs = lds + static_cast<size_t>(MC_WAVES) * RunsLayout<MC_RUN_LEN>::FLOATS * sizeof(float);
                             if (lds_runs <= 64 * 1024)  // beyond that the scratch costs more occupancy than the path gains
@@ -334,7 +362,21 @@ int launch_nt(const McorrArgs& a, int mode, size_t lds, hipStream_t stream)
                                 }
                         }
                 }
-            hipLaunchKernelGGL((mcorr_kernel<NT, 0, false>), grid, block, lds, stream, a);
+            if constexpr (NT == 3)
+                {
+                    if (a.pair && a.packed == 1)
+                        {
+                            if (a.window_floats > 0)
+                                hipLaunchKernelGGL((mcorr_kernel<NT, 0, false, false, true, true>), grid, block, lds, stream, a);
+                            else
+                                hipLaunchKernelGGL((mcorr_kernel<NT, 0, false, false, false, true>), grid, block, lds, stream, a);
+                            break;
+                        }
+                }
+            if (a.window_floats > 0)
+                hipLaunchKernelGGL((mcorr_kernel<NT, 0, false, false, true>), grid, block, lds, stream, a);
+            else
+                hipLaunchKernelGGL((mcorr_kernel<NT, 0, false>), grid, block, lds, stream, a);
             break;
         case 1:
             hipLaunchKernelGGL((mcorr_kernel<NT, 1, false>), grid, block, lds, stream, a);
@@ -352,11 +394,13 @@ int launch_nt(const McorrArgs& a, int mode, size_t lds, hipStream_t stream)
 
 int mcorr_packed_default()
 {
-    // GSH_MC_PACKED_BODY: 0 the round-1 body, 1 the packed trips, 2 the run-based path where a job qualifies (A/B switch, read once)
+    // GSH_MC_PACKED_BODY: 0 the round-1 body, 1 the packed trips, 2 the run-based path where a job qualifies, 3 the packed trips with the derived
+    // early / late taps switched off (A/B switch, read once)
     static const int v = [] {
         const char* e = std::getenv("GSH_MC_PACKED_BODY");
         if (e != nullptr && e[0] == '0') return 0;
         if (e != nullptr && e[0] == '2') return 2;
+        if (e != nullptr && e[0] == '3') return 3;  // packed trips without the derived early / late taps
         return 1;
     }();
     return v;

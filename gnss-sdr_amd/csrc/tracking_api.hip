@@ -36,6 +36,7 @@ struct gsh_bank
     unsigned long long ring_min_start{0}, ring_max_end{0};  // absolute sample range of the staged batch (ring-bound banks)
     // windowed code staging (multicorrelator.hip): possible when every job of the batch is mode 0 with code_step >= 0
     bool window_eligible{false};
+    bool pair{false};                   // the staged batch's 2- / 3-tap jobs are all mcorr_pair_eligible (multicorrelator.h)
     double win_step_max{0.0};   // largest code_phase_step_chips of the batch (code samples per input sample)
     double win_code_span_max{0.0};  // largest code_phase_step_chips * n_samples of the batch: code samples one window walks
     double win_shift_span{0.0}; // largest (max shift - min shift) of the batch
@@ -152,11 +153,14 @@ int bank_stage_jobs(gsh_bank* b, const gsh_corr_job* jobs, int n_jobs)
     int max_taps = 0, mode = jobs[0].high_dyn, min_samples = jobs[0].n_samples, max_samples = 0;
     unsigned long long max_end = 0;
     bool window_eligible = (mode == 0);
+    bool pair = true;  // every job the 3-tap launch will see may read its early tap next to the late one (multicorrelator.h mcorr_pair_eligible)
     double step_max = 0.0, shift_span = 0.0, code_span = 0.0;
     for (int i = 0; i < n_jobs; i++)
         {
             int rc = validate_job(b, jobs[i], i);
             if (rc != GSH_OK) return rc;
+            if ((jobs[i].n_taps == 2 || jobs[i].n_taps == 3) && !gsh::mcorr_pair_eligible(jobs[i].n_taps, jobs[i].shifts_chips, jobs[i].code_phase_step_chips, jobs[i].high_dyn))
+                pair = false;
             max_samples = std::max(max_samples, jobs[i].n_samples);
             if (!(jobs[i].code_phase_step_chips >= 0.0f)) window_eligible = false;
             step_max = std::max(step_max, static_cast<double>(jobs[i].code_phase_step_chips));
@@ -245,6 +249,7 @@ int bank_stage_jobs(gsh_bank* b, const gsh_corr_job* jobs, int n_jobs)
     b->max_end = max_end;
     b->max_samples = max_samples;
     b->window_eligible = window_eligible;
+    b->pair = pair;
     b->win_step_max = step_max;
     b->win_code_span_max = code_span;
     b->win_shift_span = shift_span;
@@ -514,6 +519,7 @@ extern "C"
         a.splits = splits;
         a.window_floats = bank_window_floats(b, splits);
         a.packed = gsh::mcorr_packed_default();
+        a.pair = b->pair ? 1 : 0;
         a.sample_base = b->sample_base;
         a.ring_capacity = b->ring != nullptr ? b->ring->capacity : 0ull;
         // the second code table must not cost the occupancy the fusion is meant to win: only with windowed tables or short codes

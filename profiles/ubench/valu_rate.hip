@@ -50,6 +50,80 @@ __global__ __launch_bounds__(256) void k(float* out, int iters)
                                       "v_cvt_flr_i32_f32 %2, %2\n v_cvt_f32_i32 %2, %2\n v_cvt_flr_i32_f32 %3, %3\n v_cvt_f32_i32 %3, %3\n"
                                       : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));)
                 }
+            else if (KIND == 6)  // v_fract_f32
+                {
+                    REP8(asm volatile("v_fract_f32 %0, %0\n v_fract_f32 %1, %1\n v_fract_f32 %2, %2\n v_fract_f32 %3, %3\n"
+                                      "v_fract_f32 %4, %4\n v_fract_f32 %5, %5\n v_fract_f32 %6, %6\n v_fract_f32 %7, %7\n"
+                                      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));)
+                }
+            else if (KIND == 7)  // v_cvt_flr_i32_f32 alone (result fed back as float bits)
+                {
+                    REP8(asm volatile("v_cvt_flr_i32_f32 %0, %0\n v_cvt_flr_i32_f32 %1, %1\n v_cvt_flr_i32_f32 %2, %2\n v_cvt_flr_i32_f32 %3, %3\n"
+                                      "v_cvt_flr_i32_f32 %4, %4\n v_cvt_flr_i32_f32 %5, %5\n v_cvt_flr_i32_f32 %6, %6\n v_cvt_flr_i32_f32 %7, %7\n"
+                                      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));)
+                }
+            else if (KIND == 8)  // v_lshl_add_u32
+                {
+                    REP8(asm volatile("v_lshl_add_u32 %0, %0, 2, %8\n v_lshl_add_u32 %1, %1, 2, %8\n v_lshl_add_u32 %2, %2, 2, %8\n v_lshl_add_u32 %3, %3, 2, %8\n"
+                                      "v_lshl_add_u32 %4, %4, 2, %8\n v_lshl_add_u32 %5, %5, 2, %8\n v_lshl_add_u32 %6, %6, 2, %8\n v_lshl_add_u32 %7, %7, 2, %8\n"
+                                      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c));)
+                }
+            else if (KIND == 9)  // v_cmp_ge_f32_e64 (SGPR pair) + v_cndmask_b32_e64
+                {
+                    REP8(asm volatile("v_cmp_ge_f32_e64 s[20:21], %0, %4\n v_cndmask_b32_e64 %0, %0, %1, s[20:21]\n v_cmp_ge_f32_e64 s[22:23], %1, %4\n v_cndmask_b32_e64 %1, %1, %2, s[22:23]\n"
+                                      "v_cmp_ge_f32_e64 s[20:21], %2, %4\n v_cndmask_b32_e64 %2, %2, %3, s[20:21]\n v_cmp_ge_f32_e64 s[22:23], %3, %4\n v_cndmask_b32_e64 %3, %3, %0, s[22:23]\n"
+                                      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(c) : "s20", "s21", "s22", "s23");)
+                }
+            else if (KIND == 10)  // v_cmp_ge_f32_e32 (vcc) + v_addc_co_u32
+                {
+                    REP8(asm volatile("v_cmp_ge_f32_e32 vcc, %0, %4\n v_addc_co_u32_e32 %0, vcc, %0, %1, vcc\n v_cmp_ge_f32_e32 vcc, %1, %4\n v_addc_co_u32_e32 %1, vcc, %1, %2, vcc\n"
+                                      "v_cmp_ge_f32_e32 vcc, %2, %4\n v_addc_co_u32_e32 %2, vcc, %2, %3, vcc\n v_cmp_ge_f32_e32 vcc, %3, %4\n v_addc_co_u32_e32 %3, vcc, %3, %0, vcc\n"
+                                      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(c) : "vcc");)
+                }
+            else if (KIND == 11)  // v_add_u32 / v_and_b32 mix
+                {
+                    REP8(asm volatile("v_add_u32 %0, %0, %8\n v_and_b32 %1, %1, %8\n v_add_u32 %2, %2, %8\n v_and_b32 %3, %3, %8\n"
+                                      "v_add_u32 %4, %4, %8\n v_and_b32 %5, %5, %8\n v_add_u32 %6, %6, %8\n v_and_b32 %7, %7, %8\n"
+                                      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c));)
+                }
+            else if (KIND == 12)  // v_pk_fma_f32 with op_sel broadcast (the correlator's multiply-accumulate)
+                {
+                    REP8(asm volatile("v_pk_fma_f32 %0, %0, %8, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n v_pk_fma_f32 %1, %1, %8, %1 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n"
+                                      "v_pk_fma_f32 %2, %2, %8, %2 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n v_pk_fma_f32 %3, %3, %8, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n"
+                                      "v_pk_fma_f32 %4, %4, %8, %4 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n v_pk_fma_f32 %5, %5, %8, %5 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n"
+                                      "v_pk_fma_f32 %6, %6, %8, %6 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n v_pk_fma_f32 %7, %7, %8, %7 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n"
+                                      : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(cc));)
+                }
+            else if (KIND == 13)  // v_pk_add_f32 with an SGPR pair operand and op_sel (the chip-index chain)
+                {
+                    REP8(asm volatile("v_pk_add_f32 %0, %0, s[20:21] op_sel:[0,1] op_sel_hi:[1,1]\n v_pk_add_f32 %1, %1, s[20:21] op_sel:[0,0] op_sel_hi:[1,0]\n"
+                                      "v_pk_add_f32 %2, %2, s[20:21] op_sel:[0,1] op_sel_hi:[1,1]\n v_pk_add_f32 %3, %3, s[20:21] op_sel:[0,0] op_sel_hi:[1,0]\n"
+                                      "v_pk_add_f32 %4, %4, s[20:21] op_sel:[0,1] op_sel_hi:[1,1]\n v_pk_add_f32 %5, %5, s[20:21] op_sel:[0,0] op_sel_hi:[1,0]\n"
+                                      "v_pk_add_f32 %6, %6, s[20:21] op_sel:[0,1] op_sel_hi:[1,1]\n v_pk_add_f32 %7, %7, s[20:21] op_sel:[0,0] op_sel_hi:[1,0]\n"
+                                      : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : : "s20", "s21");)
+                }
+            else if (KIND == 14)  // v_pk_fma_f32, three distinct 64-bit sources (accumulator, sample, code pair) as in the correlator
+                {
+                    REP8(asm volatile("v_pk_fma_f32 %0, %4, %6, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n v_pk_fma_f32 %1, %5, %7, %1 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n"
+                                      "v_pk_fma_f32 %2, %4, %7, %2 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n v_pk_fma_f32 %3, %5, %6, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n"
+                                      "v_pk_fma_f32 %0, %5, %7, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n v_pk_fma_f32 %1, %4, %6, %1 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n"
+                                      "v_pk_fma_f32 %2, %5, %6, %2 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n v_pk_fma_f32 %3, %4, %7, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n"
+                                      : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(p4), "v"(p5), "v"(p6), "v"(p7));)
+                }
+            else if (KIND == 15)  // v_fma_f32, three distinct sources
+                {
+                    REP8(asm volatile("v_fma_f32 %0, %4, %6, %0\n v_fma_f32 %1, %5, %7, %1\n v_fma_f32 %2, %4, %7, %2\n v_fma_f32 %3, %5, %6, %3\n"
+                                      "v_fma_f32 %0, %5, %7, %0\n v_fma_f32 %1, %4, %6, %1\n v_fma_f32 %2, %5, %6, %2\n v_fma_f32 %3, %4, %7, %3\n"
+                                      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(a4), "v"(a5), "v"(a6), "v"(a7));)
+                }
+            else if (KIND == 16)  // the mix of a correlator trip: chain add (sgpr), cvt_flr, lshlrev, two pk_fma with distinct sources, twice
+                {
+                    REP8(asm volatile("v_add_f32 %4, s20, %5\n v_cvt_flr_i32_f32 %6, %4\n v_lshlrev_b32 %6, 2, %6\n"
+                                      "v_pk_fma_f32 %0, %8, %9, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n v_pk_fma_f32 %1, %8, %9, %1 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n"
+                                      "v_add_f32 %5, s21, %4\n v_cvt_flr_i32_f32 %7, %5\n v_lshlrev_b32 %7, 2, %7\n"
+                                      "v_pk_fma_f32 %2, %9, %8, %2 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n v_pk_fma_f32 %3, %9, %8, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n"
+                                      : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(p6), "v"(p7) : "s20", "s21");)
+                }
         }
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p1.y + p2.x + p3.y + p4.x + p5.y + p6.x + p7.y;
 }
@@ -70,14 +144,14 @@ void run(const char* name, int waves_per_simd)
     hipEventSynchronize(e1);
     float ms;
     hipEventElapsedTime(&ms, e0, e1);
-    const double wave_instr_per_simd = (double)iters * 64.0 * waves_per_simd;
+    const double wave_instr_per_simd = (double)iters * (KIND == 16 ? 80.0 : 64.0) * waves_per_simd;
     printf("%-28s waves/SIMD=%d  %.3f ms  -> %.2f ns per wave-instruction per SIMD (= %.2f cycles at 2.4 GHz)\n", name, waves_per_simd, ms,
         ms * 1e6 / wave_instr_per_simd, ms * 1e6 / wave_instr_per_simd * 2.4);
     hipFree(d);
 }
 int main()
 {
-    for (int w : {1, 2, 4})
+    for (int w : {2, 6})
         {
             run<0>("v_fma_f32", w);
             run<1>("v_pk_fma_f32", w);
@@ -85,6 +159,17 @@ int main()
             run<4>("v_add_f32", w);
             run<2>("v_xor_b32/v_mov_b32", w);
             run<5>("v_cvt_flr_i32/v_cvt_f32_i32", w);
+            run<7>("v_cvt_flr_i32_f32", w);
+            run<6>("v_fract_f32", w);
+            run<8>("v_lshl_add_u32", w);
+            run<9>("v_cmp_e64 + v_cndmask_e64", w);
+            run<10>("v_cmp_e32 + v_addc_co_u32", w);
+            run<11>("v_add_u32/v_and_b32", w);
+            run<12>("v_pk_fma_f32 op_sel", w);
+            run<13>("v_pk_add_f32 sgpr op_sel", w);
+            run<14>("v_pk_fma_f32 3 distinct srcs", w);
+            run<15>("v_fma_f32 3 distinct srcs", w);
+            run<16>("trip mix (per 10: 4 pk_fma, 2 add, 2 cvt, 2 shift)", w);
         }
     return 0;
 }

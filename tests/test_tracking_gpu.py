@@ -9,6 +9,9 @@ Bars (tests/helpers.py): chip selection bit-exact (checked through exact equalit
 carrier-free input); |gpu - truth| / sum|x| <= 1e-6 (north_star's 1e-5, with margin);
 |gpu - generic| / |generic| <= 5e-5 on taps that hold a signal.
 """
+import os
+import sys
+
 import numpy as np
 import pytest
 
@@ -123,6 +126,111 @@ def test_chip_selection_bit_exact(gpu):
             assert np.array_equal(got.real.astype(np.float64), expect), (job, got, expect)
             assert np.all(got.imag == 0)
     b.close()
+
+
+def _derived_tap_jobs(rng, n, n_codes):
+    """E/P/L jobs aimed at the derived-tap trips (csrc/mcorr_device.h derived_lookup): shift sets that qualify ((-s, 0, 1 - s), s a multiple of 2^-8) and
+    sets that do not, code steps that put the chip phase exactly ON the compare threshold (dyadic steps: ties), code phases below zero and beyond one,
+    windows whose chip range crosses every power of two up to the code length."""
+    shift_sets = [[-0.5, 0.0, 0.5], [-0.25, 0.0, 0.75], [-1.0, 0.0, 0.0], [-0.75, 0.0, 0.25], [-0.00390625, 0.0, 0.99609375], [-0.3, 0.0, 0.3], [-0.5, 0.0, 0.75]]
+    steps = [1.023e6 / 25e6, 1.023e6 / 4e6, 0.5, 0.25, 0.125, 0.0625, 0.03125, 1.0, 0.040919998, 0.0409200004]
+    rems = [0.0, 0.5, 0.25, 0.999, -0.3, 1.7, 0.4999999, 0.5000001, 1.0 / 3.0]
+    jobs = []
+    for sh in shift_sets:
+        for step in steps:
+            rem = float(np.float32(rems[len(jobs) % len(rems)]))
+            step32 = float(np.float32(step))
+            length = int(min(n, (1023 + 20) / step32))  # stay inside one code period (+ margin): the path without the per-sample wrap
+            jobs.append(dict(sample_offset=int(rng.integers(0, 64)), n_samples=length, code_slot=len(jobs) % n_codes, shifts_chips=sh, rem_carr_phase_rad=0.0,
+                             phase_step_rad=0.0, rem_code_phase_chips=rem, code_phase_step_chips=step32))
+    return jobs
+
+
+def test_derived_taps_select_the_reference_chips(gpu):
+    """Integer-valued samples, zero carrier: every float32 sum is exact, so a tap's output equals sum_n x[n] code[k_t[n]] iff every chip index is the
+    oracle's.  The weights make a swapped pair of indices visible (with x = 1 only the count of each code value would be)."""
+    n = 26000
+    rng = np.random.default_rng(2024)
+    xr = rng.integers(-7, 8, 2 * n + 128).astype(np.float32)
+    x = xr.astype(np.complex64)
+    codes = [oracle.ca_code(p) for p in (2, 9, 23)]
+    b = _bank(gpu, codes)
+    b.set_stream_host(x)
+    jobs = _derived_tap_jobs(rng, n, len(codes))
+    for k in range(0, len(jobs), 10):
+        group = jobs[k:k + 10]
+        out = b.correlate(group)
+        for j, job in enumerate(group):
+            sh = np.asarray(job["shifts_chips"], np.float32)
+            idx = oracle.code_indices(job["n_samples"], sh, job["rem_code_phase_chips"], job["code_phase_step_chips"], 0.0, 1023, False)
+            seg = xr[job["sample_offset"]:job["sample_offset"] + job["n_samples"]].astype(np.float64)
+            expect = np.array([(codes[job["code_slot"]][idx[t]].astype(np.float64) * seg).sum() for t in range(3)])
+            got = out[j, :3]
+            assert np.array_equal(got.real.astype(np.float64), expect), (job, got, expect)
+            assert np.all(got.imag == 0)
+    b.close()
+
+
+def test_derived_taps_on_long_codes(gpu):
+    """The same on 10 230-chip codes (chip indices up to 2^13.3: the binades 1024 .. 8192), whole windows and the windowed code table with automatic splits."""
+    fs, n = 25e6, 25000
+    rng = np.random.default_rng(99)
+    codes = [(2 * rng.integers(0, 2, 10230) - 1).astype(np.int32) for _ in range(2)]
+    xr = rng.integers(-7, 8, 2 * n + 128).astype(np.float32)
+    b = _bank(gpu, codes)
+    b.set_stream_host(xr.astype(np.complex64))
+    step = float(np.float32(10.23e6 / fs))
+    jobs = []
+    for i in range(24):
+        sh = [[-0.5, 0.0, 0.5], [-0.25, 0.0, 0.75], [-1.0, 0.0, 0.0]][i % 3]
+        jobs.append(dict(sample_offset=int(rng.integers(0, n)), n_samples=n - int(rng.integers(0, 3)), code_slot=i % 2, shifts_chips=sh, rem_carr_phase_rad=0.0,
+                         phase_step_rad=0.0, rem_code_phase_chips=float(np.float32(rng.uniform(-0.5, 1.5))), code_phase_step_chips=step))
+    out = b.correlate(jobs)
+    for j, job in enumerate(jobs):
+        sh = np.asarray(job["shifts_chips"], np.float32)
+        idx = oracle.code_indices(job["n_samples"], sh, job["rem_code_phase_chips"], step, 0.0, 10230, False)
+        seg = xr[job["sample_offset"]:job["sample_offset"] + job["n_samples"]].astype(np.float64)
+        expect = np.array([(codes[job["code_slot"]][idx[t]].astype(np.float64) * seg).sum() for t in range(3)])
+        assert np.array_equal(out[j, :3].real.astype(np.float64), expect), (job, out[j, :3], expect)
+    b.close()
+
+
+_DERIVED_AB_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
+import oracle
+from test_tracking_gpu import _bank, _derived_tap_jobs
+from helpers import tracking_params_for
+rng = np.random.default_rng(5)
+n = 26000
+x = (rng.standard_normal(2 * n + 128) + 1j * rng.standard_normal(2 * n + 128)).astype(np.complex64)
+codes = [oracle.ca_code(p) for p in (2, 9, 23)]
+b = _bank(0, codes)
+b.set_stream_host(x)
+jobs = _derived_tap_jobs(rng, n, 3)
+for job in jobs:
+    p = tracking_params_for(25e6, float(rng.uniform(-5000, 5000)), rng)
+    job["rem_carr_phase_rad"] = p["rem_carr_phase_rad"]
+    job["phase_step_rad"] = p["phase_step_rad"]
+outs = [b.correlate(jobs[k:k + 10]) for k in range(0, len(jobs), 10)]
+np.save(sys.argv[1], np.concatenate(outs))
+"""
+
+
+def test_paired_taps_are_bit_identical(gpu, tmp_path):
+    """Random complex samples with a carrier, the same jobs with the paired-tap trips on (default) and off (GSH_MC_PACKED_BODY=3, read once per process):
+    same chips, same products, same order of summation -- the outputs must agree bit for bit."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = _DERIVED_AB_SCRIPT.format(root=root, tests=os.path.join(root, "tests"))
+    outs = {}
+    for body in ("1", "3"):
+        f = str(tmp_path / f"out_{body}.npy")
+        r = subprocess.run([sys.executable, "-c", script, f], cwd=root, env=dict(os.environ, GSH_MC_PACKED_BODY=body), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        outs[body] = np.load(f)
+    assert outs["1"].shape == outs["3"].shape and outs["1"].shape[0] >= 60
+    assert np.array_equal(outs["1"].view(np.uint32), outs["3"].view(np.uint32))
 
 
 def test_even_tap_counts_and_one_sided_shifts_on_a_windowed_code(gpu):
