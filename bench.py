@@ -19,7 +19,7 @@ value = channels*taps*epochs*blocks / time, whole job.  Default K = 20 steps = 1
   torch.distributed only hands the 128-byte communicator id round and provides the barrier / MAX-reduce of the contract -- no data.
 
 One JSON line on stdout (rank 0).  Besides the contract keys it carries
-  roofline      -- dominant kernel (mcorr_kernel<3,0,false>) vs the HBM roofline, algorithmic bytes 8N+8T per job,
+  roofline      -- dominant kernel (mcorr_kernel<3,0,false,false,false,true>: E/P/L, whole-code table, paired taps) vs the HBM roofline, algorithmic bytes 8N+8T per job,
                    duration from HIP events on the launch stream
   cpu_baseline  -- the reference's own Cpu_Multicorrelator_Real_Codes (oracle/_ref, x86 SIMD protokernels) timed on
                    this box's host cores over a bounded sample (falls back to the C port when _ref is absent)
@@ -410,7 +410,7 @@ def tracking_roofline(C, E, T, n, k_ms, pmc):
     flops = float(C) * E * n * (6.0 + 4.0 * T)
     unique = 8.0 * (E + 1) * n + 4.0 * 1023 * C + 64.0 * n_jobs
     r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-         "kernel": f"mcorr_kernel<{3 if T <= 3 else (5 if T <= 5 else 8)},0,false,false>", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
+         "kernel": f"mcorr_kernel<{3 if T <= 3 else (5 if T <= 5 else 8)},0,false,false,false,{'true' if T == 3 else 'false'}>", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
          "binding": "valu",
          "valu": {"algorithmic_flops_per_launch": flops, "achieved_tflops": flops / t / 1e12, "peak_tflops": FP32_PEAK_TFLOPS,
                   "frac": flops / t / 1e12 / FP32_PEAK_TFLOPS},
