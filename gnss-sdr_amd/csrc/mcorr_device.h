@@ -35,7 +35,8 @@ constexpr int MC_MARGIN = 32;  // guard entries on each side of the LDS code tab
 #define GSH_MC_PREFETCH_BANK 1  // trips of loads in flight per lane, batched kernel
 #endif
 #ifndef GSH_MC_PREFETCH_LOOP
-#define GSH_MC_PREFETCH_LOOP 4  // the same for the 1024-thread closed-loop kernel
+#define GSH_MC_PREFETCH_LOOP 1  // the same for the 1024-thread closed-loop kernel (4 until the end of round 2: same 9.15 us per period, and the twelve VGPRs
+                                // of the deeper queue were what pushed long-lived constants of the loop arithmetic into scratch)
 #endif
 #ifndef GSH_MC_CVT_FLR
 #define GSH_MC_CVT_FLR 1
@@ -587,7 +588,7 @@ __device__ __forceinline__ void run_segment_packed(const JobCtx& c, const float2
     const v2f w2 = table(2);
 
     // Loads run PF trips ahead of the arithmetic (a register queue, the trip loop unrolled by PF).  The batched kernel (many work-groups per
-    // compute unit) gets by with PF = 1; the closed-loop kernel has ONE work-group per channel, so it keeps PF = 4 loads in flight per lane.
+    // compute unit) gets by with PF = 1; the closed-loop kernel has ONE work-group per channel and ran PF = 4 until measurement showed PF = 1 to be as fast.
     // (Measured, round 2, profiles/r02/closed_loop_phases.txt: the depth hardly matters -- of the 11 us of a closed-loop period 2.4 us are thread
     // 0's loop arithmetic, 2.6 us fixed cost of the correlation phase (barriers, reductions) and 6 us the 13 trips of each wave.)
     const float2* const q0 = base + 2 * tid;  // the lane's pair of chunk 0
@@ -1193,24 +1194,19 @@ __device__ __forceinline__ void correlate_window(const float2* __restrict__ stre
     // wave sums in DPP steps (the last lane holds them), one row of partials per wave behind the output row, one LDS step over the waves.
     // Outputs (red[0..NOUT)) and partials (red[GSH_MAX_TAPS ..)) do not overlap, so a call needs two barriers, not three: the caller reads the
     // outputs and passes a barrier of its own before the next call writes them again.
-    {
-        float sums[2 * NT + (AUX ? 2 : 0)];
+    // (the per-value form here: in the 1024-thread kernel the all-at-once v_add_f32_dpp form of the batched kernel keeps a dozen values live through 72
+    //  instructions at the most crowded point of the function and sends registers to scratch)
 #pragma unroll
-        for (int t = 0; t < NT; t++)
-            {
-                sums[2 * t] = acc[t].x;
-                sums[2 * t + 1] = acc[t].y;
-            }
-        if (AUX)
-            {
-                sums[2 * NT] = acc_aux.x;
-                sums[2 * NT + 1] = acc_aux.y;
-            }
-        wave_scan_incl_n(sums);
-#pragma unroll
-        for (int t = 0; t < NT; t++) acc[t] = make_float2(sums[2 * t], sums[2 * t + 1]);
-        if (AUX) acc_aux = make_float2(sums[2 * NT], sums[2 * NT + 1]);
-    }
+    for (int t = 0; t < NT; t++)
+        {
+            acc[t].x = wave_scan_incl(acc[t].x);
+            acc[t].y = wave_scan_incl(acc[t].y);
+        }
+    if (AUX)
+        {
+            acc_aux.x = wave_scan_incl(acc_aux.x);
+            acc_aux.y = wave_scan_incl(acc_aux.y);
+        }
     const int wave = tid >> 6;
     float2* const part = red + GSH_MAX_TAPS;
     if ((tid & 63) == 63)

@@ -187,12 +187,23 @@ __device__ __forceinline__ float fll_pll_carrier_error(FllPllState& f, float fll
     return out;
 }
 
+// A zero the compiler cannot share: it kept ONE 64-bit zero in a VGPR pair from the kernel's first block to the state transitions that clear the
+// accumulators -- across the whole epoch loop --, and with 128 VGPRs for 1 024 threads that pair went to scratch.
+__device__ __forceinline__ float2 fresh_zero2()
+{
+    float2 z;
+    asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0" : "=v"(z.x), "=v"(z.y));
+    return z;
+}
+
 // ---- lock detectors and C/N0 (T/lock_detectors.cc, T/exponential_smoother.cc), float32 and sequential as written there ----
 __device__ float cn0_m2m4_estimator_d(const float* prompt_iq, int length, float coh_integration_time_s)  // T/lock_detectors.cc:61-110
 {
     float SNR_aux = 0.0f, Psig = 0.0f, m_2 = 0.0f, m_4 = 0.0f, aux;
     const float n = static_cast<float>(length);
     if (length == 0 || coh_integration_time_s == 0.0f) return -100.0f;
+    // (one thread runs this; unrolled eight times the loop wants sixty VGPRs of temporaries at the most crowded point of the kernel and pushes five values into scratch)
+#pragma clang loop unroll_count(2)
     for (int i = 0; i < length; i++)
         {
             const float re = prompt_iq[2 * i], im = prompt_iq[2 * i + 1];
@@ -789,7 +800,7 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
                                             lk.current_symbol = 0;
                                             lk.current_data_symbol = 0;
 #pragma unroll
-                                            for (int t = 0; t < 5; t++) lk.accv[t] = make_float2(0.0f, 0.0f);
+                                            for (int t = 0; t < 5; t++) lk.accv[t] = fresh_zero2();
                                             if (extend > 1)  // trk.cc:2114-2149: stretch the integration, narrow the loops and the correlator spacing
                                                 {
                                                     lk.ext_count = 0;
@@ -831,7 +842,7 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
                                             lk.p_data_accu[0] = lk.p_data_accu[1] = 0.0f;
                                         }
 #pragma unroll
-                                    for (int t = 0; t < 5; t++) lk.accv[t] = make_float2(0.0f, 0.0f);  // trk.cc:2241-2246
+                                    for (int t = 0; t < 5; t++) lk.accv[t] = fresh_zero2();  // trk.cc:2241-2246
                                     if (extend > 1) lk.state = 3;                                     // trk.cc:2247-2250
                                 }
                             if (lk.flag_pll_180) rec_symbol_flags |= 2;
