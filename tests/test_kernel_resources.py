@@ -1,0 +1,46 @@
+"""Register / scratch budget of the tracking kernels, read from the built library's code-object metadata (no GPU needed).
+
+VERDICT round 1 asked for a closed-loop kernel without scratch (it had 976 B per thread); small changes elsewhere in the kernel have since pushed a few long-lived constants back
+into scratch more than once (the 1 024-thread work-group leaves 128 VGPRs), so the property is pinned here.  The batched correlator's launch flavours must not spill either: a
+spilling flavour ran 45 % slower (profiles/r02/mcorr_bound_experiments.txt)."""
+import os
+import re
+
+import pytest
+
+import gnss_sdr_amd
+from kernel_metadata import kernels
+
+
+@pytest.fixture(scope="module")
+def meta():
+    lib = gnss_sdr_amd._lib.LIB_PATH
+    if not os.path.exists(lib):
+        pytest.skip("library not built")
+    k = kernels(lib)
+    assert len(k) > 50, "no gfx950 code objects found in the library"
+    return k
+
+
+def test_closed_loop_kernels_use_no_scratch(meta):
+    loop = {n: k for n, k in meta.items() if "trk_loop_kernel" in n}
+    assert len(loop) >= 4
+    for n, k in loop.items():
+        assert k[".private_segment_fixed_size"] == 0, (n, k[".private_segment_fixed_size"])
+        assert k[".vgpr_count"] <= 128, (n, k[".vgpr_count"])  # 1 024 threads per work-group
+
+
+def test_batched_correlator_flavours_use_no_scratch(meta):
+    # mcorr_kernel<NT, MODE, AUX, RUNS, WIN, PAIR>: every flavour except the run-based experiment (RUNS = true, behind GSH_MC_PACKED_BODY=2)
+    pat = re.compile(r"mcorr_kernelILi(\d)ELi(\d)ELb([01])ELb([01])ELb([01])ELb([01])E")
+    seen = 0
+    for n, k in meta.items():
+        m = pat.search(n)
+        if not m or m.group(4) == "1":
+            continue
+        seen += 1
+        assert k[".private_segment_fixed_size"] == 0, (n, k[".private_segment_fixed_size"])
+        if m.group(1) == "3" and m.group(2) == "0" and m.group(3) == "0":
+            # E/P/L, standard mode: 6 waves per SIMD for the per-tap flavour (<= 80 VGPRs), 5 for the paired-tap flavour (<= 96)
+            assert k[".vgpr_count"] <= (96 if m.group(6) == "1" else 80), (n, k[".vgpr_count"])
+    assert seen >= 12
