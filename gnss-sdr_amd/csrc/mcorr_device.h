@@ -374,6 +374,14 @@ __device__ __forceinline__ v2f pk_cmul(v2f x, v2f p)  // complex x * p
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(x), "v"(p), "v"(t));          // (-xi pi, xi pr) + t
     return r;
 }
+// the same with a wave-uniform p taken straight from an SGPR pair (no per-trip copy into VGPRs)
+__device__ __forceinline__ v2f pk_cmul_s(v2f x, v2f p)
+{
+    v2f t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(x), "s"(p));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(x), "s"(p), "v"(t));
+    return r;
+}
 // acc += y * c.lo / c.hi (the real code value broadcast to both components)
 __device__ __forceinline__ void pk_fma_lo(v2f& acc, v2f y, v2f c)
 {
@@ -704,9 +712,9 @@ __device__ __forceinline__ void run_segment_packed(const JobCtx& c, const float2
             }
         if (i + PF < n_trips) load_trip(i + PF, qa[j], qb[j]);  // uniform
         packed_trip<NT, ZP, AUX, NCH, FA, FB, KC>(c, tab, shp, k_step_nrem, aux_shp, aux_on, ia, ib, yA0, yA1, yB0, yB1, A0, A1, B0, B1, XA0, XA1, XB0, XB1);
-        pa = pk_cmul(pa, w2);
-        asm("v_pk_add_f32 %0, %0, %1" : "+v"(nfA) : "v"(stride));
-        if (NCH == 2) asm("v_pk_add_f32 %0, %0, %1" : "+v"(nfB) : "v"(stride));
+        pa = pk_cmul_s(pa, w2);  // (w2 and the stride are wave-uniform: straight from SGPRs, not copied into VGPRs every trip)
+        asm("v_pk_add_f32 %0, %0, %1" : "+v"(nfA) : "s"(stride));
+        if (NCH == 2) asm("v_pk_add_f32 %0, %0, %1" : "+v"(nfB) : "s"(stride));
     };
     using std::integral_constant;
     using no = integral_constant<bool, false>;
