@@ -171,6 +171,42 @@ def test_derived_taps_select_the_reference_chips(gpu):
     b.close()
 
 
+def test_paired_taps_random_sweep(gpu):
+    """600 random E/P/L jobs with a one-chip early-late spacing -- code steps from 0.01 to 2 chips per sample (a third of them dyadic multiples of 2^-10, where
+    chip phases land exactly on tap boundaries), code phases in [-1, 2), window starts anywhere, lengths from one sample to a code period -- against the oracle's chips."""
+    rng = np.random.default_rng(31337)
+    n_max = 30000
+    xr = rng.integers(-7, 8, 2 * n_max + 128).astype(np.float32)
+    codes = [oracle.ca_code(p) for p in (3, 11, 29)]
+    b = _bank(gpu, codes)
+    b.set_stream_host(xr.astype(np.complex64))
+    jobs = []
+    for i in range(600):
+        kind = i % 3
+        if kind == 0:
+            step = float(np.float32(rng.uniform(0.01, 2.0)))
+        elif kind == 1:
+            step = float(np.float32(rng.integers(8, 2048) / 1024.0))
+        else:
+            step = float(np.float32(1.023e6 / rng.choice([2e6, 4e6, 5e6, 10e6, 12.5e6, 16.368e6, 25e6, 50e6])))
+        s = float(np.float32(rng.choice([0.5, 0.25, 0.75, 1.0, 0.125, 0.3])))
+        sh = [float(np.float32(-s)), 0.0, float(np.float32(np.float32(-s) + np.float32(1.0)))]
+        length = int(min(n_max, max(1, rng.integers(1, int((1023 + 20) / step) + 1))))
+        jobs.append(dict(sample_offset=int(rng.integers(0, n_max)), n_samples=length, code_slot=i % 3, shifts_chips=sh, rem_carr_phase_rad=0.0, phase_step_rad=0.0,
+                         rem_code_phase_chips=float(np.float32(rng.uniform(-1.0, 2.0))), code_phase_step_chips=step))
+    for k in range(0, len(jobs), 50):
+        group = jobs[k:k + 50]
+        out = b.correlate(group)
+        for j, job in enumerate(group):
+            sh = np.asarray(job["shifts_chips"], np.float32)
+            idx = oracle.code_indices(job["n_samples"], sh, job["rem_code_phase_chips"], job["code_phase_step_chips"], 0.0, 1023, False)
+            seg = xr[job["sample_offset"]:job["sample_offset"] + job["n_samples"]].astype(np.float64)
+            expect = np.array([(codes[job["code_slot"]][idx[t]].astype(np.float64) * seg).sum() for t in range(3)])
+            assert np.array_equal(out[j, :3].real.astype(np.float64), expect), (job, out[j, :3], expect)
+            assert np.all(out[j, :3].imag == 0)
+    b.close()
+
+
 def test_derived_taps_on_long_codes(gpu):
     """The same on 10 230-chip codes (chip indices up to 2^13.3: the binades 1024 .. 8192), whole windows and the windowed code table with automatic splits."""
     fs, n = 25e6, 25000
