@@ -510,8 +510,44 @@ __device__ __forceinline__ void packed_trip(const JobCtx& c, const float* __rest
                     }
             }
     };
-    chunk(aA, yA0, yA1, A0, A1, std::integral_constant<bool, PA>{});
-    if (NCH == 2) chunk(aB, yB0, yB1, B0, B1, std::integral_constant<bool, PB>{});
+    if constexpr (PA && PB && NCH == 2 && NT == 3)
+        {
+            // both chunks paired (the common trip): all eight look-ups of the trip go out before the first multiply-accumulate waits for one -- left to itself the
+            // scheduler, short of registers, serialises chunk A's reads, its accumulates, chunk B's reads, its accumulates: two exposed LDS round trips per trip
+            struct Codes
+            {
+                v2f p, el0, el1;
+            };
+            auto codes_of = [&](v2f a) -> Codes {
+                Codes d;
+                d.p = lookup(a, shp[1], ZP, koff, std::true_type{});
+                int k0, k1;
+                chain(a, shp[2], false, k0, k1);
+                d.el0.x = code_at(k0, koff, dm1{}, std::true_type{});
+                d.el0.y = code_at(k0, koff, d0{}, std::true_type{});
+                d.el1.x = code_at(k1, koff, dm1{}, std::true_type{});
+                d.el1.y = code_at(k1, koff, d0{}, std::true_type{});
+                return d;
+            };
+            auto accumulate = [&](const Codes& d, v2f y0, v2f y1, v2f (&S0)[NT], v2f (&S1)[NT]) {
+                pk_fma_lo(S0[0], y0, d.el0);
+                pk_fma_lo(S1[0], y1, d.el1);
+                pk_fma_lo(S0[1], y0, d.p);
+                pk_fma_hi(S1[1], y1, d.p);
+                pk_fma_hi(S0[2], y0, d.el0);
+                pk_fma_hi(S1[2], y1, d.el1);
+            };
+            const Codes dA = codes_of(aA);
+            const Codes dB = codes_of(aB);
+            __builtin_amdgcn_sched_barrier(0);
+            accumulate(dA, yA0, yA1, A0, A1);
+            accumulate(dB, yB0, yB1, B0, B1);
+        }
+    else
+        {
+            chunk(aA, yA0, yA1, A0, A1, std::integral_constant<bool, PA>{});
+            if (NCH == 2) chunk(aB, yB0, yB1, B0, B1, std::integral_constant<bool, PB>{});
+        }
     if (AUX && aux_on)
         {
             const bool zs = ZP && c.aux_zero;
