@@ -543,6 +543,28 @@ __device__ __forceinline__ void packed_trip(const JobCtx& c, const float* __rest
             accumulate(dA, yA0, yA1, A0, A1);
             accumulate(dB, yB0, yB1, B0, B1);
         }
+    else if constexpr (!PA && !PB && NCH == 2 && NT <= 3)
+        {
+            // the same for the per-tap form: 4 NT look-ups, then the accumulates
+            v2f cA[NT], cB[NT];
+#pragma unroll
+            for (int t = 0; t < NT; t++) cA[t] = lookup(aA, shp[t], ZP && t == NT / 2, koff, std::true_type{});
+#pragma unroll
+            for (int t = 0; t < NT; t++) cB[t] = lookup(aB, shp[t], ZP && t == NT / 2, koff, std::true_type{});
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < NT; t++)
+                {
+                    pk_fma_lo(A0[t], yA0, cA[t]);
+                    pk_fma_hi(A1[t], yA1, cA[t]);
+                }
+#pragma unroll
+            for (int t = 0; t < NT; t++)
+                {
+                    pk_fma_lo(B0[t], yB0, cB[t]);
+                    pk_fma_hi(B1[t], yB1, cB[t]);
+                }
+        }
     else
         {
             chunk(aA, yA0, yA1, A0, A1, std::integral_constant<bool, PA>{});
