@@ -668,15 +668,22 @@ __device__ __forceinline__ void run_segment_packed(const JobCtx& c, const float2
             {
                 // a wave-uniform 64-bit base plus a 32-bit lane offset: the loads take their base from SGPRs, and no per-lane pointer is carried (and advanced) in VGPRs
                 const char* const ua = reinterpret_cast<const char*>(base + static_cast<long long>(i) * TRIP);
-                const char* const ub = ua + 16 * PPC;
 #ifdef GSH_EXP_NOLOAD  // timing experiment only (profiles/r02/mcorr_bound_experiments.txt): no sample traffic
                 va = make_float4(1.0f, static_cast<float>(i), 0.5f, 0.25f);
                 if (NCH == 2) vb = make_float4(0.5f, static_cast<float>(i), 1.0f, 0.25f);
                 asm volatile("" : "+v"(va.x), "+v"(va.y), "+v"(va.z), "+v"(va.w));
                 if (NCH == 2) asm volatile("" : "+v"(vb.x), "+v"(vb.y), "+v"(vb.z), "+v"(vb.w));
 #else
-                va = *reinterpret_cast<const float4*>(ua + lane_bytes);
-                if (NCH == 2) vb = *reinterpret_cast<const float4*>(ub + lane_bytes);
+                if constexpr (NCH == 2)
+                    {
+                        // chunk A / B at -/+ half a chunk around the middle: both inside the 13-bit immediate offset of global_load (a whole chunk, 16 PPC = 4096
+                        // bytes at 256 threads, is one more than the field holds and cost a 64-bit add per trip)
+                        const char* const mid = ua + 8 * PPC + lane_bytes;
+                        va = *reinterpret_cast<const float4*>(mid - 8 * PPC);
+                        vb = *reinterpret_cast<const float4*>(mid + 8 * PPC);
+                    }
+                else
+                    va = *reinterpret_cast<const float4*>(ua + lane_bytes);
 #endif
             }
         else
