@@ -704,7 +704,7 @@ __device__ __forceinline__ void run_segment_packed(const JobCtx& c, const float2
                     }
             }
     };
-    // paired taps (DER): one bit per chunk of 2 PPC samples, set where every value of the early and the late index chain stays inside one binade
+    // paired taps (DER): one bit per chunk of 2 PPC samples (per WAVE: see judge), set where every value of the early and the late index chain stays inside one binade
     // (margins of 1/8 chip; see packed_trip).  Lane l judges chunk 64 m + l.  All of it happens HERE, before the accumulators exist: evaluated inside the
     // trip loop its temporaries cost the loop a dozen VGPRs and with them one wave per SIMD.  Two masks = 128 chunks; what lies
     // beyond (windows longer than 2^16 samples at 256 threads) runs the per-tap chains.
@@ -712,10 +712,12 @@ __device__ __forceinline__ void run_segment_packed(const JobCtx& c, const float2
     if constexpr (DER)
         {
             // float arithmetic is enough: the margins (1/8 chip) exceed its error (< 2^-7 below the 2^16 bound) by far, and a chunk judged unsafe only loses speed
+            // A WAVE judges its own 128 samples of each chunk (its lanes' pairs), not the chunk's 2 PPC: the trip form is a per-wave choice, and of the waves of a
+            // chunk that straddles a power of two only the one or two that hold the crossing keep the per-tap chains.
             auto judge = [&](int first_chunk) -> unsigned long long {
-                const float n_lo = static_cast<float>(c.n_first + 2 * PPC * (first_chunk + lane));
+                const float n_lo = static_cast<float>(c.n_first + 2 * PPC * (first_chunk + lane) + 128 * (tid >> 6));
                 const float lo1 = c.code_step * n_lo + (sh[0] - 0.125f);
-                const float hi1 = c.code_step * (n_lo + static_cast<float>(2 * PPC - 1)) + (sh[NT - 1] + 0.125f);
+                const float hi1 = c.code_step * (n_lo + 127.0f) + (sh[NT - 1] + 0.125f);
                 const float lo2 = lo1 - c.rem_code, hi2 = hi1 - c.rem_code;
                 const bool one_binade_a = (lo1 >= 1.0f) && (hi1 < 65536.0f) && ((__float_as_uint(lo1) >> 23) == (__float_as_uint(hi1) >> 23));
                 const bool one_binade_u = (lo2 >= 1.0f) && (hi2 < 65536.0f) && ((__float_as_uint(lo2) >> 23) == (__float_as_uint(hi2) >> 23));
