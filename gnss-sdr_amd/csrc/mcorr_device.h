@@ -565,6 +565,20 @@ __device__ __forceinline__ void packed_trip(const JobCtx& c, const float* __rest
                     pk_fma_hi(B1[t], yB1, cB[t]);
                 }
         }
+    else if constexpr (!PA && NCH == 1 && NT <= 5)
+        {
+            // one chunk per trip (the 1 024-thread closed-loop kernel): the same, 2 NT look-ups and then the accumulates
+            v2f cA[NT];
+#pragma unroll
+            for (int t = 0; t < NT; t++) cA[t] = lookup(aA, shp[t], ZP && t == NT / 2, koff, std::true_type{});
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < NT; t++)
+                {
+                    pk_fma_lo(A0[t], yA0, cA[t]);
+                    pk_fma_hi(A1[t], yA1, cA[t]);
+                }
+        }
     else
         {
             chunk(aA, yA0, yA1, A0, A1, std::integral_constant<bool, PA>{});
