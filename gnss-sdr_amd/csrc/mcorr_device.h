@@ -543,7 +543,7 @@ __device__ __forceinline__ void packed_trip(const JobCtx& c, const float* __rest
             accumulate(dA, yA0, yA1, A0, A1);
             accumulate(dB, yB0, yB1, B0, B1);
         }
-    else if constexpr (!PA && !PB && NCH == 2 && NT <= 3)
+    else if constexpr (!PA && !PB && NCH == 2 && NT <= 5)
         {
             // the same for the per-tap form: 4 NT look-ups, then the accumulates
             v2f cA[NT], cB[NT];
