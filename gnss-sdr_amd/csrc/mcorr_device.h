@@ -426,8 +426,9 @@ __device__ __forceinline__ v2f pk_add_shi(v2f v, v2f k)
 //       fl(a + shift_E) = fl(a + shift_L) - 1  and  fl(fl(a + shift_E) - rem) = fl(fl(a + shift_L) - rem) - 1
 //     hold exactly (x and x - 1 are rounded to the same quantum, and 1 is an even multiple of it: round-to-nearest-even commutes with the shift), so
 //     k_E = k_L - 1: the early code value is read next to the late one and its chain -- two adds, a convert, an address per sample -- is not evaluated.
-//     Whether a 2 PPC-sample chunk satisfies the binade conditions is a property of its range of chip indices: the caller evaluates it once per chunk
-//     (one lane per chunk, a ballot) with margins, and chunks that straddle a power of two -- or reach below 1 -- take the per-tap chains as before.
+//     Whether a wave's 128 samples of a chunk satisfy the binade conditions is a property of their range of chip indices: the caller evaluates it once per
+//     chunk before the loop (one lane per chunk, a ballot per wave) with margins; a wave whose samples straddle a power of two -- or reach below 1 -- takes
+//     the per-tap chains for that trip as before.
 // The products and their order of summation are the same either way: the outputs are bit-identical with the switch off
 // (tests/test_tracking_gpu.py::test_paired_taps_are_bit_identical).
 template <int NT, bool ZP, bool AUX, int NCH, bool PA = false, bool PB = false, bool KC = false>
