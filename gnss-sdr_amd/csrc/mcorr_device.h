@@ -703,9 +703,7 @@ __device__ __forceinline__ void run_segment_packed(const JobCtx& c, const float2
             }
         else
             {
-                int iu = i;
-                asm volatile("" : "+s"(iu));  // (formed here, on demand: no per-lane induction variable for the sample index)
-                const int n0 = (c.n_first + iu * TRIP) + 2 * tid;
+                const int n0 = c.n_first + 2 * tid + i * TRIP;
                 const int lo = c.n_begin, hi = c.n_end - 1;
                 const bool a0 = (n0 >= lo) && (n0 <= hi), a1 = (n0 + 1 >= lo) && (n0 + 1 <= hi);
                 const float2 x0 = a0 ? q[0] : make_float2(0.0f, 0.0f);
@@ -757,16 +755,9 @@ __device__ __forceinline__ void run_segment_packed(const JobCtx& c, const float2
     auto trip = [&](int i, auto jc, auto fa, auto fb) {
         constexpr int j = decltype(jc)::value;
         constexpr bool FA = decltype(fa)::value, FB = decltype(fb)::value;
-        // the lane's first sample index of this trip: needed at re-seeds and edges only.  The trip number goes through an empty asm so that the compiler forms
-        // it there, on demand, instead of carrying (and advancing, one VALU instruction per trip) an induction variable per lane
-        auto first_sample = [&]() -> int {
-            int iu = i;
-            asm volatile("" : "+s"(iu));
-            return (c.n_first + iu * TRIP) + 2 * tid;
-        };
+        const int n0 = (c.n_first + i * TRIP) + 2 * tid;  // (uniform part first: used at re-seeds and edges only)
         if (until_reseed == 0)  // uniform: exact re-seed of the lane's phasor and of (float)n
             {
-                const int n0 = first_sample();
                 if (r_idx - tbl0 >= TBL)
                     {
                         tbl0 = r_idx;
@@ -787,7 +778,6 @@ __device__ __forceinline__ void run_segment_packed(const JobCtx& c, const float2
                 // chip index stays within what is staged.  (The empty volatile asm keeps this a BRANCH: if-converted, its 16 clamp /
                 // convert / select instructions ran in every trip -- a fifth of the loop's VALU work, ISA of round 2.)
                 asm volatile("" ::: "memory");
-                const int n0 = first_sample();
                 const int lo = c.n_begin, hi = c.n_end - 1;
                 ia = (v2f){static_cast<float>(min(max(n0, lo), hi)), static_cast<float>(min(max(n0 + 1, lo), hi))};
                 const int m0 = n0 + 2 * PPC;
