@@ -4,11 +4,12 @@
 Workload (config.workload): BASELINE config 2 -- GPS L1 C/A, 32 channels (PRN 1..32), fs = 25 Msps,
 N = 25 000 samples per 1 ms epoch, 3-tap E/P/L -- open-loop (pre-computed NCO parameter table), every channel
 reading its own window sequence of ONE shared complex64 IF stream (noise + 8 embedded signals at 45 dB-Hz).
-A "step" is one pass of the hot path over one batch of synthetic input: `--blocks-per-step` (256) consecutive blocks of the IF stream, each
+A "step" is one pass of the hot path over one batch of synthetic input: `--blocks-per-step` (1 400) consecutive blocks of the IF stream, each
 block = channels x epochs jobs in one launch (the resident job table is re-used block after block through gsh_bank_set_sample_base).
 Inputs (stream, codes, job table) are resident in HBM before the timed region; the stream cycles through a buffer of `--ring-blocks`
 (8) blocks = 643 MB, larger than the 256 MiB Infinity Cache, so what the kernel does not find in L2 really comes from HBM.
-value = channels*taps*epochs*blocks / time, whole job.  Default K = 20 steps = 1.1 s of GPU time (long enough for the driver's SMI samples).
+value = channels*taps*epochs*blocks / time, whole job.  One step is ~0.25 s of GPU time: the driver's K = 20 steps keep the GPU busy for ~5 s,
+long enough for its SMI samples to see it.
 
   python bench.py --gpus N --steps K --warmup W
   N > 1: launched by torch.distributed.run, one rank per GPU; every rank tracks its own 32 channels of the same
@@ -19,8 +20,13 @@ value = channels*taps*epochs*blocks / time, whole job.  Default K = 20 steps = 1
   torch.distributed only hands the 128-byte communicator id round and provides the barrier / MAX-reduce of the contract -- no data.
 
 One JSON line on stdout (rank 0).  Besides the contract keys it carries
-  roofline      -- dominant kernel (mcorr_kernel<3,0,false,false,false,true>: E/P/L, whole-code table, paired taps) vs the HBM roofline, algorithmic bytes 8N+8T per job,
+  roofline      -- dominant kernel (mcorr_kernel<3,0,false,false,false,true>: E/P/L, whole-code table, paired taps) against the roofline that BINDS it:
+                   vector-ALU issue (bound "valu": SURVEY 8(d)'s algorithmic flops over the dense FP32 peak, frac <= 1); the contract's byte rate
+                   (8N+8T per job over the HBM peak -- a rate above 1 because 32 channels share one stream) sits in roofline.contract_hbm;
                    duration from HIP events on the launch stream
+  dropin        -- what a receiver gets through the reference's own seam: 32 dll_pll_veml_tracking_hip blocks, one thread each, ONE stream, ONE
+                   Hip_Tracking_Runtime (tests/host/test_tracking_adapters bench): channel-periods/s through general_work, windows checked
+                   against 32 reference blocks
   cpu_baseline  -- the reference's own Cpu_Multicorrelator_Real_Codes (oracle/_ref, x86 SIMD protokernels) timed on
                    this box's host cores over a bounded sample (falls back to the C port when _ref is absent)
   acquisition   -- secondary metric: PCPS dwells/s for BASELINE config 3 (32 PRN x 41 bins x 25 000)
@@ -50,13 +56,15 @@ def parse():
     ap.add_argument("--epochs", type=int, default=400, help="1 ms epochs per channel per step")
     ap.add_argument("--fs", type=float, default=25e6)
     ap.add_argument("--taps", type=int, default=3)
-    ap.add_argument("--blocks-per-step", type=int, default=256, help="stream blocks (launches) one step works through")
+    ap.add_argument("--blocks-per-step", type=int, default=1400, help="stream blocks (launches) one step works through (1 400 = ~0.25 s of GPU time)")
     ap.add_argument("--ring-blocks", type=int, default=8, help="blocks of stream resident in HBM that the steps cycle through (8 = 643 MB > Infinity Cache)")
     ap.add_argument("--settle-steps", type=int, default=3,
                     help="untimed steps run during set-up, before the W warm-up steps, so that the GPU clocks have settled: after an idle "
                          "period the first ~40 ms of work run up to 25 %% slower (profiles/ab/clock_ramp.py); 0 disables")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-acq", action="store_true")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the drop-in leg (32 tracking blocks through general_work)")
+    ap.add_argument("--dropin-periods", type=int, default=400)
     ap.add_argument("--no-other-configs", action="store_true", help="skip the config 4 / config 5 figures (profiles/run_profiles.sh: keeps the "
                     "per-kernel averages of the trace about the headline workload only)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline leg")
@@ -387,21 +395,46 @@ def other_configs_metric(dev_index):
     return out
 
 
+def dropin_metric(channels, fs, periods, periods_per_call=10):
+    """What a receiver gets through the reference's own seam (north_star: "drops into a Channel unchanged"): `channels` dll_pll_veml_tracking_hip
+    blocks behind their TrackingInterface adapters, one scheduler thread each as in a flowgraph (gnss_flowgraph.cc:1227-1231), ONE 25 Msps stream,
+    ONE Hip_Tracking_Runtime whose launches advance every channel that has samples.  The C++ program (tests/host/test_tracking_adapters bench,
+    compiled against the reference's headers where /root/reference is present; the binary travels with the tree) drives general_work, times the
+    threads, and checks every block's window positions against the reference's own block over the same stream."""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "host", "test_tracking_adapters")
+    if not os.path.exists(exe):
+        return {"error": "tests/host/test_tracking_adapters was not prebuilt (needs /root/reference at build time)"}
+    r = subprocess.run([exe, "bench", str(channels), str(int(fs)), str(periods), str(periods_per_call)], capture_output=True, text=True, timeout=900, cwd="/tmp")
+    line = [l for l in r.stdout.splitlines() if l.startswith("DROPIN_JSON")]
+    if r.returncode != 0 or not line:
+        return {"error": (r.stdout[-600:] + r.stderr[-400:]).strip()}
+    d = json.loads(line[-1][len("DROPIN_JSON"):])
+    d["unit"] = "channel-periods/s through general_work (x3 taps = correlators/s)"
+    return d
+
+
 def load_pmc():
     """profiles/pmc_r02.json: per-launch counter averages of the dominant kernels under this very command (profiles/run_profiles_r02.sh +
     profiles/summarize_r02.py; rocprofv3 --pmc passes, kernel-trace only).  None when absent."""
-    try:
-        return json.load(open(os.path.join(ROOT, "profiles", "pmc_r02.json")))
-    except Exception:
-        return None
+    for name in ("pmc_r03.json", "pmc_r02.json"):
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", name)))
+            d["file"] = "profiles/" + name
+            return d
+        except Exception:
+            continue
+    return None
 
 
 def tracking_roofline(C, E, T, n, k_ms, pmc):
-    """The contract's roofline object for mcorr_kernel, plus what actually binds it (DESIGN.md section 7 has the formulas).
-    bound / achieved / peak / frac / traffic: SURVEY 8(d)'s ALGORITHMIC bytes (8N + 8T per channel-epoch: every channel charged a private read
-      of its window) over the HBM peak.  32 channels share one stream, so this "fraction" exceeds 1 -- it is a rate, not a utilisation.
-    binding "valu": the kernel is bound by vector-ALU issue (the float32 chip-index arithmetic of the taps), measured against
-      SURVEY 8(d)'s algorithmic flops (6 + 4T per channel-sample) over the dense FP32 peak, with the issue counters next to it.
+    """The roofline object for mcorr_kernel (DESIGN.md section 7 has the formulas).
+    bound / achieved / peak / frac: what BINDS the kernel -- vector-ALU issue (the float32 chip-index arithmetic of the taps): SURVEY
+      8(d)'s algorithmic flops (6 + 4T per channel-sample) per launch / kernel_ms over the dense FP32 vector peak; a utilisation (<= 1).
+    traffic: HBM bytes per launch from the PMC counters of the committed profile (pmc_static: collected by profiles/run_profiles_r03.sh under
+      this very command, not re-measured in this run).
+    contract_hbm: SURVEY 8(d)'s ALGORITHMIC bytes (8N + 8T per channel-epoch: every channel charged a private read of its window) over the HBM
+      peak.  32 channels share one stream, so this rate exceeds 1 -- it is not a utilisation.
     hbm_unique: the bytes that must leave HBM once per launch (the stream block, the codes, the results) over the HBM peak -- the honest HBM figure."""
     n_jobs = C * E
     alg_bytes = n_jobs * (8.0 * n + 8.0 * T)
@@ -409,17 +442,22 @@ def tracking_roofline(C, E, T, n, k_ms, pmc):
     achieved = alg_bytes / t / 1e9
     flops = float(C) * E * n * (6.0 + 4.0 * T)
     unique = 8.0 * (E + 1) * n + 4.0 * 1023 * C + 64.0 * n_jobs
-    r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-         "kernel": f"mcorr_kernel<{3 if T <= 3 else (5 if T <= 5 else 8)},0,false,false,false,{'true' if T == 3 else 'false'}>", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
-         "binding": "valu",
-         "valu": {"algorithmic_flops_per_launch": flops, "achieved_tflops": flops / t / 1e12, "peak_tflops": FP32_PEAK_TFLOPS,
-                  "frac": flops / t / 1e12 / FP32_PEAK_TFLOPS},
+    tflops = flops / t / 1e12
+    r = {"bound": "valu", "achieved": tflops, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP32_PEAK_TFLOPS, "traffic": None,
+         "kernel": f"mcorr_kernel<{3 if T <= 3 else (5 if T <= 5 else 8)},0,false,false,false,{'true' if T == 3 else 'false'}>", "kernel_ms": k_ms,
+         "algorithmic_flops_per_launch": flops,
+         "note": "bound by vector-ALU issue (the float32 chip-index chains of the taps), not by HBM: 32 channels read ONE stream, the block is fetched from HBM once "
+                 "and served from L2 to the other 31; MFMA does not apply (per-channel mat-vec, f32 MFMA runs at the vector rate on gfx950)",
+         "contract_hbm": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "rate_over_peak": achieved / HBM_PEAK_GBS,
+                          "algorithmic_bytes_per_launch": alg_bytes,
+                          "note": "SURVEY 8(d)'s per-unit bytes (8N + 8T per channel-epoch: every channel charged a private read of its window); a rate, "
+                                  "not a utilisation -- it exceeds 1 because the stream is shared"},
          "hbm_unique": {"bytes_per_launch": unique, "achieved_GBs": unique / t / 1e9, "frac": unique / t / 1e9 / HBM_PEAK_GBS},
          "channel_samples_per_s": float(C) * E * n / t}
     m = (pmc or {}).get("mcorr")
     if m and m.get("jobs") == n_jobs and m.get("n") == n:
         r["traffic"] = m.get("hbm_bytes_per_launch")
-        r["pmc"] = {k: m[k] for k in ("source", "kernel_avg_us", "SQ_INSTS_VALU", "SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY",
+        r["pmc_static"] = {k: m[k] for k in ("source", "kernel_avg_us", "SQ_INSTS_VALU", "SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY",
                                       "valu_insts_per_channel_sample", "valu_cycles_per_inst_per_simd", "l2_read_bytes_per_launch", "l2_GBs",
                                       "hbm_bytes_per_launch", "hbm_GBs") if k in m}
     return r
@@ -587,7 +625,15 @@ def main():
                                       f"({os.environ.get('GSH_BENCH_DIST', 'broadcast')}), converted into every GPU's ring, overlapped with the correlation" if grouped else "")},
             "roofline": tracking_roofline(C, E, T, n, k_ms, pmc),
             "kernel_only_value": float(C) * T * E / (k_ms * 1e-3),
+            # the stream group under the launches (N > 1: RCCL over xGMI inside the engine; N = 1: no group, the block is resident)
+            "rccl_ranks": world if grouped else 0,
+            "stream_group_mode": os.environ.get("GSH_BENCH_DIST", "broadcast") if grouped else None,
         }
+        if world == 1 and not a.no_dropin and not grouped:
+            try:
+                res["dropin"] = dropin_metric(C, fs, a.dropin_periods)
+            except Exception as e:
+                res["dropin"] = {"error": str(e)}
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(C, n, fs, T, a.cpu_seconds)
         if world == 1 and not a.no_acq and not grouped:

@@ -99,6 +99,7 @@ class TrkEpoch(C.Structure):
         ("code_error_filt_chips", C.c_double), ("rem_code_phase_samples", C.c_double), ("acc_carrier_phase_rad", C.c_double), ("carrier_lock_test", C.c_double),
                 ("state", C.c_int32), ("symbol_flags", C.c_int32), ("p_data_accu", C.c_float * 2),
                 ("carrier_phase_rate_step_rad", C.c_double), ("code_phase_rate_step_chips", C.c_double),
+                ("accu", C.c_float * 10),
     ]
 
 
@@ -154,6 +155,7 @@ SYMBOLS = {
     "gsh_stream_push_device": (C.c_int, [_P, _P, C.c_uint64, C.c_int, C.c_int, _P, C.POINTER(C.c_uint64)]),
     "gsh_stream_push_async": (C.c_int, [_P, _P, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64)]),
     "gsh_stream_wait": (C.c_int, [_P]),
+    "gsh_stream_push_staged": (C.c_int, [_P, _P, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64)]),
     "gsh_stream_seek": (C.c_int, [_P, C.c_uint64]),
     "gsh_comm_unique_id": (C.c_int, [_P]),
     "gsh_stream_group_create": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.c_uint64, C.c_uint32, C.c_int, C.POINTER(_P)]),
@@ -182,8 +184,12 @@ SYMBOLS = {
     "gsh_trk_pull_in": (C.c_int, [C.POINTER(TrkConf), C.c_uint64, C.c_double, C.c_uint64, C.c_double, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
     "gsh_trk_stop": (C.c_int, [_P, C.c_int]),
     "gsh_trk_run": (C.c_int, [_P, C.c_int, C.POINTER(TrkEpoch), C.POINTER(C.c_int32)]),
+    "gsh_trk_run_begin": (C.c_int, [_P, C.c_int, C.c_int]),
+    "gsh_trk_run_end": (C.c_int, [_P, C.POINTER(TrkEpoch), C.POINTER(C.c_int32)]),
+    "gsh_trk_positions": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]),
     "gsh_trk_time_run": (C.c_int, [_P, C.c_int, C.c_int, _F]),
-    "gsh_trk_write_dump": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(TrkConf), C.c_uint32, C.POINTER(TrkEpoch), C.c_int]),
+    "gsh_trk_write_dump": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(TrkConf), C.c_uint32, C.POINTER(TrkEpoch), C.c_int, C.POINTER(C.c_uint64),
+                                    C.POINTER(C.c_uint32)]),
     "gsh_acq_create": (C.c_int, [C.c_int, C.POINTER(AcqConf), C.POINTER(_P)]),
     "gsh_acq_destroy": (None, [_P]),
     "gsh_acq_set_local_code": (C.c_int, [_P, C.c_uint32, _F]),

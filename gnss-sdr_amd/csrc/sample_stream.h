@@ -33,6 +33,17 @@ struct gsh_stream
     unsigned long long read_min[HIST]{};
     hipEvent_t read_ev[HIST]{};
     int read_count{0};
+    // reader launches that have dropped out of the 16-entry history are not forgotten: before a slot is re-used the ring's own stream is made
+    // to wait for the launch it held, and `read_fold` (recorded on the ring's stream right after) stands for all of them -- every push waits on it
+    hipEvent_t read_fold{nullptr};
+    bool has_fold{false};
+    // gsh_stream_push_staged: page-locked host staging + device staging, four in rotation
+    static constexpr int NSTAGE = 4;
+    void* h_stage[NSTAGE]{};
+    void* d_stage[NSTAGE]{};
+    size_t stage_cap[NSTAGE]{};
+    hipEvent_t stage_done[NSTAGE]{};  // the conversion that read d_stage[i] (and therefore the copy out of h_stage[i]) has finished
+    int stage_next{0};
 };
 
 namespace gsh

@@ -19,6 +19,14 @@ int stream_mark_read(gsh_stream* s, unsigned long long min_index, hipStream_t st
 {
     const int slot = s->read_count % gsh_stream::HIST;
     if (s->read_ev[slot] == nullptr) GSH_HIP(hipEventCreateWithFlags(&s->read_ev[slot], hipEventDisableTiming));
+    if (s->read_count >= gsh_stream::HIST)
+        {
+            // the slot still holds the fence of a launch 16 records back: fold it into the ring's stream instead of dropping it
+            if (s->read_fold == nullptr) GSH_HIP(hipEventCreateWithFlags(&s->read_fold, hipEventDisableTiming));
+            GSH_HIP(hipStreamWaitEvent(s->stream, s->read_ev[slot], 0));
+            GSH_HIP(hipEventRecord(s->read_fold, s->stream));
+            s->has_fold = true;
+        }
     GSH_HIP(hipEventRecord(s->read_ev[slot], st));
     s->read_min[slot] = min_index;
     s->read_count++;
@@ -56,6 +64,7 @@ int write_items(gsh_stream* s, const void* d_src, unsigned long long n, int item
         const unsigned long long end = s->next + n;
         const unsigned long long bound = end > s->capacity ? end - s->capacity : 0ull;
         const int m = s->read_count < gsh_stream::HIST ? s->read_count : gsh_stream::HIST;
+        if (s->has_fold && st != s->stream) GSH_HIP(hipStreamWaitEvent(st, s->read_fold, 0));  // launches older than the history (on the ring's own stream: already ordered)
         for (int k = 1; k <= m; k++)
             {
                 const int slot = (s->read_count - k) % gsh_stream::HIST;
@@ -155,6 +164,13 @@ extern "C"
                 if (s->raw2_done[i]) (void)hipEventDestroy(s->raw2_done[i]);
             }
         if (s->pushed) (void)hipEventDestroy(s->pushed);
+        if (s->read_fold) (void)hipEventDestroy(s->read_fold);
+        for (int i = 0; i < gsh_stream::NSTAGE; i++)
+            {
+                if (s->stage_done[i]) (void)hipEventDestroy(s->stage_done[i]);
+                if (s->h_stage[i]) (void)hipHostFree(s->h_stage[i]);
+                if (s->d_stage[i]) (void)hipFree(s->d_stage[i]);
+            }
         for (int i = 0; i < gsh_stream::HIST; i++)
             {
                 if (s->push_ev[i]) (void)hipEventDestroy(s->push_ev[i]);
@@ -250,6 +266,48 @@ extern "C"
         return GSH_OK;
     }
 
+    int gsh_stream_push_staged(gsh_stream_t* s, const void* items, uint64_t n, int item_type, int inverted_spectrum, uint64_t* first_index)
+    {
+        // items -> page-locked staging (host memcpy, the caller's buffer is free on return) -> device staging (DMA on the ring's stream) ->
+        // conversion into the ring.  A staging pair is re-used four pushes later, after the conversion that read it has finished.
+        GSH_REQUIRE(s != nullptr, "null stream");
+        GSH_REQUIRE(n == 0 || items != nullptr, "null items");
+        const size_t isz = gsh::item_bytes(item_type);
+        GSH_REQUIRE(isz != 0, "unknown item type %d", item_type);
+        GSH_REQUIRE(n <= s->capacity, "a push of %llu samples exceeds the ring capacity %llu", static_cast<unsigned long long>(n), s->capacity);
+        if (first_index) *first_index = s->next;
+        if (n == 0) return GSH_OK;
+        GSH_HIP(hipSetDevice(s->device));
+        const int slot = s->stage_next;
+        s->stage_next = (s->stage_next + 1) % gsh_stream::NSTAGE;
+        const size_t bytes = static_cast<size_t>(n) * isz;
+        if (s->stage_done[slot] == nullptr)
+            GSH_HIP(hipEventCreateWithFlags(&s->stage_done[slot], hipEventDisableTiming));
+        else
+            GSH_HIP(hipEventSynchronize(s->stage_done[slot]));  // the push that used this pair four pushes ago
+        if (bytes > s->stage_cap[slot])
+            {
+                if (s->h_stage[slot]) GSH_HIP(hipHostFree(s->h_stage[slot]));
+                if (s->d_stage[slot]) GSH_HIP(hipFree(s->d_stage[slot]));
+                s->h_stage[slot] = nullptr;
+                s->d_stage[slot] = nullptr;
+                s->stage_cap[slot] = 0;
+                const size_t cap = bytes + bytes / 2;
+                GSH_HIP(hipHostMalloc(&s->h_stage[slot], cap, hipHostMallocDefault));
+                GSH_HIP(hipMalloc(&s->d_stage[slot], cap));
+                s->stage_cap[slot] = cap;
+            }
+        std::memcpy(s->h_stage[slot], items, bytes);
+        GSH_HIP(hipMemcpyAsync(s->d_stage[slot], s->h_stage[slot], bytes, hipMemcpyHostToDevice, s->stream));
+        int rc = write_items(s, s->d_stage[slot], n, item_type, inverted_spectrum ? 1 : 0, s->stream);
+        if (rc != GSH_OK) return rc;
+        GSH_HIP(hipEventRecord(s->stage_done[slot], s->stream));
+        rc = record_push(s, s->next + n, s->stream);
+        if (rc != GSH_OK) return rc;
+        s->next += n;
+        return GSH_OK;
+    }
+
     int gsh_stream_wait(gsh_stream_t* s)
     {
         GSH_REQUIRE(s != nullptr, "null stream");
@@ -262,7 +320,13 @@ extern "C"
     {
         GSH_REQUIRE(s != nullptr, "null stream");
         GSH_HIP(hipSetDevice(s->device));
-        GSH_HIP(hipStreamSynchronize(s->stream));
+        GSH_HIP(hipStreamSynchronize(s->stream));  // queued pushes (and the folded reader fences)
+        {
+            // launches on other streams that still read the ring: after the seek nothing protects what they read
+            const int m = s->read_count < gsh_stream::HIST ? s->read_count : gsh_stream::HIST;
+            for (int k = 1; k <= m; k++) GSH_HIP(hipEventSynchronize(s->read_ev[(s->read_count - k) % gsh_stream::HIST]));
+        }
+        s->has_fold = false;
         s->next = next_index;
         s->origin = next_index;  // nothing older is resident
         s->push_count = 0;

@@ -490,8 +490,21 @@ extern "C"
         GSH_REQUIRE(b != nullptr, "null bank");
         if (b->n_jobs == 0) return GSH_OK;
         if (b->d_stream == nullptr) return set_error(GSH_ERR_STATE, "no sample stream attached (gsh_bank_set_stream_*)");
-        if (b->max_end > b->stream_len)
-            return set_error(GSH_ERR_INVALID, "a job window ends at sample %llu, past the %llu-sample stream", b->max_end, b->stream_len);
+        if (b->ring == nullptr)
+            {
+                if (b->max_end + b->sample_base > b->stream_len)  // sample_base shifts every window (gsh_bank_set_sample_base)
+                    return set_error(GSH_ERR_INVALID, "a job window ends at sample %llu (sample_base %llu), past the %llu-sample stream", b->max_end + b->sample_base,
+                        b->sample_base, b->stream_len);
+            }
+        else if (b->ring_max_end != 0)
+            {
+                // the shifted windows must be resident and pushed: a base that points at samples the ring no longer (or not yet) holds would make
+                // the kernel read whatever lives at those ring positions now
+                const unsigned long long lo = b->ring_min_start + b->sample_base, hi = b->ring_max_end + b->sample_base;
+                if (lo < gsh::stream_oldest(b->ring) || hi > b->ring->next)
+                    return set_error(GSH_ERR_INVALID, "windows [%llu, %llu) (sample_base %llu) are not resident (ring holds [%llu, %llu))", lo, hi, b->sample_base,
+                        gsh::stream_oldest(b->ring), static_cast<unsigned long long>(b->ring->next));
+            }
         GSH_HIP(hipSetDevice(b->device));
         const int splits = bank_splits(b);
         if (splits > 1)

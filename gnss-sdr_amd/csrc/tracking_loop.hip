@@ -565,6 +565,16 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
                                 }
                             lk.cloop = c.track_pilot ? 0 : 1;  // trk.cc:1587-1595
                         }
+                    if (a.records != nullptr)  // stored here, while they are at hand (the record's other fields follow at the end of the period): the
+                        {                      // accumulators the loop works on -- what log_data dumps as |d_VE_accu| .. |d_VL_accu| (trk.cc:1624-1636)
+                            float* ra = a.records[static_cast<size_t>(ch) * a.n_epochs + e].accu;
+#pragma unroll
+                            for (int t = 0; t < NT; t++)
+                                {
+                                    ra[2 * t] = acc[t].x;
+                                    ra[2 * t + 1] = acc[t].y;
+                                }
+                        }
                     const bool cloop_now = c.enable_symbol_sync ? (lk.cloop != 0) : (c.cloop != 0);
                     const double corr_time = (c.enable_symbol_sync && lk.corr_time > 0.0) ? lk.corr_time : code_period;  // d_current_correlation_time_s
                     const float spc_now = (c.enable_symbol_sync && lk.narrow) ? lk.spc_now : c.spc;
@@ -592,7 +602,7 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
                                     gsh_trk_epoch& r = a.records[static_cast<size_t>(ch) * a.n_epochs + e];  // written in place, field by field
                                     {
                                         unsigned* rw = reinterpret_cast<unsigned*>(&r);
-                                        for (int i = 0; i < static_cast<int>(sizeof(gsh_trk_epoch) / 4); i++) rw[i] = 0u;
+                                        for (int i = 0; i < static_cast<int>(offsetof(gsh_trk_epoch, accu) / 4); i++) rw[i] = 0u;  // (accu, the record's tail, is already in place)
                                     }
                                     r.sample_counter = pos;
                                     r.flags = (pull_in ? 1 : 0) | 2;
@@ -1045,6 +1055,14 @@ struct gsh_trk
     size_t records_cap{0};
     int* d_done{nullptr};
     hipEvent_t ev0{nullptr}, ev1{nullptr};
+    // gsh_trk_run_begin / _end: results land in page-locked host memory so that the copies are true asynchronous DMAs
+    gsh_trk_epoch* h_records{nullptr};
+    size_t h_records_cap{0};
+    int32_t* h_done{nullptr};                // n_channels
+    unsigned long long* h_pos{nullptr};      // n_channels: TrkChannel::pos after the run
+    int32_t* h_active{nullptr};              // n_channels: TrkChannel::active after the run
+    int pending_epochs{-1};                  // >= 0: a run has been begun and not ended
+    bool pending_records{false};
 };
 
 namespace
@@ -1097,7 +1115,14 @@ int trk_launch(gsh_trk* t, int n_epochs, gsh_trk_epoch* d_records)
                 hipLaunchKernelGGL((gsh::trk_loop_kernel<3, false>), grid, block, lds, t->stream, a);
         }
     GSH_HIP(hipGetLastError());
-    if (t->ring != nullptr) return gsh::stream_mark_read(t->ring, 0ull, t->stream);  // any later push into the ring waits for this launch
+    if (t->ring != nullptr)
+        {
+            // a later push waits for this launch only if it overwrites samples at or above the oldest window a running channel starts at
+            unsigned long long lowest = ~0ull;
+            for (const auto& c : t->h_chan)
+                if (c.active && c.pos < lowest) lowest = c.pos;
+            return gsh::stream_mark_read(t->ring, lowest, t->stream);
+        }
     return GSH_OK;
 }
 }  // namespace
@@ -1161,6 +1186,9 @@ extern "C"
         if ((e = hipMalloc(&t->d_lock_backup, sizeof(gsh::LockState) * n_channels)) != hipSuccess) return fail(e, "hipMalloc(lock)");
         if ((e = hipMemset(t->d_lock, 0, sizeof(gsh::LockState) * n_channels)) != hipSuccess) return fail(e, "hipMemset(lock)");
         if ((e = hipMalloc(&t->d_done, sizeof(int) * n_channels)) != hipSuccess) return fail(e, "hipMalloc(done)");
+        if ((e = hipHostMalloc(&t->h_done, sizeof(int32_t) * n_channels, hipHostMallocDefault)) != hipSuccess) return fail(e, "hipHostMalloc(done)");
+        if ((e = hipHostMalloc(&t->h_pos, sizeof(unsigned long long) * n_channels, hipHostMallocDefault)) != hipSuccess) return fail(e, "hipHostMalloc(pos)");
+        if ((e = hipHostMalloc(&t->h_active, sizeof(int32_t) * n_channels, hipHostMallocDefault)) != hipSuccess) return fail(e, "hipHostMalloc(active)");
         if ((e = hipMalloc(&t->d_conf, sizeof(gsh_trk_conf))) != hipSuccess) return fail(e, "hipMalloc(conf)");
         if ((e = hipMemcpy(t->d_conf, &t->conf, sizeof(gsh_trk_conf), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy(conf)");
         if ((e = hipEventCreate(&t->ev0)) != hipSuccess) return fail(e, "hipEventCreate");
@@ -1191,6 +1219,10 @@ extern "C"
         if (t->d_records) (void)hipFree(t->d_records);
         if (t->d_done) (void)hipFree(t->d_done);
         if (t->d_conf) (void)hipFree(t->d_conf);
+        if (t->h_records) (void)hipHostFree(t->h_records);
+        if (t->h_done) (void)hipHostFree(t->h_done);
+        if (t->h_pos) (void)hipHostFree(t->h_pos);
+        if (t->h_active) (void)hipHostFree(t->h_active);
         if (t->ev0) (void)hipEventDestroy(t->ev0);
         if (t->ev1) (void)hipEventDestroy(t->ev1);
         if (t->stream) (void)hipStreamDestroy(t->stream);
@@ -1367,14 +1399,15 @@ extern "C"
         return GSH_OK;
     }
 
-    int gsh_trk_run(gsh_trk_t* t, int n_epochs, gsh_trk_epoch* records, int32_t* epochs_done)
+    int gsh_trk_run_begin(gsh_trk_t* t, int n_epochs, int want_records)
     {
         GSH_REQUIRE(t != nullptr, "null handle");
         GSH_REQUIRE(n_epochs >= 0, "n_epochs %d", n_epochs);
         if (t->d_stream == nullptr) return set_error(GSH_ERR_STATE, "no IF stream attached (gsh_trk_set_stream_*)");
+        if (t->pending_epochs >= 0) return set_error(GSH_ERR_STATE, "gsh_trk_run_begin: the previous run has not been ended");
         GSH_HIP(hipSetDevice(t->device));
-        const size_t n_rec = static_cast<size_t>(t->n_channels) * static_cast<size_t>(n_epochs);
-        if (records != nullptr && n_rec > t->records_cap)
+        const size_t n_rec = want_records ? static_cast<size_t>(t->n_channels) * static_cast<size_t>(n_epochs) : 0;
+        if (n_rec > t->records_cap)
             {
                 if (t->d_records) GSH_HIP(hipFree(t->d_records));
                 t->d_records = nullptr;
@@ -1382,12 +1415,67 @@ extern "C"
                 GSH_HIP(hipMalloc(&t->d_records, sizeof(gsh_trk_epoch) * n_rec));
                 t->records_cap = n_rec;
             }
-        if (records != nullptr && n_rec > 0) GSH_HIP(hipMemsetAsync(t->d_records, 0, sizeof(gsh_trk_epoch) * n_rec, t->stream));
-        int rc = trk_launch(t, n_epochs, records != nullptr ? t->d_records : nullptr);
+        if (n_rec > t->h_records_cap)
+            {
+                if (t->h_records) GSH_HIP(hipHostFree(t->h_records));
+                t->h_records = nullptr;
+                t->h_records_cap = 0;
+                GSH_HIP(hipHostMalloc(&t->h_records, sizeof(gsh_trk_epoch) * n_rec, hipHostMallocDefault));
+                t->h_records_cap = n_rec;
+            }
+        if (n_rec > 0) GSH_HIP(hipMemsetAsync(t->d_records, 0, sizeof(gsh_trk_epoch) * n_rec, t->stream));
+        int rc = trk_launch(t, n_epochs, n_rec > 0 ? t->d_records : nullptr);
         if (rc != GSH_OK) return rc;
-        if (records != nullptr && n_rec > 0) GSH_HIP(hipMemcpyAsync(records, t->d_records, sizeof(gsh_trk_epoch) * n_rec, hipMemcpyDeviceToHost, t->stream));
-        if (epochs_done != nullptr) GSH_HIP(hipMemcpyAsync(epochs_done, t->d_done, sizeof(int) * t->n_channels, hipMemcpyDeviceToHost, t->stream));
+        if (n_rec > 0) GSH_HIP(hipMemcpyAsync(t->h_records, t->d_records, sizeof(gsh_trk_epoch) * n_rec, hipMemcpyDeviceToHost, t->stream));
+        GSH_HIP(hipMemcpyAsync(t->h_done, t->d_done, sizeof(int) * t->n_channels, hipMemcpyDeviceToHost, t->stream));
+        // where every channel stands now: the two fields out of the strided state array
+        GSH_HIP(hipMemcpy2DAsync(t->h_pos, sizeof(unsigned long long), reinterpret_cast<const char*>(t->d_chan) + offsetof(gsh::TrkChannel, pos), sizeof(gsh::TrkChannel),
+            sizeof(unsigned long long), static_cast<size_t>(t->n_channels), hipMemcpyDeviceToHost, t->stream));
+        GSH_HIP(hipMemcpy2DAsync(t->h_active, sizeof(int32_t), reinterpret_cast<const char*>(t->d_chan) + offsetof(gsh::TrkChannel, active), sizeof(gsh::TrkChannel),
+            sizeof(int32_t), static_cast<size_t>(t->n_channels), hipMemcpyDeviceToHost, t->stream));
+        t->pending_epochs = n_epochs;
+        t->pending_records = n_rec > 0;
+        return GSH_OK;
+    }
+
+    int gsh_trk_run_end(gsh_trk_t* t, gsh_trk_epoch* records, int32_t* epochs_done)
+    {
+        GSH_REQUIRE(t != nullptr, "null handle");
+        if (t->pending_epochs < 0) return set_error(GSH_ERR_STATE, "gsh_trk_run_end without gsh_trk_run_begin");
+        GSH_HIP(hipSetDevice(t->device));
+        const int n_epochs = t->pending_epochs;
+        t->pending_epochs = -1;
         GSH_HIP(hipStreamSynchronize(t->stream));
+        const size_t n_rec = static_cast<size_t>(t->n_channels) * static_cast<size_t>(n_epochs);
+        if (records != nullptr && n_rec > 0)
+            {
+                if (!t->pending_records) return set_error(GSH_ERR_STATE, "gsh_trk_run_end: records asked for, but the run was begun without them");
+                std::memcpy(records, t->h_records, sizeof(gsh_trk_epoch) * n_rec);
+            }
+        if (epochs_done != nullptr) std::memcpy(epochs_done, t->h_done, sizeof(int32_t) * t->n_channels);
+        for (int ch = 0; ch < t->n_channels; ch++)
+            {
+                t->h_chan[ch].pos = t->h_pos[ch];
+                t->h_chan[ch].active = t->h_active[ch];
+            }
+        return GSH_OK;
+    }
+
+    int gsh_trk_run(gsh_trk_t* t, int n_epochs, gsh_trk_epoch* records, int32_t* epochs_done)
+    {
+        int rc = gsh_trk_run_begin(t, n_epochs, records != nullptr ? 1 : 0);
+        if (rc != GSH_OK) return rc;
+        return gsh_trk_run_end(t, records, epochs_done);
+    }
+
+    int gsh_trk_positions(gsh_trk_t* t, uint64_t* next_window, int32_t* active)
+    {
+        GSH_REQUIRE(t != nullptr, "null handle");
+        for (int ch = 0; ch < t->n_channels; ch++)
+            {
+                if (next_window != nullptr) next_window[ch] = t->h_chan[ch].pos;
+                if (active != nullptr) active[ch] = t->h_chan[ch].active;
+            }
         return GSH_OK;
     }
 

@@ -1,5 +1,6 @@
-// Tracking dump file in the reference's binary layout (dll_pll_veml_tracking::log_data, trk.cc:1599-1702): 96 bytes per period, the
-// format gnss-sdr's own readers parse (utils/python/lib/dll_pll_veml_read_tracking_dump.py, utils/matlab/libs/dll_pll_veml_read_tracking_dump.m).
+// Tracking dump file in the block's own binary layout (dll_pll_veml_tracking::log_data, trk.cc:1599-1702): 108 bytes per logged period, the
+// format save_matfile (trk.cc:1705-1716) and utils/matlab/libs/dll_pll_veml_read_tracking_dump.m parse (the Python reader under utils/python
+// predates the TOW / week-number fields).
 // Host-only code: turns gsh_trk_epoch records into that file so that the reference's plotting / analysis tooling works on a
 // device-closed loop unchanged.
 #include "gsh_internal.h"
@@ -8,7 +9,8 @@
 
 extern "C"
 {
-    int gsh_trk_write_dump(const char* path, int append, const gsh_trk_conf* conf, uint32_t prn, const gsh_trk_epoch* records, int n_records)
+    int gsh_trk_write_dump(const char* path, int append, const gsh_trk_conf* conf, uint32_t prn, const gsh_trk_epoch* records, int n_records,
+        const uint64_t* tow_ms, const uint32_t* wn)
     {
         GSH_REQUIRE(path != nullptr && conf != nullptr, "null argument");
         GSH_REQUIRE(n_records >= 0 && (n_records == 0 || records != nullptr), "bad record array");
@@ -21,7 +23,7 @@ extern "C"
             {
                 const gsh_trk_epoch& r = records[i];
                 if (r.flags & 2) continue;  // loss of lock: the reference does not call log_data in that period (trk.cc:2009-2014)
-                if (r.state == 4 && !(r.symbol_flags & 1)) continue;  // narrow tracking logs once per telemetry symbol (trk.cc:2212-2215)
+                if ((r.state == 3 || r.state == 4) && !(r.symbol_flags & 1)) continue;  // coherent integration / narrow tracking log once per telemetry symbol (trk.cc:2164-2166, 2212-2218)
                 struct __attribute__((packed)) Rec
                 {
                     float ve, e, pr, l, vl, prompt_i, prompt_q;
@@ -30,13 +32,15 @@ extern "C"
                         carr_error_filt_hz, code_error_chips, code_error_filt_chips, cn0_db_hz, carrier_lock_test, rem_code_phase_samples;
                     double sample_stamp;
                     uint32_t prn;
+                    uint64_t tow;
+                    uint32_t wn;
                 } o;
-                static_assert(sizeof(Rec) == 96, "log_data writes 96 bytes per period");
-                o.ve = veml ? mag(&r.corr[0]) : 0.0f;                       // trk.cc:1624-1633
-                o.e = mag(&r.corr[2 * (p - 1)]);
-                o.pr = mag(&r.corr[2 * p]);
-                o.l = mag(&r.corr[2 * (p + 1)]);
-                o.vl = veml ? mag(&r.corr[8]) : 0.0f;
+                static_assert(sizeof(Rec) == 108, "log_data writes 108 bytes per period (trk.cc:1705-1710)");
+                o.ve = veml ? mag(&r.accu[0]) : 0.0f;                       // |d_VE_accu| .. |d_VL_accu|, trk.cc:1624-1636
+                o.e = mag(&r.accu[2 * (p - 1)]);
+                o.pr = mag(&r.accu[2 * p]);
+                o.l = mag(&r.accu[2 * (p + 1)]);
+                o.vl = veml ? mag(&r.accu[8]) : 0.0f;
                 o.prompt_i = conf->track_pilot ? r.prompt_data[0] : r.corr[2 * p];      // trk.cc:1614-1623
                 o.prompt_q = conf->track_pilot ? r.prompt_data[1] : r.corr[2 * p + 1];
                 o.prn_start_sample = r.sample_counter + static_cast<uint64_t>(r.prn_length_samples);  // nitems_read + d_current_prn_length_samples, :1650
@@ -54,6 +58,8 @@ extern "C"
                 o.rem_code_phase_samples = static_cast<float>(r.rem_code_phase_samples);
                 o.sample_stamp = static_cast<double>(r.sample_counter + static_cast<uint64_t>(r.prn_length_samples));  // :1684
                 o.prn = prn;
+                o.tow = tow_ms != nullptr ? tow_ms[i] : 0ull;  // d_tow_from_telemetry_ms, d_wn_from_telemetry (trk.cc:1921-1935)
+                o.wn = wn != nullptr ? wn[i] : 0u;
                 if (std::fwrite(&o, sizeof(o), 1, f) != 1)
                     {
                         std::fclose(f);

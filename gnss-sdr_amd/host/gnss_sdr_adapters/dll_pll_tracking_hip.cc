@@ -31,27 +31,35 @@
 
 namespace
 {
-// channels that name the same <role>.hip_shared_ring id on the same device share one device sample ring
-std::shared_ptr<Hip_Sample_Ring> shared_ring_for(int device, int id, uint32_t vector_length)
+// Channels that name the same <role>.hip_shared_ring id on the same device share one Hip_Tracking_Runtime and, through it, one device sample ring:
+// the stream crosses PCIe once for all of them and ONE launch advances all of them (hip_tracking_runtime.h).  id < 0: a runtime (and ring) of
+// the block's own.  The ring is sized by time, not by the first joiner's code period, so that signals with different periods on the same RF
+// stream (L1 C/A 1 ms, E1 4 ms, L2C 20 ms) fit: 256 ms resident, windows of up to 40 ms contiguous; never less than 64 / 2 of the joiner's periods.
+std::shared_ptr<Hip_Tracking_Runtime> runtime_for(int device, int id, const Dll_Pll_Conf& p, int periods_per_launch)
 {
     static std::mutex mu;
-    static std::map<std::pair<int, int>, std::weak_ptr<Hip_Sample_Ring>> rings;
-    if (id < 0) return nullptr;
+    static std::map<std::pair<int, int>, std::weak_ptr<Hip_Tracking_Runtime>> runtimes;
+    const uint64_t vlen = std::max<uint32_t>(p.vector_length, 1U);
+    auto make = [&](uint64_t capacity, uint64_t window) -> std::shared_ptr<Hip_Tracking_Runtime> {
+        auto ring = std::make_shared<Hip_Sample_Ring>(device, capacity, static_cast<uint32_t>(window));
+        if (!ring->ok())
+            {
+                LOG(ERROR) << "hip sample ring (" << capacity << " samples): " << ring->last_error();
+                return nullptr;
+            }
+        return std::make_shared<Hip_Tracking_Runtime>(device, std::move(ring), periods_per_launch);
+    };
+    if (id < 0) return make(std::max<uint64_t>(16, 4ULL * (static_cast<uint64_t>(periods_per_launch) + 2)) * vlen, 2 * vlen);
     std::lock_guard<std::mutex> lk(mu);
-    auto& slot = rings[{device, id}];
-    auto ring = slot.lock();
-    if (!ring)
+    auto& slot = runtimes[{device, id}];
+    auto rt = slot.lock();
+    if (!rt)
         {
-            // 64 correlation windows: channel threads of one stream run up to a scheduler buffer apart
-            ring = std::make_shared<Hip_Sample_Ring>(device, 64ULL * vector_length, 2U * vector_length);
-            if (!ring->ok())
-                {
-                    LOG(ERROR) << "hip_shared_ring " << id << ": " << ring->last_error();
-                    return nullptr;
-                }
-            slot = ring;
+            const auto fs = static_cast<uint64_t>(std::max(p.fs_in, 1.0));
+            rt = make(std::max<uint64_t>(64 * vlen, fs * 256 / 1000), std::max<uint64_t>(2 * vlen, fs * 40 / 1000));
+            slot = rt;
         }
-    return ring;
+    return rt;
 }
 
 void set_signal(Dll_Pll_Conf& p, char system, char s0, char s1)
@@ -84,6 +92,7 @@ void DllPllTrackingHip::create_tracking_block(const ConfigurationInterface* conf
     const int device = configuration->property(role_ + ".hip_device", 0);
     const int periods = configuration->property(role_ + ".hip_periods_per_call", 1);
     const int ring_id = configuration->property(role_ + ".hip_shared_ring", -1);
+    const int per_launch = configuration->property(role_ + ".hip_periods_per_launch", std::max(16, periods));
     if (trk_params_.item_type != "gr_complex")  // as the reference adapters: item_size 0 tells the factory the block is unusable
         {
             item_size_ = 0;
@@ -98,7 +107,14 @@ void DllPllTrackingHip::create_tracking_block(const ConfigurationInterface* conf
             LOG(ERROR) << role_ << ": HIP device " << device << " not present (the MI355X tracking block has no CPU fallback)";
             return;
         }
-    tracking_sptr_ = dll_pll_veml_make_tracking_hip(trk_params_, device, periods, shared_ring_for(device, ring_id, trk_params_.vector_length));
+    auto runtime = runtime_for(device, ring_id, trk_params_, per_launch);
+    if (!runtime)
+        {
+            item_size_ = 0;
+            tracking_sptr_ = nullptr;
+            return;
+        }
+    tracking_sptr_ = dll_pll_veml_make_tracking_hip(trk_params_, periods, std::move(runtime));
     if (!tracking_sptr_->usable())
         {
             LOG(WARNING) << role_ << ": " << tracking_sptr_->last_error();

@@ -10,9 +10,11 @@
  * set_gnss_synchro, start_tracking, stop_tracking behave as BaseDllPllTracking's (base_dll_pll_tracking.cc:25-112); configuration keys are
  * Dll_Pll_Conf's (dll_pll_conf.cc:48-158) plus
  *   <role>.hip_device            GPU index (0)
- *   <role>.hip_periods_per_call  code periods one general_work call may run in a single launch (1 = the reference's cadence)
- *   <role>.hip_shared_ring       id >= 0: channels configured with the same id (and device) share one device sample ring -- the stream
- *                                crosses PCIe once for all of them; -1 (default): a private ring
+ *   <role>.hip_periods_per_call  code periods one general_work call may take (1 = the reference's cadence, at most 64)
+ *   <role>.hip_shared_ring       id >= 0: channels configured with the same id (and device) share one Hip_Tracking_Runtime and its device
+ *                                sample ring -- the stream crosses PCIe once for all of them and ONE launch advances every channel that has
+ *                                samples; -1 (default): a runtime and ring of the block's own
+ *   <role>.hip_periods_per_launch  most code periods per channel one shared launch runs (16)
  * Factory registration (one `else if` per name, as gnss_block_factory.cc:657-662 does for the CUDA block): INTEGRATION.md section 2b.
  * An unusable block (unsupported item type / signal, or no GPU) is reported the reference's way: item_size() == 0
  * (gnss_block_factory.cc:1048-1052, channel.cc:96-100).

@@ -8,7 +8,8 @@
 #include <thread>
 
 // ------------------------------------------------------------------------------------------------ Hip_Sample_Ring
-Hip_Sample_Ring::Hip_Sample_Ring(int device, uint64_t capacity_samples, uint32_t max_window_samples) : d_device(device)
+Hip_Sample_Ring::Hip_Sample_Ring(int device, uint64_t capacity_samples, uint32_t max_window_samples)
+    : d_device(device), d_capacity(capacity_samples), d_max_window(max_window_samples)
 {
     if (gsh_stream_create(device, capacity_samples, max_window_samples, &d_handle) != GSH_OK)
         {
@@ -42,6 +43,71 @@ uint64_t Hip_Sample_Ring::push_items(const void* items, uint64_t n, int item_typ
 }
 
 
+bool Hip_Sample_Ring::push_from(uint64_t first_index, const std::complex<float>* samples, uint64_t n, bool may_seek, std::chrono::milliseconds gap_timeout)
+{
+    if (d_handle == nullptr) return false;
+    if (n == 0) return true;
+    {
+        std::unique_lock<std::mutex> lk(d_mutex);
+        uint64_t oldest = 0, next = 0;
+        (void)gsh_stream_range(d_handle, &oldest, &next);
+        if (first_index + n <= next) return true;  // somebody (another channel of the stream, an earlier call) has pushed them
+        if (first_index > next)
+            {
+                if (next == oldest || may_seek)
+                    {
+                        // an empty ring starts wherever its first user is; a ring nobody reads any more follows the caller
+                        if (gsh_stream_seek(d_handle, first_index) != GSH_OK)
+                            {
+                                d_error = gsh_last_error();
+                                return false;
+                            }
+                        d_next.store(first_index, std::memory_order_release);
+                        d_origin.store(first_index, std::memory_order_release);
+                        next = first_index;
+                    }
+                else
+                    {
+                        // the samples in between are in the input buffers of slower siblings: they push them when they get there
+                        if (gap_timeout.count() <= 0) return true;  // a caller that does not need them resident itself (a block in standby) leaves it at that
+                        const bool closed = d_pushed.wait_for(lk, gap_timeout, [&] { return d_next.load(std::memory_order_acquire) >= first_index; });
+                        if (!closed)
+                            {
+                                d_error = "push_from: samples " + std::to_string(first_index) + ".. leave a gap after the ring's " + std::to_string(next) +
+                                          " that no other channel of the stream has closed";
+                                return false;
+                            }
+                        (void)gsh_stream_range(d_handle, &oldest, &next);
+                        if (first_index + n <= next) return true;
+                    }
+            }
+        const uint64_t skip = next - first_index;
+        // a call may offer more than the ring holds: the newest capacity's worth is all that can stay resident anyway
+        uint64_t count = n - skip, from = skip;
+        if (count > d_capacity)
+            {
+                from += count - d_capacity;
+                if (gsh_stream_seek(d_handle, first_index + from) != GSH_OK)
+                    {
+                        d_error = gsh_last_error();
+                        return false;
+                    }
+                d_origin.store(first_index + from, std::memory_order_release);
+                count = d_capacity;
+            }
+        uint64_t first = 0;
+        if (gsh_stream_push_staged(d_handle, samples + from, count, GSH_ITEM_GR_COMPLEX, 0, &first) != GSH_OK)
+            {
+                d_error = gsh_last_error();
+                return false;
+            }
+        d_next.store(first + count, std::memory_order_release);
+    }
+    d_pushed.notify_all();
+    return true;
+}
+
+
 bool Hip_Sample_Ring::seek(uint64_t next_index)
 {
     if (d_handle == nullptr) return false;
@@ -52,6 +118,7 @@ bool Hip_Sample_Ring::seek(uint64_t next_index)
             return false;
         }
     d_next.store(next_index, std::memory_order_release);
+    d_origin.store(next_index, std::memory_order_release);
     return true;
 }
 

@@ -51,8 +51,31 @@ public:
     uint64_t push(const std::complex<float>* samples, uint64_t n, bool inverted_spectrum = false);
     uint64_t push_ishort(const int16_t* iq, uint64_t n, bool inverted_spectrum = false);  //!< item_type ishort / cshort
     uint64_t push_ibyte(const int8_t* iq, uint64_t n, bool inverted_spectrum = false);    //!< item_type ibyte / cbyte
+    /*! What a block that shares the ring with other channel threads calls with the samples of ITS input buffer, named by their absolute index:
+        range check, de-duplication and append happen under ONE acquisition of the ring's lock, so two threads that see the same `next` cannot
+        both append.  Samples already resident are skipped (another channel of the stream pushed them); the rest is appended through page-locked
+        staging (gsh_stream_push_staged: `samples` may be re-used on return).  A block that runs AHEAD of the ring (first_index > next: the
+        samples in between belong to slower siblings that have not pushed them yet) repositions the ring when `may_seek` says nobody needs
+        what is resident, and otherwise waits up to `gap_timeout` for the siblings to close the gap (0: does not wait and pushes nothing --
+        the siblings' own pushes will cover the stretch).  Returns false on a gap that stays open or on an engine error (last_error()). */
+    bool push_from(uint64_t first_index, const std::complex<float>* samples, uint64_t n, bool may_seek,
+        std::chrono::milliseconds gap_timeout = std::chrono::milliseconds(200));
     /*! position an idle ring: the next pushed sample gets absolute index `next_index`, nothing older is resident */
     bool seek(uint64_t next_index);
+    uint64_t capacity() const { return d_capacity; }
+    uint32_t max_window() const { return d_max_window; }
+    /*! the next index to be pushed, without the lock (the value wait_for() polls) */
+    uint64_t next_index() const { return d_next.load(std::memory_order_acquire); }
+    /*! the oldest resident index, without the lock (may lag a concurrent push by one call: use it for plausibility, not for addressing) */
+    uint64_t oldest_index() const
+    {
+        const uint64_t next = d_next.load(std::memory_order_acquire), origin = d_origin.load(std::memory_order_acquire);
+        const uint64_t by_capacity = next > d_capacity ? next - d_capacity : 0;
+        return by_capacity > origin ? by_capacity : origin;
+    }
+    /*! the ring's lock, for a caller that must keep pushes out while it queues a launch that reads the ring's bookkeeping
+        (Hip_Correlator_Runtime, Hip_Tracking_Runtime) */
+    std::mutex& mutex() const { return d_mutex; }
     /*! [oldest, next) resident */
     void range(uint64_t* oldest, uint64_t* next) const;
     /*! blocks until sample index `end` has been pushed (next >= end) or the timeout expires */
@@ -64,10 +87,13 @@ private:
     uint64_t push_items(const void* items, uint64_t n, int item_type, bool inverted_spectrum);
     gsh_stream_t* d_handle{nullptr};
     int d_device{0};
+    uint64_t d_capacity{0};
+    uint32_t d_max_window{0};
     std::string d_error;
     mutable std::mutex d_mutex;  // serialises pushes against job translation (the C handle is not thread-safe)
     mutable std::condition_variable d_pushed;
     std::atomic<uint64_t> d_next{0};  // read without the lock on the fast path of wait_for (32 channel threads ask at the same instant)
+    std::atomic<uint64_t> d_origin{0};  // first index resident since the last seek
     friend class Hip_Correlator_Runtime;
 };
 

@@ -1,0 +1,350 @@
+/*!
+ * \file hip_tracking_runtime.cc
+ * \brief Channel-batching runtime behind the tracking blocks; see hip_tracking_runtime.h.
+ */
+#include "hip_tracking_runtime.h"
+#include <algorithm>
+#include <cstring>
+
+Hip_Tracking_Runtime::Hip_Tracking_Runtime(int device, std::shared_ptr<Hip_Sample_Ring> ring, int periods_per_launch, int channels_per_group)
+    : d_device(device),
+      d_ring(std::move(ring)),
+      d_periods_per_launch(std::min(std::max(periods_per_launch, 1), 256)),
+      d_channels_per_group(std::min(std::max(channels_per_group, 1), 4096))
+{
+}
+
+
+Hip_Tracking_Runtime::~Hip_Tracking_Runtime()
+{
+    for (auto& g : d_groups)
+        if (g->trk != nullptr) gsh_trk_destroy(g->trk);
+}
+
+
+// the group with this configuration that still has a free channel, or a new one (d_mutex held)
+Hip_Tracking_Runtime::Group* Hip_Tracking_Runtime::group_for(const gsh_trk_conf& conf, int max_code_length, int* channel)
+{
+    for (auto& g : d_groups)
+        {
+            if (g->max_code_length != max_code_length || std::memcmp(&g->conf, &conf, sizeof(conf)) != 0) continue;
+            for (size_t c = 0; c < g->slot_of_channel.size(); c++)
+                if (g->slot_of_channel[c] < 0)
+                    {
+                        *channel = static_cast<int>(c);
+                        return g.get();
+                    }
+        }
+    auto g = std::make_unique<Group>();
+    g->conf = conf;
+    g->max_code_length = max_code_length;
+    if (gsh_trk_create(d_device, &g->conf, d_channels_per_group, max_code_length, &g->trk) != GSH_OK)
+        {
+            d_error = std::string("gsh_trk_create: ") + gsh_last_error();
+            return nullptr;
+        }
+    if (gsh_trk_set_stream_ring(g->trk, d_ring->handle()) != GSH_OK)
+        {
+            d_error = std::string("gsh_trk_set_stream_ring: ") + gsh_last_error();
+            gsh_trk_destroy(g->trk);
+            return nullptr;
+        }
+    g->slot_of_channel.assign(static_cast<size_t>(d_channels_per_group), -1);
+    g->records.resize(static_cast<size_t>(d_channels_per_group) * static_cast<size_t>(d_periods_per_launch));
+    g->done.assign(static_cast<size_t>(d_channels_per_group), 0);
+    d_groups.push_back(std::move(g));
+    *channel = 0;
+    return d_groups.back().get();
+}
+
+
+int Hip_Tracking_Runtime::attach(const gsh_trk_conf& conf, int max_code_length)
+{
+    if (!ok())
+        {
+            std::lock_guard<std::mutex> lk(d_mutex);
+            d_error = d_ring ? "sample ring: " + d_ring->last_error() : std::string("no sample ring");
+            return -1;
+        }
+    std::lock_guard<std::mutex> lk(d_mutex);
+    int channel = -1;
+    Group* g = group_for(conf, max_code_length, &channel);
+    if (g == nullptr) return -1;
+    size_t s = 0;
+    while (s < d_slots.size() && d_slots[s]->used) s++;
+    if (s == d_slots.size()) d_slots.push_back(std::make_unique<Slot>());
+    Slot& S = *d_slots[s];
+    S = Slot{};
+    S.group = g;
+    S.channel = channel;
+    S.used = true;
+    g->slot_of_channel[static_cast<size_t>(channel)] = static_cast<int>(s);
+    return static_cast<int>(s);
+}
+
+
+void Hip_Tracking_Runtime::detach(int slot)
+{
+    stop(slot);
+    std::lock_guard<std::mutex> lk(d_mutex);
+    if (slot < 0 || slot >= static_cast<int>(d_slots.size()) || !d_slots[slot]->used) return;
+    Slot& S = *d_slots[slot];
+    S.group->slot_of_channel[static_cast<size_t>(S.channel)] = -1;
+    S.used = false;
+    S.generation++;
+}
+
+
+bool Hip_Tracking_Runtime::start(int slot, const float* code, const float* data_code, int code_length, uint64_t nitems_read, double acq_delay_samples,
+    double acq_doppler_hz, uint64_t acq_samplestamp_samples, int32_t* samples_offset, int32_t* first_prn_length)
+{
+    Group* g = nullptr;
+    int channel = -1;
+    {
+        std::lock_guard<std::mutex> lk(d_mutex);
+        if (slot < 0 || slot >= static_cast<int>(d_slots.size()) || !d_slots[slot]->used) return false;
+        g = d_slots[slot]->group;
+        channel = d_slots[slot]->channel;
+    }
+    // The handle's lock is held from the device-side start to the host-side bookkeeping: a launch of the group sees the channel either as
+    // it was before (and its records, if any, are dropped by the generation check) or started with the slot ready to receive its records --
+    // never the device running a channel whose slot does not know yet.
+    std::lock_guard<std::mutex> hl(g->handle_mutex);  // waits for a launch of the group that is in flight
+    int32_t offset = 0, first_len = 0;
+    double acc0 = 0.0;
+    std::string err;
+    if (gsh_trk_pull_in(&g->conf, nitems_read, acq_delay_samples, acq_samplestamp_samples, acq_doppler_hz, &offset, &first_len, &acc0) != GSH_OK)
+        err = std::string("gsh_trk_pull_in: ") + gsh_last_error();
+    const uint64_t start_sample = nitems_read + static_cast<uint64_t>(std::max(offset, 0));
+    if (err.empty() && gsh_trk_start_ex(g->trk, channel, code, data_code, code_length, start_sample, acq_samplestamp_samples, acq_doppler_hz, acc0) != GSH_OK)
+        err = std::string("gsh_trk_start_ex: ") + gsh_last_error();
+    std::lock_guard<std::mutex> lk(d_mutex);
+    Slot& S = *d_slots[slot];
+    S.generation++;
+    S.queue.clear();
+    S.error = err;
+    S.tracking = err.empty();
+    if (!err.empty()) return false;
+    S.next_window = start_sample;
+    if (samples_offset != nullptr) *samples_offset = offset;
+    if (first_prn_length != nullptr) *first_prn_length = first_len;
+    return true;
+}
+
+
+void Hip_Tracking_Runtime::stop(int slot)
+{
+    Group* g = nullptr;
+    int channel = -1;
+    {
+        std::lock_guard<std::mutex> lk(d_mutex);
+        if (slot < 0 || slot >= static_cast<int>(d_slots.size()) || !d_slots[slot]->used) return;
+        Slot& S = *d_slots[slot];
+        if (!S.tracking)  // the device has stopped the channel itself (loss of lock) or it never ran: only the queue is left to drop
+            {
+                S.generation++;
+                S.queue.clear();
+                return;
+            }
+        g = S.group;
+        channel = S.channel;
+    }
+    std::lock_guard<std::mutex> hl(g->handle_mutex);  // as in start(): device state and slot change together, between two launches
+    (void)gsh_trk_stop(g->trk, channel);
+    std::lock_guard<std::mutex> lk(d_mutex);
+    Slot& S = *d_slots[slot];
+    S.tracking = false;
+    S.generation++;
+    S.queue.clear();
+}
+
+
+bool Hip_Tracking_Runtime::tracking(int slot) const
+{
+    std::lock_guard<std::mutex> lk(d_mutex);
+    return slot >= 0 && slot < static_cast<int>(d_slots.size()) && d_slots[slot]->used && d_slots[slot]->tracking;
+}
+
+
+bool Hip_Tracking_Runtime::any_tracking() const
+{
+    std::lock_guard<std::mutex> lk(d_mutex);
+    for (const auto& s : d_slots)
+        if (s->used && s->tracking) return true;
+    return false;
+}
+
+
+uint64_t Hip_Tracking_Runtime::lowest_next_window_locked() const
+{
+    uint64_t lowest = UINT64_MAX;
+    for (const auto& s : d_slots)
+        if (s->used && s->tracking) lowest = std::min(lowest, s->next_window);
+    return lowest;
+}
+
+
+bool Hip_Tracking_Runtime::push(const std::complex<float>* samples, uint64_t first_index, uint64_t n, bool need_resident)
+{
+    if (!ok()) return false;
+    uint64_t lowest;
+    {
+        std::lock_guard<std::mutex> lk(d_mutex);
+        lowest = lowest_next_window_locked();
+    }
+    // never push so far ahead that the window the slowest channel correlates next would be overwritten
+    if (lowest != UINT64_MAX)
+        {
+            const uint64_t room_end = lowest + d_ring->capacity() - d_ring->max_window();
+            if (first_index >= room_end) return true;  // nothing of this call fits yet; the block is offered the samples again
+            n = std::min(n, room_end - first_index);
+        }
+    // a ring whose resident samples nobody is going to read may jump to the position of a caller that needs its own samples there
+    const bool may_seek = need_resident && ((lowest == UINT64_MAX) || (lowest >= first_index));
+    if (!d_ring->push_from(first_index, samples, n, may_seek, std::chrono::milliseconds(need_resident ? 200 : 0)))
+        {
+            std::lock_guard<std::mutex> lk(d_mutex);
+            d_error = "sample ring: " + d_ring->last_error();
+            return false;
+        }
+    return true;
+}
+
+
+int Hip_Tracking_Runtime::take(int slot, uint64_t limit_end, int max_records, gsh_trk_epoch* out)
+{
+    if (max_records <= 0 || out == nullptr) return 0;
+    std::unique_lock<std::mutex> lk(d_mutex);
+    if (slot < 0 || slot >= static_cast<int>(d_slots.size()) || !d_slots[slot]->used) return -1;
+    Slot& S = *d_slots[slot];
+    for (;;)
+        {
+            if (!S.error.empty()) return -1;
+            Group* g = S.group;
+            const uint64_t vlen = g->conf.vector_length;
+            int n = 0;
+            while (n < max_records && !S.queue.empty())
+                {
+                    const gsh_trk_epoch& r = S.queue.front();
+                    if (!(r.flags & 2))
+                        {
+                            const uint64_t need = std::max<uint64_t>(vlen, static_cast<uint64_t>(std::max(r.prn_length_samples, 0)));
+                            if (r.sample_counter + need > limit_end) break;  // the block has not been offered these samples itself yet
+                        }
+                    out[n++] = r;
+                    const bool lost = (r.flags & 2) != 0;
+                    S.queue.pop_front();
+                    if (lost) break;
+                }
+            if (n > 0 || !S.queue.empty() || !S.tracking) return n;
+            // nothing filed for this channel: is its next window resident (and inside what the block itself has seen)?
+            const uint64_t ring_next = d_ring->next_index();
+            if (S.next_window + vlen > ring_next || S.next_window + vlen > limit_end) return 0;
+            if (S.next_window < d_ring->oldest_index())
+                {
+                    // the channel fell more than the ring's capacity behind the stream: its samples are gone (the device would idle on it for ever)
+                    S.error = "the channel's next window [" + std::to_string(S.next_window) + "..) is no longer resident (ring holds [" +
+                              std::to_string(d_ring->oldest_index()) + ", " + std::to_string(ring_next) + "))";
+                    S.tracking = false;
+                    return -1;
+                }
+            if (g->in_flight)
+                {
+                    d_filed.wait(lk);  // the launch in flight may already cover this channel; look again when it has been filed
+                    continue;
+                }
+            // ---- become the launcher for the whole group
+            g->in_flight = true;
+            lk.unlock();
+            int rc = GSH_OK, n_epochs = 1;
+            std::string err;
+            std::vector<uint64_t> gen(g->slot_of_channel.size(), 0);
+            std::unique_lock<std::mutex> hl(g->handle_mutex);  // start / stop of the group's channels happen between launches, never during one
+            {
+                // who takes part, and how far the newest sample lets the furthest-behind channel run: read with the handle locked, so that the
+                // launch sees exactly the channels this snapshot describes
+                std::lock_guard<std::mutex> sl(d_mutex);
+                const uint64_t newest = d_ring->next_index();
+                uint64_t most = 1;
+                for (size_t c = 0; c < g->slot_of_channel.size(); c++)
+                    {
+                        const int s = g->slot_of_channel[c];
+                        if (s < 0) continue;
+                        const Slot& O = *d_slots[s];
+                        gen[c] = O.generation;
+                        if (O.tracking && newest > O.next_window) most = std::max(most, (newest - O.next_window) / vlen);
+                    }
+                n_epochs = static_cast<int>(std::min<uint64_t>(most, static_cast<uint64_t>(d_periods_per_launch)));
+            }
+            {
+                // pushes stay out only while the launch is queued (it reads the ring's newest index and files its reader fence)
+                std::lock_guard<std::mutex> rl(d_ring->mutex());
+                rc = gsh_trk_run_begin(g->trk, n_epochs, 1);
+            }
+            if (rc != GSH_OK) err = std::string("gsh_trk_run_begin: ") + gsh_last_error();
+            if (rc == GSH_OK)
+                {
+                    rc = gsh_trk_run_end(g->trk, g->records.data(), g->done.data());
+                    if (rc != GSH_OK) err = std::string("gsh_trk_run_end: ") + gsh_last_error();
+                }
+            lk.lock();
+            uint32_t filed = 0, served = 0;
+            for (size_t c = 0; c < g->slot_of_channel.size(); c++)
+                {
+                    const int s = g->slot_of_channel[c];
+                    if (s < 0) continue;
+                    Slot& O = *d_slots[s];
+                    if (O.generation != gen[c] || !O.tracking) continue;  // restarted / stopped while the launch ran
+                    if (rc != GSH_OK)
+                        {
+                            O.error = err;
+                            continue;
+                        }
+                    const int done = std::min(std::max(g->done[c], 0), n_epochs);
+                    for (int e = 0; e < done; e++)
+                        {
+                            const gsh_trk_epoch& r = g->records[c * static_cast<size_t>(n_epochs) + static_cast<size_t>(e)];
+                            O.queue.push_back(r);
+                            filed++;
+                            if (r.flags & 2)
+                                {
+                                    O.tracking = false;  // loss of lock: the device has stopped the channel (trk.cc:2009-2014)
+                                    break;
+                                }
+                            O.next_window = r.sample_counter + static_cast<uint64_t>(std::max(r.prn_length_samples, 0));
+                        }
+                    if (done > 0) served++;
+                }
+            g->in_flight = false;
+            hl.unlock();
+            d_stats.launches++;
+            d_stats.channel_periods += filed;
+            d_stats.channels_served += served;
+            d_stats.largest_launch = std::max(d_stats.largest_launch, filed);
+            d_filed.notify_all();
+            if (rc == GSH_OK && filed == 0 && S.queue.empty()) return 0;  // the device found nothing to do: do not spin on it
+        }
+}
+
+
+uint64_t Hip_Tracking_Runtime::next_window(int slot) const
+{
+    std::lock_guard<std::mutex> lk(d_mutex);
+    if (slot < 0 || slot >= static_cast<int>(d_slots.size())) return 0;
+    return d_slots[slot]->next_window;
+}
+
+
+std::string Hip_Tracking_Runtime::last_error(int slot) const
+{
+    std::lock_guard<std::mutex> lk(d_mutex);
+    if (slot >= 0 && slot < static_cast<int>(d_slots.size()) && !d_slots[slot]->error.empty()) return d_slots[slot]->error;
+    return d_error;
+}
+
+
+Hip_Tracking_Runtime::Stats Hip_Tracking_Runtime::stats() const
+{
+    std::lock_guard<std::mutex> lk(d_mutex);
+    return d_stats;
+}

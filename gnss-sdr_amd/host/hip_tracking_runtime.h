@@ -1,0 +1,131 @@
+/*!
+ * \file hip_tracking_runtime.h
+ * \brief Channel-batching runtime behind the tracking blocks: ONE device launch advances every channel of a stream that has work.
+ *
+ * In gnss-sdr all channels run concurrently off one input buffer (src/core/receiver/gnss_flowgraph.cc:1227-1231), each
+ * dll_pll_veml_tracking block doing one code period per general_work call on its own scheduler thread
+ * (src/algorithms/tracking/gnuradio_blocks/dll_pll_veml_tracking.cc:1898-2001, "trk.cc").  The engine's device-closed loop (gsh_trk_*)
+ * serves N channels per launch; a block that owned a one-channel handle would pay one launch and one synchronisation per channel and
+ * period.  This runtime keeps the reference's threading model -- every block still calls push / take from its own thread -- and makes the
+ * launch a shared one:
+ *
+ *   - one gsh_trk handle per loop configuration ("group": the channels of one signal class with identical parameters), a slot per
+ *     tracking block;
+ *   - the stream lives once in a device ring (Hip_Sample_Ring): push() de-duplicates by absolute sample index under one lock
+ *     (Hip_Sample_Ring::push_from), so 32 channels of a stream upload it once, through page-locked staging, while the kernel runs;
+ *   - take(): a block that finds no finished record for itself and no launch in flight for its group becomes the launcher: it queues ONE
+ *     gsh_trk_run over the group -- every started channel advances through all the periods whose samples are resident (up to
+ *     periods_per_launch) -- waits for it and files the records into per-slot queues; blocks that arrive meanwhile wait on a condition
+ *     variable and usually find their records filed when they wake (leader / followers; no extra thread, and a single-threaded caller
+ *     works unchanged).  The device therefore runs ahead of the slowest block by at most what the fastest one has pushed; a block takes
+ *     only records whose samples it has been offered itself (consume_each may not pass its own input);
+ *   - start / stop of one channel serialise with the launches of its group and nothing else.
+ *
+ * Plain C++17 over the C ABI (include/gnss_sdr_hip.h); no HIP headers, no GNU Radio.  No CPU fallback.
+ */
+#ifndef GNSS_SDR_HIP_TRACKING_RUNTIME_H
+#define GNSS_SDR_HIP_TRACKING_RUNTIME_H
+
+#include "gnss_sdr_hip.h"
+#include "hip_correlator_runtime.h"  // Hip_Sample_Ring
+#include <complex>
+#include <condition_variable>
+#include <cstdint>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+class Hip_Tracking_Runtime
+{
+public:
+    struct Stats
+    {
+        uint64_t launches{0};         //!< gsh_trk_run launches
+        uint64_t channel_periods{0};  //!< records filed (one per channel and code period)
+        uint64_t channels_served{0};  //!< sum over launches of the channels that completed at least one period in it
+        uint32_t largest_launch{0};   //!< most channel-periods filed by one launch
+    };
+
+    /*! ring: the device sample ring the channels read (shared by every block that holds this runtime).
+        periods_per_launch: most code periods per channel one launch runs (the launch stops earlier at the newest resident sample).
+        channels_per_group: slots of one gsh_trk handle (a further group is opened when they are used up). */
+    Hip_Tracking_Runtime(int device, std::shared_ptr<Hip_Sample_Ring> ring, int periods_per_launch = 16, int channels_per_group = 64);
+    ~Hip_Tracking_Runtime();
+    Hip_Tracking_Runtime(const Hip_Tracking_Runtime&) = delete;
+    Hip_Tracking_Runtime& operator=(const Hip_Tracking_Runtime&) = delete;
+
+    bool ok() const { return d_ring && d_ring->ok(); }
+    int device() const { return d_device; }
+    Hip_Sample_Ring* ring() const { return d_ring.get(); }
+
+    /*! a tracking block joins with its loop configuration; returns its slot (>= 0), -1 on failure (last_error(-1)) */
+    int attach(const gsh_trk_conf& conf, int max_code_length);
+    void detach(int slot);
+    /*! start_tracking + pull-in (trk.cc:793-866, 1949-1978) for the slot's channel: see gsh_trk_pull_in / gsh_trk_start_ex.  On return
+        *samples_offset is what the block must consume to align the stream with the replica and *first_prn_length the nominal length of the
+        first period (d_current_prn_length_samples after the pull-in). */
+    bool start(int slot, const float* code, const float* data_code, int code_length, uint64_t nitems_read, double acq_delay_samples,
+        double acq_doppler_hz, uint64_t acq_samplestamp_samples, int32_t* samples_offset, int32_t* first_prn_length);
+    /*! stop_tracking (trk.cc:1113-1116): the channel no longer advances, its queued records are dropped */
+    void stop(int slot);
+    bool tracking(int slot) const;
+    /*! true while any slot of this runtime is tracking */
+    bool any_tracking() const;
+    /*! samples [first_index, first_index + n) of the stream as the calling block sees them; see Hip_Sample_Ring::push_from.  Every block of the
+        stream calls it in EVERY general_work, whatever its state: the ring then always holds the stream up to the front-runner's read pointer
+        (the front-runner uploads, for everybody else the call is a comparison of two indices), so a channel that starts -- or starts again --
+        anywhere within the ring's capacity behind the front-runner finds its samples resident.  need_resident: the caller is tracking and
+        will wait (bounded) for slower siblings to close a gap in front of its samples; a block in standby passes false. */
+    bool push(const std::complex<float>* samples, uint64_t first_index, uint64_t n, bool need_resident = true);
+    /*! up to max_records finished periods of the slot's channel, oldest first, whose samples lie below limit_end (sample_counter +
+        max(vector_length, prn_length_samples) <= limit_end).  Launches the group's loop when the channel has resident work and nothing is
+        in flight; waits while a launch that may produce the slot's records is running.  Returns the number of records (0: the next period's
+        samples are not there yet), -1 on an engine error (last_error(slot)).  A record with flags bit 1 is a loss of lock: the channel
+        has stopped and the record is the last one returned. */
+    int take(int slot, uint64_t limit_end, int max_records, gsh_trk_epoch* out);
+    /*! absolute index of the first sample of the slot's next window (host view) */
+    uint64_t next_window(int slot) const;
+    std::string last_error(int slot) const;
+    Stats stats() const;
+
+private:
+    struct Group
+    {
+        gsh_trk_conf conf{};
+        int max_code_length{0};
+        gsh_trk_t* trk{nullptr};
+        std::vector<int> slot_of_channel;  // -1: free
+        std::mutex handle_mutex;           // the C handle: one thread at a time (launch, start, stop)
+        bool in_flight{false};             // guarded by d_mutex
+        std::vector<gsh_trk_epoch> records;
+        std::vector<int32_t> done;
+    };
+    struct Slot
+    {
+        Group* group{nullptr};
+        int channel{-1};
+        bool used{false};
+        bool tracking{false};
+        uint64_t generation{0};      // bumped by start / stop: records of a launch begun before are not filed
+        uint64_t next_window{0};
+        std::deque<gsh_trk_epoch> queue;
+        std::string error;
+    };
+    Group* group_for(const gsh_trk_conf& conf, int max_code_length, int* channel);
+    uint64_t lowest_next_window_locked() const;
+
+    int d_device;
+    std::shared_ptr<Hip_Sample_Ring> d_ring;
+    int d_periods_per_launch;
+    int d_channels_per_group;
+    mutable std::mutex d_mutex;  // slots, queues, in_flight flags, stats
+    std::condition_variable d_filed;
+    std::vector<std::unique_ptr<Group>> d_groups;
+    std::vector<std::unique_ptr<Slot>> d_slots;
+    std::string d_error;
+    Stats d_stats;
+};
+
+#endif  // GNSS_SDR_HIP_TRACKING_RUNTIME_H

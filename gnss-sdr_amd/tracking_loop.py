@@ -102,10 +102,13 @@ class TrackingLoop:
         return ms.value
 
 
-def write_dump(path: str, conf: TrkConf, prn: int, records, append: bool = False) -> None:
-    """Tracking dump file in the reference's binary layout (log_data, trk.cc:1599-1702) from a list of TrkEpoch records."""
+def write_dump(path: str, conf: TrkConf, prn: int, records, append: bool = False, tow_ms=None, wn=None) -> None:
+    """Tracking dump file in the block's binary layout (log_data, trk.cc:1599-1702: 108 bytes per logged period) from a list of TrkEpoch
+    records; tow_ms / wn: one value per record (the TOW hand-back of trk.cc:1921-1935) or None for zeros."""
     arr = (TrkEpoch * len(records))(*records)
-    check(_lib.load().gsh_trk_write_dump(str(path).encode(), int(append), C.byref(conf), prn, arr, len(records)))
+    tow = (C.c_uint64 * len(records))(*[int(v) for v in tow_ms]) if tow_ms is not None else None
+    week = (C.c_uint32 * len(records))(*[int(v) for v in wn]) if wn is not None else None
+    check(_lib.load().gsh_trk_write_dump(str(path).encode(), int(append), C.byref(conf), prn, arr, len(records), tow, week))
 
 
 def set_symbol_sync(conf, symbols_per_bit: int, secondary_code: str = "", has_secondary: bool = False, data_secondary_code: str = "") -> None:

@@ -30,7 +30,7 @@ extern "C"
 {
 #endif
 
-#define GSH_ABI_VERSION 20
+#define GSH_ABI_VERSION 21
 #define GSH_MAX_TAPS 8 /* VE/E/P/L/VL needs 5 (trk.cc:609-650); 8 leaves room for multi-tap dumps */
 
     enum
@@ -178,6 +178,10 @@ extern "C"
      * queued launch still reads (capacity >= everything in flight). */
     int gsh_stream_push_async(gsh_stream_t* s, const void* items, uint64_t n, int item_type, int inverted_spectrum, uint64_t* first_index);
     int gsh_stream_wait(gsh_stream_t* s);  /* host waits for every queued push */
+    /* Asynchronous ingest out of memory the caller wants back at once (a GNU Radio input buffer): the items are copied into page-locked
+     * staging memory owned by the ring (four buffers in rotation), from where the copy to the device and the conversion are queued on the
+     * ring's stream; `items` may be reused as soon as the call returns.  Readers wait on the ring's events as for every other push. */
+    int gsh_stream_push_staged(gsh_stream_t* s, const void* items, uint64_t n, int item_type, int inverted_spectrum, uint64_t* first_index);
     /* position an (idle) ring: the next pushed sample gets absolute index next_index and nothing older is resident -- a channel that
      * starts hours into a run does not have to fill the ring from index 0 */
     int gsh_stream_seek(gsh_stream_t* s, uint64_t next_index);
@@ -346,6 +350,8 @@ extern "C"
         float p_data_accu[2];            /* d_P_data_accu: Prompt_I / Prompt_Q of the symbol when bit 0 is set, else the running sum */
         double carrier_phase_rate_step_rad; /* d_carrier_phase_rate_step_rad [rad/sample^2] after this period (0 outside high_dyn) */
         double code_phase_rate_step_chips;  /* d_code_phase_rate_step_chips [chips/sample^2] */
+        float accu[10];                  /* d_VE_accu .. d_VL_accu as run_dll_pll / log_data saw them (E,P,L in slots 0..2 without veml): the period's
+                                            outputs in state 2, the secondary-code-wiped running sums in states 3 / 4 (trk.cc:1486-1512, 1624-1636) */
     } gsh_trk_epoch;
 
     int gsh_trk_create(int device, const gsh_trk_conf* conf, int n_channels, int max_code_length, gsh_trk_t** out);
@@ -378,14 +384,26 @@ extern "C"
      * call continues where this one stopped.  records: n_channels * n_epochs (channel-major) or NULL;
      * epochs_done[n_channels]: periods completed (a channel stops when its window would leave the stream). */
     int gsh_trk_run(gsh_trk_t* t, int n_epochs, gsh_trk_epoch* records, int32_t* epochs_done);
+    /* the same in two halves, for a caller that serialises launches against pushes into the ring itself (Hip_Tracking_Runtime): _begin queues
+     * the launch and the copies of its results into page-locked host memory on the loop's stream and returns at once -- it is the only part
+     * that looks at the ring's bookkeeping (newest sample, reader fences), so the ring's lock is needed around it alone and the next block of
+     * samples can travel while the kernel runs; _end waits for the stream and hands the results over.  One launch in flight per handle. */
+    int gsh_trk_run_begin(gsh_trk_t* t, int n_epochs, int want_records);
+    int gsh_trk_run_end(gsh_trk_t* t, gsh_trk_epoch* records, int32_t* epochs_done);
+    /* where every channel stands after the last completed run (host copy, refreshed by gsh_trk_run / _run_end and by start / stop):
+     * next_window[ch] = absolute index of the first sample of the channel's next correlation window, active[ch] != 0 while the loop advances it */
+    int gsh_trk_positions(gsh_trk_t* t, uint64_t* next_window, int32_t* active);
     /* HIP-event milliseconds of one gsh_trk_run-sized launch, averaged over reps (each rep restarts from the state at
      * entry; the state is restored afterwards) */
     int gsh_trk_time_run(gsh_trk_t* t, int n_epochs, int reps, float* avg_ms);
-    /* write (append != 0: append) the records of one channel as a tracking dump file in the reference's own binary layout
-     * (log_data, trk.cc:1599-1702: 96 bytes per period), readable by utils/python/lib/dll_pll_veml_read_tracking_dump.py and
-     * utils/matlab/libs/dll_pll_veml_read_tracking_dump.m.  Host-only; periods flagged as loss of lock are skipped, as the
-     * reference skips log_data there. */
-    int gsh_trk_write_dump(const char* path, int append, const gsh_trk_conf* conf, uint32_t prn, const gsh_trk_epoch* records, int n_records);
+    /* write (append != 0: append) the records of one channel as a tracking dump file in the block's own binary layout
+     * (log_data, trk.cc:1599-1702: 19 floats, the PRN start sample as uint64 and as double, PRN, TOW [ms] as uint64, week number =
+     * 108 bytes per logged period -- the layout save_matfile (trk.cc:1705-1716) and utils/matlab/libs/dll_pll_veml_read_tracking_dump.m
+     * parse).  Host-only.  Logged are the periods the block logs: every period of state 2, the symbol periods of states 3 / 4
+     * (trk.cc:2024, 2166, 2218); periods flagged as loss of lock are skipped, as the reference skips log_data there.  tow_ms / wn: one
+     * value per record (d_tow_from_telemetry_ms / d_wn_from_telemetry of that call, trk.cc:1921-1935) or NULL for zeros. */
+    int gsh_trk_write_dump(const char* path, int append, const gsh_trk_conf* conf, uint32_t prn, const gsh_trk_epoch* records, int n_records,
+        const uint64_t* tow_ms, const uint32_t* wn);
 
     /* ================================================================ ACQUISITION
      * gsh_acq_*: the arithmetic of class pcps_acquisition (acq.h:93-251) without its

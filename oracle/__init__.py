@@ -63,7 +63,7 @@ class TrkEpoch(C.Structure):
                 ("carr_freq_error_hz", C.c_double), ("carr_error_filt_hz", C.c_double), ("code_error_chips", C.c_double),
                 ("code_error_filt_chips", C.c_double), ("rem_code_phase_samples", C.c_double), ("acc_carrier_phase_rad", C.c_double), ("carrier_lock_test", C.c_double),
                 ("state", C.c_int32), ("symbol_flags", C.c_int32), ("p_data_accu", C.c_float * 2),
-                ("carrier_phase_rate_step_rad", C.c_double), ("code_phase_rate_step_chips", C.c_double)]
+                ("carrier_phase_rate_step_rad", C.c_double), ("code_phase_rate_step_chips", C.c_double), ("accu", C.c_float * 10)]
 
 
 _lib = None

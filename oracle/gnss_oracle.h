@@ -213,6 +213,7 @@ extern "C"
         int32_t symbol_flags;   /* bit 0: Flag_valid_symbol_output; bit 1: Flag_PLL_180_deg_phase_locked */
         float p_data_accu[2];   /* d_P_data_accu when a symbol is output (Prompt_I / Prompt_Q of the Gnss_Synchro), else the running sum */
         double carrier_phase_rate_step_rad, code_phase_rate_step_chips;  /* after update_tracking_vars (0 outside high_dyn) */
+        float accu[10];         /* d_VE_accu .. d_VL_accu the loop worked on: the outputs in state 2, the running sums in states 3 / 4 */
     } oracle_trk_epoch;
 #define ORACLE_MAX_SMOOTHER 32
 

@@ -703,6 +703,7 @@ int oracle_trk_run(const oracle_trk_conf* c, const float* code, const float* dat
                         }
                     cloop = c->track_pilot ? 0 : 1;  /* :1587-1595: pilot tracking disables the Costas loop */
                 }
+            memcpy(r->accu, out, sizeof(float) * 2 * n_taps);  /* d_VE_accu .. d_VL_accu as run_dll_pll / log_data see them (trk.cc:1624-1636) */
             const float* P = out + 2 * prompt;
             const float* E = out + 2 * (prompt - 1);
             const float* L = out + 2 * (prompt + 1);

@@ -27,7 +27,8 @@ class Output(C.Structure):
                                   "carrier_phase_step_rad", "code_phase_step_chips", "carrier_phase_rate_step_rad", "code_phase_rate_step_chips",
                                   "current_correlation_time_s")] + [
         ("rem_carr_phase_rad", C.c_float), ("corr", C.c_float * 10), ("prompt_data", C.c_float * 2), ("accu", C.c_float * 10),
-        ("p_data_accu", C.c_float * 2), ("n_events", C.c_int32), ("events", C.c_int32 * 16)]
+        ("p_data_accu", C.c_float * 2), ("n_events", C.c_int32), ("events", C.c_int32 * 16),
+        ("tow_at_current_symbol_ms", C.c_uint64)]
 
     def as_dict(self) -> dict:
         d = {}

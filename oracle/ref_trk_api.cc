@@ -36,7 +36,9 @@
 #include <boost/circular_buffer.hpp>
 
 #include "gnss_synchro.h"
+#include "gnss_time.h"
 #include "in_memory_configuration.h"
+#include "tow_to_trk.h"
 
 #define private public
 #define protected public
@@ -90,6 +92,7 @@ struct reftrk_output  /* one Gnss_Synchro as the tracking block fills it (trk.cc
     float p_data_accu[2];
     int32_t n_events;
     int32_t events[16];
+    uint64_t tow_at_current_symbol_ms;  /* Gnss_Synchro::TOW_at_current_symbol_ms of the produced item (trk.cc:2255) */
 };
 
 struct reftrk_conf_out  /* Dll_Pll_Conf after the adapter has finished with it, and what the block's constructor derived */
@@ -246,6 +249,7 @@ static void fill_output(Handle* h, const Gnss_Synchro* g, reftrk_output* o)
             o->correlation_length_ms = g->correlation_length_ms;
             o->flag_pll_180_deg_phase_locked = g->Flag_PLL_180_deg_phase_locked ? 1 : 0;
             o->prn = static_cast<int32_t>(g->PRN);
+            o->tow_at_current_symbol_ms = g->TOW_at_current_symbol_ms;
         }
     o->state = b->d_state;
     o->current_prn_length_samples = b->d_current_prn_length_samples;
@@ -306,6 +310,59 @@ int reftrk_general_work(void* hv, const float* iq, int n_items, int* consumed, r
     if (consumed != nullptr) *consumed = h->block->consumed_last;
     if (out != nullptr) fill_output(h, r > 0 ? &h->out_items[0] : nullptr, out);
     return r;
+}
+
+/* Channel::set_channel after construction (the dump file is named after it, trk.cc:1851-1873) */
+void reftrk_set_channel(void* hv, uint32_t channel)
+{
+    auto* h = static_cast<Handle*>(hv);
+    if (h->adapter)
+        h->adapter->set_channel(channel);
+    else
+        h->block->set_channel(channel);
+}
+
+/* the telemetry decoder's TOW hand-back (e.g. gps_l1_ca_telemetry_decoder_gs.cc: "telemetry_to_trk" <- shared_ptr<TOW_to_trk>), trk.cc:771-779 */
+void reftrk_deliver_tow(void* hv, const char* signal, int32_t channel, uint32_t tow, uint64_t sample_stamp, int32_t wn, uint32_t prn)
+{
+    const std::shared_ptr<TOW_to_trk> obj = std::make_shared<TOW_to_trk>(TOW_to_trk(signal, channel, tow, sample_stamp, wn, prn));
+    static_cast<Handle*>(hv)->block->deliver("telemetry_to_trk", pmt::make_any(obj));
+}
+
+/* a "timetag" stream tag on the block's input at absolute sample `offset` (signal source -> tracking, trk.cc:2256-2283) */
+void reftrk_add_input_timetag(void* hv, uint64_t offset, double rx_time, int week, int tow_ms, double tow_ms_fraction)
+{
+    const std::shared_ptr<GnssTime> t = std::make_shared<GnssTime>();
+    t->rx_time = rx_time;
+    t->week = week;
+    t->tow_ms = tow_ms;
+    t->tow_ms_fraction = tow_ms_fraction;
+    gr::tag_t tag;
+    tag.offset = offset;
+    tag.key = pmt::mp("timetag");
+    tag.value = pmt::make_any(t);
+    static_cast<Handle*>(hv)->block->input_tags.push_back(tag);
+}
+
+/* the "timetag" tags the block has attached to its output so far (trk.cc:2295-2312): returns how many (at most capacity are copied) */
+int reftrk_output_timetags(void* hv, uint64_t* offsets, int* week, int* tow_ms, double* tow_ms_fraction, double* rx_time, int capacity)
+{
+    int n = 0;
+    for (const auto& t : static_cast<Handle*>(hv)->block->output_tags)
+        {
+            if (pmt::symbol_to_string(t.key) != "timetag") continue;
+            if (n < capacity)
+                {
+                    const auto g = std::any_cast<const std::shared_ptr<GnssTime>>(pmt::any_ref(t.value));
+                    offsets[n] = t.offset;
+                    week[n] = g->week;
+                    tow_ms[n] = g->tow_ms;
+                    tow_ms_fraction[n] = g->tow_ms_fraction;
+                    rx_time[n] = g->rx_time;
+                }
+            n++;
+        }
+    return n;
 }
 
 void reftrk_clear_events(void* hv) { static_cast<Handle*>(hv)->block->published.clear(); }

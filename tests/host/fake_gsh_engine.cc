@@ -1,0 +1,290 @@
+// TEST INFRASTRUCTURE ONLY -- a CPU stand-in for the DEVICE half of the C ABI (include/gnss_sdr_hip.h), so that the host-side runtime
+// (gnss-sdr_amd/host/hip_tracking_runtime.cc), the GNU Radio block shell and the adapters can be exercised -- threads, locks, bookkeeping,
+// Gnss_Synchro items, dump, TOW -- in the CPU test suite and under ThreadSanitizer, where no GPU exists.  It is linked into TEST programs
+// only (tests/host/*_fake), in front of libgnss_sdr_hip.so: the entry points defined here interpose the library's, everything else
+// (gsh_trk_pull_in, gsh_trk_write_dump, gsh_last_error: host-only code) is the library's own.  The product has no CPU path; nothing under
+// gnss-sdr_amd/ or include/ refers to this file.
+//
+// What stands in for the kernel is the ORACLE (oracle/gnss_oracle_loop.c, the restatement pinned to the reference block): a channel's whole
+// trajectory over the test's stream is computed once at gsh_trk_start_ex -- the test hands the complete stream over beforehand
+// (fake_gsh_set_reference_stream) -- and a run releases the periods whose windows are resident in the fake ring.  Every push is checked,
+// sample for sample, against that stream at the absolute index the ring gives it: a duplicated or shifted push (two channel threads appending
+// the same samples) fails loudly (fake_gsh_push_mismatches()).
+#include "gnss_oracle.h"
+#include "gnss_sdr_hip.h"
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+namespace gsh
+{
+int set_error(int code, const char* fmt, ...);  // libgnss_sdr_hip.so (thread-local text behind gsh_last_error)
+}
+
+static_assert(sizeof(oracle_trk_conf) == sizeof(gsh_trk_conf), "oracle_trk_conf and gsh_trk_conf share one layout");
+static_assert(sizeof(oracle_trk_epoch) == sizeof(gsh_trk_epoch), "oracle_trk_epoch and gsh_trk_epoch share one layout");
+
+namespace
+{
+std::mutex g_ref_mutex;
+const float* g_ref_iq = nullptr;
+uint64_t g_ref_n = 0;
+std::atomic<uint64_t> g_mismatch{0};
+std::atomic<int> g_busy_handles{0};  // > 1 concurrent entries into one handle = a host-side locking bug
+}  // namespace
+
+struct gsh_stream
+{
+    uint64_t capacity{0}, max_window{0}, next{0}, origin{0};
+    std::atomic<int> inside{0};
+};
+
+struct FakeChannel
+{
+    bool active{false};
+    uint64_t start{0};
+    std::vector<gsh_trk_epoch> all;  // the whole trajectory over the reference stream
+    size_t released{0};
+    uint64_t pos{0};
+};
+
+struct gsh_trk
+{
+    gsh_trk_conf conf{};
+    int n_channels{0}, max_code_len{0};
+    gsh_stream* ring{nullptr};
+    std::vector<FakeChannel> ch;
+    std::vector<gsh_trk_epoch> pending_rec;
+    std::vector<int32_t> pending_done;
+    int pending_epochs{-1};
+    std::atomic<int> inside{0};
+};
+
+namespace
+{
+struct Guard  // one thread at a time per handle, as the ABI demands of its callers
+{
+    std::atomic<int>& f;
+    explicit Guard(std::atomic<int>& flag) : f(flag)
+    {
+        if (f.fetch_add(1) != 0)
+            {
+                g_busy_handles++;
+                std::fprintf(stderr, "FAKE ENGINE: two threads inside one handle at once\n");
+            }
+    }
+    ~Guard() { f.fetch_sub(1); }
+};
+
+uint64_t oldest(const gsh_stream* s)
+{
+    const uint64_t by_cap = s->next > s->capacity ? s->next - s->capacity : 0;
+    return std::max(by_cap, s->origin);
+}
+
+int push_common(gsh_stream* s, const void* items, uint64_t n, int item_type, uint64_t* first_index)
+{
+    if (s == nullptr || (n != 0 && items == nullptr)) return gsh::set_error(GSH_ERR_INVALID, "fake: null argument");
+    if (item_type != GSH_ITEM_GR_COMPLEX) return gsh::set_error(GSH_ERR_UNSUPPORTED, "fake: complex64 items only");
+    if (n > s->capacity) return gsh::set_error(GSH_ERR_INVALID, "a push of %llu samples exceeds the ring capacity %llu", (unsigned long long)n, (unsigned long long)s->capacity);
+    Guard g(s->inside);
+    if (first_index) *first_index = s->next;
+    {
+        std::lock_guard<std::mutex> lk(g_ref_mutex);
+        if (g_ref_iq != nullptr)
+            {
+                if (s->next + n > g_ref_n || std::memcmp(items, g_ref_iq + 2 * s->next, sizeof(float) * 2 * n) != 0)
+                    {
+                        g_mismatch++;
+                        std::fprintf(stderr, "FAKE ENGINE: push of %llu samples at absolute index %llu does not match the stream\n", (unsigned long long)n, (unsigned long long)s->next);
+                    }
+            }
+    }
+    s->next += n;
+    return GSH_OK;
+}
+}  // namespace
+
+extern "C"
+{
+    // ---- test hooks
+    void fake_gsh_set_reference_stream(const float* iq, uint64_t n)
+    {
+        std::lock_guard<std::mutex> lk(g_ref_mutex);
+        g_ref_iq = iq;
+        g_ref_n = n;
+    }
+    uint64_t fake_gsh_push_mismatches(void) { return g_mismatch.load(); }
+    int fake_gsh_concurrent_handle_entries(void) { return g_busy_handles.load(); }
+
+    int gsh_device_count(void) { return 1; }
+
+    // ---- sample ring
+    int gsh_stream_create(int device, uint64_t capacity_samples, uint32_t max_window_samples, gsh_stream_t** out)
+    {
+        if (out == nullptr) return gsh::set_error(GSH_ERR_INVALID, "null out pointer");
+        *out = nullptr;
+        if (device != 0) return gsh::set_error(GSH_ERR_NO_DEVICE, "device %d out of range (0..0)", device);
+        if (max_window_samples < 1 || capacity_samples < 2ull * max_window_samples) return gsh::set_error(GSH_ERR_INVALID, "fake: bad ring geometry");
+        auto* s = new gsh_stream();
+        s->capacity = capacity_samples + (capacity_samples & 1ull);
+        s->max_window = max_window_samples;
+        *out = s;
+        return GSH_OK;
+    }
+    void gsh_stream_destroy(gsh_stream_t* s) { delete s; }
+    int gsh_stream_push(gsh_stream_t* s, const void* items, uint64_t n, int item_type, int, uint64_t* first_index) { return push_common(s, items, n, item_type, first_index); }
+    int gsh_stream_push_staged(gsh_stream_t* s, const void* items, uint64_t n, int item_type, int, uint64_t* first_index) { return push_common(s, items, n, item_type, first_index); }
+    int gsh_stream_seek(gsh_stream_t* s, uint64_t next_index)
+    {
+        if (s == nullptr) return gsh::set_error(GSH_ERR_INVALID, "null stream");
+        Guard g(s->inside);
+        s->next = next_index;
+        s->origin = next_index;
+        return GSH_OK;
+    }
+    int gsh_stream_range(gsh_stream_t* s, uint64_t* lo, uint64_t* hi)
+    {
+        if (s == nullptr) return gsh::set_error(GSH_ERR_INVALID, "null stream");
+        if (lo) *lo = oldest(s);
+        if (hi) *hi = s->next;
+        return GSH_OK;
+    }
+
+    // ---- tracking loop
+    int gsh_trk_create(int device, const gsh_trk_conf* conf, int n_channels, int max_code_length, gsh_trk_t** out)
+    {
+        if (out == nullptr || conf == nullptr) return gsh::set_error(GSH_ERR_INVALID, "null argument");
+        *out = nullptr;
+        if (device != 0) return gsh::set_error(GSH_ERR_NO_DEVICE, "device %d out of range (0..0)", device);
+        auto* t = new gsh_trk();
+        t->conf = *conf;
+        t->n_channels = n_channels;
+        t->max_code_len = max_code_length;
+        t->ch.resize(static_cast<size_t>(n_channels));
+        *out = t;
+        return GSH_OK;
+    }
+    void gsh_trk_destroy(gsh_trk_t* t) { delete t; }
+    int gsh_trk_set_stream_ring(gsh_trk_t* t, gsh_stream_t* s)
+    {
+        if (t == nullptr) return gsh::set_error(GSH_ERR_INVALID, "null handle");
+        if (s != nullptr && s->max_window < t->conf.vector_length)
+            return gsh::set_error(GSH_ERR_INVALID, "the ring's max_window_samples %llu is shorter than vector_length %u", (unsigned long long)s->max_window, t->conf.vector_length);
+        t->ring = s;
+        return GSH_OK;
+    }
+    int gsh_trk_start_ex(gsh_trk_t* t, int channel, const float* code, const float* data_code, int code_length, uint64_t start_sample, uint64_t acq_sample_stamp,
+        double acq_carrier_doppler_hz, double initial_acc_carrier_phase_rad)
+    {
+        if (t == nullptr || code == nullptr || channel < 0 || channel >= t->n_channels) return gsh::set_error(GSH_ERR_INVALID, "fake: bad start arguments");
+        Guard g(t->inside);
+        const float* ref;
+        uint64_t n_ref;
+        {
+            std::lock_guard<std::mutex> lk(g_ref_mutex);
+            ref = g_ref_iq;
+            n_ref = g_ref_n;
+        }
+        if (ref == nullptr) return gsh::set_error(GSH_ERR_STATE, "fake engine: fake_gsh_set_reference_stream() has not been called");
+        FakeChannel& c = t->ch[static_cast<size_t>(channel)];
+        c = FakeChannel{};
+        c.start = start_sample;
+        c.pos = start_sample;
+        const uint64_t vlen = t->conf.vector_length;
+        const uint64_t most = start_sample + vlen <= n_ref ? (n_ref - start_sample) / (vlen > 1 ? vlen - 1 : 1) + 2 : 0;
+        c.all.resize(static_cast<size_t>(most));
+        int got = 0;
+        if (most > 0)
+            got = oracle_trk_run(reinterpret_cast<const oracle_trk_conf*>(&t->conf), code, t->conf.track_pilot ? data_code : nullptr, code_length, ref, n_ref, start_sample,
+                acq_sample_stamp, acq_carrier_doppler_hz, static_cast<int>(most), reinterpret_cast<oracle_trk_epoch*>(c.all.data()));
+        c.all.resize(static_cast<size_t>(std::max(got, 0)));
+        // the oracle starts d_acc_carrier_phase_rad at 0; the pull-in alignment's contribution (trk.cc:1966) rides on it until the first narrow-tracking
+        // period re-initialises the accumulator (check_carrier_phase_coherent_initialization, trk.cc:1350-1357)
+        for (auto& r : c.all)
+            {
+                if (r.state == 4) break;
+                r.acc_carrier_phase_rad += initial_acc_carrier_phase_rad;
+            }
+        c.active = true;
+        return GSH_OK;
+    }
+    int gsh_trk_start(gsh_trk_t* t, int channel, const float* code, const float* data_code, int code_length, uint64_t start_sample, uint64_t acq_sample_stamp,
+        double acq_carrier_doppler_hz)
+    {
+        return gsh_trk_start_ex(t, channel, code, data_code, code_length, start_sample, acq_sample_stamp, acq_carrier_doppler_hz, 0.0);
+    }
+    int gsh_trk_stop(gsh_trk_t* t, int channel)
+    {
+        if (t == nullptr || channel < 0 || channel >= t->n_channels) return gsh::set_error(GSH_ERR_INVALID, "fake: bad stop arguments");
+        Guard g(t->inside);
+        t->ch[static_cast<size_t>(channel)].active = false;
+        return GSH_OK;
+    }
+    int gsh_trk_run_begin(gsh_trk_t* t, int n_epochs, int want_records)
+    {
+        if (t == nullptr || n_epochs < 0) return gsh::set_error(GSH_ERR_INVALID, "fake: bad run arguments");
+        if (t->ring == nullptr) return gsh::set_error(GSH_ERR_STATE, "no IF stream attached (gsh_trk_set_stream_*)");
+        if (t->pending_epochs >= 0) return gsh::set_error(GSH_ERR_STATE, "gsh_trk_run_begin: the previous run has not been ended");
+        Guard g(t->inside);
+        if (t->ring->inside.load() != 0)
+            {
+                g_busy_handles++;
+                std::fprintf(stderr, "FAKE ENGINE: a launch was queued while a push was inside the ring (the ring's lock was not held)\n");
+            }
+        (void)want_records;
+        const uint64_t vlen = t->conf.vector_length, next = t->ring->next, old = oldest(t->ring);
+        t->pending_rec.assign(static_cast<size_t>(t->n_channels) * static_cast<size_t>(n_epochs), gsh_trk_epoch{});
+        t->pending_done.assign(static_cast<size_t>(t->n_channels), 0);
+        for (int c = 0; c < t->n_channels; c++)
+            {
+                FakeChannel& C = t->ch[static_cast<size_t>(c)];
+                int done = 0;
+                while (C.active && done < n_epochs && C.released < C.all.size())
+                    {
+                        const gsh_trk_epoch& r = C.all[C.released];
+                        if (r.sample_counter + vlen > next || r.sample_counter < old) break;
+                        t->pending_rec[static_cast<size_t>(c) * static_cast<size_t>(n_epochs) + static_cast<size_t>(done)] = r;
+                        done++;
+                        C.released++;
+                        if (r.flags & 2)
+                            {
+                                C.active = false;
+                                break;
+                            }
+                        C.pos = r.sample_counter + static_cast<uint64_t>(r.prn_length_samples);
+                    }
+                t->pending_done[static_cast<size_t>(c)] = done;
+            }
+        t->pending_epochs = n_epochs;
+        return GSH_OK;
+    }
+    int gsh_trk_run_end(gsh_trk_t* t, gsh_trk_epoch* records, int32_t* epochs_done)
+    {
+        if (t == nullptr) return gsh::set_error(GSH_ERR_INVALID, "null handle");
+        if (t->pending_epochs < 0) return gsh::set_error(GSH_ERR_STATE, "gsh_trk_run_end without gsh_trk_run_begin");
+        Guard g(t->inside);
+        if (records != nullptr && !t->pending_rec.empty()) std::memcpy(records, t->pending_rec.data(), sizeof(gsh_trk_epoch) * t->pending_rec.size());
+        if (epochs_done != nullptr) std::memcpy(epochs_done, t->pending_done.data(), sizeof(int32_t) * t->pending_done.size());
+        t->pending_epochs = -1;
+        return GSH_OK;
+    }
+    int gsh_trk_run(gsh_trk_t* t, int n_epochs, gsh_trk_epoch* records, int32_t* epochs_done)
+    {
+        const int rc = gsh_trk_run_begin(t, n_epochs, records != nullptr);
+        return rc != GSH_OK ? rc : gsh_trk_run_end(t, records, epochs_done);
+    }
+    int gsh_trk_positions(gsh_trk_t* t, uint64_t* next_window, int32_t* active)
+    {
+        if (t == nullptr) return gsh::set_error(GSH_ERR_INVALID, "null handle");
+        for (int c = 0; c < t->n_channels; c++)
+            {
+                if (next_window) next_window[c] = t->ch[static_cast<size_t>(c)].pos;
+                if (active) active[c] = t->ch[static_cast<size_t>(c)].active ? 1 : 0;
+            }
+        return GSH_OK;
+    }
+}

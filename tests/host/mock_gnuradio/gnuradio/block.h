@@ -6,6 +6,7 @@
 #include "gnuradio/thread/thread.h"
 #include "gnuradio/types.h"
 #include "pmt/pmt.h"
+#include <atomic>
 #include <cstdint>
 #include <functional>
 #include <map>
@@ -53,7 +54,7 @@ public:
 protected:
     basic_block(const std::string& name, io_signature::sptr in, io_signature::sptr out) : d_name(name), d_in(std::move(in)), d_out(std::move(out))
     {
-        static long next_id = 0;
+        static std::atomic<long> next_id{0};  // blocks are built from several test threads
         d_id = next_id++;
     }
     std::string d_name;

@@ -33,10 +33,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <chrono>
+#include <fstream>
 #include <map>
 #include <memory>
 #include <random>
 #include <string>
+#include <thread>
 #include <vector>
 
 // ---- the reference chain's C driver (oracle/ref_trk_api.cc)
@@ -57,6 +61,7 @@ struct reftrk_output
     float p_data_accu[2];
     int32_t n_events;
     int32_t events[16];
+    uint64_t tow_at_current_symbol_ms;
 };
 struct reftrk_conf_out
 {
@@ -82,6 +87,15 @@ void reftrk_start_tracking(void* h);
 int reftrk_general_work(void* h, const float* iq, int n_items, int* consumed, reftrk_output* out);
 void reftrk_get_conf(void* h, reftrk_conf_out* c);
 int reftrk_get_codes(void* h, float* tracking_code, float* data_code, int capacity);
+void reftrk_set_channel(void* h, uint32_t channel);
+void reftrk_stop_tracking(void* h);
+void reftrk_deliver_tow(void* h, const char* signal, int32_t channel, uint32_t tow, uint64_t sample_stamp, int32_t wn, uint32_t prn);
+void reftrk_add_input_timetag(void* h, uint64_t offset, double rx_time, int week, int tow_ms, double tow_ms_fraction);
+int reftrk_output_timetags(void* h, uint64_t* offsets, int* week, int* tow_ms, double* tow_ms_fraction, double* rx_time, int capacity);
+// present only in the *_fake build (tests/host/fake_gsh_engine.cc): the CPU stand-in for the device half of the C ABI wants the whole stream up front
+void fake_gsh_set_reference_stream(const float* iq, uint64_t n) __attribute__((weak));
+uint64_t fake_gsh_push_mismatches(void) __attribute__((weak));
+int fake_gsh_concurrent_handle_entries(void) __attribute__((weak));
 }
 
 namespace
@@ -537,6 +551,7 @@ TrajectoryStats run_pair(DllPllTrackingHip& hip, void* ref, Gnss_Synchro& syn, c
 {
     TrajectoryStats st;
     auto blk = std::dynamic_pointer_cast<gr::block>(hip.get_left_block());
+    if (fake_gsh_set_reference_stream != nullptr) fake_gsh_set_reference_stream(reinterpret_cast<const float*>(x.data()), x.size());
     syn = Gnss_Synchro{};
     syn.System = system;
     std::memcpy(syn.Signal, signal, 3);
@@ -904,11 +919,46 @@ void test_unusable_configurations()
     GpsL1CaDllPllTrackingHip hip2(cfg2.get(), R, 1, 1);
     EXPECT(hip2.item_size() == 0, "absent device: item_size must be 0, got %zu", hip2.item_size());
 }
+#include "test_tracking_runtime_cases.inc"
 }  // namespace
 
 int main(int argc, char** argv)
 {
     const bool conf_only = argc > 1 && std::string(argv[1]) == "conf";
+    const std::string mode = argc > 1 ? argv[1] : "";
+    const int host_threads = std::max(2, std::min(16, static_cast<int>(std::thread::hardware_concurrency())));
+    if (mode == "bench")  // test_tracking_adapters bench [channels fs periods periods_per_call]: the drop-in throughput leg (bench.py's `dropin`)
+        {
+            if (gsh_device_count() < 1)
+                {
+                    std::printf("no HIP device\n");
+                    return 2;
+                }
+            const int ch = argc > 2 ? std::atoi(argv[2]) : 32;
+            const long fs = argc > 3 ? std::atol(argv[3]) : 25000000L;
+            const int periods = argc > 4 ? std::atoi(argv[4]) : 400;
+            const int ppc = argc > 5 ? std::atoi(argv[5]) : 10;
+            return bench_dropin(ch, fs, periods, ppc, host_threads);
+        }
+    if (mode == "runtime")  // only the runtime cases (what the CPU suite runs against the fake engine): [channels periods periods_per_call]
+        {
+            if (gsh_device_count() < 1)
+                {
+                    std::printf("no HIP device\n");
+                    return 2;
+                }
+            const int ch = argc > 2 ? std::atoi(argv[2]) : 8;
+            const int periods = argc > 3 ? std::atoi(argv[3]) : 2400;
+            const int ppc = argc > 4 ? std::atoi(argv[4]) : 4;
+            test_restart_on_the_same_block();
+            test_many_periods_per_call();
+            test_dump_tow_and_time_tags(1);
+            test_dump_tow_and_time_tags(10);
+            test_shared_runtime_threads(ch, periods, ppc, host_threads);
+            test_shared_runtime_threads(std::max(2, ch / 2), 500, 1, host_threads);
+            std::printf(fails == 0 ? "TRACKING RUNTIME OK\n" : "%d failure(s)\n", fails);
+            return fails == 0 ? 0 : 1;
+        }
     test_conf_mapping();
     if (conf_only)
         {
@@ -925,6 +975,12 @@ int main(int argc, char** argv)
     test_galileo_e1_pilot_trajectory();
     test_other_signal_trajectories();
     test_loss_of_lock_on_noise();
+    test_restart_on_the_same_block();
+    test_many_periods_per_call();
+    test_dump_tow_and_time_tags(1);
+    test_dump_tow_and_time_tags(10);
+    test_shared_runtime_threads(32, 2400, 10, host_threads);
+    test_shared_runtime_threads(8, 500, 1, host_threads);
     std::printf(fails == 0 ? "TRACKING ADAPTERS OK\n" : "%d failure(s)\n", fails);
     return fails == 0 ? 0 : 1;
 }

@@ -28,8 +28,38 @@ def test_dll_pll_conf_mapping_equals_reference_constructor():
     assert r.returncode == 0 and "TRACKING CONF OK" in r.stdout, r.stdout[-4000:] + r.stderr[-2000:]
 
 
+def test_block_and_runtime_against_the_fake_engine():
+    """The whole adapter / block / Hip_Tracking_Runtime stack on the CPU: tests/host/test_tracking_adapters_fake is the same program linked in
+    front of tests/host/fake_gsh_engine.cc, a stand-in for the DEVICE half of the C ABI with the oracle's loop behind it (test infrastructure,
+    never part of the product).  Every trajectory (13 signals), the loss-of-lock and restart cases, several periods per call, the dump file / TOW /
+    time tags and 32 block threads on one shared runtime are compared with the reference's own blocks; the fake engine also checks that every
+    push lands at the right absolute sample index and that no two threads are inside one engine handle at once."""
+    fake = _bin() + "_fake"
+    if not os.path.exists(fake):
+        pytest.skip("tests/host/test_tracking_adapters_fake was not prebuilt and /root/reference is not present here")
+    r = subprocess.run([fake], capture_output=True, text=True, timeout=900, cwd="/tmp")
+    tail = "\n".join(l for l in r.stdout.splitlines() if "FAIL" in l or "shared stream" in l or "OK" in l or "dump" in l or "restart" in l)
+    print(tail[-3000:])
+    assert r.returncode == 0 and "TRACKING ADAPTERS OK" in r.stdout and "FAKE ENGINE" not in r.stderr, tail[-6000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_dropin_throughput_32_channels_one_stream(gpu):
+    """BASELINE config 2's shape through the drop-in seam: 32 dll_pll_veml_tracking_hip blocks, one thread each, one 25 Msps stream, one
+    Hip_Tracking_Runtime; every block's window positions equal the reference block's.  Prints channel-periods/s (bench.py's `dropin` leg)."""
+    import json
+    r = subprocess.run([_bin(), "bench", "32", "25000000", "160", "10"], capture_output=True, text=True, timeout=900, cwd="/tmp")
+    line = [l for l in r.stdout.splitlines() if l.startswith("DROPIN_JSON")]
+    assert r.returncode == 0 and line, r.stdout[-4000:] + r.stderr[-2000:]
+    d = json.loads(line[-1][len("DROPIN_JSON"):])
+    print(d)
+    assert d["windows_identical_to_reference_blocks"] and d["failures"] == 0
+    assert d["channels_per_launch"] >= 8.0, d     # the launches are shared ones
+    assert d["channel_periods_per_s"] >= 2.0e5, d  # far above one launch per channel and period; the target sits in bench.py / DESIGN.md
+
+
 @pytest.mark.gpu
 def test_tracking_adapters_follow_the_reference_block(gpu):
-    r = subprocess.run([_bin()], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([_bin()], capture_output=True, text=True, timeout=900, cwd="/tmp")
     print(r.stdout[-3000:])
     assert r.returncode == 0 and "TRACKING ADAPTERS OK" in r.stdout, r.stdout[-6000:] + r.stderr[-2000:]

@@ -1,9 +1,5 @@
-"""The tracking dump writer (gsh_trk_write_dump) against the reference's own reader: utils/python/lib/dll_pll_veml_read_tracking_dump.py is
-imported from /root/reference when it is there (this container), and an independent numpy dtype of log_data's layout (trk.cc:1599-1702)
-is used everywhere.  No GPU needed: the records come from the CPU oracle loop (same struct layout as gsh_trk_epoch)."""
+"""The tracking dump writer (gsh_trk_write_dump): an independent numpy dtype of log_data's layout (trk.cc:1599-1702, 108 bytes per record) is used.  No GPU needed: the records come from the CPU oracle loop (same struct layout as gsh_trk_epoch)."""
 import ctypes as C
-import importlib.util
-import os
 
 import numpy as np
 import pytest
@@ -15,7 +11,7 @@ LOG_DATA = np.dtype([("VE", "<f4"), ("E", "<f4"), ("P", "<f4"), ("L", "<f4"), ("
                      ("PRN_start_sample", "<u8"), ("acc_carrier_phase_rad", "<f4"), ("carrier_doppler_hz", "<f4"),
                      ("carrier_doppler_rate_hz_s", "<f4"), ("code_freq_hz", "<f4"), ("code_freq_rate_hz_s", "<f4"), ("carr_error", "<f4"),
                      ("carr_nco", "<f4"), ("code_error", "<f4"), ("code_nco", "<f4"), ("CN0_SNV_dB_Hz", "<f4"), ("carrier_lock_test", "<f4"),
-                     ("var1", "<f4"), ("var2", "<f8"), ("PRN", "<u4")])
+                     ("var1", "<f4"), ("var2", "<f8"), ("PRN", "<u4"), ("TOW_ms", "<u8"), ("WN", "<u4")])
 
 
 def _records():
@@ -28,7 +24,7 @@ def _records():
 def test_dump_layout_and_values(gsh, tmp_path):
     from gnss_sdr_amd._lib import TrkConf, TrkEpoch
     from gnss_sdr_amd.tracking_loop import write_dump
-    assert LOG_DATA.itemsize == 96
+    assert LOG_DATA.itemsize == 108   # trk.cc:1705-1710 (save_matfile's epoch_size_bytes)
     conf_o, rec_o = _records()
     conf = TrkConf.from_buffer_copy(bytes(memoryview(conf_o)))          # same layout by construction (oracle/gnss_oracle.h)
     rec = [TrkEpoch.from_buffer_copy(bytes(memoryview(r))) for r in rec_o]
@@ -49,20 +45,12 @@ def test_dump_layout_and_values(gsh, tmp_path):
         assert d["code_error"][k] == np.float32(r.code_error_chips) and d["code_nco"][k] == np.float32(r.code_error_filt_chips)
         assert d["CN0_SNV_dB_Hz"][k] == np.float32(r.cn0_db_hz) and d["carrier_lock_test"][k] == np.float32(r.carrier_lock_test)
         assert d["var1"][k] == np.float32(r.rem_code_phase_samples) and d["PRN"][k] == 4
-    # the reference's own reader parses the file (it walks past the end of the file and raises; its results up to there are what it returns
-    # when the caller handles that, as utils/python/dll_pll_veml_plot_sample.py does) -- compare its columns with ours
-    ref_reader = "/root/reference/utils/python/lib/dll_pll_veml_read_tracking_dump.py"
-    if os.path.exists(ref_reader):
-        spec = importlib.util.spec_from_file_location("ref_reader", ref_reader)
-        mod = importlib.util.module_from_spec(spec)
-        spec.loader.exec_module(mod)
-        try:
-            out = mod.dll_pll_veml_read_tracking_dump(str(path))
-        except Exception:
-            out = None
-        if out is not None:
-            for name in ("E", "P", "L", "prompt_I", "prompt_Q", "PRN_start_sample", "carrier_doppler_hz", "code_freq_hz", "CN0_SNV_dB_Hz", "PRN"):
-                col = np.array(out[name][:len(d)])
-                assert len(col) >= len(d) - 1
-                m = min(len(col), len(d))
-                assert np.array_equal(col[:m].astype(d[name].dtype), d[name][:m]), name
+    # TOW hand-back columns (trk.cc:1921-1935 -> :1690-1695): one value per record, zeros when the caller has none
+    assert not d["TOW_ms"].any() and not d["WN"].any()
+    tow = [518400000 + 20 * k for k in range(len(rec))]
+    write_dump(path, conf, 4, rec, tow_ms=tow, wn=[2200] * len(rec))
+    d = np.fromfile(path, dtype=LOG_DATA)
+    assert len(d) == len(rec) and np.array_equal(d["TOW_ms"], np.array(tow, dtype=np.uint64)) and np.all(d["WN"] == 2200)
+    # (utils/python/lib/dll_pll_veml_read_tracking_dump.py predates the TOW / WN fields of the block's record and mis-steps through a current
+    # dump file; the layout authority is the block itself: tests/host/test_tracking_adapters compares this writer's file with the file the
+    # reference block writes with dump=true, record for record.)
