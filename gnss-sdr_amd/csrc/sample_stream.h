@@ -44,6 +44,7 @@ struct gsh_stream
     size_t stage_cap[NSTAGE]{};
     hipEvent_t stage_done[NSTAGE]{};  // the conversion that read d_stage[i] (and therefore the copy out of h_stage[i]) has finished
     int stage_next{0};
+    hipEvent_t copied{nullptr};       // gsh_stream_push_pinned: the DMA out of the caller's page-locked memory has finished
 };
 
 namespace gsh

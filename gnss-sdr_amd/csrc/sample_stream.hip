@@ -165,6 +165,7 @@ extern "C"
             }
         if (s->pushed) (void)hipEventDestroy(s->pushed);
         if (s->read_fold) (void)hipEventDestroy(s->read_fold);
+        if (s->copied) (void)hipEventDestroy(s->copied);
         for (int i = 0; i < gsh_stream::NSTAGE; i++)
             {
                 if (s->stage_done[i]) (void)hipEventDestroy(s->stage_done[i]);
@@ -305,6 +306,65 @@ extern "C"
         rc = record_push(s, s->next + n, s->stream);
         if (rc != GSH_OK) return rc;
         s->next += n;
+        return GSH_OK;
+    }
+
+    int gsh_stream_push_pinned(gsh_stream_t* s, const void* items, uint64_t n, int item_type, int inverted_spectrum, uint64_t* first_index)
+    {
+        // page-locked items -> device staging (DMA straight out of the caller's memory) -> conversion into the ring; the host waits for the DMA only
+        GSH_REQUIRE(s != nullptr, "null stream");
+        GSH_REQUIRE(n == 0 || items != nullptr, "null items");
+        const size_t isz = gsh::item_bytes(item_type);
+        GSH_REQUIRE(isz != 0, "unknown item type %d", item_type);
+        GSH_REQUIRE(n <= s->capacity, "a push of %llu samples exceeds the ring capacity %llu", static_cast<unsigned long long>(n), s->capacity);
+        if (first_index) *first_index = s->next;
+        if (n == 0) return GSH_OK;
+        GSH_HIP(hipSetDevice(s->device));
+        const int slot = s->stage_next;
+        s->stage_next = (s->stage_next + 1) % gsh_stream::NSTAGE;
+        const size_t bytes = static_cast<size_t>(n) * isz;
+        if (s->stage_done[slot] == nullptr)
+            GSH_HIP(hipEventCreateWithFlags(&s->stage_done[slot], hipEventDisableTiming));
+        else
+            GSH_HIP(hipEventSynchronize(s->stage_done[slot]));  // the conversion that read this device buffer four pushes ago
+        if (s->copied == nullptr) GSH_HIP(hipEventCreateWithFlags(&s->copied, hipEventDisableTiming));
+        if (bytes > s->stage_cap[slot])
+            {
+                if (s->h_stage[slot]) GSH_HIP(hipHostFree(s->h_stage[slot]));
+                if (s->d_stage[slot]) GSH_HIP(hipFree(s->d_stage[slot]));
+                s->h_stage[slot] = nullptr;
+                s->d_stage[slot] = nullptr;
+                s->stage_cap[slot] = 0;
+                const size_t cap = bytes + bytes / 2;
+                GSH_HIP(hipHostMalloc(&s->h_stage[slot], cap, hipHostMallocDefault));  // (kept in step with the staged path, which shares the slots)
+                GSH_HIP(hipMalloc(&s->d_stage[slot], cap));
+                s->stage_cap[slot] = cap;
+            }
+        GSH_HIP(hipMemcpyAsync(s->d_stage[slot], items, bytes, hipMemcpyHostToDevice, s->stream));
+        GSH_HIP(hipEventRecord(s->copied, s->stream));
+        int rc = write_items(s, s->d_stage[slot], n, item_type, inverted_spectrum ? 1 : 0, s->stream);
+        if (rc != GSH_OK) return rc;
+        GSH_HIP(hipEventRecord(s->stage_done[slot], s->stream));
+        rc = record_push(s, s->next + n, s->stream);
+        if (rc != GSH_OK) return rc;
+        s->next += n;
+        GSH_HIP(hipEventSynchronize(s->copied));  // `items` is free again; the conversion and the readers' waits stay asynchronous
+        return GSH_OK;
+    }
+
+    int gsh_host_register(int device, void* ptr, size_t bytes)
+    {
+        GSH_REQUIRE(ptr != nullptr && bytes > 0, "null / empty range");
+        int rc = gsh::use_device(device);
+        if (rc != GSH_OK) return rc;
+        GSH_HIP(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+        return GSH_OK;
+    }
+
+    int gsh_host_unregister(void* ptr)
+    {
+        GSH_REQUIRE(ptr != nullptr, "null pointer");
+        GSH_HIP(hipHostUnregister(ptr));
         return GSH_OK;
     }
 

@@ -15,6 +15,8 @@
  *                                sample ring -- the stream crosses PCIe once for all of them and ONE launch advances every channel that has
  *                                samples; -1 (default): a runtime and ring of the block's own
  *   <role>.hip_periods_per_launch  most code periods per channel one shared launch runs (16)
+ *   <role>.hip_register_input_buffer  page-lock the block's input buffer (lazily, as general_work shows it) so that pushes are DMAs without a
+ *                                staging copy (true)
  * Factory registration (one `else if` per name, as gnss_block_factory.cc:657-662 does for the CUDA block): INTEGRATION.md section 2b.
  * An unusable block (unsupported item type / signal, or no GPU) is reported the reference's way: item_size() == 0
  * (gnss_block_factory.cc:1048-1052, channel.cc:96-100).

@@ -21,7 +21,64 @@ Hip_Sample_Ring::Hip_Sample_Ring(int device, uint64_t capacity_samples, uint32_t
 
 Hip_Sample_Ring::~Hip_Sample_Ring()
 {
-    if (d_handle != nullptr) gsh_stream_destroy(d_handle);
+    if (d_handle != nullptr) gsh_stream_destroy(d_handle);  // waits for the ring's queued copies
+    for (void* p : d_registered) (void)gsh_host_unregister(p);
+}
+
+
+bool Hip_Sample_Ring::covered_locked(uintptr_t a, uintptr_t b) const
+{
+    for (const auto& r : d_pinned)
+        if (r.first <= a && b <= r.second) return true;
+    return false;
+}
+
+
+// page-lock what is missing of [a, b) (page aligned); d_mutex held
+bool Hip_Sample_Ring::register_locked(uintptr_t a, uintptr_t b)
+{
+    std::vector<std::pair<uintptr_t, uintptr_t>> missing;
+    uintptr_t at = a;
+    for (const auto& r : d_pinned)  // sorted, disjoint
+        {
+            if (r.second <= at) continue;
+            if (r.first >= b) break;
+            if (r.first > at) missing.emplace_back(at, r.first);
+            at = std::max(at, r.second);
+        }
+    if (at < b) missing.emplace_back(at, b);
+    for (const auto& m : missing)
+        {
+            if (gsh_host_register(d_device, reinterpret_cast<void*>(m.first), static_cast<size_t>(m.second - m.first)) != GSH_OK)
+                {
+                    d_error = gsh_last_error();
+                    return false;
+                }
+            d_registered.push_back(reinterpret_cast<void*>(m.first));
+            d_pinned.emplace_back(m.first, m.second);
+        }
+    std::sort(d_pinned.begin(), d_pinned.end());
+    std::vector<std::pair<uintptr_t, uintptr_t>> merged;
+    for (const auto& r : d_pinned)
+        {
+            if (!merged.empty() && r.first <= merged.back().second)
+                merged.back().second = std::max(merged.back().second, r.second);
+            else
+                merged.push_back(r);
+        }
+    d_pinned.swap(merged);
+    return true;
+}
+
+
+bool Hip_Sample_Ring::register_host(const void* ptr, size_t bytes)
+{
+    if (d_handle == nullptr || ptr == nullptr || bytes == 0) return false;
+    constexpr uintptr_t PAGE = 4096;
+    const uintptr_t a = reinterpret_cast<uintptr_t>(ptr) & ~(PAGE - 1);
+    const uintptr_t b = (reinterpret_cast<uintptr_t>(ptr) + bytes + PAGE - 1) & ~(PAGE - 1);
+    std::lock_guard<std::mutex> lk(d_mutex);
+    return covered_locked(a, b) || register_locked(a, b);
 }
 
 
@@ -96,7 +153,22 @@ bool Hip_Sample_Ring::push_from(uint64_t first_index, const std::complex<float>*
                 count = d_capacity;
             }
         uint64_t first = 0;
-        if (gsh_stream_push_staged(d_handle, samples + from, count, GSH_ITEM_GR_COMPLEX, 0, &first) != GSH_OK)
+        // page-locked input (registered by the caller, or here when auto-registration is on) goes to the DMA engine as it lies; anything
+        // else through the ring's page-locked staging buffers
+        bool pinned = false;
+        {
+            const uintptr_t a = reinterpret_cast<uintptr_t>(samples + from), b = a + static_cast<uintptr_t>(count) * sizeof(std::complex<float>);
+            pinned = covered_locked(a, b);
+            if (!pinned && d_auto_register)
+                {
+                    constexpr uintptr_t PAGE = 4096;
+                    pinned = register_locked(a & ~(PAGE - 1), (b + PAGE - 1) & ~(PAGE - 1));
+                    if (!pinned) d_auto_register = false;  // memory that cannot be registered: stop trying, use the staging copy
+                }
+        }
+        const int rc_push = pinned ? gsh_stream_push_pinned(d_handle, samples + from, count, GSH_ITEM_GR_COMPLEX, 0, &first)
+                                   : gsh_stream_push_staged(d_handle, samples + from, count, GSH_ITEM_GR_COMPLEX, 0, &first);
+        if (rc_push != GSH_OK)
             {
                 d_error = gsh_last_error();
                 return false;

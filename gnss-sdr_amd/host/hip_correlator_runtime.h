@@ -60,6 +60,12 @@ public:
         the siblings' own pushes will cover the stretch).  Returns false on a gap that stays open or on an engine error (last_error()). */
     bool push_from(uint64_t first_index, const std::complex<float>* samples, uint64_t n, bool may_seek,
         std::chrono::milliseconds gap_timeout = std::chrono::milliseconds(200));
+    /*! Page-lock [ptr, ptr + bytes) (rounded outwards to pages; parts already locked are skipped) so that push_from can hand it to the DMA
+        engine without a staging copy.  A GNU Radio input buffer is the same memory for the whole run: after the first few calls every push is
+        a true DMA.  false (and push_from falls back to the staging copy) when the range cannot be registered. */
+    bool register_host(const void* ptr, size_t bytes);
+    /*! push_from registers whatever part of the range it is handed is not page-locked yet (default off: the caller decides) */
+    void set_auto_register(bool on) { d_auto_register = on; }
     /*! position an idle ring: the next pushed sample gets absolute index `next_index`, nothing older is resident */
     bool seek(uint64_t next_index);
     uint64_t capacity() const { return d_capacity; }
@@ -94,6 +100,12 @@ private:
     mutable std::condition_variable d_pushed;
     std::atomic<uint64_t> d_next{0};  // read without the lock on the fast path of wait_for (32 channel threads ask at the same instant)
     std::atomic<uint64_t> d_origin{0};  // first index resident since the last seek
+    // page-locked host ranges (sorted, disjoint, merged) and the pieces that were registered to cover them (what the destructor releases)
+    bool covered_locked(uintptr_t a, uintptr_t b) const;
+    bool register_locked(uintptr_t a, uintptr_t b);
+    std::vector<std::pair<uintptr_t, uintptr_t>> d_pinned;
+    std::vector<void*> d_registered;
+    bool d_auto_register{false};
     friend class Hip_Correlator_Runtime;
 };
 

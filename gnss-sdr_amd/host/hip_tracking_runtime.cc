@@ -201,7 +201,16 @@ bool Hip_Tracking_Runtime::push(const std::complex<float>* samples, uint64_t fir
         }
     // a ring whose resident samples nobody is going to read may jump to the position of a caller that needs its own samples there
     const bool may_seek = need_resident && ((lowest == UINT64_MAX) || (lowest >= first_index));
-    if (!d_ring->push_from(first_index, samples, n, may_seek, std::chrono::milliseconds(need_resident ? 200 : 0)))
+    const uint64_t before = d_ring->next_index();
+    const auto t0 = std::chrono::steady_clock::now();
+    const bool ok_push = d_ring->push_from(first_index, samples, n, may_seek, std::chrono::milliseconds(need_resident ? 200 : 0));
+    const uint64_t after = d_ring->next_index();
+    if (after > before && first_index + n >= after)  // this call appended (the counters are approximate under contention: another pusher may be in between)
+        {
+            d_push_ns.fetch_add(static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count()), std::memory_order_relaxed);
+            d_pushed_samples.fetch_add(after - before, std::memory_order_relaxed);
+        }
+    if (!ok_push)
         {
             std::lock_guard<std::mutex> lk(d_mutex);
             d_error = "sample ring: " + d_ring->last_error();
@@ -260,6 +269,7 @@ int Hip_Tracking_Runtime::take(int slot, uint64_t limit_end, int max_records, gs
             std::string err;
             std::vector<uint64_t> gen(g->slot_of_channel.size(), 0);
             std::unique_lock<std::mutex> hl(g->handle_mutex);  // start / stop of the group's channels happen between launches, never during one
+            const auto t_launch = std::chrono::steady_clock::now();
             {
                 // who takes part, and how far the newest sample lets the furthest-behind channel run: read with the handle locked, so that the
                 // launch sees exactly the channels this snapshot describes
@@ -287,7 +297,9 @@ int Hip_Tracking_Runtime::take(int slot, uint64_t limit_end, int max_records, gs
                     rc = gsh_trk_run_end(g->trk, g->records.data(), g->done.data());
                     if (rc != GSH_OK) err = std::string("gsh_trk_run_end: ") + gsh_last_error();
                 }
+            const auto launch_ns = static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_launch).count());
             lk.lock();
+            d_stats.launch_ns += launch_ns;
             uint32_t filed = 0, served = 0;
             for (size_t c = 0; c < g->slot_of_channel.size(); c++)
                 {
@@ -346,5 +358,8 @@ std::string Hip_Tracking_Runtime::last_error(int slot) const
 Hip_Tracking_Runtime::Stats Hip_Tracking_Runtime::stats() const
 {
     std::lock_guard<std::mutex> lk(d_mutex);
-    return d_stats;
+    Stats s = d_stats;
+    s.push_ns = d_push_ns.load(std::memory_order_relaxed);
+    s.pushed_samples = d_pushed_samples.load(std::memory_order_relaxed);
+    return s;
 }

@@ -28,6 +28,8 @@
 
 #include "gnss_sdr_hip.h"
 #include "hip_correlator_runtime.h"  // Hip_Sample_Ring
+#include <atomic>
+#include <chrono>
 #include <complex>
 #include <condition_variable>
 #include <cstdint>
@@ -46,6 +48,9 @@ public:
         uint64_t channel_periods{0};  //!< records filed (one per channel and code period)
         uint64_t channels_served{0};  //!< sum over launches of the channels that completed at least one period in it
         uint32_t largest_launch{0};   //!< most channel-periods filed by one launch
+        uint64_t launch_ns{0};        //!< wall time inside launches (queueing + kernel + results), summed
+        uint64_t push_ns{0};          //!< wall time the front-runner blocks spent appending samples (staging copy + queueing), summed
+        uint64_t pushed_samples{0};   //!< samples appended (every sample of the stream once, however many channels read it)
     };
 
     /*! ring: the device sample ring the channels read (shared by every block that holds this runtime).
@@ -126,6 +131,7 @@ private:
     std::vector<std::unique_ptr<Slot>> d_slots;
     std::string d_error;
     Stats d_stats;
+    std::atomic<uint64_t> d_push_ns{0}, d_pushed_samples{0};
 };
 
 #endif  // GNSS_SDR_HIP_TRACKING_RUNTIME_H

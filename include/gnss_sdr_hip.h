@@ -182,6 +182,15 @@ extern "C"
      * staging memory owned by the ring (four buffers in rotation), from where the copy to the device and the conversion are queued on the
      * ring's stream; `items` may be reused as soon as the call returns.  Readers wait on the ring's events as for every other push. */
     int gsh_stream_push_staged(gsh_stream_t* s, const void* items, uint64_t n, int item_type, int inverted_spectrum, uint64_t* first_index);
+    /* The same for items that already lie in page-locked host memory (gsh_host_register, or memory the caller allocated page-locked): no staging
+     * copy on the host -- the DMA engine reads `items` directly -- and the call returns when that DMA has finished (the conversion into the ring
+     * stays queued), so `items` may be re-used on return.  This is the path for a GNU Radio input buffer: the scheduler re-uses the same buffer
+     * for the whole run, so registering it once makes every later push a true DMA. */
+    int gsh_stream_push_pinned(gsh_stream_t* s, const void* items, uint64_t n, int item_type, int inverted_spectrum, uint64_t* first_index);
+    /* page-lock / release a range of host memory for DMA (hipHostRegister / hipHostUnregister behind the ABI: host code above it has no HIP headers).
+     * The range must be mapped; registering pages twice fails with GSH_ERR_HIP. */
+    int gsh_host_register(int device, void* ptr, size_t bytes);
+    int gsh_host_unregister(void* ptr);
     /* position an (idle) ring: the next pushed sample gets absolute index next_index and nothing older is resident -- a channel that
      * starts hours into a run does not have to fill the ring from index 0 */
     int gsh_stream_seek(gsh_stream_t* s, uint64_t next_index);

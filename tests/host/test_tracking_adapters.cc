@@ -263,7 +263,7 @@ Dll_Pll_Conf adapter_conf(const SignalCase& sc, const std::string& role)
 std::vector<SignalCase> signal_cases()
 {
     const std::string R = "Tracking";
-    auto base = [&](long fs) { return Props{{"GNSS-SDR.internal_fs_sps", std::to_string(fs)}, {R + ".hip_device", "0"}}; };
+    auto base = [&](long fs) { return Props{{"GNSS-SDR.internal_fs_sps", std::to_string(fs)}, {R + ".hip_device", "0"}, {R + ".hip_register_input_buffer", "false"}}; };
     std::vector<SignalCase> v;
     {
         Props p = base(4000000);
@@ -664,7 +664,7 @@ void test_gps_l1_trajectory()
     const double fd = 1234.0;
     const std::string R = "Tracking";
     Props p{{"GNSS-SDR.internal_fs_sps", std::to_string(fs)}, {R + ".pll_bw_hz", "35.0"}, {R + ".dll_bw_hz", "2.0"}, {R + ".early_late_space_chips", "0.5"},
-        {R + ".pull_in_time_s", "0"}, {R + ".hip_device", "0"}};
+        {R + ".pull_in_time_s", "0"}, {R + ".hip_device", "0"}, {R + ".hip_register_input_buffer", "false"}};
     auto cfg = make_config(p);
     GpsL1CaDllPllTrackingHip hip(cfg.get(), R, 1, 1);
     EXPECT(hip.implementation() == "GPS_L1_CA_DLL_PLL_Tracking_HIP" && hip.role() == R, "names");
@@ -740,7 +740,7 @@ void test_galileo_e1_pilot_trajectory()
     const double fd = -2200.0;
     const std::string R = "Tracking";
     Props p{{"GNSS-SDR.internal_fs_sps", std::to_string(fs)}, {R + ".pll_bw_hz", "15.0"}, {R + ".dll_bw_hz", "0.75"}, {R + ".early_late_space_chips", "0.15"},
-        {R + ".very_early_late_space_chips", "0.6"}, {R + ".track_pilot", "true"}, {R + ".pull_in_time_s", "0"}, {R + ".hip_device", "0"}};
+        {R + ".very_early_late_space_chips", "0.6"}, {R + ".track_pilot", "true"}, {R + ".pull_in_time_s", "0"}, {R + ".hip_device", "0"}, {R + ".hip_register_input_buffer", "false"}};
     auto cfg = make_config(p);
     GalileoE1DllPllVemlTrackingHip hip(cfg.get(), R, 1, 1);
     EXPECT(hip.implementation() == "Galileo_E1_DLL_PLL_VEML_Tracking_HIP", "name");
@@ -782,7 +782,7 @@ void signal_trajectory(const char* name, const char* ref_impl, const char* hip_i
 {
     const std::string R = "Tracking";
     Props p{{"GNSS-SDR.internal_fs_sps", std::to_string(fs)}, {R + ".pll_bw_hz", "35.0"}, {R + ".dll_bw_hz", "2.0"}, {R + ".early_late_space_chips", "0.5"},
-        {R + ".pull_in_time_s", "0"}, {R + ".hip_device", "0"}};
+        {R + ".pull_in_time_s", "0"}, {R + ".hip_device", "0"}, {R + ".hip_register_input_buffer", "false"}};
     for (const auto& kv : extra) p[kv.first] = kv.second;
     auto cfg = make_config(p);
     Adapter hip(cfg.get(), R, 1, 1);
@@ -886,7 +886,7 @@ void test_loss_of_lock_on_noise()
     const long fs = 4000000;
     const int n = 4000;
     const std::string R = "Tracking";
-    Props p{{"GNSS-SDR.internal_fs_sps", std::to_string(fs)}, {R + ".pull_in_time_s", "0"}, {R + ".hip_device", "0"}, {R + ".cn0_min", "35"},
+    Props p{{"GNSS-SDR.internal_fs_sps", std::to_string(fs)}, {R + ".pull_in_time_s", "0"}, {R + ".hip_device", "0"}, {R + ".hip_register_input_buffer", "false"}, {R + ".cn0_min", "35"},
         {R + ".max_lock_fail", "20"}};
     auto cfg = make_config(p);
     GpsL1CaDllPllTrackingHip hip(cfg.get(), R, 1, 1);
@@ -910,7 +910,7 @@ void test_loss_of_lock_on_noise()
 void test_unusable_configurations()
 {
     const std::string R = "Tracking";
-    Props p{{"GNSS-SDR.internal_fs_sps", "4000000"}, {R + ".item_type", "cshort"}, {R + ".hip_device", "0"}};
+    Props p{{"GNSS-SDR.internal_fs_sps", "4000000"}, {R + ".item_type", "cshort"}, {R + ".hip_device", "0"}, {R + ".hip_register_input_buffer", "false"}};
     auto cfg = make_config(p);
     GpsL1CaDllPllTrackingHip hip(cfg.get(), R, 1, 1);
     EXPECT(hip.item_size() == 0, "cshort items: item_size must be 0 (gnss_block_factory.cc:1048-1052), got %zu", hip.item_size());
