@@ -23,6 +23,7 @@
 #define GSH_MC_THREADS GSH_TRK_THREADS
 #include "mcorr_device.h"
 #include "sample_stream.h"
+#include <algorithm>
 #include <cmath>
 #include <cstddef>
 #include <new>
@@ -105,6 +106,13 @@ struct TrkChannel  // loop state of one channel, resident in device memory betwe
     FllPllState pll;
 };
 
+struct TrkTail  // what the host needs back from every channel after a launch, in one small contiguous copy
+{
+    unsigned long long pos;  // TrkChannel::pos: first sample of the next window
+    int done;                // periods completed in this launch
+    int active;              // TrkChannel::active
+};
+
 struct TrkArgs
 {
     const gsh_trk_conf* conf;  // device copy (a by-value struct with dynamically indexed arrays would be materialised in scratch by every thread)
@@ -117,7 +125,7 @@ struct TrkArgs
     TrkChannel* chan;
     LockState* lock;          // n_channels (used with conf.enable_lock_detectors)
     gsh_trk_epoch* records;   // n_channels * n_epochs or nullptr
-    int* epochs_done;         // n_channels
+    TrkTail* tail;            // n_channels
     int n_epochs;
 };
 
@@ -569,10 +577,10 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
                         {                      // accumulators the loop works on -- what log_data dumps as |d_VE_accu| .. |d_VL_accu| (trk.cc:1624-1636)
                             float* ra = a.records[static_cast<size_t>(ch) * a.n_epochs + e].accu;
 #pragma unroll
-                            for (int t = 0; t < NT; t++)
+                            for (int t = 0; t < 5; t++)  // (all ten slots: the device buffer is not cleared between launches)
                                 {
-                                    ra[2 * t] = acc[t].x;
-                                    ra[2 * t + 1] = acc[t].y;
+                                    ra[2 * t] = (t < NT) ? acc[t < NT ? t : 0].x : 0.0f;
+                                    ra[2 * t + 1] = (t < NT) ? acc[t < NT ? t : 0].y : 0.0f;
                                 }
                         }
                     const bool cloop_now = c.enable_symbol_sync ? (lk.cloop != 0) : (c.cloop != 0);
@@ -920,7 +928,14 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
         for (int i = tid; i < static_cast<int>(sizeof(TrkChannel) / 4); i += MC_THREADS) gs[i] = ls[i];
         for (int i = tid; i < static_cast<int>(sizeof(LockState) / 4); i += MC_THREADS) gl[i] = ll[i];
     }
-    if (tid == 0) a.epochs_done[ch] = done;
+    if (tid == 0)
+        {
+            TrkTail tl;
+            tl.pos = s.pos;
+            tl.done = done;
+            tl.active = s.active;
+            a.tail[ch] = tl;
+        }
 }
 
 // ---- host: filter design in the reference's float / double mix ---------------------------------------------------
@@ -1053,14 +1068,12 @@ struct gsh_trk
     gsh_stream* ring{nullptr};  // when set, the loop follows the live ring: positions are absolute sample indices
     gsh_trk_epoch* d_records{nullptr};
     size_t records_cap{0};
-    int* d_done{nullptr};
+    gsh::TrkTail* d_tail{nullptr};
     hipEvent_t ev0{nullptr}, ev1{nullptr};
     // gsh_trk_run_begin / _end: results land in page-locked host memory so that the copies are true asynchronous DMAs
     gsh_trk_epoch* h_records{nullptr};
     size_t h_records_cap{0};
-    int32_t* h_done{nullptr};                // n_channels
-    unsigned long long* h_pos{nullptr};      // n_channels: TrkChannel::pos after the run
-    int32_t* h_active{nullptr};              // n_channels: TrkChannel::active after the run
+    gsh::TrkTail* h_tail{nullptr};           // n_channels: position / periods done / active flag after the run
     int pending_epochs{-1};                  // >= 0: a run has been begun and not ended
     bool pending_records{false};
 };
@@ -1096,7 +1109,7 @@ int trk_launch(gsh_trk* t, int n_epochs, gsh_trk_epoch* d_records)
     a.chan = t->d_chan;
     a.lock = t->d_lock;
     a.records = d_records;
-    a.epochs_done = t->d_done;
+    a.tail = t->d_tail;
     a.n_epochs = n_epochs;
     const size_t lds = trk_lds_bytes(t);
     const dim3 grid(t->n_channels), block(gsh::mcdev::MC_THREADS);
@@ -1185,10 +1198,8 @@ extern "C"
         if ((e = hipMalloc(&t->d_lock, sizeof(gsh::LockState) * n_channels)) != hipSuccess) return fail(e, "hipMalloc(lock)");
         if ((e = hipMalloc(&t->d_lock_backup, sizeof(gsh::LockState) * n_channels)) != hipSuccess) return fail(e, "hipMalloc(lock)");
         if ((e = hipMemset(t->d_lock, 0, sizeof(gsh::LockState) * n_channels)) != hipSuccess) return fail(e, "hipMemset(lock)");
-        if ((e = hipMalloc(&t->d_done, sizeof(int) * n_channels)) != hipSuccess) return fail(e, "hipMalloc(done)");
-        if ((e = hipHostMalloc(&t->h_done, sizeof(int32_t) * n_channels, hipHostMallocDefault)) != hipSuccess) return fail(e, "hipHostMalloc(done)");
-        if ((e = hipHostMalloc(&t->h_pos, sizeof(unsigned long long) * n_channels, hipHostMallocDefault)) != hipSuccess) return fail(e, "hipHostMalloc(pos)");
-        if ((e = hipHostMalloc(&t->h_active, sizeof(int32_t) * n_channels, hipHostMallocDefault)) != hipSuccess) return fail(e, "hipHostMalloc(active)");
+        if ((e = hipMalloc(&t->d_tail, sizeof(gsh::TrkTail) * n_channels)) != hipSuccess) return fail(e, "hipMalloc(tail)");
+        if ((e = hipHostMalloc(&t->h_tail, sizeof(gsh::TrkTail) * n_channels, hipHostMallocDefault)) != hipSuccess) return fail(e, "hipHostMalloc(tail)");
         if ((e = hipMalloc(&t->d_conf, sizeof(gsh_trk_conf))) != hipSuccess) return fail(e, "hipMalloc(conf)");
         if ((e = hipMemcpy(t->d_conf, &t->conf, sizeof(gsh_trk_conf), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy(conf)");
         if ((e = hipEventCreate(&t->ev0)) != hipSuccess) return fail(e, "hipEventCreate");
@@ -1217,12 +1228,10 @@ extern "C"
         if (t->d_lock_backup) (void)hipFree(t->d_lock_backup);
         if (t->d_stream_owned) (void)hipFree(t->d_stream_owned);
         if (t->d_records) (void)hipFree(t->d_records);
-        if (t->d_done) (void)hipFree(t->d_done);
+        if (t->d_tail) (void)hipFree(t->d_tail);
         if (t->d_conf) (void)hipFree(t->d_conf);
         if (t->h_records) (void)hipHostFree(t->h_records);
-        if (t->h_done) (void)hipHostFree(t->h_done);
-        if (t->h_pos) (void)hipHostFree(t->h_pos);
-        if (t->h_active) (void)hipHostFree(t->h_active);
+        if (t->h_tail) (void)hipHostFree(t->h_tail);
         if (t->ev0) (void)hipEventDestroy(t->ev0);
         if (t->ev1) (void)hipEventDestroy(t->ev1);
         if (t->stream) (void)hipStreamDestroy(t->stream);
@@ -1423,16 +1432,12 @@ extern "C"
                 GSH_HIP(hipHostMalloc(&t->h_records, sizeof(gsh_trk_epoch) * n_rec, hipHostMallocDefault));
                 t->h_records_cap = n_rec;
             }
-        if (n_rec > 0) GSH_HIP(hipMemsetAsync(t->d_records, 0, sizeof(gsh_trk_epoch) * n_rec, t->stream));
         int rc = trk_launch(t, n_epochs, n_rec > 0 ? t->d_records : nullptr);
         if (rc != GSH_OK) return rc;
+        // two copies come back: the records (periods a channel did not run are zeroed on the host in _end, not by a fill kernel in front of the
+        // launch) and one 16-byte tail per channel
         if (n_rec > 0) GSH_HIP(hipMemcpyAsync(t->h_records, t->d_records, sizeof(gsh_trk_epoch) * n_rec, hipMemcpyDeviceToHost, t->stream));
-        GSH_HIP(hipMemcpyAsync(t->h_done, t->d_done, sizeof(int) * t->n_channels, hipMemcpyDeviceToHost, t->stream));
-        // where every channel stands now: the two fields out of the strided state array
-        GSH_HIP(hipMemcpy2DAsync(t->h_pos, sizeof(unsigned long long), reinterpret_cast<const char*>(t->d_chan) + offsetof(gsh::TrkChannel, pos), sizeof(gsh::TrkChannel),
-            sizeof(unsigned long long), static_cast<size_t>(t->n_channels), hipMemcpyDeviceToHost, t->stream));
-        GSH_HIP(hipMemcpy2DAsync(t->h_active, sizeof(int32_t), reinterpret_cast<const char*>(t->d_chan) + offsetof(gsh::TrkChannel, active), sizeof(gsh::TrkChannel),
-            sizeof(int32_t), static_cast<size_t>(t->n_channels), hipMemcpyDeviceToHost, t->stream));
+        GSH_HIP(hipMemcpyAsync(t->h_tail, t->d_tail, sizeof(gsh::TrkTail) * t->n_channels, hipMemcpyDeviceToHost, t->stream));
         t->pending_epochs = n_epochs;
         t->pending_records = n_rec > 0;
         return GSH_OK;
@@ -1450,13 +1455,19 @@ extern "C"
         if (records != nullptr && n_rec > 0)
             {
                 if (!t->pending_records) return set_error(GSH_ERR_STATE, "gsh_trk_run_end: records asked for, but the run was begun without them");
-                std::memcpy(records, t->h_records, sizeof(gsh_trk_epoch) * n_rec);
+                for (int ch = 0; ch < t->n_channels; ch++)
+                    {
+                        const int done = std::min(std::max(t->h_tail[ch].done, 0), n_epochs);
+                        gsh_trk_epoch* dst = records + static_cast<size_t>(ch) * n_epochs;
+                        if (done > 0) std::memcpy(dst, t->h_records + static_cast<size_t>(ch) * n_epochs, sizeof(gsh_trk_epoch) * static_cast<size_t>(done));
+                        if (done < n_epochs) std::memset(dst + done, 0, sizeof(gsh_trk_epoch) * static_cast<size_t>(n_epochs - done));  // periods not run: zero records
+                    }
             }
-        if (epochs_done != nullptr) std::memcpy(epochs_done, t->h_done, sizeof(int32_t) * t->n_channels);
         for (int ch = 0; ch < t->n_channels; ch++)
             {
-                t->h_chan[ch].pos = t->h_pos[ch];
-                t->h_chan[ch].active = t->h_active[ch];
+                if (epochs_done != nullptr) epochs_done[ch] = t->h_tail[ch].done;
+                t->h_chan[ch].pos = t->h_tail[ch].pos;
+                t->h_chan[ch].active = t->h_tail[ch].active;
             }
         return GSH_OK;
     }

@@ -100,8 +100,11 @@ uint64_t Hip_Sample_Ring::push_items(const void* items, uint64_t n, int item_typ
 }
 
 
-bool Hip_Sample_Ring::push_from(uint64_t first_index, const std::complex<float>* samples, uint64_t n, bool may_seek, std::chrono::milliseconds gap_timeout)
+bool Hip_Sample_Ring::push_from(uint64_t first_index, const std::complex<float>* samples, uint64_t n, bool may_seek, std::chrono::milliseconds gap_timeout,
+    uint64_t* appended, uint64_t* append_ns)
 {
+    if (appended != nullptr) *appended = 0;
+    if (append_ns != nullptr) *append_ns = 0;
     if (d_handle == nullptr) return false;
     if (n == 0) return true;
     {
@@ -166,8 +169,11 @@ bool Hip_Sample_Ring::push_from(uint64_t first_index, const std::complex<float>*
                     if (!pinned) d_auto_register = false;  // memory that cannot be registered: stop trying, use the staging copy
                 }
         }
+        const auto t0 = std::chrono::steady_clock::now();
         const int rc_push = pinned ? gsh_stream_push_pinned(d_handle, samples + from, count, GSH_ITEM_GR_COMPLEX, 0, &first)
                                    : gsh_stream_push_staged(d_handle, samples + from, count, GSH_ITEM_GR_COMPLEX, 0, &first);
+        if (appended != nullptr) *appended = count;
+        if (append_ns != nullptr) *append_ns = static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count());
         if (rc_push != GSH_OK)
             {
                 d_error = gsh_last_error();

@@ -59,7 +59,7 @@ public:
         what is resident, and otherwise waits up to `gap_timeout` for the siblings to close the gap (0: does not wait and pushes nothing --
         the siblings' own pushes will cover the stretch).  Returns false on a gap that stays open or on an engine error (last_error()). */
     bool push_from(uint64_t first_index, const std::complex<float>* samples, uint64_t n, bool may_seek,
-        std::chrono::milliseconds gap_timeout = std::chrono::milliseconds(200));
+        std::chrono::milliseconds gap_timeout = std::chrono::milliseconds(200), uint64_t* appended = nullptr, uint64_t* append_ns = nullptr);
     /*! Page-lock [ptr, ptr + bytes) (rounded outwards to pages; parts already locked are skipped) so that push_from can hand it to the DMA
         engine without a staging copy.  A GNU Radio input buffer is the same memory for the whole run: after the first few calls every push is
         a true DMA.  false (and push_from falls back to the staging copy) when the range cannot be registered. */

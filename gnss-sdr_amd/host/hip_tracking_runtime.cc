@@ -201,14 +201,12 @@ bool Hip_Tracking_Runtime::push(const std::complex<float>* samples, uint64_t fir
         }
     // a ring whose resident samples nobody is going to read may jump to the position of a caller that needs its own samples there
     const bool may_seek = need_resident && ((lowest == UINT64_MAX) || (lowest >= first_index));
-    const uint64_t before = d_ring->next_index();
-    const auto t0 = std::chrono::steady_clock::now();
-    const bool ok_push = d_ring->push_from(first_index, samples, n, may_seek, std::chrono::milliseconds(need_resident ? 200 : 0));
-    const uint64_t after = d_ring->next_index();
-    if (after > before && first_index + n >= after)  // this call appended (the counters are approximate under contention: another pusher may be in between)
+    uint64_t appended = 0, append_ns = 0;
+    const bool ok_push = d_ring->push_from(first_index, samples, n, may_seek, std::chrono::milliseconds(need_resident ? 200 : 0), &appended, &append_ns);
+    if (appended != 0)
         {
-            d_push_ns.fetch_add(static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count()), std::memory_order_relaxed);
-            d_pushed_samples.fetch_add(after - before, std::memory_order_relaxed);
+            d_push_ns.fetch_add(append_ns, std::memory_order_relaxed);
+            d_pushed_samples.fetch_add(appended, std::memory_order_relaxed);
         }
     if (!ok_push)
         {

@@ -48,18 +48,19 @@ def test_dropin_throughput_32_channels_one_stream(gpu):
     """BASELINE config 2's shape through the drop-in seam: 32 dll_pll_veml_tracking_hip blocks, one thread each, one 25 Msps stream, one
     Hip_Tracking_Runtime; every block's window positions equal the reference block's.  Prints channel-periods/s (bench.py's `dropin` leg)."""
     import json
-    r = subprocess.run([_bin(), "bench", "32", "25000000", "160", "10"], capture_output=True, text=True, timeout=900, cwd="/tmp")
+    r = subprocess.run([_bin(), "bench", "32", "25000000", "800", "20"], capture_output=True, text=True, timeout=900, cwd="/tmp")
     line = [l for l in r.stdout.splitlines() if l.startswith("DROPIN_JSON")]
     assert r.returncode == 0 and line, r.stdout[-4000:] + r.stderr[-2000:]
     d = json.loads(line[-1][len("DROPIN_JSON"):])
     print(d)
     assert d["windows_identical_to_reference_blocks"] and d["failures"] == 0
     assert d["channels_per_launch"] >= 8.0, d     # the launches are shared ones
-    assert d["channel_periods_per_s"] >= 2.0e5, d  # far above one launch per channel and period; the target sits in bench.py / DESIGN.md
+    assert d["channel_periods_per_s"] >= 3.0e5, d  # far above one launch per channel and period; the measured figure sits in bench.py's `dropin` / DESIGN.md
 
 
 @pytest.mark.gpu
 def test_tracking_adapters_follow_the_reference_block(gpu):
     r = subprocess.run([_bin()], capture_output=True, text=True, timeout=900, cwd="/tmp")
-    print(r.stdout[-3000:])
+    keep = ("FAIL", "periods", "shared stream", "dump", "restart", "noise only", "OK", "failure")
+    print("\n".join(l for l in r.stdout.splitlines() if any(k in l for k in keep))[-6000:])
     assert r.returncode == 0 and "TRACKING ADAPTERS OK" in r.stdout, r.stdout[-6000:] + r.stderr[-2000:]
