@@ -157,6 +157,8 @@ SYMBOLS = {
     "gsh_stream_wait": (C.c_int, [_P]),
     "gsh_stream_push_staged": (C.c_int, [_P, _P, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64)]),
     "gsh_stream_push_pinned": (C.c_int, [_P, _P, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64)]),
+    "gsh_stream_push_pinned_async": (C.c_int, [_P, _P, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64)]),
+    "gsh_stream_wait_copied": (C.c_int, [_P]),
     "gsh_host_register": (C.c_int, [C.c_int, _P, C.c_size_t]),
     "gsh_host_unregister": (C.c_int, [_P]),
     "gsh_stream_seek": (C.c_int, [_P, C.c_uint64]),

@@ -309,9 +309,24 @@ extern "C"
         return GSH_OK;
     }
 
+    int gsh_stream_wait_copied(gsh_stream_t* s)
+    {
+        GSH_REQUIRE(s != nullptr, "null stream");
+        if (s->copied == nullptr) return GSH_OK;  // nothing has been queued through the pinned path yet
+        GSH_HIP(hipEventSynchronize(s->copied));  // (no hipSetDevice: an event knows its device)
+        return GSH_OK;
+    }
+
     int gsh_stream_push_pinned(gsh_stream_t* s, const void* items, uint64_t n, int item_type, int inverted_spectrum, uint64_t* first_index)
     {
-        // page-locked items -> device staging (DMA straight out of the caller's memory) -> conversion into the ring; the host waits for the DMA only
+        int rc = gsh_stream_push_pinned_async(s, items, n, item_type, inverted_spectrum, first_index);
+        if (rc != GSH_OK || n == 0) return rc;
+        return gsh_stream_wait_copied(s);  // `items` is free again; the conversion and the readers' waits stay asynchronous
+    }
+
+    int gsh_stream_push_pinned_async(gsh_stream_t* s, const void* items, uint64_t n, int item_type, int inverted_spectrum, uint64_t* first_index)
+    {
+        // page-locked items -> device staging (DMA straight out of the caller's memory) -> conversion into the ring; nothing waits here
         GSH_REQUIRE(s != nullptr, "null stream");
         GSH_REQUIRE(n == 0 || items != nullptr, "null items");
         const size_t isz = gsh::item_bytes(item_type);
@@ -348,7 +363,6 @@ extern "C"
         rc = record_push(s, s->next + n, s->stream);
         if (rc != GSH_OK) return rc;
         s->next += n;
-        GSH_HIP(hipEventSynchronize(s->copied));  // `items` is free again; the conversion and the readers' waits stay asynchronous
         return GSH_OK;
     }
 

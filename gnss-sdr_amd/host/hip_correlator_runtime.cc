@@ -26,15 +26,16 @@ Hip_Sample_Ring::~Hip_Sample_Ring()
 }
 
 
-bool Hip_Sample_Ring::covered_locked(uintptr_t a, uintptr_t b) const
+// end of the registered piece that holds address `at`, 0 when none does.  A DMA must lie inside ONE registration, so pieces are never merged.
+uintptr_t Hip_Sample_Ring::piece_end_locked(uintptr_t at) const
 {
     for (const auto& r : d_pinned)
-        if (r.first <= a && b <= r.second) return true;
-    return false;
+        if (r.first <= at && at < r.second) return r.second;
+    return 0;
 }
 
 
-// page-lock what is missing of [a, b) (page aligned); d_mutex held
+// page-lock [a, b) (page aligned) minus what other pieces already hold; d_mutex held.  One registration per gap.
 bool Hip_Sample_Ring::register_locked(uintptr_t a, uintptr_t b)
 {
     std::vector<std::pair<uintptr_t, uintptr_t>> missing;
@@ -56,17 +57,8 @@ bool Hip_Sample_Ring::register_locked(uintptr_t a, uintptr_t b)
                 }
             d_registered.push_back(reinterpret_cast<void*>(m.first));
             d_pinned.emplace_back(m.first, m.second);
+            std::sort(d_pinned.begin(), d_pinned.end());
         }
-    std::sort(d_pinned.begin(), d_pinned.end());
-    std::vector<std::pair<uintptr_t, uintptr_t>> merged;
-    for (const auto& r : d_pinned)
-        {
-            if (!merged.empty() && r.first <= merged.back().second)
-                merged.back().second = std::max(merged.back().second, r.second);
-            else
-                merged.push_back(r);
-        }
-    d_pinned.swap(merged);
     return true;
 }
 
@@ -78,7 +70,7 @@ bool Hip_Sample_Ring::register_host(const void* ptr, size_t bytes)
     const uintptr_t a = reinterpret_cast<uintptr_t>(ptr) & ~(PAGE - 1);
     const uintptr_t b = (reinterpret_cast<uintptr_t>(ptr) + bytes + PAGE - 1) & ~(PAGE - 1);
     std::lock_guard<std::mutex> lk(d_mutex);
-    return covered_locked(a, b) || register_locked(a, b);
+    return register_locked(a, b);
 }
 
 
@@ -107,6 +99,8 @@ bool Hip_Sample_Ring::push_from(uint64_t first_index, const std::complex<float>*
     if (append_ns != nullptr) *append_ns = 0;
     if (d_handle == nullptr) return false;
     if (n == 0) return true;
+    bool dma_queued = false;
+    const auto t_begin = std::chrono::steady_clock::now();
     {
         std::unique_lock<std::mutex> lk(d_mutex);
         uint64_t oldest = 0, next = 0;
@@ -155,34 +149,74 @@ bool Hip_Sample_Ring::push_from(uint64_t first_index, const std::complex<float>*
                 d_origin.store(first_index + from, std::memory_order_release);
                 count = d_capacity;
             }
-        uint64_t first = 0;
-        // page-locked input (registered by the caller, or here when auto-registration is on) goes to the DMA engine as it lies; anything
-        // else through the ring's page-locked staging buffers
-        bool pinned = false;
-        {
-            const uintptr_t a = reinterpret_cast<uintptr_t>(samples + from), b = a + static_cast<uintptr_t>(count) * sizeof(std::complex<float>);
-            pinned = covered_locked(a, b);
-            if (!pinned && d_auto_register)
-                {
-                    constexpr uintptr_t PAGE = 4096;
-                    pinned = register_locked(a & ~(PAGE - 1), (b + PAGE - 1) & ~(PAGE - 1));
-                    if (!pinned) d_auto_register = false;  // memory that cannot be registered: stop trying, use the staging copy
-                }
-        }
-        const auto t0 = std::chrono::steady_clock::now();
-        const int rc_push = pinned ? gsh_stream_push_pinned(d_handle, samples + from, count, GSH_ITEM_GR_COMPLEX, 0, &first)
-                                   : gsh_stream_push_staged(d_handle, samples + from, count, GSH_ITEM_GR_COMPLEX, 0, &first);
-        if (appended != nullptr) *appended = count;
-        if (append_ns != nullptr) *append_ns = static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count());
+        // Page-locked input (registered by the caller, or here when auto-registration is on) goes to the DMA engine as it lies, one push per
+        // registered piece it spans; anything else through the ring's page-locked staging buffers.
+        int rc_push = GSH_OK;
+        uint64_t done_items = 0, first = 0, first_piece = 0;
+        while (done_items < count && rc_push == GSH_OK)
+            {
+                const std::complex<float>* cur = samples + from + done_items;
+                const uintptr_t at = reinterpret_cast<uintptr_t>(cur);
+                const uint64_t left = count - done_items;
+                uintptr_t end = piece_end_locked(at);
+                if (end == 0 && d_auto_register)
+                    {
+                        // a new stretch of the caller's buffer: lock a generous look-ahead (the scheduler's buffer is one mapping, the next calls show
+                        // the addresses right behind), and only what this call shows when that reaches past the mapping
+                        constexpr uintptr_t PAGE = 4096, AHEAD = 4u << 20;
+                        const uintptr_t lo = at & ~(PAGE - 1), need_hi = (at + left * sizeof(std::complex<float>) + PAGE - 1) & ~(PAGE - 1);
+                        uintptr_t cap_hi = lo + AHEAD;
+                        for (const auto& r : d_pinned)
+                            if (r.first > at) cap_hi = std::min(cap_hi, r.first);  // up to the next piece
+                        if (!(cap_hi > need_hi && register_locked(lo, cap_hi)) && !register_locked(lo, std::min(need_hi, std::max(cap_hi, lo + PAGE))))
+                            d_auto_register = false;  // memory that cannot be registered: stop trying, use the staging copy
+                        end = piece_end_locked(at);
+                    }
+                uint64_t chunk = left;
+                if (end != 0)
+                    {
+                        chunk = std::min<uint64_t>(left, (end - at) / sizeof(std::complex<float>));
+                        if (chunk == 0) end = 0;  // a sample straddles the piece's last bytes: copy it through staging with the rest
+                    }
+                if (end != 0)
+                    {
+                        // queued only: the wait for the DMA happens below, with the ring's lock released
+                        rc_push = gsh_stream_push_pinned_async(d_handle, cur, chunk, GSH_ITEM_GR_COMPLEX, 0, &first_piece);
+                        dma_queued = dma_queued || rc_push == GSH_OK;
+                    }
+                else
+                    {
+                        // not page-locked: up to the next registered piece (or everything) through staging
+                        chunk = left;
+                        for (const auto& r : d_pinned)
+                            if (r.first > at) { chunk = std::min<uint64_t>(chunk, (r.first - at + sizeof(std::complex<float>) - 1) / sizeof(std::complex<float>)); break; }
+                        rc_push = gsh_stream_push_staged(d_handle, cur, chunk, GSH_ITEM_GR_COMPLEX, 0, &first_piece);
+                    }
+                if (done_items == 0) first = first_piece;
+                if (rc_push == GSH_OK) done_items += chunk;
+            }
+        if (appended != nullptr) *appended = done_items;
+        if (done_items > 0) d_next.store(first + done_items, std::memory_order_release);
         if (rc_push != GSH_OK)
             {
                 d_error = gsh_last_error();
+                d_pushed.notify_all();
+                if (dma_queued) (void)gsh_stream_wait_copied(d_handle);
                 return false;
             }
-        d_next.store(first + count, std::memory_order_release);
     }
     d_pushed.notify_all();
-    return true;
+    // The caller gets its buffer back when the DMA engine has read it.  The ring's lock is free meanwhile: a launch that reads the ring can be
+    // queued (it waits for the push on the device, not here) and the siblings' index comparisons go through.
+    bool ok_wait = true;
+    if (dma_queued && gsh_stream_wait_copied(d_handle) != GSH_OK)
+        {
+            std::lock_guard<std::mutex> lk(d_mutex);
+            d_error = gsh_last_error();
+            ok_wait = false;
+        }
+    if (append_ns != nullptr) *append_ns = static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_begin).count());
+    return ok_wait;
 }
 
 

@@ -100,8 +100,8 @@ private:
     mutable std::condition_variable d_pushed;
     std::atomic<uint64_t> d_next{0};  // read without the lock on the fast path of wait_for (32 channel threads ask at the same instant)
     std::atomic<uint64_t> d_origin{0};  // first index resident since the last seek
-    // page-locked host ranges (sorted, disjoint, merged) and the pieces that were registered to cover them (what the destructor releases)
-    bool covered_locked(uintptr_t a, uintptr_t b) const;
+    // page-locked host ranges: one entry per registration, sorted and disjoint (a DMA must lie inside ONE registration), and what the destructor releases
+    uintptr_t piece_end_locked(uintptr_t at) const;
     bool register_locked(uintptr_t a, uintptr_t b);
     std::vector<std::pair<uintptr_t, uintptr_t>> d_pinned;
     std::vector<void*> d_registered;

@@ -187,6 +187,12 @@ extern "C"
      * stays queued), so `items` may be re-used on return.  This is the path for a GNU Radio input buffer: the scheduler re-uses the same buffer
      * for the whole run, so registering it once makes every later push a true DMA. */
     int gsh_stream_push_pinned(gsh_stream_t* s, const void* items, uint64_t n, int item_type, int inverted_spectrum, uint64_t* first_index);
+    /* the same in two halves: _async queues the DMA and the conversion and returns at once; gsh_stream_wait_copied blocks until every DMA queued
+     * so far has read its source (`items` of every earlier _async call may be re-used then).  wait_copied touches none of the ring's bookkeeping and
+     * may be called WITHOUT the serialisation the other entry points need -- a caller that guards the ring with a lock queues under the lock and
+     * waits outside it, so that launches which read the ring are queued while the DMA runs. */
+    int gsh_stream_push_pinned_async(gsh_stream_t* s, const void* items, uint64_t n, int item_type, int inverted_spectrum, uint64_t* first_index);
+    int gsh_stream_wait_copied(gsh_stream_t* s);
     /* page-lock / release a range of host memory for DMA (hipHostRegister / hipHostUnregister behind the ABI: host code above it has no HIP headers).
      * The range must be mapped; registering pages twice fails with GSH_ERR_HIP. */
     int gsh_host_register(int device, void* ptr, size_t bytes);

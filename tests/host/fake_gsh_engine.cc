@@ -139,6 +139,8 @@ extern "C"
     int gsh_stream_push(gsh_stream_t* s, const void* items, uint64_t n, int item_type, int, uint64_t* first_index) { return push_common(s, items, n, item_type, first_index); }
     int gsh_stream_push_staged(gsh_stream_t* s, const void* items, uint64_t n, int item_type, int, uint64_t* first_index) { return push_common(s, items, n, item_type, first_index); }
     int gsh_stream_push_pinned(gsh_stream_t* s, const void* items, uint64_t n, int item_type, int, uint64_t* first_index) { return push_common(s, items, n, item_type, first_index); }
+    int gsh_stream_push_pinned_async(gsh_stream_t* s, const void* items, uint64_t n, int item_type, int, uint64_t* first_index) { return push_common(s, items, n, item_type, first_index); }
+    int gsh_stream_wait_copied(gsh_stream_t*) { return GSH_OK; }
     int gsh_host_register(int, void*, size_t) { return GSH_OK; }
     int gsh_host_unregister(void*) { return GSH_OK; }
     int gsh_stream_seek(gsh_stream_t* s, uint64_t next_index)
