@@ -458,14 +458,36 @@ struct Plan
     //   S2 - R1 is a multiple of 32.
     static constexpr int P2 = R1 | 1;
     static constexpr int S2 = round_up_congruent(R3 * P2, R1, 32);
+#if defined(GSH_OC_EX32)
     static constexpr int LDS_FLOATS = (R1 * S1 > R2 * S2) ? R1 * S1 : R2 * S2;
-
+#else
+    // ---- 64-bit phased exchanges (round 3).  A re-distribution moves whole complex values (ds_write_b64 / ds_read_b64: half the LDS instructions of
+    // the component-at-a-time form, and a value lands in its register pair as it is), a few ROWS at a time: a reader needs one row only (k1 in
+    // exchange 1, k2 in exchange 2), so the rows are cut into NP phases of RP rows, two LDS regions take the phases alternately, and a step
+    // is "read phase p - 1, write phase p" between two barriers -- NP barriers per exchange, the reads of one phase overlap the writes of the
+    // next, and exchange 2 starts in the region exchange 1 did not end in, so no barrier separates the two exchanges either.
+    // N = 25 000: NP = 3 (9 + 9 + 7 rows), 2 x 73 KB of LDS, 6 barriers per transform (was 8 with 4 x 100 KB passes); N <= 9 000: NP = 1, 2 barriers.
+    static constexpr int LDS_BUDGET_BYTES = 160000;  // of the CU's 163 840: the kernels keep ~200 bytes of reduction scratch next to it
+    static constexpr int phases_for(int rows, int row_elems)
+    {
+        int np = 1;
+        while (2 * ((rows + np - 1) / np) * row_elems * 8 > LDS_BUDGET_BYTES) np++;
+        return np;
+    }
+    static constexpr int NP1 = phases_for(R1, S1), RP1 = (R1 + NP1 - 1) / NP1;
+    static constexpr int NP2 = phases_for(R2, S2), RP2 = (R2 + NP2 - 1) / NP2;
+    static constexpr int REGION = (RP1 * S1 > RP2 * S2) ? RP1 * S1 : RP2 * S2;  // complex elements per region
+    static constexpr int LDS_CF = 2 * REGION;
+    static constexpr int LDS_FLOATS = 2 * LDS_CF;
+    static constexpr int START1 = 0, START2 = NP1 % 2;  // region of phase 0; exchange 2 starts where exchange 1 did NOT end
+#endif
     // ---- stage 1: a[n1] = x[n1*T1 + t1]
     static GSH_HD void stage1(cf (&a)[R1], int t1)
     {
         Dft<R1>::run(a);
         mul_powers<R1>(a, unit_root(t1, N));
     }
+#if defined(GSH_OC_EX32)
     template <int COMP>
     static GSH_HD void ex1_write(const cf (&a)[R1], int t1, float* lds)
     {
@@ -478,6 +500,26 @@ struct Plan
         gsh_lds_rd_ptr p = GSH_LDS_RD_PTR(lds + k1 * S1 + n3);
         static_for<R2>([&](auto N2) GSH_AI { b[decltype(N2)::value][COMP] = p[decltype(N2)::value * R3]; });
     }
+#else
+    // phase PH of exchange 1: rows k1 in [PH * RP1, (PH + 1) * RP1), complex address (k1 - PH * RP1) * S1 + n2 * R3 + n3 inside the phase's region
+    template <int PH>
+    static GSH_HD void ex1_write(const cf (&a)[R1], int t1, cf* lds)
+    {
+        cf* reg = lds + ((PH + START1) % 2) * REGION + t1;
+        static_for<R1>([&](auto K1) GSH_AI {
+            constexpr int k1 = decltype(K1)::value;
+            if constexpr (k1 / RP1 == PH) reg[(k1 - PH * RP1) * S1] = a[k1];
+        });
+    }
+    template <int PH>
+    static GSH_HD void ex1_read(cf (&b)[R2], int t2, const cf* lds)
+    {
+        const int k1 = t2 / R3, n3 = t2 - k1 * R3;
+        if (k1 / RP1 != PH) return;  // this thread's row travels in another phase
+        const cf* p = lds + ((PH + START1) % 2) * REGION + (k1 - PH * RP1) * S1 + n3;
+        static_for<R2>([&](auto N2) GSH_AI { b[decltype(N2)::value] = p[decltype(N2)::value * R3]; });
+    }
+#endif
     // ---- stage 2
     static GSH_HD void stage2(cf (&b)[R2], int t2)
     {
@@ -485,6 +527,7 @@ struct Plan
         Dft<R2>::run(b);
         mul_powers<R2>(b, unit_root(n3, R2 * R3));
     }
+#if defined(GSH_OC_EX32)
     template <int COMP>
     static GSH_HD void ex2_write(const cf (&b)[R2], int t2, float* lds)
     {
@@ -499,6 +542,27 @@ struct Plan
         gsh_lds_rd_ptr p = GSH_LDS_RD_PTR(lds + k2 * S2 + k1);
         static_for<R3>([&](auto N3) GSH_AI { c[decltype(N3)::value][COMP] = p[decltype(N3)::value * P2]; });
     }
+#else
+    // phase PH of exchange 2: rows k2 in [PH * RP2, (PH + 1) * RP2), complex address (k2 - PH * RP2) * S2 + n3 * P2 + k1
+    template <int PH>
+    static GSH_HD void ex2_write(const cf (&b)[R2], int t2, cf* lds)
+    {
+        const int k1 = t2 / R3, n3 = t2 - k1 * R3;
+        cf* reg = lds + ((PH + START2) % 2) * REGION + n3 * P2 + k1;
+        static_for<R2>([&](auto K2) GSH_AI {
+            constexpr int k2 = decltype(K2)::value;
+            if constexpr (k2 / RP2 == PH) reg[(k2 - PH * RP2) * S2] = b[k2];
+        });
+    }
+    template <int PH>
+    static GSH_HD void ex2_read(cf (&c)[R3], int t3, const cf* lds)
+    {
+        const int k2 = t3 / R1, k1 = t3 - k2 * R1;
+        if (k2 / RP2 != PH) return;
+        const cf* p = lds + ((PH + START2) % 2) * REGION + (k2 - PH * RP2) * S2 + k1;
+        static_for<R3>([&](auto N3) GSH_AI { c[decltype(N3)::value] = p[decltype(N3)::value * P2]; });
+    }
+#endif
     // ---- stage 3: c[k3] -> X[t3 + T3*k3]
     static GSH_HD void stage3(cf (&c)[R3]) { Dft<R3>::run(c); }
 };

@@ -77,7 +77,9 @@ __device__ __forceinline__ cf wipe_phasor(float f_hz, int n, double inv_fs)
     return cf{c, -s};
 }
 
+#if defined(GSH_OC_EX32)
 // ---- the two LDS re-distributions, one float component at a time (N * 8 bytes do not fit, N * 4 do)
+typedef float oc_lds_t;
 template <class P>
 __device__ __forceinline__ void exchange1(const cf (&ra)[P::R1], cf (&rb)[P::R2], int t, float* lds)
 {
@@ -102,12 +104,46 @@ __device__ __forceinline__ void exchange2(const cf (&rb)[P::R2], cf (&rc)[P::R3]
     __syncthreads();
     if (t < P::T3) P::template ex2_read<1>(rc, t, lds);
 }
+#define GSH_OC_LDS_DECL(P) __shared__ __align__(16) float lds[P::LDS_FLOATS]
+#else
+// ---- the two LDS re-distributions: whole complex values, a few rows per phase, two regions in turn (fft_onchip.h).  Step p = "read phase
+// p - 1, write phase p", one barrier per step: the reads of a phase are in flight while the next phase is written.
+typedef cf oc_lds_t;
+template <class P>
+__device__ __forceinline__ void exchange1(const cf (&ra)[P::R1], cf (&rb)[P::R2], int t, cf* lds)
+{
+    oc::static_for<P::NP1>([&](auto PH) GSH_AI {
+        constexpr int p = decltype(PH)::value;
+        if constexpr (p > 0)
+            if (t < P::T2) P::template ex1_read<(p > 0 ? p - 1 : 0)>(rb, t, lds);
+        if (t < P::T1) P::template ex1_write<p>(ra, t, lds);
+        __syncthreads();
+    });
+    if (t < P::T2) P::template ex1_read<P::NP1 - 1>(rb, t, lds);
+}
+
+template <class P>
+__device__ __forceinline__ void exchange2(const cf (&rb)[P::R2], cf (&rc)[P::R3], int t, cf* lds)
+{
+    // (no barrier in front: phase 0 goes to the region exchange 1 did not end in, and whatever was read from it was read before exchange 1's
+    // last barrier)
+    oc::static_for<P::NP2>([&](auto PH) GSH_AI {
+        constexpr int p = decltype(PH)::value;
+        if constexpr (p > 0)
+            if (t < P::T3) P::template ex2_read<(p > 0 ? p - 1 : 0)>(rc, t, lds);
+        if (t < P::T2) P::template ex2_write<p>(rb, t, lds);
+        __syncthreads();
+    });
+    if (t < P::T3) P::template ex2_read<P::NP2 - 1>(rc, t, lds);
+}
+#define GSH_OC_LDS_DECL(P) __shared__ __align__(16) cf lds[P::LDS_CF]
+#endif
 
 // ------------------------------------------------------------------------------------------------------------
 template <class P>
 __global__ __launch_bounds__(P::THREADS) void oc_forward_kernel(OcFwdArgs a)
 {
-    __shared__ __align__(16) float lds[P::LDS_FLOATS];
+    GSH_OC_LDS_DECL(P);
     const int t = threadIdx.x;
     const int b = blockIdx.x;
     cf ra[P::R1], rb[P::R2], rc[P::R3];
@@ -172,7 +208,7 @@ __device__ __forceinline__ cf radix_root(int qr, int s)
 template <class P, int S>
 __global__ __launch_bounds__(P::THREADS) void oc_forward_split_kernel(OcFwdArgs a)
 {
-    __shared__ __align__(16) float lds[P::LDS_FLOATS];
+    GSH_OC_LDS_DECL(P);
     constexpr int M = P::N, N = S * P::N;
     const int t = threadIdx.x;
     const int b = static_cast<int>(blockIdx.x) / S, r = static_cast<int>(blockIdx.x) - b * S;
@@ -248,7 +284,7 @@ __global__ __launch_bounds__(P::THREADS) void oc_cell_kernel(OcCellArgs a)
     static_assert(S == 1 || !SECOND, "the second peak of a row needs the whole row in one work-group");
     static_assert(GRID || !OFF, "the upper-half searches are instantiated on the GRID flavour only");
     constexpr int M = P::N, N = S * P::N;
-    __shared__ __align__(16) float lds[P::LDS_FLOATS];
+    GSH_OC_LDS_DECL(P);
     __shared__ float s_v[OC_MAX_WAVES];
     __shared__ unsigned s_i[OC_MAX_WAVES];
     __shared__ float s_s[OC_MAX_WAVES];

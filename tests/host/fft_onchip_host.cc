@@ -18,7 +18,11 @@ void run_plan(const float* in_iq, float* out_iq)
     std::vector<A> a(P::T1);
     std::vector<B> b(P::T2);
     std::vector<C> c(P::T3);
+#if defined(GSH_OC_EX32)
     std::vector<float> lds(P::LDS_FLOATS, 0.0f);
+#else
+    std::vector<cf> lds(P::LDS_CF, cf{0.0f, 0.0f});
+#endif
     for (int t = 0; t < P::T1; t++)
         {
             for (int n1 = 0; n1 < P::R1; n1++)
@@ -28,6 +32,7 @@ void run_plan(const float* in_iq, float* out_iq)
                 }
             P::stage1(a[t].v, t);
         }
+#if defined(GSH_OC_EX32)
     for (int t = 0; t < P::T1; t++) P::template ex1_write<0>(a[t].v, t, lds.data());
     for (int t = 0; t < P::T2; t++) P::template ex1_read<0>(b[t].v, t, lds.data());
     for (int t = 0; t < P::T1; t++) P::template ex1_write<1>(a[t].v, t, lds.data());
@@ -37,6 +42,30 @@ void run_plan(const float* in_iq, float* out_iq)
     for (int t = 0; t < P::T3; t++) P::template ex2_read<0>(c[t].v, t, lds.data());
     for (int t = 0; t < P::T2; t++) P::template ex2_write<1>(b[t].v, t, lds.data());
     for (int t = 0; t < P::T3; t++) P::template ex2_read<1>(c[t].v, t, lds.data());
+#else
+    // the kernels' step order (pcps_onchip.hip exchange1 / exchange2): "read phase p - 1, write phase p", barrier; the reads of the last phase
+    // of exchange 1 and the first write of exchange 2 share a step, as on the device (no barrier between the two exchanges).  Readers are run
+    // BEFORE the writers of the same step here, so that a write into a region that is still being read would corrupt the result.
+    gsh::oc::static_for<P::NP1>([&](auto PH) {
+        constexpr int p = decltype(PH)::value;
+        if constexpr (p > 0)
+            for (int t = 0; t < P::T2; t++) P::template ex1_read<(p > 0 ? p - 1 : 0)>(b[t].v, t, lds.data());
+        for (int t = 0; t < P::T1; t++) P::template ex1_write<p>(a[t].v, t, lds.data());
+    });
+    // stage 2 needs exchange 1's last phase; exchange 2's phase 0 is written in the same step as that read on the device: emulate the worst
+    // order by writing phase 0 of a scratch copy first is not possible before stage 2 has run -- the device has the same dependency (a thread
+    // writes its stage-2 results after ITS reads), so the order here is read, stage 2, write, with the region check below
+    for (int t = 0; t < P::T2; t++) P::template ex1_read<P::NP1 - 1>(b[t].v, t, lds.data());
+    static_assert(((P::NP1 - 1 + P::START1) % 2) != (P::START2 % 2), "exchange 2 must start in the region exchange 1 does not end in");
+    for (int t = 0; t < P::T2; t++) P::stage2(b[t].v, t);
+    gsh::oc::static_for<P::NP2>([&](auto PH) {
+        constexpr int p = decltype(PH)::value;
+        if constexpr (p > 0)
+            for (int t = 0; t < P::T3; t++) P::template ex2_read<(p > 0 ? p - 1 : 0)>(c[t].v, t, lds.data());
+        for (int t = 0; t < P::T2; t++) P::template ex2_write<p>(b[t].v, t, lds.data());
+    });
+    for (int t = 0; t < P::T3; t++) P::template ex2_read<P::NP2 - 1>(c[t].v, t, lds.data());
+#endif
     for (int t = 0; t < P::T3; t++)
         {
             P::stage3(c[t].v);
