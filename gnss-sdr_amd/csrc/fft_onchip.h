@@ -401,19 +401,46 @@ struct Dft : DftComposite<first_factor(R), R / first_factor(R)>
 template <int R>
 GSH_HD void mul_powers(cf (&a)[R], cf w)
 {
-    cf p[R];
-    static_for<R>([&](auto K) GSH_AI {
-        constexpr int k = decltype(K)::value;
-        if constexpr (k == 1) p[1] = w;
-        if constexpr (k >= 2)
-            {
-                if constexpr (k % 2 == 0)
-                    p[k] = csqr(p[k / 2]);
-                else
-                    p[k] = cmul(p[k - 1], w);
-            }
-        if constexpr (k >= 1) a[k] = cmul(a[k], p[k]);
-    });
+    if constexpr (R >= 32)
+        {
+            // radix 32 and up: the full tree keeps R / 2 powers alive next to the R values (the sub-cell kernels, at the 128-register limit, spilled).
+            // w^k = w^(k % 8) * (w^8)^(k / 8): eight low powers by the tree, the high power stepped block by block (depth 3 + R / 8).
+            cf lo[8];
+            lo[1] = w;
+            lo[2] = csqr(w);
+            lo[3] = cmul(lo[2], w);
+            lo[4] = csqr(lo[2]);
+            lo[5] = cmul(lo[4], w);
+            lo[6] = csqr(lo[3]);
+            lo[7] = cmul(lo[6], w);
+            const cf w8 = csqr(lo[4]);
+            cf hi = w8;
+            static_for<R>([&](auto K) GSH_AI {
+                constexpr int k = decltype(K)::value;
+                if constexpr (k >= 8)
+                    {
+                        if constexpr (k % 8 == 0 && k > 8) hi = cmul(hi, w8);
+                        a[k] = cmul(a[k], hi);
+                    }
+                if constexpr (k % 8 != 0) a[k] = cmul(a[k], lo[k % 8]);
+            });
+        }
+    else
+        {
+            cf p[R];
+            static_for<R>([&](auto K) GSH_AI {
+                constexpr int k = decltype(K)::value;
+                if constexpr (k == 1) p[1] = w;
+                if constexpr (k >= 2)
+                    {
+                        if constexpr (k % 2 == 0)
+                            p[k] = csqr(p[k / 2]);
+                        else
+                            p[k] = cmul(p[k - 1], w);
+                    }
+                if constexpr (k >= 1) a[k] = cmul(a[k], p[k]);
+            });
+        }
 }
 
 // exp(-2 pi i * num / den), 0 <= num < den, den < 2^23
@@ -458,9 +485,9 @@ struct Plan
     //   S2 - R1 is a multiple of 32.
     static constexpr int P2 = R1 | 1;
     static constexpr int S2 = round_up_congruent(R3 * P2, R1, 32);
-#if defined(GSH_OC_EX32)
-    static constexpr int LDS_FLOATS = (R1 * S1 > R2 * S2) ? R1 * S1 : R2 * S2;
-#else
+    // ---- exchanges one float component at a time (rounds 1-2): N * 4 bytes of LDS, four write / read passes, 8 barriers per transform.  Kept for the
+    // plans whose N * 4 bytes leave room for several work-groups per compute unit (see EX64 below).
+    static constexpr int LDS_FLOATS32 = (R1 * S1 > R2 * S2) ? R1 * S1 : R2 * S2;
     // ---- 64-bit phased exchanges (round 3).  A re-distribution moves whole complex values (ds_write_b64 / ds_read_b64: half the LDS instructions of
     // the component-at-a-time form, and a value lands in its register pair as it is), a few ROWS at a time: a reader needs one row only (k1 in
     // exchange 1, k2 in exchange 2), so the rows are cut into NP phases of RP rows, two LDS regions take the phases alternately, and a step
@@ -478,29 +505,41 @@ struct Plan
     static constexpr int NP2 = phases_for(R2, S2), RP2 = (R2 + NP2 - 1) / NP2;
     static constexpr int REGION = (RP1 * S1 > RP2 * S2) ? RP1 * S1 : RP2 * S2;  // complex elements per region
     static constexpr int LDS_CF = 2 * REGION;
-    static constexpr int LDS_FLOATS = 2 * LDS_CF;
     static constexpr int START1 = 0, START2 = NP1 % 2;  // region of phase 0; exchange 2 starts where exchange 1 did NOT end
+    // Which form a plan uses (measured on MI355X, profiles/ab/r03/acq_exchange_ab.txt): the phased form wins where one work-group fills the compute
+    // unit anyway (25 000: +2 %, 4 x 25 000: +6 %); below that the component form's smaller footprint keeps several work-groups resident and is up to
+    // 25 % faster (8 000 points: 43 vs 53 us per batch).  The 16 000-point plan sits in between (+5 % on its own, -28 % as 8 x 16 000 = 128 000
+    // points, where the sub-cells' load loop schedules worse around the larger LDS allocation) and stays with the component form.
+    // The phased form also needs fewer registers (a value leaves its register pair when its row's phase is written: 16 384 points take 101 instead of
+    // 128 and stop spilling), so a plan whose work-group has 1 024 threads -- alone on its compute unit anyway -- uses it too.
+    // GSH_OC_EX32 / GSH_OC_EX64 force one form (A/B builds).
+#if defined(GSH_OC_EX32)
+    static constexpr bool EX64 = false;
+#elif defined(GSH_OC_EX64)
+    static constexpr bool EX64 = true;
+#else
+    static constexpr bool EX64 = LDS_FLOATS32 * 4 > 72 * 1024 || THREADS == 1024;  // (a 1 024-thread work-group is alone on its compute unit whatever its LDS)
 #endif
+    static constexpr int LDS_BYTES = EX64 ? LDS_CF * 8 : LDS_FLOATS32 * 4;
+    static constexpr int LDS_FLOATS = LDS_BYTES / 4;
     // ---- stage 1: a[n1] = x[n1*T1 + t1]
     static GSH_HD void stage1(cf (&a)[R1], int t1)
     {
         Dft<R1>::run(a);
         mul_powers<R1>(a, unit_root(t1, N));
     }
-#if defined(GSH_OC_EX32)
     template <int COMP>
-    static GSH_HD void ex1_write(const cf (&a)[R1], int t1, float* lds)
+    static GSH_HD void ex1_write32(const cf (&a)[R1], int t1, float* lds)
     {
         static_for<R1>([&](auto K1) GSH_AI { lds[decltype(K1)::value * S1 + t1] = a[decltype(K1)::value][COMP]; });
     }
     template <int COMP>
-    static GSH_HD void ex1_read(cf (&b)[R2], int t2, const float* lds)
+    static GSH_HD void ex1_read32(cf (&b)[R2], int t2, const float* lds)
     {
         const int k1 = t2 / R3, n3 = t2 - k1 * R3;
         gsh_lds_rd_ptr p = GSH_LDS_RD_PTR(lds + k1 * S1 + n3);
         static_for<R2>([&](auto N2) GSH_AI { b[decltype(N2)::value][COMP] = p[decltype(N2)::value * R3]; });
     }
-#else
     // phase PH of exchange 1: rows k1 in [PH * RP1, (PH + 1) * RP1), complex address (k1 - PH * RP1) * S1 + n2 * R3 + n3 inside the phase's region
     template <int PH>
     static GSH_HD void ex1_write(const cf (&a)[R1], int t1, cf* lds)
@@ -519,7 +558,6 @@ struct Plan
         const cf* p = lds + ((PH + START1) % 2) * REGION + (k1 - PH * RP1) * S1 + n3;
         static_for<R2>([&](auto N2) GSH_AI { b[decltype(N2)::value] = p[decltype(N2)::value * R3]; });
     }
-#endif
     // ---- stage 2
     static GSH_HD void stage2(cf (&b)[R2], int t2)
     {
@@ -527,22 +565,20 @@ struct Plan
         Dft<R2>::run(b);
         mul_powers<R2>(b, unit_root(n3, R2 * R3));
     }
-#if defined(GSH_OC_EX32)
     template <int COMP>
-    static GSH_HD void ex2_write(const cf (&b)[R2], int t2, float* lds)
+    static GSH_HD void ex2_write32(const cf (&b)[R2], int t2, float* lds)
     {
         const int k1 = t2 / R3, n3 = t2 - k1 * R3;
         float* p = lds + n3 * P2 + k1;
         static_for<R2>([&](auto K2) GSH_AI { p[decltype(K2)::value * S2] = b[decltype(K2)::value][COMP]; });
     }
     template <int COMP>
-    static GSH_HD void ex2_read(cf (&c)[R3], int t3, const float* lds)
+    static GSH_HD void ex2_read32(cf (&c)[R3], int t3, const float* lds)
     {
         const int k2 = t3 / R1, k1 = t3 - k2 * R1;
         gsh_lds_rd_ptr p = GSH_LDS_RD_PTR(lds + k2 * S2 + k1);
         static_for<R3>([&](auto N3) GSH_AI { c[decltype(N3)::value][COMP] = p[decltype(N3)::value * P2]; });
     }
-#else
     // phase PH of exchange 2: rows k2 in [PH * RP2, (PH + 1) * RP2), complex address (k2 - PH * RP2) * S2 + n3 * P2 + k1
     template <int PH>
     static GSH_HD void ex2_write(const cf (&b)[R2], int t2, cf* lds)
@@ -562,7 +598,6 @@ struct Plan
         const cf* p = lds + ((PH + START2) % 2) * REGION + (k2 - PH * RP2) * S2 + k1;
         static_for<R3>([&](auto N3) GSH_AI { c[decltype(N3)::value] = p[decltype(N3)::value * P2]; });
     }
-#endif
     // ---- stage 3: c[k3] -> X[t3 + T3*k3]
     static GSH_HD void stage3(cf (&c)[R3]) { Dft<R3>::run(c); }
 };
@@ -571,6 +606,7 @@ struct Plan
 
 // transform lengths with an on-chip plan: X(R1, R2, R3), N = R1*R2*R3 (N*4 bytes of LDS, <= 1024 threads, <= 40
 // elements per thread).  1 ms (GPS L1 / L5) and 4 ms (Galileo E1) code periods at the usual front-end rates.
+#ifndef GSH_OC_PLANS  /* (a tuning build may name a shorter list on the command line: one plan compiles in seconds) */
 #define GSH_OC_PLANS(X) \
     X(25, 25, 40) /* 25 000: 25 Msps x 1 ms, 6.25 Msps x 4 ms */ \
     X(10, 20, 20) /*  4 000:  4 Msps x 1 ms */ \
@@ -596,8 +632,12 @@ struct Plan
     X(16, 11, 31) /*  5 456: 5.456 Msps x 1 ms */ \
     X(10, 16, 16) /*  2 560: 2.56 Msps x 1 ms */ \
     X(16, 16, 40) /* 10 240: 2.56 Msps x 4 ms */
+#endif
 
 // N = S * M: one radix-S decimation-in-frequency step in front of the plan of M (pcps_onchip.hip); X(S, R1, R2, R3)
+// (no 2 x (32, 32, 32): with 32 running sums per thread next to a radix-2 front step the sub-cell kernels do not fit 128 registers without
+// scratch; 65 536 points -- no front-end rate of the reference's configurations gives it -- take the four-step path)
+#ifndef GSH_OC_SPLIT_PLANS
 #define GSH_OC_SPLIT_PLANS(X) \
     X(2, 25, 25, 40) /*  50 000: 50 Msps x 1 ms; bit-transition search at 25 Msps; 12.5 Msps x 4 ms */ \
     X(4, 25, 25, 40) /* 100 000: 25 Msps x 4 ms (Galileo E1) */ \
@@ -607,7 +647,7 @@ struct Plan
     X(8, 20, 20, 40) /* 128 000: 32 Msps x 4 ms (Galileo E1) */ \
     X(2, 25, 25, 32) /*  40 000: 40 Msps x 1 ms, 10 Msps x 4 ms; bit-transition search at 20 Msps */ \
     X(4, 25, 25, 32) /*  80 000: 4 Msps x 20 ms (GPS L2C), 20 Msps x 4 ms */ \
-    X(2, 32, 32, 32) /*  65 536 */ \
     X(2, 22, 24, 31) /*  32 736: 8.184 Msps x 4 ms (Galileo E1) */
+#endif
 
 #endif

@@ -67,6 +67,15 @@ struct OcCellArgs
     float weight;  // GRID path: every |.|^2 is scaled before it is added / stored (pcps_tong_acquisition_cc.cc:243-249); 1 otherwise
 };
 
+// x[k] for 0 <= k < n_in, else 0 -- as a load from a clamped index plus a select, not a branch around the load: the compiler turns the
+// conditional form into one s_cbranch_execz + s_waitcnt vmcnt(0) per element, i.e. R1 dependent round trips to memory instead of R1 loads in flight
+__device__ __forceinline__ cf load_or_zero(const cf* __restrict__ src, int k, int n_in)
+{
+    const bool ok = static_cast<unsigned>(k) < static_cast<unsigned>(n_in);
+    const cf v = src[ok ? k : 0];
+    return ok ? v : cf{0.0f, 0.0f};
+}
+
 // exp(-j 2 pi f n / fs) with the product reduced in double before the float sincos
 __device__ __forceinline__ cf wipe_phasor(float f_hz, int n, double inv_fs)
 {
@@ -77,67 +86,69 @@ __device__ __forceinline__ cf wipe_phasor(float f_hz, int n, double inv_fs)
     return cf{c, -s};
 }
 
-#if defined(GSH_OC_EX32)
-// ---- the two LDS re-distributions, one float component at a time (N * 8 bytes do not fit, N * 4 do)
-typedef float oc_lds_t;
+// ---- the two LDS re-distributions.  Plan::EX64 picks the form (fft_onchip.h):
+//   component form   one float component at a time (N * 8 bytes do not fit, N * 4 do): write x, read x, write y, read y
+//   phased form      whole complex values, a few rows per phase, two regions in turn; step p = "read phase p - 1, write phase p", one barrier per
+//                    step: the reads of a phase are in flight while the next phase is written, and no barrier separates the two exchanges
 template <class P>
-__device__ __forceinline__ void exchange1(const cf (&ra)[P::R1], cf (&rb)[P::R2], int t, float* lds)
+__device__ __forceinline__ void exchange1(const cf (&ra)[P::R1], cf (&rb)[P::R2], int t, unsigned char* lds_raw)
 {
-    if (t < P::T1) P::template ex1_write<0>(ra, t, lds);
-    __syncthreads();
-    if (t < P::T2) P::template ex1_read<0>(rb, t, lds);
-    __syncthreads();
-    if (t < P::T1) P::template ex1_write<1>(ra, t, lds);
-    __syncthreads();
-    if (t < P::T2) P::template ex1_read<1>(rb, t, lds);
+    if constexpr (P::EX64)
+        {
+            cf* lds = reinterpret_cast<cf*>(lds_raw);
+            oc::static_for<P::NP1>([&](auto PH) GSH_AI {
+                constexpr int p = decltype(PH)::value;
+                if constexpr (p > 0)
+                    if (t < P::T2) P::template ex1_read<(p > 0 ? p - 1 : 0)>(rb, t, lds);
+                if (t < P::T1) P::template ex1_write<p>(ra, t, lds);
+                __syncthreads();
+            });
+            if (t < P::T2) P::template ex1_read<P::NP1 - 1>(rb, t, lds);
+        }
+    else
+        {
+            float* lds = reinterpret_cast<float*>(lds_raw);
+            if (t < P::T1) P::template ex1_write32<0>(ra, t, lds);
+            __syncthreads();
+            if (t < P::T2) P::template ex1_read32<0>(rb, t, lds);
+            __syncthreads();
+            if (t < P::T1) P::template ex1_write32<1>(ra, t, lds);
+            __syncthreads();
+            if (t < P::T2) P::template ex1_read32<1>(rb, t, lds);
+        }
 }
 
 template <class P>
-__device__ __forceinline__ void exchange2(const cf (&rb)[P::R2], cf (&rc)[P::R3], int t, float* lds)
+__device__ __forceinline__ void exchange2(const cf (&rb)[P::R2], cf (&rc)[P::R3], int t, unsigned char* lds_raw)
 {
-    __syncthreads();  // every exchange-1 read has been issued and consumed
-    if (t < P::T2) P::template ex2_write<0>(rb, t, lds);
-    __syncthreads();
-    if (t < P::T3) P::template ex2_read<0>(rc, t, lds);
-    __syncthreads();
-    if (t < P::T2) P::template ex2_write<1>(rb, t, lds);
-    __syncthreads();
-    if (t < P::T3) P::template ex2_read<1>(rc, t, lds);
+    if constexpr (P::EX64)
+        {
+            // (no barrier in front: phase 0 goes to the region exchange 1 did not end in, and whatever was read from it was read before
+            // exchange 1's last barrier)
+            cf* lds = reinterpret_cast<cf*>(lds_raw);
+            oc::static_for<P::NP2>([&](auto PH) GSH_AI {
+                constexpr int p = decltype(PH)::value;
+                if constexpr (p > 0)
+                    if (t < P::T3) P::template ex2_read<(p > 0 ? p - 1 : 0)>(rc, t, lds);
+                if (t < P::T2) P::template ex2_write<p>(rb, t, lds);
+                __syncthreads();
+            });
+            if (t < P::T3) P::template ex2_read<P::NP2 - 1>(rc, t, lds);
+        }
+    else
+        {
+            float* lds = reinterpret_cast<float*>(lds_raw);
+            __syncthreads();  // every exchange-1 read has been issued and consumed
+            if (t < P::T2) P::template ex2_write32<0>(rb, t, lds);
+            __syncthreads();
+            if (t < P::T3) P::template ex2_read32<0>(rc, t, lds);
+            __syncthreads();
+            if (t < P::T2) P::template ex2_write32<1>(rb, t, lds);
+            __syncthreads();
+            if (t < P::T3) P::template ex2_read32<1>(rc, t, lds);
+        }
 }
-#define GSH_OC_LDS_DECL(P) __shared__ __align__(16) float lds[P::LDS_FLOATS]
-#else
-// ---- the two LDS re-distributions: whole complex values, a few rows per phase, two regions in turn (fft_onchip.h).  Step p = "read phase
-// p - 1, write phase p", one barrier per step: the reads of a phase are in flight while the next phase is written.
-typedef cf oc_lds_t;
-template <class P>
-__device__ __forceinline__ void exchange1(const cf (&ra)[P::R1], cf (&rb)[P::R2], int t, cf* lds)
-{
-    oc::static_for<P::NP1>([&](auto PH) GSH_AI {
-        constexpr int p = decltype(PH)::value;
-        if constexpr (p > 0)
-            if (t < P::T2) P::template ex1_read<(p > 0 ? p - 1 : 0)>(rb, t, lds);
-        if (t < P::T1) P::template ex1_write<p>(ra, t, lds);
-        __syncthreads();
-    });
-    if (t < P::T2) P::template ex1_read<P::NP1 - 1>(rb, t, lds);
-}
-
-template <class P>
-__device__ __forceinline__ void exchange2(const cf (&rb)[P::R2], cf (&rc)[P::R3], int t, cf* lds)
-{
-    // (no barrier in front: phase 0 goes to the region exchange 1 did not end in, and whatever was read from it was read before exchange 1's
-    // last barrier)
-    oc::static_for<P::NP2>([&](auto PH) GSH_AI {
-        constexpr int p = decltype(PH)::value;
-        if constexpr (p > 0)
-            if (t < P::T3) P::template ex2_read<(p > 0 ? p - 1 : 0)>(rc, t, lds);
-        if (t < P::T2) P::template ex2_write<p>(rb, t, lds);
-        __syncthreads();
-    });
-    if (t < P::T3) P::template ex2_read<P::NP2 - 1>(rc, t, lds);
-}
-#define GSH_OC_LDS_DECL(P) __shared__ __align__(16) cf lds[P::LDS_CF]
-#endif
+#define GSH_OC_LDS_DECL(P) __shared__ __align__(16) unsigned char lds[P::LDS_BYTES]
 
 // ------------------------------------------------------------------------------------------------------------
 template <class P>
@@ -162,12 +173,9 @@ __global__ __launch_bounds__(P::THREADS) void oc_forward_kernel(OcFwdArgs a)
                             oc::static_for<P::R1>([&](auto N1) GSH_AI {
                                 constexpr int n1 = decltype(N1)::value;
                                 const int k = n1 * P::T1 + t + seg * P::N;
-                                if (k < a.n_in)
-                                    {
-                                        const cf u = oc::cmul(src[k], ws);
-                                        ra[n1].x += u.x;
-                                        ra[n1].y += u.y;
-                                    }
+                                const cf u = oc::cmul(load_or_zero(src, k, a.n_in), ws);
+                                ra[n1].x += u.x;
+                                ra[n1].y += u.y;
                             });
                         }
                 }
@@ -175,7 +183,7 @@ __global__ __launch_bounds__(P::THREADS) void oc_forward_kernel(OcFwdArgs a)
                 oc::static_for<P::R1>([&](auto N1) GSH_AI {
                     constexpr int n1 = decltype(N1)::value;
                     const int k = n1 * P::T1 + t - a.place_off;
-                    ra[n1] = (k >= 0 && k < a.n_in) ? src[k] : cf{0.0f, 0.0f};
+                    ra[n1] = load_or_zero(src, k, a.n_in);
                 });
             if (a.wipe_hz != nullptr)
                 {
@@ -223,20 +231,24 @@ __global__ __launch_bounds__(P::THREADS) void oc_forward_split_kernel(OcFwdArgs 
             oc::static_for<P::R1>([&](auto N1) GSH_AI {
                 constexpr int n1 = decltype(N1)::value;
                 const int k = n1 * P::T1 + t - a.place_off;
-                ra[n1] = (k >= 0 && k < a.n_in) ? src[k] : cf{0.0f, 0.0f};
+                ra[n1] = load_or_zero(src, k, a.n_in);
             });
 #pragma clang loop unroll(disable)
             for (int q = 1; q < S; q++)
                 {
                     cf cq = radix_root(q * r, S);
                     if (wipe) cq = oc::cmul(cq, wipe_phasor(f, q * M, a.inv_fs));
+                    // The R1 running sums already take up to half the register file, and the compiler would put all R1 loads of this pass in flight on
+                    // top of them (read-only, no-alias memory: nothing orders them) and spill.  Eight at a time: the index of the next eight passes
+                    // through an empty asm that also takes the sum the previous eight ended on, so they cannot be issued before that sum exists.
+                    int kq = t + q * M - a.place_off;
                     oc::static_for<P::R1>([&](auto N1) GSH_AI {
                         constexpr int n1 = decltype(N1)::value;
-                        const int k = n1 * P::T1 + t + q * M - a.place_off;
-                        const cf v = (k >= 0 && k < a.n_in) ? src[k] : cf{0.0f, 0.0f};
+                        const cf v = load_or_zero(src, n1 * P::T1 + kq, a.n_in);
                         const cf u = oc::cmul(v, cq);
                         ra[n1].x += u.x;
                         ra[n1].y += u.y;
+                        if constexpr (n1 % 8 == 7) asm volatile("" : "+v"(kq) : "v"(ra[n1].x));
                     });
                 }
             // per-sample factor w[n] W_N^{n r}, n = n1 T1 + t: seed (t) and step (T1) of both combined before the power tree
@@ -344,6 +356,7 @@ __global__ __launch_bounds__(P::THREADS) void oc_cell_kernel(OcCellArgs a)
                                 const cf u = oc::cmul(oc::cmul_conj(Xq[n1 * P::T1], Cq[n1 * P::T1]), cq);
                                 ra[n1].x += u.x;
                                 ra[n1].y += u.y;
+
                             });
                         }
                     if (r != 0)  // uniform over the work-group
@@ -359,6 +372,10 @@ __global__ __launch_bounds__(P::THREADS) void oc_cell_kernel(OcCellArgs a)
     if (t < P::T2) P::stage2(rb, t);
     exchange2<P>(rb, rc, t, lds);
 
+    // SECOND: the row's magnitudes are parked in the exchange buffer (N floats fit: it held N complex values a phase at a time) until the row's
+    // peak is known; every exchange-2 read of every thread must have landed before the first magnitude overwrites it
+    float* mag = reinterpret_cast<float*>(lds);
+    if constexpr (SECOND) __syncthreads();
     // ---- |.|^2, optional accumulation / grid store, per-thread (max, lowest arg-max, sum)
     // element k3 of thread t is lag tau = S (t + T3 k3) + r of the length-N correlation; it enters the search as index tau - offset when
     // tau >= offset (offset + effective == N; offset != 0 only for bit_transition_flag, acq.cc:544)
@@ -387,6 +404,8 @@ __global__ __launch_bounds__(P::THREADS) void oc_cell_kernel(OcCellArgs a)
                                 if constexpr (k3 > K0 || (k3 == K0 && !MIXED)) rc[k3].x += g[base + S * P::T3 * k3];
                                 if constexpr (k3 == K0 && MIXED)
                                     if (edge_ok) rc[k3].x += g[base + S * P::T3 * k3];
+                                // (the sub-cell and second-peak flavours sit at the 128-register limit: eight grid loads in flight at a time instead of all R3)
+                                if constexpr ((S > 1 || SECOND) && k3 % 8 == 7) __builtin_amdgcn_sched_barrier(0);
                             });
                         if (a.store_grid)
                             oc::static_for<P::R3>([&](auto K3) GSH_AI {
@@ -410,10 +429,10 @@ __global__ __launch_bounds__(P::THREADS) void oc_cell_kernel(OcCellArgs a)
                             const bool better = m > best;
                             best = better ? m : best;
                             at = better ? static_cast<unsigned>(base + S * P::T3 * k3) : at;
-                            if (SECOND) rc[k3].x = m;  // kept (in place) for the second scan
+                            if (SECOND) mag[t + P::T3 * k3] = m;  // kept for the second scan -- in the exchange buffer, idle from here on, not in 40 registers
                         }
                     else if (SECOND)
-                        rc[k3].x = -1.0f;  // lags below the offset: never the second peak either
+                        mag[t + P::T3 * k3] = -1.0f;  // lags below the offset: never the second peak either
                 });
             }
         }
@@ -467,7 +486,7 @@ __global__ __launch_bounds__(P::THREADS) void oc_cell_kernel(OcCellArgs a)
                         const int tau = t + P::T3 * k3 - a.offset;   // S == 1 here; lags below the offset hold -1 and never win against 0.0
                         const bool ge1 = tau >= e1, lt2 = tau < e2;
                         const bool blank = blank_all | (wraps ? (ge1 | lt2) : (ge1 & lt2));
-                        second = blank ? second : fmaxf(second, rc[k3].x);
+                        second = blank ? second : fmaxf(second, mag[t + P::T3 * k3]);
                     });
                 }
 #pragma unroll

@@ -32,6 +32,6 @@ for n in lengths:
     acq.time_dwells(x, 32, reps=60, pipelined=True)  # clocks settle
     ms1 = min(acq.time_dwells(x, 32, reps=20) for _ in range(3))
     ms2 = min(acq.time_dwells(x, 32, reps=60, pipelined=True) for _ in range(3))
-    res = acq.dwell(x, 32)[0]
+    res = acq.dwell(x.cpu().numpy(), 32)[0]
     print(f"{tag} N={n:6d} single {ms1 * 1e3:8.1f} us  pipelined {ms2 * 1e3:8.1f} us  dwells/s {32 / (ms2 * 1e-3):9.0f}  peak (tau {res['index_time']}, bin {res['index_doppler']}) stat {res['test_statistics']:.4f}", flush=True)
     acq.close()

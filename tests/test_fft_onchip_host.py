@@ -24,16 +24,19 @@ def host():
     return C.CDLL(LIB)
 
 
+@pytest.mark.parametrize("form", [1, 2], ids=["component_exchange", "phased_64bit_exchange"])
 @pytest.mark.parametrize("n", PLANS)
-def test_onchip_plan_matches_numpy_fft(host, n):
+def test_onchip_plan_matches_numpy_fft(host, n, form):
+    """Both LDS exchange forms of every plan (the device picks one per plan, Plan::EX64; the other is one macro away in A/B builds)."""
     rng = np.random.default_rng(n)
+    host.oc_host_fft_form.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int]
     for trial in range(2):
         x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
         if trial == 1:
             x[:] = 0
             x[n // 3] = 1.0 + 0.5j  # an impulse exercises every twiddle
         out = np.zeros(n, np.complex64)
-        assert host.oc_host_fft(n, x.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)) == 0
+        assert host.oc_host_fft_form(n, x.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), form) == 0
         ref = np.fft.fft(x.astype(np.complex128))
         err = np.linalg.norm(out - ref) / np.linalg.norm(ref)
         assert err < 1.5e-6, (n, trial, err)
@@ -42,11 +45,13 @@ def test_onchip_plan_matches_numpy_fft(host, n):
 
 @pytest.mark.parametrize("n", PLANS)
 def test_plan_geometry(host, n):
-    info = (C.c_int * 5)()
+    info = (C.c_int * 8)()
     assert host.oc_host_plan_info(n, info) == 0
-    threads, lds_floats, s1, s2, p2 = list(info)
+    threads, lds_floats, s1, s2, p2, ex64, np1, np2 = list(info)
     assert threads % 64 == 0 and threads <= 1024
-    assert lds_floats * 4 + 1024 <= 160 * 1024          # one float component of the whole transform + reduction scratch
+    assert lds_floats * 4 + 1024 <= 160 * 1024          # the exchange buffer(s) of the form the plan uses + reduction scratch
+    assert ex64 == (1 if (n * 4 > 72 * 1024 or threads == 1024) else 0)    # phased form where one work-group fills the compute unit anyway (fft_onchip.h: measured)
+    assert 1 <= np1 <= 4 and 1 <= np2 <= 4
     assert p2 % 2 == 1                                   # exchange-2 writer lanes spread over the banks
 
 
