@@ -221,6 +221,7 @@ SYMBOLS = {
     "gsh_acq_noncoherent_pair_peaks": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "gsh_acq_dwell": (C.c_int, [_P, _F, C.c_uint32, C.c_int, C.c_uint32, C.POINTER(AcqResult)]),
     "gsh_acq_dwell_device": (C.c_int, [_P, _P, C.c_uint32, C.c_int, C.c_uint32, C.POINTER(AcqResult)]),
+    "gsh_acq_dwell_slots": (C.c_int, [_P, _F, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(AcqResult)]),
     "gsh_acq_dwell_step2": (C.c_int, [_P, _F, C.c_uint32, C.POINTER(C.c_uint32), _F, _F, C.c_int, C.c_uint32, C.POINTER(AcqResult)]),
     "gsh_acq_dwell_step2_device": (C.c_int, [_P, _P, C.c_uint32, C.POINTER(C.c_uint32), _F, _F, C.c_int, C.c_uint32, C.POINTER(AcqResult)]),
     "gsh_acq_dwell_cshort": (C.c_int, [_P, C.POINTER(C.c_int16), C.c_uint32, C.c_int, C.c_uint32, C.POINTER(AcqResult)]),

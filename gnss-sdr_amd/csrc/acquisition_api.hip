@@ -28,6 +28,7 @@ struct gsh_acq
     float2* d_in{nullptr};        // consumed_samples
     float2* d_spectra{nullptr};   // n_bins * n
     float2* d_codes{nullptr};     // max_prn * n   (forward FFT of the placed code, permuted layout, unconjugated)
+    float2* d_codes_sel{nullptr}; // gsh_acq_dwell_slots: the spectra of the slots of one batch side by side (allocated on first use)
     float2* d_tmp{nullptr};       // chunk_prn * n_bins * n
     float* d_grid{nullptr};       // max_prn * n_bins * effective
     gsh::RowStat* d_rows{nullptr};
@@ -565,6 +566,7 @@ extern "C"
         if (a->d_in) (void)hipFree(a->d_in);
         if (a->d_spectra) (void)hipFree(a->d_spectra);
         if (a->d_codes) (void)hipFree(a->d_codes);
+        if (a->d_codes_sel) (void)hipFree(a->d_codes_sel);
         if (a->d_tmp) (void)hipFree(a->d_tmp);
         if (a->d_grid) (void)hipFree(a->d_grid);
         if (a->d_rows) (void)hipFree(a->d_rows);
@@ -782,6 +784,38 @@ extern "C"
         rc = enqueue_dwell(a, n_prn, accumulate, dwell_count);
         if (rc != GSH_OK) return rc;
         return finish_results(a, n_prn, results);
+    }
+
+    int gsh_acq_dwell_slots(gsh_acq_t* a, const float* in_iq, uint32_t n, const uint32_t* prn_slots, gsh_acq_result* results)
+    {
+        GSH_REQUIRE(a != nullptr && in_iq != nullptr && prn_slots != nullptr && results != nullptr, "null argument");
+        GSH_REQUIRE(n >= 1 && n <= a->conf.max_prn, "n %u outside 1..%u", n, a->conf.max_prn);
+        bool prefix = true;
+        for (uint32_t i = 0; i < n; i++)
+            {
+                GSH_REQUIRE(prn_slots[i] < a->conf.max_prn, "prn slot %u outside 0..%u", prn_slots[i], a->conf.max_prn - 1);
+                if (!a->code_set[prn_slots[i]]) return set_error(GSH_ERR_STATE, "local code of prn slot %u has not been set (set_local_code)", prn_slots[i]);
+                prefix = prefix && prn_slots[i] == i;
+            }
+        GSH_HIP(hipSetDevice(a->device));
+        const size_t len = a->conf.fft_size;
+        float2* const all_codes = a->d_codes;
+        if (!prefix)
+            {
+                // the batch's code spectra side by side (a few hundred KB each, device to device): the kernels then see an ordinary batch of n codes
+                if (a->d_codes_sel == nullptr) GSH_HIP(hipMalloc(&a->d_codes_sel, sizeof(float2) * len * a->conf.max_prn));
+                for (uint32_t i = 0; i < n; i++)
+                    GSH_HIP(hipMemcpyAsync(a->d_codes_sel + static_cast<size_t>(i) * len, all_codes + static_cast<size_t>(prn_slots[i]) * len, sizeof(float2) * len,
+                        hipMemcpyDeviceToDevice, a->stream));
+            }
+        std::memcpy(a->h_stage, in_iq, sizeof(float2) * a->conf.consumed_samples);
+        GSH_HIP(hipMemcpyAsync(a->d_in, a->h_stage, sizeof(float2) * a->conf.consumed_samples, hipMemcpyHostToDevice, a->stream));
+        a->have_input = true;
+        if (!prefix) a->d_codes = a->d_codes_sel;
+        int rc = enqueue_dwell(a, n, 0, 1u);
+        a->d_codes = all_codes;
+        if (rc != GSH_OK) return rc;
+        return finish_results(a, n, results);
     }
 
     int gsh_acq_dwell_cshort(gsh_acq_t* a, const int16_t* in_iq16, uint32_t n_prn, int accumulate, uint32_t dwell_count, gsh_acq_result* results)

@@ -6,9 +6,33 @@
 #include "configuration_interface.h"
 #include <algorithm>
 #include <cmath>
+#include <map>
+#include <mutex>
 
 namespace
 {
+// Channels configured with the same <role>.hip_shared_acquisition id (>= 0) on the same device share one Hip_Acquisition_Runtime: blocks that
+// search at the same time join one dwell batch (forward transforms once for all of them).  The first block's dwell geometry defines the
+// runtime; a block whose geometry differs (another signal, another Doppler grid) keeps to its own handle.
+std::shared_ptr<Hip_Acquisition_Runtime> acquisition_runtime_for(int device, int id, const Hip_Acq_Conf& conf, int max_channels, int max_wait_us)
+{
+    static std::mutex mu;
+    static std::map<std::pair<int, int>, std::weak_ptr<Hip_Acquisition_Runtime>> runtimes;
+    if (id < 0) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    auto& slot = runtimes[{device, id}];
+    auto rt = slot.lock();
+    if (!rt)
+        {
+            Hip_Pcps_Acquisition_Core probe(conf, device);  // derives the engine-side geometry exactly as every block's core does
+            if (!probe.ok()) return nullptr;
+            rt = std::make_shared<Hip_Acquisition_Runtime>(device, probe.engine_conf(), max_channels, std::chrono::microseconds(max_wait_us));
+            if (!rt->ok()) return nullptr;
+            slot = rt;
+        }
+    return rt;
+}
+
 // base_pcps_acquisition.cc:38-66 without the command-line flag overrides
 Acq_Conf get_acq_conf(const ConfigurationInterface* configuration, const std::string& role, double chip_rate, double opt_freq, uint32_t ms_per_code)
 {
@@ -65,7 +89,10 @@ BasePcpsAcquisitionHip::BasePcpsAcquisitionHip(const ConfigurationInterface* con
     if (acq_parameters_.item_type == "gr_complex" || acq_parameters_.item_type == "cshort")
         {
             const int device = configuration->property(role + ".hip_device", 0);
-            acquisition_ = pcps_make_acquisition_hip(to_hip_conf(acq_parameters_), device, acq_parameters_.blocking_on_standby);
+            const Hip_Acq_Conf hconf = to_hip_conf(acq_parameters_);
+            auto runtime = acquisition_runtime_for(device, configuration->property(role + ".hip_shared_acquisition", -1), hconf,
+                configuration->property(role + ".hip_shared_acquisition_channels", 64), configuration->property(role + ".hip_shared_acquisition_wait_us", 2000));
+            acquisition_ = pcps_make_acquisition_hip(hconf, device, acq_parameters_.blocking_on_standby, std::move(runtime));
             if (!acquisition_->ok()) acquisition_.reset();  // item_size() == 0 -> the factory rejects the block instead of running without a GPU
         }
 }

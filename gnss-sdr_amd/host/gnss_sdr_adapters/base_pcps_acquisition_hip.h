@@ -7,7 +7,13 @@
  * BUILT ONLY INSIDE A gnss-sdr TREE (GNU Radio, Gnss_Synchro, ChannelFsm, Acq_Conf); tests/host/mock_gnuradio/ lets this
  * repository compile and drive it against the reference's own interface headers (tests/test_adapters_*.py).
  * Same constructor signature, same configuration keys (Acq_Conf::SetFromConfiguration, acq_conf.cc:29-95 -- including
- * make_two_steps / second_nbins / second_doppler_step / pfa_second_step and item_type = cshort), plus <role>.hip_device.
+ * make_two_steps / second_nbins / second_doppler_step / pfa_second_step and item_type = cshort), plus
+ *   <role>.hip_device                        GPU index (0)
+ *   <role>.hip_shared_acquisition            id >= 0: channels with the same id (and device, and dwell geometry) share one Hip_Acquisition_Runtime --
+ *                                            blocks that search at the same time cut the stream on a common grid and join ONE dwell batch: the
+ *                                            Doppler-wiped forward transforms are computed once for all of them (-1, default: every block on its own)
+ *   <role>.hip_shared_acquisition_channels   slots of the shared handle (64)
+ *   <role>.hip_shared_acquisition_wait_us    how long the first channel of a batch waits for the others that announced the same window (2000)
  * Signal-specific adapters only provide code_gen_complex_sampled(), exactly as in the reference (:133).
  * Precedent for a self-contained accelerator adapter in the reference: gps_l1_ca_dll_pll_tracking_gpu.cc:36-95.
  */
@@ -48,6 +54,8 @@ public:
     void disconnect(gr::top_block_sptr top_block) override;
     gr::basic_block_sptr get_left_block() override { return acquisition_; }
     gr::basic_block_sptr get_right_block() override { return acquisition_; }
+    //! the block itself (tests and monitors; a Channel never needs it)
+    pcps_acquisition_hip_sptr block() const { return acquisition_; }
 
     void set_gnss_synchro(Gnss_Synchro* p_gnss_synchro) override
     {

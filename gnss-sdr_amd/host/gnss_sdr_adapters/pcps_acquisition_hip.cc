@@ -12,13 +12,13 @@
 #include <algorithm>
 #include <utility>
 
-pcps_acquisition_hip_sptr pcps_make_acquisition_hip(const Hip_Acq_Conf& conf, int device, bool blocking_on_standby)
+pcps_acquisition_hip_sptr pcps_make_acquisition_hip(const Hip_Acq_Conf& conf, int device, bool blocking_on_standby, std::shared_ptr<Hip_Acquisition_Runtime> runtime)
 {
-    return pcps_acquisition_hip_sptr(new pcps_acquisition_hip(conf, device, blocking_on_standby));
+    return pcps_acquisition_hip_sptr(new pcps_acquisition_hip(conf, device, blocking_on_standby, std::move(runtime)));
 }
 
 
-pcps_acquisition_hip::pcps_acquisition_hip(const Hip_Acq_Conf& conf, int device, bool blocking_on_standby)
+pcps_acquisition_hip::pcps_acquisition_hip(const Hip_Acq_Conf& conf, int device, bool blocking_on_standby, std::shared_ptr<Hip_Acquisition_Runtime> runtime)
     : acquisition_impl_interface("pcps_acquisition_hip",
           gr::io_signature::make(1, 1, conf.cshort ? sizeof(std::complex<int16_t>) : sizeof(gr_complex)),  // acq.cc:102-103 (it_size)
           gr::io_signature::make(0, 1, sizeof(Gnss_Synchro))),
@@ -29,6 +29,28 @@ pcps_acquisition_hip::pcps_acquisition_hip(const Hip_Acq_Conf& conf, int device,
       d_blocking_on_standby(blocking_on_standby)
 {
     this->message_port_register_out(pmt::mp("events"));
+    // a shared runtime is only of use to a block whose dwell is the runtime's dwell (same transform, same Doppler grid, same statistic)
+    if (runtime && runtime->ok() && d_core.ok() && runtime->same_geometry(d_core.engine_conf()))
+        {
+            d_runtime = std::move(runtime);
+            d_slot = d_runtime->attach();
+            if (d_slot < 0) d_runtime.reset();
+        }
+}
+
+
+pcps_acquisition_hip::~pcps_acquisition_hip()
+{
+    if (d_runtime && d_slot >= 0) d_runtime->detach(d_slot);
+}
+
+
+// the block stops caring about the window it had announced (deactivated, restarted): a batch must not wait for it
+void pcps_acquisition_hip::leave_shared_window()
+{
+    if (d_runtime && d_shared_dwell) d_runtime->withdraw(d_slot);
+    d_shared_dwell = false;
+    d_skip = 0;
 }
 
 
@@ -49,6 +71,11 @@ void pcps_acquisition_hip::set_local_code(std::complex<float>* code)
     gr::thread::scoped_lock lock(d_setlock);
     d_core.set_doppler_bias(doppler_bias);
     d_core.set_local_code(code);
+    if (d_runtime && !d_runtime->set_local_code(d_slot, code))  // the same replica in this block's slot of the shared handle
+        {
+            d_runtime->detach(d_slot);
+            d_runtime.reset();
+        }
 }
 
 
@@ -56,6 +83,7 @@ void pcps_acquisition_hip::set_active(bool active)
 {
     gr::thread::scoped_lock lock(d_setlock);
     d_active = active;
+    if (!active) leave_shared_window();
 }
 
 
@@ -77,7 +105,11 @@ void pcps_acquisition_hip::set_state(int32_t state)
 {
     gr::thread::scoped_lock lock(d_setlock);
     d_state = state;
-    if (state == 0) d_core.reset();
+    if (state == 0)
+        {
+            d_core.reset();
+            leave_shared_window();
+        }
 }
 
 
@@ -85,8 +117,26 @@ void pcps_acquisition_hip::run_dwell(uint64_t sample_count)
 {
     Hip_Pcps_Acquisition_Core::AcquisitionResult result;
     const bool was_step_two = d_core.step_two();
-    const auto outcome = d_cshort ? d_core.acquisition_core(sample_count, d_data_buffer_sc.data(), &result)
-                                  : d_core.acquisition_core(sample_count, d_data_buffer.data(), &result);
+    Hip_Pcps_Acquisition_Core::Outcome outcome;
+    if (d_shared_dwell && d_runtime && !d_core.next_dwell_is_shareable())
+        {
+            // something changed while the window was buffered (set_doppler_center ...): this dwell is the block's own after all
+            d_runtime->withdraw(d_slot);
+            d_shared_dwell = false;
+        }
+    if (d_shared_dwell && d_runtime)
+        {
+            // every channel that buffered this window joins one batch: the Doppler-wiped forward transforms are computed once for all of them
+            gsh_acq_result r{};
+            const bool ok = d_runtime->dwell(d_slot, d_window, d_data_buffer.data(), &r);
+            d_shared_dwell = false;
+            outcome = d_core.acquisition_core_shared(sample_count, ok, r, &result);
+        }
+    else
+        {
+            outcome = d_cshort ? d_core.acquisition_core(sample_count, d_data_buffer_sc.data(), &result)
+                               : d_core.acquisition_core(sample_count, d_data_buffer.data(), &result);
+        }
     gr::thread::scoped_lock lock(d_setlock);
     if (outcome != Hip_Pcps_Acquisition_Core::ACQ_ERROR && d_gnss_synchro != nullptr) d_core.update_synchro(result, d_gnss_synchro);
     switch (outcome)
@@ -144,6 +194,23 @@ int pcps_acquisition_hip::general_work(int /*noutput_items*/, gr_vector_int& nin
                 }
             d_buffer_count = 0U;
             d_state = 1;
+            // a dwell that may be shared starts on the runtime's grid: the next multiple of the dwell length in absolute sample index, less than one
+            // dwell length ahead.  The block says so now, so that the batch of that window waits for it.
+            leave_shared_window();
+            if (d_runtime && d_core.next_dwell_is_shareable())
+                {
+                    d_window = d_runtime->next_window(d_sample_count);
+                    d_skip = static_cast<uint32_t>(d_window - d_sample_count);
+                    d_shared_dwell = true;
+                    d_runtime->announce(d_slot, d_window);
+                }
+        }
+    else if (d_state == 1 && d_skip > 0)
+        {
+            const uint32_t pass = std::min<uint32_t>(d_skip, static_cast<uint32_t>(ninput_items[0]));
+            d_skip -= pass;
+            d_sample_count += pass;
+            consume_each(static_cast<int>(pass));
         }
     else if (d_state == 1)
         {

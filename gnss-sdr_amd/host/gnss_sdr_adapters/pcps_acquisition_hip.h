@@ -16,6 +16,7 @@
 #include "acquisition_impl_interface.h"
 #include "channel_fsm.h"
 #include "gnss_synchro.h"
+#include "hip_acquisition_runtime.h"
 #include "hip_pcps_acquisition_core.h"
 #include <gnuradio/block.h>
 #include <complex>
@@ -25,12 +26,13 @@
 class pcps_acquisition_hip;
 using pcps_acquisition_hip_sptr = gnss_shared_ptr<pcps_acquisition_hip>;
 
-pcps_acquisition_hip_sptr pcps_make_acquisition_hip(const Hip_Acq_Conf& conf, int device, bool blocking_on_standby);
+pcps_acquisition_hip_sptr pcps_make_acquisition_hip(const Hip_Acq_Conf& conf, int device, bool blocking_on_standby,
+    std::shared_ptr<Hip_Acquisition_Runtime> runtime = nullptr);
 
 class pcps_acquisition_hip : public acquisition_impl_interface
 {
 public:
-    ~pcps_acquisition_hip() override = default;
+    ~pcps_acquisition_hip() override;
 
     void set_gnss_synchro(Gnss_Synchro* p_gnss_synchro) override
     {
@@ -60,14 +62,24 @@ public:
     }
     /*! false when the engine could not be created (no GPU, unsupported transform length): the adapter then reports item_size() == 0 */
     bool ok() const { return d_core.ok(); }
+    //! the rendezvous this block shares with the other channels of its stream (nullptr: none)
+    const std::shared_ptr<Hip_Acquisition_Runtime>& runtime() const { return d_runtime; }
 
     int general_work(int noutput_items, gr_vector_int& ninput_items, gr_vector_const_void_star& input_items,
         gr_vector_void_star& output_items) override;
 
 private:
-    friend pcps_acquisition_hip_sptr pcps_make_acquisition_hip(const Hip_Acq_Conf& conf, int device, bool blocking_on_standby);
-    pcps_acquisition_hip(const Hip_Acq_Conf& conf, int device, bool blocking_on_standby);
+    friend pcps_acquisition_hip_sptr pcps_make_acquisition_hip(const Hip_Acq_Conf& conf, int device, bool blocking_on_standby, std::shared_ptr<Hip_Acquisition_Runtime> runtime);
+    pcps_acquisition_hip(const Hip_Acq_Conf& conf, int device, bool blocking_on_standby, std::shared_ptr<Hip_Acquisition_Runtime> runtime);
     void run_dwell(uint64_t sample_count);
+    void leave_shared_window();
+
+    // channels of one stream that search at the same time share their dwell batches (hip_acquisition_runtime.h); nullptr: every dwell on d_core's own handle
+    std::shared_ptr<Hip_Acquisition_Runtime> d_runtime;
+    int d_slot{-1};
+    uint64_t d_window{0};       // first sample of the window being buffered (a line of the runtime's grid)
+    uint32_t d_skip{0};         // samples still to pass before the window starts
+    bool d_shared_dwell{false}; // the dwell of the window being buffered goes through the shared batch
 
     Hip_Pcps_Acquisition_Core d_core;
     std::vector<std::complex<float>> d_data_buffer;

@@ -38,6 +38,7 @@ Hip_Pcps_Acquisition_Core::Hip_Pcps_Acquisition_Core(const Hip_Acq_Conf& conf, i
     c.transform_path = 0;
     c.num_doppler_bins_step2 = conf.make_2_steps ? conf.num_doppler_bins_step2 : 0U;  // acq.cc:171-175
     c.doppler_step2 = conf.doppler_step2;
+    d_engine_conf = c;
     if (gsh_acq_create(device, &c, &d_handle) != GSH_OK)
         {
             d_error = gsh_last_error();
@@ -79,6 +80,7 @@ void Hip_Pcps_Acquisition_Core::set_doppler_center(int32_t doppler_center)
 void Hip_Pcps_Acquisition_Core::set_doppler_bias(int32_t doppler_bias)
 {
     if (d_handle == nullptr) return;
+    d_doppler_bias = doppler_bias;
     if (gsh_acq_set_doppler_bias(d_handle, doppler_bias) != GSH_OK) d_error = gsh_last_error();
 }
 
@@ -182,6 +184,14 @@ Hip_Pcps_Acquisition_Core::Outcome Hip_Pcps_Acquisition_Core::acquisition_core(u
     const int accumulate = d_num_noncoherent_integrations_counter > 1 ? 1 : 0;  // acq.cc:545-553
     const int rc = run_dwell(d_handle, data, false, d_step_two, d_doppler_center_step_two, d_input_power, accumulate, d_num_noncoherent_integrations_counter, &r);
     return core_after_dwell(sample_count, rc == GSH_OK, &r, result);
+}
+
+
+Hip_Pcps_Acquisition_Core::Outcome Hip_Pcps_Acquisition_Core::acquisition_core_shared(uint64_t sample_count, bool dwell_ok, const gsh_acq_result& r, AcquisitionResult* result)
+{
+    if (d_handle == nullptr || result == nullptr) return ACQ_ERROR;
+    d_num_noncoherent_integrations_counter++;  // acq.cc:668
+    return core_after_dwell(sample_count, dwell_ok, &r, result);
 }
 
 

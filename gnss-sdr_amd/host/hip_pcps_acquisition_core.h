@@ -14,13 +14,13 @@
 #ifndef GNSS_SDR_HIP_PCPS_ACQUISITION_CORE_H
 #define GNSS_SDR_HIP_PCPS_ACQUISITION_CORE_H
 
+#include "gnss_sdr_hip.h"
 #include <cmath>
 #include <complex>
 #include <cstdint>
 #include <string>
 #include <vector>
 
-struct gsh_acq;
 
 /*! The members of Acq_Conf (src/algorithms/acquisition/libs/acq_conf.h:33-87) the arithmetic depends on, same names. */
 struct Hip_Acq_Conf
@@ -108,6 +108,19 @@ public:
     /*! one dwell over d_consumed_samples samples; the caller does the buffering of acq.cc:790-815.  With make_2_steps a
         threshold crossing in step one returns ACQ_CONTINUE and arms step two for the next block (acq.cc:609-624). */
     Outcome acquisition_core(uint64_t sample_count, const std::complex<float>* data, AcquisitionResult* result);
+    /*! The first dwell of a search whose |.|^2 statistics came out of a batch shared with other channels (Hip_Acquisition_Runtime): everything
+        acquisition_core does around the dwell -- counter, thresholds, the two-step state machine (acq.cc:668, 686-727) -- with `r` in place of
+        this handle's own result.  dwell_ok = false: the shared dwell failed (treated like a failed private dwell). */
+    Outcome acquisition_core_shared(uint64_t sample_count, bool dwell_ok, const gsh_acq_result& r, AcquisitionResult* result);
+    /*! true when the NEXT dwell may go through a shared batch: the first dwell of step one of a single-dwell search over gr_complex items with the
+        statistics formed on chip and the Doppler grid centred where every channel's is (no dump, no set_doppler_center / FDMA offset) */
+    bool next_dwell_is_shareable() const
+    {
+        return d_handle != nullptr && !d_step_two && d_num_noncoherent_integrations_counter == 0 && d_acq_parameters.max_dwells <= 1U && !d_acq_parameters.cshort &&
+               !d_acq_parameters.dump && d_doppler_center == 0 && d_doppler_bias == 0;
+    }
+    /*! the dwell geometry this core gave the engine (what a shared runtime must agree with) */
+    const gsh_acq_conf& engine_conf() const { return d_engine_conf; }
     /*! the same for item_type = cshort: `data` holds d_consumed_samples interleaved int16 I,Q pairs (acq.cc:653-656) */
     Outcome acquisition_core(uint64_t sample_count, const std::complex<int16_t>* data, AcquisitionResult* result);
 
@@ -144,6 +157,8 @@ public:
 
 private:
     Hip_Acq_Conf d_acq_parameters;
+    gsh_acq_conf d_engine_conf{};
+    int32_t d_doppler_bias{0};
     gsh_acq* d_handle{nullptr};
     std::string d_error;
     uint32_t d_consumed_samples{0};

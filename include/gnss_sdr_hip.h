@@ -534,6 +534,12 @@ extern "C"
      * d_num_noncoherent_integrations_counter after the increment (acq.cc:668), used by the
      * CFAR power normalisation (acq.cc:430). */
     int gsh_acq_dwell(gsh_acq_t* a, const float* in_iq, uint32_t n_prn, int accumulate, uint32_t dwell_count, gsh_acq_result* results);
+    /* One dwell for an arbitrary subset of the handle's local codes: results[i] belongs to prn_slots[i].  First dwell of a search only
+     * (accumulate = 0, dwell count 1) and statistics only: whatever grid the handle stores is indexed by position i for this call, not by slot.
+     * This is what lets the channels of a receiver that search the same input block at the same time share one batch -- the D forward transforms
+     * are computed once for all of them instead of once per channel (Hip_Acquisition_Runtime; the reference runs one pcps_acquisition block per
+     * channel, each recomputing them, acq.cc:522-560). */
+    int gsh_acq_dwell_slots(gsh_acq_t* a, const float* in_iq, uint32_t n, const uint32_t* prn_slots, gsh_acq_result* results);
     /* same with the input block already in device memory (16-byte aligned) */
     int gsh_acq_dwell_device(gsh_acq_t* a, const void* device_in_iq, uint32_t n_prn, int accumulate, uint32_t dwell_count, gsh_acq_result* results);
     /* Step two of make_two_steps (acq.cc:294-301, 522-560 with d_step_two, 428-437 / 475-482): for each i < n a narrow

@@ -39,6 +39,7 @@
 #include "in_memory_configuration.h"
 #include "item_type_helpers.h"
 #include <array>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -46,6 +47,7 @@
 #include <memory>
 #include <random>
 #include <string>
+#include <thread>
 #include <vector>
 
 // ---- the two item_type helpers acq_conf.cc needs (item_type_helpers.h:43,48); the reference's .cc also pulls in VOLK converters
@@ -170,6 +172,134 @@ void run_simple_case(const char* name, const char* role, long fs, char system, c
     EXPECT(r.event == 1, "%s: event %ld", name, r.event);
     EXPECT(std::fabs(syn.Acq_delay_samples - static_cast<double>(delay)) <= 1.0, "%s delay %f (expected %zu)", name, syn.Acq_delay_samples, delay);
     EXPECT(std::fabs(syn.Acq_doppler_hz - fd) <= 500.0, "%s doppler %f (expected %f)", name, syn.Acq_doppler_hz, fd);
+}
+
+// ---- channels that search at the same time share their dwell batches (Hip_Acquisition_Runtime, <role>.hip_shared_acquisition) -----------------------------
+// n blocks, one scheduler thread each, the same stream.  (a) all active from sample 0: every block buffers window [0, L) and the n dwells are ONE batch;
+// event, Acq_delay_samples, Acq_doppler_hz, Acq_samplestamp_samples and the test statistic behind them must be exactly what n blocks on their own handles report over
+// the same samples.  (b) blocks activated at different read pointers: each skips to the next line of the common grid, so they still meet in one batch.
+struct SharedAcqOutcome
+{
+    long event{0};
+    double delay{0.0}, doppler{0.0};
+    uint64_t stamp{0};
+};
+
+std::vector<SharedAcqOutcome> run_acquisition_blocks(int n_blocks, int shared_id, const std::vector<std::complex<float>>& x, long fs, const std::vector<uint32_t>& prns,
+    const std::vector<size_t>& standby_samples, Hip_Acquisition_Runtime::Stats* stats)
+{
+    const std::string role = "Acquisition_1C";
+    auto conf = base_config(role, fs);
+    conf->set_property(role + ".hip_shared_acquisition", std::to_string(shared_id));
+    conf->set_property(role + ".hip_shared_acquisition_wait_us", "500000");  // the test's threads start when the OS lets them: wait for all of them
+    std::vector<std::unique_ptr<GpsL1CaPcpsAcquisitionHip>> acq;
+    std::vector<Gnss_Synchro> syn(static_cast<size_t>(n_blocks));
+    for (int c = 0; c < n_blocks; c++)
+        {
+            acq.push_back(std::make_unique<GpsL1CaPcpsAcquisitionHip>(conf.get(), role, 1, 0));
+            EXPECT(acq.back()->item_size() == sizeof(gr_complex), "shared acquisition: block %d unusable", c);
+            if (acq.back()->item_size() == 0) return {};
+            syn[static_cast<size_t>(c)].System = 'G';
+            std::memcpy(syn[static_cast<size_t>(c)].Signal, "1C", 3);
+            syn[static_cast<size_t>(c)].PRN = prns[static_cast<size_t>(c)];
+            acq.back()->set_channel(static_cast<unsigned>(c));
+            acq.back()->set_gnss_synchro(&syn[static_cast<size_t>(c)]);
+            acq.back()->set_local_code();
+        }
+    if (shared_id >= 0)
+        EXPECT(acq[0]->block()->runtime() != nullptr && acq[0]->block()->runtime() == acq[static_cast<size_t>(n_blocks) - 1]->block()->runtime(),
+            "shared acquisition: the blocks do not share one runtime");
+    std::vector<SharedAcqOutcome> out(static_cast<size_t>(n_blocks));
+    std::vector<std::thread> th;
+    std::atomic<bool> go{false};
+    for (int c = 0; c < n_blocks; c++)
+        th.emplace_back([&, c]() {
+            auto blk = std::dynamic_pointer_cast<gr::block>(acq[static_cast<size_t>(c)]->get_left_block());
+            while (!go.load()) std::this_thread::yield();
+            size_t pos = 0;
+            gr_vector_void_star outs;
+            // standby: the inactive block only consumes (and counts) what it is offered (acq.cc:768-779)
+            while (pos < standby_samples[static_cast<size_t>(c)])
+                {
+                    const size_t avail = std::min<size_t>(standby_samples[static_cast<size_t>(c)] - pos, 1000);
+                    gr_vector_int nin{static_cast<int>(avail)};
+                    gr_vector_const_void_star ins{static_cast<const void*>(x.data() + pos)};
+                    blk->consumed_last = 0;
+                    blk->general_work(0, nin, ins, outs);
+                    pos += static_cast<size_t>(blk->consumed_last);
+                }
+            acq[static_cast<size_t>(c)]->reset();  // Channel: set_active(true)
+            blk->published.clear();
+            const size_t chunk = 700 + 97 * static_cast<size_t>(c);  // every thread sees the stream in pieces of its own size
+            for (int calls = 0; calls < 100000 && blk->published.empty(); calls++)
+                {
+                    const size_t avail = std::min(chunk, x.size() - pos);
+                    if (avail == 0) break;
+                    gr_vector_int nin{static_cast<int>(avail)};
+                    gr_vector_const_void_star ins{static_cast<const void*>(x.data() + pos)};
+                    blk->consumed_last = 0;
+                    blk->general_work(0, nin, ins, outs);
+                    pos += static_cast<size_t>(blk->consumed_last);
+                }
+            SharedAcqOutcome& o = out[static_cast<size_t>(c)];
+            o.event = blk->published.empty() ? 0 : pmt::to_long(blk->published[0].second);
+            o.delay = syn[static_cast<size_t>(c)].Acq_delay_samples;
+            o.doppler = syn[static_cast<size_t>(c)].Acq_doppler_hz;
+            o.stamp = syn[static_cast<size_t>(c)].Acq_samplestamp_samples;
+        });
+    go.store(true);
+    for (auto& t : th) t.join();
+    if (stats != nullptr && shared_id >= 0 && acq[0]->block()->runtime()) *stats = acq[0]->block()->runtime()->stats();
+    return out;
+}
+
+void test_shared_acquisition()
+{
+    const long fs = 4000000;
+    const int n_blocks = 8;
+    std::vector<std::complex<float>> rep(4000);
+    gps_l1_ca_code_gen_complex_sampled(rep, 14, static_cast<int32_t>(fs), 0);
+    const auto x = make_stream(rep, 60000, fs, 1234, 1760.0, 0.12F, 5);
+    const std::vector<uint32_t> prns = {14, 3, 7, 21, 14, 30, 9, 14};  // the satellite of the stream three times, five that are not there
+    // (a) all active from the first sample
+    {
+        const std::vector<size_t> standby(static_cast<size_t>(n_blocks), 0);
+        Hip_Acquisition_Runtime::Stats st;
+        const auto shared = run_acquisition_blocks(n_blocks, 7, x, fs, prns, standby, &st);
+        const auto alone = run_acquisition_blocks(n_blocks, -1, x, fs, prns, standby, nullptr);
+        EXPECT(shared.size() == alone.size() && !shared.empty(), "shared acquisition: no results");
+        for (size_t c = 0; c < std::min(shared.size(), alone.size()); c++)
+            {
+                EXPECT(shared[c].event == alone[c].event && shared[c].event == ((prns[c] == 14) ? 1 : 2), "shared acquisition ch %zu: event %ld vs %ld on its own handle", c,
+                    shared[c].event, alone[c].event);
+                EXPECT(shared[c].delay == alone[c].delay && shared[c].doppler == alone[c].doppler && shared[c].stamp == alone[c].stamp,
+                    "shared acquisition ch %zu: delay %.3f / %.3f, Doppler %.1f / %.1f, stamp %llu / %llu", c, shared[c].delay, alone[c].delay, shared[c].doppler, alone[c].doppler,
+                    static_cast<unsigned long long>(shared[c].stamp), static_cast<unsigned long long>(alone[c].stamp));
+            }
+        std::printf("shared acquisition: %d blocks, %llu dwells in %llu batch(es) (largest %u, %llu closed by the wait limit): results identical to the blocks' own handles\n", n_blocks,
+            static_cast<unsigned long long>(st.dwells), static_cast<unsigned long long>(st.batches), st.largest_batch, static_cast<unsigned long long>(st.timeouts));
+        EXPECT(st.dwells == static_cast<uint64_t>(n_blocks) && st.batches * 4 <= st.dwells, "shared acquisition: %llu dwells in %llu batches -- the forward transforms were not shared",
+            static_cast<unsigned long long>(st.dwells), static_cast<unsigned long long>(st.batches));
+    }
+    // (b) activated at different read pointers: the common grid brings them together
+    {
+        std::vector<size_t> standby;
+        for (int c = 0; c < n_blocks; c++) standby.push_back(4000 + 311 * static_cast<size_t>(c));  // all inside (4000, 8000): the next grid line is 8000 for all
+        Hip_Acquisition_Runtime::Stats st;
+        const auto shared = run_acquisition_blocks(n_blocks, 8, x, fs, prns, standby, &st);
+        for (size_t c = 0; c < shared.size(); c++)
+            {
+                EXPECT(shared[c].event == ((prns[c] == 14) ? 1 : 2), "shared acquisition (staggered) ch %zu: event %ld", c, shared[c].event);
+                if (prns[c] == 14)
+                    EXPECT(std::fabs(shared[c].delay - 1234.0) <= 1.0 && std::fabs(shared[c].doppler - 1760.0) <= 250.0 && shared[c].stamp == 12000ULL,
+                        "shared acquisition (staggered) ch %zu: delay %.1f, Doppler %.1f, stamp %llu (window [8000, 12000))", c, shared[c].delay, shared[c].doppler,
+                        static_cast<unsigned long long>(shared[c].stamp));
+            }
+        std::printf("shared acquisition, blocks activated at 8 different read pointers: %llu dwells in %llu batch(es) (largest %u)\n", static_cast<unsigned long long>(st.dwells),
+            static_cast<unsigned long long>(st.batches), st.largest_batch);
+        EXPECT(st.dwells == static_cast<uint64_t>(n_blocks) && st.batches * 4 <= st.dwells, "shared acquisition (staggered): %llu dwells in %llu batches", static_cast<unsigned long long>(st.dwells),
+            static_cast<unsigned long long>(st.batches));
+    }
 }
 }  // namespace
 
@@ -708,6 +838,7 @@ int main()
         [](std::vector<std::complex<float>>& rep) { qzss_l5i_code_gen_complex_sampled(rep, 194, 25000000); }, 12321, -1500.0, 0.0, 28);
     reference_block_side_by_side();
     e5a_reference_block_side_by_side();
+    test_shared_acquisition();
     if (fails == 0) std::printf("ADAPTERS OK\n");
     return fails == 0 ? 0 : 1;
 }

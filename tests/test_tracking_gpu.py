@@ -337,6 +337,43 @@ def test_config2_tracking_parity(gpu):
     for j in range(8):
         assert abs(out[j, 1]) > 3 * np.sqrt(2 * n), (j, out[j])
     print(f"config2 worst |gpu-truth|/sum|x| = {worst:.3e}")
+    # ---- information SURVEY.md section 7 asks for, and the numbers TOL_REF is derived from: how far the GPU sits from the reference's two CPU
+    # protokernels on the taps that hold a signal, how far those sit from each other, and how many samples the AVX resampler puts on another chip
+    # than the generic one (the GPU selects the generic kernel's chips bit for bit: test_chip_selection_bit_exact)
+    w_gen = w_avx = w_between = 0.0
+    flips = flip_samples = 0
+    R = oracle.ref()
+    for j, job in enumerate(jobs):
+        code = codes[job["code_slot"]]
+        o32, t64, sabs = oracle_job(code, x, job)
+        strong = np.abs(t64) > 0.01 * sabs
+        if not np.any(strong):
+            continue
+        g = out[j, :3]
+        w_gen = max(w_gen, float((np.abs(g - o32) / np.abs(o32))[strong].max()))
+        if R is not None and R.ref_simd_supported():
+            win = x[job["sample_offset"]:job["sample_offset"] + n]
+            avx = oracle.ref_mcorr(code, job["shifts_chips"], win, job["rem_carr_phase_rad"], job["phase_step_rad"], job["rem_code_phase_chips"],
+                                   job["code_phase_step_chips"], simd=True)
+            w_avx = max(w_avx, float((np.abs(g - avx) / np.abs(avx))[strong].max()))
+            w_between = max(w_between, float((np.abs(avx - o32) / np.abs(o32))[strong].max()))
+            try:
+                import ctypes as C
+                ramp = np.arange(1023, dtype=np.float32)  # code[k] = k: the resampled "code" IS the chip index
+                sh = np.asarray(job["shifts_chips"], np.float32)
+                res = [np.empty(n, np.float32) for _ in range(2 * 3)]
+                for flavour, fn in enumerate((R.ref_generic_resampler, R.ref_simd_resampler)):
+                    rows = (C.POINTER(C.c_float) * 3)(*[res[3 * flavour + t].ctypes.data_as(C.POINTER(C.c_float)) for t in range(3)])
+                    fn.restype = None
+                    fn.argtypes = [C.POINTER(C.POINTER(C.c_float)), C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_uint, C.c_int, C.c_uint]
+                    fn(rows, ramp.ctypes.data, C.c_float(job["rem_code_phase_chips"]), C.c_float(job["code_phase_step_chips"]), sh.ctypes.data, 1023, 3, n)
+                flips += int(sum(np.count_nonzero(res[t] != res[3 + t]) for t in range(3)))
+                flip_samples += 3 * n
+            except Exception as e:  # an oracle/_ref built without the protokernel entry points: the figures above still stand
+                flips = -1
+    print(f"config2 parity on signal taps: worst |gpu-generic|/|generic| = {w_gen:.3e}, |gpu-u_avx|/|u_avx| = {w_avx:.3e}, "
+          f"|u_avx-generic|/|generic| = {w_between:.3e}; chips the AVX resampler selects differently from the generic one: {flips} of {flip_samples} tap-samples "
+          f"(TOL_REF = {TOL_REF:.1e})")
     # batched launch == one-by-one launches (no cross-job leakage), and launch-level determinism
     again = b.correlate(jobs)
     assert np.array_equal(out.view(np.float32), again.view(np.float32))
