@@ -123,7 +123,7 @@ int enqueue_dwell(gsh_acq* a, uint32_t n_prn, int accumulate, uint32_t dwell_cou
             if (rc != GSH_OK) return rc;
             // acq.cc:538-553 + the per-row part of :409-519: one work-group per (PRN, bin) cell, nothing leaves the CU
             return gsh::onchip_correlate(n, a->d_spectra, a->d_codes, a->d_grid, a->d_rows, a->d_subrows, a->d_results, a->d_arrivals, static_cast<int>(n_prn),
-                a->n_bins, c.bit_transition_flag ? eff : 0, eff, accumulate, c.no_grid ? 0 : 1, static_cast<int>(c.samples_per_chip), c.use_cfar, dwell_count ? dwell_count : 1u,
+                a->n_bins, c.bit_transition_flag ? eff : 0, eff, accumulate, (c.no_grid && !(a->split > 0 && !c.use_cfar)) ? 0 : 1, static_cast<int>(c.samples_per_chip), c.use_cfar, dwell_count ? dwell_count : 1u,
                 a->grid_weight, a->stream);
         }
     // acq.cc:657-664 (zero padding) + :531-535 (wipe-off, forward FFT) for every bin
@@ -468,10 +468,12 @@ extern "C"
         a->n_bins2 = static_cast<int>(c.num_doppler_bins_step2);
         a->h_bins2_hz.assign(static_cast<size_t>(a->n_bins2) * c.max_prn, 0.0f);
         a->code_set.assign(c.max_prn, 0);
-        // one compute unit per transform when the length has a plan; S work-groups per transform for N = S * M (no peak-ratio statistic, no
-        // folding there); bit_transition_flag is an epilogue predicate of the same kernels
+        // one compute unit per transform when the length has a plan; S work-groups per transform for N = S * M (no folding there);
+        // bit_transition_flag is an epilogue predicate of the same kernels.  The peak-ratio statistic on a split plan (round 3): the S sub-cells
+        // of a row each own every S-th lag, so none of them can blank around the row's peak; the row is kept in the magnitude grid instead
+        // (stored whatever no_grid says) and the PRN's last arriver scans the winning row for the second peak.
         a->onchip = (c.transform_path == 0) && gsh::onchip_supported(static_cast<int>(c.fft_size));
-        if (!a->onchip && c.transform_path == 0 && c.use_cfar && c.fold <= 1 && gsh::onchip_split(static_cast<int>(c.fft_size)) > 0)
+        if (!a->onchip && c.transform_path == 0 && c.fold <= 1 && gsh::onchip_split(static_cast<int>(c.fft_size)) > 0)
             {
                 a->onchip = true;
                 a->split = gsh::onchip_split(static_cast<int>(c.fft_size));
@@ -523,7 +525,7 @@ extern "C"
         // the four-step path keeps its inter-pass intermediate in HBM; the on-chip path only needs one row to stage a code
         const size_t tmp_rows = a->onchip ? size_t(1) : std::max(chunk * D, size_t(2));
         if ((e = hipMalloc(&a->d_tmp, sizeof(float2) * tmp_rows * n)) != hipSuccess) return fail(e, "hipMalloc(tmp)");
-        const bool need_grid = !(a->onchip && c.no_grid);
+        const bool need_grid = !(a->onchip && c.no_grid) || (a->split > 0 && !c.use_cfar);
         if (need_grid)
             {
                 if ((e = hipMalloc(&a->d_grid, sizeof(float) * P * D * eff)) != hipSuccess) return fail(e, "hipMalloc(grid)");
@@ -867,7 +869,7 @@ extern "C"
                         if (rc != GSH_OK) return rc;
                         rc = gsh::onchip_correlate(nfft, a->d_spectra, a->d_codes + static_cast<size_t>(slot) * nfft, grid, a->d_rows + static_cast<size_t>(i) * D2,
                             a->d_subrows ? a->d_subrows + static_cast<size_t>(i) * D2 * a->split : nullptr,
-                            a->d_results + i, a->d_arrivals + i, 1, D2, c.bit_transition_flag ? eff : 0, eff, accumulate, c.no_grid ? 0 : 1, static_cast<int>(c.samples_per_chip), c.use_cfar,
+                            a->d_results + i, a->d_arrivals + i, 1, D2, c.bit_transition_flag ? eff : 0, eff, accumulate, (c.no_grid && !(a->split > 0 && !c.use_cfar)) ? 0 : 1, static_cast<int>(c.samples_per_chip), c.use_cfar,
                             dwell_count ? dwell_count : 1u, a->grid_weight, a->stream);
                     }
                 else
@@ -1073,6 +1075,7 @@ extern "C"
         GSH_REQUIRE(n_prn >= 1 && n_prn <= a->conf.max_prn, "n_prn %u outside 1..%u", n_prn, a->conf.max_prn);
         if (!a->have_input) return set_error(GSH_ERR_STATE, "no input block resident: call gsh_acq_dwell[_device] once first");
         if (!a->onchip) return gsh_acq_time_dwells(a, n_prn, reps, avg_ms);  // the four-step path shares one scratch buffer
+        if (a->split > 0 && !a->conf.use_cfar) return gsh_acq_time_dwells(a, n_prn, reps, avg_ms);  // two batches in flight would share the stored rows
         GSH_HIP(hipSetDevice(a->device));
         const gsh_acq_conf& c = a->conf;
         const size_t n = c.fft_size, D = static_cast<size_t>(a->n_bins), P = c.max_prn;

@@ -414,6 +414,10 @@ __global__ __launch_bounds__(P::THREADS) void oc_cell_kernel(OcCellArgs a)
                                 if constexpr (k3 == K0 && MIXED)
                                     if (edge_ok) g[base + S * P::T3 * k3] = rc[k3].x;
                             });
+                        // split plan + peak-ratio statistic: the PRN's last arriver (another work-group, maybe another XCD) reads the winning row
+                        // back in this very launch -- every thread releases its own stores at agent scope before the arrival ticket is drawn
+                        if constexpr (S > 1)
+                            if (a.want_second) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                     }
                 oc::static_for<P::R3>([&](auto K3) GSH_AI {
                     constexpr int k3 = decltype(K3)::value;
@@ -568,6 +572,35 @@ __global__ __launch_bounds__(P::THREADS) void oc_cell_kernel(OcCellArgs a)
                         gtau = ot;
                     }
             }
+        if constexpr (S > 1)
+            {
+                if (!a.use_cfar)
+                    {
+                        // first_vs_second_peak_statistic on a split plan (acq.cc:485-513): the winning row lies in the magnitude grid (its S sub-cells
+                        // stored it, released at agent scope); this wave blanks +-samples_per_chip around the peak and takes the maximum of the rest
+                        const unsigned wbin = __shfl(gbin == 0xFFFFFFFFu ? 0u : gbin, 0, 64);
+                        const int tau_pk = static_cast<int>(__shfl(gbin == 0xFFFFFFFFu ? 0u : gtau, 0, 64));
+                        int e1 = tau_pk - a.samples_per_chip;
+                        int e2 = tau_pk + a.samples_per_chip;
+                        if (e1 < 0)
+                            e1 += a.effective;
+                        else if (e2 >= a.effective)
+                            e2 -= a.effective;
+                        const bool wraps = e1 > e2, blank_all = e1 == e2;
+                        const float* __restrict__ row = a.grid + (static_cast<size_t>(prn) * a.n_bins + wbin) * a.effective;
+                        float second = 0.0f;  // blanked cells hold 0.0
+                        for (int tau = t; tau < a.effective; tau += 64)
+                            {
+                                const bool ge1 = tau >= e1, lt2 = tau < e2;
+                                const bool blank = blank_all | (wraps ? (ge1 | lt2) : (ge1 & lt2));
+                                const float m = __builtin_nontemporal_load(row + tau);
+                                second = blank ? second : fmaxf(second, m);
+                            }
+#pragma unroll
+                        for (int off = 32; off > 0; off >>= 1) second = fmaxf(second, __shfl_down(second, off, 64));
+                        if (t == 0) s_peak = second;  // (s_peak is free: the row records are out)
+                    }
+            }
         if (t == 0)
             {
                 if (gbin == 0xFFFFFFFFu)  // every row maximum was 0: the reference leaves bin 0 / index 0
@@ -593,7 +626,7 @@ __global__ __launch_bounds__(P::THREADS) void oc_cell_kernel(OcCellArgs a)
                     }
                 else
                     {
-                        const float second_pk = row_of(static_cast<int>(gbin)).second;
+                        const float second_pk = (S == 1) ? row_of(static_cast<int>(gbin)).second : s_peak;  // S > 1: scanned by the wave just above
                         out.second_peak = second_pk;
                         out.test_statistics = gmax / second_pk;  // acq.cc:516
                     }
@@ -642,7 +675,7 @@ int launch_cells(const OcCellArgs& a, int n_blocks, hipStream_t s)
         }
     else
         {
-            GSH_REQUIRE(!a.want_second, "the peak-ratio statistic has no split plan");
+            GSH_REQUIRE(!a.want_second || (a.store_grid && a.grid != nullptr), "the peak-ratio statistic on a split plan scans the stored winning row: it needs the grid");
             GSH_REQUIRE(a.subrows != nullptr, "split plan without sub-cell records");
             if (off)
                 hipLaunchKernelGGL((oc_cell_kernel<P, S, true, false, true>), dim3(n_blocks), dim3(P::THREADS), 0, s, a);

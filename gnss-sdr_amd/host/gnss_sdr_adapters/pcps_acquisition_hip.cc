@@ -48,7 +48,7 @@ pcps_acquisition_hip::~pcps_acquisition_hip()
 // the block stops caring about the window it had announced (deactivated, restarted): a batch must not wait for it
 void pcps_acquisition_hip::leave_shared_window()
 {
-    if (d_runtime && d_shared_dwell) d_runtime->withdraw(d_slot);
+    if (d_runtime) d_runtime->withdraw(d_slot);
     d_shared_dwell = false;
     d_skip = 0;
 }
@@ -83,7 +83,10 @@ void pcps_acquisition_hip::set_active(bool active)
 {
     gr::thread::scoped_lock lock(d_setlock);
     d_active = active;
-    if (!active) leave_shared_window();
+    if (!active)
+        leave_shared_window();
+    else if (d_runtime && d_state == 0 && d_core.next_dwell_is_shareable())
+        d_runtime->searching(d_slot);  // batches about to close wait (bounded) for this channel's first window
 }
 
 

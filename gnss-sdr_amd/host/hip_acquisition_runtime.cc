@@ -84,10 +84,20 @@ bool Hip_Acquisition_Runtime::set_local_code(int slot, const std::complex<float>
 }
 
 
-void Hip_Acquisition_Runtime::announce(int slot, uint64_t window_start)
+void Hip_Acquisition_Runtime::searching(int slot)
 {
     std::lock_guard<std::mutex> lk(d_mutex);
-    if (slot >= 0 && slot < static_cast<int>(d_announced.size())) d_announced[static_cast<size_t>(slot)] = static_cast<int64_t>(window_start);
+    if (slot >= 0 && slot < static_cast<int>(d_announced.size()) && d_announced[static_cast<size_t>(slot)] == -1) d_announced[static_cast<size_t>(slot)] = -2;
+}
+
+
+void Hip_Acquisition_Runtime::announce(int slot, uint64_t window_start)
+{
+    {
+        std::lock_guard<std::mutex> lk(d_mutex);
+        if (slot >= 0 && slot < static_cast<int>(d_announced.size())) d_announced[static_cast<size_t>(slot)] = static_cast<int64_t>(window_start);
+    }
+    d_cv.notify_all();  // a batch that waited for this (until now undecided) channel looks again: it may be heading elsewhere
 }
 
 
@@ -106,7 +116,7 @@ int Hip_Acquisition_Runtime::announced_for(uint64_t window_start) const
 {
     int n = 0;
     for (const int64_t w : d_announced)
-        if (w == static_cast<int64_t>(window_start)) n++;
+        if (w == static_cast<int64_t>(window_start) || w == -2) n++;
     return n;
 }
 

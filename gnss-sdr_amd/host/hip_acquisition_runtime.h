@@ -65,6 +65,9 @@ public:
     void detach(int slot);
     /*! acq.cc:218-251 for the slot's satellite; the Doppler centre / FDMA bias are properties of the shared grid and must be 0 */
     bool set_local_code(int slot, const std::complex<float>* code);
+    /*! the block has been activated (Channel: set_active(true)) and will announce a window at its next scheduler call: a batch that is about
+        to close waits for it (bounded by max_wait) -- it may well be heading for the same window */
+    void searching(int slot);
     /*! the block starts buffering the window that begins at window_start (a grid line) */
     void announce(int slot, uint64_t window_start);
     /*! the block left the search before its dwell (set_active(false), set_state(0)) */
@@ -85,7 +88,7 @@ private:
         std::string error;
     };
     void run(const std::shared_ptr<Batch>& b, std::unique_lock<std::mutex>& lk, bool timed_out);
-    int announced_for(uint64_t window_start) const;
+    int announced_for(uint64_t window_start) const;  // slots still expected in this window's batch (announced it, or activated and undecided)
 
     int d_device;
     gsh_acq_conf d_conf{};
@@ -96,7 +99,7 @@ private:
     std::condition_variable d_cv;
     std::mutex d_handle_mutex;  // the C handle: one thread at a time
     std::vector<char> d_used;
-    std::vector<int64_t> d_announced;  // per slot: window start, -1 none
+    std::vector<int64_t> d_announced;  // per slot: window start; -1 none; -2 activated, window not known yet
     std::map<uint64_t, std::shared_ptr<Batch>> d_batches;
     Stats d_stats;
 };

@@ -77,8 +77,11 @@ def oracle_job(code, x, job: dict):
 #            kernel sits ~1e-5 from exact arithmetic (its rotator recurrence drifts; measured in
 #            tests/test_oracle_vs_ref.py) and its own QA allows 1e-3 between protokernels
 #            (volk_gnsssdr/lib/kernel_tests.h:41,88-89), so this gate cannot be tighter than a few 1e-5.
+#            Measured on MI355X for BASELINE config 2 (test_config2_tracking_parity prints it): worst |gpu - generic| / |generic| = 1.14e-5,
+#            |gpu - u_avx| / |u_avx| = 4.9e-6, and the reference's two protokernels differ from each other by 1.16e-5 -- the GPU sits closer
+#            to either of them than they sit to each other.  The gate is 2 x the measured worst (round 3; it was 5e-5).
 TOL_SCALE = 1e-5
-TOL_REF = 5e-5
+TOL_REF = 2.5e-5
 
 
 def scale_err(gpu, truth, sabs):

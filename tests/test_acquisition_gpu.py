@@ -59,8 +59,8 @@ def test_grid_matches_oracle(gpu, n, consumed, fs, bt):
     """FFT sizes with radix-2/3/4/5/8 and generic (11, 31) passes; bit_transition_flag (acq.cc:230-235) and
     fft_size = 2*consumed (sampled_ms != ms_per_code, acq.cc:111,243-247) paddings.  Every length with an on-chip plan
     (GSH_OC_PLANS / GSH_OC_SPLIT_PLANS in csrc/fft_onchip.h) goes through the whole-transform-on-chip kernels -- bit_transition_flag
-    included (upper half of the lags, acq.cc:544) --, the others (6625, 26500, the zero-padded ones, and the peak-ratio statistic at
-    split lengths) through the four-step kernels."""
+    included (upper half of the lags, acq.cc:544), and since round 3 the peak-ratio statistic at split lengths too (the winning row is kept
+    in the grid and scanned by the PRN's last arriver) --, the others (6625, 26500, the zero-padded ones) through the four-step kernels."""
     rng = np.random.default_rng(n)
     spms = fs // 1000
     prn = 7
@@ -270,6 +270,60 @@ def test_onchip_agrees_with_fourstep_and_nogrid_rules(gpu, n, fs):
             banks["nogrid"].read_grid(0)
         for acq in banks.values():
             acq.close()
+
+
+@pytest.mark.parametrize("n,fs,bt", [(50000, 50000000, False), (50000, 25000000, True), (128000, 64000000, False), (80000, 40000000, False)])
+def test_peak_ratio_statistic_on_split_plans(gpu, n, fs, bt):
+    """first_vs_second_peak_statistic (acq.cc:452-519, the statistic of every configuration that gives `threshold` instead of `pfa`) for N = S * M:
+    the S sub-cells of a row each own every S-th lag, so the +-samples_per_chip blanking around the row's peak is done by the PRN's last arriver
+    on the stored winning row.  Against the four-step kernels (an independent factorisation, second scan in row_stats_kernel): same indices, same
+    second peak, same statistic; a handle created without a grid (no_grid) gives the same answer (the rows are kept for this statistic whatever
+    no_grid says); peaks next to the row's ends (blanking window wrapped) included."""
+    spc = int(np.ceil(fs / 1.023e6))
+    consumed = n
+    per = fs // 1000
+    # code phases that put the peak within samples_per_chip of lag 0 / of the last lag: the blanked stretch wraps round the row (acq.cc:489-496)
+    x = synth_gps_l1_stream(consumed, fs, [5, 9, 12], [-3300.0, 1875.0, 500.0], [100.25, 1022.9, 0.2], cn0_dbhz=47.0, seed_noise=n + 5)
+    kw = dict(fs_in=fs, fft_size=n, consumed_samples=consumed, doppler_max=2500, doppler_step=250, samples_per_chip=spc, samples_per_code=float(per),
+              max_prn=4, use_cfar=False, bit_transition_flag=bt)
+    codes = []
+    for p in (5, 9, 12, 20):
+        c1 = oracle.ca_code_complex_sampled(p, fs)
+        codes.append(c1 if bt else np.tile(c1, (consumed + len(c1) - 1) // len(c1))[:consumed])
+    banks = {name: _bank(gpu, **kw, **bk) for name, bk in (("onchip", dict()), ("nogrid", dict(keep_grid=False)), ("fourstep", dict(transform_path=1)))}
+    out = {}
+    for name, acq in banks.items():
+        for i, c in enumerate(codes):
+            acq.set_local_code(i, c)
+        out[name] = acq.dwell(x, 4)
+    key = lambda r: (r["index_time"] % per, r["index_doppler"])
+    for i in range(4):
+        a, b, c = out["onchip"][i], out["fourstep"][i], out["nogrid"][i]
+        assert (a["index_time"], a["index_doppler"], a["second_peak"], a["test_statistics"]) == (c["index_time"], c["index_doppler"], c["second_peak"], c["test_statistics"]), (i, a, c)
+        assert a["second_peak"] > 0.0 and a["test_statistics"] == pytest.approx(a["peak"] / a["second_peak"], rel=1e-6)
+        if i < 3:   # a satellite that is there: the same peak in both factorisations (without one, which noise cell wins is rounding)
+            assert key(a) == key(b), (i, a, b)
+            # blocks of several code periods hold equally high peaks one period apart; which one ranks first is rounding, and then the blanked
+            # stretch differs -- compare the second peak only when both paths blanked around the same lag
+            if a["index_time"] == b["index_time"]:
+                assert a["second_peak"] == pytest.approx(b["second_peak"], rel=3e-4), (i, a, b)
+                assert a["test_statistics"] == pytest.approx(b["test_statistics"], rel=6e-4), (i, a, b)
+    # the stored row the last arriver scanned is the row the oracle's rule gives: recompute the second peak on the host from the grid
+    g = banks["onchip"].read_grid(0)
+    a = out["onchip"][0]
+    eff = g.shape[-1]
+    row = g[a["index_doppler"]].copy()
+    e1, e2 = a["index_time"] - spc, a["index_time"] + spc
+    if e1 < 0:
+        e1 += eff
+    elif e2 >= eff:
+        e2 -= eff
+    idx = np.arange(eff)
+    blank = (idx >= e1) | (idx < e2) if e1 > e2 else (idx >= e1) & (idx < e2)
+    row[blank] = 0.0
+    assert a["second_peak"] == row.max()
+    for acq in banks.values():
+        acq.close()
 
 
 @pytest.mark.parametrize("n,fs,bt", [(50000, 50000000, False), (50000, 25000000, True), (32000, 32000000, False), (65536, 65536000, False),
