@@ -470,8 +470,8 @@ extern "C"
         a->code_set.assign(c.max_prn, 0);
         // one compute unit per transform when the length has a plan; S work-groups per transform for N = S * M (no folding there);
         // bit_transition_flag is an epilogue predicate of the same kernels.  The peak-ratio statistic on a split plan (round 3): the S sub-cells
-        // of a row each own every S-th lag, so none of them can blank around the row's peak; the row is kept in the magnitude grid instead
-        // (stored whatever no_grid says) and the PRN's last arriver scans the winning row for the second peak.
+        // of a row each own every S-th lag, so none of them can blank around the row's peak; the rows are kept in the magnitude grid instead
+        // (stored whatever no_grid says) and a small kernel behind the cell launch scans every PRN's winning row for the second peak.
         a->onchip = (c.transform_path == 0) && gsh::onchip_supported(static_cast<int>(c.fft_size));
         if (!a->onchip && c.transform_path == 0 && c.fold <= 1 && gsh::onchip_split(static_cast<int>(c.fft_size)) > 0)
             {

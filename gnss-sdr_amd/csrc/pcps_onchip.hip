@@ -414,10 +414,7 @@ __global__ __launch_bounds__(P::THREADS) void oc_cell_kernel(OcCellArgs a)
                                 if constexpr (k3 == K0 && MIXED)
                                     if (edge_ok) g[base + S * P::T3 * k3] = rc[k3].x;
                             });
-                        // split plan + peak-ratio statistic: the PRN's last arriver (another work-group, maybe another XCD) reads the winning row
-                        // back in this very launch -- every thread releases its own stores at agent scope before the arrival ticket is drawn
-                        if constexpr (S > 1)
-                            if (a.want_second) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+
                     }
                 oc::static_for<P::R3>([&](auto K3) GSH_AI {
                     constexpr int k3 = decltype(K3)::value;
@@ -572,35 +569,6 @@ __global__ __launch_bounds__(P::THREADS) void oc_cell_kernel(OcCellArgs a)
                         gtau = ot;
                     }
             }
-        if constexpr (S > 1)
-            {
-                if (!a.use_cfar)
-                    {
-                        // first_vs_second_peak_statistic on a split plan (acq.cc:485-513): the winning row lies in the magnitude grid (its S sub-cells
-                        // stored it, released at agent scope); this wave blanks +-samples_per_chip around the peak and takes the maximum of the rest
-                        const unsigned wbin = __shfl(gbin == 0xFFFFFFFFu ? 0u : gbin, 0, 64);
-                        const int tau_pk = static_cast<int>(__shfl(gbin == 0xFFFFFFFFu ? 0u : gtau, 0, 64));
-                        int e1 = tau_pk - a.samples_per_chip;
-                        int e2 = tau_pk + a.samples_per_chip;
-                        if (e1 < 0)
-                            e1 += a.effective;
-                        else if (e2 >= a.effective)
-                            e2 -= a.effective;
-                        const bool wraps = e1 > e2, blank_all = e1 == e2;
-                        const float* __restrict__ row = a.grid + (static_cast<size_t>(prn) * a.n_bins + wbin) * a.effective;
-                        float second = 0.0f;  // blanked cells hold 0.0
-                        for (int tau = t; tau < a.effective; tau += 64)
-                            {
-                                const bool ge1 = tau >= e1, lt2 = tau < e2;
-                                const bool blank = blank_all | (wraps ? (ge1 | lt2) : (ge1 & lt2));
-                                const float m = __builtin_nontemporal_load(row + tau);
-                                second = blank ? second : fmaxf(second, m);
-                            }
-#pragma unroll
-                        for (int off = 32; off > 0; off >>= 1) second = fmaxf(second, __shfl_down(second, off, 64));
-                        if (t == 0) s_peak = second;  // (s_peak is free: the row records are out)
-                    }
-            }
         if (t == 0)
             {
                 if (gbin == 0xFFFFFFFFu)  // every row maximum was 0: the reference leaves bin 0 / index 0
@@ -626,14 +594,59 @@ __global__ __launch_bounds__(P::THREADS) void oc_cell_kernel(OcCellArgs a)
                     }
                 else
                     {
-                        const float second_pk = (S == 1) ? row_of(static_cast<int>(gbin)).second : s_peak;  // S > 1: scanned by the wave just above
+                        // (S > 1: no sub-cell sees the whole row; oc_second_peak_kernel, queued right behind this launch, scans the stored winning
+                        // row and fills in second_peak / test_statistics)
+                        const float second_pk = (S == 1) ? row_of(static_cast<int>(gbin)).second : 0.0f;
                         out.second_peak = second_pk;
-                        out.test_statistics = gmax / second_pk;  // acq.cc:516
+                        out.test_statistics = (S == 1) ? gmax / second_pk : 0.0f;  // acq.cc:516
                     }
                 a.results[prn] = out;
                 __hip_atomic_store(&a.arrivals[prn], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
             }
     }
+}
+
+// ---- first_vs_second_peak_statistic on a split plan (acq.cc:485-516).  The S sub-cells of a row each own every S-th lag, so none of them can blank
+// +-samples_per_chip around the row's peak; the rows are kept in the magnitude grid instead and, once the cell launch has formed every PRN's peak, one
+// work-group per PRN scans the winning row (a few hundred KB, 1 024 threads) and completes the record.
+struct OcSecondArgs
+{
+    const float* grid;      // n_prn * n_bins * effective
+    DevAcqResult* results;  // n_prn: index_time / index_doppler / peak set by the cell launch
+    int n_bins, effective, samples_per_chip;
+};
+
+__global__ __launch_bounds__(1024) void oc_second_peak_kernel(OcSecondArgs a)
+{
+    __shared__ float s_m[16];
+    const int prn = blockIdx.x, t = threadIdx.x;
+    const DevAcqResult r = a.results[prn];
+    const int tau_pk = static_cast<int>(r.index_time);
+    int e1 = tau_pk - a.samples_per_chip;
+    int e2 = tau_pk + a.samples_per_chip;
+    if (e1 < 0)
+        e1 += a.effective;
+    else if (e2 >= a.effective)
+        e2 -= a.effective;
+    const bool wraps = e1 > e2, blank_all = e1 == e2;  // the do-while of acq.cc:498-509 blanks everything when e1 == e2
+    const float* __restrict__ row = a.grid + (static_cast<size_t>(prn) * a.n_bins + r.index_doppler) * a.effective;
+    float second = 0.0f;  // blanked cells hold 0.0
+    for (int tau = t; tau < a.effective; tau += 1024)
+        {
+            const bool ge1 = tau >= e1, lt2 = tau < e2;
+            const bool blank = blank_all | (wraps ? (ge1 | lt2) : (ge1 & lt2));
+            second = blank ? second : fmaxf(second, row[tau]);
+        }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) second = fmaxf(second, __shfl_down(second, off, 64));
+    if ((t & 63) == 0) s_m[t >> 6] = second;
+    __syncthreads();
+    if (t == 0)
+        {
+            for (int w = 1; w < 16; w++) second = fmaxf(second, s_m[w]);
+            a.results[prn].second_peak = second;
+            a.results[prn].test_statistics = r.peak / second;  // acq.cc:516
+        }
 }
 
 template <class P>
@@ -683,6 +696,17 @@ int launch_cells(const OcCellArgs& a, int n_blocks, hipStream_t s)
                 hipLaunchKernelGGL((oc_cell_kernel<P, S, true, false, false>), dim3(n_blocks), dim3(P::THREADS), 0, s, a);
             else
                 hipLaunchKernelGGL((oc_cell_kernel<P, S, false, false, false>), dim3(n_blocks), dim3(P::THREADS), 0, s, a);
+            if (a.want_second)
+                {
+                    GSH_HIP(hipGetLastError());
+                    OcSecondArgs sa;
+                    sa.grid = a.grid;
+                    sa.results = a.results;
+                    sa.n_bins = a.n_bins;
+                    sa.effective = a.effective;
+                    sa.samples_per_chip = a.samples_per_chip;
+                    hipLaunchKernelGGL(oc_second_peak_kernel, dim3(a.n_prn), dim3(1024), 0, s, sa);
+                }
         }
     GSH_HIP(hipGetLastError());
     return GSH_OK;

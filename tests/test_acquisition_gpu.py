@@ -60,7 +60,7 @@ def test_grid_matches_oracle(gpu, n, consumed, fs, bt):
     fft_size = 2*consumed (sampled_ms != ms_per_code, acq.cc:111,243-247) paddings.  Every length with an on-chip plan
     (GSH_OC_PLANS / GSH_OC_SPLIT_PLANS in csrc/fft_onchip.h) goes through the whole-transform-on-chip kernels -- bit_transition_flag
     included (upper half of the lags, acq.cc:544), and since round 3 the peak-ratio statistic at split lengths too (the winning row is kept
-    in the grid and scanned by the PRN's last arriver) --, the others (6625, 26500, the zero-padded ones) through the four-step kernels."""
+    in the grid and scanned by a small kernel behind the cell launch) --, the others (6625, 26500, the zero-padded ones) through the four-step kernels."""
     rng = np.random.default_rng(n)
     spms = fs // 1000
     prn = 7
@@ -275,8 +275,8 @@ def test_onchip_agrees_with_fourstep_and_nogrid_rules(gpu, n, fs):
 @pytest.mark.parametrize("n,fs,bt", [(50000, 50000000, False), (50000, 25000000, True), (128000, 64000000, False), (80000, 40000000, False)])
 def test_peak_ratio_statistic_on_split_plans(gpu, n, fs, bt):
     """first_vs_second_peak_statistic (acq.cc:452-519, the statistic of every configuration that gives `threshold` instead of `pfa`) for N = S * M:
-    the S sub-cells of a row each own every S-th lag, so the +-samples_per_chip blanking around the row's peak is done by the PRN's last arriver
-    on the stored winning row.  Against the four-step kernels (an independent factorisation, second scan in row_stats_kernel): same indices, same
+    the S sub-cells of a row each own every S-th lag, so the +-samples_per_chip blanking around the row's peak is done by a small kernel behind
+    the cell launch on the stored winning row.  Against the four-step kernels (an independent factorisation, second scan in row_stats_kernel): same indices, same
     second peak, same statistic; a handle created without a grid (no_grid) gives the same answer (the rows are kept for this statistic whatever
     no_grid says); peaks next to the row's ends (blanking window wrapped) included."""
     spc = int(np.ceil(fs / 1.023e6))
@@ -308,7 +308,7 @@ def test_peak_ratio_statistic_on_split_plans(gpu, n, fs, bt):
             if a["index_time"] == b["index_time"]:
                 assert a["second_peak"] == pytest.approx(b["second_peak"], rel=3e-4), (i, a, b)
                 assert a["test_statistics"] == pytest.approx(b["test_statistics"], rel=6e-4), (i, a, b)
-    # the stored row the last arriver scanned is the row the oracle's rule gives: recompute the second peak on the host from the grid
+    # the stored row that kernel scanned is the row the oracle's rule gives: recompute the second peak on the host from the grid
     g = banks["onchip"].read_grid(0)
     a = out["onchip"][0]
     eff = g.shape[-1]
