@@ -631,7 +631,8 @@ struct Plan
     X(22, 24, 31) /* 16 368: 16.368 Msps x 1 ms, 4.092 Msps x 4 ms */ \
     X(16, 11, 31) /*  5 456: 5.456 Msps x 1 ms */ \
     X(10, 16, 16) /*  2 560: 2.56 Msps x 1 ms */ \
-    X(16, 16, 40) /* 10 240: 2.56 Msps x 4 ms */
+    X(16, 16, 40) /* 10 240: 2.56 Msps x 4 ms */ \
+    X(25, 32, 32) /* 25 600: 25.6 Msps x 1 ms, 6.4 Msps x 4 ms; the sub-transform of 128 000 = 5 x 25 600 */
 #endif
 
 // N = S * M: one radix-S decimation-in-frequency step in front of the plan of M (pcps_onchip.hip); X(S, R1, R2, R3)
@@ -644,7 +645,7 @@ struct Plan
     X(8, 25, 25, 40) /* 200 000: 50 Msps x 4 ms */ \
     X(2, 20, 20, 40) /*  32 000: 4 Msps x 8 ms (Galileo E1 8 ms block), 8 Msps x 4 ms, 32 Msps x 1 ms */ \
     X(4, 20, 20, 40) /*  64 000: 16 Msps x 4 ms */ \
-    X(8, 20, 20, 40) /* 128 000: 32 Msps x 4 ms (Galileo E1) */ \
+    X(5, 25, 32, 32) /* 128 000: 32 Msps x 4 ms (Galileo E1); five sub-cells read the product spectrum 5 times, 8 x 16 000 (rounds 1-2) read it 8 times */ \
     X(2, 25, 25, 32) /*  40 000: 40 Msps x 1 ms, 10 Msps x 4 ms; bit-transition search at 20 Msps */ \
     X(4, 25, 25, 32) /*  80 000: 4 Msps x 20 ms (GPS L2C), 20 Msps x 4 ms */ \
     X(2, 22, 24, 31) /*  32 736: 8.184 Msps x 4 ms (Galileo E1) */

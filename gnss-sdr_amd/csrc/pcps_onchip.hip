@@ -351,12 +351,15 @@ __global__ __launch_bounds__(P::THREADS) void oc_cell_kernel(OcCellArgs a)
                             const cf cq = radix_root(q * r, S);
                             const cf* __restrict__ Xq = X + static_cast<size_t>(q) * M;
                             const cf* __restrict__ Cq = C + static_cast<size_t>(q) * M;
+                            // (radix 32: the 32 running sums take half the register file; the operand loads of this pass are issued eight elements at a
+                            // time -- the offset of the next eight passes through an empty asm together with the sum the previous eight ended on)
+                            int kq = 0;
                             oc::static_for<P::R1>([&](auto N1) GSH_AI {
                                 constexpr int n1 = decltype(N1)::value;
-                                const cf u = oc::cmul(oc::cmul_conj(Xq[n1 * P::T1], Cq[n1 * P::T1]), cq);
+                                const cf u = oc::cmul(oc::cmul_conj(Xq[n1 * P::T1 + kq], Cq[n1 * P::T1 + kq]), cq);
                                 ra[n1].x += u.x;
                                 ra[n1].y += u.y;
-
+                                if constexpr (P::R1 >= 32 && n1 % 8 == 7) asm volatile("" : "+v"(kq) : "v"(ra[n1].x));
                             });
                         }
                     if (r != 0)  // uniform over the work-group

@@ -14,7 +14,7 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "host", "libfft_onchip_host.so")
 
-PLANS = [25000, 4000, 2048, 4096, 5000, 8000, 8192, 10000, 12500, 16000, 16384, 20000, 32768, 1000, 2000, 2500, 6250, 2046, 4092, 8184, 16368, 5456, 2560, 10240]
+PLANS = [25000, 4000, 2048, 4096, 5000, 8000, 8192, 10000, 12500, 16000, 16384, 20000, 32768, 1000, 2000, 2500, 6250, 2046, 4092, 8184, 16368, 5456, 2560, 10240, 25600]
 
 
 @pytest.fixture(scope="module")
