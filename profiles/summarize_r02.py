@@ -55,7 +55,7 @@ def find(d, sub):
 def main():
     d, tag = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "r02")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    lines = [f"# rocprofv3 summary {tag}  (source: profiles/run_profiles_r02.sh; raw CSVs stay in gpurun_out/)"]
+    lines = [f"# rocprofv3 summary {tag}  (source: profiles/run_profiles_{tag[:3]}.sh; raw CSVs stay in gpurun_out/)"]
     bench = None
     try:
         bench = json.loads(open(os.path.join(d, "trace.json")).read().strip().splitlines()[-1])
@@ -125,9 +125,36 @@ def main():
                 if k2 in out["oc_cell"]:
                     acq["cell_" + k2] = out["oc_cell"][k2]
             out["acquisition"] = acq
+    lines += acquisition_channel_traces(d)
     open(os.path.join(root, "profiles", f"{tag}_summary.txt"), "w").write("\n".join(lines) + "\n")
-    json.dump(out, open(os.path.join(root, "profiles", "pmc_r02.json"), "w"), indent=1, sort_keys=True)
+    json.dump(out, open(os.path.join(root, "profiles", os.environ.get("GSH_PMC_JSON", "pmc_r02.json")), "w"), indent=1, sort_keys=True)
     print("\n".join(lines))
+
+
+def acquisition_channel_traces(prof):
+    """Round 3: kernel traces of eight acquisition channels on one stream, through the shared runtime and on their own handles (tests/host/test_adapters
+    acq_shared | acq_alone).  Code transforms (set_local_code: one work-group) and signal transforms (one work-group per Doppler bin) are the same kernel and
+    are told apart by the grid."""
+    import collections
+    import re
+    lines = []
+    for mode in ("acq_shared", "acq_alone"):
+        files = glob.glob(os.path.join(prof, mode, "**", "*kernel_trace.csv"), recursive=True)
+        if not files:
+            continue
+        if not lines:
+            lines.append("\n## eight acquisition channels on one stream (tests/host/test_adapters acq_shared / acq_alone): launches of the on-chip kernels")
+        said = [ln.strip() for ln in open(os.path.join(prof, mode + ".log"), errors="replace") if ln.startswith(mode + ":")] if os.path.exists(os.path.join(prof, mode + ".log")) else []
+        lines.append(f"# {said[-1] if said else mode}")
+        c = collections.Counter()
+        for r in csv.DictReader(open(files[0])):
+            m = re.search(r"(oc_\w+)<", r["Kernel_Name"])
+            if m:
+                c[(m.group(1), int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]))] += 1
+        for (name, wgs), n in sorted(c.items()):
+            what = ("code spectrum (set_local_code)" if wgs == 1 else "signal spectra, one work-group per bin") if name == "oc_forward_kernel" else "cells (PRNs x bins)"
+            lines.append("   %-20s %5d work-groups  x %3d launches   %s" % (name, wgs, n, what))
+    return lines
 
 
 if __name__ == "__main__":

@@ -656,8 +656,25 @@ void reference_block_side_by_side()
 }
 }  // namespace
 
-int main()
+int main(int argc, char** argv)
 {
+    // `test_adapters acq_shared` / `acq_alone`: only the eight-channel acquisition case, through the shared runtime or on the blocks' own handles --
+    // what profiles/run_profiles_r03.sh traces to count the forward-transform launches of either
+    if (argc > 1 && (std::string(argv[1]) == "acq_shared" || std::string(argv[1]) == "acq_alone"))
+        {
+            const long fs = 4000000;
+            std::vector<std::complex<float>> rep(4000);
+            gps_l1_ca_code_gen_complex_sampled(rep, 14, static_cast<int32_t>(fs), 0);
+            const auto x = make_stream(rep, 60000, fs, 1234, 1760.0, 0.12F, 5);
+            const std::vector<uint32_t> prns = {14, 3, 7, 21, 14, 30, 9, 14};
+            Hip_Acquisition_Runtime::Stats st;
+            const auto out = run_acquisition_blocks(8, std::string(argv[1]) == "acq_shared" ? 7 : -1, x, fs, prns, std::vector<size_t>(8, 0), &st);
+            int found = 0;
+            for (const auto& o : out) found += o.event == 1 ? 1 : 0;
+            std::printf("%s: 8 channels, %d positive, %llu dwells in %llu shared batches\n", argv[1], found, static_cast<unsigned long long>(st.dwells),
+                static_cast<unsigned long long>(st.batches));
+            return (found == 3 && fails == 0) ? 0 : 1;
+        }
     // ------------------------------------------------------------------ GPS L1 C/A, gr_complex, CFAR threshold from pfa
     {
         const long fs = 4000000;
