@@ -8,6 +8,8 @@
 #include "sample_stream.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <limits>
 #include <new>
 #include <vector>
@@ -93,6 +95,70 @@ __global__ __launch_bounds__(1024) void input_power_kernel(const float2* __restr
             for (int w = 0; w < 16; w++) t += part[w];
             *out = t;
         }
+}
+
+// A second stream whose kernels really run next to those of `ref`.  The runtime spreads the streams of one priority over a few hardware queues and
+// offers no way to ask which; two streams on one queue run their kernels one after the other.  Whether the second lane of the pipelined dwell loop
+// overlapped with the first therefore used to depend on how many streams the process had created before (bench.py: 0.142 ms per 25 000-point batch, the same
+// loop in a fresh process 0.113 ms; profiles/ab/r03/acq_hw_queues.txt).  So: try a few streams, time one 40-us spin on each of `ref` and the candidate
+// started together, keep the first candidate for which the pair takes the time of one; fall back to a stream of another priority class (queues are per
+// class: always concurrent, but the class takes precedence at dispatch, 0.121 ms).
+__global__ void spin_kernel(long long ticks)
+{
+    const long long t0 = wall_clock64();
+    for (int i = 0; i < 100000 && wall_clock64() - t0 < ticks; i++) __builtin_amdgcn_s_sleep(8);  // bounded whatever the clock does
+}
+
+int make_concurrent_stream(hipStream_t ref, hipStream_t* out)
+{
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+    GSH_HIP(hipEventCreate(&e0));
+    GSH_HIP(hipEventCreate(&e1));
+    GSH_HIP(hipEventCreate(&e2));
+    int rate_khz = 100000;
+    int dev = 0;
+    GSH_HIP(hipGetDevice(&dev));
+    if (hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || rate_khz <= 0) rate_khz = 100000;
+    const long long ticks = static_cast<long long>(rate_khz) * 40 / 1000;  // 40 us
+    std::vector<hipStream_t> tried;
+    hipStream_t found = nullptr;
+    for (int attempt = 0; attempt < 8 && found == nullptr; attempt++)
+        {
+            hipStream_t cand = nullptr;
+            GSH_HIP(hipStreamCreateWithFlags(&cand, hipStreamNonBlocking));
+            float best = 1e9f;
+            for (int rep = 0; rep < 3; rep++)  // the first launch on a new stream also pays for its queue
+                {
+                    GSH_HIP(hipEventRecord(e0, ref));
+                    GSH_HIP(hipStreamWaitEvent(cand, e0, 0));
+                    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, ref, ticks);
+                    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, cand, ticks);
+                    GSH_HIP(hipEventRecord(e2, cand));
+                    GSH_HIP(hipStreamWaitEvent(ref, e2, 0));
+                    GSH_HIP(hipEventRecord(e1, ref));
+                    GSH_HIP(hipEventSynchronize(e1));
+                    float ms = 0.0f;
+                    GSH_HIP(hipEventElapsedTime(&ms, e0, e1));
+                    best = std::min(best, ms);
+                }
+            if (std::getenv("GSH_TRACE_STREAMS") != nullptr) std::fprintf(stderr, "gsh: stream probe %d: two 40-us spins in %.1f us\n", attempt, best * 1e3f);
+            if (best < 0.080f)  // measured: 60-64 us side by side (one spin + the event round trip), 100 us one after the other
+                found = cand;
+            else
+                tried.push_back(cand);
+        }
+    for (hipStream_t t : tried) (void)hipStreamDestroy(t);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipEventDestroy(e2);
+    if (found == nullptr)
+        {
+            int least = 0, greatest = 0;
+            GSH_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            GSH_HIP(hipStreamCreateWithPriority(&found, hipStreamNonBlocking, greatest));
+        }
+    *out = found;
+    return GSH_OK;
 }
 
 void fill_bins(gsh_acq* a)
@@ -1081,7 +1147,10 @@ extern "C"
         const size_t n = c.fft_size, D = static_cast<size_t>(a->n_bins), P = c.max_prn;
         if (a->stream2 == nullptr)
             {
-                GSH_HIP(hipStreamCreateWithFlags(&a->stream2, hipStreamNonBlocking));
+                {
+                    const int rc2 = make_concurrent_stream(a->stream, &a->stream2);  // a stream on another hardware queue than a->stream
+                    if (rc2 != GSH_OK) return rc2;
+                }
                 GSH_HIP(hipMalloc(&a->d_spectra2, sizeof(float2) * D * n));
                 GSH_HIP(hipMalloc(&a->d_rows2, sizeof(gsh::RowStat) * P * D));
                 if (a->split > 0) GSH_HIP(hipMalloc(&a->d_subrows2, sizeof(gsh::RowStat) * P * D * a->split));
