@@ -625,7 +625,17 @@ __device__ __forceinline__ void run_segment_packed(const JobCtx& c, const float2
     const int n_pairs = (span + 1) >> 1;
     const int n_full = span >> 1;                       // leading pairs whose second sample is in range
     const int odd = c.n_begin - c.n_first;              // 1: pair 0's first sample is outside the segment
-    const int n_trips = (n_pairs + NCH * PPC - 1) / (NCH * PPC);
+    const int n_trips_all = (n_pairs + NCH * PPC - 1) / (NCH * PPC);
+    // One chunk per trip (the 1024-thread kernel): a wave's 128 samples of the last trip may lie wholly beyond the segment's end -- 25 000 samples are 12.2 trips
+    // of 2 048, and only the first four of the sixteen waves have anything to do in the thirteenth.  Such a wave stops a trip early (its samples there
+    // would all be read as zero); with the waves dealt round-robin to the SIMDs every SIMD then runs 49 wave-trips instead of 52.
+    int n_trips = n_trips_all;
+    if constexpr (NCH == 1)
+        {
+            const int left = c.n_end - (c.n_first + 128 * (tid >> 6));  // samples from the wave's first slice to the end of the segment
+            n_trips = left <= 0 ? 0 : min(n_trips_all, (left + 2 * PPC - 1) / (2 * PPC));
+            n_trips = __builtin_amdgcn_readfirstlane(n_trips);  // wave-uniform: keep the loop control scalar
+        }
     const int first_plain = odd ? 1 : 0;                // trips [first_plain, last_plain) need no masking
     const int last_plain = n_full / (NCH * PPC);
     v2f A0[NT], A1[NT], B0[NT], B1[NT];
@@ -1205,13 +1215,32 @@ __host__ __device__ constexpr int code_table_floats(int code_len) { return (code
 // (a __syncthreads() has been executed); the caller must __syncthreads() again before `red` is reused.
 // AUX: one more tap with the code staged at `tab_aux` (same LDS allocation as `tab`, same length) and shift `aux_shift` is computed in the same
 // pass -- the data-component prompt of track_pilot (trk.cc:1246-1256); its sum is returned in red[NT].  Standard mode only.
-template <int NT, int MODE, bool AUX = false>
+#if defined(GSH_TRK_PROFILE) && GSH_TRK_PROFILE == 2
+#define GSH_CW_STAMP(i)                                  \
+    do                                                   \
+        {                                                \
+            if (threadIdx.x == 0) cw_stamp[i] = clock64(); \
+        }                                                \
+    while (0)
+__shared__ long long cw_stamp[8];  // phase stamps of the last correlate_window call, thread 0's view (profiling builds only)
+#else
+#define GSH_CW_STAMP(i) \
+    do                  \
+        {               \
+        }               \
+    while (0)
+#endif
+
+// SUM = false: return after the first barrier, with one row of per-wave partial sums at red[GSH_MAX_TAPS * (1 + wave) + tap] and nothing in red[0..NOUT): the caller
+// adds the rows itself (in wave order, as below, to get the same sums) in whichever waves need the result -- two barriers and one LDS round trip less per call.
+template <int NT, int MODE, bool AUX = false, bool PAIRK = false, bool SUM = true>
 __device__ __forceinline__ void correlate_window(const float2* __restrict__ stream, unsigned long long sample_offset, int n_samples,
     const float* __restrict__ tab, int code_len, const float (&sh)[NT], float rem_carr, float phase_step, float phase_rate, float rem_code,
     float code_step, float code_rate, float2* __restrict__ red, const float* tab_aux = nullptr, float aux_shift = 0.0f)
 {
     static_assert(!AUX || (MODE == 0 && NT < GSH_MAX_TAPS), "the fused tap exists for the standard mode and needs a free slot in `red`");
     const int tid = threadIdx.x;
+    GSH_CW_STAMP(0);
     JobCtx c;
     c.n_total = n_samples;
     c.code_len = code_len;
@@ -1256,6 +1285,7 @@ __device__ __forceinline__ void correlate_window(const float2* __restrict__ stre
             c.aux_code_len = code_len;
             c.aux_k_off = static_cast<int>(tab_aux - tab) + MC_MARGIN;
         }
+    GSH_CW_STAMP(1);
     if (n_samples > 0)
         {
             float smin = sh[0], smax = sh[0];
@@ -1275,12 +1305,13 @@ __device__ __forceinline__ void correlate_window(const float2* __restrict__ stre
             const bool fast = !mode_hd_code(MODE) && (code_step >= 0.0f) && (lo >= -MC_MARGIN) && (hi < code_len + MC_MARGIN) && (code_len >= MC_MARGIN);
             const bool zp = (NT & 1) && (sh[NT / 2] == 0.0f) && !mode_hd_code(MODE) && (n_samples < (1 << 24));
             if (fast && zp)
-                run_segment<NT, MODE, false, true, AUX>(c, base, tab, sh, rot, acc, &acc_aux);
+                run_segment<NT, MODE, false, true, AUX, false, PAIRK>(c, base, tab, sh, rot, acc, &acc_aux);  // PAIRK: the caller vouches for mcorr_pair_eligible taps
             else if (fast)
                 run_segment<NT, MODE, false, false, AUX>(c, base, tab, sh, rot, acc, &acc_aux);
             else
                 run_segment<NT, MODE, true, false, AUX>(c, base, tab, sh, rot, acc, &acc_aux);
         }
+    GSH_CW_STAMP(2);
     // wave sums in DPP steps (the last lane holds them), one row of partials per wave behind the output row, one LDS step over the waves.
     // Outputs (red[0..NOUT)) and partials (red[GSH_MAX_TAPS ..)) do not overlap, so a call needs two barriers, not three: the caller reads the
     // outputs and passes a barrier of its own before the next call writes them again.
@@ -1305,7 +1336,10 @@ __device__ __forceinline__ void correlate_window(const float2* __restrict__ stre
             for (int t = 0; t < NT; t++) part[wave * GSH_MAX_TAPS + t] = acc[t];
             if (AUX) part[wave * GSH_MAX_TAPS + NT] = acc_aux;
         }
+    GSH_CW_STAMP(3);
     __syncthreads();
+    GSH_CW_STAMP(4);
+    if constexpr (!SUM) return;
     constexpr int NOUT = AUX ? NT + 1 : NT;
     if (tid < NOUT)
         {
@@ -1319,24 +1353,49 @@ __device__ __forceinline__ void correlate_window(const float2* __restrict__ stre
             red[tid] = s;
         }
     __syncthreads();
+    GSH_CW_STAMP(5);
 }
 
-// the standard-mode form the batched callers use
-template <int NT>
+// After a correlate_window<..., SUM = false>: the sums of taps 0 .. NOUT-1, formed by lanes 0 .. NOUT-1 of the calling wave in the order the SUM = true
+// form uses (wave 0's partial first) and handed to every lane of the wave as wave-uniform values.  Any wave may call it; reads only.
+template <int NOUT>
+__device__ __forceinline__ void sum_wave_partials(const float2* __restrict__ red, float2 (&out)[NOUT])
+{
+    const float2* const part = red + GSH_MAX_TAPS;
+    const int lane = threadIdx.x & 63;
+    const int t = lane < NOUT ? lane : 0;
+    float2 s = make_float2(0.0f, 0.0f);
+#pragma unroll
+    for (int w = 0; w < MC_WAVES; w++)
+        {
+            s.x += part[w * GSH_MAX_TAPS + t].x;
+            s.y += part[w * GSH_MAX_TAPS + t].y;
+        }
+#pragma unroll
+    for (int k = 0; k < NOUT; k++)
+        {
+            out[k].x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s.x), k));
+            out[k].y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s.y), k));
+        }
+}
+
+// the standard-mode form the batched callers use.  PAIRK: E/P/L with the taps exactly one chip apart and the code running forward (mcorr_pair_eligible,
+// multicorrelator.h) -- the early tap is read next to the late one (packed_trip); the sums are bit-identical either way
+template <int NT, bool PAIRK = false, bool SUM = true>
 __device__ __forceinline__ void correlate_window_std(const float2* __restrict__ stream, unsigned long long sample_offset, int n_samples,
     const float* __restrict__ tab, int code_len, const float (&sh)[NT], float rem_carr, float phase_step, float rem_code, float code_step,
     float2* __restrict__ red)
 {
-    correlate_window<NT, 0>(stream, sample_offset, n_samples, tab, code_len, sh, rem_carr, phase_step, 0.0f, rem_code, code_step, 0.0f, red);
+    correlate_window<NT, 0, false, PAIRK, SUM>(stream, sample_offset, n_samples, tab, code_len, sh, rem_carr, phase_step, 0.0f, rem_code, code_step, 0.0f, red);
 }
 
 // standard mode with the fused data-component tap: red[0..NT) the taps, red[NT] the fused one
-template <int NT>
+template <int NT, bool SUM = true>
 __device__ __forceinline__ void correlate_window_std_aux(const float2* __restrict__ stream, unsigned long long sample_offset, int n_samples,
     const float* __restrict__ tab, const float* tab_aux, float aux_shift, int code_len, const float (&sh)[NT], float rem_carr, float phase_step,
     float rem_code, float code_step, float2* __restrict__ red)
 {
-    correlate_window<NT, 0, true>(stream, sample_offset, n_samples, tab, code_len, sh, rem_carr, phase_step, 0.0f, rem_code, code_step, 0.0f, red, tab_aux, aux_shift);
+    correlate_window<NT, 0, true, false, SUM>(stream, sample_offset, n_samples, tab, code_len, sh, rem_carr, phase_step, 0.0f, rem_code, code_step, 0.0f, red, tab_aux, aux_shift);
 }
 }  // namespace GSH_MC_NS
 namespace mcdev = GSH_MC_NS;

@@ -113,6 +113,13 @@ struct TrkTail  // what the host needs back from every channel after a launch, i
     int active;              // TrkChannel::active
 };
 
+struct SerialMail  // results the code-loop lane and the lock-detector lane hand to thread 0 (trk_loop_kernel)
+{
+    double code_error_chips, code_error_filt_chips;
+    int lost;
+};
+constexpr int SERIAL_WAVES = 3;
+
 struct TrkArgs
 {
     const gsh_trk_conf* conf;  // device copy (a by-value struct with dynamically indexed arrays would be materialised in scratch by every thread)
@@ -127,6 +134,9 @@ struct TrkArgs
     gsh_trk_epoch* records;   // n_channels * n_epochs or nullptr
     TrkTail* tail;            // n_channels
     int n_epochs;
+    // loop invariants the host forms once per launch with the expressions the kernel used to evaluate in every period
+    double code_period;                 // d_code_period = code_length_chips / code_chip_rate
+    unsigned long long pull_in_limit;   // samples since acquisition below which the pull-in transitory lasts (trk.cc:1912-1915), see trk_launch
 };
 
 // ---- discriminators, T/tracking_discriminators.cc (float / double mix as written there) ---------------------
@@ -418,7 +428,10 @@ __device__ __forceinline__ void publish(NextWindow& w, const TrkChannel& s, cons
 
 // HD: Dll_Pll_Conf::high_dyn -- a compile-time switch so that the standard path does not carry the high-dynamics correlator's registers
 template <int NT, bool HD>
-__global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
+// conf: the device copy of the configuration as a parameter of its own, const and __restrict__: nothing the kernel writes aliases it, so its fields are
+// fetched with scalar loads and may be hoisted -- through the pointer inside TrkArgs every c.field in thread 0's section was a vector memory load that could not
+// move above the record stores before it.
+__global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const gsh_trk_conf* __restrict__ conf)
 {
     extern __shared__ __align__(16) float lds[];
     __shared__ NextWindow win;
@@ -427,10 +440,11 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
     // latency, and no thread holds a private copy (round 1: ~1 KB of scratch per thread, 1024 threads per channel).
     __shared__ __align__(16) TrkChannel s;
     __shared__ __align__(16) LockState lk;
+    __shared__ SerialMail mail;  // between the lanes that share a period's loop arithmetic (below)
     static_assert(sizeof(TrkChannel) % 4 == 0 && sizeof(LockState) % 4 == 0, "state is copied as 32-bit words");
     const int ch = blockIdx.x;
     const int tid = threadIdx.x;
-    const gsh_trk_conf& c = *a.conf;
+    const gsh_trk_conf& c = *conf;
     {
         const unsigned* gs = reinterpret_cast<const unsigned*>(a.chan + ch);
         const unsigned* gl = reinterpret_cast<const unsigned*>(a.lock + ch);
@@ -498,111 +512,206 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
             const float phase_rate = win.phase_rate, code_rate = win.code_rate;
             // track_pilot in the standard mode: the data-component prompt (trk.cc:1246-1256) rides on the pilot's pass over the window
             const bool fused_data = !HD && c.track_pilot;
-            if (HD)  // set_high_dynamics_resampler(high_dyn), trk.cc:669-675: the high-dynamics resampler + rotator pair
-                correlate_window<NT, 1>(a.stream, wpos, static_cast<int>(c.vector_length), tab, code_len, sh, rem_carr, phase_step, phase_rate, rem_code, code_step, code_rate, red);
-            else if (fused_data)
-                correlate_window_std_aux<NT>(a.stream, wpos, static_cast<int>(c.vector_length), tab, tab_data, sh_data[0], code_len, sh, rem_carr, phase_step, rem_code, code_step, red);
-            else
-                correlate_window_std<NT>(a.stream, wpos, static_cast<int>(c.vector_length), tab, code_len, sh, rem_carr, phase_step, rem_code, code_step, red);
             float2 out[NT];
 #pragma unroll
-            for (int t = 0; t < NT; t++) out[t] = red[t];
+            for (int t = 0; t < NT; t++) out[t] = make_float2(0.0f, 0.0f);
             float2 pdata = make_float2(0.0f, 0.0f);
-            if (fused_data)
-                pdata = red[NT];
-            else if (c.track_pilot)
+            if constexpr (HD)  // set_high_dynamics_resampler(high_dyn), trk.cc:669-675: the high-dynamics resampler + rotator pair
                 {
-                    __syncthreads();  // everyone has read red[0..NT) before it is reused
-                    if (HD)
-                        correlate_window<1, 1>(a.stream, wpos, static_cast<int>(c.vector_length), tab_data, code_len, sh_data, rem_carr, phase_step, phase_rate, rem_code, code_step, code_rate, red);
-                    else
-                        correlate_window_std<1>(a.stream, wpos, static_cast<int>(c.vector_length), tab_data, code_len, sh_data, rem_carr, phase_step, rem_code, code_step, red);
-                    pdata = red[0];
+                    correlate_window<NT, 1>(a.stream, wpos, static_cast<int>(c.vector_length), tab, code_len, sh, rem_carr, phase_step, phase_rate, rem_code, code_step, code_rate, red);
+#pragma unroll
+                    for (int t = 0; t < NT; t++) out[t] = red[t];
+                    if (c.track_pilot)
+                        {
+                            __syncthreads();  // everyone has read red[0..NT) before it is reused
+                            correlate_window<1, 1>(a.stream, wpos, static_cast<int>(c.vector_length), tab_data, code_len, sh_data, rem_carr, phase_step, phase_rate, rem_code, code_step, code_rate, red);
+                            pdata = red[0];
+                        }
+                    __syncthreads();  // win and red have been read by everyone
                 }
-            __syncthreads();  // win and red have been read by everyone
+            else
+                {
+                    // Standard mode: the call returns after its first barrier with one row of partial sums per wave; only the wave that runs the loop arithmetic adds
+                    // them up (sum_wave_partials: same order, same sums), the others go straight on to the barrier that ends the period.  win is rewritten and the
+                    // rows are reused only after that barrier.  (Until round 3: sum by NT threads -> barrier -> every thread read the sums -> barrier.)
+                    if (fused_data)
+                        correlate_window_std_aux<NT, false>(a.stream, wpos, static_cast<int>(c.vector_length), tab, tab_data, sh_data[0], code_len, sh, rem_carr, phase_step, rem_code, code_step, red);
+#ifdef GSH_TRK_PAIRED_TAPS  // early tap read next to the late one: fewer instructions per trip, yet 0.5 us per period slower here (profiles/ab/r03/closed_loop_paired_taps.txt)
+                    else if (NT == 3 && (static_cast<double>(sh[2]) - static_cast<double>(sh[0]) == 1.0) && code_step > 0.0f)  // mcorr_pair_eligible (uniform)
+                        correlate_window_std<NT, true, false>(a.stream, wpos, static_cast<int>(c.vector_length), tab, code_len, sh, rem_carr, phase_step, rem_code, code_step, red);
+#endif
+                    else
+                        correlate_window_std<NT, false, false>(a.stream, wpos, static_cast<int>(c.vector_length), tab, code_len, sh, rem_carr, phase_step, rem_code, code_step, red);
+                    if (tid < 64 * SERIAL_WAVES)  // the waves that hold a lane of the loop arithmetic below
+                        {
+                            float2 sums[NT + 1];
+                            mcdev::sum_wave_partials<NT + 1>(red, sums);
+#pragma unroll
+                            for (int t = 0; t < NT; t++) out[t] = sums[t];
+                            if (fused_data) pdata = sums[NT];
+                        }
+                }
 #ifdef GSH_TRK_PROFILE
             const long long t_corr_done = clock64();
 #endif
-            if (tid == 0)
+            // ---- the loop arithmetic between two correlations.  Round 3: what does not depend on each other runs side by side on lane 0 of three different waves
+            // (three SIMDs: one lane each, a chain of dependent operations) instead of one after the other on thread 0:
+            //   wave 0  accumulators of states 3 / 4, carrier discriminator(s) + FLL/PLL filter              (s.pll, s.p_old_*, s.carrier_doppler_hz are its alone)
+            //   wave 1  code discriminator + DLL filter                                                      (s.dll is its alone; results through `mail`)
+            //   wave 2  cn0_and_tracking_lock_status: C/N0, carrier lock test, smoothers, fail counters      (the lock fields of lk are its alone; verdict through `mail`)
+            // Each derives the few common inputs itself from state it only READS; whatever another lane reads is written by thread 0 after the barrier that
+            // joins them.  The arithmetic of every value is what it was: records are bit-identical to the single-thread order (tests/test_tracking_loop_gpu.py).
+            // On a loss of lock the period's loop-filter updates have happened although the reference skips them (trk.cc:2009-2014) -- nothing reads them again:
+            // the channel stops, and gsh_trk_start builds its state afresh.
+            const double code_period = a.code_period;  // d_code_period
+            float2 acc[NT];
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[t] = out[t];
+            int run_state = 0;
+            bool pull_in = false;
+            double carr_phase_error_hz = 0.0, carr_freq_error_hz = 0.0, carr_error_filt_hz = 0.0;
+            int next_symbol = 0;
+            if ((tid & 63) == 0 && tid < 64 * SERIAL_WAVES)
                 {
-                    const double code_period = static_cast<double>(c.code_length_chips) / c.code_chip_rate;  // d_code_period
                     const int extend = (c.enable_symbol_sync && c.extend_correlation_symbols > 1) ? c.extend_correlation_symbols : 1;
                     // trk.cc:1912-1915: pull-in ends once more than pull_in_time_s whole seconds have passed since acquisition
-                    const bool pull_in = !(static_cast<unsigned long long>(c.pull_in_time_s) < (pos - acq_stamp) / static_cast<unsigned long long>(static_cast<int>(c.fs_in)));
+                    pull_in = (pos - acq_stamp) < a.pull_in_limit;
                     // the accumulators the loop works on (d_VE_accu .. d_VL_accu): the period's outputs in state 2 (trk.cc:1984-1991); in state 4
                     // save_correlation_results adds them, times the secondary code chip, to accumulators zeroed at the end of the previous period
-                    float2 acc[NT];
-#pragma unroll
-                    for (int t = 0; t < NT; t++) acc[t] = out[t];
-                    const int run_state = c.enable_symbol_sync ? lk.state : 0;
+                    run_state = c.enable_symbol_sync ? lk.state : 0;
                     if (run_state == 3 || run_state == 4)
                         {
                             float sgn = 1.0f;
+                            next_symbol = lk.current_symbol;
                             if (c.has_secondary)
                                 {
-                                    sgn = c.secondary_code[lk.current_symbol] == '0' ? 1.0f : -1.0f;
-                                    lk.current_symbol = (lk.current_symbol + 1) % c.secondary_code_length;
+                                    sgn = c.secondary_code[next_symbol] == '0' ? 1.0f : -1.0f;
+                                    next_symbol = (next_symbol + 1) % c.secondary_code_length;
                                 }
 #pragma unroll
                             for (int t = 0; t < NT; t++)
                                 {
-                                    lk.accv[t].x = __fadd_rn(lk.accv[t].x, __fmul_rn(sgn, out[t].x));  // the float += / -= of trk.cc:1493-1512
-                                    lk.accv[t].y = __fadd_rn(lk.accv[t].y, __fmul_rn(sgn, out[t].y));
-                                    acc[t] = lk.accv[t];
+                                    acc[t].x = __fadd_rn(lk.accv[t].x, __fmul_rn(sgn, out[t].x));  // the float += / -= of trk.cc:1493-1512
+                                    acc[t].y = __fadd_rn(lk.accv[t].y, __fmul_rn(sgn, out[t].y));  // (lk.accv itself is updated after the join)
                                 }
-                            const float2 pd = c.track_pilot ? pdata : out[PROMPT];
-                            if (c.symbols_per_bit > 1)
+                        }
+                    const float2 P = acc[PROMPT], E = acc[PROMPT - 1], L = acc[PROMPT + 1];
+                    if (tid == 0)
+                        {
+                            if (run_state == 3 || run_state == 4)
                                 {
-                                    float ds = 1.0f;
-                                    if (c.data_secondary_code_length > 0)
+                                    const float2 pd = c.track_pilot ? pdata : out[PROMPT];
+                                    if (c.symbols_per_bit > 1)
                                         {
-                                            ds = c.data_secondary_code[lk.current_data_symbol] == '0' ? 1.0f : -1.0f;
-                                            lk.current_data_symbol = (lk.current_data_symbol + 1) % c.data_secondary_code_length;
+                                            float ds = 1.0f;
+                                            if (c.data_secondary_code_length > 0)
+                                                {
+                                                    ds = c.data_secondary_code[lk.current_data_symbol] == '0' ? 1.0f : -1.0f;
+                                                    lk.current_data_symbol = (lk.current_data_symbol + 1) % c.data_secondary_code_length;
+                                                }
+                                            else
+                                                {
+                                                    lk.current_data_symbol = (lk.current_data_symbol + 1) % c.symbols_per_bit;
+                                                }
+                                            lk.p_data_accu[0] = __fadd_rn(lk.p_data_accu[0], __fmul_rn(ds, pd.x));
+                                            lk.p_data_accu[1] = __fadd_rn(lk.p_data_accu[1], __fmul_rn(ds, pd.y));
                                         }
                                     else
                                         {
-                                            lk.current_data_symbol = (lk.current_data_symbol + 1) % c.symbols_per_bit;
+                                            lk.p_data_accu[0] = pd.x;
+                                            lk.p_data_accu[1] = pd.y;
                                         }
-                                    lk.p_data_accu[0] = __fadd_rn(lk.p_data_accu[0], __fmul_rn(ds, pd.x));
-                                    lk.p_data_accu[1] = __fadd_rn(lk.p_data_accu[1], __fmul_rn(ds, pd.y));
+                                    lk.cloop = c.track_pilot ? 0 : 1;  // trk.cc:1587-1595
                                 }
-                            else
-                                {
-                                    lk.p_data_accu[0] = pd.x;
-                                    lk.p_data_accu[1] = pd.y;
-                                }
-                            lk.cloop = c.track_pilot ? 0 : 1;  // trk.cc:1587-1595
-                        }
-                    if (a.records != nullptr)  // stored here, while they are at hand (the record's other fields follow at the end of the period): the
-                        {                      // accumulators the loop works on -- what log_data dumps as |d_VE_accu| .. |d_VL_accu| (trk.cc:1624-1636)
-                            float* ra = a.records[static_cast<size_t>(ch) * a.n_epochs + e].accu;
+                            if (a.records != nullptr)  // stored here, while they are at hand (the record's other fields follow at the end of the period): the
+                                {                      // accumulators the loop works on -- what log_data dumps as |d_VE_accu| .. |d_VL_accu| (trk.cc:1624-1636)
+                                    float* ra = a.records[static_cast<size_t>(ch) * a.n_epochs + e].accu;
 #pragma unroll
-                            for (int t = 0; t < 5; t++)  // (all ten slots: the device buffer is not cleared between launches)
+                                    for (int t = 0; t < 5; t++)  // (all ten slots: the device buffer is not cleared between launches)
+                                        {
+                                            ra[2 * t] = (t < NT) ? acc[t < NT ? t : 0].x : 0.0f;
+                                            ra[2 * t + 1] = (t < NT) ? acc[t < NT ? t : 0].y : 0.0f;
+                                        }
+                                }
+                            // ---- run_dll_pll, carrier half, trk.cc:1260-1303 (skipped during coherent integration, state 3: trk.cc:2156-2161)
+                            if (run_state != 3)
                                 {
-                                    ra[2 * t] = (t < NT) ? acc[t < NT ? t : 0].x : 0.0f;
-                                    ra[2 * t + 1] = (t < NT) ? acc[t < NT ? t : 0].y : 0.0f;
+                                    const bool cloop_now = c.enable_symbol_sync ? (lk.cloop != 0) : (c.cloop != 0);
+                                    const double corr_time = (c.enable_symbol_sync && lk.corr_time > 0.0) ? lk.corr_time : code_period;  // d_current_correlation_time_s
+                                    carr_phase_error_hz = (cloop_now ? pll_cloop_two_quadrant_atan_d(P) : pll_four_quadrant_atan_d(P)) / GNSS_TWO_PI_D;
+                                    float carr_error_filt;
+                                    if ((pull_in && c.enable_fll_pull_in) || c.enable_fll_steady_state)
+                                        {
+                                            carr_freq_error_hz = fll_diff_atan_d(make_float2(s.p_old_re, s.p_old_im), P, 0.0, corr_time) / GNSS_TWO_PI_D;
+                                            s.p_old_re = P.x;
+                                            s.p_old_im = P.y;
+                                            if (pull_in && c.enable_fll_pull_in)
+                                                carr_error_filt = fll_pll_carrier_error(s.pll, static_cast<float>(carr_freq_error_hz), 0.0f, static_cast<float>(corr_time));
+                                            else
+                                                carr_error_filt = fll_pll_carrier_error(s.pll, static_cast<float>(carr_freq_error_hz), static_cast<float>(carr_phase_error_hz), static_cast<float>(corr_time));
+                                        }
+                                    else
+                                        {
+                                            carr_error_filt = fll_pll_carrier_error(s.pll, 0.0f, static_cast<float>(carr_phase_error_hz), static_cast<float>(corr_time));
+                                        }
+                                    carr_error_filt_hz = carr_error_filt;
+                                    s.carrier_doppler_hz = carr_error_filt_hz;
                                 }
                         }
-                    const bool cloop_now = c.enable_symbol_sync ? (lk.cloop != 0) : (c.cloop != 0);
-                    const double corr_time = (c.enable_symbol_sync && lk.corr_time > 0.0) ? lk.corr_time : code_period;  // d_current_correlation_time_s
-                    const float spc_now = (c.enable_symbol_sync && lk.narrow) ? lk.spc_now : c.spc;
-                    const float2 P = acc[PROMPT], E = acc[PROMPT - 1], L = acc[PROMPT + 1];
+                    else if (tid == 64)
+                        {
+                            // ---- run_dll_pll, code half, trk.cc:1305-1316
+                            double code_error_chips = 0.0, code_error_filt_chips = 0.0;
+                            if (run_state != 3)
+                                {
+                                    const float spc_now = (c.enable_symbol_sync && lk.narrow) ? lk.spc_now : c.spc;
+                                    if (NT == 5)
+                                        code_error_chips = dll_nc_vemlp_normalized_d(acc[0], acc[1], acc[NT - 2], acc[NT - 1]);
+                                    else
+                                        code_error_chips = dll_nc_e_minus_l_normalized_d(E, L, spc_now, c.slope, c.y_intercept);
+                                    code_error_filt_chips = loop_filter_apply(s.dll, static_cast<float>(code_error_chips));
+                                }
+                            mail.code_error_chips = code_error_chips;
+                            mail.code_error_filt_chips = code_error_filt_chips;
+                        }
+                    else
+                        {
+                            bool lost_now = false;
+                            if (c.enable_lock_detectors)
+                                {
+                                    if (lk.pull_in_latched && !pull_in)  // trk.cc:1912-1916
+                                        {
+                                            lk.pull_in_latched = 0;
+                                            lk.carrier_lock_fail_counter = 0;
+                                            lk.code_lock_fail_counter = 0;
+                                        }
+                                    if (run_state != 3)  // coherent integration runs no lock test (trk.cc:2156-2161)
+                                        lost_now = !lock_status_d(lk, c, P, run_state == 4 ? code_period * static_cast<double>(extend) : code_period, pull_in);  // trk.cc:2008, :2203
+                                }
+                            mail.lost = lost_now ? 1 : 0;
+                        }
+                }
+            __syncthreads();  // the three lanes meet
+#ifdef GSH_TRK_PROFILE
+            const long long t_join = clock64();
+#endif
+            if (tid == 0)
+                {
+                    const int extend = (c.enable_symbol_sync && c.extend_correlation_symbols > 1) ? c.extend_correlation_symbols : 1;
+                    if (run_state == 3 || run_state == 4)  // what the other lanes read above
+                        {
+                            lk.current_symbol = next_symbol;
+#pragma unroll
+                            for (int t = 0; t < NT; t++) lk.accv[t] = acc[t];
+                        }
                     float rec_cn0 = 0.0f;
                     double rec_lock_test = 0.0;
-                    bool lost = false;
                     if (c.enable_lock_detectors)
                         {
-                            if (lk.pull_in_latched && !pull_in)  // trk.cc:1912-1916
-                                {
-                                    lk.pull_in_latched = 0;
-                                    lk.carrier_lock_fail_counter = 0;
-                                    lk.code_lock_fail_counter = 0;
-                                }
-                            if (run_state != 3)  // coherent integration runs no lock test (trk.cc:2156-2161)
-                                lost = !lock_status_d(lk, c, P, run_state == 4 ? code_period * static_cast<double>(extend) : code_period, pull_in);  // trk.cc:2008, :2203
                             rec_cn0 = lk.cn0_db_hz;
                             rec_lock_test = lk.carrier_lock_test;
                         }
+                    const bool lost = mail.lost != 0;
                     if (lost)  // trk.cc:2009-2014: clear_tracking_vars, d_state = 0 -- the channel stops here
                         {
                             if (a.records != nullptr)
@@ -631,37 +740,17 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
                         }
                     else
                         {
-                    // ---- run_dll_pll, trk.cc:1260-1324 (skipped during coherent integration, state 3: trk.cc:2156-2161)
-                    double carr_phase_error_hz = 0.0, carr_freq_error_hz = 0.0, carr_error_filt_hz = 0.0, code_error_chips = 0.0, code_error_filt_chips = 0.0;
+                    // ---- run_dll_pll, the join: trk.cc:1317-1324
+                    const double code_error_chips = mail.code_error_chips, code_error_filt_chips = mail.code_error_filt_chips;
                     if (run_state != 3)
                         {
-                    carr_phase_error_hz = (cloop_now ? pll_cloop_two_quadrant_atan_d(P) : pll_four_quadrant_atan_d(P)) / GNSS_TWO_PI_D;
-                    float carr_error_filt;
-                    if ((pull_in && c.enable_fll_pull_in) || c.enable_fll_steady_state)
-                        {
-                            carr_freq_error_hz = fll_diff_atan_d(make_float2(s.p_old_re, s.p_old_im), P, 0.0, corr_time) / GNSS_TWO_PI_D;
-                            s.p_old_re = P.x;
-                            s.p_old_im = P.y;
-                            if (pull_in && c.enable_fll_pull_in)
-                                carr_error_filt = fll_pll_carrier_error(s.pll, static_cast<float>(carr_freq_error_hz), 0.0f, static_cast<float>(corr_time));
-                            else
-                                carr_error_filt = fll_pll_carrier_error(s.pll, static_cast<float>(carr_freq_error_hz), static_cast<float>(carr_phase_error_hz), static_cast<float>(corr_time));
-                        }
-                    else
-                        {
-                            carr_error_filt = fll_pll_carrier_error(s.pll, 0.0f, static_cast<float>(carr_phase_error_hz), static_cast<float>(corr_time));
-                        }
-                    carr_error_filt_hz = carr_error_filt;
-                    s.carrier_doppler_hz = carr_error_filt_hz;
-                    if (NT == 5)
-                        code_error_chips = dll_nc_vemlp_normalized_d(acc[0], acc[1], acc[NT - 2], acc[NT - 1]);
-                    else
-                        code_error_chips = dll_nc_e_minus_l_normalized_d(E, L, spc_now, c.slope, c.y_intercept);
-                    code_error_filt_chips = loop_filter_apply(s.dll, static_cast<float>(code_error_chips));
-                    s.code_freq_chips = c.code_chip_rate - code_error_filt_chips;
-                    if (c.carrier_aiding) s.code_freq_chips += s.carrier_doppler_hz * c.code_chip_rate / c.signal_carrier_freq;
+                            s.code_freq_chips = c.code_chip_rate - code_error_filt_chips;
+                            if (c.carrier_aiding) s.code_freq_chips += s.carrier_doppler_hz * c.code_chip_rate / c.signal_carrier_freq;
                         }
 
+#ifdef GSH_TRK_PROFILE
+                    const long long t_c = clock64();
+#endif
                     // ---- update_tracking_vars, trk.cc:1409-1483 (rate terms are zero outside high_dyn)
                     const double t_chip = 1.0 / s.code_freq_chips;
                     const double t_prn = t_chip * static_cast<double>(c.code_length_chips);
@@ -722,6 +811,9 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
                     s.rem_code_phase_samples = k_blk - static_cast<double>(prn_len);
                     s.rem_code_phase_chips = s.code_freq_chips * s.rem_code_phase_samples / c.fs_in;
 
+#ifdef GSH_TRK_PROFILE
+                    const long long t_d = clock64();
+#endif
                     // ---- symbol synchronisation (state 2, trk.cc:2026-2112) / symbol output (state 4, :2205-2246)
                     int rec_symbol_flags = 0;
                     float rec_pdata[2] = {0.0f, 0.0f};
@@ -902,13 +994,35 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a)
                             if (NT == 3)  // phase durations in shader clocks, in the unused VE / VL slots
                                 {
                                     r.corr[6] = static_cast<float>(t_corr_done - t_begin);
-                                    r.corr[7] = static_cast<float>(clock64() - t_corr_done);
+                                    const long long t_e = clock64();
+                                    r.corr[7] = static_cast<float>(t_e - t_corr_done);
+                                    r.corr[8] = static_cast<float>(t_join - t_corr_done);  // the three lanes side by side + the barrier that joins them
+                                    r.corr[9] = 0.0f;
+                                    r.accu[6] = static_cast<float>(t_c - t_join);          // the join
+                                    r.accu[7] = static_cast<float>(t_d - t_c);          // update_tracking_vars
+                                    r.accu[8] = static_cast<float>(t_e - t_d);          // symbol bookkeeping + the record
                                 }
 #endif
                         }
                     s.pos = pos + static_cast<unsigned long long>(prn_len);  // consume_each, trk.cc:2287
                     publish(win, s, c, a.n_stream, e + 1 < a.n_epochs, a.ring_oldest);
                     win.narrow = lk.narrow;
+#ifdef GSH_TRK_PROFILE
+                    if (NT == 3 && a.records != nullptr) a.records[static_cast<size_t>(ch) * a.n_epochs + e].accu[9] = static_cast<float>(clock64() - t_corr_done);  // ... + publish
+#if GSH_TRK_PROFILE == 2  // the correlation phase instead of the serial section: window set-up, trips, wave sums, barrier, sum over the waves + barrier, the loop's own barrier
+                    if (NT == 3 && a.records != nullptr)
+                        {
+                            gsh_trk_epoch& r = a.records[static_cast<size_t>(ch) * a.n_epochs + e];
+                            using mcdev::cw_stamp;
+                            r.corr[8] = static_cast<float>(cw_stamp[1] - t_begin);
+                            r.corr[9] = static_cast<float>(cw_stamp[2] - cw_stamp[1]);
+                            r.accu[6] = static_cast<float>(cw_stamp[3] - cw_stamp[2]);
+                            r.accu[7] = static_cast<float>(cw_stamp[4] - cw_stamp[3]);
+                            r.accu[8] = static_cast<float>(cw_stamp[5] - cw_stamp[4]);
+                            r.accu[9] = static_cast<float>(t_corr_done - cw_stamp[5]);
+                        }
+#endif
+#endif
                         }
                 }
             done = e + 1;
@@ -1111,21 +1225,28 @@ int trk_launch(gsh_trk* t, int n_epochs, gsh_trk_epoch* d_records)
     a.records = d_records;
     a.tail = t->d_tail;
     a.n_epochs = n_epochs;
+    a.code_period = static_cast<double>(t->conf.code_length_chips) / t->conf.code_chip_rate;
+    {
+        // trk.cc:1912-1915: the transitory lasts while !(pull_in_time_s < (samples since acquisition) / fs) in integer arithmetic, i.e. while the sample
+        // count is below (pull_in_time_s + 1) * fs -- one comparison per period instead of a 64-bit division
+        const unsigned long long f = static_cast<unsigned long long>(static_cast<int>(t->conf.fs_in));
+        a.pull_in_limit = (static_cast<unsigned long long>(t->conf.pull_in_time_s) + 1ull) * f;
+    }
     const size_t lds = trk_lds_bytes(t);
     const dim3 grid(t->n_channels), block(gsh::mcdev::MC_THREADS);
     if (t->conf.veml)
         {
             if (t->conf.high_dyn)
-                hipLaunchKernelGGL((gsh::trk_loop_kernel<5, true>), grid, block, lds, t->stream, a);
+                hipLaunchKernelGGL((gsh::trk_loop_kernel<5, true>), grid, block, lds, t->stream, a, a.conf);
             else
-                hipLaunchKernelGGL((gsh::trk_loop_kernel<5, false>), grid, block, lds, t->stream, a);
+                hipLaunchKernelGGL((gsh::trk_loop_kernel<5, false>), grid, block, lds, t->stream, a, a.conf);
         }
     else
         {
             if (t->conf.high_dyn)
-                hipLaunchKernelGGL((gsh::trk_loop_kernel<3, true>), grid, block, lds, t->stream, a);
+                hipLaunchKernelGGL((gsh::trk_loop_kernel<3, true>), grid, block, lds, t->stream, a, a.conf);
             else
-                hipLaunchKernelGGL((gsh::trk_loop_kernel<3, false>), grid, block, lds, t->stream, a);
+                hipLaunchKernelGGL((gsh::trk_loop_kernel<3, false>), grid, block, lds, t->stream, a, a.conf);
         }
     GSH_HIP(hipGetLastError());
     if (t->ring != nullptr)

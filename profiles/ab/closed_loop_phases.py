@@ -17,5 +17,13 @@ for ch in (32,):
     ms = loop.time_run(E, reps=3)
     rec, done = loop.run(E)
     tc = np.array([[r.corr[6] for r in rr] for rr in rec]); ts = np.array([[r.corr[7] for r in rr] for rr in rec])
+    if os.environ.get("GSH_PHASE_DETAIL") == "2":  # library built with -DGSH_TRK_PROFILE=2
+        f = lambda get: np.array([[get(r) for r in rr] for rr in rec])[:, 5:].mean()
+        print("  correlation phase, clocks: set-up %.0f  trips %.0f  wave sums + partials %.0f  barrier %.0f  sum over waves + barrier %.0f  read-out + barrier %.0f" % (
+            f(lambda r: r.corr[8]), f(lambda r: r.corr[9]), f(lambda r: r.accu[6]), f(lambda r: r.accu[7]), f(lambda r: r.accu[8]), f(lambda r: r.accu[9])))
+    elif os.environ.get("GSH_PHASE_DETAIL"):
+        f = lambda get: np.array([[get(r) for r in rr] for rr in rec])[:, 5:].mean()
+        print("  serial section, clocks: three lanes side by side + barrier %.0f  join %.0f  update_tracking_vars %.0f  symbol+record %.0f  publish %.0f" % (
+            f(lambda r: r.corr[8]), f(lambda r: r.accu[6]), f(lambda r: r.accu[7]), f(lambda r: r.accu[8]), f(lambda r: r.accu[9]) - f(lambda r: r.corr[7])))
     print("channels", ch, "us/epoch %.3f" % (ms * 1e3 / E), "correlation clocks avg %.0f  serial clocks avg %.0f  (clock64 units)" % (tc[:, 5:].mean(), ts[:, 5:].mean()))
     loop.close()
