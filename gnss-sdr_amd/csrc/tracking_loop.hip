@@ -623,16 +623,6 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                                         }
                                     lk.cloop = c.track_pilot ? 0 : 1;  // trk.cc:1587-1595
                                 }
-                            if (a.records != nullptr)  // stored here, while they are at hand (the record's other fields follow at the end of the period): the
-                                {                      // accumulators the loop works on -- what log_data dumps as |d_VE_accu| .. |d_VL_accu| (trk.cc:1624-1636)
-                                    float* ra = a.records[static_cast<size_t>(ch) * a.n_epochs + e].accu;
-#pragma unroll
-                                    for (int t = 0; t < 5; t++)  // (all ten slots: the device buffer is not cleared between launches)
-                                        {
-                                            ra[2 * t] = (t < NT) ? acc[t < NT ? t : 0].x : 0.0f;
-                                            ra[2 * t + 1] = (t < NT) ? acc[t < NT ? t : 0].y : 0.0f;
-                                        }
-                                }
                             // ---- run_dll_pll, carrier half, trk.cc:1260-1303 (skipped during coherent integration, state 3: trk.cc:2156-2161)
                             if (run_state != 3)
                                 {
@@ -673,9 +663,35 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                                 }
                             mail.code_error_chips = code_error_chips;
                             mail.code_error_filt_chips = code_error_filt_chips;
+                            if (a.records != nullptr)
+                                {
+                                    gsh_trk_epoch& r = a.records[static_cast<size_t>(ch) * a.n_epochs + e];
+                                    r.code_error_chips = code_error_chips;
+                                    r.code_error_filt_chips = code_error_filt_chips;
+                                }
                         }
                     else
                         {
+                            // this lane also writes the part of the period's record that is known before the join (thread 0 adds the loop's outputs after it, or, on a
+                            // loss of lock, clears what does not belong into that record): the accumulators the loop works on -- what log_data dumps as
+                            // |d_VE_accu| .. |d_VL_accu| (trk.cc:1624-1636) --, the correlator outputs, the window's position, state and flags
+                            gsh_trk_epoch* const rp = a.records != nullptr ? a.records + (static_cast<size_t>(ch) * a.n_epochs + e) : nullptr;
+                            if (rp != nullptr)
+                                {
+#pragma unroll
+                                    for (int t = 0; t < 5; t++)  // (all ten slots: the device buffer is not cleared between launches)
+                                        {
+                                            rp->accu[2 * t] = (t < NT) ? acc[t < NT ? t : 0].x : 0.0f;
+                                            rp->accu[2 * t + 1] = (t < NT) ? acc[t < NT ? t : 0].y : 0.0f;
+                                            rp->corr[2 * t] = (t < NT) ? out[t < NT ? t : 0].x : 0.0f;
+                                            rp->corr[2 * t + 1] = (t < NT) ? out[t < NT ? t : 0].y : 0.0f;
+                                        }
+                                    rp->prompt_data[0] = pdata.x;
+                                    rp->prompt_data[1] = pdata.y;
+                                    rp->sample_counter = pos;
+                                    rp->flags = pull_in ? 1 : 0;
+                                    rp->state = run_state;
+                                }
                             bool lost_now = false;
                             if (c.enable_lock_detectors)
                                 {
@@ -689,6 +705,11 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                                         lost_now = !lock_status_d(lk, c, P, run_state == 4 ? code_period * static_cast<double>(extend) : code_period, pull_in);  // trk.cc:2008, :2203
                                 }
                             mail.lost = lost_now ? 1 : 0;
+                            if (rp != nullptr)
+                                {
+                                    rp->cn0_db_hz = c.enable_lock_detectors ? lk.cn0_db_hz : 0.0f;
+                                    rp->carrier_lock_test = c.enable_lock_detectors ? lk.carrier_lock_test : 0.0;
+                                }
                         }
                 }
             __syncthreads();  // the three lanes meet
@@ -741,7 +762,7 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                     else
                         {
                     // ---- run_dll_pll, the join: trk.cc:1317-1324
-                    const double code_error_chips = mail.code_error_chips, code_error_filt_chips = mail.code_error_filt_chips;
+                    const double code_error_filt_chips = mail.code_error_filt_chips;
                     if (run_state != 3)
                         {
                             s.code_freq_chips = c.code_chip_rate - code_error_filt_chips;
@@ -961,33 +982,18 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                     if (a.records != nullptr)
                         {
                             gsh_trk_epoch& r = a.records[static_cast<size_t>(ch) * a.n_epochs + e];  // written in place (every field is assigned)
-                            r.state = run_state;
                             r.carrier_phase_rate_step_rad = s.carrier_phase_rate_step_rad;
                             r.code_phase_rate_step_chips = s.code_phase_rate_step_chips;
                             r.symbol_flags = rec_symbol_flags;
                             r.p_data_accu[0] = rec_pdata[0];
                             r.p_data_accu[1] = rec_pdata[1];
-                            r.sample_counter = pos;
                             r.prn_length_samples = prn_len;
-                            r.flags = pull_in ? 1 : 0;
-#pragma unroll
-                            for (int t = 0; t < 5; t++)
-                                {
-                                    r.corr[2 * t] = (t < NT) ? out[t < NT ? t : 0].x : 0.0f;
-                                    r.corr[2 * t + 1] = (t < NT) ? out[t < NT ? t : 0].y : 0.0f;
-                                }
-                            r.prompt_data[0] = pdata.x;
-                            r.prompt_data[1] = pdata.y;
                             r.rem_carr_phase_rad = s.rem_carr_phase_rad;
-                            r.cn0_db_hz = rec_cn0;
-                            r.carrier_lock_test = rec_lock_test;
                             r.carrier_doppler_hz = s.carrier_doppler_hz;
                             r.code_freq_chips = s.code_freq_chips;
                             r.carr_phase_error_hz = carr_phase_error_hz;
                             r.carr_freq_error_hz = carr_freq_error_hz;
                             r.carr_error_filt_hz = carr_error_filt_hz;
-                            r.code_error_chips = code_error_chips;
-                            r.code_error_filt_chips = code_error_filt_chips;
                             r.rem_code_phase_samples = s.rem_code_phase_samples;
                             r.acc_carrier_phase_rad = s.acc_carrier_phase_rad;
 #ifdef GSH_TRK_PROFILE
