@@ -255,6 +255,24 @@ def acquisition_metric(torch, dev_index, x_block, fs, pmc=None):
     except Exception as e:
         res["split_plan_50000"] = {"error": str(e)}
     try:
+        # BASELINE config 4's acquisition length: Galileo E1, 4 ms at 32 Msps = 128 000 points on the split plan 5 x (25, 32, 32), decimation in time
+        n4, fs4 = 128000, 32e6
+        x4 = torch.view_as_complex(torch.randn(n4, 2, device=x_block.device).contiguous())
+        acq4 = PcpsAcquisitionBank(fs_in=int(fs4), fft_size=n4, doppler_max=5000, doppler_step=250, num_doppler_bins=41, samples_per_chip=int(np.ceil(fs4 / 1.023e6)),
+                                   samples_per_code=float(n4), max_prn=32, device=dev_index, keep_grid=False)
+        rng4 = np.random.default_rng(4)
+        for p in range(32):
+            acq4.set_local_code(p, (rng4.integers(0, 2, n4) * 2 - 1).astype(np.complex64))   # +-1 replicas: the cost does not depend on the code values
+        acq4.time_dwells(x4, 32, reps=20, pipelined=True)
+        ms4_serial = acq4.time_dwells(x4, 32, reps=10)
+        ms4 = acq4.time_dwells(x4, 32, reps=20, pipelined=True)
+        res["split_plan_128000"] = {"workload": "32 PRN x 41 Doppler bins, N=128000 (Galileo E1 4 ms at 32 Msps), 1 dwell, plan 5 x (25,32,32), decimation in time",
+                                    "ms_per_batch": ms4, "ms_per_batch_single_stream": ms4_serial, "value": 32.0 / (ms4 * 1e-3), "unit": "dwells/s",
+                                    "algorithmic_GBs": 16.0 * n4 * 41 * 33 / (ms4 * 1e-3) / 1e9}
+        acq4.close()
+    except Exception as e:
+        res["split_plan_128000"] = {"error": str(e)}
+    try:
         res["cpu_baseline"] = acquisition_cpu_baseline(x_block.cpu().numpy(), fs, n)
     except Exception as e:
         res["cpu_baseline"] = {"error": str(e)}

@@ -37,6 +37,7 @@ struct gsh_acq
     gsh_acq_pair_peak* d_pair{nullptr};  // gsh_acq_noncoherent_pair_peaks: one record per bin
     gsh::RowStat* d_subrows{nullptr};  // split plans (N = S * M): the sub-cells' records, S per (PRN, bin)
     int split{0};
+    float2* d_z{nullptr};              // decimation-in-time split plans (gsh::onchip_dit): the sub-cells' length-M transforms, max_prn * n_bins * n
     gsh::DevAcqResult* d_results{nullptr};
     unsigned* d_arrivals{nullptr};          // on-chip path: per-PRN arrival counters, zero between launches
     gsh::DevAcqResult* h_results{nullptr};  // pinned
@@ -64,6 +65,7 @@ struct gsh_acq
     float2* d_spectra2{nullptr};
     gsh::RowStat* d_rows2{nullptr};
     gsh::RowStat* d_subrows2{nullptr};
+    float2* d_z2{nullptr};
     gsh::DevAcqResult* d_results2{nullptr};
     unsigned* d_arrivals2{nullptr};
     hipEvent_t ev2{nullptr};
@@ -190,7 +192,7 @@ int enqueue_dwell(gsh_acq* a, uint32_t n_prn, int accumulate, uint32_t dwell_cou
             // acq.cc:538-553 + the per-row part of :409-519: one work-group per (PRN, bin) cell, nothing leaves the CU
             return gsh::onchip_correlate(n, a->d_spectra, a->d_codes, a->d_grid, a->d_rows, a->d_subrows, a->d_results, a->d_arrivals, static_cast<int>(n_prn),
                 a->n_bins, c.bit_transition_flag ? eff : 0, eff, accumulate, (c.no_grid && !(a->split > 0 && !c.use_cfar)) ? 0 : 1, static_cast<int>(c.samples_per_chip), c.use_cfar, dwell_count ? dwell_count : 1u,
-                a->grid_weight, a->stream);
+                a->grid_weight, a->stream, a->d_z);
         }
     // acq.cc:657-664 (zero padding) + :531-535 (wipe-off, forward FFT) for every bin
     int rc = gsh::fft_forward(a->plan, a->d_in, 0, static_cast<int>(c.consumed_samples), 0, a->d_bins_hz, static_cast<double>(c.fs_in),
@@ -600,6 +602,11 @@ extern "C"
         if ((e = hipMalloc(&a->d_rows, sizeof(gsh::RowStat) * P * D)) != hipSuccess) return fail(e, "hipMalloc(rows)");
         if (a->split > 0 && (e = hipMalloc(&a->d_subrows, sizeof(gsh::RowStat) * P * std::max<size_t>(D, a->n_bins2) * a->split)) != hipSuccess)
             return fail(e, "hipMalloc(subrows)");
+        if (a->split > 0 && gsh::onchip_dit(static_cast<int>(n)))
+            {
+                const size_t cells = P * std::max<size_t>(D, a->n_bins2);
+                if ((e = hipMalloc(&a->d_z, sizeof(float2) * cells * n)) != hipSuccess) return fail(e, "hipMalloc(sub-cell transforms)");
+            }
         if ((e = hipMalloc(&a->d_results, sizeof(gsh::DevAcqResult) * P)) != hipSuccess) return fail(e, "hipMalloc(results)");
         if ((e = hipMalloc(&a->d_arrivals, sizeof(unsigned) * P)) != hipSuccess) return fail(e, "hipMalloc(arrivals)");
         if ((e = hipMemset(a->d_arrivals, 0, sizeof(unsigned) * P)) != hipSuccess) return fail(e, "hipMemset(arrivals)");
@@ -639,6 +646,8 @@ extern "C"
         if (a->d_grid) (void)hipFree(a->d_grid);
         if (a->d_rows) (void)hipFree(a->d_rows);
         if (a->d_subrows) (void)hipFree(a->d_subrows);
+        if (a->d_z) (void)hipFree(a->d_z);
+        if (a->d_z2) (void)hipFree(a->d_z2);
         if (a->d_pair) (void)hipFree(a->d_pair);
         if (a->d_subrows2) (void)hipFree(a->d_subrows2);
         if (a->d_results) (void)hipFree(a->d_results);
@@ -936,7 +945,7 @@ extern "C"
                         rc = gsh::onchip_correlate(nfft, a->d_spectra, a->d_codes + static_cast<size_t>(slot) * nfft, grid, a->d_rows + static_cast<size_t>(i) * D2,
                             a->d_subrows ? a->d_subrows + static_cast<size_t>(i) * D2 * a->split : nullptr,
                             a->d_results + i, a->d_arrivals + i, 1, D2, c.bit_transition_flag ? eff : 0, eff, accumulate, (c.no_grid && !(a->split > 0 && !c.use_cfar)) ? 0 : 1, static_cast<int>(c.samples_per_chip), c.use_cfar,
-                            dwell_count ? dwell_count : 1u, a->grid_weight, a->stream);
+                            dwell_count ? dwell_count : 1u, a->grid_weight, a->stream, a->d_z ? a->d_z + static_cast<size_t>(i) * D2 * nfft : nullptr);
                     }
                 else
                     {
@@ -1154,6 +1163,10 @@ extern "C"
                 GSH_HIP(hipMalloc(&a->d_spectra2, sizeof(float2) * D * n));
                 GSH_HIP(hipMalloc(&a->d_rows2, sizeof(gsh::RowStat) * P * D));
                 if (a->split > 0) GSH_HIP(hipMalloc(&a->d_subrows2, sizeof(gsh::RowStat) * P * D * a->split));
+                if (a->d_z != nullptr)
+                    {
+                        GSH_HIP(hipMalloc(&a->d_z2, sizeof(float2) * P * D * n));
+                    }
                 GSH_HIP(hipMalloc(&a->d_results2, sizeof(gsh::DevAcqResult) * P));
                 GSH_HIP(hipMalloc(&a->d_arrivals2, sizeof(unsigned) * P));
                 GSH_HIP(hipMemset(a->d_arrivals2, 0, sizeof(unsigned) * P));
@@ -1169,7 +1182,8 @@ extern "C"
             // no_grid handles only: two batches in flight must not share the magnitude grid
             return gsh::onchip_correlate(static_cast<int>(n), spectra, a->d_codes, a->d_grid, lane ? a->d_rows2 : a->d_rows, lane ? a->d_subrows2 : a->d_subrows,
                 lane ? a->d_results2 : a->d_results, lane ? a->d_arrivals2 : a->d_arrivals, static_cast<int>(n_prn), a->n_bins,
-                c.bit_transition_flag ? static_cast<int>(c.effective_fft_size) : 0, static_cast<int>(c.effective_fft_size), 0, 0, static_cast<int>(c.samples_per_chip), c.use_cfar, 1u, 1.0f, st);
+                c.bit_transition_flag ? static_cast<int>(c.effective_fft_size) : 0, static_cast<int>(c.effective_fft_size), 0, 0, static_cast<int>(c.samples_per_chip), c.use_cfar, 1u, 1.0f, st,
+                lane ? a->d_z2 : a->d_z);
         };
         int rc = enqueue(0);  // warm-up on both lanes
         if (rc == GSH_OK) rc = enqueue(1);

@@ -80,6 +80,9 @@ int grid_statistics(const float* grid, RowStat* rows, DevAcqResult* results, int
 bool onchip_supported(int n);
 // N = S * M with M planned (GSH_OC_SPLIT_PLANS): S, or 0.  A cell is then S independent work-groups; no second-peak statistic, no folding.
 int onchip_split(int n);
+// split plans that run decimation in time (pcps_onchip.hip, oc_subcell_dit_kernel + oc_combine_dit_kernel): their spectra -- signal and code, everything
+// onchip_forward writes for this length -- are stored residue-major, and onchip_correlate needs the scratch `z` (n_prn * n_bins * n values)
+bool onchip_dit(int n);
 int onchip_forward(int n, const float2* src, size_t src_stride, int n_in, int place_off, const float* wipe_hz, double fs, float2* dst,
     int batch, hipStream_t s, int fold = 1);
 // one work-group per (PRN, bin) cell: spectrum product, inverse transform, |.|^2, row statistics, and (by the last cell
@@ -89,6 +92,6 @@ int onchip_forward(int n, const float2* src, size_t src_stride, int n_in, int pl
 // subrows: n_prn * n_bins * onchip_split(n) records (split plans only, else nullptr)
 int onchip_correlate(int n, const float2* spectra, const float2* codes, float* grid, RowStat* rows, RowStat* subrows, DevAcqResult* results,
     unsigned* arrivals, int n_prn, int n_bins, int offset, int effective, int accumulate, int store_grid, int samples_per_chip, int use_cfar,
-    unsigned dwell_count, float weight, hipStream_t s);
+    unsigned dwell_count, float weight, hipStream_t s, float2* z = nullptr);
 }  // namespace gsh
 #endif

@@ -26,9 +26,15 @@
 #include "pcps_fft.h"
 #include "fft_onchip.h"
 #include <cmath>
+#include <cstdlib>
+
+#ifndef GSH_OC_DIT_MIN_S
+#define GSH_OC_DIT_MIN_S 4
+#endif
 
 namespace gsh
 {
+int onchip_split(int n);
 namespace
 {
 using oc::cf;
@@ -46,6 +52,8 @@ struct OcFwdArgs
     cf* dst;
     int fold;  // > 1: the wiped-off input is summed over `fold` segments of N samples (pcps_quicksync_acquisition_cc.cc:243-263)
                // (S == 1 only)
+    int residue_major;  // split plans: 1 = sub-transform r writes X[S m + r] at dst[r M + m] (the decimation-in-time cells read one residue class each);
+                        // 0 = natural order dst[S m + r]
 };
 
 struct OcCellArgs
@@ -65,6 +73,7 @@ struct OcCellArgs
     int use_cfar;
     unsigned dwell_count;
     float weight;  // GRID path: every |.|^2 is scaled before it is added / stored (pcps_tong_acquisition_cc.cc:243-249); 1 otherwise
+    cf* z;  // decimation-in-time split (oc_subcell_dit_kernel / oc_combine_dit_kernel): the sub-cells' length-M transforms, n_prn * n_bins * N values
 };
 
 // x[k] for 0 <= k < n_in, else 0 -- as a load from a clamped index plus a select, not a branch around the load: the compiler turns the
@@ -271,8 +280,16 @@ __global__ __launch_bounds__(P::THREADS) void oc_forward_split_kernel(OcFwdArgs 
     if (t < P::T3)
         {
             P::stage3(rc);
-            cf* __restrict__ dst = a.dst + static_cast<size_t>(b) * N + static_cast<size_t>(t) * S + r;
-            oc::static_for<P::R3>([&](auto K3) GSH_AI { dst[static_cast<size_t>(decltype(K3)::value) * P::T3 * S] = rc[decltype(K3)::value]; });
+            if (a.residue_major)  // uniform
+                {
+                    cf* __restrict__ dst = a.dst + static_cast<size_t>(b) * N + static_cast<size_t>(r) * M + t;
+                    oc::static_for<P::R3>([&](auto K3) GSH_AI { dst[decltype(K3)::value * P::T3] = rc[decltype(K3)::value]; });
+                }
+            else
+                {
+                    cf* __restrict__ dst = a.dst + static_cast<size_t>(b) * N + static_cast<size_t>(t) * S + r;
+                    oc::static_for<P::R3>([&](auto K3) GSH_AI { dst[static_cast<size_t>(decltype(K3)::value) * P::T3 * S] = rc[decltype(K3)::value]; });
+                }
         }
 }
 
@@ -284,6 +301,118 @@ __device__ __forceinline__ void argmax_merge(float& v, unsigned& i, float ov, un
             v = ov;
             i = oi;
         }
+}
+
+// ---- publish a row record; the LAST cell of its PRN to arrive forms the PRN's statistic (acq.cc:409-519).  Called by every thread of the work-group;
+// `sum` / `second` are thread 0's.  S > 1: the record is one of the row's S sub-cell records (merged by the last arriver); S == 1: the whole row's.
+// Placement-independent hand-off: plain store -> agent-scope release -> relaxed ticket; the last arriver acquires.
+template <int S>
+__device__ __forceinline__ void publish_row(const OcCellArgs& a, int prn, int cell, int r, float peak, unsigned tau, float sum, float second, unsigned* s_i)
+{
+    const int t = threadIdx.x;
+    if (t == 0)
+        {
+            RowStat rec;
+            rec.maxv = peak;
+            rec.idx = tau;
+            rec.sum = sum;
+            rec.second = second;
+            if constexpr (S == 1)
+                a.rows[cell] = rec;
+            else
+                a.subrows[static_cast<size_t>(cell) * S + r] = rec;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned ticket = __hip_atomic_fetch_add(&a.arrivals[prn], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_i[0] = (ticket == static_cast<unsigned>(a.n_bins * S) - 1u) ? 1u : 0u;
+        }
+    __syncthreads();
+    if (s_i[0] == 0u || t >= 64) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    {
+        // bin scan of acq.cc:417-426 / :463-474 over one wave: gmax starts at 0 and only a strictly larger row
+        // maximum replaces it, so ties keep the lowest bin
+        RowStat* rs = a.rows + static_cast<size_t>(prn) * a.n_bins;
+        // S > 1: a row is the union of its S sub-cells' lags -- maximum with the lowest index among equals, sums added; the merged record is
+        // also what gsh_acq_read_row_peaks hands out
+        auto row_of = [&](int d) GSH_AI -> RowStat {
+            if constexpr (S == 1)
+                return rs[d];
+            else
+                {
+                    const RowStat* __restrict__ sub = a.subrows + (static_cast<size_t>(prn) * a.n_bins + d) * S;
+                    RowStat m = sub[0];
+                    for (int q = 1; q < S; q++)
+                        {
+                            const RowStat o = sub[q];
+                            argmax_merge(m.maxv, m.idx, o.maxv, o.idx);
+                            m.sum += o.sum;
+                        }
+                    return m;
+                }
+        };
+        float gmax = 0.0f;
+        unsigned gbin = 0xFFFFFFFFu, gtau = 0u;
+        for (int d = t; d < a.n_bins; d += 64)
+            {
+                const RowStat rw = row_of(d);
+                if constexpr (S > 1) rs[d] = rw;
+                if (rw.maxv > gmax)
+                    {
+                        gmax = rw.maxv;
+                        gbin = static_cast<unsigned>(d);
+                        gtau = rw.idx;
+                    }
+            }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+            {
+                const float ov = __shfl_down(gmax, off, 64);
+                const unsigned ob = __shfl_down(gbin, off, 64);
+                const unsigned ot = __shfl_down(gtau, off, 64);
+                if (ov > gmax || (ov == gmax && ob < gbin))
+                    {
+                        gmax = ov;
+                        gbin = ob;
+                        gtau = ot;
+                    }
+            }
+        if (t == 0)
+            {
+                if (gbin == 0xFFFFFFFFu)  // every row maximum was 0: the reference leaves bin 0 / index 0
+                    {
+                        gbin = 0u;
+                        gtau = 0u;
+                    }
+                DevAcqResult out;
+                out.index_time = gtau;
+                out.index_doppler = gbin;
+                out.peak = gmax;
+                out.input_power = 0.0f;
+                out.second_peak = 0.0f;
+                out.test_statistics = 0.0f;
+                if (a.use_cfar)
+                    {
+                        // acq.cc:429-431: power of the bin half a grid away, / effective / 2 / dwells
+                        const unsigned opp = (gbin + static_cast<unsigned>(a.n_bins) / 2u) % static_cast<unsigned>(a.n_bins);
+                        const float per_sample = row_of(static_cast<int>(opp)).sum / static_cast<float>(static_cast<unsigned>(a.effective));
+                        const float power = static_cast<float>(static_cast<double>(per_sample) / 2.0 / static_cast<double>(a.dwell_count));
+                        out.input_power = power;
+                        out.test_statistics = (power < 1.1920928955078125e-07f) ? 0.0f : gmax / power;  // acq.cc:438-445
+                    }
+                else
+                    {
+                        // (S > 1: no sub-cell sees the whole row; oc_second_peak_kernel, queued right behind this launch, scans the stored winning
+                        // row and fills in second_peak / test_statistics)
+                        const float second_pk = (S == 1) ? row_of(static_cast<int>(gbin)).second : 0.0f;
+                        out.second_peak = second_pk;
+                        out.test_statistics = (S == 1) ? gmax / second_pk : 0.0f;  // acq.cc:516
+                    }
+                a.results[prn] = out;
+                __hip_atomic_store(&a.arrivals[prn], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+            }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -502,111 +631,153 @@ __global__ __launch_bounds__(P::THREADS) void oc_cell_kernel(OcCellArgs a)
                 for (int w = 1; w < n_waves; w++) second = fmaxf(second, s_v[w]);
         }
 
-    // ---- publish the row record; the LAST cell of this PRN to arrive forms the PRN's statistic (acq.cc:409-519).
-    // Placement-independent hand-off: plain store -> agent-scope release -> relaxed ticket; the last arriver acquires.
-    if (t == 0)
+    publish_row<S>(a, prn, cell, r, s_peak, s_tau, sum, second, s_i);
+}
+
+// ---- N = S * M, decimation in time (round 3).  The sub-cells of oc_cell_kernel<P, S> (decimation in frequency) each read the WHOLE product spectrum --
+// S times the loads, which is what bounds S >= 4.  Here the spectra are stored residue-major (OcFwdArgs::residue_major: class r of
+// X at [r M, (r + 1) M)), and with Y = conj(X) C,  y[tau] = sum_k Y[k] W_N^{k tau},  k = S k' + r:
+//     y[t' + M j] = sum_r ( Z_r[t'] W_N^{r t'} ) W_S^{r j},      Z_r = FFT_M( Y[S k' + r] over k' ).
+// oc_subcell_dit_kernel: sub-cell r reads ONLY residue class r of both spectra (2 M values: what a plain M-point cell reads), runs the unchanged three-stage
+// plan and leaves Z_r in `z`.  oc_combine_dit_kernel, the next launch on the stream: one work-group per cell -- per t' the S values, their twiddles, one
+// S-point DFT in registers, |.|^2 of the S lags t' + M j, the row's statistics -- publishes the row like a plain cell.
+// (Two launches, not a last-arriver hand-off inside one: the sub-cells of a cell run on different compute units, and making Z_r visible between them costs
+// an agent-scope release per sub-cell and an acquire per cell -- L2 write-backs and invalidations that the whole XCD pays for: 3.7 ms instead of 1.44 ms at
+// 128 000 points, profiles/ab/r03/acq_dit.txt.  The kernel boundary does the same for nothing.)
+template <class P, int S>
+__global__ __launch_bounds__(P::THREADS) void oc_subcell_dit_kernel(OcCellArgs a)
+{
+    constexpr int M = P::N, N = S * P::N;
+    GSH_OC_LDS_DECL(P);
+    const int xcd = static_cast<int>(blockIdx.x & 7u), slot_r = static_cast<int>(blockIdx.x >> 3);
+    const int slot = slot_r / S, r = slot_r - slot * S;
+    const int xp_i = xcd % a.xp, xb_i = xcd / a.xp;
+    const int bl = slot / a.prn_per, pl = slot - bl * a.prn_per;
+    const int prn = xp_i * a.prn_per + pl, bin = xb_i * a.bin_per + bl;
+    if (prn >= a.n_prn || bin >= a.n_bins) return;  // uniform over the work-group
+    const int cell = prn * a.n_bins + bin;
+    const int t = threadIdx.x;
+    cf ra[P::R1], rb[P::R2], rc[P::R3];
+    if (t < P::T1)
         {
-            RowStat rec;
-            rec.maxv = s_peak;
-            rec.idx = s_tau;
-            rec.sum = sum;
-            rec.second = second;
-            if constexpr (S == 1)
-                a.rows[cell] = rec;
-            else
-                a.subrows[static_cast<size_t>(cell) * S + r] = rec;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const unsigned ticket = __hip_atomic_fetch_add(&a.arrivals[prn], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_i[0] = (ticket == static_cast<unsigned>(a.n_bins * S) - 1u) ? 1u : 0u;
+            const cf* __restrict__ X = a.spectra + static_cast<size_t>(bin) * N + static_cast<size_t>(r) * M + t;
+            const cf* __restrict__ C = a.codes + static_cast<size_t>(prn) * N + static_cast<size_t>(r) * M + t;
+            cf xv[P::R1], cv[P::R1];
+            oc::static_for<P::R1>([&](auto N1) GSH_AI {
+                constexpr int n1 = decltype(N1)::value;
+                xv[n1] = X[n1 * P::T1];
+                cv[n1] = C[n1 * P::T1];
+            });
+            __builtin_amdgcn_sched_group_barrier(0x20, 2 * P::R1, 0);  // VMEM reads first ...
+            oc::static_for<P::R1>([&](auto N1) GSH_AI {
+                constexpr int n1 = decltype(N1)::value;
+                ra[n1] = oc::cmul_conj(xv[n1], cv[n1]);
+            });
+            __builtin_amdgcn_sched_group_barrier(0x2, 8 * P::R1, 0);   // ... then the products
+            P::stage1(ra, t);
+        }
+    exchange1<P>(ra, rb, t, lds);
+    if (t < P::T2) P::stage2(rb, t);
+    exchange2<P>(rb, rc, t, lds);
+    if (t < P::T3)
+        {
+            P::stage3(rc);
+            cf* __restrict__ zo = a.z + static_cast<size_t>(cell) * N + static_cast<size_t>(r) * M + t;
+            oc::static_for<P::R3>([&](auto K3) GSH_AI { zo[decltype(K3)::value * P::T3] = rc[decltype(K3)::value]; });
+        }
+}
+
+constexpr int OC_COMBINE_THREADS = 1024;
+template <int M, int S, bool GRID, bool OFF>
+__global__ __launch_bounds__(OC_COMBINE_THREADS) void oc_combine_dit_kernel(OcCellArgs a)
+{
+    static_assert(GRID || !OFF, "the upper-half searches are instantiated on the GRID flavour only");
+    constexpr int N = S * M;
+    __shared__ float s_v[OC_MAX_WAVES];
+    __shared__ unsigned s_i[OC_MAX_WAVES];
+    __shared__ float s_s[OC_MAX_WAVES];
+    const int cell = blockIdx.x;
+    const int prn = cell / a.n_bins;
+    const int t = threadIdx.x;
+    float best = -1.0f, sum = 0.0f;
+    unsigned at = 0xFFFFFFFFu;
+    {
+        const cf* __restrict__ zc = a.z + static_cast<size_t>(cell) * N;
+        float* __restrict__ g = a.grid + static_cast<size_t>(cell) * a.effective;
+        const int offset = OFF ? a.offset : 0;
+        // twiddles W_N^{r m}, r = 1 .. S-1, for m = t, t + THREADS, ...: exact seeds, then one complex product per step (at most M / THREADS steps: 25)
+        cf tw[S], step[S];
+        oc::static_for<S>([&](auto R) GSH_AI {
+            constexpr int rr = decltype(R)::value;
+            tw[rr] = oc::unit_root(static_cast<int>((static_cast<long long>(rr) * t) % N), N);
+            step[rr] = oc::unit_root(static_cast<int>((static_cast<long long>(rr) * OC_COMBINE_THREADS) % N), N);
+        });
+        // one (maximum, index) tracker per j: a thread meets the lags t + M j + THREADS i of one j in ascending order, so a strict '>' keeps the lowest index
+        float bj[S];
+        unsigned aj[S];
+        oc::static_for<S>([&](auto J) GSH_AI {
+            bj[decltype(J)::value] = -1.0f;
+            aj[decltype(J)::value] = 0xFFFFFFFFu;
+        });
+#pragma clang loop unroll(disable)
+        for (int m = t; m < M; m += OC_COMBINE_THREADS)
+            {
+                cf u[S];
+                oc::static_for<S>([&](auto R) GSH_AI { u[decltype(R)::value] = zc[static_cast<size_t>(decltype(R)::value) * M + m]; });
+                oc::static_for<S>([&](auto R) GSH_AI {
+                    constexpr int rr = decltype(R)::value;
+                    if constexpr (rr > 0)
+                        {
+                            u[rr] = oc::cmul(u[rr], tw[rr]);  // u[r] *= W_N^{r m}
+                            tw[rr] = oc::cmul(tw[rr], step[rr]);
+                        }
+                });
+                oc::Dft<S>::run(u);  // u[j] = y[m + M j]
+                oc::static_for<S>([&](auto J) GSH_AI {
+                    constexpr int j = decltype(J)::value;
+                    const int idx = m + M * j - offset;  // the lag's index in the search (acq.cc:544)
+                    float v = oc::norm2(u[j]);
+                    const bool in = !OFF || idx >= 0;
+                    if constexpr (GRID)
+                        {
+                            v *= a.weight;
+                            if (a.accumulate && in) v += g[idx];  // acq.cc:549-553
+                            if (a.store_grid && in) g[idx] = v;
+                        }
+                    if constexpr (OFF) v = in ? v : -1.0f;  // never better than a tracker's start value
+                    sum += (OFF && !in) ? 0.0f : v;
+                    const bool better = v > bj[j];
+                    bj[j] = better ? v : bj[j];
+                    aj[j] = better ? static_cast<unsigned>(idx) : aj[j];
+                });
+            }
+        oc::static_for<S>([&](auto J) GSH_AI { argmax_merge(best, at, bj[decltype(J)::value], aj[decltype(J)::value]); });
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        {
+            const float ov = __shfl_down(best, off, 64);
+            const unsigned oi = __shfl_down(at, off, 64);
+            sum += __shfl_down(sum, off, 64);
+            argmax_merge(best, at, ov, oi);
+        }
+    const int wave = t >> 6;
+    constexpr int n_waves = OC_COMBINE_THREADS / 64;
+    if ((t & 63) == 0)
+        {
+            s_v[wave] = best;
+            s_i[wave] = at;
+            s_s[wave] = sum;
         }
     __syncthreads();
-    if (s_i[0] == 0u || t >= 64) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    {
-        // bin scan of acq.cc:417-426 / :463-474 over one wave: gmax starts at 0 and only a strictly larger row
-        // maximum replaces it, so ties keep the lowest bin
-        RowStat* rs = a.rows + static_cast<size_t>(prn) * a.n_bins;
-        // S > 1: a row is the union of its S sub-cells' lags -- maximum with the lowest index among equals, sums added; the merged record is
-        // also what gsh_acq_read_row_peaks hands out
-        auto row_of = [&](int d) GSH_AI -> RowStat {
-            if constexpr (S == 1)
-                return rs[d];
-            else
-                {
-                    const RowStat* __restrict__ sub = a.subrows + (static_cast<size_t>(prn) * a.n_bins + d) * S;
-                    RowStat m = sub[0];
-                    for (int q = 1; q < S; q++)
-                        {
-                            const RowStat o = sub[q];
-                            argmax_merge(m.maxv, m.idx, o.maxv, o.idx);
-                            m.sum += o.sum;
-                        }
-                    return m;
-                }
-        };
-        float gmax = 0.0f;
-        unsigned gbin = 0xFFFFFFFFu, gtau = 0u;
-        for (int d = t; d < a.n_bins; d += 64)
+    if (t == 0)
+        for (int w = 1; w < n_waves; w++)
             {
-                const RowStat rw = row_of(d);
-                if constexpr (S > 1) rs[d] = rw;
-                if (rw.maxv > gmax)
-                    {
-                        gmax = rw.maxv;
-                        gbin = static_cast<unsigned>(d);
-                        gtau = rw.idx;
-                    }
+                argmax_merge(best, at, s_v[w], s_i[w]);
+                sum += s_s[w];
             }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1)
-            {
-                const float ov = __shfl_down(gmax, off, 64);
-                const unsigned ob = __shfl_down(gbin, off, 64);
-                const unsigned ot = __shfl_down(gtau, off, 64);
-                if (ov > gmax || (ov == gmax && ob < gbin))
-                    {
-                        gmax = ov;
-                        gbin = ob;
-                        gtau = ot;
-                    }
-            }
-        if (t == 0)
-            {
-                if (gbin == 0xFFFFFFFFu)  // every row maximum was 0: the reference leaves bin 0 / index 0
-                    {
-                        gbin = 0u;
-                        gtau = 0u;
-                    }
-                DevAcqResult out;
-                out.index_time = gtau;
-                out.index_doppler = gbin;
-                out.peak = gmax;
-                out.input_power = 0.0f;
-                out.second_peak = 0.0f;
-                out.test_statistics = 0.0f;
-                if (a.use_cfar)
-                    {
-                        // acq.cc:429-431: power of the bin half a grid away, / effective / 2 / dwells
-                        const unsigned opp = (gbin + static_cast<unsigned>(a.n_bins) / 2u) % static_cast<unsigned>(a.n_bins);
-                        const float per_sample = row_of(static_cast<int>(opp)).sum / static_cast<float>(static_cast<unsigned>(a.effective));
-                        const float power = static_cast<float>(static_cast<double>(per_sample) / 2.0 / static_cast<double>(a.dwell_count));
-                        out.input_power = power;
-                        out.test_statistics = (power < 1.1920928955078125e-07f) ? 0.0f : gmax / power;  // acq.cc:438-445
-                    }
-                else
-                    {
-                        // (S > 1: no sub-cell sees the whole row; oc_second_peak_kernel, queued right behind this launch, scans the stored winning
-                        // row and fills in second_peak / test_statistics)
-                        const float second_pk = (S == 1) ? row_of(static_cast<int>(gbin)).second : 0.0f;
-                        out.second_peak = second_pk;
-                        out.test_statistics = (S == 1) ? gmax / second_pk : 0.0f;  // acq.cc:516
-                    }
-                a.results[prn] = out;
-                __hip_atomic_store(&a.arrivals[prn], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
-            }
-    }
+    __syncthreads();  // s_i is reused by publish_row
+    publish_row<1>(a, prn, cell, 0, best, at, sum, 0.0f, s_i);
 }
 
 // ---- first_vs_second_peak_statistic on a split plan (acq.cc:485-516).  The S sub-cells of a row each own every S-th lag, so none of them can blank
@@ -714,7 +885,55 @@ int launch_cells(const OcCellArgs& a, int n_blocks, hipStream_t s)
     GSH_HIP(hipGetLastError());
     return GSH_OK;
 }
+
+template <class P, int S>
+int launch_cells_dit(const OcCellArgs& a, int n_blocks, hipStream_t s)
+{
+    const bool grid = a.accumulate || a.store_grid;
+    const bool off = a.offset != 0;
+    GSH_REQUIRE(!a.want_second || (a.store_grid && a.grid != nullptr), "the peak-ratio statistic on a split plan scans the stored winning row: it needs the grid");
+    GSH_REQUIRE(a.z != nullptr, "decimation-in-time split without its scratch");
+    hipLaunchKernelGGL((oc_subcell_dit_kernel<P, S>), dim3(n_blocks), dim3(P::THREADS), 0, s, a);
+    GSH_HIP(hipGetLastError());
+    const dim3 cells(static_cast<unsigned>(a.n_prn * a.n_bins)), threads(OC_COMBINE_THREADS);
+    if (off)
+        hipLaunchKernelGGL((oc_combine_dit_kernel<P::N, S, true, true>), cells, threads, 0, s, a);
+    else if (grid)
+        hipLaunchKernelGGL((oc_combine_dit_kernel<P::N, S, true, false>), cells, threads, 0, s, a);
+    else
+        hipLaunchKernelGGL((oc_combine_dit_kernel<P::N, S, false, false>), cells, threads, 0, s, a);
+    if (a.want_second)
+        {
+            GSH_HIP(hipGetLastError());
+            OcSecondArgs sa;
+            sa.grid = a.grid;
+            sa.results = a.results;
+            sa.n_bins = a.n_bins;
+            sa.effective = a.effective;
+            sa.samples_per_chip = a.samples_per_chip;
+            hipLaunchKernelGGL(oc_second_peak_kernel, dim3(a.n_prn), dim3(1024), 0, s, sa);
+        }
+    GSH_HIP(hipGetLastError());
+    return GSH_OK;
+}
 }  // namespace
+
+// split plans with at least this many sub-cells run decimation in time (GSH_OC_DIT_MIN_S in the environment overrides: 0 = never)
+int onchip_dit_min_s()
+{
+    static const int v = [] {
+        const char* e = std::getenv("GSH_OC_DIT_MIN_S");
+        return e != nullptr ? std::atoi(e) : GSH_OC_DIT_MIN_S;
+    }();
+    return v;
+}
+
+bool onchip_dit(int n)
+{
+    const int sp = onchip_split(n);
+    const int min_s = onchip_dit_min_s();
+    return sp > 0 && min_s > 0 && sp >= min_s;
+}
 
 bool onchip_supported(int n)
 {
@@ -746,6 +965,7 @@ int onchip_forward(int n, const float2* src, size_t src_stride, int n_in, int pl
     a.wipe_hz = wipe_hz;
     a.inv_fs = 1.0 / fs;
     a.dst = reinterpret_cast<cf*>(dst);
+    a.residue_major = onchip_dit(n) ? 1 : 0;
     a.fold = fold;
 #define GSH_OC_CASE(r1, r2, r3) \
     if (n == (r1) * (r2) * (r3)) return launch_forward<oc::Plan<r1, r2, r3>>(a, batch, s);
@@ -760,7 +980,7 @@ int onchip_forward(int n, const float2* src, size_t src_stride, int n_in, int pl
 
 int onchip_correlate(int n, const float2* spectra, const float2* codes, float* grid, RowStat* rows, RowStat* subrows, DevAcqResult* results,
     unsigned* arrivals, int n_prn, int n_bins, int offset, int effective, int accumulate, int store_grid, int samples_per_chip, int use_cfar,
-    unsigned dwell_count, float weight, hipStream_t s)
+    unsigned dwell_count, float weight, hipStream_t s, float2* z)
 {
     if (n_prn <= 0 || n_bins <= 0) return GSH_OK;
     GSH_REQUIRE((offset == 0 && effective == n) || (2 * offset == n && effective == offset), "lags [%d, %d + %d) of a %d-point transform: neither all of it nor its upper half", offset, offset, effective, n);
@@ -770,6 +990,7 @@ int onchip_correlate(int n, const float2* spectra, const float2* codes, float* g
     a.grid = grid;
     a.rows = rows;
     a.subrows = subrows;
+    a.z = reinterpret_cast<cf*>(z);
     a.offset = offset;
     a.results = results;
     a.arrivals = arrivals;
@@ -794,8 +1015,10 @@ int onchip_correlate(int n, const float2* spectra, const float2* codes, float* g
     if (n == (r1) * (r2) * (r3)) return launch_cells<oc::Plan<r1, r2, r3>, 1>(a, n_blocks, s);
     GSH_OC_PLANS(GSH_OC_CASE)
 #undef GSH_OC_CASE
-#define GSH_OC_CASE(sp, r1, r2, r3) \
-    if (n == (sp) * (r1) * (r2) * (r3)) return launch_cells<oc::Plan<r1, r2, r3>, sp>(a, n_blocks * (sp), s);
+    const bool dit = onchip_dit(n);
+#define GSH_OC_CASE(sp, r1, r2, r3)                                                                              \
+    if (n == (sp) * (r1) * (r2) * (r3))                                                                          \
+        return dit ? launch_cells_dit<oc::Plan<r1, r2, r3>, sp>(a, n_blocks * (sp), s) : launch_cells<oc::Plan<r1, r2, r3>, sp>(a, n_blocks * (sp), s);
     GSH_OC_SPLIT_PLANS(GSH_OC_CASE)
 #undef GSH_OC_CASE
     return set_error(GSH_ERR_UNSUPPORTED, "no on-chip plan for fft_size %d", n);
