@@ -84,8 +84,8 @@ class TrkConf(C.Structure):
                 ("data_secondary_code_length", C.c_int32), ("extend_correlation_symbols", C.c_int32), ("secondary_code", C.c_uint8 * 320), ("data_secondary_code", C.c_uint8 * 320),
                 ("pll_bw_narrow_hz", C.c_float), ("dll_bw_narrow_hz", C.c_float), ("early_late_space_narrow_chips", C.c_float), ("very_early_late_space_narrow_chips", C.c_float),
                 ("use_histogram_bit_sync", C.c_int32), ("bs_min_events_for_lock", C.c_int32), ("bs_stable_best_required", C.c_int32),
-                ("bs_use_phase_dot_detector", C.c_int32), ("bs_min_prompt_mag", C.c_float), ("pad_bs_", C.c_int32), ("bs_dominance_ratio", C.c_double),
-                ("high_dyn", C.c_int32), ("smoother_length", C.c_uint32),
+                ("bs_use_phase_dot_detector", C.c_int32), ("bs_min_prompt_mag", C.c_float), ("enable_bit_sync_time_limit", C.c_int32), ("bs_dominance_ratio", C.c_double),
+                ("high_dyn", C.c_int32), ("smoother_length", C.c_uint32), ("bit_synchronization_time_limit_s", C.c_uint32), ("enable_doppler_correction", C.c_int32),
     ]
 
 

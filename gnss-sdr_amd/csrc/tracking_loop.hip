@@ -92,6 +92,10 @@ struct LockState  // what cn0_and_tracking_lock_status keeps between periods (tr
     double carr_hist[2 * GSH_MAX_SMOOTHER][2], code_hist[2 * GSH_MAX_SMOOTHER][2];
     int carr_hist_n, code_hist_n;
     long long carr_pushes, code_pushes;
+    // experimental Doppler correction (trk.cc:1326-1346): d_dll_filt_history is only ever filled and cleared, and std::accumulate(begin, end, 0.0) adds its
+    // floats to a double in push order -- a running double sum is the same arithmetic
+    double dll_filt_sum;
+    int dll_filt_count, corrected_doppler;
 };
 
 struct TrkChannel  // loop state of one channel, resident in device memory between launches
@@ -137,6 +141,7 @@ struct TrkArgs
     // loop invariants the host forms once per launch with the expressions the kernel used to evaluate in every period
     double code_period;                 // d_code_period = code_length_chips / code_chip_rate
     unsigned long long pull_in_limit;   // samples since acquisition below which the pull-in transitory lasts (trk.cc:1912-1915), see trk_launch
+    unsigned long long bit_sync_limit;  // samples since acquisition from which a channel still in state 2 is declared lost (trk.cc:2000-2007); ~0: never
 };
 
 // ---- discriminators, T/tracking_discriminators.cc (float / double mix as written there) ---------------------
@@ -701,6 +706,8 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                                             lk.carrier_lock_fail_counter = 0;
                                             lk.code_lock_fail_counter = 0;
                                         }
+                                    // trk.cc:2000-2007, state 2 only: no secondary-code / bit synchronisation within the time limit forces the loss-of-lock condition
+                                    if (run_state == 2 && (pos - acq_stamp) >= a.bit_sync_limit) lk.carrier_lock_fail_counter = 300000;
                                     if (run_state != 3)  // coherent integration runs no lock test (trk.cc:2156-2161)
                                         lost_now = !lock_status_d(lk, c, P, run_state == 4 ? code_period * static_cast<double>(extend) : code_period, pull_in);  // trk.cc:2008, :2203
                                 }
@@ -767,6 +774,34 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                         {
                             s.code_freq_chips = c.code_chip_rate - code_error_filt_chips;
                             if (c.carrier_aiding) s.code_freq_chips += s.carrier_doppler_hz * c.code_chip_rate / c.signal_carrier_freq;
+                            if (c.enable_doppler_correction && !pull_in && !lk.corrected_doppler)  // trk.cc:1326-1346
+                                {
+                                    lk.dll_filt_sum += static_cast<double>(static_cast<float>(code_error_filt_chips));
+                                    lk.dll_filt_count++;
+                                    if (lk.dll_filt_count == 1000)
+                                        {
+                                            const float avg_code_error_chips_s = __fdiv_rn(static_cast<float>(lk.dll_filt_sum), 1000.0f);
+                                            if (fabs(static_cast<double>(avg_code_error_chips_s)) > 1.0)
+                                                {
+                                                    const float carrier_doppler_error_hz =
+                                                        __fdiv_rn(__fmul_rn(static_cast<float>(c.signal_carrier_freq), avg_code_error_chips_s), static_cast<float>(c.code_chip_rate));
+                                                    const float f0 = __fsub_rn(static_cast<float>(s.carrier_doppler_hz), carrier_doppler_error_hz);
+                                                    if (s.pll.order == 3)  // Tracking_FLL_PLL_filter::initialize, T/tracking_FLL_PLL_filter.cc:57-69
+                                                        {
+                                                            s.pll.x = __fmul_rn(2.0f, f0);
+                                                            s.pll.w = 0.0f;
+                                                        }
+                                                    else
+                                                        {
+                                                            s.pll.w = f0;
+                                                            s.pll.x = 0.0f;
+                                                        }
+                                                    lk.corrected_doppler = 1;
+                                                }
+                                            lk.dll_filt_sum = 0.0;
+                                            lk.dll_filt_count = 0;
+                                        }
+                                }
                         }
 
 #ifdef GSH_TRK_PROFILE
@@ -1237,6 +1272,10 @@ int trk_launch(gsh_trk* t, int n_epochs, gsh_trk_epoch* d_records)
         // count is below (pull_in_time_s + 1) * fs -- one comparison per period instead of a 64-bit division
         const unsigned long long f = static_cast<unsigned long long>(static_cast<int>(t->conf.fs_in));
         a.pull_in_limit = (static_cast<unsigned long long>(t->conf.pull_in_time_s) + 1ull) * f;
+        // trk.cc:2002: limit < (samples since acquisition) / fs, the same integer arithmetic
+        a.bit_sync_limit = (t->conf.enable_bit_sync_time_limit && t->conf.enable_symbol_sync)
+                               ? (static_cast<unsigned long long>(t->conf.bit_synchronization_time_limit_s) + 1ull) * f
+                               : ~0ull;
     }
     const size_t lds = trk_lds_bytes(t);
     const dim3 grid(t->n_channels), block(gsh::mcdev::MC_THREADS);

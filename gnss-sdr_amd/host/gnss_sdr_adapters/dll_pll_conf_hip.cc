@@ -332,6 +332,9 @@ bool hip_fill_trk_conf(const Dll_Pll_Conf& p, gsh_trk_conf* c, Hip_Trk_Signal* s
     c->bs_dominance_ratio = p.bs_dominance_ratio;
     c->high_dyn = p.high_dyn ? 1 : 0;
     c->smoother_length = p.smoother_length;
+    c->enable_bit_sync_time_limit = 1;  // trk.cc:2000-2007: the block applies the fail-safe unconditionally
+    c->bit_synchronization_time_limit_s = p.bit_synchronization_time_limit_s;
+    c->enable_doppler_correction = p.enable_doppler_correction ? 1 : 0;  // trk.cc:1326-1346
     return true;
 }
 

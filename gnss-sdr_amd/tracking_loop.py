@@ -34,7 +34,10 @@ def trk_conf(**kw) -> TrkConf:
              # without a secondary code and more than one symbol per bit (trk.cc:1389) -- here the caller does
              use_histogram_bit_sync=0, bs_min_events_for_lock=10, bs_stable_best_required=3, bs_use_phase_dot_detector=1,
              bs_min_prompt_mag=0.0, bs_dominance_ratio=0.6,
-             high_dyn=0, smoother_length=10)
+             high_dyn=0, smoother_length=10,
+             # the state-2 fail-safe (trk.cc:2000-2007; off unless asked for: the reference has no switch, its adapters get it switched on) and the
+             # experimental Doppler correction (trk.cc:1326-1346, Dll_Pll_Conf default false)
+             enable_bit_sync_time_limit=0, bit_synchronization_time_limit_s=20, enable_doppler_correction=0)
     d.update(kw)
     for k, v in d.items():
         setattr(c, k, v)

@@ -30,7 +30,7 @@ extern "C"
 {
 #endif
 
-#define GSH_ABI_VERSION 21
+#define GSH_ABI_VERSION 22
 #define GSH_MAX_TAPS 8 /* VE/E/P/L/VL needs 5 (trk.cc:609-650); 8 leaves room for multi-tap dumps */
 
     enum
@@ -333,11 +333,16 @@ extern "C"
         int32_t bs_stable_best_required; /* (3) */
         int32_t bs_use_phase_dot_detector; /* (1) */
         float bs_min_prompt_mag;         /* (0.0) */
-        int32_t pad_bs_;
+        int32_t enable_bit_sync_time_limit; /* 1: the fail-safe of trk.cc:2000-2007 -- a channel still in state 2 (no secondary code / bit synchronisation yet)
+                                               more than bit_synchronization_time_limit_s whole seconds after the acquisition stamp is declared lost.  The
+                                               adapters switch it on (the reference has no switch); needs enable_lock_detectors and enable_symbol_sync */
         double bs_dominance_ratio;       /* (0.6) */
         int32_t high_dyn;                /* Dll_Pll_Conf::high_dyn: the high-dynamics resampler + rotator (trk.cc:669-675) fed with the rate-of-change
                                             estimates of both NCO steps (trk.cc:1425-1443, 1458-1480) */
         uint32_t smoother_length;        /* (10) periods per average, <= GSH_MAX_SMOOTHER */
+        uint32_t bit_synchronization_time_limit_s; /* (20) Dll_Pll_Conf::bit_synchronization_time_limit_s */
+        int32_t enable_doppler_correction; /* Dll_Pll_Conf::enable_doppler_correction (false): the experimental one-shot re-initialisation of the carrier loop
+                                              when the filtered code error averages more than 1 chip/s over 1000 loop updates after pull-in (trk.cc:1326-1346) */
     } gsh_trk_conf;
 #define GSH_MAX_BITSYNC_BINS 64
 #define GSH_MAX_SMOOTHER 32

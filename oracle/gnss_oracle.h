@@ -187,11 +187,13 @@ extern "C"
         /* histogram bit synchroniser (configure_bit_synchronizer, trk.cc:1387-1406; defaults dll_pll_conf.h:43,60,75-76,88) */
         int32_t use_histogram_bit_sync, bs_min_events_for_lock, bs_stable_best_required, bs_use_phase_dot_detector;
         float bs_min_prompt_mag;
-        int32_t pad_bs_;
+        int32_t enable_bit_sync_time_limit; /* the fail-safe of trk.cc:2000-2007 (the reference applies it always; the engine's structure has a switch) */
         double bs_dominance_ratio;
         /* high dynamics (Dll_Pll_Conf::high_dyn, smoother_length; trk.cc:669-675, 1425-1443, 1458-1480) */
         int32_t high_dyn;
         uint32_t smoother_length;
+        uint32_t bit_synchronization_time_limit_s; /* Dll_Pll_Conf, trk.cc:2002 */
+        int32_t enable_doppler_correction;         /* Dll_Pll_Conf, trk.cc:1326-1346 */
     } oracle_trk_conf;
     void oracle_lock_init(oracle_lock_state* st, const oracle_trk_conf* c);
     /* cn0_and_tracking_lock_status, trk.cc:1167-1224: returns 1 while locked, 0 when loss of lock is declared */

@@ -622,6 +622,10 @@ int oracle_trk_run(const oracle_trk_conf* c, const float* code, const float* dat
     if (hd && (SL < 1 || SL > ORACLE_MAX_SMOOTHER)) return -1;
     /* histogram bit synchroniser (trk.cc:2046-2072); switched off after its first lock */
     oracle_bit_sync bs;
+    /* experimental Doppler correction (trk.cc:1326-1346): d_dll_filt_history is a boost::circular_buffer<float>(1000) that is only ever filled and
+     * cleared, and std::accumulate(begin, end, 0.0) adds its floats to a double in push order -- a running double sum is the same arithmetic */
+    double dll_filt_sum = 0.0;
+    int dll_filt_count = 0, corrected_doppler = 0;
     int use_hist = c->enable_symbol_sync && c->use_histogram_bit_sync && !c->has_secondary && c->symbols_per_bit > 1;
     int wait_for_bit_edge = 0;
     int64_t bit_sync_target_epoch = 0;
@@ -725,6 +729,10 @@ int oracle_trk_run(const oracle_trk_conf* c, const float* code, const float* dat
                             lock.carrier_lock_fail_counter = 0;
                             lock.code_lock_fail_counter = 0;
                         }
+                    /* trk.cc:2000-2007, state 2 only: no secondary-code / bit synchronisation within the time limit forces the loss-of-lock condition */
+                    if (c->enable_bit_sync_time_limit && c->enable_symbol_sync && state == 2 &&
+                        (uint64_t)c->bit_synchronization_time_limit_s < (pos - acq_sample_stamp) / (uint64_t)((int)c->fs_in))
+                        lock.carrier_lock_fail_counter = 300000;
                     const int locked = oracle_lock_status(&lock, c, P[0], P[1], state == 4 ? code_period * (double)extend : code_period, pull_in);  /* trk.cc:2008, :2203 */
                     r->cn0_db_hz = lock.cn0_db_hz;
                     r->carrier_lock_test = lock.carrier_lock_test;
@@ -767,6 +775,24 @@ int oracle_trk_run(const oracle_trk_conf* c, const float* code, const float* dat
             code_error_filt_chips = oracle_loop_filter_apply(&dll, (float)code_error_chips);
             code_freq_chips = c->code_chip_rate - code_error_filt_chips;
             if (c->carrier_aiding) code_freq_chips += carrier_doppler_hz * c->code_chip_rate / c->signal_carrier_freq;
+            /* trk.cc:1326-1346 */
+            if (c->enable_doppler_correction && !pull_in && !corrected_doppler)
+                {
+                    dll_filt_sum += (double)(float)code_error_filt_chips;
+                    dll_filt_count++;
+                    if (dll_filt_count == 1000)
+                        {
+                            const float avg_code_error_chips_s = (float)dll_filt_sum / (float)1000;
+                            if (fabs((double)avg_code_error_chips_s) > 1.0)
+                                {
+                                    const float carrier_doppler_error_hz = (float)c->signal_carrier_freq * avg_code_error_chips_s / (float)c->code_chip_rate;
+                                    oracle_fll_pll_initialize(&pll, (float)carrier_doppler_hz - carrier_doppler_error_hz);
+                                    corrected_doppler = 1;
+                                }
+                            dll_filt_sum = 0.0;
+                            dll_filt_count = 0;
+                        }
+                }
             }
 
         update_vars:;

@@ -50,7 +50,7 @@ class ConfOut(C.Structure):
                                  "bs_stable_best_required", "bs_min_events_for_lock",
                                  "enable_fll_pull_in", "enable_fll_steady_state", "track_pilot", "carrier_aiding", "high_dyn", "bs_use_phase_dot_detector",
                                  "code_length_chips", "code_samples_per_chip", "symbols_per_bit", "secondary", "veml", "cloop", "use_histogram_bit_sync",
-                                 "interchange_iq", "secondary_code_length", "data_secondary_code_length", "correlation_length_ms", "n_correlator_taps")] + [
+                                 "interchange_iq", "secondary_code_length", "data_secondary_code_length", "correlation_length_ms", "n_correlator_taps", "enable_doppler_correction")] + [
         ("secondary_code", C.c_char * 256), ("data_secondary_code", C.c_char * 256), ("system", C.c_char), ("signal", C.c_char * 3)]
 
     def as_dict(self) -> dict:
@@ -77,6 +77,7 @@ def lib():
         L.reftrk_set_acquisition.argtypes = [C.c_void_p, C.c_char, C.c_char_p, C.c_uint32, C.c_double, C.c_double, C.c_uint64]
         L.reftrk_start_tracking.argtypes = [C.c_void_p]
         L.reftrk_stop_tracking.argtypes = [C.c_void_p]
+        L.reftrk_set_doppler_correction.argtypes = [C.c_void_p, C.c_int]
         L.reftrk_forecast.argtypes = [C.c_void_p, C.c_int]
         L.reftrk_nitems_read.restype = C.c_uint64
         L.reftrk_nitems_read.argtypes = [C.c_void_p]
@@ -124,6 +125,10 @@ class RefTrackingChannel:
 
     def stop_tracking(self):
         lib().reftrk_stop_tracking(self.h)
+
+    def set_doppler_correction(self, on: bool):
+        """the block's d_trk_parameters.enable_doppler_correction (no configuration key exists for it in the reference)"""
+        lib().reftrk_set_doppler_correction(self.h, 1 if on else 0)
 
     def forecast(self, noutput: int = 1) -> int:
         return lib().reftrk_forecast(self.h, noutput)

@@ -106,7 +106,7 @@ struct reftrk_conf_out  /* Dll_Pll_Conf after the adapter has finished with it, 
         carrier_lock_test_smoother_samples, cn0_min, max_code_lock_fail, max_carrier_lock_fail, bs_stable_best_required, bs_min_events_for_lock;
     int32_t enable_fll_pull_in, enable_fll_steady_state, track_pilot, carrier_aiding, high_dyn, bs_use_phase_dot_detector;
     int32_t code_length_chips, code_samples_per_chip, symbols_per_bit, secondary, veml, cloop, use_histogram_bit_sync, interchange_iq,
-        secondary_code_length, data_secondary_code_length, correlation_length_ms, n_correlator_taps;
+        secondary_code_length, data_secondary_code_length, correlation_length_ms, n_correlator_taps, enable_doppler_correction;
     char secondary_code[256], data_secondary_code[256];
     char system, signal[3];
 };
@@ -211,6 +211,13 @@ void reftrk_start_tracking(void* hv)
         h->adapter->start_tracking();
     else
         h->block->start_tracking();
+}
+// Dll_Pll_Conf::enable_doppler_correction (dll_pll_conf.h:82) has no configuration key in the reference (dll_pll_conf.cc never reads it): the
+// experimental branch of trk.cc:1326-1346 can only be reached by setting the block's member, which is what the pin of its restatement does
+void reftrk_set_doppler_correction(void* hv, int on)
+{
+    auto* h = static_cast<Handle*>(hv);
+    h->block->d_trk_parameters.enable_doppler_correction = on != 0;
 }
 void reftrk_stop_tracking(void* hv)
 {
@@ -430,6 +437,7 @@ void reftrk_get_conf(void* hv, reftrk_conf_out* c)
     c->data_secondary_code_length = static_cast<int32_t>(b->d_data_secondary_code_length);
     c->correlation_length_ms = b->d_correlation_length_ms;
     c->n_correlator_taps = b->d_n_correlator_taps;
+    c->enable_doppler_correction = p.enable_doppler_correction ? 1 : 0;
     std::strncpy(c->secondary_code, b->d_secondary_code_string.c_str(), 255);
     std::strncpy(c->data_secondary_code, b->d_data_secondary_code_string.c_str(), 255);
 }

@@ -74,7 +74,7 @@ struct reftrk_conf_out
         carrier_lock_test_smoother_samples, cn0_min, max_code_lock_fail, max_carrier_lock_fail, bs_stable_best_required, bs_min_events_for_lock;
     int32_t enable_fll_pull_in, enable_fll_steady_state, track_pilot, carrier_aiding, high_dyn, bs_use_phase_dot_detector;
     int32_t code_length_chips, code_samples_per_chip, symbols_per_bit, secondary, veml, cloop, use_histogram_bit_sync, interchange_iq,
-        secondary_code_length, data_secondary_code_length, correlation_length_ms, n_correlator_taps;
+        secondary_code_length, data_secondary_code_length, correlation_length_ms, n_correlator_taps, enable_doppler_correction;
     char secondary_code[256], data_secondary_code[256];
     char system, signal[3];
 };
@@ -192,7 +192,10 @@ void compare_conf(const char* name, const gsh_trk_conf& c, const Hip_Trk_Signal&
     SAME(bs_dominance_ratio, r.bs_dominance_ratio);
     SAME(high_dyn, r.high_dyn);
     SAME(smoother_length, r.smoother_length);
+    SAME(bit_synchronization_time_limit_s, r.bit_synchronization_time_limit_s);
+    SAME(enable_doppler_correction, r.enable_doppler_correction);
 #undef SAME
+    EXPECT(c.enable_bit_sync_time_limit == 1, "%s: the state-2 fail-safe is not switched on", name);
     EXPECT(sig.correlation_length_ms == r.correlation_length_ms, "%s: correlation_length_ms %d vs %d", name, sig.correlation_length_ms, r.correlation_length_ms);
     EXPECT(sig.interchange_iq == (r.interchange_iq != 0), "%s: interchange_iq", name);
     if (!sig.per_prn_secondary)

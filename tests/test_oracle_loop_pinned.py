@@ -27,8 +27,10 @@ def trk_conf_from_reference(c: dict) -> oracle.TrkConf:
               "carrier_lock_th", "symbols_per_bit", "secondary_code_length", "data_secondary_code_length", "extend_correlation_symbols",
               "pll_bw_narrow_hz", "dll_bw_narrow_hz", "early_late_space_narrow_chips", "very_early_late_space_narrow_chips",
               "bs_min_events_for_lock", "bs_stable_best_required", "bs_use_phase_dot_detector", "bs_min_prompt_mag", "bs_dominance_ratio",
-              "high_dyn", "smoother_length", "vector_length", "track_pilot", "veml", "code_length_chips", "code_samples_per_chip"):
+              "high_dyn", "smoother_length", "vector_length", "track_pilot", "veml", "code_length_chips", "code_samples_per_chip",
+              "bit_synchronization_time_limit_s", "enable_doppler_correction"):
         setattr(t, k, c[k])
+    t.enable_bit_sync_time_limit = 1  # the reference applies the fail-safe of trk.cc:2000-2007 unconditionally
     t.cfo_frequency_hz = 0.0
     t.enable_lock_detectors = 1
     t.enable_symbol_sync = 1
@@ -280,3 +282,67 @@ def test_gps_l1_extended_integration_narrow_tracking():
     states = [r.state for r in rec]
     first3 = states.index(3)
     assert states[first3:first3 + 20] == [3] * 9 + [4] + [3] * 9 + [4]
+
+
+def test_bit_synchronisation_time_limit_drops_the_channel():
+    """trk.cc:2000-2007: a channel still in state 2 more than bit_synchronization_time_limit_s whole seconds after the acquisition stamp gets its carrier
+    fail counter forced and is declared lost by the lock test of the same period.  A GPS L1 signal without navigation bits never completes the preamble
+    search; with the limit at 0 s the block gives up in the first period that starts a whole second after the stamp -- the restatement in the same one."""
+    t, x, n, acq_stamp, acq_delay, acq_doppler = _gps_l1_case(1100, bit_synchronization_time_limit_s=0)
+    c, outs, rec, start = _run_both(t, x, n, acq_stamp, acq_doppler, 1100)
+    assert c["bit_synchronization_time_limit_s"] == 0
+    assert outs[-1]["state"] == 0 and len(outs) < 1100, (len(outs), outs[-1]["state"])     # the block went back to standby ...
+    assert len(rec) == len(outs), (len(rec), len(outs))                                     # ... and the restatement stopped in the same period
+    last = rec[-1]
+    assert last.flags & 2 and last.prn_length_samples == 0
+    assert (last.sample_counter - acq_stamp) // int(c["fs_in"]) == 1 and (rec[-2].sample_counter - acq_stamp) // int(c["fs_in"]) == 0
+    _check_trajectory(outs[:-1], rec[:-1], c, start, acq_doppler, c["fs_in"], 2 * n)
+    # without the limit (the default 20 s) the same channel is still tracking at that point
+    t2, x2, n2, st2, dl2, dp2 = _gps_l1_case(1100)
+    c2, outs2, rec2, start2 = _run_both(t2, x2, n2, st2, dp2, len(outs) + 20)
+    assert len(rec2) == len(outs2) == len(outs) + 20 and outs2[-1]["state"] == 2
+
+
+def _stream_with_code_rate_offset(n_samples, fs, prn, fd_carrier, code_rate_offset_chips_s, cph, cn0, seed):
+    """GPS L1 C/A signal whose code Doppler does NOT follow its carrier Doppler (what the experimental correction of trk.cc:1326-1346 looks for)"""
+    from helpers import cn0_to_amplitude
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal(n_samples) + 1j * rng.standard_normal(n_samples)
+    tt = np.arange(n_samples, dtype=np.float64)
+    f_code = 1.023e6 * (1.0 + fd_carrier / 1575.42e6) + code_rate_offset_chips_s
+    chip = np.floor(tt * (f_code / fs) + cph).astype(np.int64) % 1023
+    x += cn0_to_amplitude(cn0, fs) * oracle.ca_code(prn).astype(np.float64)[chip] * np.exp(1j * (2.0 * np.pi * fd_carrier / fs * tt))
+    return x.astype(np.complex64), f_code
+
+
+def test_experimental_doppler_correction_reinitialises_the_carrier_loop():
+    """trk.cc:1326-1346 (enable_doppler_correction): after pull-in the filtered code error is averaged over 1000 loop updates; more than 1 chip/s away from
+    what the carrier Doppler explains, the carrier loop filter is re-initialised ONCE at the Doppler the code loop implies.  A signal whose code runs
+    3 chips/s fast for its carrier makes the block do that; the restatement does it in the same period with the same value."""
+    fs, prn, fd, off, cph = 4000000, 9, 1234.0, 3.0, 333.3
+    n = fs // 1000
+    n_periods = 2150
+    x, f_code = _stream_with_code_rate_offset((n_periods + 12) * n, fs, prn, fd, off, cph, 47.0, 11)
+    p = {"GNSS-SDR.internal_fs_sps": fs, "Tracking.pll_bw_hz": 35.0, "Tracking.dll_bw_hz": 2.0, "Tracking.early_late_space_chips": 0.5,
+         "Tracking.pull_in_time_s": 0}
+    t = ref_trk.RefTrackingChannel("GPS_L1_CA_DLL_PLL_Tracking", p)
+    t.set_doppler_correction(True)  # Dll_Pll_Conf::enable_doppler_correction has no configuration key in the reference: set on the block
+    start_exact = (1023.0 - cph) / f_code * fs
+    acq_stamp, acq_delay, acq_doppler = n, start_exact % n, fd - 20.0
+    t.set_acquisition("G", "1C", prn, acq_delay, acq_doppler, acq_stamp)
+    r, consumed, o = t.work(x[:2 * n])
+    assert (r, consumed, o["state"]) == (0, 2 * n, 0)
+    t.start_tracking()
+    c, outs, rec, start = _run_both(t, x, n, acq_stamp, acq_doppler, n_periods)
+    assert c["enable_doppler_correction"] == 1
+    assert len(rec) == len(outs)
+    # the step in the filtered carrier error: exactly one period, the same one, the same size
+    jump_ref = [k for k in range(1, len(outs)) if abs(outs[k]["carr_error_filt_hz"] - outs[k - 1]["carr_error_filt_hz"]) > 1000.0]
+    jump_got = [k for k in range(1, len(rec)) if abs(rec[k].carr_error_filt_hz - rec[k - 1].carr_error_filt_hz) > 1000.0]
+    assert jump_ref and jump_ref[0] == jump_got[0], (jump_ref[:3], jump_got[:3])
+    k = jump_ref[0]
+    assert 1990 <= k <= 2010, k  # 1 s of pull-in (trk.cc:1912: whole seconds) + 1000 updates
+    step_ref = outs[k]["carr_error_filt_hz"] - outs[k - 1]["carr_error_filt_hz"]
+    step_got = rec[k].carr_error_filt_hz - rec[k - 1].carr_error_filt_hz
+    assert abs(step_ref - step_got) <= 1e-2 and abs(abs(step_ref) - 1575.42e6 * off / 1.023e6) < 500.0, (step_ref, step_got)
+    _check_trajectory(outs[:k + 1], rec[:k + 1], c, start, acq_doppler, float(fs), 2 * n)

@@ -346,3 +346,85 @@ def test_device_high_dyn_loop_matches_oracle(gpu):
     op = np.mean([np.hypot(r.corr[2], r.corr[3]) for r in ora[300:]])
     assert abs(gp - op) < 0.01 * op
     loop.close()
+
+
+def _no_bits_case():
+    # a C/A signal without navigation bits: the preamble search never completes, the channel stays in state 2
+    x, n = gps_l1_with_nav_bits(1100, FS_L1, 7, -1750.0, "1" * 60, first_bit_period=0)
+    kw = dict(fs_in=FS_L1, vector_length=n, pll_bw_hz=25.0, dll_bw_hz=2.0, pull_in_time_s=0, enable_lock_detectors=1)
+    return x, n, kw
+
+
+def test_oracle_bit_synchronisation_time_limit():
+    """trk.cc:2000-2007: still in state 2 more than bit_synchronization_time_limit_s whole seconds after the acquisition stamp -> loss of lock (restated in
+    oracle/gnss_oracle_loop.c, pinned to the reference block in tests/test_oracle_loop_pinned.py); the switch off -> the channel keeps tracking"""
+    x, n, kw = _no_bits_case()
+    conf = oracle.trk_conf(enable_bit_sync_time_limit=1, bit_synchronization_time_limit_s=0, **kw)
+    oracle.set_symbol_sync(conf, 20, GPS_CA_PREAMBLE_SYMBOLS, has_secondary=False)
+    rec = oracle.trk_run(conf, oracle.ca_code(7), x, 0, 0, -1742.0, 1100)
+    assert len(rec) == 1001 and rec[-1].flags & 2 and rec[-1].sample_counter // int(FS_L1) == 1   # the first period that starts a whole second after the stamp
+    assert all(r.state == 2 for r in rec)
+    conf.enable_bit_sync_time_limit = 0
+    assert len(oracle.trk_run(conf, oracle.ca_code(7), x, 0, 0, -1742.0, 1100)) == 1100
+
+
+@pytest.mark.gpu
+def test_device_bit_synchronisation_time_limit_matches_oracle(gpu):
+    from gnss_sdr_amd.tracking_loop import TrackingLoop, set_symbol_sync, trk_conf
+    x, n, kw = _no_bits_case()
+    extra = dict(enable_bit_sync_time_limit=1, bit_synchronization_time_limit_s=0)
+    conf_o = oracle.trk_conf(**kw, **extra)
+    oracle.set_symbol_sync(conf_o, 20, GPS_CA_PREAMBLE_SYMBOLS, has_secondary=False)
+    ora = oracle.trk_run(conf_o, oracle.ca_code(7), x, 0, 0, -1742.0, 1100)
+    conf = trk_conf(**kw, **extra)
+    set_symbol_sync(conf, 20, GPS_CA_PREAMBLE_SYMBOLS, has_secondary=False)
+    loop = TrackingLoop(conf, 2, 1023, device=gpu)
+    loop.set_stream_host(x)
+    loop.start(0, oracle.ca_code(7), 0, 0, -1742.0)
+    rec, done = loop.run(700)
+    rec2, done2 = loop.run(400)
+    got = rec[0][:int(done[0])] + rec2[0][:int(done2[0])]
+    assert len(got) == len(ora) == 1001, (len(got), len(ora))   # dropped in the same period ...
+    assert got[-1].flags & 2 and got[-1].sample_counter == ora[-1].sample_counter and got[-1].prn_length_samples == 0
+    assert [r.sample_counter for r in got] == [r.sample_counter for r in ora]
+    loop.close()
+
+
+def _code_rate_offset_case():
+    from helpers import cn0_to_amplitude
+    fs, prn, fd, off = FS_L1, 7, -1750.0, 3.0
+    n = int(fs // 1000)
+    total = 2150 * n
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(total) + 1j * rng.standard_normal(total)
+    tt = np.arange(total, dtype=np.float64)
+    f_code = 1.023e6 * (1.0 + fd / 1575.42e6) + off
+    chip = np.floor(tt * (f_code / fs)).astype(np.int64) % 1023
+    x += cn0_to_amplitude(47.0, fs) * oracle.ca_code(prn).astype(np.float64)[chip] * np.exp(1j * (2.0 * np.pi * fd / fs * tt))
+    kw = dict(fs_in=fs, vector_length=n, pll_bw_hz=35.0, dll_bw_hz=2.0, pull_in_time_s=0, enable_lock_detectors=1, enable_doppler_correction=1)
+    return x.astype(np.complex64), n, kw, off
+
+
+@pytest.mark.gpu
+def test_device_doppler_correction_matches_oracle(gpu):
+    """trk.cc:1326-1346 (experimental, no configuration key in the reference; restatement pinned to the block's branch in tests/test_oracle_loop_pinned.py):
+    the carrier loop is re-initialised once, 1000 loop updates after pull-in, in the same period and by the same amount as in the oracle loop"""
+    from gnss_sdr_amd.tracking_loop import TrackingLoop, trk_conf
+    x, n, kw, off = _code_rate_offset_case()
+    ora = oracle.trk_run(oracle.trk_conf(**kw), oracle.ca_code(7), x, 0, 0, -1742.0, 2100)
+    loop = TrackingLoop(trk_conf(**kw), 1, 1023, device=gpu)
+    loop.set_stream_host(x)
+    loop.start(0, oracle.ca_code(7), 0, 0, -1742.0)
+    rec, done = loop.run(1200)
+    rec2, done2 = loop.run(900)
+    got = rec[0] + rec2[0]
+    assert len(got) == len(ora) == 2100
+    jo = [k for k in range(1, 2100) if abs(ora[k].carr_error_filt_hz - ora[k - 1].carr_error_filt_hz) > 1000.0]
+    jg = [k for k in range(1, 2100) if abs(got[k].carr_error_filt_hz - got[k - 1].carr_error_filt_hz) > 1000.0]
+    assert jo and jg and jo[0] == jg[0] and 1990 <= jo[0] <= 2010, (jo[:3], jg[:3])
+    k = jo[0]
+    so, sg = ora[k].carr_error_filt_hz - ora[k - 1].carr_error_filt_hz, got[k].carr_error_filt_hz - got[k - 1].carr_error_filt_hz
+    # (the size follows the 1000-period average of the code error: the two loops agree at loop level there, not bit for bit)
+    assert abs(so - sg) < 10.0 and abs(abs(so) - 1575.42e6 * off / 1.023e6) < 500.0, (so, sg)
+    assert [r.sample_counter for r in got[:k + 1]] == [r.sample_counter for r in ora[:k + 1]]
+    loop.close()
