@@ -10,6 +10,8 @@ Known-answer case mirrors the reference's synthetic acquisition test
 PRN 10, Doppler 750 Hz, delay 600 chips, fs 4 Msps, doppler_max 10000, step 250; pass when the delay error is
 below 0.5 chip and the Doppler error below 2/(3*T_int).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -418,3 +420,61 @@ def test_glonass_fdma_doppler_bias(gpu, path):
     r2 = acq.dwell(x, 1)[0]
     assert r2["test_statistics"] == pytest.approx(r0["test_statistics"], rel=1e-6)
     acq.close()
+
+
+_SPLIT_PATH_SNIPPET = r"""
+import json, os, sys
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import os
+
+import numpy as np
+import oracle
+from helpers import synth_gps_l1_stream
+from gnss_sdr_amd.acquisition import PcpsAcquisitionBank
+out = {}
+for n, fs, bt, cfar in ((64000, 16000000, False, True), (128000, 32000000, False, True), (80000, 40000000, True, True), (100000, 25000000, False, False)):
+    spc = int(np.ceil(fs / 1.023e6)); per = fs // 1000
+    x = synth_gps_l1_stream(n, fs, [5, 9], [-3300.0, 1875.0], [100.25, 611.5], cn0_dbhz=47.0, seed_noise=n + 1)
+    acq = PcpsAcquisitionBank(fs_in=fs, fft_size=n, consumed_samples=n, doppler_max=2500, doppler_step=250, samples_per_chip=spc, samples_per_code=float(per),
+                              max_prn=3, use_cfar=cfar, bit_transition_flag=bt, device=int(sys.argv[1]))
+    for i, p in enumerate((5, 9, 20)):
+        c1 = oracle.ca_code_complex_sampled(p, fs)
+        acq.set_local_code(i, c1 if bt else np.tile(c1, (n + len(c1) - 1) // len(c1))[:n])
+    res = acq.dwell(x, 3)
+    g = acq.read_grid(0)
+    out[str(n)] = dict(results=[{k: (float(v) if isinstance(v, float) else int(v)) for k, v in r.items()} for r in res],
+                       grid_sum=float(g.astype(np.float64).sum()), grid_max=float(g.max()), grid_argmax=int(np.argmax(g)), per=int(per), eff=int(g.shape[-1]))
+    acq.close()
+print("SPLITJSON " + json.dumps(out))
+"""
+
+
+def test_split_plans_decimation_in_time_equals_decimation_in_frequency(gpu):
+    """N = S * M with S >= 4 runs decimation in time (sub-cells read one residue class of the residue-major spectra, a second launch combines them:
+    csrc/pcps_onchip.hip); GSH_OC_DIT_MIN_S=0 in the environment forces the round-2 decimation-in-frequency sub-cells.  Same searches through both, each in a
+    process of its own (the switch is read once): indices and Doppler bins identical, statistics and the stored grid equal to float32 rounding of two orders
+    of summation -- CFAR and peak-ratio statistic, bit-transition (upper-half) search included."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    for name, val in (("dit", None), ("dif", "0")):
+        env = dict(os.environ)
+        env.pop("GSH_OC_DIT_MIN_S", None)
+        if val is not None:
+            env["GSH_OC_DIT_MIN_S"] = val
+        p = subprocess.run([sys.executable, "-c", _SPLIT_PATH_SNIPPET, str(gpu)], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        line = [ln for ln in p.stdout.splitlines() if ln.startswith("SPLITJSON ")][-1]
+        got[name] = json.loads(line[len("SPLITJSON "):])
+    for n, a in got["dit"].items():
+        b = got["dif"][n]
+        for i, (ra, rb) in enumerate(zip(a["results"], b["results"])):
+            if i < 2:  # satellites that are there (a block of several code periods holds equally high peaks one period apart: which ranks first is rounding)
+                assert (ra["index_time"] % a["per"], ra["index_doppler"]) == (rb["index_time"] % a["per"], rb["index_doppler"]), (n, i, ra, rb)
+            assert ra["test_statistics"] == pytest.approx(rb["test_statistics"], rel=2e-4), (n, i, ra, rb)
+            assert ra["peak"] == pytest.approx(rb["peak"], rel=2e-5), (n, i)
+        assert a["grid_argmax"] // a["eff"] == b["grid_argmax"] // a["eff"] and (a["grid_argmax"] % a["eff"]) % a["per"] == (b["grid_argmax"] % a["eff"]) % a["per"], n
+        assert a["grid_max"] == pytest.approx(b["grid_max"], rel=2e-5), n
+        assert a["grid_sum"] == pytest.approx(b["grid_sum"], rel=1e-5), n
