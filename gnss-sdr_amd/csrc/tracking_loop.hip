@@ -1254,10 +1254,24 @@ int trk_launch(gsh_trk* t, int n_epochs, gsh_trk_epoch* d_records)
     if (t->ring != nullptr)
         {
             a.stream = t->ring->d_ring;
-            a.n_stream = t->ring->next;
             a.ring_capacity = t->ring->capacity;
             a.ring_oldest = gsh::stream_oldest(t->ring);
-            GSH_HIP(hipStreamWaitEvent(t->stream, t->ring->pushed, 0));  // conversions queued by gsh_stream_push_device
+            // The launch reads, and therefore waits for, only what its channels can reach in n_epochs periods -- not every push queued so far: the blocks of a
+            // stream upload well ahead of what they consume (the scheduler offers them its whole buffer), and the upload of what the NEXT launch will read
+            // runs under this one.  (A period is vector_length samples give or take the code Doppler; a channel that drifts past the estimate just stops a
+            // period early in this launch and carries on in the next.)
+            unsigned long long need = 0ull;
+            bool any = false;
+            for (int ch = 0; ch < t->n_channels; ch++)
+                if (t->h_chan[ch].active)
+                    {
+                        any = true;
+                        need = std::max(need, t->h_chan[ch].pos + static_cast<unsigned long long>(n_epochs) * (t->conf.vector_length + 8ull) + t->conf.vector_length);
+                    }
+            const unsigned long long limit = any ? std::min<unsigned long long>(t->ring->next, need) : t->ring->next;
+            a.n_stream = limit;
+            const int rcw = gsh::stream_wait_pushed(t->ring, limit, t->stream);  // conversions queued by the pushes that cover [.., limit)
+            if (rcw != GSH_OK) return rcw;
         }
     a.codes = t->d_codes;
     a.code_stride = t->max_code_len;
