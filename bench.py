@@ -214,9 +214,12 @@ def acquisition_metric(torch, dev_index, x_block, fs, pmc=None):
                               keep_grid=False)  # max_dwells = 1, dump = false: the statistics are formed on chip
     for p in range(32):
         acq.set_local_code(p, gps_l1_ca_code_sampled(p + 1, int(fs)))
-    acq.time_dwells(x_block, 32, reps=1500, pipelined=True)       # ~0.2 s untimed: the clocks settle (profiles/ab/clock_ramp.py)
+    # GSH_BENCH_ACQ_SINGLE_STREAM=1 (profiles/run_profiles_r03.sh): no second batch in flight, so that a kernel trace shows every kernel's own duration
+    # (two cell launches that share the compute units each take longer on the trace's clock than either alone)
+    two = os.environ.get("GSH_BENCH_ACQ_SINGLE_STREAM", "0") != "1"
+    acq.time_dwells(x_block, 32, reps=1500, pipelined=two)        # ~0.2 s untimed: the clocks settle (profiles/ab/clock_ramp.py)
     ms_serial = acq.time_dwells(x_block, 32, reps=20)             # one batch after the other on one stream: latency
-    ms = acq.time_dwells(x_block, 32, reps=200, pipelined=True)   # batches alternating on two streams: throughput
+    ms = acq.time_dwells(x_block, 32, reps=200, pipelined=two)    # batches alternating on two streams: throughput
     nbytes = 16.0 * n * 41 * (32 + 1)
     t = ms * 1e-3
     # (D + P D) (5 N log2 N + 6 N) flops per batch
@@ -245,9 +248,9 @@ def acquisition_metric(torch, dev_index, x_block, fs, pmc=None):
                                    samples_per_code=float(n2), max_prn=32, device=dev_index, keep_grid=False)
         for p in range(32):
             acq2.set_local_code(p, gps_l1_ca_code_sampled(p + 1, int(2 * fs)))
-        acq2.time_dwells(x2, 32, reps=100, pipelined=True)
+        acq2.time_dwells(x2, 32, reps=100, pipelined=two)
         ms2_serial = acq2.time_dwells(x2, 32, reps=20)
-        ms2 = acq2.time_dwells(x2, 32, reps=100, pipelined=True)
+        ms2 = acq2.time_dwells(x2, 32, reps=100, pipelined=two)
         res["split_plan_50000"] = {"workload": "32 PRN x 41 Doppler bins, N=50000 (50 Msps x 1 ms), 1 dwell, plan 2 x (25,25,40)", "ms_per_batch": ms2,
                                    "ms_per_batch_single_stream": ms2_serial, "value": 32.0 / (ms2 * 1e-3), "unit": "dwells/s",
                                    "algorithmic_GBs": 16.0 * n2 * 41 * 33 / (ms2 * 1e-3) / 1e9}
@@ -263,9 +266,9 @@ def acquisition_metric(torch, dev_index, x_block, fs, pmc=None):
         rng4 = np.random.default_rng(4)
         for p in range(32):
             acq4.set_local_code(p, (rng4.integers(0, 2, n4) * 2 - 1).astype(np.complex64))   # +-1 replicas: the cost does not depend on the code values
-        acq4.time_dwells(x4, 32, reps=20, pipelined=True)
+        acq4.time_dwells(x4, 32, reps=20, pipelined=two)
         ms4_serial = acq4.time_dwells(x4, 32, reps=10)
-        ms4 = acq4.time_dwells(x4, 32, reps=20, pipelined=True)
+        ms4 = acq4.time_dwells(x4, 32, reps=20, pipelined=two)
         res["split_plan_128000"] = {"workload": "32 PRN x 41 Doppler bins, N=128000 (Galileo E1 4 ms at 32 Msps), 1 dwell, plan 5 x (25,32,32), decimation in time",
                                     "ms_per_batch": ms4, "ms_per_batch_single_stream": ms4_serial, "value": 32.0 / (ms4 * 1e-3), "unit": "dwells/s",
                                     "algorithmic_GBs": 16.0 * n4 * 41 * 33 / (ms4 * 1e-3) / 1e9}

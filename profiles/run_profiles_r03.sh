@@ -10,6 +10,7 @@
 #               (tests/host/test_adapters acq_shared | acq_alone): the forward-transform launches of either, appended to the summary.
 set -u
 TAG=${1:-r03}
+export GSH_BENCH_ACQ_SINGLE_STREAM=1   # one acquisition batch at a time: the trace then shows each kernel alone (bench.py)
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
