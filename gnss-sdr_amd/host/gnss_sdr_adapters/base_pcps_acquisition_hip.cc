@@ -71,6 +71,8 @@ Hip_Acq_Conf to_hip_conf(const Acq_Conf& a)
     h.use_CFAR_algorithm_flag = a.use_CFAR_algorithm_flag;
     h.use_automatic_resampler = a.use_automatic_resampler;
     h.dump = a.dump;
+    h.dump_filename = a.dump_filename;
+    h.dump_channel = a.dump_channel;
     return h;
 }
 }  // namespace

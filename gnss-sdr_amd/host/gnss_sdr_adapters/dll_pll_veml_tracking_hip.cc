@@ -3,6 +3,8 @@
  * \brief GNU Radio block with dll_pll_veml_tracking's contract over the MI355X device-closed loop; see the header.
  */
 #include "dll_pll_veml_tracking_hip.h"
+#include "hip_mat5_writer.h"
+#include <iostream>
 #include "gnss_synchro.h"
 #include <gnuradio/io_signature.h>
 #include <gnuradio/thread/thread.h>
@@ -98,6 +100,12 @@ dll_pll_veml_tracking_hip::~dll_pll_veml_tracking_hip()
     try
         {
             flush_dump();
+            // trk.cc:175-193 (destructor): with dump_mat the binary dump is turned into <dump_filename><channel>.mat (save_matfile, :1706-1890)
+            if (d_dump && d_trk_parameters.dump_mat && !d_dump_path.empty())
+                {
+                    const long epochs = hip_tracking_dump_to_mat(d_dump_path);
+                    if (epochs < 0) std::cerr << "Problem generating the .mat file of " << d_dump_path << '\n';
+                }
             if (d_runtime && d_slot >= 0) d_runtime->detach(d_slot);
         }
     catch (...)

@@ -33,6 +33,8 @@ Hip_Acq_Conf to_hip_conf(const Acq_Conf& a)
     h.doppler_step = a.doppler_step;
     h.bit_transition_flag = a.bit_transition_flag;
     h.dump = a.dump;
+    h.dump_filename = a.dump_filename;
+    h.dump_channel = a.dump_channel;
     return h;
 }
 }  // namespace

@@ -6,11 +6,44 @@
  */
 #include "pcps_acquisition_hip.h"
 #include "GLONASS_L1_L2_CA.h"
+#include "hip_mat5_writer.h"
 #include <cstring>
 #include <gnuradio/io_signature.h>
 #include <pmt/pmt.h>
 #include <algorithm>
+#include <filesystem>
+#include <iostream>
 #include <utility>
+#include <vector>
+
+namespace
+{
+// get_dump_filename, acq.cc:58-92: directory and base name apart, the extension dropped, the directory created; empty when it cannot be
+std::string hip_acq_dump_filename(std::string dump_filename)
+{
+    std::string dump_path;
+    if (dump_filename.find_last_of('/') != std::string::npos)
+        {
+            const auto last_slash_index = dump_filename.find_last_of('/');
+            dump_path = dump_filename.substr(0, last_slash_index);
+            dump_filename = dump_filename.substr(last_slash_index + 1);
+        }
+    else
+        {
+            dump_path = std::string(".");
+        }
+    if (dump_filename.empty()) dump_filename = "acquisition";
+    if (dump_filename.substr(1).find_last_of('.') != std::string::npos) dump_filename = dump_filename.substr(0, dump_filename.find_last_of('.'));
+    std::error_code ec;
+    std::filesystem::create_directories(dump_path, ec);
+    if (ec)
+        {
+            std::cerr << "GNSS-SDR cannot create dump file for the Acquisition block. The dump path is: " << dump_path << '\n';
+            return std::string{};
+        }
+    return dump_path + static_cast<char>(std::filesystem::path::preferred_separator) + dump_filename;
+}
+}  // namespace
 
 pcps_acquisition_hip_sptr pcps_make_acquisition_hip(const Hip_Acq_Conf& conf, int device, bool blocking_on_standby, std::shared_ptr<Hip_Acquisition_Runtime> runtime)
 {
@@ -26,8 +59,11 @@ pcps_acquisition_hip::pcps_acquisition_hip(const Hip_Acq_Conf& conf, int device,
       d_data_buffer(conf.cshort ? 0U : d_core.consumed_samples()),
       d_data_buffer_sc(conf.cshort ? d_core.consumed_samples() : 0U),
       d_cshort(conf.cshort),
-      d_blocking_on_standby(blocking_on_standby)
+      d_blocking_on_standby(blocking_on_standby),
+      d_dump_filename(conf.dump ? hip_acq_dump_filename(conf.dump_filename) : std::string{}),
+      d_dump_channel(conf.dump_channel)
 {
+    d_dump = !d_dump_filename.empty();  // acq.cc:106, 120
     this->message_port_register_out(pmt::mp("events"));
     // a shared runtime is only of use to a block whose dwell is the runtime's dwell (same transform, same Doppler grid, same statistic)
     if (runtime && runtime->ok() && d_core.ok() && runtime->same_geometry(d_core.engine_conf()))
@@ -97,6 +133,53 @@ void pcps_acquisition_hip::set_doppler_center(int32_t doppler_center)
 }
 
 
+// pcps_acquisition::dump_results, acq.cc:354-406: file name, variables, classes and dimensions as there.  The container is MAT-file level 5 (written here,
+// host/hip_mat5_writer.h) where the reference's matio writes 7.3; acq_grid_narrow of make_two_steps searches is not kept on the device and is left out.
+void pcps_acquisition_hip::dump_results(const Hip_Pcps_Acquisition_Core::AcquisitionResult& result)
+{
+    d_dump_number++;
+    std::string filename = d_dump_filename;
+    filename.append("_");
+    filename.append(1, d_gnss_synchro->System);
+    filename.append("_");
+    filename.append(1, d_gnss_synchro->Signal[0]);
+    filename.append(1, d_gnss_synchro->Signal[1]);
+    filename.append("_ch_");
+    filename.append(std::to_string(d_channel));
+    filename.append("_");
+    filename.append(std::to_string(d_dump_number));
+    filename.append("_sat_");
+    filename.append(std::to_string(d_gnss_synchro->PRN));
+    filename.append(".mat");
+    const size_t eff = d_core.effective_fft_size(), bins = d_core.num_doppler_bins();
+    std::vector<float> grid(eff * bins);
+    if (!d_core.read_grid(grid.data()))
+        {
+            std::cout << "Acquisition dump: the search grid could not be read back: " << d_core.last_error() << '\n';
+            return;
+        }
+    Hip_Mat5_Writer w(filename);
+    if (!w.ok())
+        {
+            std::cout << "Unable to create or open Acquisition dump file\n";
+            return;
+        }
+    w.matrix("acq_grid", grid.data(), eff, bins);  // arma::fmat(d_effective_fft_size, d_num_doppler_bins): one column per Doppler bin
+    w.scalar<int32_t>("doppler_max", static_cast<int32_t>(d_core.doppler_max()));
+    w.scalar<int32_t>("doppler_step", static_cast<int32_t>(d_core.doppler_step()));
+    w.scalar<int32_t>("positive_acq", result.positive_acq ? 1 : 0);
+    w.scalar<float>("acq_doppler_hz", static_cast<float>(d_gnss_synchro->Acq_doppler_hz));
+    w.scalar<float>("acq_delay_samples", static_cast<float>(d_gnss_synchro->Acq_delay_samples));
+    w.scalar<float>("test_statistic", result.test_statistics);
+    w.scalar<float>("threshold", d_core.get_threshold());
+    w.scalar<float>("input_power", d_core.input_power());
+    w.scalar<uint64_t>("sample_counter", result.sample_count);
+    w.scalar<uint32_t>("PRN", d_gnss_synchro->PRN);
+    w.scalar<int32_t>("num_dwells", static_cast<int32_t>(result.num_dwells));
+    w.close();
+}
+
+
 void pcps_acquisition_hip::set_threshold(float threshold)
 {
     gr::thread::scoped_lock lock(d_setlock);
@@ -142,6 +225,8 @@ void pcps_acquisition_hip::run_dwell(uint64_t sample_count)
         }
     gr::thread::scoped_lock lock(d_setlock);
     if (outcome != Hip_Pcps_Acquisition_Core::ACQ_ERROR && d_gnss_synchro != nullptr) d_core.update_synchro(result, d_gnss_synchro);
+    if (outcome != Hip_Pcps_Acquisition_Core::ACQ_ERROR && result.search_complete && d_dump && d_channel == d_dump_channel && d_gnss_synchro != nullptr)
+        dump_results(result);  // acq.cc:719-723
     switch (outcome)
         {
         case Hip_Pcps_Acquisition_Core::ACQ_POSITIVE:
@@ -199,13 +284,18 @@ int pcps_acquisition_hip::general_work(int /*noutput_items*/, gr_vector_int& nin
             d_state = 1;
             // a dwell that may be shared starts on the runtime's grid: the next multiple of the dwell length in absolute sample index, less than one
             // dwell length ahead.  The block says so now, so that the batch of that window waits for it.
-            leave_shared_window();
             if (d_runtime && d_core.next_dwell_is_shareable())
                 {
+                    // (one step from "searching" / a previous window to the new window: withdrawing first would leave the channel unannounced for a moment,
+                    // and a batch evaluated in that moment closes without it)
                     d_window = d_runtime->next_window(d_sample_count);
                     d_skip = static_cast<uint32_t>(d_window - d_sample_count);
                     d_shared_dwell = true;
                     d_runtime->announce(d_slot, d_window);
+                }
+            else
+                {
+                    leave_shared_window();
                 }
         }
     else if (d_state == 1 && d_skip > 0)

@@ -21,6 +21,7 @@
 #include <gnuradio/block.h>
 #include <complex>
 #include <memory>
+#include <string>
 #include <vector>
 
 class pcps_acquisition_hip;
@@ -90,6 +91,12 @@ private:
     uint64_t d_sample_count{0};
     uint32_t d_buffer_count{0};
     uint32_t d_channel{0};
+    // dump (acq.cc:354-406): one .mat file per completed search of the dumped channel
+    std::string d_dump_filename;
+    uint32_t d_dump_channel{0};
+    bool d_dump{false};
+    int64_t d_dump_number{0};
+    void dump_results(const Hip_Pcps_Acquisition_Core::AcquisitionResult& result);
     int32_t d_state{0};
     bool d_active{false};
     bool d_blocking_on_standby{false};

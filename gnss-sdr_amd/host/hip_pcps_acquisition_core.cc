@@ -170,6 +170,8 @@ Hip_Pcps_Acquisition_Core::Outcome Hip_Pcps_Acquisition_Core::core_after_dwell(u
     // acq.cc:717-725
     if (d_num_noncoherent_integrations_counter == d_acq_parameters.max_dwells || result->positive_acq || d_acq_parameters.bit_transition_flag)
         {
+            result->search_complete = true;  // the block dumps here when asked to (acq.cc:719-723)
+            result->num_dwells = d_num_noncoherent_integrations_counter;
             d_num_noncoherent_integrations_counter = 0U;
         }
     return out;

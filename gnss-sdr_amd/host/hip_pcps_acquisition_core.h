@@ -49,6 +49,8 @@ struct Hip_Acq_Conf
     bool use_CFAR_algorithm_flag{true};
     bool use_automatic_resampler{false};
     bool dump{false};  //!< Acq_Conf::dump: the grid must stay readable (read_grid)
+    std::string dump_filename;  //!< Acq_Conf::dump_filename (the adapter has already put the dump directory in front, as the reference's constructor does)
+    uint32_t dump_channel{0U};  //!< Acq_Conf::dump_channel: only this channel's searches are dumped (acq.cc:555, 720)
 
     /*! acq_conf.cc:119-124 */
     void SetDerivedParams()
@@ -72,6 +74,8 @@ public:
         uint32_t index_time{0};
         bool positive_acq{false};
         bool step_two{false};  //!< the dwell that produced this result ran the narrow grid (d_step_two at acq.cc:598)
+        bool search_complete{false};  //!< acq.cc:717: the point at which the reference dumps the search and clears its dwell counter
+        uint32_t num_dwells{0};       //!< d_num_noncoherent_integrations_counter at that point (dump variable num_dwells)
     };
 
     enum Outcome
@@ -152,6 +156,8 @@ public:
     uint32_t effective_fft_size() const { return d_effective_fft_size; }
     uint32_t num_doppler_bins() const { return d_num_doppler_bins; }
     float input_power() const { return d_input_power; }
+    int32_t doppler_max() const { return d_acq_parameters.doppler_max; }
+    int32_t doppler_step() const { return d_acq_parameters.doppler_step; }
 
     static float compute_threshold(float pfa, uint32_t effective_fft_size, uint32_t num_doppler_bins, uint32_t max_dwells);
 

@@ -40,6 +40,7 @@
 #include "item_type_helpers.h"
 #include <array>
 #include <atomic>
+#include <filesystem>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -254,6 +255,56 @@ std::vector<SharedAcqOutcome> run_acquisition_blocks(int n_blocks, int shared_id
     for (auto& t : th) t.join();
     if (stats != nullptr && shared_id >= 0 && acq[0]->block()->runtime()) *stats = acq[0]->block()->runtime()->stats();
     return out;
+}
+
+// dump (acq.cc:354-406, 719-723): the dumped channel leaves one .mat per completed search -- the grid, the search parameters and the result; the file is
+// read back and checked against the published result by tests/test_adapters.py (scipy)
+void test_acquisition_dump()
+{
+    const long fs = 4000000;
+    const std::string role = "Acquisition_1C";
+    const std::string dir = "/tmp/gsh_acq_dump_test";
+    std::filesystem::remove_all(dir);
+    std::vector<std::complex<float>> rep(4000);
+    gps_l1_ca_code_gen_complex_sampled(rep, 14, static_cast<int32_t>(fs), 0);
+    const auto x = make_stream(rep, 60000, fs, 1234, 1760.0, 0.12F, 5);
+    auto conf = base_config(role, fs);
+    conf->set_property(role + ".dump", "true");
+    conf->set_property(role + ".dump_filename", dir + "/acq_dump.mat");
+    conf->set_property(role + ".dump_channel", "3");
+    for (const unsigned channel : {3U, 4U})  // channel 3 is dumped, channel 4 is not
+        {
+            GpsL1CaPcpsAcquisitionHip acq(conf.get(), role, 1, 0);
+            EXPECT(acq.item_size() == sizeof(gr_complex), "acquisition dump: block unusable");
+            if (acq.item_size() == 0) return;
+            Gnss_Synchro syn{};
+            syn.System = 'G';
+            std::memcpy(syn.Signal, "1C", 3);
+            syn.PRN = 14;
+            acq.set_channel(channel);
+            acq.set_gnss_synchro(&syn);
+            acq.set_local_code();
+            acq.reset();
+            auto blk = std::dynamic_pointer_cast<gr::block>(acq.get_left_block());
+            size_t pos = 0;
+            gr_vector_void_star outs;
+            for (int calls = 0; calls < 1000 && blk->published.empty(); calls++)
+                {
+                    const size_t avail = std::min<size_t>(1500, x.size() - pos);
+                    gr_vector_int nin{static_cast<int>(avail)};
+                    gr_vector_const_void_star ins{static_cast<const void*>(x.data() + pos)};
+                    blk->consumed_last = 0;
+                    blk->general_work(0, nin, ins, outs);
+                    pos += static_cast<size_t>(blk->consumed_last);
+                }
+            EXPECT(!blk->published.empty() && pmt::to_long(blk->published[0].second) == 1, "acquisition dump: channel %u did not find the satellite", channel);
+            const std::string file = dir + "/acq_dump_G_1C_ch_" + std::to_string(channel) + "_1_sat_14.mat";
+            const bool there = std::filesystem::exists(file);
+            EXPECT(there == (channel == 3U), "acquisition dump: %s %s", file.c_str(), there ? "written for a channel that is not dumped" : "missing");
+            if (channel == 3U)
+                std::printf("ACQ_DUMP %s delay %.3f doppler %.1f stamp %llu\n", file.c_str(), syn.Acq_delay_samples, syn.Acq_doppler_hz,
+                    static_cast<unsigned long long>(syn.Acq_samplestamp_samples));
+        }
 }
 
 void test_shared_acquisition()
@@ -860,6 +911,7 @@ int main(int argc, char** argv)
         [](std::vector<std::complex<float>>& rep) { qzss_l5i_code_gen_complex_sampled(rep, 194, 25000000); }, 12321, -1500.0, 0.0, 28);
     reference_block_side_by_side();
     e5a_reference_block_side_by_side();
+    test_acquisition_dump();
     test_shared_acquisition();
     if (fails == 0) std::printf("ADAPTERS OK\n");
     return fails == 0 ? 0 : 1;

@@ -41,6 +41,29 @@ def test_block_and_runtime_against_the_fake_engine():
     tail = "\n".join(l for l in r.stdout.splitlines() if "FAIL" in l or "shared stream" in l or "OK" in l or "dump" in l or "restart" in l)
     print(tail[-3000:])
     assert r.returncode == 0 and "TRACKING ADAPTERS OK" in r.stdout and "FAKE ENGINE" not in r.stderr, tail[-6000:] + r.stderr[-2000:]
+    _check_dump_mat("/tmp/gsh_trk_dump_test/hip_trk_ch_6")
+
+
+def _check_dump_mat(stem):
+    """dump_mat (dll_pll_veml_tracking::save_matfile, trk.cc:1706-1890): <dump>.mat holds every field of every 108-byte record of <dump>.dat under the
+    reference's variable names and classes (MAT-file level 5, host/hip_mat5_writer.h, read back here with scipy)."""
+    import numpy as np
+    import scipy.io as sio
+    rec = np.dtype([("f0", "<f4", 7), ("PRN_start_sample_count", "<u8"), ("f1", "<f4", 12), ("aux2", "<f8"), ("PRN", "<u4"), ("TOW_ms", "<u8"), ("WN", "<i4")])
+    assert rec.itemsize == 108
+    d = np.fromfile(stem + ".dat", dtype=rec)
+    m = sio.loadmat(stem + ".mat")
+    assert len(d) > 100
+    names0 = ["abs_VE", "abs_E", "abs_P", "abs_L", "abs_VL", "Prompt_I", "Prompt_Q"]
+    names1 = ["acc_carrier_phase_rad", "carrier_doppler_hz", "carrier_doppler_rate_hz", "code_freq_chips", "code_freq_rate_chips", "carr_error_hz",
+              "carr_error_filt_hz", "code_error_chips", "code_error_filt_chips", "CN0_SNV_dB_Hz", "carrier_lock_test", "aux1"]
+    assert sorted(k for k in m if not k.startswith("__")) == sorted(names0 + names1 + ["PRN_start_sample_count", "aux2", "PRN", "TOW_ms", "WN"])
+    for k, nm in enumerate(names0):
+        assert m[nm].dtype == np.float32 and m[nm].shape == (1, len(d)) and np.array_equal(m[nm][0].view(np.uint32), d["f0"][:, k].view(np.uint32)), nm
+    for k, nm in enumerate(names1):
+        assert m[nm].dtype == np.float32 and np.array_equal(m[nm][0].view(np.uint32), np.ascontiguousarray(d["f1"][:, k]).view(np.uint32)), nm
+    for nm, dt in (("PRN_start_sample_count", np.uint64), ("aux2", np.float64), ("PRN", np.uint32), ("TOW_ms", np.uint64), ("WN", np.int32)):
+        assert m[nm].dtype == dt and np.array_equal(m[nm][0], d[nm]), nm
 
 
 @pytest.mark.gpu
