@@ -1,5 +1,5 @@
 // End-to-end test of the TrackingInterface adapters (gnss-sdr_amd/host/gnss_sdr_adapters/dll_pll_tracking_hip.{h,cc},
-// dll_pll_veml_tracking_hip.{h,cc}, dll_pll_conf_hip.{h,cc}) and of Hip_Tracking_Loop, compiled against the reference's OWN headers
+// dll_pll_veml_tracking_hip.{h,cc}, dll_pll_conf_hip.{h,cc}) and of Hip_Tracking_Runtime, compiled against the reference's OWN headers
 // (tracking_interface.h, dll_pll_conf.h, gnss_synchro.h, in_memory_configuration.h, the signal constant headers, the replica
 // generators) and tests/host/mock_gnuradio/ for the GNU Radio runtime.
 //
