@@ -264,6 +264,7 @@ int Hip_Tracking_Runtime::take(int slot, uint64_t limit_end, int max_records, gs
             g->in_flight = true;
             lk.unlock();
             int rc = GSH_OK, n_epochs = 1;
+            uint64_t ring_wait = 0;
             std::string err;
             std::vector<uint64_t> gen(g->slot_of_channel.size(), 0);
             std::unique_lock<std::mutex> hl(g->handle_mutex);  // start / stop of the group's channels happen between launches, never during one
@@ -286,9 +287,12 @@ int Hip_Tracking_Runtime::take(int slot, uint64_t limit_end, int max_records, gs
             }
             {
                 // pushes stay out only while the launch is queued (it reads the ring's newest index and files its reader fence)
+                const auto t_ring = std::chrono::steady_clock::now();
                 std::lock_guard<std::mutex> rl(d_ring->mutex());
+                ring_wait = static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_ring).count());
                 rc = gsh_trk_run_begin(g->trk, n_epochs, 1);
             }
+            const auto t_begun = std::chrono::steady_clock::now();
             if (rc != GSH_OK) err = std::string("gsh_trk_run_begin: ") + gsh_last_error();
             if (rc == GSH_OK)
                 {
@@ -297,7 +301,10 @@ int Hip_Tracking_Runtime::take(int slot, uint64_t limit_end, int max_records, gs
                 }
             const auto launch_ns = static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_launch).count());
             lk.lock();
+            const auto t_file = std::chrono::steady_clock::now();
             d_stats.launch_ns += launch_ns;
+            d_stats.ring_wait_ns += ring_wait;
+            d_stats.begin_ns += static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::nanoseconds>(t_begun - t_launch).count());
             uint32_t filed = 0, served = 0;
             for (size_t c = 0; c < g->slot_of_channel.size(); c++)
                 {
@@ -327,6 +334,7 @@ int Hip_Tracking_Runtime::take(int slot, uint64_t limit_end, int max_records, gs
                 }
             g->in_flight = false;
             hl.unlock();
+            d_stats.file_ns += static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_file).count());
             d_stats.launches++;
             d_stats.channel_periods += filed;
             d_stats.channels_served += served;

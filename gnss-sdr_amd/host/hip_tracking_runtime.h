@@ -49,6 +49,9 @@ public:
         uint64_t channels_served{0};  //!< sum over launches of the channels that completed at least one period in it
         uint32_t largest_launch{0};   //!< most channel-periods filed by one launch
         uint64_t launch_ns{0};        //!< wall time inside launches (queueing + kernel + results), summed
+        uint64_t begin_ns{0};         //!< ... of which queueing the launch (gsh_trk_run_begin, ring lock included)
+        uint64_t ring_wait_ns{0};     //!< ... of which waiting for the ring (a push in progress)
+        uint64_t file_ns{0};          //!< wall time filing the records of finished launches into the blocks' queues, summed
         uint64_t push_ns{0};          //!< wall time the front-runner blocks spent appending samples (staging copy + queueing), summed
         uint64_t pushed_samples{0};   //!< samples appended (every sample of the stream once, however many channels read it)
     };
