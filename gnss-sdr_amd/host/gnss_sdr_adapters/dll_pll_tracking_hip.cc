@@ -35,7 +35,7 @@ namespace
 // the stream crosses PCIe once for all of them and ONE launch advances all of them (hip_tracking_runtime.h).  id < 0: a runtime (and ring) of
 // the block's own.  The ring is sized by time, not by the first joiner's code period, so that signals with different periods on the same RF
 // stream (L1 C/A 1 ms, E1 4 ms, L2C 20 ms) fit: 256 ms resident, windows of up to 40 ms contiguous; never less than 64 / 2 of the joiner's periods.
-std::shared_ptr<Hip_Tracking_Runtime> runtime_for(int device, int id, const Dll_Pll_Conf& p, int periods_per_launch, bool register_input)
+std::shared_ptr<Hip_Tracking_Runtime> runtime_for(int device, int id, const Dll_Pll_Conf& p, int periods_per_launch, bool register_input, int channels_per_launch)
 {
     static std::mutex mu;
     static std::map<std::pair<int, int>, std::weak_ptr<Hip_Tracking_Runtime>> runtimes;
@@ -48,7 +48,7 @@ std::shared_ptr<Hip_Tracking_Runtime> runtime_for(int device, int id, const Dll_
                 return nullptr;
             }
         ring->set_auto_register(register_input);
-        return std::make_shared<Hip_Tracking_Runtime>(device, std::move(ring), periods_per_launch);
+        return std::make_shared<Hip_Tracking_Runtime>(device, std::move(ring), periods_per_launch, id < 0 ? 1 : channels_per_launch);
     };
     if (id < 0) return make(std::max<uint64_t>(16, 4ULL * (static_cast<uint64_t>(periods_per_launch) + 2)) * vlen, 2 * vlen);
     std::lock_guard<std::mutex> lk(mu);
@@ -110,7 +110,10 @@ void DllPllTrackingHip::create_tracking_block(const ConfigurationInterface* conf
         }
     // the scheduler re-uses one input buffer for the whole run: page-locking it (lazily, the part each call shows) turns every push into a true DMA
     const bool register_input = configuration->property(role_ + ".hip_register_input_buffer", true);
-    auto runtime = runtime_for(device, ring_id, trk_params_, per_launch, register_input);
+    // most channels of one loop configuration that share a launch (one work-group each; a further handle is opened beyond that).  Every launch brings the
+    // records of all the handle's slots back, so the default stays at what BASELINE's configurations put on one GPU (32 - 50 channels per stream)
+    const int per_handle = configuration->property(role_ + ".hip_channels_per_launch", 64);
+    auto runtime = runtime_for(device, ring_id, trk_params_, per_launch, register_input, per_handle);
     if (!runtime)
         {
             item_size_ = 0;
