@@ -4,6 +4,7 @@
  */
 #include "hip_tracking_runtime.h"
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 Hip_Tracking_Runtime::Hip_Tracking_Runtime(int device, std::shared_ptr<Hip_Sample_Ring> ring, int periods_per_launch, int channels_per_group)
@@ -12,6 +13,7 @@ Hip_Tracking_Runtime::Hip_Tracking_Runtime(int device, std::shared_ptr<Hip_Sampl
       d_periods_per_launch(std::min(std::max(periods_per_launch, 1), 256)),
       d_channels_per_group(std::min(std::max(channels_per_group, 1), 4096))
 {
+    if (const char* e = std::getenv("GSH_TRK_LAUNCH_AHEAD")) d_launch_ahead = (std::atoi(e) != 0);
 }
 
 
@@ -110,6 +112,7 @@ bool Hip_Tracking_Runtime::start(int slot, const float* code, const float* data_
     // it was before (and its records, if any, are dropped by the generation check) or started with the slot ready to receive its records --
     // never the device running a channel whose slot does not know yet.
     std::lock_guard<std::mutex> hl(g->handle_mutex);  // waits for a launch of the group that is in flight
+    if (g->begun) (void)end_and_file(g, nullptr);       // ... and one queued ahead comes in first: its records belong to the channels as they were
     int32_t offset = 0, first_len = 0;
     double acc0 = 0.0;
     std::string err;
@@ -150,6 +153,7 @@ void Hip_Tracking_Runtime::stop(int slot)
         channel = S.channel;
     }
     std::lock_guard<std::mutex> hl(g->handle_mutex);  // as in start(): device state and slot change together, between two launches
+    if (g->begun) (void)end_and_file(g, nullptr);
     (void)gsh_trk_stop(g->trk, channel);
     std::lock_guard<std::mutex> lk(d_mutex);
     Slot& S = *d_slots[slot];
@@ -224,6 +228,7 @@ int Hip_Tracking_Runtime::take(int slot, uint64_t limit_end, int max_records, gs
     std::unique_lock<std::mutex> lk(d_mutex);
     if (slot < 0 || slot >= static_cast<int>(d_slots.size()) || !d_slots[slot]->used) return -1;
     Slot& S = *d_slots[slot];
+    bool waited = false;
     for (;;)
         {
             if (!S.error.empty()) return -1;
@@ -243,6 +248,11 @@ int Hip_Tracking_Runtime::take(int slot, uint64_t limit_end, int max_records, gs
                     S.queue.pop_front();
                     if (lost) break;
                 }
+            if (n > 0 && waited)
+                {
+                    d_stats.wake_ns += static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - d_last_filed).count());
+                    d_stats.wakes++;
+                }
             if (n > 0 || !S.queue.empty() || !S.tracking) return n;
             // nothing filed for this channel: is its next window resident (and inside what the block itself has seen)?
             const uint64_t ring_next = d_ring->next_index();
@@ -258,90 +268,139 @@ int Hip_Tracking_Runtime::take(int slot, uint64_t limit_end, int max_records, gs
             if (g->in_flight)
                 {
                     d_filed.wait(lk);  // the launch in flight may already cover this channel; look again when it has been filed
+                    waited = true;
                     continue;
                 }
-            // ---- become the launcher for the whole group
+            // ---- become the launcher for the whole group: end the launch that was queued ahead, or queue one and end it
             g->in_flight = true;
             lk.unlock();
-            int rc = GSH_OK, n_epochs = 1;
-            uint64_t ring_wait = 0;
-            std::string err;
-            std::vector<uint64_t> gen(g->slot_of_channel.size(), 0);
-            std::unique_lock<std::mutex> hl(g->handle_mutex);  // start / stop of the group's channels happen between launches, never during one
-            const auto t_launch = std::chrono::steady_clock::now();
+            uint32_t filed = 0;
+            bool failed = false;
             {
-                // who takes part, and how far the newest sample lets the furthest-behind channel run: read with the handle locked, so that the
-                // launch sees exactly the channels this snapshot describes
-                std::lock_guard<std::mutex> sl(d_mutex);
-                const uint64_t newest = d_ring->next_index();
-                uint64_t most = 1;
-                for (size_t c = 0; c < g->slot_of_channel.size(); c++)
-                    {
-                        const int s = g->slot_of_channel[c];
-                        if (s < 0) continue;
-                        const Slot& O = *d_slots[s];
-                        gen[c] = O.generation;
-                        if (O.tracking && newest > O.next_window) most = std::max(most, (newest - O.next_window) / vlen);
-                    }
-                n_epochs = static_cast<int>(std::min<uint64_t>(most, static_cast<uint64_t>(d_periods_per_launch)));
+                std::lock_guard<std::mutex> hl(g->handle_mutex);  // start / stop of the group's channels happen between launches, never during one
+                if (!g->begun) (void)begin_launch(g);
+                const int ended_epochs = g->begun_epochs;
+                uint64_t most = 0;
+                if (g->begun)
+                    filed = end_and_file(g, &most);
+                else
+                    failed = true;  // (begin_launch has filed the error into the slots)
+                // launch-ahead: the blocks go through what has just been filed for a while; if the ring already holds a good part of another launch, let the
+                // device start on it now
+                if (d_launch_ahead && !failed && filed != 0 && most >= static_cast<uint64_t>(std::max(1, ended_epochs / 2))) (void)begin_launch(g);
             }
-            {
-                // pushes stay out only while the launch is queued (it reads the ring's newest index and files its reader fence)
-                const auto t_ring = std::chrono::steady_clock::now();
-                std::lock_guard<std::mutex> rl(d_ring->mutex());
-                ring_wait = static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_ring).count());
-                rc = gsh_trk_run_begin(g->trk, n_epochs, 1);
-            }
-            const auto t_begun = std::chrono::steady_clock::now();
-            if (rc != GSH_OK) err = std::string("gsh_trk_run_begin: ") + gsh_last_error();
-            if (rc == GSH_OK)
-                {
-                    rc = gsh_trk_run_end(g->trk, g->records.data(), g->done.data());
-                    if (rc != GSH_OK) err = std::string("gsh_trk_run_end: ") + gsh_last_error();
-                }
-            const auto launch_ns = static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_launch).count());
             lk.lock();
-            const auto t_file = std::chrono::steady_clock::now();
-            d_stats.launch_ns += launch_ns;
-            d_stats.ring_wait_ns += ring_wait;
-            d_stats.begin_ns += static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::nanoseconds>(t_begun - t_launch).count());
-            uint32_t filed = 0, served = 0;
+            g->in_flight = false;
+            d_filed.notify_all();  // (those that found the group busy meanwhile)
+            if (!failed && filed == 0 && S.queue.empty() && S.error.empty()) return 0;  // the device found nothing to do: do not spin on it
+        }
+}
+
+
+// handle_mutex held, d_mutex not
+int Hip_Tracking_Runtime::begin_launch(Group* g)
+{
+    const uint64_t vlen = g->conf.vector_length;
+    const auto t0 = std::chrono::steady_clock::now();
+    int n_epochs = 1;
+    g->begun_generation.assign(g->slot_of_channel.size(), 0);
+    {
+        // who takes part, and how far the newest sample lets the furthest-behind channel run: read with the handle locked, so that the
+        // launch sees exactly the channels this snapshot describes
+        std::lock_guard<std::mutex> lk(d_mutex);
+        const uint64_t newest = d_ring->next_index();
+        uint64_t most = 1;
+        for (size_t c = 0; c < g->slot_of_channel.size(); c++)
+            {
+                const int s = g->slot_of_channel[c];
+                if (s < 0) continue;
+                const Slot& O = *d_slots[s];
+                g->begun_generation[c] = O.generation;
+                if (O.tracking && newest > O.next_window) most = std::max(most, (newest - O.next_window) / vlen);
+            }
+        n_epochs = static_cast<int>(std::min<uint64_t>(most, static_cast<uint64_t>(d_periods_per_launch)));
+    }
+    int rc;
+    uint64_t ring_wait;
+    {
+        // pushes stay out only while the launch is queued (it reads the ring's newest index and files its reader fence)
+        const auto t_ring = std::chrono::steady_clock::now();
+        std::lock_guard<std::mutex> rl(d_ring->mutex());
+        ring_wait = static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_ring).count());
+        rc = gsh_trk_run_begin(g->trk, n_epochs, 1);
+    }
+    const auto dt = static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count());
+    std::lock_guard<std::mutex> lk(d_mutex);
+    d_stats.begin_ns += dt;
+    d_stats.launch_ns += dt;
+    d_stats.ring_wait_ns += ring_wait;
+    if (rc != GSH_OK)
+        {
+            const std::string err = std::string("gsh_trk_run_begin: ") + gsh_last_error();
             for (size_t c = 0; c < g->slot_of_channel.size(); c++)
                 {
                     const int s = g->slot_of_channel[c];
-                    if (s < 0) continue;
-                    Slot& O = *d_slots[s];
-                    if (O.generation != gen[c] || !O.tracking) continue;  // restarted / stopped while the launch ran
-                    if (rc != GSH_OK)
-                        {
-                            O.error = err;
-                            continue;
-                        }
-                    const int done = std::min(std::max(g->done[c], 0), n_epochs);
-                    for (int e = 0; e < done; e++)
-                        {
-                            const gsh_trk_epoch& r = g->records[c * static_cast<size_t>(n_epochs) + static_cast<size_t>(e)];
-                            O.queue.push_back(r);
-                            filed++;
-                            if (r.flags & 2)
-                                {
-                                    O.tracking = false;  // loss of lock: the device has stopped the channel (trk.cc:2009-2014)
-                                    break;
-                                }
-                            O.next_window = r.sample_counter + static_cast<uint64_t>(std::max(r.prn_length_samples, 0));
-                        }
-                    if (done > 0) served++;
+                    if (s >= 0 && d_slots[s]->generation == g->begun_generation[c] && d_slots[s]->tracking) d_slots[s]->error = err;
                 }
-            g->in_flight = false;
-            hl.unlock();
-            d_stats.file_ns += static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_file).count());
-            d_stats.launches++;
-            d_stats.channel_periods += filed;
-            d_stats.channels_served += served;
-            d_stats.largest_launch = std::max(d_stats.largest_launch, filed);
-            d_filed.notify_all();
-            if (rc == GSH_OK && filed == 0 && S.queue.empty()) return 0;  // the device found nothing to do: do not spin on it
+            return 0;
         }
+    g->begun = true;
+    g->begun_epochs = n_epochs;
+    return n_epochs;
+}
+
+
+// handle_mutex held, d_mutex not.  *most_resident: the most whole periods any channel of the group could run on what the ring holds once the records are filed.
+uint32_t Hip_Tracking_Runtime::end_and_file(Group* g, uint64_t* most_resident)
+{
+    const uint64_t vlen = g->conf.vector_length;
+    const int n_epochs = g->begun_epochs;
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = gsh_trk_run_end(g->trk, g->records.data(), g->done.data());
+    const std::string err = (rc != GSH_OK) ? std::string("gsh_trk_run_end: ") + gsh_last_error() : std::string();
+    g->begun = false;
+    const auto t_file = std::chrono::steady_clock::now();
+    std::lock_guard<std::mutex> lk(d_mutex);
+    d_stats.launch_ns += static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::nanoseconds>(t_file - t0).count());
+    const uint64_t newest = d_ring->next_index();
+    uint64_t most = 0;
+    uint32_t filed = 0, served = 0;
+    for (size_t c = 0; c < g->slot_of_channel.size(); c++)
+        {
+            const int s = g->slot_of_channel[c];
+            if (s < 0) continue;
+            Slot& O = *d_slots[s];
+            if (O.generation != g->begun_generation[c] || !O.tracking) continue;  // restarted / stopped while the launch ran
+            if (rc != GSH_OK)
+                {
+                    O.error = err;
+                    continue;
+                }
+            const int done = std::min(std::max(g->done[c], 0), n_epochs);
+            for (int e = 0; e < done; e++)
+                {
+                    const gsh_trk_epoch& r = g->records[c * static_cast<size_t>(n_epochs) + static_cast<size_t>(e)];
+                    O.queue.push_back(r);
+                    filed++;
+                    if (r.flags & 2)
+                        {
+                            O.tracking = false;  // loss of lock: the device has stopped the channel (trk.cc:2009-2014)
+                            break;
+                        }
+                    O.next_window = r.sample_counter + static_cast<uint64_t>(std::max(r.prn_length_samples, 0));
+                }
+            if (done > 0) served++;
+            if (O.tracking && newest > O.next_window) most = std::max(most, (newest - O.next_window) / vlen);
+        }
+    if (most_resident != nullptr) *most_resident = most;
+    d_stats.file_ns += static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_file).count());
+    d_stats.launches++;
+    d_stats.channel_periods += filed;
+    d_stats.channels_served += served;
+    d_stats.largest_launch = std::max(d_stats.largest_launch, filed);
+    d_last_filed = std::chrono::steady_clock::now();
+    d_filed.notify_all();
+    return rc == GSH_OK ? filed : 0;
 }
 
 

@@ -19,7 +19,10 @@
  *     variable and usually find their records filed when they wake (leader / followers; no extra thread, and a single-threaded caller
  *     works unchanged).  The device therefore runs ahead of the slowest block by at most what the fastest one has pushed; a block takes
  *     only records whose samples it has been offered itself (consume_each may not pass its own input);
- *   - start / stop of one channel serialise with the launches of its group and nothing else.
+ *   - launch-ahead: the launcher, having filed a launch, queues the next one at once when at least half as many periods are already resident again,
+ *     and returns without waiting for it; the device then works while the blocks consume what was filed, and the block that next runs dry ends and files
+ *     the launch (GSH_TRK_LAUNCH_AHEAD=0 in the environment turns this off: one launch, waited for, at a time);
+ *   - start / stop of one channel serialise with the launches of its group and nothing else (a launch queued ahead is ended and filed first).
  *
  * Plain C++17 over the C ABI (include/gnss_sdr_hip.h); no HIP headers, no GNU Radio.  No CPU fallback.
  */
@@ -52,6 +55,8 @@ public:
         uint64_t begin_ns{0};         //!< ... of which queueing the launch (gsh_trk_run_begin, ring lock included)
         uint64_t ring_wait_ns{0};     //!< ... of which waiting for the ring (a push in progress)
         uint64_t file_ns{0};          //!< wall time filing the records of finished launches into the blocks' queues, summed
+        uint64_t wake_ns{0};          //!< from a launch's records being filed to a block that waited for them having taken its own, summed over those blocks
+        uint64_t wakes{0};            //!< ... how many such takes
         uint64_t push_ns{0};          //!< wall time the front-runner blocks spent appending samples (staging copy + queueing), summed
         uint64_t pushed_samples{0};   //!< samples appended (every sample of the stream once, however many channels read it)
     };
@@ -106,7 +111,12 @@ private:
         gsh_trk_t* trk{nullptr};
         std::vector<int> slot_of_channel;  // -1: free
         std::mutex handle_mutex;           // the C handle: one thread at a time (launch, start, stop)
-        bool in_flight{false};             // guarded by d_mutex
+        bool in_flight{false};             // guarded by d_mutex: a thread is queueing, ending or filing a launch of the group
+        // A launch that has been queued and not yet waited for (launch-ahead): guarded by handle_mutex.  Whoever next needs the handle -- the block that finds
+        // its queue empty, start(), stop() -- ends and files it first.
+        bool begun{false};
+        int begun_epochs{0};
+        std::vector<uint64_t> begun_generation;  // Slot::generation per channel when the launch was queued
         std::vector<gsh_trk_epoch> records;
         std::vector<int32_t> done;
     };
@@ -122,18 +132,23 @@ private:
         std::string error;
     };
     Group* group_for(const gsh_trk_conf& conf, int max_code_length, int* channel);
+    // the two halves of a launch; both with the group's handle_mutex held and d_mutex NOT held
+    int begin_launch(Group* g);                        // how far the resident samples let the group run -> gsh_trk_run_begin; returns the periods queued (0: none)
+    uint32_t end_and_file(Group* g, uint64_t* most_resident);  // gsh_trk_run_end -> the blocks' queues; returns the records filed
     uint64_t lowest_next_window_locked() const;
 
     int d_device;
     std::shared_ptr<Hip_Sample_Ring> d_ring;
     int d_periods_per_launch;
     int d_channels_per_group;
+    bool d_launch_ahead{true};
     mutable std::mutex d_mutex;  // slots, queues, in_flight flags, stats
     std::condition_variable d_filed;
     std::vector<std::unique_ptr<Group>> d_groups;
     std::vector<std::unique_ptr<Slot>> d_slots;
     std::string d_error;
     Stats d_stats;
+    std::chrono::steady_clock::time_point d_last_filed{};  // when the latest launch's records were filed (statistics)
     std::atomic<uint64_t> d_push_ns{0}, d_pushed_samples{0};
 };
 
