@@ -1232,6 +1232,8 @@ struct gsh_trk
     size_t h_records_cap{0};
     gsh::TrkTail* h_tail{nullptr};           // n_channels: position / periods done / active flag after the run
     int pending_epochs{-1};                  // >= 0: a run has been begun and not ended
+    bool host_records{true};                 // the kernel writes records and tails straight into the page-locked host buffers: no copies queued behind it, 4 - 20 us less
+                                             // per launch (profiles/ab/r03/loop_host_records.txt).  GSH_TRK_HOST_RECORDS=0: device buffers + two copies, as before
     bool pending_records{false};
 };
 
@@ -1245,7 +1247,7 @@ size_t trk_lds_bytes(const gsh_trk* t)
     return tabs * sizeof(float) + (gsh::mcdev::MC_WAVES + 1) * GSH_MAX_TAPS * sizeof(float2);  // outputs + one row of partial sums per wave (correlate_window)
 }
 
-int trk_launch(gsh_trk* t, int n_epochs, gsh_trk_epoch* d_records)
+int trk_launch(gsh_trk* t, int n_epochs, gsh_trk_epoch* d_records, gsh::TrkTail* d_tail = nullptr)
 {
     gsh::TrkArgs a;
     a.conf = t->d_conf;
@@ -1280,7 +1282,7 @@ int trk_launch(gsh_trk* t, int n_epochs, gsh_trk_epoch* d_records)
     a.chan = t->d_chan;
     a.lock = t->d_lock;
     a.records = d_records;
-    a.tail = t->d_tail;
+    a.tail = d_tail != nullptr ? d_tail : t->d_tail;
     a.n_epochs = n_epochs;
     a.code_period = static_cast<double>(t->conf.code_length_chips) / t->conf.code_chip_rate;
     {
@@ -1382,6 +1384,7 @@ extern "C"
         if ((e = hipMemset(t->d_lock, 0, sizeof(gsh::LockState) * n_channels)) != hipSuccess) return fail(e, "hipMemset(lock)");
         if ((e = hipMalloc(&t->d_tail, sizeof(gsh::TrkTail) * n_channels)) != hipSuccess) return fail(e, "hipMalloc(tail)");
         if ((e = hipHostMalloc(&t->h_tail, sizeof(gsh::TrkTail) * n_channels, hipHostMallocDefault)) != hipSuccess) return fail(e, "hipHostMalloc(tail)");
+        if (const char* hr = std::getenv("GSH_TRK_HOST_RECORDS")) t->host_records = (std::atoi(hr) != 0);
         if ((e = hipMalloc(&t->d_conf, sizeof(gsh_trk_conf))) != hipSuccess) return fail(e, "hipMalloc(conf)");
         if ((e = hipMemcpy(t->d_conf, &t->conf, sizeof(gsh_trk_conf), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy(conf)");
         if ((e = hipEventCreate(&t->ev0)) != hipSuccess) return fail(e, "hipEventCreate");
@@ -1601,7 +1604,7 @@ extern "C"
         // (grown in steps of 64 periods per channel: a caller whose launches lengthen period by period -- the tracking runtime while its channels start --
         // would otherwise free and allocate page-locked memory at every launch, 0.3 ms each time: profiles/ab/r03/dropin_blocks_r03_final.txt)
         const size_t n_cap = static_cast<size_t>(t->n_channels) * ((static_cast<size_t>(n_epochs) + 63) / 64 * 64);
-        if (n_rec > t->records_cap)
+        if (!t->host_records && n_rec > t->records_cap)
             {
                 if (t->d_records) GSH_HIP(hipFree(t->d_records));
                 t->d_records = nullptr;
@@ -1622,15 +1625,31 @@ extern "C"
         static std::atomic<int> cnt{0};
         const auto t0 = std::chrono::steady_clock::now();
 #endif
-        int rc = trk_launch(t, n_epochs, n_rec > 0 ? t->d_records : nullptr);
+        gsh_trk_epoch* rec_dst = n_rec > 0 ? t->d_records : nullptr;
+        gsh::TrkTail* tail_dst = nullptr;
+        if (t->host_records)
+            {
+                void* p = nullptr;
+                if (n_rec > 0)
+                    {
+                        GSH_HIP(hipHostGetDevicePointer(&p, t->h_records, 0));
+                        rec_dst = static_cast<gsh_trk_epoch*>(p);
+                    }
+                GSH_HIP(hipHostGetDevicePointer(&p, t->h_tail, 0));
+                tail_dst = static_cast<gsh::TrkTail*>(p);
+            }
+        int rc = trk_launch(t, n_epochs, rec_dst, tail_dst);
         if (rc != GSH_OK) return rc;
 #ifdef GSH_TRACE_TRK_BEGIN
         const auto t1 = std::chrono::steady_clock::now();
 #endif
-        // two copies come back: the records (periods a channel did not run are zeroed on the host in _end, not by a fill kernel in front of the
-        // launch) and one 16-byte tail per channel
-        if (n_rec > 0) GSH_HIP(hipMemcpyAsync(t->h_records, t->d_records, sizeof(gsh_trk_epoch) * n_rec, hipMemcpyDeviceToHost, t->stream));
-        GSH_HIP(hipMemcpyAsync(t->h_tail, t->d_tail, sizeof(gsh::TrkTail) * t->n_channels, hipMemcpyDeviceToHost, t->stream));
+        // what comes back: the records (periods a channel did not run are zeroed on the host in _end, not by a fill kernel in front of the launch) and one
+        // 16-byte tail per channel -- written by the kernel itself into the host buffers, or copied
+        if (!t->host_records)
+            {
+                if (n_rec > 0) GSH_HIP(hipMemcpyAsync(t->h_records, t->d_records, sizeof(gsh_trk_epoch) * n_rec, hipMemcpyDeviceToHost, t->stream));
+                GSH_HIP(hipMemcpyAsync(t->h_tail, t->d_tail, sizeof(gsh::TrkTail) * t->n_channels, hipMemcpyDeviceToHost, t->stream));
+            }
 #ifdef GSH_TRACE_TRK_BEGIN
         const auto t2 = std::chrono::steady_clock::now();
         acc_ns[0] += std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();

@@ -284,3 +284,22 @@ def test_loop_follows_a_live_ring(gpu):
     late.close()
     live.close()
     ring.close()
+
+
+@pytest.mark.gpu
+def test_records_written_by_the_kernel_into_host_memory_equal_the_copied_ones(gpu, tmp_path):
+    """gsh_trk_run_begin hands the kernel the page-locked host buffers themselves (the default since the end of round 3; GSH_TRK_HOST_RECORDS=0: device
+    buffers and two copies behind the kernel).  Both ways must deliver the same bytes: profiles/ab/r03/loop_records.py (8 channels, lock detectors, FLL
+    pull-in, channels that lose lock; 4 800 periods in six launches) in one process per mode."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = []
+    for mode in ("0", "1"):
+        path = str(tmp_path / f"records_{mode}.bin")
+        r = subprocess.run([sys.executable, os.path.join(root, "profiles", "ab", "r03", "loop_records.py"), path], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, GSH_TRK_HOST_RECORDS=mode), cwd=root)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        out.append(open(path, "rb").read())
+    assert len(out[0]) > 1_000_000 and out[0] == out[1]
