@@ -21,6 +21,7 @@
 #define GSH_TRK_THREADS 1024
 #endif
 #define GSH_MC_THREADS GSH_TRK_THREADS
+#include "exact_division.h"
 #include "mcorr_device.h"
 #include "sample_stream.h"
 #include <algorithm>
@@ -28,6 +29,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstddef>
+#include <type_traits>
 #include <new>
 #include <vector>
 
@@ -144,7 +146,30 @@ struct TrkArgs
     double code_period;                 // d_code_period = code_length_chips / code_chip_rate
     unsigned long long pull_in_limit;   // samples since acquisition below which the pull-in transitory lasts (trk.cc:1912-1915), see trk_launch
     unsigned long long bit_sync_limit;  // samples since acquisition from which a channel still in state 2 is declared lost (trk.cc:2000-2007); ~0: never
+    // correctly rounded reciprocals of the two launch-constant divisors of the loop arithmetic, 0.0 when the configuration does not qualify (div_by_constant below)
+    double inv_fs_in, inv_signal_carrier_freq;
 };
+
+constexpr double INV_TWO_PI_D = 1.0 / GNSS_TWO_PI_D;  // correctly rounded by the compiler; 2 pi's significand is not all ones
+// fmod(x, 2 pi) of the carrier phase remainder (a few turns): exact_division.h; arguments beyond a million turns take the library's path
+template <bool FAST>
+__device__ __forceinline__ double fmod_two_pi(double x)
+{
+    if constexpr (FAST && GSH_TRK_FAST_DIV != 0)
+        {
+            bool slow;
+            const double r = fmod_by_constant(x, GNSS_TWO_PI_D, INV_TWO_PI_D, &slow);
+            if (__builtin_expect(!slow, 1)) return r;
+        }
+    return fmod(x, GNSS_TWO_PI_D);
+}
+// div_by_constant with the "does it apply" decision taken by the caller at compile time (y is then known to be the reciprocal)
+template <bool FAST>
+__device__ __forceinline__ double div_by_constant_if(double a, double b, double y)
+{
+    if constexpr (FAST && GSH_TRK_FAST_DIV != 0) return div_by_constant_vetted(a, b, y);
+    return a / b;
+}
 
 // ---- discriminators, T/tracking_discriminators.cc (float / double mix as written there) ---------------------
 __device__ __forceinline__ double phase_unwrap_d(double p)  // :27-41
@@ -571,6 +596,7 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
             // On a loss of lock the period's loop-filter updates have happened although the reference skips them (trk.cc:2009-2014) -- nothing reads them again:
             // the channel stops, and gsh_trk_start builds its state afresh.
             const double code_period = a.code_period;  // d_code_period
+            const double inv_two_pi = (a.inv_fs_in != 0.0) ? INV_TWO_PI_D : 0.0;  // (the FLL term's dividend has the correlation time in it: under the host's verdict on the configuration)
             float2 acc[NT];
 #pragma unroll
             for (int t = 0; t < NT; t++) acc[t] = out[t];
@@ -635,11 +661,11 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                                 {
                                     const bool cloop_now = c.enable_symbol_sync ? (lk.cloop != 0) : (c.cloop != 0);
                                     const double corr_time = (c.enable_symbol_sync && lk.corr_time > 0.0) ? lk.corr_time : code_period;  // d_current_correlation_time_s
-                                    carr_phase_error_hz = (cloop_now ? pll_cloop_two_quadrant_atan_d(P) : pll_four_quadrant_atan_d(P)) / GNSS_TWO_PI_D;
+                                    carr_phase_error_hz = div_by_constant_if<GSH_TRK_FAST_DIV != 0>(cloop_now ? pll_cloop_two_quadrant_atan_d(P) : pll_four_quadrant_atan_d(P), GNSS_TWO_PI_D, INV_TWO_PI_D);  // (a float arctangent: zero, or no smaller than 1e-45)
                                     float carr_error_filt;
                                     if ((pull_in && c.enable_fll_pull_in) || c.enable_fll_steady_state)
                                         {
-                                            carr_freq_error_hz = fll_diff_atan_d(make_float2(s.p_old_re, s.p_old_im), P, 0.0, corr_time) / GNSS_TWO_PI_D;
+                                            carr_freq_error_hz = div_by_constant(fll_diff_atan_d(make_float2(s.p_old_re, s.p_old_im), P, 0.0, corr_time), GNSS_TWO_PI_D, inv_two_pi);
                                             s.p_old_re = P.x;
                                             s.p_old_im = P.y;
                                             if (pull_in && c.enable_fll_pull_in)
@@ -770,12 +796,21 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                         }
                     else
                         {
+                    // The join and update_tracking_vars hold the loop's divisions by launch constants.  Whether the exact short form applies (div_by_constant,
+                    // exact_division.h) is the host's verdict on the configuration -- ONE wave-uniform branch around the whole stretch, compile-time inside: a test at
+                    // every division would cut the lane's instruction stream into pieces the scheduler cannot interleave (8.06 instead of 7.96 us per period).
+                    int prn_len = 0;
+#ifdef GSH_TRK_PROFILE
+                    long long t_c = 0;
+#endif
+                    auto join_and_update = [&](auto fast_tag) {
+                    constexpr bool FAST = decltype(fast_tag)::value;
                     // ---- run_dll_pll, the join: trk.cc:1317-1324
                     const double code_error_filt_chips = mail.code_error_filt_chips;
                     if (run_state != 3)
                         {
                             s.code_freq_chips = c.code_chip_rate - code_error_filt_chips;
-                            if (c.carrier_aiding) s.code_freq_chips += s.carrier_doppler_hz * c.code_chip_rate / c.signal_carrier_freq;
+                            if (c.carrier_aiding) s.code_freq_chips += div_by_constant_if<FAST>(s.carrier_doppler_hz * c.code_chip_rate, c.signal_carrier_freq, a.inv_signal_carrier_freq);
                             if (c.enable_doppler_correction && !pull_in && !lk.corrected_doppler)  // trk.cc:1326-1346
                                 {
                                     lk.dll_filt_sum += static_cast<double>(static_cast<float>(code_error_filt_chips));
@@ -807,15 +842,15 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                         }
 
 #ifdef GSH_TRK_PROFILE
-                    const long long t_c = clock64();
+                    t_c = clock64();
 #endif
                     // ---- update_tracking_vars, trk.cc:1409-1483 (rate terms are zero outside high_dyn)
                     const double t_chip = 1.0 / s.code_freq_chips;
                     const double t_prn = t_chip * static_cast<double>(c.code_length_chips);
                     const double t_prn_samples = t_prn * c.fs_in;
                     const double k_blk = t_prn_samples + s.rem_code_phase_samples;
-                    const int prn_len = static_cast<int>(floor(k_blk));
-                    s.carrier_phase_step_rad = GNSS_TWO_PI_D * (s.carrier_doppler_hz + c.cfo_frequency_hz) / c.fs_in;
+                    prn_len = static_cast<int>(floor(k_blk));
+                    s.carrier_phase_step_rad = div_by_constant_if<FAST>(GNSS_TWO_PI_D * (s.carrier_doppler_hz + c.cfo_frequency_hz), c.fs_in, a.inv_fs_in);
                     if (HD)  // trk.cc:1425-1443
                         {
                             const int SL = static_cast<int>(c.smoother_length), cap = 2 * SL;
@@ -841,9 +876,9 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                     const double dphi = s.carrier_phase_step_rad * static_cast<double>(prn_len) +
                                         0.5 * s.carrier_phase_rate_step_rad * static_cast<double>(prn_len) * static_cast<double>(prn_len);
                     s.rem_carr_phase_rad += static_cast<float>(dphi);
-                    s.rem_carr_phase_rad = static_cast<float>(fmod(static_cast<double>(s.rem_carr_phase_rad), GNSS_TWO_PI_D));
+                    s.rem_carr_phase_rad = static_cast<float>(fmod_two_pi<FAST>(static_cast<double>(s.rem_carr_phase_rad)));
                     s.acc_carrier_phase_rad -= dphi;
-                    s.code_phase_step_chips = s.code_freq_chips / c.fs_in;
+                    s.code_phase_step_chips = div_by_constant_if<FAST>(s.code_freq_chips, c.fs_in, a.inv_fs_in);
                     if (HD)  // trk.cc:1458-1480
                         {
                             const int SL = static_cast<int>(c.smoother_length), cap = 2 * SL;
@@ -867,7 +902,12 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                                 }
                         }
                     s.rem_code_phase_samples = k_blk - static_cast<double>(prn_len);
-                    s.rem_code_phase_chips = s.code_freq_chips * s.rem_code_phase_samples / c.fs_in;
+                    s.rem_code_phase_chips = div_by_constant_if<FAST>(s.code_freq_chips * s.rem_code_phase_samples, c.fs_in, a.inv_fs_in);
+                    };
+                    if (a.inv_fs_in != 0.0)
+                        join_and_update(std::true_type{});
+                    else
+                        join_and_update(std::false_type{});
 
 #ifdef GSH_TRK_PROFILE
                     const long long t_d = clock64();
@@ -1247,6 +1287,22 @@ size_t trk_lds_bytes(const gsh_trk* t)
     return tabs * sizeof(float) + (gsh::mcdev::MC_WAVES + 1) * GSH_MAX_TAPS * sizeof(float2);  // outputs + one row of partial sums per wave (correlate_window)
 }
 
+// div_by_constant's preconditions for a whole configuration: the two divisors positive, finite, not with a significand of all ones, and every constant that
+// enters a dividend (sampling rate, chip rate, carrier frequency, the front end's frequency offset) of a magnitude that keeps products and residuals inside the
+// normal numbers whatever float the loop filters deliver.  Any receiver configuration passes; one that does not gets the plain divisions (reciprocals 0.0).
+bool fast_division_applies(const gsh_trk_conf& c)
+{
+    auto sane = [](double v, double lo, double hi) { return v >= lo && v <= hi; };
+    auto all_ones = [](double v) {
+        unsigned long long bits;
+        std::memcpy(&bits, &v, sizeof(bits));
+        return (bits & 0xFFFFFFFFFFFFFull) == 0xFFFFFFFFFFFFFull;
+    };
+    if (!sane(c.fs_in, 1.0, 1.0e12) || !sane(c.code_chip_rate, 1.0e-3, 1.0e12) || !sane(c.signal_carrier_freq, 1.0, 1.0e15)) return false;
+    if (!(c.cfo_frequency_hz == 0.0 || sane(std::fabs(c.cfo_frequency_hz), 1.0e-30, 1.0e12))) return false;
+    return !all_ones(c.fs_in) && !all_ones(c.signal_carrier_freq);
+}
+
 int trk_launch(gsh_trk* t, int n_epochs, gsh_trk_epoch* d_records, gsh::TrkTail* d_tail = nullptr)
 {
     gsh::TrkArgs a;
@@ -1285,6 +1341,9 @@ int trk_launch(gsh_trk* t, int n_epochs, gsh_trk_epoch* d_records, gsh::TrkTail*
     a.tail = d_tail != nullptr ? d_tail : t->d_tail;
     a.n_epochs = n_epochs;
     a.code_period = static_cast<double>(t->conf.code_length_chips) / t->conf.code_chip_rate;
+    const bool fast_div = fast_division_applies(t->conf);
+    a.inv_fs_in = fast_div ? 1.0 / t->conf.fs_in : 0.0;
+    a.inv_signal_carrier_freq = fast_div ? 1.0 / t->conf.signal_carrier_freq : 0.0;
     {
         // trk.cc:1912-1915: the transitory lasts while !(pull_in_time_s < (samples since acquisition) / fs) in integer arithmetic, i.e. while the sample
         // count is below (pull_in_time_s + 1) * fs -- one comparison per period instead of a 64-bit division
