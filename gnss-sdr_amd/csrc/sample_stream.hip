@@ -3,6 +3,7 @@
 #include "sample_stream.h"
 #include "sample_convert.h"
 #include <algorithm>
+#include <cstdlib>
 #include <new>
 
 namespace gsh
@@ -55,8 +56,20 @@ namespace
 {
 using gsh::set_error;
 
-// queue the conversion of n items at d_src into ring positions of absolute indices [first, first + n) on `st`
-int write_items(gsh_stream* s, const void* d_src, unsigned long long n, int item_type, int conj, hipStream_t st)
+// GSH_STREAM_DIRECT_DMA=0: page-locked gr_complex items go through the device staging buffer like every other item type (the path of rounds 2-3, for A/B runs)
+bool stream_direct_dma()
+{
+    static const bool on = [] {
+        const char* e = std::getenv("GSH_STREAM_DIRECT_DMA");
+        return e == nullptr || std::atoi(e) != 0;
+    }();
+    return on;
+}
+
+// queue the conversion of n items at d_src into ring positions of absolute indices [first, first + n) on `st`.  host_src: d_src is page-locked HOST memory
+// holding gr_complex items to be taken as they are -- the ring positions are then the destination of the DMA itself (no staging buffer, no second copy);
+// *copied_after (an event), when given, is recorded behind the last read of d_src.
+int write_items(gsh_stream* s, const void* d_src, unsigned long long n, int item_type, int conj, hipStream_t st, bool host_src = false, hipEvent_t copied_after = nullptr)
 {
     const size_t isz = gsh::item_bytes(item_type);
     {
@@ -78,8 +91,16 @@ int write_items(gsh_stream* s, const void* d_src, unsigned long long n, int item
             const unsigned long long p = (s->next + done) % C;
             const unsigned long long len = std::min(n - done, C - p);
             const char* src = static_cast<const char*>(d_src) + done * isz;
-            int rc = gsh::convert_to_complex(src, item_type, conj, s->d_ring + p, len, st);
-            if (rc != GSH_OK) return rc;
+            if (host_src)
+                {
+                    GSH_HIP(hipMemcpyAsync(s->d_ring + p, src, sizeof(float2) * len, hipMemcpyHostToDevice, st));
+                    if (done + len == n && copied_after != nullptr) GSH_HIP(hipEventRecord(copied_after, st));  // (before the mirror copy: that one reads the ring)
+                }
+            else
+                {
+                    int rc = gsh::convert_to_complex(src, item_type, conj, s->d_ring + p, len, st);
+                    if (rc != GSH_OK) return rc;
+                }
             if (p < M)  // keep the mirror behind the end in step
                 {
                     const unsigned long long ml = std::min(len, M - p);
@@ -279,6 +300,17 @@ extern "C"
         if (first_index) *first_index = s->next;
         if (n == 0) return GSH_OK;
         GSH_HIP(hipSetDevice(s->device));
+        if (item_type == GSH_ITEM_GR_COMPLEX && !inverted_spectrum && stream_direct_dma())
+            {
+                // items that are the ring's own format: the DMA's destination is the ring (profiles/ab/r03/dropin_direct_dma.txt)
+                if (s->copied == nullptr) GSH_HIP(hipEventCreateWithFlags(&s->copied, hipEventDisableTiming));
+                int rc = write_items(s, items, n, item_type, 0, s->stream, true, s->copied);
+                if (rc != GSH_OK) return rc;
+                rc = record_push(s, s->next + n, s->stream);
+                if (rc != GSH_OK) return rc;
+                s->next += n;
+                return GSH_OK;
+            }
         const int slot = s->stage_next;
         s->stage_next = (s->stage_next + 1) % gsh_stream::NSTAGE;
         const size_t bytes = static_cast<size_t>(n) * isz;
@@ -335,6 +367,17 @@ extern "C"
         if (first_index) *first_index = s->next;
         if (n == 0) return GSH_OK;
         GSH_HIP(hipSetDevice(s->device));
+        if (item_type == GSH_ITEM_GR_COMPLEX && !inverted_spectrum && stream_direct_dma())
+            {
+                // items that are the ring's own format: the DMA's destination is the ring (profiles/ab/r03/dropin_direct_dma.txt)
+                if (s->copied == nullptr) GSH_HIP(hipEventCreateWithFlags(&s->copied, hipEventDisableTiming));
+                int rc = write_items(s, items, n, item_type, 0, s->stream, true, s->copied);
+                if (rc != GSH_OK) return rc;
+                rc = record_push(s, s->next + n, s->stream);
+                if (rc != GSH_OK) return rc;
+                s->next += n;
+                return GSH_OK;
+            }
         const int slot = s->stage_next;
         s->stage_next = (s->stage_next + 1) % gsh_stream::NSTAGE;
         const size_t bytes = static_cast<size_t>(n) * isz;

@@ -61,6 +61,25 @@ class SampleStream:
         check(self._lib.gsh_stream_push_async(self._h, C.c_void_p(ptr), n, ITEM_TYPES[item_type], int(inverted_spectrum), C.byref(first)))
         return int(first.value)
 
+    def push_pinned(self, items: np.ndarray, item_type: str = "gr_complex", inverted_spectrum: bool = False) -> int:
+        """gsh_stream_push_pinned: `items` is page-locked for the call (gsh_host_register on its pages) and handed to the DMA engine as it lies --
+        gr_complex items straight into their ring positions; returns when the array may be reused."""
+        t = ITEM_TYPES[item_type]
+        a = np.ascontiguousarray(items, _NP[t])
+        n = a.size if t == GSH_ITEM_GR_COMPLEX else a.size // 2
+        first = C.c_uint64(0)
+        if n == 0:
+            check(self._lib.gsh_stream_push_pinned(self._h, None, 0, t, int(inverted_spectrum), C.byref(first)))
+            return int(first.value)
+        lo = a.ctypes.data & ~4095
+        hi = (a.ctypes.data + a.nbytes + 4095) & ~4095
+        check(self._lib.gsh_host_register(self.device, C.c_void_p(lo), hi - lo))
+        try:
+            check(self._lib.gsh_stream_push_pinned(self._h, C.c_void_p(a.ctypes.data), n, t, int(inverted_spectrum), C.byref(first)))
+        finally:
+            check(self._lib.gsh_host_unregister(C.c_void_p(lo)))
+        return int(first.value)
+
     def wait(self) -> None:
         check(self._lib.gsh_stream_wait(self._h))
 

@@ -45,6 +45,33 @@ def test_integer_items_convert_exactly(gpu, item, dtype, lo, hi, inv):
     assert np.array_equal(got.view(np.uint32), model.view(np.uint32))  # bit equality, including the sign of conj's zeros
 
 
+def test_page_locked_items_reach_the_ring_by_dma(gpu):
+    """gsh_stream_push_pinned: gr_complex items go by DMA straight into their ring positions (two pieces when the push wraps; the mirror behind the ring's
+    end follows: the tracking adapters' GPU tests read their windows through it), inverted-spectrum and integer items through the device staging buffer and
+    the conversion kernel.  Model: the last `cap` samples pushed, compared bit for bit after every push."""
+    rng = np.random.default_rng(17)
+    cap, win = 6000, 1500
+    s = _stream(gpu, cap, win)
+    model = np.zeros(0, np.complex64)
+    plan = [(1500, "gr_complex", False), (4000, "gr_complex", False), (999, "gr_complex", False), (5999, "gr_complex", False), (0, "gr_complex", False),
+            (1, "gr_complex", False), (3333, "gr_complex", True), (6000, "gr_complex", False), (777, "ibyte", False), (2048, "ishort", True), (4100, "gr_complex", False)]
+    for n, item, inv in plan:
+        if item == "gr_complex":
+            x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+            c = x
+        else:
+            dt = np.int8 if item == "ibyte" else np.int16
+            x = rng.integers(-100, 100, size=(n, 2)).astype(dt)
+            c = _as_complex(x)
+        first = s.push_pinned(x, item, inverted_spectrum=inv)
+        assert first == len(model)
+        model = np.concatenate([model, np.conj(c) if inv else c])
+        lo, hi = s.range()
+        assert hi == len(model) and lo == max(0, len(model) - cap)
+        assert np.array_equal(s.read(lo, hi - lo).view(np.uint32), model[lo:hi].view(np.uint32))
+    s.close()
+
+
 def test_ring_wraps_and_keeps_the_last_capacity_samples(gpu):
     rng = np.random.default_rng(5)
     cap, win = 5000, 1200
