@@ -405,7 +405,8 @@ extern "C"
      * epochs_done[n_channels]: periods completed (a channel stops when its window would leave the stream). */
     int gsh_trk_run(gsh_trk_t* t, int n_epochs, gsh_trk_epoch* records, int32_t* epochs_done);
     /* the same in two halves, for a caller that serialises launches against pushes into the ring itself (Hip_Tracking_Runtime): _begin queues
-     * the launch and the copies of its results into page-locked host memory on the loop's stream and returns at once -- it is the only part
+     * the launch on the loop's stream -- the kernel writes its results into page-locked host memory itself (GSH_TRK_HOST_RECORDS=0 in the environment:
+     * into device memory, with two copies queued behind it) -- and returns at once; it is the only part
      * that looks at the ring's bookkeeping (newest sample, reader fences), so the ring's lock is needed around it alone and the next block of
      * samples can travel while the kernel runs; _end waits for the stream and hands the results over.  One launch in flight per handle. */
     int gsh_trk_run_begin(gsh_trk_t* t, int n_epochs, int want_records);
