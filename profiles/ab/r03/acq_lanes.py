@@ -1,3 +1,7 @@
+"""Two against three acquisition batches in flight (gsh_acq_time_dwells_pipelined; the third lane is profiles/ab/r03/acq_three_lanes.patch, not in the tree:
+GSH_ACQ_PIPELINE_LANES=3 has no effect without it).  Measured at the end of round 3, same box, alternating:
+    lanes 2   112.5 112.5 112.4 112.5 / 112.9 112.9 112.9 112.7 us per batch
+    lanes 3   111.7 111.3 111.7 111.5 / 111.6 111.5 111.5 111.7 us per batch"""
 import os, sys
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 import numpy as np, torch
