@@ -94,6 +94,7 @@ void Hip_Tracking_Runtime::detach(int slot)
     S.group->slot_of_channel[static_cast<size_t>(S.channel)] = -1;
     S.used = false;
     S.generation++;
+    d_lowest_next_window.store(lowest_next_window_locked(), std::memory_order_release);
 }
 
 
@@ -127,8 +128,9 @@ bool Hip_Tracking_Runtime::start(int slot, const float* code, const float* data_
     S.queue.clear();
     S.error = err;
     S.tracking = err.empty();
+    if (err.empty()) S.next_window = start_sample;
+    d_lowest_next_window.store(lowest_next_window_locked(), std::memory_order_release);
     if (!err.empty()) return false;
-    S.next_window = start_sample;
     if (samples_offset != nullptr) *samples_offset = offset;
     if (first_prn_length != nullptr) *first_prn_length = first_len;
     return true;
@@ -160,6 +162,7 @@ void Hip_Tracking_Runtime::stop(int slot)
     S.tracking = false;
     S.generation++;
     S.queue.clear();
+    d_lowest_next_window.store(lowest_next_window_locked(), std::memory_order_release);
 }
 
 
@@ -191,11 +194,9 @@ uint64_t Hip_Tracking_Runtime::lowest_next_window_locked() const
 bool Hip_Tracking_Runtime::push(const std::complex<float>* samples, uint64_t first_index, uint64_t n, bool need_resident)
 {
     if (!ok()) return false;
-    uint64_t lowest;
-    {
-        std::lock_guard<std::mutex> lk(d_mutex);
-        lowest = lowest_next_window_locked();
-    }
+    // (kept up to date, under d_mutex, wherever a slot's next window or tracking flag changes: every block calls push in every general_work, and a scan of the
+    // slots under the runtime's lock there is one more thing 32 threads queue up for)
+    const uint64_t lowest = d_lowest_next_window.load(std::memory_order_acquire);
     // never push so far ahead that the window the slowest channel correlates next would be overwritten
     if (lowest != UINT64_MAX)
         {
@@ -263,6 +264,7 @@ int Hip_Tracking_Runtime::take(int slot, uint64_t limit_end, int max_records, gs
                     S.error = "the channel's next window [" + std::to_string(S.next_window) + "..) is no longer resident (ring holds [" +
                               std::to_string(d_ring->oldest_index()) + ", " + std::to_string(ring_next) + "))";
                     S.tracking = false;
+                    d_lowest_next_window.store(lowest_next_window_locked(), std::memory_order_release);
                     return -1;
                 }
             if (g->in_flight)
@@ -393,6 +395,7 @@ uint32_t Hip_Tracking_Runtime::end_and_file(Group* g, uint64_t* most_resident)
             if (O.tracking && newest > O.next_window) most = std::max(most, (newest - O.next_window) / vlen);
         }
     if (most_resident != nullptr) *most_resident = most;
+    d_lowest_next_window.store(lowest_next_window_locked(), std::memory_order_release);
     d_stats.file_ns += static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_file).count());
     d_stats.launches++;
     d_stats.channel_periods += filed;

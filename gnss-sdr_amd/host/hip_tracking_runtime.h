@@ -149,6 +149,7 @@ private:
     std::string d_error;
     Stats d_stats;
     std::chrono::steady_clock::time_point d_last_filed{};  // when the latest launch's records were filed (statistics)
+    std::atomic<uint64_t> d_lowest_next_window{UINT64_MAX};  // min over the tracking slots' next windows (UINT64_MAX: none), written under d_mutex
     std::atomic<uint64_t> d_push_ns{0}, d_pushed_samples{0};
 };
 
