@@ -269,7 +269,7 @@ int Hip_Tracking_Runtime::take(int slot, uint64_t limit_end, int max_records, gs
                 }
             if (g->in_flight)
                 {
-                    d_filed.wait(lk);  // the launch in flight may already cover this channel; look again when it has been filed
+                    g->filed.wait(lk);  // the launch in flight may already cover this channel; look again when it has been filed
                     waited = true;
                     continue;
                 }
@@ -293,7 +293,7 @@ int Hip_Tracking_Runtime::take(int slot, uint64_t limit_end, int max_records, gs
             }
             lk.lock();
             g->in_flight = false;
-            d_filed.notify_all();  // (those that found the group busy meanwhile)
+            g->filed.notify_all();  // (those that found the group busy meanwhile)
             if (!failed && filed == 0 && S.queue.empty() && S.error.empty()) return 0;  // the device found nothing to do: do not spin on it
         }
 }
@@ -402,7 +402,7 @@ uint32_t Hip_Tracking_Runtime::end_and_file(Group* g, uint64_t* most_resident)
     d_stats.channels_served += served;
     d_stats.largest_launch = std::max(d_stats.largest_launch, filed);
     d_last_filed = std::chrono::steady_clock::now();
-    d_filed.notify_all();
+    g->filed.notify_all();
     return rc == GSH_OK ? filed : 0;
 }
 

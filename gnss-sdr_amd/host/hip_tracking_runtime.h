@@ -112,6 +112,7 @@ private:
         std::vector<int> slot_of_channel;  // -1: free
         std::mutex handle_mutex;           // the C handle: one thread at a time (launch, start, stop)
         bool in_flight{false};             // guarded by d_mutex: a thread is queueing, ending or filing a launch of the group
+        std::condition_variable filed;     // (with d_mutex) a launch of THIS group has been filed / the group is free again: only its own blocks wake up
         // A launch that has been queued and not yet waited for (launch-ahead): guarded by handle_mutex.  Whoever next needs the handle -- the block that finds
         // its queue empty, start(), stop() -- ends and files it first.
         bool begun{false};
@@ -143,7 +144,6 @@ private:
     int d_channels_per_group;
     bool d_launch_ahead{true};
     mutable std::mutex d_mutex;  // slots, queues, in_flight flags, stats
-    std::condition_variable d_filed;
     std::vector<std::unique_ptr<Group>> d_groups;
     std::vector<std::unique_ptr<Slot>> d_slots;
     std::string d_error;
