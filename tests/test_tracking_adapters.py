@@ -28,18 +28,19 @@ def test_dll_pll_conf_mapping_equals_reference_constructor():
     assert r.returncode == 0 and "TRACKING CONF OK" in r.stdout, r.stdout[-4000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("launch_ahead", ["1", "0"])
-def test_block_and_runtime_against_the_fake_engine(launch_ahead):
+@pytest.mark.parametrize("launch_ahead,channels_per_handle", [("1", ""), ("0", ""), ("1", "4")])
+def test_block_and_runtime_against_the_fake_engine(launch_ahead, channels_per_handle):
     """The whole adapter / block / Hip_Tracking_Runtime stack on the CPU: tests/host/test_tracking_adapters_fake is the same program linked in
     front of tests/host/fake_gsh_engine.cc, a stand-in for the DEVICE half of the C ABI with the oracle's loop behind it (test infrastructure,
     never part of the product).  Every trajectory (13 signals), the loss-of-lock and restart cases, several periods per call, the dump file / TOW /
     time tags and 32 block threads on one shared runtime are compared with the reference's own blocks; the fake engine also checks that every
     push lands at the right absolute sample index and that no two threads are inside one engine handle at once.  Both forms of the runtime's launch
-    chain: the next launch queued as soon as one is filed (the default), and one launch, waited for, at a time (GSH_TRK_LAUNCH_AHEAD=0)."""
+    chain: the next launch queued as soon as one is filed (the default), and one launch, waited for, at a time (GSH_TRK_LAUNCH_AHEAD=0); and once with four
+    channels per device handle, so that the 32 blocks of the shared stream sit in eight groups with launches, and wake-ups, of their own."""
     fake = _bin() + "_fake"
     if not os.path.exists(fake):
         pytest.skip("tests/host/test_tracking_adapters_fake was not prebuilt and /root/reference is not present here")
-    r = subprocess.run([fake], capture_output=True, text=True, timeout=900, cwd="/tmp", env=dict(os.environ, GSH_TRK_LAUNCH_AHEAD=launch_ahead))
+    r = subprocess.run([fake], capture_output=True, text=True, timeout=900, cwd="/tmp", env=dict(os.environ, GSH_TRK_LAUNCH_AHEAD=launch_ahead, **({"GSH_TEST_CHANNELS_PER_LAUNCH": channels_per_handle} if channels_per_handle else {})))
     tail = "\n".join(l for l in r.stdout.splitlines() if "FAIL" in l or "shared stream" in l or "OK" in l or "dump" in l or "restart" in l)
     print(tail[-3000:])
     assert r.returncode == 0 and "TRACKING ADAPTERS OK" in r.stdout and "FAKE ENGINE" not in r.stderr, tail[-6000:] + r.stderr[-2000:]
