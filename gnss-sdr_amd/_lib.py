@@ -192,6 +192,12 @@ SYMBOLS = {
     "gsh_trk_run_begin": (C.c_int, [_P, C.c_int, C.c_int]),
     "gsh_trk_run_end": (C.c_int, [_P, C.POINTER(TrkEpoch), C.POINTER(C.c_int32)]),
     "gsh_trk_positions": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]),
+    "gsh_trk_live_configure": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
+    "gsh_trk_live_begin": (C.c_int, [_P]),
+    "gsh_trk_live_in_flight": (C.c_int, [_P, C.POINTER(C.c_int32)]),
+    "gsh_trk_live_take": (C.c_int, [_P, C.c_int, C.c_uint64, C.c_int, _P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_uint64),
+                                    C.POINTER(C.c_int32)]),
+    "gsh_trk_live_quiesce": (C.c_int, [_P]),
     "gsh_trk_time_run": (C.c_int, [_P, C.c_int, C.c_int, _F]),
     "gsh_trk_write_dump": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(TrkConf), C.c_uint32, C.POINTER(TrkEpoch), C.c_int, C.POINTER(C.c_uint64),
                                     C.POINTER(C.c_uint32)]),

@@ -1233,10 +1233,17 @@ __shared__ long long cw_stamp[8];  // phase stamps of the last correlate_window 
 
 // SUM = false: return after the first barrier, with one row of per-wave partial sums at red[GSH_MAX_TAPS * (1 + wave) + tap] and nothing in red[0..NOUT): the caller
 // adds the rows itself (in wave order, as below, to get the same sums) in whichever waves need the result -- two barriers and one LDS round trip less per call.
-template <int NT, int MODE, bool AUX = false, bool PAIRK = false, bool SUM = true>
+struct NoHook
+{
+    __device__ __forceinline__ void operator()() const {}
+};
+// hook: called by every thread after its wave's partial sums are in LDS and before the barrier that ends the correlation -- a wave that has finished its
+// trips early idles there (the oldest wave of a SIMD gets the issue slots first), which makes it the place for work nobody should wait for
+// (tracking_loop.hip, live mode: the look-out for new samples).
+template <int NT, int MODE, bool AUX = false, bool PAIRK = false, bool SUM = true, typename Hook = NoHook>
 __device__ __forceinline__ void correlate_window(const float2* __restrict__ stream, unsigned long long sample_offset, int n_samples,
     const float* __restrict__ tab, int code_len, const float (&sh)[NT], float rem_carr, float phase_step, float phase_rate, float rem_code,
-    float code_step, float code_rate, float2* __restrict__ red, const float* tab_aux = nullptr, float aux_shift = 0.0f)
+    float code_step, float code_rate, float2* __restrict__ red, const float* tab_aux = nullptr, float aux_shift = 0.0f, Hook hook = Hook())
 {
     static_assert(!AUX || (MODE == 0 && NT < GSH_MAX_TAPS), "the fused tap exists for the standard mode and needs a free slot in `red`");
     const int tid = threadIdx.x;
@@ -1337,6 +1344,7 @@ __device__ __forceinline__ void correlate_window(const float2* __restrict__ stre
             if (AUX) part[wave * GSH_MAX_TAPS + NT] = acc_aux;
         }
     GSH_CW_STAMP(3);
+    hook();
     __syncthreads();
     GSH_CW_STAMP(4);
     if constexpr (!SUM) return;
@@ -1381,21 +1389,21 @@ __device__ __forceinline__ void sum_wave_partials(const float2* __restrict__ red
 
 // the standard-mode form the batched callers use.  PAIRK: E/P/L with the taps exactly one chip apart and the code running forward (mcorr_pair_eligible,
 // multicorrelator.h) -- the early tap is read next to the late one (packed_trip); the sums are bit-identical either way
-template <int NT, bool PAIRK = false, bool SUM = true>
+template <int NT, bool PAIRK = false, bool SUM = true, typename Hook = NoHook>
 __device__ __forceinline__ void correlate_window_std(const float2* __restrict__ stream, unsigned long long sample_offset, int n_samples,
     const float* __restrict__ tab, int code_len, const float (&sh)[NT], float rem_carr, float phase_step, float rem_code, float code_step,
-    float2* __restrict__ red)
+    float2* __restrict__ red, Hook hook = Hook())
 {
-    correlate_window<NT, 0, false, PAIRK, SUM>(stream, sample_offset, n_samples, tab, code_len, sh, rem_carr, phase_step, 0.0f, rem_code, code_step, 0.0f, red);
+    correlate_window<NT, 0, false, PAIRK, SUM, Hook>(stream, sample_offset, n_samples, tab, code_len, sh, rem_carr, phase_step, 0.0f, rem_code, code_step, 0.0f, red, nullptr, 0.0f, hook);
 }
 
 // standard mode with the fused data-component tap: red[0..NT) the taps, red[NT] the fused one
-template <int NT, bool SUM = true>
+template <int NT, bool SUM = true, typename Hook = NoHook>
 __device__ __forceinline__ void correlate_window_std_aux(const float2* __restrict__ stream, unsigned long long sample_offset, int n_samples,
     const float* __restrict__ tab, const float* tab_aux, float aux_shift, int code_len, const float (&sh)[NT], float rem_carr, float phase_step,
-    float rem_code, float code_step, float2* __restrict__ red)
+    float rem_code, float code_step, float2* __restrict__ red, Hook hook = Hook())
 {
-    correlate_window<NT, 0, true, false, SUM>(stream, sample_offset, n_samples, tab, code_len, sh, rem_carr, phase_step, 0.0f, rem_code, code_step, 0.0f, red, tab_aux, aux_shift);
+    correlate_window<NT, 0, true, false, SUM, Hook>(stream, sample_offset, n_samples, tab, code_len, sh, rem_carr, phase_step, 0.0f, rem_code, code_step, 0.0f, red, tab_aux, aux_shift, hook);
 }
 }  // namespace GSH_MC_NS
 namespace mcdev = GSH_MC_NS;

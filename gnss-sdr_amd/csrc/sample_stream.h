@@ -3,6 +3,29 @@
 #ifndef GSH_SAMPLE_STREAM_H
 #define GSH_SAMPLE_STREAM_H
 #include "gsh_internal.h"
+#include <memory>
+#include <mutex>
+#include <vector>
+
+namespace gsh
+{
+// What a live loop (gsh_trk_live_*, tracking_loop.hip) leaves in page-locked host memory per channel after every code period -- and what a push
+// looks at before it overwrites the oldest samples of a ring such a loop follows.
+struct LiveTail
+{
+    unsigned long long pos;  // first sample of the channel's next correlation window
+    unsigned long long seq;  // periods completed since the handle was created (the record of period q sits in slot q % ring length)
+    int active;              // the loop still advances the channel
+    int exit_reason;         // why the channel's work-group left its last residency (LIVE_EXIT_*)
+};
+// A live handle's channels as seen by the ring they read: registered with the ring, outlives neither side (shared).
+struct LiveFloor
+{
+    std::mutex m;
+    const volatile LiveTail* tails{nullptr};  // nullptr once the owning handle is gone
+    int n{0};
+};
+}  // namespace gsh
 
 struct gsh_stream
 {
@@ -45,6 +68,12 @@ struct gsh_stream
     hipEvent_t stage_done[NSTAGE]{};  // the conversion that read d_stage[i] (and therefore the copy out of h_stage[i]) has finished
     int stage_next{0};
     hipEvent_t copied{nullptr};       // gsh_stream_push_pinned: the DMA out of the caller's page-locked memory has finished
+    // Live readers (gsh_trk_live_*): a kernel that stays resident cannot be ordered against pushes by events -- it learns how far the ring is
+    // COMPLETE from two words in device memory that a one-thread kernel, queued on the pushing stream behind every push's copies and conversion,
+    // rewrites: d_live[0] = absolute index one past the newest complete sample, d_live[1] = first index resident since the last seek.
+    unsigned long long* d_live{nullptr};
+    std::vector<std::shared_ptr<gsh::LiveFloor>> live_floors;  // what the live loops still read: a push never overwrites it (write_items)
+    std::vector<void*> parked_device, parked_host;  // outgrown staging buffers kept until the ring goes (release_buffer, sample_stream.hip)
 };
 
 namespace gsh
@@ -63,5 +92,9 @@ int stream_wait_pushed(gsh_stream* s, unsigned long long need_end, hipStream_t s
 // queue the conversion of n raw items at d_src (device memory) into ring positions [next, next + n) on the ring's own stream, after the readers'
 // fences; records `pushed` and advances `next`
 int stream_write_device_items(gsh_stream* s, const void* d_src, unsigned long long n, int item_type, int conj, hipStream_t st);
+// the two live words of the ring (allocated, and published for what is resident now, at the first call); nullptr + last error on failure
+unsigned long long* stream_live_words(gsh_stream* s);
+// lowest window start any registered live channel still has to read; ~0ull when none is active
+unsigned long long stream_live_floor(gsh_stream* s);
 }  // namespace gsh
 #endif

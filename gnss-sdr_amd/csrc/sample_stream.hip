@@ -50,6 +50,67 @@ int stream_wait_pushed(gsh_stream* s, unsigned long long need_end, hipStream_t s
     GSH_HIP(hipStreamWaitEvent(st, s->pushed, 0));  // not in the history (or "everything"): the latest push
     return GSH_OK;
 }
+
+// One thread, queued behind a push's copies and conversion on the stream that carried them: the ring is complete up to `next`.  A kernel that is
+// already resident (trk_loop_kernel in live mode) polls word 0 with agent-scope loads; the dispatch of THIS kernel is what orders the DMA's writes
+// before the store, exactly as it would for any kernel launched behind a copy.
+__global__ void publish_live_kernel(unsigned long long* live, unsigned long long next, unsigned long long origin)
+{
+    __hip_atomic_store(live + 1, origin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(live, next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+int stream_publish_live(gsh_stream* s, unsigned long long next, hipStream_t st)
+{
+    if (s->d_live == nullptr) return GSH_OK;
+    hipLaunchKernelGGL(publish_live_kernel, dim3(1), dim3(1), 0, st, s->d_live, next, s->origin);
+    GSH_HIP(hipGetLastError());
+    return GSH_OK;
+}
+
+unsigned long long* stream_live_words(gsh_stream* s)
+{
+    if (s->d_live != nullptr) return s->d_live;
+    if (hipSetDevice(s->device) != hipSuccess) return nullptr;
+    unsigned long long* w = nullptr;
+    hipError_t e = hipMalloc(&w, 2 * sizeof(unsigned long long));
+    if (e != hipSuccess)
+        {
+            hip_fail(e, "hipMalloc(live words)", __FILE__, __LINE__);
+            return nullptr;
+        }
+    s->d_live = w;
+    // what is resident now, behind everything queued so far
+    if (stream_publish_live(s, s->next, s->stream) != GSH_OK || hipStreamSynchronize(s->stream) != hipSuccess)
+        {
+            (void)hipFree(w);
+            s->d_live = nullptr;
+            set_error(GSH_ERR_HIP, "the ring's live words could not be published");
+            return nullptr;
+        }
+    return s->d_live;
+}
+
+unsigned long long stream_live_floor(gsh_stream* s)
+{
+    unsigned long long lowest = ~0ull;
+    for (auto it = s->live_floors.begin(); it != s->live_floors.end();)
+        {
+            LiveFloor& f = **it;
+            std::lock_guard<std::mutex> lk(f.m);
+            if (f.tails == nullptr)
+                {
+                    it = s->live_floors.erase(it);  // the handle is gone
+                    continue;
+                }
+            for (int c = 0; c < f.n; c++)
+                if (f.tails[c].active && f.tails[c].pos < lowest) lowest = f.tails[c].pos;
+            ++it;
+        }
+    return lowest;
+}
 }  // namespace gsh
 
 namespace
@@ -66,12 +127,33 @@ bool stream_direct_dma()
     return on;
 }
 
+// a staging buffer that has been outgrown.  hipFree waits for the WHOLE device -- with a live loop resident on it (tracking_loop.hip) that is until the
+// loop's residency ends, milliseconds during which the loop may be waiting for the very push that wants to free: while live readers are registered the
+// buffer is parked instead and released with the ring.
+hipError_t release_buffer(gsh_stream* s, void* p, bool host)
+{
+    if (!s->live_floors.empty())
+        {
+            (host ? s->parked_host : s->parked_device).push_back(p);
+            return hipSuccess;
+        }
+    return host ? hipHostFree(p) : hipFree(p);
+}
+
 // queue the conversion of n items at d_src into ring positions of absolute indices [first, first + n) on `st`.  host_src: d_src is page-locked HOST memory
 // holding gr_complex items to be taken as they are -- the ring positions are then the destination of the DMA itself (no staging buffer, no second copy);
 // *copied_after (an event), when given, is recorded behind the last read of d_src.
 int write_items(gsh_stream* s, const void* d_src, unsigned long long n, int item_type, int conj, hipStream_t st, bool host_src = false, hipEvent_t copied_after = nullptr)
 {
     const size_t isz = gsh::item_bytes(item_type);
+    if (!s->live_floors.empty())
+        {
+            // a resident loop cannot be waited for by an event (it would wait for this very push): what its channels still read is off limits instead
+            const unsigned long long floor = gsh::stream_live_floor(s);
+            if (floor != ~0ull && s->next + n > floor + s->capacity)
+                return set_error(GSH_ERR_STATE, "a push of %llu samples at %llu would overwrite sample %llu, which a live tracking channel has not correlated yet (ring capacity %llu)",
+                    n, s->next, floor, s->capacity);
+        }
     {
         // everything below `bound` is overwritten by this push: wait for the launches that still read below it
         const unsigned long long end = s->next + n;
@@ -123,7 +205,7 @@ int record_push(gsh_stream* s, unsigned long long end_index, hipStream_t st)
     GSH_HIP(hipEventRecord(s->push_ev[slot], st));
     s->push_end[slot] = end_index;
     s->push_count++;
-    return GSH_OK;
+    return gsh::stream_publish_live(s, end_index, st);
 }
 }  // namespace
 
@@ -163,7 +245,13 @@ extern "C"
             return GSH_ERR_HIP;
         };
         hipError_t e;
-        if ((e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
+        {
+            // The ring's stream gets the highest priority the device offers: the runtime keeps separate hardware queues per priority level, so a push can
+            // never end up in a queue BEHIND a resident live loop (normal / low priority) that is waiting for that very push (tracking_loop.hip, live mode).
+            int least = 0, greatest = 0;
+            if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
+            if ((e = hipStreamCreateWithPriority(&s->stream, hipStreamNonBlocking, greatest)) != hipSuccess) return fail(e, "hipStreamCreate");
+        }
         const size_t total = static_cast<size_t>(s->capacity + s->max_window + 2);
         if ((e = hipMalloc(&s->d_ring, sizeof(float2) * total)) != hipSuccess) return fail(e, "hipMalloc(ring)");
         if ((e = hipMemset(s->d_ring, 0, sizeof(float2) * total)) != hipSuccess) return fail(e, "hipMemset(ring)");
@@ -177,7 +265,10 @@ extern "C"
         if (!s) return;
         (void)hipSetDevice(s->device);
         if (s->stream) (void)hipStreamSynchronize(s->stream);
+        for (void* p : s->parked_device) (void)hipFree(p);
+        for (void* p : s->parked_host) (void)hipHostFree(p);
         if (s->d_ring) (void)hipFree(s->d_ring);
+        if (s->d_live) (void)hipFree(s->d_live);
         if (s->d_raw) (void)hipFree(s->d_raw);
         for (int i = 0; i < 2; i++)
             {
@@ -235,7 +326,7 @@ extern "C"
         const size_t bytes = static_cast<size_t>(n) * isz;
         if (bytes > s->raw_cap)
             {
-                if (s->d_raw) GSH_HIP(hipFree(s->d_raw));
+                if (s->d_raw) GSH_HIP(release_buffer(s, s->d_raw, false));
                 s->d_raw = nullptr;
                 s->raw_cap = 0;
                 GSH_HIP(hipMalloc(&s->d_raw, bytes));
@@ -271,7 +362,7 @@ extern "C"
         if (bytes > s->raw2_cap[slot])
             {
                 GSH_HIP(hipEventSynchronize(s->raw2_done[slot]));  // nothing queued may still read the buffer being replaced
-                if (s->d_raw2[slot]) GSH_HIP(hipFree(s->d_raw2[slot]));
+                if (s->d_raw2[slot]) GSH_HIP(release_buffer(s, s->d_raw2[slot], false));
                 s->d_raw2[slot] = nullptr;
                 s->raw2_cap[slot] = 0;
                 GSH_HIP(hipMalloc(&s->d_raw2[slot], bytes));
@@ -290,8 +381,9 @@ extern "C"
 
     int gsh_stream_push_staged(gsh_stream_t* s, const void* items, uint64_t n, int item_type, int inverted_spectrum, uint64_t* first_index)
     {
-        // items -> page-locked staging (host memcpy, the caller's buffer is free on return) -> device staging (DMA on the ring's stream) ->
-        // conversion into the ring.  A staging pair is re-used four pushes later, after the conversion that read it has finished.
+        // items -> page-locked staging (host memcpy: the caller's buffer is free on return, whatever kind of memory it is) -> the ring.  gr_complex items that
+        // need no conversion are copied by the DMA engine straight from the staging buffer into their ring positions; every other item type goes
+        // staging -> device staging -> conversion kernel.  A staging pair is re-used four pushes later, after the device work that read it has finished.
         GSH_REQUIRE(s != nullptr, "null stream");
         GSH_REQUIRE(n == 0 || items != nullptr, "null items");
         const size_t isz = gsh::item_bytes(item_type);
@@ -300,17 +392,6 @@ extern "C"
         if (first_index) *first_index = s->next;
         if (n == 0) return GSH_OK;
         GSH_HIP(hipSetDevice(s->device));
-        if (item_type == GSH_ITEM_GR_COMPLEX && !inverted_spectrum && stream_direct_dma())
-            {
-                // items that are the ring's own format: the DMA's destination is the ring (profiles/ab/r03/dropin_direct_dma.txt)
-                if (s->copied == nullptr) GSH_HIP(hipEventCreateWithFlags(&s->copied, hipEventDisableTiming));
-                int rc = write_items(s, items, n, item_type, 0, s->stream, true, s->copied);
-                if (rc != GSH_OK) return rc;
-                rc = record_push(s, s->next + n, s->stream);
-                if (rc != GSH_OK) return rc;
-                s->next += n;
-                return GSH_OK;
-            }
         const int slot = s->stage_next;
         s->stage_next = (s->stage_next + 1) % gsh_stream::NSTAGE;
         const size_t bytes = static_cast<size_t>(n) * isz;
@@ -320,8 +401,8 @@ extern "C"
             GSH_HIP(hipEventSynchronize(s->stage_done[slot]));  // the push that used this pair four pushes ago
         if (bytes > s->stage_cap[slot])
             {
-                if (s->h_stage[slot]) GSH_HIP(hipHostFree(s->h_stage[slot]));
-                if (s->d_stage[slot]) GSH_HIP(hipFree(s->d_stage[slot]));
+                if (s->h_stage[slot]) GSH_HIP(release_buffer(s, s->h_stage[slot], true));
+                if (s->d_stage[slot]) GSH_HIP(release_buffer(s, s->d_stage[slot], false));
                 s->h_stage[slot] = nullptr;
                 s->d_stage[slot] = nullptr;
                 s->stage_cap[slot] = 0;
@@ -331,8 +412,18 @@ extern "C"
                 s->stage_cap[slot] = cap;
             }
         std::memcpy(s->h_stage[slot], items, bytes);
-        GSH_HIP(hipMemcpyAsync(s->d_stage[slot], s->h_stage[slot], bytes, hipMemcpyHostToDevice, s->stream));
-        int rc = write_items(s, s->d_stage[slot], n, item_type, inverted_spectrum ? 1 : 0, s->stream);
+        int rc;
+        if (item_type == GSH_ITEM_GR_COMPLEX && !inverted_spectrum && stream_direct_dma())
+            {
+                // the ring's own format: the DMA's destination is the ring (profiles/ab/r03/dropin_direct_dma.txt); its SOURCE is the page-locked staging
+                // copy, never the caller's pageable buffer (an asynchronous copy out of pageable memory is only safe if the runtime happens to stage it itself)
+                rc = write_items(s, s->h_stage[slot], n, item_type, 0, s->stream, true, nullptr);
+            }
+        else
+            {
+                GSH_HIP(hipMemcpyAsync(s->d_stage[slot], s->h_stage[slot], bytes, hipMemcpyHostToDevice, s->stream));
+                rc = write_items(s, s->d_stage[slot], n, item_type, inverted_spectrum ? 1 : 0, s->stream);
+            }
         if (rc != GSH_OK) return rc;
         GSH_HIP(hipEventRecord(s->stage_done[slot], s->stream));
         rc = record_push(s, s->next + n, s->stream);
@@ -388,8 +479,8 @@ extern "C"
         if (s->copied == nullptr) GSH_HIP(hipEventCreateWithFlags(&s->copied, hipEventDisableTiming));
         if (bytes > s->stage_cap[slot])
             {
-                if (s->h_stage[slot]) GSH_HIP(hipHostFree(s->h_stage[slot]));
-                if (s->d_stage[slot]) GSH_HIP(hipFree(s->d_stage[slot]));
+                if (s->h_stage[slot]) GSH_HIP(release_buffer(s, s->h_stage[slot], true));
+                if (s->d_stage[slot]) GSH_HIP(release_buffer(s, s->d_stage[slot], false));
                 s->h_stage[slot] = nullptr;
                 s->d_stage[slot] = nullptr;
                 s->stage_cap[slot] = 0;
@@ -448,6 +539,12 @@ extern "C"
         s->origin = next_index;  // nothing older is resident
         s->push_count = 0;
         s->read_count = 0;
+        if (s->d_live != nullptr)
+            {
+                int rc = gsh::stream_publish_live(s, next_index, s->stream);
+                if (rc != GSH_OK) return rc;
+                GSH_HIP(hipStreamSynchronize(s->stream));
+            }
         return GSH_OK;
     }
 

@@ -128,6 +128,53 @@ struct SerialMail  // results the code-loop lane and the lock-detector lane hand
 };
 constexpr int SERIAL_WAVES = 3;
 
+// ---- live mode (gsh_trk_live_*): the kernel stays resident and follows the ring as it fills ------------------------------------------------------
+// A launch per batch of periods costs the host ~270 us of queueing and waiting around ~180 us of kernel (round 3) -- at the reference's cadence
+// of one period per general_work call that is all there is.  In live mode ONE launch ("residency") serves a channel for as long as samples keep coming:
+//   * the ring says how far it is complete through two words in device memory that every push rewrites behind its copies (sample_stream.hip,
+//     publish_live_kernel); an idle lane reads them during the loop arithmetic of every period, thread 0 polls them only when it has run out of samples;
+//   * every period's record goes into a per-channel ring of records in page-locked host memory, and LiveTail::seq -- stored once the records below it
+//     are known to have left the device (see the drain rule at the loop's top) -- tells the host how many there are: the host never waits for a stream;
+//   * a residency ends by itself: nothing new for idle_ticks, residency_ticks used up (so that whatever waits for the device -- hipFree, a device-wide
+//     synchronisation -- gets its turn), the host's quit word, the channel stopped, or the record ring full.  It can therefore never hang the device.
+enum
+{
+    LIVE_EXIT_NONE = 0,
+    LIVE_EXIT_IDLE = 1,      // no new samples within idle_ticks
+    LIVE_EXIT_BUDGET = 2,    // residency_ticks used up
+    LIVE_EXIT_QUIT = 3,      // the host asked (start / stop of a channel, destroy)
+    LIVE_EXIT_INACTIVE = 4,  // the channel is not tracking (never started, stopped, lost lock)
+    LIVE_EXIT_OVERRUN = 5    // the channel's next window has been overwritten in the ring
+};
+struct LiveArgs
+{
+    const unsigned long long* head;      // device memory: [0] one past the newest complete sample, [1] first resident index since the last seek
+    LiveTail* tail;                      // host memory (mapped), n_channels; nullptr: not a live launch
+    const unsigned long long* consumed;  // host memory (mapped), n_channels: records the host has taken (flow control of the record ring)
+    const int* quit;                     // host memory (mapped)
+    unsigned ring_len;                   // records per channel, a power of two
+    unsigned long long idle_ticks, residency_ticks;  // of wall_clock64() (100 MHz)
+};
+struct LiveShared  // the live form's own words in LDS (the launched form has none of them: its LDS layout, and with it its register allocation, stay what they were)
+{
+    unsigned long long seq;       // periods completed by this channel = index of the record the current period writes
+    unsigned long long consumed;  // the host's count as last read
+    unsigned long long t_start;   // wall_clock64() when the residency began
+    unsigned long long now;       // ... as the look-out lane last read it
+    // what the look-out lane (lane 0 of the first wave without loop arithmetic) read from the ring's live words while the others worked
+    unsigned long long head, origin, head_fenced;
+    unsigned long long pub_pos;   // the channel's next window as it goes out with the record
+    unsigned long long wpos;      // ... and where that window sits in the ring's memory (pub_pos mod capacity, kept up incrementally: a 64-bit remainder
+                                  // evaluated by 1 024 threads at the top of every period is a microsecond of vector instructions)
+    int quit;
+    int exit_reason;
+    int out_valid;  // the record in LDS is complete and has not been written to the host's ring yet
+    int pad_;
+};
+struct NoLiveShared
+{
+};
+
 struct TrkArgs
 {
     const gsh_trk_conf* conf;  // device copy (a by-value struct with dynamically indexed arrays would be materialised in scratch by every thread)
@@ -148,6 +195,7 @@ struct TrkArgs
     unsigned long long bit_sync_limit;  // samples since acquisition from which a channel still in state 2 is declared lost (trk.cc:2000-2007); ~0: never
     // correctly rounded reciprocals of the two launch-constant divisors of the loop arithmetic, 0.0 when the configuration does not qualify (div_by_constant below)
     double inv_fs_in, inv_signal_carrier_freq;
+    LiveArgs live;
 };
 
 constexpr double INV_TWO_PI_D = 1.0 / GNSS_TWO_PI_D;  // correctly rounded by the compiler; 2 pi's significand is not all ones
@@ -439,7 +487,7 @@ struct NextWindow  // what thread 0 publishes for the next correlation (do_corre
     unsigned long long pos;
     float rem_carr, phase_step, rem_code, code_step;
     float phase_rate, code_rate;  // high_dyn only
-    int go;
+    int go;      // 1: correlate the window; 0: leave the loop; 2 (live mode only): drain the record stores, publish, and wait for samples (live_wait)
     int narrow;  // correlate with the narrow tap spacing (after extended integration has started)
 };
 
@@ -458,8 +506,102 @@ __device__ __forceinline__ void publish(NextWindow& w, const TrkChannel& s, cons
     w.narrow = 0;  // the caller overrides it from the channel's LockState
 }
 
+// A field of a period's record: in the launched form a store into the launch's block of records (device or host memory; the end of the kernel makes it
+// visible), in the live form a store into the record's copy in LDS (see the write-out at the loop's top).
+template <bool LIVE, typename T, typename U>
+__device__ __forceinline__ void rec_set(T& dst, U value)
+{
+    dst = static_cast<T>(value);
+}
+
+// ---- live mode, thread 0 only ----------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long live_oldest(unsigned long long head, unsigned long long origin, unsigned long long capacity)
+{
+    const unsigned long long by_capacity = head > capacity ? head - capacity : 0ull;
+    return by_capacity > origin ? by_capacity : origin;
+}
+
+// End of a period (after publish() has formed the next window's NCO settings): the period's record is complete in LDS; whether the next window can be
+// correlated straight away is decided from what the look-out lane read at the end of the correlation -- no memory access on this path.  Anything else (no
+// samples yet, record ring full, budget used up, channel stopped, quit) is left to the drain round at the loop's top (win.go = 2).
+__device__ __forceinline__ void live_advance(const TrkArgs& a, TrkChannel& s, NextWindow& w, LiveShared& v, unsigned vlen)
+{
+    // (no store into host memory here: thread 0 would wait for its acknowledgement -- a PCIe round trip -- at the barrier that ends the period.  The
+    // channel's position and the count of complete records go out with the record, from the wave that writes it at the top of the next period.)
+    {
+        unsigned long long w2 = v.wpos + (s.pos - v.pub_pos);  // a period advances the window by far less than the ring holds
+        if (w2 >= a.ring_capacity) w2 -= a.ring_capacity;
+        v.wpos = w2;
+    }
+    v.pub_pos = s.pos;
+    v.seq += 1ull;
+    v.out_valid = 1;  // this period's record is complete in LDS (the lanes' stores lie before the barrier that joined them, thread 0's are its own)
+    const unsigned long long oldest = live_oldest(v.head, v.origin, a.ring_capacity);
+    const bool resident = s.active && (s.pos + vlen <= v.head) && (s.pos >= oldest);
+    const bool room = (v.seq - v.consumed) < static_cast<unsigned long long>(a.live.ring_len);
+    const bool in_budget = (v.now - v.t_start) < a.live.residency_ticks;  // (the clock is the look-out lane's reading: s_memrealtime is a memory operation, ~a microsecond)
+    w.go = (resident && room && in_budget && !v.quit) ? 1 : 2;
+}
+
+// The drain round: every record store of the channel has completed (the lanes that store have waited, a barrier lies in between), so the full count is
+// published; then wait for the next window -- polling the ring's live words in device memory, now and then the host's quit word -- until it is resident,
+// or one of the reasons to leave applies.
+__device__ __forceinline__ void live_wait(const TrkArgs& a, int ch, TrkChannel& s, NextWindow& w, LiveShared& v, unsigned vlen)
+{
+    LiveTail* th = a.live.tail + ch;
+    __hip_atomic_store(&th->pos, s.pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&th->active, s.active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&th->seq, v.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    int reason = LIVE_EXIT_NONE;
+    if (!s.active) reason = LIVE_EXIT_INACTIVE;
+    const unsigned long long t_wait = wall_clock64();
+    unsigned it = 0;
+    while (reason == LIVE_EXIT_NONE)
+        {
+            if ((it++ & 7u) == 0u && __hip_atomic_load(a.live.quit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0)
+                {
+                    reason = LIVE_EXIT_QUIT;
+                    break;
+                }
+            const unsigned long long head = __hip_atomic_load(a.live.head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long now = wall_clock64();
+            if ((now - v.t_start) >= a.live.residency_ticks)
+                {
+                    reason = LIVE_EXIT_BUDGET;
+                    break;
+                }
+            if (s.pos + vlen <= head)
+                {
+                    // (the origin word is written before the head that goes with it: read after it, it is at least as new)
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // ... and the window's samples are read afresh, not from this compute unit's L1
+                    const unsigned long long origin = __hip_atomic_load(a.live.head + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (s.pos < live_oldest(head, origin, a.ring_capacity))
+                        {
+                            reason = LIVE_EXIT_OVERRUN;
+                            break;
+                        }
+                    if ((v.seq - v.consumed) >= static_cast<unsigned long long>(a.live.ring_len))
+                        v.consumed = __hip_atomic_load(a.live.consumed + ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if ((v.seq - v.consumed) < static_cast<unsigned long long>(a.live.ring_len))
+                        {
+                            v.head = head;
+                            v.origin = origin;
+                            v.head_fenced = head;
+                            break;  // go
+                        }
+                }
+            if ((now - t_wait) >= a.live.idle_ticks)
+                reason = LIVE_EXIT_IDLE;
+            else
+                __builtin_amdgcn_s_sleep(16);
+        }
+    v.exit_reason = reason;
+    w.go = (reason == LIVE_EXIT_NONE) ? 1 : 0;
+}
+
 // HD: Dll_Pll_Conf::high_dyn -- a compile-time switch so that the standard path does not carry the high-dynamics correlator's registers
-template <int NT, bool HD>
+// LIVE: the residency form of the loop (gsh_trk_live_*) -- a compile-time switch as well: the launched form keeps the code (and the registers) it had
+template <int NT, bool HD, bool LIVE>
 // conf: the device copy of the configuration as a parameter of its own, const and __restrict__: nothing the kernel writes aliases it, so its fields are
 // fetched with scalar loads and may be hoisted -- through the pointer inside TrkArgs every c.field in thread 0's section was a vector memory load that could not
 // move above the record stores before it.
@@ -473,6 +615,12 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
     __shared__ __align__(16) TrkChannel s;
     __shared__ __align__(16) LockState lk;
     __shared__ SerialMail mail;  // between the lanes that share a period's loop arithmetic (below)
+    __shared__ std::conditional_t<LIVE, LiveShared, NoLiveShared> lv;  // (not allocated in the launched form: nothing there touches it)
+    // live form: the period's record is assembled HERE by the three lanes that know its fields and written to the host's record ring by ONE wave
+    // instruction (28 lanes x 8 bytes, system scope) at the top of the next period.  Field-by-field system-scope stores -- what visibility to a host that
+    // reads while the kernel runs demands of stores into host memory -- are one PCIe write each: 55 per record, and 32 channels of them took 53 us per period.
+    __shared__ __align__(16) std::conditional_t<LIVE, gsh_trk_epoch, NoLiveShared> lrec;
+    static_assert(sizeof(gsh_trk_epoch) % 8 == 0 && sizeof(gsh_trk_epoch) / 8 <= 64, "the record is written out as 8-byte pieces by one wave");
     static_assert(sizeof(TrkChannel) % 4 == 0 && sizeof(LockState) % 4 == 0, "state is copied as 32-bit words");
     const int ch = blockIdx.x;
     const int tid = threadIdx.x;
@@ -504,22 +652,87 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
     const float sh_data[1] = {0.0f};
     constexpr int PROMPT = NT / 2;
 
+    constexpr bool live = LIVE;
     if (tid == 0)
         {
             publish(win, s, c, a.n_stream, a.n_epochs > 0, a.ring_oldest);
             win.narrow = lk.narrow;
+            if constexpr (LIVE)
+                {
+                    // the channel's record count lives in the host's tail (this kernel is its only writer): residencies hand it on through there
+                    lv.seq = __hip_atomic_load(&a.live.tail[ch].seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    lv.exit_reason = LIVE_EXIT_NONE;
+                    lv.t_start = wall_clock64();
+                    lv.now = lv.t_start;
+                    lv.consumed = __hip_atomic_load(a.live.consumed + ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    win.go = 2;
+                    lv.head = 0ull;
+                    lv.origin = 0ull;
+                    lv.head_fenced = 0ull;
+                    lv.quit = 0;
+                    lv.out_valid = 0;
+                    lv.pub_pos = s.pos;
+                    lv.wpos = s.pos % a.ring_capacity;
+                }
         }
     __syncthreads();
 
     int done = 0;
     for (int e = 0; e < a.n_epochs; e++)
         {
+            if constexpr (LIVE)
+                {
+                    // The record of the period that has just ended goes out: the first wave without loop arithmetic copies it from LDS to its slot in the host's
+                    // ring, 8 bytes per lane, write-through (system scope: the store's acknowledgement means it has left the device -- a plain store is
+                    // acknowledged by the L2, and the count published later could overtake it).  The drain rule: that wave waits for the acknowledgement at the end
+                    // of the correlation that follows (live_hook: issued a whole correlation ago, the wait costs nothing), so at the end of period k thread 0 can
+                    // vouch for the records below k (live_advance); when the channel is about to wait or to leave, the round below (the wait, then a barrier)
+                    // lets it vouch for all of them.
+                    if ((tid >> 6) == SERIAL_WAVES && lv.out_valid)
+                        {
+                            const int piece = tid & 63;
+                            if (piece < static_cast<int>(sizeof(gsh_trk_epoch) / 8))
+                                {
+                                    const size_t slot = static_cast<size_t>(ch) * a.live.ring_len + (static_cast<unsigned>(lv.seq - 1ull) & (a.live.ring_len - 1u));
+                                    const unsigned long long v = reinterpret_cast<const unsigned long long*>(&lrec)[piece];
+                                    __hip_atomic_store(reinterpret_cast<unsigned long long*>(a.records + slot) + piece, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                }
+                            else if (piece == static_cast<int>(sizeof(gsh_trk_epoch) / 8))
+                                {
+                                    // ... and with it where the channel stands and how many records are COMPLETE: those below the one going out now (it was
+                                    // preceded by a wait for its predecessor's stores, live_hook)
+                                    LiveTail* th = a.live.tail + ch;
+                                    __hip_atomic_store(&th->pos, lv.pub_pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                    __hip_atomic_store(&th->seq, lv.seq - 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                }
+                            if (piece == 0) lv.out_valid = 0;
+                        }
+                    if (win.go == 2)  // uniform
+                        {
+                            if ((tid >> 6) == SERIAL_WAVES) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            __syncthreads();
+                            if (tid == 0) live_wait(a, ch, s, win, lv, c.vector_length);  // (the NCO settings stand: publish() formed them; only residency was open)
+                            __syncthreads();
+                        }
+                }
             if (!win.go) break;  // uniform: win is only rewritten between the barriers below
 #ifdef GSH_TRK_PROFILE
             const long long t_begin = clock64();
 #endif
             const unsigned long long pos = win.pos;
-            const unsigned long long wpos = a.ring_capacity ? pos % a.ring_capacity : pos;  // where the window sits in memory
+            unsigned long long wpos;  // where the window sits in memory
+            if constexpr (LIVE)
+                wpos = lv.wpos;
+            else
+                wpos = a.ring_capacity ? pos % a.ring_capacity : pos;
+            // where this period's record is put together: slot e of the launch's block, or -- live -- the copy in LDS.  (The address is formed where it is
+            // used, by three lanes, not carried in registers through the correlation.)
+            auto rec_ref = [&]() -> gsh_trk_epoch& {
+                if constexpr (LIVE)
+                    return lrec;
+                else
+                    return a.records[static_cast<size_t>(ch) * a.n_epochs + e];
+            };
             const float rem_carr = win.rem_carr, phase_step = win.phase_step, rem_code = win.rem_code, code_step = win.code_step;
             float sh[NT];
             {
@@ -541,6 +754,26 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                         sh[NT - 1] = el;
                     }
             }
+            // live mode, between a wave's last trip and the barrier that ends the correlation (where the waves that finish first idle anyway):
+            //   the look-out lane -- lane 0 of the first wave without loop arithmetic -- reads how far the ring is complete by now (and, every 16th period, the host's
+            //   quit word: host memory, a PCIe round trip);  its wave waits for the record it wrote out at the top of the period (the drain rule).
+            auto live_hook = [&]() {
+                if constexpr (LIVE)
+                    {
+                        if (tid == 64 * SERIAL_WAVES)
+                            {
+                                const unsigned long long head = __hip_atomic_load(a.live.head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                const unsigned long long origin = __hip_atomic_load(a.live.head + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                int quit = 0;
+                                if ((static_cast<unsigned>(lv.seq) & 15u) == 15u) quit = __hip_atomic_load(a.live.quit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                lv.now = wall_clock64();
+                                lv.head = head;
+                                lv.origin = origin;
+                                lv.quit = quit;
+                            }
+                        if ((tid >> 6) == SERIAL_WAVES) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the record written out at the top of this period has left the device
+                    }
+            };
             const float phase_rate = win.phase_rate, code_rate = win.code_rate;
             // track_pilot in the standard mode: the data-component prompt (trk.cc:1246-1256) rides on the pilot's pass over the window
             const bool fused_data = !HD && c.track_pilot;
@@ -550,6 +783,7 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
             float2 pdata = make_float2(0.0f, 0.0f);
             if constexpr (HD)  // set_high_dynamics_resampler(high_dyn), trk.cc:669-675: the high-dynamics resampler + rotator pair
                 {
+                    live_hook();  // (no idle stretch to hide it in: the high-dynamics correlator is an order of magnitude slower than the look-out)
                     correlate_window<NT, 1>(a.stream, wpos, static_cast<int>(c.vector_length), tab, code_len, sh, rem_carr, phase_step, phase_rate, rem_code, code_step, code_rate, red);
 #pragma unroll
                     for (int t = 0; t < NT; t++) out[t] = red[t];
@@ -567,13 +801,13 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                     // them up (sum_wave_partials: same order, same sums), the others go straight on to the barrier that ends the period.  win is rewritten and the
                     // rows are reused only after that barrier.  (Until round 3: sum by NT threads -> barrier -> every thread read the sums -> barrier.)
                     if (fused_data)
-                        correlate_window_std_aux<NT, false>(a.stream, wpos, static_cast<int>(c.vector_length), tab, tab_data, sh_data[0], code_len, sh, rem_carr, phase_step, rem_code, code_step, red);
+                        correlate_window_std_aux<NT, false>(a.stream, wpos, static_cast<int>(c.vector_length), tab, tab_data, sh_data[0], code_len, sh, rem_carr, phase_step, rem_code, code_step, red, live_hook);
 #ifdef GSH_TRK_PAIRED_TAPS  // early tap read next to the late one: fewer instructions per trip, yet 0.5 us per period slower here (profiles/ab/r03/closed_loop_paired_taps.txt)
                     else if (NT == 3 && (static_cast<double>(sh[2]) - static_cast<double>(sh[0]) == 1.0) && code_step > 0.0f)  // mcorr_pair_eligible (uniform)
                         correlate_window_std<NT, true, false>(a.stream, wpos, static_cast<int>(c.vector_length), tab, code_len, sh, rem_carr, phase_step, rem_code, code_step, red);
 #endif
                     else
-                        correlate_window_std<NT, false, false>(a.stream, wpos, static_cast<int>(c.vector_length), tab, code_len, sh, rem_carr, phase_step, rem_code, code_step, red);
+                        correlate_window_std<NT, false, false>(a.stream, wpos, static_cast<int>(c.vector_length), tab, code_len, sh, rem_carr, phase_step, rem_code, code_step, red, live_hook);
                     if (tid < 64 * SERIAL_WAVES)  // the waves that hold a lane of the loop arithmetic below
                         {
                             float2 sums[NT + 1];
@@ -698,9 +932,9 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                             mail.code_error_filt_chips = code_error_filt_chips;
                             if (a.records != nullptr)
                                 {
-                                    gsh_trk_epoch& r = a.records[static_cast<size_t>(ch) * a.n_epochs + e];
-                                    r.code_error_chips = code_error_chips;
-                                    r.code_error_filt_chips = code_error_filt_chips;
+                                    gsh_trk_epoch& r = rec_ref();
+                                    rec_set<LIVE>(r.code_error_chips, code_error_chips);
+                                    rec_set<LIVE>(r.code_error_filt_chips, code_error_filt_chips);
                                 }
                         }
                     else
@@ -708,22 +942,22 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                             // this lane also writes the part of the period's record that is known before the join (thread 0 adds the loop's outputs after it, or, on a
                             // loss of lock, clears what does not belong into that record): the accumulators the loop works on -- what log_data dumps as
                             // |d_VE_accu| .. |d_VL_accu| (trk.cc:1624-1636) --, the correlator outputs, the window's position, state and flags
-                            gsh_trk_epoch* const rp = a.records != nullptr ? a.records + (static_cast<size_t>(ch) * a.n_epochs + e) : nullptr;
+                            gsh_trk_epoch* const rp = a.records != nullptr ? &rec_ref() : nullptr;
                             if (rp != nullptr)
                                 {
 #pragma unroll
                                     for (int t = 0; t < 5; t++)  // (all ten slots: the device buffer is not cleared between launches)
                                         {
-                                            rp->accu[2 * t] = (t < NT) ? acc[t < NT ? t : 0].x : 0.0f;
-                                            rp->accu[2 * t + 1] = (t < NT) ? acc[t < NT ? t : 0].y : 0.0f;
-                                            rp->corr[2 * t] = (t < NT) ? out[t < NT ? t : 0].x : 0.0f;
-                                            rp->corr[2 * t + 1] = (t < NT) ? out[t < NT ? t : 0].y : 0.0f;
+                                            rec_set<LIVE>(rp->accu[2 * t], (t < NT) ? acc[t < NT ? t : 0].x : 0.0f);
+                                            rec_set<LIVE>(rp->accu[2 * t + 1], (t < NT) ? acc[t < NT ? t : 0].y : 0.0f);
+                                            rec_set<LIVE>(rp->corr[2 * t], (t < NT) ? out[t < NT ? t : 0].x : 0.0f);
+                                            rec_set<LIVE>(rp->corr[2 * t + 1], (t < NT) ? out[t < NT ? t : 0].y : 0.0f);
                                         }
-                                    rp->prompt_data[0] = pdata.x;
-                                    rp->prompt_data[1] = pdata.y;
-                                    rp->sample_counter = pos;
-                                    rp->flags = pull_in ? 1 : 0;
-                                    rp->state = run_state;
+                                    rec_set<LIVE>(rp->prompt_data[0], pdata.x);
+                                    rec_set<LIVE>(rp->prompt_data[1], pdata.y);
+                                    rec_set<LIVE>(rp->sample_counter, pos);
+                                    rec_set<LIVE>(rp->flags, pull_in ? 1 : 0);
+                                    rec_set<LIVE>(rp->state, run_state);
                                 }
                             bool lost_now = false;
                             if (c.enable_lock_detectors)
@@ -742,8 +976,8 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                             mail.lost = lost_now ? 1 : 0;
                             if (rp != nullptr)
                                 {
-                                    rp->cn0_db_hz = c.enable_lock_detectors ? lk.cn0_db_hz : 0.0f;
-                                    rp->carrier_lock_test = c.enable_lock_detectors ? lk.carrier_lock_test : 0.0;
+                                    rec_set<LIVE>(rp->cn0_db_hz, c.enable_lock_detectors ? lk.cn0_db_hz : 0.0f);
+                                    rec_set<LIVE>(rp->carrier_lock_test, c.enable_lock_detectors ? lk.carrier_lock_test : 0.0);
                                 }
                         }
                 }
@@ -751,6 +985,14 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
 #ifdef GSH_TRK_PROFILE
             const long long t_join = clock64();
 #endif
+            if constexpr (LIVE)
+              if (tid == 64 * SERIAL_WAVES && lv.head != lv.head_fenced)
+                {
+                    // samples pushed since this compute unit last looked: whatever its L1 holds of those ring positions is a lap old.  One lane's agent-scope
+                    // acquire invalidates the unit's L1; it runs beside thread 0's join and is over before the barrier that ends the period.
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    lv.head_fenced = lv.head;
+                }
             if (tid == 0)
                 {
                     const int extend = (c.enable_symbol_sync && c.extend_correlation_symbols > 1) ? c.extend_correlation_symbols : 1;
@@ -772,27 +1014,28 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                         {
                             if (a.records != nullptr)
                                 {
-                                    gsh_trk_epoch& r = a.records[static_cast<size_t>(ch) * a.n_epochs + e];  // written in place, field by field
+                                    gsh_trk_epoch& r = rec_ref();  // written in place, field by field
                                     {
                                         unsigned* rw = reinterpret_cast<unsigned*>(&r);
-                                        for (int i = 0; i < static_cast<int>(offsetof(gsh_trk_epoch, accu) / 4); i++) rw[i] = 0u;  // (accu, the record's tail, is already in place)
+                                        for (int i = 0; i < static_cast<int>(offsetof(gsh_trk_epoch, accu) / 4); i++) rec_set<LIVE>(rw[i], 0u);  // (accu, the record's tail, is already in place)
                                     }
-                                    r.sample_counter = pos;
-                                    r.flags = (pull_in ? 1 : 0) | 2;
+                                    rec_set<LIVE>(r.sample_counter, pos);
+                                    rec_set<LIVE>(r.flags, (pull_in ? 1 : 0) | 2);
 #pragma unroll
                                     for (int t = 0; t < 5; t++)
                                         {
-                                            r.corr[2 * t] = (t < NT) ? out[t < NT ? t : 0].x : 0.0f;
-                                            r.corr[2 * t + 1] = (t < NT) ? out[t < NT ? t : 0].y : 0.0f;
+                                            rec_set<LIVE>(r.corr[2 * t], (t < NT) ? out[t < NT ? t : 0].x : 0.0f);
+                                            rec_set<LIVE>(r.corr[2 * t + 1], (t < NT) ? out[t < NT ? t : 0].y : 0.0f);
                                         }
-                                    r.prompt_data[0] = pdata.x;
-                                    r.prompt_data[1] = pdata.y;
-                                    r.cn0_db_hz = rec_cn0;
-                                    r.carrier_lock_test = rec_lock_test;
-                                    r.state = run_state;
+                                    rec_set<LIVE>(r.prompt_data[0], pdata.x);
+                                    rec_set<LIVE>(r.prompt_data[1], pdata.y);
+                                    rec_set<LIVE>(r.cn0_db_hz, rec_cn0);
+                                    rec_set<LIVE>(r.carrier_lock_test, rec_lock_test);
+                                    rec_set<LIVE>(r.state, run_state);
                                 }
                             s.active = 0;
                             publish(win, s, c, a.n_stream, 0);
+                            if constexpr (LIVE) live_advance(a, s, win, lv, c.vector_length);  // (the channel is stopped: the drain round publishes this record and leaves)
                         }
                     else
                         {
@@ -1058,21 +1301,21 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
 
                     if (a.records != nullptr)
                         {
-                            gsh_trk_epoch& r = a.records[static_cast<size_t>(ch) * a.n_epochs + e];  // written in place (every field is assigned)
-                            r.carrier_phase_rate_step_rad = s.carrier_phase_rate_step_rad;
-                            r.code_phase_rate_step_chips = s.code_phase_rate_step_chips;
-                            r.symbol_flags = rec_symbol_flags;
-                            r.p_data_accu[0] = rec_pdata[0];
-                            r.p_data_accu[1] = rec_pdata[1];
-                            r.prn_length_samples = prn_len;
-                            r.rem_carr_phase_rad = s.rem_carr_phase_rad;
-                            r.carrier_doppler_hz = s.carrier_doppler_hz;
-                            r.code_freq_chips = s.code_freq_chips;
-                            r.carr_phase_error_hz = carr_phase_error_hz;
-                            r.carr_freq_error_hz = carr_freq_error_hz;
-                            r.carr_error_filt_hz = carr_error_filt_hz;
-                            r.rem_code_phase_samples = s.rem_code_phase_samples;
-                            r.acc_carrier_phase_rad = s.acc_carrier_phase_rad;
+                            gsh_trk_epoch& r = rec_ref();  // written in place (every field is assigned)
+                            rec_set<LIVE>(r.carrier_phase_rate_step_rad, s.carrier_phase_rate_step_rad);
+                            rec_set<LIVE>(r.code_phase_rate_step_chips, s.code_phase_rate_step_chips);
+                            rec_set<LIVE>(r.symbol_flags, rec_symbol_flags);
+                            rec_set<LIVE>(r.p_data_accu[0], rec_pdata[0]);
+                            rec_set<LIVE>(r.p_data_accu[1], rec_pdata[1]);
+                            rec_set<LIVE>(r.prn_length_samples, prn_len);
+                            rec_set<LIVE>(r.rem_carr_phase_rad, s.rem_carr_phase_rad);
+                            rec_set<LIVE>(r.carrier_doppler_hz, s.carrier_doppler_hz);
+                            rec_set<LIVE>(r.code_freq_chips, s.code_freq_chips);
+                            rec_set<LIVE>(r.carr_phase_error_hz, carr_phase_error_hz);
+                            rec_set<LIVE>(r.carr_freq_error_hz, carr_freq_error_hz);
+                            rec_set<LIVE>(r.carr_error_filt_hz, carr_error_filt_hz);
+                            rec_set<LIVE>(r.rem_code_phase_samples, s.rem_code_phase_samples);
+                            rec_set<LIVE>(r.acc_carrier_phase_rad, s.acc_carrier_phase_rad);
 #ifdef GSH_TRK_PROFILE
                             if (NT == 3)  // phase durations in shader clocks, in the unused VE / VL slots
                                 {
@@ -1090,12 +1333,13 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                     s.pos = pos + static_cast<unsigned long long>(prn_len);  // consume_each, trk.cc:2287
                     publish(win, s, c, a.n_stream, e + 1 < a.n_epochs, a.ring_oldest);
                     win.narrow = lk.narrow;
+                    if constexpr (LIVE) live_advance(a, s, win, lv, c.vector_length);
 #ifdef GSH_TRK_PROFILE
-                    if (NT == 3 && a.records != nullptr) a.records[static_cast<size_t>(ch) * a.n_epochs + e].accu[9] = static_cast<float>(clock64() - t_corr_done);  // ... + publish
+                    if (NT == 3 && a.records != nullptr) rec_ref().accu[9] = static_cast<float>(clock64() - t_corr_done);  // ... + publish
 #if GSH_TRK_PROFILE == 2  // the correlation phase instead of the serial section: window set-up, trips, wave sums, barrier, sum over the waves + barrier, the loop's own barrier
                     if (NT == 3 && a.records != nullptr)
                         {
-                            gsh_trk_epoch& r = a.records[static_cast<size_t>(ch) * a.n_epochs + e];
+                            gsh_trk_epoch& r = rec_ref();
                             using mcdev::cw_stamp;
                             r.corr[8] = static_cast<float>(cw_stamp[1] - t_begin);
                             r.corr[9] = static_cast<float>(cw_stamp[2] - cw_stamp[1]);
@@ -1127,11 +1371,19 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
     }
     if (tid == 0)
         {
-            TrkTail tl;
-            tl.pos = s.pos;
-            tl.done = done;
-            tl.active = s.active;
-            a.tail[ch] = tl;
+            if constexpr (LIVE)
+                {
+                    LiveTail* th = a.live.tail + ch;  // (pos, active and seq went out in the drain round that ended the loop)
+                    th->exit_reason = lv.exit_reason;
+                }
+            else
+                {
+                    TrkTail tl;
+                    tl.pos = s.pos;
+                    tl.done = done;
+                    tl.active = s.active;
+                    a.tail[ch] = tl;
+                }
         }
 }
 
@@ -1275,6 +1527,18 @@ struct gsh_trk
     bool host_records{true};                 // the kernel writes records and tails straight into the page-locked host buffers: no copies queued behind it, 4 - 20 us less
                                              // per launch (profiles/ab/r03/loop_host_records.txt).  GSH_TRK_HOST_RECORDS=0: device buffers + two copies, as before
     bool pending_records{false};
+    // ---- live mode (gsh_trk_live_*): everything the resident kernel and the host share lies in coherent page-locked host memory
+    hipStream_t live_stream{nullptr};               // lowest priority: a queue of its own kind, never the one a push travels in (sample_stream.hip)
+    gsh::LiveTail* h_live_tail{nullptr};            // n_channels
+    unsigned long long* h_live_consumed{nullptr};   // n_channels: records taken by the host
+    int* h_live_quit{nullptr};
+    gsh_trk_epoch* h_live_records{nullptr};         // n_channels * live_ring_len
+    unsigned live_ring_len{0};
+    std::vector<unsigned long long> live_next_window;  // first sample of the window behind the last record TAKEN (what the caller's block has to be offered next)
+    hipEvent_t live_ev[2]{nullptr, nullptr};
+    bool live_busy[2]{false, false};                // a residency has been queued and its event has not been seen complete yet
+    unsigned live_idle_us{200}, live_residency_us{5000};
+    std::shared_ptr<gsh::LiveFloor> live_floor;     // registered with the ring: pushes keep off what the channels still read
 };
 
 namespace
@@ -1303,15 +1567,24 @@ bool fast_division_applies(const gsh_trk_conf& c)
     return !all_ones(c.fs_in) && !all_ones(c.signal_carrier_freq);
 }
 
-int trk_launch(gsh_trk* t, int n_epochs, gsh_trk_epoch* d_records, gsh::TrkTail* d_tail = nullptr)
+int trk_launch(gsh_trk* t, int n_epochs, gsh_trk_epoch* d_records, gsh::TrkTail* d_tail = nullptr, const gsh::LiveArgs* live = nullptr)
 {
     gsh::TrkArgs a;
+    a.live = gsh::LiveArgs{};
+    if (live != nullptr) a.live = *live;
     a.conf = t->d_conf;
     a.stream = t->d_stream;
     a.n_stream = t->n_stream;
     a.ring_capacity = 0;
     a.ring_oldest = 0;
-    if (t->ring != nullptr)
+    if (live != nullptr)
+        {
+            // a residency learns how far the ring is complete from the ring's live words, not from the host: no event waits in either direction
+            a.stream = t->ring->d_ring;
+            a.ring_capacity = t->ring->capacity;
+            a.n_stream = 0ull;
+        }
+    else if (t->ring != nullptr)
         {
             a.stream = t->ring->d_ring;
             a.ring_capacity = t->ring->capacity;
@@ -1356,22 +1629,19 @@ int trk_launch(gsh_trk* t, int n_epochs, gsh_trk_epoch* d_records, gsh::TrkTail*
     }
     const size_t lds = trk_lds_bytes(t);
     const dim3 grid(t->n_channels), block(gsh::mcdev::MC_THREADS);
-    if (t->conf.veml)
-        {
-            if (t->conf.high_dyn)
-                hipLaunchKernelGGL((gsh::trk_loop_kernel<5, true>), grid, block, lds, t->stream, a, a.conf);
-            else
-                hipLaunchKernelGGL((gsh::trk_loop_kernel<5, false>), grid, block, lds, t->stream, a, a.conf);
-        }
-    else
-        {
-            if (t->conf.high_dyn)
-                hipLaunchKernelGGL((gsh::trk_loop_kernel<3, true>), grid, block, lds, t->stream, a, a.conf);
-            else
-                hipLaunchKernelGGL((gsh::trk_loop_kernel<3, false>), grid, block, lds, t->stream, a, a.conf);
-        }
+    hipStream_t st = live != nullptr ? t->live_stream : t->stream;
+    {
+        using KernelFn = void (*)(gsh::TrkArgs, const gsh_trk_conf*);
+        const bool L = live != nullptr;
+        KernelFn fn;
+        if (t->conf.veml)
+            fn = t->conf.high_dyn ? (L ? gsh::trk_loop_kernel<5, true, true> : gsh::trk_loop_kernel<5, true, false>) : (L ? gsh::trk_loop_kernel<5, false, true> : gsh::trk_loop_kernel<5, false, false>);
+        else
+            fn = t->conf.high_dyn ? (L ? gsh::trk_loop_kernel<3, true, true> : gsh::trk_loop_kernel<3, true, false>) : (L ? gsh::trk_loop_kernel<3, false, true> : gsh::trk_loop_kernel<3, false, false>);
+        hipLaunchKernelGGL(fn, grid, block, lds, st, a, a.conf);
+    }
     GSH_HIP(hipGetLastError());
-    if (t->ring != nullptr)
+    if (live == nullptr && t->ring != nullptr)
         {
             // a later push waits for this launch only if it overwrites samples at or above the oldest window a running channel starts at
             unsigned long long lowest = ~0ull;
@@ -1379,6 +1649,140 @@ int trk_launch(gsh_trk* t, int n_epochs, gsh_trk_epoch* d_records, gsh::TrkTail*
                 if (c.active && c.pos < lowest) lowest = c.pos;
             return gsh::stream_mark_read(t->ring, lowest, t->stream);
         }
+    return GSH_OK;
+}
+
+// ---- live mode, host side ---------------------------------------------------------------------------------------------------------------------
+// residencies whose event has completed are no longer in flight
+int live_reap(gsh_trk* t)
+{
+    int n = 0;
+    for (int i = 0; i < 2; i++)
+        {
+            if (!t->live_busy[i]) continue;
+            const hipError_t e = hipEventQuery(t->live_ev[i]);
+            if (e == hipSuccess)
+                t->live_busy[i] = false;
+            else if (e == hipErrorNotReady)
+                n++;
+            else
+                {
+                    (void)gsh::hip_fail(e, "hipEventQuery(residency)", __FILE__, __LINE__);
+                    return -1;
+                }
+        }
+    return n;
+}
+
+void live_release(gsh_trk* t)  // the handle's side of the registration with its ring, and the memory the registration points into
+{
+    if (t->live_floor)
+        {
+            std::lock_guard<std::mutex> lk(t->live_floor->m);
+            t->live_floor->tails = nullptr;
+            t->live_floor->n = 0;
+        }
+    t->live_floor.reset();
+}
+
+// first use: the shared words and the record ring in coherent host memory, the stream, the registration with the ring
+int live_setup(gsh_trk* t)
+{
+    if (t->h_live_tail != nullptr) return GSH_OK;
+    GSH_HIP(hipSetDevice(t->device));
+    if (const char* e = std::getenv("GSH_TRK_LIVE_IDLE_US")) t->live_idle_us = static_cast<unsigned>(std::max(1, std::atoi(e)));
+    if (const char* e = std::getenv("GSH_TRK_LIVE_RESIDENCY_US")) t->live_residency_us = static_cast<unsigned>(std::max(10, std::atoi(e)));
+    // as many records as periods the ring can hold ahead of the slowest reader, and then some: the device never has to wait for the host in practice
+    unsigned len = 64;
+    const unsigned long long want = t->ring->capacity / std::max<unsigned long long>(t->conf.vector_length, 1ull) + 32ull;
+    while (len < want && len < 4096u) len <<= 1;
+    if (const char* e = std::getenv("GSH_TRK_LIVE_RECORDS"))
+        {
+            unsigned v = static_cast<unsigned>(std::max(2, std::atoi(e))), pw = 2;
+            while (pw < v && pw < 65536u) pw <<= 1;
+            len = pw;
+        }
+    const unsigned flags = hipHostMallocCoherent | hipHostMallocMapped;
+    gsh::LiveTail* tails = nullptr;
+    unsigned long long* consumed = nullptr;
+    int* quit = nullptr;
+    gsh_trk_epoch* recs = nullptr;
+    auto undo = [&]() {
+        if (tails) (void)hipHostFree(tails);
+        if (consumed) (void)hipHostFree(consumed);
+        if (quit) (void)hipHostFree(quit);
+        if (recs) (void)hipHostFree(recs);
+    };
+    hipError_t e;
+    if ((e = hipHostMalloc(&tails, sizeof(gsh::LiveTail) * t->n_channels, flags)) != hipSuccess ||
+        (e = hipHostMalloc(&consumed, sizeof(unsigned long long) * t->n_channels, flags)) != hipSuccess ||
+        (e = hipHostMalloc(&quit, sizeof(int) * 16, flags)) != hipSuccess ||
+        (e = hipHostMalloc(&recs, sizeof(gsh_trk_epoch) * static_cast<size_t>(t->n_channels) * len, flags)) != hipSuccess)
+        {
+            undo();
+            return gsh::hip_fail(e, "hipHostMalloc(live)", __FILE__, __LINE__);
+        }
+    if (t->live_stream == nullptr)
+        {
+            int least = 0, greatest = 0;
+            if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
+            if ((e = hipStreamCreateWithPriority(&t->live_stream, hipStreamNonBlocking, least)) != hipSuccess)
+                {
+                    undo();
+                    return gsh::hip_fail(e, "hipStreamCreateWithPriority(live)", __FILE__, __LINE__);
+                }
+        }
+    for (int i = 0; i < 2; i++)
+        if (t->live_ev[i] == nullptr && (e = hipEventCreateWithFlags(&t->live_ev[i], hipEventDisableTiming)) != hipSuccess)
+            {
+                undo();
+                return gsh::hip_fail(e, "hipEventCreate(live)", __FILE__, __LINE__);
+            }
+    std::memset(recs, 0, sizeof(gsh_trk_epoch) * static_cast<size_t>(t->n_channels) * len);
+    *quit = 0;
+    t->live_next_window.assign(static_cast<size_t>(t->n_channels), 0ull);
+    for (int ch = 0; ch < t->n_channels; ch++)
+        {
+            tails[ch].pos = t->h_chan[ch].pos;
+            tails[ch].seq = 0ull;
+            tails[ch].active = t->h_chan[ch].active;
+            tails[ch].exit_reason = gsh::LIVE_EXIT_NONE;
+            consumed[ch] = 0ull;
+            t->live_next_window[ch] = t->h_chan[ch].pos;
+        }
+    t->h_live_tail = tails;
+    t->h_live_consumed = consumed;
+    t->h_live_quit = quit;
+    t->h_live_records = recs;
+    t->live_ring_len = len;
+    t->live_floor = std::make_shared<gsh::LiveFloor>();
+    t->live_floor->tails = tails;
+    t->live_floor->n = t->n_channels;
+    t->ring->live_floors.push_back(t->live_floor);
+    return GSH_OK;
+}
+
+// the host's copy of where the channels stand, after the device has gone quiet
+void live_refresh_host_state(gsh_trk* t)
+{
+    if (t->h_live_tail == nullptr) return;
+    for (int ch = 0; ch < t->n_channels; ch++)
+        {
+            t->h_chan[ch].pos = t->h_live_tail[ch].pos;
+            t->h_chan[ch].active = t->h_live_tail[ch].active;
+        }
+}
+
+int live_quiesce(gsh_trk* t)
+{
+    if (t->h_live_tail == nullptr || t->live_stream == nullptr) return GSH_OK;
+    if (!t->live_busy[0] && !t->live_busy[1]) return GSH_OK;
+    __atomic_store_n(t->h_live_quit, 1, __ATOMIC_RELEASE);
+    const hipError_t e = hipStreamSynchronize(t->live_stream);
+    __atomic_store_n(t->h_live_quit, 0, __ATOMIC_RELEASE);
+    t->live_busy[0] = t->live_busy[1] = false;
+    if (e != hipSuccess) return gsh::hip_fail(e, "hipStreamSynchronize(live)", __FILE__, __LINE__);
+    live_refresh_host_state(t);
     return GSH_OK;
 }
 }  // namespace
@@ -1451,10 +1855,12 @@ extern "C"
         if (trk_lds_bytes(t) > 64 * 1024)
             {
                 const int bytes = static_cast<int>(trk_lds_bytes(t));
-                if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(gsh::trk_loop_kernel<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes)) != hipSuccess) return fail(e, "hipFuncSetAttribute");
-                if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(gsh::trk_loop_kernel<5, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes)) != hipSuccess) return fail(e, "hipFuncSetAttribute");
-                if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(gsh::trk_loop_kernel<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes)) != hipSuccess) return fail(e, "hipFuncSetAttribute");
-                if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(gsh::trk_loop_kernel<5, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes)) != hipSuccess) return fail(e, "hipFuncSetAttribute");
+                const void* fns[8] = {reinterpret_cast<const void*>(gsh::trk_loop_kernel<3, false, false>), reinterpret_cast<const void*>(gsh::trk_loop_kernel<5, false, false>),
+                    reinterpret_cast<const void*>(gsh::trk_loop_kernel<3, true, false>), reinterpret_cast<const void*>(gsh::trk_loop_kernel<5, true, false>),
+                    reinterpret_cast<const void*>(gsh::trk_loop_kernel<3, false, true>), reinterpret_cast<const void*>(gsh::trk_loop_kernel<5, false, true>),
+                    reinterpret_cast<const void*>(gsh::trk_loop_kernel<3, true, true>), reinterpret_cast<const void*>(gsh::trk_loop_kernel<5, true, true>)};
+                for (const void* fn : fns)
+                    if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)) != hipSuccess) return fail(e, "hipFuncSetAttribute");
             }
         *out = t;
         return GSH_OK;
@@ -1464,6 +1870,16 @@ extern "C"
     {
         if (!t) return;
         (void)hipSetDevice(t->device);
+        (void)live_quiesce(t);
+        live_release(t);
+        if (t->live_stream) (void)hipStreamSynchronize(t->live_stream);
+        for (int i = 0; i < 2; i++)
+            if (t->live_ev[i]) (void)hipEventDestroy(t->live_ev[i]);
+        if (t->live_stream) (void)hipStreamDestroy(t->live_stream);
+        if (t->h_live_tail) (void)hipHostFree(t->h_live_tail);
+        if (t->h_live_consumed) (void)hipHostFree(t->h_live_consumed);
+        if (t->h_live_quit) (void)hipHostFree(t->h_live_quit);
+        if (t->h_live_records) (void)hipHostFree(t->h_live_records);
         if (t->stream) (void)hipStreamSynchronize(t->stream);
         if (t->d_codes) (void)hipFree(t->d_codes);
         if (t->d_chan) (void)hipFree(t->d_chan);
@@ -1519,6 +1935,22 @@ extern "C"
         GSH_REQUIRE(s == nullptr || s->device == t->device, "the ring lives on device %d, the loop on device %d", s ? s->device : -1, t->device);
         GSH_REQUIRE(s == nullptr || s->max_window >= t->conf.vector_length, "the ring's max_window_samples %llu is shorter than vector_length %u",
             s ? s->max_window : 0ull, t->conf.vector_length);
+        if (s != t->ring && t->h_live_tail != nullptr)
+            {
+                // live mode was set up against the old ring: wind it down, the next gsh_trk_live_begin sets it up against the new one
+                GSH_HIP(hipSetDevice(t->device));
+                int rcq = live_quiesce(t);
+                if (rcq != GSH_OK) return rcq;
+                live_release(t);
+                (void)hipHostFree(t->h_live_tail);
+                (void)hipHostFree(t->h_live_consumed);
+                (void)hipHostFree(t->h_live_quit);
+                (void)hipHostFree(t->h_live_records);
+                t->h_live_tail = nullptr;
+                t->h_live_consumed = nullptr;
+                t->h_live_quit = nullptr;
+                t->h_live_records = nullptr;
+            }
         t->ring = s;
         if (s != nullptr)
             {
@@ -1567,7 +1999,15 @@ extern "C"
     {
         GSH_REQUIRE(t != nullptr, "null handle");
         GSH_REQUIRE(channel >= 0 && channel < t->n_channels, "channel %d outside 0..%d", channel, t->n_channels - 1);
+        if (t->pending_epochs >= 0) return set_error(GSH_ERR_STATE, "gsh_trk_stop: a run has been begun and not ended");
         GSH_HIP(hipSetDevice(t->device));
+        if (live_reap(t) != 0) return set_error(GSH_ERR_STATE, "gsh_trk_stop: a live residency is in flight (gsh_trk_live_quiesce first)");
+        live_refresh_host_state(t);  // (a residency that ended by itself has moved the channels on)
+        if (t->h_live_tail != nullptr)
+            {
+                t->h_live_tail[channel].active = 0;
+                __atomic_store_n(&t->h_live_consumed[channel], t->h_live_tail[channel].seq, __ATOMIC_RELEASE);  // records not taken are dropped
+            }
         t->h_chan[channel].active = 0;
         // only the flag is written: the rest of the channel's state (device-owned between launches) stays as the loop left it
         GSH_HIP(hipMemcpyAsync(reinterpret_cast<char*>(t->d_chan + channel) + offsetof(gsh::TrkChannel, active), &t->h_chan[channel].active, sizeof(int),
@@ -1584,7 +2024,10 @@ extern "C"
         GSH_REQUIRE(code_length >= gsh::mcdev::MC_MARGIN && code_length <= t->max_code_len, "code_length %d outside %d..%d", code_length, gsh::mcdev::MC_MARGIN, t->max_code_len);
         GSH_REQUIRE(!t->conf.track_pilot || data_code != nullptr, "track_pilot needs the data-component code");
         GSH_REQUIRE(acq_sample_stamp <= start_sample, "acq_sample_stamp must not be later than start_sample");
+        if (t->pending_epochs >= 0) return set_error(GSH_ERR_STATE, "gsh_trk_start: a run has been begun and not ended");
         GSH_HIP(hipSetDevice(t->device));
+        if (live_reap(t) != 0) return set_error(GSH_ERR_STATE, "gsh_trk_start: a live residency is in flight (gsh_trk_live_quiesce first)");
+        live_refresh_host_state(t);  // (a residency that ended by itself has moved the channels on)
         const gsh_trk_conf& c = t->conf;
         gsh::TrkChannel s{};
         // start_tracking, trk.cc:803-826, and the pull-in state, :1956-1958
@@ -1606,6 +2049,14 @@ extern "C"
         gsh::design_loop_filter(s.dll, static_cast<float>(code_period), c.dll_bw_hz, c.dll_filter_order, false);     // trk.cc:604, 845-849
         gsh::design_fll_pll(s.pll, c.fll_bw_hz, c.pll_bw_hz, c.pll_filter_order, static_cast<float>(acq_carrier_doppler_hz));  // trk.cc:605, 844, 848
         t->h_chan[channel] = s;
+        if (t->h_live_tail != nullptr)
+            {
+                t->h_live_tail[channel].pos = s.pos;
+                t->h_live_tail[channel].active = 1;
+                t->h_live_tail[channel].exit_reason = gsh::LIVE_EXIT_NONE;
+                __atomic_store_n(&t->h_live_consumed[channel], t->h_live_tail[channel].seq, __ATOMIC_RELEASE);  // records of the previous run that nobody took are dropped
+                t->live_next_window[static_cast<size_t>(channel)] = s.pos;
+            }
         float* dst = t->d_codes + static_cast<size_t>(channel) * 2 * t->max_code_len;
         GSH_HIP(hipMemcpyAsync(dst, code, sizeof(float) * code_length, hipMemcpyHostToDevice, t->stream));
         if (data_code) GSH_HIP(hipMemcpyAsync(dst + t->max_code_len, data_code, sizeof(float) * code_length, hipMemcpyHostToDevice, t->stream));
@@ -1659,6 +2110,8 @@ extern "C"
         if (t->d_stream == nullptr) return set_error(GSH_ERR_STATE, "no IF stream attached (gsh_trk_set_stream_*)");
         if (t->pending_epochs >= 0) return set_error(GSH_ERR_STATE, "gsh_trk_run_begin: the previous run has not been ended");
         GSH_HIP(hipSetDevice(t->device));
+        if (live_reap(t) != 0) return set_error(GSH_ERR_STATE, "gsh_trk_run_begin: a live residency is in flight (gsh_trk_live_quiesce first)");
+        live_refresh_host_state(t);  // (a residency that ended by itself has moved the channels on)
         const size_t n_rec = want_records ? static_cast<size_t>(t->n_channels) * static_cast<size_t>(n_epochs) : 0;
         // (grown in steps of 64 periods per channel: a caller whose launches lengthen period by period -- the tracking runtime while its channels start --
         // would otherwise free and allocate page-locked memory at every launch, 0.3 ms each time: profiles/ab/r03/dropin_blocks_r03_final.txt)
@@ -1698,7 +2151,19 @@ extern "C"
                 tail_dst = static_cast<gsh::TrkTail*>(p);
             }
         int rc = trk_launch(t, n_epochs, rec_dst, tail_dst);
-        if (rc != GSH_OK) return rc;
+        if (rc != GSH_OK)
+            {
+                // the kernel may have been queued before the failure (the ring's reader fence): nothing of this launch may still be writing into the host
+                // buffers, or be unknown to the ring, when the caller sees the error -- wait for the stream and take the positions the kernel left
+                if (hipStreamSynchronize(t->stream) == hipSuccess && t->host_records)
+                    for (int ch = 0; ch < t->n_channels; ch++)
+                        if (t->h_tail[ch].done > 0)
+                            {
+                                t->h_chan[ch].pos = t->h_tail[ch].pos;
+                                t->h_chan[ch].active = t->h_tail[ch].active;
+                            }
+                return rc;
+            }
 #ifdef GSH_TRACE_TRK_BEGIN
         const auto t1 = std::chrono::steady_clock::now();
 #endif
@@ -1746,8 +2211,117 @@ extern "C"
                 if (epochs_done != nullptr) epochs_done[ch] = t->h_tail[ch].done;
                 t->h_chan[ch].pos = t->h_tail[ch].pos;
                 t->h_chan[ch].active = t->h_tail[ch].active;
+                if (t->h_live_tail != nullptr)  // a handle that alternates between launches and residencies: the live view follows
+                    {
+                        t->h_live_tail[ch].pos = t->h_tail[ch].pos;
+                        t->h_live_tail[ch].active = t->h_tail[ch].active;
+                        if (t->h_live_consumed[ch] == t->h_live_tail[ch].seq) t->live_next_window[static_cast<size_t>(ch)] = t->h_tail[ch].pos;
+                    }
             }
         return GSH_OK;
+    }
+
+    // ---- live mode ------------------------------------------------------------------------------------------------------------------------------
+    int gsh_trk_live_configure(gsh_trk_t* t, uint32_t idle_timeout_us, uint32_t residency_us)
+    {
+        GSH_REQUIRE(t != nullptr, "null handle");
+        GSH_REQUIRE(idle_timeout_us >= 1 && idle_timeout_us <= 1000000u, "idle_timeout_us %u outside 1..1000000", idle_timeout_us);
+        GSH_REQUIRE(residency_us >= 10 && residency_us <= 10000000u, "residency_us %u outside 10..10000000", residency_us);
+        t->live_idle_us = idle_timeout_us;
+        t->live_residency_us = residency_us;
+        return GSH_OK;
+    }
+
+    int gsh_trk_live_begin(gsh_trk_t* t)
+    {
+        GSH_REQUIRE(t != nullptr, "null handle");
+        if (t->ring == nullptr) return set_error(GSH_ERR_STATE, "live mode follows a sample ring (gsh_trk_set_stream_ring)");
+        if (t->pending_epochs >= 0) return set_error(GSH_ERR_STATE, "gsh_trk_live_begin: a run has been begun and not ended");
+        GSH_HIP(hipSetDevice(t->device));
+        int rc = live_setup(t);
+        if (rc != GSH_OK) return rc;
+        const int in_flight = live_reap(t);
+        if (in_flight < 0) return GSH_ERR_HIP;
+        if (in_flight >= 2) return GSH_OK;  // one running, one queued behind it: nothing to add
+        const int slot = t->live_busy[0] ? 1 : 0;
+        gsh::LiveArgs L{};
+        L.head = gsh::stream_live_words(t->ring);
+        if (L.head == nullptr) return GSH_ERR_HIP;
+        void* p = nullptr;
+        GSH_HIP(hipHostGetDevicePointer(&p, t->h_live_tail, 0));
+        L.tail = static_cast<gsh::LiveTail*>(p);
+        GSH_HIP(hipHostGetDevicePointer(&p, t->h_live_consumed, 0));
+        L.consumed = static_cast<const unsigned long long*>(p);
+        GSH_HIP(hipHostGetDevicePointer(&p, t->h_live_quit, 0));
+        L.quit = static_cast<const int*>(p);
+        L.ring_len = t->live_ring_len;
+        L.idle_ticks = 100ull * t->live_idle_us;            // wall_clock64() counts at 100 MHz
+        L.residency_ticks = 100ull * t->live_residency_us;
+        GSH_HIP(hipHostGetDevicePointer(&p, t->h_live_records, 0));
+        rc = trk_launch(t, 0x7fffffff, static_cast<gsh_trk_epoch*>(p), nullptr, &L);
+        if (rc != GSH_OK) return rc;
+        GSH_HIP(hipEventRecord(t->live_ev[slot], t->live_stream));
+        t->live_busy[slot] = true;
+        return GSH_OK;
+    }
+
+    int gsh_trk_live_in_flight(gsh_trk_t* t, int32_t* n)
+    {
+        GSH_REQUIRE(t != nullptr && n != nullptr, "null argument");
+        const int k = live_reap(t);
+        if (k < 0) return GSH_ERR_HIP;
+        *n = k;
+        return GSH_OK;
+    }
+
+    int gsh_trk_live_take(gsh_trk_t* t, int channel, uint64_t limit_end, int max_records, gsh_trk_epoch* out, int32_t* n_out, int32_t* pending,
+        uint64_t* next_window, int32_t* active)
+    {
+        GSH_REQUIRE(t != nullptr && n_out != nullptr, "null argument");
+        GSH_REQUIRE(channel >= 0 && channel < t->n_channels, "channel %d outside 0..%d", channel, t->n_channels - 1);
+        GSH_REQUIRE(max_records == 0 || out != nullptr, "null record buffer");
+        *n_out = 0;
+        if (t->h_live_tail == nullptr) return set_error(GSH_ERR_STATE, "gsh_trk_live_take before the first gsh_trk_live_begin");
+        // No lock, no device call: the channel's tail and record ring are memory the kernel writes and this thread reads.  seq is stored by the device after
+        // the records below it have left it (tracking_loop.hip, the drain rule); the loads here follow in program order.
+        const volatile gsh::LiveTail* tail = t->h_live_tail + channel;
+        const unsigned long long seq = __atomic_load_n(&t->h_live_tail[channel].seq, __ATOMIC_ACQUIRE);
+        unsigned long long consumed = t->h_live_consumed[channel];
+        const unsigned long long vlen = t->conf.vector_length;
+        const gsh_trk_epoch* ring = t->h_live_records + static_cast<size_t>(channel) * t->live_ring_len;
+        int n = 0;
+        unsigned long long nw = t->live_next_window[static_cast<size_t>(channel)];
+        while (n < max_records && consumed < seq)
+            {
+                const gsh_trk_epoch& r = ring[consumed & (t->live_ring_len - 1u)];
+                const bool lost = (r.flags & 2) != 0;
+                if (!lost)
+                    {
+                        const unsigned long long need = std::max<unsigned long long>(vlen, static_cast<unsigned long long>(std::max(r.prn_length_samples, 0)));
+                        if (r.sample_counter + need > limit_end) break;  // the caller has not been offered these samples itself yet
+                    }
+                out[n++] = r;
+                consumed++;
+                if (lost) break;  // the channel has stopped: this is its last record
+                nw = r.sample_counter + static_cast<unsigned long long>(std::max(r.prn_length_samples, 0));
+            }
+        if (n > 0)
+            {
+                t->live_next_window[static_cast<size_t>(channel)] = nw;
+                __atomic_store_n(&t->h_live_consumed[channel], consumed, __ATOMIC_RELEASE);
+            }
+        *n_out = n;
+        if (pending != nullptr) *pending = static_cast<int32_t>(std::min<unsigned long long>(seq - consumed, 0x7fffffffull));
+        if (next_window != nullptr) *next_window = nw;
+        if (active != nullptr) *active = tail->active;
+        return GSH_OK;
+    }
+
+    int gsh_trk_live_quiesce(gsh_trk_t* t)
+    {
+        GSH_REQUIRE(t != nullptr, "null handle");
+        GSH_HIP(hipSetDevice(t->device));
+        return live_quiesce(t);
     }
 
     int gsh_trk_run(gsh_trk_t* t, int n_epochs, gsh_trk_epoch* records, int32_t* epochs_done)

@@ -99,6 +99,34 @@ class TrackingLoop:
             out = None
         return out, list(done)
 
+    # ---- live mode (gsh_trk_live_*): the loop stays resident and follows the ring; records are read from host memory without a device call
+    def live_configure(self, idle_timeout_us: int = 200, residency_us: int = 5000) -> None:
+        check(self._lib.gsh_trk_live_configure(self._h, idle_timeout_us, residency_us))
+
+    def live_begin(self) -> None:
+        check(self._lib.gsh_trk_live_begin(self._h))
+
+    def live_in_flight(self) -> int:
+        n = C.c_int32(0)
+        check(self._lib.gsh_trk_live_in_flight(self._h, C.byref(n)))
+        return n.value
+
+    def live_take(self, channel: int, max_records: int = 64, limit_end: int = 2**64 - 1):
+        """-> (records, pending, next_window, active)"""
+        rec = (TrkEpoch * max_records)()
+        n, pending, active = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        nw = C.c_uint64(0)
+        check(self._lib.gsh_trk_live_take(self._h, channel, C.c_uint64(limit_end), max_records, rec, C.byref(n), C.byref(pending), C.byref(nw), C.byref(active)))
+        out = []
+        for i in range(n.value):  # copies: the ctypes array is reused by nobody, but records outlive it this way
+            r = TrkEpoch()
+            C.memmove(C.byref(r), C.byref(rec[i]), C.sizeof(TrkEpoch))
+            out.append(r)
+        return out, pending.value, nw.value, active.value
+
+    def live_quiesce(self) -> None:
+        check(self._lib.gsh_trk_live_quiesce(self._h))
+
     def time_run(self, n_epochs: int, reps: int = 5) -> float:
         ms = C.c_float(0.0)
         check(self._lib.gsh_trk_time_run(self._h, n_epochs, reps, C.byref(ms)))

@@ -30,7 +30,7 @@ extern "C"
 {
 #endif
 
-#define GSH_ABI_VERSION 22
+#define GSH_ABI_VERSION 23
 #define GSH_MAX_TAPS 8 /* VE/E/P/L/VL needs 5 (trk.cc:609-650); 8 leaves room for multi-tap dumps */
 
     enum
@@ -411,6 +411,30 @@ extern "C"
      * samples can travel while the kernel runs; _end waits for the stream and hands the results over.  One launch in flight per handle. */
     int gsh_trk_run_begin(gsh_trk_t* t, int n_epochs, int want_records);
     int gsh_trk_run_end(gsh_trk_t* t, gsh_trk_epoch* records, int32_t* epochs_done);
+    /* ---- live mode: the loop follows the ring as it fills, without a launch per batch of periods.
+     * In the reference every channel's block is called once per code period (trk.cc:1898-2001) off one shared buffer
+     * (src/core/receiver/gnss_flowgraph.cc:1227-1231); at that cadence a launch per call is all host time.  gsh_trk_live_begin queues a RESIDENCY of the loop
+     * kernel instead: every started channel correlates its next window as soon as the ring (gsh_trk_set_stream_ring) holds it -- pushes announce
+     * themselves to the resident kernel through the ring, no event, no host --, and leaves one record per period in a ring of records in page-locked
+     * host memory that gsh_trk_live_take reads without a lock or a device call.  A residency ends by itself when nothing new has arrived for
+     * idle_timeout_us (200), after residency_us (5000: anything that waits for the whole device gets its turn), when the host asks (gsh_trk_live_quiesce)
+     * or when no channel has work; up to two may be queued, the second takes over when the first ends.  Loop arithmetic, records and trajectories are
+     * those of gsh_trk_run, bit for bit.
+     * Threads: _begin, _in_flight, _quiesce, start, stop, run*: one at a time per handle (the caller's lock).  _take: any thread, at most one per
+     * CHANNEL at a time, concurrently with everything except start / stop of that channel and gsh_trk_destroy.
+     * Pushes into the ring never overwrite samples a live channel has not correlated yet: they fail with GSH_ERR_STATE instead (an event cannot order
+     * a push behind a kernel that is waiting for that push); the caller keeps its pushes below lowest next window + ring capacity. */
+    int gsh_trk_live_configure(gsh_trk_t* t, uint32_t idle_timeout_us, uint32_t residency_us);
+    int gsh_trk_live_begin(gsh_trk_t* t);
+    int gsh_trk_live_in_flight(gsh_trk_t* t, int32_t* residencies);  /* queued or running */
+    /* up to max_records finished periods of one channel, oldest first, whose samples lie below limit_end (sample_counter + max(vector_length,
+     * prn_length_samples) <= limit_end; UINT64_MAX: no limit).  A record with flags bit 1 (loss of lock) ends the take and is the channel's last.
+     * *pending: records finished and not taken; *next_window: first sample of the window behind the last record taken; *active: the device still
+     * advances the channel. */
+    int gsh_trk_live_take(gsh_trk_t* t, int channel, uint64_t limit_end, int max_records, gsh_trk_epoch* out, int32_t* n_out, int32_t* pending,
+        uint64_t* next_window, int32_t* active);
+    /* tell the residencies in flight to leave, wait for them; records not yet taken stay where they are.  Needed before start / stop / run. */
+    int gsh_trk_live_quiesce(gsh_trk_t* t);
     /* where every channel stands after the last completed run (host copy, refreshed by gsh_trk_run / _run_end and by start / stop):
      * next_window[ch] = absolute index of the first sample of the channel's next correlation window, active[ch] != 0 while the loop advances it */
     int gsh_trk_positions(gsh_trk_t* t, uint64_t* next_window, int32_t* active);
