@@ -159,6 +159,7 @@ SYMBOLS = {
     "gsh_stream_push_pinned": (C.c_int, [_P, _P, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64)]),
     "gsh_stream_push_pinned_async": (C.c_int, [_P, _P, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64)]),
     "gsh_stream_wait_copied": (C.c_int, [_P]),
+    "gsh_stream_wait_copied_upto": (C.c_int, [_P, C.c_uint64, C.POINTER(C.c_uint64)]),
     "gsh_host_register": (C.c_int, [C.c_int, _P, C.c_size_t]),
     "gsh_host_unregister": (C.c_int, [_P]),
     "gsh_stream_seek": (C.c_int, [_P, C.c_uint64]),
@@ -196,7 +197,7 @@ SYMBOLS = {
     "gsh_trk_live_begin": (C.c_int, [_P]),
     "gsh_trk_live_in_flight": (C.c_int, [_P, C.POINTER(C.c_int32)]),
     "gsh_trk_live_take": (C.c_int, [_P, C.c_int, C.c_uint64, C.c_int, _P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_uint64),
-                                    C.POINTER(C.c_int32)]),
+                                    C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "gsh_trk_live_quiesce": (C.c_int, [_P]),
     "gsh_trk_time_run": (C.c_int, [_P, C.c_int, C.c_int, _F]),
     "gsh_trk_write_dump": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(TrkConf), C.c_uint32, C.POINTER(TrkEpoch), C.c_int, C.POINTER(C.c_uint64),

@@ -842,7 +842,7 @@ extern "C"
         int rc = gsh::stream_window(ring, first_sample, a->conf.consumed_samples, &w);
         if (rc != GSH_OK) return rc;
         GSH_HIP(hipSetDevice(a->device));
-        GSH_HIP(hipStreamWaitEvent(a->stream, ring->pushed, 0));  // conversions queued by gsh_stream_push_device
+        if (ring->pushed != nullptr) GSH_HIP(hipStreamWaitEvent(a->stream, ring->pushed, 0));  // conversions queued by gsh_stream_push_device
         rc = gsh_acq_dwell_device(a, w, n_prn, accumulate, dwell_count, results);
         if (rc != GSH_OK) return rc;
         return gsh::stream_mark_read(ring, first_sample, a->stream);  // (the dwell has already been waited for when results were asked for; harmless otherwise)

@@ -38,7 +38,7 @@ struct gsh_stream
     size_t raw_cap{0};                 // bytes
     unsigned long long next{0};        // absolute index of the next sample to be pushed
     unsigned long long origin{0};      // absolute index of the first sample ever pushed since the last seek (nothing older is resident)
-    hipEvent_t pushed{nullptr};        // recorded after the last push's device work
+    hipEvent_t pushed{nullptr};        // the history entry (push_ev) recorded last: "after the latest push's device work"; not owned
     void* d_raw2[2]{nullptr, nullptr}; // gsh_stream_push_async: two device staging buffers, used alternately
     size_t raw2_cap[2]{0, 0};
     hipEvent_t raw2_done[2]{nullptr, nullptr};  // the conversion that read staging buffer i has finished
@@ -67,13 +67,13 @@ struct gsh_stream
     size_t stage_cap[NSTAGE]{};
     hipEvent_t stage_done[NSTAGE]{};  // the conversion that read d_stage[i] (and therefore the copy out of h_stage[i]) has finished
     int stage_next{0};
-    hipEvent_t copied{nullptr};       // gsh_stream_push_pinned: the DMA out of the caller's page-locked memory has finished
     // Live readers (gsh_trk_live_*): a kernel that stays resident cannot be ordered against pushes by events -- it learns how far the ring is
     // COMPLETE from two words in device memory that a one-thread kernel, queued on the pushing stream behind every push's copies and conversion,
     // rewrites: d_live[0] = absolute index one past the newest complete sample, d_live[1] = first index resident since the last seek.
     unsigned long long* d_live{nullptr};
     std::vector<std::shared_ptr<gsh::LiveFloor>> live_floors;  // what the live loops still read: a push never overwrites it (write_items)
     std::vector<void*> parked_device, parked_host;  // outgrown staging buffers kept until the ring goes (release_buffer, sample_stream.hip)
+    std::mutex hist_mutex;  // the push history above is also read by gsh_stream_wait_copied_upto, from any thread
 };
 
 namespace gsh

@@ -47,7 +47,7 @@ int stream_wait_pushed(gsh_stream* s, unsigned long long need_end, hipStream_t s
                     return GSH_OK;
                 }
         }
-    GSH_HIP(hipStreamWaitEvent(st, s->pushed, 0));  // not in the history (or "everything"): the latest push
+    if (s->pushed != nullptr) GSH_HIP(hipStreamWaitEvent(st, s->pushed, 0));  // not in the history (or "everything"): the latest push
     return GSH_OK;
 }
 
@@ -199,12 +199,17 @@ namespace
 // after a push's device work has been queued on `st`: the "latest" event and the (end index, event) history entry
 int record_push(gsh_stream* s, unsigned long long end_index, hipStream_t st)
 {
-    GSH_HIP(hipEventRecord(s->pushed, st));
-    const int slot = s->push_count % gsh_stream::HIST;
-    if (s->push_ev[slot] == nullptr) GSH_HIP(hipEventCreateWithFlags(&s->push_ev[slot], hipEventDisableTiming));
-    GSH_HIP(hipEventRecord(s->push_ev[slot], st));
-    s->push_end[slot] = end_index;
-    s->push_count++;
+    {
+        // ONE event per push (every driver call here is ~6 us on the thread that appends, and the blocks of a stream wait for it): the history entry; `pushed`
+        // -- "the latest push" -- is whichever entry was recorded last
+        std::lock_guard<std::mutex> lk(s->hist_mutex);
+        const int slot = s->push_count % gsh_stream::HIST;
+        if (s->push_ev[slot] == nullptr) GSH_HIP(hipEventCreateWithFlags(&s->push_ev[slot], hipEventDisableTiming));
+        GSH_HIP(hipEventRecord(s->push_ev[slot], st));
+        s->push_end[slot] = end_index;
+        s->push_count++;
+        s->pushed = s->push_ev[slot];
+    }
     return gsh::stream_publish_live(s, end_index, st);
 }
 }  // namespace
@@ -250,12 +255,13 @@ extern "C"
             // never end up in a queue BEHIND a resident live loop (normal / low priority) that is waiting for that very push (tracking_loop.hip, live mode).
             int least = 0, greatest = 0;
             if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
-            if ((e = hipStreamCreateWithPriority(&s->stream, hipStreamNonBlocking, greatest)) != hipSuccess) return fail(e, "hipStreamCreate");
+            int prio = greatest;
+            if (const char* pe = std::getenv("GSH_STREAM_PRIORITY")) prio = std::min(std::max(std::atoi(pe), greatest), least);  // (A/B runs)
+            if ((e = hipStreamCreateWithPriority(&s->stream, hipStreamNonBlocking, prio)) != hipSuccess) return fail(e, "hipStreamCreate");
         }
         const size_t total = static_cast<size_t>(s->capacity + s->max_window + 2);
         if ((e = hipMalloc(&s->d_ring, sizeof(float2) * total)) != hipSuccess) return fail(e, "hipMalloc(ring)");
         if ((e = hipMemset(s->d_ring, 0, sizeof(float2) * total)) != hipSuccess) return fail(e, "hipMemset(ring)");
-        if ((e = hipEventCreateWithFlags(&s->pushed, hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
         *out = s;
         return GSH_OK;
     }
@@ -275,9 +281,7 @@ extern "C"
                 if (s->d_raw2[i]) (void)hipFree(s->d_raw2[i]);
                 if (s->raw2_done[i]) (void)hipEventDestroy(s->raw2_done[i]);
             }
-        if (s->pushed) (void)hipEventDestroy(s->pushed);
         if (s->read_fold) (void)hipEventDestroy(s->read_fold);
-        if (s->copied) (void)hipEventDestroy(s->copied);
         for (int i = 0; i < gsh_stream::NSTAGE; i++)
             {
                 if (s->stage_done[i]) (void)hipEventDestroy(s->stage_done[i]);
@@ -435,8 +439,36 @@ extern "C"
     int gsh_stream_wait_copied(gsh_stream_t* s)
     {
         GSH_REQUIRE(s != nullptr, "null stream");
-        if (s->copied == nullptr) return GSH_OK;  // nothing has been queued through the pinned path yet
-        GSH_HIP(hipEventSynchronize(s->copied));  // (no hipSetDevice: an event knows its device)
+        hipEvent_t ev;
+        {
+            std::lock_guard<std::mutex> lk(s->hist_mutex);
+            ev = s->pushed;
+        }
+        if (ev == nullptr) return GSH_OK;    // nothing has been queued yet
+        GSH_HIP(hipEventSynchronize(ev));    // the latest push has reached the ring: every DMA out of the callers' memory lies before that (no hipSetDevice: an event knows its device)
+        return GSH_OK;
+    }
+
+    int gsh_stream_wait_copied_upto(gsh_stream_t* s, uint64_t end_index, uint64_t* complete_upto)
+    {
+        GSH_REQUIRE(s != nullptr, "null stream");
+        hipEvent_t ev = nullptr;
+        unsigned long long covered = 0;
+        {
+            // the oldest recorded push that reaches end_index (ends grow with the push count); pushes that have dropped out of the history were queued
+            // before every one in it on streams that complete in order for this purpose: the oldest entry stands for them
+            std::lock_guard<std::mutex> lk(s->hist_mutex);
+            const int n = s->push_count < gsh_stream::HIST ? s->push_count : gsh_stream::HIST;
+            for (int k = n; k >= 1; k--)
+                {
+                    const int slot = (s->push_count - k) % gsh_stream::HIST;
+                    ev = s->push_ev[slot];
+                    covered = s->push_end[slot];
+                    if (s->push_end[slot] >= end_index) break;
+                }
+        }
+        if (ev != nullptr) GSH_HIP(hipEventSynchronize(ev));  // (an event that has been re-recorded for a later push meanwhile only makes the wait longer)
+        if (complete_upto != nullptr) *complete_upto = covered;
         return GSH_OK;
     }
 
@@ -461,8 +493,7 @@ extern "C"
         if (item_type == GSH_ITEM_GR_COMPLEX && !inverted_spectrum && stream_direct_dma())
             {
                 // items that are the ring's own format: the DMA's destination is the ring (profiles/ab/r03/dropin_direct_dma.txt)
-                if (s->copied == nullptr) GSH_HIP(hipEventCreateWithFlags(&s->copied, hipEventDisableTiming));
-                int rc = write_items(s, items, n, item_type, 0, s->stream, true, s->copied);
+                int rc = write_items(s, items, n, item_type, 0, s->stream, true, nullptr);
                 if (rc != GSH_OK) return rc;
                 rc = record_push(s, s->next + n, s->stream);
                 if (rc != GSH_OK) return rc;
@@ -476,7 +507,6 @@ extern "C"
             GSH_HIP(hipEventCreateWithFlags(&s->stage_done[slot], hipEventDisableTiming));
         else
             GSH_HIP(hipEventSynchronize(s->stage_done[slot]));  // the conversion that read this device buffer four pushes ago
-        if (s->copied == nullptr) GSH_HIP(hipEventCreateWithFlags(&s->copied, hipEventDisableTiming));
         if (bytes > s->stage_cap[slot])
             {
                 if (s->h_stage[slot]) GSH_HIP(release_buffer(s, s->h_stage[slot], true));
@@ -490,7 +520,6 @@ extern "C"
                 s->stage_cap[slot] = cap;
             }
         GSH_HIP(hipMemcpyAsync(s->d_stage[slot], items, bytes, hipMemcpyHostToDevice, s->stream));
-        GSH_HIP(hipEventRecord(s->copied, s->stream));
         int rc = write_items(s, s->d_stage[slot], n, item_type, inverted_spectrum ? 1 : 0, s->stream);
         if (rc != GSH_OK) return rc;
         GSH_HIP(hipEventRecord(s->stage_done[slot], s->stream));
@@ -537,7 +566,10 @@ extern "C"
         s->has_fold = false;
         s->next = next_index;
         s->origin = next_index;  // nothing older is resident
-        s->push_count = 0;
+        {
+            std::lock_guard<std::mutex> lk(s->hist_mutex);
+            s->push_count = 0;
+        }
         s->read_count = 0;
         if (s->d_live != nullptr)
             {

@@ -661,6 +661,7 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                 {
                     // the channel's record count lives in the host's tail (this kernel is its only writer): residencies hand it on through there
                     lv.seq = __hip_atomic_load(&a.live.tail[ch].seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(&a.live.tail[ch].exit_reason, static_cast<int>(LIVE_EXIT_NONE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // resident (the host looks)
                     lv.exit_reason = LIVE_EXIT_NONE;
                     lv.t_start = wall_clock64();
                     lv.now = lv.t_start;
@@ -1374,7 +1375,7 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
             if constexpr (LIVE)
                 {
                     LiveTail* th = a.live.tail + ch;  // (pos, active and seq went out in the drain round that ended the loop)
-                    th->exit_reason = lv.exit_reason;
+                    __hip_atomic_store(&th->exit_reason, lv.exit_reason, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // no longer resident
                 }
             else
                 {
@@ -1539,6 +1540,7 @@ struct gsh_trk
     bool live_busy[2]{false, false};                // a residency has been queued and its event has not been seen complete yet
     unsigned live_idle_us{200}, live_residency_us{5000};
     std::shared_ptr<gsh::LiveFloor> live_floor;     // registered with the ring: pushes keep off what the channels still read
+    std::atomic<bool> live_ready{false};            // live_setup has run: what gsh_trk_live_take (any thread) reads is in place
 };
 
 namespace
@@ -1726,7 +1728,9 @@ int live_setup(gsh_trk* t)
         {
             int least = 0, greatest = 0;
             if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
-            if ((e = hipStreamCreateWithPriority(&t->live_stream, hipStreamNonBlocking, least)) != hipSuccess)
+            int prio = least;
+            if (const char* pe = std::getenv("GSH_TRK_LIVE_PRIORITY")) prio = std::min(std::max(std::atoi(pe), greatest), least);  // (A/B runs)
+            if ((e = hipStreamCreateWithPriority(&t->live_stream, hipStreamNonBlocking, prio)) != hipSuccess)
                 {
                     undo();
                     return gsh::hip_fail(e, "hipStreamCreateWithPriority(live)", __FILE__, __LINE__);
@@ -1746,7 +1750,7 @@ int live_setup(gsh_trk* t)
             tails[ch].pos = t->h_chan[ch].pos;
             tails[ch].seq = 0ull;
             tails[ch].active = t->h_chan[ch].active;
-            tails[ch].exit_reason = gsh::LIVE_EXIT_NONE;
+            tails[ch].exit_reason = gsh::LIVE_EXIT_IDLE;  // (no work-group is resident for the channel)
             consumed[ch] = 0ull;
             t->live_next_window[ch] = t->h_chan[ch].pos;
         }
@@ -1759,6 +1763,7 @@ int live_setup(gsh_trk* t)
     t->live_floor->tails = tails;
     t->live_floor->n = t->n_channels;
     t->ring->live_floors.push_back(t->live_floor);
+    t->live_ready.store(true, std::memory_order_release);
     return GSH_OK;
 }
 
@@ -1946,6 +1951,7 @@ extern "C"
                 (void)hipHostFree(t->h_live_consumed);
                 (void)hipHostFree(t->h_live_quit);
                 (void)hipHostFree(t->h_live_records);
+                t->live_ready.store(false, std::memory_order_release);
                 t->h_live_tail = nullptr;
                 t->h_live_consumed = nullptr;
                 t->h_live_quit = nullptr;
@@ -2053,7 +2059,7 @@ extern "C"
             {
                 t->h_live_tail[channel].pos = s.pos;
                 t->h_live_tail[channel].active = 1;
-                t->h_live_tail[channel].exit_reason = gsh::LIVE_EXIT_NONE;
+                t->h_live_tail[channel].exit_reason = gsh::LIVE_EXIT_IDLE;
                 __atomic_store_n(&t->h_live_consumed[channel], t->h_live_tail[channel].seq, __ATOMIC_RELEASE);  // records of the previous run that nobody took are dropped
                 t->live_next_window[static_cast<size_t>(channel)] = s.pos;
             }
@@ -2275,13 +2281,21 @@ extern "C"
     }
 
     int gsh_trk_live_take(gsh_trk_t* t, int channel, uint64_t limit_end, int max_records, gsh_trk_epoch* out, int32_t* n_out, int32_t* pending,
-        uint64_t* next_window, int32_t* active)
+        uint64_t* next_window, int32_t* active, int32_t* resident)
     {
         GSH_REQUIRE(t != nullptr && n_out != nullptr, "null argument");
         GSH_REQUIRE(channel >= 0 && channel < t->n_channels, "channel %d outside 0..%d", channel, t->n_channels - 1);
         GSH_REQUIRE(max_records == 0 || out != nullptr, "null record buffer");
         *n_out = 0;
-        if (t->h_live_tail == nullptr) return set_error(GSH_ERR_STATE, "gsh_trk_live_take before the first gsh_trk_live_begin");
+        if (!t->live_ready.load(std::memory_order_acquire))
+            {
+                // no residency has ever been queued: nothing is finished; the channel stands where start / the last launch left it
+                if (pending != nullptr) *pending = 0;
+                if (next_window != nullptr) *next_window = t->h_chan[channel].pos;
+                if (active != nullptr) *active = t->h_chan[channel].active;
+                if (resident != nullptr) *resident = 0;
+                return GSH_OK;
+            }
         // No lock, no device call: the channel's tail and record ring are memory the kernel writes and this thread reads.  seq is stored by the device after
         // the records below it have left it (tracking_loop.hip, the drain rule); the loads here follow in program order.
         const volatile gsh::LiveTail* tail = t->h_live_tail + channel;
@@ -2314,6 +2328,7 @@ extern "C"
         if (pending != nullptr) *pending = static_cast<int32_t>(std::min<unsigned long long>(seq - consumed, 0x7fffffffull));
         if (next_window != nullptr) *next_window = nw;
         if (active != nullptr) *active = tail->active;
+        if (resident != nullptr) *resident = (tail->exit_reason == gsh::LIVE_EXIT_NONE) ? 1 : 0;
         return GSH_OK;
     }
 

@@ -31,14 +31,21 @@
 
 namespace
 {
-// Channels that name the same <role>.hip_shared_ring id on the same device share one Hip_Tracking_Runtime and, through it, one device sample ring:
-// the stream crosses PCIe once for all of them and ONE launch advances all of them (hip_tracking_runtime.h).  id < 0: a runtime (and ring) of
-// the block's own.  The ring is sized by time, not by the first joiner's code period, so that signals with different periods on the same RF
-// stream (L1 C/A 1 ms, E1 4 ms, L2C 20 ms) fit: 256 ms resident, windows of up to 40 ms contiguous; never less than 64 / 2 of the joiner's periods.
-std::shared_ptr<Hip_Tracking_Runtime> runtime_for(int device, int id, const Dll_Pll_Conf& p, int periods_per_launch, bool register_input, int channels_per_launch)
+// Which blocks share one Hip_Tracking_Runtime and, through it, one device sample ring -- the stream then crosses PCIe once for all of them and one resident
+// loop kernel (or one launch) advances all of them (hip_tracking_runtime.h):
+//   <role>.hip_shared_ring  absent / -2  every block of this role (= signal class: "Tracking_1C", ...) on this device: the reference's channels of one signal
+//                                        read one buffer (gnss_flowgraph.cc:1227-1231), so this is the default
+//                           >= 0         every block on this device that names the same id, whatever its role (signals of one RF stream: L1 C/A + E1)
+//                           -1           a runtime (and ring) of the block's own.  Needed when blocks of one role are fed from DIFFERENT streams (receivers
+//                                        with several RF chains per signal): the ring de-duplicates pushes by absolute sample index, which only holds for
+//                                        blocks that see the same stream.
+// The ring is sized by time, not by the first joiner's code period, so that signals with different periods on the same RF stream (L1 C/A 1 ms, E1 4 ms,
+// L2C 20 ms) fit: 256 ms resident, windows of up to 40 ms contiguous; never less than 64 / 2 of the joiner's periods.
+std::shared_ptr<Hip_Tracking_Runtime> runtime_for(int device, int id, const std::string& role, const Dll_Pll_Conf& p, int periods_per_launch, bool register_input,
+    int channels_per_launch, bool live)
 {
     static std::mutex mu;
-    static std::map<std::pair<int, int>, std::weak_ptr<Hip_Tracking_Runtime>> runtimes;
+    static std::map<std::pair<int, std::string>, std::weak_ptr<Hip_Tracking_Runtime>> runtimes;
     const uint64_t vlen = std::max<uint32_t>(p.vector_length, 1U);
     auto make = [&](uint64_t capacity, uint64_t window) -> std::shared_ptr<Hip_Tracking_Runtime> {
         auto ring = std::make_shared<Hip_Sample_Ring>(device, capacity, static_cast<uint32_t>(window));
@@ -48,11 +55,11 @@ std::shared_ptr<Hip_Tracking_Runtime> runtime_for(int device, int id, const Dll_
                 return nullptr;
             }
         ring->set_auto_register(register_input);
-        return std::make_shared<Hip_Tracking_Runtime>(device, std::move(ring), periods_per_launch, id < 0 ? 1 : channels_per_launch);
+        return std::make_shared<Hip_Tracking_Runtime>(device, std::move(ring), periods_per_launch, id == -1 ? 1 : channels_per_launch, live);
     };
-    if (id < 0) return make(std::max<uint64_t>(16, 4ULL * (static_cast<uint64_t>(periods_per_launch) + 2)) * vlen, 2 * vlen);
+    if (id == -1) return make(std::max<uint64_t>(16, 4ULL * (static_cast<uint64_t>(periods_per_launch) + 2)) * vlen, 2 * vlen);
     std::lock_guard<std::mutex> lk(mu);
-    auto& slot = runtimes[{device, id}];
+    auto& slot = runtimes[{device, id >= 0 ? "id:" + std::to_string(id) : "role:" + role}];
     auto rt = slot.lock();
     if (!rt)
         {
@@ -91,8 +98,13 @@ DllPllTrackingHip::DllPllTrackingHip(const ConfigurationInterface* configuration
 void DllPllTrackingHip::create_tracking_block(const ConfigurationInterface* configuration)
 {
     const int device = configuration->property(role_ + ".hip_device", 0);
+    // code periods one general_work call may consume and emit when its input covers them: 1 is the reference's cadence (trk.cc:1898-2001: one period, then
+    // back to the scheduler); larger values save scheduler round trips when the receiver post-processes a file faster than real time (the runtime's throughput
+    // at 1 / 20: bench.py -> dropin).  The device works ahead of the blocks either way -- this key only sets how much a block takes per call.
     const int periods = configuration->property(role_ + ".hip_periods_per_call", 1);
-    const int ring_id = configuration->property(role_ + ".hip_shared_ring", -1);
+    const int ring_id = configuration->property(role_ + ".hip_shared_ring", -2);
+    // the loop kernel stays resident and follows the ring (hip_tracking_runtime.h, "LIVE mode"); false: one launch per batch of periods, as in round 3
+    const bool live = configuration->property(role_ + ".hip_live", true);
     const int per_launch = configuration->property(role_ + ".hip_periods_per_launch", std::max(16, periods));
     if (trk_params_.item_type != "gr_complex")  // as the reference adapters: item_size 0 tells the factory the block is unusable
         {
@@ -113,7 +125,7 @@ void DllPllTrackingHip::create_tracking_block(const ConfigurationInterface* conf
     // most channels of one loop configuration that share a launch (one work-group each; a further handle is opened beyond that).  Every launch brings the
     // records of all the handle's slots back, so the default stays at what BASELINE's configurations put on one GPU (32 - 50 channels per stream)
     const int per_handle = configuration->property(role_ + ".hip_channels_per_launch", 64);
-    auto runtime = runtime_for(device, ring_id, trk_params_, per_launch, register_input, per_handle);
+    auto runtime = runtime_for(device, ring_id, role_, trk_params_, per_launch, register_input, per_handle, live);
     if (!runtime)
         {
             item_size_ = 0;

@@ -360,6 +360,15 @@ void dll_pll_veml_tracking_hip::fill_symbol(Gnss_Synchro* out, const gsh_trk_epo
 }
 
 
+// consume_each, after making sure that what goes back to the scheduler is no longer being read by a DMA this block (or a sibling on the same buffer) queued:
+// push() does not wait for its copies -- the look-ahead a block is offered beyond what it consumes stays valid, and is copied while the blocks work
+void dll_pll_veml_tracking_hip::give_back(int n_items)
+{
+    if (d_usable && n_items > 0 && d_runtime) (void)d_runtime->release_input(this->nitems_read(0) + static_cast<uint64_t>(n_items));
+    consume_each(n_items);
+}
+
+
 // an engine failure: the channel goes back to acquisition the reference's way ("events" 3), the block to standby
 void dll_pll_veml_tracking_hip::drop_channel(int ninput)
 {
@@ -367,7 +376,7 @@ void dll_pll_veml_tracking_hip::drop_channel(int ninput)
     d_state = 0;
     if (d_slot >= 0) d_runtime->stop(d_slot);
     this->message_port_pub(pmt::mp("events"), pmt::from_long(3));
-    consume_each(ninput);
+    give_back(ninput);
 }
 
 
@@ -389,7 +398,7 @@ int dll_pll_veml_tracking_hip::general_work(int noutput_items, gr_vector_int& ni
     switch (d_state)
         {
         case 0:  // standby: consume at full throttle (trk.cc:1941-1947)
-            consume_each(ninput_items[0]);
+            give_back(ninput_items[0]);
             return 0;
         case 1:  // pull-in: skip samples until the incoming signal is aligned with the local replica (trk.cc:1949-1978)
             {
@@ -405,7 +414,7 @@ int dll_pll_veml_tracking_hip::general_work(int noutput_items, gr_vector_int& ni
                 d_current_prn_length_samples = first_len;  // trk.cc:1964
                 d_loop_fields = gsh_trk_epoch{};
                 d_state = 2;
-                consume_each(samples_offset);
+                give_back(samples_offset);
                 return 0;
             }
         default:
@@ -426,7 +435,7 @@ int dll_pll_veml_tracking_hip::general_work(int noutput_items, gr_vector_int& ni
             uint32_t wn = 0;
             estimate_tow(read_pos, d_current_prn_length_samples, &tow_ms, &wn);
             fill_symbol(&out[0], r, true, tow_ms);
-            consume_each(d_current_prn_length_samples);
+            give_back(d_current_prn_length_samples);
             return 1;
         }
     if (!pushed)
@@ -475,6 +484,6 @@ int dll_pll_veml_tracking_hip::general_work(int noutput_items, gr_vector_int& ni
                 }
         }
     flush_dump();
-    consume_each(static_cast<int>(consumed));
+    give_back(static_cast<int>(consumed));
     return produced;
 }

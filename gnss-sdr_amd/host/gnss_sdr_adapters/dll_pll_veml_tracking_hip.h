@@ -87,6 +87,7 @@ private:
     void dump_record(const gsh_trk_epoch& r, uint64_t tow_ms, uint32_t wn);
     void flush_dump();
     void drop_channel(int ninput);
+    void give_back(int n_items);
 
     Dll_Pll_Conf d_trk_parameters;
     gsh_trk_conf d_conf{};

@@ -93,7 +93,7 @@ uint64_t Hip_Sample_Ring::push_items(const void* items, uint64_t n, int item_typ
 
 
 bool Hip_Sample_Ring::push_from(uint64_t first_index, const std::complex<float>* samples, uint64_t n, bool may_seek, std::chrono::milliseconds gap_timeout,
-    uint64_t* appended, uint64_t* append_ns)
+    uint64_t* appended, uint64_t* append_ns, bool wait_copy, bool try_only)
 {
     if (appended != nullptr) *appended = 0;
     if (append_ns != nullptr) *append_ns = 0;
@@ -102,7 +102,13 @@ bool Hip_Sample_Ring::push_from(uint64_t first_index, const std::complex<float>*
     bool dma_queued = false;
     const auto t_begin = std::chrono::steady_clock::now();
     {
-        std::unique_lock<std::mutex> lk(d_mutex);
+        std::unique_lock<std::mutex> lk(d_mutex, std::defer_lock);
+        if (try_only)
+            {
+                if (!lk.try_lock()) return true;
+            }
+        else
+            lk.lock();
         uint64_t oldest = 0, next = 0;
         (void)gsh_stream_range(d_handle, &oldest, &next);
         if (first_index + n <= next) return true;  // somebody (another channel of the stream, an earlier call) has pushed them
@@ -209,7 +215,7 @@ bool Hip_Sample_Ring::push_from(uint64_t first_index, const std::complex<float>*
     // The caller gets its buffer back when the DMA engine has read it.  The ring's lock is free meanwhile: a launch that reads the ring can be
     // queued (it waits for the push on the device, not here) and the siblings' index comparisons go through.
     bool ok_wait = true;
-    if (dma_queued && gsh_stream_wait_copied(d_handle) != GSH_OK)
+    if (dma_queued && wait_copy && gsh_stream_wait_copied(d_handle) != GSH_OK)
         {
             std::lock_guard<std::mutex> lk(d_mutex);
             d_error = gsh_last_error();
@@ -217,6 +223,25 @@ bool Hip_Sample_Ring::push_from(uint64_t first_index, const std::complex<float>*
         }
     if (append_ns != nullptr) *append_ns = static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_begin).count());
     return ok_wait;
+}
+
+
+bool Hip_Sample_Ring::wait_copied_upto(uint64_t end)
+{
+    if (d_handle == nullptr) return false;
+    if (end <= d_copied_upto.load(std::memory_order_acquire)) return true;  // the usual case: copied long ago
+    if (end > d_next.load(std::memory_order_acquire)) end = d_next.load(std::memory_order_acquire);  // what has not been pushed has not been handed to the DMA engine either
+    uint64_t upto = 0;
+    if (gsh_stream_wait_copied_upto(d_handle, end, &upto) != GSH_OK)
+        {
+            std::lock_guard<std::mutex> lk(d_mutex);
+            d_error = gsh_last_error();
+            return false;
+        }
+    upto = std::max(upto, end);
+    uint64_t seen = d_copied_upto.load(std::memory_order_relaxed);
+    while (seen < upto && !d_copied_upto.compare_exchange_weak(seen, upto, std::memory_order_release)) {}
+    return true;
 }
 
 

@@ -59,7 +59,12 @@ public:
         what is resident, and otherwise waits up to `gap_timeout` for the siblings to close the gap (0: does not wait and pushes nothing --
         the siblings' own pushes will cover the stretch).  Returns false on a gap that stays open or on an engine error (last_error()). */
     bool push_from(uint64_t first_index, const std::complex<float>* samples, uint64_t n, bool may_seek,
-        std::chrono::milliseconds gap_timeout = std::chrono::milliseconds(200), uint64_t* appended = nullptr, uint64_t* append_ns = nullptr);
+        std::chrono::milliseconds gap_timeout = std::chrono::milliseconds(200), uint64_t* appended = nullptr, uint64_t* append_ns = nullptr, bool wait_copy = true,
+        bool try_only = false);  //!< try_only: when another thread holds the ring (it is appending, most likely the same samples), return at once without appending
+    /*! For a caller of push_from(..., wait_copy = false): returns when every sample below `end` that was pushed by DMA out of the caller's own memory has
+        been read from it -- the caller may hand that part of its buffer back.  A GNU Radio block gives back only what it consumes; what it was OFFERED beyond
+        that (and pushed ahead) stays valid, so its copy need not be waited for in the call that queued it. */
+    bool wait_copied_upto(uint64_t end);
     /*! Page-lock [ptr, ptr + bytes) (rounded outwards to pages; parts already locked are skipped) so that push_from can hand it to the DMA
         engine without a staging copy.  A GNU Radio input buffer is the same memory for the whole run: after the first few calls every push is
         a true DMA.  false (and push_from falls back to the staging copy) when the range cannot be registered. */
@@ -100,6 +105,7 @@ private:
     mutable std::condition_variable d_pushed;
     std::atomic<uint64_t> d_next{0};  // read without the lock on the fast path of wait_for (32 channel threads ask at the same instant)
     std::atomic<uint64_t> d_origin{0};  // first index resident since the last seek
+    std::atomic<uint64_t> d_copied_upto{0};  // samples below this index are known to have left the callers' buffers
     // page-locked host ranges: one entry per registration, sorted and disjoint (a DMA must lie inside ONE registration), and what the destructor releases
     uintptr_t piece_end_locked(uintptr_t at) const;
     bool register_locked(uintptr_t a, uintptr_t b);

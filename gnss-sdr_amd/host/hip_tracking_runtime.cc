@@ -4,16 +4,35 @@
  */
 #include "hip_tracking_runtime.h"
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 
-Hip_Tracking_Runtime::Hip_Tracking_Runtime(int device, std::shared_ptr<Hip_Sample_Ring> ring, int periods_per_launch, int channels_per_group)
+namespace
+{
+constexpr size_t MAX_SLOTS = 4096;  // d_slots is reserved for this many once: readers without the lock (push) never see it move
+int64_t now_ns()
+{
+    return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+}  // namespace
+
+
+Hip_Tracking_Runtime::Hip_Tracking_Runtime(int device, std::shared_ptr<Hip_Sample_Ring> ring, int periods_per_launch, int channels_per_group, bool live)
     : d_device(device),
       d_ring(std::move(ring)),
       d_periods_per_launch(std::min(std::max(periods_per_launch, 1), 256)),
-      d_channels_per_group(std::min(std::max(channels_per_group, 1), 4096))
+      d_channels_per_group(std::min(std::max(channels_per_group, 1), 4096)),
+      d_live(live)
 {
     if (const char* e = std::getenv("GSH_TRK_LAUNCH_AHEAD")) d_launch_ahead = (std::atoi(e) != 0);
+    if (const char* e = std::getenv("GSH_TRK_LIVE")) d_live = (std::atoi(e) != 0);
+    if (const char* e = std::getenv("GSH_TRK_LIVE_SPIN_US")) d_spin_us = std::max(0, std::atoi(e));
+    if (const char* e = std::getenv("GSH_TRK_PUSH_TRY")) d_push_try = (std::atoi(e) != 0);
+    if (const char* e = std::getenv("GSH_TRK_PUSH_BATCH")) d_push_batch = std::max(1, std::atoi(e));
+    if (const char* e = std::getenv("GSH_TRK_PUSH_SPARE_SLOWEST")) d_push_spare_slowest = (std::atoi(e) != 0);
+    d_slots.reserve(MAX_SLOTS);
 }
 
 
@@ -74,9 +93,28 @@ int Hip_Tracking_Runtime::attach(const gsh_trk_conf& conf, int max_code_length)
     if (g == nullptr) return -1;
     size_t s = 0;
     while (s < d_slots.size() && d_slots[s]->used) s++;
-    if (s == d_slots.size()) d_slots.push_back(std::make_unique<Slot>());
+    if (s == d_slots.size())
+        {
+            if (d_slots.size() >= MAX_SLOTS)
+                {
+                    d_error = "more than " + std::to_string(MAX_SLOTS) + " tracking blocks on one runtime";
+                    return -1;
+                }
+            d_slots.push_back(std::make_unique<Slot>());
+            d_n_slots.store(d_slots.size(), std::memory_order_release);
+        }
+    {
+        uint64_t v = d_min_vlen.load(std::memory_order_relaxed);
+        if (v == 0 || conf.vector_length < v) d_min_vlen.store(conf.vector_length, std::memory_order_relaxed);
+    }
     Slot& S = *d_slots[s];
-    S = Slot{};
+    S.tracking = false;
+    S.live_tracking.store(false, std::memory_order_release);
+    S.live_next_window.store(0, std::memory_order_release);
+    S.generation++;
+    S.next_window = 0;
+    S.queue.clear();
+    S.error.clear();
     S.group = g;
     S.channel = channel;
     S.used = true;
@@ -93,6 +131,7 @@ void Hip_Tracking_Runtime::detach(int slot)
     Slot& S = *d_slots[slot];
     S.group->slot_of_channel[static_cast<size_t>(S.channel)] = -1;
     S.used = false;
+    S.live_tracking.store(false, std::memory_order_release);
     S.generation++;
     d_lowest_next_window.store(lowest_next_window_locked(), std::memory_order_release);
 }
@@ -114,6 +153,8 @@ bool Hip_Tracking_Runtime::start(int slot, const float* code, const float* data_
     // never the device running a channel whose slot does not know yet.
     std::lock_guard<std::mutex> hl(g->handle_mutex);  // waits for a launch of the group that is in flight
     if (g->begun) (void)end_and_file(g, nullptr);       // ... and one queued ahead comes in first: its records belong to the channels as they were
+    if (d_live) quiesce_live(g);                        // residencies leave (the other channels' records stay in their rings; the next take brings a residency back)
+    std::lock_guard<std::mutex> tl(d_slots[slot]->take_mutex);  // the block's own thread is not in the middle of a take of the old channel state
     int32_t offset = 0, first_len = 0;
     double acc0 = 0.0;
     std::string err;
@@ -129,6 +170,8 @@ bool Hip_Tracking_Runtime::start(int slot, const float* code, const float* data_
     S.error = err;
     S.tracking = err.empty();
     if (err.empty()) S.next_window = start_sample;
+    S.live_next_window.store(start_sample, std::memory_order_release);
+    S.live_tracking.store(err.empty(), std::memory_order_release);
     d_lowest_next_window.store(lowest_next_window_locked(), std::memory_order_release);
     if (!err.empty()) return false;
     if (samples_offset != nullptr) *samples_offset = offset;
@@ -149,6 +192,7 @@ void Hip_Tracking_Runtime::stop(int slot)
             {
                 S.generation++;
                 S.queue.clear();
+                S.live_tracking.store(false, std::memory_order_release);
                 return;
             }
         g = S.group;
@@ -156,10 +200,13 @@ void Hip_Tracking_Runtime::stop(int slot)
     }
     std::lock_guard<std::mutex> hl(g->handle_mutex);  // as in start(): device state and slot change together, between two launches
     if (g->begun) (void)end_and_file(g, nullptr);
+    if (d_live) quiesce_live(g);
+    std::lock_guard<std::mutex> tl(d_slots[slot]->take_mutex);
     (void)gsh_trk_stop(g->trk, channel);
     std::lock_guard<std::mutex> lk(d_mutex);
     Slot& S = *d_slots[slot];
     S.tracking = false;
+    S.live_tracking.store(false, std::memory_order_release);
     S.generation++;
     S.queue.clear();
     d_lowest_next_window.store(lowest_next_window_locked(), std::memory_order_release);
@@ -194,9 +241,11 @@ uint64_t Hip_Tracking_Runtime::lowest_next_window_locked() const
 bool Hip_Tracking_Runtime::push(const std::complex<float>* samples, uint64_t first_index, uint64_t n, bool need_resident)
 {
     if (!ok()) return false;
+    if (first_index + n <= d_ring->next_index()) return true;  // somebody (another channel of the stream, an earlier call) has pushed them: all but the front-runner leave here
     // (kept up to date, under d_mutex, wherever a slot's next window or tracking flag changes: every block calls push in every general_work, and a scan of the
-    // slots under the runtime's lock there is one more thing 32 threads queue up for)
-    const uint64_t lowest = d_lowest_next_window.load(std::memory_order_acquire);
+    // slots under the runtime's lock there is one more thing 32 threads queue up for.  Live mode: the blocks' takes move their windows without the lock; the
+    // front-runner -- nobody else gets here -- scans their atomics)
+    const uint64_t lowest = d_live ? lowest_next_window_live() : d_lowest_next_window.load(std::memory_order_acquire);
     // never push so far ahead that the window the slowest channel correlates next would be overwritten
     if (lowest != UINT64_MAX)
         {
@@ -206,8 +255,30 @@ bool Hip_Tracking_Runtime::push(const std::complex<float>* samples, uint64_t fir
         }
     // a ring whose resident samples nobody is going to read may jump to the position of a caller that needs its own samples there
     const bool may_seek = need_resident && ((lowest == UINT64_MAX) || (lowest >= first_index));
+    bool try_only = false;
+    if (d_live && lowest != UINT64_MAX)
+        {
+            // Live mode, channels tracking: appending costs ~20 - 30 us of driver calls however little is appended, and every block of the stream is offered the
+            // same new samples at the same moment.
+            const uint64_t ring_next = d_ring->next_index();
+            const uint64_t vlen = std::max<uint64_t>(d_min_vlen.load(std::memory_order_relaxed), 1);
+            if (ring_next >= first_index)
+                {
+                    const uint64_t pending = first_index + n - ring_next;
+                    const uint64_t runway = ring_next > lowest ? ring_next - lowest : 0;
+                    // (2) a sliver is not worth the driver calls while the device still has periods in hand: the samples are offered again, with more behind them
+                    if (pending < static_cast<uint64_t>(d_push_batch) * vlen && runway >= 3 * vlen) return true;
+                    // (1) a small append by a block that finds the ring busy is left to the thread that is at it; behind a large one (several periods per call) the
+                    // blocks queue up instead -- measured both ways, profiles/ab/r04/dropin_push_ab.txt
+                    try_only = d_push_try && pending < 6 * vlen;
+                    // (3) ... and not by the block that everybody is waiting for: the readers of a shared upstream buffer advance as fast as the slowest of them,
+                    // and the slowest -- whose progress is what makes the scheduler offer new samples -- is the first to see them.  A sibling with periods in
+                    // hand is microseconds behind; the 20 us of driver calls are better spent there.
+                    if (try_only && d_push_spare_slowest && first_index < lowest + 2 * vlen && runway >= 3 * vlen) return true;
+                }
+        }
     uint64_t appended = 0, append_ns = 0;
-    const bool ok_push = d_ring->push_from(first_index, samples, n, may_seek, std::chrono::milliseconds(need_resident ? 200 : 0), &appended, &append_ns);
+    const bool ok_push = d_ring->push_from(first_index, samples, n, may_seek, std::chrono::milliseconds(need_resident ? 200 : 0), &appended, &append_ns, /*wait_copy=*/false, try_only);
     if (appended != 0)
         {
             d_push_ns.fetch_add(append_ns, std::memory_order_relaxed);
@@ -226,6 +297,11 @@ bool Hip_Tracking_Runtime::push(const std::complex<float>* samples, uint64_t fir
 int Hip_Tracking_Runtime::take(int slot, uint64_t limit_end, int max_records, gsh_trk_epoch* out)
 {
     if (max_records <= 0 || out == nullptr) return 0;
+    if (d_live)
+        {
+            if (slot < 0 || slot >= static_cast<int>(d_n_slots.load(std::memory_order_acquire))) return -1;
+            return take_live(*d_slots[slot], limit_end, max_records, out);
+        }
     std::unique_lock<std::mutex> lk(d_mutex);
     if (slot < 0 || slot >= static_cast<int>(d_slots.size()) || !d_slots[slot]->used) return -1;
     Slot& S = *d_slots[slot];
@@ -295,6 +371,179 @@ int Hip_Tracking_Runtime::take(int slot, uint64_t limit_end, int max_records, gs
             g->in_flight = false;
             g->filed.notify_all();  // (those that found the group busy meanwhile)
             if (!failed && filed == 0 && S.queue.empty() && S.error.empty()) return 0;  // the device found nothing to do: do not spin on it
+        }
+}
+
+
+// ------------------------------------------------------------------------------------------------ live mode
+uint64_t Hip_Tracking_Runtime::lowest_next_window_live() const
+{
+    uint64_t lowest = UINT64_MAX;
+    const size_t n = d_n_slots.load(std::memory_order_acquire);
+    for (size_t i = 0; i < n; i++)
+        {
+            const Slot& S = *d_slots[i];
+            if (S.live_tracking.load(std::memory_order_acquire)) lowest = std::min(lowest, S.live_next_window.load(std::memory_order_acquire));
+        }
+    return lowest;
+}
+
+
+// handle_mutex held
+void Hip_Tracking_Runtime::quiesce_live(Group* g)
+{
+    if (gsh_trk_live_quiesce(g->trk) != GSH_OK)
+        {
+            std::lock_guard<std::mutex> lk(d_mutex);
+            d_error = std::string("gsh_trk_live_quiesce: ") + gsh_last_error();
+        }
+}
+
+
+// A block has work resident and no record: up to two residencies of the group's loop are kept queued (the second takes over when the first has used up
+// its time on the device).  Whoever gets the handle does it; everybody else -- and anybody who comes while start / stop hold the handle -- just goes on polling.
+void Hip_Tracking_Runtime::ensure_live(Group* g, bool wait_for_handle)
+{
+    std::unique_lock<std::mutex> hl(g->handle_mutex, std::defer_lock);
+    if (wait_for_handle)
+        hl.lock();
+    else if (!hl.try_lock())
+        return;
+    if (g->live_failed) return;
+    int32_t n = 0;
+    std::string err;
+    if (gsh_trk_live_in_flight(g->trk, &n) != GSH_OK) err = std::string("gsh_trk_live_in_flight: ") + gsh_last_error();
+    uint32_t begun = 0;
+    while (err.empty() && n < 2)
+        {
+            // the ring's lock: the first residency registers the group with the ring (what pushes must keep off, the ring's live words), and pushes read that list
+            std::lock_guard<std::mutex> rl(d_ring->mutex());
+            if (gsh_trk_live_begin(g->trk) != GSH_OK)
+                err = std::string("gsh_trk_live_begin: ") + gsh_last_error();
+            else
+                {
+                    n++;
+                    begun++;
+                }
+        }
+    g->live_checked_ns.store(now_ns(), std::memory_order_release);
+    if (begun != 0)
+        {
+            d_live_residencies.fetch_add(begun, std::memory_order_relaxed);
+            std::lock_guard<std::mutex> lk(d_mutex);
+            uint32_t serving = 0;
+            for (const int sl : g->slot_of_channel)
+                if (sl >= 0 && d_slots[sl]->tracking) serving++;
+            d_stats.channels_served += static_cast<uint64_t>(begun) * serving;  // (a residency serves every channel of the group that is tracking)
+        }
+    if (!err.empty())
+        {
+            g->live_failed = true;
+            std::lock_guard<std::mutex> lk(d_mutex);
+            for (size_t c = 0; c < g->slot_of_channel.size(); c++)
+                {
+                    const int s = g->slot_of_channel[c];
+                    if (s >= 0 && d_slots[s]->tracking) d_slots[s]->error = err;
+                }
+        }
+}
+
+
+int Hip_Tracking_Runtime::take_live(Slot& S, uint64_t limit_end, int max_records, gsh_trk_epoch* out)
+{
+    std::lock_guard<std::mutex> tl(S.take_mutex);  // (uncontended: start / stop of this very channel are the only other takers)
+    Group* g = S.group;
+    if (!S.live_tracking.load(std::memory_order_acquire))
+        {
+            std::lock_guard<std::mutex> lk(d_mutex);
+            return (S.used && S.error.empty()) ? 0 : -1;
+        }
+    const uint64_t vlen = g->conf.vector_length;
+    int64_t t_wait = 0, t_deadline = 0;
+    bool asked_blocking = false;
+    for (;;)
+        {
+            int32_t n = 0, pending = 0, active = 0, resident = 0;
+            uint64_t nw = 0;
+            if (gsh_trk_live_take(g->trk, S.channel, limit_end, max_records, out, &n, &pending, &nw, &active, &resident) != GSH_OK)
+                {
+                    std::lock_guard<std::mutex> lk(d_mutex);
+                    S.error = std::string("gsh_trk_live_take: ") + gsh_last_error();
+                    S.tracking = false;
+                    S.live_tracking.store(false, std::memory_order_release);
+                    return -1;
+                }
+            if (n > 0)
+                {
+                    S.live_next_window.store(nw, std::memory_order_release);
+                    d_live_records.fetch_add(static_cast<uint64_t>(n), std::memory_order_relaxed);
+                    if (t_wait != 0)
+                        {
+                            d_record_wait_ns.fetch_add(static_cast<uint64_t>(now_ns() - t_wait), std::memory_order_relaxed);
+                            d_record_waits.fetch_add(1, std::memory_order_relaxed);
+                        }
+                    if (out[n - 1].flags & 2)  // loss of lock: the device has stopped the channel (trk.cc:2009-2014)
+                        {
+                            std::lock_guard<std::mutex> lk(d_mutex);
+                            S.tracking = false;
+                            S.live_tracking.store(false, std::memory_order_release);
+                        }
+                    return n;
+                }
+            {
+                std::lock_guard<std::mutex> lk(d_mutex);  // (rare path from here on: an error filed by ensure_live, or nothing to hand out)
+                if (!S.error.empty()) return -1;
+            }
+            if (pending > 0) return 0;  // finished periods wait in the ring of records, but the block has not been offered their samples itself yet
+            if (!active)                // the device no longer advances the channel and there is no record left to say why: nothing will come
+                return 0;
+            const uint64_t ring_next = d_ring->next_index();
+            if (nw + vlen > ring_next || nw + vlen > limit_end) return 0;  // the next window is not resident yet (or not the block's to consume)
+            if (nw < d_ring->oldest_index())
+                {
+                    std::lock_guard<std::mutex> lk(d_mutex);
+                    S.error = "the channel's next window [" + std::to_string(nw) + "..) is no longer resident (ring holds [" + std::to_string(d_ring->oldest_index()) + ", " +
+                              std::to_string(ring_next) + "))";
+                    S.tracking = false;
+                    S.live_tracking.store(false, std::memory_order_release);
+                    return -1;
+                }
+            // The window is resident and its record is not there: a residency is working on it, or none is in flight.  Make sure of the latter now and then,
+            // and look again: the device needs ~10 us per period.
+            const int64_t now = now_ns();
+            if (t_wait == 0)
+                {
+                    t_wait = now;
+                    t_deadline = now + 2000000;  // give up after 2 ms (start / stop of another channel hold the residencies off for a moment): the scheduler calls again
+                }
+            // (the channel's tail says whether its work-group is inside a residency right now: while it is, nobody needs to ask the driver -- 32 blocks polling
+            // event states would get in the way of the thread that is appending samples; the look after a millisecond is a safety net only)
+            if ((!resident || now - t_wait > 1000000) && now - g->live_checked_ns.load(std::memory_order_acquire) > 20000)
+                {
+                    const uint64_t before = d_live_residencies.load(std::memory_order_relaxed);
+                    ensure_live(g);
+                    // a residency queued just now -- the group's first sets up its host memory and loads the kernel, milliseconds -- gets its time: a block
+                    // that comes back empty-handed although its samples are resident costs the scheduler a round trip (and call-for-call parity with the
+                    // reference block, which the side-by-side tests hold it to)
+                    if (d_live_residencies.load(std::memory_order_relaxed) != before) t_deadline = now_ns() + 50000000;
+                }
+            if (now >= t_deadline)
+                {
+                    if (!asked_blocking)
+                        {
+                            // nobody could make sure of a residency in all that time: start / stop of another channel hold the group's handle (they quiesce the
+                            // residencies and restart a channel -- milliseconds, more with a slow engine).  Queue behind them this once, then give the device its time.
+                            asked_blocking = true;
+                            ensure_live(g, /*wait_for_handle=*/true);
+                            t_deadline = now_ns() + 50000000;
+                            continue;
+                        }
+                    return 0;  // the scheduler calls again
+                }
+            if (now - t_wait > static_cast<int64_t>(d_spin_us) * 1000)
+                std::this_thread::sleep_for(std::chrono::microseconds(20));
+            else
+                for (int k = 0; k < 64; k++) __builtin_ia32_pause();
         }
 }
 
@@ -411,7 +660,7 @@ uint64_t Hip_Tracking_Runtime::next_window(int slot) const
 {
     std::lock_guard<std::mutex> lk(d_mutex);
     if (slot < 0 || slot >= static_cast<int>(d_slots.size())) return 0;
-    return d_slots[slot]->next_window;
+    return d_live ? d_slots[slot]->live_next_window.load(std::memory_order_acquire) : d_slots[slot]->next_window;
 }
 
 
@@ -429,5 +678,13 @@ Hip_Tracking_Runtime::Stats Hip_Tracking_Runtime::stats() const
     Stats s = d_stats;
     s.push_ns = d_push_ns.load(std::memory_order_relaxed);
     s.pushed_samples = d_pushed_samples.load(std::memory_order_relaxed);
+    if (d_live)
+        {
+            s.residencies = d_live_residencies.load(std::memory_order_relaxed);
+            s.launches += s.residencies;
+            s.channel_periods += d_live_records.load(std::memory_order_relaxed);
+            s.record_wait_ns = d_record_wait_ns.load(std::memory_order_relaxed);
+            s.record_waits = d_record_waits.load(std::memory_order_relaxed);
+        }
     return s;
 }

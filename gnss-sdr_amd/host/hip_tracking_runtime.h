@@ -22,6 +22,12 @@
  *   - launch-ahead: the launcher, having filed a launch, queues the next one at once when at least half as many periods are already resident again,
  *     and returns without waiting for it; the device then works while the blocks consume what was filed, and the block that next runs dry ends and files
  *     the launch (GSH_TRK_LAUNCH_AHEAD=0 in the environment turns this off: one launch, waited for, at a time);
+ *   - LIVE mode (the default; GSH_TRK_LIVE=0 or live = false restores the launches above): the group's loop kernel stays resident
+ *     (gsh_trk_live_begin), learns of new samples from the ring itself and leaves every period's record in a ring of records in page-locked host
+ *     memory; take() then is a read of that memory (gsh_trk_live_take: no lock of the runtime, no device call, no wake-up of anybody), and a
+ *     block that finds its next window resident but no record yet makes sure a residency is in flight and waits for the record (microseconds).
+ *     At the reference's cadence -- one code period per general_work call, trk.cc:1898-2001 -- this is what removes the ~270 us of host time
+ *     around every launch.  start / stop quiesce the group's residencies first (the device side of both needs the loop state at rest);
  *   - start / stop of one channel serialise with the launches of its group and nothing else (a launch queued ahead is ended and filed first).
  *
  * Plain C++17 over the C ABI (include/gnss_sdr_hip.h); no HIP headers, no GNU Radio.  No CPU fallback.
@@ -59,12 +65,16 @@ public:
         uint64_t wakes{0};            //!< ... how many such takes
         uint64_t push_ns{0};          //!< wall time the front-runner blocks spent appending samples (staging copy + queueing), summed
         uint64_t pushed_samples{0};   //!< samples appended (every sample of the stream once, however many channels read it)
+        uint64_t residencies{0};      //!< live mode: residencies of the loop kernel queued (counted in `launches` as well)
+        uint64_t record_wait_ns{0};   //!< live mode: wall time blocks spent waiting for a record whose window was resident, summed
+        uint64_t record_waits{0};     //!< ... how many such waits
     };
 
     /*! ring: the device sample ring the channels read (shared by every block that holds this runtime).
         periods_per_launch: most code periods per channel one launch runs (the launch stops earlier at the newest resident sample).
         channels_per_group: slots of one gsh_trk handle (a further group is opened when they are used up). */
-    Hip_Tracking_Runtime(int device, std::shared_ptr<Hip_Sample_Ring> ring, int periods_per_launch = 16, int channels_per_group = 64);
+    Hip_Tracking_Runtime(int device, std::shared_ptr<Hip_Sample_Ring> ring, int periods_per_launch = 16, int channels_per_group = 64, bool live = true);
+    bool live() const { return d_live; }
     ~Hip_Tracking_Runtime();
     Hip_Tracking_Runtime(const Hip_Tracking_Runtime&) = delete;
     Hip_Tracking_Runtime& operator=(const Hip_Tracking_Runtime&) = delete;
@@ -92,6 +102,10 @@ public:
         anywhere within the ring's capacity behind the front-runner finds its samples resident.  need_resident: the caller is tracking and
         will wait (bounded) for slower siblings to close a gap in front of its samples; a block in standby passes false. */
     bool push(const std::complex<float>* samples, uint64_t first_index, uint64_t n, bool need_resident = true);
+    /*! Before the calling block hands samples below `upto` back to the scheduler (consume_each): those it pushed by DMA out of the scheduler's buffer
+        have left it.  push() itself does not wait for its copies any more -- what a block is offered beyond what it consumes stays valid, and the copy
+        of the look-ahead runs while the blocks work through the periods in front of it. */
+    bool release_input(uint64_t upto) { return d_ring->wait_copied_upto(upto); }
     /*! up to max_records finished periods of the slot's channel, oldest first, whose samples lie below limit_end (sample_counter +
         max(vector_length, prn_length_samples) <= limit_end).  Launches the group's loop when the channel has resident work and nothing is
         in flight; waits while a launch that may produce the slot's records is running.  Returns the number of records (0: the next period's
@@ -120,6 +134,9 @@ private:
         std::vector<uint64_t> begun_generation;  // Slot::generation per channel when the launch was queued
         std::vector<gsh_trk_epoch> records;
         std::vector<int32_t> done;
+        // live mode
+        bool live_failed{false};                  // gsh_trk_live_begin failed once: the group stays with launches (guarded by handle_mutex; read racily as a hint)
+        std::atomic<int64_t> live_checked_ns{0};  // when a block last made sure a residency was in flight (steady_clock)
     };
     struct Slot
     {
@@ -131,9 +148,18 @@ private:
         uint64_t next_window{0};
         std::deque<gsh_trk_epoch> queue;
         std::string error;
+        // live mode: the block's own thread reads records without d_mutex; start / stop (other threads) exclude it through take_mutex.  The two
+        // atomics mirror `tracking` / `next_window` for push(), which scans them without a lock.
+        std::mutex take_mutex;
+        std::atomic<bool> live_tracking{false};
+        std::atomic<uint64_t> live_next_window{0};
     };
     Group* group_for(const gsh_trk_conf& conf, int max_code_length, int* channel);
     // the two halves of a launch; both with the group's handle_mutex held and d_mutex NOT held
+    int take_live(Slot& S, uint64_t limit_end, int max_records, gsh_trk_epoch* out);
+    void ensure_live(Group* g, bool wait_for_handle = false);  // a residency in flight (and one queued behind it) for the group, if nobody else is at it
+    void quiesce_live(Group* g);                       // handle_mutex held
+    uint64_t lowest_next_window_live() const;          // no lock: min over the slots' live_next_window
     int begin_launch(Group* g);                        // how far the resident samples let the group run -> gsh_trk_run_begin; returns the periods queued (0: none)
     uint32_t end_and_file(Group* g, uint64_t* most_resident);  // gsh_trk_run_end -> the blocks' queues; returns the records filed
     uint64_t lowest_next_window_locked() const;
@@ -143,6 +169,14 @@ private:
     int d_periods_per_launch;
     int d_channels_per_group;
     bool d_launch_ahead{true};
+    bool d_live{true};
+    bool d_push_try{true};                 // live mode: a block that finds the ring busy does not queue up behind the thread that is appending
+    bool d_push_spare_slowest{true};
+    int d_push_batch{2};                    // live mode: appends smaller than this many code periods wait for more (while the device has work in hand)
+    int d_spin_us{40};                 // how long a block polls for a record before it starts sleeping between looks
+    std::atomic<uint64_t> d_min_vlen{0};  // shortest code period (samples) among the loop configurations attached so far
+    std::atomic<size_t> d_n_slots{0};  // slots ever created (d_slots never shrinks and is reserved up front: readers without the lock index below this)
+    std::atomic<uint64_t> d_live_records{0}, d_live_residencies{0}, d_record_wait_ns{0}, d_record_waits{0};
     mutable std::mutex d_mutex;  // slots, queues, in_flight flags, stats
     std::vector<std::unique_ptr<Group>> d_groups;
     std::vector<std::unique_ptr<Slot>> d_slots;

@@ -116,7 +116,7 @@ class TrackingLoop:
         rec = (TrkEpoch * max_records)()
         n, pending, active = C.c_int32(0), C.c_int32(0), C.c_int32(0)
         nw = C.c_uint64(0)
-        check(self._lib.gsh_trk_live_take(self._h, channel, C.c_uint64(limit_end), max_records, rec, C.byref(n), C.byref(pending), C.byref(nw), C.byref(active)))
+        check(self._lib.gsh_trk_live_take(self._h, channel, C.c_uint64(limit_end), max_records, rec, C.byref(n), C.byref(pending), C.byref(nw), C.byref(active), None))
         out = []
         for i in range(n.value):  # copies: the ctypes array is reused by nobody, but records outlive it this way
             r = TrkEpoch()

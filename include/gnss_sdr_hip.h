@@ -193,6 +193,10 @@ extern "C"
      * waits outside it, so that launches which read the ring are queued while the DMA runs. */
     int gsh_stream_push_pinned_async(gsh_stream_t* s, const void* items, uint64_t n, int item_type, int inverted_spectrum, uint64_t* first_index);
     int gsh_stream_wait_copied(gsh_stream_t* s);
+    /* ... and for a caller that gets its memory back piece by piece (a GNU Radio block returns input to the scheduler only up to what it consumes): blocks
+     * until every push that covers samples below end_index has been read out of the caller's memory (and has reached the ring); pushes queued behind
+     * those may still be in flight.  *complete_upto (may be NULL): the index up to which the ring is now known to be complete.  Any thread. */
+    int gsh_stream_wait_copied_upto(gsh_stream_t* s, uint64_t end_index, uint64_t* complete_upto);
     /* page-lock / release a range of host memory for DMA (hipHostRegister / hipHostUnregister behind the ABI: host code above it has no HIP headers).
      * The range must be mapped; registering pages twice fails with GSH_ERR_HIP. */
     int gsh_host_register(int device, void* ptr, size_t bytes);
@@ -430,9 +434,10 @@ extern "C"
     /* up to max_records finished periods of one channel, oldest first, whose samples lie below limit_end (sample_counter + max(vector_length,
      * prn_length_samples) <= limit_end; UINT64_MAX: no limit).  A record with flags bit 1 (loss of lock) ends the take and is the channel's last.
      * *pending: records finished and not taken; *next_window: first sample of the window behind the last record taken; *active: the device still
-     * advances the channel. */
+     * advances the channel; *resident: the channel's work-group is inside a running residency right now (0: it has left -- idle, time budget, quit --
+     * or none has started yet: a caller that waits for a record then knows to ask for one, without a device call). */
     int gsh_trk_live_take(gsh_trk_t* t, int channel, uint64_t limit_end, int max_records, gsh_trk_epoch* out, int32_t* n_out, int32_t* pending,
-        uint64_t* next_window, int32_t* active);
+        uint64_t* next_window, int32_t* active, int32_t* resident);
     /* tell the residencies in flight to leave, wait for them; records not yet taken stay where they are.  Needed before start / stop / run. */
     int gsh_trk_live_quiesce(gsh_trk_t* t);
     /* where every channel stands after the last completed run (host copy, refreshed by gsh_trk_run / _run_end and by start / stop):

@@ -16,6 +16,7 @@
 #include <atomic>
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <mutex>
 #include <vector>
 
@@ -38,7 +39,8 @@ std::atomic<int> g_busy_handles{0};  // > 1 concurrent entries into one handle =
 
 struct gsh_stream
 {
-    uint64_t capacity{0}, max_window{0}, next{0}, origin{0};
+    uint64_t capacity{0}, max_window{0};
+    std::atomic<uint64_t> next{0}, origin{0};  // (atomic: live takes read them from the block threads while a push is in progress)
     std::atomic<int> inside{0};
 };
 
@@ -49,6 +51,23 @@ struct FakeChannel
     std::vector<gsh_trk_epoch> all;  // the whole trajectory over the reference stream
     size_t released{0};
     uint64_t pos{0};
+    // live mode: records the "device" has finished and the host has not taken; one block thread at a time per channel (checked)
+    std::deque<gsh_trk_epoch> produced;
+    uint64_t taken_next{0};
+    std::atomic<int> inside{0};
+    FakeChannel() = default;
+    FakeChannel(const FakeChannel& o) : active(o.active), start(o.start), all(o.all), released(o.released), pos(o.pos), produced(o.produced), taken_next(o.taken_next) {}
+    FakeChannel& operator=(const FakeChannel& o)
+    {
+        active = o.active;
+        start = o.start;
+        all = o.all;
+        released = o.released;
+        pos = o.pos;
+        produced = o.produced;
+        taken_next = o.taken_next;
+        return *this;
+    }
 };
 
 struct gsh_trk
@@ -61,6 +80,9 @@ struct gsh_trk
     std::vector<int32_t> pending_done;
     int pending_epochs{-1};
     std::atomic<int> inside{0};
+    // live mode: a "residency" serves a bounded number of records and then ends by itself, so that the runtime's relaunch path is exercised
+    std::atomic<bool> live_ready{false};
+    std::atomic<int> live_left{0};  // records the residency in flight may still produce (0: none in flight)
 };
 
 namespace
@@ -81,8 +103,9 @@ struct Guard  // one thread at a time per handle, as the ABI demands of its call
 
 uint64_t oldest(const gsh_stream* s)
 {
-    const uint64_t by_cap = s->next > s->capacity ? s->next - s->capacity : 0;
-    return std::max(by_cap, s->origin);
+    const uint64_t next = s->next.load(), origin = s->origin.load();
+    const uint64_t by_cap = next > s->capacity ? next - s->capacity : 0;
+    return std::max(by_cap, origin);
 }
 
 int push_common(gsh_stream* s, const void* items, uint64_t n, int item_type, uint64_t* first_index)
@@ -91,19 +114,20 @@ int push_common(gsh_stream* s, const void* items, uint64_t n, int item_type, uin
     if (item_type != GSH_ITEM_GR_COMPLEX) return gsh::set_error(GSH_ERR_UNSUPPORTED, "fake: complex64 items only");
     if (n > s->capacity) return gsh::set_error(GSH_ERR_INVALID, "a push of %llu samples exceeds the ring capacity %llu", (unsigned long long)n, (unsigned long long)s->capacity);
     Guard g(s->inside);
-    if (first_index) *first_index = s->next;
+    const uint64_t at = s->next.load();
+    if (first_index) *first_index = at;
     {
         std::lock_guard<std::mutex> lk(g_ref_mutex);
         if (g_ref_iq != nullptr)
             {
-                if (s->next + n > g_ref_n || std::memcmp(items, g_ref_iq + 2 * s->next, sizeof(float) * 2 * n) != 0)
+                if (at + n > g_ref_n || std::memcmp(items, g_ref_iq + 2 * at, sizeof(float) * 2 * n) != 0)
                     {
                         g_mismatch++;
-                        std::fprintf(stderr, "FAKE ENGINE: push of %llu samples at absolute index %llu does not match the stream\n", (unsigned long long)n, (unsigned long long)s->next);
+                        std::fprintf(stderr, "FAKE ENGINE: push of %llu samples at absolute index %llu does not match the stream\n", (unsigned long long)n, (unsigned long long)at);
                     }
             }
     }
-    s->next += n;
+    s->next.store(at + n);
     return GSH_OK;
 }
 }  // namespace
@@ -141,21 +165,27 @@ extern "C"
     int gsh_stream_push_pinned(gsh_stream_t* s, const void* items, uint64_t n, int item_type, int, uint64_t* first_index) { return push_common(s, items, n, item_type, first_index); }
     int gsh_stream_push_pinned_async(gsh_stream_t* s, const void* items, uint64_t n, int item_type, int, uint64_t* first_index) { return push_common(s, items, n, item_type, first_index); }
     int gsh_stream_wait_copied(gsh_stream_t*) { return GSH_OK; }
+    int gsh_stream_wait_copied_upto(gsh_stream_t* s, uint64_t, uint64_t* complete_upto)
+    {
+        if (s == nullptr) return gsh::set_error(GSH_ERR_INVALID, "null stream");
+        if (complete_upto) *complete_upto = s->next.load();
+        return GSH_OK;
+    }
     int gsh_host_register(int, void*, size_t) { return GSH_OK; }
     int gsh_host_unregister(void*) { return GSH_OK; }
     int gsh_stream_seek(gsh_stream_t* s, uint64_t next_index)
     {
         if (s == nullptr) return gsh::set_error(GSH_ERR_INVALID, "null stream");
         Guard g(s->inside);
-        s->next = next_index;
-        s->origin = next_index;
+        s->next.store(next_index);
+        s->origin.store(next_index);
         return GSH_OK;
     }
     int gsh_stream_range(gsh_stream_t* s, uint64_t* lo, uint64_t* hi)
     {
         if (s == nullptr) return gsh::set_error(GSH_ERR_INVALID, "null stream");
         if (lo) *lo = oldest(s);
-        if (hi) *hi = s->next;
+        if (hi) *hi = s->next.load();
         return GSH_OK;
     }
 
@@ -187,6 +217,8 @@ extern "C"
     {
         if (t == nullptr || code == nullptr || channel < 0 || channel >= t->n_channels) return gsh::set_error(GSH_ERR_INVALID, "fake: bad start arguments");
         Guard g(t->inside);
+        if (t->live_left.load() > 0) return gsh::set_error(GSH_ERR_STATE, "gsh_trk_start: a live residency is in flight (gsh_trk_live_quiesce first)");
+        Guard gc(t->ch[static_cast<size_t>(channel)].inside);  // (a take of this channel at the same time is the caller's bug)
         const float* ref;
         uint64_t n_ref;
         {
@@ -215,6 +247,7 @@ extern "C"
                 r.acc_carrier_phase_rad += initial_acc_carrier_phase_rad;
             }
         c.active = true;
+        c.taken_next = start_sample;
         return GSH_OK;
     }
     int gsh_trk_start(gsh_trk_t* t, int channel, const float* code, const float* data_code, int code_length, uint64_t start_sample, uint64_t acq_sample_stamp,
@@ -226,7 +259,10 @@ extern "C"
     {
         if (t == nullptr || channel < 0 || channel >= t->n_channels) return gsh::set_error(GSH_ERR_INVALID, "fake: bad stop arguments");
         Guard g(t->inside);
+        if (t->live_left.load() > 0) return gsh::set_error(GSH_ERR_STATE, "gsh_trk_stop: a live residency is in flight (gsh_trk_live_quiesce first)");
+        Guard gc(t->ch[static_cast<size_t>(channel)].inside);
         t->ch[static_cast<size_t>(channel)].active = false;
+        t->ch[static_cast<size_t>(channel)].produced.clear();
         return GSH_OK;
     }
     int gsh_trk_run_begin(gsh_trk_t* t, int n_epochs, int want_records)
@@ -241,7 +277,8 @@ extern "C"
                 std::fprintf(stderr, "FAKE ENGINE: a launch was queued while a push was inside the ring (the ring's lock was not held)\n");
             }
         (void)want_records;
-        const uint64_t vlen = t->conf.vector_length, next = t->ring->next, old = oldest(t->ring);
+        if (t->live_left.load() > 0) return gsh::set_error(GSH_ERR_STATE, "gsh_trk_run_begin: a live residency is in flight (gsh_trk_live_quiesce first)");
+        const uint64_t vlen = t->conf.vector_length, next = t->ring->next.load(), old = oldest(t->ring);
         t->pending_rec.assign(static_cast<size_t>(t->n_channels) * static_cast<size_t>(n_epochs), gsh_trk_epoch{});
         t->pending_done.assign(static_cast<size_t>(t->n_channels), 0);
         for (int c = 0; c < t->n_channels; c++)
@@ -281,6 +318,86 @@ extern "C"
     {
         const int rc = gsh_trk_run_begin(t, n_epochs, records != nullptr);
         return rc != GSH_OK ? rc : gsh_trk_run_end(t, records, epochs_done);
+    }
+    // ---- live mode.  The stand-in "device" works at take time: what a resident kernel would have finished by now -- every period whose window lies in
+    // the fake ring while a residency is in flight -- is moved to the channel's queue of finished records, then handed out under the same rules as the
+    // library's gsh_trk_live_take.  A residency ends by itself after a bounded number of records (the kernel's time budget, in miniature).
+    int gsh_trk_live_configure(gsh_trk_t* t, uint32_t, uint32_t) { return t != nullptr ? GSH_OK : gsh::set_error(GSH_ERR_INVALID, "null handle"); }
+    int gsh_trk_live_begin(gsh_trk_t* t)
+    {
+        if (t == nullptr) return gsh::set_error(GSH_ERR_INVALID, "null handle");
+        if (t->ring == nullptr) return gsh::set_error(GSH_ERR_STATE, "live mode follows a sample ring (gsh_trk_set_stream_ring)");
+        if (t->pending_epochs >= 0) return gsh::set_error(GSH_ERR_STATE, "gsh_trk_live_begin: a run has been begun and not ended");
+        Guard g(t->inside);
+        if (t->ring->inside.load() != 0)
+            {
+                g_busy_handles++;
+                std::fprintf(stderr, "FAKE ENGINE: a residency was queued while a push was inside the ring (the ring's lock was not held)\n");
+            }
+        t->live_ready.store(true);
+        if (t->live_left.load() <= 0) t->live_left.store(37 * std::max(1, t->n_channels / 8));
+        return GSH_OK;
+    }
+    int gsh_trk_live_in_flight(gsh_trk_t* t, int32_t* n)
+    {
+        if (t == nullptr || n == nullptr) return gsh::set_error(GSH_ERR_INVALID, "null argument");
+        Guard g(t->inside);
+        *n = t->live_left.load() > 0 ? 1 : 0;
+        return GSH_OK;
+    }
+    int gsh_trk_live_quiesce(gsh_trk_t* t)
+    {
+        if (t == nullptr) return gsh::set_error(GSH_ERR_INVALID, "null handle");
+        Guard g(t->inside);
+        t->live_left.store(0);
+        return GSH_OK;
+    }
+    int gsh_trk_live_take(gsh_trk_t* t, int channel, uint64_t limit_end, int max_records, gsh_trk_epoch* out, int32_t* n_out, int32_t* pending, uint64_t* next_window,
+        int32_t* active, int32_t* resident)
+    {
+        if (resident) *resident = (t != nullptr && t->live_left.load() > 0) ? 1 : 0;
+        if (t == nullptr || n_out == nullptr || channel < 0 || channel >= t->n_channels) return gsh::set_error(GSH_ERR_INVALID, "fake: bad take arguments");
+        *n_out = 0;
+        FakeChannel& C = t->ch[static_cast<size_t>(channel)];
+        if (!t->live_ready.load())
+            {
+                if (pending) *pending = 0;
+                if (next_window) *next_window = C.pos;
+                if (active) *active = C.active ? 1 : 0;
+                return GSH_OK;
+            }
+        Guard gc(C.inside);  // one thread per channel at a time; other channels' takes, pushes and residency management run beside it
+        const uint64_t vlen = t->conf.vector_length;
+        while (C.active && C.released < C.all.size() && t->live_left.load() > 0)
+            {
+                const gsh_trk_epoch& r = C.all[C.released];
+                if (r.sample_counter + vlen > t->ring->next.load() || r.sample_counter < oldest(t->ring)) break;
+                t->live_left.fetch_sub(1);
+                C.produced.push_back(r);
+                C.released++;
+                if (r.flags & 2)
+                    {
+                        C.active = false;
+                        break;
+                    }
+                C.pos = r.sample_counter + static_cast<uint64_t>(r.prn_length_samples);
+            }
+        int n = 0;
+        while (n < max_records && !C.produced.empty())
+            {
+                const gsh_trk_epoch& r = C.produced.front();
+                const bool lost = (r.flags & 2) != 0;
+                if (!lost && r.sample_counter + std::max<uint64_t>(vlen, static_cast<uint64_t>(std::max(r.prn_length_samples, 0))) > limit_end) break;
+                out[n++] = r;
+                if (!lost) C.taken_next = r.sample_counter + static_cast<uint64_t>(std::max(r.prn_length_samples, 0));
+                C.produced.pop_front();
+                if (lost) break;
+            }
+        *n_out = n;
+        if (pending) *pending = static_cast<int32_t>(C.produced.size());
+        if (next_window) *next_window = C.taken_next;
+        if (active) *active = C.active ? 1 : 0;
+        return GSH_OK;
     }
     int gsh_trk_positions(gsh_trk_t* t, uint64_t* next_window, int32_t* active)
     {

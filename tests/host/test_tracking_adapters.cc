@@ -524,11 +524,16 @@ struct RefPeriod
     reftrk_output o{};
 };
 
+// The throughput leg replays a stream that is periodic in g_cycle_len samples (0: every other case -- the stream is what the vector holds): the vector then holds
+// one cycle plus a mirror of its beginning, so that what a call is offered is contiguous wherever it starts, and positions keep counting up.
+size_t g_cycle_len = 0;
+inline size_t stream_offset(size_t pos) { return g_cycle_len != 0 ? pos % g_cycle_len : pos; }
+
 RefPeriod ref_call(void* ref, const std::vector<std::complex<float>>& x, size_t& pos, int available)
 {
     RefPeriod p;
-    const int avail = static_cast<int>(std::min<size_t>(static_cast<size_t>(available), x.size() - pos));
-    p.produced = reftrk_general_work(ref, reinterpret_cast<const float*>(x.data() + pos), avail, &p.consumed, &p.o);
+    const int avail = static_cast<int>(std::min<size_t>(static_cast<size_t>(available), x.size() - stream_offset(pos)));
+    p.produced = reftrk_general_work(ref, reinterpret_cast<const float*>(x.data() + stream_offset(pos)), avail, &p.consumed, &p.o);
     pos += static_cast<size_t>(p.consumed);
     return p;
 }
@@ -930,7 +935,7 @@ int main(int argc, char** argv)
     const bool conf_only = argc > 1 && std::string(argv[1]) == "conf";
     const std::string mode = argc > 1 ? argv[1] : "";
     const int host_threads = std::max(2, std::min(16, static_cast<int>(std::thread::hardware_concurrency())));
-    if (mode == "bench")  // test_tracking_adapters bench [channels fs periods periods_per_call]: the drop-in throughput leg (bench.py's `dropin`)
+    if (mode == "bench")  // test_tracking_adapters bench [channels fs periods periods_per_call [seconds]]: the drop-in throughput leg (bench.py's `dropin`)
         {
             if (gsh_device_count() < 1)
                 {
@@ -941,7 +946,8 @@ int main(int argc, char** argv)
             const long fs = argc > 3 ? std::atol(argv[3]) : 25000000L;
             const int periods = argc > 4 ? std::atoi(argv[4]) : 400;
             const int ppc = argc > 5 ? std::atoi(argv[5]) : 10;
-            return bench_dropin(ch, fs, periods, ppc, host_threads);
+            const double seconds = argc > 6 ? std::atof(argv[6]) : 0.0;  // > 0: replay a 2 400-period stream for that long (periods = the cap)
+            return bench_dropin(ch, fs, periods, ppc, host_threads, seconds);
         }
     if (mode == "runtime")  // only the runtime cases (what the CPU suite runs against the fake engine): [channels periods periods_per_call]
         {
