@@ -64,7 +64,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-acq", action="store_true")
     ap.add_argument("--no-dropin", action="store_true", help="skip the drop-in leg (32 tracking blocks through general_work)")
-    ap.add_argument("--dropin-periods", type=int, default=2400, help="code periods per channel of the drop-in leg (the first quarter is set-up, the rest is timed)")
+    ap.add_argument("--dropin-seconds", type=float, default=2.6, help="wall time of each drop-in run (a 2 400-period stream replayed seamlessly; the first 600 periods are set-up)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the config 4 / config 5 figures (profiles/run_profiles.sh: keeps the "
                     "per-kernel averages of the trace about the headline workload only)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline leg")
@@ -275,10 +275,16 @@ def acquisition_metric(torch, dev_index, x_block, fs, pmc=None):
         acq4.close()
     except Exception as e:
         res["split_plan_128000"] = {"error": str(e)}
+    # CPU baselines: the reference's own block (kind "reference"; its transform here is oracle/ref_fft.cc, not FFTW), and the numpy / pocketfft restatement
+    # (kind "port": the faster transform, not the reference's code) -- both reported, neither is the target
     try:
-        res["cpu_baseline"] = acquisition_cpu_baseline(x_block.cpu().numpy(), fs, n)
+        res["cpu_baseline"] = acquisition_reference_baseline(x_block.cpu().numpy(), fs, n)
     except Exception as e:
         res["cpu_baseline"] = {"error": str(e)}
+    try:
+        res["cpu_baseline_port"] = acquisition_cpu_baseline(x_block.cpu().numpy(), fs, n)
+    except Exception as e:
+        res["cpu_baseline_port"] = {"error": str(e)}
     return res
 
 
@@ -314,6 +320,69 @@ def acquisition_cpu_baseline(x, fs, n, target_s=6.0):
             "sample": f"{n_dwells} dwells (1 PRN x 41 bins x {n} samples each) over {cores} processes, numpy/scipy-pocketfft "
                       f"restatement of pcps_acquisition (the reference's FFTW/VOLK are not available here)",
             "single_process_dwells_per_s": 1.0 / t1, "seconds": dt}
+
+
+def acquisition_reference_baseline(x, fs, n, target_s=8.0):
+    """SURVEY.md 8d (ii), kind "reference": the reference's OWN pcps_acquisition block (oracle/_ref/libgnsssdr_ref_acq.so: pcps_acquisition.cc compiled in place,
+    acq.cc:522-560 through general_work, :749-853) with the CPU FFT we ship behind gr::fft (oracle/ref_fft.cc: mixed radix, double precision -- FFTW and VOLK are not
+    available in this image, so the transform is slower than the reference's own; the block's loops, wipe-off, magnitude and statistics are the reference's).  One
+    thread per PRN like the reference's channels; one dwell = 41 Doppler bins over one 1 ms block."""
+    import threading
+    from oracle import ref_acq
+    if not ref_acq.available():
+        return {"error": "oracle/_ref/libgnsssdr_ref_acq.so was not built (needs /root/reference at build time)"}
+    import oracle
+    role = "Acquisition_1C"
+    props = {"GNSS-SDR.internal_fs_sps": int(fs), role + ".blocking": "true", role + ".doppler_max": 5000, role + ".doppler_step": 250, role + ".max_dwells": 1,
+             role + ".pfa": 0.001}
+    x1 = np.ascontiguousarray(x[:n], np.complex64)
+
+    def make(prn):
+        b = ref_acq.RefAcqBlock(ref_acq.K_PCPS, props, 1.023e6, 2e6, 1, role=role, prn=prn, signal="1C", system="G")
+        b.set_local_code(oracle.ca_code_complex_sampled(prn, int(fs)))
+        return b
+
+    def dwell(b):
+        b.set_active(True)
+        pos = 0
+        for _ in range(8):  # state 0 -> 1 -> the dwell: a few general_work calls, as the scheduler makes them
+            _, c = b.work(x1[pos:] if pos < n else x1)
+            pos = (pos + c) % n
+            if not b.status()["active"]:
+                return
+
+    b0 = make(1)
+    dwell(b0)                       # warm-up: FFT plan, page faults
+    t0 = time.perf_counter()
+    dwell(b0)
+    t1 = time.perf_counter() - t0   # one dwell on one thread
+    b0.close()
+    threads = min(os.cpu_count() or 1, 32)   # one per PRN, as the reference's channels
+    reps = int(max(1, min(200, target_s / max(t1, 1e-3))))
+    blocks = [make(p + 1) for p in range(threads)]
+    for b in blocks:
+        dwell(b)
+    done = [0] * threads
+
+    def work(i):
+        for _ in range(reps):
+            dwell(blocks[i])
+            done[i] += 1
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(threads)]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt = time.perf_counter() - t0
+    for b in blocks:
+        b.close()
+    n_dwells = sum(done)
+    return {"value": n_dwells / dt, "unit": "dwells/s", "cores": threads, "kind": "reference",
+            "sample": f"{n_dwells} dwells (1 PRN x 41 bins x {n} samples each) by {threads} threads, each driving its own pcps_acquisition block (the reference's source, "
+                      f"compiled in place) through general_work; gr::fft = oracle/ref_fft.cc (no FFTW in this image)",
+            "single_thread_dwells_per_s": 1.0 / t1, "seconds": dt}
 
 
 def pcie_inclusive_metric(torch, dev_index, x_dev, jobs, C, E, T, n_samples, reps=24):
@@ -366,7 +435,7 @@ def pcie_inclusive_metric(torch, dev_index, x_dev, jobs, C, E, T, n_samples, rep
                     "gsh_stream_push_async, next block's copy overlapped with this block's correlation; `sequential`: nothing overlapped"}
 
 
-def closed_loop_metric(dev_index, x_dev, n_samples, fs, n, dop, cph, channels=32, epochs=200):
+def closed_loop_metric(dev_index, x_dev, n_samples, fs, n, dop, cph, channels=32, epochs=200, lock_detectors=False, live=False):
     """Secondary metric: the DLL/PLL loop closed on the device (gsh_trk_*), BASELINE config 2 shape -- every channel runs
     `epochs` consecutive code periods with its own discriminators / loop filters / NCO update between them, one launch."""
     try:
@@ -374,7 +443,10 @@ def closed_loop_metric(dev_index, x_dev, n_samples, fs, n, dop, cph, channels=32
     except Exception as e:
         return {"error": f"tracking loop unavailable: {e}"}
     from gnss_sdr_amd.codes import gps_l1_ca_code
-    conf = trk_conf(fs_in=fs, vector_length=n, pll_bw_hz=35.0, dll_bw_hz=2.0)
+    # lock_detectors: cn0_and_tracking_lock_status on the device as well (what the tracking adapters run with); the fail limits are out of reach so that
+    # the channels without a signal keep running for the timing
+    conf = trk_conf(fs_in=fs, vector_length=n, pll_bw_hz=35.0, dll_bw_hz=2.0, enable_lock_detectors=int(lock_detectors), max_carrier_lock_fail=1 << 30,
+                    max_code_lock_fail=1 << 30)
     loop = TrackingLoop(conf, channels, 1023, device=dev_index)
     loop.set_stream_device(x_dev.data_ptr(), n_samples, keepalive=x_dev)
     rng = np.random.default_rng(0x5EED0006)
@@ -394,10 +466,59 @@ def closed_loop_metric(dev_index, x_dev, n_samples, fs, n, dop, cph, channels=32
         if abs(np.mean([r.carrier_doppler_hz for r in tail]) - dop[c]) < 5.0:
             locked += 1
     loop.close()
-    return {"metric": "correlators/s, loop closed on device", "value": channels * 3 * epochs / (ms * 1e-3), "unit": "correlators/s",
-            "ms_per_launch": ms, "us_per_epoch": ms * 1e3 / epochs, "channels": channels, "epochs_per_launch": epochs,
-            "channels_with_signal_locked": f"{locked}/{min(channels, len(dop))}",
-            "real_time_factor": epochs * 1e-3 / (ms * 1e-3)}
+    out = {"metric": "correlators/s, loop closed on device", "value": channels * 3 * epochs / (ms * 1e-3), "unit": "correlators/s",
+           "ms_per_launch": ms, "us_per_epoch": ms * 1e3 / epochs, "channels": channels, "epochs_per_launch": epochs, "lock_detectors": bool(lock_detectors),
+           "channels_with_signal_locked": f"{locked}/{min(channels, len(dop))}",
+           "real_time_factor": epochs * 1e-3 / (ms * 1e-3)}
+    # what binds it: the correlation's vector instructions (6 + 4 T flops per channel-sample) on the compute units the channels occupy -- one each
+    flops = float(channels) * epochs * (6 + 4 * 3) * n
+    peak = 157.3e12
+    out["roofline"] = {"bound": "valu", "achieved": flops / (ms * 1e-3) / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": flops / (ms * 1e-3) / peak,
+                       "frac_of_the_compute_units_in_use": flops / (ms * 1e-3) / (peak * min(channels, 256) / 256.0),
+                       "note": "one work-group (one compute unit) per channel; a period is a dependent chain: window -> 16-wave sums -> loop arithmetic on three lanes -> next window"}
+    if live:
+        out["live"] = closed_loop_live(dev_index, x_dev, n_samples, fs, n, dop, cph, channels, epochs, conf)
+    return out
+
+
+def closed_loop_live(dev_index, x_dev, n_samples, fs, n, dop, cph, channels, epochs, conf):
+    """The same channels in LIVE mode (gsh_trk_live_*): one residency of the loop kernel follows a ring that already holds the block; the records are read
+    from page-locked host memory while it runs.  Rate = the slowest channel's progress between two marks."""
+    from gnss_sdr_amd.codes import gps_l1_ca_code
+    from gnss_sdr_amd.sample_stream import SampleStream
+    from gnss_sdr_amd.tracking_loop import TrackingLoop
+    ring = SampleStream(n_samples + 2 * n, 2 * n, device=dev_index)
+    ring.push_device(x_dev.data_ptr(), n_samples)
+    loop = TrackingLoop(conf, channels, 1023, device=dev_index)
+    loop.set_stream_ring(ring)
+    rng = np.random.default_rng(0x5EED0006)
+    for c in range(channels):
+        if c < len(dop):
+            f_code = 1.023e6 * (1 + dop[c] / 1575.42e6)
+            loop.start(c, gps_l1_ca_code(c + 1), int(round((1023.0 - cph[c]) / f_code * fs)), 0, float(dop[c]) + rng.uniform(-20, 20))
+        else:
+            loop.start(c, gps_l1_ca_code(c % 32 + 1), int(rng.integers(0, n)), 0, float(rng.uniform(-5000, 5000)))
+    loop.live_configure(idle_timeout_us=2000, residency_us=2000000)
+    lo, hi = 30, epochs - 20
+    t_lo = t_hi = None
+    loop.live_begin()
+    watch = list(range(0, channels, max(1, channels // 32)))  # (a look costs Python a few microseconds per channel)
+    t_end = time.perf_counter() + 5.0
+    while t_hi is None and time.perf_counter() < t_end:
+        p = min(loop.live_take(c, 0)[1] for c in watch)
+        now = time.perf_counter()
+        if t_lo is None and p >= lo:
+            t_lo, p_lo = now, p
+        if p >= hi:
+            t_hi, p_hi = now, p
+    loop.live_quiesce()
+    loop.close()
+    ring.close()
+    if t_hi is None or t_lo is None or p_hi <= p_lo:
+        return {"error": "the residency did not finish its periods within 5 s"}
+    us = (t_hi - t_lo) * 1e6 / (p_hi - p_lo)
+    return {"us_per_epoch": us, "value": channels * 3 / (us * 1e-6), "unit": "correlators/s", "periods_timed": p_hi - p_lo,
+            "note": "one residency, no launch per batch of periods; records written to a ring in page-locked host memory as they finish"}
 
 
 def other_configs_metric(dev_index):
@@ -416,7 +537,7 @@ def other_configs_metric(dev_index):
     return out
 
 
-def dropin_metric(channels, fs, periods, periods_per_call=20):
+def dropin_metric(channels, fs, periods, periods_per_call=20, seconds=0.0):
     """What a receiver gets through the reference's own seam (north_star: "drops into a Channel unchanged"): `channels` dll_pll_veml_tracking_hip
     blocks behind their TrackingInterface adapters, one scheduler thread each as in a flowgraph (gnss_flowgraph.cc:1227-1231), ONE 25 Msps stream,
     ONE Hip_Tracking_Runtime whose launches advance every channel that has samples.  The C++ program (tests/host/test_tracking_adapters bench,
@@ -426,13 +547,76 @@ def dropin_metric(channels, fs, periods, periods_per_call=20):
     exe = os.path.join(ROOT, "tests", "host", "test_tracking_adapters")
     if not os.path.exists(exe):
         return {"error": "tests/host/test_tracking_adapters was not prebuilt (needs /root/reference at build time)"}
-    r = subprocess.run([exe, "bench", str(channels), str(int(fs)), str(periods), str(periods_per_call)], capture_output=True, text=True, timeout=900, cwd="/tmp")
+    # seconds > 0: a 2 400-period stream replayed seamlessly for that long (the steady window then lasts seconds, not tens of milliseconds); periods = the cap
+    r = subprocess.run([exe, "bench", str(channels), str(int(fs)), str(periods), str(periods_per_call)] + ([f"{seconds:g}"] if seconds > 0 else []), capture_output=True,
+                       text=True, timeout=900, cwd="/tmp")
     line = [l for l in r.stdout.splitlines() if l.startswith("DROPIN_JSON")]
     if r.returncode != 0 or not line:
         return {"error": (r.stdout[-600:] + r.stderr[-400:]).strip()}
     d = json.loads(line[-1][len("DROPIN_JSON"):])
     d["unit"] = "channel-periods/s through general_work (x3 taps = correlators/s)"
     return d
+
+
+def sharded_legs(torch, dist, dev, local, rank, world, ring, block, fs, n, C, epochs=200):
+    """The two other paths a receiver runs, on the rings of the stream group (every rank calls this; rank 0 gets the figures): SURVEY.md 8e --
+    closed loop: channel c -> GPU c mod G, here C channels per GPU (weak scaling), each GPU's loop bound to ITS ring of the replicated stream;
+    acquisition: PRN p -> GPU p mod G over the same replicated 1 ms block (strong scaling: 32 PRNs x 41 bins in all, 32 / G per GPU).
+    Times are HIP-event / wall times per rank, reduced with MAX over the ranks like the headline."""
+    from gnss_sdr_amd.acquisition import PcpsAcquisitionBank
+    from gnss_sdr_amd.codes import gps_l1_ca_code, gps_l1_ca_code_sampled
+    from gnss_sdr_amd.tracking_loop import TrackingLoop, trk_conf
+    out = {}
+
+    def reduce_max(v):
+        if dist is None:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    lo, hi = ring.range()
+    base = hi - block  # the newest whole block in the ring
+    try:
+        conf = trk_conf(fs_in=fs, vector_length=n, pll_bw_hz=35.0, dll_bw_hz=2.0)
+        loop = TrackingLoop(conf, C, 1023, device=local)
+        loop.set_stream_ring(ring)
+        rng = np.random.default_rng(0x5EED0006 + rank)
+        for c in range(C):
+            loop.start(c, gps_l1_ca_code((rank * C + c) % 32 + 1), base + int(rng.integers(0, n)), base, float(rng.uniform(-5000, 5000)))
+        loop.time_run(epochs, reps=10)
+        ms = reduce_max(loop.time_run(epochs, reps=5))
+        loop.close()
+        out["closed_loop_sharded"] = {"metric": "correlators/s, loop closed on device, channels sharded over the GPUs", "value": float(world) * C * 3 * epochs / (ms * 1e-3),
+                                      "unit": "correlators/s", "ms_per_launch": ms, "us_per_epoch": ms * 1e3 / epochs, "channels_per_gpu": C, "n_gpus": world,
+                                      "scaling": "weak"}
+    except Exception as e:
+        out["closed_loop_sharded"] = {"error": str(e)}
+        reduce_max(0.0)
+    try:
+        mine = [p for p in range(1, 33) if (p - 1) % world == rank]
+        acq = PcpsAcquisitionBank(fs_in=int(fs), fft_size=n, doppler_max=5000, doppler_step=250, samples_per_chip=int(np.ceil(fs / 1.023e6)), samples_per_code=float(n),
+                                  max_prn=max(len(mine), 1), num_doppler_bins=41, device=local)
+        for k, p in enumerate(mine):
+            acq.set_local_code(k, gps_l1_ca_code_sampled(p, int(fs)))
+        for _ in range(5):
+            acq.dwell_ring(ring, base + 7, max(len(mine), 1))
+        reps = 50
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            acq.dwell_ring(ring, base + 7, max(len(mine), 1))
+        dt = reduce_max(time.perf_counter() - t0)
+        acq.close()
+        out["acquisition_sharded"] = {"metric": "acquisition dwells/s (1 PRN x 41 Doppler bins), PRNs sharded over the GPUs", "value": 32.0 * reps / dt, "unit": "dwells/s",
+                                      "ms_per_batch_of_32_prn": dt / reps * 1e3, "prn_per_gpu": len(mine), "n_gpus": world, "scaling": "strong",
+                                      "note": "wall time of synchronous dwells out of the ring (results read back every call), not the pipelined kernel rate of the N = 1 leg"}
+    except Exception as e:
+        out["acquisition_sharded"] = {"error": str(e)}
+        reduce_max(0.0)
+    return out
 
 
 def load_pmc():
@@ -622,6 +806,10 @@ def main():
             if not np.all(err <= 1e-6):
                 raise SystemExit(f"bench: GPU result of job {j} disagrees with the oracle: {out[j, :T]} vs {t64}")
 
+    sharded = None
+    if grouped:
+        # the closed loop and the acquisition on the replicated stream (every rank takes part; see sharded_legs)
+        sharded = sharded_legs(torch, dist, dev, local, rank, world, ring, block, fs, n, C)
     if rank == 0:
         pmc = load_pmc()
         total_corr = float(C) * T * E * BPS * a.steps * world
@@ -650,6 +838,8 @@ def main():
             "rccl_ranks": world if grouped else 0,
             "stream_group_mode": os.environ.get("GSH_BENCH_DIST", "broadcast") if grouped else None,
         }
+        if sharded is not None:
+            res.update(sharded)
         # ---- the other GPU legs first, while the device is still at its working clocks (the CPU legs below leave it idle for ~40 s; what runs after
         # them starts from the idle power state however long its own warm-up is)
         if world == 1 and not a.no_acq and not grouped:
@@ -659,6 +849,8 @@ def main():
                 res["acquisition"] = {"error": str(e)}
             try:
                 res["closed_loop"] = closed_loop_metric(local, x0, block, fs, n, dop, cph, channels=C, epochs=min(E - 2, 200))
+                # ... with the lock detectors on (what the tracking adapters run), launched and as one live residency
+                res["closed_loop_lock_detectors"] = closed_loop_metric(local, x0, block, fs, n, dop, cph, channels=C, epochs=min(E - 2, 200), lock_detectors=True, live=True)
                 # one compute unit per channel: 32 channels use an eighth of the chip, 256 (BASELINE config 5's channel count) fill it
                 res["closed_loop_256ch"] = closed_loop_metric(local, x0, block, fs, n, dop, cph, channels=256, epochs=min(E - 2, 200))
             except Exception as e:
@@ -675,7 +867,9 @@ def main():
         # ---- then the legs with a CPU part: the drop-in seam (32 block threads + 32 reference blocks as the checker) and the CPU baseline
         if world == 1 and not a.no_dropin and not grouped:
             try:
-                res["dropin"] = dropin_metric(C, fs, a.dropin_periods)
+                # the reference's cadence (one code period per general_work call, trk.cc:1898-2001) and 20 periods per call, each over a steady window of seconds
+                res["dropin"] = dropin_metric(C, fs, 4000000, 20, a.dropin_seconds)
+                res["dropin"]["one_period_per_call"] = dropin_metric(C, fs, 4000000, 1, a.dropin_seconds)
             except Exception as e:
                 res["dropin"] = {"error": str(e)}
         if world == 1 and not a.no_cpu_baseline:

@@ -423,6 +423,7 @@ template <class P, int S, bool GRID, bool SECOND, bool OFF>
 __global__ __launch_bounds__(P::THREADS) void oc_cell_kernel(OcCellArgs a)
 {
     static_assert(S == 1 || !SECOND, "the second peak of a row needs the whole row in one work-group");
+    static_assert(!SECOND || P::N * 4 <= P::LDS_BYTES, "the peak-ratio flavour parks the row's N magnitudes in the exchange buffer: a plan whose buffer is smaller needs another place for them");
     static_assert(GRID || !OFF, "the upper-half searches are instantiated on the GRID flavour only");
     constexpr int M = P::N, N = S * P::N;
     GSH_OC_LDS_DECL(P);

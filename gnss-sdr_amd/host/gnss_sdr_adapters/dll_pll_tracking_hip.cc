@@ -18,10 +18,12 @@
 #include <algorithm>
 #include <array>
 #include <cmath>
+#include <cstdlib>
 #include <iostream>
 #include <map>
 #include <mutex>
 #include <utility>
+#include <vector>
 
 #if USE_GLOG_AND_GFLAGS
 #include <glog/logging.h>
@@ -41,30 +43,90 @@ namespace
 //                                        blocks that see the same stream.
 // The ring is sized by time, not by the first joiner's code period, so that signals with different periods on the same RF stream (L1 C/A 1 ms, E1 4 ms,
 // L2C 20 ms) fit: 256 ms resident, windows of up to 40 ms contiguous; never less than 64 / 2 of the joiner's periods.
-std::shared_ptr<Hip_Tracking_Runtime> runtime_for(int device, int id, const std::string& role, const Dll_Pll_Conf& p, int periods_per_launch, bool register_input,
-    int channels_per_launch, bool live)
+// <role>.hip_devices = 0,1,2,...: the stream is resident in several GPUs of the node and the blocks of the role are dealt to them in turn (SURVEY.md 8e:
+// channel c -> GPU c mod G; <role>.hip_device, when given, pins a block instead).  The ring then is ONE Hip_Sample_Ring over the engine's stream group: whichever
+// block is offered new samples first pushes them once -- into the ingest GPU, devices[0], over PCIe -- and RCCL replicates them over xGMI into every device's
+// ring; each device has its own Hip_Tracking_Runtime (its handles and residencies) on the shared ring.
+struct SharedStream
+{
+    std::weak_ptr<Hip_Sample_Ring> ring;
+    unsigned dealt{0};  // blocks handed a device so far (round robin)
+};
+
+std::vector<int> parse_devices(const std::string& list)
+{
+    std::vector<int> out;
+    size_t at = 0;
+    while (at < list.size())
+        {
+            const size_t comma = list.find(',', at);
+            const std::string tok = list.substr(at, comma == std::string::npos ? std::string::npos : comma - at);
+            if (!tok.empty()) out.push_back(std::atoi(tok.c_str()));
+            if (comma == std::string::npos) break;
+            at = comma + 1;
+        }
+    return out;
+}
+
+std::shared_ptr<Hip_Tracking_Runtime> runtime_for(int device, bool device_given, const std::vector<int>& devices, int id, const std::string& role, const Dll_Pll_Conf& p,
+    int periods_per_launch, bool register_input, int channels_per_launch, bool live, int* device_out)
 {
     static std::mutex mu;
     static std::map<std::pair<int, std::string>, std::weak_ptr<Hip_Tracking_Runtime>> runtimes;
+    static std::map<std::string, SharedStream> streams;
     const uint64_t vlen = std::max<uint32_t>(p.vector_length, 1U);
-    auto make = [&](uint64_t capacity, uint64_t window) -> std::shared_ptr<Hip_Tracking_Runtime> {
-        auto ring = std::make_shared<Hip_Sample_Ring>(device, capacity, static_cast<uint32_t>(window));
+    const bool grouped = devices.size() > 1 && id != -1;
+    auto make_ring = [&](uint64_t capacity, uint64_t window) -> std::shared_ptr<Hip_Sample_Ring> {
+        auto ring = grouped ? std::make_shared<Hip_Sample_Ring>(devices, capacity, static_cast<uint32_t>(window))
+                            : std::make_shared<Hip_Sample_Ring>(device, capacity, static_cast<uint32_t>(window));
         if (!ring->ok())
             {
                 LOG(ERROR) << "hip sample ring (" << capacity << " samples): " << ring->last_error();
                 return nullptr;
             }
         ring->set_auto_register(register_input);
-        return std::make_shared<Hip_Tracking_Runtime>(device, std::move(ring), periods_per_launch, id == -1 ? 1 : channels_per_launch, live);
+        return ring;
     };
-    if (id == -1) return make(std::max<uint64_t>(16, 4ULL * (static_cast<uint64_t>(periods_per_launch) + 2)) * vlen, 2 * vlen);
+    *device_out = device;
+    if (id == -1)
+        {
+            auto ring = make_ring(std::max<uint64_t>(16, 4ULL * (static_cast<uint64_t>(periods_per_launch) + 2)) * vlen, 2 * vlen);
+            return ring ? std::make_shared<Hip_Tracking_Runtime>(device, std::move(ring), periods_per_launch, 1, live) : nullptr;
+        }
     std::lock_guard<std::mutex> lk(mu);
-    auto& slot = runtimes[{device, id >= 0 ? "id:" + std::to_string(id) : "role:" + role}];
+    const std::string key = id >= 0 ? "id:" + std::to_string(id) : "role:" + role;
+    std::shared_ptr<Hip_Sample_Ring> ring;
+    if (grouped)
+        {
+            SharedStream& st = streams[key];
+            ring = st.ring.lock();
+            if (!ring)
+                {
+                    const auto fs = static_cast<uint64_t>(std::max(p.fs_in, 1.0));
+                    ring = make_ring(std::max<uint64_t>(64 * vlen, fs * 256 / 1000), std::max<uint64_t>(2 * vlen, fs * 40 / 1000));
+                    if (!ring) return nullptr;
+                    st.ring = ring;
+                    st.dealt = 0;
+                }
+            if (!device_given) device = devices[st.dealt++ % devices.size()];
+            if (ring->handle_for(device) == nullptr)
+                {
+                    LOG(ERROR) << role << ": hip_device " << device << " is not one of hip_devices";
+                    return nullptr;
+                }
+            *device_out = device;
+        }
+    auto& slot = runtimes[{device, key}];
     auto rt = slot.lock();
     if (!rt)
         {
-            const auto fs = static_cast<uint64_t>(std::max(p.fs_in, 1.0));
-            rt = make(std::max<uint64_t>(64 * vlen, fs * 256 / 1000), std::max<uint64_t>(2 * vlen, fs * 40 / 1000));
+            if (!ring)
+                {
+                    const auto fs = static_cast<uint64_t>(std::max(p.fs_in, 1.0));
+                    ring = make_ring(std::max<uint64_t>(64 * vlen, fs * 256 / 1000), std::max<uint64_t>(2 * vlen, fs * 40 / 1000));
+                    if (!ring) return nullptr;
+                }
+            rt = std::make_shared<Hip_Tracking_Runtime>(device, std::move(ring), periods_per_launch, channels_per_launch, live);
             slot = rt;
         }
     return rt;
@@ -97,7 +159,9 @@ DllPllTrackingHip::DllPllTrackingHip(const ConfigurationInterface* configuration
 
 void DllPllTrackingHip::create_tracking_block(const ConfigurationInterface* configuration)
 {
-    const int device = configuration->property(role_ + ".hip_device", 0);
+    const int device_key = configuration->property(role_ + ".hip_device", -1);
+    const std::vector<int> devices = parse_devices(configuration->property(role_ + ".hip_devices", std::string("")));
+    int device = device_key >= 0 ? device_key : (devices.empty() ? 0 : devices[0]);
     // code periods one general_work call may consume and emit when its input covers them: 1 is the reference's cadence (trk.cc:1898-2001: one period, then
     // back to the scheduler); larger values save scheduler round trips when the receiver post-processes a file faster than real time (the runtime's throughput
     // at 1 / 20: bench.py -> dropin).  The device works ahead of the blocks either way -- this key only sets how much a block takes per call.
@@ -113,7 +177,9 @@ void DllPllTrackingHip::create_tracking_block(const ConfigurationInterface* conf
             LOG(WARNING) << trk_params_.item_type << " unknown tracking item type.";
             return;
         }
-    if (gsh_device_count() <= device)
+    for (const int d : devices)
+        if (d < 0 || gsh_device_count() <= d) device = d;  // (reported by the check below)
+    if (device < 0 || gsh_device_count() <= device)
         {
             item_size_ = 0;
             tracking_sptr_ = nullptr;
@@ -125,7 +191,7 @@ void DllPllTrackingHip::create_tracking_block(const ConfigurationInterface* conf
     // most channels of one loop configuration that share a launch (one work-group each; a further handle is opened beyond that).  Every launch brings the
     // records of all the handle's slots back, so the default stays at what BASELINE's configurations put on one GPU (32 - 50 channels per stream)
     const int per_handle = configuration->property(role_ + ".hip_channels_per_launch", 64);
-    auto runtime = runtime_for(device, ring_id, role_, trk_params_, per_launch, register_input, per_handle, live);
+    auto runtime = runtime_for(device, device_key >= 0, devices, ring_id, role_, trk_params_, per_launch, register_input, per_handle, live, &device);
     if (!runtime)
         {
             item_size_ = 0;

@@ -68,114 +68,113 @@ void galileo_e5a_noncoherentIQ_acquisition_caf_hip::set_local_code(std::complex<
 }
 
 
+// The block's scheduler entry: the five states of galileo_e5a_noncoherent_iq_acquisition_caf_cc::general_work (e5a.cc:240-733) -- idle, restart, fill the block
+// buffer, search, report -- as one small dispatcher over four steps.  What the steps consume and when they move on is the reference block's, call for call (the
+// side-by-side runs in tests/host/test_adapters.cc compare consumed counts and events with it); the search itself runs on the GPU (d_core).
 int galileo_e5a_noncoherentIQ_acquisition_caf_hip::general_work(int /*noutput_items*/, gr_vector_int& ninput_items, gr_vector_const_void_star& input_items,
     gr_vector_void_star& output_items)
 {
-    int acquisition_message = -1;  // 1 = ACQ_SUCCESS, 2 = ACQ_FAIL
-    int return_value = 0;          // number of Gnss_Synchro objects produced
-
-    if (!d_active)  // e5a.cc:249-254
+    const int offered = ninput_items[0];
+    const auto* in = reinterpret_cast<const gr_complex*>(input_items[0]);
+    if (!d_active)  // not asked to search: the stream passes by (e5a.cc:249-254)
         {
-            d_sample_counter += static_cast<uint64_t>(ninput_items[0]);
-            consume_each(ninput_items[0]);
+            pass_by(offered);
             return 0;
         }
-
     switch (d_state)
         {
-        case 0:  // restart (e5a.cc:262-274)
-            {
-                d_gnss_synchro->Acq_delay_samples = 0.0;
-                d_gnss_synchro->Acq_doppler_hz = 0.0;
-                d_gnss_synchro->Acq_samplestamp_samples = 0ULL;
-                d_gnss_synchro->Acq_doppler_step = 0U;
-                d_core.init();
-                d_state = 1;
-                break;
-            }
-        case 1:  // load the buffer until it holds a block (e5a.cc:276-298)
-            {
-                const auto* in = reinterpret_cast<const gr_complex*>(input_items[0]);
-                int buff_increment;
-                if ((ninput_items[0] + d_buffer_count) <= d_fft_size)
-                    {
-                        buff_increment = ninput_items[0];
-                    }
-                else
-                    {
-                        buff_increment = d_fft_size - d_buffer_count;
-                    }
-                std::copy(in, in + buff_increment, d_inbuffer.begin() + d_buffer_count);
-                // if the buffer will be full in the next iteration
-                if (d_buffer_count >= static_cast<int>(d_fft_size - d_gr_stream_buffer))
-                    {
-                        d_state = 2;
-                    }
-                d_buffer_count += buff_increment;
-                d_sample_counter += static_cast<uint64_t>(buff_increment);
-                consume_each(buff_increment);
-                break;
-            }
-        case 2:  // the search (e5a.cc:300-670), on the GPU
-            {
-                const auto* in = reinterpret_cast<const gr_complex*>(input_items[0]);
-                if (d_buffer_count < d_fft_size)
-                    {
-                        std::copy(in, in + (d_fft_size - d_buffer_count), d_inbuffer.begin() + d_buffer_count);
-                    }
-                d_sample_counter += static_cast<uint64_t>(d_fft_size - d_buffer_count);
-
-                const int next = d_core.work(d_sample_counter, d_inbuffer.data());
-                if (next < 0)
-                    {
-                        // the engine failed (the error is in d_core.last_error()): report a negative acquisition instead of running on stale values
-                        std::cerr << "galileo_e5a_noncoherentIQ_acquisition_caf_hip: " << d_core.last_error() << '\n';
-                        d_state = 4;
-                    }
-                else
-                    {
-                        // the core fills its own result record whenever the block would have written the Gnss_Synchro (e5a.cc:506-514, :634-636)
-                        const Hip_Detector_Result& r = d_core.result();
-                        d_gnss_synchro->Acq_delay_samples = r.Acq_delay_samples;
-                        d_gnss_synchro->Acq_doppler_hz = r.Acq_doppler_hz;
-                        d_gnss_synchro->Acq_samplestamp_samples = r.Acq_samplestamp_samples;
-                        d_gnss_synchro->Acq_doppler_step = r.Acq_doppler_step;
-                        d_state = next;
-                    }
-                consume_each(d_fft_size - d_buffer_count);
-                d_buffer_count = 0;
-                break;
-            }
-        case 3:  // positive acquisition (e5a.cc:672-707)
-            {
-                d_active = false;
-                d_state = 0;
-                acquisition_message = 1;
-                this->message_port_pub(pmt::mp("events"), pmt::from_long(acquisition_message));
-                d_sample_counter += static_cast<uint64_t>(ninput_items[0]);
-                consume_each(ninput_items[0]);
-                if (d_enable_monitor_output)
-                    {
-                        auto** out = reinterpret_cast<Gnss_Synchro**>(&output_items[0]);
-                        Gnss_Synchro current_synchro_data = Gnss_Synchro();
-                        current_synchro_data = *d_gnss_synchro;
-                        *out[0] = std::move(current_synchro_data);
-                        return_value = 1;
-                    }
-                break;
-            }
-        case 4:  // negative acquisition (e5a.cc:709-731)
-            {
-                d_active = false;
-                d_state = 0;
-                d_sample_counter += static_cast<uint64_t>(ninput_items[0]);
-                consume_each(ninput_items[0]);
-                acquisition_message = 2;
-                this->message_port_pub(pmt::mp("events"), pmt::from_long(acquisition_message));
-                break;
-            }
+        case 0:
+            begin_search();
+            return 0;
+        case 1:
+            fill_block(in, offered);
+            return 0;
+        case 2:
+            search_block(in);
+            return 0;
+        case 3:
+            return report(true, offered, output_items);
+        case 4:
+            return report(false, offered, output_items);
+        default:
+            return 0;
         }
-    return return_value;
+}
+
+
+void galileo_e5a_noncoherentIQ_acquisition_caf_hip::pass_by(int offered)
+{
+    d_sample_counter += static_cast<uint64_t>(offered);
+    consume_each(offered);
+}
+
+
+// state 0 (e5a.cc:262-274): a fresh search -- the synchro's acquisition fields cleared, the detector's dwell counters reset; nothing is consumed in this call
+void galileo_e5a_noncoherentIQ_acquisition_caf_hip::begin_search()
+{
+    d_gnss_synchro->Acq_delay_samples = 0.0;
+    d_gnss_synchro->Acq_doppler_hz = 0.0;
+    d_gnss_synchro->Acq_samplestamp_samples = 0ULL;
+    d_gnss_synchro->Acq_doppler_step = 0U;
+    d_core.init();
+    d_state = 1;
+}
+
+
+// state 1 (e5a.cc:276-298): samples go into the block buffer, as many as fit.  The hand-over to the search is decided on the fill level the buffer had BEFORE
+// this call: once less than one scheduler buffer (d_gr_stream_buffer) was missing, the next call is the search, which tops the block up from its own input.
+void galileo_e5a_noncoherentIQ_acquisition_caf_hip::fill_block(const gr_complex* in, int offered)
+{
+    const int taken = std::min(offered, d_fft_size - d_buffer_count);
+    const bool search_next = d_buffer_count >= static_cast<int>(d_fft_size - d_gr_stream_buffer);
+    std::copy_n(in, taken, d_inbuffer.begin() + d_buffer_count);
+    d_buffer_count += taken;
+    d_sample_counter += static_cast<uint64_t>(taken);
+    consume_each(taken);
+    if (search_next) d_state = 2;
+}
+
+
+// state 2 (e5a.cc:300-670): the block is completed from the head of the input and searched -- on the GPU.  The core answers with the next state (1: another
+// dwell, 3 / 4: positive / negative) and has filled its result record wherever the reference block writes the Gnss_Synchro (e5a.cc:506-514, :634-636).
+void galileo_e5a_noncoherentIQ_acquisition_caf_hip::search_block(const gr_complex* in)
+{
+    const int missing = d_fft_size - d_buffer_count;
+    if (missing > 0) std::copy_n(in, missing, d_inbuffer.begin() + d_buffer_count);
+    d_sample_counter += static_cast<uint64_t>(missing);
+    const int next = d_core.work(d_sample_counter, d_inbuffer.data());
+    if (next < 0)
+        {
+            // the engine failed (the error is in d_core.last_error()): report a negative acquisition instead of running on stale values
+            std::cerr << "galileo_e5a_noncoherentIQ_acquisition_caf_hip: " << d_core.last_error() << '\n';
+            d_state = 4;
+        }
+    else
+        {
+            const Hip_Detector_Result& r = d_core.result();
+            d_gnss_synchro->Acq_delay_samples = r.Acq_delay_samples;
+            d_gnss_synchro->Acq_doppler_hz = r.Acq_doppler_hz;
+            d_gnss_synchro->Acq_samplestamp_samples = r.Acq_samplestamp_samples;
+            d_gnss_synchro->Acq_doppler_step = r.Acq_doppler_step;
+            d_state = next;
+        }
+    consume_each(missing);
+    d_buffer_count = 0;
+}
+
+
+// states 3 and 4 (e5a.cc:672-731): the verdict goes out on "events" (1 = ACQ_SUCCESS, 2 = ACQ_FAIL), the block goes idle, the call's whole input is consumed;
+// a positive verdict also leaves the synchro on the monitor output when that is enabled.  Returns the items produced.
+int galileo_e5a_noncoherentIQ_acquisition_caf_hip::report(bool positive, int offered, gr_vector_void_star& output_items)
+{
+    d_active = false;
+    d_state = 0;
+    this->message_port_pub(pmt::mp("events"), pmt::from_long(positive ? 1 : 2));
+    pass_by(offered);
+    if (!positive || !d_enable_monitor_output) return 0;
+    auto** out = reinterpret_cast<Gnss_Synchro**>(&output_items[0]);
+    *out[0] = *d_gnss_synchro;
+    return 1;
 }
 
 

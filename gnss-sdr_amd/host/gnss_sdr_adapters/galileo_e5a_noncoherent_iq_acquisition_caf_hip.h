@@ -57,6 +57,13 @@ private:
     galileo_e5a_noncoherentIQ_acquisition_caf_hip(const Hip_Acq_Conf& conf, bool enable_monitor_output, bool both_signal_components_, int CAF_window_hz_,
         int Zero_padding_, int device);
 
+    // the steps of general_work (states of e5a.cc:240-733)
+    void pass_by(int offered);
+    void begin_search();
+    void fill_block(const gr_complex* in, int offered);
+    void search_block(const gr_complex* in);
+    int report(bool positive, int offered, gr_vector_void_star& output_items);
+
     Hip_Galileo_E5a_Noncoherent_Iq_Core d_core;
     std::vector<std::complex<float>> d_inbuffer;
     std::weak_ptr<ChannelFsm> d_channel_fsm;

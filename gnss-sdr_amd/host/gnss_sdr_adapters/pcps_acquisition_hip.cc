@@ -199,23 +199,19 @@ void pcps_acquisition_hip::set_state(int32_t state)
 }
 
 
-void pcps_acquisition_hip::run_dwell(uint64_t sample_count)
+// The dwell runs with d_setlock released (it waits for the GPU; setters from the control thread must get through meanwhile), so everything it needs of the
+// block's shared-window state is handed over as it stood under the lock: the runtime is held by the caller's own reference for the duration (set_local_code may
+// drop the block's), and the slot / window / "this window is a shared one" values cannot change under its feet.
+void pcps_acquisition_hip::run_dwell(uint64_t sample_count, const std::shared_ptr<Hip_Acquisition_Runtime>& runtime, int slot, uint64_t window, bool shared_dwell)
 {
     Hip_Pcps_Acquisition_Core::AcquisitionResult result;
     const bool was_step_two = d_core.step_two();
     Hip_Pcps_Acquisition_Core::Outcome outcome;
-    if (d_shared_dwell && d_runtime && !d_core.next_dwell_is_shareable())
-        {
-            // something changed while the window was buffered (set_doppler_center ...): this dwell is the block's own after all
-            d_runtime->withdraw(d_slot);
-            d_shared_dwell = false;
-        }
-    if (d_shared_dwell && d_runtime)
+    if (shared_dwell && runtime)
         {
             // every channel that buffered this window joins one batch: the Doppler-wiped forward transforms are computed once for all of them
             gsh_acq_result r{};
-            const bool ok = d_runtime->dwell(d_slot, d_window, d_data_buffer.data(), &r);
-            d_shared_dwell = false;
+            const bool ok = runtime->dwell(slot, window, d_data_buffer.data(), &r);
             outcome = d_core.acquisition_core_shared(sample_count, ok, r, &result);
         }
     else
@@ -328,8 +324,20 @@ int pcps_acquisition_hip::general_work(int /*noutput_items*/, gr_vector_int& nin
     else
         {
             const uint64_t stamp = d_sample_count;
+            // (decided and recorded under the lock: is this buffered window still one of a shared batch?)
+            const std::shared_ptr<Hip_Acquisition_Runtime> runtime = d_runtime;
+            const int slot = d_slot;
+            const uint64_t window = d_window;
+            bool shared = d_shared_dwell && runtime;
+            if (shared && !d_core.next_dwell_is_shareable())
+                {
+                    // something changed while the window was buffered (set_doppler_center ...): this dwell is the block's own after all
+                    runtime->withdraw(slot);
+                    shared = false;
+                }
+            d_shared_dwell = false;
             lk.unlock();
-            run_dwell(stamp);
+            run_dwell(stamp, runtime, slot, window, shared);
             consume_each(0);
         }
     return 0;

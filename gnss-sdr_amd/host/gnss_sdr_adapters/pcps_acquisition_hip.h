@@ -72,7 +72,7 @@ public:
 private:
     friend pcps_acquisition_hip_sptr pcps_make_acquisition_hip(const Hip_Acq_Conf& conf, int device, bool blocking_on_standby, std::shared_ptr<Hip_Acquisition_Runtime> runtime);
     pcps_acquisition_hip(const Hip_Acq_Conf& conf, int device, bool blocking_on_standby, std::shared_ptr<Hip_Acquisition_Runtime> runtime);
-    void run_dwell(uint64_t sample_count);
+    void run_dwell(uint64_t sample_count, const std::shared_ptr<Hip_Acquisition_Runtime>& runtime, int slot, uint64_t window, bool shared_dwell);
     void leave_shared_window();
 
     // channels of one stream that search at the same time share their dwell batches (hip_acquisition_runtime.h); nullptr: every dwell on d_core's own handle

@@ -4,6 +4,7 @@
  */
 #include "hip_correlator_runtime.h"
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 
@@ -11,6 +12,7 @@
 Hip_Sample_Ring::Hip_Sample_Ring(int device, uint64_t capacity_samples, uint32_t max_window_samples)
     : d_device(device), d_capacity(capacity_samples), d_max_window(max_window_samples)
 {
+    d_devices.assign(1, device);
     if (gsh_stream_create(device, capacity_samples, max_window_samples, &d_handle) != GSH_OK)
         {
             d_error = gsh_last_error();
@@ -19,10 +21,89 @@ Hip_Sample_Ring::Hip_Sample_Ring(int device, uint64_t capacity_samples, uint32_t
 }
 
 
+Hip_Sample_Ring::Hip_Sample_Ring(const std::vector<int>& devices, uint64_t capacity_samples, uint32_t max_window_samples)
+    : d_device(devices.empty() ? 0 : devices[0]), d_capacity(capacity_samples), d_max_window(max_window_samples)
+{
+    d_devices = devices;
+    if (devices.size() <= 1)
+        {
+            if (gsh_stream_create(d_device, capacity_samples, max_window_samples, &d_handle) != GSH_OK)
+                {
+                    d_error = gsh_last_error();
+                    d_handle = nullptr;
+                }
+            return;
+        }
+    // scatter + all-gather uses every xGMI link of the ingest GPU at once (csrc/stream_group.hip); GSH_GROUP_MODE=broadcast: ncclBroadcast
+    const char* m = std::getenv("GSH_GROUP_MODE");
+    const int mode = (m != nullptr && std::string(m) == "broadcast") ? GSH_GROUP_BROADCAST : GSH_GROUP_SCATTER_ALLGATHER;
+    if (gsh_stream_group_create(devices.data(), static_cast<int>(devices.size()), capacity_samples, max_window_samples, mode, &d_group) != GSH_OK)
+        {
+            d_error = gsh_last_error();
+            d_group = nullptr;
+            return;
+        }
+    d_handle = gsh_stream_group_ring(d_group, 0);
+}
+
+
 Hip_Sample_Ring::~Hip_Sample_Ring()
 {
-    if (d_handle != nullptr) gsh_stream_destroy(d_handle);  // waits for the ring's queued copies
+    if (d_group != nullptr)
+        gsh_stream_group_destroy(d_group);  // (the rings are the group's)
+    else if (d_handle != nullptr)
+        gsh_stream_destroy(d_handle);  // waits for the ring's queued copies
     for (void* p : d_registered) (void)gsh_host_unregister(p);
+    for (auto& b : d_stage)
+        if (!b.empty()) (void)gsh_host_unregister(b.data());
+}
+
+
+gsh_stream_t* Hip_Sample_Ring::handle_for(int device) const
+{
+    if (d_group == nullptr) return device == d_device ? d_handle : nullptr;
+    for (size_t i = 0; i < d_devices.size(); i++)
+        if (d_devices[i] == device) return gsh_stream_group_ring(d_group, static_cast<int>(i));
+    return nullptr;
+}
+
+
+// d_mutex held.  Page-locked items: the DMA engine (or, in a group, the copy to the ingest GPU) reads them where they lie; the caller waits with
+// wait_copied_upto before it hands the memory back.
+int Hip_Sample_Ring::append_pinned(const std::complex<float>* items, uint64_t n, uint64_t* first)
+{
+    if (d_group == nullptr) return gsh_stream_push_pinned_async(d_handle, items, n, GSH_ITEM_GR_COMPLEX, 0, first);
+    return gsh_stream_group_push(d_group, items, n, GSH_ITEM_GR_COMPLEX, 0, first);
+}
+
+
+// d_mutex held.  Anything else goes through a page-locked copy: the ring's own (gsh_stream_push_staged), or -- in a group -- one of four buffers here, each
+// re-used once the append that read it last has reached the ring.
+int Hip_Sample_Ring::append_pageable(const std::complex<float>* items, uint64_t n, uint64_t* first)
+{
+    if (d_group == nullptr) return gsh_stream_push_staged(d_handle, items, n, GSH_ITEM_GR_COMPLEX, 0, first);
+    const int slot = d_stage_next;
+    d_stage_next = (d_stage_next + 1) % NSTAGE;
+    if (d_stage_end[slot] != 0)
+        {
+            const int rc = gsh_stream_wait_copied_upto(d_handle, d_stage_end[slot], nullptr);
+            if (rc != GSH_OK) return rc;
+        }
+    if (d_stage[slot].size() < n)
+        {
+            if (!d_stage[slot].empty()) (void)gsh_host_unregister(d_stage[slot].data());
+            d_stage[slot].assign(static_cast<size_t>(n + n / 2), std::complex<float>());
+            (void)gsh_host_register(d_device, d_stage[slot].data(), d_stage[slot].size() * sizeof(std::complex<float>));  // (best effort: an unregistered buffer is copied by the runtime's own staging)
+        }
+    std::memcpy(d_stage[slot].data(), items, static_cast<size_t>(n) * sizeof(std::complex<float>));
+    uint64_t at = 0;
+    const int rc = gsh_stream_group_push(d_group, d_stage[slot].data(), n, GSH_ITEM_GR_COMPLEX, 0, &at);
+    if (rc == GSH_OK)
+        {
+            d_stage_end[slot] = at + n;
+            if (first != nullptr) *first = at;
+        }
+    return rc;
 }
 
 
@@ -80,7 +161,9 @@ uint64_t Hip_Sample_Ring::push_items(const void* items, uint64_t n, int item_typ
     uint64_t first = 0;
     {
         std::lock_guard<std::mutex> lk(d_mutex);
-        if (gsh_stream_push(d_handle, items, n, item_type, inverted_spectrum ? 1 : 0, &first) != GSH_OK)
+        const int rc = d_group == nullptr ? gsh_stream_push(d_handle, items, n, item_type, inverted_spectrum ? 1 : 0, &first)
+                                          : gsh_stream_group_push(d_group, items, n, item_type, inverted_spectrum ? 1 : 0, &first);
+        if (rc != GSH_OK || (d_group != nullptr && gsh_stream_group_wait(d_group) != GSH_OK))  // (`items` is the caller's again on return)
             {
                 d_error = gsh_last_error();
                 return UINT64_MAX;
@@ -117,7 +200,7 @@ bool Hip_Sample_Ring::push_from(uint64_t first_index, const std::complex<float>*
                 if (next == oldest || may_seek)
                     {
                         // an empty ring starts wherever its first user is; a ring nobody reads any more follows the caller
-                        if (gsh_stream_seek(d_handle, first_index) != GSH_OK)
+                        if (seek_locked(first_index) != GSH_OK)
                             {
                                 d_error = gsh_last_error();
                                 return false;
@@ -147,7 +230,7 @@ bool Hip_Sample_Ring::push_from(uint64_t first_index, const std::complex<float>*
         if (count > d_capacity)
             {
                 from += count - d_capacity;
-                if (gsh_stream_seek(d_handle, first_index + from) != GSH_OK)
+                if (seek_locked(first_index + from) != GSH_OK)
                     {
                         d_error = gsh_last_error();
                         return false;
@@ -167,15 +250,14 @@ bool Hip_Sample_Ring::push_from(uint64_t first_index, const std::complex<float>*
                 uintptr_t end = piece_end_locked(at);
                 if (end == 0 && d_auto_register)
                     {
-                        // a new stretch of the caller's buffer: lock a generous look-ahead (the scheduler's buffer is one mapping, the next calls show
-                        // the addresses right behind), and only what this call shows when that reaches past the mapping
-                        constexpr uintptr_t PAGE = 4096, AHEAD = 4u << 20;
+                        // a new stretch of the caller's buffer: page-lock what this call shows, and nothing beyond it -- the addresses behind it may belong to
+                        // another mapping altogether.  A scheduler's buffer is the same memory for the whole run: after its first pass everything is registered.
+                        constexpr uintptr_t PAGE = 4096;
                         const uintptr_t lo = at & ~(PAGE - 1), need_hi = (at + left * sizeof(std::complex<float>) + PAGE - 1) & ~(PAGE - 1);
-                        uintptr_t cap_hi = lo + AHEAD;
+                        uintptr_t hi = need_hi;
                         for (const auto& r : d_pinned)
-                            if (r.first > at) cap_hi = std::min(cap_hi, r.first);  // up to the next piece
-                        if (!(cap_hi > need_hi && register_locked(lo, cap_hi)) && !register_locked(lo, std::min(need_hi, std::max(cap_hi, lo + PAGE))))
-                            d_auto_register = false;  // memory that cannot be registered: stop trying, use the staging copy
+                            if (r.first > at) hi = std::min(hi, r.first);  // up to the next piece
+                        if (!register_locked(lo, std::max(hi, lo + PAGE))) d_auto_register = false;  // memory that cannot be registered: stop trying, use the staging copy
                         end = piece_end_locked(at);
                     }
                 uint64_t chunk = left;
@@ -187,7 +269,7 @@ bool Hip_Sample_Ring::push_from(uint64_t first_index, const std::complex<float>*
                 if (end != 0)
                     {
                         // queued only: the wait for the DMA happens below, with the ring's lock released
-                        rc_push = gsh_stream_push_pinned_async(d_handle, cur, chunk, GSH_ITEM_GR_COMPLEX, 0, &first_piece);
+                        rc_push = append_pinned(cur, chunk, &first_piece);
                         dma_queued = dma_queued || rc_push == GSH_OK;
                     }
                 else
@@ -196,7 +278,7 @@ bool Hip_Sample_Ring::push_from(uint64_t first_index, const std::complex<float>*
                         chunk = left;
                         for (const auto& r : d_pinned)
                             if (r.first > at) { chunk = std::min<uint64_t>(chunk, (r.first - at + sizeof(std::complex<float>) - 1) / sizeof(std::complex<float>)); break; }
-                        rc_push = gsh_stream_push_staged(d_handle, cur, chunk, GSH_ITEM_GR_COMPLEX, 0, &first_piece);
+                        rc_push = append_pageable(cur, chunk, &first_piece);
                     }
                 if (done_items == 0) first = first_piece;
                 if (rc_push == GSH_OK) done_items += chunk;
@@ -245,11 +327,25 @@ bool Hip_Sample_Ring::wait_copied_upto(uint64_t end)
 }
 
 
+// position every ring of the stream (d_mutex held)
+int Hip_Sample_Ring::seek_locked(uint64_t next_index)
+{
+    if (d_group == nullptr) return gsh_stream_seek(d_handle, next_index);
+    for (int i = 0; i < gsh_stream_group_size(d_group); i++)
+        {
+            const int rc = gsh_stream_seek(gsh_stream_group_ring(d_group, i), next_index);
+            if (rc != GSH_OK) return rc;
+        }
+    for (uint64_t& e : d_stage_end) e = 0;  // (a seek waits for everything queued)
+    return GSH_OK;
+}
+
+
 bool Hip_Sample_Ring::seek(uint64_t next_index)
 {
     if (d_handle == nullptr) return false;
     std::lock_guard<std::mutex> lk(d_mutex);
-    if (gsh_stream_seek(d_handle, next_index) != GSH_OK)
+    if (seek_locked(next_index) != GSH_OK)
         {
             d_error = gsh_last_error();
             return false;

@@ -41,6 +41,11 @@ public:
     /*! capacity_samples: how much of the stream stays resident; max_window_samples: longest correlation window (2 * vector_length
         covers dll_pll_veml_tracking's forecast, trk.cc:747-754) */
     Hip_Sample_Ring(int device, uint64_t capacity_samples, uint32_t max_window_samples);
+    /*! The same stream in SEVERAL GPUs of the node (channels shard over them): one ring per device, kept identical by the engine's
+        stream group (gsh_stream_group_*: every appended block enters devices[0] over PCIe ONCE and is replicated to the others over RCCL / xGMI).
+        To its users this is still one ring -- one lock, one index space, one push_from that de-duplicates across the blocks of all devices --;
+        whoever binds a device handle to it asks for that device's ring with handle_for().  One device: exactly the constructor above. */
+    Hip_Sample_Ring(const std::vector<int>& devices, uint64_t capacity_samples, uint32_t max_window_samples);
     ~Hip_Sample_Ring();
     Hip_Sample_Ring(const Hip_Sample_Ring&) = delete;
     Hip_Sample_Ring& operator=(const Hip_Sample_Ring&) = delete;
@@ -92,10 +97,24 @@ public:
     /*! blocks until sample index `end` has been pushed (next >= end) or the timeout expires */
     bool wait_for(uint64_t end, std::chrono::milliseconds timeout) const;
     gsh_stream_t* handle() const { return d_handle; }
+    /*! the ring that lives on `device` (nullptr when the stream is not resident there) */
+    gsh_stream_t* handle_for(int device) const;
+    const std::vector<int>& devices() const { return d_devices; }
     int device() const { return d_device; }
 
 private:
     uint64_t push_items(const void* items, uint64_t n, int item_type, bool inverted_spectrum);
+    // the two ways complex64 items reach the ring(s) from push_from (d_mutex held): out of page-locked memory as it lies, or through a page-locked copy
+    int append_pinned(const std::complex<float>* items, uint64_t n, uint64_t* first);
+    int append_pageable(const std::complex<float>* items, uint64_t n, uint64_t* first);
+    int seek_locked(uint64_t next_index);
+    gsh_stream_group_t* d_group{nullptr};  // several devices: the rings belong to it (d_handle = the ingest device's)
+    std::vector<int> d_devices;
+    // group mode: page-locked staging of our own for items that are not (the group's copy to the ingest GPU reads the caller's memory asynchronously)
+    static constexpr int NSTAGE = 4;
+    std::vector<std::complex<float>> d_stage[NSTAGE];
+    uint64_t d_stage_end[NSTAGE]{};  // absolute index behind the append that last used the buffer
+    int d_stage_next{0};
     gsh_stream_t* d_handle{nullptr};
     int d_device{0};
     uint64_t d_capacity{0};

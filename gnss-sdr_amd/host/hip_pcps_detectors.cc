@@ -704,73 +704,67 @@ void Hip_Galileo_E5a_Noncoherent_Iq_Core::init()
 }
 
 
-// e5a.cc:546-631, expression for expression (the float / double mix decides the last bits of the normalisations)
+// The CAF stage of the E5a detector (galileo_e5a_noncoherent_iq_acquisition_caf_cc.cc:546-631, "e5a.cc"): the per-bin maxima of the I (and Q) searches are
+// smoothed along the Doppler axis before the peak is taken -- every bin becomes a triangle-weighted mean of the bins within +-H of it, H = CAF_window_hz /
+// (2 doppler_step), weight 1 - |distance| / (2 H), the window cut off at the ends of the grid.  Restated here as ONE windowed mean evaluated over three stretches of
+// the grid (leading edge, interior, trailing edge); what differs between the stretches -- and between the I and Q profiles -- is kept exactly, because the float
+// results are pinned to the reference block's (tests/detector_cases.py):
+//   * distance with or without its sign: the reference drops the sign only in some of its loops; where it keeps it, the bins above the centre weigh MORE than 1;
+//   * the normaliser (the sum of the weights the window would have with unsigned distances), each with its own association of the float operations, and the
+//     trailing edge's Q normaliser partly in double.
 void Hip_Galileo_E5a_Noncoherent_Iq_Core::caf_filter()
 {
-    const int num_bins = static_cast<int>(d_num_doppler_bins);
-    const int CAF_bins_half = d_CAF_window_hz / (2 * d_acq_params.doppler_step);
-    const float weighting_factor = 0.5F / static_cast<float>(CAF_bins_half);
-    float accum;
-    // Initialize first iterations
-    for (int doppler_index = 0; doppler_index < CAF_bins_half; doppler_index++)
+    const int bins = static_cast<int>(d_num_doppler_bins);
+    const int H = d_CAF_window_hz / (2 * d_acq_params.doppler_step);
+    const float Hf = static_cast<float>(H);
+    const float w = 0.5F / Hf;
+
+    // sum over bins [lo, hi) of profile[i] * weight(centre, i), accumulated in float in index order
+    auto windowed_sum = [w](const std::vector<float>& profile, int centre, int lo, int hi, bool unsigned_distance) {
+        float sum = 0.0F;
+        for (int i = lo; i < hi; i++)
+            {
+                const int distance = unsigned_distance ? std::abs(centre - i) : (centre - i);
+                sum += profile[static_cast<size_t>(i)] * (1.0F - w * static_cast<float>(distance));
+            }
+        return sum;
+    };
+    // one output bin: the I mean, plus the Q mean when both components are searched
+    auto smooth = [&](int centre, int lo, int hi, bool unsigned_I, bool unsigned_Q, float norm_I, float norm_Q) {
+        float value = windowed_sum(d_CAF_vector_I, centre, lo, hi, unsigned_I);
+        value /= norm_I;
+        if (d_both_signal_components)
+            {
+                float q = windowed_sum(d_CAF_vector_Q, centre, lo, hi, unsigned_Q);
+                q /= norm_Q;
+                value += q;
+            }
+        d_CAF_vector[static_cast<size_t>(centre)] = value;
+    };
+
+    // leading edge: the window starts at bin 0 (e5a.cc:551-571).  I keeps the sign of the distance, Q does not.
+    for (int c = 0; c < H; c++)
         {
-            d_CAF_vector[doppler_index] = 0;
-            for (int i = 0; i < CAF_bins_half + doppler_index + 1; i++)
-                {
-                    d_CAF_vector[doppler_index] += d_CAF_vector_I[i] * (1.0F - weighting_factor * static_cast<float>((doppler_index - i)));
-                }
-            d_CAF_vector[doppler_index] /= 1.0F + static_cast<float>(CAF_bins_half + doppler_index) - weighting_factor * static_cast<float>(CAF_bins_half) * ((static_cast<float>(CAF_bins_half) + 1.0F) / 2.0F) - weighting_factor * static_cast<float>(doppler_index) * (static_cast<float>(doppler_index) + 1.0F) / 2.0F;
-            if (d_both_signal_components)
-                {
-                    accum = 0;
-                    for (int i = 0; i < CAF_bins_half + doppler_index + 1; i++)
-                        {
-                            accum += d_CAF_vector_Q[i] * (1.0F - weighting_factor * static_cast<float>(std::abs(doppler_index - i)));
-                        }
-                    accum /= 1.0F + static_cast<float>(CAF_bins_half + doppler_index) - weighting_factor * static_cast<float>(CAF_bins_half) * static_cast<float>(CAF_bins_half + 1) / 2.0F - weighting_factor * static_cast<float>(doppler_index) * static_cast<float>(doppler_index + 1) / 2.0F;
-                    d_CAF_vector[doppler_index] += accum;
-                }
+            const float cf = static_cast<float>(c);
+            const float norm_I = 1.0F + static_cast<float>(H + c) - w * Hf * ((Hf + 1.0F) / 2.0F) - w * cf * (cf + 1.0F) / 2.0F;
+            const float norm_Q = 1.0F + static_cast<float>(H + c) - w * Hf * static_cast<float>(H + 1) / 2.0F - w * cf * static_cast<float>(c + 1) / 2.0F;
+            smooth(c, 0, H + c + 1, false, true, norm_I, norm_Q);
         }
-    // Body loop
-    for (int doppler_index = CAF_bins_half; doppler_index < num_bins - CAF_bins_half; doppler_index++)
+    // interior: the whole window fits (e5a.cc:573-591).  Both profiles keep the sign; one normaliser for every bin.
+    {
+        const float norm = 1.0F + 2.0F * Hf - 2.0F * w * Hf * static_cast<float>(H + 1) / 2.0F;
+        for (int c = H; c < bins - H; c++) smooth(c, c - H, c + H + 1, false, false, norm, norm);
+    }
+    // trailing edge: the window ends with the grid (e5a.cc:593-613).  Unsigned distances; the Q normaliser's two halved terms are halved in double.
+    for (int c = bins - H; c < bins; c++)
         {
-            d_CAF_vector[doppler_index] = 0;
-            for (int i = doppler_index - CAF_bins_half; i < doppler_index + CAF_bins_half + 1; i++)
-                {
-                    d_CAF_vector[doppler_index] += d_CAF_vector_I[i] * (1.0F - weighting_factor * static_cast<float>((doppler_index - i)));
-                }
-            d_CAF_vector[doppler_index] /= 1.0F + 2.0F * static_cast<float>(CAF_bins_half) - 2.0F * weighting_factor * static_cast<float>(CAF_bins_half) * static_cast<float>(CAF_bins_half + 1) / 2.0F;
-            if (d_both_signal_components)
-                {
-                    accum = 0;
-                    for (int i = doppler_index - CAF_bins_half; i < doppler_index + CAF_bins_half + 1; i++)
-                        {
-                            accum += d_CAF_vector_Q[i] * (1 - weighting_factor * static_cast<float>((doppler_index - i)));
-                        }
-                    accum /= 1.0F + 2.0F * static_cast<float>(CAF_bins_half) - 2.0F * weighting_factor * static_cast<float>(CAF_bins_half) * static_cast<float>(CAF_bins_half + 1) / 2.0F;
-                    d_CAF_vector[doppler_index] += accum;
-                }
-        }
-    // Final iterations
-    for (int doppler_index = num_bins - CAF_bins_half; doppler_index < num_bins; doppler_index++)
-        {
-            if (doppler_index < 0) continue;  // (a window wider than the grid: the reference indexes out of bounds here)
-            d_CAF_vector[doppler_index] = 0;
-            for (int i = doppler_index - CAF_bins_half; i < num_bins; i++)
-                {
-                    d_CAF_vector[doppler_index] += d_CAF_vector_I[i] * (1.0F - weighting_factor * static_cast<float>(std::abs(doppler_index - i)));
-                }
-            d_CAF_vector[doppler_index] /= 1.0F + static_cast<float>(CAF_bins_half) + static_cast<float>(num_bins - doppler_index - 1) - weighting_factor * static_cast<float>(CAF_bins_half) * (static_cast<float>(CAF_bins_half) + 1.0F) / 2.0F - weighting_factor * (num_bins - doppler_index - 1) * static_cast<float>(num_bins - doppler_index) / 2.0F;
-            if (d_both_signal_components)
-                {
-                    accum = 0;
-                    for (int i = doppler_index - CAF_bins_half; i < num_bins; i++)
-                        {
-                            accum += d_CAF_vector_Q[i] * (1.0F - weighting_factor * static_cast<float>(std::abs(doppler_index - i)));
-                        }
-                    accum /= static_cast<float>(1.0F + static_cast<float>(CAF_bins_half) + static_cast<float>(num_bins - doppler_index - 1) - weighting_factor * static_cast<float>(CAF_bins_half) * static_cast<float>(CAF_bins_half + 1.0) / 2.0 - weighting_factor * static_cast<float>(num_bins - doppler_index - 1) * static_cast<float>(num_bins - doppler_index) / 2.0);
-                    d_CAF_vector[doppler_index] += accum;
-                }
+            if (c < 0) continue;  // (a window wider than the grid: the reference indexes out of bounds here)
+            const int beyond = bins - c - 1;  // bins of the window above the centre
+            const float norm_I = 1.0F + Hf + static_cast<float>(beyond) - w * Hf * (Hf + 1.0F) / 2.0F - w * static_cast<float>(beyond) * static_cast<float>(bins - c) / 2.0F;
+            const float whole = 1.0F + Hf + static_cast<float>(beyond);
+            const float norm_Q = static_cast<float>(static_cast<double>(whole) - static_cast<double>(w * Hf * static_cast<float>(H + 1.0)) / 2.0 -
+                                                    static_cast<double>(w * static_cast<float>(beyond) * static_cast<float>(bins - c)) / 2.0);
+            smooth(c, c - H, bins, true, true, norm_I, norm_Q);
         }
 }
 

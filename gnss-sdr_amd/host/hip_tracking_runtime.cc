@@ -64,9 +64,11 @@ Hip_Tracking_Runtime::Group* Hip_Tracking_Runtime::group_for(const gsh_trk_conf&
             d_error = std::string("gsh_trk_create: ") + gsh_last_error();
             return nullptr;
         }
-    if (gsh_trk_set_stream_ring(g->trk, d_ring->handle()) != GSH_OK)
+    // (a stream that is resident in several GPUs -- Hip_Sample_Ring over a stream group -- has one ring per device: this runtime's)
+    if (d_ring->handle_for(d_device) == nullptr || gsh_trk_set_stream_ring(g->trk, d_ring->handle_for(d_device)) != GSH_OK)
         {
-            d_error = std::string("gsh_trk_set_stream_ring: ") + gsh_last_error();
+            d_error = d_ring->handle_for(d_device) == nullptr ? "the sample ring is not resident on device " + std::to_string(d_device)
+                                                               : std::string("gsh_trk_set_stream_ring: ") + gsh_last_error();
             gsh_trk_destroy(g->trk);
             return nullptr;
         }
@@ -451,18 +453,18 @@ void Hip_Tracking_Runtime::ensure_live(Group* g, bool wait_for_handle)
 
 int Hip_Tracking_Runtime::take_live(Slot& S, uint64_t limit_end, int max_records, gsh_trk_epoch* out)
 {
-    std::lock_guard<std::mutex> tl(S.take_mutex);  // (uncontended: start / stop of this very channel are the only other takers)
+    std::unique_lock<std::mutex> tl(S.take_mutex);  // (uncontended: start / stop of this very channel are the only other takers)
     Group* g = S.group;
-    if (!S.live_tracking.load(std::memory_order_acquire))
-        {
-            std::lock_guard<std::mutex> lk(d_mutex);
-            return (S.used && S.error.empty()) ? 0 : -1;
-        }
     const uint64_t vlen = g->conf.vector_length;
     int64_t t_wait = 0, t_deadline = 0;
     bool asked_blocking = false;
     for (;;)
         {
+            if (!S.live_tracking.load(std::memory_order_acquire))  // (looked at again after every wait: stop may have come in between)
+                {
+                    std::lock_guard<std::mutex> lk(d_mutex);
+                    return (S.used && S.error.empty()) ? 0 : -1;
+                }
             int32_t n = 0, pending = 0, active = 0, resident = 0;
             uint64_t nw = 0;
             if (gsh_trk_live_take(g->trk, S.channel, limit_end, max_records, out, &n, &pending, &nw, &active, &resident) != GSH_OK)
@@ -534,7 +536,9 @@ int Hip_Tracking_Runtime::take_live(Slot& S, uint64_t limit_end, int max_records
                             // nobody could make sure of a residency in all that time: start / stop of another channel hold the group's handle (they quiesce the
                             // residencies and restart a channel -- milliseconds, more with a slow engine).  Queue behind them this once, then give the device its time.
                             asked_blocking = true;
+                            tl.unlock();  // (stop() of this channel takes the handle first and this slot's lock second: never wait for the handle with the slot held)
                             ensure_live(g, /*wait_for_handle=*/true);
+                            tl.lock();
                             t_deadline = now_ns() + 50000000;
                             continue;
                         }

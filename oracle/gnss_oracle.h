@@ -7,7 +7,7 @@
  * Parity status: PINNED.  Every function below is checked bit-for-bit
  * (integer/code outputs) or value-for-value (float32 outputs, exact equality)
  * against the reference's own sources compiled into oracle/_ref/ by
- * tests/test_oracle_vs_ref.py, and against the .npz files in tests/golden/ minted from
+ * tests/test_oracle_golden.py, and against the .npz files in tests/golden/ minted from
  * oracle/_ref (tests/golden/make_golden.py).
  *
  * All file:line citations are relative to /root/reference/.

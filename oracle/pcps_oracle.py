@@ -13,7 +13,7 @@ and index for index when the blocks run on an exact-definition float64 DFT inste
 What stays outside the reference tree is the transform itself: gr::fft::fft_complex_fwd/rev is FFTW3f (gnss_sdr_fft.h:26-61), not
 vendored, not installed; FFTW's float32 rounding is not reproduced by anybody here.  Peak INDICES -- what north_star requires
 bit-exact -- do not depend on it (asserted with two different transforms).  The in-tree kernels go through oracle_sincos /
-oracle_index_max (== the volk_gnsssdr `_generic` protokernels, bit-exact, tests/test_oracle_vs_ref.py); VOLK's element-wise kernels
+oracle_index_max (== the volk_gnsssdr `_generic` protokernels, bit-exact, tests/test_oracle_golden.py); VOLK's element-wise kernels
 are restated as their `_generic` definitions (cmul below).
 """
 from __future__ import annotations

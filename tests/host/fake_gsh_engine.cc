@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <mutex>
@@ -39,9 +40,15 @@ std::atomic<int> g_busy_handles{0};  // > 1 concurrent entries into one handle =
 
 struct gsh_stream
 {
+    int device{0};
     uint64_t capacity{0}, max_window{0};
     std::atomic<uint64_t> next{0}, origin{0};  // (atomic: live takes read them from the block threads while a push is in progress)
     std::atomic<int> inside{0};
+};
+
+struct gsh_stream_group
+{
+    std::vector<gsh_stream*> rings;
 };
 
 struct FakeChannel
@@ -72,6 +79,7 @@ struct FakeChannel
 
 struct gsh_trk
 {
+    int device{0};
     gsh_trk_conf conf{};
     int n_channels{0}, max_code_len{0};
     gsh_stream* ring{nullptr};
@@ -144,16 +152,25 @@ extern "C"
     uint64_t fake_gsh_push_mismatches(void) { return g_mismatch.load(); }
     int fake_gsh_concurrent_handle_entries(void) { return g_busy_handles.load(); }
 
-    int gsh_device_count(void) { return 1; }
+    // FAKE_GSH_DEVICES=N in the environment: the stand-in pretends to N devices (the multi-GPU layout of the adapters, exercised on the CPU)
+    int gsh_device_count(void)
+    {
+        static const int n = [] {
+            const char* e = std::getenv("FAKE_GSH_DEVICES");
+            return e != nullptr ? std::max(1, std::atoi(e)) : 1;
+        }();
+        return n;
+    }
 
     // ---- sample ring
     int gsh_stream_create(int device, uint64_t capacity_samples, uint32_t max_window_samples, gsh_stream_t** out)
     {
         if (out == nullptr) return gsh::set_error(GSH_ERR_INVALID, "null out pointer");
         *out = nullptr;
-        if (device != 0) return gsh::set_error(GSH_ERR_NO_DEVICE, "device %d out of range (0..0)", device);
+        if (device < 0 || device >= gsh_device_count()) return gsh::set_error(GSH_ERR_NO_DEVICE, "device %d out of range (0..%d)", device, gsh_device_count() - 1);
         if (max_window_samples < 1 || capacity_samples < 2ull * max_window_samples) return gsh::set_error(GSH_ERR_INVALID, "fake: bad ring geometry");
         auto* s = new gsh_stream();
+        s->device = device;
         s->capacity = capacity_samples + (capacity_samples & 1ull);
         s->max_window = max_window_samples;
         *out = s;
@@ -189,13 +206,63 @@ extern "C"
         return GSH_OK;
     }
 
+    // ---- the block-replication group (single process, several devices): one fake ring per device, every push lands in all of them -- and is checked
+    // against the reference stream in each (push_common)
+    int gsh_stream_group_create(const int* devices, int n_devices, uint64_t capacity_samples, uint32_t max_window_samples, int, gsh_stream_group_t** out)
+    {
+        if (out == nullptr || devices == nullptr || n_devices < 1) return gsh::set_error(GSH_ERR_INVALID, "fake: bad group arguments");
+        *out = nullptr;
+        auto* g = new gsh_stream_group();
+        for (int i = 0; i < n_devices; i++)
+            {
+                gsh_stream_t* s = nullptr;
+                if (gsh_stream_create(devices[i], capacity_samples, max_window_samples, &s) != GSH_OK)
+                    {
+                        gsh_stream_group_destroy(g);
+                        return GSH_ERR_NO_DEVICE;
+                    }
+                g->rings.push_back(s);
+            }
+        *out = g;
+        return GSH_OK;
+    }
+    void gsh_stream_group_destroy(gsh_stream_group_t* g)
+    {
+        if (g == nullptr) return;
+        for (gsh_stream* s : g->rings) delete s;
+        delete g;
+    }
+    int gsh_stream_group_size(const gsh_stream_group_t* g) { return g != nullptr ? static_cast<int>(g->rings.size()) : 0; }
+    gsh_stream_t* gsh_stream_group_ring(gsh_stream_group_t* g, int i) { return (g != nullptr && i >= 0 && i < static_cast<int>(g->rings.size())) ? g->rings[static_cast<size_t>(i)] : nullptr; }
+    int gsh_stream_group_push(gsh_stream_group_t* g, const void* host_items, uint64_t n, int item_type, int, uint64_t* first_index)
+    {
+        if (g == nullptr || g->rings.empty()) return gsh::set_error(GSH_ERR_INVALID, "null group");
+        uint64_t first = 0;
+        for (size_t i = 0; i < g->rings.size(); i++)
+            {
+                uint64_t f = 0;
+                const int rc = push_common(g->rings[i], host_items, n, item_type, &f);
+                if (rc != GSH_OK) return rc;
+                if (i == 0) first = f;
+                if (f != first)
+                    {
+                        g_mismatch++;
+                        std::fprintf(stderr, "FAKE ENGINE: the rings of a group have drifted apart (%llu vs %llu)\n", (unsigned long long)f, (unsigned long long)first);
+                    }
+            }
+        if (first_index) *first_index = first;
+        return GSH_OK;
+    }
+    int gsh_stream_group_wait(gsh_stream_group_t* g) { return g != nullptr ? GSH_OK : gsh::set_error(GSH_ERR_INVALID, "null group"); }
+
     // ---- tracking loop
     int gsh_trk_create(int device, const gsh_trk_conf* conf, int n_channels, int max_code_length, gsh_trk_t** out)
     {
         if (out == nullptr || conf == nullptr) return gsh::set_error(GSH_ERR_INVALID, "null argument");
         *out = nullptr;
-        if (device != 0) return gsh::set_error(GSH_ERR_NO_DEVICE, "device %d out of range (0..0)", device);
+        if (device < 0 || device >= gsh_device_count()) return gsh::set_error(GSH_ERR_NO_DEVICE, "device %d out of range (0..%d)", device, gsh_device_count() - 1);
         auto* t = new gsh_trk();
+        t->device = device;
         t->conf = *conf;
         t->n_channels = n_channels;
         t->max_code_len = max_code_length;
@@ -207,6 +274,7 @@ extern "C"
     int gsh_trk_set_stream_ring(gsh_trk_t* t, gsh_stream_t* s)
     {
         if (t == nullptr) return gsh::set_error(GSH_ERR_INVALID, "null handle");
+        if (s != nullptr && s->device != t->device) return gsh::set_error(GSH_ERR_INVALID, "the ring lives on device %d, the loop on device %d", s->device, t->device);
         if (s != nullptr && s->max_window < t->conf.vector_length)
             return gsh::set_error(GSH_ERR_INVALID, "the ring's max_window_samples %llu is shorter than vector_length %u", (unsigned long long)s->max_window, t->conf.vector_length);
         t->ring = s;

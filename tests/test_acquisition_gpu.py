@@ -30,13 +30,14 @@ def _bank(gpu, **kw):
 
 
 def _same_peak(res, ora, prec, tag):
-    """indices equal, or a documented float64 near-tie between the two candidates"""
+    """indices equal, or a documented float64 near-tie between the two candidates.  Returns True when the near-tie escape was taken."""
     if res["index_time"] == ora["index_time"] and res["index_doppler"] == ora["index_doppler"]:
-        return
+        return False
     g = prec.grid
     a = g[res["index_doppler"], res["index_time"]]
     b = g[ora["index_doppler"], ora["index_time"]]
     assert abs(a - b) <= 2e-5 * max(a, b), f"{tag}: peak index mismatch gpu={res} oracle={ora} (float64 values {a} vs {b})"
+    return True
 
 
 @pytest.mark.parametrize("n,consumed,fs,bt", [(4000, 4000, 4000000, False), (2048, 2048, 2048000, False),
@@ -167,10 +168,11 @@ def test_config3_32prn_41bins(gpu, path):
             acq.set_local_code(p, oracle.ca_code_complex_sampled(p + 1, fs))
         results = acq.dwell(x, 32)
         detected = 0
+        near_ties = 0
         for p in range(32):
             exp, prec = _cfg3_oracle(p, use_cfar, kw, x, fs)
             res = results[p]
-            _same_peak(res, exp, prec, f"prn {p + 1}")
+            near_ties += int(_same_peak(res, exp, prec, f"prn {p + 1}"))
             assert res["test_statistics"] == pytest.approx(exp["test_statistics"], rel=5e-3), (p, res, exp)
             if p < 8:
                 assert (res["index_time"], res["index_doppler"]) == (exp["index_time"], exp["index_doppler"]), (p, res, exp)
@@ -190,6 +192,9 @@ def test_config3_32prn_41bins(gpu, path):
                 assert p < 8 or res["test_statistics"] < thr, (p, res, thr)
         if use_cfar:
             assert detected >= 6, detected
+        # the noise-only PRNs may report another cell than the oracle where two cells of the float64 grid lie within 2e-5 of each other (_same_peak): how often
+        print(f"config3 path {path}, {'CFAR' if use_cfar else 'peak ratio'}: {near_ties} of 24 noise-only PRNs took the near-tie escape")
+        assert near_ties <= 1, near_ties
         acq.close()
 
 

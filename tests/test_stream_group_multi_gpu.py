@@ -28,6 +28,8 @@ def _n_devices() -> int:
 
 def _need_two():
     n = _n_devices()
+    if n < 2 and os.environ.get("GSH_TEST_GROUP_OF_ONE") == "1":
+        return n  # (self-test of the test code on a one-GPU box: a group of one exercises everything but the collective)
     if n < 2:
         pytest.skip(f"{n} HIP device(s) visible: the multi-GPU RCCL path needs at least two")
     return n
@@ -177,3 +179,128 @@ def test_one_process_per_gpu_group(gpu, mode):
                 pytest.fail(f"rank {r} ({mode}) did not finish")
             assert p.exitcode == 0, f"rank {r} ({mode}) exited with {p.exitcode}"
             assert open(f"{result_path}.{r}").read() == "ok", f"rank {r} ({mode})"
+
+
+def _trk_scenario(fs, n, epochs):
+    prns, dops, cphs = [5, 18, 9, 27], [-1900.0, 3300.0, 700.0, -3100.0], [100.0, 900.5, 333.0, 12.0]
+    total = (epochs + 3) * n
+    x = synth_gps_l1_stream(total, fs, prns, dops, cphs, cn0_dbhz=47.0, seed_noise=31)
+    x8 = np.clip(np.round(np.stack([x.real, x.imag], axis=1) * 25.0), -127, 127).astype(np.int8)
+    starts = [int(round((1023.0 - cph) / (1.023e6 * (1 + fd / 1575.42e6)) * fs)) for fd, cph in zip(dops, cphs)]
+    return prns, dops, starts, total, x8
+
+
+def _records_bytes(recs):
+    return b"".join(bytes(memoryview(r)) for r in recs)
+
+
+@pytest.mark.parametrize("live", [False, True])
+def test_closed_loops_on_every_ring_of_the_group_match_private_rings(gpu, live):
+    """SURVEY 8e for the path a receiver runs: the DLL/PLL loop closed on the device (gsh_trk_*), channel c on GPU c mod G, every GPU's loop bound to ITS ring of
+    the group -- launched after every replicated block, and as live residencies that follow the ring.  The records of every channel must equal, byte for byte, those
+    of the same channel on a private ring of the same GPU fed with the same items."""
+    n_dev = _need_two()
+    import time
+    from gnss_sdr_amd.sample_stream import SampleStream, StreamGroup
+    from gnss_sdr_amd.tracking_loop import TrackingLoop, trk_conf
+    fs, n, epochs = 4e6, 4000, 120
+    prns, dops, starts, total, x8 = _trk_scenario(fs, n, epochs)
+    devices = list(range(n_dev))
+    kw = dict(fs_in=fs, vector_length=n, pll_bw_hz=35.0, dll_bw_hz=3.0, enable_lock_detectors=1, pull_in_time_s=0)
+    cap, win = 40 * n, 2 * n
+    blk = 7 * n + 11
+
+    def run(rings, push, wait):
+        loops, chan_of = [], []
+        for i, d in enumerate(devices):
+            mine = [c for c in range(len(prns)) if c % n_dev == i]
+            lp = TrackingLoop(trk_conf(**kw), max(len(mine), 1), 1023, device=d)
+            lp.set_stream_ring(rings[i])
+            for k, c in enumerate(mine):
+                lp.start(k, oracle.ca_code(prns[c]), starts[c], 0, dops[c] + 6.0)
+            if live:
+                lp.live_configure(idle_timeout_us=200000, residency_us=2000000)
+            loops.append(lp)
+            chan_of.append(mine)
+        got = {c: [] for c in range(len(prns))}
+        pushed = 0
+        if live:
+            for lp in loops:
+                lp.live_begin()
+        while pushed < total:
+            m = min(blk, total - pushed)
+            push(x8[pushed:pushed + m], m)
+            pushed += m
+            if not live:
+                for i, lp in enumerate(loops):
+                    rec, done = lp.run(10)  # (no host wait between the collective and the launch that reads its result: the ring's events order them)
+                    for k, c in enumerate(chan_of[i]):
+                        got[c] += rec[k]
+            else:
+                want = {c: max(0, (pushed - starts[c]) // n - 1) for c in got}
+                t_end = time.time() + 5.0
+                while time.time() < t_end and any(len(got[c]) < want[c] for c in got):
+                    for i, lp in enumerate(loops):
+                        for k, c in enumerate(chan_of[i]):
+                            got[c] += lp.live_take(k, 64)[0]
+        if live:
+            for i, lp in enumerate(loops):
+                lp.live_quiesce()
+                for k, c in enumerate(chan_of[i]):
+                    got[c] += lp.live_take(k, 256)[0]
+        wait()
+        for lp in loops:
+            lp.close()
+        return got
+
+    g = StreamGroup.local(devices, cap, win, mode="scatter_allgather")
+    group_got = run([g.ring(i) for i in range(n_dev)], lambda a, m: g.push(a, m, "ibyte"), g.wait)
+    g.close()
+    priv = [SampleStream(cap, win, device=d) for d in devices]
+
+    def push_all(a, m):
+        for r in priv:
+            r.push(a, "ibyte")
+
+    priv_got = run(priv, push_all, lambda: None)
+    for c in range(len(prns)):
+        assert len(group_got[c]) >= epochs - 12, (c, len(group_got[c]))
+        assert _records_bytes(group_got[c]) == _records_bytes(priv_got[c]), f"channel {c} (device {c % n_dev}, live={live})"
+        assert abs(np.mean([r.carrier_doppler_hz for r in group_got[c][-40:]]) - dops[c]) < 3.0
+
+
+def test_acquisition_prn_shards_on_every_ring_of_the_group(gpu):
+    """"acquisition: PRN p -> GPU p mod G" -- every GPU searches its share of the PRNs over the SAME replicated block (gsh_acq_dwell_ring on its
+    ring of the group); results equal those of the same search over a private ring of that GPU, and the union finds every embedded satellite."""
+    n_dev = _need_two()
+    from gnss_sdr_amd.acquisition import PcpsAcquisitionBank
+    from gnss_sdr_amd.sample_stream import SampleStream, StreamGroup
+    fs, n = 4e6, 4000
+    sig_prns, dops, cphs = [3, 8, 14, 22, 30], [1500.0, -3250.0, 250.0, 4000.0, -750.0], [10.0, 444.0, 901.5, 77.0, 600.0]
+    x = synth_gps_l1_stream(6 * n, fs, sig_prns, dops, cphs, cn0_dbhz=50.0, seed_noise=41)
+    x8 = np.clip(np.round(np.stack([x.real, x.imag], axis=1) * 25.0), -127, 127).astype(np.int8)
+    devices = list(range(n_dev))
+    cap, win = 12 * n, 2 * n
+    kw = dict(fs_in=int(fs), fft_size=n, doppler_max=5000, doppler_step=250, samples_per_chip=4, samples_per_code=float(n))
+    g = StreamGroup.local(devices, cap, win, mode="broadcast")
+    g.push(x8, len(x8), "ibyte")
+    priv = [SampleStream(cap, win, device=d) for d in devices]
+    for r in priv:
+        r.push(x8, "ibyte")
+    found = {}
+    for i, d in enumerate(devices):
+        mine = [p for p in range(1, 33) if (p - 1) % n_dev == i]
+        res = []
+        for ring in (g.ring(i), priv[i]):
+            acq = PcpsAcquisitionBank(max_prn=len(mine), device=d, **kw)
+            for k, p in enumerate(mine):
+                acq.set_local_code(k, oracle.ca_code_complex_sampled(p, int(fs)))
+            res.append(acq.dwell_ring(ring, 2 * n + 123, len(mine)))
+            acq.close()
+        for k, p in enumerate(mine):
+            a, b = res[0][k], res[1][k]
+            assert (a["index_time"], a["index_doppler"], a["test_statistics"], a["doppler_hz"]) == (b["index_time"], b["index_doppler"], b["test_statistics"], b["doppler_hz"]), (d, p, a, b)
+            found[p] = a
+    g.close()
+    for p, fd in zip(sig_prns, dops):
+        assert abs(found[p]["doppler_hz"] - fd) <= 250 and found[p]["test_statistics"] > 4.0 * np.median([found[q]["test_statistics"] for q in found if q not in sig_prns]), (p, found[p])

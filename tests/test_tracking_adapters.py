@@ -47,6 +47,31 @@ def test_block_and_runtime_against_the_fake_engine(launch_ahead, channels_per_ha
     _check_dump_mat("/tmp/gsh_trk_dump_test/hip_trk_ch_6")
 
 
+def test_launched_mode_against_the_fake_engine():
+    """The same program with the runtime's live mode off (GSH_TRK_LIVE=0): one launch per batch of periods, queued ahead, as in round 3 -- the path a
+    configuration with <role>.hip_live=false takes."""
+    fake = _bin() + "_fake"
+    if not os.path.exists(fake):
+        pytest.skip("tests/host/test_tracking_adapters_fake was not prebuilt and /root/reference is not present here")
+    r = subprocess.run([fake], capture_output=True, text=True, timeout=900, cwd="/tmp", env=dict(os.environ, GSH_TRK_LIVE="0"))
+    assert r.returncode == 0 and "TRACKING ADAPTERS OK" in r.stdout and "FAKE ENGINE" not in r.stderr, r.stdout[-4000:] + r.stderr[-2000:]
+
+
+def test_blocks_dealt_over_three_devices_share_one_replicated_stream():
+    """<role>.hip_devices = 0,1,2 (SURVEY.md 8e behind the adapters): 32 blocks of one role dealt over three devices in turn, ONE Hip_Sample_Ring over the
+    engine's stream group -- whichever block is offered new samples first pushes them once, every device's ring receives them --, one runtime (handles,
+    residencies) per device.  On the CPU the stand-in engine plays three devices: it checks every ring's pushes against the stream sample for sample, that the
+    rings never drift apart, that a loop only ever follows a ring of its own device, and that no two threads are inside one handle; the blocks' windows are
+    compared with the reference's own blocks as everywhere else."""
+    fake = _bin() + "_fake"
+    if not os.path.exists(fake):
+        pytest.skip("tests/host/test_tracking_adapters_fake was not prebuilt and /root/reference is not present here")
+    r = subprocess.run([fake, "runtime", "32", "2400", "10"], capture_output=True, text=True, timeout=900, cwd="/tmp",
+                       env=dict(os.environ, FAKE_GSH_DEVICES="3", GSH_TEST_HIP_DEVICES="0,1,2"))
+    print("\n".join(l for l in r.stdout.splitlines() if "shared stream" in l or "FAIL" in l)[-2000:])
+    assert r.returncode == 0 and "TRACKING RUNTIME OK" in r.stdout and "FAKE ENGINE" not in r.stderr, r.stdout[-4000:] + r.stderr[-2000:]
+
+
 def _check_dump_mat(stem):
     """dump_mat (dll_pll_veml_tracking::save_matfile, trk.cc:1706-1890): <dump>.mat holds every field of every 108-byte record of <dump>.dat under the
     reference's variable names and classes (MAT-file level 5, host/hip_mat5_writer.h, read back here with scipy)."""

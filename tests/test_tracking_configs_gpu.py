@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 
 import oracle
-from helpers import TOL_REF, add_code_signal, cn0_to_amplitude, golden_e1_l5_codes
+from helpers import TOL_REF, add_code_signal, cn0_to_amplitude, golden_e1_l5_codes, protokernel_distances
 from test_tracking_gpu import _bank, _check
 
 pytestmark = pytest.mark.gpu
@@ -33,6 +33,17 @@ def _nco(fs, fd, f_carrier, chip_rate, spc, rng):
                 phase_step_rad=float(np.float32(2 * np.pi * fd / fs)),
                 rem_code_phase_chips=float(np.float32(rng.uniform(0, 1) * spc)),
                 code_phase_step_chips=float(np.float32(chip_rate * (1 + fd / f_carrier) / fs * spc)))
+
+
+def _hold_to_protokernels(tag, out, jobs, codes, x):
+    """north_star's 1e-5 against the reference's volk path, where it can be held (helpers.TOL_DISPATCH): on these long Galileo E1 / 50 Msps windows the reference's
+    AVX resampler selects other chips than its generic one and the two protokernels sit 1e-3 .. 1e-2 apart -- the GPU (the generic kernel's chips, bit for bit) is
+    held to the generic kernel at TOL_REF and to "no further from _u_avx than _generic is"."""
+    w_gen, w_avx, w_between = protokernel_distances(out, jobs, codes, x)
+    print(f"{tag} on signal taps: |gpu-generic|/|generic| = {w_gen:.3e}" + ("" if w_avx is None else f", |gpu-u_avx|/|u_avx| = {w_avx:.3e}, |u_avx-generic|/|generic| = {w_between:.3e}"))
+    assert w_gen <= TOL_REF, (tag, w_gen)
+    if w_avx is not None:
+        assert w_avx <= max(1e-5, w_between + TOL_REF), (tag, w_avx, w_between)
 
 
 def test_config4_galileo_e1_50_channels(gpu):
@@ -73,6 +84,7 @@ def test_config4_galileo_e1_50_channels(gpu):
         assert abs(out[j, 2]) > 2.5 * np.sqrt(2 * n), (j, out[j])
         assert abs(out[j + 1, 0]) > 2.5 * np.sqrt(2 * n), (j, out[j + 1])
     print(f"config4 worst |gpu-truth|/sum|x| = {worst:.3e} over {len(jobs)} jobs")
+    _hold_to_protokernels("config4", out, jobs[:24], codes, x)
     b.close()
 
 
@@ -147,6 +159,8 @@ def test_config5_multi_constellation_256_channels(gpu):
     out = b.correlate(jobs)
     worst = _check(out, jobs, codes, x, tol_ref=TOL_REF)
     print(f"config5 worst |gpu-truth|/sum|x| = {worst:.3e} over {len(jobs)} jobs (256 channels)")
+    sig = [j for j, job in enumerate(jobs) if (job["code_slot"] == jobs[2]["code_slot"]) or (job is jobs[96 + 2 * 4]) or (job is jobs[96 + 2 * 4 + 1])]
+    _hold_to_protokernels("config5", out[sig], [jobs[j] for j in sig], codes, x)
     # order independence: the same jobs reversed give the same numbers job by job
     out_r = b.correlate(jobs[::-1])
     assert np.array_equal(out_r[::-1].view(np.float32), out.view(np.float32))
