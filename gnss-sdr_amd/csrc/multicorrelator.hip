@@ -350,6 +350,7 @@ int launch_nt(const McorrArgs& a, int mode, size_t lds, hipStream_t stream)
     switch (mode)
         {
         case 0:
+#ifdef GSH_MC_RUNS_EXPERIMENT  // the run-based body (round 2, slower, 16 - 32 B of scratch per thread): only in a library built with this macro (profiles/ab/build_variant.py)
             if constexpr (NT <= 5)
                 {
                     if (a.packed == 2 && a.window_floats == 0)
@@ -362,6 +363,7 @@ int launch_nt(const McorrArgs& a, int mode, size_t lds, hipStream_t stream)
                                 }
                         }
                 }
+#endif
             if constexpr (NT == 3)
                 {
                     if (a.pair && a.packed == 1)
@@ -399,7 +401,9 @@ int mcorr_packed_default()
     static const int v = [] {
         const char* e = std::getenv("GSH_MC_PACKED_BODY");
         if (e != nullptr && e[0] == '0') return 0;
+#ifdef GSH_MC_RUNS_EXPERIMENT
         if (e != nullptr && e[0] == '2') return 2;
+#endif
         if (e != nullptr && e[0] == '3') return 3;  // packed trips without the derived early / late taps
         return 1;
     }();

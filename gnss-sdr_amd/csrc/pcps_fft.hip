@@ -177,18 +177,15 @@ __device__ __forceinline__ void stockham_pass_generic(int r, const float2* __res
             float2* yo = y + inst * len_s0 + q + s * r * p;
             // odd prime r: with s_j = a_j + a_{r-j}, d_j = a_j - a_{r-j} (j = 1 .. h = (r-1)/2)
             //   X[k], X[r-k] = (a_0 + sum_j s_j cos(2 pi j k / r))  -+  i (sum_j d_j sin(2 pi j k / r))
-            // -- real coefficients times complex values: half the multiplies and half the table reads of r^2 complex products
-            float2 sd[MAX_GENERIC_RADIX];  // s_1..s_h, then d_1..d_h
+            // -- real coefficients times complex values: half the multiplies and half the table reads of r^2 complex products.
+            // s_j and d_j are formed from the pass's INPUT buffer (LDS, untouched during the pass) wherever they are used: a per-thread array of them indexed
+            // by a run-time j lived in scratch (496 B per thread until round 4 -- private memory behind the vector memory path, slower than the LDS reads that
+            // replace it); the sums are the same operations on the same operands, so the results are bit for bit what they were.
             const int h = (r - 1) >> 1;
+            const int sm = s * m;
             const float2 a0 = xi[0];
             float2 sum = a0;
-            for (int j = 1; j <= h; j++)
-                {
-                    const float2 u = xi[s * m * j], v = xi[s * m * (r - j)];
-                    sd[j - 1] = cadd(u, v);
-                    sd[h + j - 1] = make_float2(u.x - v.x, u.y - v.y);
-                    sum = cadd(sum, sd[j - 1]);
-                }
+            for (int j = 1; j <= h; j++) sum = cadd(sum, cadd(xi[sm * j], xi[sm * (r - j)]));
             yo[0] = sum;
             for (int k = 1; k <= h; k++)
                 {
@@ -199,10 +196,13 @@ __device__ __forceinline__ void stockham_pass_generic(int r, const float2* __res
                             e += k;
                             if (e >= r) e -= r;
                             const float2 w = tw[e * root_stride];  // (cos, -sin) of 2 pi e / r
-                            pp.x = fmaf(sd[j - 1].x, w.x, pp.x);
-                            pp.y = fmaf(sd[j - 1].y, w.x, pp.y);
-                            qq.x = fmaf(sd[h + j - 1].x, w.y, qq.x);  // w.y = -sin: qq = -sum d sin
-                            qq.y = fmaf(sd[h + j - 1].y, w.y, qq.y);
+                            const float2 u = xi[sm * j], v = xi[sm * (r - j)];
+                            const float2 sj = cadd(u, v);
+                            const float2 dj = make_float2(u.x - v.x, u.y - v.y);
+                            pp.x = fmaf(sj.x, w.x, pp.x);
+                            pp.y = fmaf(sj.y, w.x, pp.y);
+                            qq.x = fmaf(dj.x, w.y, qq.x);  // w.y = -sin: qq = -sum d sin
+                            qq.y = fmaf(dj.y, w.y, qq.y);
                         }
                     // X[k] = P - i Q with Q = sum d sin = -qq  ->  P + i qq = (P.x - qq.y, P.y + qq.x);  X[r-k] = P - i qq
                     const float2 xk = make_float2(pp.x - qq.y, pp.y + qq.x);

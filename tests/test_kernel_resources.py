@@ -58,3 +58,17 @@ def test_on_chip_acquisition_kernels_use_no_scratch(meta):
     assert not spilling, spilling
     for n, k in oc.items():
         assert k[".vgpr_count"] <= 128, (n, k[".vgpr_count"])
+
+
+def test_no_kernel_of_the_library_uses_scratch(meta):
+    """EVERY kernel of libgnss_sdr_hip.so: the four-step acquisition kernels (csrc/pcps_fft.hip: fwd_cols_kernel, rows_kernel<0|1>,
+    inv_cols_kernel) carried 496 B per thread -- the generic-radix butterfly's per-thread array of sums and differences, indexed at run time; it now re-reads the
+    pass's input from LDS instead.  The run-based correlator experiment (16 - 32 B) is only compiled with -DGSH_MC_RUNS_EXPERIMENT."""
+    spilling = {n: k[".private_segment_fixed_size"] for n, k in meta.items() if k[".private_segment_fixed_size"] != 0 and "ELb0ELb1ELb0ELb0EE" not in n}
+    assert not spilling, spilling
+    dynamic = [n for n, k in meta.items() if k.get(".uses_dynamic_stack")]
+    assert not dynamic, dynamic
+    for n, k in meta.items():
+        wg = k.get(".max_flat_workgroup_size", 256)
+        # a work-group of 1 024 threads leaves 128 registers per thread, one of 512 leaves 256
+        assert k[".vgpr_count"] + k.get(".agpr_count", 0) <= 512 // max(1, (wg + 255) // 256), (n, k[".vgpr_count"], wg)
