@@ -1373,11 +1373,36 @@ __device__ __forceinline__ void sum_wave_partials(const float2* __restrict__ red
     const int lane = threadIdx.x & 63;
     const int t = lane < NOUT ? lane : 0;
     float2 s = make_float2(0.0f, 0.0f);
-#pragma unroll
-    for (int w = 0; w < MC_WAVES; w++)
+    if constexpr (MC_WAVES == 16)
         {
-            s.x += part[w * GSH_MAX_TAPS + t].x;
-            s.y += part[w * GSH_MAX_TAPS + t].y;
+            // All sixteen rows are fetched before the first addition.  Left to itself the compiler (at the register limit of the 1 024-thread kernel, scheduling for
+            // fewer live values everywhere) emitted read - wait - add eight times over: eight dependent LDS round trips, ~600 clocks of every period of the closed loop.
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            f4 q[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                {
+                    const float2 u = part[(2 * i) * GSH_MAX_TAPS + t], v = part[(2 * i + 1) * GSH_MAX_TAPS + t];
+                    q[i] = f4{u.x, u.y, v.x, v.y};
+                }
+            asm volatile("" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7]));  // (every row in a register here)
+#pragma unroll
+            for (int i = 0; i < 8; i++)  // the same additions in the same order
+                {
+                    s.x += q[i][0];
+                    s.y += q[i][1];
+                    s.x += q[i][2];
+                    s.y += q[i][3];
+                }
+        }
+    else
+        {
+#pragma unroll
+            for (int w = 0; w < MC_WAVES; w++)
+                {
+                    s.x += part[w * GSH_MAX_TAPS + t].x;
+                    s.y += part[w * GSH_MAX_TAPS + t].y;
+                }
         }
 #pragma unroll
     for (int k = 0; k < NOUT; k++)

@@ -70,6 +70,11 @@ struct LockState  // what cn0_and_tracking_lock_status keeps between periods (tr
     int cn0_estimation_counter, carrier_lock_fail_counter, code_lock_fail_counter, pull_in_latched;
     float cn0_db_hz;
     double carrier_lock_test;
+    // Round 4: the C/N0 half and the carrier-lock half of cn0_and_tracking_lock_status run on two different waves (trk_loop_kernel).  Neither reads a
+    // word the other writes, so what both need to know about the prompt buffer exists twice:
+    int cn0_slot;              // cn0_estimation_counter % cn0_samples once the buffer is full (kept instead of divided for)
+    int carr_counter, carr_slot, pull_in_latched_carr;  // the carrier-lock wave's copies of cn0_estimation_counter (while the buffer fills), cn0_slot, pull_in_latched
+    float first_prompt[2];     // its copy of d_Prompt_buffer[0] -- the one element carrier_lock_detector(buffer, 1) looks at (trk.cc:1184)
     // symbol synchronisation / narrow tracking (trk.cc:2026-2104, state 4 :2197-2252, save_correlation_results :1486-1596)
     int state;                 // d_state: 2 or 4
     int cloop;                 // d_cloop
@@ -124,9 +129,17 @@ struct TrkTail  // what the host needs back from every channel after a launch, i
 struct SerialMail  // results the code-loop lane and the lock-detector lane hand to thread 0 (trk_loop_kernel)
 {
     double code_error_chips, code_error_filt_chips;
-    int lost;
+    int lost;          // the code lock fail counter is over its limit (C/N0 wave)
+    int lost_carrier;  // the carrier lock fail counter is (carrier-lock wave)
 };
-constexpr int SERIAL_WAVES = 3;
+#ifndef GSH_TRK_SERIAL_WAVES
+#define GSH_TRK_SERIAL_WAVES 4
+#endif
+#ifndef GSH_TRK_PREFIX_ALL
+#define GSH_TRK_PREFIX_ALL 1
+#endif
+constexpr int SERIAL_WAVES = GSH_TRK_SERIAL_WAVES;  // wave 0 carrier loop, wave 1 code loop, wave 2 C/N0 estimator, wave 3 carrier lock test + the record's early fields
+constexpr int CN0_WAVE = 2, CARR_LOCK_WAVE = SERIAL_WAVES - 1;  // (three serial waves: both halves on wave 2, one after the other)
 
 // ---- live mode (gsh_trk_live_*): the kernel stays resident and follows the ring as it fills ------------------------------------------------------
 // A launch per batch of periods costs the host ~270 us of queueing and waiting around ~180 us of kernel (round 3) -- at the reference's cadence
@@ -295,21 +308,45 @@ __device__ __forceinline__ float2 fresh_zero2()
 }
 
 // ---- lock detectors and C/N0 (T/lock_detectors.cc, T/exponential_smoother.cc), float32 and sequential as written there ----
-__device__ float cn0_m2m4_estimator_d(const float* prompt_iq, int length, float coh_integration_time_s)  // T/lock_detectors.cc:61-110
+// cn0_m2m4_estimator's three sums -- Psig = sum |re|, m_2 = sum (im^2 + re^2), m_4 = sum (im^2 + re^2)^2, each added up in buffer order starting from 0.0f
+// (T/lock_detectors.cc:68-80) -- formed by the WHOLE wave: lane i holds the terms of buffered prompt i, and a step hands the running sums one lane up
+// (v_add_f32_dpp row_shr:1: s[l] = s[l-1] + x[l]; the first lane of a row has no source and keeps what it holds).  Once lane l-1 holds its prefix
+// ((x0 + x1) + ...) + x(l-1), the next step leaves lane l with that plus x(l) -- the additions of the one-thread loop, in its order (0.0f + x0 is x0 for
+// these non-negative terms) -- and every further step recomputes the same value: fifteen steps settle a row of sixteen lanes whatever n is, no loop, no count.
+// Rows go one after the other; the first lane of the next row gets the previous row's last prefix over v_readlane.  On return lane n-1 holds the totals.
+// One thread walking the LDS buffer took ~1 700 clocks for 20 prompts (ten dependent LDS round trips); this is 2 x 45 instructions.  (Round 3 tried the lanes
+// with one v_readlane per term: slower than the loop.)
+#define GSH_M2M4_STEP                                                        \
+    "v_add_f32_dpp %0, %0, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"      \
+    "v_add_f32_dpp %1, %1, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"      \
+    "v_add_f32_dpp %2, %2, %5 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+__device__ __forceinline__ void m2m4_sums_wave(float& psig, float& m2, float& m4, int n)
 {
-    float SNR_aux = 0.0f, Psig = 0.0f, m_2 = 0.0f, m_4 = 0.0f, aux;
-    const float n = static_cast<float>(length);
-    if (length == 0 || coh_integration_time_s == 0.0f) return -100.0f;
-    // (one thread runs this; unrolled eight times the loop wants sixty VGPRs of temporaries at the most crowded point of the kernel and pushes five values into scratch)
-#pragma clang loop unroll_count(2)
-    for (int i = 0; i < length; i++)
+    const float xa = psig, xb = m2, xc = m4;
+#pragma clang loop unroll(disable)
+    for (int base = 0; base < n; base += 16)
         {
-            const float re = prompt_iq[2 * i], im = prompt_iq[2 * i + 1];
-            Psig = __fadd_rn(Psig, fabsf(re));
-            aux = __fadd_rn(__fmul_rn(im, im), __fmul_rn(re, re));
-            m_2 = __fadd_rn(m_2, aux);
-            m_4 = __fadd_rn(m_4, __fmul_rn(aux, aux));
+            if (base > 0)
+                {
+                    psig = __fadd_rn(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, psig), base - 1)), xa);
+                    m2 = __fadd_rn(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m2), base - 1)), xb);
+                    m4 = __fadd_rn(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m4), base - 1)), xc);
+                }
+            // (a DPP operand written by the instruction before wants two wait states -- the compiler does not look into this text: s_nop 1 up front; inside,
+            // every sum is read three instructions after it was written)
+            asm volatile("s_nop 1\n\t" GSH_M2M4_STEP GSH_M2M4_STEP GSH_M2M4_STEP GSH_M2M4_STEP GSH_M2M4_STEP GSH_M2M4_STEP GSH_M2M4_STEP GSH_M2M4_STEP
+                             GSH_M2M4_STEP GSH_M2M4_STEP GSH_M2M4_STEP GSH_M2M4_STEP GSH_M2M4_STEP GSH_M2M4_STEP GSH_M2M4_STEP
+                         : "+v"(psig), "+v"(m2), "+v"(m4)
+                         : "v"(xa), "v"(xb), "v"(xc));
         }
+}
+#undef GSH_M2M4_STEP
+
+// the rest of cn0_m2m4_estimator (T/lock_detectors.cc:81-110) on the three sums
+__device__ __forceinline__ float cn0_from_sums_d(float Psig, float m_2, float m_4, int length, float coh_integration_time_s)
+{
+    float SNR_aux = 0.0f, aux;
+    const float n = static_cast<float>(length);
     Psig = __fdiv_rn(Psig, n);
     Psig = __fmul_rn(Psig, Psig);
     m_2 = __fdiv_rn(m_2, n);
@@ -346,8 +383,11 @@ __device__ float carrier_lock_detector_d(const float* prompt_iq, int length)  //
     return __fdiv_rn(nbd, nbp);
 }
 
-__device__ float smoother_smooth_d(SmootherState& s, float raw)  // T/exponential_smoother.cc:83-112
+// T/exponential_smoother.cc:83-112.  The state comes out of LDS in one go and only what changed goes back: field-by-field accesses were a chain of LDS round trips
+// on the one lane the period waits for.
+__device__ __forceinline__ float smoother_smooth_d(SmootherState& st, float raw)
 {
+    SmootherState s = st;
     float smoothed;
     if (s.initializing)
         {
@@ -357,6 +397,7 @@ __device__ float smoother_smooth_d(SmootherState& s, float raw)  // T/exponentia
             if (s.init_counter == s.samples_for_initialization)
                 {
                     s.old_value = __fdiv_rn(s.init_sum, static_cast<float>(s.init_counter));
+                    st.old_value = s.old_value;
                     if (s.old_value < __fadd_rn(s.min_value, s.offset))
                         {
                             s.init_counter = 0;  // flush buffer and start again
@@ -364,55 +405,91 @@ __device__ float smoother_smooth_d(SmootherState& s, float raw)  // T/exponentia
                         }
                     else
                         {
-                            s.initializing = 0;
+                            st.initializing = 0;
                         }
                 }
+            st.init_counter = s.init_counter;
+            st.init_sum = s.init_sum;
         }
     else
         {
             smoothed = __fadd_rn(__fmul_rn(s.alpha, raw), __fmul_rn(s.one_minus_alpha, s.old_value));
-            s.old_value = smoothed;
+            st.old_value = smoothed;
         }
     return smoothed;
 }
 
-// cn0_and_tracking_lock_status, trk.cc:1167-1224: true while locked
-__device__ bool lock_status_d(LockState& st, const gsh_trk_conf& c, float2 P, double coh_integration_time_s, bool pull_in_transitory)
+// cn0_and_tracking_lock_status, trk.cc:1167-1224, in two halves that share no word of state (each returns true when ITS fail counter is over its limit; the block's
+// verdict is their OR, and it is formed -- and both counters are cleared, :1205-1206 -- by thread 0 after the join):
+//   C/N0 half: the prompt goes into the buffer, M2M4 estimate from the sums the wave has formed (have_sums; otherwise the buffer is still filling), smoother, code lock counter
+__device__ __forceinline__ bool cn0_half_d(LockState& st, const gsh_trk_conf& c, float2 P, int cnt, int slot, float Psig, float m_2, float m_4, double coh_integration_time_s,
+    bool pull_in_transitory)
 {
     const int ns = c.cn0_samples;
-    if (st.cn0_estimation_counter < ns)
+    st.cn0_estimation_counter = cnt + 1;
+    if (cnt < ns)
         {
-            st.prompt_buffer[2 * st.cn0_estimation_counter] = P.x;
-            st.prompt_buffer[2 * st.cn0_estimation_counter + 1] = P.y;
-            st.cn0_estimation_counter++;
-            return true;
-        }
-    const int slot = st.cn0_estimation_counter % ns;
-    st.prompt_buffer[2 * slot] = P.x;
-    st.prompt_buffer[2 * slot + 1] = P.y;
-    st.cn0_estimation_counter++;
-    const float cn0_raw = cn0_m2m4_estimator_d(st.prompt_buffer, ns, static_cast<float>(coh_integration_time_s));
-    st.cn0_db_hz = smoother_smooth_d(st.cn0_smoother, cn0_raw);
-    // carrier_lock_detector(d_Prompt_buffer.data(), 1): length ONE, as the reference calls it (trk.cc:1184)
-    st.carrier_lock_test = static_cast<double>(smoother_smooth_d(st.carrier_lock_test_smoother, carrier_lock_detector_d(st.prompt_buffer, 1)));
-    if (!pull_in_transitory)
-        {
-            if (st.carrier_lock_test < c.carrier_lock_th)
-                st.carrier_lock_fail_counter++;
-            else if (st.carrier_lock_fail_counter > 0)
-                st.carrier_lock_fail_counter--;
-            if (st.cn0_db_hz < static_cast<float>(c.cn0_min))
-                st.code_lock_fail_counter++;
-            else if (st.code_lock_fail_counter > 0)
-                st.code_lock_fail_counter--;
-        }
-    if (st.carrier_lock_fail_counter > c.max_carrier_lock_fail || st.code_lock_fail_counter > c.max_code_lock_fail)
-        {
-            st.carrier_lock_fail_counter = 0;
-            st.code_lock_fail_counter = 0;
+            st.prompt_buffer[2 * cnt] = P.x;
+            st.prompt_buffer[2 * cnt + 1] = P.y;
             return false;
         }
-    return true;
+    st.prompt_buffer[2 * slot] = P.x;
+    st.prompt_buffer[2 * slot + 1] = P.y;
+    st.cn0_slot = (slot + 1 == ns) ? 0 : slot + 1;
+    const float coh = static_cast<float>(coh_integration_time_s);
+    const float cn0_raw = (coh == 0.0f) ? -100.0f : cn0_from_sums_d(Psig, m_2, m_4, ns, coh);  // (length == 0 cannot happen: cn0_samples >= 1)
+    const float cn0 = smoother_smooth_d(st.cn0_smoother, cn0_raw);
+    st.cn0_db_hz = cn0;
+    int fails = st.code_lock_fail_counter;
+    if (!pull_in_transitory)
+        {
+            if (cn0 < static_cast<float>(c.cn0_min))
+                fails++;
+            else if (fails > 0)
+                fails--;
+            st.code_lock_fail_counter = fails;
+        }
+    return fails > c.max_code_lock_fail;
+}
+
+//   carrier-lock half: carrier_lock_detector(d_Prompt_buffer.data(), 1) -- length ONE, as the reference calls it (trk.cc:1184): the buffer's FIRST element, whichever
+//   period put it there --, smoother, carrier lock counter.  The wave keeps its own copy of that element and of the buffer's fill / write position.
+__device__ __forceinline__ bool carrier_lock_half_d(LockState& st, const gsh_trk_conf& c, float2 P, bool pull_in_transitory)
+{
+    const int ns = c.cn0_samples;
+    const int cnt = st.carr_counter;
+    if (cnt < ns)
+        {
+            if (cnt == 0)
+                {
+                    st.first_prompt[0] = P.x;
+                    st.first_prompt[1] = P.y;
+                }
+            st.carr_counter = cnt + 1;
+            return false;
+        }
+    const int slot = st.carr_slot;
+    float first[2] = {st.first_prompt[0], st.first_prompt[1]};
+    if (slot == 0)
+        {
+            first[0] = P.x;
+            first[1] = P.y;
+            st.first_prompt[0] = P.x;
+            st.first_prompt[1] = P.y;
+        }
+    st.carr_slot = (slot + 1 == ns) ? 0 : slot + 1;
+    const double test = static_cast<double>(smoother_smooth_d(st.carrier_lock_test_smoother, carrier_lock_detector_d(first, 1)));
+    st.carrier_lock_test = test;
+    int fails = st.carrier_lock_fail_counter;
+    if (!pull_in_transitory)
+        {
+            if (test < c.carrier_lock_th)
+                fails++;
+            else if (fails > 0)
+                fails--;
+            st.carrier_lock_fail_counter = fails;
+        }
+    return fails > c.max_carrier_lock_fail;
 }
 
 // HistogramBitSynchronizer::update, T/bit_synchronizer.cc:41-124: true on the lock event
@@ -599,6 +676,30 @@ __device__ __forceinline__ void live_wait(const TrkArgs& a, int ch, TrkChannel& 
     w.go = (reason == LIVE_EXIT_NONE) ? 1 : 0;
 }
 
+enum : unsigned
+{
+    CF_SYMBOL_SYNC = 1u << 0,
+    CF_LOCK_DETECTORS = 1u << 1,
+    CF_TRACK_PILOT = 1u << 2,
+    CF_HAS_SECONDARY = 1u << 3,
+    CF_FLL_PULL_IN = 1u << 4,
+    CF_FLL_STEADY = 1u << 5,
+    CF_DOPPLER_CORRECTION = 1u << 6,
+    CF_CARRIER_AIDING = 1u << 7,
+    CF_EXTEND_GT1 = 1u << 8,
+    CF_SYMBOLS_GT1 = 1u << 9,
+    CF_DATA_SECONDARY = 1u << 10,
+    CF_CLOOP = 1u << 11,
+};
+__device__ __forceinline__ unsigned conf_switches(const gsh_trk_conf& c)
+{
+    return (c.enable_symbol_sync ? CF_SYMBOL_SYNC : 0u) | (c.enable_lock_detectors ? CF_LOCK_DETECTORS : 0u) | (c.track_pilot ? CF_TRACK_PILOT : 0u) |
+           (c.has_secondary ? CF_HAS_SECONDARY : 0u) | (c.enable_fll_pull_in ? CF_FLL_PULL_IN : 0u) | (c.enable_fll_steady_state ? CF_FLL_STEADY : 0u) |
+           (c.enable_doppler_correction ? CF_DOPPLER_CORRECTION : 0u) | (c.carrier_aiding ? CF_CARRIER_AIDING : 0u) |
+           (c.extend_correlation_symbols > 1 ? CF_EXTEND_GT1 : 0u) | (c.symbols_per_bit > 1 ? CF_SYMBOLS_GT1 : 0u) |
+           (c.data_secondary_code_length > 0 ? CF_DATA_SECONDARY : 0u) | (c.cloop != 0 ? CF_CLOOP : 0u);
+}
+
 // HD: Dll_Pll_Conf::high_dyn -- a compile-time switch so that the standard path does not carry the high-dynamics correlator's registers
 // LIVE: the residency form of the loop (gsh_trk_live_*) -- a compile-time switch as well: the launched form keeps the code (and the registers) it had
 template <int NT, bool HD, bool LIVE>
@@ -625,6 +726,10 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
     const int ch = blockIdx.x;
     const int tid = threadIdx.x;
     const gsh_trk_conf& c = *conf;
+    // The configuration's switches in ONE word, formed once per launch: every `c.flag` in the loop arithmetic was a scalar load the lane then waited for
+    // (s_load_dword - s_waitcnt - branch, a data-cache round trip each, two dozen of them on the path of every period); a bit test of a register is not.
+    const unsigned cf = conf_switches(c);
+    auto CF = [cf](unsigned bit) { return (cf & bit) != 0u; };
     {
         const unsigned* gs = reinterpret_cast<const unsigned*>(a.chan + ch);
         const unsigned* gl = reinterpret_cast<const unsigned*>(a.lock + ch);
@@ -640,11 +745,11 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
     // ---- local replicas stay in LDS for the whole launch
     float* tab = lds;
     float* tab_data = lds + code_table_floats(code_len);
-    float2* red = reinterpret_cast<float2*>(tab_data + (c.track_pilot ? code_table_floats(code_len) : 0));
+    float2* red = reinterpret_cast<float2*>(tab_data + (CF(CF_TRACK_PILOT) ? code_table_floats(code_len) : 0));
     if (s.active)
         {
             stage_code_table(tab, a.codes + static_cast<size_t>(ch) * 2 * a.code_stride, code_len);
-            if (c.track_pilot) stage_code_table(tab_data, a.codes + (static_cast<size_t>(ch) * 2 + 1) * a.code_stride, code_len);
+            if (CF(CF_TRACK_PILOT)) stage_code_table(tab_data, a.codes + (static_cast<size_t>(ch) * 2 + 1) * a.code_stride, code_len);
         }
 
     // ---- tap offsets in code samples, trk.cc:632-648 / :829-840 (wide) and :2130-2148 (narrow): formed from the configuration at the top of
@@ -777,7 +882,7 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
             };
             const float phase_rate = win.phase_rate, code_rate = win.code_rate;
             // track_pilot in the standard mode: the data-component prompt (trk.cc:1246-1256) rides on the pilot's pass over the window
-            const bool fused_data = !HD && c.track_pilot;
+            const bool fused_data = !HD && CF(CF_TRACK_PILOT);
             float2 out[NT];
 #pragma unroll
             for (int t = 0; t < NT; t++) out[t] = make_float2(0.0f, 0.0f);
@@ -788,7 +893,7 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                     correlate_window<NT, 1>(a.stream, wpos, static_cast<int>(c.vector_length), tab, code_len, sh, rem_carr, phase_step, phase_rate, rem_code, code_step, code_rate, red);
 #pragma unroll
                     for (int t = 0; t < NT; t++) out[t] = red[t];
-                    if (c.track_pilot)
+                    if (CF(CF_TRACK_PILOT))
                         {
                             __syncthreads();  // everyone has read red[0..NT) before it is reused
                             correlate_window<1, 1>(a.stream, wpos, static_cast<int>(c.vector_length), tab_data, code_len, sh_data, rem_carr, phase_step, phase_rate, rem_code, code_step, code_rate, red);
@@ -821,11 +926,13 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
 #ifdef GSH_TRK_PROFILE
             const long long t_corr_done = clock64();
 #endif
-            // ---- the loop arithmetic between two correlations.  Round 3: what does not depend on each other runs side by side on lane 0 of three different waves
-            // (three SIMDs: one lane each, a chain of dependent operations) instead of one after the other on thread 0:
+            // ---- the loop arithmetic between two correlations.  What does not depend on each other runs side by side on lane 0 of four different waves
+            // (four SIMDs: one lane each, a chain of dependent operations) instead of one after the other on thread 0:
             //   wave 0  accumulators of states 3 / 4, carrier discriminator(s) + FLL/PLL filter              (s.pll, s.p_old_*, s.carrier_doppler_hz are its alone)
             //   wave 1  code discriminator + DLL filter                                                      (s.dll is its alone; results through `mail`)
-            //   wave 2  cn0_and_tracking_lock_status: C/N0, carrier lock test, smoothers, fail counters      (the lock fields of lk are its alone; verdict through `mail`)
+            //   wave 2  cn0_and_tracking_lock_status, C/N0 half: M2M4 sums by the whole wave, estimate, smoother, code lock counter
+            //   wave 3  ... carrier-lock half: carrier lock test, smoother, carrier lock counter; and the record's fields that are known before the join
+            // (round 3 had the two halves on one lane: the period waited 2 900 clocks longer for it than for the carrier loop).
             // Each derives the few common inputs itself from state it only READS; whatever another lane reads is written by thread 0 after the barrier that
             // joins them.  The arithmetic of every value is what it was: records are bit-identical to the single-thread order (tests/test_tracking_loop_gpu.py).
             // On a loss of lock the period's loop-filter updates have happened although the reference skips them (trk.cc:2009-2014) -- nothing reads them again:
@@ -839,40 +946,83 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
             bool pull_in = false;
             double carr_phase_error_hz = 0.0, carr_freq_error_hz = 0.0, carr_error_filt_hz = 0.0;
             int next_symbol = 0;
+            // the (wave-uniform) inputs of the lanes below, from state that is only read here
+            auto form_inputs = [&]() {
+                // trk.cc:1912-1915: pull-in ends once more than pull_in_time_s whole seconds have passed since acquisition
+                pull_in = (pos - acq_stamp) < a.pull_in_limit;
+                // the accumulators the loop works on (d_VE_accu .. d_VL_accu): the period's outputs in state 2 (trk.cc:1984-1991); in state 4
+                // save_correlation_results adds them, times the secondary code chip, to accumulators zeroed at the end of the previous period
+                run_state = CF(CF_SYMBOL_SYNC) ? lk.state : 0;
+                if (run_state == 3 || run_state == 4)
+                    {
+                        float sgn = 1.0f;
+                        next_symbol = lk.current_symbol;
+                        if (CF(CF_HAS_SECONDARY))
+                            {
+                                sgn = c.secondary_code[next_symbol] == '0' ? 1.0f : -1.0f;
+                                next_symbol = (next_symbol + 1) % c.secondary_code_length;
+                            }
+#pragma unroll
+                        for (int t = 0; t < NT; t++)
+                            {
+                                acc[t].x = __fadd_rn(lk.accv[t].x, __fmul_rn(sgn, out[t].x));  // the float += / -= of trk.cc:1493-1512
+                                acc[t].y = __fadd_rn(lk.accv[t].y, __fmul_rn(sgn, out[t].y));  // (lk.accv itself is updated after the join)
+                            }
+                    }
+            };
+            // ---- C/N0 wave, all 64 lanes: the M2M4 sums over the prompt buffer as it will be once this period's prompt is in (m2m4_sums_wave)
+            int cn0_cnt = 0, cn0_slot = 0;
+            float cn0_psig = 0.0f, cn0_m2 = 0.0f, cn0_m4 = 0.0f;
+            auto cn0_sums = [&]() {
+                if (CF(CF_LOCK_DETECTORS) && run_state != 3)
+                    {
+                        const int ns = c.cn0_samples;
+                        cn0_cnt = lk.cn0_estimation_counter;
+                        cn0_slot = lk.cn0_slot;
+                        if (cn0_cnt >= ns)  // uniform
+                            {
+                                const int lane = tid & 63;
+                                float2 bp = make_float2(0.0f, 0.0f);
+                                if (lane < ns) bp = *reinterpret_cast<const float2*>(&lk.prompt_buffer[2 * lane]);
+                                if (lane == cn0_slot) bp = acc[PROMPT];
+                                float xa = fabsf(bp.x);
+                                float xb = __fadd_rn(__fmul_rn(bp.y, bp.y), __fmul_rn(bp.x, bp.x));
+                                float xc = __fmul_rn(xb, xb);
+                                m2m4_sums_wave(xa, xb, xc, ns);
+                                cn0_psig = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xa), ns - 1));
+                                cn0_m2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xb), ns - 1));
+                                cn0_m4 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xc), ns - 1));
+                            }
+                    }
+            };
+#if GSH_TRK_PREFIX_ALL
+            if (tid < 64 * SERIAL_WAVES)
+                {
+                    form_inputs();
+                    if ((tid >> 6) == CN0_WAVE) cn0_sums();
+                }
+#else
+            if ((tid >> 6) == CN0_WAVE && CF(CF_LOCK_DETECTORS))
+                {
+                    form_inputs();
+                    cn0_sums();
+                }
+            else if ((tid & 63) == 0 && tid < 64 * SERIAL_WAVES)
+                form_inputs();
+#endif
             if ((tid & 63) == 0 && tid < 64 * SERIAL_WAVES)
                 {
-                    const int extend = (c.enable_symbol_sync && c.extend_correlation_symbols > 1) ? c.extend_correlation_symbols : 1;
-                    // trk.cc:1912-1915: pull-in ends once more than pull_in_time_s whole seconds have passed since acquisition
-                    pull_in = (pos - acq_stamp) < a.pull_in_limit;
-                    // the accumulators the loop works on (d_VE_accu .. d_VL_accu): the period's outputs in state 2 (trk.cc:1984-1991); in state 4
-                    // save_correlation_results adds them, times the secondary code chip, to accumulators zeroed at the end of the previous period
-                    run_state = c.enable_symbol_sync ? lk.state : 0;
-                    if (run_state == 3 || run_state == 4)
-                        {
-                            float sgn = 1.0f;
-                            next_symbol = lk.current_symbol;
-                            if (c.has_secondary)
-                                {
-                                    sgn = c.secondary_code[next_symbol] == '0' ? 1.0f : -1.0f;
-                                    next_symbol = (next_symbol + 1) % c.secondary_code_length;
-                                }
-#pragma unroll
-                            for (int t = 0; t < NT; t++)
-                                {
-                                    acc[t].x = __fadd_rn(lk.accv[t].x, __fmul_rn(sgn, out[t].x));  // the float += / -= of trk.cc:1493-1512
-                                    acc[t].y = __fadd_rn(lk.accv[t].y, __fmul_rn(sgn, out[t].y));  // (lk.accv itself is updated after the join)
-                                }
-                        }
+                    const int extend = (CF(CF_SYMBOL_SYNC) && CF(CF_EXTEND_GT1)) ? c.extend_correlation_symbols : 1;
                     const float2 P = acc[PROMPT], E = acc[PROMPT - 1], L = acc[PROMPT + 1];
                     if (tid == 0)
                         {
                             if (run_state == 3 || run_state == 4)
                                 {
-                                    const float2 pd = c.track_pilot ? pdata : out[PROMPT];
-                                    if (c.symbols_per_bit > 1)
+                                    const float2 pd = CF(CF_TRACK_PILOT) ? pdata : out[PROMPT];
+                                    if (CF(CF_SYMBOLS_GT1))
                                         {
                                             float ds = 1.0f;
-                                            if (c.data_secondary_code_length > 0)
+                                            if (CF(CF_DATA_SECONDARY))
                                                 {
                                                     ds = c.data_secondary_code[lk.current_data_symbol] == '0' ? 1.0f : -1.0f;
                                                     lk.current_data_symbol = (lk.current_data_symbol + 1) % c.data_secondary_code_length;
@@ -889,21 +1039,21 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                                             lk.p_data_accu[0] = pd.x;
                                             lk.p_data_accu[1] = pd.y;
                                         }
-                                    lk.cloop = c.track_pilot ? 0 : 1;  // trk.cc:1587-1595
+                                    lk.cloop = CF(CF_TRACK_PILOT) ? 0 : 1;  // trk.cc:1587-1595
                                 }
                             // ---- run_dll_pll, carrier half, trk.cc:1260-1303 (skipped during coherent integration, state 3: trk.cc:2156-2161)
                             if (run_state != 3)
                                 {
-                                    const bool cloop_now = c.enable_symbol_sync ? (lk.cloop != 0) : (c.cloop != 0);
-                                    const double corr_time = (c.enable_symbol_sync && lk.corr_time > 0.0) ? lk.corr_time : code_period;  // d_current_correlation_time_s
+                                    const bool cloop_now = CF(CF_SYMBOL_SYNC) ? (lk.cloop != 0) : CF(CF_CLOOP);
+                                    const double corr_time = (CF(CF_SYMBOL_SYNC) && lk.corr_time > 0.0) ? lk.corr_time : code_period;  // d_current_correlation_time_s
                                     carr_phase_error_hz = div_by_constant_if<GSH_TRK_FAST_DIV != 0>(cloop_now ? pll_cloop_two_quadrant_atan_d(P) : pll_four_quadrant_atan_d(P), GNSS_TWO_PI_D, INV_TWO_PI_D);  // (a float arctangent: zero, or no smaller than 1e-45)
                                     float carr_error_filt;
-                                    if ((pull_in && c.enable_fll_pull_in) || c.enable_fll_steady_state)
+                                    if ((pull_in && CF(CF_FLL_PULL_IN)) || CF(CF_FLL_STEADY))
                                         {
                                             carr_freq_error_hz = div_by_constant(fll_diff_atan_d(make_float2(s.p_old_re, s.p_old_im), P, 0.0, corr_time), GNSS_TWO_PI_D, inv_two_pi);
                                             s.p_old_re = P.x;
                                             s.p_old_im = P.y;
-                                            if (pull_in && c.enable_fll_pull_in)
+                                            if (pull_in && CF(CF_FLL_PULL_IN))
                                                 carr_error_filt = fll_pll_carrier_error(s.pll, static_cast<float>(carr_freq_error_hz), 0.0f, static_cast<float>(corr_time));
                                             else
                                                 carr_error_filt = fll_pll_carrier_error(s.pll, static_cast<float>(carr_freq_error_hz), static_cast<float>(carr_phase_error_hz), static_cast<float>(corr_time));
@@ -922,7 +1072,7 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                             double code_error_chips = 0.0, code_error_filt_chips = 0.0;
                             if (run_state != 3)
                                 {
-                                    const float spc_now = (c.enable_symbol_sync && lk.narrow) ? lk.spc_now : c.spc;
+                                    const float spc_now = (CF(CF_SYMBOL_SYNC) && lk.narrow) ? lk.spc_now : c.spc;
                                     if (NT == 5)
                                         code_error_chips = dll_nc_vemlp_normalized_d(acc[0], acc[1], acc[NT - 2], acc[NT - 1]);
                                     else
@@ -939,8 +1089,29 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                                 }
                         }
                     else
+                      {
+                        if (tid == 64 * CN0_WAVE)
                         {
-                            // this lane also writes the part of the period's record that is known before the join (thread 0 adds the loop's outputs after it, or, on a
+                            // ---- cn0_and_tracking_lock_status, C/N0 half (cn0_half_d)
+                            bool lost_now = false;
+                            if (CF(CF_LOCK_DETECTORS))
+                                {
+                                    if (lk.pull_in_latched && !pull_in)  // trk.cc:1912-1916
+                                        {
+                                            lk.pull_in_latched = 0;
+                                            lk.code_lock_fail_counter = 0;
+                                        }
+                                    if (run_state != 3)  // coherent integration runs no lock test (trk.cc:2156-2161)
+                                        lost_now = cn0_half_d(lk, c, P, cn0_cnt, cn0_slot, cn0_psig, cn0_m2, cn0_m4,
+                                            run_state == 4 ? code_period * static_cast<double>(extend) : code_period, pull_in);  // trk.cc:2008, :2203
+                                }
+                            mail.lost = lost_now ? 1 : 0;
+                            if (a.records != nullptr) rec_set<LIVE>(rec_ref().cn0_db_hz, CF(CF_LOCK_DETECTORS) ? lk.cn0_db_hz : 0.0f);
+                        }
+                        if (tid == 64 * CARR_LOCK_WAVE)
+                        {
+                            // ---- carrier-lock half (carrier_lock_half_d).
+                            // This lane also writes the part of the period's record that is known before the join (thread 0 adds the loop's outputs after it, or, on a
                             // loss of lock, clears what does not belong into that record): the accumulators the loop works on -- what log_data dumps as
                             // |d_VE_accu| .. |d_VL_accu| (trk.cc:1624-1636) --, the correlator outputs, the window's position, state and flags
                             gsh_trk_epoch* const rp = a.records != nullptr ? &rec_ref() : nullptr;
@@ -961,28 +1132,23 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                                     rec_set<LIVE>(rp->state, run_state);
                                 }
                             bool lost_now = false;
-                            if (c.enable_lock_detectors)
+                            if (CF(CF_LOCK_DETECTORS))
                                 {
-                                    if (lk.pull_in_latched && !pull_in)  // trk.cc:1912-1916
+                                    if (lk.pull_in_latched_carr && !pull_in)  // trk.cc:1912-1916
                                         {
-                                            lk.pull_in_latched = 0;
+                                            lk.pull_in_latched_carr = 0;
                                             lk.carrier_lock_fail_counter = 0;
-                                            lk.code_lock_fail_counter = 0;
                                         }
                                     // trk.cc:2000-2007, state 2 only: no secondary-code / bit synchronisation within the time limit forces the loss-of-lock condition
                                     if (run_state == 2 && (pos - acq_stamp) >= a.bit_sync_limit) lk.carrier_lock_fail_counter = 300000;
-                                    if (run_state != 3)  // coherent integration runs no lock test (trk.cc:2156-2161)
-                                        lost_now = !lock_status_d(lk, c, P, run_state == 4 ? code_period * static_cast<double>(extend) : code_period, pull_in);  // trk.cc:2008, :2203
+                                    if (run_state != 3) lost_now = carrier_lock_half_d(lk, c, P, pull_in);
                                 }
-                            mail.lost = lost_now ? 1 : 0;
-                            if (rp != nullptr)
-                                {
-                                    rec_set<LIVE>(rp->cn0_db_hz, c.enable_lock_detectors ? lk.cn0_db_hz : 0.0f);
-                                    rec_set<LIVE>(rp->carrier_lock_test, c.enable_lock_detectors ? lk.carrier_lock_test : 0.0);
-                                }
+                            mail.lost_carrier = lost_now ? 1 : 0;
+                            if (rp != nullptr) rec_set<LIVE>(rp->carrier_lock_test, CF(CF_LOCK_DETECTORS) ? lk.carrier_lock_test : 0.0);
                         }
+                      }
                 }
-            __syncthreads();  // the three lanes meet
+            __syncthreads();  // the four lanes meet
 #ifdef GSH_TRK_PROFILE
             const long long t_join = clock64();
 #endif
@@ -996,7 +1162,7 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                 }
             if (tid == 0)
                 {
-                    const int extend = (c.enable_symbol_sync && c.extend_correlation_symbols > 1) ? c.extend_correlation_symbols : 1;
+                    const int extend = (CF(CF_SYMBOL_SYNC) && CF(CF_EXTEND_GT1)) ? c.extend_correlation_symbols : 1;
                     if (run_state == 3 || run_state == 4)  // what the other lanes read above
                         {
                             lk.current_symbol = next_symbol;
@@ -1005,14 +1171,16 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                         }
                     float rec_cn0 = 0.0f;
                     double rec_lock_test = 0.0;
-                    if (c.enable_lock_detectors)
+                    if (CF(CF_LOCK_DETECTORS))
                         {
                             rec_cn0 = lk.cn0_db_hz;
                             rec_lock_test = lk.carrier_lock_test;
                         }
-                    const bool lost = mail.lost != 0;
+                    const bool lost = (mail.lost | mail.lost_carrier) != 0;
                     if (lost)  // trk.cc:2009-2014: clear_tracking_vars, d_state = 0 -- the channel stops here
                         {
+                            lk.carrier_lock_fail_counter = 0;  // trk.cc:1205-1206
+                            lk.code_lock_fail_counter = 0;
                             if (a.records != nullptr)
                                 {
                                     gsh_trk_epoch& r = rec_ref();  // written in place, field by field
@@ -1054,8 +1222,8 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                     if (run_state != 3)
                         {
                             s.code_freq_chips = c.code_chip_rate - code_error_filt_chips;
-                            if (c.carrier_aiding) s.code_freq_chips += div_by_constant_if<FAST>(s.carrier_doppler_hz * c.code_chip_rate, c.signal_carrier_freq, a.inv_signal_carrier_freq);
-                            if (c.enable_doppler_correction && !pull_in && !lk.corrected_doppler)  // trk.cc:1326-1346
+                            if (CF(CF_CARRIER_AIDING)) s.code_freq_chips += div_by_constant_if<FAST>(s.carrier_doppler_hz * c.code_chip_rate, c.signal_carrier_freq, a.inv_signal_carrier_freq);
+                            if (CF(CF_DOPPLER_CORRECTION) && !pull_in && !lk.corrected_doppler)  // trk.cc:1326-1346
                                 {
                                     lk.dll_filt_sum += static_cast<double>(static_cast<float>(code_error_filt_chips));
                                     lk.dll_filt_count++;
@@ -1159,7 +1327,7 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                     // ---- symbol synchronisation (state 2, trk.cc:2026-2112) / symbol output (state 4, :2205-2246)
                     int rec_symbol_flags = 0;
                     float rec_pdata[2] = {0.0f, 0.0f};
-                    if (c.enable_symbol_sync && run_state == 3)
+                    if (CF(CF_SYMBOL_SYNC) && run_state == 3)
                         {
                             // trk.cc:2162-2194: a telemetry symbol may complete inside the coherent integration; then count the period
                             rec_pdata[0] = lk.p_data_accu[0];
@@ -1177,14 +1345,14 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                                     lk.state = 4;
                                 }
                         }
-                    else if (c.enable_symbol_sync)
+                    else if (CF(CF_SYMBOL_SYNC))
                         {
                             if (run_state == 2)
                                 {
                                     bool next_state = false;
                                     if (!pull_in)
                                         {
-                                            if (!c.has_secondary && c.symbols_per_bit > 1 && lk.use_hist)  // trk.cc:2046-2072
+                                            if (!CF(CF_HAS_SECONDARY) && CF(CF_SYMBOLS_GT1) && lk.use_hist)  // trk.cc:2046-2072
                                                 {
                                                     const bool lock_event = bit_sync_update_d(lk, c, out[PROMPT], true);
                                                     if (lock_event)
@@ -1208,7 +1376,7 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                                                                 }
                                                         }
                                                 }
-                                            if (!next_state && (c.has_secondary || c.symbols_per_bit > 1))
+                                            if (!next_state && (CF(CF_HAS_SECONDARY) || CF(CF_SYMBOLS_GT1)))
                                                 {
                                                     const int len = c.secondary_code_length;
                                                     if (lk.ring_count < len)  // d_Prompt_circular_buffer.push_back(*d_Prompt)
@@ -1243,7 +1411,7 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                                                                 }
                                                         }
                                                 }
-                                            if (!c.has_secondary && c.symbols_per_bit <= 1) next_state = true;  // trk.cc:2091-2094
+                                            if (!CF(CF_HAS_SECONDARY) && !CF(CF_SYMBOLS_GT1)) next_state = true;  // trk.cc:2091-2094
                                         }
                                     if (next_state)  // trk.cc:2101-2112, 2151-2154 (no extended integration)
                                         {
@@ -2083,6 +2251,7 @@ extern "C"
         init_smoother(lk.cn0_smoother, c.cn0_smoother_alpha, cn0_init, 25.0F, 12.0F);                        // class defaults, T/exponential_smoother.h:64-65
         init_smoother(lk.carrier_lock_test_smoother, c.carrier_lock_test_smoother_alpha, c.carrier_lock_test_smoother_samples, -1.0F, 0.0F);  // trk.cc:688-692
         lk.pull_in_latched = 1;
+        lk.pull_in_latched_carr = 1;
         lk.carrier_lock_test = 1.0;  // d_carrier_lock_test(1.0): constructor and clear_tracking_vars (trk.cc:112, 1040)
         if (c.enable_symbol_sync && c.extend_correlation_symbols > 1)
             {

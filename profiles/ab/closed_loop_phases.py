@@ -8,8 +8,10 @@ import gnss_sdr_amd, oracle
 from gnss_sdr_amd.tracking_loop import TrackingLoop, trk_conf
 fs, n, E = 25e6, 25000, 200
 x = torch.view_as_complex(torch.randn((E + 3) * n, 2, device="cuda")).contiguous()
+# GSH_LOOP_AB_CONF=lock: with the lock detectors / C/N0 estimator (what the tracking adapters run with)
+extra = dict(enable_lock_detectors=1, max_code_lock_fail=1 << 30, max_carrier_lock_fail=1 << 30) if os.environ.get("GSH_LOOP_AB_CONF", "") == "lock" else {}
 for ch in (32,):
-    loop = TrackingLoop(trk_conf(fs_in=fs, vector_length=n, pll_bw_hz=35.0, dll_bw_hz=2.0), ch, 1023, device=0)
+    loop = TrackingLoop(trk_conf(fs_in=fs, vector_length=n, pll_bw_hz=35.0, dll_bw_hz=2.0, **extra), ch, 1023, device=0)
     loop.set_stream_device(x.data_ptr(), x.numel(), keepalive=x)
     rng = np.random.default_rng(1)
     for c in range(ch):
@@ -25,5 +27,5 @@ for ch in (32,):
         f = lambda get: np.array([[get(r) for r in rr] for rr in rec])[:, 5:].mean()
         print("  serial section, clocks: three lanes side by side + barrier %.0f  join %.0f  update_tracking_vars %.0f  symbol+record %.0f  publish %.0f" % (
             f(lambda r: r.corr[8]), f(lambda r: r.accu[6]), f(lambda r: r.accu[7]), f(lambda r: r.accu[8]), f(lambda r: r.accu[9]) - f(lambda r: r.corr[7])))
-    print("channels", ch, "us/epoch %.3f" % (ms * 1e3 / E), "correlation clocks avg %.0f  serial clocks avg %.0f  (clock64 units)" % (tc[:, 5:].mean(), ts[:, 5:].mean()))
+    print(os.path.basename(os.environ.get("GSH_LIB_PATH", "current")), os.environ.get("GSH_LOOP_AB_CONF", ""), "channels", ch, "us/epoch %.3f" % (ms * 1e3 / E), "correlation clocks avg %.0f  serial clocks avg %.0f  (clock64 units)" % (tc[:, 5:].mean(), ts[:, 5:].mean()))
     loop.close()
