@@ -601,20 +601,20 @@ __device__ __forceinline__ unsigned long long live_oldest(unsigned long long hea
 // End of a period (after publish() has formed the next window's NCO settings): the period's record is complete in LDS; whether the next window can be
 // correlated straight away is decided from what the look-out lane read at the end of the correlation -- no memory access on this path.  Anything else (no
 // samples yet, record ring full, budget used up, channel stopped, quit) is left to the drain round at the loop's top (win.go = 2).
-__device__ __forceinline__ void live_advance(const TrkArgs& a, TrkChannel& s, NextWindow& w, LiveShared& v, unsigned vlen)
+__device__ __forceinline__ void live_advance(const TrkArgs& a, unsigned long long s_pos, int s_active, NextWindow& w, LiveShared& v, unsigned vlen)
 {
     // (no store into host memory here: thread 0 would wait for its acknowledgement -- a PCIe round trip -- at the barrier that ends the period.  The
     // channel's position and the count of complete records go out with the record, from the wave that writes it at the top of the next period.)
     {
-        unsigned long long w2 = v.wpos + (s.pos - v.pub_pos);  // a period advances the window by far less than the ring holds
+        unsigned long long w2 = v.wpos + (s_pos - v.pub_pos);  // a period advances the window by far less than the ring holds
         if (w2 >= a.ring_capacity) w2 -= a.ring_capacity;
         v.wpos = w2;
     }
-    v.pub_pos = s.pos;
+    v.pub_pos = s_pos;
     v.seq += 1ull;
     v.out_valid = 1;  // this period's record is complete in LDS (the lanes' stores lie before the barrier that joined them, thread 0's are its own)
     const unsigned long long oldest = live_oldest(v.head, v.origin, a.ring_capacity);
-    const bool resident = s.active && (s.pos + vlen <= v.head) && (s.pos >= oldest);
+    const bool resident = s_active && (s_pos + vlen <= v.head) && (s_pos >= oldest);
     const bool room = (v.seq - v.consumed) < static_cast<unsigned long long>(a.live.ring_len);
     const bool in_budget = (v.now - v.t_start) < a.live.residency_ticks;  // (the clock is the look-out lane's reading: s_memrealtime is a memory operation, ~a microsecond)
     w.go = (resident && room && in_budget && !v.quit) ? 1 : 2;
@@ -1016,6 +1016,12 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                     const float2 P = acc[PROMPT], E = acc[PROMPT - 1], L = acc[PROMPT + 1];
                     if (tid == 0)
                         {
+                            // the carrier filter's state and the previous prompt come out of LDS in one go, up front (pinned by the asm: see the note at join_and_update)
+                            FllPllState pl = s.pll;
+                            float p_old_re = s.p_old_re, p_old_im = s.p_old_im;
+                            if constexpr (!(NT == 5 && HD && LIVE))  // (that flavour sits at the register limit: thirteen more live values there are 24 B of scratch)
+                                asm volatile("" : "+v"(pl.w), "+v"(pl.x), "+v"(pl.w0p), "+v"(pl.w0p2), "+v"(pl.w0p3), "+v"(pl.w0f), "+v"(pl.w0f2), "+v"(pl.a2), "+v"(pl.a3), "+v"(pl.b3),
+                                             "+v"(pl.order), "+v"(p_old_re), "+v"(p_old_im));
                             if (run_state == 3 || run_state == 4)
                                 {
                                     const float2 pd = CF(CF_TRACK_PILOT) ? pdata : out[PROMPT];
@@ -1050,18 +1056,20 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                                     float carr_error_filt;
                                     if ((pull_in && CF(CF_FLL_PULL_IN)) || CF(CF_FLL_STEADY))
                                         {
-                                            carr_freq_error_hz = div_by_constant(fll_diff_atan_d(make_float2(s.p_old_re, s.p_old_im), P, 0.0, corr_time), GNSS_TWO_PI_D, inv_two_pi);
+                                            carr_freq_error_hz = div_by_constant(fll_diff_atan_d(make_float2(p_old_re, p_old_im), P, 0.0, corr_time), GNSS_TWO_PI_D, inv_two_pi);
                                             s.p_old_re = P.x;
                                             s.p_old_im = P.y;
                                             if (pull_in && CF(CF_FLL_PULL_IN))
-                                                carr_error_filt = fll_pll_carrier_error(s.pll, static_cast<float>(carr_freq_error_hz), 0.0f, static_cast<float>(corr_time));
+                                                carr_error_filt = fll_pll_carrier_error(pl, static_cast<float>(carr_freq_error_hz), 0.0f, static_cast<float>(corr_time));
                                             else
-                                                carr_error_filt = fll_pll_carrier_error(s.pll, static_cast<float>(carr_freq_error_hz), static_cast<float>(carr_phase_error_hz), static_cast<float>(corr_time));
+                                                carr_error_filt = fll_pll_carrier_error(pl, static_cast<float>(carr_freq_error_hz), static_cast<float>(carr_phase_error_hz), static_cast<float>(corr_time));
                                         }
                                     else
                                         {
-                                            carr_error_filt = fll_pll_carrier_error(s.pll, 0.0f, static_cast<float>(carr_phase_error_hz), static_cast<float>(corr_time));
+                                            carr_error_filt = fll_pll_carrier_error(pl, 0.0f, static_cast<float>(carr_phase_error_hz), static_cast<float>(corr_time));
                                         }
+                                    s.pll.w = pl.w;  // (the filter's memories; its coefficients are not written)
+                                    s.pll.x = pl.x;
                                     carr_error_filt_hz = carr_error_filt;
                                     s.carrier_doppler_hz = carr_error_filt_hz;
                                 }
@@ -1204,7 +1212,7 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                                 }
                             s.active = 0;
                             publish(win, s, c, a.n_stream, 0);
-                            if constexpr (LIVE) live_advance(a, s, win, lv, c.vector_length);  // (the channel is stopped: the drain round publishes this record and leaves)
+                            if constexpr (LIVE) live_advance(a, s.pos, 0, win, lv, c.vector_length);  // (the channel is stopped: the drain round publishes this record and leaves)
                         }
                     else
                         {
@@ -1215,14 +1223,25 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
 #ifdef GSH_TRK_PROFILE
                     long long t_c = 0;
 #endif
+                    // Thread 0 works on REGISTER copies of the channel state from here to the end of the period: what it needs comes out of LDS in one go at the top
+                    // (the asm below pins the reads there -- the compiler, scheduling for few live values, had put every read in front of its first use: a dozen
+                    // LDS round trips on the one lane the work-group waits for), what it changes goes back in one go, and the record and the next window are formed
+                    // from the registers (they used to re-read what had just been written).
+                    double st_code_freq = s.code_freq_chips, st_rem_code_samples = s.rem_code_phase_samples, st_acc_phase = s.acc_carrier_phase_rad;
+                    double st_doppler = s.carrier_doppler_hz, st_phase_rate = s.carrier_phase_rate_step_rad, st_code_rate = s.code_phase_rate_step_chips;
+                    float st_rem_carr = s.rem_carr_phase_rad;
+                    double code_error_filt_chips = mail.code_error_filt_chips;
+                    if constexpr (!(NT == 5 && HD && LIVE))  // (that flavour sits at the register limit: pinned there, the values cost 24 B of scratch)
+                        asm volatile("" : "+v"(st_code_freq), "+v"(st_rem_code_samples), "+v"(st_acc_phase), "+v"(st_doppler), "+v"(st_phase_rate), "+v"(st_code_rate), "+v"(st_rem_carr),
+                                     "+v"(code_error_filt_chips));
+                    double st_phase_step = 0.0, st_code_step = 0.0, st_rem_code_chips = 0.0;
                     auto join_and_update = [&](auto fast_tag) {
                     constexpr bool FAST = decltype(fast_tag)::value;
                     // ---- run_dll_pll, the join: trk.cc:1317-1324
-                    const double code_error_filt_chips = mail.code_error_filt_chips;
                     if (run_state != 3)
                         {
-                            s.code_freq_chips = c.code_chip_rate - code_error_filt_chips;
-                            if (CF(CF_CARRIER_AIDING)) s.code_freq_chips += div_by_constant_if<FAST>(s.carrier_doppler_hz * c.code_chip_rate, c.signal_carrier_freq, a.inv_signal_carrier_freq);
+                            st_code_freq = c.code_chip_rate - code_error_filt_chips;
+                            if (CF(CF_CARRIER_AIDING)) st_code_freq += div_by_constant_if<FAST>(st_doppler * c.code_chip_rate, c.signal_carrier_freq, a.inv_signal_carrier_freq);
                             if (CF(CF_DOPPLER_CORRECTION) && !pull_in && !lk.corrected_doppler)  // trk.cc:1326-1346
                                 {
                                     lk.dll_filt_sum += static_cast<double>(static_cast<float>(code_error_filt_chips));
@@ -1234,7 +1253,7 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                                                 {
                                                     const float carrier_doppler_error_hz =
                                                         __fdiv_rn(__fmul_rn(static_cast<float>(c.signal_carrier_freq), avg_code_error_chips_s), static_cast<float>(c.code_chip_rate));
-                                                    const float f0 = __fsub_rn(static_cast<float>(s.carrier_doppler_hz), carrier_doppler_error_hz);
+                                                    const float f0 = __fsub_rn(static_cast<float>(st_doppler), carrier_doppler_error_hz);
                                                     if (s.pll.order == 3)  // Tracking_FLL_PLL_filter::initialize, T/tracking_FLL_PLL_filter.cc:57-69
                                                         {
                                                             s.pll.x = __fmul_rn(2.0f, f0);
@@ -1257,16 +1276,16 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                     t_c = clock64();
 #endif
                     // ---- update_tracking_vars, trk.cc:1409-1483 (rate terms are zero outside high_dyn)
-                    const double t_chip = 1.0 / s.code_freq_chips;
+                    const double t_chip = 1.0 / st_code_freq;
                     const double t_prn = t_chip * static_cast<double>(c.code_length_chips);
                     const double t_prn_samples = t_prn * c.fs_in;
-                    const double k_blk = t_prn_samples + s.rem_code_phase_samples;
+                    const double k_blk = t_prn_samples + st_rem_code_samples;
                     prn_len = static_cast<int>(floor(k_blk));
-                    s.carrier_phase_step_rad = div_by_constant_if<FAST>(GNSS_TWO_PI_D * (s.carrier_doppler_hz + c.cfo_frequency_hz), c.fs_in, a.inv_fs_in);
+                    st_phase_step = div_by_constant_if<FAST>(GNSS_TWO_PI_D * (st_doppler + c.cfo_frequency_hz), c.fs_in, a.inv_fs_in);
                     if (HD)  // trk.cc:1425-1443
                         {
                             const int SL = static_cast<int>(c.smoother_length), cap = 2 * SL;
-                            lk.carr_hist[lk.carr_pushes % cap][0] = s.carrier_phase_step_rad;
+                            lk.carr_hist[lk.carr_pushes % cap][0] = st_phase_step;
                             lk.carr_hist[lk.carr_pushes % cap][1] = static_cast<double>(prn_len);
                             lk.carr_pushes++;
                             if (lk.carr_hist_n < cap) lk.carr_hist_n++;
@@ -1282,19 +1301,19 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                                         }
                                     cp1 /= static_cast<double>(SL);
                                     cp2 /= static_cast<double>(SL);
-                                    s.carrier_phase_rate_step_rad = (smp != 0.0) ? (cp2 - cp1) / smp : 0.0;
+                                    st_phase_rate = (smp != 0.0) ? (cp2 - cp1) / smp : 0.0;
                                 }
                         }
-                    const double dphi = s.carrier_phase_step_rad * static_cast<double>(prn_len) +
-                                        0.5 * s.carrier_phase_rate_step_rad * static_cast<double>(prn_len) * static_cast<double>(prn_len);
-                    s.rem_carr_phase_rad += static_cast<float>(dphi);
-                    s.rem_carr_phase_rad = static_cast<float>(fmod_two_pi<FAST>(static_cast<double>(s.rem_carr_phase_rad)));
-                    s.acc_carrier_phase_rad -= dphi;
-                    s.code_phase_step_chips = div_by_constant_if<FAST>(s.code_freq_chips, c.fs_in, a.inv_fs_in);
+                    const double dphi = st_phase_step * static_cast<double>(prn_len) +
+                                        0.5 * st_phase_rate * static_cast<double>(prn_len) * static_cast<double>(prn_len);
+                    st_rem_carr += static_cast<float>(dphi);
+                    st_rem_carr = static_cast<float>(fmod_two_pi<FAST>(static_cast<double>(st_rem_carr)));
+                    st_acc_phase -= dphi;
+                    st_code_step = div_by_constant_if<FAST>(st_code_freq, c.fs_in, a.inv_fs_in);
                     if (HD)  // trk.cc:1458-1480
                         {
                             const int SL = static_cast<int>(c.smoother_length), cap = 2 * SL;
-                            lk.code_hist[lk.code_pushes % cap][0] = s.code_phase_step_chips;
+                            lk.code_hist[lk.code_pushes % cap][0] = st_code_step;
                             lk.code_hist[lk.code_pushes % cap][1] = static_cast<double>(prn_len);
                             lk.code_pushes++;
                             if (lk.code_hist_n < cap) lk.code_hist_n++;
@@ -1310,11 +1329,11 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                                         }
                                     cp1 /= static_cast<double>(SL);
                                     cp2 /= static_cast<double>(SL);
-                                    if (smp >= 1.0) s.code_phase_rate_step_chips = (cp2 - cp1) / smp;
+                                    if (smp >= 1.0) st_code_rate = (cp2 - cp1) / smp;
                                 }
                         }
-                    s.rem_code_phase_samples = k_blk - static_cast<double>(prn_len);
-                    s.rem_code_phase_chips = div_by_constant_if<FAST>(s.code_freq_chips * s.rem_code_phase_samples, c.fs_in, a.inv_fs_in);
+                    st_rem_code_samples = k_blk - static_cast<double>(prn_len);
+                    st_rem_code_chips = div_by_constant_if<FAST>(st_code_freq * st_rem_code_samples, c.fs_in, a.inv_fs_in);
                     };
                     if (a.inv_fs_in != 0.0)
                         join_and_update(std::true_type{});
@@ -1451,7 +1470,7 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                                 {
                                     if (!lk.acc_phase_initialized)  // check_carrier_phase_coherent_initialization, trk.cc:1350-1357
                                         {
-                                            s.acc_carrier_phase_rad = -static_cast<double>(s.rem_carr_phase_rad);
+                                            st_acc_phase = -static_cast<double>(st_rem_carr);
                                             lk.acc_phase_initialized = 1;
                                         }
                                     rec_pdata[0] = lk.p_data_accu[0];
@@ -1471,20 +1490,20 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                     if (a.records != nullptr)
                         {
                             gsh_trk_epoch& r = rec_ref();  // written in place (every field is assigned)
-                            rec_set<LIVE>(r.carrier_phase_rate_step_rad, s.carrier_phase_rate_step_rad);
-                            rec_set<LIVE>(r.code_phase_rate_step_chips, s.code_phase_rate_step_chips);
+                            rec_set<LIVE>(r.carrier_phase_rate_step_rad, st_phase_rate);
+                            rec_set<LIVE>(r.code_phase_rate_step_chips, st_code_rate);
                             rec_set<LIVE>(r.symbol_flags, rec_symbol_flags);
                             rec_set<LIVE>(r.p_data_accu[0], rec_pdata[0]);
                             rec_set<LIVE>(r.p_data_accu[1], rec_pdata[1]);
                             rec_set<LIVE>(r.prn_length_samples, prn_len);
-                            rec_set<LIVE>(r.rem_carr_phase_rad, s.rem_carr_phase_rad);
-                            rec_set<LIVE>(r.carrier_doppler_hz, s.carrier_doppler_hz);
-                            rec_set<LIVE>(r.code_freq_chips, s.code_freq_chips);
+                            rec_set<LIVE>(r.rem_carr_phase_rad, st_rem_carr);
+                            rec_set<LIVE>(r.carrier_doppler_hz, st_doppler);
+                            rec_set<LIVE>(r.code_freq_chips, st_code_freq);
                             rec_set<LIVE>(r.carr_phase_error_hz, carr_phase_error_hz);
                             rec_set<LIVE>(r.carr_freq_error_hz, carr_freq_error_hz);
                             rec_set<LIVE>(r.carr_error_filt_hz, carr_error_filt_hz);
-                            rec_set<LIVE>(r.rem_code_phase_samples, s.rem_code_phase_samples);
-                            rec_set<LIVE>(r.acc_carrier_phase_rad, s.acc_carrier_phase_rad);
+                            rec_set<LIVE>(r.rem_code_phase_samples, st_rem_code_samples);
+                            rec_set<LIVE>(r.acc_carrier_phase_rad, st_acc_phase);
 #ifdef GSH_TRK_PROFILE
                             if (NT == 3)  // phase durations in shader clocks, in the unused VE / VL slots
                                 {
@@ -1499,10 +1518,35 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                                 }
 #endif
                         }
-                    s.pos = pos + static_cast<unsigned long long>(prn_len);  // consume_each, trk.cc:2287
-                    publish(win, s, c, a.n_stream, e + 1 < a.n_epochs, a.ring_oldest);
-                    win.narrow = lk.narrow;
-                    if constexpr (LIVE) live_advance(a, s, win, lv, c.vector_length);
+                    const unsigned long long new_pos = pos + static_cast<unsigned long long>(prn_len);  // consume_each, trk.cc:2287
+                    // the state goes back to LDS (for the launch's end, and for the lanes of the next period) ...
+                    s.code_freq_chips = st_code_freq;
+                    s.carrier_phase_step_rad = st_phase_step;
+                    s.code_phase_step_chips = st_code_step;
+                    s.rem_code_phase_samples = st_rem_code_samples;
+                    s.rem_code_phase_chips = st_rem_code_chips;
+                    s.acc_carrier_phase_rad = st_acc_phase;
+                    s.rem_carr_phase_rad = st_rem_carr;
+                    s.pos = new_pos;
+                    if (HD)
+                        {
+                            s.carrier_phase_rate_step_rad = st_phase_rate;
+                            s.code_phase_rate_step_chips = st_code_rate;
+                        }
+                    // ... and the next window is formed from the registers (publish(): do_correlation_step's casts, trk.cc:1237-1243; the channel is active here)
+                    {
+                        const float spcf = static_cast<float>(c.code_samples_per_chip);
+                        win.pos = new_pos;
+                        win.rem_carr = st_rem_carr;
+                        win.phase_step = static_cast<float>(st_phase_step);
+                        win.rem_code = __fmul_rn(static_cast<float>(st_rem_code_chips), spcf);
+                        win.code_step = __fmul_rn(static_cast<float>(st_code_step), spcf);
+                        win.phase_rate = static_cast<float>(st_phase_rate);
+                        win.code_rate = __fmul_rn(static_cast<float>(st_code_rate), spcf);
+                        win.go = (e + 1 < a.n_epochs && new_pos + c.vector_length <= a.n_stream && new_pos >= a.ring_oldest) ? 1 : 0;
+                        win.narrow = lk.narrow;
+                    }
+                    if constexpr (LIVE) live_advance(a, new_pos, 1, win, lv, c.vector_length);
 #ifdef GSH_TRK_PROFILE
                     if (NT == 3 && a.records != nullptr) rec_ref().accu[9] = static_cast<float>(clock64() - t_corr_done);  // ... + publish
 #if GSH_TRK_PROFILE == 2  // the correlation phase instead of the serial section: window set-up, trips, wave sums, barrier, sum over the waves + barrier, the loop's own barrier
