@@ -131,7 +131,37 @@ struct SerialMail  // results the code-loop lane and the lock-detector lane hand
     double code_error_chips, code_error_filt_chips;
     int lost;          // the code lock fail counter is over its limit (C/N0 wave)
     int lost_carrier;  // the carrier lock fail counter is (carrier-lock wave)
+    // The lanes do not meet at a barrier: each says when it is done by writing the period's number (LDS operations of one wave are carried out in order, so a lane
+    // that has seen the number sees what was written before it), and thread 0 waits only for what it needs -- the code loop's output always, the lock detectors'
+    // verdict only in a period in which a fail counter CAN pass its limit (may_trip_*: left by the detectors' lanes for the next period).  Otherwise the two
+    // detector lanes -- the longest of the four -- run beside thread 0's join / update_tracking_vars and are met at the barrier that ends the period.
+    // (what thread 0 looks at when it has done its own part, side by side: ONE 32-byte read)
+    alignas(16) int code_seq;
+    int inputs_cn0, inputs_carr;        // the detector lanes have read the state thread 0 goes on to change (form_inputs)
+    int pad0;
+    int may_trip_code, may_trip_carr;
+    int cn0_seq, carr_seq;
 };
+// true when the code lane and the two `inputs` words say `seq`; may_trip = may_trip_code | may_trip_carr as read in the same go
+__device__ __forceinline__ bool join_ready(SerialMail& m, int seq, int& may_trip)
+{
+    typedef int i4 __attribute__((ext_vector_type(4)));
+    typedef int i2 __attribute__((ext_vector_type(2)));
+    const i4 lo = *reinterpret_cast<volatile i4*>(&m.code_seq);
+    const i2 hi = *reinterpret_cast<volatile i2*>(&m.may_trip_code);
+    may_trip = hi[0] | hi[1];
+    return lo[0] == seq && lo[1] == seq && lo[2] == seq;
+}
+__device__ __forceinline__ void lane_says(int& word, int value)
+{
+    asm volatile("" ::: "memory");
+    __hip_atomic_store(&word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lane_waits(int& word, int value)
+{
+    while (__hip_atomic_load(&word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != value) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+}
 #ifndef GSH_TRK_SERIAL_WAVES
 #define GSH_TRK_SERIAL_WAVES 4
 #endif
@@ -270,14 +300,29 @@ __device__ __forceinline__ double dll_nc_vemlp_normalized_d(float2 ve, float2 e,
 }
 
 // ---- loop filters ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float loop_filter_apply(LoopFilterState& f, float x)  // T/tracking_loop_filter.cc:63-98
+// The two 4-deep histories are kept newest first (a shift register) instead of as the reference's ring with a moving index: in_h[i] / out_h[i] here are its
+// d_inputs[(d_current_index + i) % 4] / d_outputs[...] -- the same products added in the same order, without a run-time index into LDS (each a dependent round trip
+// on the code lane; idx stays 0).  The state comes out of LDS in one go (PIN: pinned up front, as in join_and_update).
+template <bool PIN>
+__device__ __forceinline__ float loop_filter_apply(LoopFilterState& fs, float x)  // T/tracking_loop_filter.cc:63-98
 {
+    LoopFilterState f = fs;
+    if constexpr (PIN)
+        asm volatile("" : "+v"(f.in_c[0]), "+v"(f.in_c[1]), "+v"(f.in_c[2]), "+v"(f.in_c[3]), "+v"(f.out_c[0]), "+v"(f.out_c[1]), "+v"(f.out_c[2]), "+v"(f.out_c[3]),
+                     "+v"(f.in_h[0]), "+v"(f.in_h[1]), "+v"(f.in_h[2]), "+v"(f.out_h[0]), "+v"(f.out_h[1]), "+v"(f.out_h[2]), "+v"(f.n_in), "+v"(f.n_out));
     float r = 0.0f;
-    for (int i = 0; i < f.n_out; i++) r += f.out_c[i] * f.out_h[(f.idx + i) & 3];
-    f.idx = (f.idx + 3) & 3;  // d_current_index-- with wrap over MAX_LOOP_HISTORY_LENGTH = 4
-    f.in_h[f.idx] = x;
-    for (int i = 0; i < f.n_in; i++) r += f.in_c[i] * f.in_h[(f.idx + i) & 3];
-    f.out_h[f.idx] = r;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        if (i < f.n_out) r += f.out_c[i] * f.out_h[i];
+    const float ih[4] = {x, f.in_h[0], f.in_h[1], f.in_h[2]};
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        if (i < f.n_in) r += f.in_c[i] * ih[i];
+#pragma unroll
+    for (int i = 0; i < 4; i++) fs.in_h[i] = ih[i];
+    fs.out_h[0] = r;
+#pragma unroll
+    for (int i = 1; i < 4; i++) fs.out_h[i] = f.out_h[i - 1];
     return r;
 }
 __device__ __forceinline__ float fll_pll_carrier_error(FllPllState& f, float fll_disc, float pll_disc, float t)  // T/tracking_FLL_PLL_filter.cc:72-99
@@ -762,6 +807,10 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
         {
             publish(win, s, c, a.n_stream, a.n_epochs > 0, a.ring_oldest);
             win.narrow = lk.narrow;
+            mail.code_seq = mail.cn0_seq = mail.carr_seq = mail.inputs_cn0 = mail.inputs_carr = 0;
+            mail.lost = mail.lost_carrier = 0;
+            mail.may_trip_code = (lk.code_lock_fail_counter + 1 > c.max_code_lock_fail) ? 1 : 0;
+            mail.may_trip_carr = (lk.carrier_lock_fail_counter + 1 > c.max_carrier_lock_fail) ? 1 : 0;
             if constexpr (LIVE)
                 {
                     // the channel's record count lives in the host's tail (this kernel is its only writer): residencies hand it on through there
@@ -995,10 +1044,16 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                             }
                     }
             };
+            const int seq = e + 1;  // the period's number inside the launch: what the lanes say when they are done
+            auto say = [&](int& word) {
+                if constexpr (!HD) lane_says(word, seq);  // (the high-dynamics flavours join at a barrier, below)
+            };
 #if GSH_TRK_PREFIX_ALL
             if (tid < 64 * SERIAL_WAVES)
                 {
                     form_inputs();
+                    if (tid == 64 * CN0_WAVE) say(mail.inputs_cn0);
+                    if (tid == 64 * CARR_LOCK_WAVE) say(mail.inputs_carr);
                     if ((tid >> 6) == CN0_WAVE) cn0_sums();
                 }
 #else
@@ -1009,6 +1064,8 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                 }
             else if ((tid & 63) == 0 && tid < 64 * SERIAL_WAVES)
                 form_inputs();
+            if (tid == 64 * CN0_WAVE) say(mail.inputs_cn0);
+            if (tid == 64 * CARR_LOCK_WAVE) say(mail.inputs_carr);
 #endif
             if ((tid & 63) == 0 && tid < 64 * SERIAL_WAVES)
                 {
@@ -1019,7 +1076,7 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                             // the carrier filter's state and the previous prompt come out of LDS in one go, up front (pinned by the asm: see the note at join_and_update)
                             FllPllState pl = s.pll;
                             float p_old_re = s.p_old_re, p_old_im = s.p_old_im;
-                            if constexpr (!(NT == 5 && HD && LIVE))  // (that flavour sits at the register limit: thirteen more live values there are 24 B of scratch)
+                            if constexpr (!HD)  // (the high-dynamics flavours sit at the register limit: thirteen more live values there are scratch)
                                 asm volatile("" : "+v"(pl.w), "+v"(pl.x), "+v"(pl.w0p), "+v"(pl.w0p2), "+v"(pl.w0p3), "+v"(pl.w0f), "+v"(pl.w0f2), "+v"(pl.a2), "+v"(pl.a3), "+v"(pl.b3),
                                              "+v"(pl.order), "+v"(p_old_re), "+v"(p_old_im));
                             if (run_state == 3 || run_state == 4)
@@ -1085,10 +1142,11 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                                         code_error_chips = dll_nc_vemlp_normalized_d(acc[0], acc[1], acc[NT - 2], acc[NT - 1]);
                                     else
                                         code_error_chips = dll_nc_e_minus_l_normalized_d(E, L, spc_now, c.slope, c.y_intercept);
-                                    code_error_filt_chips = loop_filter_apply(s.dll, static_cast<float>(code_error_chips));
+                                    code_error_filt_chips = loop_filter_apply<!HD>(s.dll, static_cast<float>(code_error_chips));
                                 }
                             mail.code_error_chips = code_error_chips;
                             mail.code_error_filt_chips = code_error_filt_chips;
+                            say(mail.code_seq);
                             if (a.records != nullptr)
                                 {
                                     gsh_trk_epoch& r = rec_ref();
@@ -1114,7 +1172,9 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                                             run_state == 4 ? code_period * static_cast<double>(extend) : code_period, pull_in);  // trk.cc:2008, :2203
                                 }
                             mail.lost = lost_now ? 1 : 0;
+                            mail.may_trip_code = (CF(CF_LOCK_DETECTORS) && lk.code_lock_fail_counter + 1 > c.max_code_lock_fail) ? 1 : 0;  // (next period: the counter moves by one)
                             if (a.records != nullptr) rec_set<LIVE>(rec_ref().cn0_db_hz, CF(CF_LOCK_DETECTORS) ? lk.cn0_db_hz : 0.0f);
+                            say(mail.cn0_seq);
                         }
                         if (tid == 64 * CARR_LOCK_WAVE)
                         {
@@ -1152,14 +1212,19 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                                     if (run_state != 3) lost_now = carrier_lock_half_d(lk, c, P, pull_in);
                                 }
                             mail.lost_carrier = lost_now ? 1 : 0;
+                            mail.may_trip_carr = (CF(CF_LOCK_DETECTORS) && lk.carrier_lock_fail_counter + 1 > c.max_carrier_lock_fail) ? 1 : 0;
                             if (rp != nullptr) rec_set<LIVE>(rp->carrier_lock_test, CF(CF_LOCK_DETECTORS) ? lk.carrier_lock_test : 0.0);
+                            // (thread 0 rewrites some of this lane's record fields when the channel loses lock: the stores above have to have landed by then)
+                            if constexpr (!LIVE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            say(mail.carr_seq);
                         }
                       }
                 }
-            __syncthreads();  // the four lanes meet
-#ifdef GSH_TRK_PROFILE
-            const long long t_join = clock64();
-#endif
+            // No barrier here when the lock detectors run: see SerialMail.  Without them there is nothing to overlap and the barrier is the cheaper meeting (thread 0's
+            // look at the words costs an LDS round trip and a few comparisons, ~200 clocks: 8.05 against 7.93 us per period); the high-dynamics flavours, at the
+            // register limit, keep the barrier as well.
+            const bool flag_join = !HD && CF(CF_LOCK_DETECTORS);  // (uniform over the work-group)
+            if (!flag_join) __syncthreads();
             if constexpr (LIVE)
               if (tid == 64 * SERIAL_WAVES && lv.head != lv.head_fenced)
                 {
@@ -1170,6 +1235,29 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                 }
             if (tid == 0)
                 {
+                    bool lost = false;
+                    if (!flag_join)
+                        lost = (mail.lost | mail.lost_carrier) != 0;
+                    else
+                        {
+                            asm volatile("" ::: "memory");
+                            int may_trip = 0;
+                            while (!join_ready(mail, seq, may_trip))  // (the `inputs` words long since: they are the first thing their lanes do)
+                                ;
+                            asm volatile("" ::: "memory");
+                            // can a fail counter pass its limit in this period?  Only from within one of its limit (the lanes said so last period -- or have said so for
+                            // the next one already, having finished: then their verdict is in, and a limit passed now leaves the counter within one of it), or when the
+                            // bit synchronisation time limit sets the carrier counter to 300000 (trk.cc:2000-2007) -- then the verdict is waited for
+                            if (CF(CF_LOCK_DETECTORS) && (may_trip != 0 || (run_state == 2 && (pos - acq_stamp) >= a.bit_sync_limit)))
+                                {
+                                    lane_waits(mail.cn0_seq, seq);
+                                    lane_waits(mail.carr_seq, seq);
+                                    lost = (mail.lost | mail.lost_carrier) != 0;
+                                }
+                        }
+#ifdef GSH_TRK_PROFILE
+                    const long long t_join = clock64();
+#endif
                     const int extend = (CF(CF_SYMBOL_SYNC) && CF(CF_EXTEND_GT1)) ? c.extend_correlation_symbols : 1;
                     if (run_state == 3 || run_state == 4)  // what the other lanes read above
                         {
@@ -1177,16 +1265,15 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
 #pragma unroll
                             for (int t = 0; t < NT; t++) lk.accv[t] = acc[t];
                         }
-                    float rec_cn0 = 0.0f;
-                    double rec_lock_test = 0.0;
-                    if (CF(CF_LOCK_DETECTORS))
-                        {
-                            rec_cn0 = lk.cn0_db_hz;
-                            rec_lock_test = lk.carrier_lock_test;
-                        }
-                    const bool lost = (mail.lost | mail.lost_carrier) != 0;
                     if (lost)  // trk.cc:2009-2014: clear_tracking_vars, d_state = 0 -- the channel stops here
                         {
+                            float rec_cn0 = 0.0f;
+                            double rec_lock_test = 0.0;
+                            if (CF(CF_LOCK_DETECTORS))
+                                {
+                                    rec_cn0 = lk.cn0_db_hz;
+                                    rec_lock_test = lk.carrier_lock_test;
+                                }
                             lk.carrier_lock_fail_counter = 0;  // trk.cc:1205-1206
                             lk.code_lock_fail_counter = 0;
                             if (a.records != nullptr)
@@ -1231,7 +1318,7 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                     double st_doppler = s.carrier_doppler_hz, st_phase_rate = s.carrier_phase_rate_step_rad, st_code_rate = s.code_phase_rate_step_chips;
                     float st_rem_carr = s.rem_carr_phase_rad;
                     double code_error_filt_chips = mail.code_error_filt_chips;
-                    if constexpr (!(NT == 5 && HD && LIVE))  // (that flavour sits at the register limit: pinned there, the values cost 24 B of scratch)
+                    if constexpr (!HD)  // (the high-dynamics flavours sit at the register limit: pinned there, the values cost scratch)
                         asm volatile("" : "+v"(st_code_freq), "+v"(st_rem_code_samples), "+v"(st_acc_phase), "+v"(st_doppler), "+v"(st_phase_rate), "+v"(st_code_rate), "+v"(st_rem_carr),
                                      "+v"(code_error_filt_chips));
                     double st_phase_step = 0.0, st_code_step = 0.0, st_rem_code_chips = 0.0;
@@ -1579,8 +1666,10 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
         unsigned* gl = reinterpret_cast<unsigned*>(lock_out + ch);
         const unsigned* ls = reinterpret_cast<const unsigned*>(&s);
         const unsigned* ll = reinterpret_cast<const unsigned*>(&lk);
-        for (int i = tid; i < static_cast<int>(sizeof(TrkChannel) / 4); i += MC_THREADS) gs[i] = ls[i];
-        for (int i = tid; i < static_cast<int>(sizeof(LockState) / 4); i += MC_THREADS) gl[i] = ll[i];
+        int t2 = tid;  // (laundered as well: the per-thread byte offset of the prologue's copy loops was kept for these -- 8 B of scratch in the tightest flavour)
+        asm volatile("" : "+v"(t2));
+        for (int i = t2; i < static_cast<int>(sizeof(TrkChannel) / 4); i += MC_THREADS) gs[i] = ls[i];
+        for (int i = t2; i < static_cast<int>(sizeof(LockState) / 4); i += MC_THREADS) gl[i] = ll[i];
     }
     if (tid == 0)
         {
@@ -1675,7 +1764,7 @@ void design_loop_filter(LoopFilterState& f, float T, float bw, int order, bool l
             f.in_h[i] = 0.0F;
             f.out_h[i] = 0.0F;
         }
-    f.idx = 3;
+    f.idx = 0;  // (unused: the device keeps the histories newest first, loop_filter_apply)
 }
 
 // Tracking_FLL_PLL_filter::set_params + initialize, T/tracking_FLL_PLL_filter.cc:23-69
