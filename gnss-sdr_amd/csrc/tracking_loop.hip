@@ -126,6 +126,13 @@ struct TrkTail  // what the host needs back from every channel after a launch, i
     int active;              // TrkChannel::active
 };
 
+struct HotConstants  // the configuration's values thread 0 needs in every period, in LDS: they come in with its state in ONE pinned batch of reads (each was an s_load the lane waited for)
+{
+    double code_chip_rate, signal_carrier_freq, fs_in, cfo_frequency_hz;
+    unsigned code_length_chips, vector_length;
+    float code_samples_per_chip_f;
+    int pad;
+};
 struct SerialMail  // results the code-loop lane and the lock-detector lane hand to thread 0 (trk_loop_kernel)
 {
     double code_error_chips, code_error_filt_chips;
@@ -761,6 +768,7 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
     __shared__ __align__(16) TrkChannel s;
     __shared__ __align__(16) LockState lk;
     __shared__ SerialMail mail;  // between the lanes that share a period's loop arithmetic (below)
+    __shared__ __align__(16) HotConstants hc;
     __shared__ std::conditional_t<LIVE, LiveShared, NoLiveShared> lv;  // (not allocated in the launched form: nothing there touches it)
     // live form: the period's record is assembled HERE by the three lanes that know its fields and written to the host's record ring by ONE wave
     // instruction (28 lanes x 8 bytes, system scope) at the top of the next period.  Field-by-field system-scope stores -- what visibility to a host that
@@ -807,6 +815,13 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
         {
             publish(win, s, c, a.n_stream, a.n_epochs > 0, a.ring_oldest);
             win.narrow = lk.narrow;
+            hc.code_chip_rate = c.code_chip_rate;
+            hc.signal_carrier_freq = c.signal_carrier_freq;
+            hc.fs_in = c.fs_in;
+            hc.cfo_frequency_hz = c.cfo_frequency_hz;
+            hc.code_length_chips = c.code_length_chips;
+            hc.vector_length = c.vector_length;
+            hc.code_samples_per_chip_f = static_cast<float>(c.code_samples_per_chip);
             mail.code_seq = mail.cn0_seq = mail.carr_seq = mail.inputs_cn0 = mail.inputs_carr = 0;
             mail.lost = mail.lost_carrier = 0;
             mail.may_trip_code = (lk.code_lock_fail_counter + 1 > c.max_code_lock_fail) ? 1 : 0;
@@ -1318,17 +1333,24 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                     double st_doppler = s.carrier_doppler_hz, st_phase_rate = s.carrier_phase_rate_step_rad, st_code_rate = s.code_phase_rate_step_chips;
                     float st_rem_carr = s.rem_carr_phase_rad;
                     double code_error_filt_chips = mail.code_error_filt_chips;
+                    // (high-dynamics flavours: straight from the configuration, where they are used -- values the compiler may fetch again cost no register)
+                    double k_chip_rate = HD ? c.code_chip_rate : hc.code_chip_rate, k_carrier_freq = HD ? c.signal_carrier_freq : hc.signal_carrier_freq;
+                    double k_fs_in = HD ? c.fs_in : hc.fs_in, k_cfo = HD ? c.cfo_frequency_hz : hc.cfo_frequency_hz;
+                    unsigned k_code_length = HD ? c.code_length_chips : hc.code_length_chips, k_vlen = HD ? c.vector_length : hc.vector_length;
+                    float k_spcf = HD ? static_cast<float>(c.code_samples_per_chip) : hc.code_samples_per_chip_f;
+                    int st_narrow = HD ? 0 : lk.narrow;
                     if constexpr (!HD)  // (the high-dynamics flavours sit at the register limit: pinned there, the values cost scratch)
                         asm volatile("" : "+v"(st_code_freq), "+v"(st_rem_code_samples), "+v"(st_acc_phase), "+v"(st_doppler), "+v"(st_phase_rate), "+v"(st_code_rate), "+v"(st_rem_carr),
-                                     "+v"(code_error_filt_chips));
+                                     "+v"(code_error_filt_chips), "+v"(k_chip_rate), "+v"(k_carrier_freq), "+v"(k_fs_in), "+v"(k_cfo), "+v"(k_code_length), "+v"(k_vlen), "+v"(k_spcf),
+                                     "+v"(st_narrow));
                     double st_phase_step = 0.0, st_code_step = 0.0, st_rem_code_chips = 0.0;
                     auto join_and_update = [&](auto fast_tag) {
                     constexpr bool FAST = decltype(fast_tag)::value;
                     // ---- run_dll_pll, the join: trk.cc:1317-1324
                     if (run_state != 3)
                         {
-                            st_code_freq = c.code_chip_rate - code_error_filt_chips;
-                            if (CF(CF_CARRIER_AIDING)) st_code_freq += div_by_constant_if<FAST>(st_doppler * c.code_chip_rate, c.signal_carrier_freq, a.inv_signal_carrier_freq);
+                            st_code_freq = k_chip_rate - code_error_filt_chips;
+                            if (CF(CF_CARRIER_AIDING)) st_code_freq += div_by_constant_if<FAST>(st_doppler * k_chip_rate, k_carrier_freq, a.inv_signal_carrier_freq);
                             if (CF(CF_DOPPLER_CORRECTION) && !pull_in && !lk.corrected_doppler)  // trk.cc:1326-1346
                                 {
                                     lk.dll_filt_sum += static_cast<double>(static_cast<float>(code_error_filt_chips));
@@ -1364,11 +1386,11 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
 #endif
                     // ---- update_tracking_vars, trk.cc:1409-1483 (rate terms are zero outside high_dyn)
                     const double t_chip = 1.0 / st_code_freq;
-                    const double t_prn = t_chip * static_cast<double>(c.code_length_chips);
-                    const double t_prn_samples = t_prn * c.fs_in;
+                    const double t_prn = t_chip * static_cast<double>(k_code_length);
+                    const double t_prn_samples = t_prn * k_fs_in;
                     const double k_blk = t_prn_samples + st_rem_code_samples;
                     prn_len = static_cast<int>(floor(k_blk));
-                    st_phase_step = div_by_constant_if<FAST>(GNSS_TWO_PI_D * (st_doppler + c.cfo_frequency_hz), c.fs_in, a.inv_fs_in);
+                    st_phase_step = div_by_constant_if<FAST>(GNSS_TWO_PI_D * (st_doppler + k_cfo), k_fs_in, a.inv_fs_in);
                     if (HD)  // trk.cc:1425-1443
                         {
                             const int SL = static_cast<int>(c.smoother_length), cap = 2 * SL;
@@ -1396,7 +1418,7 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                     st_rem_carr += static_cast<float>(dphi);
                     st_rem_carr = static_cast<float>(fmod_two_pi<FAST>(static_cast<double>(st_rem_carr)));
                     st_acc_phase -= dphi;
-                    st_code_step = div_by_constant_if<FAST>(st_code_freq, c.fs_in, a.inv_fs_in);
+                    st_code_step = div_by_constant_if<FAST>(st_code_freq, k_fs_in, a.inv_fs_in);
                     if (HD)  // trk.cc:1458-1480
                         {
                             const int SL = static_cast<int>(c.smoother_length), cap = 2 * SL;
@@ -1420,7 +1442,7 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                                 }
                         }
                     st_rem_code_samples = k_blk - static_cast<double>(prn_len);
-                    st_rem_code_chips = div_by_constant_if<FAST>(st_code_freq * st_rem_code_samples, c.fs_in, a.inv_fs_in);
+                    st_rem_code_chips = div_by_constant_if<FAST>(st_code_freq * st_rem_code_samples, k_fs_in, a.inv_fs_in);
                     };
                     if (a.inv_fs_in != 0.0)
                         join_and_update(std::true_type{});
@@ -1545,6 +1567,7 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                                                     s.pll.w = keep_w;
                                                     s.pll.x = keep_x;
                                                     lk.narrow = 1;
+                                                    st_narrow = 1;
                                                     lk.spc_now = c.early_late_space_narrow_chips;
                                                 }
                                             else
@@ -1622,7 +1645,7 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                         }
                     // ... and the next window is formed from the registers (publish(): do_correlation_step's casts, trk.cc:1237-1243; the channel is active here)
                     {
-                        const float spcf = static_cast<float>(c.code_samples_per_chip);
+                        const float spcf = k_spcf;
                         win.pos = new_pos;
                         win.rem_carr = st_rem_carr;
                         win.phase_step = static_cast<float>(st_phase_step);
@@ -1630,10 +1653,10 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                         win.code_step = __fmul_rn(static_cast<float>(st_code_step), spcf);
                         win.phase_rate = static_cast<float>(st_phase_rate);
                         win.code_rate = __fmul_rn(static_cast<float>(st_code_rate), spcf);
-                        win.go = (e + 1 < a.n_epochs && new_pos + c.vector_length <= a.n_stream && new_pos >= a.ring_oldest) ? 1 : 0;
-                        win.narrow = lk.narrow;
+                        win.go = (e + 1 < a.n_epochs && new_pos + k_vlen <= a.n_stream && new_pos >= a.ring_oldest) ? 1 : 0;
+                        win.narrow = HD ? lk.narrow : st_narrow;
                     }
-                    if constexpr (LIVE) live_advance(a, new_pos, 1, win, lv, c.vector_length);
+                    if constexpr (LIVE) live_advance(a, new_pos, 1, win, lv, k_vlen);
 #ifdef GSH_TRK_PROFILE
                     if (NT == 3 && a.records != nullptr) rec_ref().accu[9] = static_cast<float>(clock64() - t_corr_done);  // ... + publish
 #if GSH_TRK_PROFILE == 2  // the correlation phase instead of the serial section: window set-up, trips, wave sums, barrier, sum over the waves + barrier, the loop's own barrier
