@@ -610,7 +610,11 @@ __device__ __forceinline__ void packed_trip(const JobCtx& c, const float* __rest
 // a lane's seed is T[4 + r] * L (one complex product), read from the table with v_readlane.  More than 60 re-seeds: the table is refilled.
 // NCH = 2 chunks per trip (four samples per lane) for the 256-thread batched kernel; NCH = 1 for the 1024-thread closed-loop kernel
 // (128 VGPRs per lane).  One summation order for every tap count, so fused and unfused jobs stay bit-identical.
-template <int NT, bool ZP, bool AUX, int NCH, int PF, bool DER = false, bool KC = false>
+// MRG (round 4, the 1 024-thread closed-loop kernel): ONE accumulator set.  Every sample is rotated by its own phasor -- pa for the pair's first sample, pa inc for its
+// second, pa w / pa w inc for chunk B: three more complex products per trip (six packed instructions) -- and all four products of a tap go into the same
+// accumulator; the fold at the end is gone.  24 accumulator registers become 6, which is what lets a 1 024-thread work-group (128 VGPRs) run TWO chunks per
+// trip: the per-trip overhead (phasor step, index step, loop control, edge tests, the wait for the look-ups) is paid once per four samples instead of once per two.
+template <int NT, bool ZP, bool AUX, int NCH, int PF, bool DER = false, bool KC = false, bool MRG = false>
 __device__ __forceinline__ void run_segment_packed(const JobCtx& c, const float2* __restrict__ base, const float* __restrict__ tab,
     const float (&sh)[NT], float2 (&acc)[NT], float2* acc_aux)
 {
@@ -630,10 +634,11 @@ __device__ __forceinline__ void run_segment_packed(const JobCtx& c, const float2
     // of 2 048, and only the first four of the sixteen waves have anything to do in the thirteenth.  Such a wave stops a trip early (its samples there
     // would all be read as zero); with the waves dealt round-robin to the SIMDs every SIMD then runs 49 wave-trips instead of 52.
     int n_trips = n_trips_all;
-    if constexpr (NCH == 1)
+    if constexpr (NCH == 1 || MRG)
         {
+            // (two chunks per trip: the wave's first samples of trip i are those of its chunk A, at n_first + i 2 NCH PPC + 128 wave)
             const int left = c.n_end - (c.n_first + 128 * (tid >> 6));  // samples from the wave's first slice to the end of the segment
-            n_trips = left <= 0 ? 0 : min(n_trips_all, (left + 2 * PPC - 1) / (2 * PPC));
+            n_trips = left <= 0 ? 0 : min(n_trips_all, (left + 2 * NCH * PPC - 1) / (2 * NCH * PPC));
             n_trips = __builtin_amdgcn_readfirstlane(n_trips);  // wave-uniform: keep the loop control scalar
         }
     const int first_plain = odd ? 1 : 0;                // trips [first_plain, last_plain) need no masking
@@ -677,6 +682,7 @@ __device__ __forceinline__ void run_segment_packed(const JobCtx& c, const float2
         return r;
     };
     const v2f w2 = table(2);
+    const v2f inc_s = table(0), w_s = table(1);  // exp(-j step), exp(-j 2 PPC step): wave-uniform (MRG: used in every trip; otherwise in the fold)
 
     // Loads run PF trips ahead of the arithmetic (a register queue, the trip loop unrolled by PF).  The batched kernel (many work-groups per
     // compute unit) gets by with PF = 1; the closed-loop kernel has ONE work-group per channel and ran PF = 4 until measurement showed PF = 1 to be as fast.
@@ -794,16 +800,33 @@ __device__ __forceinline__ void run_segment_packed(const JobCtx& c, const float2
                 if (NCH == 2) ib = (v2f){static_cast<float>(min(max(m0, lo), hi)), static_cast<float>(min(max(m0 + 1, lo), hi))};
             }
         // rotate first: the samples' registers are then free for the loads of trip i + PF, which take this trip's place in the queue
-        const v2f yA0 = pk_cmul((v2f){qa[j].x, qa[j].y}, pa);
-        const v2f yA1 = pk_cmul((v2f){qa[j].z, qa[j].w}, pa);
-        v2f yB0 = zero, yB1 = zero;
-        if (NCH == 2)
+        v2f yA0, yA1, yB0 = zero, yB1 = zero;
+        if constexpr (MRG)
             {
-                yB0 = pk_cmul((v2f){qb[j].x, qb[j].y}, pa);
-                yB1 = pk_cmul((v2f){qb[j].z, qb[j].w}, pa);
+                yA0 = pk_cmul((v2f){qa[j].x, qa[j].y}, pa);
+                yA1 = pk_cmul((v2f){qa[j].z, qa[j].w}, pk_cmul_s(pa, inc_s));
+                if (NCH == 2)
+                    {
+                        const v2f pb = pk_cmul_s(pa, w_s);
+                        yB0 = pk_cmul((v2f){qb[j].x, qb[j].y}, pb);
+                        yB1 = pk_cmul((v2f){qb[j].z, qb[j].w}, pk_cmul_s(pb, inc_s));
+                    }
+            }
+        else
+            {
+                yA0 = pk_cmul((v2f){qa[j].x, qa[j].y}, pa);
+                yA1 = pk_cmul((v2f){qa[j].z, qa[j].w}, pa);
+                if (NCH == 2)
+                    {
+                        yB0 = pk_cmul((v2f){qb[j].x, qb[j].y}, pa);
+                        yB1 = pk_cmul((v2f){qb[j].z, qb[j].w}, pa);
+                    }
             }
         if (i + PF < n_trips) load_trip(i + PF, qa[j], qb[j]);  // uniform
-        packed_trip<NT, ZP, AUX, NCH, FA, FB, KC>(c, tab, shp, k_step_nrem, aux_shp, aux_on, ia, ib, yA0, yA1, yB0, yB1, A0, A1, B0, B1, XA0, XA1, XB0, XB1);
+        if constexpr (MRG)  // (one set: the four references name the same registers, the accumulates follow one another)
+            packed_trip<NT, ZP, AUX, NCH, FA, FB, KC>(c, tab, shp, k_step_nrem, aux_shp, aux_on, ia, ib, yA0, yA1, yB0, yB1, A0, A0, A0, A0, XA0, XA0, XA0, XA0);
+        else
+            packed_trip<NT, ZP, AUX, NCH, FA, FB, KC>(c, tab, shp, k_step_nrem, aux_shp, aux_on, ia, ib, yA0, yA1, yB0, yB1, A0, A1, B0, B1, XA0, XA1, XB0, XB1);
         pa = pk_cmul_s(pa, w2);  // (w2 and the stride are wave-uniform: straight from SGPRs, not copied into VGPRs every trip)
         asm("v_pk_add_f32 %0, %0, %1" : "+v"(nfA) : "s"(stride));
         if (NCH == 2) asm("v_pk_add_f32 %0, %0, %1" : "+v"(nfB) : "s"(stride));
@@ -869,9 +892,23 @@ __device__ __forceinline__ void run_segment_packed(const JobCtx& c, const float2
                     (void)go;
                 }
         }
+    if constexpr (MRG)
+        {
+#pragma unroll
+            for (int t = 0; t < NT; t++)
+                {
+                    acc[t].x += A0[t].x;
+                    acc[t].y += A0[t].y;
+                }
+            if (aux_on)
+                {
+                    acc_aux->x += XA0.x;
+                    acc_aux->y += XA0.y;
+                }
+            return;
+        }
     // fold: acc += A0 + inc * A1 + w * (B0 + inc * B1)
-    const v2f incv = table(0), wv = table(1);
-    const float2 inc = make_float2(incv.x, incv.y), w = make_float2(wv.x, wv.y);
+    const float2 inc = make_float2(inc_s.x, inc_s.y), w = make_float2(w_s.x, w_s.y);
 #pragma unroll
     for (int t = 0; t < NT; t++)
         {
@@ -1097,10 +1134,14 @@ __device__ __forceinline__ void run_segment(const JobCtx& c, const float2* __res
 #if GSH_MC_PACKED
     if (!WRAP && MODE == 0 && c.packed && c.n_total < (1 << 24))
         {
+#ifndef GSH_MC_MERGED
+#define GSH_MC_MERGED 1
+#endif
+            constexpr bool MRG = GSH_MC_MERGED && MC_THREADS > 256;  // one accumulator set (run_segment_packed): the 1 024-thread closed-loop kernel
 #ifdef GSH_MC_NCH
             constexpr int NCH = (NT <= 3 && !AUX) ? GSH_MC_NCH : 1;
 #else
-            constexpr int NCH = (MC_THREADS <= 256) ? 2 : 1;
+            constexpr int NCH = (MC_THREADS <= 256 || (MRG && NT <= 3 && !AUX)) ? 2 : 1;
 #endif
 #ifdef GSH_MC_PREFETCH
             constexpr int PF = GSH_MC_PREFETCH;
@@ -1110,10 +1151,10 @@ __device__ __forceinline__ void run_segment(const JobCtx& c, const float2* __res
             if constexpr (PAIRK && NT == 3 && ZP && !AUX && PF == 1)
                 {
                     // early read next to late (packed_trip); the caller vouches for the job: shifts exactly one chip apart, code running forward
-                    run_segment_packed<NT, ZP, AUX, NCH, PF, true, KC>(c, base, tab, sh, acc, acc_aux);
+                    run_segment_packed<NT, ZP, AUX, NCH, PF, true, KC, MRG>(c, base, tab, sh, acc, acc_aux);
                     return;
                 }
-            run_segment_packed<NT, ZP, AUX, NCH, PF, false, KC>(c, base, tab, sh, acc, acc_aux);
+            run_segment_packed<NT, ZP, AUX, NCH, PF, false, KC, MRG>(c, base, tab, sh, acc, acc_aux);
             return;
         }
 #endif
