@@ -12,7 +12,7 @@ x = torch.view_as_complex(x).contiguous()
 # GSH_LOOP_AB_CONF: "lock" = with the lock detectors / C/N0 estimator (what the tracking adapters run with); "sync" = + symbol synchronisation (GPS L1 C/A preamble search)
 extra = {"": {}, "lock": dict(enable_lock_detectors=1, max_code_lock_fail=1 << 30, max_carrier_lock_fail=1 << 30),
          "sync": dict(enable_lock_detectors=1, max_code_lock_fail=1 << 30, max_carrier_lock_fail=1 << 30, enable_symbol_sync=1, symbols_per_bit=20, pull_in_time_s=0)}[os.environ.get("GSH_LOOP_AB_CONF", "")]
-for ch in (32, 256):
+for ch in ([int(os.environ['GSH_LOOP_AB_CH'])] if os.environ.get('GSH_LOOP_AB_CH') else [32, 256]):  # GSH_LOOP_AB_CH: one channel count only (counter passes)
     loop = TrackingLoop(trk_conf(fs_in=fs, vector_length=n, pll_bw_hz=35.0, dll_bw_hz=2.0, **extra), ch, 1023, device=0)
     loop.set_stream_device(x.data_ptr(), x.numel(), keepalive=x)
     rng = np.random.default_rng(1)
