@@ -888,26 +888,36 @@ void test_other_signal_trajectories()
 
 void test_loss_of_lock_on_noise()
 {
-    // noise only, with the lock thresholds tightened so that the detectors act within a few hundred periods: cn0_min 35 dB-Hz,
+    // (Round 4: cn0_min 40, not 35.  On noise the two loops part after a few hundred periods -- a rounding difference in a correlator output flips a window length,
+    //  and from there the noise-driven trajectories are different ones; the M2M4 estimate of this noise wanders between 22 and 35.3 dB-Hz, so with the limit at 35
+    //  the period in which the twenty-first fail comes depended on which trajectory it was.  At 40 every period after the pull-in transitory fails in both chains.)
+    // noise only, with the lock thresholds tightened so that the detectors act within a few hundred periods: cn0_min 40 dB-Hz,
     // max_lock_fail 20 (dll_pll_conf.cc: <role>.cn0_min, <role>.max_lock_fail).  Both chains must drop the channel in the same period, with
     // "events" 3 and one item carrying Flag_valid_symbol_output = false (trk.cc:1208-1221, 2009-2014, 2285-2294).
     const long fs = 4000000;
     const int n = 4000;
     const std::string R = "Tracking";
-    Props p{{"GNSS-SDR.internal_fs_sps", std::to_string(fs)}, {R + ".pull_in_time_s", "0"}, {R + ".hip_device", "0"}, {R + ".hip_register_input_buffer", "false"}, {R + ".cn0_min", "35"},
+    Props p{{"GNSS-SDR.internal_fs_sps", std::to_string(fs)}, {R + ".pull_in_time_s", "0"}, {R + ".hip_device", "0"}, {R + ".hip_register_input_buffer", "false"}, {R + ".cn0_min", "40"},
         {R + ".max_lock_fail", "20"}};
-    auto cfg = make_config(p);
+    Props ph = p;
+    if (std::getenv("GSH_TEST_LOSS_DUMP") != nullptr)  // the HIP block's records to <file>1.dat (a debugging aid; the reference block is not given the key)
+        {
+            ph[R + ".dump"] = "true";
+            ph[R + ".dump_mat"] = "false";
+            ph[R + ".dump_filename"] = std::getenv("GSH_TEST_LOSS_DUMP");
+        }
+    auto cfg = make_config(ph);
     GpsL1CaDllPllTrackingHip hip(cfg.get(), R, 1, 1);
     if (hip.item_size() == 0) return;
     void* ref = make_ref("GPS_L1_CA_DLL_PLL_Tracking", R, p);
-    EXPECT(hip.trk_conf().cn0_min == 35 && hip.trk_conf().max_code_lock_fail == 20, "cn0_min %d max_code_lock_fail %d", hip.trk_conf().cn0_min,
+    EXPECT(hip.trk_conf().cn0_min == 40 && hip.trk_conf().max_code_lock_fail == 20, "cn0_min %d max_code_lock_fail %d", hip.trk_conf().cn0_min,
         hip.trk_conf().max_code_lock_fail);
     std::vector<float> code(1023, 1.0F);
     const auto x = synth(code, nullptr, 0.0, 1.023e6, 1, fs, 0.0, 1575.42e6, static_cast<size_t>(2600) * n, 0.0F, {}, nullptr, 21);  // noise only
     Gnss_Synchro syn;
     const TrajectoryStats st = run_pair(hip, ref, syn, x, n, 2500, 'G', "1C", 3, 100.0, 500.0, n);
-    std::printf("noise only: loss of lock at period %d (HIP block) / %d (reference), %d periods with identical windows\n", st.loss_period_hip, st.loss_period_ref,
-        st.same_windows);
+    std::printf("noise only: loss of lock at period %d (HIP block) / %d (reference), %d periods with identical windows; last C/N0 %.2f / %.2f dB-Hz, Doppler %.1f / %.1f Hz\n",
+        st.loss_period_hip, st.loss_period_ref, st.same_windows, st.final_cn0_hip, st.final_cn0_ref, st.final_doppler_hip, st.final_doppler_ref);
     EXPECT(st.loss_period_ref >= 0, "the reference did not drop the channel in %d periods -- test set-up", st.periods);
     EXPECT(st.loss_period_hip == st.loss_period_ref, "loss of lock at period %d vs reference %d", st.loss_period_hip, st.loss_period_ref);
     EXPECT(st.loss_item_hip && st.loss_item_ref, "loss of lock must come with an item whose Flag_valid_symbol_output is false (hip %d, reference %d)", st.loss_item_hip,
@@ -966,6 +976,13 @@ int main(int argc, char** argv)
             test_shared_runtime_threads(ch, periods, ppc, host_threads);
             test_shared_runtime_threads(std::max(2, ch / 2), 500, 1, host_threads);
             std::printf(fails == 0 ? "TRACKING RUNTIME OK\n" : "%d failure(s)\n", fails);
+            return fails == 0 ? 0 : 1;
+        }
+    if (mode == "loss")  // only the loss-of-lock case
+        {
+            if (gsh_device_count() < 1) return 2;
+            test_loss_of_lock_on_noise();
+            std::printf(fails == 0 ? "LOSS OF LOCK OK\n" : "%d failure(s)\n", fails);
             return fails == 0 ? 0 : 1;
         }
     test_conf_mapping();

@@ -225,6 +225,29 @@ def test_lock_detectors_and_cn0_on_device(gpu):
     loop.close()
 
 
+def test_carrier_lock_counter_drops_a_noise_channel(gpu):
+    """The two halves of cn0_and_tracking_lock_status run on two waves of the loop kernel and thread 0 waits for their verdict only in a period in which a fail
+    counter can pass its limit (csrc/tracking_loop.hip, SerialMail).  Here the CARRIER counter is the one that passes it (the code limit is out of reach): on noise
+    the smoothed carrier lock test stays far below carrier_lock_th, so every period after the pull-in transitory fails and the channel is dropped
+    max_carrier_lock_fail + 1 periods later -- in the same period as in the oracle loop; then the same with the code counter, with both, and with the symbol
+    synchronisation running."""
+    fs, n, epochs = 4e6, 4000, 1100
+    x = synth_gps_l1_stream((epochs + 3) * n, fs, [], [], [], seed_noise=21)
+    for kw in (dict(max_carrier_lock_fail=20, max_code_lock_fail=1 << 30), dict(max_carrier_lock_fail=1 << 30, max_code_lock_fail=20, cn0_min=40),
+               dict(max_carrier_lock_fail=20, max_code_lock_fail=20, cn0_min=40, enable_symbol_sync=1, symbols_per_bit=20)):
+        conf = dict(dict(fs_in=fs, vector_length=n, pll_bw_hz=35.0, dll_bw_hz=2.0, pull_in_time_s=0, enable_lock_detectors=1, cn0_min=35), **kw)
+        loop = _loop(gpu, conf, n_channels=1, max_len=1023)
+        loop.set_stream_host(x)
+        loop.start(0, oracle.ca_code(3), 100, 0, 500.0)
+        rec, done = loop.run(epochs)
+        loop.close()
+        ora = oracle.trk_run(oracle.trk_conf(**conf), oracle.ca_code(3), x, 100, 0, 500.0, epochs)
+        assert ora[-1].flags & 2 and len(ora) < epochs, kw
+        assert int(done[0]) == len(ora) and rec[0][int(done[0]) - 1].flags & 2, (kw, int(done[0]), len(ora))
+        first_free = next(i for i, r in enumerate(rec[0]) if not (r.flags & 1))
+        assert int(done[0]) - 1 == first_free + 20, (kw, int(done[0]), first_free)  # the twenty-first fail after the pull-in transitory
+
+
 def test_loop_follows_a_live_ring(gpu):
     """gsh_trk_set_stream_ring: the loop works through whatever the ring holds at each gsh_trk_run call and continues after the next
     push; the ring is much shorter than the stream (it wraps many times) and is fed with 8-bit items.  Same kernel, same arithmetic,
