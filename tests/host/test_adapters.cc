@@ -655,6 +655,96 @@ void e5a_reference_block_side_by_side()
     }
 }
 
+// The reference's own pcps_acquisition block searching the window that starts at `window_start`: inactive (it only consumes and counts, acq.cc:768-779) up to that
+// read pointer, activated there, fed the stream in chunks until it reports.  What a rendezvoused HIP block -- which skipped to the same line of the common grid
+// before it buffered its window -- must report too.
+SharedAcqOutcome reference_block_from(const std::vector<std::complex<float>>& x, long fs, uint32_t prn, size_t window_start, size_t chunk)
+{
+    typedef std::map<std::string, std::string> P;
+    const std::string R = "Acquisition_1C";
+    const P props{{"GNSS-SDR.internal_fs_sps", std::to_string(fs)}, {R + ".doppler_max", "5000"}, {R + ".doppler_step", "250"}, {R + ".blocking", "true"}, {R + ".pfa", "0.001"}};
+    std::vector<const char*> k, v;
+    for (const auto& kv : props)
+        {
+            k.push_back(kv.first.c_str());
+            v.push_back(kv.second.c_str());
+        }
+    const int32_t extra[3] = {0, 0, 0};
+    SharedAcqOutcome o;
+    void* ref = refacq_create(0, R.c_str(), k.data(), v.data(), static_cast<int>(k.size()), GPS_L1_CA_CODE_RATE_CPS, GPS_L1_CA_OPT_ACQ_FS_SPS, 1, extra);
+    EXPECT(ref != nullptr, "reference block for the grid-aligned window");
+    if (ref == nullptr) return o;
+    refacq_status st{};
+    refacq_get_status(ref, &st);
+    std::vector<std::complex<float>> code(st.consumed_samples);
+    {
+        const size_t spms = static_cast<size_t>(fs / 1000);
+        std::vector<std::complex<float>> one(spms);
+        gps_l1_ca_code_gen_complex_sampled(one, prn, static_cast<int32_t>(fs), 0);
+        for (size_t i = 0; i < code.size(); i++) code[i] = one[i % spms];
+    }
+    refacq_set_satellite(ref, 'G', "1C", prn);
+    refacq_set_local_code(ref, reinterpret_cast<const float*>(code.data()), nullptr);
+    size_t pos = 0;
+    while (pos < window_start)  // standby
+        {
+            const size_t avail = std::min<size_t>(window_start - pos, 1000);
+            int rc = 0;
+            refacq_general_work(ref, x.data() + pos, static_cast<int>(avail), 1, &rc);
+            pos += static_cast<size_t>(rc);
+        }
+    refacq_set_active(ref, 1);
+    for (int calls = 0; calls < 100000; calls++)
+        {
+            const size_t avail = std::min(chunk, x.size() - pos);
+            if (avail == 0) break;
+            int rc = 0;
+            refacq_general_work(ref, x.data() + pos, static_cast<int>(avail), 1, &rc);
+            pos += static_cast<size_t>(rc);
+            refacq_get_status(ref, &st);
+            if (st.n_events > 0) break;
+        }
+    refacq_get_status(ref, &st);
+    o.event = st.n_events > 0 ? st.events[st.n_events - 1] : 0;
+    o.delay = st.acq_delay_samples;
+    o.doppler = st.acq_doppler_hz;
+    o.stamp = st.acq_samplestamp_samples;
+    refacq_destroy(ref);
+    return o;
+}
+
+// the rendezvous changes WHICH samples a search looks at (a block skips to the next line of the common grid); so the rendezvoused blocks are held
+// against reference blocks fed exactly those grid-aligned windows -- not only against HIP blocks on their own handles.
+void rendezvoused_blocks_against_reference_blocks()
+{
+    const long fs = 4000000;
+    const int n_blocks = 8;
+    std::vector<std::complex<float>> rep(4000);
+    gps_l1_ca_code_gen_complex_sampled(rep, 14, static_cast<int32_t>(fs), 0);
+    const auto x = make_stream(rep, 60000, fs, 1234, 1760.0, 0.12F, 5);
+    const std::vector<uint32_t> prns = {14, 3, 7, 21, 14, 30, 9, 14};
+    for (int variant = 0; variant < 2; variant++)
+        {
+            std::vector<size_t> standby;
+            for (int c = 0; c < n_blocks; c++) standby.push_back(variant == 0 ? 0 : 4100 + 311 * static_cast<size_t>(c));  // 0: window [0, 4000); staggered: the grid line 8000 for all
+            const size_t window_start = variant == 0 ? 0 : 8000;
+            Hip_Acquisition_Runtime::Stats st;
+            const auto shared = run_acquisition_blocks(n_blocks, 9 + variant, x, fs, prns, standby, &st);
+            int same = 0;
+            for (size_t c = 0; c < shared.size(); c++)
+                {
+                    const SharedAcqOutcome r = reference_block_from(x, fs, prns[c], window_start, 700 + 97 * c);
+                    const bool ok = shared[c].event == r.event && (r.event != 1 || (shared[c].delay == r.delay && shared[c].doppler == r.doppler && shared[c].stamp == r.stamp));
+                    EXPECT(ok, "rendezvoused block %zu (PRN %u, window from %zu): event %ld / %ld, delay %.3f / %.3f, Doppler %.1f / %.1f, stamp %llu / %llu (HIP / reference block)", c,
+                        prns[c], window_start, shared[c].event, r.event, shared[c].delay, r.delay, shared[c].doppler, r.doppler, static_cast<unsigned long long>(shared[c].stamp),
+                        static_cast<unsigned long long>(r.stamp));
+                    same += ok ? 1 : 0;
+                }
+            std::printf("rendezvoused acquisition, window from sample %zu: %d of %zu blocks report what the reference block reports over that window (event, delay, Doppler, stamp)\n",
+                window_start, same, shared.size());
+        }
+}
+
 void reference_block_side_by_side()
 {
     const long fs = 4000000;
@@ -910,6 +1000,7 @@ int main(int argc, char** argv)
     run_simple_case<QzssL5iPcpsAcquisitionHip>("QZSS L5I", "Acquisition_J5", 25000000, 'J', "J5", 194, "QZSS_L5i_PCPS_Acquisition_HIP",
         [](std::vector<std::complex<float>>& rep) { qzss_l5i_code_gen_complex_sampled(rep, 194, 25000000); }, 12321, -1500.0, 0.0, 28);
     reference_block_side_by_side();
+    rendezvoused_blocks_against_reference_blocks();
     e5a_reference_block_side_by_side();
     test_acquisition_dump();
     test_shared_acquisition();
