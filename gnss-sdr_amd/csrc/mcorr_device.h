@@ -1137,7 +1137,10 @@ __device__ __forceinline__ void run_segment(const JobCtx& c, const float2* __res
 #ifndef GSH_MC_MERGED
 #define GSH_MC_MERGED 1
 #endif
-            constexpr bool MRG = GSH_MC_MERGED && MC_THREADS > 256;  // one accumulator set (run_segment_packed): the 1 024-thread closed-loop kernel
+#ifndef GSH_MC_MERGED_BANK
+#define GSH_MC_MERGED_BANK 0  // 1: the batched 256-thread kernel too (A/B switch: profiles/ab/r04/mcorr_merged_ab.txt -- slower there, the trip is bound by instruction issue)
+#endif
+            constexpr bool MRG = GSH_MC_MERGED && (MC_THREADS > 256 || GSH_MC_MERGED_BANK);  // one accumulator set (run_segment_packed): the 1 024-thread closed-loop kernel
 #ifdef GSH_MC_NCH
             constexpr int NCH = (NT <= 3 && !AUX) ? GSH_MC_NCH : 1;
 #else

@@ -78,7 +78,7 @@ def main():
     legs = {name: read_counters(os.path.join(d, name)) for name in ("fetch", "write", "sq1", "sq2", "tcc")}
     out = {}
     for label, sub, extra in (("mcorr", "mcorr_kernel<3, 0, false", {}), ("oc_cell", "oc_cell_kernel", {}), ("oc_forward", "oc_forward_kernel", {}),
-                              ("trk_loop", "trk_loop_kernel<3, false>", {}), ("oc_subcell_dit", "oc_subcell_dit_kernel", {}), ("oc_combine_dit", "oc_combine_dit_kernel", {})):
+                              ("trk_loop", "trk_loop_kernel<3, false, false>", {}), ("oc_subcell_dit", "oc_subcell_dit_kernel", {}), ("oc_combine_dit", "oc_combine_dit_kernel", {})):
         rec = {}
         for leg in legs.values():
             kk = find(leg, sub)
