@@ -25,6 +25,12 @@ namespace GSH_MC_NS
 constexpr int MC_THREADS = GSH_MC_THREADS;
 constexpr int MC_WAVES = MC_THREADS / 64;
 constexpr int MC_MARGIN = 32;  // guard entries on each side of the LDS code table
+#ifndef GSH_MC_SCAN_ALL_AT_ONCE
+#define GSH_MC_SCAN_ALL_AT_ONCE 1  // wave sums of the 1 024-thread kernel: one v_add_f32_dpp per value and step (round 4: 7.63 -> 7.50 us per period)
+#endif
+#ifndef GSH_MC_SINGLE_SEED
+#define GSH_MC_SINGLE_SEED 1  // one transcendental evaluation per lane and window in the 1 024-thread kernel (run_segment_packed; round 4: 7.50 -> 7.43 us per period)
+#endif
 #ifndef GSH_MC_RESEED
 #define GSH_MC_RESEED 32
 #endif
@@ -656,7 +662,39 @@ __device__ __forceinline__ void run_segment_packed(const JobCtx& c, const float2
     const bool aux_on = AUX && c.aux_on;
     const double sd = static_cast<double>(c.phase_step);
 
-    const float2 Lf = expmj(static_cast<double>(2 * tid) * sd);
+    // MRG, windows of at most RESEED trips (one exact seed per lane and window -- every tracking window below 65 536 samples): ONE transcendental evaluation per lane instead
+    // of two.  The lane evaluates its own seed exp(-j (rem + (n_first + 2 tid) step)) directly; lanes 0..2 of every wave evaluate the three wave-uniform rotations
+    // instead and get their seeds from lane 3's, two samples back per lane (products with conj(inc)^2: one to three more roundings on three lanes of sixty-four).
+    const bool single = GSH_MC_SINGLE_SEED && MRG && (n_trips_all <= RESEED);  // uniform
+    v2f seed_direct = zero, single_inc = zero, single_w = zero, single_w2 = zero;
+    if (single)
+        {
+            double ph;
+            if (lane == 0)
+                ph = sd;
+            else if (lane == 1)
+                ph = static_cast<double>(2 * PPC) * sd;
+            else if (lane == 2)
+                ph = static_cast<double>(2 * NCH * PPC) * sd;
+            else
+                ph = static_cast<double>(c.rem_carr) + static_cast<double>(c.n_first + 2 * tid) * sd;
+            const float2 E = expmj(ph);
+            auto lane_of = [&](int l) -> float2 {
+                return make_float2(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, E.x), l)),
+                    __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, E.y), l)));
+            };
+            const float2 i1 = lane_of(0), w1 = lane_of(1), w21 = lane_of(2), s3 = lane_of(3);
+            const float2 ci = make_float2(i1.x, -i1.y);
+            const float2 q = cmul(ci, ci);
+            const float2 s2 = cmul(s3, q), s1 = cmul(s2, q), s0 = cmul(s1, q);
+            const float2 mine = lane == 0 ? s0 : (lane == 1 ? s1 : (lane == 2 ? s2 : E));
+            seed_direct = (v2f){mine.x, mine.y};
+            single_inc = (v2f){i1.x, i1.y};
+            single_w = (v2f){w1.x, w1.y};
+            single_w2 = (v2f){w21.x, w21.y};
+        }
+    float2 Lf = make_float2(1.0f, 0.0f);
+    if (!single) Lf = expmj(static_cast<double>(2 * tid) * sd);
     const v2f L = {Lf.x, Lf.y};
     auto fill_table = [&](int r0) -> float2 {  // entry of this lane for the re-seeds r0 .. r0 + TBL - 1
         double ph;
@@ -674,15 +712,16 @@ __device__ __forceinline__ void run_segment_packed(const JobCtx& c, const float2
             }
         return expmj(ph);
     };
-    float2 T = fill_table(0);
+    float2 T = make_float2(1.0f, 0.0f);
+    if (!single) T = fill_table(0);
     auto table = [&](int l) -> v2f {
         v2f r;
         r.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, T.x), l));
         r.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, T.y), l));
         return r;
     };
-    const v2f w2 = table(2);
-    const v2f inc_s = table(0), w_s = table(1);  // exp(-j step), exp(-j 2 PPC step): wave-uniform (MRG: used in every trip; otherwise in the fold)
+    const v2f w2 = single ? single_w2 : table(2);
+    const v2f inc_s = single ? single_inc : table(0), w_s = single ? single_w : table(1);  // exp(-j step), exp(-j 2 PPC step): wave-uniform (MRG: used in every trip; otherwise in the fold)
 
     // Loads run PF trips ahead of the arithmetic (a register queue, the trip loop unrolled by PF).  The batched kernel (many work-groups per
     // compute unit) gets by with PF = 1; the closed-loop kernel has ONE work-group per channel and ran PF = 4 until measurement showed PF = 1 to be as fast.
@@ -774,12 +813,15 @@ __device__ __forceinline__ void run_segment_packed(const JobCtx& c, const float2
         const int n0 = (c.n_first + i * TRIP) + 2 * tid;  // (uniform part first: used at re-seeds and edges only)
         if (until_reseed == 0)  // uniform: exact re-seed of the lane's phasor and of (float)n
             {
-                if (r_idx - tbl0 >= TBL)
+                if (!single && r_idx - tbl0 >= TBL)
                     {
                         tbl0 = r_idx;
                         T = fill_table(tbl0);
                     }
-                pa = pk_cmul(table(4 + r_idx - tbl0), L);
+                if (single)
+                    pa = seed_direct;
+                else
+                    pa = pk_cmul(table(4 + r_idx - tbl0), L);
                 nfA = (v2f){static_cast<float>(n0), static_cast<float>(n0 + 1)};
                 nfB = (v2f){static_cast<float>(n0 + 2 * PPC), static_cast<float>(n0 + 2 * PPC + 1)};
                 until_reseed = RESEED;
@@ -1368,16 +1410,42 @@ __device__ __forceinline__ void correlate_window(const float2* __restrict__ stre
     // outputs and passes a barrier of its own before the next call writes them again.
     // (the per-value form here: in the 1024-thread kernel the all-at-once v_add_f32_dpp form of the batched kernel keeps a dozen values live through 72
     //  instructions at the most crowded point of the function and sends registers to scratch)
+#if GSH_MC_SCAN_ALL_AT_ONCE
+    // (round 4: with one accumulator set the registers are there -- one v_add_f32_dpp per value and step instead of v_mov_b32_dpp + v_add_f32)
+    if constexpr (mode_hd_code(MODE) == false && NT <= 3)
+        {
+            constexpr int NV = 2 * NT + (AUX ? 2 : 0);
+            float v[NV];
 #pragma unroll
-    for (int t = 0; t < NT; t++)
-        {
-            acc[t].x = wave_scan_incl(acc[t].x);
-            acc[t].y = wave_scan_incl(acc[t].y);
+            for (int t = 0; t < NT; t++)
+                {
+                    v[2 * t] = acc[t].x;
+                    v[2 * t + 1] = acc[t].y;
+                }
+            if (AUX)
+                {
+                    v[2 * NT] = acc_aux.x;
+                    v[2 * NT + 1] = acc_aux.y;
+                }
+            wave_scan_incl_n<NV>(v);
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[t] = make_float2(v[2 * t], v[2 * t + 1]);
+            if (AUX) acc_aux = make_float2(v[2 * NT], v[2 * NT + 1]);
         }
-    if (AUX)
+    else
+#endif
         {
-            acc_aux.x = wave_scan_incl(acc_aux.x);
-            acc_aux.y = wave_scan_incl(acc_aux.y);
+#pragma unroll
+            for (int t = 0; t < NT; t++)
+                {
+                    acc[t].x = wave_scan_incl(acc[t].x);
+                    acc[t].y = wave_scan_incl(acc[t].y);
+                }
+            if (AUX)
+                {
+                    acc_aux.x = wave_scan_incl(acc_aux.x);
+                    acc_aux.y = wave_scan_incl(acc_aux.y);
+                }
         }
     const int wave = tid >> 6;
     float2* const part = red + GSH_MAX_TAPS;

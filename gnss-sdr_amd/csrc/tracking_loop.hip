@@ -1060,6 +1060,7 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                     }
             };
             const int seq = e + 1;  // the period's number inside the launch: what the lanes say when they are done
+            const bool flag_join = !HD && CF(CF_LOCK_DETECTORS);  // how the lanes meet (below); uniform over the work-group
             auto say = [&](int& word) {
                 if constexpr (!HD) lane_says(word, seq);  // (the high-dynamics flavours join at a barrier, below)
             };
@@ -1230,7 +1231,9 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                             mail.may_trip_carr = (CF(CF_LOCK_DETECTORS) && lk.carrier_lock_fail_counter + 1 > c.max_carrier_lock_fail) ? 1 : 0;
                             if (rp != nullptr) rec_set<LIVE>(rp->carrier_lock_test, CF(CF_LOCK_DETECTORS) ? lk.carrier_lock_test : 0.0);
                             // (thread 0 rewrites some of this lane's record fields when the channel loses lock: the stores above have to have landed by then)
-                            if constexpr (!LIVE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            // (only where the lanes meet through the words: in front of a barrier the wait would hold everybody up for the stores' round trip)
+                            if constexpr (!LIVE)
+                                if (flag_join) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                             say(mail.carr_seq);
                         }
                       }
@@ -1238,7 +1241,6 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
             // No barrier here when the lock detectors run: see SerialMail.  Without them there is nothing to overlap and the barrier is the cheaper meeting (thread 0's
             // look at the words costs an LDS round trip and a few comparisons, ~200 clocks: 8.05 against 7.93 us per period); the high-dynamics flavours, at the
             // register limit, keep the barrier as well.
-            const bool flag_join = !HD && CF(CF_LOCK_DETECTORS);  // (uniform over the work-group)
             if (!flag_join) __syncthreads();
             if constexpr (LIVE)
               if (tid == 64 * SERIAL_WAVES && lv.head != lv.head_fenced)
