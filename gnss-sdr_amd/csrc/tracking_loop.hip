@@ -148,6 +148,9 @@ struct SerialMail  // results the code-loop lane and the lock-detector lane hand
     int pad0;
     int may_trip_code, may_trip_carr;
     int cn0_seq, carr_seq;
+#ifdef GSH_TRK_PROFILE
+    long long t_lane[4];  // when each of the four lanes was done, in clocks since the correlation ended (-DGSH_TRK_PROFILE=3 puts them into the record)
+#endif
 };
 // true when the code lane and the two `inputs` words say `seq`; may_trip = may_trip_code | may_trip_carr as read in the same go
 __device__ __forceinline__ bool join_ready(SerialMail& m, int seq, int& may_trip)
@@ -1141,6 +1144,9 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                                         {
                                             carr_error_filt = fll_pll_carrier_error(pl, 0.0f, static_cast<float>(carr_phase_error_hz), static_cast<float>(corr_time));
                                         }
+#ifdef GSH_TRK_PROFILE
+                                    mail.t_lane[0] = clock64() - t_corr_done;
+#endif
                                     s.pll.w = pl.w;  // (the filter's memories; its coefficients are not written)
                                     s.pll.x = pl.x;
                                     carr_error_filt_hz = carr_error_filt;
@@ -1162,6 +1168,9 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                                 }
                             mail.code_error_chips = code_error_chips;
                             mail.code_error_filt_chips = code_error_filt_chips;
+#ifdef GSH_TRK_PROFILE
+                            mail.t_lane[1] = clock64() - t_corr_done;
+#endif
                             say(mail.code_seq);
                             if (a.records != nullptr)
                                 {
@@ -1190,6 +1199,9 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                             mail.lost = lost_now ? 1 : 0;
                             mail.may_trip_code = (CF(CF_LOCK_DETECTORS) && lk.code_lock_fail_counter + 1 > c.max_code_lock_fail) ? 1 : 0;  // (next period: the counter moves by one)
                             if (a.records != nullptr) rec_set<LIVE>(rec_ref().cn0_db_hz, CF(CF_LOCK_DETECTORS) ? lk.cn0_db_hz : 0.0f);
+#ifdef GSH_TRK_PROFILE
+                            mail.t_lane[2] = clock64() - t_corr_done;
+#endif
                             say(mail.cn0_seq);
                         }
                         if (tid == 64 * CARR_LOCK_WAVE)
@@ -1234,6 +1246,9 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                             // (only where the lanes meet through the words: in front of a barrier the wait would hold everybody up for the stores' round trip)
                             if constexpr (!LIVE)
                                 if (flag_join) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef GSH_TRK_PROFILE
+                            mail.t_lane[3] = clock64() - t_corr_done;
+#endif
                             say(mail.carr_seq);
                         }
                       }
@@ -1661,6 +1676,16 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                     if constexpr (LIVE) live_advance(a, new_pos, 1, win, lv, k_vlen);
 #ifdef GSH_TRK_PROFILE
                     if (NT == 3 && a.records != nullptr) rec_ref().accu[9] = static_cast<float>(clock64() - t_corr_done);  // ... + publish
+#if GSH_TRK_PROFILE == 3  // when each lane was done (the detector lanes' stamps are last period's when they run beside thread 0)
+                    if (NT == 3 && a.records != nullptr)
+                        {
+                            gsh_trk_epoch& r = rec_ref();
+                            r.accu[6] = static_cast<float>(mail.t_lane[0]);
+                            r.accu[7] = static_cast<float>(mail.t_lane[1]);
+                            r.accu[8] = static_cast<float>(mail.t_lane[2]);
+                            r.corr[9] = static_cast<float>(mail.t_lane[3]);
+                        }
+#endif
 #if GSH_TRK_PROFILE == 2  // the correlation phase instead of the serial section: window set-up, trips, wave sums, barrier, sum over the waves + barrier, the loop's own barrier
                     if (NT == 3 && a.records != nullptr)
                         {

@@ -23,6 +23,10 @@ for ch in (32,):
         f = lambda get: np.array([[get(r) for r in rr] for rr in rec])[:, 5:].mean()
         print("  correlation phase, clocks: set-up %.0f  trips %.0f  wave sums + partials %.0f  barrier %.0f  sum over waves + barrier %.0f  read-out + barrier %.0f" % (
             f(lambda r: r.corr[8]), f(lambda r: r.corr[9]), f(lambda r: r.accu[6]), f(lambda r: r.accu[7]), f(lambda r: r.accu[8]), f(lambda r: r.accu[9])))
+    elif os.environ.get("GSH_PHASE_DETAIL") == "3":  # library built with -DGSH_TRK_PROFILE=3
+        f = lambda get: np.array([[get(r) for r in rr] for rr in rec])[:, 5:].mean()
+        print("  lanes done, clocks after the correlation: carrier %.0f  code %.0f  C/N0 %.0f  carrier lock + record %.0f   (meeting over at %.0f)" % (
+            f(lambda r: r.accu[6]), f(lambda r: r.accu[7]), f(lambda r: r.accu[8]), f(lambda r: r.corr[9]), f(lambda r: r.corr[8])))
     elif os.environ.get("GSH_PHASE_DETAIL"):
         f = lambda get: np.array([[get(r) for r in rr] for rr in rec])[:, 5:].mean()
         print("  serial section, clocks: three lanes side by side + barrier %.0f  join %.0f  update_tracking_vars %.0f  symbol+record %.0f  publish %.0f" % (
