@@ -660,19 +660,24 @@ __device__ __forceinline__ void live_advance(const TrkArgs& a, unsigned long lon
 {
     // (no store into host memory here: thread 0 would wait for its acknowledgement -- a PCIe round trip -- at the barrier that ends the period.  The
     // channel's position and the count of complete records go out with the record, from the wave that writes it at the top of the next period.)
+    // The words come out of LDS in one go (pinned by the asm: read one by one in front of their uses they were half a dozen dependent round trips on thread 0's path).
+    unsigned long long seq = v.seq, consumed = v.consumed, t_start = v.t_start, now = v.now, head = v.head, origin = v.origin, pub_pos = v.pub_pos, wpos = v.wpos;
+    int quit = v.quit;
+    asm volatile("" : "+v"(seq), "+v"(consumed), "+v"(t_start), "+v"(now), "+v"(head), "+v"(origin), "+v"(pub_pos), "+v"(wpos), "+v"(quit));
     {
-        unsigned long long w2 = v.wpos + (s_pos - v.pub_pos);  // a period advances the window by far less than the ring holds
+        unsigned long long w2 = wpos + (s_pos - pub_pos);  // a period advances the window by far less than the ring holds
         if (w2 >= a.ring_capacity) w2 -= a.ring_capacity;
         v.wpos = w2;
     }
     v.pub_pos = s_pos;
-    v.seq += 1ull;
-    v.out_valid = 1;  // this period's record is complete in LDS (the lanes' stores lie before the barrier that joined them, thread 0's are its own)
-    const unsigned long long oldest = live_oldest(v.head, v.origin, a.ring_capacity);
-    const bool resident = s_active && (s_pos + vlen <= v.head) && (s_pos >= oldest);
-    const bool room = (v.seq - v.consumed) < static_cast<unsigned long long>(a.live.ring_len);
-    const bool in_budget = (v.now - v.t_start) < a.live.residency_ticks;  // (the clock is the look-out lane's reading: s_memrealtime is a memory operation, ~a microsecond)
-    w.go = (resident && room && in_budget && !v.quit) ? 1 : 2;
+    seq += 1ull;
+    v.seq = seq;
+    v.out_valid = 1;  // this period's record is complete in LDS (the lanes' stores lie before the barrier that ends the period, thread 0's are its own)
+    const unsigned long long oldest = live_oldest(head, origin, a.ring_capacity);
+    const bool resident = s_active && (s_pos + vlen <= head) && (s_pos >= oldest);
+    const bool room = (seq - consumed) < static_cast<unsigned long long>(a.live.ring_len);
+    const bool in_budget = (now - t_start) < a.live.residency_ticks;  // (the clock is the look-out lane's reading: s_memrealtime is a memory operation, ~a microsecond)
+    w.go = (resident && room && in_budget && !quit) ? 1 : 2;
 }
 
 // The drain round: every record store of the channel has completed (the lanes that store have waited, a barrier lies in between), so the full count is
@@ -928,7 +933,7 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                     }
             }
             // live mode, between a wave's last trip and the barrier that ends the correlation (where the waves that finish first idle anyway):
-            //   the look-out lane -- lane 0 of the first wave without loop arithmetic -- reads how far the ring is complete by now (and, every 16th period, the host's
+            //   the look-out lane -- lane 0 of the first wave without loop arithmetic -- reads how far the ring is complete by now (and, every 64th period -- half a millisecond --, the host's
             //   quit word: host memory, a PCIe round trip);  its wave waits for the record it wrote out at the top of the period (the drain rule).
             auto live_hook = [&]() {
                 if constexpr (LIVE)
@@ -938,7 +943,7 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                                 const unsigned long long head = __hip_atomic_load(a.live.head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                 const unsigned long long origin = __hip_atomic_load(a.live.head + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                 int quit = 0;
-                                if ((static_cast<unsigned>(lv.seq) & 15u) == 15u) quit = __hip_atomic_load(a.live.quit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                if ((static_cast<unsigned>(lv.seq) & 63u) == 63u) quit = __hip_atomic_load(a.live.quit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                                 lv.now = wall_clock64();
                                 lv.head = head;
                                 lv.origin = origin;
