@@ -225,6 +225,32 @@ def test_lock_detectors_and_cn0_on_device(gpu):
     loop.close()
 
 
+@pytest.mark.parametrize("cn0_samples", [1, 7, 16, 17, 33, 64])
+def test_cn0_estimator_over_buffers_of_every_shape(gpu, cn0_samples):
+    """The M2M4 sums are formed by the 64 lanes of one wave in rows of sixteen (csrc/tracking_loop.hip, m2m4_sums_wave): buffer lengths inside one row, exactly one row,
+    one element into the next row, three rows and all four -- C/N0 and carrier lock test along the oracle loop's, and the carrier-lock half's own copy of the buffer's
+    first element (it is what carrier_lock_detector(buffer, 1) looks at, trk.cc:1184) with buffers of one element and of many."""
+    fs, n, epochs = 2.046e6, 2046, 260
+    kw = dict(fs_in=fs, vector_length=n, pll_bw_hz=25.0, dll_bw_hz=2.0, pull_in_time_s=0, enable_lock_detectors=1, cn0_samples=cn0_samples, cn0_min=25)
+    x = synth_gps_l1_stream((epochs + 3) * n, fs, [4], [1500.0], [0.0], cn0_dbhz=47.0, seed_noise=5)
+    loop = _loop(gpu, kw, n_channels=1, max_len=1023)
+    loop.set_stream_host(x)
+    loop.start(0, oracle.ca_code(4), 0, 0, 1492.0)
+    rec, done = loop.run(epochs)
+    loop.close()
+    ora = oracle.trk_run(oracle.trk_conf(**kw), oracle.ca_code(4), x, 0, 0, 1492.0, epochs)
+    assert int(done[0]) == len(ora) == epochs
+    g_cn0, o_cn0 = np.array([r.cn0_db_hz for r in rec[0]]), np.array([r.cn0_db_hz for r in ora])
+    g_lt, o_lt = np.array([r.carrier_lock_test for r in rec[0]]), np.array([r.carrier_lock_test for r in ora])
+    assert np.all(g_cn0[:cn0_samples] == 0.0) and np.array_equal(g_cn0 == 0.0, o_cn0 == 0.0)
+    finite = np.isfinite(o_cn0) & np.isfinite(g_cn0)
+    assert np.array_equal(np.isfinite(o_cn0), np.isfinite(g_cn0))
+    # a buffer of one or a few prompts gives a wild estimate (and -100 dB-Hz where the estimator gives up): the same wild one on both sides
+    tol = 0.25 if cn0_samples >= 16 else 1.5
+    assert np.max(np.abs(g_cn0[finite] - o_cn0[finite])) < tol, (cn0_samples, np.max(np.abs(g_cn0[finite] - o_cn0[finite])))
+    assert np.max(np.abs(g_lt - o_lt)) < 2e-2
+
+
 def test_carrier_lock_counter_drops_a_noise_channel(gpu):
     """The two halves of cn0_and_tracking_lock_status run on two waves of the loop kernel and thread 0 waits for their verdict only in a period in which a fail
     counter can pass its limit (csrc/tracking_loop.hip, SerialMail).  Here the CARRIER counter is the one that passes it (the code limit is out of reach): on noise
