@@ -406,7 +406,9 @@ __device__ __forceinline__ float cn0_from_sums_d(float Psig, float m_2, float m_
     Psig = __fmul_rn(Psig, Psig);
     m_2 = __fdiv_rn(m_2, n);
     m_4 = __fdiv_rn(m_4, n);
-    aux = __fsqrt_rn(__fsub_rn(__fmul_rn(__fmul_rn(2.0f, m_2), m_2), m_4));
+    // sqrtf, not __fsqrt_rn: hipcc renders the intrinsic as a bare v_sqrt_f32 (one ulp), sqrtf as the correctly rounded sequence (v_sqrt_f32 + two residual tests) -- what
+    // std::sqrt in T/lock_detectors.cc:93 is.  (Found in round 4 with a buffer of ONE prompt, where the estimator's denominator is m_2 - sqrt(m_2^2): zero, or one ulp.)
+    aux = sqrtf(__fsub_rn(__fmul_rn(__fmul_rn(2.0f, m_2), m_2), m_4));
     float denominator;
     if (isnan(aux))
         {
