@@ -780,7 +780,7 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
     __shared__ SerialMail mail;  // between the lanes that share a period's loop arithmetic (below)
     __shared__ __align__(16) HotConstants hc;
     __shared__ std::conditional_t<LIVE, LiveShared, NoLiveShared> lv;  // (not allocated in the launched form: nothing there touches it)
-    // live form: the period's record is assembled HERE by the three lanes that know its fields and written to the host's record ring by ONE wave
+    // live form: the period's record is assembled HERE by the lanes that know its fields and written to the host's record ring by ONE wave
     // instruction (28 lanes x 8 bytes, system scope) at the top of the next period.  Field-by-field system-scope stores -- what visibility to a host that
     // reads while the kernel runs demands of stores into host memory -- are one PCIe write each: 55 per record, and 32 channels of them took 53 us per period.
     __shared__ __align__(16) std::conditional_t<LIVE, gsh_trk_epoch, NoLiveShared> lrec;
@@ -906,7 +906,7 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
             else
                 wpos = a.ring_capacity ? pos % a.ring_capacity : pos;
             // where this period's record is put together: slot e of the launch's block, or -- live -- the copy in LDS.  (The address is formed where it is
-            // used, by three lanes, not carried in registers through the correlation.)
+            // used, by the lanes that write it, not carried in registers through the correlation.)
             auto rec_ref = [&]() -> gsh_trk_epoch& {
                 if constexpr (LIVE)
                     return lrec;
@@ -1644,7 +1644,7 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                                     r.corr[6] = static_cast<float>(t_corr_done - t_begin);
                                     const long long t_e = clock64();
                                     r.corr[7] = static_cast<float>(t_e - t_corr_done);
-                                    r.corr[8] = static_cast<float>(t_join - t_corr_done);  // the three lanes side by side + the barrier that joins them
+                                    r.corr[8] = static_cast<float>(t_join - t_corr_done);  // the four lanes side by side + their meeting (barrier or words)
                                     r.corr[9] = 0.0f;
                                     r.accu[6] = static_cast<float>(t_c - t_join);          // the join
                                     r.accu[7] = static_cast<float>(t_d - t_c);          // update_tracking_vars

@@ -29,7 +29,7 @@ for ch in (32,):
             f(lambda r: r.accu[6]), f(lambda r: r.accu[7]), f(lambda r: r.accu[8]), f(lambda r: r.corr[9]), f(lambda r: r.corr[8])))
     elif os.environ.get("GSH_PHASE_DETAIL"):
         f = lambda get: np.array([[get(r) for r in rr] for rr in rec])[:, 5:].mean()
-        print("  serial section, clocks: three lanes side by side + barrier %.0f  join %.0f  update_tracking_vars %.0f  symbol+record %.0f  publish %.0f" % (
+        print("  serial section, clocks: lanes side by side + meeting %.0f  join %.0f  update_tracking_vars %.0f  symbol+record %.0f  publish %.0f" % (
             f(lambda r: r.corr[8]), f(lambda r: r.accu[6]), f(lambda r: r.accu[7]), f(lambda r: r.accu[8]), f(lambda r: r.accu[9]) - f(lambda r: r.corr[7])))
     print(os.path.basename(os.environ.get("GSH_LIB_PATH", "current")), os.environ.get("GSH_LOOP_AB_CONF", ""), "channels", ch, "us/epoch %.3f" % (ms * 1e3 / E), "correlation clocks avg %.0f  serial clocks avg %.0f  (clock64 units)" % (tc[:, 5:].mean(), ts[:, 5:].mean()))
     loop.close()
