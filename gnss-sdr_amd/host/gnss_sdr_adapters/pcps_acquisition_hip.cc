@@ -11,6 +11,7 @@
 #include <gnuradio/io_signature.h>
 #include <pmt/pmt.h>
 #include <algorithm>
+#include <cmath>
 #include <filesystem>
 #include <iostream>
 #include <utility>
@@ -134,7 +135,8 @@ void pcps_acquisition_hip::set_doppler_center(int32_t doppler_center)
 
 
 // pcps_acquisition::dump_results, acq.cc:354-406: file name, variables, classes and dimensions as there.  The container is MAT-file level 5 (written here,
-// host/hip_mat5_writer.h) where the reference's matio writes 7.3; acq_grid_narrow of make_two_steps searches is not kept on the device and is left out.
+// host/hip_mat5_writer.h) where the reference's matio writes 7.3.  make_two_steps searches: acq_grid is the wide grid of step one, acq_grid_narrow the narrow one of
+// step two -- the core keeps host copies of both, since on the device the narrow grid takes the place of the wide grid's first rows (Hip_Pcps_Acquisition_Core::read_grid).
 void pcps_acquisition_hip::dump_results(const Hip_Pcps_Acquisition_Core::AcquisitionResult& result)
 {
     d_dump_number++;
@@ -176,6 +178,16 @@ void pcps_acquisition_hip::dump_results(const Hip_Pcps_Acquisition_Core::Acquisi
     w.scalar<uint64_t>("sample_counter", result.sample_count);
     w.scalar<uint32_t>("PRN", d_gnss_synchro->PRN);
     w.scalar<int32_t>("num_dwells", static_cast<int32_t>(result.num_dwells));
+    if (d_core.make_two_steps())  // acq.cc:392-400
+        {
+            const size_t bins2 = d_core.num_doppler_bins_step2();
+            std::vector<float> narrow(eff * bins2);
+            d_core.read_narrow_grid(narrow.data());
+            const float doppler_grid_narrow_min = d_core.doppler_center_step_two() - static_cast<float>(std::floor(static_cast<double>(bins2) / 2.0)) * d_core.doppler_step2();
+            w.matrix("acq_grid_narrow", narrow.data(), eff, bins2);
+            w.scalar<float>("doppler_step_narrow", d_core.doppler_step2());
+            w.scalar<float>("doppler_grid_narrow_min", doppler_grid_narrow_min);
+        }
     w.close();
 }
 

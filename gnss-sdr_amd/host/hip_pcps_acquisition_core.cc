@@ -3,6 +3,7 @@
  * \brief See the header.  Sizes follow acq.cc:110-117, the dwell / threshold logic acq.cc:686-727.
  */
 #include "hip_pcps_acquisition_core.h"
+#include <algorithm>
 #include "gnss_sdr_hip.h"
 
 Hip_Pcps_Acquisition_Core::Hip_Pcps_Acquisition_Core(const Hip_Acq_Conf& conf, int device, uint32_t num_doppler_bins_override)
@@ -184,7 +185,9 @@ Hip_Pcps_Acquisition_Core::Outcome Hip_Pcps_Acquisition_Core::acquisition_core(u
     d_num_noncoherent_integrations_counter++;  // acq.cc:668
     gsh_acq_result r{};
     const int accumulate = d_num_noncoherent_integrations_counter > 1 ? 1 : 0;  // acq.cc:545-553
+    const bool was_step_two = d_step_two;
     const int rc = run_dwell(d_handle, data, false, d_step_two, d_doppler_center_step_two, d_input_power, accumulate, d_num_noncoherent_integrations_counter, &r);
+    if (rc == GSH_OK) keep_dump_grids(was_step_two);
     return core_after_dwell(sample_count, rc == GSH_OK, &r, result);
 }
 
@@ -193,6 +196,7 @@ Hip_Pcps_Acquisition_Core::Outcome Hip_Pcps_Acquisition_Core::acquisition_core_s
 {
     if (d_handle == nullptr || result == nullptr) return ACQ_ERROR;
     d_num_noncoherent_integrations_counter++;  // acq.cc:668
+    if (dwell_ok) keep_dump_grids(d_step_two);
     return core_after_dwell(sample_count, dwell_ok, &r, result);
 }
 
@@ -217,13 +221,48 @@ Hip_Pcps_Acquisition_Core::Outcome Hip_Pcps_Acquisition_Core::acquisition_core(u
         {
             rc = run_dwell(d_handle, data, true, false, 0.0F, 0.0F, accumulate, d_num_noncoherent_integrations_counter, &r);
         }
+    if (rc == GSH_OK) keep_dump_grids(d_step_two);
     return core_after_dwell(sample_count, rc == GSH_OK, &r, result);
+}
+
+
+void Hip_Pcps_Acquisition_Core::keep_dump_grids(bool dwell_was_step_two)
+{
+    if (!(d_acq_parameters.dump && d_acq_parameters.make_2_steps) || d_handle == nullptr) return;
+    const size_t eff = d_effective_fft_size, wide = static_cast<size_t>(d_num_doppler_bins) * eff, narrow = static_cast<size_t>(d_acq_parameters.num_doppler_bins_step2) * eff;
+    if (d_dump_narrow_grid.size() != narrow) d_dump_narrow_grid.assign(narrow, 0.0F);
+    std::vector<float> g(wide);
+    if (gsh_acq_read_grid(d_handle, 0, g.data()) != GSH_OK) return;  // (the dump then reads the device itself, as for a one-step search)
+    if (dwell_was_step_two)
+        std::copy(g.begin(), g.begin() + static_cast<std::ptrdiff_t>(narrow), d_dump_narrow_grid.begin());  // rows 0 .. nbins2 - 1 of the PRN's grid
+    else
+        {
+            d_dump_grid.swap(g);
+            d_have_dump_grid = true;
+        }
+}
+
+
+bool Hip_Pcps_Acquisition_Core::read_narrow_grid(float* grid) const
+{
+    const size_t narrow = static_cast<size_t>(d_acq_parameters.num_doppler_bins_step2) * d_effective_fft_size;
+    if (grid == nullptr || narrow == 0) return false;
+    if (d_dump_narrow_grid.size() == narrow)
+        std::copy(d_dump_narrow_grid.begin(), d_dump_narrow_grid.end(), grid);
+    else
+        std::fill(grid, grid + narrow, 0.0F);
+    return true;
 }
 
 
 bool Hip_Pcps_Acquisition_Core::read_grid(float* grid)
 {
     if (d_handle == nullptr) return false;
+    if (d_have_dump_grid && d_dump_grid.size() == static_cast<size_t>(d_num_doppler_bins) * d_effective_fft_size)
+        {
+            std::copy(d_dump_grid.begin(), d_dump_grid.end(), grid);
+            return true;
+        }
     if (gsh_acq_read_grid(d_handle, 0, grid) != GSH_OK)
         {
             d_error = gsh_last_error();

@@ -148,8 +148,17 @@ public:
         if (result.step_two) s->Acq_doppler_step = d_acq_parameters.doppler_step2;  // acq.cc:598-601
     }
 
-    /*! dump support (acq.cc:555-558): D rows of d_effective_fft_size floats */
+    /*! dump support (acq.cc:555-558): D rows of d_effective_fft_size floats.  In a make_two_steps search the device's narrow grid takes the place of the wide grid's
+     *  first rows (as d_magnitude_grid is reused, acq.cc:526), so a dumping block keeps host copies the way the reference keeps d_grid and d_narrow_grid (acq.cc:555-558):
+     *  the wide grid after every step-one dwell, the narrow one after every step-two dwell (keep_dump_grids, called by the acquisition_core entry points). */
     bool read_grid(float* grid);
+    /*! acq_grid_narrow of dump_results (acq.cc:392-400): num_doppler_bins_step2 rows of d_effective_fft_size floats -- zeros until a step-two dwell has run, then
+     *  whatever the last one left, across searches, as the reference's d_narrow_grid */
+    bool read_narrow_grid(float* grid) const;
+    bool make_two_steps() const { return d_acq_parameters.make_2_steps; }
+    uint32_t num_doppler_bins_step2() const { return d_acq_parameters.num_doppler_bins_step2; }
+    float doppler_step2() const { return d_acq_parameters.doppler_step2; }
+    float doppler_center_step_two() const { return d_doppler_center_step_two; }
 
     uint32_t consumed_samples() const { return d_consumed_samples; }
     uint32_t fft_size() const { return d_fft_size; }
@@ -178,6 +187,9 @@ private:
     float d_input_power{0.0F};
     float d_doppler_center_step_two{0.0F};
     bool d_step_two{false};
+    std::vector<float> d_dump_grid, d_dump_narrow_grid;  // host copies for dump_results of a make_two_steps search (see read_grid)
+    bool d_have_dump_grid{false};
+    void keep_dump_grids(bool dwell_was_step_two);
     std::vector<std::complex<float>> d_cshort_scratch;
 
     Outcome core_after_dwell(uint64_t sample_count, bool dwell_ok, const void* gsh_result, AcquisitionResult* result);

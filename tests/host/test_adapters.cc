@@ -305,6 +305,46 @@ void test_acquisition_dump()
                 std::printf("ACQ_DUMP %s delay %.3f doppler %.1f stamp %llu\n", file.c_str(), syn.Acq_delay_samples, syn.Acq_doppler_hz,
                     static_cast<unsigned long long>(syn.Acq_samplestamp_samples));
         }
+    // make_two_steps (acq.cc:392-400): the file also holds the narrow grid of step two, its step and its first Doppler
+    {
+        const std::string dir2 = "/tmp/gsh_acq_dump_test2";
+        std::filesystem::remove_all(dir2);
+        auto conf2 = base_config(role, fs);
+        conf2->set_property(role + ".dump", "true");
+        conf2->set_property(role + ".dump_filename", dir2 + "/acq_dump.mat");
+        conf2->set_property(role + ".dump_channel", "0");
+        conf2->set_property(role + ".make_two_steps", "true");
+        conf2->set_property(role + ".second_nbins", "8");
+        conf2->set_property(role + ".second_doppler_step", "62.5");
+        GpsL1CaPcpsAcquisitionHip acq(conf2.get(), role, 1, 0);
+        if (acq.item_size() == 0) return;
+        Gnss_Synchro syn{};
+        syn.System = 'G';
+        std::memcpy(syn.Signal, "1C", 3);
+        syn.PRN = 14;
+        acq.set_channel(0);
+        acq.set_gnss_synchro(&syn);
+        acq.set_local_code();
+        acq.reset();
+        auto blk = std::dynamic_pointer_cast<gr::block>(acq.get_left_block());
+        size_t pos = 0;
+        gr_vector_void_star outs;
+        for (int calls = 0; calls < 1000 && blk->published.empty(); calls++)
+            {
+                const size_t avail = std::min<size_t>(1500, x.size() - pos);
+                gr_vector_int nin{static_cast<int>(avail)};
+                gr_vector_const_void_star ins{static_cast<const void*>(x.data() + pos)};
+                blk->consumed_last = 0;
+                blk->general_work(0, nin, ins, outs);
+                pos += static_cast<size_t>(blk->consumed_last);
+            }
+        EXPECT(!blk->published.empty() && pmt::to_long(blk->published[0].second) == 1, "acquisition dump, two steps: the satellite was not found");
+        // (the search completes twice: after step one -- positive_acq 0, the narrow grid still empty -- and after step two; the second file is the one to look at)
+        const std::string file = dir2 + "/acq_dump_G_1C_ch_0_2_sat_14.mat";
+        EXPECT(std::filesystem::exists(file) || std::filesystem::exists(dir2 + "/acq_dump_G_1C_ch_0_1_sat_14.mat"), "acquisition dump, two steps: no file in %s", dir2.c_str());
+        std::printf("ACQ_DUMP2 %s delay %.3f doppler %.1f stamp %llu\n", std::filesystem::exists(file) ? file.c_str() : (dir2 + "/acq_dump_G_1C_ch_0_1_sat_14.mat").c_str(),
+            syn.Acq_delay_samples, syn.Acq_doppler_hz, static_cast<unsigned long long>(syn.Acq_samplestamp_samples));
+    }
 }
 
 void test_shared_acquisition()

@@ -20,6 +20,29 @@ def test_gnss_sdr_adapters_end_to_end(gpu):
     r = subprocess.run([BIN], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ADAPTERS OK" in r.stdout, r.stdout[-4000:] + r.stderr[-2000:]
     _check_acquisition_dump(r.stdout)
+    _check_acquisition_dump_two_steps(r.stdout)
+
+
+def _check_acquisition_dump_two_steps(stdout):
+    """make_two_steps (acq.cc:392-400): acq_grid is the wide grid of step one, acq_grid_narrow the second_nbins columns of step two, doppler_step_narrow and
+    doppler_grid_narrow_min place its columns -- and the block's reported Doppler is the narrow grid's arg-max column, truncated to an integer (acq.cc:436)."""
+    import numpy as np
+    import scipy.io as sio
+    line = [ln for ln in stdout.splitlines() if ln.startswith("ACQ_DUMP2 ")][-1].split()
+    path, delay, doppler = line[1], float(line[3]), float(line[5])
+    m = sio.loadmat(path)
+    assert {"acq_grid", "acq_grid_narrow", "doppler_step_narrow", "doppler_grid_narrow_min"} <= set(m)
+    g, gn = m["acq_grid"], m["acq_grid_narrow"]
+    assert g.shape == (4000, 40) and gn.dtype == np.float32 and gn.shape == (4000, 8), (g.shape, gn.shape)
+    assert float(m["doppler_step_narrow"][0, 0]) == 62.5
+    tau1, bin1 = np.unravel_index(int(np.argmax(g)), g.shape)
+    centre = -5000 + 250 * bin1                                   # step one's Doppler: the centre of the narrow grid (acq.cc:619)
+    assert float(m["doppler_grid_narrow_min"][0, 0]) == pytest.approx(centre - 4 * 62.5)
+    tau2, bin2 = np.unravel_index(int(np.argmax(gn)), gn.shape)
+    assert gn.max() > 0.0 and float(tau2) == pytest.approx(delay) and tau1 == tau2
+    assert float(int(centre + (bin2 - 4) * 62.5)) == pytest.approx(doppler)
+    # the wide grid is step one's, whole: its column of the centre bin is not the narrow grid's first column
+    assert not np.array_equal(g[:, 0], gn[:, 0])
 
 
 def _check_acquisition_dump(stdout):
