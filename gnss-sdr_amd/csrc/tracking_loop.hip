@@ -1896,7 +1896,7 @@ struct gsh_trk
     std::vector<unsigned long long> live_next_window;  // first sample of the window behind the last record TAKEN (what the caller's block has to be offered next)
     hipEvent_t live_ev[2]{nullptr, nullptr};
     bool live_busy[2]{false, false};                // a residency has been queued and its event has not been seen complete yet
-    unsigned live_idle_us{200}, live_residency_us{5000};
+    unsigned live_idle_us{1000}, live_residency_us{20000};  // (round 4: 200 us / 5 ms until the quit word was polled often enough to end a residency within half a millisecond; a restart is ~0.25 ms of nobody advancing: +5 - 8 % through the blocks, profiles/ab/r04/dropin_push_notes.txt)
     std::shared_ptr<gsh::LiveFloor> live_floor;     // registered with the ring: pushes keep off what the channels still read
     std::atomic<bool> live_ready{false};            // live_setup has run: what gsh_trk_live_take (any thread) reads is in place
 };

@@ -421,7 +421,7 @@ extern "C"
      * kernel instead: every started channel correlates its next window as soon as the ring (gsh_trk_set_stream_ring) holds it -- pushes announce
      * themselves to the resident kernel through the ring, no event, no host --, and leaves one record per period in a ring of records in page-locked
      * host memory that gsh_trk_live_take reads without a lock or a device call.  A residency ends by itself when nothing new has arrived for
-     * idle_timeout_us (200), after residency_us (5000: anything that waits for the whole device gets its turn), when the host asks (gsh_trk_live_quiesce)
+     * idle_timeout_us (1000), after residency_us (20000: anything that waits for the whole device gets its turn), when the host asks (gsh_trk_live_quiesce)
      * or when no channel has work; up to two may be queued, the second takes over when the first ends.  Loop arithmetic, records and trajectories are
      * those of gsh_trk_run, bit for bit.
      * Threads: _begin, _in_flight, _quiesce, start, stop, run*: one at a time per handle (the caller's lock).  _take: any thread, at most one per
