@@ -69,3 +69,36 @@ def test_seeds_of_the_three_lanes_that_evaluate_the_rotations(step):
     for lane, got in ((2, s2), (1, s1), (0, s0)):
         want = e(rem + (n_first + 2 * (64 * wave + lane)) * step)
         assert abs(float(got[0]) - float(want[0])) < 6e-7 and abs(float(got[1]) - float(want[1])) < 6e-7, (lane, got, want)
+
+
+def test_thread_0_never_misses_a_loss_of_lock():
+    """The lanes of the loop arithmetic meet through LDS words, and thread 0 waits for the lock detectors' verdict only in a period in which a fail counter CAN pass its
+    limit: when the detector lane said so at the end of the last period (may_trip = counter + 1 > limit), or when thread 0 itself sees the bit-synchronisation time limit force
+    the carrier counter to 300000 (trk.cc:2000-2007).  The word may already hold the value for the NEXT period when thread 0 reads it (the lane has finished): then the verdict
+    is in as well, and a limit passed in this period leaves the counter within one of it.  Model: random walks of a counter (trk.cc:1196-1207: +1 on a failed test, -1 on a
+    passed one while positive, untouched during the pull-in transitory, cleared once when it ends) -- a loss must imply a wait under either reading of the word."""
+    rng = np.random.default_rng(11)
+    for trial in range(4000):
+        limit = int(rng.integers(0, 6))
+        counter, latched = int(rng.integers(0, limit + 2)), True
+        may_trip_prev = counter + 1 > limit
+        for period in range(60):
+            pull_in = period < 5 and trial % 3 == 0
+            forced = rng.random() < 0.02
+            if latched and not pull_in:
+                latched, counter = False, 0
+            if forced:
+                counter = 300000
+            if not pull_in:
+                if rng.random() < 0.55:
+                    counter += 1
+                elif counter > 0:
+                    counter -= 1
+            lost = counter > limit
+            may_trip_next = counter + 1 > limit
+            for word in (may_trip_prev, may_trip_next):      # what thread 0 may read: last period's value, or -- the lane being done -- the next one's
+                waits = word or forced
+                assert waits or not lost, (trial, period, limit, counter)
+            if lost:
+                break
+            may_trip_prev = may_trip_next
