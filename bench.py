@@ -133,6 +133,25 @@ def build_jobs(channels, epochs, n, fs, taps, dop, cph, rank):
     return make_jobs(rows), rows
 
 
+def host_cpu_quota():
+    """What the box actually grants this process of its logical CPUs: the cgroup CPU quota (cgroup v2 cpu.max, v1 cfs_quota / cfs_period) and the affinity mask --
+    the reason `effective_parallelism` sits far below `host_logical_cpus` on a leased container."""
+    out = {"affinity_cpus": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None, "cgroup_cpu_max": None, "cgroup_cpus": None}
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        out["cgroup_cpu_max"] = f"{quota} {period}"
+        out["cgroup_cpus"] = None if quota == "max" else float(quota) / float(period)
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            out["cgroup_cpu_max"] = f"{q} {per}"
+            out["cgroup_cpus"] = None if q <= 0 else q / per
+        except Exception:
+            pass
+    return out
+
+
 def cpu_baseline(channels, n, fs, taps, target_s):
     """The reference CPU path on this box's host cores over a bounded sample of the same workload."""
     import oracle
@@ -191,6 +210,7 @@ def cpu_baseline(channels, n, fs, taps, target_s):
         "unit": "correlators/s",
         "cores": cores,                       # threads used
         "host_logical_cpus": os.cpu_count(),
+        "host_cpu_quota": host_cpu_quota(),   # cgroup quota / affinity: what of those CPUs the container may use
         "single_thread_value": rate_1 * taps,
         "effective_parallelism": (rate_best / rate_1) if rate_1 > 0 else None,   # what the threads delivered, in single-thread units
         "kind": kind,
@@ -626,6 +646,60 @@ def sharded_legs(torch, dist, dev, local, rank, world, ring, block, fs, n, C, ep
     return out
 
 
+def rccl_one_rank_metric(torch, dev_index, x_dev, block):
+    """The stream group with ONE rank forced through RCCL (GSH_GROUP_FORCE_RCCL): ncclCommInitRank(1 rank), then every 8-bit block through ncclBroadcast, or the
+    grouped ncclSend / ncclRecv to itself + ncclAllGather, on the ring's stream, cast into the ring behind it.  All the RCCL evidence a single-GPU box can give
+    (the pool has no multi-GPU node): the ring must come out bit-identical to a group that exchanges nothing."""
+    import numpy as np
+    from gnss_sdr_amd.sample_stream import StreamGroup
+    raw = torch.view_as_real(x_dev[:block]).mul(30.0).round_().clamp_(-127, 127).to(torch.int8).reshape(-1).contiguous()
+    torch.cuda.synchronize()
+    out = {"rccl_ranks": 1, "block_samples": int(block)}
+    plain = StreamGroup.from_rank(dev_index, 0, 1, None, 3 * block + 2, block // 2, "broadcast")
+    plain.push_device(raw.data_ptr(), block, "ibyte")
+    plain.wait()
+    want = plain.ring(0).read(block - block // 2, block // 2).view(np.uint32)
+    for mode in ("broadcast", "scatter_allgather"):
+        g = StreamGroup.from_rank(dev_index, 0, 1, None, 3 * block + 2, block // 2, mode, force_rccl=True)
+        first = g.push_device(raw.data_ptr(), block, "ibyte")
+        g.wait()
+        same = bool(np.array_equal(g.ring(0).read(first + block - block // 2, block // 2).view(np.uint32), want))
+        reps = 20
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            g.push_device(raw.data_ptr(), block, "ibyte")
+        g.wait()
+        dt = (time.perf_counter() - t0) / reps
+        info = g.rccl_info()
+        out[mode] = {"ring_identical_to_a_group_without_exchange": same, "rccl_calls": info["collectives"], "ms_per_block": dt * 1e3,
+                     "raw_GBs_through_the_collectives": 2.0 * block / dt / 1e9}
+        out["rccl_version"] = info["version"]
+        out["communicator_ranks"] = info["ranks"]
+        g.close()
+    plain.close()
+    return out
+
+
+def bench_summary(res):
+    """The headline figures of every leg once more, short, at the END of the line (the driver keeps the tail of stdout)."""
+    def get(d, *keys):
+        for k in keys:
+            if not isinstance(d, dict) or k not in d:
+                return None
+            d = d[k]
+        return d
+    s = {"tracking_Mcorr_s": res["value"] / 1e6, "tracking_kernel_ms": get(res, "roofline", "kernel_ms"), "tracking_valu_frac": get(res, "roofline", "frac"),
+         "acq_dwells_s": get(res, "acquisition", "value"), "acq_ms_per_batch": get(res, "acquisition", "ms_per_batch"),
+         "acq_hbm_frac": get(res, "acquisition", "roofline", "frac"),
+         "closed_loop_us": get(res, "closed_loop", "us_per_epoch"), "closed_loop_detectors_us": get(res, "closed_loop_lock_detectors", "us_per_epoch"),
+         "closed_loop_live_us": get(res, "closed_loop_lock_detectors", "live", "us_per_epoch"), "closed_loop_256ch_us": get(res, "closed_loop_256ch", "us_per_epoch"),
+         "closed_loop_config4_us": get(res, "closed_loop_config4", "us_per_epoch"),
+         "dropin_20_Mcps": get(res, "dropin", "value"), "dropin_1_Mcps": get(res, "dropin", "one_period_per_call", "value"),
+         "rccl_ranks_exercised": get(res, "rccl_one_rank", "communicator_ranks"), "rccl_version": get(res, "rccl_one_rank", "rccl_version"),
+         "cpu_baseline_Mcorr_s": (get(res, "cpu_baseline", "value") or 0) / 1e6}
+    return {k: (round(v, 4) if isinstance(v, float) else v) for k, v in s.items()}
+
+
 def load_pmc():
     """profiles/pmc_r02.json: per-launch counter averages of the dominant kernels under this very command (profiles/run_profiles_r02.sh +
     profiles/summarize_r02.py; rocprofv3 --pmc passes, kernel-trace only).  None when absent."""
@@ -871,6 +945,10 @@ def main():
                 res["pcie_inclusive"] = pcie_inclusive_metric(torch, local, x0, jobs, C, E, T, block)
             except Exception as e:
                 res["pcie_inclusive"] = {"error": str(e)}
+            try:
+                res["rccl_one_rank"] = rccl_one_rank_metric(torch, local, x0, block)
+            except Exception as e:
+                res["rccl_one_rank"] = {"error": str(e)}
         # ---- then the legs with a CPU part: the drop-in seam (32 block threads + 32 reference blocks as the checker) and the CPU baseline
         if world == 1 and not a.no_dropin and not grouped:
             try:
@@ -881,6 +959,7 @@ def main():
                 res["dropin"] = {"error": str(e)}
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(C, n, fs, T, a.cpu_seconds)
+        res["summary"] = bench_summary(res)
         print(json.dumps(res))
     bank.close()
     if G is not None:

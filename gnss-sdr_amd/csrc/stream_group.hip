@@ -17,6 +17,7 @@
 #include "sample_stream.h"
 #include <dlfcn.h>
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -50,6 +51,7 @@ struct Rccl
     int (*GroupStart)(){nullptr};
     int (*GroupEnd)(){nullptr};
     const char* (*GetErrorString)(int){nullptr};
+    int (*GetVersion)(int*){nullptr};
 };
 
 Rccl* rccl()
@@ -75,6 +77,7 @@ Rccl* rccl()
         r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
         r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+        r.GetVersion = reinterpret_cast<decltype(r.GetVersion)>(sym("ncclGetVersion"));
     });
     const bool ok = r.lib && r.GetUniqueId && r.CommInitRank && r.CommInitAll && r.CommDestroy && r.Broadcast && r.AllGather && r.Send && r.Recv && r.GroupStart &&
                     r.GroupEnd;
@@ -102,6 +105,9 @@ struct gsh_stream_group
     std::vector<void*> piece[2];        // scatter + all-gather: the 1/N this rank receives
     size_t stage_cap{0};                // bytes per staging buffer
     int slot{0};
+    bool use_rccl{false};               // world > 1, or a group of one that was asked to go through RCCL all the same (GSH_GROUP_FORCE_RCCL)
+    int rccl_ranks{0};                  // ranks of the communicator(s) created (0: none)
+    uint64_t rccl_calls{0};             // collectives / point-to-point calls issued
 };
 
 namespace
@@ -163,8 +169,8 @@ int group_alloc(gsh_stream_group** out, const int* devices, int n_local, uint64_
 // ring's stage[slot] holds it
 int replicate(gsh_stream_group* g, size_t bytes, int slot)
 {
+    if (!g->use_rccl) return GSH_OK;
     Rccl* R = rccl();
-    if (g->world == 1) return GSH_OK;
     GSH_REQUIRE(R != nullptr, "RCCL (librccl.so) could not be loaded");
     const size_t padded = padded_bytes(bytes, g->world);
     const size_t chunk = padded / static_cast<size_t>(g->world);
@@ -176,6 +182,7 @@ int replicate(gsh_stream_group* g, size_t bytes, int slot)
                 {
                     GSH_HIP(hipSetDevice(g->rings[i]->device));
                     GSH_RCCL(R->Broadcast(g->stage[slot][i], g->stage[slot][i], padded, ncclInt8, 0, g->comms[i], g->rings[i]->stream));
+                    g->rccl_calls++;
                 }
             GSH_RCCL(R->GroupEnd());
             return GSH_OK;
@@ -187,8 +194,12 @@ int replicate(gsh_stream_group* g, size_t bytes, int slot)
             GSH_HIP(hipSetDevice(g->rings[i]->device));
             if (g->ranks[i] == 0)
                 for (int r = 0; r < g->world; r++)
-                    GSH_RCCL(R->Send(static_cast<const char*>(g->stage[slot][i]) + static_cast<size_t>(r) * chunk, chunk, ncclInt8, r, g->comms[i], g->rings[i]->stream));
+                    {
+                        GSH_RCCL(R->Send(static_cast<const char*>(g->stage[slot][i]) + static_cast<size_t>(r) * chunk, chunk, ncclInt8, r, g->comms[i], g->rings[i]->stream));
+                        g->rccl_calls++;
+                    }
             GSH_RCCL(R->Recv(g->piece[slot][i], chunk, ncclInt8, 0, g->comms[i], g->rings[i]->stream));
+            g->rccl_calls++;
         }
     GSH_RCCL(R->GroupEnd());
     // all-gather of the pieces completes the block everywhere
@@ -197,9 +208,17 @@ int replicate(gsh_stream_group* g, size_t bytes, int slot)
         {
             GSH_HIP(hipSetDevice(g->rings[i]->device));
             GSH_RCCL(R->AllGather(g->piece[slot][i], g->stage[slot][i], chunk, ncclInt8, g->comms[i], g->rings[i]->stream));
+            g->rccl_calls++;
         }
     GSH_RCCL(R->GroupEnd());
     return GSH_OK;
+}
+
+bool force_rccl(int mode)
+{
+    if (mode & GSH_GROUP_FORCE_RCCL) return true;
+    const char* e = std::getenv("GSH_GROUP_FORCE_RCCL");
+    return e != nullptr && e[0] != '\0' && e[0] != '0';
 }
 
 int root_local_index(const gsh_stream_group* g)
@@ -261,14 +280,17 @@ extern "C"
         GSH_REQUIRE(out != nullptr && devices != nullptr, "null argument");
         *out = nullptr;
         GSH_REQUIRE(n_devices >= 1 && n_devices <= 64, "n_devices %d outside 1..64", n_devices);
+        const bool forced = force_rccl(mode);
+        mode &= ~GSH_GROUP_FORCE_RCCL;
         GSH_REQUIRE(mode == GSH_GROUP_BROADCAST || mode == GSH_GROUP_SCATTER_ALLGATHER, "unknown mode %d", mode);
         gsh_stream_group* g = nullptr;
         int rc = group_alloc(&g, devices, n_devices, capacity_samples, max_window_samples);
         if (rc != GSH_OK) return rc;
         g->world = n_devices;
         g->mode = mode;
+        g->use_rccl = n_devices > 1 || forced;
         for (int i = 0; i < n_devices; i++) g->ranks.push_back(i);
-        if (n_devices > 1)
+        if (g->use_rccl)
             {
                 Rccl* R = rccl();
                 if (R == nullptr)
@@ -282,6 +304,7 @@ extern "C"
                         gsh_stream_group_destroy(g);
                         return set_error(GSH_ERR_HIP, "RCCL: ncclCommInitAll failed: %s", R->GetErrorString ? R->GetErrorString(e) : "?");
                     }
+                g->rccl_ranks = n_devices;
             }
         *out = g;
         return GSH_OK;
@@ -294,6 +317,8 @@ extern "C"
         *out = nullptr;
         GSH_REQUIRE(world >= 1 && rank >= 0 && rank < world, "rank %d / world %d", rank, world);
         GSH_REQUIRE(world == 1 || id128 != nullptr, "a communicator id is needed for world > 1 (gsh_comm_unique_id on one rank, handed to all)");
+        const bool forced = force_rccl(mode);
+        mode &= ~GSH_GROUP_FORCE_RCCL;
         GSH_REQUIRE(mode == GSH_GROUP_BROADCAST || mode == GSH_GROUP_SCATTER_ALLGATHER, "unknown mode %d", mode);
         gsh_stream_group* g = nullptr;
         int rc = group_alloc(&g, &device, 1, capacity_samples, max_window_samples);
@@ -301,7 +326,8 @@ extern "C"
         g->world = world;
         g->mode = mode;
         g->ranks.push_back(rank);
-        if (world > 1)
+        g->use_rccl = world > 1 || forced;
+        if (g->use_rccl)
             {
                 Rccl* R = rccl();
                 if (R == nullptr)
@@ -310,7 +336,17 @@ extern "C"
                         return set_error(GSH_ERR_HIP, "RCCL (librccl.so) could not be loaded");
                     }
                 ncclUniqueId id;
-                std::memcpy(id.internal, id128, 128);
+                if (id128 != nullptr)
+                    std::memcpy(id.internal, id128, 128);
+                else  // (a forced group of one that was given no id makes its own)
+                    {
+                        const int e = R->GetUniqueId(&id);
+                        if (e != 0)
+                            {
+                                gsh_stream_group_destroy(g);
+                                return set_error(GSH_ERR_HIP, "RCCL: ncclGetUniqueId failed: %s", R->GetErrorString ? R->GetErrorString(e) : "?");
+                            }
+                    }
                 (void)hipSetDevice(device);
                 const int e = R->CommInitRank(&g->comms[0], world, id, rank);
                 if (e != 0)
@@ -318,6 +354,7 @@ extern "C"
                         gsh_stream_group_destroy(g);
                         return set_error(GSH_ERR_HIP, "RCCL: ncclCommInitRank failed: %s", R->GetErrorString ? R->GetErrorString(e) : "?");
                     }
+                g->rccl_ranks = world;
             }
         *out = g;
         return GSH_OK;
@@ -359,6 +396,24 @@ extern "C"
     int gsh_stream_group_push_device(gsh_stream_group_t* g, const void* device_items, uint64_t n, int item_type, int inverted_spectrum, uint64_t* first_index)
     {
         return push_common(g, device_items, true, n, item_type, inverted_spectrum, first_index);
+    }
+
+    int gsh_stream_group_rccl_info(const gsh_stream_group_t* g, int32_t* rccl_ranks, int32_t* rccl_version, uint64_t* collectives)
+    {
+        GSH_REQUIRE(g != nullptr, "null group");
+        if (rccl_ranks) *rccl_ranks = g->rccl_ranks;
+        if (collectives) *collectives = g->rccl_calls;
+        if (rccl_version)
+            {
+                *rccl_version = 0;
+                if (g->rccl_ranks > 0)  // (never loads RCCL on behalf of a group that did not use it)
+                    {
+                        Rccl* R = rccl();
+                        int v = 0;
+                        if (R != nullptr && R->GetVersion != nullptr && R->GetVersion(&v) == 0) *rccl_version = v;
+                    }
+            }
+        return GSH_OK;
     }
 
     int gsh_stream_group_wait(gsh_stream_group_t* g)

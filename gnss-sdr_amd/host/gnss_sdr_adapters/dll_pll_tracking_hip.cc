@@ -35,8 +35,9 @@ namespace
 {
 // Which blocks share one Hip_Tracking_Runtime and, through it, one device sample ring -- the stream then crosses PCIe once for all of them and one resident
 // loop kernel (or one launch) advances all of them (hip_tracking_runtime.h):
-//   <role>.hip_shared_ring  absent / -2  every block of this role (= signal class: "Tracking_1C", ...) on this device: the reference's channels of one signal
-//                                        read one buffer (gnss_flowgraph.cc:1227-1231), so this is the default
+//   <role>.hip_shared_ring  absent / -2  every block of this role (= signal class: "Tracking_1C", ...) and RF chain (Channels_<signal>.RF_channel_ID) on this device:
+//                                        the reference's channels of one signal read one buffer (gnss_flowgraph.cc:1227-1231), so this is the default.  Receivers
+//                                        that route single channels elsewhere (Channel<i>.RF_channel_ID) fall back to -1 (create_tracking_block)
 //                           >= 0         every block on this device that names the same id, whatever its role (signals of one RF stream: L1 C/A + E1)
 //                           -1           a runtime (and ring) of the block's own.  Needed when blocks of one role are fed from DIFFERENT streams (receivers
 //                                        with several RF chains per signal): the ring de-duplicates pushes by absolute sample index, which only holds for
@@ -166,7 +167,35 @@ void DllPllTrackingHip::create_tracking_block(const ConfigurationInterface* conf
     // back to the scheduler); larger values save scheduler round trips when the receiver post-processes a file faster than real time (the runtime's throughput
     // at 1 / 20: bench.py -> dropin).  The device works ahead of the blocks either way -- this key only sets how much a block takes per call.
     const int periods = configuration->property(role_ + ".hip_periods_per_call", 1);
-    const int ring_id = configuration->property(role_ + ".hip_shared_ring", -2);
+    int ring_id = configuration->property(role_ + ".hip_shared_ring", -2);
+    std::string stream_tag;
+    if (ring_id == -2)
+        {
+            // "Every block of the role shares one ring" holds only for blocks that are fed the SAME stream: the ring de-duplicates pushes by absolute sample index.
+            // The flowgraph connects channel i to sig_conditioner_[RF_channel_ID], taken from Channels_<signal>.RF_channel_ID and overridden per channel by
+            // Channel<i>.RF_channel_ID (gnss_flowgraph.cc:1107-1108, 1227-1231).  The signal's chain is part of the sharing key; a receiver that routes single channels
+            // to other chains is not shared by default at all (the block does not know its channel number here: the factory passes the role only) -- such receivers
+            // name their groups themselves, <role>.hip_shared_ring = id per chain.
+            const std::string sig(trk_params_.signal);
+            const int rf_chain = configuration->property("Channels_" + sig + ".RF_channel_ID", 0);
+            stream_tag = ":rf" + std::to_string(rf_chain);
+            int n_channels = 0;
+            for (const char* s : {"1C", "2S", "L5", "1B", "5X", "7X", "E6", "1G", "2G", "B1", "B3", "J1", "J5"})
+                n_channels += std::max(0, configuration->property(std::string("Channels_") + s + ".count", 0));
+            n_channels = std::min(n_channels, 512);
+            for (int i = 0; i < n_channels; i++)
+                {
+                    const int own = configuration->property("Channel" + std::to_string(i) + ".RF_channel_ID", rf_chain);
+                    if (own != rf_chain)
+                        {
+                            LOG(WARNING) << role_ << ": Channel" << i << ".RF_channel_ID = " << own << " routes a channel to another RF chain than Channels_" << sig
+                                         << ".RF_channel_ID = " << rf_chain << ": the blocks of this role get a sample ring each (set " << role_
+                                         << ".hip_shared_ring = <id per chain> to share one per chain)";
+                            ring_id = -1;
+                            break;
+                        }
+                }
+        }
     // the loop kernel stays resident and follows the ring (hip_tracking_runtime.h, "LIVE mode"); false: one launch per batch of periods, as in round 3
     const bool live = configuration->property(role_ + ".hip_live", true);
     const int per_launch = configuration->property(role_ + ".hip_periods_per_launch", std::max(16, periods));
@@ -191,7 +220,7 @@ void DllPllTrackingHip::create_tracking_block(const ConfigurationInterface* conf
     // most channels of one loop configuration that share a launch (one work-group each; a further handle is opened beyond that).  Every launch brings the
     // records of all the handle's slots back, so the default stays at what BASELINE's configurations put on one GPU (32 - 50 channels per stream)
     const int per_handle = configuration->property(role_ + ".hip_channels_per_launch", 64);
-    auto runtime = runtime_for(device, device_key >= 0, devices, ring_id, role_, trk_params_, per_launch, register_input, per_handle, live, &device);
+    auto runtime = runtime_for(device, device_key >= 0, devices, ring_id, role_ + stream_tag, trk_params_, per_launch, register_input, per_handle, live, &device);
     if (!runtime)
         {
             item_size_ = 0;

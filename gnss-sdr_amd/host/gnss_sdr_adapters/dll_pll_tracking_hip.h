@@ -9,12 +9,23 @@
  * Constructor signature, role(), implementation(), item_size(), connect / disconnect, get_left_block / get_right_block, set_channel,
  * set_gnss_synchro, start_tracking, stop_tracking behave as BaseDllPllTracking's (base_dll_pll_tracking.cc:25-112); configuration keys are
  * Dll_Pll_Conf's (dll_pll_conf.cc:48-158) plus
- *   <role>.hip_device            GPU index (0)
+ *   <role>.hip_device            GPU index (0); pins the block to that GPU when <role>.hip_devices is given as well
+ *   <role>.hip_devices           "0,1,2,...": the stream is kept resident in several GPUs of the node (ONE Hip_Sample_Ring over gsh_stream_group_*: one push over
+ *                                PCIe into devices[0], RCCL replication over xGMI) and the blocks of the role are dealt to them in turn -- channel c -> GPU
+ *                                c mod G; a Hip_Tracking_Runtime per device.  Default: hip_device only
  *   <role>.hip_periods_per_call  code periods one general_work call may take (1 = the reference's cadence, at most 64)
- *   <role>.hip_shared_ring       id >= 0: channels configured with the same id (and device) share one Hip_Tracking_Runtime and its device
- *                                sample ring -- the stream crosses PCIe once for all of them and ONE launch advances every channel that has
- *                                samples; -1 (default): a runtime and ring of the block's own
- *   <role>.hip_periods_per_launch  most code periods per channel one shared launch runs (16)
+ *   <role>.hip_live              true (default): the loop kernel stays RESIDENT and follows the device sample ring, general_work reads finished records out of
+ *                                page-locked memory (no launch per batch of periods); false: one launch advances every channel that has samples
+ *   <role>.hip_shared_ring       which blocks share one Hip_Tracking_Runtime and, through it, one device sample ring (the stream crosses PCIe once for all of
+ *                                them; one residency / launch advances them all):
+ *                                  -2 (default)  every block of this role fed from the same RF chain (Channels_<signal>.RF_channel_ID) on the same device.  When
+ *                                                any Channel<i>.RF_channel_ID routes a single channel to another chain the default falls back to -1: the ring
+ *                                                de-duplicates pushes by absolute sample index, which only holds for blocks that see the same stream
+ *                                  >= 0          every block on the device that names the same id, whatever its role (L1 C/A + E1 of one RF stream; or one id
+ *                                                per RF chain in receivers with per-channel routing)
+ *                                  -1            a runtime and ring of the block's own
+ *   <role>.hip_periods_per_launch   launched mode: most code periods per channel one shared launch runs (max(16, hip_periods_per_call))
+ *   <role>.hip_channels_per_launch  most channels of one loop configuration behind one device handle (64: one work-group each; a further handle beyond that)
  *   <role>.hip_register_input_buffer  page-lock the block's input buffer (lazily, as general_work shows it) so that pushes are DMAs without a
  *                                staging copy (true)
  * Factory registration (one `else if` per name, as gnss_block_factory.cc:657-662 does for the CUDA block): INTEGRATION.md section 2b.

@@ -252,6 +252,7 @@ class StreamGroup:
     """gsh_stream_group_*: one block replicated into the sample rings of several GPUs over RCCL (one process per GPU: from_rank; one process
     driving several GPUs: local)."""
     MODES = {"broadcast": 0, "scatter_allgather": 1}
+    FORCE_RCCL = 0x100   # GSH_GROUP_FORCE_RCCL: a group of one builds its communicator and runs the mode's collectives all the same
 
     def __init__(self, handle, lib):
         self._h, self._lib = handle, lib
@@ -263,20 +264,29 @@ class StreamGroup:
         return buf.raw
 
     @classmethod
-    def from_rank(cls, device: int, rank: int, world: int, unique_id: bytes | None, capacity_samples: int, max_window_samples: int, mode: str = "broadcast"):
+    def from_rank(cls, device: int, rank: int, world: int, unique_id: bytes | None, capacity_samples: int, max_window_samples: int, mode: str = "broadcast",
+                  force_rccl: bool = False):
         L = _lib.load()
         h = C.c_void_p()
         idb = C.create_string_buffer(unique_id, 128) if unique_id is not None else None
-        check(L.gsh_stream_group_create_rank(device, rank, world, idb, capacity_samples, max_window_samples, cls.MODES[mode], C.byref(h)))
+        check(L.gsh_stream_group_create_rank(device, rank, world, idb, capacity_samples, max_window_samples,
+                                             cls.MODES[mode] | (cls.FORCE_RCCL if force_rccl else 0), C.byref(h)))
         return cls(h, L)
 
     @classmethod
-    def local(cls, devices, capacity_samples: int, max_window_samples: int, mode: str = "broadcast"):
+    def local(cls, devices, capacity_samples: int, max_window_samples: int, mode: str = "broadcast", force_rccl: bool = False):
         L = _lib.load()
         h = C.c_void_p()
         arr = (C.c_int * len(devices))(*devices)
-        check(L.gsh_stream_group_create(arr, len(devices), capacity_samples, max_window_samples, cls.MODES[mode], C.byref(h)))
+        check(L.gsh_stream_group_create(arr, len(devices), capacity_samples, max_window_samples,
+                                        cls.MODES[mode] | (cls.FORCE_RCCL if force_rccl else 0), C.byref(h)))
         return cls(h, L)
+
+    def rccl_info(self) -> dict:
+        """{'ranks': ranks of the communicator the group built (0: RCCL untouched), 'version': ncclGetVersion code, 'collectives': RCCL calls issued}"""
+        ranks, ver, calls = C.c_int32(0), C.c_int32(0), C.c_uint64(0)
+        check(self._lib.gsh_stream_group_rccl_info(self._h, C.byref(ranks), C.byref(ver), C.byref(calls)))
+        return dict(ranks=int(ranks.value), version=int(ver.value), collectives=int(calls.value))
 
     def close(self):
         if self._h:

@@ -30,7 +30,7 @@ extern "C"
 {
 #endif
 
-#define GSH_ABI_VERSION 23
+#define GSH_ABI_VERSION 24
 #define GSH_MAX_TAPS 8 /* VE/E/P/L/VL needs 5 (trk.cc:609-650); 8 leaves room for multi-tap dumps */
 
     enum
@@ -215,6 +215,11 @@ extern "C"
     typedef struct gsh_stream_group gsh_stream_group_t;
 #define GSH_GROUP_BROADCAST 0
 #define GSH_GROUP_SCATTER_ALLGATHER 1
+/* OR'ed into `mode`: a group of ONE rank normally needs no exchange and never touches RCCL; with this flag it builds its communicator
+ * (ncclCommInitAll / ncclCommInitRank with one rank) and sends every block through the mode's collectives all the same -- ncclBroadcast, or
+ * the grouped ncclSend / ncclRecv to itself + ncclAllGather -- so that the dlopen, the hand-declared signatures and the stream ordering can be
+ * exercised on a single-GPU box.  The environment variable GSH_GROUP_FORCE_RCCL=1 sets it for every group of one.  No effect on world > 1. */
+#define GSH_GROUP_FORCE_RCCL 0x100
     /* one process drives all n_devices GPUs (ncclCommInitAll); local ring i belongs to devices[i], rank i */
     int gsh_stream_group_create(const int* devices, int n_devices, uint64_t capacity_samples, uint32_t max_window_samples, int mode, gsh_stream_group_t** out);
     /* one process per GPU: id128 = 128 bytes from gsh_comm_unique_id() on one rank, handed to every rank by whoever launched them
@@ -230,6 +235,10 @@ extern "C"
     int gsh_stream_group_push(gsh_stream_group_t* g, const void* host_items, uint64_t n, int item_type, int inverted_spectrum, uint64_t* first_index);
     int gsh_stream_group_push_device(gsh_stream_group_t* g, const void* device_items, uint64_t n, int item_type, int inverted_spectrum, uint64_t* first_index);
     int gsh_stream_group_wait(gsh_stream_group_t* g);
+    /* what the group has done with RCCL so far: *rccl_ranks = ranks of the communicator(s) the group created (0: none -- a group of one without
+     * GSH_GROUP_FORCE_RCCL), *rccl_version = ncclGetVersion's code (0 when RCCL was never loaded), *collectives = RCCL collective / point-to-point
+     * calls this group has issued (broadcasts, sends, receives, all-gathers).  Any pointer may be NULL. */
+    int gsh_stream_group_rccl_info(const gsh_stream_group_t* g, int32_t* rccl_ranks, int32_t* rccl_version, uint64_t* collectives);
     int gsh_stream_range(gsh_stream_t* s, uint64_t* oldest, uint64_t* next);
     /* copy resident samples [index, index + n) back to the host as complex64 (tests, dumps) */
     int gsh_stream_read(gsh_stream_t* s, uint64_t index, uint64_t n, float* out_iq);

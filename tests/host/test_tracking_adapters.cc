@@ -969,6 +969,7 @@ int main(int argc, char** argv)
             const int ch = argc > 2 ? std::atoi(argv[2]) : 8;
             const int periods = argc > 3 ? std::atoi(argv[3]) : 2400;
             const int ppc = argc > 4 ? std::atoi(argv[4]) : 4;
+            test_shared_ring_follows_the_rf_chain();
             test_restart_on_the_same_block();
             test_many_periods_per_call();
             test_dump_tow_and_time_tags(1);
@@ -1001,6 +1002,7 @@ int main(int argc, char** argv)
     test_galileo_e1_pilot_trajectory();
     test_other_signal_trajectories();
     test_loss_of_lock_on_noise();
+    test_shared_ring_follows_the_rf_chain();
     test_restart_on_the_same_block();
     test_many_periods_per_call();
     test_dump_tow_and_time_tags(1);

@@ -19,16 +19,26 @@ def _blocks(rng, sizes):
     return [rng.integers(-128, 128, size=(n, 2)).astype(np.int8) for n in sizes]
 
 
+@pytest.mark.parametrize("rccl", [False, True], ids=["no_exchange", "one_rank_rccl"])
 @pytest.mark.parametrize("mode", ["broadcast", "scatter_allgather"])
-@pytest.mark.parametrize("how", ["local", "rank"])
-def test_group_of_one_equals_local_push(gpu, mode, how):
+@pytest.mark.parametrize("how", ["local", "rank", "rank_own_id"])
+def test_group_of_one_equals_local_push(gpu, mode, how, rccl):
+    """rccl = True (GSH_GROUP_FORCE_RCCL): the group of one builds a one-rank communicator (ncclCommInitAll / ncclCommInitRank) and every block goes
+    through ncclBroadcast, or the grouped ncclSend / ncclRecv to itself + ncclAllGather, on the ring's stream -- the only RCCL evidence a single-GPU
+    box can give: the dlopen, the hand-declared signatures, the ncclUniqueId by value, the stream ordering against the cast that follows."""
     from gnss_sdr_amd.sample_stream import SampleStream, StreamGroup
     cap, win = 40000, 9000
     if how == "local":
-        g = StreamGroup.local([gpu], cap, win, mode=mode)
+        g = StreamGroup.local([gpu], cap, win, mode=mode, force_rccl=rccl)
+    elif how == "rank":
+        g = StreamGroup.from_rank(gpu, 0, 1, StreamGroup.unique_id(), cap, win, mode=mode, force_rccl=rccl)
     else:
-        g = StreamGroup.from_rank(gpu, 0, 1, StreamGroup.unique_id(), cap, win, mode=mode)
+        g = StreamGroup.from_rank(gpu, 0, 1, None, cap, win, mode=mode, force_rccl=rccl)
     assert g.size() == 1
+    info = g.rccl_info()
+    assert info["ranks"] == (1 if rccl else 0) and info["collectives"] == 0
+    if rccl:
+        assert info["version"] > 20000, info    # ncclGetVersion answered: RCCL is loaded and its symbols resolve
     ring = g.ring(0)
     ref = SampleStream(cap, win, device=gpu)
     rng = np.random.default_rng(3)
@@ -43,10 +53,16 @@ def test_group_of_one_equals_local_push(gpu, mode, how):
         n = min(hi - lo, win)
         for start in (lo, hi - n):
             assert np.array_equal(ring.read(start, n).view(np.uint32), ref.read(start, n).view(np.uint32))
+    info = g.rccl_info()
+    # 7 non-empty blocks: one broadcast each, or send + receive + all-gather each
+    assert info["collectives"] == (0 if not rccl else 7 * (1 if mode == "broadcast" else 3)), info
+    if rccl:
+        print(f"one-rank RCCL group ({how}, {mode}): ncclGetVersion {info['version']}, {info['collectives']} RCCL calls, ring bit-identical to a local push")
     g.close()
 
 
-def test_bank_on_group_ring_is_bit_identical_to_private_ring(gpu):
+@pytest.mark.parametrize("rccl", [None, "broadcast", "scatter_allgather"], ids=["no_exchange", "rccl_broadcast", "rccl_scatter_allgather"])
+def test_bank_on_group_ring_is_bit_identical_to_private_ring(gpu, rccl):
     from gnss_sdr_amd.sample_stream import SampleStream, StreamGroup
     from gnss_sdr_amd.tracking import CorrelatorBank
     fs, n = 4e6, 4000
@@ -55,7 +71,8 @@ def test_bank_on_group_ring_is_bit_identical_to_private_ring(gpu):
     x = synth_gps_l1_stream(total, fs, [1, 2, 3], dopplers, [5.0, 300.0, 800.0], seed_noise=21)
     x8 = np.clip(np.round(np.stack([x.real, x.imag], axis=1) * 30.0), -127, 127).astype(np.int8)
     cap = 9 * n + 2
-    g = StreamGroup.local([gpu], cap, 2 * n)
+    # (rccl: the block reaches the ring through a one-rank communicator's collectives; the launch that reads it is ordered behind them by the ring's events alone)
+    g = StreamGroup.local([gpu], cap, 2 * n, mode=rccl or "broadcast", force_rccl=rccl is not None)
     priv = SampleStream(cap, 2 * n, device=gpu)
     rng = np.random.default_rng(2)
     params = [tracking_params_for(fs, d, rng) for d in dopplers]
@@ -77,6 +94,7 @@ def test_bank_on_group_ring_is_bit_identical_to_private_ring(gpu):
         outs.append(np.concatenate(got, axis=0))
         bank.close()
     assert outs[0].shape == outs[1].shape and np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
+    assert (g.rccl_info()["collectives"] > 0) == (rccl is not None)
     g.close()
 
 

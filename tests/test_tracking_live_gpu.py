@@ -209,3 +209,88 @@ def test_live_rules(gpu):
     assert len(got[0]) == n_before + 0 or got[0][n_before].sample_counter == rec[0][1].sample_counter + rec[0][1].prn_length_samples
     live.close()
     ring.close()
+
+
+# ---- the live flavours at the BASELINE shapes, DIRECTLY: the records of a residency are held to the launched run byte for byte AND to the oracle loop in the same
+# test (round 4 reached the LIVE kernels at N = 25 000 and N = 128 000 / five taps + pilot only through the adapter program, and the oracle only transitively)
+def _shape(name):
+    from helpers import add_code_signal, cn0_to_amplitude, golden_e1_l5_codes
+    if name == "config2_25Msps_3taps":
+        fs, n, epochs = 25e6, 25000, 210
+        prns, dops, cphs = [3, 22], [2750.0, -4100.0], [17.25, 640.0]
+        x = synth_gps_l1_stream((epochs + 3) * n, fs, prns, dops, cphs, cn0_dbhz=46.0, seed_noise=91)
+        kw = dict(fs_in=fs, vector_length=n, pll_bw_hz=35.0, dll_bw_hz=2.0, enable_lock_detectors=1, early_late_space_chips=0.5)
+        codes = [(oracle.ca_code(p), None) for p in prns]
+        starts = [int(round((1023.0 - cph) / (1.023e6 * (1 + fd / 1575.42e6)) * fs)) for fd, cph in zip(dops, cphs)]
+        hand_over = [fd + 7.0 for fd in dops]
+        return dict(fs=fs, n=n, epochs=epochs, x=x, kw=kw, codes=codes, starts=starts, dops=hand_over, taps=3, max_len=1023, scale=20.0)
+    # BASELINE config 4: Galileo E1, 32 Msps, 4 ms windows of 128 000 samples, VE/E/P/L/VL on the pilot + the data prompt (trk.cc:1246-1256)
+    fs, n, epochs = 32e6, 128000, 203
+    g = golden_e1_l5_codes()
+    rng = np.random.default_rng(43)
+    n_stream = (epochs + 3) * n
+    x = (rng.standard_normal(n_stream, dtype=np.float32) + 1j * rng.standard_normal(n_stream, dtype=np.float32)).astype(np.complex64)
+    amp = cn0_to_amplitude(45.0, fs)
+    sig = [(7, -1830.0, 3000.0), (19, 2410.0, 511.0)]
+    starts, hand_over, codes = [], [], []
+    for prn_i, fd, ph in sig:
+        rate = 1.023e6 * (1 + fd / 1575.42e6) / fs * 2.0
+        add_code_signal(x, (g["e1b"][prn_i] - g["e1c"][prn_i]) / np.sqrt(2.0), fs, rate, ph, fd, amp)
+        starts.append(int(round((8184.0 - ph) / rate)))
+        hand_over.append(fd - 5.0)
+        codes.append((g["e1c"][prn_i], g["e1b"][prn_i]))
+    kw = dict(fs_in=fs, vector_length=n, code_length_chips=4092, code_samples_per_chip=2, veml=1, track_pilot=1, cloop=0, early_late_space_chips=0.15,
+              very_early_late_space_chips=0.5, pll_bw_hz=15.0, dll_bw_hz=0.75, pll_filter_order=3, dll_filter_order=2, enable_lock_detectors=1)
+    return dict(fs=fs, n=n, epochs=epochs, x=x, kw=kw, codes=codes, starts=starts, dops=hand_over, taps=5, max_len=8184, scale=20.0)
+
+
+@pytest.mark.parametrize("shape", ["config2_25Msps_3taps", "config4_e1_32Msps_5taps_pilot"])
+def test_live_at_the_baseline_shapes_equals_launched_run_and_oracle(gpu, shape):
+    from gnss_sdr_amd.sample_stream import SampleStream
+    from test_tracking_loop_gpu import _compare
+    s = _shape(shape)
+    n, epochs = s["n"], s["epochs"]
+    # the front-end's 8-bit items, as the ring receives them; the flat run and the oracle read the same values as complex64
+    x8 = np.clip(np.round(np.stack([s["x"].real, s["x"].imag], axis=1) * s["scale"]), -127, 127).astype(np.int8)
+    xf = (x8[:, 0].astype(np.float32) + 1j * x8[:, 1].astype(np.float32)).astype(np.complex64)
+    total = len(xf)
+    nch = len(s["codes"])
+    flat = _loop(gpu, s["kw"], n_channels=nch, max_len=s["max_len"])
+    flat.set_stream_host(xf)
+    for ch in range(nch):
+        flat.start(ch, s["codes"][ch][0], s["starts"][ch], 0, s["dops"][ch], data_code=s["codes"][ch][1])
+    rec_flat, done_flat = flat.run(epochs)
+    flat.close()
+    assert all(d >= 200 for d in done_flat), done_flat
+
+    ring = SampleStream(9 * n + 7, 2 * n, device=gpu)   # shorter than the stream: it wraps
+    live = _loop(gpu, s["kw"], n_channels=nch, max_len=s["max_len"])
+    live.set_stream_ring(ring)
+    for ch in range(nch):
+        live.start(ch, s["codes"][ch][0], s["starts"][ch], 0, s["dops"][ch], data_code=s["codes"][ch][1])
+    got, lost = [[] for _ in range(nch)], [False] * nch
+    pushed, blk = 0, 3 * n + n // 2
+    while pushed < total:
+        m = min(blk, total - pushed)
+        ring.push(x8[pushed:pushed + m], "ibyte")
+        pushed += m
+        if live.live_in_flight() == 0:
+            live.live_begin()
+        want = [min(done_flat[ch], max(0, (pushed - s["starts"][ch]) // n - 1)) for ch in range(nch)]
+        _drain(live, got, lost, 3.0, want)
+    _drain(live, got, lost, 1.0)
+    live.live_quiesce()
+    _drain(live, got, lost, 0.2)
+    live.close()
+    ring.close()
+    conf_o = oracle.trk_conf(**s["kw"])
+    for ch in range(nch):
+        assert len(got[ch]) == done_flat[ch], (shape, ch, len(got[ch]), done_flat[ch])
+        assert _bytes(got[ch]) == _bytes(rec_flat[ch][:done_flat[ch]]), f"{shape} channel {ch}: live records differ from the launched run"
+        # ... and the first 200 periods of the LIVE records against the oracle loop, the same bars as the launched loop's (test_tracking_loop_gpu._compare)
+        ora = oracle.trk_run(conf_o, s["codes"][ch][0], xf, s["starts"][ch], 0, s["dops"][ch], 200, data_code=s["codes"][ch][1])
+        assert len(ora) == 200
+        stats = _compare(got[ch][:200], ora, s["taps"], f"{shape} live ch{ch}", xmax=6.0 * s["scale"])
+        assert stats["compared"] == 200
+        tail = got[ch][150:200]
+        assert abs(np.mean([r.carrier_doppler_hz for r in tail]) - (s["dops"][ch] + (-7.0 if s["taps"] == 3 else 5.0))) < 3.0, (shape, ch)
