@@ -188,6 +188,8 @@ SYMBOLS = {
     "gsh_trk_set_stream_ring": (C.c_int, [_P, _P]),
     "gsh_trk_start": (C.c_int, [_P, C.c_int, _F, _F, C.c_int, C.c_uint64, C.c_uint64, C.c_double]),
     "gsh_trk_start_ex": (C.c_int, [_P, C.c_int, _F, _F, C.c_int, C.c_uint64, C.c_uint64, C.c_double, C.c_double]),
+    "gsh_trk_pull_in_over": (C.c_int, [C.POINTER(TrkConf), C.c_uint64, C.c_uint64]),
+    "gsh_trk_start_flags": (C.c_int, [_P, C.c_int, _F, _F, C.c_int, C.c_uint64, C.c_uint64, C.c_double, C.c_double, C.c_uint32]),
     "gsh_trk_pull_in": (C.c_int, [C.POINTER(TrkConf), C.c_uint64, C.c_double, C.c_uint64, C.c_double, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
     "gsh_trk_stop": (C.c_int, [_P, C.c_int]),
     "gsh_trk_run": (C.c_int, [_P, C.c_int, C.POINTER(TrkEpoch), C.POINTER(C.c_int32)]),

@@ -112,7 +112,7 @@ struct TrkChannel  // loop state of one channel, resident in device memory betwe
     double carrier_doppler_hz, carrier_phase_step_rad, code_freq_chips, code_phase_step_chips;
     double rem_code_phase_samples, rem_code_phase_chips, acc_carrier_phase_rad;
     double carrier_phase_rate_step_rad, code_phase_rate_step_chips;  // high_dyn (trk.cc:1425-1443, 1458-1480); 0 otherwise
-    unsigned long long pos, acq_stamp;
+    unsigned long long pos, acq_stamp;  // acq_stamp: bit 63 set = the pull-in transitory was over at the hand-over call (GSH_TRK_START_PULL_IN_OVER); the stamp is the rest
     float rem_carr_phase_rad, p_old_re, p_old_im;
     int active, code_len;
     LoopFilterState dll;
@@ -803,7 +803,9 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
     }
     __syncthreads();
     const int code_len = s.code_len;
-    const unsigned long long acq_stamp = s.acq_stamp;
+    const unsigned long long acq_stamp = s.acq_stamp & 0x7fffffffffffffffull;
+    // (trk.cc:1910-1917 looks at its latch in the pull-in call too, where a read pointer behind the acquisition's stamp wraps the unsigned difference: gsh_trk_pull_in_over)
+    const unsigned long long pull_in_limit = (s.acq_stamp >> 63) ? 0ull : a.pull_in_limit;
 
     // ---- local replicas stay in LDS for the whole launch
     float* tab = lds;
@@ -1023,7 +1025,7 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
             // the (wave-uniform) inputs of the lanes below, from state that is only read here
             auto form_inputs = [&]() {
                 // trk.cc:1912-1915: pull-in ends once more than pull_in_time_s whole seconds have passed since acquisition
-                pull_in = (pos - acq_stamp) < a.pull_in_limit;
+                pull_in = (pos - acq_stamp) < pull_in_limit;
                 // the accumulators the loop works on (d_VE_accu .. d_VL_accu): the period's outputs in state 2 (trk.cc:1984-1991); in state 4
                 // save_correlation_results adds them, times the secondary code chip, to accumulators zeroed at the end of the previous period
                 run_state = CF(CF_SYMBOL_SYNC) ? lk.state : 0;
@@ -2353,6 +2355,14 @@ extern "C"
         return GSH_OK;
     }
 
+    int gsh_trk_pull_in_over(const gsh_trk_conf* conf, uint64_t nitems_read, uint64_t acq_sample_stamp)
+    {
+        // trk.cc:1912 as written: uint32 < (uint64 - uint64) / int -- the int is converted to uint64 for the division
+        if (conf == nullptr || static_cast<int>(conf->fs_in) <= 0) return 0;
+        const uint64_t elapsed_s = (nitems_read - acq_sample_stamp) / static_cast<uint64_t>(static_cast<int>(conf->fs_in));
+        return static_cast<uint64_t>(conf->pull_in_time_s) < elapsed_s ? 1 : 0;
+    }
+
     int gsh_trk_start(gsh_trk_t* t, int channel, const float* code, const float* data_code, int code_length, uint64_t start_sample,
         uint64_t acq_sample_stamp, double acq_carrier_doppler_hz)
     {
@@ -2383,7 +2393,15 @@ extern "C"
     int gsh_trk_start_ex(gsh_trk_t* t, int channel, const float* code, const float* data_code, int code_length, uint64_t start_sample,
         uint64_t acq_sample_stamp, double acq_carrier_doppler_hz, double initial_acc_carrier_phase_rad)
     {
+        return gsh_trk_start_flags(t, channel, code, data_code, code_length, start_sample, acq_sample_stamp, acq_carrier_doppler_hz, initial_acc_carrier_phase_rad, 0U);
+    }
+
+    int gsh_trk_start_flags(gsh_trk_t* t, int channel, const float* code, const float* data_code, int code_length, uint64_t start_sample,
+        uint64_t acq_sample_stamp, double acq_carrier_doppler_hz, double initial_acc_carrier_phase_rad, uint32_t flags)
+    {
         GSH_REQUIRE(t != nullptr && code != nullptr, "null argument");
+        GSH_REQUIRE((flags & ~GSH_TRK_START_PULL_IN_OVER) == 0U, "unknown start flags 0x%x", flags);
+        GSH_REQUIRE(acq_sample_stamp < (1ull << 63), "acq_sample_stamp out of range");
         GSH_REQUIRE(channel >= 0 && channel < t->n_channels, "channel %d outside 0..%d", channel, t->n_channels - 1);
         GSH_REQUIRE(code_length >= gsh::mcdev::MC_MARGIN && code_length <= t->max_code_len, "code_length %d outside %d..%d", code_length, gsh::mcdev::MC_MARGIN, t->max_code_len);
         GSH_REQUIRE(!t->conf.track_pilot || data_code != nullptr, "track_pilot needs the data-component code");
@@ -2406,7 +2424,7 @@ extern "C"
         s.p_old_re = 0.0F;
         s.p_old_im = 0.0F;
         s.pos = start_sample;
-        s.acq_stamp = acq_sample_stamp;
+        s.acq_stamp = acq_sample_stamp | ((flags & GSH_TRK_START_PULL_IN_OVER) ? (1ull << 63) : 0ull);
         s.active = 1;
         s.code_len = code_length;
         const double code_period = static_cast<double>(c.code_length_chips) / c.code_chip_rate;

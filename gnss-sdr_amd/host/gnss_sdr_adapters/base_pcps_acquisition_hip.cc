@@ -102,6 +102,7 @@ BasePcpsAcquisitionHip::BasePcpsAcquisitionHip(const ConfigurationInterface* con
 
 void BasePcpsAcquisitionHip::set_local_code()
 {
+    if (!acquisition_ || gnss_synchro_ == nullptr) return;
     // base_pcps_acquisition.cc:206-222
     std::vector<std::complex<float>> code(code_length_);
     const auto sampling_freq = acq_parameters_.use_automatic_resampler ? acq_parameters_.resampled_fs : acq_parameters_.fs_in;

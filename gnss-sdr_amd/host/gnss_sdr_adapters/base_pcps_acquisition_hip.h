@@ -60,17 +60,39 @@ public:
     void set_gnss_synchro(Gnss_Synchro* p_gnss_synchro) override
     {
         gnss_synchro_ = p_gnss_synchro;
-        acquisition_->set_gnss_synchro(p_gnss_synchro);
+        if (acquisition_) acquisition_->set_gnss_synchro(p_gnss_synchro);
     }
-    void set_channel(unsigned int channel) override { acquisition_->set_channel(channel); }
-    void set_channel_fsm(std::weak_ptr<ChannelFsm> channel_fsm) override { acquisition_->set_channel_fsm(std::move(channel_fsm)); }
-    void set_doppler_center(int doppler_center) override { acquisition_->set_doppler_center(doppler_center); }
-    signed int mag() override { return static_cast<signed int>(acquisition_->mag()); }
-    void reset() override { acquisition_->set_active(true); }
-    void stop_acquisition() override { acquisition_->set_active(false); }
-    void set_resampler_latency(uint32_t latency_samples) override { acquisition_->set_resampler_latency(latency_samples); }
+    // (an unusable adapter -- item_size() == 0: no GPU, unsupported item type -- has no block; a Channel calls these from its constructor all the same, channel.cc:53-61)
+    void set_channel(unsigned int channel) override
+    {
+        if (acquisition_) acquisition_->set_channel(channel);
+    }
+    void set_channel_fsm(std::weak_ptr<ChannelFsm> channel_fsm) override
+    {
+        if (acquisition_) acquisition_->set_channel_fsm(std::move(channel_fsm));
+    }
+    void set_doppler_center(int doppler_center) override
+    {
+        if (acquisition_) acquisition_->set_doppler_center(doppler_center);
+    }
+    signed int mag() override { return acquisition_ ? static_cast<signed int>(acquisition_->mag()) : 0; }
+    void reset() override
+    {
+        if (acquisition_) acquisition_->set_active(true);
+    }
+    void stop_acquisition() override
+    {
+        if (acquisition_) acquisition_->set_active(false);
+    }
+    void set_resampler_latency(uint32_t latency_samples) override
+    {
+        if (acquisition_) acquisition_->set_resampler_latency(latency_samples);
+    }
     void set_local_code() override;
-    void set_state(int state) { acquisition_->set_state(state); }
+    void set_state(int state)
+    {
+        if (acquisition_) acquisition_->set_state(state);
+    }
 
 protected:
     Gnss_Synchro* gnss_synchro_{nullptr};

@@ -227,6 +227,8 @@ void DllPllTrackingHip::create_tracking_block(const ConfigurationInterface* conf
             tracking_sptr_ = nullptr;
             return;
         }
+    // live mode's watchdog: a resident window without a record for this long = the device is not delivering; the channel is given up ("events" 3)
+    runtime->set_record_timeout_ms(configuration->property(role_ + ".hip_record_timeout_ms", 1000));
     tracking_sptr_ = dll_pll_veml_make_tracking_hip(trk_params_, periods, std::move(runtime));
     if (!tracking_sptr_->usable())
         {
@@ -257,10 +259,24 @@ void DllPllTrackingHip::disconnect(gr::top_block_sptr top_block)
 
 gr::basic_block_sptr DllPllTrackingHip::get_left_block() { return tracking_sptr_; }
 gr::basic_block_sptr DllPllTrackingHip::get_right_block() { return tracking_sptr_; }
-void DllPllTrackingHip::set_channel(unsigned int channel) { tracking_sptr_->set_channel(channel); }
-void DllPllTrackingHip::set_gnss_synchro(Gnss_Synchro* p_gnss_synchro) { tracking_sptr_->set_gnss_synchro(p_gnss_synchro); }
-void DllPllTrackingHip::start_tracking() { tracking_sptr_->start_tracking(); }
-void DllPllTrackingHip::stop_tracking() { tracking_sptr_->stop_tracking(); }
+// (an unusable adapter -- item_size() == 0: no GPU, unsupported item type -- has no block: the factory drops it, gnss_block_factory.cc:1048-1052, but a Channel that is
+//  built all the same calls these from its constructor, channel.cc:53-61; they must not crash)
+void DllPllTrackingHip::set_channel(unsigned int channel)
+{
+    if (tracking_sptr_) tracking_sptr_->set_channel(channel);
+}
+void DllPllTrackingHip::set_gnss_synchro(Gnss_Synchro* p_gnss_synchro)
+{
+    if (tracking_sptr_) tracking_sptr_->set_gnss_synchro(p_gnss_synchro);
+}
+void DllPllTrackingHip::start_tracking()
+{
+    if (tracking_sptr_) tracking_sptr_->start_tracking();
+}
+void DllPllTrackingHip::stop_tracking()
+{
+    if (tracking_sptr_) tracking_sptr_->stop_tracking();
+}
 
 
 GpsL1CaDllPllTrackingHip::GpsL1CaDllPllTrackingHip(const ConfigurationInterface* configuration, const std::string& role, unsigned int in_streams,

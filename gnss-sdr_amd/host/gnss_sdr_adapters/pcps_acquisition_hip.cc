@@ -231,38 +231,44 @@ void pcps_acquisition_hip::run_dwell(uint64_t sample_count, const std::shared_pt
             outcome = d_cshort ? d_core.acquisition_core(sample_count, d_data_buffer_sc.data(), &result)
                                : d_core.acquisition_core(sample_count, d_data_buffer.data(), &result);
         }
-    gr::thread::scoped_lock lock(d_setlock);
-    if (outcome != Hip_Pcps_Acquisition_Core::ACQ_ERROR && d_gnss_synchro != nullptr) d_core.update_synchro(result, d_gnss_synchro);
-    if (outcome != Hip_Pcps_Acquisition_Core::ACQ_ERROR && result.search_complete && d_dump && d_channel == d_dump_channel && d_gnss_synchro != nullptr)
-        dump_results(result);  // acq.cc:719-723
-    switch (outcome)
-        {
-        case Hip_Pcps_Acquisition_Core::ACQ_POSITIVE:
-            d_state = 0;
-            d_active = false;
-            if (auto fsm = d_channel_fsm.lock())
-                {
-                    fsm->Event_valid_acquisition();
-                }
-            else
-                {
-                    this->message_port_pub(pmt::mp("events"), pmt::from_long(1));
-                }
-            break;
-        case Hip_Pcps_Acquisition_Core::ACQ_CONTINUE:
-            d_buffer_count = 0U;
-            // step one crossed its threshold and armed the fine-Doppler step: the reference restarts from state 0 (acq.cc:607, 617-624);
-            // otherwise gather the next non-coherent dwell (acq.cc:694-698)
-            d_state = (!was_step_two && d_core.step_two()) ? 0 : 1;
-            break;
-        case Hip_Pcps_Acquisition_Core::ACQ_NEGATIVE:
-        case Hip_Pcps_Acquisition_Core::ACQ_ERROR:  // a GPU failure must look like "not found", never throw here
-        default:
-            d_state = 0;
-            d_active = false;
-            this->message_port_pub(pmt::mp("events"), pmt::from_long(2));
-            break;
-        }
+    // What the search decided is filed under the lock; the channel is TOLD with the lock released.  The reference calls ChannelFsm::Event_valid_acquisition with d_setlock
+    // held (acquisition_core locks it for the whole dwell, acq.cc:650, 318-326) while ChannelFsm::Event_start_acquisition, holding the FSM's mutex, calls
+    // acq_->reset() -> set_active(), which takes d_setlock (channel_fsm.cc:81-93, 178-182): two locks taken in both orders.  The FSM's states keep the reference out of
+    // that corner most of the time; here the corner does not exist.
+    std::shared_ptr<ChannelFsm> fsm_to_tell;
+    long event = 0;
+    {
+        gr::thread::scoped_lock lock(d_setlock);
+        if (outcome != Hip_Pcps_Acquisition_Core::ACQ_ERROR && d_gnss_synchro != nullptr) d_core.update_synchro(result, d_gnss_synchro);
+        if (outcome != Hip_Pcps_Acquisition_Core::ACQ_ERROR && result.search_complete && d_dump && d_channel == d_dump_channel && d_gnss_synchro != nullptr)
+            dump_results(result);  // acq.cc:719-723
+        switch (outcome)
+            {
+            case Hip_Pcps_Acquisition_Core::ACQ_POSITIVE:
+                d_state = 0;
+                d_active = false;
+                fsm_to_tell = d_channel_fsm.lock();
+                if (!fsm_to_tell) event = 1;
+                break;
+            case Hip_Pcps_Acquisition_Core::ACQ_CONTINUE:
+                d_buffer_count = 0U;
+                // step one crossed its threshold and armed the fine-Doppler step: the reference restarts from state 0 (acq.cc:607, 617-624);
+                // otherwise gather the next non-coherent dwell (acq.cc:694-698)
+                d_state = (!was_step_two && d_core.step_two()) ? 0 : 1;
+                break;
+            case Hip_Pcps_Acquisition_Core::ACQ_NEGATIVE:
+            case Hip_Pcps_Acquisition_Core::ACQ_ERROR:  // a GPU failure must look like "not found", never throw here
+            default:
+                d_state = 0;
+                d_active = false;
+                event = 2;
+                break;
+            }
+    }
+    if (fsm_to_tell)
+        fsm_to_tell->Event_valid_acquisition();  // acq.cc:322-326: the channel FSM is told directly, to keep the acquisition-to-tracking delay short
+    else if (event != 0)
+        this->message_port_pub(pmt::mp("events"), pmt::from_long(event));  // 1 = ACQ_SUCCESS, 2 = ACQ_FAIL (acq.cc:331, 350)
 }
 
 

@@ -15,7 +15,7 @@ Hip_Sample_Ring::Hip_Sample_Ring(int device, uint64_t capacity_samples, uint32_t
     d_devices.assign(1, device);
     if (gsh_stream_create(device, capacity_samples, max_window_samples, &d_handle) != GSH_OK)
         {
-            d_error = gsh_last_error();
+            set_error(gsh_last_error());
             d_handle = nullptr;
         }
 }
@@ -29,7 +29,7 @@ Hip_Sample_Ring::Hip_Sample_Ring(const std::vector<int>& devices, uint64_t capac
         {
             if (gsh_stream_create(d_device, capacity_samples, max_window_samples, &d_handle) != GSH_OK)
                 {
-                    d_error = gsh_last_error();
+                    set_error(gsh_last_error());
                     d_handle = nullptr;
                 }
             return;
@@ -39,7 +39,7 @@ Hip_Sample_Ring::Hip_Sample_Ring(const std::vector<int>& devices, uint64_t capac
     const int mode = (m != nullptr && std::string(m) == "broadcast") ? GSH_GROUP_BROADCAST : GSH_GROUP_SCATTER_ALLGATHER;
     if (gsh_stream_group_create(devices.data(), static_cast<int>(devices.size()), capacity_samples, max_window_samples, mode, &d_group) != GSH_OK)
         {
-            d_error = gsh_last_error();
+            set_error(gsh_last_error());
             d_group = nullptr;
             return;
         }
@@ -133,7 +133,7 @@ bool Hip_Sample_Ring::register_locked(uintptr_t a, uintptr_t b)
         {
             if (gsh_host_register(d_device, reinterpret_cast<void*>(m.first), static_cast<size_t>(m.second - m.first)) != GSH_OK)
                 {
-                    d_error = gsh_last_error();
+                    set_error(gsh_last_error());
                     return false;
                 }
             d_registered.push_back(reinterpret_cast<void*>(m.first));
@@ -165,7 +165,7 @@ uint64_t Hip_Sample_Ring::push_items(const void* items, uint64_t n, int item_typ
                                           : gsh_stream_group_push(d_group, items, n, item_type, inverted_spectrum ? 1 : 0, &first);
         if (rc != GSH_OK || (d_group != nullptr && gsh_stream_group_wait(d_group) != GSH_OK))  // (`items` is the caller's again on return)
             {
-                d_error = gsh_last_error();
+                set_error(gsh_last_error());
                 return UINT64_MAX;
             }
         d_next.store(first + n, std::memory_order_release);
@@ -202,11 +202,10 @@ bool Hip_Sample_Ring::push_from(uint64_t first_index, const std::complex<float>*
                         // an empty ring starts wherever its first user is; a ring nobody reads any more follows the caller
                         if (seek_locked(first_index) != GSH_OK)
                             {
-                                d_error = gsh_last_error();
+                                set_error(gsh_last_error());
                                 return false;
                             }
-                        d_next.store(first_index, std::memory_order_release);
-                        d_origin.store(first_index, std::memory_order_release);
+                        reposition_locked(first_index);
                         next = first_index;
                     }
                 else
@@ -216,8 +215,8 @@ bool Hip_Sample_Ring::push_from(uint64_t first_index, const std::complex<float>*
                         const bool closed = d_pushed.wait_for(lk, gap_timeout, [&] { return d_next.load(std::memory_order_acquire) >= first_index; });
                         if (!closed)
                             {
-                                d_error = "push_from: samples " + std::to_string(first_index) + ".. leave a gap after the ring's " + std::to_string(next) +
-                                          " that no other channel of the stream has closed";
+                                set_error("push_from: samples " + std::to_string(first_index) + ".. leave a gap after the ring's " + std::to_string(next) +
+                                          " that no other channel of the stream has closed");
                                 return false;
                             }
                         (void)gsh_stream_range(d_handle, &oldest, &next);
@@ -232,7 +231,7 @@ bool Hip_Sample_Ring::push_from(uint64_t first_index, const std::complex<float>*
                 from += count - d_capacity;
                 if (seek_locked(first_index + from) != GSH_OK)
                     {
-                        d_error = gsh_last_error();
+                        set_error(gsh_last_error());
                         return false;
                     }
                 d_origin.store(first_index + from, std::memory_order_release);
@@ -287,7 +286,7 @@ bool Hip_Sample_Ring::push_from(uint64_t first_index, const std::complex<float>*
         if (done_items > 0) d_next.store(first + done_items, std::memory_order_release);
         if (rc_push != GSH_OK)
             {
-                d_error = gsh_last_error();
+                set_error(gsh_last_error());
                 d_pushed.notify_all();
                 if (dma_queued) (void)gsh_stream_wait_copied(d_handle);
                 return false;
@@ -300,7 +299,7 @@ bool Hip_Sample_Ring::push_from(uint64_t first_index, const std::complex<float>*
     if (dma_queued && wait_copy && gsh_stream_wait_copied(d_handle) != GSH_OK)
         {
             std::lock_guard<std::mutex> lk(d_mutex);
-            d_error = gsh_last_error();
+            set_error(gsh_last_error());
             ok_wait = false;
         }
     if (append_ns != nullptr) *append_ns = static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_begin).count());
@@ -317,7 +316,7 @@ bool Hip_Sample_Ring::wait_copied_upto(uint64_t end)
     if (gsh_stream_wait_copied_upto(d_handle, end, &upto) != GSH_OK)
         {
             std::lock_guard<std::mutex> lk(d_mutex);
-            d_error = gsh_last_error();
+            set_error(gsh_last_error());
             return false;
         }
     upto = std::max(upto, end);
@@ -341,17 +340,26 @@ int Hip_Sample_Ring::seek_locked(uint64_t next_index)
 }
 
 
+// after a successful seek (gsh_stream_seek has synchronised the ring's stream: nothing is in flight): what "has left the callers' buffers" means starts afresh at the
+// new position -- a high-water mark kept from before a BACKWARD seek would let give_back() hand memory back while a DMA out of it is still queued
+void Hip_Sample_Ring::reposition_locked(uint64_t next_index)
+{
+    d_next.store(next_index, std::memory_order_release);
+    d_origin.store(next_index, std::memory_order_release);
+    d_copied_upto.store(next_index, std::memory_order_release);
+}
+
+
 bool Hip_Sample_Ring::seek(uint64_t next_index)
 {
     if (d_handle == nullptr) return false;
     std::lock_guard<std::mutex> lk(d_mutex);
     if (seek_locked(next_index) != GSH_OK)
         {
-            d_error = gsh_last_error();
+            set_error(gsh_last_error());
             return false;
         }
-    d_next.store(next_index, std::memory_order_release);
-    d_origin.store(next_index, std::memory_order_release);
+    reposition_locked(next_index);
     return true;
 }
 

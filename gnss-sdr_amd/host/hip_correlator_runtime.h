@@ -51,7 +51,12 @@ public:
     Hip_Sample_Ring& operator=(const Hip_Sample_Ring&) = delete;
 
     bool ok() const { return d_handle != nullptr; }
-    const std::string& last_error() const { return d_error; }
+    /*! (a copy, taken under the error text's own lock: block threads read it while another thread's failing push writes it) */
+    std::string last_error() const
+    {
+        std::lock_guard<std::mutex> lk(d_error_mutex);
+        return d_error;
+    }
     /*! append samples; returns the absolute index of the first one (UINT64_MAX on failure).  One producer thread. */
     uint64_t push(const std::complex<float>* samples, uint64_t n, bool inverted_spectrum = false);
     uint64_t push_ishort(const int16_t* iq, uint64_t n, bool inverted_spectrum = false);  //!< item_type ishort / cshort
@@ -120,6 +125,13 @@ private:
     uint64_t d_capacity{0};
     uint32_t d_max_window{0};
     std::string d_error;
+    mutable std::mutex d_error_mutex;  // d_error only (innermost: taken with or without d_mutex held, never the other way round)
+    void set_error(const std::string& e)
+    {
+        std::lock_guard<std::mutex> lk(d_error_mutex);
+        d_error = e;
+    }
+    void reposition_locked(uint64_t next_index);
     mutable std::mutex d_mutex;  // serialises pushes against job translation (the C handle is not thread-safe)
     mutable std::condition_variable d_pushed;
     std::atomic<uint64_t> d_next{0};  // read without the lock on the fast path of wait_for (32 channel threads ask at the same instant)

@@ -111,6 +111,7 @@ int Hip_Tracking_Runtime::attach(const gsh_trk_conf& conf, int max_code_length)
     }
     Slot& S = *d_slots[s];
     S.tracking = false;
+    S.device_active = false;
     S.live_tracking.store(false, std::memory_order_release);
     S.live_next_window.store(0, std::memory_order_release);
     S.generation++;
@@ -163,14 +164,18 @@ bool Hip_Tracking_Runtime::start(int slot, const float* code, const float* data_
     if (gsh_trk_pull_in(&g->conf, nitems_read, acq_delay_samples, acq_samplestamp_samples, acq_doppler_hz, &offset, &first_len, &acc0) != GSH_OK)
         err = std::string("gsh_trk_pull_in: ") + gsh_last_error();
     const uint64_t start_sample = nitems_read + static_cast<uint64_t>(std::max(offset, 0));
-    if (err.empty() && gsh_trk_start_ex(g->trk, channel, code, data_code, code_length, start_sample, acq_samplestamp_samples, acq_doppler_hz, acc0) != GSH_OK)
-        err = std::string("gsh_trk_start_ex: ") + gsh_last_error();
+    // (the reference's pull-in latch is looked at in this very call, with the read pointer as it is now: behind the acquisition's stamp, the transitory is over at once)
+    const uint32_t flags = gsh_trk_pull_in_over(&g->conf, nitems_read, acq_samplestamp_samples) ? GSH_TRK_START_PULL_IN_OVER : 0U;
+    if (err.empty() && gsh_trk_start_flags(g->trk, channel, code, data_code, code_length, start_sample, acq_samplestamp_samples, acq_doppler_hz, acc0, flags) != GSH_OK)
+        err = std::string("gsh_trk_start_flags: ") + gsh_last_error();
     std::lock_guard<std::mutex> lk(d_mutex);
     Slot& S = *d_slots[slot];
     S.generation++;
     S.queue.clear();
     S.error = err;
     S.tracking = err.empty();
+    S.device_active = err.empty();
+    S.starved_since_ns = 0;
     if (err.empty()) S.next_window = start_sample;
     S.live_next_window.store(start_sample, std::memory_order_release);
     S.live_tracking.store(err.empty(), std::memory_order_release);
@@ -190,7 +195,7 @@ void Hip_Tracking_Runtime::stop(int slot)
         std::lock_guard<std::mutex> lk(d_mutex);
         if (slot < 0 || slot >= static_cast<int>(d_slots.size()) || !d_slots[slot]->used) return;
         Slot& S = *d_slots[slot];
-        if (!S.tracking)  // the device has stopped the channel itself (loss of lock) or it never ran: only the queue is left to drop
+        if (!S.tracking && !S.device_active)  // the device has stopped the channel itself (loss of lock) or it never ran: only the queue is left to drop
             {
                 S.generation++;
                 S.queue.clear();
@@ -208,6 +213,7 @@ void Hip_Tracking_Runtime::stop(int slot)
     std::lock_guard<std::mutex> lk(d_mutex);
     Slot& S = *d_slots[slot];
     S.tracking = false;
+    S.device_active = false;
     S.live_tracking.store(false, std::memory_order_release);
     S.generation++;
     S.queue.clear();
@@ -477,6 +483,7 @@ int Hip_Tracking_Runtime::take_live(Slot& S, uint64_t limit_end, int max_records
                 }
             if (n > 0)
                 {
+                    S.starved_since_ns = 0;
                     S.live_next_window.store(nw, std::memory_order_release);
                     d_live_records.fetch_add(static_cast<uint64_t>(n), std::memory_order_relaxed);
                     if (t_wait != 0)
@@ -488,6 +495,7 @@ int Hip_Tracking_Runtime::take_live(Slot& S, uint64_t limit_end, int max_records
                         {
                             std::lock_guard<std::mutex> lk(d_mutex);
                             S.tracking = false;
+                            S.device_active = false;
                             S.live_tracking.store(false, std::memory_order_release);
                         }
                     return n;
@@ -496,11 +504,17 @@ int Hip_Tracking_Runtime::take_live(Slot& S, uint64_t limit_end, int max_records
                 std::lock_guard<std::mutex> lk(d_mutex);  // (rare path from here on: an error filed by ensure_live, or nothing to hand out)
                 if (!S.error.empty()) return -1;
             }
-            if (pending > 0) return 0;  // finished periods wait in the ring of records, but the block has not been offered their samples itself yet
-            if (!active)                // the device no longer advances the channel and there is no record left to say why: nothing will come
-                return 0;
+            if (pending > 0 || !active)  // finished periods wait in the ring of records, but the block has not been offered their samples itself yet; or the device no
+                {                        // longer advances the channel and there is no record left to say why: nothing will come
+                    S.starved_since_ns = 0;
+                    return 0;
+                }
             const uint64_t ring_next = d_ring->next_index();
-            if (nw + vlen > ring_next || nw + vlen > limit_end) return 0;  // the next window is not resident yet (or not the block's to consume)
+            if (nw + vlen > ring_next || nw + vlen > limit_end)  // the next window is not resident yet (or not the block's to consume)
+                {
+                    S.starved_since_ns = 0;
+                    return 0;
+                }
             if (nw < d_ring->oldest_index())
                 {
                     std::lock_guard<std::mutex> lk(d_mutex);
@@ -513,6 +527,20 @@ int Hip_Tracking_Runtime::take_live(Slot& S, uint64_t limit_end, int max_records
             // The window is resident and its record is not there: a residency is working on it, or none is in flight.  Make sure of the latter now and then,
             // and look again: the device needs ~10 us per period.
             const int64_t now = now_ns();
+            if (S.starved_since_ns == 0)
+                S.starved_since_ns = now;
+            else if (now - S.starved_since_ns > d_record_timeout_ns.load(std::memory_order_relaxed))
+                {
+                    // the window has been resident for a long time and the device has not delivered: a residency that never reports (a hung kernel, a lost device).  The
+                    // block must not go on asking for ever -- the channel is given up the reference's way (the block publishes "events" 3, the FSM re-acquires)
+                    std::lock_guard<std::mutex> lk(d_mutex);
+                    S.error = "no record for the resident window [" + std::to_string(nw) + ", +" + std::to_string(vlen) + ") after " +
+                              std::to_string((now - S.starved_since_ns) / 1000000) + " ms (" + (resident ? "a residency is running" : "no residency took it up") + ")";
+                    S.tracking = false;
+                    S.live_tracking.store(false, std::memory_order_release);
+                    S.starved_since_ns = 0;
+                    return -1;
+                }
             if (t_wait == 0)
                 {
                     t_wait = now;
@@ -545,7 +573,13 @@ int Hip_Tracking_Runtime::take_live(Slot& S, uint64_t limit_end, int max_records
                     return 0;  // the scheduler calls again
                 }
             if (now - t_wait > static_cast<int64_t>(d_spin_us) * 1000)
-                std::this_thread::sleep_for(std::chrono::microseconds(20));
+                {
+                    // (start / stop of this channel wait for the slot's lock with the group's handle held, and while they wait no sibling can make sure of a residency:
+                    // the lock is not kept across the sleep.  Whatever changed meanwhile is looked at again at the top of the loop.)
+                    tl.unlock();
+                    std::this_thread::sleep_for(std::chrono::microseconds(20));
+                    tl.lock();
+                }
             else
                 for (int k = 0; k < 64; k++) __builtin_ia32_pause();
         }
@@ -640,6 +674,7 @@ uint32_t Hip_Tracking_Runtime::end_and_file(Group* g, uint64_t* most_resident)
                     if (r.flags & 2)
                         {
                             O.tracking = false;  // loss of lock: the device has stopped the channel (trk.cc:2009-2014)
+                            O.device_active = false;
                             break;
                         }
                     O.next_window = r.sample_counter + static_cast<uint64_t>(std::max(r.prn_length_samples, 0));

@@ -75,6 +75,10 @@ public:
         channels_per_group: slots of one gsh_trk handle (a further group is opened when they are used up). */
     Hip_Tracking_Runtime(int device, std::shared_ptr<Hip_Sample_Ring> ring, int periods_per_launch = 16, int channels_per_group = 64, bool live = true);
     bool live() const { return d_live; }
+    /*! live mode watchdog: a channel whose next window has been resident for this long without the device delivering its record is given up with an error (the block
+        then publishes "events" 3 and the channel goes back to acquisition) -- a residency that never reports must not leave a block calling take() for ever.
+        Default 1000 ms (the device needs ~10 us per period); <role>.hip_record_timeout_ms. */
+    void set_record_timeout_ms(int ms) { d_record_timeout_ns.store(static_cast<int64_t>(std::max(ms, 1)) * 1000000); }
     ~Hip_Tracking_Runtime();
     Hip_Tracking_Runtime(const Hip_Tracking_Runtime&) = delete;
     Hip_Tracking_Runtime& operator=(const Hip_Tracking_Runtime&) = delete;
@@ -144,6 +148,8 @@ private:
         int channel{-1};
         bool used{false};
         bool tracking{false};
+        bool device_active{false};   // the device may still be advancing the channel (started, and neither stopped by the host nor by a loss-of-lock record): what stop()
+                                     // has to undo even when `tracking` is already false -- a take that failed, a channel given up by the watchdog
         uint64_t generation{0};      // bumped by start / stop: records of a launch begun before are not filed
         uint64_t next_window{0};
         std::deque<gsh_trk_epoch> queue;
@@ -153,6 +159,7 @@ private:
         std::mutex take_mutex;
         std::atomic<bool> live_tracking{false};
         std::atomic<uint64_t> live_next_window{0};
+        int64_t starved_since_ns{0};  // (take_mutex) since when the channel's next window has been resident without a record; 0: not waiting
     };
     Group* group_for(const gsh_trk_conf& conf, int max_code_length, int* channel);
     // the two halves of a launch; both with the group's handle_mutex held and d_mutex NOT held
@@ -174,6 +181,7 @@ private:
     bool d_push_spare_slowest{true};
     int d_push_batch{2};                    // live mode: appends smaller than this many code periods wait for more (while the device has work in hand)
     int d_spin_us{40};                 // how long a block polls for a record before it starts sleeping between looks
+    std::atomic<int64_t> d_record_timeout_ns{1000000000};
     std::atomic<uint64_t> d_min_vlen{0};  // shortest code period (samples) among the loop configurations attached so far
     std::atomic<size_t> d_n_slots{0};  // slots ever created (d_slots never shrinks and is reserved up front: readers without the lock index below this)
     std::atomic<uint64_t> d_live_records{0}, d_live_residencies{0}, d_record_wait_ns{0}, d_record_waits{0};

@@ -78,14 +78,15 @@ class TrackingLoop:
         check(self._lib.gsh_trk_set_stream_ring(self._h, ring._h if ring is not None else None))
 
     def start(self, channel: int, code: np.ndarray, start_sample: int, acq_sample_stamp: int, acq_carrier_doppler_hz: float,
-              data_code: np.ndarray | None = None) -> None:
+              data_code: np.ndarray | None = None, pull_in_over: bool = False) -> None:
+        """pull_in_over: the pull-in transitory was over at the hand-over call already (GSH_TRK_START_PULL_IN_OVER, see gsh_trk_pull_in_over)."""
         code = np.ascontiguousarray(code, np.float32)
         dc = None
         if data_code is not None:
             data_code = np.ascontiguousarray(data_code, np.float32)
             dc = fptr(data_code)
-        check(self._lib.gsh_trk_start(self._h, channel, fptr(code), dc, len(code), int(start_sample), int(acq_sample_stamp),
-                                      float(acq_carrier_doppler_hz)))
+        check(self._lib.gsh_trk_start_flags(self._h, channel, fptr(code), dc, len(code), int(start_sample), int(acq_sample_stamp),
+                                            float(acq_carrier_doppler_hz), 0.0, 1 if pull_in_over else 0))
 
     def run(self, n_epochs: int, want_records: bool = True):
         """-> (records[channel][epoch] as lists of TrkEpoch, epochs_done per channel)"""

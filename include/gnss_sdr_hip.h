@@ -411,6 +411,17 @@ extern "C"
      * start_sample for gsh_trk_start_ex is nitems_read + samples_offset. */
     int gsh_trk_pull_in(const gsh_trk_conf* conf, uint64_t nitems_read, double acq_delay_samples, uint64_t acq_sample_stamp, double acq_carrier_doppler_hz,
         int32_t* samples_offset, int32_t* first_prn_length_samples, double* acc_carrier_phase_rad);
+    /* The pull-in transitory (d_pull_in_transitory, trk.cc:1073, 1910-1917) is a latch that EVERY general_work call looks at -- the pull-in call (state 1) included:
+     *   pull_in_time_s < (nitems_read(0) - d_acq_sample_stamp) / (int)fs_in        in unsigned 64-bit arithmetic.
+     * A tracking block whose read pointer is still BEHIND the acquisition's sample stamp at that call (it runs only when two code periods of input are there, the
+     * acquisition block consumes whatever it is offered: tracking behind acquisition is the normal order of things in a flowgraph) wraps that difference round to
+     * ~2^64 and the transitory is over before the first period: bit synchronisation starts at once and the lock detectors count from the first test.  Returns 1 when
+     * that is the case for the pull-in call at read pointer nitems_read (host only) -> GSH_TRK_START_PULL_IN_OVER for gsh_trk_start_flags. */
+    int gsh_trk_pull_in_over(const gsh_trk_conf* conf, uint64_t nitems_read, uint64_t acq_sample_stamp);
+#define GSH_TRK_START_PULL_IN_OVER 1u
+    /* gsh_trk_start_ex + flags (GSH_TRK_START_PULL_IN_OVER: the channel starts with the pull-in transitory already over, see above) */
+    int gsh_trk_start_flags(gsh_trk_t* t, int channel, const float* code, const float* data_code, int code_length, uint64_t start_sample,
+        uint64_t acq_sample_stamp, double acq_carrier_doppler_hz, double initial_acc_carrier_phase_rad, uint32_t flags);
     /* stop_tracking / clear_tracking_vars for one channel: the loop no longer advances it (its state stays readable) */
     int gsh_trk_stop(gsh_trk_t* t, int channel);
     /* n_epochs code periods of every started channel in ONE launch; the loop state stays on the device, so a later

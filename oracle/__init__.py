@@ -118,6 +118,11 @@ def lib():
         L.oracle_trk_run.argtypes = [C.POINTER(TrkConf), _f32p, C.c_void_p, C.c_int, _f32p, C.c_uint64, C.c_uint64, C.c_uint64,
                                      C.c_double, C.c_int, C.POINTER(TrkEpoch)]
         L.oracle_trk_run.restype = C.c_int
+        L.oracle_trk_run_flags.argtypes = [C.POINTER(TrkConf), _f32p, C.c_void_p, C.c_int, _f32p, C.c_uint64, C.c_uint64, C.c_uint64,
+                                           C.c_double, C.c_int, C.POINTER(TrkEpoch), C.c_uint]
+        L.oracle_trk_run_flags.restype = C.c_int
+        L.oracle_pull_in_over.argtypes = [C.POINTER(TrkConf), C.c_uint64, C.c_uint64]
+        L.oracle_pull_in_over.restype = C.c_int
         L.oracle_cn0_m2m4_estimator.argtypes = [_f32p, C.c_int, C.c_float]
         L.oracle_cn0_m2m4_estimator.restype = C.c_float
         L.oracle_carrier_lock_detector.argtypes = [_f32p, C.c_int]
@@ -386,16 +391,17 @@ def trk_conf(**kw) -> TrkConf:
     return c
 
 
-def trk_run(conf: TrkConf, code, x, start_sample, acq_sample_stamp, acq_doppler_hz, n_epochs, data_code=None):
-    """closed DLL/PLL loop of one channel on the CPU; returns the list of completed TrkEpoch records"""
+def trk_run(conf: TrkConf, code, x, start_sample, acq_sample_stamp, acq_doppler_hz, n_epochs, data_code=None, pull_in_over=False):
+    """closed DLL/PLL loop of one channel on the CPU; returns the list of completed TrkEpoch records.  pull_in_over: the pull-in transitory was over at the
+    pull-in call already (a read pointer behind the acquisition's stamp wraps trk.cc:1912's unsigned difference)"""
     code = np.ascontiguousarray(code, np.float32)
     rec = (TrkEpoch * n_epochs)()
     dc = None
     if data_code is not None:
         data_code = np.ascontiguousarray(data_code, np.float32)
         dc = data_code.ctypes.data_as(C.c_void_p)
-    n = lib().oracle_trk_run(C.byref(conf), code, dc, len(code), _iq(x), len(x), int(start_sample), int(acq_sample_stamp),
-                             float(acq_doppler_hz), n_epochs, rec)
+    n = lib().oracle_trk_run_flags(C.byref(conf), code, dc, len(code), _iq(x), len(x), int(start_sample), int(acq_sample_stamp),
+                                   float(acq_doppler_hz), n_epochs, rec, 1 if pull_in_over else 0)
     return list(rec)[:n]
 
 

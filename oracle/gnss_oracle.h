@@ -223,6 +223,13 @@ extern "C"
     int oracle_trk_run(const oracle_trk_conf* c, const float* code, const float* data_code, int code_len, const float* stream_iq,
         uint64_t n_stream, uint64_t start_sample, uint64_t acq_sample_stamp, double acq_carrier_doppler_hz, int n_epochs,
         oracle_trk_epoch* rec);
+    /* ... with flags; bit 0 = ORACLE_TRK_PULL_IN_OVER: the pull-in transitory was over at the pull-in call already (trk.cc:1910-1917 evaluated with the read pointer
+     * of THAT call: oracle_pull_in_over) */
+#define ORACLE_TRK_PULL_IN_OVER 1u
+    int oracle_pull_in_over(const oracle_trk_conf* c, uint64_t nitems_read, uint64_t acq_sample_stamp);
+    int oracle_trk_run_flags(const oracle_trk_conf* c, const float* code, const float* data_code, int code_len, const float* stream_iq,
+        uint64_t n_stream, uint64_t start_sample, uint64_t acq_sample_stamp, double acq_carrier_doppler_hz, int n_epochs,
+        oracle_trk_epoch* rec, unsigned flags);
 
 #ifdef __cplusplus
 }

@@ -564,6 +564,23 @@ int oracle_trk_run(const oracle_trk_conf* c, const float* code, const float* dat
     uint64_t n_stream, uint64_t start_sample, uint64_t acq_sample_stamp, double acq_carrier_doppler_hz, int n_epochs,
     oracle_trk_epoch* rec)
 {
+    return oracle_trk_run_flags(c, code, data_code, code_len, stream_iq, n_stream, start_sample, acq_sample_stamp, acq_carrier_doppler_hz, n_epochs, rec, 0U);
+}
+
+/* trk.cc:1910-1917: d_pull_in_transitory is looked at by EVERY general_work call, the pull-in call (state 1) included, with the block's read pointer as it is THEN:
+ *   pull_in_time_s < (nitems_read(0) - d_acq_sample_stamp) / (int)fs_in   (unsigned 64-bit)
+ * -- a read pointer still behind the acquisition's stamp wraps the difference and ends the transitory before the first period. */
+int oracle_pull_in_over(const oracle_trk_conf* c, uint64_t nitems_read, uint64_t acq_sample_stamp)
+{
+    if ((int)c->fs_in <= 0) return 0;
+    return (uint64_t)c->pull_in_time_s < (nitems_read - acq_sample_stamp) / (uint64_t)((int)c->fs_in) ? 1 : 0;
+}
+
+/* flags bit 0 (ORACLE_TRK_PULL_IN_OVER): the transitory was already over at the pull-in call (oracle_pull_in_over) */
+int oracle_trk_run_flags(const oracle_trk_conf* c, const float* code, const float* data_code, int code_len, const float* stream_iq,
+    uint64_t n_stream, uint64_t start_sample, uint64_t acq_sample_stamp, double acq_carrier_doppler_hz, int n_epochs,
+    oracle_trk_epoch* rec, unsigned flags)
+{
     const int n_taps = c->veml ? 5 : 3;
     const int prompt = c->veml ? 2 : 1;
     float shifts[5] = {0, 0, 0, 0, 0};
@@ -650,7 +667,7 @@ int oracle_trk_run(const oracle_trk_conf* c, const float* code, const float* dat
             oracle_trk_epoch* r = &rec[e];
             memset(r, 0, sizeof(*r));
             /* trk.cc:1912-1915: pull-in ends once more than pull_in_time_s whole seconds have passed since acquisition */
-            const int pull_in = !((uint64_t)c->pull_in_time_s < (pos - acq_sample_stamp) / (uint64_t)((int)c->fs_in));
+            const int pull_in = !(flags & 1U) && !((uint64_t)c->pull_in_time_s < (pos - acq_sample_stamp) / (uint64_t)((int)c->fs_in));
             float out[16];
             /* do_correlation_step, trk.cc:1232-1257 (rate terms are 0 outside high_dyn) */
             const float rem_code = (float)rem_code_phase_chips * spcf;

@@ -14,10 +14,14 @@
 #include "gnss_sdr_hip.h"
 #include <algorithm>
 #include <atomic>
+#include <cmath>
+#include <complex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <limits>
+#include <map>
 #include <mutex>
 #include <vector>
 
@@ -91,7 +95,183 @@ struct gsh_trk
     // live mode: a "residency" serves a bounded number of records and then ends by itself, so that the runtime's relaunch path is exercised
     std::atomic<bool> live_ready{false};
     std::atomic<int> live_left{0};  // records the residency in flight may still produce (0: none in flight)
+    std::atomic<bool> dead_residency{false};  // fault injection: the residency in flight never produces a record
 };
+
+typedef std::complex<double> cd;
+
+struct gsh_acq
+{
+    int device{0};
+    gsh_acq_conf conf{};
+    std::vector<std::vector<cd>> codes;    // conj(FFT(replica)) per slot
+    std::vector<std::vector<float>> grids;  // |.|^2, bins x effective_fft_size, per slot (or per position for dwell_slots)
+    std::atomic<int> inside{0};
+};
+
+namespace
+{
+// ---- fault injection (round 5: SURVEY section 5 "engine errors must surface as 'no detection' / loss of lock, never as an exception across the GNU Radio thread").
+// fake_gsh_inject_fault(kind, after, count, channel): the next `count` (< 0: all) calls of that kind are failed with GSH_ERR_HIP once `after` more calls of the kind
+// have passed; for the per-channel kinds (live take, start) only calls that name `channel` count (< 0: any channel).
+enum Fault_Kind
+{
+    FAULT_PUSH = 0,       // gsh_stream_push* / gsh_stream_group_push
+    FAULT_LIVE_TAKE = 1,  // gsh_trk_live_take
+    FAULT_RESIDENCY = 2,  // gsh_trk_live_begin succeeds but the residency never reports a record
+    FAULT_ACQ_DWELL = 3,  // gsh_acq_dwell*, gsh_acq_dwell_slots
+    FAULT_TRK_START = 4,  // gsh_trk_start_ex
+    FAULT_RUN = 5,        // gsh_trk_run_begin (launched mode)
+    FAULT_ACQ_CREATE = 6,
+    FAULT_KINDS = 7
+};
+struct Fault
+{
+    std::atomic<long> after{0}, count{0};
+    std::atomic<int> channel{-1};
+    std::atomic<long> hits{0};
+};
+Fault g_faults[FAULT_KINDS];
+
+bool fake_fault_hit(int kind, int channel = -1)
+{
+    Fault& f = g_faults[kind];
+    if (f.count.load() == 0) return false;
+    const int want = f.channel.load();
+    if (want >= 0 && channel != want) return false;
+    // (several block threads come through here at once: exactly `after` calls pass, exactly `count` fail)
+    long a = f.after.load();
+    while (a > 0)
+        if (f.after.compare_exchange_weak(a, a - 1)) return false;
+    long c = f.count.load();
+    for (;;)
+        {
+            if (c == 0) return false;
+            if (c < 0) break;  // every call from now on
+            if (f.count.compare_exchange_weak(c, c - 1)) break;
+        }
+    f.hits.fetch_add(1);
+    return true;
+}
+
+// unnormalised DFT (forward: exp(-j...), inverse: exp(+j...)), decimation in time over the prime factors of the length
+void fake_fft_rec(const cd* in, size_t stride, size_t n, cd* out, const std::vector<cd>& w, size_t wstep, bool inverse)
+{
+    if (n == 1)
+        {
+            out[0] = in[0];
+            return;
+        }
+    size_t p = 2;
+    while (n % p != 0) p++;
+    const size_t m = n / p;
+    std::vector<cd> sub(n);
+    for (size_t r = 0; r < p; r++) fake_fft_rec(in + r * stride, stride * p, m, sub.data() + r * m, w, wstep * p, inverse);
+    const size_t N = w.size();
+    for (size_t k = 0; k < n; k++)
+        {
+            cd acc(0.0, 0.0);
+            for (size_t r = 0; r < p; r++)
+                {
+                    const size_t idx = (r * k * wstep) % N;
+                    const cd tw = inverse ? std::conj(w[idx]) : w[idx];
+                    acc += sub[r * m + (k % m)] * tw;
+                }
+            out[k] = acc;
+        }
+}
+void fake_fft(std::vector<cd>& x, bool inverse)
+{
+    static std::mutex mu;
+    static std::map<size_t, std::vector<cd>> tables;
+    const size_t n = x.size();
+    const std::vector<cd>* w;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        auto& t = tables[n];
+        if (t.empty())
+            {
+                t.resize(n);
+                for (size_t k = 0; k < n; k++) t[k] = std::polar(1.0, -2.0 * M_PI * static_cast<double>(k) / static_cast<double>(n));
+            }
+        w = &t;
+    }
+    std::vector<cd> y(n);
+    fake_fft_rec(x.data(), 1, n, y.data(), *w, 1, inverse);
+    x.swap(y);
+}
+
+// one search of gsh_acq_dwell / _dwell_slots / _dwell_step2 (step_center != nullptr)
+int fake_acq_search(gsh_acq* a, const float* in_iq, const std::vector<uint32_t>& slots, const float* step_center, const float* power_step_one, int accumulate,
+    uint32_t dwell_count, gsh_acq_result* results, bool grid_by_position)
+{
+    const gsh_acq_conf& c = a->conf;
+    const uint32_t N = c.fft_size, E = c.effective_fft_size;
+    const double fs = static_cast<double>(c.fs_in);
+    for (size_t i = 0; i < slots.size(); i++)
+        {
+            if (slots[i] >= a->codes.size() || a->codes[slots[i]].size() != N) return gsh::set_error(GSH_ERR_STATE, "fake: no local code in slot %u", slots[i]);
+            const bool step2 = step_center != nullptr;
+            const uint32_t bins = step2 ? c.num_doppler_bins_step2 : c.num_doppler_bins;
+            std::vector<float>& grid = a->grids[grid_by_position ? i : slots[i]];
+            if (!accumulate || grid.size() != static_cast<size_t>(bins) * E) grid.assign(static_cast<size_t>(bins) * E, 0.0F);
+            float best = 0.0F;
+            uint32_t best_bin = 0, best_t = 0;
+            for (uint32_t d = 0; d < bins; d++)
+                {
+                    // acq.cc:284-301: the bin's frequency; the wipe-off phase step is formed in float there, which moves nothing a peak index could see
+                    const double f = step2 ? static_cast<double>(step_center[i] + (static_cast<float>(d) - static_cast<float>(std::floor(c.num_doppler_bins_step2 / 2.0))) * c.doppler_step2)
+                                           : static_cast<double>(c.doppler_bias + (-c.doppler_max + c.doppler_center + c.doppler_step * static_cast<int32_t>(d)));
+                    std::vector<cd> x(N, cd(0.0, 0.0));
+                    for (uint32_t k = 0; k < N && k < c.consumed_samples; k++)
+                        x[k] = cd(in_iq[2 * k], in_iq[2 * k + 1]) * std::polar(1.0, -2.0 * M_PI * std::fmod(f * static_cast<double>(k) / fs, 1.0));
+                    fake_fft(x, false);
+                    for (uint32_t k = 0; k < N; k++) x[k] *= a->codes[slots[i]][k];
+                    fake_fft(x, true);
+                    float* row = grid.data() + static_cast<size_t>(d) * E;
+                    float row_max = -1.0F;
+                    uint32_t row_t = 0;
+                    for (uint32_t k = 0; k < E; k++)
+                        {
+                            const float m = static_cast<float>(std::norm(x[k]));
+                            row[k] = accumulate ? row[k] + m : m;
+                            if (row[k] > row_max)
+                                {
+                                    row_max = row[k];
+                                    row_t = k;
+                                }
+                        }
+                    if (row_max > best)  // strict: the first bin wins ties (acq.cc:420)
+                        {
+                            best = row_max;
+                            best_bin = d;
+                            best_t = row_t;
+                        }
+                }
+            gsh_acq_result& r = results[i];
+            r = gsh_acq_result{};
+            r.index_time = best_t;
+            r.index_doppler = best_bin;
+            r.peak = best;
+            if (!step2)
+                {
+                    const uint32_t opp = (best_bin + bins / 2) % bins;  // acq.cc:428-431
+                    float sum = 0.0F;
+                    for (uint32_t k = 0; k < E; k++) sum += grid[static_cast<size_t>(opp) * E + k];
+                    r.input_power = sum / static_cast<float>(E) / 2.0F / static_cast<float>(std::max<uint32_t>(dwell_count, 1));
+                    r.doppler_hz = -c.doppler_max + c.doppler_center + c.doppler_step * static_cast<int32_t>(best_bin);
+                }
+            else
+                {
+                    r.input_power = power_step_one != nullptr ? power_step_one[i] : 0.0F;
+                    r.doppler_hz = static_cast<int32_t>(step_center[i] + (static_cast<float>(best_bin) - static_cast<float>(std::floor(c.num_doppler_bins_step2 / 2.0))) * c.doppler_step2);
+                }
+            r.test_statistics = r.input_power < std::numeric_limits<float>::epsilon() ? 0.0F : best / r.input_power;
+            r.acq_delay_samples = std::fmod(static_cast<float>(best_t), c.samples_per_code);
+        }
+    return GSH_OK;
+}
+}  // namespace
 
 namespace
 {
@@ -121,6 +301,7 @@ int push_common(gsh_stream* s, const void* items, uint64_t n, int item_type, uin
     if (s == nullptr || (n != 0 && items == nullptr)) return gsh::set_error(GSH_ERR_INVALID, "fake: null argument");
     if (item_type != GSH_ITEM_GR_COMPLEX) return gsh::set_error(GSH_ERR_UNSUPPORTED, "fake: complex64 items only");
     if (n > s->capacity) return gsh::set_error(GSH_ERR_INVALID, "a push of %llu samples exceeds the ring capacity %llu", (unsigned long long)n, (unsigned long long)s->capacity);
+    if (n != 0 && fake_fault_hit(FAULT_PUSH)) return gsh::set_error(GSH_ERR_HIP, "fake engine: injected failure of a push (hipMemcpyAsync: an illegal memory access was encountered)");
     Guard g(s->inside);
     const uint64_t at = s->next.load();
     if (first_index) *first_index = at;
@@ -150,6 +331,24 @@ extern "C"
         g_ref_n = n;
     }
     uint64_t fake_gsh_push_mismatches(void) { return g_mismatch.load(); }
+    void fake_gsh_inject_fault(int kind, long after, long count, int channel)
+    {
+        if (kind < 0 || kind >= FAULT_KINDS) return;
+        g_faults[kind].after.store(after);
+        g_faults[kind].channel.store(channel);
+        g_faults[kind].count.store(count);
+    }
+    long fake_gsh_fault_hits(int kind) { return (kind >= 0 && kind < FAULT_KINDS) ? g_faults[kind].hits.load() : 0; }
+    void fake_gsh_clear_faults(void)
+    {
+        for (auto& f : g_faults)
+            {
+                f.count.store(0);
+                f.after.store(0);
+                f.channel.store(-1);
+                f.hits.store(0);
+            }
+    }
     int fake_gsh_concurrent_handle_entries(void) { return g_busy_handles.load(); }
 
     // FAKE_GSH_DEVICES=N in the environment: the stand-in pretends to N devices (the multi-GPU layout of the adapters, exercised on the CPU)
@@ -283,7 +482,13 @@ extern "C"
     int gsh_trk_start_ex(gsh_trk_t* t, int channel, const float* code, const float* data_code, int code_length, uint64_t start_sample, uint64_t acq_sample_stamp,
         double acq_carrier_doppler_hz, double initial_acc_carrier_phase_rad)
     {
+        return gsh_trk_start_flags(t, channel, code, data_code, code_length, start_sample, acq_sample_stamp, acq_carrier_doppler_hz, initial_acc_carrier_phase_rad, 0U);
+    }
+    int gsh_trk_start_flags(gsh_trk_t* t, int channel, const float* code, const float* data_code, int code_length, uint64_t start_sample, uint64_t acq_sample_stamp,
+        double acq_carrier_doppler_hz, double initial_acc_carrier_phase_rad, uint32_t flags)
+    {
         if (t == nullptr || code == nullptr || channel < 0 || channel >= t->n_channels) return gsh::set_error(GSH_ERR_INVALID, "fake: bad start arguments");
+        if (fake_fault_hit(FAULT_TRK_START, channel)) return gsh::set_error(GSH_ERR_HIP, "fake engine: injected failure of gsh_trk_start");
         Guard g(t->inside);
         if (t->live_left.load() > 0) return gsh::set_error(GSH_ERR_STATE, "gsh_trk_start: a live residency is in flight (gsh_trk_live_quiesce first)");
         Guard gc(t->ch[static_cast<size_t>(channel)].inside);  // (a take of this channel at the same time is the caller's bug)
@@ -304,8 +509,9 @@ extern "C"
         c.all.resize(static_cast<size_t>(most));
         int got = 0;
         if (most > 0)
-            got = oracle_trk_run(reinterpret_cast<const oracle_trk_conf*>(&t->conf), code, t->conf.track_pilot ? data_code : nullptr, code_length, ref, n_ref, start_sample,
-                acq_sample_stamp, acq_carrier_doppler_hz, static_cast<int>(most), reinterpret_cast<oracle_trk_epoch*>(c.all.data()));
+            got = oracle_trk_run_flags(reinterpret_cast<const oracle_trk_conf*>(&t->conf), code, t->conf.track_pilot ? data_code : nullptr, code_length, ref, n_ref, start_sample,
+                acq_sample_stamp, acq_carrier_doppler_hz, static_cast<int>(most), reinterpret_cast<oracle_trk_epoch*>(c.all.data()),
+                (flags & GSH_TRK_START_PULL_IN_OVER) ? ORACLE_TRK_PULL_IN_OVER : 0U);
         c.all.resize(static_cast<size_t>(std::max(got, 0)));
         // the oracle starts d_acc_carrier_phase_rad at 0; the pull-in alignment's contribution (trk.cc:1966) rides on it until the first narrow-tracking
         // period re-initialises the accumulator (check_carrier_phase_coherent_initialization, trk.cc:1350-1357)
@@ -338,6 +544,7 @@ extern "C"
         if (t == nullptr || n_epochs < 0) return gsh::set_error(GSH_ERR_INVALID, "fake: bad run arguments");
         if (t->ring == nullptr) return gsh::set_error(GSH_ERR_STATE, "no IF stream attached (gsh_trk_set_stream_*)");
         if (t->pending_epochs >= 0) return gsh::set_error(GSH_ERR_STATE, "gsh_trk_run_begin: the previous run has not been ended");
+        if (fake_fault_hit(FAULT_RUN)) return gsh::set_error(GSH_ERR_HIP, "fake engine: injected failure of a launch");
         Guard g(t->inside);
         if (t->ring->inside.load() != 0)
             {
@@ -403,6 +610,7 @@ extern "C"
                 std::fprintf(stderr, "FAKE ENGINE: a residency was queued while a push was inside the ring (the ring's lock was not held)\n");
             }
         t->live_ready.store(true);
+        if (fake_fault_hit(FAULT_RESIDENCY)) t->dead_residency.store(true);  // the kernel is "in flight" and never writes a record (a hung device)
         if (t->live_left.load() <= 0) t->live_left.store(37 * std::max(1, t->n_channels / 8));
         return GSH_OK;
     }
@@ -418,6 +626,7 @@ extern "C"
         if (t == nullptr) return gsh::set_error(GSH_ERR_INVALID, "null handle");
         Guard g(t->inside);
         t->live_left.store(0);
+        t->dead_residency.store(false);
         return GSH_OK;
     }
     int gsh_trk_live_take(gsh_trk_t* t, int channel, uint64_t limit_end, int max_records, gsh_trk_epoch* out, int32_t* n_out, int32_t* pending, uint64_t* next_window,
@@ -426,6 +635,7 @@ extern "C"
         if (resident) *resident = (t != nullptr && t->live_left.load() > 0) ? 1 : 0;
         if (t == nullptr || n_out == nullptr || channel < 0 || channel >= t->n_channels) return gsh::set_error(GSH_ERR_INVALID, "fake: bad take arguments");
         *n_out = 0;
+        if (fake_fault_hit(FAULT_LIVE_TAKE, channel)) return gsh::set_error(GSH_ERR_HIP, "fake engine: injected failure of gsh_trk_live_take (channel %d)", channel);
         FakeChannel& C = t->ch[static_cast<size_t>(channel)];
         if (!t->live_ready.load())
             {
@@ -436,7 +646,7 @@ extern "C"
             }
         Guard gc(C.inside);  // one thread per channel at a time; other channels' takes, pushes and residency management run beside it
         const uint64_t vlen = t->conf.vector_length;
-        while (C.active && C.released < C.all.size() && t->live_left.load() > 0)
+        while (C.active && C.released < C.all.size() && t->live_left.load() > 0 && !t->dead_residency.load())
             {
                 const gsh_trk_epoch& r = C.all[C.released];
                 if (r.sample_counter + vlen > t->ring->next.load() || r.sample_counter < oldest(t->ring)) break;
@@ -475,6 +685,97 @@ extern "C"
                 if (next_window) next_window[c] = t->ch[static_cast<size_t>(c)].pos;
                 if (active) active[c] = t->ch[static_cast<size_t>(c)].active ? 1 : 0;
             }
+        return GSH_OK;
+    }
+
+    // ---- acquisition (round 5: the whole Channel -- acquisition adapter, ChannelFsm, tracking adapter -- runs on the CPU under ThreadSanitizer).  The stand-in
+    // computes what include/gnss_sdr_hip.h documents for gsh_acq_*: replica placed per the padding rules, FFT, conjugate; per Doppler bin wipe-off, FFT, product,
+    // inverse FFT, |.|^2 (+= for non-coherent dwells); the max-to-input-power statistic.  Double-precision mixed-radix transforms: slow and exact enough that every
+    // peak index and Doppler bin equals the reference block's.  Plain and two-step CFAR searches of gr_complex / cshort items; nothing else (GSH_ERR_UNSUPPORTED).
+    int gsh_acq_create(int device, const gsh_acq_conf* conf, gsh_acq_t** out)
+    {
+        if (out == nullptr || conf == nullptr) return gsh::set_error(GSH_ERR_INVALID, "null argument");
+        *out = nullptr;
+        if (device < 0 || device >= gsh_device_count()) return gsh::set_error(GSH_ERR_NO_DEVICE, "device %d out of range (0..%d)", device, gsh_device_count() - 1);
+        if (conf->use_cfar == 0 || conf->bit_transition_flag != 0 || conf->fold > 1) return gsh::set_error(GSH_ERR_UNSUPPORTED, "fake engine: plain CFAR searches only");
+        if (fake_fault_hit(FAULT_ACQ_CREATE)) return gsh::set_error(GSH_ERR_HIP, "fake engine: injected failure of gsh_acq_create");
+        auto* a = new gsh_acq();
+        a->device = device;
+        a->conf = *conf;
+        if (a->conf.num_doppler_bins == 0)
+            a->conf.num_doppler_bins = static_cast<uint32_t>(std::ceil(2.0 * conf->doppler_max / static_cast<double>(conf->doppler_step)));
+        a->codes.assign(conf->max_prn, std::vector<cd>());
+        a->grids.assign(conf->max_prn, std::vector<float>());
+        *out = a;
+        return GSH_OK;
+    }
+    void gsh_acq_destroy(gsh_acq_t* a) { delete a; }
+    int gsh_acq_set_local_code(gsh_acq_t* a, uint32_t slot, const float* code_iq)
+    {
+        if (a == nullptr || code_iq == nullptr || slot >= a->conf.max_prn) return gsh::set_error(GSH_ERR_INVALID, "fake: bad set_local_code arguments");
+        Guard g(a->inside);
+        const uint32_t N = a->conf.fft_size, C = a->conf.consumed_samples;
+        std::vector<cd> x(N, cd(0.0, 0.0));
+        // acq.cc:236-247: the replica at the front, or -- when the block integrates more than one code period -- behind N - C zeros
+        const uint32_t off = (C < N) ? C : 0;
+        for (uint32_t i = 0; i < C && off + i < N; i++) x[off + i] = cd(code_iq[2 * i], code_iq[2 * i + 1]);
+        fake_fft(x, false);
+        for (auto& v : x) v = std::conj(v);
+        a->codes[slot] = std::move(x);
+        return GSH_OK;
+    }
+    int gsh_acq_set_doppler_center(gsh_acq_t* a, int32_t doppler_center)
+    {
+        if (a == nullptr) return gsh::set_error(GSH_ERR_INVALID, "null handle");
+        Guard g(a->inside);
+        a->conf.doppler_center = doppler_center;
+        return GSH_OK;
+    }
+    int gsh_acq_set_doppler_bias(gsh_acq_t* a, int32_t doppler_bias)
+    {
+        if (a == nullptr) return gsh::set_error(GSH_ERR_INVALID, "null handle");
+        Guard g(a->inside);
+        a->conf.doppler_bias = doppler_bias;
+        return GSH_OK;
+    }
+    int gsh_acq_dwell(gsh_acq_t* a, const float* in_iq, uint32_t n_prn, int accumulate, uint32_t dwell_count, gsh_acq_result* results)
+    {
+        if (a == nullptr || in_iq == nullptr || results == nullptr || n_prn > a->conf.max_prn) return gsh::set_error(GSH_ERR_INVALID, "fake: bad dwell arguments");
+        Guard g(a->inside);
+        if (fake_fault_hit(FAULT_ACQ_DWELL)) return gsh::set_error(GSH_ERR_HIP, "fake engine: injected failure of a dwell");
+        std::vector<uint32_t> slots(n_prn);
+        for (uint32_t i = 0; i < n_prn; i++) slots[i] = i;
+        return fake_acq_search(a, in_iq, slots, nullptr, nullptr, accumulate, dwell_count, results, false);
+    }
+    int gsh_acq_dwell_slots(gsh_acq_t* a, const float* in_iq, uint32_t n, const uint32_t* prn_slots, gsh_acq_result* results)
+    {
+        if (a == nullptr || in_iq == nullptr || results == nullptr || prn_slots == nullptr) return gsh::set_error(GSH_ERR_INVALID, "fake: bad dwell arguments");
+        Guard g(a->inside);
+        if (fake_fault_hit(FAULT_ACQ_DWELL)) return gsh::set_error(GSH_ERR_HIP, "fake engine: injected failure of a dwell");
+        return fake_acq_search(a, in_iq, std::vector<uint32_t>(prn_slots, prn_slots + n), nullptr, nullptr, 0, 1, results, true);
+    }
+    int gsh_acq_dwell_cshort(gsh_acq_t* a, const int16_t* in_iq16, uint32_t n_prn, int accumulate, uint32_t dwell_count, gsh_acq_result* results)
+    {
+        if (a == nullptr || in_iq16 == nullptr) return gsh::set_error(GSH_ERR_INVALID, "fake: bad dwell arguments");
+        std::vector<float> x(2 * static_cast<size_t>(a->conf.consumed_samples));
+        for (size_t i = 0; i < x.size(); i++) x[i] = static_cast<float>(in_iq16[i]);
+        return gsh_acq_dwell(a, x.data(), n_prn, accumulate, dwell_count, results);
+    }
+    int gsh_acq_dwell_step2(gsh_acq_t* a, const float* in_iq, uint32_t n, const uint32_t* prn_slots, const float* doppler_center_step_two, const float* input_power_step_one,
+        int accumulate, uint32_t dwell_count, gsh_acq_result* results)
+    {
+        if (a == nullptr || in_iq == nullptr || results == nullptr || prn_slots == nullptr || doppler_center_step_two == nullptr)
+            return gsh::set_error(GSH_ERR_INVALID, "fake: bad step-two arguments");
+        Guard g(a->inside);
+        if (fake_fault_hit(FAULT_ACQ_DWELL)) return gsh::set_error(GSH_ERR_HIP, "fake engine: injected failure of a dwell");
+        return fake_acq_search(a, in_iq, std::vector<uint32_t>(prn_slots, prn_slots + n), doppler_center_step_two, input_power_step_one, accumulate, dwell_count, results, false);
+    }
+    int gsh_acq_read_grid(gsh_acq_t* a, uint32_t prn_slot, float* grid)
+    {
+        if (a == nullptr || grid == nullptr || prn_slot >= a->grids.size()) return gsh::set_error(GSH_ERR_INVALID, "fake: bad read_grid arguments");
+        Guard g(a->inside);
+        if (a->grids[prn_slot].empty()) return gsh::set_error(GSH_ERR_STATE, "no dwell has filled this grid");
+        std::memcpy(grid, a->grids[prn_slot].data(), sizeof(float) * a->grids[prn_slot].size());
         return GSH_OK;
     }
 }

@@ -1,6 +1,8 @@
 #ifndef MOCK_GR_BLOCK_H
 #define MOCK_GR_BLOCK_H
-// names and signatures of gr::basic_block / gr::block that gnss-sdr's acquisition blocks use; no scheduler behind them
+// names and signatures of gr::basic_block / gr::block that gnss-sdr's blocks use.  No scheduler lives here: a test either drives general_work by hand
+// (published / deliver() below) or puts the blocks into tests/host/mini_flowgraph.h, a thread-per-block scheduler over these classes -- messages published on a
+// port that top_block::msg_connect has wired are then queued at the subscriber and handled on the SUBSCRIBER's thread, as GNU Radio's scheduler does
 #include "gnuradio/gr_complex.h"
 #include "gnuradio/io_signature.h"
 #include "gnuradio/thread/thread.h"
@@ -8,6 +10,7 @@
 #include "pmt/pmt.h"
 #include <atomic>
 #include <cstdint>
+#include <deque>
 #include <functional>
 #include <map>
 #include <memory>
@@ -35,21 +38,86 @@ public:
     io_signature::sptr input_signature() const { return d_in; }
     io_signature::sptr output_signature() const { return d_out; }
     void message_port_register_out(pmt::pmt_t port) { d_out_ports.push_back(pmt::symbol_to_string(port)); }
-    void message_port_pub(pmt::pmt_t port, pmt::pmt_t msg) { published.emplace_back(pmt::symbol_to_string(port), std::move(msg)); }
+    void message_port_pub(pmt::pmt_t port, pmt::pmt_t msg)
+    {
+        const std::string name = pmt::symbol_to_string(port);
+        std::vector<std::pair<std::weak_ptr<basic_block>, std::string>> to;
+        {
+            std::lock_guard<std::mutex> lk(d_msg_mu);
+            published.emplace_back(name, msg);
+            auto it = d_subscribers.find(name);
+            if (it != d_subscribers.end()) to = it->second;
+        }
+        for (auto& sub : to)
+            if (auto dst = sub.first.lock()) dst->post(sub.second, msg);
+    }
     void message_port_register_in(pmt::pmt_t port) { d_in_ports.push_back(pmt::symbol_to_string(port)); }
     template <typename F>
     void set_msg_handler(pmt::pmt_t port, F handler) { d_handlers[pmt::symbol_to_string(port)] = handler; }
-    // test harness: deliver a message to an input port as the scheduler would
+    // test harness: deliver a message to an input port as the scheduler would -- at once, on the caller's thread
     void deliver(const std::string& port, pmt::pmt_t msg)
     {
         auto it = d_handlers.find(port);
         if (it != d_handlers.end()) it->second(msg);
+    }
+    // ---- the scheduler's side of message passing (mini_flowgraph.h): a message for this block is queued, the block's own thread handles it
+    void post(const std::string& port, pmt::pmt_t msg)
+    {
+        std::function<void()> wake;
+        {
+            std::lock_guard<std::mutex> lk(d_msg_mu);
+            d_inbox.emplace_back(port, std::move(msg));
+            wake = d_wake;
+        }
+        if (wake) wake();
+    }
+    bool has_pending_messages()
+    {
+        std::lock_guard<std::mutex> lk(d_msg_mu);
+        return !d_inbox.empty();
+    }
+    int handle_pending_messages()  // on the block's thread, between two general_work calls
+    {
+        int n = 0;
+        for (;;)
+            {
+                std::pair<std::string, pmt::pmt_t> m;
+                {
+                    std::lock_guard<std::mutex> lk(d_msg_mu);
+                    if (d_inbox.empty()) return n;
+                    m = std::move(d_inbox.front());
+                    d_inbox.pop_front();
+                }
+                deliver(m.first, m.second);
+                n++;
+            }
+    }
+    void set_wake(std::function<void()> f)
+    {
+        std::lock_guard<std::mutex> lk(d_msg_mu);
+        d_wake = std::move(f);
+    }
+    void subscribe(const std::string& port, const std::shared_ptr<basic_block>& dst, const std::string& dst_port)
+    {
+        std::lock_guard<std::mutex> lk(d_msg_mu);
+        d_subscribers[port].emplace_back(dst, dst_port);
+    }
+    void unsubscribe(const std::string& port, const std::shared_ptr<basic_block>& dst, const std::string& dst_port)
+    {
+        std::lock_guard<std::mutex> lk(d_msg_mu);
+        auto& v = d_subscribers[port];
+        for (auto it = v.begin(); it != v.end();)
+            it = (it->first.lock() == dst && it->second == dst_port) ? v.erase(it) : std::next(it);
     }
     std::vector<std::string> d_in_ports;
     std::map<std::string, std::function<void(pmt::pmt_t)>> d_handlers;
     // test harness view of what the block sent
     std::vector<std::pair<std::string, pmt::pmt_t>> published;
     std::vector<std::string> d_out_ports;
+    std::mutex d_msg_mu;
+    std::deque<std::pair<std::string, pmt::pmt_t>> d_inbox;
+    std::map<std::string, std::vector<std::pair<std::weak_ptr<basic_block>, std::string>>> d_subscribers;
+    std::function<void()> d_wake;
 
 protected:
     basic_block(const std::string& name, io_signature::sptr in, io_signature::sptr out) : d_name(name), d_in(std::move(in)), d_out(std::move(out))
@@ -66,7 +134,8 @@ typedef std::shared_ptr<basic_block> basic_block_sptr;
 class block : public basic_block
 {
 public:
-    virtual int general_work(int noutput_items, gr_vector_int& ninput_items, gr_vector_const_void_star& input_items, gr_vector_void_star& output_items) = 0;
+    // (not pure in GNU Radio either: a message-only block such as channel_msg_receiver_cc never overrides it)
+    virtual int general_work(int /*noutput_items*/, gr_vector_int& /*ninput_items*/, gr_vector_const_void_star& /*input_items*/, gr_vector_void_star& /*output_items*/) { return -1; }
     virtual void forecast(int, gr_vector_int&) {}
     virtual bool start() { return true; }
     virtual bool stop() { return true; }
@@ -113,7 +182,9 @@ public:
     }
     std::vector<tag_t> input_tags, output_tags;  // test harness view
     uint64_t d_nitems_read{0}, d_nitems_written{0};
-    void set_max_noutput_items(int) {}
+    void set_max_noutput_items(int m) { d_max_noutput = m; }
+    int max_noutput_items() const { return d_max_noutput; }
+    int d_max_noutput{0};  // 0: not set
     // test harness view
     int consumed_last{0};
     long long consumed_total{0};

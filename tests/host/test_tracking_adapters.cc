@@ -886,6 +886,45 @@ void test_other_signal_trajectories()
         {{"Tracking.pll_bw_hz", "5.0"}, {"Tracking.dll_bw_hz", "0.5"}}, 120, "", 1, 0.0, true, 25, "", 30.0);
 }
 
+
+// ---- the hand-over as it happens in a flowgraph: the tracking block runs only when two code periods of input are there, the acquisition block consumes whatever it is
+// offered, so at start_tracking the tracking block's read pointer is usually BEHIND Acq_samplestamp_samples.  The reference looks at its pull-in latch in every
+// general_work, the pull-in call included (trk.cc:1910-1917): nitems_read - d_acq_sample_stamp wraps round (unsigned) and the transitory is over before the first period --
+// bit synchronisation starts at once, a second earlier than with the read pointer ahead of the stamp.  Found by running the reference's own Channel (tests/host/test_channel.cc).
+void test_handover_with_the_read_pointer_behind_the_stamp()
+{
+    const long fs = 4000000;
+    const int n = 4000;
+    const uint32_t prn = 14;
+    const double fd = -1530.0;
+    const std::string R = "Tracking";
+    Props p{{"GNSS-SDR.internal_fs_sps", std::to_string(fs)}, {R + ".pll_bw_hz", "35.0"}, {R + ".dll_bw_hz", "2.0"}, {R + ".early_late_space_chips", "0.5"},
+        {R + ".pull_in_time_s", "0"}, {R + ".hip_device", "0"}, {R + ".hip_register_input_buffer", "false"}};
+    auto cfg = make_config(p);
+    GpsL1CaDllPllTrackingHip hip(cfg.get(), R, 1, 1);
+    if (hip.item_size() == 0) return;
+    void* ref = make_ref("GPS_L1_CA_DLL_PLL_Tracking", R, p);
+    const int n_periods = 700;
+    std::vector<int8_t> symbols(static_cast<size_t>(n_periods) + 40, 1);
+    const std::vector<int8_t> bits = random_symbols(static_cast<size_t>(n_periods) / 20 + 4, 31);
+    for (size_t k = 0; k < symbols.size(); k++) symbols[k] = bits[std::min(bits.size() - 1, (k + 13) / 20)];
+    std::vector<float> code(1023);
+    gps_l1_ca_code_gen_float(code, static_cast<int32_t>(prn), 0);
+    const auto x = synth(code, nullptr, 0.0, 1.023e6, 1, fs, fd, 1575.42e6, static_cast<size_t>(n_periods + 12) * n, amp_for_cn0(47.0, fs), symbols, nullptr, 17);
+    Gnss_Synchro syn;
+    // run_pair offers both blocks 2 n samples in standby: the read pointer stands at 8000 when start_tracking comes; the acquisition's stamp is 9500, its code phase
+    // the 2500 samples from there to the next code period (the stream's periods start at multiples of ~4000)
+    const TrajectoryStats st = run_pair(hip, ref, syn, x, n, n_periods, 'G', "1C", prn, 2500.0, fd + 9.0, static_cast<uint64_t>(2 * n + 1500));
+    std::printf("hand-over with the read pointer behind the stamp: %d periods, %d with identical windows, symbols ref/hip/matched %d/%d/%d, first symbol at period %d / %d\n", st.periods,
+        st.same_windows, st.symbols_ref, st.symbols_hip, st.symbols_matched, st.first_symbol_period_ref, st.first_symbol_period_hip);
+    EXPECT(st.first_symbol_period_ref >= 0 && st.first_symbol_period_ref < 900, "the reference block did not leave the pull-in transitory at once (first symbol at period %d)", st.first_symbol_period_ref);
+    EXPECT(st.first_symbol_period_hip == st.first_symbol_period_ref, "first symbol at period %d vs reference %d", st.first_symbol_period_hip, st.first_symbol_period_ref);
+    EXPECT(st.symbols_hip == st.symbols_ref && st.symbols_matched == st.symbols_ref && st.symbols_ref >= 5, "symbol timing: ref %d hip %d matched %d", st.symbols_ref, st.symbols_hip, st.symbols_matched);
+    EXPECT(st.same_windows >= st.periods * 9 / 10, "window positions identical for only %d of %d periods", st.same_windows, st.periods);
+    EXPECT(st.hip_event == 0 && st.ref_events == 0, "no loss of lock expected (hip event %ld, reference events %d)", st.hip_event, st.ref_events);
+    reftrk_destroy(ref);
+}
+
 void test_loss_of_lock_on_noise()
 {
     // (Round 4: cn0_min 40, not 35.  On noise the two loops part after a few hundred periods -- a rounding difference in a correlator output flips a window length,
@@ -1001,6 +1040,7 @@ int main(int argc, char** argv)
     test_gps_l1_trajectory();
     test_galileo_e1_pilot_trajectory();
     test_other_signal_trajectories();
+    test_handover_with_the_read_pointer_behind_the_stamp();
     test_loss_of_lock_on_noise();
     test_shared_ring_follows_the_rf_chain();
     test_restart_on_the_same_block();

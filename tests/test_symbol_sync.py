@@ -287,6 +287,47 @@ def test_device_gps_l1_histogram_bit_sync_matches_oracle(gpu):
     loop.close()
 
 
+def test_oracle_pull_in_over_at_the_hand_over_starts_bit_sync_at_once():
+    """The reference looks at its pull-in latch in the pull-in call too (trk.cc:1910-1917), with the read pointer as it is THEN: behind the acquisition's stamp --
+    the normal order in a flowgraph -- the unsigned difference wraps and the transitory is over before the first period (oracle_pull_in_over).  The histogram
+    synchroniser then works from period 0: the same hand-over as above, 1000 periods earlier.  Pinned to the reference block in tests/host/test_tracking_adapters.cc
+    (test_handover_with_the_read_pointer_behind_the_stamp) and, through the reference's own Channel, in tests/host/test_channel.cc."""
+    x, n, bits, kw = _gps_hist_case()
+    conf = oracle.trk_conf(use_histogram_bit_sync=1, **kw)
+    oracle.set_symbol_sync(conf, 20, GPS_CA_PREAMBLE_SYMBOLS, has_secondary=False)
+    L = oracle.lib()
+    assert L.oracle_pull_in_over(conf, 8000, 10000) == 1 and L.oracle_pull_in_over(conf, 12000, 10000) == 0 and L.oracle_pull_in_over(conf, 10000 + int(FS_L1) + 1, 10000) == 1
+    late = oracle.trk_run(conf, oracle.ca_code(7), x, 0, 0, -1742.0, 1600)
+    early = oracle.trk_run(conf, oracle.ca_code(7), x, 0, 0, -1742.0, 1600, pull_in_over=True)
+    f_late, f_early = [r.state for r in late].index(4), [r.state for r in early].index(4)
+    assert f_late == 1220 and f_early == 220, (f_late, f_early)
+    assert all((r.flags & 1) == 0 for r in early) and all((r.flags & 1) == 1 for r in late[:999])
+
+
+@pytest.mark.gpu
+def test_device_pull_in_over_matches_oracle(gpu):
+    from gnss_sdr_amd import _lib
+    from gnss_sdr_amd.tracking_loop import TrackingLoop, set_symbol_sync, trk_conf
+    x, n, bits, kw = _gps_hist_case()
+    conf_o = oracle.trk_conf(use_histogram_bit_sync=1, **kw)
+    oracle.set_symbol_sync(conf_o, 20, GPS_CA_PREAMBLE_SYMBOLS, has_secondary=False)
+    ora = oracle.trk_run(conf_o, oracle.ca_code(7), x, 0, 0, -1742.0, 700, pull_in_over=True)
+    conf = trk_conf(use_histogram_bit_sync=1, **kw)
+    set_symbol_sync(conf, 20, GPS_CA_PREAMBLE_SYMBOLS, has_secondary=False)
+    L = _lib.load()
+    assert L.gsh_trk_pull_in_over(conf, 8000, 10000) == 1 and L.gsh_trk_pull_in_over(conf, 12000, 10000) == 0
+    loop = TrackingLoop(conf, 2, 1023, device=gpu)
+    loop.set_stream_host(x)
+    loop.start(0, oracle.ca_code(7), 0, 0, -1742.0, pull_in_over=True)
+    loop.start(1, oracle.ca_code(7), 0, 0, -1742.0)                    # the same channel with the transitory running: a second behind
+    rec, _ = loop.run(700)
+    assert [r.state for r in rec[0]] == [r.state for r in ora] and [r.state for r in rec[0]].index(4) == 220
+    assert [r.symbol_flags for r in rec[0]] == [r.symbol_flags for r in ora]
+    assert [r.flags for r in rec[0]] == [r.flags for r in ora]
+    assert all(r.state == 2 and (r.flags & 1) for r in rec[1])
+    loop.close()
+
+
 # ---- high dynamics inside the loop (Dll_Pll_Conf::high_dyn; trk.cc:669-675, 1425-1443, 1458-1480) -------------------------------------
 def _chirp_case():
     fs, n, epochs = 4e6, 4000, 700

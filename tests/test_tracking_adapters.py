@@ -115,3 +115,59 @@ def test_tracking_adapters_follow_the_reference_block(gpu):
     keep = ("FAIL", "periods", "shared stream", "dump", "restart", "noise only", "OK", "failure")
     print("\n".join(l for l in r.stdout.splitlines() if any(k in l for k in keep))[-6000:])
     assert r.returncode == 0 and "TRACKING ADAPTERS OK" in r.stdout, r.stdout[-6000:] + r.stderr[-2000:]
+
+
+# ---- the reference's own Channel / ChannelFsm / channel_msg_receiver_cc over the HIP adapters (tests/host/test_channel.cc, round 5) ---------------------------------------------
+CHAN = os.path.join(ROOT, "tests", "host", "test_channel")
+
+
+def _chan(fake):
+    exe = CHAN + ("_fake" if fake else "")
+    if not os.path.exists(exe):
+        import __graft_entry__ as g
+        if not g.build_channel_test():
+            pytest.skip("tests/host/test_channel was not prebuilt and /root/reference is not present here")
+    return exe
+
+
+def _run_chan(exe, *args, timeout=900):
+    r = subprocess.run([exe, *args], capture_output=True, text=True, timeout=timeout, cwd="/tmp")
+    keep = ("FAIL", "channel life", "hand-over", "churn:", "fault ", "CHANNEL", "failure")
+    print("\\n".join(l for l in r.stdout.splitlines() if any(k in l for k in keep))[-6000:])
+    assert r.returncode == 0 and "CHANNEL OK" in r.stdout and "FAKE ENGINE" not in r.stderr, r.stdout[-5000:] + r.stderr[-2000:]
+    return r.stdout
+
+
+def test_channel_life_reference_channel_over_hip_adapters_fake_engine():
+    """north_star: "drops into a Channel unchanged".  The reference's Channel, ChannelFsm and channel_msg_receiver_cc (compiled in place) over GpsL1CaPcpsAcquisitionHip +
+    GpsL1CaDllPllTrackingHip, one thread per block, token-scheduled: acquisition of an absent satellite fails ("events" 2 -> FSM -> queue -> control assigns the next one),
+    the present one is acquired, the acquisition block's thread calls ChannelFsm::Event_valid_acquisition directly -> start_tracking, the signal is removed -> lock detectors
+    -> "events" 3 -> channel_msg_receiver_cc -> FSM standby -> queue -> re-acquisition attempts until the signal is back -> tracked to the end.  The same Channel class over
+    the reference's own adapters runs the same stream: every event (who, what, satellite, source position), every hand-over (Acq_delay_samples, Acq_doppler_hz,
+    Acq_samplestamp_samples), the acquisition block's consumed counts call for call, the tracking block's read pointers and every item the telemetry decoder receives are
+    compared.  CPU: the fake engine (oracle loop, a double-precision PCPS search) stands in for the device."""
+    out = _run_chan(_chan(True), "life")
+    assert "events identical" in out
+
+
+def test_channel_churn_fake_engine():
+    """Twelve channels on one stream, free-running block threads, four of them forced to lose lock every 200 ms of stream (telemetry fault message) and re-acquired through
+    the FSM while eight track: start_tracking / stop_tracking of a churner quiesce the live residency they all share.  The steady channels keep every window, publish no
+    event and stop at the reference receiver's read pointers."""
+    _run_chan(_chan(True), "churn")
+
+
+def test_engine_failures_surface_as_channel_events_fake_engine():
+    """an engine failure must reach the Channel as loss of lock ("events" 3) or a failed acquisition ("events" 2), never as an exception across general_work
+    or a hung thread.  Injected into the fake engine: a push fails once / for good, gsh_trk_live_take fails for one channel, a residency never reports (the runtime's record
+    watchdog), a dwell fails, gsh_trk_start fails, a launch fails in launched mode."""
+    _run_chan(_chan(True), "faults")
+
+
+@pytest.mark.gpu
+def test_channel_life_and_churn_on_the_gpu(gpu):
+    """The same program against libgnss_sdr_hip.so: the channel life token-scheduled beside the reference receiver (identical events, hand-overs, consumed counts), then BASELINE
+    config 2's 32 channels on one stream with 8 of them churning through the FSM while 24 track on the shared live residency (prints the stall per start / stop)."""
+    exe = _chan(False)
+    _run_chan(exe, "life")
+    _run_chan(exe, "churn", "32", "8", "2.4", "1", timeout=1500)

@@ -285,8 +285,9 @@ def test_live_at_the_baseline_shapes_equals_launched_run_and_oracle(gpu, shape):
     ring.close()
     conf_o = oracle.trk_conf(**s["kw"])
     for ch in range(nch):
-        assert len(got[ch]) == done_flat[ch], (shape, ch, len(got[ch]), done_flat[ch])
-        assert _bytes(got[ch]) == _bytes(rec_flat[ch][:done_flat[ch]]), f"{shape} channel {ch}: live records differ from the launched run"
+        # (the launched run was asked for `epochs` periods; the residency goes on to the last window the stream holds)
+        assert done_flat[ch] <= len(got[ch]) <= done_flat[ch] + 4, (shape, ch, len(got[ch]), done_flat[ch])
+        assert _bytes(got[ch][:done_flat[ch]]) == _bytes(rec_flat[ch][:done_flat[ch]]), f"{shape} channel {ch}: live records differ from the launched run"
         # ... and the first 200 periods of the LIVE records against the oracle loop, the same bars as the launched loop's (test_tracking_loop_gpu._compare)
         ora = oracle.trk_run(conf_o, s["codes"][ch][0], xf, s["starts"][ch], 0, s["dops"][ch], 200, data_code=s["codes"][ch][1])
         assert len(ora) == 200
