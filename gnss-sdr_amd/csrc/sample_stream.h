@@ -24,6 +24,10 @@ struct LiveFloor
     std::mutex m;
     const volatile LiveTail* tails{nullptr};  // nullptr once the owning handle is gone
     int n{0};
+    // the ring is being destroyed under the handle (gsh_stream_destroy): the handle's residencies must leave and forget the ring before its memory goes.
+    // Set by the handle with its registration; called by the ring WITHOUT m held (the callback unregisters, which takes m).
+    void (*ring_gone)(void* owner){nullptr};
+    void* owner{nullptr};
 };
 }  // namespace gsh
 

@@ -270,6 +270,26 @@ extern "C"
     {
         if (!s) return;
         (void)hipSetDevice(s->device);
+        // live tracking handles that still follow this ring: their resident kernels read d_ring and the live words -- they are told to leave and to forget the ring
+        // BEFORE the memory goes (their next gsh_trk_live_begin / run then fails with GSH_ERR_STATE: the block gives its channel up the reference's way)
+        {
+            std::vector<std::shared_ptr<gsh::LiveFloor>> floors;
+            floors.swap(s->live_floors);
+            for (auto& f : floors)
+                {
+                    void (*gone)(void*) = nullptr;
+                    void* owner = nullptr;
+                    {
+                        std::lock_guard<std::mutex> lk(f->m);
+                        if (f->tails != nullptr)
+                            {
+                                gone = f->ring_gone;
+                                owner = f->owner;
+                            }
+                    }
+                    if (gone != nullptr) gone(owner);
+                }
+        }
         if (s->stream) (void)hipStreamSynchronize(s->stream);
         for (void* p : s->parked_device) (void)hipFree(p);
         for (void* p : s->parked_host) (void)hipHostFree(p);
@@ -556,6 +576,15 @@ extern "C"
     int gsh_stream_seek(gsh_stream_t* s, uint64_t next_index)
     {
         GSH_REQUIRE(s != nullptr, "null stream");
+        if (!s->live_floors.empty())
+            {
+                // a resident loop cannot be fenced by events: a seek under it would let the next push overwrite a window it is correlating right now.  While a live channel
+                // is active the ring only moves forward (the caller quiesces the loops -- gsh_trk_live_quiesce / gsh_trk_stop -- or pushes the gap).
+                const unsigned long long floor = gsh::stream_live_floor(s);
+                if (floor != ~0ull)
+                    return set_error(GSH_ERR_STATE, "gsh_stream_seek to %llu while a live tracking channel still reads the ring at %llu (stop or quiesce the loops first)",
+                        static_cast<unsigned long long>(next_index), floor);
+            }
         GSH_HIP(hipSetDevice(s->device));
         GSH_HIP(hipStreamSynchronize(s->stream));  // queued pushes (and the folded reader fences)
         {

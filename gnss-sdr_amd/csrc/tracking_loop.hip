@@ -2047,6 +2047,22 @@ void live_release(gsh_trk* t)  // the handle's side of the registration with its
     t->live_floor.reset();
 }
 
+int live_quiesce(gsh_trk* t);
+
+// gsh_stream_destroy found this handle still registered with the ring: the residencies leave (the ring's memory is about to be freed), the registration goes, the
+// handle forgets the ring.  The record rings in host memory stay (block threads may be reading them); what the channels had finished can still be taken.  Whatever
+// the handle is asked to do with a stream next fails with GSH_ERR_STATE until gsh_trk_set_stream_* gives it one.
+void live_ring_gone(void* owner)
+{
+    gsh_trk* t = static_cast<gsh_trk*>(owner);
+    (void)hipSetDevice(t->device);
+    (void)live_quiesce(t);
+    live_release(t);
+    t->ring = nullptr;
+    t->d_stream = nullptr;
+    t->n_stream = 0;
+}
+
 // first use: the shared words and the record ring in coherent host memory, the stream, the registration with the ring
 int live_setup(gsh_trk* t)
 {
@@ -2122,6 +2138,8 @@ int live_setup(gsh_trk* t)
     t->live_floor = std::make_shared<gsh::LiveFloor>();
     t->live_floor->tails = tails;
     t->live_floor->n = t->n_channels;
+    t->live_floor->owner = t;
+    t->live_floor->ring_gone = &live_ring_gone;
     t->ring->live_floors.push_back(t->live_floor);
     t->live_ready.store(true, std::memory_order_release);
     return GSH_OK;
@@ -2148,6 +2166,27 @@ int live_quiesce(gsh_trk* t)
     t->live_busy[0] = t->live_busy[1] = false;
     if (e != hipSuccess) return gsh::hip_fail(e, "hipStreamSynchronize(live)", __FILE__, __LINE__);
     live_refresh_host_state(t);
+    return GSH_OK;
+}
+
+// live mode was set up against a ring the handle is leaving (another ring, a flat stream): residencies leave, the registration with the old ring goes, the host
+// memory of the record rings is released; the next gsh_trk_live_begin starts from scratch
+int live_wind_down(gsh_trk* t)
+{
+    if (t->h_live_tail == nullptr) return GSH_OK;
+    GSH_HIP(hipSetDevice(t->device));
+    const int rcq = live_quiesce(t);
+    if (rcq != GSH_OK) return rcq;
+    live_release(t);
+    (void)hipHostFree(t->h_live_tail);
+    (void)hipHostFree(t->h_live_consumed);
+    (void)hipHostFree(t->h_live_quit);
+    (void)hipHostFree(t->h_live_records);
+    t->live_ready.store(false, std::memory_order_release);
+    t->h_live_tail = nullptr;
+    t->h_live_consumed = nullptr;
+    t->h_live_quit = nullptr;
+    t->h_live_records = nullptr;
     return GSH_OK;
 }
 }  // namespace
@@ -2267,6 +2306,12 @@ extern "C"
     {
         GSH_REQUIRE(t != nullptr && iq != nullptr && n_samples >= 1, "null / empty stream");
         GSH_HIP(hipSetDevice(t->device));
+        {
+            // (a residency still follows the ring the handle is leaving: it goes first -- it would keep reading the old ring, and its registration would keep
+            // pushes into that ring off the channels' stale positions)
+            const int rcq = live_wind_down(t);
+            if (rcq != GSH_OK) return rcq;
+        }
         if (n_samples + 2 > t->stream_owned_cap)
             {
                 if (t->d_stream_owned) GSH_HIP(hipFree(t->d_stream_owned));
@@ -2288,6 +2333,10 @@ extern "C"
     {
         GSH_REQUIRE(t != nullptr && device_iq != nullptr && n_samples >= 1, "null / empty stream");
         GSH_REQUIRE((reinterpret_cast<uintptr_t>(device_iq) & 15u) == 0, "device stream must be 16-byte aligned");
+        {
+            const int rcq = live_wind_down(t);  // as in gsh_trk_set_stream_host
+            if (rcq != GSH_OK) return rcq;
+        }
         t->d_stream = static_cast<const float2*>(device_iq);
         t->n_stream = n_samples;
         t->ring = nullptr;
@@ -2302,20 +2351,8 @@ extern "C"
             s ? s->max_window : 0ull, t->conf.vector_length);
         if (s != t->ring && t->h_live_tail != nullptr)
             {
-                // live mode was set up against the old ring: wind it down, the next gsh_trk_live_begin sets it up against the new one
-                GSH_HIP(hipSetDevice(t->device));
-                int rcq = live_quiesce(t);
+                const int rcq = live_wind_down(t);  // live mode was set up against the old ring; the next gsh_trk_live_begin sets it up against the new one
                 if (rcq != GSH_OK) return rcq;
-                live_release(t);
-                (void)hipHostFree(t->h_live_tail);
-                (void)hipHostFree(t->h_live_consumed);
-                (void)hipHostFree(t->h_live_quit);
-                (void)hipHostFree(t->h_live_records);
-                t->live_ready.store(false, std::memory_order_release);
-                t->h_live_tail = nullptr;
-                t->h_live_consumed = nullptr;
-                t->h_live_quit = nullptr;
-                t->h_live_records = nullptr;
             }
         t->ring = s;
         if (s != nullptr)
@@ -2405,7 +2442,9 @@ extern "C"
         GSH_REQUIRE(channel >= 0 && channel < t->n_channels, "channel %d outside 0..%d", channel, t->n_channels - 1);
         GSH_REQUIRE(code_length >= gsh::mcdev::MC_MARGIN && code_length <= t->max_code_len, "code_length %d outside %d..%d", code_length, gsh::mcdev::MC_MARGIN, t->max_code_len);
         GSH_REQUIRE(!t->conf.track_pilot || data_code != nullptr, "track_pilot needs the data-component code");
-        GSH_REQUIRE(acq_sample_stamp <= start_sample, "acq_sample_stamp must not be later than start_sample");
+        // (acq_sample_stamp may lie BEYOND start_sample: a tracking block more than a code period behind the acquisition's stamp starts on an earlier code period,
+        //  trk.cc:1949-1978.  The loop's two elapsed-time tests -- pull-in transitory, bit-synchronisation time limit, trk.cc:1912, 2002 -- then see the unsigned
+        //  difference wrapped round, here as there: such a channel is declared lost as soon as its C/N0 buffer has filled.  Found with 32 free-running channels.)
         if (t->pending_epochs >= 0) return set_error(GSH_ERR_STATE, "gsh_trk_start: a run has been begun and not ended");
         GSH_HIP(hipSetDevice(t->device));
         if (live_reap(t) != 0) return set_error(GSH_ERR_STATE, "gsh_trk_start: a live residency is in flight (gsh_trk_live_quiesce first)");

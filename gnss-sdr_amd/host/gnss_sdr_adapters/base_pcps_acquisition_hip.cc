@@ -6,8 +6,10 @@
 #include "configuration_interface.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <map>
 #include <mutex>
+#include <vector>
 
 namespace
 {
@@ -31,6 +33,32 @@ std::shared_ptr<Hip_Acquisition_Runtime> acquisition_runtime_for(int device, int
             slot = rt;
         }
     return rt;
+}
+
+// <role>.hip_devices = 0,1,2,...: the acquisition blocks of a role are dealt over these GPUs in the order they are built -- the factory builds channel 0, 1, 2, ... in turn
+// (gnss_block_factory.cc:1040-1054), so channel c searches on GPU c mod G (SURVEY 8e "PRN p -> GPU p mod G": a channel searches one PRN at a time), next to its tracking block,
+// which <role>.hip_devices of the tracking role deals the same way (dll_pll_tracking_hip.cc).  <role>.hip_device, when given, pins a block.  An acquisition block reads its
+// own input buffer (acq.cc:790-815), not the device sample ring, so nothing has to be replicated for it.
+int acquisition_device_for(const ConfigurationInterface* configuration, const std::string& role)
+{
+    const int pinned = configuration->property(role + ".hip_device", -1);
+    if (pinned >= 0) return pinned;
+    const std::string list = configuration->property(role + ".hip_devices", std::string(""));
+    std::vector<int> devices;
+    size_t at = 0;
+    while (at < list.size())
+        {
+            const size_t comma = list.find(',', at);
+            const std::string tok = list.substr(at, comma == std::string::npos ? std::string::npos : comma - at);
+            if (!tok.empty()) devices.push_back(std::atoi(tok.c_str()));
+            if (comma == std::string::npos) break;
+            at = comma + 1;
+        }
+    if (devices.empty()) return 0;
+    static std::mutex mu;
+    static std::map<std::string, unsigned> dealt;
+    std::lock_guard<std::mutex> lk(mu);
+    return devices[dealt[role + "|" + list]++ % devices.size()];
 }
 
 // base_pcps_acquisition.cc:38-66 without the command-line flag overrides
@@ -90,7 +118,8 @@ BasePcpsAcquisitionHip::BasePcpsAcquisitionHip(const ConfigurationInterface* con
     // item types the engine ingests directly; the reference routes cbyte through a converter block (base_pcps_acquisition.cc:89-93)
     if (acq_parameters_.item_type == "gr_complex" || acq_parameters_.item_type == "cshort")
         {
-            const int device = configuration->property(role + ".hip_device", 0);
+            const int device = acquisition_device_for(configuration, role);
+            device_ = device;
             const Hip_Acq_Conf hconf = to_hip_conf(acq_parameters_);
             auto runtime = acquisition_runtime_for(device, configuration->property(role + ".hip_shared_acquisition", -1), hconf,
                 configuration->property(role + ".hip_shared_acquisition_channels", 64), configuration->property(role + ".hip_shared_acquisition_wait_us", 2000));

@@ -8,7 +8,9 @@
  * repository compile and drive it against the reference's own interface headers (tests/test_adapters_*.py).
  * Same constructor signature, same configuration keys (Acq_Conf::SetFromConfiguration, acq_conf.cc:29-95 -- including
  * make_two_steps / second_nbins / second_doppler_step / pfa_second_step and item_type = cshort), plus
- *   <role>.hip_device                        GPU index (0)
+ *   <role>.hip_device                        GPU index (0); pins the block when <role>.hip_devices is given as well
+ *   <role>.hip_devices                       "0,1,2,...": the blocks of the role are dealt over these GPUs in the order the factory builds them: channel c searches on
+ *                                            GPU c mod G, next to its tracking block (same key of the tracking role)
  *   <role>.hip_shared_acquisition            id >= 0: channels with the same id (and device, and dwell geometry) share one Hip_Acquisition_Runtime --
  *                                            blocks that search at the same time cut the stream on a common grid and join ONE dwell batch: the
  *                                            Doppler-wiped forward transforms are computed once for all of them (-1, default: every block on its own)
@@ -56,6 +58,8 @@ public:
     gr::basic_block_sptr get_right_block() override { return acquisition_; }
     //! the block itself (tests and monitors; a Channel never needs it)
     pcps_acquisition_hip_sptr block() const { return acquisition_; }
+    //! the GPU this block searches on (<role>.hip_device, or its turn of <role>.hip_devices)
+    int device() const { return device_; }
 
     void set_gnss_synchro(Gnss_Synchro* p_gnss_synchro) override
     {
@@ -106,6 +110,7 @@ private:
     const unsigned int code_length_;
     std::vector<std::complex<float>> code_;
     pcps_acquisition_hip_sptr acquisition_;
+    int device_{0};
 };
 
 #endif  // GNSS_SDR_BASE_PCPS_ACQUISITION_HIP_H

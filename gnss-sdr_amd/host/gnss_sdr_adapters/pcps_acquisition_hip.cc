@@ -9,6 +9,11 @@
 #include "hip_mat5_writer.h"
 #include <cstring>
 #include <gnuradio/io_signature.h>
+#if USE_GLOG_AND_GFLAGS
+#include <glog/logging.h>
+#else
+#include <absl/log/log.h>
+#endif
 #include <pmt/pmt.h>
 #include <algorithm>
 #include <cmath>
@@ -237,6 +242,7 @@ void pcps_acquisition_hip::run_dwell(uint64_t sample_count, const std::shared_pt
     // that corner most of the time; here the corner does not exist.
     std::shared_ptr<ChannelFsm> fsm_to_tell;
     long event = 0;
+    if (outcome == Hip_Pcps_Acquisition_Core::ACQ_ERROR) LOG(ERROR) << "pcps_acquisition_hip: channel " << d_channel << ": " << d_core.last_error() << " -- reported as a failed acquisition";
     {
         gr::thread::scoped_lock lock(d_setlock);
         if (outcome != Hip_Pcps_Acquisition_Core::ACQ_ERROR && d_gnss_synchro != nullptr) d_core.update_synchro(result, d_gnss_synchro);

@@ -923,6 +923,24 @@ void test_handover_with_the_read_pointer_behind_the_stamp()
     EXPECT(st.same_windows >= st.periods * 9 / 10, "window positions identical for only %d of %d periods", st.same_windows, st.periods);
     EXPECT(st.hip_event == 0 && st.ref_events == 0, "no loss of lock expected (hip event %ld, reference events %d)", st.hip_event, st.ref_events);
     reftrk_destroy(ref);
+    // ... and MORE than a code period behind: the pull-in lands on a code period that still starts before the stamp, so in the first periods of state 2 the
+    // bit-synchronisation time limit's elapsed time (trk.cc:2002, the same unsigned difference) is ~2^64 / fs seconds: "time limit reached", the carrier fail counter
+    // jumps to 300000 and the channel is dropped as soon as the lock test runs at all, i.e. when the C/N0 buffer has its 20 prompts.  A quirk; ours too.
+    {
+        Props p2 = p;
+        p2[R + ".hip_shared_ring"] = "-1";  // (the stream starts again at sample 0: a ring of its own, not the one the first block left at the end of the stream)
+        auto cfg2 = make_config(p2);
+        GpsL1CaDllPllTrackingHip hip2(cfg2.get(), R, 1, 1);
+        void* ref2 = make_ref("GPS_L1_CA_DLL_PLL_Tracking", R, p);
+        Gnss_Synchro syn2;
+        const TrajectoryStats s2 = run_pair(hip2, ref2, syn2, x, n, 200, 'G', "1C", prn, 2000.0, fd + 9.0, static_cast<uint64_t>(2 * n + 10000));
+        std::printf("hand-over with the read pointer 2.5 code periods behind the stamp: loss of lock at period %d (HIP block) / %d (reference), %d periods with identical windows\n",
+            s2.loss_period_hip, s2.loss_period_ref, s2.same_windows);
+        EXPECT(s2.loss_period_ref >= 15 && s2.loss_period_ref <= 25, "the reference block kept the channel (loss at period %d): test set-up", s2.loss_period_ref);
+        EXPECT(s2.loss_period_hip == s2.loss_period_ref, "loss of lock at period %d vs reference %d", s2.loss_period_hip, s2.loss_period_ref);
+        EXPECT(s2.loss_item_hip && s2.loss_item_ref, "the loss must come with an item whose Flag_valid_symbol_output is false");
+        reftrk_destroy(ref2);
+    }
 }
 
 void test_loss_of_lock_on_noise()

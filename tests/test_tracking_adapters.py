@@ -164,6 +164,13 @@ def test_engine_failures_surface_as_channel_events_fake_engine():
     _run_chan(_chan(True), "faults")
 
 
+def test_acquisition_and_tracking_blocks_of_a_channel_are_dealt_to_the_same_gpu():
+    """<role>.hip_devices = 0,1,2 on both roles: channel c's acquisition block and tracking block land on GPU c mod 3; hip_device pins.  The fake engine plays three devices."""
+    exe = _chan(True)
+    r = subprocess.run([exe, "devices"], capture_output=True, text=True, timeout=300, cwd="/tmp", env=dict(os.environ, FAKE_GSH_DEVICES="3"))
+    assert r.returncode == 0 and "dealt 0 1 2 0 1 2 0" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 @pytest.mark.gpu
 def test_channel_life_and_churn_on_the_gpu(gpu):
     """The same program against libgnss_sdr_hip.so: the channel life token-scheduled beside the reference receiver (identical events, hand-overs, consumed counts), then BASELINE

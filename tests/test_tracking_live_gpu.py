@@ -295,3 +295,59 @@ def test_live_at_the_baseline_shapes_equals_launched_run_and_oracle(gpu, shape):
         assert stats["compared"] == 200
         tail = got[ch][150:200]
         assert abs(np.mean([r.carrier_doppler_hz for r in tail]) - (s["dops"][ch] + (-7.0 if s["taps"] == 3 else 5.0))) < 3.0, (shape, ch)
+
+
+def test_ring_destroyed_under_a_live_residency(gpu):
+    """SURVEY section 5 / round-4 verdict: an engine failure must not crash the receiver.  gsh_stream_destroy of the ring a residency is following: the ring tells the loop's
+    handle first (the resident kernel leaves, the registration goes), THEN frees its memory.  The handle is left without a stream -- gsh_trk_live_begin fails with
+    GSH_ERR_STATE, which a tracking block turns into "events" 3 --; the records the channels had finished can still be taken; and with a new ring, positioned where the
+    slowest channel stands, the very same handle goes on: all records byte-identical to one launched run over the flat stream.  Also: gsh_stream_seek is refused while a
+    live channel still reads the ring (a seek under a resident kernel could let a push overwrite the window it is correlating)."""
+    from gnss_sdr_amd import GshError
+    from gnss_sdr_amd.sample_stream import SampleStream
+    epochs = 500
+    prns, dops, starts, total, x8, xf = _scenario(epochs)
+    prns, dops, starts = prns[:2], dops[:2], starts[:2]      # the two satellites that are there
+    rec_flat, done_flat = _flat_run(gpu, prns, dops, starts, xf, epochs)
+    ring = SampleStream(40 * N + 7, 2 * N, device=gpu)
+    live = _loop(gpu, KW, n_channels=2)
+    live.set_stream_ring(ring)
+    for ch in range(2):
+        live.start(ch, oracle.ca_code(prns[ch]), starts[ch], 0, dops[ch] + 6.0)
+    live.live_configure(idle_timeout_us=500000, residency_us=5000000)   # the residency stays for half a second after its last period: it IS resident when the ring goes
+    got, lost = [[], []], [False, False]
+    first = 180 * N
+    ring.push(x8[:first], "ibyte")
+    live.live_begin()
+    _drain(live, got, lost, 3.0, [150, 150])
+    assert min(len(g) for g in got) >= 150 and live.live_in_flight() >= 1
+    with pytest.raises(GshError):
+        ring.seek(0)                      # refused: live channels still read the ring
+    ring.close()                          # <- the ring goes under the resident kernel
+    assert live.live_in_flight() == 0
+    with pytest.raises(GshError):
+        live.live_begin()                 # no stream any more: GSH_ERR_STATE
+    _drain(live, got, lost, 0.3)          # what had been finished is still there
+    nxt = [live.live_take(ch, 1)[2] for ch in range(2)]
+    assert all(len(got[ch]) >= 150 for ch in range(2)) and lost == [False, False]
+    # a new ring where the slowest channel stands; the handle goes on from its own state
+    ring2 = SampleStream(40 * N + 7, 2 * N, device=gpu)
+    at = min(nxt)
+    ring2.seek(at)
+    live.set_stream_ring(ring2)
+    pushed = at
+    while pushed < total:
+        m = min(9 * N, total - pushed)
+        ring2.push(x8[pushed:pushed + m], "ibyte")
+        pushed += m
+        if live.live_in_flight() == 0:
+            live.live_begin()
+        _drain(live, got, lost, 2.0, [min(done_flat[ch], max(0, (pushed - starts[ch]) // N - 1)) for ch in range(2)])
+    _drain(live, got, lost, 0.5)
+    live.live_quiesce()
+    _drain(live, got, lost, 0.2)
+    for ch in range(2):
+        assert done_flat[ch] <= len(got[ch]) <= done_flat[ch] + 4, (ch, len(got[ch]), done_flat[ch])
+        assert _bytes(got[ch][:done_flat[ch]]) == _bytes(rec_flat[ch][:done_flat[ch]]), f"channel {ch}: records differ from the launched run after the ring was replaced"
+    live.close()
+    ring2.close()
