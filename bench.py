@@ -508,6 +508,54 @@ def closed_loop_metric(dev_index, x_dev, n_samples, fs, n, dop, cph, channels=32
     return out
 
 
+def closed_loop_config4_metric(torch, dev_index, channels=50, epochs=60):
+    """BASELINE config 4 with the loop closed on the device: Galileo E1, 50 channels, fs 32 Msps, 4 ms windows of 128 000 samples, VE/E/P/L/VL on the pilot (E1C) + the data
+    prompt (E1B) = 5 + 1 correlators per channel-period (trk.cc:1246-1256), lock detectors on.  One launch of `epochs` periods per channel over a resident stream
+    (noise + four E1 signals at 45 dB-Hz so that some channels really track; the others run noise-driven, which costs the same)."""
+    from gnss_sdr_amd.tracking_loop import TrackingLoop, trk_conf
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import add_code_signal, cn0_to_amplitude, golden_e1_l5_codes
+    fs, n = 32e6, 128000
+    g = golden_e1_l5_codes()
+    n_stream = (epochs + 3) * n
+    gen = torch.Generator(device=f"cuda:{dev_index}").manual_seed(0x5EED0004)
+    x = torch.view_as_complex(torch.randn(n_stream, 2, device=f"cuda:{dev_index}", generator=gen).contiguous())
+    sig = [(0, -1830.0, 3000.0), (11, 2410.0, 511.0), (23, 655.0, 7000.5), (37, -3120.0, 123.0)]
+    add = np.zeros(n_stream, np.complex64)
+    amp = cn0_to_amplitude(45.0, fs)
+    starts = {}
+    for ch, fd, ph in sig:
+        rate = 1.023e6 * (1 + fd / 1575.42e6) / fs * 2.0
+        add_code_signal(add, (g["e1b"][ch] - g["e1c"][ch]) / np.sqrt(2.0), fs, rate, ph, fd, amp)
+        starts[ch] = (int(round((8184.0 - ph) / rate)), fd)
+    x += torch.from_numpy(add).to(x.device)
+    conf = trk_conf(fs_in=fs, vector_length=n, code_length_chips=4092, code_samples_per_chip=2, veml=1, track_pilot=1, cloop=0, early_late_space_chips=0.15,
+                    very_early_late_space_chips=0.5, pll_bw_hz=15.0, dll_bw_hz=0.75, pll_filter_order=3, dll_filter_order=2, enable_lock_detectors=1,
+                    max_carrier_lock_fail=1 << 30, max_code_lock_fail=1 << 30)
+    loop = TrackingLoop(conf, channels, 8184, device=dev_index)
+    loop.set_stream_device(x.data_ptr(), n_stream, keepalive=x)
+    rng = np.random.default_rng(0x5EED0007)
+    for c in range(channels):
+        if c in starts:
+            loop.start(c, g["e1c"][c], starts[c][0], 0, starts[c][1] - 5.0, data_code=g["e1b"][c])
+        else:
+            loop.start(c, g["e1c"][c % 50], int(rng.integers(0, n)), 0, float(rng.uniform(-4000, 4000)), data_code=g["e1b"][c % 50])
+    loop.time_run(epochs, reps=3)
+    ms = loop.time_run(epochs, reps=5)
+    rec, done = loop.run(epochs)
+    locked = sum(1 for c in starts if c < channels and abs(np.mean([r.carrier_doppler_hz for r in rec[c][-10:]]) - starts[c][1]) < 3.0)
+    loop.close()
+    corr = 6  # five pilot taps + the data prompt
+    flops = float(channels) * epochs * ((6 + 4 * 5) + (6 + 4 * 1)) * n   # SURVEY 8d's figure per correlator call: 6 + 4 T flops per sample, pilot call + data call
+    peak = 157.3e12
+    return {"metric": "correlators/s, loop closed on device, BASELINE config 4", "workload": f"Galileo E1, {channels} channels, fs 32 Msps, 128000-sample (4 ms) windows, 5 + 1 taps, lock detectors on",
+            "value": channels * corr * epochs / (ms * 1e-3), "unit": "correlators/s", "ms_per_launch": ms, "us_per_epoch": ms * 1e3 / epochs, "channels": channels,
+            "epochs_per_launch": epochs, "channels_with_signal_locked": f"{locked}/{sum(1 for c in starts if c < channels)}", "real_time_factor": epochs * 4e-3 / (ms * 1e-3),
+            "roofline": {"bound": "valu", "achieved": flops / (ms * 1e-3) / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": flops / (ms * 1e-3) / peak,
+                         "frac_of_the_compute_units_in_use": flops / (ms * 1e-3) / (peak * min(channels, 256) / 256.0),
+                         "note": "one compute unit per channel (50 of 256); a 4 ms period is 128000 samples x (5 pilot taps + the data prompt) = 62.5 trips of 2048 samples per wave"}}
+
+
 def closed_loop_live(dev_index, x_dev, n_samples, fs, n, dop, cph, channels, epochs, conf):
     """The same channels in LIVE mode (gsh_trk_live_*): one residency of the loop kernel follows a ring that already holds the block; the records are read
     from page-locked host memory while it runs.  Rate = the slowest channel's progress between two marks."""
@@ -936,6 +984,10 @@ def main():
                 res["closed_loop_256ch"] = closed_loop_metric(local, x0, block, fs, n, dop, cph, channels=256, epochs=min(E - 2, 200))
             except Exception as e:
                 res["closed_loop"] = {"error": str(e)}
+            try:
+                res["closed_loop_config4"] = closed_loop_config4_metric(torch, local)
+            except Exception as e:
+                res["closed_loop_config4"] = {"error": str(e)}
             if not a.no_other_configs:
                 try:
                     res["other_configs"] = other_configs_metric(local)

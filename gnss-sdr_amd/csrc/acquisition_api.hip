@@ -36,6 +36,7 @@ struct gsh_acq
     gsh::RowStat* d_rows{nullptr};
     gsh_acq_pair_peak* d_pair{nullptr};  // gsh_acq_noncoherent_pair_peaks: one record per bin
     gsh::RowStat* d_subrows{nullptr};  // split plans (N = S * M): the sub-cells' records, S per (PRN, bin)
+    gsh::RowStat* d_waverows{nullptr}; // on-chip path: the cells' per-wave partial records, ONCHIP_MAX_WAVES per (PRN, bin, sub-cell) (pcps_fft.h)
     int split{0};
     float2* d_z{nullptr};              // decimation-in-time split plans (gsh::onchip_dit): the sub-cells' length-M transforms, max_prn * n_bins * n
     gsh::DevAcqResult* d_results{nullptr};
@@ -65,6 +66,7 @@ struct gsh_acq
     float2* d_spectra2{nullptr};
     gsh::RowStat* d_rows2{nullptr};
     gsh::RowStat* d_subrows2{nullptr};
+    gsh::RowStat* d_waverows2{nullptr};
     float2* d_z2{nullptr};
     gsh::DevAcqResult* d_results2{nullptr};
     unsigned* d_arrivals2{nullptr};
@@ -192,7 +194,7 @@ int enqueue_dwell(gsh_acq* a, uint32_t n_prn, int accumulate, uint32_t dwell_cou
             // acq.cc:538-553 + the per-row part of :409-519: one work-group per (PRN, bin) cell, nothing leaves the CU
             return gsh::onchip_correlate(n, a->d_spectra, a->d_codes, a->d_grid, a->d_rows, a->d_subrows, a->d_results, a->d_arrivals, static_cast<int>(n_prn),
                 a->n_bins, c.bit_transition_flag ? eff : 0, eff, accumulate, (c.no_grid && !(a->split > 0 && !c.use_cfar)) ? 0 : 1, static_cast<int>(c.samples_per_chip), c.use_cfar, dwell_count ? dwell_count : 1u,
-                a->grid_weight, a->stream, a->d_z);
+                a->grid_weight, a->stream, a->d_z, a->d_waverows);
         }
     // acq.cc:657-664 (zero padding) + :531-535 (wipe-off, forward FFT) for every bin
     int rc = gsh::fft_forward(a->plan, a->d_in, 0, static_cast<int>(c.consumed_samples), 0, a->d_bins_hz, static_cast<double>(c.fs_in),
@@ -602,6 +604,8 @@ extern "C"
         if ((e = hipMalloc(&a->d_rows, sizeof(gsh::RowStat) * P * D)) != hipSuccess) return fail(e, "hipMalloc(rows)");
         if (a->split > 0 && (e = hipMalloc(&a->d_subrows, sizeof(gsh::RowStat) * P * std::max<size_t>(D, a->n_bins2) * a->split)) != hipSuccess)
             return fail(e, "hipMalloc(subrows)");
+        if (a->onchip && (e = hipMalloc(&a->d_waverows, sizeof(gsh::RowStat) * P * std::max<size_t>(D, a->n_bins2) * static_cast<size_t>(std::max(a->split, 1)) * gsh::ONCHIP_MAX_WAVES)) != hipSuccess)
+            return fail(e, "hipMalloc(wave records)");
         if (a->split > 0 && gsh::onchip_dit(static_cast<int>(n)))
             {
                 const size_t cells = P * std::max<size_t>(D, a->n_bins2);
@@ -646,6 +650,8 @@ extern "C"
         if (a->d_grid) (void)hipFree(a->d_grid);
         if (a->d_rows) (void)hipFree(a->d_rows);
         if (a->d_subrows) (void)hipFree(a->d_subrows);
+        if (a->d_waverows) (void)hipFree(a->d_waverows);
+        if (a->d_waverows2) (void)hipFree(a->d_waverows2);
         if (a->d_z) (void)hipFree(a->d_z);
         if (a->d_z2) (void)hipFree(a->d_z2);
         if (a->d_pair) (void)hipFree(a->d_pair);
@@ -945,7 +951,8 @@ extern "C"
                         rc = gsh::onchip_correlate(nfft, a->d_spectra, a->d_codes + static_cast<size_t>(slot) * nfft, grid, a->d_rows + static_cast<size_t>(i) * D2,
                             a->d_subrows ? a->d_subrows + static_cast<size_t>(i) * D2 * a->split : nullptr,
                             a->d_results + i, a->d_arrivals + i, 1, D2, c.bit_transition_flag ? eff : 0, eff, accumulate, (c.no_grid && !(a->split > 0 && !c.use_cfar)) ? 0 : 1, static_cast<int>(c.samples_per_chip), c.use_cfar,
-                            dwell_count ? dwell_count : 1u, a->grid_weight, a->stream, a->d_z ? a->d_z + static_cast<size_t>(i) * D2 * nfft : nullptr);
+                            dwell_count ? dwell_count : 1u, a->grid_weight, a->stream, a->d_z ? a->d_z + static_cast<size_t>(i) * D2 * nfft : nullptr,
+                            a->d_waverows + static_cast<size_t>(i) * D2 * static_cast<size_t>(std::max(a->split, 1)) * gsh::ONCHIP_MAX_WAVES);
                     }
                 else
                     {
@@ -1163,6 +1170,7 @@ extern "C"
                 GSH_HIP(hipMalloc(&a->d_spectra2, sizeof(float2) * D * n));
                 GSH_HIP(hipMalloc(&a->d_rows2, sizeof(gsh::RowStat) * P * D));
                 if (a->split > 0) GSH_HIP(hipMalloc(&a->d_subrows2, sizeof(gsh::RowStat) * P * D * a->split));
+                GSH_HIP(hipMalloc(&a->d_waverows2, sizeof(gsh::RowStat) * P * D * static_cast<size_t>(std::max(a->split, 1)) * gsh::ONCHIP_MAX_WAVES));
                 if (a->d_z != nullptr)
                     {
                         GSH_HIP(hipMalloc(&a->d_z2, sizeof(float2) * P * D * n));
@@ -1183,7 +1191,7 @@ extern "C"
             return gsh::onchip_correlate(static_cast<int>(n), spectra, a->d_codes, a->d_grid, lane ? a->d_rows2 : a->d_rows, lane ? a->d_subrows2 : a->d_subrows,
                 lane ? a->d_results2 : a->d_results, lane ? a->d_arrivals2 : a->d_arrivals, static_cast<int>(n_prn), a->n_bins,
                 c.bit_transition_flag ? static_cast<int>(c.effective_fft_size) : 0, static_cast<int>(c.effective_fft_size), 0, 0, static_cast<int>(c.samples_per_chip), c.use_cfar, 1u, 1.0f, st,
-                lane ? a->d_z2 : a->d_z);
+                lane ? a->d_z2 : a->d_z, lane ? a->d_waverows2 : a->d_waverows);
         };
         int rc = enqueue(0);  // warm-up on both lanes
         if (rc == GSH_OK) rc = enqueue(1);

@@ -90,8 +90,11 @@ int onchip_forward(int n, const float2* src, size_t src_stride, int n_in, int pl
 // read only when `accumulate` and written only when `store_grid`
 // lags [offset, offset + effective) of the transform enter the search (offset + effective == n; offset != 0: bit_transition_flag);
 // subrows: n_prn * n_bins * onchip_split(n) records (split plans only, else nullptr)
+// waverows: n_prn * n_bins * max(onchip_split(n), 1) * ONCHIP_MAX_WAVES per-wave partial records: every flavour but the single-transform peak-ratio search lets the
+// cells' waves leave their partials there and forms rows and statistic in a small kernel queued behind the cells (no barrier, release or ticket at the end of a cell)
+constexpr int ONCHIP_MAX_WAVES = 16;
 int onchip_correlate(int n, const float2* spectra, const float2* codes, float* grid, RowStat* rows, RowStat* subrows, DevAcqResult* results,
     unsigned* arrivals, int n_prn, int n_bins, int offset, int effective, int accumulate, int store_grid, int samples_per_chip, int use_cfar,
-    unsigned dwell_count, float weight, hipStream_t s, float2* z = nullptr);
+    unsigned dwell_count, float weight, hipStream_t s, float2* z = nullptr, RowStat* waverows = nullptr);
 }  // namespace gsh
 #endif

@@ -27,9 +27,17 @@
 #include "fft_onchip.h"
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 
 #ifndef GSH_OC_DIT_MIN_S
 #define GSH_OC_DIT_MIN_S 4
+#endif
+#ifndef GSH_OC_CELLS_PER_WG_DEFAULT
+#define GSH_OC_CELLS_PER_WG_DEFAULT 6
+#endif
+#ifndef GSH_OC_STAGGER_GROUPS_DEFAULT
+#define GSH_OC_STAGGER_GROUPS_DEFAULT 0
+#define GSH_OC_STAGGER_TICKS_DEFAULT 0
 #endif
 
 namespace gsh
@@ -39,7 +47,38 @@ namespace
 {
 using oc::cf;
 
-constexpr int OC_MAX_WAVES = 16;
+constexpr int OC_MAX_WAVES = ONCHIP_MAX_WAVES;
+
+// -DGSH_OC_PROFILE (profiles/ab/build_variant.py; never in the shipped library): every wave of every cell of the headline flavour leaves the shader clock
+// (s_memtime) at eight points of its life -- entry, operands loaded + products, stage 1, exchange 1, stage 2, exchange 2, stage 3 + wave reduction, row published --
+// and the 100 MHz wall clock at entry and exit; gsh_debug_oc_profile copies them out (profiles/ab/r05/oc_cell_phases.py -> profiles/oc_cell_annotated.txt)
+#ifdef GSH_OC_PROFILE
+constexpr int OC_PROF_WORDS = 10;
+__device__ unsigned long long g_oc_prof[4096 * OC_MAX_WAVES * OC_PROF_WORDS];
+#define OC_STAMP(k)                                                                                                                         \
+    do                                                                                                                                      \
+        {                                                                                                                                   \
+            if ((threadIdx.x & 63) == 0 && cell < 4096) g_oc_prof[(static_cast<size_t>(cell) * OC_MAX_WAVES + (threadIdx.x >> 6)) * OC_PROF_WORDS + (k)] = __builtin_amdgcn_s_memtime(); \
+        }                                                                                                                                   \
+    while (0)
+#define OC_STAMP_WALL(k)                                                                                                                    \
+    do                                                                                                                                      \
+        {                                                                                                                                   \
+            if ((threadIdx.x & 63) == 0 && cell < 4096) g_oc_prof[(static_cast<size_t>(cell) * OC_MAX_WAVES + (threadIdx.x >> 6)) * OC_PROF_WORDS + (k)] = wall_clock64(); \
+        }                                                                                                                                   \
+    while (0)
+#else
+#define OC_STAMP(k) \
+    do              \
+        {           \
+        }           \
+    while (0)
+#define OC_STAMP_WALL(k) \
+    do                   \
+        {                \
+        }                \
+    while (0)
+#endif
 
 struct OcFwdArgs
 {
@@ -63,6 +102,8 @@ struct OcCellArgs
     float* grid;        // n_prn * n_bins * effective (touched only when store_grid / accumulate)
     RowStat* rows;      // n_prn * n_bins
     RowStat* subrows;   // S > 1: n_prn * n_bins * S records of the sub-cells, merged into `rows` by the PRN's last arriver
+    RowStat* waverows;  // flavours without the second peak: n_prn * n_bins * S * OC_MAX_WAVES per-WAVE partial records (maximum, lowest arg-max, sum) -- a cell's waves leave
+                        // them and go; oc_rows_kernel, queued behind the cells, merges them in the order the in-kernel reduction used and forms the statistic
     int offset;         // first lag of the transform that enters the search (bit_transition_flag: effective; else 0)
     DevAcqResult* results;   // n_prn
     unsigned* arrivals;      // n_prn arrival counters (zero between launches): the last cell of a PRN forms its statistic
@@ -74,6 +115,14 @@ struct OcCellArgs
     unsigned dwell_count;
     float weight;  // GRID path: every |.|^2 is scaled before it is added / stored (pcps_tong_acquisition_cc.cc:243-249); 1 otherwise
     cf* z;  // decimation-in-time split (oc_subcell_dit_kernel / oc_combine_dit_kernel): the sub-cells' length-M transforms, n_prn * n_bins * N values
+    int cells_per_wg;   // oc_cell_kernel: a work-group carries out this many cells one after the other (slot, slot + gridDim / 8, ...): the staggered start of a
+                        // work-group's sixteen waves -- 3.5 of a cell's 21 us, profiles/oc_cell_annotated.txt -- is paid once per work-group instead of once per cell
+    int slots_per_xcd;  // prn_per * bin_per * S
+    int prefetch_next;    // the idle threads of stage 3 touch the next cell's bin spectrum (cells_per_wg > 1)
+    int stagger_groups;   // > 1: the work-groups of the launch's FIRST round (blockIdx < stagger_first) start in this many groups, stagger_ticks of the 100 MHz clock apart:
+    int stagger_ticks;    // all 256 compute units loading their operands in the same microseconds and transforming in the same microseconds leaves the L2 idle 60 % of
+    int stagger_first;    // the time and overrun the rest (7.4 us for 400 KB per unit, against 1.9 us when they come apart); every cell takes the same time, so
+                          // an offset given once stays for the whole launch (profiles/oc_cell_annotated.txt)
 };
 
 // x[k] for 0 <= k < n_in, else 0 -- as a load from a clamped index plus a select, not a branch around the load: the compiler turns the
@@ -99,7 +148,21 @@ __device__ __forceinline__ cf wipe_phasor(float f_hz, int n, double inv_fs)
 //   component form   one float component at a time (N * 8 bytes do not fit, N * 4 do): write x, read x, write y, read y
 //   phased form      whole complex values, a few rows per phase, two regions in turn; step p = "read phase p - 1, write phase p", one barrier per
 //                    step: the reads of a phase are in flight while the next phase is written, and no barrier separates the two exchanges
-template <class P>
+// every element of `v` "written" by an empty asm: ends the live range of whatever the registers held, without an instruction (oc_cell_kernel's pass loop)
+template <int R>
+__device__ __forceinline__ void fresh_values(cf (&v)[R])
+{
+    oc::static_for<R>([&](auto K) GSH_AI {
+        constexpr int k = decltype(K)::value;
+        float x, y;
+        asm volatile("" : "=v"(x), "=v"(y));
+        v[k] = cf{x, y};
+    });
+}
+
+// FRESH (oc_cell_kernel's pass loop): the destination registers are declared written (fresh_values) right in front of the first read that fills them -- not earlier:
+// the source registers die phase by phase, and both arrays whole do not fit the register file
+template <class P, bool FRESH = false>
 __device__ __forceinline__ void exchange1(const cf (&ra)[P::R1], cf (&rb)[P::R2], int t, unsigned char* lds_raw)
 {
     if constexpr (P::EX64)
@@ -107,11 +170,13 @@ __device__ __forceinline__ void exchange1(const cf (&ra)[P::R1], cf (&rb)[P::R2]
             cf* lds = reinterpret_cast<cf*>(lds_raw);
             oc::static_for<P::NP1>([&](auto PH) GSH_AI {
                 constexpr int p = decltype(PH)::value;
+                if constexpr (p == 1 && FRESH) fresh_values<P::R2>(rb);
                 if constexpr (p > 0)
                     if (t < P::T2) P::template ex1_read<(p > 0 ? p - 1 : 0)>(rb, t, lds);
                 if (t < P::T1) P::template ex1_write<p>(ra, t, lds);
                 __syncthreads();
             });
+            if constexpr (P::NP1 == 1 && FRESH) fresh_values<P::R2>(rb);
             if (t < P::T2) P::template ex1_read<P::NP1 - 1>(rb, t, lds);
         }
     else
@@ -119,6 +184,7 @@ __device__ __forceinline__ void exchange1(const cf (&ra)[P::R1], cf (&rb)[P::R2]
             float* lds = reinterpret_cast<float*>(lds_raw);
             if (t < P::T1) P::template ex1_write32<0>(ra, t, lds);
             __syncthreads();
+            if constexpr (FRESH) fresh_values<P::R2>(rb);
             if (t < P::T2) P::template ex1_read32<0>(rb, t, lds);
             __syncthreads();
             if (t < P::T1) P::template ex1_write32<1>(ra, t, lds);
@@ -127,7 +193,7 @@ __device__ __forceinline__ void exchange1(const cf (&ra)[P::R1], cf (&rb)[P::R2]
         }
 }
 
-template <class P>
+template <class P, bool FRESH = false>
 __device__ __forceinline__ void exchange2(const cf (&rb)[P::R2], cf (&rc)[P::R3], int t, unsigned char* lds_raw)
 {
     if constexpr (P::EX64)
@@ -137,11 +203,13 @@ __device__ __forceinline__ void exchange2(const cf (&rb)[P::R2], cf (&rc)[P::R3]
             cf* lds = reinterpret_cast<cf*>(lds_raw);
             oc::static_for<P::NP2>([&](auto PH) GSH_AI {
                 constexpr int p = decltype(PH)::value;
+                if constexpr (p == 1 && FRESH) fresh_values<P::R3>(rc);
                 if constexpr (p > 0)
                     if (t < P::T3) P::template ex2_read<(p > 0 ? p - 1 : 0)>(rc, t, lds);
                 if (t < P::T2) P::template ex2_write<p>(rb, t, lds);
                 __syncthreads();
             });
+            if constexpr (P::NP2 == 1 && FRESH) fresh_values<P::R3>(rc);
             if (t < P::T3) P::template ex2_read<P::NP2 - 1>(rc, t, lds);
         }
     else
@@ -150,6 +218,7 @@ __device__ __forceinline__ void exchange2(const cf (&rb)[P::R2], cf (&rc)[P::R3]
             __syncthreads();  // every exchange-1 read has been issued and consumed
             if (t < P::T2) P::template ex2_write32<0>(rb, t, lds);
             __syncthreads();
+            if constexpr (FRESH) fresh_values<P::R3>(rc);
             if (t < P::T3) P::template ex2_read32<0>(rc, t, lds);
             __syncthreads();
             if (t < P::T2) P::template ex2_write32<1>(rb, t, lds);
@@ -303,6 +372,72 @@ __device__ __forceinline__ void argmax_merge(float& v, unsigned& i, float ov, un
         }
 }
 
+// ---- the bin scan of acq.cc:417-426 / :463-474 and the statistic of :428-445 / :516 for one PRN, by ONE wave (t < 64): gmax starts at 0 and only a strictly
+// larger row maximum replaces it, so ties keep the lowest bin.  row_of(d): the row's record (maximum, lowest arg-max, sum, second peak).
+template <int S, class RowOf>
+__device__ __forceinline__ void prn_statistic(const OcCellArgs& a, int prn, int t, RowStat* rs, RowOf row_of)
+{
+    float gmax = 0.0f;
+    unsigned gbin = 0xFFFFFFFFu, gtau = 0u;
+    for (int d = t; d < a.n_bins; d += 64)
+        {
+            const RowStat rw = row_of(d);
+            if constexpr (S > 1) rs[d] = rw;
+            if (rw.maxv > gmax)
+                {
+                    gmax = rw.maxv;
+                    gbin = static_cast<unsigned>(d);
+                    gtau = rw.idx;
+                }
+        }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        {
+            const float ov = __shfl_down(gmax, off, 64);
+            const unsigned ob = __shfl_down(gbin, off, 64);
+            const unsigned ot = __shfl_down(gtau, off, 64);
+            if (ov > gmax || (ov == gmax && ob < gbin))
+                {
+                    gmax = ov;
+                    gbin = ob;
+                    gtau = ot;
+                }
+        }
+    if (t == 0)
+        {
+            if (gbin == 0xFFFFFFFFu)  // every row maximum was 0: the reference leaves bin 0 / index 0
+                {
+                    gbin = 0u;
+                    gtau = 0u;
+                }
+            DevAcqResult out;
+            out.index_time = gtau;
+            out.index_doppler = gbin;
+            out.peak = gmax;
+            out.input_power = 0.0f;
+            out.second_peak = 0.0f;
+            out.test_statistics = 0.0f;
+            if (a.use_cfar)
+                {
+                    // acq.cc:429-431: power of the bin half a grid away, / effective / 2 / dwells
+                    const unsigned opp = (gbin + static_cast<unsigned>(a.n_bins) / 2u) % static_cast<unsigned>(a.n_bins);
+                    const float per_sample = row_of(static_cast<int>(opp)).sum / static_cast<float>(static_cast<unsigned>(a.effective));
+                    const float power = static_cast<float>(static_cast<double>(per_sample) / 2.0 / static_cast<double>(a.dwell_count));
+                    out.input_power = power;
+                    out.test_statistics = (power < 1.1920928955078125e-07f) ? 0.0f : gmax / power;  // acq.cc:438-445
+                }
+            else
+                {
+                    // (S > 1: no sub-cell sees the whole row; oc_second_peak_kernel, queued right behind this launch, scans the stored winning
+                    // row and fills in second_peak / test_statistics)
+                    const float second_pk = (S == 1) ? row_of(static_cast<int>(gbin)).second : 0.0f;
+                    out.second_peak = second_pk;
+                    out.test_statistics = (S == 1) ? gmax / second_pk : 0.0f;  // acq.cc:516
+                }
+            a.results[prn] = out;
+        }
+}
+
 // ---- publish a row record; the LAST cell of its PRN to arrive forms the PRN's statistic (acq.cc:409-519).  Called by every thread of the work-group;
 // `sum` / `second` are thread 0's.  S > 1: the record is one of the row's S sub-cell records (merged by the last arriver); S == 1: the whole row's.
 // Placement-independent hand-off: plain store -> agent-scope release -> relaxed ticket; the last arriver acquires.
@@ -331,8 +466,6 @@ __device__ __forceinline__ void publish_row(const OcCellArgs& a, int prn, int ce
     if (s_i[0] == 0u || t >= 64) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     {
-        // bin scan of acq.cc:417-426 / :463-474 over one wave: gmax starts at 0 and only a strictly larger row
-        // maximum replaces it, so ties keep the lowest bin
         RowStat* rs = a.rows + static_cast<size_t>(prn) * a.n_bins;
         // S > 1: a row is the union of its S sub-cells' lags -- maximum with the lowest index among equals, sums added; the merged record is
         // also what gsh_acq_read_row_peaks hands out
@@ -352,67 +485,52 @@ __device__ __forceinline__ void publish_row(const OcCellArgs& a, int prn, int ce
                     return m;
                 }
         };
-        float gmax = 0.0f;
-        unsigned gbin = 0xFFFFFFFFu, gtau = 0u;
-        for (int d = t; d < a.n_bins; d += 64)
-            {
-                const RowStat rw = row_of(d);
-                if constexpr (S > 1) rs[d] = rw;
-                if (rw.maxv > gmax)
-                    {
-                        gmax = rw.maxv;
-                        gbin = static_cast<unsigned>(d);
-                        gtau = rw.idx;
-                    }
-            }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1)
-            {
-                const float ov = __shfl_down(gmax, off, 64);
-                const unsigned ob = __shfl_down(gbin, off, 64);
-                const unsigned ot = __shfl_down(gtau, off, 64);
-                if (ov > gmax || (ov == gmax && ob < gbin))
-                    {
-                        gmax = ov;
-                        gbin = ob;
-                        gtau = ot;
-                    }
-            }
-        if (t == 0)
-            {
-                if (gbin == 0xFFFFFFFFu)  // every row maximum was 0: the reference leaves bin 0 / index 0
-                    {
-                        gbin = 0u;
-                        gtau = 0u;
-                    }
-                DevAcqResult out;
-                out.index_time = gtau;
-                out.index_doppler = gbin;
-                out.peak = gmax;
-                out.input_power = 0.0f;
-                out.second_peak = 0.0f;
-                out.test_statistics = 0.0f;
-                if (a.use_cfar)
-                    {
-                        // acq.cc:429-431: power of the bin half a grid away, / effective / 2 / dwells
-                        const unsigned opp = (gbin + static_cast<unsigned>(a.n_bins) / 2u) % static_cast<unsigned>(a.n_bins);
-                        const float per_sample = row_of(static_cast<int>(opp)).sum / static_cast<float>(static_cast<unsigned>(a.effective));
-                        const float power = static_cast<float>(static_cast<double>(per_sample) / 2.0 / static_cast<double>(a.dwell_count));
-                        out.input_power = power;
-                        out.test_statistics = (power < 1.1920928955078125e-07f) ? 0.0f : gmax / power;  // acq.cc:438-445
-                    }
-                else
-                    {
-                        // (S > 1: no sub-cell sees the whole row; oc_second_peak_kernel, queued right behind this launch, scans the stored winning
-                        // row and fills in second_peak / test_statistics)
-                        const float second_pk = (S == 1) ? row_of(static_cast<int>(gbin)).second : 0.0f;
-                        out.second_peak = second_pk;
-                        out.test_statistics = (S == 1) ? gmax / second_pk : 0.0f;  // acq.cc:516
-                    }
-                a.results[prn] = out;
-                __hip_atomic_store(&a.arrivals[prn], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
-            }
+        prn_statistic<S>(a, prn, t, rs, row_of);
+        if (t == 0) __hip_atomic_store(&a.arrivals[prn], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
     }
+}
+
+// ---- the cells WITHOUT a hand-off (round 5; every flavour that does not want the second peak).  Until round 4 every cell ended with: barrier, thread 0 merges the
+// sixteen waves' partial records, stores the row, waits for the store, agent-scope release, a ticket from an atomic counter, barrier -- 4 of a cell's 21 us with the
+// whole compute unit waiting (profiles/oc_cell_annotated.txt), 1312 times per batch, to save one small launch.  Now a wave leaves its partial record (maximum, lowest
+// arg-max, sum) in `waverows` and is done; this kernel, one wave per PRN, queued behind the cells, merges the partials -- waves in ascending order, the order of the
+// reduction it replaces, so every sum is the same float -- and runs the bin scan and the statistic.  n_waves: waves per cell work-group; s_rt: sub-cells per row.
+__global__ __launch_bounds__(64) void oc_rows_kernel(OcCellArgs a, int n_waves, int s_rt)
+{
+    const int prn = blockIdx.x, t = threadIdx.x;
+    RowStat* rs = a.rows + static_cast<size_t>(prn) * a.n_bins;
+    // sub-cell q of row d: the waves' partials merged in ascending wave order (thread 0 of the cell used to take its own wave's and add waves 1, 2, ... to it)
+    auto sub_of = [&](int d, int q) GSH_AI -> RowStat {
+        const RowStat* __restrict__ w = a.waverows + ((static_cast<size_t>(prn) * a.n_bins + d) * s_rt + q) * OC_MAX_WAVES;
+        RowStat m = w[0];
+        for (int k = 1; k < n_waves; k++)
+            {
+                const RowStat o = w[k];
+                argmax_merge(m.maxv, m.idx, o.maxv, o.idx);
+                m.sum += o.sum;
+            }
+        m.second = 0.0f;
+        return m;
+    };
+    // a row is the union of its sub-cells' lags: maximum with the lowest index among equals, sums added in ascending sub-cell order
+    auto row_of = [&](int d) GSH_AI -> RowStat {
+        RowStat row = sub_of(d, 0);
+        for (int q = 1; q < s_rt; q++)
+            {
+                const RowStat m = sub_of(d, q);
+                argmax_merge(row.maxv, row.idx, m.maxv, m.idx);
+                row.sum += m.sum;
+            }
+        return row;
+    };
+    for (int d = t; d < a.n_bins; d += 64)  // what gsh_acq_read_row_peaks (and, on split plans, the sub-cell records' readers) hand out
+        {
+            if (s_rt > 1)
+                for (int q = 0; q < s_rt; q++) a.subrows[(static_cast<size_t>(prn) * a.n_bins + d) * s_rt + q] = sub_of(d, q);
+            rs[d] = row_of(d);
+        }
+    // (the statistic forms its rows from the partials again rather than reading back what other lanes have just stored)
+    prn_statistic<1>(a, prn, t, rs, row_of);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -436,19 +554,45 @@ __global__ __launch_bounds__(P::THREADS) void oc_cell_kernel(OcCellArgs a)
     // ---- which cell: block b runs on XCD b % 8; each XCD owns a (PRN range) x (bin range) tile and walks it
     // PRN-fastest, so the cells in flight on one XCD share a few code spectra and a few bin spectra in its L2
     // (S > 1: the S sub-cells of a cell follow each other on the same XCD -- they read the same two spectra)
-    const int xcd = static_cast<int>(blockIdx.x & 7u), slot_r = static_cast<int>(blockIdx.x >> 3);
+    const int xcd = static_cast<int>(blockIdx.x & 7u);
+    if (a.stagger_groups > 1 && static_cast<int>(blockIdx.x) < a.stagger_first)  // uniform over the work-group
+        {
+            const unsigned long long until = wall_clock64() + static_cast<unsigned long long>((static_cast<int>(blockIdx.x >> 3) % a.stagger_groups) * a.stagger_ticks);
+            while (wall_clock64() < until) __builtin_amdgcn_s_sleep(8);
+        }
+    const int passes = SECOND ? 1 : a.cells_per_wg;  // (the peak-ratio flavours end in a hand-off that not every thread returns from: one cell per work-group)
+#pragma clang loop unroll(disable)
+    for (int pass = 0; pass < passes; pass++)
+    {
+    // (the thread index passes through an empty asm in every pass: whatever is derived from it -- twiddle seeds, LDS addresses -- is formed afresh, as in a new work-group,
+    // instead of being kept in registers across the passes: the cell needs every one of its 128 registers)
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    const int slot_r = static_cast<int>(blockIdx.x >> 3) + pass * static_cast<int>(gridDim.x >> 3);
+    if (slot_r >= a.slots_per_xcd) break;  // uniform over the work-group
     const int slot = slot_r / S, r = slot_r - slot * S;
     const int xp_i = xcd % a.xp, xb_i = xcd / a.xp;
     const int bl = slot / a.prn_per, pl = slot - bl * a.prn_per;
     const int prn = xp_i * a.prn_per + pl, bin = xb_i * a.bin_per + bl;
-    if (prn >= a.n_prn || bin >= a.n_bins) return;  // uniform over the work-group
+    if (prn >= a.n_prn || bin >= a.n_bins) continue;  // uniform over the work-group
     const int cell = prn * a.n_bins + bin;
-    const int t = threadIdx.x;
+    if (pass > 0) __syncthreads();  // the previous cell's last reads of the exchange buffer have been issued and consumed before this cell's first writes
+    OC_STAMP_WALL(8);
+    OC_STAMP(0);
 
     cf ra[P::R1], rb[P::R2], rc[P::R3];
+    // The three stages' registers are written under `t < T1 / T2 / T3`; inside the pass loop a lane that does not take part keeps "whatever the register held", which
+    // the register allocator reads as: the previous pass's values stay live round the back edge -- 180 registers nobody needs, i.e. scratch.  An empty asm that
+    // OUTPUTS every element, placed right in front of the stage that writes them, ends those live ranges without an instruction (zero-filling them at the top of the
+    // pass did too, and starved the operand loads of registers: 7.4 us instead of 1.9 for the 50 loads of a thread).
+    if constexpr (!SECOND) fresh_values<P::R1>(ra);
     if (t < P::T1)
         {
+#ifdef GSH_OC_PROFILE_SAME_BIN  /* (timing experiment only: every cell reads the spectrum of bin 0 / bin & 7 -- the results are wrong, the loads hit L2) */
+            const cf* __restrict__ X = a.spectra + static_cast<size_t>(bin & (GSH_OC_PROFILE_SAME_BIN)) * N + t;
+#else
             const cf* __restrict__ X = a.spectra + static_cast<size_t>(bin) * N + t;
+#endif
             const cf* __restrict__ C = a.codes + static_cast<size_t>(prn) * N + t;
             if constexpr (S == 1)
                 {
@@ -466,6 +610,10 @@ __global__ __launch_bounds__(P::THREADS) void oc_cell_kernel(OcCellArgs a)
                         ra[n1] = oc::cmul_conj(xv[n1], cv[n1]);
                     });
                     __builtin_amdgcn_sched_group_barrier(0x2, 8 * P::R1, 0);   // ... then the products
+#ifdef GSH_OC_PROFILE
+                    asm volatile("" ::"v"(ra[P::R1 - 1].x), "v"(ra[0].x));  // (the stamp below must not be scheduled above the last product)
+#endif
+                    OC_STAMP(1);
                 }
             else
                 {
@@ -500,10 +648,26 @@ __global__ __launch_bounds__(P::THREADS) void oc_cell_kernel(OcCellArgs a)
                         }
                 }
             P::stage1(ra, t);
+#ifdef GSH_OC_PROFILE
+            asm volatile("" ::"v"(ra[P::R1 - 1].x), "v"(ra[0].x));
+#endif
         }
-    exchange1<P>(ra, rb, t, lds);
+    OC_STAMP(2);
+    exchange1<P, !SECOND>(ra, rb, t, lds);
+#ifdef GSH_OC_PROFILE
+    asm volatile("" ::"v"(rb[P::R2 - 1].x), "v"(rb[0].x));
+#endif
+    OC_STAMP(3);
     if (t < P::T2) P::stage2(rb, t);
-    exchange2<P>(rb, rc, t, lds);
+#ifdef GSH_OC_PROFILE
+    asm volatile("" ::"v"(rb[P::R2 - 1].x), "v"(rb[0].x));
+#endif
+    OC_STAMP(4);
+    exchange2<P, !SECOND>(rb, rc, t, lds);
+#ifdef GSH_OC_PROFILE
+    asm volatile("" ::"v"(rc[P::R3 - 1].x), "v"(rc[0].x));
+#endif
+    OC_STAMP(5);
 
     // SECOND: the row's magnitudes are parked in the exchange buffer (N floats fit: it held N complex values a phase at a time) until the row's
     // peak is known; every exchange-2 read of every thread must have landed before the first magnitude overwrites it
@@ -514,6 +678,34 @@ __global__ __launch_bounds__(P::THREADS) void oc_cell_kernel(OcCellArgs a)
     // tau >= offset (offset + effective == N; offset != 0 only for bit_transition_flag, acq.cc:544)
     float best = -1.0f, sum = 0.0f;
     unsigned at = 0xFFFFFFFFu;
+    if constexpr (!SECOND && !GRID && S == 1 && P::T3 + 64 <= P::THREADS)
+        {
+            // The threads that have no stage-3 butterfly (radix 40: 375 of them) touch the bin spectrum of the work-group's NEXT cell, one word per 64 bytes: an XCD's
+            // 4 MB of L2 hold a round's 8 bin spectra and 4 code spectra, not the search's 41 -- every new bin comes over the fabric (2.4 of the operand phase's 7.4 us,
+            // measured by letting every cell read bin 0: profiles/oc_cell_annotated.txt), and here it comes while the other threads transform.
+            if (t >= P::T3 && a.prefetch_next)
+                {
+                    const int nslot_r = slot_r + static_cast<int>(gridDim.x >> 3);
+                    if (pass + 1 < passes && nslot_r < a.slots_per_xcd)
+                        {
+                            const int nbin = xb_i * a.bin_per + (nslot_r / S) / a.prn_per;
+                            if (nbin < a.n_bins && nbin != bin)
+                                {
+                                    // (the prn_per work-groups that go to that bin next take every prn_per-th line each)
+                                    constexpr int IDLE = P::THREADS - P::T3, LINES = N * 8 / 64;
+                                    const int share = a.prn_per > 4 ? 4 : a.prn_per, mine = (nslot_r / S) % share;
+                                    const float* __restrict__ base = reinterpret_cast<const float*>(a.spectra + static_cast<size_t>(nbin) * N);
+                                    float acc = 0.0f;
+                                    constexpr int PER = (LINES + IDLE - 1) / IDLE;  // enough for share == 1; fewer lines each when the bin is shared
+                                    oc::static_for<PER>([&](auto K) GSH_AI {
+                                        const int line = ((t - P::T3) + decltype(K)::value * IDLE) * share + mine;
+                                        if (decltype(K)::value * IDLE * share < LINES) acc += base[static_cast<size_t>(line < LINES ? line : mine) * 16];
+                                    });
+                                    asm volatile("" ::"v"(acc));  // (the loads are real: their data is waited for, by threads that have nothing else to do)
+                                }
+                        }
+                }
+        }
     if (t < P::T3)
         {
             P::stage3(rc);
@@ -581,6 +773,26 @@ __global__ __launch_bounds__(P::THREADS) void oc_cell_kernel(OcCellArgs a)
     const int wave = t >> 6;
     constexpr int n_waves = P::THREADS / 64;
     static_assert(n_waves <= OC_MAX_WAVES, "work-group too large for the reduction scratch");
+#ifdef GSH_OC_PROFILE
+    asm volatile("" ::"v"(best), "v"(sum));
+#endif
+    OC_STAMP(6);
+    if constexpr (!SECOND)
+        {
+            // the wave's partial record, and the wave is done: no barrier, no hand-off -- oc_rows_kernel, queued behind this launch, merges and decides
+            if ((t & 63) == 0)
+                {
+                    RowStat rec;
+                    rec.maxv = best;
+                    rec.idx = at;
+                    rec.sum = sum;
+                    rec.second = 0.0f;
+                    a.waverows[(static_cast<size_t>(cell) * S + r) * OC_MAX_WAVES + wave] = rec;
+                }
+            OC_STAMP(7);
+            OC_STAMP_WALL(9);
+            continue;
+        }
     if ((t & 63) == 0)
         {
             s_v[wave] = best;
@@ -633,6 +845,9 @@ __global__ __launch_bounds__(P::THREADS) void oc_cell_kernel(OcCellArgs a)
         }
 
     publish_row<S>(a, prn, cell, r, s_peak, s_tau, sum, second, s_i);
+    OC_STAMP(7);
+    OC_STAMP_WALL(9);
+    }  // pass
 }
 
 // ---- N = S * M, decimation in time (round 3).  The sub-cells of oc_cell_kernel<P, S> (decimation in frequency) each read the WHOLE product spectrum --
@@ -841,11 +1056,37 @@ int launch_forward_split(const OcFwdArgs& a, int batch, hipStream_t s)
     return GSH_OK;
 }
 
-template <class P, int S>
-int launch_cells(const OcCellArgs& a, int n_blocks, hipStream_t s)
+// GSH_OC_CELLS_PER_WG in the environment: cells one work-group of the cell kernel carries out in turn (flavours without the in-kernel hand-off)
+int onchip_cells_per_wg()
 {
+    static const int v = [] {
+        const char* e = std::getenv("GSH_OC_CELLS_PER_WG");
+        return e != nullptr ? std::max(1, std::atoi(e)) : GSH_OC_CELLS_PER_WG_DEFAULT;
+    }();
+    return v;
+}
+
+template <class P, int S>
+int launch_cells(const OcCellArgs& a_in, int n_blocks, hipStream_t s)
+{
+    OcCellArgs a = a_in;
+    a.slots_per_xcd = a.prn_per * a.bin_per * S;
+    if (!((S == 1) && a.want_second))
+        {
+            // work-groups per XCD: an XCD's 32 compute units take one of these work-groups each.  Up to GSH_OC_WG_PER_XCD (28) of them are occupied for the whole launch --
+            // four are left to whatever else is in flight: with two batches in flight the other batch's forward transforms (41 work-groups) run there instead of waiting
+            // for a whole batch of cells (32 per XCD: 138 us alone but 112 us pipelined; 28: 139 / 99) -- and the cells are dealt to them in passes
+            static const int wg_per_xcd = [] { const char* e = std::getenv("GSH_OC_WG_PER_XCD"); return e != nullptr ? std::max(1, std::atoi(e)) : 28; }();
+            a.cells_per_wg = std::min(onchip_cells_per_wg(), std::max(1, a.slots_per_xcd));
+            int per_xcd = (a.slots_per_xcd + a.cells_per_wg - 1) / a.cells_per_wg;
+            per_xcd = std::max(per_xcd, std::min(wg_per_xcd, a.slots_per_xcd));
+            a.cells_per_wg = (a.slots_per_xcd + per_xcd - 1) / per_xcd;
+            n_blocks = 8 * per_xcd;
+        }
     const bool grid = a.accumulate || a.store_grid;
     const bool off = a.offset != 0;  // the upper-half (bit_transition_flag) searches run the GRID flavour whether or not a grid is kept
+    const bool in_kernel_statistic = (S == 1) && a.want_second;  // the second peak of a row needs the row's peak inside the cell: those flavours keep the hand-off
+    if (!in_kernel_statistic) GSH_REQUIRE(a.waverows != nullptr, "on-chip cells without the per-wave record buffer");
     if constexpr (S == 1)
         {
             if (off && a.want_second)
@@ -860,6 +1101,11 @@ int launch_cells(const OcCellArgs& a, int n_blocks, hipStream_t s)
                 hipLaunchKernelGGL((oc_cell_kernel<P, 1, false, true, false>), dim3(n_blocks), dim3(P::THREADS), 0, s, a);
             else
                 hipLaunchKernelGGL((oc_cell_kernel<P, 1, false, false, false>), dim3(n_blocks), dim3(P::THREADS), 0, s, a);
+            if (!in_kernel_statistic)
+                {
+                    GSH_HIP(hipGetLastError());
+                    hipLaunchKernelGGL(oc_rows_kernel, dim3(a.n_prn), dim3(64), 0, s, a, P::THREADS / 64, 1);
+                }
         }
     else
         {
@@ -871,6 +1117,8 @@ int launch_cells(const OcCellArgs& a, int n_blocks, hipStream_t s)
                 hipLaunchKernelGGL((oc_cell_kernel<P, S, true, false, false>), dim3(n_blocks), dim3(P::THREADS), 0, s, a);
             else
                 hipLaunchKernelGGL((oc_cell_kernel<P, S, false, false, false>), dim3(n_blocks), dim3(P::THREADS), 0, s, a);
+            GSH_HIP(hipGetLastError());
+            hipLaunchKernelGGL(oc_rows_kernel, dim3(a.n_prn), dim3(64), 0, s, a, P::THREADS / 64, S);
             if (a.want_second)
                 {
                     GSH_HIP(hipGetLastError());
@@ -981,7 +1229,7 @@ int onchip_forward(int n, const float2* src, size_t src_stride, int n_in, int pl
 
 int onchip_correlate(int n, const float2* spectra, const float2* codes, float* grid, RowStat* rows, RowStat* subrows, DevAcqResult* results,
     unsigned* arrivals, int n_prn, int n_bins, int offset, int effective, int accumulate, int store_grid, int samples_per_chip, int use_cfar,
-    unsigned dwell_count, float weight, hipStream_t s, float2* z)
+    unsigned dwell_count, float weight, hipStream_t s, float2* z, RowStat* waverows)
 {
     if (n_prn <= 0 || n_bins <= 0) return GSH_OK;
     GSH_REQUIRE((offset == 0 && effective == n) || (2 * offset == n && effective == offset), "lags [%d, %d + %d) of a %d-point transform: neither all of it nor its upper half", offset, offset, effective, n);
@@ -991,6 +1239,7 @@ int onchip_correlate(int n, const float2* spectra, const float2* codes, float* g
     a.grid = grid;
     a.rows = rows;
     a.subrows = subrows;
+    a.waverows = waverows;
     a.z = reinterpret_cast<cf*>(z);
     a.offset = offset;
     a.results = results;
@@ -1012,6 +1261,22 @@ int onchip_correlate(int n, const float2* spectra, const float2* codes, float* g
     a.dwell_count = dwell_count ? dwell_count : 1u;
     a.weight = weight;
     const int n_blocks = 8 * a.prn_per * a.bin_per;
+    a.cells_per_wg = 1;
+    a.slots_per_xcd = a.prn_per * a.bin_per;  // (x S in launch_cells)
+    {
+        // GSH_OC_STAGGER="groups,ticks" (A/B): see OcCellArgs::stagger_groups
+        static const int groups = [] { const char* e = std::getenv("GSH_OC_STAGGER"); return e != nullptr ? std::atoi(e) : GSH_OC_STAGGER_GROUPS_DEFAULT; }();
+        static const int ticks = [] {
+            const char* e = std::getenv("GSH_OC_STAGGER");
+            const char* c = e != nullptr ? std::strchr(e, ',') : nullptr;
+            return c != nullptr ? std::atoi(c + 1) : GSH_OC_STAGGER_TICKS_DEFAULT;
+        }();
+        static const int prefetch = [] { const char* e = std::getenv("GSH_OC_PREFETCH"); return e != nullptr ? std::atoi(e) : 1; }();
+        a.prefetch_next = prefetch;
+        a.stagger_groups = groups;
+        a.stagger_ticks = ticks;
+        a.stagger_first = 256;  // one work-group per compute unit in the first round
+    }
 #define GSH_OC_CASE(r1, r2, r3) \
     if (n == (r1) * (r2) * (r3)) return launch_cells<oc::Plan<r1, r2, r3>, 1>(a, n_blocks, s);
     GSH_OC_PLANS(GSH_OC_CASE)
@@ -1026,3 +1291,12 @@ int onchip_correlate(int n, const float2* spectra, const float2* codes, float* g
 }
 
 }  // namespace gsh
+
+#ifdef GSH_OC_PROFILE
+extern "C" int gsh_debug_oc_profile(unsigned long long* out, size_t n_words)
+{
+    const size_t all = sizeof(gsh::g_oc_prof) / sizeof(unsigned long long);
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(gsh::g_oc_prof), sizeof(unsigned long long) * (n_words < all ? n_words : all), 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#endif

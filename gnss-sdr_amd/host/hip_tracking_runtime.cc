@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <thread>
+#include <sys/prctl.h>
 
 namespace
 {
@@ -29,6 +30,8 @@ Hip_Tracking_Runtime::Hip_Tracking_Runtime(int device, std::shared_ptr<Hip_Sampl
     if (const char* e = std::getenv("GSH_TRK_LAUNCH_AHEAD")) d_launch_ahead = (std::atoi(e) != 0);
     if (const char* e = std::getenv("GSH_TRK_LIVE")) d_live = (std::atoi(e) != 0);
     if (const char* e = std::getenv("GSH_TRK_LIVE_SPIN_US")) d_spin_us = std::max(0, std::atoi(e));
+    if (const char* e = std::getenv("GSH_TRK_LIVE_SLEEP_US")) d_sleep_us = std::max(1, std::atoi(e));
+    if (const char* e = std::getenv("GSH_TRK_TIMER_SLACK_NS")) d_timer_slack_ns = std::max(0, std::atoi(e));
     if (const char* e = std::getenv("GSH_TRK_PUSH_TRY")) d_push_try = (std::atoi(e) != 0);
     if (const char* e = std::getenv("GSH_TRK_PUSH_BATCH")) d_push_batch = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("GSH_TRK_PUSH_SPARE_SLOWEST")) d_push_spare_slowest = (std::atoi(e) != 0);
@@ -577,7 +580,17 @@ int Hip_Tracking_Runtime::take_live(Slot& S, uint64_t limit_end, int max_records
                     // (start / stop of this channel wait for the slot's lock with the group's handle held, and while they wait no sibling can make sure of a residency:
                     // the lock is not kept across the sleep.  Whatever changed meanwhile is looked at again at the top of the loop.)
                     tl.unlock();
-                    std::this_thread::sleep_for(std::chrono::microseconds(20));
+                    if (d_timer_slack_ns > 0)
+                        {
+                            // a 20 us sleep with the default 50 us timer slack is a 70 us sleep -- longer than the whole wait for a record.  Once per block thread.
+                            static thread_local bool slack_set = false;
+                            if (!slack_set)
+                                {
+                                    (void)prctl(PR_SET_TIMERSLACK, static_cast<unsigned long>(d_timer_slack_ns), 0, 0, 0);
+                                    slack_set = true;
+                                }
+                        }
+                    std::this_thread::sleep_for(std::chrono::microseconds(d_sleep_us));
                     tl.lock();
                 }
             else

@@ -182,6 +182,8 @@ private:
     int d_push_batch{2};                    // live mode: appends smaller than this many code periods wait for more (while the device has work in hand)
     int d_spin_us{40};                 // how long a block polls for a record before it starts sleeping between looks
     std::atomic<int64_t> d_record_timeout_ns{1000000000};
+    int d_sleep_us{20};                // ... and how long each of those sleeps is asked to be
+    int d_timer_slack_ns{0};           // > 0: the block threads' timer slack while they wait for records (the kernel's default, 50 us, is longer than the wait itself); 0: left alone
     std::atomic<uint64_t> d_min_vlen{0};  // shortest code period (samples) among the loop configurations attached so far
     std::atomic<size_t> d_n_slots{0};  // slots ever created (d_slots never shrinks and is reserved up front: readers without the lock index below this)
     std::atomic<uint64_t> d_live_records{0}, d_live_residencies{0}, d_record_wait_ns{0}, d_record_waits{0};

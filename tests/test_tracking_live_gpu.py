@@ -309,7 +309,7 @@ def test_ring_destroyed_under_a_live_residency(gpu):
     prns, dops, starts, total, x8, xf = _scenario(epochs)
     prns, dops, starts = prns[:2], dops[:2], starts[:2]      # the two satellites that are there
     rec_flat, done_flat = _flat_run(gpu, prns, dops, starts, xf, epochs)
-    ring = SampleStream(40 * N + 7, 2 * N, device=gpu)
+    ring = SampleStream(200 * N + 7, 2 * N, device=gpu)
     live = _loop(gpu, KW, n_channels=2)
     live.set_stream_ring(ring)
     for ch in range(2):
@@ -331,7 +331,7 @@ def test_ring_destroyed_under_a_live_residency(gpu):
     nxt = [live.live_take(ch, 1)[2] for ch in range(2)]
     assert all(len(got[ch]) >= 150 for ch in range(2)) and lost == [False, False]
     # a new ring where the slowest channel stands; the handle goes on from its own state
-    ring2 = SampleStream(40 * N + 7, 2 * N, device=gpu)
+    ring2 = SampleStream(200 * N + 7, 2 * N, device=gpu)
     at = min(nxt)
     ring2.seek(at)
     live.set_stream_ring(ring2)
