@@ -560,7 +560,11 @@ __global__ __launch_bounds__(P::THREADS) void oc_cell_kernel(OcCellArgs a)
             const unsigned long long until = wall_clock64() + static_cast<unsigned long long>((static_cast<int>(blockIdx.x >> 3) % a.stagger_groups) * a.stagger_ticks);
             while (wall_clock64() < until) __builtin_amdgcn_s_sleep(8);
         }
-    const int passes = SECOND ? 1 : a.cells_per_wg;  // (the peak-ratio flavours end in a hand-off that not every thread returns from: one cell per work-group)
+    // several cells per work-group: where a work-group has its compute unit to itself (the plans with the large exchange buffer or 1 024 threads -- the same ones
+    // that use the phased exchanges); the small plans keep several work-groups resident per unit, whose starts and ends overlap anyway, and their registers for occupancy.
+    // (The peak-ratio flavours end in a hand-off that not every thread returns from: one cell per work-group.)
+    constexpr bool PERSIST = !SECOND && P::EX64;
+    const int passes = PERSIST ? a.cells_per_wg : 1;
 #pragma clang loop unroll(disable)
     for (int pass = 0; pass < passes; pass++)
     {
@@ -585,7 +589,7 @@ __global__ __launch_bounds__(P::THREADS) void oc_cell_kernel(OcCellArgs a)
     // the register allocator reads as: the previous pass's values stay live round the back edge -- 180 registers nobody needs, i.e. scratch.  An empty asm that
     // OUTPUTS every element, placed right in front of the stage that writes them, ends those live ranges without an instruction (zero-filling them at the top of the
     // pass did too, and starved the operand loads of registers: 7.4 us instead of 1.9 for the 50 loads of a thread).
-    if constexpr (!SECOND) fresh_values<P::R1>(ra);
+    if constexpr (PERSIST) fresh_values<P::R1>(ra);
     if (t < P::T1)
         {
 #ifdef GSH_OC_PROFILE_SAME_BIN  /* (timing experiment only: every cell reads the spectrum of bin 0 / bin & 7 -- the results are wrong, the loads hit L2) */
@@ -653,7 +657,7 @@ __global__ __launch_bounds__(P::THREADS) void oc_cell_kernel(OcCellArgs a)
 #endif
         }
     OC_STAMP(2);
-    exchange1<P, !SECOND>(ra, rb, t, lds);
+    exchange1<P, PERSIST>(ra, rb, t, lds);
 #ifdef GSH_OC_PROFILE
     asm volatile("" ::"v"(rb[P::R2 - 1].x), "v"(rb[0].x));
 #endif
@@ -663,7 +667,7 @@ __global__ __launch_bounds__(P::THREADS) void oc_cell_kernel(OcCellArgs a)
     asm volatile("" ::"v"(rb[P::R2 - 1].x), "v"(rb[0].x));
 #endif
     OC_STAMP(4);
-    exchange2<P, !SECOND>(rb, rc, t, lds);
+    exchange2<P, PERSIST>(rb, rc, t, lds);
 #ifdef GSH_OC_PROFILE
     asm volatile("" ::"v"(rc[P::R3 - 1].x), "v"(rc[0].x));
 #endif
@@ -678,7 +682,7 @@ __global__ __launch_bounds__(P::THREADS) void oc_cell_kernel(OcCellArgs a)
     // tau >= offset (offset + effective == N; offset != 0 only for bit_transition_flag, acq.cc:544)
     float best = -1.0f, sum = 0.0f;
     unsigned at = 0xFFFFFFFFu;
-    if constexpr (!SECOND && !GRID && S == 1 && P::T3 + 64 <= P::THREADS)
+    if constexpr (PERSIST && !GRID && S == 1 && P::T3 + 64 <= P::THREADS)
         {
             // The threads that have no stage-3 butterfly (radix 40: 375 of them) touch the bin spectrum of the work-group's NEXT cell, one word per 64 bytes: an XCD's
             // 4 MB of L2 hold a round's 8 bin spectra and 4 code spectra, not the search's 41 -- every new bin comes over the fabric (2.4 of the operand phase's 7.4 us,
@@ -1071,7 +1075,7 @@ int launch_cells(const OcCellArgs& a_in, int n_blocks, hipStream_t s)
 {
     OcCellArgs a = a_in;
     a.slots_per_xcd = a.prn_per * a.bin_per * S;
-    if (!((S == 1) && a.want_second))
+    if (!((S == 1) && a.want_second) && P::EX64)
         {
             // work-groups per XCD: an XCD's 32 compute units take one of these work-groups each.  Up to GSH_OC_WG_PER_XCD (28) of them are occupied for the whole launch --
             // four are left to whatever else is in flight: with two batches in flight the other batch's forward transforms (41 work-groups) run there instead of waiting

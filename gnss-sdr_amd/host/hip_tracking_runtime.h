@@ -183,7 +183,12 @@ private:
     int d_spin_us{40};                 // how long a block polls for a record before it starts sleeping between looks
     std::atomic<int64_t> d_record_timeout_ns{1000000000};
     int d_sleep_us{20};                // ... and how long each of those sleeps is asked to be
-    int d_timer_slack_ns{0};           // > 0: the block threads' timer slack while they wait for records (the kernel's default, 50 us, is longer than the wait itself); 0: left alone
+    int d_spin_us_single{0};           // the same two for a block that takes ONE period per call (the reference's cadence): no polling, short sleeps
+    int d_sleep_us_single{25};
+    int d_single_max_records{4};       // ... "one period per call" = at most this many records asked for (2 and 4 periods per call gain as much from the sleeping wait; from 8 on
+                                       // the records of a call arrive over a longer stretch than a sleep and polling wins: profiles/ab/r05/dropin_wait_notes.txt)
+    int d_timer_slack_ns{1000};        // the timer slack of a block thread that takes one period per call and sleeps for its record (the kernel's default, 50 us, is longer than
+                                       // the whole wait); 0: left alone
     std::atomic<uint64_t> d_min_vlen{0};  // shortest code period (samples) among the loop configurations attached so far
     std::atomic<size_t> d_n_slots{0};  // slots ever created (d_slots never shrinks and is reserved up front: readers without the lock index below this)
     std::atomic<uint64_t> d_live_records{0}, d_live_residencies{0}, d_record_wait_ns{0}, d_record_waits{0};
