@@ -212,7 +212,8 @@ bool Hip_Sample_Ring::push_from(uint64_t first_index, const std::complex<float>*
                     {
                         // the samples in between are in the input buffers of slower siblings: they push them when they get there
                         if (gap_timeout.count() <= 0) return true;  // a caller that does not need them resident itself (a block in standby) leaves it at that
-                        const bool closed = d_pushed.wait_for(lk, gap_timeout, [&] { return d_next.load(std::memory_order_acquire) >= first_index; });
+                        // (wait_until on the system clock = pthread_cond_timedwait; wait_for is pthread_cond_clockwait, which gcc 11's ThreadSanitizer does not know releases the mutex)
+                        const bool closed = d_pushed.wait_until(lk, std::chrono::system_clock::now() + gap_timeout, [&] { return d_next.load(std::memory_order_acquire) >= first_index; });
                         if (!closed)
                             {
                                 set_error("push_from: samples " + std::to_string(first_index) + ".. leave a gap after the ring's " + std::to_string(next) +
@@ -396,7 +397,7 @@ bool Hip_Sample_Ring::wait_for(uint64_t end, std::chrono::milliseconds timeout) 
 {
     if (d_next.load(std::memory_order_acquire) >= end) return true;  // the usual case: no lock, no convoy behind a running launch
     std::unique_lock<std::mutex> lk(d_mutex);
-    return d_pushed.wait_for(lk, timeout, [&] { return d_next.load(std::memory_order_acquire) >= end; });
+    return d_pushed.wait_until(lk, std::chrono::system_clock::now() + timeout, [&] { return d_next.load(std::memory_order_acquire) >= end; });
 }
 
 

@@ -160,6 +160,12 @@ bool Hip_Tracking_Runtime::start(int slot, const float* code, const float* data_
     // it was before (and its records, if any, are dropped by the generation check) or started with the slot ready to receive its records --
     // never the device running a channel whose slot does not know yet.
     std::lock_guard<std::mutex> hl(g->handle_mutex);  // waits for a launch of the group that is in flight
+    struct Held_Off  // (the record watchdog of the group's other channels: this is the host holding the residencies off, not the device keeping quiet)
+    {
+        Group* g;
+        explicit Held_Off(Group* gg) : g(gg) { g->held_off_ns.store(now_ns(), std::memory_order_release); }
+        ~Held_Off() { g->held_off_ns.store(now_ns(), std::memory_order_release); }
+    } held_off(g);
     if (g->begun) (void)end_and_file(g, nullptr);       // ... and one queued ahead comes in first: its records belong to the channels as they were
     if (d_live) quiesce_live(g);                        // residencies leave (the other channels' records stay in their rings; the next take brings a residency back)
     std::lock_guard<std::mutex> tl(d_slots[slot]->take_mutex);  // the block's own thread is not in the middle of a take of the old channel state
@@ -211,10 +217,12 @@ void Hip_Tracking_Runtime::stop(int slot)
         channel = S.channel;
     }
     std::lock_guard<std::mutex> hl(g->handle_mutex);  // as in start(): device state and slot change together, between two launches
+    g->held_off_ns.store(now_ns(), std::memory_order_release);
     if (g->begun) (void)end_and_file(g, nullptr);
     if (d_live) quiesce_live(g);
     std::lock_guard<std::mutex> tl(d_slots[slot]->take_mutex);
     (void)gsh_trk_stop(g->trk, channel);
+    g->held_off_ns.store(now_ns(), std::memory_order_release);
     std::lock_guard<std::mutex> lk(d_mutex);
     Slot& S = *d_slots[slot];
     S.tracking = false;
@@ -421,7 +429,8 @@ void Hip_Tracking_Runtime::ensure_live(Group* g, bool wait_for_handle)
     if (wait_for_handle)
         hl.lock();
     else if (!hl.try_lock())
-        return;
+        return;  // somebody (start / stop, a sibling's check) has the handle right now.  (start / stop stamp held_off_ns themselves; a sibling's check must not:
+                 // the channels of a group whose residency never reports would keep each other's watchdogs from ever firing)
     if (g->live_failed) return;
     int32_t n = 0;
     std::string err;
@@ -532,7 +541,8 @@ int Hip_Tracking_Runtime::take_live(Slot& S, uint64_t limit_end, int max_records
             // The window is resident and its record is not there: a residency is working on it, or none is in flight.  Make sure of the latter now and then,
             // and look again: the device needs ~10 us per period.
             const int64_t now = now_ns();
-            if (S.starved_since_ns == 0)
+            // (time in which start / stop of a sibling held the residencies off is not the device's silence: the clock starts again behind it)
+            if (S.starved_since_ns == 0 || g->held_off_ns.load(std::memory_order_acquire) > S.starved_since_ns)
                 S.starved_since_ns = now;
             else if (now - S.starved_since_ns > d_record_timeout_ns.load(std::memory_order_relaxed))
                 {

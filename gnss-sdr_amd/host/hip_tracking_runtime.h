@@ -141,6 +141,8 @@ private:
         // live mode
         bool live_failed{false};                  // gsh_trk_live_begin failed once: the group stays with launches (guarded by handle_mutex; read racily as a hint)
         std::atomic<int64_t> live_checked_ns{0};  // when a block last made sure a residency was in flight (steady_clock)
+        std::atomic<int64_t> held_off_ns{0};      // when start / stop of one of the group's channels last held the handle (the residencies are quiesced meanwhile): the record
+                                                  // watchdog does not count that as the device's silence
     };
     struct Slot
     {

@@ -158,6 +158,7 @@ private:
         std::shared_ptr<Edge_Buffer> in, out;
         uint64_t read{0};
         bool idle{false};
+        uint64_t idle_seen{0};  // free-running mode: the input position the block was short of input at (all_idle_locked)
         bool traced{false};
         std::vector<uint64_t> trace;
         Node_Stats st;
@@ -217,7 +218,12 @@ private:
     bool all_idle_locked()
     {
         for (auto& nd : d_nodes)
-            if (!nd->idle || nd->blk->has_pending_messages()) return false;
+            {
+                if (!nd->idle || nd->blk->has_pending_messages()) return false;
+                // (a block thread that went to sleep short of input and has not yet seen the source's latest release is NOT idle: it will run as soon as it gets the
+                // mutex -- on a loaded host that can take longer than wait_until_drained's next look, and the graph would be declared drained with periods to go)
+                if (!d_token && (nd->from_source ? d_head.load() : (nd->in ? nd->in->written : 0)) != nd->idle_seen) return false;
+            }
         return true;
     }
 
@@ -451,6 +457,7 @@ private:
                     }
                 fruitless = 0;
                 nd.idle = true;
+                nd.idle_seen = seen;
                 d_cv.notify_all();
                 // (a block that went idle with some items on hand is woken when more arrive or a message comes, not while the same items sit there)
                 d_cv.wait(lk, [&] {

@@ -639,6 +639,7 @@ struct Churn_Result
     std::vector<double> longest_gap;              // per channel: the tracking block's longest wall-clock time between two calls that consumed
     std::vector<int> faults_sent;
     std::vector<std::string> errors;  // HIP receiver: the tracking blocks' last engine errors
+    std::vector<uint64_t> final_read;  // the tracking blocks' read pointers when the flowgraph had drained
     double seconds{0.0};
 };
 
@@ -681,6 +682,12 @@ Churn_Result run_churn(const std::string& kind, const Props& props, const std::v
         {
             const auto blk = r->ch[static_cast<size_t>(c)]->get_left_block_trk();
             R.trk_positions.push_back(r->fg->trace_of(blk));
+            R.final_read.push_back(r->fg->items_read(blk));
+            if (std::getenv("GSH_TEST_LOG") != nullptr && R.final_read.back() + static_cast<uint64_t>(3 * vlen) < x.size())
+                {
+                    std::printf("  (channel %d: read pointer %llu of %zu when the flowgraph had drained)\n", c, static_cast<unsigned long long>(R.final_read.back()), x.size());
+                    r->fg->dump_state();
+                }
             size_t v = 0, l = 0;
             {
                 std::lock_guard<std::mutex> lk(r->nav[static_cast<size_t>(c)]->blk->mu);
@@ -880,6 +887,11 @@ void test_faults()
     auto wins_of = [](const Churn_Result& r, int c) { return std::count_if(r.events[static_cast<size_t>(c)].begin(), r.events[static_cast<size_t>(c)].end(), [](const Event& e) { return e.what == 1; }); };
     auto tracked_to_the_end = [&](const Churn_Result& r, int c) { return !r.trk_positions[static_cast<size_t>(c)].empty() && r.trk_positions[static_cast<size_t>(c)].back() + 3 * 4000 >= x.size() && wins_of(r, c) == losses_of(r, c) + 1; };
 
+    auto where_it_stopped = [&](const Churn_Result& r, int c) {
+        const auto& p = r.trk_positions[static_cast<size_t>(c)];
+        return (p.empty() ? std::string("no period taken") : std::to_string(p.size()) + " periods, the last at " + std::to_string(p.back())) + " of " + std::to_string(x.size()) + ", read pointer at the end " +
+               std::to_string(r.final_read[static_cast<size_t>(c)]) + (static_cast<size_t>(c) < r.errors.size() && !r.errors[static_cast<size_t>(c)].empty() ? "; last engine error: " + r.errors[static_cast<size_t>(c)] : std::string());
+    };
     // 1. one push fails, 40 pushes into the run: the block that was pushing drops its channel ("events" 3: trk.cc:1208-1221's message), the FSM re-acquires it; the ring is
     //    whole again with the next block's push; every channel is tracking at the end
     fault_case("one push fails", FAULT_PUSH, 40, 1, -1, x, n_channels, {}, [&](const Churn_Result& r, long hits) {
@@ -888,7 +900,7 @@ void test_faults()
         for (int c = 0; c < n_channels; c++)
             {
                 losses += losses_of(r, c);
-                EXPECT(tracked_to_the_end(r, c), "channel %d is not tracking at the end of the stream: %s", c, events_string(r.events[static_cast<size_t>(c)], 16).c_str());
+                EXPECT(tracked_to_the_end(r, c), "channel %d is not tracking at the end of the stream: %s(%s)", c, events_string(r.events[static_cast<size_t>(c)], 16).c_str(), where_it_stopped(r, c).c_str());
             }
         EXPECT(losses >= 1 && losses <= 2, "%ld channels dropped for one failed push (the block that pushed, and at most the one that found the ring behind)", losses);
     });
@@ -906,7 +918,7 @@ void test_faults()
         for (int c = 0; c < n_channels; c++)
             {
                 losses += losses_of(r, c);
-                EXPECT(tracked_to_the_end(r, c), "channel %d is not tracking at the end of the stream: %s", c, events_string(r.events[static_cast<size_t>(c)], 16).c_str());
+                EXPECT(tracked_to_the_end(r, c), "channel %d is not tracking at the end of the stream: %s(%s)", c, events_string(r.events[static_cast<size_t>(c)], 16).c_str(), where_it_stopped(r, c).c_str());
             }
         EXPECT(losses == 1, "%ld channels dropped for one failed take", losses);
     });
@@ -918,7 +930,7 @@ void test_faults()
         for (int c = 0; c < n_channels; c++)
             {
                 losses += losses_of(r, c);
-                EXPECT(tracked_to_the_end(r, c), "channel %d is not tracking at the end of the stream: %s", c, events_string(r.events[static_cast<size_t>(c)], 16).c_str());
+                EXPECT(tracked_to_the_end(r, c), "channel %d is not tracking at the end of the stream: %s(%s)", c, events_string(r.events[static_cast<size_t>(c)], 16).c_str(), where_it_stopped(r, c).c_str());
             }
         EXPECT(losses >= 1, "no channel was given up although the device delivered nothing");
     });
@@ -929,7 +941,7 @@ void test_faults()
         for (int c = 0; c < n_channels; c++)
             {
                 failed += static_cast<size_t>(std::count_if(r.events[static_cast<size_t>(c)].begin(), r.events[static_cast<size_t>(c)].end(), [](const Event& e) { return e.what == 0; }));
-                EXPECT(tracked_to_the_end(r, c), "channel %d is not tracking at the end of the stream: %s", c, events_string(r.events[static_cast<size_t>(c)], 16).c_str());
+                EXPECT(tracked_to_the_end(r, c), "channel %d is not tracking at the end of the stream: %s(%s)", c, events_string(r.events[static_cast<size_t>(c)], 16).c_str(), where_it_stopped(r, c).c_str());
             }
         EXPECT(failed >= 2, "%zu failed acquisitions for two failed dwells", failed);  // (a first dwell on a weak satellite fails now and then without any help)
     });
@@ -940,7 +952,7 @@ void test_faults()
         for (int c = 0; c < n_channels; c++)
             {
                 losses += losses_of(r, c);
-                EXPECT(tracked_to_the_end(r, c), "channel %d is not tracking at the end of the stream: %s", c, events_string(r.events[static_cast<size_t>(c)], 16).c_str());
+                EXPECT(tracked_to_the_end(r, c), "channel %d is not tracking at the end of the stream: %s(%s)", c, events_string(r.events[static_cast<size_t>(c)], 16).c_str(), where_it_stopped(r, c).c_str());
             }
         EXPECT(losses == 1, "%ld channels dropped for one failed start", losses);
     });
@@ -951,7 +963,7 @@ void test_faults()
         for (int c = 0; c < n_channels; c++)
             {
                 losses += losses_of(r, c);
-                EXPECT(tracked_to_the_end(r, c), "channel %d is not tracking at the end of the stream: %s", c, events_string(r.events[static_cast<size_t>(c)], 16).c_str());
+                EXPECT(tracked_to_the_end(r, c), "channel %d is not tracking at the end of the stream: %s(%s)", c, events_string(r.events[static_cast<size_t>(c)], 16).c_str(), where_it_stopped(r, c).c_str());
             }
         EXPECT(losses >= 1, "no channel dropped for a failed launch");
     });
