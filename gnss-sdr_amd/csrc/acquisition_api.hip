@@ -60,17 +60,23 @@ struct gsh_acq
     uint32_t* d_tc_delays{nullptr};
     float2* d_tc_out{nullptr};
     hipEvent_t ev0{nullptr}, ev1{nullptr};
-    // second issue lane for gsh_acq_time_dwells_pipelined (on-chip path): its own stream and per-batch buffers, so that
-    // batch k+1's forward transforms fill the compute units batch k's last cells leave idle
-    hipStream_t stream2{nullptr};
-    float2* d_spectra2{nullptr};
-    gsh::RowStat* d_rows2{nullptr};
-    gsh::RowStat* d_subrows2{nullptr};
-    gsh::RowStat* d_waverows2{nullptr};
-    float2* d_z2{nullptr};
-    gsh::DevAcqResult* d_results2{nullptr};
-    unsigned* d_arrivals2{nullptr};
-    hipEvent_t ev2{nullptr};
+    // further issue lanes for gsh_acq_time_dwells_pipelined (on-chip path): a stream and per-batch buffers each, so that batch k+1's forward transforms
+    // and first cells fill the compute units batch k's last cells leave idle (lane 0 is the handle's own stream and buffers)
+    struct Lane
+    {
+        hipStream_t stream{nullptr};
+        float2* d_spectra{nullptr};
+        gsh::RowStat* d_rows{nullptr};
+        gsh::RowStat* d_subrows{nullptr};
+        gsh::RowStat* d_waverows{nullptr};
+        float2* d_z{nullptr};
+        gsh::DevAcqResult* d_results{nullptr};
+        unsigned* d_arrivals{nullptr};
+        hipEvent_t ev{nullptr};
+    };
+    static constexpr int MAX_LANES = 4;
+    Lane lane[MAX_LANES];
+    int n_lanes{1};
 };
 
 namespace
@@ -113,7 +119,7 @@ __global__ void spin_kernel(long long ticks)
     for (int i = 0; i < 100000 && wall_clock64() - t0 < ticks; i++) __builtin_amdgcn_s_sleep(8);  // bounded whatever the clock does
 }
 
-int make_concurrent_stream(hipStream_t ref, hipStream_t* out)
+int make_concurrent_stream(hipStream_t ref, const std::vector<hipStream_t>& others, hipStream_t* out)
 {
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
     GSH_HIP(hipEventCreate(&e0));
@@ -135,17 +141,24 @@ int make_concurrent_stream(hipStream_t ref, hipStream_t* out)
                 {
                     GSH_HIP(hipEventRecord(e0, ref));
                     GSH_HIP(hipStreamWaitEvent(cand, e0, 0));
+                    for (hipStream_t o : others) GSH_HIP(hipStreamWaitEvent(o, e0, 0));
                     hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, ref, ticks);
+                    for (hipStream_t o : others) hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, o, ticks);
                     hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, cand, ticks);
                     GSH_HIP(hipEventRecord(e2, cand));
                     GSH_HIP(hipStreamWaitEvent(ref, e2, 0));
+                    for (hipStream_t o : others)  // (the lanes already found run side by side with `ref`: the candidate must with all of them)
+                        {
+                            GSH_HIP(hipEventRecord(e2, o));
+                            GSH_HIP(hipStreamWaitEvent(ref, e2, 0));
+                        }
                     GSH_HIP(hipEventRecord(e1, ref));
                     GSH_HIP(hipEventSynchronize(e1));
                     float ms = 0.0f;
                     GSH_HIP(hipEventElapsedTime(&ms, e0, e1));
                     best = std::min(best, ms);
                 }
-            if (std::getenv("GSH_TRACE_STREAMS") != nullptr) std::fprintf(stderr, "gsh: stream probe %d: two 40-us spins in %.1f us\n", attempt, best * 1e3f);
+            if (std::getenv("GSH_TRACE_STREAMS") != nullptr) std::fprintf(stderr, "gsh: stream probe %d: %zu 40-us spins in %.1f us\n", attempt, others.size() + 2, best * 1e3f);
             if (best < 0.080f)  // measured: 60-64 us side by side (one spin + the event round trip), 100 us one after the other
                 found = cand;
             else
@@ -651,24 +664,28 @@ extern "C"
         if (a->d_rows) (void)hipFree(a->d_rows);
         if (a->d_subrows) (void)hipFree(a->d_subrows);
         if (a->d_waverows) (void)hipFree(a->d_waverows);
-        if (a->d_waverows2) (void)hipFree(a->d_waverows2);
         if (a->d_z) (void)hipFree(a->d_z);
-        if (a->d_z2) (void)hipFree(a->d_z2);
         if (a->d_pair) (void)hipFree(a->d_pair);
-        if (a->d_subrows2) (void)hipFree(a->d_subrows2);
         if (a->d_results) (void)hipFree(a->d_results);
         if (a->d_arrivals) (void)hipFree(a->d_arrivals);
         if (a->h_results) (void)hipHostFree(a->h_results);
         if (a->h_stage) (void)hipHostFree(a->h_stage);
         if (a->ev0) (void)hipEventDestroy(a->ev0);
         if (a->ev1) (void)hipEventDestroy(a->ev1);
-        if (a->stream2) (void)hipStreamSynchronize(a->stream2);
-        if (a->d_spectra2) (void)hipFree(a->d_spectra2);
-        if (a->d_rows2) (void)hipFree(a->d_rows2);
-        if (a->d_results2) (void)hipFree(a->d_results2);
-        if (a->d_arrivals2) (void)hipFree(a->d_arrivals2);
-        if (a->ev2) (void)hipEventDestroy(a->ev2);
-        if (a->stream2) (void)hipStreamDestroy(a->stream2);
+        for (int l = 1; l < gsh_acq::MAX_LANES; l++)
+            {
+                gsh_acq::Lane& ln = a->lane[l];
+                if (ln.stream) (void)hipStreamSynchronize(ln.stream);
+                if (ln.d_spectra) (void)hipFree(ln.d_spectra);
+                if (ln.d_rows) (void)hipFree(ln.d_rows);
+                if (ln.d_subrows) (void)hipFree(ln.d_subrows);
+                if (ln.d_waverows) (void)hipFree(ln.d_waverows);
+                if (ln.d_z) (void)hipFree(ln.d_z);
+                if (ln.d_results) (void)hipFree(ln.d_results);
+                if (ln.d_arrivals) (void)hipFree(ln.d_arrivals);
+                if (ln.ev) (void)hipEventDestroy(ln.ev);
+                if (ln.stream) (void)hipStreamDestroy(ln.stream);
+            }
         if (a->stream) (void)hipStreamDestroy(a->stream);
         delete a;
     }
@@ -1161,52 +1178,70 @@ extern "C"
         GSH_HIP(hipSetDevice(a->device));
         const gsh_acq_conf& c = a->conf;
         const size_t n = c.fft_size, D = static_cast<size_t>(a->n_bins), P = c.max_prn;
-        if (a->stream2 == nullptr)
+        // lanes: two by default.  (GSH_ACQ_LANES: profiles/oc_cell_annotated.txt)
+        static const int want_lanes = [] { const char* e = std::getenv("GSH_ACQ_LANES"); return e != nullptr ? std::min(std::max(std::atoi(e), 2), static_cast<int>(gsh_acq::MAX_LANES)) : 2; }();
+        {
+            gsh_acq::Lane& l0 = a->lane[0];
+            l0.stream = a->stream;
+            l0.d_spectra = a->d_spectra;
+            l0.d_rows = a->d_rows;
+            l0.d_subrows = a->d_subrows;
+            l0.d_waverows = a->d_waverows;
+            l0.d_z = a->d_z;
+            l0.d_results = a->d_results;
+            l0.d_arrivals = a->d_arrivals;
+        }
+        while (a->n_lanes < want_lanes)
             {
+                gsh_acq::Lane& ln = a->lane[a->n_lanes];
                 {
-                    const int rc2 = make_concurrent_stream(a->stream, &a->stream2);  // a stream on another hardware queue than a->stream
+                    std::vector<hipStream_t> others;
+                    for (int l = 1; l < a->n_lanes; l++) others.push_back(a->lane[l].stream);
+                    const int rc2 = make_concurrent_stream(a->stream, others, &ln.stream);  // a stream on another hardware queue than the lanes so far
                     if (rc2 != GSH_OK) return rc2;
                 }
-                GSH_HIP(hipMalloc(&a->d_spectra2, sizeof(float2) * D * n));
-                GSH_HIP(hipMalloc(&a->d_rows2, sizeof(gsh::RowStat) * P * D));
-                if (a->split > 0) GSH_HIP(hipMalloc(&a->d_subrows2, sizeof(gsh::RowStat) * P * D * a->split));
-                GSH_HIP(hipMalloc(&a->d_waverows2, sizeof(gsh::RowStat) * P * D * static_cast<size_t>(std::max(a->split, 1)) * gsh::ONCHIP_MAX_WAVES));
+                GSH_HIP(hipMalloc(&ln.d_spectra, sizeof(float2) * D * n));
+                GSH_HIP(hipMalloc(&ln.d_rows, sizeof(gsh::RowStat) * P * D));
+                if (a->split > 0) GSH_HIP(hipMalloc(&ln.d_subrows, sizeof(gsh::RowStat) * P * D * a->split));
+                GSH_HIP(hipMalloc(&ln.d_waverows, sizeof(gsh::RowStat) * P * D * static_cast<size_t>(std::max(a->split, 1)) * gsh::ONCHIP_MAX_WAVES));
                 if (a->d_z != nullptr)
                     {
-                        GSH_HIP(hipMalloc(&a->d_z2, sizeof(float2) * P * D * n));
+                        GSH_HIP(hipMalloc(&ln.d_z, sizeof(float2) * P * D * n));
                     }
-                GSH_HIP(hipMalloc(&a->d_results2, sizeof(gsh::DevAcqResult) * P));
-                GSH_HIP(hipMalloc(&a->d_arrivals2, sizeof(unsigned) * P));
-                GSH_HIP(hipMemset(a->d_arrivals2, 0, sizeof(unsigned) * P));
-                GSH_HIP(hipEventCreate(&a->ev2));
+                GSH_HIP(hipMalloc(&ln.d_results, sizeof(gsh::DevAcqResult) * P));
+                GSH_HIP(hipMalloc(&ln.d_arrivals, sizeof(unsigned) * P));
+                GSH_HIP(hipMemset(ln.d_arrivals, 0, sizeof(unsigned) * P));
+                GSH_HIP(hipEventCreate(&ln.ev));
+                a->n_lanes++;
             }
-        auto enqueue = [&](int lane) -> int {
-            hipStream_t st = lane ? a->stream2 : a->stream;
-            float2* spectra = lane ? a->d_spectra2 : a->d_spectra;
+        const int lanes = want_lanes;
+        auto enqueue = [&](int l) -> int {
+            const gsh_acq::Lane& ln = a->lane[l];
             GSH_REQUIRE(c.fold <= 1, "the pipelined timing loop does not fold");
             int rc = gsh::onchip_forward(static_cast<int>(n), a->d_in, 0, static_cast<int>(c.consumed_samples), 0, a->d_bins_hz,
-                static_cast<double>(c.fs_in), spectra, a->n_bins, st);
+                static_cast<double>(c.fs_in), ln.d_spectra, a->n_bins, ln.stream);
             if (rc != GSH_OK) return rc;
-            // no_grid handles only: two batches in flight must not share the magnitude grid
-            return gsh::onchip_correlate(static_cast<int>(n), spectra, a->d_codes, a->d_grid, lane ? a->d_rows2 : a->d_rows, lane ? a->d_subrows2 : a->d_subrows,
-                lane ? a->d_results2 : a->d_results, lane ? a->d_arrivals2 : a->d_arrivals, static_cast<int>(n_prn), a->n_bins,
-                c.bit_transition_flag ? static_cast<int>(c.effective_fft_size) : 0, static_cast<int>(c.effective_fft_size), 0, 0, static_cast<int>(c.samples_per_chip), c.use_cfar, 1u, 1.0f, st,
-                lane ? a->d_z2 : a->d_z, lane ? a->d_waverows2 : a->d_waverows);
+            // no_grid handles only: the batches in flight must not share the magnitude grid
+            return gsh::onchip_correlate(static_cast<int>(n), ln.d_spectra, a->d_codes, a->d_grid, ln.d_rows, ln.d_subrows, ln.d_results, ln.d_arrivals, static_cast<int>(n_prn), a->n_bins,
+                c.bit_transition_flag ? static_cast<int>(c.effective_fft_size) : 0, static_cast<int>(c.effective_fft_size), 0, 0, static_cast<int>(c.samples_per_chip), c.use_cfar, 1u, 1.0f, ln.stream,
+                ln.d_z, ln.d_waverows);
         };
-        int rc = enqueue(0);  // warm-up on both lanes
-        if (rc == GSH_OK) rc = enqueue(1);
+        int rc = GSH_OK;
+        for (int l = 0; l < lanes && rc == GSH_OK; l++) rc = enqueue(l);  // warm-up on every lane
         if (rc != GSH_OK) return rc;
-        GSH_HIP(hipStreamSynchronize(a->stream));
-        GSH_HIP(hipStreamSynchronize(a->stream2));
+        for (int l = 0; l < lanes; l++) GSH_HIP(hipStreamSynchronize(a->lane[l].stream));
         GSH_HIP(hipEventRecord(a->ev0, a->stream));
-        GSH_HIP(hipStreamWaitEvent(a->stream2, a->ev0, 0));
+        for (int l = 1; l < lanes; l++) GSH_HIP(hipStreamWaitEvent(a->lane[l].stream, a->ev0, 0));
         for (int i = 0; i < reps; i++)
             {
-                rc = enqueue(i & 1);
+                rc = enqueue(i % lanes);
                 if (rc != GSH_OK) return rc;
             }
-        GSH_HIP(hipEventRecord(a->ev2, a->stream2));
-        GSH_HIP(hipStreamWaitEvent(a->stream, a->ev2, 0));
+        for (int l = 1; l < lanes; l++)
+            {
+                GSH_HIP(hipEventRecord(a->lane[l].ev, a->lane[l].stream));
+                GSH_HIP(hipStreamWaitEvent(a->stream, a->lane[l].ev, 0));
+            }
         GSH_HIP(hipEventRecord(a->ev1, a->stream));
         GSH_HIP(hipEventSynchronize(a->ev1));
         float ms = 0.0f;

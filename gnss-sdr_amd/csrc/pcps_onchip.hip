@@ -118,7 +118,7 @@ struct OcCellArgs
     int cells_per_wg;   // oc_cell_kernel: a work-group carries out this many cells one after the other (slot, slot + gridDim / 8, ...): the staggered start of a
                         // work-group's sixteen waves -- 3.5 of a cell's 21 us, profiles/oc_cell_annotated.txt -- is paid once per work-group instead of once per cell
     int slots_per_xcd;  // prn_per * bin_per * S
-    int prefetch_next;    // the idle threads of stage 3 touch the next cell's bin spectrum (cells_per_wg > 1)
+    int prefetch_next;    // >= 1: the idle threads of stage 3 touch the next cell's bin spectrum (cells_per_wg > 1); >= 2: the idle WAVES also load their own operands of it
     int stagger_groups;   // > 1: the work-groups of the launch's FIRST round (blockIdx < stagger_first) start in this many groups, stagger_ticks of the 100 MHz clock apart:
     int stagger_ticks;    // all 256 compute units loading their operands in the same microseconds and transforming in the same microseconds leaves the L2 idle 60 % of
     int stagger_first;    // the time and overrun the rest (7.4 us for 400 KB per unit, against 1.9 us when they come apart); every cell takes the same time, so
@@ -565,6 +565,19 @@ __global__ __launch_bounds__(P::THREADS) void oc_cell_kernel(OcCellArgs a)
     // (The peak-ratio flavours end in a hand-off that not every thread returns from: one cell per work-group.)
     constexpr bool PERSIST = !SECOND && P::EX64;
     const int passes = PERSIST ? a.cells_per_wg : 1;
+    // The waves that have no stage-3 butterfly at all (radix 40: threads 640 .. 1 023, six of sixteen) load their OWN operands of the work-group's next cell while the
+    // others transform: they enter the next pass with their stage-1 inputs in registers, and the pass's operand phase -- every unit of the chip asking the L2 at
+    // once, a third of the cell -- is the other ten waves' only.  The pass loop exists twice, and a wave takes one or the other for the whole launch: the idle waves'
+    // copy carries the 2 R1 product registers across the passes and has no stage 3 (nor its 2 R3 registers); the other copy is the loop as it was.  (One loop
+    // with the array carried for every wave did not fit: the registers of a value that is written on one side of a branch and read a pass later are not given to
+    // the other side's stage 3.)  Both copies meet the same barriers, pass for pass.
+    constexpr int OPF_FIRST = (P::T3 + 63) / 64 * 64;  // first thread of the first wholly idle wave
+    constexpr bool OPF = PERSIST && !GRID && S == 1 && OPF_FIRST + 64 <= P::THREADS;
+    auto pass_loop = [&](auto IDLE_TAG) GSH_AI {
+    constexpr bool IDLE = decltype(IDLE_TAG)::value;
+    [[maybe_unused]] cf pa[IDLE ? P::R1 : 1];
+    [[maybe_unused]] bool have_operands = false;
+    if constexpr (IDLE) fresh_values<P::R1>(pa);
 #pragma clang loop unroll(disable)
     for (int pass = 0; pass < passes; pass++)
     {
@@ -572,6 +585,7 @@ __global__ __launch_bounds__(P::THREADS) void oc_cell_kernel(OcCellArgs a)
     // instead of being kept in registers across the passes: the cell needs every one of its 128 registers)
     int t = threadIdx.x;
     asm volatile("" : "+v"(t));
+    if constexpr (OPF) __builtin_assume(IDLE ? t >= OPF_FIRST : t < OPF_FIRST);
     const int slot_r = static_cast<int>(blockIdx.x >> 3) + pass * static_cast<int>(gridDim.x >> 3);
     if (slot_r >= a.slots_per_xcd) break;  // uniform over the work-group
     const int slot = slot_r / S, r = slot_r - slot * S;
@@ -602,11 +616,20 @@ __global__ __launch_bounds__(P::THREADS) void oc_cell_kernel(OcCellArgs a)
                 {
                     // all 2 * R1 operand loads are issued before the first product: the cell's registers are still free here, and one round of
                     // L2 / Infinity-Cache latency is cheaper than the two the scheduler otherwise settles for (12 loads, wait, 38 loads)
+                    if (IDLE && have_operands)  // (uniform over the wave)
+                        oc::static_for<P::R1>([&](auto N1) GSH_AI { ra[decltype(N1)::value] = pa[decltype(N1)::value]; });
+                    else
+                    {
                     cf xv[P::R1], cv[P::R1];
                     oc::static_for<P::R1>([&](auto N1) GSH_AI {
                         constexpr int n1 = decltype(N1)::value;
+#ifdef GSH_OC_PROFILE_NO_LOADS  /* (timing experiment only: the operands are made up -- what the cell costs without its 400 KB) */
+                        xv[n1] = cf{static_cast<float>(t) * 1e-3f, static_cast<float>(n1 + bin)};
+                        cv[n1] = cf{static_cast<float>(n1 + prn), static_cast<float>(t) * 1e-3f};
+#else
                         xv[n1] = X[n1 * P::T1];
                         cv[n1] = C[n1 * P::T1];
+#endif
                     });
                     __builtin_amdgcn_sched_group_barrier(0x20, 2 * P::R1, 0);  // VMEM reads first ...
                     oc::static_for<P::R1>([&](auto N1) GSH_AI {
@@ -614,6 +637,7 @@ __global__ __launch_bounds__(P::THREADS) void oc_cell_kernel(OcCellArgs a)
                         ra[n1] = oc::cmul_conj(xv[n1], cv[n1]);
                     });
                     __builtin_amdgcn_sched_group_barrier(0x2, 8 * P::R1, 0);   // ... then the products
+                    }
 #ifdef GSH_OC_PROFILE
                     asm volatile("" ::"v"(ra[P::R1 - 1].x), "v"(ra[0].x));  // (the stamp below must not be scheduled above the last product)
 #endif
@@ -682,35 +706,60 @@ __global__ __launch_bounds__(P::THREADS) void oc_cell_kernel(OcCellArgs a)
     // tau >= offset (offset + effective == N; offset != 0 only for bit_transition_flag, acq.cc:544)
     float best = -1.0f, sum = 0.0f;
     unsigned at = 0xFFFFFFFFu;
-    if constexpr (PERSIST && !GRID && S == 1 && P::T3 + 64 <= P::THREADS)
+    // The threads that have no stage-3 butterfly (radix 40: 375 of them) touch the bin spectrum of the work-group's NEXT cell, one word per 64 bytes: an XCD's
+    // 4 MB of L2 hold a round's 8 bin spectra and 4 code spectra, not the search's 41 -- every new bin comes over the fabric (2.4 of the operand phase's 7.4 us,
+    // measured by letting every cell read bin 0: profiles/oc_cell_annotated.txt), and here it comes while the other threads transform.
+    constexpr bool TOUCH = PERSIST && !GRID && S == 1 && P::T3 + 64 <= P::THREADS;
+    const int nslot_r = slot_r + static_cast<int>(gridDim.x >> 3);
+    const bool next_pass = TOUCH && pass + 1 < passes && nslot_r < a.slots_per_xcd;  // uniform over the work-group
+    if constexpr (IDLE)
         {
-            // The threads that have no stage-3 butterfly (radix 40: 375 of them) touch the bin spectrum of the work-group's NEXT cell, one word per 64 bytes: an XCD's
-            // 4 MB of L2 hold a round's 8 bin spectra and 4 code spectra, not the search's 41 -- every new bin comes over the fabric (2.4 of the operand phase's 7.4 us,
-            // measured by letting every cell read bin 0: profiles/oc_cell_annotated.txt), and here it comes while the other threads transform.
-            if (t >= P::T3 && a.prefetch_next)
+            // this wave's own operands of the next cell (every lane loads and multiplies -- the lanes past T1, which have no stage-1 butterfly, the last butterfly's
+            // operands over again)
+            const int nbl = nslot_r / a.prn_per, npl = nslot_r - nbl * a.prn_per;
+            const int nprn = xp_i * a.prn_per + npl, nbin_own = xb_i * a.bin_per + nbl;
+            have_operands = next_pass && a.prefetch_next >= 2 && nprn < a.n_prn && nbin_own < a.n_bins;
+            if (have_operands)
                 {
-                    const int nslot_r = slot_r + static_cast<int>(gridDim.x >> 3);
-                    if (pass + 1 < passes && nslot_r < a.slots_per_xcd)
-                        {
-                            const int nbin = xb_i * a.bin_per + (nslot_r / S) / a.prn_per;
-                            if (nbin < a.n_bins && nbin != bin)
-                                {
-                                    // (the prn_per work-groups that go to that bin next take every prn_per-th line each)
-                                    constexpr int IDLE = P::THREADS - P::T3, LINES = N * 8 / 64;
-                                    const int share = a.prn_per > 4 ? 4 : a.prn_per, mine = (nslot_r / S) % share;
-                                    const float* __restrict__ base = reinterpret_cast<const float*>(a.spectra + static_cast<size_t>(nbin) * N);
-                                    float acc = 0.0f;
-                                    constexpr int PER = (LINES + IDLE - 1) / IDLE;  // enough for share == 1; fewer lines each when the bin is shared
-                                    oc::static_for<PER>([&](auto K) GSH_AI {
-                                        const int line = ((t - P::T3) + decltype(K)::value * IDLE) * share + mine;
-                                        if (decltype(K)::value * IDLE * share < LINES) acc += base[static_cast<size_t>(line < LINES ? line : mine) * 16];
-                                    });
-                                    asm volatile("" ::"v"(acc));  // (the loads are real: their data is waited for, by threads that have nothing else to do)
-                                }
-                        }
+                    const int tt = t < P::T1 ? t : P::T1 - 1;
+                    const cf* __restrict__ X = a.spectra + static_cast<size_t>(nbin_own) * N + tt;
+                    const cf* __restrict__ C = a.codes + static_cast<size_t>(nprn) * N + tt;
+                    cf xv[P::R1], cv[P::R1];
+                    oc::static_for<P::R1>([&](auto N1) GSH_AI {
+                        constexpr int n1 = decltype(N1)::value;
+                        xv[n1] = X[n1 * P::T1];
+                        cv[n1] = C[n1 * P::T1];
+                    });
+                    __builtin_amdgcn_sched_group_barrier(0x20, 2 * P::R1, 0);
+                    oc::static_for<P::R1>([&](auto N1) GSH_AI {
+                        constexpr int n1 = decltype(N1)::value;
+                        pa[n1] = oc::cmul_conj(xv[n1], cv[n1]);
+                    });
+                    __builtin_amdgcn_sched_group_barrier(0x2, 8 * P::R1, 0);
                 }
+            else
+                fresh_values<P::R1>(pa);  // (nothing is carried: says so to the register allocator)
         }
-    if (t < P::T3)
+    if constexpr (TOUCH)
+        if (t >= P::T3 && a.prefetch_next && next_pass)
+            {
+                const int nbin = xb_i * a.bin_per + (nslot_r / S) / a.prn_per;
+                if (nbin < a.n_bins && nbin != bin)
+                    {
+                        // (the prn_per work-groups that go to that bin next take every prn_per-th line each)
+                        constexpr int IDLE_THREADS = P::THREADS - P::T3, LINES = N * 8 / 64;
+                        const int share = a.prn_per > 4 ? 4 : a.prn_per, mine = (nslot_r / S) % share;
+                        const float* __restrict__ base = reinterpret_cast<const float*>(a.spectra + static_cast<size_t>(nbin) * N);
+                        float acc = 0.0f;
+                        constexpr int PER = (LINES + IDLE_THREADS - 1) / IDLE_THREADS;  // enough for share == 1; fewer lines each when the bin is shared
+                        oc::static_for<PER>([&](auto K) GSH_AI {
+                            const int line = ((t - P::T3) + decltype(K)::value * IDLE_THREADS) * share + mine;
+                            if (decltype(K)::value * IDLE_THREADS * share < LINES) acc += base[static_cast<size_t>(line < LINES ? line : mine) * 16];
+                        });
+                        asm volatile("" ::"v"(acc));  // (the loads are real: their data is waited for, by threads that have nothing else to do)
+                    }
+            }
+    if (!IDLE && t < P::T3)
         {
             P::stage3(rc);
             float* __restrict__ g = a.grid + static_cast<size_t>(cell) * a.effective;
@@ -852,6 +901,16 @@ __global__ __launch_bounds__(P::THREADS) void oc_cell_kernel(OcCellArgs a)
     OC_STAMP(7);
     OC_STAMP_WALL(9);
     }  // pass
+    };  // pass_loop
+    if constexpr (OPF)
+        {
+            if (__builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x)) >= OPF_FIRST)
+                pass_loop(std::true_type{});
+            else
+                pass_loop(std::false_type{});
+        }
+    else
+        pass_loop(std::false_type{});
 }
 
 // ---- N = S * M, decimation in time (round 3).  The sub-cells of oc_cell_kernel<P, S> (decimation in frequency) each read the WHOLE product spectrum --
@@ -1275,7 +1334,7 @@ int onchip_correlate(int n, const float2* spectra, const float2* codes, float* g
             const char* c = e != nullptr ? std::strchr(e, ',') : nullptr;
             return c != nullptr ? std::atoi(c + 1) : GSH_OC_STAGGER_TICKS_DEFAULT;
         }();
-        static const int prefetch = [] { const char* e = std::getenv("GSH_OC_PREFETCH"); return e != nullptr ? std::atoi(e) : 1; }();
+        static const int prefetch = [] { const char* e = std::getenv("GSH_OC_PREFETCH"); return e != nullptr ? std::atoi(e) : 2; }();  // 0 none, 1 the next bin's lines, 2 + the idle waves' own operands
         a.prefetch_next = prefetch;
         a.stagger_groups = groups;
         a.stagger_ticks = ticks;
