@@ -797,8 +797,28 @@ def tracking_roofline(C, E, T, n, k_ms, pmc):
     return r
 
 
+class _OnlyTheLineOnStdout:
+    """stdout carries ONE line, the JSON: whatever else a library writes there while the legs run (this image's RCCL prints a five-line banner on stdout when a
+    communicator is created) goes to stderr.  File descriptor 1 points at stderr for the run; the line is written to the saved descriptor at the end."""
+
+    def __init__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def line(self, text):
+        sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)  # (the C library's buffer: it holds the banner when stdout is a pipe)
+        except Exception:
+            pass
+        os.write(self.saved, (text + "\n").encode())
+
+
 def main():
     a = parse()
+    the_line = _OnlyTheLineOnStdout()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -1012,7 +1032,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(C, n, fs, T, a.cpu_seconds)
         res["summary"] = bench_summary(res)
-        print(json.dumps(res))
+        the_line.line(json.dumps(res))
     bank.close()
     if G is not None:
         G.close()

@@ -58,7 +58,7 @@ def main():
     lines = [f"# rocprofv3 summary {tag}  (source: profiles/run_profiles_{tag[:3]}.sh; raw CSVs stay in gpurun_out/)"]
     bench = None
     try:
-        bench = json.loads(open(os.path.join(d, "trace.json")).read().strip().splitlines()[-1])
+        bench = json.loads([l for l in open(os.path.join(d, "trace.json")).read().strip().splitlines() if l.startswith("{")][-1])  # (RCCL prints a banner on stdout too)
         lines.append(f"bench line of the traced run: value={bench['value']:.4g} {bench['unit']}  ms_per_step={bench['ms_per_step']:.4f}  "
                      f"kernel_ms={bench['roofline']['kernel_ms']:.4f}")
     except Exception as e:
