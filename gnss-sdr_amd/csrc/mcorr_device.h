@@ -1186,7 +1186,11 @@ __device__ __forceinline__ void run_segment(const JobCtx& c, const float2* __res
 #ifdef GSH_MC_NCH
             constexpr int NCH = (NT <= 3 && !AUX) ? GSH_MC_NCH : 1;
 #else
+#ifdef GSH_MC_NCH_WIDE  /* (A/B: two chunks per trip for the five-tap and pilot + data flavours of the merged form too) */
+            constexpr int NCH = (MC_THREADS <= 256 || MRG) ? 2 : 1;
+#else
             constexpr int NCH = (MC_THREADS <= 256 || (MRG && NT <= 3 && !AUX)) ? 2 : 1;
+#endif
 #endif
 #ifdef GSH_MC_PREFETCH
             constexpr int PF = GSH_MC_PREFETCH;
