@@ -40,6 +40,9 @@ constexpr int MC_MARGIN = 32;  // guard entries on each side of the LDS code tab
 #ifndef GSH_MC_PREFETCH_BANK
 #define GSH_MC_PREFETCH_BANK 1  // trips of loads in flight per lane, batched kernel
 #endif
+#ifndef GSH_MC_EARLY_LOADS
+#define GSH_MC_EARLY_LOADS 0  // 1: run_segment_packed, closed-loop form, issues the first trips' loads ahead of the seed evaluation (measured: 0.8 % slower, profiles/ab/r05/closed_loop_notes.txt)
+#endif
 #ifndef GSH_MC_PREFETCH_LOOP
 #define GSH_MC_PREFETCH_LOOP 1  // the same for the 1024-thread closed-loop kernel (4 until the end of round 2: same 9.15 us per period, and the twelve VGPRs
                                 // of the deeper queue were what pushed long-lived constants of the loop arithmetic into scratch)
@@ -649,6 +652,72 @@ __device__ __forceinline__ void run_segment_packed(const JobCtx& c, const float2
         }
     const int first_plain = odd ? 1 : 0;                // trips [first_plain, last_plain) need no masking
     const int last_plain = n_full / (NCH * PPC);
+    // Loads run PF trips ahead of the arithmetic (a register queue, the trip loop unrolled by PF).  The batched kernel (many work-groups per
+    // compute unit) gets by with PF = 1; the closed-loop kernel has ONE work-group per channel and ran PF = 4 until measurement showed PF = 1 to be as fast.
+    // (Measured, round 2, profiles/r02/closed_loop_phases.txt: the depth hardly matters -- of the 11 us of a closed-loop period 2.4 us are thread
+    // 0's loop arithmetic, 2.6 us fixed cost of the correlation phase (barriers, reductions) and 6 us the 13 trips of each wave.)
+    const float2* const q0 = base + 2 * tid;  // the lane's pair of chunk 0
+    constexpr int TRIP = 2 * NCH * PPC;        // samples (float2) a trip advances by
+    // the four samples of trip i for this lane: 16-byte loads in the body; at the segment's edges (odd head, partial tail) the samples outside
+    // [n_begin, n_end) are read as zero -- never loaded.  Edge trips go through the same queue, so their latency is hidden like the others'.
+    const unsigned lane_bytes = 16u * static_cast<unsigned>(tid);  // the lane's 16 bytes inside a chunk
+    auto load_trip = [&](int i, float4& va, float4& vb) {
+        const float2* q = q0 + static_cast<long long>(i) * TRIP;
+        if ((i >= first_plain) && (i < last_plain))  // uniform
+            {
+                // a wave-uniform 64-bit base plus a 32-bit lane offset: the loads take their base from SGPRs, and no per-lane pointer is carried (and advanced) in VGPRs
+                const char* const ua = reinterpret_cast<const char*>(base + static_cast<long long>(i) * TRIP);
+#ifdef GSH_EXP_NOLOAD  // timing experiment only (profiles/r02/mcorr_bound_experiments.txt): no sample traffic
+                va = make_float4(1.0f, static_cast<float>(i), 0.5f, 0.25f);
+                if (NCH == 2) vb = make_float4(0.5f, static_cast<float>(i), 1.0f, 0.25f);
+                asm volatile("" : "+v"(va.x), "+v"(va.y), "+v"(va.z), "+v"(va.w));
+                if (NCH == 2) asm volatile("" : "+v"(vb.x), "+v"(vb.y), "+v"(vb.z), "+v"(vb.w));
+#else
+                if constexpr (NCH == 2)
+                    {
+                        // chunk A / B at -/+ half a chunk around the middle: both inside the 13-bit immediate offset of global_load (a whole chunk, 16 PPC = 4096
+                        // bytes at 256 threads, is one more than the field holds and cost a 64-bit add per trip)
+                        const char* const mid = ua + 8 * PPC + lane_bytes;
+                        va = *reinterpret_cast<const float4*>(mid - 8 * PPC);
+                        vb = *reinterpret_cast<const float4*>(mid + 8 * PPC);
+                    }
+                else
+                    va = *reinterpret_cast<const float4*>(ua + lane_bytes);
+#endif
+            }
+        else
+            {
+                const int n0 = c.n_first + 2 * tid + i * TRIP;
+                const int lo = c.n_begin, hi = c.n_end - 1;
+                const bool a0 = (n0 >= lo) && (n0 <= hi), a1 = (n0 + 1 >= lo) && (n0 + 1 <= hi);
+                const float2 x0 = a0 ? q[0] : make_float2(0.0f, 0.0f);
+                const float2 x1 = a1 ? q[1] : make_float2(0.0f, 0.0f);
+                va = make_float4(x0.x, x0.y, x1.x, x1.y);
+                if (NCH == 2)
+                    {
+                        const int m0 = n0 + 2 * PPC;
+                        const bool b0 = (m0 >= lo) && (m0 <= hi), b1 = (m0 + 1 >= lo) && (m0 + 1 <= hi);
+                        const float2 z0 = b0 ? q[2 * PPC] : make_float2(0.0f, 0.0f);
+                        const float2 z1 = b1 ? q[2 * PPC + 1] : make_float2(0.0f, 0.0f);
+                        vb = make_float4(z0.x, z0.y, z1.x, z1.y);
+                    }
+            }
+    };
+    // The first PF trips' loads: right in front of the first trip.  (EARLY_LOADS, an A/B switch for the 1 024-thread closed-loop form: issued HERE instead, ahead of the
+    // seeds' transcendental evaluation and the tables below, so that the period's first L2 round trip runs under the set-up -- measured 7.60 against 7.54 us per period:
+    // the other waves of the unit already cover that latency, and the eight registers held through the set-up cost more.)
+    constexpr bool EARLY_LOADS = GSH_MC_EARLY_LOADS && MRG && MC_THREADS > 256;
+    float4 qa[PF], qb[PF];
+    auto first_loads = [&]() {
+#pragma unroll
+        for (int j = 0; j < PF; j++)
+            {
+                qa[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                qb[j] = qa[j];
+                if (j < n_trips) load_trip(j, qa[j], qb[j]);  // uniform
+            }
+    };
+    if constexpr (EARLY_LOADS) first_loads();
     v2f A0[NT], A1[NT], B0[NT], B1[NT];
     v2f XA0 = zero, XA1 = zero, XB0 = zero, XB1 = zero;  // the fused tap (AUX)
 #pragma unroll
@@ -723,57 +792,6 @@ __device__ __forceinline__ void run_segment_packed(const JobCtx& c, const float2
     const v2f w2 = single ? single_w2 : table(2);
     const v2f inc_s = single ? single_inc : table(0), w_s = single ? single_w : table(1);  // exp(-j step), exp(-j 2 PPC step): wave-uniform (MRG: used in every trip; otherwise in the fold)
 
-    // Loads run PF trips ahead of the arithmetic (a register queue, the trip loop unrolled by PF).  The batched kernel (many work-groups per
-    // compute unit) gets by with PF = 1; the closed-loop kernel has ONE work-group per channel and ran PF = 4 until measurement showed PF = 1 to be as fast.
-    // (Measured, round 2, profiles/r02/closed_loop_phases.txt: the depth hardly matters -- of the 11 us of a closed-loop period 2.4 us are thread
-    // 0's loop arithmetic, 2.6 us fixed cost of the correlation phase (barriers, reductions) and 6 us the 13 trips of each wave.)
-    const float2* const q0 = base + 2 * tid;  // the lane's pair of chunk 0
-    constexpr int TRIP = 2 * NCH * PPC;        // samples (float2) a trip advances by
-    // the four samples of trip i for this lane: 16-byte loads in the body; at the segment's edges (odd head, partial tail) the samples outside
-    // [n_begin, n_end) are read as zero -- never loaded.  Edge trips go through the same queue, so their latency is hidden like the others'.
-    const unsigned lane_bytes = 16u * static_cast<unsigned>(tid);  // the lane's 16 bytes inside a chunk
-    auto load_trip = [&](int i, float4& va, float4& vb) {
-        const float2* q = q0 + static_cast<long long>(i) * TRIP;
-        if ((i >= first_plain) && (i < last_plain))  // uniform
-            {
-                // a wave-uniform 64-bit base plus a 32-bit lane offset: the loads take their base from SGPRs, and no per-lane pointer is carried (and advanced) in VGPRs
-                const char* const ua = reinterpret_cast<const char*>(base + static_cast<long long>(i) * TRIP);
-#ifdef GSH_EXP_NOLOAD  // timing experiment only (profiles/r02/mcorr_bound_experiments.txt): no sample traffic
-                va = make_float4(1.0f, static_cast<float>(i), 0.5f, 0.25f);
-                if (NCH == 2) vb = make_float4(0.5f, static_cast<float>(i), 1.0f, 0.25f);
-                asm volatile("" : "+v"(va.x), "+v"(va.y), "+v"(va.z), "+v"(va.w));
-                if (NCH == 2) asm volatile("" : "+v"(vb.x), "+v"(vb.y), "+v"(vb.z), "+v"(vb.w));
-#else
-                if constexpr (NCH == 2)
-                    {
-                        // chunk A / B at -/+ half a chunk around the middle: both inside the 13-bit immediate offset of global_load (a whole chunk, 16 PPC = 4096
-                        // bytes at 256 threads, is one more than the field holds and cost a 64-bit add per trip)
-                        const char* const mid = ua + 8 * PPC + lane_bytes;
-                        va = *reinterpret_cast<const float4*>(mid - 8 * PPC);
-                        vb = *reinterpret_cast<const float4*>(mid + 8 * PPC);
-                    }
-                else
-                    va = *reinterpret_cast<const float4*>(ua + lane_bytes);
-#endif
-            }
-        else
-            {
-                const int n0 = c.n_first + 2 * tid + i * TRIP;
-                const int lo = c.n_begin, hi = c.n_end - 1;
-                const bool a0 = (n0 >= lo) && (n0 <= hi), a1 = (n0 + 1 >= lo) && (n0 + 1 <= hi);
-                const float2 x0 = a0 ? q[0] : make_float2(0.0f, 0.0f);
-                const float2 x1 = a1 ? q[1] : make_float2(0.0f, 0.0f);
-                va = make_float4(x0.x, x0.y, x1.x, x1.y);
-                if (NCH == 2)
-                    {
-                        const int m0 = n0 + 2 * PPC;
-                        const bool b0 = (m0 >= lo) && (m0 <= hi), b1 = (m0 + 1 >= lo) && (m0 + 1 <= hi);
-                        const float2 z0 = b0 ? q[2 * PPC] : make_float2(0.0f, 0.0f);
-                        const float2 z1 = b1 ? q[2 * PPC + 1] : make_float2(0.0f, 0.0f);
-                        vb = make_float4(z0.x, z0.y, z1.x, z1.y);
-                    }
-            }
-    };
     // paired taps (DER): one bit per chunk of 2 PPC samples (per WAVE: see judge), set where every value of the early and the late index chain stays inside one binade
     // (margins of 1/8 chip; see packed_trip).  Lane l judges chunk 64 m + l.  All of it happens HERE, before the accumulators exist: evaluated inside the
     // trip loop its temporaries cost the loop a dozen VGPRs and with them one wave per SIMD.  Two masks = 128 chunks; what lies
@@ -796,14 +814,7 @@ __device__ __forceinline__ void run_segment_packed(const JobCtx& c, const float2
             der_mask0 = judge(0);
             if (NCH * n_trips > 64) der_mask1 = judge(64);  // uniform
         }
-    float4 qa[PF], qb[PF];
-#pragma unroll
-    for (int j = 0; j < PF; j++)
-        {
-            qa[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            qb[j] = qa[j];
-            if (j < n_trips) load_trip(j, qa[j], qb[j]);  // uniform
-        }
+    if constexpr (!EARLY_LOADS) first_loads();
     v2f pa = zero, nfA = zero, nfB = zero;
     int until_reseed = 0, r_idx = 0, tbl0 = 0;
     // one trip; j: its slot in the load queue; FA / FB (compile time): chunk A / B reads its early tap next to the late one
