@@ -24,6 +24,9 @@
 // bit_transition_flag (acq.cc:110-112, :544): only the lags [offset, offset + effective) of the transform enter the search, as index
 // tau - offset -- an epilogue predicate.
 #include "pcps_fft.h"
+#ifndef GSH_OC_PASS_BARRIER
+#define GSH_OC_PASS_BARRIER 0  // 1: a barrier between the passes of oc_cell_kernel whatever the plan (A/B)
+#endif
 #include "fft_onchip.h"
 #include <cmath>
 #include <cstdlib>
@@ -594,7 +597,13 @@ __global__ __launch_bounds__(P::THREADS) void oc_cell_kernel(OcCellArgs a)
     const int prn = xp_i * a.prn_per + pl, bin = xb_i * a.bin_per + bl;
     if (prn >= a.n_prn || bin >= a.n_bins) continue;  // uniform over the work-group
     const int cell = prn * a.n_bins + bin;
-    if (pass > 0) __syncthreads();  // the previous cell's last reads of the exchange buffer have been issued and consumed before this cell's first writes
+    // Between two passes: the previous cell's last reads of the exchange buffer must have been consumed before this cell's first writes.  With the phased exchanges that
+    // needs no barrier of its own when exchange 2 ENDS in the region exchange 1 does not START in (25 x 25 x 40: three phases each, regions 0 1 0 / 1 0 1): the reads
+    // still in flight are of region 1, the first write goes to region 0 -- which nobody has read since the last barrier of exchange 2 --, and the barrier behind that
+    // write is behind every wave's last read.  Without it a wave that is done with its stage 3 (the waves of a SIMD take turns: 4 600, 7 100, 9 400 clocks) starts on
+    // the next cell's operands at once instead of waiting for the slowest (profiles/oc_cell_annotated.txt).
+    constexpr bool PASS_BARRIER = !P::EX64 || ((P::NP2 - 1 + P::START2) % 2 == P::START1) || GSH_OC_PASS_BARRIER;
+    if (PASS_BARRIER && pass > 0) __syncthreads();
     OC_STAMP_WALL(8);
     OC_STAMP(0);
 
@@ -617,7 +626,7 @@ __global__ __launch_bounds__(P::THREADS) void oc_cell_kernel(OcCellArgs a)
                     // all 2 * R1 operand loads are issued before the first product: the cell's registers are still free here, and one round of
                     // L2 / Infinity-Cache latency is cheaper than the two the scheduler otherwise settles for (12 loads, wait, 38 loads)
                     if (IDLE && have_operands)  // (uniform over the wave)
-                        oc::static_for<P::R1>([&](auto N1) GSH_AI { ra[decltype(N1)::value] = pa[decltype(N1)::value]; });
+                        oc::static_for<P::R1>([&](auto N1) GSH_AI { ra[decltype(N1)::value] = pa[IDLE ? decltype(N1)::value : 0]; });
                     else
                     {
                     cf xv[P::R1], cv[P::R1];
@@ -794,6 +803,7 @@ __global__ __launch_bounds__(P::THREADS) void oc_cell_kernel(OcCellArgs a)
                             });
 
                     }
+                int k_best = -1;
                 oc::static_for<P::R3>([&](auto K3) GSH_AI {
                     constexpr int k3 = decltype(K3)::value;
                     if constexpr (k3 >= K0)
@@ -807,12 +817,13 @@ __global__ __launch_bounds__(P::THREADS) void oc_cell_kernel(OcCellArgs a)
                                 sum += m;
                             const bool better = m > best;
                             best = better ? m : best;
-                            at = better ? static_cast<unsigned>(base + S * P::T3 * k3) : at;
+                            k_best = better ? k3 : k_best;  // (the element, an inline constant; its index is formed once, below -- not one add per element)
                             if (SECOND) mag[t + P::T3 * k3] = m;  // kept for the second scan -- in the exchange buffer, idle from here on, not in 40 registers
                         }
                     else if (SECOND)
                         mag[t + P::T3 * k3] = -1.0f;  // lags below the offset: never the second peak either
                 });
+                at = k_best < 0 ? 0xFFFFFFFFu : static_cast<unsigned>(base + S * P::T3 * k_best);
             }
         }
 #pragma unroll

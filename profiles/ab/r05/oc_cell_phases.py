@@ -81,3 +81,9 @@ starts_us = (wall[order, 0, 0] - t0) * 0.01
 print("cells entered by time (us since the first): " + ", ".join(f"{int((starts_us < t).sum())} by {t}" for t in (5, 20, 40, 60, 80, 100, 120)))
 late = (wall[:, 0, 0] - t0) * 0.01 > 5 * cell_us
 print(f"cells that start after {5 * cell_us:.0f} us (the sixth round): {int(late.sum())}")
+# per wave: the waves 10 .. 15 have no stage-3 butterfly (radix 40: threads 640 .. 1 023) and load their own operands of the next cell there
+print()
+print("median clocks per stage and wave (rows: waves 0 .. 15; columns: operands, stage 1, exchange 1, stage 2, exchange 2, stage 3 / prefetch, end):")
+for w in range(WAVES):
+    d = [(clk[:, w, k + 1] - clk[:, w, k]).astype(np.float64) for k in range(7)]
+    print(f"  wave {w:2d}  " + " ".join(f"{np.median(v):7.0f}" for v in d))
