@@ -214,7 +214,46 @@ struct JobCtx
     int aux_code_len{1};
     int aux_k_off{MC_MARGIN};
     int aux_k_lo{0}, aux_k_hi{-1};
+    // closed-loop kernel, windows of one exact seed per lane (run_segment_packed, `single`): the factors of the lanes' seeds, evaluated by two otherwise idle waves
+    // beside thread 0's end of the previous period (seed_table_fill below; tracking_loop.hip) -- null: every lane evaluates its own
+    const float2* seed_tab{nullptr};
 };
+// seed tables: exp(-j (rem + (n_first + 2 tid) step)) = A[-n_first] * W[tid / 64] * B[tid % 64]
+constexpr int SEED_B = 0;     // 64: exp(-j 2 l step)
+constexpr int SEED_W = 64;    // 16: exp(-j 128 v step)
+constexpr int SEED_A = 80;    //  2: exp(-j (rem - odd step)), odd = 0, 1
+constexpr int SEED_INC = 82;  // exp(-j step), exp(-j 2 PPC step), exp(-j 4 PPC step)
+constexpr int SEED_ENTRIES = 88;
+// one entry per lane of two waves (which = 0: the lane factors; 1: the wave factors, the two window parities, the three wave-uniform rotations).
+// The arguments are formed as run_segment_packed forms them (double products of the float step), each evaluated once (expmj: <= 2e-7 rad).
+__device__ __forceinline__ void seed_table_fill(float2* __restrict__ tab, float step, float rem, int lane, int which)
+{
+    asm volatile("" : "+v"(lane));  // (addresses formed here, not hoisted out of the caller's loop)
+    const double sd = static_cast<double>(step);
+    if (which == 0)
+        tab[SEED_B + lane] = expmj(static_cast<double>(2 * lane) * sd);
+    else if (lane < 21)
+        {
+            double ph;
+            int at;
+            if (lane < 16)
+                {
+                    ph = static_cast<double>(128 * lane) * sd;
+                    at = SEED_W + lane;
+                }
+            else if (lane < 18)
+                {
+                    ph = static_cast<double>(rem) + static_cast<double>(-(lane - 16)) * sd;
+                    at = SEED_A + (lane - 16);
+                }
+            else
+                {
+                    ph = (lane == 18 ? 1.0 : static_cast<double>((lane == 19 ? 2 : 4) * MC_PAIRS_PER_CHUNK)) * sd;
+                    at = SEED_INC + (lane - 18);
+                }
+            tab[at] = expmj(ph);
+        }
+}
 
 // One chunk = 256 pairs = 512 consecutive samples; thread `tid` owns samples n0, n0+1.
 // ZP: the centre tap's shift is exactly 0.0f (the prompt of an E/P/L or VE/E/P/L/VL set): (a + 0.0f) == a, so its add is skipped.
@@ -634,6 +673,20 @@ __device__ __forceinline__ void run_segment_packed(const JobCtx& c, const float2
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const v2f zero = {0.0f, 0.0f};
+    // seed tables (c.seed_tab, the closed-loop kernel): the six reads go out first -- their LDS round trip runs under the scalar set-up below
+    float2 tb_b = make_float2(1.0f, 0.0f), tb_wv = tb_b, tb_a0 = tb_b, tb_inc = tb_b, tb_w = tb_b, tb_w2 = tb_b;
+    if (c.seed_tab != nullptr)  // uniform
+        {
+            int tl = tid;
+            asm volatile("" : "+v"(tl));
+            const float2* __restrict__ S = c.seed_tab;
+            tb_b = S[SEED_B + (tl & 63)];
+            tb_wv = S[SEED_W + (tl >> 6)];
+            tb_a0 = S[SEED_A - c.n_first];
+            tb_inc = S[SEED_INC];
+            tb_w = S[SEED_INC + 1];
+            tb_w2 = S[SEED_INC + (NCH == 2 ? 2 : 1)];
+        }
     const int span = c.n_end - c.n_first;
     const int n_pairs = (span + 1) >> 1;
     const int n_full = span >> 1;                       // leading pairs whose second sample is in range
@@ -736,7 +789,23 @@ __device__ __forceinline__ void run_segment_packed(const JobCtx& c, const float2
     // instead and get their seeds from lane 3's, two samples back per lane (products with conj(inc)^2: one to three more roundings on three lanes of sixty-four).
     const bool single = GSH_MC_SINGLE_SEED && MRG && (n_trips_all <= RESEED);  // uniform
     v2f seed_direct = zero, single_inc = zero, single_w = zero, single_w2 = zero;
-    if (single)
+    if (single && c.seed_tab != nullptr)  // uniform
+        {
+            // the seed from its three factors (two complex products), the rotations from the table: a dozen instructions instead of a transcendental evaluation
+            // per lane -- sixteen waves' worth of them were a seventh of the period's vector instructions
+            // (the table's addresses are formed HERE, from a thread index the compiler cannot see through: hoisted out of the period loop as loop invariants they
+            // would sit in registers the loop's constants need -- scratch)
+            const float2 sdir = cmul(cmul(tb_a0, tb_wv), tb_b);
+            seed_direct = (v2f){sdir.x, sdir.y};
+            auto uniform = [&](float2 u) -> v2f {
+                return (v2f){__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, u.x))),
+                    __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, u.y)))};
+            };
+            single_inc = uniform(tb_inc);
+            single_w = uniform(tb_w);
+            single_w2 = uniform(tb_w2);
+        }
+    else if (single)
         {
             double ph;
             if (lane == 0)
@@ -1344,7 +1413,7 @@ struct NoHook
 template <int NT, int MODE, bool AUX = false, bool PAIRK = false, bool SUM = true, typename Hook = NoHook>
 __device__ __forceinline__ void correlate_window(const float2* __restrict__ stream, unsigned long long sample_offset, int n_samples,
     const float* __restrict__ tab, int code_len, const float (&sh)[NT], float rem_carr, float phase_step, float phase_rate, float rem_code,
-    float code_step, float code_rate, float2* __restrict__ red, const float* tab_aux = nullptr, float aux_shift = 0.0f, Hook hook = Hook())
+    float code_step, float code_rate, float2* __restrict__ red, const float* tab_aux = nullptr, float aux_shift = 0.0f, Hook hook = Hook(), const float2* seed_tab = nullptr)
 {
     static_assert(!AUX || (MODE == 0 && NT < GSH_MAX_TAPS), "the fused tap exists for the standard mode and needs a free slot in `red`");
     const int tid = threadIdx.x;
@@ -1362,6 +1431,7 @@ __device__ __forceinline__ void correlate_window(const float2* __restrict__ stre
     c.n_end = n_samples;
     const int odd = static_cast<int>(sample_offset & 1ULL);
     c.n_first = -odd;
+    c.seed_tab = seed_tab;
     const float2* __restrict__ base = stream + (sample_offset - static_cast<unsigned long long>(odd));
     int rot[NT];
     rot[0] = 0;
@@ -1544,18 +1614,18 @@ __device__ __forceinline__ void sum_wave_partials(const float2* __restrict__ red
 template <int NT, bool PAIRK = false, bool SUM = true, typename Hook = NoHook>
 __device__ __forceinline__ void correlate_window_std(const float2* __restrict__ stream, unsigned long long sample_offset, int n_samples,
     const float* __restrict__ tab, int code_len, const float (&sh)[NT], float rem_carr, float phase_step, float rem_code, float code_step,
-    float2* __restrict__ red, Hook hook = Hook())
+    float2* __restrict__ red, Hook hook = Hook(), const float2* seed_tab = nullptr)
 {
-    correlate_window<NT, 0, false, PAIRK, SUM, Hook>(stream, sample_offset, n_samples, tab, code_len, sh, rem_carr, phase_step, 0.0f, rem_code, code_step, 0.0f, red, nullptr, 0.0f, hook);
+    correlate_window<NT, 0, false, PAIRK, SUM, Hook>(stream, sample_offset, n_samples, tab, code_len, sh, rem_carr, phase_step, 0.0f, rem_code, code_step, 0.0f, red, nullptr, 0.0f, hook, seed_tab);
 }
 
 // standard mode with the fused data-component tap: red[0..NT) the taps, red[NT] the fused one
 template <int NT, bool SUM = true, typename Hook = NoHook>
 __device__ __forceinline__ void correlate_window_std_aux(const float2* __restrict__ stream, unsigned long long sample_offset, int n_samples,
     const float* __restrict__ tab, const float* tab_aux, float aux_shift, int code_len, const float (&sh)[NT], float rem_carr, float phase_step,
-    float rem_code, float code_step, float2* __restrict__ red, Hook hook = Hook())
+    float rem_code, float code_step, float2* __restrict__ red, Hook hook = Hook(), const float2* seed_tab = nullptr)
 {
-    correlate_window<NT, 0, true, false, SUM, Hook>(stream, sample_offset, n_samples, tab, code_len, sh, rem_carr, phase_step, 0.0f, rem_code, code_step, 0.0f, red, tab_aux, aux_shift, hook);
+    correlate_window<NT, 0, true, false, SUM, Hook>(stream, sample_offset, n_samples, tab, code_len, sh, rem_carr, phase_step, 0.0f, rem_code, code_step, 0.0f, red, tab_aux, aux_shift, hook, seed_tab);
 }
 }  // namespace GSH_MC_NS
 namespace mcdev = GSH_MC_NS;

@@ -148,6 +148,9 @@ struct SerialMail  // results the code-loop lane and the lock-detector lane hand
     int pad0;
     int may_trip_code, may_trip_carr;
     int cn0_seq, carr_seq;
+    // thread 0 -> the two seed-table waves: the next window's carrier phase and phase step are final (right behind update_tracking_vars)
+    int step_seq;
+    float seed_step, seed_rem;
 #ifdef GSH_TRK_PROFILE
     long long t_lane[4];  // when each of the four lanes was done, in clocks since the correlation ended (-DGSH_TRK_PROFILE=3 puts them into the record)
 #endif
@@ -172,6 +175,9 @@ __device__ __forceinline__ void lane_waits(int& word, int value)
     while (__hip_atomic_load(&word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != value) __builtin_amdgcn_s_sleep(1);
     asm volatile("" ::: "memory");
 }
+#ifndef GSH_TRK_SEED_TABLES
+#define GSH_TRK_SEED_TABLES 1  // the lanes' seeds from tables two idle waves fill beside thread 0's end of the period (0: every lane evaluates its own; A/B)
+#endif
 #ifndef GSH_TRK_SERIAL_WAVES
 #define GSH_TRK_SERIAL_WAVES 4
 #endif
@@ -623,6 +629,7 @@ struct NextWindow  // what thread 0 publishes for the next correlation (do_corre
     float phase_rate, code_rate;  // high_dyn only
     int go;      // 1: correlate the window; 0: leave the loop; 2 (live mode only): drain the record stores, publish, and wait for samples (live_wait)
     int narrow;  // correlate with the narrow tap spacing (after extended integration has started)
+    int seed_ok; // the seed tables in LDS were formed from exactly this rem_carr and phase_step (GSH_TRK_SEED_TABLES)
 };
 
 __device__ __forceinline__ void publish(NextWindow& w, const TrkChannel& s, const gsh_trk_conf& c, unsigned long long n_stream, int more,
@@ -638,6 +645,7 @@ __device__ __forceinline__ void publish(NextWindow& w, const TrkChannel& s, cons
     w.code_rate = __fmul_rn(static_cast<float>(s.code_phase_rate_step_chips), spcf);
     w.go = (more && s.active && s.pos + c.vector_length <= n_stream && s.pos >= ring_oldest) ? 1 : 0;
     w.narrow = 0;  // the caller overrides it from the channel's LockState
+    w.seed_ok = 0;
 }
 
 // A field of a period's record: in the launched form a store into the launch's block of records (device or host memory; the end of the kernel makes it
@@ -778,6 +786,8 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
     __shared__ __align__(16) TrkChannel s;
     __shared__ __align__(16) LockState lk;
     __shared__ SerialMail mail;  // between the lanes that share a period's loop arithmetic (below)
+    constexpr bool SEEDS = GSH_TRK_SEED_TABLES && !HD;
+    __shared__ __align__(16) float2 seed_tab[SEEDS ? mcdev::SEED_ENTRIES : 1];
     __shared__ __align__(16) HotConstants hc;
     __shared__ std::conditional_t<LIVE, LiveShared, NoLiveShared> lv;  // (not allocated in the launched form: nothing there touches it)
     // live form: the period's record is assembled HERE by the lanes that know its fields and written to the host's record ring by ONE wave
@@ -835,6 +845,7 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
             hc.vector_length = c.vector_length;
             hc.code_samples_per_chip_f = static_cast<float>(c.code_samples_per_chip);
             mail.code_seq = mail.cn0_seq = mail.carr_seq = mail.inputs_cn0 = mail.inputs_carr = 0;
+            mail.step_seq = 0;
             mail.lost = mail.lost_carrier = 0;
             mail.may_trip_code = (lk.code_lock_fail_counter + 1 > c.max_code_lock_fail) ? 1 : 0;
             mail.may_trip_carr = (lk.carrier_lock_fail_counter + 1 > c.max_carrier_lock_fail) ? 1 : 0;
@@ -856,8 +867,18 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                     lv.pub_pos = s.pos;
                     lv.wpos = s.pos % a.ring_capacity;
                 }
+            if constexpr (SEEDS) win.seed_ok = 1;  // (filled right below: EVERY period of every launch takes its seeds from the tables -- a launch's first period
+                                                   // from a per-lane evaluation would make the records depend on where the launches' boundaries fall)
         }
     __syncthreads();
+    if constexpr (SEEDS)
+        {
+            int tl = tid;
+            asm volatile("" : "+v"(tl));  // (nothing of this may be kept for the loop: its registers are spoken for)
+            const int wv = tl >> 6;
+            if (wv == SERIAL_WAVES + 1 || wv == SERIAL_WAVES + 2) mcdev::seed_table_fill(seed_tab, win.phase_step, win.rem_carr, tl & 63, wv - (SERIAL_WAVES + 1));
+            __syncthreads();
+        }
 
     int done = 0;
     for (int e = 0; e < a.n_epochs; e++)
@@ -916,6 +937,7 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                     return a.records[static_cast<size_t>(ch) * a.n_epochs + e];
             };
             const float rem_carr = win.rem_carr, phase_step = win.phase_step, rem_code = win.rem_code, code_step = win.code_step;
+            const float2* const seeds = (SEEDS && GSH_TRK_SEED_TABLES != 2 && win.seed_ok) ? seed_tab : nullptr;  // uniform
             float sh[NT];
             {
                 const float spcf = static_cast<float>(c.code_samples_per_chip);
@@ -983,13 +1005,13 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                     // them up (sum_wave_partials: same order, same sums), the others go straight on to the barrier that ends the period.  win is rewritten and the
                     // rows are reused only after that barrier.  (Until round 3: sum by NT threads -> barrier -> every thread read the sums -> barrier.)
                     if (fused_data)
-                        correlate_window_std_aux<NT, false>(a.stream, wpos, static_cast<int>(c.vector_length), tab, tab_data, sh_data[0], code_len, sh, rem_carr, phase_step, rem_code, code_step, red, live_hook);
+                        correlate_window_std_aux<NT, false>(a.stream, wpos, static_cast<int>(c.vector_length), tab, tab_data, sh_data[0], code_len, sh, rem_carr, phase_step, rem_code, code_step, red, live_hook, seeds);
 #ifdef GSH_TRK_PAIRED_TAPS  // early tap read next to the late one: fewer instructions per trip, yet 0.5 us per period slower here (profiles/ab/r03/closed_loop_paired_taps.txt)
                     else if (NT == 3 && (static_cast<double>(sh[2]) - static_cast<double>(sh[0]) == 1.0) && code_step > 0.0f)  // mcorr_pair_eligible (uniform)
                         correlate_window_std<NT, true, false>(a.stream, wpos, static_cast<int>(c.vector_length), tab, code_len, sh, rem_carr, phase_step, rem_code, code_step, red);
 #endif
                     else
-                        correlate_window_std<NT, false, false>(a.stream, wpos, static_cast<int>(c.vector_length), tab, code_len, sh, rem_carr, phase_step, rem_code, code_step, red, live_hook);
+                        correlate_window_std<NT, false, false>(a.stream, wpos, static_cast<int>(c.vector_length), tab, code_len, sh, rem_carr, phase_step, rem_code, code_step, red, live_hook, seeds);
                     if (tid < 64 * SERIAL_WAVES)  // the waves that hold a lane of the loop arithmetic below
                         {
                             float2 sums[NT + 1];
@@ -1340,6 +1362,7 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                                 }
                             s.active = 0;
                             publish(win, s, c, a.n_stream, 0);
+                            if constexpr (SEEDS) lane_says(mail.step_seq, seq);  // (the table waves must not wait for ever; win.seed_ok is 0)
                             if constexpr (LIVE) live_advance(a, s.pos, 0, win, lv, c.vector_length);  // (the channel is stopped: the drain round publishes this record and leaves)
                         }
                     else
@@ -1474,6 +1497,12 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                         join_and_update(std::true_type{});
                     else
                         join_and_update(std::false_type{});
+                    if constexpr (SEEDS)
+                        {
+                            mail.seed_step = static_cast<float>(st_phase_step);
+                            mail.seed_rem = st_rem_carr;
+                            lane_says(mail.step_seq, seq);
+                        }
 
 #ifdef GSH_TRK_PROFILE
                     const long long t_d = clock64();
@@ -1681,6 +1710,10 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                         win.code_rate = __fmul_rn(static_cast<float>(st_code_rate), spcf);
                         win.go = (e + 1 < a.n_epochs && new_pos + k_vlen <= a.n_stream && new_pos >= a.ring_oldest) ? 1 : 0;
                         win.narrow = HD ? lk.narrow : st_narrow;
+                        // (the tables are formed from what was said behind update_tracking_vars, and nothing between there and here assigns to st_phase_step or
+                        // st_rem_carr -- the symbol machine and the record only read them --, so they are this window's: no look back into LDS on the lane the
+                        // work-group waits for)
+                        win.seed_ok = SEEDS ? 1 : 0;
                     }
                     if constexpr (LIVE) live_advance(a, new_pos, 1, win, lv, k_vlen);
 #ifdef GSH_TRK_PROFILE
@@ -1709,6 +1742,20 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                         }
 #endif
 #endif
+                        }
+                }
+            if constexpr (SEEDS)
+                {
+                    // The seed tables of the NEXT window: two waves that have nothing else to do until the barrier that ends the period wait for thread 0's word
+                    // (behind update_tracking_vars: carrier phase and phase step are final there; the symbol machine, the record and the next window -- a
+                    // thousand clocks of thread 0 -- follow) and evaluate one factor per lane.  Nobody waits for them but that barrier.
+                    int tl = tid;
+                    asm volatile("" : "+v"(tl));
+                    const int wv = tl >> 6;
+                    if (GSH_TRK_SEED_TABLES != 3 && (wv == SERIAL_WAVES + 1 || wv == SERIAL_WAVES + 2))  // uniform over the wave
+                        {
+                            lane_waits(mail.step_seq, e + 1);
+                            mcdev::seed_table_fill(seed_tab, mail.seed_step, mail.seed_rem, tl & 63, wv - (SERIAL_WAVES + 1));
                         }
                 }
             done = e + 1;
