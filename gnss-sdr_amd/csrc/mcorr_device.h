@@ -832,7 +832,7 @@ __device__ __forceinline__ void run_segment_packed(const JobCtx& c, const float2
             single_w2 = (v2f){w21.x, w21.y};
         }
     float2 Lf = make_float2(1.0f, 0.0f);
-    if (!single) Lf = expmj(static_cast<double>(2 * tid) * sd);
+    if (!single) Lf = expmj(static_cast<double>(2 * tid) * sd);  // (from the seed tables, W[tid / 64] B[tid % 64], config 4's period is 0.6 % LONGER: profiles/ab/r05/closed_loop_notes.txt)
     const v2f L = {Lf.x, Lf.y};
     auto fill_table = [&](int r0) -> float2 {  // entry of this lane for the re-seeds r0 .. r0 + TBL - 1
         double ph;
