@@ -1298,6 +1298,9 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                 }
             if (tid == 0)
                 {
+#ifdef GSH_TRK_EXP_EARLY_SAY  /* (timing experiment only: the table waves start on last period's values -- wrong seeds, no waiting) */
+                    if constexpr (SEEDS) lane_says(mail.step_seq, seq);
+#endif
                     bool lost = false;
                     if (!flag_join)
                         lost = (mail.lost | mail.lost_carrier) != 0;
