@@ -633,7 +633,7 @@ def dropin_metric(channels, fs, periods, periods_per_call=20, seconds=0.0):
     return d
 
 
-def sharded_legs(torch, dist, dev, local, rank, world, ring, block, fs, n, C, epochs=200):
+def sharded_legs(torch, cp, dev, local, rank, world, ring, block, fs, n, C, epochs=200):
     """The two other paths a receiver runs, on the rings of the stream group (every rank calls this; rank 0 gets the figures): SURVEY.md 8e --
     closed loop: channel c -> GPU c mod G, here C channels per GPU (weak scaling), each GPU's loop bound to ITS ring of the replicated stream;
     acquisition: PRN p -> GPU p mod G over the same replicated 1 ms block (strong scaling: 32 PRNs x 41 bins in all, 32 / G per GPU).
@@ -643,12 +643,8 @@ def sharded_legs(torch, dist, dev, local, rank, world, ring, block, fs, n, C, ep
     from gnss_sdr_amd.tracking_loop import TrackingLoop, trk_conf
     out = {}
 
-    def reduce_max(v):
-        if dist is None:
-            return v
-        t = torch.tensor([v], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
+    from gnss_sdr_amd.sharding import prns_of, weak_channel_prn
+    reduce_max = cp.reduce_max
 
     lo, hi = ring.range()
     base = hi - block  # the newest whole block in the ring
@@ -658,7 +654,7 @@ def sharded_legs(torch, dist, dev, local, rank, world, ring, block, fs, n, C, ep
         loop.set_stream_ring(ring)
         rng = np.random.default_rng(0x5EED0006 + rank)
         for c in range(C):
-            loop.start(c, gps_l1_ca_code((rank * C + c) % 32 + 1), base + int(rng.integers(0, n)), base, float(rng.uniform(-5000, 5000)))
+            loop.start(c, gps_l1_ca_code(weak_channel_prn(rank, C, c)), base + int(rng.integers(0, n)), base, float(rng.uniform(-5000, 5000)))
         loop.time_run(epochs, reps=10)
         ms = reduce_max(loop.time_run(epochs, reps=5))
         loop.close()
@@ -669,7 +665,7 @@ def sharded_legs(torch, dist, dev, local, rank, world, ring, block, fs, n, C, ep
         out["closed_loop_sharded"] = {"error": str(e)}
         reduce_max(0.0)
     try:
-        mine = [p for p in range(1, 33) if (p - 1) % world == rank]
+        mine = prns_of(rank, world, 32)
         acq = PcpsAcquisitionBank(fs_in=int(fs), fft_size=n, doppler_max=5000, doppler_step=250, samples_per_chip=int(np.ceil(fs / 1.023e6)), samples_per_code=float(n),
                                   max_prn=max(len(mine), 1), num_doppler_bins=41, device=local)
         for k, p in enumerate(mine):
@@ -678,8 +674,7 @@ def sharded_legs(torch, dist, dev, local, rank, world, ring, block, fs, n, C, ep
             acq.dwell_ring(ring, base + 7, max(len(mine), 1))
         reps = 50
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+        cp.barrier()
         t0 = time.perf_counter()
         for _ in range(reps):
             acq.dwell_ring(ring, base + 7, max(len(mine), 1))
@@ -816,12 +811,40 @@ class _OnlyTheLineOnStdout:
         os.write(self.saved, (text + "\n").encode())
 
 
+def spawn_ranks(a):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks here, the way the driver does (torch.distributed.run, one rank
+    per GPU, rendezvous on 127.0.0.1), and hand their exit code on.  Rank 0's JSON line goes straight to this process's stdout."""
+    import socket
+    import subprocess
+    import torch
+    share = os.environ.get("GSH_BENCH_SHARE_GPU") == "1"
+    visible = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if visible < a.gpus and not share:
+        raise SystemExit(f"bench.py --gpus {a.gpus}: only {visible} GPU(s) visible on this node (one rank per GPU; GSH_BENCH_SHARE_GPU=1 is the self-test "
+                         "that puts every rank on GPU 0, with GSH_RCCL_LIBRARY naming the stand-in collective library)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     a = parse()
+    if a.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        spawn_ranks(a)
     the_line = _OnlyTheLineOnStdout()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started {world} rank(s) (WORLD_SIZE): they must agree")
     import torch
     import gnss_sdr_amd
     from gnss_sdr_amd.tracking import CorrelatorBank
@@ -831,18 +854,15 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP engine has no CPU fallback)")
     if os.environ.get("GSH_BENCH_SHARE_GPU") == "1":
-        local = 0  # self-test of the N > 1 code path on a one-GPU box (with GSH_BENCH_BACKEND=gloo): every rank uses GPU 0
+        local = 0  # self-test of the N > 1 code path on a one-GPU box (with GSH_BENCH_BACKEND=gloo and GSH_RCCL_LIBRARY=the stand-in): every rank uses GPU 0
+    elif local >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} wants GPU {local}, only {torch.cuda.device_count()} visible")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("GSH_BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm; only the barrier / MAX-reduce / id hand-over use it
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+    from gnss_sdr_amd.sharding import ControlPlane, weak_channel_prn
+    # "nccl" is RCCL on ROCm; only the barrier / MAX-reduce / id hand-over use it (gnss-sdr_amd/sharding.py)
+    cp = ControlPlane(os.environ.get("GSH_BENCH_BACKEND", "nccl"), device=dev)
+    assert (cp.rank, cp.world) == (rank, world)
 
     fs, n, C, E, T = a.fs, int(round(a.fs * 1e-3)), a.channels, a.epochs, a.taps
     block = (E + 2) * n                    # one stream block: E epochs + the run-in the per-channel window offsets need
@@ -860,7 +880,7 @@ def main():
     stream = cs.cuda_stream
     bank = CorrelatorBank(C, 1023, device=local)
     for c in range(C):
-        bank.set_code(c, gps_l1_ca_code((rank * C + c) % 32 + 1))
+        bank.set_code(c, gps_l1_ca_code(weak_channel_prn(rank, C, c)))
     jobs, rows = build_jobs(C, E, n, fs, T, dop, cph, rank)
     bank.set_splits(1)
     G = ring = raw_src = None
@@ -876,10 +896,8 @@ def main():
         # N > 1 (or the self-test of that path): every block reaches the GPUs through the engine's stream group -- 8-bit items in, complex64
         # in every GPU's ring -- and the correlator bank reads the ring
         from gnss_sdr_amd.sample_stream import StreamGroup
-        uid = [StreamGroup.unique_id() if (rank == 0 and world > 1) else None]
-        if dist and world > 1:
-            dist.broadcast_object_list(uid, src=0)     # 128 bytes of control plane
-        G = StreamGroup.from_rank(local, rank, world, uid[0], 3 * block + 2, block // 2, os.environ.get("GSH_BENCH_DIST", "broadcast"))
+        uid = cp.communicator_id()                      # 128 bytes of control plane (None for a world of one)
+        G = StreamGroup.from_rank(local, rank, world, uid, 3 * block + 2, block // 2, os.environ.get("GSH_BENCH_DIST", "broadcast"))
         ring = G.ring(0)
         if rank == 0:
             raw_src = torch.view_as_real(x0).mul(30.0).round_().clamp_(-127, 127).to(torch.int8).reshape(-1).contiguous()
@@ -914,8 +932,7 @@ def main():
         for k in range(a.warmup):
             step(a.settle_steps + k)
         torch.cuda.synchronize()
-        if dist:
-            dist.barrier()
+        cp.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for k in range(a.steps):
@@ -923,14 +940,11 @@ def main():
         torch.cuda.synchronize()
         if G is not None:
             G.wait()
-        if dist:
-            dist.barrier()
+        cp.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-    if dist:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    reduce_max, reduce_sum = cp.reduce_max, cp.reduce_sum
+    dt = reduce_max(dt)
 
     # ---- roofline of the dominant kernel: HIP events on the launch stream, inputs resident; taken straight after the timed region,
     # before the host-side spot check lets the GPU fall idle again
@@ -939,26 +953,39 @@ def main():
 
     # ---- spot-check against the oracle (not timed): a few jobs of the last launch
     out = bank.read_outputs()
-    if rank == 0:
-        from helpers import oracle_job, scale_err
-        if not grouped:
-            # time_launches() re-ran the last launch: the block the final step ended on
-            base_last = ((max(a.settle_steps, 0) + a.warmup + a.steps) * BPS - 1) % NB * block
-            xh = x[base_last:base_last + block].cpu().numpy()
-        else:
-            # the ring holds the 8-bit block converted back to float: that is what the kernel correlated
-            xh = (raw_src.to(torch.float32).reshape(-1, 2)).cpu().numpy()
-            xh = (xh[:, 0] + 1j * xh[:, 1]).astype(np.complex64)
-        for j in (0, 1, C + 3, len(rows) - 1):
-            o32, t64, sabs = oracle_job(oracle.ca_code(rows[j]["code_slot"] % 32 + 1), xh, rows[j])
-            err = scale_err(out[j, :T], t64, sabs)
-            if not np.all(err <= 1e-6):
-                raise SystemExit(f"bench: GPU result of job {j} disagrees with the oracle: {out[j, :T]} vs {t64}")
+    from helpers import oracle_job, scale_err
+    if not grouped:
+        # time_launches() re-ran the last launch: the block the final step ended on
+        base_last = ((max(a.settle_steps, 0) + a.warmup + a.steps) * BPS - 1) % NB * block
+        xh = x[base_last:base_last + block].cpu().numpy()
+    else:
+        # the ring holds the 8-bit block converted back to float: that is what the kernel correlated.  Only rank 0 made the block; every other rank checks
+        # what REACHED ITS RING through the group (its own copy read back from its own HBM) -- a wrong chunk offset anywhere shows here
+        lo_r, hi_r = ring.range()
+        xh = np.concatenate([ring.read(hi_r - block + k, min(1 << 20, block - k)) for k in range(0, block, 1 << 20)])
+        if rank == 0:
+            want = raw_src.to(torch.float32).reshape(-1, 2).cpu().numpy()
+            if not np.array_equal(xh.view(np.float32).reshape(-1, 2), want):
+                raise SystemExit("bench: rank 0's ring does not hold the block it pushed")
+    worst = 0.0
+    for j in (0, 1, C + 3, len(rows) - 1):
+        o32, t64, sabs = oracle_job(oracle.ca_code(weak_channel_prn(rank, C, rows[j]["code_slot"])), xh, rows[j])
+        err = scale_err(out[j, :T], t64, sabs)
+        if not np.all(err <= 1e-6):
+            raise SystemExit(f"bench: rank {rank}: GPU result of job {j} disagrees with the oracle: {out[j, :T]} vs {t64}")
+        worst = max(worst, float(np.max(err)))
+    if grouped:
+        # every rank's ring must hold the same block: a checksum of checksums over the ranks
+        crc = float(int(np.frombuffer(xh.tobytes(), dtype=np.uint32).sum(dtype=np.uint64)) % (1 << 40))
+        if not cp.same_everywhere(crc):
+            raise SystemExit(f"bench: rank {rank}: the replicated block differs between the ranks")
+    spot = {"ranks_checked": int(round(reduce_sum(1.0))), "jobs_per_rank": 4, "worst_err": reduce_max(worst), "bar": 1e-6,
+            "what": "|gpu - float64 truth| / sum|x| of 4 jobs of the last launch on EVERY rank" + (", each against its own ring's copy of the replicated block" if grouped else "")}
 
     sharded = None
     if grouped:
         # the closed loop and the acquisition on the replicated stream (every rank takes part; see sharded_legs)
-        sharded = sharded_legs(torch, dist, dev, local, rank, world, ring, block, fs, n, C)
+        sharded = sharded_legs(torch, cp, dev, local, rank, world, ring, block, fs, n, C)
     if rank == 0:
         pmc = load_pmc()
         total_corr = float(C) * T * E * BPS * a.steps * world
@@ -984,9 +1011,15 @@ def main():
             "roofline": tracking_roofline(C, E, T, n, k_ms, pmc),
             "kernel_only_value": float(C) * T * E / (k_ms * 1e-3),
             # the stream group under the launches (N > 1: RCCL over xGMI inside the engine; N = 1: no group, the block is resident)
-            "rccl_ranks": world if grouped else 0,
+            "rccl_ranks": G.rccl_info()["ranks"] if G is not None else 0,
             "stream_group_mode": os.environ.get("GSH_BENCH_DIST", "broadcast") if grouped else None,
+            "spot_check": spot,
         }
+        if G is not None and res["rccl_ranks"] > 0:
+            from gnss_sdr_amd.sample_stream import StreamGroup
+            res["rccl_library"] = StreamGroup.library()
+            res["rccl_library_is_test_stub"] = G.rccl_info()["version"] == 99999   # tests/host/fake_rccl.cc: a functional self-test, its rates mean nothing
+            res["rccl_calls"] = G.rccl_info()["collectives"]
         if sharded is not None:
             res.update(sharded)
         # ---- the other GPU legs first, while the device is still at its working clocks (the CPU legs below leave it idle for ~40 s; what runs after
@@ -1036,9 +1069,7 @@ def main():
     bank.close()
     if G is not None:
         G.close()
-    if dist:
-        dist.barrier()
-        dist.destroy_process_group()
+    cp.close()
 
 
 if __name__ == "__main__":

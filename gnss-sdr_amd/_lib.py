@@ -173,6 +173,8 @@ SYMBOLS = {
     "gsh_stream_group_push_device": (C.c_int, [_P, _P, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64)]),
     "gsh_stream_group_wait": (C.c_int, [_P]),
     "gsh_stream_group_rccl_info": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]),
+    "gsh_stream_group_plan": (C.c_int, [C.c_uint64, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),
+    "gsh_comm_library": (C.c_int, [C.c_char_p, C.c_int]),
     "gsh_stream_range": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "gsh_stream_read": (C.c_int, [_P, C.c_uint64, C.c_uint64, _F]),
     "gsh_convert_samples_device": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, _P, C.c_uint64, _P]),

@@ -17,10 +17,12 @@
 #include "sample_stream.h"
 #include <dlfcn.h>
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <string>
 #include <vector>
 
 namespace
@@ -54,31 +56,62 @@ struct Rccl
     int (*GetVersion)(int*){nullptr};
 };
 
+// GSH_RCCL_LIBRARY=<path> names the collective library to load instead of the system's librccl (a site's own RCCL build; the test-only stand-in
+// tests/host/libfake_rccl.so that lets the N > 1 paths below run on a one-GPU box).  Read at every group / id creation: a process may switch between
+// groups, never while a group made with the other library is alive.
+struct RcclSlot
+{
+    std::mutex m;
+    std::string chosen;   // the GSH_RCCL_LIBRARY value the table below was resolved for
+    bool resolved{false};
+    Rccl table;
+    std::string path;     // where the loaded library lives (dladdr)
+};
+
+RcclSlot& slot()
+{
+    static RcclSlot s;
+    return s;
+}
+
 Rccl* rccl()
 {
-    static Rccl r;
-    static std::once_flag once;
-    std::call_once(once, [] {
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
-            {
-                r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-                if (r.lib != nullptr) break;
-            }
-        if (r.lib == nullptr) return;
-        auto sym = [&](const char* n) { return dlsym(r.lib, n); };
-        r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
-        r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
-        r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(sym("ncclCommInitAll"));
-        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
-        r.Broadcast = reinterpret_cast<decltype(r.Broadcast)>(sym("ncclBroadcast"));
-        r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
-        r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
-        r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
-        r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
-        r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
-        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
-        r.GetVersion = reinterpret_cast<decltype(r.GetVersion)>(sym("ncclGetVersion"));
-    });
+    RcclSlot& S = slot();
+    std::lock_guard<std::mutex> lock(S.m);
+    const char* env = std::getenv("GSH_RCCL_LIBRARY");
+    const std::string want = env ? env : "";
+    Rccl& r = S.table;
+    if (!S.resolved || want != S.chosen)
+        {
+            r = Rccl();
+            S.path.clear();
+            S.chosen = want;
+            S.resolved = true;
+            if (!want.empty())
+                r.lib = dlopen(want.c_str(), RTLD_NOW | RTLD_LOCAL);  // (named explicitly: no silent fall-back to the system's library)
+            else
+                for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+                    {
+                        r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+                        if (r.lib != nullptr) break;
+                    }
+            if (r.lib == nullptr) return nullptr;
+            auto sym = [&](const char* n) { return dlsym(r.lib, n); };
+            r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+            r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+            r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(sym("ncclCommInitAll"));
+            r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+            r.Broadcast = reinterpret_cast<decltype(r.Broadcast)>(sym("ncclBroadcast"));
+            r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
+            r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
+            r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
+            r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
+            r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
+            r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+            r.GetVersion = reinterpret_cast<decltype(r.GetVersion)>(sym("ncclGetVersion"));
+            Dl_info info;
+            if (r.Broadcast != nullptr && dladdr(reinterpret_cast<void*>(r.Broadcast), &info) != 0 && info.dli_fname != nullptr) S.path = info.dli_fname;
+        }
     const bool ok = r.lib && r.GetUniqueId && r.CommInitRank && r.CommInitAll && r.CommDestroy && r.Broadcast && r.AllGather && r.Send && r.Recv && r.GroupStart &&
                     r.GroupEnd;
     return ok ? &r : nullptr;
@@ -165,6 +198,31 @@ int group_alloc(gsh_stream_group** out, const int* devices, int n_local, uint64_
     return GSH_OK;
 }
 
+// The exchange plan of one rank for one block: the ONLY place where chunk sizes, offsets, peers and the grouping of the calls are decided.  replicate()
+// below issues exactly these operations through RCCL; gsh_stream_group_plan hands the same list to whoever wants to check it (tests execute it over
+// torch.distributed / gloo on CPU tensors: tests/test_sharding_gloo.py).
+int make_plan(uint64_t bytes, int world, int rank, int mode, std::vector<gsh_group_op_t>& ops, uint64_t* padded_out)
+{
+    ops.clear();
+    const uint64_t padded = padded_bytes(static_cast<size_t>(bytes), world);
+    const uint64_t chunk = padded / static_cast<uint64_t>(world);
+    if (padded_out) *padded_out = padded;
+    if (mode == GSH_GROUP_BROADCAST)
+        {
+            // phase 0: the whole (padded) staging buffer from rank 0, in place
+            ops.push_back(gsh_group_op_t{GSH_GROUP_OP_BROADCAST, 0, 0, GSH_GROUP_BUF_STAGE, GSH_GROUP_BUF_STAGE, 0, 0, padded});
+            return GSH_OK;
+        }
+    // phase 0 -- scatter: rank 0 sends piece r to rank r over its link to r (its own piece to itself); everybody receives its piece
+    if (rank == 0)
+        for (int r = 0; r < world; r++)
+            ops.push_back(gsh_group_op_t{GSH_GROUP_OP_SEND, r, 0, GSH_GROUP_BUF_STAGE, GSH_GROUP_BUF_NONE, static_cast<uint64_t>(r) * chunk, 0, chunk});
+    ops.push_back(gsh_group_op_t{GSH_GROUP_OP_RECV, 0, 0, GSH_GROUP_BUF_NONE, GSH_GROUP_BUF_PIECE, 0, 0, chunk});
+    // phase 1 -- the all-gather of the pieces completes the block everywhere (piece of rank r lands at r * chunk of every staging buffer)
+    ops.push_back(gsh_group_op_t{GSH_GROUP_OP_ALLGATHER, 0, 1, GSH_GROUP_BUF_PIECE, GSH_GROUP_BUF_STAGE, 0, 0, chunk});
+    return GSH_OK;
+}
+
 // queue the replication of `bytes` raw bytes: on the root's local ring the block is in stage[slot][root_local]; afterwards every local
 // ring's stage[slot] holds it
 int replicate(gsh_stream_group* g, size_t bytes, int slot)
@@ -172,45 +230,49 @@ int replicate(gsh_stream_group* g, size_t bytes, int slot)
     if (!g->use_rccl) return GSH_OK;
     Rccl* R = rccl();
     GSH_REQUIRE(R != nullptr, "RCCL (librccl.so) could not be loaded");
-    const size_t padded = padded_bytes(bytes, g->world);
-    const size_t chunk = padded / static_cast<size_t>(g->world);
     const size_t n_local = g->rings.size();
-    if (g->mode == GSH_GROUP_BROADCAST)
+    std::vector<std::vector<gsh_group_op_t>> plans(n_local);
+    int phases = 0;
+    for (size_t i = 0; i < n_local; i++)
         {
-            GSH_RCCL(R->GroupStart());
+            make_plan(bytes, g->world, g->ranks[i], g->mode, plans[i], nullptr);
+            for (const gsh_group_op_t& op : plans[i]) phases = std::max(phases, op.phase + 1);
+        }
+    for (int phase = 0; phase < phases; phase++)
+        {
+            GSH_RCCL(R->GroupStart());  // (one group per phase: with several local ranks in one thread every call of a phase must be in flight together)
             for (size_t i = 0; i < n_local; i++)
                 {
                     GSH_HIP(hipSetDevice(g->rings[i]->device));
-                    GSH_RCCL(R->Broadcast(g->stage[slot][i], g->stage[slot][i], padded, ncclInt8, 0, g->comms[i], g->rings[i]->stream));
-                    g->rccl_calls++;
+                    hipStream_t st = g->rings[i]->stream;
+                    auto buf = [&](int which) -> char* {
+                        return static_cast<char*>(which == GSH_GROUP_BUF_STAGE ? g->stage[slot][i] : (which == GSH_GROUP_BUF_PIECE ? g->piece[slot][i] : nullptr));
+                    };
+                    for (const gsh_group_op_t& op : plans[i])
+                        {
+                            if (op.phase != phase) continue;
+                            switch (op.op)
+                                {
+                                case GSH_GROUP_OP_BROADCAST:
+                                    GSH_RCCL(R->Broadcast(buf(op.src_buf) + op.src_offset, buf(op.dst_buf) + op.dst_offset, op.bytes, ncclInt8, op.peer, g->comms[i], st));
+                                    break;
+                                case GSH_GROUP_OP_SEND:
+                                    GSH_RCCL(R->Send(buf(op.src_buf) + op.src_offset, op.bytes, ncclInt8, op.peer, g->comms[i], st));
+                                    break;
+                                case GSH_GROUP_OP_RECV:
+                                    GSH_RCCL(R->Recv(buf(op.dst_buf) + op.dst_offset, op.bytes, ncclInt8, op.peer, g->comms[i], st));
+                                    break;
+                                case GSH_GROUP_OP_ALLGATHER:
+                                    GSH_RCCL(R->AllGather(buf(op.src_buf) + op.src_offset, buf(op.dst_buf) + op.dst_offset, op.bytes, ncclInt8, g->comms[i], st));
+                                    break;
+                                default:
+                                    return set_error(GSH_ERR_STATE, "unknown group operation %d", op.op);
+                                }
+                            g->rccl_calls++;
+                        }
                 }
             GSH_RCCL(R->GroupEnd());
-            return GSH_OK;
         }
-    // scatter: rank 0 sends piece r to rank r over its link to r; everybody receives its piece
-    GSH_RCCL(R->GroupStart());
-    for (size_t i = 0; i < n_local; i++)
-        {
-            GSH_HIP(hipSetDevice(g->rings[i]->device));
-            if (g->ranks[i] == 0)
-                for (int r = 0; r < g->world; r++)
-                    {
-                        GSH_RCCL(R->Send(static_cast<const char*>(g->stage[slot][i]) + static_cast<size_t>(r) * chunk, chunk, ncclInt8, r, g->comms[i], g->rings[i]->stream));
-                        g->rccl_calls++;
-                    }
-            GSH_RCCL(R->Recv(g->piece[slot][i], chunk, ncclInt8, 0, g->comms[i], g->rings[i]->stream));
-            g->rccl_calls++;
-        }
-    GSH_RCCL(R->GroupEnd());
-    // all-gather of the pieces completes the block everywhere
-    GSH_RCCL(R->GroupStart());
-    for (size_t i = 0; i < n_local; i++)
-        {
-            GSH_HIP(hipSetDevice(g->rings[i]->device));
-            GSH_RCCL(R->AllGather(g->piece[slot][i], g->stage[slot][i], chunk, ncclInt8, g->comms[i], g->rings[i]->stream));
-            g->rccl_calls++;
-        }
-    GSH_RCCL(R->GroupEnd());
     return GSH_OK;
 }
 
@@ -413,6 +475,32 @@ extern "C"
                         if (R != nullptr && R->GetVersion != nullptr && R->GetVersion(&v) == 0) *rccl_version = v;
                     }
             }
+        return GSH_OK;
+    }
+
+    int gsh_stream_group_plan(uint64_t bytes, int world, int rank, int mode, gsh_group_op_t* ops, int max_ops, int* n_ops, uint64_t* padded_bytes_out)
+    {
+        GSH_REQUIRE(n_ops != nullptr, "null argument");
+        GSH_REQUIRE(world >= 1 && world <= 64 && rank >= 0 && rank < world, "rank %d / world %d", rank, world);
+        mode &= ~GSH_GROUP_FORCE_RCCL;
+        GSH_REQUIRE(mode == GSH_GROUP_BROADCAST || mode == GSH_GROUP_SCATTER_ALLGATHER, "unknown mode %d", mode);
+        std::vector<gsh_group_op_t> plan;
+        make_plan(bytes, world, rank, mode, plan, padded_bytes_out);
+        *n_ops = static_cast<int>(plan.size());
+        GSH_REQUIRE(ops == nullptr || max_ops >= *n_ops, "the plan has %d operations, room for %d", *n_ops, max_ops);
+        if (ops != nullptr) std::copy(plan.begin(), plan.end(), ops);
+        return GSH_OK;
+    }
+
+    int gsh_comm_library(char* path, int capacity)
+    {
+        GSH_REQUIRE(path != nullptr && capacity > 0, "null buffer");
+        path[0] = '\0';
+        Rccl* R = rccl();
+        GSH_REQUIRE(R != nullptr, "RCCL (librccl.so, or what GSH_RCCL_LIBRARY names) could not be loaded");
+        RcclSlot& S = slot();
+        std::lock_guard<std::mutex> lock(S.m);
+        std::snprintf(path, static_cast<size_t>(capacity), "%s", S.path.c_str());
         return GSH_OK;
     }
 

@@ -263,6 +263,32 @@ class StreamGroup:
         check(_lib.load().gsh_comm_unique_id(buf))
         return buf.raw
 
+    class _Op(C.Structure):
+        _fields_ = [("op", C.c_int32), ("peer", C.c_int32), ("phase", C.c_int32), ("src_buf", C.c_int32), ("dst_buf", C.c_int32),
+                    ("src_offset", C.c_uint64), ("dst_offset", C.c_uint64), ("bytes", C.c_uint64)]
+
+    OPS = {0: "broadcast", 1: "send", 2: "recv", 3: "allgather"}
+    BUFS = {0: None, 1: "stage", 2: "piece"}
+
+    @classmethod
+    def plan(cls, nbytes: int, world: int, rank: int, mode: str = "broadcast"):
+        """gsh_stream_group_plan: (padded_bytes, [dict(op, peer, phase, src_buf, dst_buf, src_offset, dst_offset, bytes)]) -- the operations a push of
+        `nbytes` raw bytes issues on `rank`, the list the engine itself walks.  Needs no GPU."""
+        L = _lib.load()
+        n, padded = C.c_int(0), C.c_uint64(0)
+        check(L.gsh_stream_group_plan(nbytes, world, rank, cls.MODES[mode], None, 0, C.byref(n), C.byref(padded)))
+        ops = (cls._Op * max(n.value, 1))()
+        check(L.gsh_stream_group_plan(nbytes, world, rank, cls.MODES[mode], ops, n.value, C.byref(n), C.byref(padded)))
+        return int(padded.value), [dict(op=cls.OPS[o.op], peer=int(o.peer), phase=int(o.phase), src_buf=cls.BUFS[o.src_buf], dst_buf=cls.BUFS[o.dst_buf],
+                                        src_offset=int(o.src_offset), dst_offset=int(o.dst_offset), bytes=int(o.bytes)) for o in ops[:n.value]]
+
+    @staticmethod
+    def library() -> str:
+        """File name of the collective library the engine has loaded (gsh_comm_library): the system's librccl, or what GSH_RCCL_LIBRARY names."""
+        buf = C.create_string_buffer(1024)
+        check(_lib.load().gsh_comm_library(buf, 1024))
+        return buf.value.decode()
+
     @classmethod
     def from_rank(cls, device: int, rank: int, world: int, unique_id: bytes | None, capacity_samples: int, max_window_samples: int, mode: str = "broadcast",
                   force_rccl: bool = False):

@@ -1,92 +1,108 @@
-"""Multi-GPU layout of the hot path: channels (tracking) / PRNs (acquisition) are independent units that all read the
-same IF sample stream (gnss_flowgraph.cc:1227-1231 connects one conditioner to every channel), so they shard
-across ranks with no reduction; the only exchange step is getting each sample block to every GPU once.
+"""Host-side control plane of the multi-GPU layout, one process per GPU -- what bench.py --gpus N runs on every rank.
 
-One process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI on MI355X, "gloo" in the CPU tests).
-The ingest rank owns the block and broadcasts it; results stay on the rank that owns the channel.
-"""
+Channels (tracking) and PRNs (acquisition) are independent units that all read the same IF sample stream (gnss_flowgraph.cc:1227-1231 connects one
+conditioner to every channel), so they shard over the ranks with no reduction: channel c -> GPU c mod G, PRN p -> GPU (p - 1) mod G.  The one exchange
+step -- every sample block reaching every GPU once -- is NOT here: it happens inside the engine (gsh_stream_group_*, csrc/stream_group.hip: RCCL over
+xGMI).  torch.distributed ("nccl" = RCCL on ROCm; "gloo" in the CPU tests and the shared-GPU self-test) carries only the 128-byte communicator id, the
+barrier and the MAX / SUM reductions of the timing contract.  The reference's whole multi-GPU logic is a random device pick
+(cuda_multicorrelator.cu:136-155); the layout here is north_star's."""
 from __future__ import annotations
 
-from typing import List, Sequence
+import os
+from typing import List
 
 
-def shard_range(n_units: int, world: int, rank: int) -> range:
-    """Contiguous, balanced partition: the first n_units % world ranks get one extra unit."""
+def channel_owner(channel: int, world: int) -> int:
+    """channel c -> GPU c mod G."""
+    return channel % world
+
+
+def channels_of(rank: int, world: int, n_channels: int) -> List[int]:
+    """Strong scaling: the channels of a fixed set that `rank` tracks."""
+    _check(rank, world)
+    return [c for c in range(n_channels) if channel_owner(c, world) == rank]
+
+
+def weak_channel_prn(rank: int, channels_per_gpu: int, slot: int) -> int:
+    """Weak scaling (bench.py): every GPU tracks channels_per_gpu channels; slot s of rank r is global channel r * C + s and tracks PRN (r * C + s) mod 32 + 1."""
+    return (rank * channels_per_gpu + slot) % 32 + 1
+
+
+def prn_owner(prn: int, world: int) -> int:
+    """PRN p (1-based) -> GPU (p - 1) mod G."""
+    return (prn - 1) % world
+
+
+def prns_of(rank: int, world: int, n_prn: int = 32) -> List[int]:
+    _check(rank, world)
+    return [p for p in range(1, n_prn + 1) if prn_owner(p, world) == rank]
+
+
+def _check(rank: int, world: int) -> None:
     if world < 1 or not (0 <= rank < world):
         raise ValueError(f"rank {rank} outside world {world}")
-    q, r = divmod(n_units, world)
-    start = rank * q + min(rank, r)
-    return range(start, start + q + (1 if rank < r else 0))
 
 
-def owner_of(unit: int, n_units: int, world: int) -> int:
-    q, r = divmod(n_units, world)
-    cut = r * (q + 1)
-    if unit < cut:
-        return unit // (q + 1)
-    return r + (unit - cut) // max(q, 1)
+class ControlPlane:
+    """The launcher's environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*) turned into the few collective services a rank needs around the engine.
+    world == 1 needs no torch.distributed at all."""
 
+    def __init__(self, backend: str = "nccl", device=None):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        _check(self.rank, self.world)
+        self.backend = backend
+        self.dist = None
+        self._dev = None
+        if self.world > 1:
+            import torch
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=device)
+                self._dev = device
+            else:
+                dist.init_process_group(backend, rank=self.rank, world_size=self.world)
+                self._dev = torch.device("cpu")   # (gloo reduces host tensors)
+            self.dist = dist
 
-def broadcast_block(block, src: int = 0, async_op: bool = False):
-    """Replicate one IF sample block (a real-view torch tensor, any device) from the ingest rank.
-    A single large message per block: the broadcast is latency-bound at real-time rates (25 Msps * 8 B = 0.2 GB/s
-    against ~153 GB/s per xGMI link), so blocks should hold >= 10 ms of samples."""
-    import torch.distributed as dist
-    return dist.broadcast(block, src=src, async_op=async_op)
+    def barrier(self) -> None:
+        if self.dist is not None:
+            self.dist.barrier()
 
+    def _reduce(self, v: float, op: str) -> float:
+        if self.dist is None:
+            return float(v)
+        import torch
+        t = torch.tensor([v], dtype=torch.float64, device=self._dev)
+        self.dist.all_reduce(t, op=getattr(self.dist.ReduceOp, op))
+        return float(t.item())
 
-class BlockDistributor:
-    """Replicates raw IF sample blocks from the ingest rank to every rank, shaped for xGMI rather than for a switch.
+    def reduce_max(self, v: float) -> float:
+        return self._reduce(v, "MAX")
 
-    xGMI is point-to-point: a GPU has one link to each of its 7 peers (~153 GB/s each).  A ring broadcast pushes the whole
-    block through ONE link per hop; here the ingest rank instead SCATTERS 1/world of the block to every peer over all of its
-    links at once, then an ALL-GATHER lets every rank collect the other pieces over all of its own links -- every link
-    carries block/world bytes twice instead of one link carrying the whole block.  Blocks travel in the front-end's raw
-    item type (ibyte: 2 bytes per sample instead of 8 for complex64); each rank converts on its own GPU
-    (gsh_convert_samples_device).  mode="broadcast" keeps the single dist.broadcast as a fallback.
+    def reduce_min(self, v: float) -> float:
+        return self._reduce(v, "MIN")
 
-    Buffers are flat uint8/int8 tensors of the same length on every rank; `nbytes` is padded to a multiple of world."""
+    def reduce_sum(self, v: float) -> float:
+        return self._reduce(v, "SUM")
 
-    def __init__(self, nbytes: int, world: int, rank: int, src: int = 0, mode: str = "scatter_allgather"):
-        if mode not in ("scatter_allgather", "broadcast"):
-            raise ValueError(mode)
-        self.world, self.rank, self.src, self.mode = world, rank, src, mode
-        self.chunk = (nbytes + world - 1) // world
-        self.padded = self.chunk * world
+    def same_everywhere(self, v: float) -> bool:
+        """True on every rank iff all ranks hold the same value (a checksum of checksums)."""
+        return self.reduce_max(v) == self.reduce_min(v)
 
-    def start(self, dst, src_block=None, piece=None):
-        """Queue the distribution of one block.  dst: flat tensor of `padded` bytes on every rank (receives the block);
-        src_block: the block on the ingest rank (may be `dst` itself); piece: a `chunk`-byte scratch tensor per rank.
-        Returns a list of work handles; call finish() before reading dst."""
-        import torch.distributed as dist
+    def communicator_id(self) -> bytes | None:
+        """The engine's 128-byte communicator id: made by gsh_comm_unique_id on rank 0, handed to every rank.  None for a world of one."""
         if self.world == 1:
-            if src_block is not None and src_block.data_ptr() != dst.data_ptr():
-                dst.copy_(src_block)
-            return []
-        if self.mode == "broadcast":
-            if self.rank == self.src and src_block is not None and src_block.data_ptr() != dst.data_ptr():
-                dst.copy_(src_block)
-            return [dist.broadcast(dst, src=self.src, async_op=True)]
-        pieces = list(src_block.view(self.world, self.chunk).unbind(0)) if self.rank == self.src else None
-        w1 = dist.scatter(piece, scatter_list=pieces, src=self.src, async_op=True)
-        if dist.get_backend() != "nccl":
-            w1.wait()  # RCCL runs both on the communicator's stream, in order; gloo's asynchronous ops are unordered
-        w2 = dist.all_gather_into_tensor(dst, piece, async_op=True)
-        return [w1, w2]
+            return None
+        from .sample_stream import StreamGroup
+        box = [StreamGroup.unique_id() if self.rank == 0 else None]
+        self.dist.broadcast_object_list(box, src=0)
+        return box[0]
 
-    @staticmethod
-    def finish(works) -> None:
-        for w in works:
-            w.wait()
-
-
-def epoch_major_jobs(channel_ids: Sequence[int], per_channel: dict, epochs: int, n_samples: int, shifts: Sequence[float]) -> List[dict]:
-    """Job table for one rank's channels: epoch-major, channel-minor, so that jobs reading the same samples are
-    adjacent and land on the same XCD (multicorrelator.hip remaps blockIdx accordingly).
-    per_channel[c] = (first_sample_offset, dict of NCO fields)."""
-    rows = []
-    for e in range(epochs):
-        for slot, c in enumerate(channel_ids):
-            off, p = per_channel[c]
-            rows.append(dict(sample_offset=off + e * n_samples, n_samples=n_samples, code_slot=slot, shifts_chips=list(shifts), **p))
-    return rows
+    def close(self) -> None:
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+            self.dist = None

@@ -239,6 +239,32 @@ extern "C"
      * GSH_GROUP_FORCE_RCCL), *rccl_version = ncclGetVersion's code (0 when RCCL was never loaded), *collectives = RCCL collective / point-to-point
      * calls this group has issued (broadcasts, sends, receives, all-gathers).  Any pointer may be NULL. */
     int gsh_stream_group_rccl_info(const gsh_stream_group_t* g, int32_t* rccl_ranks, int32_t* rccl_version, uint64_t* collectives);
+    /* the exchange plan of ONE rank for one block of `bytes` raw bytes: the list of collective / point-to-point operations gsh_stream_group_push issues
+     * for it, in order -- the single place where chunk sizes, offsets and peers are decided (the push walks this very list).  Operations of the same
+     * `phase` go out between one ncclGroupStart / ncclGroupEnd.  Buffers: STAGE = the rank's staging buffer of *padded_bytes (the block, zero-extended to
+     * world x chunk, chunk a multiple of 16), PIECE = its chunk-sized scratch.  Needs no GPU: a launcher can size its messages from it, the CPU suite
+     * executes it over torch.distributed / gloo (tests/test_sharding_gloo.py).  ops may be NULL (count only). */
+#define GSH_GROUP_OP_BROADCAST 0 /* ncclBroadcast(src, dst, bytes, root = peer) */
+#define GSH_GROUP_OP_SEND 1      /* ncclSend(src, bytes, peer) */
+#define GSH_GROUP_OP_RECV 2      /* ncclRecv(dst, bytes, peer) */
+#define GSH_GROUP_OP_ALLGATHER 3 /* ncclAllGather(src, dst, bytes per rank) */
+#define GSH_GROUP_BUF_NONE 0
+#define GSH_GROUP_BUF_STAGE 1
+#define GSH_GROUP_BUF_PIECE 2
+    typedef struct
+    {
+        int32_t op;
+        int32_t peer;
+        int32_t phase;
+        int32_t src_buf, dst_buf;
+        uint64_t src_offset, dst_offset;
+        uint64_t bytes;
+    } gsh_group_op_t;
+    int gsh_stream_group_plan(uint64_t bytes, int world, int rank, int mode, gsh_group_op_t* ops, int max_ops, int* n_ops, uint64_t* padded_bytes);
+    /* the collective library in use: file name of the loaded librccl (the system's, or what the environment variable GSH_RCCL_LIBRARY names -- a site's own
+     * build, or the test-only stand-in tests/host/libfake_rccl.so with which the N > 1 paths run on a one-GPU box).  GSH_RCCL_LIBRARY is read whenever a
+     * group or an id is made; it must not change while a group made with the other library is alive. */
+    int gsh_comm_library(char* path, int capacity);
     int gsh_stream_range(gsh_stream_t* s, uint64_t* oldest, uint64_t* next);
     /* copy resident samples [index, index + n) back to the host as complex64 (tests, dumps) */
     int gsh_stream_read(gsh_stream_t* s, uint64_t index, uint64_t n, float* out_iq);

@@ -1,14 +1,22 @@
-"""The RCCL path of the block-replication group with MORE THAN ONE GPU (gsh_stream_group_*, csrc/stream_group.hip; SURVEY.md 8e: "RCCL broadcast
-of the shared input sample block over xGMI").  The round's GPU boxes have one MI355X, where RCCL only ever sees a group of one
-(tests/test_stream_group_gpu.py); these tests skip there and run the moment >= 2 devices are visible -- the driver's 8-GPU node -- so that
-the first multi-GPU run proves the collective instead of hoping for it:
+"""The N > 1 path of the block-replication group (gsh_stream_group_*, csrc/stream_group.hip; SURVEY.md 8e: "RCCL broadcast of the shared input sample
+block over xGMI"), executed in two transports:
 
-  * one process driving all GPUs (gsh_stream_group_create, ncclCommInitAll): after every push, every device's ring holds bit for bit what a
+  * "rccl"  -- the system's RCCL across >= 2 visible GPUs (the driver's 8-GPU node); skipped on a one-GPU box, where RCCL refuses two ranks on one device;
+  * "stub"  -- tests/host/libfake_rccl.so (tests/host/fake_rccl.cc, TEST INFRASTRUCTURE, selected through GSH_RCCL_LIBRARY) standing in for librccl.so: the
+               engine's own code -- gsh_stream_group_plan's chunk offsets and padded tails, the root-local index, the scatter's send-to-self, the two staging
+               slots under back-to-back pushes, the event ordering against the cast and the readers -- runs with 3 ranks (not a power of two) on ONE device.
+               The stand-in is stream-ordered and asynchronous within a process, file-backed between processes; it proves the plan, not the wire.
+
+  * one process driving all ranks (gsh_stream_group_create, ncclCommInitAll): after every push, every rank's ring holds bit for bit what a
     local gsh_stream_push of the same 8-bit items leaves on that device, in both group modes (broadcast / scatter + all-gather);
-  * a correlator bank bound to each device's ring returns exactly what a bank on a private ring of that device returns;
-  * one process per GPU (gsh_stream_group_create_rank, the layout bench.py --gpus N uses): ranks are fresh interpreters (multiprocessing, spawn), the
-    communicator id travels through a file, rank 0 supplies the blocks, every rank checks its own ring against the items."""
+  * a correlator bank bound to each rank's ring returns exactly what a bank on a private ring of that device returns;
+  * one process per rank (gsh_stream_group_create_rank, the layout bench.py --gpus N uses): ranks are fresh interpreters (multiprocessing, spawn), the
+    communicator id travels through a file, rank 0 supplies the blocks, every rank checks its own ring against the items;
+  * closed loops and acquisition PRN shards on every ring of the group;
+  * bench.py --gpus 2 end to end (ranks spawned by bench.py itself)."""
+import json
 import os
+import subprocess
 import sys
 import tempfile
 
@@ -20,19 +28,30 @@ from helpers import synth_gps_l1_stream, tracking_params_for
 
 pytestmark = pytest.mark.gpu
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FAKE_RCCL = os.path.join(ROOT, "tests", "host", "libfake_rccl.so")
+STUB_RANKS = 3
+
 
 def _n_devices() -> int:
     import gnss_sdr_amd
     return int(gnss_sdr_amd.load().gsh_device_count())
 
 
-def _need_two():
+@pytest.fixture(params=["rccl", "stub"])
+def devices(request, monkeypatch, gpu):
+    """The device of every rank of the group under test: rank i -> devices[i]."""
     n = _n_devices()
-    if n < 2 and os.environ.get("GSH_TEST_GROUP_OF_ONE") == "1":
-        return n  # (self-test of the test code on a one-GPU box: a group of one exercises everything but the collective)
-    if n < 2:
-        pytest.skip(f"{n} HIP device(s) visible: the multi-GPU RCCL path needs at least two")
-    return n
+    if request.param == "rccl":
+        if n < 2:
+            pytest.skip(f"{n} HIP device(s) visible: real RCCL needs one device per rank (the stub transport covers this box)")
+        monkeypatch.delenv("GSH_RCCL_LIBRARY", raising=False)
+        return list(range(min(n, 8)))
+    assert os.path.exists(FAKE_RCCL), "tests/host/libfake_rccl.so was not built (__graft_entry__.build)"
+    monkeypatch.setenv("GSH_RCCL_LIBRARY", FAKE_RCCL)
+    from gnss_sdr_amd.sample_stream import StreamGroup
+    assert os.path.samefile(StreamGroup.library(), FAKE_RCCL)
+    return [r % n for r in range(STUB_RANKS)]
 
 
 def _blocks(rng, sizes):
@@ -40,10 +59,9 @@ def _blocks(rng, sizes):
 
 
 @pytest.mark.parametrize("mode", ["broadcast", "scatter_allgather"])
-def test_every_ring_of_the_group_equals_a_local_push(gpu, mode):
-    n_dev = _need_two()
+def test_every_ring_of_the_group_equals_a_local_push(devices, mode):
+    n_dev = len(devices)
     from gnss_sdr_amd.sample_stream import SampleStream, StreamGroup
-    devices = list(range(n_dev))
     cap, win = 40000, 9000
     g = StreamGroup.local(devices, cap, win, mode=mode)
     assert g.size() == n_dev
@@ -67,8 +85,8 @@ def test_every_ring_of_the_group_equals_a_local_push(gpu, mode):
     g.close()
 
 
-def test_banks_on_every_device_of_the_group_match_private_rings(gpu):
-    n_dev = _need_two()
+def test_banks_on_every_device_of_the_group_match_private_rings(devices):
+    n_dev = len(devices)
     from gnss_sdr_amd.sample_stream import SampleStream, StreamGroup
     from gnss_sdr_amd.tracking import CorrelatorBank
     fs, n = 4e6, 4000
@@ -77,7 +95,6 @@ def test_banks_on_every_device_of_the_group_match_private_rings(gpu):
     x = synth_gps_l1_stream(total, fs, [1, 2, 3], dopplers, [5.0, 300.0, 800.0], seed_noise=21)
     x8 = np.clip(np.round(np.stack([x.real, x.imag], axis=1) * 30.0), -127, 127).astype(np.int8)
     cap = 9 * n + 2
-    devices = list(range(n_dev))
     g = StreamGroup.local(devices, cap, 2 * n, mode="scatter_allgather")
     rng = np.random.default_rng(2)
     params = [tracking_params_for(fs, d, rng) for d in dopplers]
@@ -120,7 +137,7 @@ def test_banks_on_every_device_of_the_group_match_private_rings(gpu):
         assert a.shape == e.shape and np.array_equal(a.view(np.uint32), e.view(np.uint32)), f"device {d}"
 
 
-def _rank_main(rank, world, id_path, mode, result_path):
+def _rank_main(rank, world, device, id_path, mode, result_path):
     """One process per GPU, as bench.py --gpus N runs: gsh_stream_group_create_rank with a communicator id from rank 0."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
@@ -140,7 +157,7 @@ def _rank_main(rank, world, id_path, mode, result_path):
             time.sleep(0.01)
         uid = open(id_path, "rb").read()
     cap, win = 40000, 9000
-    g = StreamGroup.from_rank(rank, rank, world, uid, cap, win, mode=mode)
+    g = StreamGroup.from_rank(device, rank, world, uid, cap, win, mode=mode)
     ring = g.ring(0)
     rng = np.random.default_rng(11)  # every rank draws the same blocks: rank 0 pushes them, the others use them to check their ring
     ok, total = True, 0
@@ -160,15 +177,15 @@ def _rank_main(rank, world, id_path, mode, result_path):
 
 
 @pytest.mark.parametrize("mode", ["broadcast", "scatter_allgather"])
-def test_one_process_per_gpu_group(gpu, mode):
-    n_dev = _need_two()
+def test_one_process_per_gpu_group(devices, mode):
+    n_dev = len(devices)
     import multiprocessing as mp
     world = min(n_dev, 8)
     ctx = mp.get_context("spawn")  # fresh interpreters: one HIP runtime per rank, nothing inherited from the pytest process
     with tempfile.TemporaryDirectory() as tmp:
         id_path, result_path = os.path.join(tmp, "nccl_id"), os.path.join(tmp, "result")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC
-        procs = [ctx.Process(target=_rank_main, args=(r, world, id_path, mode, result_path)) for r in range(world)]
+        procs = [ctx.Process(target=_rank_main, args=(r, world, devices[r], id_path, mode, result_path)) for r in range(world)]
         for p in procs:
             p.start()
         for p in procs:
@@ -195,17 +212,16 @@ def _records_bytes(recs):
 
 
 @pytest.mark.parametrize("live", [False, True])
-def test_closed_loops_on_every_ring_of_the_group_match_private_rings(gpu, live):
+def test_closed_loops_on_every_ring_of_the_group_match_private_rings(devices, live):
     """SURVEY 8e for the path a receiver runs: the DLL/PLL loop closed on the device (gsh_trk_*), channel c on GPU c mod G, every GPU's loop bound to ITS ring of
     the group -- launched after every replicated block, and as live residencies that follow the ring.  The records of every channel must equal, byte for byte, those
     of the same channel on a private ring of the same GPU fed with the same items."""
-    n_dev = _need_two()
+    n_dev = len(devices)
     import time
     from gnss_sdr_amd.sample_stream import SampleStream, StreamGroup
     from gnss_sdr_amd.tracking_loop import TrackingLoop, trk_conf
     fs, n, epochs = 4e6, 4000, 120
     prns, dops, starts, total, x8 = _trk_scenario(fs, n, epochs)
-    devices = list(range(n_dev))
     kw = dict(fs_in=fs, vector_length=n, pll_bw_hz=35.0, dll_bw_hz=3.0, enable_lock_detectors=1, pull_in_time_s=0)
     cap, win = 40 * n, 2 * n
     blk = 7 * n + 11
@@ -269,17 +285,16 @@ def test_closed_loops_on_every_ring_of_the_group_match_private_rings(gpu, live):
         assert abs(np.mean([r.carrier_doppler_hz for r in group_got[c][-40:]]) - dops[c]) < 3.0
 
 
-def test_acquisition_prn_shards_on_every_ring_of_the_group(gpu):
+def test_acquisition_prn_shards_on_every_ring_of_the_group(devices):
     """"acquisition: PRN p -> GPU p mod G" -- every GPU searches its share of the PRNs over the SAME replicated block (gsh_acq_dwell_ring on its
     ring of the group); results equal those of the same search over a private ring of that GPU, and the union finds every embedded satellite."""
-    n_dev = _need_two()
+    n_dev = len(devices)
     from gnss_sdr_amd.acquisition import PcpsAcquisitionBank
     from gnss_sdr_amd.sample_stream import SampleStream, StreamGroup
     fs, n = 4e6, 4000
     sig_prns, dops, cphs = [3, 8, 14, 22, 30], [1500.0, -3250.0, 250.0, 4000.0, -750.0], [10.0, 444.0, 901.5, 77.0, 600.0]
     x = synth_gps_l1_stream(6 * n, fs, sig_prns, dops, cphs, cn0_dbhz=50.0, seed_noise=41)
     x8 = np.clip(np.round(np.stack([x.real, x.imag], axis=1) * 25.0), -127, 127).astype(np.int8)
-    devices = list(range(n_dev))
     cap, win = 12 * n, 2 * n
     kw = dict(fs_in=int(fs), fft_size=n, doppler_max=5000, doppler_step=250, samples_per_chip=4, samples_per_code=float(n))
     g = StreamGroup.local(devices, cap, win, mode="broadcast")
@@ -304,3 +319,36 @@ def test_acquisition_prn_shards_on_every_ring_of_the_group(gpu):
     g.close()
     for p, fd in zip(sig_prns, dops):
         assert abs(found[p]["doppler_hz"] - fd) <= 250 and found[p]["test_statistics"] > 4.0 * np.median([found[q]["test_statistics"] for q in found if q not in sig_prns]), (p, found[p])
+
+
+@pytest.mark.parametrize("dist_mode", ["broadcast", "scatter_allgather"])
+def test_bench_gpus_2_spawns_its_ranks_and_shards(devices, dist_mode):
+    """`python bench.py --gpus 2` with no launcher around it: bench.py starts its two ranks itself (torch.distributed.run), every rank takes its channels of the
+    stream that the engine's group replicates (gsh_stream_group_create_rank), rank 0 prints the line.  On a one-GPU box: both ranks on GPU 0
+    (GSH_BENCH_SHARE_GPU), torch.distributed over gloo for the barrier / MAX-reduce / id hand-over, the stand-in library under the engine."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    stub = "GSH_RCCL_LIBRARY" in os.environ
+    if stub:
+        env.update(GSH_BENCH_SHARE_GPU="1", GSH_BENCH_BACKEND="gloo")
+    env["GSH_BENCH_DIST"] = dist_mode
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--settle-steps", "0", "--blocks-per-step", "3",
+                        "--epochs", "40"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["stream_group_mode"] == dist_mode, d
+    assert d["scaling"] == "weak" and d["value"] > 0 and d["steps"] == 2
+    assert d["spot_check"]["ranks_checked"] == 2 and d["spot_check"]["worst_err"] <= 1e-6, d["spot_check"]
+    assert d["rccl_library_is_test_stub"] == stub
+    for leg in ("closed_loop_sharded", "acquisition_sharded"):
+        assert leg in d and "error" not in d[leg] and d[leg]["n_gpus"] == 2 and d[leg]["value"] > 0, d.get(leg)
+
+
+def test_bench_gpus_more_than_visible_fails_loudly(gpu, monkeypatch):
+    n = _n_devices()
+    monkeypatch.delenv("GSH_BENCH_SHARE_GPU", raising=False)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n + 1), "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
+                       timeout=300, cwd=ROOT)
+    assert r.returncode != 0 and "visible" in (r.stderr + r.stdout), (r.returncode, r.stderr[-500:])
