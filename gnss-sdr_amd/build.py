@@ -16,6 +16,10 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
                "-Wall", "-Wno-unused-function"]
 
 
+# translation units that #include another .hip (the same kernels at another work-group size)
+INCLUDED_SOURCES = {"multicorrelator_t128.hip": ["multicorrelator.hip"]}
+
+
 def sources() -> list[str]:
     return sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")))
 
@@ -51,7 +55,8 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
-        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
+        src_t = max([os.path.getmtime(src)] + [os.path.getmtime(os.path.join(_HERE, "csrc", d)) for d in INCLUDED_SOURCES.get(os.path.basename(src), [])])
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(src_t, hdr_t):
             jobs.append([hipcc] + flags + inc + ["-c", src, "-o", obj])
 
     def run(cmd):

@@ -217,7 +217,42 @@ struct JobCtx
     // closed-loop kernel, windows of one exact seed per lane (run_segment_packed, `single`): the factors of the lanes' seeds, evaluated by two otherwise idle waves
     // beside thread 0's end of the previous period (seed_table_fill below; tracking_loop.hip) -- null: every lane evaluates its own
     const float2* seed_tab{nullptr};
+    // batched kernel (multicorrelator.hip): the factors of every lane's seeds for THIS job, evaluated once per work-group by one wave beside the code staging
+    // (fac_table_fill below) -- null: every lane evaluates its own two transcendentals (run_segment_packed)
+    const float2* fac_tab{nullptr};
 };
+// factor table of the batched kernel: the seed of lane tid at re-seed r is A[r] * (WH[tid / 32] * B[tid % 32])
+//   = exp(-j (rem + (n_first + 2 PPC NCH RESEED r) step)) * exp(-j 64 (tid / 32) step) * exp(-j 2 (tid % 32) step)
+// 64 entries, one per lane of the filling wave: each evaluated ONCE per job and work-group instead of two evaluations per lane of every wave
+// (round 6: 77 of a wave's 1 857 vector instructions per 25 000-sample job, profiles/ab/r06/session4.txt).
+constexpr int FAC_B = 0;      // 32: exp(-j 2 l step)
+constexpr int FAC_WH = 32;    //  8: exp(-j 64 h step), h = tid / 32 (work-groups of up to 256 threads)
+constexpr int FAC_INC = 40;   //  3: exp(-j step), exp(-j 2 PPC step), exp(-j 2 NCH PPC step)
+constexpr int FAC_A = 44;     // 20: the exact phasor of the chunk's first sample at re-seed r
+constexpr int FAC_NA = 20;
+constexpr int FAC_ENTRIES = 64;
+static_assert(MC_THREADS > 256 || MC_THREADS / 32 <= FAC_INC - FAC_WH, "factor table: one WH entry per 32 threads");
+// trips between exact re-seeds of run_segment_packed for NCH chunks per trip
+__host__ __device__ constexpr int packed_reseed_trips(int nch) { return (GSH_MC_RESEED + nch - 1) / nch; }
+// called by ONE wave (lane = its lane index); the arguments are formed as run_segment_packed forms them (double products of the float step)
+template <int NCH>
+__device__ __forceinline__ void fac_table_fill(float2* __restrict__ tab, float step, float rem, int n_first, int lane)
+{
+    const double sd = static_cast<double>(step);
+    double ph;
+    if (lane < FAC_WH)
+        ph = static_cast<double>(2 * lane) * sd;
+    else if (lane < FAC_INC)
+        ph = static_cast<double>(64 * (lane - FAC_WH)) * sd;
+    else if (lane < FAC_A)
+        ph = (lane == FAC_INC ? 1.0 : (lane == FAC_INC + 1 ? static_cast<double>(2 * MC_THREADS) : static_cast<double>(2 * NCH * MC_THREADS))) * sd;
+    else
+        {
+            const long long nb = static_cast<long long>(n_first) + static_cast<long long>(2 * MC_THREADS * NCH * packed_reseed_trips(NCH)) * (lane - FAC_A);
+            ph = static_cast<double>(rem) + static_cast<double>(nb) * sd;
+        }
+    tab[lane] = expmj(ph);
+}
 // seed tables: exp(-j (rem + (n_first + 2 tid) step)) = A[-n_first] * W[tid / 64] * B[tid % 64]
 constexpr int SEED_B = 0;     // 64: exp(-j 2 l step)
 constexpr int SEED_W = 64;    // 16: exp(-j 128 v step)
@@ -668,7 +703,7 @@ __device__ __forceinline__ void run_segment_packed(const JobCtx& c, const float2
 {
     static_assert(NCH == 1 || NCH == 2, "one or two chunks per trip");
     constexpr int PPC = MC_PAIRS_PER_CHUNK;
-    constexpr int RESEED = (MC_RESEED + NCH - 1) / NCH;  // trips between exact re-seeds
+    constexpr int RESEED = packed_reseed_trips(NCH);     // trips between exact re-seeds
     constexpr int TBL = 60;                               // re-seed entries per table fill
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -831,8 +866,17 @@ __device__ __forceinline__ void run_segment_packed(const JobCtx& c, const float2
             single_w = (v2f){w1.x, w1.y};
             single_w2 = (v2f){w21.x, w21.y};
         }
+    // batched kernel: the work-group's factor table (JobCtx::fac_tab) when it covers every re-seed of this segment
+    const bool fac = !MRG && NCH == 2 && (c.fac_tab != nullptr) && (n_trips_all <= FAC_NA * RESEED);  // uniform
     float2 Lf = make_float2(1.0f, 0.0f);
-    if (!single) Lf = expmj(static_cast<double>(2 * tid) * sd);  // (from the seed tables, W[tid / 64] B[tid % 64], config 4's period is 0.6 % LONGER: profiles/ab/r05/closed_loop_notes.txt)
+    if (fac)
+        {
+            int tl = tid;
+            asm volatile("" : "+v"(tl));
+            Lf = cmul(c.fac_tab[FAC_WH + (tl >> 5)], c.fac_tab[FAC_B + (tl & 31)]);
+        }
+    else if (!single)
+        Lf = expmj(static_cast<double>(2 * tid) * sd);  // (from the seed tables, W[tid / 64] B[tid % 64], config 4's period is 0.6 % LONGER: profiles/ab/r05/closed_loop_notes.txt)
     const v2f L = {Lf.x, Lf.y};
     auto fill_table = [&](int r0) -> float2 {  // entry of this lane for the re-seeds r0 .. r0 + TBL - 1
         double ph;
@@ -851,21 +895,40 @@ __device__ __forceinline__ void run_segment_packed(const JobCtx& c, const float2
         return expmj(ph);
     };
     float2 T = make_float2(1.0f, 0.0f);
-    if (!single) T = fill_table(0);
+    if (!single && !fac) T = fill_table(0);
     auto table = [&](int l) -> v2f {
         v2f r;
         r.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, T.x), l));
         r.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, T.y), l));
         return r;
     };
-    const v2f w2 = single ? single_w2 : table(2);
-    const v2f inc_s = single ? single_inc : table(0), w_s = single ? single_w : table(1);  // exp(-j step), exp(-j 2 PPC step): wave-uniform (MRG: used in every trip; otherwise in the fold)
+    auto fac_uniform = [&](int at) -> v2f {  // a wave-uniform table entry, in SGPRs
+        const float2 u = c.fac_tab[at];
+        return (v2f){__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, u.x))),
+            __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, u.y)))};
+    };
+    v2f w2, inc_s, w_s;  // exp(-j 2 NCH PPC step), exp(-j step), exp(-j 2 PPC step): wave-uniform (MRG: used in every trip; otherwise in the fold)
+    if (fac)
+        {
+            inc_s = fac_uniform(FAC_INC);
+            w_s = fac_uniform(FAC_INC + 1);
+            w2 = fac_uniform(FAC_INC + 2);
+        }
+    else
+        {
+            w2 = single ? single_w2 : table(2);
+            inc_s = single ? single_inc : table(0);
+            w_s = single ? single_w : table(1);
+        }
 
     // paired taps (DER): one bit per chunk of 2 PPC samples (per WAVE: see judge), set where every value of the early and the late index chain stays inside one binade
     // (margins of 1/8 chip; see packed_trip).  Lane l judges chunk 64 m + l.  All of it happens HERE, before the accumulators exist: evaluated inside the
     // trip loop its temporaries cost the loop a dozen VGPRs and with them one wave per SIMD.  Two masks = 128 chunks; what lies
     // beyond (windows longer than 2^16 samples at 256 threads) runs the per-tap chains.
-    unsigned long long der_mask0 = 0ULL, der_mask1 = 0ULL;  // chunks 0..63, 64..127
+    constexpr int NM = MC_THREADS >= 128 ? 2 : 4;  // masks of 64 chunks: at least 32 768 samples of a window whatever the work-group size
+    unsigned long long der_mask[NM];               // chunks 0..63, 64..127, ...
+#pragma unroll
+    for (int m = 0; m < NM; m++) der_mask[m] = 0ULL;
     if constexpr (DER)
         {
             // float arithmetic is enough: the margins (1/8 chip) exceed its error (< 2^-7 below the 2^16 bound) by far, and a chunk judged unsafe only loses speed
@@ -880,8 +943,10 @@ __device__ __forceinline__ void run_segment_packed(const JobCtx& c, const float2
                 const bool one_binade_u = (lo2 >= 1.0f) && (hi2 < 65536.0f) && ((__float_as_uint(lo2) >> 23) == (__float_as_uint(hi2) >> 23));
                 return __ballot(one_binade_a && one_binade_u);
             };
-            der_mask0 = judge(0);
-            if (NCH * n_trips > 64) der_mask1 = judge(64);  // uniform
+            der_mask[0] = judge(0);
+#pragma unroll
+            for (int m = 1; m < NM; m++)
+                if (NCH * n_trips > 64 * m) der_mask[m] = judge(64 * m);  // uniform
         }
     if constexpr (!EARLY_LOADS) first_loads();
     v2f pa = zero, nfA = zero, nfB = zero;
@@ -893,13 +958,18 @@ __device__ __forceinline__ void run_segment_packed(const JobCtx& c, const float2
         const int n0 = (c.n_first + i * TRIP) + 2 * tid;  // (uniform part first: used at re-seeds and edges only)
         if (until_reseed == 0)  // uniform: exact re-seed of the lane's phasor and of (float)n
             {
-                if (!single && r_idx - tbl0 >= TBL)
+                if (!single && !fac && r_idx - tbl0 >= TBL)
                     {
                         tbl0 = r_idx;
                         T = fill_table(tbl0);
                     }
                 if (single)
                     pa = seed_direct;
+                else if (fac)
+                    {
+                        const float2 ar = c.fac_tab[FAC_A + r_idx];  // (uniform address: one LDS broadcast read)
+                        pa = pk_cmul((v2f){ar.x, ar.y}, L);
+                    }
                 else
                     pa = pk_cmul(table(4 + r_idx - tbl0), L);
                 nfA = (v2f){static_cast<float>(n0), static_cast<float>(n0 + 1)};
@@ -967,8 +1037,10 @@ __device__ __forceinline__ void run_segment_packed(const JobCtx& c, const float2
                 return ((i >= first_plain) && (i < last_plain)) ? (NCH == 2 ? 3U : 1U) : 0U;
 #endif
                 const int ch = NCH * i;
-                const unsigned long long mask = (ch < 64) ? der_mask0 : der_mask1;  // uniform select
-                const bool plain = (i >= first_plain) && (i < last_plain) && (ch < 128);
+                unsigned long long mask = der_mask[0];  // uniform selects
+#pragma unroll
+                for (int m = 1; m < NM; m++) mask = (ch >= 64 * m) ? der_mask[m] : mask;
+                const bool plain = (i >= first_plain) && (i < last_plain) && (ch < 64 * NM);
                 const unsigned bits = static_cast<unsigned>(mask >> (ch & 63)) & (NCH == 2 ? 3U : 1U);
                 return plain ? bits : 0U;
             };

@@ -32,6 +32,7 @@ struct McorrArgs
     unsigned long long sample_base;  // added to every job's sample_offset at launch (gsh_bank_set_sample_base): the same resident job table serves block after block
     unsigned long long ring_capacity;// > 0: the stream is a gsh_stream ring, positions are taken modulo its capacity (windows stay contiguous: mirror)
     int packed;                      // 1: the packed four-samples-per-lane body may be used (default); 0: the round-1 body (A/B runs)
+    int fac;                         // 1: the carrier seeds come from the work-group's factor table (default); 0: two evaluations per lane (A/B runs, GSH_MC_FAC=0)
     int pair;                        // 1: every job with two or three taps in this batch is an E/P/L set with a zero-shift prompt, early and late exactly one chip
                                      // apart and the code running forward (the host checked): the 3-tap launch reads early next to late (mcorr_device.h)
     const int* aux;                  // device, n_jobs, or nullptr.  aux[j] >= 0: job j also computes the single tap of job aux[j] (same window and
@@ -42,6 +43,8 @@ struct McorrArgs
 // instance; all jobs of one launch must share `mode` (gsh_corr_job::high_dyn).
 // 1 unless the environment says GSH_MC_PACKED_BODY=0 (read once; A/B switch for profiles/ab/mcorr_ab.py)
 int mcorr_packed_default();
+// 1 unless the environment says GSH_MC_FAC=0 (read once; A/B switch)
+int mcorr_fac_default();
 
 int mcorr_launch(const McorrArgs& args, int max_taps, int mode, int max_code_len, hipStream_t stream);
 
@@ -55,6 +58,9 @@ struct McorrClassPlan
     bool aux[4];
 };
 int mcorr_launch_classes(const McorrArgs& args, const McorrClassPlan& plan, int mode, int max_code_len, hipStream_t stream);
+// the same through the 128-thread kernels (csrc/multicorrelator_t128.hip); mcorr_launch / mcorr_launch_classes choose, callers do not
+int mcorr_launch_t128(const McorrArgs& args, int max_taps, int mode, int max_code_len, hipStream_t stream);
+int mcorr_launch_classes_t128(const McorrArgs& args, const McorrClassPlan& plan, int mode, int max_code_len, hipStream_t stream);
 
 // dynamic LDS bytes the kernel needs for a code of max_code_len samples
 size_t mcorr_lds_bytes(int max_code_len);

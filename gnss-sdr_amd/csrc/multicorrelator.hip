@@ -25,7 +25,16 @@
 //     T complex results: algorithmic traffic 8*N + 8*T bytes per job;
 //   * blockIdx is remapped so that consecutive jobs (host order: epoch-major, channel-minor,
 //     i.e. jobs that read the same samples) run on the same XCD and share its L2.
+// Two work-group sizes of the same source (round 6): this translation unit builds the 256-thread kernels (four waves per job: every flavour, and the launcher
+// every caller sees); multicorrelator_t128.hip includes it again with GSH_MC_THREADS = 128 and builds the E/P/L whole-code flavours with TWO waves per job.
+// What a job costs besides its trips -- set-up, edge trips, fold, wave sums: ~330 vector instructions per WAVE (profiles/ab/r06/session5.txt) -- is then paid
+// twice, not four times: 5 928 instead of 6 689 vector instructions per 25 000-sample job, 173 us instead of 184 per launch of 12 800 jobs.  With few jobs in
+// flight (closed-loop batches, split windows) four waves per job finish a job sooner and keep the chip fuller: mcorr_launch picks per launch.
 #include "multicorrelator.h"
+#ifdef GSH_MC_VARIANT_128
+#define mcorr_kernel mcorr_kernel_t128
+#define mcorr_reduce_partials mcorr_reduce_partials_t128
+#endif
 #include "mcorr_device.h"
 #include <cmath>
 #include <cstdlib>
@@ -209,6 +218,16 @@ __global__ __launch_bounds__(MC_THREADS, ((NT <= 3 && !AUX) ? GSH_MC_MIN_WAVES :
     else if (AUX)
         lds_floats = ((lds_floats + 3) & ~3) + (a.window_floats > 0 ? a.window_floats : a.code_stride + 2 * MC_MARGIN);  // same `red` place for every work-group
     float2* red = reinterpret_cast<float2*>(lds + ((lds_floats + 3) & ~3));
+    // ---- the factors of every lane's carrier seeds for this job (mcorr_device.h fac_table_fill): one evaluation per lane of the first wave, beside the staging
+    float2* const fac = red + MC_WAVES * GSH_MAX_TAPS;
+    if constexpr (MODE == 0 && MC_THREADS <= 256)
+        {
+            if (a.packed != 0 && a.fac != 0)
+                {
+                    if ((tid >> 6) == 0) fac_table_fill<2>(fac, c.phase_step, c.rem_carr, c.n_first, tid);
+                    c.fac_tab = fac;
+                }
+        }
 
     float2 acc[NT];
 #pragma unroll
@@ -233,7 +252,7 @@ __global__ __launch_bounds__(MC_THREADS, ((NT <= 3 && !AUX) ? GSH_MC_MIN_WAVES :
                 {
                     if constexpr (RUNS)
                         {
-                            float* const runs_lds = reinterpret_cast<float*>(red + MC_WAVES * GSH_MAX_TAPS) + (tid >> 6) * RunsLayout<MC_RUN_LEN>::FLOATS;
+                            float* const runs_lds = reinterpret_cast<float*>(fac + FAC_ENTRIES) + (tid >> 6) * RunsLayout<MC_RUN_LEN>::FLOATS;
                             run_segment_runs<NT, MC_RUN_LEN>(c, base, tab, sh, acc, runs_lds);
                         }
                 }
@@ -394,6 +413,7 @@ int launch_nt(const McorrArgs& a, int mode, size_t lds, hipStream_t stream)
 }
 }  // namespace
 
+#ifndef GSH_MC_VARIANT_128
 int mcorr_packed_default()
 {
     // GSH_MC_PACKED_BODY: 0 the round-1 body, 1 the packed trips, 2 the run-based path where a job qualifies, 3 the packed trips with the derived
@@ -410,28 +430,69 @@ int mcorr_packed_default()
     return v;
 }
 
+int mcorr_fac_default()
+{
+    static const int v = [] {
+        const char* e = std::getenv("GSH_MC_FAC");
+        return (e != nullptr && e[0] == '0') ? 0 : 1;
+    }();
+    return v;
+}
+
+#endif  // !GSH_MC_VARIANT_128
+
+#ifdef GSH_MC_VARIANT_128
+#define mcorr_lds_bytes_window mcorr_lds_bytes_window_t128
+#define mcorr_lds_bytes_fused mcorr_lds_bytes_fused_t128
+#define mcorr_lds_bytes mcorr_lds_bytes_t128
+#define mcorr_launch mcorr_launch_t128
+#define mcorr_launch_classes mcorr_launch_classes_t128
+namespace
+{
+#endif
 size_t mcorr_lds_bytes_window(int window_floats)
 {
     const size_t tab = (static_cast<size_t>(window_floats) + 3) & ~static_cast<size_t>(3);
-    return tab * sizeof(float) + MC_WAVES * GSH_MAX_TAPS * sizeof(float2);
+    return tab * sizeof(float) + (MC_WAVES * GSH_MAX_TAPS + FAC_ENTRIES) * sizeof(float2);
 }
 
 size_t mcorr_lds_bytes_fused(int max_code_len, int window_floats)
 {
     const size_t one = window_floats > 0 ? static_cast<size_t>(window_floats) : static_cast<size_t>(max_code_len) + 2 * MC_MARGIN;
     const size_t tab = ((one + 3) & ~static_cast<size_t>(3)) + ((one + 3) & ~static_cast<size_t>(3));
-    return tab * sizeof(float) + MC_WAVES * GSH_MAX_TAPS * sizeof(float2);
+    return tab * sizeof(float) + (MC_WAVES * GSH_MAX_TAPS + FAC_ENTRIES) * sizeof(float2);
 }
 
 size_t mcorr_lds_bytes(int max_code_len)
 {
     const size_t tab = (static_cast<size_t>(max_code_len) + 2 * MC_MARGIN + 3) & ~static_cast<size_t>(3);
-    return tab * sizeof(float) + MC_WAVES * GSH_MAX_TAPS * sizeof(float2);
+    return tab * sizeof(float) + (MC_WAVES * GSH_MAX_TAPS + FAC_ENTRIES) * sizeof(float2);
 }
+
+#ifdef GSH_MC_VARIANT_128
+}  // namespace
+#else
+// work-group size of a launch: 128 threads (two waves per job) for the E/P/L whole-code flavours once the launch holds at least two rounds of them (2 x 2 560
+// work-groups: a job then takes twice as long, and a chip that is not full wants the shorter jobs); GSH_MC_WG=128 / 256 forces one (A/B runs)
+bool use_128(const McorrArgs& a, int max_taps, int mode)
+{
+    static const int forced = [] {
+        const char* e = std::getenv("GSH_MC_WG");
+        return e != nullptr ? std::atoi(e) : 0;
+    }();
+    const bool possible = mode == 0 && a.aux == nullptr && a.window_floats == 0 && max_taps >= 2 && max_taps <= 3 && a.packed == 1;
+    if (!possible || forced == 256) return false;
+    if (forced == 128) return true;
+    return static_cast<long long>(a.n_launch) * a.splits >= 2 * 2560;
+}
+#endif
 
 int mcorr_launch(const McorrArgs& a, int max_taps, int mode, int max_code_len, hipStream_t stream)
 {
     if (a.n_jobs <= 0) return GSH_OK;
+#ifndef GSH_MC_VARIANT_128
+    if (use_128(a, max_taps, mode)) return mcorr_launch_t128(a, max_taps, mode, max_code_len, stream);
+#endif
     GSH_REQUIRE(max_taps >= 1 && max_taps <= GSH_MAX_TAPS, "n_taps %d outside 1..%d", max_taps, GSH_MAX_TAPS);
     GSH_REQUIRE(a.splits >= 1, "splits must be >= 1");
     const size_t lds = a.aux != nullptr ? mcorr_lds_bytes_fused(max_code_len, a.window_floats)
@@ -468,6 +529,20 @@ int mcorr_launch_classes(const McorrArgs& args, const McorrClassPlan& plan, int 
             a.job_list = plan.list + plan.offset[c];
             a.n_launch = plan.count[c];
             if (!plan.aux[c]) a.aux = nullptr;
+#ifndef GSH_MC_VARIANT_128
+            if (use_128(a, class_taps[c], mode))
+                {
+                    // this class alone through the two-wave kernels (the partials, if any, are summed once below)
+                    McorrClassPlan one = plan;
+                    for (int o = 0; o < 4; o++)
+                        if (o != c) one.count[o] = 0;
+                    McorrArgs b1 = args;
+                    b1.splits = args.splits;
+                    const int rc1 = mcorr_launch_classes_t128(b1, one, mode, max_code_len, stream);
+                    if (rc1 != GSH_OK) return rc1;
+                    continue;
+                }
+#endif
             const size_t lds = a.aux != nullptr ? mcorr_lds_bytes_fused(max_code_len, a.window_floats)
                                                 : (a.window_floats > 0 ? mcorr_lds_bytes_window(a.window_floats) : mcorr_lds_bytes(max_code_len));
             GSH_REQUIRE(lds <= 160 * 1024, "local code of %d samples does not fit the 160 KiB LDS", max_code_len);

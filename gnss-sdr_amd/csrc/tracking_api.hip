@@ -532,6 +532,7 @@ extern "C"
         a.splits = splits;
         a.window_floats = bank_window_floats(b, splits);
         a.packed = gsh::mcorr_packed_default();
+        a.fac = gsh::mcorr_fac_default();
         a.pair = b->pair ? 1 : 0;
         a.sample_base = b->sample_base;
         a.ring_capacity = b->ring != nullptr ? b->ring->capacity : 0ull;

@@ -32,7 +32,7 @@ def test_closed_loop_kernels_use_no_scratch(meta):
 
 def test_batched_correlator_flavours_use_no_scratch(meta):
     # mcorr_kernel<NT, MODE, AUX, RUNS, WIN, PAIR>: every flavour except the run-based experiment (RUNS = true, behind GSH_MC_PACKED_BODY=2)
-    pat = re.compile(r"mcorr_kernelILi(\d)ELi(\d)ELb([01])ELb([01])ELb([01])ELb([01])E")
+    pat = re.compile(r"mcorr_kernel(?:_t128)?ILi(\d)ELi(\d)ELb([01])ELb([01])ELb([01])ELb([01])E")
     seen = 0
     for n, k in meta.items():
         m = pat.search(n)

@@ -207,6 +207,46 @@ def test_paired_taps_random_sweep(gpu):
     b.close()
 
 
+def test_two_wave_work_groups_of_large_launches(gpu):
+    """A launch of at least 5 120 E/P/L jobs runs the 128-thread kernels (two waves per job, csrc/multicorrelator_t128.hip), smaller ones the 256-thread kernels
+    (mcorr_launch picks).  The same 5 400 jobs in one launch and in batches of 900: chip selection exact in both (integer-valued carrier-free input: the sums are
+    exact in float32 whatever the order of summation, so the two launches must agree bit for bit and with the oracle's chips), and with noise and a carrier both
+    within the accumulator bar of the float64 truth."""
+    rng = np.random.default_rng(424242)
+    n_max = 9000
+    xr = rng.integers(-7, 8, 2 * n_max + 128).astype(np.float32)
+    codes = [oracle.ca_code(p) for p in (5, 17, 23, 31)]
+    b = _bank(gpu, codes)
+    b.set_stream_host(xr.astype(np.complex64))
+    jobs = []
+    for i in range(5400):
+        step = float(np.float32(1.023e6 / rng.choice([4e6, 5e6, 10e6, 12.5e6, 25e6]))) if i % 2 else float(np.float32(rng.uniform(0.03, 0.5)))
+        length = int(min(n_max, max(1, rng.integers(1, int(1040 / step) + 1))))
+        jobs.append(dict(sample_offset=int(rng.integers(0, n_max)), n_samples=length, code_slot=i % 4, shifts_chips=[-0.5, 0.0, 0.5], rem_carr_phase_rad=0.0, phase_step_rad=0.0,
+                         rem_code_phase_chips=float(np.float32(rng.uniform(-0.5, 1.5))), code_phase_step_chips=step))
+    big = b.correlate(jobs)
+    small = np.concatenate([b.correlate(jobs[k:k + 900]) for k in range(0, len(jobs), 900)], axis=0)
+    assert np.array_equal(big.view(np.uint32), small.view(np.uint32))
+    for j in range(0, len(jobs), 9):
+        job = jobs[j]
+        idx = oracle.code_indices(job["n_samples"], np.asarray(job["shifts_chips"], np.float32), job["rem_code_phase_chips"], job["code_phase_step_chips"], 0.0, 1023, False)
+        seg = xr[job["sample_offset"]:job["sample_offset"] + job["n_samples"]].astype(np.float64)
+        expect = np.array([(codes[job["code_slot"]][idx[t]].astype(np.float64) * seg).sum() for t in range(3)])
+        assert np.array_equal(big[j, :3].real.astype(np.float64), expect), (job, big[j, :3], expect)
+    # noise + carrier: both work-group sizes against the float64 truth
+    x = (rng.standard_normal(2 * n_max + 128) + 1j * rng.standard_normal(2 * n_max + 128)).astype(np.complex64)
+    b.set_stream_host(x)
+    for job in jobs:
+        job.update(rem_carr_phase_rad=float(np.float32(rng.uniform(0, 6.28))), phase_step_rad=float(np.float32(rng.uniform(-0.02, 0.02))))
+    big = b.correlate(jobs)
+    small = np.concatenate([b.correlate(jobs[k:k + 900]) for k in range(0, len(jobs), 900)], axis=0)
+    pick = list(range(0, len(jobs), 27))
+    w_big = _check(big[pick], [jobs[j] for j in pick], codes, x)
+    w_small = _check(small[pick], [jobs[j] for j in pick], codes, x)
+    print(f"two-wave kernels: worst |gpu-truth|/sum|x| = {w_big:.2e}; four-wave kernels: {w_small:.2e}")
+    b.close()
+
+
 def test_derived_taps_on_long_codes(gpu):
     """The same on 10 230-chip codes (chip indices up to 2^13.3: the binades 1024 .. 8192), whole windows and the windowed code table with automatic splits."""
     fs, n = 25e6, 25000
