@@ -182,21 +182,24 @@ def cpu_baseline(channels, n, fs, taps, target_s):
                 R.ref_set_flavour(0)
         return oracle.lib().oracle_mcorr_time(codes, 1023, shifts, taps, xi, len(x), n, channels, epochs, threads, params, out)
 
-    # one thread first: the yardstick for how much parallelism the box actually delivers (cgroup quotas, SMT siblings and memory channels
-    # make that much less than os.cpu_count() suggests)
-    threads = 1
-    run(16)
-    rate_1 = channels * 64 / max(run(64), 1e-9) if channels >= 1 else 0.0
-    # pick the thread count that serves the CPU best (more threads than memory channels can hurt this streaming kernel)
-    best = (0.0, cores)
-    for cand in sorted({min(cores, c) for c in (8, 16, 32, 64, 128, 256, cores)}):
-        threads = cand
-        e = max(16, 2 * cand * 16 // channels)
-        run(e)
+    # threads = what the box grants this process (cgroup quota / affinity), not its logical CPU count: 256 threads on a 16-CPU quota fight over the same cores and the
+    # figure wanders (0.31 ... 0.64 M correlators/s across rounds).  The sweep 1, 2, 4, ..., quota (SURVEY 8d / BASELINE.md section 4) is reported beside it.
+    q = host_cpu_quota()
+    granted = min([v for v in (q.get("affinity_cpus"), q.get("cgroup_cpus"), os.cpu_count()) if v] or [1])
+    quota_threads = max(1, min(channels, int(np.floor(granted + 1e-9)) or 1))
+    sweep, cand = [], 1
+    while True:
+        threads = min(cand, quota_threads)
+        e = max(16, 2 * threads * 16 // channels)
+        run(e)                                    # warm-up at this thread count
+        e = max(e, 64 if threads == 1 else e)
         rate = channels * e / max(run(e), 1e-9)
-        if rate > best[0]:
-            best = (rate, cand)
-    threads = best[1]
+        sweep.append({"threads": threads, "value": rate * taps})
+        if threads >= quota_threads:
+            break
+        cand *= 2
+    rate_1 = sweep[0]["value"] / taps
+    threads = quota_threads
     cores = threads
     epochs = 64
     t = run(epochs)  # calibration, then grow the sample until it fills about target_s of wall time
@@ -212,6 +215,8 @@ def cpu_baseline(channels, n, fs, taps, target_s):
         "host_logical_cpus": os.cpu_count(),
         "host_cpu_quota": host_cpu_quota(),   # cgroup quota / affinity: what of those CPUs the container may use
         "single_thread_value": rate_1 * taps,
+        "thread_sweep": sweep,                # correlators/s at 1, 2, 4, ..., quota threads (short samples)
+        "best_of_sweep": max(sweep, key=lambda r: r["value"]),
         "effective_parallelism": (rate_best / rate_1) if rate_1 > 0 else None,   # what the threads delivered, in single-thread units
         "kind": kind,
         "sample": f"{channels} channels x {epochs} epochs of {n} samples, {taps} taps, {cores} threads, "
@@ -246,6 +251,7 @@ def acquisition_metric(torch, dev_index, x_block, fs, pmc=None):
     flops = (41 + 32 * 41) * (5.0 * n * np.log2(n) + 6.0 * n)
     unique = 8.0 * n + 8.0 * n * 32 + 16.0 * 32      # the input block, the 32 code spectra, the result records: what must come from HBM once
     roof = {"bound": "hbm", "achieved": nbytes / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / t / 1e9 / HBM_PEAK_GBS, "traffic": None,
+            "frac_single_stream": nbytes / (ms_serial * 1e-3) / 1e9 / HBM_PEAK_GBS, "frac_is": "pipelined (two batches in flight)",
             "algorithmic_bytes_per_batch": nbytes, "kernels": "oc_forward_kernel + oc_cell_kernel<Plan<25,25,40>,false,false>",
             "binding": "valu+lds (one transform per compute unit: register butterflies, LDS exchanges between barriers)",
             "valu": {"algorithmic_flops_per_batch": flops, "achieved_tflops": flops / t / 1e12, "peak_tflops": FP32_PEAK_TFLOPS,
@@ -256,7 +262,8 @@ def acquisition_metric(torch, dev_index, x_block, fs, pmc=None):
         roof["traffic"] = m.get("hbm_bytes_per_batch")
         roof["pmc"] = {k: v for k, v in m.items() if k not in ("n", "n_prn", "n_bins")}
     res = {"metric": "acquisition dwells/s", "value": 32.0 / (ms * 1e-3), "unit": "dwells/s", "ms_per_batch": ms,
-           "ms_per_batch_single_stream": ms_serial,
+           "value_is": "PIPELINED: batches alternate on two streams, two in flight (throughput); value_single_stream is one batch after the other on one stream",
+           "value_single_stream": 32.0 / (ms_serial * 1e-3), "ms_per_batch_single_stream": ms_serial,
            "config": {"workload": "GPS L1 C/A PCPS, 32 PRN x 41 Doppler bins, N=25000, 1 dwell"},
            "roofline": roof}
     acq.close()
@@ -732,8 +739,12 @@ def bench_summary(res):
             d = d[k]
         return d
     s = {"tracking_Mcorr_s": res["value"] / 1e6, "tracking_kernel_ms": get(res, "roofline", "kernel_ms"), "tracking_valu_frac": get(res, "roofline", "frac"),
-         "acq_dwells_s": get(res, "acquisition", "value"), "acq_ms_per_batch": get(res, "acquisition", "ms_per_batch"),
-         "acq_hbm_frac": get(res, "acquisition", "roofline", "frac"),
+         "acq_dwells_s_pipelined": get(res, "acquisition", "value"), "acq_dwells_s_single_stream": get(res, "acquisition", "value_single_stream"),
+         "acq_ms_per_batch_pipelined": get(res, "acquisition", "ms_per_batch"), "acq_ms_per_batch_single_stream": get(res, "acquisition", "ms_per_batch_single_stream"),
+         "acq_hbm_frac_pipelined": get(res, "acquisition", "roofline", "frac"), "acq_hbm_frac_single_stream": get(res, "acquisition", "roofline", "frac_single_stream"),
+         "acq_128000_ms": get(res, "acquisition", "split_plan_128000", "ms_per_batch"), "acq_50000_ms": get(res, "acquisition", "split_plan_50000", "ms_per_batch"),
+         "hbm_read_probe_GBs": res.get("hbm_read_probe_GBs"), "hbm_unique_frac": res.get("hbm_unique_frac"), "valu_issue_frac": res.get("valu_issue_frac"),
+         "cpu_baseline_threads": get(res, "cpu_baseline", "cores"),
          "closed_loop_us": get(res, "closed_loop", "us_per_epoch"), "closed_loop_detectors_us": get(res, "closed_loop_lock_detectors", "us_per_epoch"),
          "closed_loop_live_us": get(res, "closed_loop_lock_detectors", "live", "us_per_epoch"), "closed_loop_256ch_us": get(res, "closed_loop_256ch", "us_per_epoch"),
          "closed_loop_config4_us": get(res, "closed_loop_config4", "us_per_epoch"),
@@ -773,7 +784,9 @@ def tracking_roofline(C, E, T, n, k_ms, pmc):
     unique = 8.0 * (E + 1) * n + 4.0 * 1023 * C + 64.0 * n_jobs
     tflops = flops / t / 1e12
     r = {"bound": "valu", "achieved": tflops, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP32_PEAK_TFLOPS, "traffic": None,
-         "kernel": f"mcorr_kernel<{3 if T <= 3 else (5 if T <= 5 else 8)},0,false,false,false,{'true' if T == 3 else 'false'}>", "kernel_ms": k_ms,
+         "kernel": (f"mcorr_kernel_t128<3,0,false,false,false,true> (two waves per job: launches of >= 5 120 E/P/L jobs, csrc/multicorrelator_t128.hip)"
+                    if (T == 3 and n_jobs >= 5120) else f"mcorr_kernel<{3 if T <= 3 else (5 if T <= 5 else 8)},0,false,false,false,{'true' if T == 3 else 'false'}>"),
+         "kernel_ms": k_ms, "traffic_source": None,
          "algorithmic_flops_per_launch": flops,
          "note": "bound by vector-ALU issue (the float32 chip-index chains of the taps), not by HBM: 32 channels read ONE stream, the block is fetched from HBM once "
                  "and served from L2 to the other 31; MFMA does not apply (per-channel mat-vec, f32 MFMA runs at the vector rate on gfx950)",
@@ -786,6 +799,11 @@ def tracking_roofline(C, E, T, n, k_ms, pmc):
     m = (pmc or {}).get("mcorr")
     if m and m.get("jobs") == n_jobs and m.get("n") == n:
         r["traffic"] = m.get("hbm_bytes_per_launch")
+        r["traffic_source"] = "static:" + str((pmc or {}).get("file")) + " (rocprofv3 --pmc passes of the builder's profiling run of this command, not counters of THIS run)"
+        if m.get("SQ_INSTS_VALU") and m.get("kernel_avg_us"):
+            # share of the vector-ALU issue slots the launch used: 4 clocks per wave64 instruction over 1 024 SIMDs x the kernel's clocks (static counters, 2.4 GHz)
+            r["valu_issue_frac"] = 4.0 * m["SQ_INSTS_VALU"] / (1024.0 * m["kernel_avg_us"] * 1e-6 * 2.4e9)
+            r["valu_issue_frac_source"] = r["traffic_source"]
         r["pmc_static"] = {k: m[k] for k in ("source", "kernel_avg_us", "SQ_INSTS_VALU", "SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY",
                                       "valu_insts_per_channel_sample", "valu_cycles_per_inst_per_simd", "l2_read_bytes_per_launch", "l2_GBs",
                                       "hbm_bytes_per_launch", "hbm_GBs") if k in m}
@@ -1002,7 +1020,9 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"GPS L1 C/A tracking, {C} channels/GPU x {E} epochs/block x {BPS} blocks/step, fs={fs / 1e6:g} Msps, N={n}, {T}-tap E/P/L, open-loop",
+            "config": {"workload": f"GPS L1 C/A tracking, {C} channels/GPU x {E} epochs/block x {BPS} blocks/step, fs={fs / 1e6:g} Msps, N={n}, {T}-tap E/P/L, open-loop; "
+                                   + ("the IF stream is RESIDENT in HBM before the timed region (host-to-device transfer excluded: pcie_inclusive is the end-to-end figure)"
+                                      if not grouped else "every 8-bit block enters GPU 0 from device memory and is replicated by the engine inside the timed region"),
                        "channels_per_gpu": C, "epochs_per_block": E, "blocks_per_step": BPS, "samples_per_epoch": n, "taps": T,
                        "stream_resident_bytes": int(8 * NB * block) if not grouped else int(8 * (3 * block + 2)),
                        "timed_region_s": dt,
@@ -1020,6 +1040,24 @@ def main():
             res["rccl_library"] = StreamGroup.library()
             res["rccl_library_is_test_stub"] = G.rccl_info()["version"] == 99999   # tests/host/fake_rccl.cc: a functional self-test, its rates mean nothing
             res["rccl_calls"] = G.rccl_info()["collectives"]
+        # the figures a reader needs first, as top-level scalars (the nested objects explain them)
+        rf = res["roofline"]
+        res["traffic_source"] = rf.get("traffic_source")
+        res["contract_hbm_rate_over_peak"] = rf["contract_hbm"]["rate_over_peak"]   # SURVEY 8(d) bytes / time / 8 TB/s: a RATE (> 1: 32 channels share one stream)
+        res["hbm_unique_frac"] = rf["hbm_unique"]["frac"]                            # bytes that must leave HBM once per launch / time / 8 TB/s: the utilisation
+        res["valu_issue_frac"] = rf.get("valu_issue_frac")                           # what binds the kernel (static counters)
+        try:
+            import ctypes
+            gbs = ctypes.c_double(0.0)
+            from gnss_sdr_amd import _lib as _gl
+            _gl.check(_gl.load().gsh_probe_read_bandwidth(local, 2 << 30, 8, ctypes.byref(gbs)))
+            res["hbm_read_probe_GBs"] = gbs.value        # measured streaming read of 2 GiB (> Infinity Cache) with 16-byte loads, this device, this run
+            res["hbm_read_probe_frac_of_nominal"] = gbs.value / HBM_PEAK_GBS
+            res["contract_hbm_rate_over_measured"] = rf["contract_hbm"]["achieved"] / gbs.value
+            res["hbm_unique_frac_of_measured"] = rf["hbm_unique"]["achieved_GBs"] / gbs.value
+        except Exception as e:
+            res["hbm_read_probe_GBs"] = None
+            res["hbm_read_probe_error"] = str(e)
         if sharded is not None:
             res.update(sharded)
         # ---- the other GPU legs first, while the device is still at its working clocks (the CPU legs below leave it idle for ~40 s; what runs after

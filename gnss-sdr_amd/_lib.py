@@ -123,6 +123,7 @@ _F = C.POINTER(C.c_float)
 SYMBOLS = {
     "gsh_abi_version": (C.c_int, []),
     "gsh_device_count": (C.c_int, []),
+    "gsh_probe_read_bandwidth": (C.c_int, [C.c_int, C.c_uint64, C.c_int, C.POINTER(C.c_double)]),
     "gsh_last_error": (C.c_char_p, []),
     "gsh_device_name": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
     "gsh_mcorr_create": (C.c_int, [C.c_int, C.POINTER(_P)]),

@@ -2513,6 +2513,11 @@ extern "C"
         s.p_old_re = 0.0F;
         s.p_old_im = 0.0F;
         s.pos = start_sample;
+        // d_pull_in_transitory is a LATCH in the reference (trk.cc:1910-1917: once false it stays false); the kernel re-evaluates pos - acq_stamp < limit every period.
+        // A stamp beyond start_sample means the pull-in call's read pointer was below the stamp too (start_sample = nitems_read + offset >= nitems_read): the unsigned
+        // difference wrapped there and released the latch at that very call -- without this the wrapped difference would read "over" only until pos passes the stamp
+        // and then switch the FLL pull-in and the lock-counter gating back ON (round-5 review).
+        if (acq_sample_stamp > start_sample) flags |= GSH_TRK_START_PULL_IN_OVER;
         s.acq_stamp = acq_sample_stamp | ((flags & GSH_TRK_START_PULL_IN_OVER) ? (1ull << 63) : 0ull);
         s.active = 1;
         s.code_len = code_length;

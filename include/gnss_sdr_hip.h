@@ -48,6 +48,10 @@ extern "C"
     int gsh_device_count(void);               /* 0 when no GPU is visible */
     const char* gsh_last_error(void);         /* thread-local, never NULL */
     int gsh_device_name(int device, char* buf, size_t buflen);
+    /* diagnostic: streaming-read bandwidth of the device as THIS library's loads see it -- a `bytes`-sized buffer (allocated here; larger than the 256 MiB Infinity
+     * Cache to measure HBM) read `reps` times with 16-byte loads by a full grid, HIP-event timed; *gb_per_s = bytes x reps / time.  The figure rooflines are
+     * stated against beside the nominal peak. */
+    int gsh_probe_read_bandwidth(int device, uint64_t bytes, int reps, double* gb_per_s);
 
     /* ================================================================== TRACKING
      * (1) gsh_mcorr_*: one-to-one replacement of class Cpu_Multicorrelator_Real_Codes

@@ -618,6 +618,9 @@ int oracle_trk_run_flags(const oracle_trk_conf* c, const float* code, const floa
     uint64_t pos = start_sample;
     oracle_lock_state lock;
     int pull_in_latched = 1;  /* d_pull_in_transitory, cleared once (trk.cc:1910-1917) */
+    /* a stamp beyond start_sample: the pull-in call's read pointer (<= start_sample) was below the stamp, the unsigned difference wrapped and the reference's latch
+     * was released at that call for good -- never to come back when pos passes the stamp */
+    if (acq_sample_stamp > start_sample) flags |= 1U;
     /* symbol synchronisation (trk.cc:2026-2104) and narrow tracking (state 4, :2197-2252) */
     int state = 2, cloop = c->cloop;
     float ring[2 * ORACLE_MAX_SECONDARY];  /* d_Prompt_circular_buffer: boost::circular_buffer of capacity d_secondary_code_length */

@@ -107,13 +107,13 @@ def _compare(ref_outs, rec, c, first_pos):
     return worst
 
 
-def _run_both(t, x, n, acq_stamp, acq_doppler, n_periods):
+def _run_both(t, x, n, acq_stamp, acq_doppler, n_periods, max_skip=None):
     c = t.conf()
     code, data_code = t.codes()
     # pull-in call (trk.cc:1949-1978): aligns the stream, produces nothing
     pos0 = t.nitems_read()
     r, consumed, o = t.work(x[pos0:pos0 + 2 * n])
-    assert r == 0 and o["state"] == 2 and 0 <= consumed <= n
+    assert r == 0 and o["state"] == 2 and 0 <= consumed <= (max_skip or n)   # (a stamp ahead of the read pointer: T_prn - fmod(negative) exceeds a period)
     start = pos0 + consumed
     outs, pos, state_before = [], start, 2
     while len(outs) < n_periods:
@@ -155,6 +155,51 @@ def test_gps_l1_loop_trajectory_equals_reference_block():
     # the loop pulled the 20 Hz Doppler error in and holds the signal
     assert abs(rec[-1].carrier_doppler_hz - 1234.0) < 5.0
     assert rec[-1].cn0_db_hz > 40.0
+
+
+def test_acquisition_stamp_ahead_of_the_read_pointer_releases_the_pull_in_latch_for_good():
+    """trk.cc:1910-1917: d_pull_in_transitory is a latch.  With the acquisition's stamp AHEAD of the block's read pointer at the pull-in call the unsigned difference
+    wraps, the latch is released there and never comes back -- not even when the read pointer passes the stamp a few periods later, where a test re-evaluated every
+    period would read "inside the transitory" again and switch the FLL pull-in and the lock-counter gating back on (round-5 review).  The block and the restatement
+    over 300 periods, the FLL pull-in enabled so that a returning transitory would bend the carrier loop."""
+    fs, prn, fd, cph = 4000000, 7, -2100.0, 700.25
+    n = fs // 1000
+    n_periods = 300
+    x = synth_gps_l1_stream((n_periods + 14) * n, fs, [prn], [fd], [cph], cn0_dbhz=46.0, seed_noise=23)
+    p = {"GNSS-SDR.internal_fs_sps": fs, "Tracking.pll_bw_hz": 30.0, "Tracking.dll_bw_hz": 2.0, "Tracking.early_late_space_chips": 0.5, "Tracking.pull_in_time_s": 1,
+         "Tracking.enable_fll_pull_in": "true", "Tracking.fll_bw_hz": 10.0}
+    t = ref_trk.RefTrackingChannel("GPS_L1_CA_DLL_PLL_Tracking", p)
+    f_code = 1.023e6 * (1 + fd / 1575.42e6)
+    start_exact = (1023.0 - cph) / f_code * fs
+    acq_stamp = 6 * n + 77                       # four periods ahead of the read pointer of the pull-in call (2 n)
+    acq_delay = (start_exact - acq_stamp) % n    # code start as the acquisition would report it for a block that begins at its stamp
+    acq_doppler = fd + 25.0
+    t.set_acquisition("G", "1C", prn, acq_delay, acq_doppler, acq_stamp)
+    r, consumed, o = t.work(x[:2 * n])
+    assert (r, consumed, o["state"]) == (0, 2 * n, 0)
+    t.start_tracking()
+    c, outs, rec, start = _run_both(t, x, n, acq_stamp, acq_doppler, n_periods, max_skip=2 * n)
+    assert start < acq_stamp < rec[5].sample_counter              # tracking began before the stamp and ran past it
+    # (the bit-synchronisation time limit, trk.cc:2000-2007, sees the same wrapped difference while the read pointer is behind the stamp; this block is past it when its
+    #  C/N0 buffer has filled and lives on)
+    assert len(rec) == len(outs) == 21 and outs[-1]["state"] == 0 and rec[-1].flags & 2, (len(rec), len(outs))
+    # (the bit-synchronisation time limit saw the wrapped difference in the first periods and forced the carrier fail counter, trk.cc:2000-2007: block and restatement
+    #  give the channel up in the period its C/N0 buffer fills -- the seventeen periods between the stamp and that one are what this test is about)
+    pos = start
+    for k, (o, r_) in enumerate(zip(outs[:-1], rec[:-1])):
+        assert r_.sample_counter == pos and r_.prn_length_samples == o["consumed"], (k, r_.sample_counter, pos, o["consumed"])
+        pos += o["consumed"]
+        ref_corr, got = np.array(o["corr"][:6]), np.array(list(r_.corr)[:6])
+        assert np.max(np.abs(ref_corr - got)) <= 2e-5 * max(1.0, np.max(np.abs(ref_corr))), (k, ref_corr, got)
+        assert abs(o["code_freq_chips"] - r_.code_freq_chips) <= 1e-6, k
+        assert abs(o["carr_error_filt_hz"] - r_.carr_error_filt_hz) <= 1e-3, (k, o["carr_error_filt_hz"], r_.carr_error_filt_hz)
+        assert abs(o["carrier_lock_test"] - r_.carrier_lock_test) <= 1e-4, k
+    assert all((r_.flags & 1) == 0 for r_ in rec), "the transitory must stay over"
+    # the same stream with the FLL left on (a transitory that returned) takes another trajectory: the comparison above can tell the two apart
+    conf = trk_conf_from_reference(c)
+    code, _ = t.codes()
+    back = oracle.trk_run(conf, code, x, start, start, acq_doppler, len(outs) - 1)   # stamp AT the start: one second of pull-in
+    assert all((r_.flags & 1) for r_ in back) and max(abs(a.carr_error_filt_hz - b.carr_error_filt_hz) for a, b in zip(rec, back)) > 0.1
 
 
 def _check_trajectory(outs, rec, c, start, acq_doppler, fs, standby_end, corr_tol=2e-5):

@@ -225,6 +225,32 @@ def test_lock_detectors_and_cn0_on_device(gpu):
     loop.close()
 
 
+def test_stamp_ahead_of_the_start_keeps_the_pull_in_transitory_over(gpu):
+    """trk.cc:1910-1917: d_pull_in_transitory is a latch.  A channel whose acquisition stamp lies beyond its first sample had the latch released at the pull-in call (the
+    unsigned difference wrapped); it must not come back when the window position passes the stamp (gsh_trk_start_flags sets GSH_TRK_START_PULL_IN_OVER by itself,
+    as the oracle does -- pinned to the reference block in tests/test_oracle_loop_pinned.py).  FLL pull-in on: a returning transitory would bend the carrier loop."""
+    fs, n, epochs = 4e6, 4000, 120
+    kw = dict(fs_in=fs, vector_length=n, pll_bw_hz=30.0, dll_bw_hz=2.0, pull_in_time_s=1, enable_fll_pull_in=1, fll_bw_hz=10.0, enable_lock_detectors=1,
+              bit_synchronization_time_limit_s=70)
+    prn, fd, cph = 7, -2100.0, 700.25
+    x = synth_gps_l1_stream((epochs + 10) * n, fs, [prn], [fd], [cph], cn0_dbhz=46.0, seed_noise=23)
+    start = int(round((1023.0 - cph) / (1.023e6 * (1 + fd / 1575.42e6)) * fs))
+    stamp = start + 4 * n + 77
+    loop = _loop(gpu, kw, n_channels=2, max_len=1023)
+    loop.set_stream_host(x)
+    loop.start(0, oracle.ca_code(prn), start, stamp, fd + 25.0)                       # no flag passed: the engine sees stamp > start
+    loop.start(1, oracle.ca_code(prn), start, stamp, fd + 25.0, pull_in_over=True)    # what Hip_Tracking_Runtime passes
+    rec, done = loop.run(epochs)
+    ora = oracle.trk_run(oracle.trk_conf(**kw), oracle.ca_code(prn), x, start, stamp, fd + 25.0, epochs)
+    assert rec[0][10].sample_counter > stamp
+    for ch in (0, 1):
+        assert done[ch] == len(ora)
+        assert not any(r.flags & 1 for r in rec[ch][:done[ch]])
+        _compare(rec[ch], ora, 3, f"stamp ahead ch{ch}")
+    assert bytes(memoryview(rec[0][-1])) == bytes(memoryview(rec[1][-1]))
+    loop.close()
+
+
 @pytest.mark.parametrize("cn0_samples", [1, 7, 16, 17, 33, 64])
 def test_cn0_estimator_over_buffers_of_every_shape(gpu, cn0_samples):
     """The M2M4 sums are formed by the 64 lanes of one wave in rows of sixteen (csrc/tracking_loop.hip, m2m4_sums_wave): buffer lengths inside one row, exactly one row,
