@@ -5,6 +5,10 @@
  *   kind 0  pulse_blanking_cc   (src/algorithms/input_filter/gnuradio_blocks/pulse_blanking_cc.cc)
  *   kind 1  Notch               (.../notch_cc.cc)
  *   kind 2  NotchLite           (.../notch_lite_cc.cc)
+ * and, through refconv_* (round 6), the front-end blocks whose arithmetic the engine's casts and resampler must reproduce bit for bit:
+ *   kind 3 / 4 / 5  direct_resampler_conditioner_cc / _cb / _cs   (src/algorithms/resampler/gnuradio_blocks/: gr_complex, lv_8sc_t, lv_16sc_t items)
+ *   kind 6  cshort_to_gr_complex                (src/algorithms/data_type_adapter/gnuradio_blocks/)
+ *   kind 7  interleaved_byte_to_complex_byte    kind 8  interleaved_byte_to_complex_short    kind 9  interleaved_short_to_complex_short
  * A block is driven through its own general_work by a harness that plays the GNU Radio scheduler: the caller hands `n_items` input items (with the
  * block's history already in front, as the scheduler would) and room for `noutput_items`, and learns what the block consumed and produced.
  * Used by tests/test_notch_oracle_pinned.py to pin oracle/notch_oracle.py and the pulse-blanking restatement in oracle/fir_oracle.py.
@@ -28,7 +32,14 @@
 #include "gnss_block_interface.h"
 #include "gnss_sdr_fft.h"
 
+#include "cshort_to_gr_complex.h"
+#include "interleaved_byte_to_complex_byte.h"
+#include "interleaved_byte_to_complex_short.h"
+#include "interleaved_short_to_complex_short.h"
 #define private public
+#include "direct_resampler_conditioner_cb.h"
+#include "direct_resampler_conditioner_cc.h"
+#include "direct_resampler_conditioner_cs.h"
 #include "notch_cc.h"
 #include "notch_lite_cc.h"
 #include "pulse_blanking_cc.h"
@@ -145,5 +156,95 @@ extern "C"
                 z0_iq[1] = h->lite->z_0_.imag();
                 break;
             }
+    }
+
+    /* ---- front-end blocks: resamplers and data-type adapters (items of any size; the caller knows them) */
+    struct ConvHandle
+    {
+        std::shared_ptr<gr::block> blk;
+        int in_item{0}, out_item{0};
+    };
+
+    void* refconv_create(int kind, double fs_in, double fs_out)
+    {
+        try
+            {
+                auto h = std::make_unique<ConvHandle>();
+                switch (kind)
+                    {
+                    case 3:
+                        h->blk = direct_resampler_make_conditioner_cc(fs_in, fs_out);
+                        h->in_item = h->out_item = 8;
+                        break;
+                    case 4:
+                        h->blk = direct_resampler_make_conditioner_cb(fs_in, fs_out);
+                        h->in_item = h->out_item = 2;
+                        break;
+                    case 5:
+                        h->blk = direct_resampler_make_conditioner_cs(fs_in, fs_out);
+                        h->in_item = h->out_item = 4;
+                        break;
+                    case 6:
+                        h->blk = make_cshort_to_gr_complex();
+                        h->in_item = 4;
+                        h->out_item = 8;
+                        break;
+                    case 7:
+                        h->blk = make_interleaved_byte_to_complex_byte();
+                        h->in_item = 1;
+                        h->out_item = 2;
+                        break;
+                    case 8:
+                        h->blk = make_interleaved_byte_to_complex_short();
+                        h->in_item = 1;
+                        h->out_item = 4;
+                        break;
+                    case 9:
+                        h->blk = make_interleaved_short_to_complex_short();
+                        h->in_item = 2;
+                        h->out_item = 4;
+                        break;
+                    default:
+                        return nullptr;
+                    }
+                return h.release();
+            }
+        catch (const std::exception& e)
+            {
+                std::cerr << "refconv_create: " << e.what() << '\n';
+                return nullptr;
+            }
+    }
+
+    void refconv_destroy(void* hv) { delete static_cast<ConvHandle*>(hv); }
+    int refconv_item_sizes(void* hv, int* in_item, int* out_item)
+    {
+        auto* h = static_cast<ConvHandle*>(hv);
+        *in_item = h->in_item;
+        *out_item = h->out_item;
+        return 0;
+    }
+
+    /* the block's forecast for noutput_items outputs (what the scheduler would make available before calling) */
+    int refconv_forecast(void* hv, int noutput_items)
+    {
+        auto* h = static_cast<ConvHandle*>(hv);
+        gr_vector_int req{0};
+        h->blk->forecast(noutput_items, req);
+        return req[0];
+    }
+
+    /* one scheduler call over n_items input items; returns items produced, *consumed = what the block passed to consume_each; the stream positions advance */
+    int refconv_general_work(void* hv, const void* in, int n_items, int noutput_items, void* out, int* consumed)
+    {
+        auto* h = static_cast<ConvHandle*>(hv);
+        gr_vector_int ninput{n_items};
+        gr_vector_const_void_star iv{in};
+        gr_vector_void_star ov{out};
+        h->blk->consumed_last = 0;
+        const int r = h->blk->general_work(noutput_items, ninput, iv, ov);
+        *consumed = h->blk->consumed_last;
+        h->blk->mock_advance(r);
+        return r;
     }
 }

@@ -171,6 +171,12 @@ public:
             if (pmt::eqv(t.key, key)) k.push_back(t);
         v.swap(k);
     }
+    // relative to the read pointer of the call (GNU Radio: get_tags_in_window)
+    void get_tags_in_window(std::vector<tag_t>& v, unsigned which, uint64_t rel_start, uint64_t rel_end, const pmt::pmt_t& key)
+    {
+        get_tags_in_range(v, which, d_nitems_read + rel_start, d_nitems_read + rel_end, key);
+    }
+    void add_item_tag(unsigned, const tag_t& t) { output_tags.push_back(t); }
     void add_item_tag(unsigned, uint64_t offset, const pmt::pmt_t& key, const pmt::pmt_t& value, const pmt::pmt_t& srcid = pmt::pmt_t())
     {
         tag_t t;
