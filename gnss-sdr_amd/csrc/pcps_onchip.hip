@@ -548,9 +548,14 @@ __global__ __launch_bounds__(64) void oc_rows_kernel(OcCellArgs a, int n_waves, 
 // GRID: the magnitude grid is read (accumulate) and / or written (store_grid); SECOND: the peak-ratio statistic's
 // second peak is wanted.  Both are compile-time so that the headline configuration (CFAR statistic, single dwell,
 // no dump) carries neither the grid addressing nor the second scan in its register budget.
-template <class P, int S, bool GRID, bool SECOND, bool OFF>
+// DIT (round 6): the sub-cells of a decimation-in-time split (see oc_combine_dit_kernel below) as a flavour of THIS kernel -- sub-cell r of cell (prn, bin) is a plain
+// M-point cell over residue class r of both spectra that stores its transform Z_r instead of searching it -- so that they get the pass loop, the idle waves' operand
+// prefetch and the touch of the next bin spectrum instead of one freshly dispatched work-group per sub-cell (128 000 points: 603 us of a batch's 926 were sub-cells).
+template <class P, int S, bool GRID, bool SECOND, bool OFF, bool DIT = false>
 __global__ __launch_bounds__(P::THREADS) void oc_cell_kernel(OcCellArgs a)
 {
+    static_assert(!DIT || (S > 1 && !GRID && !SECOND && !OFF), "a decimation-in-time sub-cell only transforms");
+    constexpr bool PLAIN = (S == 1) || DIT;  // the operands are one M-point slice of each spectrum, multiplied element by element
     static_assert(S == 1 || !SECOND, "the second peak of a row needs the whole row in one work-group");
     static_assert(!SECOND || P::N * 4 <= P::LDS_BYTES, "the peak-ratio flavour parks the row's N magnitudes in the exchange buffer: a plan whose buffer is smaller needs another place for them");
     static_assert(GRID || !OFF, "the upper-half searches are instantiated on the GRID flavour only");
@@ -583,7 +588,7 @@ __global__ __launch_bounds__(P::THREADS) void oc_cell_kernel(OcCellArgs a)
     // with the array carried for every wave did not fit: the registers of a value that is written on one side of a branch and read a pass later are not given to
     // the other side's stage 3.)  Both copies meet the same barriers, pass for pass.
     constexpr int OPF_FIRST = (P::T3 + 63) / 64 * 64;  // first thread of the first wholly idle wave
-    constexpr bool OPF = PERSIST && !GRID && S == 1 && OPF_FIRST + 64 <= P::THREADS;
+    constexpr bool OPF = PERSIST && !GRID && PLAIN && OPF_FIRST + 64 <= P::THREADS;
     auto pass_loop = [&](auto IDLE_TAG) GSH_AI {
     constexpr bool IDLE = decltype(IDLE_TAG)::value;
     [[maybe_unused]] cf pa[IDLE ? P::R1 : 1];
@@ -626,10 +631,10 @@ __global__ __launch_bounds__(P::THREADS) void oc_cell_kernel(OcCellArgs a)
 #ifdef GSH_OC_PROFILE_SAME_BIN  /* (timing experiment only: every cell reads the spectrum of bin 0 / bin & 7 -- the results are wrong, the loads hit L2) */
             const cf* __restrict__ X = a.spectra + static_cast<size_t>(bin & (GSH_OC_PROFILE_SAME_BIN)) * N + t;
 #else
-            const cf* __restrict__ X = a.spectra + static_cast<size_t>(bin) * N + t;
+            const cf* __restrict__ X = a.spectra + static_cast<size_t>(bin) * N + (DIT ? static_cast<size_t>(r) * M : 0) + t;
 #endif
-            const cf* __restrict__ C = a.codes + static_cast<size_t>(prn) * N + t;
-            if constexpr (S == 1)
+            const cf* __restrict__ C = a.codes + static_cast<size_t>(prn) * N + (DIT ? static_cast<size_t>(r) * M : 0) + t;
+            if constexpr (PLAIN)
                 {
                     // all 2 * R1 operand loads are issued before the first product: the cell's registers are still free here, and one round of
                     // L2 / Infinity-Cache latency is cheaper than the two the scheduler otherwise settles for (12 loads, wait, 38 loads)
@@ -726,21 +731,25 @@ __global__ __launch_bounds__(P::THREADS) void oc_cell_kernel(OcCellArgs a)
     // The threads that have no stage-3 butterfly (radix 40: 375 of them) touch the bin spectrum of the work-group's NEXT cell, one word per 64 bytes: an XCD's
     // 4 MB of L2 hold a round's 8 bin spectra and 4 code spectra, not the search's 41 -- every new bin comes over the fabric (2.4 of the operand phase's 7.4 us,
     // measured by letting every cell read bin 0: profiles/oc_cell_annotated.txt), and here it comes while the other threads transform.
-    constexpr bool TOUCH = PERSIST && !GRID && S == 1 && P::T3 + 64 <= P::THREADS;
+#ifndef GSH_OC_DIT_TOUCH
+#define GSH_OC_DIT_TOUCH 0  // (A/B) the touch on decimation-in-time sub-cells: the whole next bin spectrum is five times what the next sub-cell reads
+#endif
+    constexpr bool TOUCH = PERSIST && !GRID && PLAIN && (!DIT || GSH_OC_DIT_TOUCH) && P::T3 + 64 <= P::THREADS;
     const int nslot_r = slot_r + static_cast<int>(gridDim.x >> 3);
-    const bool next_pass = TOUCH && pass + 1 < passes && nslot_r < a.slots_per_xcd;  // uniform over the work-group
+    const bool next_pass = (TOUCH || OPF) && pass + 1 < passes && nslot_r < a.slots_per_xcd;  // uniform over the work-group
     if constexpr (IDLE)
         {
             // this wave's own operands of the next cell (every lane loads and multiplies -- the lanes past T1, which have no stage-1 butterfly, the last butterfly's
             // operands over again)
-            const int nbl = nslot_r / a.prn_per, npl = nslot_r - nbl * a.prn_per;
+            const int nslot = nslot_r / S, nr = nslot_r - nslot * S;
+            const int nbl = nslot / a.prn_per, npl = nslot - nbl * a.prn_per;
             const int nprn = xp_i * a.prn_per + npl, nbin_own = xb_i * a.bin_per + nbl;
             have_operands = next_pass && a.prefetch_next >= 2 && nprn < a.n_prn && nbin_own < a.n_bins;
             if (have_operands)
                 {
                     const int tt = t < P::T1 ? t : P::T1 - 1;
-                    const cf* __restrict__ X = a.spectra + static_cast<size_t>(nbin_own) * N + tt;
-                    const cf* __restrict__ C = a.codes + static_cast<size_t>(nprn) * N + tt;
+                    const cf* __restrict__ X = a.spectra + static_cast<size_t>(nbin_own) * N + (DIT ? static_cast<size_t>(nr) * M : 0) + tt;
+                    const cf* __restrict__ C = a.codes + static_cast<size_t>(nprn) * N + (DIT ? static_cast<size_t>(nr) * M : 0) + tt;
                     cf xv[P::R1], cv[P::R1];
                     oc::static_for<P::R1>([&](auto N1) GSH_AI {
                         constexpr int n1 = decltype(N1)::value;
@@ -776,6 +785,19 @@ __global__ __launch_bounds__(P::THREADS) void oc_cell_kernel(OcCellArgs a)
                         asm volatile("" ::"v"(acc));  // (the loads are real: their data is waited for, by threads that have nothing else to do)
                     }
             }
+    if constexpr (DIT)
+        {
+            // the sub-cell's whole result: Z_r, for oc_combine_dit_kernel (queued behind this launch)
+            if (!IDLE && t < P::T3)
+                {
+                    P::stage3(rc);
+                    cf* __restrict__ zo = a.z + static_cast<size_t>(cell) * N + static_cast<size_t>(r) * M + t;
+                    oc::static_for<P::R3>([&](auto K3) GSH_AI { zo[decltype(K3)::value * P::T3] = rc[decltype(K3)::value]; });
+                }
+            OC_STAMP(7);
+            OC_STAMP_WALL(9);
+            continue;
+        }
     if (!IDLE && t < P::T3)
         {
             P::stage3(rc);
@@ -986,6 +1008,14 @@ __global__ __launch_bounds__(P::THREADS) void oc_subcell_dit_kernel(OcCellArgs a
 }
 
 constexpr int OC_COMBINE_THREADS = 1024;
+#ifndef GSH_OC_COMBINE_PAIRS
+#define GSH_OC_COMBINE_PAIRS 1  // 0: one lag class per thread and trip, 8-byte loads, nothing in flight across trips (the round-3 form: A/B builds)
+#endif
+// Round 6: the combine step was bound by LATENCY, not by bandwidth (346 us of a 128 000-point batch's 926: 1.34 GB of Z at 3.9 TB/s, the device streams 6.1): a
+// thread's trip was S 8-byte loads, a wait for all of them, and the arithmetic -- 25 dependent round trips to HBM per work-group.  Now a thread owns the PAIR of lags
+// (2 i, 2 i + 1) of every residue class per trip (16-byte loads: a wave reads 1 KiB per instruction) and the next trip's S loads are issued BEFORE the current
+// trip's arithmetic (a two-deep register queue), so a compute unit always has loads in flight.  The twiddles of the pair's second lag are the first's times the
+// constant W_N^r; the trackers still meet the lags of one j in ascending order (lowest index wins ties).
 template <int M, int S, bool GRID, bool OFF>
 __global__ __launch_bounds__(OC_COMBINE_THREADS) void oc_combine_dit_kernel(OcCellArgs a)
 {
@@ -1003,19 +1033,83 @@ __global__ __launch_bounds__(OC_COMBINE_THREADS) void oc_combine_dit_kernel(OcCe
         const cf* __restrict__ zc = a.z + static_cast<size_t>(cell) * N;
         float* __restrict__ g = a.grid + static_cast<size_t>(cell) * a.effective;
         const int offset = OFF ? a.offset : 0;
+        // one (maximum, index) tracker per j: a thread meets the lags of one j in ascending order, so a strict '>' keeps the lowest index
+        float bj[S];
+        unsigned aj[S];
+        oc::static_for<S>([&](auto J) GSH_AI {
+            bj[decltype(J)::value] = -1.0f;
+            aj[decltype(J)::value] = 0xFFFFFFFFu;
+        });
+        // the S-point DFT of one lag class m (u[r] = Z_r[m] already times W_N^{r m}): |.|^2 of the lags m + M j into the grid, the sum and the trackers
+        auto lags_of = [&](cf (&u)[S], int m) GSH_AI {
+            oc::Dft<S>::run(u);  // u[j] = y[m + M j]
+            oc::static_for<S>([&](auto J) GSH_AI {
+                constexpr int j = decltype(J)::value;
+                const int idx = m + M * j - offset;  // the lag's index in the search (acq.cc:544)
+                float v = oc::norm2(u[j]);
+                const bool in = !OFF || idx >= 0;
+                if constexpr (GRID)
+                    {
+                        v *= a.weight;
+                        if (a.accumulate && in) v += g[idx];  // acq.cc:549-553
+                        if (a.store_grid && in) g[idx] = v;
+                    }
+                if constexpr (OFF) v = in ? v : -1.0f;  // never better than a tracker's start value
+                sum += (OFF && !in) ? 0.0f : v;
+                const bool better = v > bj[j];
+                bj[j] = better ? v : bj[j];
+                aj[j] = better ? static_cast<unsigned>(idx) : aj[j];
+            });
+        };
+#if GSH_OC_COMBINE_PAIRS
+        static_assert(M % 2 == 0, "pairs of lag classes");
+        constexpr int PAIRS = M / 2, STRIDE = OC_COMBINE_THREADS;
+        // twiddles W_N^{r m} at m = 2 t (exact seeds), the pair's second lag is one W_N^r further, a trip 2 THREADS lags further (at most M / 2 / THREADS steps: 13)
+        cf tw[S], one[S], step[S];
+        oc::static_for<S>([&](auto R) GSH_AI {
+            constexpr int rr = decltype(R)::value;
+            tw[rr] = oc::unit_root(static_cast<int>((static_cast<long long>(rr) * 2 * t) % N), N);
+            one[rr] = oc::unit_root(rr % N, N);
+            step[rr] = oc::unit_root(static_cast<int>((static_cast<long long>(rr) * 2 * STRIDE) % N), N);
+        });
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        f4 q[S];
+        auto load = [&](int i) GSH_AI {
+            oc::static_for<S>([&](auto R) GSH_AI {
+                q[decltype(R)::value] = *reinterpret_cast<const f4*>(zc + static_cast<size_t>(decltype(R)::value) * M + 2 * i);
+            });
+        };
+        int i = t;
+        if (i < PAIRS) load(i);
+#pragma clang loop unroll(disable)
+        for (; i < PAIRS; i += STRIDE)
+            {
+                cf u0[S], u1[S];
+                oc::static_for<S>([&](auto R) GSH_AI {
+                    constexpr int rr = decltype(R)::value;
+                    u0[rr] = cf{q[rr][0], q[rr][1]};
+                    u1[rr] = cf{q[rr][2], q[rr][3]};
+                });
+                if (i + STRIDE < PAIRS) load(i + STRIDE);  // the next trip's loads fly during this trip's arithmetic
+                oc::static_for<S>([&](auto R) GSH_AI {
+                    constexpr int rr = decltype(R)::value;
+                    if constexpr (rr > 0)
+                        {
+                            u0[rr] = oc::cmul(u0[rr], tw[rr]);                       // Z_r[m] W_N^{r m}
+                            u1[rr] = oc::cmul(u1[rr], oc::cmul(tw[rr], one[rr]));     // Z_r[m + 1] W_N^{r (m + 1)}
+                            tw[rr] = oc::cmul(tw[rr], step[rr]);
+                        }
+                });
+                lags_of(u0, 2 * i);
+                lags_of(u1, 2 * i + 1);
+            }
+#else
         // twiddles W_N^{r m}, r = 1 .. S-1, for m = t, t + THREADS, ...: exact seeds, then one complex product per step (at most M / THREADS steps: 25)
         cf tw[S], step[S];
         oc::static_for<S>([&](auto R) GSH_AI {
             constexpr int rr = decltype(R)::value;
             tw[rr] = oc::unit_root(static_cast<int>((static_cast<long long>(rr) * t) % N), N);
             step[rr] = oc::unit_root(static_cast<int>((static_cast<long long>(rr) * OC_COMBINE_THREADS) % N), N);
-        });
-        // one (maximum, index) tracker per j: a thread meets the lags t + M j + THREADS i of one j in ascending order, so a strict '>' keeps the lowest index
-        float bj[S];
-        unsigned aj[S];
-        oc::static_for<S>([&](auto J) GSH_AI {
-            bj[decltype(J)::value] = -1.0f;
-            aj[decltype(J)::value] = 0xFFFFFFFFu;
         });
 #pragma clang loop unroll(disable)
         for (int m = t; m < M; m += OC_COMBINE_THREADS)
@@ -1030,25 +1124,9 @@ __global__ __launch_bounds__(OC_COMBINE_THREADS) void oc_combine_dit_kernel(OcCe
                             tw[rr] = oc::cmul(tw[rr], step[rr]);
                         }
                 });
-                oc::Dft<S>::run(u);  // u[j] = y[m + M j]
-                oc::static_for<S>([&](auto J) GSH_AI {
-                    constexpr int j = decltype(J)::value;
-                    const int idx = m + M * j - offset;  // the lag's index in the search (acq.cc:544)
-                    float v = oc::norm2(u[j]);
-                    const bool in = !OFF || idx >= 0;
-                    if constexpr (GRID)
-                        {
-                            v *= a.weight;
-                            if (a.accumulate && in) v += g[idx];  // acq.cc:549-553
-                            if (a.store_grid && in) g[idx] = v;
-                        }
-                    if constexpr (OFF) v = in ? v : -1.0f;  // never better than a tracker's start value
-                    sum += (OFF && !in) ? 0.0f : v;
-                    const bool better = v > bj[j];
-                    bj[j] = better ? v : bj[j];
-                    aj[j] = better ? static_cast<unsigned>(idx) : aj[j];
-                });
+                lags_of(u, m);
             }
+#endif
         oc::static_for<S>([&](auto J) GSH_AI { argmax_merge(best, at, bj[decltype(J)::value], aj[decltype(J)::value]); });
     }
 #pragma unroll
@@ -1224,7 +1302,24 @@ int launch_cells_dit(const OcCellArgs& a, int n_blocks, hipStream_t s)
     const bool off = a.offset != 0;
     GSH_REQUIRE(!a.want_second || (a.store_grid && a.grid != nullptr), "the peak-ratio statistic on a split plan scans the stored winning row: it needs the grid");
     GSH_REQUIRE(a.z != nullptr, "decimation-in-time split without its scratch");
-    hipLaunchKernelGGL((oc_subcell_dit_kernel<P, S>), dim3(n_blocks), dim3(P::THREADS), 0, s, a);
+    {
+        // the sub-cells: persistent work-groups walking their XCD's slots in passes where the plan has its compute unit to itself (launch_cells has the reasoning);
+        // GSH_OC_DIT_PERSIST=0: one freshly dispatched work-group per sub-cell, as until round 5 (A/B)
+        static const int persist = [] { const char* e = std::getenv("GSH_OC_DIT_PERSIST"); return e != nullptr ? std::atoi(e) : 0; }();
+        if (P::EX64 && persist)
+            {
+                static const int wg_per_xcd = [] { const char* e = std::getenv("GSH_OC_WG_PER_XCD"); return e != nullptr ? std::max(1, std::atoi(e)) : 28; }();
+                OcCellArgs b = a;
+                b.slots_per_xcd = a.prn_per * a.bin_per * S;
+                b.cells_per_wg = std::min(onchip_cells_per_wg(), std::max(1, b.slots_per_xcd));
+                int per_xcd = (b.slots_per_xcd + b.cells_per_wg - 1) / b.cells_per_wg;
+                per_xcd = std::max(per_xcd, std::min(wg_per_xcd, b.slots_per_xcd));
+                b.cells_per_wg = (b.slots_per_xcd + per_xcd - 1) / per_xcd;
+                hipLaunchKernelGGL((oc_cell_kernel<P, S, false, false, false, true>), dim3(8 * per_xcd), dim3(P::THREADS), 0, s, b);
+            }
+        else
+            hipLaunchKernelGGL((oc_subcell_dit_kernel<P, S>), dim3(n_blocks), dim3(P::THREADS), 0, s, a);
+    }
     GSH_HIP(hipGetLastError());
     const dim3 cells(static_cast<unsigned>(a.n_prn * a.n_bins)), threads(OC_COMBINE_THREADS);
     if (off)
