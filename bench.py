@@ -757,7 +757,7 @@ def bench_summary(res):
 def load_pmc():
     """profiles/pmc_r02.json: per-launch counter averages of the dominant kernels under this very command (profiles/run_profiles_r02.sh +
     profiles/summarize_r02.py; rocprofv3 --pmc passes, kernel-trace only).  None when absent."""
-    for name in ("pmc_r05.json", "pmc_r04.json", "pmc_r03.json", "pmc_r02.json"):
+    for name in ("pmc_r06.json", "pmc_r05.json", "pmc_r04.json", "pmc_r03.json", "pmc_r02.json"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", name)))
             d["file"] = "profiles/" + name

@@ -80,6 +80,8 @@ def main():
     for label, sub, extra in (("mcorr", "mcorr_kernel<3, 0, false", {}), ("oc_cell", "oc_cell_kernel", {}), ("oc_forward", "oc_forward_kernel", {}),
                               ("trk_loop", "trk_loop_kernel<3, false, false>", {}), ("oc_subcell_dit", "oc_subcell_dit_kernel", {}), ("oc_combine_dit", "oc_combine_dit_kernel", {})):
         rec = {}
+        if label == "mcorr" and find(stats, "mcorr_kernel_t128<3, 0, false"):
+            sub = "mcorr_kernel_t128<3, 0, false"   # round 6: launches of >= 5 120 E/P/L jobs run the two-wave kernels (csrc/multicorrelator_t128.hip)
         for leg in legs.values():
             kk = find(leg, sub)
             if kk:
