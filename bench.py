@@ -260,6 +260,8 @@ def acquisition_metric(torch, dev_index, x_block, fs, pmc=None):
     m = (pmc or {}).get("acquisition")
     if m and m.get("n") == n and m.get("n_prn") == 32 and m.get("n_bins") == 41:
         roof["traffic"] = m.get("hbm_bytes_per_batch")
+        roof["traffic_source"] = "static:" + str((pmc or {}).get("file")) + " (the builder's profiling run of this command)"
+        roof["traffic_is"] = "memory-fabric bytes (FETCH_SIZE / WRITE_SIZE count Infinity Cache hits as well as HBM accesses): an upper bound of the HBM traffic"
         roof["pmc"] = {k: v for k, v in m.items() if k not in ("n", "n_prn", "n_bins")}
     res = {"metric": "acquisition dwells/s", "value": 32.0 / (ms * 1e-3), "unit": "dwells/s", "ms_per_batch": ms,
            "value_is": "PIPELINED: batches alternate on two streams, two in flight (throughput); value_single_stream is one batch after the other on one stream",

@@ -1193,25 +1193,29 @@ extern "C"
         }
         while (a->n_lanes < want_lanes)
             {
+                // (every resource only where the slot does not hold one yet: a call that failed part-way -- an allocation refused -- left what it had got in the slot, and
+                //  the next call must finish that lane, not overwrite its pointers; the handle's destructor frees whatever a slot holds.  Round-5 review.)
                 gsh_acq::Lane& ln = a->lane[a->n_lanes];
-                {
-                    std::vector<hipStream_t> others;
-                    for (int l = 1; l < a->n_lanes; l++) others.push_back(a->lane[l].stream);
-                    const int rc2 = make_concurrent_stream(a->stream, others, &ln.stream);  // a stream on another hardware queue than the lanes so far
-                    if (rc2 != GSH_OK) return rc2;
-                }
-                GSH_HIP(hipMalloc(&ln.d_spectra, sizeof(float2) * D * n));
-                GSH_HIP(hipMalloc(&ln.d_rows, sizeof(gsh::RowStat) * P * D));
-                if (a->split > 0) GSH_HIP(hipMalloc(&ln.d_subrows, sizeof(gsh::RowStat) * P * D * a->split));
-                GSH_HIP(hipMalloc(&ln.d_waverows, sizeof(gsh::RowStat) * P * D * static_cast<size_t>(std::max(a->split, 1)) * gsh::ONCHIP_MAX_WAVES));
-                if (a->d_z != nullptr)
+                if (ln.stream == nullptr)
+                    {
+                        std::vector<hipStream_t> others;
+                        for (int l = 1; l < a->n_lanes; l++) others.push_back(a->lane[l].stream);
+                        const int rc2 = make_concurrent_stream(a->stream, others, &ln.stream);  // a stream on another hardware queue than the lanes so far
+                        if (rc2 != GSH_OK) return rc2;
+                    }
+                if (ln.d_spectra == nullptr) GSH_HIP(hipMalloc(&ln.d_spectra, sizeof(float2) * D * n));
+                if (ln.d_rows == nullptr) GSH_HIP(hipMalloc(&ln.d_rows, sizeof(gsh::RowStat) * P * D));
+                if (a->split > 0 && ln.d_subrows == nullptr) GSH_HIP(hipMalloc(&ln.d_subrows, sizeof(gsh::RowStat) * P * D * a->split));
+                if (ln.d_waverows == nullptr)
+                    GSH_HIP(hipMalloc(&ln.d_waverows, sizeof(gsh::RowStat) * P * D * static_cast<size_t>(std::max(a->split, 1)) * gsh::ONCHIP_MAX_WAVES));
+                if (a->d_z != nullptr && ln.d_z == nullptr)
                     {
                         GSH_HIP(hipMalloc(&ln.d_z, sizeof(float2) * P * D * n));
                     }
-                GSH_HIP(hipMalloc(&ln.d_results, sizeof(gsh::DevAcqResult) * P));
-                GSH_HIP(hipMalloc(&ln.d_arrivals, sizeof(unsigned) * P));
+                if (ln.d_results == nullptr) GSH_HIP(hipMalloc(&ln.d_results, sizeof(gsh::DevAcqResult) * P));
+                if (ln.d_arrivals == nullptr) GSH_HIP(hipMalloc(&ln.d_arrivals, sizeof(unsigned) * P));
                 GSH_HIP(hipMemset(ln.d_arrivals, 0, sizeof(unsigned) * P));
-                GSH_HIP(hipEventCreate(&ln.ev));
+                if (ln.ev == nullptr) GSH_HIP(hipEventCreate(&ln.ev));
                 a->n_lanes++;
             }
         const int lanes = want_lanes;

@@ -186,6 +186,12 @@ __device__ __forceinline__ void lane_waits(int& word, int value)
 #endif
 constexpr int SERIAL_WAVES = GSH_TRK_SERIAL_WAVES;  // wave 0 carrier loop, wave 1 code loop, wave 2 C/N0 estimator, wave 3 carrier lock test + the record's early fields
 constexpr int CN0_WAVE = 2, CARR_LOCK_WAVE = SERIAL_WAVES - 1;  // (three serial waves: both halves on wave 2, one after the other)
+// the seed tables are filled by waves SERIAL_WAVES + 1 and SERIAL_WAVES + 2, one entry per lane (16 W entries: work-groups of up to 1 024 threads): a build with
+// fewer waves would read tables nobody fills (round-5 review)
+#if defined(GSH_TRK_SEED_TABLES) && !GSH_TRK_SEED_TABLES
+#else
+static_assert(GSH_MC_THREADS / 64 >= GSH_TRK_SERIAL_WAVES + 3 && GSH_MC_THREADS <= 1024, "the closed-loop kernel's seed tables need waves SERIAL_WAVES + 1 and + 2, and cover 16 waves");
+#endif
 
 // ---- live mode (gsh_trk_live_*): the kernel stays resident and follows the ring as it fills ------------------------------------------------------
 // A launch per batch of periods costs the host ~270 us of queueing and waiting around ~180 us of kernel (round 3) -- at the reference's cadence

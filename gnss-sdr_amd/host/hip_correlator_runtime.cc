@@ -8,6 +8,21 @@
 #include <cstring>
 #include <thread>
 
+namespace
+{
+// A timed wait on the STEADY clock (a wall-clock step from NTP or a manual set must not stretch or cut the 200 ms gap timeout); gcc 11's ThreadSanitizer does not
+// understand pthread_cond_clockwait, which the steady-clock wait_for compiles to, so builds under TSAN take the system clock (round-5 review)
+template <class Lock, class Rep, class Period, class Pred>
+bool wait_with_timeout(std::condition_variable& cv, Lock& lk, const std::chrono::duration<Rep, Period>& timeout, Pred pred)
+{
+#if defined(__SANITIZE_THREAD__)
+    return cv.wait_until(lk, std::chrono::system_clock::now() + timeout, pred);
+#else
+    return cv.wait_for(lk, timeout, pred);
+#endif
+}
+}  // namespace
+
 // ------------------------------------------------------------------------------------------------ Hip_Sample_Ring
 Hip_Sample_Ring::Hip_Sample_Ring(int device, uint64_t capacity_samples, uint32_t max_window_samples)
     : d_device(device), d_capacity(capacity_samples), d_max_window(max_window_samples)
@@ -200,7 +215,11 @@ bool Hip_Sample_Ring::push_from(uint64_t first_index, const std::complex<float>*
                 if (next == oldest || may_seek)
                     {
                         // an empty ring starts wherever its first user is; a ring nobody reads any more follows the caller
-                        if (seek_locked(first_index) != GSH_OK)
+                        const int rc_seek = seek_locked(first_index);
+                        if (rc_seek == GSH_ERR_STATE && may_seek && next != oldest)
+                            return true;  // a live tail is still winding down on the device (gsh_stream_seek refuses while one is active: the host's flags were cleared by a
+                                          // watchdog or a failed take before the device's): not a ring error -- the block is offered its samples again (round-5 review)
+                        if (rc_seek != GSH_OK)
                             {
                                 set_error(gsh_last_error());
                                 return false;
@@ -213,7 +232,7 @@ bool Hip_Sample_Ring::push_from(uint64_t first_index, const std::complex<float>*
                         // the samples in between are in the input buffers of slower siblings: they push them when they get there
                         if (gap_timeout.count() <= 0) return true;  // a caller that does not need them resident itself (a block in standby) leaves it at that
                         // (wait_until on the system clock = pthread_cond_timedwait; wait_for is pthread_cond_clockwait, which gcc 11's ThreadSanitizer does not know releases the mutex)
-                        const bool closed = d_pushed.wait_until(lk, std::chrono::system_clock::now() + gap_timeout, [&] { return d_next.load(std::memory_order_acquire) >= first_index; });
+                        const bool closed = wait_with_timeout(d_pushed, lk, gap_timeout, [&] { return d_next.load(std::memory_order_acquire) >= first_index; });
                         if (!closed)
                             {
                                 set_error("push_from: samples " + std::to_string(first_index) + ".. leave a gap after the ring's " + std::to_string(next) +
@@ -397,7 +416,7 @@ bool Hip_Sample_Ring::wait_for(uint64_t end, std::chrono::milliseconds timeout) 
 {
     if (d_next.load(std::memory_order_acquire) >= end) return true;  // the usual case: no lock, no convoy behind a running launch
     std::unique_lock<std::mutex> lk(d_mutex);
-    return d_pushed.wait_until(lk, std::chrono::system_clock::now() + timeout, [&] { return d_next.load(std::memory_order_acquire) >= end; });
+    return wait_with_timeout(d_pushed, lk, timeout, [&] { return d_next.load(std::memory_order_acquire) >= end; });
 }
 
 

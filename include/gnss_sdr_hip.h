@@ -165,6 +165,9 @@ extern "C"
         GSH_ITEM_BYTE = 2        /* interleaved int8 I,Q (item_type ibyte / cbyte), 2 bytes per sample */
     };
     int gsh_stream_create(int device, uint64_t capacity_samples, uint32_t max_window_samples, gsh_stream_t** out);
+    /* Destroying a ring that tracking handles are bound to (gsh_trk_set_stream_ring) tells those handles -- a live residency on it is wound down first, then the
+     * memory goes -- but it is NOT synchronised against other threads' calls on those handles or against their destruction: the caller keeps gsh_stream_destroy
+     * from racing with gsh_trk_* calls on handles bound to the ring (Hip_Tracking_Runtime does, under its handle mutex). */
     void gsh_stream_destroy(gsh_stream_t* s);
     /* append n samples held in host memory; *first_index (may be NULL) receives the absolute index of items[0].
      * Synchronous: the samples are resident (and any older ones they displace are gone) on return. */
