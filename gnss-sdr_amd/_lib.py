@@ -196,6 +196,7 @@ SYMBOLS = {
     "gsh_trk_pull_in": (C.c_int, [C.POINTER(TrkConf), C.c_uint64, C.c_double, C.c_uint64, C.c_double, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
     "gsh_trk_stop": (C.c_int, [_P, C.c_int]),
     "gsh_trk_run": (C.c_int, [_P, C.c_int, C.POINTER(TrkEpoch), C.POINTER(C.c_int32)]),
+    "gsh_trk_set_split": (C.c_int, [_P, C.c_int]),
     "gsh_trk_run_begin": (C.c_int, [_P, C.c_int, C.c_int]),
     "gsh_trk_run_end": (C.c_int, [_P, C.POINTER(TrkEpoch), C.POINTER(C.c_int32)]),
     "gsh_trk_positions": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]),

@@ -261,7 +261,7 @@ constexpr int SEED_INC = 82;  // exp(-j step), exp(-j 2 PPC step), exp(-j 4 PPC 
 constexpr int SEED_ENTRIES = 88;
 // one entry per lane of two waves (which = 0: the lane factors; 1: the wave factors, the two window parities, the three wave-uniform rotations).
 // The arguments are formed as run_segment_packed forms them (double products of the float step), each evaluated once (expmj: <= 2e-7 rad).
-__device__ __forceinline__ void seed_table_fill(float2* __restrict__ tab, float step, float rem, int lane, int which)
+__device__ __forceinline__ void seed_table_fill(float2* __restrict__ tab, float step, double rem, int lane, int which)
 {
     asm volatile("" : "+v"(lane));  // (addresses formed here, not hoisted out of the caller's loop)
     const double sd = static_cast<double>(step);
@@ -278,7 +278,7 @@ __device__ __forceinline__ void seed_table_fill(float2* __restrict__ tab, float 
                 }
             else if (lane < 18)
                 {
-                    ph = static_cast<double>(rem) + static_cast<double>(-(lane - 16)) * sd;
+                    ph = rem + static_cast<double>(-(lane - 16)) * sd;
                     at = SEED_A + (lane - 16);
                 }
             else
@@ -288,6 +288,11 @@ __device__ __forceinline__ void seed_table_fill(float2* __restrict__ tab, float 
                 }
             tab[at] = expmj(ph);
         }
+}
+// (the window's carrier phase remainder as the loop publishes it; a SEGMENT of a window that starts n_begin samples in passes rem + n_begin * step, formed in double)
+__device__ __forceinline__ void seed_table_fill(float2* __restrict__ tab, float step, float rem, int lane, int which)
+{
+    seed_table_fill(tab, step, static_cast<double>(rem), lane, which);
 }
 
 // One chunk = 256 pairs = 512 consecutive samples; thread `tid` owns samples n0, n0+1.
@@ -717,7 +722,7 @@ __device__ __forceinline__ void run_segment_packed(const JobCtx& c, const float2
             const float2* __restrict__ S = c.seed_tab;
             tb_b = S[SEED_B + (tl & 63)];
             tb_wv = S[SEED_W + (tl >> 6)];
-            tb_a0 = S[SEED_A - c.n_first];
+            tb_a0 = S[SEED_A + (c.n_begin - c.n_first)];  // (0 / 1: whether the pair of the segment's first sample starts one sample before it)
             tb_inc = S[SEED_INC];
             tb_w = S[SEED_INC + 1];
             tb_w2 = S[SEED_INC + (NCH == 2 ? 2 : 1)];
@@ -1485,8 +1490,12 @@ struct NoHook
 template <int NT, int MODE, bool AUX = false, bool PAIRK = false, bool SUM = true, typename Hook = NoHook>
 __device__ __forceinline__ void correlate_window(const float2* __restrict__ stream, unsigned long long sample_offset, int n_samples,
     const float* __restrict__ tab, int code_len, const float (&sh)[NT], float rem_carr, float phase_step, float phase_rate, float rem_code,
-    float code_step, float code_rate, float2* __restrict__ red, const float* tab_aux = nullptr, float aux_shift = 0.0f, Hook hook = Hook(), const float2* seed_tab = nullptr)
+    float code_step, float code_rate, float2* __restrict__ red, const float* tab_aux = nullptr, float aux_shift = 0.0f, Hook hook = Hook(), const float2* seed_tab = nullptr,
+    int seg_begin = 0, int seg_end = -1)
 {
+    // seg_begin / seg_end (round 6): correlate only the samples [seg_begin, seg_end) of the window -- one of several work-groups that share a window
+    // (tracking_loop.hip, cooperating work-groups); the sample indices the chip look-ups and the phasors use stay those of the whole window.  A seed table handed
+    // in must then have been formed for rem_carr + seg_begin * phase_step.
     static_assert(!AUX || (MODE == 0 && NT < GSH_MAX_TAPS), "the fused tap exists for the standard mode and needs a free slot in `red`");
     const int tid = threadIdx.x;
     GSH_CW_STAMP(0);
@@ -1499,12 +1508,14 @@ __device__ __forceinline__ void correlate_window(const float2* __restrict__ stre
     c.rem_code = rem_code;
     c.code_step = code_step;
     c.code_rate = code_rate;
-    c.n_begin = 0;
-    c.n_end = n_samples;
-    const int odd = static_cast<int>(sample_offset & 1ULL);
-    c.n_first = -odd;
+    if (seg_end < 0) seg_end = n_samples;
+    c.n_begin = seg_begin;
+    c.n_end = seg_end;
+    const unsigned long long seg_offset = sample_offset + static_cast<unsigned long long>(seg_begin);
+    const int odd = static_cast<int>(seg_offset & 1ULL);
+    c.n_first = seg_begin - odd;
     c.seed_tab = seed_tab;
-    const float2* __restrict__ base = stream + (sample_offset - static_cast<unsigned long long>(odd));
+    const float2* __restrict__ base = stream + (seg_offset - static_cast<unsigned long long>(odd));
     int rot[NT];
     rot[0] = 0;
     if (mode_hd_code(MODE))
@@ -1536,7 +1547,7 @@ __device__ __forceinline__ void correlate_window(const float2* __restrict__ stre
             c.aux_k_off = static_cast<int>(tab_aux - tab) + MC_MARGIN;
         }
     GSH_CW_STAMP(1);
-    if (n_samples > 0)
+    if (seg_end > seg_begin)
         {
             float smin = sh[0], smax = sh[0];
 #pragma unroll
@@ -1550,8 +1561,8 @@ __device__ __forceinline__ void correlate_window(const float2* __restrict__ stre
                     smin = fminf(smin, aux_shift);
                     smax = fmaxf(smax, aux_shift);
                 }
-            const int lo = raw_chip_std(__fmul_rn(code_step, 0.0f), smin, rem_code);
-            const int hi = raw_chip_std(__fmul_rn(code_step, static_cast<float>(n_samples - 1)), smax, rem_code);
+            const int lo = raw_chip_std(__fmul_rn(code_step, static_cast<float>(seg_begin)), smin, rem_code);
+            const int hi = raw_chip_std(__fmul_rn(code_step, static_cast<float>(seg_end - 1)), smax, rem_code);
             const bool fast = !mode_hd_code(MODE) && (code_step >= 0.0f) && (lo >= -MC_MARGIN) && (hi < code_len + MC_MARGIN) && (code_len >= MC_MARGIN);
             const bool zp = (NT & 1) && (sh[NT / 2] == 0.0f) && !mode_hd_code(MODE) && (n_samples < (1 << 24));
             if (fast && zp)
@@ -1686,18 +1697,20 @@ __device__ __forceinline__ void sum_wave_partials(const float2* __restrict__ red
 template <int NT, bool PAIRK = false, bool SUM = true, typename Hook = NoHook>
 __device__ __forceinline__ void correlate_window_std(const float2* __restrict__ stream, unsigned long long sample_offset, int n_samples,
     const float* __restrict__ tab, int code_len, const float (&sh)[NT], float rem_carr, float phase_step, float rem_code, float code_step,
-    float2* __restrict__ red, Hook hook = Hook(), const float2* seed_tab = nullptr)
+    float2* __restrict__ red, Hook hook = Hook(), const float2* seed_tab = nullptr, int seg_begin = 0, int seg_end = -1)
 {
-    correlate_window<NT, 0, false, PAIRK, SUM, Hook>(stream, sample_offset, n_samples, tab, code_len, sh, rem_carr, phase_step, 0.0f, rem_code, code_step, 0.0f, red, nullptr, 0.0f, hook, seed_tab);
+    correlate_window<NT, 0, false, PAIRK, SUM, Hook>(stream, sample_offset, n_samples, tab, code_len, sh, rem_carr, phase_step, 0.0f, rem_code, code_step, 0.0f, red, nullptr, 0.0f, hook, seed_tab,
+        seg_begin, seg_end);
 }
 
 // standard mode with the fused data-component tap: red[0..NT) the taps, red[NT] the fused one
 template <int NT, bool SUM = true, typename Hook = NoHook>
 __device__ __forceinline__ void correlate_window_std_aux(const float2* __restrict__ stream, unsigned long long sample_offset, int n_samples,
     const float* __restrict__ tab, const float* tab_aux, float aux_shift, int code_len, const float (&sh)[NT], float rem_carr, float phase_step,
-    float rem_code, float code_step, float2* __restrict__ red, Hook hook = Hook(), const float2* seed_tab = nullptr)
+    float rem_code, float code_step, float2* __restrict__ red, Hook hook = Hook(), const float2* seed_tab = nullptr, int seg_begin = 0, int seg_end = -1)
 {
-    correlate_window<NT, 0, true, false, SUM, Hook>(stream, sample_offset, n_samples, tab, code_len, sh, rem_carr, phase_step, 0.0f, rem_code, code_step, 0.0f, red, tab_aux, aux_shift, hook, seed_tab);
+    correlate_window<NT, 0, true, false, SUM, Hook>(stream, sample_offset, n_samples, tab, code_len, sh, rem_carr, phase_step, 0.0f, rem_code, code_step, 0.0f, red, tab_aux, aux_shift, hook, seed_tab,
+        seg_begin, seg_end);
 }
 }  // namespace GSH_MC_NS
 namespace mcdev = GSH_MC_NS;

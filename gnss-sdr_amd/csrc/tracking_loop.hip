@@ -138,6 +138,7 @@ struct SerialMail  // results the code-loop lane and the lock-detector lane hand
     double code_error_chips, code_error_filt_chips;
     int lost;          // the code lock fail counter is over its limit (C/N0 wave)
     int lost_carrier;  // the carrier lock fail counter is (carrier-lock wave)
+    int coop_err;      // COOP kernels: a partner work-group did not answer in time (the loop ends at the top of the next period)
     // The lanes do not meet at a barrier: each says when it is done by writing the period's number (LDS operations of one wave are carried out in order, so a lane
     // that has seen the number sees what was written before it), and thread 0 waits only for what it needs -- the code loop's output always, the lock detectors'
     // verdict only in a period in which a fail counter CAN pass its limit (may_trip_*: left by the detectors' lanes for the next period).  Otherwise the two
@@ -261,7 +262,20 @@ struct TrkArgs
     // correctly rounded reciprocals of the two launch-constant divisors of the loop arithmetic, 0.0 when the configuration does not qualify (div_by_constant below)
     double inv_fs_in, inv_signal_carrier_freq;
     LiveArgs live;
+    // cooperating work-groups (COOP kernels, gsh_trk_set_split): coop_g work-groups share every window of a channel.  coop_box: per channel COOP_STRIDE(g) 64-bit
+    // words (value | tag << 32) -- the next window's seven words from the channel's main work-group, then each helper's 2 (NT + 1) partial sums; the word behind
+    // the last channel's is the launch's error flag.  coop_seq0: the tag of this launch's first window (tags never repeat over a handle's life).
+    unsigned long long* coop_box;
+    int coop_g;
+    unsigned coop_seq0;
+    int coop_channels;
+    int coop_helper_trips;   // > 0: trips of a helper's segment (A/B override, GSH_TRK_SPLIT_HELPER_TRIPS)
+    __host__ __device__ int coop_n_channels() const { return coop_channels; }
 };
+constexpr int COOP_BOX_WORDS = 8;       // pos lo, pos hi, rem_carr, phase_step, rem_code, code_step, flags (go | narrow << 1), spare
+constexpr int COOP_PART_WORDS = 16;     // a helper's sums: 2 (NT + 1) <= 12 words
+__host__ __device__ constexpr int coop_stride(int g) { return COOP_BOX_WORDS + COOP_PART_WORDS * (g > 1 ? g - 1 : 0); }
+constexpr unsigned long long COOP_TIMEOUT_TICKS = 20000000ull;  // 0.2 s of wall_clock64 (100 MHz): a partner that never answers must not hang the device
 
 constexpr double INV_TWO_PI_D = 1.0 / GNSS_TWO_PI_D;  // correctly rounded by the compiler; 2 pi's significand is not all ones
 // fmod(x, 2 pi) of the carrier phase remainder (a few turns): exact_division.h; arguments beyond a million turns take the library's path
@@ -778,7 +792,8 @@ __device__ __forceinline__ unsigned conf_switches(const gsh_trk_conf& c)
 
 // HD: Dll_Pll_Conf::high_dyn -- a compile-time switch so that the standard path does not carry the high-dynamics correlator's registers
 // LIVE: the residency form of the loop (gsh_trk_live_*) -- a compile-time switch as well: the launched form keeps the code (and the registers) it had
-template <int NT, bool HD, bool LIVE>
+// COOP (round 6, gsh_trk_set_split): a.coop_g work-groups on different compute units share every window of a channel -- see the block comment at `coop` below
+template <int NT, bool HD, bool LIVE, bool COOP = false>
 // conf: the device copy of the configuration as a parameter of its own, const and __restrict__: nothing the kernel writes aliases it, so its fields are
 // fetched with scalar loads and may be hoisted -- through the pointer inside TrkArgs every c.field in thread 0's section was a vector memory load that could not
 // move above the record stores before it.
@@ -802,7 +817,17 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
     __shared__ __align__(16) std::conditional_t<LIVE, gsh_trk_epoch, NoLiveShared> lrec;
     static_assert(sizeof(gsh_trk_epoch) % 8 == 0 && sizeof(gsh_trk_epoch) / 8 <= 64, "the record is written out as 8-byte pieces by one wave");
     static_assert(sizeof(TrkChannel) % 4 == 0 && sizeof(LockState) % 4 == 0, "state is copied as 32-bit words");
-    const int ch = blockIdx.x;
+    static_assert(!COOP || (!HD && !LIVE), "cooperating work-groups exist for the launched standard-mode loop");
+    // COOP: block b sits on XCD b % 8; the coop_g work-groups of a channel take consecutive slots of ONE XCD (a hand-off between them is an L2 round trip: ~350 ns,
+    // profiles/ubench/pingpong.hip), channel = (slot / coop_g) * 8 + xcd
+    int ch = blockIdx.x, coop_rank = 0;
+    if constexpr (COOP)
+        {
+            const int xcd = static_cast<int>(blockIdx.x & 7u), q = static_cast<int>(blockIdx.x >> 3);
+            coop_rank = q % a.coop_g;
+            ch = (q / a.coop_g) * 8 + xcd;
+            if (ch >= static_cast<int>(a.coop_n_channels())) return;
+        }
     const int tid = threadIdx.x;
     const gsh_trk_conf& c = *conf;
     // The configuration's switches in ONE word, formed once per launch: every `c.flag` in the loop arithmetic was a scalar load the lane then waited for
@@ -838,6 +863,182 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
     const float sh_data[1] = {0.0f};
     constexpr int PROMPT = NT / 2;
 
+    // ---- coop: cooperating work-groups.  A channel's period is issue-bound on its one compute unit (12 870 wave-instructions on four SIMDs) while most of the chip
+    // idles at the headline channel count.  With a.coop_g > 1 the window [0, vector_length) is cut into coop_g segments: the channel's MAIN work-group (rank 0)
+    // correlates segment 0, runs the loop arithmetic and, at the top of every period, puts the window's seven words into the channel's box (one relaxed agent-scope
+    // 64-bit store per word, value | tag << 32: no fence, no flag -- a reader takes a word when its tag is the period's); the HELPERS (ranks 1 ..) wait for the
+    // box, fill their own seed tables for rem_carr + seg_begin * phase_step, correlate their segment and leave 2 (NT + 1) tagged partial sums, which the main
+    // work-group's serial waves add to their own in rank order.  Every wait is bounded (COOP_TIMEOUT_TICKS): a partner that never runs raises the launch's error
+    // word, which ends the channel's loop instead of hanging the device.  The sums are those of a different order of summation than the one-work-group form's:
+    // records agree with it to rounding, not bit for bit -- hence a switch (gsh_trk_set_split), not the default.
+    unsigned long long* const coop_mine = COOP ? a.coop_box + static_cast<size_t>(ch) * coop_stride(a.coop_g) : nullptr;
+    unsigned long long* const coop_err = COOP ? a.coop_box + static_cast<size_t>(a.coop_channels) * coop_stride(a.coop_g) : nullptr;
+    int seg_begin = 0, seg_end = static_cast<int>(c.vector_length);
+    if constexpr (COOP)
+        {
+            // Whole trips: a correlation costs ~1 us whatever its length plus ~0.6 us per trip of 2 x NCH x 1 024 samples per lane-pair row (mcorr_device.h), so
+            // segments are cut at trip boundaries.  T trips over coop_g work-groups: every helper takes h = floor(T / g + 0.4) of them (at least one), the main
+            // work-group the rest at the FRONT of the window -- it starts a hand-off before the helpers and their sums need another one to arrive, so the odd trip
+            // is its (7 trips: 4 + 3; 1 + 2 + 2 + 2; with eight work-groups seven helpers take one each and the main one only joins).
+            const int n = static_cast<int>(c.vector_length);
+            const int trip = (NT <= 3 && !CF(CF_TRACK_PILOT)) ? 4 * MC_THREADS : 2 * MC_THREADS;
+            const int T = (n + trip - 1) / trip;
+            const int helpers = a.coop_g - 1;
+            int h = helpers > 0 ? max(1, (10 * T + 4 * a.coop_g) / (10 * a.coop_g)) : 0;
+            if (a.coop_helper_trips > 0) h = a.coop_helper_trips;
+            const int main_trips = max(0, T - helpers * h);
+            if (coop_rank == 0)
+                {
+                    seg_begin = 0;
+                    seg_end = min(n, main_trips * trip);
+                }
+            else
+                {
+                    seg_begin = min(n, (main_trips + (coop_rank - 1) * h) * trip);
+                    seg_end = (coop_rank == helpers) ? n : min(n, seg_begin + h * trip);
+                    if (seg_end < seg_begin) seg_end = seg_begin;
+                }
+        }
+    if constexpr (COOP)
+        if (coop_rank > 0)
+            {
+                __syncthreads();  // code table(s) staged
+                for (int e = 0; e < a.n_epochs; e++)
+                    {
+                        const unsigned tag = a.coop_seq0 + static_cast<unsigned>(e);
+                        if ((tid >> 6) == 0)
+                            {
+                                // lanes 0 .. 6 take the window's words as soon as all of them carry this period's tag
+                                const int lane = tid & 63;
+                                unsigned long long v = 0ull;
+                                const unsigned long long t0 = wall_clock64();
+                                bool failed = false;
+                                for (;;)
+                                    {
+                                        if (lane < 7) v = __hip_atomic_load(coop_mine + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                        if (__all(lane >= 7 || static_cast<unsigned>(v >> 32) == tag)) break;
+                                        if (wall_clock64() - t0 > COOP_TIMEOUT_TICKS)
+                                            {
+                                                failed = true;
+                                                break;
+                                            }
+                                        __builtin_amdgcn_s_sleep(1);
+                                    }
+                                const unsigned lo = static_cast<unsigned>(v);
+                                const unsigned w0 = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(lo), 0));
+                                const unsigned w1 = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(lo), 1));
+                                if (lane == 0)
+                                    {
+                                        if (failed) __hip_atomic_store(coop_err, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                        win.pos = static_cast<unsigned long long>(w0) | (static_cast<unsigned long long>(w1) << 32);
+                                        win.phase_rate = 0.0f;
+                                        win.code_rate = 0.0f;
+                                        win.seed_ok = SEEDS ? 1 : 0;
+                                    }
+                                if (lane == 2) win.rem_carr = __uint_as_float(lo);
+                                if (lane == 3) win.phase_step = __uint_as_float(lo);
+                                if (lane == 4) win.rem_code = __uint_as_float(lo);
+                                if (lane == 5) win.code_step = __uint_as_float(lo);
+                                if (lane == 6)
+                                    {
+                                        win.go = failed ? 0 : static_cast<int>(lo & 1u);
+                                        win.narrow = static_cast<int>((lo >> 1) & 1u);
+                                    }
+                            }
+                        if constexpr (SEEDS)
+                            {
+                                // the helper's own seed table, for rem_carr + seg_begin * phase_step: its two table waves take the two words they need out of the box
+                                // themselves, beside wave 0 (a fill behind wave 0's broadcast would sit on the helper's critical path; per-lane seeds cost it 0.75 us)
+                                int tl = tid;
+                                asm volatile("" : "+v"(tl));
+                                const int wv = tl >> 6;
+                                if (wv == SERIAL_WAVES + 1 || wv == SERIAL_WAVES + 2)
+                                    {
+                                        const int lane = tl & 63;
+                                        unsigned long long v = 0ull;
+                                        const unsigned long long t0 = wall_clock64();
+                                        bool ok = true;
+                                        for (;;)
+                                            {
+                                                if (lane < 7) v = __hip_atomic_load(coop_mine + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                                if (__all(lane >= 7 || static_cast<unsigned>(v >> 32) == tag)) break;
+                                                if (wall_clock64() - t0 > COOP_TIMEOUT_TICKS)
+                                                    {
+                                                        ok = false;
+                                                        break;
+                                                    }
+                                                __builtin_amdgcn_s_sleep(1);
+                                            }
+                                        const int lo = static_cast<int>(static_cast<unsigned>(v));
+                                        const float b_rem = __int_as_float(__builtin_amdgcn_readlane(lo, 2)), b_step = __int_as_float(__builtin_amdgcn_readlane(lo, 3));
+                                        const bool go = ok && (__builtin_amdgcn_readlane(lo, 6) & 1) != 0;
+                                        if (go)
+                                            mcdev::seed_table_fill(seed_tab, b_step, static_cast<double>(b_rem) + static_cast<double>(seg_begin) * static_cast<double>(b_step), lane,
+                                                wv - (SERIAL_WAVES + 1));
+                                    }
+                            }
+                        __syncthreads();
+                        if (!win.go) break;  // uniform
+#ifdef GSH_COOP_PROFILE
+                        const unsigned long long tp_seen = wall_clock64();
+#endif
+                        const unsigned long long wpos = a.ring_capacity ? win.pos % a.ring_capacity : win.pos;
+                        float sh[NT];
+                        {
+                            const float spcf = static_cast<float>(c.code_samples_per_chip);
+                            const float el = (win.narrow ? c.early_late_space_narrow_chips : c.early_late_space_chips) * spcf;
+                            const float vel = (win.narrow ? c.very_early_late_space_narrow_chips : c.very_early_late_space_chips) * spcf;
+                            if (NT == 5)
+                                {
+                                    sh[0] = -vel;
+                                    sh[1] = -el;
+                                    sh[2] = 0.0f;
+                                    sh[NT - 2] = el;
+                                    sh[NT - 1] = vel;
+                                }
+                            else
+                                {
+                                    sh[0] = -el;
+                                    sh[1] = 0.0f;
+                                    sh[NT - 1] = el;
+                                }
+                        }
+                        const float2* const seeds = SEEDS ? seed_tab : nullptr;
+                        if (CF(CF_TRACK_PILOT))
+                            correlate_window_std_aux<NT, false>(a.stream, wpos, static_cast<int>(c.vector_length), tab, tab_data, sh_data[0], code_len, sh, win.rem_carr, win.phase_step, win.rem_code,
+                                win.code_step, red, mcdev::NoHook(), seeds, seg_begin, seg_end);
+                        else
+                            correlate_window_std<NT, false, false>(a.stream, wpos, static_cast<int>(c.vector_length), tab, code_len, sh, win.rem_carr, win.phase_step, win.rem_code, win.code_step, red,
+                                mcdev::NoHook(), seeds, seg_begin, seg_end);
+                        if ((tid >> 6) == 0)
+                            {
+                                float2 sums[NT + 1];
+                                mcdev::sum_wave_partials<NT + 1>(red, sums);
+                                const int lane = tid & 63;
+                                float mine = 0.0f;
+#pragma unroll
+                                for (int t = 0; t < NT + 1; t++)
+                                    {
+                                        mine = (lane == 2 * t) ? sums[t].x : mine;
+                                        mine = (lane == 2 * t + 1) ? sums[t].y : mine;
+                                    }
+                                if (lane < 2 * (NT + 1))
+                                    __hip_atomic_store(coop_mine + COOP_BOX_WORDS + COOP_PART_WORDS * (coop_rank - 1) + lane,
+                                        static_cast<unsigned long long>(__float_as_uint(mine)) | (static_cast<unsigned long long>(tag) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef GSH_COOP_PROFILE
+                                if (ch == 0 && coop_rank == 1 && lane == 0 && e >= 8)
+                                    {
+                                        atomicAdd(coop_err + 1, tp_seen);                 // [1] sum of "seen" stamps
+                                        atomicAdd(coop_err + 2, wall_clock64());          // [2] sum of "partial stored" stamps
+                                        atomicAdd(coop_err + 3, 1ull);
+                                    }
+#endif
+                            }
+                        __syncthreads();  // the rows and win are rewritten by the next period
+                    }
+                return;
+            }
+
     constexpr bool live = LIVE;
     if (tid == 0)
         {
@@ -853,6 +1054,7 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
             mail.code_seq = mail.cn0_seq = mail.carr_seq = mail.inputs_cn0 = mail.inputs_carr = 0;
             mail.step_seq = 0;
             mail.lost = mail.lost_carrier = 0;
+            mail.coop_err = 0;
             mail.may_trip_code = (lk.code_lock_fail_counter + 1 > c.max_code_lock_fail) ? 1 : 0;
             mail.may_trip_carr = (lk.carrier_lock_fail_counter + 1 > c.max_carrier_lock_fail) ? 1 : 0;
             if constexpr (LIVE)
@@ -923,6 +1125,30 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                             if (tid == 0) live_wait(a, ch, s, win, lv, c.vector_length);  // (the NCO settings stand: publish() formed them; only residency was open)
                             __syncthreads();
                         }
+                }
+            if constexpr (COOP)
+                {
+                    // this period's window for the helpers (win is final behind the barrier that ended the last period): seven lanes of a wave without loop arithmetic
+                    if ((tid >> 6) == SERIAL_WAVES + 3)
+                        {
+                            const int lane = tid & 63;
+                            const unsigned long long pos = win.pos;
+                            unsigned w = 0u;
+                            w = lane == 0 ? static_cast<unsigned>(pos) : w;
+                            w = lane == 1 ? static_cast<unsigned>(pos >> 32) : w;
+                            w = lane == 2 ? __float_as_uint(win.rem_carr) : w;
+                            w = lane == 3 ? __float_as_uint(win.phase_step) : w;
+                            w = lane == 4 ? __float_as_uint(win.rem_code) : w;
+                            w = lane == 5 ? __float_as_uint(win.code_step) : w;
+                            w = lane == 6 ? ((win.go && !mail.coop_err) ? 1u : 0u) | (win.narrow ? 2u : 0u) : w;
+                            if (lane < 7)
+                                __hip_atomic_store(coop_mine + lane, static_cast<unsigned long long>(w) | (static_cast<unsigned long long>(a.coop_seq0 + static_cast<unsigned>(e)) << 32),
+                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef GSH_COOP_PROFILE
+                            if (ch == 0 && lane == 0 && e >= 8 && win.go) atomicAdd(coop_err + 4, wall_clock64());  // [4] sum of "published" stamps
+#endif
+                        }
+                    if (mail.coop_err) break;  // uniform (written before the barrier that ended the last period)
                 }
             if (!win.go) break;  // uniform: win is only rewritten between the barriers below
 #ifdef GSH_TRK_PROFILE
@@ -1011,17 +1237,65 @@ __global__ __launch_bounds__(MC_THREADS) void trk_loop_kernel(TrkArgs a, const g
                     // them up (sum_wave_partials: same order, same sums), the others go straight on to the barrier that ends the period.  win is rewritten and the
                     // rows are reused only after that barrier.  (Until round 3: sum by NT threads -> barrier -> every thread read the sums -> barrier.)
                     if (fused_data)
-                        correlate_window_std_aux<NT, false>(a.stream, wpos, static_cast<int>(c.vector_length), tab, tab_data, sh_data[0], code_len, sh, rem_carr, phase_step, rem_code, code_step, red, live_hook, seeds);
+                        correlate_window_std_aux<NT, false>(a.stream, wpos, static_cast<int>(c.vector_length), tab, tab_data, sh_data[0], code_len, sh, rem_carr, phase_step, rem_code, code_step, red, live_hook, seeds,
+                            seg_begin, seg_end);
 #ifdef GSH_TRK_PAIRED_TAPS  // early tap read next to the late one: fewer instructions per trip, yet 0.5 us per period slower here (profiles/ab/r03/closed_loop_paired_taps.txt)
                     else if (NT == 3 && (static_cast<double>(sh[2]) - static_cast<double>(sh[0]) == 1.0) && code_step > 0.0f)  // mcorr_pair_eligible (uniform)
                         correlate_window_std<NT, true, false>(a.stream, wpos, static_cast<int>(c.vector_length), tab, code_len, sh, rem_carr, phase_step, rem_code, code_step, red);
 #endif
                     else
-                        correlate_window_std<NT, false, false>(a.stream, wpos, static_cast<int>(c.vector_length), tab, code_len, sh, rem_carr, phase_step, rem_code, code_step, red, live_hook, seeds);
+                        correlate_window_std<NT, false, false>(a.stream, wpos, static_cast<int>(c.vector_length), tab, code_len, sh, rem_carr, phase_step, rem_code, code_step, red, live_hook, seeds,
+                            seg_begin, seg_end);
                     if (tid < 64 * SERIAL_WAVES)  // the waves that hold a lane of the loop arithmetic below
                         {
                             float2 sums[NT + 1];
                             mcdev::sum_wave_partials<NT + 1>(red, sums);
+#ifdef GSH_COOP_PROFILE
+                            if (COOP && ch == 0 && tid == 0 && e >= 8) atomicAdd(coop_err + 5, wall_clock64());  // [5] own segment done
+#endif
+                            if constexpr (COOP)
+                                {
+                                    // the helpers' partial sums, added in rank order (every serial wave takes them itself: no barrier between the correlation and the lanes)
+                                    const int lane = tid & 63;
+                                    const int n_words = 2 * (NT + 1);
+                                    const unsigned tag = a.coop_seq0 + static_cast<unsigned>(e);
+                                    for (int r = 1; r < a.coop_g; r++)
+                                        {
+                                            unsigned long long v = 0ull;
+                                            const unsigned long long* src = coop_mine + COOP_BOX_WORDS + COOP_PART_WORDS * (r - 1);
+                                            const unsigned long long t0 = wall_clock64();
+                                            bool failed = mail.coop_err != 0;
+                                            while (!failed)
+                                                {
+                                                    if (lane < n_words) v = __hip_atomic_load(src + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                                    if (__all(lane >= n_words || static_cast<unsigned>(v >> 32) == tag)) break;
+                                                    if (wall_clock64() - t0 > COOP_TIMEOUT_TICKS) failed = true;
+                                                }
+                                            if (failed)
+                                                {
+                                                    if (lane == 0)
+                                                        {
+                                                            __hip_atomic_store(coop_err, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                                            mail.coop_err = 1;
+                                                        }
+                                                    v = 0ull;
+                                                }
+                                            const int bits = static_cast<int>(static_cast<unsigned>(v));
+#pragma unroll
+                                            for (int t = 0; t < NT + 1; t++)
+                                                {
+                                                    sums[t].x += __int_as_float(__builtin_amdgcn_readlane(bits, 2 * t));
+                                                    sums[t].y += __int_as_float(__builtin_amdgcn_readlane(bits, 2 * t + 1));
+                                                }
+                                        }
+#ifdef GSH_COOP_PROFILE
+                                    if (ch == 0 && tid == 0 && e >= 8)
+                                        {
+                                            atomicAdd(coop_err + 6, wall_clock64());  // [6] gathered
+                                            atomicAdd(coop_err + 7, 1ull);
+                                        }
+#endif
+                                }
 #pragma unroll
                             for (int t = 0; t < NT; t++) out[t] = sums[t];
                             if (fused_data) pdata = sums[NT];
@@ -1957,6 +2231,10 @@ struct gsh_trk
     unsigned live_idle_us{1000}, live_residency_us{20000};  // (round 4: 200 us / 5 ms until the quit word was polled often enough to end a residency within half a millisecond; a restart is ~0.25 ms of nobody advancing: +5 - 8 % through the blocks, profiles/ab/r04/dropin_push_notes.txt)
     std::shared_ptr<gsh::LiveFloor> live_floor;     // registered with the ring: pushes keep off what the channels still read
     std::atomic<bool> live_ready{false};            // live_setup has run: what gsh_trk_live_take (any thread) reads is in place
+    // ---- cooperating work-groups (gsh_trk_set_split): launched standard-mode runs only
+    int split{1};                                   // work-groups per channel
+    unsigned long long* d_coop{nullptr};            // n_channels * coop_stride(split) + 1 tagged words (TrkArgs::coop_box)
+    unsigned coop_seq{1};                           // tag of the next launch's first window
 };
 
 namespace
@@ -2046,8 +2324,26 @@ int trk_launch(gsh_trk* t, int n_epochs, gsh_trk_epoch* d_records, gsh::TrkTail*
                                : ~0ull;
     }
     const size_t lds = trk_lds_bytes(t);
-    const dim3 grid(t->n_channels), block(gsh::mcdev::MC_THREADS);
+    const bool coop = live == nullptr && t->split > 1 && t->d_coop != nullptr && !t->conf.high_dyn;
+    a.coop_box = coop ? t->d_coop : nullptr;
+    a.coop_g = coop ? t->split : 1;
+    a.coop_channels = t->n_channels;
+    {
+        static const int user = [] { const char* e = std::getenv("GSH_TRK_SPLIT_HELPER_TRIPS"); return e != nullptr ? std::atoi(e) : 0; }();
+        a.coop_helper_trips = user;
+    }
+    a.coop_seq0 = t->coop_seq;
+    if (coop) t->coop_seq += static_cast<unsigned>(n_epochs) + 2u;  // (tags never repeat within 2^32 periods)
+    const dim3 grid(coop ? static_cast<unsigned>((t->n_channels + 7) / 8 * 8 * t->split) : static_cast<unsigned>(t->n_channels)), block(gsh::mcdev::MC_THREADS);
     hipStream_t st = live != nullptr ? t->live_stream : t->stream;
+    if (coop)
+        {
+            if (t->conf.veml)
+                hipLaunchKernelGGL((gsh::trk_loop_kernel<5, false, false, true>), grid, block, lds, st, a, a.conf);
+            else
+                hipLaunchKernelGGL((gsh::trk_loop_kernel<3, false, false, true>), grid, block, lds, st, a, a.conf);
+        }
+    else
     {
         using KernelFn = void (*)(gsh::TrkArgs, const gsh_trk_conf*);
         const bool L = live != nullptr;
@@ -2068,6 +2364,19 @@ int trk_launch(gsh_trk* t, int n_epochs, gsh_trk_epoch* d_records, gsh::TrkTail*
             return gsh::stream_mark_read(t->ring, lowest, t->stream);
         }
     return GSH_OK;
+}
+
+// after a launched run has completed (the stream is idle): did a cooperating work-group give up on its partner?
+int coop_check(gsh_trk* t)
+{
+    if (t->d_coop == nullptr || t->split <= 1) return GSH_OK;
+    unsigned long long* err = t->d_coop + static_cast<size_t>(t->n_channels) * gsh::coop_stride(t->split);
+    unsigned long long v = 0ull;
+    GSH_HIP(hipMemcpy(&v, err, sizeof(v), hipMemcpyDeviceToHost));
+    if (v == 0ull) return GSH_OK;
+    GSH_HIP(hipMemset(err, 0, sizeof(v)));
+    return set_error(GSH_ERR_STATE, "gsh_trk_run: a cooperating work-group did not answer within 0.2 s (gsh_trk_set_split needs every work-group of the launch resident at once: "
+                                    "nothing else may occupy the device's compute units meanwhile); the channels stopped where they were");
 }
 
 // ---- live mode, host side ---------------------------------------------------------------------------------------------------------------------
@@ -2349,6 +2658,7 @@ extern "C"
         if (t->d_stream_owned) (void)hipFree(t->d_stream_owned);
         if (t->d_records) (void)hipFree(t->d_records);
         if (t->d_tail) (void)hipFree(t->d_tail);
+        if (t->d_coop) (void)hipFree(t->d_coop);
         if (t->d_conf) (void)hipFree(t->d_conf);
         if (t->h_records) (void)hipHostFree(t->h_records);
         if (t->h_tail) (void)hipHostFree(t->h_tail);
@@ -2677,6 +2987,7 @@ extern "C"
         const int n_epochs = t->pending_epochs;
         t->pending_epochs = -1;
         GSH_HIP(hipStreamSynchronize(t->stream));
+        const int rc_coop = coop_check(t);
         const size_t n_rec = static_cast<size_t>(t->n_channels) * static_cast<size_t>(n_epochs);
         if (records != nullptr && n_rec > 0)
             {
@@ -2700,6 +3011,36 @@ extern "C"
                         t->h_live_tail[ch].active = t->h_tail[ch].active;
                         if (t->h_live_consumed[ch] == t->h_live_tail[ch].seq) t->live_next_window[static_cast<size_t>(ch)] = t->h_tail[ch].pos;
                     }
+            }
+        return rc_coop;
+    }
+
+    int gsh_trk_set_split(gsh_trk_t* t, int work_groups_per_channel)
+    {
+        GSH_REQUIRE(t != nullptr, "null handle");
+        GSH_REQUIRE(work_groups_per_channel >= 1 && work_groups_per_channel <= 8, "work_groups_per_channel %d outside 1..8", work_groups_per_channel);
+        if (t->pending_epochs >= 0) return set_error(GSH_ERR_STATE, "gsh_trk_set_split: a run has been begun and not ended");
+        GSH_HIP(hipSetDevice(t->device));
+        if (live_reap(t) != 0) return set_error(GSH_ERR_STATE, "gsh_trk_set_split: a live residency is in flight (gsh_trk_live_quiesce first)");
+        if (work_groups_per_channel > 1)
+            {
+                GSH_REQUIRE(!t->conf.high_dyn, "cooperating work-groups exist for the standard correlator (high_dyn = 0)");
+                hipDeviceProp_t prop;
+                GSH_HIP(hipGetDeviceProperties(&prop, t->device));
+                const int blocks = (t->n_channels + 7) / 8 * 8 * work_groups_per_channel;
+                // every work-group of a launch must be resident at once (they wait for each other): one 1 024-thread work-group per compute unit
+                GSH_REQUIRE(blocks <= prop.multiProcessorCount, "%d channels x %d work-groups need %d compute units at once, the device has %d", t->n_channels, work_groups_per_channel,
+                    blocks, prop.multiProcessorCount);
+            }
+        GSH_HIP(hipStreamSynchronize(t->stream));
+        if (t->d_coop != nullptr) GSH_HIP(hipFree(t->d_coop));
+        t->d_coop = nullptr;
+        t->split = work_groups_per_channel;
+        if (work_groups_per_channel > 1)
+            {
+                const size_t words = static_cast<size_t>(t->n_channels) * gsh::coop_stride(work_groups_per_channel) + 1 + 16;  // (+ 16: phase clocks of profiling builds)
+                GSH_HIP(hipMalloc(&t->d_coop, words * sizeof(unsigned long long)));
+                GSH_HIP(hipMemset(t->d_coop, 0, words * sizeof(unsigned long long)));  // tag 0 is never a period's (coop_seq starts at 1)
             }
         return GSH_OK;
     }
@@ -2864,6 +3205,17 @@ extern "C"
         GSH_HIP(hipMemcpyAsync(t->d_lock, t->d_lock_backup, lbytes, hipMemcpyDeviceToDevice, t->stream));
         GSH_HIP(hipStreamSynchronize(t->stream));
         *avg_ms = total / static_cast<float>(reps);
-        return GSH_OK;
+        return coop_check(t);
     }
 }
+
+#ifdef GSH_COOP_PROFILE
+// profiling builds only (profiles/ab/r06/coop_phases.py): the eight phase-clock sums channel 0 left behind the launch's error word, then cleared
+extern "C" int gsh_debug_coop_profile(gsh_trk_t* t, unsigned long long* out8)
+{
+    if (t == nullptr || t->d_coop == nullptr || out8 == nullptr) return -1;
+    unsigned long long* base = t->d_coop + static_cast<size_t>(t->n_channels) * gsh::coop_stride(t->split);
+    if (hipMemcpy(out8, base, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return hipMemset(base + 1, 0, 7 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif

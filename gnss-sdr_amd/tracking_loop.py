@@ -128,6 +128,10 @@ class TrackingLoop:
     def live_quiesce(self) -> None:
         check(self._lib.gsh_trk_live_quiesce(self._h))
 
+    def set_split(self, work_groups_per_channel: int) -> None:
+        """gsh_trk_set_split: work-groups that share every window of a channel in launched runs (1 = off)."""
+        check(self._lib.gsh_trk_set_split(self._h, work_groups_per_channel))
+
     def time_run(self, n_epochs: int, reps: int = 5) -> float:
         ms = C.c_float(0.0)
         check(self._lib.gsh_trk_time_run(self._h, n_epochs, reps, C.byref(ms)))

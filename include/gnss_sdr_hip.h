@@ -461,6 +461,15 @@ extern "C"
      * call continues where this one stopped.  records: n_channels * n_epochs (channel-major) or NULL;
      * epochs_done[n_channels]: periods completed (a channel stops when its window would leave the stream). */
     int gsh_trk_run(gsh_trk_t* t, int n_epochs, gsh_trk_epoch* records, int32_t* epochs_done);
+    /* Cooperating work-groups (round 6): `work_groups_per_channel` work-groups on different compute units share every window of a channel in LAUNCHED runs
+     * (gsh_trk_run / _run_begin / _time_run; standard correlator only) -- each correlates its segment of the window, the channel's main work-group adds the partial
+     * sums in a fixed order and runs the loop.  For few channels on a large device; MEASURED at 32 channels, 25 Msps: 7.29 us per period with one work-group,
+     * 6.75 - 7.4 with two, 7.2 - 7.8 with four, ~9 with eight -- two hand-overs through L2 per period (~0.7 us each) eat most of what the shorter
+     * correlation saves, so this is an option, not the default.  The sums are
+     * formed in another order than with one work-group per channel, so records agree with that form to rounding (same bars against the oracle), not bit for bit;
+     * live residencies always run one work-group per channel.  Needs (ceil(n_channels / 8) x 8 x work_groups_per_channel) compute units free at once; a partner
+     * that does not get to run within 0.2 s ends the run with GSH_ERR_STATE instead of hanging the device.  1 = off (default). */
+    int gsh_trk_set_split(gsh_trk_t* t, int work_groups_per_channel);
     /* the same in two halves, for a caller that serialises launches against pushes into the ring itself (Hip_Tracking_Runtime): _begin queues
      * the launch on the loop's stream -- the kernel writes its results into page-locked host memory itself (GSH_TRK_HOST_RECORDS=0 in the environment:
      * into device memory, with two copies queued behind it) -- and returns at once; it is the only part

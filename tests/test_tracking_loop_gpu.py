@@ -379,3 +379,75 @@ def test_records_written_by_the_kernel_into_host_memory_equal_the_copied_ones(gp
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         out.append(open(path, "rb").read())
     assert len(out[0]) > 1_000_000 and out[0] == out[1]
+
+
+@pytest.mark.parametrize("groups", [2, 3, 4])
+def test_cooperating_work_groups_hold_the_oracles_bars(gpu, groups):
+    """gsh_trk_set_split: several work-groups share every window of a channel (launched runs, standard correlator).  The partial sums are
+    added in rank order -- another order of summation than the one-work-group form's -- so the claim is the SAME bars against the pinned oracle
+    loop (not identity with the one-work-group records), at the headline shape (25 Msps: 7 trips per window, so every work-group has a segment)
+    and at a short window (4 Msps: one trip -- the helpers' segments are empty and they only hand zeros over)."""
+    from gnss_sdr_amd import GshError
+    for fs, n, epochs, bw in ((25e6, 25000, 60, 2.0), (4e6, 4000, 120, 4.0)):
+        kw = dict(fs_in=fs, vector_length=n, pll_bw_hz=35.0, dll_bw_hz=bw, enable_lock_detectors=1)
+        prns, dops, cphs = [5, 12, 30], [2300.0, -4100.0, 150.0], [100.2, 640.7, 1001.9]
+        x = synth_gps_l1_stream((epochs + 3) * n, fs, prns, dops, cphs, cn0_dbhz=46.0, seed_noise=77)
+        loop = _loop(gpu, kw, n_channels=4, max_len=1023)  # channel 3 never started: its work-groups leave at once, helpers included
+        loop.set_stream_host(x)
+        loop.set_split(groups)
+        conf_o = oracle.trk_conf(**kw)
+        starts = []
+        for ch, (prn, fd, cph) in enumerate(zip(prns, dops, cphs)):
+            f_code = 1.023e6 * (1 + fd / 1575.42e6)
+            starts.append(int(round((1023.0 - cph) / f_code * fs)) + ch * 17)
+            loop.start(ch, oracle.ca_code(prn), starts[-1], 0, fd + 8.0)
+        rec, done = loop.run(epochs // 2)
+        rec2, done2 = loop.run(epochs - epochs // 2)   # a second launch: the tags of the hand-over words go on, nothing stale is taken
+        assert done[3] == 0 and done2[3] == 0
+        for ch, (prn, fd) in enumerate(zip(prns, dops)):
+            ora = oracle.trk_run(conf_o, oracle.ca_code(prn), x, starts[ch], 0, fd + 8.0, epochs)
+            assert done[ch] + done2[ch] == epochs == len(ora)
+            _compare(rec[ch] + rec2[ch], ora, 3, f"split{groups} fs{fs:g} ch{ch}")
+        # switching back gives the one-work-group form again (and frees the hand-over words)
+        loop.set_split(1)
+        rec3, done3 = loop.run(2)
+        assert done3[:3] == [2, 2, 2]
+        loop.close()
+    # what the switch refuses: the high-dynamics correlator, more work-groups than the device can hold at once
+    hd = _loop(gpu, dict(fs_in=4e6, vector_length=4000, high_dyn=1), n_channels=1, max_len=1023)
+    with pytest.raises(GshError):
+        hd.set_split(2)
+    hd.close()
+    big = _loop(gpu, dict(fs_in=4e6, vector_length=4000), n_channels=200, max_len=1023)
+    with pytest.raises(GshError):
+        big.set_split(8)
+    big.close()
+
+
+def test_cooperating_work_groups_with_the_pilot_and_data_taps(gpu):
+    """the VE/E/P/L/VL + data-prompt form (six sums per hand-over) over two and four work-groups"""
+    fs, n, epochs = 32e6, 128000, 24
+    g = golden_e1_l5_codes()
+    rng = np.random.default_rng(43)
+    n_stream = (epochs + 2) * n
+    x = (rng.standard_normal(n_stream) + 1j * rng.standard_normal(n_stream)).astype(np.complex64)
+    amp = cn0_to_amplitude(45.0, fs)
+    fd, ph = 2210.0, 5000.0
+    rate = 1.023e6 * (1 + fd / 1575.42e6) / fs * 2.0
+    add_code_signal(x, (g["e1b"][11] - g["e1c"][11]) / np.sqrt(2.0), fs, rate, ph, fd, amp)
+    kw = dict(fs_in=fs, vector_length=n, code_length_chips=4092, code_samples_per_chip=2, veml=1, track_pilot=1, cloop=0,
+              early_late_space_chips=0.15, very_early_late_space_chips=0.5, pll_bw_hz=15.0, dll_bw_hz=0.75, pll_filter_order=3, dll_filter_order=2)
+    start = int(round((8184.0 - ph) / rate))
+    conf_o = oracle.trk_conf(**kw)
+    ora = oracle.trk_run(conf_o, g["e1c"][11], x, start, 0, fd - 5.0, epochs, data_code=g["e1b"][11])
+    for groups in (2, 4):
+        loop = _loop(gpu, kw, n_channels=1, max_len=8184)
+        loop.set_stream_host(x)
+        loop.set_split(groups)
+        loop.start(0, g["e1c"][11], start, 0, fd - 5.0, data_code=g["e1b"][11])
+        rec, done = loop.run(epochs)
+        assert done[0] == len(ora)
+        _compare(rec[0], ora, 5, f"e1 split{groups}")
+        for rg, ro in zip(rec[0], ora):
+            assert abs(rg.prompt_data[0] - ro.prompt_data[0]) <= 2e-4 * max(50.0, abs(complex(*ro.prompt_data)))
+        loop.close()
