@@ -618,7 +618,55 @@ def other_configs_metric(dev_index):
         ms = m.measure(codes, rows, n_stream, splits=0, device=dev_index)
         out[key] = {"workload": name, "ms_per_launch": ms, "correlators_per_s": correlators / (ms * 1e-3),
                     "channel_samples_per_s": samples / (ms * 1e-3)}
+    try:
+        out["mcorr16_config2_shape"] = mcorr16_metric(dev_index)
+    except Exception as e:  # the 16-bit family is a side figure: never the reason the line is missing
+        out["mcorr16_config2_shape"] = {"error": str(e)}
     return out
+
+
+def mcorr16_metric(dev_index, channels=32, epochs=400, n=25000):
+    """The 16-bit correlator family (Cpu_Multicorrelator_16sc's arithmetic, gsh_bank16_*) at BASELINE config 2's shape: complex int16 stream and codes, E/P/L,
+    12 800 jobs per launch; four jobs of the launch checked bit for bit against the oracle, the reference's own object timed on one core when oracle/_ref travelled."""
+    import numpy as np
+    import torch
+    from gnss_sdr_amd.tracking16 import CorrelatorBank16, make_job16
+    import oracle
+    rng = np.random.default_rng(0x16)
+    x = rng.integers(-50, 51, size=((epochs + 1) * n, 2)).astype(np.int16)
+    xd = torch.from_numpy(x).to(torch.device("cuda", dev_index))
+    codes = [np.stack([oracle.ca_code(c + 1), np.zeros(1023, np.float32)], -1).astype(np.int16) for c in range(channels)]
+    bank = CorrelatorBank16(channels, 1023, device=dev_index)
+    for c in range(channels):
+        bank.set_code(c, codes[c])
+    bank.set_stream_device(xd.data_ptr(), len(x), keepalive=xd)
+    shifts = np.array([-0.5, 0.0, 0.5], np.float32)
+    jobs, plain = [], []
+    for e in range(epochs):
+        for c in range(channels):
+            par = (float(np.float32(rng.uniform(0, 6.28))), float(np.float32(2 * np.pi * rng.uniform(-5000, 5000) / 25e6)), float(np.float32(rng.uniform(0, 1))), float(np.float32(1.023e6 / 25e6)))
+            off = e * n + int(rng.integers(0, n))
+            jobs.append(make_job16(off, n, c, *par, shifts))
+            plain.append((off, c, par))
+    bank.upload(jobs)
+    ms = min(bank.time_launches(5) for _ in range(2))
+    got = bank.read()
+    ok = True
+    for j in (0, len(jobs) // 3, len(jobs) // 2 + 7, len(jobs) - 1):
+        off, c, par = plain[j]
+        ok = ok and bool(np.array_equal(got[j, :3], oracle.mcorr16(codes[c], shifts, x[off:off + n], *par)))
+    bank.close()
+    res = {"workload": "32 ch x 400 epochs x 25000 samples, complex int16, E/P/L (Cpu_Multicorrelator_16sc's arithmetic)", "ms_per_launch": ms,
+           "correlators_per_s": len(jobs) * 3 / (ms * 1e-3), "spot_check_bit_exact_vs_oracle": ok, "dtype": "s16 (float32 rotation)"}
+    R = oracle.ref()
+    if R is not None and hasattr(R, "ref_mcorr16_time"):
+        out = np.zeros((3, 2), np.int16)
+        for name, simd in (("cpu_reference_generic_us_per_call", 0), ("cpu_reference_simd_us_per_call", 1)):
+            R.ref_set_flavour(simd)
+            s = R.ref_mcorr16_time(codes[0].reshape(-1), 1023, shifts, 3, x.reshape(-1), len(x), n, 100, 0.3, 0.001, 0.2, float(np.float32(1.023e6 / 25e6)), out.reshape(-1))
+            res[name] = s / 100 * 1e6
+        R.ref_set_flavour(0)
+    return res
 
 
 def dropin_metric(channels, fs, periods, periods_per_call=20, seconds=0.0):

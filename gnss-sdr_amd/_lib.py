@@ -41,6 +41,22 @@ class CorrJob(C.Structure):
     ]
 
 
+class Corr16Job(C.Structure):
+    """gsh_corr16_job (72 bytes)."""
+    _fields_ = [
+        ("sample_offset", C.c_uint64),
+        ("n_samples", C.c_int32),
+        ("code_slot", C.c_int32),
+        ("rem_carr_phase_rad", C.c_float),
+        ("phase_step_rad", C.c_float),
+        ("rem_code_phase_chips", C.c_float),
+        ("code_phase_step_chips", C.c_float),
+        ("n_taps", C.c_int32),
+        ("reserved", C.c_int32),
+        ("shifts_chips", C.c_float * GSH_MAX_TAPS),
+    ]
+
+
 class AcqConf(C.Structure):
     """gsh_acq_conf."""
     _fields_ = [
@@ -120,6 +136,7 @@ class AcqResult(C.Structure):
 # every symbol include/gnss_sdr_hip.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
 _F = C.POINTER(C.c_float)
+_I16 = C.POINTER(C.c_int16)
 SYMBOLS = {
     "gsh_abi_version": (C.c_int, []),
     "gsh_device_count": (C.c_int, []),
@@ -135,6 +152,23 @@ SYMBOLS = {
     "gsh_mcorr_carrier_wipeoff_multicorrelator_resampler": (C.c_int, [_P] + [C.c_float] * 6 + [C.c_int]),
     "gsh_mcorr_carrier_wipeoff_multicorrelator_resampler6": (C.c_int, [_P] + [C.c_float] * 5 + [C.c_int]),
     "gsh_mcorr_free": (C.c_int, [_P]),
+    "gsh_mcorr16_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
+    "gsh_mcorr16_destroy": (None, [_P]),
+    "gsh_mcorr16_init": (C.c_int, [_P, C.c_int, C.c_int]),
+    "gsh_mcorr16_set_local_code_and_taps": (C.c_int, [_P, C.c_int, _I16, _F]),
+    "gsh_mcorr16_set_input_output_vectors": (C.c_int, [_P, _I16, _I16]),
+    "gsh_mcorr16_carrier_wipeoff_multicorrelator_resampler": (C.c_int, [_P] + [C.c_float] * 4 + [C.c_int]),
+    "gsh_mcorr16_free": (C.c_int, [_P]),
+    "gsh_bank16_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    "gsh_bank16_destroy": (None, [_P]),
+    "gsh_bank16_set_code": (C.c_int, [_P, C.c_int, _I16, C.c_int]),
+    "gsh_bank16_set_stream_host": (C.c_int, [_P, _I16, C.c_uint64]),
+    "gsh_bank16_set_stream_device": (C.c_int, [_P, _P, C.c_uint64]),
+    "gsh_bank16_correlate": (C.c_int, [_P, C.POINTER(Corr16Job), C.c_int, _I16]),
+    "gsh_bank16_upload_jobs": (C.c_int, [_P, C.POINTER(Corr16Job), C.c_int]),
+    "gsh_bank16_launch": (C.c_int, [_P]),
+    "gsh_bank16_read_outputs": (C.c_int, [_P, _I16, C.c_int]),
+    "gsh_bank16_time_launches": (C.c_int, [_P, C.c_int, _F]),
     "gsh_bank_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     "gsh_bank_destroy": (None, [_P]),
     "gsh_bank_set_code": (C.c_int, [_P, C.c_int, _F, C.c_int]),

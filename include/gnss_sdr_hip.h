@@ -148,6 +148,61 @@ extern "C"
      * without being re-staged and re-uploaded every time.  The caller keeps the shifted windows inside the stream / resident in the ring. */
     int gsh_bank_set_sample_base(gsh_bank_t* b, uint64_t sample_base);
 
+    /*
+     * (3) The 16-bit family: gsh_mcorr16_* replaces class Cpu_Multicorrelator_16sc
+     *     (src/algorithms/tracking/libs/cpu_multicorrelator_16sc.h:38-57, .cc:25-120) method for method, gsh_bank16_* is its batched form.
+     *     Samples, local code and correlator outputs are complex int16 (lv_16sc_t: interleaved I, Q).  Results are those of the reference's
+     *     generic protokernels BIT FOR BIT (K/volk_gnsssdr_16ic_xn_resampler_16ic_xn.h:60-78, K/volk_gnsssdr_16ic_x2_rotator_dot_prod_16ic_xn.h:66-102):
+     *     float32 rotation rounded to int16 per sample, the phasor recurrence with its renormalisation every 256 samples, integer products kept
+     *     to 16 bits, sums that saturate at every addition in sample order.  (The reference's SSE / AVX2 protokernels of the same kernel differ
+     *     from its generic one by a few units -- four interleaved partial sums, another phase schedule; the generic one is what its QA compares
+     *     against and what is reproduced here.)  No block of the reference instantiates this class; it is built for completeness of the family.
+     */
+    typedef struct gsh_mcorr16 gsh_mcorr16_t;
+    int gsh_mcorr16_create(int device, gsh_mcorr16_t** out);
+    void gsh_mcorr16_destroy(gsh_mcorr16_t* h);
+    /* cpu_multicorrelator_16sc.cc:25-41  bool init(int max_signal_length_samples, int n_correlators) */
+    int gsh_mcorr16_init(gsh_mcorr16_t* h, int max_signal_length_samples, int n_correlators);
+    /* .cc:44-53  bool set_local_code_and_taps(int, const lv_16sc_t*, float*): the code is copied to the device, `shifts_chips` is BORROWED and re-read at every call */
+    int gsh_mcorr16_set_local_code_and_taps(gsh_mcorr16_t* h, int code_length_chips, const int16_t* local_code_in_iq, float* shifts_chips);
+    /* .cc:56-62  bool set_input_output_vectors(lv_16sc_t* corr_out, const lv_16sc_t* sig_in): both BORROWED */
+    int gsh_mcorr16_set_input_output_vectors(gsh_mcorr16_t* h, int16_t* corr_out_iq, const int16_t* sig_in_iq);
+    /* .cc:80-96  bool Carrier_wipeoff_multicorrelator_resampler(5 args): synchronous, corr_out[0 .. n_correlators) valid on return */
+    int gsh_mcorr16_carrier_wipeoff_multicorrelator_resampler(gsh_mcorr16_t* h, float rem_carrier_phase_in_rad, float phase_step_rad, float rem_code_phase_chips,
+        float code_phase_step_chips, int signal_length_samples);
+    /* .cc:107-120 bool free() */
+    int gsh_mcorr16_free(gsh_mcorr16_t* h);
+
+    typedef struct gsh_bank16 gsh_bank16_t;
+    typedef struct gsh_corr16_job
+    {
+        uint64_t sample_offset;      /* first sample of the window inside the attached int16 stream */
+        int32_t n_samples;           /* signal_length_samples */
+        int32_t code_slot;
+        float rem_carr_phase_rad;    /* .cc:81 */
+        float phase_step_rad;        /* .cc:82 */
+        float rem_code_phase_chips;  /* .cc:83 */
+        float code_phase_step_chips; /* .cc:84 */
+        int32_t n_taps;              /* 1..GSH_MAX_TAPS */
+        int32_t reserved;
+        float shifts_chips[GSH_MAX_TAPS];
+    } gsh_corr16_job;                /* 72 bytes, POD */
+    int gsh_bank16_create(int device, int n_code_slots, int max_code_length, gsh_bank16_t** out);
+    void gsh_bank16_destroy(gsh_bank16_t* b);
+    int gsh_bank16_set_code(gsh_bank16_t* b, int slot, const int16_t* code_iq, int code_length);
+    /* the IF stream as complex int16: _host copies it to the device, _device borrows device memory (4-byte aligned) */
+    int gsh_bank16_set_stream_host(gsh_bank16_t* b, const int16_t* iq, uint64_t n_samples);
+    int gsh_bank16_set_stream_device(gsh_bank16_t* b, const void* device_iq, uint64_t n_samples);
+    /* one synchronous batch; out_iq: n_jobs * GSH_MAX_TAPS complex int16 (job-major, tap-minor; taps >= n_taps are zero).  The two carrier phasors of
+     * every job are formed on the host with the C library, by the expressions of cpu_multicorrelator_16sc.cc:89-93. */
+    int gsh_bank16_correlate(gsh_bank16_t* b, const gsh_corr16_job* jobs, int n_jobs, int16_t* out_iq);
+    /* the same in pieces (upload once, launch many, read once); gsh_bank16_launch is asynchronous on the bank's stream */
+    int gsh_bank16_upload_jobs(gsh_bank16_t* b, const gsh_corr16_job* jobs, int n_jobs);
+    int gsh_bank16_launch(gsh_bank16_t* b);
+    int gsh_bank16_read_outputs(gsh_bank16_t* b, int16_t* out_iq, int n_jobs);
+    /* HIP-event timing of `reps` back-to-back launches (both kernels) of the uploaded job table: average milliseconds per launch */
+    int gsh_bank16_time_launches(gsh_bank16_t* b, int reps, float* avg_ms);
+
     /* ================================================================ SAMPLE STREAM (device-resident ring)
      * gsh_stream_*: the IF sample stream of one RF front-end kept in device memory, addressed by ABSOLUTE sample index
      * (sample 0 = the first sample ever pushed), so that every channel's correlation window refers to bytes that crossed

@@ -20,6 +20,7 @@ _f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
 _f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
 _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 _u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+_i16p = np.ctypeslib.ndpointer(dtype=np.int16, flags="C_CONTIGUOUS")
 
 
 
@@ -100,6 +101,13 @@ def lib():
         L.oracle_index_max.restype = None
         L.oracle_mcorr_time.argtypes = [_f32p, C.c_int, _f32p, C.c_int, _f32p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, _f32p, _f32p]
         L.oracle_mcorr_time.restype = C.c_double
+        # ---- the 16-bit family
+        L.oracle_mcorr16_phasors.argtypes = [C.c_float, C.c_float, _f32p]
+        L.oracle_mcorr16_phasors.restype = None
+        L.oracle_mcorr16_phasor.argtypes = [_i16p, C.c_int, _f32p, C.c_int, _i16p, C.c_int] + [C.c_float] * 6 + [_i16p]
+        L.oracle_mcorr16_phasor.restype = C.c_int
+        L.oracle_mcorr16.argtypes = [_i16p, C.c_int, _f32p, C.c_int, _i16p, C.c_int] + [C.c_float] * 4 + [_i16p]
+        L.oracle_mcorr16.restype = C.c_int
         # ---- loop closure (gnss_oracle_loop.c)
         L.oracle_fll_diff_atan.argtypes = [C.c_float] * 4 + [C.c_double] * 2
         L.oracle_fll_diff_atan.restype = C.c_double
@@ -164,6 +172,13 @@ def ref():
             R.ref_gps_l5q_code_gen_float.argtypes = [_f32p, C.c_uint]
             R.ref_resampler_generic.argtypes = [C.POINTER(C.POINTER(C.c_float)), _f32p, C.c_float, C.c_float, _f32p, C.c_uint, C.c_int, C.c_uint]
             R.ref_hd_resampler_generic.argtypes = [C.POINTER(C.POINTER(C.c_float)), _f32p, C.c_float, C.c_float, C.c_float, _f32p, C.c_uint, C.c_int, C.c_uint]
+            if hasattr(R, "ref_mcorr16_run"):  # the 16-bit family
+                R.ref_mcorr16_run.argtypes = [_i16p, C.c_int, _f32p, C.c_int, _i16p, C.c_int] + [C.c_float] * 4 + [_i16p]
+                R.ref_mcorr16_run.restype = C.c_int
+                R.ref_mcorr16_phasors.argtypes = [C.c_float, C.c_float, _f32p]
+                R.ref_mcorr16_phasors.restype = None
+                R.ref_mcorr16_time.argtypes = [_i16p, C.c_int, _f32p, C.c_int, _i16p, C.c_long, C.c_int, C.c_int] + [C.c_float] * 4 + [_i16p]
+                R.ref_mcorr16_time.restype = C.c_double
             if hasattr(R, "ref_fll_diff_atan"):  # loop-closure objects (added with SURVEY 8f-1)
                 R.ref_fll_diff_atan.argtypes = [C.c_float] * 4 + [C.c_double] * 2
                 R.ref_fll_diff_atan.restype = C.c_double
@@ -263,6 +278,52 @@ def ref_mcorr(code, shifts, x, rem_carr, phase_step, rem_code, code_step, phase_
     finally:
         R.ref_set_flavour(0)
     return out.view(np.complex64)
+
+
+# --------------------------------------------------------------------------- the 16-bit family
+
+def _iq16(x) -> np.ndarray:
+    """int16 I/Q as a contiguous [n, 2] array (accepts [n, 2] integers or a complex array with integer parts)."""
+    x = np.asarray(x)
+    if np.iscomplexobj(x):
+        x = np.stack([x.real, x.imag], axis=-1)
+    return np.ascontiguousarray(x, dtype=np.int16).reshape(-1, 2)
+
+
+def mcorr16_phasors(rem_carr: float, phase_step: float) -> np.ndarray:
+    """(phase0 re, im, increment re, im) as Cpu_Multicorrelator_16sc forms them before the kernel call."""
+    out = np.empty(4, np.float32)
+    lib().oracle_mcorr16_phasors(rem_carr, phase_step, out)
+    return out
+
+
+def mcorr16(code_iq, shifts, x_iq, rem_carr, phase_step, rem_code, code_step) -> np.ndarray:
+    """One Cpu_Multicorrelator_16sc call, restated (generic protokernels).  Returns int16[n_taps, 2]."""
+    code = _iq16(code_iq)
+    xi = _iq16(x_iq)
+    shifts = np.ascontiguousarray(shifts, np.float32)
+    out = np.empty((len(shifts), 2), np.int16)
+    rc = lib().oracle_mcorr16(code.reshape(-1), len(code), shifts, len(shifts), xi.reshape(-1), len(xi), rem_carr, phase_step, rem_code, code_step, out.reshape(-1))
+    if rc != 0:
+        raise RuntimeError(f"oracle_mcorr16 failed: {rc}")
+    return out
+
+
+def ref_mcorr16(code_iq, shifts, x_iq, rem_carr, phase_step, rem_code, code_step, simd=False) -> np.ndarray:
+    """The reference's own Cpu_Multicorrelator_16sc (oracle/_ref)."""
+    R = ref()
+    if R is None or not hasattr(R, "ref_mcorr16_run"):
+        raise RuntimeError("oracle/_ref is not built (or predates the 16-bit family)")
+    code = _iq16(code_iq)
+    xi = _iq16(x_iq)
+    shifts = np.ascontiguousarray(shifts, np.float32)
+    out = np.empty((len(shifts), 2), np.int16)
+    R.ref_set_flavour(int(simd))
+    try:
+        R.ref_mcorr16_run(code.reshape(-1), len(code), shifts, len(shifts), xi.reshape(-1), len(xi), rem_carr, phase_step, rem_code, code_step, out.reshape(-1))
+    finally:
+        R.ref_set_flavour(0)
+    return out
 
 
 # --------------------------------------------------------------------------- loop closure helpers

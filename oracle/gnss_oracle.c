@@ -263,6 +263,79 @@ int oracle_mcorr(const float* code, int code_len, const float* shifts, int n_tap
     return 0;
 }
 
+/* ------------------------------------------------------------------------- */
+/* the 16-bit family: Cpu_Multicorrelator_16sc (the tail)      */
+/* ------------------------------------------------------------------------- */
+
+/* the two phasors as T/cpu_multicorrelator_16sc.cc:89-93 forms them: (cos rem, -sin rem) with libm's float functions and std::exp of the
+ * imaginary float argument (libstdc++ -> cexpf).  out4: phase0 re, im, increment re, im */
+void oracle_mcorr16_phasors(float rem_carr, float phase_step, float* out4)
+{
+    out4[0] = cosf(rem_carr);
+    out4[1] = -sinf(rem_carr);
+    const cf32 inc = cexpf(0.0F + (-phase_step) * I);
+    out4[2] = crealf(inc);
+    out4[3] = cimagf(inc);
+}
+
+static inline int16_t sat16(int32_t v) { return (int16_t)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v)); }
+
+/*
+ * K/volk_gnsssdr_16ic_xn_resampler_16ic_xn.h:60-78 (chip selection: the float32 expression of the 32f resampler, floor taken in double of a
+ * float -- the same integer) followed by K/volk_gnsssdr_16ic_x2_rotator_dot_prod_16ic_xn.h:66-102 (generic), phasors handed in:
+ * every sample is rotated in float32, rounded to the nearest even integer and kept as int16 (low 16 bits), the phasor is renormalised at
+ * n = 0, 256, 512 ... AFTER it has been used and BEFORE it is advanced, the product with the code sample is the low 16 bits of the complex
+ * integer product, and every tap's two sums saturate at each addition (so the result depends on the order: n ascending).
+ * in / code / out: interleaved int16 I, Q.
+ */
+int oracle_mcorr16_phasor(const int16_t* code_iq, int code_len, const float* shifts, int n_taps, const int16_t* in_iq, int n,
+    float ph_re, float ph_im, float inc_re, float inc_im, float rem_code, float code_step, int16_t* out_iq)
+{
+    if (n_taps <= 0 || n_taps > 64 || n < 0 || code_len <= 0) return -1;
+    int16_t acc_r[64], acc_i[64];
+    for (int t = 0; t < n_taps; t++) acc_r[t] = acc_i[t] = 0;
+    for (int i = 0; i < n; i++)
+        {
+            const float xr = (float)in_iq[2 * i], xi = (float)in_iq[2 * i + 1];
+            const float yr = xr * ph_re - xi * ph_im, yi = xr * ph_im + xi * ph_re; /* :77 */
+            const int32_t wr = (int16_t)(int32_t)rintf(yr), wi = (int16_t)(int32_t)rintf(yi); /* :78 */
+            if ((i & 255) == 0) /* :81-90 */
+                {
+                    const float h = hypotf(ph_re, ph_im);
+                    ph_re /= h;
+                    ph_im /= h;
+                }
+            {
+                const float nr = ph_re * inc_re - ph_im * inc_im, ni = ph_re * inc_im + ph_im * inc_re; /* :92 */
+                ph_re = nr;
+                ph_im = ni;
+            }
+            for (int t = 0; t < n_taps; t++)
+                {
+                    const int k = chip_std(code_step, (unsigned)i, shifts[t], rem_code, (unsigned)code_len);
+                    const int32_t cr = code_iq[2 * k], ci = code_iq[2 * k + 1];
+                    const int16_t pr = (int16_t)(wr * cr - wi * ci), pi = (int16_t)(wr * ci + wi * cr); /* :95 */
+                    acc_r[t] = sat16((int32_t)acc_r[t] + pr); /* :97 */
+                    acc_i[t] = sat16((int32_t)acc_i[t] + pi);
+                }
+        }
+    for (int t = 0; t < n_taps; t++)
+        {
+            out_iq[2 * t] = acc_r[t];
+            out_iq[2 * t + 1] = acc_i[t];
+        }
+    return 0;
+}
+
+/* One Cpu_Multicorrelator_16sc::Carrier_wipeoff_multicorrelator_resampler call, T/cpu_multicorrelator_16sc.cc:80-96 */
+int oracle_mcorr16(const int16_t* code_iq, int code_len, const float* shifts, int n_taps, const int16_t* in_iq, int n,
+    float rem_carr, float phase_step, float rem_code, float code_step, int16_t* out_iq)
+{
+    float p[4];
+    oracle_mcorr16_phasors(rem_carr, phase_step, p);
+    return oracle_mcorr16_phasor(code_iq, code_len, shifts, n_taps, in_iq, n, p[0], p[1], p[2], p[3], rem_code, code_step, out_iq);
+}
+
 /* float64 truth; chip selection is the reference's float32 expression, the rest exact. */
 int oracle_mcorr_f64(const float* code, int code_len, const float* shifts, int n_taps, const float* in_iq, int n,
     float rem_carr, float phase_step, float phase_rate_step, float rem_code, float code_step,

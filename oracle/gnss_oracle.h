@@ -59,6 +59,19 @@ extern "C"
         float rem_carr, float phase_step, float phase_rate_step, float rem_code, float code_step,
         float code_rate_step, int high_dyn, double* out_iq, double* sum_abs);
 
+    /*
+     * The 16-bit family: one Cpu_Multicorrelator_16sc::Carrier_wipeoff_multicorrelator_resampler call,
+     * T/cpu_multicorrelator_16sc.cc:80-96 over K/volk_gnsssdr_16ic_xn_resampler_16ic_xn.h:60-78 and
+     * K/volk_gnsssdr_16ic_x2_rotator_dot_prod_16ic_xn.h:66-102 (generic).  code / in / out: interleaved int16 I, Q.
+     * _phasors: the two complex floats the class forms with libm before it calls the kernel (phase0 re, im, increment re, im);
+     * _phasor: the kernels alone with those handed in.
+     */
+    void oracle_mcorr16_phasors(float rem_carr, float phase_step, float* out4);
+    int oracle_mcorr16_phasor(const int16_t* code_iq, int code_len, const float* shifts, int n_taps, const int16_t* in_iq, int n,
+        float ph_re, float ph_im, float inc_re, float inc_im, float rem_code, float code_step, int16_t* out_iq);
+    int oracle_mcorr16(const int16_t* code_iq, int code_len, const float* shifts, int n_taps, const int16_t* in_iq, int n,
+        float rem_carr, float phase_step, float rem_code, float code_step, int16_t* out_iq);
+
     /* K/volk_gnsssdr_s32f_sincos_32fc.h:390-400 (generic) */
     void oracle_sincos(float* out_iq, float phase_inc, float* phase, unsigned int n);
     /* K/volk_gnsssdr_32f_index_max_32u.h:446-465 (generic; first index wins ties) */

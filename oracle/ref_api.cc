@@ -4,6 +4,7 @@
  * C entry points over the *reference's own* objects, compiled from
  * /root/reference by oracle/Makefile:
  *   - Cpu_Multicorrelator_Real_Codes  (src/algorithms/tracking/libs/cpu_multicorrelator_real_codes.cc)
+ *   - Cpu_Multicorrelator_16sc        (src/algorithms/tracking/libs/cpu_multicorrelator_16sc.cc)
  *   - gps_l1_ca_code_gen_*            (src/algorithms/libs/gps_sdr_signal_replica.cc)
  *   - galileo_e1_code_gen_*           (src/algorithms/libs/galileo_e1_signal_replica.cc)
  *   - gps_l5{i,q}_code_gen_*          (src/algorithms/libs/gps_l5_signal_replica.cc)
@@ -14,6 +15,7 @@
  * (bench.py cpu_baseline, kind "reference").
  */
 #include "cpu_multicorrelator_real_codes.h"
+#include "cpu_multicorrelator_16sc.h"
 #include "tracking_FLL_PLL_filter.h"
 #include "tracking_discriminators.h"
 #include "tracking_loop_filter.h"
@@ -46,6 +48,10 @@ extern "C"
     void ref_simd_rotator_dot_prod(lv_32fc_t*, const lv_32fc_t*, const lv_32fc_t, lv_32fc_t*, const float**, int, unsigned int);
     void ref_simd_hd_rotator_dot_prod(lv_32fc_t*, const lv_32fc_t*, const lv_32fc_t, const lv_32fc_t, lv_32fc_t*, const float**, int, unsigned int);
     void ref_generic_sincos(lv_32fc_t*, float, float*, unsigned int);
+    void ref_generic_resampler_16ic(lv_16sc_t**, const lv_16sc_t*, float, float, float*, unsigned int, int, unsigned int);
+    void ref_simd_resampler_16ic(lv_16sc_t**, const lv_16sc_t*, float, float, float*, unsigned int, int, unsigned int);
+    void ref_generic_rotator_dot_prod_16ic(lv_16sc_t*, const lv_16sc_t*, const lv_32fc_t, lv_32fc_t*, const lv_16sc_t**, int, unsigned int);
+    void ref_simd_rotator_dot_prod_16ic(lv_16sc_t*, const lv_16sc_t*, const lv_32fc_t, lv_32fc_t*, const lv_16sc_t**, int, unsigned int);
     void ref_generic_index_max(uint32_t*, const float*, uint32_t);
 }
 
@@ -90,6 +96,16 @@ extern "C"
         (g_flavour.load() ? ref_simd_hd_rotator_dot_prod : ref_generic_hd_rotator_dot_prod)(res, in, inc, inc_rate, ph, a, nv, n);
     }
 
+    void volk_gnsssdr_16ic_xn_resampler_16ic_xn(lv_16sc_t** r, const lv_16sc_t* c, float rem, float step, float* sh, unsigned int L, int nv, unsigned int n)
+    {
+        (g_flavour.load() ? ref_simd_resampler_16ic : ref_generic_resampler_16ic)(r, c, rem, step, sh, L, nv, n);
+    }
+
+    void volk_gnsssdr_16ic_x2_rotator_dot_prod_16ic_xn(lv_16sc_t* res, const lv_16sc_t* in, const lv_32fc_t inc, lv_32fc_t* ph, const lv_16sc_t** a, int nv, unsigned int n)
+    {
+        (g_flavour.load() ? ref_simd_rotator_dot_prod_16ic : ref_generic_rotator_dot_prod_16ic)(res, in, inc, ph, a, nv, n);
+    }
+
     /* ---- test-facing API --------------------------------------------------------- */
 
     /* returns 1 if the SIMD flavour can run on this CPU */
@@ -131,6 +147,58 @@ extern "C"
         std::memcpy(out_iq, out.data(), sizeof(float) * 2 * n_taps);
         mc.free();
         return 0;
+    }
+
+    /*
+     * One call of the reference's 16-bit correlator object (cpu_multicorrelator_16sc.cc): init(2*n) -> set_local_code_and_taps ->
+     * set_input_output_vectors -> Carrier_wipeoff_multicorrelator_resampler.  code / in / out: interleaved int16 I, Q.
+     */
+    int ref_mcorr16_run(const int16_t* code_iq, int code_len, const float* shifts, int n_taps, const int16_t* in_iq, int n,
+        float rem_carr, float phase_step, float rem_code, float code_step, int16_t* out_iq)
+    {
+        Cpu_Multicorrelator_16sc mc;
+        std::vector<float> taps(shifts, shifts + n_taps);
+        std::vector<lv_16sc_t> out(n_taps);
+        mc.init(2 * n, n_taps);
+        mc.set_local_code_and_taps(code_len, reinterpret_cast<const lv_16sc_t*>(code_iq), taps.data());
+        mc.set_input_output_vectors(out.data(), reinterpret_cast<const lv_16sc_t*>(in_iq));
+        mc.Carrier_wipeoff_multicorrelator_resampler(rem_carr, phase_step, rem_code, code_step, n);
+        std::memcpy(out_iq, out.data(), sizeof(int16_t) * 2 * n_taps);
+        mc.free();
+        return 0;
+    }
+
+    /* the two phasors the class hands to the kernel, formed by the same expressions (cpu_multicorrelator_16sc.cc:89-93) in this library's C++ */
+    void ref_mcorr16_phasors(float rem_carr, float phase_step, float* out4)
+    {
+        const lv_32fc_t p0 = lv_cmake(std::cos(rem_carr), -std::sin(rem_carr));
+        const lv_32fc_t inc = std::exp(lv_32fc_t(0, -phase_step));
+        out4[0] = p0.real();
+        out4[1] = p0.imag();
+        out4[2] = inc.real();
+        out4[3] = inc.imag();
+    }
+
+    /* epochs back-to-back calls of one 16-bit object over consecutive windows of a stream: seconds (the timing leg of bench.py's 16-bit entry) */
+    double ref_mcorr16_time(const int16_t* code_iq, int code_len, const float* shifts, int n_taps, const int16_t* stream_iq, long stream_len, int n,
+        int epochs, float rem_carr, float phase_step, float rem_code, float code_step, int16_t* out_iq)
+    {
+        Cpu_Multicorrelator_16sc mc;
+        std::vector<float> taps(shifts, shifts + n_taps);
+        std::vector<lv_16sc_t> out(n_taps);
+        mc.init(2 * n, n_taps);
+        mc.set_local_code_and_taps(code_len, reinterpret_cast<const lv_16sc_t*>(code_iq), taps.data());
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int e = 0; e < epochs; e++)
+            {
+                const long off = (static_cast<long>(e) * n) % (stream_len - n + 1);
+                mc.set_input_output_vectors(out.data(), reinterpret_cast<const lv_16sc_t*>(stream_iq) + off);
+                mc.Carrier_wipeoff_multicorrelator_resampler(rem_carr, phase_step, rem_code, code_step, n);
+            }
+        const auto t1 = std::chrono::steady_clock::now();
+        std::memcpy(out_iq, out.data(), sizeof(int16_t) * 2 * n_taps);
+        mc.free();
+        return std::chrono::duration<double>(t1 - t0).count();
     }
 
     /*

@@ -22,6 +22,8 @@
  *   volk_gnsssdr_32fc_32f_high_dynamic_rotator_dot_prod_32fc_xn.h :68 generic
  *   volk_gnsssdr_s32f_sincos_32fc.h                             :390 generic
  *   volk_gnsssdr_32f_index_max_32u.h                            :446 generic
+ *   volk_gnsssdr_16ic_xn_resampler_16ic_xn.h                    :60 generic, :438 u_avx
+ *   volk_gnsssdr_16ic_x2_rotator_dot_prod_16ic_xn.h             :66 generic, :596 u_sse3
  */
 #include <stdlib.h>
 #include <string.h>
@@ -47,6 +49,8 @@
 #include "volk_gnsssdr_s32f_sincos_32fc.h"
 #include "volk_gnsssdr_32f_index_max_32u.h"
 #include "volk_gnsssdr_16ic_convert_32fc.h"
+#include "volk_gnsssdr_16ic_xn_resampler_16ic_xn.h"
+#include "volk_gnsssdr_16ic_x2_rotator_dot_prod_16ic_xn.h"
 
 void FLV(resampler)(float** result, const float* local_code, float rem, float step,
     float* shifts, unsigned int code_len, int n_vec, unsigned int n)
@@ -83,6 +87,27 @@ void FLV(hd_rotator_dot_prod)(lv_32fc_t* result, const lv_32fc_t* in, const lv_3
 {
     /* only generic protokernels exist for this kernel */
     volk_gnsssdr_32fc_32f_high_dynamic_rotator_dot_prod_32fc_xn_generic(result, in, phase_inc, phase_inc_rate, phase, in_a, n_vec, n);
+}
+
+/* the 16-bit family */
+void FLV(resampler_16ic)(lv_16sc_t** result, const lv_16sc_t* local_code, float rem, float step,
+    float* shifts, unsigned int code_len, int n_vec, unsigned int n)
+{
+#if defined(REF_FLAVOUR_SIMD)
+    volk_gnsssdr_16ic_xn_resampler_16ic_xn_u_avx(result, local_code, rem, step, shifts, code_len, n_vec, n);
+#else
+    volk_gnsssdr_16ic_xn_resampler_16ic_xn_generic(result, local_code, rem, step, shifts, code_len, n_vec, n);
+#endif
+}
+
+void FLV(rotator_dot_prod_16ic)(lv_16sc_t* result, const lv_16sc_t* in, const lv_32fc_t phase_inc,
+    lv_32fc_t* phase, const lv_16sc_t** in_a, int n_vec, unsigned int n)
+{
+#if defined(REF_FLAVOUR_SIMD)
+    volk_gnsssdr_16ic_x2_rotator_dot_prod_16ic_xn_u_sse3(result, in, phase_inc, phase, in_a, n_vec, n);
+#else
+    volk_gnsssdr_16ic_x2_rotator_dot_prod_16ic_xn_generic(result, in, phase_inc, phase, in_a, n_vec, n);
+#endif
 }
 
 #if !defined(REF_FLAVOUR_SIMD)

@@ -44,6 +44,15 @@ void volk_gnsssdr_32fc_32f_high_dynamic_rotator_dot_prod_32fc_xn(lv_32fc_t* resu
     const lv_32fc_t* in_common, const lv_32fc_t phase_inc, const lv_32fc_t phase_inc_rate,
     lv_32fc_t* phase, const float** in_a, int num_a_vectors, unsigned int num_points);
 
+/* the 16-bit family's two dispatchers (cpu_multicorrelator_16sc.cc:68-75,93) */
+void volk_gnsssdr_16ic_xn_resampler_16ic_xn(lv_16sc_t** result, const lv_16sc_t* local_code,
+    float rem_code_phase_chips, float code_phase_step_chips, float* shifts_chips,
+    unsigned int code_length_chips, int num_out_vectors, unsigned int num_points);
+
+void volk_gnsssdr_16ic_x2_rotator_dot_prod_16ic_xn(lv_16sc_t* result, const lv_16sc_t* in_common,
+    const lv_32fc_t phase_inc, lv_32fc_t* phase, const lv_16sc_t** in_a, int num_a_vectors,
+    unsigned int num_points);
+
 /* dispatchers the acquisition blocks call (pcps_acquisition.cc:280,419,466,512,655); bound to the `_generic` protokernels */
 void volk_gnsssdr_s32f_sincos_32fc(lv_32fc_t* out, const float phase_inc, float* phase, unsigned int num_points);
 void volk_gnsssdr_32f_index_max_32u(uint32_t* target, const float* src0, uint32_t num_points);

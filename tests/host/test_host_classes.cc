@@ -4,6 +4,7 @@
 // Built by __graft_entry__.build(); run by tests/test_host_classes_gpu.py.  Prints "HOST CLASSES OK" on success.
 #include "gnss_oracle.h"
 #include "hip_multicorrelator_real_codes.h"
+#include "hip_multicorrelator_16sc.h"
 #include "hip_pcps_acquisition_core.h"
 #include "hip_pcps_detectors.h"
 #include "hip_acq_resampler.h"
@@ -102,6 +103,42 @@ int main()
         // use before init must fail loudly, not compute garbage
         Hip_Multicorrelator_Real_Codes cold;
         EXPECT(!cold.Carrier_wipeoff_multicorrelator_resampler(0.F, 0.F, 0.F, 0.F, 0.1F, 0.F, 100), "uninitialised correlate must fail");
+    }
+    // ---------------------------------------------------------------- the 16-bit correlator (Cpu_Multicorrelator_16sc's call pattern), bit for bit
+    {
+        const int n = 25000, n_taps = 3;
+        std::mt19937 gen(16);
+        std::uniform_int_distribution<int> amp(-60, 60);
+        std::vector<std::complex<int16_t>> in(n + 40), code(1023), outs(n_taps);
+        for (auto& v : in) v = std::complex<int16_t>(static_cast<int16_t>(amp(gen)), static_cast<int16_t>(amp(gen)));
+        std::vector<float> ca(1023);
+        oracle_gps_l1_ca_code_gen_float(ca.data(), 5, 0);
+        for (int i = 0; i < 1023; i++) code[i] = std::complex<int16_t>(static_cast<int16_t>(ca[i]), 0);
+        std::vector<float> shifts = {-0.5F, 0.0F, 0.5F};
+        Hip_Multicorrelator_16sc mc;
+        EXPECT(mc.init(2 * n, n_taps), "16sc init: %s", mc.last_error().c_str());
+        EXPECT(mc.set_local_code_and_taps(1023, code.data(), shifts.data()), "16sc set_local_code_and_taps: %s", mc.last_error().c_str());
+        for (int epoch = 0; epoch < 3; epoch++)
+            {
+                const std::complex<int16_t>* win = in.data() + epoch * 13;
+                const float rem_carr = 0.4F + 1.1F * epoch, phase_step = 0.0123F * (epoch - 1), rem_code = 0.37F * epoch, code_step = 0.04092F;
+                EXPECT(mc.set_input_output_vectors(outs.data(), win), "16sc set_input_output_vectors");
+                EXPECT(mc.Carrier_wipeoff_multicorrelator_resampler(rem_carr, phase_step, rem_code, code_step, n), "16sc correlate: %s", mc.last_error().c_str());
+                int16_t want[6];
+                oracle_mcorr16(reinterpret_cast<const int16_t*>(code.data()), 1023, shifts.data(), n_taps, reinterpret_cast<const int16_t*>(win), n, rem_carr, phase_step, rem_code,
+                    code_step, want);
+                for (int t = 0; t < n_taps; t++)
+                    EXPECT(outs[t].real() == want[2 * t] && outs[t].imag() == want[2 * t + 1], "16sc epoch %d tap %d: (%d, %d) against the oracle's (%d, %d)", epoch, t,
+                        outs[t].real(), outs[t].imag(), want[2 * t], want[2 * t + 1]);
+                if (epoch == 0) shifts[2] = 0.25F;  // borrowed taps, changed in place
+            }
+        mc.update_local_code(n, 0.25F, 0.04F);
+        EXPECT(mc.last_error().empty(), "16sc update_local_code: %s", mc.last_error().c_str());
+        EXPECT(mc.free(), "16sc free");
+        Hip_Multicorrelator_16sc cold;
+        outs[0] = std::complex<int16_t>(7, 7);
+        cold.set_input_output_vectors(outs.data(), in.data());
+        EXPECT(!cold.Carrier_wipeoff_multicorrelator_resampler(0.F, 0.F, 0.F, 0.1F, 100), "16sc: an uninitialised correlate must fail");
     }
     // ---------------------------------------------------------------- acquisition, pcps_acquisition call pattern
     {
