@@ -464,7 +464,7 @@ def pcie_inclusive_metric(torch, dev_index, x_dev, jobs, C, E, T, n_samples, rep
                     "gsh_stream_push_async, next block's copy overlapped with this block's correlation; `sequential`: nothing overlapped"}
 
 
-def closed_loop_metric(dev_index, x_dev, n_samples, fs, n, dop, cph, channels=32, epochs=200, lock_detectors=False, live=False):
+def closed_loop_metric(dev_index, x_dev, n_samples, fs, n, dop, cph, channels=32, epochs=200, lock_detectors=False, live=False, split=1):
     """Secondary metric: the DLL/PLL loop closed on the device (gsh_trk_*), BASELINE config 2 shape -- every channel runs
     `epochs` consecutive code periods with its own discriminators / loop filters / NCO update between them, one launch."""
     try:
@@ -478,6 +478,8 @@ def closed_loop_metric(dev_index, x_dev, n_samples, fs, n, dop, cph, channels=32
                     max_code_lock_fail=1 << 30)
     loop = TrackingLoop(conf, channels, 1023, device=dev_index)
     loop.set_stream_device(x_dev.data_ptr(), n_samples, keepalive=x_dev)
+    if split > 1:
+        loop.set_split(split)  # gsh_trk_set_split: `split` cooperating work-groups share every window of a channel
     rng = np.random.default_rng(0x5EED0006)
     for c in range(channels):
         if c < len(dop):  # hand-over from a (simulated) acquisition: code start of the embedded signal, Doppler off by <= 20 Hz
@@ -497,6 +499,7 @@ def closed_loop_metric(dev_index, x_dev, n_samples, fs, n, dop, cph, channels=32
     loop.close()
     out = {"metric": "correlators/s, loop closed on device", "value": channels * 3 * epochs / (ms * 1e-3), "unit": "correlators/s",
            "ms_per_launch": ms, "us_per_epoch": ms * 1e3 / epochs, "channels": channels, "epochs_per_launch": epochs, "lock_detectors": bool(lock_detectors),
+           "work_groups_per_channel": split,
            "channels_with_signal_locked": f"{locked}/{min(channels, len(dop))}",
            "real_time_factor": epochs * 1e-3 / (ms * 1e-3)}
     # what binds it: the correlation's vector instructions (6 + 4 T flops per channel-sample) on the compute units the channels occupy -- one each
@@ -517,7 +520,7 @@ def closed_loop_metric(dev_index, x_dev, n_samples, fs, n, dop, cph, channels=32
     return out
 
 
-def closed_loop_config4_metric(torch, dev_index, channels=50, epochs=60):
+def closed_loop_config4_metric(torch, dev_index, channels=50, epochs=60, split=1):
     """BASELINE config 4 with the loop closed on the device: Galileo E1, 50 channels, fs 32 Msps, 4 ms windows of 128 000 samples, VE/E/P/L/VL on the pilot (E1C) + the data
     prompt (E1B) = 5 + 1 correlators per channel-period (trk.cc:1246-1256), lock detectors on.  One launch of `epochs` periods per channel over a resident stream
     (noise + four E1 signals at 45 dB-Hz so that some channels really track; the others run noise-driven, which costs the same)."""
@@ -543,6 +546,8 @@ def closed_loop_config4_metric(torch, dev_index, channels=50, epochs=60):
                     max_carrier_lock_fail=1 << 30, max_code_lock_fail=1 << 30)
     loop = TrackingLoop(conf, channels, 8184, device=dev_index)
     loop.set_stream_device(x.data_ptr(), n_stream, keepalive=x)
+    if split > 1:
+        loop.set_split(split)
     rng = np.random.default_rng(0x5EED0007)
     for c in range(channels):
         if c in starts:
@@ -559,10 +564,11 @@ def closed_loop_config4_metric(torch, dev_index, channels=50, epochs=60):
     peak = 157.3e12
     return {"metric": "correlators/s, loop closed on device, BASELINE config 4", "workload": f"Galileo E1, {channels} channels, fs 32 Msps, 128000-sample (4 ms) windows, 5 + 1 taps, lock detectors on",
             "value": channels * corr * epochs / (ms * 1e-3), "unit": "correlators/s", "ms_per_launch": ms, "us_per_epoch": ms * 1e3 / epochs, "channels": channels,
-            "epochs_per_launch": epochs, "channels_with_signal_locked": f"{locked}/{sum(1 for c in starts if c < channels)}", "real_time_factor": epochs * 4e-3 / (ms * 1e-3),
+            "epochs_per_launch": epochs, "work_groups_per_channel": split, "channels_with_signal_locked": f"{locked}/{sum(1 for c in starts if c < channels)}",
+            "real_time_factor": epochs * 4e-3 / (ms * 1e-3),
             "roofline": {"bound": "valu", "achieved": flops / (ms * 1e-3) / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": flops / (ms * 1e-3) / peak,
-                         "frac_of_the_compute_units_in_use": flops / (ms * 1e-3) / (peak * min(channels, 256) / 256.0),
-                         "note": "one compute unit per channel (50 of 256); a 4 ms period is 128000 samples x (5 pilot taps + the data prompt) = 62.5 trips of 2048 samples per wave"}}
+                         "frac_of_the_compute_units_in_use": flops / (ms * 1e-3) / (peak * min(channels * split, 256) / 256.0),
+                         "note": "one compute unit per channel and cooperating work-group (50 x split of 256); a 4 ms period is 128000 samples x (5 pilot taps + the data prompt) = 62.5 trips of 2048 samples per wave"}}
 
 
 def closed_loop_live(dev_index, x_dev, n_samples, fs, n, dop, cph, channels, epochs, conf):
@@ -798,6 +804,9 @@ def bench_summary(res):
          "closed_loop_us": get(res, "closed_loop", "us_per_epoch"), "closed_loop_detectors_us": get(res, "closed_loop_lock_detectors", "us_per_epoch"),
          "closed_loop_live_us": get(res, "closed_loop_lock_detectors", "live", "us_per_epoch"), "closed_loop_256ch_us": get(res, "closed_loop_256ch", "us_per_epoch"),
          "closed_loop_config4_us": get(res, "closed_loop_config4", "us_per_epoch"),
+         "closed_loop_config2_2wg_us": get(res, "closed_loop_cooperating", "config2_2_work_groups", "us_per_epoch"),
+         "closed_loop_config4_4wg_us": get(res, "closed_loop_cooperating", "config4_4_work_groups", "us_per_epoch"),
+         "mcorr16_Mcorr_s": (get(res, "other_configs", "mcorr16_config2_shape", "correlators_per_s") or 0) / 1e6,
          "dropin_20_Mcps": get(res, "dropin", "value"), "dropin_1_Mcps": get(res, "dropin", "one_period_per_call", "value"),
          "rccl_ranks_exercised": get(res, "rccl_one_rank", "communicator_ranks"), "rccl_version": get(res, "rccl_one_rank", "rccl_version"),
          "cpu_baseline_Mcorr_s": (get(res, "cpu_baseline", "value") or 0) / 1e6}
@@ -1129,6 +1138,14 @@ def main():
                 res["closed_loop_config4"] = closed_loop_config4_metric(torch, local)
             except Exception as e:
                 res["closed_loop_config4"] = {"error": str(e)}
+            # the same two shapes with cooperating work-groups (gsh_trk_set_split: an option -- sums in another order, records equal to rounding): where the
+            # channels leave most of the chip idle and a window is long, several compute units share every window of a channel
+            try:
+                res["closed_loop_cooperating"] = {
+                    "config2_2_work_groups": closed_loop_metric(local, x0, block, fs, n, dop, cph, channels=C, epochs=min(E - 2, 200), lock_detectors=True, split=2),
+                    "config4_4_work_groups": closed_loop_config4_metric(torch, local, split=4)}
+            except Exception as e:
+                res["closed_loop_cooperating"] = {"error": str(e)}
             if not a.no_other_configs:
                 try:
                     res["other_configs"] = other_configs_metric(local)

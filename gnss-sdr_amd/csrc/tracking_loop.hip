@@ -3018,10 +3018,22 @@ extern "C"
     int gsh_trk_set_split(gsh_trk_t* t, int work_groups_per_channel)
     {
         GSH_REQUIRE(t != nullptr, "null handle");
-        GSH_REQUIRE(work_groups_per_channel >= 1 && work_groups_per_channel <= 8, "work_groups_per_channel %d outside 1..8", work_groups_per_channel);
+        GSH_REQUIRE(work_groups_per_channel >= 0 && work_groups_per_channel <= 8, "work_groups_per_channel %d outside 0..8", work_groups_per_channel);
         if (t->pending_epochs >= 0) return set_error(GSH_ERR_STATE, "gsh_trk_set_split: a run has been begun and not ended");
         GSH_HIP(hipSetDevice(t->device));
         if (live_reap(t) != 0) return set_error(GSH_ERR_STATE, "gsh_trk_set_split: a live residency is in flight (gsh_trk_live_quiesce first)");
+        if (work_groups_per_channel == 0)
+            {
+                // by the window's length in trips and the compute units the channels leave free (measured, profiles/ab/r06/session17.txt: 7 trips -- 25 000 samples,
+                // E/P/L -- 7.27 -> 6.74 us with two and no gain beyond; 62.5 trips -- 128 000 samples, 5 + 1 taps -- 36.5 -> 22.0 / 18.0 / 16.1 us with two / three / four)
+                hipDeviceProp_t prop;
+                GSH_HIP(hipGetDeviceProperties(&prop, t->device));
+                const int trip = (!t->conf.veml && !t->conf.track_pilot) ? 4 * gsh::mcdev::MC_THREADS : 2 * gsh::mcdev::MC_THREADS;
+                const int trips = (static_cast<int>(t->conf.vector_length) + trip - 1) / trip;
+                const int room = prop.multiProcessorCount / ((t->n_channels + 7) / 8 * 8);
+                const int want = trips >= 24 ? 4 : (trips >= 12 ? 3 : (trips >= 6 ? 2 : 1));
+                work_groups_per_channel = t->conf.high_dyn ? 1 : std::max(1, std::min(want, room));
+            }
         if (work_groups_per_channel > 1)
             {
                 GSH_REQUIRE(!t->conf.high_dyn, "cooperating work-groups exist for the standard correlator (high_dyn = 0)");

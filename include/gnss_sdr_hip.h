@@ -523,7 +523,9 @@ extern "C"
      * correlation saves, so this is an option, not the default.  The sums are
      * formed in another order than with one work-group per channel, so records agree with that form to rounding (same bars against the oracle), not bit for bit;
      * live residencies always run one work-group per channel.  Needs (ceil(n_channels / 8) x 8 x work_groups_per_channel) compute units free at once; a partner
-     * that does not get to run within 0.2 s ends the run with GSH_ERR_STATE instead of hanging the device.  1 = off (default). */
+     * that does not get to run within 0.2 s ends the run with GSH_ERR_STATE instead of hanging the device.  1 = off (default).
+     * Where it pays is the LONG window: BASELINE config 4 (50 channels, 128 000 samples, 5 + 1 taps) 36.5 us per period with one work-group, 22.0 with two,
+     * 16.1 with four.  0 = choose by the window's length in trips and the compute units the channels leave free (2 for 25 000-sample E/P/L windows, 4 for config 4). */
     int gsh_trk_set_split(gsh_trk_t* t, int work_groups_per_channel);
     /* the same in two halves, for a caller that serialises launches against pushes into the ring itself (Hip_Tracking_Runtime): _begin queues
      * the launch on the loop's stream -- the kernel writes its results into page-locked host memory itself (GSH_TRK_HOST_RECORDS=0 in the environment:
