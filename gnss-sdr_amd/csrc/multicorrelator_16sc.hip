@@ -503,13 +503,14 @@ extern "C"
         GSH_REQUIRE(b != nullptr && (iq != nullptr || n_samples == 0), "null argument");
         GSH_HIP(hipSetDevice(b->device));
         GSH_HIP(hipStreamSynchronize(b->stream));
-        if (n_samples > b->stream_owned_cap)
+        if (n_samples > b->stream_owned_cap || b->d_stream_owned == nullptr)
             {
                 if (b->d_stream_owned) GSH_HIP(hipFree(b->d_stream_owned));
                 b->d_stream_owned = nullptr;
                 b->stream_owned_cap = 0;
-                GSH_HIP(hipMalloc(&b->d_stream_owned, sizeof(short2) * static_cast<size_t>(n_samples)));
-                b->stream_owned_cap = static_cast<size_t>(n_samples);
+                const size_t cap = std::max<size_t>(static_cast<size_t>(n_samples), 64);  // (an empty stream is a stream: a call over zero samples answers zeros, as the reference's loop does)
+                GSH_HIP(hipMalloc(&b->d_stream_owned, sizeof(short2) * cap));
+                b->stream_owned_cap = cap;
             }
         if (n_samples > 0) GSH_HIP(hipMemcpy(b->d_stream_owned, iq, sizeof(short2) * static_cast<size_t>(n_samples), hipMemcpyHostToDevice));
         b->d_stream = b->d_stream_owned;

@@ -148,4 +148,7 @@ def test_errors_are_reported_not_computed(gpu):
     mc.set_input_output_vectors(out, np.zeros((100, 2), np.int16))
     with pytest.raises(GshError):
         mc.Carrier_wipeoff_multicorrelator_resampler(0.0, 0.0, 0.0, 0.1, 101)  # longer than init() sized
+    out[:] = 5
+    mc.Carrier_wipeoff_multicorrelator_resampler(0.0, 0.0, 0.0, 0.1, 0)  # zero samples: the reference's loop leaves zeros
+    assert not out.any()
     mc.close()
