@@ -688,6 +688,55 @@ __device__ __forceinline__ void packed_trip(const JobCtx& c, const float* __rest
         }
 }
 
+// EARLY CODES (round 6 experiment, GSH_MC_EARLY_CODES): the both-chunks-paired trip in two halves, so that the caller can issue the trip's eight look-ups BEFORE it
+// waits for the trip's samples and rotates them -- the chip-index chains need no sample, so they cover the tail of the loads' latency, and the rotations cover the
+// look-ups' -- instead of wait, rotate, chains, look-ups, wait, accumulate.  Same instructions, same products, same order of summation.
+struct PairedCodes
+{
+    v2f p, el0, el1;
+};
+template <bool ZP, bool KC>
+__device__ __forceinline__ PairedCodes paired_codes_of(const JobCtx& c, const float* __restrict__ tab, v2f shP, v2f shL, v2f k_step_nrem, v2f nf)
+{
+    typedef const __attribute__((address_space(3))) float* lds_float_ptr;
+    const int koff = KC ? MC_MARGIN : c.k_off;
+    const v2f a = pk_mul_slo(nf, k_step_nrem);
+    auto at = [&](int k, int d) -> float {
+        if constexpr (KC)
+            {
+                unsigned byte_addr;
+                asm("v_lshlrev_b32 %0, 2, %1" : "=v"(byte_addr) : "v"(k));
+                return reinterpret_cast<lds_float_ptr>(byte_addr)[MC_MARGIN + d];
+            }
+        else
+            return tab[k + koff + d];
+    };
+    PairedCodes d;
+    {
+        const v2f u = ZP ? pk_add_shi(a, k_step_nrem) : pk_add_shi(pk_add_slo(a, shP), k_step_nrem);
+        d.p.x = at(floor_to_int(u.x), 0);
+        d.p.y = at(floor_to_int(u.y), 0);
+    }
+    {
+        const v2f u = pk_add_shi(pk_add_slo(a, shL), k_step_nrem);
+        const int k0 = floor_to_int(u.x), k1 = floor_to_int(u.y);
+        d.el0.x = at(k0, -1);
+        d.el0.y = at(k0, 0);
+        d.el1.x = at(k1, -1);
+        d.el1.y = at(k1, 0);
+    }
+    return d;
+}
+__device__ __forceinline__ void paired_accumulate(const PairedCodes& d, v2f y0, v2f y1, v2f (&S0)[3], v2f (&S1)[3])
+{
+    pk_fma_lo(S0[0], y0, d.el0);
+    pk_fma_lo(S1[0], y1, d.el1);
+    pk_fma_lo(S0[1], y0, d.p);
+    pk_fma_hi(S1[1], y1, d.p);
+    pk_fma_hi(S0[2], y0, d.el0);
+    pk_fma_hi(S1[2], y1, d.el1);
+}
+
 // The whole segment on the packed path -- head, body and tail are trips of ONE loop.
 // Carrier phasors: a lane needs exp(-j (rem + n step)) for its own samples at every exact re-seed.  Evaluating that per lane (a double-
 // precision range reduction + sincosf, ~70 VALU instructions) a dozen times per window cost as much as a third of the hot loop (PMC, round 2:
@@ -996,6 +1045,17 @@ __device__ __forceinline__ void run_segment_packed(const JobCtx& c, const float2
                 const int m0 = n0 + 2 * PPC;
                 if (NCH == 2) ib = (v2f){static_cast<float>(min(max(m0, lo), hi)), static_cast<float>(min(max(m0 + 1, lo), hi))};
             }
+#ifndef GSH_MC_EARLY_CODES
+#define GSH_MC_EARLY_CODES 0
+#endif
+        constexpr bool EARLY_CODES = GSH_MC_EARLY_CODES && FA && FB && NCH == 2 && NT == 3 && !AUX && !MRG;
+        PairedCodes dA, dB;
+        if constexpr (EARLY_CODES)
+            {
+                dA = paired_codes_of<ZP, KC>(c, tab, shp[1], shp[2], k_step_nrem, ia);
+                dB = paired_codes_of<ZP, KC>(c, tab, shp[1], shp[2], k_step_nrem, ib);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         // rotate first: the samples' registers are then free for the loads of trip i + PF, which take this trip's place in the queue
         v2f yA0, yA1, yB0 = zero, yB1 = zero;
         if constexpr (MRG)
@@ -1020,7 +1080,16 @@ __device__ __forceinline__ void run_segment_packed(const JobCtx& c, const float2
                     }
             }
         if (i + PF < n_trips) load_trip(i + PF, qa[j], qb[j]);  // uniform
-        if constexpr (MRG)  // (one set: the four references name the same registers, the accumulates follow one another)
+        if constexpr (EARLY_CODES)
+            {
+                if constexpr (NT == 3)
+                    {
+                        __builtin_amdgcn_sched_barrier(0);
+                        paired_accumulate(dA, yA0, yA1, A0, A1);
+                        paired_accumulate(dB, yB0, yB1, B0, B1);
+                    }
+            }
+        else if constexpr (MRG)  // (one set: the four references name the same registers, the accumulates follow one another)
             packed_trip<NT, ZP, AUX, NCH, FA, FB, KC>(c, tab, shp, k_step_nrem, aux_shp, aux_on, ia, ib, yA0, yA1, yB0, yB1, A0, A0, A0, A0, XA0, XA0, XA0, XA0);
         else
             packed_trip<NT, ZP, AUX, NCH, FA, FB, KC>(c, tab, shp, k_step_nrem, aux_shp, aux_on, ia, ib, yA0, yA1, yB0, yB1, A0, A1, B0, B1, XA0, XA1, XB0, XB1);
