@@ -229,6 +229,9 @@ void DllPllTrackingHip::create_tracking_block(const ConfigurationInterface* conf
         }
     // live mode's watchdog: a resident window without a record for this long = the device is not delivering; the channel is given up ("events" 3)
     runtime->set_record_timeout_ms(configuration->property(role_ + ".hip_record_timeout_ms", 1000));
+    // launched mode: work-groups that share every window of a channel (hip_tracking_runtime.h); the blocks of a role share the runtime, the first one's value stands
+    if (configuration->property(role_ + ".hip_work_groups_per_channel", 1) != 1)
+        runtime->set_work_groups_per_channel(configuration->property(role_ + ".hip_work_groups_per_channel", 1));
     tracking_sptr_ = dll_pll_veml_make_tracking_hip(trk_params_, periods, std::move(runtime));
     if (!tracking_sptr_->usable())
         {

@@ -26,6 +26,8 @@
  *                                  -1            a runtime and ring of the block's own
  *   <role>.hip_periods_per_launch   launched mode: most code periods per channel one shared launch runs (max(16, hip_periods_per_call))
  *   <role>.hip_channels_per_launch  most channels of one loop configuration behind one device handle (64: one work-group each; a further handle beyond that)
+ *   <role>.hip_work_groups_per_channel   launched mode (hip_live=false) only: 1 (default); 2 .. 8 compute units share every correlation window of a channel, 0 lets the
+ *                                engine choose (gsh_trk_set_split) -- for long windows (Galileo E1: 4 ms) on a device with room; sums equal to rounding
  *   <role>.hip_record_timeout_ms    live mode: a channel whose next window has been resident this long without a record from the device is given up -- the block
  *                                publishes "events" 3 and the channel goes back to acquisition (1000; the device needs ~10 us per period)
  *   <role>.hip_register_input_buffer  page-lock the block's input buffer (lazily, as general_work shows it) so that pushes are DMAs without a

@@ -29,6 +29,7 @@ Hip_Tracking_Runtime::Hip_Tracking_Runtime(int device, std::shared_ptr<Hip_Sampl
 {
     if (const char* e = std::getenv("GSH_TRK_LAUNCH_AHEAD")) d_launch_ahead = (std::atoi(e) != 0);
     if (const char* e = std::getenv("GSH_TRK_LIVE")) d_live = (std::atoi(e) != 0);
+    if (const char* e = std::getenv("GSH_TRK_WORK_GROUPS")) set_work_groups_per_channel(std::atoi(e));  // (tests: <role>.hip_work_groups_per_channel)
     if (const char* e = std::getenv("GSH_TRK_LIVE_SPIN_US")) d_spin_us = d_spin_us_single = std::max(0, std::atoi(e));
     if (const char* e = std::getenv("GSH_TRK_LIVE_SLEEP_US")) d_sleep_us = d_sleep_us_single = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("GSH_TRK_LIVE_SPIN_US_SINGLE")) d_spin_us_single = std::max(0, std::atoi(e));
@@ -77,6 +78,8 @@ Hip_Tracking_Runtime::Group* Hip_Tracking_Runtime::group_for(const gsh_trk_conf&
             gsh_trk_destroy(g->trk);
             return nullptr;
         }
+    // cooperating work-groups (launched mode): a request the engine refuses for this handle leaves it with one work-group per channel
+    if (!d_live && d_work_groups_per_channel != 1 && gsh_trk_set_split(g->trk, d_work_groups_per_channel) != GSH_OK) (void)gsh_trk_set_split(g->trk, 1);
     g->slot_of_channel.assign(static_cast<size_t>(d_channels_per_group), -1);
     g->records.resize(static_cast<size_t>(d_channels_per_group) * static_cast<size_t>(d_periods_per_launch));
     g->done.assign(static_cast<size_t>(d_channels_per_group), 0);

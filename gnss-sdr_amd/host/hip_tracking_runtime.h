@@ -79,6 +79,13 @@ public:
         then publishes "events" 3 and the channel goes back to acquisition) -- a residency that never reports must not leave a block calling take() for ever.
         Default 1000 ms (the device needs ~10 us per period); <role>.hip_record_timeout_ms. */
     void set_record_timeout_ms(int ms) { d_record_timeout_ns.store(static_cast<int64_t>(std::max(ms, 1)) * 1000000); }
+    /*! launched mode only (live residencies keep one work-group per channel): work-groups that share every window of a channel, gsh_trk_set_split -- 1 (default)
+        one, 2 .. 8 that many, 0 the engine's own choice by window length and free compute units.  Worth it for long windows on a device with room (Galileo E1's
+        128 000-sample periods: 36.5 -> 16 us per period with four); the sums are those of another order of summation, equal to rounding.  A handle on which the
+        engine refuses the request (high dynamics, more work-groups than the device holds at once) runs with one.  <role>.hip_work_groups_per_channel;
+        call before the first block attaches. */
+    void set_work_groups_per_channel(int n) { d_work_groups_per_channel = std::min(std::max(n, 0), 8); }
+    int work_groups_per_channel() const { return d_work_groups_per_channel; }
     ~Hip_Tracking_Runtime();
     Hip_Tracking_Runtime(const Hip_Tracking_Runtime&) = delete;
     Hip_Tracking_Runtime& operator=(const Hip_Tracking_Runtime&) = delete;
@@ -179,6 +186,7 @@ private:
     int d_channels_per_group;
     bool d_launch_ahead{true};
     bool d_live{true};
+    int d_work_groups_per_channel{1};  // launched mode: gsh_trk_set_split of every handle opened
     bool d_push_try{true};                 // live mode: a block that finds the ring busy does not queue up behind the thread that is appending
     bool d_push_spare_slowest{true};
     int d_push_batch{2};                    // live mode: appends smaller than this many code periods wait for more (while the device has work in hand)

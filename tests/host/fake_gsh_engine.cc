@@ -597,6 +597,7 @@ extern "C"
     // ---- live mode.  The stand-in "device" works at take time: what a resident kernel would have finished by now -- every period whose window lies in
     // the fake ring while a residency is in flight -- is moved to the channel's queue of finished records, then handed out under the same rules as the
     // library's gsh_trk_live_take.  A residency ends by itself after a bounded number of records (the kernel's time budget, in miniature).
+    int gsh_trk_set_split(gsh_trk_t* t, int g) { return (t != nullptr && g >= 0 && g <= 8) ? GSH_OK : gsh::set_error(GSH_ERR_INVALID, "gsh_trk_set_split"); }
     int gsh_trk_live_configure(gsh_trk_t* t, uint32_t, uint32_t) { return t != nullptr ? GSH_OK : gsh::set_error(GSH_ERR_INVALID, "null handle"); }
     int gsh_trk_live_begin(gsh_trk_t* t)
     {

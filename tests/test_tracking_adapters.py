@@ -117,6 +117,17 @@ def test_tracking_adapters_follow_the_reference_block(gpu):
     assert r.returncode == 0 and "TRACKING ADAPTERS OK" in r.stdout, r.stdout[-6000:] + r.stderr[-2000:]
 
 
+@pytest.mark.gpu
+def test_tracking_adapters_in_launched_mode_with_cooperating_work_groups(gpu):
+    """<role>.hip_live=false + <role>.hip_work_groups_per_channel=2 (here through the runtime's test switches): every handle the runtime opens runs its launches
+    with two work-groups per channel (gsh_trk_set_split); the thirteen signals' trajectories, restarts, dump files and the 32 blocks of the shared stream are
+    compared with the reference's own blocks as in the default mode -- the sums differ from the one-work-group form's by rounding only."""
+    r = subprocess.run([_bin()], capture_output=True, text=True, timeout=900, cwd="/tmp", env=dict(os.environ, GSH_TRK_LIVE="0", GSH_TRK_WORK_GROUPS="2"))
+    keep = ("FAIL", "periods", "shared stream", "OK", "failure")
+    print("\n".join(l for l in r.stdout.splitlines() if any(k in l for k in keep))[-4000:])
+    assert r.returncode == 0 and "TRACKING ADAPTERS OK" in r.stdout, r.stdout[-6000:] + r.stderr[-2000:]
+
+
 # ---- the reference's own Channel / ChannelFsm / channel_msg_receiver_cc over the HIP adapters (tests/host/test_channel.cc, round 5) ---------------------------------------------
 CHAN = os.path.join(ROOT, "tests", "host", "test_channel")
 
