@@ -30,7 +30,7 @@ extern "C"
 {
 #endif
 
-#define GSH_ABI_VERSION 24
+#define GSH_ABI_VERSION 25
 #define GSH_MAX_TAPS 8 /* VE/E/P/L/VL needs 5 (trk.cc:609-650); 8 leaves room for multi-tap dumps */
 
     enum

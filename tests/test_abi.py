@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol(gsh):
     declared = _header_functions()
     assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
     assert _lib.missing_symbols() == []
-    assert gsh.gsh_abi_version() == 24
+    assert gsh.gsh_abi_version() == 25
 
 
 def test_struct_layouts_match_header():
