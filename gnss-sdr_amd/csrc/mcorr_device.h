@@ -50,6 +50,12 @@ constexpr int MC_MARGIN = 32;  // guard entries on each side of the LDS code tab
 #ifndef GSH_MC_CVT_FLR
 #define GSH_MC_CVT_FLR 1
 #endif
+#ifndef GSH_MC_PKRTZ
+#define GSH_MC_PKRTZ 1  // the paired trip's eight floor() + convert as four v_cvt_pkrtz_f16_f32 over chains scaled by 2^-24 (packed_trip; 0: eight v_cvt_flr_i32_f32, the form of
+                        // rounds 2 - 5).  Measured, round 6 (profiles/ab/r06/session25.txt): 176 - 182 us against 187 - 190 per launch of 12 800 jobs.  The other candidate -- the
+                        // floor as the rounding of a v_pk_fma_f32 under round-toward-minus-infinity, the mode switched by two s_setreg around the four instructions -- was
+                        // bit-exact too and gained 1 - 2 % (session23.txt): not kept.
+#endif
 #ifndef GSH_MC_DER_MIXED
 #define GSH_MC_DER_MIXED 0  // 1: in a trip with one unsafe chunk the other chunk still pairs its taps (two more loop bodies: measured, the register
                             // allocator then spills and the launch is 45 % slower -- profiles/r02/paired_taps.txt)
@@ -522,7 +528,7 @@ __device__ __forceinline__ v2f pk_add_shi(v2f v, v2f k)
 template <int NT, bool ZP, bool AUX, int NCH, bool PA = false, bool PB = false, bool KC = false>
 __device__ __forceinline__ void packed_trip(const JobCtx& c, const float* __restrict__ tab, const v2f (&shp)[NT],
     v2f k_step_nrem, v2f aux_shp, bool aux_on, v2f nfA, v2f nfB, v2f yA0, v2f yA1, v2f yB0, v2f yB1, v2f (&A0)[NT], v2f (&A1)[NT], v2f (&B0)[NT],
-    v2f (&B1)[NT], v2f& XA0, v2f& XA1, v2f& XB0, v2f& XB1)
+    v2f (&B1)[NT], v2f& XA0, v2f& XA1, v2f& XB0, v2f& XB1, v2f scaled_step_nrem = (v2f){0.0f, 0.0f}, v2f scaled_shP_shL = (v2f){0.0f, 0.0f})
 {
     static_assert(!(PA || PB) || NT == 3, "paired taps: early / prompt / late");
     const v2f zero = {0.0f, 0.0f};
@@ -626,8 +632,68 @@ __device__ __forceinline__ void packed_trip(const JobCtx& c, const float* __rest
                 pk_fma_hi(S0[2], y0, d.el0);
                 pk_fma_hi(S1[2], y1, d.el1);
             };
+#if GSH_MC_PKRTZ
+            Codes dA, dB;
+            if constexpr (KC)
+                {
+                    // TWO FLOORS PER INSTRUCTION (round 6).  The eight chains of the trip end in floor() + convert (v_cvt_flr_i32_f32, half rate, one value each).  Here the
+                    // chains run on constants scaled by 2^-24 -- step, shifts and -rem times a power of two: every product and sum is the unscaled one times 2^-24 bit for
+                    // bit, as long as nothing leaves the normal range, which the caller's judgement of the trip vouches for (every chain value of a paired trip lies in
+                    // [1, 2040)) -- and v_cvt_pkrtz_f16_f32 converts two of them at once: round toward zero (= floor, the values are positive) to half precision, whose
+                    // quantum below 2^-13 is 2^-24, so the bit pattern of the half IS the integer floor(u) for u < 2048.  The pair of 16-bit patterns becomes two byte
+                    // addresses with v_lshlrev_b16 (gfx9: the upper half of the destination is zeroed) and v_lshrrev_b32 by 14.
+                    const v2f aAs = pk_mul_slo(nfA, scaled_step_nrem);
+                    const v2f aBs = pk_mul_slo(nfB, scaled_step_nrem);
+                    v2f uPA, uPB;
+                    if (ZP)
+                        {
+                            uPA = pk_add_shi(aAs, scaled_step_nrem);
+                            uPB = pk_add_shi(aBs, scaled_step_nrem);
+                        }
+                    else
+                        {
+                            uPA = pk_add_shi(pk_add_slo(aAs, scaled_shP_shL), scaled_step_nrem);
+                            uPB = pk_add_shi(pk_add_slo(aBs, scaled_shP_shL), scaled_step_nrem);
+                        }
+                    const v2f uLA = pk_add_shi(pk_add_shi(aAs, scaled_shP_shL), scaled_step_nrem);
+                    const v2f uLB = pk_add_shi(pk_add_shi(aBs, scaled_shP_shL), scaled_step_nrem);
+                    auto two_floors = [](v2f u, unsigned& byte0, unsigned& byte1) {
+                        unsigned pk;
+                        asm("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(pk) : "v"(u.x), "v"(u.y));
+                        asm("v_lshlrev_b16_e32 %0, 2, %1" : "=v"(byte0) : "v"(pk));
+                        asm("v_lshrrev_b32_e32 %0, 14, %1" : "=v"(byte1) : "v"(pk));
+                    };
+                    auto at = [&](unsigned byte_addr, auto dc) -> float {
+                        constexpr int D = decltype(dc)::value;
+                        return reinterpret_cast<lds_float_ptr>(byte_addr)[MC_MARGIN + D];
+                    };
+                    unsigned b0, b1, b2, b3, b4, b5, b6, b7;
+                    two_floors(uPA, b0, b1);
+                    two_floors(uLA, b2, b3);
+                    two_floors(uPB, b4, b5);
+                    two_floors(uLB, b6, b7);
+                    dA.p.x = at(b0, d0{});
+                    dA.p.y = at(b1, d0{});
+                    dA.el0.x = at(b2, dm1{});
+                    dA.el0.y = at(b2, d0{});
+                    dA.el1.x = at(b3, dm1{});
+                    dA.el1.y = at(b3, d0{});
+                    dB.p.x = at(b4, d0{});
+                    dB.p.y = at(b5, d0{});
+                    dB.el0.x = at(b6, dm1{});
+                    dB.el0.y = at(b6, d0{});
+                    dB.el1.x = at(b7, dm1{});
+                    dB.el1.y = at(b7, d0{});
+                }
+            else
+                {
+                    dA = codes_of(aA);
+                    dB = codes_of(aB);
+                }
+#else
             const Codes dA = codes_of(aA);
             const Codes dB = codes_of(aB);
+#endif
             __builtin_amdgcn_sched_barrier(0);
             accumulate(dA, yA0, yA1, A0, A1);
             accumulate(dB, yB0, yB1, B0, B1);
@@ -865,6 +931,18 @@ __device__ __forceinline__ void run_segment_packed(const JobCtx& c, const float2
 #pragma unroll
     for (int t = 0; t < NT; t++) A0[t] = A1[t] = B0[t] = B1[t] = zero;
     const v2f k_step_nrem = {c.code_step, -c.rem_code};
+#if GSH_MC_PKRTZ
+    // the chain constants times 2^-24 for the paired trips' two-floors-per-instruction form (packed_trip); exact unless one of them is so small that its scaled value
+    // would be denormal -- then no trip of this segment takes the paired form (scaled_ok, below)
+    constexpr float PK_SCALE = 0x1p-24f;
+    auto scales_exactly = [](float x) -> bool { return x == 0.0f || fabsf(x) >= 0x1p-100f; };
+    auto uniform = [](float x) -> float { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x))); };  // (a product is a VGPR value)
+    const v2f scaled_step_nrem = {uniform(c.code_step * PK_SCALE), uniform(-c.rem_code * PK_SCALE)};
+    const v2f scaled_shP_shL = {uniform(sh[NT / 2] * PK_SCALE), uniform(sh[NT - 1] * PK_SCALE)};
+    const bool scaled_ok = scales_exactly(c.code_step) && scales_exactly(c.rem_code) && scales_exactly(sh[NT / 2]) && scales_exactly(sh[NT - 1]);  // uniform
+#else
+    const v2f scaled_step_nrem = {0.0f, 0.0f}, scaled_shP_shL = {0.0f, 0.0f};
+#endif
     v2f shp[NT];
 #pragma unroll
     for (int t = 0; t < NT; t++) shp[t] = (v2f){sh[t], sh[t]};
@@ -993,9 +1071,18 @@ __device__ __forceinline__ void run_segment_packed(const JobCtx& c, const float2
                 const float lo1 = c.code_step * n_lo + (sh[0] - 0.125f);
                 const float hi1 = c.code_step * (n_lo + 127.0f) + (sh[NT - 1] + 0.125f);
                 const float lo2 = lo1 - c.rem_code, hi2 = hi1 - c.rem_code;
-                const bool one_binade_a = (lo1 >= 1.0f) && (hi1 < 65536.0f) && ((__float_as_uint(lo1) >> 23) == (__float_as_uint(hi1) >> 23));
-                const bool one_binade_u = (lo2 >= 1.0f) && (hi2 < 65536.0f) && ((__float_as_uint(lo2) >> 23) == (__float_as_uint(hi2) >> 23));
+#if GSH_MC_PKRTZ
+                constexpr float HI = 2040.0f;  // the half-precision pattern of u * 2^-24 is floor(u) below 2048 (packed_trip)
+#else
+                constexpr float HI = 65536.0f;
+#endif
+                const bool one_binade_a = (lo1 >= 1.0f) && (hi1 < HI) && ((__float_as_uint(lo1) >> 23) == (__float_as_uint(hi1) >> 23));
+                const bool one_binade_u = (lo2 >= 1.0f) && (hi2 < HI) && ((__float_as_uint(lo2) >> 23) == (__float_as_uint(hi2) >> 23));
+#if GSH_MC_PKRTZ
+                return __ballot(one_binade_a && one_binade_u && scaled_ok);
+#else
                 return __ballot(one_binade_a && one_binade_u);
+#endif
             };
             der_mask[0] = judge(0);
 #pragma unroll
@@ -1092,7 +1179,8 @@ __device__ __forceinline__ void run_segment_packed(const JobCtx& c, const float2
         else if constexpr (MRG)  // (one set: the four references name the same registers, the accumulates follow one another)
             packed_trip<NT, ZP, AUX, NCH, FA, FB, KC>(c, tab, shp, k_step_nrem, aux_shp, aux_on, ia, ib, yA0, yA1, yB0, yB1, A0, A0, A0, A0, XA0, XA0, XA0, XA0);
         else
-            packed_trip<NT, ZP, AUX, NCH, FA, FB, KC>(c, tab, shp, k_step_nrem, aux_shp, aux_on, ia, ib, yA0, yA1, yB0, yB1, A0, A1, B0, B1, XA0, XA1, XB0, XB1);
+            packed_trip<NT, ZP, AUX, NCH, FA, FB, KC>(c, tab, shp, k_step_nrem, aux_shp, aux_on, ia, ib, yA0, yA1, yB0, yB1, A0, A1, B0, B1, XA0, XA1, XB0, XB1, scaled_step_nrem,
+                scaled_shP_shL);
         pa = pk_cmul_s(pa, w2);  // (w2 and the stride are wave-uniform: straight from SGPRs, not copied into VGPRs every trip)
         asm("v_pk_add_f32 %0, %0, %1" : "+v"(nfA) : "s"(stride));
         if (NCH == 2) asm("v_pk_add_f32 %0, %0, %1" : "+v"(nfB) : "s"(stride));

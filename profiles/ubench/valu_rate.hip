@@ -124,6 +124,56 @@ __global__ __launch_bounds__(256) void k(float* out, int iters)
                                       "v_pk_fma_f32 %2, %9, %8, %2 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n v_pk_fma_f32 %3, %9, %8, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n"
                                       : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(p6), "v"(p7) : "s20", "s21");)
                 }
+            else if (KIND == 17)  // v_cvt_pkrtz_f16_f32 (round 6: two floor()s of non-negative scaled chip positions per instruction)
+                {
+                    REP8(asm volatile("v_cvt_pkrtz_f16_f32 %0, %0, %1\n v_cvt_pkrtz_f16_f32 %1, %1, %2\n v_cvt_pkrtz_f16_f32 %2, %2, %3\n v_cvt_pkrtz_f16_f32 %3, %3, %4\n"
+                                      "v_cvt_pkrtz_f16_f32 %4, %4, %5\n v_cvt_pkrtz_f16_f32 %5, %5, %6\n v_cvt_pkrtz_f16_f32 %6, %6, %7\n v_cvt_pkrtz_f16_f32 %7, %7, %0\n"
+                                      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));)
+                }
+            else if (KIND == 18)  // v_lshlrev_b16 / v_lshrrev_b32 (the two halves of a packed pair of indices to byte addresses)
+                {
+                    REP8(asm volatile("v_lshlrev_b16_e32 %0, 2, %0\n v_lshrrev_b32_e32 %1, 14, %1\n v_lshlrev_b16_e32 %2, 2, %2\n v_lshrrev_b32_e32 %3, 14, %3\n"
+                                      "v_lshlrev_b16_e32 %4, 2, %4\n v_lshrrev_b32_e32 %5, 14, %5\n v_lshlrev_b16_e32 %6, 2, %6\n v_lshrrev_b32_e32 %7, 14, %7\n"
+                                      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));)
+                }
+            else if (KIND == 19)  // v_lshlrev_b32_sdwa, word selects
+                {
+                    REP8(asm volatile("v_lshlrev_b32_sdwa %0, 2, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n v_lshlrev_b32_sdwa %1, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n"
+                                      "v_lshlrev_b32_sdwa %2, 2, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n v_lshlrev_b32_sdwa %3, 2, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n"
+                                      "v_lshlrev_b32_sdwa %4, 2, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n v_lshlrev_b32_sdwa %5, 2, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n"
+                                      "v_lshlrev_b32_sdwa %6, 2, %6 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n v_lshlrev_b32_sdwa %7, 2, %7 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n"
+                                      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));)
+                }
+            else if (KIND == 20)  // the rounding-mode window: s_setreg, four v_pk_fma_f32, s_setreg, two v_add_f32 (8 wave-instructions counted: the VALU ones + 2)
+                {
+                    REP8(asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 2\n v_pk_fma_f32 %0, %0, %8, %0\n v_pk_fma_f32 %1, %1, %8, %1\n v_pk_fma_f32 %2, %2, %8, %2\n v_pk_fma_f32 %3, %3, %8, %3\n"
+                                      "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0\n v_pk_add_f32 %4, %4, %8\n v_pk_add_f32 %5, %5, %8\n"
+                                      : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(cc));)
+                }
+            else if (KIND == 21)  // the same eight instructions without the two s_setreg (6 VALU, counted as 8 like KIND 20: the difference is what the mode switches cost)
+                {
+                    REP8(asm volatile("v_pk_fma_f32 %0, %0, %8, %0\n v_pk_fma_f32 %1, %1, %8, %1\n v_pk_fma_f32 %2, %2, %8, %2\n v_pk_fma_f32 %3, %3, %8, %3\n"
+                                      "v_pk_add_f32 %4, %4, %8\n v_pk_add_f32 %5, %5, %8\n"
+                                      : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(cc));)
+                }
+            else if (KIND == 22)  // v_floor_f32 / v_cvt_i32_f32 / v_cvt_u32_f32 / v_cvt_f16_f32
+                {
+                    REP8(asm volatile("v_floor_f32 %0, %0\n v_cvt_i32_f32 %1, %1\n v_cvt_u32_f32 %2, %2\n v_cvt_f16_f32 %3, %3\n"
+                                      "v_floor_f32 %4, %4\n v_cvt_i32_f32 %5, %5\n v_cvt_u32_f32 %6, %6\n v_cvt_f16_f32 %7, %7\n"
+                                      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));)
+                }
+            else if (KIND == 23)  // v_floor_f32 alone
+                {
+                    REP8(asm volatile("v_floor_f32 %0, %0\n v_floor_f32 %1, %1\n v_floor_f32 %2, %2\n v_floor_f32 %3, %3\n"
+                                      "v_floor_f32 %4, %4\n v_floor_f32 %5, %5\n v_floor_f32 %6, %6\n v_floor_f32 %7, %7\n"
+                                      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));)
+                }
+            else if (KIND == 24)  // v_cvt_u32_f32 alone
+                {
+                    REP8(asm volatile("v_cvt_u32_f32 %0, %0\n v_cvt_u32_f32 %1, %1\n v_cvt_u32_f32 %2, %2\n v_cvt_u32_f32 %3, %3\n"
+                                      "v_cvt_u32_f32 %4, %4\n v_cvt_u32_f32 %5, %5\n v_cvt_u32_f32 %6, %6\n v_cvt_u32_f32 %7, %7\n"
+                                      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));)
+                }
         }
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p1.y + p2.x + p3.y + p4.x + p5.y + p6.x + p7.y;
 }
@@ -170,6 +220,14 @@ int main()
             run<14>("v_pk_fma_f32 3 distinct srcs", w);
             run<15>("v_fma_f32 3 distinct srcs", w);
             run<16>("trip mix (per 10: 4 pk_fma, 2 add, 2 cvt, 2 shift)", w);
+            run<17>("v_cvt_pkrtz_f16_f32", w);
+            run<18>("v_lshlrev_b16/v_lshrrev_b32", w);
+            run<19>("v_lshlrev_b32_sdwa WORD_0/1", w);
+            run<20>("2 s_setreg + 4 pk_fma + 2 pk_add (as 8)", w);
+            run<21>("4 pk_fma + 2 pk_add (as 8)", w);
+            run<22>("floor/cvt_i32/cvt_u32/cvt_f16 mix", w);
+            run<23>("v_floor_f32", w);
+            run<24>("v_cvt_u32_f32", w);
         }
     return 0;
 }

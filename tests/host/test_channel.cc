@@ -775,26 +775,48 @@ void test_channel_churn(int n_channels, int n_churn, double seconds, bool with_r
                     state = (e.what == 1) ? 2 : 1;
                 }
         }
-    // ---- the steady channels never noticed: one acquisition, no loss, every window taken
+    // ---- the steady channels never noticed: no loss of lock once they track, every window taken.  (The one loss a steady channel may see is the reference's own: a hand-over
+    // that finds the tracking block more than a code period behind the acquisition's stamp is dropped when the C/N0 buffer has its 20 prompts -- trk.cc:2002 on a wrapped
+    // unsigned difference, pinned to the reference block in test_tracking_adapters.cc -- and acquired again.  Whether a free-running acquisition thread gets that far ahead is
+    // the scheduler's choice, so such a drop within 40 code periods of its hand-over is counted, not failed; anything later is a failure.)
     double worst_gap = 0.0;
+    size_t early_drops = 0;
+    std::vector<uint64_t> steady_from(static_cast<size_t>(n_channels), 0);
     for (int c = n_churn; c < n_channels; c++)
         {
             const auto& ev = hip.events[static_cast<size_t>(c)];
-            EXPECT(ev.size() >= 1 && ev.back().what == 1 && std::count_if(ev.begin(), ev.end(), [](const Event& e) { return e.what == 2; }) == 0, "steady channel %d: %s", c,
-                events_string(ev, 12).c_str());
-            EXPECT(hip.lost_items[static_cast<size_t>(c)] == 0, "steady channel %d published %zu loss-of-lock items", c, hip.lost_items[static_cast<size_t>(c)]);
+            size_t drops = 0;
+            bool legal = ev.size() >= 1 && ev.back().what == 1;
+            uint64_t last_win = 0;
+            for (const Event& e : ev)
+                {
+                    if (e.what == 1) last_win = e.source_head;
+                    if (e.what == 2)
+                        {
+                            drops++;
+                            if (e.source_head > last_win + static_cast<uint64_t>(40 * vlen)) legal = false;
+                        }
+                }
+            EXPECT(legal, "steady channel %d: %s", c, events_string(ev, 12).c_str());
+            EXPECT(hip.lost_items[static_cast<size_t>(c)] == drops, "steady channel %d published %zu loss-of-lock items for %zu hand-overs dropped by the time limit", c,
+                hip.lost_items[static_cast<size_t>(c)], drops);
+            early_drops += drops;
+            steady_from[static_cast<size_t>(c)] = drops ? last_win : 0;
             worst_gap = std::max(worst_gap, hip.longest_gap[static_cast<size_t>(c)]);
-            // every window taken: from the first period on, the read pointer advances by one code period (+-1 sample) per call, to the end of the stream
+            // every window taken: from the first period of the tracking that lasted, the read pointer advances by one code period (+-1 sample) per call, to the end of the stream
             const auto& pos = hip.trk_positions[static_cast<size_t>(c)];
             size_t k = 0;
-            while (k + 1 < pos.size() && (pos[k + 1] - pos[k] < static_cast<uint64_t>(vlen - 2) || pos[k + 1] - pos[k] > static_cast<uint64_t>(vlen + 2) || k < 8)) k++;
+            while (k + 1 < pos.size() && pos[k] < steady_from[static_cast<size_t>(c)]) k++;
+            const size_t k0 = k;
+            while (k + 1 < pos.size() && (pos[k + 1] - pos[k] < static_cast<uint64_t>(vlen - 2) || pos[k + 1] - pos[k] > static_cast<uint64_t>(vlen + 2) || k < k0 + 8)) k++;
             size_t odd = 0;
             for (size_t i = k; i + 1 < pos.size(); i++)
                 if (pos[i + 1] - pos[i] < static_cast<uint64_t>(vlen - 2) || pos[i + 1] - pos[i] > static_cast<uint64_t>(vlen + 2)) odd++;
             EXPECT(odd == 0 && !pos.empty() && pos.back() + static_cast<uint64_t>(3 * vlen) >= x.size(), "steady channel %d: %zu read-pointer steps that are not one code period; stopped at %llu of %zu", c, odd,
                 pos.empty() ? 0ULL : static_cast<unsigned long long>(pos.back()), x.size());
         }
-    std::printf("churn: the %d steady channels: one acquisition each, no loss of lock, every code period taken to the end of the stream; their longest wall-clock pause between two "
+    if (early_drops) std::printf("churn: %zu hand-overs of steady channels found the tracking block more than a code period behind the stamp and were dropped by the time limit (trk.cc:2002)\n", early_drops);
+    std::printf("churn: the %d steady channels: no loss of lock once tracking, every code period taken to the end of the stream; their longest wall-clock pause between two "
                 "periods: %.1f ms\n",
         n_channels - n_churn, worst_gap * 1e3);
     if (!with_reference) return;
@@ -808,9 +830,12 @@ void test_channel_churn(int n_channels, int n_churn, double seconds, bool with_r
         {
             const auto &a = hip.trk_positions[static_cast<size_t>(c)], &b = ref.trk_positions[static_cast<size_t>(c)];
             // compare from where both are tracking (past both pull-ins)
-            const uint64_t from = std::max(hip.handovers[static_cast<size_t>(c)].empty() ? 0 : hip.handovers[static_cast<size_t>(c)][0].source_head,
-                                      ref.handovers[static_cast<size_t>(c)].empty() ? 0 : ref.handovers[static_cast<size_t>(c)][0].source_head) +
-                                  static_cast<uint64_t>(16 * vlen);
+            const auto &hh = hip.handovers[static_cast<size_t>(c)], &rh = ref.handovers[static_cast<size_t>(c)];
+            const uint64_t from = std::max(hh.empty() ? 0 : hh.back().source_head, rh.empty() ? 0 : rh.back().source_head) + static_cast<uint64_t>(16 * vlen);
+            // (free-running threads: the two receivers acquire a satellite at different moments -- a failed first dwell, a hand-over dropped by the time limit -- and the
+            //  one that started later has fewer 20 ms symbols by the difference)
+            const uint64_t h_last = hh.empty() ? 0 : hh.back().source_head, r_last = rh.empty() ? 0 : rh.back().source_head;
+            const size_t late = static_cast<size_t>((h_last > r_last ? h_last - r_last : r_last - h_last) / static_cast<uint64_t>(20 * vlen)) + 2;
             size_t compared = 0;
             const double exact = compare_positions(("churn, steady channel " + std::to_string(c)).c_str(), a, b, from, &compared);
             // (free-running threads: the two receivers acquire at different moments, so the two loops start from different estimates and carry code phases a few
@@ -819,8 +844,10 @@ void test_channel_churn(int n_channels, int n_churn, double seconds, bool with_r
             EXPECT(compared > 100 && exact >= 0.5, "steady channel %d: %zu read pointers compared with the reference receiver's, %.3f %% exact", c, compared, 100.0 * exact);
             total += compared;
             worst_exact = std::min(worst_exact, exact);
-            EXPECT(hip.valid_symbols[static_cast<size_t>(c)] + 60 >= ref.valid_symbols[static_cast<size_t>(c)] && ref.valid_symbols[static_cast<size_t>(c)] + 60 >= hip.valid_symbols[static_cast<size_t>(c)],
-                "steady channel %d: %zu symbols vs the reference receiver's %zu", c, hip.valid_symbols[static_cast<size_t>(c)], ref.valid_symbols[static_cast<size_t>(c)]);
+            EXPECT(hip.valid_symbols[static_cast<size_t>(c)] + 60 + late >= ref.valid_symbols[static_cast<size_t>(c)] && ref.valid_symbols[static_cast<size_t>(c)] + 60 + late >= hip.valid_symbols[static_cast<size_t>(c)],
+                "steady channel %d: %zu symbols vs the reference receiver's %zu (last hand-overs at source positions %llu and %llu; reference events %s)", c,
+                hip.valid_symbols[static_cast<size_t>(c)], ref.valid_symbols[static_cast<size_t>(c)], static_cast<unsigned long long>(h_last), static_cast<unsigned long long>(r_last),
+                events_string(ref.events[static_cast<size_t>(c)], 12).c_str());
         }
     std::printf("churn: steady channels against the reference receiver (%.1f s): %zu read pointers compared, at least %.3f %% of a channel's exactly the reference block's, the rest one sample off\n",
         ref.seconds, total, 100.0 * worst_exact);

@@ -271,6 +271,45 @@ def test_derived_taps_on_long_codes(gpu):
     b.close()
 
 
+def test_paired_taps_near_2048_chips_and_with_tiny_code_phases(gpu):
+    """The paired trips take two floors per instruction (csrc/mcorr_device.h, GSH_MC_PKRTZ): the chip-index chains run on constants scaled by 2^-24 and
+    v_cvt_pkrtz_f16_f32 leaves floor(u) as the half-precision bit pattern -- exact for 1 <= u < 2048 and as long as no scaled constant is denormal.  Here: 2 046-chip
+    codes (BeiDou B1I's length: the last chips lie beyond the bound, so the waves that hold them must take the one-floor form), code phases of 1e-37, 1e-30, -1e-33
+    (their scaled values would be denormal: no trip may take the scaled chains), exact zeros, and steps that put u on integers.  Integer-valued samples and no carrier:
+    a tap's sum is exact, so it equals the oracle's iff every chip index is the reference's."""
+    rng = np.random.default_rng(2048)
+    n_max = 52000
+    xr = rng.integers(-7, 8, 2 * n_max + 128).astype(np.float32)
+    codes = [(2 * rng.integers(0, 2, 2046) - 1).astype(np.int32) for _ in range(3)]
+    b = _bank(gpu, codes)
+    b.set_stream_host(xr.astype(np.complex64))
+    rems = [0.0, 1e-37, 1e-30, -1e-33, 0.25, 0.999, -0.3, 1.7, 1.0 / 3.0]
+    steps = [2.046e6 / 25e6, 2.046e6 / 50e6, 0.0625, 0.5, 0.040919998, 2.046e6 / 10e6]
+    jobs = []
+    for i, (rem, step) in enumerate((r, s) for r in rems for s in steps):
+        step32 = float(np.float32(step))
+        length = int(min(n_max, (2046 + 20) / step32))
+        s_ = [0.5, 0.25, 1.0][i % 3]
+        jobs.append(dict(sample_offset=int(rng.integers(0, 64)), n_samples=length, code_slot=i % 3, shifts_chips=[-s_, 0.0, 1.0 - s_], rem_carr_phase_rad=0.0,
+                         phase_step_rad=0.0, rem_code_phase_chips=float(np.float32(rem)), code_phase_step_chips=step32))
+    for k in range(0, len(jobs), 9):
+        group = jobs[k:k + 9]
+        out = b.correlate(group)
+        for j, job in enumerate(group):
+            sh = np.asarray(job["shifts_chips"], np.float32)
+            idx = oracle.code_indices(job["n_samples"], sh, job["rem_code_phase_chips"], job["code_phase_step_chips"], 0.0, 2046, False)
+            seg = xr[job["sample_offset"]:job["sample_offset"] + job["n_samples"]].astype(np.float64)
+            expect = np.array([(codes[job["code_slot"]][idx[t]].astype(np.float64) * seg).sum() for t in range(3)])
+            assert np.array_equal(out[j, :3].real.astype(np.float64), expect), (job, out[j, :3], expect)
+            assert np.all(out[j, :3].imag == 0)
+    # the same jobs in one launch of the two-wave kernels (>= 5 120 jobs): bit-identical sums
+    many = (jobs * (5120 // len(jobs) + 1))[:5200]
+    big = b.correlate(many)
+    ref = np.concatenate([b.correlate(jobs[k:k + 9]) for k in range(0, len(jobs), 9)], axis=0)
+    assert np.array_equal(big[:len(jobs)].view(np.uint32), ref.view(np.uint32)) and np.array_equal(big[len(jobs):2 * len(jobs)].view(np.uint32), ref.view(np.uint32))
+    b.close()
+
+
 _DERIVED_AB_SCRIPT = r"""
 import sys, numpy as np
 sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
