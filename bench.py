@@ -9,7 +9,10 @@ block = channels x epochs jobs in one launch (the resident job table is re-used 
 Inputs (stream, codes, job table) are resident in HBM before the timed region; the stream cycles through a buffer of `--ring-blocks`
 (8) blocks = 643 MB, larger than the 256 MiB Infinity Cache, so what the kernel does not find in L2 really comes from HBM.
 value = channels*taps*epochs*blocks / time, whole job.  One step is ~0.25 s of GPU time: the driver's K = 20 steps keep the GPU busy for ~5 s,
-long enough for its SMI samples to see it.
+long enough for its SMI samples to see it.  At N = 1 the blocks alternate over `--launches-in-flight` (2) correlator banks, each with a HIP stream of
+its own: consecutive blocks are independent jobs, so the start of one launch fills the drain of the previous one and the gap between two launches of one
+stream (172 -> 160 us per block, profiles/ab/r06/session30.txt); `value_single_stream` is one launch after the other on one stream, as `value` was until round 6,
+and roofline.kernel_ms is one launch alone.
 
   python bench.py --gpus N --steps K --warmup W
   N > 1: launched by torch.distributed.run, one rank per GPU; every rank tracks its own 32 channels of the same
@@ -61,6 +64,10 @@ def parse():
     ap.add_argument("--settle-steps", type=int, default=3,
                     help="untimed steps run during set-up, before the W warm-up steps, so that the GPU clocks have settled: after an idle "
                          "period the first ~40 ms of work run up to 25 %% slower (profiles/ab/clock_ramp.py); 0 disables")
+    ap.add_argument("--launches-in-flight", type=int, default=2,
+                    help="N = 1: blocks alternate over this many correlator banks, each on a stream of its own (2: the start of one launch fills the drain of the "
+                         "other and the gap between two launches of one stream, profiles/ab/r06/session30.txt); 1: one bank, one stream, as until round 6.  "
+                         "value_single_stream is reported either way")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-acq", action="store_true")
     ap.add_argument("--no-dropin", action="store_true", help="skip the drop-in leg (32 tracking blocks through general_work)")
@@ -794,7 +801,8 @@ def bench_summary(res):
                 return None
             d = d[k]
         return d
-    s = {"tracking_Mcorr_s": res["value"] / 1e6, "tracking_kernel_ms": get(res, "roofline", "kernel_ms"), "tracking_valu_frac": get(res, "roofline", "frac"),
+    s = {"tracking_Mcorr_s": res["value"] / 1e6, "tracking_launches_in_flight": res.get("launches_in_flight"),
+         "tracking_Mcorr_s_single_stream": (res.get("value_single_stream") or 0) / 1e6, "tracking_kernel_ms": get(res, "roofline", "kernel_ms"), "tracking_valu_frac": get(res, "roofline", "frac"),
          "acq_dwells_s_pipelined": get(res, "acquisition", "value"), "acq_dwells_s_single_stream": get(res, "acquisition", "value_single_stream"),
          "acq_ms_per_batch_pipelined": get(res, "acquisition", "ms_per_batch"), "acq_ms_per_batch_single_stream": get(res, "acquisition", "ms_per_batch_single_stream"),
          "acq_hbm_frac_pipelined": get(res, "acquisition", "roofline", "frac"), "acq_hbm_frac_single_stream": get(res, "acquisition", "roofline", "frac_single_stream"),
@@ -961,6 +969,7 @@ def main():
     jobs, rows = build_jobs(C, E, n, fs, T, dop, cph, rank)
     bank.set_splits(1)
     G = ring = raw_src = None
+    more_banks, more_streams = [], []
     if not grouped:
         # N = 1: NB copies of the block back to back; the steps cycle through them (643 MB: what misses L2 comes from HBM, not from the
         # 256 MiB Infinity Cache)
@@ -969,6 +978,17 @@ def main():
             x[k * block:(k + 1) * block] = x0
         bank.set_stream_device(x.data_ptr(), NB * block, keepalive=x)
         bank.upload_jobs(jobs)
+        # launches in flight: one more bank (its own job table and output rows) and stream per extra launch -- consecutive blocks are independent jobs of the
+        # open-loop path, so block b + 1 may start while block b drains
+        for _ in range(max(a.launches_in_flight, 1) - 1):
+            b2 = CorrelatorBank(C, 1023, device=local)
+            for c in range(C):
+                b2.set_code(c, gps_l1_ca_code(weak_channel_prn(rank, C, c)))
+            b2.set_splits(1)
+            b2.set_stream_device(x.data_ptr(), NB * block, keepalive=x)
+            b2.upload_jobs(jobs)
+            more_banks.append(b2)
+            more_streams.append(torch.cuda.Stream(device=dev))
     else:
         # N > 1 (or the self-test of that path): every block reaches the GPUs through the engine's stream group -- 8-bit items in, complex64
         # in every GPU's ring -- and the correlator bank reads the ring
@@ -987,11 +1007,14 @@ def main():
 
     state = {"blk": 0, "next_first": None}
 
-    def step(k):
+    def step(k, in_flight=None):
         if not grouped:
+            banks = [bank] + (more_banks if in_flight is None else more_banks[:in_flight - 1])
+            streams = [stream] + [t.cuda_stream for t in more_streams]
             for j in range(BPS):
-                bank.set_sample_base(((k * BPS + j) % NB) * block)
-                bank.launch(stream)
+                b = (k * BPS + j) % len(banks)
+                banks[b].set_sample_base(((k * BPS + j) % NB) * block)
+                banks[b].launch(streams[b])
             return
         for j in range(BPS):
             # block b + 1 is queued for replication, then block b is correlated: the bank waits for the push that covers ITS windows only,
@@ -1022,6 +1045,22 @@ def main():
         dt = time.perf_counter() - t0
     reduce_max, reduce_sum = cp.reduce_max, cp.reduce_sum
     dt = reduce_max(dt)
+    # the same steps with ONE launch at a time on one stream (what `value` was until round 6), over a fifth of the steps
+    dt_single, steps_single = None, 0
+    if not grouped and more_banks:
+        steps_single = max(2, a.steps // 5)
+        k0 = a.settle_steps + a.warmup + a.steps
+        with torch.cuda.stream(cs):
+            step(k0, in_flight=1)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(steps_single):
+                step(k0 + 1 + k, in_flight=1)
+            torch.cuda.synchronize()
+            dt_single = time.perf_counter() - t0
+        last_launch = (k0 + 1 + steps_single) * BPS - 1
+    else:
+        last_launch = (max(a.settle_steps, 0) + a.warmup + a.steps) * BPS - 1
 
     # ---- roofline of the dominant kernel: HIP events on the launch stream, inputs resident; taken straight after the timed region,
     # before the host-side spot check lets the GPU fall idle again
@@ -1033,7 +1072,7 @@ def main():
     from helpers import oracle_job, scale_err
     if not grouped:
         # time_launches() re-ran the last launch: the block the final step ended on
-        base_last = ((max(a.settle_steps, 0) + a.warmup + a.steps) * BPS - 1) % NB * block
+        base_last = last_launch % NB * block
         xh = x[base_last:base_last + block].cpu().numpy()
     else:
         # the ring holds the 8-bit block converted back to float: that is what the kernel correlated.  Only rank 0 made the block; every other rank checks
@@ -1051,6 +1090,16 @@ def main():
         if not np.all(err <= 1e-6):
             raise SystemExit(f"bench: rank {rank}: GPU result of job {j} disagrees with the oracle: {out[j, :T]} vs {t64}")
         worst = max(worst, float(np.max(err)))
+    for b2 in more_banks:
+        # the other banks computed too: three jobs of their last launch against the oracle (the ring's blocks are copies of one block, so whichever block
+        # a bank ended on, xh holds its samples)
+        out2 = b2.read_outputs()
+        for j in (0, C + 3, len(rows) - 1):
+            o32, t64, sabs = oracle_job(oracle.ca_code(weak_channel_prn(rank, C, rows[j]["code_slot"])), xh, rows[j])
+            err = scale_err(out2[j, :T], t64, sabs)
+            if not np.all(err <= 1e-6):
+                raise SystemExit(f"bench: rank {rank}: job {j} of a second bank disagrees with the oracle: {out2[j, :T]} vs {t64}")
+            worst = max(worst, float(np.max(err)))
     if grouped:
         # every rank's ring must hold the same block: a checksum of checksums over the ranks
         crc = float(int(np.frombuffer(xh.tobytes(), dtype=np.uint32).sum(dtype=np.uint64)) % (1 << 40))
@@ -1079,7 +1128,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"GPS L1 C/A tracking, {C} channels/GPU x {E} epochs/block x {BPS} blocks/step, fs={fs / 1e6:g} Msps, N={n}, {T}-tap E/P/L, open-loop; "
+            "config": {"workload": f"GPS L1 C/A tracking, {C} channels/GPU x {E} epochs/block x {BPS} blocks/step, fs={fs / 1e6:g} Msps, N={n}, {T}-tap E/P/L, open-loop, "
+                                   + (f"{1 + len(more_banks)} launches in flight (blocks alternate over that many banks and streams); " if more_banks else "one launch at a time; ")
                                    + ("the IF stream is RESIDENT in HBM before the timed region (host-to-device transfer excluded: pcie_inclusive is the end-to-end figure)"
                                       if not grouped else "every 8-bit block enters GPU 0 from device memory and is replicated by the engine inside the timed region"),
                        "channels_per_gpu": C, "epochs_per_block": E, "blocks_per_step": BPS, "samples_per_epoch": n, "taps": T,
@@ -1089,6 +1139,11 @@ def main():
                                       f"({os.environ.get('GSH_BENCH_DIST', 'broadcast')}), converted into every GPU's ring, overlapped with the correlation" if grouped else "")},
             "roofline": tracking_roofline(C, E, T, n, k_ms, pmc),
             "kernel_only_value": float(C) * T * E / (k_ms * 1e-3),
+            # `value` = blocks alternating over launches_in_flight banks and streams; value_single_stream = one launch after the other on one stream (what
+            # `value` was until round 6), timed straight after over a fifth of the steps; roofline.kernel_ms = one launch alone (HIP events, one stream)
+            "launches_in_flight": 1 + len(more_banks),
+            "value_single_stream": (float(C) * T * E * BPS * steps_single / dt_single) if dt_single else None,
+            "ms_per_step_single_stream": (dt_single / steps_single * 1e3) if dt_single else None,
             # the stream group under the launches (N > 1: RCCL over xGMI inside the engine; N = 1: no group, the block is resident)
             "rccl_ranks": G.rccl_info()["ranks"] if G is not None else 0,
             "stream_group_mode": os.environ.get("GSH_BENCH_DIST", "broadcast") if grouped else None,
@@ -1172,6 +1227,8 @@ def main():
         res["summary"] = bench_summary(res)
         the_line.line(json.dumps(res))
     bank.close()
+    for b2 in more_banks:
+        b2.close()
     if G is not None:
         G.close()
     cp.close()

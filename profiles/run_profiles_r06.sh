@@ -15,7 +15,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 2 --warmup 1 --settle-steps 1 --blocks-per-step 16 --no-cpu-baseline --no-other-configs --no-dropin"
+BENCH="python $ROOT/bench.py --steps 2 --warmup 1 --settle-steps 1 --blocks-per-step 16 --launches-in-flight 1 --no-cpu-baseline --no-other-configs --no-dropin"   # one tracking launch at a time too: the trace shows each kernel alone, as roofline.kernel_ms is measured
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- $BENCH > $OUT/trace.json 2> $OUT/trace.err
 for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE" \
             "sq1:SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" \
