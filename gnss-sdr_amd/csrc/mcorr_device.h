@@ -56,6 +56,9 @@ constexpr int MC_MARGIN = 32;  // guard entries on each side of the LDS code tab
                         // floor as the rounding of a v_pk_fma_f32 under round-toward-minus-infinity, the mode switched by two s_setreg around the four instructions -- was
                         // bit-exact too and gained 1 - 2 % (session23.txt): not kept.
 #endif
+#ifndef GSH_MC_RUNLEN
+#define GSH_MC_RUNLEN 1  // the paired trips of a segment as counted runs (run_segment_packed); 0: the trip kind asked before every trip, rounds 2 - 6
+#endif
 #ifndef GSH_MC_DER_MIXED
 #define GSH_MC_DER_MIXED 0  // 1: in a trip with one unsafe chunk the other chunk still pairs its taps (two more loop bodies: measured, the register
                             // allocator then spills and the launch is 45 % slower -- profiles/r02/paired_taps.txt)
@@ -869,9 +872,7 @@ __device__ __forceinline__ void run_segment_packed(const JobCtx& c, const float2
     // the four samples of trip i for this lane: 16-byte loads in the body; at the segment's edges (odd head, partial tail) the samples outside
     // [n_begin, n_end) are read as zero -- never loaded.  Edge trips go through the same queue, so their latency is hidden like the others'.
     const unsigned lane_bytes = 16u * static_cast<unsigned>(tid);  // the lane's 16 bytes inside a chunk
-    auto load_trip = [&](int i, float4& va, float4& vb) {
-        const float2* q = q0 + static_cast<long long>(i) * TRIP;
-        if ((i >= first_plain) && (i < last_plain))  // uniform
+    auto load_plain = [&](int i, float4& va, float4& vb) {
             {
                 // a wave-uniform 64-bit base plus a 32-bit lane offset: the loads take their base from SGPRs, and no per-lane pointer is carried (and advanced) in VGPRs
                 const char* const ua = reinterpret_cast<const char*>(base + static_cast<long long>(i) * TRIP);
@@ -893,7 +894,9 @@ __device__ __forceinline__ void run_segment_packed(const JobCtx& c, const float2
                     va = *reinterpret_cast<const float4*>(ua + lane_bytes);
 #endif
             }
-        else
+    };
+    auto load_edge = [&](int i, float4& va, float4& vb) {
+        const float2* q = q0 + static_cast<long long>(i) * TRIP;
             {
                 const int n0 = c.n_first + 2 * tid + i * TRIP;
                 const int lo = c.n_begin, hi = c.n_end - 1;
@@ -910,6 +913,12 @@ __device__ __forceinline__ void run_segment_packed(const JobCtx& c, const float2
                         vb = make_float4(z0.x, z0.y, z1.x, z1.y);
                     }
             }
+    };
+    auto load_trip = [&](int i, float4& va, float4& vb) {
+        if ((i >= first_plain) && (i < last_plain))  // uniform
+            load_plain(i, va, vb);
+        else
+            load_edge(i, va, vb);
     };
     // The first PF trips' loads: right in front of the first trip.  (EARLY_LOADS, an A/B switch for the 1 024-thread closed-loop form: issued HERE instead, ahead of the
     // seeds' transcendental evaluation and the tables below, so that the period's first L2 round trip runs under the set-up -- measured 7.60 against 7.54 us per period:
@@ -1166,6 +1175,17 @@ __device__ __forceinline__ void run_segment_packed(const JobCtx& c, const float2
                         yB1 = pk_cmul((v2f){qb[j].z, qb[j].w}, pa);
                     }
             }
+#if GSH_MC_RUNLEN
+        if constexpr (FA && (FB || NCH == 1))
+            {
+                // (a paired trip is a plain one: the trip PF ahead lies at or beyond the first plain trip, and one comparison says whether it is plain itself)
+                if (i + PF < last_plain)  // uniform
+                    load_plain(i + PF, qa[j], qb[j]);
+                else if (i + PF < n_trips)
+                    load_edge(i + PF, qa[j], qb[j]);
+            }
+        else
+#endif
         if (i + PF < n_trips) load_trip(i + PF, qa[j], qb[j]);  // uniform
         if constexpr (EARLY_CODES)
             {
@@ -1208,6 +1228,43 @@ __device__ __forceinline__ void run_segment_packed(const JobCtx& c, const float2
             };
             constexpr unsigned ALL = (NCH == 2) ? 3U : 1U;
             int i = 0;
+#if GSH_MC_RUNLEN && !GSH_MC_DER_MIXED && !defined(GSH_EXP_ALLSAFE)
+            // RUN LENGTHS (round 6).  The form above asks flags(i) before EVERY trip: a dozen and a half dependent scalar instructions (mask select, shift, range tests,
+            // selects) between the last vector instruction of one trip and the first of the next, in which this wave issues nothing.  Asked once per RUN instead: how many
+            // trips from i on may pair their taps -- the trailing ones of the judgement mask from chunk NCH i on (both chunks of a trip: m & m >> 1 on the even bits),
+            // capped by the mask word's end and by the last plain trip -- and the run is a counted loop.
+            (void)flags;
+            auto paired_run = [&](int i0) -> int {
+                const int ch = NCH * i0;
+                if (i0 < first_plain || i0 >= last_plain || ch >= 64 * NM) return 0;  // uniform
+                unsigned long long mask = der_mask[0];
+#pragma unroll
+                for (int m = 1; m < NM; m++) mask = (ch >= 64 * m) ? der_mask[m] : mask;
+                unsigned long long m = mask >> (ch & 63);  // bit 0: chunk ch; zeros come in from the top, so a run ends at the word's end at the latest
+                constexpr unsigned long long UNITS = (NCH == 2) ? 0x5555555555555555ULL : ~0ULL;
+                if (NCH == 2) m &= (m >> 1);
+                const unsigned long long stop = ~m & UNITS;  // lowest set bit: the first trip that may not pair
+                const int run = (stop != 0ULL) ? static_cast<int>(__builtin_ctzll(stop)) / NCH : 64 / NCH;
+                return min(run, last_plain - i0);
+            };
+            // (the shape of the loops is the one below -- a run of paired trips, then ONE trip of the other kind -- because that is the shape whose joins the register
+            //  allocator gets through without copies: an if / else of the two kinds put two dozen v_mov_b64 and a scratch slot at every end of a run.  A run that
+            //  ends at a mask word's end is followed by one per-tap trip it did not need: one in 32.)
+            while (i < n_trips)
+                {
+                    int run = paired_run(i);
+                    while (run > 0)
+                        {
+                            trip(i, j0{}, yes{}, integral_constant<bool, NCH == 2>{});
+                            i++;
+                            run--;
+                        }
+                    if (i >= n_trips) break;
+                    trip(i, j0{}, no{}, no{});
+                    i++;
+                }
+            (void)ALL;
+#else
             while (i < n_trips)
                 {
                     unsigned f = flags(i);
@@ -1229,6 +1286,7 @@ __device__ __forceinline__ void run_segment_packed(const JobCtx& c, const float2
                         trip(i, j0{}, no{}, no{});
                     i++;
                 }
+#endif
         }
     else
         {
