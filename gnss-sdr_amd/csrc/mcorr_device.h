@@ -1102,9 +1102,10 @@ __device__ __forceinline__ void run_segment_packed(const JobCtx& c, const float2
     v2f pa = zero, nfA = zero, nfB = zero;
     int until_reseed = 0, r_idx = 0, tbl0 = 0;
     // one trip; j: its slot in the load queue; FA / FB (compile time): chunk A / B reads its early tap next to the late one
-    auto trip = [&](int i, auto jc, auto fa, auto fb) {
+    auto trip = [&](int i, auto jc, auto fa, auto fb, auto kp) {
         constexpr int j = decltype(jc)::value;
         constexpr bool FA = decltype(fa)::value, FB = decltype(fb)::value;
+        constexpr bool KP = decltype(kp)::value;  // the caller knows that trip i is a plain one (first_plain <= i < last_plain)
         const int n0 = (c.n_first + i * TRIP) + 2 * tid;  // (uniform part first: used at re-seeds and edges only)
         if (until_reseed == 0)  // uniform: exact re-seed of the lane's phasor and of (float)n
             {
@@ -1128,7 +1129,7 @@ __device__ __forceinline__ void run_segment_packed(const JobCtx& c, const float2
                 r_idx++;
             }
         until_reseed--;
-        const bool plain = (i >= first_plain) && (i < last_plain);  // uniform
+        const bool plain = KP || ((i >= first_plain) && (i < last_plain));  // uniform
         v2f ia = nfA, ib = nfB;
         if (!(FA || FB) && !plain)  // (derived trips are plain ones)
             {
@@ -1176,7 +1177,7 @@ __device__ __forceinline__ void run_segment_packed(const JobCtx& c, const float2
                     }
             }
 #if GSH_MC_RUNLEN
-        if constexpr (FA && (FB || NCH == 1))
+        if constexpr ((FA && (FB || NCH == 1)) || KP)
             {
                 // (a paired trip is a plain one: the trip PF ahead lies at or beyond the first plain trip, and one comparison says whether it is plain itself)
                 if (i + PF < last_plain)  // uniform
@@ -1255,12 +1256,12 @@ __device__ __forceinline__ void run_segment_packed(const JobCtx& c, const float2
                     int run = paired_run(i);
                     while (run > 0)
                         {
-                            trip(i, j0{}, yes{}, integral_constant<bool, NCH == 2>{});
+                            trip(i, j0{}, yes{}, integral_constant<bool, NCH == 2>{}, no{});
                             i++;
                             run--;
                         }
                     if (i >= n_trips) break;
-                    trip(i, j0{}, no{}, no{});
+                    trip(i, j0{}, no{}, no{}, no{});
                     i++;
                 }
             (void)ALL;
@@ -1270,7 +1271,7 @@ __device__ __forceinline__ void run_segment_packed(const JobCtx& c, const float2
                     unsigned f = flags(i);
                     while (f == ALL)
                         {
-                            trip(i, j0{}, yes{}, integral_constant<bool, NCH == 2>{});
+                            trip(i, j0{}, yes{}, integral_constant<bool, NCH == 2>{}, no{});
                             i++;
                             if (i >= n_trips) break;
                             f = flags(i);
@@ -1278,16 +1279,32 @@ __device__ __forceinline__ void run_segment_packed(const JobCtx& c, const float2
                     if (i >= n_trips) break;
 #if GSH_MC_DER_MIXED
                     if (NCH == 2 && f == 1U)
-                        trip(i, j0{}, yes{}, no{});
+                        trip(i, j0{}, yes{}, no{}, no{});
                     else if (NCH == 2 && f == 2U)
-                        trip(i, j0{}, no{}, yes{});
+                        trip(i, j0{}, no{}, yes{}, no{});
                     else
 #endif
-                        trip(i, j0{}, no{}, no{});
+                        trip(i, j0{}, no{}, no{}, no{});
                     i++;
                 }
 #endif
         }
+#if GSH_MC_RUNLEN
+    else if constexpr (PF == 1)
+        {
+            // the trips of a segment in three counted ranges -- at most one masked trip at the head, the plain trips, the masked tail -- so that a plain trip neither asks
+            // what it is nor what the trip after it is with more than one comparison (see the paired runs above)
+            using j0 = integral_constant<int, 0>;
+            int i = 0;
+            if (first_plain > 0 && n_trips > 0)
+                {
+                    trip(0, j0{}, no{}, no{}, no{});
+                    i = 1;
+                }
+            for (; i < last_plain; i++) trip(i, j0{}, no{}, no{}, yes{});
+            for (; i < n_trips; i++) trip(i, j0{}, no{}, no{}, no{});
+        }
+#endif
     else
         {
             for (int i0 = 0; i0 < n_trips; i0 += PF)
@@ -1295,7 +1312,7 @@ __device__ __forceinline__ void run_segment_packed(const JobCtx& c, const float2
                     auto slot = [&](auto jc) -> bool {
                         const int i = i0 + decltype(jc)::value;
                         if (i >= n_trips) return false;  // uniform
-                        trip(i, jc, no{}, no{});
+                        trip(i, jc, no{}, no{}, no{});
                         return true;
                     };
                     bool go = slot(integral_constant<int, 0>{});
