@@ -1080,15 +1080,14 @@ __device__ __forceinline__ void run_segment_packed(const JobCtx& c, const float2
                 const float lo1 = c.code_step * n_lo + (sh[0] - 0.125f);
                 const float hi1 = c.code_step * (n_lo + 127.0f) + (sh[NT - 1] + 0.125f);
                 const float lo2 = lo1 - c.rem_code, hi2 = hi1 - c.rem_code;
-#if GSH_MC_PKRTZ
-                constexpr float HI = 2040.0f;  // the half-precision pattern of u * 2^-24 is floor(u) below 2048 (packed_trip)
-#else
-                constexpr float HI = 65536.0f;
-#endif
+                // (only the form that converts two chains per instruction needs the tighter bound and the scaled constants: whole-code tables, two chunks per trip --
+                //  packed_trip.  The windowed tables of long codes pair their taps up to 2^16 as before.)
+                constexpr bool TWO_FLOORS = GSH_MC_PKRTZ && KC && NCH == 2 && NT == 3;
+                constexpr float HI = TWO_FLOORS ? 2040.0f : 65536.0f;  // the half-precision pattern of u * 2^-24 is floor(u) below 2048
                 const bool one_binade_a = (lo1 >= 1.0f) && (hi1 < HI) && ((__float_as_uint(lo1) >> 23) == (__float_as_uint(hi1) >> 23));
                 const bool one_binade_u = (lo2 >= 1.0f) && (hi2 < HI) && ((__float_as_uint(lo2) >> 23) == (__float_as_uint(hi2) >> 23));
 #if GSH_MC_PKRTZ
-                return __ballot(one_binade_a && one_binade_u && scaled_ok);
+                return __ballot(one_binade_a && one_binade_u && (scaled_ok || !TWO_FLOORS));
 #else
                 return __ballot(one_binade_a && one_binade_u);
 #endif
