@@ -73,6 +73,7 @@ struct gsh_acq
         gsh::DevAcqResult* d_results{nullptr};
         unsigned* d_arrivals{nullptr};
         hipEvent_t ev{nullptr};
+        hipEvent_t ev_cells{nullptr};  // recorded behind the lane's last cell launches (decimation-in-time plans: the next batch's cells wait for it, gsh_acq_time_dwells_pipelined)
     };
     static constexpr int MAX_LANES = 4;
     Lane lane[MAX_LANES];
@@ -672,6 +673,8 @@ extern "C"
         if (a->h_stage) (void)hipHostFree(a->h_stage);
         if (a->ev0) (void)hipEventDestroy(a->ev0);
         if (a->ev1) (void)hipEventDestroy(a->ev1);
+        for (int l = 0; l < gsh_acq::MAX_LANES; l++)
+            if (a->lane[l].ev_cells) (void)hipEventDestroy(a->lane[l].ev_cells);
         for (int l = 1; l < gsh_acq::MAX_LANES; l++)
             {
                 gsh_acq::Lane& ln = a->lane[l];
@@ -1219,16 +1222,34 @@ extern "C"
                 a->n_lanes++;
             }
         const int lanes = want_lanes;
+        // Decimation-in-time plans (round 6, session 43): the sub-cells WRITE n_prn x n_bins x N values of Z and the combine launch READS them back -- with one batch's
+        // sub-cells beside the other's combine launch the memory sees both directions at once and the pair runs slower than one after the other (non-temporal Z:
+        // 0.905 ms per 128 000-point batch against 0.82 alone).  So on the plans with non-temporal Z (pcps_onchip.hip, onchip_dit_nontemporal) only the FORWARD transforms of the next batch (41 x S work-groups, which leave
+        // most of the device idle) overlap the previous batch: its cells wait for the previous batch's.  GSH_ACQ_DIT_ORDERED=0: free-running lanes, as before.
+        static const bool dit_ordered = [] { const char* e = std::getenv("GSH_ACQ_DIT_ORDERED"); return e == nullptr || std::atoi(e) != 0; }();
+        const bool ordered = dit_ordered && a->d_z != nullptr && gsh::onchip_dit_nontemporal(a->split);
+        if (ordered)
+            for (int l = 0; l < lanes; l++)
+                if (a->lane[l].ev_cells == nullptr) GSH_HIP(hipEventCreateWithFlags(&a->lane[l].ev_cells, hipEventDisableTiming));
+        auto enqueue_cells = [&](const gsh_acq::Lane& ln) -> int {
+            // no_grid handles only: the batches in flight must not share the magnitude grid
+            return gsh::onchip_correlate(static_cast<int>(n), ln.d_spectra, a->d_codes, a->d_grid, ln.d_rows, ln.d_subrows, ln.d_results, ln.d_arrivals, static_cast<int>(n_prn), a->n_bins,
+                c.bit_transition_flag ? static_cast<int>(c.effective_fft_size) : 0, static_cast<int>(c.effective_fft_size), 0, 0, static_cast<int>(c.samples_per_chip), c.use_cfar, 1u, 1.0f, ln.stream,
+                ln.d_z, ln.d_waverows);
+        };
+        int last_lane = -1;
         auto enqueue = [&](int l) -> int {
             const gsh_acq::Lane& ln = a->lane[l];
             GSH_REQUIRE(c.fold <= 1, "the pipelined timing loop does not fold");
             int rc = gsh::onchip_forward(static_cast<int>(n), a->d_in, 0, static_cast<int>(c.consumed_samples), 0, a->d_bins_hz,
                 static_cast<double>(c.fs_in), ln.d_spectra, a->n_bins, ln.stream);
             if (rc != GSH_OK) return rc;
-            // no_grid handles only: the batches in flight must not share the magnitude grid
-            return gsh::onchip_correlate(static_cast<int>(n), ln.d_spectra, a->d_codes, a->d_grid, ln.d_rows, ln.d_subrows, ln.d_results, ln.d_arrivals, static_cast<int>(n_prn), a->n_bins,
-                c.bit_transition_flag ? static_cast<int>(c.effective_fft_size) : 0, static_cast<int>(c.effective_fft_size), 0, 0, static_cast<int>(c.samples_per_chip), c.use_cfar, 1u, 1.0f, ln.stream,
-                ln.d_z, ln.d_waverows);
+            if (ordered && last_lane >= 0 && last_lane != l) GSH_HIP(hipStreamWaitEvent(ln.stream, a->lane[last_lane].ev_cells, 0));
+            rc = enqueue_cells(ln);
+            if (rc != GSH_OK) return rc;
+            if (ordered) GSH_HIP(hipEventRecord(ln.ev_cells, ln.stream));
+            last_lane = l;
+            return GSH_OK;
         };
         int rc = GSH_OK;
         for (int l = 0; l < lanes && rc == GSH_OK; l++) rc = enqueue(l);  // warm-up on every lane

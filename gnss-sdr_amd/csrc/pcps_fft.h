@@ -83,6 +83,8 @@ int onchip_split(int n);
 // split plans that run decimation in time (pcps_onchip.hip, oc_subcell_dit_kernel + oc_combine_dit_kernel): their spectra -- signal and code, everything
 // onchip_forward writes for this length -- are stored residue-major, and onchip_correlate needs the scratch `z` (n_prn * n_bins * n values)
 bool onchip_dit(int n);
+// Z of a decimation-in-time split into `split` sub-cells is accessed with the non-temporal hint, and the batches of the pipelined loop run their cells in order
+bool onchip_dit_nontemporal(int split);
 int onchip_forward(int n, const float2* src, size_t src_stride, int n_in, int place_off, const float* wipe_hz, double fs, float2* dst,
     int batch, hipStream_t s, int fold = 1);
 // one work-group per (PRN, bin) cell: spectrum product, inverse transform, |.|^2, row statistics, and (by the last cell

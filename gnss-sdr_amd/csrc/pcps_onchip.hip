@@ -964,6 +964,15 @@ __global__ __launch_bounds__(P::THREADS) void oc_cell_kernel(OcCellArgs a)
 // (Two launches, not a last-arriver hand-off inside one: the sub-cells of a cell run on different compute units, and making Z_r visible between them costs
 // an agent-scope release per sub-cell and an acquire per cell -- L2 write-backs and invalidations that the whole XCD pays for: 3.7 ms instead of 1.44 ms at
 // 128 000 points, profiles/ab/r03/acq_dit.txt.  The kernel boundary does the same for nothing.)
+#ifndef GSH_OC_Z_NT_BELOW_S
+#define GSH_OC_Z_NT_BELOW_S 8  // the splits into fewer sub-cells than this get the hints (onchip_dit_nontemporal below has the measurements)
+#endif
+#ifndef GSH_OC_Z_NT_STORE
+#define GSH_OC_Z_NT_STORE 1  // the sub-cells' Z stores carry the non-temporal hint (0: A/B builds)
+#endif
+#ifndef GSH_OC_Z_NT_LOAD
+#define GSH_OC_Z_NT_LOAD 1  // the combine launch's Z loads carry the non-temporal hint (0: A/B builds)
+#endif
 template <class P, int S>
 __global__ __launch_bounds__(P::THREADS) void oc_subcell_dit_kernel(OcCellArgs a)
 {
@@ -1003,11 +1012,26 @@ __global__ __launch_bounds__(P::THREADS) void oc_subcell_dit_kernel(OcCellArgs a
         {
             P::stage3(rc);
             cf* __restrict__ zo = a.z + static_cast<size_t>(cell) * N + static_cast<size_t>(r) * M + t;
-            oc::static_for<P::R3>([&](auto K3) GSH_AI { zo[decltype(K3)::value * P::T3] = rc[decltype(K3)::value]; });
+            // Z is written once here and read once by the combine launch: with the non-temporal hint it does not push the spectra every sub-cell re-reads out of
+            // the L2 and the Infinity Cache (128 000 points: 0.924 -> 0.82 ms per batch, profiles/ab/r06/session43-45.txt)
+            // (chosen at compile time: behind a run-time condition the two stores are merged into one and the hint is lost -- session 46)
+            if constexpr (GSH_OC_Z_NT_STORE && S < GSH_OC_Z_NT_BELOW_S)
+                oc::static_for<P::R3>([&](auto K3) GSH_AI { __builtin_nontemporal_store(rc[decltype(K3)::value], &zo[decltype(K3)::value * P::T3]); });
+            else
+                oc::static_for<P::R3>([&](auto K3) GSH_AI { zo[decltype(K3)::value * P::T3] = rc[decltype(K3)::value]; });
         }
 }
 
 constexpr int OC_COMBINE_THREADS = 1024;
+#ifndef GSH_OC_COMBINE_HANDOFF
+#define GSH_OC_COMBINE_HANDOFF 0  // 1: every work-group of the combine launch ends with the store - release - ticket hand-off, the last one forms the statistic (until round 6: A/B builds)
+#endif
+#ifndef GSH_OC_COMBINE_PARTS
+#define GSH_OC_COMBINE_PARTS 1  // work-groups per cell of the combine launch (GSH_OC_COMBINE_PARTS in the environment overrides)
+#endif
+#ifndef GSH_OC_COMBINE_WG
+#define GSH_OC_COMBINE_WG 1024  // threads per work-group of the combine launch (GSH_OC_COMBINE_THREADS in the environment overrides)
+#endif
 #ifndef GSH_OC_COMBINE_PAIRS
 #define GSH_OC_COMBINE_PAIRS 1  // 0: one lag class per thread and trip, 8-byte loads, nothing in flight across trips (the round-3 form: A/B builds)
 #endif
@@ -1016,15 +1040,18 @@ constexpr int OC_COMBINE_THREADS = 1024;
 // (2 i, 2 i + 1) of every residue class per trip (16-byte loads: a wave reads 1 KiB per instruction) and the next trip's S loads are issued BEFORE the current
 // trip's arithmetic (a two-deep register queue), so a compute unit always has loads in flight.  The twiddles of the pair's second lag are the first's times the
 // constant W_N^r; the trackers still meet the lags of one j in ascending order (lowest index wins ties).
-template <int M, int S, bool GRID, bool OFF>
+template <int M, int S, bool GRID, bool OFF, int H>
 __global__ __launch_bounds__(OC_COMBINE_THREADS) void oc_combine_dit_kernel(OcCellArgs a)
 {
     static_assert(GRID || !OFF, "the upper-half searches are instantiated on the GRID flavour only");
+    static_assert(H == 1 || GSH_OC_COMBINE_PAIRS, "parts of a cell are cut from its pairs of lag classes");
     constexpr int N = S * M;
+#if GSH_OC_COMBINE_HANDOFF
     __shared__ float s_v[OC_MAX_WAVES];
     __shared__ unsigned s_i[OC_MAX_WAVES];
     __shared__ float s_s[OC_MAX_WAVES];
-    const int cell = blockIdx.x;
+#endif
+    const int cell = static_cast<int>(blockIdx.x) / H, part = static_cast<int>(blockIdx.x) - cell * H;
     const int prn = cell / a.n_bins;
     const int t = threadIdx.x;
     float best = -1.0f, sum = 0.0f;
@@ -1063,23 +1090,32 @@ __global__ __launch_bounds__(OC_COMBINE_THREADS) void oc_combine_dit_kernel(OcCe
         };
 #if GSH_OC_COMBINE_PAIRS
         static_assert(M % 2 == 0, "pairs of lag classes");
-        constexpr int PAIRS = M / 2, STRIDE = OC_COMBINE_THREADS;
-        // twiddles W_N^{r m} at m = 2 t (exact seeds), the pair's second lag is one W_N^r further, a trip 2 THREADS lags further (at most M / 2 / THREADS steps: 13)
+        // part `part` of the cell's H: the pairs [lo, hi) (H > 1: the combine launch's work-groups are 1 / H of a cell's work, so that its last, partly filled
+        // round of work-groups on the device's compute units is 1 / H as long -- round 6, session 41)
+        constexpr int PAIRS_ALL = M / 2, PER_PART = (PAIRS_ALL + H - 1) / H;
+        const int STRIDE = static_cast<int>(blockDim.x);
+        const int lo = part * PER_PART, PAIRS = (lo + PER_PART < PAIRS_ALL) ? lo + PER_PART : PAIRS_ALL;
+        // twiddles W_N^{r m} at m = 2 (lo + t) (exact seeds), the pair's second lag is one W_N^r further, a trip 2 THREADS lags further
         cf tw[S], one[S], step[S];
         oc::static_for<S>([&](auto R) GSH_AI {
             constexpr int rr = decltype(R)::value;
-            tw[rr] = oc::unit_root(static_cast<int>((static_cast<long long>(rr) * 2 * t) % N), N);
+            tw[rr] = oc::unit_root(static_cast<int>((static_cast<long long>(rr) * 2 * (lo + t)) % N), N);
             one[rr] = oc::unit_root(rr % N, N);
             step[rr] = oc::unit_root(static_cast<int>((static_cast<long long>(rr) * 2 * STRIDE) % N), N);
         });
         typedef float f4 __attribute__((ext_vector_type(4)));
         f4 q[S];
+        constexpr bool nt = GSH_OC_Z_NT_LOAD && S < GSH_OC_Z_NT_BELOW_S;
         auto load = [&](int i) GSH_AI {
             oc::static_for<S>([&](auto R) GSH_AI {
-                q[decltype(R)::value] = *reinterpret_cast<const f4*>(zc + static_cast<size_t>(decltype(R)::value) * M + 2 * i);
+                const f4* src = reinterpret_cast<const f4*>(zc + static_cast<size_t>(decltype(R)::value) * M + 2 * i);
+                if constexpr (nt)
+                    q[decltype(R)::value] = __builtin_nontemporal_load(src);
+                else
+                    q[decltype(R)::value] = *src;
             });
         };
-        int i = t;
+        int i = lo + t;
         if (i < PAIRS) load(i);
 #pragma clang loop unroll(disable)
         for (; i < PAIRS; i += STRIDE)
@@ -1109,10 +1145,10 @@ __global__ __launch_bounds__(OC_COMBINE_THREADS) void oc_combine_dit_kernel(OcCe
         oc::static_for<S>([&](auto R) GSH_AI {
             constexpr int rr = decltype(R)::value;
             tw[rr] = oc::unit_root(static_cast<int>((static_cast<long long>(rr) * t) % N), N);
-            step[rr] = oc::unit_root(static_cast<int>((static_cast<long long>(rr) * OC_COMBINE_THREADS) % N), N);
+            step[rr] = oc::unit_root(static_cast<int>((static_cast<long long>(rr) * static_cast<int>(blockDim.x)) % N), N);
         });
 #pragma clang loop unroll(disable)
-        for (int m = t; m < M; m += OC_COMBINE_THREADS)
+        for (int m = t; m < M; m += static_cast<int>(blockDim.x))
             {
                 cf u[S];
                 oc::static_for<S>([&](auto R) GSH_AI { u[decltype(R)::value] = zc[static_cast<size_t>(decltype(R)::value) * M + m]; });
@@ -1138,7 +1174,8 @@ __global__ __launch_bounds__(OC_COMBINE_THREADS) void oc_combine_dit_kernel(OcCe
             argmax_merge(best, at, ov, oi);
         }
     const int wave = t >> 6;
-    constexpr int n_waves = OC_COMBINE_THREADS / 64;
+#if GSH_OC_COMBINE_HANDOFF
+    const int n_waves = static_cast<int>(blockDim.x) / 64;
     if ((t & 63) == 0)
         {
             s_v[wave] = best;
@@ -1153,7 +1190,21 @@ __global__ __launch_bounds__(OC_COMBINE_THREADS) void oc_combine_dit_kernel(OcCe
                 sum += s_s[w];
             }
     __syncthreads();  // s_i is reused by publish_row
-    publish_row<1>(a, prn, cell, 0, best, at, sum, 0.0f, s_i);
+    publish_row<H>(a, prn, cell, part, best, at, sum, 0.0f, s_i);
+#else
+    // no hand-off at the end of a work-group (round 6, session 41 -- what round 5 did for the plain cells): a wave leaves its partial record and is done; oc_rows_kernel,
+    // queued behind this launch, merges waves and parts in ascending order (the order of the reduction it replaces: every sum the same float) and forms the statistic
+    (void)prn;
+    if ((t & 63) == 0)
+        {
+            RowStat rec;
+            rec.maxv = best;
+            rec.idx = at;
+            rec.sum = sum;
+            rec.second = 0.0f;
+            a.waverows[(static_cast<size_t>(cell) * H + part) * OC_MAX_WAVES + wave] = rec;
+        }
+#endif
 }
 
 // ---- first_vs_second_peak_statistic on a split plan (acq.cc:485-516).  The S sub-cells of a row each own every S-th lag, so none of them can blank
@@ -1321,13 +1372,45 @@ int launch_cells_dit(const OcCellArgs& a, int n_blocks, hipStream_t s)
             hipLaunchKernelGGL((oc_subcell_dit_kernel<P, S>), dim3(n_blocks), dim3(P::THREADS), 0, s, a);
     }
     GSH_HIP(hipGetLastError());
-    const dim3 cells(static_cast<unsigned>(a.n_prn * a.n_bins)), threads(OC_COMBINE_THREADS);
-    if (off)
-        hipLaunchKernelGGL((oc_combine_dit_kernel<P::N, S, true, true>), cells, threads, 0, s, a);
-    else if (grid)
-        hipLaunchKernelGGL((oc_combine_dit_kernel<P::N, S, true, false>), cells, threads, 0, s, a);
+    // parts per cell (1, 2 or 4; never more than the S records a row has room for) and threads per work-group of the combine launch
+    static const int parts_env = [] { const char* e = std::getenv("GSH_OC_COMBINE_PARTS"); return e != nullptr ? std::atoi(e) : GSH_OC_COMBINE_PARTS; }();
+    static const int threads_env = [] { const char* e = std::getenv("GSH_OC_COMBINE_THREADS"); return e != nullptr ? std::atoi(e) : GSH_OC_COMBINE_WG; }();
+    const int parts = (parts_env >= 4 && S >= 4) ? 4 : (parts_env >= 2 && S >= 2) ? 2 : 1;
+    const dim3 threads(static_cast<unsigned>(std::min(OC_COMBINE_THREADS, std::max(64, threads_env / 64 * 64))));
+    GSH_REQUIRE(parts == 1 || a.subrows != nullptr, "a combine launch over parts of cells without the parts' records");
+    GSH_REQUIRE(GSH_OC_COMBINE_HANDOFF || a.waverows != nullptr, "a combine launch without the per-wave record buffer");
+    const dim3 cells(static_cast<unsigned>(a.n_prn * a.n_bins * parts));
+    auto combine = [&](auto Hc) {
+        constexpr int H = decltype(Hc)::value;
+        if (off)
+            hipLaunchKernelGGL((oc_combine_dit_kernel<P::N, S, true, true, H>), cells, threads, 0, s, a);
+        else if (grid)
+            hipLaunchKernelGGL((oc_combine_dit_kernel<P::N, S, true, false, H>), cells, threads, 0, s, a);
+        else
+            hipLaunchKernelGGL((oc_combine_dit_kernel<P::N, S, false, false, H>), cells, threads, 0, s, a);
+    };
+    if constexpr (S >= 4)
+        {
+            if (parts == 4)
+                combine(std::integral_constant<int, 4>{});
+            else if (parts == 2)
+                combine(std::integral_constant<int, 2>{});
+            else
+                combine(std::integral_constant<int, 1>{});
+        }
+    else if constexpr (S >= 2)
+        {
+            if (parts == 2)
+                combine(std::integral_constant<int, 2>{});
+            else
+                combine(std::integral_constant<int, 1>{});
+        }
     else
-        hipLaunchKernelGGL((oc_combine_dit_kernel<P::N, S, false, false>), cells, threads, 0, s, a);
+        combine(std::integral_constant<int, 1>{});
+#if !GSH_OC_COMBINE_HANDOFF
+    GSH_HIP(hipGetLastError());
+    hipLaunchKernelGGL(oc_rows_kernel, dim3(a.n_prn), dim3(64), 0, s, a, static_cast<int>(threads.x) / 64, parts);
+#endif
     if (a.want_second)
         {
             GSH_HIP(hipGetLastError());
@@ -1343,6 +1426,11 @@ int launch_cells_dit(const OcCellArgs& a, int n_blocks, hipStream_t s)
     return GSH_OK;
 }
 }  // namespace
+
+// Z of a decimation-in-time split with the non-temporal hint, and then its batches' cells one after the other (gsh_acq_time_dwells_pipelined): by measurement
+// (profiles/ab/r06/session44.txt, session45.txt) -- S = 4, 5 (100 000 / 128 000 points): 0.72 -> 0.667 / 0.877 -> 0.826 ms per batch; S = 8 (200 000 points, 2.1 GB of
+// Z per batch): 1.495 ms with plain accesses and free-running lanes against 1.615.  A compile-time choice (GSH_OC_Z_NT_BELOW_S).
+bool onchip_dit_nontemporal(int split) { return GSH_OC_Z_NT_STORE && GSH_OC_Z_NT_LOAD && split >= 2 && split < GSH_OC_Z_NT_BELOW_S; }
 
 // split plans with at least this many sub-cells run decimation in time (GSH_OC_DIT_MIN_S in the environment overrides: 0 = never)
 int onchip_dit_min_s()
