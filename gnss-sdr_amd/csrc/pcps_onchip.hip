@@ -121,6 +121,7 @@ struct OcCellArgs
     unsigned dwell_count;
     float weight;  // GRID path: every |.|^2 is scaled before it is added / stored (pcps_tong_acquisition_cc.cc:243-249); 1 otherwise
     cf* z;  // decimation-in-time split (oc_subcell_dit_kernel / oc_combine_dit_kernel): the sub-cells' length-M transforms, n_prn * n_bins * N values
+    int dit_r_major;  // oc_subcell_dit_kernel: an XCD walks its sub-cells residue class by residue class (all its cells' sub-cell 0, then all its cells' sub-cell 1, ...)
     int cells_per_wg;   // oc_cell_kernel: a work-group carries out this many cells one after the other (slot, slot + gridDim / 8, ...): the staggered start of a
                         // work-group's sixteen waves -- 3.5 of a cell's 21 us, profiles/oc_cell_annotated.txt -- is paid once per work-group instead of once per cell
     int slots_per_xcd;  // prn_per * bin_per * S
@@ -964,6 +965,9 @@ __global__ __launch_bounds__(P::THREADS) void oc_cell_kernel(OcCellArgs a)
 // (Two launches, not a last-arriver hand-off inside one: the sub-cells of a cell run on different compute units, and making Z_r visible between them costs
 // an agent-scope release per sub-cell and an acquire per cell -- L2 write-backs and invalidations that the whole XCD pays for: 3.7 ms instead of 1.44 ms at
 // 128 000 points, profiles/ab/r03/acq_dit.txt.  The kernel boundary does the same for nothing.)
+#ifndef GSH_OC_DIT_R_MAJOR
+#define GSH_OC_DIT_R_MAJOR -1  // OcCellArgs::dit_r_major: -1 = chosen per split (launch_cells_dit), 0 / 1 = never / always
+#endif
 #ifndef GSH_OC_Z_NT_BELOW_S
 #define GSH_OC_Z_NT_BELOW_S 8  // the splits into fewer sub-cells than this get the hints (onchip_dit_nontemporal below has the measurements)
 #endif
@@ -979,7 +983,10 @@ __global__ __launch_bounds__(P::THREADS) void oc_subcell_dit_kernel(OcCellArgs a
     constexpr int M = P::N, N = S * P::N;
     GSH_OC_LDS_DECL(P);
     const int xcd = static_cast<int>(blockIdx.x & 7u), slot_r = static_cast<int>(blockIdx.x >> 3);
-    const int slot = slot_r / S, r = slot_r - slot * S;
+    // the order in which an XCD's compute units meet its sub-cells decides what its 4 MB of L2 must hold: cell by cell (r fastest) the 32 sub-cells in flight read
+    // ~10 bin and 20 code residue classes of 8 M bytes each (6 MB at M = 25 600); class by class (r slowest) 8 bin classes and the XCD's 4 code classes (2.5 MB)
+    const int cells_per_xcd = a.prn_per * a.bin_per;
+    const int slot = a.dit_r_major ? slot_r % cells_per_xcd : slot_r / S, r = a.dit_r_major ? slot_r / cells_per_xcd : slot_r - slot * S;
     const int xp_i = xcd % a.xp, xb_i = xcd / a.xp;
     const int bl = slot / a.prn_per, pl = slot - bl * a.prn_per;
     const int prn = xp_i * a.prn_per + pl, bin = xb_i * a.bin_per + bl;
@@ -1347,8 +1354,15 @@ int launch_cells(const OcCellArgs& a_in, int n_blocks, hipStream_t s)
 }
 
 template <class P, int S>
-int launch_cells_dit(const OcCellArgs& a, int n_blocks, hipStream_t s)
+int launch_cells_dit(const OcCellArgs& a_in, int n_blocks, hipStream_t s)
 {
+    OcCellArgs a = a_in;
+    {
+        // class by class where Z carries the non-temporal hint (S = 4, 5: 0.670 -> 0.653 / 0.822 -> 0.721 ms per batch); at S = 8, with plain accesses and free-running
+        // lanes, cell by cell stays better (1.50 against 1.565 ms) -- profiles/ab/r06/session49.txt.  GSH_OC_DIT_R_MAJOR = 0 / 1 in the environment overrides.
+        static const int r_major = [] { const char* e = std::getenv("GSH_OC_DIT_R_MAJOR"); return e != nullptr ? std::atoi(e) : GSH_OC_DIT_R_MAJOR; }();
+        a.dit_r_major = r_major < 0 ? (onchip_dit_nontemporal(S) ? 1 : 0) : r_major;
+    }
     const bool grid = a.accumulate || a.store_grid;
     const bool off = a.offset != 0;
     GSH_REQUIRE(!a.want_second || (a.store_grid && a.grid != nullptr), "the peak-ratio statistic on a split plan scans the stored winning row: it needs the grid");
@@ -1528,6 +1542,7 @@ int onchip_correlate(int n, const float2* spectra, const float2* codes, float* g
     const int n_blocks = 8 * a.prn_per * a.bin_per;
     a.cells_per_wg = 1;
     a.slots_per_xcd = a.prn_per * a.bin_per;  // (x S in launch_cells)
+    a.dit_r_major = 0;  // (launch_cells_dit decides)
     {
         // GSH_OC_STAGGER="groups,ticks" (A/B): see OcCellArgs::stagger_groups
         static const int groups = [] { const char* e = std::getenv("GSH_OC_STAGGER"); return e != nullptr ? std::atoi(e) : GSH_OC_STAGGER_GROUPS_DEFAULT; }();
