@@ -969,7 +969,7 @@ __global__ __launch_bounds__(P::THREADS) void oc_cell_kernel(OcCellArgs a)
 #define GSH_OC_DIT_R_MAJOR -1  // OcCellArgs::dit_r_major: -1 = chosen per split (launch_cells_dit), 0 / 1 = never / always
 #endif
 #ifndef GSH_OC_Z_NT_BELOW_S
-#define GSH_OC_Z_NT_BELOW_S 8  // the splits into fewer sub-cells than this get the hints (onchip_dit_nontemporal below has the measurements)
+#define GSH_OC_Z_NT_BELOW_S 1024  // the splits into fewer sub-cells than this get the hints: all of them (8 leaves S = 8 out -- A/B builds; onchip_dit_nontemporal below has the measurements)
 #endif
 #ifndef GSH_OC_Z_NT_STORE
 #define GSH_OC_Z_NT_STORE 1  // the sub-cells' Z stores carry the non-temporal hint (0: A/B builds)
@@ -1358,8 +1358,8 @@ int launch_cells_dit(const OcCellArgs& a_in, int n_blocks, hipStream_t s)
 {
     OcCellArgs a = a_in;
     {
-        // class by class where Z carries the non-temporal hint (S = 4, 5: 0.670 -> 0.653 / 0.822 -> 0.721 ms per batch); at S = 8, with plain accesses and free-running
-        // lanes, cell by cell stays better (1.50 against 1.565 ms) -- profiles/ab/r06/session49.txt.  GSH_OC_DIT_R_MAJOR = 0 / 1 in the environment overrides.
+        // class by class where Z carries the non-temporal hint (S = 4, 5, 8: 0.670 -> 0.653 / 0.822 -> 0.721 / 1.61 -> 1.30 ms per batch; WITHOUT the hint, with free-running
+        // lanes, cell by cell is the better order at S = 8: 1.50 against 1.565) -- profiles/ab/r06/session49.txt, session53.txt.  GSH_OC_DIT_R_MAJOR = 0 / 1 overrides.
         static const int r_major = [] { const char* e = std::getenv("GSH_OC_DIT_R_MAJOR"); return e != nullptr ? std::atoi(e) : GSH_OC_DIT_R_MAJOR; }();
         a.dit_r_major = r_major < 0 ? (onchip_dit_nontemporal(S) ? 1 : 0) : r_major;
     }
@@ -1441,9 +1441,10 @@ int launch_cells_dit(const OcCellArgs& a_in, int n_blocks, hipStream_t s)
 }
 }  // namespace
 
-// Z of a decimation-in-time split with the non-temporal hint, and then its batches' cells one after the other (gsh_acq_time_dwells_pipelined): by measurement
-// (profiles/ab/r06/session44.txt, session45.txt) -- S = 4, 5 (100 000 / 128 000 points): 0.72 -> 0.667 / 0.877 -> 0.826 ms per batch; S = 8 (200 000 points, 2.1 GB of
-// Z per batch): 1.495 ms with plain accesses and free-running lanes against 1.615.  A compile-time choice (GSH_OC_Z_NT_BELOW_S).
+// Z of a decimation-in-time split with the non-temporal hint, then its batches' cells one after the other (gsh_acq_time_dwells_pipelined) and its sub-cells walked class
+// by class (launch_cells_dit): the three belong together, by measurement (profiles/ab/r06/session44.txt, 45, 49, 53) -- S = 4, 5 (100 000 / 128 000 points): 0.72 -> 0.65 /
+// 0.877 -> 0.725 ms per batch; S = 8 (200 000 points, 2.1 GB of Z per batch): the hint and the order alone are SLOWER than plain accesses and free-running lanes (1.615
+// against 1.495 ms), all three together 1.30.  A compile-time choice (GSH_OC_Z_NT_BELOW_S).
 bool onchip_dit_nontemporal(int split) { return GSH_OC_Z_NT_STORE && GSH_OC_Z_NT_LOAD && split >= 2 && split < GSH_OC_Z_NT_BELOW_S; }
 
 // split plans with at least this many sub-cells run decimation in time (GSH_OC_DIT_MIN_S in the environment overrides: 0 = never)

@@ -822,8 +822,24 @@ void test_channel_churn(int n_channels, int n_churn, double seconds, bool with_r
     if (!with_reference) return;
     // ---- the same receiver over the reference's blocks: its steady channels stop at the same read pointers (the moment of each acquisition differs with the threads'
     // timing, the code periods tracked do not)
-    const Churn_Result ref = run_churn("reference", props, x, vlen, n_channels, n_churn, fault_period);
+    Churn_Result ref = run_churn("reference", props, x, vlen, n_channels, n_churn, fault_period);
     if (!ref.ok) return;
+    // (Round 6, profiles/ab/r06/session53.txt: on a loaded host -- 16 busy processes beside the receivers' hundred threads -- the REFERENCE receiver of this harness now and
+    //  then ends with a steady channel that was acquired, kept every code period (its read pointers pass the comparison below) and yet handed its decoder not one valid
+    //  symbol: 2 of 12 loaded runs, 1 of ~8 suite runs on an idle box.  That is the yardstick failing, not the engine; a comparison needs a usable reference run, so a
+    //  reference run with such a channel is repeated ONCE, loudly.  The HIP receiver's run is never repeated.)
+    {
+        int silent = -1;
+        for (int c = n_churn; c < n_channels && silent < 0; c++)
+            if (ref.valid_symbols[static_cast<size_t>(c)] == 0 && hip.valid_symbols[static_cast<size_t>(c)] > 80 && !ref.events[static_cast<size_t>(c)].empty() && ref.events[static_cast<size_t>(c)].back().what == 1) silent = c;
+        if (silent >= 0)
+            {
+                std::printf("churn: the reference receiver's steady channel %d was acquired (%s) and produced no valid symbol (the HIP receiver's: %zu): reference run repeated once\n", silent,
+                    events_string(ref.events[static_cast<size_t>(silent)], 12).c_str(), hip.valid_symbols[static_cast<size_t>(silent)]);
+                ref = run_churn("reference", props, x, vlen, n_channels, n_churn, fault_period);
+                if (!ref.ok) return;
+            }
+    }
     size_t total = 0;
     double worst_exact = 1.0;
     for (int c = n_churn; c < n_channels; c++)
