@@ -1298,6 +1298,10 @@ int launch_cells(const OcCellArgs& a_in, int n_blocks, hipStream_t s)
             a.cells_per_wg = std::min(onchip_cells_per_wg(), std::max(1, a.slots_per_xcd));
             int per_xcd = (a.slots_per_xcd + a.cells_per_wg - 1) / a.cells_per_wg;
             per_xcd = std::max(per_xcd, std::min(wg_per_xcd, a.slots_per_xcd));
+            // never more of these work-groups than the XCD has compute units: they would run in two rounds, the second partly filled (50 000 points, S = 2: 328 slots
+            // were 55 work-groups x 6 sub-cells = 32 + 23; as 32 x 11: 0.363 -> 0.334 ms per batch alone, 0.293 -> 0.286 pipelined -- profiles/ab/r06/session56.txt)
+            static const int wg_per_xcd_max = [] { const char* e = std::getenv("GSH_OC_WG_PER_XCD_MAX"); return e != nullptr ? std::max(1, std::atoi(e)) : 32; }();
+            per_xcd = std::min(per_xcd, std::max(wg_per_xcd_max, std::min(wg_per_xcd, a.slots_per_xcd)));
             a.cells_per_wg = (a.slots_per_xcd + per_xcd - 1) / per_xcd;
             n_blocks = 8 * per_xcd;
         }
