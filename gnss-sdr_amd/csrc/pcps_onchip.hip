@@ -1530,8 +1530,10 @@ int onchip_correlate(int n, const float2* spectra, const float2* codes, float* g
     a.arrivals = arrivals;
     a.n_prn = n_prn;
     a.n_bins = n_bins;
+    // XCDs across the PRNs (the rest across the bins).  GSH_OC_XP in the environment caps it (A/B: profiles/ab/r06/session61.txt)
+    static const int xp_cap = [] { const char* e = std::getenv("GSH_OC_XP"); return e != nullptr ? std::max(1, std::min(8, std::atoi(e))) : 8; }();
     int xp = 1;
-    while (xp < 8 && 2 * xp <= n_prn) xp *= 2;
+    while (xp < xp_cap && 2 * xp <= n_prn) xp *= 2;
     const int xb = 8 / xp;
     a.xp = xp;
     a.prn_per = (n_prn + xp - 1) / xp;
