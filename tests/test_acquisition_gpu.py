@@ -483,3 +483,40 @@ def test_split_plans_decimation_in_time_equals_decimation_in_frequency(gpu):
         assert a["grid_argmax"] // a["eff"] == b["grid_argmax"] // a["eff"] and (a["grid_argmax"] % a["eff"]) % a["per"] == (b["grid_argmax"] % a["eff"]) % a["per"], n
         assert a["grid_max"] == pytest.approx(b["grid_max"], rel=2e-5), n
         assert a["grid_sum"] == pytest.approx(b["grid_sum"], rel=1e-5), n
+
+
+@pytest.mark.parametrize("switches", [{"GSH_OC_COMBINE_PARTS": "2"}, {"GSH_OC_COMBINE_PARTS": "4", "GSH_OC_COMBINE_THREADS": "512"},
+                                      {"GSH_OC_DIT_R_MAJOR": "0", "GSH_ACQ_DIT_ORDERED": "0"}],
+                         ids=["two_parts_per_cell", "four_parts_512_threads", "cell_by_cell_free_lanes"])
+def test_decimation_in_time_launch_switches_change_nothing(gpu, switches):
+    """Round 6: the combine launch of a decimation-in-time split leaves per-wave records and oc_rows_kernel forms the rows; how a cell's lag classes are cut into
+    work-groups (GSH_OC_COMBINE_PARTS / _THREADS) and in which order an XCD walks the sub-cells (GSH_OC_DIT_R_MAJOR) are launch geometry.  The same searches as
+    above under each set of switches, each in a process of its own, against the default.  The order of the sub-cells changes no float: everything IDENTICAL.  Parts and
+    threads move the points at which a thread's twiddle recurrence is seeded, so a lag's value moves by float32 rounding: the bars of the decimation-in-time against
+    decimation-in-frequency comparison above (equally high peaks one code period apart may swap ranks)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    for name, extra in (("default", {}), ("switched", switches)):
+        env = {k: v for k, v in os.environ.items() if not k.startswith(("GSH_OC_", "GSH_ACQ_"))}
+        env.update(extra)
+        p = subprocess.run([sys.executable, "-c", _SPLIT_PATH_SNIPPET, str(gpu)], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        line = [ln for ln in p.stdout.splitlines() if ln.startswith("SPLITJSON ")][-1]
+        got[name] = json.loads(line[len("SPLITJSON "):])
+    exact = "GSH_OC_COMBINE_PARTS" not in switches
+    for n, a in got["default"].items():
+        b = got["switched"][n]
+        if exact:
+            assert a == b, n
+            continue
+        for i, (ra, rb) in enumerate(zip(a["results"], b["results"])):
+            if i < 2:
+                assert (ra["index_time"] % a["per"], ra["index_doppler"]) == (rb["index_time"] % a["per"], rb["index_doppler"]), (n, i, ra, rb)
+            assert ra["test_statistics"] == pytest.approx(rb["test_statistics"], rel=2e-4), (n, i, ra, rb)
+            assert ra["peak"] == pytest.approx(rb["peak"], rel=2e-5), (n, i)
+        assert a["grid_argmax"] // a["eff"] == b["grid_argmax"] // a["eff"] and (a["grid_argmax"] % a["eff"]) % a["per"] == (b["grid_argmax"] % a["eff"]) % a["per"], n
+        assert a["grid_max"] == pytest.approx(b["grid_max"], rel=2e-5), n
+        assert a["grid_sum"] == pytest.approx(b["grid_sum"], rel=1e-5), n
